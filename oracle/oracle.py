@@ -1,0 +1,217 @@
+"""ctypes bindings for the CPU oracle (oracle/*.c).
+
+TEST INFRASTRUCTURE ONLY.  Importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg; never from the product package (dali_amd/).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith(".c")]
+    stale = force or not os.path.exists(_LIB_PATH) or any(
+        os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.orc_crop_anchor.restype = C.c_int64
+        _lib.orc_crop_anchor.argtypes = [C.c_double, C.c_int64, C.c_int64, C.c_int]
+        _lib.orc_float2half.restype = C.c_uint16
+        _lib.orc_float2half.argtypes = [C.c_float]
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+# ---------------------------------------------------------------- RNG / crop
+def philox_block(ctr, key):
+    ctr = np.asarray(ctr, dtype=np.uint32)
+    key = np.asarray(key, dtype=np.uint32)
+    out = np.zeros(4, dtype=np.uint32)
+    lib().orc_philox_block(_p(ctr, C.c_uint32), _p(key, C.c_uint32), _p(out, C.c_uint32))
+    return out
+
+
+class Philox(C.Structure):
+    _fields_ = [("key", C.c_uint64), ("ctr", C.c_uint64 * 2), ("phase", C.c_int),
+                ("out", C.c_uint32 * 4)]
+
+    def __init__(self, key=0, ctr_hi=0, ctr_lo=0, phase=0):
+        super().__init__()
+        lib().orc_philox_init(C.byref(self), C.c_uint64(key & (2**64 - 1)), C.c_uint64(ctr_hi),
+                              C.c_uint64(ctr_lo), C.c_int(phase))
+
+    def next(self):
+        f = lib().orc_philox_next
+        f.restype = C.c_uint32
+        return f(C.byref(self))
+
+    def skipahead(self, n):
+        lib().orc_philox_skipahead(C.byref(self), C.c_uint64(n))
+
+    def skipahead_sequence(self, n):
+        lib().orc_philox_skipahead_sequence(C.byref(self), C.c_uint64(n))
+
+
+def rrc_batch(seed, iteration, shapes_hw, aspect=(3 / 4, 4 / 3), area=(0.08, 1.0), num_attempts=10):
+    shapes = np.ascontiguousarray(shapes_hw, dtype=np.int32).reshape(-1, 2)
+    n = shapes.shape[0]
+    anchors = np.zeros((n, 2), np.int32)
+    crops = np.zeros((n, 2), np.int32)
+    lib().orc_rrc_batch(C.c_int64(seed), C.c_int64(iteration), C.c_int(n), _p(shapes, C.c_int),
+                        C.c_float(aspect[0]), C.c_float(aspect[1]), C.c_float(area[0]),
+                        C.c_float(area[1]), C.c_int(num_attempts), _p(anchors, C.c_int),
+                        _p(crops, C.c_int))
+    return anchors, crops
+
+
+def coin_flip_batch(seed, iteration, batch, probability=0.5):
+    out = np.zeros(batch, np.int32)
+    lib().orc_coin_flip_batch(C.c_int64(seed), C.c_int64(iteration), C.c_int(batch),
+                              C.c_float(probability), _p(out, C.c_int32))
+    return out
+
+
+def crop_anchor(norm, crop, insz, rounding="round"):
+    return int(lib().orc_crop_anchor(float(np.float32(norm)), int(crop), int(insz),
+                                     1 if rounding == "round" else 0))
+
+
+# ---------------------------------------------------------------- resample
+FILTER_NN, FILTER_LINEAR, FILTER_TRIANGULAR = 0, 1, 2
+
+
+def resample_u8(img, out_hw, roi=None, min_filter=FILTER_LINEAR, mag_filter=FILTER_LINEAR,
+                antialias=True, round_mode=0, return_info=False):
+    """img: u8 HWC.  roi = (y0, x0, y1, x1) floats or None."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    if img.ndim == 2:
+        img = img[:, :, None]
+    H, W, Cn = img.shape
+    oh, ow = int(out_hw[0]), int(out_hw[1])
+    out = np.zeros((oh, ow, Cn), np.uint8)
+    info = np.zeros(8, np.int32)
+    r = np.asarray(roi if roi is not None else (0, 0, 0, 0), dtype=np.float32)
+    rc = lib().orc_resample_u8(_p(img, C.c_uint8), H, W, Cn, 1 if roi is not None else 0,
+                               _p(r, C.c_float), oh, ow, min_filter, mag_filter,
+                               1 if antialias else 0, round_mode, _p(out, C.c_uint8), None,
+                               _p(info, C.c_int))
+    if rc:
+        raise RuntimeError(f"orc_resample_u8 failed: {rc}")
+    return (out, info) if return_info else out
+
+
+def triangular_support(radius):
+    return lib().orc_triangular_support(C.c_float(radius))
+
+
+def init_triangular(out_size, srcx0, scale, radius):
+    sup = triangular_support(radius)
+    idx = np.zeros(out_size, np.int32)
+    co = np.zeros(out_size * sup, np.float32)
+    lib().orc_init_triangular(out_size, C.c_float(srcx0), C.c_float(scale), C.c_float(radius),
+                              _p(idx, C.c_int32), _p(co, C.c_float))
+    return idx, co.reshape(out_size, sup)
+
+
+# ---------------------------------------------------------------- CMN
+F32, F16, U8, I8 = 0, 1, 2, 3
+_NP = {F32: np.float32, F16: np.float16, U8: np.uint8, I8: np.int8}
+
+
+def float2half(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    out = np.zeros(a.shape, np.uint16)
+    lib().orc_float2half_array(_p(a, C.c_float), _p(out, C.c_uint16), C.c_int64(a.size))
+    return out.view(np.float16)
+
+
+def cmn_norm_args(mean, std, scale=1.0, shift=0.0):
+    mean = np.atleast_1d(np.asarray(mean, np.float32))
+    std = np.atleast_1d(np.asarray(std, np.float32))
+    n = max(mean.size, std.size)
+    mo = np.zeros(n, np.float32)
+    io = np.zeros(n, np.float32)
+    k = lib().orc_cmn_norm_args(_p(mean, C.c_float), mean.size, _p(std, C.c_float), std.size,
+                                C.c_float(scale), C.c_float(shift), _p(mo, C.c_float),
+                                _p(io, C.c_float))
+    return mo[:k].copy(), io[:k].copy()
+
+
+def cmn_u8(img, anchor_yx, crop_hw, mirror=False, mean=None, inv_std=None, layout="CHW",
+           pad_output=False, pad_oob=False, fill_values=(), dtype=F32):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    H, W, Cn = img.shape
+    ch, cw = int(crop_hw[0]), int(crop_hw[1])
+    cout = Cn
+    if pad_output:
+        cout = 1
+        while cout < Cn:
+            cout *= 2
+    shape = (cout, ch, cw) if layout == "CHW" else (ch, cw, cout)
+    out = np.zeros(shape, _NP[dtype])
+    mean = np.zeros(0, np.float32) if mean is None else np.ascontiguousarray(mean, np.float32)
+    inv = np.zeros(0, np.float32) if inv_std is None else np.ascontiguousarray(inv_std, np.float32)
+    fv = np.ascontiguousarray(fill_values, np.float32)
+    rc = lib().orc_cmn_u8(_p(img, C.c_uint8), H, W, Cn, int(anchor_yx[0]), int(anchor_yx[1]), ch, cw,
+                          1 if mirror else 0, _p(mean, C.c_float), _p(inv, C.c_float), mean.size,
+                          1 if layout == "CHW" else 0, 1 if pad_output else 0,
+                          1 if pad_oob else 0, _p(fv, C.c_float), fv.size, dtype,
+                          out.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise RuntimeError("crop window out of bounds")
+    return out
+
+
+# ---------------------------------------------------------------- JPEG
+def jpeg_info(data):
+    buf = np.frombuffer(data, dtype=np.uint8)
+    info = np.zeros(15, np.int32)
+    rc = lib().orc_jpeg_info(_p(buf, C.c_uint8), C.c_size_t(buf.size), _p(info, C.c_int))
+    if rc:
+        raise RuntimeError(f"orc_jpeg_info failed: {rc}")
+    return dict(width=int(info[0]), height=int(info[1]), ncomp=int(info[2]),
+                progressive=bool(info[3]), hmax=int(info[4]), vmax=int(info[5]),
+                orientation=int(info[6]),
+                sampling=[(int(info[7 + 2 * i]), int(info[8 + 2 * i])) for i in range(int(info[2]))])
+
+
+def jpeg_decode_rgb(data, return_coefs=False):
+    buf = np.frombuffer(data, dtype=np.uint8)
+    inf = jpeg_info(data)
+    H, W = inf["height"], inf["width"]
+    rgb = np.zeros((H, W, 3), np.uint8)
+    coef_ptrs = (C.POINTER(C.c_int16) * 4)()
+    coefs = []
+    qt = np.zeros((4, 64), np.uint16)
+    if return_coefs:
+        mcux = -(-W // (8 * inf["hmax"]))
+        mcuy = -(-H // (8 * inf["vmax"]))
+        for i, (h, v) in enumerate(inf["sampling"]):
+            a = np.zeros((mcuy * v, mcux * h, 64), np.int16)
+            coefs.append(a)
+            coef_ptrs[i] = _p(a, C.c_int16)
+    rc = lib().orc_jpeg_decode_rgb(_p(buf, C.c_uint8), C.c_size_t(buf.size), _p(rgb, C.c_uint8),
+                                   coef_ptrs if return_coefs else None,
+                                   _p(qt, C.c_uint16) if return_coefs else None)
+    if rc:
+        raise RuntimeError(f"orc_jpeg_decode_rgb failed: {rc}")
+    return (rgb, coefs, qt, inf) if return_coefs else rgb
