@@ -1,0 +1,162 @@
+"""ctypes bindings of the two C-ABI libraries (include/dali_amd_kernels.h, include/dali_amd_host.h).
+
+The product path fails loudly when a library is missing: there is NO CPU fallback for the
+device kernels.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBDIR = os.path.join(_HERE, "lib")
+KERNELS_LIB = os.path.join(_LIBDIR, "libdali_amd_kernels.so")
+HOST_LIB = os.path.join(_LIBDIR, "libdali_amd_host.so")
+
+
+class DaliAmdError(RuntimeError):
+    pass
+
+
+# ------------------------------------------------------------------ enums
+UINT8, FLOAT16, FLOAT, INT8 = 0, 1, 2, 3
+LAYOUT_HWC, LAYOUT_CHW = 0, 1
+INTERP_NN, INTERP_LINEAR, INTERP_TRIANGULAR = 0, 1, 2
+JPEG_GRAY, JPEG_YCC, JPEG_RGB = 0, 1, 2
+
+
+# ------------------------------------------------------------------ structs (kernels)
+class JpegIdctDesc(C.Structure):
+    _fields_ = [("coef", C.c_void_p), ("plane", C.c_void_p), ("blocks_x", C.c_int32),
+                ("nblocks", C.c_int32), ("pitch", C.c_int32), ("wg_start", C.c_int32),
+                ("quant", C.c_uint16 * 64)]
+
+
+class JpegColorDesc(C.Structure):
+    _fields_ = [("plane", C.c_void_p * 3), ("pitch", C.c_int32 * 3), ("h_samp", C.c_int32 * 3),
+                ("v_samp", C.c_int32 * 3), ("down_w", C.c_int32 * 3), ("down_h", C.c_int32 * 3),
+                ("width", C.c_int32), ("height", C.c_int32), ("color", C.c_int32),
+                ("out", C.c_void_p), ("out_pitch", C.c_int32), ("wg_start", C.c_int32)]
+
+
+class ResampleArgs(C.Structure):
+    _fields_ = [("in_", C.c_void_p), ("in_h", C.c_int32), ("in_w", C.c_int32),
+                ("channels", C.c_int32), ("in_pitch", C.c_int32), ("use_roi", C.c_int32),
+                ("roi_y0", C.c_float), ("roi_x0", C.c_float), ("roi_y1", C.c_float),
+                ("roi_x1", C.c_float), ("out_h", C.c_int32), ("out_w", C.c_int32),
+                ("min_filter", C.c_int32), ("mag_filter", C.c_int32), ("antialias", C.c_int32),
+                ("out", C.c_void_p), ("out_dtype", C.c_int32), ("out_layout", C.c_int32),
+                ("normalize", C.c_int32), ("mirror", C.c_int32), ("mean", C.c_float * 4),
+                ("inv_std", C.c_float * 4)]
+
+
+class ResampleDesc(C.Structure):
+    _fields_ = [("in_", C.c_void_p), ("out", C.c_void_p), ("in_h", C.c_int32), ("in_w", C.c_int32),
+                ("channels", C.c_int32), ("in_pitch", C.c_int32), ("out_h", C.c_int32),
+                ("out_w", C.c_int32), ("first_axis", C.c_int32), ("origin", C.c_float * 2),
+                ("scale", C.c_float * 2), ("fscale", C.c_float * 2), ("fanchor", C.c_float * 2),
+                ("support", C.c_int32 * 2), ("lo", C.c_int32 * 2), ("ext", C.c_int32 * 2),
+                ("tile_w", C.c_int32), ("tile_h", C.c_int32), ("tiles_x", C.c_int32),
+                ("tiles_y", C.c_int32), ("wg_start", C.c_int32), ("out_dtype", C.c_int32),
+                ("out_layout", C.c_int32), ("normalize", C.c_int32), ("mirror", C.c_int32),
+                ("mean", C.c_float * 4), ("inv_std", C.c_float * 4), ("even_mask", C.c_uint32 * 8),
+                ("lds_bytes", C.c_int32)]
+
+
+class CmnDesc(C.Structure):
+    _fields_ = [("in_", C.c_void_p), ("in_h", C.c_int32), ("in_w", C.c_int32),
+                ("channels", C.c_int32), ("in_pitch", C.c_int32), ("anchor_y", C.c_int32),
+                ("anchor_x", C.c_int32), ("crop_h", C.c_int32), ("crop_w", C.c_int32),
+                ("mirror", C.c_int32), ("normalize", C.c_int32), ("mean", C.c_float * 4),
+                ("inv_std", C.c_float * 4), ("fill", C.c_float * 4), ("out_channels", C.c_int32),
+                ("out_dtype", C.c_int32), ("out_layout", C.c_int32), ("out", C.c_void_p),
+                ("wg_start", C.c_int32)]
+
+
+# ------------------------------------------------------------------ structs (host)
+class JpegInfo(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("num_components", C.c_int32),
+                ("progressive", C.c_int32), ("h_samp", C.c_int32 * 4), ("v_samp", C.c_int32 * 4),
+                ("hmax", C.c_int32), ("vmax", C.c_int32), ("blocks_x", C.c_int32 * 4),
+                ("blocks_y", C.c_int32 * 4), ("down_w", C.c_int32 * 4), ("down_h", C.c_int32 * 4),
+                ("orientation", C.c_int32), ("color", C.c_int32), ("restart_interval", C.c_int32),
+                ("coef_elems", C.c_int64 * 4)]
+
+
+class PhiloxState(C.Structure):
+    _fields_ = [("key", C.c_uint64), ("ctr", C.c_uint64 * 2), ("phase", C.c_int32)]
+
+
+# ------------------------------------------------------------------ loading
+_kernels = None
+_host = None
+
+_KERNEL_SYMBOLS = [
+    "daliamdGetLastErrorMessage", "daliamdClearLastError", "daliamdVersion", "daliamdDeviceCount",
+    "daliamdSetDevice", "daliamdDeviceInfo", "daliamdStreamCreate", "daliamdStreamDestroy",
+    "daliamdStreamSynchronize", "daliamdStreamWaitEvent", "daliamdEventCreate",
+    "daliamdEventDestroy", "daliamdEventRecord", "daliamdEventSynchronize", "daliamdEventElapsedMs",
+    "daliamdMalloc", "daliamdFree", "daliamdHostAlloc", "daliamdHostFree", "daliamdMemcpyH2DAsync",
+    "daliamdMemcpyD2HAsync", "daliamdMemcpyD2DAsync", "daliamdMemsetAsync",
+    "daliamdJpegIdctSetup", "daliamdJpegIdctRun", "daliamdJpegColorSetup", "daliamdJpegColorRun",
+    "daliamdResampleSetup", "daliamdResampleRun", "daliamdCmnSetup", "daliamdCmnRun",
+]
+
+_HOST_SYMBOLS = [
+    "daliamdHostGetLastErrorMessage", "daliamdJpegParse", "daliamdJpegDecodeCoefficients",
+    "daliamdRandomCropBatch", "daliamdCoinFlipBatch", "daliamdPhiloxAdvanceSequence",
+    "daliamdPhiloxStateToString", "daliamdPhiloxStateFromString", "daliamdPhiloxGenerate",
+    "daliamdCmnNormArgs", "daliamdCropAnchor",
+]
+
+
+def declared_kernel_symbols():
+    return list(_KERNEL_SYMBOLS)
+
+
+def declared_host_symbols():
+    return list(_HOST_SYMBOLS)
+
+
+def kernels():
+    """libdali_amd_kernels.so (HIP).  Raises if it has not been built."""
+    global _kernels
+    if _kernels is None:
+        if not os.path.exists(KERNELS_LIB):
+            raise DaliAmdError(
+                f"{KERNELS_LIB} is missing: the gfx950 kernel library has not been built "
+                "(run `python -c 'import __graft_entry__ as g; g.build()'`). "
+                "There is no CPU fallback for device operators.")
+        # torch bundles its own libamdhip64 (requested by file name, soname libamdhip64.so.7).  Load it
+        # FIRST so that this library's NEEDED libamdhip64.so.7 resolves to the same runtime instance;
+        # the other order would put two HIP runtimes in the process.
+        import torch  # noqa: F401
+        lib = C.CDLL(KERNELS_LIB)
+        lib.daliamdGetLastErrorMessage.restype = C.c_char_p
+        _kernels = lib
+    return _kernels
+
+
+def host():
+    """libdali_amd_host.so (C++ host side)."""
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_LIB):
+            raise DaliAmdError(f"{HOST_LIB} is missing: run __graft_entry__.build()")
+        lib = C.CDLL(HOST_LIB)
+        lib.daliamdHostGetLastErrorMessage.restype = C.c_char_p
+        lib.daliamdCropAnchor.restype = C.c_int64
+        lib.daliamdCropAnchor.argtypes = [C.c_float, C.c_int64, C.c_int64, C.c_int]
+        _host = lib
+    return _host
+
+
+def check(rc):
+    """Raises DaliAmdError carrying the library's thread-local message when rc != 0."""
+    if rc != 0:
+        msg = kernels().daliamdGetLastErrorMessage()
+        raise DaliAmdError(f"[dali_amd kernels error {rc}] {msg.decode() if msg else ''}")
+
+
+def check_host(rc):
+    if rc != 0:
+        msg = host().daliamdHostGetLastErrorMessage()
+        raise DaliAmdError(f"[dali_amd host error] {msg.decode() if msg else ''}")

@@ -1,0 +1,125 @@
+// Library plumbing of the C ABI: last-error, device / stream / event / memory helpers.
+// These give the C++ host executor what the reference takes from CUDAStreamPool,
+// CUDAEventPool and mm:: resources (include/dali/core/cuda_stream_pool.h,
+// cuda_event_pool.h, mm/) without the host ever including HIP headers.
+#include <cstring>
+#include "common.h"
+
+namespace daliamd {
+static thread_local char g_last_error[1024] = "";
+
+void SetLastError(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+  va_end(ap);
+}
+}  // namespace daliamd
+
+extern "C" {
+
+const char *daliamdGetLastErrorMessage(void) { return daliamd::g_last_error; }
+void daliamdClearLastError(void) { daliamd::g_last_error[0] = 0; }
+int daliamdVersion(void) { return 100; }
+
+daliamdResult_t daliamdDeviceCount(int *count) {
+  DALIAMD_REQUIRE(count, DALIAMD_ERROR_INVALID_ARGUMENT, "count is NULL");
+  hipError_t e = hipGetDeviceCount(count);
+  if (e != hipSuccess) { *count = 0; (void)hipGetLastError(); }
+  return DALIAMD_SUCCESS;
+}
+daliamdResult_t daliamdSetDevice(int device_id) {
+  DALIAMD_HIP_CHECK(hipSetDevice(device_id));
+  return DALIAMD_SUCCESS;
+}
+daliamdResult_t daliamdDeviceInfo(int device_id, char *arch_name, int arch_name_len, int *num_cus,
+                                  size_t *total_mem) {
+  hipDeviceProp_t p;
+  DALIAMD_HIP_CHECK(hipGetDeviceProperties(&p, device_id));
+  if (arch_name && arch_name_len > 0) {
+    strncpy(arch_name, p.gcnArchName, arch_name_len - 1);
+    arch_name[arch_name_len - 1] = 0;
+  }
+  if (num_cus) *num_cus = p.multiProcessorCount;
+  if (total_mem) *total_mem = p.totalGlobalMem;
+  return DALIAMD_SUCCESS;
+}
+daliamdResult_t daliamdStreamCreate(daliamdStream_t *stream, int non_blocking) {
+  DALIAMD_REQUIRE(stream, DALIAMD_ERROR_INVALID_ARGUMENT, "stream is NULL");
+  hipStream_t s;
+  DALIAMD_HIP_CHECK(hipStreamCreateWithFlags(&s, non_blocking ? hipStreamNonBlocking : hipStreamDefault));
+  *stream = s;
+  return DALIAMD_SUCCESS;
+}
+daliamdResult_t daliamdStreamDestroy(daliamdStream_t stream) {
+  DALIAMD_HIP_CHECK(hipStreamDestroy((hipStream_t)stream));
+  return DALIAMD_SUCCESS;
+}
+daliamdResult_t daliamdStreamSynchronize(daliamdStream_t stream) {
+  DALIAMD_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  return DALIAMD_SUCCESS;
+}
+daliamdResult_t daliamdStreamWaitEvent(daliamdStream_t stream, daliamdEvent_t event) {
+  DALIAMD_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+  return DALIAMD_SUCCESS;
+}
+daliamdResult_t daliamdEventCreate(daliamdEvent_t *event, int enable_timing) {
+  DALIAMD_REQUIRE(event, DALIAMD_ERROR_INVALID_ARGUMENT, "event is NULL");
+  hipEvent_t e;
+  DALIAMD_HIP_CHECK(hipEventCreateWithFlags(&e, enable_timing ? hipEventDefault : hipEventDisableTiming));
+  *event = e;
+  return DALIAMD_SUCCESS;
+}
+daliamdResult_t daliamdEventDestroy(daliamdEvent_t event) {
+  DALIAMD_HIP_CHECK(hipEventDestroy((hipEvent_t)event));
+  return DALIAMD_SUCCESS;
+}
+daliamdResult_t daliamdEventRecord(daliamdEvent_t event, daliamdStream_t stream) {
+  DALIAMD_HIP_CHECK(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+  return DALIAMD_SUCCESS;
+}
+daliamdResult_t daliamdEventSynchronize(daliamdEvent_t event) {
+  DALIAMD_HIP_CHECK(hipEventSynchronize((hipEvent_t)event));
+  return DALIAMD_SUCCESS;
+}
+daliamdResult_t daliamdEventElapsedMs(daliamdEvent_t start, daliamdEvent_t stop, float *ms) {
+  DALIAMD_REQUIRE(ms, DALIAMD_ERROR_INVALID_ARGUMENT, "ms is NULL");
+  DALIAMD_HIP_CHECK(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+  return DALIAMD_SUCCESS;
+}
+daliamdResult_t daliamdMalloc(void **ptr, size_t bytes) {
+  DALIAMD_REQUIRE(ptr, DALIAMD_ERROR_INVALID_ARGUMENT, "ptr is NULL");
+  DALIAMD_HIP_CHECK(hipMalloc(ptr, bytes));
+  return DALIAMD_SUCCESS;
+}
+daliamdResult_t daliamdFree(void *ptr) {
+  DALIAMD_HIP_CHECK(hipFree(ptr));
+  return DALIAMD_SUCCESS;
+}
+daliamdResult_t daliamdHostAlloc(void **ptr, size_t bytes) {
+  DALIAMD_REQUIRE(ptr, DALIAMD_ERROR_INVALID_ARGUMENT, "ptr is NULL");
+  DALIAMD_HIP_CHECK(hipHostMalloc(ptr, bytes, hipHostMallocDefault));
+  return DALIAMD_SUCCESS;
+}
+daliamdResult_t daliamdHostFree(void *ptr) {
+  DALIAMD_HIP_CHECK(hipHostFree(ptr));
+  return DALIAMD_SUCCESS;
+}
+daliamdResult_t daliamdMemcpyH2DAsync(void *dst, const void *src, size_t bytes, daliamdStream_t s) {
+  DALIAMD_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)s));
+  return DALIAMD_SUCCESS;
+}
+daliamdResult_t daliamdMemcpyD2HAsync(void *dst, const void *src, size_t bytes, daliamdStream_t s) {
+  DALIAMD_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)s));
+  return DALIAMD_SUCCESS;
+}
+daliamdResult_t daliamdMemcpyD2DAsync(void *dst, const void *src, size_t bytes, daliamdStream_t s) {
+  DALIAMD_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s));
+  return DALIAMD_SUCCESS;
+}
+daliamdResult_t daliamdMemsetAsync(void *dst, int value, size_t bytes, daliamdStream_t s) {
+  DALIAMD_HIP_CHECK(hipMemsetAsync(dst, value, bytes, (hipStream_t)s));
+  return DALIAMD_SUCCESS;
+}
+
+}  // extern "C"

@@ -1,0 +1,190 @@
+// Batched chroma upsampling + YCbCr->RGB (or gray->RGB) for gfx950.
+//
+// Arithmetic: libjpeg-turbo jdsample.c "fancy" triangle upsampling (h2v1, h2v2, h1v2), box
+// replication for the other integral ratios, jdcolor.c 16-bit fixed-point BT.601 full-range
+// conversion -- what the reference's CPU decoder produces (fancy upsampling is always on for
+// the CPU backend: dali/operators/imgcodec/image_decoder.h:297-305).  Integer => bit-exact.
+// The first/last-column special cases of jdsample.c are algebraically the general formula with
+// the neighbour index clamped to [0, downsampled_width-1]; rows above/below the component are
+// the replicated edge rows jdmainct.c provides as context => clamp to [0, downsampled_height-1].
+//
+// Mapping: one thread produces 8 consecutive output pixels (24 bytes) of one row: an 8-byte
+// luma load, <=3 small chroma loads per chroma row, three 8-byte stores when the output pitch
+// allows (pitch % 8 == 0), byte stores otherwise.  Workgroup = 32 x 8 threads = 256 x 8 px tile.
+// HBM traffic per pixel: 1 + 2/(h*v ratio) bytes read, 3 bytes written.
+#include "common.h"
+
+namespace daliamd {
+
+constexpr int kColorThreads = 256;
+constexpr int kTileW = 256;  // pixels
+constexpr int kTileH = 8;
+
+#define SCALEBITS 16
+#define ONE_HALF (1 << (SCALEBITS - 1))
+#define FIXC(x) ((int32_t)((x) * (1L << SCALEBITS) + 0.5))
+
+__device__ __forceinline__ uint32_t Clamp8(int v) { return (uint32_t)min(max(v, 0), 255); }
+
+enum UpsampleMode { kFull = 0, kH2V1 = 1, kH2V2 = 2, kH1V2 = 3, kBox = 4 };
+
+__device__ __forceinline__ int ClampI(int v, int lo, int hi) { return min(max(v, lo), hi); }
+
+// Fetches the 8 upsampled chroma samples for pixels x0..x0+7 of output row y.
+__device__ __forceinline__ void UpsampleRow8(const uint8_t *__restrict__ plane, int pitch, int mode, int hx,
+                                             int vx, int dw, int dh, int x0, int y, int out[8]) {
+  if (mode == kFull) {
+    const uint8_t *p = plane + (size_t)y * pitch + x0;
+    uint2 v = *reinterpret_cast<const uint2 *>(p);  // planes are padded to 8-sample blocks
+#pragma unroll
+    for (int i = 0; i < 4; i++) { out[i] = (v.x >> (8 * i)) & 255; out[4 + i] = (v.y >> (8 * i)) & 255; }
+  } else if (mode == kH2V1) {
+    const uint8_t *p = plane + (size_t)y * pitch;
+    int k0 = x0 >> 1;
+    int s[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) s[i] = p[ClampI(k0 - 1 + i, 0, dw - 1)];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      out[2 * i] = (s[1 + i] * 3 + s[i] + 1) >> 2;
+      out[2 * i + 1] = (s[1 + i] * 3 + s[2 + i] + 2) >> 2;
+    }
+  } else if (mode == kH2V2) {
+    int r = y >> 1;
+    int r1 = ClampI((y & 1) ? r + 1 : r - 1, 0, dh - 1);
+    const uint8_t *p0 = plane + (size_t)r * pitch, *p1 = plane + (size_t)r1 * pitch;
+    int k0 = x0 >> 1;
+    int s[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      int k = ClampI(k0 - 1 + i, 0, dw - 1);
+      s[i] = p0[k] * 3 + p1[k];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      out[2 * i] = (s[1 + i] * 3 + s[i] + 8) >> 4;
+      out[2 * i + 1] = (s[1 + i] * 3 + s[2 + i] + 7) >> 4;
+    }
+  } else if (mode == kH1V2) {
+    int r = y >> 1;
+    int r1 = ClampI((y & 1) ? r + 1 : r - 1, 0, dh - 1);
+    int bias = (y & 1) ? 2 : 1;
+    const uint8_t *p0 = plane + (size_t)r * pitch + x0, *p1 = plane + (size_t)r1 * pitch + x0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = (p0[i] * 3 + p1[i] + bias) >> 2;
+  } else {
+    const uint8_t *p = plane + (size_t)(y / vx) * pitch;
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = p[(x0 + i) / hx];
+  }
+}
+
+__device__ __forceinline__ int ModeOf(const daliamdJpegColorDesc &d, int c, int hmax, int vmax) {
+  int h = d.h_samp[c], v = d.v_samp[c];
+  if (h == hmax && v == vmax) return kFull;
+  if (h * 2 == hmax && v == vmax && d.down_w[c] > 2) return kH2V1;
+  if (h == hmax && v * 2 == vmax) return kH1V2;
+  if (h * 2 == hmax && v * 2 == vmax && d.down_w[c] > 2) return kH2V2;
+  return kBox;
+}
+
+__global__ __launch_bounds__(kColorThreads) void JpegColorKernel(const daliamdJpegColorDesc *__restrict__ descs,
+                                                                 int ndesc, int total_wg) {
+  int wg = XcdRemap(blockIdx.x, total_wg);
+  if (wg < 0) return;
+  int di = FindDesc(descs, ndesc, wg);
+  const daliamdJpegColorDesc &d = descs[di];
+  int tiles_x = (d.width + kTileW - 1) / kTileW;
+  int t = wg - d.wg_start;
+  int ty = t / tiles_x, tx = t - ty * tiles_x;
+  int x0 = tx * kTileW + (threadIdx.x & 31) * 8;
+  int y = ty * kTileH + (threadIdx.x >> 5);
+  if (x0 >= d.width || y >= d.height) return;
+
+  int ncomp = d.color == DALIAMD_JPEG_GRAY ? 1 : 3;
+  int hmax = 1, vmax = 1;
+  for (int c = 0; c < ncomp; c++) { hmax = max(hmax, d.h_samp[c]); vmax = max(vmax, d.v_samp[c]); }
+
+  int s[3][8];
+  for (int c = 0; c < ncomp; c++) {
+    int mode = ModeOf(d, c, hmax, vmax);
+    UpsampleRow8(d.plane[c], d.pitch[c], mode, hmax / d.h_samp[c], vmax / d.v_samp[c], d.down_w[c],
+                 d.down_h[c], x0, y, s[c]);
+  }
+  uint32_t px[24];
+  if (d.color == DALIAMD_JPEG_GRAY) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) px[3 * i] = px[3 * i + 1] = px[3 * i + 2] = (uint32_t)s[0][i];
+  } else if (d.color == DALIAMD_JPEG_RGB) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) { px[3 * i] = s[0][i]; px[3 * i + 1] = s[1][i]; px[3 * i + 2] = s[2][i]; }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      int yy = s[0][i], cb = s[1][i] - 128, cr = s[2][i] - 128;
+      int r = yy + ((FIXC(1.40200) * cr + ONE_HALF) >> SCALEBITS);
+      int g = yy + (((-FIXC(0.34414)) * cb + ONE_HALF + (-FIXC(0.71414)) * cr) >> SCALEBITS);
+      int b = yy + ((FIXC(1.77200) * cb + ONE_HALF) >> SCALEBITS);
+      px[3 * i] = Clamp8(r); px[3 * i + 1] = Clamp8(g); px[3 * i + 2] = Clamp8(b);
+    }
+  }
+  uint8_t *o = d.out + (size_t)y * d.out_pitch + (size_t)x0 * 3;
+  int npx = min(8, d.width - x0);
+  if (npx == 8 && ((d.out_pitch & 7) == 0) && ((reinterpret_cast<uintptr_t>(d.out) & 7) == 0)) {
+    uint32_t w[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++)
+      w[j] = px[4 * j] | (px[4 * j + 1] << 8) | (px[4 * j + 2] << 16) | (px[4 * j + 3] << 24);
+    uint2 *o2 = reinterpret_cast<uint2 *>(o);
+    o2[0] = make_uint2(w[0], w[1]);
+    o2[1] = make_uint2(w[2], w[3]);
+    o2[2] = make_uint2(w[4], w[5]);
+  } else {
+    for (int i = 0; i < npx * 3; i++) o[i] = (uint8_t)px[i];
+  }
+}
+
+}  // namespace daliamd
+
+extern "C" {
+
+daliamdResult_t daliamdJpegColorSetup(daliamdJpegColorDesc *descs, int n, int *num_workgroups) {
+  DALIAMD_REQUIRE(descs && num_workgroups && n >= 0, DALIAMD_ERROR_INVALID_ARGUMENT,
+                  "daliamdJpegColorSetup: NULL argument");
+  int wg = 0;
+  for (int i = 0; i < n; i++) {
+    auto &d = descs[i];
+    DALIAMD_REQUIRE(d.width > 0 && d.height > 0, DALIAMD_ERROR_INVALID_ARGUMENT,
+                    "daliamdJpegColorSetup: desc %d has empty image", i);
+    DALIAMD_REQUIRE(d.out_pitch >= 3 * d.width, DALIAMD_ERROR_INVALID_ARGUMENT,
+                    "daliamdJpegColorSetup: desc %d out_pitch %d < 3*width", i, d.out_pitch);
+    int ncomp = d.color == DALIAMD_JPEG_GRAY ? 1 : 3;
+    int hmax = 1, vmax = 1;
+    for (int c = 0; c < ncomp; c++) {
+      DALIAMD_REQUIRE(d.h_samp[c] >= 1 && d.h_samp[c] <= 4 && d.v_samp[c] >= 1 && d.v_samp[c] <= 4,
+                      DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdJpegColorSetup: bad sampling factors");
+      hmax = hmax > d.h_samp[c] ? hmax : d.h_samp[c];
+      vmax = vmax > d.v_samp[c] ? vmax : d.v_samp[c];
+    }
+    for (int c = 0; c < ncomp; c++)
+      DALIAMD_REQUIRE(hmax % d.h_samp[c] == 0 && vmax % d.v_samp[c] == 0, DALIAMD_ERROR_UNSUPPORTED,
+                      "daliamdJpegColorSetup: fractional chroma sampling ratios are not supported");
+    d.wg_start = wg;
+    wg += ((d.width + daliamd::kTileW - 1) / daliamd::kTileW) * ((d.height + daliamd::kTileH - 1) / daliamd::kTileH);
+  }
+  *num_workgroups = wg;
+  return DALIAMD_SUCCESS;
+}
+
+daliamdResult_t daliamdJpegColorRun(daliamdStream_t stream, const daliamdJpegColorDesc *descs_dev, int n,
+                                    int num_workgroups) {
+  if (n == 0 || num_workgroups == 0) return DALIAMD_SUCCESS;
+  DALIAMD_REQUIRE(descs_dev && n > 0 && num_workgroups > 0, DALIAMD_ERROR_INVALID_ARGUMENT,
+                  "daliamdJpegColorRun: invalid argument");
+  hipLaunchKernelGGL(daliamd::JpegColorKernel, dim3(daliamd::XcdGrid(num_workgroups)),
+                     dim3(daliamd::kColorThreads), 0, (hipStream_t)stream, descs_dev, n, num_workgroups);
+  DALIAMD_HIP_CHECK(hipGetLastError());
+  return DALIAMD_SUCCESS;
+}
+
+}  // extern "C"

@@ -1,0 +1,146 @@
+// Batched dequantise + 8x8 inverse DCT for gfx950 (wave64).
+//
+// Arithmetic: libjpeg-turbo's accurate integer IDCT ("islow", CONST_BITS 13 / PASS1_BITS 2),
+// i.e. what the reference's CPU decoder computes through nvImageCodec
+// (dali/operators/imgcodec/image_decoder.h:289-305,810-815).  Integer math => bit-exact.
+//
+// Mapping: 8 lanes per 8x8 block, 8 blocks per wave, 32 blocks per 256-thread workgroup.
+//   pass 1: lane (b, c) loads column c of block b with ONE 16-byte load (blocks are stored
+//           column-major exactly for this), dequantises and runs the column butterfly in
+//           registers;
+//   LDS transpose (int32, block stride padded to 72 dwords => conflict-free ds_write_b32);
+//   pass 2: lane (b, r) reads row r with two ds_read_b128, runs the row butterfly,
+//           range-limits and stores 8 output bytes with one 8-byte store.
+// HBM traffic per block: 128 B read + 64 B written; no other global traffic.
+#include "common.h"
+
+namespace daliamd {
+
+#define CONST_BITS 13
+#define PASS1_BITS 2
+#define FIX_0_298631336 2446
+#define FIX_0_390180644 3196
+#define FIX_0_541196100 4433
+#define FIX_0_765366865 6270
+#define FIX_0_899976223 7373
+#define FIX_1_175875602 9633
+#define FIX_1_501321110 12299
+#define FIX_1_847759065 15137
+#define FIX_1_961570560 16069
+#define FIX_2_053119869 16819
+#define FIX_2_562915447 20995
+#define FIX_3_072711026 25172
+
+__device__ __forceinline__ int32_t Descale(int32_t x, int n) { return (x + (1 << (n - 1))) >> n; }
+
+// One 8-point pass of the islow butterfly.  in[0..7] -> out[0..7] (not yet descaled).
+__device__ __forceinline__ void Butterfly8(const int32_t in[8], int32_t out[8]) {
+  int32_t z2 = in[2], z3 = in[6];
+  int32_t z1 = (z2 + z3) * FIX_0_541196100;
+  int32_t tmp2 = z1 + z3 * (-FIX_1_847759065);
+  int32_t tmp3 = z1 + z2 * FIX_0_765366865;
+  int32_t tmp0 = (in[0] + in[4]) * (1 << CONST_BITS);
+  int32_t tmp1 = (in[0] - in[4]) * (1 << CONST_BITS);
+  int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+  tmp0 = in[7]; tmp1 = in[5]; tmp2 = in[3]; tmp3 = in[1];
+  z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
+  int32_t z4 = tmp1 + tmp3;
+  int32_t z5 = (z3 + z4) * FIX_1_175875602;
+  tmp0 *= FIX_0_298631336; tmp1 *= FIX_2_053119869; tmp2 *= FIX_3_072711026; tmp3 *= FIX_1_501321110;
+  z1 *= -FIX_0_899976223; z2 *= -FIX_2_562915447; z3 *= -FIX_1_961570560; z4 *= -FIX_0_390180644;
+  z3 += z5; z4 += z5;
+  tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+  out[0] = tmp10 + tmp3; out[7] = tmp10 - tmp3;
+  out[1] = tmp11 + tmp2; out[6] = tmp11 - tmp2;
+  out[2] = tmp12 + tmp1; out[5] = tmp12 - tmp1;
+  out[3] = tmp13 + tmp0; out[4] = tmp13 - tmp0;
+}
+
+// range_limit[x & RANGE_MASK] of libjpeg (table centred on 128): 10-bit signed wrap, +128, clamp
+__device__ __forceinline__ uint32_t RangeLimit(int32_t x) {
+  int32_t v = ((x & 1023) ^ 512) - 512 + 128;
+  return (uint32_t)min(max(v, 0), 255);
+}
+
+constexpr int kIdctThreads = 256;
+constexpr int kBlocksPerWg = kIdctThreads / 8;
+constexpr int kLdsBlockStride = 72;  // dwords; 64 + 8 padding
+
+typedef int16_t short8 __attribute__((ext_vector_type(8)));
+typedef uint16_t ushort8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(kIdctThreads) void JpegIdctKernel(const daliamdJpegIdctDesc *__restrict__ descs,
+                                                               int ndesc, int total_wg) {
+  __shared__ int32_t lds[kBlocksPerWg * kLdsBlockStride];
+  int wg = XcdRemap(blockIdx.x, total_wg);
+  if (wg < 0) return;
+  int di = FindDesc(descs, ndesc, wg);
+  const daliamdJpegIdctDesc &d = descs[di];
+  int tid = threadIdx.x;
+  int lb = tid >> 3;  // local block
+  int c = tid & 7;    // column in pass 1, row in pass 2
+  int blk = (wg - d.wg_start) * kBlocksPerWg + lb;
+  bool active = blk < d.nblocks;
+  if (active) {
+    short8 v = *reinterpret_cast<const short8 *>(d.coef + (size_t)blk * 64 + c * 8);
+    ushort8 q = *reinterpret_cast<const ushort8 *>(d.quant + c * 8);
+    int32_t in[8], o[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) in[r] = (int32_t)v[r] * (int32_t)q[r];
+    Butterfly8(in, o);
+    int32_t *w = lds + lb * kLdsBlockStride + c;
+#pragma unroll
+    for (int r = 0; r < 8; r++) w[r * 8] = Descale(o[r], CONST_BITS - PASS1_BITS);
+  }
+  __syncthreads();
+  if (active) {
+    const int4 *rp = reinterpret_cast<const int4 *>(lds + lb * kLdsBlockStride + c * 8);
+    int4 a = rp[0], b = rp[1];
+    int32_t in[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    int32_t o[8];
+    Butterfly8(in, o);
+    const int S = CONST_BITS + PASS1_BITS + 3;
+    uint32_t lo = RangeLimit(Descale(o[0], S)) | (RangeLimit(Descale(o[1], S)) << 8) |
+                  (RangeLimit(Descale(o[2], S)) << 16) | (RangeLimit(Descale(o[3], S)) << 24);
+    uint32_t hi = RangeLimit(Descale(o[4], S)) | (RangeLimit(Descale(o[5], S)) << 8) |
+                  (RangeLimit(Descale(o[6], S)) << 16) | (RangeLimit(Descale(o[7], S)) << 24);
+    int by = blk / d.blocks_x, bx = blk - by * d.blocks_x;
+    uint2 *dst = reinterpret_cast<uint2 *>(d.plane + (size_t)(by * 8 + c) * d.pitch + bx * 8);
+    *dst = make_uint2(lo, hi);
+  }
+}
+
+}  // namespace daliamd
+
+extern "C" {
+
+daliamdResult_t daliamdJpegIdctSetup(daliamdJpegIdctDesc *descs, int n, int *num_workgroups) {
+  DALIAMD_REQUIRE(descs && num_workgroups && n >= 0, DALIAMD_ERROR_INVALID_ARGUMENT,
+                  "daliamdJpegIdctSetup: NULL argument");
+  int wg = 0;
+  for (int i = 0; i < n; i++) {
+    DALIAMD_REQUIRE(descs[i].nblocks >= 0 && descs[i].blocks_x > 0, DALIAMD_ERROR_INVALID_ARGUMENT,
+                    "daliamdJpegIdctSetup: desc %d has invalid block counts", i);
+    DALIAMD_REQUIRE((descs[i].pitch & 7) == 0 && descs[i].pitch >= descs[i].blocks_x * 8,
+                    DALIAMD_ERROR_INVALID_ARGUMENT,
+                    "daliamdJpegIdctSetup: desc %d: pitch %d must be a multiple of 8 and >= %d", i,
+                    descs[i].pitch, descs[i].blocks_x * 8);
+    descs[i].wg_start = wg;
+    wg += (descs[i].nblocks + daliamd::kBlocksPerWg - 1) / daliamd::kBlocksPerWg;
+  }
+  *num_workgroups = wg;
+  return DALIAMD_SUCCESS;
+}
+
+daliamdResult_t daliamdJpegIdctRun(daliamdStream_t stream, const daliamdJpegIdctDesc *descs_dev, int n,
+                                   int num_workgroups) {
+  if (n == 0 || num_workgroups == 0) return DALIAMD_SUCCESS;
+  DALIAMD_REQUIRE(descs_dev && n > 0 && num_workgroups > 0, DALIAMD_ERROR_INVALID_ARGUMENT,
+                  "daliamdJpegIdctRun: invalid argument");
+  hipLaunchKernelGGL(daliamd::JpegIdctKernel, dim3(daliamd::XcdGrid(num_workgroups)),
+                     dim3(daliamd::kIdctThreads), 0, (hipStream_t)stream, descs_dev, n, num_workgroups);
+  DALIAMD_HIP_CHECK(hipGetLastError());
+  return DALIAMD_SUCCESS;
+}
+
+}  // extern "C"

@@ -1,0 +1,93 @@
+/*
+ * dali_amd_host.h -- C ABI of libdali_amd_host.so: the CPU-side pieces of the hot path that the
+ * reference also keeps on the host (header parsing, entropy decode in the "hybrid" decoder,
+ * random crop generation, argument preparation).  Pure host code (g++), no HIP.
+ *
+ * Conventions as in dali_amd_kernels.h: int status (0 = success), thread-local message via
+ * daliamdHostGetLastErrorMessage(), caller owns all buffers, no exceptions across the ABI.
+ */
+#ifndef DALI_AMD_HOST_H_
+#define DALI_AMD_HOST_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DALIAMD_HOST_API __attribute__((visibility("default")))
+
+DALIAMD_HOST_API const char *daliamdHostGetLastErrorMessage(void);
+
+/* ----------------------------------------------------------------------------------------------
+ * JPEG stream parsing + Huffman entropy decoding (baseline and progressive, 8-bit).
+ * Replaces ImageDecoder::ParseSample (nvimgcodecCodeStreamGetImageInfo,
+ * dali/operators/imgcodec/image_decoder.h:473-500) and the CPU half of the hybrid decode
+ * nvImageCodec performs for device="mixed" (image_decoder.h:810-815).
+ * -------------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t width, height;
+  int32_t num_components;   /* 1 or 3 (4 = CMYK/YCCK: parsed, not decodable) */
+  int32_t progressive;
+  int32_t h_samp[4], v_samp[4];
+  int32_t hmax, vmax;
+  int32_t blocks_x[4], blocks_y[4]; /* allocated blocks per component (padded to the MCU) */
+  int32_t down_w[4], down_h[4];     /* ceil(width*h/hmax), ceil(height*v/vmax) */
+  int32_t orientation;              /* EXIF orientation 1..8 (1 when absent) */
+  int32_t color;                    /* 0 gray, 1 YCbCr, 2 RGB (daliamdJpegColor_t) */
+  int32_t restart_interval;
+  int64_t coef_elems[4];            /* int16 elements of each component's coefficient array */
+} daliamdJpegInfo;
+
+DALIAMD_HOST_API int daliamdJpegParse(const uint8_t *data, size_t size, daliamdJpegInfo *info);
+
+/* Entropy-decodes the stream into per-component coefficient arrays
+ *   coef[c] : int16 [blocks_y][blocks_x][64], each block COLUMN-MAJOR (element = col*8 + row),
+ *             un-dequantised; the arrays are cleared by the callee;
+ *   quant   : uint16 [num_components][64] in the same column-major element order.
+ * This is exactly the layout daliamdJpegIdctDesc consumes. */
+DALIAMD_HOST_API int daliamdJpegDecodeCoefficients(const uint8_t *data, size_t size, const daliamdJpegInfo *info,
+                                                  int16_t *const coef[4], uint16_t *quant);
+
+/* ----------------------------------------------------------------------------------------------
+ * Random machinery, bit-compatible with the reference's host code.
+ *   Philox4x32-10                 include/dali/core/random/philox.h:27-160
+ *   RandomCropGenerator           dali/operators/image/crop/random_crop_generator_util.cc:36-101
+ *   per-sample stream derivation  dali/operators/random/rng_base.h:95-140,
+ *                                 dali/operators/image/crop/random_crop_attr.h:87-95
+ *   coin_flip                     dali/operators/random/random_dist.h:293-312
+ * -------------------------------------------------------------------------------------------- */
+typedef struct {
+  uint64_t key;
+  uint64_t ctr[2]; /* [0] = low counter word pair, [1] = high ("sequence") */
+  int32_t phase;
+} daliamdPhiloxState;
+
+/* One batch of RandomResizedCrop windows: sample i of iteration `master` uses
+ * Philox(key ^ 0x12345678abcdefe, ctr_hi + i*65537, ctr_lo, phase).  After the call the caller
+ * advances master.ctr[1] by the batch size (OperatorWithRng::Advance). */
+DALIAMD_HOST_API int daliamdRandomCropBatch(const daliamdPhiloxState *master, int batch, const int32_t *shapes_hw,
+                                           float aspect_lo, float aspect_hi, float area_lo, float area_hi,
+                                           int num_attempts, int32_t *anchors_yx, int32_t *crops_hw);
+DALIAMD_HOST_API int daliamdCoinFlipBatch(const daliamdPhiloxState *master, int batch, const float *probability,
+                                         int probability_stride, int32_t *out);
+DALIAMD_HOST_API void daliamdPhiloxAdvanceSequence(daliamdPhiloxState *state, uint64_t n);
+DALIAMD_HOST_API int daliamdPhiloxStateToString(const daliamdPhiloxState *state, char *buf, int buf_len);
+DALIAMD_HOST_API int daliamdPhiloxStateFromString(daliamdPhiloxState *state, const char *str);
+/* Raw generator, for tests: fills out[0..n) with successive outputs and advances the state. */
+DALIAMD_HOST_API void daliamdPhiloxGenerate(daliamdPhiloxState *state, uint32_t *out, int n);
+
+/* CropMirrorNormalize argument preparation (double arithmetic, float result):
+ * mean' = fma(-shift, std/scale, mean), inv_std = scale/std
+ * (dali/operators/image/crop/crop_mirror_normalize.h:120-149).  Returns the number of entries
+ * written (0 when normalisation is the identity and is skipped), or -1 on error. */
+DALIAMD_HOST_API int daliamdCmnNormArgs(const float *mean, int nmean, const float *stddev, int nstd, float scale,
+                                       float shift, float *mean_out, float *inv_std_out);
+/* CropAttr::CalculateAnchor (dali/operators/image/crop/crop_attr.cc:224-240) */
+DALIAMD_HOST_API int64_t daliamdCropAnchor(float anchor_norm, int64_t crop, int64_t in, int round_half_away);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DALI_AMD_HOST_H_ */

@@ -1,0 +1,211 @@
+/*
+ * dali_amd_kernels.h -- C ABI of libdali_amd_kernels.so (hand-written gfx950 HIP kernels).
+ *
+ * This is the drop-in boundary for the JPEG -> RandomResizedCrop -> CropMirrorNormalize hot path
+ * (and its sibling per-sample kernels).  It replaces the reference's *kernel-level* contract
+ *     Kernel::Setup(KernelContext&, in_shapes, args) -> KernelRequirements
+ *     Kernel::Run  (KernelContext&, OutListGPU, InListGPU, args)    with ctx.gpu.stream
+ * (dali/kernels/context.h:34-189, dali/kernels/kernel_manager.h) for the kernels listed below.
+ *
+ * Conventions (modelled on include/dali/dali.h:140-164):
+ *   - every entry point returns daliamdResult_t; on failure a thread-local message is available
+ *     through daliamdGetLastErrorMessage();
+ *   - no exceptions cross the ABI, no torch/HIP types appear in signatures: streams and events are
+ *     opaque `void*` (hipStream_t / hipEvent_t values), buffers are plain pointers + sizes;
+ *   - "*Setup" functions are pure host code: they turn per-sample arguments into POD descriptor
+ *     tables in caller-owned HOST memory; the caller copies the tables to the device;
+ *   - "*Run" functions take DEVICE pointers to those tables and only ENQUEUE work on the given
+ *     stream; they never allocate, never synchronise and are hipGraph-capturable;
+ *   - the caller owns every buffer.
+ */
+#ifndef DALI_AMD_KERNELS_H_
+#define DALI_AMD_KERNELS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DALIAMD_API __attribute__((visibility("default")))
+
+typedef enum {
+  DALIAMD_SUCCESS = 0,
+  DALIAMD_ERROR_INVALID_ARGUMENT = 1,
+  DALIAMD_ERROR_UNSUPPORTED = 2,
+  DALIAMD_ERROR_OUT_OF_RANGE = 3,
+  DALIAMD_ERROR_HIP = 4,
+  DALIAMD_ERROR_INTERNAL = 5,
+  DALIAMD_ERROR_CORRUPT_STREAM = 6
+} daliamdResult_t;
+
+typedef void *daliamdStream_t; /* hipStream_t */
+typedef void *daliamdEvent_t;  /* hipEvent_t  */
+
+/* ----------------------------------------------------------------------------------------------
+ * Library / device plumbing (what the reference gets from CUDAStreamPool / CUDAEventPool /
+ * mm:: resources: include/dali/core/cuda_stream_pool.h, cuda_event_pool.h, mm/).
+ * -------------------------------------------------------------------------------------------- */
+DALIAMD_API const char *daliamdGetLastErrorMessage(void);
+DALIAMD_API void daliamdClearLastError(void);
+DALIAMD_API int daliamdVersion(void);
+DALIAMD_API daliamdResult_t daliamdDeviceCount(int *count);
+DALIAMD_API daliamdResult_t daliamdSetDevice(int device_id);
+DALIAMD_API daliamdResult_t daliamdDeviceInfo(int device_id, char *arch_name, int arch_name_len,
+                                              int *num_cus, size_t *total_mem);
+DALIAMD_API daliamdResult_t daliamdStreamCreate(daliamdStream_t *stream, int non_blocking);
+DALIAMD_API daliamdResult_t daliamdStreamDestroy(daliamdStream_t stream);
+DALIAMD_API daliamdResult_t daliamdStreamSynchronize(daliamdStream_t stream);
+DALIAMD_API daliamdResult_t daliamdStreamWaitEvent(daliamdStream_t stream, daliamdEvent_t event);
+DALIAMD_API daliamdResult_t daliamdEventCreate(daliamdEvent_t *event, int enable_timing);
+DALIAMD_API daliamdResult_t daliamdEventDestroy(daliamdEvent_t event);
+DALIAMD_API daliamdResult_t daliamdEventRecord(daliamdEvent_t event, daliamdStream_t stream);
+DALIAMD_API daliamdResult_t daliamdEventSynchronize(daliamdEvent_t event);
+DALIAMD_API daliamdResult_t daliamdEventElapsedMs(daliamdEvent_t start, daliamdEvent_t stop, float *ms);
+DALIAMD_API daliamdResult_t daliamdMalloc(void **ptr, size_t bytes);
+DALIAMD_API daliamdResult_t daliamdFree(void *ptr);
+DALIAMD_API daliamdResult_t daliamdHostAlloc(void **ptr, size_t bytes); /* pinned */
+DALIAMD_API daliamdResult_t daliamdHostFree(void *ptr);
+DALIAMD_API daliamdResult_t daliamdMemcpyH2DAsync(void *dst, const void *src, size_t bytes, daliamdStream_t s);
+DALIAMD_API daliamdResult_t daliamdMemcpyD2HAsync(void *dst, const void *src, size_t bytes, daliamdStream_t s);
+DALIAMD_API daliamdResult_t daliamdMemcpyD2DAsync(void *dst, const void *src, size_t bytes, daliamdStream_t s);
+DALIAMD_API daliamdResult_t daliamdMemsetAsync(void *dst, int value, size_t bytes, daliamdStream_t s);
+
+/* Element types of kernel outputs (subset of DALIDataType, include/dali/core/dali_data_type.h) */
+typedef enum { DALIAMD_UINT8 = 0, DALIAMD_FLOAT16 = 1, DALIAMD_FLOAT = 2, DALIAMD_INT8 = 3 } daliamdDType_t;
+typedef enum { DALIAMD_LAYOUT_HWC = 0, DALIAMD_LAYOUT_CHW = 1 } daliamdLayout_t;
+
+/* ----------------------------------------------------------------------------------------------
+ * JPEG: dequantise + 8x8 inverse DCT + chroma upsampling + YCbCr->RGB.
+ * Replaces the arithmetic nvImageCodec performs for ImageDecoder
+ * (dali/operators/imgcodec/image_decoder.h:810-815); libjpeg-turbo semantics: integer "islow"
+ * IDCT, fancy (triangle) upsampling, BT.601 full range -- bit-exact with the CPU decoder.
+ *
+ * Coefficient layout (produced by the host or GPU entropy decoder): per component a dense array
+ * of 8x8 blocks in raster order [blocks_y][blocks_x][64] of int16, each block stored COLUMN-MAJOR
+ * (element index = col*8 + row) so one 16-byte load yields one column for IDCT pass 1.
+ * -------------------------------------------------------------------------------------------- */
+typedef struct {
+  const int16_t *coef; /* device: [nblocks][64], column-major blocks                      */
+  uint8_t *plane;      /* device: component plane, [blocks_y*8][pitch]                    */
+  int32_t blocks_x;    /* blocks per row (already padded to the MCU)                       */
+  int32_t nblocks;     /* blocks_x * blocks_y                                              */
+  int32_t pitch;       /* plane row pitch in bytes, multiple of 8                          */
+  int32_t wg_start;    /* filled by Setup: first workgroup of this component               */
+  uint16_t quant[64];  /* quantisation table, same column-major element order as the blocks */
+} daliamdJpegIdctDesc;
+
+/* Fills wg_start of descs[0..n) and returns the grid size. */
+DALIAMD_API daliamdResult_t daliamdJpegIdctSetup(daliamdJpegIdctDesc *descs_host, int n, int *num_workgroups);
+DALIAMD_API daliamdResult_t daliamdJpegIdctRun(daliamdStream_t stream, const daliamdJpegIdctDesc *descs_dev,
+                                               int n, int num_workgroups);
+
+typedef enum {
+  DALIAMD_JPEG_GRAY = 0,   /* 1 component                                   */
+  DALIAMD_JPEG_YCC = 1,    /* 3 components, YCbCr -> RGB                    */
+  DALIAMD_JPEG_RGB = 2     /* 3 components stored as RGB (Adobe transform 0) */
+} daliamdJpegColor_t;
+
+typedef struct {
+  const uint8_t *plane[3]; /* device component planes (output of the IDCT)                  */
+  int32_t pitch[3];
+  int32_t h_samp[3], v_samp[3]; /* sampling factors; hmax/vmax = max over components         */
+  int32_t down_w[3], down_h[3]; /* downsampled_width/height of each component (samples)      */
+  int32_t width, height;        /* image size                                                */
+  int32_t color;                /* daliamdJpegColor_t                                        */
+  uint8_t *out;                 /* device: RGB u8 HWC                                        */
+  int32_t out_pitch;            /* bytes per output row (>= 3*width)                         */
+  int32_t wg_start;             /* filled by Setup                                           */
+} daliamdJpegColorDesc;
+
+DALIAMD_API daliamdResult_t daliamdJpegColorSetup(daliamdJpegColorDesc *descs_host, int n, int *num_workgroups);
+DALIAMD_API daliamdResult_t daliamdJpegColorRun(daliamdStream_t stream, const daliamdJpegColorDesc *descs_dev,
+                                                int n, int num_workgroups);
+
+/* ----------------------------------------------------------------------------------------------
+ * Separable resampling (RandomResizedCrop / Resize) with an optional fused
+ * CropMirrorNormalize epilogue.
+ * Replaces SeparableResamplingGPUImpl::{Setup,Run} (dali/kernels/imgproc/resample/
+ * separable_impl.h:90-190, resampling_setup.cc:271-469, resampling_batch.cu:25-109) and, when
+ * fused, SliceHwc2HwcChwNormalizeGPU (dali/kernels/slice/slice_hwc2chw_normalize_gpu.cu:631-990).
+ * Arithmetic follows the CPU backend (pre-normalised coefficients, mul+add, fp32 intermediate,
+ * reference pass order): dali/kernels/imgproc/resample/{resampling_impl_cpu.cc:22-47,
+ * resampling_impl_cpu.h:50-390, separable_cpu.h:152-241}.
+ * -------------------------------------------------------------------------------------------- */
+typedef enum { DALIAMD_INTERP_NN = 0, DALIAMD_INTERP_LINEAR = 1, DALIAMD_INTERP_TRIANGULAR = 2 } daliamdInterp_t;
+
+typedef struct {
+  /* input image, u8 HWC */
+  const uint8_t *in;
+  int32_t in_h, in_w, channels, in_pitch;
+  /* region of interest in source pixels: [roi_y0, roi_y1) x [roi_x0, roi_x1); use_roi = 0: whole */
+  int32_t use_roi;
+  float roi_y0, roi_x0, roi_y1, roi_x1;
+  int32_t out_h, out_w;
+  int32_t min_filter, mag_filter, antialias; /* daliamdInterp_t; defaults LINEAR, LINEAR, 1 */
+  /* output */
+  void *out;
+  int32_t out_dtype;  /* daliamdDType_t: UINT8 (plain resize) or FLOAT16 / FLOAT (fused CMN) */
+  int32_t out_layout; /* daliamdLayout_t */
+  int32_t normalize;  /* 1: out = (u8 - mean[c]) * inv_std[c] after rounding to u8 */
+  int32_t mirror;     /* 1: horizontal flip of the output */
+  float mean[4], inv_std[4];
+} daliamdResampleArgs;
+
+typedef struct {
+  const uint8_t *in;
+  void *out;
+  int32_t in_h, in_w, channels, in_pitch;
+  int32_t out_h, out_w;
+  int32_t first_axis;        /* 0: horizontal pass first; 1: vertical pass first (cost model)   */
+  float origin[2], scale[2]; /* [0] = x, [1] = y; origin of the second axis is ROI-relative     */
+  float fscale[2], fanchor[2];
+  int32_t support[2];
+  int32_t lo[2], ext[2];     /* clamp window of each axis (absolute start, extent)              */
+  int32_t tile_w, tile_h, tiles_x, tiles_y;
+  int32_t wg_start;
+  int32_t out_dtype, out_layout, normalize, mirror;
+  float mean[4], inv_std[4];
+  uint32_t even_mask[8];     /* H-last: per output column, 1 = round half to even               */
+  int32_t lds_bytes;
+} daliamdResampleDesc;
+
+/* Fills descs_host[0..n); returns the grid size and the dynamic LDS bytes the launch needs. */
+DALIAMD_API daliamdResult_t daliamdResampleSetup(const daliamdResampleArgs *args_host, int n,
+                                                 daliamdResampleDesc *descs_host,
+                                                 int *num_workgroups, int *lds_bytes);
+DALIAMD_API daliamdResult_t daliamdResampleRun(daliamdStream_t stream, const daliamdResampleDesc *descs_dev,
+                                               int n, int num_workgroups, int lds_bytes);
+
+/* ----------------------------------------------------------------------------------------------
+ * Stand-alone CropMirrorNormalize: u8 HWC -> {fp16, fp32, u8, i8} HWC/CHW with crop, horizontal
+ * mirror, per-channel normalisation, channel padding and out-of-bounds fill.
+ * Replaces SliceFlipNormalizePermutePad (CPU arithmetic:
+ * dali/kernels/slice/slice_flip_normalize_permute_pad_cpu.h:37-64) and the GPU fast path
+ * dali/kernels/slice/slice_hwc2chw_normalize_gpu.cu:631-990.
+ * fp16 stores round to nearest, ties away from zero, like the CPU backend
+ * (include/dali/util/half.hpp:231-243).
+ * -------------------------------------------------------------------------------------------- */
+typedef struct {
+  const uint8_t *in;
+  int32_t in_h, in_w, channels, in_pitch;
+  int32_t anchor_y, anchor_x, crop_h, crop_w;
+  int32_t mirror;
+  int32_t normalize; /* 0: plain conversion */
+  float mean[4], inv_std[4];
+  float fill[4];
+  int32_t out_channels; /* channels or next_pow2(channels) when pad_output */
+  int32_t out_dtype, out_layout;
+  void *out;
+  int32_t wg_start; /* filled by Setup */
+} daliamdCmnDesc;
+
+DALIAMD_API daliamdResult_t daliamdCmnSetup(daliamdCmnDesc *descs_host, int n, int *num_workgroups);
+DALIAMD_API daliamdResult_t daliamdCmnRun(daliamdStream_t stream, const daliamdCmnDesc *descs_dev, int n,
+                                          int num_workgroups);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DALI_AMD_KERNELS_H_ */

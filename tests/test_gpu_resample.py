@@ -1,0 +1,124 @@
+"""GPU parity: fused separable resampling (+CMN epilogue) vs the CPU oracle.
+
+Tolerance (stated, fp32 interpolation): every u8 output within 1 LSB of the oracle and at most
+0.1 % of the elements different at all.  The kernel follows the CPU backend's arithmetic order
+(pre-normalised coefficients, separate mul/add, reference pass order, SSE2-body/tail rounding split),
+so in practice the result is expected to be bit-identical; the assertions print the observed
+mismatch count."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests.util import synth_image
+
+pytestmark = pytest.mark.gpu
+
+
+def _to_dev(img, pitch_align=1):
+    h, w, c = img.shape
+    pitch = (w * c + pitch_align - 1) // pitch_align * pitch_align
+    buf = torch.zeros(h * pitch + 64, dtype=torch.uint8, device="cuda")
+    view = torch.as_strided(buf, (h, w, c), (pitch, c, 1), 0)
+    view.copy_(torch.from_numpy(img))
+    return view
+
+
+def _check(got, ref, what):
+    d = np.abs(got.astype(np.int32) - ref.astype(np.int32))
+    nbad = int((d > 0).sum())
+    print(f"{what}: max diff {d.max()}, mismatches {nbad}/{d.size}")
+    assert d.max() <= 1, what
+    assert nbad <= max(1, d.size // 1000), what
+
+
+@pytest.mark.parametrize("pitch_align", [1, 4, 64])
+def test_rrc_like_rois_match_oracle(pitch_align):
+    from dali_amd import backend as B
+    rng = np.random.default_rng(5)
+    sizes = [(375, 500), (500, 375), (480, 640), (333, 500), (256, 384), (97, 131), (768, 1024)]
+    imgs, rois = [], []
+    for i in range(21):
+        h, w = sizes[i % len(sizes)]
+        imgs.append(synth_image(rng, h, w))
+    anchors, crops = O.rrc_batch(99, 0, [im.shape[:2] for im in imgs])
+    for i in range(len(imgs)):
+        rois.append((anchors[i][0], anchors[i][1], anchors[i][0] + crops[i][0], anchors[i][1] + crops[i][1]))
+    dev = [_to_dev(im, pitch_align) for im in imgs]
+    out = B.resample_batch(dev, (224, 224), rois=rois)
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    orders = []
+    for i, im in enumerate(imgs):
+        ref, info = O.resample_u8(im, (224, 224), roi=rois[i], return_info=True)
+        orders.append(int(info[0]))
+        _check(out[i], ref, f"sample {i} shape {im.shape} roi {rois[i]} first_axis {info[0]}")
+    assert 0 in orders and 1 in orders, "both pass orders must be exercised"
+
+
+def test_whole_image_up_and_down_scaling():
+    from dali_amd import backend as B
+    rng = np.random.default_rng(6)
+    cases = [((64, 48), (224, 224)), ((300, 300), (93, 479)), ((479, 93), (93, 93)), ((1000, 40), (50, 50)),
+             ((33, 777), (64, 64)), ((16, 16), (16, 16)), ((1, 1), (7, 5)), ((2, 300), (300, 2))]
+    for (h, w), osz in cases:
+        for c in (1, 3, 4):
+            im = synth_image(rng, h, w, 3)
+            im = im[:, :, :1] if c == 1 else (np.concatenate([im, im[:, :, :1]], 2) if c == 4 else im)
+            im = np.ascontiguousarray(im)
+            out = B.resample_batch([_to_dev(im)], osz).cpu().numpy()[0]
+            ref = O.resample_u8(im, osz)
+            _check(out, ref, f"{(h, w, c)} -> {osz}")
+
+
+def test_linear_no_antialias_and_flipped_roi():
+    from dali_amd import backend as B
+    from dali_amd import _capi as capi
+    rng = np.random.default_rng(8)
+    im = synth_image(rng, 200, 300)
+    dev = _to_dev(im, 4)
+    out = B.resample_batch([dev], (100, 120), antialias=False).cpu().numpy()[0]
+    _check(out, O.resample_u8(im, (100, 120), antialias=False), "no antialias")
+    roi = (150.0, 280.0, 20.0, 10.0)  # flipped in both axes
+    out = B.resample_batch([dev], (64, 96), rois=[roi]).cpu().numpy()[0]
+    _check(out, O.resample_u8(im, (64, 96), roi=roi), "flipped roi")
+    roi = (10.5, 20.25, 150.75, 220.5)  # fractional
+    out = B.resample_batch([dev], (224, 224), rois=[roi]).cpu().numpy()[0]
+    _check(out, O.resample_u8(im, (224, 224), roi=roi), "fractional roi")
+
+
+def test_extreme_downscale_uses_small_tiles():
+    from dali_amd import backend as B
+    rng = np.random.default_rng(9)
+    im = synth_image(rng, 1500, 2000)
+    out = B.resample_batch([_to_dev(im, 4)], (32, 32)).cpu().numpy()[0]
+    _check(out, O.resample_u8(im, (32, 32)), "2000x1500 -> 32x32")
+
+
+@pytest.mark.parametrize("dtype", ["float16", "float32"])
+@pytest.mark.parametrize("layout", ["CHW", "HWC"])
+def test_fused_rrc_cmn_matches_oracle_composition(dtype, layout):
+    """RRC -> CMN fused on the GPU == oracle RRC (u8) followed by oracle CMN, bit for bit wherever the
+    u8 intermediate agrees."""
+    from dali_amd import backend as B
+    from dali_amd import _capi as capi
+    rng = np.random.default_rng(10)
+    imgs = [synth_image(rng, h, w) for (h, w) in [(375, 500), (500, 375), (480, 640), (256, 384)] * 2]
+    anchors, crops = O.rrc_batch(4321, 3, [im.shape[:2] for im in imgs])
+    rois = [(a[0], a[1], a[0] + c[0], a[1] + c[1]) for a, c in zip(anchors, crops)]
+    mirror = O.coin_flip_batch(17, 3, len(imgs), 0.5)
+    mean, inv = O.cmn_norm_args([0.485 * 255, 0.456 * 255, 0.406 * 255], [0.229 * 255, 0.224 * 255, 0.225 * 255])
+    dt = capi.FLOAT16 if dtype == "float16" else capi.FLOAT
+    lay = capi.LAYOUT_CHW if layout == "CHW" else capi.LAYOUT_HWC
+    out = B.resample_batch([_to_dev(im, 16) for im in imgs], (224, 224), rois=rois, out_dtype=dt, out_layout=lay,
+                           mean=mean, inv_std=inv, mirror=mirror)
+    u8 = B.resample_batch([_to_dev(im, 16) for im in imgs], (224, 224), rois=rois).cpu().numpy()
+    out = out.cpu().numpy()
+    for i, im in enumerate(imgs):
+        # the GPU's own u8 result, normalised by the oracle, must equal the fused output exactly
+        ref = O.cmn_u8(u8[i], (0, 0), (224, 224), mirror=bool(mirror[i]), mean=mean, inv_std=inv, layout=layout,
+                       dtype=O.F16 if dtype == "float16" else O.F32)
+        assert np.array_equal(out[i].view(np.uint16 if dtype == "float16" else np.uint32),
+                              ref.view(np.uint16 if dtype == "float16" else np.uint32)), f"sample {i}"
+        # and the u8 intermediate obeys the resampling tolerance
+        _check(u8[i], O.resample_u8(im, (224, 224), roi=rois[i]), f"u8 sample {i}")
