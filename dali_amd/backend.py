@@ -35,8 +35,12 @@ class _DescUploader:
     def __init__(self):
         self._free = []   # (pinned tensor, event)
 
-    def upload(self, ctypes_array, device):
-        nbytes = C.sizeof(ctypes_array)
+    def upload(self, table, device):
+        """table: numpy structured array or ctypes array."""
+        if isinstance(table, np.ndarray):
+            nbytes, src = table.nbytes, table.ctypes.data
+        else:
+            nbytes, src = C.sizeof(table), C.addressof(table)
         slot = None
         for i, (buf, ev) in enumerate(self._free):
             if buf.numel() >= nbytes and ev.query():
@@ -47,7 +51,7 @@ class _DescUploader:
             ev = torch.cuda.Event()
         else:
             buf, ev = slot
-        C.memmove(buf.data_ptr(), C.addressof(ctypes_array), nbytes)
+        C.memmove(buf.data_ptr(), src, nbytes)
         dev = torch.empty(nbytes, dtype=torch.uint8, device=device)
         dev.copy_(buf[:nbytes], non_blocking=True)
         ev.record()
@@ -87,23 +91,22 @@ class JpegBatchPlan:
             if inf.num_components not in (1, 3):
                 raise capi.DaliAmdError(
                     f"sample {i}: JPEG with {inf.num_components} components is not supported")
-        # layout: coefficient elements (int16), plane bytes, output bytes
-        self.coef_off = np.zeros((self.n, 3), np.int64)
-        self.plane_off = np.zeros((self.n, 3), np.int64)
-        self.out_off = np.zeros(self.n, np.int64)
-        self.out_pitch = np.zeros(self.n, np.int64)
-        co = po = oo = 0
-        for i in range(self.n):
-            inf = self.infos[i]
-            for c in range(inf.num_components):
-                self.coef_off[i, c] = co
-                co += inf.coef_elems[c]
-                self.plane_off[i, c] = po
-                po += inf.coef_elems[c]          # one byte per coefficient
-            self.out_off[i] = oo
-            self.out_pitch[i] = _align(3 * inf.width, out_pitch_align)
-            oo += _align(self.out_pitch[i] * inf.height, 256)
-        self.coef_elems, self.plane_bytes, self.out_bytes = int(co), int(po), int(oo)
+        # per-sample geometry as arrays (vectorised descriptor construction)
+        inf = np.frombuffer(self.infos, dtype=np.dtype(capi.JpegInfo))[:self.n]
+        self.inf = inf
+        ncomp = inf["num_components"].astype(np.int64)
+        elems = inf["coef_elems"][:, :3].astype(np.int64) * (np.arange(3)[None, :] < ncomp[:, None])
+        flat = elems.reshape(-1)
+        starts = np.concatenate([[0], np.cumsum(flat)[:-1]]).reshape(-1, 3) if self.n else np.zeros((0, 3), np.int64)
+        self.coef_off = starts                     # int16 elements
+        self.plane_off = starts                    # bytes: one byte per coefficient
+        self.out_pitch = (3 * inf["width"].astype(np.int64) + out_pitch_align - 1) // out_pitch_align * out_pitch_align
+        osz = (self.out_pitch * inf["height"] + 255) // 256 * 256
+        self.out_off = np.concatenate([[0], np.cumsum(osz)[:-1]]).astype(np.int64) if self.n else np.zeros(0, np.int64)
+        self.coef_elems = int(flat.sum())
+        self.plane_bytes = self.coef_elems
+        self.out_bytes = int(osz.sum())
+        self.comp_mask = (np.arange(3)[None, :] < ncomp[:, None])
         self.quant = np.zeros((self.n, 3, 64), np.uint16)
 
     def shapes(self):
@@ -136,35 +139,37 @@ class JpegBatchPlan:
             list(_thread_pool(num_threads).map(one, range(self.n)))
 
     def build_descs(self, coef_dev, planes_dev, out_dev):
-        """IDCT + colour descriptor tables for device buffers (torch tensors)."""
+        """IDCT + colour descriptor tables (numpy structured arrays mirroring the C structs)."""
         lib = capi.kernels()
-        ncomp_total = sum(self.infos[i].num_components for i in range(self.n))
-        idct = (capi.JpegIdctDesc * max(ncomp_total, 1))()
-        color = (capi.JpegColorDesc * max(self.n, 1))()
+        inf, m = self.inf, self.comp_mask
         cb, pb, ob = coef_dev.data_ptr(), planes_dev.data_ptr(), out_dev.data_ptr()
-        k = 0
-        for i in range(self.n):
-            inf = self.infos[i]
-            cd = color[i]
-            for c in range(inf.num_components):
-                d = idct[k]
-                d.coef = cb + 2 * int(self.coef_off[i, c])
-                d.plane = pb + int(self.plane_off[i, c])
-                d.blocks_x = inf.blocks_x[c]
-                d.nblocks = inf.blocks_x[c] * inf.blocks_y[c]
-                d.pitch = inf.blocks_x[c] * 8
-                C.memmove(d.quant, self.quant[i, c].ctypes.data, 128)
-                cd.plane[c] = d.plane
-                cd.pitch[c] = d.pitch
-                cd.h_samp[c], cd.v_samp[c] = inf.h_samp[c], inf.v_samp[c]
-                cd.down_w[c], cd.down_h[c] = inf.down_w[c], inf.down_h[c]
-                k += 1
-            cd.width, cd.height, cd.color = inf.width, inf.height, inf.color
-            cd.out = ob + int(self.out_off[i])
-            cd.out_pitch = int(self.out_pitch[i])
+        ncomp_total = int(m.sum())
+        idct = np.zeros(max(ncomp_total, 1), np.dtype(capi.JpegIdctDesc))
+        color = np.zeros(max(self.n, 1), np.dtype(capi.JpegColorDesc))
+        if self.n:
+            bx = inf["blocks_x"][:, :3]
+            by = inf["blocks_y"][:, :3]
+            plane_ptr = pb + self.plane_off
+            idct["coef"][:ncomp_total] = (cb + 2 * self.coef_off)[m]
+            idct["plane"][:ncomp_total] = plane_ptr[m]
+            idct["blocks_x"][:ncomp_total] = bx[m]
+            idct["nblocks"][:ncomp_total] = (bx * by)[m]
+            idct["pitch"][:ncomp_total] = (bx * 8)[m]
+            idct["quant"][:ncomp_total] = self.quant[m]
+            color["plane"][:self.n] = np.where(m, plane_ptr, 0)
+            color["pitch"][:self.n] = np.where(m, bx * 8, 0)
+            color["h_samp"][:self.n] = np.where(m, inf["h_samp"][:, :3], 1)
+            color["v_samp"][:self.n] = np.where(m, inf["v_samp"][:, :3], 1)
+            color["down_w"][:self.n] = inf["down_w"][:, :3]
+            color["down_h"][:self.n] = inf["down_h"][:, :3]
+            color["width"][:self.n] = inf["width"]
+            color["height"][:self.n] = inf["height"]
+            color["color"][:self.n] = inf["color"]
+            color["out"][:self.n] = ob + self.out_off
+            color["out_pitch"][:self.n] = self.out_pitch
         n_idct_wg, n_color_wg = C.c_int(0), C.c_int(0)
-        capi.check(lib.daliamdJpegIdctSetup(idct, ncomp_total, C.byref(n_idct_wg)))
-        capi.check(lib.daliamdJpegColorSetup(color, self.n, C.byref(n_color_wg)))
+        capi.check(lib.daliamdJpegIdctSetup(idct.ctypes.data_as(C.c_void_p), ncomp_total, C.byref(n_idct_wg)))
+        capi.check(lib.daliamdJpegColorSetup(color.ctypes.data_as(C.c_void_p), self.n, C.byref(n_color_wg)))
         return (idct, ncomp_total, n_idct_wg.value), (color, self.n, n_color_wg.value)
 
     def output_views(self, out_dev):
@@ -177,8 +182,9 @@ class JpegBatchPlan:
         return views
 
 
-def jpeg_gpu_stage(plan, coef_dev, planes_dev, out_dev, descs=None):
-    """Enqueues dequant+IDCT and upsample+colour for a planned batch on the current stream."""
+def jpeg_gpu_stage(plan, coef_dev, planes_dev, out_dev, descs=None, split_events=None):
+    """Enqueues dequant+IDCT and upsample+colour for a planned batch on the current stream.
+    split_events: optional (event_before_color,) recorded between the two kernels (bench timing)."""
     lib = capi.kernels()
     if descs is None:
         descs = plan.build_descs(coef_dev, planes_dev, out_dev)
@@ -188,6 +194,8 @@ def jpeg_gpu_stage(plan, coef_dev, planes_dev, out_dev, descs=None):
     color_dev = _uploader.upload(color, dev)
     s = current_stream_ptr(dev)
     capi.check(lib.daliamdJpegIdctRun(s, C.c_void_p(idct_dev.data_ptr()), n_idct, wg_idct))
+    if split_events:
+        split_events[0].record()
     capi.check(lib.daliamdJpegColorRun(s, C.c_void_p(color_dev.data_ptr()), n_color, wg_color))
     return idct_dev, color_dev
 
@@ -238,31 +246,42 @@ def resample_batch(images, out_size, rois=None, interp_min=capi.INTERP_LINEAR, i
     if out is None:
         shape = (n, ch, oh, ow) if out_layout == capi.LAYOUT_CHW else (n, oh, ow, ch)
         out = torch.empty(shape, dtype=_TORCH_DTYPE[out_dtype], device=dev)
-    args = (capi.ResampleArgs * max(n, 1))()
     esz = out.element_size()
     per_sample = oh * ow * ch * esz
-    for i, img in enumerate(images):
-        if img.dtype != torch.uint8 or img.dim() != 3 or img.stride(2) != 1 or img.stride(1) != img.shape[2]:
-            raise capi.DaliAmdError("resample_batch expects u8 HWC tensors with dense pixels")
-        a = args[i]
-        a.in_ = img.data_ptr()
-        a.in_h, a.in_w, a.channels = img.shape
-        a.in_pitch = img.stride(0)
-        if rois is not None and rois[i] is not None:
-            a.use_roi = 1
-            a.roi_y0, a.roi_x0, a.roi_y1, a.roi_x1 = [float(v) for v in rois[i]]
-        a.out_h, a.out_w = oh, ow
-        a.min_filter, a.mag_filter, a.antialias = interp_min, interp_mag, 1 if antialias else 0
-        a.out = out.data_ptr() + i * per_sample
-        a.out_dtype, a.out_layout = out_dtype, out_layout
-        a.normalize = 1 if normalize else 0
-        a.mirror = int(mirror[i]) if mirror is not None else 0
+    args = np.zeros(max(n, 1), np.dtype(capi.ResampleArgs))
+    if n:
+        for img in images:
+            if img.dtype != torch.uint8 or img.dim() != 3 or img.stride(2) != 1 or img.stride(1) != img.shape[2]:
+                raise capi.DaliAmdError("resample_batch expects u8 HWC tensors with dense pixels")
+        a = args[:n]
+        a["in_"] = [img.data_ptr() for img in images]
+        shp = np.array([tuple(img.shape) for img in images], np.int32)
+        a["in_h"], a["in_w"], a["channels"] = shp[:, 0], shp[:, 1], shp[:, 2]
+        a["in_pitch"] = [img.stride(0) for img in images]
+        if rois is not None:
+            if isinstance(rois, np.ndarray):
+                r = rois.astype(np.float32)
+                a["use_roi"] = 1
+            else:
+                r = np.array([rr if rr is not None else (0, 0, 0, 0) for rr in rois], np.float32)
+                a["use_roi"] = [rr is not None for rr in rois]
+            a["roi_y0"], a["roi_x0"], a["roi_y1"], a["roi_x1"] = r[:, 0], r[:, 1], r[:, 2], r[:, 3]
+        a["out_h"], a["out_w"] = oh, ow
+        a["min_filter"], a["mag_filter"], a["antialias"] = interp_min, interp_mag, 1 if antialias else 0
+        a["out"] = out.data_ptr() + per_sample * np.arange(n, dtype=np.int64)
+        a["out_dtype"], a["out_layout"] = out_dtype, out_layout
+        a["normalize"] = 1 if normalize else 0
+        if mirror is not None:
+            a["mirror"] = np.asarray(mirror, np.int32)
         if normalize:
-            _fill4(a.mean, mean)
-            _fill4(a.inv_std, inv_std)
-    descs = (capi.ResampleDesc * max(n, 1))()
+            m4, i4 = np.zeros(4, np.float32), np.zeros(4, np.float32)
+            _fill4(m4, mean)
+            _fill4(i4, inv_std)
+            a["mean"], a["inv_std"] = m4, i4
+    descs = np.zeros(max(n, 1), np.dtype(capi.ResampleDesc))
     nwg, lds = C.c_int(0), C.c_int(0)
-    capi.check(lib.daliamdResampleSetup(args, n, descs, C.byref(nwg), C.byref(lds)))
+    capi.check(lib.daliamdResampleSetup(args.ctypes.data_as(C.c_void_p), n, descs.ctypes.data_as(C.c_void_p),
+                                        C.byref(nwg), C.byref(lds)))
     descs_dev = _uploader.upload(descs, dev)
     capi.check(lib.daliamdResampleRun(current_stream_ptr(dev), C.c_void_p(descs_dev.data_ptr()), n, nwg.value,
                                       lds.value))

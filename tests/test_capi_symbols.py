@@ -1,0 +1,75 @@
+"""The C-ABI libraries load and export every symbol the headers declare (no compute calls: no GPU here)."""
+import ctypes as C
+import os
+import re
+
+from dali_amd import _capi as capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header, macro):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    return sorted(set(re.findall(macro + r"\s+[\w\s\*]+?\b(daliamd\w+)\s*\(", text)))
+
+
+def test_kernel_library_exports_all_declared_symbols():
+    names = _declared("dali_amd_kernels.h", "DALIAMD_API")
+    assert len(names) >= 30
+    assert sorted(capi.declared_kernel_symbols()) == names, "python binding list out of sync with the header"
+    lib = capi.kernels()
+    for n in names:
+        assert hasattr(lib, n), f"{n} is declared in include/dali_amd_kernels.h but not exported"
+    assert lib.daliamdVersion() >= 100
+
+
+def test_host_library_exports_all_declared_symbols():
+    names = _declared("dali_amd_host.h", "DALIAMD_HOST_API")
+    assert sorted(capi.declared_host_symbols()) == names
+    lib = capi.host()
+    for n in names:
+        assert hasattr(lib, n), f"{n} is declared in include/dali_amd_host.h but not exported"
+
+
+def test_struct_sizes_match_the_c_headers():
+    """ctypes mirrors are compiled against: build a tiny C program printing sizeof() of each struct."""
+    import subprocess
+    import tempfile
+    src = r'''
+#include <stdio.h>
+#include "dali_amd_kernels.h"
+#include "dali_amd_host.h"
+int main() {
+  printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(daliamdJpegIdctDesc), sizeof(daliamdJpegColorDesc),
+         sizeof(daliamdResampleArgs), sizeof(daliamdResampleDesc), sizeof(daliamdCmnDesc), sizeof(daliamdJpegInfo),
+         sizeof(daliamdPhiloxState));
+  return 0;
+}'''
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "s.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")])
+        sizes = [int(x) for x in subprocess.check_output([os.path.join(d, "s")]).split()]
+    mirrors = [capi.JpegIdctDesc, capi.JpegColorDesc, capi.ResampleArgs, capi.ResampleDesc, capi.CmnDesc,
+               capi.JpegInfo, capi.PhiloxState]
+    assert sizes == [C.sizeof(m) for m in mirrors]
+
+
+def test_setup_functions_validate_arguments():
+    lib = capi.kernels()
+    import numpy as np
+    args = np.zeros(1, np.dtype(capi.ResampleArgs))
+    descs = np.zeros(1, np.dtype(capi.ResampleDesc))
+    nwg, lds = C.c_int(0), C.c_int(0)
+    rc = lib.daliamdResampleSetup(args.ctypes.data_as(C.c_void_p), 1, descs.ctypes.data_as(C.c_void_p), C.byref(nwg),
+                                  C.byref(lds))
+    assert rc == 1 and b"empty" in lib.daliamdGetLastErrorMessage()
+    a = args[0]
+    a["in_h"], a["in_w"], a["channels"], a["in_pitch"], a["out_h"], a["out_w"] = 100, 80, 3, 240, 20, 30
+    a["min_filter"], a["mag_filter"], a["antialias"] = 1, 1, 1
+    rc = lib.daliamdResampleSetup(args.ctypes.data_as(C.c_void_p), 1, descs.ctypes.data_as(C.c_void_p), C.byref(nwg),
+                                  C.byref(lds))
+    assert rc == 0 and nwg.value == descs[0]["tiles_x"] * descs[0]["tiles_y"] > 0 and 0 < lds.value <= 60 * 1024
+    a["channels"] = 7
+    rc = lib.daliamdResampleSetup(args.ctypes.data_as(C.c_void_p), 1, descs.ctypes.data_as(C.c_void_p), C.byref(nwg),
+                                  C.byref(lds))
+    assert rc == 2  # DALIAMD_ERROR_UNSUPPORTED
