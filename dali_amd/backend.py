@@ -182,7 +182,7 @@ class JpegBatchPlan:
         return views
 
 
-def jpeg_gpu_stage(plan, coef_dev, planes_dev, out_dev, descs=None, split_events=None):
+def jpeg_gpu_stage(plan, coef_dev, planes_dev, out_dev, descs=None, split_events=None, start_event=None):
     """Enqueues dequant+IDCT and upsample+colour for a planned batch on the current stream.
     split_events: optional (event_before_color,) recorded between the two kernels (bench timing)."""
     lib = capi.kernels()
@@ -193,6 +193,8 @@ def jpeg_gpu_stage(plan, coef_dev, planes_dev, out_dev, descs=None, split_events
     idct_dev = _uploader.upload(idct, dev)
     color_dev = _uploader.upload(color, dev)
     s = current_stream_ptr(dev)
+    if start_event is not None:
+        start_event.record()   # after the descriptor uploads: brackets the kernels only
     capi.check(lib.daliamdJpegIdctRun(s, C.c_void_p(idct_dev.data_ptr()), n_idct, wg_idct))
     if split_events:
         split_events[0].record()
@@ -231,7 +233,7 @@ def _fill4(dst, src):
 
 def resample_batch(images, out_size, rois=None, interp_min=capi.INTERP_LINEAR, interp_mag=capi.INTERP_LINEAR,
                    antialias=True, out_dtype=capi.UINT8, out_layout=capi.LAYOUT_HWC, mean=None, inv_std=None,
-                   mirror=None, out=None, return_descs=False):
+                   mirror=None, out=None, return_descs=False, start_event=None):
     """Resamples a batch of u8 HWC device tensors (possibly row-strided views) to out_size=(H, W).
 
     rois[i] = (y0, x0, y1, x1) in source pixels or None.  With mean/inv_std the CropMirrorNormalize
@@ -283,6 +285,8 @@ def resample_batch(images, out_size, rois=None, interp_min=capi.INTERP_LINEAR, i
     capi.check(lib.daliamdResampleSetup(args.ctypes.data_as(C.c_void_p), n, descs.ctypes.data_as(C.c_void_p),
                                         C.byref(nwg), C.byref(lds)))
     descs_dev = _uploader.upload(descs, dev)
+    if start_event is not None:
+        start_event.record()
     capi.check(lib.daliamdResampleRun(current_stream_ptr(dev), C.c_void_p(descs_dev.data_ptr()), n, nwg.value,
                                       lds.value))
     descs_dev.record_stream(torch.cuda.current_stream(dev))

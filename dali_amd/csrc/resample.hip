@@ -32,6 +32,7 @@ namespace daliamd {
 
 constexpr int kResampleThreads = 256;
 constexpr int kMaxLds = 60 * 1024;
+constexpr int kTargetLds = 26 * 1024;
 
 // ---------------------------------------------------------------------------------------------
 // shared host/device arithmetic
@@ -79,7 +80,7 @@ __device__ __forceinline__ uint32_t RoundU8(float v, bool half_even) {
 }
 
 // half_float::detail::float2half_impl<round_to_nearest>, ties away from zero (half.hpp:464-536)
-__device__ __forceinline__ uint16_t Float2HalfAway(float f) {
+__device__ __noinline__ uint16_t Float2HalfAwaySlow(float f) {
   uint32_t bits = __float_as_uint(f);
   uint32_t e = (bits >> 23) & 0xff;
   uint32_t sign = (bits >> 16) & 0x8000;
@@ -96,23 +97,42 @@ __device__ __forceinline__ uint16_t Float2HalfAway(float f) {
   return (uint16_t)(h + rnd);
 }
 
+// Fast path: in the normal half range the ties-away result is the hardware round-to-nearest-even
+// result, plus one unit in the last place exactly when the dropped bits are 0x1000 (a tie) and RNE
+// rounded down (kept LSB even).
+__device__ __forceinline__ uint16_t Float2HalfAway(float f) {
+  uint32_t bits = __float_as_uint(f);
+  uint32_t e = (bits >> 23) & 0xff;
+  if (e >= 113 && e < 142) {
+    _Float16 hf = (_Float16)f;  // v_cvt_f16_f32, round to nearest even
+    uint16_t h = __builtin_bit_cast(uint16_t, hf);
+    bool tie_down = ((bits & 0x1FFF) == 0x1000) && ((bits & 0x2000) == 0);
+    return tie_down ? (uint16_t)(h + 1) : h;
+  }
+  if ((bits & 0x7fffffff) == 0) return (uint16_t)(bits >> 16);
+  return Float2HalfAwaySlow(f);
+}
+
 struct Epilogue {
   void *out;
   int out_h, out_w, channels;
   int dtype, layout, normalize, mirror;
-  float mean[4], inv_std[4];
 
-  __device__ __forceinline__ void Store(int y, int x, int c, uint32_t v) const {
+  // element offset of (y, x, channel 0) and the per-channel stride
+  __device__ __forceinline__ size_t Base(int y, int x, size_t *cstride) const {
     int xo = mirror ? out_w - 1 - x : x;
-    size_t o = layout == DALIAMD_LAYOUT_CHW ? ((size_t)c * out_h + y) * out_w + xo
-                                            : ((size_t)y * out_w + xo) * channels + c;
+    if (layout == DALIAMD_LAYOUT_CHW) { *cstride = (size_t)out_h * out_w; return (size_t)y * out_w + xo; }
+    *cstride = 1;
+    return ((size_t)y * out_w + xo) * channels;
+  }
+  // mean / inv_std are passed by value: a runtime-indexed member array would live in scratch memory
+  __device__ __forceinline__ void Store(size_t o, uint32_t v, float mean, float inv_std) const {
+    float f = (float)v;
     if (dtype == DALIAMD_UINT8) {
-      float f = (float)v;
-      if (normalize) f = RoundU8(((float)v - mean[c]) * inv_std[c], false);
+      if (normalize) f = RoundU8((f - mean) * inv_std, false);
       reinterpret_cast<uint8_t *>(out)[o] = (uint8_t)f;
     } else {
-      float f = (float)v;
-      if (normalize) f = (f - mean[c]) * inv_std[c];
+      if (normalize) f = (f - mean) * inv_std;
       if (dtype == DALIAMD_FLOAT16) reinterpret_cast<uint16_t *>(out)[o] = Float2HalfAway(f);
       else reinterpret_cast<float *>(out)[o] = f;
     }
@@ -122,27 +142,45 @@ struct Epilogue {
 // ---------------------------------------------------------------------------------------------
 // kernel
 // ---------------------------------------------------------------------------------------------
+// Descriptor lookup: tile counts are usually identical across the batch, so first try the uniform
+// guess (two independent loads); fall back to the binary search.
+__device__ __forceinline__ int FindResampleDesc(const daliamdResampleDesc *descs, int n, int wg, int total_wg) {
+  int g = (int)(((long long)wg * n) / total_wg);
+  if (descs[g].wg_start <= wg && (g + 1 == n || wg < descs[g + 1].wg_start)) return g;
+  return FindDesc(descs, n, wg);
+}
+
+__device__ __forceinline__ void MinMax4(int a, int b, int c, int d, int *lo, int *hi) {
+  *lo = min(min(a, b), min(c, d));
+  *hi = max(max(a, b), max(c, d));
+}
+
+#define SEL4(c, a0, a1, a2, a3) ((c) == 0 ? (a0) : (c) == 1 ? (a1) : (c) == 2 ? (a2) : (a3))
+
 __global__ __launch_bounds__(kResampleThreads) void ResampleKernel(const daliamdResampleDesc *__restrict__ descs,
                                                                    int ndesc, int total_wg) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   int wg = XcdRemap(blockIdx.x, total_wg);
   if (wg < 0) return;
-  const daliamdResampleDesc &d = descs[FindDesc(descs, ndesc, wg)];
+  const daliamdResampleDesc &d = descs[FindResampleDesc(descs, ndesc, wg, total_wg)];
   const int tid = threadIdx.x;
   const int C = d.channels;
-  const int TH = d.tile_h, TW = d.tile_w;
+  const int TH = d.tile_h, TW = d.tile_w;       // powers of two
+  const int tw_log2 = 31 - __clz(TW);
   int t = wg - d.wg_start;
   int ty = t / d.tiles_x, tx = t - ty * d.tiles_x;
   const int oy0 = ty * TH, ox0 = tx * TW;
   const int th = min(TH, d.out_h - oy0), tw = min(TW, d.out_w - ox0);
   const int sup_x = d.support[0], sup_y = d.support[1];
 
-  float *cy = lds;                  // [TH][sup_y]
-  float *cx = cy + TH * sup_y;      // [TW][sup_x]
-  int *iy = reinterpret_cast<int *>(cx + TW * sup_x);  // [TH]
-  int *ix = iy + TH;                // [TW]
-  float *tmp = reinterpret_cast<float *>(ix + TW);
-  tmp = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(tmp) + 15) & ~(uintptr_t)15);
+  // LDS carve-up: coefficient tables, first-tap indices, per-tap source offsets, staged window, tmp
+  float *cy = lds;                                        // [TH][sup_y]
+  float *cx = cy + TH * sup_y;                            // [TW][sup_x]
+  int *yt = reinterpret_cast<int *>(cx + TW * sup_x);     // [TH][sup_y] per-tap row offset
+  int *xt = yt + TH * sup_y;                              // [TW][sup_x] per-tap column offset (elements)
+  int *iy = xt + TW * sup_x;                              // [TH]
+  int *ix = iy + TH;                                      // [TW]
+  uint8_t *stage = reinterpret_cast<uint8_t *>((reinterpret_cast<uintptr_t>(ix + TW) + 15) & ~(uintptr_t)15);
 
   // ---- index / coefficient tables (InitializeResamplingFilter) ----
   for (int i = tid; i < th + tw; i += kResampleThreads) {
@@ -169,133 +207,199 @@ __global__ __launch_bounds__(kResampleThreads) void ResampleKernel(const daliamd
   Epilogue ep;
   ep.out = d.out; ep.out_h = d.out_h; ep.out_w = d.out_w; ep.channels = C;
   ep.dtype = d.out_dtype; ep.layout = d.out_layout; ep.normalize = d.normalize; ep.mirror = d.mirror;
-#pragma unroll
-  for (int c = 0; c < 4; c++) { ep.mean[c] = d.mean[c]; ep.inv_std[c] = d.inv_std[c]; }
+  const float mean0 = d.mean[0], mean1 = d.mean[1], mean2 = d.mean[2], mean3 = d.mean[3];
+  const float inv0 = d.inv_std[0], inv1 = d.inv_std[1], inv2 = d.inv_std[2], inv3 = d.inv_std[3];
 
   const uint8_t *__restrict__ in = d.in;
   const int pitch = d.in_pitch;
+  const bool vfirst = d.first_axis == 1;
+  const bool staged = d.staged != 0;  // 0: source window too large for LDS, read it from global memory
 
-  if (d.first_axis == 1) {
-    // ================= vertical pass first (source rows -> LDS), then horizontal =================
-    // second axis = x: taps are clamped to the ROI window [lo_x, lo_x + ext_x)
-    const int ext_x = d.ext[0], lo_x = d.lo[0];
-    int a0 = ClampI(ix[0], 0, ext_x - 1), a1 = ClampI(ix[0] + sup_x - 1, 0, ext_x - 1);
-    int b0 = ClampI(ix[tw - 1], 0, ext_x - 1), b1 = ClampI(ix[tw - 1] + sup_x - 1, 0, ext_x - 1);
-    const int c_lo = min(min(a0, a1), min(b0, b1));
-    const int c_hi = max(max(a0, a1), max(b0, b1)) + 1;
-    const int nbytes = (c_hi - c_lo) * C;      // tmp row length in elements
-    const int in_h = d.ext[1];                 // first axis: clamp to the whole image
-    const uint8_t *row0 = in + (size_t)(lo_x + c_lo) * C;
-    if ((pitch & 3) == 0) {
-      // dword path: every row has the same alignment
-      const int shift = (int)(reinterpret_cast<uintptr_t>(row0) & 3);
-      const uint8_t *arow0 = row0 - shift;
-      const int ndw = (nbytes + shift + 3) >> 2;
-      // bytes of the image buffer reachable from arow0 (never read past in + in_h * pitch)
-      const ptrdiff_t buf_end = (ptrdiff_t)in_h * pitch - (arow0 - in);
-      for (int i = tid; i < th * ndw; i += kResampleThreads) {
-        int y = i / ndw, j = i - y * ndw;
-        const float *co = cy + y * sup_y;
-        int r0 = iy[y];
-        float a[4] = {0, 0, 0, 0};
-        for (int k = 0; k < sup_y; k++) {
-          int r = ClampI(r0 + k, 0, in_h - 1);
-          ptrdiff_t off = (ptrdiff_t)r * pitch + 4 * j;
-          uint32_t v;
-          if (off >= -(arow0 - in) && off + 4 <= buf_end) {
-            v = *reinterpret_cast<const uint32_t *>(arow0 + off);
-          } else {  // first/last dword of the buffer: assemble from the in-bounds bytes
-            v = 0;
-            for (int b = 0; b < 4; b++) {
-              ptrdiff_t o = off + b;
-              if (o >= -(arow0 - in) && o < buf_end) v |= (uint32_t)arow0[o] << (8 * b);
-            }
+  // ---- source window of this tile: rows [y_lo, y_hi] x columns [x_lo, x_hi] (in each axis' clamp frame) ----
+  // first-pass axis: taps clamped to the whole image; second-pass axis: to the ROI window [lo, lo+ext)
+  const int ex = d.ext[0] - 1, ey = d.ext[1] - 1;
+  int x_lo, x_hi, y_lo, y_hi;
+  MinMax4(ClampI(ix[0], 0, ex), ClampI(ix[0] + sup_x - 1, 0, ex), ClampI(ix[tw - 1], 0, ex),
+          ClampI(ix[tw - 1] + sup_x - 1, 0, ex), &x_lo, &x_hi);
+  MinMax4(ClampI(iy[0], 0, ey), ClampI(iy[0] + sup_y - 1, 0, ey), ClampI(iy[th - 1], 0, ey),
+          ClampI(iy[th - 1] + sup_y - 1, 0, ey), &y_lo, &y_hi);
+  const int ncols = x_hi - x_lo + 1, nrows = y_hi - y_lo + 1;
+  const int NB = ncols * C;                              // bytes per window row
+  const int LP = (NB + 15 + 15) & ~15;                   // LDS row pitch (room for the alignment shift)
+  const uint8_t *win = in + (size_t)(d.lo[1] + y_lo) * pitch + (size_t)(d.lo[0] + x_lo) * C;
+  const uintptr_t win_addr = reinterpret_cast<uintptr_t>(win);
+  float *tmp = reinterpret_cast<float *>(stage + (staged ? (size_t)nrows * LP : 0));
+  const int rowlen = tw * C;                             // H-first tmp row length
+
+  // ---- per-tap offset tables ----
+  //   xt: element offset of tap k of column x inside a window row
+  //   yt: V-first: byte offset of element 0 of the tapped row inside `stage` (or `win` when not staged)
+  //       H-first: element offset of the tapped row inside tmp
+  for (int i = tid; i < tw * sup_x; i += kResampleThreads) {
+    int x = i / sup_x, k = i - x * sup_x;
+    xt[i] = (ClampI(ix[x] + k, 0, ex) - x_lo) * C;
+  }
+  for (int i = tid; i < th * sup_y; i += kResampleThreads) {
+    int y = i / sup_y, k = i - y * sup_y;
+    int r = ClampI(iy[y] + k, 0, ey) - y_lo;
+    int v;
+    if (!vfirst) v = r * rowlen;
+    else if (staged) v = r * LP + (int)((win_addr + (size_t)r * pitch) & 15);
+    else v = r * pitch;
+    yt[i] = v;
+  }
+
+  // ---- stage the window in LDS with 16-byte coalesced loads (each row keeps its own alignment shift) ----
+  if (staged) {
+    const uintptr_t buf_lo = reinterpret_cast<uintptr_t>(in);
+    const uintptr_t buf_hi = buf_lo + (size_t)d.in_h * pitch;
+    for (int r = tid >> 4; r < nrows; r += kResampleThreads / 16) {
+      uintptr_t ra = win_addr + (size_t)r * pitch;
+      int sh = (int)(ra & 15);
+      int nch = (sh + NB + 15) >> 4;
+      uint8_t *dst = stage + r * LP;
+      for (int q = tid & 15; q < nch; q += 16) {
+        uintptr_t g = ra - sh + 16 * q;
+        uint4 v;
+        if (g >= buf_lo && g + 16 <= buf_hi) {
+          v = *reinterpret_cast<const uint4 *>(g);
+        } else {  // chunk straddles the buffer boundary: assemble from the in-bounds bytes
+          uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+#pragma unroll
+          for (int b = 0; b < 16; b++) {
+            uintptr_t a = g + b;
+            uint32_t byte = (a >= buf_lo && a < buf_hi) ? (uint32_t)(*reinterpret_cast<const uint8_t *>(a)) : 0u;
+            byte <<= 8 * (b & 3);
+            if (b < 4) w0 |= byte; else if (b < 8) w1 |= byte; else if (b < 12) w2 |= byte; else w3 |= byte;
           }
-          float w = co[k];
-#pragma unroll
-          for (int b = 0; b < 4; b++) a[b] += (float)((v >> (8 * b)) & 255) * w;
+          v = make_uint4(w0, w1, w2, w3);
         }
-        float *trow = tmp + y * nbytes;
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-          int e = 4 * j + b - shift;
-          if (e >= 0 && e < nbytes) trow[e] = a[b];
+        *reinterpret_cast<uint4 *>(dst + 16 * q) = v;
+      }
+    }
+  }
+  __syncthreads();
+  const uint8_t *src = staged ? stage : win;  // byte-addressed source rows (LDS or global)
+
+  if (vfirst) {
+    // ================= vertical pass (window rows -> tmp[th][NB]), then horizontal =================
+    if (staged && (pitch & 3) == 0) {
+      // every row has the same shift modulo 4: produce 4 consecutive elements from one LDS dword per tap
+      const int s4 = (int)(win_addr & 3);
+      const int ndw = (NB + s4 + 3) >> 2;
+      for (int y = tid >> 6; y < th; y += kResampleThreads / 64) {
+        const float *co = cy + y * sup_y;
+        const int *ro = yt + y * sup_y;
+        float *trow = tmp + y * NB;
+        for (int j = tid & 63; j < ndw; j += 64) {
+          float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+          const uint8_t *col = stage + 4 * j - s4;
+          for (int k = 0; k < sup_y; k++) {
+            uint32_t v = *reinterpret_cast<const uint32_t *>(col + ro[k]);
+            float w = co[k];
+            a0 += (float)(v & 255) * w;
+            a1 += (float)((v >> 8) & 255) * w;
+            a2 += (float)((v >> 16) & 255) * w;
+            a3 += (float)(v >> 24) * w;
+          }
+          int e = 4 * j - s4;
+          if (e >= 0 && e + 3 < NB) {
+            trow[e] = a0; trow[e + 1] = a1; trow[e + 2] = a2; trow[e + 3] = a3;
+          } else {
+            if (e >= 0 && e < NB) trow[e] = a0;
+            if (e + 1 >= 0 && e + 1 < NB) trow[e + 1] = a1;
+            if (e + 2 >= 0 && e + 2 < NB) trow[e + 2] = a2;
+            if (e + 3 >= 0 && e + 3 < NB) trow[e + 3] = a3;
+          }
         }
       }
     } else {
-      for (int i = tid; i < th * nbytes; i += kResampleThreads) {
-        int y = i / nbytes, j = i - y * nbytes;
+      for (int y = tid >> 6; y < th; y += kResampleThreads / 64) {
         const float *co = cy + y * sup_y;
-        int r0 = iy[y];
-        float a = 0;
-        for (int k = 0; k < sup_y; k++) {
-          int r = ClampI(r0 + k, 0, in_h - 1);
-          a += (float)row0[(size_t)r * pitch + j] * co[k];
+        const int *ro = yt + y * sup_y;
+        for (int e = tid & 63; e < NB; e += 64) {
+          float a = 0;
+          for (int k = 0; k < sup_y; k++) a += (float)src[ro[k] + e] * co[k];
+          tmp[y * NB + e] = a;
         }
-        tmp[y * nbytes + j] = a;
       }
     }
     __syncthreads();
-    const int n_out = th * tw * C;
-    for (int i = tid; i < n_out; i += kResampleThreads) {
-      int c = i % C;
-      int xy = i / C;
-      int x = xy % tw, y = xy / tw;
+    const int x = tid & (TW - 1);
+    if (x < tw) {
       const float *co = cx + x * sup_x;
-      const float *trow = tmp + y * nbytes;
-      int s0 = ix[x];
-      float a = 0;
-      for (int k = 0; k < sup_x; k++) {
-        int sx = ClampI(s0 + k, 0, ext_x - 1) - c_lo;
-        a += co[k] * trow[sx * C + c];
+      const int *xo = xt + x * sup_x;
+      const int gx = ox0 + x;
+      const bool even = (d.even_mask[(gx >> 5) & 7] >> (gx & 31)) & 1;
+      for (int y = tid >> tw_log2; y < th; y += kResampleThreads >> tw_log2) {
+        const float *trow = tmp + y * NB;
+        float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        for (int k = 0; k < sup_x; k++) {
+          float w = co[k];
+          const float *p = trow + xo[k];
+          a0 += w * p[0];
+          if (C > 1) a1 += w * p[1];
+          if (C > 2) a2 += w * p[2];
+          if (C > 3) a3 += w * p[3];
+        }
+        size_t cs, o = ep.Base(oy0 + y, gx, &cs);
+        ep.Store(o, RoundU8(a0, even), mean0, inv0);
+        if (C > 1) ep.Store(o + cs, RoundU8(a1, even), mean1, inv1);
+        if (C > 2) ep.Store(o + 2 * cs, RoundU8(a2, even), mean2, inv2);
+        if (C > 3) ep.Store(o + 3 * cs, RoundU8(a3, even), mean3, inv3);
       }
-      int gx = ox0 + x;
-      bool even = (d.even_mask[(gx >> 5) & 7] >> (gx & 31)) & 1;
-      ep.Store(oy0 + y, gx, c, RoundU8(a, even));
     }
   } else {
-    // ================= horizontal pass first (gather along rows -> LDS), then vertical =================
-    const int ext_y = d.ext[1], lo_y = d.lo[1];
-    int a0 = ClampI(iy[0], 0, ext_y - 1), a1 = ClampI(iy[0] + sup_y - 1, 0, ext_y - 1);
-    int b0 = ClampI(iy[th - 1], 0, ext_y - 1), b1 = ClampI(iy[th - 1] + sup_y - 1, 0, ext_y - 1);
-    const int r_lo = min(min(a0, a1), min(b0, b1));
-    const int r_hi = max(max(a0, a1), max(b0, b1)) + 1;
-    const int nrows = r_hi - r_lo;
-    const int in_w = d.ext[0];
-    const int rowlen = tw * C;
-    const uint8_t *base = in + (size_t)(lo_y + r_lo) * pitch;
-    for (int i = tid; i < nrows * rowlen; i += kResampleThreads) {
-      int r = i / rowlen, j = i - r * rowlen;
-      int x = j / C, c = j - x * C;
+    // ================= horizontal pass (window rows -> tmp[nrows][tw*C]), then vertical =================
+    const int x = tid & (TW - 1);
+    if (x < tw) {
       const float *co = cx + x * sup_x;
-      const uint8_t *row = base + (size_t)r * pitch + c;
-      int s0 = ix[x];
-      float a = 0;
-      for (int k = 0; k < sup_x; k++) {
-        int sx = ClampI(s0 + k, 0, in_w - 1);
-        a += co[k] * (float)row[sx * C];
+      const int *xo = xt + x * sup_x;
+      for (int r = tid >> tw_log2; r < nrows; r += kResampleThreads >> tw_log2) {
+        const uint8_t *srow = staged ? stage + r * LP + (int)((win_addr + (size_t)r * pitch) & 15)
+                                     : win + (size_t)r * pitch;
+        float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        for (int k = 0; k < sup_x; k++) {
+          float w = co[k];
+          const uint8_t *p = srow + xo[k];
+          a0 += w * (float)p[0];
+          if (C > 1) a1 += w * (float)p[1];
+          if (C > 2) a2 += w * (float)p[2];
+          if (C > 3) a3 += w * (float)p[3];
+        }
+        float *tp = tmp + r * rowlen + x * C;
+        tp[0] = a0;
+        if (C > 1) tp[1] = a1;
+        if (C > 2) tp[2] = a2;
+        if (C > 3) tp[3] = a3;
       }
-      tmp[i] = a;
     }
     __syncthreads();
-    const int n_out = th * rowlen;
     const int flat_w = d.out_w * C;
-    for (int i = tid; i < n_out; i += kResampleThreads) {
-      int y = i / rowlen, j = i - y * rowlen;
-      int x = j / C, c = j - x * C;
-      const float *co = cy + y * sup_y;
-      int s0 = iy[y];
-      float a = 0;
-      for (int k = 0; k < sup_y; k++) {
-        int sy = ClampI(s0 + k, 0, ext_y - 1) - r_lo;
-        a += tmp[sy * rowlen + j] * co[k];
+    if (x < tw) {
+      for (int y = tid >> tw_log2; y < th; y += kResampleThreads >> tw_log2) {
+        const float *co = cy + y * sup_y;
+        const int *ro = yt + y * sup_y;
+        const float *tcol = tmp + x * C;
+        float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        for (int k = 0; k < sup_y; k++) {
+          float w = co[k];
+          const float *p = tcol + ro[k];
+          a0 += p[0] * w;
+          if (C > 1) a1 += p[1] * w;
+          if (C > 2) a2 += p[2] * w;
+          if (C > 3) a3 += p[3] * w;
+        }
+        // ResampleVert: 256-element tiles, 16-lane SIMD body then scalar tail
+        int fi = (ox0 + x) * C;
+        size_t cs, o = ep.Base(oy0 + y, ox0 + x, &cs);
+#define VLAST_EVEN(f) ((f) < ((f) & ~255) + ((min(((f) & ~255) + 256, flat_w) - ((f) & ~255)) & ~15))
+        ep.Store(o, RoundU8(a0, VLAST_EVEN(fi)), mean0, inv0);
+        if (C > 1) ep.Store(o + cs, RoundU8(a1, VLAST_EVEN(fi + 1)), mean1, inv1);
+        if (C > 2) ep.Store(o + 2 * cs, RoundU8(a2, VLAST_EVEN(fi + 2)), mean2, inv2);
+        if (C > 3) ep.Store(o + 3 * cs, RoundU8(a3, VLAST_EVEN(fi + 3)), mean3, inv3);
+#undef VLAST_EVEN
       }
-      // ResampleVert: 256-element tiles, 16-lane SIMD body then scalar tail
-      int fi = (ox0 + x) * C + c;
-      int t0 = fi & ~255;
-      int tend = min(t0 + 256, flat_w);
-      bool even = fi < t0 + ((tend - t0) & ~15);
-      ep.Store(oy0 + y, ox0 + x, c, RoundU8(a, even));
     }
   }
 }
@@ -434,33 +538,43 @@ static int SetupOne(const daliamdResampleArgs &a, daliamdResampleDesc &d, int in
     }
   }
 
-  // tile selection: keep tmp + tables inside the LDS budget
-  int tw = 32, th = 16;
-  auto lds_need = [&](int tw_, int th_) -> size_t {
-    size_t tables = (size_t)th_ * d.support[1] + (size_t)tw_ * d.support[0] + th_ + tw_;
-    size_t tmp_elems;
-    if (d.first_axis == 1) {
-      size_t ncols = (size_t)std::ceil(tw_ * std::abs(d.scale[0])) + d.support[0] + 2;
-      tmp_elems = (size_t)th_ * ncols * a.channels;
-    } else {
-      size_t nrows = (size_t)std::ceil(th_ * std::abs(d.scale[1])) + d.support[1] + 2;
-      tmp_elems = nrows * (size_t)tw_ * a.channels;
-    }
-    return (tables + tmp_elems) * 4 + 16;
+  // tile selection: keep tables + staged source window + tmp inside the LDS budget.  When even small tiles
+  // cannot hold their source window (extreme down-scaling) fall back to reading the source from global memory.
+  auto lds_need = [&](int tw_, int th_, bool staged) -> size_t {
+    size_t tables = 2 * ((size_t)th_ * d.support[1] + (size_t)tw_ * d.support[0]) + th_ + tw_;
+    size_t ncols = (size_t)std::ceil(tw_ * std::abs(d.scale[0])) + d.support[0] + 2;
+    size_t nrows = (size_t)std::ceil(th_ * std::abs(d.scale[1])) + d.support[1] + 2;
+    ncols = std::min<size_t>(ncols, a.in_w);
+    nrows = std::min<size_t>(nrows, a.in_h);
+    size_t lp = (ncols * a.channels + 15 + 15) & ~(size_t)15;
+    size_t stage = staged ? nrows * lp : 0;
+    size_t tmp_elems = d.first_axis == 1 ? (size_t)th_ * ncols * a.channels : nrows * (size_t)tw_ * a.channels;
+    return tables * 4 + 16 + stage + tmp_elems * 4;
   };
-  while (lds_need(tw, th) > (size_t)kMaxLds && (tw > 1 || th > 1)) {
-    bool shrink_h;
-    if (d.first_axis == 1) shrink_h = th > 1;   // tmp = th x cols: rows are the cheap thing to drop
-    else shrink_h = !(tw > 1);                  // tmp = rows x tw: columns are the cheap thing to drop
-    if (shrink_h) th >>= 1; else tw >>= 1;
+  auto shrink = [&](int &tw_, int &th_, bool staged, int min_area, size_t budget) {
+    tw_ = 32; th_ = 16;
+    while (lds_need(tw_, th_, staged) > budget && tw_ * th_ > min_area) {
+      double fx = tw_ * std::abs(d.scale[0]) + d.support[0], fy = th_ * std::abs(d.scale[1]) + d.support[1];
+      bool shrink_h = th_ > 1 && (fy >= fx || tw_ == 1);
+      if (shrink_h) th_ >>= 1; else tw_ >>= 1;
+    }
+    return lds_need(tw_, th_, staged) <= budget;
+  };
+  // 1) comfortable budget: 6 workgroups per CU (160 KiB LDS) so memory latency stays hidden;
+  // 2) whole LDS budget with smaller tiles; 3) no staging at all.
+  int tw, th;
+  bool staged = shrink(tw, th, true, 128, kTargetLds) || shrink(tw, th, true, 64, kMaxLds);
+  if (!staged) {
+    bool ok = shrink(tw, th, false, 1, kMaxLds);
+    DALIAMD_REQUIRE(ok, DALIAMD_ERROR_UNSUPPORTED,
+                    "daliamdResampleSetup: sample %d: scale %g x %g needs more LDS than available", index,
+                    d.scale[0], d.scale[1]);
   }
-  DALIAMD_REQUIRE(lds_need(tw, th) <= (size_t)kMaxLds, DALIAMD_ERROR_UNSUPPORTED,
-                  "daliamdResampleSetup: sample %d: scale %g x %g needs more LDS than available", index,
-                  d.scale[0], d.scale[1]);
+  d.staged = staged ? 1 : 0;
   d.tile_w = tw; d.tile_h = th;
   d.tiles_x = (a.out_w + tw - 1) / tw;
   d.tiles_y = (a.out_h + th - 1) / th;
-  d.lds_bytes = (int)lds_need(tw, th);
+  d.lds_bytes = (int)lds_need(tw, th, staged);
   return DALIAMD_SUCCESS;
 }
 

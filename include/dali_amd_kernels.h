@@ -169,6 +169,7 @@ typedef struct {
   float mean[4], inv_std[4];
   uint32_t even_mask[8];     /* H-last: per output column, 1 = round half to even               */
   int32_t lds_bytes;
+  int32_t staged;            /* 1: the tile's source window is staged in LDS; 0: read from global memory */
 } daliamdResampleDesc;
 
 /* Fills descs_host[0..n); returns the grid size and the dynamic LDS bytes the launch needs. */
