@@ -1,0 +1,206 @@
+"""ctypes binding of the C++ host framework's flat C API (dali_amd/host/c_api.cpp) -- the counterpart
+of the reference's pybind11 module `nvidia.dali.backend_impl`."""
+import ctypes as C
+import json
+
+from . import _capi as capi
+
+
+def _lib():
+    capi.kernels()      # torch + the kernel library first (single HIP runtime, see _capi.kernels)
+    lib = capi.host()
+    if not getattr(lib, "_pipeline_api_ready", False):
+        lib.daliamdOpSpecCreate.restype = C.c_void_p
+        lib.daliamdPipelineCreate.restype = C.c_void_p
+        lib.daliamdPipelineStream.restype = C.c_void_p
+        lib.daliamdPipelineSeed.restype = C.c_int64
+        lib.daliamdPipelineCreate.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int]
+        for f in ("daliamdOpSpecDestroy", "daliamdPipelineDestroy"):
+            getattr(lib, f).argtypes = [C.c_void_p]
+            getattr(lib, f).restype = None
+        lib.daliamdOpSpecAddArgInt.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        lib.daliamdOpSpecAddArgBool.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        lib.daliamdOpSpecAddArgFloat.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+        lib.daliamdOpSpecAddArgStr.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+        lib.daliamdOpSpecAddArgIntVec.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64), C.c_int]
+        lib.daliamdOpSpecAddArgFloatVec.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.c_int]
+        lib.daliamdOpSpecAddArgStrVec.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int]
+        lib.daliamdOpSpecAddInput.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        lib.daliamdOpSpecAddOutput.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        lib.daliamdOpSpecAddArgumentInput.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+        lib.daliamdPipelineAddOperator.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p]
+        lib.daliamdPipelineBuild.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int]
+        lib.daliamdPipelineRun.argtypes = [C.c_void_p]
+        lib.daliamdPipelineOutputs.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        lib.daliamdPipelineOutputInfo.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_char_p, C.c_int]
+        lib.daliamdPipelineOutputSample.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p),
+                                                    C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int64)]
+        lib.daliamdPipelineFeedInput.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                                                 C.c_int, C.c_int, C.c_int, C.c_char_p]
+        lib.daliamdPipelineReaderMeta.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]
+        for f in ("daliamdPipelineReaderNames", "daliamdPipelineCheckpoint", "daliamdPipelineLastLaunches"):
+            getattr(lib, f).argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        lib.daliamdPipelineRestore.argtypes = [C.c_void_p, C.c_char_p]
+        lib.daliamdPipelineStream.argtypes = [C.c_void_p]
+        lib.daliamdPipelineSeed.argtypes = [C.c_void_p]
+        lib._pipeline_api_ready = True
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = _lib().daliamdHostGetLastErrorMessage()
+        raise RuntimeError(msg.decode(errors="replace") if msg else "unknown error")
+
+
+def _string_out(fn, *args):
+    lib = _lib()
+    need = fn(*args, None, 0)
+    if need < 0:
+        check(1)
+    buf = C.create_string_buffer(max(need, 1))
+    rc = fn(*args, buf, need)
+    if rc < 0:
+        check(1)
+    return buf.value.decode()
+
+
+_schema_cache = {}
+
+
+def schema_names():
+    return [s for s in _string_out(_lib().daliamdSchemaList).split("\n") if s]
+
+
+def get_schema(name):
+    if name not in _schema_cache:
+        lib = _lib()
+        lib.daliamdSchemaInfo.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+        _schema_cache[name] = json.loads(_string_out(lib.daliamdSchemaInfo, name.encode()))
+    return _schema_cache[name]
+
+
+class OpSpec:
+    def __init__(self, schema_name):
+        self._lib = _lib()
+        self.schema_name = schema_name
+        self._h = self._lib.daliamdOpSpecCreate(schema_name.encode())
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.daliamdOpSpecDestroy(self._h)
+            self._h = None
+
+    def add_arg(self, name, value):
+        import numpy as np
+        from . import types
+        lib, h, n = self._lib, self._h, name.encode()
+        if isinstance(value, types._DALIEnum):
+            value = int(value)
+        if isinstance(value, (bool, np.bool_)):
+            lib.daliamdOpSpecAddArgBool(h, n, int(value))
+        elif isinstance(value, (int, np.integer)):
+            lib.daliamdOpSpecAddArgInt(h, n, int(value))
+        elif isinstance(value, (float, np.floating)):
+            lib.daliamdOpSpecAddArgFloat(h, n, float(value))
+        elif isinstance(value, str):
+            lib.daliamdOpSpecAddArgStr(h, n, value.encode())
+        elif isinstance(value, (list, tuple, np.ndarray)):
+            vals = [int(v) if isinstance(v, types._DALIEnum) else v for v in (value.tolist() if isinstance(value, np.ndarray) else value)]
+            if len(vals) and all(isinstance(v, str) for v in vals):
+                arr = (C.c_char_p * len(vals))(*[v.encode() for v in vals])
+                lib.daliamdOpSpecAddArgStrVec(h, n, arr, len(vals))
+            elif all(isinstance(v, (int, np.integer)) and not isinstance(v, bool) for v in vals):
+                arr = (C.c_int64 * len(vals))(*[int(v) for v in vals])
+                lib.daliamdOpSpecAddArgIntVec(h, n, arr, len(vals))
+            else:
+                arr = (C.c_double * len(vals))(*[float(v) for v in vals])
+                lib.daliamdOpSpecAddArgFloatVec(h, n, arr, len(vals))
+        else:
+            raise TypeError(f"Unsupported value for argument `{name}` of operator `{self.schema_name}`: "
+                            f"{type(value).__name__}")
+
+    def add_input(self, name, device):
+        self._lib.daliamdOpSpecAddInput(self._h, name.encode(), 1 if device == "gpu" else 0)
+
+    def add_output(self, name, device):
+        self._lib.daliamdOpSpecAddOutput(self._h, name.encode(), 1 if device == "gpu" else 0)
+
+    def add_argument_input(self, arg, tensor_name):
+        self._lib.daliamdOpSpecAddArgumentInput(self._h, arg.encode(), tensor_name.encode())
+
+
+class BackendPipeline:
+    def __init__(self, batch_size, num_threads, device_id, seed, prefetch_queue_depth, exec_async):
+        self._lib = _lib()
+        self._h = self._lib.daliamdPipelineCreate(batch_size, num_threads, device_id, seed, prefetch_queue_depth,
+                                                  1 if exec_async else 0)
+        if not self._h:
+            check(1)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.daliamdPipelineDestroy(self._h)
+            self._h = None
+
+    def add_operator(self, spec, name):
+        check(self._lib.daliamdPipelineAddOperator(self._h, spec._h, name.encode()))
+
+    def build(self, outputs):
+        names = (C.c_char_p * len(outputs))(*[n.encode() for n, _ in outputs])
+        gpu = (C.c_int * len(outputs))(*[1 if d == "gpu" else 0 for _, d in outputs])
+        check(self._lib.daliamdPipelineBuild(self._h, names, gpu, len(outputs)))
+
+    def run(self):
+        check(self._lib.daliamdPipelineRun(self._h))
+
+    def outputs(self):
+        n = C.c_int(0)
+        check(self._lib.daliamdPipelineOutputs(self._h, C.byref(n)))
+        return n.value
+
+    def output_info(self, idx):
+        info = (C.c_int64 * 4)()
+        layout = C.create_string_buffer(16)
+        check(self._lib.daliamdPipelineOutputInfo(self._h, idx, info, layout, 16))
+        return dict(gpu=bool(info[0]), dtype=int(info[1]), num_samples=int(info[2]), dense=bool(info[3]),
+                    layout=layout.value.decode())
+
+    def output_sample(self, idx, i):
+        ptr, shape, ndim, pitch = C.c_void_p(), (C.c_int64 * 8)(), C.c_int(0), C.c_int64(0)
+        check(self._lib.daliamdPipelineOutputSample(self._h, idx, i, C.byref(ptr), shape, C.byref(ndim), C.byref(pitch)))
+        return ptr.value or 0, tuple(shape[:ndim.value]), int(pitch.value)
+
+    def feed_input(self, name, arrays, dtype, layout):
+        import numpy as np
+        n = len(arrays)
+        ndim = arrays[0].ndim if n else 1
+        ptrs = (C.c_void_p * max(n, 1))(*[a.ctypes.data for a in arrays])
+        shapes = np.array([a.shape for a in arrays], np.int64).reshape(-1)
+        check(self._lib.daliamdPipelineFeedInput(self._h, name.encode(), ptrs,
+                                                 shapes.ctypes.data_as(C.POINTER(C.c_int64)), ndim, n, dtype,
+                                                 (layout or "").encode()))
+
+    def reader_meta(self, name):
+        meta = (C.c_int64 * 6)()
+        check(self._lib.daliamdPipelineReaderMeta(self._h, name.encode(), meta))
+        return dict(epoch_size=int(meta[0]), epoch_size_padded=int(meta[1]), number_of_shards=int(meta[2]),
+                    shard_id=int(meta[3]), pad_last_batch=int(meta[4]), stick_to_shard=int(meta[5]))
+
+    def reader_names(self):
+        return [s for s in _string_out(self._lib.daliamdPipelineReaderNames, self._h).split("\n") if s]
+
+    def checkpoint(self):
+        return _string_out(self._lib.daliamdPipelineCheckpoint, self._h)
+
+    def restore(self, cpt):
+        check(self._lib.daliamdPipelineRestore(self._h, cpt.encode()))
+
+    def last_launches(self):
+        return [s for s in _string_out(self._lib.daliamdPipelineLastLaunches, self._h).split("\n") if s]
+
+    def stream(self):
+        return self._lib.daliamdPipelineStream(self._h)
+
+    def seed(self):
+        return int(self._lib.daliamdPipelineSeed(self._h))

@@ -34,7 +34,8 @@ class JpegColorDesc(C.Structure):
     _fields_ = [("plane", C.c_void_p * 3), ("pitch", C.c_int32 * 3), ("h_samp", C.c_int32 * 3),
                 ("v_samp", C.c_int32 * 3), ("down_w", C.c_int32 * 3), ("down_h", C.c_int32 * 3),
                 ("width", C.c_int32), ("height", C.c_int32), ("color", C.c_int32),
-                ("out", C.c_void_p), ("out_pitch", C.c_int32), ("wg_start", C.c_int32)]
+                ("out", C.c_void_p), ("out_pitch", C.c_int32), ("wg_start", C.c_int32),
+                ("orientation", C.c_int32), ("reserved", C.c_int32)]
 
 
 class ResampleArgs(C.Structure):

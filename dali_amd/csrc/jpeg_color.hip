@@ -128,8 +128,27 @@ __global__ __launch_bounds__(kColorThreads) void JpegColorKernel(const daliamdJp
       px[3 * i] = Clamp8(r); px[3 * i + 1] = Clamp8(g); px[3 * i + 2] = Clamp8(b);
     }
   }
-  uint8_t *o = d.out + (size_t)y * d.out_pitch + (size_t)x0 * 3;
   int npx = min(8, d.width - x0);
+  if (d.orientation > 1) {
+    // undo the EXIF orientation: source pixel (y, x) lands at (oy, ox) of the upright image
+    const int W = d.width, H = d.height;
+    for (int i = 0; i < npx; i++) {
+      int x = x0 + i, oy, ox;
+      switch (d.orientation) {
+        case 2: oy = y; ox = W - 1 - x; break;
+        case 3: oy = H - 1 - y; ox = W - 1 - x; break;
+        case 4: oy = H - 1 - y; ox = x; break;
+        case 5: oy = x; ox = y; break;
+        case 6: oy = x; ox = H - 1 - y; break;
+        case 7: oy = W - 1 - x; ox = H - 1 - y; break;
+        default: oy = W - 1 - x; ox = y; break;  // 8
+      }
+      uint8_t *p = d.out + (size_t)oy * d.out_pitch + (size_t)ox * 3;
+      p[0] = (uint8_t)px[3 * i]; p[1] = (uint8_t)px[3 * i + 1]; p[2] = (uint8_t)px[3 * i + 2];
+    }
+    return;
+  }
+  uint8_t *o = d.out + (size_t)y * d.out_pitch + (size_t)x0 * 3;
   if (npx == 8 && ((d.out_pitch & 7) == 0) && ((reinterpret_cast<uintptr_t>(d.out) & 7) == 0)) {
     uint32_t w[6];
 #pragma unroll
@@ -156,7 +175,9 @@ daliamdResult_t daliamdJpegColorSetup(daliamdJpegColorDesc *descs, int n, int *n
     auto &d = descs[i];
     DALIAMD_REQUIRE(d.width > 0 && d.height > 0, DALIAMD_ERROR_INVALID_ARGUMENT,
                     "daliamdJpegColorSetup: desc %d has empty image", i);
-    DALIAMD_REQUIRE(d.out_pitch >= 3 * d.width, DALIAMD_ERROR_INVALID_ARGUMENT,
+    DALIAMD_REQUIRE(d.orientation >= 0 && d.orientation <= 8, DALIAMD_ERROR_INVALID_ARGUMENT,
+                    "daliamdJpegColorSetup: desc %d: invalid EXIF orientation %d", i, d.orientation);
+    DALIAMD_REQUIRE(d.out_pitch >= 3 * (d.orientation >= 5 ? d.height : d.width), DALIAMD_ERROR_INVALID_ARGUMENT,
                     "daliamdJpegColorSetup: desc %d out_pitch %d < 3*width", i, d.out_pitch);
     int ncomp = d.color == DALIAMD_JPEG_GRAY ? 1 : 3;
     int hmax = 1, vmax = 1;

@@ -1,0 +1,388 @@
+// C++ host framework of dali_amd: tensor lists, thread pool, operator schema / spec / registry and
+// the workspace handed to operators.  It mirrors the reference's drop-in boundary for out-of-tree
+// operators at the scale this hot path needs:
+//   OpSchema + DALI_SCHEMA            dali/pipeline/operator/op_schema.h:1096-1109
+//   OpSpec                            dali/pipeline/operator/op_spec.h
+//   OperatorBase / Setup / Run        dali/pipeline/operator/operator.h:76-252
+//   DALI_REGISTER_OPERATOR + registry dali/pipeline/operator/operator.h:327-333, operator_factory.h:37-139
+//   Workspace                         dali/pipeline/workspace/workspace.h
+//   TensorList                        dali/pipeline/data/tensor_list.h
+//   ThreadPool::AddWork / RunAll      dali/pipeline/util/thread_pool.h
+// Host code never includes HIP headers: the device is reached only through the C ABI in
+// include/dali_amd_kernels.h.
+#ifndef DALI_AMD_HOST_FRAMEWORK_H_
+#define DALI_AMD_HOST_FRAMEWORK_H_
+
+#include <atomic>
+#include <condition_variable>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <utility>
+#include <vector>
+
+#include "dali_amd_kernels.h"
+
+namespace daliamd_host {
+
+// ---------------------------------------------------------------------------------------------
+// errors (DALI_ENFORCE / DALI_FAIL -> std::runtime_error, dali/core/error_handling.h)
+// ---------------------------------------------------------------------------------------------
+template <typename... Args>
+std::string make_string(const Args &...args) {
+  std::ostringstream ss;
+  (void)std::initializer_list<int>{(ss << args, 0)...};
+  return ss.str();
+}
+#define DALI_FAIL(...) throw std::runtime_error(::daliamd_host::make_string(__VA_ARGS__))
+#define DALI_ENFORCE(cond, ...)                                                                  \
+  do {                                                                                           \
+    if (!(cond)) throw std::runtime_error(::daliamd_host::make_string("Assert on \"", #cond,      \
+                                                                       "\" failed: ", __VA_ARGS__)); \
+  } while (0)
+// kernel-library call that must succeed
+#define KCHECK(expr)                                                                             \
+  do {                                                                                           \
+    int _rc = (expr);                                                                            \
+    if (_rc != 0) DALI_FAIL("device library error ", _rc, ": ", daliamdGetLastErrorMessage());    \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// types
+// ---------------------------------------------------------------------------------------------
+// values follow DALIDataType (include/dali/core/dali_data_type.h) for the types used here
+enum DALIDataType : int {
+  DALI_NO_TYPE = -1, DALI_UINT8 = 0, DALI_UINT16 = 1, DALI_UINT32 = 2, DALI_UINT64 = 3, DALI_INT8 = 4,
+  DALI_INT16 = 5, DALI_INT32 = 6, DALI_INT64 = 7, DALI_FLOAT16 = 8, DALI_FLOAT = 9, DALI_FLOAT64 = 10,
+  DALI_BOOL = 11
+};
+int TypeSize(DALIDataType t);
+const char *TypeName(DALIDataType t);
+int ToKernelDType(DALIDataType t);  // daliamdDType_t or throws
+
+enum class StorageDevice { CPU = 0, GPU = 1 };
+enum class OpType { CPU = 0, GPU = 1, MIXED = 2 };
+OpType ParseOpType(const std::string &device);
+const char *OpTypeName(OpType t);
+
+using TensorShape = std::vector<int64_t>;
+inline int64_t volume(const TensorShape &s) {
+  int64_t v = 1;
+  for (auto e : s) v *= e;
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Buffer + TensorList
+// ---------------------------------------------------------------------------------------------
+// Grow-only allocation (like the reference's Buffer with DALI_BUFFER_GROWTH_FACTOR): host memory is
+// pinned when a GPU is present (so H2D copies are asynchronous), plain otherwise.
+class Buffer {
+ public:
+  explicit Buffer(StorageDevice dev) : dev_(dev) {}
+  ~Buffer();
+  Buffer(const Buffer &) = delete;
+  Buffer &operator=(const Buffer &) = delete;
+  void Reserve(size_t bytes);
+  void *data() const { return ptr_; }
+  size_t capacity() const { return cap_; }
+  StorageDevice device() const { return dev_; }
+
+ private:
+  StorageDevice dev_;
+  void *ptr_ = nullptr;
+  size_t cap_ = 0;
+  bool pinned_ = false;
+};
+
+struct DeferredResample;  // see ops_image.cpp: RandomResizedCrop -> CropMirrorNormalize fusion
+
+class TensorList {
+ public:
+  explicit TensorList(StorageDevice dev) : buf_(std::make_shared<Buffer>(dev)), dev_(dev) {}
+  StorageDevice device() const { return dev_; }
+  int num_samples() const { return (int)shapes_.size(); }
+  DALIDataType type() const { return type_; }
+  const std::string &layout() const { return layout_; }
+  void SetLayout(const std::string &l) { layout_ = l; }
+  const TensorShape &shape(int i) const { return shapes_[i]; }
+  // bytes between rows of sample i for image-like (HWC) data; dense when 0
+  int64_t row_pitch(int i) const { return pitch_[i]; }
+  void *raw(int i) const { return static_cast<char *>(buf_->data()) + offsets_[i]; }
+  size_t nbytes(int i) const { return sizes_[i]; }
+  bool is_dense() const;
+  size_t total_bytes() const { return total_; }
+
+  // Allocates one contiguous block; every sample starts at a 256-byte boundary.  For 3-D u8 samples
+  // `pitch_align` > 1 pads each row to that many bytes (internal hand-off between device operators).
+  void Resize(const std::vector<TensorShape> &shapes, DALIDataType type, int pitch_align = 1);
+  // shares storage and metadata (zero-copy pass-through)
+  void ShareData(const TensorList &other);
+  // metadata only; used when an operator's work is deferred to its consumer
+  std::shared_ptr<DeferredResample> deferred;
+
+  // source info (readers): file name per sample, used in error messages like the reference's
+  std::vector<std::string> source_info;
+
+ private:
+  std::shared_ptr<Buffer> buf_;
+  StorageDevice dev_;
+  DALIDataType type_ = DALI_NO_TYPE;
+  std::string layout_;
+  std::vector<TensorShape> shapes_;
+  std::vector<int64_t> offsets_, pitch_;
+  std::vector<size_t> sizes_;
+  size_t total_ = 0;
+};
+
+// ---------------------------------------------------------------------------------------------
+// ThreadPool (AddWork(fn(thread_id), priority) + RunAll(), dali/pipeline/util/thread_pool.h)
+// ---------------------------------------------------------------------------------------------
+class ThreadPool {
+ public:
+  explicit ThreadPool(int num_threads);
+  ~ThreadPool();
+  using Work = std::function<void(int)>;
+  void AddWork(Work w, int64_t priority = 0);
+  // runs everything added so far (highest priority first) and waits; rethrows the first exception
+  void RunAll();
+  int NumThreads() const { return (int)threads_.size(); }
+
+ private:
+  void Loop(int tid);
+  std::vector<std::thread> threads_;
+  std::vector<std::pair<int64_t, Work>> pending_, running_;
+  std::mutex m_;
+  std::condition_variable cv_work_, cv_done_;
+  size_t next_ = 0, done_ = 0;
+  bool stop_ = false;
+  std::vector<std::string> errors_;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Arguments, OpSchema, OpSpec
+// ---------------------------------------------------------------------------------------------
+enum class ArgType { INT, FLOAT, BOOL, STRING, INT_VEC, FLOAT_VEC, STRING_VEC, NONE };
+
+struct ArgValue {
+  ArgType type = ArgType::NONE;
+  int64_t i = 0;
+  double f = 0;
+  std::string s;
+  std::vector<int64_t> iv;
+  std::vector<double> fv;
+  std::vector<std::string> sv;
+  static ArgValue Int(int64_t v) { ArgValue a; a.type = ArgType::INT; a.i = v; return a; }
+  static ArgValue Float(double v) { ArgValue a; a.type = ArgType::FLOAT; a.f = v; return a; }
+  static ArgValue Bool(bool v) { ArgValue a; a.type = ArgType::BOOL; a.i = v; return a; }
+  static ArgValue Str(std::string v) { ArgValue a; a.type = ArgType::STRING; a.s = std::move(v); return a; }
+  static ArgValue IntVec(std::vector<int64_t> v) { ArgValue a; a.type = ArgType::INT_VEC; a.iv = std::move(v); return a; }
+  static ArgValue FloatVec(std::vector<double> v) { ArgValue a; a.type = ArgType::FLOAT_VEC; a.fv = std::move(v); return a; }
+  static ArgValue StrVec(std::vector<std::string> v) { ArgValue a; a.type = ArgType::STRING_VEC; a.sv = std::move(v); return a; }
+};
+const char *ArgTypeName(ArgType t);
+
+struct ArgDef {
+  std::string name, doc;
+  ArgType type = ArgType::NONE;
+  bool required = false;
+  bool tensor_ok = false;   // may be supplied per sample through an argument input
+  bool deprecated = false;
+  ArgValue def;
+};
+
+class OpSchema {
+ public:
+  explicit OpSchema(std::string name) : name_(std::move(name)) {}
+  OpSchema &DocStr(std::string d) { doc_ = std::move(d); return *this; }
+  OpSchema &NumInput(int n) { min_in_ = max_in_ = n; return *this; }
+  OpSchema &NumInput(int lo, int hi) { min_in_ = lo; max_in_ = hi; return *this; }
+  OpSchema &NumOutput(int n) { num_out_ = n; return *this; }
+  OpSchema &AddArg(const std::string &name, const std::string &doc, ArgType type, bool tensor_ok = false);
+  OpSchema &AddOptionalArg(const std::string &name, const std::string &doc, ArgValue def, bool tensor_ok = false);
+  // optional argument without a default (absent unless given), e.g. `seed`, `fill_value`
+  OpSchema &AddOptionalTypeArg(const std::string &name, const std::string &doc, ArgType type, bool tensor_ok = false);
+  OpSchema &DeprecateArg(const std::string &name);
+  OpSchema &AddParent(const std::string &parent) { parents_.push_back(parent); return *this; }
+  OpSchema &AddRandomSeedArg();
+  OpSchema &InputLayout(int idx, std::vector<std::string> layouts) { in_layouts_[idx] = std::move(layouts); return *this; }
+  OpSchema &AllowSequences() { return *this; }
+  OpSchema &MakeInternal() { internal_ = true; return *this; }
+
+  const std::string &name() const { return name_; }
+  const std::string &doc() const { return doc_; }
+  int MinNumInput() const { return min_in_; }
+  int MaxNumInput() const { return max_in_; }
+  int NumOutput() const { return num_out_; }
+  bool IsInternal() const { return internal_; }
+  bool HasRandomSeedArg() const;
+  // own + inherited
+  std::vector<ArgDef> AllArgs() const;
+  const ArgDef *FindArg(const std::string &name) const;
+  const std::vector<std::string> *InputLayouts(int idx) const;
+
+ private:
+  std::string name_, doc_;
+  int min_in_ = 0, max_in_ = 0, num_out_ = 1;
+  bool internal_ = false;
+  std::vector<ArgDef> args_;
+  std::vector<std::string> parents_;
+  std::map<int, std::vector<std::string>> in_layouts_;
+};
+
+class SchemaRegistry {
+ public:
+  static OpSchema &RegisterSchema(const std::string &name);
+  static const OpSchema &GetSchema(const std::string &name);
+  static const OpSchema *TryGetSchema(const std::string &name);
+  static std::vector<std::string> Names();
+};
+
+#define DALI_AMD_CONCAT_(a, b) a##b
+#define DALI_AMD_CONCAT(a, b) DALI_AMD_CONCAT_(a, b)
+// DALI_SCHEMA(Name).DocStr(..).NumInput(..)...;   (op_schema.h:1096-1109)
+#define DALI_SCHEMA(OpName)                                                               \
+  static ::daliamd_host::OpSchema &DALI_AMD_CONCAT(schema_reg_, __LINE__) [[maybe_unused]] = \
+      ::daliamd_host::SchemaRegistry::RegisterSchema(#OpName)
+
+class OpSpec {
+ public:
+  OpSpec() = default;
+  explicit OpSpec(std::string schema_name) : name_(std::move(schema_name)) {}
+  const std::string &SchemaName() const { return name_; }
+  const OpSchema &GetSchema() const { return SchemaRegistry::GetSchema(name_); }
+  OpSpec &AddArg(const std::string &name, ArgValue v) { args_[name] = std::move(v); return *this; }
+  OpSpec &AddInput(const std::string &name, StorageDevice dev) { inputs_.push_back({name, dev}); return *this; }
+  OpSpec &AddOutput(const std::string &name, StorageDevice dev) { outputs_.push_back({name, dev}); return *this; }
+  OpSpec &AddArgumentInput(const std::string &arg, const std::string &tensor) { arg_inputs_[arg] = tensor; return *this; }
+
+  bool ArgumentDefined(const std::string &name) const { return args_.count(name) || arg_inputs_.count(name); }
+  bool HasTensorArgument(const std::string &name) const { return arg_inputs_.count(name) != 0; }
+  // explicit value, else schema default, else throws
+  const ArgValue &Arg(const std::string &name) const;
+  const ArgValue *TryArg(const std::string &name) const;
+  int64_t GetInt(const std::string &name) const;
+  double GetFloat(const std::string &name) const;
+  bool GetBool(const std::string &name) const;
+  std::string GetString(const std::string &name) const;
+  std::vector<int64_t> GetIntVec(const std::string &name) const;      // scalar promoted to 1-vector
+  std::vector<double> GetFloatVec(const std::string &name) const;
+
+  struct IO { std::string name; StorageDevice dev; };
+  const std::vector<IO> &Inputs() const { return inputs_; }
+  const std::vector<IO> &Outputs() const { return outputs_; }
+  const std::map<std::string, std::string> &ArgumentInputs() const { return arg_inputs_; }
+  const std::map<std::string, ArgValue> &Args() const { return args_; }
+  // checks names/types against the schema; fills nothing
+  void Validate() const;
+
+ private:
+  std::string name_;
+  std::map<std::string, ArgValue> args_;
+  std::vector<IO> inputs_, outputs_;
+  std::map<std::string, std::string> arg_inputs_;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Workspace + OperatorBase + registry
+// ---------------------------------------------------------------------------------------------
+struct OutputDesc {
+  std::vector<TensorShape> shape;
+  DALIDataType type = DALI_NO_TYPE;
+};
+
+class Pipeline;
+
+class Workspace {
+ public:
+  Pipeline *pipeline = nullptr;
+  std::vector<std::shared_ptr<TensorList>> inputs, outputs;
+  std::map<std::string, std::shared_ptr<TensorList>> argument_inputs;
+  ThreadPool *thread_pool = nullptr;
+  daliamdStream_t stream = nullptr;  // device operators enqueue here and must not synchronise
+  int batch_size = 0;                // requested (max) batch size of this iteration
+  int64_t iteration = 0;
+
+  const TensorList &Input(int i) const { return *inputs.at(i); }
+  TensorList &Output(int i) const { return *outputs.at(i); }
+  const TensorList &ArgumentInput(const std::string &name) const;
+  bool HasArgumentInput(const std::string &name) const { return argument_inputs.count(name) != 0; }
+  int NumInput() const { return (int)inputs.size(); }
+  int NumOutput() const { return (int)outputs.size(); }
+  int GetInputBatchSize(int i) const { return inputs.at(i)->num_samples(); }
+  ThreadPool &GetThreadPool() const { return *thread_pool; }
+};
+
+// ReaderMeta (dali/pipeline/operator/operator.h:46-58)
+struct ReaderMeta {
+  int64_t epoch_size = -1, epoch_size_padded = -1;
+  int number_of_shards = -1, shard_id = -1;
+  int pad_last_batch = -1, stick_to_shard = -1;
+};
+
+class OperatorBase {
+ public:
+  explicit OperatorBase(const OpSpec &spec);
+  virtual ~OperatorBase() = default;
+  // returns true when the executor should allocate outputs from `output_desc`
+  virtual bool SetupImpl(std::vector<OutputDesc> &output_desc, const Workspace &ws) = 0;
+  virtual void RunImpl(Workspace &ws) = 0;
+  virtual ReaderMeta GetReaderMeta() const { return {}; }
+  // checkpointing (operator.h:186-215): textual state, empty for stateless operators
+  virtual std::string SaveState() const { return ""; }
+  virtual void RestoreState(const std::string &) {}
+  // row pitch alignment requested for the image-like output `idx` (1 = dense)
+  virtual int OutputPitchAlign(int) const { return 1; }
+  const OpSpec &spec() const { return spec_; }
+
+ protected:
+  OpSpec spec_;
+  int num_threads_, max_batch_size_, device_id_;
+};
+
+using OpFactory = std::function<std::unique_ptr<OperatorBase>(const OpSpec &)>;
+class OperatorRegistry {
+ public:
+  static void Register(const std::string &name, OpType type, OpFactory f);
+  static std::unique_ptr<OperatorBase> Create(const std::string &name, OpType type, const OpSpec &spec);
+  static bool IsRegistered(const std::string &name, OpType type);
+  static std::vector<OpType> Backends(const std::string &name);
+};
+struct OpRegisterer {
+  OpRegisterer(const std::string &name, OpType t, OpFactory f) { OperatorRegistry::Register(name, t, std::move(f)); }
+};
+// DALI_REGISTER_OPERATOR(Name, Class, CPU|GPU|MIXED)   (operator.h:327-333)
+#define DALI_REGISTER_OPERATOR(OpName, OpClass, Device)                                              \
+  static ::daliamd_host::OpRegisterer DALI_AMD_CONCAT(op_reg_, __LINE__)(                              \
+      #OpName, ::daliamd_host::OpType::Device,                                                        \
+      [](const ::daliamd_host::OpSpec &s) -> std::unique_ptr<::daliamd_host::OperatorBase> {          \
+        return std::make_unique<OpClass>(s);                                                          \
+      })
+
+// per-sample (or broadcast) argument access: value from the spec or from an argument input
+// (ArgValue<T>, dali/pipeline/operator/arg_helper.h)
+std::vector<float> GetPerSampleFloat(const OpSpec &spec, const Workspace &ws, const std::string &name, int nsamples);
+std::vector<int> GetPerSampleInt(const OpSpec &spec, const Workspace &ws, const std::string &name, int nsamples);
+
+// Pinned staging + asynchronous upload of descriptor tables, shared by device operators.
+class DescUploader {
+ public:
+  // copies `bytes` to a device buffer valid until the slot comes round again (slots >= queue depth + 1)
+  void *Upload(const void *host, size_t bytes, daliamdStream_t stream);
+  ~DescUploader();
+
+ private:
+  struct Slot { void *pinned = nullptr, *dev = nullptr; size_t cap = 0; daliamdEvent_t ev = nullptr; bool used = false; };
+  std::vector<Slot> slots_ = std::vector<Slot>(4);
+  int next_ = 0;
+};
+
+}  // namespace daliamd_host
+#endif  // DALI_AMD_HOST_FRAMEWORK_H_

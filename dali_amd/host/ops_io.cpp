@@ -1,0 +1,408 @@
+// Source operators: ExternalSource, readers.file (with the reference's shard / shuffle / padding
+// semantics) and the CPU -> GPU copy inserted for `.gpu()`.
+//   FileReader / FileLabelLoader   dali/operators/reader/file_reader_op.{h,cc}, loader/file_label_loader.cc:34-92
+//   Loader (shards, shuffle)       dali/operators/reader/loader/loader.h:78-503, loader.cc:78-87
+//   discovery (sorted dirs/files)  dali/operators/reader/loader/discover_files.cc:38-143
+//   ExternalSource                 dali/pipeline/operator/builtin/external_source.{h,cc}
+#include <dirent.h>
+#include <fcntl.h>
+#include <fnmatch.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <deque>
+#include <fstream>
+#include <random>
+
+#include "ops.h"
+#include "pipeline.h"
+
+namespace daliamd_host {
+
+// =============================================================================================
+// ExternalSource
+// =============================================================================================
+DALI_SCHEMA(ExternalSource)
+    .DocStr("Allows externally provided data to be passed as an input to the pipeline "
+            "(fed with `Pipeline.feed_input`).")
+    .NumInput(0)
+    .NumOutput(1)
+    .AddOptionalArg("blocking", "Whether to block when no data is available (ignored; an empty queue is an error).",
+                    ArgValue::Bool(false))
+    .AddOptionalArg("no_copy", "Ignored: fed data is always copied into pipeline-owned memory.", ArgValue::Bool(false))
+    .AddOptionalTypeArg("layout", "Layout of the fed data.", ArgType::STRING)
+    .AddOptionalTypeArg("dtype", "Expected data type (checked when set).", ArgType::INT)
+    .AddOptionalTypeArg("ndim", "Expected number of dimensions (checked when set).", ArgType::INT);
+
+class ExternalSourceOp : public OperatorBase {
+ public:
+  explicit ExternalSourceOp(const OpSpec &spec) : OperatorBase(spec) {}
+
+  void Feed(const std::vector<const void *> &data, const std::vector<TensorShape> &shapes, DALIDataType type,
+            const std::string &layout) {
+    DALI_ENFORCE(data.size() == shapes.size(), "ExternalSource: data / shape count mismatch");
+    DALI_ENFORCE((int)data.size() <= max_batch_size_, "ExternalSource expects a batch of at most ", max_batch_size_,
+                 " samples, got ", data.size());
+    if (const ArgValue *d = spec_.TryArg("dtype"))
+      DALI_ENFORCE(d->i == (int)type, "ExternalSource expected data of type ", TypeName((DALIDataType)d->i), " and got ",
+                   TypeName(type));
+    if (const ArgValue *nd = spec_.TryArg("ndim"))
+      for (auto &s : shapes) DALI_ENFORCE((int64_t)s.size() == nd->i, "ExternalSource expected ", nd->i, "-D data");
+    auto tl = std::make_shared<TensorList>(StorageDevice::CPU);
+    tl->Resize(shapes, type);
+    tl->SetLayout(layout);
+    for (size_t i = 0; i < data.size(); i++) memcpy(tl->raw((int)i), data[i], tl->nbytes((int)i));
+    std::lock_guard<std::mutex> g(m_);
+    queue_.push_back(std::move(tl));
+  }
+
+  bool SetupImpl(std::vector<OutputDesc> &, const Workspace &) override { return false; }
+  void RunImpl(Workspace &ws) override {
+    std::shared_ptr<TensorList> tl;
+    {
+      std::lock_guard<std::mutex> g(m_);
+      DALI_ENFORCE(!queue_.empty(), "No data was provided to the ExternalSource. Make sure to feed it properly "
+                   "(call feed_input before each run).");
+      tl = std::move(queue_.front());
+      queue_.pop_front();
+    }
+    ws.Output(0).ShareData(*tl);
+    if (const ArgValue *l = spec_.TryArg("layout"))
+      if (ws.Output(0).layout().empty()) ws.Output(0).SetLayout(l->s);
+  }
+
+ private:
+  std::mutex m_;
+  std::deque<std::shared_ptr<TensorList>> queue_;
+};
+DALI_REGISTER_OPERATOR(ExternalSource, ExternalSourceOp, CPU);
+
+void FeedExternalSource(OperatorBase *op, const std::vector<const void *> &data, const std::vector<TensorShape> &shapes,
+                        DALIDataType type, const std::string &layout) {
+  auto *es = dynamic_cast<ExternalSourceOp *>(op);
+  DALI_ENFORCE(es, "The operator is not an ExternalSource");
+  es->Feed(data, shapes, type, layout);
+}
+
+// =============================================================================================
+// readers.file
+// =============================================================================================
+DALI_SCHEMA(LoaderBase)
+    .DocStr("Common reader arguments.")
+    .MakeInternal()
+    .AddOptionalArg("random_shuffle", "Determines whether to randomly shuffle data. A prefetch buffer with a size equal "
+                    "to ``initial_fill`` is used to read data sequentially, and then samples are selected randomly to "
+                    "form a batch.", ArgValue::Bool(false))
+    .AddOptionalArg("initial_fill", "Size of the buffer that is used for shuffling.", ArgValue::Int(1024))
+    .AddOptionalArg("num_shards", "Partitions the data into the specified number of parts (shards).", ArgValue::Int(1))
+    .AddOptionalArg("shard_id", "Index of the shard to read.", ArgValue::Int(0))
+    .AddOptionalArg("tensor_init_bytes", "Hint for how much memory to allocate per image.", ArgValue::Int(1048576))
+    .AddOptionalArg("stick_to_shard", "Determines whether the reader should stick to a data shard instead of going "
+                    "through the entire dataset.", ArgValue::Bool(false))
+    .AddOptionalArg("read_ahead", "Determines whether the accessed data should be read ahead.", ArgValue::Bool(false))
+    .AddOptionalArg("prefetch_queue_depth", "Number of batches prefetched by the internal loader.", ArgValue::Int(1))
+    .AddOptionalArg("skip_cached_images", "Ignored (no decoder cache).", ArgValue::Bool(false))
+    .AddOptionalArg("lazy_init", "Parse and prepare the dataset metadata only during the first run.", ArgValue::Bool(false))
+    .AddOptionalArg("pad_last_batch", "If set to True, pads the shard by repeating the last sample.", ArgValue::Bool(false))
+    .AddOptionalArg("dont_use_mmap", "Use plain file I/O instead of memory mapping (always the case here).",
+                    ArgValue::Bool(false))
+    .AddRandomSeedArg();
+
+DALI_SCHEMA(readers__File)
+    .DocStr("Reads file contents and returns file-label pairs.\n\nThe labels are the indices of the alphabetically "
+            "sorted sub-directories of ``file_root`` (or come from ``file_list`` / ``labels``).")
+    .NumInput(0)
+    .NumOutput(2)
+    .AddOptionalTypeArg("file_root", "Path to a directory that contains the data files.", ArgType::STRING)
+    .AddOptionalTypeArg("file_list", "Path to a text file with rows ``filename label``.", ArgType::STRING)
+    .AddOptionalTypeArg("files", "A list of file paths to read the data from.", ArgType::STRING_VEC)
+    .AddOptionalTypeArg("labels", "Labels accompanying ``files`` (default: the file index).", ArgType::INT_VEC)
+    .AddOptionalTypeArg("file_filters", "Glob patterns to filter the files (default: known image extensions).",
+                        ArgType::STRING_VEC)
+    .AddOptionalTypeArg("dir_filters", "Glob patterns to filter the sub-directories.", ArgType::STRING_VEC)
+    .AddOptionalArg("case_sensitive_filter", "Match the filters case-sensitively.", ArgValue::Bool(false))
+    .AddOptionalArg("shuffle_after_epoch", "Reshuffle the whole dataset after each epoch.", ArgValue::Bool(false))
+    .AddOptionalArg("shuffle_after_epoch_seed", "Seed for shuffle_after_epoch.", ArgValue::Int(0))
+    .AddParent("LoaderBase");
+
+DALI_SCHEMA(FileReader).DocStr("Legacy alias of readers.file").NumInput(0).NumOutput(2).AddParent("readers__File");
+
+static size_t start_index(size_t shard_id, size_t shard_num, size_t size) { return size * shard_id / shard_num; }
+static int64_t num_samples(size_t shard_num, size_t size) { return (int64_t)std::ceil(size * 1.0 / shard_num); }
+
+static std::vector<std::string> ListDir(const std::string &dir, bool want_dirs, const std::vector<std::string> &filters,
+                                        bool case_sensitive) {
+  DIR *d = opendir(dir.c_str());
+  DALI_ENFORCE(d != nullptr, "Failed to open ", dir);
+  std::vector<std::string> out;
+  while (dirent *e = readdir(d)) {
+    std::string name = e->d_name;
+    if (name == "." || name == "..") continue;
+    struct stat s;
+    if (stat((dir + "/" + name).c_str(), &s) != 0) { closedir(d); DALI_FAIL("Could not access ", dir, "/", name); }
+    bool is_dir = S_ISDIR(s.st_mode);
+    if (is_dir != want_dirs) continue;
+    bool ok = filters.empty();
+    for (auto &f : filters) ok |= fnmatch(f.c_str(), name.c_str(), case_sensitive ? 0 : FNM_CASEFOLD) == 0;
+    if (ok) out.push_back(name);
+  }
+  closedir(d);
+  std::sort(out.begin(), out.end());
+  return out;
+}
+
+class FileReaderOp : public OperatorBase {
+ public:
+  explicit FileReaderOp(const OpSpec &spec)
+      : OperatorBase(spec),
+        shuffle_(spec.GetBool("random_shuffle")),
+        initial_fill_(shuffle_ ? (int)spec.GetInt("initial_fill") : 1),
+        num_shards_((int)spec.GetInt("num_shards")),
+        shard_id_((int)spec.GetInt("shard_id")),
+        stick_to_shard_(spec.GetBool("stick_to_shard")),
+        pad_last_batch_(spec.GetBool("pad_last_batch")) {
+    DALI_ENFORCE(num_shards_ > shard_id_, "num_shards needs to be greater than shard_id");
+    DALI_ENFORCE(shard_id_ >= 0, "shard_id must be non-negative");
+    DALI_ENFORCE(initial_fill_ > 0, "initial_fill must be positive");
+    Discover();
+    DALI_ENFORCE((int64_t)num_shards_ <= Size(), "The number of input samples: ", Size(),
+                 ", needs to be at least equal to the requested number of shards: ", num_shards_, ".");
+    std::seed_seq seq({spec.GetInt("seed")});
+    rng_ = std::default_random_engine(seq);
+    virtual_shard_id_ = shard_id_;
+    Reset(true);
+  }
+
+  ReaderMeta GetReaderMeta() const override {
+    ReaderMeta m;
+    m.epoch_size = Size();
+    m.epoch_size_padded = pad_last_batch_ ? num_samples(num_shards_, Size()) * num_shards_ : Size();
+    m.number_of_shards = num_shards_;
+    m.shard_id = shard_id_;
+    m.pad_last_batch = pad_last_batch_;
+    m.stick_to_shard = stick_to_shard_;
+    return m;
+  }
+
+  bool SetupImpl(std::vector<OutputDesc> &, const Workspace &) override { return false; }
+
+  void RunImpl(Workspace &ws) override {
+    // one batch of (index) picks, then the file reads go to the thread pool
+    std::vector<int64_t> picks(max_batch_size_);
+    for (int i = 0; i < max_batch_size_; i++) picks[i] = NextIndex(i == 0);
+    std::vector<TensorShape> shapes(max_batch_size_), lshape(max_batch_size_, TensorShape{1});
+    std::vector<off_t> sizes(max_batch_size_);
+    for (int i = 0; i < max_batch_size_; i++) {
+      struct stat s;
+      const std::string path = Path(picks[i]);
+      DALI_ENFORCE(stat(path.c_str(), &s) == 0, "Could not open file ", path);
+      sizes[i] = s.st_size;
+      shapes[i] = {(int64_t)s.st_size};
+    }
+    TensorList &data = ws.Output(0), &labels = ws.Output(1);
+    data.Resize(shapes, DALI_UINT8);
+    labels.Resize(lshape, DALI_INT32);
+    data.source_info.resize(max_batch_size_);
+    for (int i = 0; i < max_batch_size_; i++) {
+      *static_cast<int32_t *>(labels.raw(i)) = entries_[picks[i]].second;
+      data.source_info[i] = Path(picks[i]);
+      ws.GetThreadPool().AddWork([this, &data, &picks, &sizes, i](int) {
+        const std::string path = Path(picks[i]);
+        int fd = open(path.c_str(), O_RDONLY);
+        DALI_ENFORCE(fd >= 0, "Could not open file ", path);
+        char *dst = static_cast<char *>(data.raw(i));
+        off_t got = 0;
+        while (got < sizes[i]) {
+          ssize_t r = read(fd, dst + got, sizes[i] - got);
+          if (r <= 0) break;
+          got += r;
+        }
+        close(fd);
+        DALI_ENFORCE(got == sizes[i], "Failed to read file ", path);
+      }, sizes[i]);
+    }
+    ws.GetThreadPool().RunAll();
+  }
+
+  // checkpoint: position in the stream + rng (loader.h:279,335,485-503)
+  std::string SaveState() const override {
+    std::ostringstream ss;
+    ss << current_index_ << " " << virtual_shard_id_ << " " << read_in_shard_ << " " << returned_ << " " << epoch_ << " "
+       << rng_;
+    return ss.str();
+  }
+  void RestoreState(const std::string &s) override {
+    std::istringstream ss(s);
+    ss >> current_index_ >> virtual_shard_id_ >> read_in_shard_ >> returned_ >> epoch_ >> rng_;
+    buffer_.clear();
+    last_pick_ = -1;
+  }
+
+ private:
+  int64_t Size() const { return (int64_t)entries_.size(); }
+  std::string Path(int64_t idx) const {
+    const std::string &f = entries_[idx].first;
+    return (root_.empty() || (!f.empty() && f[0] == '/')) ? f : root_ + "/" + f;
+  }
+
+  void Discover() {
+    if (const ArgValue *files = spec_.TryArg("files")) {
+      std::vector<std::string> names = files->type == ArgType::STRING ? std::vector<std::string>{files->s} : files->sv;
+      std::vector<int64_t> labels;
+      if (spec_.TryArg("labels")) labels = spec_.GetIntVec("labels");
+      DALI_ENFORCE(labels.empty() || labels.size() == names.size(), "Provided ", labels.size(), " labels for ",
+                   names.size(), " files.");
+      for (size_t i = 0; i < names.size(); i++) entries_.push_back({names[i], labels.empty() ? (int)i : (int)labels[i]});
+      if (spec_.TryArg("file_root")) root_ = spec_.GetString("file_root");
+    } else if (spec_.TryArg("file_list")) {
+      std::string list = spec_.GetString("file_list");
+      if (spec_.TryArg("file_root")) root_ = spec_.GetString("file_root");
+      else { size_t p = list.rfind('/'); root_ = p == std::string::npos ? "." : list.substr(0, p); }
+      std::ifstream f(list);
+      DALI_ENFORCE(f.good(), "Failed to open ", list);
+      std::string line;
+      while (std::getline(f, line)) {
+        if (line.empty()) continue;
+        size_t sp = line.rfind(' ');
+        DALI_ENFORCE(sp != std::string::npos, "Malformed line in file_list: ", line);
+        entries_.push_back({line.substr(0, sp), std::stoi(line.substr(sp + 1))});
+      }
+    } else {
+      DALI_ENFORCE(spec_.TryArg("file_root"), "Either `file_root`, `file_list` or `files` must be specified");
+      root_ = spec_.GetString("file_root");
+      std::vector<std::string> filters = {"*.jpg", "*.jpeg", "*.png", "*.bmp", "*.tif", "*.tiff", "*.pnm", "*.ppm",
+                                          "*.pgm", "*.pbm", "*.jp2", "*.webp", "*.flac", "*.ogg", "*.wav"};
+      std::vector<std::string> dir_filters;
+      if (const ArgValue *ff = spec_.TryArg("file_filters")) filters = ff->type == ArgType::STRING ? std::vector<std::string>{ff->s} : ff->sv;
+      if (const ArgValue *df = spec_.TryArg("dir_filters")) dir_filters = df->type == ArgType::STRING ? std::vector<std::string>{df->s} : df->sv;
+      bool cs = spec_.GetBool("case_sensitive_filter");
+      auto subdirs = ListDir(root_, true, dir_filters, cs);
+      for (size_t d = 0; d < subdirs.size(); d++)
+        for (auto &f : ListDir(root_ + "/" + subdirs[d], false, filters, cs)) entries_.push_back({subdirs[d] + "/" + f, (int)d});
+    }
+    DALI_ENFORCE(!entries_.empty(), "No files found.");
+  }
+
+  // sequential stream over the dataset, starting at this shard and (unless stick_to_shard) moving
+  // on to the next shard every epoch (loader.h:413-452)
+  void Reset(bool wrap_to_shard) {
+    current_index_ = wrap_to_shard ? (int64_t)start_index(virtual_shard_id_, num_shards_, Size()) : 0;
+  }
+  bool IsNextShard(int64_t idx) const {
+    return idx >= Size() || (stick_to_shard_ && shard_id_ + 1 < num_shards_ &&
+                             idx >= (int64_t)start_index(shard_id_ + 1, num_shards_, Size()));
+  }
+  int64_t ReadSequential() {
+    if (IsNextShard(current_index_)) Reset(stick_to_shard_);
+    int64_t idx = current_index_++;
+    // shard bookkeeping (IncreaseReadSampleCounter, loader.h:440-457)
+    read_in_shard_++;
+    int64_t rel_end = (int64_t)start_index(virtual_shard_id_ + 1, num_shards_, Size()) -
+                      (int64_t)start_index(virtual_shard_id_, num_shards_, Size());
+    if (read_in_shard_ >= rel_end) {
+      shard_ends_.push_back(total_read_ + 1);
+      if (!stick_to_shard_) virtual_shard_id_ = (virtual_shard_id_ + 1) % num_shards_;
+      read_in_shard_ = 0;
+    }
+    total_read_++;
+    return idx;
+  }
+
+  // one sample of the output stream: shuffle buffer + last-batch padding (loader.h:207-345)
+  int64_t NextIndex(bool is_new_batch) {
+    if (buffer_.empty() && !filled_) {
+      for (int i = 0; i < initial_fill_; i++) {
+        int64_t seq = total_read_;  // by value: ReadSequential() advances total_read_
+        int64_t idx = ReadSequential();
+        buffer_.push_back({seq, idx});
+      }
+      filled_ = true;
+    }
+    // the current epoch (shard) is depleted when everything read before its end mark was returned
+    if (!shard_ends_.empty() && consumed_ >= shard_ends_.front()) {
+      bool pad = (returned_ < num_samples(num_shards_, Size()) || !is_new_batch) && pad_last_batch_;
+      if (pad && last_pick_ >= 0) {
+        returned_++;
+        return last_pick_;
+      }
+      shard_ends_.pop_front();
+      returned_ = 0;
+      epoch_++;
+    }
+    // candidates: buffered samples that belong to the current epoch
+    int64_t limit = shard_ends_.empty() ? total_read_ : shard_ends_.front();
+    int ncand = 0;
+    for (auto &b : buffer_) ncand += b.first < limit;
+    DALI_ENFORCE(ncand > 0, "Internal error: shuffle buffer has no sample of the current epoch");
+    int pick = 0;
+    if (shuffle_) pick = std::uniform_int_distribution<>(0, ncand - 1)(rng_);
+    int pos = -1;
+    for (int i = 0, k = 0; i < (int)buffer_.size(); i++) {
+      if (buffer_[i].first < limit) {
+        if (k == pick) { pos = i; break; }
+        k++;
+      }
+    }
+    int64_t idx = buffer_[pos].second;
+    {
+      int64_t seq = total_read_;
+      int64_t next = ReadSequential();
+      buffer_[pos] = {seq, next};
+    }
+    consumed_++;
+    returned_++;
+    last_pick_ = idx;
+    return idx;
+  }
+
+  bool shuffle_;
+  int initial_fill_, num_shards_, shard_id_;
+  bool stick_to_shard_, pad_last_batch_;
+  std::string root_;
+  std::vector<std::pair<std::string, int>> entries_;
+  std::default_random_engine rng_;
+  int virtual_shard_id_ = 0;
+  int64_t current_index_ = 0, read_in_shard_ = 0, total_read_ = 0, consumed_ = 0, returned_ = 0, epoch_ = 0;
+  int64_t last_pick_ = -1;
+  bool filled_ = false;
+  std::vector<std::pair<int64_t, int64_t>> buffer_;  // (sequence number, dataset index)
+  std::deque<int64_t> shard_ends_;                   // sequence numbers at which an epoch (shard) ends
+};
+DALI_REGISTER_OPERATOR(readers__File, FileReaderOp, CPU);
+DALI_REGISTER_OPERATOR(FileReader, FileReaderOp, CPU);
+
+// =============================================================================================
+// CPU -> GPU copy (`.gpu()`): pinned host tensor list -> device, asynchronous on the pipeline stream
+// (the reference's __Copy_CpuToGpu_ nodes, pipeline.cc:805-810)
+// =============================================================================================
+DALI_SCHEMA(_CopyToGpu).DocStr("Copies a CPU batch to the GPU.").NumInput(1).NumOutput(1).MakeInternal();
+
+class CopyToGpuOp : public OperatorBase {
+ public:
+  explicit CopyToGpuOp(const OpSpec &spec) : OperatorBase(spec) {}
+  bool SetupImpl(std::vector<OutputDesc> &desc, const Workspace &ws) override {
+    const TensorList &in = ws.Input(0);
+    desc[0].type = in.type();
+    desc[0].shape.clear();
+    for (int i = 0; i < in.num_samples(); i++) desc[0].shape.push_back(in.shape(i));
+    return true;
+  }
+  void RunImpl(Workspace &ws) override {
+    const TensorList &in = ws.Input(0);
+    TensorList &out = ws.Output(0);
+    out.SetLayout(in.layout());
+    out.source_info = in.source_info;
+    // both lists use the same 256-byte-aligned packing: one copy
+    if (in.num_samples() > 0 && in.total_bytes() == out.total_bytes()) {
+      KCHECK(daliamdMemcpyH2DAsync(out.raw(0), in.raw(0), in.total_bytes(), ws.stream));
+    } else {
+      for (int i = 0; i < in.num_samples(); i++)
+        KCHECK(daliamdMemcpyH2DAsync(out.raw(i), in.raw(i), in.nbytes(i), ws.stream));
+    }
+    NoteLaunch(ws, "h2d_copy");
+  }
+};
+DALI_REGISTER_OPERATOR(_CopyToGpu, CopyToGpuOp, MIXED);
+
+}  // namespace daliamd_host

@@ -1,0 +1,319 @@
+#include "pipeline.h"
+
+#include <algorithm>
+#include <chrono>
+
+#include "ops.h"
+
+namespace daliamd_host {
+
+static constexpr int kMaxSeeds = 1024;  // pipeline.h:714
+
+Pipeline::Pipeline(const PipelineParams &p) : params_(p) {
+  DALI_ENFORCE(p.batch_size > 0, "Batch size must be greater than 0, got ", p.batch_size);
+  DALI_ENFORCE(p.num_threads > 0, "num_threads must be greater than 0, got ", p.num_threads);
+  DALI_ENFORCE(p.prefetch_queue_depth > 0, "prefetch_queue_depth must be greater than 0");
+  using Clock = std::chrono::high_resolution_clock;
+  original_seed_ = p.seed >= 0 ? p.seed : (int64_t)Clock::now().time_since_epoch().count();
+  // per-operator seeds: std::seed_seq{seed}.generate(...) like pipeline.cc:303-308
+  seeds_.resize(kMaxSeeds);
+  std::seed_seq ss{original_seed_};
+  ss.generate(seeds_.begin(), seeds_.end());
+  ring_ = p.prefetch_queue_depth + 1;
+  int ndev = 0;
+  daliamdDeviceCount(&ndev);
+  have_gpu_ = ndev > 0;
+}
+
+Pipeline::~Pipeline() {
+  {
+    std::lock_guard<std::mutex> g(m_);
+    stop_ = true;
+  }
+  cv_req_.notify_all();
+  if (worker_.joinable()) worker_.join();
+  if (stream_) daliamdStreamSynchronize(stream_);
+  nodes_.clear();
+  for (auto e : slot_events_) if (e) daliamdEventDestroy(e);
+  if (stream_) daliamdStreamDestroy(stream_);
+}
+
+static std::string TensorKey(const std::string &name, StorageDevice d) {
+  return name + (d == StorageDevice::GPU ? "_gpu" : "_cpu");
+}
+
+int Pipeline::AddOperator(OpSpec spec, const std::string &inst_name) {
+  DALI_ENFORCE(!built_, "Alterations to the pipeline after \"Build()\" has been called are not allowed");
+  for (auto &n : nodes_) DALI_ENFORCE(n.name != inst_name, "Operator instance name \"", inst_name, "\" is not unique");
+  const OpSchema &schema = spec.GetSchema();  // throws for unknown operators
+  std::string dev = spec.TryArg("device") ? spec.GetString("device") : "cpu";
+  OpType type = ParseOpType(dev);
+  // inject what the executor owns (pipeline.cc:812-832)
+  spec.AddArg("max_batch_size", ArgValue::Int(params_.batch_size));
+  spec.AddArg("num_threads", ArgValue::Int(params_.num_threads));
+  spec.AddArg("device_id", ArgValue::Int(params_.device_id));
+  if (type != OpType::CPU) spec.AddArg("gpu_prefetch_queue_depth", ArgValue::Int(params_.prefetch_queue_depth));
+  if (schema.HasRandomSeedArg() && !spec.ArgumentDefined("seed")) {
+    spec.AddArg("seed", ArgValue::Int(seeds_[current_seed_]));
+    current_seed_ = (current_seed_ + 1) % kMaxSeeds;
+  }
+  spec.Validate();
+  Node n;
+  n.name = inst_name;
+  n.type = type;
+  // inputs must already exist with the requested storage device
+  for (auto &in : spec.Inputs()) {
+    auto it = tensor_producer_.find(TensorKey(in.name, in.dev));
+    if (it == tensor_producer_.end()) {
+      bool other = tensor_producer_.count(TensorKey(in.name, in.dev == StorageDevice::GPU ? StorageDevice::CPU
+                                                                                           : StorageDevice::GPU));
+      DALI_ENFORCE(!other, "Operator \"", inst_name, "\" (", spec.SchemaName(), ") requests input \"", in.name,
+                   "\" on the ", in.dev == StorageDevice::GPU ? "GPU" : "CPU", " but it is produced on the other "
+                   "device. Use `.gpu()` to move the data to the device; device-to-host transfers inside the graph "
+                   "are not supported.");
+      DALI_FAIL("Input \"", in.name, "\" of operator \"", inst_name, "\" is not produced by any operator");
+    }
+    if (type == OpType::CPU || type == OpType::MIXED)
+      DALI_ENFORCE(in.dev == StorageDevice::CPU, (type == OpType::CPU ? "CPU" : "Mixed"), " operator \"", inst_name,
+                   "\" cannot take a GPU input");
+    n.in_node.push_back(it->second.first);
+    n.in_idx.push_back(it->second.second);
+  }
+  for (auto &kv : spec.ArgumentInputs()) {
+    auto it = tensor_producer_.find(TensorKey(kv.second, StorageDevice::CPU));
+    DALI_ENFORCE(it != tensor_producer_.end(), "Argument input \"", kv.first, "\" of operator \"", inst_name,
+                 "\" must be a CPU tensor produced earlier in the graph");
+    n.arg_in.push_back({kv.first, it->second});
+  }
+  int idx = (int)nodes_.size();
+  int k = 0;
+  for (auto &out : spec.Outputs()) {
+    StorageDevice expect = type == OpType::CPU ? StorageDevice::CPU : StorageDevice::GPU;
+    DALI_ENFORCE(out.dev == expect, "Operator \"", inst_name, "\" produces ", expect == StorageDevice::GPU ? "GPU" : "CPU",
+                 " outputs");
+    std::string key = TensorKey(out.name, out.dev);
+    DALI_ENFORCE(!tensor_producer_.count(key), "Tensor \"", out.name, "\" is produced twice");
+    tensor_producer_[key] = {idx, k++};
+  }
+  n.spec = std::move(spec);
+  nodes_.push_back(std::move(n));
+  return idx;
+}
+
+void Pipeline::Build(const std::vector<std::pair<std::string, std::string>> &outputs) {
+  DALI_ENFORCE(!built_, "\"Build()\" can only be called once");
+  DALI_ENFORCE(!outputs.empty(), "There must be at least one output");
+  bool needs_gpu = false;
+  for (auto &n : nodes_) needs_gpu |= n.type != OpType::CPU;
+  if (needs_gpu) {
+    DALI_ENFORCE(have_gpu_, "The pipeline contains device (\"gpu\"/\"mixed\") operators but no MI355X/ROCm device "
+                 "is available. There is no CPU fallback for device operators.");
+    KCHECK(daliamdSetDevice(params_.device_id));
+    KCHECK(daliamdStreamCreate(&stream_, 1));
+  }
+  for (auto &o : outputs) {
+    StorageDevice d = o.second == "gpu" ? StorageDevice::GPU : StorageDevice::CPU;
+    auto it = tensor_producer_.find(TensorKey(o.first, d));
+    DALI_ENFORCE(it != tensor_producer_.end(), "Requested output \"", o.first, "\" on device \"", o.second,
+                 "\" is not produced by any operator");
+    outputs_.push_back(it->second);
+  }
+  thread_pool_ = std::make_unique<ThreadPool>(params_.num_threads);
+  // instantiate operators (InstantiateOperator, operator.cc:157-169) and their output rings
+  for (auto &n : nodes_) {
+    try {
+      n.op = OperatorRegistry::Create(n.spec.SchemaName(), n.type, n.spec);
+    } catch (const std::exception &e) {
+      DALI_FAIL("Error when constructing operator \"", n.name, "\" (", n.spec.SchemaName(), "): ", e.what());
+    }
+    n.out_ring.resize(n.spec.Outputs().size());
+    for (size_t k = 0; k < n.out_ring.size(); k++)
+      for (int s = 0; s < ring_; s++) n.out_ring[k].push_back(std::make_shared<TensorList>(n.spec.Outputs()[k].dev));
+  }
+  // graph-level fusion: RandomResizedCrop / Resize feeding ONLY a CropMirrorNormalize is deferred into it
+  std::vector<int> consumers(nodes_.size(), 0);
+  for (auto &n : nodes_) for (int p : n.in_node) consumers[p]++;
+  for (auto &o : outputs_) consumers[o.first] += 2;  // pipeline outputs are never deferred
+  for (auto &n : nodes_) {
+    if (n.spec.SchemaName() != "CropMirrorNormalize" || n.in_node.empty()) continue;
+    Node &p = nodes_[n.in_node[0]];
+    if (consumers[n.in_node[0]] == 1 && p.type == OpType::GPU) TryEnableFusion(p.op.get(), n.op.get());
+  }
+  slot_events_.assign(ring_, nullptr);
+  if (stream_)
+    for (auto &e : slot_events_) KCHECK(daliamdEventCreate(&e, 0));
+  built_ = true;
+  if (params_.exec_async) worker_ = std::thread([this] { WorkerLoop(); });
+}
+
+void Pipeline::NoteLaunch(const std::string &what) {
+  std::lock_guard<std::mutex> g(launches_m_);
+  last_launches_.push_back(what);
+}
+std::vector<std::string> Pipeline::LastLaunches() const {
+  std::lock_guard<std::mutex> g(launches_m_);
+  return last_launches_;
+}
+void NoteLaunch(const Workspace &ws, const std::string &what) {
+  if (ws.pipeline) ws.pipeline->NoteLaunch(what);
+}
+
+void Pipeline::RunIteration(int64_t it, int slot, Iteration &res) {
+  res.slot = slot;
+  {
+    std::lock_guard<std::mutex> g(launches_m_);
+    last_launches_.clear();
+  }
+  try {
+    if (stream_) {
+      KCHECK(daliamdSetDevice(params_.device_id));
+      // the buffers of this ring slot (pinned staging included) were last used `ring_` iterations ago
+      if (it >= ring_) KCHECK(daliamdEventSynchronize(slot_events_[slot]));
+    }
+    for (auto &n : nodes_) {
+      Workspace ws;
+      ws.pipeline = this;
+      ws.thread_pool = thread_pool_.get();
+      ws.stream = stream_;
+      ws.batch_size = params_.batch_size;
+      ws.iteration = it;
+      for (size_t i = 0; i < n.in_node.size(); i++) ws.inputs.push_back(nodes_[n.in_node[i]].out_ring[n.in_idx[i]][slot]);
+      for (auto &a : n.arg_in) ws.argument_inputs[a.first] = nodes_[a.second.first].out_ring[a.second.second][slot];
+      for (auto &r : n.out_ring) ws.outputs.push_back(r[slot]);
+      try {
+        std::vector<OutputDesc> desc(ws.outputs.size());
+        if (n.op->SetupImpl(desc, ws)) {
+          for (size_t k = 0; k < desc.size(); k++) ws.outputs[k]->Resize(desc[k].shape, desc[k].type, n.op->OutputPitchAlign((int)k));
+        }
+        n.op->RunImpl(ws);
+      } catch (const std::exception &e) {
+        // error_reporting.h: decorate with the operator's origin
+        DALI_FAIL("Error in ", OpTypeName(n.type), " operator `", n.spec.SchemaName(), "` (instance \"", n.name, "\"): ",
+                  e.what());
+      }
+    }
+    if (stream_) KCHECK(daliamdEventRecord(slot_events_[slot], stream_));
+  } catch (const std::exception &e) {
+    res.failed = true;
+    res.error = e.what();
+  }
+}
+
+void Pipeline::WorkerLoop() {
+  for (;;) {
+    int64_t it;
+    {
+      std::unique_lock<std::mutex> lk(m_);
+      cv_req_.wait(lk, [this] { return stop_ || !requests_.empty(); });
+      if (stop_) return;
+      it = requests_.front();
+      requests_.pop_front();
+    }
+    Iteration res;
+    RunIteration(it, (int)(it % ring_), res);
+    {
+      std::lock_guard<std::mutex> g(m_);
+      results_.push_back(std::move(res));
+    }
+    cv_res_.notify_all();
+  }
+}
+
+void Pipeline::Run() {
+  DALI_ENFORCE(built_, "\"Build()\" must be called before \"Run()\"");
+  // never run further ahead than the ring allows while the consumer still holds one iteration
+  if (scheduled_ - consumed_ >= params_.prefetch_queue_depth + (holding_ ? 0 : 1))
+    DALI_FAIL("Trying to schedule more iterations than the prefetch queue depth (", params_.prefetch_queue_depth,
+              ") allows; call Outputs() first");
+  int64_t it = scheduled_++;
+  if (params_.exec_async) {
+    {
+      std::lock_guard<std::mutex> g(m_);
+      requests_.push_back(it);
+    }
+    cv_req_.notify_all();
+  } else {
+    Iteration res;
+    RunIteration(it, (int)(it % ring_), res);
+    std::lock_guard<std::mutex> g(m_);
+    results_.push_back(std::move(res));
+  }
+}
+
+std::vector<std::shared_ptr<TensorList>> Pipeline::Outputs() {
+  DALI_ENFORCE(built_, "\"Build()\" must be called before \"Outputs()\"");
+  DALI_ENFORCE(scheduled_ > consumed_, "There are no iterations scheduled; call Run() before Outputs()");
+  Iteration res;
+  {
+    std::unique_lock<std::mutex> lk(m_);
+    cv_res_.wait(lk, [this] { return !results_.empty(); });
+    res = std::move(results_.front());
+    results_.pop_front();
+  }
+  consumed_++;
+  holding_ = true;
+  if (res.failed) throw std::runtime_error(res.error);
+  if (stream_) KCHECK(daliamdEventSynchronize(slot_events_[res.slot]));
+  std::vector<std::shared_ptr<TensorList>> out;
+  for (auto &o : outputs_) out.push_back(nodes_[o.first].out_ring[o.second][res.slot]);
+  return out;
+}
+
+void Pipeline::FeedInput(const std::string &op_name, const std::vector<const void *> &data,
+                         const std::vector<TensorShape> &shapes, DALIDataType type, const std::string &layout) {
+  for (auto &n : nodes_) {
+    if (n.name != op_name) continue;
+    DALI_ENFORCE(n.op, "\"Build()\" must be called before feeding inputs");
+    FeedExternalSource(n.op.get(), data, shapes, type, layout);
+    return;
+  }
+  DALI_FAIL("Could not find an ExternalSource operator named \"", op_name, "\"");
+}
+
+ReaderMeta Pipeline::GetReaderMeta(const std::string &op_name) const {
+  for (auto &n : nodes_) {
+    if (n.name != op_name) continue;
+    DALI_ENFORCE(n.op, "\"Build()\" must be called first");
+    ReaderMeta m = n.op->GetReaderMeta();
+    DALI_ENFORCE(m.epoch_size >= 0, "Operator \"", op_name, "\" is not a reader");
+    return m;
+  }
+  DALI_FAIL("Operator \"", op_name, "\" not found in the pipeline");
+}
+
+std::vector<std::string> Pipeline::ReaderNames() const {
+  std::vector<std::string> out;
+  for (auto &n : nodes_)
+    if (n.op && n.op->GetReaderMeta().epoch_size >= 0) out.push_back(n.name);
+  return out;
+}
+
+std::string Pipeline::SaveCheckpoint() const {
+  DALI_ENFORCE(scheduled_ == consumed_, "Checkpoints can only be taken when no iterations are in flight");
+  std::string out;
+  for (auto &n : nodes_) {
+    std::string s = n.op ? n.op->SaveState() : "";
+    if (!s.empty()) out += n.name + "=" + s + "\n";
+  }
+  return out;
+}
+
+void Pipeline::RestoreCheckpoint(const std::string &cpt) {
+  DALI_ENFORCE(built_ && scheduled_ == consumed_, "Checkpoints can only be restored on an idle, built pipeline");
+  size_t pos = 0;
+  while (pos < cpt.size()) {
+    size_t nl = cpt.find('\n', pos);
+    if (nl == std::string::npos) nl = cpt.size();
+    std::string line = cpt.substr(pos, nl - pos);
+    pos = nl + 1;
+    size_t eq = line.find('=');
+    if (eq == std::string::npos) continue;
+    std::string name = line.substr(0, eq), state = line.substr(eq + 1);
+    bool found = false;
+    for (auto &n : nodes_)
+      if (n.name == name) { n.op->RestoreState(state); found = true; }
+    DALI_ENFORCE(found, "Checkpoint refers to an unknown operator \"", name, "\"");
+  }
+}
+
+}  // namespace daliamd_host

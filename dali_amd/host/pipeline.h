@@ -1,0 +1,109 @@
+// Pipeline + HIP stream/event executor.
+// Reference counterparts: Pipeline (dali/pipeline/pipeline.h:87-589, pipeline.cc:566-832) and the
+// exec2 executor (dali/pipeline/executor/executor2/exec2.cc:97-145, exec_node_task.cc:329-414).
+//
+// MI355X design: one pipeline = one GPU.  A worker thread runs iterations ahead of the consumer
+// (prefetch_queue_depth): host stages (file read, Huffman on the thread pool, random parameters) of
+// iteration i+1 overlap the device stages of iteration i, which are only ENQUEUED on the pipeline's
+// HIP stream (pinned H2D staging -> decode kernels -> fused resample/normalise).  Every operator
+// output lives in a ring of depth+1 buffers; an iteration-done event guards pinned-buffer reuse and
+// is what Outputs() waits on.  No collective, no cross-GPU traffic: multi-GPU = N pipelines with
+// disjoint shards.
+#ifndef DALI_AMD_HOST_PIPELINE_H_
+#define DALI_AMD_HOST_PIPELINE_H_
+
+#include <deque>
+#include <random>
+#include "framework.h"
+
+namespace daliamd_host {
+
+struct PipelineParams {
+  int batch_size = 1;
+  int num_threads = 1;
+  int device_id = 0;
+  int64_t seed = -1;  // < 0: derived from the clock
+  int prefetch_queue_depth = 2;
+  bool exec_async = true;
+};
+
+class Pipeline {
+ public:
+  explicit Pipeline(const PipelineParams &p);
+  ~Pipeline();
+
+  // adds an operator instance; `inst_name` must be unique (the Python layer generates one when the
+  // user gives no `name=`).  Returns the operator index.
+  int AddOperator(OpSpec spec, const std::string &inst_name);
+  void Build(const std::vector<std::pair<std::string, std::string>> &outputs);  // (tensor name, device)
+  bool IsBuilt() const { return built_; }
+
+  // schedules one iteration
+  void Run();
+  // waits for the oldest scheduled iteration and returns its outputs (released at the next call)
+  std::vector<std::shared_ptr<TensorList>> Outputs();
+  // feed one batch to an ExternalSource operator instance
+  void FeedInput(const std::string &op_name, const std::vector<const void *> &data,
+                 const std::vector<TensorShape> &shapes, DALIDataType type, const std::string &layout);
+  ReaderMeta GetReaderMeta(const std::string &op_name) const;
+  std::vector<std::string> ReaderNames() const;
+  // textual checkpoint: one line per stateful operator ("<name>=<state>")
+  std::string SaveCheckpoint() const;
+  void RestoreCheckpoint(const std::string &cpt);
+  // which device kernels the last iteration launched ("fused_resample_cmn", "jpeg_idct", ...)
+  std::vector<std::string> LastLaunches() const;
+
+  const PipelineParams &params() const { return params_; }
+  int64_t seed() const { return original_seed_; }
+  daliamdStream_t stream() const { return stream_; }
+
+ private:
+  struct Node {
+    std::string name;
+    OpSpec spec;
+    OpType type;
+    std::unique_ptr<OperatorBase> op;
+    std::vector<int> in_node, in_idx;                 // producer of each regular input
+    std::vector<std::pair<std::string, std::pair<int, int>>> arg_in;  // arg name -> producer
+    std::vector<std::vector<std::shared_ptr<TensorList>>> out_ring;   // [output][slot]
+  };
+  struct Iteration { int slot; daliamdEvent_t done = nullptr; std::string error; bool failed = false; };
+
+  void RunIteration(int64_t it, int slot, Iteration &res);
+  void WorkerLoop();
+
+  PipelineParams params_;
+  int64_t original_seed_;
+  std::vector<int64_t> seeds_;
+  size_t current_seed_ = 0;
+  std::vector<Node> nodes_;
+  std::map<std::string, std::pair<int, int>> tensor_producer_;  // "name_device" -> (node, out idx)
+  std::vector<std::pair<int, int>> outputs_;
+  bool built_ = false;
+  bool have_gpu_ = false;
+  std::unique_ptr<ThreadPool> thread_pool_;
+  daliamdStream_t stream_ = nullptr;
+  int ring_ = 3;
+
+  // scheduling
+  std::thread worker_;
+  std::mutex m_;
+  std::condition_variable cv_req_, cv_res_;
+  std::deque<int64_t> requests_;
+  std::deque<Iteration> results_;
+  std::vector<daliamdEvent_t> slot_events_;
+  int64_t scheduled_ = 0, consumed_ = 0;
+  bool stop_ = false;
+  bool holding_ = false;  // the consumer holds the outputs of iteration consumed_-1
+  std::vector<std::string> last_launches_;
+  mutable std::mutex launches_m_;
+
+ public:
+  void NoteLaunch(const std::string &what);
+};
+
+// Operators report the kernels they enqueue so tests can assert that the device path really ran.
+void NoteLaunch(const Workspace &ws, const std::string &what);
+
+}  // namespace daliamd_host
+#endif  // DALI_AMD_HOST_PIPELINE_H_

@@ -1,0 +1,62 @@
+"""PyTorch (ROCm) iterators over dali_amd pipelines: DALIGenericIterator / DALIClassificationIterator
+(reference: dali/python/nvidia/dali/plugin/pytorch/__init__.py:43-283, torch_utils.py:34-102).
+
+Each output batch becomes a dense torch tensor on the pipeline's GPU (or in host memory for CPU outputs).
+The device copy is one torch.stack over zero-copy views of the pipeline's buffers, issued on torch's current
+stream -- the equivalent of the reference's feed_ndarray / copy_to_external."""
+import numpy as np
+import torch
+
+from .. import types
+from ..tensors import TensorListGPU
+from .base_iterator import LastBatchPolicy, _DaliBaseIterator  # noqa: F401
+
+
+def feed_ndarray(tensor_or_tl, arr, cuda_stream=None, non_blocking=False):
+    """Copies a dali_amd TensorList into a preallocated torch tensor (API parity with
+    nvidia.dali.plugin.pytorch.feed_ndarray)."""
+    if isinstance(tensor_or_tl, TensorListGPU):
+        src = tensor_or_tl.as_tensor()
+    else:
+        src = torch.from_numpy(np.ascontiguousarray(tensor_or_tl.as_array()))
+    assert tuple(src.shape) == tuple(arr.shape), f"Shapes do not match: DALI {tuple(src.shape)} vs torch {tuple(arr.shape)}"
+    arr.copy_(src, non_blocking=non_blocking)
+    return arr
+
+
+class DALIGenericIterator(_DaliBaseIterator):
+    def __init__(self, pipelines, output_map, size=-1, reader_name=None, auto_reset=False, fill_last_batch=None,
+                 dynamic_shape=False, last_batch_padded=False, last_batch_policy=LastBatchPolicy.FILL,
+                 prepare_first_batch=True):
+        assert len(set(output_map)) == len(output_map), "output_map names should be distinct"
+        self.output_map = list(output_map)
+        super().__init__(pipelines, size, reader_name, auto_reset, fill_last_batch, last_batch_padded,
+                         last_batch_policy, prepare_first_batch)
+
+    def _convert(self, outputs_per_pipe, valid_per_pipe):
+        result = []
+        for g, outs in enumerate(outputs_per_pipe):
+            assert len(outs) == len(self.output_map), \
+                f"The pipeline returns {len(outs)} outputs but output_map has {len(self.output_map)} names"
+            valid = None if valid_per_pipe is None else int(valid_per_pipe[g])
+            entry = {}
+            for name, tl in zip(self.output_map, outs):
+                if isinstance(tl, TensorListGPU):
+                    t = tl.as_tensor()          # a fresh dense tensor: safe past the next pipeline run
+                else:
+                    t = torch.from_numpy(np.ascontiguousarray(tl.as_array()))
+                if valid is not None and valid < t.shape[0]:
+                    t = t[:valid]
+                entry[name] = t
+            result.append(entry)
+        return result
+
+
+class DALIClassificationIterator(DALIGenericIterator):
+    """Returns 2 outputs (data and label) as a list of dicts with keys "data" and "label"."""
+
+    def __init__(self, pipelines, size=-1, reader_name=None, auto_reset=False, fill_last_batch=None,
+                 dynamic_shape=False, last_batch_padded=False, last_batch_policy=LastBatchPolicy.FILL,
+                 prepare_first_batch=True):
+        super().__init__(pipelines, ["data", "label"], size, reader_name, auto_reset, fill_last_batch, dynamic_shape,
+                         last_batch_padded, last_batch_policy, prepare_first_batch)

@@ -1,0 +1,169 @@
+"""TensorListCPU / TensorListGPU / TensorCPU / TensorGPU: the objects Pipeline.run() returns
+(reference: dali/python/backend_impl.cc:1542-2470).  Device tensors expose __cuda_array_interface__ so
+torch / cupy can view them without a copy; the memory belongs to the pipeline and stays valid until the
+next run()/outputs() call, like the reference's share_outputs/release_outputs contract."""
+import ctypes as C
+
+import numpy as np
+
+from . import types
+
+
+class _Tensor:
+    def __init__(self, owner, ptr, shape, pitch, dtype, layout, gpu):
+        self._owner, self._ptr, self._shape, self._pitch = owner, ptr, tuple(shape), pitch
+        self.dtype, self._layout, self._gpu = dtype, layout, gpu
+
+    def shape(self):
+        return list(self._shape)
+
+    def layout(self):
+        return self._layout
+
+    def data_ptr(self):
+        return self._ptr
+
+    def _strides(self):
+        item = np.dtype(types.to_numpy_type(self.dtype)).itemsize
+        strides = [item]
+        for d in reversed(self._shape[1:]):
+            strides.insert(0, strides[0] * d)
+        if self._pitch and len(self._shape) == 3:
+            strides[0] = self._pitch
+        return tuple(strides)
+
+
+class TensorCPU(_Tensor):
+    def __array__(self, dtype=None, copy=None):
+        return self.as_array() if dtype is None else self.as_array().astype(dtype)
+
+    def as_array(self):
+        np_t = np.dtype(types.to_numpy_type(self.dtype))
+        n = int(np.prod(self._shape)) if len(self._shape) else 1
+        if n == 0:
+            return np.zeros(self._shape, np_t)
+        buf = (C.c_char * (n * np_t.itemsize)).from_address(self._ptr)
+        return np.frombuffer(buf, dtype=np_t).reshape(self._shape).copy()
+
+
+class TensorGPU(_Tensor):
+    @property
+    def __cuda_array_interface__(self):
+        np_t = np.dtype(types.to_numpy_type(self.dtype))
+        return {"shape": self._shape, "typestr": np_t.str, "data": (self._ptr, False), "version": 3,
+                "strides": self._strides()}
+
+    def as_torch(self):
+        import torch
+        if int(np.prod(self._shape)) == 0:
+            return torch.empty(self._shape, dtype=_torch_dtype(self.dtype), device="cuda")
+        return torch.as_tensor(self, device="cuda")
+
+    def as_cpu(self):
+        t = self.as_torch().contiguous().cpu()
+        return t.numpy()
+
+
+def _torch_dtype(dali_type):
+    import torch
+    return {0: torch.uint8, 4: torch.int8, 5: torch.int16, 6: torch.int32, 7: torch.int64, 8: torch.float16,
+            9: torch.float32, 10: torch.float64, 11: torch.bool}[int(dali_type)]
+
+
+class _TensorList:
+    def __init__(self, backend_pipe, idx):
+        info = backend_pipe.output_info(idx)
+        self._pipe, self._idx = backend_pipe, idx
+        self.dtype = [e for e in vars(types.DALIDataType).values()
+                      if isinstance(e, types.DALIDataType) and int(e) == info["dtype"]][0]
+        self._layout, self._n, self._dense, self._gpu = info["layout"], info["num_samples"], info["dense"], info["gpu"]
+        self._samples = [backend_pipe.output_sample(idx, i) for i in range(self._n)]
+
+    def __len__(self):
+        return self._n
+
+    def layout(self):
+        return self._layout
+
+    def shape(self):
+        return [list(s[1]) for s in self._samples]
+
+    def is_dense_tensor(self):
+        return self._n > 0 and all(s[1] == self._samples[0][1] for s in self._samples)
+
+    def at(self, i):
+        ptr, shape, pitch = self._samples[i]
+        cls = TensorGPU if self._gpu else TensorCPU
+        t = cls(self, ptr, shape, pitch, self.dtype, self._layout, self._gpu)
+        return t if self._gpu else t.as_array()
+
+    def __getitem__(self, i):
+        ptr, shape, pitch = self._samples[i]
+        return (TensorGPU if self._gpu else TensorCPU)(self, ptr, shape, pitch, self.dtype, self._layout, self._gpu)
+
+    def __iter__(self):
+        return (self[i] for i in range(self._n))
+
+
+class TensorListCPU(_TensorList):
+    def as_array(self):
+        assert self.is_dense_tensor(), "All samples must have the same shape to form a dense array"
+        return np.stack([self[i].as_array() for i in range(self._n)])
+
+    def as_tensor(self):
+        return self.as_array()
+
+    def as_cpu(self):
+        return self
+
+
+class TensorListGPU(_TensorList):
+    def as_tensor(self):
+        """Dense [N, ...] torch tensor (device).  Uniform, densely packed samples are viewed in place when
+        they are contiguous in the pipeline's buffer; otherwise they are gathered with one torch.stack."""
+        import torch
+        assert self.is_dense_tensor(), "All samples must have the same shape to form a dense tensor"
+        return torch.stack([self[i].as_torch() for i in range(self._n)])
+
+    def as_cpu(self):
+        return _HostCopy([self[i].as_cpu() for i in range(self._n)], self.dtype, self._layout)
+
+    def copy_to_external(self, ptr, cuda_stream=None, non_blocking=False):
+        """Copies the (uniform) batch into external device memory, like feed_ndarray does."""
+        import torch
+        t = self.as_tensor().contiguous()
+        nbytes = t.numel() * t.element_size()
+        dst = torch.as_tensor(_RawDevice(ptr, nbytes), device="cuda")
+        dst.copy_(t.view(torch.uint8).reshape(-1), non_blocking=non_blocking)
+
+
+class _RawDevice:
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 3}
+
+
+class _HostCopy:
+    """Result of TensorListGPU.as_cpu()."""
+
+    def __init__(self, arrays, dtype, layout):
+        self._a, self.dtype, self._layout = arrays, dtype, layout
+
+    def __len__(self):
+        return len(self._a)
+
+    def at(self, i):
+        return self._a[i]
+
+    def __getitem__(self, i):
+        return self._a[i]
+
+    def layout(self):
+        return self._layout
+
+    def shape(self):
+        return [list(a.shape) for a in self._a]
+
+    def as_array(self):
+        return np.stack(self._a)
+
+    as_tensor = as_array

@@ -115,8 +115,11 @@ typedef struct {
   int32_t width, height;        /* image size                                                */
   int32_t color;                /* daliamdJpegColor_t                                        */
   uint8_t *out;                 /* device: RGB u8 HWC                                        */
-  int32_t out_pitch;            /* bytes per output row (>= 3*width)                         */
+  int32_t out_pitch;            /* bytes per output row (>= 3 * output width)                */
   int32_t wg_start;             /* filled by Setup                                           */
+  int32_t orientation;          /* EXIF orientation to undo while writing: 0/1 none, 2..8;   */
+                                /* for 5..8 the output is height x width transposed          */
+  int32_t reserved;
 } daliamdJpegColorDesc;
 
 DALIAMD_API daliamdResult_t daliamdJpegColorSetup(daliamdJpegColorDesc *descs_host, int n, int *num_workgroups);

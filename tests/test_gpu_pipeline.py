@@ -1,0 +1,176 @@
+"""GPU end-to-end: the DALI-style pipeline (readers.file -> decoders.image(mixed) -> random_resized_crop ->
+crop_mirror_normalize) through the C++ host framework, checked against the oracle composition, plus the
+iterator and operator-fusion behaviour."""
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image, ImageOps
+
+from oracle import oracle as O
+from tests.util import encode_jpeg, synth_image, synth_jpeg_batch
+
+pytestmark = pytest.mark.gpu
+
+MEAN = [0.485 * 255, 0.456 * 255, 0.406 * 255]
+STD = [0.229 * 255, 0.224 * 255, 0.225 * 255]
+
+
+@pytest.fixture(scope="module")
+def jpeg_dir(tmp_path_factory):
+    root = tmp_path_factory.mktemp("jpegs")
+    rng = np.random.default_rng(21)
+    files = []
+    enc = synth_jpeg_batch(rng, 24, sizes=[(120, 160), (160, 120), (200, 200), (97, 131), (240, 320)])
+    for i, e in enumerate(enc):
+        d = root / f"class_{i % 3}"
+        os.makedirs(d, exist_ok=True)
+        p = d / f"img_{i:03d}.jpg"
+        p.write_bytes(e)
+    for c in range(3):
+        for f in sorted(os.listdir(root / f"class_{c}")):
+            files.append((str(root / f"class_{c}" / f), c))
+    return str(root), files
+
+
+def _train_pipe(root, bs, fused=True, **reader_kw):
+    from dali_amd import fn, types
+    from dali_amd.pipeline import Pipeline
+    pipe = Pipeline(batch_size=bs, num_threads=4, device_id=0, seed=3, prefetch_queue_depth=2)
+    with pipe:
+        jpegs, labels = fn.readers.file(file_root=root, name="Reader", **reader_kw)
+        images = fn.decoders.image(jpegs, device="mixed", output_type=types.RGB)
+        crops = fn.random_resized_crop(images, size=[64, 80], seed=1234)
+        flip = fn.random.coin_flip(probability=0.5, seed=4321)
+        out = fn.crop_mirror_normalize(crops, dtype=types.FLOAT16, output_layout="CHW", mean=MEAN, std=STD, mirror=flip)
+        if fused:
+            pipe.set_outputs(out, labels)
+        else:
+            pipe.set_outputs(out, labels, crops)
+    pipe.build()
+    return pipe
+
+
+def _oracle_batch(files, picks, it, bs, out_hw=(64, 80)):
+    imgs = [O.jpeg_decode_rgb(open(files[k][0], "rb").read()) for k in picks]
+    anchors, crops = O.rrc_batch(1234, it, [im.shape[:2] for im in imgs])
+    mirror = O.coin_flip_batch(4321, it, bs, 0.5)
+    mean, inv = O.cmn_norm_args(MEAN, STD)
+    u8, f16 = [], []
+    for i, im in enumerate(imgs):
+        roi = (anchors[i][0], anchors[i][1], anchors[i][0] + crops[i][0], anchors[i][1] + crops[i][1])
+        r = O.resample_u8(im, out_hw, roi=roi)
+        u8.append(r)
+        f16.append(O.cmn_u8(r, (0, 0), out_hw, mirror=bool(mirror[i]), mean=mean, inv_std=inv, dtype=O.F16))
+    return np.stack(u8), np.stack(f16)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_train_pipeline_matches_oracle(jpeg_dir, fused):
+    root, files = jpeg_dir
+    bs = 8
+    pipe = _train_pipe(root, bs, fused=fused)
+    for it in range(4):
+        outs = pipe.run()
+        data = outs[0].as_tensor().cpu().numpy()
+        labels = outs[1].as_array().reshape(-1)
+        picks = [(it * bs + i) % len(files) for i in range(bs)]
+        assert list(labels) == [files[k][1] for k in picks]
+        ref_u8, ref_f16 = _oracle_batch(files, picks, it, bs)
+        assert data.shape == (bs, 3, 64, 80) and data.dtype == np.float16
+        assert np.array_equal(data.view(np.uint16), ref_f16.view(np.uint16)), f"iteration {it}"
+        kernels = pipe.executed_kernels()
+        if fused:
+            assert "fused_resample_cmn" in kernels and "resample" not in kernels and "cmn" not in kernels
+        else:
+            assert "resample" in kernels and "cmn" in kernels and "fused_resample_cmn" not in kernels
+            assert np.array_equal(outs[2].as_tensor().cpu().numpy(), ref_u8)
+        assert "jpeg_idct" in kernels and "jpeg_color" in kernels
+
+
+def test_decoder_output_and_exif_orientation(tmp_path):
+    from dali_amd import fn
+    from dali_amd.pipeline import Pipeline
+    rng = np.random.default_rng(2)
+    files = []
+    for o in range(1, 9):
+        img = Image.fromarray(synth_image(rng, 40 + o, 64))
+        exif = Image.Exif()
+        exif[0x0112] = o
+        p = tmp_path / f"o{o}.jpg"
+        img.save(p, "JPEG", quality=90, exif=exif)
+        files.append(str(p))
+    for adjust in (True, False):
+        pipe = Pipeline(batch_size=8, num_threads=2, device_id=0)
+        with pipe:
+            enc, _ = fn.readers.file(files=files)
+            pipe.set_outputs(fn.decoders.image(enc, device="mixed", adjust_orientation=adjust))
+        (out,) = pipe.run()
+        assert out.layout() == "HWC"
+        for i, f in enumerate(files):
+            im = Image.open(f)
+            ref = np.asarray((ImageOps.exif_transpose(im) if adjust else im).convert("RGB"))
+            got = out[i].as_cpu()
+            assert got.shape == ref.shape, (i, adjust)
+            assert np.array_equal(got, ref), (i, adjust)
+
+
+def test_decoder_error_names_the_file(tmp_path):
+    from dali_amd import fn
+    from dali_amd.pipeline import Pipeline
+    good = tmp_path / "good.jpg"
+    good.write_bytes(encode_jpeg(synth_image(np.random.default_rng(0), 32, 32)))
+    bad = tmp_path / "broken.jpg"
+    bad.write_bytes(b"\xff\xd8 this is not a jpeg")
+    pipe = Pipeline(batch_size=2, num_threads=2, device_id=0)
+    with pipe:
+        enc, _ = fn.readers.file(files=[str(good), str(bad)])
+        pipe.set_outputs(fn.decoders.image(enc, device="mixed"))
+    with pytest.raises(RuntimeError, match="broken.jpg"):
+        pipe.run()
+
+
+def test_standalone_cmn_with_crop_and_pad(jpeg_dir):
+    from dali_amd import fn, types
+    from dali_amd.pipeline import Pipeline
+    root, files = jpeg_dir
+    pipe = Pipeline(batch_size=6, num_threads=2, device_id=0)
+    with pipe:
+        enc, _ = fn.readers.file(file_root=root)
+        img = fn.decoders.image(enc, device="mixed")
+        out = fn.crop_mirror_normalize(img, crop=(90, 100), dtype=types.FLOAT, output_layout="HWC", mean=[128.0],
+                                       std=[64.0], pad_output=True, crop_pos_x=0.25, crop_pos_y=1.0)
+        pipe.set_outputs(out)
+    (out,) = pipe.run()
+    got = out.as_tensor().cpu().numpy()
+    mean, inv = O.cmn_norm_args([128.0], [64.0])
+    for i in range(6):
+        im = O.jpeg_decode_rgb(open(files[i][0], "rb").read())
+        ay, ax = O.crop_anchor(1.0, 90, im.shape[0]), O.crop_anchor(0.25, 100, im.shape[1])
+        ref = O.cmn_u8(im, (ay, ax), (90, 100), mean=mean, inv_std=inv, layout="HWC", pad_output=True, dtype=O.F32)
+        assert np.array_equal(got[i].view(np.uint32), ref.view(np.uint32))
+    assert pipe.executed_kernels().count("cmn") == 1
+
+
+def test_iterator_two_shards(jpeg_dir):
+    from dali_amd.plugin.pytorch import DALIGenericIterator, LastBatchPolicy
+    root, files = jpeg_dir
+    pipes = [_train_pipe(root, 4, shard_id=k, num_shards=2, pad_last_batch=True) for k in range(2)]
+    it = DALIGenericIterator(pipes, ["data", "label"], reader_name="Reader", last_batch_policy=LastBatchPolicy.PARTIAL,
+                             auto_reset=True)
+    seen = [[], []]
+    for batch in it:
+        for g in range(2):
+            assert batch[g]["data"].is_cuda and batch[g]["data"].dtype == torch.float16
+            assert batch[g]["data"].shape[1:] == (3, 64, 80)
+            seen[g] += [int(v) for v in batch[g]["label"].reshape(-1)]
+    assert len(seen[0]) == 12 and len(seen[1]) == 12
+    assert seen[0] + seen[1] == [f[1] for f in files]
+    # second epoch: shards rotate
+    seen2 = [[], []]
+    for batch in it:
+        for g in range(2):
+            seen2[g] += [int(v) for v in batch[g]["label"].reshape(-1)]
+    assert seen2[0] == seen[1] and seen2[1] == seen[0]

@@ -1,0 +1,276 @@
+"""Host framework tests that need no GPU: schema registry -> fn generation, graph validation, the
+readers.file shard / shuffle / padding semantics, random operators vs the oracle, checkpointing, iterator
+epoch accounting.  (Reference behaviour: dali/operators/reader/loader/loader.h:78-503, loader.cc:78-87,
+dali/python/nvidia/dali/plugin/base_iterator.py.)"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+
+@pytest.fixture(scope="module")
+def dataset(tmp_path_factory):
+    """3 classes, 23 files; file content = global index as 4 little-endian bytes."""
+    root = tmp_path_factory.mktemp("ds")
+    files = []
+    k = 0
+    for c, n in (("apple", 9), ("banana", 6), ("cherry", 8)):
+        os.makedirs(root / c)
+        for i in range(n):
+            p = root / c / f"img_{i:03d}.jpg"
+            p.write_bytes(np.int32(k).tobytes())
+            files.append((str(p), {"apple": 0, "banana": 1, "cherry": 2}[c]))
+            k += 1
+    (root / "apple" / "notes.txt").write_text("ignored: extension not in the default filters")
+    return str(root), files
+
+
+def _reader_pipe(root, bs, **kw):
+    from dali_amd import fn
+    from dali_amd.pipeline import Pipeline
+    pipe = Pipeline(batch_size=bs, num_threads=2, device_id=0, seed=11, prefetch_queue_depth=kw.pop("depth", 2))
+    with pipe:
+        data, label = fn.readers.file(file_root=root, name="Reader", **kw)
+        pipe.set_outputs(data, label)
+    pipe.build()
+    return pipe
+
+
+def _run_indices(pipe, iters):
+    idx, lab = [], []
+    for _ in range(iters):
+        d, l = pipe.run()
+        idx.append([int(np.frombuffer(d.at(i).tobytes(), np.int32)[0]) for i in range(len(d))])
+        lab.append([int(l.at(i)[0]) for i in range(len(l))])
+    return np.array(idx), np.array(lab)
+
+
+def test_fn_namespace_is_generated_from_schemas():
+    from dali_amd import fn, ops
+    for path in ("readers.file", "decoders.image", "random.coin_flip", "random.uniform", "random_resized_crop",
+                 "crop_mirror_normalize", "external_source"):
+        obj = fn
+        for p in path.split("."):
+            obj = getattr(obj, p)
+        assert callable(obj)
+    assert "file_root" in fn.readers.file.__doc__ and "random_area" in fn.random_resized_crop.__doc__
+    assert ops.readers.File.schema_name == "readers__File" and ops.RandomResizedCrop.schema_name == "RandomResizedCrop"
+    assert fn._to_snake_case("RandomResizedCrop") == "random_resized_crop"
+    assert fn._to_snake_case("CoinFlip") == "coin_flip" and fn._to_snake_case("BBoxPaste") == "bbox_paste"
+
+
+def test_reader_labels_sorted_dirs_and_sequential_order(dataset):
+    root, files = dataset
+    pipe = _reader_pipe(root, 5)
+    idx, lab = _run_indices(pipe, 5)
+    flat = idx.reshape(-1)
+    assert list(flat[:23]) == list(range(23))          # alphabetical dirs, then files; .txt ignored
+    assert list(flat[23:]) == [0, 1]                   # wraps into the next epoch without padding
+    assert [files[i][1] for i in flat] == list(lab.reshape(-1))
+    meta = pipe.reader_meta("Reader")
+    assert meta == dict(epoch_size=23, epoch_size_padded=23, number_of_shards=1, shard_id=0, pad_last_batch=0,
+                        stick_to_shard=0)
+
+
+def test_reader_shards_partition_the_dataset(dataset):
+    root, _ = dataset
+    seen = []
+    for k in range(4):
+        pipe = _reader_pipe(root, 1, shard_id=k, num_shards=4, stick_to_shard=True)
+        start, end = 23 * k // 4, 23 * (k + 1) // 4     # loader.cc:78-82
+        idx, _ = _run_indices(pipe, end - start + 2)
+        flat = list(idx.reshape(-1))
+        assert flat[: end - start] == list(range(start, end))
+        assert flat[end - start:] == [start, start + 1]  # stick_to_shard: wraps inside its own shard
+        seen += flat[: end - start]
+    assert sorted(seen) == list(range(23))
+
+
+def test_reader_rotates_shards_between_epochs(dataset):
+    root, _ = dataset
+    pipe = _reader_pipe(root, 1, shard_id=1, num_shards=2)
+    idx, _ = _run_indices(pipe, 23)
+    flat = list(idx.reshape(-1))
+    assert flat[:12] == list(range(11, 23))             # epoch 0: shard 1 = [11, 23)
+    assert flat[12:] == list(range(0, 11))              # epoch 1: moves on to shard 0
+
+
+def test_reader_pad_last_batch(dataset):
+    root, _ = dataset
+    # shard 0 of 2 has 11 samples, shard 1 has 12; with padding both yield ceil(23/2) = 12 per epoch and the last
+    # batch is padded by repeating the final sample
+    pipe = _reader_pipe(root, 5, shard_id=0, num_shards=2, pad_last_batch=True, stick_to_shard=True)
+    idx, _ = _run_indices(pipe, 3)
+    flat = list(idx.reshape(-1))
+    assert flat[:11] == list(range(11)) and flat[11:15] == [10, 10, 10, 10]
+    meta = pipe.reader_meta("Reader")
+    assert meta["epoch_size"] == 23 and meta["epoch_size_padded"] == 24 and meta["pad_last_batch"] == 1
+
+
+def test_reader_random_shuffle_is_a_permutation_and_seeded(dataset):
+    root, _ = dataset
+    a, _ = _run_indices(_reader_pipe(root, 23, random_shuffle=True, initial_fill=8, seed=5), 2)
+    b, _ = _run_indices(_reader_pipe(root, 23, random_shuffle=True, initial_fill=8, seed=5), 2)
+    c, _ = _run_indices(_reader_pipe(root, 23, random_shuffle=True, initial_fill=8, seed=6), 2)
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    for epoch in a:
+        assert sorted(epoch) == list(range(23))         # every epoch is a permutation
+    assert list(a[0]) != list(range(23))
+    # a reservoir of 8 cannot move a sample more than ~8 + position forward: sample k appears after >= k - 8 draws
+    pos = {v: i for i, v in enumerate(a[0])}
+    assert all(pos[k] >= k - 8 for k in range(23))
+
+
+def test_reader_file_list_and_files_args(dataset, tmp_path):
+    root, files = dataset
+    from dali_amd import fn
+    from dali_amd.pipeline import Pipeline
+    lst = tmp_path / "list.txt"
+    lst.write_text("\n".join(f"{os.path.relpath(p, root)} {100 + l}" for p, l in files[:4]) + "\n")
+    pipe = Pipeline(batch_size=4, num_threads=1, device_id=0)
+    with pipe:
+        d, l = fn.readers.file(file_root=root, file_list=str(lst))
+        pipe.set_outputs(d, l)
+    d, l = pipe.run()
+    assert [int(l.at(i)[0]) for i in range(4)] == [100, 100, 100, 100]
+    pipe = Pipeline(batch_size=3, num_threads=1, device_id=0)
+    with pipe:
+        d, l = fn.readers.file(files=[files[5][0], files[20][0], files[9][0]], labels=[7, 8, 9])
+        pipe.set_outputs(d, l)
+    d, l = pipe.run()
+    assert [int(np.frombuffer(d.at(i).tobytes(), np.int32)[0]) for i in range(3)] == [5, 20, 9]
+    assert [int(l.at(i)[0]) for i in range(3)] == [7, 8, 9]
+
+
+def test_graph_validation_errors(dataset):
+    root, _ = dataset
+    from dali_amd import fn
+    from dali_amd.pipeline import Pipeline
+    pipe = Pipeline(batch_size=2, num_threads=1, device_id=0)
+    with pipe:
+        d, l = fn.readers.file(file_root=root)
+        with pytest.raises(TypeError, match="unexpected keyword"):
+            fn.random.coin_flip(probabilty=0.3)
+        with pytest.raises(RuntimeError, match="not available for device \"cpu\""):
+            fn.decoders.image(d)                       # no CPU fallback for device operators
+        with pytest.raises(ValueError, match="expects between"):
+            fn.random_resized_crop(size=[8, 8], device="gpu")
+        with pytest.raises(ValueError, match="cannot take a GPU input"):
+            fn.decoders.image(d.gpu(), device="mixed")
+        pipe.set_outputs(d, l)
+    with pytest.raises(RuntimeError, match="num_shards needs to be greater than shard_id"):
+        p2 = Pipeline(batch_size=2, num_threads=1, device_id=0)
+        with p2:
+            p2.set_outputs(*fn.readers.file(file_root=root, shard_id=3, num_shards=2))
+        p2.build()
+    with pytest.raises(RuntimeError, match="required argument"):
+        p3 = Pipeline(batch_size=2, num_threads=1, device_id=0)
+        with p3:
+            d, l = fn.readers.file(file_root=root)
+            img = fn.decoders.image(d, device="mixed")
+            p3.set_outputs(fn.random_resized_crop(img))   # `size` is required
+        p3.build()
+
+
+def test_random_ops_match_oracle_and_checkpoint_roundtrip():
+    from dali_amd import fn
+    from dali_amd.pipeline import Pipeline, pipeline_def
+
+    @pipeline_def(batch_size=16, num_threads=2, device_id=0, seed=99, prefetch_queue_depth=1)
+    def pipe_fn(p):
+        return fn.random.coin_flip(probability=p, seed=1234), fn.random.uniform(range=[-2.0, 3.0], seed=77)
+
+    pipe = pipe_fn(0.3)
+    # outputs are views of pipeline-owned buffers, valid until the next run(): copy them out right away
+    outs = [tuple(o.as_array() for o in pipe.run()) for _ in range(4)]
+    for it, (flip, uni) in enumerate(outs):
+        assert np.array_equal(flip.reshape(-1), O.coin_flip_batch(1234, it, 16, 0.3))
+        u = uni.reshape(-1)
+        assert u.dtype == np.float32 and (u >= -2).all() and (u < 3).all()
+    # uniform = fma(u32, (nextafter(3,-2) - (-2)) * 2^-32, -2): restated from random_dist.h:175-205
+    g = O.Philox(77, 0, 0)
+    r = g.next()
+    mx = np.nextafter(np.float32(3), np.float32(-2))
+    factor = np.float32((mx - np.float32(-2)) * np.float32(2.0 ** -32))
+    expect = min(np.float32(np.float64(np.float32(r)) * np.float64(factor) + np.float64(np.float32(-2))), mx)
+    assert outs[0][1].reshape(-1)[0] == expect
+    # checkpoint after 4 iterations, restore into a fresh pipeline: the streams continue identically
+    cpt = pipe.checkpoint()
+    nxt = tuple(o.as_array() for o in pipe.run())
+    pipe2 = Pipeline(batch_size=16, num_threads=2, device_id=0, seed=99, prefetch_queue_depth=1, checkpoint=cpt)
+    with pipe2:
+        pipe2.set_outputs(fn.random.coin_flip(probability=0.3, seed=1234), fn.random.uniform(range=[-2.0, 3.0], seed=77))
+    res = pipe2.run()
+    assert np.array_equal(res[0].as_array(), nxt[0]) and np.array_equal(res[1].as_array(), nxt[1])
+
+
+def test_pipeline_seed_assigns_distinct_reproducible_op_seeds():
+    from dali_amd import fn
+    from dali_amd.pipeline import pipeline_def
+
+    @pipeline_def(batch_size=64, num_threads=1, device_id=0)
+    def p():
+        return fn.random.coin_flip(), fn.random.coin_flip()
+
+    a = [o.as_array() for o in p(seed=5).run()]
+    b = [o.as_array() for o in p(seed=5).run()]
+    c = [o.as_array() for o in p(seed=6).run()]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert not np.array_equal(a[0], a[1])      # the two operators got different seeds
+    assert not np.array_equal(a[0], c[0])
+
+
+def test_external_source_feed_and_callback():
+    from dali_amd import fn
+    from dali_amd.pipeline import Pipeline
+    pipe = Pipeline(batch_size=3, num_threads=1, device_id=0, prefetch_queue_depth=1)
+    with pipe:
+        x = fn.external_source(name="x")
+        pipe.set_outputs(x)
+    pipe.build()
+    with pytest.raises(RuntimeError, match="No data was provided"):
+        pipe.run()
+    pipe = Pipeline(batch_size=3, num_threads=1, device_id=0, prefetch_queue_depth=1)
+    batches = [[np.full((2, i + 1), 10 * k + i, np.int32) for i in range(3)] for k in range(3)]
+    with pipe:
+        pipe.set_outputs(fn.external_source(source=iter(batches), layout="AB"))
+    for k in range(3):
+        (out,) = pipe.run()
+        assert out.layout() == "AB" and out.shape() == [[2, 1], [2, 2], [2, 3]]
+        assert all((out.at(i) == 10 * k + i).all() for i in range(3))
+
+
+def test_iterator_epochs_with_reader(dataset):
+    root, _ = dataset
+    from dali_amd.plugin.pytorch import DALIGenericIterator, LastBatchPolicy
+
+    def labels_of(it):
+        return [[int(v) for v in b[0]["label"].reshape(-1)] for b in it]
+
+    # FILL without padding: 23 samples, batch 5 -> 5 batches; the tail wraps into the next epoch
+    it = DALIGenericIterator([_reader_pipe(root, 5)], ["data", "label"], reader_name="Reader", auto_reset=True)
+    assert len(it) == 5
+    e0 = labels_of(it)
+    assert len(e0) == 5 and all(len(b) == 5 for b in e0)
+    e1 = labels_of(it)
+    assert len(e1) == 5   # 2 samples were read ahead: 21 left -> still 5 batches
+    # PARTIAL: last batch trimmed to the 3 real samples
+    it = DALIGenericIterator([_reader_pipe(root, 5, pad_last_batch=True)], ["data", "label"], reader_name="Reader",
+                             last_batch_policy=LastBatchPolicy.PARTIAL, auto_reset=True)
+    e = labels_of(it)
+    assert [len(b) for b in e] == [5, 5, 5, 5, 3]
+    assert [len(b) for b in labels_of(it)] == [5, 5, 5, 5, 3]
+    # DROP: only full batches
+    it = DALIGenericIterator([_reader_pipe(root, 5)], ["data", "label"], reader_name="Reader",
+                             last_batch_policy=LastBatchPolicy.DROP, auto_reset=True)
+    assert len(it) == 4 and [len(b) for b in labels_of(it)] == [5, 5, 5, 5]
+    # two pipelines = two shards, like one per GPU
+    pipes = [_reader_pipe(root, 4, shard_id=k, num_shards=2, pad_last_batch=True) for k in range(2)]
+    it = DALIGenericIterator(pipes, ["data", "label"], reader_name="Reader", auto_reset=True)
+    n = 0
+    for batch in it:
+        assert len(batch) == 2 and batch[0]["label"].shape[0] == 4
+        n += 1
+    assert n == 3   # ceil(23/2) = 12 per shard -> 3 batches of 4
