@@ -215,3 +215,21 @@ def jpeg_decode_rgb(data, return_coefs=False):
     if rc:
         raise RuntimeError(f"orc_jpeg_decode_rgb failed: {rc}")
     return (rgb, coefs, qt, inf) if return_coefs else rgb
+
+
+# ---------------------------------------------------------------- whole path (CPU baseline)
+def pipeline_batch(jpegs, rrc_seed, flip_seed, iteration, out_hw=(224, 224), mean=None, inv_std=None, nthreads=0):
+    """decode -> RandomResizedCrop -> CropMirrorNormalize(fp16 CHW) for a batch on an OpenMP team."""
+    n = len(jpegs)
+    bufs = [np.frombuffer(j, dtype=np.uint8) for j in jpegs]
+    ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+    sizes = (C.c_size_t * n)(*[b.size for b in bufs])
+    out = np.zeros((n, 3, out_hw[0], out_hw[1]), np.float16)
+    mean = np.ascontiguousarray(mean, np.float32)
+    inv = np.ascontiguousarray(inv_std, np.float32)
+    failed = lib().orc_pipeline_batch(ptrs, sizes, n, C.c_int64(rrc_seed), C.c_int64(flip_seed), C.c_int64(iteration),
+                                      int(out_hw[0]), int(out_hw[1]), _p(mean, C.c_float), _p(inv, C.c_float),
+                                      out.ctypes.data_as(C.c_void_p), int(nthreads))
+    if failed:
+        raise RuntimeError(f"{failed} samples failed in the oracle pipeline")
+    return out
