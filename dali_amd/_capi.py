@@ -72,6 +72,36 @@ class CmnDesc(C.Structure):
                 ("wg_start", C.c_int32)]
 
 
+class WarpAffineDesc(C.Structure):
+    _fields_ = [("in_", C.c_void_p), ("out", C.c_void_p), ("in_h", C.c_int32), ("in_w", C.c_int32),
+                ("channels", C.c_int32), ("in_pitch", C.c_int32), ("out_h", C.c_int32), ("out_w", C.c_int32),
+                ("out_pitch", C.c_int32), ("matrix", C.c_float * 6), ("interp", C.c_int32),
+                ("border_clamp", C.c_int32), ("fill", C.c_float * 4), ("wg_start", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+MAX_BLUR_WINDOW = 63
+
+
+class GaussianBlurDesc(C.Structure):
+    _fields_ = [("in_", C.c_void_p), ("out", C.c_void_p), ("h", C.c_int32), ("w", C.c_int32),
+                ("channels", C.c_int32), ("in_pitch", C.c_int32), ("out_pitch", C.c_int32),
+                ("size_x", C.c_int32), ("size_y", C.c_int32), ("window_x", C.c_float * 64),
+                ("window_y", C.c_float * 64), ("tile_w", C.c_int32), ("tile_h", C.c_int32),
+                ("tiles_x", C.c_int32), ("wg_start", C.c_int32), ("lds_bytes", C.c_int32)]
+
+
+MAX_ERASE_REGIONS = 8
+
+
+class PointwiseDesc(C.Structure):
+    _fields_ = [("in_", C.c_void_p), ("out", C.c_void_p), ("h", C.c_int32), ("w", C.c_int32),
+                ("channels", C.c_int32), ("in_pitch", C.c_int32), ("out_pitch", C.c_int32),
+                ("transform", C.c_int32), ("matrix", C.c_float * 9), ("offset", C.c_float * 3),
+                ("num_regions", C.c_int32), ("region", (C.c_int32 * 4) * 8), ("fill", C.c_float * 4),
+                ("wg_start", C.c_int32)]
+
+
 # ------------------------------------------------------------------ structs (host)
 class JpegInfo(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("num_components", C.c_int32),
@@ -99,6 +129,8 @@ _KERNEL_SYMBOLS = [
     "daliamdMemcpyD2HAsync", "daliamdMemcpyD2DAsync", "daliamdMemsetAsync",
     "daliamdJpegIdctSetup", "daliamdJpegIdctRun", "daliamdJpegColorSetup", "daliamdJpegColorRun",
     "daliamdResampleSetup", "daliamdResampleRun", "daliamdCmnSetup", "daliamdCmnRun",
+    "daliamdWarpAffineSetup", "daliamdWarpAffineRun", "daliamdGaussianWindow", "daliamdGaussianBlurSetup",
+    "daliamdGaussianBlurRun", "daliamdColorTwistMatrix", "daliamdPointwiseSetup", "daliamdPointwiseRun",
 ]
 
 _HOST_SYMBOLS = [

@@ -387,3 +387,117 @@ def cmn_norm_args(mean, std, scale=1.0, shift=0.0):
     if k < 0:
         capi.check_host(1)
     return mo[:k].copy(), io[:k].copy()
+
+
+# =====================================================================================
+# heavy augmentation kernels (configs[2]): thin batch drivers over the C ABI
+# =====================================================================================
+def _img_fields(d, img, out):
+    d["in_"], d["out"] = img.data_ptr(), out.data_ptr()
+
+
+def warp_affine_batch(images, matrices, out_size=None, interp=capi.INTERP_LINEAR, fill_value=None):
+    """matrices[i]: 2x3 dst->src.  fill_value None -> clamp border."""
+    lib = capi.kernels()
+    n = len(images)
+    dev = images[0].device
+    descs = np.zeros(n, np.dtype(capi.WarpAffineDesc))
+    outs = []
+    for i, img in enumerate(images):
+        h, w, c = img.shape
+        oh, ow = (h, w) if out_size is None else out_size
+        out = torch.empty((oh, ow, c), dtype=torch.uint8, device=dev)
+        outs.append(out)
+        d = descs[i]
+        d["in_"], d["out"] = img.data_ptr(), out.data_ptr()
+        d["in_h"], d["in_w"], d["channels"], d["in_pitch"] = h, w, c, img.stride(0)
+        d["out_h"], d["out_w"], d["out_pitch"] = oh, ow, ow * c
+        d["matrix"] = np.asarray(matrices[i], np.float32).reshape(6)
+        d["interp"] = interp
+        d["border_clamp"] = 1 if fill_value is None else 0
+        if fill_value is not None:
+            d["fill"] = np.broadcast_to(np.asarray(fill_value, np.float32), (4,)) if np.ndim(fill_value) == 0 else \
+                np.pad(np.asarray(fill_value, np.float32), (0, 4 - len(fill_value)))
+    nwg = C.c_int(0)
+    capi.check(lib.daliamdWarpAffineSetup(descs.ctypes.data_as(C.c_void_p), n, C.byref(nwg)))
+    dd = _uploader.upload(descs, dev)
+    capi.check(lib.daliamdWarpAffineRun(current_stream_ptr(dev), C.c_void_p(dd.data_ptr()), n, nwg.value))
+    return outs
+
+
+def gaussian_window(sigma=0.0, window_size=0):
+    lib = capi.kernels()
+    w = np.zeros(64, np.float32)
+    s = C.c_float(0)
+    d = lib.daliamdGaussianWindow(C.c_float(sigma), int(window_size), w.ctypes.data_as(C.c_void_p), C.byref(s))
+    if d < 0:
+        capi.check(1)
+    return w[:d].copy()
+
+
+def gaussian_blur_batch(images, sigma=0.0, window_size=0):
+    lib = capi.kernels()
+    n = len(images)
+    dev = images[0].device
+    descs = np.zeros(n, np.dtype(capi.GaussianBlurDesc))
+    sig = np.broadcast_to(np.asarray(sigma, np.float32), (n,))
+    wsz = np.broadcast_to(np.asarray(window_size, np.int32), (n,))
+    outs = []
+    for i, img in enumerate(images):
+        h, w, c = img.shape
+        out = torch.empty((h, w, c), dtype=torch.uint8, device=dev)
+        outs.append(out)
+        win = gaussian_window(float(sig[i]), int(wsz[i]))
+        d = descs[i]
+        d["in_"], d["out"] = img.data_ptr(), out.data_ptr()
+        d["h"], d["w"], d["channels"], d["in_pitch"], d["out_pitch"] = h, w, c, img.stride(0), w * c
+        d["size_x"] = d["size_y"] = win.size
+        d["window_x"][:win.size] = win
+        d["window_y"][:win.size] = win
+    nwg, lds = C.c_int(0), C.c_int(0)
+    capi.check(lib.daliamdGaussianBlurSetup(descs.ctypes.data_as(C.c_void_p), n, C.byref(nwg), C.byref(lds)))
+    dd = _uploader.upload(descs, dev)
+    capi.check(lib.daliamdGaussianBlurRun(current_stream_ptr(dev), C.c_void_p(dd.data_ptr()), n, nwg.value, lds.value))
+    return outs
+
+
+def color_twist_matrix(hue=0.0, saturation=1.0, value=1.0, brightness=1.0, contrast=1.0):
+    lib = capi.kernels()
+    m = np.zeros(9, np.float32)
+    off = C.c_float(0)
+    lib.daliamdColorTwistMatrix(C.c_float(hue), C.c_float(saturation), C.c_float(value), C.c_float(brightness),
+                                C.c_float(contrast), m.ctypes.data_as(C.c_void_p), C.byref(off))
+    return m.reshape(3, 3), np.float32(off.value)
+
+
+def pointwise_batch(images, matrices=None, offsets=None, regions=None, fill=(0.0,)):
+    """Colour transform (matrices[i] 3x3 + offsets[i]) and/or erase (regions[i] = list of (y0, x0, y1, x1))."""
+    lib = capi.kernels()
+    n = len(images)
+    dev = images[0].device
+    descs = np.zeros(n, np.dtype(capi.PointwiseDesc))
+    outs = []
+    for i, img in enumerate(images):
+        h, w, c = img.shape
+        out = torch.empty((h, w, c), dtype=torch.uint8, device=dev)
+        outs.append(out)
+        d = descs[i]
+        d["in_"], d["out"] = img.data_ptr(), out.data_ptr()
+        d["h"], d["w"], d["channels"], d["in_pitch"], d["out_pitch"] = h, w, c, img.stride(0), w * c
+        if matrices is not None:
+            d["transform"] = 1
+            d["matrix"] = np.asarray(matrices[i], np.float32).reshape(9)
+            d["offset"] = np.broadcast_to(np.asarray(offsets[i], np.float32), (3,))
+        if regions is not None:
+            regs = regions[i]
+            d["num_regions"] = len(regs)
+            for k, r in enumerate(regs):
+                y0, x0, y1, x1 = r
+                d["region"][k] = (max(0, y0), max(0, x0), min(h, y1), min(w, x1))
+        f = list(fill)
+        d["fill"] = [f[0]] * 4 if len(f) == 1 else (f + [0.0] * 4)[:4]
+    nwg = C.c_int(0)
+    capi.check(lib.daliamdPointwiseSetup(descs.ctypes.data_as(C.c_void_p), n, C.byref(nwg)))
+    dd = _uploader.upload(descs, dev)
+    capi.check(lib.daliamdPointwiseRun(current_stream_ptr(dev), C.c_void_p(dd.data_ptr()), n, nwg.value))
+    return outs

@@ -1,0 +1,403 @@
+// Heavy-augmentation kernels for gfx950: warp_affine, separable Gaussian blur, colour twist (3x3 linear
+// transform) and erase.  u8 HWC -> u8 HWC, one launch per batch per operator, block -> sample through the
+// wg_start prefix (common.h).  Arithmetic order follows the reference's CPU kernels (see the header).
+#include <cmath>
+#include <cstring>
+#include "common.h"
+
+namespace daliamd {
+
+__device__ __forceinline__ uint32_t SatU8(float v) {  // ConvertSat<uint8_t>: std::round then clamp
+  if (!(v > 0.0f)) return 0;
+  float r = floorf(v);
+  r += (v - r >= 0.5f) ? 1.0f : 0.0f;
+  return (uint32_t)fminf(r, 255.0f);
+}
+__device__ __forceinline__ int ClampInt(int v, int lo, int hi) { return min(max(v, lo), hi); }
+
+// =============================================================================================
+// warp_affine
+// =============================================================================================
+// The CPU kernel walks each output row adding ds/dx per pixel, re-anchoring every 256 pixels
+// (warp_cpu.h:160-176).  To be bit-identical every thread replays that chain of float additions up to its
+// first pixel (<= 255 dependent adds; cheap next to the 4-tap gather) and then produces kWarpPx pixels.
+constexpr int kWarpThreads = 256;
+constexpr int kWarpPx = 4;
+constexpr int kWarpTileW = 256;  // must equal the CPU re-anchoring period
+constexpr int kWarpRows = kWarpThreads / (kWarpTileW / kWarpPx);  // 4 rows per workgroup
+
+__device__ __forceinline__ float WarpFetch(const daliamdWarpAffineDesc &d, int x, int y, int c, float fillc) {
+  if ((unsigned)x < (unsigned)d.in_w && (unsigned)y < (unsigned)d.in_h)
+    return (float)d.in[(size_t)y * d.in_pitch + x * d.channels + c];
+  if (!d.border_clamp) return fillc;
+  x = ClampInt(x, 0, d.in_w - 1);
+  y = ClampInt(y, 0, d.in_h - 1);
+  return (float)d.in[(size_t)y * d.in_pitch + x * d.channels + c];
+}
+
+__global__ __launch_bounds__(kWarpThreads) void WarpAffineKernel(const daliamdWarpAffineDesc *__restrict__ descs,
+                                                                 int ndesc, int total_wg) {
+  int wg = XcdRemap(blockIdx.x, total_wg);
+  if (wg < 0) return;
+  const daliamdWarpAffineDesc &d = descs[FindDesc(descs, ndesc, wg)];
+  const int tiles_x = (d.out_w + kWarpTileW - 1) / kWarpTileW;
+  int t = wg - d.wg_start;
+  int ty = t / tiles_x, tx = t - ty * tiles_x;
+  int y = ty * kWarpRows + threadIdx.x / (kWarpTileW / kWarpPx);
+  int x_tile = tx * kWarpTileW;
+  int x0 = x_tile + (threadIdx.x % (kWarpTileW / kWarpPx)) * kWarpPx;
+  if (y >= d.out_h || x0 >= d.out_w) return;
+  const float m0 = d.matrix[0], m1 = d.matrix[1], m2 = d.matrix[2], m3 = d.matrix[3], m4 = d.matrix[4], m5 = d.matrix[5];
+  // map_coords(mapping, (0, y)): affine(M, (0.5, y + 0.5)), sum = t; sum += m*v (transform.h:134-145)
+  float vx = 0 + 0.5f, vy = y + 0.5f;
+  float sx = m2; sx += m0 * vx; sx += m1 * vy;
+  float sy = m5; sy += m3 * vx; sy += m4 * vy;
+  const float dtx = kWarpTileW * m0, dty = kWarpTileW * m3;
+  for (int k = 0; k < tx; k++) { sx += dtx; sy += dty; }
+  for (int k = x_tile; k < x0; k++) { sx += m0; sy += m3; }
+  const int C = d.channels;
+  const int npx = min(kWarpPx, d.out_w - x0);
+  uint8_t *o = d.out + (size_t)y * d.out_pitch + (size_t)x0 * C;
+  const float f0 = (float)SatU8(d.fill[0]), f1 = (float)SatU8(d.fill[1]), f2 = (float)SatU8(d.fill[2]),
+              f3 = (float)SatU8(d.fill[3]);
+  for (int p = 0; p < npx; p++, sx += m0, sy += m3) {
+    if (d.interp == DALIAMD_INTERP_NN) {
+      int ix = (int)floorf(sx), iy = (int)floorf(sy);
+      for (int c = 0; c < C; c++) {
+        float fc = c == 0 ? f0 : c == 1 ? f1 : c == 2 ? f2 : f3;
+        o[p * C + c] = (uint8_t)WarpFetch(d, ix, iy, c, fc);
+      }
+    } else {
+      float fx = sx - 0.5f, fy = sy - 0.5f;
+      int ix = (int)floorf(fx), iy = (int)floorf(fy);
+      float qx = fx - ix, px = 1 - qx, qy = fy - iy;
+      for (int c = 0; c < C; c++) {
+        float fc = c == 0 ? f0 : c == 1 ? f1 : c == 2 ? f2 : f3;
+        float s00 = WarpFetch(d, ix, iy, c, fc), s01 = WarpFetch(d, ix + 1, iy, c, fc);
+        float s10 = WarpFetch(d, ix, iy + 1, c, fc), s11 = WarpFetch(d, ix + 1, iy + 1, c, fc);
+        float s0 = s00 * px + s01 * qx;
+        float s1 = s10 * px + s11 * qx;
+        o[p * C + c] = (uint8_t)SatU8(s0 + (s1 - s0) * qy);
+      }
+    }
+  }
+}
+
+// =============================================================================================
+// gaussian blur: LDS-tiled separable convolution, both passes in one kernel
+// =============================================================================================
+constexpr int kBlurThreads = 256;
+constexpr int kBlurMaxLds = 60 * 1024;
+
+__device__ __forceinline__ int Reflect101(int idx, int size) {
+  if (size < 2) return size - 1;
+  for (;;) {
+    if (idx < 0) idx = -idx;
+    else if (idx >= size) idx = 2 * size - 2 - idx;
+    else break;
+  }
+  return idx;
+}
+
+__global__ __launch_bounds__(kBlurThreads) void GaussianBlurKernel(const daliamdGaussianBlurDesc *__restrict__ descs,
+                                                                   int ndesc, int total_wg) {
+  extern __shared__ __attribute__((aligned(16))) float blur_lds[];
+  int wg = XcdRemap(blockIdx.x, total_wg);
+  if (wg < 0) return;
+  const daliamdGaussianBlurDesc &d = descs[FindDesc(descs, ndesc, wg)];
+  const int C = d.channels, TW = d.tile_w, TH = d.tile_h;
+  const int rx = (d.size_x - 1) / 2, ry = (d.size_y - 1) / 2;
+  int t = wg - d.wg_start;
+  int ty = t / d.tiles_x, tx = t - ty * d.tiles_x;
+  const int ox0 = tx * TW, oy0 = ty * TH;
+  const int tw = min(TW, d.w - ox0), th = min(TH, d.h - oy0);
+  const int in_rows = th + 2 * ry, in_cols = tw + 2 * rx;
+  const int row_elems = tw * C;                        // tmp row length
+  const int src_pitch = (in_cols * C + 3) & ~3;        // staged source row pitch (bytes)
+  float *wx = blur_lds;                                // [size_x]
+  float *wy = wx + d.size_x;                           // [size_y]
+  float *tmp = wy + d.size_y;                          // [in_rows][row_elems]
+  uint8_t *src = reinterpret_cast<uint8_t *>(tmp + (size_t)(TH + 2 * ry) * TW * C);  // [in_rows][src_pitch]
+  const int tid = threadIdx.x;
+  for (int i = tid; i < d.size_x; i += kBlurThreads) wx[i] = d.window_x[i];
+  for (int i = tid; i < d.size_y; i += kBlurThreads) wy[i] = d.window_y[i];
+  // ---- stage the halo-extended source tile; reflect-101 indices are resolved here ----
+  for (int r = tid / 64; r < in_rows; r += kBlurThreads / 64) {
+    const uint8_t *row = d.in + (size_t)Reflect101(oy0 - ry + r, d.h) * d.in_pitch;
+    uint8_t *dst = src + r * src_pitch;
+    for (int cx = tid % 64; cx < in_cols; cx += 64) {
+      const uint8_t *p = row + (size_t)Reflect101(ox0 - rx + cx, d.w) * C;
+      for (int c = 0; c < C; c++) dst[cx * C + c] = p[c];
+    }
+  }
+  __syncthreads();
+  // ---- W pass: tmp[r][x*C+c] = sum_k src[r][(x+k)*C+c] * wx[k], taps in order ----
+  for (int r = tid / 64; r < in_rows; r += kBlurThreads / 64) {
+    const uint8_t *srow = src + r * src_pitch;
+    float *trow = tmp + r * row_elems;
+    for (int e = tid % 64; e < row_elems; e += 64) {
+      float acc = 0;
+      const uint8_t *p = srow + e;
+      for (int k = 0; k < d.size_x; k++) acc += (float)p[k * C] * wx[k];
+      trow[e] = acc;
+    }
+  }
+  __syncthreads();
+  // ---- H pass ----
+  for (int y = tid / 64; y < th; y += kBlurThreads / 64) {
+    uint8_t *orow = d.out + (size_t)(oy0 + y) * d.out_pitch + (size_t)ox0 * C;
+    for (int e = tid % 64; e < row_elems; e += 64) {
+      float acc = 0;
+      const float *p = tmp + y * row_elems + e;
+      for (int k = 0; k < d.size_y; k++) acc += wy[k] * p[k * row_elems];
+      orow[e] = (uint8_t)SatU8(acc);
+    }
+  }
+}
+
+// =============================================================================================
+// pointwise: colour twist (3x3 matrix + offset) and / or erase, 4 pixels per thread
+// =============================================================================================
+constexpr int kPwThreads = 256;
+constexpr int kPwPx = 4;
+
+__global__ __launch_bounds__(kPwThreads) void PointwiseKernel(const daliamdPointwiseDesc *__restrict__ descs, int ndesc,
+                                                              int total_wg) {
+  int wg = XcdRemap(blockIdx.x, total_wg);
+  if (wg < 0) return;
+  const daliamdPointwiseDesc &d = descs[FindDesc(descs, ndesc, wg)];
+  const int C = d.channels;
+  const int groups_per_row = (d.w + kPwPx - 1) / kPwPx;
+  long long g = (long long)(wg - d.wg_start) * kPwThreads + threadIdx.x;
+  if (g >= (long long)groups_per_row * d.h) return;
+  int y = (int)(g / groups_per_row);
+  int x0 = (int)(g - (long long)y * groups_per_row) * kPwPx;
+  int npx = min(kPwPx, d.w - x0);
+  const uint8_t *ip = d.in + (size_t)y * d.in_pitch + (size_t)x0 * C;
+  uint8_t *op = d.out + (size_t)y * d.out_pitch + (size_t)x0 * C;
+  for (int p = 0; p < npx; p++) {
+    int x = x0 + p;
+    bool erased = false;
+    for (int r = 0; r < d.num_regions; r++)
+      erased |= y >= d.region[r][0] && y < d.region[r][2] && x >= d.region[r][1] && x < d.region[r][3];
+    if (erased) {
+      for (int c = 0; c < C; c++) op[p * C + c] = (uint8_t)SatU8(c == 0 ? d.fill[0] : c == 1 ? d.fill[1] : c == 2 ? d.fill[2] : d.fill[3]);
+    } else if (d.transform) {
+      float v0 = (float)ip[p * 3], v1 = (float)ip[p * 3 + 1], v2 = (float)ip[p * 3 + 2];
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        float s = d.matrix[3 * i] * v0;   // mat * vec: s = m[i][0]*v[0]; s += m[i][j]*v[j]   (mat.h:283-292)
+        s += d.matrix[3 * i + 1] * v1;
+        s += d.matrix[3 * i + 2] * v2;
+        op[p * 3 + i] = (uint8_t)SatU8(s + d.offset[i]);
+      }
+    } else {
+      for (int c = 0; c < C; c++) op[p * C + c] = ip[p * C + c];
+    }
+  }
+}
+
+// host-side 3x3 helpers for the colour-twist matrix (include/dali/core/geom/mat.h:260-299,551-612)
+static void Mat3Mul(const float a[9], const float b[9], float out[9]) {
+  float r[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      float s = a[3 * i] * b[j];
+      s += a[3 * i + 1] * b[3 + j];
+      s += a[3 * i + 2] * b[6 + j];
+      r[3 * i + j] = s;
+    }
+  memcpy(out, r, sizeof(r));
+}
+static void Mat3Diag(float v, float out[9]) {
+  for (int i = 0; i < 9; i++) out[i] = 0;
+  out[0] = out[4] = out[8] = v;
+}
+static void Mat3Inverse(const float *a, float *out) {
+  float A[3][3], B[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  memcpy(A, a, sizeof(A));
+  for (int v = 0; v < 3; v++) {
+    float mx = std::fabs(A[v][v]);
+    int maxr = v;
+    for (int i = v + 1; i < 3; i++) {
+      float q = std::fabs(A[i][v]);
+      if (q > mx) { mx = q; maxr = i; }
+    }
+    if (!mx) break;
+    if (maxr != v)
+      for (int j = 0; j < 3; j++) { std::swap(A[v][j], A[maxr][j]); std::swap(B[v][j], B[maxr][j]); }
+    float x = 1.0f / A[v][v];
+    A[v][v] = 1;
+    for (int j = v + 1; j < 3; j++) A[v][j] *= x;
+    for (int j = 0; j < 3; j++) B[v][j] *= x;
+    for (int i = 0; i < 3; i++) {
+      if (i == v) continue;
+      float c = -A[i][v];
+      A[i][v] = 0;
+      for (int j = v + 1; j < 3; j++) A[i][j] = std::fma(c, A[v][j], A[i][j]);
+      for (int j = 0; j < 3; j++) B[i][j] = std::fma(c, B[v][j], B[i][j]);
+    }
+  }
+  memcpy(out, B, sizeof(B));
+}
+
+}  // namespace daliamd
+
+extern "C" {
+
+using namespace daliamd;
+
+daliamdResult_t daliamdWarpAffineSetup(daliamdWarpAffineDesc *descs, int n, int *num_workgroups) {
+  DALIAMD_REQUIRE(descs && num_workgroups && n >= 0, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdWarpAffineSetup: NULL argument");
+  int wg = 0;
+  for (int i = 0; i < n; i++) {
+    auto &d = descs[i];
+    DALIAMD_REQUIRE(d.in_h > 0 && d.in_w > 0 && d.out_h > 0 && d.out_w > 0, DALIAMD_ERROR_INVALID_ARGUMENT,
+                    "daliamdWarpAffineSetup: sample %d has an empty input or output", i);
+    DALIAMD_REQUIRE(d.channels >= 1 && d.channels <= 4, DALIAMD_ERROR_UNSUPPORTED,
+                    "daliamdWarpAffineSetup: sample %d: %d channels (supported: 1..4)", i, d.channels);
+    DALIAMD_REQUIRE(d.interp == DALIAMD_INTERP_NN || d.interp == DALIAMD_INTERP_LINEAR, DALIAMD_ERROR_UNSUPPORTED,
+                    "daliamdWarpAffineSetup: only nearest and linear interpolation are supported");
+    d.wg_start = wg;
+    wg += ((d.out_w + kWarpTileW - 1) / kWarpTileW) * ((d.out_h + kWarpRows - 1) / kWarpRows);
+  }
+  *num_workgroups = wg;
+  return DALIAMD_SUCCESS;
+}
+
+daliamdResult_t daliamdWarpAffineRun(daliamdStream_t stream, const daliamdWarpAffineDesc *descs_dev, int n, int nwg) {
+  if (n == 0 || nwg == 0) return DALIAMD_SUCCESS;
+  DALIAMD_REQUIRE(descs_dev && n > 0 && nwg > 0, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdWarpAffineRun: invalid argument");
+  hipLaunchKernelGGL(WarpAffineKernel, dim3(XcdGrid(nwg)), dim3(kWarpThreads), 0, (hipStream_t)stream, descs_dev, n, nwg);
+  DALIAMD_HIP_CHECK(hipGetLastError());
+  return DALIAMD_SUCCESS;
+}
+
+int daliamdGaussianWindow(float sigma, int window_size, float *window, float *sigma_used) {
+  if (sigma < 0 || window_size < 0) { SetLastError("sigma and window_size must be non-negative"); return -1; }
+  if (sigma == 0 && window_size == 0) { SetLastError("`sigma` and `window_size` shouldn't be 0 at the same time"); return -1; }
+  if (window_size == 0) window_size = 2 * (int)ceilf(sigma * 3) + 1;
+  else if (sigma == 0) { int radius = (window_size - 1) / 2; sigma = (float)((radius - 1) * 0.3 + 0.8); }
+  if ((window_size & 1) == 0) { SetLastError("Kernel window should have odd length, got: %d", window_size); return -1; }
+  if (window_size > DALIAMD_MAX_BLUR_WINDOW) {
+    SetLastError("Gaussian window of %d taps exceeds the supported maximum of %d", window_size, DALIAMD_MAX_BLUR_WINDOW);
+    return -1;
+  }
+  int r = (window_size - 1) / 2;
+  float exp_scale = 0.5f / (sigma * sigma);
+  float sum = 0.f;
+  for (int x = -r; x < 0; x++) {
+    window[x + r] = (float)exp((double)(-(x * x * exp_scale)));
+    sum += window[x + r];
+  }
+  sum *= 2.;
+  sum += 1.0;
+  float scale = 1.f / sum;
+  window[r] = scale;
+  for (int x = 0; x < r; x++) {
+    window[x] *= scale;
+    window[2 * r - x] = window[x];
+  }
+  if (sigma_used) *sigma_used = sigma;
+  return window_size;
+}
+
+daliamdResult_t daliamdGaussianBlurSetup(daliamdGaussianBlurDesc *descs, int n, int *num_workgroups, int *lds_bytes) {
+  DALIAMD_REQUIRE(descs && num_workgroups && lds_bytes && n >= 0, DALIAMD_ERROR_INVALID_ARGUMENT,
+                  "daliamdGaussianBlurSetup: NULL argument");
+  int wg = 0, lds = 0;
+  for (int i = 0; i < n; i++) {
+    auto &d = descs[i];
+    DALIAMD_REQUIRE(d.h > 0 && d.w > 0 && d.channels >= 1 && d.channels <= 4, DALIAMD_ERROR_INVALID_ARGUMENT,
+                    "daliamdGaussianBlurSetup: sample %d has an invalid shape", i);
+    DALIAMD_REQUIRE((d.size_x & 1) && (d.size_y & 1) && d.size_x <= DALIAMD_MAX_BLUR_WINDOW &&
+                    d.size_y <= DALIAMD_MAX_BLUR_WINDOW && d.size_x > 0 && d.size_y > 0, DALIAMD_ERROR_UNSUPPORTED,
+                    "daliamdGaussianBlurSetup: sample %d: window sizes must be odd and <= %d", i, DALIAMD_MAX_BLUR_WINDOW);
+    int tw = 64, th = 16;
+    auto need = [&](int tw_, int th_) {
+      size_t rows = th_ + d.size_y - 1, cols = tw_ + d.size_x - 1;
+      size_t src_pitch = (cols * d.channels + 3) & ~(size_t)3;
+      return (size_t)(d.size_x + d.size_y) * 4 + rows * tw_ * d.channels * 4 + rows * src_pitch + 16;
+    };
+    while (need(tw, th) > (size_t)kBlurMaxLds && (tw > 8 || th > 1)) {
+      if (th > 1 && (th + d.size_y >= tw + d.size_x || tw <= 8)) th >>= 1; else tw >>= 1;
+    }
+    DALIAMD_REQUIRE(need(tw, th) <= (size_t)kBlurMaxLds, DALIAMD_ERROR_UNSUPPORTED,
+                    "daliamdGaussianBlurSetup: sample %d needs more LDS than available", i);
+    d.tile_w = tw; d.tile_h = th;
+    d.tiles_x = (d.w + tw - 1) / tw;
+    d.lds_bytes = (int)need(tw, th);
+    d.wg_start = wg;
+    wg += d.tiles_x * ((d.h + th - 1) / th);
+    lds = lds > d.lds_bytes ? lds : d.lds_bytes;
+  }
+  *num_workgroups = wg;
+  *lds_bytes = lds;
+  return DALIAMD_SUCCESS;
+}
+
+daliamdResult_t daliamdGaussianBlurRun(daliamdStream_t stream, const daliamdGaussianBlurDesc *descs_dev, int n, int nwg,
+                                       int lds_bytes) {
+  if (n == 0 || nwg == 0) return DALIAMD_SUCCESS;
+  DALIAMD_REQUIRE(descs_dev && n > 0 && nwg > 0 && lds_bytes >= 0 && lds_bytes <= kBlurMaxLds,
+                  DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdGaussianBlurRun: invalid argument");
+  hipLaunchKernelGGL(GaussianBlurKernel, dim3(XcdGrid(nwg)), dim3(kBlurThreads), lds_bytes, (hipStream_t)stream,
+                     descs_dev, n, nwg);
+  DALIAMD_HIP_CHECK(hipGetLastError());
+  return DALIAMD_SUCCESS;
+}
+
+void daliamdColorTwistMatrix(float hue, float saturation, float value, float brightness, float contrast, float *matrix,
+                             float *offset) {
+  const float rgb2yiq[9] = {.299f, .587f, .114f, .596f, -.274f, -.321f, .211f, -.523f, .311f};
+  float yiq2rgb[9];
+  Mat3Inverse(rgb2yiq, yiq2rgb);
+  const float h_rad = (float)(hue * M_PI / 180);
+  float hm[9], sm[9], t[9], dgl[9];
+  Mat3Diag(1, hm);
+  hm[4] = (float)cos((double)h_rad); hm[8] = (float)cos((double)h_rad);
+  hm[5] = (float)sin((double)h_rad); hm[7] = (float)-sin((double)h_rad);
+  Mat3Diag(1, sm);
+  sm[4] = saturation; sm[8] = saturation;
+  Mat3Diag(brightness, t);
+  Mat3Diag(contrast, dgl);
+  Mat3Mul(t, dgl, t);
+  Mat3Mul(t, yiq2rgb, t);
+  Mat3Mul(t, hm, t);
+  Mat3Mul(t, sm, t);
+  Mat3Diag(value, dgl);
+  Mat3Mul(t, dgl, t);
+  Mat3Mul(t, rgb2yiq, t);
+  memcpy(matrix, t, sizeof(t));
+  const float half_range = 128.f;
+  *offset = (half_range - half_range * contrast) * brightness;
+}
+
+daliamdResult_t daliamdPointwiseSetup(daliamdPointwiseDesc *descs, int n, int *num_workgroups) {
+  DALIAMD_REQUIRE(descs && num_workgroups && n >= 0, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdPointwiseSetup: NULL argument");
+  int wg = 0;
+  for (int i = 0; i < n; i++) {
+    auto &d = descs[i];
+    DALIAMD_REQUIRE(d.h >= 0 && d.w >= 0 && d.channels >= 1 && d.channels <= 4, DALIAMD_ERROR_INVALID_ARGUMENT,
+                    "daliamdPointwiseSetup: sample %d has an invalid shape", i);
+    DALIAMD_REQUIRE(!d.transform || d.channels == 3, DALIAMD_ERROR_UNSUPPORTED,
+                    "daliamdPointwiseSetup: the colour transform needs 3-channel input, sample %d has %d", i, d.channels);
+    DALIAMD_REQUIRE(d.num_regions >= 0 && d.num_regions <= DALIAMD_MAX_ERASE_REGIONS, DALIAMD_ERROR_UNSUPPORTED,
+                    "daliamdPointwiseSetup: sample %d: at most %d erase regions are supported", i, DALIAMD_MAX_ERASE_REGIONS);
+    d.wg_start = wg;
+    long long groups = (long long)((d.w + kPwPx - 1) / kPwPx) * d.h;
+    wg += (int)((groups + kPwThreads - 1) / kPwThreads);
+  }
+  *num_workgroups = wg;
+  return DALIAMD_SUCCESS;
+}
+
+daliamdResult_t daliamdPointwiseRun(daliamdStream_t stream, const daliamdPointwiseDesc *descs_dev, int n, int nwg) {
+  if (n == 0 || nwg == 0) return DALIAMD_SUCCESS;
+  DALIAMD_REQUIRE(descs_dev && n > 0 && nwg > 0, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdPointwiseRun: invalid argument");
+  hipLaunchKernelGGL(PointwiseKernel, dim3(XcdGrid(nwg)), dim3(kPwThreads), 0, (hipStream_t)stream, descs_dev, n, nwg);
+  DALIAMD_HIP_CHECK(hipGetLastError());
+  return DALIAMD_SUCCESS;
+}
+
+}  // extern "C"

@@ -439,6 +439,33 @@ std::vector<int> GetPerSampleInt(const OpSpec &spec, const Workspace &ws, const 
   return out;
 }
 
+std::vector<std::vector<float>> GetPerSampleFloatVec(const OpSpec &spec, const Workspace &ws, const std::string &name,
+                                                     int n) {
+  std::vector<std::vector<float>> out(n);
+  if (spec.HasTensorArgument(name)) {
+    const TensorList &t = ws.ArgumentInput(name);
+    DALI_ENFORCE(t.num_samples() == n, "Argument input \"", name, "\" has ", t.num_samples(), " samples, expected ", n);
+    for (int i = 0; i < n; i++) {
+      int64_t cnt = volume(t.shape(i));
+      out[i].resize(cnt);
+      for (int64_t k = 0; k < cnt; k++) {
+        switch (t.type()) {
+          case DALI_FLOAT: out[i][k] = static_cast<const float *>(t.raw(i))[k]; break;
+          case DALI_FLOAT64: out[i][k] = (float)static_cast<const double *>(t.raw(i))[k]; break;
+          case DALI_INT32: out[i][k] = (float)static_cast<const int32_t *>(t.raw(i))[k]; break;
+          case DALI_INT64: out[i][k] = (float)static_cast<const int64_t *>(t.raw(i))[k]; break;
+          default: DALI_FAIL("Unsupported type ", TypeName(t.type()), " for argument input \"", name, "\"");
+        }
+      }
+    }
+  } else {
+    std::vector<float> v;
+    for (double f : spec.GetFloatVec(name)) v.push_back((float)f);
+    for (auto &o : out) o = v;
+  }
+  return out;
+}
+
 // ------------------------------------------------------------------------------------------ DescUploader
 void *DescUploader::Upload(const void *host, size_t bytes, daliamdStream_t stream) {
   Slot &s = slots_[next_];

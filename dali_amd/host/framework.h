@@ -370,6 +370,9 @@ struct OpRegisterer {
 // (ArgValue<T>, dali/pipeline/operator/arg_helper.h)
 std::vector<float> GetPerSampleFloat(const OpSpec &spec, const Workspace &ws, const std::string &name, int nsamples);
 std::vector<int> GetPerSampleInt(const OpSpec &spec, const Workspace &ws, const std::string &name, int nsamples);
+// vector-valued argument: per-sample tensors (any length) or one broadcast list
+std::vector<std::vector<float>> GetPerSampleFloatVec(const OpSpec &spec, const Workspace &ws, const std::string &name,
+                                                     int nsamples);
 
 // Pinned staging + asynchronous upload of descriptor tables, shared by device operators.
 class DescUploader {

@@ -1,0 +1,352 @@
+// Heavy-augmentation operators (BASELINE.json configs[2]), host side; arithmetic in libdali_amd_kernels.so.
+//   WarpAffine    dali/operators/image/remap/warp_affine.cc:19-57, warp_affine_params.h:44-78, warp_attr.cc:20-43
+//   GaussianBlur  dali/operators/image/convolution/gaussian_blur.cc:33-73, gaussian_blur_params.h:27-83
+//   ColorTwist    dali/operators/image/color/color_twist.{h,cc}
+//   Erase         dali/operators/generic/erase/erase.cc:29-160, erase_utils.h:52-165
+#include <cmath>
+
+#include "ops.h"
+#include "pipeline.h"
+
+namespace daliamd_host {
+
+enum { DALI_INTERP_NN = 0, DALI_INTERP_LINEAR = 1 };
+
+static void CheckU8Hwc(const TensorList &in, const char *op) {
+  DALI_ENFORCE(in.type() == DALI_UINT8, op, " (gpu): only uint8 input is supported, got ", TypeName(in.type()));
+  for (int i = 0; i < in.num_samples(); i++)
+    DALI_ENFORCE(in.shape(i).size() == 3, op, " expects three-dimensional HWC input");
+}
+static int InPitch(const TensorList &in, int i) {
+  return (int)(in.row_pitch(i) ? in.row_pitch(i) : in.shape(i)[1] * in.shape(i)[2]);
+}
+static void CheckOutDtype(const OpSpec &spec, const char *op) {
+  if (const ArgValue *d = spec.TryArg("dtype"))
+    DALI_ENFORCE(d->i == DALI_UINT8, op, ": output dtype must equal the input type (uint8) in this build");
+}
+
+// =============================================================================================
+DALI_SCHEMA(WarpAffine)
+    .DocStr("Applies an affine transformation to the images.\n\nThe matrix maps destination to source coordinates "
+            "(``inverse_map=True``, the default) in (x, y) order with pixel centres at half-integers.")
+    .NumInput(1)
+    .NumOutput(1)
+    .AddOptionalTypeArg("matrix", "Transform matrix: 6 values, rows of a 2x3 matrix.", ArgType::FLOAT_VEC, true)
+    .AddOptionalArg("inverse_map", "Set to False if the given transform is a destination to source mapping... "
+                    "(True: matrix maps destination to source).", ArgValue::Bool(true))
+    .AddOptionalTypeArg("size", "Output size, in pixels (H, W).", ArgType::FLOAT_VEC, true)
+    .AddOptionalTypeArg("fill_value", "Value used to fill areas that are outside the source image. If not specified, "
+                        "the source coordinates are clamped (border pixels are repeated).", ArgType::FLOAT)
+    .AddOptionalArg("interp_type", "Type of interpolation used (INTERP_NN or INTERP_LINEAR).", ArgValue::Int(DALI_INTERP_LINEAR))
+    .AddOptionalTypeArg("dtype", "Output data type (same as input).", ArgType::INT)
+    .InputLayout(0, {"HWC"});
+
+class WarpAffineGpu : public OperatorBase {
+ public:
+  explicit WarpAffineGpu(const OpSpec &spec) : OperatorBase(spec) {
+    CheckOutDtype(spec, "WarpAffine");
+    int64_t it = spec.GetInt("interp_type");
+    DALI_ENFORCE(it == DALI_INTERP_NN || it == DALI_INTERP_LINEAR, "WarpAffine supports INTERP_NN and INTERP_LINEAR, got ", it);
+    interp_ = it == DALI_INTERP_NN ? DALIAMD_INTERP_NN : DALIAMD_INTERP_LINEAR;
+    invert_ = !spec.GetBool("inverse_map");
+    has_fill_ = spec.TryArg("fill_value") != nullptr;
+    if (has_fill_) fill_ = (float)spec.GetFloat("fill_value");
+    DALI_ENFORCE(spec.ArgumentDefined("matrix"), "`matrix` argument must be provided");
+  }
+  bool SetupImpl(std::vector<OutputDesc> &desc, const Workspace &ws) override {
+    const TensorList &in = ws.Input(0);
+    CheckU8Hwc(in, "WarpAffine");
+    int n = in.num_samples();
+    auto mats = GetPerSampleFloatVec(spec_, ws, "matrix", n);
+    std::vector<std::vector<float>> sizes;
+    if (spec_.ArgumentDefined("size")) sizes = GetPerSampleFloatVec(spec_, ws, "size", n);
+    descs_.assign(n, daliamdWarpAffineDesc{});
+    desc[0].type = DALI_UINT8;
+    desc[0].shape.resize(n);
+    for (int i = 0; i < n; i++) {
+      DALI_ENFORCE(mats[i].size() == 6, "`matrix` parameter must have 6 elements, got ", mats[i].size());
+      auto &d = descs_[i];
+      const TensorShape &s = in.shape(i);
+      d.in = static_cast<const uint8_t *>(in.raw(i));
+      d.in_h = (int)s[0]; d.in_w = (int)s[1]; d.channels = (int)s[2]; d.in_pitch = InPitch(in, i);
+      d.out_h = d.in_h; d.out_w = d.in_w;
+      if (!sizes.empty()) {
+        DALI_ENFORCE(sizes[i].size() == 2, "`size` must hold (H, W)");
+        d.out_h = (int)sizes[i][0]; d.out_w = (int)sizes[i][1];
+        DALI_ENFORCE(d.out_h > 0 && d.out_w > 0, "`size` must be positive");
+      }
+      d.out_pitch = d.out_w * d.channels;
+      const float *m = mats[i].data();
+      if (invert_) {
+        // affine_mat_inv (include/dali/core/geom/transform.h:166-174; 2x2 inverse mat.h:610-622)
+        float det = m[0] * m[4] - m[1] * m[3];
+        DALI_ENFORCE(det != 0, "Cannot calculate the inverse of a singular matrix.");
+        float i00 = m[4] / det, i01 = -m[1] / det, i10 = -m[3] / det, i11 = m[0] / det;
+        float t0 = (-i00) * m[2]; t0 += (-i01) * m[5];
+        float t1 = (-i10) * m[2]; t1 += (-i11) * m[5];
+        float inv[6] = {i00, i01, t0, i10, i11, t1};
+        memcpy(d.matrix, inv, sizeof(inv));
+      } else {
+        memcpy(d.matrix, m, 6 * sizeof(float));
+      }
+      d.interp = interp_;
+      d.border_clamp = !has_fill_;
+      for (int c = 0; c < 4; c++) d.fill[c] = fill_;
+      desc[0].shape[i] = {d.out_h, d.out_w, d.channels};
+    }
+    return true;
+  }
+  void RunImpl(Workspace &ws) override {
+    TensorList &out = ws.Output(0);
+    out.SetLayout("HWC");
+    int n = (int)descs_.size();
+    if (!n) return;
+    for (int i = 0; i < n; i++) descs_[i].out = static_cast<uint8_t *>(out.raw(i));
+    int nwg = 0;
+    KCHECK(daliamdWarpAffineSetup(descs_.data(), n, &nwg));
+    auto *dev = static_cast<const daliamdWarpAffineDesc *>(uploader_.Upload(descs_.data(), n * sizeof(descs_[0]), ws.stream));
+    KCHECK(daliamdWarpAffineRun(ws.stream, dev, n, nwg));
+    NoteLaunch(ws, "warp_affine");
+  }
+
+ private:
+  int interp_;
+  bool invert_, has_fill_;
+  float fill_ = 0;
+  std::vector<daliamdWarpAffineDesc> descs_;
+  DescUploader uploader_;
+};
+DALI_REGISTER_OPERATOR(WarpAffine, WarpAffineGpu, GPU);
+
+// =============================================================================================
+DALI_SCHEMA(GaussianBlur)
+    .DocStr("Applies a Gaussian Blur to the input.\n\nGaussian blur is calculated by applying a convolution with a Gaussian "
+            "kernel, parameterized with ``window_size`` and ``sigma``. If only the sigma is specified, the window size is "
+            "``2 * ceil(3 * sigma) + 1``; if only the window size is provided, "
+            "``sigma = ((window_size - 1) / 2 - 1) * 0.3 + 0.8``. Values can be given per axis in (H, W) order.")
+    .NumInput(1)
+    .NumOutput(1)
+    .AddOptionalArg("sigma", "Sigma value for the Gaussian Kernel.", ArgValue::FloatVec({0.0}), true)
+    .AddOptionalArg("window_size", "The diameter of the kernel.", ArgValue::IntVec({0}), true)
+    .AddOptionalTypeArg("dtype", "Output data type (same as input).", ArgType::INT)
+    .InputLayout(0, {"HWC"});
+
+class GaussianBlurGpu : public OperatorBase {
+ public:
+  explicit GaussianBlurGpu(const OpSpec &spec) : OperatorBase(spec) { CheckOutDtype(spec, "GaussianBlur"); }
+  bool SetupImpl(std::vector<OutputDesc> &desc, const Workspace &ws) override {
+    const TensorList &in = ws.Input(0);
+    CheckU8Hwc(in, "GaussianBlur");
+    int n = in.num_samples();
+    auto sig = GetPerSampleFloatVec(spec_, ws, "sigma", n);
+    auto win = GetPerSampleFloatVec(spec_, ws, "window_size", n);
+    descs_.assign(n, daliamdGaussianBlurDesc{});
+    desc[0].type = DALI_UINT8;
+    desc[0].shape.resize(n);
+    for (int i = 0; i < n; i++) {
+      auto &d = descs_[i];
+      const TensorShape &s = in.shape(i);
+      d.in = static_cast<const uint8_t *>(in.raw(i));
+      d.h = (int)s[0]; d.w = (int)s[1]; d.channels = (int)s[2]; d.in_pitch = InPitch(in, i);
+      d.out_pitch = d.w * d.channels;
+      DALI_ENFORCE((sig[i].size() == 1 || sig[i].size() == 2) && (win[i].size() == 1 || win[i].size() == 2),
+                   "`sigma` and `window_size` take one value or one value per axis (H, W)");
+      // per-axis values are given in layout order (H, W); window_x is the W axis
+      float sy = sig[i][0], sx = sig[i].back();
+      int wy = (int)win[i][0], wx = (int)win[i].back();
+      int dx = daliamdGaussianWindow(sx, wx, d.window_x, nullptr);
+      DALI_ENFORCE(dx > 0, daliamdGetLastErrorMessage());
+      int dy = daliamdGaussianWindow(sy, wy, d.window_y, nullptr);
+      DALI_ENFORCE(dy > 0, daliamdGetLastErrorMessage());
+      d.size_x = dx; d.size_y = dy;
+      desc[0].shape[i] = s;
+    }
+    return true;
+  }
+  void RunImpl(Workspace &ws) override {
+    TensorList &out = ws.Output(0);
+    out.SetLayout("HWC");
+    int n = (int)descs_.size();
+    if (!n) return;
+    for (int i = 0; i < n; i++) descs_[i].out = static_cast<uint8_t *>(out.raw(i));
+    int nwg = 0, lds = 0;
+    KCHECK(daliamdGaussianBlurSetup(descs_.data(), n, &nwg, &lds));
+    auto *dev = static_cast<const daliamdGaussianBlurDesc *>(uploader_.Upload(descs_.data(), n * sizeof(descs_[0]), ws.stream));
+    KCHECK(daliamdGaussianBlurRun(ws.stream, dev, n, nwg, lds));
+    NoteLaunch(ws, "gaussian_blur");
+  }
+
+ private:
+  std::vector<daliamdGaussianBlurDesc> descs_;
+  DescUploader uploader_;
+};
+DALI_REGISTER_OPERATOR(GaussianBlur, GaussianBlurGpu, GPU);
+
+// =============================================================================================
+// ColorTwist and Erase share the pointwise kernel
+// =============================================================================================
+static void FillPointwiseCommon(daliamdPointwiseDesc &d, const TensorList &in, int i) {
+  const TensorShape &s = in.shape(i);
+  d.in = static_cast<const uint8_t *>(in.raw(i));
+  d.h = (int)s[0]; d.w = (int)s[1]; d.channels = (int)s[2]; d.in_pitch = InPitch(in, i);
+  d.out_pitch = d.w * d.channels;
+}
+static void LaunchPointwise(Workspace &ws, DescUploader &up, std::vector<daliamdPointwiseDesc> &descs, const char *what) {
+  TensorList &out = ws.Output(0);
+  out.SetLayout("HWC");
+  int n = (int)descs.size();
+  if (!n) return;
+  for (int i = 0; i < n; i++) descs[i].out = static_cast<uint8_t *>(out.raw(i));
+  int nwg = 0;
+  KCHECK(daliamdPointwiseSetup(descs.data(), n, &nwg));
+  auto *dev = static_cast<const daliamdPointwiseDesc *>(up.Upload(descs.data(), n * sizeof(descs[0]), ws.stream));
+  KCHECK(daliamdPointwiseRun(ws.stream, dev, n, nwg));
+  NoteLaunch(ws, what);
+}
+
+DALI_SCHEMA(ColorTwist)
+    .DocStr("Adjusts hue, saturation, value, brightness and contrast of the image.\n\n"
+            "The transformation is the matrix ``B * C * Yiq2Rgb * Hue(h) * Sat(s) * V * Rgb2Yiq`` applied per pixel, plus the "
+            "offset ``(128 - 128 * contrast) * brightness``.")
+    .NumInput(1)
+    .NumOutput(1)
+    .AddOptionalArg("hue", "Hue delta, in degrees.", ArgValue::Float(0.0), true)
+    .AddOptionalArg("saturation", "The saturation multiplier.", ArgValue::Float(1.0), true)
+    .AddOptionalArg("value", "The value multiplier.", ArgValue::Float(1.0), true)
+    .AddOptionalArg("brightness", "Brightness change factor.", ArgValue::Float(1.0), true)
+    .AddOptionalArg("contrast", "Contrast change factor.", ArgValue::Float(1.0), true)
+    .AddOptionalTypeArg("dtype", "Output data type (same as input).", ArgType::INT)
+    .InputLayout(0, {"HWC"});
+
+class ColorTwistGpu : public OperatorBase {
+ public:
+  explicit ColorTwistGpu(const OpSpec &spec) : OperatorBase(spec) { CheckOutDtype(spec, "ColorTwist"); }
+  bool SetupImpl(std::vector<OutputDesc> &desc, const Workspace &ws) override {
+    const TensorList &in = ws.Input(0);
+    CheckU8Hwc(in, "ColorTwist");
+    int n = in.num_samples();
+    auto hue = GetPerSampleFloat(spec_, ws, "hue", n), sat = GetPerSampleFloat(spec_, ws, "saturation", n),
+         val = GetPerSampleFloat(spec_, ws, "value", n), bri = GetPerSampleFloat(spec_, ws, "brightness", n),
+         con = GetPerSampleFloat(spec_, ws, "contrast", n);
+    descs_.assign(n, daliamdPointwiseDesc{});
+    desc[0].type = DALI_UINT8;
+    desc[0].shape.resize(n);
+    for (int i = 0; i < n; i++) {
+      auto &d = descs_[i];
+      FillPointwiseCommon(d, in, i);
+      DALI_ENFORCE(d.channels == 3, "ColorTwist expects 3-channel (RGB) input, got ", d.channels, " channels");
+      d.transform = 1;
+      float off;
+      daliamdColorTwistMatrix(hue[i], sat[i], val[i], bri[i], con[i], d.matrix, &off);
+      d.offset[0] = d.offset[1] = d.offset[2] = off;
+      desc[0].shape[i] = in.shape(i);
+    }
+    return true;
+  }
+  void RunImpl(Workspace &ws) override { LaunchPointwise(ws, uploader_, descs_, "color_twist"); }
+
+ private:
+  std::vector<daliamdPointwiseDesc> descs_;
+  DescUploader uploader_;
+};
+DALI_REGISTER_OPERATOR(ColorTwist, ColorTwistGpu, GPU);
+
+DALI_SCHEMA(Erase)
+    .DocStr("Erases one or more regions from the input tensors.\n\nThe region is specified by ``anchor`` (starting point) and "
+            "``shape`` (dimensions) given for the (H, W) axes; several regions can be given as multiples of the number of axes.")
+    .NumInput(1)
+    .NumOutput(1)
+    .AddOptionalArg("anchor", "Coordinates for the anchor or the starting point of the erase region.", ArgValue::FloatVec({}), true)
+    .AddOptionalArg("shape", "Values for shape or dimensions of the erase region.", ArgValue::FloatVec({}), true)
+    .AddOptionalTypeArg("axes", "Order of dimensions used for anchor and shape, as dimension indices.", ArgType::INT_VEC)
+    .AddOptionalTypeArg("axis_names", "Order of dimensions used for anchor and shape, as layout names (default \"HW\").",
+                        ArgType::STRING)
+    .AddOptionalArg("fill_value", "Value to fill the erased region (one value or one per channel).", ArgValue::FloatVec({0.0}), true)
+    .AddOptionalArg("normalized_anchor", "Whether the anchor is given in normalized coordinates.", ArgValue::Bool(false))
+    .AddOptionalArg("normalized_shape", "Whether the shape is given in normalized coordinates.", ArgValue::Bool(false))
+    .AddOptionalTypeArg("normalized", "Whether anchor and shape are given in normalized coordinates.", ArgType::BOOL)
+    .AddOptionalArg("centered_anchor", "If True, the anchors refer to the center of the region.", ArgValue::Bool(false))
+    .InputLayout(0, {"HWC"});
+
+class EraseGpu : public OperatorBase {
+ public:
+  explicit EraseGpu(const OpSpec &spec) : OperatorBase(spec) {
+    norm_anchor_ = spec.GetBool("normalized_anchor");
+    norm_shape_ = spec.GetBool("normalized_shape");
+    if (spec.TryArg("normalized")) {
+      DALI_ENFORCE(!spec.Args().count("normalized_anchor") && !spec.Args().count("normalized_shape"),
+                   "`normalized` argument is incompatible with providing a separate value for `normalized_anchor` and "
+                   "`normalized_shape`");
+      norm_anchor_ = norm_shape_ = spec.GetBool("normalized");
+    }
+    centered_ = spec.GetBool("centered_anchor");
+    // axes: indices into HWC, or names; default = all but C, i.e. (H, W)
+    axes_ = {0, 1};
+    if (spec.TryArg("axis_names")) {
+      std::string names = spec.GetString("axis_names");
+      axes_.clear();
+      for (char ch : names) {
+        DALI_ENFORCE(ch == 'H' || ch == 'W', "Erase (gpu) supports the H and W axes, got '", std::string(1, ch), "'");
+        axes_.push_back(ch == 'H' ? 0 : 1);
+      }
+    } else if (spec.TryArg("axes")) {
+      axes_.clear();
+      for (auto a : spec.GetIntVec("axes")) {
+        DALI_ENFORCE(a == 0 || a == 1, "Erase (gpu) supports axes 0 (H) and 1 (W), got ", a);
+        axes_.push_back((int)a);
+      }
+    }
+    DALI_ENFORCE(!axes_.empty(), "At least one axis is required");
+  }
+  bool SetupImpl(std::vector<OutputDesc> &desc, const Workspace &ws) override {
+    const TensorList &in = ws.Input(0);
+    CheckU8Hwc(in, "Erase");
+    int n = in.num_samples();
+    auto anchors = GetPerSampleFloatVec(spec_, ws, "anchor", n), shapes = GetPerSampleFloatVec(spec_, ws, "shape", n);
+    auto fills = GetPerSampleFloatVec(spec_, ws, "fill_value", n);
+    descs_.assign(n, daliamdPointwiseDesc{});
+    desc[0].type = DALI_UINT8;
+    desc[0].shape.resize(n);
+    int naxes = (int)axes_.size();
+    for (int i = 0; i < n; i++) {
+      auto &d = descs_[i];
+      FillPointwiseCommon(d, in, i);
+      auto a = anchors[i], s = shapes[i];
+      if (a.empty() && !s.empty()) a.assign(s.size(), 0.0f);
+      DALI_ENFORCE(a.size() == s.size(), "`anchor` and `shape` must have the same number of elements");
+      DALI_ENFORCE(s.size() % naxes == 0, "The number of `anchor`/`shape` values must be a multiple of the number of axes");
+      int nregions = (int)s.size() / naxes;
+      DALI_ENFORCE(nregions <= DALIAMD_MAX_ERASE_REGIONS, "At most ", DALIAMD_MAX_ERASE_REGIONS, " regions are supported");
+      d.num_regions = nregions;
+      int dims[2] = {d.h, d.w};
+      for (int r = 0, k = 0; r < nregions; r++) {
+        int64_t lo[2] = {0, 0}, hi[2] = {d.h, d.w};
+        for (int j = 0; j < naxes; j++, k++) {
+          int axis = axes_[j];
+          float anchor_val = norm_anchor_ ? a[k] * dims[axis] : a[k];
+          float shape_val = norm_shape_ ? s[k] * dims[axis] : s[k];
+          if (centered_) anchor_val -= shape_val / 2;
+          lo[axis] = (int64_t)anchor_val;
+          hi[axis] = (int64_t)(anchor_val + shape_val);
+        }
+        d.region[r][0] = (int)std::max<int64_t>(0, lo[0]); d.region[r][1] = (int)std::max<int64_t>(0, lo[1]);
+        d.region[r][2] = (int)std::min<int64_t>(d.h, hi[0]); d.region[r][3] = (int)std::min<int64_t>(d.w, hi[1]);
+      }
+      const auto &f = fills[i];
+      DALI_ENFORCE(f.size() == 1 || (int)f.size() == d.channels, "`fill_value` must hold one value or one per channel");
+      for (int c = 0; c < 4; c++) d.fill[c] = f.size() == 1 ? f[0] : (c < (int)f.size() ? f[c] : 0.0f);
+      desc[0].shape[i] = in.shape(i);
+    }
+    return true;
+  }
+  void RunImpl(Workspace &ws) override { LaunchPointwise(ws, uploader_, descs_, "erase"); }
+
+ private:
+  bool norm_anchor_, norm_shape_, centered_;
+  std::vector<int> axes_;
+  std::vector<daliamdPointwiseDesc> descs_;
+  DescUploader uploader_;
+};
+DALI_REGISTER_OPERATOR(Erase, EraseGpu, GPU);
+
+}  // namespace daliamd_host

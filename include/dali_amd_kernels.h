@@ -209,6 +209,68 @@ DALIAMD_API daliamdResult_t daliamdCmnSetup(daliamdCmnDesc *descs_host, int n, i
 DALIAMD_API daliamdResult_t daliamdCmnRun(daliamdStream_t stream, const daliamdCmnDesc *descs_dev, int n,
                                           int num_workgroups);
 
+/* ----------------------------------------------------------------------------------------------
+ * Heavy-augmentation kernels (BASELINE.json configs[2]): warp_affine, gaussian_blur, color_twist, erase.
+ * u8 HWC in, u8 HWC out; arithmetic follows the reference's CPU kernels operation by operation:
+ *   warp    dali/kernels/imgproc/warp_cpu.h:143-178 + sampler.h:258-338 (incremental source coordinates
+ *           re-anchored every 256 px, bilinear s0 + (s1 - s0) * qy, constant or clamp border)
+ *   blur    dali/kernels/imgproc/convolution/convolution_cpu.h:241-340 (W pass then H pass, float intermediate,
+ *           reflect-101 border, taps accumulated in order)
+ *   twist   dali/kernels/imgproc/pointwise/linear_transformation_cpu.h:57-77 (M * px + offset)
+ *   erase   dali/kernels/erase/erase_cpu.h (copy + fill of clipped regions)
+ * -------------------------------------------------------------------------------------------- */
+typedef struct {
+  const uint8_t *in;
+  uint8_t *out;
+  int32_t in_h, in_w, channels, in_pitch;
+  int32_t out_h, out_w, out_pitch;
+  float matrix[6];      /* row-major 2x3, maps DESTINATION (x, y) to SOURCE (x, y) */
+  int32_t interp;       /* DALIAMD_INTERP_NN or DALIAMD_INTERP_LINEAR */
+  int32_t border_clamp; /* 1: clamp to edge; 0: constant `fill` */
+  float fill[4];
+  int32_t wg_start;     /* filled by Setup */
+  int32_t reserved;
+} daliamdWarpAffineDesc;
+DALIAMD_API daliamdResult_t daliamdWarpAffineSetup(daliamdWarpAffineDesc *descs_host, int n, int *num_workgroups);
+DALIAMD_API daliamdResult_t daliamdWarpAffineRun(daliamdStream_t stream, const daliamdWarpAffineDesc *descs_dev, int n,
+                                                 int num_workgroups);
+
+#define DALIAMD_MAX_BLUR_WINDOW 63
+typedef struct {
+  const uint8_t *in;
+  uint8_t *out;
+  int32_t h, w, channels, in_pitch, out_pitch;
+  int32_t size_x, size_y;                 /* odd window diameters (<= DALIAMD_MAX_BLUR_WINDOW) */
+  float window_x[DALIAMD_MAX_BLUR_WINDOW + 1], window_y[DALIAMD_MAX_BLUR_WINDOW + 1];
+  int32_t tile_w, tile_h, tiles_x, wg_start, lds_bytes;  /* filled by Setup */
+} daliamdGaussianBlurDesc;
+/* host helper: FillGaussian (dali/operators/image/convolution/gaussian_blur_params.h:60-83); returns the diameter
+ * (2*ceil(3*sigma)+1 when window_size == 0; sigma derived from the window when sigma == 0) or < 0 on error */
+DALIAMD_API int daliamdGaussianWindow(float sigma, int window_size, float *window, float *sigma_used);
+DALIAMD_API daliamdResult_t daliamdGaussianBlurSetup(daliamdGaussianBlurDesc *descs_host, int n, int *num_workgroups,
+                                                    int *lds_bytes);
+DALIAMD_API daliamdResult_t daliamdGaussianBlurRun(daliamdStream_t stream, const daliamdGaussianBlurDesc *descs_dev,
+                                                  int n, int num_workgroups, int lds_bytes);
+
+#define DALIAMD_MAX_ERASE_REGIONS 8
+typedef struct {
+  const uint8_t *in;
+  uint8_t *out;
+  int32_t h, w, channels, in_pitch, out_pitch;
+  int32_t transform;    /* 1: out = sat(M * px + offset) (3 channels); 0: copy */
+  float matrix[9], offset[3];
+  int32_t num_regions;  /* rectangles filled after the transform (erase) */
+  int32_t region[DALIAMD_MAX_ERASE_REGIONS][4]; /* y0, x0, y1, x1 (already clipped) */
+  float fill[4];
+  int32_t wg_start;     /* filled by Setup */
+} daliamdPointwiseDesc;
+/* host helper: colour-twist matrix/offset (dali/operators/image/color/color_twist.h:50-83,156-170) */
+DALIAMD_API void daliamdColorTwistMatrix(float hue, float saturation, float value, float brightness, float contrast,
+                                         float *matrix9, float *offset);
+DALIAMD_API daliamdResult_t daliamdPointwiseSetup(daliamdPointwiseDesc *descs_host, int n, int *num_workgroups);
+DALIAMD_API daliamdResult_t daliamdPointwiseRun(daliamdStream_t stream, const daliamdPointwiseDesc *descs_dev, int n,
+                                                int num_workgroups);
+
 #ifdef __cplusplus
 }
 #endif

@@ -233,3 +233,81 @@ def pipeline_batch(jpegs, rrc_seed, flip_seed, iteration, out_hw=(224, 224), mea
     if failed:
         raise RuntimeError(f"{failed} samples failed in the oracle pipeline")
     return out
+
+
+# ---------------------------------------------------------------- heavy augmentation (configs[2])
+def warp_affine_u8(img, matrix, out_hw=None, interp=1, fill=None):
+    """matrix: 2x3 dst->src.  fill=None -> clamp border; else constant border (scalar or per channel)."""
+    img = np.ascontiguousarray(img, np.uint8)
+    H, W, Cn = img.shape
+    oh, ow = out_hw if out_hw is not None else (H, W)
+    out = np.zeros((oh, ow, Cn), np.uint8)
+    m = np.ascontiguousarray(matrix, np.float32).reshape(6)
+    fv = None
+    if fill is not None:
+        fv = np.ascontiguousarray(np.broadcast_to(np.asarray(fill, np.float32), (Cn,)))
+    lib().orc_warp_affine_u8(_p(img, C.c_uint8), H, W, Cn, _p(m, C.c_float), int(oh), int(ow), int(interp),
+                             _p(fv, C.c_float) if fv is not None else None, _p(out, C.c_uint8))
+    return out
+
+
+def affine_inverse(matrix):
+    m = np.ascontiguousarray(matrix, np.float32).reshape(6)
+    out = np.zeros(6, np.float32)
+    lib().orc_affine_inverse_2x3(_p(m, C.c_float), _p(out, C.c_float))
+    return out.reshape(2, 3)
+
+
+def gaussian_window(sigma=0.0, window_size=0):
+    if window_size == 0:
+        window_size = lib().orc_gaussian_diameter(C.c_float(sigma))
+    elif sigma == 0:
+        f = lib().orc_gaussian_sigma_from_diameter
+        f.restype = C.c_float
+        sigma = f(int(window_size))
+    w = np.zeros(window_size, np.float32)
+    lib().orc_gaussian_window(C.c_float(sigma), int(window_size), _p(w, C.c_float))
+    return w
+
+
+def gaussian_blur_u8(img, window_x, window_y=None):
+    img = np.ascontiguousarray(img, np.uint8)
+    H, W, Cn = img.shape
+    wx = np.ascontiguousarray(window_x, np.float32)
+    wy = wx if window_y is None else np.ascontiguousarray(window_y, np.float32)
+    out = np.zeros_like(img)
+    lib().orc_gaussian_blur_u8(_p(img, C.c_uint8), H, W, Cn, _p(wx, C.c_float), wx.size, _p(wy, C.c_float), wy.size,
+                               _p(out, C.c_uint8))
+    return out
+
+
+def color_twist_matrix(hue=0.0, saturation=1.0, value=1.0, brightness=1.0, contrast=1.0):
+    m = np.zeros(9, np.float32)
+    off = C.c_float(0)
+    lib().orc_color_twist_matrix(C.c_float(hue), C.c_float(saturation), C.c_float(value), C.c_float(brightness),
+                                 C.c_float(contrast), _p(m, C.c_float), C.byref(off))
+    return m.reshape(3, 3), np.float32(off.value)
+
+
+def linear_transform_u8(img, matrix, offset):
+    img = np.ascontiguousarray(img, np.uint8)
+    m = np.ascontiguousarray(matrix, np.float32).reshape(9)
+    o = np.ascontiguousarray(np.broadcast_to(np.asarray(offset, np.float32), (3,)))
+    out = np.zeros_like(img)
+    lib().orc_linear_transform_u8(_p(img, C.c_uint8), C.c_int64(img.shape[0] * img.shape[1]), _p(m, C.c_float),
+                                  _p(o, C.c_float), _p(out, C.c_uint8))
+    return out
+
+
+def erase_u8(img, anchors_yx, shapes_yx, fill=(0.0,), normalized_anchor=False, normalized_shape=False,
+             centered_anchor=False):
+    img = np.ascontiguousarray(img, np.uint8)
+    H, W, Cn = img.shape
+    a = np.ascontiguousarray(anchors_yx, np.float32).reshape(-1, 2)
+    s = np.ascontiguousarray(shapes_yx, np.float32).reshape(-1, 2)
+    f = np.ascontiguousarray(fill, np.float32).reshape(-1)
+    out = np.zeros_like(img)
+    flags = (1 if normalized_anchor else 0) | (2 if normalized_shape else 0) | (4 if centered_anchor else 0)
+    lib().orc_erase_u8(_p(img, C.c_uint8), H, W, Cn, _p(a, C.c_float), _p(s, C.c_float), a.shape[0], flags,
+                       _p(f, C.c_float), f.size, _p(out, C.c_uint8))
+    return out

@@ -1,0 +1,114 @@
+"""GPU parity for the heavy-augmentation kernels (BASELINE.json configs[2]) against the oracle: bit-exact
+(the kernels replay the CPU arithmetic order, including the incremental warp coordinates)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests.util import synth_image
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(img):
+    return torch.from_numpy(np.ascontiguousarray(img)).cuda()
+
+
+def _rot_matrix(theta_deg, scale, cx, cy):
+    """dst->src: rotation about the centre combined with a scale."""
+    t = np.deg2rad(theta_deg)
+    c, s = np.cos(t) / scale, np.sin(t) / scale
+    m = np.array([[c, -s, 0], [s, c, 0]], np.float32)
+    m[0, 2] = cx - m[0, 0] * cx - m[0, 1] * cy
+    m[1, 2] = cy - m[1, 0] * cx - m[1, 1] * cy
+    return m
+
+
+@pytest.mark.parametrize("interp", [0, 1])
+@pytest.mark.parametrize("fill", [None, 0.0, (10.0, 200.0, 300.0)])
+def test_warp_affine_matches_oracle(interp, fill):
+    from dali_amd import backend as B
+    rng = np.random.default_rng(1)
+    imgs = [synth_image(rng, h, w) for h, w in [(512, 512), (97, 300), (300, 641)]]
+    mats = [_rot_matrix(rng.uniform(-30, 30), rng.uniform(0.8, 1.2), im.shape[1] / 2, im.shape[0] / 2) for im in imgs]
+    outs = B.warp_affine_batch([_dev(im) for im in imgs], mats, interp=interp, fill_value=fill)
+    for im, m, o in zip(imgs, mats, outs):
+        ref = O.warp_affine_u8(im, m, interp=interp, fill=fill)
+        got = o.cpu().numpy()
+        assert np.array_equal(got, ref), f"{im.shape} interp {interp} fill {fill}: {np.abs(got.astype(int) - ref).max()}"
+
+
+def test_warp_affine_output_size_identity_and_inverse():
+    from dali_amd import backend as B
+    rng = np.random.default_rng(2)
+    im = synth_image(rng, 120, 200)
+    ident = np.array([[1, 0, 0], [0, 1, 0]], np.float32)
+    out = B.warp_affine_batch([_dev(im)], [ident])[0].cpu().numpy()
+    assert np.array_equal(out, im)
+    # output larger than the input, translation, constant border
+    m = np.array([[1, 0, -30.5], [0, 1, -20.25]], np.float32)
+    out = B.warp_affine_batch([_dev(im)], [m], out_size=(200, 700), fill_value=7.0)[0].cpu().numpy()
+    assert np.array_equal(out, O.warp_affine_u8(im, m, out_hw=(200, 700), fill=7.0))
+    # src->dst matrix inverted like `inverse_map=False`
+    fwd = _rot_matrix(20, 1.1, 100, 60)
+    inv = O.affine_inverse(fwd)
+    assert np.allclose(np.vstack([inv, [0, 0, 1]]) @ np.vstack([fwd, [0, 0, 1]]), np.eye(3), atol=1e-5)
+
+
+@pytest.mark.parametrize("sigma,window", [(3.0, 0), (1.0, 0), (0.0, 5), (7.5, 0), (0.8, 11)])
+def test_gaussian_blur_matches_oracle(sigma, window):
+    from dali_amd import backend as B
+    rng = np.random.default_rng(3)
+    imgs = [synth_image(rng, h, w) for h, w in [(512, 512), (33, 70), (5, 9), (130, 257)]]
+    imgs.append(synth_image(rng, 64, 64, 1)[:, :, None])
+    win = O.gaussian_window(sigma, window)
+    assert np.array_equal(B.gaussian_window(sigma, window), win)
+    if sigma == 3.0:
+        assert win.size == 19 and abs(win.sum() - 1) < 1e-6
+    outs = B.gaussian_blur_batch([_dev(im) for im in imgs], sigma=sigma, window_size=window)
+    for im, o in zip(imgs, outs):
+        ref = O.gaussian_blur_u8(im, win)
+        got = o.cpu().numpy()
+        assert np.array_equal(got, ref), f"{im.shape} sigma {sigma}: {np.abs(got.astype(int) - ref).max()}"
+    # sanity against a float64 convolution: within 1 LSB
+    im = imgs[0].astype(np.float64)
+    pad = np.pad(im, ((win.size // 2,) * 2, (win.size // 2,) * 2, (0, 0)), mode="reflect")
+    tmp = sum(pad[:, k:k + im.shape[1]] * win[k] for k in range(win.size))
+    ref64 = sum(tmp[k:k + im.shape[0]] * win[k] for k in range(win.size))
+    assert np.abs(outs[0].cpu().numpy() - ref64).max() <= 1.0
+
+
+def test_color_twist_and_erase_match_oracle():
+    from dali_amd import backend as B
+    rng = np.random.default_rng(4)
+    imgs = [synth_image(rng, h, w) for h, w in [(512, 512), (61, 47), (1, 5)]]
+    params = [(rng.uniform(-30, 30), rng.uniform(.7, 1.3), rng.uniform(.8, 1.2), rng.uniform(.8, 1.2),
+               rng.uniform(.8, 1.2)) for _ in imgs]
+    mats, offs = [], []
+    for p in params:
+        m, off = B.color_twist_matrix(*p)
+        mo, offo = O.color_twist_matrix(*p)
+        assert np.array_equal(m, mo) and off == offo
+        mats.append(m)
+        offs.append(off)
+    outs = B.pointwise_batch([_dev(im) for im in imgs], mats, offs)
+    for im, m, off, o in zip(imgs, mats, offs, outs):
+        assert np.array_equal(o.cpu().numpy(), O.linear_transform_u8(im, m, off))
+    # identity twist is exact
+    m, off = B.color_twist_matrix()
+    out = B.pointwise_batch([_dev(imgs[0])], [m], [off])[0].cpu().numpy()
+    assert np.abs(out.astype(int) - imgs[0]).max() <= 1
+    # erase: normalised anchor/shape like SURVEY 8d (anchor U(0,.7), shape U(.1,.3)), two regions, per-channel fill
+    im = imgs[0]
+    H, W = im.shape[:2]
+    anchors = np.array([[0.1, 0.6], [0.65, 0.05]], np.float32)
+    shapes = np.array([[0.3, 0.25], [0.5, 0.2]], np.float32)
+    ref = O.erase_u8(im, anchors, shapes, fill=(1.0, 2.0, 3.0), normalized_anchor=True, normalized_shape=True)
+    regs = []
+    for a, s in zip(anchors, shapes):
+        ay, ax = np.float32(a[0] * np.float32(H)), np.float32(a[1] * np.float32(W))
+        sy, sx = np.float32(s[0] * np.float32(H)), np.float32(s[1] * np.float32(W))
+        regs.append((int(ay), int(ax), int(np.float32(ay + sy)), int(np.float32(ax + sx))))
+    out = B.pointwise_batch([_dev(im)], regions=[regs], fill=(1.0, 2.0, 3.0))[0].cpu().numpy()
+    assert np.array_equal(out, ref)
+    assert (out != im).any() and (out == im).any()

@@ -174,3 +174,50 @@ def test_iterator_two_shards(jpeg_dir):
         for g in range(2):
             seen2[g] += [int(v) for v in batch[g]["label"].reshape(-1)]
     assert seen2[0] == seen[1] and seen2[1] == seen[0]
+
+
+def test_heavy_augmentation_pipeline_matches_oracle():
+    """configs[2]: warp_affine + gaussian_blur(sigma=3) + color_twist + erase on 512x512 images, random parameters
+    from fn.random.uniform / external_source, compared with the oracle chain bit for bit."""
+    from dali_amd import fn, types
+    from dali_amd.pipeline import Pipeline
+    rng = np.random.default_rng(5)
+    bs = 6
+    imgs = [synth_image(rng, 512, 512) for _ in range(bs)]
+    mats = []
+    for _ in range(bs):
+        t, s = np.deg2rad(rng.uniform(-30, 30)), rng.uniform(0.8, 1.2)
+        c, sn = np.cos(t) / s, np.sin(t) / s
+        m = np.array([[c, -sn, 0], [sn, c, 0]], np.float32)
+        m[0, 2] = 256 - m[0, 0] * 256 - m[0, 1] * 256
+        m[1, 2] = 256 - m[1, 0] * 256 - m[1, 1] * 256
+        mats.append(m.reshape(6))
+    pipe = Pipeline(batch_size=bs, num_threads=2, device_id=0, seed=17, prefetch_queue_depth=1)
+    with pipe:
+        x = fn.external_source(name="images", layout="HWC")
+        m = fn.external_source(name="matrix")
+        hue = fn.random.uniform(range=[-30.0, 30.0], seed=1)
+        sat = fn.random.uniform(range=[0.7, 1.3], seed=2)
+        bri = fn.random.uniform(range=[0.8, 1.2], seed=3)
+        con = fn.random.uniform(range=[0.8, 1.2], seed=4)
+        anchor = fn.random.uniform(range=[0.0, 0.7], shape=[2], seed=5)
+        shape = fn.random.uniform(range=[0.1, 0.3], shape=[2], seed=6)
+        y = fn.warp_affine(x.gpu(), matrix=m, fill_value=0.0, interp_type=types.INTERP_LINEAR)
+        y = fn.gaussian_blur(y, sigma=3.0)
+        y = fn.color_twist(y, hue=hue, saturation=sat, brightness=bri, contrast=con)
+        y = fn.erase(y, anchor=anchor, shape=shape, normalized=True, fill_value=0.0)
+        pipe.set_outputs(y, hue, sat, bri, con, anchor, shape)
+    pipe.build()
+    pipe.feed_input("images", imgs, layout="HWC")
+    pipe.feed_input("matrix", mats)
+    out, hue, sat, bri, con, anchor, shape = pipe.run()
+    assert pipe.executed_kernels() == ["h2d_copy", "warp_affine", "gaussian_blur", "color_twist", "erase"]
+    win = O.gaussian_window(3.0)
+    for i in range(bs):
+        ref = O.warp_affine_u8(imgs[i], mats[i], interp=1, fill=0.0)
+        ref = O.gaussian_blur_u8(ref, win)
+        mm, off = O.color_twist_matrix(float(hue.at(i)), float(sat.at(i)), 1.0, float(bri.at(i)), float(con.at(i)))
+        ref = O.linear_transform_u8(ref, mm, off)
+        ref = O.erase_u8(ref, anchor.at(i), shape.at(i), fill=(0.0,), normalized_anchor=True, normalized_shape=True)
+        got = out[i].as_cpu()
+        assert np.array_equal(got, ref), f"sample {i}: max diff {np.abs(got.astype(int) - ref).max()}"
