@@ -131,6 +131,8 @@ _KERNEL_SYMBOLS = [
     "daliamdResampleSetup", "daliamdResampleRun", "daliamdCmnSetup", "daliamdCmnRun",
     "daliamdWarpAffineSetup", "daliamdWarpAffineRun", "daliamdGaussianWindow", "daliamdGaussianBlurSetup",
     "daliamdGaussianBlurRun", "daliamdColorTwistMatrix", "daliamdPointwiseSetup", "daliamdPointwiseRun",
+    "daliamdHannWindow", "daliamdSpectrogramSetup", "daliamdSpectrogramRun", "daliamdMelFilterBankWeights",
+    "daliamdMelFilterBankSetup", "daliamdMelFilterBankRun", "daliamdToDecibelsRun",
 ]
 
 _HOST_SYMBOLS = [

@@ -1,0 +1,338 @@
+// Audio operators (BASELINE.json configs[3]): decoders.audio (host WAV parse), spectrogram, mel_filter_bank,
+// to_decibels (device).  Arithmetic in libdali_amd_kernels.so.
+//   decoders.audio   dali/operators/decoder/audio/audio_decoder_op.cc:25-179, generic_decoder.cc:140-220
+//   Spectrogram      dali/operators/signal/fft/spectrogram.cc:30-87,152-296
+//   MelFilterBank    dali/operators/audio/mel_scale/mel_filter_bank.cc:22-62
+//   ToDecibels       dali/operators/signal/decibel/to_decibels_op.h:35-50, to_decibels_op_cpu.cc:22-47
+#include <cmath>
+#include <cstring>
+
+#include "ops.h"
+#include "pipeline.h"
+
+namespace daliamd_host {
+
+// =============================================================================================
+// decoders.audio: PCM WAV (16-bit integer or 32-bit float) -> float32, like libsndfile's sf_readf_float
+// =============================================================================================
+DALI_SCHEMA(decoders__Audio)
+    .DocStr("Decodes waveforms from encoded audio data.\n\nSupported in this build: RIFF/WAVE with 16-bit PCM or 32-bit "
+            "float samples. The output is float32 in [-1, 1); the second output is the sampling rate.")
+    .NumInput(1)
+    .NumOutput(2)
+    .AddOptionalArg("downmix", "If set to True, downmix all input channels to mono (1-D output).", ArgValue::Bool(false))
+    .AddOptionalArg("dtype", "Output data type (FLOAT only).", ArgValue::Int(DALI_FLOAT))
+    .AddOptionalTypeArg("sample_rate", "Resampling is not supported in this build; must match the file if given.",
+                        ArgType::FLOAT, true)
+    .AddOptionalArg("quality", "Ignored (no resampling).", ArgValue::Float(50.0));
+DALI_SCHEMA(AudioDecoder).DocStr("Legacy alias of decoders.audio").NumInput(1).NumOutput(2).AddParent("decoders__Audio");
+
+struct WavInfo { int channels = 0, bits = 0, tag = 0; int64_t frames = 0; double rate = 0; const uint8_t *data = nullptr; };
+
+static WavInfo ParseWav(const uint8_t *p, size_t n, const std::string &src) {
+  auto fail = [&](const char *why) { DALI_FAIL("Failed to decode ", src, ": ", why); };
+  if (n < 12 || memcmp(p, "RIFF", 4) || memcmp(p + 8, "WAVE", 4)) fail("not a RIFF/WAVE stream (only WAV is supported)");
+  WavInfo w;
+  size_t pos = 12;
+  bool have_fmt = false;
+  while (pos + 8 <= n) {
+    uint32_t size;
+    memcpy(&size, p + pos + 4, 4);
+    const uint8_t *body = p + pos + 8;
+    if (!memcmp(p + pos, "fmt ", 4)) {
+      if (size < 16 || pos + 8 + size > n) fail("truncated fmt chunk");
+      uint16_t tag, ch, bits;
+      uint32_t rate;
+      memcpy(&tag, body, 2); memcpy(&ch, body + 2, 2); memcpy(&rate, body + 4, 4); memcpy(&bits, body + 14, 2);
+      if (tag == 0xFFFE && size >= 26) memcpy(&tag, body + 24, 2);  // WAVE_FORMAT_EXTENSIBLE sub-format
+      w.tag = tag; w.channels = ch; w.rate = rate; w.bits = bits;
+      have_fmt = true;
+    } else if (!memcmp(p + pos, "data", 4)) {
+      if (!have_fmt) fail("data chunk before fmt chunk");
+      size_t avail = std::min<size_t>(size, n - (pos + 8));
+      if (!((w.tag == 1 && w.bits == 16) || (w.tag == 3 && w.bits == 32))) fail("unsupported sample format (PCM16 / float32 only)");
+      if (w.channels < 1) fail("no channels");
+      w.frames = (int64_t)(avail / (w.bits / 8) / w.channels);
+      w.data = body;
+      return w;
+    }
+    pos += 8 + size + (size & 1);
+  }
+  fail("no data chunk");
+  return w;
+}
+
+class AudioDecoderCpu : public OperatorBase {
+ public:
+  explicit AudioDecoderCpu(const OpSpec &spec) : OperatorBase(spec), downmix_(spec.GetBool("downmix")) {
+    DALI_ENFORCE(spec.GetInt("dtype") == DALI_FLOAT, "decoders.audio: only dtype=FLOAT is supported");
+  }
+  bool SetupImpl(std::vector<OutputDesc> &desc, const Workspace &ws) override {
+    const TensorList &in = ws.Input(0);
+    int n = in.num_samples();
+    infos_.resize(n);
+    desc[0].type = DALI_FLOAT; desc[1].type = DALI_FLOAT;
+    desc[0].shape.resize(n); desc[1].shape.assign(n, TensorShape{});
+    for (int i = 0; i < n; i++) {
+      std::string src = i < (int)in.source_info.size() && !in.source_info[i].empty() ? in.source_info[i] : make_string("sample #", i);
+      infos_[i] = ParseWav(static_cast<const uint8_t *>(in.raw(i)), in.nbytes(i), src);
+      if (downmix_ || infos_[i].channels == 1) desc[0].shape[i] = {infos_[i].frames};
+      else desc[0].shape[i] = {infos_[i].frames, infos_[i].channels};
+    }
+    if (spec_.ArgumentDefined("sample_rate")) {
+      auto sr = GetPerSampleFloat(spec_, ws, "sample_rate", n);
+      for (int i = 0; i < n; i++)
+        DALI_ENFORCE(sr[i] <= 0 || sr[i] == (float)infos_[i].rate, "decoders.audio: resampling (", infos_[i].rate, " -> ",
+                     sr[i], " Hz) is not supported in this build");
+    }
+    return true;
+  }
+  void RunImpl(Workspace &ws) override {
+    TensorList &out = ws.Output(0), &rate = ws.Output(1);
+    for (int i = 0; i < out.num_samples(); i++) {
+      ws.GetThreadPool().AddWork([&, i](int) {
+        const WavInfo &w = infos_[i];
+        float *o = static_cast<float *>(out.raw(i));
+        bool mono_out = downmix_ || w.channels == 1;
+        for (int64_t f = 0; f < w.frames; f++) {
+          float acc = 0;
+          for (int c = 0; c < w.channels; c++) {
+            float v;
+            if (w.tag == 1) { int16_t s; memcpy(&s, w.data + (f * w.channels + c) * 2, 2); v = s * (1.0f / 32768); }
+            else memcpy(&v, w.data + (f * w.channels + c) * 4, 4);
+            if (mono_out) acc += v; else o[f * w.channels + c] = v;
+          }
+          if (mono_out) o[f] = w.channels == 1 ? acc : acc / w.channels;
+        }
+        *static_cast<float *>(rate.raw(i)) = (float)w.rate;
+      }, infos_[i].frames);
+    }
+    ws.GetThreadPool().RunAll();
+  }
+
+ private:
+  bool downmix_;
+  std::vector<WavInfo> infos_;
+};
+DALI_REGISTER_OPERATOR(decoders__Audio, AudioDecoderCpu, CPU);
+DALI_REGISTER_OPERATOR(AudioDecoder, AudioDecoderCpu, CPU);
+
+// =============================================================================================
+// Spectrogram
+// =============================================================================================
+DALI_SCHEMA(Spectrogram)
+    .DocStr("Produces a spectrogram from a 1D signal (for example, audio).\n\nInput data is expected to be one channel "
+            "float32. The output is laid out frequency-major (\"ft\"): (nfft/2+1, number of windows).")
+    .NumInput(1)
+    .NumOutput(1)
+    .AddOptionalTypeArg("nfft", "Size of the FFT (a power of two here). Default: window_length.", ArgType::INT)
+    .AddOptionalArg("window_length", "Window size in number of samples.", ArgValue::Int(512))
+    .AddOptionalArg("window_step", "Step between the STFT windows in number of samples.", ArgValue::Int(256))
+    .AddOptionalTypeArg("window_fn", "Samples of the window function (default: Hann).", ArgType::FLOAT_VEC)
+    .AddOptionalArg("power", "Exponent of the magnitude of the spectrum: 1 (amplitude) or 2 (power).", ArgValue::Int(2))
+    .AddOptionalArg("center_windows", "Indicates whether extracted windows should be padded so that the window function is "
+                    "centered at multiples of window_step.", ArgValue::Bool(true))
+    .AddOptionalArg("reflect_padding", "Indicates the padding policy when sampling outside the bounds of the signal.",
+                    ArgValue::Bool(true))
+    .AddOptionalArg("layout", "Output layout: \"ft\" (frequency-major; the only one supported here).", ArgValue::Str("ft"));
+
+class SpectrogramGpu : public OperatorBase {
+ public:
+  explicit SpectrogramGpu(const OpSpec &spec) : OperatorBase(spec), window_dev_(StorageDevice::GPU) {
+    p_.window_length = (int)spec.GetInt("window_length");
+    p_.nfft = spec.TryArg("nfft") ? (int)spec.GetInt("nfft") : p_.window_length;
+    p_.window_step = (int)spec.GetInt("window_step");
+    p_.power = (int)spec.GetInt("power");
+    p_.center_windows = spec.GetBool("center_windows");
+    p_.reflect_padding = spec.GetBool("reflect_padding");
+    DALI_ENFORCE(spec.GetString("layout") == "ft", "Spectrogram (gpu): only layout=\"ft\" is supported");
+    window_.resize(p_.window_length);
+    if (spec.TryArg("window_fn")) {
+      auto w = spec.GetFloatVec("window_fn");
+      DALI_ENFORCE((int)w.size() == p_.window_length, "Window function should match the specified `window_length`");
+      for (int i = 0; i < p_.window_length; i++) window_[i] = (float)w[i];
+    } else {
+      daliamdHannWindow(p_.window_length, window_.data());
+    }
+  }
+  bool SetupImpl(std::vector<OutputDesc> &desc, const Workspace &ws) override {
+    const TensorList &in = ws.Input(0);
+    DALI_ENFORCE(in.type() == DALI_FLOAT, "Spectrogram expects float32 input, got ", TypeName(in.type()));
+    int n = in.num_samples();
+    descs_.assign(n, daliamdSpectrogramDesc{});
+    for (int i = 0; i < n; i++) {
+      DALI_ENFORCE(in.shape(i).size() == 1, "Spectrogram expects a 1-D (single channel) signal");
+      descs_[i].in = static_cast<const float *>(in.raw(i));
+      descs_[i].length = in.shape(i)[0];
+    }
+    KCHECK(daliamdSpectrogramSetup(descs_.data(), n, &p_, &nwg_, &lds_));
+    desc[0].type = DALI_FLOAT;
+    desc[0].shape.resize(n);
+    for (int i = 0; i < n; i++) desc[0].shape[i] = {p_.nfft / 2 + 1, descs_[i].num_windows};
+    return true;
+  }
+  void RunImpl(Workspace &ws) override {
+    TensorList &out = ws.Output(0);
+    out.SetLayout("ft");
+    int n = (int)descs_.size();
+    if (!n) return;
+    if (!window_uploaded_) {
+      window_dev_.Reserve(window_.size() * sizeof(float));
+      KCHECK(daliamdMemcpyH2DAsync(window_dev_.data(), window_.data(), window_.size() * sizeof(float), ws.stream));
+      KCHECK(daliamdStreamSynchronize(ws.stream));  // one-time: `window_` is pageable host memory
+      window_uploaded_ = true;
+    }
+    for (int i = 0; i < n; i++) descs_[i].out = static_cast<float *>(out.raw(i));
+    auto *dev = static_cast<const daliamdSpectrogramDesc *>(uploader_.Upload(descs_.data(), n * sizeof(descs_[0]), ws.stream));
+    KCHECK(daliamdSpectrogramRun(ws.stream, dev, n, &p_, static_cast<const float *>(window_dev_.data()), nwg_, lds_));
+    NoteLaunch(ws, "spectrogram");
+  }
+
+ private:
+  daliamdSpectrogramParams p_{};
+  std::vector<float> window_;
+  Buffer window_dev_;
+  bool window_uploaded_ = false;
+  int nwg_ = 0, lds_ = 0;
+  std::vector<daliamdSpectrogramDesc> descs_;
+  DescUploader uploader_;
+};
+DALI_REGISTER_OPERATOR(Spectrogram, SpectrogramGpu, GPU);
+
+// =============================================================================================
+// MelFilterBank
+// =============================================================================================
+DALI_SCHEMA(MelFilterBank)
+    .DocStr("Converts a spectrogram to a mel spectrogram by applying a bank of triangular filters.\n\nThe frequency ('f') "
+            "dimension is the first one (\"ft\" layout). Implemented as a dense filterbank x frames matrix product on the "
+            "MI355X f32 matrix cores.")
+    .NumInput(1)
+    .NumOutput(1)
+    .AddOptionalArg("nfilter", "Number of mel filters.", ArgValue::Int(128))
+    .AddOptionalArg("sample_rate", "Sampling rate of the audio signal.", ArgValue::Float(44100.0))
+    .AddOptionalArg("freq_low", "The minimum frequency.", ArgValue::Float(0.0))
+    .AddOptionalArg("freq_high", "The maximum frequency. If not provided, sample_rate / 2 is used.", ArgValue::Float(0.0))
+    .AddOptionalArg("normalize", "Normalize the triangular filter weights by the width of their frequency bands.",
+                    ArgValue::Bool(true))
+    .AddOptionalArg("mel_formula", "\"slaney\" or \"htk\".", ArgValue::Str("slaney"));
+
+class MelFilterBankGpu : public OperatorBase {
+ public:
+  explicit MelFilterBankGpu(const OpSpec &spec) : OperatorBase(spec), weights_dev_(StorageDevice::GPU) {
+    nfilter_ = (int)spec.GetInt("nfilter");
+    sample_rate_ = (float)spec.GetFloat("sample_rate");
+    freq_low_ = (float)spec.GetFloat("freq_low");
+    freq_high_ = (float)spec.GetFloat("freq_high");
+    normalize_ = spec.GetBool("normalize");
+    std::string f = spec.GetString("mel_formula");
+    DALI_ENFORCE(f == "slaney" || f == "htk", "Unsupported mel_formula value \"", f, "\". Supported values are: \"slaney\", \"htk\"");
+    formula_ = f == "htk";
+    DALI_ENFORCE(nfilter_ > 0, "`nfilter` must be positive");
+  }
+  bool SetupImpl(std::vector<OutputDesc> &desc, const Workspace &ws) override {
+    const TensorList &in = ws.Input(0);
+    DALI_ENFORCE(in.type() == DALI_FLOAT, "MelFilterBank expects float32 input");
+    int n = in.num_samples();
+    descs_.assign(n, daliamdMelDesc{});
+    desc[0].type = DALI_FLOAT;
+    desc[0].shape.resize(n);
+    for (int i = 0; i < n; i++) {
+      DALI_ENFORCE(in.shape(i).size() == 2, "MelFilterBank expects a 2-D (frequency, time) spectrogram");
+      int nb = (int)in.shape(i)[0];
+      DALI_ENFORCE(nbins_ == 0 || nb == nbins_, "All spectrograms must have the same number of frequency bins (got ", nb,
+                   " after ", nbins_, ")");
+      nbins_ = nb;
+      descs_[i].in = static_cast<const float *>(in.raw(i));
+      descs_[i].frames = (int)in.shape(i)[1];
+      desc[0].shape[i] = {nfilter_, in.shape(i)[1]};
+    }
+    return true;
+  }
+  void RunImpl(Workspace &ws) override {
+    TensorList &out = ws.Output(0);
+    out.SetLayout("ft");
+    int n = (int)descs_.size();
+    if (!n) return;
+    if (weights_.empty()) {
+      weights_.resize((size_t)nfilter_ * nbins_);
+      KCHECK(daliamdMelFilterBankWeights(nfilter_, 2 * (nbins_ - 1), sample_rate_, freq_low_, freq_high_, normalize_, formula_,
+                                         weights_.data()));
+      weights_dev_.Reserve(weights_.size() * sizeof(float));
+      KCHECK(daliamdMemcpyH2DAsync(weights_dev_.data(), weights_.data(), weights_.size() * sizeof(float), ws.stream));
+      KCHECK(daliamdStreamSynchronize(ws.stream));  // one-time upload from pageable memory
+    }
+    for (int i = 0; i < n; i++) descs_[i].out = static_cast<float *>(out.raw(i));
+    int nwg = 0;
+    KCHECK(daliamdMelFilterBankSetup(descs_.data(), n, &nwg));
+    auto *dev = static_cast<const daliamdMelDesc *>(uploader_.Upload(descs_.data(), n * sizeof(descs_[0]), ws.stream));
+    KCHECK(daliamdMelFilterBankRun(ws.stream, dev, n, nwg, static_cast<const float *>(weights_dev_.data()), nfilter_, nbins_));
+    NoteLaunch(ws, "mel_filter_bank_mfma");
+  }
+
+ private:
+  int nfilter_, nbins_ = 0, formula_ = 0;
+  float sample_rate_, freq_low_, freq_high_;
+  bool normalize_;
+  std::vector<float> weights_;
+  Buffer weights_dev_;
+  std::vector<daliamdMelDesc> descs_;
+  DescUploader uploader_;
+};
+DALI_REGISTER_OPERATOR(MelFilterBank, MelFilterBankGpu, GPU);
+
+// =============================================================================================
+// ToDecibels
+// =============================================================================================
+DALI_SCHEMA(ToDecibels)
+    .DocStr("Converts a magnitude (real, positive) to the decibel scale: "
+            "``min_ratio = pow(10, cutoff_db / multiplier); out[i] = multiplier * log10(max(min_ratio, input[i] / reference))``.")
+    .NumInput(1)
+    .NumOutput(1)
+    .AddOptionalArg("multiplier", "Factor by which the logarithm is multiplied (10 for power, 20 for magnitude).", ArgValue::Float(10.0))
+    .AddOptionalTypeArg("reference", "Reference magnitude. If not provided, the maximum value of the input is used.", ArgType::FLOAT)
+    .AddOptionalArg("cutoff_db", "Minimum or cut-off ratio in dB.", ArgValue::Float(-200.0));
+
+class ToDecibelsGpu : public OperatorBase {
+ public:
+  explicit ToDecibelsGpu(const OpSpec &spec) : OperatorBase(spec) {
+    multiplier_ = (float)spec.GetFloat("multiplier");
+    cutoff_ = (float)spec.GetFloat("cutoff_db");
+    if (spec.TryArg("reference")) {
+      reference_ = (float)spec.GetFloat("reference");
+      DALI_ENFORCE(reference_ != 0, "`reference` argument can't be zero");
+      DALI_ENFORCE(reference_ > 0, "`reference` must be positive");
+    }
+  }
+  bool SetupImpl(std::vector<OutputDesc> &desc, const Workspace &ws) override {
+    const TensorList &in = ws.Input(0);
+    DALI_ENFORCE(in.type() == DALI_FLOAT, "ToDecibels expects float32 input");
+    desc[0].type = DALI_FLOAT;
+    desc[0].shape.clear();
+    for (int i = 0; i < in.num_samples(); i++) desc[0].shape.push_back(in.shape(i));
+    return true;
+  }
+  void RunImpl(Workspace &ws) override {
+    const TensorList &in = ws.Input(0);
+    TensorList &out = ws.Output(0);
+    out.SetLayout(in.layout());
+    int n = in.num_samples();
+    if (!n) return;
+    descs_.assign(n, daliamdDecibelDesc{});
+    for (int i = 0; i < n; i++) {
+      descs_[i].in = static_cast<const float *>(in.raw(i));
+      descs_[i].out = static_cast<float *>(out.raw(i));
+      descs_[i].size = volume(in.shape(i));
+    }
+    auto *dev = static_cast<const daliamdDecibelDesc *>(uploader_.Upload(descs_.data(), n * sizeof(descs_[0]), ws.stream));
+    KCHECK(daliamdToDecibelsRun(ws.stream, dev, n, multiplier_, reference_, cutoff_));
+    NoteLaunch(ws, "to_decibels");
+  }
+
+ private:
+  float multiplier_, cutoff_, reference_ = 0.0f;
+  std::vector<daliamdDecibelDesc> descs_;
+  DescUploader uploader_;
+};
+DALI_REGISTER_OPERATOR(ToDecibels, ToDecibelsGpu, GPU);
+
+}  // namespace daliamd_host

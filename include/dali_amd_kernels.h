@@ -271,6 +271,59 @@ DALIAMD_API daliamdResult_t daliamdPointwiseSetup(daliamdPointwiseDesc *descs_ho
 DALIAMD_API daliamdResult_t daliamdPointwiseRun(daliamdStream_t stream, const daliamdPointwiseDesc *descs_dev, int n,
                                                 int num_workgroups);
 
+/* ----------------------------------------------------------------------------------------------
+ * Audio features (BASELINE.json configs[3]): spectrogram -> mel filter bank -> decibels, f32.
+ *   spectrogram  window extraction (centred, reflect-101 / zero padding) fused with a radix-2 FFT in LDS and the
+ *                power / magnitude spectrum; replaces ExtractWindows* + cuFFT R2C + fft_postprocess
+ *                (dali/kernels/signal/window/extract_windows_gpu.cuh:153-302, signal/fft/stft_gpu_impl.cu:116-265)
+ *   mel          dense (nfilter x nbins) . (nbins x frames) GEMM on the f32 matrix cores
+ *                (v_mfma_f32_16x16x4_f32); weights = the reference's triangular filters
+ *                (dali/kernels/audio/mel_scale/mel_scale.h:79-130, mel_filter_bank_cpu.cc:77-111)
+ *   decibels     mul * log10(max(min_ratio, x / ref)), ref given or the per-sample maximum (wave64 shuffle +
+ *                LDS reduction) (dali/kernels/signal/decibel/decibel_calculator.h:25-52, to_decibels_cpu.cc:54-66)
+ * Layout: "ft" (frequency-major): spectrogram [nfft/2+1][frames], mel [nfilter][frames].
+ * -------------------------------------------------------------------------------------------- */
+typedef struct {
+  const float *in;      /* device: signal, `length` samples */
+  float *out;           /* device: [nfft/2+1][num_windows] */
+  int64_t length;
+  int32_t num_windows;  /* filled by Setup */
+  int32_t wg_start;     /* filled by Setup */
+} daliamdSpectrogramDesc;
+typedef struct {
+  int32_t nfft, window_length, window_step;
+  int32_t center_windows, reflect_padding, power; /* power: 1 magnitude, 2 power */
+} daliamdSpectrogramParams;
+DALIAMD_API void daliamdHannWindow(int n, float *window);
+DALIAMD_API daliamdResult_t daliamdSpectrogramSetup(daliamdSpectrogramDesc *descs_host, int n,
+                                                   const daliamdSpectrogramParams *params, int *num_workgroups,
+                                                   int *lds_bytes);
+DALIAMD_API daliamdResult_t daliamdSpectrogramRun(daliamdStream_t stream, const daliamdSpectrogramDesc *descs_dev, int n,
+                                                 const daliamdSpectrogramParams *params, const float *window_dev,
+                                                 int num_workgroups, int lds_bytes);
+
+typedef struct {
+  const float *in;      /* device: [nbins][frames] */
+  float *out;           /* device: [nfilter][frames] */
+  int32_t frames;
+  int32_t wg_start;     /* filled by Setup */
+} daliamdMelDesc;
+/* host helper: dense weights [nfilter][nfft/2+1]; mel_formula 0 = slaney, 1 = htk; freq_high <= 0 -> sample_rate/2 */
+DALIAMD_API daliamdResult_t daliamdMelFilterBankWeights(int nfilter, int nfft, float sample_rate, float freq_low,
+                                                       float freq_high, int normalize, int mel_formula, float *weights);
+DALIAMD_API daliamdResult_t daliamdMelFilterBankSetup(daliamdMelDesc *descs_host, int n, int *num_workgroups);
+DALIAMD_API daliamdResult_t daliamdMelFilterBankRun(daliamdStream_t stream, const daliamdMelDesc *descs_dev, int n,
+                                                   int num_workgroups, const float *weights_dev, int nfilter, int nbins);
+
+typedef struct {
+  const float *in;
+  float *out;
+  int64_t size;
+} daliamdDecibelDesc;
+/* reference <= 0: use the per-sample maximum (1 when that maximum is 0) */
+DALIAMD_API daliamdResult_t daliamdToDecibelsRun(daliamdStream_t stream, const daliamdDecibelDesc *descs_dev, int n,
+                                                float multiplier, float reference, float cutoff_db);
+
 #ifdef __cplusplus
 }
 #endif

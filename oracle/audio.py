@@ -1,0 +1,198 @@
+"""ORACLE (test infrastructure only -- never imported by the product package).
+
+numpy restatement of the reference's audio feature path (BASELINE.json configs[3]):
+
+  Hann window (periodic, half-sample shifted)   dali/kernels/signal/window/window_functions.h:25-33
+  window extraction, centring, reflect-101 pad  dali/kernels/signal/window/extract_windows_cpu.cc:96-145,
+                                                extract_windows_args.h:38-43 (num_windows)
+  FFT size / window centring inside nfft        dali/kernels/signal/fft/fft_cpu_impl_ffts.cc:105-111
+  spectrum type (power / magnitude)             dali/operators/signal/fft/spectrogram.cc:128-146
+  mel filter bank (weights in double, Slaney / HTK scales, area normalisation)
+                                                dali/kernels/audio/mel_scale/mel_scale.h:27-130,
+                                                mel_filter_bank_cpu.cc:44-111
+  decibels                                      dali/kernels/signal/decibel/decibel_calculator.h:25-52,
+                                                to_decibels_cpu.cc:54-66
+  WAV decode (PCM16 -> float in [-1, 1))        dali/operators/decoder/audio/generic_decoder.cc:140-220 (libsndfile)
+
+The reference's CPU FFT is the un-vendored FFTS library; like the reference's own tests
+(dali/test/python/operator_2/test_spectrogram.py:188, eps 1e-4) the oracle uses a float64 FFT (numpy.fft.rfft)
+and the comparison is tolerance-based: PARITY for the FFT stage is "within 1e-4 relative", not bit-exact.
+"""
+import io
+import struct
+
+import numpy as np
+
+
+def hann_window(n):
+    a = 2 * np.pi / n
+    t = np.arange(n, dtype=np.float64)
+    return (0.5 * (1.0 - np.cos(a * (t + 0.5)))).astype(np.float32)
+
+
+def num_windows(length, window_size, step, centered):
+    if not centered:
+        length -= window_size
+    return length // step + 1
+
+
+def _reflect101(idx, size):
+    if size < 2:
+        return np.full_like(idx, size - 1)
+    idx = idx.copy()
+    while True:
+        lo, hi = idx < 0, idx >= size
+        if not (lo.any() or hi.any()):
+            return idx
+        idx[lo] = -idx[lo]
+        idx[hi] = 2 * size - 2 - idx[hi]
+
+
+def spectrogram(x, nfft=None, window_length=512, window_step=256, window_fn=None, power=2, center_windows=True,
+                reflect_padding=True):
+    """x: float32 [L].  Returns float32 [nfft/2+1, T] ("ft" layout)."""
+    x = np.asarray(x, np.float32)
+    nfft = window_length if nfft is None else nfft
+    assert window_length <= nfft
+    win = hann_window(window_length) if window_fn is None else np.asarray(window_fn, np.float32)
+    L = x.shape[0]
+    T = num_windows(L, window_length, window_step, center_windows)
+    center = window_length // 2 if center_windows else 0
+    starts = np.arange(T, dtype=np.int64) * window_step - center
+    idx = starts[:, None] + np.arange(window_length, dtype=np.int64)[None, :]
+    if reflect_padding:
+        frames = x[_reflect101(idx, L)] * win[None, :]           # float32 product, like the CPU kernel
+    else:
+        ok = (idx >= 0) & (idx < L)
+        frames = np.where(ok, x[np.clip(idx, 0, L - 1)] * win[None, :], np.float32(0))
+    frames = frames.astype(np.float32)
+    buf = np.zeros((T, nfft), np.float64)
+    s = (nfft - window_length) // 2
+    buf[:, s:s + window_length] = frames
+    X = np.fft.rfft(buf, axis=1)
+    p = X.real ** 2 + X.imag ** 2
+    if power == 1:
+        p = np.sqrt(p)
+    return p.T.astype(np.float32)
+
+
+def _hz_to_mel(hz, formula):
+    hz = float(hz)
+    if formula == "htk":
+        return 1127.0 * np.log(1.0 + hz / 700.0)
+    fsp, min_log_hz = 200.0 / 3.0, 1000.0
+    min_log_mel, step_log = (min_log_hz - 0.0) / fsp, 0.068751777
+    return min_log_mel + np.log(hz / min_log_hz) / step_log if hz >= min_log_hz else (hz - 0.0) / fsp
+
+
+def _mel_to_hz(mel, formula):
+    mel = float(mel)
+    if formula == "htk":
+        return 700.0 * (np.exp(mel / 1127.0) - 1.0)
+    fsp, min_log_hz = 200.0 / 3.0, 1000.0
+    min_log_mel, step_log = (min_log_hz - 0.0) / fsp, 0.068751777
+    return min_log_hz * np.exp(step_log * (mel - min_log_mel)) if mel >= min_log_mel else 0.0 + mel * fsp
+
+
+def mel_weights(nfilter, nfft, sample_rate, freq_low=0.0, freq_high=0.0, normalize=True, mel_formula="slaney"):
+    """Dense [nfilter, nfft/2+1] float32 matrix equivalent to MelFilterImplBase + ComputeFreqMajor."""
+    if freq_high <= 0:
+        freq_high = sample_rate / 2
+    mel_low, mel_high = _hz_to_mel(freq_low, mel_formula), _hz_to_mel(freq_high, mel_formula)
+    hz_step = float(sample_rate) / nfft
+    mel_delta = (mel_high - mel_low) / (nfilter + 1)
+    nbin = nfft // 2 + 1
+    inv = 1.0 / hz_step
+    b0 = int(np.ceil(freq_low * inv))
+    b1 = min(int(np.ceil(freq_high * inv)), nbin)
+    weights_down = np.zeros(nbin, np.float32)
+    norm = np.ones(nfilter, np.float32)
+    intervals = np.full(nbin, -1, np.int64)
+    mel0, mel1 = mel_low, mel_low + mel_delta
+    fftbin = b0
+    f = fftbin * hz_step
+    for interval in range(nfilter + 1):
+        if interval == nfilter:
+            mel1 = mel_high
+        f0, f1 = _mel_to_hz(mel0, mel_formula), _mel_to_hz(mel1, mel_formula)
+        if normalize and interval < nfilter:
+            f2 = _mel_to_hz(mel1 + mel_delta, mel_formula)
+            norm[interval] = np.float32(2.0 / (f2 - f0))
+        slope = 1.0 / (f1 - f0)
+        while fftbin < b1 and f < f1:
+            weights_down[fftbin] = np.float32((f1 - f) * slope)
+            intervals[fftbin] = interval
+            fftbin += 1
+            f = fftbin * hz_step
+        mel0, mel1 = mel1, mel1 + mel_delta
+    W = np.zeros((nfilter, nbin), np.float32)
+    for b in range(b0, b1):
+        up = intervals[b]
+        wd = weights_down[b]
+        wu = np.float32(1) - wd
+        down = up - 1
+        if down >= 0:
+            W[down, b] = wd * norm[down] if normalize else wd
+        if 0 <= up < nfilter:
+            W[up, b] = wu * norm[up] if normalize else wu
+    return W
+
+
+def mel_filter_bank(spec, nfilter=128, sample_rate=44100.0, freq_low=0.0, freq_high=0.0, normalize=True,
+                    mel_formula="slaney"):
+    """spec: float32 [nfft/2+1, T] -> float32 [nfilter, T]; accumulation over bins in increasing order, float32,
+    multiply then add (ComputeFreqMajor)."""
+    spec = np.asarray(spec, np.float32)
+    nfft = 2 * (spec.shape[0] - 1)
+    W = mel_weights(nfilter, nfft, sample_rate, freq_low, freq_high, normalize, mel_formula)
+    out = np.zeros((nfilter, spec.shape[1]), np.float32)
+    for b in range(spec.shape[0]):
+        nz = np.nonzero(W[:, b])[0]
+        for m in nz:
+            out[m] += W[m, b] * spec[b]
+    return out
+
+
+def to_decibels(x, multiplier=10.0, reference=0.0, cutoff_db=-200.0):
+    x = np.asarray(x, np.float32)
+    min_ratio = np.float32(10.0 ** (cutoff_db / multiplier))
+    if min_ratio == 0:
+        min_ratio = np.nextafter(np.float32(0), np.float32(1))
+    if reference == 0.0:
+        s_ref = np.float32(x.max()) if x.size else np.float32(1)
+        if s_ref == 0:
+            s_ref = np.float32(1)
+    else:
+        s_ref = np.float32(reference)
+    inv = np.float32(1) if s_ref == 1 else np.float32(1) / s_ref
+    mul_log2 = np.float32(np.float32(multiplier) * np.float32(0.3010299956639812))
+    return (mul_log2 * np.log2(np.maximum(min_ratio, x * inv))).astype(np.float32)
+
+
+def decode_wav(data):
+    """PCM WAV -> (float32 [T] or [T, C] in [-1, 1), sample_rate) like sf_readf_float."""
+    b = io.BytesIO(data)
+    riff, _, wave = struct.unpack("<4sI4s", b.read(12))
+    assert riff == b"RIFF" and wave == b"WAVE"
+    fmt = None
+    while True:
+        hdr = b.read(8)
+        if len(hdr) < 8:
+            raise ValueError("no data chunk")
+        cid, size = struct.unpack("<4sI", hdr)
+        if cid == b"fmt ":
+            fmt = struct.unpack("<HHIIHH", b.read(16))
+            b.read(size - 16)
+        elif cid == b"data":
+            raw = b.read(size)
+            break
+        else:
+            b.read(size + (size & 1))
+    tag, ch, rate, _, _, bits = fmt
+    if tag == 1 and bits == 16:
+        a = np.frombuffer(raw, "<i2").astype(np.float32) / np.float32(32768)
+    elif tag == 3 and bits == 32:
+        a = np.frombuffer(raw, "<f4").astype(np.float32)
+    else:
+        raise ValueError("unsupported WAV encoding")
+    return (a.reshape(-1, ch) if ch > 1 else a), float(rate)

@@ -1,0 +1,131 @@
+"""GPU parity for the audio path (BASELINE.json configs[3]): decoders.audio -> spectrogram(nfft=1024) ->
+mel_filter_bank(80) -> to_decibels, against the numpy oracle (float64 FFT).
+
+Stated tolerances (the reference's own, dali/test/python/operator_2/test_spectrogram.py:188,
+operator_1/test_mel_filter_bank.py:199, operator_2/test_to_decibels.py:120):
+  spectrogram  |got - ref| <= 1e-4 * max(ref) + 1e-6        (f32 radix-2 FFT vs f64 FFT)
+  mel          |got - ref| <= 1e-3 relative to the row scale  (we hold 1e-5: MFMA fma chain vs mul+add)
+  decibels     |got - ref| <= 1e-4 * |ref| + 1e-3 dB
+"""
+import io
+import struct
+
+import numpy as np
+import pytest
+
+from oracle import audio as A
+
+pytestmark = pytest.mark.gpu
+
+
+def synth_signal(rng, seconds, sr=16000):
+    """band-limited noise + 3 chirps."""
+    n = int(seconds * sr)
+    t = np.arange(n) / sr
+    x = rng.normal(0, 0.05, n)
+    x = np.convolve(x, np.ones(8) / 8, mode="same")
+    for _ in range(3):
+        f0, f1 = rng.uniform(100, 3000), rng.uniform(200, 7000)
+        x += 0.2 * np.sin(2 * np.pi * (f0 * t + 0.5 * (f1 - f0) * t * t / seconds))
+    return np.clip(x, -0.99, 0.99)
+
+
+def to_wav(x, sr=16000):
+    pcm = np.round(x * 32767).astype("<i2")
+    b = io.BytesIO()
+    b.write(b"RIFF" + struct.pack("<I", 36 + pcm.nbytes) + b"WAVE")
+    b.write(b"fmt " + struct.pack("<IHHIIHH", 16, 1, 1, sr, sr * 2, 2, 16))
+    b.write(b"data" + struct.pack("<I", pcm.nbytes) + pcm.tobytes())
+    return b.getvalue()
+
+
+def _audio_pipe(bs, **kw):
+    from dali_amd import fn
+    from dali_amd.pipeline import Pipeline
+    pipe = Pipeline(batch_size=bs, num_threads=4, device_id=0, prefetch_queue_depth=1)
+    with pipe:
+        enc = fn.external_source(name="wav")
+        audio, rate = fn.decoders.audio(enc, downmix=True)
+        spec = fn.spectrogram(audio.gpu(), nfft=kw.get("nfft", 1024), window_length=kw.get("wl", 1024),
+                              window_step=kw.get("step", 256), power=kw.get("power", 2),
+                              center_windows=kw.get("center", True), reflect_padding=kw.get("reflect", True))
+        mel = fn.mel_filter_bank(spec, nfilter=kw.get("nfilter", 80), sample_rate=16000.0, freq_high=8000.0,
+                                 mel_formula=kw.get("formula", "slaney"), normalize=kw.get("normalize", True))
+        db = fn.to_decibels(mel, multiplier=10.0, cutoff_db=-80.0)
+        pipe.set_outputs(audio, rate, spec, mel, db)
+    pipe.build()
+    return pipe
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(nfft=512, wl=400, step=160, nfilter=64, formula="htk"),
+                                dict(power=1, center=False, nfilter=128), dict(reflect=False, normalize=False, nfilter=23)])
+def test_audio_pipeline_matches_oracle(kw):
+    rng = np.random.default_rng(11)
+    sigs = [synth_signal(rng, s) for s in (1.3, 2.0, 0.7, 3.1)]
+    wavs = [to_wav(s) for s in sigs]
+    pipe = _audio_pipe(len(wavs), **kw)
+    pipe.feed_input("wav", wavs)
+    audio, rate, spec, mel, db = pipe.run()
+    assert pipe.executed_kernels() == ["h2d_copy", "spectrogram", "mel_filter_bank_mfma", "to_decibels"]
+    for i, w in enumerate(wavs):
+        ref_audio, sr = A.decode_wav(w)
+        assert np.array_equal(audio.at(i), ref_audio) and float(rate.at(i)) == sr == 16000.0
+        ref_spec = A.spectrogram(ref_audio, nfft=kw.get("nfft", 1024), window_length=kw.get("wl", 1024),
+                                 window_step=kw.get("step", 256), power=kw.get("power", 2),
+                                 center_windows=kw.get("center", True), reflect_padding=kw.get("reflect", True))
+        got_spec = spec[i].as_cpu()
+        assert got_spec.shape == ref_spec.shape
+        err = np.abs(got_spec - ref_spec).max()
+        assert err <= 1e-4 * ref_spec.max() + 1e-6, f"spectrogram sample {i}: {err} vs max {ref_spec.max()}"
+        # mel / dB are checked on the GPU's own spectrogram so each stage has its own tolerance
+        ref_mel = A.mel_filter_bank(got_spec, kw.get("nfilter", 80), 16000.0, 0.0, 8000.0, kw.get("normalize", True),
+                                    kw.get("formula", "slaney"))
+        got_mel = mel[i].as_cpu()
+        scale = np.abs(ref_mel).max(axis=1, keepdims=True) + 1e-12
+        assert (np.abs(got_mel - ref_mel) / scale).max() <= 1e-5, f"mel sample {i}"
+        ref_db = A.to_decibels(got_mel, 10.0, 0.0, -80.0)
+        got_db = db[i].as_cpu()
+        assert np.abs(got_db - ref_db).max() <= 1e-3, f"dB sample {i}"
+        assert got_db.max() <= 1e-4 and got_db.min() >= -80.0 - 1e-3
+
+
+def test_mel_weights_match_oracle_and_reference_properties():
+    import ctypes as C
+    from dali_amd import _capi as capi
+    lib = capi.kernels()
+    for nf, nfft, sr, lo, hi, norm, formula in [(80, 1024, 16000.0, 0.0, 8000.0, True, "slaney"),
+                                               (128, 2048, 44100.0, 0.0, 0.0, True, "slaney"),
+                                               (40, 512, 16000.0, 300.0, 7000.0, False, "htk")]:
+        W = np.zeros((nf, nfft // 2 + 1), np.float32)
+        rc = lib.daliamdMelFilterBankWeights(nf, nfft, C.c_float(sr), C.c_float(lo), C.c_float(hi), int(norm),
+                                             1 if formula == "htk" else 0, W.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        ref = A.mel_weights(nf, nfft, sr, lo, hi, norm, formula)
+        assert np.array_equal(W, ref)
+        # triangular filters: every row is non-negative, unimodal, and neighbours overlap
+        assert (W >= 0).all() and (W.sum(1) > 0).all()
+        peaks = W.argmax(1)
+        assert (np.diff(peaks) > 0).all()
+        if not norm:   # un-normalised triangles sum to 1 across filters inside the covered band
+            inside = slice(peaks[0] + 1, peaks[-1])
+            assert np.allclose(W[:, inside].sum(0), 1.0, atol=1e-5)
+
+
+def test_to_decibels_reference_and_silence():
+    from dali_amd import fn
+    from dali_amd.pipeline import Pipeline
+    rng = np.random.default_rng(3)
+    data = [np.abs(rng.normal(0, 1, (7, 33))).astype(np.float32), np.zeros((4, 5), np.float32),
+            (rng.uniform(0, 1e-12, (3, 3))).astype(np.float32)]
+    for ref, cutoff, mult in [(None, -200.0, 10.0), (2.5, -60.0, 20.0)]:
+        pipe = Pipeline(batch_size=3, num_threads=1, device_id=0, prefetch_queue_depth=1)
+        with pipe:
+            x = fn.external_source(name="x")
+            kw = {} if ref is None else {"reference": ref}
+            pipe.set_outputs(fn.to_decibels(x.gpu(), multiplier=mult, cutoff_db=cutoff, **kw))
+        pipe.feed_input("x", data)
+        (out,) = pipe.run()
+        for i, d in enumerate(data):
+            want = A.to_decibels(d, mult, 0.0 if ref is None else ref, cutoff)
+            got = out[i].as_cpu()
+            assert np.abs(got - want).max() <= 1e-3 + 1e-4 * np.abs(want).max(), (i, ref)
