@@ -134,6 +134,115 @@ def cpu_baseline(enc, seconds_budget=20.0):
                       f"oracle (-O3 -msse2, OpenMP, one task per sample), {cores} threads, {el:.2f} s wall"}
 
 
+def bench_heavy_aug(args, device):
+    """configs[2]: warp_affine + gaussian_blur(sigma=3) + color_twist + erase on 512x512 u8 images, batch 128,
+    images resident in HBM.  One JSON line with per-kernel achieved GB/s (algorithmic bytes: 3*512*512 in + out)."""
+    import torch
+    from dali_amd import backend as B
+    from tests.util import synth_image
+    n = 128
+    rng = np.random.default_rng(1234)
+    base = [torch.from_numpy(synth_image(rng, 512, 512)).to(device) for _ in range(8)]
+    imgs = [base[i % 8].clone() for i in range(n)]
+
+    def params():
+        mats = []
+        for _ in range(n):
+            t, s = np.deg2rad(rng.uniform(-30, 30)), rng.uniform(0.8, 1.2)
+            c, sn = np.cos(t) / s, np.sin(t) / s
+            m = np.array([[c, -sn, 0], [sn, c, 0]], np.float32)
+            m[0, 2] = 256 - m[0, 0] * 256 - m[0, 1] * 256
+            m[1, 2] = 256 - m[1, 0] * 256 - m[1, 1] * 256
+            mats.append(m)
+        tw = [B.color_twist_matrix(rng.uniform(-30, 30), rng.uniform(.7, 1.3), 1.0, rng.uniform(.8, 1.2),
+                                   rng.uniform(.8, 1.2)) for _ in range(n)]
+        regs = []
+        for _ in range(n):
+            a, sh = rng.uniform(0, .7, 2) * 512, rng.uniform(.1, .3, 2) * 512
+            regs.append([(int(a[0]), int(a[1]), int(a[0] + sh[0]), int(a[1] + sh[1]))])
+        return mats, [t[0] for t in tw], [t[1] for t in tw], regs
+
+    names = ["WarpAffineKernel", "GaussianBlurKernel", "PointwiseKernel(color_twist)", "PointwiseKernel(erase)"]
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
+
+    def step(e=None):
+        mats, tm, to, regs = params()
+        if e: e[0].record()
+        x = B.warp_affine_batch(imgs, mats, fill_value=0.0)
+        if e: e[1].record()
+        x = B.gaussian_blur_batch(x, sigma=3.0)
+        if e: e[2].record()
+        x = B.pointwise_batch(x, tm, to)
+        if e: e[3].record()
+        x = B.pointwise_batch(x, regions=regs, fill=(0.0,))
+        if e: e[4].record()
+        return x
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(ev[k])
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    per = {}
+    bytes_per = 2 * 3 * 512 * 512 * n
+    for j, nm in enumerate(names):
+        ms = float(np.mean([e[j].elapsed_time(e[j + 1]) for e in ev]))
+        per[nm] = {"algorithmic_bytes": bytes_per, "avg_ms_incl_desc_upload": ms, "achieved_GBps": bytes_per / (ms * 1e-3) / 1e9}
+    dom = max(per, key=lambda k: per[k]["avg_ms_incl_desc_upload"])
+    print(json.dumps({"metric": "images/sec heavy-aug 512^2 b128 (warp_affine+gaussian_blur(sigma=3)+color_twist+erase)",
+                      "value": n * args.steps / el, "unit": "images/s", "n_gpus": 1, "steps": args.steps,
+                      "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
+                      "scaling": "weak", "vs_baseline": None, "dtype": "u8 in/out, f32 arithmetic", "data": "synthetic",
+                      "config": {"workload": "configs[2]: 128 x 512x512x3 u8 resident in HBM"},
+                      "roofline": {"bound": "hbm", "kernel": dom, "achieved": per[dom]["achieved_GBps"],
+                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": per[dom]["achieved_GBps"] / HBM_PEAK_GBS,
+                                   "traffic": None, "per_kernel": per}}))
+
+
+def bench_audio(args, device):
+    """configs[3]: spectrogram(nfft=1024, step 256) -> mel_filter_bank(80) -> to_decibels on 64 signals of 8-16 s at
+    16 kHz, signals resident in HBM."""
+    import torch
+    from dali_amd import fn
+    from dali_amd.pipeline import Pipeline
+    rng = np.random.default_rng(1234)
+    n = 64
+    sigs = [rng.normal(0, 0.1, int(rng.uniform(8, 16) * 16000)).astype(np.float32) for _ in range(n)]
+    pipe = Pipeline(batch_size=n, num_threads=4, device_id=device.index or 0, prefetch_queue_depth=1, exec_async=False)
+    with pipe:
+        x = fn.external_source(name="x")
+        spec = fn.spectrogram(x.gpu(), nfft=1024, window_length=1024, window_step=256)
+        mel = fn.mel_filter_bank(spec, nfilter=80, sample_rate=16000.0, freq_high=8000.0)
+        pipe.set_outputs(fn.to_decibels(mel, multiplier=10.0, cutoff_db=-80.0))
+    pipe.build()
+    frames = sum(len(s) // 256 + 1 for s in sigs)
+    for _ in range(args.warmup):
+        pipe.feed_input("x", sigs)
+        pipe.run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pipe.feed_input("x", sigs)
+        pipe.run()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    samples = sum(len(s) for s in sigs)
+    algo = {"SpectrogramKernel": 4 * samples + 4 * 513 * frames, "MelKernel": 4 * 513 * frames + 4 * 80 * frames,
+            "DecibelKernel": 8 * 80 * frames}
+    print(json.dumps({"metric": "utterances/sec spectrogram(1024)->mel(80)->dB b64 (incl. H2D of the signals)",
+                      "value": n * args.steps / el, "unit": "utterances/s", "n_gpus": 1, "steps": args.steps,
+                      "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
+                      "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                      "config": {"workload": "configs[3]: 64 mono signals, 16 kHz, 8-16 s", "frames": frames,
+                                 "mel_gemm_flops": 2 * 80 * 513 * frames},
+                      "roofline": {"bound": "hbm", "kernel": "see profiles/ (rocprofv3 kernel trace)", "achieved": None,
+                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                                   "algorithmic_bytes": algo}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,6 +250,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="imagenet", choices=["imagenet", "heavy_aug", "audio"],
+                    help="imagenet = the headline metric (default); heavy_aug / audio = configs[2] / configs[3] side benches")
     args = ap.parse_args()
 
     import torch
@@ -156,6 +267,11 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    if args.workload == "heavy_aug":
+        return bench_heavy_aug(args, device)
+    if args.workload == "audio":
+        return bench_audio(args, device)
 
     B = args.batch
     enc = make_dataset(rank * B, B)  # shard `rank` of `world` (contiguous, like loader.cc:78-87)
