@@ -30,6 +30,16 @@ class JpegIdctDesc(C.Structure):
                 ("quant", C.c_uint16 * 64)]
 
 
+class JpegHuffDesc(C.Structure):
+    _fields_ = [("ecs", C.c_void_p), ("clean", C.c_void_p), ("clean_len", C.c_void_p),
+                ("status", C.c_void_p), ("coef", C.c_void_p * 3), ("ecs_len", C.c_int32),
+                ("blocks_per_mcu", C.c_int32), ("mcus_x", C.c_int32), ("total_blocks", C.c_int32),
+                ("blocks_x", C.c_int32 * 3), ("h_samp", C.c_int32 * 3), ("v_samp", C.c_int32 * 3),
+                ("comp_of_block", C.c_uint8 * 12), ("h_of_block", C.c_uint8 * 12),
+                ("v_of_block", C.c_uint8 * 12), ("dc_sel", C.c_uint8 * 4), ("ac_sel", C.c_uint8 * 4),
+                ("bits", (C.c_uint8 * 16) * 4), ("vals", (C.c_uint8 * 256) * 4)]
+
+
 class JpegColorDesc(C.Structure):
     _fields_ = [("plane", C.c_void_p * 3), ("pitch", C.c_int32 * 3), ("h_samp", C.c_int32 * 3),
                 ("v_samp", C.c_int32 * 3), ("down_w", C.c_int32 * 3), ("down_h", C.c_int32 * 3),
@@ -112,6 +122,16 @@ class JpegInfo(C.Structure):
                 ("coef_elems", C.c_int64 * 4)]
 
 
+class JpegScan(C.Structure):
+    _fields_ = [("eligible", C.c_int32), ("blocks_per_mcu", C.c_int32), ("mcus_x", C.c_int32),
+                ("mcus_y", C.c_int32), ("ecs_offset", C.c_int64), ("ecs_length", C.c_int64),
+                ("comp_of_block", C.c_uint8 * 10), ("h_of_block", C.c_uint8 * 10),
+                ("v_of_block", C.c_uint8 * 10), ("dc_sel", C.c_uint8 * 4), ("ac_sel", C.c_uint8 * 4),
+                ("dc_bits", (C.c_uint8 * 16) * 4), ("dc_vals", (C.c_uint8 * 256) * 4),
+                ("ac_bits", (C.c_uint8 * 16) * 4), ("ac_vals", (C.c_uint8 * 256) * 4),
+                ("quant", (C.c_uint16 * 64) * 4)]
+
+
 class PhiloxState(C.Structure):
     _fields_ = [("key", C.c_uint64), ("ctr", C.c_uint64 * 2), ("phase", C.c_int32)]
 
@@ -127,7 +147,7 @@ _KERNEL_SYMBOLS = [
     "daliamdEventDestroy", "daliamdEventRecord", "daliamdEventSynchronize", "daliamdEventElapsedMs",
     "daliamdMalloc", "daliamdFree", "daliamdHostAlloc", "daliamdHostFree", "daliamdMemcpyH2DAsync",
     "daliamdMemcpyD2HAsync", "daliamdMemcpyD2DAsync", "daliamdMemsetAsync",
-    "daliamdJpegIdctSetup", "daliamdJpegIdctRun", "daliamdJpegColorSetup", "daliamdJpegColorRun",
+    "daliamdJpegIdctSetup", "daliamdJpegIdctRun", "daliamdJpegHuffmanRun", "daliamdJpegColorSetup", "daliamdJpegColorRun",
     "daliamdResampleSetup", "daliamdResampleRun", "daliamdCmnSetup", "daliamdCmnRun",
     "daliamdWarpAffineSetup", "daliamdWarpAffineRun", "daliamdGaussianWindow", "daliamdGaussianBlurSetup",
     "daliamdGaussianBlurRun", "daliamdColorTwistMatrix", "daliamdPointwiseSetup", "daliamdPointwiseRun",
@@ -137,6 +157,7 @@ _KERNEL_SYMBOLS = [
 
 _HOST_SYMBOLS = [
     "daliamdHostGetLastErrorMessage", "daliamdJpegParse", "daliamdJpegDecodeCoefficients",
+    "daliamdJpegAnalyzeScan",
     "daliamdRandomCropBatch", "daliamdCoinFlipBatch", "daliamdPhiloxAdvanceSequence",
     "daliamdPhiloxStateToString", "daliamdPhiloxStateFromString", "daliamdPhiloxGenerate",
     "daliamdCmnNormArgs", "daliamdCropAnchor",

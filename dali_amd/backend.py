@@ -138,6 +138,112 @@ class JpegBatchPlan:
         else:
             list(_thread_pool(num_threads).map(one, range(self.n)))
 
+    def analyze_scans(self):
+        """Scan analysis of every stream (daliamdJpegAnalyzeScan): eligibility for the GPU Huffman decoder,
+        Huffman/quantisation tables, position of the entropy-coded segment."""
+        host = capi.host()
+        self.scans = (capi.JpegScan * max(self.n, 1))()
+        for i, e in enumerate(self.encoded):
+            capi.check_host(host.daliamdJpegAnalyzeScan(e.ctypes.data_as(C.c_void_p), C.c_size_t(e.size),
+                                                        C.byref(self.infos[i]), C.byref(self.scans[i])))
+        self.scan = np.frombuffer(self.scans, dtype=np.dtype(capi.JpegScan))[:self.n]
+        self.gpu_eligible = self.scan["eligible"].astype(bool) if self.n else np.zeros(0, bool)
+        return self.gpu_eligible
+
+    def entropy_decode_gpu(self, coef_dev, num_threads=None):
+        """Entropy-decodes the batch into `coef_dev` (int16 device tensor of self.coef_elems elements):
+        eligible streams on the GPU (daliamdJpegHuffmanRun), the rest (progressive, restart markers,
+        multi-scan) on the host.  Returns the device status tensor (one int32 per GPU-decoded stream) and the
+        list of sample indices it refers to; call `check_gpu_status` once the stream is synchronised."""
+        lib = capi.kernels()
+        dev = coef_dev.device
+        if not hasattr(self, "scan"):
+            self.analyze_scans()
+        sel = np.nonzero(self.gpu_eligible)[0]
+        rest = np.nonzero(~self.gpu_eligible)[0]
+        sc, inf = self.scan, self.inf
+        keep = []
+        # quantisation tables of the GPU-decoded streams come from the scan analysis
+        self.quant[sel] = sc["quant"][sel, :3]
+        if len(sel):
+            ecs_len = sc["ecs_length"][sel].astype(np.int64)
+            ecs_off = np.concatenate([[0], np.cumsum(_align(ecs_len, 16))[:-1]])
+            clean_off = np.concatenate([[0], np.cumsum(_align(ecs_len + 32, 16))[:-1]])
+            total_in = int(_align(ecs_len, 16).sum())
+            total_clean = int(_align(ecs_len + 32, 16).sum())
+            stage = torch.empty(total_in, dtype=torch.uint8, pin_memory=True)
+            stage_np = stage.numpy()
+            for j, i in enumerate(sel):
+                o, l = int(sc["ecs_offset"][i]), int(ecs_len[j])
+                stage_np[ecs_off[j]:ecs_off[j] + l] = self.encoded[i][o:o + l]
+            ecs_dev = stage.to(dev, non_blocking=True)
+            clean_dev = torch.empty(total_clean, dtype=torch.uint8, device=dev)
+            aux = torch.zeros(2 * len(sel), dtype=torch.int32, device=dev)   # [clean_len..., status...]
+            coef_dev.zero_()
+            d = np.zeros(len(sel), np.dtype(capi.JpegHuffDesc))
+            d["ecs"] = ecs_dev.data_ptr() + ecs_off
+            d["clean"] = clean_dev.data_ptr() + clean_off
+            d["clean_len"] = aux.data_ptr() + 4 * np.arange(len(sel))
+            d["status"] = aux.data_ptr() + 4 * (len(sel) + np.arange(len(sel)))
+            d["coef"] = np.where(self.comp_mask[sel], coef_dev.data_ptr() + 2 * self.coef_off[sel], 0)
+            d["ecs_len"] = ecs_len
+            d["blocks_per_mcu"] = sc["blocks_per_mcu"][sel]
+            d["mcus_x"] = sc["mcus_x"][sel]
+            d["total_blocks"] = sc["mcus_x"][sel] * sc["mcus_y"][sel] * sc["blocks_per_mcu"][sel]
+            d["blocks_x"] = inf["blocks_x"][sel, :3]
+            d["h_samp"] = inf["h_samp"][sel, :3]
+            d["v_samp"] = inf["v_samp"][sel, :3]
+            d["comp_of_block"][:, :10] = sc["comp_of_block"][sel]
+            d["h_of_block"][:, :10] = sc["h_of_block"][sel]
+            d["v_of_block"][:, :10] = sc["v_of_block"][sel]
+            d["dc_sel"] = sc["dc_sel"][sel]
+            d["ac_sel"] = sc["ac_sel"][sel]
+            d["bits"][:, 0:2] = sc["dc_bits"][sel, 0:2]
+            d["bits"][:, 2:4] = sc["ac_bits"][sel, 0:2]
+            d["vals"][:, 0:2] = sc["dc_vals"][sel, 0:2]
+            d["vals"][:, 2:4] = sc["ac_vals"][sel, 0:2]
+            d_dev = _uploader.upload(d, dev)
+            capi.check(lib.daliamdJpegHuffmanRun(current_stream_ptr(dev), C.c_void_p(d_dev.data_ptr()), len(sel)))
+            status = aux[len(sel):]
+            keep += [stage, ecs_dev, clean_dev, aux, d_dev]
+        else:
+            status = torch.zeros(0, dtype=torch.int32, device=dev)
+        if len(rest):
+            host = capi.host()
+
+            def one(i):
+                n_el = int(self.inf["coef_elems"][i, :3][self.comp_mask[i]].sum())
+                buf = torch.empty(n_el, dtype=torch.int16, pin_memory=True)
+                ptrs = (C.c_void_p * 4)()
+                for c in range(self.infos[i].num_components):
+                    ptrs[c] = buf.data_ptr() + 2 * int(self.coef_off[i, c] - self.coef_off[i, 0])
+                e = self.encoded[i]
+                rc = host.daliamdJpegDecodeCoefficients(e.ctypes.data_as(C.c_void_p), C.c_size_t(e.size),
+                                                        C.byref(self.infos[i]), ptrs,
+                                                        self.quant[i].ctypes.data_as(C.c_void_p))
+                if rc:
+                    msg = host.daliamdHostGetLastErrorMessage()
+                    raise capi.DaliAmdError(f"sample {i}: {msg.decode() if msg else 'decode failed'}")
+                return buf
+
+            bufs = list(_thread_pool(num_threads).map(one, rest)) if len(rest) > 1 else [one(int(rest[0]))]
+            for i, buf in zip(rest, bufs):
+                o = int(self.coef_off[i, 0])
+                coef_dev[o:o + buf.numel()].copy_(buf, non_blocking=True)
+            keep += bufs
+        self._huff_keep = keep
+        self._huff_sel = sel
+        return status, sel
+
+    def check_gpu_status(self, status):
+        """Raises for GPU-decoded streams whose entropy-coded segment was short of blocks (corrupt / truncated)."""
+        st = status.cpu().numpy()
+        bad = np.nonzero(st)[0]
+        if len(bad):
+            i = int(self._huff_sel[bad[0]])
+            raise capi.DaliAmdError(f"sample {i}: corrupt JPEG data: the entropy-coded segment ends before the last "
+                                    f"MCU (GPU Huffman status {int(st[bad[0]])})")
+
     def build_descs(self, coef_dev, planes_dev, out_dev):
         """IDCT + colour descriptor tables (numpy structured arrays mirroring the C structs)."""
         lib = capi.kernels()
@@ -202,24 +308,36 @@ def jpeg_gpu_stage(plan, coef_dev, planes_dev, out_dev, descs=None, split_events
     return idct_dev, color_dev
 
 
-def decode_jpeg_batch(encoded, device="cuda", num_threads=None, out_pitch_align=16):
-    """Hybrid decode of a batch of JPEG byte strings -> list of u8 HWC RGB device tensors.
+def decode_jpeg_batch(encoded, device="cuda", num_threads=None, out_pitch_align=16, huffman="gpu"):
+    """Decodes a batch of JPEG byte strings -> list of u8 HWC RGB device tensors.
 
-    Host: header parse + Huffman (thread pool) into pinned memory; device: everything else."""
+    huffman="gpu": entropy decoding on the device for baseline single-scan streams (host for the rest);
+    huffman="host": header parse + Huffman on the host thread pool into pinned memory (the hybrid path).
+    Dequantisation, IDCT, upsampling and colour conversion always run on the device."""
     device = torch.device(device)
     plan = JpegBatchPlan(encoded, out_pitch_align)
-    coef_host = torch.empty(max(plan.coef_elems, 1), dtype=torch.int16, pin_memory=True)
-    plan.entropy_decode(coef_host, num_threads)
-    coef_dev = coef_host.to(device, non_blocking=True)
+    status = None
+    if huffman == "gpu":
+        coef_host = None
+        coef_dev = torch.empty(max(plan.coef_elems, 1), dtype=torch.int16, device=device)
+        status, _ = plan.entropy_decode_gpu(coef_dev, num_threads)
+    elif huffman == "host":
+        coef_host = torch.empty(max(plan.coef_elems, 1), dtype=torch.int16, pin_memory=True)
+        plan.entropy_decode(coef_host, num_threads)
+        coef_dev = coef_host.to(device, non_blocking=True)
+    else:
+        raise ValueError(f"huffman must be 'gpu' or 'host', got {huffman!r}")
     planes = torch.empty(max(plan.plane_bytes, 1), dtype=torch.uint8, device=device)
     out = torch.empty(max(plan.out_bytes, 1), dtype=torch.uint8, device=device)
     keep = jpeg_gpu_stage(plan, coef_dev, planes, out)
     views = plan.output_views(out)
+    if status is not None and status.numel():
+        plan.check_gpu_status(status)   # synchronises
     # keep scratch alive until the stream has consumed it
-    for t in (coef_dev, planes, coef_host) + tuple(keep):
+    for t in (coef_dev, planes) + tuple(keep):
         if t.is_cuda:
             t.record_stream(torch.cuda.current_stream(device))
-    plan._keepalive = (coef_host,)
+    plan._keepalive = (coef_host, coef_dev)
     return views, plan
 
 

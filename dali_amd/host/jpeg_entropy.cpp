@@ -174,6 +174,9 @@ struct Decoder {
   int last_dc[4], eobrun = 0;
   int16_t *coef[4] = {};
   const daliamdJpegInfo *expect = nullptr;  // geometry the caller sized the coefficient arrays for
+  bool analyze_only = false;                // stop at the first SOS and report it instead of decoding
+  int num_scans = 0;
+  size_t first_ecs = 0;
 
   static int R16(const uint8_t *p) { return (p[0] << 8) | p[1]; }
 
@@ -498,6 +501,8 @@ struct Decoder {
           Ss = p[1 + 2 * ns]; Se = p[2 + 2 * ns]; Ah = p[3 + 2 * ns] >> 4; Al = p[3 + 2 * ns] & 15;
           if (!progressive) { Ss = 0; Se = 63; Ah = Al = 0; }
           if (Se > 63 || Ss > Se || Al > 13) return Fail("bad spectral selection / approximation");
+          num_scans++;
+          if (analyze_only) { first_ecs = pos; return 0; }
           rc = DecodeScan();
           break;
         }
@@ -548,6 +553,53 @@ int daliamdJpegParse(const uint8_t *data, size_t size, daliamdJpegInfo *info) {
   // colour-space markers (APP14) may legally follow SOF only in exotic files; the common
   // APPn-before-SOF order is what the header probe covers.
   FillInfo(d, info);
+  return 0;
+}
+
+int daliamdJpegAnalyzeScan(const uint8_t *data, size_t size, const daliamdJpegInfo *info, daliamdJpegScan *scan) {
+  using namespace daliamd_host;
+  if (!data || !info || !scan) return Fail("daliamdJpegAnalyzeScan: NULL argument");
+  memset(scan, 0, sizeof(*scan));
+  Decoder d;
+  d.data = data; d.size = size;
+  d.analyze_only = true;
+  int rc = d.Run(false);
+  if (rc) return rc;
+  if (d.num_scans != 1 || d.progressive || d.restart_interval != 0 || d.ns != d.ncomp || (d.ncomp != 1 && d.ncomp != 3))
+    return 0;  // not eligible (scan->eligible stays 0)
+  for (int s = 0; s < d.ns; s++)
+    if (d.scomp[s] != s) return 0;  // components out of order: leave it to the host decoder
+  int bpm = 0;
+  for (int c = 0; c < d.ncomp; c++) {
+    if (d.std_[c] > 1 || d.sta[c] > 1) return 0;  // the kernel keeps two DC + two AC tables (baseline limit)
+    if (!d.dc[d.std_[c]].present || !d.ac[d.sta[c]].present || !d.qt_present[d.comp[c].tq]) return 0;
+    for (int v = 0; v < d.comp[c].v; v++)
+      for (int h = 0; h < d.comp[c].h; h++) {
+        if (bpm >= 10) return 0;
+        scan->comp_of_block[bpm] = (uint8_t)c; scan->h_of_block[bpm] = (uint8_t)h; scan->v_of_block[bpm] = (uint8_t)v;
+        bpm++;
+      }
+    scan->dc_sel[c] = (uint8_t)d.std_[c]; scan->ac_sel[c] = (uint8_t)d.sta[c];
+    for (int k = 0; k < 64; k++) scan->quant[c][kZZ.v[k]] = d.qt[d.comp[c].tq][k];
+  }
+  for (int t = 0; t < 4; t++) {
+    if (d.dc[t].present) { memcpy(scan->dc_bits[t], d.dc[t].bits + 1, 16); memcpy(scan->dc_vals[t], d.dc[t].vals, 256); }
+    if (d.ac[t].present) { memcpy(scan->ac_bits[t], d.ac[t].bits + 1, 16); memcpy(scan->ac_vals[t], d.ac[t].vals, 256); }
+  }
+  scan->blocks_per_mcu = bpm;
+  scan->mcus_x = (d.width + 8 * d.hmax - 1) / (8 * d.hmax);
+  scan->mcus_y = (d.height + 8 * d.vmax - 1) / (8 * d.vmax);
+  // entropy-coded segment: from the end of the SOS header to the next real marker
+  size_t q = d.first_ecs;
+  while (q + 1 < size) {
+    if (data[q] == 0xFF && data[q + 1] != 0 && data[q + 1] != 0xFF) break;
+    q++;
+  }
+  if (q + 1 >= size) q = size;
+  if (q < size && data[q] == 0xFF && data[q + 1] >= 0xD0 && data[q + 1] <= 0xD7) return 0;  // RST without DRI: host path
+  scan->ecs_offset = (int64_t)d.first_ecs;
+  scan->ecs_length = (int64_t)(q - d.first_ecs);
+  scan->eligible = 1;
   return 0;
 }
 

@@ -50,6 +50,24 @@ DALIAMD_HOST_API int daliamdJpegParse(const uint8_t *data, size_t size, daliamdJ
 DALIAMD_HOST_API int daliamdJpegDecodeCoefficients(const uint8_t *data, size_t size, const daliamdJpegInfo *info,
                                                   int16_t *const coef[4], uint16_t *quant);
 
+
+/* Scan analysis for the GPU entropy decoder (libdali_amd_kernels: daliamdJpegHuffman*).  A stream is eligible
+ * when it is baseline (SOF0/SOF1), has ONE scan that interleaves all components (or is grayscale), and uses no
+ * restart markers; everything else (progressive, multi-scan, DRI) goes through daliamdJpegDecodeCoefficients. */
+typedef struct {
+  int32_t eligible;
+  int32_t blocks_per_mcu, mcus_x, mcus_y;
+  int64_t ecs_offset, ecs_length;     /* entropy-coded segment inside the stream, up to (excluding) the next marker */
+  uint8_t comp_of_block[10];          /* component of each block of an MCU, in decode order */
+  uint8_t h_of_block[10], v_of_block[10]; /* position of that block inside the component's MCU footprint */
+  uint8_t dc_sel[4], ac_sel[4];       /* per component: Huffman table slot (0..3) */
+  uint8_t dc_bits[4][16], dc_vals[4][256]; /* DHT contents per slot (class 0) */
+  uint8_t ac_bits[4][16], ac_vals[4][256]; /* DHT contents per slot (class 1) */
+  uint16_t quant[4][64];              /* per component, column-major element order (as daliamdJpegIdctDesc.quant) */
+} daliamdJpegScan;
+DALIAMD_HOST_API int daliamdJpegAnalyzeScan(const uint8_t *data, size_t size, const daliamdJpegInfo *info,
+                                           daliamdJpegScan *scan);
+
 /* ----------------------------------------------------------------------------------------------
  * Random machinery, bit-compatible with the reference's host code.
  *   Philox4x32-10                 include/dali/core/random/philox.h:27-160

@@ -101,6 +101,42 @@ DALIAMD_API daliamdResult_t daliamdJpegIdctSetup(daliamdJpegIdctDesc *descs_host
 DALIAMD_API daliamdResult_t daliamdJpegIdctRun(daliamdStream_t stream, const daliamdJpegIdctDesc *descs_dev,
                                                int n, int num_workgroups);
 
+/* ----------------------------------------------------------------------------------------------
+ * JPEG Huffman entropy decoding on the GPU (baseline, one interleaved scan, no restart markers).
+ * Replaces the GPU Huffman stage nvJPEG runs for device="mixed" when the stream is larger than
+ * hybrid_huffman_threshold (dali/operators/imgcodec/image_decoder.h:810-815,
+ * dali/operators/imgcodec/decoder_schema.cc "hybrid_huffman_threshold").  Output layout and values
+ * are those of daliamdJpegDecodeCoefficients (dali_amd_host.h), i.e. the input of daliamdJpegIdctRun.
+ * The caller fills the descriptor from the scan analysis (daliamdJpegAnalyzeScan) and
+ *   - uploads the entropy-coded segment (without the trailing marker) to `ecs`,
+ *   - zero-fills the coefficient arrays and `status` (daliamdMemsetAsync) before the launch,
+ *   - provides `clean`: ecs_len + 32 bytes of scratch, 4-byte aligned.
+ * After the launch *status is 0 on success, 2 when the segment holds fewer blocks than the frame
+ * header promises (truncated / corrupt stream: decode it with the host decoder to get the diagnosis).
+ * -------------------------------------------------------------------------------------------- */
+#define DALIAMD_JPEG_MAX_BLOCKS_PER_MCU 10
+typedef struct {
+  const uint8_t *ecs;      /* device: entropy-coded segment (still byte-stuffed)                  */
+  uint8_t *clean;          /* device scratch: un-stuffed stream                                    */
+  int32_t *clean_len;      /* device scratch: one int                                              */
+  int32_t *status;         /* device: one int, pre-zeroed                                          */
+  int16_t *coef[3];        /* device: per component [blocks_y][blocks_x][64], pre-zeroed           */
+  int32_t ecs_len;
+  int32_t blocks_per_mcu;  /* sum of h*v over the components                                       */
+  int32_t mcus_x;          /* MCUs per row                                                         */
+  int32_t total_blocks;    /* mcus_x * mcus_y * blocks_per_mcu                                     */
+  int32_t blocks_x[3];     /* allocated blocks per row of each component                           */
+  int32_t h_samp[3], v_samp[3];
+  uint8_t comp_of_block[12];  /* component of the k-th block of an MCU                             */
+  uint8_t h_of_block[12], v_of_block[12]; /* its position inside the component's MCU footprint     */
+  uint8_t dc_sel[4], ac_sel[4];  /* per component: table selector, 0 or 1                           */
+  uint8_t bits[4][16];     /* DHT code-length counts: [0],[1] = DC tables 0,1; [2],[3] = AC 0,1    */
+  uint8_t vals[4][256];    /* DHT symbol lists, same order                                         */
+} daliamdJpegHuffDesc;
+
+/* Two launches (byte un-stuffing, then the self-synchronising parallel decode); one workgroup per stream. */
+DALIAMD_API daliamdResult_t daliamdJpegHuffmanRun(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev, int n);
+
 typedef enum {
   DALIAMD_JPEG_GRAY = 0,   /* 1 component                                   */
   DALIAMD_JPEG_YCC = 1,    /* 3 components, YCbCr -> RGB                    */

@@ -1,4 +1,4 @@
-"""GPU parity: hybrid JPEG decode (host Huffman -> gfx950 IDCT / upsample / colour) vs the oracle.
+"""GPU parity: JPEG decode (GPU or host Huffman -> gfx950 IDCT / upsample / colour) vs the oracle.
 Integer arithmetic => bit-exact."""
 import numpy as np
 import pytest
@@ -17,7 +17,8 @@ def _decode_gpu(enc, **kw):
     return [v.cpu().numpy() for v in views]
 
 
-def test_decode_matches_oracle_all_modes():
+@pytest.mark.parametrize("huffman", ["gpu", "host"])
+def test_decode_matches_oracle_all_modes(huffman):
     rng = np.random.default_rng(7)
     enc = []
     for (h, w) in [(1, 1), (8, 8), (17, 23), (33, 47), (100, 75), (375, 500), (31, 17), (2, 3), (5, 64), (257, 255)]:
@@ -28,11 +29,79 @@ def test_decode_matches_oracle_all_modes():
             enc.append(encode_jpeg(synth_image(rng, h, w), **({"quality": 85} | kw)))
         enc.append(encode_jpeg(synth_image(rng, h, w, 1), 80))
         enc.append(encode_jpeg(synth_image(rng, h, w, 1), 80, progressive=True))
-    got = _decode_gpu(enc)
+    got = _decode_gpu(enc, huffman=huffman)
     for i, e in enumerate(enc):
         ref = O.jpeg_decode_rgb(e)
         assert got[i].shape == ref.shape
         assert np.array_equal(got[i], ref), f"sample {i}: max diff {np.abs(got[i].astype(int) - ref).max()}"
+
+
+def _coefficients(enc, huffman):
+    """Raw entropy-decoder output (int16 coefficient arrays) of both decoders."""
+    from dali_amd import backend as B
+    plan = B.JpegBatchPlan(enc)
+    if huffman == "gpu":
+        coef = torch.empty(max(plan.coef_elems, 1), dtype=torch.int16, device="cuda")
+        status, sel = plan.entropy_decode_gpu(coef)
+        torch.cuda.synchronize()
+        plan.check_gpu_status(status)
+        return coef.cpu().numpy(), plan
+    coef = torch.empty(max(plan.coef_elems, 1), dtype=torch.int16)
+    plan.entropy_decode(coef)
+    return coef.numpy(), plan
+
+
+def test_gpu_huffman_coefficients_equal_host_decoder():
+    """The GPU entropy decoder must reproduce the host decoder's coefficient arrays exactly: sizes from one
+    block to 6 MP, every subsampling, optimised Huffman tables, flat images (which never self-synchronise and
+    exercise the relaxation's worst case) and noise at quality 100 (long codes, many stuffed bytes)."""
+    rng = np.random.default_rng(99)
+    enc = []
+    for (h, w) in [(1, 1), (8, 8), (16, 16), (17, 23), (64, 48), (375, 500), (500, 375), (1080, 1920)]:
+        for sub in ("4:4:4", "4:2:2", "4:2:0", "4:1:1"):
+            enc.append(encode_jpeg(synth_image(rng, h, w), 90, subsampling=sub))
+        enc.append(encode_jpeg(synth_image(rng, h, w), 75, optimize=True))
+        enc.append(encode_jpeg(synth_image(rng, h, w, 1), 80))
+    enc.append(encode_jpeg(np.full((480, 640, 3), 128, np.uint8), 90))                      # flat: DC+EOB only
+    enc.append(encode_jpeg(np.full((333, 517, 3), (255, 0, 31), np.uint8), 50, subsampling="4:4:4"))
+    enc.append(encode_jpeg(rng.integers(0, 256, (512, 768, 3), dtype=np.uint8), 100))      # white noise, q100
+    enc.append(encode_jpeg(rng.integers(0, 256, (2000, 3000, 3), dtype=np.uint8), 95))     # ~6 MP, long stream
+    half = synth_image(rng, 300, 400)
+    half[:, 200:] = 7                                                                       # half flat
+    enc.append(encode_jpeg(half, 85))
+    got, plan = _coefficients(enc, "gpu")
+    assert plan.gpu_eligible.all()
+    ref, _ = _coefficients(enc, "host")
+    assert got.shape == ref.shape
+    if not np.array_equal(got, ref):
+        for i in range(plan.n):
+            a, b = int(plan.coef_off[i, 0]), int(plan.coef_off[i + 1, 0]) if i + 1 < plan.n else got.size
+            assert np.array_equal(got[a:b], ref[a:b]), \
+                f"sample {i} ({len(enc[i])} B): {np.count_nonzero(got[a:b] != ref[a:b])} coefficients differ, " \
+                f"first at {np.nonzero(got[a:b] != ref[a:b])[0][0]}"
+
+
+def test_gpu_huffman_eligibility_and_mixed_batches():
+    rng = np.random.default_rng(5)
+    img = synth_image(rng, 120, 160)
+    enc = [encode_jpeg(img, 85), encode_jpeg(img, 85, progressive=True), encode_jpeg(img, 85, restart_marker_blocks=4),
+           encode_jpeg(img[..., 0], 85), encode_jpeg(img, 85, optimize=True)]
+    from dali_amd import backend as B
+    plan = B.JpegBatchPlan(enc)
+    assert plan.analyze_scans().tolist() == [True, False, False, True, True]
+    got = _decode_gpu(enc, huffman="gpu")
+    for i, e in enumerate(enc):
+        assert np.array_equal(got[i], O.jpeg_decode_rgb(e)), f"sample {i}"
+
+
+def test_gpu_huffman_truncated_stream_raises():
+    from dali_amd import backend as B
+    from dali_amd._capi import DaliAmdError
+    rng = np.random.default_rng(6)
+    e = encode_jpeg(synth_image(rng, 200, 300), 85)
+    cut = e[:len(e) // 2] + b"\xff\xd9"
+    with pytest.raises(DaliAmdError, match="corrupt JPEG data"):
+        B.decode_jpeg_batch([cut], device="cuda", huffman="gpu")
 
 
 def test_decode_imagenet_like_batch_dense_and_padded_pitch():
