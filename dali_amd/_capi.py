@@ -31,10 +31,11 @@ class JpegIdctDesc(C.Structure):
 
 
 class JpegHuffDesc(C.Structure):
-    _fields_ = [("ecs", C.c_void_p), ("clean", C.c_void_p), ("clean_len", C.c_void_p),
-                ("status", C.c_void_p), ("coef", C.c_void_p * 3), ("ecs_len", C.c_int32),
-                ("blocks_per_mcu", C.c_int32), ("mcus_x", C.c_int32), ("total_blocks", C.c_int32),
-                ("blocks_x", C.c_int32 * 3), ("h_samp", C.c_int32 * 3), ("v_samp", C.c_int32 * 3),
+    _fields_ = [("ecs", C.c_void_p), ("scratch", C.c_void_p), ("status", C.c_void_p), ("coef", C.c_void_p * 3),
+                ("ecs_len", C.c_int32), ("blocks_per_mcu", C.c_int32), ("mcus_x", C.c_int32),
+                ("total_blocks", C.c_int32), ("blocks_x", C.c_int32 * 3), ("h_samp", C.c_int32 * 3),
+                ("v_samp", C.c_int32 * 3), ("tile_start", C.c_int32), ("num_tiles", C.c_int32),
+                ("seg_start", C.c_int32), ("num_segments", C.c_int32),
                 ("comp_of_block", C.c_uint8 * 12), ("h_of_block", C.c_uint8 * 12),
                 ("v_of_block", C.c_uint8 * 12), ("dc_sel", C.c_uint8 * 4), ("ac_sel", C.c_uint8 * 4),
                 ("bits", (C.c_uint8 * 16) * 4), ("vals", (C.c_uint8 * 256) * 4)]
@@ -147,7 +148,8 @@ _KERNEL_SYMBOLS = [
     "daliamdEventDestroy", "daliamdEventRecord", "daliamdEventSynchronize", "daliamdEventElapsedMs",
     "daliamdMalloc", "daliamdFree", "daliamdHostAlloc", "daliamdHostFree", "daliamdMemcpyH2DAsync",
     "daliamdMemcpyD2HAsync", "daliamdMemcpyD2DAsync", "daliamdMemsetAsync",
-    "daliamdJpegIdctSetup", "daliamdJpegIdctRun", "daliamdJpegHuffmanRun", "daliamdJpegColorSetup", "daliamdJpegColorRun",
+    "daliamdJpegIdctSetup", "daliamdJpegIdctRun", "daliamdJpegHuffmanScratchBytes", "daliamdJpegHuffmanSetup",
+    "daliamdJpegHuffmanRun", "daliamdJpegColorSetup", "daliamdJpegColorRun",
     "daliamdResampleSetup", "daliamdResampleRun", "daliamdCmnSetup", "daliamdCmnRun",
     "daliamdWarpAffineSetup", "daliamdWarpAffineRun", "daliamdGaussianWindow", "daliamdGaussianBlurSetup",
     "daliamdGaussianBlurRun", "daliamdColorTwistMatrix", "daliamdPointwiseSetup", "daliamdPointwiseRun",

@@ -150,64 +150,103 @@ class JpegBatchPlan:
         self.gpu_eligible = self.scan["eligible"].astype(bool) if self.n else np.zeros(0, bool)
         return self.gpu_eligible
 
+    def upload_streams(self, device):
+        """Copies the entropy-coded segments of the GPU-eligible streams to the device (16-byte aligned, one
+        pinned staging buffer, one H2D copy) and allocates the decoder's scratch.  Idempotent."""
+        if getattr(self, "_ecs_dev", None) is not None and self._ecs_dev.device == device:
+            return
+        lib = capi.kernels()
+        if not hasattr(self, "scan"):
+            self.analyze_scans()
+        sc = self.scan
+        sel = np.nonzero(self.gpu_eligible)[0]
+        self._huff_sel = sel
+        ecs_len = sc["ecs_length"][sel].astype(np.int64)
+        self._ecs_len = ecs_len
+        self._ecs_off = np.concatenate([[0], np.cumsum(_align(ecs_len, 16))[:-1]]).astype(np.int64)
+        need = np.zeros(len(sel), np.int64)
+        nb = C.c_size_t(0)
+        for j in range(len(sel)):
+            capi.check(lib.daliamdJpegHuffmanScratchBytes(int(ecs_len[j]), C.byref(nb)))
+            need[j] = nb.value
+        self._scratch_off = np.concatenate([[0], np.cumsum(need)[:-1]]).astype(np.int64)
+        stage = torch.empty(max(int(_align(ecs_len, 16).sum()), 16), dtype=torch.uint8, pin_memory=True)
+        stage_np = stage.numpy()
+        for j, i in enumerate(sel):
+            o, l = int(sc["ecs_offset"][i]), int(ecs_len[j])
+            stage_np[self._ecs_off[j]:self._ecs_off[j] + l] = self.encoded[i][o:o + l]
+        self._ecs_stage = stage
+        self._ecs_dev = stage.to(device, non_blocking=True)
+        self._scratch_dev = torch.empty(max(int(need.sum()), 256), dtype=torch.uint8, device=device)
+        self._huff_status = torch.zeros(max(len(sel), 1), dtype=torch.int32, device=device)
+        self.stream_bytes = int(ecs_len.sum())
+        self.huffman_scratch_bytes = int(need.sum())
+        # quantisation tables of the GPU-decoded streams come from the scan analysis
+        self.quant[sel] = sc["quant"][sel, :3]
+
+    def huffman_descs(self, coef_dev):
+        """daliamdJpegHuffDesc table of the GPU-eligible streams (numpy structured array) + the two grid sizes."""
+        lib = capi.kernels()
+        sc, inf, sel = self.scan, self.inf, self._huff_sel
+        m = len(sel)
+        d = np.zeros(max(m, 1), np.dtype(capi.JpegHuffDesc))[:m]
+        d["ecs"] = self._ecs_dev.data_ptr() + self._ecs_off
+        d["scratch"] = self._scratch_dev.data_ptr() + self._scratch_off
+        d["status"] = self._huff_status.data_ptr() + 4 * np.arange(m)
+        d["coef"] = np.where(self.comp_mask[sel], coef_dev.data_ptr() + 2 * self.coef_off[sel], 0)
+        d["ecs_len"] = self._ecs_len
+        d["blocks_per_mcu"] = sc["blocks_per_mcu"][sel]
+        d["mcus_x"] = sc["mcus_x"][sel]
+        d["total_blocks"] = sc["mcus_x"][sel] * sc["mcus_y"][sel] * sc["blocks_per_mcu"][sel]
+        d["blocks_x"] = inf["blocks_x"][sel, :3]
+        d["h_samp"] = inf["h_samp"][sel, :3]
+        d["v_samp"] = inf["v_samp"][sel, :3]
+        d["comp_of_block"][:, :10] = sc["comp_of_block"][sel]
+        d["h_of_block"][:, :10] = sc["h_of_block"][sel]
+        d["v_of_block"][:, :10] = sc["v_of_block"][sel]
+        d["dc_sel"] = sc["dc_sel"][sel]
+        d["ac_sel"] = sc["ac_sel"][sel]
+        d["bits"][:, 0:2] = sc["dc_bits"][sel, 0:2]
+        d["bits"][:, 2:4] = sc["ac_bits"][sel, 0:2]
+        d["vals"][:, 0:2] = sc["dc_vals"][sel, 0:2]
+        d["vals"][:, 2:4] = sc["ac_vals"][sel, 0:2]
+        ntiles, nsegs = C.c_int(0), C.c_int(0)
+        capi.check(lib.daliamdJpegHuffmanSetup(d.ctypes.data_as(C.c_void_p), m, C.byref(ntiles), C.byref(nsegs)))
+        return d, ntiles.value, nsegs.value
+
+    def run_gpu_huffman(self, coef_dev, descs=None, events=None):
+        """Zero-fills the coefficient arrays and launches the GPU entropy decoder for the uploaded streams on the
+        current stream.  events: optional (before, after) events for timing."""
+        lib = capi.kernels()
+        dev = coef_dev.device
+        m = len(self._huff_sel)
+        if descs is None:
+            descs = self.huffman_descs(coef_dev)
+        table, ntiles, nsegs = descs
+        d_dev = _uploader.upload(table, dev) if m else None
+        s = current_stream_ptr(dev)
+        if events:
+            events[0].record()
+        capi.check(lib.daliamdMemsetAsync(C.c_void_p(coef_dev.data_ptr()), 0,
+                                          C.c_size_t(coef_dev.numel() * coef_dev.element_size()), s))
+        if m:
+            capi.check(lib.daliamdJpegHuffmanRun(s, C.c_void_p(d_dev.data_ptr()), m, ntiles, nsegs))
+        if events:
+            events[1].record()
+        self._huff_keep = [d_dev]
+        return self._huff_status[:m]
+
     def entropy_decode_gpu(self, coef_dev, num_threads=None):
         """Entropy-decodes the batch into `coef_dev` (int16 device tensor of self.coef_elems elements):
         eligible streams on the GPU (daliamdJpegHuffmanRun), the rest (progressive, restart markers,
         multi-scan) on the host.  Returns the device status tensor (one int32 per GPU-decoded stream) and the
         list of sample indices it refers to; call `check_gpu_status` once the stream is synchronised."""
-        lib = capi.kernels()
         dev = coef_dev.device
-        if not hasattr(self, "scan"):
-            self.analyze_scans()
-        sel = np.nonzero(self.gpu_eligible)[0]
+        self.upload_streams(dev)
+        sel = self._huff_sel
         rest = np.nonzero(~self.gpu_eligible)[0]
-        sc, inf = self.scan, self.inf
+        status = self.run_gpu_huffman(coef_dev)
         keep = []
-        # quantisation tables of the GPU-decoded streams come from the scan analysis
-        self.quant[sel] = sc["quant"][sel, :3]
-        if len(sel):
-            ecs_len = sc["ecs_length"][sel].astype(np.int64)
-            ecs_off = np.concatenate([[0], np.cumsum(_align(ecs_len, 16))[:-1]])
-            clean_off = np.concatenate([[0], np.cumsum(_align(ecs_len + 32, 16))[:-1]])
-            total_in = int(_align(ecs_len, 16).sum())
-            total_clean = int(_align(ecs_len + 32, 16).sum())
-            stage = torch.empty(total_in, dtype=torch.uint8, pin_memory=True)
-            stage_np = stage.numpy()
-            for j, i in enumerate(sel):
-                o, l = int(sc["ecs_offset"][i]), int(ecs_len[j])
-                stage_np[ecs_off[j]:ecs_off[j] + l] = self.encoded[i][o:o + l]
-            ecs_dev = stage.to(dev, non_blocking=True)
-            clean_dev = torch.empty(total_clean, dtype=torch.uint8, device=dev)
-            aux = torch.zeros(2 * len(sel), dtype=torch.int32, device=dev)   # [clean_len..., status...]
-            coef_dev.zero_()
-            d = np.zeros(len(sel), np.dtype(capi.JpegHuffDesc))
-            d["ecs"] = ecs_dev.data_ptr() + ecs_off
-            d["clean"] = clean_dev.data_ptr() + clean_off
-            d["clean_len"] = aux.data_ptr() + 4 * np.arange(len(sel))
-            d["status"] = aux.data_ptr() + 4 * (len(sel) + np.arange(len(sel)))
-            d["coef"] = np.where(self.comp_mask[sel], coef_dev.data_ptr() + 2 * self.coef_off[sel], 0)
-            d["ecs_len"] = ecs_len
-            d["blocks_per_mcu"] = sc["blocks_per_mcu"][sel]
-            d["mcus_x"] = sc["mcus_x"][sel]
-            d["total_blocks"] = sc["mcus_x"][sel] * sc["mcus_y"][sel] * sc["blocks_per_mcu"][sel]
-            d["blocks_x"] = inf["blocks_x"][sel, :3]
-            d["h_samp"] = inf["h_samp"][sel, :3]
-            d["v_samp"] = inf["v_samp"][sel, :3]
-            d["comp_of_block"][:, :10] = sc["comp_of_block"][sel]
-            d["h_of_block"][:, :10] = sc["h_of_block"][sel]
-            d["v_of_block"][:, :10] = sc["v_of_block"][sel]
-            d["dc_sel"] = sc["dc_sel"][sel]
-            d["ac_sel"] = sc["ac_sel"][sel]
-            d["bits"][:, 0:2] = sc["dc_bits"][sel, 0:2]
-            d["bits"][:, 2:4] = sc["ac_bits"][sel, 0:2]
-            d["vals"][:, 0:2] = sc["dc_vals"][sel, 0:2]
-            d["vals"][:, 2:4] = sc["ac_vals"][sel, 0:2]
-            d_dev = _uploader.upload(d, dev)
-            capi.check(lib.daliamdJpegHuffmanRun(current_stream_ptr(dev), C.c_void_p(d_dev.data_ptr()), len(sel)))
-            status = aux[len(sel):]
-            keep += [stage, ecs_dev, clean_dev, aux, d_dev]
-        else:
-            status = torch.zeros(0, dtype=torch.int32, device=dev)
         if len(rest):
             host = capi.host()
 
@@ -231,8 +270,7 @@ class JpegBatchPlan:
                 o = int(self.coef_off[i, 0])
                 coef_dev[o:o + buf.numel()].copy_(buf, non_blocking=True)
             keep += bufs
-        self._huff_keep = keep
-        self._huff_sel = sel
+        self._huff_keep += keep
         return status, sel
 
     def check_gpu_status(self, status):

@@ -5,36 +5,247 @@
 // column-major coefficient layout the host decoder (dali_amd/host/jpeg_entropy.cpp) produces, so results are
 // bit-identical by construction and the IDCT kernel does not care who decoded the stream.
 //
-// Algorithm: self-synchronising parallel decode (the entropy-coded segment is one long serial bit stream):
-//   kernel 1  UnstuffKernel   one workgroup per image removes the 0xFF00 byte stuffing (count / scan / scatter)
-//   kernel 2  HuffmanDecodeKernel    one workgroup (1024 lanes) per image:
-//     a) lane i takes the i-th slice of the clean stream and decodes the symbols that START in its slice from a
-//        guessed state (bit position = slice start, block-in-MCU 0, zig-zag index 0); lane 0 has the true state;
-//     b) relaxation: lane i publishes the state it reached to lane i+1; lanes whose input changed decode again.
-//        Huffman streams re-synchronise after a few symbols, so this converges in a handful of rounds; since
-//        lane 0 is right from the start, round r fixes at least lane r, so the loop is bounded by the lane count
-//        and needs no failure path;
-//     c) an exclusive scan of the completed-block counts gives every lane its first block ordinal;
-//     d) write pass: lanes decode once more and scatter the non-zero coefficients (the buffer is pre-zeroed);
-//        DC differences are written as lane-local running sums per component;
-//     e) an exclusive scan per component of the lanes' DC sums turns them into absolute DC values.
-// HBM traffic: the stream is read a few times (L2 resident: <= 0.5 MB per image) + sparse 2-byte coefficient stores.
+// The entropy-coded segment of an image is ONE serial bit stream; the decoder state is (bit position, block index
+// inside the MCU, zig-zag index).  Parallelism comes from self-synchronisation: a decoder started from a guessed
+// state at an arbitrary byte falls into step with the true decoder after a while.  Work is cut into pieces whose
+// size does not depend on the image (so a batch with one 500 KB stream and many 50 KB streams still fills the chip):
+//
+//   tile     16 KB of the stuffed stream    (un-stuffing, 1024 lanes x 16 bytes)
+//   slice    256 bytes of the clean stream  (one decoder lane)
+//   segment  116 slices = 29 KB             (one 128-lane workgroup: 12 warm-up lanes + 116 slices)
+//
+//   1 UnstuffCountKernel    per tile: number of bytes that survive the removal of the 0xFF00 stuffing
+//   2 UnstuffScatterKernel  per tile: compaction through LDS to its final place in the clean stream
+//   3 BuildTablesKernel     per image: two-level code tables (11-bit first level, direct second level for the long
+//                           codes) + MCU geometry -> global scratch, copied into LDS by the decoding workgroups
+//   4 SyncKernel            per segment: every lane decodes its slice from a guessed state, then the relaxation
+//                           "publish the state you reached to the next lane, decode again if your input changed"
+//                           runs until nothing changes.  The 12 warm-up lanes replay the end of the previous
+//                           segment so that the first slice of the segment starts from the true state with
+//                           overwhelming probability.  No values are extracted in this pass.
+//   5 PropagateKernel       per image, serial over its segments: checks that every segment started from the state
+//                           its predecessor ended in (if not - pathological streams - repairs it with the same
+//                           relaxation, so correctness never depends on luck), assigns block ordinals
+//   6 WriteKernel           per segment: decodes once more from the now-known states and scatters the non-zero
+//                           coefficients (the arrays are pre-zeroed); DC differences as lane-local running sums
+//   7 DcFixKernel           per segment: prefix sums of the DC sums -> absolute DC values
+//
+// The decode loop is VALU-issue bound (a wave64 instruction occupies a SIMD16 for 4 cycles and divergent branches
+// execute the union of their bodies), hence: table entries carry (code length, magnitude bits, zig-zag advance), a
+// two-dword bit window with the next dword prefetched through the global (not flat) path, no loops on the rare paths.
+#include <cstring>
 #include "common.h"
 
 namespace daliamd {
 
-constexpr int kHuffThreads = 1024;
-constexpr int kFastBits = 9;
-constexpr int kMinSliceBytes = 32;
+constexpr int kTileThreads = 1024;
+constexpr int kTileBytes = kTileThreads * 16;
+constexpr int kSliceBytes = 256;
+constexpr int kSegThreads = 128;
+constexpr int kWarmLanes = 12;
+constexpr int kSegLanes = kSegThreads - kWarmLanes;
+constexpr int kSegBytes = kSegLanes * kSliceBytes;
+constexpr int kFastBits = 11;
+constexpr int kL2Entries = 1024;
+constexpr int kCleanPadBytes = 40;
 
-struct HuffLds {
-  uint16_t fast[4][1 << kFastBits];  // [0],[1] = DC tables 0,1; [2],[3] = AC tables 0,1; entry = (len << 8) | symbol
-  int32_t maxcode[4][18];
+// Explicit global address space: a generic pointer would make these `flat` accesses, which count against the LDS
+// counter as well and would serialise the table look-ups behind the stream prefetch.
+using GlobalWords = const uint32_t __attribute__((address_space(1)));
+using GlobalCoef = int16_t __attribute__((address_space(1)));
+using GlobalBytes = uint8_t __attribute__((address_space(1)));
+using GlobalU32 = uint32_t __attribute__((address_space(1)));
+
+// ------------------------------------------------------------------------------------------------ scratch layout
+struct LaneRec {     // one per slice
+  uint64_t in, out;  // packed decoder state at the start / end of the slice
+  int32_t nblk;      // blocks completed inside the slice
+  int32_t dc0, dc1, dc2, count;  // write pass: sums of the DC differences per component, number of DC symbols
+  int32_t reserved;
+};
+struct SegRec {  // one per segment
+  uint64_t out;  // state at the end of the segment
+  int32_t nblk_total, block_base;
+  int32_t dc_total[3];
+  int32_t reserved;
+};
+
+struct HuffTables {
+  uint16_t fast[4][1 << kFastBits];  // [0],[1] = DC tables 0,1; [2],[3] = AC tables 0,1
+  uint16_t l2[4][kL2Entries];        // codes longer than kFastBits, indexed by (16-bit code window) - l2_first
+  int32_t l2_first[4];
+  int32_t l2_size[4];                // entries in use; -1: the long codes span more than kL2Entries -> search
+  int32_t maxcode[4][18];            // canonical-code search tables (T.81 F.2.2.3), the fallback
   int32_t valoff[4][18];
   uint8_t vals[4][256];
   uint8_t zz[64];                    // zig-zag index -> column-major position
-  uint8_t blk_comp[12], blk_dc[12], blk_ac[12];  // per block of the MCU: component, DC slot, AC slot
+  uint8_t blk_comp[16];              // component of the k-th block of the MCU
+  int32_t blk_sx[12], blk_sy[12];    // coefficient-array stride (elements) per MCU column / MCU row
+  GlobalCoef *blk_base[12];          // address of that block in MCU (0, 0)
+  uint32_t dc_mask, ac_mask;         // bit k: table selector of the k-th block of the MCU
+  int32_t bpm, mcus_x, total_blocks, reserved[3];
 };
+static_assert(sizeof(HuffTables) % 16 == 0, "copied with 16-byte accesses");
+
+struct ScratchLayout {
+  size_t tile_kept, clean, tables, lanes, segs, total;
+};
+__host__ __device__ inline size_t AlignUp(size_t v, size_t a) { return (v + a - 1) / a * a; }
+__host__ __device__ inline ScratchLayout MakeLayout(int ecs_len, int num_tiles, int num_segments) {
+  ScratchLayout l;
+  size_t o = 16;  // [0]: int32 clean_len
+  l.tile_kept = o;
+  o += AlignUp(sizeof(int32_t) * (size_t)num_tiles, 16);
+  l.clean = o;
+  o += AlignUp((size_t)ecs_len + 64, 16);
+  l.tables = o;
+  o += sizeof(HuffTables);
+  l.lanes = o;
+  o += sizeof(LaneRec) * (size_t)num_segments * kSegLanes;
+  l.segs = o;
+  o += sizeof(SegRec) * (size_t)num_segments;
+  l.total = AlignUp(o, 256);
+  return l;
+}
+inline int NumTiles(int head, int len) {
+  int t = (head + len + kTileBytes - 1) / kTileBytes;
+  return t > 0 ? t : 1;
+}
+inline int NumSegments(int len) { return len > kSegBytes ? (len + kSegBytes - 1) / kSegBytes : 1; }
+
+struct ImageRef {
+  const daliamdJpegHuffDesc *d;
+  int local;  // tile / segment index inside the image
+};
+// workgroup -> (image, tile) / (image, segment); descriptors are sorted by their start indices
+template <bool TILES>
+__device__ __forceinline__ ImageRef FindImage(const daliamdJpegHuffDesc *descs, int n, int wg) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    int start = TILES ? descs[mid].tile_start : descs[mid].seg_start;
+    if (start <= wg) lo = mid; else hi = mid - 1;
+  }
+  return ImageRef{descs + lo, wg - (TILES ? descs[lo].tile_start : descs[lo].seg_start)};
+}
+
+// Exclusive scan of one int per lane over the workgroup (NW waves); returns the exclusive prefix, sets `total`.
+template <int NW>
+__device__ __forceinline__ int WorkgroupExclusiveScan(int v, int *wave_sums, int &total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    int t = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += t;
+  }
+  if (lane == 63) wave_sums[wave] = incl;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < NW; w++) {
+    int s = wave_sums[w];
+    if (w < wave) base += s;
+    tot += s;
+  }
+  __syncthreads();  // wave_sums may be reused by the caller's next scan
+  total = tot;
+  return base + incl - v;
+}
+
+// ------------------------------------------------------------------------------------------------ un-stuffing
+// 16 bytes of the stuffed stream per lane -> mask of the bytes that stay (bit j = byte j).
+struct TileChunk {
+  uint32_t w[4];
+  uint32_t keep;
+};
+__device__ __forceinline__ TileChunk LoadChunk(const daliamdJpegHuffDesc &d, int tile) {
+  const int head = (int)(reinterpret_cast<uintptr_t>(d.ecs) & 15);  // bytes between the 16-byte boundary and the segment
+  const int end = head + d.ecs_len;
+  const int g = tile * kTileBytes + (int)threadIdx.x * 16;
+  TileChunk c{{0, 0, 0, 0}, 0};
+  uint32_t prev = 0;
+  if (g < end) {
+    GlobalWords *p = (GlobalWords *)__builtin_assume_aligned((const void *)(d.ecs - head + g), 16);
+    c.w[0] = p[0]; c.w[1] = p[1]; c.w[2] = p[2]; c.w[3] = p[3];
+    if (g > head) prev = ((const GlobalBytes *)(d.ecs - head))[g - 1];
+  }
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    uint32_t b = (c.w[j >> 2] >> (8 * (j & 3))) & 255u;
+    bool valid = g + j >= head && g + j < end;
+    bool stuffed = b == 0 && prev == 0xFF && g + j > head;  // the first byte of the segment has no predecessor
+    if (valid && !stuffed) c.keep |= 1u << j;
+    prev = b;
+  }
+  return c;
+}
+
+__global__ __launch_bounds__(kTileThreads) void UnstuffCountKernel(const daliamdJpegHuffDesc *__restrict__ descs, int n) {
+  __shared__ int wave_sums[kTileThreads / 64];
+  const ImageRef r = FindImage<true>(descs, n, blockIdx.x);
+  const daliamdJpegHuffDesc &d = *r.d;
+  const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments);
+  TileChunk c = LoadChunk(d, r.local);
+  int total;
+  WorkgroupExclusiveScan<kTileThreads / 64>(__popc(c.keep), wave_sums, total);
+  if (threadIdx.x == 0) reinterpret_cast<int32_t *>(d.scratch + lay.tile_kept)[r.local] = total;
+}
+
+__global__ __launch_bounds__(kTileThreads) void UnstuffScatterKernel(const daliamdJpegHuffDesc *__restrict__ descs, int n) {
+  __shared__ uint32_t stage[kTileBytes / 4 + 4];
+  __shared__ int wave_sums[kTileThreads / 64];
+  const ImageRef r = FindImage<true>(descs, n, blockIdx.x);
+  const daliamdJpegHuffDesc &d = *r.d;
+  const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments);
+  const int tid = threadIdx.x;
+  // clean-stream position of this tile = bytes kept by the tiles before it
+  const int32_t *tile_kept = reinterpret_cast<const int32_t *>(d.scratch + lay.tile_kept);
+  int before = 0, base;
+  for (int t = tid; t < r.local; t += kTileThreads) before += tile_kept[t];
+  WorkgroupExclusiveScan<kTileThreads / 64>(before, wave_sums, base);
+  const int shift = base & 3;  // stage byte i <-> clean byte (base - shift) + i
+  TileChunk c = LoadChunk(d, r.local);
+  int total;
+  int o = shift + WorkgroupExclusiveScan<kTileThreads / 64>(__popc(c.keep), wave_sums, total);
+  uint8_t *stage_b = reinterpret_cast<uint8_t *>(stage);
+  if (c.keep == 0xFFFFu && (o & 3) == 0) {
+    uint32_t *p = stage + (o >> 2);  // common case: nothing to drop, dword aligned
+    p[0] = c.w[0]; p[1] = c.w[1]; p[2] = c.w[2]; p[3] = c.w[3];
+  } else {
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+      if (c.keep & (1u << j)) stage_b[o++] = (uint8_t)(c.w[j >> 2] >> (8 * (j & 3)));
+  }
+  __syncthreads();
+  GlobalBytes *dst_b = (GlobalBytes *)(d.scratch + lay.clean) + (base - shift);
+  GlobalU32 *dst_w = (GlobalU32 *)dst_b;
+  const int lo = shift, hi = shift + total;  // stage bytes [lo, hi) belong to this tile
+  for (int w = tid; w * 4 < hi; w += kTileThreads) {
+    if (w * 4 >= lo && w * 4 + 4 <= hi) {
+      dst_w[w] = stage[w];
+    } else {  // first / last dword, shared with the neighbouring tiles: byte stores
+      for (int b = 0; b < 4; b++)
+        if (w * 4 + b >= lo && w * 4 + b < hi) dst_b[w * 4 + b] = stage_b[w * 4 + b];
+    }
+  }
+  if (r.local == d.num_tiles - 1) {
+    const int clean_len = base + total;
+    if (tid == 0) *reinterpret_cast<int32_t *>(d.scratch) = clean_len;
+    // all-ones padding: never a valid code, lets the bit window run past the end
+    if (tid < kCleanPadBytes) ((GlobalBytes *)(d.scratch + lay.clean))[clean_len + tid] = 0xFF;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ tables
+// Table entry: bits 0-6 zig-zag advance (1..64), 7-10 magnitude bits s, 11-15 code length.
+//   DC symbol (category s):  advance 1
+//   AC symbol (run r, size s): s != 0: r + 1;  ZRL (0xF0): 16;  any other s == 0 (EOB): 64 = "to the end of the block"
+__host__ __device__ __forceinline__ uint32_t MakeEntry(int len, int sym, bool is_dc) {
+  int s = sym & 15, r = sym >> 4;
+  int adv = is_dc ? 1 : (s ? r + 1 : (r == 15 ? 16 : 64));
+  return (uint32_t)((len << 11) | (s << 7) | adv);
+}
 
 // zig-zag scan order expressed in column-major block positions (= the transposed zig-zag)
 __device__ __constant__ uint8_t kZigZagColMajor[64] = {
@@ -42,301 +253,608 @@ __device__ __constant__ uint8_t kZigZagColMajor[64] = {
     28, 21, 14, 7, 15, 22, 29, 36, 43, 50, 57, 58, 51, 44, 37, 30, 23, 31, 38, 45, 52, 59, 60, 53, 46, 39, 47, 54, 61, 62,
     55, 63};
 
-// ------------------------------------------------------------------------------------------------ unstuff
-__global__ __launch_bounds__(kHuffThreads) void UnstuffKernel(const daliamdJpegHuffDesc *__restrict__ descs) {
-  __shared__ int scan[kHuffThreads];
+template <int THREADS>
+__device__ __forceinline__ void CopyTables(HuffTables &dst, const HuffTables *src) {
+  const uint4 *s = reinterpret_cast<const uint4 *>(src);
+  uint4 *t = reinterpret_cast<uint4 *>(&dst);
+  for (int i = threadIdx.x; i < (int)(sizeof(HuffTables) / 16); i += THREADS) t[i] = s[i];
+}
+
+__global__ __launch_bounds__(256) void BuildTablesKernel(const daliamdJpegHuffDesc *__restrict__ descs) {
+  __shared__ __attribute__((aligned(16))) HuffTables L;
   const daliamdJpegHuffDesc &d = descs[blockIdx.x];
+  const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments);
   const int tid = threadIdx.x;
-  const int len = d.ecs_len;
-  const int chunk = (len + kHuffThreads - 1) / kHuffThreads;
-  const int b0 = min(tid * chunk, len), b1 = min(b0 + chunk, len);
-  const uint8_t *src = d.ecs;
-  int stuffed = 0;
   {
-    uint8_t prev = b0 > 0 && b0 < b1 ? src[b0 - 1] : 0;
-    for (int i = b0; i < b1; i++) {
-      uint8_t b = src[i];
-      stuffed += (b == 0 && prev == 0xFF);
-      prev = b;
-    }
+    uint4 *z = reinterpret_cast<uint4 *>(&L);
+    for (int i = tid; i < (int)(sizeof(HuffTables) / 16); i += 256) z[i] = make_uint4(0, 0, 0, 0);
   }
-  scan[tid] = stuffed;
   __syncthreads();
-  for (int off = 1; off < kHuffThreads; off <<= 1) {  // Hillis-Steele inclusive scan
-    int v = tid >= off ? scan[tid - off] : 0;
-    __syncthreads();
-    scan[tid] += v;
-    __syncthreads();
+  if (tid < 64) L.zz[tid] = kZigZagColMajor[tid];
+  for (int t = tid; t < 4 * 256; t += 256) L.vals[t >> 8][t & 255] = d.vals[t >> 8][t & 255];
+  if (tid < 12 && tid < d.blocks_per_mcu) {
+    const int comp = d.comp_of_block[tid];
+    L.blk_comp[tid] = (uint8_t)comp;
+    L.blk_sx[tid] = d.h_samp[comp] * 64;
+    L.blk_sy[tid] = d.v_samp[comp] * d.blocks_x[comp] * 64;
+    L.blk_base[tid] = (GlobalCoef *)d.coef[comp] + ((size_t)d.v_of_block[tid] * d.blocks_x[comp] + d.h_of_block[tid]) * 64;
   }
-  uint8_t *dst = d.clean;
-  int o = b0 - (scan[tid] - stuffed);
-  {
-    uint8_t prev = b0 > 0 && b0 < b1 ? src[b0 - 1] : 0;
-    for (int i = b0; i < b1; i++) {
-      uint8_t b = src[i];
-      if (!(b == 0 && prev == 0xFF)) dst[o++] = b;
-      prev = b;
+  if (tid == 0) {
+    uint32_t dc_mask = 0, ac_mask = 0;
+    for (int k = 0; k < d.blocks_per_mcu; k++) {
+      int comp = d.comp_of_block[k];
+      dc_mask |= (uint32_t)(d.dc_sel[comp] & 1) << k;
+      ac_mask |= (uint32_t)(d.ac_sel[comp] & 1) << k;
     }
+    L.dc_mask = dc_mask;
+    L.ac_mask = ac_mask;
+    L.bpm = d.blocks_per_mcu;
+    L.mcus_x = d.mcus_x;
+    L.total_blocks = d.total_blocks;
   }
-  if (tid == kHuffThreads - 1) {
-    int clean_len = len - scan[kHuffThreads - 1];
-    *d.clean_len = clean_len;
-    for (int k = 0; k < 24; k++) dst[clean_len + k] = 0xFF;  // all-ones padding: never a valid code
+  __syncthreads();
+  if (tid < 4) {
+    // canonical code assignment (ITU-T T.81 Annex C): per code length the largest code and the symbol offset
+    int code = 0, p = 0;
+    int l2_first = 1 << 16, l2_end = 0;
+    for (int l = 1; l <= 16; l++) {
+      const int n = d.bits[tid][l - 1];
+      L.valoff[tid][l] = p - code;
+      if (n && l > kFastBits) {
+        if (l2_end == 0) l2_first = (code << (16 - l)) & 0xFFFF;
+        l2_end = ((code + n) << (16 - l));  // one past the last 16-bit window of the codes seen so far
+      }
+      p += n;
+      code += n;
+      L.maxcode[tid][l] = n ? code - 1 : -1;
+      code <<= 1;
+    }
+    const int size = l2_end ? l2_end - l2_first : 0;
+    L.l2_first[tid] = l2_first;
+    L.l2_size[tid] = size <= kL2Entries ? size : -1;  // -1: too spread out for the direct table, LongCode searches
   }
+  __syncthreads();
+  // every table entry is found independently: the shortest length whose code range contains the window's prefix
+  for (int idx = tid; idx < 4 * (1 << kFastBits); idx += 256) {
+    const int t = idx >> kFastBits, w = idx & ((1 << kFastBits) - 1);
+    uint16_t e = 0;
+    for (int l = 1; l <= kFastBits; l++) {
+      const int cd = w >> (kFastBits - l);
+      if (cd <= L.maxcode[t][l]) {
+        e = (uint16_t)MakeEntry(l, L.vals[t][(cd + L.valoff[t][l]) & 255], t < 2);
+        break;
+      }
+    }
+    L.fast[t][w] = e;
+  }
+  for (int idx = tid; idx < 4 * kL2Entries; idx += 256) {
+    const int t = idx / kL2Entries, j = idx % kL2Entries;
+    uint16_t e = 0;
+    if (j < L.l2_size[t]) {
+      const int w = L.l2_first[t] + j;
+      for (int l = kFastBits + 1; l <= 16; l++) {
+        const int cd = w >> (16 - l);
+        if (cd <= L.maxcode[t][l]) {
+          e = (uint16_t)MakeEntry(l, L.vals[t][(cd + L.valoff[t][l]) & 255], t < 2);
+          break;
+        }
+      }
+    }
+    L.l2[t][j] = e;
+  }
+  __syncthreads();
+  const uint4 *s = reinterpret_cast<const uint4 *>(&L);
+  uint4 *t = reinterpret_cast<uint4 *>(d.scratch + lay.tables);
+  for (int i = tid; i < (int)(sizeof(HuffTables) / 16); i += 256) t[i] = s[i];
 }
 
 // ------------------------------------------------------------------------------------------------ decode
-struct BitWindow {
-  const uint32_t *words;  // clean stream, dword aligned
-  uint64_t w;             // bits [32*k, 32*k + 64) of the stream, MSB first
-  int k;
-  __device__ __forceinline__ void Seek(uint32_t pos) {
-    k = (int)(pos >> 5);
-    uint32_t a = __builtin_bswap32(words[k]), b = __builtin_bswap32(words[k + 1]);
-    w = ((uint64_t)a << 32) | b;
-  }
-  // the 32 bits starting at bit `pos` (pos >= 32*k)
-  __device__ __forceinline__ uint32_t Peek32(uint32_t pos) {
-    uint32_t off = pos - ((uint32_t)k << 5);
-    while (off > 32) {
-      k++;
-      w = (w << 32) | __builtin_bswap32(words[k + 1]);
-      off -= 32;
-    }
-    return (uint32_t)((w << off) >> 32);
-  }
-};
-
 struct DecodeState {
   uint32_t pos;  // bit position of the next symbol
-  int c;         // block index inside the MCU
-  int z;         // zig-zag index of the next coefficient (0 = DC)
+  uint32_t c;    // block index inside the MCU
+  uint32_t z;    // zig-zag index of the next coefficient (0 = DC)
 };
 __device__ __forceinline__ uint64_t Pack(const DecodeState &s) {
   return ((uint64_t)s.pos << 16) | ((uint64_t)s.c << 8) | (uint64_t)s.z;
 }
 __device__ __forceinline__ DecodeState Unpack(uint64_t v) {
-  return DecodeState{(uint32_t)(v >> 16), (int)((v >> 8) & 255), (int)(v & 255)};
+  return DecodeState{(uint32_t)(v >> 16), (uint32_t)((v >> 8) & 255), (uint32_t)(v & 255)};
 }
+constexpr uint64_t kNoState = ~0ull;  // unpacks to a position past any stream
 
 struct DcAcc {
   int sum0 = 0, sum1 = 0, sum2 = 0;  // running sums of the DC differences this lane decoded, per component
   int count = 0;                     // number of DC symbols this lane decoded
 };
 
-__device__ __forceinline__ int16_t *BlockPtr(const daliamdJpegHuffDesc &d, const HuffLds &L, int ordinal) {
-  if (ordinal >= d.total_blocks) return nullptr;
-  const int bpm = d.blocks_per_mcu;
-  int mcu = ordinal / bpm, k = ordinal - mcu * bpm;
-  int cc = L.blk_comp[k];
-  int my = mcu / d.mcus_x, mx = mcu - my * d.mcus_x;
-  int bx = mx * d.h_samp[cc] + d.h_of_block[k], by = my * d.v_samp[cc] + d.v_of_block[k];
-  return d.coef[cc] + ((size_t)by * d.blocks_x[cc] + bx) * 64;
-}
-
-// Decodes the symbols that start in [st.pos, end_bits); returns the number of blocks completed.
-// WRITE: also scatters the coefficients, the block in progress at st being block ordinal `ord`.
-template <bool WRITE>
-__device__ __forceinline__ int DecodeRange(const daliamdJpegHuffDesc &d, const HuffLds &L, BitWindow &bw, DecodeState &st,
-                                           uint32_t end_bits, int ord, DcAcc &dc) {
-  int nblk = 0;
-  const int bpm = d.blocks_per_mcu;
-  uint32_t pos = st.pos;
-  int c = st.c, z = st.z;
-  bw.Seek(pos);
-  int16_t *blk = nullptr;
-  if (WRITE) blk = BlockPtr(d, L, ord);
-  while (pos < end_bits) {
-    uint32_t peek = bw.Peek32(pos);
-    int slot = z == 0 ? L.blk_dc[c] : L.blk_ac[c];
-    uint32_t e = L.fast[slot][peek >> (32 - kFastBits)];
-    int len, sym;
-    if (e) {
-      len = e >> 8;
-      sym = e & 255;
-    } else {
-      uint32_t code16 = peek >> 16;
-      len = 16;
-      sym = 0;  // invalid code (garbage start state or the padding): consume 16 bits, decode nothing
-      for (int l = kFastBits + 1; l <= 16; l++) {
-        int cd = (int)(code16 >> (16 - l));
-        if (cd <= L.maxcode[slot][l]) {
-          len = l;
-          sym = L.vals[slot][(cd + L.valoff[slot][l]) & 255];
-          break;
-        }
+// Position of a block ordinal in the MCU grid, advanced incrementally.
+struct BlockCursor {
+  int ordinal, k, mx, my;
+  __device__ __forceinline__ void Init(const HuffTables &L, int ord) {
+    ordinal = ord;
+    int mcu = ord / L.bpm;
+    k = ord - mcu * L.bpm;
+    my = mcu / L.mcus_x;
+    mx = mcu - my * L.mcus_x;
+  }
+  __device__ __forceinline__ void Next(const HuffTables &L) {
+    ordinal++;
+    if (++k == L.bpm) {
+      k = 0;
+      if (++mx == L.mcus_x) {
+        mx = 0;
+        my++;
       }
-    }
-    int s = sym & 15;
-    int val = 0;
-    if (s) {
-      uint32_t m = (peek << len) >> (32 - s);
-      val = m < (1u << (s - 1)) ? (int)m - (1 << s) + 1 : (int)m;
-    }
-    pos += len + s;
-    if (z == 0) {
-      if (WRITE) {
-        int comp = L.blk_comp[c];
-        int cur;
-        if (comp == 0) cur = (dc.sum0 += val);
-        else if (comp == 1) cur = (dc.sum1 += val);
-        else cur = (dc.sum2 += val);
-        if (blk) blk[0] = (int16_t)cur;
-        dc.count++;
-      }
-      z = 1;
-    } else {
-      int r = sym >> 4;
-      if (s == 0) {
-        z = r == 15 ? z + 16 : 64;
-      } else {
-        z += r;
-        if (WRITE && blk && z < 64) blk[L.zz[z]] = (int16_t)val;
-        z++;
-      }
-    }
-    if (z >= 64) {
-      z = 0;
-      c = c + 1 == bpm ? 0 : c + 1;
-      nblk++;
-      if (WRITE) blk = BlockPtr(d, L, ord + nblk);
     }
   }
-  st.pos = pos;
+  __device__ __forceinline__ GlobalCoef *Ptr(const HuffTables &L) const {
+    if (ordinal >= L.total_blocks) return nullptr;
+    return L.blk_base[k] + ((size_t)my * (size_t)L.blk_sy[k] + (size_t)(mx * L.blk_sx[k]));
+  }
+};
+
+// Rare path: the code is longer than kFastBits bits (or is not a code at all).
+__device__ __forceinline__ uint32_t LongCode(const HuffTables &L, uint32_t slot, uint32_t peek, bool is_dc) {
+  const uint32_t code16 = peek >> 16;
+  uint32_t e = 0;
+  const int size = L.l2_size[slot];
+  if (size >= 0) {
+    const int idx = (int)code16 - L.l2_first[slot];
+    if (idx >= 0 && idx < size) e = L.l2[slot][idx];
+  } else {
+    for (int l = kFastBits + 1; l <= 16; l++) {
+      int cd = (int)(code16 >> (16 - l));
+      if (cd <= L.maxcode[slot][l]) {
+        e = MakeEntry(l, L.vals[slot][(cd + L.valoff[slot][l]) & 255], is_dc);
+        break;
+      }
+    }
+  }
+  // not a code (garbage start state, or the padding behind the stream): consume 16 bits, decode nothing
+  return e ? e : MakeEntry(16, 0, is_dc);
+}
+
+// Decodes the symbols that start in [st.pos, end_bits); returns the number of blocks completed.  Positions only:
+// no value is extracted (synchronisation passes).
+__device__ __forceinline__ int DecodeRange(const HuffTables &L, GlobalWords *__restrict__ words, DecodeState &st,
+                                           uint32_t end_bits) {
+  int nblk = 0;
+  uint32_t c = st.c, z = st.z;
+  int rem = (int)(end_bits - st.pos);  // bits left before the end of the slice (<= 0: done)
+  // bit window: hi:lo = stream bits [32k, 32k+64), `off` of hi's bits already consumed; the following dword is in flight
+  int k = (int)(st.pos >> 5);
+  uint32_t off = st.pos & 31;
+  uint32_t hi = __builtin_bswap32(words[k]), lo = __builtin_bswap32(words[k + 1]), nxt = words[k + 2];
+  const uint16_t *fast = &L.fast[0][0];
+  const uint32_t dc_mask = L.dc_mask, ac_mask = L.ac_mask, bpm = (uint32_t)L.bpm;
+  while (rem > 0) {
+    const uint32_t peek = (uint32_t)(((((uint64_t)hi << 32) | lo) << off) >> 32);
+    const bool is_dc = z == 0;
+    const uint32_t slot = (((is_dc ? dc_mask : ac_mask) >> c) & 1u) + (is_dc ? 0u : 2u);
+    uint32_t e = fast[(slot << kFastBits) + (peek >> (32 - kFastBits))];
+    if (__builtin_expect(e == 0, 0)) e = LongCode(L, slot, peek, is_dc);
+    const uint32_t used = (e >> 11) + ((e >> 7) & 15);
+    rem -= (int)used;
+    off += used;
+    z += e & 127;
+    if (off >= 32) {
+      hi = lo;
+      lo = __builtin_bswap32(nxt);
+      k++;
+      nxt = words[k + 2];
+      off -= 32;
+    }
+    const bool end_of_block = z >= 64;
+    const uint32_t c1 = c + 1 == bpm ? 0 : c + 1;
+    z = end_of_block ? 0 : z;
+    c = end_of_block ? c1 : c;
+    nblk += end_of_block ? 1 : 0;
+  }
+  st.pos = end_bits - (uint32_t)rem;
   st.c = c;
   st.z = z;
   return nblk;
 }
 
-__global__ __launch_bounds__(kHuffThreads) void HuffmanDecodeKernel(const daliamdJpegHuffDesc *__restrict__ descs) {
-  __shared__ HuffLds L;
-  __shared__ uint64_t state[kHuffThreads + 1];
-  __shared__ int iscan[kHuffThreads];
-  __shared__ int dscan[3][kHuffThreads];
-  const daliamdJpegHuffDesc &d = descs[blockIdx.x];
-  const int tid = threadIdx.x;
-  // ---- tables ----
-  for (int t = tid; t < 4 * (1 << kFastBits); t += kHuffThreads) L.fast[t >> kFastBits][t & ((1 << kFastBits) - 1)] = 0;
-  if (tid < 64) L.zz[tid] = kZigZagColMajor[tid];
-  if (tid < 12) {
-    int comp = tid < d.blocks_per_mcu ? d.comp_of_block[tid] : 0;
-    L.blk_comp[tid] = (uint8_t)comp;
-    L.blk_dc[tid] = d.dc_sel[comp] & 1;
-    L.blk_ac[tid] = 2 + (d.ac_sel[comp] & 1);
-  }
-  for (int t = tid; t < 4 * 256; t += kHuffThreads) L.vals[t >> 8][t & 255] = d.vals[t >> 8][t & 255];
-  __syncthreads();
-  if (tid < 4) {
-    // canonical code assignment (ITU-T T.81 Annex C), one lane per table
-    int code = 0, p = 0;
-    for (int l = 1; l <= 16; l++) {
-      int n = d.bits[tid][l - 1];
-      L.valoff[tid][l] = p - code;
-      for (int i = 0; i < n; i++, p++, code++) {
-        if (l <= kFastBits) {
-          int first = code << (kFastBits - l);
-          uint16_t e = (uint16_t)((l << 8) | L.vals[tid][p & 255]);
-          for (int j = 0; j < (1 << (kFastBits - l)); j++) L.fast[tid][(first + j) & ((1 << kFastBits) - 1)] = e;
-        }
+constexpr int kStreamWords = 20;  // dwords of the clean stream buffered in LDS per lane
+constexpr int kReloadSteps = 16;  // symbols between two reloads: 16 x 31 bits at most < 16 dwords <= kStreamWords - 3
+                                  // (small on purpose: 36 KB of LDS per workgroup keeps 4 workgroups on a CU)
+
+// Write pass of one slice: decodes the symbols that start in [st.pos, end_bits) once more, now extracting the values,
+// and scatters the non-zero coefficients into the (pre-zeroed) arrays; the block in progress at `st` is block
+// ordinal `ord`.  The DC entry receives the lane-local running sum of the differences (DcFixKernel adds the level
+// at the start of the slice).
+//
+// gfx9 has ONE in-order counter for vector-memory loads and stores, so a stream prefetch that is waited for while
+// coefficient stores are in flight would wait for those stores as well (measured: 3x slower).  The stream therefore
+// goes through a small per-lane LDS buffer that the whole wave refills at the same step, every kReloadSteps
+// symbols: one wait per 16 symbols instead of one per refill of the bit window.
+__device__ __forceinline__ void WriteRange(const HuffTables &L, GlobalWords *__restrict__ words, DecodeState st,
+                                           uint32_t end_bits, int ord, bool live, uint32_t *sbuf, DcAcc &dc) {
+  uint32_t c = st.c, z = st.z;
+  int rem = (int)(end_bits - st.pos);
+  int k = (int)(st.pos >> 5), kbase = 0;
+  uint32_t off = st.pos & 31;
+  uint32_t hi = 0, lo = 0, nxt = 0;
+  const uint16_t *fast = &L.fast[0][0];
+  const uint32_t dc_mask = L.dc_mask, ac_mask = L.ac_mask, bpm = (uint32_t)L.bpm;
+  BlockCursor cur;
+  cur.Init(L, live ? ord : 0);
+  GlobalCoef *blk = live ? cur.Ptr(L) : nullptr;
+  for (int step = 0; __ballot(live) != 0; step++) {  // wave-uniform trip count
+    if ((step & (kReloadSteps - 1)) == 0 && live) {
+      kbase = k;
+#pragma unroll
+      for (int q = 0; q < kStreamWords; q++) sbuf[q] = words[k + q];
+      hi = __builtin_bswap32(sbuf[0]);
+      lo = __builtin_bswap32(sbuf[1]);
+      nxt = sbuf[2];
+    }
+    if (live) {
+      const uint32_t peek = (uint32_t)(((((uint64_t)hi << 32) | lo) << off) >> 32);
+      const bool is_dc = z == 0;
+      const uint32_t slot = (((is_dc ? dc_mask : ac_mask) >> c) & 1u) + (is_dc ? 0u : 2u);
+      uint32_t e = fast[(slot << kFastBits) + (peek >> (32 - kFastBits))];
+      if (__builtin_expect(e == 0, 0)) e = LongCode(L, slot, peek, is_dc);
+      const uint32_t len = e >> 11, s = (e >> 7) & 15, adv = e & 127;
+      // magnitude bits -> value (T.81 F.2.2.1 EXTEND); s == 0 gives 0
+      const uint32_t m = ((peek << len) >> 1) >> (31 - s);
+      const uint32_t half = (1u << s) >> 1;
+      int val = (int)m + (m < half ? 1 - (int)(1u << s) : 0);
+      uint32_t zt = z + adv - 1;  // zig-zag index of the coefficient this symbol carries (AC)
+      if (is_dc) {
+        const int comp = L.blk_comp[c];
+        if (comp == 0) val = (dc.sum0 += val);
+        else if (comp == 1) val = (dc.sum1 += val);
+        else val = (dc.sum2 += val);
+        dc.count++;
+        zt = 0;
       }
-      L.maxcode[tid][l] = n ? code - 1 : -1;
-      code <<= 1;
+      if (blk && (is_dc || (s && zt < 64))) blk[L.zz[zt]] = (int16_t)val;
+      const uint32_t used = len + s;
+      rem -= (int)used;
+      off += used;
+      z += adv;
+      if (off >= 32) {
+        hi = lo;
+        lo = __builtin_bswap32(nxt);
+        k++;
+        nxt = sbuf[k + 2 - kbase];
+        off -= 32;
+      }
+      if (z >= 64) {
+        z = 0;
+        c = c + 1 == bpm ? 0 : c + 1;
+        cur.Next(L);
+        blk = cur.Ptr(L);
+      }
+      live = rem > 0;
     }
   }
-  __syncthreads();
+}
 
-  const int clean_len = *d.clean_len;
-  const uint32_t total_bits = (uint32_t)clean_len * 8u;
-  // slice size in bytes (multiple of 4) such that the lanes cover the stream
-  const int slice = max(kMinSliceBytes, ((clean_len + kHuffThreads - 1) / kHuffThreads + 3) & ~3);
-  const uint32_t my_begin = min((uint32_t)tid * (uint32_t)slice * 8u, total_bits);
-  const uint32_t my_end = min((uint32_t)(tid + 1) * (uint32_t)slice * 8u, total_bits);
-  BitWindow bw;
-  bw.words = reinterpret_cast<const uint32_t *>(d.clean);
-
-  // ---- (a) speculative decode ----
-  DecodeState in{my_begin, 0, 0}, out;
-  DcAcc unused;
-  state[tid] = Pack(in);
-  out = in;
+// One decoder lane of the relaxation.
+struct Lane {
+  uint32_t begin, end;  // bit range of the slice (clipped to the stream)
+  bool active;          // the slice holds data
+  uint64_t in = kNoState, out = kNoState;
   int nblk = 0;
-  if (in.pos < my_end) nblk = DecodeRange<false>(d, L, bw, out, my_end, 0, unused);
-  // ---- (b) relaxation ----
-  for (int round = 0; round <= kHuffThreads; round++) {
+};
+
+// "Publish the state you reached to the next lane, decode again if your input changed", until nothing changes.
+// state[t] is the published input of lane t; lanes whose `in` already equals it do not decode.  Lane 0's input is
+// never written here, so whatever the caller put there is taken as the truth; each round fixes at least one more
+// lane, which bounds the loop by the lane count.
+template <int THREADS>
+__device__ __forceinline__ void Relax(const HuffTables &L, GlobalWords *words, uint64_t *state, Lane &ln) {
+  const int tid = threadIdx.x;
+  for (int round = 0; round <= THREADS; round++) {
+    const uint64_t ni = state[tid];
+    if (ln.active && ni != ln.in) {
+      ln.in = ni;
+      DecodeState st = Unpack(ni);
+      ln.nblk = 0;
+      if (st.pos < ln.end) ln.nblk = DecodeRange(L, words, st, ln.end);
+      ln.out = Pack(st);
+    }
     __syncthreads();
     int changed = 0;
-    uint64_t o = Pack(out);
-    if (tid + 1 < kHuffThreads && my_begin < total_bits && state[tid + 1] != o) {
-      state[tid + 1] = o;
+    if (ln.active && tid + 1 < THREADS && state[tid + 1] != ln.out) {
+      state[tid + 1] = ln.out;
       changed = 1;
     }
     if (!__syncthreads_or(changed)) break;
-    uint64_t ni = state[tid];
-    if (ni != Pack(in)) {
-      in = Unpack(ni);
-      out = in;
-      nblk = 0;
-      if (in.pos < my_end) nblk = DecodeRange<false>(d, L, bw, out, my_end, 0, unused);
-    }
   }
-  // ---- (c) first block ordinal of every lane ----
-  iscan[tid] = nblk;
+}
+
+__device__ __forceinline__ Lane MakeLane(long long slice_index, uint32_t total_bits) {
+  Lane ln;
+  if (slice_index < 0) {
+    ln.begin = ln.end = 0;
+    ln.active = false;
+    return ln;
+  }
+  const unsigned long long b = (unsigned long long)slice_index * (kSliceBytes * 8ull);
+  ln.begin = (uint32_t)(b < total_bits ? b : total_bits);
+  ln.end = (uint32_t)(b + kSliceBytes * 8ull < total_bits ? b + kSliceBytes * 8ull : total_bits);
+  ln.active = ln.begin < total_bits;
+  return ln;
+}
+
+__global__ __launch_bounds__(kSegThreads) void SyncKernel(const daliamdJpegHuffDesc *__restrict__ descs, int n, int nseg) {
+  __shared__ __attribute__((aligned(16))) HuffTables L;
+  __shared__ uint64_t state[kSegThreads];
+  __shared__ int wave_sums[kSegThreads / 64];
+  const int wg = XcdRemap(blockIdx.x, nseg);
+  if (wg < 0) return;
+  const ImageRef r = FindImage<false>(descs, n, wg);
+  const daliamdJpegHuffDesc &d = *r.d;
+  const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments);
+  const int tid = threadIdx.x, seg = r.local;
+  const int clean_len = *reinterpret_cast<const int32_t *>(d.scratch);
+  LaneRec *recs = reinterpret_cast<LaneRec *>(d.scratch + lay.lanes) + (size_t)seg * kSegLanes;
+  SegRec *segrec = reinterpret_cast<SegRec *>(d.scratch + lay.segs) + seg;
+  if (seg > 0 && (long long)seg * kSegBytes >= clean_len) {  // segment behind the end of the stream
+    if (tid >= kWarmLanes) recs[tid - kWarmLanes] = LaneRec{kNoState, kNoState, 0, 0, 0, 0, 0, 0};
+    if (tid == 0) *segrec = SegRec{kNoState, 0, 0, {0, 0, 0}, 0};
+    return;
+  }
+  CopyTables<kSegThreads>(L, reinterpret_cast<const HuffTables *>(d.scratch + lay.tables));
+  const uint32_t total_bits = (uint32_t)clean_len * 8u;
+  // lanes [0, kWarmLanes) replay the last slices of the previous segment, lanes [kWarmLanes, ..) are this segment's
+  Lane ln = MakeLane((long long)seg * kSegLanes + tid - kWarmLanes, total_bits);
+  state[tid] = Pack(DecodeState{ln.begin, 0, 0});  // the guess; exact for the very first slice of the image
   __syncthreads();
-  for (int off = 1; off < kHuffThreads; off <<= 1) {
-    int v = tid >= off ? iscan[tid - off] : 0;
-    __syncthreads();
-    iscan[tid] += v;
-    __syncthreads();
+  Relax<kSegThreads>(L, (GlobalWords *)(d.scratch + lay.clean), state, ln);
+  int total;
+  WorkgroupExclusiveScan<kSegThreads / 64>(tid >= kWarmLanes ? ln.nblk : 0, wave_sums, total);
+  if (tid >= kWarmLanes) {
+    recs[tid - kWarmLanes] = LaneRec{ln.in, ln.out, ln.nblk, 0, 0, 0, 0, 0};
+    // the last slice with data ends the segment (an empty stream: the first lane passes its input on)
+    const bool next_has_data = tid + 1 < kSegThreads && ln.end < total_bits;
+    if (ln.active && !next_has_data) *segrec = SegRec{ln.out, total, 0, {0, 0, 0}, 0};
+    if (total_bits == 0 && tid == kWarmLanes) *segrec = SegRec{Pack(DecodeState{0, 0, 0}), 0, 0, {0, 0, 0}, 0};
   }
-  const int ord = iscan[tid] - nblk;
-  // ---- (d) write pass ----
-  DcAcc dc;
-  DecodeState ws = in;
-  if (in.pos < my_end) DecodeRange<true>(d, L, bw, ws, my_end, ord, dc);
-  // ---- (e) absolute DC values: exclusive scan of the lane sums, per component ----
-  dscan[0][tid] = dc.sum0;
-  dscan[1][tid] = dc.sum1;
-  dscan[2][tid] = dc.sum2;
-  __syncthreads();
-  for (int off = 1; off < kHuffThreads; off <<= 1) {
-    int v0 = 0, v1 = 0, v2 = 0;
-    if (tid >= off) {
-      v0 = dscan[0][tid - off];
-      v1 = dscan[1][tid - off];
-      v2 = dscan[2][tid - off];
+}
+
+__global__ __launch_bounds__(kSegThreads) void PropagateKernel(const daliamdJpegHuffDesc *__restrict__ descs) {
+  __shared__ __attribute__((aligned(16))) HuffTables L;
+  __shared__ uint64_t state[kSegThreads];
+  __shared__ int wave_sums[kSegThreads / 64];
+  const daliamdJpegHuffDesc &d = descs[blockIdx.x];
+  const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments);
+  const int tid = threadIdx.x;
+  const int clean_len = *reinterpret_cast<const int32_t *>(d.scratch);
+  const uint32_t total_bits = (uint32_t)clean_len * 8u;
+  LaneRec *all_recs = reinterpret_cast<LaneRec *>(d.scratch + lay.lanes);
+  SegRec *segs = reinterpret_cast<SegRec *>(d.scratch + lay.segs);
+  uint64_t truth = Pack(DecodeState{0, 0, 0});
+  int block_base = 0;
+  bool tables_loaded = false;
+  for (int seg = 0; seg < d.num_segments; seg++) {
+    if (seg > 0 && (long long)seg * kSegBytes >= clean_len) {
+      if (tid == 0) {
+        segs[seg].out = truth;
+        segs[seg].block_base = block_base;
+      }
+      continue;
     }
-    __syncthreads();
-    dscan[0][tid] += v0;
-    dscan[1][tid] += v1;
-    dscan[2][tid] += v2;
-    __syncthreads();
-  }
-  const int base0 = dscan[0][tid] - dc.sum0, base1 = dscan[1][tid] - dc.sum1, base2 = dscan[2][tid] - dc.sum2;
-  if (dc.count > 0 && (base0 | base1 | base2)) {
-    // blocks whose DC this lane decoded: ordinals [first, first + count)
-    const int first = ord + (in.z != 0 ? 1 : 0);
-    for (int k = 0; k < dc.count; k++) {
-      int16_t *p = BlockPtr(d, L, first + k);
-      if (!p) break;
-      int bi = (first + k) % d.blocks_per_mcu;
-      int cc = L.blk_comp[bi];
-      int add = cc == 0 ? base0 : cc == 1 ? base1 : base2;
-      p[0] = (int16_t)(p[0] + add);
+    LaneRec *recs = all_recs + (size_t)seg * kSegLanes;
+    if (total_bits != 0 && recs[0].in != truth) {
+      // The warm-up lanes did not synchronise before this segment (long flat or periodic content): repair it.
+      if (!tables_loaded) {
+        CopyTables<kSegThreads>(L, reinterpret_cast<const HuffTables *>(d.scratch + lay.tables));
+        tables_loaded = true;
+      }
+      Lane ln = MakeLane(tid < kSegLanes ? (long long)seg * kSegLanes + tid : -1, total_bits);
+      if (tid < kSegLanes) {
+        ln.in = recs[tid].in;
+        ln.out = recs[tid].out;
+        ln.nblk = recs[tid].nblk;
+      }
+      state[tid] = tid == 0 ? truth : ln.in;
+      __syncthreads();
+      Relax<kSegThreads>(L, (GlobalWords *)(d.scratch + lay.clean), state, ln);
+      int total;
+      WorkgroupExclusiveScan<kSegThreads / 64>(ln.nblk, wave_sums, total);
+      if (tid < kSegLanes) {
+        recs[tid].in = ln.in;
+        recs[tid].out = ln.out;
+        recs[tid].nblk = ln.nblk;
+        const bool next_has_data = tid + 1 < kSegLanes && ln.end < total_bits;
+        if (ln.active && !next_has_data) {
+          segs[seg].out = ln.out;
+          segs[seg].nblk_total = total;
+        }
+      }
+      __threadfence();
+      __syncthreads();  // the records written above are read below (same workgroup)
     }
+    if (tid == 0) segs[seg].block_base = block_base;
+    block_base += segs[seg].nblk_total;
+    truth = segs[seg].out;
   }
   // the segment must hold every block the frame header promises (the padding may add garbage after them)
-  if (tid == 0 && iscan[kHuffThreads - 1] < d.total_blocks) *d.status = 2;
+  if (tid == 0 && block_base < d.total_blocks) *d.status = 2;
+}
+
+__global__ __launch_bounds__(kSegThreads) void WriteKernel(const daliamdJpegHuffDesc *__restrict__ descs, int n, int nseg) {
+  __shared__ __attribute__((aligned(16))) HuffTables L;
+  __shared__ __attribute__((aligned(16))) uint32_t sbuf[kSegThreads * kStreamWords];
+  __shared__ int wave_sums[kSegThreads / 64];
+  const int wg = XcdRemap(blockIdx.x, nseg);
+  if (wg < 0) return;
+  const ImageRef r = FindImage<false>(descs, n, wg);
+  const daliamdJpegHuffDesc &d = *r.d;
+  const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments);
+  const int tid = threadIdx.x, seg = r.local;
+  const int clean_len = *reinterpret_cast<const int32_t *>(d.scratch);
+  if (seg > 0 && (long long)seg * kSegBytes >= clean_len) return;
+  CopyTables<kSegThreads>(L, reinterpret_cast<const HuffTables *>(d.scratch + lay.tables));
+  LaneRec *recs = reinterpret_cast<LaneRec *>(d.scratch + lay.lanes) + (size_t)seg * kSegLanes;
+  SegRec *segrec = reinterpret_cast<SegRec *>(d.scratch + lay.segs) + seg;
+  const uint32_t total_bits = (uint32_t)clean_len * 8u;
+  Lane ln = MakeLane(tid < kSegLanes ? (long long)seg * kSegLanes + tid : -1, total_bits);
+  if (tid < kSegLanes) {
+    ln.in = recs[tid].in;
+    ln.nblk = recs[tid].nblk;
+  }
+  int total;
+  const int ord = segrec->block_base + WorkgroupExclusiveScan<kSegThreads / 64>(ln.nblk, wave_sums, total);
+  DcAcc dc;
+  DecodeState st = Unpack(ln.in);
+  WriteRange(L, (GlobalWords *)(d.scratch + lay.clean), st, ln.end, ord, ln.active && st.pos < ln.end,
+             sbuf + tid * kStreamWords, dc);
+  if (tid < kSegLanes) {
+    recs[tid].dc0 = dc.sum0;
+    recs[tid].dc1 = dc.sum1;
+    recs[tid].dc2 = dc.sum2;
+    recs[tid].count = dc.count;
+  }
+  int t0, t1, t2;
+  WorkgroupExclusiveScan<kSegThreads / 64>(dc.sum0, wave_sums, t0);
+  WorkgroupExclusiveScan<kSegThreads / 64>(dc.sum1, wave_sums, t1);
+  WorkgroupExclusiveScan<kSegThreads / 64>(dc.sum2, wave_sums, t2);
+  if (tid == 0) {
+    segrec->dc_total[0] = t0;
+    segrec->dc_total[1] = t1;
+    segrec->dc_total[2] = t2;
+  }
+}
+
+__global__ __launch_bounds__(kSegThreads) void DcFixKernel(const daliamdJpegHuffDesc *__restrict__ descs, int n, int nseg) {
+  __shared__ int wave_sums[kSegThreads / 64];
+  __shared__ int geom[4];
+  __shared__ uint8_t blk_comp[16];
+  __shared__ int blk_sx[12], blk_sy[12];
+  __shared__ GlobalCoef *blk_base[12];
+  const int wg = XcdRemap(blockIdx.x, nseg);
+  if (wg < 0) return;
+  const ImageRef r = FindImage<false>(descs, n, wg);
+  const daliamdJpegHuffDesc &d = *r.d;
+  const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments);
+  const int tid = threadIdx.x, seg = r.local;
+  const int clean_len = *reinterpret_cast<const int32_t *>(d.scratch);
+  if (seg > 0 && (long long)seg * kSegBytes >= clean_len) return;
+  const HuffTables *T = reinterpret_cast<const HuffTables *>(d.scratch + lay.tables);
+  if (tid < 12) {
+    blk_comp[tid] = T->blk_comp[tid];
+    blk_sx[tid] = T->blk_sx[tid];
+    blk_sy[tid] = T->blk_sy[tid];
+    blk_base[tid] = T->blk_base[tid];
+  }
+  if (tid == 0) {
+    geom[0] = T->bpm;
+    geom[1] = T->mcus_x;
+    geom[2] = T->total_blocks;
+  }
+  const LaneRec *recs = reinterpret_cast<const LaneRec *>(d.scratch + lay.lanes) + (size_t)seg * kSegLanes;
+  const SegRec *segs = reinterpret_cast<const SegRec *>(d.scratch + lay.segs);
+  // DC level at the start of this segment = totals of the segments before it
+  int p0 = 0, p1 = 0, p2 = 0;
+  for (int j = tid; j < seg; j += kSegThreads) {
+    p0 += segs[j].dc_total[0];
+    p1 += segs[j].dc_total[1];
+    p2 += segs[j].dc_total[2];
+  }
+  int s0, s1, s2, unused;
+  WorkgroupExclusiveScan<kSegThreads / 64>(p0, wave_sums, s0);
+  WorkgroupExclusiveScan<kSegThreads / 64>(p1, wave_sums, s1);
+  WorkgroupExclusiveScan<kSegThreads / 64>(p2, wave_sums, s2);
+  LaneRec rec{kNoState, kNoState, 0, 0, 0, 0, 0, 0};
+  if (tid < kSegLanes) rec = recs[tid];
+  const int base0 = s0 + WorkgroupExclusiveScan<kSegThreads / 64>(rec.dc0, wave_sums, unused);
+  const int base1 = s1 + WorkgroupExclusiveScan<kSegThreads / 64>(rec.dc1, wave_sums, unused);
+  const int base2 = s2 + WorkgroupExclusiveScan<kSegThreads / 64>(rec.dc2, wave_sums, unused);
+  const int ord = segs[seg].block_base + WorkgroupExclusiveScan<kSegThreads / 64>(rec.nblk, wave_sums, unused);
+  if (rec.count > 0 && (base0 | base1 | base2)) {
+    // the blocks this lane wrote: ordinals [first, first + count); four read-modify-writes in flight at a time
+    const int bpm = geom[0], mcus_x = geom[1], total_blocks = geom[2];
+    int ordinal = ord + ((rec.in & 255) != 0 ? 1 : 0);
+    int mcu = ordinal / bpm, k = ordinal - mcu * bpm, my = mcu / mcus_x, mx = mcu - my * mcus_x;
+    int left = min(rec.count, total_blocks - ordinal);
+    while (left > 0) {
+      GlobalCoef *p[4];
+      int add[4], v[4];
+      const int m = min(left, 4);
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        p[i] = blk_base[k] + ((size_t)my * (size_t)blk_sy[k] + (size_t)(mx * blk_sx[k]));
+        const int cc = blk_comp[k];
+        add[i] = cc == 0 ? base0 : cc == 1 ? base1 : base2;
+        if (i < m) {
+          v[i] = p[i][0];
+          if (++k == bpm) {
+            k = 0;
+            if (++mx == mcus_x) {
+              mx = 0;
+              my++;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        if (i < m) p[i][0] = (int16_t)(v[i] + add[i]);
+      left -= m;
+    }
+  }
 }
 
 }  // namespace daliamd
 
 extern "C" {
 
-daliamdResult_t daliamdJpegHuffmanRun(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev, int n) {
+daliamdResult_t daliamdJpegHuffmanScratchBytes(int ecs_len, size_t *bytes) {
+  DALIAMD_REQUIRE(ecs_len >= 0 && bytes, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdJpegHuffmanScratchBytes: invalid argument");
+  *bytes = daliamd::MakeLayout(ecs_len, daliamd::NumTiles(15, ecs_len), daliamd::NumSegments(ecs_len)).total;
+  return DALIAMD_SUCCESS;
+}
+
+daliamdResult_t daliamdJpegHuffmanSetup(daliamdJpegHuffDesc *descs_host, int n, int *num_tiles, int *num_segments) {
+  DALIAMD_REQUIRE(n >= 0 && (n == 0 || descs_host) && num_tiles && num_segments, DALIAMD_ERROR_INVALID_ARGUMENT,
+                  "daliamdJpegHuffmanSetup: invalid argument");
+  int tiles = 0, segs = 0;
+  for (int i = 0; i < n; i++) {
+    daliamdJpegHuffDesc &d = descs_host[i];
+    DALIAMD_REQUIRE(d.ecs && d.scratch && d.status && d.ecs_len >= 0, DALIAMD_ERROR_INVALID_ARGUMENT,
+                    "daliamdJpegHuffmanSetup: sample %d: NULL buffer or negative length", i);
+    DALIAMD_REQUIRE((reinterpret_cast<uintptr_t>(d.scratch) & 15) == 0, DALIAMD_ERROR_INVALID_ARGUMENT,
+                    "daliamdJpegHuffmanSetup: sample %d: scratch must be 16-byte aligned", i);
+    DALIAMD_REQUIRE(d.blocks_per_mcu >= 1 && d.blocks_per_mcu <= DALIAMD_JPEG_MAX_BLOCKS_PER_MCU && d.mcus_x >= 1 &&
+                        d.total_blocks >= 1 && d.total_blocks % d.blocks_per_mcu == 0,
+                    DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdJpegHuffmanSetup: sample %d: bad MCU geometry", i);
+    for (int k = 0; k < d.blocks_per_mcu; k++) {
+      DALIAMD_REQUIRE(d.comp_of_block[k] < 3 && d.coef[d.comp_of_block[k]], DALIAMD_ERROR_INVALID_ARGUMENT,
+                      "daliamdJpegHuffmanSetup: sample %d: block %d refers to a missing component", i, k);
+    }
+    d.tile_start = tiles;
+    d.num_tiles = daliamd::NumTiles((int)(reinterpret_cast<uintptr_t>(d.ecs) & 15), d.ecs_len);
+    d.seg_start = segs;
+    d.num_segments = daliamd::NumSegments(d.ecs_len);
+    tiles += d.num_tiles;
+    segs += d.num_segments;
+  }
+  *num_tiles = tiles;
+  *num_segments = segs;
+  return DALIAMD_SUCCESS;
+}
+
+daliamdResult_t daliamdJpegHuffmanRun(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev, int n, int num_tiles,
+                                      int num_segments) {
   if (n == 0) return DALIAMD_SUCCESS;
-  DALIAMD_REQUIRE(descs_dev && n > 0, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdJpegHuffmanRun: invalid argument");
-  hipLaunchKernelGGL(daliamd::UnstuffKernel, dim3(n), dim3(daliamd::kHuffThreads), 0, (hipStream_t)stream, descs_dev);
-  hipLaunchKernelGGL(daliamd::HuffmanDecodeKernel, dim3(n), dim3(daliamd::kHuffThreads), 0, (hipStream_t)stream, descs_dev);
+  DALIAMD_REQUIRE(descs_dev && n > 0 && num_tiles >= n && num_segments >= n, DALIAMD_ERROR_INVALID_ARGUMENT,
+                  "daliamdJpegHuffmanRun: invalid argument");
+  using namespace daliamd;
+  hipStream_t s = (hipStream_t)stream;
+  const int seg_grid = XcdGrid(num_segments);
+  hipLaunchKernelGGL(UnstuffCountKernel, dim3(num_tiles), dim3(kTileThreads), 0, s, descs_dev, n);
+  hipLaunchKernelGGL(UnstuffScatterKernel, dim3(num_tiles), dim3(kTileThreads), 0, s, descs_dev, n);
+  hipLaunchKernelGGL(BuildTablesKernel, dim3(n), dim3(256), 0, s, descs_dev);
+  hipLaunchKernelGGL(SyncKernel, dim3(seg_grid), dim3(kSegThreads), 0, s, descs_dev, n, num_segments);
+  hipLaunchKernelGGL(PropagateKernel, dim3(n), dim3(kSegThreads), 0, s, descs_dev);
+  hipLaunchKernelGGL(WriteKernel, dim3(seg_grid), dim3(kSegThreads), 0, s, descs_dev, n, num_segments);
+  hipLaunchKernelGGL(DcFixKernel, dim3(seg_grid), dim3(kSegThreads), 0, s, descs_dev, n, num_segments);
   DALIAMD_HIP_CHECK(hipGetLastError());
   return DALIAMD_SUCCESS;
 }

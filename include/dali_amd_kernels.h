@@ -108,17 +108,21 @@ DALIAMD_API daliamdResult_t daliamdJpegIdctRun(daliamdStream_t stream, const dal
  * dali/operators/imgcodec/decoder_schema.cc "hybrid_huffman_threshold").  Output layout and values
  * are those of daliamdJpegDecodeCoefficients (dali_amd_host.h), i.e. the input of daliamdJpegIdctRun.
  * The caller fills the descriptor from the scan analysis (daliamdJpegAnalyzeScan) and
- *   - uploads the entropy-coded segment (without the trailing marker) to `ecs`,
+ *   - uploads the entropy-coded segment (without the trailing marker) to `ecs`; the bytes up to the next
+ *     16-byte boundary behind it must be readable,
  *   - zero-fills the coefficient arrays and `status` (daliamdMemsetAsync) before the launch,
- *   - provides `clean`: ecs_len + 32 bytes of scratch, 4-byte aligned.
- * After the launch *status is 0 on success, 2 when the segment holds fewer blocks than the frame
+ *   - provides `scratch`: daliamdJpegHuffmanScratchBytes(ecs_len) bytes, 16-byte aligned (clean stream,
+ *     code tables, per-slice decoder states),
+ *   - calls daliamdJpegHuffmanSetup on the host table, copies it to the device, calls daliamdJpegHuffmanRun.
+ * The work is cut into image-independent pieces (16 KB tiles for the byte un-stuffing, 61 KB segments of 256-byte
+ * slices for the self-synchronising parallel decode), so a batch of very differently sized streams still fills
+ * the device.  After the launch *status is 0 on success, 2 when the segment holds fewer blocks than the frame
  * header promises (truncated / corrupt stream: decode it with the host decoder to get the diagnosis).
  * -------------------------------------------------------------------------------------------- */
 #define DALIAMD_JPEG_MAX_BLOCKS_PER_MCU 10
 typedef struct {
   const uint8_t *ecs;      /* device: entropy-coded segment (still byte-stuffed)                  */
-  uint8_t *clean;          /* device scratch: un-stuffed stream                                    */
-  int32_t *clean_len;      /* device scratch: one int                                              */
+  uint8_t *scratch;        /* device scratch, see above                                            */
   int32_t *status;         /* device: one int, pre-zeroed                                          */
   int16_t *coef[3];        /* device: per component [blocks_y][blocks_x][64], pre-zeroed           */
   int32_t ecs_len;
@@ -127,6 +131,8 @@ typedef struct {
   int32_t total_blocks;    /* mcus_x * mcus_y * blocks_per_mcu                                     */
   int32_t blocks_x[3];     /* allocated blocks per row of each component                           */
   int32_t h_samp[3], v_samp[3];
+  int32_t tile_start, num_tiles;   /* filled by Setup: un-stuffing workgroups of this stream       */
+  int32_t seg_start, num_segments; /* filled by Setup: decoding workgroups of this stream          */
   uint8_t comp_of_block[12];  /* component of the k-th block of an MCU                             */
   uint8_t h_of_block[12], v_of_block[12]; /* its position inside the component's MCU footprint     */
   uint8_t dc_sel[4], ac_sel[4];  /* per component: table selector, 0 or 1                           */
@@ -134,8 +140,13 @@ typedef struct {
   uint8_t vals[4][256];    /* DHT symbol lists, same order                                         */
 } daliamdJpegHuffDesc;
 
-/* Two launches (byte un-stuffing, then the self-synchronising parallel decode); one workgroup per stream. */
-DALIAMD_API daliamdResult_t daliamdJpegHuffmanRun(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev, int n);
+DALIAMD_API daliamdResult_t daliamdJpegHuffmanScratchBytes(int ecs_len, size_t *bytes);
+/* Validates the table, fills tile_start/num_tiles/seg_start/num_segments, returns the two grid sizes. */
+DALIAMD_API daliamdResult_t daliamdJpegHuffmanSetup(daliamdJpegHuffDesc *descs_host, int n, int *num_tiles,
+                                                    int *num_segments);
+/* Seven launches: un-stuff (count, scatter), tables, synchronise, propagate, write, DC prefix. */
+DALIAMD_API daliamdResult_t daliamdJpegHuffmanRun(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev, int n,
+                                                  int num_tiles, int num_segments);
 
 typedef enum {
   DALIAMD_JPEG_GRAY = 0,   /* 1 component                                   */

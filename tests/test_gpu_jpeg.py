@@ -41,7 +41,7 @@ def _coefficients(enc, huffman):
     from dali_amd import backend as B
     plan = B.JpegBatchPlan(enc)
     if huffman == "gpu":
-        coef = torch.empty(max(plan.coef_elems, 1), dtype=torch.int16, device="cuda")
+        coef = torch.full((max(plan.coef_elems, 1),), 0x5555, dtype=torch.int16, device="cuda")  # the decoder zero-fills
         status, sel = plan.entropy_decode_gpu(coef)
         torch.cuda.synchronize()
         plan.check_gpu_status(status)
