@@ -60,7 +60,7 @@ def make_dataset(first_index, count):
 class HotPath:
     """Device-resident batch + the per-step launch sequence."""
 
-    def __init__(self, enc, device, seed=1234, huffman="gpu"):
+    def __init__(self, enc, device, seed=1234, huffman="gpu", inflight=2):
         import torch
         from dali_amd import backend as B
         self.torch, self.B = torch, B
@@ -85,10 +85,25 @@ class HotPath:
                 raise SystemExit("bench: GPU Huffman output differs from the host entropy decoder")
         else:
             self.coef_dev = self.coef_host.to(device)
-        self.planes = torch.empty(self.plan.plane_bytes, dtype=torch.uint8, device=device)
-        self.rgb = torch.empty(self.plan.out_bytes, dtype=torch.uint8, device=device)
-        self.out = torch.empty((self.n, 3, 224, 224), dtype=torch.float16, device=device)
-        self.views = self.plan.output_views(self.rgb)
+        # `inflight` batches are processed concurrently, each on its own HIP stream with its own buffers (what the
+        # reference's executor does with prefetch_queue_depth=2: the decode of batch i+1 overlaps the resize of batch i)
+        self.slots = []
+        for k in range(inflight):
+            slot = {"stream": torch.cuda.Stream(device=device),
+                    "coef": self.coef_dev if k == 0 else torch.empty_like(self.coef_dev),
+                    "planes": torch.empty(self.plan.plane_bytes, dtype=torch.uint8, device=device),
+                    "rgb": torch.empty(self.plan.out_bytes, dtype=torch.uint8, device=device),
+                    "out": torch.empty((self.n, 3, 224, 224), dtype=torch.float16, device=device),
+                    "ws": self.plan.new_huffman_workspace(device) if huffman == "gpu" else None}
+            if huffman != "gpu" and k > 0:
+                slot["coef"].copy_(self.coef_dev)
+            slot["views"] = self.plan.output_views(slot["rgb"])
+            slot["image_table"] = B.ImageTable(slot["views"])
+            self.slots.append(slot)
+        self.views = self.slots[0]["views"]
+        self.out = self.slots[0]["out"]
+        self.rgb = self.slots[0]["rgb"]
+        self.host_s = 0.0
         self.shapes = np.array([v.shape[:2] for v in self.views], np.int32)
         self.rrc_master = B.philox_state(seed)
         self.flip_master = B.philox_state(seed + 1)
@@ -104,27 +119,32 @@ class HotPath:
         self.bytes_huffman = (3 * self.plan.stream_bytes + 2 * self.plan.coef_elems) if huffman == "gpu" else 0
         self.bytes_color = self.plan.plane_bytes + 3 * P       # planes in + RGB out
 
-    def step(self, record=None):
+    def step(self, record=None, index=0):
+        """Enqueues one pass of the hot path over the batch on the stream of slot index % inflight."""
         torch, B = self.torch, self.B
         from dali_amd import _capi as capi
         ev = record
-        if self.huffman == "gpu":
-            self.plan.run_gpu_huffman(self.coef_dev, events=ev[5:7] if ev else None)
-        B.jpeg_gpu_stage(self.plan, self.coef_dev, self.planes, self.rgb, split_events=ev[1:2] if ev else None,
-                         start_event=ev[0] if ev else None)
-        anchors, crops = B.random_crop_batch(self.rrc_master, self.shapes)
-        mirror = B.coin_flip_batch(self.flip_master, self.n, 0.5)
-        self.rrc_master.ctr[1] += self.n   # OperatorWithRng::Advance
-        self.flip_master.ctr[1] += self.n
-        rois = np.concatenate([anchors, anchors + crops], 1).astype(np.float32)
-        self.last_rois = (anchors, crops)
-        if ev:
-            ev[2].record()
-        B.resample_batch(self.views, (224, 224), rois=rois, out_dtype=capi.FLOAT16, out_layout=capi.LAYOUT_CHW,
-                         mean=self.mean, inv_std=self.inv_std, mirror=mirror, out=self.out,
-                         start_event=ev[3] if ev else None)
-        if ev:
-            ev[4].record()
+        slot = self.slots[index % len(self.slots)]
+        t0 = time.perf_counter()
+        with torch.cuda.stream(slot["stream"]):
+            if self.huffman == "gpu":
+                self.plan.run_gpu_huffman(slot["coef"], events=ev[5:7] if ev else None, ws=slot["ws"])
+            B.jpeg_gpu_stage(self.plan, slot["coef"], slot["planes"], slot["rgb"], split_events=ev[1:2] if ev else None,
+                             start_event=ev[0] if ev else None)
+            anchors, crops = B.random_crop_batch(self.rrc_master, self.shapes)
+            mirror = B.coin_flip_batch(self.flip_master, self.n, 0.5)
+            self.rrc_master.ctr[1] += self.n   # OperatorWithRng::Advance
+            self.flip_master.ctr[1] += self.n
+            rois = np.concatenate([anchors, anchors + crops], 1).astype(np.float32)
+            self.last_rois = (anchors, crops)
+            if ev:
+                ev[2].record()
+            B.resample_batch(slot["image_table"], (224, 224), rois=rois, out_dtype=capi.FLOAT16, out_layout=capi.LAYOUT_CHW,
+                             mean=self.mean, inv_std=self.inv_std, mirror=mirror, out=slot["out"],
+                             start_event=ev[3] if ev else None)
+            if ev:
+                ev[4].record()
+        self.host_s += time.perf_counter() - t0
         return anchors, crops
 
     def resample_bytes(self, crops):
@@ -269,6 +289,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="batches processed concurrently, each on its own HIP stream (executor prefetch depth)")
     ap.add_argument("--huffman", default="gpu", choices=["gpu", "host"],
                     help="gpu: the step starts from JPEG bytes in HBM (default); host: from host-decoded coefficient blocks")
     ap.add_argument("--workload", default="imagenet", choices=["imagenet", "heavy_aug", "audio"],
@@ -296,21 +318,22 @@ def main():
 
     B = args.batch
     enc = make_dataset(rank * B, B)  # shard `rank` of `world` (contiguous, like loader.cc:78-87)
-    hp = HotPath(enc, device, huffman=args.huffman)
+    hp = HotPath(enc, device, huffman=args.huffman, inflight=max(1, args.inflight))
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        hp.step()
+    for w in range(args.warmup):
+        hp.step(index=w)
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(7)] for _ in range(args.steps)]
     resample_bytes = []
     barrier()
+    hp.host_s = 0.0
     t0 = time.perf_counter()
     for k in range(args.steps):
-        _, crops = hp.step(record=ev[k])
+        _, crops = hp.step(record=ev[k], index=k)
         resample_bytes.append(hp.resample_bytes(crops))
     barrier()
     elapsed = time.perf_counter() - t0
@@ -347,7 +370,8 @@ def main():
                                    "ImageNet-like synthetic JPEGs (seed 1234), inputs = " +
                                    ("JPEG entropy-coded segments (bytes) resident in HBM" if args.huffman == "gpu" else
                                     "host-entropy-decoded coefficient blocks resident in HBM"),
-                       "huffman": args.huffman,
+                       "huffman": args.huffman, "batches_in_flight": len(hp.slots),
+                       "host_ms_per_step": 1e3 * hp.host_s / args.steps,
                        "jpeg_bytes_per_batch": getattr(hp.plan, "stream_bytes", None),
                        "global_batch": world * B, "parallelism": f"shard{world} (shard_id/num_shards, no collective)",
                        "pixels_per_batch": hp.pixels},

@@ -177,22 +177,27 @@ class JpegBatchPlan:
             stage_np[self._ecs_off[j]:self._ecs_off[j] + l] = self.encoded[i][o:o + l]
         self._ecs_stage = stage
         self._ecs_dev = stage.to(device, non_blocking=True)
-        self._scratch_dev = torch.empty(max(int(need.sum()), 256), dtype=torch.uint8, device=device)
-        self._huff_status = torch.zeros(max(len(sel), 1), dtype=torch.int32, device=device)
         self.stream_bytes = int(ecs_len.sum())
         self.huffman_scratch_bytes = int(need.sum())
+        self._huff_ws = self.new_huffman_workspace(device)
         # quantisation tables of the GPU-decoded streams come from the scan analysis
         self.quant[sel] = sc["quant"][sel, :3]
 
-    def huffman_descs(self, coef_dev):
+    def new_huffman_workspace(self, device):
+        """Decoder scratch + status words for one batch in flight (pipelined callers keep one per slot)."""
+        return {"scratch": torch.empty(max(self.huffman_scratch_bytes, 256), dtype=torch.uint8, device=device),
+                "status": torch.zeros(max(len(self._huff_sel), 1), dtype=torch.int32, device=device)}
+
+    def huffman_descs(self, coef_dev, ws=None):
         """daliamdJpegHuffDesc table of the GPU-eligible streams (numpy structured array) + the two grid sizes."""
         lib = capi.kernels()
+        ws = ws or self._huff_ws
         sc, inf, sel = self.scan, self.inf, self._huff_sel
         m = len(sel)
         d = np.zeros(max(m, 1), np.dtype(capi.JpegHuffDesc))[:m]
         d["ecs"] = self._ecs_dev.data_ptr() + self._ecs_off
-        d["scratch"] = self._scratch_dev.data_ptr() + self._scratch_off
-        d["status"] = self._huff_status.data_ptr() + 4 * np.arange(m)
+        d["scratch"] = ws["scratch"].data_ptr() + self._scratch_off
+        d["status"] = ws["status"].data_ptr() + 4 * np.arange(m)
         d["coef"] = np.where(self.comp_mask[sel], coef_dev.data_ptr() + 2 * self.coef_off[sel], 0)
         d["ecs_len"] = self._ecs_len
         d["blocks_per_mcu"] = sc["blocks_per_mcu"][sel]
@@ -214,14 +219,15 @@ class JpegBatchPlan:
         capi.check(lib.daliamdJpegHuffmanSetup(d.ctypes.data_as(C.c_void_p), m, C.byref(ntiles), C.byref(nsegs)))
         return d, ntiles.value, nsegs.value
 
-    def run_gpu_huffman(self, coef_dev, descs=None, events=None):
+    def run_gpu_huffman(self, coef_dev, descs=None, events=None, ws=None):
         """Zero-fills the coefficient arrays and launches the GPU entropy decoder for the uploaded streams on the
         current stream.  events: optional (before, after) events for timing."""
         lib = capi.kernels()
         dev = coef_dev.device
         m = len(self._huff_sel)
+        ws = ws or self._huff_ws
         if descs is None:
-            descs = self.huffman_descs(coef_dev)
+            descs = self.huffman_descs(coef_dev, ws)
         table, ntiles, nsegs = descs
         d_dev = _uploader.upload(table, dev) if m else None
         s = current_stream_ptr(dev)
@@ -234,7 +240,7 @@ class JpegBatchPlan:
         if events:
             events[1].record()
         self._huff_keep = [d_dev]
-        return self._huff_status[:m]
+        return ws["status"][:m]
 
     def entropy_decode_gpu(self, coef_dev, num_threads=None):
         """Entropy-decodes the batch into `coef_dev` (int16 device tensor of self.coef_elems elements):
@@ -387,6 +393,23 @@ def _fill4(dst, src):
         dst[i] = float(src[i]) if i < len(src) else (float(src[-1]) if len(src) == 1 else 0.0)
 
 
+class ImageTable:
+    """Addresses and geometry of a batch of u8 HWC device images as numpy columns (validated once), so that the
+    per-batch descriptor construction is vectorised instead of touching every tensor from Python."""
+
+    def __init__(self, images):
+        for img in images:
+            if img.dtype != torch.uint8 or img.dim() != 3 or img.stride(2) != 1 or img.stride(1) != img.shape[2]:
+                raise capi.DaliAmdError("expected u8 HWC tensors with dense pixels")
+        self.n = len(images)
+        self.device = images[0].device if self.n else torch.device("cuda")
+        self.ptr = np.array([img.data_ptr() for img in images], np.uint64)
+        shp = np.array([tuple(img.shape) for img in images], np.int32).reshape(-1, 3)
+        self.h, self.w, self.c = shp[:, 0], shp[:, 1], shp[:, 2]
+        self.pitch = np.array([img.stride(0) for img in images], np.int32)
+        self.images = images   # keeps the storage alive
+
+
 def resample_batch(images, out_size, rois=None, interp_min=capi.INTERP_LINEAR, interp_mag=capi.INTERP_LINEAR,
                    antialias=True, out_dtype=capi.UINT8, out_layout=capi.LAYOUT_HWC, mean=None, inv_std=None,
                    mirror=None, out=None, return_descs=False, start_event=None):
@@ -396,10 +419,11 @@ def resample_batch(images, out_size, rois=None, interp_min=capi.INTERP_LINEAR, i
     epilogue is fused: output dtype float16/float32, layout CHW or HWC, optional per-sample mirror.
     Returns a dense tensor [N, ...]."""
     lib = capi.kernels()
-    n = len(images)
+    tab = images if isinstance(images, ImageTable) else ImageTable(images)
+    n = tab.n
     oh, ow = int(out_size[0]), int(out_size[1])
-    dev = images[0].device if n else torch.device("cuda")
-    ch = images[0].shape[2] if n else 3
+    dev = tab.device
+    ch = int(tab.c[0]) if n else 3
     normalize = mean is not None
     if out is None:
         shape = (n, ch, oh, ow) if out_layout == capi.LAYOUT_CHW else (n, oh, ow, ch)
@@ -408,14 +432,10 @@ def resample_batch(images, out_size, rois=None, interp_min=capi.INTERP_LINEAR, i
     per_sample = oh * ow * ch * esz
     args = np.zeros(max(n, 1), np.dtype(capi.ResampleArgs))
     if n:
-        for img in images:
-            if img.dtype != torch.uint8 or img.dim() != 3 or img.stride(2) != 1 or img.stride(1) != img.shape[2]:
-                raise capi.DaliAmdError("resample_batch expects u8 HWC tensors with dense pixels")
         a = args[:n]
-        a["in_"] = [img.data_ptr() for img in images]
-        shp = np.array([tuple(img.shape) for img in images], np.int32)
-        a["in_h"], a["in_w"], a["channels"] = shp[:, 0], shp[:, 1], shp[:, 2]
-        a["in_pitch"] = [img.stride(0) for img in images]
+        a["in_"] = tab.ptr
+        a["in_h"], a["in_w"], a["channels"] = tab.h, tab.w, tab.c
+        a["in_pitch"] = tab.pitch
         if rois is not None:
             if isinstance(rois, np.ndarray):
                 r = rois.astype(np.float32)

@@ -309,6 +309,12 @@ class Workspace {
   daliamdStream_t stream = nullptr;  // device operators enqueue here and must not synchronise
   int batch_size = 0;                // requested (max) batch size of this iteration
   int64_t iteration = 0;
+  // Checks that can only be made once the device work of this iteration has finished (e.g. status words written
+  // by a kernel).  The pipeline runs them in Outputs(), after waiting for the iteration; a check reports by throwing.
+  std::vector<std::function<void()>> *completion_checks = nullptr;
+  void AddCompletionCheck(std::function<void()> fn) const {
+    if (completion_checks) completion_checks->push_back(std::move(fn));
+  }
 
   const TensorList &Input(int i) const { return *inputs.at(i); }
   TensorList &Output(int i) const { return *outputs.at(i); }

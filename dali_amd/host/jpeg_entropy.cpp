@@ -591,8 +591,11 @@ int daliamdJpegAnalyzeScan(const uint8_t *data, size_t size, const daliamdJpegIn
   scan->mcus_y = (d.height + 8 * d.vmax - 1) / (8 * d.vmax);
   // entropy-coded segment: from the end of the SOS header to the next real marker
   size_t q = d.first_ecs;
-  while (q + 1 < size) {
-    if (data[q] == 0xFF && data[q + 1] != 0 && data[q + 1] != 0xFF) break;
+  while (q + 1 < size) {  // memchr: about one byte in 256 is 0xFF, the rest is skipped at memory speed
+    const void *hit = memchr(data + q, 0xFF, size - 1 - q);
+    if (!hit) { q = size; break; }
+    q = (size_t)(static_cast<const uint8_t *>(hit) - data);
+    if (data[q + 1] != 0 && data[q + 1] != 0xFF) break;
     q++;
   }
   if (q + 1 >= size) q = size;

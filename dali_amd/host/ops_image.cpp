@@ -7,6 +7,7 @@
 //   CropAttr                 dali/operators/image/crop/crop_attr.cc:21-240
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "dali_amd_host.h"
 #include "ops.h"
@@ -37,9 +38,10 @@ static int ToKernelInterp(int64_t dali_interp) {
 // =============================================================================================
 DALI_SCHEMA(decoders__Image)
     .DocStr("Decodes images.\n\nSupported format in this MI355X-native build: JPEG (baseline and progressive, 8-bit, "
-            "grayscale / YCbCr / RGB).  The entropy decoding runs on the host thread pool; dequantisation, inverse DCT, "
-            "chroma upsampling and colour conversion run on the GPU and are bit-exact with libjpeg-turbo's accurate "
-            "integer path, i.e. with DALI's CPU backend.\n\nThe output is in HWC layout.")
+            "grayscale / YCbCr / RGB).  Baseline single-scan streams without restart markers are decoded entirely on "
+            "the GPU (Huffman included); the others are entropy-decoded on the host thread pool.  Dequantisation, "
+            "inverse DCT, chroma upsampling and colour conversion always run on the GPU and are bit-exact with "
+            "libjpeg-turbo's accurate integer path, i.e. with DALI's CPU backend.\n\nThe output is in HWC layout.")
     .NumInput(1)
     .NumOutput(1)
     .AddOptionalArg("output_type", "The color space of the output image (RGB or GRAY-as-RGB inputs only).",
@@ -49,7 +51,8 @@ DALI_SCHEMA(decoders__Image)
     .AddOptionalArg("use_fast_idct", "Ignored: the accurate integer IDCT is always used.", ArgValue::Bool(false))
     .AddOptionalArg("jpeg_fancy_upsampling", "Fancy (triangle) chroma upsampling is always used, like DALI's CPU backend.",
                     ArgValue::Bool(false))
-    .AddOptionalArg("hybrid_huffman_threshold", "Ignored (Huffman decoding always runs on the host here).",
+    .AddOptionalArg("hybrid_huffman_threshold", "When given explicitly: images with fewer pixels (H*W) are "
+                    "Huffman-decoded on the host; by default every supported stream is entropy-decoded on the GPU.",
                     ArgValue::Int(1000000))
     .AddOptionalArg("device_memory_padding", "Ignored.", ArgValue::Int(16 * 1024 * 1024))
     .AddOptionalArg("host_memory_padding", "Ignored.", ArgValue::Int(8 * 1024 * 1024))
@@ -78,11 +81,20 @@ class ImageDecoderMixed : public OperatorBase {
     DALI_ENFORCE(ot == DALI_RGB || ot == DALI_ANY_DATA, "decoders.image: only output_type=RGB is supported, got ", ot);
     DALI_ENFORCE(spec.GetInt("dtype") == DALI_UINT8, "decoders.image: only dtype=UINT8 is supported");
     adjust_orientation_ = spec.GetBool("adjust_orientation");
+    // Entropy decoding runs on the GPU for every stream the kernel supports.  An EXPLICIT hybrid_huffman_threshold
+    // keeps the reference's meaning: streams with fewer pixels than that are Huffman-decoded on the host.
+    if (spec.Args().count("hybrid_huffman_threshold")) huffman_threshold_ = spec.GetInt("hybrid_huffman_threshold");
+    if (const char *env = getenv("DALI_AMD_HOST_HUFFMAN")) host_huffman_only_ = atoi(env) != 0;
     ring_ = (int)spec.GetInt("gpu_prefetch_queue_depth") + 1;
     for (int i = 0; i < ring_; i++) {
       staging_.emplace_back(std::make_unique<Buffer>(StorageDevice::CPU));
       coef_dev_.emplace_back(std::make_unique<Buffer>(StorageDevice::GPU));
       planes_.emplace_back(std::make_unique<Buffer>(StorageDevice::GPU));
+      ecs_stage_.emplace_back(std::make_unique<Buffer>(StorageDevice::CPU));
+      ecs_dev_.emplace_back(std::make_unique<Buffer>(StorageDevice::GPU));
+      scratch_.emplace_back(std::make_unique<Buffer>(StorageDevice::GPU));
+      status_dev_.emplace_back(std::make_unique<Buffer>(StorageDevice::GPU));
+      status_host_.emplace_back(std::make_unique<Buffer>(StorageDevice::CPU));
     }
   }
   int OutputPitchAlign(int) const override { return kImagePitchAlign; }
@@ -94,19 +106,32 @@ class ImageDecoderMixed : public OperatorBase {
     const int n = in.num_samples();
     DALI_ENFORCE(in.type() == DALI_UINT8, "decoders.image expects encoded streams as 1-D uint8 tensors");
     infos_.resize(n);
+    scans_.resize(n);
     auto src = [&](int i) { return i < (int)in.source_info.size() && !in.source_info[i].empty() ? in.source_info[i]
                                                                                                : make_string("sample #", i); };
-    // ---- parse (cheap) ----
+    // ---- header parse + scan analysis (thread pool: the analysis walks the stream once to find its end) ----
     for (int i = 0; i < n; i++) {
-      if (daliamdJpegParse(static_cast<const uint8_t *>(in.raw(i)), in.nbytes(i), &infos_[i]) != 0)
-        DALI_FAIL("Failed to parse ", src(i), ": ", daliamdHostGetLastErrorMessage());
-      DALI_ENFORCE(infos_[i].num_components == 1 || infos_[i].num_components == 3, "Failed to decode ", src(i),
-                   ": JPEG with ", infos_[i].num_components, " components (CMYK/YCCK) is not supported");
+      ws.GetThreadPool().AddWork([&, i](int) {
+        const uint8_t *data = static_cast<const uint8_t *>(in.raw(i));
+        if (daliamdJpegParse(data, in.nbytes(i), &infos_[i]) != 0)
+          DALI_FAIL("Failed to parse ", src(i), ": ", daliamdHostGetLastErrorMessage());
+        DALI_ENFORCE(infos_[i].num_components == 1 || infos_[i].num_components == 3, "Failed to decode ", src(i),
+                     ": JPEG with ", infos_[i].num_components, " components (CMYK/YCCK) is not supported");
+        scans_[i].eligible = 0;
+        if (!host_huffman_only_ && (int64_t)infos_[i].width * infos_[i].height >= huffman_threshold_ &&
+            daliamdJpegAnalyzeScan(data, in.nbytes(i), &infos_[i], &scans_[i]) != 0)
+          scans_[i].eligible = 0;  // the host decoder will produce the diagnosis
+      }, (int64_t)in.nbytes(i));
     }
+    ws.GetThreadPool().RunAll();
     // ---- layout ----
     std::vector<TensorShape> shapes(n);
     coef_off_.assign(n * 3, 0);
+    ecs_off_.assign(n, 0);
+    scratch_off_.assign(n, 0);
+    gpu_samples_.clear();
     int64_t elems = 0;
+    size_t ecs_bytes = 0, scratch_bytes = 0;
     int ncomp_total = 0;
     for (int i = 0; i < n; i++) {
       const auto &inf = infos_[i];
@@ -117,31 +142,118 @@ class ImageDecoderMixed : public OperatorBase {
         elems += inf.coef_elems[c];
         ncomp_total++;
       }
+      if (scans_[i].eligible) {
+        DALI_ENFORCE(scans_[i].ecs_length < (int64_t)1 << 30, "Failed to decode ", src(i), ": entropy-coded segment too long");
+        size_t need = 0;
+        KCHECK(daliamdJpegHuffmanScratchBytes((int)scans_[i].ecs_length, &need));
+        ecs_off_[i] = ecs_bytes;
+        scratch_off_[i] = scratch_bytes;
+        ecs_bytes += ((size_t)scans_[i].ecs_length + 15) & ~(size_t)15;
+        scratch_bytes += need;
+        gpu_samples_.push_back(i);
+      }
     }
+    const int ngpu = (int)gpu_samples_.size();
     const int slot = (int)(ws.iteration % ring_);
     Buffer &stage = *staging_[slot], &cdev = *coef_dev_[slot], &planes = *planes_[slot];
-    stage.Reserve((size_t)elems * 2 + 256);
+    Buffer &ecs_stage = *ecs_stage_[slot], &ecs_dev = *ecs_dev_[slot], &scratch = *scratch_[slot];
+    Buffer &status_dev = *status_dev_[slot], &status_host = *status_host_[slot];
+    if (ngpu < n) stage.Reserve((size_t)elems * 2 + 256);
     cdev.Reserve((size_t)elems * 2 + 256);
     planes.Reserve((size_t)elems + 256);
+    ecs_stage.Reserve(ecs_bytes + 256);
+    ecs_dev.Reserve(ecs_bytes + 256);
+    scratch.Reserve(scratch_bytes + 256);
+    status_dev.Reserve(sizeof(int32_t) * (size_t)std::max(n, 1));
+    status_host.Reserve(sizeof(int32_t) * (size_t)std::max(n, 1));
     out.Resize(shapes, DALI_UINT8, kImagePitchAlign);
     out.SetLayout("HWC");
     out.source_info = in.source_info;
     quant_.assign((size_t)n * 3 * 64, 0);
-    // ---- entropy decode on the thread pool, biggest streams first ----
+    // ---- thread pool: gather the entropy-coded segments (GPU path) / entropy decode (host path) ----
     int16_t *coef_host = static_cast<int16_t *>(stage.data());
     for (int i = 0; i < n; i++) {
-      ws.GetThreadPool().AddWork([&, i](int) {
+      const bool gpu = scans_[i].eligible != 0;
+      ws.GetThreadPool().AddWork([&, i, gpu](int) {
+        const uint8_t *data = static_cast<const uint8_t *>(in.raw(i));
+        if (gpu) {
+          memcpy(static_cast<uint8_t *>(ecs_stage.data()) + ecs_off_[i], data + scans_[i].ecs_offset,
+                 (size_t)scans_[i].ecs_length);
+          for (int c = 0; c < infos_[i].num_components; c++) memcpy(&quant_[(size_t)i * 192 + c * 64], scans_[i].quant[c], 128);
+          return;
+        }
         int16_t *ptrs[4] = {nullptr, nullptr, nullptr, nullptr};
         for (int c = 0; c < infos_[i].num_components; c++) ptrs[c] = coef_host + coef_off_[i * 3 + c];
-        if (daliamdJpegDecodeCoefficients(static_cast<const uint8_t *>(in.raw(i)), in.nbytes(i), &infos_[i], ptrs,
-                                          &quant_[(size_t)i * 192]) != 0)
+        if (daliamdJpegDecodeCoefficients(data, in.nbytes(i), &infos_[i], ptrs, &quant_[(size_t)i * 192]) != 0)
           DALI_FAIL("Failed to decode ", src(i), ": ", daliamdHostGetLastErrorMessage());
-      }, (int64_t)in.nbytes(i));
+      }, gpu ? (int64_t)in.nbytes(i) / 16 : (int64_t)in.nbytes(i));
     }
     ws.GetThreadPool().RunAll();
     if (n == 0) return;
-    // ---- H2D + kernels ----
-    KCHECK(daliamdMemcpyH2DAsync(cdev.data(), coef_host, (size_t)elems * 2, ws.stream));
+    // ---- entropy decoding on the device ----
+    int16_t *coef = static_cast<int16_t *>(cdev.data());
+    if (ngpu) {
+      KCHECK(daliamdMemcpyH2DAsync(ecs_dev.data(), ecs_stage.data(), ecs_bytes, ws.stream));
+      KCHECK(daliamdMemsetAsync(cdev.data(), 0, (size_t)elems * 2, ws.stream));
+      KCHECK(daliamdMemsetAsync(status_dev.data(), 0, sizeof(int32_t) * (size_t)ngpu, ws.stream));
+      huff_.assign(ngpu, daliamdJpegHuffDesc{});
+      for (int j = 0; j < ngpu; j++) {
+        const int i = gpu_samples_[j];
+        const auto &inf = infos_[i];
+        const auto &sc = scans_[i];
+        auto &d = huff_[j];
+        d.ecs = static_cast<const uint8_t *>(ecs_dev.data()) + ecs_off_[i];
+        d.scratch = static_cast<uint8_t *>(scratch.data()) + scratch_off_[i];
+        d.status = static_cast<int32_t *>(status_dev.data()) + j;
+        d.ecs_len = (int32_t)sc.ecs_length;
+        d.blocks_per_mcu = sc.blocks_per_mcu;
+        d.mcus_x = sc.mcus_x;
+        d.total_blocks = sc.mcus_x * sc.mcus_y * sc.blocks_per_mcu;
+        for (int c = 0; c < inf.num_components; c++) {
+          d.coef[c] = coef + coef_off_[i * 3 + c];
+          d.blocks_x[c] = inf.blocks_x[c];
+          d.h_samp[c] = inf.h_samp[c];
+          d.v_samp[c] = inf.v_samp[c];
+          d.dc_sel[c] = sc.dc_sel[c];
+          d.ac_sel[c] = sc.ac_sel[c];
+        }
+        memcpy(d.comp_of_block, sc.comp_of_block, 10);
+        memcpy(d.h_of_block, sc.h_of_block, 10);
+        memcpy(d.v_of_block, sc.v_of_block, 10);
+        for (int t = 0; t < 2; t++) {
+          memcpy(d.bits[t], sc.dc_bits[t], 16);
+          memcpy(d.bits[2 + t], sc.ac_bits[t], 16);
+          memcpy(d.vals[t], sc.dc_vals[t], 256);
+          memcpy(d.vals[2 + t], sc.ac_vals[t], 256);
+        }
+      }
+      int ntiles = 0, nsegs = 0;
+      KCHECK(daliamdJpegHuffmanSetup(huff_.data(), ngpu, &ntiles, &nsegs));
+      auto *huff_dev = static_cast<const daliamdJpegHuffDesc *>(
+          up_huff_.Upload(huff_.data(), huff_.size() * sizeof(huff_[0]), ws.stream));
+      KCHECK(daliamdJpegHuffmanRun(ws.stream, huff_dev, ngpu, ntiles, nsegs));
+      KCHECK(daliamdMemcpyD2HAsync(status_host.data(), status_dev.data(), sizeof(int32_t) * (size_t)ngpu, ws.stream));
+      NoteLaunch(ws, "jpeg_huffman");
+      // the status words are valid once the iteration has finished: checked when its outputs are handed over
+      std::vector<int> samples = gpu_samples_;
+      std::vector<std::string> names(ngpu);
+      for (int j = 0; j < ngpu; j++) names[j] = src(samples[j]);
+      const int32_t *st = static_cast<const int32_t *>(status_host.data());
+      ws.AddCompletionCheck([st, names] {
+        for (size_t j = 0; j < names.size(); j++)
+          if (st[j] != 0)
+            DALI_FAIL("Failed to decode ", names[j], ": corrupt JPEG data: the entropy-coded segment ends before the "
+                      "last MCU (GPU Huffman status ", st[j], ")");
+      });
+    }
+    // host-decoded streams (progressive, restart markers, multi-scan, below the threshold): H2D of their coefficients
+    for (int i = 0; i < n; i++) {
+      if (scans_[i].eligible) continue;
+      int64_t first = coef_off_[i * 3], count = 0;
+      for (int c = 0; c < infos_[i].num_components; c++) count += infos_[i].coef_elems[c];
+      KCHECK(daliamdMemcpyH2DAsync(coef + first, coef_host + first, (size_t)count * 2, ws.stream));
+    }
+    // ---- dequantisation + IDCT, upsampling + colour conversion ----
     idct_.assign(ncomp_total, daliamdJpegIdctDesc{});
     color_.assign(n, daliamdJpegColorDesc{});
     int k = 0;
@@ -150,7 +262,7 @@ class ImageDecoderMixed : public OperatorBase {
       auto &cd = color_[i];
       for (int c = 0; c < inf.num_components; c++) {
         auto &d = idct_[k++];
-        d.coef = static_cast<const int16_t *>(cdev.data()) + coef_off_[i * 3 + c];
+        d.coef = coef + coef_off_[i * 3 + c];
         d.plane = static_cast<uint8_t *>(planes.data()) + coef_off_[i * 3 + c];
         d.blocks_x = inf.blocks_x[c];
         d.nblocks = inf.blocks_x[c] * inf.blocks_y[c];
@@ -171,9 +283,9 @@ class ImageDecoderMixed : public OperatorBase {
     KCHECK(daliamdJpegIdctSetup(idct_.data(), ncomp_total, &wg_idct));
     KCHECK(daliamdJpegColorSetup(color_.data(), n, &wg_color));
     auto *idct_dev = static_cast<const daliamdJpegIdctDesc *>(
-        uploader_.Upload(idct_.data(), idct_.size() * sizeof(idct_[0]), ws.stream));
+        up_idct_.Upload(idct_.data(), idct_.size() * sizeof(idct_[0]), ws.stream));
     auto *color_dev = static_cast<const daliamdJpegColorDesc *>(
-        uploader_.Upload(color_.data(), color_.size() * sizeof(color_[0]), ws.stream));
+        up_color_.Upload(color_.data(), color_.size() * sizeof(color_[0]), ws.stream));
     KCHECK(daliamdJpegIdctRun(ws.stream, idct_dev, ncomp_total, wg_idct));
     KCHECK(daliamdJpegColorRun(ws.stream, color_dev, n, wg_color));
     NoteLaunch(ws, "jpeg_idct");
@@ -182,14 +294,20 @@ class ImageDecoderMixed : public OperatorBase {
 
  private:
   bool adjust_orientation_;
+  bool host_huffman_only_ = false;
+  int64_t huffman_threshold_ = 0;
   int ring_;
-  std::vector<std::unique_ptr<Buffer>> staging_, coef_dev_, planes_;
+  std::vector<std::unique_ptr<Buffer>> staging_, coef_dev_, planes_, ecs_stage_, ecs_dev_, scratch_, status_dev_, status_host_;
   std::vector<daliamdJpegInfo> infos_;
+  std::vector<daliamdJpegScan> scans_;
+  std::vector<int> gpu_samples_;
   std::vector<int64_t> coef_off_;
+  std::vector<size_t> ecs_off_, scratch_off_;
   std::vector<uint16_t> quant_;
+  std::vector<daliamdJpegHuffDesc> huff_;
   std::vector<daliamdJpegIdctDesc> idct_;
   std::vector<daliamdJpegColorDesc> color_;
-  DescUploader uploader_;
+  DescUploader up_huff_, up_idct_, up_color_;
 };
 DALI_REGISTER_OPERATOR(decoders__Image, ImageDecoderMixed, MIXED);
 DALI_REGISTER_OPERATOR(ImageDecoder, ImageDecoderMixed, MIXED);

@@ -148,7 +148,7 @@ void Pipeline::Build(const std::vector<std::pair<std::string, std::string>> &out
 
 void Pipeline::NoteLaunch(const std::string &what) {
   std::lock_guard<std::mutex> g(launches_m_);
-  last_launches_.push_back(what);
+  cur_launches_.push_back(what);
 }
 std::vector<std::string> Pipeline::LastLaunches() const {
   std::lock_guard<std::mutex> g(launches_m_);
@@ -162,7 +162,7 @@ void Pipeline::RunIteration(int64_t it, int slot, Iteration &res) {
   res.slot = slot;
   {
     std::lock_guard<std::mutex> g(launches_m_);
-    last_launches_.clear();
+    cur_launches_.clear();
   }
   try {
     if (stream_) {
@@ -177,6 +177,8 @@ void Pipeline::RunIteration(int64_t it, int slot, Iteration &res) {
       ws.stream = stream_;
       ws.batch_size = params_.batch_size;
       ws.iteration = it;
+      std::vector<std::function<void()>> node_checks;
+      ws.completion_checks = &node_checks;
       for (size_t i = 0; i < n.in_node.size(); i++) ws.inputs.push_back(nodes_[n.in_node[i]].out_ring[n.in_idx[i]][slot]);
       for (auto &a : n.arg_in) ws.argument_inputs[a.first] = nodes_[a.second.first].out_ring[a.second.second][slot];
       for (auto &r : n.out_ring) ws.outputs.push_back(r[slot]);
@@ -186,6 +188,18 @@ void Pipeline::RunIteration(int64_t it, int slot, Iteration &res) {
           for (size_t k = 0; k < desc.size(); k++) ws.outputs[k]->Resize(desc[k].shape, desc[k].type, n.op->OutputPitchAlign((int)k));
         }
         n.op->RunImpl(ws);
+        for (auto &chk : node_checks) {
+          // same decoration as synchronous errors
+          std::string where = make_string("Error in ", OpTypeName(n.type), " operator `", n.spec.SchemaName(),
+                                          "` (instance \"", n.name, "\"): ");
+          res.checks.push_back([chk, where] {
+            try {
+              chk();
+            } catch (const std::exception &e) {
+              throw std::runtime_error(where + e.what());
+            }
+          });
+        }
       } catch (const std::exception &e) {
         // error_reporting.h: decorate with the operator's origin
         DALI_FAIL("Error in ", OpTypeName(n.type), " operator `", n.spec.SchemaName(), "` (instance \"", n.name, "\"): ",
@@ -197,6 +211,8 @@ void Pipeline::RunIteration(int64_t it, int slot, Iteration &res) {
     res.failed = true;
     res.error = e.what();
   }
+  std::lock_guard<std::mutex> g(launches_m_);
+  res.launches = cur_launches_;
 }
 
 void Pipeline::WorkerLoop() {
@@ -252,8 +268,13 @@ std::vector<std::shared_ptr<TensorList>> Pipeline::Outputs() {
   }
   consumed_++;
   holding_ = true;
+  {
+    std::lock_guard<std::mutex> g(launches_m_);
+    last_launches_ = res.launches;
+  }
   if (res.failed) throw std::runtime_error(res.error);
   if (stream_) KCHECK(daliamdEventSynchronize(slot_events_[res.slot]));
+  for (auto &chk : res.checks) chk();
   std::vector<std::shared_ptr<TensorList>> out;
   for (auto &o : outputs_) out.push_back(nodes_[o.first].out_ring[o.second][res.slot]);
   return out;

@@ -50,7 +50,7 @@ class Pipeline {
   // textual checkpoint: one line per stateful operator ("<name>=<state>")
   std::string SaveCheckpoint() const;
   void RestoreCheckpoint(const std::string &cpt);
-  // which device kernels the last iteration launched ("fused_resample_cmn", "jpeg_idct", ...)
+  // which device kernels the iteration last returned by Outputs() launched ("fused_resample_cmn", "jpeg_idct", ...)
   std::vector<std::string> LastLaunches() const;
 
   const PipelineParams &params() const { return params_; }
@@ -67,7 +67,14 @@ class Pipeline {
     std::vector<std::pair<std::string, std::pair<int, int>>> arg_in;  // arg name -> producer
     std::vector<std::vector<std::shared_ptr<TensorList>>> out_ring;   // [output][slot]
   };
-  struct Iteration { int slot; daliamdEvent_t done = nullptr; std::string error; bool failed = false; };
+  struct Iteration {
+    int slot;
+    daliamdEvent_t done = nullptr;
+    std::string error;
+    bool failed = false;
+    std::vector<std::function<void()>> checks;  // run by Outputs() once the device work is complete
+    std::vector<std::string> launches;          // device kernels this iteration enqueued
+  };
 
   void RunIteration(int64_t it, int slot, Iteration &res);
   void WorkerLoop();
@@ -95,7 +102,8 @@ class Pipeline {
   int64_t scheduled_ = 0, consumed_ = 0;
   bool stop_ = false;
   bool holding_ = false;  // the consumer holds the outputs of iteration consumed_-1
-  std::vector<std::string> last_launches_;
+  std::vector<std::string> last_launches_;  // of the iteration handed out last
+  std::vector<std::string> cur_launches_;   // of the iteration being built (worker thread)
   mutable std::mutex launches_m_;
 
  public:

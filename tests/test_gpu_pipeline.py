@@ -87,7 +87,7 @@ def test_train_pipeline_matches_oracle(jpeg_dir, fused):
         else:
             assert "resample" in kernels and "cmn" in kernels and "fused_resample_cmn" not in kernels
             assert np.array_equal(outs[2].as_tensor().cpu().numpy(), ref_u8)
-        assert "jpeg_idct" in kernels and "jpeg_color" in kernels
+        assert "jpeg_huffman" in kernels and "jpeg_idct" in kernels and "jpeg_color" in kernels
 
 
 def test_decoder_output_and_exif_orientation(tmp_path):
@@ -129,6 +129,52 @@ def test_decoder_error_names_the_file(tmp_path):
         enc, _ = fn.readers.file(files=[str(good), str(bad)])
         pipe.set_outputs(fn.decoders.image(enc, device="mixed"))
     with pytest.raises(RuntimeError, match="broken.jpg"):
+        pipe.run()
+
+
+def test_decoder_gpu_and_host_huffman_paths_agree(tmp_path):
+    """Baseline streams take the GPU entropy decoder, progressive / restart-marker streams the host one, and an
+    explicit hybrid_huffman_threshold sends small images to the host as in the reference; all bit-exact."""
+    from dali_amd import fn
+    from dali_amd.pipeline import Pipeline
+    rng = np.random.default_rng(8)
+    encs = [encode_jpeg(synth_image(rng, 96, 128), 85), encode_jpeg(synth_image(rng, 96, 128), 85, progressive=True),
+            encode_jpeg(synth_image(rng, 200, 150), 75, restart_marker_blocks=5), encode_jpeg(synth_image(rng, 64, 64, 1), 80),
+            encode_jpeg(synth_image(rng, 300, 400), 90, subsampling="4:4:4"), encode_jpeg(synth_image(rng, 17, 9), 60)]
+    files = []
+    for i, e in enumerate(encs):
+        p = tmp_path / f"f{i}.jpg"
+        p.write_bytes(e)
+        files.append(str(p))
+    refs = [O.jpeg_decode_rgb(e) for e in encs]
+    for kw, expect_gpu in [({}, True), ({"hybrid_huffman_threshold": 10 ** 9}, False), ({"hybrid_huffman_threshold": 20000}, True)]:
+        pipe = Pipeline(batch_size=len(files), num_threads=3, device_id=0)
+        with pipe:
+            enc, _ = fn.readers.file(files=files)
+            pipe.set_outputs(fn.decoders.image(enc, device="mixed", **kw))
+        for _ in range(3):   # the ring of staging buffers comes round
+            (out,) = pipe.run()
+            assert ("jpeg_huffman" in pipe.executed_kernels()) == expect_gpu
+            for i, ref in enumerate(refs):
+                assert np.array_equal(out[i].as_cpu(), ref), (kw, i)
+
+
+def test_decoder_truncated_stream_is_reported_with_the_file_name(tmp_path):
+    """A stream that parses but runs out of entropy-coded data is detected by the GPU decoder's status word; the
+    error surfaces when the outputs of that iteration are requested and names the sample."""
+    from dali_amd import fn
+    from dali_amd.pipeline import Pipeline
+    rng = np.random.default_rng(9)
+    good = encode_jpeg(synth_image(rng, 120, 160), 85)
+    cut = encode_jpeg(synth_image(rng, 240, 320), 85)
+    cut = cut[:len(cut) // 2] + b"\xff\xd9"
+    (tmp_path / "fine.jpg").write_bytes(good)
+    (tmp_path / "truncated.jpg").write_bytes(cut)
+    pipe = Pipeline(batch_size=2, num_threads=2, device_id=0)
+    with pipe:
+        enc, _ = fn.readers.file(files=[str(tmp_path / "fine.jpg"), str(tmp_path / "truncated.jpg")])
+        pipe.set_outputs(fn.decoders.image(enc, device="mixed"))
+    with pytest.raises(RuntimeError, match="truncated.jpg.*corrupt JPEG data"):
         pipe.run()
 
 
