@@ -104,6 +104,7 @@ class HotPath:
         self.out = self.slots[0]["out"]
         self.rgb = self.slots[0]["rgb"]
         self.host_s = 0.0
+        self.kernel_events = []
         self.shapes = np.array([v.shape[:2] for v in self.views], np.int32)
         self.rrc_master = B.philox_state(seed)
         self.flip_master = B.philox_state(seed + 1)
@@ -115,8 +116,6 @@ class HotPath:
         P = sum(int(s[0]) * int(s[1]) for s in self.shapes)
         self.pixels = P
         self.bytes_idct = 3 * self.plan.coef_elems            # 2 B coefficient in + 1 B sample out
-        # entropy decode: stream in, clean stream out + in, coefficient arrays out
-        self.bytes_huffman = (3 * self.plan.stream_bytes + 2 * self.plan.coef_elems) if huffman == "gpu" else 0
         self.bytes_color = self.plan.plane_bytes + 3 * P       # planes in + RGB out
 
     def step(self, record=None, index=0):
@@ -128,7 +127,12 @@ class HotPath:
         t0 = time.perf_counter()
         with torch.cuda.stream(slot["stream"]):
             if self.huffman == "gpu":
-                self.plan.run_gpu_huffman(slot["coef"], events=ev[5:7] if ev else None, ws=slot["ws"])
+                ke = None
+                if ev:
+                    ke = B.KernelEvents(len(B.HUFFMAN_KERNELS))
+                    self.kernel_events.append(ke)
+                self.plan.run_gpu_huffman(slot["coef"], events=ev[5:7] if ev else None, ws=slot["ws"],
+                                          kernel_events=ke.handles if ke else None)
             B.jpeg_gpu_stage(self.plan, slot["coef"], slot["planes"], slot["rgb"], split_events=ev[1:2] if ev else None,
                              start_event=ev[0] if ev else None)
             anchors, crops = B.random_crop_batch(self.rrc_master, self.shapes)
@@ -171,6 +175,47 @@ def cpu_baseline(enc, seconds_budget=20.0):
     return {"value": done / el, "unit": "images/s", "cores": cores, "kind": "port",
             "sample": f"{done} images = {it} pass(es) over the {len(enc)}-image batch; decode+RRC+CMN per image on the C "
                       f"oracle (-O3 -msse2, OpenMP, one task per sample), {cores} threads, {el:.2f} s wall"}
+
+
+def e2e_pipeline(enc, device_id, iters=30, threads=None):
+    """The same hot path through the product's DALI-style pipeline (C++ host framework): readers.file (page cache)
+    -> decoders.image(mixed: header parse + scan analysis on the host thread pool, H2D of the entropy-coded
+    segments, GPU Huffman/IDCT/colour) -> random_resized_crop + crop_mirror_normalize (fused).  PCIe-inclusive and
+    host-inclusive, therefore reported next to `value`, never as `value`."""
+    import shutil
+    import tempfile
+    from dali_amd import fn, types
+    from dali_amd.pipeline import Pipeline
+    threads = threads or effective_cpu_count()
+    root = tempfile.mkdtemp(prefix="dali_amd_bench_")
+    try:
+        os.makedirs(os.path.join(root, "c0"))
+        for i, e in enumerate(enc):
+            with open(os.path.join(root, "c0", f"{i:05d}.jpg"), "wb") as f:
+                f.write(e)
+        pipe = Pipeline(batch_size=len(enc), num_threads=threads, device_id=device_id, seed=1234, prefetch_queue_depth=2)
+        with pipe:
+            jpegs, labels = fn.readers.file(file_root=root, name="Reader")
+            images = fn.decoders.image(jpegs, device="mixed", output_type=types.RGB)
+            crops = fn.random_resized_crop(images, size=[224, 224])
+            out = fn.crop_mirror_normalize(crops, dtype=types.FLOAT16, output_layout="CHW",
+                                           mean=[0.485 * 255, 0.456 * 255, 0.406 * 255],
+                                           std=[0.229 * 255, 0.224 * 255, 0.225 * 255],
+                                           mirror=fn.random.coin_flip(probability=0.5))
+            pipe.set_outputs(out, labels)
+        pipe.build()
+        for _ in range(3):
+            pipe.run()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            pipe.run()
+        el = time.perf_counter() - t0
+        return {"value": iters * len(enc) / el, "unit": "images/s", "ms_per_batch": 1e3 * el / iters,
+                "host_threads": threads, "kernels": pipe.executed_kernels(),
+                "note": "dali_amd.Pipeline end to end from encoded files in the page cache (file read, header parse, "
+                        "H2D of the JPEG bytes, all device stages, fp16 CHW batch on the device); one HIP stream"}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
 
 
 def bench_heavy_aug(args, device):
@@ -289,6 +334,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end dali_amd.Pipeline leg")
     ap.add_argument("--inflight", type=int, default=2,
                     help="batches processed concurrently, each on its own HIP stream (executor prefetch depth)")
     ap.add_argument("--huffman", default="gpu", choices=["gpu", "host"],
@@ -352,8 +398,16 @@ def main():
         "ResampleKernel": (float(np.mean(resample_bytes)), ms_resample),
     }
     if args.huffman == "gpu":
-        kern["JpegHuffman(7 kernels: unstuff x2, tables, sync, propagate, write, dcfix)"] = (
-            hp.bytes_huffman, float(np.mean([e[5].elapsed_time(e[6]) for e in ev])))
+        # per-kernel durations of the entropy decoder (events recorded between its launches, same stream)
+        per = np.array([ke.elapsed_ms() for ke in hp.kernel_events]).mean(0)
+        sb, ce = hp.plan.stream_bytes, hp.plan.coef_elems
+        huff_bytes = {"UnstuffCountKernel": sb, "UnstuffScatterKernel": 2 * sb, "BuildTablesKernel": 27 * 1024 * B,
+                      "SyncKernel": sb, "PropagateKernel": 0, "WriteKernel": sb + 2 * ce,
+                      "DcFixKernel": 4 * (ce // 64)}
+        from dali_amd.backend import HUFFMAN_KERNELS
+        for name, ms in zip(HUFFMAN_KERNELS, per):
+            kern[name] = (huff_bytes[name], float(ms))
+        huffman_total_ms = float(np.mean([e[5].elapsed_time(e[6]) for e in ev]))
     dominant = max(kern, key=lambda k: kern[k][1])
     ach = kern[dominant][0] / (kern[dominant][1] * 1e-3) / 1e9
 
@@ -371,6 +425,7 @@ def main():
                                    ("JPEG entropy-coded segments (bytes) resident in HBM" if args.huffman == "gpu" else
                                     "host-entropy-decoded coefficient blocks resident in HBM"),
                        "huffman": args.huffman, "batches_in_flight": len(hp.slots),
+                       "huffman_ms_per_batch(memset + 7 kernels)": huffman_total_ms if args.huffman == "gpu" else None,
                        "host_ms_per_step": 1e3 * hp.host_s / args.steps,
                        "jpeg_bytes_per_batch": getattr(hp.plan, "stream_bytes", None),
                        "global_batch": world * B, "parallelism": f"shard{world} (shard_id/num_shards, no collective)",
@@ -384,6 +439,10 @@ def main():
                                  "note": "host entropy decoder on the same batch (one pass, thread pool): the CPU half "
                                          "of the hybrid variant (--huffman host); not part of `value`"},
         }
+        if world == 1 and not args.no_e2e:
+            del hp
+            torch.cuda.empty_cache()
+            line["e2e_pipeline"] = e2e_pipeline(enc, local_rank)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(enc)
         print(json.dumps(line))

@@ -219,7 +219,7 @@ class JpegBatchPlan:
         capi.check(lib.daliamdJpegHuffmanSetup(d.ctypes.data_as(C.c_void_p), m, C.byref(ntiles), C.byref(nsegs)))
         return d, ntiles.value, nsegs.value
 
-    def run_gpu_huffman(self, coef_dev, descs=None, events=None, ws=None):
+    def run_gpu_huffman(self, coef_dev, descs=None, events=None, ws=None, kernel_events=None):
         """Zero-fills the coefficient arrays and launches the GPU entropy decoder for the uploaded streams on the
         current stream.  events: optional (before, after) events for timing."""
         lib = capi.kernels()
@@ -235,7 +235,9 @@ class JpegBatchPlan:
             events[0].record()
         capi.check(lib.daliamdMemsetAsync(C.c_void_p(coef_dev.data_ptr()), 0,
                                           C.c_size_t(coef_dev.numel() * coef_dev.element_size()), s))
-        if m:
+        if m and kernel_events is not None:   # ctypes array of 8 daliamdEvent_t (see KernelEvents)
+            capi.check(lib.daliamdJpegHuffmanRunProfiled(s, C.c_void_p(d_dev.data_ptr()), m, ntiles, nsegs, kernel_events))
+        elif m:
             capi.check(lib.daliamdJpegHuffmanRun(s, C.c_void_p(d_dev.data_ptr()), m, ntiles, nsegs))
         if events:
             events[1].record()
@@ -391,6 +393,39 @@ def decode_jpeg_batch(encoded, device="cuda", num_threads=None, out_pitch_align=
 def _fill4(dst, src):
     for i in range(4):
         dst[i] = float(src[i]) if i < len(src) else (float(src[-1]) if len(src) == 1 else 0.0)
+
+
+HUFFMAN_KERNELS = ("UnstuffCountKernel", "UnstuffScatterKernel", "BuildTablesKernel", "SyncKernel",
+                   "PropagateKernel", "WriteKernel", "DcFixKernel")
+
+
+class KernelEvents:
+    """n+1 timing events of the kernel library (daliamdEvent*) bracketing n consecutive kernels of one launch call."""
+
+    def __init__(self, n):
+        lib = capi.kernels()
+        self.n = n
+        self.handles = (C.c_void_p * (n + 1))()
+        for i in range(n + 1):
+            capi.check(lib.daliamdEventCreate(C.byref(self.handles, i * C.sizeof(C.c_void_p)), 1))
+
+    def elapsed_ms(self):
+        """Per-kernel durations; call after the stream has been synchronised."""
+        lib = capi.kernels()
+        out, ms = [], C.c_float(0)
+        for i in range(self.n):
+            capi.check(lib.daliamdEventElapsedMs(C.c_void_p(self.handles[i]), C.c_void_p(self.handles[i + 1]), C.byref(ms)))
+            out.append(ms.value)
+        return out
+
+    def __del__(self):
+        try:
+            lib = capi.kernels()
+            for h in self.handles:
+                if h:
+                    lib.daliamdEventDestroy(C.c_void_p(h))
+        except Exception:
+            pass
 
 
 class ImageTable:

@@ -840,23 +840,44 @@ daliamdResult_t daliamdJpegHuffmanSetup(daliamdJpegHuffDesc *descs_host, int n, 
   return DALIAMD_SUCCESS;
 }
 
-daliamdResult_t daliamdJpegHuffmanRun(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev, int n, int num_tiles,
-                                      int num_segments) {
+static daliamdResult_t LaunchHuffman(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev, int n, int num_tiles,
+                                     int num_segments, daliamdEvent_t *events) {
   if (n == 0) return DALIAMD_SUCCESS;
   DALIAMD_REQUIRE(descs_dev && n > 0 && num_tiles >= n && num_segments >= n, DALIAMD_ERROR_INVALID_ARGUMENT,
                   "daliamdJpegHuffmanRun: invalid argument");
   using namespace daliamd;
   hipStream_t s = (hipStream_t)stream;
   const int seg_grid = XcdGrid(num_segments);
+  int e = 0;
+  auto mark = [&]() -> hipError_t { return events ? hipEventRecord((hipEvent_t)events[e++], s) : hipSuccess; };
+  DALIAMD_HIP_CHECK(mark());
   hipLaunchKernelGGL(UnstuffCountKernel, dim3(num_tiles), dim3(kTileThreads), 0, s, descs_dev, n);
+  DALIAMD_HIP_CHECK(mark());
   hipLaunchKernelGGL(UnstuffScatterKernel, dim3(num_tiles), dim3(kTileThreads), 0, s, descs_dev, n);
+  DALIAMD_HIP_CHECK(mark());
   hipLaunchKernelGGL(BuildTablesKernel, dim3(n), dim3(256), 0, s, descs_dev);
+  DALIAMD_HIP_CHECK(mark());
   hipLaunchKernelGGL(SyncKernel, dim3(seg_grid), dim3(kSegThreads), 0, s, descs_dev, n, num_segments);
+  DALIAMD_HIP_CHECK(mark());
   hipLaunchKernelGGL(PropagateKernel, dim3(n), dim3(kSegThreads), 0, s, descs_dev);
+  DALIAMD_HIP_CHECK(mark());
   hipLaunchKernelGGL(WriteKernel, dim3(seg_grid), dim3(kSegThreads), 0, s, descs_dev, n, num_segments);
+  DALIAMD_HIP_CHECK(mark());
   hipLaunchKernelGGL(DcFixKernel, dim3(seg_grid), dim3(kSegThreads), 0, s, descs_dev, n, num_segments);
+  DALIAMD_HIP_CHECK(mark());
   DALIAMD_HIP_CHECK(hipGetLastError());
   return DALIAMD_SUCCESS;
+}
+
+daliamdResult_t daliamdJpegHuffmanRun(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev, int n, int num_tiles,
+                                      int num_segments) {
+  return LaunchHuffman(stream, descs_dev, n, num_tiles, num_segments, nullptr);
+}
+
+daliamdResult_t daliamdJpegHuffmanRunProfiled(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev, int n,
+                                              int num_tiles, int num_segments, daliamdEvent_t *events) {
+  DALIAMD_REQUIRE(events, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdJpegHuffmanRunProfiled: events is NULL");
+  return LaunchHuffman(stream, descs_dev, n, num_tiles, num_segments, events);
 }
 
 }  // extern "C"

@@ -147,6 +147,12 @@ DALIAMD_API daliamdResult_t daliamdJpegHuffmanSetup(daliamdJpegHuffDesc *descs_h
 /* Seven launches: un-stuff (count, scatter), tables, synchronise, propagate, write, DC prefix. */
 DALIAMD_API daliamdResult_t daliamdJpegHuffmanRun(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev, int n,
                                                   int num_tiles, int num_segments);
+/* Same launches with events[0..7] (created with timing enabled) recorded before each kernel and after the last:
+ * events[i] .. events[i+1] brackets kernel i of {un-stuff count, un-stuff scatter, tables, synchronise, propagate,
+ * write, DC prefix}.  For benchmarks. */
+#define DALIAMD_JPEG_HUFFMAN_KERNELS 7
+DALIAMD_API daliamdResult_t daliamdJpegHuffmanRunProfiled(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev,
+                                                          int n, int num_tiles, int num_segments, daliamdEvent_t *events);
 
 typedef enum {
   DALIAMD_JPEG_GRAY = 0,   /* 1 component                                   */
