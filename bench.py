@@ -47,6 +47,21 @@ def effective_cpu_count():
     return n
 
 
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*_traffic.json, produced by
+    tools/collect_profiles.sh: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH_SIZE correction).  bench.py
+    cannot run rocprofv3 around itself, so this is the figure of the profiled run of this same command."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        k = json.load(open(files[-1]))["kernels"].get(kernel, {})
+        return k.get("hbm_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
+    except (OSError, ValueError, KeyError):
+        return None, None
+
+
 def make_dataset(first_index, count):
     """Synthetic ImageNet-like JPEGs.  Image i depends only on its global index."""
     from tests.util import synth_jpeg_batch
@@ -410,6 +425,7 @@ def main():
         huffman_total_ms = float(np.mean([e[5].elapsed_time(e[6]) for e in ev]))
     dominant = max(kern, key=lambda k: kern[k][1])
     ach = kern[dominant][0] / (kern[dominant][1] * 1e-3) / 1e9
+    traffic, traffic_src = measured_traffic(dominant)
 
     if rank == 0:
         value = world * B * args.steps / elapsed
@@ -431,7 +447,7 @@ def main():
                        "global_batch": world * B, "parallelism": f"shard{world} (shard_id/num_shards, no collective)",
                        "pixels_per_batch": hp.pixels},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "per_kernel": {k: {"algorithmic_bytes": v[0], "avg_ms": v[1],
                                             "achieved_GBps": v[0] / (v[1] * 1e-3) / 1e9} for k, v in kern.items()}},
             "e2e_host_huffman": {"huffman_s_per_batch": hp.huffman_s,

@@ -238,13 +238,13 @@ __global__ __launch_bounds__(kTileThreads) void UnstuffScatterKernel(const dalia
 }
 
 // ------------------------------------------------------------------------------------------------ tables
-// Table entry: bits 0-6 zig-zag advance (1..64), 7-10 magnitude bits s, 11-15 code length.
+// Table entry: bits 0-6 zig-zag advance (1..64), 7-11 bits consumed (code length + magnitude bits s), 12-15 s.
 //   DC symbol (category s):  advance 1
 //   AC symbol (run r, size s): s != 0: r + 1;  ZRL (0xF0): 16;  any other s == 0 (EOB): 64 = "to the end of the block"
 __host__ __device__ __forceinline__ uint32_t MakeEntry(int len, int sym, bool is_dc) {
   int s = sym & 15, r = sym >> 4;
   int adv = is_dc ? 1 : (s ? r + 1 : (r == 15 ? 16 : 64));
-  return (uint32_t)((len << 11) | (s << 7) | adv);
+  return (uint32_t)((s << 12) | ((len + s) << 7) | adv);
 }
 
 // zig-zag scan order expressed in column-major block positions (= the transposed zig-zag)
@@ -433,7 +433,7 @@ __device__ __forceinline__ int DecodeRange(const HuffTables &L, GlobalWords *__r
     const uint32_t slot = (((is_dc ? dc_mask : ac_mask) >> c) & 1u) + (is_dc ? 0u : 2u);
     uint32_t e = fast[(slot << kFastBits) + (peek >> (32 - kFastBits))];
     if (__builtin_expect(e == 0, 0)) e = LongCode(L, slot, peek, is_dc);
-    const uint32_t used = (e >> 11) + ((e >> 7) & 15);
+    const uint32_t used = (e >> 7) & 31;
     rem -= (int)used;
     off += used;
     z += e & 127;
@@ -496,7 +496,7 @@ __device__ __forceinline__ void WriteRange(const HuffTables &L, GlobalWords *__r
       const uint32_t slot = (((is_dc ? dc_mask : ac_mask) >> c) & 1u) + (is_dc ? 0u : 2u);
       uint32_t e = fast[(slot << kFastBits) + (peek >> (32 - kFastBits))];
       if (__builtin_expect(e == 0, 0)) e = LongCode(L, slot, peek, is_dc);
-      const uint32_t len = e >> 11, s = (e >> 7) & 15, adv = e & 127;
+      const uint32_t used = (e >> 7) & 31, s = e >> 12, adv = e & 127, len = used - s;
       // magnitude bits -> value (T.81 F.2.2.1 EXTEND); s == 0 gives 0
       const uint32_t m = ((peek << len) >> 1) >> (31 - s);
       const uint32_t half = (1u << s) >> 1;
@@ -511,7 +511,6 @@ __device__ __forceinline__ void WriteRange(const HuffTables &L, GlobalWords *__r
         zt = 0;
       }
       if (blk && (is_dc || (s && zt < 64))) blk[L.zz[zt]] = (int16_t)val;
-      const uint32_t used = len + s;
       rem -= (int)used;
       off += used;
       z += adv;
