@@ -27,7 +27,8 @@ JPEG_GRAY, JPEG_YCC, JPEG_RGB = 0, 1, 2
 class JpegIdctDesc(C.Structure):
     _fields_ = [("coef", C.c_void_p), ("plane", C.c_void_p), ("blocks_x", C.c_int32),
                 ("nblocks", C.c_int32), ("pitch", C.c_int32), ("wg_start", C.c_int32),
-                ("quant", C.c_uint16 * 64)]
+                ("quant", C.c_uint16 * 64), ("rect_x0", C.c_int32), ("rect_y0", C.c_int32),
+                ("rect_w", C.c_int32), ("reserved", C.c_int32)]
 
 
 class JpegHuffDesc(C.Structure):
@@ -38,7 +39,7 @@ class JpegHuffDesc(C.Structure):
                 ("seg_start", C.c_int32), ("num_segments", C.c_int32),
                 ("comp_of_block", C.c_uint8 * 12), ("h_of_block", C.c_uint8 * 12),
                 ("v_of_block", C.c_uint8 * 12), ("dc_sel", C.c_uint8 * 4), ("ac_sel", C.c_uint8 * 4),
-                ("bits", (C.c_uint8 * 16) * 4), ("vals", (C.c_uint8 * 256) * 4)]
+                ("bits", (C.c_uint8 * 16) * 4), ("vals", (C.c_uint8 * 256) * 4), ("rect", (C.c_int32 * 4) * 3)]
 
 
 class JpegColorDesc(C.Structure):
@@ -46,7 +47,14 @@ class JpegColorDesc(C.Structure):
                 ("v_samp", C.c_int32 * 3), ("down_w", C.c_int32 * 3), ("down_h", C.c_int32 * 3),
                 ("width", C.c_int32), ("height", C.c_int32), ("color", C.c_int32),
                 ("out", C.c_void_p), ("out_pitch", C.c_int32), ("wg_start", C.c_int32),
-                ("orientation", C.c_int32), ("reserved", C.c_int32)]
+                ("orientation", C.c_int32), ("reserved", C.c_int32), ("roi_x0", C.c_int32),
+                ("roi_y0", C.c_int32), ("roi_w", C.c_int32), ("roi_h", C.c_int32), ("out_x0", C.c_int32),
+                ("out_y0", C.c_int32)]
+
+
+class JpegRoiPlan(C.Structure):
+    _fields_ = [("roi_x0", C.c_int32), ("roi_y0", C.c_int32), ("roi_w", C.c_int32), ("roi_h", C.c_int32),
+                ("out_x0", C.c_int32), ("out_y0", C.c_int32), ("rect", (C.c_int32 * 4) * 3)]
 
 
 class ResampleArgs(C.Structure):
@@ -149,7 +157,7 @@ _KERNEL_SYMBOLS = [
     "daliamdMalloc", "daliamdFree", "daliamdHostAlloc", "daliamdHostFree", "daliamdMemcpyH2DAsync",
     "daliamdMemcpyD2HAsync", "daliamdMemcpyD2DAsync", "daliamdMemsetAsync",
     "daliamdJpegIdctSetup", "daliamdJpegIdctRun", "daliamdJpegHuffmanScratchBytes", "daliamdJpegHuffmanSetup",
-    "daliamdJpegHuffmanRun", "daliamdJpegHuffmanRunProfiled", "daliamdJpegColorSetup", "daliamdJpegColorRun",
+    "daliamdJpegHuffmanRun", "daliamdJpegHuffmanRunProfiled", "daliamdJpegColorSetup", "daliamdJpegPlanRoi", "daliamdJpegColorRun",
     "daliamdResampleSetup", "daliamdResampleRun", "daliamdCmnSetup", "daliamdCmnRun",
     "daliamdWarpAffineSetup", "daliamdWarpAffineRun", "daliamdGaussianWindow", "daliamdGaussianBlurSetup",
     "daliamdGaussianBlurRun", "daliamdColorTwistMatrix", "daliamdPointwiseSetup", "daliamdPointwiseRun",

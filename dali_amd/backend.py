@@ -78,7 +78,9 @@ def _thread_pool(num_threads=None):
 class JpegBatchPlan:
     """Geometry + buffer layout of one batch of JPEG streams (host side, no device work)."""
 
-    def __init__(self, encoded, out_pitch_align=16):
+    def __init__(self, encoded, out_pitch_align=16, rois=None):
+        """rois: optional per-sample windows (y0, x0, h, w) in image pixels (None entries = whole image): only the
+        window is decoded (region-of-interest decode; EXIF orientation is not applied by this driver)."""
         host = capi.host()
         self.n = len(encoded)
         self.encoded = [np.frombuffer(e, dtype=np.uint8) if not isinstance(e, np.ndarray) else
@@ -100,8 +102,26 @@ class JpegBatchPlan:
         starts = np.concatenate([[0], np.cumsum(flat)[:-1]]).reshape(-1, 3) if self.n else np.zeros((0, 3), np.int64)
         self.coef_off = starts                     # int16 elements
         self.plane_off = starts                    # bytes: one byte per coefficient
-        self.out_pitch = (3 * inf["width"].astype(np.int64) + out_pitch_align - 1) // out_pitch_align * out_pitch_align
-        osz = (self.out_pitch * inf["height"] + 255) // 256 * 256
+        # region-of-interest plans (daliamdJpegPlanRoi): window in source pixels + block rectangles per component
+        self.out_h, self.out_w = inf["height"].astype(np.int64).copy(), inf["width"].astype(np.int64).copy()
+        self.roi_plans = None
+        if rois is not None and self.n:
+            lib = capi.kernels()
+            self.roi_plans = np.zeros(self.n, np.dtype(capi.JpegRoiPlan))
+            self.has_roi = np.zeros(self.n, bool)
+            for i, r in enumerate(rois):
+                if r is None:
+                    continue
+                hs = (C.c_int32 * 3)(*[int(v) for v in inf["h_samp"][i, :3]])
+                vs = (C.c_int32 * 3)(*[int(v) for v in inf["v_samp"][i, :3]])
+                plan = capi.JpegRoiPlan()
+                capi.check(lib.daliamdJpegPlanRoi(int(inf["width"][i]), int(inf["height"][i]), int(ncomp[i]), hs, vs, 1,
+                                                  int(r[0]), int(r[1]), int(r[2]), int(r[3]), C.byref(plan)))
+                self.roi_plans[i] = np.frombuffer(plan, dtype=np.dtype(capi.JpegRoiPlan))[0]
+                self.has_roi[i] = True
+                self.out_h[i], self.out_w[i] = int(r[2]), int(r[3])
+        self.out_pitch = (3 * self.out_w + out_pitch_align - 1) // out_pitch_align * out_pitch_align
+        osz = (self.out_pitch * self.out_h + 255) // 256 * 256
         self.out_off = np.concatenate([[0], np.cumsum(osz)[:-1]]).astype(np.int64) if self.n else np.zeros(0, np.int64)
         self.coef_elems = int(flat.sum())
         self.plane_bytes = self.coef_elems
@@ -110,7 +130,7 @@ class JpegBatchPlan:
         self.quant = np.zeros((self.n, 3, 64), np.uint16)
 
     def shapes(self):
-        return [(self.infos[i].height, self.infos[i].width, 3) for i in range(self.n)]
+        return [(int(self.out_h[i]), int(self.out_w[i]), 3) for i in range(self.n)]
 
     def entropy_decode(self, coef_host, num_threads=None):
         """Huffman-decodes every stream into `coef_host` (int16 host tensor/array of
@@ -215,6 +235,8 @@ class JpegBatchPlan:
         d["bits"][:, 2:4] = sc["ac_bits"][sel, 0:2]
         d["vals"][:, 0:2] = sc["dc_vals"][sel, 0:2]
         d["vals"][:, 2:4] = sc["ac_vals"][sel, 0:2]
+        if self.roi_plans is not None:
+            d["rect"] = np.where(self.has_roi[sel][:, None, None], self.roi_plans["rect"][sel], 0)
         ntiles, nsegs = C.c_int(0), C.c_int(0)
         capi.check(lib.daliamdJpegHuffmanSetup(d.ctypes.data_as(C.c_void_p), m, C.byref(ntiles), C.byref(nsegs)))
         return d, ntiles.value, nsegs.value
@@ -308,6 +330,15 @@ class JpegBatchPlan:
             idct["nblocks"][:ncomp_total] = (bx * by)[m]
             idct["pitch"][:ncomp_total] = (bx * 8)[m]
             idct["quant"][:ncomp_total] = self.quant[m]
+            if self.roi_plans is not None:
+                rect = self.roi_plans["rect"]                       # [n, 3, 4]
+                roi3 = np.broadcast_to(self.has_roi[:, None], m.shape)
+                rw = np.where(roi3, rect[:, :, 2] - rect[:, :, 0], 0)
+                rh = rect[:, :, 3] - rect[:, :, 1]
+                idct["rect_x0"][:ncomp_total] = np.where(roi3, rect[:, :, 0], 0)[m]
+                idct["rect_y0"][:ncomp_total] = np.where(roi3, rect[:, :, 1], 0)[m]
+                idct["rect_w"][:ncomp_total] = rw[m]
+                idct["nblocks"][:ncomp_total] = np.where(roi3, rw * rh, bx * by)[m]
             color["plane"][:self.n] = np.where(m, plane_ptr, 0)
             color["pitch"][:self.n] = np.where(m, bx * 8, 0)
             color["h_samp"][:self.n] = np.where(m, inf["h_samp"][:, :3], 1)
@@ -319,6 +350,9 @@ class JpegBatchPlan:
             color["color"][:self.n] = inf["color"]
             color["out"][:self.n] = ob + self.out_off
             color["out_pitch"][:self.n] = self.out_pitch
+            if self.roi_plans is not None:
+                for f in ("roi_x0", "roi_y0", "roi_w", "roi_h", "out_x0", "out_y0"):
+                    color[f][:self.n] = np.where(self.has_roi, self.roi_plans[f], 0)
         n_idct_wg, n_color_wg = C.c_int(0), C.c_int(0)
         capi.check(lib.daliamdJpegIdctSetup(idct.ctypes.data_as(C.c_void_p), ncomp_total, C.byref(n_idct_wg)))
         capi.check(lib.daliamdJpegColorSetup(color.ctypes.data_as(C.c_void_p), self.n, C.byref(n_color_wg)))
@@ -328,7 +362,7 @@ class JpegBatchPlan:
         views = []
         for i in range(self.n):
             inf = self.infos[i]
-            v = torch.as_strided(out_dev, (inf.height, inf.width, 3), (int(self.out_pitch[i]), 3, 1),
+            v = torch.as_strided(out_dev, (int(self.out_h[i]), int(self.out_w[i]), 3), (int(self.out_pitch[i]), 3, 1),
                                  int(self.out_off[i]))
             views.append(v)
         return views
@@ -354,14 +388,15 @@ def jpeg_gpu_stage(plan, coef_dev, planes_dev, out_dev, descs=None, split_events
     return idct_dev, color_dev
 
 
-def decode_jpeg_batch(encoded, device="cuda", num_threads=None, out_pitch_align=16, huffman="gpu"):
+def decode_jpeg_batch(encoded, device="cuda", num_threads=None, out_pitch_align=16, huffman="gpu", rois=None):
     """Decodes a batch of JPEG byte strings -> list of u8 HWC RGB device tensors.
+    rois: optional per-sample windows (y0, x0, h, w): region-of-interest decode (decoders.image_crop & co.).
 
     huffman="gpu": entropy decoding on the device for baseline single-scan streams (host for the rest);
     huffman="host": header parse + Huffman on the host thread pool into pinned memory (the hybrid path).
     Dequantisation, IDCT, upsampling and colour conversion always run on the device."""
     device = torch.device(device)
-    plan = JpegBatchPlan(encoded, out_pitch_align)
+    plan = JpegBatchPlan(encoded, out_pitch_align, rois=rois)
     status = None
     if huffman == "gpu":
         coef_host = None

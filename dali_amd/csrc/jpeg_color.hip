@@ -30,52 +30,72 @@ enum UpsampleMode { kFull = 0, kH2V1 = 1, kH2V2 = 2, kH1V2 = 3, kBox = 4 };
 
 __device__ __forceinline__ int ClampI(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
-// Fetches the 8 upsampled chroma samples for pixels x0..x0+7 of output row y.
+// Triangle filter along x for the pixels x0..x0+7 from the (already vertically combined) samples around them.
+// sv[i] = sample (x0 >> 1) - 1 + i (clamped), i = 0..6; SHIFT/BIAS as in jdsample.c (h2v1: 2 / 1,2; h2v2: 4 / 8,7).
+template <int SHIFT, int BIAS_EVEN, int BIAS_ODD>
+__device__ __forceinline__ void TriangleX8(const int sv[7], bool odd, int out[8]) {
+  if (!odd) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      out[2 * i] = (sv[1 + i] * 3 + sv[i] + BIAS_EVEN) >> SHIFT;
+      out[2 * i + 1] = (sv[1 + i] * 3 + sv[2 + i] + BIAS_ODD) >> SHIFT;
+    }
+  } else {  // x0 odd: the first pixel is the odd half of sample (x0 >> 1)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      out[2 * i] = (sv[1 + i] * 3 + sv[2 + i] + BIAS_ODD) >> SHIFT;
+      out[2 * i + 1] = (sv[2 + i] * 3 + sv[1 + i] + BIAS_EVEN) >> SHIFT;
+    }
+  }
+}
+
+// Fetches the 8 upsampled samples of one component for pixels x0..x0+7 of output row y (any x0: with a region of
+// interest the 8-pixel groups are aligned to the region, not to the image).
 __device__ __forceinline__ void UpsampleRow8(const uint8_t *__restrict__ plane, int pitch, int mode, int hx,
                                              int vx, int dw, int dh, int x0, int y, int out[8]) {
   if (mode == kFull) {
-    const uint8_t *p = plane + (size_t)y * pitch + x0;
-    uint2 v = *reinterpret_cast<const uint2 *>(p);  // planes are padded to 8-sample blocks
+    const uint8_t *p = plane + (size_t)y * pitch;
+    if ((x0 & 7) == 0) {
+      uint2 v = *reinterpret_cast<const uint2 *>(p + x0);  // planes are padded to 8-sample blocks
 #pragma unroll
-    for (int i = 0; i < 4; i++) { out[i] = (v.x >> (8 * i)) & 255; out[4 + i] = (v.y >> (8 * i)) & 255; }
+      for (int i = 0; i < 4; i++) { out[i] = (v.x >> (8 * i)) & 255; out[4 + i] = (v.y >> (8 * i)) & 255; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; i++) out[i] = p[min(x0 + i, pitch - 1)];
+    }
   } else if (mode == kH2V1) {
     const uint8_t *p = plane + (size_t)y * pitch;
     int k0 = x0 >> 1;
-    int s[6];
+    int s[7];
 #pragma unroll
-    for (int i = 0; i < 6; i++) s[i] = p[ClampI(k0 - 1 + i, 0, dw - 1)];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      out[2 * i] = (s[1 + i] * 3 + s[i] + 1) >> 2;
-      out[2 * i + 1] = (s[1 + i] * 3 + s[2 + i] + 2) >> 2;
-    }
+    for (int i = 0; i < 7; i++) s[i] = p[ClampI(k0 - 1 + i, 0, dw - 1)];
+    TriangleX8<2, 1, 2>(s, x0 & 1, out);
   } else if (mode == kH2V2) {
     int r = y >> 1;
     int r1 = ClampI((y & 1) ? r + 1 : r - 1, 0, dh - 1);
     const uint8_t *p0 = plane + (size_t)r * pitch, *p1 = plane + (size_t)r1 * pitch;
     int k0 = x0 >> 1;
-    int s[6];
+    int s[7];
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
+    for (int i = 0; i < 7; i++) {
       int k = ClampI(k0 - 1 + i, 0, dw - 1);
       s[i] = p0[k] * 3 + p1[k];
     }
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      out[2 * i] = (s[1 + i] * 3 + s[i] + 8) >> 4;
-      out[2 * i + 1] = (s[1 + i] * 3 + s[2 + i] + 7) >> 4;
-    }
+    TriangleX8<4, 8, 7>(s, x0 & 1, out);
   } else if (mode == kH1V2) {
     int r = y >> 1;
     int r1 = ClampI((y & 1) ? r + 1 : r - 1, 0, dh - 1);
     int bias = (y & 1) ? 2 : 1;
-    const uint8_t *p0 = plane + (size_t)r * pitch + x0, *p1 = plane + (size_t)r1 * pitch + x0;
+    const uint8_t *p0 = plane + (size_t)r * pitch, *p1 = plane + (size_t)r1 * pitch;
 #pragma unroll
-    for (int i = 0; i < 8; i++) out[i] = (p0[i] * 3 + p1[i] + bias) >> 2;
+    for (int i = 0; i < 8; i++) {
+      int x = min(x0 + i, pitch - 1);
+      out[i] = (p0[x] * 3 + p1[x] + bias) >> 2;
+    }
   } else {
     const uint8_t *p = plane + (size_t)(y / vx) * pitch;
 #pragma unroll
-    for (int i = 0; i < 8; i++) out[i] = p[(x0 + i) / hx];
+    for (int i = 0; i < 8; i++) out[i] = p[min((x0 + i) / hx, pitch - 1)];
   }
 }
 
@@ -94,12 +114,17 @@ __global__ __launch_bounds__(kColorThreads) void JpegColorKernel(const daliamdJp
   if (wg < 0) return;
   int di = FindDesc(descs, ndesc, wg);
   const daliamdJpegColorDesc &d = descs[di];
-  int tiles_x = (d.width + kTileW - 1) / kTileW;
+  // region of the (un-rotated) image to produce; the 8-pixel groups are aligned to its origin so that the output
+  // rows keep their 8-byte store alignment
+  const bool roi = d.roi_w > 0;
+  const int rx0 = roi ? d.roi_x0 : 0, ry0 = roi ? d.roi_y0 : 0;
+  const int rx1 = roi ? d.roi_x0 + d.roi_w : d.width, ry1 = roi ? d.roi_y0 + d.roi_h : d.height;
+  int tiles_x = (rx1 - rx0 + kTileW - 1) / kTileW;
   int t = wg - d.wg_start;
   int ty = t / tiles_x, tx = t - ty * tiles_x;
-  int x0 = tx * kTileW + (threadIdx.x & 31) * 8;
-  int y = ty * kTileH + (threadIdx.x >> 5);
-  if (x0 >= d.width || y >= d.height) return;
+  int x0 = rx0 + tx * kTileW + (threadIdx.x & 31) * 8;
+  int y = ry0 + ty * kTileH + (threadIdx.x >> 5);
+  if (x0 >= rx1 || y >= ry1) return;
 
   int ncomp = d.color == DALIAMD_JPEG_GRAY ? 1 : 3;
   int hmax = 1, vmax = 1;
@@ -128,7 +153,8 @@ __global__ __launch_bounds__(kColorThreads) void JpegColorKernel(const daliamdJp
       px[3 * i] = Clamp8(r); px[3 * i + 1] = Clamp8(g); px[3 * i + 2] = Clamp8(b);
     }
   }
-  int npx = min(8, d.width - x0);
+  int npx = min(8, rx1 - x0);
+  const int out_x0 = roi ? d.out_x0 : 0, out_y0 = roi ? d.out_y0 : 0;
   if (d.orientation > 1) {
     // undo the EXIF orientation: source pixel (y, x) lands at (oy, ox) of the upright image
     const int W = d.width, H = d.height;
@@ -143,12 +169,12 @@ __global__ __launch_bounds__(kColorThreads) void JpegColorKernel(const daliamdJp
         case 7: oy = W - 1 - x; ox = H - 1 - y; break;
         default: oy = W - 1 - x; ox = y; break;  // 8
       }
-      uint8_t *p = d.out + (size_t)oy * d.out_pitch + (size_t)ox * 3;
+      uint8_t *p = d.out + (size_t)(oy - out_y0) * d.out_pitch + (size_t)(ox - out_x0) * 3;
       p[0] = (uint8_t)px[3 * i]; p[1] = (uint8_t)px[3 * i + 1]; p[2] = (uint8_t)px[3 * i + 2];
     }
     return;
   }
-  uint8_t *o = d.out + (size_t)y * d.out_pitch + (size_t)x0 * 3;
+  uint8_t *o = d.out + (size_t)(y - out_y0) * d.out_pitch + (size_t)(x0 - out_x0) * 3;
   if (npx == 8 && ((d.out_pitch & 7) == 0) && ((reinterpret_cast<uintptr_t>(d.out) & 7) == 0)) {
     uint32_t w[6];
 #pragma unroll
@@ -177,7 +203,14 @@ daliamdResult_t daliamdJpegColorSetup(daliamdJpegColorDesc *descs, int n, int *n
                     "daliamdJpegColorSetup: desc %d has empty image", i);
     DALIAMD_REQUIRE(d.orientation >= 0 && d.orientation <= 8, DALIAMD_ERROR_INVALID_ARGUMENT,
                     "daliamdJpegColorSetup: desc %d: invalid EXIF orientation %d", i, d.orientation);
-    DALIAMD_REQUIRE(d.out_pitch >= 3 * (d.orientation >= 5 ? d.height : d.width), DALIAMD_ERROR_INVALID_ARGUMENT,
+    DALIAMD_REQUIRE(d.roi_w >= 0 && d.roi_h >= 0 && (d.roi_w == 0 || (d.roi_h > 0 && d.roi_x0 >= 0 && d.roi_y0 >= 0 &&
+                                                                       d.roi_x0 + d.roi_w <= d.width &&
+                                                                       d.roi_y0 + d.roi_h <= d.height)),
+                    DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdJpegColorSetup: desc %d: region of interest out of bounds", i);
+    DALIAMD_REQUIRE(d.roi_w > 0 || (d.out_x0 == 0 && d.out_y0 == 0), DALIAMD_ERROR_INVALID_ARGUMENT,
+                    "daliamdJpegColorSetup: desc %d: output origin without a region of interest", i);
+    const int pw = d.roi_w > 0 ? d.roi_w : d.width, ph = d.roi_w > 0 ? d.roi_h : d.height;  // produced source pixels
+    DALIAMD_REQUIRE(d.out_pitch >= 3 * (d.orientation >= 5 ? ph : pw), DALIAMD_ERROR_INVALID_ARGUMENT,
                     "daliamdJpegColorSetup: desc %d out_pitch %d < 3*width", i, d.out_pitch);
     int ncomp = d.color == DALIAMD_JPEG_GRAY ? 1 : 3;
     int hmax = 1, vmax = 1;
@@ -191,9 +224,59 @@ daliamdResult_t daliamdJpegColorSetup(daliamdJpegColorDesc *descs, int n, int *n
       DALIAMD_REQUIRE(hmax % d.h_samp[c] == 0 && vmax % d.v_samp[c] == 0, DALIAMD_ERROR_UNSUPPORTED,
                       "daliamdJpegColorSetup: fractional chroma sampling ratios are not supported");
     d.wg_start = wg;
-    wg += ((d.width + daliamd::kTileW - 1) / daliamd::kTileW) * ((d.height + daliamd::kTileH - 1) / daliamd::kTileH);
+    wg += ((pw + daliamd::kTileW - 1) / daliamd::kTileW) * ((ph + daliamd::kTileH - 1) / daliamd::kTileH);
   }
   *num_workgroups = wg;
+  return DALIAMD_SUCCESS;
+}
+
+daliamdResult_t daliamdJpegPlanRoi(int width, int height, int num_components, const int32_t *h_samp,
+                                   const int32_t *v_samp, int orientation, int up_y0, int up_x0, int up_h, int up_w,
+                                   daliamdJpegRoiPlan *plan) {
+  DALIAMD_REQUIRE(plan && h_samp && v_samp && width > 0 && height > 0 && (num_components == 1 || num_components == 3),
+                  DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdJpegPlanRoi: invalid argument");
+  DALIAMD_REQUIRE(orientation >= 0 && orientation <= 8, DALIAMD_ERROR_INVALID_ARGUMENT,
+                  "daliamdJpegPlanRoi: invalid EXIF orientation %d", orientation);
+  const int W = width, H = height;
+  const int UW = orientation >= 5 ? H : W, UH = orientation >= 5 ? W : H;  // upright image
+  DALIAMD_REQUIRE(up_h > 0 && up_w > 0 && up_y0 >= 0 && up_x0 >= 0 && up_y0 + up_h <= UH && up_x0 + up_w <= UW,
+                  DALIAMD_ERROR_OUT_OF_RANGE, "daliamdJpegPlanRoi: window [%d:%d, %d:%d] does not fit a %dx%d image", up_y0,
+                  up_y0 + up_h, up_x0, up_x0 + up_w, UH, UW);
+  // inverse of the orientation mapping of JpegColorKernel: upright window -> source window
+  int sx0, sy0, sw, sh;
+  switch (orientation) {
+    case 2: sx0 = W - (up_x0 + up_w); sy0 = up_y0; sw = up_w; sh = up_h; break;
+    case 3: sx0 = W - (up_x0 + up_w); sy0 = H - (up_y0 + up_h); sw = up_w; sh = up_h; break;
+    case 4: sx0 = up_x0; sy0 = H - (up_y0 + up_h); sw = up_w; sh = up_h; break;
+    case 5: sx0 = up_y0; sw = up_h; sy0 = up_x0; sh = up_w; break;
+    case 6: sx0 = up_y0; sw = up_h; sy0 = H - (up_x0 + up_w); sh = up_w; break;
+    case 7: sx0 = W - (up_y0 + up_h); sw = up_h; sy0 = H - (up_x0 + up_w); sh = up_w; break;
+    case 8: sx0 = W - (up_y0 + up_h); sw = up_h; sy0 = up_x0; sh = up_w; break;
+    default: sx0 = up_x0; sy0 = up_y0; sw = up_w; sh = up_h; break;
+  }
+  plan->roi_x0 = sx0; plan->roi_y0 = sy0; plan->roi_w = sw; plan->roi_h = sh;
+  plan->out_x0 = up_x0; plan->out_y0 = up_y0;
+  int hmax = 1, vmax = 1;
+  for (int c = 0; c < num_components; c++) {
+    DALIAMD_REQUIRE(h_samp[c] >= 1 && h_samp[c] <= 4 && v_samp[c] >= 1 && v_samp[c] <= 4, DALIAMD_ERROR_INVALID_ARGUMENT,
+                    "daliamdJpegPlanRoi: bad sampling factors");
+    hmax = hmax > h_samp[c] ? hmax : h_samp[c];
+    vmax = vmax > v_samp[c] ? vmax : v_samp[c];
+  }
+  for (int c = 0; c < 3; c++) plan->rect[c][0] = plan->rect[c][1] = plan->rect[c][2] = plan->rect[c][3] = 0;
+  for (int c = 0; c < num_components; c++) {
+    // samples of this component the colour kernel reads for the window: the co-sited ones plus one neighbour on
+    // each side where it interpolates (fancy upsampling); conservative for the box modes
+    const int hf = hmax / h_samp[c], vf = vmax / v_samp[c];
+    const int dw = (W * h_samp[c] + hmax - 1) / hmax, dh = (H * v_samp[c] + vmax - 1) / vmax;
+    int lo_x = sx0 / hf, hi_x = (sx0 + sw - 1) / hf, lo_y = sy0 / vf, hi_y = (sy0 + sh - 1) / vf;
+    if (hf > 1) { lo_x -= 1; hi_x += 1; }
+    if (vf > 1) { lo_y -= 1; hi_y += 1; }
+    lo_x = lo_x < 0 ? 0 : lo_x; lo_y = lo_y < 0 ? 0 : lo_y;
+    hi_x = hi_x > dw - 1 ? dw - 1 : hi_x; hi_y = hi_y > dh - 1 ? dh - 1 : hi_y;
+    plan->rect[c][0] = lo_x >> 3; plan->rect[c][1] = lo_y >> 3;
+    plan->rect[c][2] = (hi_x >> 3) + 1; plan->rect[c][3] = (hi_y >> 3) + 1;
+  }
   return DALIAMD_SUCCESS;
 }
 

@@ -83,7 +83,13 @@ struct HuffTables {
   int32_t blk_sx[12], blk_sy[12];    // coefficient-array stride (elements) per MCU column / MCU row
   GlobalCoef *blk_base[12];          // address of that block in MCU (0, 0)
   uint32_t dc_mask, ac_mask;         // bit k: table selector of the k-th block of the MCU
-  int32_t bpm, mcus_x, total_blocks, reserved[3];
+  int32_t bpm, mcus_x, total_blocks;
+  // region-of-interest decode: blocks outside their component's rectangle are parsed but not stored
+  int32_t use_rect;
+  int32_t last_ordinal;              // first block ordinal behind the last MCU row that is needed
+  int32_t reserved;
+  uint8_t blk_hs[16], blk_vs[16], blk_ho[16], blk_vo[16];  // block position = (mx*hs + ho, my*vs + vo)
+  int32_t blk_rect[12][4];           // {x0, y0, x1, y1} of the block's component
 };
 static_assert(sizeof(HuffTables) % 16 == 0, "copied with 16-byte accesses");
 
@@ -278,6 +284,11 @@ __global__ __launch_bounds__(256) void BuildTablesKernel(const daliamdJpegHuffDe
     L.blk_sx[tid] = d.h_samp[comp] * 64;
     L.blk_sy[tid] = d.v_samp[comp] * d.blocks_x[comp] * 64;
     L.blk_base[tid] = (GlobalCoef *)d.coef[comp] + ((size_t)d.v_of_block[tid] * d.blocks_x[comp] + d.h_of_block[tid]) * 64;
+    L.blk_hs[tid] = (uint8_t)d.h_samp[comp];
+    L.blk_vs[tid] = (uint8_t)d.v_samp[comp];
+    L.blk_ho[tid] = d.h_of_block[tid];
+    L.blk_vo[tid] = d.v_of_block[tid];
+    for (int j = 0; j < 4; j++) L.blk_rect[tid][j] = d.rect[comp][j];
   }
   if (tid == 0) {
     uint32_t dc_mask = 0, ac_mask = 0;
@@ -291,6 +302,19 @@ __global__ __launch_bounds__(256) void BuildTablesKernel(const daliamdJpegHuffDe
     L.bpm = d.blocks_per_mcu;
     L.mcus_x = d.mcus_x;
     L.total_blocks = d.total_blocks;
+    // region of interest: any non-empty rectangle switches the filter on
+    int use_rect = 0, last_mcu_row = 0;
+    for (int k = 0; k < d.blocks_per_mcu; k++) {
+      int comp = d.comp_of_block[k];
+      if (d.rect[comp][2] > d.rect[comp][0] && d.rect[comp][3] > d.rect[comp][1]) {
+        use_rect = 1;
+        int rows = (d.rect[comp][3] + d.v_samp[comp] - 1) / d.v_samp[comp];  // MCU rows up to the rectangle's bottom
+        last_mcu_row = rows > last_mcu_row ? rows : last_mcu_row;
+      }
+    }
+    L.use_rect = use_rect;
+    int last = last_mcu_row * d.mcus_x * d.blocks_per_mcu;
+    L.last_ordinal = use_rect && last < d.total_blocks ? last : d.total_blocks;
   }
   __syncthreads();
   if (tid < 4) {
@@ -388,7 +412,11 @@ struct BlockCursor {
     }
   }
   __device__ __forceinline__ GlobalCoef *Ptr(const HuffTables &L) const {
-    if (ordinal >= L.total_blocks) return nullptr;
+    if (ordinal >= L.last_ordinal) return nullptr;
+    if (L.use_rect) {
+      const int bx = mx * L.blk_hs[k] + L.blk_ho[k], by = my * L.blk_vs[k] + L.blk_vo[k];
+      if (bx < L.blk_rect[k][0] || by < L.blk_rect[k][1] || bx >= L.blk_rect[k][2] || by >= L.blk_rect[k][3]) return nullptr;
+    }
     return L.blk_base[k] + ((size_t)my * (size_t)L.blk_sy[k] + (size_t)(mx * L.blk_sx[k]));
   }
 };
@@ -702,8 +730,8 @@ __global__ __launch_bounds__(kSegThreads) void WriteKernel(const daliamdJpegHuff
   const int ord = segrec->block_base + WorkgroupExclusiveScan<kSegThreads / 64>(ln.nblk, wave_sums, total);
   DcAcc dc;
   DecodeState st = Unpack(ln.in);
-  WriteRange(L, (GlobalWords *)(d.scratch + lay.clean), st, ln.end, ord, ln.active && st.pos < ln.end,
-             sbuf + tid * kStreamWords, dc);
+  WriteRange(L, (GlobalWords *)(d.scratch + lay.clean), st, ln.end, ord,
+             ln.active && st.pos < ln.end && ord < L.last_ordinal, sbuf + tid * kStreamWords, dc);
   if (tid < kSegLanes) {
     recs[tid].dc0 = dc.sum0;
     recs[tid].dc1 = dc.sum1;
@@ -727,6 +755,8 @@ __global__ __launch_bounds__(kSegThreads) void DcFixKernel(const daliamdJpegHuff
   __shared__ uint8_t blk_comp[16];
   __shared__ int blk_sx[12], blk_sy[12];
   __shared__ GlobalCoef *blk_base[12];
+  __shared__ int blk_pos[12][4];   // hs, ho, vs, vo
+  __shared__ int blk_rect[12][4];  // region of interest of the block's component
   const int wg = XcdRemap(blockIdx.x, nseg);
   if (wg < 0) return;
   const ImageRef r = FindImage<false>(descs, n, wg);
@@ -741,11 +771,17 @@ __global__ __launch_bounds__(kSegThreads) void DcFixKernel(const daliamdJpegHuff
     blk_sx[tid] = T->blk_sx[tid];
     blk_sy[tid] = T->blk_sy[tid];
     blk_base[tid] = T->blk_base[tid];
+    blk_pos[tid][0] = T->blk_hs[tid];
+    blk_pos[tid][1] = T->blk_ho[tid];
+    blk_pos[tid][2] = T->blk_vs[tid];
+    blk_pos[tid][3] = T->blk_vo[tid];
+    for (int j = 0; j < 4; j++) blk_rect[tid][j] = T->blk_rect[tid][j];
   }
   if (tid == 0) {
     geom[0] = T->bpm;
     geom[1] = T->mcus_x;
-    geom[2] = T->total_blocks;
+    geom[2] = T->last_ordinal;  // blocks behind it were not written
+    geom[3] = T->use_rect;
   }
   const LaneRec *recs = reinterpret_cast<const LaneRec *>(d.scratch + lay.lanes) + (size_t)seg * kSegLanes;
   const SegRec *segs = reinterpret_cast<const SegRec *>(d.scratch + lay.segs);
@@ -768,21 +804,28 @@ __global__ __launch_bounds__(kSegThreads) void DcFixKernel(const daliamdJpegHuff
   const int ord = segs[seg].block_base + WorkgroupExclusiveScan<kSegThreads / 64>(rec.nblk, wave_sums, unused);
   if (rec.count > 0 && (base0 | base1 | base2)) {
     // the blocks this lane wrote: ordinals [first, first + count); four read-modify-writes in flight at a time
-    const int bpm = geom[0], mcus_x = geom[1], total_blocks = geom[2];
+    const int bpm = geom[0], mcus_x = geom[1], total_blocks = geom[2], use_rect = geom[3];
     int ordinal = ord + ((rec.in & 255) != 0 ? 1 : 0);
     int mcu = ordinal / bpm, k = ordinal - mcu * bpm, my = mcu / mcus_x, mx = mcu - my * mcus_x;
     int left = min(rec.count, total_blocks - ordinal);
     while (left > 0) {
       GlobalCoef *p[4];
       int add[4], v[4];
+      bool stored[4];
       const int m = min(left, 4);
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         p[i] = blk_base[k] + ((size_t)my * (size_t)blk_sy[k] + (size_t)(mx * blk_sx[k]));
         const int cc = blk_comp[k];
         add[i] = cc == 0 ? base0 : cc == 1 ? base1 : base2;
+        stored[i] = i < m;
+        if (use_rect && i < m) {
+          const int bx = mx * blk_pos[k][0] + blk_pos[k][1], by = my * blk_pos[k][2] + blk_pos[k][3];
+          stored[i] = bx >= blk_rect[k][0] && by >= blk_rect[k][1] && bx < blk_rect[k][2] && by < blk_rect[k][3];
+        }
+        v[i] = 0;
         if (i < m) {
-          v[i] = p[i][0];
+          if (stored[i]) v[i] = p[i][0];
           if (++k == bpm) {
             k = 0;
             if (++mx == mcus_x) {
@@ -794,7 +837,7 @@ __global__ __launch_bounds__(kSegThreads) void DcFixKernel(const daliamdJpegHuff
       }
 #pragma unroll
       for (int i = 0; i < 4; i++)
-        if (i < m) p[i][0] = (int16_t)(v[i] + add[i]);
+        if (stored[i]) p[i][0] = (int16_t)(v[i] + add[i]);
       left -= m;
     }
   }

@@ -81,8 +81,18 @@ __global__ __launch_bounds__(kIdctThreads) void JpegIdctKernel(const daliamdJpeg
   int c = tid & 7;    // column in pass 1, row in pass 2
   int blk = (wg - d.wg_start) * kBlocksPerWg + lb;
   bool active = blk < d.nblocks;
+  // position of the block in the component: raster order over the whole component or over the requested rectangle
+  int by, bx;
+  if (d.rect_w > 0) {
+    by = blk / d.rect_w;
+    bx = d.rect_x0 + (blk - by * d.rect_w);
+    by += d.rect_y0;
+  } else {
+    by = blk / d.blocks_x;
+    bx = blk - by * d.blocks_x;
+  }
   if (active) {
-    short8 v = *reinterpret_cast<const short8 *>(d.coef + (size_t)blk * 64 + c * 8);
+    short8 v = *reinterpret_cast<const short8 *>(d.coef + ((size_t)by * d.blocks_x + bx) * 64 + c * 8);
     ushort8 q = *reinterpret_cast<const ushort8 *>(d.quant + c * 8);
     int32_t in[8], o[8];
 #pragma unroll
@@ -104,7 +114,6 @@ __global__ __launch_bounds__(kIdctThreads) void JpegIdctKernel(const daliamdJpeg
                   (RangeLimit(Descale(o[2], S)) << 16) | (RangeLimit(Descale(o[3], S)) << 24);
     uint32_t hi = RangeLimit(Descale(o[4], S)) | (RangeLimit(Descale(o[5], S)) << 8) |
                   (RangeLimit(Descale(o[6], S)) << 16) | (RangeLimit(Descale(o[7], S)) << 24);
-    int by = blk / d.blocks_x, bx = blk - by * d.blocks_x;
     uint2 *dst = reinterpret_cast<uint2 *>(d.plane + (size_t)(by * 8 + c) * d.pitch + bx * 8);
     *dst = make_uint2(lo, hi);
   }
@@ -121,6 +130,10 @@ daliamdResult_t daliamdJpegIdctSetup(daliamdJpegIdctDesc *descs, int n, int *num
   for (int i = 0; i < n; i++) {
     DALIAMD_REQUIRE(descs[i].nblocks >= 0 && descs[i].blocks_x > 0, DALIAMD_ERROR_INVALID_ARGUMENT,
                     "daliamdJpegIdctSetup: desc %d has invalid block counts", i);
+    DALIAMD_REQUIRE(descs[i].rect_w >= 0 && descs[i].rect_x0 >= 0 && descs[i].rect_y0 >= 0 &&
+                        descs[i].rect_x0 + descs[i].rect_w <= descs[i].blocks_x &&
+                        (descs[i].rect_w == 0 || descs[i].nblocks % descs[i].rect_w == 0),
+                    DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdJpegIdctSetup: desc %d: bad block rectangle", i);
     DALIAMD_REQUIRE((descs[i].pitch & 7) == 0 && descs[i].pitch >= descs[i].blocks_x * 8,
                     DALIAMD_ERROR_INVALID_ARGUMENT,
                     "daliamdJpegIdctSetup: desc %d: pitch %d must be a multiple of 8 and >= %d", i,

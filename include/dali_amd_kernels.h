@@ -94,6 +94,9 @@ typedef struct {
   int32_t pitch;       /* plane row pitch in bytes, multiple of 8                          */
   int32_t wg_start;    /* filled by Setup: first workgroup of this component               */
   uint16_t quant[64];  /* quantisation table, same column-major element order as the blocks */
+  /* Region-of-interest decode: only the blocks [rect_y0, ..) x [rect_x0, rect_x0 + rect_w) are transformed;
+   * nblocks = rect_w * rect_h then.  rect_w == 0: the whole component. */
+  int32_t rect_x0, rect_y0, rect_w, reserved;
 } daliamdJpegIdctDesc;
 
 /* Fills wg_start of descs[0..n) and returns the grid size. */
@@ -138,6 +141,10 @@ typedef struct {
   uint8_t dc_sel[4], ac_sel[4];  /* per component: table selector, 0 or 1                           */
   uint8_t bits[4][16];     /* DHT code-length counts: [0],[1] = DC tables 0,1; [2],[3] = AC 0,1    */
   uint8_t vals[4][256];    /* DHT symbol lists, same order                                         */
+  /* Region-of-interest decode: per component the block rectangle {x0, y0, x1, y1} (x1/y1 exclusive) whose
+   * coefficients are needed; blocks outside are parsed (the stream is serial) but not stored, and the parse stops
+   * after the last MCU row that intersects a rectangle.  All zero: every block. */
+  int32_t rect[3][4];
 } daliamdJpegHuffDesc;
 
 DALIAMD_API daliamdResult_t daliamdJpegHuffmanScratchBytes(int ecs_len, size_t *bytes);
@@ -173,9 +180,28 @@ typedef struct {
   int32_t orientation;          /* EXIF orientation to undo while writing: 0/1 none, 2..8;   */
                                 /* for 5..8 the output is height x width transposed          */
   int32_t reserved;
+  /* Region-of-interest decode: only the source pixels [roi_y0, roi_y0 + roi_h) x [roi_x0, roi_x0 + roi_w) of the
+   * (un-rotated) image are produced; `out` then receives the window whose upright-image origin is
+   * (out_y0, out_x0), i.e. upright pixel (oy, ox) lands at out[(oy - out_y0) * out_pitch + 3 * (ox - out_x0)].
+   * roi_w == 0: the whole image (out_x0 = out_y0 = 0). */
+  int32_t roi_x0, roi_y0, roi_w, roi_h, out_x0, out_y0;
 } daliamdJpegColorDesc;
 
 DALIAMD_API daliamdResult_t daliamdJpegColorSetup(daliamdJpegColorDesc *descs_host, int n, int *num_workgroups);
+
+/* Region-of-interest decode (the reference's decoders.image_crop / image_slice / image_random_crop hand a region to
+ * nvImageCodec: dali/operators/imgcodec/image_decoder.h:683-716, roi_image_decoder.h:36-91).  Host helper: turns a
+ * window of the UPRIGHT (orientation-adjusted) image into what the three decode stages need: the window in the
+ * un-rotated source image + output origin (daliamdJpegColorDesc.roi_*, out_*), and per component the rectangle of
+ * 8x8 blocks whose samples the colour stage will read (daliamdJpegHuffDesc.rect, daliamdJpegIdctDesc.rect_*). */
+typedef struct {
+  int32_t roi_x0, roi_y0, roi_w, roi_h; /* source (un-rotated) pixels                      */
+  int32_t out_x0, out_y0;               /* upright-image origin of the output window       */
+  int32_t rect[3][4];                   /* per component: block x0, y0, x1, y1 (exclusive) */
+} daliamdJpegRoiPlan;
+DALIAMD_API daliamdResult_t daliamdJpegPlanRoi(int width, int height, int num_components, const int32_t *h_samp,
+                                               const int32_t *v_samp, int orientation, int up_y0, int up_x0, int up_h,
+                                               int up_w, daliamdJpegRoiPlan *plan);
 DALIAMD_API daliamdResult_t daliamdJpegColorRun(daliamdStream_t stream, const daliamdJpegColorDesc *descs_dev,
                                                 int n, int num_workgroups);
 

@@ -104,6 +104,43 @@ def test_gpu_huffman_truncated_stream_raises():
         B.decode_jpeg_batch([cut], device="cuda", huffman="gpu")
 
 
+@pytest.mark.parametrize("huffman", ["gpu", "host"])
+def test_region_of_interest_decode_equals_decode_then_crop(huffman):
+    """decoders.image_crop / image_random_crop semantics (dali/test/python/decoder/test_image.py:118-216): decoding a
+    window must give exactly the pixels of the full decode, for every chroma layout (the window's edges need the
+    neighbouring chroma samples for fancy upsampling) and for windows touching the image borders."""
+    rng = np.random.default_rng(31)
+    enc, rois = [], []
+    for (h, w) in [(64, 64), (97, 131), (375, 500), (31, 17), (8, 8), (200, 333)]:
+        for kw in [dict(subsampling="4:4:4"), dict(subsampling="4:2:2"), dict(subsampling="4:2:0"),
+                   dict(subsampling="4:1:1"), dict(subsampling="4:2:0", progressive=True)]:
+            e = encode_jpeg(synth_image(rng, h, w), 85, **kw)
+            for _ in range(3):
+                ch, cw = int(rng.integers(1, h + 1)), int(rng.integers(1, w + 1))
+                y0, x0 = int(rng.integers(0, h - ch + 1)), int(rng.integers(0, w - cw + 1))
+                enc.append(e)
+                rois.append((y0, x0, ch, cw))
+            enc.append(e)
+            rois.append((0, 0, h, w))                                   # the whole image as a window
+            enc.append(e)
+            rois.append((h - 1, w - 1, 1, 1))                            # the last pixel
+        g = encode_jpeg(synth_image(rng, h, w, 1), 80)
+        enc.append(g)
+        rois.append((h // 3, w // 4, max(1, h // 2), max(1, w // 2)))
+    enc.append(encode_jpeg(synth_image(rng, 120, 160), 90))
+    rois.append(None)                                                    # mixed with an un-cropped sample
+    got = _decode_gpu(enc, huffman=huffman, rois=rois)
+    cache = {}
+    for i, (e, r) in enumerate(zip(enc, rois)):
+        if id(e) not in cache:
+            cache[id(e)] = O.jpeg_decode_rgb(e)
+        ref = cache[id(e)]
+        if r is not None:
+            ref = ref[r[0]:r[0] + r[2], r[1]:r[1] + r[3]]
+        assert got[i].shape == ref.shape, (i, r)
+        assert np.array_equal(got[i], ref), f"sample {i} roi {r}: max diff {np.abs(got[i].astype(int) - ref).max()}"
+
+
 def test_decode_imagenet_like_batch_dense_and_padded_pitch():
     rng = np.random.default_rng(1234)
     enc = synth_jpeg_batch(rng, 48)
