@@ -133,10 +133,26 @@ class ImageDecoderMixed : public OperatorBase {
     int64_t elems = 0;
     size_t ecs_bytes = 0, scratch_bytes = 0;
     int ncomp_total = 0;
+    // region-of-interest decode (decoders.image_crop / image_random_crop): windows of the upright images
+    upright_hw_.resize(2 * n);
+    for (int i = 0; i < n; i++) {
+      bool swap = adjust_orientation_ && infos_[i].orientation >= 5;
+      upright_hw_[2 * i] = swap ? infos_[i].width : infos_[i].height;
+      upright_hw_[2 * i + 1] = swap ? infos_[i].height : infos_[i].width;
+    }
+    rois_.assign(4 * n, 0);
+    ComputeRois(ws, n);
+    plans_.assign(n, daliamdJpegRoiPlan{});
     for (int i = 0; i < n; i++) {
       const auto &inf = infos_[i];
-      bool swap = adjust_orientation_ && inf.orientation >= 5;
-      shapes[i] = {swap ? inf.width : inf.height, swap ? inf.height : inf.width, 3};
+      shapes[i] = {upright_hw_[2 * i], upright_hw_[2 * i + 1], 3};
+      if (rois_[4 * i + 2] > 0) {
+        if (daliamdJpegPlanRoi(inf.width, inf.height, inf.num_components, inf.h_samp, inf.v_samp,
+                               adjust_orientation_ ? inf.orientation : 1, rois_[4 * i], rois_[4 * i + 1], rois_[4 * i + 2],
+                               rois_[4 * i + 3], &plans_[i]) != DALIAMD_SUCCESS)
+          DALI_FAIL("Failed to decode ", src(i), ": ", daliamdGetLastErrorMessage());
+        shapes[i] = {rois_[4 * i + 2], rois_[4 * i + 3], 3};
+      }
       for (int c = 0; c < inf.num_components; c++) {
         coef_off_[i * 3 + c] = elems;
         elems += inf.coef_elems[c];
@@ -220,6 +236,7 @@ class ImageDecoderMixed : public OperatorBase {
         memcpy(d.comp_of_block, sc.comp_of_block, 10);
         memcpy(d.h_of_block, sc.h_of_block, 10);
         memcpy(d.v_of_block, sc.v_of_block, 10);
+        if (plans_[i].roi_w > 0) memcpy(d.rect, plans_[i].rect, sizeof(d.rect));
         for (int t = 0; t < 2; t++) {
           memcpy(d.bits[t], sc.dc_bits[t], 16);
           memcpy(d.bits[2 + t], sc.ac_bits[t], 16);
@@ -267,6 +284,11 @@ class ImageDecoderMixed : public OperatorBase {
         d.blocks_x = inf.blocks_x[c];
         d.nblocks = inf.blocks_x[c] * inf.blocks_y[c];
         d.pitch = inf.blocks_x[c] * 8;
+        if (plans_[i].roi_w > 0) {
+          const int32_t *r = plans_[i].rect[c];
+          d.rect_x0 = r[0]; d.rect_y0 = r[1]; d.rect_w = r[2] - r[0];
+          d.nblocks = (r[2] - r[0]) * (r[3] - r[1]);
+        }
         memcpy(d.quant, &quant_[(size_t)i * 192 + c * 64], 128);
         cd.plane[c] = d.plane;
         cd.pitch[c] = d.pitch;
@@ -278,6 +300,10 @@ class ImageDecoderMixed : public OperatorBase {
       cd.out = static_cast<uint8_t *>(out.raw(i));
       cd.out_pitch = (int32_t)out.row_pitch(i);
       cd.orientation = adjust_orientation_ ? inf.orientation : 1;
+      if (plans_[i].roi_w > 0) {
+        cd.roi_x0 = plans_[i].roi_x0; cd.roi_y0 = plans_[i].roi_y0; cd.roi_w = plans_[i].roi_w; cd.roi_h = plans_[i].roi_h;
+        cd.out_x0 = plans_[i].out_x0; cd.out_y0 = plans_[i].out_y0;
+      }
     }
     int wg_idct = 0, wg_color = 0;
     KCHECK(daliamdJpegIdctSetup(idct_.data(), ncomp_total, &wg_idct));
@@ -292,7 +318,13 @@ class ImageDecoderMixed : public OperatorBase {
     NoteLaunch(ws, "jpeg_color");
   }
 
+ protected:
+  // Fills rois_[4*i .. 4*i+3] = {y0, x0, h, w} (h == 0: whole image) from upright_hw_ = {H, W} per sample.
+  virtual void ComputeRois(const Workspace &, int) {}
+  std::vector<int32_t> upright_hw_, rois_;
+
  private:
+  std::vector<daliamdJpegRoiPlan> plans_;
   bool adjust_orientation_;
   bool host_huffman_only_ = false;
   int64_t huffman_threshold_ = 0;
@@ -309,6 +341,127 @@ class ImageDecoderMixed : public OperatorBase {
   std::vector<daliamdJpegColorDesc> color_;
   DescUploader up_huff_, up_idct_, up_color_;
 };
+// ---- decoders.image_random_crop: RandomCropAttr window, only the window is decoded --------------------------
+// (dali/operators/imgcodec/decoder_schema.cc:270-299, roi_image_decoder.h:79-91, operators/image/crop/random_crop_attr.h)
+DALI_SCHEMA(decoders__ImageRandomCrop)
+    .DocStr("Decodes images and randomly crops them.\n\nThe cropping window's area (relative to the entire image) and "
+            "aspect ratio can be restricted to a range of values specified by ``random_area`` and "
+            "``random_aspect_ratio``.  Only the blocks of the JPEG that the window touches are dequantised, "
+            "transformed and colour-converted (region-of-interest decoding); the entropy-coded stream is parsed up to "
+            "the last MCU row of the window.\n\nThe output is in HWC layout.")
+    .NumInput(1)
+    .NumOutput(1)
+    .AddParent("decoders__Image")
+    .AddParent("RandomCropAttr");
+DALI_SCHEMA(ImageDecoderRandomCrop).DocStr("Legacy alias of decoders.image_random_crop").NumInput(1).NumOutput(1)
+    .AddParent("decoders__ImageRandomCrop");
+DALI_SCHEMA(experimental__decoders__ImageRandomCrop).DocStr("Alias of decoders.image_random_crop").NumInput(1).NumOutput(1)
+    .AddParent("decoders__ImageRandomCrop");
+
+class ImageDecoderRandomCropMixed : public ImageDecoderMixed {
+ public:
+  explicit ImageDecoderRandomCropMixed(const OpSpec &spec) : ImageDecoderMixed(spec) {
+    auto ar = spec.GetFloatVec("random_aspect_ratio"), area = spec.GetFloatVec("random_area");
+    if (ar.size() == 1) ar.push_back(ar[0]);
+    if (area.size() == 1) area.push_back(area[0]);
+    DALI_ENFORCE(ar.size() == 2 && ar[0] <= ar[1], "Provided empty range");
+    DALI_ENFORCE(area.size() == 2 && area[0] <= area[1], "Provided empty range");
+    ar_lo_ = (float)ar[0]; ar_hi_ = (float)ar[1]; area_lo_ = (float)area[0]; area_hi_ = (float)area[1];
+    num_attempts_ = (int)spec.GetInt("num_attempts");
+    master_.key = (uint64_t)spec.GetInt("seed");
+    master_.ctr[0] = master_.ctr[1] = 0;
+    master_.phase = 0;
+  }
+  std::string SaveState() const override {
+    char buf[96];
+    daliamdPhiloxStateToString(&master_, buf, sizeof(buf));
+    return buf;
+  }
+  void RestoreState(const std::string &s) override {
+    DALI_ENFORCE(daliamdPhiloxStateFromString(&master_, s.c_str()) == 0, daliamdHostGetLastErrorMessage());
+  }
+
+ protected:
+  void ComputeRois(const Workspace &, int n) override {
+    anchors_.resize(2 * n); crops_.resize(2 * n);
+    if (daliamdRandomCropBatch(&master_, n, upright_hw_.data(), ar_lo_, ar_hi_, area_lo_, area_hi_, num_attempts_,
+                               anchors_.data(), crops_.data()) != 0)
+      DALI_FAIL(daliamdHostGetLastErrorMessage());
+    for (int i = 0; i < n; i++) {
+      rois_[4 * i] = anchors_[2 * i]; rois_[4 * i + 1] = anchors_[2 * i + 1];
+      rois_[4 * i + 2] = crops_[2 * i]; rois_[4 * i + 3] = crops_[2 * i + 1];
+    }
+    daliamdPhiloxAdvanceSequence(&master_, (uint64_t)n);  // OperatorWithRng::Advance(batch)
+  }
+
+ private:
+  int num_attempts_;
+  float ar_lo_, ar_hi_, area_lo_, area_hi_;
+  daliamdPhiloxState master_;
+  std::vector<int32_t> anchors_, crops_;
+};
+
+// ---- decoders.image_crop: CropAttr window (fixed size, normalised anchor) ---------------------------------------
+// (decoder_schema.cc:168-196, roi_image_decoder.h:47-61, operators/image/crop/crop_attr.cc:90-240)
+DALI_SCHEMA(decoders__ImageCrop)
+    .DocStr("Decodes images and extracts regions-of-interest (ROI) that are specified by fixed window dimensions and "
+            "variable anchors.  Only the window is decoded.\n\nThe output is in HWC layout.")
+    .NumInput(1)
+    .NumOutput(1)
+    .AddParent("decoders__Image")
+    .AddParent("CropAttr");
+DALI_SCHEMA(ImageDecoderCrop).DocStr("Legacy alias of decoders.image_crop").NumInput(1).NumOutput(1)
+    .AddParent("decoders__ImageCrop");
+DALI_SCHEMA(experimental__decoders__ImageCrop).DocStr("Alias of decoders.image_crop").NumInput(1).NumOutput(1)
+    .AddParent("decoders__ImageCrop");
+
+class ImageDecoderCropMixed : public ImageDecoderMixed {
+ public:
+  explicit ImageDecoderCropMixed(const OpSpec &spec) : ImageDecoderMixed(spec) {
+    std::string r = spec.GetString("rounding");
+    DALI_ENFORCE(r == "round" || r == "truncate", "Unsupported rounding \"", r, "\"");
+    round_ = r == "round";
+    DALI_ENFORCE(spec.ArgumentDefined("crop") || (spec.ArgumentDefined("crop_w") && spec.ArgumentDefined("crop_h")),
+                 "decoders.image_crop needs `crop` or both `crop_w` and `crop_h`");
+  }
+
+ protected:
+  void ComputeRois(const Workspace &ws, int n) override {
+    auto pos_x = GetPerSampleFloat(spec_, ws, "crop_pos_x", n), pos_y = GetPerSampleFloat(spec_, ws, "crop_pos_y", n);
+    std::vector<float> crop_h, crop_w;
+    if (spec_.ArgumentDefined("crop_h")) crop_h = GetPerSampleFloat(spec_, ws, "crop_h", n);
+    if (spec_.ArgumentDefined("crop_w")) crop_w = GetPerSampleFloat(spec_, ws, "crop_w", n);
+    for (int i = 0; i < n; i++) {
+      int64_t H = upright_hw_[2 * i], W = upright_hw_[2 * i + 1], ch = H, cw = W;
+      if (spec_.ArgumentDefined("crop")) {
+        DALI_ENFORCE(!spec_.HasTensorArgument("crop"), "Per-sample `crop` tensors are not supported yet");
+        auto c = spec_.GetFloatVec("crop");
+        DALI_ENFORCE(c.size() == 2, "`crop` must hold (crop_H, crop_W)");
+        ch = (int64_t)c[0]; cw = (int64_t)c[1];
+      }
+      if (!crop_h.empty()) ch = (int64_t)crop_h[i];
+      if (!crop_w.empty()) cw = (int64_t)crop_w[i];
+      DALI_ENFORCE(ch > 0 && cw > 0, "Crop window must have a positive size");
+      DALI_ENFORCE(pos_x[i] >= 0.0f && pos_x[i] <= 1.0f && pos_y[i] >= 0.0f && pos_y[i] <= 1.0f,
+                   "Anchor for dimension ", 0, " is out of range [0.0, 1.0]");
+      int64_t ay = daliamdCropAnchor(pos_y[i], ch, H, round_), ax = daliamdCropAnchor(pos_x[i], cw, W, round_);
+      // CropWindow::EnforceInRange (roi_image_decoder.h:36-45)
+      DALI_ENFORCE(ay >= 0 && ax >= 0 && ay + ch <= H && ax + cw <= W, "Cropping window [", ay, ":", ay + ch, ", ", ax,
+                   ":", ax + cw, "] is out of the bounds of the ", H, "x", W, " image");
+      rois_[4 * i] = (int32_t)ay; rois_[4 * i + 1] = (int32_t)ax; rois_[4 * i + 2] = (int32_t)ch; rois_[4 * i + 3] = (int32_t)cw;
+    }
+  }
+
+ private:
+  bool round_;
+};
+
+DALI_REGISTER_OPERATOR(decoders__ImageRandomCrop, ImageDecoderRandomCropMixed, MIXED);
+DALI_REGISTER_OPERATOR(ImageDecoderRandomCrop, ImageDecoderRandomCropMixed, MIXED);
+DALI_REGISTER_OPERATOR(experimental__decoders__ImageRandomCrop, ImageDecoderRandomCropMixed, MIXED);
+DALI_REGISTER_OPERATOR(decoders__ImageCrop, ImageDecoderCropMixed, MIXED);
+DALI_REGISTER_OPERATOR(ImageDecoderCrop, ImageDecoderCropMixed, MIXED);
+DALI_REGISTER_OPERATOR(experimental__decoders__ImageCrop, ImageDecoderCropMixed, MIXED);
 DALI_REGISTER_OPERATOR(decoders__Image, ImageDecoderMixed, MIXED);
 DALI_REGISTER_OPERATOR(ImageDecoder, ImageDecoderMixed, MIXED);
 DALI_REGISTER_OPERATOR(experimental__decoders__Image, ImageDecoderMixed, MIXED);
@@ -482,6 +635,264 @@ class RandomResizedCropGpu : public OperatorBase {
 DALI_REGISTER_OPERATOR(RandomResizedCrop, RandomResizedCropGpu, GPU);
 
 // =============================================================================================
+// Resize (fn.resize): ResizeAttr size arithmetic on the host + the same resampling kernel
+//   schema / flags      dali/operators/image/resize/resize_attr.cc:24-113, resize_attr_base.cc:22-86
+//   AdjustOutputSize    dali/operators/image/resize/resize_attr_base.cc:88-188
+//   CalculateSampleParams  dali/operators/image/resize/resize_attr_base.h:50-116
+//   operator            dali/operators/image/resize/resize.cc:21-96
+// =============================================================================================
+DALI_SCHEMA(ResizeAttrBase)
+    .DocStr("Resize attributes placeholder")
+    .MakeInternal()
+    .AddOptionalArg("mode", "Resize mode: \"default\" (missing extents keep the aspect ratio), \"stretch\" (missing "
+                    "extents are not scaled), \"not_larger\", \"not_smaller\" (keep the aspect ratio so that no extent "
+                    "exceeds / falls below the requested size).", ArgValue::Str("default"))
+    .AddOptionalArg("subpixel_scale", "If True, fractional sizes, directly specified or calculated, will cause the input "
+                    "ROI to be adjusted to keep the scale factor.", ArgValue::Bool(true))
+    .AddOptionalTypeArg("roi_start", "Origin of the input region of interest (ROI), in the order of `size` (y, x).",
+                        ArgType::FLOAT_VEC, true)
+    .AddOptionalTypeArg("roi_end", "End of the input region of interest (ROI).", ArgType::FLOAT_VEC, true)
+    .AddOptionalArg("roi_relative", "If true, ROI coordinates are relative to the input size.", ArgValue::Bool(false))
+    .AddOptionalTypeArg("max_size", "Limit of the output size (one value, or one per axis).", ArgType::FLOAT_VEC);
+
+DALI_SCHEMA(ResizeAttr)
+    .DocStr("Resize attributes placeholder")
+    .MakeInternal()
+    .AddOptionalArg("resize_x", "The length of the X dimension of the resized image.", ArgValue::Float(0.0), true)
+    .AddOptionalArg("resize_y", "The length of the Y dimension of the resized image.", ArgValue::Float(0.0), true)
+    .AddOptionalTypeArg("size", "The desired output size (H, W); 0 = derive from the other extent and `mode`.",
+                        ArgType::FLOAT_VEC, true)
+    .AddOptionalArg("resize_shorter", "The length of the shorter dimension of the resized image.", ArgValue::Float(0.0), true)
+    .AddOptionalArg("resize_longer", "The length of the longer dimension of the resized image.", ArgValue::Float(0.0), true)
+    .AddParent("ResizeAttrBase");
+
+DALI_SCHEMA(Resize)
+    .DocStr("Resize images.\n\nExpects a three-dimensional uint8 input in HWC layout.")
+    .NumInput(1)
+    .NumOutput(1)
+    .AddParent("ResizeAttr")
+    .AddParent("ResamplingFilterAttr")
+    .InputLayout(0, {"HWC"});
+
+enum class ResizeMode { Default, Stretch, NotLarger, NotSmaller };
+
+// out_size: requested (0 = unspecified) -> final fractional size per dimension
+static void AdjustOutputSize(float *out_size, const float *in_size, int ndim, ResizeMode mode, const float *max_size) {
+  double scale[3] = {1, 1, 1};
+  bool given[3] = {false, false, false};
+  int ngiven = 0;
+  for (int d = 0; d < ndim; d++) {
+    given[d] = out_size[d] != 0 && in_size[d] != 0;
+    scale[d] = in_size[d] ? out_size[d] / in_size[d] : 1;
+    ngiven += given[d];
+  }
+  if (ngiven == 0) {  // nothing to go by: keep the size
+    for (int d = 0; d < ndim; d++) out_size[d] = in_size[d];
+    return;
+  }
+  auto apply_limit = [&] {
+    if (!max_size) return;
+    for (int d = 0; d < ndim; d++)
+      if (max_size[d] > 0 && std::fabs(out_size[d]) > max_size[d]) {
+        out_size[d] = std::copysign(max_size[d], out_size[d]);
+        scale[d] = out_size[d] / in_size[d];
+      }
+  };
+  if (mode == ResizeMode::Default) {
+    if (ngiven < ndim) {  // the missing extents follow the (geometric) mean scale of the given ones
+      double mean_scale = 1;
+      for (int d = 0; d < ndim; d++)
+        if (given[d]) mean_scale *= std::fabs(scale[d]);
+      if (ngiven > 1) mean_scale = std::pow(mean_scale, 1.0 / ngiven);
+      for (int d = 0; d < ndim; d++)
+        if (!given[d]) {
+          scale[d] = mean_scale;
+          out_size[d] = (float)(in_size[d] * scale[d]);
+        }
+    }
+    apply_limit();
+  } else if (mode == ResizeMode::Stretch) {
+    for (int d = 0; d < ndim; d++)
+      if (!given[d]) { scale[d] = 1; out_size[d] = in_size[d]; }
+    apply_limit();
+  } else {
+    double final_scale = 0;
+    bool first = true;
+    for (int d = 0; d < ndim; d++) {
+      if (!given[d]) continue;
+      float sc = (float)std::fabs(scale[d]);
+      if (first || (mode == ResizeMode::NotSmaller && sc > final_scale) || (mode == ResizeMode::NotLarger && sc < final_scale))
+        final_scale = sc;
+      first = false;
+    }
+    if (max_size)
+      for (int d = 0; d < ndim; d++)
+        if (max_size[d] > 0) final_scale = std::min(final_scale, (double)max_size[d] / in_size[d]);
+    for (int d = 0; d < ndim; d++)
+      if (!given[d] || std::fabs(scale[d]) != final_scale) {
+        scale[d] = std::copysign(final_scale, scale[d]);
+        out_size[d] = (float)(in_size[d] * scale[d]);
+      }
+  }
+}
+
+class ResizeGpu : public OperatorBase {
+ public:
+  explicit ResizeGpu(const OpSpec &spec) : OperatorBase(spec), filters_(spec) {
+    has_shorter_ = spec.ArgumentDefined("resize_shorter");
+    has_longer_ = spec.ArgumentDefined("resize_longer");
+    has_x_ = spec.ArgumentDefined("resize_x");
+    has_y_ = spec.ArgumentDefined("resize_y");
+    has_size_ = spec.ArgumentDefined("size");
+    has_max_size_ = spec.ArgumentDefined("max_size");
+    bool has_mode = spec.ArgumentDefined("mode");
+    subpixel_scale_ = spec.GetBool("subpixel_scale");
+    DALI_ENFORCE((int)(has_x_ || has_y_) + has_size_ + has_shorter_ + has_longer_ == 1,
+                 "Exactly one method of specifying size must be used. The available methods:\n"
+                 "    - separate resize_x, resize_y, resize_z arguments\n    - size argument\n    - resize_longer\n"
+                 "    - resize_shorter");
+    DALI_ENFORCE(has_shorter_ + has_longer_ + has_mode <= 1,
+                 "`resize_shorter`, ``resize_longer`` and ``mode`` arguments are mutually exclusive");
+    bool roi_s = spec.ArgumentDefined("roi_start"), roi_e = spec.ArgumentDefined("roi_end");
+    DALI_ENFORCE(roi_s == roi_e, "``roi_start`` and ``roi_end`` must be specified together");
+    has_roi_ = roi_s;
+    roi_relative_ = spec.GetBool("roi_relative");
+    if (has_shorter_) mode_ = ResizeMode::NotSmaller;
+    else if (has_longer_) mode_ = ResizeMode::NotLarger;
+    else if (has_mode) {
+      std::string m = spec.GetString("mode");
+      if (m == "default") mode_ = ResizeMode::Default;
+      else if (m == "stretch") mode_ = ResizeMode::Stretch;
+      else if (m == "not_larger") mode_ = ResizeMode::NotLarger;
+      else if (m == "not_smaller") mode_ = ResizeMode::NotSmaller;
+      else DALI_FAIL("Invalid resize mode: \"", m, "\"");
+    }
+    if (has_max_size_) {
+      auto ms = spec.GetFloatVec("max_size");
+      DALI_ENFORCE(ms.size() == 1 || ms.size() == 2, "`max_size` must hold one value or one per spatial dimension");
+      max_size_[0] = (float)ms[0];
+      max_size_[1] = (float)(ms.size() == 2 ? ms[1] : ms[0]);
+    }
+  }
+  void EnableFusion() { fused_ = true; }
+
+  bool SetupImpl(std::vector<OutputDesc> &desc, const Workspace &ws) override {
+    const TensorList &in = ws.Input(0);
+    const int n = in.num_samples();
+    DALI_ENFORCE(in.type() == DALI_UINT8, "Resize (gpu): only uint8 input is supported, got ", TypeName(in.type()));
+    std::vector<float> rx, ry, rs;
+    std::vector<std::vector<float>> size, roi_start, roi_end;
+    if (has_x_) rx = GetPerSampleFloat(spec_, ws, "resize_x", n);
+    if (has_y_) ry = GetPerSampleFloat(spec_, ws, "resize_y", n);
+    if (has_shorter_) rs = GetPerSampleFloat(spec_, ws, "resize_shorter", n);
+    if (has_longer_) rs = GetPerSampleFloat(spec_, ws, "resize_longer", n);
+    if (has_size_) size = GetPerSampleFloatVec(spec_, ws, "size", n);
+    if (has_roi_) {
+      roi_start = GetPerSampleFloatVec(spec_, ws, "roi_start", n);
+      roi_end = GetPerSampleFloatVec(spec_, ws, "roi_end", n);
+    }
+    args_.assign(n, daliamdResampleArgs{});
+    desc[0].type = DALI_UINT8;
+    desc[0].shape.resize(n);
+    int ch = 3;
+    for (int i = 0; i < n; i++) {
+      auto &a = args_[i];
+      FillSourceArgs(a, in, i);
+      ch = a.channels;
+      const int in_hw[2] = {a.in_h, a.in_w};
+      float req[2] = {0, 0};  // H, W
+      if (has_x_ || has_y_) {
+        req[0] = has_y_ ? ry[i] : 0;
+        req[1] = has_x_ ? rx[i] : 0;
+      } else if (has_shorter_ || has_longer_) {
+        req[0] = req[1] = rs[i];
+      } else {
+        DALI_ENFORCE(size[i].size() == 2, "`size` must have one entry per spatial dimension (2), got ", size[i].size());
+        req[0] = size[i][0]; req[1] = size[i][1];
+      }
+      // CalculateInputRoI
+      float lo[2], hi[2], in_size[2];
+      for (int d = 0; d < 2; d++) {
+        if (has_roi_ && in_hw[d] > 0) {
+          DALI_ENFORCE(roi_start[i].size() == 2 && roi_end[i].size() == 2, "`roi_start`/`roi_end` must have 2 entries");
+          double l = roi_start[i][d], h = roi_end[i][d];
+          if (roi_relative_) { l *= in_hw[d]; h *= in_hw[d]; }
+          const float min_size = 1e-3f;  // a degenerate region is widened instead of dividing by zero
+          if (std::fabs(h - l) < min_size) {
+            float off = l <= h ? 0.5f * min_size : -0.5f * min_size;
+            l -= off; h += off;
+          }
+          lo[d] = (float)l; hi[d] = (float)h;
+        } else {
+          lo[d] = 0; hi[d] = (float)in_hw[d];
+        }
+      }
+      // CalculateSampleParams
+      for (int d = 0; d < 2; d++) {
+        float sz = hi[d] - lo[d];
+        if (sz < 0) { std::swap(hi[d], lo[d]); req[d] = -req[d]; sz = -sz; }
+        in_size[d] = sz;
+      }
+      AdjustOutputSize(req, in_size, 2, mode_, has_max_size_ ? max_size_ : nullptr);
+      int out_hw[2];
+      for (int d = 0; d < 2; d++) {
+        DALI_ENFORCE(lo[d] != hi[d] || req[d] == 0, "Cannot produce non-empty output from empty input");
+        DALI_ENFORCE(req[d] >= 0, "Resize (gpu): negative sizes / flipped regions of interest are not supported yet");
+        out_hw[d] = std::max(1, (int)std::round(std::fabs(req[d])));
+        if (subpixel_scale_ && (float)out_hw[d] != std::fabs(req[d])) {
+          // the rounded size differs from the fractional one: shrink/grow the region around its centre
+          double adj = std::min(10.0, std::max(-10.0, (double)out_hw[d] / std::fabs(req[d])));
+          double center = 0.5 * lo[d] + 0.5 * hi[d];
+          double nlo = std::min(1e9, std::max(-1e9, center + (lo[d] - center) * adj));
+          double nhi = std::min(1e9, std::max(-1e9, center + (hi[d] - center) * adj));
+          lo[d] = (float)nlo; hi[d] = (float)nhi;
+        }
+      }
+      a.use_roi = 1;
+      a.roi_y0 = lo[0]; a.roi_x0 = lo[1]; a.roi_y1 = hi[0]; a.roi_x1 = hi[1];
+      a.out_h = out_hw[0]; a.out_w = out_hw[1];
+      a.min_filter = filters_.min_filter; a.mag_filter = filters_.mag_filter; a.antialias = filters_.antialias;
+      a.out_dtype = DALIAMD_UINT8; a.out_layout = DALIAMD_LAYOUT_HWC;
+      desc[0].shape[i] = TensorShape{out_hw[0], out_hw[1], ch};
+    }
+    n_ = n; ch_ = ch;
+    uniform_ = n > 0;
+    for (int i = 1; i < n; i++) uniform_ &= args_[i].out_h == args_[0].out_h && args_[i].out_w == args_[0].out_w;
+    if (fused_ && uniform_) return false;  // the consumer launches the fused kernel
+    return true;
+  }
+
+  void RunImpl(Workspace &ws) override {
+    TensorList &out = ws.Output(0);
+    out.SetLayout("HWC");
+    if (fused_ && uniform_) {
+      auto d = std::make_shared<DeferredResample>();
+      d->source = ws.inputs[0];
+      d->args = args_;
+      d->out_h = args_[0].out_h; d->out_w = args_[0].out_w; d->channels = ch_;
+      out.Resize({}, DALI_UINT8);
+      out.deferred = d;
+      return;
+    }
+    out.deferred.reset();
+    for (int i = 0; i < n_; i++) args_[i].out = out.raw(i);
+    LaunchResample(ws, uploader_, args_, descs_, "resample");
+  }
+
+ private:
+  FilterArgs filters_;
+  bool has_shorter_, has_longer_, has_x_, has_y_, has_size_, has_max_size_, has_roi_, roi_relative_, subpixel_scale_;
+  ResizeMode mode_ = ResizeMode::Default;
+  float max_size_[2] = {0, 0};
+  bool fused_ = false, uniform_ = false;
+  int n_ = 0, ch_ = 3;
+  std::vector<daliamdResampleArgs> args_;
+  std::vector<daliamdResampleDesc> descs_;
+  DescUploader uploader_;
+};
+DALI_REGISTER_OPERATOR(Resize, ResizeGpu, GPU);
+
+// =============================================================================================
 // CropMirrorNormalize
 // =============================================================================================
 DALI_SCHEMA(CropAttr)
@@ -567,7 +978,7 @@ class CropMirrorNormalizeGpu : public OperatorBase {
   bool SetupImpl(std::vector<OutputDesc> &desc, const Workspace &ws) override {
     const TensorList &in = ws.Input(0);
     const DeferredResample *def = in.deferred.get();
-    DALI_ENFORCE(!fused_input_ || def, "internal: the producer did not hand over its resampling arguments");
+    // a fused producer may still hand over a real tensor list (fn.resize with per-sample output sizes)
     int n = def ? (int)def->args.size() : in.num_samples();
     if (!def) DALI_ENFORCE(in.type() == DALI_UINT8, "CropMirrorNormalize (gpu): only uint8 input is supported, got ",
                            TypeName(in.type()));
@@ -685,9 +1096,11 @@ DALI_REGISTER_OPERATOR(CropMirrorNormalize, CropMirrorNormalizeGpu, GPU);
 
 void TryEnableFusion(OperatorBase *producer, OperatorBase *consumer) {
   auto *rrc = dynamic_cast<RandomResizedCropGpu *>(producer);
+  auto *rsz = dynamic_cast<ResizeGpu *>(producer);
   auto *cmn = dynamic_cast<CropMirrorNormalizeGpu *>(consumer);
-  if (!rrc || !cmn || !cmn->CanFuse()) return;
-  rrc->EnableFusion();
+  if ((!rrc && !rsz) || !cmn || !cmn->CanFuse()) return;
+  if (rrc) rrc->EnableFusion();
+  if (rsz) rsz->EnableFusion();  // defers only the batches whose outputs all have the same size
   cmn->ExpectFusedInput();
 }
 

@@ -311,3 +311,24 @@ def erase_u8(img, anchors_yx, shapes_yx, fill=(0.0,), normalized_anchor=False, n
     lib().orc_erase_u8(_p(img, C.c_uint8), H, W, Cn, _p(a, C.c_float), _p(s, C.c_float), a.shape[0], flags,
                        _p(f, C.c_float), f.size, _p(out, C.c_uint8))
     return out
+
+
+RESIZE_MODES = {"default": 0, "stretch": 1, "not_larger": 2, "not_smaller": 3}
+
+
+def resize_params(in_hw, size=(0, 0), mode="default", max_size=None, subpixel_scale=True, roi=None, roi_relative=False):
+    """fn.resize size/region arithmetic for one 2-D sample.  size = requested (H, W), 0 = unspecified;
+    roi = (start_y, start_x, end_y, end_x).  Returns (out_hw, (y0, x0, y1, x1)) with the source region as floats."""
+    inp = np.asarray(in_hw, np.int32)
+    req = np.asarray(size, np.float32)
+    ms = None if max_size is None else np.asarray(np.broadcast_to(max_size, 2), np.float32).copy()
+    r = np.asarray(roi if roi is not None else (0, 0, 0, 0), np.float32)
+    out_hw = np.zeros(2, np.int32)
+    lo, hi = np.zeros(2, np.float32), np.zeros(2, np.float32)
+    rc = lib().orc_resize_params(_p(inp, C.c_int32), _p(req, C.c_float), RESIZE_MODES[mode],
+                                 _p(ms, C.c_float) if ms is not None else None, 1 if subpixel_scale else 0,
+                                 1 if roi is not None else 0, 1 if roi_relative else 0, _p(r, C.c_float),
+                                 _p(out_hw, C.c_int32), _p(lo, C.c_float), _p(hi, C.c_float))
+    if rc:
+        raise RuntimeError("Cannot produce non-empty output from empty input")
+    return (int(out_hw[0]), int(out_hw[1])), (float(lo[0]), float(lo[1]), float(hi[0]), float(hi[1]))

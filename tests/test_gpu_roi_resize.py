@@ -1,0 +1,171 @@
+"""GPU end-to-end: region-of-interest decoders (decoders.image_crop / image_random_crop) and fn.resize through the
+C++ pipeline, checked against the oracle compositions "decode, then crop" and "ResizeAttr arithmetic + resampling"."""
+import numpy as np
+import pytest
+from PIL import Image, ImageOps
+
+from oracle import oracle as O
+from tests.util import encode_jpeg, synth_image
+
+pytestmark = pytest.mark.gpu
+
+MEAN = [0.485 * 255, 0.456 * 255, 0.406 * 255]
+STD = [0.229 * 255, 0.224 * 255, 0.225 * 255]
+
+
+@pytest.fixture(scope="module")
+def files(tmp_path_factory):
+    root = tmp_path_factory.mktemp("roi")
+    rng = np.random.default_rng(77)
+    out = []
+    specs = [((120, 160), dict(subsampling="4:2:0")), ((200, 150), dict(subsampling="4:4:4")),
+             ((97, 131), dict(subsampling="4:2:2")), ((240, 320), dict(subsampling="4:2:0", progressive=True)),
+             ((64, 48), dict(subsampling="4:1:1")), ((333, 500), dict(subsampling="4:2:0", restart_marker_blocks=7)),
+             ((180, 180), dict(subsampling="4:2:0", optimize=True)), ((75, 211), dict(subsampling="4:2:0"))]
+    for i, (hw, kw) in enumerate(specs):
+        p = root / f"img{i}.jpg"
+        p.write_bytes(encode_jpeg(synth_image(rng, *hw), 85, **kw))
+        out.append(str(p))
+    return out
+
+
+def _decoded(files):
+    return [O.jpeg_decode_rgb(open(f, "rb").read()) for f in files]
+
+
+def test_image_random_crop_equals_decode_then_crop(files):
+    from dali_amd import fn
+    from dali_amd.pipeline import Pipeline
+    bs = len(files)
+    pipe = Pipeline(batch_size=bs, num_threads=3, device_id=0, prefetch_queue_depth=2)
+    with pipe:
+        enc, _ = fn.readers.file(files=files)
+        pipe.set_outputs(fn.decoders.image_random_crop(enc, device="mixed", seed=1234, random_area=[0.1, 0.9]))
+    ref = _decoded(files)
+    for it in range(4):
+        (out,) = pipe.run()
+        assert "jpeg_huffman" in pipe.executed_kernels()
+        anchors, crops = O.rrc_batch(1234, it, [r.shape[:2] for r in ref], area=(0.1, 0.9))
+        for i in range(bs):
+            (y0, x0), (h, w) = anchors[i], crops[i]
+            got = out[i].as_cpu()
+            assert got.shape == (h, w, 3), (it, i)
+            assert np.array_equal(got, ref[i][y0:y0 + h, x0:x0 + w]), (it, i)
+
+
+def test_image_crop_fixed_window_and_per_sample_anchor(files):
+    from dali_amd import fn
+    from dali_amd.pipeline import Pipeline
+    bs = len(files)
+    pos_x = np.linspace(0, 1, bs).astype(np.float32)
+    pipe = Pipeline(batch_size=bs, num_threads=2, device_id=0)
+    with pipe:
+        enc, _ = fn.readers.file(files=files)
+        px = fn.external_source(source=lambda: [np.array(v, np.float32) for v in pos_x], batch=True)
+        pipe.set_outputs(fn.decoders.image_crop(enc, device="mixed", crop=(40, 33), crop_pos_x=px, crop_pos_y=0.3))
+    (out,) = pipe.run()
+    for i, r in enumerate(_decoded(files)):
+        y0 = O.crop_anchor(0.3, 40, r.shape[0])
+        x0 = O.crop_anchor(float(pos_x[i]), 33, r.shape[1])
+        assert np.array_equal(out[i].as_cpu(), r[y0:y0 + 40, x0:x0 + 33]), i
+
+
+def test_image_crop_with_exif_orientation(tmp_path):
+    """The window is a window of the UPRIGHT image (image_decoder.h:676-684)."""
+    from dali_amd import fn
+    from dali_amd.pipeline import Pipeline
+    rng = np.random.default_rng(5)
+    paths = []
+    for o in range(1, 9):
+        img = Image.fromarray(synth_image(rng, 72 + 8 * o, 100))
+        exif = Image.Exif()
+        exif[0x0112] = o
+        p = tmp_path / f"o{o}.jpg"
+        img.save(p, "JPEG", quality=90, exif=exif)
+        paths.append(str(p))
+    pipe = Pipeline(batch_size=8, num_threads=2, device_id=0)
+    with pipe:
+        enc, _ = fn.readers.file(files=paths)
+        pipe.set_outputs(fn.decoders.image_crop(enc, device="mixed", crop=(50, 37), crop_pos_x=0.8, crop_pos_y=0.25))
+    (out,) = pipe.run()
+    for i, f in enumerate(paths):
+        ref = np.asarray(ImageOps.exif_transpose(Image.open(f)).convert("RGB"))
+        y0, x0 = O.crop_anchor(0.25, 50, ref.shape[0]), O.crop_anchor(0.8, 37, ref.shape[1])
+        assert np.array_equal(out[i].as_cpu(), ref[y0:y0 + 50, x0:x0 + 37]), f"orientation {i + 1}"
+
+
+def test_image_crop_out_of_bounds_is_an_error(files):
+    from dali_amd import fn
+    from dali_amd.pipeline import Pipeline
+    pipe = Pipeline(batch_size=2, num_threads=2, device_id=0)
+    with pipe:
+        enc, _ = fn.readers.file(files=files[:2])
+        pipe.set_outputs(fn.decoders.image_crop(enc, device="mixed", crop=(1000, 10)))
+    with pytest.raises(RuntimeError, match="out of the bounds"):
+        pipe.run()
+
+
+RESIZE_CASES = [
+    (dict(size=[100, 150]), dict(size=(100, 150))),
+    (dict(resize_x=90), dict(size=(0, 90))),
+    (dict(resize_y=77.5), dict(size=(77.5, 0))),
+    (dict(resize_x=64, resize_y=0, mode="stretch"), dict(size=(0, 64), mode="stretch")),
+    (dict(resize_shorter=80), dict(size=(80, 80), mode="not_smaller")),
+    (dict(resize_longer=112), dict(size=(112, 112), mode="not_larger")),
+    (dict(resize_shorter=100, max_size=[140]), dict(size=(100, 100), mode="not_smaller", max_size=140)),
+    (dict(size=[60, 60], mode="not_larger"), dict(size=(60, 60), mode="not_larger")),
+    (dict(size=[50, 70], roi_start=[0.1, 0.2], roi_end=[0.9, 0.7], roi_relative=True),
+     dict(size=(50, 70), roi=(0.1, 0.2, 0.9, 0.7), roi_relative=True)),
+    (dict(resize_shorter=71.3, subpixel_scale=False), dict(size=(71.3, 71.3), mode="not_smaller", subpixel_scale=False)),
+]
+
+
+@pytest.mark.parametrize("dali_kw,oracle_kw", RESIZE_CASES)
+def test_resize_matches_oracle(files, dali_kw, oracle_kw):
+    from dali_amd import fn, types
+    from dali_amd.pipeline import Pipeline
+    bs = len(files)
+    pipe = Pipeline(batch_size=bs, num_threads=3, device_id=0)
+    with pipe:
+        enc, _ = fn.readers.file(files=files)
+        img = fn.decoders.image(enc, device="mixed")
+        pipe.set_outputs(fn.resize(img, interp_type=types.INTERP_TRIANGULAR, **dali_kw))
+    (out,) = pipe.run()
+    assert "resample" in pipe.executed_kernels()
+    for i, r in enumerate(_decoded(files)):
+        out_hw, roi = O.resize_params(r.shape[:2], **oracle_kw)
+        ref = O.resample_u8(r, out_hw, roi=roi, min_filter=O.FILTER_TRIANGULAR, mag_filter=O.FILTER_TRIANGULAR)
+        got = out[i].as_cpu()
+        assert got.shape == ref.shape, (i, got.shape, ref.shape)
+        assert np.array_equal(got, ref), f"sample {i}: max diff {np.abs(got.astype(int) - ref).max()}"
+
+
+def test_roi_decode_resize_cmn_pipeline_matches_oracle(files):
+    """The validation / NVIDIA-benchmark flavour of the hot path (hw_decoder_bench.py:178-188):
+    decoders.image_random_crop -> resize -> crop_mirror_normalize; resize + CMN run as ONE fused kernel."""
+    from dali_amd import fn, types
+    from dali_amd.pipeline import Pipeline
+    bs = len(files)
+    pipe = Pipeline(batch_size=bs, num_threads=3, device_id=0, prefetch_queue_depth=2)
+    with pipe:
+        enc, _ = fn.readers.file(files=files)
+        img = fn.decoders.image_random_crop(enc, device="mixed", seed=99)
+        img = fn.resize(img, size=[64, 80])
+        flip = fn.random.coin_flip(probability=0.5, seed=7)
+        pipe.set_outputs(fn.crop_mirror_normalize(img, dtype=types.FLOAT16, output_layout="CHW", mean=MEAN, std=STD,
+                                                  mirror=flip))
+    ref_imgs = _decoded(files)
+    mean, inv = O.cmn_norm_args(MEAN, STD)
+    for it in range(3):
+        (out,) = pipe.run()
+        assert "fused_resample_cmn" in pipe.executed_kernels()
+        anchors, crops = O.rrc_batch(99, it, [r.shape[:2] for r in ref_imgs])
+        mirror = O.coin_flip_batch(7, it, bs, 0.5)
+        got = out.as_tensor().cpu().numpy()
+        for i in range(bs):
+            (y0, x0), (h, w) = anchors[i], crops[i]
+            crop = np.ascontiguousarray(ref_imgs[i][y0:y0 + h, x0:x0 + w])
+            out_hw, roi = O.resize_params((h, w), (64, 80))
+            rs = O.resample_u8(crop, out_hw, roi=roi)
+            ref = O.cmn_u8(rs, (0, 0), (64, 80), mirror=bool(mirror[i]), mean=mean, inv_std=inv, layout="CHW", dtype=O.F16)
+            assert np.array_equal(got[i].view(np.uint16), ref.view(np.uint16)), (it, i)
