@@ -192,7 +192,7 @@ def cpu_baseline(enc, seconds_budget=20.0):
                       f"oracle (-O3 -msse2, OpenMP, one task per sample), {cores} threads, {el:.2f} s wall"}
 
 
-def e2e_pipeline(enc, device_id, iters=30, threads=None):
+def e2e_pipeline(enc, device_id, iters=30, threads=None, roi_decode=False):
     """The same hot path through the product's DALI-style pipeline (C++ host framework): readers.file (page cache)
     -> decoders.image(mixed: header parse + scan analysis on the host thread pool, H2D of the entropy-coded
     segments, GPU Huffman/IDCT/colour) -> random_resized_crop + crop_mirror_normalize (fused).  PCIe-inclusive and
@@ -208,11 +208,16 @@ def e2e_pipeline(enc, device_id, iters=30, threads=None):
         for i, e in enumerate(enc):
             with open(os.path.join(root, "c0", f"{i:05d}.jpg"), "wb") as f:
                 f.write(e)
-        pipe = Pipeline(batch_size=len(enc), num_threads=threads, device_id=device_id, seed=1234, prefetch_queue_depth=2)
+        # four sequential stages (file reads | parse + staging | H2D | kernels) need three batches in flight to overlap
+        pipe = Pipeline(batch_size=len(enc), num_threads=threads, device_id=device_id, seed=1234, prefetch_queue_depth=3)
         with pipe:
             jpegs, labels = fn.readers.file(file_root=root, name="Reader")
-            images = fn.decoders.image(jpegs, device="mixed", output_type=types.RGB)
-            crops = fn.random_resized_crop(images, size=[224, 224])
+            if roi_decode:   # the variant NVIDIA's own benchmark uses (hw_decoder_bench.py:178-188): ROI decode + resize
+                images = fn.decoders.image_random_crop(jpegs, device="mixed", output_type=types.RGB)
+                crops = fn.resize(images, size=[224, 224])
+            else:
+                images = fn.decoders.image(jpegs, device="mixed", output_type=types.RGB)
+                crops = fn.random_resized_crop(images, size=[224, 224])
             out = fn.crop_mirror_normalize(crops, dtype=types.FLOAT16, output_layout="CHW",
                                            mean=[0.485 * 255, 0.456 * 255, 0.406 * 255],
                                            std=[0.229 * 255, 0.224 * 255, 0.225 * 255],
@@ -226,9 +231,9 @@ def e2e_pipeline(enc, device_id, iters=30, threads=None):
             pipe.run()
         el = time.perf_counter() - t0
         return {"value": iters * len(enc) / el, "unit": "images/s", "ms_per_batch": 1e3 * el / iters,
-                "host_threads": threads, "kernels": pipe.executed_kernels(),
+                "host_threads": threads, "prefetch_queue_depth": 3, "kernels": pipe.executed_kernels(),
                 "note": "dali_amd.Pipeline end to end from encoded files in the page cache (file read, header parse, "
-                        "H2D of the JPEG bytes, all device stages, fp16 CHW batch on the device); one HIP stream"}
+                        "H2D of the JPEG bytes on a copy stream, all device stages, fp16 CHW batch on the device)"}
     finally:
         shutil.rmtree(root, ignore_errors=True)
 
@@ -459,6 +464,9 @@ def main():
             del hp
             torch.cuda.empty_cache()
             line["e2e_pipeline"] = e2e_pipeline(enc, local_rank)
+            line["e2e_pipeline_roi_decode"] = e2e_pipeline(enc, local_rank, roi_decode=True)
+            line["e2e_pipeline_roi_decode"]["note"] = ("same, with decoders.image_random_crop -> resize -> "
+                                                       "crop_mirror_normalize: only the crop window is decoded")
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(enc)
         print(json.dumps(line))

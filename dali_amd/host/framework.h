@@ -307,6 +307,9 @@ class Workspace {
   std::map<std::string, std::shared_ptr<TensorList>> argument_inputs;
   ThreadPool *thread_pool = nullptr;
   daliamdStream_t stream = nullptr;  // device operators enqueue here and must not synchronise
+  // Second stream for bulk host->device transfers: a copy issued here for iteration i+1 overlaps the kernels of
+  // iteration i on `stream`.  The operator orders the two with an event (record on copy_stream, wait on stream).
+  daliamdStream_t copy_stream = nullptr;
   int batch_size = 0;                // requested (max) batch size of this iteration
   int64_t iteration = 0;
   // Checks that can only be made once the device work of this iteration has finished (e.g. status words written

@@ -93,9 +93,13 @@ class ImageDecoderMixed : public OperatorBase {
       ecs_stage_.emplace_back(std::make_unique<Buffer>(StorageDevice::CPU));
       ecs_dev_.emplace_back(std::make_unique<Buffer>(StorageDevice::GPU));
       scratch_.emplace_back(std::make_unique<Buffer>(StorageDevice::GPU));
-      status_dev_.emplace_back(std::make_unique<Buffer>(StorageDevice::GPU));
       status_host_.emplace_back(std::make_unique<Buffer>(StorageDevice::CPU));
     }
+    h2d_done_.assign(ring_, nullptr);
+  }
+  ~ImageDecoderMixed() override {
+    for (auto e : h2d_done_)
+      if (e) daliamdEventDestroy(e);
   }
   int OutputPitchAlign(int) const override { return kImagePitchAlign; }
   bool SetupImpl(std::vector<OutputDesc> &, const Workspace &) override { return false; }
@@ -109,7 +113,24 @@ class ImageDecoderMixed : public OperatorBase {
     scans_.resize(n);
     auto src = [&](int i) { return i < (int)in.source_info.size() && !in.source_info[i].empty() ? in.source_info[i]
                                                                                                : make_string("sample #", i); };
-    // ---- header parse + scan analysis (thread pool: the analysis walks the stream once to find its end) ----
+    // ---- one thread-pool pass per sample: header parse, scan analysis and (GPU path) the copy of the entropy-coded
+    // bytes into the pinned staging buffer.  Staging offsets come from the FILE sizes, which are known up front, so
+    // no second pass is needed once the segment lengths are known (cost: the transfer is longer by the few hundred
+    // header bytes of each file).
+    const int slot = (int)(ws.iteration % ring_);
+    Buffer &ecs_stage = *ecs_stage_[slot];
+    ecs_off_.assign(n, 0);
+    size_t ecs_bytes = 0;
+    for (int i = 0; i < n; i++) {
+      ecs_off_[i] = ecs_bytes;
+      ecs_bytes += ((size_t)in.nbytes(i) + 15) & ~(size_t)15;
+    }
+    // the three descriptor tables of the iteration live behind the JPEG bytes in the same staging buffer, so that
+    // ONE host->device copy (on the copy stream) carries everything the kernels need
+    auto align16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t table_bytes = align16((size_t)n * sizeof(daliamdJpegHuffDesc)) + align16((size_t)n * 3 * sizeof(daliamdJpegIdctDesc)) +
+                               align16((size_t)n * sizeof(daliamdJpegColorDesc));
+    ecs_stage.Reserve(ecs_bytes + table_bytes + 256);
     for (int i = 0; i < n; i++) {
       ws.GetThreadPool().AddWork([&, i](int) {
         const uint8_t *data = static_cast<const uint8_t *>(in.raw(i));
@@ -121,17 +142,19 @@ class ImageDecoderMixed : public OperatorBase {
         if (!host_huffman_only_ && (int64_t)infos_[i].width * infos_[i].height >= huffman_threshold_ &&
             daliamdJpegAnalyzeScan(data, in.nbytes(i), &infos_[i], &scans_[i]) != 0)
           scans_[i].eligible = 0;  // the host decoder will produce the diagnosis
+        if (scans_[i].eligible)
+          memcpy(static_cast<uint8_t *>(ecs_stage.data()) + ecs_off_[i], data + scans_[i].ecs_offset,
+                 (size_t)scans_[i].ecs_length);
       }, (int64_t)in.nbytes(i));
     }
     ws.GetThreadPool().RunAll();
     // ---- layout ----
     std::vector<TensorShape> shapes(n);
     coef_off_.assign(n * 3, 0);
-    ecs_off_.assign(n, 0);
     scratch_off_.assign(n, 0);
     gpu_samples_.clear();
     int64_t elems = 0;
-    size_t ecs_bytes = 0, scratch_bytes = 0;
+    size_t scratch_bytes = 0;
     int ncomp_total = 0;
     // region-of-interest decode (decoders.image_crop / image_random_crop): windows of the upright images
     upright_hw_.resize(2 * n);
@@ -162,65 +185,67 @@ class ImageDecoderMixed : public OperatorBase {
         DALI_ENFORCE(scans_[i].ecs_length < (int64_t)1 << 30, "Failed to decode ", src(i), ": entropy-coded segment too long");
         size_t need = 0;
         KCHECK(daliamdJpegHuffmanScratchBytes((int)scans_[i].ecs_length, &need));
-        ecs_off_[i] = ecs_bytes;
         scratch_off_[i] = scratch_bytes;
-        ecs_bytes += ((size_t)scans_[i].ecs_length + 15) & ~(size_t)15;
         scratch_bytes += need;
         gpu_samples_.push_back(i);
       }
     }
     const int ngpu = (int)gpu_samples_.size();
-    const int slot = (int)(ws.iteration % ring_);
     Buffer &stage = *staging_[slot], &cdev = *coef_dev_[slot], &planes = *planes_[slot];
-    Buffer &ecs_stage = *ecs_stage_[slot], &ecs_dev = *ecs_dev_[slot], &scratch = *scratch_[slot];
-    Buffer &status_dev = *status_dev_[slot], &status_host = *status_host_[slot];
+    Buffer &ecs_dev = *ecs_dev_[slot], &scratch = *scratch_[slot];
+    Buffer &status_host = *status_host_[slot];
     if (ngpu < n) stage.Reserve((size_t)elems * 2 + 256);
     cdev.Reserve((size_t)elems * 2 + 256);
     planes.Reserve((size_t)elems + 256);
-    ecs_stage.Reserve(ecs_bytes + 256);
-    ecs_dev.Reserve(ecs_bytes + 256);
+    ecs_dev.Reserve(ecs_bytes + table_bytes + 256);
     scratch.Reserve(scratch_bytes + 256);
-    status_dev.Reserve(sizeof(int32_t) * (size_t)std::max(n, 1));
     status_host.Reserve(sizeof(int32_t) * (size_t)std::max(n, 1));
     out.Resize(shapes, DALI_UINT8, kImagePitchAlign);
     out.SetLayout("HWC");
     out.source_info = in.source_info;
     quant_.assign((size_t)n * 3 * 64, 0);
-    // ---- thread pool: gather the entropy-coded segments (GPU path) / entropy decode (host path) ----
+    // ---- host entropy decode of the streams the GPU kernel does not take (thread pool) ----
     int16_t *coef_host = static_cast<int16_t *>(stage.data());
     for (int i = 0; i < n; i++) {
-      const bool gpu = scans_[i].eligible != 0;
-      ws.GetThreadPool().AddWork([&, i, gpu](int) {
+      if (scans_[i].eligible) {
+        for (int c = 0; c < infos_[i].num_components; c++) memcpy(&quant_[(size_t)i * 192 + c * 64], scans_[i].quant[c], 128);
+        continue;
+      }
+      ws.GetThreadPool().AddWork([&, i](int) {
         const uint8_t *data = static_cast<const uint8_t *>(in.raw(i));
-        if (gpu) {
-          memcpy(static_cast<uint8_t *>(ecs_stage.data()) + ecs_off_[i], data + scans_[i].ecs_offset,
-                 (size_t)scans_[i].ecs_length);
-          for (int c = 0; c < infos_[i].num_components; c++) memcpy(&quant_[(size_t)i * 192 + c * 64], scans_[i].quant[c], 128);
-          return;
-        }
         int16_t *ptrs[4] = {nullptr, nullptr, nullptr, nullptr};
         for (int c = 0; c < infos_[i].num_components; c++) ptrs[c] = coef_host + coef_off_[i * 3 + c];
         if (daliamdJpegDecodeCoefficients(data, in.nbytes(i), &infos_[i], ptrs, &quant_[(size_t)i * 192]) != 0)
           DALI_FAIL("Failed to decode ", src(i), ": ", daliamdHostGetLastErrorMessage());
-      }, gpu ? (int64_t)in.nbytes(i) / 16 : (int64_t)in.nbytes(i));
+      }, (int64_t)in.nbytes(i));
     }
-    ws.GetThreadPool().RunAll();
+    if (ngpu < n) ws.GetThreadPool().RunAll();
     if (n == 0) return;
     // ---- entropy decoding on the device ----
     int16_t *coef = static_cast<int16_t *>(cdev.data());
+    // descriptor tables: built in the pinned staging buffer, addressed on the device at the same offsets
+    uint8_t *stage_base = static_cast<uint8_t *>(ecs_stage.data());
+    const uint8_t *dev_base = static_cast<const uint8_t *>(ecs_dev.data());
+    const size_t huff_off = align16(ecs_bytes), idct_off = huff_off + align16((size_t)ngpu * sizeof(daliamdJpegHuffDesc));
+    const size_t color_off = idct_off + align16((size_t)ncomp_total * sizeof(daliamdJpegIdctDesc));
+    const size_t upload_bytes = color_off + align16((size_t)n * sizeof(daliamdJpegColorDesc));
+    daliamdJpegHuffDesc *huff = reinterpret_cast<daliamdJpegHuffDesc *>(stage_base + huff_off);
+    daliamdJpegIdctDesc *idct = reinterpret_cast<daliamdJpegIdctDesc *>(stage_base + idct_off);
+    daliamdJpegColorDesc *color = reinterpret_cast<daliamdJpegColorDesc *>(stage_base + color_off);
+    memset(stage_base + huff_off, 0, upload_bytes - huff_off);
+    int ntiles = 0, nsegs = 0;
     if (ngpu) {
-      KCHECK(daliamdMemcpyH2DAsync(ecs_dev.data(), ecs_stage.data(), ecs_bytes, ws.stream));
-      KCHECK(daliamdMemsetAsync(cdev.data(), 0, (size_t)elems * 2, ws.stream));
-      KCHECK(daliamdMemsetAsync(status_dev.data(), 0, sizeof(int32_t) * (size_t)ngpu, ws.stream));
-      huff_.assign(ngpu, daliamdJpegHuffDesc{});
+      // status words: pinned host memory the kernels write directly (no copy back); cleared here by the CPU
+      int32_t *status = static_cast<int32_t *>(status_host.data());
+      memset(status, 0, sizeof(int32_t) * (size_t)ngpu);
       for (int j = 0; j < ngpu; j++) {
         const int i = gpu_samples_[j];
         const auto &inf = infos_[i];
         const auto &sc = scans_[i];
-        auto &d = huff_[j];
-        d.ecs = static_cast<const uint8_t *>(ecs_dev.data()) + ecs_off_[i];
+        auto &d = huff[j];
+        d.ecs = dev_base + ecs_off_[i];
         d.scratch = static_cast<uint8_t *>(scratch.data()) + scratch_off_[i];
-        d.status = static_cast<int32_t *>(status_dev.data()) + j;
+        d.status = status + j;
         d.ecs_len = (int32_t)sc.ecs_length;
         d.blocks_per_mcu = sc.blocks_per_mcu;
         d.mcus_x = sc.mcus_x;
@@ -244,18 +269,11 @@ class ImageDecoderMixed : public OperatorBase {
           memcpy(d.vals[2 + t], sc.ac_vals[t], 256);
         }
       }
-      int ntiles = 0, nsegs = 0;
-      KCHECK(daliamdJpegHuffmanSetup(huff_.data(), ngpu, &ntiles, &nsegs));
-      auto *huff_dev = static_cast<const daliamdJpegHuffDesc *>(
-          up_huff_.Upload(huff_.data(), huff_.size() * sizeof(huff_[0]), ws.stream));
-      KCHECK(daliamdJpegHuffmanRun(ws.stream, huff_dev, ngpu, ntiles, nsegs));
-      KCHECK(daliamdMemcpyD2HAsync(status_host.data(), status_dev.data(), sizeof(int32_t) * (size_t)ngpu, ws.stream));
-      NoteLaunch(ws, "jpeg_huffman");
+      KCHECK(daliamdJpegHuffmanSetup(huff, ngpu, &ntiles, &nsegs));
       // the status words are valid once the iteration has finished: checked when its outputs are handed over
-      std::vector<int> samples = gpu_samples_;
       std::vector<std::string> names(ngpu);
-      for (int j = 0; j < ngpu; j++) names[j] = src(samples[j]);
-      const int32_t *st = static_cast<const int32_t *>(status_host.data());
+      for (int j = 0; j < ngpu; j++) names[j] = src(gpu_samples_[j]);
+      const int32_t *st = status;
       ws.AddCompletionCheck([st, names] {
         for (size_t j = 0; j < names.size(); j++)
           if (st[j] != 0)
@@ -263,22 +281,13 @@ class ImageDecoderMixed : public OperatorBase {
                       "last MCU (GPU Huffman status ", st[j], ")");
       });
     }
-    // host-decoded streams (progressive, restart markers, multi-scan, below the threshold): H2D of their coefficients
-    for (int i = 0; i < n; i++) {
-      if (scans_[i].eligible) continue;
-      int64_t first = coef_off_[i * 3], count = 0;
-      for (int c = 0; c < infos_[i].num_components; c++) count += infos_[i].coef_elems[c];
-      KCHECK(daliamdMemcpyH2DAsync(coef + first, coef_host + first, (size_t)count * 2, ws.stream));
-    }
-    // ---- dequantisation + IDCT, upsampling + colour conversion ----
-    idct_.assign(ncomp_total, daliamdJpegIdctDesc{});
-    color_.assign(n, daliamdJpegColorDesc{});
+    // ---- dequantisation + IDCT, upsampling + colour conversion: descriptors ----
     int k = 0;
     for (int i = 0; i < n; i++) {
       const auto &inf = infos_[i];
-      auto &cd = color_[i];
+      auto &cd = color[i];
       for (int c = 0; c < inf.num_components; c++) {
-        auto &d = idct_[k++];
+        auto &d = idct[k++];
         d.coef = coef + coef_off_[i * 3 + c];
         d.plane = static_cast<uint8_t *>(planes.data()) + coef_off_[i * 3 + c];
         d.blocks_x = inf.blocks_x[c];
@@ -306,14 +315,33 @@ class ImageDecoderMixed : public OperatorBase {
       }
     }
     int wg_idct = 0, wg_color = 0;
-    KCHECK(daliamdJpegIdctSetup(idct_.data(), ncomp_total, &wg_idct));
-    KCHECK(daliamdJpegColorSetup(color_.data(), n, &wg_color));
-    auto *idct_dev = static_cast<const daliamdJpegIdctDesc *>(
-        up_idct_.Upload(idct_.data(), idct_.size() * sizeof(idct_[0]), ws.stream));
-    auto *color_dev = static_cast<const daliamdJpegColorDesc *>(
-        up_color_.Upload(color_.data(), color_.size() * sizeof(color_[0]), ws.stream));
-    KCHECK(daliamdJpegIdctRun(ws.stream, idct_dev, ncomp_total, wg_idct));
-    KCHECK(daliamdJpegColorRun(ws.stream, color_dev, n, wg_color));
+    KCHECK(daliamdJpegIdctSetup(idct, ncomp_total, &wg_idct));
+    KCHECK(daliamdJpegColorSetup(color, n, &wg_color));
+    // ---- ONE transfer (JPEG bytes + the three tables) on the copy stream: it overlaps the kernels of the previous
+    // iteration; the compute stream waits for it through an event ----
+    daliamdStream_t cs = ws.copy_stream ? ws.copy_stream : ws.stream;
+    KCHECK(daliamdMemcpyH2DAsync(ecs_dev.data(), ecs_stage.data(), upload_bytes, cs));
+    if (cs != ws.stream) {
+      if (!h2d_done_[slot]) KCHECK(daliamdEventCreate(&h2d_done_[slot], 0));
+      KCHECK(daliamdEventRecord(h2d_done_[slot], cs));
+      KCHECK(daliamdStreamWaitEvent(ws.stream, h2d_done_[slot]));
+    }
+    if (ngpu) {
+      KCHECK(daliamdMemsetAsync(cdev.data(), 0, (size_t)elems * 2, ws.stream));
+      KCHECK(daliamdJpegHuffmanRun(ws.stream, reinterpret_cast<const daliamdJpegHuffDesc *>(dev_base + huff_off), ngpu,
+                                   ntiles, nsegs));
+      NoteLaunch(ws, "jpeg_huffman");
+    }
+    // host-decoded streams (progressive, restart markers, multi-scan, below the threshold): H2D of their coefficients
+    for (int i = 0; i < n; i++) {
+      if (scans_[i].eligible) continue;
+      int64_t first = coef_off_[i * 3], count = 0;
+      for (int c = 0; c < infos_[i].num_components; c++) count += infos_[i].coef_elems[c];
+      KCHECK(daliamdMemcpyH2DAsync(coef + first, coef_host + first, (size_t)count * 2, ws.stream));
+    }
+    KCHECK(daliamdJpegIdctRun(ws.stream, reinterpret_cast<const daliamdJpegIdctDesc *>(dev_base + idct_off), ncomp_total,
+                              wg_idct));
+    KCHECK(daliamdJpegColorRun(ws.stream, reinterpret_cast<const daliamdJpegColorDesc *>(dev_base + color_off), n, wg_color));
     NoteLaunch(ws, "jpeg_idct");
     NoteLaunch(ws, "jpeg_color");
   }
@@ -325,21 +353,18 @@ class ImageDecoderMixed : public OperatorBase {
 
  private:
   std::vector<daliamdJpegRoiPlan> plans_;
+  std::vector<daliamdEvent_t> h2d_done_;
   bool adjust_orientation_;
   bool host_huffman_only_ = false;
   int64_t huffman_threshold_ = 0;
   int ring_;
-  std::vector<std::unique_ptr<Buffer>> staging_, coef_dev_, planes_, ecs_stage_, ecs_dev_, scratch_, status_dev_, status_host_;
+  std::vector<std::unique_ptr<Buffer>> staging_, coef_dev_, planes_, ecs_stage_, ecs_dev_, scratch_, status_host_;
   std::vector<daliamdJpegInfo> infos_;
   std::vector<daliamdJpegScan> scans_;
   std::vector<int> gpu_samples_;
   std::vector<int64_t> coef_off_;
   std::vector<size_t> ecs_off_, scratch_off_;
   std::vector<uint16_t> quant_;
-  std::vector<daliamdJpegHuffDesc> huff_;
-  std::vector<daliamdJpegIdctDesc> idct_;
-  std::vector<daliamdJpegColorDesc> color_;
-  DescUploader up_huff_, up_idct_, up_color_;
 };
 // ---- decoders.image_random_crop: RandomCropAttr window, only the window is decoded --------------------------
 // (dali/operators/imgcodec/decoder_schema.cc:270-299, roi_image_decoder.h:79-91, operators/image/crop/random_crop_attr.h)

@@ -193,12 +193,17 @@ class FileReaderOp : public OperatorBase {
     for (int i = 0; i < max_batch_size_; i++) picks[i] = NextIndex(i == 0);
     std::vector<TensorShape> shapes(max_batch_size_), lshape(max_batch_size_, TensorShape{1});
     std::vector<off_t> sizes(max_batch_size_);
+    if (size_cache_.size() != entries_.size()) size_cache_.assign(entries_.size(), -1);
     for (int i = 0; i < max_batch_size_; i++) {
-      struct stat s;
-      const std::string path = Path(picks[i]);
-      DALI_ENFORCE(stat(path.c_str(), &s) == 0, "Could not open file ", path);
-      sizes[i] = s.st_size;
-      shapes[i] = {(int64_t)s.st_size};
+      off_t &cached = size_cache_[picks[i]];  // the dataset is static: one stat() per file, not one per epoch
+      if (cached < 0) {
+        struct stat s;
+        const std::string path = Path(picks[i]);
+        DALI_ENFORCE(stat(path.c_str(), &s) == 0, "Could not open file ", path);
+        cached = s.st_size;
+      }
+      sizes[i] = cached;
+      shapes[i] = {(int64_t)cached};
     }
     TensorList &data = ws.Output(0), &labels = ws.Output(1);
     data.Resize(shapes, DALI_UINT8);
@@ -240,6 +245,7 @@ class FileReaderOp : public OperatorBase {
   }
 
  private:
+  std::vector<off_t> size_cache_;
   int64_t Size() const { return (int64_t)entries_.size(); }
   std::string Path(int64_t idx) const {
     const std::string &f = entries_[idx].first;

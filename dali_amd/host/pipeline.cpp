@@ -20,6 +20,7 @@ Pipeline::Pipeline(const PipelineParams &p) : params_(p) {
   std::seed_seq ss{original_seed_};
   ss.generate(seeds_.begin(), seeds_.end());
   ring_ = p.prefetch_queue_depth + 1;
+  if (const char *t = getenv("DALI_AMD_TRACE")) trace_ = atoi(t) != 0;
   int ndev = 0;
   daliamdDeviceCount(&ndev);
   have_gpu_ = ndev > 0;
@@ -31,10 +32,22 @@ Pipeline::~Pipeline() {
     stop_ = true;
   }
   cv_req_.notify_all();
+  cv_mid_.notify_all();
+  cv_dev_done_.notify_all();
+  if (cpu_worker_.joinable()) cpu_worker_.join();
   if (worker_.joinable()) worker_.join();
   if (stream_) daliamdStreamSynchronize(stream_);
+  if (trace_ && traced_iterations_ > 0) {
+    fprintf(stderr, "[dali_amd trace] host time per iteration over %lld iterations (worker thread):\n",
+            (long long)traced_iterations_);
+    for (auto &n : nodes_)
+      fprintf(stderr, "[dali_amd trace]   %-40s %8.3f ms\n", n.name.c_str(), 1e3 * n.host_seconds / traced_iterations_);
+    fprintf(stderr, "[dali_amd trace]   %-40s %8.3f ms\n", "(host stage waiting for its ring slot)",
+            1e3 * slot_wait_seconds_ / traced_iterations_);
+  }
   nodes_.clear();
   for (auto e : slot_events_) if (e) daliamdEventDestroy(e);
+  if (copy_stream_) daliamdStreamDestroy(copy_stream_);
   if (stream_) daliamdStreamDestroy(stream_);
 }
 
@@ -110,6 +123,7 @@ void Pipeline::Build(const std::vector<std::pair<std::string, std::string>> &out
                  "is available. There is no CPU fallback for device operators.");
     KCHECK(daliamdSetDevice(params_.device_id));
     KCHECK(daliamdStreamCreate(&stream_, 1));
+    KCHECK(daliamdStreamCreate(&copy_stream_, 1));
   }
   for (auto &o : outputs) {
     StorageDevice d = o.second == "gpu" ? StorageDevice::GPU : StorageDevice::CPU;
@@ -119,6 +133,7 @@ void Pipeline::Build(const std::vector<std::pair<std::string, std::string>> &out
     outputs_.push_back(it->second);
   }
   thread_pool_ = std::make_unique<ThreadPool>(params_.num_threads);
+  cpu_thread_pool_ = std::make_unique<ThreadPool>(params_.num_threads);
   // instantiate operators (InstantiateOperator, operator.cc:157-169) and their output rings
   for (auto &n : nodes_) {
     try {
@@ -143,7 +158,10 @@ void Pipeline::Build(const std::vector<std::pair<std::string, std::string>> &out
   if (stream_)
     for (auto &e : slot_events_) KCHECK(daliamdEventCreate(&e, 0));
   built_ = true;
-  if (params_.exec_async) worker_ = std::thread([this] { WorkerLoop(); });
+  if (params_.exec_async) {
+    cpu_worker_ = std::thread([this] { CpuWorkerLoop(); });
+    worker_ = std::thread([this] { DeviceWorkerLoop(); });
+  }
 }
 
 void Pipeline::NoteLaunch(const std::string &what) {
@@ -158,23 +176,37 @@ void NoteLaunch(const Workspace &ws, const std::string &what) {
   if (ws.pipeline) ws.pipeline->NoteLaunch(what);
 }
 
-void Pipeline::RunIteration(int64_t it, int slot, Iteration &res) {
+void Pipeline::RunStage(bool device_stage, int64_t it, int slot, Iteration &res) {
   res.slot = slot;
-  {
+  if (device_stage) {
     std::lock_guard<std::mutex> g(launches_m_);
     cur_launches_.clear();
   }
   try {
-    if (stream_) {
+    if (res.failed) throw std::runtime_error(res.error);  // the host stage already failed: nothing to enqueue
+    if (stream_ && device_stage) KCHECK(daliamdSetDevice(params_.device_id));
+    if (stream_ && !device_stage) {
       KCHECK(daliamdSetDevice(params_.device_id));
-      // the buffers of this ring slot (pinned staging included) were last used `ring_` iterations ago
-      if (it >= ring_) KCHECK(daliamdEventSynchronize(slot_events_[slot]));
+      // the buffers of this ring slot (pinned staging included) were last used `ring_` iterations ago: wait until
+      // that iteration's device work has been enqueued (its event recorded) and has completed
+      if (it >= ring_) {
+        auto t_wait = std::chrono::steady_clock::now();
+        {
+          std::unique_lock<std::mutex> lk(m_);
+          cv_dev_done_.wait(lk, [&] { return stop_ || device_stages_done_ > it - ring_; });
+          if (stop_) return;
+        }
+        KCHECK(daliamdEventSynchronize(slot_events_[slot]));
+        if (trace_) slot_wait_seconds_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait).count();
+      }
     }
     for (auto &n : nodes_) {
+      if ((n.type != OpType::CPU) != device_stage) continue;
       Workspace ws;
       ws.pipeline = this;
-      ws.thread_pool = thread_pool_.get();
+      ws.thread_pool = device_stage ? thread_pool_.get() : cpu_thread_pool_.get();
       ws.stream = stream_;
+      ws.copy_stream = copy_stream_;
       ws.batch_size = params_.batch_size;
       ws.iteration = it;
       std::vector<std::function<void()>> node_checks;
@@ -182,6 +214,7 @@ void Pipeline::RunIteration(int64_t it, int slot, Iteration &res) {
       for (size_t i = 0; i < n.in_node.size(); i++) ws.inputs.push_back(nodes_[n.in_node[i]].out_ring[n.in_idx[i]][slot]);
       for (auto &a : n.arg_in) ws.argument_inputs[a.first] = nodes_[a.second.first].out_ring[a.second.second][slot];
       for (auto &r : n.out_ring) ws.outputs.push_back(r[slot]);
+      auto t_node = std::chrono::steady_clock::now();
       try {
         std::vector<OutputDesc> desc(ws.outputs.size());
         if (n.op->SetupImpl(desc, ws)) {
@@ -205,17 +238,29 @@ void Pipeline::RunIteration(int64_t it, int slot, Iteration &res) {
         DALI_FAIL("Error in ", OpTypeName(n.type), " operator `", n.spec.SchemaName(), "` (instance \"", n.name, "\"): ",
                   e.what());
       }
+      if (trace_) n.host_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_node).count();
     }
-    if (stream_) KCHECK(daliamdEventRecord(slot_events_[slot], stream_));
+    if (trace_ && device_stage) traced_iterations_++;
   } catch (const std::exception &e) {
     res.failed = true;
     res.error = e.what();
   }
-  std::lock_guard<std::mutex> g(launches_m_);
-  res.launches = cur_launches_;
+  if (device_stage) {
+    // recorded even after a failure: the slot's next user waits for this event
+    if (stream_) daliamdEventRecord(slot_events_[slot], stream_);
+    {
+      std::lock_guard<std::mutex> g(launches_m_);
+      res.launches = cur_launches_;
+    }
+    {
+      std::lock_guard<std::mutex> g(m_);
+      device_stages_done_ = it + 1;
+    }
+    cv_dev_done_.notify_all();
+  }
 }
 
-void Pipeline::WorkerLoop() {
+void Pipeline::CpuWorkerLoop() {
   for (;;) {
     int64_t it;
     {
@@ -226,10 +271,30 @@ void Pipeline::WorkerLoop() {
       requests_.pop_front();
     }
     Iteration res;
-    RunIteration(it, (int)(it % ring_), res);
+    RunStage(false, it, (int)(it % ring_), res);
     {
       std::lock_guard<std::mutex> g(m_);
-      results_.push_back(std::move(res));
+      if (stop_) return;
+      mid_.emplace_back(it, std::move(res));
+    }
+    cv_mid_.notify_all();
+  }
+}
+
+void Pipeline::DeviceWorkerLoop() {
+  for (;;) {
+    std::pair<int64_t, Iteration> job;
+    {
+      std::unique_lock<std::mutex> lk(m_);
+      cv_mid_.wait(lk, [this] { return stop_ || !mid_.empty(); });
+      if (stop_) return;
+      job = std::move(mid_.front());
+      mid_.pop_front();
+    }
+    RunStage(true, job.first, (int)(job.first % ring_), job.second);
+    {
+      std::lock_guard<std::mutex> g(m_);
+      results_.push_back(std::move(job.second));
     }
     cv_res_.notify_all();
   }
@@ -250,7 +315,8 @@ void Pipeline::Run() {
     cv_req_.notify_all();
   } else {
     Iteration res;
-    RunIteration(it, (int)(it % ring_), res);
+    RunStage(false, it, (int)(it % ring_), res);
+    RunStage(true, it, (int)(it % ring_), res);
     std::lock_guard<std::mutex> g(m_);
     results_.push_back(std::move(res));
   }

@@ -66,6 +66,7 @@ class Pipeline {
     std::vector<int> in_node, in_idx;                 // producer of each regular input
     std::vector<std::pair<std::string, std::pair<int, int>>> arg_in;  // arg name -> producer
     std::vector<std::vector<std::shared_ptr<TensorList>>> out_ring;   // [output][slot]
+    double host_seconds = 0;  // time the worker spent in SetupImpl + RunImpl (enqueueing included), DALI_AMD_TRACE=1
   };
   struct Iteration {
     int slot;
@@ -76,8 +77,13 @@ class Pipeline {
     std::vector<std::string> launches;          // device kernels this iteration enqueued
   };
 
-  void RunIteration(int64_t it, int slot, Iteration &res);
-  void WorkerLoop();
+  // One iteration = host stage (CPU operators: readers, random numbers, external sources) followed by the device
+  // stage (mixed + gpu operators: their host-side preparation and the enqueueing of device work).  With
+  // exec_async the two stages run on two threads, so the file reads of iteration i+1 overlap the header parsing /
+  // descriptor building / launches of iteration i (the reference's separate CPU and mixed/GPU stage threads).
+  void RunStage(bool device_stage, int64_t it, int slot, Iteration &res);
+  void CpuWorkerLoop();
+  void DeviceWorkerLoop();
 
   PipelineParams params_;
   int64_t original_seed_;
@@ -87,17 +93,24 @@ class Pipeline {
   std::map<std::string, std::pair<int, int>> tensor_producer_;  // "name_device" -> (node, out idx)
   std::vector<std::pair<int, int>> outputs_;
   bool built_ = false;
+  bool trace_ = false;  // DALI_AMD_TRACE=1: per-operator host time summary on stderr when the pipeline is destroyed
+  int64_t traced_iterations_ = 0;
+  double slot_wait_seconds_ = 0;  // host stage blocked on the ring slot's previous user
   bool have_gpu_ = false;
-  std::unique_ptr<ThreadPool> thread_pool_;
+  std::unique_ptr<ThreadPool> thread_pool_;      // device-stage operators (e.g. the decoder's header parsing)
+  std::unique_ptr<ThreadPool> cpu_thread_pool_;  // host-stage operators (e.g. the reader's file reads)
   daliamdStream_t stream_ = nullptr;
+  daliamdStream_t copy_stream_ = nullptr;  // bulk H2D staging, overlaps the compute stream
   int ring_ = 3;
 
   // scheduling
-  std::thread worker_;
+  std::thread worker_, cpu_worker_;
   std::mutex m_;
-  std::condition_variable cv_req_, cv_res_;
+  std::condition_variable cv_req_, cv_res_, cv_mid_, cv_dev_done_;
   std::deque<int64_t> requests_;
+  std::deque<std::pair<int64_t, Iteration>> mid_;  // host stage done, device stage pending
   std::deque<Iteration> results_;
+  int64_t device_stages_done_ = 0;  // iterations whose device stage has been enqueued (slot event recorded)
   std::vector<daliamdEvent_t> slot_events_;
   int64_t scheduled_ = 0, consumed_ = 0;
   bool stop_ = false;
