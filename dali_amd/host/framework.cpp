@@ -467,7 +467,11 @@ std::vector<std::vector<float>> GetPerSampleFloatVec(const OpSpec &spec, const W
 }
 
 // ------------------------------------------------------------------------------------------ DescUploader
-void *DescUploader::Upload(const void *host, size_t bytes, daliamdStream_t stream) {
+void *DescUploader::Upload(const void *host, size_t bytes, daliamdStream_t stream, int min_slots) {
+  if ((int)slots_.size() < min_slots) {  // grow: new (unused) slots go behind the cursor
+    slots_.resize(min_slots);
+  }
+  if (next_ >= (int)slots_.size()) next_ = 0;
   Slot &s = slots_[next_];
   next_ = (next_ + 1) % (int)slots_.size();
   if (s.used) KCHECK(daliamdEventSynchronize(s.ev));  // the previous copy from this slot must be done

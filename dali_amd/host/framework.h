@@ -310,6 +310,7 @@ class Workspace {
   // Second stream for bulk host->device transfers: a copy issued here for iteration i+1 overlaps the kernels of
   // iteration i on `stream`.  The operator orders the two with an event (record on copy_stream, wait on stream).
   daliamdStream_t copy_stream = nullptr;
+  int ring = 3;                      // iterations that may be in flight (prefetch_queue_depth + 1)
   int batch_size = 0;                // requested (max) batch size of this iteration
   int64_t iteration = 0;
   // Checks that can only be made once the device work of this iteration has finished (e.g. status words written
@@ -386,8 +387,10 @@ std::vector<std::vector<float>> GetPerSampleFloatVec(const OpSpec &spec, const W
 // Pinned staging + asynchronous upload of descriptor tables, shared by device operators.
 class DescUploader {
  public:
-  // copies `bytes` to a device buffer valid until the slot comes round again (slots >= queue depth + 1)
-  void *Upload(const void *host, size_t bytes, daliamdStream_t stream);
+  // copies `bytes` to a device buffer that stays valid for `min_slots` further uploads.  Consecutive iterations run
+  // on different streams, so the reuse of a buffer is NOT ordered by a stream: callers pass the pipeline's ring
+  // (Workspace::ring) + 1, and the executor guarantees that the iteration `ring` steps back has completed.
+  void *Upload(const void *host, size_t bytes, daliamdStream_t stream, int min_slots = 4);
   ~DescUploader();
 
  private:

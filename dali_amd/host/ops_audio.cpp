@@ -179,11 +179,13 @@ class SpectrogramGpu : public OperatorBase {
     if (!window_uploaded_) {
       window_dev_.Reserve(window_.size() * sizeof(float));
       KCHECK(daliamdMemcpyH2DAsync(window_dev_.data(), window_.data(), window_.size() * sizeof(float), ws.stream));
+      // one-time upload shared by all later iterations, which run on other streams: make it visible to them
+      KCHECK(daliamdStreamSynchronize(ws.stream));
       KCHECK(daliamdStreamSynchronize(ws.stream));  // one-time: `window_` is pageable host memory
       window_uploaded_ = true;
     }
     for (int i = 0; i < n; i++) descs_[i].out = static_cast<float *>(out.raw(i));
-    auto *dev = static_cast<const daliamdSpectrogramDesc *>(uploader_.Upload(descs_.data(), n * sizeof(descs_[0]), ws.stream));
+    auto *dev = static_cast<const daliamdSpectrogramDesc *>(uploader_.Upload(descs_.data(), n * sizeof(descs_[0]), ws.stream, ws.ring + 1));
     KCHECK(daliamdSpectrogramRun(ws.stream, dev, n, &p_, static_cast<const float *>(window_dev_.data()), nwg_, lds_));
     NoteLaunch(ws, "spectrogram");
   }
@@ -259,12 +261,13 @@ class MelFilterBankGpu : public OperatorBase {
                                          weights_.data()));
       weights_dev_.Reserve(weights_.size() * sizeof(float));
       KCHECK(daliamdMemcpyH2DAsync(weights_dev_.data(), weights_.data(), weights_.size() * sizeof(float), ws.stream));
+      KCHECK(daliamdStreamSynchronize(ws.stream));  // one-time upload read by later iterations on other streams
       KCHECK(daliamdStreamSynchronize(ws.stream));  // one-time upload from pageable memory
     }
     for (int i = 0; i < n; i++) descs_[i].out = static_cast<float *>(out.raw(i));
     int nwg = 0;
     KCHECK(daliamdMelFilterBankSetup(descs_.data(), n, &nwg));
-    auto *dev = static_cast<const daliamdMelDesc *>(uploader_.Upload(descs_.data(), n * sizeof(descs_[0]), ws.stream));
+    auto *dev = static_cast<const daliamdMelDesc *>(uploader_.Upload(descs_.data(), n * sizeof(descs_[0]), ws.stream, ws.ring + 1));
     KCHECK(daliamdMelFilterBankRun(ws.stream, dev, n, nwg, static_cast<const float *>(weights_dev_.data()), nfilter_, nbins_));
     NoteLaunch(ws, "mel_filter_bank_mfma");
   }
@@ -323,7 +326,7 @@ class ToDecibelsGpu : public OperatorBase {
       descs_[i].out = static_cast<float *>(out.raw(i));
       descs_[i].size = volume(in.shape(i));
     }
-    auto *dev = static_cast<const daliamdDecibelDesc *>(uploader_.Upload(descs_.data(), n * sizeof(descs_[0]), ws.stream));
+    auto *dev = static_cast<const daliamdDecibelDesc *>(uploader_.Upload(descs_.data(), n * sizeof(descs_[0]), ws.stream, ws.ring + 1));
     KCHECK(daliamdToDecibelsRun(ws.stream, dev, n, multiplier_, reference_, cutoff_));
     NoteLaunch(ws, "to_decibels");
   }

@@ -104,7 +104,7 @@ class WarpAffineGpu : public OperatorBase {
     for (int i = 0; i < n; i++) descs_[i].out = static_cast<uint8_t *>(out.raw(i));
     int nwg = 0;
     KCHECK(daliamdWarpAffineSetup(descs_.data(), n, &nwg));
-    auto *dev = static_cast<const daliamdWarpAffineDesc *>(uploader_.Upload(descs_.data(), n * sizeof(descs_[0]), ws.stream));
+    auto *dev = static_cast<const daliamdWarpAffineDesc *>(uploader_.Upload(descs_.data(), n * sizeof(descs_[0]), ws.stream, ws.ring + 1));
     KCHECK(daliamdWarpAffineRun(ws.stream, dev, n, nwg));
     NoteLaunch(ws, "warp_affine");
   }
@@ -171,7 +171,7 @@ class GaussianBlurGpu : public OperatorBase {
     for (int i = 0; i < n; i++) descs_[i].out = static_cast<uint8_t *>(out.raw(i));
     int nwg = 0, lds = 0;
     KCHECK(daliamdGaussianBlurSetup(descs_.data(), n, &nwg, &lds));
-    auto *dev = static_cast<const daliamdGaussianBlurDesc *>(uploader_.Upload(descs_.data(), n * sizeof(descs_[0]), ws.stream));
+    auto *dev = static_cast<const daliamdGaussianBlurDesc *>(uploader_.Upload(descs_.data(), n * sizeof(descs_[0]), ws.stream, ws.ring + 1));
     KCHECK(daliamdGaussianBlurRun(ws.stream, dev, n, nwg, lds));
     NoteLaunch(ws, "gaussian_blur");
   }
@@ -199,7 +199,7 @@ static void LaunchPointwise(Workspace &ws, DescUploader &up, std::vector<daliamd
   for (int i = 0; i < n; i++) descs[i].out = static_cast<uint8_t *>(out.raw(i));
   int nwg = 0;
   KCHECK(daliamdPointwiseSetup(descs.data(), n, &nwg));
-  auto *dev = static_cast<const daliamdPointwiseDesc *>(up.Upload(descs.data(), n * sizeof(descs[0]), ws.stream));
+  auto *dev = static_cast<const daliamdPointwiseDesc *>(up.Upload(descs.data(), n * sizeof(descs[0]), ws.stream, ws.ring + 1));
   KCHECK(daliamdPointwiseRun(ws.stream, dev, n, nwg));
   NoteLaunch(ws, what);
 }

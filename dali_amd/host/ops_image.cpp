@@ -551,7 +551,7 @@ static void LaunchResample(Workspace &ws, DescUploader &up, std::vector<daliamdR
   descs.resize(n);
   int nwg = 0, lds = 0;
   KCHECK(daliamdResampleSetup(args.data(), n, descs.data(), &nwg, &lds));
-  auto *dev = static_cast<const daliamdResampleDesc *>(up.Upload(descs.data(), descs.size() * sizeof(descs[0]), ws.stream));
+  auto *dev = static_cast<const daliamdResampleDesc *>(up.Upload(descs.data(), descs.size() * sizeof(descs[0]), ws.stream, ws.ring + 1));
   KCHECK(daliamdResampleRun(ws.stream, dev, n, nwg, lds));
   NoteLaunch(ws, what);
 }
@@ -1095,7 +1095,7 @@ class CropMirrorNormalizeGpu : public OperatorBase {
     }
     int nwg = 0;
     KCHECK(daliamdCmnSetup(descs_.data(), n, &nwg));
-    auto *dev = static_cast<const daliamdCmnDesc *>(uploader_.Upload(descs_.data(), descs_.size() * sizeof(descs_[0]), ws.stream));
+    auto *dev = static_cast<const daliamdCmnDesc *>(uploader_.Upload(descs_.data(), descs_.size() * sizeof(descs_[0]), ws.stream, ws.ring + 1));
     KCHECK(daliamdCmnRun(ws.stream, dev, n, nwg));
     NoteLaunch(ws, "cmn");
   }

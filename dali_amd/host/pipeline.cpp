@@ -36,7 +36,7 @@ Pipeline::~Pipeline() {
   cv_dev_done_.notify_all();
   if (cpu_worker_.joinable()) cpu_worker_.join();
   if (worker_.joinable()) worker_.join();
-  if (stream_) daliamdStreamSynchronize(stream_);
+  for (auto st : streams_) daliamdStreamSynchronize(st);
   if (trace_ && traced_iterations_ > 0) {
     fprintf(stderr, "[dali_amd trace] host time per iteration over %lld iterations (worker thread):\n",
             (long long)traced_iterations_);
@@ -48,7 +48,7 @@ Pipeline::~Pipeline() {
   nodes_.clear();
   for (auto e : slot_events_) if (e) daliamdEventDestroy(e);
   if (copy_stream_) daliamdStreamDestroy(copy_stream_);
-  if (stream_) daliamdStreamDestroy(stream_);
+  for (auto st : streams_) daliamdStreamDestroy(st);
 }
 
 static std::string TensorKey(const std::string &name, StorageDevice d) {
@@ -122,7 +122,8 @@ void Pipeline::Build(const std::vector<std::pair<std::string, std::string>> &out
     DALI_ENFORCE(have_gpu_, "The pipeline contains device (\"gpu\"/\"mixed\") operators but no MI355X/ROCm device "
                  "is available. There is no CPU fallback for device operators.");
     KCHECK(daliamdSetDevice(params_.device_id));
-    KCHECK(daliamdStreamCreate(&stream_, 1));
+    streams_.assign(ring_, nullptr);
+    for (auto &st : streams_) KCHECK(daliamdStreamCreate(&st, 1));
     KCHECK(daliamdStreamCreate(&copy_stream_, 1));
   }
   for (auto &o : outputs) {
@@ -155,7 +156,7 @@ void Pipeline::Build(const std::vector<std::pair<std::string, std::string>> &out
     if (consumers[n.in_node[0]] == 1 && p.type == OpType::GPU) TryEnableFusion(p.op.get(), n.op.get());
   }
   slot_events_.assign(ring_, nullptr);
-  if (stream_)
+  if (!streams_.empty())
     for (auto &e : slot_events_) KCHECK(daliamdEventCreate(&e, 0));
   built_ = true;
   if (params_.exec_async) {
@@ -184,8 +185,8 @@ void Pipeline::RunStage(bool device_stage, int64_t it, int slot, Iteration &res)
   }
   try {
     if (res.failed) throw std::runtime_error(res.error);  // the host stage already failed: nothing to enqueue
-    if (stream_ && device_stage) KCHECK(daliamdSetDevice(params_.device_id));
-    if (stream_ && !device_stage) {
+    if (!streams_.empty() && device_stage) KCHECK(daliamdSetDevice(params_.device_id));
+    if (!streams_.empty() && !device_stage) {
       KCHECK(daliamdSetDevice(params_.device_id));
       // the buffers of this ring slot (pinned staging included) were last used `ring_` iterations ago: wait until
       // that iteration's device work has been enqueued (its event recorded) and has completed
@@ -205,8 +206,9 @@ void Pipeline::RunStage(bool device_stage, int64_t it, int slot, Iteration &res)
       Workspace ws;
       ws.pipeline = this;
       ws.thread_pool = device_stage ? thread_pool_.get() : cpu_thread_pool_.get();
-      ws.stream = stream_;
+      ws.stream = streams_.empty() ? nullptr : streams_[slot];
       ws.copy_stream = copy_stream_;
+      ws.ring = ring_;
       ws.batch_size = params_.batch_size;
       ws.iteration = it;
       std::vector<std::function<void()>> node_checks;
@@ -247,7 +249,7 @@ void Pipeline::RunStage(bool device_stage, int64_t it, int slot, Iteration &res)
   }
   if (device_stage) {
     // recorded even after a failure: the slot's next user waits for this event
-    if (stream_) daliamdEventRecord(slot_events_[slot], stream_);
+    if (!streams_.empty()) daliamdEventRecord(slot_events_[slot], streams_[slot]);
     {
       std::lock_guard<std::mutex> g(launches_m_);
       res.launches = cur_launches_;
@@ -339,7 +341,7 @@ std::vector<std::shared_ptr<TensorList>> Pipeline::Outputs() {
     last_launches_ = res.launches;
   }
   if (res.failed) throw std::runtime_error(res.error);
-  if (stream_) KCHECK(daliamdEventSynchronize(slot_events_[res.slot]));
+  if (!streams_.empty()) KCHECK(daliamdEventSynchronize(slot_events_[res.slot]));
   for (auto &chk : res.checks) chk();
   std::vector<std::shared_ptr<TensorList>> out;
   for (auto &o : outputs_) out.push_back(nodes_[o.first].out_ring[o.second][res.slot]);

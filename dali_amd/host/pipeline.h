@@ -55,7 +55,8 @@ class Pipeline {
 
   const PipelineParams &params() const { return params_; }
   int64_t seed() const { return original_seed_; }
-  daliamdStream_t stream() const { return stream_; }
+  daliamdStream_t stream() const { return streams_.empty() ? nullptr : streams_[0]; }
+  int ring() const { return ring_; }
 
  private:
   struct Node {
@@ -99,8 +100,10 @@ class Pipeline {
   bool have_gpu_ = false;
   std::unique_ptr<ThreadPool> thread_pool_;      // device-stage operators (e.g. the decoder's header parsing)
   std::unique_ptr<ThreadPool> cpu_thread_pool_;  // host-stage operators (e.g. the reader's file reads)
-  daliamdStream_t stream_ = nullptr;
-  daliamdStream_t copy_stream_ = nullptr;  // bulk H2D staging, overlaps the compute stream
+  // one compute stream per ring slot: consecutive iterations use different streams, so the latency-bound tail of one
+  // batch's kernels (the entropy decoder's relaxation rounds) overlaps the start of the next batch's
+  std::vector<daliamdStream_t> streams_;
+  daliamdStream_t copy_stream_ = nullptr;  // bulk H2D staging, overlaps the compute streams
   int ring_ = 3;
 
   // scheduling
