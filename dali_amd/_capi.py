@@ -36,8 +36,8 @@ class JpegHuffDesc(C.Structure):
                 ("ecs_len", C.c_int32), ("blocks_per_mcu", C.c_int32), ("mcus_x", C.c_int32),
                 ("total_blocks", C.c_int32), ("blocks_x", C.c_int32 * 3), ("h_samp", C.c_int32 * 3),
                 ("v_samp", C.c_int32 * 3), ("tile_start", C.c_int32), ("num_tiles", C.c_int32),
-                ("seg_start", C.c_int32), ("num_segments", C.c_int32),
-                ("comp_of_block", C.c_uint8 * 12), ("h_of_block", C.c_uint8 * 12),
+                ("seg_start", C.c_int32), ("num_segments", C.c_int32), ("blk_wg_start", C.c_int32),
+                ("reserved", C.c_int32), ("comp_of_block", C.c_uint8 * 12), ("h_of_block", C.c_uint8 * 12),
                 ("v_of_block", C.c_uint8 * 12), ("dc_sel", C.c_uint8 * 4), ("ac_sel", C.c_uint8 * 4),
                 ("bits", (C.c_uint8 * 16) * 4), ("vals", (C.c_uint8 * 256) * 4), ("rect", (C.c_int32 * 4) * 3)]
 

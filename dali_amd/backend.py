@@ -186,8 +186,9 @@ class JpegBatchPlan:
         self._ecs_off = np.concatenate([[0], np.cumsum(_align(ecs_len, 16))[:-1]]).astype(np.int64)
         need = np.zeros(len(sel), np.int64)
         nb = C.c_size_t(0)
+        total_blocks = (sc["mcus_x"][sel] * sc["mcus_y"][sel] * sc["blocks_per_mcu"][sel]).astype(np.int64)
         for j in range(len(sel)):
-            capi.check(lib.daliamdJpegHuffmanScratchBytes(int(ecs_len[j]), C.byref(nb)))
+            capi.check(lib.daliamdJpegHuffmanScratchBytes(int(ecs_len[j]), int(total_blocks[j]), C.byref(nb)))
             need[j] = nb.value
         self._scratch_off = np.concatenate([[0], np.cumsum(need)[:-1]]).astype(np.int64)
         stage = torch.empty(max(int(_align(ecs_len, 16).sum()), 16), dtype=torch.uint8, pin_memory=True)
@@ -237,30 +238,30 @@ class JpegBatchPlan:
         d["vals"][:, 2:4] = sc["ac_vals"][sel, 0:2]
         if self.roi_plans is not None:
             d["rect"] = np.where(self.has_roi[sel][:, None, None], self.roi_plans["rect"][sel], 0)
-        ntiles, nsegs = C.c_int(0), C.c_int(0)
-        capi.check(lib.daliamdJpegHuffmanSetup(d.ctypes.data_as(C.c_void_p), m, C.byref(ntiles), C.byref(nsegs)))
-        return d, ntiles.value, nsegs.value
+        ntiles, nsegs, nbwg = C.c_int(0), C.c_int(0), C.c_int(0)
+        capi.check(lib.daliamdJpegHuffmanSetup(d.ctypes.data_as(C.c_void_p), m, C.byref(ntiles), C.byref(nsegs),
+                                               C.byref(nbwg)))
+        return d, ntiles.value, nsegs.value, nbwg.value
 
     def run_gpu_huffman(self, coef_dev, descs=None, events=None, ws=None, kernel_events=None):
-        """Zero-fills the coefficient arrays and launches the GPU entropy decoder for the uploaded streams on the
-        current stream.  events: optional (before, after) events for timing."""
+        """Launches the GPU entropy decoder for the uploaded streams on the current stream (every decoded block is
+        written exactly once as a full line: no zero-fill).  events: optional (before, after) events for timing."""
         lib = capi.kernels()
         dev = coef_dev.device
         m = len(self._huff_sel)
         ws = ws or self._huff_ws
         if descs is None:
             descs = self.huffman_descs(coef_dev, ws)
-        table, ntiles, nsegs = descs
+        table, ntiles, nsegs, nbwg = descs
         d_dev = _uploader.upload(table, dev) if m else None
         s = current_stream_ptr(dev)
         if events:
             events[0].record()
-        capi.check(lib.daliamdMemsetAsync(C.c_void_p(coef_dev.data_ptr()), 0,
-                                          C.c_size_t(coef_dev.numel() * coef_dev.element_size()), s))
-        if m and kernel_events is not None:   # ctypes array of 8 daliamdEvent_t (see KernelEvents)
-            capi.check(lib.daliamdJpegHuffmanRunProfiled(s, C.c_void_p(d_dev.data_ptr()), m, ntiles, nsegs, kernel_events))
+        if m and kernel_events is not None:   # ctypes array of daliamdEvent_t (see KernelEvents)
+            capi.check(lib.daliamdJpegHuffmanRunProfiled(s, C.c_void_p(d_dev.data_ptr()), m, ntiles, nsegs, nbwg,
+                                                         kernel_events))
         elif m:
-            capi.check(lib.daliamdJpegHuffmanRun(s, C.c_void_p(d_dev.data_ptr()), m, ntiles, nsegs))
+            capi.check(lib.daliamdJpegHuffmanRun(s, C.c_void_p(d_dev.data_ptr()), m, ntiles, nsegs, nbwg))
         if events:
             events[1].record()
         self._huff_keep = [d_dev]
@@ -431,7 +432,7 @@ def _fill4(dst, src):
 
 
 HUFFMAN_KERNELS = ("UnstuffCountKernel", "UnstuffScatterKernel", "BuildTablesKernel", "SyncKernel",
-                   "PropagateKernel", "WriteKernel", "DcFixKernel")
+                   "PropagateKernel", "WriteKernel", "DcScanKernel", "ExpandKernel")
 
 
 class KernelEvents:

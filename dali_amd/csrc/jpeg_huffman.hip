@@ -26,9 +26,12 @@
 //   5 PropagateKernel       per image, serial over its segments: checks that every segment started from the state
 //                           its predecessor ended in (if not - pathological streams - repairs it with the same
 //                           relaxation, so correctness never depends on luck), assigns block ordinals
-//   6 WriteKernel           per segment: decodes once more from the now-known states and scatters the non-zero
-//                           coefficients (the arrays are pre-zeroed); DC differences as lane-local running sums
-//   7 DcFixKernel           per segment: prefix sums of the DC sums -> absolute DC values
+//   6 WriteKernel           per segment: decodes once more from the now-known states, extracting the values, and
+//                           appends one 32-bit record per symbol to the image's record stream (sequential per lane);
+//                           DC values as lane-local running sums of the differences; notes where every block starts
+//   7 DcScanKernel          per segment: prefix sums of the per-slice DC sums -> DC level at the start of every slice
+//   8 ExpandKernel          per block: builds the 8x8 block from its records in LDS, adds the DC level, stores it as
+//                           ONE full 128-byte line (no zero-fill, no partial writes, no read-modify-write)
 //
 // The decode loop is VALU-issue bound (a wave64 instruction occupies a SIMD16 for 4 cycles and divergent branches
 // execute the union of their bodies), hence: table entries carry (code length, magnitude bits, zig-zag advance), a
@@ -46,7 +49,7 @@ constexpr int kWarmLanes = 12;
 constexpr int kSegLanes = kSegThreads - kWarmLanes;
 constexpr int kSegBytes = kSegLanes * kSliceBytes;
 constexpr int kFastBits = 11;
-constexpr int kL2Entries = 1024;
+constexpr int kL2Entries = 512;
 constexpr int kCleanPadBytes = 40;
 
 // Explicit global address space: a generic pointer would make these `flat` accesses, which count against the LDS
@@ -57,17 +60,32 @@ using GlobalBytes = uint8_t __attribute__((address_space(1)));
 using GlobalU32 = uint32_t __attribute__((address_space(1)));
 
 // ------------------------------------------------------------------------------------------------ scratch layout
-struct LaneRec {     // one per slice
-  uint64_t in, out;  // packed decoder state at the start / end of the slice
-  int32_t nblk;      // blocks completed inside the slice
-  int32_t dc0, dc1, dc2, count;  // write pass: sums of the DC differences per component, number of DC symbols
-  int32_t reserved;
+struct LaneRec {      // one per slice
+  uint64_t in, out;   // packed decoder state at the start / end of the slice
+  int32_t nblk;       // blocks completed inside the slice
+  int32_t nsym;       // symbols that start inside the slice = records the write pass emits for it
+  int32_t dc[3];      // write pass: sum of the DC differences the slice holds, per component
+  int32_t base[3];    // DcScanKernel: DC level at the start of the slice, per component
 };
 struct SegRec {  // one per segment
   uint64_t out;  // state at the end of the segment
   int32_t nblk_total, block_base;
+  int32_t nsym_total, rec_base;
   int32_t dc_total[3];
   int32_t reserved;
+};
+// The write pass does not scatter 2-byte coefficients into the (185 MB per batch) coefficient arrays - that costs
+// 3.6x the algorithmic HBM traffic in partial-line writes plus a zero-fill plus a read-modify-write pass for the DC
+// prediction.  It appends one 32-bit RECORD per symbol to a per-image stream (sequential per lane, so the lines
+// fill up in L2) and notes where every block starts; ExpandKernel then builds each 8x8 block in LDS and stores it
+// as one full 128-byte line, adding the DC level on the way.
+//   record: bits 0-15 value (AC coefficient, or the lane-local running sum of the DC differences),
+//           bits 16-21 position inside the block (column-major), bit 22 = first record of a block (DC),
+//           bit 23 = carries a coefficient (clear for ZRL / end-of-block symbols)
+constexpr uint32_t kRecDc = 1u << 22, kRecValid = 1u << 23;
+struct BlockIndex {
+  uint32_t first_record;  // index of the block's DC record in the image's record stream
+  uint32_t lane;          // slice (image-wide index) that decoded the DC: its LaneRec holds the DC level
 };
 
 struct HuffTables {
@@ -94,10 +112,10 @@ struct HuffTables {
 static_assert(sizeof(HuffTables) % 16 == 0, "copied with 16-byte accesses");
 
 struct ScratchLayout {
-  size_t tile_kept, clean, tables, lanes, segs, total;
+  size_t tile_kept, clean, tables, lanes, segs, records, blocks, total;
 };
 __host__ __device__ inline size_t AlignUp(size_t v, size_t a) { return (v + a - 1) / a * a; }
-__host__ __device__ inline ScratchLayout MakeLayout(int ecs_len, int num_tiles, int num_segments) {
+__host__ __device__ inline ScratchLayout MakeLayout(int ecs_len, int num_tiles, int num_segments, int total_blocks) {
   ScratchLayout l;
   size_t o = 16;  // [0]: int32 clean_len
   l.tile_kept = o;
@@ -109,7 +127,12 @@ __host__ __device__ inline ScratchLayout MakeLayout(int ecs_len, int num_tiles, 
   l.lanes = o;
   o += sizeof(LaneRec) * (size_t)num_segments * kSegLanes;
   l.segs = o;
-  o += sizeof(SegRec) * (size_t)num_segments;
+  o += AlignUp(sizeof(SegRec) * (size_t)num_segments, 16);
+  // every symbol consumes at least 2 bits (streams with a 1-bit code are not eligible): <= 4 records per byte
+  l.records = o;
+  o += sizeof(uint32_t) * (4 * (size_t)ecs_len + 64);
+  l.blocks = o;
+  o += sizeof(BlockIndex) * ((size_t)total_blocks + 1);
   l.total = AlignUp(o, 256);
   return l;
 }
@@ -191,7 +214,7 @@ __global__ __launch_bounds__(kTileThreads) void UnstuffCountKernel(const daliamd
   __shared__ int wave_sums[kTileThreads / 64];
   const ImageRef r = FindImage<true>(descs, n, blockIdx.x);
   const daliamdJpegHuffDesc &d = *r.d;
-  const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments);
+  const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments, d.total_blocks);
   TileChunk c = LoadChunk(d, r.local);
   int total;
   WorkgroupExclusiveScan<kTileThreads / 64>(__popc(c.keep), wave_sums, total);
@@ -203,7 +226,7 @@ __global__ __launch_bounds__(kTileThreads) void UnstuffScatterKernel(const dalia
   __shared__ int wave_sums[kTileThreads / 64];
   const ImageRef r = FindImage<true>(descs, n, blockIdx.x);
   const daliamdJpegHuffDesc &d = *r.d;
-  const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments);
+  const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments, d.total_blocks);
   const int tid = threadIdx.x;
   // clean-stream position of this tile = bytes kept by the tiles before it
   const int32_t *tile_kept = reinterpret_cast<const int32_t *>(d.scratch + lay.tile_kept);
@@ -269,7 +292,7 @@ __device__ __forceinline__ void CopyTables(HuffTables &dst, const HuffTables *sr
 __global__ __launch_bounds__(256) void BuildTablesKernel(const daliamdJpegHuffDesc *__restrict__ descs) {
   __shared__ __attribute__((aligned(16))) HuffTables L;
   const daliamdJpegHuffDesc &d = descs[blockIdx.x];
-  const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments);
+  const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments, d.total_blocks);
   const int tid = threadIdx.x;
   {
     uint4 *z = reinterpret_cast<uint4 *>(&L);
@@ -388,37 +411,6 @@ constexpr uint64_t kNoState = ~0ull;  // unpacks to a position past any stream
 
 struct DcAcc {
   int sum0 = 0, sum1 = 0, sum2 = 0;  // running sums of the DC differences this lane decoded, per component
-  int count = 0;                     // number of DC symbols this lane decoded
-};
-
-// Position of a block ordinal in the MCU grid, advanced incrementally.
-struct BlockCursor {
-  int ordinal, k, mx, my;
-  __device__ __forceinline__ void Init(const HuffTables &L, int ord) {
-    ordinal = ord;
-    int mcu = ord / L.bpm;
-    k = ord - mcu * L.bpm;
-    my = mcu / L.mcus_x;
-    mx = mcu - my * L.mcus_x;
-  }
-  __device__ __forceinline__ void Next(const HuffTables &L) {
-    ordinal++;
-    if (++k == L.bpm) {
-      k = 0;
-      if (++mx == L.mcus_x) {
-        mx = 0;
-        my++;
-      }
-    }
-  }
-  __device__ __forceinline__ GlobalCoef *Ptr(const HuffTables &L) const {
-    if (ordinal >= L.last_ordinal) return nullptr;
-    if (L.use_rect) {
-      const int bx = mx * L.blk_hs[k] + L.blk_ho[k], by = my * L.blk_vs[k] + L.blk_vo[k];
-      if (bx < L.blk_rect[k][0] || by < L.blk_rect[k][1] || bx >= L.blk_rect[k][2] || by >= L.blk_rect[k][3]) return nullptr;
-    }
-    return L.blk_base[k] + ((size_t)my * (size_t)L.blk_sy[k] + (size_t)(mx * L.blk_sx[k]));
-  }
 };
 
 // Rare path: the code is longer than kFastBits bits (or is not a code at all).
@@ -445,8 +437,8 @@ __device__ __forceinline__ uint32_t LongCode(const HuffTables &L, uint32_t slot,
 // Decodes the symbols that start in [st.pos, end_bits); returns the number of blocks completed.  Positions only:
 // no value is extracted (synchronisation passes).
 __device__ __forceinline__ int DecodeRange(const HuffTables &L, GlobalWords *__restrict__ words, DecodeState &st,
-                                           uint32_t end_bits) {
-  int nblk = 0;
+                                           uint32_t end_bits, int &nsym_out) {
+  int nblk = 0, nsym = 0;
   uint32_t c = st.c, z = st.z;
   int rem = (int)(end_bits - st.pos);  // bits left before the end of the slice (<= 0: done)
   // bit window: hi:lo = stream bits [32k, 32k+64), `off` of hi's bits already consumed; the following dword is in flight
@@ -465,6 +457,7 @@ __device__ __forceinline__ int DecodeRange(const HuffTables &L, GlobalWords *__r
     rem -= (int)used;
     off += used;
     z += e & 127;
+    nsym++;
     if (off >= 32) {
       hi = lo;
       lo = __builtin_bswap32(nxt);
@@ -481,81 +474,125 @@ __device__ __forceinline__ int DecodeRange(const HuffTables &L, GlobalWords *__r
   st.pos = end_bits - (uint32_t)rem;
   st.c = c;
   st.z = z;
+  nsym_out = nsym;
   return nblk;
 }
 
-constexpr int kStreamWords = 20;  // dwords of the clean stream buffered in LDS per lane
-constexpr int kReloadSteps = 16;  // symbols between two reloads: 16 x 31 bits at most < 16 dwords <= kStreamWords - 3
-                                  // (small on purpose: 36 KB of LDS per workgroup keeps 4 workgroups on a CU)
+constexpr int kGroupSteps = 8;   // symbols between two wave-uniform "points" of the write pass
+constexpr int kRingWords = 32;   // dwords of the clean stream buffered in LDS per lane (ring)
 
 // Write pass of one slice: decodes the symbols that start in [st.pos, end_bits) once more, now extracting the values,
-// and scatters the non-zero coefficients into the (pre-zeroed) arrays; the block in progress at `st` is block
-// ordinal `ord`.  The DC entry receives the lane-local running sum of the differences (DcFixKernel adds the level
-// at the start of the slice).
+// and appends one record per symbol to `rec` (this slice's part of the image's record stream; exactly the `nsym`
+// records the synchronisation pass counted).  The block in progress at `st` is block ordinal `ord`; every DC record
+// registers its block in the block index.  DC records carry the lane-local running sum of the differences of their
+// component (ExpandKernel adds the level at the start of the slice).
 //
-// gfx9 has ONE in-order counter for vector-memory loads and stores, so a stream prefetch that is waited for while
-// coefficient stores are in flight would wait for those stores as well (measured: 3x slower).  The stream therefore
-// goes through a small per-lane LDS buffer that the whole wave refills at the same step, every kReloadSteps
-// symbols: one wait per 16 symbols instead of one per refill of the bit window.
+// gfx9 has ONE in-order counter for vector-memory loads and stores: waiting for a load also waits for every store
+// issued before it.  So the loop is software-pipelined around wave-uniform points, kGroupSteps symbols apart:
+// at a point the lane (1) takes delivery of the 8 stream dwords it requested at the previous point (long arrived:
+// the wait costs nothing) and appends them to its LDS ring, (2) stores the records and block-index entries of the
+// last 8 symbols, kept in registers until now, (3) requests the next 8 stream dwords.  Between two points there
+// is no vector-memory instruction at all: the bit window is refilled from the LDS ring.
 __device__ __forceinline__ void WriteRange(const HuffTables &L, GlobalWords *__restrict__ words, DecodeState st,
-                                           uint32_t end_bits, int ord, bool live, uint32_t *sbuf, DcAcc &dc) {
+                                           uint32_t end_bits, int ord, bool live, uint32_t *ring,
+                                           GlobalU32 *__restrict__ rec, uint32_t rec_index, uint32_t lane_id,
+                                           BlockIndex *__restrict__ blocks, DcAcc &dc) {
   uint32_t c = st.c, z = st.z;
   int rem = (int)(end_bits - st.pos);
-  int k = (int)(st.pos >> 5), kbase = 0;
+  int k = (int)(st.pos >> 5);  // dword index of `hi`
+  int kl = k;                  // the ring holds dwords [.., kl)
   uint32_t off = st.pos & 31;
   uint32_t hi = 0, lo = 0, nxt = 0;
   const uint16_t *fast = &L.fast[0][0];
   const uint32_t dc_mask = L.dc_mask, ac_mask = L.ac_mask, bpm = (uint32_t)L.bpm;
-  BlockCursor cur;
-  cur.Init(L, live ? ord : 0);
-  GlobalCoef *blk = live ? cur.Ptr(L) : nullptr;
-  for (int step = 0; __ballot(live) != 0; step++) {  // wave-uniform trip count
-    if ((step & (kReloadSteps - 1)) == 0 && live) {
-      kbase = k;
+  int ordinal = ord;  // block the next symbol belongs to
+  if (live) {         // prologue: 24 dwords straight into the ring (the only exposed memory latency of the pass)
 #pragma unroll
-      for (int q = 0; q < kStreamWords; q++) sbuf[q] = words[k + q];
-      hi = __builtin_bswap32(sbuf[0]);
-      lo = __builtin_bswap32(sbuf[1]);
-      nxt = sbuf[2];
+    for (int q = 0; q < 24; q++) ring[(k + q) & (kRingWords - 1)] = words[k + q];
+    kl = k + 24;
+    hi = __builtin_bswap32(ring[k & (kRingWords - 1)]);
+    lo = __builtin_bswap32(ring[(k + 1) & (kRingWords - 1)]);
+    nxt = ring[(k + 2) & (kRingWords - 1)];
+  }
+  uint32_t pre[8];        // stream dwords [kl, kl + 8) in flight
+  bool have_pre = false;
+  uint32_t r[kGroupSteps];  // records of the current group
+  int nrec = 0;
+  int group_ord = ordinal;  // `ordinal` and "inside a block" at the start of the group whose records are in r[]
+  bool group_mid_block = z != 0;
+  while (__ballot(live || nrec > 0) != 0) {  // wave-uniform trip count
+    // ---------------- point ----------------
+    if (have_pre) {
+#pragma unroll
+      for (int q = 0; q < 8; q++) ring[(kl + q) & (kRingWords - 1)] = pre[q];
+      kl += 8;
+      have_pre = false;
     }
-    if (live) {
-      const uint32_t peek = (uint32_t)(((((uint64_t)hi << 32) | lo) << off) >> 32);
-      const bool is_dc = z == 0;
-      const uint32_t slot = (((is_dc ? dc_mask : ac_mask) >> c) & 1u) + (is_dc ? 0u : 2u);
-      uint32_t e = fast[(slot << kFastBits) + (peek >> (32 - kFastBits))];
-      if (__builtin_expect(e == 0, 0)) e = LongCode(L, slot, peek, is_dc);
-      const uint32_t used = (e >> 7) & 31, s = e >> 12, adv = e & 127, len = used - s;
-      // magnitude bits -> value (T.81 F.2.2.1 EXTEND); s == 0 gives 0
-      const uint32_t m = ((peek << len) >> 1) >> (31 - s);
-      const uint32_t half = (1u << s) >> 1;
-      int val = (int)m + (m < half ? 1 - (int)(1u << s) : 0);
-      uint32_t zt = z + adv - 1;  // zig-zag index of the coefficient this symbol carries (AC)
-      if (is_dc) {
-        const int comp = L.blk_comp[c];
-        if (comp == 0) val = (dc.sum0 += val);
-        else if (comp == 1) val = (dc.sum1 += val);
-        else val = (dc.sum2 += val);
-        dc.count++;
-        zt = 0;
+    if (nrec > 0) {
+      int dc_ord = group_ord + (group_mid_block ? 1 : 0);  // ordinal of the first DC record of the group
+#pragma unroll
+      for (int q = 0; q < kGroupSteps; q++) {
+        if (q < nrec) {
+          rec[rec_index + q] = r[q];
+          if (r[q] & kRecDc) {
+            if (dc_ord < L.total_blocks) blocks[dc_ord] = BlockIndex{rec_index + q, lane_id};
+            dc_ord++;
+          }
+        }
       }
-      if (blk && (is_dc || (s && zt < 64))) blk[L.zz[zt]] = (int16_t)val;
-      rem -= (int)used;
-      off += used;
-      z += adv;
-      if (off >= 32) {
-        hi = lo;
-        lo = __builtin_bswap32(nxt);
-        k++;
-        nxt = sbuf[k + 2 - kbase];
-        off -= 32;
+      rec_index += (uint32_t)nrec;
+      nrec = 0;
+    }
+    if (live && kl - k <= 24) {  // room in the ring: request the next 8 dwords (delivered at the next point)
+#pragma unroll
+      for (int q = 0; q < 8; q++) pre[q] = words[kl + q];
+      have_pre = true;
+    }
+    group_ord = ordinal;
+    group_mid_block = z != 0;
+    // ---------------- 8 symbols, no vector-memory instruction ----------------
+#pragma unroll
+    for (int j = 0; j < kGroupSteps; j++) {
+      if (live) {
+        const uint32_t peek = (uint32_t)(((((uint64_t)hi << 32) | lo) << off) >> 32);
+        const bool is_dc = z == 0;
+        const uint32_t slot = (((is_dc ? dc_mask : ac_mask) >> c) & 1u) + (is_dc ? 0u : 2u);
+        uint32_t e = fast[(slot << kFastBits) + (peek >> (32 - kFastBits))];
+        if (__builtin_expect(e == 0, 0)) e = LongCode(L, slot, peek, is_dc);
+        const uint32_t used = (e >> 7) & 31, s = e >> 12, adv = e & 127, len = used - s;
+        // magnitude bits -> value (T.81 F.2.2.1 EXTEND); s == 0 gives 0
+        const uint32_t m = ((peek << len) >> 1) >> (31 - s);
+        const uint32_t half = (1u << s) >> 1;
+        int val = (int)m + (m < half ? 1 - (int)(1u << s) : 0);
+        uint32_t zt = z + adv - 1;  // zig-zag index of the coefficient this symbol carries (AC)
+        uint32_t flags = (s && zt < 64) ? kRecValid : 0;
+        if (is_dc) {
+          const int comp = L.blk_comp[c];
+          if (comp == 0) val = (dc.sum0 += val);
+          else if (comp == 1) val = (dc.sum1 += val);
+          else val = (dc.sum2 += val);
+          zt = 0;
+          flags = kRecDc | kRecValid;
+        }
+        r[j] = ((uint32_t)val & 0xFFFFu) | ((uint32_t)L.zz[zt & 63] << 16) | flags;
+        nrec = j + 1;
+        rem -= (int)used;
+        off += used;
+        z += adv;
+        if (off >= 32) {
+          hi = lo;
+          lo = __builtin_bswap32(nxt);
+          k++;
+          nxt = ring[(k + 2) & (kRingWords - 1)];
+          off -= 32;
+        }
+        if (z >= 64) {
+          z = 0;
+          c = c + 1 == bpm ? 0 : c + 1;
+          ordinal++;
+        }
+        live = rem > 0;
       }
-      if (z >= 64) {
-        z = 0;
-        c = c + 1 == bpm ? 0 : c + 1;
-        cur.Next(L);
-        blk = cur.Ptr(L);
-      }
-      live = rem > 0;
     }
   }
 }
@@ -565,7 +602,7 @@ struct Lane {
   uint32_t begin, end;  // bit range of the slice (clipped to the stream)
   bool active;          // the slice holds data
   uint64_t in = kNoState, out = kNoState;
-  int nblk = 0;
+  int nblk = 0, nsym = 0;
 };
 
 // "Publish the state you reached to the next lane, decode again if your input changed", until nothing changes.
@@ -580,8 +617,8 @@ __device__ __forceinline__ void Relax(const HuffTables &L, GlobalWords *words, u
     if (ln.active && ni != ln.in) {
       ln.in = ni;
       DecodeState st = Unpack(ni);
-      ln.nblk = 0;
-      if (st.pos < ln.end) ln.nblk = DecodeRange(L, words, st, ln.end);
+      ln.nblk = ln.nsym = 0;
+      if (st.pos < ln.end) ln.nblk = DecodeRange(L, words, st, ln.end, ln.nsym);
       ln.out = Pack(st);
     }
     __syncthreads();
@@ -616,14 +653,14 @@ __global__ __launch_bounds__(kSegThreads) void SyncKernel(const daliamdJpegHuffD
   if (wg < 0) return;
   const ImageRef r = FindImage<false>(descs, n, wg);
   const daliamdJpegHuffDesc &d = *r.d;
-  const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments);
+  const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments, d.total_blocks);
   const int tid = threadIdx.x, seg = r.local;
   const int clean_len = *reinterpret_cast<const int32_t *>(d.scratch);
   LaneRec *recs = reinterpret_cast<LaneRec *>(d.scratch + lay.lanes) + (size_t)seg * kSegLanes;
   SegRec *segrec = reinterpret_cast<SegRec *>(d.scratch + lay.segs) + seg;
   if (seg > 0 && (long long)seg * kSegBytes >= clean_len) {  // segment behind the end of the stream
-    if (tid >= kWarmLanes) recs[tid - kWarmLanes] = LaneRec{kNoState, kNoState, 0, 0, 0, 0, 0, 0};
-    if (tid == 0) *segrec = SegRec{kNoState, 0, 0, {0, 0, 0}, 0};
+    if (tid >= kWarmLanes) recs[tid - kWarmLanes] = LaneRec{kNoState, kNoState, 0, 0, {0, 0, 0}, {0, 0, 0}};
+    if (tid == 0) *segrec = SegRec{kNoState, 0, 0, 0, 0, {0, 0, 0}, 0};
     return;
   }
   CopyTables<kSegThreads>(L, reinterpret_cast<const HuffTables *>(d.scratch + lay.tables));
@@ -633,14 +670,15 @@ __global__ __launch_bounds__(kSegThreads) void SyncKernel(const daliamdJpegHuffD
   state[tid] = Pack(DecodeState{ln.begin, 0, 0});  // the guess; exact for the very first slice of the image
   __syncthreads();
   Relax<kSegThreads>(L, (GlobalWords *)(d.scratch + lay.clean), state, ln);
-  int total;
+  int total, total_sym;
   WorkgroupExclusiveScan<kSegThreads / 64>(tid >= kWarmLanes ? ln.nblk : 0, wave_sums, total);
+  WorkgroupExclusiveScan<kSegThreads / 64>(tid >= kWarmLanes ? ln.nsym : 0, wave_sums, total_sym);
   if (tid >= kWarmLanes) {
-    recs[tid - kWarmLanes] = LaneRec{ln.in, ln.out, ln.nblk, 0, 0, 0, 0, 0};
+    recs[tid - kWarmLanes] = LaneRec{ln.in, ln.out, ln.nblk, ln.nsym, {0, 0, 0}, {0, 0, 0}};
     // the last slice with data ends the segment (an empty stream: the first lane passes its input on)
     const bool next_has_data = tid + 1 < kSegThreads && ln.end < total_bits;
-    if (ln.active && !next_has_data) *segrec = SegRec{ln.out, total, 0, {0, 0, 0}, 0};
-    if (total_bits == 0 && tid == kWarmLanes) *segrec = SegRec{Pack(DecodeState{0, 0, 0}), 0, 0, {0, 0, 0}, 0};
+    if (ln.active && !next_has_data) *segrec = SegRec{ln.out, total, 0, total_sym, 0, {0, 0, 0}, 0};
+    if (total_bits == 0 && tid == kWarmLanes) *segrec = SegRec{Pack(DecodeState{0, 0, 0}), 0, 0, 0, 0, {0, 0, 0}, 0};
   }
 }
 
@@ -649,20 +687,21 @@ __global__ __launch_bounds__(kSegThreads) void PropagateKernel(const daliamdJpeg
   __shared__ uint64_t state[kSegThreads];
   __shared__ int wave_sums[kSegThreads / 64];
   const daliamdJpegHuffDesc &d = descs[blockIdx.x];
-  const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments);
+  const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments, d.total_blocks);
   const int tid = threadIdx.x;
   const int clean_len = *reinterpret_cast<const int32_t *>(d.scratch);
   const uint32_t total_bits = (uint32_t)clean_len * 8u;
   LaneRec *all_recs = reinterpret_cast<LaneRec *>(d.scratch + lay.lanes);
   SegRec *segs = reinterpret_cast<SegRec *>(d.scratch + lay.segs);
   uint64_t truth = Pack(DecodeState{0, 0, 0});
-  int block_base = 0;
+  int block_base = 0, rec_base = 0;
   bool tables_loaded = false;
   for (int seg = 0; seg < d.num_segments; seg++) {
     if (seg > 0 && (long long)seg * kSegBytes >= clean_len) {
       if (tid == 0) {
         segs[seg].out = truth;
         segs[seg].block_base = block_base;
+        segs[seg].rec_base = rec_base;
       }
       continue;
     }
@@ -678,42 +717,54 @@ __global__ __launch_bounds__(kSegThreads) void PropagateKernel(const daliamdJpeg
         ln.in = recs[tid].in;
         ln.out = recs[tid].out;
         ln.nblk = recs[tid].nblk;
+        ln.nsym = recs[tid].nsym;
       }
       state[tid] = tid == 0 ? truth : ln.in;
       __syncthreads();
       Relax<kSegThreads>(L, (GlobalWords *)(d.scratch + lay.clean), state, ln);
-      int total;
+      int total, total_sym;
       WorkgroupExclusiveScan<kSegThreads / 64>(ln.nblk, wave_sums, total);
+      WorkgroupExclusiveScan<kSegThreads / 64>(ln.nsym, wave_sums, total_sym);
       if (tid < kSegLanes) {
         recs[tid].in = ln.in;
         recs[tid].out = ln.out;
         recs[tid].nblk = ln.nblk;
+        recs[tid].nsym = ln.nsym;
         const bool next_has_data = tid + 1 < kSegLanes && ln.end < total_bits;
         if (ln.active && !next_has_data) {
           segs[seg].out = ln.out;
           segs[seg].nblk_total = total;
+          segs[seg].nsym_total = total_sym;
         }
       }
       __threadfence();
       __syncthreads();  // the records written above are read below (same workgroup)
     }
-    if (tid == 0) segs[seg].block_base = block_base;
+    if (tid == 0) {
+      segs[seg].block_base = block_base;
+      segs[seg].rec_base = rec_base;
+    }
     block_base += segs[seg].nblk_total;
+    rec_base += segs[seg].nsym_total;
     truth = segs[seg].out;
   }
   // the segment must hold every block the frame header promises (the padding may add garbage after them)
   if (tid == 0 && block_base < d.total_blocks) *d.status = 2;
+  if (tid == 0) {
+    reinterpret_cast<int32_t *>(d.scratch)[1] = rec_base;    // records of the whole stream
+    reinterpret_cast<int32_t *>(d.scratch)[2] = block_base;  // blocks the stream really holds (truncated streams: fewer)
+  }
 }
 
 __global__ __launch_bounds__(kSegThreads) void WriteKernel(const daliamdJpegHuffDesc *__restrict__ descs, int n, int nseg) {
   __shared__ __attribute__((aligned(16))) HuffTables L;
-  __shared__ __attribute__((aligned(16))) uint32_t sbuf[kSegThreads * kStreamWords];
+  __shared__ __attribute__((aligned(16))) uint32_t ring[kSegThreads * kRingWords];
   __shared__ int wave_sums[kSegThreads / 64];
   const int wg = XcdRemap(blockIdx.x, nseg);
   if (wg < 0) return;
   const ImageRef r = FindImage<false>(descs, n, wg);
   const daliamdJpegHuffDesc &d = *r.d;
-  const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments);
+  const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments, d.total_blocks);
   const int tid = threadIdx.x, seg = r.local;
   const int clean_len = *reinterpret_cast<const int32_t *>(d.scratch);
   if (seg > 0 && (long long)seg * kSegBytes >= clean_len) return;
@@ -725,18 +776,23 @@ __global__ __launch_bounds__(kSegThreads) void WriteKernel(const daliamdJpegHuff
   if (tid < kSegLanes) {
     ln.in = recs[tid].in;
     ln.nblk = recs[tid].nblk;
+    ln.nsym = recs[tid].nsym;
   }
   int total;
   const int ord = segrec->block_base + WorkgroupExclusiveScan<kSegThreads / 64>(ln.nblk, wave_sums, total);
+  const int rec_off = segrec->rec_base + WorkgroupExclusiveScan<kSegThreads / 64>(ln.nsym, wave_sums, total);
   DcAcc dc;
   DecodeState st = Unpack(ln.in);
-  WriteRange(L, (GlobalWords *)(d.scratch + lay.clean), st, ln.end, ord,
-             ln.active && st.pos < ln.end && ord < L.last_ordinal, sbuf + tid * kStreamWords, dc);
+  // region of interest: slices behind the last needed block are not decoded again; the slice that STARTS at that
+  // block still is, so that the DC record ending the last needed block exists
+  const bool live = ln.active && st.pos < ln.end && ord <= L.last_ordinal;
+  WriteRange(L, (GlobalWords *)(d.scratch + lay.clean), st, ln.end, ord, live, ring + tid * kRingWords,
+             (GlobalU32 *)(d.scratch + lay.records), (uint32_t)rec_off, (uint32_t)(seg * kSegLanes + tid),
+             reinterpret_cast<BlockIndex *>(d.scratch + lay.blocks), dc);
   if (tid < kSegLanes) {
-    recs[tid].dc0 = dc.sum0;
-    recs[tid].dc1 = dc.sum1;
-    recs[tid].dc2 = dc.sum2;
-    recs[tid].count = dc.count;
+    recs[tid].dc[0] = dc.sum0;
+    recs[tid].dc[1] = dc.sum1;
+    recs[tid].dc[2] = dc.sum2;
   }
   int t0, t1, t2;
   WorkgroupExclusiveScan<kSegThreads / 64>(dc.sum0, wave_sums, t0);
@@ -749,97 +805,92 @@ __global__ __launch_bounds__(kSegThreads) void WriteKernel(const daliamdJpegHuff
   }
 }
 
-__global__ __launch_bounds__(kSegThreads) void DcFixKernel(const daliamdJpegHuffDesc *__restrict__ descs, int n, int nseg) {
+// DC prediction: the level at the start of every slice = sum of the differences of all slices before it.
+__global__ __launch_bounds__(kSegThreads) void DcScanKernel(const daliamdJpegHuffDesc *__restrict__ descs, int n, int nseg) {
   __shared__ int wave_sums[kSegThreads / 64];
-  __shared__ int geom[4];
-  __shared__ uint8_t blk_comp[16];
-  __shared__ int blk_sx[12], blk_sy[12];
-  __shared__ GlobalCoef *blk_base[12];
-  __shared__ int blk_pos[12][4];   // hs, ho, vs, vo
-  __shared__ int blk_rect[12][4];  // region of interest of the block's component
   const int wg = XcdRemap(blockIdx.x, nseg);
   if (wg < 0) return;
   const ImageRef r = FindImage<false>(descs, n, wg);
   const daliamdJpegHuffDesc &d = *r.d;
-  const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments);
+  const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments, d.total_blocks);
   const int tid = threadIdx.x, seg = r.local;
   const int clean_len = *reinterpret_cast<const int32_t *>(d.scratch);
   if (seg > 0 && (long long)seg * kSegBytes >= clean_len) return;
-  const HuffTables *T = reinterpret_cast<const HuffTables *>(d.scratch + lay.tables);
-  if (tid < 12) {
-    blk_comp[tid] = T->blk_comp[tid];
-    blk_sx[tid] = T->blk_sx[tid];
-    blk_sy[tid] = T->blk_sy[tid];
-    blk_base[tid] = T->blk_base[tid];
-    blk_pos[tid][0] = T->blk_hs[tid];
-    blk_pos[tid][1] = T->blk_ho[tid];
-    blk_pos[tid][2] = T->blk_vs[tid];
-    blk_pos[tid][3] = T->blk_vo[tid];
-    for (int j = 0; j < 4; j++) blk_rect[tid][j] = T->blk_rect[tid][j];
-  }
-  if (tid == 0) {
-    geom[0] = T->bpm;
-    geom[1] = T->mcus_x;
-    geom[2] = T->last_ordinal;  // blocks behind it were not written
-    geom[3] = T->use_rect;
-  }
-  const LaneRec *recs = reinterpret_cast<const LaneRec *>(d.scratch + lay.lanes) + (size_t)seg * kSegLanes;
+  LaneRec *recs = reinterpret_cast<LaneRec *>(d.scratch + lay.lanes) + (size_t)seg * kSegLanes;
   const SegRec *segs = reinterpret_cast<const SegRec *>(d.scratch + lay.segs);
-  // DC level at the start of this segment = totals of the segments before it
-  int p0 = 0, p1 = 0, p2 = 0;
-  for (int j = tid; j < seg; j += kSegThreads) {
-    p0 += segs[j].dc_total[0];
-    p1 += segs[j].dc_total[1];
-    p2 += segs[j].dc_total[2];
+  int p[3] = {0, 0, 0};
+  for (int j = tid; j < seg; j += kSegThreads)
+    for (int c = 0; c < 3; c++) p[c] += segs[j].dc_total[c];
+  for (int c = 0; c < 3; c++) {
+    int seg_base, unused;
+    WorkgroupExclusiveScan<kSegThreads / 64>(p[c], wave_sums, seg_base);
+    const int mine = tid < kSegLanes ? recs[tid].dc[c] : 0;
+    const int base = seg_base + WorkgroupExclusiveScan<kSegThreads / 64>(mine, wave_sums, unused);
+    if (tid < kSegLanes) recs[tid].base[c] = base;
   }
-  int s0, s1, s2, unused;
-  WorkgroupExclusiveScan<kSegThreads / 64>(p0, wave_sums, s0);
-  WorkgroupExclusiveScan<kSegThreads / 64>(p1, wave_sums, s1);
-  WorkgroupExclusiveScan<kSegThreads / 64>(p2, wave_sums, s2);
-  LaneRec rec{kNoState, kNoState, 0, 0, 0, 0, 0, 0};
-  if (tid < kSegLanes) rec = recs[tid];
-  const int base0 = s0 + WorkgroupExclusiveScan<kSegThreads / 64>(rec.dc0, wave_sums, unused);
-  const int base1 = s1 + WorkgroupExclusiveScan<kSegThreads / 64>(rec.dc1, wave_sums, unused);
-  const int base2 = s2 + WorkgroupExclusiveScan<kSegThreads / 64>(rec.dc2, wave_sums, unused);
-  const int ord = segs[seg].block_base + WorkgroupExclusiveScan<kSegThreads / 64>(rec.nblk, wave_sums, unused);
-  if (rec.count > 0 && (base0 | base1 | base2)) {
-    // the blocks this lane wrote: ordinals [first, first + count); four read-modify-writes in flight at a time
-    const int bpm = geom[0], mcus_x = geom[1], total_blocks = geom[2], use_rect = geom[3];
-    int ordinal = ord + ((rec.in & 255) != 0 ? 1 : 0);
-    int mcu = ordinal / bpm, k = ordinal - mcu * bpm, my = mcu / mcus_x, mx = mcu - my * mcus_x;
-    int left = min(rec.count, total_blocks - ordinal);
-    while (left > 0) {
-      GlobalCoef *p[4];
-      int add[4], v[4];
-      bool stored[4];
-      const int m = min(left, 4);
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        p[i] = blk_base[k] + ((size_t)my * (size_t)blk_sy[k] + (size_t)(mx * blk_sx[k]));
-        const int cc = blk_comp[k];
-        add[i] = cc == 0 ? base0 : cc == 1 ? base1 : base2;
-        stored[i] = i < m;
-        if (use_rect && i < m) {
-          const int bx = mx * blk_pos[k][0] + blk_pos[k][1], by = my * blk_pos[k][2] + blk_pos[k][3];
-          stored[i] = bx >= blk_rect[k][0] && by >= blk_rect[k][1] && bx < blk_rect[k][2] && by < blk_rect[k][3];
-        }
-        v[i] = 0;
-        if (i < m) {
-          if (stored[i]) v[i] = p[i][0];
-          if (++k == bpm) {
-            k = 0;
-            if (++mx == mcus_x) {
-              mx = 0;
-              my++;
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-        if (stored[i]) p[i][0] = (int16_t)(v[i] + add[i]);
-      left -= m;
+}
+
+// Builds every needed 8x8 block from its records and stores it as one full 128-byte line: 8 lanes per block
+// (coalesced record loads, 16 bytes of the line each), 32 blocks per workgroup.
+constexpr int kExpandThreads = 256;
+constexpr int kExpandBlocks = kExpandThreads / 8;
+__global__ __launch_bounds__(kExpandThreads) void ExpandKernel(const daliamdJpegHuffDesc *__restrict__ descs, int n,
+                                                               int nwg) {
+  __shared__ __attribute__((aligned(16))) int16_t stage[kExpandBlocks][72];  // 64 + padding
+  const int wg = XcdRemap(blockIdx.x, nwg);
+  if (wg < 0) return;
+  // workgroup -> image (descriptors sorted by blk_wg_start)
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].blk_wg_start <= wg) lo = mid; else hi = mid - 1;
+  }
+  const daliamdJpegHuffDesc &d = descs[lo];
+  const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments, d.total_blocks);
+  const HuffTables *T = reinterpret_cast<const HuffTables *>(d.scratch + lay.tables);
+  const int lb = threadIdx.x >> 3, part = threadIdx.x & 7;
+  const int ordinal = (wg - d.blk_wg_start) * kExpandBlocks + lb;
+  const int decoded_blocks = reinterpret_cast<const int32_t *>(d.scratch)[2];  // < total_blocks: corrupt stream (status 2)
+  bool needed = ordinal < T->last_ordinal && ordinal < decoded_blocks;
+  int k = 0, mx = 0, my = 0;
+  if (needed) {
+    const int bpm = T->bpm, mcus_x = T->mcus_x;
+    const int mcu = ordinal / bpm;
+    k = ordinal - mcu * bpm;
+    my = mcu / mcus_x;
+    mx = mcu - my * mcus_x;
+    if (T->use_rect) {
+      const int bx = mx * T->blk_hs[k] + T->blk_ho[k], by = my * T->blk_vs[k] + T->blk_vo[k];
+      needed = bx >= T->blk_rect[k][0] && by >= T->blk_rect[k][1] && bx < T->blk_rect[k][2] && by < T->blk_rect[k][3];
     }
+  }
+  uint4 *blk_v = reinterpret_cast<uint4 *>(&stage[lb][0]);
+  blk_v[part] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+  if (needed) {
+    const BlockIndex *index = reinterpret_cast<const BlockIndex *>(d.scratch + lay.blocks);
+    const BlockIndex bi = index[ordinal];
+    const GlobalWords *rec = (const GlobalWords *)(d.scratch + lay.records);
+    const uint32_t total_records = (uint32_t)reinterpret_cast<const int32_t *>(d.scratch)[1];
+    // the block's records end where the next block's begin (the write pass registers the block behind the last
+    // needed one as well); the last block of the image ends with the stream
+    uint32_t end = ordinal + 1 < decoded_blocks && ordinal + 1 < d.total_blocks ? index[ordinal + 1].first_record : total_records;
+    end = min(end, total_records);
+    const uint32_t count = bi.first_record < end ? min(end - bi.first_record, 72u) : 0u;  // <= 1 DC + 63 AC + 3 ZRL + EOB
+    for (uint32_t i = part; i < count; i += 8) {
+      const uint32_t w = rec[bi.first_record + i];
+      if (i > 0 && (w & kRecDc)) break;  // defensive: never run into the next block
+      if (w & kRecValid) {
+        int v = (int)(int16_t)(w & 0xFFFF);
+        if (i == 0) v += reinterpret_cast<const LaneRec *>(d.scratch + lay.lanes)[bi.lane].base[T->blk_comp[k]];
+        stage[lb][(w >> 16) & 63] = (int16_t)v;
+      }
+    }
+  }
+  __syncthreads();
+  if (needed) {
+    uint4 *dst = reinterpret_cast<uint4 *>((int16_t *)(T->blk_base[k] + ((size_t)my * (size_t)T->blk_sy[k] + (size_t)(mx * T->blk_sx[k]))));
+    dst[part] = blk_v[part];
   }
 }
 
@@ -847,16 +898,18 @@ __global__ __launch_bounds__(kSegThreads) void DcFixKernel(const daliamdJpegHuff
 
 extern "C" {
 
-daliamdResult_t daliamdJpegHuffmanScratchBytes(int ecs_len, size_t *bytes) {
-  DALIAMD_REQUIRE(ecs_len >= 0 && bytes, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdJpegHuffmanScratchBytes: invalid argument");
-  *bytes = daliamd::MakeLayout(ecs_len, daliamd::NumTiles(15, ecs_len), daliamd::NumSegments(ecs_len)).total;
+daliamdResult_t daliamdJpegHuffmanScratchBytes(int ecs_len, int total_blocks, size_t *bytes) {
+  DALIAMD_REQUIRE(ecs_len >= 0 && total_blocks >= 0 && bytes, DALIAMD_ERROR_INVALID_ARGUMENT,
+                  "daliamdJpegHuffmanScratchBytes: invalid argument");
+  *bytes = daliamd::MakeLayout(ecs_len, daliamd::NumTiles(15, ecs_len), daliamd::NumSegments(ecs_len), total_blocks).total;
   return DALIAMD_SUCCESS;
 }
 
-daliamdResult_t daliamdJpegHuffmanSetup(daliamdJpegHuffDesc *descs_host, int n, int *num_tiles, int *num_segments) {
-  DALIAMD_REQUIRE(n >= 0 && (n == 0 || descs_host) && num_tiles && num_segments, DALIAMD_ERROR_INVALID_ARGUMENT,
-                  "daliamdJpegHuffmanSetup: invalid argument");
-  int tiles = 0, segs = 0;
+daliamdResult_t daliamdJpegHuffmanSetup(daliamdJpegHuffDesc *descs_host, int n, int *num_tiles, int *num_segments,
+                                        int *num_block_workgroups) {
+  DALIAMD_REQUIRE(n >= 0 && (n == 0 || descs_host) && num_tiles && num_segments && num_block_workgroups,
+                  DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdJpegHuffmanSetup: invalid argument");
+  int tiles = 0, segs = 0, bwgs = 0;
   for (int i = 0; i < n; i++) {
     daliamdJpegHuffDesc &d = descs_host[i];
     DALIAMD_REQUIRE(d.ecs && d.scratch && d.status && d.ecs_len >= 0, DALIAMD_ERROR_INVALID_ARGUMENT,
@@ -869,24 +922,32 @@ daliamdResult_t daliamdJpegHuffmanSetup(daliamdJpegHuffDesc *descs_host, int n, 
     for (int k = 0; k < d.blocks_per_mcu; k++) {
       DALIAMD_REQUIRE(d.comp_of_block[k] < 3 && d.coef[d.comp_of_block[k]], DALIAMD_ERROR_INVALID_ARGUMENT,
                       "daliamdJpegHuffmanSetup: sample %d: block %d refers to a missing component", i, k);
+      DALIAMD_REQUIRE((reinterpret_cast<uintptr_t>(d.coef[d.comp_of_block[k]]) & 15) == 0, DALIAMD_ERROR_INVALID_ARGUMENT,
+                      "daliamdJpegHuffmanSetup: sample %d: coefficient arrays must be 16-byte aligned", i);
     }
+    for (int t = 0; t < 4; t++)  // record capacity: every symbol consumes at least two bits
+      DALIAMD_REQUIRE(d.bits[t][0] == 0, DALIAMD_ERROR_UNSUPPORTED,
+                      "daliamdJpegHuffmanSetup: sample %d: Huffman table %d has a 1-bit code (decode it on the host)", i, t);
     d.tile_start = tiles;
     d.num_tiles = daliamd::NumTiles((int)(reinterpret_cast<uintptr_t>(d.ecs) & 15), d.ecs_len);
     d.seg_start = segs;
     d.num_segments = daliamd::NumSegments(d.ecs_len);
+    d.blk_wg_start = bwgs;
     tiles += d.num_tiles;
     segs += d.num_segments;
+    bwgs += (d.total_blocks + daliamd::kExpandBlocks - 1) / daliamd::kExpandBlocks;
   }
   *num_tiles = tiles;
   *num_segments = segs;
+  *num_block_workgroups = bwgs;
   return DALIAMD_SUCCESS;
 }
 
 static daliamdResult_t LaunchHuffman(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev, int n, int num_tiles,
-                                     int num_segments, daliamdEvent_t *events) {
+                                     int num_segments, int num_block_workgroups, daliamdEvent_t *events) {
   if (n == 0) return DALIAMD_SUCCESS;
-  DALIAMD_REQUIRE(descs_dev && n > 0 && num_tiles >= n && num_segments >= n, DALIAMD_ERROR_INVALID_ARGUMENT,
-                  "daliamdJpegHuffmanRun: invalid argument");
+  DALIAMD_REQUIRE(descs_dev && n > 0 && num_tiles >= n && num_segments >= n && num_block_workgroups >= n,
+                  DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdJpegHuffmanRun: invalid argument");
   using namespace daliamd;
   hipStream_t s = (hipStream_t)stream;
   const int seg_grid = XcdGrid(num_segments);
@@ -905,21 +966,25 @@ static daliamdResult_t LaunchHuffman(daliamdStream_t stream, const daliamdJpegHu
   DALIAMD_HIP_CHECK(mark());
   hipLaunchKernelGGL(WriteKernel, dim3(seg_grid), dim3(kSegThreads), 0, s, descs_dev, n, num_segments);
   DALIAMD_HIP_CHECK(mark());
-  hipLaunchKernelGGL(DcFixKernel, dim3(seg_grid), dim3(kSegThreads), 0, s, descs_dev, n, num_segments);
+  hipLaunchKernelGGL(DcScanKernel, dim3(seg_grid), dim3(kSegThreads), 0, s, descs_dev, n, num_segments);
+  DALIAMD_HIP_CHECK(mark());
+  hipLaunchKernelGGL(ExpandKernel, dim3(XcdGrid(num_block_workgroups)), dim3(kExpandThreads), 0, s, descs_dev, n,
+                     num_block_workgroups);
   DALIAMD_HIP_CHECK(mark());
   DALIAMD_HIP_CHECK(hipGetLastError());
   return DALIAMD_SUCCESS;
 }
 
 daliamdResult_t daliamdJpegHuffmanRun(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev, int n, int num_tiles,
-                                      int num_segments) {
-  return LaunchHuffman(stream, descs_dev, n, num_tiles, num_segments, nullptr);
+                                      int num_segments, int num_block_workgroups) {
+  return LaunchHuffman(stream, descs_dev, n, num_tiles, num_segments, num_block_workgroups, nullptr);
 }
 
 daliamdResult_t daliamdJpegHuffmanRunProfiled(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev, int n,
-                                              int num_tiles, int num_segments, daliamdEvent_t *events) {
+                                              int num_tiles, int num_segments, int num_block_workgroups,
+                                              daliamdEvent_t *events) {
   DALIAMD_REQUIRE(events, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdJpegHuffmanRunProfiled: events is NULL");
-  return LaunchHuffman(stream, descs_dev, n, num_tiles, num_segments, events);
+  return LaunchHuffman(stream, descs_dev, n, num_tiles, num_segments, num_block_workgroups, events);
 }
 
 }  // extern "C"

@@ -572,6 +572,8 @@ int daliamdJpegAnalyzeScan(const uint8_t *data, size_t size, const daliamdJpegIn
   int bpm = 0;
   for (int c = 0; c < d.ncomp; c++) {
     if (d.std_[c] > 1 || d.sta[c] > 1) return 0;  // the kernel keeps two DC + two AC tables (baseline limit)
+    // the kernel's record buffer is sized for symbols of at least two bits
+    if (d.dc[d.std_[c]].bits[1] != 0 || d.ac[d.sta[c]].bits[1] != 0) return 0;
     if (!d.dc[d.std_[c]].present || !d.ac[d.sta[c]].present || !d.qt_present[d.comp[c].tq]) return 0;
     for (int v = 0; v < d.comp[c].v; v++)
       for (int h = 0; h < d.comp[c].h; h++) {

@@ -184,7 +184,8 @@ class ImageDecoderMixed : public OperatorBase {
       if (scans_[i].eligible) {
         DALI_ENFORCE(scans_[i].ecs_length < (int64_t)1 << 30, "Failed to decode ", src(i), ": entropy-coded segment too long");
         size_t need = 0;
-        KCHECK(daliamdJpegHuffmanScratchBytes((int)scans_[i].ecs_length, &need));
+        KCHECK(daliamdJpegHuffmanScratchBytes((int)scans_[i].ecs_length,
+                                              scans_[i].mcus_x * scans_[i].mcus_y * scans_[i].blocks_per_mcu, &need));
         scratch_off_[i] = scratch_bytes;
         scratch_bytes += need;
         gpu_samples_.push_back(i);
@@ -233,7 +234,7 @@ class ImageDecoderMixed : public OperatorBase {
     daliamdJpegIdctDesc *idct = reinterpret_cast<daliamdJpegIdctDesc *>(stage_base + idct_off);
     daliamdJpegColorDesc *color = reinterpret_cast<daliamdJpegColorDesc *>(stage_base + color_off);
     memset(stage_base + huff_off, 0, upload_bytes - huff_off);
-    int ntiles = 0, nsegs = 0;
+    int ntiles = 0, nsegs = 0, nbwg = 0;
     if (ngpu) {
       // status words: pinned host memory the kernels write directly (no copy back); cleared here by the CPU
       int32_t *status = static_cast<int32_t *>(status_host.data());
@@ -269,7 +270,7 @@ class ImageDecoderMixed : public OperatorBase {
           memcpy(d.vals[2 + t], sc.ac_vals[t], 256);
         }
       }
-      KCHECK(daliamdJpegHuffmanSetup(huff, ngpu, &ntiles, &nsegs));
+      KCHECK(daliamdJpegHuffmanSetup(huff, ngpu, &ntiles, &nsegs, &nbwg));
       // the status words are valid once the iteration has finished: checked when its outputs are handed over
       std::vector<std::string> names(ngpu);
       for (int j = 0; j < ngpu; j++) names[j] = src(gpu_samples_[j]);
@@ -327,9 +328,8 @@ class ImageDecoderMixed : public OperatorBase {
       KCHECK(daliamdStreamWaitEvent(ws.stream, h2d_done_[slot]));
     }
     if (ngpu) {
-      KCHECK(daliamdMemsetAsync(cdev.data(), 0, (size_t)elems * 2, ws.stream));
       KCHECK(daliamdJpegHuffmanRun(ws.stream, reinterpret_cast<const daliamdJpegHuffDesc *>(dev_base + huff_off), ngpu,
-                                   ntiles, nsegs));
+                                   ntiles, nsegs, nbwg));
       NoteLaunch(ws, "jpeg_huffman");
     }
     // host-decoded streams (progressive, restart markers, multi-scan, below the threshold): H2D of their coefficients

@@ -113,9 +113,10 @@ DALIAMD_API daliamdResult_t daliamdJpegIdctRun(daliamdStream_t stream, const dal
  * The caller fills the descriptor from the scan analysis (daliamdJpegAnalyzeScan) and
  *   - uploads the entropy-coded segment (without the trailing marker) to `ecs`; the bytes up to the next
  *     16-byte boundary behind it must be readable,
- *   - zero-fills the coefficient arrays and `status` (daliamdMemsetAsync) before the launch,
- *   - provides `scratch`: daliamdJpegHuffmanScratchBytes(ecs_len) bytes, 16-byte aligned (clean stream,
- *     code tables, per-slice decoder states),
+ *   - zero-fills `status` before the launch (the coefficient arrays need no initialisation: every block that is
+ *     decoded is written exactly once, as a full 128-byte line),
+ *   - provides `scratch`: daliamdJpegHuffmanScratchBytes(ecs_len, total_blocks) bytes, 16-byte aligned (clean
+ *     stream, code tables, per-slice decoder states, the record stream of the write pass, the block index),
  *   - calls daliamdJpegHuffmanSetup on the host table, copies it to the device, calls daliamdJpegHuffmanRun.
  * The work is cut into image-independent pieces (16 KB tiles for the byte un-stuffing, 61 KB segments of 256-byte
  * slices for the self-synchronising parallel decode), so a batch of very differently sized streams still fills
@@ -127,7 +128,7 @@ typedef struct {
   const uint8_t *ecs;      /* device: entropy-coded segment (still byte-stuffed)                  */
   uint8_t *scratch;        /* device scratch, see above                                            */
   int32_t *status;         /* device: one int, pre-zeroed                                          */
-  int16_t *coef[3];        /* device: per component [blocks_y][blocks_x][64], pre-zeroed           */
+  int16_t *coef[3];        /* device: per component [blocks_y][blocks_x][64], 16-byte aligned      */
   int32_t ecs_len;
   int32_t blocks_per_mcu;  /* sum of h*v over the components                                       */
   int32_t mcus_x;          /* MCUs per row                                                         */
@@ -136,6 +137,7 @@ typedef struct {
   int32_t h_samp[3], v_samp[3];
   int32_t tile_start, num_tiles;   /* filled by Setup: un-stuffing workgroups of this stream       */
   int32_t seg_start, num_segments; /* filled by Setup: decoding workgroups of this stream          */
+  int32_t blk_wg_start, reserved;  /* filled by Setup: block-expansion workgroups of this stream   */
   uint8_t comp_of_block[12];  /* component of the k-th block of an MCU                             */
   uint8_t h_of_block[12], v_of_block[12]; /* its position inside the component's MCU footprint     */
   uint8_t dc_sel[4], ac_sel[4];  /* per component: table selector, 0 or 1                           */
@@ -147,19 +149,21 @@ typedef struct {
   int32_t rect[3][4];
 } daliamdJpegHuffDesc;
 
-DALIAMD_API daliamdResult_t daliamdJpegHuffmanScratchBytes(int ecs_len, size_t *bytes);
-/* Validates the table, fills tile_start/num_tiles/seg_start/num_segments, returns the two grid sizes. */
+DALIAMD_API daliamdResult_t daliamdJpegHuffmanScratchBytes(int ecs_len, int total_blocks, size_t *bytes);
+/* Validates the table (DALIAMD_ERROR_UNSUPPORTED for a Huffman table with a 1-bit code: use the host decoder), fills
+ * tile_start/num_tiles/seg_start/num_segments/blk_wg_start, returns the three grid sizes. */
 DALIAMD_API daliamdResult_t daliamdJpegHuffmanSetup(daliamdJpegHuffDesc *descs_host, int n, int *num_tiles,
-                                                    int *num_segments);
-/* Seven launches: un-stuff (count, scatter), tables, synchronise, propagate, write, DC prefix. */
+                                                    int *num_segments, int *num_block_workgroups);
+/* Eight launches: un-stuff (count, scatter), tables, synchronise, propagate, write (records), DC scan, expand. */
 DALIAMD_API daliamdResult_t daliamdJpegHuffmanRun(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev, int n,
-                                                  int num_tiles, int num_segments);
-/* Same launches with events[0..7] (created with timing enabled) recorded before each kernel and after the last:
+                                                  int num_tiles, int num_segments, int num_block_workgroups);
+/* Same launches with events[0..8] (created with timing enabled) recorded before each kernel and after the last:
  * events[i] .. events[i+1] brackets kernel i of {un-stuff count, un-stuff scatter, tables, synchronise, propagate,
- * write, DC prefix}.  For benchmarks. */
-#define DALIAMD_JPEG_HUFFMAN_KERNELS 7
+ * write, DC scan, expand}.  For benchmarks. */
+#define DALIAMD_JPEG_HUFFMAN_KERNELS 8
 DALIAMD_API daliamdResult_t daliamdJpegHuffmanRunProfiled(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev,
-                                                          int n, int num_tiles, int num_segments, daliamdEvent_t *events);
+                                                          int n, int num_tiles, int num_segments,
+                                                          int num_block_workgroups, daliamdEvent_t *events);
 
 typedef enum {
   DALIAMD_JPEG_GRAY = 0,   /* 1 component                                   */
