@@ -80,7 +80,7 @@ struct SegRec {  // one per segment
 // fill up in L2) and notes where every block starts; ExpandKernel then builds each 8x8 block in LDS and stores it
 // as one full 128-byte line, adding the DC level on the way.
 //   record: bits 0-15 value (AC coefficient, or the lane-local running sum of the DC differences),
-//           bits 16-21 position inside the block (column-major), bit 22 = first record of a block (DC),
+//           bits 16-21 zig-zag index of the coefficient, bit 22 = first record of a block (DC),
 //           bit 23 = carries a coefficient (clear for ZRL / end-of-block symbols)
 constexpr uint32_t kRecDc = 1u << 22, kRecValid = 1u << 23;
 struct BlockIndex {
@@ -478,6 +478,12 @@ __device__ __forceinline__ int DecodeRange(const HuffTables &L, GlobalWords *__r
   return nblk;
 }
 
+// 16 bytes at a 4-byte aligned address in one instruction (gfx9 global accesses need dword alignment only).  Scattered
+// accesses cost the texture-address unit one cycle or more PER LANE, so a lane moving its 32 bytes with two of
+// these instead of eight dword accesses is the difference between a TA-bound and a VALU-bound write pass.
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+using GlobalQuadA4 = u32x4_a4 __attribute__((address_space(1)));
+
 constexpr int kGroupSteps = 8;   // symbols between two wave-uniform "points" of the write pass
 constexpr int kRingWords = 32;   // dwords of the clean stream buffered in LDS per lane (ring)
 
@@ -505,10 +511,20 @@ __device__ __forceinline__ void WriteRange(const HuffTables &L, GlobalWords *__r
   uint32_t hi = 0, lo = 0, nxt = 0;
   const uint16_t *fast = &L.fast[0][0];
   const uint32_t dc_mask = L.dc_mask, ac_mask = L.ac_mask, bpm = (uint32_t)L.bpm;
+  // component of the k-th block of the MCU, two bits each (no LDS look-up on the DC path)
+  uint32_t comp_bits = 0;
+  for (uint32_t kk = 0; kk < bpm; kk++) comp_bits |= (uint32_t)L.blk_comp[kk] << (2 * kk);
   int ordinal = ord;  // block the next symbol belongs to
   if (live) {         // prologue: 24 dwords straight into the ring (the only exposed memory latency of the pass)
+    const GlobalQuadA4 *src = (const GlobalQuadA4 *)(words + k);
 #pragma unroll
-    for (int q = 0; q < 24; q++) ring[(k + q) & (kRingWords - 1)] = words[k + q];
+    for (int q = 0; q < 6; q++) {
+      const u32x4_a4 v = src[q];
+      ring[(k + 4 * q) & (kRingWords - 1)] = v.x;
+      ring[(k + 4 * q + 1) & (kRingWords - 1)] = v.y;
+      ring[(k + 4 * q + 2) & (kRingWords - 1)] = v.z;
+      ring[(k + 4 * q + 3) & (kRingWords - 1)] = v.w;
+    }
     kl = k + 24;
     hi = __builtin_bswap32(ring[k & (kRingWords - 1)]);
     lo = __builtin_bswap32(ring[(k + 1) & (kRingWords - 1)]);
@@ -529,23 +545,31 @@ __device__ __forceinline__ void WriteRange(const HuffTables &L, GlobalWords *__r
       have_pre = false;
     }
     if (nrec > 0) {
+      if (nrec == kGroupSteps) {  // the common case: the lane's 8 records as two 16-byte stores
+        GlobalQuadA4 *dst = (GlobalQuadA4 *)(rec + rec_index);
+        dst[0] = u32x4_a4{r[0], r[1], r[2], r[3]};
+        dst[1] = u32x4_a4{r[4], r[5], r[6], r[7]};
+      } else {
+#pragma unroll
+        for (int q = 0; q < kGroupSteps; q++)
+          if (q < nrec) rec[rec_index + q] = r[q];
+      }
       int dc_ord = group_ord + (group_mid_block ? 1 : 0);  // ordinal of the first DC record of the group
 #pragma unroll
       for (int q = 0; q < kGroupSteps; q++) {
-        if (q < nrec) {
-          rec[rec_index + q] = r[q];
-          if (r[q] & kRecDc) {
-            if (dc_ord < L.total_blocks) blocks[dc_ord] = BlockIndex{rec_index + q, lane_id};
-            dc_ord++;
-          }
+        if (q < nrec && (r[q] & kRecDc)) {
+          if (dc_ord < L.total_blocks) blocks[dc_ord] = BlockIndex{rec_index + q, lane_id};
+          dc_ord++;
         }
       }
       rec_index += (uint32_t)nrec;
       nrec = 0;
     }
     if (live && kl - k <= 24) {  // room in the ring: request the next 8 dwords (delivered at the next point)
-#pragma unroll
-      for (int q = 0; q < 8; q++) pre[q] = words[kl + q];
+      const GlobalQuadA4 *src = (const GlobalQuadA4 *)(words + kl);
+      const u32x4_a4 a = src[0], b = src[1];
+      pre[0] = a.x; pre[1] = a.y; pre[2] = a.z; pre[3] = a.w;
+      pre[4] = b.x; pre[5] = b.y; pre[6] = b.z; pre[7] = b.w;
       have_pre = true;
     }
     group_ord = ordinal;
@@ -567,14 +591,14 @@ __device__ __forceinline__ void WriteRange(const HuffTables &L, GlobalWords *__r
         uint32_t zt = z + adv - 1;  // zig-zag index of the coefficient this symbol carries (AC)
         uint32_t flags = (s && zt < 64) ? kRecValid : 0;
         if (is_dc) {
-          const int comp = L.blk_comp[c];
+          const uint32_t comp = (comp_bits >> (2 * c)) & 3u;
           if (comp == 0) val = (dc.sum0 += val);
           else if (comp == 1) val = (dc.sum1 += val);
           else val = (dc.sum2 += val);
           zt = 0;
           flags = kRecDc | kRecValid;
         }
-        r[j] = ((uint32_t)val & 0xFFFFu) | ((uint32_t)L.zz[zt & 63] << 16) | flags;
+        r[j] = ((uint32_t)val & 0xFFFFu) | ((zt & 63u) << 16) | flags;
         nrec = j + 1;
         rem -= (int)used;
         off += used;
@@ -831,12 +855,22 @@ __global__ __launch_bounds__(kSegThreads) void DcScanKernel(const daliamdJpegHuf
 }
 
 // Builds every needed 8x8 block from its records and stores it as one full 128-byte line: 8 lanes per block
-// (coalesced record loads, 16 bytes of the line each), 32 blocks per workgroup.
+// (coalesced record loads, 16 bytes of the line each), 32 blocks at a time, 256 blocks per workgroup (the per-image
+// constants are fetched once per workgroup).
 constexpr int kExpandThreads = 256;
-constexpr int kExpandBlocks = kExpandThreads / 8;
+constexpr int kExpandBlocks = kExpandThreads / 8;  // blocks in flight
+constexpr int kExpandPerWg = 256;                  // blocks per workgroup
+struct ExpandGeom {
+  int32_t bpm, mcus_x, last_ordinal, use_rect, decoded_blocks, total_blocks;
+  uint32_t total_records;
+  uint8_t comp[16], hs[16], vs[16], ho[16], vo[16], zz[64];
+  int32_t sx[12], sy[12], rect[12][4];
+  GlobalCoef *base[12];
+};
 __global__ __launch_bounds__(kExpandThreads) void ExpandKernel(const daliamdJpegHuffDesc *__restrict__ descs, int n,
                                                                int nwg) {
   __shared__ __attribute__((aligned(16))) int16_t stage[kExpandBlocks][72];  // 64 + padding
+  __shared__ ExpandGeom G;
   const int wg = XcdRemap(blockIdx.x, nwg);
   if (wg < 0) return;
   // workgroup -> image (descriptors sorted by blk_wg_start)
@@ -848,49 +882,68 @@ __global__ __launch_bounds__(kExpandThreads) void ExpandKernel(const daliamdJpeg
   const daliamdJpegHuffDesc &d = descs[lo];
   const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments, d.total_blocks);
   const HuffTables *T = reinterpret_cast<const HuffTables *>(d.scratch + lay.tables);
-  const int lb = threadIdx.x >> 3, part = threadIdx.x & 7;
-  const int ordinal = (wg - d.blk_wg_start) * kExpandBlocks + lb;
-  const int decoded_blocks = reinterpret_cast<const int32_t *>(d.scratch)[2];  // < total_blocks: corrupt stream (status 2)
-  bool needed = ordinal < T->last_ordinal && ordinal < decoded_blocks;
-  int k = 0, mx = 0, my = 0;
-  if (needed) {
-    const int bpm = T->bpm, mcus_x = T->mcus_x;
-    const int mcu = ordinal / bpm;
-    k = ordinal - mcu * bpm;
-    my = mcu / mcus_x;
-    mx = mcu - my * mcus_x;
-    if (T->use_rect) {
-      const int bx = mx * T->blk_hs[k] + T->blk_ho[k], by = my * T->blk_vs[k] + T->blk_vo[k];
-      needed = bx >= T->blk_rect[k][0] && by >= T->blk_rect[k][1] && bx < T->blk_rect[k][2] && by < T->blk_rect[k][3];
-    }
+  const int tid = threadIdx.x;
+  if (tid < 12) {
+    G.comp[tid] = T->blk_comp[tid]; G.hs[tid] = T->blk_hs[tid]; G.vs[tid] = T->blk_vs[tid];
+    G.ho[tid] = T->blk_ho[tid]; G.vo[tid] = T->blk_vo[tid];
+    G.sx[tid] = T->blk_sx[tid]; G.sy[tid] = T->blk_sy[tid];
+    G.base[tid] = T->blk_base[tid];
+    for (int j = 0; j < 4; j++) G.rect[tid][j] = T->blk_rect[tid][j];
   }
-  uint4 *blk_v = reinterpret_cast<uint4 *>(&stage[lb][0]);
-  blk_v[part] = make_uint4(0, 0, 0, 0);
+  if (tid >= 64 && tid < 128) G.zz[tid - 64] = T->zz[tid - 64];
+  if (tid == 128) {
+    G.bpm = T->bpm; G.mcus_x = T->mcus_x; G.last_ordinal = T->last_ordinal; G.use_rect = T->use_rect;
+    G.decoded_blocks = reinterpret_cast<const int32_t *>(d.scratch)[2];  // < total_blocks: corrupt stream (status 2)
+    G.total_blocks = d.total_blocks;
+    G.total_records = (uint32_t)reinterpret_cast<const int32_t *>(d.scratch)[1];
+  }
   __syncthreads();
-  if (needed) {
-    const BlockIndex *index = reinterpret_cast<const BlockIndex *>(d.scratch + lay.blocks);
-    const BlockIndex bi = index[ordinal];
-    const GlobalWords *rec = (const GlobalWords *)(d.scratch + lay.records);
-    const uint32_t total_records = (uint32_t)reinterpret_cast<const int32_t *>(d.scratch)[1];
-    // the block's records end where the next block's begin (the write pass registers the block behind the last
-    // needed one as well); the last block of the image ends with the stream
-    uint32_t end = ordinal + 1 < decoded_blocks && ordinal + 1 < d.total_blocks ? index[ordinal + 1].first_record : total_records;
-    end = min(end, total_records);
-    const uint32_t count = bi.first_record < end ? min(end - bi.first_record, 72u) : 0u;  // <= 1 DC + 63 AC + 3 ZRL + EOB
-    for (uint32_t i = part; i < count; i += 8) {
-      const uint32_t w = rec[bi.first_record + i];
-      if (i > 0 && (w & kRecDc)) break;  // defensive: never run into the next block
-      if (w & kRecValid) {
-        int v = (int)(int16_t)(w & 0xFFFF);
-        if (i == 0) v += reinterpret_cast<const LaneRec *>(d.scratch + lay.lanes)[bi.lane].base[T->blk_comp[k]];
-        stage[lb][(w >> 16) & 63] = (int16_t)v;
+  const BlockIndex *index = reinterpret_cast<const BlockIndex *>(d.scratch + lay.blocks);
+  const GlobalWords *rec = (const GlobalWords *)(d.scratch + lay.records);
+  const LaneRec *lanes = reinterpret_cast<const LaneRec *>(d.scratch + lay.lanes);
+  const int lb = tid >> 3, part = tid & 7;
+  uint4 *blk_v = reinterpret_cast<uint4 *>(&stage[lb][0]);
+  const int first_ordinal = (wg - d.blk_wg_start) * kExpandPerWg;
+  for (int it = 0; it < kExpandPerWg / kExpandBlocks; it++) {
+    const int ordinal = first_ordinal + it * kExpandBlocks + lb;
+    if (first_ordinal + it * kExpandBlocks >= G.last_ordinal) break;  // uniform
+    bool needed = ordinal < G.last_ordinal && ordinal < G.decoded_blocks;
+    int k = 0, mx = 0, my = 0;
+    if (needed) {
+      const int mcu = ordinal / G.bpm;
+      k = ordinal - mcu * G.bpm;
+      my = mcu / G.mcus_x;
+      mx = mcu - my * G.mcus_x;
+      if (G.use_rect) {
+        const int bx = mx * G.hs[k] + G.ho[k], by = my * G.vs[k] + G.vo[k];
+        needed = bx >= G.rect[k][0] && by >= G.rect[k][1] && bx < G.rect[k][2] && by < G.rect[k][3];
       }
     }
-  }
-  __syncthreads();
-  if (needed) {
-    uint4 *dst = reinterpret_cast<uint4 *>((int16_t *)(T->blk_base[k] + ((size_t)my * (size_t)T->blk_sy[k] + (size_t)(mx * T->blk_sx[k]))));
-    dst[part] = blk_v[part];
+    blk_v[part] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    if (needed) {
+      const BlockIndex bi = index[ordinal];
+      // the block's records end where the next block's begin (the write pass registers the block behind the last
+      // needed one as well); the last block of the image ends with the stream
+      uint32_t end = ordinal + 1 < G.decoded_blocks && ordinal + 1 < G.total_blocks ? index[ordinal + 1].first_record
+                                                                                  : G.total_records;
+      end = min(end, G.total_records);
+      const uint32_t count = bi.first_record < end ? min(end - bi.first_record, 72u) : 0u;  // 1 DC + 63 AC + 3 ZRL + EOB
+      for (uint32_t i = part; i < count; i += 8) {
+        const uint32_t w = rec[bi.first_record + i];
+        if (i > 0 && (w & kRecDc)) break;  // defensive: never run into the next block
+        if (w & kRecValid) {
+          int v = (int)(int16_t)(w & 0xFFFF);
+          if (i == 0) v += lanes[bi.lane].base[G.comp[k]];  // DC: lane-local sum + level at the start of that lane
+          stage[lb][G.zz[(w >> 16) & 63]] = (int16_t)v;
+        }
+      }
+    }
+    __syncthreads();
+    if (needed) {
+      uint4 *dst = reinterpret_cast<uint4 *>((int16_t *)(G.base[k] + ((size_t)my * (size_t)G.sy[k] + (size_t)(mx * G.sx[k]))));
+      dst[part] = blk_v[part];
+    }
   }
 }
 
@@ -935,7 +988,7 @@ daliamdResult_t daliamdJpegHuffmanSetup(daliamdJpegHuffDesc *descs_host, int n, 
     d.blk_wg_start = bwgs;
     tiles += d.num_tiles;
     segs += d.num_segments;
-    bwgs += (d.total_blocks + daliamd::kExpandBlocks - 1) / daliamd::kExpandBlocks;
+    bwgs += (d.total_blocks + daliamd::kExpandPerWg - 1) / daliamd::kExpandPerWg;
   }
   *num_tiles = tiles;
   *num_segments = segs;
