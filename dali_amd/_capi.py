@@ -52,6 +52,15 @@ class JpegColorDesc(C.Structure):
                 ("out_y0", C.c_int32)]
 
 
+class NormalizeDesc(C.Structure):
+    _fields_ = [("in_", C.c_void_p), ("out", C.c_void_p), ("outer", C.c_int64), ("reduced", C.c_int64),
+                ("inner", C.c_int64), ("sum_mean", C.c_void_p), ("sum_var", C.c_void_p), ("mean", C.c_void_p),
+                ("inv_std", C.c_void_p), ("stat_count", C.c_double), ("scalar_mean", C.c_float),
+                ("scalar_inv_std", C.c_float), ("use_scalar_mean", C.c_int32), ("use_scalar_inv_std", C.c_int32),
+                ("in_dtype", C.c_int32), ("out_dtype", C.c_int32), ("owns_stats", C.c_int32),
+                ("stat_wg_start", C.c_int32), ("stat_chunks", C.c_int32), ("apply_wg_start", C.c_int32)]
+
+
 class JpegRoiPlan(C.Structure):
     _fields_ = [("roi_x0", C.c_int32), ("roi_y0", C.c_int32), ("roi_w", C.c_int32), ("roi_h", C.c_int32),
                 ("out_x0", C.c_int32), ("out_y0", C.c_int32), ("rect", (C.c_int32 * 4) * 3)]
@@ -155,7 +164,7 @@ _KERNEL_SYMBOLS = [
     "daliamdStreamSynchronize", "daliamdStreamWaitEvent", "daliamdEventCreate",
     "daliamdEventDestroy", "daliamdEventRecord", "daliamdEventSynchronize", "daliamdEventElapsedMs",
     "daliamdMalloc", "daliamdFree", "daliamdHostAlloc", "daliamdHostFree", "daliamdMemcpyH2DAsync",
-    "daliamdMemcpyD2HAsync", "daliamdMemcpyD2DAsync", "daliamdMemsetAsync",
+    "daliamdMemcpyD2HAsync", "daliamdMemcpyD2DAsync", "daliamdMemsetAsync", "daliamdMemcpy2DD2DAsync",
     "daliamdJpegIdctSetup", "daliamdJpegIdctRun", "daliamdJpegHuffmanScratchBytes", "daliamdJpegHuffmanSetup",
     "daliamdJpegHuffmanRun", "daliamdJpegHuffmanRunProfiled", "daliamdJpegColorSetup", "daliamdJpegPlanRoi", "daliamdJpegColorRun",
     "daliamdResampleSetup", "daliamdResampleRun", "daliamdCmnSetup", "daliamdCmnRun",
@@ -163,6 +172,7 @@ _KERNEL_SYMBOLS = [
     "daliamdGaussianBlurRun", "daliamdColorTwistMatrix", "daliamdPointwiseSetup", "daliamdPointwiseRun",
     "daliamdHannWindow", "daliamdSpectrogramSetup", "daliamdSpectrogramRun", "daliamdMelFilterBankWeights",
     "daliamdMelFilterBankSetup", "daliamdMelFilterBankRun", "daliamdToDecibelsRun",
+    "daliamdNormalizeSetup", "daliamdNormalizeRun",
 ]
 
 _HOST_SYMBOLS = [

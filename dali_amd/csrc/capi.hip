@@ -121,5 +121,11 @@ daliamdResult_t daliamdMemsetAsync(void *dst, int value, size_t bytes, daliamdSt
   DALIAMD_HIP_CHECK(hipMemsetAsync(dst, value, bytes, (hipStream_t)s));
   return DALIAMD_SUCCESS;
 }
+daliamdResult_t daliamdMemcpy2DD2DAsync(void *dst, size_t dst_pitch, const void *src, size_t src_pitch, size_t width_bytes,
+                                        size_t height, daliamdStream_t s) {
+  DALIAMD_HIP_CHECK(hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, width_bytes, height, hipMemcpyDeviceToDevice,
+                                     (hipStream_t)s));
+  return DALIAMD_SUCCESS;
+}
 
 }  // extern "C"

@@ -71,6 +71,9 @@ DALIAMD_API daliamdResult_t daliamdMemcpyH2DAsync(void *dst, const void *src, si
 DALIAMD_API daliamdResult_t daliamdMemcpyD2HAsync(void *dst, const void *src, size_t bytes, daliamdStream_t s);
 DALIAMD_API daliamdResult_t daliamdMemcpyD2DAsync(void *dst, const void *src, size_t bytes, daliamdStream_t s);
 DALIAMD_API daliamdResult_t daliamdMemsetAsync(void *dst, int value, size_t bytes, daliamdStream_t s);
+/* rows of `width_bytes` between two pitched device buffers (e.g. a row-padded image -> dense) */
+DALIAMD_API daliamdResult_t daliamdMemcpy2DD2DAsync(void *dst, size_t dst_pitch, const void *src, size_t src_pitch,
+                                                    size_t width_bytes, size_t height, daliamdStream_t s);
 
 /* Element types of kernel outputs (subset of DALIDataType, include/dali/core/dali_data_type.h) */
 typedef enum { DALIAMD_UINT8 = 0, DALIAMD_FLOAT16 = 1, DALIAMD_FLOAT = 2, DALIAMD_INT8 = 3 } daliamdDType_t;
@@ -406,6 +409,37 @@ typedef struct {
 /* reference <= 0: use the per-sample maximum (1 when that maximum is 0) */
 DALIAMD_API daliamdResult_t daliamdToDecibelsRun(daliamdStream_t stream, const daliamdDecibelDesc *descs_dev, int n,
                                                 float multiplier, float reference, float cutoff_db);
+
+/* ----------------------------------------------------------------------------------------------
+ * fn.normalize: out = (in - mean) * scale / stddev + shift with mean / stddev given or computed over a contiguous group
+ * of axes (dali/operators/math/normalize/normalize.cc:24-123, normalize_utils.h:133-220,
+ * dali/kernels/normalize/normalize_cpu.h:38-70, dali/kernels/reduce/mean_stddev_gpu_impl.cuh).
+ * A sample is viewed as [outer][reduced][inner]; one statistic per (outer, inner) pair.  Sums are accumulated in
+ * fp64 (exact for uint8 input).  Batch normalisation: every descriptor points at the SAME sum/mean/inv_std arrays,
+ * stat_count is the total over the batch and only one descriptor has owns_stats = 1.
+ * -------------------------------------------------------------------------------------------- */
+typedef struct {
+  const void *in;               /* device, dense; uint8 or float                                        */
+  void *out;                    /* device, dense, same shape                                            */
+  int64_t outer, reduced, inner;
+  double *sum_mean, *sum_var;   /* device accumulators [outer*inner], zero-filled by the caller         */
+  float *mean, *inv_std;        /* device [outer*inner]: results of the reductions (unused with scalars) */
+  double stat_count;            /* elements each statistic is taken over                                */
+  float scalar_mean, scalar_inv_std; /* used when use_scalar_* is set: inv_std = scale / stddev          */
+  int32_t use_scalar_mean, use_scalar_inv_std;
+  int32_t in_dtype, out_dtype;  /* daliamdDType_t                                                       */
+  int32_t owns_stats;           /* 1: this descriptor finalises the accumulators it points at           */
+  int32_t stat_wg_start, stat_chunks, apply_wg_start; /* filled by Setup                                */
+} daliamdNormalizeDesc;
+
+DALIAMD_API daliamdResult_t daliamdNormalizeSetup(daliamdNormalizeDesc *descs_host, int n, int *stat_workgroups,
+                                                  int *apply_workgroups, int64_t *max_bins);
+/* calc_mean / calc_stddev: run the reductions (sum -> mean; sum of squared deviations -> scale / sqrt(var / (N - ddof)
+ * + epsilon), 0 where that is not finite, like the reference); then the element-wise pass. */
+DALIAMD_API daliamdResult_t daliamdNormalizeRun(daliamdStream_t stream, const daliamdNormalizeDesc *descs_dev, int n,
+                                                int stat_workgroups, int apply_workgroups, int64_t max_bins,
+                                                int calc_mean, int calc_stddev, int ddof, float epsilon, float scale,
+                                                float shift);
 
 #ifdef __cplusplus
 }
