@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kBlurThreads) void GaussianBlurKernel(const daliamd
   const int tw = min(TW, d.w - ox0), th = min(TH, d.h - oy0);
   const int in_rows = th + 2 * ry, in_cols = tw + 2 * rx;
   const int row_elems = tw * C;                        // tmp row length
-  const int src_pitch = (in_cols * C + 3) & ~3;        // staged source row pitch (bytes)
+  const int src_pitch = ((in_cols + 4) * C + 4 + 3) & ~3;  // staged source row pitch (bytes): + lead + blocking overrun
   float *wx = blur_lds;                                // [size_x]
   float *wy = wx + d.size_x;                           // [size_y]
   float *tmp = wy + d.size_y;                          // [in_rows][row_elems]
@@ -121,36 +121,79 @@ __global__ __launch_bounds__(kBlurThreads) void GaussianBlurKernel(const daliamd
   const int tid = threadIdx.x;
   for (int i = tid; i < d.size_x; i += kBlurThreads) wx[i] = d.window_x[i];
   for (int i = tid; i < d.size_y; i += kBlurThreads) wy[i] = d.window_y[i];
-  // ---- stage the halo-extended source tile; reflect-101 indices are resolved here ----
+  // ---- stage the halo-extended source tile; reflect-101 indices are resolved here.  Interior tiles (no reflection
+  // in x) copy whole aligned dwords: LDS byte i of a row <-> global byte (row start rounded down to 4) + i, the
+  // passes below skip the `lead` bytes in front.  Edge tiles take the byte-wise path. ----
+  const bool interior_x = ox0 - rx >= 0 && ox0 + tw + rx <= d.w;
   for (int r = tid / 64; r < in_rows; r += kBlurThreads / 64) {
     const uint8_t *row = d.in + (size_t)Reflect101(oy0 - ry + r, d.h) * d.in_pitch;
     uint8_t *dst = src + r * src_pitch;
-    for (int cx = tid % 64; cx < in_cols; cx += 64) {
-      const uint8_t *p = row + (size_t)Reflect101(ox0 - rx + cx, d.w) * C;
-      for (int c = 0; c < C; c++) dst[cx * C + c] = p[c];
+    if (interior_x) {
+      const uint8_t *g = row + (size_t)(ox0 - rx) * C;
+      const int lead = (int)(reinterpret_cast<uintptr_t>(g) & 3);
+      const uint32_t *gw = reinterpret_cast<const uint32_t *>(g - lead);
+      uint32_t *dw = reinterpret_cast<uint32_t *>(dst);
+      const int ndw = (lead + in_cols * C + 3) >> 2;
+      for (int j = tid % 64; j < ndw; j += 64) dw[j] = gw[j];
+    } else {
+      for (int cx = tid % 64; cx < in_cols; cx += 64) {
+        const uint8_t *p = row + (size_t)Reflect101(ox0 - rx + cx, d.w) * C;
+        for (int c = 0; c < C; c++) dst[cx * C + c] = p[c];
+      }
     }
   }
   __syncthreads();
-  // ---- W pass: tmp[r][x*C+c] = sum_k src[r][(x+k)*C+c] * wx[k], taps in order ----
+  // ---- W pass: tmp[r][x*C+c] = sum_k src[r][(x+k)*C+c] * wx[k], taps in order.  Each thread produces 4 consecutive
+  // pixels of one channel: the 4 + size_x - 1 source bytes are read once and reused (register blocking) ----
+  const int groups = (tw + 3) >> 2;  // groups of 4 pixels per row
   for (int r = tid / 64; r < in_rows; r += kBlurThreads / 64) {
-    const uint8_t *srow = src + r * src_pitch;
+    const uint8_t *rowp = d.in + (size_t)Reflect101(oy0 - ry + r, d.h) * d.in_pitch + (size_t)(ox0 - rx) * C;
+    const int lead = interior_x ? (int)(reinterpret_cast<uintptr_t>(rowp) & 3) : 0;
+    const uint8_t *srow = src + r * src_pitch + lead;
     float *trow = tmp + r * row_elems;
-    for (int e = tid % 64; e < row_elems; e += 64) {
-      float acc = 0;
-      const uint8_t *p = srow + e;
-      for (int k = 0; k < d.size_x; k++) acc += (float)p[k * C] * wx[k];
-      trow[e] = acc;
+    for (int item = tid % 64; item < groups * C; item += 64) {
+      const int g4 = item / C, c = item - g4 * C;
+      const int x = g4 * 4;
+      const uint8_t *p = srow + x * C + c;
+      float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+      float v0 = (float)p[0], v1 = (float)p[C], v2 = (float)p[2 * C], v3;
+#pragma unroll 4
+      for (int k = 0; k < d.size_x; k++) {
+        v3 = (float)p[(k + 3) * C];   // (x + 3 + k): in range for the last group too: the staged row is padded
+        const float w = wx[k];
+        a0 += v0 * w; a1 += v1 * w; a2 += v2 * w; a3 += v3 * w;
+        v0 = v1; v1 = v2; v2 = v3;
+      }
+      float *t = trow + x * C + c;
+      t[0] = a0;
+      if (x + 1 < tw) t[C] = a1;
+      if (x + 2 < tw) t[2 * C] = a2;
+      if (x + 3 < tw) t[3 * C] = a3;
     }
   }
   __syncthreads();
-  // ---- H pass ----
-  for (int y = tid / 64; y < th; y += kBlurThreads / 64) {
-    uint8_t *orow = d.out + (size_t)(oy0 + y) * d.out_pitch + (size_t)ox0 * C;
+  // ---- H pass: 4 consecutive rows per thread (register blocking over the taps), taps in order ----
+  const int rgroups = (th + 3) >> 2;
+  for (int yg = tid / 64; yg < rgroups; yg += kBlurThreads / 64) {
+    const int y = yg * 4;
     for (int e = tid % 64; e < row_elems; e += 64) {
-      float acc = 0;
       const float *p = tmp + y * row_elems + e;
-      for (int k = 0; k < d.size_y; k++) acc += wy[k] * p[k * row_elems];
-      orow[e] = (uint8_t)SatU8(acc);
+      float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+      // rows y+k .. y+k+3; rows beyond the staged area are only read for outputs that are not stored
+      const int last = in_rows - 1;
+      float v0 = p[0], v1 = p[min(1, last - y) * row_elems], v2 = p[min(2, last - y) * row_elems], v3;
+#pragma unroll 4
+      for (int k = 0; k < d.size_y; k++) {
+        v3 = p[min(k + 3, last - y) * row_elems];
+        const float w = wy[k];
+        a0 += w * v0; a1 += w * v1; a2 += w * v2; a3 += w * v3;
+        v0 = v1; v1 = v2; v2 = v3;
+      }
+      uint8_t *o = d.out + (size_t)(oy0 + y) * d.out_pitch + (size_t)ox0 * C + e;
+      o[0] = (uint8_t)SatU8(a0);
+      if (y + 1 < th) o[d.out_pitch] = (uint8_t)SatU8(a1);
+      if (y + 2 < th) o[2 * (size_t)d.out_pitch] = (uint8_t)SatU8(a2);
+      if (y + 3 < th) o[3 * (size_t)d.out_pitch] = (uint8_t)SatU8(a3);
     }
   }
 }
@@ -316,7 +359,7 @@ daliamdResult_t daliamdGaussianBlurSetup(daliamdGaussianBlurDesc *descs, int n, 
     int tw = 64, th = 16;
     auto need = [&](int tw_, int th_) {
       size_t rows = th_ + d.size_y - 1, cols = tw_ + d.size_x - 1;
-      size_t src_pitch = (cols * d.channels + 3) & ~(size_t)3;
+      size_t src_pitch = ((cols + 4) * d.channels + 4 + 3) & ~(size_t)3;  // + alignment lead + register-blocking overrun
       return (size_t)(d.size_x + d.size_y) * 4 + rows * tw_ * d.channels * 4 + rows * src_pitch + 16;
     };
     while (need(tw, th) > (size_t)kBlurMaxLds && (tw > 8 || th > 1)) {
