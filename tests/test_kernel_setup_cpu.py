@@ -1,0 +1,125 @@
+"""Host-side halves of the C ABI that need no GPU: descriptor validation / grid sizing (`*Setup`), scratch sizing and
+the region-of-interest planner.  They are pure host code inside libdali_amd_kernels.so."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from dali_amd import _capi as capi
+
+
+def _plan(w, h, ncomp, hs, vs, orientation, y0, x0, hh, ww):
+    lib = capi.kernels()
+    plan = capi.JpegRoiPlan()
+    rc = lib.daliamdJpegPlanRoi(w, h, ncomp, (C.c_int32 * 3)(*hs), (C.c_int32 * 3)(*vs), orientation, y0, x0, hh, ww,
+                                C.byref(plan))
+    return rc, plan
+
+
+def test_roi_plan_identity_and_block_rectangles():
+    # 4:2:0, 100 x 80 image, window rows 16..48, columns 32..64
+    rc, p = _plan(100, 80, 3, (2, 1, 1), (2, 1, 1), 1, 16, 32, 32, 32)
+    assert rc == 0
+    assert (p.roi_x0, p.roi_y0, p.roi_w, p.roi_h, p.out_x0, p.out_y0) == (32, 16, 32, 32, 32, 16)
+    # luma: exactly the co-sited samples -> blocks x 4..8, y 2..6
+    assert list(p.rect[0]) == [4, 2, 8, 6]
+    # chroma (half resolution, one neighbour on each side for the triangle filter): samples x 15..32, y 7..24
+    assert list(p.rect[1]) == [1, 0, 5, 4] and list(p.rect[2]) == [1, 0, 5, 4]
+
+
+def test_roi_plan_clamps_at_the_image_border_and_covers_whole_image():
+    rc, p = _plan(100, 80, 3, (2, 1, 1), (2, 1, 1), 1, 0, 0, 80, 100)
+    assert rc == 0
+    assert list(p.rect[0]) == [0, 0, 13, 10]           # ceil(100/8), ceil(80/8)
+    assert list(p.rect[1]) == [0, 0, 7, 5]              # chroma 50 x 40 samples
+
+
+@pytest.mark.parametrize("orientation", range(1, 9))
+def test_roi_plan_orientation_maps_the_window_back_to_the_source(orientation):
+    """Brute force: push every source pixel through the EXIF mapping used by the colour kernel and check that the
+    planned source window is exactly the pre-image of the upright window."""
+    W, H = 37, 23                                     # source (stored) size
+    UH, UW = (W, H) if orientation >= 5 else (H, W)
+    y0, x0, hh, ww = 3, 5, 9, 11
+    rc, p = _plan(W, H, 3, (1, 1, 1), (1, 1, 1), orientation, y0, x0, hh, ww)
+    assert rc == 0 and (p.out_y0, p.out_x0) == (y0, x0)
+    inside = np.zeros((H, W), bool)
+    for y in range(H):
+        for x in range(W):
+            oy, ox = {1: (y, x), 2: (y, W - 1 - x), 3: (H - 1 - y, W - 1 - x), 4: (H - 1 - y, x), 5: (x, y),
+                      6: (x, H - 1 - y), 7: (W - 1 - x, H - 1 - y), 8: (W - 1 - x, y)}[orientation]
+            assert 0 <= oy < UH and 0 <= ox < UW
+            inside[y, x] = y0 <= oy < y0 + hh and x0 <= ox < x0 + ww
+    ys, xs = np.nonzero(inside)
+    assert (p.roi_y0, p.roi_x0) == (ys.min(), xs.min())
+    assert (p.roi_h, p.roi_w) == (ys.max() - ys.min() + 1, xs.max() - xs.min() + 1)
+    assert inside[p.roi_y0:p.roi_y0 + p.roi_h, p.roi_x0:p.roi_x0 + p.roi_w].all()
+
+
+def test_roi_plan_rejects_windows_outside_the_image():
+    rc, _ = _plan(100, 80, 3, (2, 1, 1), (2, 1, 1), 1, 70, 0, 20, 10)
+    assert rc != 0
+    assert b"does not fit" in capi.kernels().daliamdGetLastErrorMessage()
+    rc, _ = _plan(100, 80, 3, (2, 1, 1), (2, 1, 1), 6, 0, 0, 90, 10)   # rotated: the upright image is 100 x 80 (H x W)
+    assert rc == 0
+
+
+def test_huffman_scratch_grows_with_the_stream_and_the_block_count():
+    lib = capi.kernels()
+    sizes = []
+    for ecs, blocks in [(0, 1), (1000, 6), (100_000, 4400), (100_000, 8800), (1_000_000, 4400)]:
+        n = C.c_size_t(0)
+        assert lib.daliamdJpegHuffmanScratchBytes(ecs, blocks, C.byref(n)) == 0
+        sizes.append(n.value)
+        assert n.value % 256 == 0 and n.value >= ecs + 64
+    assert sizes == sorted(sizes)
+    assert lib.daliamdJpegHuffmanScratchBytes(-1, 1, C.byref(C.c_size_t())) != 0
+
+
+def _huff_desc(ecs_len=5000, total_blocks=600, bits0=0):
+    d = capi.JpegHuffDesc()
+    d.ecs, d.scratch, d.status = 0x1000, 0x2000, 0x3000     # fake device addresses: Setup never dereferences them
+    for c in range(3):
+        d.coef[c] = 0x10000 * (c + 1)
+        d.blocks_x[c] = 10 if c else 20
+        d.h_samp[c] = d.v_samp[c] = 1 if c else 2
+    d.ecs_len, d.blocks_per_mcu, d.mcus_x, d.total_blocks = ecs_len, 6, 10, total_blocks
+    for k, comp in enumerate([0, 0, 0, 0, 1, 2]):
+        d.comp_of_block[k] = comp
+    for t in range(4):
+        d.bits[t][0] = bits0
+        d.bits[t][1] = 1
+    return d
+
+
+def test_huffman_setup_sizes_the_three_grids_and_validates():
+    lib = capi.kernels()
+    descs = (capi.JpegHuffDesc * 3)(_huff_desc(5000, 600), _huff_desc(100_000, 6000), _huff_desc(40_000, 2400))
+    tiles, segs, bwg = C.c_int(), C.c_int(), C.c_int()
+    assert lib.daliamdJpegHuffmanSetup(descs, 3, C.byref(tiles), C.byref(segs), C.byref(bwg)) == 0
+    assert [d.tile_start for d in descs] == [0, 1, 8] and tiles.value == 11          # 16 KB tiles
+    assert [d.seg_start for d in descs] == [0, 1, 5] and segs.value == 7             # 116 slices of 256 bytes
+    assert [d.blk_wg_start for d in descs] == [0, 3, 27] and bwg.value == 37         # 256 blocks per workgroup
+    bad = (capi.JpegHuffDesc * 1)(_huff_desc(total_blocks=601))                      # not a whole number of MCUs
+    assert lib.daliamdJpegHuffmanSetup(bad, 1, C.byref(tiles), C.byref(segs), C.byref(bwg)) != 0
+    one_bit = (capi.JpegHuffDesc * 1)(_huff_desc(bits0=1))                           # a 1-bit code: host decoder's job
+    assert lib.daliamdJpegHuffmanSetup(one_bit, 1, C.byref(tiles), C.byref(segs), C.byref(bwg)) == 2   # UNSUPPORTED
+    assert b"1-bit code" in lib.daliamdGetLastErrorMessage()
+
+
+def test_normalize_setup_views_and_grids():
+    lib = capi.kernels()
+    descs = (capi.NormalizeDesc * 3)()
+    for d, (o, r, i) in zip(descs, [(1, 480 * 640, 3), (513, 1000, 1), (1, 300, 513)]):
+        d.in_, d.out = 0x1000, 0x2000
+        d.outer, d.reduced, d.inner = o, r, i
+        d.in_dtype, d.out_dtype = capi.UINT8, capi.FLOAT
+    sw, aw, bins = C.c_int(), C.c_int(), C.c_int64()
+    assert lib.daliamdNormalizeSetup(descs, 3, C.byref(sw), C.byref(aw), C.byref(bins)) == 0
+    assert bins.value == 513                                        # the largest outer*inner of the batch
+    assert descs[0].stat_chunks == -(-480 * 640 * 3 // 65536)      # narrow inner: 64 K elements per workgroup
+    assert descs[1].stat_chunks == 1                               # one workgroup per row of 1000
+    assert descs[2].stat_chunks == -(-300 // 64) * 3               # wide inner: 64 rows x 256 columns per workgroup
+    assert sw.value == descs[0].stat_chunks + 513 + descs[2].stat_chunks
+    descs[0].in_dtype = capi.FLOAT16
+    assert lib.daliamdNormalizeSetup(descs, 3, C.byref(sw), C.byref(aw), C.byref(bins)) != 0
