@@ -62,6 +62,23 @@ def measured_traffic(kernel):
         return None, None
 
 
+def measured_copy_ceiling(device, mib=1024, iters=10):
+    """Device-to-device copy of `mib` MiB (hipMemcpyDtoD through torch): read + write bytes per second.  The honest
+    denominator next to the 8 TB/s vendor figure."""
+    import torch
+    src = torch.empty(mib << 20, dtype=torch.uint8, device=device)
+    dst = torch.empty_like(src)
+    for _ in range(2):
+        dst.copy_(src)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        dst.copy_(src)
+    b.record()
+    torch.cuda.synchronize()
+    return 2.0 * (mib << 20) * iters / (a.elapsed_time(b) * 1e-3) / 1e9
+
+
 def make_dataset(first_index, count):
     """Synthetic ImageNet-like JPEGs.  Image i depends only on its global index."""
     from tests.util import synth_jpeg_batch
@@ -421,8 +438,8 @@ def main():
         # per-kernel durations of the entropy decoder (events recorded between its launches, same stream)
         per = np.array([ke.elapsed_ms() for ke in hp.kernel_events]).mean(0)
         sb, ce = hp.plan.stream_bytes, hp.plan.coef_elems
-        # records: one 32-bit word per symbol; not known exactly on the host: ~1.3 symbols per stream byte here
-        rec = int(4 * 1.3 * sb)
+        symbols = hp.plan.huffman_symbol_count(hp.slots[0]["ws"])   # one 32-bit record per symbol
+        rec = 4 * symbols
         huff_bytes = {"UnstuffCountKernel": sb, "UnstuffScatterKernel": 2 * sb, "BuildTablesKernel": 27 * 1024 * B,
                       "SyncKernel": sb, "PropagateKernel": 0, "WriteKernel": sb + rec, "DcScanKernel": 0,
                       "ExpandKernel": rec + 2 * ce}
@@ -436,10 +453,14 @@ def main():
 
     if rank == 0:
         value = world * B * args.steps / elapsed
+        step_ms = 1e3 * elapsed / args.steps
+        step_bytes = float(sum(v[0] for v in kern.values()))
+        copy_ceiling = measured_copy_ceiling(device)
+        post_entropy = hp.bytes_idct + hp.bytes_color + float(np.mean(resample_bytes))
         line = {
             "metric": "images/sec JPEG->RRC->CMN 224^2 b256 per GPU",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/i32 decode, f32 resample, f16 out", "data": "synthetic",
             "config": {"workload": "configs[1]: HIP JPEG " + ("Huffman decode -> " if args.huffman == "gpu" else "") +
                                    "dequant+IDCT -> upsample+YCbCr->RGB -> fused "
@@ -455,8 +476,23 @@ def main():
                        "pixels_per_batch": hp.pixels},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "measured_copy_ceiling_GBps": copy_ceiling, "frac_of_measured_ceiling": ach / copy_ceiling,
+                         "note": "the dominant kernel of the GPU entropy decoder is a serial-bit latency chain, not an "
+                                 "HBM stream (SURVEY.md 8(d)); whole_step prices all kernels of one pass together",
+                         "whole_step": {"algorithmic_bytes": step_bytes, "achieved_GBps": step_bytes / (step_ms * 1e-3) / 1e9,
+                                        "frac": step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        "frac_of_measured_ceiling": step_bytes / (step_ms * 1e-3) / 1e9 / copy_ceiling},
                          "per_kernel": {k: {"algorithmic_bytes": v[0], "avg_ms": v[1],
                                             "achieved_GBps": v[0] / (v[1] * 1e-3) / 1e9} for k, v in kern.items()}},
+            "ceilings": {
+                "hbm_post_entropy_images_per_s": B / (post_entropy / (HBM_PEAK_GBS * 1e9)),
+                "pcie_gen5_x16_images_per_s": 64e9 / (hp.plan.stream_bytes / B) if args.huffman == "gpu" else None,
+                "entropy_decode_images_per_s": B / (huffman_total_ms * 1e-3) if args.huffman == "gpu" else None,
+                "note": "SURVEY.md 8(d): HBM bound of everything after the entropy decoder, H2D bound of the JPEG bytes "
+                        "(64 GB/s), and the measured rate of the GPU entropy decoder alone (all 8 kernels, this run)"},
+            "entropy_decode": ({"symbols_per_batch": symbols, "symbols_per_s": symbols / (huffman_total_ms * 1e-3),
+                                "bitstream_GBps": hp.plan.stream_bytes / (huffman_total_ms * 1e-3) / 1e9}
+                               if args.huffman == "gpu" else None),
             "e2e_host_huffman": {"huffman_s_per_batch": hp.huffman_s,
                                  "host_threads": effective_cpu_count(),
                                  "note": "host entropy decoder on the same batch (one pass, thread pool): the CPU half "

@@ -304,6 +304,16 @@ class JpegBatchPlan:
         self._huff_keep += keep
         return status, sel
 
+    def huffman_symbol_count(self, ws=None):
+        """Number of Huffman symbols (= 32-bit records) the last GPU entropy decode of this batch produced; read from the
+        per-stream scratch headers (int32 [1], jpeg_huffman.hip MakeLayout).  Synchronises."""
+        ws = ws or self._huff_ws
+        if not len(self._huff_sel):
+            return 0
+        words = ws["scratch"].view(torch.int32)
+        idx = torch.as_tensor(self._scratch_off // 4 + 1, device=words.device)
+        return int(words[idx].to(torch.int64).sum().item())
+
     def check_gpu_status(self, status):
         """Raises for GPU-decoded streams whose entropy-coded segment was short of blocks (corrupt / truncated)."""
         st = status.cpu().numpy()

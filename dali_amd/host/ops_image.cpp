@@ -862,8 +862,8 @@ class ResizeGpu : public OperatorBase {
       int out_hw[2];
       for (int d = 0; d < 2; d++) {
         DALI_ENFORCE(lo[d] != hi[d] || req[d] == 0, "Cannot produce non-empty output from empty input");
-        DALI_ENFORCE(req[d] >= 0, "Resize (gpu): negative sizes / flipped regions of interest are not supported yet");
         out_hw[d] = std::max(1, (int)std::round(std::fabs(req[d])));
+        if (req[d] < 0) std::swap(lo[d], hi[d]);  // a negative size flips: the region is traversed backwards
         if (subpixel_scale_ && (float)out_hw[d] != std::fabs(req[d])) {
           // the rounded size differs from the fractional one: shrink/grow the region around its centre
           double adj = std::min(10.0, std::max(-10.0, (double)out_hw[d] / std::fabs(req[d])));
@@ -873,6 +873,7 @@ class ResizeGpu : public OperatorBase {
           lo[d] = (float)nlo; hi[d] = (float)nhi;
         }
       }
+      AdjustSample(ws, i, n, lo, hi, out_hw);
       a.use_roi = 1;
       a.roi_y0 = lo[0]; a.roi_x0 = lo[1]; a.roi_y1 = hi[0]; a.roi_x1 = hi[1];
       a.out_h = out_hw[0]; a.out_w = out_hw[1];
@@ -904,6 +905,11 @@ class ResizeGpu : public OperatorBase {
     LaunchResample(ws, uploader_, args_, descs_, "resample");
   }
 
+ protected:
+  // hook for operators that derive their region from the resized image (ResizeCropMirror): lo/hi = source region
+  // (y, x), out_hw = output size of sample i
+  virtual void AdjustSample(const Workspace &, int, int, float *, float *, int *) {}
+
  private:
   FilterArgs filters_;
   bool has_shorter_, has_longer_, has_x_, has_y_, has_size_, has_max_size_, has_roi_, roi_relative_, subpixel_scale_;
@@ -916,6 +922,90 @@ class ResizeGpu : public OperatorBase {
   DescUploader uploader_;
 };
 DALI_REGISTER_OPERATOR(Resize, ResizeGpu, GPU);
+
+// ---- ResizeCropMirror: resize, then a CropAttr window of the resized image, then flips - as ONE resampling of the
+// back-projected window (resize_crop_mirror.cc:85-118) ----
+DALI_SCHEMA(ResizeCropMirrorAttr)
+    .DocStr("ResizeCropMirror attributes placeholder")
+    .MakeInternal()
+    .AddOptionalArg("mirror", "Mask for flipping: 0 - no flip, 1 - horizontal flip, 2 - vertical flip (bitwise combination).",
+                    ArgValue::Int(0), true)
+    .AddParent("ResizeAttr")
+    .AddParent("CropAttr");
+
+DALI_SCHEMA(ResizeCropMirror)
+    .DocStr("Performs a fused resize, crop, mirror operation.\n\nThe result of the operation is equivalent to applying "
+            "``resize``, followed by ``crop`` and ``flip``. Internally, the operator calculates the relevant region of "
+            "interest and performs a single resizing operation on that region.")
+    .NumInput(1)
+    .NumOutput(1)
+    .AddParent("ResizeCropMirrorAttr")
+    .AddParent("ResamplingFilterAttr")
+    .InputLayout(0, {"HWC"});
+
+DALI_SCHEMA(FastResizeCropMirror)
+    .DocStr("Legacy alias for ResizedCropMirror, with antialiasing disabled by default.")
+    .NumInput(1)
+    .NumOutput(1)
+    .AddParent("ResizeCropMirror")
+    .AddOptionalArg("antialias", "If enabled, it applies an antialiasing filter when scaling down.", ArgValue::Bool(false))
+    .InputLayout(0, {"HWC"});
+
+class ResizeCropMirrorGpu : public ResizeGpu {
+ public:
+  explicit ResizeCropMirrorGpu(const OpSpec &spec) : ResizeGpu(spec) {
+    std::string r = spec.GetString("rounding");
+    DALI_ENFORCE(r == "round" || r == "truncate", "``rounding`` value ", r,
+                 " is not supported. Supported values are \"round\", or \"truncate\".");
+    round_ = r == "round";
+    has_crop_ = spec.ArgumentDefined("crop");
+    has_wh_ = spec.ArgumentDefined("crop_w") || spec.ArgumentDefined("crop_h");
+    DALI_ENFORCE(spec.ArgumentDefined("crop_w") == spec.ArgumentDefined("crop_h"),
+                 "`crop_w` and `crop_h` arguments must be provided together");
+    DALI_ENFORCE(!(has_crop_ && has_wh_), "`crop` argument is not compatible with `crop_h`, `crop_w`, `crop_d`");
+    if (has_crop_) {
+      DALI_ENFORCE(!spec.HasTensorArgument("crop"), "Per-sample `crop` tensors are not supported yet");
+      auto c = spec.GetFloatVec("crop");
+      DALI_ENFORCE(c.size() == 2, "`crop` argument should have 2 or 3 elements depending on the input data shape");
+      crop_[0] = (int)c[0]; crop_[1] = (int)c[1];
+    }
+  }
+
+ protected:
+  void AdjustSample(const Workspace &ws, int i, int n, float *lo, float *hi, int *out_hw) override {
+    if (i == 0) {  // per-batch argument fetch
+      mirror_ = GetPerSampleInt(spec_, ws, "mirror", n);
+      pos_[1] = GetPerSampleFloat(spec_, ws, "crop_pos_x", n);
+      pos_[0] = GetPerSampleFloat(spec_, ws, "crop_pos_y", n);
+      if (has_wh_) {
+        wh_[0] = GetPerSampleFloat(spec_, ws, "crop_h", n);
+        wh_[1] = GetPerSampleFloat(spec_, ws, "crop_w", n);
+      }
+    }
+    for (int d = 0; d < 2; d++) {
+      // the crop window in the resized image (crop_attr.cc:168-240); a non-positive extent means "whole axis"
+      int64_t crop = has_crop_ ? crop_[d] : has_wh_ ? (int64_t)(int)wh_[d][i] : 0;
+      float norm = pos_[d][i];
+      if (crop <= 0) { crop = out_hw[d]; norm = 0.5f; }
+      DALI_ENFORCE(norm >= 0.0f && norm <= 1.0f, "Anchor for dimension ", d, " (", norm, ") is out of range [0.0, 1.0]");
+      int64_t anchor = daliamdCropAnchor(norm, crop, out_hw[d], round_);
+      // back-projection to source coordinates
+      double ratio = ((double)hi[d] - (double)lo[d]) / out_hw[d], offset = lo[d];
+      lo[d] = (float)((double)anchor * ratio + offset);
+      hi[d] = (float)((double)(anchor + crop) * ratio + offset);
+      if (mirror_[i] & (1 << (1 - d))) std::swap(lo[d], hi[d]);   // 1: horizontal (W), 2: vertical (H)
+      out_hw[d] = (int)crop;
+    }
+  }
+
+ private:
+  bool round_, has_crop_, has_wh_;
+  int crop_[2] = {0, 0};
+  std::vector<int> mirror_;
+  std::vector<float> pos_[2], wh_[2];
+};
+DALI_REGISTER_OPERATOR(ResizeCropMirror, ResizeCropMirrorGpu, GPU);
+DALI_REGISTER_OPERATOR(FastResizeCropMirror, ResizeCropMirrorGpu, GPU);
 
 // =============================================================================================
 // CropMirrorNormalize

@@ -332,3 +332,27 @@ def resize_params(in_hw, size=(0, 0), mode="default", max_size=None, subpixel_sc
     if rc:
         raise RuntimeError("Cannot produce non-empty output from empty input")
     return (int(out_hw[0]), int(out_hw[1])), (float(lo[0]), float(lo[1]), float(hi[0]), float(hi[1]))
+
+
+def resize_crop_mirror_params(in_hw, crop=(0, 0), crop_pos=(0.5, 0.5), mirror=0, rounding="round", **resize_kw):
+    """fn.resize_crop_mirror: the ResizeAttr arithmetic, then the CropAttr window of the RESIZED image projected back
+    into source coordinates, then the flips as swapped region ends (resize_crop_mirror.cc:85-118; crop window
+    crop_attr.cc:168-240).  crop = (H, W), non-positive = whole axis; crop_pos = (y, x) normalised; mirror bit 0 =
+    horizontal, bit 1 = vertical.  Returns (out_hw, (y0, x0, y1, x1))."""
+    out_hw, roi = resize_params(in_hw, **resize_kw)
+    lo = [np.float32(roi[0]), np.float32(roi[1])]
+    hi = [np.float32(roi[2]), np.float32(roi[3])]
+    out = list(out_hw)
+    for d in range(2):
+        c, norm = int(crop[d]), np.float32(crop_pos[d])
+        if c <= 0:
+            c, norm = out_hw[d], np.float32(0.5)
+        anchor = crop_anchor(float(norm), c, out_hw[d], rounding)
+        ratio = (float(hi[d]) - float(lo[d])) / out_hw[d]          # double arithmetic, float storage
+        offset = float(lo[d])
+        lo[d] = np.float32(anchor * ratio + offset)
+        hi[d] = np.float32((anchor + c) * ratio + offset)
+        if mirror & (1 << (1 - d)):
+            lo[d], hi[d] = hi[d], lo[d]
+        out[d] = c
+    return (out[0], out[1]), (float(lo[0]), float(lo[1]), float(hi[0]), float(hi[1]))

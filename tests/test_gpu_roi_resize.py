@@ -169,3 +169,120 @@ def test_roi_decode_resize_cmn_pipeline_matches_oracle(files):
             rs = O.resample_u8(crop, out_hw, roi=roi)
             ref = O.cmn_u8(rs, (0, 0), (64, 80), mirror=bool(mirror[i]), mean=mean, inv_std=inv, layout="CHW", dtype=O.F16)
             assert np.array_equal(got[i].view(np.uint16), ref.view(np.uint16)), (it, i)
+
+
+def test_resize_flipped_region_matches_oracle(files):
+    """roi_start > roi_end flips the axis (resize_attr_base.h:62-96): the region is traversed backwards."""
+    from dali_amd import fn, types
+    from dali_amd.pipeline import Pipeline
+    bs = len(files)
+    pipe = Pipeline(batch_size=bs, num_threads=3, device_id=0)
+    with pipe:
+        enc, _ = fn.readers.file(files=files)
+        img = fn.decoders.image(enc, device="mixed")
+        pipe.set_outputs(fn.resize(img, size=[40, 56], roi_start=[0.9, 0.1], roi_end=[0.2, 0.8], roi_relative=True),
+                         fn.resize(img, resize_x=48, roi_start=[0.0, 1.0], roi_end=[1.0, 0.0], roi_relative=True))
+    flipped_y, mirrored = pipe.run()
+    for i, r in enumerate(_decoded(files)):
+        out_hw, roi = O.resize_params(r.shape[:2], size=(40, 56), roi=(0.9, 0.1, 0.2, 0.8), roi_relative=True)
+        assert roi[0] > roi[2] and roi[1] < roi[3]
+        ref = O.resample_u8(r, out_hw, roi=roi)
+        assert np.array_equal(flipped_y[i].as_cpu(), ref), i
+        # a whole-image horizontal flip is the mirror image of the plain resize (up to float rounding of the taps)
+        out_hw, roi = O.resize_params(r.shape[:2], size=(0, 48), roi=(0.0, 1.0, 1.0, 0.0), roi_relative=True)
+        ref = O.resample_u8(r, out_hw, roi=roi)
+        got = mirrored[i].as_cpu()
+        assert np.array_equal(got, ref), i
+        plain = O.resample_u8(r, out_hw, roi=(roi[0], roi[3], roi[2], roi[1]))
+        assert np.abs(got.astype(int) - plain[:, ::-1]).max() <= 1
+
+
+RCM_CASES = [
+    dict(resize_kw=dict(resize_shorter=96), crop=(80, 80), mirror=0),
+    dict(resize_kw=dict(resize_shorter=96), crop=(80, 64), mirror=1, pos=(0.25, 0.75)),
+    dict(resize_kw=dict(size=[90, 120]), crop=(64, 100), mirror=2, pos=(1.0, 0.0)),
+    dict(resize_kw=dict(resize_longer=100), crop=(50, 60), mirror=3, rounding="truncate", pos=(0.3, 0.6)),
+    dict(resize_kw=dict(resize_x=77), crop=(0, 0), mirror=1),                         # no crop: the whole resized image
+    dict(resize_kw=dict(size=[60, 60]), crop=(80, 72), mirror=0),                     # window larger than the image
+    # test_resize_crop_mirror.py:75-78: a region that is already flipped in x, stretched, then cropped and mirrored
+    dict(resize_kw=dict(size=[100, 130], mode="stretch", roi_start=[0.3, 0.8], roi_end=[0.9, 0.1], roi_relative=True),
+         crop=(70, 90), mirror=1, pos=(0.4, 0.2)),
+    dict(resize_kw=dict(size=[110, 90], roi_start=[0.7, 0.2], roi_end=[0.1, 0.8], roi_relative=True),
+         crop=(100, 64), mirror=2, pos=(0.0, 1.0)),
+]
+
+
+@pytest.mark.parametrize("case", RCM_CASES)
+def test_resize_crop_mirror_matches_oracle(files, case):
+    from dali_amd import fn
+    from dali_amd.pipeline import Pipeline
+    bs = len(files)
+    kw = dict(case["resize_kw"])
+    okw = {}
+    if "resize_shorter" in kw:
+        okw = dict(size=(kw["resize_shorter"],) * 2, mode="not_smaller")
+    elif "resize_longer" in kw:
+        okw = dict(size=(kw["resize_longer"],) * 2, mode="not_larger")
+    elif "resize_x" in kw:
+        okw = dict(size=(0, kw["resize_x"]))
+    else:
+        okw = dict(size=tuple(kw["size"]))
+    if "mode" in kw:
+        okw["mode"] = kw["mode"]
+    if "roi_start" in kw:
+        okw.update(roi=tuple(kw["roi_start"]) + tuple(kw["roi_end"]), roi_relative=True)
+    pos = case.get("pos", (0.5, 0.5))
+    if case["crop"] != (0, 0):
+        kw.update(crop=[float(c) for c in case["crop"]], crop_pos_y=pos[0], crop_pos_x=pos[1])
+    pipe = Pipeline(batch_size=bs, num_threads=3, device_id=0)
+    with pipe:
+        enc, _ = fn.readers.file(files=files)
+        img = fn.decoders.image(enc, device="mixed")
+        pipe.set_outputs(fn.resize_crop_mirror(img, mirror=case["mirror"], rounding=case.get("rounding", "round"), **kw),
+                         fn.resize(img, **case["resize_kw"]))
+    out, resized = pipe.run()
+    assert out.layout() == "HWC"
+    for i, r in enumerate(_decoded(files)):
+        out_hw, roi = O.resize_crop_mirror_params(r.shape[:2], crop=case["crop"], crop_pos=pos, mirror=case["mirror"],
+                                                  rounding=case.get("rounding", "round"), **okw)
+        ref = O.resample_u8(r, out_hw, roi=roi)
+        got = out[i].as_cpu()
+        assert got.shape == ref.shape, (i, got.shape, ref.shape)
+        assert np.array_equal(got, ref), f"sample {i}: max diff {np.abs(got.astype(int) - ref).max()}"
+        # the operator's contract: equivalent to resize, then crop, then flip (where the window is inside the image)
+        rs = resized[i].as_cpu()
+        ch, cw = out_hw
+        if ch <= rs.shape[0] and cw <= rs.shape[1]:
+            ay = O.crop_anchor(pos[0] if case["crop"][0] > 0 else 0.5, ch, rs.shape[0], case.get("rounding", "round"))
+            ax = O.crop_anchor(pos[1] if case["crop"][1] > 0 else 0.5, cw, rs.shape[1], case.get("rounding", "round"))
+            seq = rs[ay:ay + ch, ax:ax + cw]
+            if case["mirror"] & 1:
+                seq = seq[:, ::-1]
+            if case["mirror"] & 2:
+                seq = seq[::-1]
+            assert np.abs(got.astype(int) - seq).max() <= 1, i
+
+
+def test_resize_crop_mirror_per_sample_mirror_and_fused_normalize(files):
+    """Per-sample `mirror` from a DataNode, and ResizeCropMirror -> CropMirrorNormalize runs as one fused kernel."""
+    from dali_amd import fn, types
+    from dali_amd.pipeline import Pipeline
+    bs = len(files)
+    pipe = Pipeline(batch_size=bs, num_threads=3, device_id=0)
+    with pipe:
+        enc, _ = fn.readers.file(files=files)
+        img = fn.decoders.image(enc, device="mixed")
+        flip = fn.random.coin_flip(probability=0.5, seed=5)
+        rcm = fn.resize_crop_mirror(img, resize_shorter=72, crop=[64.0, 64.0], mirror=flip)
+        pipe.set_outputs(fn.crop_mirror_normalize(rcm, dtype=types.FLOAT, output_layout="CHW", mean=MEAN, std=STD))
+    (out,) = pipe.run()
+    assert "fused_resample_cmn" in pipe.executed_kernels()
+    mirror = O.coin_flip_batch(5, 0, bs, 0.5)
+    mean, inv = O.cmn_norm_args(MEAN, STD)
+    got = out.as_tensor().cpu().numpy()
+    for i, r in enumerate(_decoded(files)):
+        out_hw, roi = O.resize_crop_mirror_params(r.shape[:2], crop=(64, 64), mirror=int(mirror[i]), size=(72, 72),
+                                                  mode="not_smaller")
+        rs = O.resample_u8(r, out_hw, roi=roi)
+        ref = O.cmn_u8(rs, (0, 0), (64, 64), mean=mean, inv_std=inv, layout="CHW", dtype=O.F32)
+        assert np.array_equal(got[i], ref), i     # the fused kernel rounds to u8 exactly where the two-op chain does

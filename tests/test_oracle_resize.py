@@ -54,3 +54,29 @@ def test_region_of_interest_absolute_relative_and_degenerate():
 
 def test_output_is_at_least_one_pixel():
     assert O.resize_params((1000, 10), (10, 0), "default")[0] == (10, 1)
+
+
+@pytest.mark.parametrize("mirror", [0, 1, 2, 3])
+def test_resize_crop_mirror_equals_resize_then_crop_then_flip(mirror):
+    """The reference's own check of the fused operator (test_resize_crop_mirror.py:27-84): one resampling of the
+    back-projected window == resize -> crop -> flip, max difference 1."""
+    from tests.util import synth_image
+    rng = np.random.default_rng(11 + mirror)
+    img = synth_image(rng, 150, 210)
+    for size, mode, roi, crop, pos in [((96, 96), "not_smaller", None, (80, 72), (0.3, 0.9)),
+                                       ((100, 130), "stretch", (0.3, 0.8, 0.9, 0.1), (70, 90), (0.4, 0.2)),
+                                       ((120, 0), "default", (0.7, 0.2, 0.1, 0.8), (64, 64), (1.0, 0.0))]:
+        kw = dict(size=size, mode=mode, roi=roi, roi_relative=roi is not None)
+        out_hw, win = O.resize_crop_mirror_params(img.shape[:2], crop=crop, crop_pos=pos, mirror=mirror, **kw)
+        fused = O.resample_u8(img, out_hw, roi=win)
+        rs_hw, rs_roi = O.resize_params(img.shape[:2], **kw)
+        resized = O.resample_u8(img, rs_hw, roi=rs_roi)
+        ay, ax = O.crop_anchor(pos[0], crop[0], rs_hw[0]), O.crop_anchor(pos[1], crop[1], rs_hw[1])
+        seq = resized[ay:ay + crop[0], ax:ax + crop[1]]
+        if mirror & 1:
+            seq = seq[:, ::-1]
+        if mirror & 2:
+            seq = seq[::-1]
+        assert fused.shape == seq.shape == (crop[0], crop[1], 3)
+        d = np.abs(fused.astype(int) - seq)
+        assert d.max() <= 1 and d.mean() < 1e-3 * 255, (size, d.max(), d.mean())
