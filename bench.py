@@ -209,7 +209,7 @@ def cpu_baseline(enc, seconds_budget=20.0):
                       f"oracle (-O3 -msse2, OpenMP, one task per sample), {cores} threads, {el:.2f} s wall"}
 
 
-def e2e_pipeline(enc, device_id, iters=30, threads=None, roi_decode=False):
+def e2e_pipeline(enc, device_id, iters=30, threads=None, roi_decode=False, cache_mb=0):
     """The same hot path through the product's DALI-style pipeline (C++ host framework): readers.file (page cache)
     -> decoders.image(mixed: header parse + scan analysis on the host thread pool, H2D of the entropy-coded
     segments, GPU Huffman/IDCT/colour) -> random_resized_crop + crop_mirror_normalize (fused).  PCIe-inclusive and
@@ -233,7 +233,8 @@ def e2e_pipeline(enc, device_id, iters=30, threads=None, roi_decode=False):
                 images = fn.decoders.image_random_crop(jpegs, device="mixed", output_type=types.RGB)
                 crops = fn.resize(images, size=[224, 224])
             else:
-                images = fn.decoders.image(jpegs, device="mixed", output_type=types.RGB)
+                cache = dict(cache_size=cache_mb, cache_type="threshold") if cache_mb else {}
+                images = fn.decoders.image(jpegs, device="mixed", output_type=types.RGB, **cache)
                 crops = fn.random_resized_crop(images, size=[224, 224])
             out = fn.crop_mirror_normalize(crops, dtype=types.FLOAT16, output_layout="CHW",
                                            mean=[0.485 * 255, 0.456 * 255, 0.406 * 255],
@@ -505,6 +506,11 @@ def main():
             line["e2e_pipeline_roi_decode"] = e2e_pipeline(enc, local_rank, roi_decode=True)
             line["e2e_pipeline_roi_decode"]["note"] = ("same, with decoders.image_random_crop -> resize -> "
                                                        "crop_mirror_normalize: only the crop window is decoded")
+            line["e2e_pipeline_decoder_cache"] = e2e_pipeline(enc, local_rank, iters=100, cache_mb=512)
+            line["e2e_pipeline_decoder_cache"]["note"] = (
+                "same as e2e_pipeline with decoders.image(cache_size=512, cache_type='threshold'): epoch >= 2 of a data "
+                "set whose decoded images fit in HBM (here: the one batch).  The files are still read; decoded images "
+                "are handed to the fused resample kernel in place from the cache blob")
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(enc)
         print(json.dumps(line))

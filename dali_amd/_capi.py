@@ -162,7 +162,7 @@ _KERNEL_SYMBOLS = [
     "daliamdGetLastErrorMessage", "daliamdClearLastError", "daliamdVersion", "daliamdDeviceCount",
     "daliamdSetDevice", "daliamdDeviceInfo", "daliamdStreamCreate", "daliamdStreamDestroy",
     "daliamdStreamSynchronize", "daliamdStreamWaitEvent", "daliamdEventCreate",
-    "daliamdEventDestroy", "daliamdEventRecord", "daliamdEventSynchronize", "daliamdEventElapsedMs",
+    "daliamdEventDestroy", "daliamdEventRecord", "daliamdEventSynchronize", "daliamdEventQuery", "daliamdEventElapsedMs",
     "daliamdMalloc", "daliamdFree", "daliamdHostAlloc", "daliamdHostFree", "daliamdMemcpyH2DAsync",
     "daliamdMemcpyD2HAsync", "daliamdMemcpyD2DAsync", "daliamdMemsetAsync", "daliamdMemcpy2DD2DAsync",
     "daliamdJpegIdctSetup", "daliamdJpegIdctRun", "daliamdJpegHuffmanScratchBytes", "daliamdJpegHuffmanSetup",
@@ -181,6 +181,8 @@ _HOST_SYMBOLS = [
     "daliamdRandomCropBatch", "daliamdCoinFlipBatch", "daliamdPhiloxAdvanceSequence",
     "daliamdPhiloxStateToString", "daliamdPhiloxStateFromString", "daliamdPhiloxGenerate",
     "daliamdCmnNormArgs", "daliamdCropAnchor",
+    "daliamdImageCachePolicyCreate", "daliamdImageCachePolicyDestroy", "daliamdImageCachePolicyOnDecode",
+    "daliamdImageCachePolicyFind",
 ]
 
 
@@ -220,6 +222,13 @@ def host():
         lib = C.CDLL(HOST_LIB)
         lib.daliamdHostGetLastErrorMessage.restype = C.c_char_p
         lib.daliamdCropAnchor.restype = C.c_int64
+        lib.daliamdImageCachePolicyCreate.restype = C.c_void_p
+        lib.daliamdImageCachePolicyCreate.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64]
+        lib.daliamdImageCachePolicyDestroy.argtypes = [C.c_void_p]
+        lib.daliamdImageCachePolicyOnDecode.restype = C.c_int64
+        lib.daliamdImageCachePolicyOnDecode.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint64]
+        lib.daliamdImageCachePolicyFind.restype = C.c_int64
+        lib.daliamdImageCachePolicyFind.argtypes = [C.c_void_p, C.c_char_p]
         lib.daliamdCropAnchor.argtypes = [C.c_float, C.c_int64, C.c_int64, C.c_int]
         _host = lib
     return _host

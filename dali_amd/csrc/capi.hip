@@ -82,6 +82,18 @@ daliamdResult_t daliamdEventSynchronize(daliamdEvent_t event) {
   DALIAMD_HIP_CHECK(hipEventSynchronize((hipEvent_t)event));
   return DALIAMD_SUCCESS;
 }
+daliamdResult_t daliamdEventQuery(daliamdEvent_t event, int *done) {
+  DALIAMD_REQUIRE(done, DALIAMD_ERROR_INVALID_ARGUMENT, "done is NULL");
+  hipError_t e = hipEventQuery((hipEvent_t)event);
+  if (e == hipErrorNotReady) {
+    (void)hipGetLastError();  // "not ready" is an answer, not an error
+    *done = 0;
+    return DALIAMD_SUCCESS;
+  }
+  DALIAMD_HIP_CHECK(e);
+  *done = 1;
+  return DALIAMD_SUCCESS;
+}
 daliamdResult_t daliamdEventElapsedMs(daliamdEvent_t start, daliamdEvent_t stop, float *ms) {
   DALIAMD_REQUIRE(ms, DALIAMD_ERROR_INVALID_ARGUMENT, "ms is NULL");
   DALIAMD_HIP_CHECK(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));

@@ -81,15 +81,31 @@ void Buffer::Reserve(size_t bytes) {
 
 // ------------------------------------------------------------------------------------------ TensorList
 void TensorList::Resize(const std::vector<TensorShape> &shapes, DALIDataType type, int pitch_align) {
+  Resize(shapes, type, pitch_align, {}, {}, nullptr);
+}
+
+void TensorList::Resize(const std::vector<TensorShape> &shapes, DALIDataType type, int pitch_align,
+                        const std::vector<void *> &ext_ptr, const std::vector<int64_t> &ext_pitch,
+                        std::shared_ptr<void> keepalive) {
   type_ = type;
   shapes_ = shapes;
   int n = (int)shapes.size();
   offsets_.assign(n, 0); pitch_.assign(n, 0); sizes_.assign(n, 0);
+  bool any_ext = false;
+  for (void *p : ext_ptr) any_ext |= p != nullptr;
+  if (any_ext) { ext_ = ext_ptr; ext_.resize(n, nullptr); ext_owner_ = std::move(keepalive); }
+  else { ext_.clear(); ext_owner_.reset(); }
   size_t off = 0;
   int esz = TypeSize(type);
   for (int i = 0; i < n; i++) {
     const auto &s = shapes[i];
     size_t bytes;
+    if (any_ext && ext_[i]) {
+      pitch_[i] = ext_pitch[i];
+      sizes_[i] = s.size() == 3 && ext_pitch[i] ? (size_t)(ext_pitch[i] * s[0]) : (size_t)volume(s) * esz;
+      offsets_[i] = (int64_t)off;
+      continue;
+    }
     if (pitch_align > 1 && s.size() == 3) {
       int64_t row = s[1] * s[2] * esz;
       int64_t p = (row + pitch_align - 1) / pitch_align * pitch_align;
@@ -109,6 +125,7 @@ void TensorList::Resize(const std::vector<TensorShape> &shapes, DALIDataType typ
 }
 
 bool TensorList::is_dense() const {
+  for (void *p : ext_) if (p) return false;
   for (size_t i = 0; i < shapes_.size(); i++) {
     if (pitch_[i] && shapes_[i].size() == 3 && pitch_[i] != shapes_[i][1] * shapes_[i][2] * TypeSize(type_)) return false;
   }
@@ -118,6 +135,7 @@ bool TensorList::is_dense() const {
 void TensorList::ShareData(const TensorList &o) {
   buf_ = o.buf_; dev_ = o.dev_; type_ = o.type_; layout_ = o.layout_; shapes_ = o.shapes_;
   offsets_ = o.offsets_; pitch_ = o.pitch_; sizes_ = o.sizes_; total_ = o.total_;
+  ext_ = o.ext_; ext_owner_ = o.ext_owner_;
   deferred = o.deferred; source_info = o.source_info;
 }
 

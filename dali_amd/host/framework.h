@@ -115,7 +115,7 @@ class TensorList {
   const TensorShape &shape(int i) const { return shapes_[i]; }
   // bytes between rows of sample i for image-like (HWC) data; dense when 0
   int64_t row_pitch(int i) const { return pitch_[i]; }
-  void *raw(int i) const { return static_cast<char *>(buf_->data()) + offsets_[i]; }
+  void *raw(int i) const { return ext_.empty() || !ext_[i] ? static_cast<char *>(buf_->data()) + offsets_[i] : ext_[i]; }
   size_t nbytes(int i) const { return sizes_[i]; }
   bool is_dense() const;
   size_t total_bytes() const { return total_; }
@@ -123,6 +123,12 @@ class TensorList {
   // Allocates one contiguous block; every sample starts at a 256-byte boundary.  For 3-D u8 samples
   // `pitch_align` > 1 pads each row to that many bytes (internal hand-off between device operators).
   void Resize(const std::vector<TensorShape> &shapes, DALIDataType type, int pitch_align = 1);
+  // Same, but sample i lives in caller-owned memory when ext_ptr[i] != nullptr (row pitch ext_pitch[i]): no space is
+  // set aside for it in the block and raw(i) returns that pointer.  `keepalive` owns the external memory (the decoded
+  // image cache hands out views of its entries this way - no copy on a hit).
+  void Resize(const std::vector<TensorShape> &shapes, DALIDataType type, int pitch_align, const std::vector<void *> &ext_ptr,
+              const std::vector<int64_t> &ext_pitch, std::shared_ptr<void> keepalive);
+  bool is_external(int i) const { return !ext_.empty() && ext_[i]; }
   // shares storage and metadata (zero-copy pass-through)
   void ShareData(const TensorList &other);
   // metadata only; used when an operator's work is deferred to its consumer
@@ -140,6 +146,8 @@ class TensorList {
   std::vector<int64_t> offsets_, pitch_;
   std::vector<size_t> sizes_;
   size_t total_ = 0;
+  std::vector<void *> ext_;
+  std::shared_ptr<void> ext_owner_;
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -1,0 +1,238 @@
+// Decoded-image cache: see image_cache.h for the reference files this follows.
+#include "image_cache.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+
+#include "dali_amd_host.h"
+#include "framework.h"
+#include "host_common.h"
+
+namespace daliamd_host {
+
+// ------------------------------------------------------------------------------------------ policy
+ImageCachePolicy::ImageCachePolicy(const std::string &type, size_t cache_size, size_t threshold)
+    : largest_(type == "largest"), cache_size_(cache_size), threshold_(type == "largest" ? 0 : threshold) {
+  if (type != "threshold" && type != "largest") DALI_FAIL("unexpected cache policy `", type, "`");
+  DALI_ENFORCE(threshold_ <= cache_size_, "Cache size should fit at least one image");
+}
+
+int64_t ImageCachePolicy::Find(const std::string &key) const {
+  auto it = stored_.find(key);
+  return it == stored_.end() ? -1 : it->second;
+}
+
+void ImageCachePolicy::Erase(const std::string &key) { stored_.erase(key); }  // the space is not reclaimed
+
+// ImageCacheBlob::Add (image_cache_blob.cc:89-115): append at the tail while there is room
+int64_t ImageCachePolicy::Store(const std::string &key, size_t data_size, size_t stored_size, size_t threshold) {
+  if (data_size < threshold) return -1;
+  DALI_ENFORCE(!key.empty(), "internal: cache key is empty");
+  if (stored_.count(key)) return -1;
+  if (cache_size_ - tail_ < stored_size) {
+    full_ = true;
+    return -1;
+  }
+  int64_t at = (int64_t)tail_;
+  stored_[key] = at;
+  tail_ += stored_size;
+  return at;
+}
+
+int64_t ImageCachePolicy::OnDecode(const std::string &key, size_t data_size, size_t stored_size) {
+  if (!largest_) return Store(key, data_size, stored_size, threshold_);
+  // ImageCacheLargest::Add (image_cache_largest.cc:25-89).  Until a key comes round a second time we only rank:
+  // `biggest_` holds the set of largest images seen so far whose sizes sum to at most the blob size.
+  if (!start_caching_) {
+    if (images_.count(key)) {
+      // second pass begins: the ranked set becomes the set of images to keep
+      start_caching_ = true;
+      images_.clear();
+      for (; !biggest_.empty(); biggest_.pop()) images_.insert(biggest_.top().second);
+    } else {
+      images_.insert(key);
+      if (biggest_total_ + stored_size <= cache_size_) {
+        biggest_.push({stored_size, key});
+        biggest_total_ += stored_size;
+      } else {
+        full_ = true;
+        if (stored_size <= cache_size_) {
+          // make room by dropping strictly smaller candidates, smallest first; whatever still fits comes back
+          std::vector<Candidate> dropped;
+          while (!biggest_.empty() && biggest_total_ + stored_size > cache_size_ && biggest_.top().first < stored_size) {
+            biggest_total_ -= biggest_.top().first;
+            dropped.push_back(biggest_.top());
+            biggest_.pop();
+          }
+          if (biggest_total_ + stored_size <= cache_size_) {
+            biggest_.push({stored_size, key});
+            biggest_total_ += stored_size;
+          }
+          for (auto it = dropped.rbegin(); it != dropped.rend(); ++it) {  // largest of the dropped ones first
+            if (biggest_total_ + it->first <= cache_size_) {
+              biggest_total_ += it->first;
+              biggest_.push(*it);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (start_caching_ && images_.count(key)) return Store(key, data_size, stored_size, 0);
+  return -1;
+}
+
+// ------------------------------------------------------------------------------------------ cache
+ImageCache::Fence::~Fence() {
+  if (event) daliamdEventDestroy(event);
+}
+
+namespace {
+std::mutex g_factory_mutex;
+struct Instance { std::weak_ptr<ImageCache> cache; ImageCache::Params params; };
+std::map<int, Instance> g_caches;
+}  // namespace
+
+std::shared_ptr<ImageCache> ImageCache::Get(int device_id, const Params &params) {
+  std::lock_guard<std::mutex> g(g_factory_mutex);
+  auto it = g_caches.find(device_id);
+  if (it != g_caches.end()) {
+    if (auto c = it->second.cache.lock()) {
+      DALI_ENFORCE(it->second.params == params, "Cache for device ", device_id,
+                   " was already initialized with other parameters");
+      return c;
+    }
+  }
+  std::shared_ptr<ImageCache> c(new ImageCache(params));
+  g_caches[device_id] = {c, params};
+  return c;
+}
+
+ImageCache::ImageCache(const Params &params) : params_(params), policy_(params.type, params.size, params.threshold) {
+  void *p = nullptr;
+  KCHECK(daliamdMalloc(&p, std::max<size_t>(params.size, 256)));
+  blob_ = static_cast<uint8_t *>(p);
+}
+
+ImageCache::~ImageCache() {
+  // every stream that reads or writes the blob belongs to a pipeline holding this cache: they are idle by now
+  if (params_.debug && !stats_.empty()) PrintStats();
+  entries_.clear();
+  pending_.clear();
+  if (blob_) daliamdFree(blob_);
+}
+
+bool ImageCache::Lookup(const std::string &key, Entry *entry, daliamdStream_t stream) {
+  if (key.empty()) return false;
+  std::lock_guard<std::mutex> g(m_);
+  auto it = entries_.find(key);
+  if (it == entries_.end()) return false;
+  Entry &e = it->second;
+  if (e.fence) {
+    if (!e.fence->done) {
+      int done = 0;
+      KCHECK(daliamdEventQuery(e.fence->event, &done));
+      e.fence->done = done != 0;
+    }
+    if (e.fence->done) e.fence.reset();
+    else KCHECK(daliamdStreamWaitEvent(stream, e.fence->event));
+  }
+  *entry = e;
+  if (params_.debug) stats_[key].reads++;
+  return true;
+}
+
+uint8_t *ImageCache::Reserve(const std::string &key, int h, int w, int c, int64_t pitch) {
+  if (key.empty()) return nullptr;
+  std::lock_guard<std::mutex> g(m_);
+  if (params_.debug) stats_[key].decodes++;
+  if (entries_.count(key) || pending_.count(key)) return nullptr;
+  const size_t data_size = (size_t)h * w * c;
+  const size_t stored = ((size_t)h * pitch + 255) & ~(size_t)255;  // every slot starts at a 256-byte boundary
+  int64_t at = policy_.OnDecode(key, data_size, stored);
+  if (at < 0) return nullptr;
+  Entry e;
+  e.data = blob_ + at;
+  e.h = h; e.w = w; e.c = c; e.pitch = pitch;
+  pending_[key] = e;
+  return e.data;
+}
+
+void ImageCache::Commit(const std::vector<std::string> &keys, daliamdStream_t stream) {
+  if (keys.empty()) return;
+  auto fence = std::make_shared<Fence>();
+  KCHECK(daliamdEventCreate(&fence->event, 0));
+  KCHECK(daliamdEventRecord(fence->event, stream));
+  std::lock_guard<std::mutex> g(m_);
+  for (auto &k : keys) {
+    auto it = pending_.find(k);
+    if (it == pending_.end()) continue;
+    it->second.fence = fence;
+    entries_[k] = it->second;
+    pending_.erase(it);
+    if (params_.debug) stats_[k].cached = true;
+  }
+}
+
+void ImageCache::Invalidate(const std::string &key) {
+  std::lock_guard<std::mutex> g(m_);
+  entries_.erase(key);
+  pending_.erase(key);
+  policy_.Erase(key);
+  if (params_.debug) stats_[key].cached = false;
+}
+
+// same report as ImageCacheBlob::print_stats (image_cache_blob.cc:129-160); DALI_LOG_FILE redirects it
+void ImageCache::PrintStats() const {
+  static std::mutex stats_mutex;
+  std::lock_guard<std::mutex> g(stats_mutex);
+  size_t cached = 0;
+  for (auto &kv : stats_) cached += kv.second.cached;
+  const char *log_filename = std::getenv("DALI_LOG_FILE");
+  std::ofstream log_file;
+  if (log_filename) log_file.open(log_filename);
+  std::ostream &out = log_filename ? log_file : std::cout;
+  out << "#################### CACHE STATS ####################" << std::endl;
+  out << "cache_size: " << policy_.cache_size() << std::endl;
+  out << "cache_threshold: " << policy_.threshold() << std::endl;
+  out << "is_cache_full: " << (int)policy_.is_full() << std::endl;
+  out << "images_seen: " << stats_.size() << std::endl;
+  out << "images_cached: " << cached << std::endl;
+  out << "images_not_cached: " << stats_.size() - cached << std::endl;
+  for (auto &kv : stats_) {
+    out << "image[" << kv.first << "] : is_cached[" << (int)kv.second.cached << "] decodes[" << kv.second.decodes
+        << "] reads[" << kv.second.reads << "]";
+    auto it = entries_.find(kv.first);
+    if (it != entries_.end()) out << " shape[" << it->second.h << ", " << it->second.w << ", " << it->second.c << "]";
+    out << std::endl;
+  }
+  out << "#################### END   STATS ####################" << std::endl;
+}
+
+}  // namespace daliamd_host
+
+// ------------------------------------------------------------------------------------------ C ABI (bookkeeping only)
+extern "C" {
+void *daliamdImageCachePolicyCreate(const char *type, uint64_t cache_size, uint64_t threshold) {
+  try {
+    return new daliamd_host::ImageCachePolicy(type ? type : "", (size_t)cache_size, (size_t)threshold);
+  } catch (const std::exception &e) {
+    daliamd_host::Fail("%s", e.what());
+    return nullptr;
+  }
+}
+void daliamdImageCachePolicyDestroy(void *policy) { delete static_cast<daliamd_host::ImageCachePolicy *>(policy); }
+int64_t daliamdImageCachePolicyOnDecode(void *policy, const char *key, uint64_t data_size, uint64_t stored_size) {
+  try {
+    return static_cast<daliamd_host::ImageCachePolicy *>(policy)->OnDecode(key, (size_t)data_size, (size_t)stored_size);
+  } catch (const std::exception &e) {
+    daliamd_host::Fail("%s", e.what());
+    return -1;
+  }
+}
+int64_t daliamdImageCachePolicyFind(void *policy, const char *key) {
+  return static_cast<daliamd_host::ImageCachePolicy *>(policy)->Find(key);
+}
+}

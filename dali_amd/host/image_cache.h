@@ -1,0 +1,110 @@
+// Decoded-image cache of the mixed image decoder (`cache_size`, `cache_type`, `cache_threshold`, `cache_debug`).
+//
+// Behaviour follows the reference's decoder cache:
+//   CachedDecoderImpl / CachedDecoderAttr   dali/operators/decoder/cache/cached_decoder_impl.cc:24-135
+//   ImageCacheBlob  ("threshold")          dali/operators/decoder/cache/image_cache_blob.cc:27-135
+//   ImageCacheLargest ("largest")          dali/operators/decoder/cache/image_cache_largest.cc:25-89
+//   ImageCacheFactory (one per device)     dali/operators/decoder/cache/image_cache_factory.cc:22-70
+//
+// MI355X design: the blob is one HBM allocation (a shard of decoded ImageNet fits in 288 GB) and there is NO copy on
+// either side of it.  On a miss the decoder's colour kernel writes the RGB image straight into its cache slot; on a
+// hit the output TensorList of the decoder points at the slot (TensorList::Resize with external samples).  The
+// bookkeeping (which key goes where) is host-only and split out as ImageCachePolicy so that it runs without a GPU.
+#ifndef DALI_AMD_HOST_IMAGE_CACHE_H_
+#define DALI_AMD_HOST_IMAGE_CACHE_H_
+
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <queue>
+#include <set>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "dali_amd_kernels.h"
+
+namespace daliamd_host {
+
+// Host-only bookkeeping: decides, per decode of `key`, whether (and at which offset of the blob) the image is kept.
+class ImageCachePolicy {
+ public:
+  // type: "threshold" (keep every image of at least `threshold` bytes until the blob is full) or "largest" (first
+  // pass over the data: find the largest images that fit together; they are stored from the second pass on)
+  ImageCachePolicy(const std::string &type, size_t cache_size, size_t threshold);
+  // One decode of `key`: `data_size` = H*W*C (compared with the threshold, image_cache_blob.cc:95), `stored_size` =
+  // bytes the image takes in the blob.  Returns the blob offset it must be written to, or -1 when it is not kept.
+  int64_t OnDecode(const std::string &key, size_t data_size, size_t stored_size);
+  // offset of a stored image or -1
+  int64_t Find(const std::string &key) const;
+  void Erase(const std::string &key);
+  size_t bytes_used() const { return tail_; }
+  size_t cache_size() const { return cache_size_; }
+  size_t threshold() const { return threshold_; }
+  bool is_full() const { return full_; }
+
+ private:
+  int64_t Store(const std::string &key, size_t data_size, size_t stored_size, size_t threshold);
+  bool largest_;
+  size_t cache_size_, threshold_, tail_ = 0;
+  bool full_ = false;
+  std::unordered_map<std::string, int64_t> stored_;
+  // "largest": candidates of the first pass, smallest on top
+  using Candidate = std::pair<size_t, std::string>;
+  std::priority_queue<Candidate, std::vector<Candidate>, std::greater<Candidate>> biggest_;
+  size_t biggest_total_ = 0;
+  std::set<std::string> images_;
+  bool start_caching_ = false;
+};
+
+class ImageCache {
+ public:
+  // all work that wrote a group of entries; readers on other streams wait for it
+  struct Fence {
+    ~Fence();
+    daliamdEvent_t event = nullptr;
+    bool done = false;
+  };
+  struct Entry {
+    uint8_t *data = nullptr;
+    int32_t h = 0, w = 0, c = 0;
+    int64_t pitch = 0;
+    std::shared_ptr<Fence> fence;  // null once the write is known to have finished
+  };
+  struct Params {
+    std::string type;
+    size_t size, threshold;
+    bool debug;
+    bool operator==(const Params &o) const { return type == o.type && size == o.size && threshold == o.threshold && debug == o.debug; }
+  };
+
+  // the cache of `device_id`, shared by every decoder instance on that device (all must ask for the same parameters)
+  static std::shared_ptr<ImageCache> Get(int device_id, const Params &params);
+  ~ImageCache();
+
+  // A committed entry.  Makes `stream` wait for the entry's write when that may still be in flight.
+  bool Lookup(const std::string &key, Entry *entry, daliamdStream_t stream);
+  // A decode of `key` is about to be enqueued: returns the slot it should write to (rows of `pitch` bytes), or nullptr
+  // when the policy does not keep it.  The entry stays invisible to Lookup until Commit.
+  uint8_t *Reserve(const std::string &key, int h, int w, int c, int64_t pitch);
+  // The decodes reserved since the last Commit by this caller are enqueued on `stream`.
+  void Commit(const std::vector<std::string> &keys, daliamdStream_t stream);
+  // The decode behind a reserved/committed entry failed
+  void Invalidate(const std::string &key);
+
+ private:
+  explicit ImageCache(const Params &params);
+  struct Stats { int64_t decodes = 0, reads = 0; bool cached = false; };
+  void PrintStats() const;
+  Params params_;
+  ImageCachePolicy policy_;
+  uint8_t *blob_ = nullptr;
+  mutable std::mutex m_;
+  std::unordered_map<std::string, Entry> entries_, pending_;
+  std::map<std::string, Stats> stats_;
+};
+
+}  // namespace daliamd_host
+
+#endif  // DALI_AMD_HOST_IMAGE_CACHE_H_

@@ -10,6 +10,7 @@
 #include <cstdlib>
 
 #include "dali_amd_host.h"
+#include "image_cache.h"
 #include "ops.h"
 #include "pipeline.h"
 
@@ -65,18 +66,22 @@ DALI_SCHEMA(decoders__Image)
     .AddOptionalArg("split_stages", "Deprecated, ignored.", ArgValue::Bool(false))
     .AddOptionalArg("use_chunk_allocator", "Deprecated, ignored.", ArgValue::Bool(false))
     .AddOptionalArg("memory_stats", "Deprecated, ignored.", ArgValue::Bool(false))
-    .AddOptionalArg("cache_size", "Ignored (no decoder cache).", ArgValue::Int(0))
-    .AddOptionalArg("cache_type", "Ignored.", ArgValue::Str(""))
-    .AddOptionalArg("cache_threshold", "Ignored.", ArgValue::Int(0))
-    .AddOptionalArg("cache_debug", "Ignored.", ArgValue::Bool(false))
-    .AddOptionalArg("cache_batch_copy", "Ignored.", ArgValue::Bool(true))
+    .AddOptionalArg("cache_size", "Total size of the decoder cache in megabytes. When provided, the decoded images that "
+                    "are larger than `cache_threshold` will be cached in GPU memory.", ArgValue::Int(0))
+    .AddOptionalArg("cache_type", "``threshold``: caches every image with a size that is larger than `cache_threshold` "
+                    "until the cache is full (warm-up: 1 epoch). ``largest``: stores the largest images that can fit in "
+                    "the cache (warm-up: 2 epochs).", ArgValue::Str(""))
+    .AddOptionalArg("cache_threshold", "The size threshold, in bytes, for decoded images to be cached.", ArgValue::Int(0))
+    .AddOptionalArg("cache_debug", "Prints the debug information about the decoder cache.", ArgValue::Bool(false))
+    .AddOptionalArg("cache_batch_copy", "Accepted for compatibility: cached images are handed out in place, there is no "
+                    "copy to batch.", ArgValue::Bool(true))
     .InputLayout(0, {""});
 DALI_SCHEMA(ImageDecoder).DocStr("Legacy alias of decoders.image").NumInput(1).NumOutput(1).AddParent("decoders__Image");
 DALI_SCHEMA(experimental__decoders__Image).DocStr("Alias of decoders.image").NumInput(1).NumOutput(1).AddParent("decoders__Image");
 
 class ImageDecoderMixed : public OperatorBase {
  public:
-  explicit ImageDecoderMixed(const OpSpec &spec) : OperatorBase(spec) {
+  explicit ImageDecoderMixed(const OpSpec &spec, bool allow_cache = true) : OperatorBase(spec) {
     int64_t ot = spec.GetInt("output_type");
     DALI_ENFORCE(ot == DALI_RGB || ot == DALI_ANY_DATA, "decoders.image: only output_type=RGB is supported, got ", ot);
     DALI_ENFORCE(spec.GetInt("dtype") == DALI_UINT8, "decoders.image: only dtype=UINT8 is supported");
@@ -96,6 +101,14 @@ class ImageDecoderMixed : public OperatorBase {
       status_host_.emplace_back(std::make_unique<Buffer>(StorageDevice::CPU));
     }
     h2d_done_.assign(ring_, nullptr);
+    // decoded-image cache (cached_decoder_impl.cc:24-48); the fused crop decoders have no cache options
+    if (allow_cache && spec.Args().count("cache_size")) {
+      const size_t bytes = (size_t)spec.GetInt("cache_size") * 1024 * 1024;
+      const size_t threshold = (size_t)spec.GetInt("cache_threshold");
+      if (bytes > 0 && bytes >= threshold)
+        cache_ = ImageCache::Get((int)spec.GetInt("device_id"),
+                                 ImageCache::Params{spec.GetString("cache_type"), bytes, threshold, spec.GetBool("cache_debug")});
+    }
   }
   ~ImageDecoderMixed() override {
     for (auto e : h2d_done_)
@@ -119,11 +132,23 @@ class ImageDecoderMixed : public OperatorBase {
     // header bytes of each file).
     const int slot = (int)(ws.iteration % ring_);
     Buffer &ecs_stage = *ecs_stage_[slot];
+    // ---- decoded-image cache: a hit needs no work at all, its output sample IS the cache entry ----
+    hit_.assign(n, 0);
+    cached_.assign(n, ImageCache::Entry{});
+    int nact = n;
+    if (cache_) {
+      for (int i = 0; i < n; i++) {
+        if (i < (int)in.source_info.size() && cache_->Lookup(in.source_info[i], &cached_[i], ws.stream)) {
+          hit_[i] = 1;
+          nact--;
+        }
+      }
+    }
     ecs_off_.assign(n, 0);
     size_t ecs_bytes = 0;
     for (int i = 0; i < n; i++) {
       ecs_off_[i] = ecs_bytes;
-      ecs_bytes += ((size_t)in.nbytes(i) + 15) & ~(size_t)15;
+      if (!hit_[i]) ecs_bytes += ((size_t)in.nbytes(i) + 15) & ~(size_t)15;
     }
     // the three descriptor tables of the iteration live behind the JPEG bytes in the same staging buffer, so that
     // ONE host->device copy (on the copy stream) carries everything the kernels need
@@ -132,6 +157,11 @@ class ImageDecoderMixed : public OperatorBase {
                                align16((size_t)n * sizeof(daliamdJpegColorDesc));
     ecs_stage.Reserve(ecs_bytes + table_bytes + 256);
     for (int i = 0; i < n; i++) {
+      if (hit_[i]) {
+        infos_[i] = daliamdJpegInfo{};  // no components: every per-component loop below skips the sample
+        scans_[i].eligible = 0;
+        continue;
+      }
       ws.GetThreadPool().AddWork([&, i](int) {
         const uint8_t *data = static_cast<const uint8_t *>(in.raw(i));
         if (daliamdJpegParse(data, in.nbytes(i), &infos_[i]) != 0)
@@ -166,9 +196,32 @@ class ImageDecoderMixed : public OperatorBase {
     rois_.assign(4 * n, 0);
     ComputeRois(ws, n);
     plans_.assign(n, daliamdJpegRoiPlan{});
+    std::vector<void *> ext_ptr(cache_ ? n : 0, nullptr);
+    std::vector<int64_t> ext_pitch(cache_ ? n : 0, 0);
+    // slots reserved in this run; dropped again unless the decodes get enqueued (an exception on the way out)
+    struct Reserved {
+      ImageCache *cache;
+      std::vector<std::string> keys;
+      ~Reserved() { for (auto &k : keys) cache->Invalidate(k); }
+    } reserved{cache_.get(), {}};
     for (int i = 0; i < n; i++) {
       const auto &inf = infos_[i];
+      if (hit_[i]) {
+        shapes[i] = {cached_[i].h, cached_[i].w, cached_[i].c};
+        ext_ptr[i] = cached_[i].data;
+        ext_pitch[i] = cached_[i].pitch;
+        continue;
+      }
       shapes[i] = {upright_hw_[2 * i], upright_hw_[2 * i + 1], 3};
+      if (cache_ && i < (int)in.source_info.size()) {
+        // a miss the policy keeps is decoded straight into its cache slot
+        const int64_t pitch = (shapes[i][1] * 3 + kImagePitchAlign - 1) / kImagePitchAlign * kImagePitchAlign;
+        if (uint8_t *slot_ptr = cache_->Reserve(in.source_info[i], (int)shapes[i][0], (int)shapes[i][1], 3, pitch)) {
+          ext_ptr[i] = slot_ptr;
+          ext_pitch[i] = pitch;
+          reserved.keys.push_back(in.source_info[i]);
+        }
+      }
       if (rois_[4 * i + 2] > 0) {
         if (daliamdJpegPlanRoi(inf.width, inf.height, inf.num_components, inf.h_samp, inf.v_samp,
                                adjust_orientation_ ? inf.orientation : 1, rois_[4 * i], rois_[4 * i + 1], rois_[4 * i + 2],
@@ -195,19 +248,20 @@ class ImageDecoderMixed : public OperatorBase {
     Buffer &stage = *staging_[slot], &cdev = *coef_dev_[slot], &planes = *planes_[slot];
     Buffer &ecs_dev = *ecs_dev_[slot], &scratch = *scratch_[slot];
     Buffer &status_host = *status_host_[slot];
-    if (ngpu < n) stage.Reserve((size_t)elems * 2 + 256);
+    if (ngpu < nact) stage.Reserve((size_t)elems * 2 + 256);
     cdev.Reserve((size_t)elems * 2 + 256);
     planes.Reserve((size_t)elems + 256);
     ecs_dev.Reserve(ecs_bytes + table_bytes + 256);
     scratch.Reserve(scratch_bytes + 256);
     status_host.Reserve(sizeof(int32_t) * (size_t)std::max(n, 1));
-    out.Resize(shapes, DALI_UINT8, kImagePitchAlign);
+    out.Resize(shapes, DALI_UINT8, kImagePitchAlign, ext_ptr, ext_pitch, cache_);
     out.SetLayout("HWC");
     out.source_info = in.source_info;
     quant_.assign((size_t)n * 3 * 64, 0);
     // ---- host entropy decode of the streams the GPU kernel does not take (thread pool) ----
     int16_t *coef_host = static_cast<int16_t *>(stage.data());
     for (int i = 0; i < n; i++) {
+      if (hit_[i]) continue;
       if (scans_[i].eligible) {
         for (int c = 0; c < infos_[i].num_components; c++) memcpy(&quant_[(size_t)i * 192 + c * 64], scans_[i].quant[c], 128);
         continue;
@@ -220,8 +274,8 @@ class ImageDecoderMixed : public OperatorBase {
           DALI_FAIL("Failed to decode ", src(i), ": ", daliamdHostGetLastErrorMessage());
       }, (int64_t)in.nbytes(i));
     }
-    if (ngpu < n) ws.GetThreadPool().RunAll();
-    if (n == 0) return;
+    if (ngpu < nact) ws.GetThreadPool().RunAll();
+    if (nact == 0) return;  // empty batch, or every sample came from the cache
     // ---- entropy decoding on the device ----
     int16_t *coef = static_cast<int16_t *>(cdev.data());
     // descriptor tables: built in the pinned staging buffer, addressed on the device at the same offsets
@@ -229,7 +283,7 @@ class ImageDecoderMixed : public OperatorBase {
     const uint8_t *dev_base = static_cast<const uint8_t *>(ecs_dev.data());
     const size_t huff_off = align16(ecs_bytes), idct_off = huff_off + align16((size_t)ngpu * sizeof(daliamdJpegHuffDesc));
     const size_t color_off = idct_off + align16((size_t)ncomp_total * sizeof(daliamdJpegIdctDesc));
-    const size_t upload_bytes = color_off + align16((size_t)n * sizeof(daliamdJpegColorDesc));
+    const size_t upload_bytes = color_off + align16((size_t)nact * sizeof(daliamdJpegColorDesc));
     daliamdJpegHuffDesc *huff = reinterpret_cast<daliamdJpegHuffDesc *>(stage_base + huff_off);
     daliamdJpegIdctDesc *idct = reinterpret_cast<daliamdJpegIdctDesc *>(stage_base + idct_off);
     daliamdJpegColorDesc *color = reinterpret_cast<daliamdJpegColorDesc *>(stage_base + color_off);
@@ -275,7 +329,10 @@ class ImageDecoderMixed : public OperatorBase {
       std::vector<std::string> names(ngpu);
       for (int j = 0; j < ngpu; j++) names[j] = src(gpu_samples_[j]);
       const int32_t *st = status;
-      ws.AddCompletionCheck([st, names] {
+      std::shared_ptr<ImageCache> cache = cache_;
+      ws.AddCompletionCheck([st, names, cache] {
+        for (size_t j = 0; j < names.size(); j++)
+          if (st[j] != 0 && cache) cache->Invalidate(names[j]);  // a slot may hold the broken image
         for (size_t j = 0; j < names.size(); j++)
           if (st[j] != 0)
             DALI_FAIL("Failed to decode ", names[j], ": corrupt JPEG data: the entropy-coded segment ends before the "
@@ -283,10 +340,11 @@ class ImageDecoderMixed : public OperatorBase {
       });
     }
     // ---- dequantisation + IDCT, upsampling + colour conversion: descriptors ----
-    int k = 0;
+    int k = 0, kc = 0;
     for (int i = 0; i < n; i++) {
+      if (hit_[i]) continue;
       const auto &inf = infos_[i];
-      auto &cd = color[i];
+      auto &cd = color[kc++];
       for (int c = 0; c < inf.num_components; c++) {
         auto &d = idct[k++];
         d.coef = coef + coef_off_[i * 3 + c];
@@ -317,7 +375,7 @@ class ImageDecoderMixed : public OperatorBase {
     }
     int wg_idct = 0, wg_color = 0;
     KCHECK(daliamdJpegIdctSetup(idct, ncomp_total, &wg_idct));
-    KCHECK(daliamdJpegColorSetup(color, n, &wg_color));
+    KCHECK(daliamdJpegColorSetup(color, nact, &wg_color));
     // ---- ONE transfer (JPEG bytes + the three tables) on the copy stream: it overlaps the kernels of the previous
     // iteration; the compute stream waits for it through an event ----
     daliamdStream_t cs = ws.copy_stream ? ws.copy_stream : ws.stream;
@@ -334,16 +392,21 @@ class ImageDecoderMixed : public OperatorBase {
     }
     // host-decoded streams (progressive, restart markers, multi-scan, below the threshold): H2D of their coefficients
     for (int i = 0; i < n; i++) {
-      if (scans_[i].eligible) continue;
+      if (scans_[i].eligible || hit_[i]) continue;
       int64_t first = coef_off_[i * 3], count = 0;
       for (int c = 0; c < infos_[i].num_components; c++) count += infos_[i].coef_elems[c];
       KCHECK(daliamdMemcpyH2DAsync(coef + first, coef_host + first, (size_t)count * 2, ws.stream));
     }
     KCHECK(daliamdJpegIdctRun(ws.stream, reinterpret_cast<const daliamdJpegIdctDesc *>(dev_base + idct_off), ncomp_total,
                               wg_idct));
-    KCHECK(daliamdJpegColorRun(ws.stream, reinterpret_cast<const daliamdJpegColorDesc *>(dev_base + color_off), n, wg_color));
+    KCHECK(daliamdJpegColorRun(ws.stream, reinterpret_cast<const daliamdJpegColorDesc *>(dev_base + color_off), nact,
+                               wg_color));
     NoteLaunch(ws, "jpeg_idct");
     NoteLaunch(ws, "jpeg_color");
+    if (cache_) {
+      cache_->Commit(reserved.keys, ws.stream);  // visible to later iterations (and other pipelines) from here on
+      reserved.keys.clear();
+    }
   }
 
  protected:
@@ -353,6 +416,9 @@ class ImageDecoderMixed : public OperatorBase {
 
  private:
   std::vector<daliamdJpegRoiPlan> plans_;
+  std::shared_ptr<ImageCache> cache_;
+  std::vector<uint8_t> hit_;
+  std::vector<ImageCache::Entry> cached_;
   std::vector<daliamdEvent_t> h2d_done_;
   bool adjust_orientation_;
   bool host_huffman_only_ = false;
@@ -385,7 +451,7 @@ DALI_SCHEMA(experimental__decoders__ImageRandomCrop).DocStr("Alias of decoders.i
 
 class ImageDecoderRandomCropMixed : public ImageDecoderMixed {
  public:
-  explicit ImageDecoderRandomCropMixed(const OpSpec &spec) : ImageDecoderMixed(spec) {
+  explicit ImageDecoderRandomCropMixed(const OpSpec &spec) : ImageDecoderMixed(spec, false) {
     auto ar = spec.GetFloatVec("random_aspect_ratio"), area = spec.GetFloatVec("random_area");
     if (ar.size() == 1) ar.push_back(ar[0]);
     if (area.size() == 1) area.push_back(area[0]);
@@ -442,7 +508,7 @@ DALI_SCHEMA(experimental__decoders__ImageCrop).DocStr("Alias of decoders.image_c
 
 class ImageDecoderCropMixed : public ImageDecoderMixed {
  public:
-  explicit ImageDecoderCropMixed(const OpSpec &spec) : ImageDecoderMixed(spec) {
+  explicit ImageDecoderCropMixed(const OpSpec &spec) : ImageDecoderMixed(spec, false) {
     std::string r = spec.GetString("rounding");
     DALI_ENFORCE(r == "round" || r == "truncate", "Unsupported rounding \"", r, "\"");
     round_ = r == "round";

@@ -105,6 +105,20 @@ DALIAMD_HOST_API int daliamdCmnNormArgs(const float *mean, int nmean, const floa
 /* CropAttr::CalculateAnchor (dali/operators/image/crop/crop_attr.cc:224-240) */
 DALIAMD_HOST_API int64_t daliamdCropAnchor(float anchor_norm, int64_t crop, int64_t in, int round_half_away);
 
+/* Bookkeeping of the decoded-image cache of decoders.image (`cache_size`, `cache_type`, `cache_threshold`): which
+ * image is kept and at which offset of the one HBM blob.  Host only - the decoder writes the decoded image at
+ * blob + offset and later hands out that address; no copy on either side.
+ *   type "threshold": ImageCacheBlob::Add     (dali/operators/decoder/cache/image_cache_blob.cc:89-115)
+ *   type "largest":   ImageCacheLargest::Add  (dali/operators/decoder/cache/image_cache_largest.cc:25-89)
+ * Create returns NULL (and sets the host error message) for an unknown type or a threshold above the cache size.
+ * OnDecode registers one decode of `key` (data_size = H*W*C is compared with the threshold; stored_size = bytes taken
+ * in the blob) and returns the offset to store it at, or -1 when it is not kept.  Find: offset of a kept image or -1. */
+DALIAMD_HOST_API void *daliamdImageCachePolicyCreate(const char *type, uint64_t cache_size, uint64_t threshold);
+DALIAMD_HOST_API void daliamdImageCachePolicyDestroy(void *policy);
+DALIAMD_HOST_API int64_t daliamdImageCachePolicyOnDecode(void *policy, const char *key, uint64_t data_size,
+                                                         uint64_t stored_size);
+DALIAMD_HOST_API int64_t daliamdImageCachePolicyFind(void *policy, const char *key);
+
 #ifdef __cplusplus
 }
 #endif

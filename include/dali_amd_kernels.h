@@ -62,6 +62,8 @@ DALIAMD_API daliamdResult_t daliamdEventCreate(daliamdEvent_t *event, int enable
 DALIAMD_API daliamdResult_t daliamdEventDestroy(daliamdEvent_t event);
 DALIAMD_API daliamdResult_t daliamdEventRecord(daliamdEvent_t event, daliamdStream_t stream);
 DALIAMD_API daliamdResult_t daliamdEventSynchronize(daliamdEvent_t event);
+/* *done = 1 when all work captured by the last record of `event` has finished, 0 otherwise (never blocks) */
+DALIAMD_API daliamdResult_t daliamdEventQuery(daliamdEvent_t event, int *done);
 DALIAMD_API daliamdResult_t daliamdEventElapsedMs(daliamdEvent_t start, daliamdEvent_t stop, float *ms);
 DALIAMD_API daliamdResult_t daliamdMalloc(void **ptr, size_t bytes);
 DALIAMD_API daliamdResult_t daliamdFree(void *ptr);
