@@ -111,8 +111,33 @@ struct HuffTables {
 };
 static_assert(sizeof(HuffTables) % 16 == 0, "copied with 16-byte accesses");
 
+// Tables of the position-only passes (SyncKernel / PropagateKernel).  They do not extract values, so one look-up may
+// step over TWO symbols: a 32-bit entry holds, for the kFastBits-bit window,
+//   bits 16-29  the first symbol alone:      z advance (7 bits) | bits used << 7 (5 bits) | 1 << 12 (symbol count)
+//   bits  0-13  first + second symbol:       same fields summed (count 2); a copy of the upper half when the window
+//                                            holds no second symbol
+// A second symbol exists for AC tables only, when the first one is not an end-of-block and the CODE of the second lies
+// inside the window behind the first symbol's bits (its magnitude bits need not).  Whether the pair may be taken is
+// decided per step: the first symbol must not complete the block and the second must start inside the slice.
+// On the ImageNet-like bench set 64 % of the steps take a pair (tools/sync_sim.cpp): 0.61x the steps.
+struct SyncTables {
+  uint32_t t32[4][1 << kFastBits];   // [0],[1] = DC tables 0,1; [2],[3] = AC tables 0,1; 0 = code longer than the window
+  uint16_t l2[4][kL2Entries];
+  int32_t l2_first[4];
+  int32_t l2_size[4];
+  int32_t maxcode[4][18];
+  int32_t valoff[4][18];
+  uint8_t vals[4][256];
+  uint32_t dc_mask, ac_mask;
+  int32_t bpm, reserved;
+};
+static_assert(sizeof(SyncTables) % 16 == 0, "copied with 16-byte accesses");
+__host__ __device__ __forceinline__ uint32_t SyncHalf(uint32_t z, uint32_t used, uint32_t count) {
+  return z | (used << 7) | (count << 12);
+}
+
 struct ScratchLayout {
-  size_t tile_kept, clean, tables, lanes, segs, records, blocks, total;
+  size_t tile_kept, clean, tables, sync_tables, lanes, segs, records, blocks, total;
 };
 __host__ __device__ inline size_t AlignUp(size_t v, size_t a) { return (v + a - 1) / a * a; }
 __host__ __device__ inline ScratchLayout MakeLayout(int ecs_len, int num_tiles, int num_segments, int total_blocks) {
@@ -124,6 +149,8 @@ __host__ __device__ inline ScratchLayout MakeLayout(int ecs_len, int num_tiles, 
   o += AlignUp((size_t)ecs_len + 64, 16);
   l.tables = o;
   o += sizeof(HuffTables);
+  l.sync_tables = o;
+  o += sizeof(SyncTables);
   l.lanes = o;
   o += sizeof(LaneRec) * (size_t)num_segments * kSegLanes;
   l.segs = o;
@@ -282,11 +309,11 @@ __device__ __constant__ uint8_t kZigZagColMajor[64] = {
     28, 21, 14, 7, 15, 22, 29, 36, 43, 50, 57, 58, 51, 44, 37, 30, 23, 31, 38, 45, 52, 59, 60, 53, 46, 39, 47, 54, 61, 62,
     55, 63};
 
-template <int THREADS>
-__device__ __forceinline__ void CopyTables(HuffTables &dst, const HuffTables *src) {
+template <int THREADS, typename Tables>
+__device__ __forceinline__ void CopyTables(Tables &dst, const Tables *src) {
   const uint4 *s = reinterpret_cast<const uint4 *>(src);
   uint4 *t = reinterpret_cast<uint4 *>(&dst);
-  for (int i = threadIdx.x; i < (int)(sizeof(HuffTables) / 16); i += THREADS) t[i] = s[i];
+  for (int i = threadIdx.x; i < (int)(sizeof(Tables) / 16); i += THREADS) t[i] = s[i];
 }
 
 __global__ __launch_bounds__(256) void BuildTablesKernel(const daliamdJpegHuffDesc *__restrict__ descs) {
@@ -393,6 +420,41 @@ __global__ __launch_bounds__(256) void BuildTablesKernel(const daliamdJpegHuffDe
   const uint4 *s = reinterpret_cast<const uint4 *>(&L);
   uint4 *t = reinterpret_cast<uint4 *>(d.scratch + lay.tables);
   for (int i = tid; i < (int)(sizeof(HuffTables) / 16); i += 256) t[i] = s[i];
+  // ---- tables of the position-only passes, straight to global memory ----
+  SyncTables *S = reinterpret_cast<SyncTables *>(d.scratch + lay.sync_tables);
+  for (int idx = tid; idx < 4 * (1 << kFastBits); idx += 256) {
+    const int tb = idx >> kFastBits, w = idx & ((1 << kFastBits) - 1);
+    const uint32_t e1 = L.fast[tb][w];
+    uint32_t e = 0;
+    if (e1) {
+      const uint32_t z1 = e1 & 127, u1 = (e1 >> 7) & 31;
+      const uint32_t one = SyncHalf(z1, u1, 1);
+      uint32_t both = one;
+      if (tb >= 2 && z1 < 64 && u1 < (uint32_t)kFastBits) {
+        const uint32_t e2 = L.fast[tb][(w << u1) & ((1 << kFastBits) - 1)];
+        const uint32_t z2 = e2 & 127, u2 = (e2 >> 7) & 31, len2 = u2 - (e2 >> 12);
+        if (e2 && u1 + len2 <= (uint32_t)kFastBits) both = SyncHalf(z1 + z2, u1 + u2, 2);
+      }
+      e = (one << 16) | both;
+    }
+    S->t32[tb][w] = e;
+  }
+  for (int i = tid; i < 4 * kL2Entries; i += 256) S->l2[i / kL2Entries][i % kL2Entries] = L.l2[i / kL2Entries][i % kL2Entries];
+  for (int i = tid; i < 4 * 256; i += 256) S->vals[i >> 8][i & 255] = L.vals[i >> 8][i & 255];
+  if (tid < 4 * 18) {
+    S->maxcode[tid / 18][tid % 18] = L.maxcode[tid / 18][tid % 18];
+    S->valoff[tid / 18][tid % 18] = L.valoff[tid / 18][tid % 18];
+  }
+  if (tid < 4) {
+    S->l2_first[tid] = L.l2_first[tid];
+    S->l2_size[tid] = L.l2_size[tid];
+  }
+  if (tid == 0) {
+    S->dc_mask = L.dc_mask;
+    S->ac_mask = L.ac_mask;
+    S->bpm = L.bpm;
+    S->reserved = 0;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ decode
@@ -414,7 +476,8 @@ struct DcAcc {
 };
 
 // Rare path: the code is longer than kFastBits bits (or is not a code at all).
-__device__ __forceinline__ uint32_t LongCode(const HuffTables &L, uint32_t slot, uint32_t peek, bool is_dc) {
+template <typename Tables>
+__device__ __forceinline__ uint32_t LongCode(const Tables &L, uint32_t slot, uint32_t peek, bool is_dc) {
   const uint32_t code16 = peek >> 16;
   uint32_t e = 0;
   const int size = L.l2_size[slot];
@@ -436,7 +499,7 @@ __device__ __forceinline__ uint32_t LongCode(const HuffTables &L, uint32_t slot,
 
 // Decodes the symbols that start in [st.pos, end_bits); returns the number of blocks completed.  Positions only:
 // no value is extracted (synchronisation passes).
-__device__ __forceinline__ int DecodeRange(const HuffTables &L, GlobalWords *__restrict__ words, DecodeState &st,
+__device__ __forceinline__ int DecodeRange(const SyncTables &L, GlobalWords *__restrict__ words, DecodeState &st,
                                            uint32_t end_bits, int &nsym_out) {
   int nblk = 0, nsym = 0;
   uint32_t c = st.c, z = st.z;
@@ -445,19 +508,27 @@ __device__ __forceinline__ int DecodeRange(const HuffTables &L, GlobalWords *__r
   int k = (int)(st.pos >> 5);
   uint32_t off = st.pos & 31;
   uint32_t hi = __builtin_bswap32(words[k]), lo = __builtin_bswap32(words[k + 1]), nxt = words[k + 2];
-  const uint16_t *fast = &L.fast[0][0];
+  const uint32_t *t32 = &L.t32[0][0];
   const uint32_t dc_mask = L.dc_mask, ac_mask = L.ac_mask, bpm = (uint32_t)L.bpm;
   while (rem > 0) {
     const uint32_t peek = (uint32_t)(((((uint64_t)hi << 32) | lo) << off) >> 32);
     const bool is_dc = z == 0;
     const uint32_t slot = (((is_dc ? dc_mask : ac_mask) >> c) & 1u) + (is_dc ? 0u : 2u);
-    uint32_t e = fast[(slot << kFastBits) + (peek >> (32 - kFastBits))];
-    if (__builtin_expect(e == 0, 0)) e = LongCode(L, slot, peek, is_dc);
-    const uint32_t used = (e >> 7) & 31;
+    uint32_t e = t32[(slot << kFastBits) + (peek >> (32 - kFastBits))];
+    if (__builtin_expect(e == 0, 0)) {
+      const uint32_t e16 = LongCode(L, slot, peek, is_dc);
+      e = SyncHalf(e16 & 127, (e16 >> 7) & 31, 1) * 0x10001u;
+    }
+    // the pair may be taken when the first symbol leaves the block open and the second one starts inside the slice:
+    // both differences negative <=> the sign bit of their AND is set
+    const int first_z = (int)((e >> 16) & 127), first_used = (int)((e >> 23) & 31);
+    const int ok = ((int)z + first_z - 64) & (first_used - rem);
+    const uint32_t f = ok < 0 ? e : e >> 16;
+    const uint32_t used = (f >> 7) & 31;
     rem -= (int)used;
     off += used;
-    z += e & 127;
-    nsym++;
+    z += f & 127;
+    nsym += (int)((f >> 12) & 3);
     if (off >= 32) {
       hi = lo;
       lo = __builtin_bswap32(nxt);
@@ -634,7 +705,7 @@ struct Lane {
 // never written here, so whatever the caller put there is taken as the truth; each round fixes at least one more
 // lane, which bounds the loop by the lane count.
 template <int THREADS>
-__device__ __forceinline__ void Relax(const HuffTables &L, GlobalWords *words, uint64_t *state, Lane &ln) {
+__device__ __forceinline__ void Relax(const SyncTables &L, GlobalWords *words, uint64_t *state, Lane &ln) {
   const int tid = threadIdx.x;
   for (int round = 0; round <= THREADS; round++) {
     const uint64_t ni = state[tid];
@@ -670,7 +741,7 @@ __device__ __forceinline__ Lane MakeLane(long long slice_index, uint32_t total_b
 }
 
 __global__ __launch_bounds__(kSegThreads) void SyncKernel(const daliamdJpegHuffDesc *__restrict__ descs, int n, int nseg) {
-  __shared__ __attribute__((aligned(16))) HuffTables L;
+  __shared__ __attribute__((aligned(16))) SyncTables L;
   __shared__ uint64_t state[kSegThreads];
   __shared__ int wave_sums[kSegThreads / 64];
   const int wg = XcdRemap(blockIdx.x, nseg);
@@ -687,7 +758,7 @@ __global__ __launch_bounds__(kSegThreads) void SyncKernel(const daliamdJpegHuffD
     if (tid == 0) *segrec = SegRec{kNoState, 0, 0, 0, 0, {0, 0, 0}, 0};
     return;
   }
-  CopyTables<kSegThreads>(L, reinterpret_cast<const HuffTables *>(d.scratch + lay.tables));
+  CopyTables<kSegThreads>(L, reinterpret_cast<const SyncTables *>(d.scratch + lay.sync_tables));
   const uint32_t total_bits = (uint32_t)clean_len * 8u;
   // lanes [0, kWarmLanes) replay the last slices of the previous segment, lanes [kWarmLanes, ..) are this segment's
   Lane ln = MakeLane((long long)seg * kSegLanes + tid - kWarmLanes, total_bits);
@@ -707,7 +778,7 @@ __global__ __launch_bounds__(kSegThreads) void SyncKernel(const daliamdJpegHuffD
 }
 
 __global__ __launch_bounds__(kSegThreads) void PropagateKernel(const daliamdJpegHuffDesc *__restrict__ descs) {
-  __shared__ __attribute__((aligned(16))) HuffTables L;
+  __shared__ __attribute__((aligned(16))) SyncTables L;
   __shared__ uint64_t state[kSegThreads];
   __shared__ int wave_sums[kSegThreads / 64];
   const daliamdJpegHuffDesc &d = descs[blockIdx.x];
@@ -733,7 +804,7 @@ __global__ __launch_bounds__(kSegThreads) void PropagateKernel(const daliamdJpeg
     if (total_bits != 0 && recs[0].in != truth) {
       // The warm-up lanes did not synchronise before this segment (long flat or periodic content): repair it.
       if (!tables_loaded) {
-        CopyTables<kSegThreads>(L, reinterpret_cast<const HuffTables *>(d.scratch + lay.tables));
+        CopyTables<kSegThreads>(L, reinterpret_cast<const SyncTables *>(d.scratch + lay.sync_tables));
         tables_loaded = true;
       }
       Lane ln = MakeLane(tid < kSegLanes ? (long long)seg * kSegLanes + tid : -1, total_bits);

@@ -1,0 +1,213 @@
+// Host-side model of the GPU entropy decoder's synchronisation pass (dali_amd/csrc/jpeg_huffman.hip: DecodeRange /
+// Relax / SyncKernel).  Development tool only: it replays the relaxation on real streams and reports, per workgroup,
+// the number of rounds and the length of the critical path (sum over rounds of the longest re-decode), so that slice
+// sizes / table shapes / start guesses can be compared without GPU time.
+//
+//   g++ -O2 -std=c++17 -Iinclude tools/sync_sim.cpp -Ldali_amd/lib -ldali_amd_host -Wl,-rpath,$PWD/dali_amd/lib -o /tmp/sync_sim
+//   /tmp/sync_sim DIR [slice_bytes=256] [seg_threads=128] [warm=12] [pair_bits=0]
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <dirent.h>
+#include <string>
+#include <vector>
+
+#include "dali_amd_host.h"
+
+struct State { uint32_t pos, c, z; bool operator==(const State &o) const { return pos == o.pos && c == o.c && z == o.z; } };
+
+static uint32_t MakeEntry(int len, int sym, bool is_dc) {
+  int s = sym & 15, r = sym >> 4;
+  int adv = is_dc ? 1 : (s ? r + 1 : (r == 15 ? 16 : 64));
+  return (uint32_t)((s << 12) | ((len + s) << 7) | adv);
+}
+
+struct Image {
+  std::vector<uint8_t> clean;
+  std::vector<uint16_t> tab[4];  // direct 16-bit tables: slots dc0, dc1, ac0, ac1
+  uint32_t dc_mask = 0, ac_mask = 0, bpm = 1;
+  uint32_t total_bits = 0;
+  // pair tables (pair_bits > 0): index = next pair_bits bits; fields of up to two symbols of the SAME ac table
+  struct Pair { uint8_t adv1, z1, adv12, z12, n; };
+  std::vector<Pair> pair[2];
+};
+
+static void BuildTable(std::vector<uint16_t> &t, const uint8_t *bits, const uint8_t *vals, bool is_dc) {
+  t.assign(65536, (uint16_t)MakeEntry(16, 0, is_dc));
+  int code = 0, k = 0;
+  for (int l = 1; l <= 16; l++) {
+    for (int i = 0; i < bits[l - 1]; i++, k++, code++) {
+      uint16_t e = (uint16_t)MakeEntry(l, vals[k], is_dc);
+      int first = code << (16 - l), count = 1 << (16 - l);
+      for (int j = 0; j < count; j++) t[first + j] = e;
+    }
+    code <<= 1;
+  }
+}
+
+static inline uint32_t Peek16(const Image &im, uint32_t pos) {
+  size_t b = pos >> 3;
+  uint32_t w = ((uint32_t)im.clean[b] << 24) | ((uint32_t)im.clean[b + 1] << 16) | ((uint32_t)im.clean[b + 2] << 8) | im.clean[b + 3];
+  return (w << (pos & 7)) >> 16;
+}
+
+static int g_pair_bits = 0;
+
+// mirrors DecodeRange: symbols that START in [st.pos, end)
+static int Decode(const Image &im, State &st, uint32_t end, int &nsym, int &steps) {
+  int nblk = 0;
+  nsym = 0; steps = 0;
+  uint32_t pos = st.pos, c = st.c, z = st.z;
+  while ((int)(end - pos) > 0) {
+    const bool is_dc = z == 0;
+    const uint32_t slot = (((is_dc ? im.dc_mask : im.ac_mask) >> c) & 1u) + (is_dc ? 0u : 2u);
+    uint32_t peek = Peek16(im, pos);
+    uint32_t used, zinc;
+    int n = 1;
+    if (g_pair_bits && !is_dc) {
+      const Image::Pair &p = im.pair[slot - 2][peek >> (16 - g_pair_bits)];
+      if (p.n == 2 && (int)p.adv1 < (int)(end - pos) && z + p.z1 < 64) { used = p.adv12; zinc = p.z12; n = 2; }
+      else if (p.n >= 1) { used = p.adv1; zinc = p.z1; }
+      else { uint32_t e = im.tab[slot][peek]; used = (e >> 7) & 31; zinc = e & 127; }
+    } else {
+      uint32_t e = im.tab[slot][peek];
+      used = (e >> 7) & 31; zinc = e & 127;
+    }
+    pos += used; z += zinc; nsym += n; steps++;
+    if (z >= 64) { z = 0; c = c + 1 == im.bpm ? 0 : c + 1; nblk++; }
+  }
+  st.pos = pos; st.c = c; st.z = z;
+  return nblk;
+}
+
+static bool Load(const std::string &path, Image &im) {
+  FILE *f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  std::vector<uint8_t> data;
+  uint8_t buf[65536];
+  size_t n;
+  while ((n = fread(buf, 1, sizeof buf, f)) > 0) data.insert(data.end(), buf, buf + n);
+  fclose(f);
+  daliamdJpegInfo info;
+  daliamdJpegScan sc;
+  if (daliamdJpegParse(data.data(), data.size(), &info) != 0) return false;
+  if (daliamdJpegAnalyzeScan(data.data(), data.size(), &info, &sc) != 0 || !sc.eligible) return false;
+  const uint8_t *p = data.data() + sc.ecs_offset;
+  for (int64_t i = 0; i < sc.ecs_length; i++) {
+    im.clean.push_back(p[i]);
+    if (p[i] == 0xFF && i + 1 < sc.ecs_length && p[i + 1] == 0) i++;
+  }
+  im.total_bits = (uint32_t)im.clean.size() * 8;
+  im.clean.resize(im.clean.size() + 64, 0);
+  im.bpm = sc.blocks_per_mcu;
+  for (int k = 0; k < sc.blocks_per_mcu; k++) {
+    int comp = sc.comp_of_block[k];
+    im.dc_mask |= (uint32_t)(sc.dc_sel[comp] & 1) << k;
+    im.ac_mask |= (uint32_t)(sc.ac_sel[comp] & 1) << k;
+  }
+  for (int t = 0; t < 2; t++) {
+    BuildTable(im.tab[t], sc.dc_bits[t], sc.dc_vals[t], true);
+    BuildTable(im.tab[2 + t], sc.ac_bits[t], sc.ac_vals[t], false);
+  }
+  if (g_pair_bits) {
+    const int B = g_pair_bits;
+    for (int t = 0; t < 2; t++) {
+      im.pair[t].assign(1u << B, Image::Pair{0, 0, 0, 0, 0});
+      for (uint32_t w = 0; w < (1u << B); w++) {
+        Image::Pair &q = im.pair[t][w];
+        uint32_t e1 = im.tab[2 + t][(w << (16 - B)) & 0xFFFF];
+        int u1 = (e1 >> 7) & 31, z1 = e1 & 127, s1 = (e1 >> 12) & 15;
+        if (u1 - s1 > B) continue;  // the CODE must be inside the index (the magnitude bits need not be)
+        q.adv1 = u1; q.z1 = z1; q.n = 1;
+        if (z1 >= 64 || u1 >= B) continue;  // EOB: the block ends
+        uint32_t rest = (w << u1) & ((1u << B) - 1);
+        uint32_t e2 = im.tab[2 + t][(rest << (16 - B)) & 0xFFFF];
+        int u2 = (e2 >> 7) & 31, z2 = e2 & 127, s2 = (e2 >> 12) & 15;
+        if (u1 + (u2 - s2) > B) continue;  // second code not fully determined by the index bits
+        q.adv12 = u1 + u2; q.z12 = std::min(z1 + z2, 64 + 63); q.n = 2;
+      }
+    }
+  }
+  return true;
+}
+
+int main(int argc, char **argv) {
+  if (argc < 2) return 1;
+  const int slice = argc > 2 ? atoi(argv[2]) : 256, T = argc > 3 ? atoi(argv[3]) : 128, warm = argc > 4 ? atoi(argv[4]) : 12;
+  g_pair_bits = argc > 5 ? atoi(argv[5]) : 0;
+  const int seg_lanes = T - warm;
+  std::vector<std::string> files;
+  DIR *dp = opendir(argv[1]);
+  while (dirent *e = readdir(dp)) if (strstr(e->d_name, ".jpg")) files.push_back(std::string(argv[1]) + "/" + e->d_name);
+  closedir(dp);
+  std::sort(files.begin(), files.end());
+  std::vector<long> wg_path, wg_rounds;
+  long total_steps = 0, total_syms = 0, ideal_syms = 0, busy_wave_steps = 0;
+  for (auto &fn : files) {
+    Image im;
+    if (!Load(fn, im)) { fprintf(stderr, "skip %s\n", fn.c_str()); continue; }
+    const long nslices = (im.total_bits / 8 + slice - 1) / slice;
+    const long nseg = std::max<long>(1, (nslices + seg_lanes - 1) / seg_lanes);
+    for (long seg = 0; seg < nseg; seg++) {
+      struct L { uint32_t begin, end; bool active; State in, out; bool has_in; int nsym, steps; };
+      std::vector<L> ln(T);
+      std::vector<State> state(T);
+      for (int t = 0; t < T; t++) {
+        long si = seg * seg_lanes + t - warm;
+        L &l = ln[t];
+        l.has_in = false;
+        if (si < 0) { l.begin = l.end = 0; l.active = false; }
+        else {
+          unsigned long long b = (unsigned long long)si * slice * 8ull;
+          l.begin = (uint32_t)std::min<unsigned long long>(b, im.total_bits);
+          l.end = (uint32_t)std::min<unsigned long long>(b + slice * 8ull, im.total_bits);
+          l.active = l.begin < im.total_bits;
+        }
+        state[t] = State{l.begin, 0, 0};
+        l.nsym = l.steps = 0;
+      }
+      long path = 0, rounds = 0;
+      for (int round = 0; round <= T; round++) {
+        long wave_max[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        bool any = false;
+        for (int t = 0; t < T; t++) {
+          L &l = ln[t];
+          if (l.active && !(l.has_in && l.in == state[t])) {
+            l.in = state[t]; l.has_in = true;
+            State st = l.in;
+            l.nsym = l.steps = 0;
+            if (st.pos < l.end) Decode(im, st, l.end, l.nsym, l.steps);
+            l.out = st;
+            wave_max[t / 64] = std::max<long>(wave_max[t / 64], l.steps);
+            total_steps += l.steps; total_syms += l.nsym;
+            any = true;
+          }
+        }
+        long m = 0;
+        for (int w = 0; w < T / 64; w++) { m = std::max(m, wave_max[w]); busy_wave_steps += wave_max[w]; }
+        path += m;
+        if (any) rounds++;
+        bool changed = false;
+        for (int t = 0; t + 1 < T; t++)
+          if (ln[t].active && !(state[t + 1] == ln[t].out)) { state[t + 1] = ln[t].out; changed = true; }
+        if (!changed) break;
+      }
+      for (int t = warm; t < T; t++) ideal_syms += ln[t].nsym;
+      wg_path.push_back(path);
+      wg_rounds.push_back(rounds);
+    }
+  }
+  std::sort(wg_path.begin(), wg_path.end());
+  std::sort(wg_rounds.begin(), wg_rounds.end());
+  auto pct = [&](std::vector<long> &v, double p) { return v[(size_t)std::min<double>(v.size() - 1, p * v.size())]; };
+  double mean_path = 0; for (long p : wg_path) mean_path += p; mean_path /= wg_path.size();
+  printf("slice %d  threads %d  warm %d  pair_bits %d\n", slice, T, warm, g_pair_bits);
+  printf("workgroups %zu   symbols (final states) %ld   decoded symbol-executions %ld (x%.2f)  lane-steps %ld\n", wg_path.size(),
+         ideal_syms, total_syms, (double)total_syms / ideal_syms, total_steps);
+  printf("rounds: p50 %ld p90 %ld p99 %ld max %ld\n", pct(wg_rounds, .5), pct(wg_rounds, .9), pct(wg_rounds, .99), wg_rounds.back());
+  printf("critical path (steps): mean %.0f p50 %ld p90 %ld p99 %ld max %ld   wave-steps total %ld\n", mean_path, pct(wg_path, .5),
+         pct(wg_path, .9), pct(wg_path, .99), wg_path.back(), busy_wave_steps);
+  return 0;
+}
