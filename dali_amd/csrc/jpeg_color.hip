@@ -16,9 +16,19 @@
 
 namespace daliamd {
 
+// Explicit global address space: the pointers come out of a descriptor in memory, and the generic ("flat") accesses
+// the compiler would otherwise emit are slower and tie up the LDS counter as well.
+using GBytes = const uint8_t __attribute__((address_space(1)));
+using GWords = const uint32_t __attribute__((address_space(1)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+using GPair = const u32x2 __attribute__((address_space(1)));
+using GOutBytes = uint8_t __attribute__((address_space(1)));
+using GOutPair = u32x2 __attribute__((address_space(1)));
+
 constexpr int kColorThreads = 256;
 constexpr int kTileW = 256;  // pixels
-constexpr int kTileH = 8;
+constexpr int kRowsPerThread = 4;  // consecutive rows per thread: the per-image set-up is paid once for all of them
+constexpr int kTileH = 8 * kRowsPerThread;
 
 #define SCALEBITS 16
 #define ONE_HALF (1 << (SCALEBITS - 1))
@@ -49,14 +59,34 @@ __device__ __forceinline__ void TriangleX8(const int sv[7], bool odd, int out[8]
   }
 }
 
+// Samples k0-1 .. k0+5 of one row with three dword loads instead of seven byte loads (k0 and the row start are
+// multiples of 4; rows are padded to 8-sample blocks, so the dword behind k0 is inside the row unless k0 is its last
+// dword - then the samples it would hold are beyond the component anyway and ClampRight7 replaces them).
+// The left neighbour of sample 0 is sample 0.
+__device__ __forceinline__ void LoadSamples7(GBytes *__restrict__ row, int pitch, int k0, int s[7]) {
+  const uint32_t a = *reinterpret_cast<GWords *>(row + max(k0 - 4, 0));
+  const uint32_t b = *reinterpret_cast<GWords *>(row + k0);
+  const uint32_t c = *reinterpret_cast<GWords *>(row + min(k0 + 4, pitch - 4));
+  s[0] = k0 ? (int)(a >> 24) : (int)(b & 255);
+  s[1] = (int)(b & 255); s[2] = (int)((b >> 8) & 255); s[3] = (int)((b >> 16) & 255); s[4] = (int)(b >> 24);
+  s[5] = (int)(c & 255); s[6] = (int)((c >> 8) & 255);
+}
+// Neighbour indices are clamped to the last sample dw-1 (>= k0): every later entry repeats its predecessor.
+__device__ __forceinline__ void ClampRight7(int s[7], int k0, int dw) {
+  if (k0 + 5 > dw - 1) {
+#pragma unroll
+    for (int i = 2; i < 7; i++) s[i] = k0 - 1 + i > dw - 1 ? s[i - 1] : s[i];
+  }
+}
+
 // Fetches the 8 upsampled samples of one component for pixels x0..x0+7 of output row y (any x0: with a region of
 // interest the 8-pixel groups are aligned to the region, not to the image).
-__device__ __forceinline__ void UpsampleRow8(const uint8_t *__restrict__ plane, int pitch, int mode, int hx,
+__device__ __forceinline__ void UpsampleRow8(GBytes *__restrict__ plane, int pitch, int mode, int hx,
                                              int vx, int dw, int dh, int x0, int y, int out[8]) {
   if (mode == kFull) {
-    const uint8_t *p = plane + (size_t)y * pitch;
+    GBytes *p = plane + (size_t)y * pitch;
     if ((x0 & 7) == 0) {
-      uint2 v = *reinterpret_cast<const uint2 *>(p + x0);  // planes are padded to 8-sample blocks
+      u32x2 v = *reinterpret_cast<GPair *>(p + x0);  // planes are padded to 8-sample blocks
 #pragma unroll
       for (int i = 0; i < 4; i++) { out[i] = (v.x >> (8 * i)) & 255; out[4 + i] = (v.y >> (8 * i)) & 255; }
     } else {
@@ -64,36 +94,50 @@ __device__ __forceinline__ void UpsampleRow8(const uint8_t *__restrict__ plane, 
       for (int i = 0; i < 8; i++) out[i] = p[min(x0 + i, pitch - 1)];
     }
   } else if (mode == kH2V1) {
-    const uint8_t *p = plane + (size_t)y * pitch;
+    GBytes *p = plane + (size_t)y * pitch;
     int k0 = x0 >> 1;
     int s[7];
+    if (((k0 | pitch) & 3) == 0 && (reinterpret_cast<uintptr_t>(plane) & 3) == 0) {
+      LoadSamples7(p, pitch, k0, s);
+      ClampRight7(s, k0, dw);
+    } else {
 #pragma unroll
-    for (int i = 0; i < 7; i++) s[i] = p[ClampI(k0 - 1 + i, 0, dw - 1)];
+      for (int i = 0; i < 7; i++) s[i] = p[ClampI(k0 - 1 + i, 0, dw - 1)];
+    }
     TriangleX8<2, 1, 2>(s, x0 & 1, out);
   } else if (mode == kH2V2) {
     int r = y >> 1;
     int r1 = ClampI((y & 1) ? r + 1 : r - 1, 0, dh - 1);
-    const uint8_t *p0 = plane + (size_t)r * pitch, *p1 = plane + (size_t)r1 * pitch;
+    GBytes *p0 = plane + (size_t)r * pitch, *p1 = plane + (size_t)r1 * pitch;
     int k0 = x0 >> 1;
     int s[7];
+    if (((k0 | pitch) & 3) == 0 && (reinterpret_cast<uintptr_t>(plane) & 3) == 0) {
+      int a[7], b[7];
+      LoadSamples7(p0, pitch, k0, a);
+      LoadSamples7(p1, pitch, k0, b);
 #pragma unroll
-    for (int i = 0; i < 7; i++) {
-      int k = ClampI(k0 - 1 + i, 0, dw - 1);
-      s[i] = p0[k] * 3 + p1[k];
+      for (int i = 0; i < 7; i++) s[i] = a[i] * 3 + b[i];
+      ClampRight7(s, k0, dw);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 7; i++) {
+        int k = ClampI(k0 - 1 + i, 0, dw - 1);
+        s[i] = p0[k] * 3 + p1[k];
+      }
     }
     TriangleX8<4, 8, 7>(s, x0 & 1, out);
   } else if (mode == kH1V2) {
     int r = y >> 1;
     int r1 = ClampI((y & 1) ? r + 1 : r - 1, 0, dh - 1);
     int bias = (y & 1) ? 2 : 1;
-    const uint8_t *p0 = plane + (size_t)r * pitch, *p1 = plane + (size_t)r1 * pitch;
+    GBytes *p0 = plane + (size_t)r * pitch, *p1 = plane + (size_t)r1 * pitch;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
       int x = min(x0 + i, pitch - 1);
       out[i] = (p0[x] * 3 + p1[x] + bias) >> 2;
     }
   } else {
-    const uint8_t *p = plane + (size_t)(y / vx) * pitch;
+    GBytes *p = plane + (size_t)(y / vx) * pitch;
 #pragma unroll
     for (int i = 0; i < 8; i++) out[i] = p[min((x0 + i) / hx, pitch - 1)];
   }
@@ -106,6 +150,83 @@ __device__ __forceinline__ int ModeOf(const daliamdJpegColorDesc &d, int c, int 
   if (h == hmax && v * 2 == vmax) return kH1V2;
   if (h * 2 == hmax && v * 2 == vmax && d.down_w[c] > 2) return kH2V2;
   return kBox;
+}
+
+// ---- the common case in one piece: YCbCr 4:2:0 (luma full, both chroma planes h2v2), 8-pixel groups aligned to the
+// planes, upright output.  A thread produces 8 x 4 pixels; the four output rows y0..y0+3 (y0 even) need the chroma rows
+// r-1 .. r+2 (r = y0/2).  ALL loads of the thread (8 luma + 24 chroma dwords) are issued before the first use, so one
+// memory round trip covers four rows (the row-by-row form cannot overlap them: the stores may alias the planes).
+__device__ __forceinline__ void Chroma7(uint32_t a, uint32_t b, uint32_t c, bool first, int s[7]) {
+  s[0] = first ? (int)(b & 255) : (int)(a >> 24);
+  s[1] = (int)(b & 255); s[2] = (int)((b >> 8) & 255); s[3] = (int)((b >> 16) & 255); s[4] = (int)(b >> 24);
+  s[5] = (int)(c & 255); s[6] = (int)((c >> 8) & 255);
+}
+__device__ __forceinline__ void ColorRows420(const daliamdJpegColorDesc &d, int x0, int y0, int rx1, int ry1, int out_x0,
+                                             int out_y0) {
+  const int k0 = x0 >> 1, r = y0 >> 1;
+  uint32_t ca[2][4], cb[2][4], cc[2][4];  // [component][chroma row r-1+j]: dwords left of / at / right of k0
+  u32x2 luma[4];
+#pragma unroll
+  for (int c = 0; c < 2; c++) {
+    GBytes *plane = (GBytes *)d.plane[1 + c];
+    const int pitch = d.pitch[1 + c], dh = d.down_h[1 + c];
+    const int ka = max(k0 - 4, 0), kc = min(k0 + 4, pitch - 4);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      GBytes *row = plane + (size_t)ClampI(r - 1 + j, 0, dh - 1) * pitch;
+      ca[c][j] = *reinterpret_cast<GWords *>(row + ka);
+      cb[c][j] = *reinterpret_cast<GWords *>(row + k0);
+      cc[c][j] = *reinterpret_cast<GWords *>(row + kc);
+    }
+  }
+  {
+    GBytes *plane = (GBytes *)d.plane[0];
+    const int pitch = d.pitch[0];
+#pragma unroll
+    for (int j = 0; j < 4; j++) luma[j] = *reinterpret_cast<GPair *>(plane + (size_t)min(y0 + j, ry1 - 1) * pitch + x0);
+  }
+  const int npx = min(8, rx1 - x0);
+  const int dw1 = d.down_w[1], dw2 = d.down_w[2];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int y = y0 + j;
+    if (y >= ry1) break;
+    // output row y0+j: nearer chroma row r + (j >> 1), further one r - 1 (j = 0), r + 1 (j = 1), r (j = 2), r + 2 (j = 3)
+    const int near = 1 + (j >> 1), far = j == 0 ? 0 : j == 1 ? 2 : j == 2 ? 1 : 3;
+    int up[2][8];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      int n7[7], f7[7], s[7];
+      Chroma7(ca[c][near], cb[c][near], cc[c][near], k0 == 0, n7);
+      Chroma7(ca[c][far], cb[c][far], cc[c][far], k0 == 0, f7);
+#pragma unroll
+      for (int i = 0; i < 7; i++) s[i] = n7[i] * 3 + f7[i];
+      ClampRight7(s, k0, c == 0 ? dw1 : dw2);
+      TriangleX8<4, 8, 7>(s, false, up[c]);
+    }
+    uint32_t px[24];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int yy = (int)(((i < 4 ? luma[j].x : luma[j].y) >> (8 * (i & 3))) & 255);
+      const int u = up[0][i] - 128, v = up[1][i] - 128;
+      const int rr = yy + ((FIXC(1.40200) * v + ONE_HALF) >> SCALEBITS);
+      const int gg = yy + (((-FIXC(0.34414)) * u + ONE_HALF + (-FIXC(0.71414)) * v) >> SCALEBITS);
+      const int bb = yy + ((FIXC(1.77200) * u + ONE_HALF) >> SCALEBITS);
+      px[3 * i] = Clamp8(rr); px[3 * i + 1] = Clamp8(gg); px[3 * i + 2] = Clamp8(bb);
+    }
+    GOutBytes *o = (GOutBytes *)d.out + (size_t)(y - out_y0) * d.out_pitch + (size_t)(x0 - out_x0) * 3;
+    if (npx == 8) {
+      uint32_t w[6];
+#pragma unroll
+      for (int q = 0; q < 6; q++) w[q] = px[4 * q] | (px[4 * q + 1] << 8) | (px[4 * q + 2] << 16) | (px[4 * q + 3] << 24);
+      GOutPair *o2 = reinterpret_cast<GOutPair *>(o);
+      o2[0] = u32x2{w[0], w[1]};
+      o2[1] = u32x2{w[2], w[3]};
+      o2[2] = u32x2{w[4], w[5]};
+    } else {
+      for (int i = 0; i < npx * 3; i++) o[i] = (uint8_t)px[i];
+    }
+  }
 }
 
 __global__ __launch_bounds__(kColorThreads) void JpegColorKernel(const daliamdJpegColorDesc *__restrict__ descs,
@@ -123,69 +244,83 @@ __global__ __launch_bounds__(kColorThreads) void JpegColorKernel(const daliamdJp
   int t = wg - d.wg_start;
   int ty = t / tiles_x, tx = t - ty * tiles_x;
   int x0 = rx0 + tx * kTileW + (threadIdx.x & 31) * 8;
-  int y = ry0 + ty * kTileH + (threadIdx.x >> 5);
-  if (x0 >= rx1 || y >= ry1) return;
+  const int y_first = ry0 + ty * kTileH + (threadIdx.x >> 5) * kRowsPerThread;
+  if (x0 >= rx1 || y_first >= ry1) return;
 
   int ncomp = d.color == DALIAMD_JPEG_GRAY ? 1 : 3;
   int hmax = 1, vmax = 1;
   for (int c = 0; c < ncomp; c++) { hmax = max(hmax, d.h_samp[c]); vmax = max(vmax, d.v_samp[c]); }
-
-  int s[3][8];
-  for (int c = 0; c < ncomp; c++) {
-    int mode = ModeOf(d, c, hmax, vmax);
-    UpsampleRow8(d.plane[c], d.pitch[c], mode, hmax / d.h_samp[c], vmax / d.v_samp[c], d.down_w[c],
-                 d.down_h[c], x0, y, s[c]);
-  }
-  uint32_t px[24];
-  if (d.color == DALIAMD_JPEG_GRAY) {
-#pragma unroll
-    for (int i = 0; i < 8; i++) px[3 * i] = px[3 * i + 1] = px[3 * i + 2] = (uint32_t)s[0][i];
-  } else if (d.color == DALIAMD_JPEG_RGB) {
-#pragma unroll
-    for (int i = 0; i < 8; i++) { px[3 * i] = s[0][i]; px[3 * i + 1] = s[1][i]; px[3 * i + 2] = s[2][i]; }
-  } else {
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      int yy = s[0][i], cb = s[1][i] - 128, cr = s[2][i] - 128;
-      int r = yy + ((FIXC(1.40200) * cr + ONE_HALF) >> SCALEBITS);
-      int g = yy + (((-FIXC(0.34414)) * cb + ONE_HALF + (-FIXC(0.71414)) * cr) >> SCALEBITS);
-      int b = yy + ((FIXC(1.77200) * cb + ONE_HALF) >> SCALEBITS);
-      px[3 * i] = Clamp8(r); px[3 * i + 1] = Clamp8(g); px[3 * i + 2] = Clamp8(b);
-    }
-  }
-  int npx = min(8, rx1 - x0);
+  int mode[3] = {kFull, kFull, kFull};
+  for (int c = 0; c < ncomp; c++) mode[c] = ModeOf(d, c, hmax, vmax);
+  const int npx = min(8, rx1 - x0);
   const int out_x0 = roi ? d.out_x0 : 0, out_y0 = roi ? d.out_y0 : 0;
-  if (d.orientation > 1) {
-    // undo the EXIF orientation: source pixel (y, x) lands at (oy, ox) of the upright image
-    const int W = d.width, H = d.height;
-    for (int i = 0; i < npx; i++) {
-      int x = x0 + i, oy, ox;
-      switch (d.orientation) {
-        case 2: oy = y; ox = W - 1 - x; break;
-        case 3: oy = H - 1 - y; ox = W - 1 - x; break;
-        case 4: oy = H - 1 - y; ox = x; break;
-        case 5: oy = x; ox = y; break;
-        case 6: oy = x; ox = H - 1 - y; break;
-        case 7: oy = W - 1 - x; ox = H - 1 - y; break;
-        default: oy = W - 1 - x; ox = y; break;  // 8
-      }
-      uint8_t *p = d.out + (size_t)(oy - out_y0) * d.out_pitch + (size_t)(ox - out_x0) * 3;
-      p[0] = (uint8_t)px[3 * i]; p[1] = (uint8_t)px[3 * i + 1]; p[2] = (uint8_t)px[3 * i + 2];
-    }
+  const bool wide_ok = ((d.out_pitch & 7) == 0) && ((reinterpret_cast<uintptr_t>(d.out) & 7) == 0);
+  const bool wide_stores = npx == 8 && wide_ok;
+  // wave-uniform: the whole image takes the fast path or none of it does
+  if (d.color == DALIAMD_JPEG_YCC && mode[0] == kFull && mode[1] == kH2V2 && mode[2] == kH2V2 && d.orientation <= 1 &&
+      wide_ok && ((rx0 & 7) | (ry0 & 1)) == 0 && ((d.pitch[0] & 7) | (d.pitch[1] & 3) | (d.pitch[2] & 3)) == 0 &&
+      (reinterpret_cast<uintptr_t>(d.plane[0]) & 7) == 0 &&
+      ((reinterpret_cast<uintptr_t>(d.plane[1]) | reinterpret_cast<uintptr_t>(d.plane[2])) & 3) == 0) {
+    ColorRows420(d, x0, y_first, rx1, ry1, out_x0, out_y0);
     return;
   }
-  uint8_t *o = d.out + (size_t)(y - out_y0) * d.out_pitch + (size_t)(x0 - out_x0) * 3;
-  if (npx == 8 && ((d.out_pitch & 7) == 0) && ((reinterpret_cast<uintptr_t>(d.out) & 7) == 0)) {
-    uint32_t w[6];
+
+  for (int row = 0; row < kRowsPerThread; row++) {
+    const int y = y_first + row;
+    if (y >= ry1) break;
+    int s[3][8];
+    for (int c = 0; c < ncomp; c++)
+      UpsampleRow8((GBytes *)d.plane[c], d.pitch[c], mode[c], hmax / d.h_samp[c], vmax / d.v_samp[c], d.down_w[c], d.down_h[c], x0, y,
+                   s[c]);
+    uint32_t px[24];
+    if (d.color == DALIAMD_JPEG_GRAY) {
 #pragma unroll
-    for (int j = 0; j < 6; j++)
-      w[j] = px[4 * j] | (px[4 * j + 1] << 8) | (px[4 * j + 2] << 16) | (px[4 * j + 3] << 24);
-    uint2 *o2 = reinterpret_cast<uint2 *>(o);
-    o2[0] = make_uint2(w[0], w[1]);
-    o2[1] = make_uint2(w[2], w[3]);
-    o2[2] = make_uint2(w[4], w[5]);
-  } else {
-    for (int i = 0; i < npx * 3; i++) o[i] = (uint8_t)px[i];
+      for (int i = 0; i < 8; i++) px[3 * i] = px[3 * i + 1] = px[3 * i + 2] = (uint32_t)s[0][i];
+    } else if (d.color == DALIAMD_JPEG_RGB) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) { px[3 * i] = s[0][i]; px[3 * i + 1] = s[1][i]; px[3 * i + 2] = s[2][i]; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        int yy = s[0][i], cb = s[1][i] - 128, cr = s[2][i] - 128;
+        int r = yy + ((FIXC(1.40200) * cr + ONE_HALF) >> SCALEBITS);
+        int g = yy + (((-FIXC(0.34414)) * cb + ONE_HALF + (-FIXC(0.71414)) * cr) >> SCALEBITS);
+        int b = yy + ((FIXC(1.77200) * cb + ONE_HALF) >> SCALEBITS);
+        px[3 * i] = Clamp8(r); px[3 * i + 1] = Clamp8(g); px[3 * i + 2] = Clamp8(b);
+      }
+    }
+    if (d.orientation > 1) {
+      // undo the EXIF orientation: source pixel (y, x) lands at (oy, ox) of the upright image
+      const int W = d.width, H = d.height;
+      for (int i = 0; i < npx; i++) {
+        int x = x0 + i, oy, ox;
+        switch (d.orientation) {
+          case 2: oy = y; ox = W - 1 - x; break;
+          case 3: oy = H - 1 - y; ox = W - 1 - x; break;
+          case 4: oy = H - 1 - y; ox = x; break;
+          case 5: oy = x; ox = y; break;
+          case 6: oy = x; ox = H - 1 - y; break;
+          case 7: oy = W - 1 - x; ox = H - 1 - y; break;
+          default: oy = W - 1 - x; ox = y; break;  // 8
+        }
+        GOutBytes *p = (GOutBytes *)d.out + (size_t)(oy - out_y0) * d.out_pitch + (size_t)(ox - out_x0) * 3;
+        p[0] = (uint8_t)px[3 * i]; p[1] = (uint8_t)px[3 * i + 1]; p[2] = (uint8_t)px[3 * i + 2];
+      }
+      continue;
+    }
+    GOutBytes *o = (GOutBytes *)d.out + (size_t)(y - out_y0) * d.out_pitch + (size_t)(x0 - out_x0) * 3;
+    if (wide_stores) {
+      uint32_t w[6];
+#pragma unroll
+      for (int j = 0; j < 6; j++)
+        w[j] = px[4 * j] | (px[4 * j + 1] << 8) | (px[4 * j + 2] << 16) | (px[4 * j + 3] << 24);
+      GOutPair *o2 = reinterpret_cast<GOutPair *>(o);
+      o2[0] = u32x2{w[0], w[1]};
+      o2[1] = u32x2{w[2], w[3]};
+      o2[2] = u32x2{w[4], w[5]};
+    } else {
+      for (int i = 0; i < npx * 3; i++) o[i] = (uint8_t)px[i];
+    }
   }
 }
 

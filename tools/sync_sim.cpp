@@ -137,6 +137,7 @@ int main(int argc, char **argv) {
   if (argc < 2) return 1;
   const int slice = argc > 2 ? atoi(argv[2]) : 256, T = argc > 3 ? atoi(argv[3]) : 128, warm = argc > 4 ? atoi(argv[4]) : 12;
   g_pair_bits = argc > 5 ? atoi(argv[5]) : 0;
+  const int r0_bytes = argc > 6 ? atoi(argv[6]) : 0;  // > 0: round 0 decodes only the last r0_bytes of each slice
   const int seg_lanes = T - warm;
   std::vector<std::string> files;
   DIR *dp = opendir(argv[1]);
@@ -169,6 +170,7 @@ int main(int argc, char **argv) {
         l.nsym = l.steps = 0;
       }
       long path = 0, rounds = 0;
+      std::string trace;
       for (int round = 0; round <= T; round++) {
         long wave_max[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         bool any = false;
@@ -177,6 +179,10 @@ int main(int argc, char **argv) {
           if (l.active && !(l.has_in && l.in == state[t])) {
             l.in = state[t]; l.has_in = true;
             State st = l.in;
+            if (round == 0 && r0_bytes > 0 && t > 0 && l.end - l.begin > (uint32_t)r0_bytes * 8) {
+              st.pos = l.end - r0_bytes * 8;
+              l.has_in = false;  // a partial decode: never accepted as the final one
+            }
             l.nsym = l.steps = 0;
             if (st.pos < l.end) Decode(im, st, l.end, l.nsym, l.steps);
             l.out = st;
@@ -188,13 +194,15 @@ int main(int argc, char **argv) {
         long m = 0;
         for (int w = 0; w < T / 64; w++) { m = std::max(m, wave_max[w]); busy_wave_steps += wave_max[w]; }
         path += m;
-        if (any) rounds++;
+        if (any) { rounds++; trace += " " + std::to_string(m); }
         bool changed = false;
         for (int t = 0; t + 1 < T; t++)
           if (ln[t].active && !(state[t + 1] == ln[t].out)) { state[t + 1] = ln[t].out; changed = true; }
         if (!changed) break;
       }
       for (int t = warm; t < T; t++) ideal_syms += ln[t].nsym;
+      if (getenv("SIM_TRACE") && path > atol(getenv("SIM_TRACE")))
+        printf("  %s seg %ld/%ld path %ld rounds:%s\n", fn.c_str() + fn.size() - 8, seg, nseg, path, trace.c_str());
       wg_path.push_back(path);
       wg_rounds.push_back(rounds);
     }
