@@ -969,15 +969,24 @@ __global__ __launch_bounds__(kExpandThreads) void ExpandKernel(const daliamdJpeg
     G.total_records = (uint32_t)reinterpret_cast<const int32_t *>(d.scratch)[1];
   }
   __syncthreads();
-  const BlockIndex *index = reinterpret_cast<const BlockIndex *>(d.scratch + lay.blocks);
+  // {first_record, lane} pairs as dwords; everything below is read through the global address space so that the
+  // loads may stay in flight across the LDS traffic and the barriers
+  const GlobalWords *index = (const GlobalWords *)(d.scratch + lay.blocks);
   const GlobalWords *rec = (const GlobalWords *)(d.scratch + lay.records);
-  const LaneRec *lanes = reinterpret_cast<const LaneRec *>(d.scratch + lay.lanes);
+  const GlobalWords *lane_words = (const GlobalWords *)(d.scratch + lay.lanes);
+  constexpr int kLaneWords = (int)(sizeof(LaneRec) / 4), kBaseWord = (int)(offsetof(LaneRec, base) / 4);
+  constexpr int kIters = kExpandPerWg / kExpandBlocks;
   const int lb = tid >> 3, part = tid & 7;
   uint4 *blk_v = reinterpret_cast<uint4 *>(&stage[lb][0]);
   const int first_ordinal = (wg - d.blk_wg_start) * kExpandPerWg;
-  for (int it = 0; it < kExpandPerWg / kExpandBlocks; it++) {
+
+  // ---- geometry and index entries of all the blocks this thread touches: issued up front (one round trip) ----
+  uint32_t first_rec[kIters], end_rec[kIters], src_lane[kIters];
+  int kk[kIters], mxs[kIters], mys[kIters];
+  uint32_t need_mask = 0;
+#pragma unroll
+  for (int it = 0; it < kIters; it++) {
     const int ordinal = first_ordinal + it * kExpandBlocks + lb;
-    if (first_ordinal + it * kExpandBlocks >= G.last_ordinal) break;  // uniform
     bool needed = ordinal < G.last_ordinal && ordinal < G.decoded_blocks;
     int k = 0, mx = 0, my = 0;
     if (needed) {
@@ -990,29 +999,69 @@ __global__ __launch_bounds__(kExpandThreads) void ExpandKernel(const daliamdJpeg
         needed = bx >= G.rect[k][0] && by >= G.rect[k][1] && bx < G.rect[k][2] && by < G.rect[k][3];
       }
     }
+    kk[it] = k; mxs[it] = mx; mys[it] = my;
+    first_rec[it] = end_rec[it] = src_lane[it] = 0;
+    if (needed) {
+      need_mask |= 1u << it;
+      first_rec[it] = index[2 * (size_t)ordinal];
+      src_lane[it] = index[2 * (size_t)ordinal + 1];
+      // the block's records end where the next block's begin (the write pass registers the block behind the last
+      // needed one as well); the last block of the image ends with the stream
+      end_rec[it] = ordinal + 1 < G.decoded_blocks && ordinal + 1 < G.total_blocks ? index[2 * (size_t)ordinal + 2]
+                                                                                   : G.total_records;
+    }
+  }
+  // records of one block: three per lane cover 24, a typical block; longer ones finish in a loop
+  uint32_t w_next[3] = {0, 0, 0}, count_next = 0;
+  int dc_base_next = 0;
+  auto fetch = [&](int it) {
+    w_next[0] = w_next[1] = w_next[2] = 0;
+    count_next = 0;
+    dc_base_next = 0;
+    if ((need_mask >> it) & 1) {
+      const uint32_t end = min(end_rec[it], G.total_records);
+      count_next = first_rec[it] < end ? min(end - first_rec[it], 72u) : 0u;  // 1 DC + 63 AC + 3 ZRL + EOB
+#pragma unroll
+      for (int j = 0; j < 3; j++)
+        if ((uint32_t)(part + 8 * j) < count_next) w_next[j] = rec[first_rec[it] + part + 8 * j];
+      // DC: lane-local sum + level at the start of the lane that decoded it
+      if (part == 0) dc_base_next = (int)lane_words[(size_t)src_lane[it] * kLaneWords + kBaseWord + G.comp[kk[it]]];
+    }
+  };
+  fetch(0);
+#pragma unroll
+  for (int it = 0; it < kIters; it++) {
+    if (first_ordinal + it * kExpandBlocks >= G.last_ordinal) break;  // uniform
+    const bool needed = (need_mask >> it) & 1;
+    const uint32_t w0 = w_next[0], w1 = w_next[1], w2 = w_next[2], count = count_next;
+    const int dc_base = dc_base_next;
+    if (it + 1 < kIters) fetch(it + 1);  // in flight while this block is assembled
     blk_v[part] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     if (needed) {
-      const BlockIndex bi = index[ordinal];
-      // the block's records end where the next block's begin (the write pass registers the block behind the last
-      // needed one as well); the last block of the image ends with the stream
-      uint32_t end = ordinal + 1 < G.decoded_blocks && ordinal + 1 < G.total_blocks ? index[ordinal + 1].first_record
-                                                                                  : G.total_records;
-      end = min(end, G.total_records);
-      const uint32_t count = bi.first_record < end ? min(end - bi.first_record, 72u) : 0u;  // 1 DC + 63 AC + 3 ZRL + EOB
-      for (uint32_t i = part; i < count; i += 8) {
-        const uint32_t w = rec[bi.first_record + i];
-        if (i > 0 && (w & kRecDc)) break;  // defensive: never run into the next block
-        if (w & kRecValid) {
+      const uint32_t ws[3] = {w0, w1, w2};
+      bool open = true;
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const uint32_t i = (uint32_t)(part + 8 * j), w = ws[j];
+        if (i >= count) open = false;
+        if (open && i > 0 && (w & kRecDc)) open = false;  // defensive: never run into the next block
+        if (open && (w & kRecValid)) {
           int v = (int)(int16_t)(w & 0xFFFF);
-          if (i == 0) v += lanes[bi.lane].base[G.comp[k]];  // DC: lane-local sum + level at the start of that lane
+          if (i == 0) v += dc_base;
           stage[lb][G.zz[(w >> 16) & 63]] = (int16_t)v;
         }
+      }
+      for (uint32_t i = (uint32_t)part + 24; open && i < count; i += 8) {
+        const uint32_t w = rec[first_rec[it] + i];
+        if (w & kRecDc) break;
+        if (w & kRecValid) stage[lb][G.zz[(w >> 16) & 63]] = (int16_t)(w & 0xFFFF);
       }
     }
     __syncthreads();
     if (needed) {
-      uint4 *dst = reinterpret_cast<uint4 *>((int16_t *)(G.base[k] + ((size_t)my * (size_t)G.sy[k] + (size_t)(mx * G.sx[k]))));
+      const int k = kk[it];
+      uint4 *dst = reinterpret_cast<uint4 *>((int16_t *)(G.base[k] + ((size_t)mys[it] * (size_t)G.sy[k] + (size_t)(mxs[it] * G.sx[k]))));
       dst[part] = blk_v[part];
     }
   }
