@@ -477,7 +477,7 @@ struct DcAcc {
 
 // Rare path: the code is longer than kFastBits bits (or is not a code at all).
 template <typename Tables>
-__device__ __forceinline__ uint32_t LongCode(const Tables &L, uint32_t slot, uint32_t peek, bool is_dc) {
+__device__ __noinline__ uint32_t LongCode(const Tables &L, uint32_t slot, uint32_t peek, bool is_dc) {
   const uint32_t code16 = peek >> 16;
   uint32_t e = 0;
   const int size = L.l2_size[slot];
@@ -654,38 +654,41 @@ __device__ __forceinline__ void WriteRange(const HuffTables &L, GlobalWords *__r
         const uint32_t slot = (((is_dc ? dc_mask : ac_mask) >> c) & 1u) + (is_dc ? 0u : 2u);
         uint32_t e = fast[(slot << kFastBits) + (peek >> (32 - kFastBits))];
         if (__builtin_expect(e == 0, 0)) e = LongCode(L, slot, peek, is_dc);
-        const uint32_t used = (e >> 7) & 31, s = e >> 12, adv = e & 127, len = used - s;
-        // magnitude bits -> value (T.81 F.2.2.1 EXTEND); s == 0 gives 0
-        const uint32_t m = ((peek << len) >> 1) >> (31 - s);
-        const uint32_t half = (1u << s) >> 1;
-        int val = (int)m + (m < half ? 1 - (int)(1u << s) : 0);
+        const uint32_t used = (e >> 7) & 31, s = e >> 12, adv = e & 127;
+        // magnitude bits -> value (T.81 F.2.2.1 EXTEND): the s bits behind the code; s == 0 gives 0
+        const uint32_t m = __builtin_amdgcn_ubfe(peek, 32u - used, s);
+        const uint32_t full = (1u << s) - 1u;          // 2^s - 1
+        int val = (int)m - (int)(m <= (full >> 1) ? full : 0u);
         uint32_t zt = z + adv - 1;  // zig-zag index of the coefficient this symbol carries (AC)
         uint32_t flags = (s && zt < 64) ? kRecValid : 0;
-        if (is_dc) {
-          const uint32_t comp = (comp_bits >> (2 * c)) & 3u;
-          if (comp == 0) val = (dc.sum0 += val);
-          else if (comp == 1) val = (dc.sum1 += val);
-          else val = (dc.sum2 += val);
-          zt = 0;
-          flags = kRecDc | kRecValid;
-        }
+        // DC: the record carries the lane-local running sum of its component's differences (no branches: the three
+        // sums live in registers and every step offers them a masked increment)
+        const uint32_t comp = (comp_bits >> (2 * c)) & 3u;
+        const int dval = is_dc ? val : 0;
+        dc.sum0 += comp == 0 ? dval : 0;
+        dc.sum1 += comp == 1 ? dval : 0;
+        dc.sum2 += comp == 2 ? dval : 0;
+        const int sum = comp == 0 ? dc.sum0 : comp == 1 ? dc.sum1 : dc.sum2;
+        val = is_dc ? sum : val;
+        zt = is_dc ? 0u : zt;
+        flags = is_dc ? (kRecDc | kRecValid) : flags;
         r[j] = ((uint32_t)val & 0xFFFFu) | ((zt & 63u) << 16) | flags;
         nrec = j + 1;
         rem -= (int)used;
         off += used;
         z += adv;
-        if (off >= 32) {
-          hi = lo;
-          lo = __builtin_bswap32(nxt);
-          k++;
-          nxt = ring[(k + 2) & (kRingWords - 1)];
-          off -= 32;
-        }
-        if (z >= 64) {
-          z = 0;
-          c = c + 1 == bpm ? 0 : c + 1;
-          ordinal++;
-        }
+        // window refill without a branch: the ring read is unconditional (it re-reads the same dword until k moves)
+        const bool refill = off >= 32;
+        hi = refill ? lo : hi;
+        lo = refill ? __builtin_bswap32(nxt) : lo;
+        k += refill ? 1 : 0;
+        off &= 31;
+        nxt = ring[(k + 2) & (kRingWords - 1)];
+        const bool end_of_block = z >= 64;
+        const uint32_t c1 = c + 1 == bpm ? 0 : c + 1;
+        z = end_of_block ? 0 : z;
+        c = end_of_block ? c1 : c;
+        ordinal += end_of_block ? 1 : 0;
         live = rem > 0;
       }
     }

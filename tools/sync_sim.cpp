@@ -54,6 +54,8 @@ static inline uint32_t Peek16(const Image &im, uint32_t pos) {
 }
 
 static int g_pair_bits = 0;
+long g_cls[4] = {0, 0, 0, 0};
+std::vector<long> g_wmax;
 
 // mirrors DecodeRange: symbols that START in [st.pos, end)
 static int Decode(const Image &im, State &st, uint32_t end, int &nsym, int &steps) {
@@ -178,6 +180,7 @@ int main(int argc, char **argv) {
           L &l = ln[t];
           if (l.active && !(l.has_in && l.in == state[t])) {
             l.in = state[t]; l.has_in = true;
+            const State old_out = l.out; const bool had = l.has_in;
             State st = l.in;
             if (round == 0 && r0_bytes > 0 && t > 0 && l.end - l.begin > (uint32_t)r0_bytes * 8) {
               st.pos = l.end - r0_bytes * 8;
@@ -186,6 +189,10 @@ int main(int argc, char **argv) {
             l.nsym = l.steps = 0;
             if (st.pos < l.end) Decode(im, st, l.end, l.nsym, l.steps);
             l.out = st;
+            if (had && round >= 2) {
+              extern long g_cls[4];
+              if (st == old_out) g_cls[0]++; else if (st.pos == old_out.pos && st.z == old_out.z) g_cls[1]++; else g_cls[2]++;
+            }
             wave_max[t / 64] = std::max<long>(wave_max[t / 64], l.steps);
             total_steps += l.steps; total_syms += l.nsym;
             any = true;
@@ -200,6 +207,7 @@ int main(int argc, char **argv) {
           if (ln[t].active && !(state[t + 1] == ln[t].out)) { state[t + 1] = ln[t].out; changed = true; }
         if (!changed) break;
       }
+      { extern std::vector<long> g_wmax; long m = 0; for (int t = warm; t < T; t++) m = std::max<long>(m, ln[t].nsym); g_wmax.push_back(m); }
       for (int t = warm; t < T; t++) ideal_syms += ln[t].nsym;
       if (getenv("SIM_TRACE") && path > atol(getenv("SIM_TRACE")))
         printf("  %s seg %ld/%ld path %ld rounds:%s\n", fn.c_str() + fn.size() - 8, seg, nseg, path, trace.c_str());
@@ -217,5 +225,8 @@ int main(int argc, char **argv) {
   printf("rounds: p50 %ld p90 %ld p99 %ld max %ld\n", pct(wg_rounds, .5), pct(wg_rounds, .9), pct(wg_rounds, .99), wg_rounds.back());
   printf("critical path (steps): mean %.0f p50 %ld p90 %ld p99 %ld max %ld   wave-steps total %ld\n", mean_path, pct(wg_path, .5),
          pct(wg_path, .9), pct(wg_path, .99), wg_path.back(), busy_wave_steps);
+  std::sort(g_wmax.begin(), g_wmax.end());
+  printf("write pass: longest lane (symbols) per workgroup: p50 %ld p90 %ld p99 %ld max %ld\n", pct(g_wmax, .5), pct(g_wmax, .9), pct(g_wmax, .99), g_wmax.back());
+  printf("re-decodes in rounds >= 2: same out %ld, same (pos,z) other c %ld, other pos %ld\n", g_cls[0], g_cls[1], g_cls[2]);
   return 0;
 }
