@@ -60,13 +60,20 @@ using GlobalBytes = uint8_t __attribute__((address_space(1)));
 using GlobalU32 = uint32_t __attribute__((address_space(1)));
 
 // ------------------------------------------------------------------------------------------------ scratch layout
+// The synchronisation passes work on slices of kSliceBytes; the write pass splits every slice at its midpoint into
+// two WRITE LANES (the time of that pass is the length of its longest lane, and the machine has room for twice the
+// lanes).  The state at the midpoint is a by-product of the final synchronisation decode of the slice.
 struct LaneRec {      // one per slice
   uint64_t in, out;   // packed decoder state at the start / end of the slice
+  uint64_t mid;       // ... at the first symbol that starts at or behind the midpoint (= in when in is behind it)
   int32_t nblk;       // blocks completed inside the slice
   int32_t nsym;       // symbols that start inside the slice = records the write pass emits for it
-  int32_t dc[3];      // write pass: sum of the DC differences the slice holds, per component
-  int32_t base[3];    // DcScanKernel: DC level at the start of the slice, per component
+  int32_t nblk_a;     // ... of them before the midpoint
+  int32_t nsym_a;
+  int32_t dc[2][3];   // write pass: sum of the DC differences each half holds, per component
+  int32_t base[2][3]; // DcScanKernel: DC level at the start of each half, per component
 };
+static_assert(sizeof(LaneRec) == 88, "ExpandKernel addresses the base[] words directly");
 struct SegRec {  // one per segment
   uint64_t out;  // state at the end of the segment
   int32_t nblk_total, block_base;
@@ -85,7 +92,7 @@ struct SegRec {  // one per segment
 constexpr uint32_t kRecDc = 1u << 22, kRecValid = 1u << 23;
 struct BlockIndex {
   uint32_t first_record;  // index of the block's DC record in the image's record stream
-  uint32_t lane;          // slice (image-wide index) that decoded the DC: its LaneRec holds the DC level
+  uint32_t lane;          // write lane (image-wide: 2 * slice + half) that decoded the DC: its LaneRec holds the DC level
 };
 
 struct HuffTables {
@@ -499,8 +506,9 @@ __device__ __noinline__ uint32_t LongCode(const Tables &L, uint32_t slot, uint32
 
 // Decodes the symbols that start in [st.pos, end_bits); returns the number of blocks completed.  Positions only:
 // no value is extracted (synchronisation passes).
+struct HalfCount { uint64_t mid; int nblk, nsym; };  // state at the midpoint, blocks / symbols before it
 __device__ __forceinline__ int DecodeRange(const SyncTables &L, GlobalWords *__restrict__ words, DecodeState &st,
-                                           uint32_t end_bits, int &nsym_out) {
+                                           uint32_t mid_bits, uint32_t end_bits, int &nsym_out, HalfCount &half) {
   int nblk = 0, nsym = 0;
   uint32_t c = st.c, z = st.z;
   int rem = (int)(end_bits - st.pos);  // bits left before the end of the slice (<= 0: done)
@@ -510,38 +518,47 @@ __device__ __forceinline__ int DecodeRange(const SyncTables &L, GlobalWords *__r
   uint32_t hi = __builtin_bswap32(words[k]), lo = __builtin_bswap32(words[k + 1]), nxt = words[k + 2];
   const uint32_t *t32 = &L.t32[0][0];
   const uint32_t dc_mask = L.dc_mask, ac_mask = L.ac_mask, bpm = (uint32_t)L.bpm;
-  while (rem > 0) {
-    const uint32_t peek = (uint32_t)(((((uint64_t)hi << 32) | lo) << off) >> 32);
-    const bool is_dc = z == 0;
-    const uint32_t slot = (((is_dc ? dc_mask : ac_mask) >> c) & 1u) + (is_dc ? 0u : 2u);
-    uint32_t e = t32[(slot << kFastBits) + (peek >> (32 - kFastBits))];
-    if (__builtin_expect(e == 0, 0)) {
-      const uint32_t e16 = LongCode(L, slot, peek, is_dc);
-      e = SyncHalf(e16 & 127, (e16 >> 7) & 31, 1) * 0x10001u;
+  // symbols that start in [pos, end - limit); called for the two halves of the slice in turn (no per-symbol cost
+  // for the midpoint: the first loop simply stops there)
+  auto run = [&](int limit) {
+    while (rem > limit) {
+      const uint32_t peek = (uint32_t)(((((uint64_t)hi << 32) | lo) << off) >> 32);
+      const bool is_dc = z == 0;
+      const uint32_t slot = (((is_dc ? dc_mask : ac_mask) >> c) & 1u) + (is_dc ? 0u : 2u);
+      uint32_t e = t32[(slot << kFastBits) + (peek >> (32 - kFastBits))];
+      if (__builtin_expect(e == 0, 0)) {
+        const uint32_t e16 = LongCode(L, slot, peek, is_dc);
+        e = SyncHalf(e16 & 127, (e16 >> 7) & 31, 1) * 0x10001u;
+      }
+      // the pair may be taken when the first symbol leaves the block open and the second one starts inside the range:
+      // both differences negative <=> the sign bit of their AND is set
+      const int first_z = (int)((e >> 16) & 127), first_used = (int)((e >> 23) & 31);
+      const int ok = ((int)z + first_z - 64) & (first_used - (rem - limit));
+      const uint32_t f = ok < 0 ? e : e >> 16;
+      const uint32_t used = (f >> 7) & 31;
+      rem -= (int)used;
+      off += used;
+      z += f & 127;
+      nsym += (int)((f >> 12) & 3);
+      if (off >= 32) {
+        hi = lo;
+        lo = __builtin_bswap32(nxt);
+        k++;
+        nxt = words[k + 2];
+        off -= 32;
+      }
+      const bool end_of_block = z >= 64;
+      const uint32_t c1 = c + 1 == bpm ? 0 : c + 1;
+      z = end_of_block ? 0 : z;
+      c = end_of_block ? c1 : c;
+      nblk += end_of_block ? 1 : 0;
     }
-    // the pair may be taken when the first symbol leaves the block open and the second one starts inside the slice:
-    // both differences negative <=> the sign bit of their AND is set
-    const int first_z = (int)((e >> 16) & 127), first_used = (int)((e >> 23) & 31);
-    const int ok = ((int)z + first_z - 64) & (first_used - rem);
-    const uint32_t f = ok < 0 ? e : e >> 16;
-    const uint32_t used = (f >> 7) & 31;
-    rem -= (int)used;
-    off += used;
-    z += f & 127;
-    nsym += (int)((f >> 12) & 3);
-    if (off >= 32) {
-      hi = lo;
-      lo = __builtin_bswap32(nxt);
-      k++;
-      nxt = words[k + 2];
-      off -= 32;
-    }
-    const bool end_of_block = z >= 64;
-    const uint32_t c1 = c + 1 == bpm ? 0 : c + 1;
-    z = end_of_block ? 0 : z;
-    c = end_of_block ? c1 : c;
-    nblk += end_of_block ? 1 : 0;
-  }
+  };
+  run(mid_bits < end_bits ? (int)(end_bits - mid_bits) : 0);
+  half.mid = Pack(DecodeState{end_bits - (uint32_t)rem, c, z});
+  half.nblk = nblk;
+  half.nsym = nsym;
+  run(0);
   st.pos = end_bits - (uint32_t)rem;
   st.c = c;
   st.z = z;
@@ -556,7 +573,10 @@ typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 using GlobalQuadA4 = u32x4_a4 __attribute__((address_space(1)));
 
 constexpr int kGroupSteps = 8;   // symbols between two wave-uniform "points" of the write pass
-constexpr int kRingWords = 32;   // dwords of the clean stream buffered in LDS per lane (ring)
+constexpr int kRingWords = 16;   // dwords of the clean stream buffered in LDS per lane (ring)
+constexpr int kRingNeed = 10;    // a group reads up to dword k + 2 + 7 (eight symbols of at most 27 bits)
+constexpr int kWriteThreads = 256;
+constexpr int kWriteLanes = 2 * kSegLanes;  // two write lanes per slice of the segment
 
 // Write pass of one slice: decodes the symbols that start in [st.pos, end_bits) once more, now extracting the values,
 // and appends one record per symbol to `rec` (this slice's part of the image's record stream; exactly the `nsym`
@@ -586,22 +606,22 @@ __device__ __forceinline__ void WriteRange(const HuffTables &L, GlobalWords *__r
   uint32_t comp_bits = 0;
   for (uint32_t kk = 0; kk < bpm; kk++) comp_bits |= (uint32_t)L.blk_comp[kk] << (2 * kk);
   int ordinal = ord;  // block the next symbol belongs to
-  if (live) {         // prologue: 24 dwords straight into the ring (the only exposed memory latency of the pass)
+  if (live) {         // prologue: 12 dwords straight into the ring (the only exposed memory latency of the pass)
     const GlobalQuadA4 *src = (const GlobalQuadA4 *)(words + k);
 #pragma unroll
-    for (int q = 0; q < 6; q++) {
+    for (int q = 0; q < 3; q++) {
       const u32x4_a4 v = src[q];
       ring[(k + 4 * q) & (kRingWords - 1)] = v.x;
       ring[(k + 4 * q + 1) & (kRingWords - 1)] = v.y;
       ring[(k + 4 * q + 2) & (kRingWords - 1)] = v.z;
       ring[(k + 4 * q + 3) & (kRingWords - 1)] = v.w;
     }
-    kl = k + 24;
+    kl = k + 12;
     hi = __builtin_bswap32(ring[k & (kRingWords - 1)]);
     lo = __builtin_bswap32(ring[(k + 1) & (kRingWords - 1)]);
     nxt = ring[(k + 2) & (kRingWords - 1)];
   }
-  uint32_t pre[8];        // stream dwords [kl, kl + 8) in flight
+  uint32_t pre[4];        // stream dwords [kl, kl + 4) in flight
   bool have_pre = false;
   uint32_t r[kGroupSteps];  // records of the current group
   int nrec = 0;
@@ -611,9 +631,21 @@ __device__ __forceinline__ void WriteRange(const HuffTables &L, GlobalWords *__r
     // ---------------- point ----------------
     if (have_pre) {
 #pragma unroll
-      for (int q = 0; q < 8; q++) ring[(kl + q) & (kRingWords - 1)] = pre[q];
-      kl += 8;
+      for (int q = 0; q < 4; q++) ring[(kl + q) & (kRingWords - 1)] = pre[q];
+      kl += 4;
       have_pre = false;
+    }
+    // Safety net: the usual 4 dwords per point cover 16 bits per symbol.  A lane that could run dry inside the next
+    // group (eight symbols in a row longer than that) fetches synchronously; real streams never get here.
+    while (__ballot(live && kl - k < kRingNeed) != 0) {
+      if (live && kl - k < kRingNeed) {
+        const u32x4_a4 v = *(const GlobalQuadA4 *)(words + kl);
+        ring[kl & (kRingWords - 1)] = v.x;
+        ring[(kl + 1) & (kRingWords - 1)] = v.y;
+        ring[(kl + 2) & (kRingWords - 1)] = v.z;
+        ring[(kl + 3) & (kRingWords - 1)] = v.w;
+        kl += 4;
+      }
     }
     if (nrec > 0) {
       if (nrec == kGroupSteps) {  // the common case: the lane's 8 records as two 16-byte stores
@@ -636,11 +668,9 @@ __device__ __forceinline__ void WriteRange(const HuffTables &L, GlobalWords *__r
       rec_index += (uint32_t)nrec;
       nrec = 0;
     }
-    if (live && kl - k <= 24) {  // room in the ring: request the next 8 dwords (delivered at the next point)
-      const GlobalQuadA4 *src = (const GlobalQuadA4 *)(words + kl);
-      const u32x4_a4 a = src[0], b = src[1];
+    if (live && kl - k <= kRingWords - 4) {  // room in the ring: request the next 4 dwords (delivered at the next point)
+      const u32x4_a4 a = *(const GlobalQuadA4 *)(words + kl);
       pre[0] = a.x; pre[1] = a.y; pre[2] = a.z; pre[3] = a.w;
-      pre[4] = b.x; pre[5] = b.y; pre[6] = b.z; pre[7] = b.w;
       have_pre = true;
     }
     group_ord = ordinal;
@@ -699,8 +729,8 @@ __device__ __forceinline__ void WriteRange(const HuffTables &L, GlobalWords *__r
 struct Lane {
   uint32_t begin, end;  // bit range of the slice (clipped to the stream)
   bool active;          // the slice holds data
-  uint64_t in = kNoState, out = kNoState;
-  int nblk = 0, nsym = 0;
+  uint64_t in = kNoState, out = kNoState, mid = kNoState;
+  int nblk = 0, nsym = 0, nblk_a = 0, nsym_a = 0;
 };
 
 // "Publish the state you reached to the next lane, decode again if your input changed", until nothing changes.
@@ -716,8 +746,12 @@ __device__ __forceinline__ void Relax(const SyncTables &L, GlobalWords *words, u
       ln.in = ni;
       DecodeState st = Unpack(ni);
       ln.nblk = ln.nsym = 0;
-      if (st.pos < ln.end) ln.nblk = DecodeRange(L, words, st, ln.end, ln.nsym);
+      HalfCount half{ni, 0, 0};
+      if (st.pos < ln.end) ln.nblk = DecodeRange(L, words, st, ln.begin + kSliceBytes * 4u, ln.end, ln.nsym, half);
       ln.out = Pack(st);
+      ln.mid = half.mid;
+      ln.nblk_a = half.nblk;
+      ln.nsym_a = half.nsym;
     }
     __syncthreads();
     int changed = 0;
@@ -757,7 +791,7 @@ __global__ __launch_bounds__(kSegThreads) void SyncKernel(const daliamdJpegHuffD
   LaneRec *recs = reinterpret_cast<LaneRec *>(d.scratch + lay.lanes) + (size_t)seg * kSegLanes;
   SegRec *segrec = reinterpret_cast<SegRec *>(d.scratch + lay.segs) + seg;
   if (seg > 0 && (long long)seg * kSegBytes >= clean_len) {  // segment behind the end of the stream
-    if (tid >= kWarmLanes) recs[tid - kWarmLanes] = LaneRec{kNoState, kNoState, 0, 0, {0, 0, 0}, {0, 0, 0}};
+    if (tid >= kWarmLanes) recs[tid - kWarmLanes] = LaneRec{kNoState, kNoState, kNoState, 0, 0, 0, 0, {}, {}};
     if (tid == 0) *segrec = SegRec{kNoState, 0, 0, 0, 0, {0, 0, 0}, 0};
     return;
   }
@@ -772,7 +806,7 @@ __global__ __launch_bounds__(kSegThreads) void SyncKernel(const daliamdJpegHuffD
   WorkgroupExclusiveScan<kSegThreads / 64>(tid >= kWarmLanes ? ln.nblk : 0, wave_sums, total);
   WorkgroupExclusiveScan<kSegThreads / 64>(tid >= kWarmLanes ? ln.nsym : 0, wave_sums, total_sym);
   if (tid >= kWarmLanes) {
-    recs[tid - kWarmLanes] = LaneRec{ln.in, ln.out, ln.nblk, ln.nsym, {0, 0, 0}, {0, 0, 0}};
+    recs[tid - kWarmLanes] = LaneRec{ln.in, ln.out, ln.mid, ln.nblk, ln.nsym, ln.nblk_a, ln.nsym_a, {}, {}};
     // the last slice with data ends the segment (an empty stream: the first lane passes its input on)
     const bool next_has_data = tid + 1 < kSegThreads && ln.end < total_bits;
     if (ln.active && !next_has_data) *segrec = SegRec{ln.out, total, 0, total_sym, 0, {0, 0, 0}, 0};
@@ -814,8 +848,11 @@ __global__ __launch_bounds__(kSegThreads) void PropagateKernel(const daliamdJpeg
       if (tid < kSegLanes) {
         ln.in = recs[tid].in;
         ln.out = recs[tid].out;
+        ln.mid = recs[tid].mid;
         ln.nblk = recs[tid].nblk;
         ln.nsym = recs[tid].nsym;
+        ln.nblk_a = recs[tid].nblk_a;
+        ln.nsym_a = recs[tid].nsym_a;
       }
       state[tid] = tid == 0 ? truth : ln.in;
       __syncthreads();
@@ -826,8 +863,11 @@ __global__ __launch_bounds__(kSegThreads) void PropagateKernel(const daliamdJpeg
       if (tid < kSegLanes) {
         recs[tid].in = ln.in;
         recs[tid].out = ln.out;
+        recs[tid].mid = ln.mid;
         recs[tid].nblk = ln.nblk;
         recs[tid].nsym = ln.nsym;
+        recs[tid].nblk_a = ln.nblk_a;
+        recs[tid].nsym_a = ln.nsym_a;
         const bool next_has_data = tid + 1 < kSegLanes && ln.end < total_bits;
         if (ln.active && !next_has_data) {
           segs[seg].out = ln.out;
@@ -854,10 +894,10 @@ __global__ __launch_bounds__(kSegThreads) void PropagateKernel(const daliamdJpeg
   }
 }
 
-__global__ __launch_bounds__(kSegThreads) void WriteKernel(const daliamdJpegHuffDesc *__restrict__ descs, int n, int nseg) {
+__global__ __launch_bounds__(kWriteThreads) void WriteKernel(const daliamdJpegHuffDesc *__restrict__ descs, int n, int nseg) {
   __shared__ __attribute__((aligned(16))) HuffTables L;
-  __shared__ __attribute__((aligned(16))) uint32_t ring[kSegThreads * kRingWords];
-  __shared__ int wave_sums[kSegThreads / 64];
+  __shared__ __attribute__((aligned(16))) uint32_t ring[kWriteThreads * kRingWords];
+  __shared__ int wave_sums[kWriteThreads / 64];
   const int wg = XcdRemap(blockIdx.x, nseg);
   if (wg < 0) return;
   const ImageRef r = FindImage<false>(descs, n, wg);
@@ -866,36 +906,45 @@ __global__ __launch_bounds__(kSegThreads) void WriteKernel(const daliamdJpegHuff
   const int tid = threadIdx.x, seg = r.local;
   const int clean_len = *reinterpret_cast<const int32_t *>(d.scratch);
   if (seg > 0 && (long long)seg * kSegBytes >= clean_len) return;
-  CopyTables<kSegThreads>(L, reinterpret_cast<const HuffTables *>(d.scratch + lay.tables));
+  CopyTables<kWriteThreads>(L, reinterpret_cast<const HuffTables *>(d.scratch + lay.tables));
   LaneRec *recs = reinterpret_cast<LaneRec *>(d.scratch + lay.lanes) + (size_t)seg * kSegLanes;
   SegRec *segrec = reinterpret_cast<SegRec *>(d.scratch + lay.segs) + seg;
   const uint32_t total_bits = (uint32_t)clean_len * 8u;
-  Lane ln = MakeLane(tid < kSegLanes ? (long long)seg * kSegLanes + tid : -1, total_bits);
-  if (tid < kSegLanes) {
-    ln.in = recs[tid].in;
-    ln.nblk = recs[tid].nblk;
-    ln.nsym = recs[tid].nsym;
+  // write lane = (slice, half): the first half ends at the slice's midpoint, the second starts from the state the
+  // synchronisation pass noted there
+  const int slice = tid >> 1, half = tid & 1;
+  const bool has = tid < kWriteLanes;
+  const Lane ln = MakeLane(has ? (long long)seg * kSegLanes + slice : -1, total_bits);
+  const uint32_t mid_bits = min(ln.begin + kSliceBytes * 4u, ln.end);
+  const uint32_t end_bits = half ? ln.end : mid_bits;
+  uint64_t in = kNoState;
+  int nblk = 0, nsym = 0;
+  if (has) {
+    const LaneRec &rc = recs[slice];
+    in = half ? rc.mid : rc.in;
+    nblk = half ? rc.nblk - rc.nblk_a : rc.nblk_a;
+    nsym = half ? rc.nsym - rc.nsym_a : rc.nsym_a;
   }
   int total;
-  const int ord = segrec->block_base + WorkgroupExclusiveScan<kSegThreads / 64>(ln.nblk, wave_sums, total);
-  const int rec_off = segrec->rec_base + WorkgroupExclusiveScan<kSegThreads / 64>(ln.nsym, wave_sums, total);
+  const int ord = segrec->block_base + WorkgroupExclusiveScan<kWriteThreads / 64>(nblk, wave_sums, total);
+  const int rec_off = segrec->rec_base + WorkgroupExclusiveScan<kWriteThreads / 64>(nsym, wave_sums, total);
   DcAcc dc;
-  DecodeState st = Unpack(ln.in);
-  // region of interest: slices behind the last needed block are not decoded again; the slice that STARTS at that
+  DecodeState st = Unpack(in);
+  // region of interest: lanes behind the last needed block are not decoded again; the lane that STARTS at that
   // block still is, so that the DC record ending the last needed block exists
-  const bool live = ln.active && st.pos < ln.end && ord <= L.last_ordinal;
-  WriteRange(L, (GlobalWords *)(d.scratch + lay.clean), st, ln.end, ord, live, ring + tid * kRingWords,
-             (GlobalU32 *)(d.scratch + lay.records), (uint32_t)rec_off, (uint32_t)(seg * kSegLanes + tid),
+  const bool live = ln.active && st.pos < end_bits && ord <= L.last_ordinal;
+  WriteRange(L, (GlobalWords *)(d.scratch + lay.clean), st, end_bits, ord, live, ring + tid * kRingWords,
+             (GlobalU32 *)(d.scratch + lay.records), (uint32_t)rec_off, (uint32_t)((seg * kSegLanes + slice) * 2 + half),
              reinterpret_cast<BlockIndex *>(d.scratch + lay.blocks), dc);
-  if (tid < kSegLanes) {
-    recs[tid].dc[0] = dc.sum0;
-    recs[tid].dc[1] = dc.sum1;
-    recs[tid].dc[2] = dc.sum2;
+  if (has) {
+    recs[slice].dc[half][0] = dc.sum0;
+    recs[slice].dc[half][1] = dc.sum1;
+    recs[slice].dc[half][2] = dc.sum2;
   }
   int t0, t1, t2;
-  WorkgroupExclusiveScan<kSegThreads / 64>(dc.sum0, wave_sums, t0);
-  WorkgroupExclusiveScan<kSegThreads / 64>(dc.sum1, wave_sums, t1);
-  WorkgroupExclusiveScan<kSegThreads / 64>(dc.sum2, wave_sums, t2);
+  WorkgroupExclusiveScan<kWriteThreads / 64>(dc.sum0, wave_sums, t0);
+  WorkgroupExclusiveScan<kWriteThreads / 64>(dc.sum1, wave_sums, t1);
+  WorkgroupExclusiveScan<kWriteThreads / 64>(dc.sum2, wave_sums, t2);
   if (tid == 0) {
     segrec->dc_total[0] = t0;
     segrec->dc_total[1] = t1;
@@ -903,9 +952,9 @@ __global__ __launch_bounds__(kSegThreads) void WriteKernel(const daliamdJpegHuff
   }
 }
 
-// DC prediction: the level at the start of every slice = sum of the differences of all slices before it.
-__global__ __launch_bounds__(kSegThreads) void DcScanKernel(const daliamdJpegHuffDesc *__restrict__ descs, int n, int nseg) {
-  __shared__ int wave_sums[kSegThreads / 64];
+// DC prediction: the level at the start of every write lane = sum of the differences of all lanes before it.
+__global__ __launch_bounds__(kWriteThreads) void DcScanKernel(const daliamdJpegHuffDesc *__restrict__ descs, int n, int nseg) {
+  __shared__ int wave_sums[kWriteThreads / 64];
   const int wg = XcdRemap(blockIdx.x, nseg);
   if (wg < 0) return;
   const ImageRef r = FindImage<false>(descs, n, wg);
@@ -917,14 +966,14 @@ __global__ __launch_bounds__(kSegThreads) void DcScanKernel(const daliamdJpegHuf
   LaneRec *recs = reinterpret_cast<LaneRec *>(d.scratch + lay.lanes) + (size_t)seg * kSegLanes;
   const SegRec *segs = reinterpret_cast<const SegRec *>(d.scratch + lay.segs);
   int p[3] = {0, 0, 0};
-  for (int j = tid; j < seg; j += kSegThreads)
+  for (int j = tid; j < seg; j += kWriteThreads)
     for (int c = 0; c < 3; c++) p[c] += segs[j].dc_total[c];
   for (int c = 0; c < 3; c++) {
     int seg_base, unused;
-    WorkgroupExclusiveScan<kSegThreads / 64>(p[c], wave_sums, seg_base);
-    const int mine = tid < kSegLanes ? recs[tid].dc[c] : 0;
-    const int base = seg_base + WorkgroupExclusiveScan<kSegThreads / 64>(mine, wave_sums, unused);
-    if (tid < kSegLanes) recs[tid].base[c] = base;
+    WorkgroupExclusiveScan<kWriteThreads / 64>(p[c], wave_sums, seg_base);
+    const int mine = tid < kWriteLanes ? recs[tid >> 1].dc[tid & 1][c] : 0;
+    const int base = seg_base + WorkgroupExclusiveScan<kWriteThreads / 64>(mine, wave_sums, unused);
+    if (tid < kWriteLanes) recs[tid >> 1].base[tid & 1][c] = base;
   }
 }
 
@@ -1028,7 +1077,9 @@ __global__ __launch_bounds__(kExpandThreads) void ExpandKernel(const daliamdJpeg
       for (int j = 0; j < 3; j++)
         if ((uint32_t)(part + 8 * j) < count_next) w_next[j] = rec[first_rec[it] + part + 8 * j];
       // DC: lane-local sum + level at the start of the lane that decoded it
-      if (part == 0) dc_base_next = (int)lane_words[(size_t)src_lane[it] * kLaneWords + kBaseWord + G.comp[kk[it]]];
+      if (part == 0)  // base[half][component] of the slice's record
+        dc_base_next = (int)lane_words[(size_t)(src_lane[it] >> 1) * kLaneWords + kBaseWord + (src_lane[it] & 1) * 3 +
+                                       G.comp[kk[it]]];
     }
   };
   fetch(0);
@@ -1140,9 +1191,9 @@ static daliamdResult_t LaunchHuffman(daliamdStream_t stream, const daliamdJpegHu
   DALIAMD_HIP_CHECK(mark());
   hipLaunchKernelGGL(PropagateKernel, dim3(n), dim3(kSegThreads), 0, s, descs_dev);
   DALIAMD_HIP_CHECK(mark());
-  hipLaunchKernelGGL(WriteKernel, dim3(seg_grid), dim3(kSegThreads), 0, s, descs_dev, n, num_segments);
+  hipLaunchKernelGGL(WriteKernel, dim3(seg_grid), dim3(kWriteThreads), 0, s, descs_dev, n, num_segments);
   DALIAMD_HIP_CHECK(mark());
-  hipLaunchKernelGGL(DcScanKernel, dim3(seg_grid), dim3(kSegThreads), 0, s, descs_dev, n, num_segments);
+  hipLaunchKernelGGL(DcScanKernel, dim3(seg_grid), dim3(kWriteThreads), 0, s, descs_dev, n, num_segments);
   DALIAMD_HIP_CHECK(mark());
   hipLaunchKernelGGL(ExpandKernel, dim3(XcdGrid(num_block_workgroups)), dim3(kExpandThreads), 0, s, descs_dev, n,
                      num_block_workgroups);
