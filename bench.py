@@ -92,13 +92,14 @@ def make_dataset(first_index, count):
 class HotPath:
     """Device-resident batch + the per-step launch sequence."""
 
-    def __init__(self, enc, device, seed=1234, huffman="gpu", inflight=2):
+    def __init__(self, enc, device, seed=1234, huffman="gpu", inflight=2, fused_idct=True):
         import torch
         from dali_amd import backend as B
         self.torch, self.B = torch, B
         self.device = device
         self.n = len(enc)
         self.huffman = huffman
+        self.fused_idct = fused_idct and huffman == "gpu"   # the entropy decoder writes the planes itself
         self.plan = B.JpegBatchPlan(enc, out_pitch_align=16)
         self.coef_host = torch.empty(self.plan.coef_elems, dtype=torch.int16, pin_memory=True)
         t0 = time.perf_counter()
@@ -115,6 +116,17 @@ class HotPath:
             self.plan.check_gpu_status(status)
             if not torch.equal(self.coef_dev.cpu(), self.coef_host):
                 raise SystemExit("bench: GPU Huffman output differs from the host entropy decoder")
+            if self.fused_idct:   # ... and its fused dequantisation + IDCT the stand-alone IDCT kernel's planes
+                ref_planes = torch.zeros(self.plan.plane_bytes, dtype=torch.uint8, device=device)
+                got_planes = torch.zeros_like(ref_planes)
+                scratch_rgb = torch.empty(self.plan.out_bytes, dtype=torch.uint8, device=device)
+                B.jpeg_gpu_stage(self.plan, self.coef_dev, ref_planes, scratch_rgb)
+                status = self.plan.run_gpu_huffman(None, planes_dev=got_planes)
+                torch.cuda.synchronize()
+                self.plan.check_gpu_status(status)
+                if not torch.equal(ref_planes, got_planes):
+                    raise SystemExit("bench: fused Huffman+IDCT planes differ from the IDCT kernel's")
+                del ref_planes, got_planes, scratch_rgb
         else:
             self.coef_dev = self.coef_host.to(device)
         # `inflight` batches are processed concurrently, each on its own HIP stream with its own buffers (what the
@@ -164,9 +176,10 @@ class HotPath:
                     ke = B.KernelEvents(len(B.HUFFMAN_KERNELS))
                     self.kernel_events.append(ke)
                 self.plan.run_gpu_huffman(slot["coef"], events=ev[5:7] if ev else None, ws=slot["ws"],
-                                          kernel_events=ke.handles if ke else None)
+                                          kernel_events=ke.handles if ke else None,
+                                          planes_dev=slot["planes"] if self.fused_idct else None)
             B.jpeg_gpu_stage(self.plan, slot["coef"], slot["planes"], slot["rgb"], split_events=ev[1:2] if ev else None,
-                             start_event=ev[0] if ev else None)
+                             start_event=ev[0] if ev else None, fused_huffman=self.fused_idct)
             anchors, crops = B.random_crop_batch(self.rrc_master, self.shapes)
             mirror = B.coin_flip_batch(self.flip_master, self.n, 0.5)
             self.rrc_master.ctr[1] += self.n   # OperatorWithRng::Advance
@@ -377,6 +390,9 @@ def main():
                     help="batches processed concurrently, each on its own HIP stream (executor prefetch depth)")
     ap.add_argument("--huffman", default="gpu", choices=["gpu", "host"],
                     help="gpu: the step starts from JPEG bytes in HBM (default); host: from host-decoded coefficient blocks")
+    ap.add_argument("--no-fused-idct", action="store_true",
+                    help="store the coefficients and run the stand-alone IDCT kernel (the GPU entropy decoder's default is "
+                         "to dequantise + inverse-transform the blocks itself)")
     ap.add_argument("--workload", default="imagenet", choices=["imagenet", "heavy_aug", "audio"],
                     help="imagenet = the headline metric (default); heavy_aug / audio = configs[2] / configs[3] side benches")
     args = ap.parse_args()
@@ -402,7 +418,7 @@ def main():
 
     B = args.batch
     enc = make_dataset(rank * B, B)  # shard `rank` of `world` (contiguous, like loader.cc:78-87)
-    hp = HotPath(enc, device, huffman=args.huffman, inflight=max(1, args.inflight))
+    hp = HotPath(enc, device, huffman=args.huffman, inflight=max(1, args.inflight), fused_idct=not args.no_fused_idct)
 
     def barrier():
         if world > 1:
@@ -431,10 +447,11 @@ def main():
     ms_color = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
     ms_resample = float(np.mean([e[3].elapsed_time(e[4]) for e in ev]))
     kern = {
-        "JpegIdctKernel": (hp.bytes_idct, ms_idct),
         "JpegColorKernel": (hp.bytes_color, ms_color),
         "ResampleKernel": (float(np.mean(resample_bytes)), ms_resample),
     }
+    if not hp.fused_idct:
+        kern["JpegIdctKernel"] = (hp.bytes_idct, ms_idct)
     if args.huffman == "gpu":
         # per-kernel durations of the entropy decoder (events recorded between its launches, same stream)
         per = np.array([ke.elapsed_ms() for ke in hp.kernel_events]).mean(0)
@@ -443,7 +460,8 @@ def main():
         rec = 4 * symbols
         huff_bytes = {"UnstuffCountKernel": sb, "UnstuffScatterKernel": 2 * sb, "BuildTablesKernel": 27 * 1024 * B,
                       "SyncKernel": sb, "PropagateKernel": 0, "WriteKernel": sb + rec, "DcScanKernel": 0,
-                      "ExpandKernel": rec + 2 * ce}
+                      # records in; coefficients out, or (fused dequantisation + IDCT) the 8-bit samples
+                      "ExpandKernel": rec + (ce if hp.fused_idct else 2 * ce)}
         from dali_amd.backend import HUFFMAN_KERNELS
         for name, ms in zip(HUFFMAN_KERNELS, per):
             kern[name] = (huff_bytes[name], float(ms))
@@ -464,12 +482,12 @@ def main():
             "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/i32 decode, f32 resample, f16 out", "data": "synthetic",
             "config": {"workload": "configs[1]: HIP JPEG " + ("Huffman decode -> " if args.huffman == "gpu" else "") +
-                                   "dequant+IDCT -> upsample+YCbCr->RGB -> fused "
+                                   ("(fused) " if hp.fused_idct else "") + "dequant+IDCT -> upsample+YCbCr->RGB -> fused "
                                    "RandomResizedCrop+CropMirrorNormalize, 224x224, batch=256/GPU, fp16 CHW out; "
                                    "ImageNet-like synthetic JPEGs (seed 1234), inputs = " +
                                    ("JPEG entropy-coded segments (bytes) resident in HBM" if args.huffman == "gpu" else
                                     "host-entropy-decoded coefficient blocks resident in HBM"),
-                       "huffman": args.huffman, "batches_in_flight": len(hp.slots),
+                       "huffman": args.huffman, "fused_dequant_idct": hp.fused_idct, "batches_in_flight": len(hp.slots),
                        "huffman_ms_per_batch(8 kernels)": huffman_total_ms if args.huffman == "gpu" else None,
                        "host_ms_per_step": 1e3 * hp.host_s / args.steps,
                        "jpeg_bytes_per_batch": getattr(hp.plan, "stream_bytes", None),

@@ -209,8 +209,10 @@ class JpegBatchPlan:
         return {"scratch": torch.empty(max(self.huffman_scratch_bytes, 256), dtype=torch.uint8, device=device),
                 "status": torch.zeros(max(len(self._huff_sel), 1), dtype=torch.int32, device=device)}
 
-    def huffman_descs(self, coef_dev, ws=None):
-        """daliamdJpegHuffDesc table of the GPU-eligible streams (numpy structured array) + the two grid sizes."""
+    def huffman_descs(self, coef_dev, ws=None, planes_dev=None):
+        """daliamdJpegHuffDesc table of the GPU-eligible streams (numpy structured array) + the grid sizes.
+        planes_dev: fused output - the decoder dequantises and inverse-transforms the blocks itself and writes the
+        component planes (the input of the colour kernel); coef_dev may be None then."""
         lib = capi.kernels()
         ws = ws or self._huff_ws
         sc, inf, sel = self.scan, self.inf, self._huff_sel
@@ -219,7 +221,12 @@ class JpegBatchPlan:
         d["ecs"] = self._ecs_dev.data_ptr() + self._ecs_off
         d["scratch"] = ws["scratch"].data_ptr() + self._scratch_off
         d["status"] = ws["status"].data_ptr() + 4 * np.arange(m)
-        d["coef"] = np.where(self.comp_mask[sel], coef_dev.data_ptr() + 2 * self.coef_off[sel], 0)
+        if coef_dev is not None:
+            d["coef"] = np.where(self.comp_mask[sel], coef_dev.data_ptr() + 2 * self.coef_off[sel], 0)
+        if planes_dev is not None:
+            d["plane"] = np.where(self.comp_mask[sel], planes_dev.data_ptr() + self.plane_off[sel], 0)
+            d["plane_pitch"] = np.where(self.comp_mask[sel], inf["blocks_x"][sel, :3] * 8, 0)
+            d["quant"] = self.quant[sel]
         d["ecs_len"] = self._ecs_len
         d["blocks_per_mcu"] = sc["blocks_per_mcu"][sel]
         d["mcus_x"] = sc["mcus_x"][sel]
@@ -243,15 +250,16 @@ class JpegBatchPlan:
                                                C.byref(nbwg)))
         return d, ntiles.value, nsegs.value, nbwg.value
 
-    def run_gpu_huffman(self, coef_dev, descs=None, events=None, ws=None, kernel_events=None):
+    def run_gpu_huffman(self, coef_dev, descs=None, events=None, ws=None, kernel_events=None, planes_dev=None):
         """Launches the GPU entropy decoder for the uploaded streams on the current stream (every decoded block is
-        written exactly once as a full line: no zero-fill).  events: optional (before, after) events for timing."""
+        written exactly once as a full line: no zero-fill).  events: optional (before, after) events for timing.
+        planes_dev: fused dequantisation + IDCT (see huffman_descs)."""
         lib = capi.kernels()
-        dev = coef_dev.device
+        dev = (coef_dev if coef_dev is not None else planes_dev).device
         m = len(self._huff_sel)
         ws = ws or self._huff_ws
         if descs is None:
-            descs = self.huffman_descs(coef_dev, ws)
+            descs = self.huffman_descs(coef_dev, ws, planes_dev)
         table, ntiles, nsegs, nbwg = descs
         d_dev = _uploader.upload(table, dev) if m else None
         s = current_stream_ptr(dev)
@@ -267,7 +275,7 @@ class JpegBatchPlan:
         self._huff_keep = [d_dev]
         return ws["status"][:m]
 
-    def entropy_decode_gpu(self, coef_dev, num_threads=None):
+    def entropy_decode_gpu(self, coef_dev, num_threads=None, planes_dev=None):
         """Entropy-decodes the batch into `coef_dev` (int16 device tensor of self.coef_elems elements):
         eligible streams on the GPU (daliamdJpegHuffmanRun), the rest (progressive, restart markers,
         multi-scan) on the host.  Returns the device status tensor (one int32 per GPU-decoded stream) and the
@@ -276,7 +284,7 @@ class JpegBatchPlan:
         self.upload_streams(dev)
         sel = self._huff_sel
         rest = np.nonzero(~self.gpu_eligible)[0]
-        status = self.run_gpu_huffman(coef_dev)
+        status = self.run_gpu_huffman(coef_dev, planes_dev=planes_dev)
         keep = []
         if len(rest):
             host = capi.host()
@@ -323,10 +331,15 @@ class JpegBatchPlan:
             raise capi.DaliAmdError(f"sample {i}: corrupt JPEG data: the entropy-coded segment ends before the last "
                                     f"MCU (GPU Huffman status {int(st[bad[0]])})")
 
-    def build_descs(self, coef_dev, planes_dev, out_dev):
-        """IDCT + colour descriptor tables (numpy structured arrays mirroring the C structs)."""
+    def build_descs(self, coef_dev, planes_dev, out_dev, fused_huffman=False):
+        """IDCT + colour descriptor tables (numpy structured arrays mirroring the C structs).
+        fused_huffman: the GPU entropy decoder already wrote the planes of the streams it decoded (huffman_descs with
+        planes_dev): only the host-decoded streams go through the IDCT kernel."""
         lib = capi.kernels()
         inf, m = self.inf, self.comp_mask
+        color_mask = m
+        if fused_huffman:
+            m = m & ~self.gpu_eligible[:, None]
         cb, pb, ob = coef_dev.data_ptr(), planes_dev.data_ptr(), out_dev.data_ptr()
         ncomp_total = int(m.sum())
         idct = np.zeros(max(ncomp_total, 1), np.dtype(capi.JpegIdctDesc))
@@ -350,10 +363,10 @@ class JpegBatchPlan:
                 idct["rect_y0"][:ncomp_total] = np.where(roi3, rect[:, :, 1], 0)[m]
                 idct["rect_w"][:ncomp_total] = rw[m]
                 idct["nblocks"][:ncomp_total] = np.where(roi3, rw * rh, bx * by)[m]
-            color["plane"][:self.n] = np.where(m, plane_ptr, 0)
-            color["pitch"][:self.n] = np.where(m, bx * 8, 0)
-            color["h_samp"][:self.n] = np.where(m, inf["h_samp"][:, :3], 1)
-            color["v_samp"][:self.n] = np.where(m, inf["v_samp"][:, :3], 1)
+            color["plane"][:self.n] = np.where(color_mask, plane_ptr, 0)
+            color["pitch"][:self.n] = np.where(color_mask, bx * 8, 0)
+            color["h_samp"][:self.n] = np.where(color_mask, inf["h_samp"][:, :3], 1)
+            color["v_samp"][:self.n] = np.where(color_mask, inf["v_samp"][:, :3], 1)
             color["down_w"][:self.n] = inf["down_w"][:, :3]
             color["down_h"][:self.n] = inf["down_h"][:, :3]
             color["width"][:self.n] = inf["width"]
@@ -379,12 +392,14 @@ class JpegBatchPlan:
         return views
 
 
-def jpeg_gpu_stage(plan, coef_dev, planes_dev, out_dev, descs=None, split_events=None, start_event=None):
+def jpeg_gpu_stage(plan, coef_dev, planes_dev, out_dev, descs=None, split_events=None, start_event=None,
+                   fused_huffman=False):
     """Enqueues dequant+IDCT and upsample+colour for a planned batch on the current stream.
-    split_events: optional (event_before_color,) recorded between the two kernels (bench timing)."""
+    split_events: optional (event_before_color,) recorded between the two kernels (bench timing).
+    fused_huffman: see JpegBatchPlan.build_descs."""
     lib = capi.kernels()
     if descs is None:
-        descs = plan.build_descs(coef_dev, planes_dev, out_dev)
+        descs = plan.build_descs(coef_dev, planes_dev, out_dev, fused_huffman=fused_huffman)
     (idct, n_idct, wg_idct), (color, n_color, wg_color) = descs
     dev = coef_dev.device
     idct_dev = _uploader.upload(idct, dev)
@@ -392,7 +407,8 @@ def jpeg_gpu_stage(plan, coef_dev, planes_dev, out_dev, descs=None, split_events
     s = current_stream_ptr(dev)
     if start_event is not None:
         start_event.record()   # after the descriptor uploads: brackets the kernels only
-    capi.check(lib.daliamdJpegIdctRun(s, C.c_void_p(idct_dev.data_ptr()), n_idct, wg_idct))
+    if n_idct:
+        capi.check(lib.daliamdJpegIdctRun(s, C.c_void_p(idct_dev.data_ptr()), n_idct, wg_idct))
     if split_events:
         split_events[0].record()
     capi.check(lib.daliamdJpegColorRun(s, C.c_void_p(color_dev.data_ptr()), n_color, wg_color))
@@ -409,19 +425,22 @@ def decode_jpeg_batch(encoded, device="cuda", num_threads=None, out_pitch_align=
     device = torch.device(device)
     plan = JpegBatchPlan(encoded, out_pitch_align, rois=rois)
     status = None
+    planes = torch.empty(max(plan.plane_bytes, 1), dtype=torch.uint8, device=device)
     if huffman == "gpu":
+        # the GPU entropy decoder writes the component planes itself (fused dequantisation + IDCT); the coefficient
+        # buffer only carries the host-decoded streams (progressive, restart markers, ...) to the IDCT kernel
         coef_host = None
         coef_dev = torch.empty(max(plan.coef_elems, 1), dtype=torch.int16, device=device)
-        status, _ = plan.entropy_decode_gpu(coef_dev, num_threads)
+        status, _ = plan.entropy_decode_gpu(coef_dev, num_threads, planes_dev=planes)
     elif huffman == "host":
         coef_host = torch.empty(max(plan.coef_elems, 1), dtype=torch.int16, pin_memory=True)
         plan.entropy_decode(coef_host, num_threads)
         coef_dev = coef_host.to(device, non_blocking=True)
     else:
         raise ValueError(f"huffman must be 'gpu' or 'host', got {huffman!r}")
-    planes = torch.empty(max(plan.plane_bytes, 1), dtype=torch.uint8, device=device)
     out = torch.empty(max(plan.out_bytes, 1), dtype=torch.uint8, device=device)
-    keep = jpeg_gpu_stage(plan, coef_dev, planes, out)
+    keep = jpeg_gpu_stage(plan, coef_dev, planes, out,
+                          descs=plan.build_descs(coef_dev, planes, out, fused_huffman=huffman == "gpu"))
     views = plan.output_views(out)
     if status is not None and status.numel():
         plan.check_gpu_status(status)   # synchronises

@@ -38,6 +38,7 @@
 // two-dword bit window with the next dword prefetched through the global (not flat) path, no loops on the rare paths.
 #include <cstring>
 #include "common.h"
+#include "jpeg_idct_math.h"
 
 namespace daliamd {
 
@@ -115,6 +116,9 @@ struct HuffTables {
   int32_t reserved;
   uint8_t blk_hs[16], blk_vs[16], blk_ho[16], blk_vo[16];  // block position = (mx*hs + ho, my*vs + vo)
   int32_t blk_rect[12][4];           // {x0, y0, x1, y1} of the block's component
+  // fused output (dequantise + IDCT inside ExpandKernel): plane of the block's component, or all null
+  GlobalBytes *blk_plane[12];
+  int32_t blk_pitch[12];
 };
 static_assert(sizeof(HuffTables) % 16 == 0, "copied with 16-byte accesses");
 
@@ -346,6 +350,8 @@ __global__ __launch_bounds__(256) void BuildTablesKernel(const daliamdJpegHuffDe
     L.blk_ho[tid] = d.h_of_block[tid];
     L.blk_vo[tid] = d.v_of_block[tid];
     for (int j = 0; j < 4; j++) L.blk_rect[tid][j] = d.rect[comp][j];
+    L.blk_plane[tid] = (GlobalBytes *)d.plane[comp];
+    L.blk_pitch[tid] = d.plane_pitch[comp];
   }
   if (tid == 0) {
     uint32_t dc_mask = 0, ac_mask = 0;
@@ -989,10 +995,15 @@ struct ExpandGeom {
   uint8_t comp[16], hs[16], vs[16], ho[16], vo[16], zz[64];
   int32_t sx[12], sy[12], rect[12][4];
   GlobalCoef *base[12];
+  GlobalBytes *plane[12];
+  int32_t pitch[12];
+  int32_t fused;
 };
 __global__ __launch_bounds__(kExpandThreads) void ExpandKernel(const daliamdJpegHuffDesc *__restrict__ descs, int n,
                                                                int nwg) {
   __shared__ __attribute__((aligned(16))) int16_t stage[kExpandBlocks][72];  // 64 + padding
+  __shared__ __attribute__((aligned(16))) int32_t trans[kExpandBlocks][72];  // fused output: IDCT transpose buffer
+  __shared__ __attribute__((aligned(16))) uint16_t quant[3][64];
   __shared__ ExpandGeom G;
   const int wg = XcdRemap(blockIdx.x, nwg);
   if (wg < 0) return;
@@ -1012,6 +1023,12 @@ __global__ __launch_bounds__(kExpandThreads) void ExpandKernel(const daliamdJpeg
     G.sx[tid] = T->blk_sx[tid]; G.sy[tid] = T->blk_sy[tid];
     G.base[tid] = T->blk_base[tid];
     for (int j = 0; j < 4; j++) G.rect[tid][j] = T->blk_rect[tid][j];
+    G.plane[tid] = T->blk_plane[tid];
+    G.pitch[tid] = T->blk_pitch[tid];
+  }
+  if (tid >= 192 && tid < 192 + 48) {  // 3 x 64 quantisation values, four per thread
+    const int c = (tid - 192) >> 4, j = ((tid - 192) & 15) * 4;
+    for (int q = 0; q < 4; q++) quant[c][j + q] = d.quant[c][j + q];
   }
   if (tid >= 64 && tid < 128) G.zz[tid - 64] = T->zz[tid - 64];
   if (tid == 128) {
@@ -1019,6 +1036,7 @@ __global__ __launch_bounds__(kExpandThreads) void ExpandKernel(const daliamdJpeg
     G.decoded_blocks = reinterpret_cast<const int32_t *>(d.scratch)[2];  // < total_blocks: corrupt stream (status 2)
     G.total_blocks = d.total_blocks;
     G.total_records = (uint32_t)reinterpret_cast<const int32_t *>(d.scratch)[1];
+    G.fused = d.plane[d.comp_of_block[0]] != nullptr;
   }
   __syncthreads();
   // {first_record, lane} pairs as dwords; everything below is read through the global address space so that the
@@ -1113,10 +1131,49 @@ __global__ __launch_bounds__(kExpandThreads) void ExpandKernel(const daliamdJpeg
       }
     }
     __syncthreads();
+    if (!G.fused) {
+      if (needed) {
+        const int k = kk[it];
+        uint4 *dst = reinterpret_cast<uint4 *>((int16_t *)(G.base[k] + ((size_t)mys[it] * (size_t)G.sy[k] + (size_t)(mxs[it] * G.sx[k]))));
+        dst[part] = blk_v[part];
+      }
+      continue;
+    }
+    // ---- fused output: dequantise + inverse DCT (JpegIdctKernel's two passes on the block sitting in LDS: lane
+    // `part` owns column `part` in pass 1 and row `part` in pass 2) and store the 8x8 samples to the plane ----
+    if (needed) {
+      const int comp = G.comp[kk[it]];
+      const uint4 raw = blk_v[part];
+      const uint32_t rw[4] = {raw.x, raw.y, raw.z, raw.w};
+      int32_t in[8], o[8];
+#pragma unroll
+      for (int r8 = 0; r8 < 8; r8++) {
+        const int16_t cv = (int16_t)(rw[r8 >> 1] >> (16 * (r8 & 1)));
+        in[r8] = (int32_t)cv * (int32_t)quant[comp][part * 8 + r8];
+      }
+      Butterfly8(in, o);
+      int32_t *w = &trans[lb][part];
+#pragma unroll
+      for (int r8 = 0; r8 < 8; r8++) w[r8 * 8] = Descale(o[r8], CONST_BITS - PASS1_BITS);
+    }
+    __syncthreads();
     if (needed) {
       const int k = kk[it];
-      uint4 *dst = reinterpret_cast<uint4 *>((int16_t *)(G.base[k] + ((size_t)mys[it] * (size_t)G.sy[k] + (size_t)(mxs[it] * G.sx[k]))));
-      dst[part] = blk_v[part];
+      const int4 *rp = reinterpret_cast<const int4 *>(&trans[lb][part * 8]);
+      const int4 a = rp[0], b = rp[1];
+      int32_t in[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      int32_t o[8];
+      Butterfly8(in, o);
+      const int S = CONST_BITS + PASS1_BITS + 3;
+      const uint32_t lo = RangeLimit(Descale(o[0], S)) | (RangeLimit(Descale(o[1], S)) << 8) |
+                          (RangeLimit(Descale(o[2], S)) << 16) | (RangeLimit(Descale(o[3], S)) << 24);
+      const uint32_t hi = RangeLimit(Descale(o[4], S)) | (RangeLimit(Descale(o[5], S)) << 8) |
+                          (RangeLimit(Descale(o[6], S)) << 16) | (RangeLimit(Descale(o[7], S)) << 24);
+      const int bx = mxs[it] * G.hs[k] + G.ho[k], by = mys[it] * G.vs[k] + G.vo[k];
+      typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+      using GlobalPair = u32x2_t __attribute__((address_space(1)));
+      GlobalPair *dst = (GlobalPair *)(G.plane[k] + (size_t)(by * 8 + part) * G.pitch[k] + (size_t)bx * 8);
+      *dst = u32x2_t{lo, hi};
     }
   }
 }
@@ -1146,11 +1203,22 @@ daliamdResult_t daliamdJpegHuffmanSetup(daliamdJpegHuffDesc *descs_host, int n, 
     DALIAMD_REQUIRE(d.blocks_per_mcu >= 1 && d.blocks_per_mcu <= DALIAMD_JPEG_MAX_BLOCKS_PER_MCU && d.mcus_x >= 1 &&
                         d.total_blocks >= 1 && d.total_blocks % d.blocks_per_mcu == 0,
                     DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdJpegHuffmanSetup: sample %d: bad MCU geometry", i);
+    const bool fused = d.comp_of_block[0] < 3 && d.plane[d.comp_of_block[0]] != nullptr;
     for (int k = 0; k < d.blocks_per_mcu; k++) {
-      DALIAMD_REQUIRE(d.comp_of_block[k] < 3 && d.coef[d.comp_of_block[k]], DALIAMD_ERROR_INVALID_ARGUMENT,
+      const int comp = d.comp_of_block[k];
+      DALIAMD_REQUIRE(comp < 3 && (fused ? d.plane[comp] != nullptr : d.coef[comp] != nullptr),
+                      DALIAMD_ERROR_INVALID_ARGUMENT,
                       "daliamdJpegHuffmanSetup: sample %d: block %d refers to a missing component", i, k);
-      DALIAMD_REQUIRE((reinterpret_cast<uintptr_t>(d.coef[d.comp_of_block[k]]) & 15) == 0, DALIAMD_ERROR_INVALID_ARGUMENT,
-                      "daliamdJpegHuffmanSetup: sample %d: coefficient arrays must be 16-byte aligned", i);
+      if (fused) {
+        DALIAMD_REQUIRE((reinterpret_cast<uintptr_t>(d.plane[comp]) & 7) == 0 && (d.plane_pitch[comp] & 7) == 0 &&
+                            d.plane_pitch[comp] >= d.blocks_x[comp] * 8,
+                        DALIAMD_ERROR_INVALID_ARGUMENT,
+                        "daliamdJpegHuffmanSetup: sample %d: planes must be 8-byte aligned with a pitch that is a "
+                        "multiple of 8 and covers blocks_x * 8 samples", i);
+      } else {
+        DALIAMD_REQUIRE((reinterpret_cast<uintptr_t>(d.coef[comp]) & 15) == 0, DALIAMD_ERROR_INVALID_ARGUMENT,
+                        "daliamdJpegHuffmanSetup: sample %d: coefficient arrays must be 16-byte aligned", i);
+      }
     }
     for (int t = 0; t < 4; t++)  // record capacity: every symbol consumes at least two bits
       DALIAMD_REQUIRE(d.bits[t][0] == 0, DALIAMD_ERROR_UNSUPPORTED,

@@ -307,6 +307,10 @@ class ImageDecoderMixed : public OperatorBase {
         d.total_blocks = sc.mcus_x * sc.mcus_y * sc.blocks_per_mcu;
         for (int c = 0; c < inf.num_components; c++) {
           d.coef[c] = coef + coef_off_[i * 3 + c];
+          // fused output: the decoder dequantises + inverse-transforms its blocks and writes the planes itself
+          d.plane[c] = static_cast<uint8_t *>(planes.data()) + coef_off_[i * 3 + c];
+          d.plane_pitch[c] = inf.blocks_x[c] * 8;
+          memcpy(d.quant[c], &quant_[(size_t)i * 192 + c * 64], 128);
           d.blocks_x[c] = inf.blocks_x[c];
           d.h_samp[c] = inf.h_samp[c];
           d.v_samp[c] = inf.v_samp[c];
@@ -346,20 +350,22 @@ class ImageDecoderMixed : public OperatorBase {
       const auto &inf = infos_[i];
       auto &cd = color[kc++];
       for (int c = 0; c < inf.num_components; c++) {
-        auto &d = idct[k++];
-        d.coef = coef + coef_off_[i * 3 + c];
-        d.plane = static_cast<uint8_t *>(planes.data()) + coef_off_[i * 3 + c];
-        d.blocks_x = inf.blocks_x[c];
-        d.nblocks = inf.blocks_x[c] * inf.blocks_y[c];
-        d.pitch = inf.blocks_x[c] * 8;
-        if (plans_[i].roi_w > 0) {
-          const int32_t *r = plans_[i].rect[c];
-          d.rect_x0 = r[0]; d.rect_y0 = r[1]; d.rect_w = r[2] - r[0];
-          d.nblocks = (r[2] - r[0]) * (r[3] - r[1]);
+        cd.plane[c] = static_cast<uint8_t *>(planes.data()) + coef_off_[i * 3 + c];
+        cd.pitch[c] = inf.blocks_x[c] * 8;
+        if (!scans_[i].eligible) {  // host-decoded coefficients: the stand-alone IDCT kernel
+          auto &d = idct[k++];
+          d.coef = coef + coef_off_[i * 3 + c];
+          d.plane = static_cast<uint8_t *>(planes.data()) + coef_off_[i * 3 + c];
+          d.blocks_x = inf.blocks_x[c];
+          d.nblocks = inf.blocks_x[c] * inf.blocks_y[c];
+          d.pitch = cd.pitch[c];
+          if (plans_[i].roi_w > 0) {
+            const int32_t *r = plans_[i].rect[c];
+            d.rect_x0 = r[0]; d.rect_y0 = r[1]; d.rect_w = r[2] - r[0];
+            d.nblocks = (r[2] - r[0]) * (r[3] - r[1]);
+          }
+          memcpy(d.quant, &quant_[(size_t)i * 192 + c * 64], 128);
         }
-        memcpy(d.quant, &quant_[(size_t)i * 192 + c * 64], 128);
-        cd.plane[c] = d.plane;
-        cd.pitch[c] = d.pitch;
         cd.h_samp[c] = inf.h_samp[c]; cd.v_samp[c] = inf.v_samp[c];
         cd.down_w[c] = inf.down_w[c]; cd.down_h[c] = inf.down_h[c];
       }
@@ -374,7 +380,8 @@ class ImageDecoderMixed : public OperatorBase {
       }
     }
     int wg_idct = 0, wg_color = 0;
-    KCHECK(daliamdJpegIdctSetup(idct, ncomp_total, &wg_idct));
+    const int nidct = k;  // components of the host-decoded streams only
+    KCHECK(daliamdJpegIdctSetup(idct, nidct, &wg_idct));
     KCHECK(daliamdJpegColorSetup(color, nact, &wg_color));
     // ---- ONE transfer (JPEG bytes + the three tables) on the copy stream: it overlaps the kernels of the previous
     // iteration; the compute stream waits for it through an event ----
@@ -397,11 +404,12 @@ class ImageDecoderMixed : public OperatorBase {
       for (int c = 0; c < infos_[i].num_components; c++) count += infos_[i].coef_elems[c];
       KCHECK(daliamdMemcpyH2DAsync(coef + first, coef_host + first, (size_t)count * 2, ws.stream));
     }
-    KCHECK(daliamdJpegIdctRun(ws.stream, reinterpret_cast<const daliamdJpegIdctDesc *>(dev_base + idct_off), ncomp_total,
-                              wg_idct));
+    if (nidct)
+      KCHECK(daliamdJpegIdctRun(ws.stream, reinterpret_cast<const daliamdJpegIdctDesc *>(dev_base + idct_off), nidct,
+                                wg_idct));
     KCHECK(daliamdJpegColorRun(ws.stream, reinterpret_cast<const daliamdJpegColorDesc *>(dev_base + color_off), nact,
                                wg_color));
-    NoteLaunch(ws, "jpeg_idct");
+    if (nidct) NoteLaunch(ws, "jpeg_idct");
     NoteLaunch(ws, "jpeg_color");
     if (cache_) {
       cache_->Commit(reserved.keys, ws.stream);  // visible to later iterations (and other pipelines) from here on

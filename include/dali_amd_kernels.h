@@ -133,7 +133,7 @@ typedef struct {
   const uint8_t *ecs;      /* device: entropy-coded segment (still byte-stuffed)                  */
   uint8_t *scratch;        /* device scratch, see above                                            */
   int32_t *status;         /* device: one int, pre-zeroed                                          */
-  int16_t *coef[3];        /* device: per component [blocks_y][blocks_x][64], 16-byte aligned      */
+  int16_t *coef[3];        /* device: per component [blocks_y][blocks_x][64], 16-byte aligned (or see plane) */
   int32_t ecs_len;
   int32_t blocks_per_mcu;  /* sum of h*v over the components                                       */
   int32_t mcus_x;          /* MCUs per row                                                         */
@@ -152,6 +152,15 @@ typedef struct {
    * coefficients are needed; blocks outside are parsed (the stream is serial) but not stored, and the parse stops
    * after the last MCU row that intersects a rectangle.  All zero: every block. */
   int32_t rect[3][4];
+  /* Optional fused output.  With plane[c] != NULL for the components of the stream the decoder dequantises and
+   * inverse-transforms every block it assembles (the arithmetic of daliamdJpegIdctRun) and writes the 8x8 samples
+   * into the component planes - [blocks_y*8][plane_pitch[c]], the input of daliamdJpegColorRun - instead of storing
+   * the coefficients; coef[] is not used then and the 2 x 2 bytes per coefficient of traffic between the two kernels
+   * disappear.  plane[c] must be 8-byte aligned, plane_pitch[c] a multiple of 8 (>= blocks_x[c] * 8). */
+  uint8_t *plane[3];
+  int32_t plane_pitch[3];
+  int32_t reserved2;
+  uint16_t quant[3][64];   /* per component, column-major element order as daliamdJpegIdctDesc.quant */
 } daliamdJpegHuffDesc;
 
 DALIAMD_API daliamdResult_t daliamdJpegHuffmanScratchBytes(int ecs_len, int total_blocks, size_t *bytes);

@@ -83,6 +83,37 @@ def test_gpu_huffman_coefficients_equal_host_decoder():
                 f"first at {np.nonzero(got[a:b] != ref[a:b])[0][0]}"
 
 
+def test_gpu_huffman_fused_idct_planes_equal_the_idct_kernel():
+    """The entropy decoder's fused output (dequantise + IDCT inside ExpandKernel, planes instead of coefficients) is
+    bit-identical to storing the coefficients and running JpegIdctKernel - full images and block rectangles."""
+    from dali_amd import backend as B
+    rng = np.random.default_rng(21)
+    enc = []
+    for (h, w), kw in [((375, 500), dict(subsampling="4:2:0")), ((96, 131), dict(subsampling="4:4:4")),
+                       ((200, 333), dict(subsampling="4:2:2")), ((64, 48), dict(subsampling="4:1:1", quality=98)),
+                       ((130, 70), dict(subsampling="4:2:0", quality=20)), ((1, 1), {}), ((8, 9), {})]:
+        enc.append(encode_jpeg(synth_image(rng, h, w), **({"quality": 85} | kw)))
+    enc.append(encode_jpeg(synth_image(rng, 77, 91, 1), 80))                      # grayscale
+    for rois in (None, [(10, 20, 100, 200), (3, 5, 60, 100), None, (8, 8, 32, 24), None, None, None, (0, 0, 77, 91)]):
+        plan = B.JpegBatchPlan(enc, 16, rois=rois)
+        assert plan.analyze_scans().all()
+        dev = torch.device("cuda")
+        plan.upload_streams(dev)
+        coef = torch.zeros(plan.coef_elems, dtype=torch.int16, device=dev)
+        ref = torch.zeros(plan.plane_bytes, dtype=torch.uint8, device=dev)
+        got = torch.zeros_like(ref)
+        rgb = torch.empty(max(plan.out_bytes, 1), dtype=torch.uint8, device=dev)
+        status = plan.run_gpu_huffman(coef)
+        B.jpeg_gpu_stage(plan, coef, ref, rgb)                                    # IDCT kernel -> ref planes
+        torch.cuda.synchronize()
+        plan.check_gpu_status(status)
+        status = plan.run_gpu_huffman(None, planes_dev=got)                        # fused -> planes, no coefficients
+        torch.cuda.synchronize()
+        plan.check_gpu_status(status)
+        assert torch.equal(ref, got)
+        assert int(ref.count_nonzero()) > 0
+
+
 def test_gpu_huffman_eligibility_and_mixed_batches():
     rng = np.random.default_rng(5)
     img = synth_image(rng, 120, 160)

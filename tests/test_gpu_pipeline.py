@@ -87,7 +87,9 @@ def test_train_pipeline_matches_oracle(jpeg_dir, fused):
         else:
             assert "resample" in kernels and "cmn" in kernels and "fused_resample_cmn" not in kernels
             assert np.array_equal(outs[2].as_tensor().cpu().numpy(), ref_u8)
-        assert "jpeg_huffman" in kernels and "jpeg_idct" in kernels and "jpeg_color" in kernels
+        # (the stand-alone IDCT kernel only runs for streams the host entropy decoder took: the GPU decoder's block
+        # output is already dequantised and inverse-transformed)
+        assert "jpeg_huffman" in kernels and "jpeg_color" in kernels
 
 
 def test_decoder_output_and_exif_orientation(tmp_path):
