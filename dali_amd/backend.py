@@ -460,7 +460,7 @@ def _fill4(dst, src):
         dst[i] = float(src[i]) if i < len(src) else (float(src[-1]) if len(src) == 1 else 0.0)
 
 
-HUFFMAN_KERNELS = ("UnstuffCountKernel", "UnstuffScatterKernel", "BuildTablesKernel", "SyncKernel",
+HUFFMAN_KERNELS = ("PrepareKernel", "UnstuffScatterKernel", "SyncKernel",
                    "PropagateKernel", "WriteKernel", "DcScanKernel", "ExpandKernel")
 
 

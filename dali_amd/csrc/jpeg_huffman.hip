@@ -248,8 +248,8 @@ __device__ __forceinline__ TileChunk LoadChunk(const daliamdJpegHuffDesc &d, int
   return c;
 }
 
-__global__ __launch_bounds__(kTileThreads) void UnstuffCountKernel(const daliamdJpegHuffDesc *__restrict__ descs, int n) {
-  __shared__ int wave_sums[kTileThreads / 64];
+// First pass of the un-stuffing: bytes each tile keeps (PrepareKernel).
+__device__ __forceinline__ void CountTile(const daliamdJpegHuffDesc *__restrict__ descs, int n, int *wave_sums) {
   const ImageRef r = FindImage<true>(descs, n, blockIdx.x);
   const daliamdJpegHuffDesc &d = *r.d;
   const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments, d.total_blocks);
@@ -327,18 +327,18 @@ __device__ __forceinline__ void CopyTables(Tables &dst, const Tables *src) {
   for (int i = threadIdx.x; i < (int)(sizeof(Tables) / 16); i += THREADS) t[i] = s[i];
 }
 
-__global__ __launch_bounds__(256) void BuildTablesKernel(const daliamdJpegHuffDesc *__restrict__ descs) {
-  __shared__ __attribute__((aligned(16))) HuffTables L;
-  const daliamdJpegHuffDesc &d = descs[blockIdx.x];
+// Code tables of one stream (all threads of a PrepareKernel workgroup).
+__device__ __forceinline__ void BuildTables(const daliamdJpegHuffDesc &d, HuffTables &L) {
+  constexpr int NT = kTileThreads;
   const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments, d.total_blocks);
   const int tid = threadIdx.x;
   {
     uint4 *z = reinterpret_cast<uint4 *>(&L);
-    for (int i = tid; i < (int)(sizeof(HuffTables) / 16); i += 256) z[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < (int)(sizeof(HuffTables) / 16); i += NT) z[i] = make_uint4(0, 0, 0, 0);
   }
   __syncthreads();
   if (tid < 64) L.zz[tid] = kZigZagColMajor[tid];
-  for (int t = tid; t < 4 * 256; t += 256) L.vals[t >> 8][t & 255] = d.vals[t >> 8][t & 255];
+  for (int t = tid; t < 4 * 256; t += NT) L.vals[t >> 8][t & 255] = d.vals[t >> 8][t & 255];
   if (tid < 12 && tid < d.blocks_per_mcu) {
     const int comp = d.comp_of_block[tid];
     L.blk_comp[tid] = (uint8_t)comp;
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256) void BuildTablesKernel(const daliamdJpegHuffDe
   }
   __syncthreads();
   // every table entry is found independently: the shortest length whose code range contains the window's prefix
-  for (int idx = tid; idx < 4 * (1 << kFastBits); idx += 256) {
+  for (int idx = tid; idx < 4 * (1 << kFastBits); idx += NT) {
     const int t = idx >> kFastBits, w = idx & ((1 << kFastBits) - 1);
     uint16_t e = 0;
     for (int l = 1; l <= kFastBits; l++) {
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256) void BuildTablesKernel(const daliamdJpegHuffDe
     }
     L.fast[t][w] = e;
   }
-  for (int idx = tid; idx < 4 * kL2Entries; idx += 256) {
+  for (int idx = tid; idx < 4 * kL2Entries; idx += NT) {
     const int t = idx / kL2Entries, j = idx % kL2Entries;
     uint16_t e = 0;
     if (j < L.l2_size[t]) {
@@ -432,10 +432,10 @@ __global__ __launch_bounds__(256) void BuildTablesKernel(const daliamdJpegHuffDe
   __syncthreads();
   const uint4 *s = reinterpret_cast<const uint4 *>(&L);
   uint4 *t = reinterpret_cast<uint4 *>(d.scratch + lay.tables);
-  for (int i = tid; i < (int)(sizeof(HuffTables) / 16); i += 256) t[i] = s[i];
+  for (int i = tid; i < (int)(sizeof(HuffTables) / 16); i += NT) t[i] = s[i];
   // ---- tables of the position-only passes, straight to global memory ----
   SyncTables *S = reinterpret_cast<SyncTables *>(d.scratch + lay.sync_tables);
-  for (int idx = tid; idx < 4 * (1 << kFastBits); idx += 256) {
+  for (int idx = tid; idx < 4 * (1 << kFastBits); idx += NT) {
     const int tb = idx >> kFastBits, w = idx & ((1 << kFastBits) - 1);
     const uint32_t e1 = L.fast[tb][w];
     uint32_t e = 0;
@@ -452,8 +452,8 @@ __global__ __launch_bounds__(256) void BuildTablesKernel(const daliamdJpegHuffDe
     }
     S->t32[tb][w] = e;
   }
-  for (int i = tid; i < 4 * kL2Entries; i += 256) S->l2[i / kL2Entries][i % kL2Entries] = L.l2[i / kL2Entries][i % kL2Entries];
-  for (int i = tid; i < 4 * 256; i += 256) S->vals[i >> 8][i & 255] = L.vals[i >> 8][i & 255];
+  for (int i = tid; i < 4 * kL2Entries; i += NT) S->l2[i / kL2Entries][i % kL2Entries] = L.l2[i / kL2Entries][i % kL2Entries];
+  for (int i = tid; i < 4 * 256; i += NT) S->vals[i >> 8][i & 255] = L.vals[i >> 8][i & 255];
   if (tid < 4 * 18) {
     S->maxcode[tid / 18][tid % 18] = L.maxcode[tid / 18][tid % 18];
     S->valoff[tid / 18][tid % 18] = L.valoff[tid / 18][tid % 18];
@@ -468,6 +468,16 @@ __global__ __launch_bounds__(256) void BuildTablesKernel(const daliamdJpegHuffDe
     S->bpm = L.bpm;
     S->reserved = 0;
   }
+}
+
+// One launch for the two jobs that only need the descriptors: workgroups [0, num_tiles) count the bytes their tile of
+// the stuffed stream keeps, workgroups [num_tiles, num_tiles + n) build the code tables of one stream each.
+__global__ __launch_bounds__(kTileThreads) void PrepareKernel(const daliamdJpegHuffDesc *__restrict__ descs, int n,
+                                                              int num_tiles) {
+  __shared__ __attribute__((aligned(16))) HuffTables L;
+  __shared__ int wave_sums[kTileThreads / 64];
+  if ((int)blockIdx.x < num_tiles) CountTile(descs, n, wave_sums);
+  else BuildTables(descs[blockIdx.x - num_tiles], L);
 }
 
 // ------------------------------------------------------------------------------------------------ decode
@@ -1249,11 +1259,9 @@ static daliamdResult_t LaunchHuffman(daliamdStream_t stream, const daliamdJpegHu
   int e = 0;
   auto mark = [&]() -> hipError_t { return events ? hipEventRecord((hipEvent_t)events[e++], s) : hipSuccess; };
   DALIAMD_HIP_CHECK(mark());
-  hipLaunchKernelGGL(UnstuffCountKernel, dim3(num_tiles), dim3(kTileThreads), 0, s, descs_dev, n);
+  hipLaunchKernelGGL(PrepareKernel, dim3(num_tiles + n), dim3(kTileThreads), 0, s, descs_dev, n, num_tiles);
   DALIAMD_HIP_CHECK(mark());
   hipLaunchKernelGGL(UnstuffScatterKernel, dim3(num_tiles), dim3(kTileThreads), 0, s, descs_dev, n);
-  DALIAMD_HIP_CHECK(mark());
-  hipLaunchKernelGGL(BuildTablesKernel, dim3(n), dim3(256), 0, s, descs_dev);
   DALIAMD_HIP_CHECK(mark());
   hipLaunchKernelGGL(SyncKernel, dim3(seg_grid), dim3(kSegThreads), 0, s, descs_dev, n, num_segments);
   DALIAMD_HIP_CHECK(mark());

@@ -130,11 +130,12 @@ struct Epilogue {
     float f = (float)v;
     if (dtype == DALIAMD_UINT8) {
       if (normalize) f = RoundU8((f - mean) * inv_std, false);
-      reinterpret_cast<uint8_t *>(out)[o] = (uint8_t)f;
+      ((uint8_t __attribute__((address_space(1))) *)out)[o] = (uint8_t)f;
     } else {
       if (normalize) f = (f - mean) * inv_std;
-      if (dtype == DALIAMD_FLOAT16) reinterpret_cast<uint16_t *>(out)[o] = Float2HalfAway(f);
-      else reinterpret_cast<float *>(out)[o] = f;
+      // (explicit global address space: generic stores would also count against the LDS counter)
+      if (dtype == DALIAMD_FLOAT16) ((uint16_t __attribute__((address_space(1))) *)out)[o] = Float2HalfAway(f);
+      else ((float __attribute__((address_space(1))) *)out)[o] = f;
     }
   }
 };
@@ -262,13 +263,15 @@ __global__ __launch_bounds__(kResampleThreads) void ResampleKernel(const daliamd
         uintptr_t g = ra - sh + 16 * q;
         uint4 v;
         if (g >= buf_lo && g + 16 <= buf_hi) {
-          v = *reinterpret_cast<const uint4 *>(g);
+          typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+          const u32x4_t t = *(const u32x4_t __attribute__((address_space(1))) *)g;  // global, not generic: the loads
+          v = make_uint4(t.x, t.y, t.z, t.w);                                       // of a row may overlap the LDS stores
         } else {  // chunk straddles the buffer boundary: assemble from the in-bounds bytes
           uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
 #pragma unroll
           for (int b = 0; b < 16; b++) {
             uintptr_t a = g + b;
-            uint32_t byte = (a >= buf_lo && a < buf_hi) ? (uint32_t)(*reinterpret_cast<const uint8_t *>(a)) : 0u;
+            uint32_t byte = (a >= buf_lo && a < buf_hi) ? (uint32_t)(*(const uint8_t __attribute__((address_space(1))) *)a) : 0u;
             byte <<= 8 * (b & 3);
             if (b < 4) w0 |= byte; else if (b < 8) w1 |= byte; else if (b < 12) w2 |= byte; else w3 |= byte;
           }

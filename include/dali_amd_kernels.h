@@ -168,13 +168,14 @@ DALIAMD_API daliamdResult_t daliamdJpegHuffmanScratchBytes(int ecs_len, int tota
  * tile_start/num_tiles/seg_start/num_segments/blk_wg_start, returns the three grid sizes. */
 DALIAMD_API daliamdResult_t daliamdJpegHuffmanSetup(daliamdJpegHuffDesc *descs_host, int n, int *num_tiles,
                                                     int *num_segments, int *num_block_workgroups);
-/* Eight launches: un-stuff (count, scatter), tables, synchronise, propagate, write (records), DC scan, expand. */
+/* Seven launches: prepare (un-stuff count + code tables), un-stuff scatter, synchronise, propagate, write (records),
+ * DC scan, expand. */
 DALIAMD_API daliamdResult_t daliamdJpegHuffmanRun(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev, int n,
                                                   int num_tiles, int num_segments, int num_block_workgroups);
-/* Same launches with events[0..8] (created with timing enabled) recorded before each kernel and after the last:
- * events[i] .. events[i+1] brackets kernel i of {un-stuff count, un-stuff scatter, tables, synchronise, propagate,
- * write, DC scan, expand}.  For benchmarks. */
-#define DALIAMD_JPEG_HUFFMAN_KERNELS 8
+/* Same launches with events[0..7] (created with timing enabled) recorded before each kernel and after the last:
+ * events[i] .. events[i+1] brackets kernel i of {prepare, un-stuff scatter, synchronise, propagate, write, DC scan,
+ * expand}.  For benchmarks. */
+#define DALIAMD_JPEG_HUFFMAN_KERNELS 7
 DALIAMD_API daliamdResult_t daliamdJpegHuffmanRunProfiled(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev,
                                                           int n, int num_tiles, int num_segments,
                                                           int num_block_workgroups, daliamdEvent_t *events);
