@@ -93,6 +93,7 @@ class Buffer {
   void Reserve(size_t bytes);
   void *data() const { return ptr_; }
   size_t capacity() const { return cap_; }
+  bool pinned() const { return pinned_; }
   StorageDevice device() const { return dev_; }
 
  private:
@@ -129,6 +130,10 @@ class TensorList {
   void Resize(const std::vector<TensorShape> &shapes, DALIDataType type, int pitch_align, const std::vector<void *> &ext_ptr,
               const std::vector<int64_t> &ext_pitch, std::shared_ptr<void> keepalive);
   bool is_external(int i) const { return !ext_.empty() && ext_[i]; }
+  // the one block behind the samples (raw(i) - base() is sample i's offset) and whether it is page-locked: a device
+  // operator may then transfer straight from it instead of staging a copy
+  const void *base() const { return buf_->data(); }
+  bool pinned() const { return buf_->pinned(); }
   // shares storage and metadata (zero-copy pass-through)
   void ShareData(const TensorList &other);
   // metadata only; used when an operator's work is deferred to its consumer

@@ -6,6 +6,7 @@
 //   CropMirrorNormalize      dali/operators/image/crop/crop_mirror_normalize.{h,cc}, new_crop_mirror_normalize.cu
 //   CropAttr                 dali/operators/image/crop/crop_attr.cc:21-240
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 
@@ -113,6 +114,13 @@ class ImageDecoderMixed : public OperatorBase {
   ~ImageDecoderMixed() override {
     for (auto e : h2d_done_)
       if (e) daliamdEventDestroy(e);
+    if (trace_ && trace_runs_ > 0) {
+      static const char *names[] = {"parse + scan analysis + staging copy (thread pool)", "layout, windows, allocation",
+                                    "host entropy decode of the other streams", "descriptor tables",
+                                    "transfer + kernel launches"};
+      for (int i = 0; i < 5; i++)
+        fprintf(stderr, "[dali_amd trace]     decoder: %-52s %8.3f ms\n", names[i], 1e3 * trace_s_[i] / trace_runs_);
+    }
   }
   int OutputPitchAlign(int) const override { return kImagePitchAlign; }
   bool SetupImpl(std::vector<OutputDesc> &, const Workspace &) override { return false; }
@@ -122,6 +130,14 @@ class ImageDecoderMixed : public OperatorBase {
     TensorList &out = ws.Output(0);
     const int n = in.num_samples();
     DALI_ENFORCE(in.type() == DALI_UINT8, "decoders.image expects encoded streams as 1-D uint8 tensors");
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](int phase) {  // DALI_AMD_TRACE=1: host time of the phases of this operator
+      if (!trace_) return;
+      auto t = std::chrono::steady_clock::now();
+      trace_s_[phase] += std::chrono::duration<double>(t - t_last).count();
+      t_last = t;
+    };
+    trace_runs_++;
     infos_.resize(n);
     scans_.resize(n);
     auto src = [&](int i) { return i < (int)in.source_info.size() && !in.source_info[i].empty() ? in.source_info[i]
@@ -144,18 +160,25 @@ class ImageDecoderMixed : public OperatorBase {
         }
       }
     }
+    // The reader's output already sits in page-locked memory (Buffer::Reserve): the whole block is transferred as it
+    // is and the entropy-coded segments are addressed inside it - no staging copy of the JPEG bytes.  (With cache
+    // hits in the batch, or input from elsewhere, the segments of the active samples are packed into the staging
+    // buffer as before.)
+    const bool direct = nact == n && n > 0 && in.device() == StorageDevice::CPU && in.pinned() && !in.is_external(0);
     ecs_off_.assign(n, 0);
     size_t ecs_bytes = 0;
     for (int i = 0; i < n; i++) {
-      ecs_off_[i] = ecs_bytes;
+      ecs_off_[i] = direct ? (size_t)(static_cast<const uint8_t *>(in.raw(i)) - static_cast<const uint8_t *>(in.base()))
+                           : ecs_bytes;
       if (!hit_[i]) ecs_bytes += ((size_t)in.nbytes(i) + 15) & ~(size_t)15;
     }
+    if (direct) ecs_bytes = (in.total_bytes() + 15) & ~(size_t)15;
     // the three descriptor tables of the iteration live behind the JPEG bytes in the same staging buffer, so that
     // ONE host->device copy (on the copy stream) carries everything the kernels need
     auto align16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
     const size_t table_bytes = align16((size_t)n * sizeof(daliamdJpegHuffDesc)) + align16((size_t)n * 3 * sizeof(daliamdJpegIdctDesc)) +
                                align16((size_t)n * sizeof(daliamdJpegColorDesc));
-    ecs_stage.Reserve(ecs_bytes + table_bytes + 256);
+    ecs_stage.Reserve((direct ? 0 : ecs_bytes) + table_bytes + 256);
     for (int i = 0; i < n; i++) {
       if (hit_[i]) {
         infos_[i] = daliamdJpegInfo{};  // no components: every per-component loop below skips the sample
@@ -172,12 +195,13 @@ class ImageDecoderMixed : public OperatorBase {
         if (!host_huffman_only_ && (int64_t)infos_[i].width * infos_[i].height >= huffman_threshold_ &&
             daliamdJpegAnalyzeScan(data, in.nbytes(i), &infos_[i], &scans_[i]) != 0)
           scans_[i].eligible = 0;  // the host decoder will produce the diagnosis
-        if (scans_[i].eligible)
+        if (scans_[i].eligible && !direct)
           memcpy(static_cast<uint8_t *>(ecs_stage.data()) + ecs_off_[i], data + scans_[i].ecs_offset,
                  (size_t)scans_[i].ecs_length);
       }, (int64_t)in.nbytes(i));
     }
     ws.GetThreadPool().RunAll();
+    lap(0);
     // ---- layout ----
     std::vector<TensorShape> shapes(n);
     coef_off_.assign(n * 3, 0);
@@ -258,6 +282,7 @@ class ImageDecoderMixed : public OperatorBase {
     out.SetLayout("HWC");
     out.source_info = in.source_info;
     quant_.assign((size_t)n * 3 * 64, 0);
+    lap(1);
     // ---- host entropy decode of the streams the GPU kernel does not take (thread pool) ----
     int16_t *coef_host = static_cast<int16_t *>(stage.data());
     for (int i = 0; i < n; i++) {
@@ -275,6 +300,7 @@ class ImageDecoderMixed : public OperatorBase {
       }, (int64_t)in.nbytes(i));
     }
     if (ngpu < nact) ws.GetThreadPool().RunAll();
+    lap(2);
     if (nact == 0) return;  // empty batch, or every sample came from the cache
     // ---- entropy decoding on the device ----
     int16_t *coef = static_cast<int16_t *>(cdev.data());
@@ -284,10 +310,12 @@ class ImageDecoderMixed : public OperatorBase {
     const size_t huff_off = align16(ecs_bytes), idct_off = huff_off + align16((size_t)ngpu * sizeof(daliamdJpegHuffDesc));
     const size_t color_off = idct_off + align16((size_t)ncomp_total * sizeof(daliamdJpegIdctDesc));
     const size_t upload_bytes = color_off + align16((size_t)nact * sizeof(daliamdJpegColorDesc));
-    daliamdJpegHuffDesc *huff = reinterpret_cast<daliamdJpegHuffDesc *>(stage_base + huff_off);
-    daliamdJpegIdctDesc *idct = reinterpret_cast<daliamdJpegIdctDesc *>(stage_base + idct_off);
-    daliamdJpegColorDesc *color = reinterpret_cast<daliamdJpegColorDesc *>(stage_base + color_off);
-    memset(stage_base + huff_off, 0, upload_bytes - huff_off);
+    // host copy of the tables: behind the packed segments, or (direct transfer) at the start of the staging buffer
+    uint8_t *tab_host = stage_base + (direct ? 0 : huff_off);
+    daliamdJpegHuffDesc *huff = reinterpret_cast<daliamdJpegHuffDesc *>(tab_host);
+    daliamdJpegIdctDesc *idct = reinterpret_cast<daliamdJpegIdctDesc *>(tab_host + (idct_off - huff_off));
+    daliamdJpegColorDesc *color = reinterpret_cast<daliamdJpegColorDesc *>(tab_host + (color_off - huff_off));
+    memset(tab_host, 0, upload_bytes - huff_off);
     int ntiles = 0, nsegs = 0, nbwg = 0;
     if (ngpu) {
       // status words: pinned host memory the kernels write directly (no copy back); cleared here by the CPU
@@ -298,7 +326,7 @@ class ImageDecoderMixed : public OperatorBase {
         const auto &inf = infos_[i];
         const auto &sc = scans_[i];
         auto &d = huff[j];
-        d.ecs = dev_base + ecs_off_[i];
+        d.ecs = dev_base + ecs_off_[i] + (direct ? (size_t)sc.ecs_offset : 0);
         d.scratch = static_cast<uint8_t *>(scratch.data()) + scratch_off_[i];
         d.status = status + j;
         d.ecs_len = (int32_t)sc.ecs_length;
@@ -383,10 +411,16 @@ class ImageDecoderMixed : public OperatorBase {
     const int nidct = k;  // components of the host-decoded streams only
     KCHECK(daliamdJpegIdctSetup(idct, nidct, &wg_idct));
     KCHECK(daliamdJpegColorSetup(color, nact, &wg_color));
+    lap(3);
     // ---- ONE transfer (JPEG bytes + the three tables) on the copy stream: it overlaps the kernels of the previous
     // iteration; the compute stream waits for it through an event ----
     daliamdStream_t cs = ws.copy_stream ? ws.copy_stream : ws.stream;
-    KCHECK(daliamdMemcpyH2DAsync(ecs_dev.data(), ecs_stage.data(), upload_bytes, cs));
+    if (direct) {
+      KCHECK(daliamdMemcpyH2DAsync(ecs_dev.data(), in.base(), in.total_bytes(), cs));
+      KCHECK(daliamdMemcpyH2DAsync(static_cast<uint8_t *>(ecs_dev.data()) + huff_off, tab_host, upload_bytes - huff_off, cs));
+    } else {
+      KCHECK(daliamdMemcpyH2DAsync(ecs_dev.data(), ecs_stage.data(), upload_bytes, cs));
+    }
     if (cs != ws.stream) {
       if (!h2d_done_[slot]) KCHECK(daliamdEventCreate(&h2d_done_[slot], 0));
       KCHECK(daliamdEventRecord(h2d_done_[slot], cs));
@@ -415,6 +449,7 @@ class ImageDecoderMixed : public OperatorBase {
       cache_->Commit(reserved.keys, ws.stream);  // visible to later iterations (and other pipelines) from here on
       reserved.keys.clear();
     }
+    lap(4);
   }
 
  protected:
@@ -424,6 +459,9 @@ class ImageDecoderMixed : public OperatorBase {
 
  private:
   std::vector<daliamdJpegRoiPlan> plans_;
+  bool trace_ = getenv("DALI_AMD_TRACE") && atoi(getenv("DALI_AMD_TRACE")) != 0;
+  double trace_s_[5] = {0, 0, 0, 0, 0};
+  int64_t trace_runs_ = 0;
   std::shared_ptr<ImageCache> cache_;
   std::vector<uint8_t> hit_;
   std::vector<ImageCache::Entry> cached_;
