@@ -184,7 +184,7 @@ _HOST_SYMBOLS = [
     "daliamdPhiloxStateToString", "daliamdPhiloxStateFromString", "daliamdPhiloxGenerate",
     "daliamdCmnNormArgs", "daliamdCropAnchor",
     "daliamdImageCachePolicyCreate", "daliamdImageCachePolicyDestroy", "daliamdImageCachePolicyOnDecode",
-    "daliamdImageCachePolicyFind",
+    "daliamdImageCachePolicyFind", "daliamdImageProbe", "daliamdImageDecodeRgb",
 ]
 
 

@@ -100,6 +100,7 @@ class ImageDecoderMixed : public OperatorBase {
       ecs_dev_.emplace_back(std::make_unique<Buffer>(StorageDevice::GPU));
       scratch_.emplace_back(std::make_unique<Buffer>(StorageDevice::GPU));
       status_host_.emplace_back(std::make_unique<Buffer>(StorageDevice::CPU));
+      raster_stage_.emplace_back(std::make_unique<Buffer>(StorageDevice::CPU));
     }
     h2d_done_.assign(ring_, nullptr);
     // decoded-image cache (cached_decoder_impl.cc:24-48); the fused crop decoders have no cache options
@@ -160,6 +161,20 @@ class ImageDecoderMixed : public OperatorBase {
         }
       }
     }
+    // Samples that are not JPEG (PNG, BMP, PNM): decoded on the host thread pool further down and uploaded; for the JPEG
+    // machinery they do not exist, like cache hits.
+    raster_.assign(n, 0);
+    int nraster = 0;
+    for (int i = 0; i < n; i++) {
+      const uint8_t *b = static_cast<const uint8_t *>(in.raw(i));
+      if (!hit_[i] && !(in.nbytes(i) >= 3 && b[0] == 0xFF && b[1] == 0xD8 && b[2] == 0xFF)) {
+        raster_[i] = 1;
+        hit_[i] = 2;  // skipped by every JPEG loop
+        nraster++;
+        nact--;
+      }
+    }
+    raster_hw_.assign(2 * (size_t)n, 0);
     // The reader's output already sits in page-locked memory (Buffer::Reserve): the whole block is transferred as it
     // is and the entropy-coded segments are addressed inside it - no staging copy of the JPEG bytes.  (With cache
     // hits in the batch, or input from elsewhere, the segments of the active samples are packed into the staging
@@ -183,6 +198,12 @@ class ImageDecoderMixed : public OperatorBase {
       if (hit_[i]) {
         infos_[i] = daliamdJpegInfo{};  // no components: every per-component loop below skips the sample
         scans_[i].eligible = 0;
+        if (raster_[i]) {
+          daliamdImageFormat fmt;
+          if (daliamdImageProbe(static_cast<const uint8_t *>(in.raw(i)), in.nbytes(i), &fmt, &raster_hw_[2 * i + 1],
+                                &raster_hw_[2 * i]) != 0)
+            DALI_FAIL("Failed to decode ", src(i), ": ", daliamdHostGetLastErrorMessage());
+        }
         continue;
       }
       ws.GetThreadPool().AddWork([&, i](int) {
@@ -216,6 +237,7 @@ class ImageDecoderMixed : public OperatorBase {
       bool swap = adjust_orientation_ && infos_[i].orientation >= 5;
       upright_hw_[2 * i] = swap ? infos_[i].width : infos_[i].height;
       upright_hw_[2 * i + 1] = swap ? infos_[i].height : infos_[i].width;
+      if (raster_[i]) { upright_hw_[2 * i] = raster_hw_[2 * i]; upright_hw_[2 * i + 1] = raster_hw_[2 * i + 1]; }
     }
     rois_.assign(4 * n, 0);
     ComputeRois(ws, n);
@@ -230,6 +252,11 @@ class ImageDecoderMixed : public OperatorBase {
     } reserved{cache_.get(), {}};
     for (int i = 0; i < n; i++) {
       const auto &inf = infos_[i];
+      if (raster_[i]) {
+        const bool window = rois_[4 * i + 2] > 0;
+        shapes[i] = {window ? rois_[4 * i + 2] : upright_hw_[2 * i], window ? rois_[4 * i + 3] : upright_hw_[2 * i + 1], 3};
+        continue;
+      }
       if (hit_[i]) {
         shapes[i] = {cached_[i].h, cached_[i].w, cached_[i].c};
         ext_ptr[i] = cached_[i].data;
@@ -299,9 +326,38 @@ class ImageDecoderMixed : public OperatorBase {
           DALI_FAIL("Failed to decode ", src(i), ": ", daliamdHostGetLastErrorMessage());
       }, (int64_t)in.nbytes(i));
     }
-    if (ngpu < nact) ws.GetThreadPool().RunAll();
+    // ---- the other container formats: host decode into page-locked memory laid out like the output, one upload each
+    if (nraster) {
+      Buffer &rs = *raster_stage_[slot];
+      std::vector<size_t> roff(n, 0);
+      size_t rbytes = 0;
+      for (int i = 0; i < n; i++) {
+        if (!raster_[i]) continue;
+        roff[i] = rbytes;
+        rbytes += ((size_t)out.shape(i)[0] * (size_t)out.row_pitch(i) + 255) & ~(size_t)255;
+      }
+      rs.Reserve(rbytes + 256);
+      for (int i = 0; i < n; i++) {
+        if (!raster_[i]) continue;
+        ws.GetThreadPool().AddWork([&, i](int) {
+          const bool window = rois_[4 * i + 2] > 0;
+          if (daliamdImageDecodeRgb(static_cast<const uint8_t *>(in.raw(i)), in.nbytes(i),
+                                    static_cast<uint8_t *>(rs.data()) + roff[i], out.row_pitch(i), window ? rois_[4 * i] : 0,
+                                    window ? rois_[4 * i + 1] : 0, window ? rois_[4 * i + 2] : 0,
+                                    window ? rois_[4 * i + 3] : 0) != 0)
+            DALI_FAIL("Failed to decode ", src(i), ": ", daliamdHostGetLastErrorMessage());
+        }, (int64_t)in.nbytes(i));
+      }
+      ws.GetThreadPool().RunAll();
+      for (int i = 0; i < n; i++)
+        if (raster_[i])
+          KCHECK(daliamdMemcpyH2DAsync(out.raw(i), static_cast<uint8_t *>(rs.data()) + roff[i],
+                                       (size_t)out.shape(i)[0] * (size_t)out.row_pitch(i), ws.stream));
+    } else if (ngpu < nact) {
+      ws.GetThreadPool().RunAll();
+    }
     lap(2);
-    if (nact == 0) return;  // empty batch, or every sample came from the cache
+    if (nact == 0) return;  // empty batch, or every sample came from the cache / was not a JPEG
     // ---- entropy decoding on the device ----
     int16_t *coef = static_cast<int16_t *>(cdev.data());
     // descriptor tables: built in the pinned staging buffer, addressed on the device at the same offsets
@@ -463,14 +519,15 @@ class ImageDecoderMixed : public OperatorBase {
   double trace_s_[5] = {0, 0, 0, 0, 0};
   int64_t trace_runs_ = 0;
   std::shared_ptr<ImageCache> cache_;
-  std::vector<uint8_t> hit_;
+  std::vector<uint8_t> hit_, raster_;
+  std::vector<int32_t> raster_hw_;
   std::vector<ImageCache::Entry> cached_;
   std::vector<daliamdEvent_t> h2d_done_;
   bool adjust_orientation_;
   bool host_huffman_only_ = false;
   int64_t huffman_threshold_ = 0;
   int ring_;
-  std::vector<std::unique_ptr<Buffer>> staging_, coef_dev_, planes_, ecs_stage_, ecs_dev_, scratch_, status_host_;
+  std::vector<std::unique_ptr<Buffer>> staging_, coef_dev_, planes_, ecs_stage_, ecs_dev_, scratch_, status_host_, raster_stage_;
   std::vector<daliamdJpegInfo> infos_;
   std::vector<daliamdJpegScan> scans_;
   std::vector<int> gpu_samples_;

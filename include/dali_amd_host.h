@@ -105,6 +105,19 @@ DALIAMD_HOST_API int daliamdCmnNormArgs(const float *mean, int nmean, const floa
 /* CropAttr::CalculateAnchor (dali/operators/image/crop/crop_attr.cc:224-240) */
 DALIAMD_HOST_API int64_t daliamdCropAnchor(float anchor_norm, int64_t crop, int64_t in, int round_half_away);
 
+/* The loss-less container formats decoders.image accepts next to JPEG ("Supported formats: JPEG, JPEG 2000, TIFF, PNG,
+ * BMP, PNM, PPM, PGM, PBM, WebP", dali/operators/imgcodec/decoder_schema.cc:149), decoded on the host to 8-bit RGB
+ * (gray replicated, alpha dropped, 16-bit samples reduced to their high byte).  Not implemented: TIFF, JPEG 2000, WebP.
+ * daliamdImageProbe: format and - except for JPEG, see daliamdJpegParse - the image size, from the header only.
+ * daliamdImageDecodeRgb: the window {y0, x0, h, w} of the image (h == w == 0: all of it) into rows of `pitch` bytes. */
+typedef enum {
+  DALIAMD_IMAGE_UNKNOWN = 0, DALIAMD_IMAGE_JPEG = 1, DALIAMD_IMAGE_PNG = 2, DALIAMD_IMAGE_BMP = 3, DALIAMD_IMAGE_PNM = 4
+} daliamdImageFormat;
+DALIAMD_HOST_API int daliamdImageProbe(const uint8_t *data, size_t size, daliamdImageFormat *format, int32_t *width,
+                                      int32_t *height);
+DALIAMD_HOST_API int daliamdImageDecodeRgb(const uint8_t *data, size_t size, uint8_t *out, int64_t pitch, int32_t y0,
+                                          int32_t x0, int32_t h, int32_t w);
+
 /* Bookkeeping of the decoded-image cache of decoders.image (`cache_size`, `cache_type`, `cache_threshold`): which
  * image is kept and at which offset of the one HBM blob.  Host only - the decoder writes the decoded image at
  * blob + offset and later hands out that address; no copy on either side.
