@@ -249,8 +249,8 @@ __device__ __forceinline__ TileChunk LoadChunk(const daliamdJpegHuffDesc &d, int
 }
 
 // First pass of the un-stuffing: bytes each tile keeps (PrepareKernel).
-__device__ __forceinline__ void CountTile(const daliamdJpegHuffDesc *__restrict__ descs, int n, int *wave_sums) {
-  const ImageRef r = FindImage<true>(descs, n, blockIdx.x);
+__device__ __forceinline__ void CountTile(const daliamdJpegHuffDesc *__restrict__ descs, int n, int tile, int *wave_sums) {
+  const ImageRef r = FindImage<true>(descs, n, tile);
   const daliamdJpegHuffDesc &d = *r.d;
   const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments, d.total_blocks);
   TileChunk c = LoadChunk(d, r.local);
@@ -470,14 +470,15 @@ __device__ __forceinline__ void BuildTables(const daliamdJpegHuffDesc &d, HuffTa
   }
 }
 
-// One launch for the two jobs that only need the descriptors: workgroups [0, num_tiles) count the bytes their tile of
-// the stuffed stream keeps, workgroups [num_tiles, num_tiles + n) build the code tables of one stream each.
+// One launch for the two jobs that only need the descriptors: workgroups [0, n) build the code tables of one stream
+// each (a long chain of short phases: they go first so that they run next to the tile workgroups instead of behind
+// them), workgroups [n, n + num_tiles) count the bytes their tile of the stuffed stream keeps.
 __global__ __launch_bounds__(kTileThreads) void PrepareKernel(const daliamdJpegHuffDesc *__restrict__ descs, int n,
                                                               int num_tiles) {
   __shared__ __attribute__((aligned(16))) HuffTables L;
   __shared__ int wave_sums[kTileThreads / 64];
-  if ((int)blockIdx.x < num_tiles) CountTile(descs, n, wave_sums);
-  else BuildTables(descs[blockIdx.x - num_tiles], L);
+  if ((int)blockIdx.x < n) BuildTables(descs[blockIdx.x], L);
+  else CountTile(descs, n, (int)blockIdx.x - n, wave_sums);
 }
 
 // ------------------------------------------------------------------------------------------------ decode
