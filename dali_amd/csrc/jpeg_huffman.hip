@@ -123,14 +123,17 @@ struct HuffTables {
 static_assert(sizeof(HuffTables) % 16 == 0, "copied with 16-byte accesses");
 
 // Tables of the position-only passes (SyncKernel / PropagateKernel).  They do not extract values, so one look-up may
-// step over TWO symbols: a 32-bit entry holds, for the kFastBits-bit window,
-//   bits 16-29  the first symbol alone:      z advance (7 bits) | bits used << 7 (5 bits) | 1 << 12 (symbol count)
-//   bits  0-13  first + second symbol:       same fields summed (count 2); a copy of the upper half when the window
-//                                            holds no second symbol
-// A second symbol exists for AC tables only, when the first one is not an end-of-block and the CODE of the second lies
-// inside the window behind the first symbol's bits (its magnitude bits need not).  Whether the pair may be taken is
-// decided per step: the first symbol must not complete the block and the second must start inside the slice.
-// On the ImageNet-like bench set 64 % of the steps take a pair (tools/sync_sim.cpp): 0.61x the steps.
+// step over a GROUP of up to three symbols of one block: a 32-bit entry holds, for the kFastBits-bit window,
+//   bits  0-13  the whole group:  z advance (7 bits) | bits used << 7 (5 bits) | symbol count << 12 (1..3)
+//   bits 14-23  what precedes the group's LAST symbol: z advance (6 bits) | bits used << 6 (4 bits); zero for a
+//               single symbol.  The group may be taken when these symbols leave the block open and the last one
+//               still starts inside the range - decided per step
+//   bits 24-31  groups of three only: the first symbol alone, bits used (4 bits) | (z advance - 1) << 4, for the
+//               (rare) step that cannot take the group; with two symbols the fields above already describe it
+// A group continues behind a symbol when that one is not an end-of-block and the CODE of the next lies inside the
+// window behind it (its magnitude bits need not).  DC entries continue into the AC table of their block when all the
+// blocks that use the DC table use the same AC table.
+// On the ImageNet-like bench set (tools/sync_sim.cpp): pairs 0.61x the steps, this 0.54x.
 struct SyncTables {
   uint32_t t32[4][1 << kFastBits];   // [0],[1] = DC tables 0,1; [2],[3] = AC tables 0,1; 0 = code longer than the window
   uint16_t l2[4][kL2Entries];
@@ -143,9 +146,10 @@ struct SyncTables {
   int32_t bpm, reserved;
 };
 static_assert(sizeof(SyncTables) % 16 == 0, "copied with 16-byte accesses");
-__host__ __device__ __forceinline__ uint32_t SyncHalf(uint32_t z, uint32_t used, uint32_t count) {
+__host__ __device__ __forceinline__ uint32_t SyncGroup(uint32_t z, uint32_t used, uint32_t count) {
   return z | (used << 7) | (count << 12);
 }
+constexpr int kSyncGroup = 3;
 
 struct ScratchLayout {
   size_t tile_kept, clean, tables, sync_tables, lanes, segs, records, blocks, total;
@@ -440,15 +444,27 @@ __device__ __forceinline__ void BuildTables(const daliamdJpegHuffDesc &d, HuffTa
     const uint32_t e1 = L.fast[tb][w];
     uint32_t e = 0;
     if (e1) {
-      const uint32_t z1 = e1 & 127, u1 = (e1 >> 7) & 31;
-      const uint32_t one = SyncHalf(z1, u1, 1);
-      uint32_t both = one;
-      if (tb >= 2 && z1 < 64 && u1 < (uint32_t)kFastBits) {
-        const uint32_t e2 = L.fast[tb][(w << u1) & ((1 << kFastBits) - 1)];
-        const uint32_t z2 = e2 & 127, u2 = (e2 >> 7) & 31, len2 = u2 - (e2 >> 12);
-        if (e2 && u1 + len2 <= (uint32_t)kFastBits) both = SyncHalf(z1 + z2, u1 + u2, 2);
+      // table the block continues with: an AC table itself, or the one AC table every block of this DC table uses
+      int ac = tb;
+      if (tb < 2) {
+        ac = -1;
+        for (int k = 0; k < L.bpm; k++) {
+          if ((int)((L.dc_mask >> k) & 1u) != tb) continue;
+          const int a = 2 + (int)((L.ac_mask >> k) & 1u);
+          ac = ac == -1 || ac == a ? a : -2;
+        }
       }
-      e = (one << 16) | both;
+      uint32_t z = e1 & 127, used = (e1 >> 7) & 31, count = 1, zprev = 0, uprev = 0;
+      const uint32_t z1 = z, u1 = used;
+      while (ac >= 2 && count < (uint32_t)kSyncGroup && z < 64 && used < (uint32_t)kFastBits) {
+        const uint32_t e2 = L.fast[ac][(w << used) & ((1 << kFastBits) - 1)];
+        const uint32_t z2 = e2 & 127, u2 = (e2 >> 7) & 31, len2 = u2 - (e2 >> 12);
+        if (!e2 || used + len2 > (uint32_t)kFastBits) break;  // the next code is not determined by the window
+        zprev = z; uprev = used;
+        z += z2; used += u2; count++;
+      }
+      e = SyncGroup(z, used, count) | (zprev << 14) | (uprev << 20);
+      if (count == 3) e |= (u1 << 24) | ((z1 - 1) << 28);
     }
     S->t32[tb][w] = e;
   }
@@ -545,18 +561,23 @@ __device__ __forceinline__ int DecodeRange(const SyncTables &L, GlobalWords *__r
       uint32_t e = t32[(slot << kFastBits) + (peek >> (32 - kFastBits))];
       if (__builtin_expect(e == 0, 0)) {
         const uint32_t e16 = LongCode(L, slot, peek, is_dc);
-        e = SyncHalf(e16 & 127, (e16 >> 7) & 31, 1) * 0x10001u;
+        e = SyncGroup(e16 & 127, (e16 >> 7) & 31, 1);
       }
-      // the pair may be taken when the first symbol leaves the block open and the second one starts inside the range:
-      // both differences negative <=> the sign bit of their AND is set
-      const int first_z = (int)((e >> 16) & 127), first_used = (int)((e >> 23) & 31);
-      const int ok = ((int)z + first_z - 64) & (first_used - (rem - limit));
-      const uint32_t f = ok < 0 ? e : e >> 16;
-      const uint32_t used = (f >> 7) & 31;
+      // the group may be taken when the symbols before its last one leave the block open and the last one starts
+      // inside the range: both differences negative <=> the sign bit of their AND is set
+      const int zprev = (int)((e >> 14) & 63), uprev = (int)((e >> 20) & 15);
+      const int ok = ((int)z + zprev - 64) & (uprev - (rem - limit));
+      uint32_t used = (e >> 7) & 31, zinc = e & 127, count = (e >> 12) & 3;
+      if (__builtin_expect(ok >= 0, 0)) {  // rare: take the first symbol only
+        const bool three = count == 3;
+        used = three ? (e >> 24) & 15 : (uint32_t)uprev;
+        zinc = three ? ((e >> 28) & 15) + 1 : (uint32_t)zprev;
+        count = 1;
+      }
       rem -= (int)used;
       off += used;
-      z += f & 127;
-      nsym += (int)((f >> 12) & 3);
+      z += zinc;
+      nsym += (int)count;
       if (off >= 32) {
         hi = lo;
         lo = __builtin_bswap32(nxt);

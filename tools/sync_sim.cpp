@@ -30,8 +30,8 @@ struct Image {
   uint32_t dc_mask = 0, ac_mask = 0, bpm = 1;
   uint32_t total_bits = 0;
   // pair tables (pair_bits > 0): index = next pair_bits bits; fields of up to two symbols of the SAME ac table
-  struct Pair { uint8_t adv1, z1, adv12, z12, n; };
-  std::vector<Pair> pair[2];
+  struct Pair { uint8_t adv1, z1, adv12, z12, n, zprev, advprev; };
+  std::vector<Pair> pair[4];  // per table slot (dc0, dc1, ac0, ac1)
 };
 
 static void BuildTable(std::vector<uint16_t> &t, const uint8_t *bits, const uint8_t *vals, bool is_dc) {
@@ -54,6 +54,8 @@ static inline uint32_t Peek16(const Image &im, uint32_t pos) {
 }
 
 static int g_pair_bits = 0;
+static int g_group = 2;      // symbols per look-up at most
+static int g_dc_chain = 0;   // DC entries continue into the AC table of the same class
 long g_cls[4] = {0, 0, 0, 0};
 std::vector<long> g_wmax;
 
@@ -68,9 +70,9 @@ static int Decode(const Image &im, State &st, uint32_t end, int &nsym, int &step
     uint32_t peek = Peek16(im, pos);
     uint32_t used, zinc;
     int n = 1;
-    if (g_pair_bits && !is_dc) {
-      const Image::Pair &p = im.pair[slot - 2][peek >> (16 - g_pair_bits)];
-      if (p.n == 2 && (int)p.adv1 < (int)(end - pos) && z + p.z1 < 64) { used = p.adv12; zinc = p.z12; n = 2; }
+    if (g_pair_bits && (!is_dc || g_dc_chain)) {
+      const Image::Pair &p = im.pair[slot][peek >> (16 - g_pair_bits)];
+      if (p.n >= 2 && (int)p.advprev < (int)(end - pos) && z + p.zprev < 64) { used = p.adv12; zinc = p.z12; n = p.n; }
       else if (p.n >= 1) { used = p.adv1; zinc = p.z1; }
       else { uint32_t e = im.tab[slot][peek]; used = (e >> 7) & 31; zinc = e & 127; }
     } else {
@@ -115,20 +117,27 @@ static bool Load(const std::string &path, Image &im) {
   }
   if (g_pair_bits) {
     const int B = g_pair_bits;
-    for (int t = 0; t < 2; t++) {
-      im.pair[t].assign(1u << B, Image::Pair{0, 0, 0, 0, 0});
+    for (int t = 0; t < 4; t++) {
+      im.pair[t].assign(1u << B, Image::Pair{0, 0, 0, 0, 0, 0, 0});
+      if (t < 2 && !g_dc_chain) continue;
+      const int ac = t < 2 ? 2 + t : t;  // table the block continues with (same class)
       for (uint32_t w = 0; w < (1u << B); w++) {
         Image::Pair &q = im.pair[t][w];
-        uint32_t e1 = im.tab[2 + t][(w << (16 - B)) & 0xFFFF];
+        uint32_t e1 = im.tab[t][(w << (16 - B)) & 0xFFFF];
         int u1 = (e1 >> 7) & 31, z1 = e1 & 127, s1 = (e1 >> 12) & 15;
         if (u1 - s1 > B) continue;  // the CODE must be inside the index (the magnitude bits need not be)
         q.adv1 = u1; q.z1 = z1; q.n = 1;
-        if (z1 >= 64 || u1 >= B) continue;  // EOB: the block ends
-        uint32_t rest = (w << u1) & ((1u << B) - 1);
-        uint32_t e2 = im.tab[2 + t][(rest << (16 - B)) & 0xFFFF];
-        int u2 = (e2 >> 7) & 31, z2 = e2 & 127, s2 = (e2 >> 12) & 15;
-        if (u1 + (u2 - s2) > B) continue;  // second code not fully determined by the index bits
-        q.adv12 = u1 + u2; q.z12 = std::min(z1 + z2, 64 + 63); q.n = 2;
+        int used = u1, zz = z1, cnt = 1, zprev = 0, advprev = 0;
+        while (cnt < g_group && zz < 64 && used < B) {
+          uint32_t rest = (w << used) & ((1u << B) - 1);
+          uint32_t e2 = im.tab[ac][(rest << (16 - B)) & 0xFFFF];
+          int u2 = (e2 >> 7) & 31, z2 = e2 & 127, s2 = (e2 >> 12) & 15;
+          if (used + (u2 - s2) > B) break;  // next code not fully determined by the index bits
+          zprev = zz; advprev = used;
+          used += u2; zz += z2; cnt++;
+          if (z2 >= 64) break;
+        }
+        if (cnt >= 2 && used < 32 && zz < 128) { q.adv12 = used; q.z12 = zz; q.n = cnt; q.zprev = zprev; q.advprev = advprev; }
       }
     }
   }
@@ -139,7 +148,9 @@ int main(int argc, char **argv) {
   if (argc < 2) return 1;
   const int slice = argc > 2 ? atoi(argv[2]) : 256, T = argc > 3 ? atoi(argv[3]) : 128, warm = argc > 4 ? atoi(argv[4]) : 12;
   g_pair_bits = argc > 5 ? atoi(argv[5]) : 0;
-  const int r0_bytes = argc > 6 ? atoi(argv[6]) : 0;  // > 0: round 0 decodes only the last r0_bytes of each slice
+  const int r0_bytes = argc > 6 ? atoi(argv[6]) : 0;
+  g_group = argc > 7 ? atoi(argv[7]) : 2;
+  g_dc_chain = argc > 8 ? atoi(argv[8]) : 0;  // > 0: round 0 decodes only the last r0_bytes of each slice
   const int seg_lanes = T - warm;
   std::vector<std::string> files;
   DIR *dp = opendir(argv[1]);
