@@ -217,7 +217,33 @@ class JpegBatchPlan:
         ws = ws or self._huff_ws
         sc, inf, sel = self.scan, self.inf, self._huff_sel
         m = len(sel)
-        d = np.zeros(max(m, 1), np.dtype(capi.JpegHuffDesc))[:m]
+        # everything that only depends on the streams (tables, geometry, quantisation) is laid out once per plan;
+        # a call copies that template and fills in the buffer addresses
+        tmpl = getattr(self, "_huff_template", None)
+        if tmpl is None:
+            t = np.zeros(max(m, 1), np.dtype(capi.JpegHuffDesc))[:m]
+            t["ecs_len"] = self._ecs_len
+            t["blocks_per_mcu"] = sc["blocks_per_mcu"][sel]
+            t["mcus_x"] = sc["mcus_x"][sel]
+            t["total_blocks"] = sc["mcus_x"][sel] * sc["mcus_y"][sel] * sc["blocks_per_mcu"][sel]
+            t["blocks_x"] = inf["blocks_x"][sel, :3]
+            t["h_samp"] = inf["h_samp"][sel, :3]
+            t["v_samp"] = inf["v_samp"][sel, :3]
+            t["comp_of_block"][:, :10] = sc["comp_of_block"][sel]
+            t["h_of_block"][:, :10] = sc["h_of_block"][sel]
+            t["v_of_block"][:, :10] = sc["v_of_block"][sel]
+            t["dc_sel"] = sc["dc_sel"][sel]
+            t["ac_sel"] = sc["ac_sel"][sel]
+            t["bits"][:, 0:2] = sc["dc_bits"][sel, 0:2]
+            t["bits"][:, 2:4] = sc["ac_bits"][sel, 0:2]
+            t["vals"][:, 0:2] = sc["dc_vals"][sel, 0:2]
+            t["vals"][:, 2:4] = sc["ac_vals"][sel, 0:2]
+            t["quant"] = self.quant[sel]
+            t["plane_pitch"] = np.where(self.comp_mask[sel], inf["blocks_x"][sel, :3] * 8, 0)
+            if self.roi_plans is not None:
+                t["rect"] = np.where(self.has_roi[sel][:, None, None], self.roi_plans["rect"][sel], 0)
+            tmpl = self._huff_template = t
+        d = tmpl.copy()
         d["ecs"] = self._ecs_dev.data_ptr() + self._ecs_off
         d["scratch"] = ws["scratch"].data_ptr() + self._scratch_off
         d["status"] = ws["status"].data_ptr() + 4 * np.arange(m)
@@ -225,26 +251,8 @@ class JpegBatchPlan:
             d["coef"] = np.where(self.comp_mask[sel], coef_dev.data_ptr() + 2 * self.coef_off[sel], 0)
         if planes_dev is not None:
             d["plane"] = np.where(self.comp_mask[sel], planes_dev.data_ptr() + self.plane_off[sel], 0)
-            d["plane_pitch"] = np.where(self.comp_mask[sel], inf["blocks_x"][sel, :3] * 8, 0)
-            d["quant"] = self.quant[sel]
-        d["ecs_len"] = self._ecs_len
-        d["blocks_per_mcu"] = sc["blocks_per_mcu"][sel]
-        d["mcus_x"] = sc["mcus_x"][sel]
-        d["total_blocks"] = sc["mcus_x"][sel] * sc["mcus_y"][sel] * sc["blocks_per_mcu"][sel]
-        d["blocks_x"] = inf["blocks_x"][sel, :3]
-        d["h_samp"] = inf["h_samp"][sel, :3]
-        d["v_samp"] = inf["v_samp"][sel, :3]
-        d["comp_of_block"][:, :10] = sc["comp_of_block"][sel]
-        d["h_of_block"][:, :10] = sc["h_of_block"][sel]
-        d["v_of_block"][:, :10] = sc["v_of_block"][sel]
-        d["dc_sel"] = sc["dc_sel"][sel]
-        d["ac_sel"] = sc["ac_sel"][sel]
-        d["bits"][:, 0:2] = sc["dc_bits"][sel, 0:2]
-        d["bits"][:, 2:4] = sc["ac_bits"][sel, 0:2]
-        d["vals"][:, 0:2] = sc["dc_vals"][sel, 0:2]
-        d["vals"][:, 2:4] = sc["ac_vals"][sel, 0:2]
-        if self.roi_plans is not None:
-            d["rect"] = np.where(self.has_roi[sel][:, None, None], self.roi_plans["rect"][sel], 0)
+        else:
+            d["plane_pitch"] = 0
         ntiles, nsegs, nbwg = C.c_int(0), C.c_int(0), C.c_int(0)
         capi.check(lib.daliamdJpegHuffmanSetup(d.ctypes.data_as(C.c_void_p), m, C.byref(ntiles), C.byref(nsegs),
                                                C.byref(nbwg)))
