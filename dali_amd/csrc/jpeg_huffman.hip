@@ -14,28 +14,37 @@
 //   slice    256 bytes of the clean stream  (one decoder lane)
 //   segment  116 slices = 29 KB             (one 128-lane workgroup: 12 warm-up lanes + 116 slices)
 //
-//   1 UnstuffCountKernel    per tile: number of bytes that survive the removal of the 0xFF00 stuffing
+//   1 PrepareKernel         per tile: number of bytes that survive the removal of the 0xFF00 stuffing; and, in extra
+//                           workgroups of the same launch (they need nothing but the descriptor), per image: two-level
+//                           code tables (11-bit first level, direct second level for the long codes), the symbol-group
+//                           tables of the position-only passes and the MCU geometry -> global scratch, copied into
+//                           LDS by the decoding workgroups
 //   2 UnstuffScatterKernel  per tile: compaction through LDS to its final place in the clean stream
-//   3 BuildTablesKernel     per image: two-level code tables (11-bit first level, direct second level for the long
-//                           codes) + MCU geometry -> global scratch, copied into LDS by the decoding workgroups
-//   4 SyncKernel            per segment: every lane decodes its slice from a guessed state, then the relaxation
+//   3 SyncKernel            per segment: every lane decodes its slice from a guessed state, then the relaxation
 //                           "publish the state you reached to the next lane, decode again if your input changed"
 //                           runs until nothing changes.  The 12 warm-up lanes replay the end of the previous
 //                           segment so that the first slice of the segment starts from the true state with
-//                           overwhelming probability.  No values are extracted in this pass.
-//   5 PropagateKernel       per image, serial over its segments: checks that every segment started from the state
+//                           overwhelming probability.  No values are extracted in this pass, so one table look-up
+//                           steps over up to three symbols; every decode also notes the state at the slice's midpoint
+//   4 PropagateKernel       per image, serial over its segments: checks that every segment started from the state
 //                           its predecessor ended in (if not - pathological streams - repairs it with the same
 //                           relaxation, so correctness never depends on luck), assigns block ordinals
-//   6 WriteKernel           per segment: decodes once more from the now-known states, extracting the values, and
-//                           appends one 32-bit record per symbol to the image's record stream (sequential per lane);
-//                           DC values as lane-local running sums of the differences; notes where every block starts
-//   7 DcScanKernel          per segment: prefix sums of the per-slice DC sums -> DC level at the start of every slice
-//   8 ExpandKernel          per block: builds the 8x8 block from its records in LDS, adds the DC level, stores it as
-//                           ONE full 128-byte line (no zero-fill, no partial writes, no read-modify-write)
+//   5 WriteKernel           per segment, one lane per HALF slice (232 lanes in 256 threads): decodes once more from
+//                           the now-known states, extracting the values, and appends one 32-bit record per symbol to
+//                           the image's record stream (sequential per lane); DC values as lane-local running sums of
+//                           the differences; notes where every block starts
+//   6 DcScanKernel          per segment: prefix sums of the per-lane DC sums -> DC level at the start of every lane
+//   7 ExpandKernel          per block: builds the 8x8 block from its records in LDS, adds the DC level and either
+//                           dequantises + inverse-transforms it on the spot and stores the 8x8 samples to the component
+//                           plane (fused output, the default of the callers) or stores the coefficients as ONE full
+//                           128-byte line (no zero-fill, no partial writes, no read-modify-write)
 //
-// The decode loop is VALU-issue bound (a wave64 instruction occupies a SIMD16 for 4 cycles and divergent branches
-// execute the union of their bodies), hence: table entries carry (code length, magnitude bits, zig-zag advance), a
-// two-dword bit window with the next dword prefetched through the global (not flat) path, no loops on the rare paths.
+// What bounds the decode loops (measured): the position-only pass is a latency chain - a wave's step is
+// ~55 dependent instructions and the kernel lasts as long as the workgroup with the longest chain of slices that do
+// not self-synchronise - so its steps were made fewer (symbol groups); the write pass is VALU-issue bound (a wave64
+// instruction occupies a SIMD16 for 4 cycles and divergent branches execute the union of their bodies), hence short
+// lanes, 4 waves per SIMD, branch-free DC / refill code, a two-dword bit window fed from an LDS ring, and no
+// vector-memory instruction between two wave-uniform points.
 #include <cstring>
 #include "common.h"
 #include "jpeg_idct_math.h"
