@@ -54,10 +54,23 @@ __global__ __launch_bounds__(kWarpThreads) void WarpAffineKernel(const daliamdWa
   float sy = m5; sy += m3 * vx; sy += m4 * vy;
   const float dtx = kWarpTileW * m0, dty = kWarpTileW * m3;
   for (int k = 0; k < tx; k++) { sx += dtx; sy += dty; }
-  for (int k = x_tile; k < x0; k++) { sx += m0; sy += m3; }
+  // x0 - x_tile = kWarpPx * lane: the replayed additions in groups of kWarpPx * 2 with a remainder, so that the loop
+  // overhead (per-lane trip count = a divergent branch per iteration) is paid once per eight additions
+  {
+    const int hops = (x0 - x_tile) / kWarpPx;  // lane index inside the row
+    for (int k = 0; k + 2 <= hops; k += 2) {
+#pragma unroll
+      for (int q = 0; q < 2 * kWarpPx; q++) { sx += m0; sy += m3; }
+    }
+    if (hops & 1) {
+#pragma unroll
+      for (int q = 0; q < kWarpPx; q++) { sx += m0; sy += m3; }
+    }
+  }
   const int C = d.channels;
   const int npx = min(kWarpPx, d.out_w - x0);
   uint8_t *o = d.out + (size_t)y * d.out_pitch + (size_t)x0 * C;
+  const bool fast3 = C == 3 && ((reinterpret_cast<uintptr_t>(d.in) | (uintptr_t)d.in_pitch) & 3) == 0;
   const float f0 = (float)SatU8(d.fill[0]), f1 = (float)SatU8(d.fill[1]), f2 = (float)SatU8(d.fill[2]),
               f3 = (float)SatU8(d.fill[3]);
   for (int p = 0; p < npx; p++, sx += m0, sy += m3) {
@@ -71,6 +84,28 @@ __global__ __launch_bounds__(kWarpThreads) void WarpAffineKernel(const daliamdWa
       float fx = sx - 0.5f, fy = sy - 0.5f;
       int ix = (int)floorf(fx), iy = (int)floorf(fy);
       float qx = fx - ix, px = 1 - qx, qy = fy - iy;
+      if (fast3 && ix >= 0 && iy >= 0 && ix + 4 < d.in_w && iy + 1 < d.in_h) {
+        // interior, 3 channels: the 2 x 2 x 3 bytes as one 12-byte load per row (dword aligned) + byte alignment
+        typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+        using GlobalTriple = const u32x3 __attribute__((address_space(1)));
+        const size_t b0 = (size_t)iy * d.in_pitch + (size_t)ix * 3, b1 = b0 + d.in_pitch;
+        const u32x3 r0 = *(GlobalTriple *)(d.in + (b0 & ~(size_t)3)), r1 = *(GlobalTriple *)(d.in + (b1 & ~(size_t)3));
+        const uint32_t h0 = (uint32_t)(b0 & 3), h1 = (uint32_t)(b1 & 3);
+        const uint32_t a0 = __builtin_amdgcn_alignbyte(r0.y, r0.x, h0), a1 = __builtin_amdgcn_alignbyte(r0.z, r0.y, h0);
+        const uint32_t c0 = __builtin_amdgcn_alignbyte(r1.y, r1.x, h1), c1 = __builtin_amdgcn_alignbyte(r1.z, r1.y, h1);
+        // bytes: a0 = {s00.0, s00.1, s00.2, s01.0}, a1 = {s01.1, s01.2, ..}; same for the lower row
+        const float t00[3] = {(float)(a0 & 255), (float)((a0 >> 8) & 255), (float)((a0 >> 16) & 255)};
+        const float t01[3] = {(float)(a0 >> 24), (float)(a1 & 255), (float)((a1 >> 8) & 255)};
+        const float t10[3] = {(float)(c0 & 255), (float)((c0 >> 8) & 255), (float)((c0 >> 16) & 255)};
+        const float t11[3] = {(float)(c0 >> 24), (float)(c1 & 255), (float)((c1 >> 8) & 255)};
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          float s0 = t00[c] * px + t01[c] * qx;
+          float s1 = t10[c] * px + t11[c] * qx;
+          o[p * 3 + c] = (uint8_t)SatU8(s0 + (s1 - s0) * qy);
+        }
+        continue;
+      }
       for (int c = 0; c < C; c++) {
         float fc = c == 0 ? f0 : c == 1 ? f1 : c == 2 ? f2 : f3;
         float s00 = WarpFetch(d, ix, iy, c, fc), s01 = WarpFetch(d, ix + 1, iy, c, fc);
