@@ -391,7 +391,8 @@ daliamdResult_t daliamdGaussianBlurSetup(daliamdGaussianBlurDesc *descs, int n, 
     DALIAMD_REQUIRE((d.size_x & 1) && (d.size_y & 1) && d.size_x <= DALIAMD_MAX_BLUR_WINDOW &&
                     d.size_y <= DALIAMD_MAX_BLUR_WINDOW && d.size_x > 0 && d.size_y > 0, DALIAMD_ERROR_UNSUPPORTED,
                     "daliamdGaussianBlurSetup: sample %d: window sizes must be odd and <= %d", i, DALIAMD_MAX_BLUR_WINDOW);
-    int tw = 64, th = 16;
+    // tall tiles: the W pass also runs over the 2 * radius halo rows, so its overhead is (th + 2r) / th
+    int tw = 64, th = 32;
     auto need = [&](int tw_, int th_) {
       size_t rows = th_ + d.size_y - 1, cols = tw_ + d.size_x - 1;
       size_t src_pitch = ((cols + 4) * d.channels + 4 + 3) & ~(size_t)3;  // + alignment lead + register-blocking overrun
