@@ -35,6 +35,7 @@ def _lib():
         lib.daliamdPipelineOutputInfo.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_char_p, C.c_int]
         lib.daliamdPipelineOutputSample.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p),
                                                     C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int64)]
+        lib.daliamdPipelineOutputSamples.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.daliamdPipelineFeedInput.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
                                                  C.c_int, C.c_int, C.c_int, C.c_char_p]
         lib.daliamdPipelineReaderMeta.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]
@@ -170,6 +171,21 @@ class BackendPipeline:
         ptr, shape, ndim, pitch = C.c_void_p(), (C.c_int64 * 8)(), C.c_int(0), C.c_int64(0)
         check(self._lib.daliamdPipelineOutputSample(self._h, idx, i, C.byref(ptr), shape, C.byref(ndim), C.byref(pitch)))
         return ptr.value or 0, tuple(shape[:ndim.value]), int(pitch.value)
+
+    def output_samples(self, idx, n):
+        """(ptr, shape, row_pitch) of every sample of output `idx` with ONE call into the library."""
+        import numpy as np
+        if n == 0:
+            return []
+        ptrs = np.zeros(n, np.uint64)
+        shapes = np.zeros((n, 8), np.int64)
+        ndims = np.zeros(n, np.int32)
+        pitches = np.zeros(n, np.int64)
+        check(self._lib.daliamdPipelineOutputSamples(self._h, idx, ptrs.ctypes.data_as(C.c_void_p),
+                                                     shapes.ctypes.data_as(C.c_void_p), ndims.ctypes.data_as(C.c_void_p),
+                                                     pitches.ctypes.data_as(C.c_void_p)))
+        pl, sl, nl, tl = ptrs.tolist(), shapes.tolist(), ndims.tolist(), pitches.tolist()
+        return [(pl[i], tuple(sl[i][:nl[i]]), tl[i]) for i in range(n)]
 
     def feed_input(self, name, arrays, dtype, layout):
         import numpy as np

@@ -193,6 +193,20 @@ API int daliamdPipelineOutputSample(void *h, int idx, int sample, void **ptr, in
     *row_pitch = tl.row_pitch(sample);
   });
 }
+// All samples of one output in one call: ptrs[n], shapes[n][8], ndims[n], row_pitches[n] (n = num_samples of OutputInfo)
+API int daliamdPipelineOutputSamples(void *h, int idx, void **ptrs, int64_t *shapes, int *ndims, int64_t *row_pitches) {
+  return Guard([&] {
+    auto &tl = *static_cast<PipelineHandle *>(h)->outputs.at(idx);
+    for (int i = 0; i < tl.num_samples(); i++) {
+      const TensorShape &s = tl.shape(i);
+      DALI_ENFORCE(s.size() <= 8, "Too many dimensions");
+      ptrs[i] = tl.raw(i);
+      ndims[i] = (int)s.size();
+      for (size_t d = 0; d < s.size(); d++) shapes[(size_t)i * 8 + d] = s[d];
+      row_pitches[i] = tl.row_pitch(i);
+    }
+  });
+}
 API int daliamdPipelineFeedInput(void *h, const char *op_name, const void *const *data, const int64_t *shapes, int ndim, int n,
                                  int dtype, const char *layout) {
   return Guard([&] {

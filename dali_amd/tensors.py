@@ -77,7 +77,7 @@ class _TensorList:
         self.dtype = [e for e in vars(types.DALIDataType).values()
                       if isinstance(e, types.DALIDataType) and int(e) == info["dtype"]][0]
         self._layout, self._n, self._dense, self._gpu = info["layout"], info["num_samples"], info["dense"], info["gpu"]
-        self._samples = [backend_pipe.output_sample(idx, i) for i in range(self._n)]
+        self._samples = backend_pipe.output_samples(idx, self._n)
 
     def __len__(self):
         return self._n
