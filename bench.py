@@ -172,8 +172,10 @@ class HotPath:
         with torch.cuda.stream(slot["stream"]):
             if self.huffman == "gpu":
                 ke = None
-                if ev:
-                    ke = B.KernelEvents(len(B.HUFFMAN_KERNELS))
+                if ev:   # per-kernel events of the entropy decoder: created before the timed region, one set per step
+                    pool = getattr(self, "kernel_event_pool", ())
+                    k = len(self.kernel_events)
+                    ke = pool[k] if k < len(pool) else B.KernelEvents(len(B.HUFFMAN_KERNELS))
                     self.kernel_events.append(ke)
                 self.plan.run_gpu_huffman(slot["coef"], events=ev[5:7] if ev else None, ws=slot["ws"],
                                           kernel_events=ke.handles if ke else None,
@@ -428,6 +430,9 @@ def main():
     for w in range(args.warmup):
         hp.step(index=w)
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(7)] for _ in range(args.steps)]
+    if args.huffman == "gpu":
+        from dali_amd import backend as _backend
+        hp.kernel_event_pool = [_backend.KernelEvents(len(_backend.HUFFMAN_KERNELS)) for _ in range(args.steps)]
     resample_bytes = []
     barrier()
     hp.host_s = 0.0

@@ -75,6 +75,17 @@ def _thread_pool(num_threads=None):
 # =====================================================================================
 # JPEG
 # =====================================================================================
+_DTYPES = {}
+
+
+def _dtype(ctypes_struct):
+    """numpy dtype mirroring a ctypes structure; the conversion walks every field, so it is done once per type."""
+    dt = _DTYPES.get(ctypes_struct)
+    if dt is None:
+        dt = _DTYPES[ctypes_struct] = np.dtype(ctypes_struct)
+    return dt
+
+
 class JpegBatchPlan:
     """Geometry + buffer layout of one batch of JPEG streams (host side, no device work)."""
 
@@ -94,7 +105,7 @@ class JpegBatchPlan:
                 raise capi.DaliAmdError(
                     f"sample {i}: JPEG with {inf.num_components} components is not supported")
         # per-sample geometry as arrays (vectorised descriptor construction)
-        inf = np.frombuffer(self.infos, dtype=np.dtype(capi.JpegInfo))[:self.n]
+        inf = np.frombuffer(self.infos, dtype=_dtype(capi.JpegInfo))[:self.n]
         self.inf = inf
         ncomp = inf["num_components"].astype(np.int64)
         elems = inf["coef_elems"][:, :3].astype(np.int64) * (np.arange(3)[None, :] < ncomp[:, None])
@@ -107,7 +118,7 @@ class JpegBatchPlan:
         self.roi_plans = None
         if rois is not None and self.n:
             lib = capi.kernels()
-            self.roi_plans = np.zeros(self.n, np.dtype(capi.JpegRoiPlan))
+            self.roi_plans = np.zeros(self.n, _dtype(capi.JpegRoiPlan))
             self.has_roi = np.zeros(self.n, bool)
             for i, r in enumerate(rois):
                 if r is None:
@@ -117,7 +128,7 @@ class JpegBatchPlan:
                 plan = capi.JpegRoiPlan()
                 capi.check(lib.daliamdJpegPlanRoi(int(inf["width"][i]), int(inf["height"][i]), int(ncomp[i]), hs, vs, 1,
                                                   int(r[0]), int(r[1]), int(r[2]), int(r[3]), C.byref(plan)))
-                self.roi_plans[i] = np.frombuffer(plan, dtype=np.dtype(capi.JpegRoiPlan))[0]
+                self.roi_plans[i] = np.frombuffer(plan, dtype=_dtype(capi.JpegRoiPlan))[0]
                 self.has_roi[i] = True
                 self.out_h[i], self.out_w[i] = int(r[2]), int(r[3])
         self.out_pitch = (3 * self.out_w + out_pitch_align - 1) // out_pitch_align * out_pitch_align
@@ -166,7 +177,7 @@ class JpegBatchPlan:
         for i, e in enumerate(self.encoded):
             capi.check_host(host.daliamdJpegAnalyzeScan(e.ctypes.data_as(C.c_void_p), C.c_size_t(e.size),
                                                         C.byref(self.infos[i]), C.byref(self.scans[i])))
-        self.scan = np.frombuffer(self.scans, dtype=np.dtype(capi.JpegScan))[:self.n]
+        self.scan = np.frombuffer(self.scans, dtype=_dtype(capi.JpegScan))[:self.n]
         self.gpu_eligible = self.scan["eligible"].astype(bool) if self.n else np.zeros(0, bool)
         return self.gpu_eligible
 
@@ -221,7 +232,7 @@ class JpegBatchPlan:
         # a call copies that template and fills in the buffer addresses
         tmpl = getattr(self, "_huff_template", None)
         if tmpl is None:
-            t = np.zeros(max(m, 1), np.dtype(capi.JpegHuffDesc))[:m]
+            t = np.zeros(max(m, 1), _dtype(capi.JpegHuffDesc))[:m]
             t["ecs_len"] = self._ecs_len
             t["blocks_per_mcu"] = sc["blocks_per_mcu"][sel]
             t["mcus_x"] = sc["mcus_x"][sel]
@@ -350,8 +361,8 @@ class JpegBatchPlan:
             m = m & ~self.gpu_eligible[:, None]
         cb, pb, ob = coef_dev.data_ptr(), planes_dev.data_ptr(), out_dev.data_ptr()
         ncomp_total = int(m.sum())
-        idct = np.zeros(max(ncomp_total, 1), np.dtype(capi.JpegIdctDesc))
-        color = np.zeros(max(self.n, 1), np.dtype(capi.JpegColorDesc))
+        idct = np.zeros(max(ncomp_total, 1), _dtype(capi.JpegIdctDesc))
+        color = np.zeros(max(self.n, 1), _dtype(capi.JpegColorDesc))
         if self.n:
             bx = inf["blocks_x"][:, :3]
             by = inf["blocks_y"][:, :3]
@@ -538,7 +549,7 @@ def resample_batch(images, out_size, rois=None, interp_min=capi.INTERP_LINEAR, i
         out = torch.empty(shape, dtype=_TORCH_DTYPE[out_dtype], device=dev)
     esz = out.element_size()
     per_sample = oh * ow * ch * esz
-    args = np.zeros(max(n, 1), np.dtype(capi.ResampleArgs))
+    args = np.zeros(max(n, 1), _dtype(capi.ResampleArgs))
     if n:
         a = args[:n]
         a["in_"] = tab.ptr
@@ -564,7 +575,7 @@ def resample_batch(images, out_size, rois=None, interp_min=capi.INTERP_LINEAR, i
             _fill4(m4, mean)
             _fill4(i4, inv_std)
             a["mean"], a["inv_std"] = m4, i4
-    descs = np.zeros(max(n, 1), np.dtype(capi.ResampleDesc))
+    descs = np.zeros(max(n, 1), _dtype(capi.ResampleDesc))
     nwg, lds = C.c_int(0), C.c_int(0)
     capi.check(lib.daliamdResampleSetup(args.ctypes.data_as(C.c_void_p), n, descs.ctypes.data_as(C.c_void_p),
                                         C.byref(nwg), C.byref(lds)))
@@ -685,7 +696,7 @@ def warp_affine_batch(images, matrices, out_size=None, interp=capi.INTERP_LINEAR
     lib = capi.kernels()
     n = len(images)
     dev = images[0].device
-    descs = np.zeros(n, np.dtype(capi.WarpAffineDesc))
+    descs = np.zeros(n, _dtype(capi.WarpAffineDesc))
     outs = []
     for i, img in enumerate(images):
         h, w, c = img.shape
@@ -723,7 +734,7 @@ def gaussian_blur_batch(images, sigma=0.0, window_size=0):
     lib = capi.kernels()
     n = len(images)
     dev = images[0].device
-    descs = np.zeros(n, np.dtype(capi.GaussianBlurDesc))
+    descs = np.zeros(n, _dtype(capi.GaussianBlurDesc))
     sig = np.broadcast_to(np.asarray(sigma, np.float32), (n,))
     wsz = np.broadcast_to(np.asarray(window_size, np.int32), (n,))
     outs = []
@@ -759,7 +770,7 @@ def pointwise_batch(images, matrices=None, offsets=None, regions=None, fill=(0.0
     lib = capi.kernels()
     n = len(images)
     dev = images[0].device
-    descs = np.zeros(n, np.dtype(capi.PointwiseDesc))
+    descs = np.zeros(n, _dtype(capi.PointwiseDesc))
     outs = []
     for i, img in enumerate(images):
         h, w, c = img.shape
