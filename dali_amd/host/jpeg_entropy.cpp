@@ -273,7 +273,8 @@ struct Decoder {
     int ci = scomp[s_idx];
     const HuffTable &dt = dc[std_[s_idx]], &at = ac[sta[s_idx]];
     br.Refill();
-    int s = DecodeSymbol(br, dt);
+    int s = DecodeSymbol(br, dt) & 15;  // a (corrupt) table may list categories > 15: keep the bit count sane (the
+                                        // GPU decoder's table entries mask the symbol the same way)
     if (s) { br.Refill(); s = Extend(br.Get(s), s); }
     last_dc[ci] += s;
     blk[0] = (int16_t)last_dc[ci];
@@ -301,7 +302,7 @@ struct Decoder {
   inline void BlockDcFirst(BitReader &br, int16_t *blk, int s_idx) {
     int ci = scomp[s_idx];
     br.Refill();
-    int s = DecodeSymbol(br, dc[std_[s_idx]]);
+    int s = DecodeSymbol(br, dc[std_[s_idx]]) & 15;
     if (s) { br.Refill(); s = Extend(br.Get(s), s); }
     last_dc[ci] += s;
     blk[0] = (int16_t)(last_dc[ci] * (1 << Al));
