@@ -150,7 +150,8 @@ int main(int argc, char **argv) {
   g_pair_bits = argc > 5 ? atoi(argv[5]) : 0;
   const int r0_bytes = argc > 6 ? atoi(argv[6]) : 0;
   g_group = argc > 7 ? atoi(argv[7]) : 2;
-  g_dc_chain = argc > 8 ? atoi(argv[8]) : 0;  // > 0: round 0 decodes only the last r0_bytes of each slice
+  g_dc_chain = argc > 8 ? atoi(argv[8]) : 0;
+  const int overlap = argc > 9 ? atoi(argv[9]) : 0;  // > 0: round 0 starts this many bytes BEFORE the slice (private warm-up)  // > 0: round 0 decodes only the last r0_bytes of each slice
   const int seg_lanes = T - warm;
   std::vector<std::string> files;
   DIR *dp = opendir(argv[1]);
@@ -192,14 +193,26 @@ int main(int argc, char **argv) {
           if (l.active && !(l.has_in && l.in == state[t])) {
             l.in = state[t]; l.has_in = true;
             const State old_out = l.out; const bool had = l.has_in;
+            const State old_in = l.in;
             State st = l.in;
             if (round == 0 && r0_bytes > 0 && t > 0 && l.end - l.begin > (uint32_t)r0_bytes * 8) {
               st.pos = l.end - r0_bytes * 8;
               l.has_in = false;  // a partial decode: never accepted as the final one
             }
             l.nsym = l.steps = 0;
+            int warm_steps = 0;
+            if (round == 0 && overlap > 0 && t > 0 && l.begin >= (uint32_t)overlap * 8) {
+              State w{l.begin - (uint32_t)overlap * 8, 0, 0};
+              int ns = 0;
+              Decode(im, w, l.begin, ns, warm_steps);
+              st = w;              // whatever state the private warm-up reached at the start of the slice
+              l.has_in = false;    // a guess, never accepted as the final decode
+            }
             if (st.pos < l.end) Decode(im, st, l.end, l.nsym, l.steps);
+            l.steps += warm_steps;
             l.out = st;
+            if (getenv("SIM_LANES") && round >= 2 && fn.find(getenv("SIM_LANES")) != std::string::npos)
+              printf("    %s seg %ld round %d lane %d in (%u,%u,%u) was (%u,%u,%u) -> out (%u,%u,%u) was (%u,%u,%u) steps %d\n", fn.c_str() + fn.size() - 8, seg, round, t, l.in.pos, l.in.c, l.in.z, old_in.pos, old_in.c, old_in.z, st.pos, st.c, st.z, old_out.pos, old_out.c, old_out.z, l.steps);
             if (had && round >= 2) {
               extern long g_cls[4];
               if (st == old_out) g_cls[0]++; else if (st.pos == old_out.pos && st.z == old_out.z) g_cls[1]++; else g_cls[2]++;
