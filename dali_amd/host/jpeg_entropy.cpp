@@ -44,7 +44,9 @@ struct HuffTable {
   int32_t maxcode[18];
   int32_t valoff[17];
 
-  bool Build(bool is_ac) {
+  // lookup = false: only the canonical-code bookkeeping and its validation (the scan analysis for the GPU decoder
+  // hands on bits[] / vals[] and never decodes with these tables)
+  bool Build(bool is_ac, bool lookup = true) {
     uint32_t code = 0;
     int p = 0;
     uint32_t codes[257];
@@ -64,6 +66,8 @@ struct HuffTable {
       code <<= 1;
     }
     maxcode[17] = 0x7fffffff;
+    present = true;
+    if (!lookup) return true;
     memset(look, 0, sizeof(look));
     for (int i = 0; i < n; i++) {
       int l = sizes[i];
@@ -263,7 +267,7 @@ struct Decoder {
       memset(t.vals, 0, sizeof(t.vals));
       memcpy(t.vals, p, count);
       p += count; len -= count;
-      if (!t.Build(tc == 1)) return Fail("invalid Huffman table");
+      if (!t.Build(tc == 1, !analyze_only)) return Fail("invalid Huffman table");
     }
     return 0;
   }
