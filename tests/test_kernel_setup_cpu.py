@@ -123,3 +123,29 @@ def test_normalize_setup_views_and_grids():
     assert sw.value == descs[0].stat_chunks + 513 + descs[2].stat_chunks
     descs[0].in_dtype = capi.FLOAT16
     assert lib.daliamdNormalizeSetup(descs, 3, C.byref(sw), C.byref(aw), C.byref(bins)) != 0
+
+
+def test_huffman_setup_fused_output_needs_aligned_planes_not_coefficients():
+    """With plane[] set the decoder writes samples instead of coefficients: coef may be NULL, the planes must allow
+    8-byte stores."""
+    lib = capi.kernels()
+    tiles, segs, bwg = C.c_int(), C.c_int(), C.c_int()
+
+    def fused(pitch0=160, plane0=0x40000, with_coef=False):
+        d = _huff_desc()
+        for c in range(3):
+            if not with_coef:
+                d.coef[c] = 0
+            d.plane[c] = 0x40000 * (c + 1)
+            d.plane_pitch[c] = 80 if c else 160
+        d.plane[0], d.plane_pitch[0] = plane0, pitch0
+        return (capi.JpegHuffDesc * 1)(d)
+    assert lib.daliamdJpegHuffmanSetup(fused(), 1, C.byref(tiles), C.byref(segs), C.byref(bwg)) == 0
+    assert lib.daliamdJpegHuffmanSetup(fused(with_coef=True), 1, C.byref(tiles), C.byref(segs), C.byref(bwg)) == 0
+    for bad in (fused(pitch0=164), fused(pitch0=152), fused(plane0=0x40004)):   # pitch % 8, pitch < blocks_x*8, alignment
+        assert lib.daliamdJpegHuffmanSetup(bad, 1, C.byref(tiles), C.byref(segs), C.byref(bwg)) != 0
+        assert b"planes must be 8-byte aligned" in lib.daliamdGetLastErrorMessage()
+    neither = _huff_desc()
+    for c in range(3):
+        neither.coef[c] = 0
+    assert lib.daliamdJpegHuffmanSetup((capi.JpegHuffDesc * 1)(neither), 1, C.byref(tiles), C.byref(segs), C.byref(bwg)) != 0
