@@ -166,6 +166,9 @@ class ThreadPool {
   void AddWork(Work w, int64_t priority = 0);
   // runs everything added so far (highest priority first) and waits; rethrows the first exception
   void RunAll();
+  // drops work that was added but never run (an operator threw between AddWork and RunAll: the closures refer to
+  // its dead stack frame and must not execute in the next RunAll)
+  void Discard() { pending_.clear(); }
   int NumThreads() const { return (int)threads_.size(); }
 
  private:

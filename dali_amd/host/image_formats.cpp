@@ -232,6 +232,15 @@ int ParseBmpHeader(const uint8_t *d, size_t n, BmpHeader *h) {
   if (h->compression == 3 && h->bits != 16 && h->bits != 32) return Fail("BMP: bit fields need 16 or 32 bits per pixel");
   if (h->bits != 1 && h->bits != 4 && h->bits != 8 && h->bits != 16 && h->bits != 24 && h->bits != 32)
     return Fail("BMP: unsupported bit count %d", h->bits);
+  if (h->compression == 3) {
+    for (int c = 0; c < 3; c++) {  // a channel mask is one contiguous run of bits
+      const uint32_t m = h->mask[c];
+      if (m) {
+        const uint32_t low = m & (0u - m);  // lowest set bit; m + low clears the run if it is contiguous
+        if (((uint64_t)m + low) & m) return Fail("BMP: channel mask 0x%08X is not contiguous", m);
+      }
+    }
+  }
   if (h->bits <= 8 && h->ncolors == 0) h->ncolors = 1 << h->bits;
   if (h->bits <= 8 && (h->ncolors < 0 || h->ncolors > 256)) return Fail("BMP: invalid palette size");
   return 0;
@@ -242,7 +251,8 @@ inline uint8_t MaskedTo8(uint32_t v, uint32_t mask) {
   int shift = 0, width = 0;
   while (!((mask >> shift) & 1)) shift++;
   while (shift + width < 32 && ((mask >> (shift + width)) & 1)) width++;
-  const uint32_t x = (v & mask) >> shift, mx = (1u << width) - 1;
+  // 64-bit: a 32-bit wide mask makes (1u << width) undefined and x * 255 overflows above 24 bits
+  const uint64_t x = (v & mask) >> shift, mx = (1ull << width) - 1;
   return (uint8_t)(x * 255 / mx);  // truncating, like Pillow's BGR;15 / BGR;16 unpackers
 }
 

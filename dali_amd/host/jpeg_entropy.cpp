@@ -195,12 +195,14 @@ struct Decoder {
       return le ? (r16(o) | (r16(o + 2) << 16)) : ((r16(o) << 16) | r16(o + 2));
     };
     if (r16(2) != 42) return;
-    uint32_t off = r32(4);
+    // every offset comes from the stream: compare without wrap-around (64-bit arithmetic)
+    const uint64_t off = r32(4);
     if (off + 2 > n) return;
-    uint32_t cnt = r16(off);
+    const uint32_t cnt = r16((uint32_t)off);
     for (uint32_t i = 0; i < cnt; i++) {
-      uint32_t e = off + 2 + 12 * i;
-      if (e + 12 > n) return;
+      const uint64_t e64 = off + 2 + 12ull * i;
+      if (e64 + 12 > n) return;
+      const uint32_t e = (uint32_t)e64;
       if (r16(e) == 0x0112) {
         uint32_t v = r16(e + 8);
         if (v >= 1 && v <= 8) orientation = (int)v;

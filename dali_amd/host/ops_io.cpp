@@ -230,18 +230,39 @@ class FileReaderOp : public OperatorBase {
     ws.GetThreadPool().RunAll();
   }
 
-  // checkpoint: position in the stream + rng (loader.h:279,335,485-503)
+  // checkpoint (loader.h:279,335,485-503): the COMPLETE reader state - position of the sequential stream, shard
+  // bookkeeping, the samples sitting in the shuffle buffer (read ahead but not yet returned), the epoch end marks and
+  // the rng - so a restored reader continues with exactly the sample the saved one would have returned next, whether
+  // it is a fresh instance or one that has already run.
   std::string SaveState() const override {
     std::ostringstream ss;
-    ss << current_index_ << " " << virtual_shard_id_ << " " << read_in_shard_ << " " << returned_ << " " << epoch_ << " "
-       << rng_;
+    ss << current_index_ << " " << virtual_shard_id_ << " " << read_in_shard_ << " " << total_read_ << " " << consumed_
+       << " " << returned_ << " " << epoch_ << " " << last_pick_ << " " << (filled_ ? 1 : 0) << " " << buffer_.size();
+    for (auto &b : buffer_) ss << " " << b.first << " " << b.second;
+    ss << " " << shard_ends_.size();
+    for (int64_t e : shard_ends_) ss << " " << e;
+    ss << " " << rng_;
     return ss.str();
   }
   void RestoreState(const std::string &s) override {
     std::istringstream ss(s);
-    ss >> current_index_ >> virtual_shard_id_ >> read_in_shard_ >> returned_ >> epoch_ >> rng_;
-    buffer_.clear();
-    last_pick_ = -1;
+    int filled = 0;
+    size_t nbuf = 0, nends = 0;
+    ss >> current_index_ >> virtual_shard_id_ >> read_in_shard_ >> total_read_ >> consumed_ >> returned_ >> epoch_ >>
+        last_pick_ >> filled >> nbuf;
+    DALI_ENFORCE(!ss.fail() && nbuf <= (size_t)initial_fill_, "readers.file: malformed checkpoint");
+    buffer_.assign(nbuf, {0, 0});
+    for (auto &b : buffer_) ss >> b.first >> b.second;
+    ss >> nends;
+    DALI_ENFORCE(!ss.fail() && nends <= (1u << 20), "readers.file: malformed checkpoint");
+    shard_ends_.assign(nends, 0);
+    for (auto &e : shard_ends_) ss >> e;
+    ss >> std::ws >> rng_;  // libstdc++ reads the engine with skipws cleared
+    DALI_ENFORCE(!ss.fail(), "readers.file: malformed checkpoint");
+    for (auto &b : buffer_) DALI_ENFORCE(b.second >= 0 && b.second < Size(), "readers.file: checkpoint of another dataset");
+    DALI_ENFORCE(last_pick_ < Size() && current_index_ >= 0 && current_index_ <= Size(),
+                 "readers.file: checkpoint of another dataset");
+    filled_ = filled != 0;
   }
 
  private:

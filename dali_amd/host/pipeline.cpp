@@ -236,6 +236,7 @@ void Pipeline::RunStage(bool device_stage, int64_t it, int slot, Iteration &res)
           });
         }
       } catch (const std::exception &e) {
+        ws.thread_pool->Discard();
         // error_reporting.h: decorate with the operator's origin
         DALI_FAIL("Error in ", OpTypeName(n.type), " operator `", n.spec.SchemaName(), "` (instance \"", n.name, "\"): ",
                   e.what());

@@ -2,8 +2,11 @@
 (reference: dali/python/nvidia/dali/plugin/pytorch/__init__.py:43-283, torch_utils.py:34-102).
 
 Each output batch becomes a dense torch tensor on the pipeline's GPU (or in host memory for CPU outputs).
-The device copy is one torch.stack over zero-copy views of the pipeline's buffers, issued on torch's current
-stream -- the equivalent of the reference's feed_ndarray / copy_to_external."""
+The device copy is ONE copy of the batch (viewed in place in the pipeline's buffer) into a tensor the caller owns
+-- the equivalent of the reference's feed_ndarray / copy_to_external -- issued on a side stream of the iterator and
+completed before __next__ returns: the pipeline reuses the buffer a few iterations later on its own streams, so the
+read must not be left pending on torch's stream (and waiting for torch's CURRENT stream would wait for the
+consumer's training step as well)."""
 import numpy as np
 import torch
 
@@ -14,13 +17,22 @@ from .base_iterator import LastBatchPolicy, _DaliBaseIterator  # noqa: F401
 
 def feed_ndarray(tensor_or_tl, arr, cuda_stream=None, non_blocking=False):
     """Copies a dali_amd TensorList into a preallocated torch tensor (API parity with
-    nvidia.dali.plugin.pytorch.feed_ndarray)."""
+    nvidia.dali.plugin.pytorch.feed_ndarray, torch_utils.py:34-75).  `cuda_stream`: the torch stream to copy on
+    (default: the current one).  Unless `non_blocking`, the copy has completed on return, i.e. the pipeline may
+    reuse the source buffer."""
     if isinstance(tensor_or_tl, TensorListGPU):
         src = tensor_or_tl.as_tensor()
     else:
         src = torch.from_numpy(np.ascontiguousarray(tensor_or_tl.as_array()))
     assert tuple(src.shape) == tuple(arr.shape), f"Shapes do not match: DALI {tuple(src.shape)} vs torch {tuple(arr.shape)}"
-    arr.copy_(src, non_blocking=non_blocking)
+    if arr.is_cuda:
+        stream = cuda_stream if isinstance(cuda_stream, torch.cuda.Stream) else torch.cuda.current_stream(arr.device)
+        with torch.cuda.stream(stream):
+            arr.copy_(src, non_blocking=True)
+        if not non_blocking:
+            stream.synchronize()
+    else:
+        arr.copy_(src)
     return arr
 
 
@@ -30,6 +42,7 @@ class DALIGenericIterator(_DaliBaseIterator):
                  prepare_first_batch=True):
         assert len(set(output_map)) == len(output_map), "output_map names should be distinct"
         self.output_map = list(output_map)
+        self._copy_streams = {}
         super().__init__(pipelines, size, reader_name, auto_reset, fill_last_batch, last_batch_padded,
                          last_batch_policy, prepare_first_batch)
 
@@ -42,7 +55,13 @@ class DALIGenericIterator(_DaliBaseIterator):
             entry = {}
             for name, tl in zip(self.output_map, outs):
                 if isinstance(tl, TensorListGPU):
-                    t = tl.as_tensor()          # a fresh dense tensor: safe past the next pipeline run
+                    src = tl.as_tensor()        # in-place view of the pipeline's buffer (or a gathered copy)
+                    side = self._copy_streams.get(src.device)
+                    if side is None:
+                        side = self._copy_streams[src.device] = torch.cuda.Stream(device=src.device)
+                    t = torch.empty(src.shape, dtype=src.dtype, device=src.device)
+                    feed_ndarray(tl, t, cuda_stream=side)     # complete on return: the slot may be reused
+                    t.record_stream(side)
                 else:
                     t = torch.from_numpy(np.ascontiguousarray(tl.as_array()))
                 if valid is not None and valid < t.shape[0]:

@@ -118,12 +118,29 @@ class TensorListCPU(_TensorList):
 
 
 class TensorListGPU(_TensorList):
+    def _contiguous_view(self):
+        """Zero-copy [N, ...] view when the (uniform) samples sit back to back in the pipeline's buffer, else None."""
+        import torch
+        if self._n == 0 or not self.is_dense_tensor():
+            return None
+        ptr0, shape, pitch = self._samples[0]
+        np_t = np.dtype(types.to_numpy_type(self.dtype))
+        nbytes = int(np.prod(shape)) * np_t.itemsize
+        if nbytes == 0 or (pitch and len(shape) == 3 and pitch != shape[1] * shape[2] * np_t.itemsize):
+            return None
+        if any(self._samples[i][0] != ptr0 + i * nbytes for i in range(self._n)):
+            return None
+        iface = {"shape": (self._n,) + tuple(shape), "typestr": np_t.str, "data": (ptr0, False), "version": 3}
+        return torch.as_tensor(_Interface(iface, self), device="cuda")
+
     def as_tensor(self):
-        """Dense [N, ...] torch tensor (device).  Uniform, densely packed samples are viewed in place when
-        they are contiguous in the pipeline's buffer; otherwise they are gathered with one torch.stack."""
+        """Dense [N, ...] torch tensor (device).  Uniform samples that are contiguous in the pipeline's buffer are
+        viewed IN PLACE (no copy; the memory belongs to the pipeline and is valid until the next run()/outputs(),
+        the reference's share_outputs contract); otherwise they are gathered with one torch.stack."""
         import torch
         assert self.is_dense_tensor(), "All samples must have the same shape to form a dense tensor"
-        return torch.stack([self[i].as_torch() for i in range(self._n)])
+        view = self._contiguous_view()
+        return view if view is not None else torch.stack([self[i].as_torch() for i in range(self._n)])
 
     def as_cpu(self):
         return _HostCopy([self[i].as_cpu() for i in range(self._n)], self.dtype, self._layout)
@@ -135,6 +152,11 @@ class TensorListGPU(_TensorList):
         nbytes = t.numel() * t.element_size()
         dst = torch.as_tensor(_RawDevice(ptr, nbytes), device="cuda")
         dst.copy_(t.view(torch.uint8).reshape(-1), non_blocking=non_blocking)
+
+
+class _Interface:
+    def __init__(self, iface, owner):
+        self.__cuda_array_interface__, self._owner = iface, owner
 
 
 class _RawDevice:

@@ -90,3 +90,57 @@ def test_raster_decoders_survive_mutations():
             decoded += rc == 0
             refused += rc != 0
     assert decoded > 100 and refused > 100
+
+
+def test_exif_ifd_offset_cannot_wrap():
+    """A 32-bit IFD offset of 0xFFFFFFFE used to pass `off + 2 > n` by wrap-around and read 4 GB past the APP1
+    payload.  The parser must ignore such an Exif block (orientation stays 1) - and not crash."""
+    host = capi.host()
+    rng = np.random.default_rng(3)
+    good = encode_jpeg(synth_image(rng, 16, 16), 85)
+    for order, off in ((b"MM\x00*", b"\xff\xff\xff\xfe"), (b"II*\x00", b"\xfe\xff\xff\xff"),
+                       (b"MM\x00*", b"\xff\xff\xff\xf2"), (b"MM\x00*", b"\x7f\xff\xff\xff")):
+        payload = b"Exif\x00\x00" + order + off + b"\x00" * 8
+        app1 = b"\xff\xe1" + (len(payload) + 2).to_bytes(2, "big") + payload
+        for data in (b"\xff\xd8" + app1, good[:2] + app1 + good[2:]):
+            buf = np.frombuffer(data, np.uint8)
+            info = capi.JpegInfo()
+            rc = host.daliamdJpegParse(buf.ctypes.data_as(C.c_void_p), C.c_size_t(len(data)), C.byref(info))
+            if len(data) > 100:
+                assert rc == 0 and info.orientation == 1
+    # an entry table that runs past the payload is ignored as well
+    payload = b"Exif\x00\x00MM\x00*\x00\x00\x00\x08\xff\xff" + b"\x00" * 4
+    data = good[:2] + b"\xff\xe1" + (len(payload) + 2).to_bytes(2, "big") + payload + good[2:]
+    buf = np.frombuffer(data, np.uint8)
+    info = capi.JpegInfo()
+    assert host.daliamdJpegParse(buf.ctypes.data_as(C.c_void_p), C.c_size_t(len(data)), C.byref(info)) == 0
+    assert info.orientation == 1
+
+
+def test_bmp_bitfield_masks_full_width_and_non_contiguous():
+    """BI_BITFIELDS with a 32-bit wide channel mask used to divide by zero ((1u << 32) - 1 == 0 on x86); masks
+    with holes are refused."""
+    import struct
+    host = capi.host()
+
+    def bmp(masks, pixel):
+        hdr = struct.pack("<IiiHHIIiiII", 40, 2, 1, 1, 32, 3, 8, 0, 0, 0, 0)
+        body = hdr + struct.pack("<III", *masks) + struct.pack("<II", pixel, pixel)
+        return b"BM" + struct.pack("<IHHI", 14 + len(body), 0, 0, 14 + 40 + 12) + body
+
+    def decode(data):
+        buf = np.frombuffer(data, np.uint8)
+        fmt, w, h = C.c_int(), C.c_int32(), C.c_int32()
+        if host.daliamdImageProbe(buf.ctypes.data_as(C.c_void_p), C.c_size_t(len(data)), C.byref(fmt), C.byref(w),
+                                  C.byref(h)) != 0:
+            return None
+        out = np.zeros((h.value, 3 * w.value), np.uint8)
+        rc = host.daliamdImageDecodeRgb(buf.ctypes.data_as(C.c_void_p), C.c_size_t(len(data)),
+                                        out.ctypes.data_as(C.c_void_p), C.c_int64(out.shape[1]), 0, 0, 0, 0)
+        return out if rc == 0 else None
+
+    out = decode(bmp((0xFFFFFFFF, 0x0000FF00, 0x000000FF), 0x80FF4020))
+    assert out is not None and out[0, 0] == 0x80FF4020 * 255 // 0xFFFFFFFF and out[0, 1] == 0x40 and out[0, 2] == 0x20
+    out = decode(bmp((0xFF000000, 0x00FFFFFF, 0), 0x12FFFFFF))     # 24-bit wide mask: x * 255 needs 64 bits
+    assert out is not None and out[0, 0] == 0x12 and out[0, 1] == 255
+    assert decode(bmp((0x00FF00FF, 0x0000FF00, 0), 0)) is None      # mask with a hole

@@ -274,3 +274,37 @@ def test_iterator_epochs_with_reader(dataset):
         assert len(batch) == 2 and batch[0]["label"].shape[0] == 4
         n += 1
     assert n == 3   # ceil(23/2) = 12 per shard -> 3 batches of 4
+
+
+@pytest.mark.parametrize("shuffle", [False, True])
+@pytest.mark.parametrize("pad", [False, True])
+def test_reader_checkpoint_roundtrip(dataset, shuffle, pad):
+    """A restored reader continues with exactly the samples the saved one returns next - across an epoch boundary,
+    with samples sitting in the shuffle buffer, into a fresh pipeline and into one that has already run
+    (reference: loader.h:279,335,485-503 checkpointing of the loader position + rng)."""
+    from dali_amd import fn
+    from dali_amd.pipeline import Pipeline
+    root, files = dataset
+    kw = dict(random_shuffle=shuffle, initial_fill=7, pad_last_batch=pad, num_shards=2, shard_id=1)
+
+    def make(cpt=None):
+        pipe = Pipeline(batch_size=5, num_threads=2, device_id=0, seed=11, prefetch_queue_depth=1, checkpoint=cpt)
+        with pipe:
+            data, label = fn.readers.file(file_root=root, name="Reader", **kw)
+            pipe.set_outputs(data, label)
+        pipe.build()
+        return pipe
+
+    pipe = make()
+    _run_indices(pipe, 3)                      # 15 samples: past the first epoch of a 12-sample shard
+    cpt = pipe.checkpoint()
+    expect, expect_lab = _run_indices(pipe, 6)
+    fresh = make(cpt)
+    got, got_lab = _run_indices(fresh, 6)
+    assert np.array_equal(got, expect) and np.array_equal(got_lab, expect_lab)
+    # restoring into a reader that has already run ahead replays the same stream again
+    used = make()
+    _run_indices(used, 5)
+    used._backend.restore(cpt)
+    again, _ = _run_indices(used, 6)
+    assert np.array_equal(again, expect)
