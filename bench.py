@@ -3,9 +3,11 @@
 (224x224, batch 256 per GPU, fp16 CHW output) on N MI355X, plus the roofline of the dominant
 kernel and the CPU baseline (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 200 --warmup 8
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Data set: 1024 synthetic ImageNet-like JPEGs per GPU = 4 distinct batches of 256 which the steps
+rotate through (the entropy decoder's time depends on the content, one batch would be one sample of it).
 One "step" = one pass of the hot path over one batch whose inputs are already resident in HBM:
   JPEG entropy-coded segments (bytes)  ->  zero-fill + un-stuff + Huffman decode  [UnstuffKernel, HuffmanDecodeKernel]
                                        ->  dequant + IDCT                         [JpegIdctKernel]
@@ -17,8 +19,11 @@ Descriptor-table construction and upload are inside the timed region; the header
 coefficient blocks are produced once by the host entropy decoder and are the HBM-resident input (the host Huffman
 time is then reported as `e2e_host_huffman`, never inside `value`).
 
-Multi-GPU: sample sharding exactly like readers.file(shard_id, num_shards): rank r owns images
-[r*B, (r+1)*B) of the synthetic dataset; no collective on the data path ("scaling": "weak").
+Multi-GPU: sample sharding exactly like readers.file(shard_id, num_shards): rank r owns the contiguous shard
+[r*1024, (r+1)*1024) of a world*1024-image data set (loader.cc:78-87); no collective on the data path ("scaling":
+"weak").  For N > 1 the line also carries `e2e_pipeline_sharded`: BASELINE configs[4] through dali_amd.Pipeline on
+every rank (readers.file(shard_id=rank, num_shards=N) over the shared data set directory, batch 512 per GPU, host
+threads pinned to the GPU's NUMA node), timed with the same barrier / max-over-ranks rule.
 """
 import argparse
 import ctypes as C
@@ -79,24 +84,21 @@ def measured_copy_ceiling(device, mib=1024, iters=10):
     return 2.0 * (mib << 20) * iters / (a.elapsed_time(b) * 1e-3) / 1e9
 
 
-def make_dataset(first_index, count):
-    """Synthetic ImageNet-like JPEGs.  Image i depends only on its global index."""
-    from tests.util import synth_jpeg_batch
-    out = []
-    for i in range(first_index, first_index + count):
-        rng = np.random.default_rng([1234, i])
-        out.extend(synth_jpeg_batch(rng, 1))
-    return out
+def make_dataset(first_index, count, workers=0):
+    """Synthetic ImageNet-like JPEGs.  Image i depends only on its global index.  Forks generator
+    processes: call before torch / the HIP runtime are initialised."""
+    from dali_amd.testing import synth_dataset
+    return synth_dataset(first_index, count, seed=1234, workers=workers)
 
 
 class HotPath:
-    """Device-resident batch + the per-step launch sequence."""
+    """One device-resident batch + the per-step launch sequence (all launches on `stream`)."""
 
-    def __init__(self, enc, device, seed=1234, huffman="gpu", inflight=2, fused_idct=True):
+    def __init__(self, enc, device, stream, seed=1234, huffman="gpu", fused_idct=True, first_iteration=0):
         import torch
         from dali_amd import backend as B
         self.torch, self.B = torch, B
-        self.device = device
+        self.device, self.stream = device, stream
         self.n = len(enc)
         self.huffman = huffman
         self.fused_idct = fused_idct and huffman == "gpu"   # the entropy decoder writes the planes itself
@@ -109,18 +111,18 @@ class HotPath:
             if not self.plan.analyze_scans().all():
                 raise SystemExit("bench: the synthetic batch must be baseline single-scan JPEG")
             self.plan.upload_streams(device)
-            self.coef_dev = torch.empty(self.plan.coef_elems, dtype=torch.int16, device=device)
+            self.coef = torch.empty(self.plan.coef_elems, dtype=torch.int16, device=device)
             # one-time self check: the GPU entropy decoder reproduces the host decoder's coefficients exactly
-            status = self.plan.run_gpu_huffman(self.coef_dev)
+            status = self.plan.run_gpu_huffman(self.coef)
             torch.cuda.synchronize()
             self.plan.check_gpu_status(status)
-            if not torch.equal(self.coef_dev.cpu(), self.coef_host):
+            if not torch.equal(self.coef.cpu(), self.coef_host):
                 raise SystemExit("bench: GPU Huffman output differs from the host entropy decoder")
             if self.fused_idct:   # ... and its fused dequantisation + IDCT the stand-alone IDCT kernel's planes
                 ref_planes = torch.zeros(self.plan.plane_bytes, dtype=torch.uint8, device=device)
                 got_planes = torch.zeros_like(ref_planes)
                 scratch_rgb = torch.empty(self.plan.out_bytes, dtype=torch.uint8, device=device)
-                B.jpeg_gpu_stage(self.plan, self.coef_dev, ref_planes, scratch_rgb)
+                B.jpeg_gpu_stage(self.plan, self.coef, ref_planes, scratch_rgb)
                 status = self.plan.run_gpu_huffman(None, planes_dev=got_planes)
                 torch.cuda.synchronize()
                 self.plan.check_gpu_status(status)
@@ -128,33 +130,25 @@ class HotPath:
                     raise SystemExit("bench: fused Huffman+IDCT planes differ from the IDCT kernel's")
                 del ref_planes, got_planes, scratch_rgb
         else:
-            self.coef_dev = self.coef_host.to(device)
-        # `inflight` batches are processed concurrently, each on its own HIP stream with its own buffers (what the
-        # reference's executor does with prefetch_queue_depth=2: the decode of batch i+1 overlaps the resize of batch i)
-        self.slots = []
-        for k in range(inflight):
-            slot = {"stream": torch.cuda.Stream(device=device),
-                    "coef": self.coef_dev if k == 0 else torch.empty_like(self.coef_dev),
-                    "planes": torch.empty(self.plan.plane_bytes, dtype=torch.uint8, device=device),
-                    "rgb": torch.empty(self.plan.out_bytes, dtype=torch.uint8, device=device),
-                    "out": torch.empty((self.n, 3, 224, 224), dtype=torch.float16, device=device),
-                    "ws": self.plan.new_huffman_workspace(device) if huffman == "gpu" else None}
-            if huffman != "gpu" and k > 0:
-                slot["coef"].copy_(self.coef_dev)
-            slot["views"] = self.plan.output_views(slot["rgb"])
-            slot["image_table"] = B.ImageTable(slot["views"])
-            self.slots.append(slot)
-        self.views = self.slots[0]["views"]
-        self.out = self.slots[0]["out"]
-        self.rgb = self.slots[0]["rgb"]
+            self.coef = self.coef_host.to(device)
+        self.coef_host = None
+        self.planes = torch.empty(self.plan.plane_bytes, dtype=torch.uint8, device=device)
+        self.rgb = torch.empty(self.plan.out_bytes, dtype=torch.uint8, device=device)
+        self.out = torch.empty((self.n, 3, 224, 224), dtype=torch.float16, device=device)
+        self.ws = self.plan.new_huffman_workspace(device) if huffman == "gpu" else None
+        self.views = self.plan.output_views(self.rgb)
+        self.image_table = B.ImageTable(self.views)
         self.host_s = 0.0
         self.kernel_events = []
         self.shapes = np.array([v.shape[:2] for v in self.views], np.int32)
+        # one RandomResizedCrop / CoinFlip operator pair runs over the whole data set: the generator of a batch is the
+        # master advanced by the batches before it (OperatorWithRng::Advance)
         self.rrc_master = B.philox_state(seed)
         self.flip_master = B.philox_state(seed + 1)
+        self.rrc_master.ctr[1] += first_iteration * self.n
+        self.flip_master.ctr[1] += first_iteration * self.n
         self.mean, self.inv_std = B.cmn_norm_args([0.485 * 255, 0.456 * 255, 0.406 * 255],
                                                   [0.229 * 255, 0.224 * 255, 0.225 * 255])
-        self.events = None
         self.last_rois = None
         # algorithmic bytes per launch
         P = sum(int(s[0]) * int(s[1]) for s in self.shapes)
@@ -162,36 +156,30 @@ class HotPath:
         self.bytes_idct = 3 * self.plan.coef_elems            # 2 B coefficient in + 1 B sample out
         self.bytes_color = self.plan.plane_bytes + 3 * P       # planes in + RGB out
 
-    def step(self, record=None, index=0):
-        """Enqueues one pass of the hot path over the batch on the stream of slot index % inflight."""
+    def step(self, record=None, kernel_events=None, advance=1):
+        """Enqueues one pass of the hot path over the batch.  `advance`: iterations of the operator pair between two
+        passes over THIS batch (= the number of distinct batches the steps rotate through)."""
         torch, B = self.torch, self.B
         from dali_amd import _capi as capi
         ev = record
-        slot = self.slots[index % len(self.slots)]
         t0 = time.perf_counter()
-        with torch.cuda.stream(slot["stream"]):
+        with torch.cuda.stream(self.stream):
             if self.huffman == "gpu":
-                ke = None
-                if ev:   # per-kernel events of the entropy decoder: created before the timed region, one set per step
-                    pool = getattr(self, "kernel_event_pool", ())
-                    k = len(self.kernel_events)
-                    ke = pool[k] if k < len(pool) else B.KernelEvents(len(B.HUFFMAN_KERNELS))
-                    self.kernel_events.append(ke)
-                self.plan.run_gpu_huffman(slot["coef"], events=ev[5:7] if ev else None, ws=slot["ws"],
-                                          kernel_events=ke.handles if ke else None,
-                                          planes_dev=slot["planes"] if self.fused_idct else None)
-            B.jpeg_gpu_stage(self.plan, slot["coef"], slot["planes"], slot["rgb"], split_events=ev[1:2] if ev else None,
+                self.plan.run_gpu_huffman(self.coef, events=ev[5:7] if ev else None, ws=self.ws,
+                                          kernel_events=kernel_events.handles if kernel_events else None,
+                                          planes_dev=self.planes if self.fused_idct else None)
+            B.jpeg_gpu_stage(self.plan, self.coef, self.planes, self.rgb, split_events=ev[1:2] if ev else None,
                              start_event=ev[0] if ev else None, fused_huffman=self.fused_idct)
             anchors, crops = B.random_crop_batch(self.rrc_master, self.shapes)
             mirror = B.coin_flip_batch(self.flip_master, self.n, 0.5)
-            self.rrc_master.ctr[1] += self.n   # OperatorWithRng::Advance
-            self.flip_master.ctr[1] += self.n
+            self.rrc_master.ctr[1] += advance * self.n   # OperatorWithRng::Advance
+            self.flip_master.ctr[1] += advance * self.n
             rois = np.concatenate([anchors, anchors + crops], 1).astype(np.float32)
             self.last_rois = (anchors, crops)
             if ev:
                 ev[2].record()
-            B.resample_batch(slot["image_table"], (224, 224), rois=rois, out_dtype=capi.FLOAT16, out_layout=capi.LAYOUT_CHW,
-                             mean=self.mean, inv_std=self.inv_std, mirror=mirror, out=slot["out"],
+            B.resample_batch(self.image_table, (224, 224), rois=rois, out_dtype=capi.FLOAT16, out_layout=capi.LAYOUT_CHW,
+                             mean=self.mean, inv_std=self.inv_std, mirror=mirror, out=self.out,
                              start_event=ev[3] if ev else None)
             if ev:
                 ev[4].record()
@@ -224,51 +212,107 @@ def cpu_baseline(enc, seconds_budget=20.0):
                       f"oracle (-O3 -msse2, OpenMP, one task per sample), {cores} threads, {el:.2f} s wall"}
 
 
-def e2e_pipeline(enc, device_id, iters=30, threads=None, roi_decode=False, cache_mb=0):
+def pillow_baseline(enc, seconds_budget=20.0):
+    """Secondary, informational CPU baseline: Pillow / libjpeg-turbo (SIMD IDCT and
+    colour conversion) decode + Image.resize(box=crop window, BILINEAR) + numpy CropMirrorNormalize, one task per
+    sample in a ThreadPoolExecutor over all usable host cores (Pillow releases the GIL in decode and resize).  Same
+    crop windows and mirror bits as the product (oracle Philox); the resize filter is Pillow's, not DALI's - this
+    is a speed reference of a tuned CPU decoder, the parity reference is `cpu_baseline`."""
+    import io
+    from concurrent.futures import ThreadPoolExecutor
+    from PIL import Image
+    from oracle import oracle as O
+    cores = effective_cpu_count()
+    mean = np.array([0.485 * 255, 0.456 * 255, 0.406 * 255], np.float32)
+    inv = (1.0 / np.array([0.229 * 255, 0.224 * 255, 0.225 * 255])).astype(np.float32)
+    shapes = []
+    for e in enc:
+        w, h = Image.open(io.BytesIO(e)).size
+        shapes.append((h, w))
+
+    def one(job):
+        e, (ay, ax), (ch, cw), flip = job
+        im = Image.open(io.BytesIO(e)).convert("RGB")
+        r = im.resize((224, 224), Image.BILINEAR, box=(ax, ay, ax + cw, ay + ch))
+        a = np.asarray(r, np.float32)
+        if flip:
+            a = a[:, ::-1]
+        return ((a - mean) * inv).transpose(2, 0, 1).astype(np.float16)
+
+    done, it = 0, 0
+    with ThreadPoolExecutor(cores) as pool:
+        t0 = time.perf_counter()
+        while True:
+            anchors, crops = O.rrc_batch(1234, it, shapes)
+            flips = O.coin_flip_batch(1235, it, len(enc), 0.5)
+            out = list(pool.map(one, zip(enc, anchors, crops, flips)))
+            assert out[0].shape == (3, 224, 224)
+            done += len(enc)
+            it += 1
+            el = time.perf_counter() - t0
+            if el * cores >= seconds_budget or el > 30:
+                break
+    from PIL import features
+    return {"value": done / el, "unit": "images/s", "cores": cores, "kind": "pillow",
+            "libjpeg_turbo": features.version("jpg"),
+            "sample": f"{done} images = {it} pass(es) over the first {len(enc)}-image batch; Pillow decode + resize(box, "
+                      f"BILINEAR) + numpy CMN, ThreadPoolExecutor({cores}), {el:.2f} s wall"}
+
+
+def write_dataset(root, enc, first_index=0):
+    """Data set directory for readers.file: root/<class 0..9>/img_<global index>.jpg (sorted order = index order
+    inside a class; labels = class directory)."""
+    for c in range(10):
+        os.makedirs(os.path.join(root, f"{c:02d}"), exist_ok=True)
+    for i, e in enumerate(enc):
+        g = first_index + i
+        with open(os.path.join(root, f"{g % 10:02d}", f"img_{g:07d}.jpg"), "wb") as f:
+            f.write(e)
+
+
+def e2e_pipeline(root, batch, device_id, iters=40, threads=None, roi_decode=False, cache_mb=0, shard_id=0, num_shards=1,
+                 depth=4, sync=None, set_affinity=False):
     """The same hot path through the product's DALI-style pipeline (C++ host framework): readers.file (page cache)
     -> decoders.image(mixed: header parse + scan analysis on the host thread pool, H2D of the entropy-coded
     segments, GPU Huffman/IDCT/colour) -> random_resized_crop + crop_mirror_normalize (fused).  PCIe-inclusive and
-    host-inclusive, therefore reported next to `value`, never as `value`."""
-    import shutil
-    import tempfile
+    host-inclusive, therefore reported next to `value`, never as `value`.  `sync`: barrier callable bracketing the
+    timed region (multi-rank runs); returns this rank's elapsed seconds in "elapsed_s"."""
     from dali_amd import fn, types
     from dali_amd.pipeline import Pipeline
     threads = threads or effective_cpu_count()
-    root = tempfile.mkdtemp(prefix="dali_amd_bench_")
-    try:
-        os.makedirs(os.path.join(root, "c0"))
-        for i, e in enumerate(enc):
-            with open(os.path.join(root, "c0", f"{i:05d}.jpg"), "wb") as f:
-                f.write(e)
-        # four sequential stages (file reads | parse + staging | H2D | kernels) need several batches in flight to overlap
-        pipe = Pipeline(batch_size=len(enc), num_threads=threads, device_id=device_id, seed=1234, prefetch_queue_depth=4)
-        with pipe:
-            jpegs, labels = fn.readers.file(file_root=root, name="Reader")
-            if roi_decode:   # the variant NVIDIA's own benchmark uses (hw_decoder_bench.py:178-188): ROI decode + resize
-                images = fn.decoders.image_random_crop(jpegs, device="mixed", output_type=types.RGB)
-                crops = fn.resize(images, size=[224, 224])
-            else:
-                cache = dict(cache_size=cache_mb, cache_type="threshold") if cache_mb else {}
-                images = fn.decoders.image(jpegs, device="mixed", output_type=types.RGB, **cache)
-                crops = fn.random_resized_crop(images, size=[224, 224])
-            out = fn.crop_mirror_normalize(crops, dtype=types.FLOAT16, output_layout="CHW",
-                                           mean=[0.485 * 255, 0.456 * 255, 0.406 * 255],
-                                           std=[0.229 * 255, 0.224 * 255, 0.225 * 255],
-                                           mirror=fn.random.coin_flip(probability=0.5))
-            pipe.set_outputs(out, labels)
-        pipe.build()
-        for _ in range(10):   # every ring slot allocates its pinned / device buffers on first use
-            pipe.run()
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            pipe.run()
-        el = time.perf_counter() - t0
-        return {"value": iters * len(enc) / el, "unit": "images/s", "ms_per_batch": 1e3 * el / iters,
-                "host_threads": threads, "prefetch_queue_depth": 4, "kernels": pipe.executed_kernels(),
-                "note": "dali_amd.Pipeline end to end from encoded files in the page cache (file read, header parse, "
-                        "H2D of the JPEG bytes on a copy stream, all device stages, fp16 CHW batch on the device)"}
-    finally:
-        shutil.rmtree(root, ignore_errors=True)
+    # four sequential stages (file reads | parse + staging | H2D | kernels) need several batches in flight to overlap
+    pipe = Pipeline(batch_size=batch, num_threads=threads, device_id=device_id, seed=1234, prefetch_queue_depth=depth,
+                    set_affinity=set_affinity)
+    with pipe:
+        jpegs, labels = fn.readers.file(file_root=root, name="Reader", shard_id=shard_id, num_shards=num_shards)
+        if roi_decode:   # the variant NVIDIA's own benchmark uses (hw_decoder_bench.py:178-188): ROI decode + resize
+            images = fn.decoders.image_random_crop(jpegs, device="mixed", output_type=types.RGB)
+            crops = fn.resize(images, size=[224, 224])
+        else:
+            cache = dict(cache_size=cache_mb, cache_type="threshold") if cache_mb else {}
+            images = fn.decoders.image(jpegs, device="mixed", output_type=types.RGB, **cache)
+            crops = fn.random_resized_crop(images, size=[224, 224])
+        out = fn.crop_mirror_normalize(crops, dtype=types.FLOAT16, output_layout="CHW",
+                                       mean=[0.485 * 255, 0.456 * 255, 0.406 * 255],
+                                       std=[0.229 * 255, 0.224 * 255, 0.225 * 255],
+                                       mirror=fn.random.coin_flip(probability=0.5))
+        pipe.set_outputs(out, labels)
+    pipe.build()
+    for _ in range(2 * depth + 2):   # every ring slot allocates its pinned / device buffers on first use
+        pipe.run()
+    if sync:
+        sync()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        pipe.run()
+    if sync:
+        sync()
+    el = time.perf_counter() - t0
+    return {"value": iters * batch / el, "unit": "images/s", "ms_per_batch": 1e3 * el / iters, "elapsed_s": el,
+            "batch": batch, "iters": iters, "host_threads": threads, "prefetch_queue_depth": depth,
+            "shard_id": shard_id, "num_shards": num_shards, "kernels": pipe.executed_kernels(),
+            "note": "dali_amd.Pipeline end to end from encoded files in the page cache (file read, header parse, "
+                    "H2D of the JPEG bytes on a copy stream, all device stages, fp16 CHW batch on the device)"}
 
 
 def bench_heavy_aug(args, device):
@@ -276,7 +320,7 @@ def bench_heavy_aug(args, device):
     images resident in HBM.  One JSON line with per-kernel achieved GB/s (algorithmic bytes: 3*512*512 in + out)."""
     import torch
     from dali_amd import backend as B
-    from tests.util import synth_image
+    from dali_amd.testing import synth_image
     n = 128
     rng = np.random.default_rng(1234)
     base = [torch.from_numpy(synth_image(rng, 512, 512)).to(device) for _ in range(8)]
@@ -383,11 +427,14 @@ def bench_audio(args, device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
+    ap.add_argument("--batches", type=int, default=4,
+                    help="distinct batches the steps rotate through (data set = batches * batch images per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end dali_amd.Pipeline leg")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end dali_amd.Pipeline legs")
+    ap.add_argument("--e2e-batch", type=int, default=512, help="batch per GPU of the sharded end-to-end leg (configs[4])")
     ap.add_argument("--inflight", type=int, default=2,
                     help="batches processed concurrently, each on its own HIP stream (executor prefetch depth)")
     ap.add_argument("--huffman", default="gpu", choices=["gpu", "host"],
@@ -399,14 +446,30 @@ def main():
                     help="imagenet = the headline metric (default); heavy_aug / audio = configs[2] / configs[3] side benches")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    B = args.batch
+    nb = max(1, args.batches)
+    inflight = max(1, min(args.inflight, nb))
+    while nb % inflight:       # a batch always runs on the same stream
+        inflight -= 1
+    per_rank = nb * B
+    enc_all = None
+    if args.workload == "imagenet":
+        # shard `rank` of `world` (contiguous, like loader.cc:78-87) of a world * per_rank image data set; generated in
+        # forked workers BEFORE the HIP runtime comes up in this process
+        t_gen = time.perf_counter()
+        enc_all = make_dataset(rank * per_rank, per_rank, workers=max(1, effective_cpu_count() // max(1, local_world)))
+        t_gen = time.perf_counter() - t_gen
+
+    import torch
+    import torch.distributed as dist
+
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
@@ -418,9 +481,10 @@ def main():
     if args.workload == "audio":
         return bench_audio(args, device)
 
-    B = args.batch
-    enc = make_dataset(rank * B, B)  # shard `rank` of `world` (contiguous, like loader.cc:78-87)
-    hp = HotPath(enc, device, huffman=args.huffman, inflight=max(1, args.inflight), fused_idct=not args.no_fused_idct)
+    streams = [torch.cuda.Stream(device=device) for _ in range(inflight)]
+    paths = [HotPath(enc_all[b * B:(b + 1) * B], device, streams[b % inflight], huffman=args.huffman,
+                     fused_idct=not args.no_fused_idct, first_iteration=b) for b in range(nb)]
+    fused = paths[0].fused_idct
 
     def barrier():
         if world > 1:
@@ -428,17 +492,20 @@ def main():
         torch.cuda.synchronize()
 
     for w in range(args.warmup):
-        hp.step(index=w)
+        paths[w % nb].step(advance=nb)
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(7)] for _ in range(args.steps)]
+    kev = None
     if args.huffman == "gpu":
         from dali_amd import backend as _backend
-        hp.kernel_event_pool = [_backend.KernelEvents(len(_backend.HUFFMAN_KERNELS)) for _ in range(args.steps)]
+        kev = [_backend.KernelEvents(len(_backend.HUFFMAN_KERNELS)) for _ in range(args.steps)]
     resample_bytes = []
     barrier()
-    hp.host_s = 0.0
+    for hp in paths:
+        hp.host_s = 0.0
     t0 = time.perf_counter()
     for k in range(args.steps):
-        _, crops = hp.step(record=ev[k], index=k)
+        hp = paths[(args.warmup + k) % nb]
+        _, crops = hp.step(record=ev[k], kernel_events=kev[k] if kev else None, advance=nb)
         resample_bytes.append(hp.resample_bytes(crops))
     barrier()
     elapsed = time.perf_counter() - t0
@@ -447,28 +514,28 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # per-kernel average durations from the events recorded inside the timed region
+    # per-kernel average durations from the events recorded inside the timed region; algorithmic bytes averaged over
+    # the same steps (the batches differ)
+    step_paths = [paths[(args.warmup + k) % nb] for k in range(args.steps)]
+    mean_of = lambda f: float(np.mean([f(hp) for hp in step_paths]))  # noqa: E731
     ms_idct = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
     ms_color = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
     ms_resample = float(np.mean([e[3].elapsed_time(e[4]) for e in ev]))
+    bytes_idct, bytes_color = mean_of(lambda hp: hp.bytes_idct), mean_of(lambda hp: hp.bytes_color)
+    stream_bytes = mean_of(lambda hp: hp.plan.stream_bytes) if args.huffman == "gpu" else None
     kern = {
-        "JpegColorKernel": (hp.bytes_color, ms_color),
+        "JpegColorKernel": (bytes_color, ms_color),
         "ResampleKernel": (float(np.mean(resample_bytes)), ms_resample),
     }
-    if not hp.fused_idct:
-        kern["JpegIdctKernel"] = (hp.bytes_idct, ms_idct)
+    if not fused:
+        kern["JpegIdctKernel"] = (bytes_idct, ms_idct)
     if args.huffman == "gpu":
         # per-kernel durations of the entropy decoder (events recorded between its launches, same stream)
-        per = np.array([ke.elapsed_ms() for ke in hp.kernel_events]).mean(0)
-        sb, ce = hp.plan.stream_bytes, hp.plan.coef_elems
-        symbols = hp.plan.huffman_symbol_count(hp.slots[0]["ws"])   # one 32-bit record per symbol
-        rec = 4 * symbols
-        # PrepareKernel: the stream read once (byte counts) + the 60 KB of code tables it writes per stream
-        huff_bytes = {"PrepareKernel": sb + 60 * 1024 * B, "UnstuffScatterKernel": 2 * sb,
-                      "SyncKernel": sb, "PropagateKernel": 0, "WriteKernel": sb + rec, "DcScanKernel": 0,
-                      # records in; coefficients out, or (fused dequantisation + IDCT) the 8-bit samples
-                      "ExpandKernel": rec + (ce if hp.fused_idct else 2 * ce)}
-        from dali_amd.backend import HUFFMAN_KERNELS
+        per = np.array([ke.elapsed_ms() for ke in kev]).mean(0)
+        sb, ce = stream_bytes, mean_of(lambda hp: hp.plan.coef_elems)
+        symbols = float(np.mean([hp.plan.huffman_symbol_count(hp.ws) for hp in paths]))
+        from dali_amd.backend import HUFFMAN_KERNELS, huffman_algorithmic_bytes
+        huff_bytes = huffman_algorithmic_bytes(sb, ce, symbols, B, fused)
         for name, ms in zip(HUFFMAN_KERNELS, per):
             kern[name] = (huff_bytes[name], float(ms))
         huffman_total_ms = float(np.mean([e[5].elapsed_time(e[6]) for e in ev]))
@@ -476,67 +543,108 @@ def main():
     ach = kern[dominant][0] / (kern[dominant][1] * 1e-3) / 1e9
     traffic, traffic_src = measured_traffic(dominant)
 
+    line = None
     if rank == 0:
         value = world * B * args.steps / elapsed
         step_ms = 1e3 * elapsed / args.steps
         step_bytes = float(sum(v[0] for v in kern.values()))
         copy_ceiling = measured_copy_ceiling(device)
-        post_entropy = hp.bytes_idct + hp.bytes_color + float(np.mean(resample_bytes))
+        # SURVEY.md 8(d) end-to-end formula: 6 P (coefficients in, RGB out) + 3 s P + 6 O (fused resample + CMN)
+        post_entropy = 2 * bytes_idct + float(np.mean(resample_bytes))
+        nk = len(HUFFMAN_KERNELS) if args.huffman == "gpu" else 0
         line = {
             "metric": "images/sec JPEG->RRC->CMN 224^2 b256 per GPU",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/i32 decode, f32 resample, f16 out", "data": "synthetic",
             "config": {"workload": "configs[1]: HIP JPEG " + ("Huffman decode -> " if args.huffman == "gpu" else "") +
-                                   ("(fused) " if hp.fused_idct else "") + "dequant+IDCT -> upsample+YCbCr->RGB -> fused "
-                                   "RandomResizedCrop+CropMirrorNormalize, 224x224, batch=256/GPU, fp16 CHW out; "
-                                   "ImageNet-like synthetic JPEGs (seed 1234), inputs = " +
+                                   ("(fused) " if fused else "") + "dequant+IDCT -> upsample+YCbCr->RGB -> fused "
+                                   f"RandomResizedCrop+CropMirrorNormalize, 224x224, batch={B}/GPU, fp16 CHW out; "
+                                   f"{per_rank} ImageNet-like synthetic JPEGs per GPU (seed 1234) = {nb} distinct batches "
+                                   "rotated across the steps, inputs = " +
                                    ("JPEG entropy-coded segments (bytes) resident in HBM" if args.huffman == "gpu" else
                                     "host-entropy-decoded coefficient blocks resident in HBM"),
-                       "huffman": args.huffman, "fused_dequant_idct": hp.fused_idct, "batches_in_flight": len(hp.slots),
-                       "huffman_ms_per_batch(7 kernels)": huffman_total_ms if args.huffman == "gpu" else None,
-                       "host_ms_per_step": 1e3 * hp.host_s / args.steps,
-                       "jpeg_bytes_per_batch": getattr(hp.plan, "stream_bytes", None),
+                       "huffman": args.huffman, "fused_dequant_idct": fused, "batches_in_flight": inflight,
+                       "distinct_batches": nb, "dataset_images_per_gpu": per_rank, "dataset_generation_s": t_gen,
+                       f"huffman_ms_per_batch({nk} kernels)": huffman_total_ms if args.huffman == "gpu" else None,
+                       "host_ms_per_step": 1e3 * sum(hp.host_s for hp in paths) / args.steps,
+                       "jpeg_bytes_per_batch": stream_bytes,
                        "global_batch": world * B, "parallelism": f"shard{world} (shard_id/num_shards, no collective)",
-                       "pixels_per_batch": hp.pixels},
+                       "pixels_per_batch": mean_of(lambda hp: hp.pixels)},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "measured_copy_ceiling_GBps": copy_ceiling, "frac_of_measured_ceiling": ach / copy_ceiling,
-                         "note": "the dominant kernel of the GPU entropy decoder is a serial-bit latency chain, not an "
-                                 "HBM stream (SURVEY.md 8(d)); whole_step prices all kernels of one pass together",
-                         "whole_step": {"algorithmic_bytes": step_bytes, "achieved_GBps": step_bytes / (step_ms * 1e-3) / 1e9,
-                                        "frac": step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                        "frac_of_measured_ceiling": step_bytes / (step_ms * 1e-3) / 1e9 / copy_ceiling},
+                         "note": "the entropy decoder's kernels are serial-bit decode loops, not HBM streams (SURVEY.md "
+                                 "8(d)); whole_step prices one pass by the end-to-end formula 6P + 3sP + 6O (+ the JPEG "
+                                 "bytes), i.e. WITHOUT the decoder's internal scratch traffic",
+                         "whole_step": {"algorithmic_bytes": post_entropy + (stream_bytes or 0),
+                                        "achieved_GBps": (post_entropy + (stream_bytes or 0)) / (step_ms * 1e-3) / 1e9,
+                                        "frac": (post_entropy + (stream_bytes or 0)) / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        "frac_of_measured_ceiling":
+                                            (post_entropy + (stream_bytes or 0)) / (step_ms * 1e-3) / 1e9 / copy_ceiling,
+                                        "sum_of_per_kernel_algorithmic_bytes": step_bytes},
                          "per_kernel": {k: {"algorithmic_bytes": v[0], "avg_ms": v[1],
                                             "achieved_GBps": v[0] / (v[1] * 1e-3) / 1e9} for k, v in kern.items()}},
             "ceilings": {
                 "hbm_post_entropy_images_per_s": B / (post_entropy / (HBM_PEAK_GBS * 1e9)),
-                "pcie_gen5_x16_images_per_s": 64e9 / (hp.plan.stream_bytes / B) if args.huffman == "gpu" else None,
+                "pcie_gen5_x16_images_per_s": 64e9 / (stream_bytes / B) if args.huffman == "gpu" else None,
                 "entropy_decode_images_per_s": B / (huffman_total_ms * 1e-3) if args.huffman == "gpu" else None,
                 "note": "SURVEY.md 8(d): HBM bound of everything after the entropy decoder, H2D bound of the JPEG bytes "
-                        "(64 GB/s), and the measured rate of the GPU entropy decoder alone (all 7 kernels, this run)"},
+                        "(64 GB/s), and the measured rate of the GPU entropy decoder alone (all its kernels, this run)"},
             "entropy_decode": ({"symbols_per_batch": symbols, "symbols_per_s": symbols / (huffman_total_ms * 1e-3),
-                                "bitstream_GBps": hp.plan.stream_bytes / (huffman_total_ms * 1e-3) / 1e9}
+                                "bitstream_GBps": stream_bytes / (huffman_total_ms * 1e-3) / 1e9}
                                if args.huffman == "gpu" else None),
-            "e2e_host_huffman": {"huffman_s_per_batch": hp.huffman_s,
+            "e2e_host_huffman": {"huffman_s_per_batch": float(np.mean([hp.huffman_s for hp in paths])),
                                  "host_threads": effective_cpu_count(),
-                                 "note": "host entropy decoder on the same batch (one pass, thread pool): the CPU half "
+                                 "note": "host entropy decoder on the same batches (one pass, thread pool): the CPU half "
                                          "of the hybrid variant (--huffman host); not part of `value`"},
         }
-        if world == 1 and not args.no_e2e:
-            del hp
-            torch.cuda.empty_cache()
-            line["e2e_pipeline"] = e2e_pipeline(enc, local_rank)
-            line["e2e_pipeline_roi_decode"] = e2e_pipeline(enc, local_rank, roi_decode=True)
-            line["e2e_pipeline_roi_decode"]["note"] = ("same, with decoders.image_random_crop -> resize -> "
-                                                       "crop_mirror_normalize: only the crop window is decoded")
-            line["e2e_pipeline_decoder_cache"] = e2e_pipeline(enc, local_rank, iters=100, cache_mb=512)
-            line["e2e_pipeline_decoder_cache"]["note"] = (
-                "same as e2e_pipeline with decoders.image(cache_size=512, cache_type='threshold'): epoch >= 2 of a data "
-                "set whose decoded images fit in HBM (here: the one batch).  The files are still read; decoded images "
-                "are handed to the fused resample kernel in place from the cache blob")
+    del paths, step_paths, hp
+    torch.cuda.empty_cache()
+
+    if not args.no_e2e:
+        import shutil
+        import tempfile
+        if world == 1:
+            root = tempfile.mkdtemp(prefix="dali_amd_bench_")
+            try:
+                write_dataset(root, enc_all)
+                line["e2e_pipeline"] = e2e_pipeline(root, B, local_rank)
+                line["e2e_pipeline_roi_decode"] = e2e_pipeline(root, B, local_rank, roi_decode=True)
+                line["e2e_pipeline_roi_decode"]["note"] = ("same, with decoders.image_random_crop -> resize -> "
+                                                           "crop_mirror_normalize: only the crop window is decoded")
+                line["e2e_pipeline_decoder_cache"] = e2e_pipeline(root, B, local_rank, iters=100, cache_mb=1024)
+                line["e2e_pipeline_decoder_cache"]["note"] = (
+                    "same as e2e_pipeline with decoders.image(cache_size=1024, cache_type='threshold'): epoch >= 2 of a "
+                    "data set whose decoded images fit in HBM.  The files are still read; decoded images are handed to "
+                    "the fused resample kernel in place from the cache blob")
+            finally:
+                shutil.rmtree(root, ignore_errors=True)
+        else:
+            # BASELINE configs[4]: every rank runs the whole pipeline on its shard of the SHARED data set directory
+            # (readers.file(shard_id=rank, num_shards=world)), batch 512 per GPU, host threads split between the
+            # ranks of the node and pinned to their GPU's NUMA node (set_affinity)
+            root = os.path.join(tempfile.gettempdir(), f"dali_amd_bench_shared_{os.environ.get('MASTER_PORT', '0')}")
+            write_dataset(root, enc_all, first_index=rank * per_rank)
+            barrier()
+            threads = max(2, effective_cpu_count() // max(1, local_world))
+            res = e2e_pipeline(root, args.e2e_batch, local_rank, iters=30, threads=threads, shard_id=rank,
+                               num_shards=world, sync=barrier, set_affinity=True)
+            t = torch.tensor([res["elapsed_s"]], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            barrier()
+            if rank == 0:
+                res["elapsed_s_max_over_ranks"] = float(t.item())
+                res["value"] = world * res["batch"] * res["iters"] / float(t.item())
+                res["note"] = ("configs[4]: whole-job images/s of dali_amd.Pipeline on every rank, readers.file(shard_id=rank, "
+                               f"num_shards={world}) over one shared data set of {world * per_rank} files, batch "
+                               f"{res['batch']}/GPU, {threads} host threads per rank, set_affinity=True; barrier + max over ranks")
+                line["e2e_pipeline_sharded"] = res
+                shutil.rmtree(root, ignore_errors=True)
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(enc)
+            line["cpu_baseline"] = cpu_baseline(enc_all[:B])
+            line["cpu_baseline_pillow"] = pillow_baseline(enc_all[:B])
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -132,12 +132,14 @@ class OpSpec:
 
 
 class BackendPipeline:
-    def __init__(self, batch_size, num_threads, device_id, seed, prefetch_queue_depth, exec_async):
+    def __init__(self, batch_size, num_threads, device_id, seed, prefetch_queue_depth, exec_async, set_affinity=False):
         self._lib = _lib()
         self._h = self._lib.daliamdPipelineCreate(batch_size, num_threads, device_id, seed, prefetch_queue_depth,
                                                   1 if exec_async else 0)
         if not self._h:
             check(1)
+        if set_affinity:
+            check(self._lib.daliamdPipelineSetAffinity(C.c_void_p(self._h), 1))
 
     def __del__(self):
         if getattr(self, "_h", None):

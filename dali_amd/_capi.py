@@ -162,7 +162,8 @@ _host = None
 
 _KERNEL_SYMBOLS = [
     "daliamdGetLastErrorMessage", "daliamdClearLastError", "daliamdVersion", "daliamdDeviceCount",
-    "daliamdSetDevice", "daliamdDeviceInfo", "daliamdStreamCreate", "daliamdStreamDestroy",
+    "daliamdSetDevice", "daliamdDeviceInfo", "daliamdDevicePciBusId", "daliamdRangePush", "daliamdRangePop",
+    "daliamdStreamCreate", "daliamdStreamDestroy",
     "daliamdStreamSynchronize", "daliamdStreamWaitEvent", "daliamdEventCreate",
     "daliamdEventDestroy", "daliamdEventRecord", "daliamdEventSynchronize", "daliamdEventQuery", "daliamdEventElapsedMs",
     "daliamdMalloc", "daliamdFree", "daliamdHostAlloc", "daliamdHostFree", "daliamdMemcpyH2DAsync",

@@ -483,6 +483,17 @@ HUFFMAN_KERNELS = ("PrepareKernel", "UnstuffScatterKernel", "SyncKernel",
                    "PropagateKernel", "WriteKernel", "DcScanKernel", "ExpandKernel")
 
 
+def huffman_algorithmic_bytes(stream_bytes, coef_elems, symbols, num_streams, fused):
+    """Algorithmic HBM bytes per launch of each kernel of daliamdJpegHuffmanRun for a batch of
+    `num_streams` streams with `stream_bytes` entropy-coded bytes, `coef_elems` coefficients and `symbols` symbols."""
+    rec = 4 * symbols   # one 32-bit record per symbol
+    return {"PrepareKernel": stream_bytes + 60 * 1024 * num_streams,   # stream read once + 60 KB of code tables per stream
+            "UnstuffScatterKernel": 2 * stream_bytes, "SyncKernel": stream_bytes, "PropagateKernel": 0,
+            "WriteKernel": stream_bytes + rec, "DcScanKernel": 0,
+            # records in; coefficients out, or (fused dequantisation + IDCT) the 8-bit samples
+            "ExpandKernel": rec + (coef_elems if fused else 2 * coef_elems)}
+
+
 class KernelEvents:
     """n+1 timing events of the kernel library (daliamdEvent*) bracketing n consecutive kernels of one launch call."""
 

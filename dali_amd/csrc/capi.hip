@@ -2,6 +2,7 @@
 // These give the C++ host executor what the reference takes from CUDAStreamPool,
 // CUDAEventPool and mm:: resources (include/dali/core/cuda_stream_pool.h,
 // cuda_event_pool.h, mm/) without the host ever including HIP headers.
+#include <dlfcn.h>
 #include <cstring>
 #include "common.h"
 
@@ -16,6 +17,26 @@ void SetLastError(const char *fmt, ...) {
 }
 }  // namespace daliamd
 
+// Profiler ranges (the reference's DomainTimeRange / nvtx ranges, include/dali/core/nvtx.h:53-82) through roctx,
+// resolved at first use so that the library does not depend on the tracer being installed.
+namespace {
+struct Roctx {
+  int (*push)(const char *) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    void *h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return;
+    push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+    pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+    if (!push || !pop) push = nullptr, pop = nullptr;
+  }
+};
+Roctx &GetRoctx() {
+  static Roctx r;
+  return r;
+}
+}  // namespace
 extern "C" {
 
 const char *daliamdGetLastErrorMessage(void) { return daliamd::g_last_error; }
@@ -44,6 +65,21 @@ daliamdResult_t daliamdDeviceInfo(int device_id, char *arch_name, int arch_name_
   if (total_mem) *total_mem = p.totalGlobalMem;
   return DALIAMD_SUCCESS;
 }
+daliamdResult_t daliamdDevicePciBusId(int device_id, char *bus_id, int len) {
+  DALIAMD_REQUIRE(bus_id && len >= 16, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdDevicePciBusId: buffer of >= 16 bytes needed");
+  DALIAMD_HIP_CHECK(hipDeviceGetPCIBusId(bus_id, len, device_id));
+  return DALIAMD_SUCCESS;
+}
+
+void daliamdRangePush(const char *name) {
+  Roctx &r = GetRoctx();
+  if (r.push) r.push(name ? name : "");
+}
+void daliamdRangePop(void) {
+  Roctx &r = GetRoctx();
+  if (r.pop) r.pop();
+}
+
 daliamdResult_t daliamdStreamCreate(daliamdStream_t *stream, int non_blocking) {
   DALIAMD_REQUIRE(stream, DALIAMD_ERROR_INVALID_ARGUMENT, "stream is NULL");
   hipStream_t s;

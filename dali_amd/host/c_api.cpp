@@ -148,6 +148,10 @@ API void *daliamdPipelineCreate(int batch_size, int num_threads, int device_id, 
   });
   return h;
 }
+// before Build(): Pipeline(set_affinity=True) (reference pipeline.py:164)
+API int daliamdPipelineSetAffinity(void *h, int on) {
+  return Guard([&] { static_cast<PipelineHandle *>(h)->pipe->SetAffinity(on != 0); });
+}
 API void daliamdPipelineDestroy(void *h) { delete static_cast<PipelineHandle *>(h); }
 API int64_t daliamdPipelineSeed(void *h) { return static_cast<PipelineHandle *>(h)->pipe->seed(); }
 

@@ -1,7 +1,13 @@
 #include "framework.h"
 
+#include <pthread.h>
+#include <sched.h>
+
 #include <algorithm>
+#include <cctype>
+#include <cstdio>
 #include <cstdlib>
+#include <fstream>
 
 namespace daliamd_host {
 
@@ -140,9 +146,63 @@ void TensorList::ShareData(const TensorList &o) {
 }
 
 // ------------------------------------------------------------------------------------------ ThreadPool
-ThreadPool::ThreadPool(int n) {
+ThreadPool::ThreadPool(int n, const std::vector<int> &cpus) {
   n = std::max(1, n);
-  for (int i = 0; i < n; i++) threads_.emplace_back([this, i] { Loop(i); });
+  for (int i = 0; i < n; i++)
+    threads_.emplace_back([this, i, cpus] {
+      BindThisThread(cpus);
+      Loop(i);
+    });
+}
+
+std::vector<int> ParseCpuList(const std::string &list) {
+  std::vector<int> out;
+  size_t pos = 0;
+  while (pos < list.size()) {
+    size_t end = list.find(',', pos);
+    if (end == std::string::npos) end = list.size();
+    std::string tok = list.substr(pos, end - pos);
+    pos = end + 1;
+    int a = 0, b = 0;
+    if (sscanf(tok.c_str(), "%d-%d", &a, &b) == 2) {
+      for (int c = a; c <= b && c < 4096; c++) out.push_back(c);
+    } else if (sscanf(tok.c_str(), "%d", &a) == 1) {
+      out.push_back(a);
+    }
+  }
+  return out;
+}
+
+void BindThisThread(const std::vector<int> &cpus) {
+  if (cpus.empty()) return;
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  for (int c : cpus)
+    if (c >= 0 && c < CPU_SETSIZE) CPU_SET(c, &set);
+  pthread_setaffinity_np(pthread_self(), sizeof(set), &set);  // best effort
+}
+
+std::vector<int> DeviceLocalCpus(int device_id) {
+  std::vector<int> local;
+  if (const char *env = getenv("DALI_AFFINITY_MASK")) {
+    local = ParseCpuList(env);
+  } else {
+    char bus[64] = "";
+    if (daliamdDevicePciBusId(device_id, bus, sizeof(bus)) != DALIAMD_SUCCESS) return {};
+    std::string id = bus;
+    for (auto &ch : id) ch = (char)tolower(ch);
+    std::ifstream f("/sys/bus/pci/devices/" + id + "/local_cpulist");
+    std::string line;
+    if (!f || !std::getline(f, line)) return {};
+    local = ParseCpuList(line);
+  }
+  cpu_set_t allowed;
+  CPU_ZERO(&allowed);
+  if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return {};
+  std::vector<int> out;
+  for (int c : local)
+    if (c >= 0 && c < CPU_SETSIZE && CPU_ISSET(c, &allowed)) out.push_back(c);
+  return out;
 }
 ThreadPool::~ThreadPool() {
   {

@@ -160,7 +160,9 @@ class TensorList {
 // ---------------------------------------------------------------------------------------------
 class ThreadPool {
  public:
-  explicit ThreadPool(int num_threads);
+  // cpus: when not empty, every worker is bound to this CPU set (Pipeline(set_affinity=True): the cores local to the
+  // GPU's NUMA node; the reference binds through NVML, dali/pipeline/util/thread_pool.cc)
+  explicit ThreadPool(int num_threads, const std::vector<int> &cpus = {});
   ~ThreadPool();
   using Work = std::function<void(int)>;
   void AddWork(Work w, int64_t priority = 0);
@@ -181,6 +183,14 @@ class ThreadPool {
   bool stop_ = false;
   std::vector<std::string> errors_;
 };
+
+// CPUs local to a device: /sys/bus/pci/devices/<bus id>/local_cpulist intersected with the CPUs this process may
+// run on (empty when unknown: callers then leave the affinity alone).  DALI_AFFINITY_MASK ("0,1,4-7") overrides,
+// as in the reference.
+std::vector<int> DeviceLocalCpus(int device_id);
+std::vector<int> ParseCpuList(const std::string &list);
+// binds the calling thread to `cpus` (no-op for an empty set)
+void BindThisThread(const std::vector<int> &cpus);
 
 // ---------------------------------------------------------------------------------------------
 // Arguments, OpSchema, OpSpec

@@ -133,8 +133,11 @@ void Pipeline::Build(const std::vector<std::pair<std::string, std::string>> &out
                  "\" is not produced by any operator");
     outputs_.push_back(it->second);
   }
-  thread_pool_ = std::make_unique<ThreadPool>(params_.num_threads);
-  cpu_thread_pool_ = std::make_unique<ThreadPool>(params_.num_threads);
+  // set_affinity: worker threads (and with them the first touch of their pinned staging buffers) stay on the
+  // GPU's NUMA node - with 8 GPUs behind two sockets the H2D copies otherwise cross the socket link
+  if (params_.set_affinity && needs_gpu) local_cpus_ = DeviceLocalCpus(params_.device_id);
+  thread_pool_ = std::make_unique<ThreadPool>(params_.num_threads, local_cpus_);
+  cpu_thread_pool_ = std::make_unique<ThreadPool>(params_.num_threads, local_cpus_);
   // instantiate operators (InstantiateOperator, operator.cc:157-169) and their output rings
   for (auto &n : nodes_) {
     try {
@@ -160,8 +163,8 @@ void Pipeline::Build(const std::vector<std::pair<std::string, std::string>> &out
     for (auto &e : slot_events_) KCHECK(daliamdEventCreate(&e, 0));
   built_ = true;
   if (params_.exec_async) {
-    cpu_worker_ = std::thread([this] { CpuWorkerLoop(); });
-    worker_ = std::thread([this] { DeviceWorkerLoop(); });
+    cpu_worker_ = std::thread([this] { BindThisThread(local_cpus_); CpuWorkerLoop(); });
+    worker_ = std::thread([this] { BindThisThread(local_cpus_); DeviceWorkerLoop(); });
   }
 }
 
@@ -183,6 +186,11 @@ void Pipeline::RunStage(bool device_stage, int64_t it, int slot, Iteration &res)
     std::lock_guard<std::mutex> g(launches_m_);
     cur_launches_.clear();
   }
+  struct Range {  // profiler range (roctx), closed on every exit path
+    explicit Range(const std::string &n) { daliamdRangePush(n.c_str()); }
+    ~Range() { daliamdRangePop(); }
+  };
+  Range stage_range(device_stage ? "dali_amd device stage" : "dali_amd host stage");
   try {
     if (res.failed) throw std::runtime_error(res.error);  // the host stage already failed: nothing to enqueue
     if (!streams_.empty() && device_stage) KCHECK(daliamdSetDevice(params_.device_id));
@@ -217,6 +225,7 @@ void Pipeline::RunStage(bool device_stage, int64_t it, int slot, Iteration &res)
       for (auto &a : n.arg_in) ws.argument_inputs[a.first] = nodes_[a.second.first].out_ring[a.second.second][slot];
       for (auto &r : n.out_ring) ws.outputs.push_back(r[slot]);
       auto t_node = std::chrono::steady_clock::now();
+      Range op_range(n.name);
       try {
         std::vector<OutputDesc> desc(ws.outputs.size());
         if (n.op->SetupImpl(desc, ws)) {

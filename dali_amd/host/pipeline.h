@@ -25,6 +25,7 @@ struct PipelineParams {
   int64_t seed = -1;  // < 0: derived from the clock
   int prefetch_queue_depth = 2;
   bool exec_async = true;
+  bool set_affinity = false;  // bind worker threads to the CPUs local to the device (pipeline.py:164)
 };
 
 class Pipeline {
@@ -55,6 +56,7 @@ class Pipeline {
 
   const PipelineParams &params() const { return params_; }
   int64_t seed() const { return original_seed_; }
+  void SetAffinity(bool on) { params_.set_affinity = on; }  // before Build()
   daliamdStream_t stream() const { return streams_.empty() ? nullptr : streams_[0]; }
   int ring() const { return ring_; }
 
@@ -108,6 +110,7 @@ class Pipeline {
 
   // scheduling
   std::thread worker_, cpu_worker_;
+  std::vector<int> local_cpus_;  // set_affinity: CPUs of the device's NUMA node (empty: unbound)
   std::mutex m_;
   std::condition_variable cv_req_, cv_res_, cv_mid_, cv_dev_done_;
   std::deque<int64_t> requests_;

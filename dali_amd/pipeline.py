@@ -16,7 +16,8 @@ _tls = threading.local()
 
 class Pipeline:
     """See nvidia.dali.Pipeline.  Supported arguments: batch_size, num_threads, device_id, seed,
-    prefetch_queue_depth, exec_pipelined/exec_async (async execution = the prefetching worker thread);
+    prefetch_queue_depth, exec_pipelined/exec_async (async execution = the prefetching worker thread), set_affinity
+    (worker threads bound to the CPUs of the GPU's NUMA node; DALI_AFFINITY_MASK overrides the set);
     the remaining reference arguments are accepted and ignored."""
 
     def __init__(self, batch_size=-1, num_threads=-1, device_id=-1, seed=-1, exec_pipelined=True,
@@ -35,6 +36,7 @@ class Pipeline:
             prefetch_queue_depth = max(prefetch_queue_depth.get("cpu_size", 2), prefetch_queue_depth.get("gpu_size", 2))
         self._prefetch_queue_depth = int(prefetch_queue_depth) if exec_pipelined else 1
         self._exec_async = bool(exec_async and exec_pipelined)
+        self._set_affinity = bool(set_affinity)
         self._enable_checkpointing = enable_checkpointing
         self._restore_from = checkpoint
         self._ops = []          # (schema_name, instance_name, device, init_args, inputs, arg_inputs, outputs)
@@ -137,7 +139,7 @@ class Pipeline:
                 outs = self.define_graph()
             self.set_outputs(*(outs if isinstance(outs, (list, tuple)) else [outs]))
         be = _b.BackendPipeline(self._max_batch_size, self._num_threads, self._device_id, self._seed,
-                                self._prefetch_queue_depth, self._exec_async)
+                                self._prefetch_queue_depth, self._exec_async, self._set_affinity)
         for schema_name, inst, device, init_args, inputs, arg_inputs, outs in self._ops:
             spec = _b.OpSpec(schema_name)
             spec.add_arg("device", device)

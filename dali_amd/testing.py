@@ -1,0 +1,81 @@
+"""Seeded synthetic inputs for tests and benchmarks: ImageNet-like images / JPEG streams (SURVEY.md section 8(d):
+sizes from {500x375, 375x500, 640x480, 333x500, 500x500, 256x384, 1024x768 (5 %)}, multi-octave value noise +
+linear gradients, quality 90 for 20 % / 75 for 80 %, 4:2:0 85 % / 4:4:4 10 % / grayscale 5 %, baseline Huffman).
+Needs numpy + Pillow only (no torch, no GPU), so data sets can be generated in forked worker processes before the
+device is initialised."""
+import io
+
+import numpy as np
+from PIL import Image
+
+
+def synth_image(rng, h, w, c=3, octaves=6, decay=0.85, noise=3.0):
+    """1/f-like multi-octave value noise + linear gradients + sensor noise: compresses like a natural
+    photograph (about 100 KB at ImageNet sizes with the q75/q90 mix of synth_jpeg_batch)."""
+    acc = np.zeros((h, w, c), np.float32)
+    for o in range(octaves):
+        gh, gw = max(2, (h >> (octaves - 1 - o)) + 1), max(2, (w >> (octaves - 1 - o)) + 1)
+        base = rng.integers(0, 256, (gh, gw, c)).astype(np.uint8)
+        planes = [np.asarray(Image.fromarray(base[:, :, k]).resize((w, h), Image.BILINEAR), np.float32)
+                  for k in range(c)]
+        acc += (np.stack(planes, -1) - 128.0) * (decay ** o)
+    acc = acc / np.sqrt((decay ** (2 * np.arange(octaves))).sum()) * 1.6 + 128.0
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    for _ in range(2):
+        a, b = rng.uniform(-0.2, 0.2, 2)
+        acc += (a * xx + b * yy)[:, :, None]
+    acc += rng.normal(0, noise, acc.shape)
+    img = np.clip(acc, 0, 255).astype(np.uint8)
+    return img if c > 1 else img[:, :, 0]
+
+
+def encode_jpeg(img, quality=85, subsampling="4:2:0", **kw):
+    b = io.BytesIO()
+    im = Image.fromarray(img)
+    if im.mode == "L":
+        im.save(b, "JPEG", quality=quality, **kw)
+    else:
+        im.save(b, "JPEG", quality=quality, subsampling=subsampling, **kw)
+    return b.getvalue()
+
+
+IMAGENET_LIKE_SIZES = [(375, 500), (500, 375), (480, 640), (500, 333), (500, 500), (384, 256), (768, 1024)]
+
+
+def synth_jpeg_batch(rng, n, sizes=None, gray_frac=0.05):
+    """n encoded streams drawn like SURVEY.md section 8(d): 80 % q75 / 20 % q90; 85 % 4:2:0, 10 % 4:4:4,
+    5 % grayscale; sizes ImageNet-like."""
+    sizes = sizes or IMAGENET_LIKE_SIZES
+    out = []
+    for _ in range(n):
+        if sizes is IMAGENET_LIKE_SIZES:
+            k = 6 if rng.random() < 0.05 else rng.integers(0, 6)
+        else:
+            k = rng.integers(0, len(sizes))
+        h, w = sizes[k]
+        q = 90 if rng.random() < 0.2 else 75
+        r = rng.random()
+        if r < gray_frac:
+            out.append(encode_jpeg(synth_image(rng, h, w, 1), q))
+        elif r < gray_frac + 0.10:
+            out.append(encode_jpeg(synth_image(rng, h, w), q, "4:4:4"))
+        else:
+            out.append(encode_jpeg(synth_image(rng, h, w), q, "4:2:0"))
+    return out
+
+
+def synth_dataset_image(index, seed=1234):
+    """Image `index` of the synthetic data set: depends only on (seed, index), so every rank of a sharded run
+    generates exactly its own shard and all ranks agree on the whole set."""
+    return synth_jpeg_batch(np.random.default_rng([seed, int(index)]), 1)[0]
+
+
+def synth_dataset(first_index, count, seed=1234, workers=0):
+    """Encoded JPEGs [first_index, first_index + count) of the synthetic data set; `workers` > 1 forks that many
+    generator processes (call before the GPU runtime is initialised in this process)."""
+    idx = range(int(first_index), int(first_index) + int(count))
+    if workers and workers > 1 and count >= 2 * workers:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(workers) as pool:
+            return pool.map(synth_dataset_image, idx, chunksize=max(1, count // (4 * workers)))
+    return [synth_dataset_image(i, seed) for i in idx]

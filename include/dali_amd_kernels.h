@@ -54,6 +54,14 @@ DALIAMD_API daliamdResult_t daliamdDeviceCount(int *count);
 DALIAMD_API daliamdResult_t daliamdSetDevice(int device_id);
 DALIAMD_API daliamdResult_t daliamdDeviceInfo(int device_id, char *arch_name, int arch_name_len,
                                               int *num_cus, size_t *total_mem);
+/* PCI bus id "dddd:bb:dd.f" of the device (>= 16 bytes): the host executor derives the device's NUMA-local CPUs from
+ * /sys/bus/pci/devices/<id>/local_cpulist for Pipeline(set_affinity=True) (the reference asks NVML:
+ * dali/util/nvml.h, pipeline.py:164). */
+DALIAMD_API daliamdResult_t daliamdDevicePciBusId(int device_id, char *bus_id, int len);
+/* Profiler ranges around the executor's stages and operators (reference: include/dali/core/nvtx.h:53-82); roctx is
+ * resolved at first use, both calls do nothing when it is not installed. */
+DALIAMD_API void daliamdRangePush(const char *name);
+DALIAMD_API void daliamdRangePop(void);
 DALIAMD_API daliamdResult_t daliamdStreamCreate(daliamdStream_t *stream, int non_blocking);
 DALIAMD_API daliamdResult_t daliamdStreamDestroy(daliamdStream_t stream);
 DALIAMD_API daliamdResult_t daliamdStreamSynchronize(daliamdStream_t stream);

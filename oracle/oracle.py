@@ -119,6 +119,22 @@ def resample_u8(img, out_hw, roi=None, min_filter=FILTER_LINEAR, mag_filter=FILT
     return (out, info) if return_info else out
 
 
+def resample_f32(img, out_hw, roi=None, min_filter=FILTER_LINEAR, mag_filter=FILTER_LINEAR, antialias=True):
+    """Same as resample_u8 with the float result of the second pass (fn.resize(dtype=FLOAT))."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    if img.ndim == 2:
+        img = img[:, :, None]
+    H, W, Cn = img.shape
+    oh, ow = int(out_hw[0]), int(out_hw[1])
+    out = np.zeros((oh, ow, Cn), np.float32)
+    r = np.asarray(roi if roi is not None else (0, 0, 0, 0), dtype=np.float32)
+    rc = lib().orc_resample_u8_to_f32(_p(img, C.c_uint8), H, W, Cn, 1 if roi is not None else 0, _p(r, C.c_float), oh, ow,
+                                      min_filter, mag_filter, 1 if antialias else 0, _p(out, C.c_float))
+    if rc:
+        raise RuntimeError(f"orc_resample_u8_to_f32 failed: {rc}")
+    return out
+
+
 def triangular_support(radius):
     return lib().orc_triangular_support(C.c_float(radius))
 

@@ -230,9 +230,10 @@ static void setup_sample(orc_resample_setup *s, int H, int W, int use_roi, const
  *             1 = half-away everywhere, 2 = half-even everywhere
  * Returns 0 on success.
  */
-int orc_resample_u8(const uint8_t *in, int H, int W, int C, int use_roi, const float *roi,
-                    int outH, int outW, int min_filter, int mag_filter, int antialias,
-                    int round_mode, uint8_t *out, float *tmp_out /* optional */, int *info) {
+static int resample_impl(const uint8_t *in, int H, int W, int C, int use_roi, const float *roi,
+                         int outH, int outW, int min_filter, int mag_filter, int antialias,
+                         int round_mode, uint8_t *out, float *out_f32 /* optional: unrounded result */,
+                         float *tmp_out /* optional */, int *info) {
   if (H <= 0 || W <= 0 || outH <= 0 || outW <= 0 || C <= 0) return 1;
   orc_resample_setup s;
   setup_sample(&s, H, W, use_roi, roi, outH, outW, min_filter, mag_filter, antialias);
@@ -260,7 +261,7 @@ int orc_resample_u8(const uint8_t *in, int H, int W, int C, int use_roi, const f
     info[0] = first; info[1] = second; info[2] = s.support[0]; info[3] = s.support[1];
     info[4] = tmp_w; info[5] = tmp_h; info[6] = s.roi_lo[0]; info[7] = s.roi_lo[1];
   }
-  if (tmp_w <= 0 || tmp_h <= 0) { memset(out, 0, (size_t)outH * outW * C); return 0; }
+  if (tmp_w <= 0 || tmp_h <= 0) { if (out) memset(out, 0, (size_t)outH * outW * C); return 0; }
 
   float *tmp = (float *)malloc(sizeof(float) * (size_t)tmp_w * tmp_h * C);
   int max_out = outW > outH ? outW : outH;
@@ -316,7 +317,7 @@ int orc_resample_u8(const uint8_t *in, int H, int W, int C, int use_roi, const f
       horz_regions(outW, tmp_w, idx, sup, 16, mask);
       for (int y = 0; y < outH; y++) {
         const float *row = tmp + (size_t)y * tmp_w * C;
-        uint8_t *orow = out + (size_t)y * outW * C;
+        uint8_t *orow = out ? out + (size_t)y * outW * C : NULL;
         for (int x = 0; x < outW; x++) {
           int x0 = idx[x];
           int even = round_mode == 2 || (round_mode == 0 && mask[x]);
@@ -326,14 +327,15 @@ int orc_resample_u8(const uint8_t *in, int H, int W, int C, int use_roi, const f
               int sx = clampi(x0 + k, 0, tmp_w - 1);
               acc += coef[x * sup + k] * row[sx * C + c];
             }
-            orow[x * C + c] = even ? sat_u8_half_even(acc) : sat_u8_half_away(acc);
+            if (out_f32) out_f32[((size_t)y * outW + x) * C + c] = acc;
+            if (out) orow[x * C + c] = even ? sat_u8_half_even(acc) : sat_u8_half_away(acc);
           }
         }
       }
     } else { /* vertical over tmp cols (tmp_w == outW) */
       int flat_w = outW * C;
       for (int y = 0; y < outH; y++) {
-        uint8_t *orow = out + (size_t)y * outW * C;
+        uint8_t *orow = out ? out + (size_t)y * outW * C : NULL;
         for (int x0 = 0; x0 < flat_w; x0 += 256) { /* ResampleVert tile, resampling_impl_cpu.h:362-390 */
           int end = x0 + 256 <= flat_w ? x0 + 256 : flat_w;
           int i = x0;
@@ -345,7 +347,8 @@ int orc_resample_u8(const uint8_t *in, int H, int W, int C, int use_roi, const f
               acc += tmp[(size_t)sy * tmp_w * C + i] * coef[y * sup + k];
             }
             int even = round_mode == 2 || (round_mode == 0 && i < simd_end);
-            orow[i] = even ? sat_u8_half_even(acc) : sat_u8_half_away(acc);
+            if (out_f32) out_f32[(size_t)y * outW * C + i] = acc;
+            if (out) orow[i] = even ? sat_u8_half_even(acc) : sat_u8_half_away(acc);
           }
         }
       }
@@ -353,6 +356,21 @@ int orc_resample_u8(const uint8_t *in, int H, int W, int C, int use_roi, const f
   }
   free(tmp); free(idx); free(coef); free(mask);
   return 0;
+}
+
+int orc_resample_u8(const uint8_t *in, int H, int W, int C, int use_roi, const float *roi,
+                    int outH, int outW, int min_filter, int mag_filter, int antialias,
+                    int round_mode, uint8_t *out, float *tmp_out /* optional */, int *info) {
+  return resample_impl(in, H, W, C, use_roi, roi, outH, outW, min_filter, mag_filter, antialias, round_mode, out, NULL,
+                       tmp_out, info);
+}
+
+/* Same resampling with the float result of the second pass returned as it is (fn.resize(dtype=FLOAT):
+ * the final ConvertSat<float> is the identity).  out: float [outH][outW][C]. */
+int orc_resample_u8_to_f32(const uint8_t *in, int H, int W, int C, int use_roi, const float *roi,
+                           int outH, int outW, int min_filter, int mag_filter, int antialias, float *out) {
+  return resample_impl(in, H, W, C, use_roi, roi, outH, outW, min_filter, mag_filter, antialias, 0, NULL, out, NULL,
+                       NULL);
 }
 
 /* Known-answer helpers mirroring resampling_impl_cpu_test.cc:27-90 */

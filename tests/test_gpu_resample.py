@@ -122,3 +122,20 @@ def test_fused_rrc_cmn_matches_oracle_composition(dtype, layout):
                               ref.view(np.uint16 if dtype == "float16" else np.uint32)), f"sample {i}"
         # and the u8 intermediate obeys the resampling tolerance
         _check(u8[i], O.resample_u8(im, (224, 224), roi=rois[i]), f"u8 sample {i}")
+
+
+def test_checkerboard_vs_onnx_reference_on_the_gpu():
+    """The reference's golden pin (test_resize.py:919-1029, atol 1) through the HIP kernel: 22 x 22 checkerboard ->
+    17 x 13, antialiased linear (the kernel's triangular filter), against the ONNX reference restated in
+    tests/onnx_resize_ref.py - independent of the oracle."""
+    from dali_amd import backend as B
+    from tests import onnx_resize_ref as R
+    board = R.checkerboard_22_22()
+    ref = R.interpolate_nd(board, R.linear_coeffs_antialias, (17, 13))
+    img = np.repeat(board[:, :, None], 3, axis=2)
+    out = B.resample_batch([_to_dev(img)], (17, 13))
+    torch.cuda.synchronize()
+    got = out[0].cpu().numpy().astype(np.float64)
+    for c in range(3):
+        assert np.abs(got[:, :, c] - ref).max() <= 1.0, c
+    assert np.array_equal(out[0].cpu().numpy(), O.resample_u8(img, (17, 13)))

@@ -119,3 +119,23 @@ def test_gradient_image_recovers_roi():
     y0, y1 = out[2, 112, 1] * (H - 1) / 255, out[-3, 112, 1] * (H - 1) / 255
     assert abs(x0 - (roi[1] + 2.5 * 240 / 224)) < 3 and abs(x1 - (roi[3] - 2.5 * 240 / 224)) < 3
     assert abs(y0 - (roi[0] + 2.5 * 180 / 224)) < 3 and abs(y1 - (roi[2] - 2.5 * 180 / 224)) < 3
+
+
+@pytest.mark.parametrize("antialias", [False, True])
+def test_checkerboard_vs_onnx_reference(antialias):
+    """The reference's golden pin for the linear filters (test_resize.py:919-1029): the 22 x 22 checkerboard resized to
+    17 x 13 must be within atol 1 of the ONNX reference implementation (regenerated by tests/onnx_resize_ref.py; the
+    golden .npy files themselves live in DALI_extra).  Compared on the FLOAT output like the reference test, so the
+    oracle's u8 rounding model plays no part."""
+    from tests import onnx_resize_ref as R
+    board = R.checkerboard_22_22()
+    ref = R.interpolate_nd(board, R.linear_coeffs_antialias if antialias else (lambda x, _: R.linear_coeffs(x)), (17, 13))
+    got = O.resample_f32(board, (17, 13), antialias=antialias)[:, :, 0]
+    assert got.shape == (17, 13)
+    np.testing.assert_allclose(got, ref, atol=1)
+    # the filters are the same continuous kernels: the agreement is in fact at float accuracy
+    assert np.abs(got - ref).max() < 2e-3
+    # and the rounded u8 result is the rounded reference wherever that is not a tie
+    u8 = O.resample_u8(board, (17, 13), antialias=antialias)[:, :, 0]
+    clear = np.abs(ref - np.floor(ref) - 0.5) > 1e-2
+    assert np.array_equal(u8[clear], np.floor(ref + 0.5).astype(np.uint8)[clear])

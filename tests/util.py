@@ -1,60 +1,4 @@
-"""Shared helpers for the test-suite: seeded synthetic images / JPEG streams."""
-import io
-
-import numpy as np
-from PIL import Image
-
-
-def synth_image(rng, h, w, c=3, octaves=6, decay=0.85, noise=3.0):
-    """1/f-like multi-octave value noise + linear gradients + sensor noise: compresses like a natural
-    photograph (about 100 KB at ImageNet sizes with the q75/q90 mix of synth_jpeg_batch)."""
-    acc = np.zeros((h, w, c), np.float32)
-    for o in range(octaves):
-        gh, gw = max(2, (h >> (octaves - 1 - o)) + 1), max(2, (w >> (octaves - 1 - o)) + 1)
-        base = rng.integers(0, 256, (gh, gw, c)).astype(np.uint8)
-        planes = [np.asarray(Image.fromarray(base[:, :, k]).resize((w, h), Image.BILINEAR), np.float32)
-                  for k in range(c)]
-        acc += (np.stack(planes, -1) - 128.0) * (decay ** o)
-    acc = acc / np.sqrt((decay ** (2 * np.arange(octaves))).sum()) * 1.6 + 128.0
-    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
-    for _ in range(2):
-        a, b = rng.uniform(-0.2, 0.2, 2)
-        acc += (a * xx + b * yy)[:, :, None]
-    acc += rng.normal(0, noise, acc.shape)
-    img = np.clip(acc, 0, 255).astype(np.uint8)
-    return img if c > 1 else img[:, :, 0]
-
-
-def encode_jpeg(img, quality=85, subsampling="4:2:0", **kw):
-    b = io.BytesIO()
-    im = Image.fromarray(img)
-    if im.mode == "L":
-        im.save(b, "JPEG", quality=quality, **kw)
-    else:
-        im.save(b, "JPEG", quality=quality, subsampling=subsampling, **kw)
-    return b.getvalue()
-
-
-IMAGENET_LIKE_SIZES = [(375, 500), (500, 375), (480, 640), (500, 333), (500, 500), (384, 256), (768, 1024)]
-
-
-def synth_jpeg_batch(rng, n, sizes=None, gray_frac=0.05):
-    """n encoded streams drawn like SURVEY.md section 8(d): 80 % q75 / 20 % q90; 85 % 4:2:0, 10 % 4:4:4,
-    5 % grayscale; sizes ImageNet-like."""
-    sizes = sizes or IMAGENET_LIKE_SIZES
-    out = []
-    for _ in range(n):
-        if sizes is IMAGENET_LIKE_SIZES:
-            k = 6 if rng.random() < 0.05 else rng.integers(0, 6)
-        else:
-            k = rng.integers(0, len(sizes))
-        h, w = sizes[k]
-        q = 90 if rng.random() < 0.2 else 75
-        r = rng.random()
-        if r < gray_frac:
-            out.append(encode_jpeg(synth_image(rng, h, w, 1), q))
-        elif r < gray_frac + 0.10:
-            out.append(encode_jpeg(synth_image(rng, h, w), q, "4:4:4"))
-        else:
-            out.append(encode_jpeg(synth_image(rng, h, w), q, "4:2:0"))
-    return out
+"""Shared helpers for the test-suite: seeded synthetic images / JPEG streams (they live in dali_amd/testing.py so
+that bench.py does not depend on the test package)."""
+from dali_amd.testing import (IMAGENET_LIKE_SIZES, encode_jpeg, synth_dataset, synth_dataset_image,  # noqa: F401
+                              synth_image, synth_jpeg_batch)
