@@ -118,6 +118,7 @@ class HotPath:
             self.plan.check_gpu_status(status)
             if not torch.equal(self.coef.cpu(), self.coef_host):
                 raise SystemExit("bench: GPU Huffman output differs from the host entropy decoder")
+            self.symbols = B.count_huffman_symbols(self.coef, self.plan.coef_elems)   # exact, for the symbol rate
             if self.fused_idct:   # ... and its fused dequantisation + IDCT the stand-alone IDCT kernel's planes
                 ref_planes = torch.zeros(self.plan.plane_bytes, dtype=torch.uint8, device=device)
                 got_planes = torch.zeros_like(ref_planes)
@@ -254,7 +255,7 @@ def pillow_baseline(enc, seconds_budget=20.0):
                 break
     from PIL import features
     return {"value": done / el, "unit": "images/s", "cores": cores, "kind": "pillow",
-            "libjpeg_turbo": features.version("jpg"),
+            "libjpeg_turbo": features.version("libjpeg_turbo") or features.version("jpg"),
             "sample": f"{done} images = {it} pass(es) over the first {len(enc)}-image batch; Pillow decode + resize(box, "
                       f"BILINEAR) + numpy CMN, ThreadPoolExecutor({cores}), {el:.2f} s wall"}
 
@@ -270,7 +271,7 @@ def write_dataset(root, enc, first_index=0):
             f.write(e)
 
 
-def e2e_pipeline(root, batch, device_id, iters=40, threads=None, roi_decode=False, cache_mb=0, shard_id=0, num_shards=1,
+def e2e_pipeline(root, batch, device_id, iters=200, threads=None, roi_decode=False, cache_mb=0, shard_id=0, num_shards=1,
                  depth=4, sync=None, set_affinity=False):
     """The same hot path through the product's DALI-style pipeline (C++ host framework): readers.file (page cache)
     -> decoders.image(mixed: header parse + scan analysis on the host thread pool, H2D of the entropy-coded
@@ -298,7 +299,9 @@ def e2e_pipeline(root, batch, device_id, iters=40, threads=None, roi_decode=Fals
                                        mirror=fn.random.coin_flip(probability=0.5))
         pipe.set_outputs(out, labels)
     pipe.build()
-    for _ in range(2 * depth + 2):   # every ring slot allocates its pinned / device buffers on first use
+    # every ring slot allocates its pinned / device buffers on first use and grows them until it has seen the largest
+    # batch of the data set: (ring slots) x (distinct batches) iterations before the clock starts
+    for _ in range(max(24, (depth + 1) * 5)):
         pipe.run()
     if sync:
         sync()
@@ -533,9 +536,9 @@ def main():
         # per-kernel durations of the entropy decoder (events recorded between its launches, same stream)
         per = np.array([ke.elapsed_ms() for ke in kev]).mean(0)
         sb, ce = stream_bytes, mean_of(lambda hp: hp.plan.coef_elems)
-        symbols = float(np.mean([hp.plan.huffman_symbol_count(hp.ws) for hp in paths]))
+        symbols = float(np.mean([hp.symbols for hp in paths]))
         from dali_amd.backend import HUFFMAN_KERNELS, huffman_algorithmic_bytes
-        huff_bytes = huffman_algorithmic_bytes(sb, ce, symbols, B, fused)
+        huff_bytes = huffman_algorithmic_bytes(sb, ce, B, fused)
         for name, ms in zip(HUFFMAN_KERNELS, per):
             kern[name] = (huff_bytes[name], float(ms))
         huffman_total_ms = float(np.mean([e[5].elapsed_time(e[6]) for e in ev]))
@@ -550,7 +553,8 @@ def main():
         step_bytes = float(sum(v[0] for v in kern.values()))
         copy_ceiling = measured_copy_ceiling(device)
         # SURVEY.md 8(d) end-to-end formula: 6 P (coefficients in, RGB out) + 3 s P + 6 O (fused resample + CMN)
-        post_entropy = 2 * bytes_idct + float(np.mean(resample_bytes))
+        post_entropy = (2 * mean_of(lambda hp: hp.plan.coef_elems) + 3 * mean_of(lambda hp: hp.pixels) +
+                        float(np.mean(resample_bytes)))
         nk = len(HUFFMAN_KERNELS) if args.huffman == "gpu" else 0
         line = {
             "metric": "images/sec JPEG->RRC->CMN 224^2 b256 per GPU",
@@ -613,7 +617,7 @@ def main():
                 line["e2e_pipeline_roi_decode"] = e2e_pipeline(root, B, local_rank, roi_decode=True)
                 line["e2e_pipeline_roi_decode"]["note"] = ("same, with decoders.image_random_crop -> resize -> "
                                                            "crop_mirror_normalize: only the crop window is decoded")
-                line["e2e_pipeline_decoder_cache"] = e2e_pipeline(root, B, local_rank, iters=100, cache_mb=1024)
+                line["e2e_pipeline_decoder_cache"] = e2e_pipeline(root, B, local_rank, iters=300, cache_mb=1024)
                 line["e2e_pipeline_decoder_cache"]["note"] = (
                     "same as e2e_pipeline with decoders.image(cache_size=1024, cache_type='threshold'): epoch >= 2 of a "
                     "data set whose decoded images fit in HBM.  The files are still read; decoded images are handed to "
@@ -628,7 +632,7 @@ def main():
             write_dataset(root, enc_all, first_index=rank * per_rank)
             barrier()
             threads = max(2, effective_cpu_count() // max(1, local_world))
-            res = e2e_pipeline(root, args.e2e_batch, local_rank, iters=30, threads=threads, shard_id=rank,
+            res = e2e_pipeline(root, args.e2e_batch, local_rank, iters=100, threads=threads, shard_id=rank,
                                num_shards=world, sync=barrier, set_affinity=True)
             t = torch.tensor([res["elapsed_s"]], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -331,15 +331,15 @@ class JpegBatchPlan:
         self._huff_keep += keep
         return status, sel
 
-    def huffman_symbol_count(self, ws=None):
-        """Number of Huffman symbols (= 32-bit records) the last GPU entropy decode of this batch produced; read from the
-        per-stream scratch headers (int32 [1], jpeg_huffman.hip MakeLayout).  Synchronises."""
+    def huffman_block_starts(self, ws=None):
+        """Block starts the last GPU entropy decode of this batch found per stream (int32 [2] of the per-stream scratch
+        headers, jpeg_huffman.hip MakeLayout): blocks + 1 for a complete stream.  Synchronises."""
         ws = ws or self._huff_ws
         if not len(self._huff_sel):
-            return 0
+            return np.zeros(0, np.int64)
         words = ws["scratch"].view(torch.int32)
-        idx = torch.as_tensor(self._scratch_off // 4 + 1, device=words.device)
-        return int(words[idx].to(torch.int64).sum().item())
+        idx = torch.as_tensor(self._scratch_off // 4 + 2, device=words.device)
+        return words[idx].cpu().numpy().astype(np.int64)
 
     def check_gpu_status(self, status):
         """Raises for GPU-decoded streams whose entropy-coded segment was short of blocks (corrupt / truncated)."""
@@ -479,19 +479,40 @@ def _fill4(dst, src):
         dst[i] = float(src[i]) if i < len(src) else (float(src[-1]) if len(src) == 1 else 0.0)
 
 
-HUFFMAN_KERNELS = ("PrepareKernel", "UnstuffScatterKernel", "SyncKernel",
-                   "PropagateKernel", "WriteKernel", "DcScanKernel", "ExpandKernel")
+HUFFMAN_KERNELS = ("PrepareKernel", "UnstuffScatterKernel", "SyncKernel", "PropagateKernel", "DcKernel", "BlockKernel")
 
 
-def huffman_algorithmic_bytes(stream_bytes, coef_elems, symbols, num_streams, fused):
+def huffman_algorithmic_bytes(stream_bytes, coef_elems, num_streams, fused):
     """Algorithmic HBM bytes per launch of each kernel of daliamdJpegHuffmanRun for a batch of
-    `num_streams` streams with `stream_bytes` entropy-coded bytes, `coef_elems` coefficients and `symbols` symbols."""
-    rec = 4 * symbols   # one 32-bit record per symbol
+    `num_streams` streams with `stream_bytes` entropy-coded bytes and `coef_elems` coefficients (64 per block)."""
+    blocks = coef_elems / 64
     return {"PrepareKernel": stream_bytes + 60 * 1024 * num_streams,   # stream read once + 60 KB of code tables per stream
-            "UnstuffScatterKernel": 2 * stream_bytes, "SyncKernel": stream_bytes, "PropagateKernel": 0,
-            "WriteKernel": stream_bytes + rec, "DcScanKernel": 0,
-            # records in; coefficients out, or (fused dequantisation + IDCT) the 8-bit samples
-            "ExpandKernel": rec + (coef_elems if fused else 2 * coef_elems)}
+            "UnstuffScatterKernel": 2 * stream_bytes,
+            "SyncKernel": stream_bytes + 4 * blocks,       # + the block starts out
+            "PropagateKernel": 0,
+            "DcKernel": (4 + 10) * blocks,                  # start in; position, level and segment of the block out
+            # stream + per-block position / level in; 8-bit samples (fused dequantisation + IDCT) or coefficients out
+            "BlockKernel": stream_bytes + 10 * blocks + (coef_elems if fused else 2 * coef_elems)}
+
+
+def count_huffman_symbols(coef, coef_elems):
+    """Huffman symbols of a batch from its decoded coefficients (int16 tensor, 64 per block, column-major blocks): per
+    block the DC symbol, one symbol per non-zero AC coefficient, a ZRL per full run of 16 zeros in front of one, and the
+    end-of-block unless the last coefficient of the scan is non-zero.  Exact; runs where the tensor lives."""
+    a = torch.as_tensor(coef)[:coef_elems].reshape(-1, 64)
+    scan = torch.tensor([0, 8, 1, 2, 9, 16, 24, 17, 10, 3, 4, 11, 18, 25, 32, 40, 33, 26, 19, 12, 5, 6, 13, 20, 27, 34, 41,
+                         48, 56, 49, 42, 35, 28, 21, 14, 7, 15, 22, 29, 36, 43, 50, 57, 58, 51, 44, 37, 30, 23, 31, 38, 45,
+                         52, 59, 60, 53, 46, 39, 47, 54, 61, 62, 55, 63], device=a.device)   # column-major block -> scan order
+    pos = torch.arange(1, 64, device=a.device, dtype=torch.int32)[None, :]
+    total = 0
+    for lo in range(0, a.shape[0], 1 << 17):
+        nz = a[lo:lo + (1 << 17)][:, scan][:, 1:] != 0
+        total += nz.shape[0] + int(nz.sum()) + int((~nz[:, -1]).sum())
+        idx = torch.where(nz, pos, torch.zeros_like(pos))
+        prev = torch.cummax(idx, dim=1).values
+        prev = torch.cat([torch.zeros_like(prev[:, :1]), prev[:, :-1]], dim=1)   # scan index of the previous non-zero
+        total += int(torch.where(nz, (pos - prev - 1) // 16, torch.zeros_like(pos)).sum())
+    return total
 
 
 class KernelEvents:

@@ -1,0 +1,312 @@
+// Per-lane core of the GPU Huffman entropy decoder (jpeg_huffman.hip), written so that the SAME code compiles for the
+// device and for the host: tools/huff_model.cpp replays the whole pipeline (tables, synchronisation with block-start
+// lists, DC pass, block decode) lane by lane on the CPU and is checked against the host entropy decoder in the CPU
+// test-suite, so the logic of the kernels is exercised without a GPU.  Everything that needs the machine (LDS
+// staging, wave shuffles, barriers, the IDCT) stays in jpeg_huffman.hip.
+#ifndef DALI_AMD_CSRC_HUFF_CORE_H_
+#define DALI_AMD_CSRC_HUFF_CORE_H_
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define HUFF_HD __host__ __device__ __forceinline__
+#else
+#define HUFF_HD inline
+#endif
+
+namespace daliamd {
+
+constexpr int kFastBits = 11;    // first-level window of every code table
+constexpr int kL2Entries = 512;  // direct second-level table for the codes longer than kFastBits
+constexpr int kSyncGroup = 3;    // symbols one look-up of the position-only pass may step over
+
+// Table entry: bits 0-6 zig-zag advance (1..64), 7-11 bits consumed (code length + magnitude bits s), 12-15 s.
+//   DC symbol (category s):  advance 1
+//   AC symbol (run r, size s): s != 0: r + 1;  ZRL (0xF0): 16;  any other s == 0 (EOB): 64 = "to the end of the block"
+HUFF_HD uint32_t MakeEntry(int len, int sym, bool is_dc) {
+  int s = sym & 15, r = sym >> 4;
+  int adv = is_dc ? 1 : (s ? r + 1 : (r == 15 ? 16 : 64));
+  return (uint32_t)((s << 12) | ((len + s) << 7) | adv);
+}
+HUFF_HD uint32_t SyncGroup(uint32_t z, uint32_t used, uint32_t count) { return z | (used << 7) | (count << 12); }
+
+// Code tables of the value-extracting passes (DC pass, block decode).
+struct HuffTables {
+  uint16_t fast[4][1 << kFastBits];  // [0],[1] = DC tables 0,1; [2],[3] = AC tables 0,1
+  uint16_t l2[4][kL2Entries];        // codes longer than kFastBits, indexed by (16-bit code window) - l2_first
+  int32_t l2_first[4];
+  int32_t l2_size[4];                // entries in use; -1: the long codes span more than kL2Entries -> search
+  int32_t maxcode[4][18];            // canonical-code search tables (T.81 F.2.2.3), the fallback
+  int32_t valoff[4][18];
+  uint8_t vals[4][256];
+  uint32_t dc_mask, ac_mask;         // bit k: table selector of the k-th block of the MCU
+  int32_t bpm, reserved;
+};
+static_assert(sizeof(HuffTables) % 16 == 0, "copied with 16-byte accesses");
+
+// Tables of the position-only passes (SyncKernel / PropagateKernel).  They do not extract values, so one look-up may
+// step over a GROUP of up to three symbols of one block: a 32-bit entry holds, for the kFastBits-bit window,
+//   bits  0-13  the whole group:  z advance (7 bits) | bits used << 7 (5 bits) | symbol count << 12 (1..3)
+//   bits 14-23  what precedes the group's LAST symbol: z advance (6 bits) | bits used << 6 (4 bits); zero for a
+//               single symbol.  The group may be taken when these symbols leave the block open - decided per step
+//   bits 24-31  groups of three only: the first symbol alone, bits used (4 bits) | (z advance - 1) << 4, for the
+//               (rare) step that cannot take the group; with two symbols the fields above already describe it
+// A group continues behind a symbol when that one is not an end-of-block and the CODE of the next lies inside the
+// window behind it (its magnitude bits need not).  DC entries continue into the AC table of their block when all the
+// blocks that use the DC table use the same AC table.
+struct SyncTables {
+  uint32_t t32[4][1 << kFastBits];   // [0],[1] = DC tables 0,1; [2],[3] = AC tables 0,1; 0 = code longer than the window
+  uint16_t l2[4][kL2Entries];
+  int32_t l2_first[4];
+  int32_t l2_size[4];
+  int32_t maxcode[4][18];
+  int32_t valoff[4][18];
+  uint8_t vals[4][256];
+  uint32_t dc_mask, ac_mask;
+  int32_t bpm, reserved;
+};
+static_assert(sizeof(SyncTables) % 16 == 0, "copied with 16-byte accesses");
+
+// ------------------------------------------------------------------------------------------------ table construction
+// Canonical code assignment (ITU-T T.81 Annex C) of one table: per code length the largest code and the symbol
+// offset; range of the 16-bit windows of the codes longer than kFastBits.
+HUFF_HD void CodeRanges(const uint8_t bits[16], int32_t maxcode[18], int32_t valoff[18], int32_t *l2_first_out,
+                        int32_t *l2_size_out) {
+  int code = 0, p = 0;
+  int l2_first = 1 << 16, l2_end = 0;
+  maxcode[0] = -1; valoff[0] = 0; maxcode[17] = -1; valoff[17] = 0;
+  for (int l = 1; l <= 16; l++) {
+    const int n = bits[l - 1];
+    valoff[l] = p - code;
+    if (n && l > kFastBits) {
+      if (l2_end == 0) l2_first = (code << (16 - l)) & 0xFFFF;
+      l2_end = ((code + n) << (16 - l));  // one past the last 16-bit window of the codes seen so far
+    }
+    p += n;
+    code += n;
+    maxcode[l] = n ? code - 1 : -1;
+    code <<= 1;
+  }
+  const int size = l2_end ? l2_end - l2_first : 0;
+  *l2_first_out = l2_first;
+  *l2_size_out = size <= kL2Entries ? size : -1;  // -1: too spread out for the direct table, LongCode searches
+}
+
+// First-level entry for the kFastBits-bit window w: the shortest length whose code range contains the window's prefix
+// (0: the code is longer than the window).
+template <typename Tables>
+HUFF_HD uint16_t FastEntry(const Tables &L, int t, int w) {
+  for (int l = 1; l <= kFastBits; l++) {
+    const int cd = w >> (kFastBits - l);
+    if (cd <= L.maxcode[t][l]) return (uint16_t)MakeEntry(l, L.vals[t][(cd + L.valoff[t][l]) & 255], t < 2);
+  }
+  return 0;
+}
+// Second-level entry j (16-bit window l2_first + j).
+template <typename Tables>
+HUFF_HD uint16_t L2Entry(const Tables &L, int t, int j) {
+  if (j >= L.l2_size[t]) return 0;
+  const int w = L.l2_first[t] + j;
+  for (int l = kFastBits + 1; l <= 16; l++) {
+    const int cd = w >> (16 - l);
+    if (cd <= L.maxcode[t][l]) return (uint16_t)MakeEntry(l, L.vals[t][(cd + L.valoff[t][l]) & 255], t < 2);
+  }
+  return 0;
+}
+// Symbol-group entry of the position-only tables for window w of table tb (needs the finished fast[] tables).
+HUFF_HD uint32_t SyncEntry(const HuffTables &L, int tb, int w) {
+  const uint32_t e1 = L.fast[tb][w];
+  if (!e1) return 0;
+  // table the block continues with: an AC table itself, or the one AC table every block of this DC table uses
+  int ac = tb;
+  if (tb < 2) {
+    ac = -1;
+    for (int k = 0; k < L.bpm; k++) {
+      if ((int)((L.dc_mask >> k) & 1u) != tb) continue;
+      const int a = 2 + (int)((L.ac_mask >> k) & 1u);
+      ac = ac == -1 || ac == a ? a : -2;
+    }
+  }
+  uint32_t z = e1 & 127, used = (e1 >> 7) & 31, count = 1, zprev = 0, uprev = 0;
+  const uint32_t z1 = z, u1 = used;
+  while (ac >= 2 && count < (uint32_t)kSyncGroup && z < 64 && used < (uint32_t)kFastBits) {
+    const uint32_t e2 = L.fast[ac][(w << used) & ((1 << kFastBits) - 1)];
+    const uint32_t z2 = e2 & 127, u2 = (e2 >> 7) & 31, len2 = u2 - (e2 >> 12);
+    if (!e2 || used + len2 > (uint32_t)kFastBits) break;  // the next code is not determined by the window
+    zprev = z; uprev = used;
+    z += z2; used += u2; count++;
+  }
+  uint32_t e = SyncGroup(z, used, count) | (zprev << 14) | (uprev << 20);
+  if (count == 3) e |= (u1 << 24) | ((z1 - 1) << 28);
+  return e;
+}
+
+// ------------------------------------------------------------------------------------------------ decoder state
+struct DecodeState {
+  uint32_t pos;  // bit position of the next symbol
+  uint32_t c;    // block index inside the MCU
+  uint32_t z;    // zig-zag index of the next coefficient (0 = DC)
+};
+HUFF_HD uint64_t Pack(const DecodeState &s) { return ((uint64_t)s.pos << 16) | ((uint64_t)s.c << 8) | (uint64_t)s.z; }
+HUFF_HD DecodeState Unpack(uint64_t v) {
+  return DecodeState{(uint32_t)(v >> 16), (uint32_t)((v >> 8) & 255), (uint32_t)(v & 255)};
+}
+constexpr uint64_t kNoState = ~0ull;  // unpacks to a position past any stream
+
+HUFF_HD uint32_t Bswap32(uint32_t v) { return __builtin_bswap32(v); }
+
+// Rare path: the code is longer than kFastBits bits (or is not a code at all).  Out of line on the device.
+template <typename Tables>
+#if defined(__HIPCC__)
+__host__ __device__ __noinline__
+#else
+inline
+#endif
+uint32_t LongCode(const Tables &L, uint32_t slot, uint32_t peek, bool is_dc) {
+  const uint32_t code16 = peek >> 16;
+  uint32_t e = 0;
+  const int size = L.l2_size[slot];
+  if (size >= 0) {
+    const int idx = (int)code16 - L.l2_first[slot];
+    if (idx >= 0 && idx < size) e = L.l2[slot][idx];
+  } else {
+    for (int l = kFastBits + 1; l <= 16; l++) {
+      int cd = (int)(code16 >> (16 - l));
+      if (cd <= L.maxcode[slot][l]) {
+        e = MakeEntry(l, L.vals[slot][(cd + L.valoff[slot][l]) & 255], is_dc);
+        break;
+      }
+    }
+  }
+  // not a code (garbage start state, or the padding behind the stream): consume 16 bits, decode nothing
+  return e ? e : MakeEntry(16, 0, is_dc);
+}
+
+// ------------------------------------------------------------------------------------------------ position-only pass
+// Decodes the groups of symbols that start in [st.pos, end_bits) - positions only - and reports where every block
+// STARTS through `store(j, rem)`: the j-th block found starts `rem` bits before end_bits (negative: a group may run a
+// few symbols past the end).  A block starts where the previous one ends; the very first block of a stream starts
+// at bit 0, which only the decode that begins there sees.  Returns the number of block starts.
+//
+// Every step reports the position it reached for the CURRENT index; the index only advances when the step ended a
+// block (the last report of an index is the one that counts), so the caller's store needs no branch and no execution
+// mask and is off the dependency chain of the step.
+template <typename Tables, typename Words, typename Store>
+HUFF_HD int SyncDecodeRange(const Tables &L, Words words, DecodeState &st, uint32_t end_bits, Store store) {
+  int nb = 0;
+  uint32_t c = st.c, z = st.z;
+  int rem = (int)(end_bits - st.pos);  // bits left before the end of the slice (<= 0: done)
+  if (st.pos == 0) {                   // the stream's first block
+    store(0, rem);
+    nb = 1;
+  }
+  // bit window: hi:lo = stream bits [32k, 32k+64), `off` of hi's bits already consumed; the following dword is in flight
+  int k = (int)(st.pos >> 5);
+  uint32_t off = st.pos & 31;
+  uint32_t hi = Bswap32(words[k]), lo = Bswap32(words[k + 1]), nxt = words[k + 2];
+  const uint32_t dc_mask = L.dc_mask, ac_mask = L.ac_mask, bpm = (uint32_t)L.bpm;
+  while (rem > 0) {
+    const uint32_t peek = (uint32_t)(((((uint64_t)hi << 32) | lo) << off) >> 32);
+    const bool is_dc = z == 0;
+    const uint32_t slot = (((is_dc ? dc_mask : ac_mask) >> c) & 1u) + (is_dc ? 0u : 2u);
+    uint32_t e = L.t32[slot][peek >> (32 - kFastBits)];
+    if (__builtin_expect(e == 0, 0)) {
+      const uint32_t e16 = LongCode(L, slot, peek, is_dc);
+      e = SyncGroup(e16 & 127, (e16 >> 7) & 31, 1);
+    }
+    // the group may be taken when the symbols before its last one leave the block open
+    const uint32_t zprev = (e >> 14) & 63;
+    uint32_t used = (e >> 7) & 31, zinc = e & 127;
+    if (__builtin_expect(z + zprev >= 64, 0)) {  // rare: take the first symbol only
+      const bool three = ((e >> 12) & 3) == 3;
+      used = three ? (e >> 24) & 15 : (e >> 20) & 15;
+      zinc = three ? ((e >> 28) & 15) + 1 : zprev;
+    }
+    rem -= (int)used;
+    off += used;
+    z += zinc;
+    if (off >= 32) {
+      hi = lo;
+      lo = Bswap32(nxt);
+      k++;
+      nxt = words[k + 2];
+      off -= 32;
+    }
+    const bool end_of_block = z >= 64;
+    store(nb, rem);
+    const uint32_t c1 = c + 1 == bpm ? 0 : c + 1;
+    z = end_of_block ? 0 : z;
+    c = end_of_block ? c1 : c;
+    nb += end_of_block ? 1 : 0;
+  }
+  st.pos = end_bits - (uint32_t)rem;
+  st.c = c;
+  st.z = z;
+  return nb;
+}
+
+// ------------------------------------------------------------------------------------------------ value passes
+// T.81 F.2.2.1 EXTEND: the low s bits of `bits` are the magnitude bits m -> value; s == 0 gives 0.
+HUFF_HD int Extend(uint32_t bits, uint32_t s) {
+  const uint32_t full = (1u << s) - 1u;  // 2^s - 1
+  const uint32_t m = bits & full;
+  return (int)m - (int)(m <= (full >> 1) ? full : 0u);
+}
+// 32 stream bits starting at bit `pos` (big-endian bit order; `words` = the clean stream as little-endian dwords)
+template <typename Words>
+HUFF_HD uint32_t Peek32(Words words, uint32_t pos) {
+  const uint32_t k = pos >> 5, off = pos & 31;
+  const uint32_t hi = Bswap32(words[k]), lo = Bswap32(words[k + 1]);
+  return (uint32_t)(((((uint64_t)hi << 32) | lo) << off) >> 32);
+}
+
+// DC symbol of the block that starts at bit `pos`, decoded with DC table `sel`: returns the difference, *used = bits
+// consumed (code + magnitude: at most 16 + 11 bits, so one 32-bit window is enough).
+template <typename Tables, typename Words>
+HUFF_HD int DecodeDc(const Tables &L, Words words, uint32_t pos, uint32_t sel, uint32_t *used_out) {
+  const uint32_t peek = Peek32(words, pos);
+  uint32_t e = L.fast[sel][peek >> (32 - kFastBits)];
+  if (__builtin_expect(e == 0, 0)) e = LongCode(L, sel, peek, true);
+  const uint32_t used = (e >> 7) & 31, s = e >> 12;
+  *used_out = used;
+  return Extend(peek >> (32 - used), s);
+}
+
+// AC coefficients of one block: symbols from bit `pos` (just behind the DC symbol) until the block is full or an
+// end-of-block arrives.  coef[z] (z = zig-zag index 1..63) receives the values; coef[64] is a scratch slot that
+// swallows what does not carry a coefficient (end-of-block, ZRL past the end, a run that overshoots the block in a
+// corrupt stream), so the store needs no condition.  The block must be zero-filled by the caller.
+template <typename Tables, typename Words, typename Coef>
+HUFF_HD void DecodeBlockAc(const Tables &L, Words words, uint32_t pos, uint32_t ac_slot, Coef coef) {
+  int k = (int)(pos >> 5);
+  uint32_t off = pos & 31;
+  uint32_t hi = Bswap32(words[k]), lo = Bswap32(words[k + 1]), nxt = words[k + 2];
+  uint32_t z = 1;
+  while (z < 64) {
+    const uint32_t peek = (uint32_t)(((((uint64_t)hi << 32) | lo) << off) >> 32);
+    uint32_t e = L.fast[ac_slot][peek >> (32 - kFastBits)];
+    if (__builtin_expect(e == 0, 0)) e = LongCode(L, ac_slot, peek, false);
+    const uint32_t used = (e >> 7) & 31, s = e >> 12, adv = e & 127;
+    const int val = Extend(peek >> (32 - used), s);
+    z += adv;                                   // index behind the coefficient this symbol carries
+    const uint32_t at = z - 1 < 64 ? z - 1 : 64;  // 64: nothing to store (s == 0 stores a zero where it lands: harmless,
+    coef[at] = (int16_t)val;                    // the positions of a block are visited in increasing order)
+    off += used;
+    if (off >= 32) {
+      hi = lo;
+      lo = Bswap32(nxt);
+      k++;
+      nxt = words[k + 2];
+      off -= 32;
+    }
+  }
+}
+
+// zig-zag scan order expressed in column-major block positions (= the transposed zig-zag): coefficient z of the scan
+// sits at column kZigZagColMajorHost[z] / 8, row kZigZagColMajorHost[z] % 8
+constexpr uint8_t kZigZagColMajorTable[64] = {
+    0, 8, 1, 2, 9, 16, 24, 17, 10, 3, 4, 11, 18, 25, 32, 40, 33, 26, 19, 12, 5, 6, 13, 20, 27, 34, 41, 48, 56, 49, 42, 35,
+    28, 21, 14, 7, 15, 22, 29, 36, 43, 50, 57, 58, 51, 44, 37, 30, 23, 31, 38, 45, 52, 59, 60, 53, 46, 39, 47, 54, 61, 62,
+    55, 63};
+
+}  // namespace daliamd
+#endif  // DALI_AMD_CSRC_HUFF_CORE_H_

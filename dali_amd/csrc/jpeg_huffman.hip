@@ -1,9 +1,8 @@
 // GPU Huffman entropy decoder for baseline JPEG (one interleaved scan, no restart markers) on gfx950.
 //
 // Reference counterpart: the GPU Huffman stage of nvJPEG inside nvImageCodec, reached from
-// ImageDecoder::RunImplImpl (dali/operators/imgcodec/image_decoder.h:810-815).  The output is the same
-// column-major coefficient layout the host decoder (dali_amd/host/jpeg_entropy.cpp) produces, so results are
-// bit-identical by construction and the IDCT kernel does not care who decoded the stream.
+// ImageDecoder::RunImplImpl (dali/operators/imgcodec/image_decoder.h:810-815).  The output is what the host decoder
+// (dali_amd/host/jpeg_entropy.cpp) + the IDCT kernel produce, bit for bit.
 //
 // The entropy-coded segment of an image is ONE serial bit stream; the decoder state is (bit position, block index
 // inside the MCU, zig-zag index).  Parallelism comes from self-synchronisation: a decoder started from a guessed
@@ -11,42 +10,39 @@
 // size does not depend on the image (so a batch with one 500 KB stream and many 50 KB streams still fills the chip):
 //
 //   tile     16 KB of the stuffed stream    (un-stuffing, 1024 lanes x 16 bytes)
-//   slice    256 bytes of the clean stream  (one decoder lane)
-//   segment  116 slices = 29 KB             (one 128-lane workgroup: 12 warm-up lanes + 116 slices)
+//   slice    256 bytes of the clean stream  (one decoder lane of the synchronisation)
+//   segment  244 slices = 61 KB             (one 256-lane workgroup: 12 warm-up lanes + 244 slices)
+//   block    one 8x8 block                  (one lane of the value pass)
 //
 //   1 PrepareKernel         per tile: number of bytes that survive the removal of the 0xFF00 stuffing; and, in extra
 //                           workgroups of the same launch (they need nothing but the descriptor), per image: two-level
-//                           code tables (11-bit first level, direct second level for the long codes), the symbol-group
-//                           tables of the position-only passes and the MCU geometry -> global scratch, copied into
-//                           LDS by the decoding workgroups
+//                           code tables (11-bit first level, direct second level for the long codes) and the
+//                           symbol-group tables of the position-only passes -> global scratch
 //   2 UnstuffScatterKernel  per tile: compaction through LDS to its final place in the clean stream
-//   3 SyncKernel            per segment: every lane decodes its slice from a guessed state, then the relaxation
-//                           "publish the state you reached to the next lane, decode again if your input changed"
-//                           runs until nothing changes.  The 12 warm-up lanes replay the end of the previous
-//                           segment so that the first slice of the segment starts from the true state with
-//                           overwhelming probability.  No values are extracted in this pass, so one table look-up
-//                           steps over up to three symbols; every decode also notes the state at the slice's midpoint
+//   3 SyncKernel            per segment: every lane decodes its slice from a guessed state - positions only, up to three
+//                           symbols per table look-up -, then the relaxation "publish the state you reached to the next
+//                           lane, decode again if your input changed" runs until nothing changes.  The 12 warm-up lanes
+//                           replay the end of the previous segment so that the first slice of the segment starts from
+//                           the true state with overwhelming probability.  Every decode notes WHERE EACH BLOCK STARTS
+//                           (a short list per lane in LDS, one store per step, no branch); the converged lists are
+//                           written out densely per segment
 //   4 PropagateKernel       per image, serial over its segments: checks that every segment started from the state
 //                           its predecessor ended in (if not - pathological streams - repairs it with the same
 //                           relaxation, so correctness never depends on luck), assigns block ordinals
-//   5 WriteKernel           per segment, one lane per HALF slice (232 lanes in 256 threads): decodes once more from
-//                           the now-known states, extracting the values, and appends one 32-bit record per symbol to
-//                           the image's record stream (sequential per lane); DC values as lane-local running sums of
-//                           the differences; notes where every block starts
-//   6 DcScanKernel          per segment: prefix sums of the per-lane DC sums -> DC level at the start of every lane
-//   7 ExpandKernel          per block: builds the 8x8 block from its records in LDS, adds the DC level and either
-//                           dequantises + inverse-transforms it on the spot and stores the 8x8 samples to the component
-//                           plane (fused output, the default of the callers) or stores the coefficients as ONE full
-//                           128-byte line (no zero-fill, no partial writes, no read-modify-write)
+//   5 DcKernel              per segment, one lane per block: decodes the block's DC difference (one look-up), prefix
+//                           sums per component inside the segment; notes the bit position behind the DC symbol
+//   6 BlockKernel           one lane per block: AC symbols -> coefficients of the lane's block in LDS (the loop knows
+//                           nothing but one code table: no DC / block bookkeeping, ~26 instructions per symbol); then
+//                           the wave dequantises + inverse-transforms its 64 blocks, 8 lanes per block, and stores the
+//                           8x8 samples to the component plane (or the coefficients, for callers that want them)
 //
-// What bounds the decode loops (measured): the position-only pass is a latency chain - a wave's step is
-// ~55 dependent instructions and the kernel lasts as long as the workgroup with the longest chain of slices that do
-// not self-synchronise - so its steps were made fewer (symbol groups); the write pass is VALU-issue bound (a wave64
-// instruction occupies a SIMD16 for 4 cycles and divergent branches execute the union of their bodies), hence short
-// lanes, 4 waves per SIMD, branch-free DC / refill code, a two-dword bit window fed from an LDS ring, and no
-// vector-memory instruction between two wave-uniform points.
+// Round 1's decoder ran a second full sequential decode per half slice that appended one 32-bit record per symbol to
+// a stream in HBM (WriteKernel, 80 instructions per symbol), a DC scan and an expand kernel that gathered the records
+// of each block again: 2 x 137 MB of scratch traffic per 256-image batch and 0.36 ms.  Knowing the block starts makes
+// the value pass embarrassingly parallel, its inner loop three times shorter, and the record stream disappears.
 #include <cstring>
 #include "common.h"
+#include "huff_core.h"
 #include "jpeg_idct_math.h"
 
 namespace daliamd {
@@ -54,13 +50,17 @@ namespace daliamd {
 constexpr int kTileThreads = 1024;
 constexpr int kTileBytes = kTileThreads * 16;
 constexpr int kSliceBytes = 256;
-constexpr int kSegThreads = 128;
+constexpr int kSegThreads = 256;
 constexpr int kWarmLanes = 12;
 constexpr int kSegLanes = kSegThreads - kWarmLanes;
 constexpr int kSegBytes = kSegLanes * kSliceBytes;
-constexpr int kFastBits = 11;
-constexpr int kL2Entries = 512;
 constexpr int kCleanPadBytes = 40;
+// Block-start lists of the synchronisation pass: kListCap entries per lane in LDS + one slot that swallows the
+// overflow; the stride (in 16-bit entries) is an odd number of dwords so that lanes at the same index hit different banks.
+constexpr int kListCap = 33;
+constexpr int kListStride = 34;
+// A block takes at least 4 bits (streams with a 1-bit code are refused), a group may overshoot the slice by 3 symbols.
+constexpr int kMaxStartsPerSlice = kSliceBytes * 8 / 4 + 32;
 
 // Explicit global address space: a generic pointer would make these `flat` accesses, which count against the LDS
 // counter as well and would serialise the table look-ups behind the stream prefetch.
@@ -68,122 +68,57 @@ using GlobalWords = const uint32_t __attribute__((address_space(1)));
 using GlobalCoef = int16_t __attribute__((address_space(1)));
 using GlobalBytes = uint8_t __attribute__((address_space(1)));
 using GlobalU32 = uint32_t __attribute__((address_space(1)));
+using GlobalI32 = int32_t __attribute__((address_space(1)));
+using GlobalU16 = uint16_t __attribute__((address_space(1)));
 
 // ------------------------------------------------------------------------------------------------ scratch layout
-// The synchronisation passes work on slices of kSliceBytes; the write pass splits every slice at its midpoint into
-// two WRITE LANES (the time of that pass is the length of its longest lane, and the machine has room for twice the
-// lanes).  The state at the midpoint is a by-product of the final synchronisation decode of the slice.
 struct LaneRec {      // one per slice
   uint64_t in, out;   // packed decoder state at the start / end of the slice
-  uint64_t mid;       // ... at the first symbol that starts at or behind the midpoint (= in when in is behind it)
-  int32_t nblk;       // blocks completed inside the slice
-  int32_t nsym;       // symbols that start inside the slice = records the write pass emits for it
-  int32_t nblk_a;     // ... of them before the midpoint
-  int32_t nsym_a;
-  int32_t dc[2][3];   // write pass: sum of the DC differences each half holds, per component
-  int32_t base[2][3]; // DcScanKernel: DC level at the start of each half, per component
+  int32_t nstart;     // blocks that start in the slice (= entries it contributed to the segment's start list)
+  int32_t reserved;
 };
-static_assert(sizeof(LaneRec) == 88, "ExpandKernel addresses the base[] words directly");
+static_assert(sizeof(LaneRec) == 24, "layout");
 struct SegRec {  // one per segment
   uint64_t out;  // state at the end of the segment
-  int32_t nblk_total, block_base;
-  int32_t nsym_total, rec_base;
-  int32_t dc_total[3];
+  int32_t nstart_total;  // block starts found in the segment
+  int32_t block_base;    // ... in the segments before it = ordinal of the segment's first start (PropagateKernel)
+  int32_t dc_total[3];   // DcKernel: sum of the DC differences of the segment's blocks, per component
   int32_t reserved;
 };
-// The write pass does not scatter 2-byte coefficients into the (185 MB per batch) coefficient arrays - that costs
-// 3.6x the algorithmic HBM traffic in partial-line writes plus a zero-fill plus a read-modify-write pass for the DC
-// prediction.  It appends one 32-bit RECORD per symbol to a per-image stream (sequential per lane, so the lines
-// fill up in L2) and notes where every block starts; ExpandKernel then builds each 8x8 block in LDS and stores it
-// as one full 128-byte line, adding the DC level on the way.
-//   record: bits 0-15 value (AC coefficient, or the lane-local running sum of the DC differences),
-//           bits 16-21 zig-zag index of the coefficient, bit 22 = first record of a block (DC),
-//           bit 23 = carries a coefficient (clear for ZRL / end-of-block symbols)
-constexpr uint32_t kRecDc = 1u << 22, kRecValid = 1u << 23;
-struct BlockIndex {
-  uint32_t first_record;  // index of the block's DC record in the image's record stream
-  uint32_t lane;          // write lane (image-wide: 2 * slice + half) that decoded the DC: its LaneRec holds the DC level
-};
-
-struct HuffTables {
-  uint16_t fast[4][1 << kFastBits];  // [0],[1] = DC tables 0,1; [2],[3] = AC tables 0,1
-  uint16_t l2[4][kL2Entries];        // codes longer than kFastBits, indexed by (16-bit code window) - l2_first
-  int32_t l2_first[4];
-  int32_t l2_size[4];                // entries in use; -1: the long codes span more than kL2Entries -> search
-  int32_t maxcode[4][18];            // canonical-code search tables (T.81 F.2.2.3), the fallback
-  int32_t valoff[4][18];
-  uint8_t vals[4][256];
-  uint8_t zz[64];                    // zig-zag index -> column-major position
-  uint8_t blk_comp[16];              // component of the k-th block of the MCU
-  int32_t blk_sx[12], blk_sy[12];    // coefficient-array stride (elements) per MCU column / MCU row
-  GlobalCoef *blk_base[12];          // address of that block in MCU (0, 0)
-  uint32_t dc_mask, ac_mask;         // bit k: table selector of the k-th block of the MCU
-  int32_t bpm, mcus_x, total_blocks;
-  // region-of-interest decode: blocks outside their component's rectangle are parsed but not stored
-  int32_t use_rect;
-  int32_t last_ordinal;              // first block ordinal behind the last MCU row that is needed
-  int32_t reserved;
-  uint8_t blk_hs[16], blk_vs[16], blk_ho[16], blk_vo[16];  // block position = (mx*hs + ho, my*vs + vo)
-  int32_t blk_rect[12][4];           // {x0, y0, x1, y1} of the block's component
-  // fused output (dequantise + IDCT inside ExpandKernel): plane of the block's component, or all null
-  GlobalBytes *blk_plane[12];
-  int32_t blk_pitch[12];
-};
-static_assert(sizeof(HuffTables) % 16 == 0, "copied with 16-byte accesses");
-
-// Tables of the position-only passes (SyncKernel / PropagateKernel).  They do not extract values, so one look-up may
-// step over a GROUP of up to three symbols of one block: a 32-bit entry holds, for the kFastBits-bit window,
-//   bits  0-13  the whole group:  z advance (7 bits) | bits used << 7 (5 bits) | symbol count << 12 (1..3)
-//   bits 14-23  what precedes the group's LAST symbol: z advance (6 bits) | bits used << 6 (4 bits); zero for a
-//               single symbol.  The group may be taken when these symbols leave the block open and the last one
-//               still starts inside the range - decided per step
-//   bits 24-31  groups of three only: the first symbol alone, bits used (4 bits) | (z advance - 1) << 4, for the
-//               (rare) step that cannot take the group; with two symbols the fields above already describe it
-// A group continues behind a symbol when that one is not an end-of-block and the CODE of the next lies inside the
-// window behind it (its magnitude bits need not).  DC entries continue into the AC table of their block when all the
-// blocks that use the DC table use the same AC table.
-// On the ImageNet-like bench set (tools/sync_sim.cpp): pairs 0.61x the steps, this 0.54x.
-struct SyncTables {
-  uint32_t t32[4][1 << kFastBits];   // [0],[1] = DC tables 0,1; [2],[3] = AC tables 0,1; 0 = code longer than the window
-  uint16_t l2[4][kL2Entries];
-  int32_t l2_first[4];
-  int32_t l2_size[4];
-  int32_t maxcode[4][18];
-  int32_t valoff[4][18];
-  uint8_t vals[4][256];
-  uint32_t dc_mask, ac_mask;
-  int32_t bpm, reserved;
-};
-static_assert(sizeof(SyncTables) % 16 == 0, "copied with 16-byte accesses");
-__host__ __device__ __forceinline__ uint32_t SyncGroup(uint32_t z, uint32_t used, uint32_t count) {
-  return z | (used << 7) | (count << 12);
-}
-constexpr int kSyncGroup = 3;
+static_assert(sizeof(SegRec) == 32, "layout");
 
 struct ScratchLayout {
-  size_t tile_kept, clean, tables, sync_tables, lanes, segs, records, blocks, total;
+  size_t tile_kept, clean, tables, sync_tables, lanes, segs, seg_starts, blk_pos, blk_dc, blk_seg, total;
+  int seg_cap;  // entries per segment in seg_starts
 };
 __host__ __device__ inline size_t AlignUp(size_t v, size_t a) { return (v + a - 1) / a * a; }
 __host__ __device__ inline ScratchLayout MakeLayout(int ecs_len, int num_tiles, int num_segments, int total_blocks) {
   ScratchLayout l;
-  size_t o = 16;  // [0]: int32 clean_len
+  size_t o = 16;  // int32 [0] clean_len, [2] block starts found in the whole stream
   l.tile_kept = o;
   o += AlignUp(sizeof(int32_t) * (size_t)num_tiles, 16);
   l.clean = o;
-  o += AlignUp((size_t)ecs_len + 64, 16);
+  o += AlignUp((size_t)ecs_len + 256, 16);
   l.tables = o;
   o += sizeof(HuffTables);
   l.sync_tables = o;
   o += sizeof(SyncTables);
   l.lanes = o;
-  o += sizeof(LaneRec) * (size_t)num_segments * kSegLanes;
+  o += AlignUp(sizeof(LaneRec) * (size_t)num_segments * kSegLanes, 16);
   l.segs = o;
   o += AlignUp(sizeof(SegRec) * (size_t)num_segments, 16);
-  // every symbol consumes at least 2 bits (streams with a 1-bit code are not eligible): <= 4 records per byte
-  l.records = o;
-  o += sizeof(uint32_t) * (4 * (size_t)ecs_len + 64);
-  l.blocks = o;
-  o += sizeof(BlockIndex) * ((size_t)total_blocks + 1);
+  // block starts per segment, densely: a stream holds total_blocks real blocks (+ a few phantom ones parsed from the
+  // padding behind it), so no segment can own more than that - nor more than its slices can hold
+  const long long by_slices = (long long)kSegLanes * kMaxStartsPerSlice, by_blocks = (long long)total_blocks + 128;
+  l.seg_cap = (int)(by_slices < by_blocks ? by_slices : by_blocks);
+  l.seg_starts = o;
+  o += AlignUp(sizeof(uint32_t) * (size_t)num_segments * (size_t)l.seg_cap, 16);
+  l.blk_pos = o;   // per block: bit position behind its DC symbol
+  o += AlignUp(sizeof(uint32_t) * (size_t)total_blocks, 16);
+  l.blk_dc = o;    // per block: its DC level relative to the start of its segment
+  o += AlignUp(sizeof(int32_t) * (size_t)total_blocks, 16);
+  l.blk_seg = o;   // per block: the segment it starts in
+  o += AlignUp(sizeof(uint16_t) * (size_t)total_blocks, 16);
   l.total = AlignUp(o, 256);
   return l;
 }
@@ -318,21 +253,6 @@ __global__ __launch_bounds__(kTileThreads) void UnstuffScatterKernel(const dalia
 }
 
 // ------------------------------------------------------------------------------------------------ tables
-// Table entry: bits 0-6 zig-zag advance (1..64), 7-11 bits consumed (code length + magnitude bits s), 12-15 s.
-//   DC symbol (category s):  advance 1
-//   AC symbol (run r, size s): s != 0: r + 1;  ZRL (0xF0): 16;  any other s == 0 (EOB): 64 = "to the end of the block"
-__host__ __device__ __forceinline__ uint32_t MakeEntry(int len, int sym, bool is_dc) {
-  int s = sym & 15, r = sym >> 4;
-  int adv = is_dc ? 1 : (s ? r + 1 : (r == 15 ? 16 : 64));
-  return (uint32_t)((s << 12) | ((len + s) << 7) | adv);
-}
-
-// zig-zag scan order expressed in column-major block positions (= the transposed zig-zag)
-__device__ __constant__ uint8_t kZigZagColMajor[64] = {
-    0, 8, 1, 2, 9, 16, 24, 17, 10, 3, 4, 11, 18, 25, 32, 40, 33, 26, 19, 12, 5, 6, 13, 20, 27, 34, 41, 48, 56, 49, 42, 35,
-    28, 21, 14, 7, 15, 22, 29, 36, 43, 50, 57, 58, 51, 44, 37, 30, 23, 31, 38, 45, 52, 59, 60, 53, 46, 39, 47, 54, 61, 62,
-    55, 63};
-
 template <int THREADS, typename Tables>
 __device__ __forceinline__ void CopyTables(Tables &dst, const Tables *src) {
   const uint4 *s = reinterpret_cast<const uint4 *>(src);
@@ -340,7 +260,8 @@ __device__ __forceinline__ void CopyTables(Tables &dst, const Tables *src) {
   for (int i = threadIdx.x; i < (int)(sizeof(Tables) / 16); i += THREADS) t[i] = s[i];
 }
 
-// Code tables of one stream (all threads of a PrepareKernel workgroup).
+// Code tables of one stream (all threads of a PrepareKernel workgroup); every entry is found independently
+// (huff_core.h: FastEntry / L2Entry / SyncEntry).
 __device__ __forceinline__ void BuildTables(const daliamdJpegHuffDesc &d, HuffTables &L) {
   constexpr int NT = kTileThreads;
   const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments, d.total_blocks);
@@ -350,22 +271,7 @@ __device__ __forceinline__ void BuildTables(const daliamdJpegHuffDesc &d, HuffTa
     for (int i = tid; i < (int)(sizeof(HuffTables) / 16); i += NT) z[i] = make_uint4(0, 0, 0, 0);
   }
   __syncthreads();
-  if (tid < 64) L.zz[tid] = kZigZagColMajor[tid];
   for (int t = tid; t < 4 * 256; t += NT) L.vals[t >> 8][t & 255] = d.vals[t >> 8][t & 255];
-  if (tid < 12 && tid < d.blocks_per_mcu) {
-    const int comp = d.comp_of_block[tid];
-    L.blk_comp[tid] = (uint8_t)comp;
-    L.blk_sx[tid] = d.h_samp[comp] * 64;
-    L.blk_sy[tid] = d.v_samp[comp] * d.blocks_x[comp] * 64;
-    L.blk_base[tid] = (GlobalCoef *)d.coef[comp] + ((size_t)d.v_of_block[tid] * d.blocks_x[comp] + d.h_of_block[tid]) * 64;
-    L.blk_hs[tid] = (uint8_t)d.h_samp[comp];
-    L.blk_vs[tid] = (uint8_t)d.v_samp[comp];
-    L.blk_ho[tid] = d.h_of_block[tid];
-    L.blk_vo[tid] = d.v_of_block[tid];
-    for (int j = 0; j < 4; j++) L.blk_rect[tid][j] = d.rect[comp][j];
-    L.blk_plane[tid] = (GlobalBytes *)d.plane[comp];
-    L.blk_pitch[tid] = d.plane_pitch[comp];
-  }
   if (tid == 0) {
     uint32_t dc_mask = 0, ac_mask = 0;
     for (int k = 0; k < d.blocks_per_mcu; k++) {
@@ -376,107 +282,26 @@ __device__ __forceinline__ void BuildTables(const daliamdJpegHuffDesc &d, HuffTa
     L.dc_mask = dc_mask;
     L.ac_mask = ac_mask;
     L.bpm = d.blocks_per_mcu;
-    L.mcus_x = d.mcus_x;
-    L.total_blocks = d.total_blocks;
-    // region of interest: any non-empty rectangle switches the filter on
-    int use_rect = 0, last_mcu_row = 0;
-    for (int k = 0; k < d.blocks_per_mcu; k++) {
-      int comp = d.comp_of_block[k];
-      if (d.rect[comp][2] > d.rect[comp][0] && d.rect[comp][3] > d.rect[comp][1]) {
-        use_rect = 1;
-        int rows = (d.rect[comp][3] + d.v_samp[comp] - 1) / d.v_samp[comp];  // MCU rows up to the rectangle's bottom
-        last_mcu_row = rows > last_mcu_row ? rows : last_mcu_row;
-      }
-    }
-    L.use_rect = use_rect;
-    int last = last_mcu_row * d.mcus_x * d.blocks_per_mcu;
-    L.last_ordinal = use_rect && last < d.total_blocks ? last : d.total_blocks;
+  }
+  if (tid >= 64 && tid < 68) {
+    const int t = tid - 64;
+    int32_t first, size;
+    CodeRanges(d.bits[t], L.maxcode[t], L.valoff[t], &first, &size);
+    L.l2_first[t] = first;
+    L.l2_size[t] = size;
   }
   __syncthreads();
-  if (tid < 4) {
-    // canonical code assignment (ITU-T T.81 Annex C): per code length the largest code and the symbol offset
-    int code = 0, p = 0;
-    int l2_first = 1 << 16, l2_end = 0;
-    for (int l = 1; l <= 16; l++) {
-      const int n = d.bits[tid][l - 1];
-      L.valoff[tid][l] = p - code;
-      if (n && l > kFastBits) {
-        if (l2_end == 0) l2_first = (code << (16 - l)) & 0xFFFF;
-        l2_end = ((code + n) << (16 - l));  // one past the last 16-bit window of the codes seen so far
-      }
-      p += n;
-      code += n;
-      L.maxcode[tid][l] = n ? code - 1 : -1;
-      code <<= 1;
-    }
-    const int size = l2_end ? l2_end - l2_first : 0;
-    L.l2_first[tid] = l2_first;
-    L.l2_size[tid] = size <= kL2Entries ? size : -1;  // -1: too spread out for the direct table, LongCode searches
-  }
-  __syncthreads();
-  // every table entry is found independently: the shortest length whose code range contains the window's prefix
-  for (int idx = tid; idx < 4 * (1 << kFastBits); idx += NT) {
-    const int t = idx >> kFastBits, w = idx & ((1 << kFastBits) - 1);
-    uint16_t e = 0;
-    for (int l = 1; l <= kFastBits; l++) {
-      const int cd = w >> (kFastBits - l);
-      if (cd <= L.maxcode[t][l]) {
-        e = (uint16_t)MakeEntry(l, L.vals[t][(cd + L.valoff[t][l]) & 255], t < 2);
-        break;
-      }
-    }
-    L.fast[t][w] = e;
-  }
-  for (int idx = tid; idx < 4 * kL2Entries; idx += NT) {
-    const int t = idx / kL2Entries, j = idx % kL2Entries;
-    uint16_t e = 0;
-    if (j < L.l2_size[t]) {
-      const int w = L.l2_first[t] + j;
-      for (int l = kFastBits + 1; l <= 16; l++) {
-        const int cd = w >> (16 - l);
-        if (cd <= L.maxcode[t][l]) {
-          e = (uint16_t)MakeEntry(l, L.vals[t][(cd + L.valoff[t][l]) & 255], t < 2);
-          break;
-        }
-      }
-    }
-    L.l2[t][j] = e;
-  }
+  for (int idx = tid; idx < 4 * (1 << kFastBits); idx += NT)
+    L.fast[idx >> kFastBits][idx & ((1 << kFastBits) - 1)] = FastEntry(L, idx >> kFastBits, idx & ((1 << kFastBits) - 1));
+  for (int idx = tid; idx < 4 * kL2Entries; idx += NT) L.l2[idx / kL2Entries][idx % kL2Entries] = L2Entry(L, idx / kL2Entries, idx % kL2Entries);
   __syncthreads();
   const uint4 *s = reinterpret_cast<const uint4 *>(&L);
   uint4 *t = reinterpret_cast<uint4 *>(d.scratch + lay.tables);
   for (int i = tid; i < (int)(sizeof(HuffTables) / 16); i += NT) t[i] = s[i];
   // ---- tables of the position-only passes, straight to global memory ----
   SyncTables *S = reinterpret_cast<SyncTables *>(d.scratch + lay.sync_tables);
-  for (int idx = tid; idx < 4 * (1 << kFastBits); idx += NT) {
-    const int tb = idx >> kFastBits, w = idx & ((1 << kFastBits) - 1);
-    const uint32_t e1 = L.fast[tb][w];
-    uint32_t e = 0;
-    if (e1) {
-      // table the block continues with: an AC table itself, or the one AC table every block of this DC table uses
-      int ac = tb;
-      if (tb < 2) {
-        ac = -1;
-        for (int k = 0; k < L.bpm; k++) {
-          if ((int)((L.dc_mask >> k) & 1u) != tb) continue;
-          const int a = 2 + (int)((L.ac_mask >> k) & 1u);
-          ac = ac == -1 || ac == a ? a : -2;
-        }
-      }
-      uint32_t z = e1 & 127, used = (e1 >> 7) & 31, count = 1, zprev = 0, uprev = 0;
-      const uint32_t z1 = z, u1 = used;
-      while (ac >= 2 && count < (uint32_t)kSyncGroup && z < 64 && used < (uint32_t)kFastBits) {
-        const uint32_t e2 = L.fast[ac][(w << used) & ((1 << kFastBits) - 1)];
-        const uint32_t z2 = e2 & 127, u2 = (e2 >> 7) & 31, len2 = u2 - (e2 >> 12);
-        if (!e2 || used + len2 > (uint32_t)kFastBits) break;  // the next code is not determined by the window
-        zprev = z; uprev = used;
-        z += z2; used += u2; count++;
-      }
-      e = SyncGroup(z, used, count) | (zprev << 14) | (uprev << 20);
-      if (count == 3) e |= (u1 << 24) | ((z1 - 1) << 28);
-    }
-    S->t32[tb][w] = e;
-  }
+  for (int idx = tid; idx < 4 * (1 << kFastBits); idx += NT)
+    S->t32[idx >> kFastBits][idx & ((1 << kFastBits) - 1)] = SyncEntry(L, idx >> kFastBits, idx & ((1 << kFastBits) - 1));
   for (int i = tid; i < 4 * kL2Entries; i += NT) S->l2[i / kL2Entries][i % kL2Entries] = L.l2[i / kL2Entries][i % kL2Entries];
   for (int i = tid; i < 4 * 256; i += NT) S->vals[i >> 8][i & 255] = L.vals[i >> 8][i & 255];
   if (tid < 4 * 18) {
@@ -506,309 +331,14 @@ __global__ __launch_bounds__(kTileThreads) void PrepareKernel(const daliamdJpegH
   else CountTile(descs, n, (int)blockIdx.x - n, wave_sums);
 }
 
-// ------------------------------------------------------------------------------------------------ decode
-struct DecodeState {
-  uint32_t pos;  // bit position of the next symbol
-  uint32_t c;    // block index inside the MCU
-  uint32_t z;    // zig-zag index of the next coefficient (0 = DC)
-};
-__device__ __forceinline__ uint64_t Pack(const DecodeState &s) {
-  return ((uint64_t)s.pos << 16) | ((uint64_t)s.c << 8) | (uint64_t)s.z;
-}
-__device__ __forceinline__ DecodeState Unpack(uint64_t v) {
-  return DecodeState{(uint32_t)(v >> 16), (uint32_t)((v >> 8) & 255), (uint32_t)(v & 255)};
-}
-constexpr uint64_t kNoState = ~0ull;  // unpacks to a position past any stream
-
-struct DcAcc {
-  int sum0 = 0, sum1 = 0, sum2 = 0;  // running sums of the DC differences this lane decoded, per component
-};
-
-// Rare path: the code is longer than kFastBits bits (or is not a code at all).
-template <typename Tables>
-__device__ __noinline__ uint32_t LongCode(const Tables &L, uint32_t slot, uint32_t peek, bool is_dc) {
-  const uint32_t code16 = peek >> 16;
-  uint32_t e = 0;
-  const int size = L.l2_size[slot];
-  if (size >= 0) {
-    const int idx = (int)code16 - L.l2_first[slot];
-    if (idx >= 0 && idx < size) e = L.l2[slot][idx];
-  } else {
-    for (int l = kFastBits + 1; l <= 16; l++) {
-      int cd = (int)(code16 >> (16 - l));
-      if (cd <= L.maxcode[slot][l]) {
-        e = MakeEntry(l, L.vals[slot][(cd + L.valoff[slot][l]) & 255], is_dc);
-        break;
-      }
-    }
-  }
-  // not a code (garbage start state, or the padding behind the stream): consume 16 bits, decode nothing
-  return e ? e : MakeEntry(16, 0, is_dc);
-}
-
-// Decodes the symbols that start in [st.pos, end_bits); returns the number of blocks completed.  Positions only:
-// no value is extracted (synchronisation passes).
-struct HalfCount { uint64_t mid; int nblk, nsym; };  // state at the midpoint, blocks / symbols before it
-__device__ __forceinline__ int DecodeRange(const SyncTables &L, GlobalWords *__restrict__ words, DecodeState &st,
-                                           uint32_t mid_bits, uint32_t end_bits, int &nsym_out, HalfCount &half) {
-  int nblk = 0, nsym = 0;
-  uint32_t c = st.c, z = st.z;
-  int rem = (int)(end_bits - st.pos);  // bits left before the end of the slice (<= 0: done)
-  // bit window: hi:lo = stream bits [32k, 32k+64), `off` of hi's bits already consumed; the following dword is in flight
-  int k = (int)(st.pos >> 5);
-  uint32_t off = st.pos & 31;
-  uint32_t hi = __builtin_bswap32(words[k]), lo = __builtin_bswap32(words[k + 1]), nxt = words[k + 2];
-  const uint32_t *t32 = &L.t32[0][0];
-  const uint32_t dc_mask = L.dc_mask, ac_mask = L.ac_mask, bpm = (uint32_t)L.bpm;
-  // symbols that start in [pos, end - limit); called for the two halves of the slice in turn (no per-symbol cost
-  // for the midpoint: the first loop simply stops there)
-  auto run = [&](int limit) {
-    while (rem > limit) {
-      const uint32_t peek = (uint32_t)(((((uint64_t)hi << 32) | lo) << off) >> 32);
-      const bool is_dc = z == 0;
-      const uint32_t slot = (((is_dc ? dc_mask : ac_mask) >> c) & 1u) + (is_dc ? 0u : 2u);
-      uint32_t e = t32[(slot << kFastBits) + (peek >> (32 - kFastBits))];
-      if (__builtin_expect(e == 0, 0)) {
-        const uint32_t e16 = LongCode(L, slot, peek, is_dc);
-        e = SyncGroup(e16 & 127, (e16 >> 7) & 31, 1);
-      }
-      // the group may be taken when the symbols before its last one leave the block open and the last one starts
-      // inside the range: both differences negative <=> the sign bit of their AND is set
-      const int zprev = (int)((e >> 14) & 63), uprev = (int)((e >> 20) & 15);
-      const int ok = ((int)z + zprev - 64) & (uprev - (rem - limit));
-      uint32_t used = (e >> 7) & 31, zinc = e & 127, count = (e >> 12) & 3;
-      if (__builtin_expect(ok >= 0, 0)) {  // rare: take the first symbol only
-        const bool three = count == 3;
-        used = three ? (e >> 24) & 15 : (uint32_t)uprev;
-        zinc = three ? ((e >> 28) & 15) + 1 : (uint32_t)zprev;
-        count = 1;
-      }
-      rem -= (int)used;
-      off += used;
-      z += zinc;
-      nsym += (int)count;
-      if (off >= 32) {
-        hi = lo;
-        lo = __builtin_bswap32(nxt);
-        k++;
-        nxt = words[k + 2];
-        off -= 32;
-      }
-      const bool end_of_block = z >= 64;
-      const uint32_t c1 = c + 1 == bpm ? 0 : c + 1;
-      z = end_of_block ? 0 : z;
-      c = end_of_block ? c1 : c;
-      nblk += end_of_block ? 1 : 0;
-    }
-  };
-  run(mid_bits < end_bits ? (int)(end_bits - mid_bits) : 0);
-  half.mid = Pack(DecodeState{end_bits - (uint32_t)rem, c, z});
-  half.nblk = nblk;
-  half.nsym = nsym;
-  run(0);
-  st.pos = end_bits - (uint32_t)rem;
-  st.c = c;
-  st.z = z;
-  nsym_out = nsym;
-  return nblk;
-}
-
-// 16 bytes at a 4-byte aligned address in one instruction (gfx9 global accesses need dword alignment only).  Scattered
-// accesses cost the texture-address unit one cycle or more PER LANE, so a lane moving its 32 bytes with two of
-// these instead of eight dword accesses is the difference between a TA-bound and a VALU-bound write pass.
-typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-using GlobalQuadA4 = u32x4_a4 __attribute__((address_space(1)));
-
-constexpr int kGroupSteps = 8;   // symbols between two wave-uniform "points" of the write pass
-constexpr int kRingWords = 16;   // dwords of the clean stream buffered in LDS per lane (ring)
-constexpr int kRingNeed = 10;    // a group reads up to dword k + 2 + 7 (eight symbols of at most 27 bits)
-constexpr int kWriteThreads = 256;
-constexpr int kWriteLanes = 2 * kSegLanes;  // two write lanes per slice of the segment
-
-// Write pass of one slice: decodes the symbols that start in [st.pos, end_bits) once more, now extracting the values,
-// and appends one record per symbol to `rec` (this slice's part of the image's record stream; exactly the `nsym`
-// records the synchronisation pass counted).  The block in progress at `st` is block ordinal `ord`; every DC record
-// registers its block in the block index.  DC records carry the lane-local running sum of the differences of their
-// component (ExpandKernel adds the level at the start of the slice).
-//
-// gfx9 has ONE in-order counter for vector-memory loads and stores: waiting for a load also waits for every store
-// issued before it.  So the loop is software-pipelined around wave-uniform points, kGroupSteps symbols apart:
-// at a point the lane (1) takes delivery of the 8 stream dwords it requested at the previous point (long arrived:
-// the wait costs nothing) and appends them to its LDS ring, (2) stores the records and block-index entries of the
-// last 8 symbols, kept in registers until now, (3) requests the next 8 stream dwords.  Between two points there
-// is no vector-memory instruction at all: the bit window is refilled from the LDS ring.
-__device__ __forceinline__ void WriteRange(const HuffTables &L, GlobalWords *__restrict__ words, DecodeState st,
-                                           uint32_t end_bits, int ord, bool live, uint32_t *ring,
-                                           GlobalU32 *__restrict__ rec, uint32_t rec_index, uint32_t lane_id,
-                                           BlockIndex *__restrict__ blocks, DcAcc &dc) {
-  uint32_t c = st.c, z = st.z;
-  int rem = (int)(end_bits - st.pos);
-  int k = (int)(st.pos >> 5);  // dword index of `hi`
-  int kl = k;                  // the ring holds dwords [.., kl)
-  uint32_t off = st.pos & 31;
-  uint32_t hi = 0, lo = 0, nxt = 0;
-  const uint16_t *fast = &L.fast[0][0];
-  const uint32_t dc_mask = L.dc_mask, ac_mask = L.ac_mask, bpm = (uint32_t)L.bpm;
-  // component of the k-th block of the MCU, two bits each (no LDS look-up on the DC path)
-  uint32_t comp_bits = 0;
-  for (uint32_t kk = 0; kk < bpm; kk++) comp_bits |= (uint32_t)L.blk_comp[kk] << (2 * kk);
-  int ordinal = ord;  // block the next symbol belongs to
-  if (live) {         // prologue: 12 dwords straight into the ring (the only exposed memory latency of the pass)
-    const GlobalQuadA4 *src = (const GlobalQuadA4 *)(words + k);
-#pragma unroll
-    for (int q = 0; q < 3; q++) {
-      const u32x4_a4 v = src[q];
-      ring[(k + 4 * q) & (kRingWords - 1)] = v.x;
-      ring[(k + 4 * q + 1) & (kRingWords - 1)] = v.y;
-      ring[(k + 4 * q + 2) & (kRingWords - 1)] = v.z;
-      ring[(k + 4 * q + 3) & (kRingWords - 1)] = v.w;
-    }
-    kl = k + 12;
-    hi = __builtin_bswap32(ring[k & (kRingWords - 1)]);
-    lo = __builtin_bswap32(ring[(k + 1) & (kRingWords - 1)]);
-    nxt = ring[(k + 2) & (kRingWords - 1)];
-  }
-  uint32_t pre[4];        // stream dwords [kl, kl + 4) in flight
-  bool have_pre = false;
-  uint32_t r[kGroupSteps];  // records of the current group
-  int nrec = 0;
-  int group_ord = ordinal;  // `ordinal` and "inside a block" at the start of the group whose records are in r[]
-  bool group_mid_block = z != 0;
-  while (__ballot(live || nrec > 0) != 0) {  // wave-uniform trip count
-    // ---------------- point ----------------
-    if (have_pre) {
-#pragma unroll
-      for (int q = 0; q < 4; q++) ring[(kl + q) & (kRingWords - 1)] = pre[q];
-      kl += 4;
-      have_pre = false;
-    }
-    // Safety net: the usual 4 dwords per point cover 16 bits per symbol.  A lane that could run dry inside the next
-    // group (eight symbols in a row longer than that) fetches synchronously; real streams never get here.
-    while (__ballot(live && kl - k < kRingNeed) != 0) {
-      if (live && kl - k < kRingNeed) {
-        const u32x4_a4 v = *(const GlobalQuadA4 *)(words + kl);
-        ring[kl & (kRingWords - 1)] = v.x;
-        ring[(kl + 1) & (kRingWords - 1)] = v.y;
-        ring[(kl + 2) & (kRingWords - 1)] = v.z;
-        ring[(kl + 3) & (kRingWords - 1)] = v.w;
-        kl += 4;
-      }
-    }
-    if (nrec > 0) {
-      if (nrec == kGroupSteps) {  // the common case: the lane's 8 records as two 16-byte stores
-        GlobalQuadA4 *dst = (GlobalQuadA4 *)(rec + rec_index);
-        dst[0] = u32x4_a4{r[0], r[1], r[2], r[3]};
-        dst[1] = u32x4_a4{r[4], r[5], r[6], r[7]};
-      } else {
-#pragma unroll
-        for (int q = 0; q < kGroupSteps; q++)
-          if (q < nrec) rec[rec_index + q] = r[q];
-      }
-      int dc_ord = group_ord + (group_mid_block ? 1 : 0);  // ordinal of the first DC record of the group
-#pragma unroll
-      for (int q = 0; q < kGroupSteps; q++) {
-        if (q < nrec && (r[q] & kRecDc)) {
-          if (dc_ord < L.total_blocks) blocks[dc_ord] = BlockIndex{rec_index + q, lane_id};
-          dc_ord++;
-        }
-      }
-      rec_index += (uint32_t)nrec;
-      nrec = 0;
-    }
-    if (live && kl - k <= kRingWords - 4) {  // room in the ring: request the next 4 dwords (delivered at the next point)
-      const u32x4_a4 a = *(const GlobalQuadA4 *)(words + kl);
-      pre[0] = a.x; pre[1] = a.y; pre[2] = a.z; pre[3] = a.w;
-      have_pre = true;
-    }
-    group_ord = ordinal;
-    group_mid_block = z != 0;
-    // ---------------- 8 symbols, no vector-memory instruction ----------------
-#pragma unroll
-    for (int j = 0; j < kGroupSteps; j++) {
-      if (live) {
-        const uint32_t peek = (uint32_t)(((((uint64_t)hi << 32) | lo) << off) >> 32);
-        const bool is_dc = z == 0;
-        const uint32_t slot = (((is_dc ? dc_mask : ac_mask) >> c) & 1u) + (is_dc ? 0u : 2u);
-        uint32_t e = fast[(slot << kFastBits) + (peek >> (32 - kFastBits))];
-        if (__builtin_expect(e == 0, 0)) e = LongCode(L, slot, peek, is_dc);
-        const uint32_t used = (e >> 7) & 31, s = e >> 12, adv = e & 127;
-        // magnitude bits -> value (T.81 F.2.2.1 EXTEND): the s bits behind the code; s == 0 gives 0
-        const uint32_t m = __builtin_amdgcn_ubfe(peek, 32u - used, s);
-        const uint32_t full = (1u << s) - 1u;          // 2^s - 1
-        int val = (int)m - (int)(m <= (full >> 1) ? full : 0u);
-        uint32_t zt = z + adv - 1;  // zig-zag index of the coefficient this symbol carries (AC)
-        uint32_t flags = (s && zt < 64) ? kRecValid : 0;
-        // DC: the record carries the lane-local running sum of its component's differences (no branches: the three
-        // sums live in registers and every step offers them a masked increment)
-        const uint32_t comp = (comp_bits >> (2 * c)) & 3u;
-        const int dval = is_dc ? val : 0;
-        dc.sum0 += comp == 0 ? dval : 0;
-        dc.sum1 += comp == 1 ? dval : 0;
-        dc.sum2 += comp == 2 ? dval : 0;
-        const int sum = comp == 0 ? dc.sum0 : comp == 1 ? dc.sum1 : dc.sum2;
-        val = is_dc ? sum : val;
-        zt = is_dc ? 0u : zt;
-        flags = is_dc ? (kRecDc | kRecValid) : flags;
-        r[j] = ((uint32_t)val & 0xFFFFu) | ((zt & 63u) << 16) | flags;
-        nrec = j + 1;
-        rem -= (int)used;
-        off += used;
-        z += adv;
-        // window refill without a branch: the ring read is unconditional (it re-reads the same dword until k moves)
-        const bool refill = off >= 32;
-        hi = refill ? lo : hi;
-        lo = refill ? __builtin_bswap32(nxt) : lo;
-        k += refill ? 1 : 0;
-        off &= 31;
-        nxt = ring[(k + 2) & (kRingWords - 1)];
-        const bool end_of_block = z >= 64;
-        const uint32_t c1 = c + 1 == bpm ? 0 : c + 1;
-        z = end_of_block ? 0 : z;
-        c = end_of_block ? c1 : c;
-        ordinal += end_of_block ? 1 : 0;
-        live = rem > 0;
-      }
-    }
-  }
-}
-
+// ------------------------------------------------------------------------------------------------ synchronisation
 // One decoder lane of the relaxation.
 struct Lane {
   uint32_t begin, end;  // bit range of the slice (clipped to the stream)
   bool active;          // the slice holds data
-  uint64_t in = kNoState, out = kNoState, mid = kNoState;
-  int nblk = 0, nsym = 0, nblk_a = 0, nsym_a = 0;
+  uint64_t in = kNoState, out = kNoState;
+  int nstart = 0;       // blocks that start in the slice, by the lane's latest decode
 };
-
-// "Publish the state you reached to the next lane, decode again if your input changed", until nothing changes.
-// state[t] is the published input of lane t; lanes whose `in` already equals it do not decode.  Lane 0's input is
-// never written here, so whatever the caller put there is taken as the truth; each round fixes at least one more
-// lane, which bounds the loop by the lane count.
-template <int THREADS>
-__device__ __forceinline__ void Relax(const SyncTables &L, GlobalWords *words, uint64_t *state, Lane &ln) {
-  const int tid = threadIdx.x;
-  for (int round = 0; round <= THREADS; round++) {
-    const uint64_t ni = state[tid];
-    if (ln.active && ni != ln.in) {
-      ln.in = ni;
-      DecodeState st = Unpack(ni);
-      ln.nblk = ln.nsym = 0;
-      HalfCount half{ni, 0, 0};
-      if (st.pos < ln.end) ln.nblk = DecodeRange(L, words, st, ln.begin + kSliceBytes * 4u, ln.end, ln.nsym, half);
-      ln.out = Pack(st);
-      ln.mid = half.mid;
-      ln.nblk_a = half.nblk;
-      ln.nsym_a = half.nsym;
-    }
-    __syncthreads();
-    int changed = 0;
-    if (ln.active && tid + 1 < THREADS && state[tid + 1] != ln.out) {
-      state[tid + 1] = ln.out;
-      changed = 1;
-    }
-    if (!__syncthreads_or(changed)) break;
-  }
-}
 
 __device__ __forceinline__ Lane MakeLane(long long slice_index, uint32_t total_bits) {
   Lane ln;
@@ -824,9 +354,57 @@ __device__ __forceinline__ Lane MakeLane(long long slice_index, uint32_t total_b
   return ln;
 }
 
+// "Publish the state you reached to the next lane, decode again if your input changed", until nothing changes.
+// state[t] is the published input of lane t; lanes whose `in` already equals it do not decode.  Lane 0's input is
+// never written here, so whatever the caller put there is taken as the truth; each round fixes at least one more
+// lane, which bounds the loop by the lane count.  `list` = this lane's block-start list in LDS.
+__device__ __forceinline__ void Relax(const SyncTables &L, GlobalWords *words, uint64_t *state, Lane &ln, uint16_t *list) {
+  const int tid = threadIdx.x;
+  for (int round = 0; round <= kSegThreads; round++) {
+    const uint64_t ni = state[tid];
+    if (ln.active && ni != ln.in) {
+      ln.in = ni;
+      DecodeState st = Unpack(ni);
+      ln.nstart = 0;
+      if (st.pos < ln.end)
+        ln.nstart = SyncDecodeRange(L, words, st, ln.end, [&](int nb, int rem) { list[nb < kListCap ? nb : kListCap] = (uint16_t)rem; });
+      ln.out = Pack(st);
+    }
+    __syncthreads();
+    int changed = 0;
+    if (ln.active && tid + 1 < kSegThreads && state[tid + 1] != ln.out) {
+      state[tid + 1] = ln.out;
+      changed = 1;
+    }
+    if (!__syncthreads_or(changed)) break;
+  }
+}
+
+// After the relaxation: the segment's block starts, densely, as absolute bit positions (the lists of its lanes one
+// after the other).  `first` = the first lane that belongs to the segment (the warm-up lanes before it replayed the
+// previous one).  Lanes whose list outgrew its LDS slots (long runs of nearly empty blocks) decode once more,
+// writing straight to memory.  Returns the number of starts in the segment.
+__device__ __forceinline__ int WriteSegmentStarts(const SyncTables &L, GlobalWords *words, const Lane &ln, const uint16_t *list,
+                                                  bool mine, GlobalU32 *seg_starts, int seg_cap, int *wave_sums) {
+  int total;
+  const int base = WorkgroupExclusiveScan<kSegThreads / 64>(mine ? ln.nstart : 0, wave_sums, total);
+  if (mine && ln.nstart <= kListCap) {
+    for (int j = 0; j < ln.nstart; j++)
+      if (base + j < seg_cap) seg_starts[base + j] = ln.end - (uint32_t)(int32_t)(int16_t)list[j];
+  } else if (mine) {
+    DecodeState st = Unpack(ln.in);
+    const uint32_t end = ln.end;
+    SyncDecodeRange(L, words, st, end, [&](int nb, int rem) {
+      if (base + nb < seg_cap) seg_starts[base + nb] = end - (uint32_t)rem;
+    });
+  }
+  return total;
+}
+
 __global__ __launch_bounds__(kSegThreads) void SyncKernel(const daliamdJpegHuffDesc *__restrict__ descs, int n, int nseg) {
   __shared__ __attribute__((aligned(16))) SyncTables L;
   __shared__ uint64_t state[kSegThreads];
+  __shared__ uint16_t lists[kSegThreads * kListStride];
   __shared__ int wave_sums[kSegThreads / 64];
   const int wg = XcdRemap(blockIdx.x, nseg);
   if (wg < 0) return;
@@ -838,8 +416,8 @@ __global__ __launch_bounds__(kSegThreads) void SyncKernel(const daliamdJpegHuffD
   LaneRec *recs = reinterpret_cast<LaneRec *>(d.scratch + lay.lanes) + (size_t)seg * kSegLanes;
   SegRec *segrec = reinterpret_cast<SegRec *>(d.scratch + lay.segs) + seg;
   if (seg > 0 && (long long)seg * kSegBytes >= clean_len) {  // segment behind the end of the stream
-    if (tid >= kWarmLanes) recs[tid - kWarmLanes] = LaneRec{kNoState, kNoState, kNoState, 0, 0, 0, 0, {}, {}};
-    if (tid == 0) *segrec = SegRec{kNoState, 0, 0, 0, 0, {0, 0, 0}, 0};
+    if (tid >= kWarmLanes) recs[tid - kWarmLanes] = LaneRec{kNoState, kNoState, 0, 0};
+    if (tid == 0) *segrec = SegRec{kNoState, 0, 0, {0, 0, 0}, 0};
     return;
   }
   CopyTables<kSegThreads>(L, reinterpret_cast<const SyncTables *>(d.scratch + lay.sync_tables));
@@ -848,22 +426,25 @@ __global__ __launch_bounds__(kSegThreads) void SyncKernel(const daliamdJpegHuffD
   Lane ln = MakeLane((long long)seg * kSegLanes + tid - kWarmLanes, total_bits);
   state[tid] = Pack(DecodeState{ln.begin, 0, 0});  // the guess; exact for the very first slice of the image
   __syncthreads();
-  Relax<kSegThreads>(L, (GlobalWords *)(d.scratch + lay.clean), state, ln);
-  int total, total_sym;
-  WorkgroupExclusiveScan<kSegThreads / 64>(tid >= kWarmLanes ? ln.nblk : 0, wave_sums, total);
-  WorkgroupExclusiveScan<kSegThreads / 64>(tid >= kWarmLanes ? ln.nsym : 0, wave_sums, total_sym);
-  if (tid >= kWarmLanes) {
-    recs[tid - kWarmLanes] = LaneRec{ln.in, ln.out, ln.mid, ln.nblk, ln.nsym, ln.nblk_a, ln.nsym_a, {}, {}};
+  GlobalWords *words = (GlobalWords *)(d.scratch + lay.clean);
+  uint16_t *list = lists + tid * kListStride;
+  Relax(L, words, state, ln, list);
+  const bool mine = tid >= kWarmLanes;
+  const int total = WriteSegmentStarts(L, words, ln, list, mine, (GlobalU32 *)(d.scratch + lay.seg_starts) + (size_t)seg * lay.seg_cap,
+                                       lay.seg_cap, wave_sums);
+  if (mine) {
+    recs[tid - kWarmLanes] = LaneRec{ln.in, ln.out, ln.nstart, 0};
     // the last slice with data ends the segment (an empty stream: the first lane passes its input on)
     const bool next_has_data = tid + 1 < kSegThreads && ln.end < total_bits;
-    if (ln.active && !next_has_data) *segrec = SegRec{ln.out, total, 0, total_sym, 0, {0, 0, 0}, 0};
-    if (total_bits == 0 && tid == kWarmLanes) *segrec = SegRec{Pack(DecodeState{0, 0, 0}), 0, 0, 0, 0, {0, 0, 0}, 0};
+    if (ln.active && !next_has_data) *segrec = SegRec{ln.out, total, 0, {0, 0, 0}, 0};
+    if (total_bits == 0 && tid == kWarmLanes) *segrec = SegRec{Pack(DecodeState{0, 0, 0}), 0, 0, {0, 0, 0}, 0};
   }
 }
 
 __global__ __launch_bounds__(kSegThreads) void PropagateKernel(const daliamdJpegHuffDesc *__restrict__ descs) {
   __shared__ __attribute__((aligned(16))) SyncTables L;
   __shared__ uint64_t state[kSegThreads];
+  __shared__ uint16_t lists[kSegThreads * kListStride];
   __shared__ int wave_sums[kSegThreads / 64];
   const daliamdJpegHuffDesc &d = descs[blockIdx.x];
   const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments, d.total_blocks);
@@ -872,15 +453,15 @@ __global__ __launch_bounds__(kSegThreads) void PropagateKernel(const daliamdJpeg
   const uint32_t total_bits = (uint32_t)clean_len * 8u;
   LaneRec *all_recs = reinterpret_cast<LaneRec *>(d.scratch + lay.lanes);
   SegRec *segs = reinterpret_cast<SegRec *>(d.scratch + lay.segs);
+  GlobalWords *words = (GlobalWords *)(d.scratch + lay.clean);
   uint64_t truth = Pack(DecodeState{0, 0, 0});
-  int block_base = 0, rec_base = 0;
+  int block_base = 0;
   bool tables_loaded = false;
   for (int seg = 0; seg < d.num_segments; seg++) {
     if (seg > 0 && (long long)seg * kSegBytes >= clean_len) {
       if (tid == 0) {
         segs[seg].out = truth;
         segs[seg].block_base = block_base;
-        segs[seg].rec_base = rec_base;
       }
       continue;
     }
@@ -891,60 +472,60 @@ __global__ __launch_bounds__(kSegThreads) void PropagateKernel(const daliamdJpeg
         CopyTables<kSegThreads>(L, reinterpret_cast<const SyncTables *>(d.scratch + lay.sync_tables));
         tables_loaded = true;
       }
-      Lane ln = MakeLane(tid < kSegLanes ? (long long)seg * kSegLanes + tid : -1, total_bits);
-      if (tid < kSegLanes) {
-        ln.in = recs[tid].in;
-        ln.out = recs[tid].out;
-        ln.mid = recs[tid].mid;
-        ln.nblk = recs[tid].nblk;
-        ln.nsym = recs[tid].nsym;
-        ln.nblk_a = recs[tid].nblk_a;
-        ln.nsym_a = recs[tid].nsym_a;
-      }
-      state[tid] = tid == 0 ? truth : ln.in;
+      // every lane decodes again (its start list lives in LDS only while the kernel that decoded it runs)
+      const bool mine = tid < kSegLanes;
+      Lane ln = MakeLane(mine ? (long long)seg * kSegLanes + tid : -1, total_bits);
+      state[tid] = tid == 0 ? truth : (mine ? recs[tid].in : kNoState);
       __syncthreads();
-      Relax<kSegThreads>(L, (GlobalWords *)(d.scratch + lay.clean), state, ln);
-      int total, total_sym;
-      WorkgroupExclusiveScan<kSegThreads / 64>(ln.nblk, wave_sums, total);
-      WorkgroupExclusiveScan<kSegThreads / 64>(ln.nsym, wave_sums, total_sym);
-      if (tid < kSegLanes) {
-        recs[tid].in = ln.in;
-        recs[tid].out = ln.out;
-        recs[tid].mid = ln.mid;
-        recs[tid].nblk = ln.nblk;
-        recs[tid].nsym = ln.nsym;
-        recs[tid].nblk_a = ln.nblk_a;
-        recs[tid].nsym_a = ln.nsym_a;
+      uint16_t *list = lists + tid * kListStride;
+      Relax(L, words, state, ln, list);
+      const int total = WriteSegmentStarts(L, words, ln, list, mine,
+                                           (GlobalU32 *)(d.scratch + lay.seg_starts) + (size_t)seg * lay.seg_cap, lay.seg_cap,
+                                           wave_sums);
+      if (mine) {
+        recs[tid] = LaneRec{ln.in, ln.out, ln.nstart, 0};
         const bool next_has_data = tid + 1 < kSegLanes && ln.end < total_bits;
         if (ln.active && !next_has_data) {
           segs[seg].out = ln.out;
-          segs[seg].nblk_total = total;
-          segs[seg].nsym_total = total_sym;
+          segs[seg].nstart_total = total;
         }
       }
       __threadfence();
       __syncthreads();  // the records written above are read below (same workgroup)
     }
-    if (tid == 0) {
-      segs[seg].block_base = block_base;
-      segs[seg].rec_base = rec_base;
-    }
-    block_base += segs[seg].nblk_total;
-    rec_base += segs[seg].nsym_total;
+    if (tid == 0) segs[seg].block_base = block_base;
+    block_base += segs[seg].nstart_total;
     truth = segs[seg].out;
   }
-  // the segment must hold every block the frame header promises (the padding may add garbage after them)
-  if (tid == 0 && block_base < d.total_blocks) *d.status = 2;
-  if (tid == 0) {
-    reinterpret_cast<int32_t *>(d.scratch)[1] = rec_base;    // records of the whole stream
-    reinterpret_cast<int32_t *>(d.scratch)[2] = block_base;  // blocks the stream really holds (truncated streams: fewer)
-  }
+  // every block of the frame must have started AND ended inside the segment (the end of the last one is the start
+  // of a block that does not exist; the padding may add garbage after it)
+  if (tid == 0 && block_base - 1 < d.total_blocks) *d.status = 2;
+  if (tid == 0) reinterpret_cast<int32_t *>(d.scratch)[2] = block_base;  // block starts the stream really holds
 }
 
-__global__ __launch_bounds__(kWriteThreads) void WriteKernel(const daliamdJpegHuffDesc *__restrict__ descs, int n, int nseg) {
-  __shared__ __attribute__((aligned(16))) HuffTables L;
-  __shared__ __attribute__((aligned(16))) uint32_t ring[kWriteThreads * kRingWords];
-  __shared__ int wave_sums[kWriteThreads / 64];
+// ------------------------------------------------------------------------------------------------ value passes
+// First block ordinal behind the last MCU row a region-of-interest decode needs (total_blocks: everything).
+__device__ __forceinline__ int LastOrdinal(const daliamdJpegHuffDesc &d) {
+  int use_rect = 0, last_mcu_row = 0;
+  for (int k = 0; k < d.blocks_per_mcu; k++) {
+    const int comp = d.comp_of_block[k];
+    if (d.rect[comp][2] > d.rect[comp][0] && d.rect[comp][3] > d.rect[comp][1]) {
+      use_rect = 1;
+      const int rows = (d.rect[comp][3] + d.v_samp[comp] - 1) / d.v_samp[comp];  // MCU rows up to the rectangle's bottom
+      last_mcu_row = rows > last_mcu_row ? rows : last_mcu_row;
+    }
+  }
+  const long long last = (long long)last_mcu_row * d.mcus_x * d.blocks_per_mcu;
+  return use_rect && last < d.total_blocks ? (int)last : d.total_blocks;
+}
+
+// DC pass, one workgroup per segment, one lane per block that starts in it: the DC difference of the block (one table
+// look-up in the tables in L2), inclusive prefix sums per component over the segment (the levels relative to the
+// segment's start; BlockKernel adds the totals of the segments before), the bit position behind the DC symbol.
+constexpr int kDcThreads = 256;
+__global__ __launch_bounds__(kDcThreads) void DcKernel(const daliamdJpegHuffDesc *__restrict__ descs, int n, int nseg) {
+  __shared__ int wave_sums[kDcThreads / 64];
+  __shared__ uint8_t comp_of[16], dcsel_of[16];
   const int wg = XcdRemap(blockIdx.x, nseg);
   if (wg < 0) return;
   const ImageRef r = FindImage<false>(descs, n, wg);
@@ -952,100 +533,110 @@ __global__ __launch_bounds__(kWriteThreads) void WriteKernel(const daliamdJpegHu
   const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments, d.total_blocks);
   const int tid = threadIdx.x, seg = r.local;
   const int clean_len = *reinterpret_cast<const int32_t *>(d.scratch);
-  if (seg > 0 && (long long)seg * kSegBytes >= clean_len) return;
-  CopyTables<kWriteThreads>(L, reinterpret_cast<const HuffTables *>(d.scratch + lay.tables));
-  LaneRec *recs = reinterpret_cast<LaneRec *>(d.scratch + lay.lanes) + (size_t)seg * kSegLanes;
   SegRec *segrec = reinterpret_cast<SegRec *>(d.scratch + lay.segs) + seg;
-  const uint32_t total_bits = (uint32_t)clean_len * 8u;
-  // write lane = (slice, half): the first half ends at the slice's midpoint, the second starts from the state the
-  // synchronisation pass noted there
-  const int slice = tid >> 1, half = tid & 1;
-  const bool has = tid < kWriteLanes;
-  const Lane ln = MakeLane(has ? (long long)seg * kSegLanes + slice : -1, total_bits);
-  const uint32_t mid_bits = min(ln.begin + kSliceBytes * 4u, ln.end);
-  const uint32_t end_bits = half ? ln.end : mid_bits;
-  uint64_t in = kNoState;
-  int nblk = 0, nsym = 0;
-  if (has) {
-    const LaneRec &rc = recs[slice];
-    in = half ? rc.mid : rc.in;
-    nblk = half ? rc.nblk - rc.nblk_a : rc.nblk_a;
-    nsym = half ? rc.nsym - rc.nsym_a : rc.nsym_a;
+  if (seg > 0 && (long long)seg * kSegBytes >= clean_len) return;  // dc_total is already zero
+  if (tid < d.blocks_per_mcu) {
+    comp_of[tid] = d.comp_of_block[tid];
+    dcsel_of[tid] = d.dc_sel[d.comp_of_block[tid]] & 1;
   }
-  int total;
-  const int ord = segrec->block_base + WorkgroupExclusiveScan<kWriteThreads / 64>(nblk, wave_sums, total);
-  const int rec_off = segrec->rec_base + WorkgroupExclusiveScan<kWriteThreads / 64>(nsym, wave_sums, total);
-  DcAcc dc;
-  DecodeState st = Unpack(in);
-  // region of interest: lanes behind the last needed block are not decoded again; the lane that STARTS at that
-  // block still is, so that the DC record ending the last needed block exists
-  const bool live = ln.active && st.pos < end_bits && ord <= L.last_ordinal;
-  WriteRange(L, (GlobalWords *)(d.scratch + lay.clean), st, end_bits, ord, live, ring + tid * kRingWords,
-             (GlobalU32 *)(d.scratch + lay.records), (uint32_t)rec_off, (uint32_t)((seg * kSegLanes + slice) * 2 + half),
-             reinterpret_cast<BlockIndex *>(d.scratch + lay.blocks), dc);
-  if (has) {
-    recs[slice].dc[half][0] = dc.sum0;
-    recs[slice].dc[half][1] = dc.sum1;
-    recs[slice].dc[half][2] = dc.sum2;
+  __syncthreads();
+  const int bpm = d.blocks_per_mcu;
+  const int total_starts = reinterpret_cast<const int32_t *>(d.scratch)[2];
+  const int last_ordinal = LastOrdinal(d);
+  const int block_base = segrec->block_base;
+  int nstart = segrec->nstart_total;
+  nstart = nstart < lay.seg_cap ? nstart : lay.seg_cap;
+  const HuffTables &T = *reinterpret_cast<const HuffTables *>(d.scratch + lay.tables);
+  GlobalWords *words = (GlobalWords *)(d.scratch + lay.clean);
+  GlobalWords *starts = (GlobalWords *)(d.scratch + lay.seg_starts) + (size_t)seg * lay.seg_cap;
+  GlobalU32 *blk_pos = (GlobalU32 *)(d.scratch + lay.blk_pos);
+  GlobalI32 *blk_dc = (GlobalI32 *)(d.scratch + lay.blk_dc);
+  GlobalU16 *blk_seg = (GlobalU16 *)(d.scratch + lay.blk_seg);
+  int carry[3] = {0, 0, 0};
+  for (int j0 = 0; j0 < nstart; j0 += kDcThreads) {
+    const int j = j0 + tid, ordinal = block_base + j;
+    // a block counts when it starts AND ends inside the stream (its end is the next start) and the decode needs it
+    const bool valid = j < nstart && ordinal < last_ordinal && ordinal + 1 < total_starts;
+    int diff = 0;
+    uint32_t comp = 0, pos = 0, used = 0;
+    if (valid) {
+      const int k = ordinal % bpm;
+      comp = comp_of[k];
+      pos = starts[j];
+      diff = DecodeDc(T, words, pos, dcsel_of[k], &used);
+    }
+    int mine = 0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const int v = valid && comp == (uint32_t)c ? diff : 0;
+      int total;
+      const int incl = WorkgroupExclusiveScan<kDcThreads / 64>(v, wave_sums, total) + v + carry[c];
+      carry[c] += total;
+      mine = comp == (uint32_t)c ? incl : mine;
+    }
+    if (valid) {
+      blk_pos[ordinal] = pos + used;
+      blk_dc[ordinal] = mine;
+      blk_seg[ordinal] = (uint16_t)seg;
+    }
   }
-  int t0, t1, t2;
-  WorkgroupExclusiveScan<kWriteThreads / 64>(dc.sum0, wave_sums, t0);
-  WorkgroupExclusiveScan<kWriteThreads / 64>(dc.sum1, wave_sums, t1);
-  WorkgroupExclusiveScan<kWriteThreads / 64>(dc.sum2, wave_sums, t2);
-  if (tid == 0) {
-    segrec->dc_total[0] = t0;
-    segrec->dc_total[1] = t1;
-    segrec->dc_total[2] = t2;
-  }
+  if (tid < 3) segrec->dc_total[tid] = carry[tid];
 }
 
-// DC prediction: the level at the start of every write lane = sum of the differences of all lanes before it.
-__global__ __launch_bounds__(kWriteThreads) void DcScanKernel(const daliamdJpegHuffDesc *__restrict__ descs, int n, int nseg) {
-  __shared__ int wave_sums[kWriteThreads / 64];
-  const int wg = XcdRemap(blockIdx.x, nseg);
-  if (wg < 0) return;
-  const ImageRef r = FindImage<false>(descs, n, wg);
-  const daliamdJpegHuffDesc &d = *r.d;
-  const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments, d.total_blocks);
-  const int tid = threadIdx.x, seg = r.local;
-  const int clean_len = *reinterpret_cast<const int32_t *>(d.scratch);
-  if (seg > 0 && (long long)seg * kSegBytes >= clean_len) return;
-  LaneRec *recs = reinterpret_cast<LaneRec *>(d.scratch + lay.lanes) + (size_t)seg * kSegLanes;
-  const SegRec *segs = reinterpret_cast<const SegRec *>(d.scratch + lay.segs);
-  int p[3] = {0, 0, 0};
-  for (int j = tid; j < seg; j += kWriteThreads)
-    for (int c = 0; c < 3; c++) p[c] += segs[j].dc_total[c];
-  for (int c = 0; c < 3; c++) {
-    int seg_base, unused;
-    WorkgroupExclusiveScan<kWriteThreads / 64>(p[c], wave_sums, seg_base);
-    const int mine = tid < kWriteLanes ? recs[tid >> 1].dc[tid & 1][c] : 0;
-    const int base = seg_base + WorkgroupExclusiveScan<kWriteThreads / 64>(mine, wave_sums, unused);
-    if (tid < kWriteLanes) recs[tid >> 1].base[tid & 1][c] = base;
-  }
+// Value pass.  A workgroup owns a run of MCUs of one image; its waves take TASKS of 64 blocks that all use the same
+// AC table (luma / chroma blocks differ 2-3x in their number of symbols: a wave's loop lasts as long as its longest
+// block), one block per lane: the lane zero-fills nothing but decodes its AC symbols straight into its 64-coefficient
+// slot in LDS (natural zig-zag order, plus the DC level), then the wave transforms its 64 blocks 8 at a time with 8
+// lanes per block - JpegIdctKernel's two passes (lane `part` owns column `part` in pass 1 and row `part` in pass 2),
+// reading the coefficients through the zig-zag - and stores the samples.  Waves never wait for each other.
+constexpr int kBlockThreads = 128;
+constexpr int kBlockWaves = kBlockThreads / 64;
+constexpr int kCoefStride = 66;  // int16 per block: 64 coefficients, the scratch slot, one pad (33 dwords: odd -> no bank conflicts)
+constexpr int kBlocksPerWg = 768;
+__host__ __device__ inline int McusPerWg(int bpm) {
+  const int m = (kBlocksPerWg / bpm) / 64 * 64;
+  return m > 64 ? m : 64;
 }
-
-// Builds every needed 8x8 block from its records and stores it as one full 128-byte line: 8 lanes per block
-// (coalesced record loads, 16 bytes of the line each), 32 blocks at a time, 256 blocks per workgroup (the per-image
-// constants are fetched once per workgroup).
-constexpr int kExpandThreads = 256;
-constexpr int kExpandBlocks = kExpandThreads / 8;  // blocks in flight
-constexpr int kExpandPerWg = 256;                  // blocks per workgroup
-struct ExpandGeom {
-  int32_t bpm, mcus_x, last_ordinal, use_rect, decoded_blocks, total_blocks;
-  uint32_t total_records;
-  uint8_t comp[16], hs[16], vs[16], ho[16], vo[16], zz[64];
-  int32_t sx[12], sy[12], rect[12][4];
+struct AcTables {  // the AC half of HuffTables, indexed by table selector (LongCode / DecodeBlockAc address members by name)
+  uint16_t fast[2][1 << kFastBits];
+  uint16_t l2[2][kL2Entries];
+  int32_t l2_first[2], l2_size[2];
+  int32_t maxcode[2][18], valoff[2][18];
+  uint8_t vals[2][256];
+};
+struct BlockGeom {
+  int32_t bpm, mcus_x, total_mcus, last_ordinal, use_rect, total_starts, fused, n0;
+  uint8_t klist[12];  // block indices of the MCU, the ones with AC table 0 first
+  uint8_t comp[12], acs[12], hs[12], vs[12], ho[12], vo[12];
+  int32_t sx[12], sy[12], rect[12][4], pitch[12];
   GlobalCoef *base[12];
   GlobalBytes *plane[12];
-  int32_t pitch[12];
-  int32_t fused;
 };
-__global__ __launch_bounds__(kExpandThreads) void ExpandKernel(const daliamdJpegHuffDesc *__restrict__ descs, int n,
-                                                               int nwg) {
-  __shared__ __attribute__((aligned(16))) int16_t stage[kExpandBlocks][72];  // 64 + padding
-  __shared__ __attribute__((aligned(16))) int32_t trans[kExpandBlocks][72];  // fused output: IDCT transpose buffer
+struct BlockInfo {  // per block of a task: where its output goes
+  uint64_t dst;     // fused: top-left sample of the block in its plane; else the block's 64 coefficients
+  int32_t pitch;
+  int32_t comp_needed;  // component | needed << 8
+};
+// position in the scan (zig-zag index) of the coefficient at column-major block position p = column * 8 + row
+__device__ __constant__ uint8_t kScanIndexOfColMajor[64] = {
+    0, 2, 3, 9, 10, 20, 21, 35, 1, 4, 8, 11, 19, 22, 34, 36, 5, 7, 12, 18, 23, 33, 37, 48, 6, 13, 17, 24, 32, 38, 47, 49,
+    14, 16, 25, 31, 39, 46, 50, 57, 15, 26, 30, 40, 45, 51, 56, 58, 27, 29, 41, 44, 52, 55, 59, 62, 28, 42, 43, 53, 54, 60,
+    61, 63};
+
+// LDS accesses of one wave are executed in order; this only keeps the compiler from moving them across the point
+__device__ __forceinline__ void WaveSync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHuffDesc *__restrict__ descs, int n, int nwg) {
+  __shared__ __attribute__((aligned(16))) AcTables T;
+  __shared__ __attribute__((aligned(16))) int16_t coef[kBlockWaves][64 * kCoefStride];
+  __shared__ __attribute__((aligned(16))) int32_t trans[kBlockWaves][8][72];
+  __shared__ __attribute__((aligned(16))) BlockInfo info[kBlockWaves][64];
   __shared__ __attribute__((aligned(16))) uint16_t quant[3][64];
-  __shared__ ExpandGeom G;
+  __shared__ BlockGeom G;
   const int wg = XcdRemap(blockIdx.x, nwg);
   if (wg < 0) return;
   // workgroup -> image (descriptors sorted by blk_wg_start)
@@ -1056,165 +647,157 @@ __global__ __launch_bounds__(kExpandThreads) void ExpandKernel(const daliamdJpeg
   }
   const daliamdJpegHuffDesc &d = descs[lo];
   const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments, d.total_blocks);
-  const HuffTables *T = reinterpret_cast<const HuffTables *>(d.scratch + lay.tables);
-  const int tid = threadIdx.x;
-  if (tid < 12) {
-    G.comp[tid] = T->blk_comp[tid]; G.hs[tid] = T->blk_hs[tid]; G.vs[tid] = T->blk_vs[tid];
-    G.ho[tid] = T->blk_ho[tid]; G.vo[tid] = T->blk_vo[tid];
-    G.sx[tid] = T->blk_sx[tid]; G.sy[tid] = T->blk_sy[tid];
-    G.base[tid] = T->blk_base[tid];
-    for (int j = 0; j < 4; j++) G.rect[tid][j] = T->blk_rect[tid][j];
-    G.plane[tid] = T->blk_plane[tid];
-    G.pitch[tid] = T->blk_pitch[tid];
+  const HuffTables *H = reinterpret_cast<const HuffTables *>(d.scratch + lay.tables);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  {  // the AC tables: fast[2..3] and l2[2..3] are contiguous in HuffTables
+    const uint4 *s = reinterpret_cast<const uint4 *>(&H->fast[2][0]);
+    uint4 *t = reinterpret_cast<uint4 *>(&T.fast[0][0]);
+    for (int i = tid; i < (int)(sizeof(T.fast) / 16); i += kBlockThreads) t[i] = s[i];
+    s = reinterpret_cast<const uint4 *>(&H->l2[2][0]);
+    t = reinterpret_cast<uint4 *>(&T.l2[0][0]);
+    for (int i = tid; i < (int)(sizeof(T.l2) / 16); i += kBlockThreads) t[i] = s[i];
+    for (int i = tid; i < 2 * 256; i += kBlockThreads) T.vals[i >> 8][i & 255] = H->vals[2 + (i >> 8)][i & 255];
+    if (tid < 36) {
+      T.maxcode[tid / 18][tid % 18] = H->maxcode[2 + tid / 18][tid % 18];
+      T.valoff[tid / 18][tid % 18] = H->valoff[2 + tid / 18][tid % 18];
+    }
+    if (tid < 2) {
+      T.l2_first[tid] = H->l2_first[2 + tid];
+      T.l2_size[tid] = H->l2_size[2 + tid];
+    }
   }
-  if (tid >= 192 && tid < 192 + 48) {  // 3 x 64 quantisation values, four per thread
-    const int c = (tid - 192) >> 4, j = ((tid - 192) & 15) * 4;
+  if (tid < 12 && tid < d.blocks_per_mcu) {
+    const int comp = d.comp_of_block[tid];
+    G.comp[tid] = (uint8_t)comp;
+    G.acs[tid] = d.ac_sel[comp] & 1;
+    G.hs[tid] = (uint8_t)d.h_samp[comp];
+    G.vs[tid] = (uint8_t)d.v_samp[comp];
+    G.ho[tid] = d.h_of_block[tid];
+    G.vo[tid] = d.v_of_block[tid];
+    G.sx[tid] = d.h_samp[comp] * 64;
+    G.sy[tid] = d.v_samp[comp] * d.blocks_x[comp] * 64;
+    G.base[tid] = (GlobalCoef *)d.coef[comp] + ((size_t)d.v_of_block[tid] * d.blocks_x[comp] + d.h_of_block[tid]) * 64;
+    for (int j = 0; j < 4; j++) G.rect[tid][j] = d.rect[comp][j];
+    G.plane[tid] = (GlobalBytes *)d.plane[comp];
+    G.pitch[tid] = d.plane_pitch[comp];
+  }
+  if (tid >= 64 && tid < 64 + 48) {  // 3 x 64 quantisation values, four per thread
+    const int c = (tid - 64) >> 4, j = ((tid - 64) & 15) * 4;
     for (int q = 0; q < 4; q++) quant[c][j + q] = d.quant[c][j + q];
   }
-  if (tid >= 64 && tid < 128) G.zz[tid - 64] = T->zz[tid - 64];
-  if (tid == 128) {
-    G.bpm = T->bpm; G.mcus_x = T->mcus_x; G.last_ordinal = T->last_ordinal; G.use_rect = T->use_rect;
-    G.decoded_blocks = reinterpret_cast<const int32_t *>(d.scratch)[2];  // < total_blocks: corrupt stream (status 2)
-    G.total_blocks = d.total_blocks;
-    G.total_records = (uint32_t)reinterpret_cast<const int32_t *>(d.scratch)[1];
+  if (tid == 127) {
+    G.bpm = d.blocks_per_mcu;
+    G.mcus_x = d.mcus_x;
+    G.total_mcus = d.total_blocks / d.blocks_per_mcu;
+    G.last_ordinal = LastOrdinal(d);
+    int use_rect = 0;
+    for (int k = 0; k < d.blocks_per_mcu; k++) {
+      const int comp = d.comp_of_block[k];
+      use_rect |= d.rect[comp][2] > d.rect[comp][0] && d.rect[comp][3] > d.rect[comp][1];
+    }
+    G.use_rect = use_rect;
+    G.total_starts = reinterpret_cast<const int32_t *>(d.scratch)[2];
     G.fused = d.plane[d.comp_of_block[0]] != nullptr;
+    int n0 = 0;
+    for (int k = 0; k < d.blocks_per_mcu; k++)
+      if ((d.ac_sel[d.comp_of_block[k]] & 1) == 0) G.klist[n0++] = (uint8_t)k;
+    G.n0 = n0;
+    for (int k = 0; k < d.blocks_per_mcu; k++)
+      if ((d.ac_sel[d.comp_of_block[k]] & 1) != 0) G.klist[n0++] = (uint8_t)k;
   }
   __syncthreads();
-  // {first_record, lane} pairs as dwords; everything below is read through the global address space so that the
-  // loads may stay in flight across the LDS traffic and the barriers
-  const GlobalWords *index = (const GlobalWords *)(d.scratch + lay.blocks);
-  const GlobalWords *rec = (const GlobalWords *)(d.scratch + lay.records);
-  const GlobalWords *lane_words = (const GlobalWords *)(d.scratch + lay.lanes);
-  constexpr int kLaneWords = (int)(sizeof(LaneRec) / 4), kBaseWord = (int)(offsetof(LaneRec, base) / 4);
-  constexpr int kIters = kExpandPerWg / kExpandBlocks;
-  const int lb = tid >> 3, part = tid & 7;
-  uint4 *blk_v = reinterpret_cast<uint4 *>(&stage[lb][0]);
-  const int first_ordinal = (wg - d.blk_wg_start) * kExpandPerWg;
-
-  // ---- geometry and index entries of all the blocks this thread touches: issued up front (one round trip) ----
-  uint32_t first_rec[kIters], end_rec[kIters], src_lane[kIters];
-  int kk[kIters], mxs[kIters], mys[kIters];
-  uint32_t need_mask = 0;
+  const int bpm = G.bpm, mpw = McusPerWg(bpm);
+  const int m0 = (wg - d.blk_wg_start) * mpw;
+  if ((long long)m0 * bpm >= G.last_ordinal) return;  // behind the last needed MCU row (uniform)
+  const int M = min(mpw, G.total_mcus - m0);
+  const int n0 = G.n0, n1 = bpm - n0;
+  const int tasks0 = (M * n0 + 63) >> 6, tasks1 = (M * n1 + 63) >> 6;
+  GlobalWords *words = (GlobalWords *)(d.scratch + lay.clean);
+  const GlobalU32 *blk_pos = (const GlobalU32 *)(d.scratch + lay.blk_pos);
+  const GlobalI32 *blk_dc = (const GlobalI32 *)(d.scratch + lay.blk_dc);
+  const GlobalU16 *blk_seg = (const GlobalU16 *)(d.scratch + lay.blk_seg);
+  const SegRec *segs = reinterpret_cast<const SegRec *>(d.scratch + lay.segs);
+  const int part = lane & 7, lb = lane >> 3;
+  int zi[8];  // scan index of the coefficients of column `part`
 #pragma unroll
-  for (int it = 0; it < kIters; it++) {
-    const int ordinal = first_ordinal + it * kExpandBlocks + lb;
-    bool needed = ordinal < G.last_ordinal && ordinal < G.decoded_blocks;
-    int k = 0, mx = 0, my = 0;
-    if (needed) {
-      const int mcu = ordinal / G.bpm;
-      k = ordinal - mcu * G.bpm;
-      my = mcu / G.mcus_x;
-      mx = mcu - my * G.mcus_x;
-      if (G.use_rect) {
-        const int bx = mx * G.hs[k] + G.ho[k], by = my * G.vs[k] + G.vo[k];
-        needed = bx >= G.rect[k][0] && by >= G.rect[k][1] && bx < G.rect[k][2] && by < G.rect[k][3];
-      }
+  for (int r8 = 0; r8 < 8; r8++) zi[r8] = kScanIndexOfColMajor[part * 8 + r8];
+  int16_t *wcoef = &coef[wave][0];
+  int16_t *mycoef = wcoef + lane * kCoefStride;
+  for (int task = wave; task < tasks0 + tasks1; task += kBlockWaves) {
+    const bool cls = task >= tasks0;
+    const int ncls = cls ? n1 : n0;
+    const int j = (cls ? task - tasks0 : task) * 64 + lane;
+    const int mi = j / ncls, k = G.klist[(cls ? n0 : 0) + (j - mi * ncls)];
+    const int mcu = m0 + mi, ordinal = mcu * bpm + k;
+    const int my = mcu / G.mcus_x, mx = mcu - my * G.mcus_x;
+    const int bx = mx * G.hs[k] + G.ho[k], by = my * G.vs[k] + G.vo[k];
+    bool needed = mi < M && ordinal < G.last_ordinal && ordinal + 1 < G.total_starts;
+    if (G.use_rect) needed = needed && bx >= G.rect[k][0] && by >= G.rect[k][1] && bx < G.rect[k][2] && by < G.rect[k][3];
+    const int comp = G.comp[k];
+    {
+      uint4 *z = reinterpret_cast<uint4 *>(wcoef);
+      for (int i = lane; i < 64 * kCoefStride * 2 / 16; i += 64) z[i] = make_uint4(0, 0, 0, 0);
+      BlockInfo bi;
+      bi.dst = G.fused ? (uint64_t)(uintptr_t)(G.plane[k] + (size_t)(by * 8) * G.pitch[k] + (size_t)bx * 8)
+                       : (uint64_t)(uintptr_t)(G.base[k] + ((size_t)my * (size_t)G.sy[k] + (size_t)(mx * G.sx[k])));
+      bi.pitch = G.pitch[k];
+      bi.comp_needed = comp | (needed ? 256 : 0);
+      info[wave][lane] = bi;
     }
-    kk[it] = k; mxs[it] = mx; mys[it] = my;
-    first_rec[it] = end_rec[it] = src_lane[it] = 0;
+    WaveSync();
     if (needed) {
-      need_mask |= 1u << it;
-      first_rec[it] = index[2 * (size_t)ordinal];
-      src_lane[it] = index[2 * (size_t)ordinal + 1];
-      // the block's records end where the next block's begin (the write pass registers the block behind the last
-      // needed one as well); the last block of the image ends with the stream
-      end_rec[it] = ordinal + 1 < G.decoded_blocks && ordinal + 1 < G.total_blocks ? index[2 * (size_t)ordinal + 2]
-                                                                                   : G.total_records;
+      // DC level: the block's level inside its segment + the differences of all the segments before (an image is a
+      // handful of segments; only a stream of many megabytes makes this loop long)
+      int dc = blk_dc[ordinal];
+      const int seg = blk_seg[ordinal];
+      for (int s = 0; s < seg; s++) dc += segs[s].dc_total[comp];
+      mycoef[0] = (int16_t)dc;
+      DecodeBlockAc(T, words, blk_pos[ordinal], (uint32_t)G.acs[k], mycoef);
     }
-  }
-  // records of one block: three per lane cover 24, a typical block; longer ones finish in a loop
-  uint32_t w_next[3] = {0, 0, 0}, count_next = 0;
-  int dc_base_next = 0;
-  auto fetch = [&](int it) {
-    w_next[0] = w_next[1] = w_next[2] = 0;
-    count_next = 0;
-    dc_base_next = 0;
-    if ((need_mask >> it) & 1) {
-      const uint32_t end = min(end_rec[it], G.total_records);
-      count_next = first_rec[it] < end ? min(end - first_rec[it], 72u) : 0u;  // 1 DC + 63 AC + 3 ZRL + EOB
+    WaveSync();
+#pragma unroll 1
+    for (int it = 0; it < 8; it++) {
+      const int b = it * 8 + lb;
+      const BlockInfo bi = info[wave][b];
+      const bool live = (bi.comp_needed >> 8) != 0;
+      const int16_t *cb = wcoef + b * kCoefStride;
+      if (!G.fused) {
+        if (live) {  // the block as one 128-byte line of column-major coefficients, 16 bytes per lane
+          uint32_t w[4];
 #pragma unroll
-      for (int j = 0; j < 3; j++)
-        if ((uint32_t)(part + 8 * j) < count_next) w_next[j] = rec[first_rec[it] + part + 8 * j];
-      // DC: lane-local sum + level at the start of the lane that decoded it
-      if (part == 0)  // base[half][component] of the slice's record
-        dc_base_next = (int)lane_words[(size_t)(src_lane[it] >> 1) * kLaneWords + kBaseWord + (src_lane[it] & 1) * 3 +
-                                       G.comp[kk[it]]];
-    }
-  };
-  fetch(0);
-#pragma unroll
-  for (int it = 0; it < kIters; it++) {
-    if (first_ordinal + it * kExpandBlocks >= G.last_ordinal) break;  // uniform
-    const bool needed = (need_mask >> it) & 1;
-    const uint32_t w0 = w_next[0], w1 = w_next[1], w2 = w_next[2], count = count_next;
-    const int dc_base = dc_base_next;
-    if (it + 1 < kIters) fetch(it + 1);  // in flight while this block is assembled
-    blk_v[part] = make_uint4(0, 0, 0, 0);
-    __syncthreads();
-    if (needed) {
-      const uint32_t ws[3] = {w0, w1, w2};
-      bool open = true;
-#pragma unroll
-      for (int j = 0; j < 3; j++) {
-        const uint32_t i = (uint32_t)(part + 8 * j), w = ws[j];
-        if (i >= count) open = false;
-        if (open && i > 0 && (w & kRecDc)) open = false;  // defensive: never run into the next block
-        if (open && (w & kRecValid)) {
-          int v = (int)(int16_t)(w & 0xFFFF);
-          if (i == 0) v += dc_base;
-          stage[lb][G.zz[(w >> 16) & 63]] = (int16_t)v;
+          for (int q = 0; q < 4; q++) w[q] = (uint32_t)(uint16_t)cb[zi[2 * q]] | ((uint32_t)(uint16_t)cb[zi[2 * q + 1]] << 16);
+          reinterpret_cast<uint4 *>((uintptr_t)bi.dst)[part] = make_uint4(w[0], w[1], w[2], w[3]);
         }
+        continue;
       }
-      for (uint32_t i = (uint32_t)part + 24; open && i < count; i += 8) {
-        const uint32_t w = rec[first_rec[it] + i];
-        if (w & kRecDc) break;
-        if (w & kRecValid) stage[lb][G.zz[(w >> 16) & 63]] = (int16_t)(w & 0xFFFF);
-      }
-    }
-    __syncthreads();
-    if (!G.fused) {
-      if (needed) {
-        const int k = kk[it];
-        uint4 *dst = reinterpret_cast<uint4 *>((int16_t *)(G.base[k] + ((size_t)mys[it] * (size_t)G.sy[k] + (size_t)(mxs[it] * G.sx[k]))));
-        dst[part] = blk_v[part];
-      }
-      continue;
-    }
-    // ---- fused output: dequantise + inverse DCT (JpegIdctKernel's two passes on the block sitting in LDS: lane
-    // `part` owns column `part` in pass 1 and row `part` in pass 2) and store the 8x8 samples to the plane ----
-    if (needed) {
-      const int comp = G.comp[kk[it]];
-      const uint4 raw = blk_v[part];
-      const uint32_t rw[4] = {raw.x, raw.y, raw.z, raw.w};
-      int32_t in[8], o[8];
+      if (live) {
+        const int c = bi.comp_needed & 255;
+        int32_t in[8], o[8];
 #pragma unroll
-      for (int r8 = 0; r8 < 8; r8++) {
-        const int16_t cv = (int16_t)(rw[r8 >> 1] >> (16 * (r8 & 1)));
-        in[r8] = (int32_t)cv * (int32_t)quant[comp][part * 8 + r8];
-      }
-      Butterfly8(in, o);
-      int32_t *w = &trans[lb][part];
+        for (int r8 = 0; r8 < 8; r8++) in[r8] = (int32_t)cb[zi[r8]] * (int32_t)quant[c][part * 8 + r8];
+        Butterfly8(in, o);
+        int32_t *w = &trans[wave][lb][part];
 #pragma unroll
-      for (int r8 = 0; r8 < 8; r8++) w[r8 * 8] = Descale(o[r8], CONST_BITS - PASS1_BITS);
-    }
-    __syncthreads();
-    if (needed) {
-      const int k = kk[it];
-      const int4 *rp = reinterpret_cast<const int4 *>(&trans[lb][part * 8]);
-      const int4 a = rp[0], b = rp[1];
-      int32_t in[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-      int32_t o[8];
-      Butterfly8(in, o);
-      const int S = CONST_BITS + PASS1_BITS + 3;
-      const uint32_t lo = RangeLimit(Descale(o[0], S)) | (RangeLimit(Descale(o[1], S)) << 8) |
-                          (RangeLimit(Descale(o[2], S)) << 16) | (RangeLimit(Descale(o[3], S)) << 24);
-      const uint32_t hi = RangeLimit(Descale(o[4], S)) | (RangeLimit(Descale(o[5], S)) << 8) |
-                          (RangeLimit(Descale(o[6], S)) << 16) | (RangeLimit(Descale(o[7], S)) << 24);
-      const int bx = mxs[it] * G.hs[k] + G.ho[k], by = mys[it] * G.vs[k] + G.vo[k];
-      typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-      using GlobalPair = u32x2_t __attribute__((address_space(1)));
-      GlobalPair *dst = (GlobalPair *)(G.plane[k] + (size_t)(by * 8 + part) * G.pitch[k] + (size_t)bx * 8);
-      *dst = u32x2_t{lo, hi};
+        for (int r8 = 0; r8 < 8; r8++) w[r8 * 8] = Descale(o[r8], CONST_BITS - PASS1_BITS);
+      }
+      WaveSync();
+      if (live) {
+        const int4 *rp = reinterpret_cast<const int4 *>(&trans[wave][lb][part * 8]);
+        const int4 a = rp[0], bq = rp[1];
+        int32_t in[8] = {a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w};
+        int32_t o[8];
+        Butterfly8(in, o);
+        const int S = CONST_BITS + PASS1_BITS + 3;
+        const uint32_t lo32 = RangeLimit(Descale(o[0], S)) | (RangeLimit(Descale(o[1], S)) << 8) |
+                              (RangeLimit(Descale(o[2], S)) << 16) | (RangeLimit(Descale(o[3], S)) << 24);
+        const uint32_t hi32 = RangeLimit(Descale(o[4], S)) | (RangeLimit(Descale(o[5], S)) << 8) |
+                              (RangeLimit(Descale(o[6], S)) << 16) | (RangeLimit(Descale(o[7], S)) << 24);
+        typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+        using GlobalPair = u32x2_t __attribute__((address_space(1)));
+        GlobalPair *dst = (GlobalPair *)((GlobalBytes *)(uintptr_t)bi.dst + (size_t)part * bi.pitch);
+        *dst = u32x2_t{lo32, hi32};
+      }
+      WaveSync();
     }
   }
 }
@@ -1261,17 +844,20 @@ daliamdResult_t daliamdJpegHuffmanSetup(daliamdJpegHuffDesc *descs_host, int n, 
                         "daliamdJpegHuffmanSetup: sample %d: coefficient arrays must be 16-byte aligned", i);
       }
     }
-    for (int t = 0; t < 4; t++)  // record capacity: every symbol consumes at least two bits
+    for (int t = 0; t < 4; t++)  // a block takes at least four bits then: bounds the block-start lists
       DALIAMD_REQUIRE(d.bits[t][0] == 0, DALIAMD_ERROR_UNSUPPORTED,
                       "daliamdJpegHuffmanSetup: sample %d: Huffman table %d has a 1-bit code (decode it on the host)", i, t);
     d.tile_start = tiles;
     d.num_tiles = daliamd::NumTiles((int)(reinterpret_cast<uintptr_t>(d.ecs) & 15), d.ecs_len);
     d.seg_start = segs;
     d.num_segments = daliamd::NumSegments(d.ecs_len);
+    DALIAMD_REQUIRE(d.num_segments <= 65535, DALIAMD_ERROR_UNSUPPORTED,
+                    "daliamdJpegHuffmanSetup: sample %d: entropy-coded segment too long (decode it on the host)", i);
     d.blk_wg_start = bwgs;
     tiles += d.num_tiles;
     segs += d.num_segments;
-    bwgs += (d.total_blocks + daliamd::kExpandPerWg - 1) / daliamd::kExpandPerWg;
+    const int mcus = d.total_blocks / d.blocks_per_mcu, mpw = daliamd::McusPerWg(d.blocks_per_mcu);
+    bwgs += (mcus + mpw - 1) / mpw;
   }
   *num_tiles = tiles;
   *num_segments = segs;
@@ -1298,11 +884,9 @@ static daliamdResult_t LaunchHuffman(daliamdStream_t stream, const daliamdJpegHu
   DALIAMD_HIP_CHECK(mark());
   hipLaunchKernelGGL(PropagateKernel, dim3(n), dim3(kSegThreads), 0, s, descs_dev);
   DALIAMD_HIP_CHECK(mark());
-  hipLaunchKernelGGL(WriteKernel, dim3(seg_grid), dim3(kWriteThreads), 0, s, descs_dev, n, num_segments);
+  hipLaunchKernelGGL(DcKernel, dim3(seg_grid), dim3(kDcThreads), 0, s, descs_dev, n, num_segments);
   DALIAMD_HIP_CHECK(mark());
-  hipLaunchKernelGGL(DcScanKernel, dim3(seg_grid), dim3(kWriteThreads), 0, s, descs_dev, n, num_segments);
-  DALIAMD_HIP_CHECK(mark());
-  hipLaunchKernelGGL(ExpandKernel, dim3(XcdGrid(num_block_workgroups)), dim3(kExpandThreads), 0, s, descs_dev, n,
+  hipLaunchKernelGGL(BlockKernel, dim3(XcdGrid(num_block_workgroups)), dim3(kBlockThreads), 0, s, descs_dev, n,
                      num_block_workgroups);
   DALIAMD_HIP_CHECK(mark());
   DALIAMD_HIP_CHECK(hipGetLastError());

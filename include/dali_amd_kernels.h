@@ -129,10 +129,10 @@ DALIAMD_API daliamdResult_t daliamdJpegIdctRun(daliamdStream_t stream, const dal
  *   - zero-fills `status` before the launch (the coefficient arrays need no initialisation: every block that is
  *     decoded is written exactly once, as a full 128-byte line),
  *   - provides `scratch`: daliamdJpegHuffmanScratchBytes(ecs_len, total_blocks) bytes, 16-byte aligned (clean
- *     stream, code tables, per-slice decoder states, the record stream of the write pass, the block index),
+ *     stream, code tables, per-slice decoder states, the block starts of every segment, 10 bytes per block),
  *   - calls daliamdJpegHuffmanSetup on the host table, copies it to the device, calls daliamdJpegHuffmanRun.
  * The work is cut into image-independent pieces (16 KB tiles for the byte un-stuffing, 61 KB segments of 256-byte
- * slices for the self-synchronising parallel decode), so a batch of very differently sized streams still fills
+ * slices for the self-synchronising parallel decode, one lane per 8x8 block for the values), so a batch of very differently sized streams still fills
  * the device.  After the launch *status is 0 on success, 2 when the segment holds fewer blocks than the frame
  * header promises (truncated / corrupt stream: decode it with the host decoder to get the diagnosis).
  * -------------------------------------------------------------------------------------------- */
@@ -150,7 +150,7 @@ typedef struct {
   int32_t h_samp[3], v_samp[3];
   int32_t tile_start, num_tiles;   /* filled by Setup: un-stuffing workgroups of this stream       */
   int32_t seg_start, num_segments; /* filled by Setup: decoding workgroups of this stream          */
-  int32_t blk_wg_start, reserved;  /* filled by Setup: block-expansion workgroups of this stream   */
+  int32_t blk_wg_start, reserved;  /* filled by Setup: block-decoding workgroups of this stream    */
   uint8_t comp_of_block[12];  /* component of the k-th block of an MCU                             */
   uint8_t h_of_block[12], v_of_block[12]; /* its position inside the component's MCU footprint     */
   uint8_t dc_sel[4], ac_sel[4];  /* per component: table selector, 0 or 1                           */
@@ -176,14 +176,14 @@ DALIAMD_API daliamdResult_t daliamdJpegHuffmanScratchBytes(int ecs_len, int tota
  * tile_start/num_tiles/seg_start/num_segments/blk_wg_start, returns the three grid sizes. */
 DALIAMD_API daliamdResult_t daliamdJpegHuffmanSetup(daliamdJpegHuffDesc *descs_host, int n, int *num_tiles,
                                                     int *num_segments, int *num_block_workgroups);
-/* Seven launches: prepare (un-stuff count + code tables), un-stuff scatter, synchronise, propagate, write (records),
- * DC scan, expand. */
+/* Six launches: prepare (un-stuff count + code tables), un-stuff scatter, synchronise (positions + block starts),
+ * propagate (segment hand-over, block ordinals), DC (one lane per block), block decode + dequantisation + IDCT. */
 DALIAMD_API daliamdResult_t daliamdJpegHuffmanRun(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev, int n,
                                                   int num_tiles, int num_segments, int num_block_workgroups);
-/* Same launches with events[0..7] (created with timing enabled) recorded before each kernel and after the last:
- * events[i] .. events[i+1] brackets kernel i of {prepare, un-stuff scatter, synchronise, propagate, write, DC scan,
- * expand}.  For benchmarks. */
-#define DALIAMD_JPEG_HUFFMAN_KERNELS 7
+/* Same launches with events[0..6] (created with timing enabled) recorded before each kernel and after the last:
+ * events[i] .. events[i+1] brackets kernel i of {prepare, un-stuff scatter, synchronise, propagate, DC, block}.
+ * For benchmarks. */
+#define DALIAMD_JPEG_HUFFMAN_KERNELS 6
 DALIAMD_API daliamdResult_t daliamdJpegHuffmanRunProfiled(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev,
                                                           int n, int num_tiles, int num_segments,
                                                           int num_block_workgroups, daliamdEvent_t *events);

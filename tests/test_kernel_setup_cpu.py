@@ -98,8 +98,8 @@ def test_huffman_setup_sizes_the_three_grids_and_validates():
     tiles, segs, bwg = C.c_int(), C.c_int(), C.c_int()
     assert lib.daliamdJpegHuffmanSetup(descs, 3, C.byref(tiles), C.byref(segs), C.byref(bwg)) == 0
     assert [d.tile_start for d in descs] == [0, 1, 8] and tiles.value == 11          # 16 KB tiles
-    assert [d.seg_start for d in descs] == [0, 1, 5] and segs.value == 7             # 116 slices of 256 bytes
-    assert [d.blk_wg_start for d in descs] == [0, 3, 27] and bwg.value == 37         # 256 blocks per workgroup
+    assert [d.seg_start for d in descs] == [0, 1, 3] and segs.value == 4             # 244 slices of 256 bytes
+    assert [d.blk_wg_start for d in descs] == [0, 1, 9] and bwg.value == 13          # 128 MCUs of 6 blocks per workgroup
     bad = (capi.JpegHuffDesc * 1)(_huff_desc(total_blocks=601))                      # not a whole number of MCUs
     assert lib.daliamdJpegHuffmanSetup(bad, 1, C.byref(tiles), C.byref(segs), C.byref(bwg)) != 0
     one_bit = (capi.JpegHuffDesc * 1)(_huff_desc(bits0=1))                           # a 1-bit code: host decoder's job
