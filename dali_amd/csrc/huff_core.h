@@ -12,6 +12,14 @@
 #else
 #define HUFF_HD inline
 #endif
+// A value that is the same in every lane of the wave: kept in a scalar register on the device.  Besides saving vector
+// registers this matters for the waits: a value loaded from LDS right before a loop that itself writes to LDS would
+// otherwise be waited for (lgkmcnt(0), i.e. for the loop's own store as well) at its use in EVERY iteration.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define HUFF_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+#else
+#define HUFF_UNIFORM(x) ((uint32_t)(x))
+#endif
 
 namespace daliamd {
 
@@ -187,39 +195,49 @@ uint32_t LongCode(const Tables &L, uint32_t slot, uint32_t peek, bool is_dc) {
 // few symbols past the end).  A block starts where the previous one ends; the very first block of a stream starts
 // at bit 0, which only the decode that begins there sees.  Returns the number of block starts.
 //
-// Every step reports the position it reached for the CURRENT index; the index only advances when the step ended a
-// block (the last report of an index is the one that counts), so the caller's store needs no branch and no execution
-// mask and is off the dependency chain of the step.
+// Every step reports the position it reached for the CURRENT index - store(j, rem, ended) - and the index only
+// advances when the step ended a block (`ended`; the last report of an index is the one that counts).  A store into
+// LDS simply writes every time: no branch, no execution mask, off the dependency chain of the step.  A store that is
+// expensive (global memory) looks at `ended`.
 template <typename Tables, typename Words, typename Store>
 HUFF_HD int SyncDecodeRange(const Tables &L, Words words, DecodeState &st, uint32_t end_bits, Store store) {
   int nb = 0;
   uint32_t c = st.c, z = st.z;
   int rem = (int)(end_bits - st.pos);  // bits left before the end of the slice (<= 0: done)
   if (st.pos == 0) {                   // the stream's first block
-    store(0, rem);
+    store(0, rem, true);
     nb = 1;
   }
   // bit window: hi:lo = stream bits [32k, 32k+64), `off` of hi's bits already consumed; the following dword is in flight
   int k = (int)(st.pos >> 5);
   uint32_t off = st.pos & 31;
   uint32_t hi = Bswap32(words[k]), lo = Bswap32(words[k + 1]), nxt = words[k + 2];
-  const uint32_t dc_mask = L.dc_mask, ac_mask = L.ac_mask, bpm = (uint32_t)L.bpm;
+  const uint32_t dc_mask = HUFF_UNIFORM(L.dc_mask), ac_mask = HUFF_UNIFORM(L.ac_mask), bpm = HUFF_UNIFORM(L.bpm);
+  // The report of a step is handed to `store` right BEHIND the table look-up of the next step: an LDS store issued
+  // in front of the look-up would sit in front of it in the (in-order) LDS queue and add its service time to the
+  // dependency chain of every step; behind it, it drains while the step computes.
+  int s_nb = nb, s_rem = rem;
+  bool s_ended = false;
   while (rem > 0) {
     const uint32_t peek = (uint32_t)(((((uint64_t)hi << 32) | lo) << off) >> 32);
     const bool is_dc = z == 0;
     const uint32_t slot = (((is_dc ? dc_mask : ac_mask) >> c) & 1u) + (is_dc ? 0u : 2u);
     uint32_t e = L.t32[slot][peek >> (32 - kFastBits)];
+    store(s_nb, s_rem, s_ended);
     if (__builtin_expect(e == 0, 0)) {
       const uint32_t e16 = LongCode(L, slot, peek, is_dc);
       e = SyncGroup(e16 & 127, (e16 >> 7) & 31, 1);
     }
-    // the group may be taken when the symbols before its last one leave the block open
-    const uint32_t zprev = (e >> 14) & 63;
+    // The group may be taken when the symbols before its last one leave the block open.  (Round 1 also required the
+    // last symbol to start inside the range; measured, that costs more per step than it saves in relaxation rounds -
+    // the rounds of the bench set are identical with and without it.)
+    const int zprev = (int)((e >> 14) & 63), uprev = (int)((e >> 20) & 15);
+    const int ok = (int)z + zprev - 64;
     uint32_t used = (e >> 7) & 31, zinc = e & 127;
-    if (__builtin_expect(z + zprev >= 64, 0)) {  // rare: take the first symbol only
+    if (__builtin_expect(ok >= 0, 0)) {  // rare: take the first symbol only
       const bool three = ((e >> 12) & 3) == 3;
-      used = three ? (e >> 24) & 15 : (e >> 20) & 15;
-      zinc = three ? ((e >> 28) & 15) + 1 : zprev;
+      used = three ? (e >> 24) & 15 : (uint32_t)uprev;
+      zinc = three ? ((e >> 28) & 15) + 1 : (uint32_t)zprev;
     }
     rem -= (int)used;
     off += used;
@@ -232,12 +250,15 @@ HUFF_HD int SyncDecodeRange(const Tables &L, Words words, DecodeState &st, uint3
       off -= 32;
     }
     const bool end_of_block = z >= 64;
-    store(nb, rem);
+    s_nb = nb;
+    s_rem = rem;
+    s_ended = end_of_block;
     const uint32_t c1 = c + 1 == bpm ? 0 : c + 1;
     z = end_of_block ? 0 : z;
     c = end_of_block ? c1 : c;
     nb += end_of_block ? 1 : 0;
   }
+  store(s_nb, s_rem, s_ended);
   st.pos = end_bits - (uint32_t)rem;
   st.c = c;
   st.z = z;
@@ -271,15 +292,33 @@ HUFF_HD int DecodeDc(const Tables &L, Words words, uint32_t pos, uint32_t sel, u
   return Extend(peek >> (32 - used), s);
 }
 
-// AC coefficients of one block: symbols from bit `pos` (just behind the DC symbol) until the block is full or an
-// end-of-block arrives.  coef[z] (z = zig-zag index 1..63) receives the values; coef[64] is a scratch slot that
+// Bit window over the clean stream: hi:lo = stream bits [32k, 32k+64), `off` of hi's bits already consumed; the dword
+// behind them is in flight (`nxt`, still little-endian).  Opening a window only issues its three loads, so a caller
+// can open the window of its NEXT piece of work before it finishes the current one.
+struct BitWindow {
+  int k;
+  uint32_t off, hi, lo, nxt;
+};
+template <typename Words>
+HUFF_HD BitWindow OpenWindow(Words words, uint32_t pos) {
+  BitWindow w;
+  w.k = (int)(pos >> 5);
+  w.off = pos & 31;
+  w.hi = words[w.k];  // byte-swapped at first use
+  w.lo = words[w.k + 1];
+  w.nxt = words[w.k + 2];
+  return w;
+}
+
+// AC coefficients of one block: symbols from the window's position (just behind the DC symbol) until the block is full
+// or an end-of-block arrives.  coef[z] (z = zig-zag index 1..63) receives the values; coef[64] is a scratch slot that
 // swallows what does not carry a coefficient (end-of-block, ZRL past the end, a run that overshoots the block in a
 // corrupt stream), so the store needs no condition.  The block must be zero-filled by the caller.
 template <typename Tables, typename Words, typename Coef>
-HUFF_HD void DecodeBlockAc(const Tables &L, Words words, uint32_t pos, uint32_t ac_slot, Coef coef) {
-  int k = (int)(pos >> 5);
-  uint32_t off = pos & 31;
-  uint32_t hi = Bswap32(words[k]), lo = Bswap32(words[k + 1]), nxt = words[k + 2];
+HUFF_HD void DecodeBlockAc(const Tables &L, Words words, const BitWindow &win, uint32_t ac_slot, Coef coef) {
+  int k = win.k;
+  uint32_t off = win.off;
+  uint32_t hi = Bswap32(win.hi), lo = Bswap32(win.lo), nxt = win.nxt;
   uint32_t z = 1;
   while (z < 64) {
     const uint32_t peek = (uint32_t)(((((uint64_t)hi << 32) | lo) << off) >> 32);
@@ -299,6 +338,10 @@ HUFF_HD void DecodeBlockAc(const Tables &L, Words words, uint32_t pos, uint32_t 
       off -= 32;
     }
   }
+}
+template <typename Tables, typename Words, typename Coef>
+HUFF_HD void DecodeBlockAc(const Tables &L, Words words, uint32_t pos, uint32_t ac_slot, Coef coef) {
+  DecodeBlockAc(L, words, OpenWindow(words, pos), ac_slot, coef);
 }
 
 // zig-zag scan order expressed in column-major block positions (= the transposed zig-zag): coefficient z of the scan

