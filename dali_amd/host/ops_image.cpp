@@ -650,6 +650,174 @@ class ImageDecoderCropMixed : public ImageDecoderMixed {
   bool round_;
 };
 
+// ---- decoders.image_slice: SliceAttr window (named start / end / shape arguments or anchor + shape inputs) --------
+// (decoder_schema.cc:200-252, generic/slice/slice_attr.h:40-352, slice_attr.cc:21-110)
+DALI_SCHEMA(SliceAttr)
+    .DocStr("Slice attributes placeholder")
+    .MakeInternal()
+    .AddOptionalArg("axes", "Order of dimensions used for the anchor and shape slice inputs as dimension indices.",
+                    ArgValue::IntVec({1, 0}))
+    .AddOptionalArg("axis_names", "Order of the dimensions used for the anchor and shape slice inputs, as described in "
+                    "layout.  If a value is provided, it has a higher priority than `axes`.", ArgValue::Str("WH"))
+    .AddOptionalTypeArg("start", "Start coordinates of the slice.", ArgType::INT_VEC, true)
+    .AddOptionalTypeArg("rel_start", "Start relative coordinates of the slice (range [0.0 - 1.0]).", ArgType::FLOAT_VEC, true)
+    .AddOptionalTypeArg("end", "End coordinates of the slice.", ArgType::INT_VEC, true)
+    .AddOptionalTypeArg("rel_end", "End relative coordinates of the slice (range [0.0 - 1.0]).", ArgType::FLOAT_VEC, true)
+    .AddOptionalTypeArg("shape", "Shape of the slice.", ArgType::INT_VEC, true)
+    .AddOptionalTypeArg("rel_shape", "Relative shape of the slice (range [0.0 - 1.0]).", ArgType::FLOAT_VEC, true)
+    .AddOptionalArg("normalized_anchor", "Determines whether the anchor positional input should be interpreted as "
+                    "normalized (range [0.0, 1.0]) or as absolute coordinates (float anchors only).", ArgValue::Bool(true))
+    .AddOptionalArg("normalized_shape", "Determines whether the shape positional input should be interpreted as "
+                    "normalized (range [0.0, 1.0]) or as absolute coordinates (float shapes only).", ArgValue::Bool(true));
+
+DALI_SCHEMA(decoders__ImageSlice)
+    .DocStr("Decodes images and extracts regions of interest.  The slice is given by start and end coordinates or start "
+            "coordinates and shape (`start` / `rel_start`, `end` / `rel_end`, `shape` / `rel_shape`), or by two extra "
+            "positional inputs `anchor` and `shape` (normalised by default, \"WH\" order).  Only the window is "
+            "decoded.\n\nThe output is in HWC layout.")
+    .NumInput(1, 3)
+    .NumOutput(1)
+    .AddParent("decoders__Image")
+    .AddParent("SliceAttr");
+DALI_SCHEMA(ImageDecoderSlice).DocStr("Legacy alias of decoders.image_slice").NumInput(1, 3).NumOutput(1)
+    .AddParent("decoders__ImageSlice");
+DALI_SCHEMA(experimental__decoders__ImageSlice).DocStr("Alias of decoders.image_slice").NumInput(1, 3).NumOutput(1)
+    .AddParent("decoders__ImageSlice");
+
+class ImageDecoderSliceMixed : public ImageDecoderMixed {
+ public:
+  explicit ImageDecoderSliceMixed(const OpSpec &spec) : ImageDecoderMixed(spec, false) {
+    const bool start = spec.ArgumentDefined("start"), rel_start = spec.ArgumentDefined("rel_start");
+    DALI_ENFORCE(!(start && rel_start), "\"start\" and \"rel_start\" arguments are mutually exclusive");
+    const int ends = spec.ArgumentDefined("end") + spec.ArgumentDefined("rel_end") + spec.ArgumentDefined("shape") +
+                     spec.ArgumentDefined("rel_shape");
+    DALI_ENFORCE(ends <= 1, "\"end\", \"rel_end\", \"shape\", and \"rel_shape\" arguments are mutually exclusive");
+    named_ = start || rel_start || ends > 0;
+    // axes of the slice arguments in the HWC image: axis_names wins over axes (AxisArgs, operators/util/axis_args.h)
+    std::string names = spec.GetString("axis_names");
+    if (spec.ArgumentDefined("axis_names") || !spec.ArgumentDefined("axes")) {
+      for (char c : names) {
+        DALI_ENFORCE(c == 'H' || c == 'W', "decoders.image_slice: axis \"", std::string(1, c), "\" is not a spatial axis "
+                     "of an HWC image");
+        axes_.push_back(c == 'H' ? 0 : 1);
+      }
+    } else {
+      for (int64_t a : spec.GetIntVec("axes")) {
+        if (a < 0) a += 3;
+        DALI_ENFORCE(a == 0 || a == 1, "decoders.image_slice: only the spatial axes (0, 1) of an HWC image can be sliced");
+        axes_.push_back((int)a);
+      }
+    }
+    DALI_ENFORCE(axes_.size() <= 2 && (axes_.size() < 2 || axes_[0] != axes_[1]), "Axis indices must be unique");
+  }
+
+ protected:
+  void ComputeRois(const Workspace &ws, int n) override {
+    const bool positional = ws.NumInput() == 3;
+    DALI_ENFORCE(ws.NumInput() == 1 || positional, "decoders.image_slice takes the encoded images and, optionally, the "
+                 "anchor AND the shape of the slice");
+    DALI_ENFORCE(!(positional && named_), "Named slice arguments (start / end / shape ...) are incompatible with the "
+                 "positional anchor and shape inputs");
+    std::vector<std::vector<float>> a, b;   // per sample: start-like and end-like values per listed axis
+    enum { kNone, kAbs, kRel } a_kind = kNone;
+    enum { kEndNone, kEnd, kRelEnd, kShape, kRelShape } b_kind = kEndNone;
+    bool norm_anchor = false, norm_shape = false;
+    if (positional) {
+      a = InputAsFloat(ws.Input(1), n, &norm_anchor);
+      b = InputAsFloat(ws.Input(2), n, &norm_shape);
+      DALI_ENFORCE(ws.Input(1).type() == ws.Input(2).type(), "Anchor and shape should have the same type. Got: ",
+                   TypeName(ws.Input(1).type()), " and ", TypeName(ws.Input(2).type()));
+      norm_anchor = norm_anchor && spec_.GetBool("normalized_anchor");
+      norm_shape = norm_shape && spec_.GetBool("normalized_shape");
+    } else {
+      if (spec_.ArgumentDefined("start")) { a = GetPerSampleFloatVec(spec_, ws, "start", n); a_kind = kAbs; }
+      else if (spec_.ArgumentDefined("rel_start")) { a = GetPerSampleFloatVec(spec_, ws, "rel_start", n); a_kind = kRel; }
+      if (spec_.ArgumentDefined("end")) { b = GetPerSampleFloatVec(spec_, ws, "end", n); b_kind = kEnd; }
+      else if (spec_.ArgumentDefined("rel_end")) { b = GetPerSampleFloatVec(spec_, ws, "rel_end", n); b_kind = kRelEnd; }
+      else if (spec_.ArgumentDefined("shape")) { b = GetPerSampleFloatVec(spec_, ws, "shape", n); b_kind = kShape; }
+      else if (spec_.ArgumentDefined("rel_shape")) { b = GetPerSampleFloatVec(spec_, ws, "rel_shape", n); b_kind = kRelShape; }
+    }
+    for (int i = 0; i < n; i++) {
+      const int64_t extent[2] = {upright_hw_[2 * i], upright_hw_[2 * i + 1]};
+      int64_t anchor[2] = {0, 0}, shape[2] = {extent[0], extent[1]};
+      for (size_t k = 0; k < axes_.size(); k++) {
+        const int dim = axes_[k];
+        const double ext = (double)extent[dim];
+        double anchor_val = 0, end_val = ext;
+        if (positional) {
+          DALI_ENFORCE(a[i].size() == axes_.size() && b[i].size() == axes_.size(), "Expected ", axes_.size(),
+                       " elements for slice arguments (start/shape). Got ", a[i].size());
+          anchor_val = a[i][k];
+          double shape_val = b[i][k];
+          if (norm_anchor && norm_shape) {  // one multiplication after the sum (slice_attr.h:312-315)
+            end_val = (anchor_val + shape_val) * ext;
+            anchor_val *= ext;
+          } else {
+            if (norm_anchor) anchor_val *= ext;
+            if (norm_shape) shape_val *= ext;
+            end_val = anchor_val + shape_val;
+          }
+        } else {
+          if (a_kind != kNone && !a[i].empty()) {
+            DALI_ENFORCE(a[i].size() == axes_.size(), "Expected ", axes_.size(), " elements for the slice start");
+            anchor_val = a_kind == kAbs ? (double)a[i][k] : (double)a[i][k] * ext;
+          }
+          if (b_kind != kEndNone && !b[i].empty()) {
+            DALI_ENFORCE(b[i].size() == axes_.size(), "Expected ", axes_.size(), " elements for the slice end / shape");
+            const double v = b[i][k];
+            if (b_kind == kEnd) end_val = v;
+            else if (b_kind == kRelEnd) end_val = v * ext;
+            else if (b_kind == kShape) { DALI_ENFORCE(v >= 0, "shape value out of range. Got: ", v); end_val = anchor_val + v; }
+            else if (a_kind == kRel && !a[i].empty()) {  // rel_start + rel_shape: multiply once after the sum
+              DALI_ENFORCE(v >= 0, "negative shapes are not allowed. Got: ", v);
+              end_val = ((double)a[i][k] + v) * ext;
+            } else { DALI_ENFORCE(v >= 0, "negative shapes are not allowed. Got: ", v); end_val = anchor_val + v * ext; }
+          }
+        }
+        DALI_ENFORCE(end_val >= anchor_val, "end coordinates can't be before start coordinates. Got: start=", anchor_val,
+                     " end=", end_val);
+        anchor[dim] = std::llround(anchor_val);
+        shape[dim] = std::llround(end_val) - anchor[dim];
+      }
+      // CropWindow::EnforceInRange (roi_image_decoder.h:36-45)
+      DALI_ENFORCE(anchor[0] >= 0 && anchor[1] >= 0 && shape[0] > 0 && shape[1] > 0 && anchor[0] + shape[0] <= extent[0] &&
+                       anchor[1] + shape[1] <= extent[1],
+                   "Cropping window [", anchor[0], ":", anchor[0] + shape[0], ", ", anchor[1], ":", anchor[1] + shape[1],
+                   "] is out of the bounds of the ", extent[0], "x", extent[1], " image");
+      rois_[4 * i] = (int32_t)anchor[0]; rois_[4 * i + 1] = (int32_t)anchor[1];
+      rois_[4 * i + 2] = (int32_t)shape[0]; rois_[4 * i + 3] = (int32_t)shape[1];
+    }
+  }
+
+ private:
+  // a CPU input of 1-D samples as floats; *is_float: the element type is a floating-point type
+  static std::vector<std::vector<float>> InputAsFloat(const TensorList &t, int n, bool *is_float) {
+    DALI_ENFORCE(t.device() == StorageDevice::CPU, "decoders.image_slice: the anchor and shape inputs must be CPU tensors");
+    DALI_ENFORCE(t.num_samples() == n, "The anchor / shape inputs must have one sample per image");
+    *is_float = t.type() == DALI_FLOAT || t.type() == DALI_FLOAT64;
+    std::vector<std::vector<float>> out(n);
+    for (int i = 0; i < n; i++) {
+      const int64_t cnt = volume(t.shape(i));
+      out[i].resize(cnt);
+      for (int64_t k = 0; k < cnt; k++) {
+        switch (t.type()) {
+          case DALI_FLOAT: out[i][k] = static_cast<const float *>(t.raw(i))[k]; break;
+          case DALI_FLOAT64: out[i][k] = (float)static_cast<const double *>(t.raw(i))[k]; break;
+          case DALI_INT32: out[i][k] = (float)static_cast<const int32_t *>(t.raw(i))[k]; break;
+          case DALI_INT64: out[i][k] = (float)static_cast<const int64_t *>(t.raw(i))[k]; break;
+          default: DALI_FAIL("Unsupported type of anchor and shape arguments: ", TypeName(t.type()));
+        }
+      }
+    }
+    return out;
+  }
+  bool named_;
+  std::vector<int> axes_;
+};
+DALI_REGISTER_OPERATOR(decoders__ImageSlice, ImageDecoderSliceMixed, MIXED);
+DALI_REGISTER_OPERATOR(ImageDecoderSlice, ImageDecoderSliceMixed, MIXED);
+DALI_REGISTER_OPERATOR(experimental__decoders__ImageSlice, ImageDecoderSliceMixed, MIXED);
+
 DALI_REGISTER_OPERATOR(decoders__ImageRandomCrop, ImageDecoderRandomCropMixed, MIXED);
 DALI_REGISTER_OPERATOR(ImageDecoderRandomCrop, ImageDecoderRandomCropMixed, MIXED);
 DALI_REGISTER_OPERATOR(experimental__decoders__ImageRandomCrop, ImageDecoderRandomCropMixed, MIXED);

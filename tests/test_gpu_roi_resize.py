@@ -286,3 +286,79 @@ def test_resize_crop_mirror_per_sample_mirror_and_fused_normalize(files):
         rs = O.resample_u8(r, out_hw, roi=roi)
         ref = O.cmn_u8(rs, (0, 0), (64, 64), mean=mean, inv_std=inv, layout="CHW", dtype=O.F32)
         assert np.array_equal(got[i], ref), i     # the fused kernel rounds to u8 exactly where the two-op chain does
+
+
+def _llround(v):
+    return int(np.floor(v + 0.5)) if v >= 0 else -int(np.floor(-v + 0.5))
+
+
+@pytest.mark.parametrize("case", ["rel_start_rel_shape", "start_end", "start_shape_axes_hw", "positional_normalized",
+                                  "positional_absolute_int"])
+def test_image_slice_equals_decode_then_slice(files, case):
+    """decoders.image_slice (decoder_schema.cc:200-252, slice_attr.h:40-352): every way of giving the window decodes
+    exactly that window; anchor / end are rounded separately (llround) like the reference's CropWindowGenerator."""
+    from dali_amd import fn
+    from dali_amd.pipeline import Pipeline
+    bs = len(files)
+    ref = _decoded(files)
+    rng = np.random.default_rng(5)
+    pipe = Pipeline(batch_size=bs, num_threads=3, device_id=0, prefetch_queue_depth=1)
+    expect = []
+    with pipe:
+        enc, _ = fn.readers.file(files=files)
+        if case == "rel_start_rel_shape":     # default axis order "WH"
+            out = fn.decoders.image_slice(enc, device="mixed", rel_start=[0.25, 0.1], rel_shape=[0.5, 0.6])
+            for r in ref:
+                H, W = r.shape[:2]
+                x0, x1 = _llround(0.25 * W), _llround((0.25 + 0.5) * W)
+                y0, y1 = _llround(np.float32(0.1) * H), _llround((np.float64(np.float32(0.1)) + np.float64(np.float32(0.6))) * H)
+                expect.append(r[y0:y1, x0:x1])
+        elif case == "start_end":
+            out = fn.decoders.image_slice(enc, device="mixed", start=[10, 5], end=[40, 47])
+            expect = [r[5:47, 10:40] for r in ref]
+        elif case == "start_shape_axes_hw":
+            out = fn.decoders.image_slice(enc, device="mixed", start=[7, 3], shape=[33, 20], axis_names="HW")
+            expect = [r[7:40, 3:23] for r in ref]
+        elif case == "positional_normalized":
+            anchors = rng.uniform(0, 0.4, (bs, 2)).astype(np.float32)
+            shapes = rng.uniform(0.2, 0.5, (bs, 2)).astype(np.float32)
+            a = fn.external_source(name="a")
+            s = fn.external_source(name="s")
+            out = fn.decoders.image_slice(enc, a, s, device="mixed")
+            for r, an, sh in zip(ref, anchors, shapes):
+                H, W = r.shape[:2]
+                x0, x1 = _llround(float(an[0]) * W), _llround((float(an[0]) + float(sh[0])) * W)
+                y0, y1 = _llround(float(an[1]) * H), _llround((float(an[1]) + float(sh[1])) * H)
+                expect.append(r[y0:y1, x0:x1])
+        else:
+            anchors = rng.integers(0, 20, (bs, 2)).astype(np.int32)
+            shapes = rng.integers(8, 28, (bs, 2)).astype(np.int32)
+            a = fn.external_source(name="a")
+            s = fn.external_source(name="s")
+            out = fn.decoders.image_slice(enc, a, s, device="mixed", axis_names="HW")
+            expect = [r[an[0]:an[0] + sh[0], an[1]:an[1] + sh[1]] for r, an, sh in zip(ref, anchors, shapes)]
+        pipe.set_outputs(out)
+    pipe.build()
+    if case.startswith("positional"):
+        pipe.feed_input("a", anchors)
+        pipe.feed_input("s", shapes)
+    (res,) = pipe.run()
+    for i in range(bs):
+        got = res[i].as_cpu()
+        assert got.shape == expect[i].shape, (case, i, got.shape, expect[i].shape)
+        assert np.array_equal(got, expect[i]), (case, i)
+
+
+def test_image_slice_argument_errors(files):
+    from dali_amd import fn
+    from dali_amd.pipeline import Pipeline
+    for kw, msg in ((dict(start=[0, 0], rel_start=[0.0, 0.0]), "mutually exclusive"),
+                    (dict(end=[5, 5], shape=[5, 5]), "mutually exclusive"),
+                    (dict(start=[0, 0], shape=[10000, 4]), "out of the bounds")):
+        pipe = Pipeline(batch_size=len(files), num_threads=2, device_id=0, prefetch_queue_depth=1)
+        with pipe:
+            enc, _ = fn.readers.file(files=files)
+            pipe.set_outputs(fn.decoders.image_slice(enc, device="mixed", **kw))
+        with pytest.raises(RuntimeError, match=msg):
+            pipe.build()
+            pipe.run()
