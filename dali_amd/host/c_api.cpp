@@ -5,6 +5,8 @@
 
 #include "dali_amd_host.h"
 #include "host_common.h"
+#include <dlfcn.h>
+
 #include "pipeline.h"
 
 using namespace daliamd_host;
@@ -106,6 +108,21 @@ API int daliamdSchemaInfo(const char *name, char *buf, int len) {
   });
   if (rc) return -1;
   return CopyOut(out, buf, len);
+}
+
+// ---------------------------------------------------------------------------------------- plug-ins
+// dlopen of an operator library: its static initialisers (DALI_SCHEMA / DALI_REGISTER_OPERATOR of
+// dali_amd/host/framework.h) add schemas and factories to the registries (PluginManager::LoadLibrary,
+// dali/plugin/plugin_manager.cc:26-41).
+API int daliamdLoadLibrary(const char *path, int global_symbols) {
+  return Guard([&] {
+    DALI_ENFORCE(path && *path, "Failed to load library: empty path");
+    void *handle = dlopen(path, (global_symbols ? RTLD_GLOBAL : RTLD_LOCAL) | RTLD_LAZY);
+    if (handle == nullptr) {
+      const char *err = dlerror();
+      DALI_FAIL("Failed to load library ", path, ": ", err ? err : "unknown error");
+    }
+  });
 }
 
 // ---------------------------------------------------------------------------------------- OpSpec

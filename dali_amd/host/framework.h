@@ -30,6 +30,10 @@
 
 #include "dali_amd_kernels.h"
 
+// Everything declared here is the plug-in interface: the library is built with hidden visibility, but an operator
+// library loaded later (daliamdLoadLibrary / dali_amd.plugin_manager.load_library; reference
+// dali/plugin/plugin_manager.cc:26-41) resolves these classes and registries against libdali_amd_host.so.
+#pragma GCC visibility push(default)
 namespace daliamd_host {
 
 // ---------------------------------------------------------------------------------------------
@@ -426,4 +430,5 @@ class DescUploader {
 };
 
 }  // namespace daliamd_host
+#pragma GCC visibility pop
 #endif  // DALI_AMD_HOST_FRAMEWORK_H_
