@@ -427,6 +427,47 @@ def bench_audio(args, device):
                                    "algorithmic_bytes": algo}}))
 
 
+def bench_cpu_backend(args):
+    """BASELINE configs[0]: the ImageNet train pipe on the product's CPU backend (decoders.image -> random_resized_crop
+    -> crop_mirror_normalize, 224 x 224, batch 32) through dali_amd.Pipeline - plumbing, no GPU.  One JSON line."""
+    import shutil
+    import tempfile
+    from dali_amd import fn, types
+    from dali_amd.pipeline import Pipeline
+    B, threads = 32, effective_cpu_count()
+    enc = make_dataset(0, 256, workers=threads)
+    root = tempfile.mkdtemp(prefix="dali_amd_bench_cpu_")
+    try:
+        write_dataset(root, enc)
+        pipe = Pipeline(batch_size=B, num_threads=threads, device_id=None, seed=1234, prefetch_queue_depth=2)
+        with pipe:
+            jpegs, labels = fn.readers.file(file_root=root, name="Reader")
+            images = fn.decoders.image(jpegs, device="cpu", output_type=types.RGB)
+            crops = fn.random_resized_crop(images, size=[224, 224])
+            out = fn.crop_mirror_normalize(crops, dtype=types.FLOAT16, output_layout="CHW",
+                                           mean=[0.485 * 255, 0.456 * 255, 0.406 * 255],
+                                           std=[0.229 * 255, 0.224 * 255, 0.225 * 255],
+                                           mirror=fn.random.coin_flip(probability=0.5))
+            pipe.set_outputs(out, labels)
+        pipe.build()
+        for _ in range(max(1, args.warmup)):
+            pipe.run()
+        steps = min(args.steps, 64)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            pipe.run()
+        el = time.perf_counter() - t0
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+    print(json.dumps({"metric": "images/sec JPEG->RRC->CMN 224^2 b32, CPU backend", "value": steps * B / el,
+                      "unit": "images/s", "n_gpus": 0, "steps": steps, "warmup": max(1, args.warmup),
+                      "ms_per_step": 1e3 * el / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                      "dtype": "u8/i32 decode, f32 resample, f16 out", "data": "synthetic",
+                      "config": {"workload": "configs[0]: ImageNet train pipe on the CPU backend of dali_amd.Pipeline, "
+                                             "batch 32, 224x224 fp16 CHW", "host_threads": threads,
+                                 "kernels": pipe.executed_kernels()}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -445,8 +486,9 @@ def main():
     ap.add_argument("--no-fused-idct", action="store_true",
                     help="store the coefficients and run the stand-alone IDCT kernel (the GPU entropy decoder's default is "
                          "to dequantise + inverse-transform the blocks itself)")
-    ap.add_argument("--workload", default="imagenet", choices=["imagenet", "heavy_aug", "audio"],
-                    help="imagenet = the headline metric (default); heavy_aug / audio = configs[2] / configs[3] side benches")
+    ap.add_argument("--workload", default="imagenet", choices=["imagenet", "heavy_aug", "audio", "cpu"],
+                    help="imagenet = the headline metric (default); heavy_aug / audio = configs[2] / configs[3] side benches; "
+                         "cpu = configs[0], the train pipe on the CPU backend (no GPU needed)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -456,6 +498,8 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
+    if args.workload == "cpu":
+        return bench_cpu_backend(args)
     B = args.batch
     nb = max(1, args.batches)
     inflight = max(1, min(args.inflight, nb))

@@ -179,11 +179,11 @@ _KERNEL_SYMBOLS = [
 ]
 
 _HOST_SYMBOLS = [
-    "daliamdHostGetLastErrorMessage", "daliamdJpegParse", "daliamdJpegDecodeCoefficients",
+    "daliamdHostGetLastErrorMessage", "daliamdJpegParse", "daliamdJpegDecodeCoefficients", "daliamdJpegDecodeRgbHost",
     "daliamdJpegAnalyzeScan",
     "daliamdRandomCropBatch", "daliamdCoinFlipBatch", "daliamdPhiloxAdvanceSequence",
     "daliamdPhiloxStateToString", "daliamdPhiloxStateFromString", "daliamdPhiloxGenerate",
-    "daliamdCmnNormArgs", "daliamdCropAnchor",
+    "daliamdCmnNormArgs", "daliamdCropAnchor", "daliamdResampleRunHost", "daliamdCmnRunHost",
     "daliamdImageCachePolicyCreate", "daliamdImageCachePolicyDestroy", "daliamdImageCachePolicyOnDecode",
     "daliamdImageCachePolicyFind", "daliamdImageProbe", "daliamdImageDecodeRgb",
 ]

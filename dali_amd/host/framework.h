@@ -336,6 +336,7 @@ class Workspace {
   std::vector<std::shared_ptr<TensorList>> inputs, outputs;
   std::map<std::string, std::shared_ptr<TensorList>> argument_inputs;
   ThreadPool *thread_pool = nullptr;
+  OpType backend = OpType::GPU;  // the backend the running operator instance was created for
   daliamdStream_t stream = nullptr;  // device operators enqueue here and must not synchronise
   // Second stream for bulk host->device transfers: a copy issued here for iteration i+1 overlaps the kernels of
   // iteration i on `stream`.  The operator orders the two with an event (record on copy_stream, wait on stream).

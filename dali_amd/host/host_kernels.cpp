@@ -1,0 +1,277 @@
+// CPU execution of the per-sample descriptors the device kernels consume: separable resampling (+ the fused
+// CropMirrorNormalize epilogue) and stand-alone CropMirrorNormalize.  The operators build ONE set of descriptors
+// (daliamdResampleSetup / the CropMirrorNormalize argument code) whatever the backend; device="gpu" uploads them and
+// launches the HIP kernel, device="cpu" hands each sample to these functions on the operator's thread pool - one
+// task per sample, like the reference's CPU operators (dali/operators/image/resize/resize_op_impl_cpu.h:84-107,
+// dali/operators/image/crop/crop_mirror_normalize.cc:116-144).
+//
+// Arithmetic = the reference CPU kernels (and therefore = csrc/resample.hip, csrc/cmn.hip, which follow them):
+//   coefficient tables   InitializeResamplingFilter   dali/kernels/imgproc/resample/resampling_impl_cpu.cc:22-47
+//   filter evaluation    ResamplingFilter::operator() dali/kernels/imgproc/resample/resampling_filters.cuh:48-67
+//   two passes, fp32 tmp SeparableResampleCPU         dali/kernels/imgproc/resample/separable_cpu.h:152-241,
+//                                                     resampling_impl_cpu.h:50-123,362-390
+//   u8 rounding          SSE2 body half-even, scalar tail half-away (kernels/common/simd.h:53-56, core/convert.h:306-321)
+//   CMN                  slice_flip_normalize_permute_pad_cpu.h:37-64, half.hpp:231-243 (fp16 ties away from zero)
+// This file is built with -ffp-contract=off: multiply and add are rounded separately, as on baseline x86-64.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "dali_amd_host.h"
+#include "host_common.h"
+
+namespace daliamd_host {
+namespace {
+
+// the 3-entry triangular table {0, 1, 0}, linearly interpolated (host branch of ResamplingFilter::operator())
+inline float TriEval(float x) {
+  if (!(x > -1)) return 0;
+  if (x >= 3) return 0;
+  const int x0 = (int)std::floor(x), x1 = x0 + 1;
+  const float d = x - x0;
+  const float f0 = x0 < 0.0f ? 0.0f : (x0 == 1 ? 1.0f : 0.0f);
+  const float f1 = x1 >= 3 ? 0.0f : (x1 == 1 ? 1.0f : 0.0f);
+  return f0 + d * (f1 - f0);
+}
+
+struct AxisTable {
+  std::vector<int32_t> first;  // first tap of every output position
+  std::vector<float> coef;     // [out][support], normalised
+};
+AxisTable BuildTable(int out_size, float origin, float scale, float fanchor, float fscale, int support) {
+  AxisTable t;
+  t.first.resize(out_size);
+  t.coef.resize((size_t)out_size * support);
+  float start = origin;
+  start += 0.5f * scale - 0.5f - fanchor;
+  for (int o = 0; o < out_size; o++) {
+    const float sx0f = o * scale + start;
+    const int sx0 = (int)std::ceil(sx0f);
+    const float f0 = sx0 - sx0f;
+    float *co = &t.coef[(size_t)o * support];
+    float sum = 0;
+    for (int k = 0; k < support; k++) {
+      co[k] = TriEval((f0 + k) * fscale);
+      sum += co[k];
+    }
+    if (sum)
+      for (int k = 0; k < support; k++) co[k] /= sum;
+    t.first[o] = sx0;
+  }
+  return t;
+}
+
+inline int ClampI(int v, int lo, int hi) { return std::min(std::max(v, lo), hi); }
+
+inline uint32_t RoundU8(float v, bool half_even) {
+  if (half_even) {
+    const float c = std::fmin(std::fmax(v, 0.0f), 255.0f);  // NaN -> 0
+    return (uint32_t)std::nearbyint(c);                     // default rounding mode: to nearest even
+  }
+  if (!(v > 0.0f)) return 0;
+  float r = std::floor(v);
+  r += (v - r >= 0.5f) ? 1.0f : 0.0f;
+  return (uint32_t)std::fmin(r, 255.0f);
+}
+
+// half_float::detail::float2half_impl<round_to_nearest> with ties away from zero (util/half.hpp:464-536)
+uint16_t Float2HalfAway(float f) {
+  uint32_t bits;
+  memcpy(&bits, &f, 4);
+  const uint32_t e = (bits >> 23) & 0xff, sign = (bits >> 16) & 0x8000, mant = bits & 0x7FFFFF;
+  uint32_t base;
+  int shift;
+  if (e < 103) { base = 0; shift = 24; }
+  else if (e < 113) { base = 0x0400u >> (113 - e); shift = 126 - (int)e; }
+  else if (e < 143) { base = (e - 112) << 10; shift = 13; }
+  else if (e < 255) { base = 0x7C00; shift = 24; }
+  else { base = 0x7C00; shift = 13; }
+  const uint32_t h = (base | sign) + (mant >> shift);
+  const uint32_t rnd = ((mant >> (shift - 1)) | (e == 102 ? 1u : 0u)) & ((h & 0x7C00) != 0x7C00 ? 1u : 0u);
+  return (uint16_t)(h + rnd);
+}
+
+inline float RoundAway(float v) {  // std::round
+  float r = std::trunc(v);
+  const float d = v - r;
+  if (d >= 0.5f) r += 1.0f;
+  else if (d <= -0.5f) r -= 1.0f;
+  return r;
+}
+
+// epilogue of the resampling kernel: the rounded u8 value -> plain / normalised output element
+struct Epilogue {
+  void *out;
+  int out_h, out_w, channels, dtype, layout, normalize, mirror;
+  size_t Base(int y, int x, size_t *cstride) const {
+    const int xo = mirror ? out_w - 1 - x : x;
+    if (layout == DALIAMD_LAYOUT_CHW) { *cstride = (size_t)out_h * out_w; return (size_t)y * out_w + xo; }
+    *cstride = 1;
+    return ((size_t)y * out_w + xo) * channels;
+  }
+  void Store(size_t o, uint32_t v, float mean, float inv_std) const {
+    float f = (float)v;
+    if (dtype == DALIAMD_UINT8) {
+      if (normalize) f = (float)RoundU8((f - mean) * inv_std, false);
+      static_cast<uint8_t *>(out)[o] = (uint8_t)f;
+    } else {
+      if (normalize) f = (f - mean) * inv_std;
+      if (dtype == DALIAMD_FLOAT16) static_cast<uint16_t *>(out)[o] = Float2HalfAway(f);
+      else static_cast<float *>(out)[o] = f;
+    }
+  }
+};
+
+}  // namespace
+}  // namespace daliamd_host
+
+using namespace daliamd_host;
+
+extern "C" int daliamdResampleRunHost(const daliamdResampleDesc *desc) {
+  if (!desc || !desc->in || !desc->out) return Fail("daliamdResampleRunHost: NULL descriptor or buffer");
+  const daliamdResampleDesc &d = *desc;
+  const int C = d.channels, pitch = d.in_pitch;
+  if (C < 1 || C > 4) return Fail("daliamdResampleRunHost: %d channels (supported: 1..4)", C);
+  const int sup_x = d.support[0], sup_y = d.support[1];
+  const AxisTable tx = BuildTable(d.out_w, d.origin[0], d.scale[0], d.fanchor[0], d.fscale[0], sup_x);
+  const AxisTable ty = BuildTable(d.out_h, d.origin[1], d.scale[1], d.fanchor[1], d.fscale[1], sup_y);
+  // taps are clamped to [0, ext) inside the frame that starts at lo (first-pass axis: the whole image; second-pass
+  // axis: the source region the first pass produced)
+  const int ex = d.ext[0] - 1, ey = d.ext[1] - 1;
+  const uint8_t *base = d.in + (size_t)d.lo[1] * pitch + (size_t)d.lo[0] * C;
+  Epilogue ep{d.out, d.out_h, d.out_w, C, d.out_dtype, d.out_layout, d.normalize, d.mirror};
+  if (d.first_axis == 1) {
+    // vertical pass: tmp[out_h][ext_x * C], then horizontal
+    const int NB = d.ext[0] * C;
+    std::vector<float> tmp((size_t)d.out_h * NB);
+    std::vector<const uint8_t *> rows(sup_y);
+    for (int y = 0; y < d.out_h; y++) {
+      const float *co = &ty.coef[(size_t)y * sup_y];
+      for (int k = 0; k < sup_y; k++) rows[k] = base + (size_t)ClampI(ty.first[y] + k, 0, ey) * pitch;
+      float *trow = &tmp[(size_t)y * NB];
+      for (int e = 0; e < NB; e++) {
+        float a = 0;
+        for (int k = 0; k < sup_y; k++) a += (float)rows[k][e] * co[k];
+        trow[e] = a;
+      }
+    }
+    // Rounding of an H-last pass (ResampleHorz, resampling_impl_cpu.h:286-336,477-485): the row is cut into the
+    // left-clamped / regular / right-clamped column regions, every region runs 16 columns at a time through the SSE2
+    // body (half to even) and finishes in a scalar tail (half away from zero).  The descriptor carries this as a
+    // 256-column bit mask for the kernel; here it is derived for any width.
+    std::vector<uint8_t> even_col(d.out_w, 0);
+    {
+      const int ow = d.out_w, in_w = d.ext[0];
+      const bool flipped = tx.first[ow - 1] < tx.first[0];
+      int first_regular = 0, last_regular = ow - 1;
+      if (flipped) {
+        while (first_regular < ow && tx.first[first_regular] + sup_x > in_w) first_regular++;
+        while (last_regular >= 0 && tx.first[last_regular] < 0) last_regular--;
+      } else {
+        while (first_regular < ow && tx.first[first_regular] < 0) first_regular++;
+        while (last_regular >= 0 && tx.first[last_regular] + sup_x > in_w) last_regular--;
+      }
+      const int bounds[5] = {0, std::min(first_regular, last_regular + 1), first_regular, last_regular + 1, ow};
+      int x = 0;
+      for (int r = 0; r < 4; r++) {
+        const int ox1 = bounds[r + 1];
+        for (; x + 16 <= ox1; x += 16)
+          for (int l = 0; l < 16; l++) even_col[x + l] = 1;
+        x = std::max(x, ox1);
+      }
+    }
+    std::vector<int> xo(sup_x);
+    for (int x = 0; x < d.out_w; x++) {
+      const float *co = &tx.coef[(size_t)x * sup_x];
+      for (int k = 0; k < sup_x; k++) xo[k] = ClampI(tx.first[x] + k, 0, ex) * C;
+      const bool even = even_col[x] != 0;
+      for (int y = 0; y < d.out_h; y++) {
+        const float *trow = &tmp[(size_t)y * NB];
+        float a[4] = {0, 0, 0, 0};
+        for (int k = 0; k < sup_x; k++)
+          for (int c = 0; c < C; c++) a[c] += co[k] * trow[xo[k] + c];
+        size_t cs;
+        const size_t o = ep.Base(y, x, &cs);
+        for (int c = 0; c < C; c++) ep.Store(o + c * cs, RoundU8(a[c], even), d.mean[c], d.inv_std[c]);
+      }
+    }
+  } else {
+    // horizontal pass: tmp[ext_y][out_w * C], then vertical
+    const int rowlen = d.out_w * C, nrows = d.ext[1];
+    std::vector<float> tmp((size_t)nrows * rowlen);
+    std::vector<int> xo(sup_x);
+    for (int x = 0; x < d.out_w; x++) {
+      const float *co = &tx.coef[(size_t)x * sup_x];
+      for (int k = 0; k < sup_x; k++) xo[k] = ClampI(tx.first[x] + k, 0, ex) * C;
+      for (int r = 0; r < nrows; r++) {
+        const uint8_t *srow = base + (size_t)r * pitch;
+        float a[4] = {0, 0, 0, 0};
+        for (int k = 0; k < sup_x; k++)
+          for (int c = 0; c < C; c++) a[c] += co[k] * (float)srow[xo[k] + c];
+        for (int c = 0; c < C; c++) tmp[(size_t)r * rowlen + (size_t)x * C + c] = a[c];
+      }
+    }
+    const int flat_w = rowlen;
+    std::vector<const float *> rows(sup_y);
+    for (int y = 0; y < d.out_h; y++) {
+      const float *co = &ty.coef[(size_t)y * sup_y];
+      for (int k = 0; k < sup_y; k++) rows[k] = &tmp[(size_t)ClampI(ty.first[y] + k, 0, ey) * rowlen];
+      for (int x = 0; x < d.out_w; x++) {
+        size_t cs;
+        const size_t o = ep.Base(y, x, &cs);
+        for (int c = 0; c < C; c++) {
+          const int fi = x * C + c;
+          float a = 0;
+          for (int k = 0; k < sup_y; k++) a += rows[k][fi] * co[k];
+          // ResampleVert: 256-element tiles, 16-lane SIMD body (half to even) then scalar tail (half away)
+          const int t0 = fi & ~255, tend = std::min(t0 + 256, flat_w);
+          const bool even = fi < t0 + ((tend - t0) & ~15);
+          ep.Store(o + c * cs, RoundU8(a, even), d.mean[c], d.inv_std[c]);
+        }
+      }
+    }
+  }
+  return 0;
+}
+
+extern "C" int daliamdCmnRunHost(const daliamdCmnDesc *desc) {
+  if (!desc || !desc->in || !desc->out) return Fail("daliamdCmnRunHost: NULL descriptor or buffer");
+  const daliamdCmnDesc &d = *desc;
+  const int cw = d.crop_w, ch = d.crop_h, C = d.channels, Co = d.out_channels;
+  const bool chw = d.out_layout == DALIAMD_LAYOUT_CHW;
+  for (int y = 0; y < ch; y++) {
+    const int sy = d.anchor_y + y;
+    const bool row_in = sy >= 0 && sy < d.in_h;
+    const uint8_t *row = d.in + (size_t)(row_in ? sy : 0) * d.in_pitch;
+    for (int x = 0; x < cw; x++) {
+      const int sx = d.mirror ? d.anchor_x + (cw - 1 - x) : d.anchor_x + x;
+      const bool inside = row_in && sx >= 0 && sx < d.in_w;
+      for (int c = 0; c < Co; c++) {
+        float v;
+        if (c < C && inside) {
+          v = (float)row[(size_t)sx * C + c];
+          if (d.normalize) v = (v - d.mean[c]) * d.inv_std[c];
+        } else {
+          v = d.fill[c];
+        }
+        const size_t o = chw ? ((size_t)c * ch + y) * cw + x : ((size_t)y * cw + x) * Co + c;
+        switch (d.out_dtype) {
+          case DALIAMD_FLOAT: static_cast<float *>(d.out)[o] = v; break;
+          case DALIAMD_FLOAT16: static_cast<uint16_t *>(d.out)[o] = Float2HalfAway(v); break;
+          case DALIAMD_UINT8: {
+            const float r = RoundAway(v);
+            static_cast<uint8_t *>(d.out)[o] = (uint8_t)(!(r > 0.0f) ? 0.0f : std::fmin(r, 255.0f));
+          } break;
+          default: {
+            float r = RoundAway(v);
+            r = r != r ? 0.0f : std::fmin(std::fmax(r, -128.0f), 127.0f);
+            static_cast<int8_t *>(d.out)[o] = (int8_t)r;
+          }
+        }
+      }
+    }
+  }
+  return 0;
+}

@@ -650,6 +650,84 @@ class ImageDecoderCropMixed : public ImageDecoderMixed {
   bool round_;
 };
 
+// ---- decoders.image, device="cpu": the whole decode on the host thread pool ------------------------------------
+// ImageDecoder<CPUBackend> (dali/operators/imgcodec/image_decoder.h:613-880, registered host_decoder.cc:35-48): header
+// parse -> output shapes (EXIF orientation swaps height and width, :677-681) -> one task per sample
+// (:724-749) decoding with libjpeg-turbo semantics (accurate IDCT, fancy upsampling: :289-305).  Product code:
+// daliamdJpegDecodeRgbHost (host/jpeg_pixels.cpp) - the same bytes as the device path.
+class ImageDecoderCpu : public OperatorBase {
+ public:
+  explicit ImageDecoderCpu(const OpSpec &spec) : OperatorBase(spec) {
+    const int64_t ot = spec.GetInt("output_type");
+    DALI_ENFORCE(ot == DALI_RGB || ot == DALI_ANY_DATA, "decoders.image: only output_type=RGB is supported, got ", ot);
+    DALI_ENFORCE(spec.GetInt("dtype") == DALI_UINT8, "decoders.image: only dtype=UINT8 is supported");
+    adjust_orientation_ = spec.GetBool("adjust_orientation");
+  }
+  bool SetupImpl(std::vector<OutputDesc> &desc, const Workspace &ws) override {
+    const TensorList &in = ws.Input(0);
+    const int n = in.num_samples();
+    DALI_ENFORCE(in.type() == DALI_UINT8, "decoders.image expects encoded streams as 1-D uint8 tensors");
+    infos_.resize(n);
+    raster_.assign(n, 0);
+    orient_.assign(n, 1);
+    desc[0].type = DALI_UINT8;
+    desc[0].shape.resize(n);
+    auto src = [&](int i) { return i < (int)in.source_info.size() && !in.source_info[i].empty() ? in.source_info[i]
+                                                                                                  : make_string("sample ", i); };
+    for (int i = 0; i < n; i++) {
+      const uint8_t *data = static_cast<const uint8_t *>(in.raw(i));
+      const size_t size = (size_t)in.nbytes(i);
+      daliamdImageFormat fmt = DALIAMD_IMAGE_UNKNOWN;
+      int32_t w = 0, h = 0;
+      if (daliamdImageProbe(data, size, &fmt, &w, &h) != 0)
+        DALI_FAIL("Failed to decode ", src(i), ": ", daliamdHostGetLastErrorMessage());
+      if (fmt == DALIAMD_IMAGE_JPEG) {
+        if (daliamdJpegParse(data, size, &infos_[i]) != 0)
+          DALI_FAIL("Failed to parse ", src(i), ": ", daliamdHostGetLastErrorMessage());
+        DALI_ENFORCE(infos_[i].num_components == 1 || infos_[i].num_components == 3, "Failed to decode ", src(i),
+                     ": JPEG with ", infos_[i].num_components, " components (CMYK/YCCK) is not supported");
+        orient_[i] = adjust_orientation_ ? infos_[i].orientation : 1;
+        w = infos_[i].width; h = infos_[i].height;
+        if (orient_[i] >= 5 && orient_[i] <= 8) std::swap(w, h);
+      } else {
+        raster_[i] = 1;
+      }
+      desc[0].shape[i] = TensorShape{h, w, 3};
+    }
+    return true;
+  }
+  void RunImpl(Workspace &ws) override {
+    const TensorList &in = ws.Input(0);
+    TensorList &out = ws.Output(0);
+    out.SetLayout("HWC");
+    out.source_info = in.source_info;
+    const int n = in.num_samples();
+    for (int i = 0; i < n; i++) {
+      ws.GetThreadPool().AddWork([this, &in, &out, i](int) {
+        const uint8_t *data = static_cast<const uint8_t *>(in.raw(i));
+        const size_t size = (size_t)in.nbytes(i);
+        uint8_t *dst = static_cast<uint8_t *>(out.raw(i));
+        const int64_t pitch = out.row_pitch(i) ? out.row_pitch(i) : out.shape(i)[1] * 3;
+        const int rc = raster_[i] ? daliamdImageDecodeRgb(data, size, dst, pitch, 0, 0, 0, 0)
+                                  : daliamdJpegDecodeRgbHost(data, size, &infos_[i], orient_[i], dst, pitch);
+        if (rc != 0)
+          DALI_FAIL("Failed to decode ", i < (int)in.source_info.size() ? in.source_info[i] : make_string("sample ", i), ": ",
+                    daliamdHostGetLastErrorMessage());
+      }, in.nbytes(i));
+    }
+    ws.GetThreadPool().RunAll();
+    NoteLaunch(ws, "host_jpeg_decode");
+  }
+
+ private:
+  bool adjust_orientation_;
+  std::vector<daliamdJpegInfo> infos_;
+  std::vector<int> raster_, orient_;
+};
+DALI_REGISTER_OPERATOR(decoders__Image, ImageDecoderCpu, CPU);
+DALI_REGISTER_OPERATOR(ImageDecoder, ImageDecoderCpu, CPU);
+DALI_REGISTER_OPERATOR(experimental__decoders__Image, ImageDecoderCpu, CPU);
+
 // ---- decoders.image_slice: SliceAttr window (named start / end / shape arguments or anchor + shape inputs) --------
 // (decoder_schema.cc:200-252, generic/slice/slice_attr.h:40-352, slice_attr.cc:21-110)
 DALI_SCHEMA(SliceAttr)
@@ -888,6 +966,16 @@ static void LaunchResample(Workspace &ws, DescUploader &up, std::vector<daliamdR
   descs.resize(n);
   int nwg = 0, lds = 0;
   KCHECK(daliamdResampleSetup(args.data(), n, descs.data(), &nwg, &lds));
+  if (ws.backend == OpType::CPU) {
+    // CPU backend: the same descriptors, one thread-pool task per sample (resize_op_impl_cpu.h:84-107)
+    for (int i = 0; i < n; i++)
+      ws.GetThreadPool().AddWork([&descs, i](int) {
+        if (daliamdResampleRunHost(&descs[i]) != 0) DALI_FAIL(daliamdHostGetLastErrorMessage());
+      }, (int64_t)descs[i].in_h * descs[i].in_w);
+    ws.GetThreadPool().RunAll();
+    NoteLaunch(ws, std::string("host_") + what);
+    return;
+  }
   auto *dev = static_cast<const daliamdResampleDesc *>(up.Upload(descs.data(), descs.size() * sizeof(descs[0]), ws.stream, ws.ring + 1));
   KCHECK(daliamdResampleRun(ws.stream, dev, n, nwg, lds));
   NoteLaunch(ws, what);
@@ -995,6 +1083,7 @@ class RandomResizedCropGpu : public OperatorBase {
   DescUploader uploader_;
 };
 DALI_REGISTER_OPERATOR(RandomResizedCrop, RandomResizedCropGpu, GPU);
+DALI_REGISTER_OPERATOR(RandomResizedCrop, RandomResizedCropGpu, CPU);
 
 // =============================================================================================
 // Resize (fn.resize): ResizeAttr size arithmetic on the host + the same resampling kernel
@@ -1259,6 +1348,7 @@ class ResizeGpu : public OperatorBase {
   DescUploader uploader_;
 };
 DALI_REGISTER_OPERATOR(Resize, ResizeGpu, GPU);
+DALI_REGISTER_OPERATOR(Resize, ResizeGpu, CPU);
 
 // ---- ResizeCropMirror: resize, then a CropAttr window of the resized image, then flips - as ONE resampling of the
 // back-projected window (resize_crop_mirror.cc:85-118) ----
@@ -1342,7 +1432,9 @@ class ResizeCropMirrorGpu : public ResizeGpu {
   std::vector<float> pos_[2], wh_[2];
 };
 DALI_REGISTER_OPERATOR(ResizeCropMirror, ResizeCropMirrorGpu, GPU);
+DALI_REGISTER_OPERATOR(ResizeCropMirror, ResizeCropMirrorGpu, CPU);
 DALI_REGISTER_OPERATOR(FastResizeCropMirror, ResizeCropMirrorGpu, GPU);
+DALI_REGISTER_OPERATOR(FastResizeCropMirror, ResizeCropMirrorGpu, CPU);
 
 // =============================================================================================
 // CropMirrorNormalize
@@ -1522,6 +1614,15 @@ class CropMirrorNormalizeGpu : public OperatorBase {
     }
     int nwg = 0;
     KCHECK(daliamdCmnSetup(descs_.data(), n, &nwg));
+    if (ws.backend == OpType::CPU) {  // crop_mirror_normalize.cc:116-144: one task per sample
+      for (int i = 0; i < n; i++)
+        ws.GetThreadPool().AddWork([this, i](int) {
+          if (daliamdCmnRunHost(&descs_[i]) != 0) DALI_FAIL(daliamdHostGetLastErrorMessage());
+        }, (int64_t)descs_[i].crop_h * descs_[i].crop_w);
+      ws.GetThreadPool().RunAll();
+      NoteLaunch(ws, "host_cmn");
+      return;
+    }
     auto *dev = static_cast<const daliamdCmnDesc *>(uploader_.Upload(descs_.data(), descs_.size() * sizeof(descs_[0]), ws.stream, ws.ring + 1));
     KCHECK(daliamdCmnRun(ws.stream, dev, n, nwg));
     NoteLaunch(ws, "cmn");
@@ -1545,6 +1646,7 @@ class CropMirrorNormalizeGpu : public OperatorBase {
   DescUploader uploader_;
 };
 DALI_REGISTER_OPERATOR(CropMirrorNormalize, CropMirrorNormalizeGpu, GPU);
+DALI_REGISTER_OPERATOR(CropMirrorNormalize, CropMirrorNormalizeGpu, CPU);  // same class: host kernels when run on the CPU
 
 void TryEnableFusion(OperatorBase *producer, OperatorBase *consumer) {
   auto *rrc = dynamic_cast<RandomResizedCropGpu *>(producer);

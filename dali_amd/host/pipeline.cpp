@@ -168,9 +168,10 @@ void Pipeline::Build(const std::vector<std::pair<std::string, std::string>> &out
   }
 }
 
+// launches are noted by the stage thread that runs the operator: the list of the iteration it is working on
+static thread_local std::vector<std::string> *tl_launches = nullptr;
 void Pipeline::NoteLaunch(const std::string &what) {
-  std::lock_guard<std::mutex> g(launches_m_);
-  cur_launches_.push_back(what);
+  if (tl_launches) tl_launches->push_back(what);
 }
 std::vector<std::string> Pipeline::LastLaunches() const {
   std::lock_guard<std::mutex> g(launches_m_);
@@ -182,10 +183,10 @@ void NoteLaunch(const Workspace &ws, const std::string &what) {
 
 void Pipeline::RunStage(bool device_stage, int64_t it, int slot, Iteration &res) {
   res.slot = slot;
-  if (device_stage) {
-    std::lock_guard<std::mutex> g(launches_m_);
-    cur_launches_.clear();
-  }
+  struct LaunchScope {  // host stage and device stage of different iterations run concurrently: per-iteration lists
+    explicit LaunchScope(std::vector<std::string> *l) { tl_launches = l; }
+    ~LaunchScope() { tl_launches = nullptr; }
+  } launch_scope(&res.launches);
   struct Range {  // profiler range (roctx), closed on every exit path
     explicit Range(const std::string &n) { daliamdRangePush(n.c_str()); }
     ~Range() { daliamdRangePop(); }
@@ -213,6 +214,7 @@ void Pipeline::RunStage(bool device_stage, int64_t it, int slot, Iteration &res)
       if ((n.type != OpType::CPU) != device_stage) continue;
       Workspace ws;
       ws.pipeline = this;
+      ws.backend = n.type;
       ws.thread_pool = device_stage ? thread_pool_.get() : cpu_thread_pool_.get();
       ws.stream = streams_.empty() ? nullptr : streams_[slot];
       ws.copy_stream = copy_stream_;
@@ -260,10 +262,6 @@ void Pipeline::RunStage(bool device_stage, int64_t it, int slot, Iteration &res)
   if (device_stage) {
     // recorded even after a failure: the slot's next user waits for this event
     if (!streams_.empty()) daliamdEventRecord(slot_events_[slot], streams_[slot]);
-    {
-      std::lock_guard<std::mutex> g(launches_m_);
-      res.launches = cur_launches_;
-    }
     {
       std::lock_guard<std::mutex> g(m_);
       device_stages_done_ = it + 1;

@@ -77,7 +77,7 @@ class Pipeline {
     std::string error;
     bool failed = false;
     std::vector<std::function<void()>> checks;  // run by Outputs() once the device work is complete
-    std::vector<std::string> launches;          // device kernels this iteration enqueued
+    std::vector<std::string> launches;          // kernels (device, or host_* for the CPU backend) of this iteration
   };
 
   // One iteration = host stage (CPU operators: readers, random numbers, external sources) followed by the device
@@ -122,7 +122,6 @@ class Pipeline {
   bool stop_ = false;
   bool holding_ = false;  // the consumer holds the outputs of iteration consumed_-1
   std::vector<std::string> last_launches_;  // of the iteration handed out last
-  std::vector<std::string> cur_launches_;   // of the iteration being built (worker thread)
   mutable std::mutex launches_m_;
 
  public:

@@ -12,6 +12,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "dali_amd_kernels.h" /* descriptor PODs shared with the device library (plain C, no HIP) */
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -50,6 +52,13 @@ DALIAMD_HOST_API int daliamdJpegParse(const uint8_t *data, size_t size, daliamdJ
 DALIAMD_HOST_API int daliamdJpegDecodeCoefficients(const uint8_t *data, size_t size, const daliamdJpegInfo *info,
                                                   int16_t *const coef[4], uint16_t *quant);
 
+/* The whole decode on the host: entropy decode + dequantisation + accurate integer IDCT + fancy (triangle) chroma
+ * upsampling + BT.601 YCbCr -> RGB (gray replicated) + EXIF orientation `orientation` (0/1: as stored; 5..8: the
+ * output is height x width turned, i.e. `out` holds info->width rows of info->height pixels).  out: u8 RGB rows of
+ * `pitch` bytes.  This is decoders.image(device="cpu") - ImageDecoder<CPUBackend>, dali/operators/imgcodec/
+ * image_decoder.h:613-880 / host_decoder.cc:35-48 over libjpeg-turbo; the same bytes the device path produces. */
+DALIAMD_HOST_API int daliamdJpegDecodeRgbHost(const uint8_t *data, size_t size, const daliamdJpegInfo *info,
+                                             int orientation, uint8_t *out, int64_t pitch);
 
 /* Scan analysis for the GPU entropy decoder (libdali_amd_kernels: daliamdJpegHuffman*).  A stream is eligible
  * when it is baseline (SOF0/SOF1), has ONE scan that interleaves all components (or is grayscale), and uses no
@@ -104,6 +113,18 @@ DALIAMD_HOST_API int daliamdCmnNormArgs(const float *mean, int nmean, const floa
                                        float shift, float *mean_out, float *inv_std_out);
 /* CropAttr::CalculateAnchor (dali/operators/image/crop/crop_attr.cc:224-240) */
 DALIAMD_HOST_API int64_t daliamdCropAnchor(float anchor_norm, int64_t crop, int64_t in, int round_half_away);
+
+/* ----------------------------------------------------------------------------------------------
+ * CPU backend of the resampling / CropMirrorNormalize operators: ONE sample of a descriptor table that was filled for
+ * the device kernels (daliamdResampleSetup; daliamdCmnDesc), executed on the calling thread with host pointers in
+ * `in` / `out`.  Same arithmetic as the kernels, which follow the reference's CPU kernels
+ * (dali/kernels/imgproc/resample/separable_cpu.h:152-241, resampling_impl_cpu.{h,cc},
+ * dali/kernels/slice/slice_flip_normalize_permute_pad_cpu.h:37-64): RandomResizedCrop / Resize / CropMirrorNormalize
+ * registered for CPU (random_resized_crop.cc:54, resize.cc, crop_mirror_normalize.cc:83) call these, one thread-pool
+ * task per sample (resize_op_impl_cpu.h:84-107).
+ * -------------------------------------------------------------------------------------------- */
+DALIAMD_HOST_API int daliamdResampleRunHost(const daliamdResampleDesc *desc);
+DALIAMD_HOST_API int daliamdCmnRunHost(const daliamdCmnDesc *desc);
 
 /* The loss-less container formats decoders.image accepts next to JPEG ("Supported formats: JPEG, JPEG 2000, TIFF, PNG,
  * BMP, PNM, PPM, PGM, PBM, WebP", dali/operators/imgcodec/decoder_schema.cc:149), decoded on the host to 8-bit RGB

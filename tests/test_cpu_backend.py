@@ -1,0 +1,120 @@
+"""BASELINE.json configs[0]: the ImageNet train pipe on the CPU backend - decoders.image -> random_resized_crop ->
+crop_mirror_normalize, 224 x 224, batch 32 - through dali_amd.Pipeline with NO GPU, checked against the oracle bit
+for bit.  The CPU operators are product code (host/jpeg_pixels.cpp, host/host_kernels.cpp: the reference registers
+the same three operators for CPU, host_decoder.cc:35-48, random_resized_crop.cc:54, crop_mirror_normalize.cc:83);
+nothing under oracle/ is used by them."""
+import io
+import os
+
+import numpy as np
+import pytest
+from PIL import Image, ImageOps
+
+from oracle import oracle as O
+from tests.util import encode_jpeg, synth_image, synth_jpeg_batch
+
+MEAN = [0.485 * 255, 0.456 * 255, 0.406 * 255]
+STD = [0.229 * 255, 0.224 * 255, 0.225 * 255]
+
+
+@pytest.fixture(scope="module")
+def dataset(tmp_path_factory):
+    root = tmp_path_factory.mktemp("cpu_ds")
+    rng = np.random.default_rng(1234)
+    enc = synth_jpeg_batch(rng, 40, sizes=[(375, 500), (500, 375), (333, 500), (256, 384), (97, 131)])
+    files = []
+    for i, e in enumerate(enc):
+        d = root / f"{i % 4}"
+        os.makedirs(d, exist_ok=True)
+        (d / f"img_{i:04d}.jpg").write_bytes(e)
+    for c in range(4):
+        for f in sorted(os.listdir(root / f"{c}")):
+            files.append((str(root / f"{c}" / f), c))
+    return str(root), files
+
+
+def test_configs0_cpu_train_pipeline_equals_oracle(dataset):
+    from dali_amd import fn, types
+    from dali_amd.pipeline import Pipeline
+    root, files = dataset
+    B = 32
+    pipe = Pipeline(batch_size=B, num_threads=4, device_id=None, seed=1234, prefetch_queue_depth=2)
+    with pipe:
+        jpegs, labels = fn.readers.file(file_root=root, name="Reader")
+        images = fn.decoders.image(jpegs, device="cpu", output_type=types.RGB)
+        crops = fn.random_resized_crop(images, size=[224, 224], seed=1234)
+        out = fn.crop_mirror_normalize(crops, dtype=types.FLOAT16, output_layout="CHW", mean=MEAN, std=STD,
+                                       mirror=fn.random.coin_flip(probability=0.5, seed=1235))
+        pipe.set_outputs(out, labels, images)
+    pipe.build()
+    mean, inv = O.cmn_norm_args(MEAN, STD)
+    for it in range(2):
+        data, lab, imgs = pipe.run()
+        got = data.as_array()
+        picks = [(it * B + i) % len(files) for i in range(B)]
+        assert got.shape == (B, 3, 224, 224) and got.dtype == np.float16
+        assert list(lab.as_array().reshape(-1)) == [files[k][1] for k in picks]
+        enc = [open(files[k][0], "rb").read() for k in picks]
+        for i in range(B):
+            assert np.array_equal(imgs.at(i), O.jpeg_decode_rgb(enc[i])), (it, i)
+        ref = O.pipeline_batch(enc, 1234, 1235, it, mean=mean, inv_std=inv, nthreads=4)
+        assert np.array_equal(got.view(np.uint16), ref.view(np.uint16)), f"iteration {it}"
+        assert {"host_jpeg_decode", "host_resample", "host_cmn"} <= set(pipe.executed_kernels())
+
+
+def test_cpu_decoder_orientation_and_raster_formats(tmp_path):
+    from dali_amd import fn
+    from dali_amd.pipeline import Pipeline
+    rng = np.random.default_rng(2)
+    files = []
+    for o in range(1, 9):
+        img = Image.fromarray(synth_image(rng, 40 + o, 64))
+        exif = Image.Exif()
+        exif[0x0112] = o
+        p = tmp_path / f"o{o}.jpg"
+        img.save(p, "JPEG", quality=90, exif=exif)
+        files.append(str(p))
+    p = tmp_path / "x.png"
+    Image.fromarray(synth_image(rng, 33, 21)).save(p, "PNG")
+    files.append(str(p))
+    p = tmp_path / "g.jpg"
+    p.write_bytes(encode_jpeg(synth_image(rng, 50, 70, 1), 80, progressive=True))
+    files.append(str(p))
+    for adjust in (True, False):
+        pipe = Pipeline(batch_size=len(files), num_threads=2, device_id=None)
+        with pipe:
+            enc, _ = fn.readers.file(files=files)
+            pipe.set_outputs(fn.decoders.image(enc, device="cpu", adjust_orientation=adjust))
+        (out,) = pipe.run()
+        assert out.layout() == "HWC"
+        for i, f in enumerate(files):
+            im = Image.open(f)
+            ref = np.asarray((ImageOps.exif_transpose(im) if adjust else im).convert("RGB"))
+            assert np.array_equal(out.at(i), ref), (i, adjust)
+
+
+def test_cpu_resize_and_stand_alone_cmn_match_oracle(dataset):
+    """fn.resize and a cropping crop_mirror_normalize on the CPU backend (device inferred from the CPU input)."""
+    from dali_amd import fn, types
+    from dali_amd.pipeline import Pipeline
+    root, files = dataset
+    B = 8
+    pipe = Pipeline(batch_size=B, num_threads=3, device_id=None, prefetch_queue_depth=1)
+    with pipe:
+        jpegs, _ = fn.readers.file(file_root=root)
+        images = fn.decoders.image(jpegs, device="cpu")
+        small = fn.resize(images, resize_shorter=160)
+        out = fn.crop_mirror_normalize(small, dtype=types.FLOAT, output_layout="HWC", crop=(128, 112), mean=MEAN, std=STD,
+                                       crop_pos_x=0.25, crop_pos_y=0.75, mirror=1)
+        pipe.set_outputs(out, small)
+    (got, small_out) = pipe.run()
+    mean, inv = O.cmn_norm_args(MEAN, STD)
+    for i in range(B):
+        img = O.jpeg_decode_rgb(open(files[i][0], "rb").read())
+        out_hw, roi = O.resize_params(img.shape[:2], size=(160, 160), mode="not_smaller")   # = resize_shorter=160
+        r = small_out.at(i)
+        assert r.shape[:2] == tuple(out_hw), (i, r.shape, out_hw)
+        assert np.array_equal(r, O.resample_u8(img, out_hw, roi=roi)), i
+        ay, ax = int(O.crop_anchor(0.75, 128, r.shape[0])), int(O.crop_anchor(0.25, 112, r.shape[1]))
+        ref = O.cmn_u8(r, (ay, ax), (128, 112), mirror=True, mean=mean, inv_std=inv, dtype=O.F32, layout="HWC")
+        assert np.array_equal(got.at(i), ref), i

@@ -154,7 +154,7 @@ def test_graph_validation_errors(dataset):
         with pytest.raises(TypeError, match="unexpected keyword"):
             fn.random.coin_flip(probabilty=0.3)
         with pytest.raises(RuntimeError, match="not available for device \"cpu\""):
-            fn.decoders.image(d)                       # no CPU fallback for device operators
+            fn.gaussian_blur(d, sigma=1.0)             # no silent CPU fallback for device-only operators
         with pytest.raises(ValueError, match="expects between"):
             fn.random_resized_crop(size=[8, 8], device="gpu")
         with pytest.raises(ValueError, match="cannot take a GPU input"):
