@@ -49,7 +49,7 @@ class JpegColorDesc(C.Structure):
                 ("v_samp", C.c_int32 * 3), ("down_w", C.c_int32 * 3), ("down_h", C.c_int32 * 3),
                 ("width", C.c_int32), ("height", C.c_int32), ("color", C.c_int32),
                 ("out", C.c_void_p), ("out_pitch", C.c_int32), ("wg_start", C.c_int32),
-                ("orientation", C.c_int32), ("reserved", C.c_int32), ("roi_x0", C.c_int32),
+                ("orientation", C.c_int32), ("out_format", C.c_int32), ("roi_x0", C.c_int32),
                 ("roi_y0", C.c_int32), ("roi_w", C.c_int32), ("roi_h", C.c_int32), ("out_x0", C.c_int32),
                 ("out_y0", C.c_int32)]
 
@@ -179,7 +179,7 @@ _KERNEL_SYMBOLS = [
 ]
 
 _HOST_SYMBOLS = [
-    "daliamdHostGetLastErrorMessage", "daliamdJpegParse", "daliamdJpegDecodeCoefficients", "daliamdJpegDecodeRgbHost",
+    "daliamdHostGetLastErrorMessage", "daliamdJpegParse", "daliamdJpegDecodeCoefficients", "daliamdJpegDecodeRgbHost", "daliamdJpegOutputChannels", "daliamdJpegDecodeHost", "daliamdConvertRgbRows",
     "daliamdJpegAnalyzeScan",
     "daliamdRandomCropBatch", "daliamdCoinFlipBatch", "daliamdPhiloxAdvanceSequence",
     "daliamdPhiloxStateToString", "daliamdPhiloxStateFromString", "daliamdPhiloxGenerate",

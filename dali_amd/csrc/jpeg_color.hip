@@ -35,6 +35,8 @@ constexpr int kTileH = 8 * kRowsPerThread;
 #define FIXC(x) ((int32_t)((x) * (1L << SCALEBITS) + 0.5))
 
 __device__ __forceinline__ uint32_t Clamp8(int v) { return (uint32_t)min(max(v, 0), 255); }
+// ConvertSat<uint8_t>(float): clamp, round half away from zero
+__device__ __forceinline__ uint32_t SatRound8(float v) { return !(v > 0.0f) ? 0u : v >= 255.0f ? 255u : (uint32_t)(v + 0.5f); }
 
 enum UpsampleMode { kFull = 0, kH2V1 = 1, kH2V2 = 2, kH1V2 = 3, kBox = 4 };
 
@@ -247,17 +249,23 @@ __global__ __launch_bounds__(kColorThreads) void JpegColorKernel(const daliamdJp
   const int y_first = ry0 + ty * kTileH + (threadIdx.x >> 5) * kRowsPerThread;
   if (x0 >= rx1 || y_first >= ry1) return;
 
-  int ncomp = d.color == DALIAMD_JPEG_GRAY ? 1 : 3;
+  const int nstored = d.color == DALIAMD_JPEG_GRAY ? 1 : 3;
   int hmax = 1, vmax = 1;
-  for (int c = 0; c < ncomp; c++) { hmax = max(hmax, d.h_samp[c]); vmax = max(vmax, d.v_samp[c]); }
+  for (int c = 0; c < nstored; c++) { hmax = max(hmax, d.h_samp[c]); vmax = max(vmax, d.v_samp[c]); }
+  // output format (decoders.image output_type): a gray output of a gray / YCbCr stream is its luma plane alone
+  // (libjpeg-turbo's JCS_GRAYSCALE output, which the reference asks nvImageCodec for: image_decoder.h:538-541)
+  const int fmt = d.out_format;
+  const int oc = fmt == DALIAMD_JPEG_OUT_GRAY ? 1 : 3;
+  const bool luma_only = fmt == DALIAMD_JPEG_OUT_GRAY && d.color != DALIAMD_JPEG_RGB;
+  const int ncomp = luma_only ? 1 : nstored;
   int mode[3] = {kFull, kFull, kFull};
   for (int c = 0; c < ncomp; c++) mode[c] = ModeOf(d, c, hmax, vmax);
   const int npx = min(8, rx1 - x0);
   const int out_x0 = roi ? d.out_x0 : 0, out_y0 = roi ? d.out_y0 : 0;
   const bool wide_ok = ((d.out_pitch & 7) == 0) && ((reinterpret_cast<uintptr_t>(d.out) & 7) == 0);
-  const bool wide_stores = npx == 8 && wide_ok;
+  const bool wide_stores = npx == 8 && wide_ok && oc == 3;
   // wave-uniform: the whole image takes the fast path or none of it does
-  if (d.color == DALIAMD_JPEG_YCC && mode[0] == kFull && mode[1] == kH2V2 && mode[2] == kH2V2 && d.orientation <= 1 &&
+  if (fmt == DALIAMD_JPEG_OUT_RGB && d.color == DALIAMD_JPEG_YCC && mode[0] == kFull && mode[1] == kH2V2 && mode[2] == kH2V2 && d.orientation <= 1 &&
       wide_ok && ((rx0 & 7) | (ry0 & 1)) == 0 && ((d.pitch[0] & 7) | (d.pitch[1] & 3) | (d.pitch[2] & 3)) == 0 &&
       (reinterpret_cast<uintptr_t>(d.plane[0]) & 7) == 0 &&
       ((reinterpret_cast<uintptr_t>(d.plane[1]) | reinterpret_cast<uintptr_t>(d.plane[2])) & 3) == 0) {
@@ -273,7 +281,10 @@ __global__ __launch_bounds__(kColorThreads) void JpegColorKernel(const daliamdJp
       UpsampleRow8((GBytes *)d.plane[c], d.pitch[c], mode[c], hmax / d.h_samp[c], vmax / d.v_samp[c], d.down_w[c], d.down_h[c], x0, y,
                    s[c]);
     uint32_t px[24];
-    if (d.color == DALIAMD_JPEG_GRAY) {
+    if (luma_only) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) px[i] = (uint32_t)s[0][i];
+    } else if (d.color == DALIAMD_JPEG_GRAY) {
 #pragma unroll
       for (int i = 0; i < 8; i++) px[3 * i] = px[3 * i + 1] = px[3 * i + 2] = (uint32_t)s[0][i];
     } else if (d.color == DALIAMD_JPEG_RGB) {
@@ -287,6 +298,24 @@ __global__ __launch_bounds__(kColorThreads) void JpegColorKernel(const daliamdJp
         int g = yy + (((-FIXC(0.34414)) * cb + ONE_HALF + (-FIXC(0.71414)) * cr) >> SCALEBITS);
         int b = yy + ((FIXC(1.77200) * cb + ONE_HALF) >> SCALEBITS);
         px[3 * i] = Clamp8(r); px[3 * i + 1] = Clamp8(g); px[3 * i + 2] = Clamp8(b);
+      }
+    }
+    // RGB -> the requested format (ConvertCPU / ConvertGPU of the reference, operators/imgcodec/util/convert.h:140-192:
+    // BGR = swap; YCbCr = ITU-R BT.601 with head room, float, ConvertSat; gray = 0.299 R + 0.587 G + 0.114 B)
+    if (!luma_only && fmt != DALIAMD_JPEG_OUT_RGB) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const uint32_t r8 = px[3 * i], g8 = px[3 * i + 1], b8 = px[3 * i + 2];
+        const float r = (float)r8, g = (float)g8, b = (float)b8;
+        if (fmt == DALIAMD_JPEG_OUT_BGR) {
+          px[3 * i] = b8; px[3 * i + 2] = r8;
+        } else if (fmt == DALIAMD_JPEG_OUT_YCBCR) {
+          px[3 * i] = SatRound8(0.25678823529f * r + 0.50412941176f * g + 0.09790588235f * b + 16.0f);
+          px[3 * i + 1] = SatRound8(-0.14822289945f * r + -0.29099278682f * g + 0.43921568627f * b + 128.0f);
+          px[3 * i + 2] = SatRound8(0.43921568627f * r + -0.36778831435f * g + -0.07142737192f * b + 128.0f);
+        } else {  // gray from a stream stored as RGB
+          px[i] = SatRound8(0.299f * r + 0.587f * g + 0.114f * b);
+        }
       }
     }
     if (d.orientation > 1) {
@@ -303,12 +332,13 @@ __global__ __launch_bounds__(kColorThreads) void JpegColorKernel(const daliamdJp
           case 7: oy = W - 1 - x; ox = H - 1 - y; break;
           default: oy = W - 1 - x; ox = y; break;  // 8
         }
-        GOutBytes *p = (GOutBytes *)d.out + (size_t)(oy - out_y0) * d.out_pitch + (size_t)(ox - out_x0) * 3;
-        p[0] = (uint8_t)px[3 * i]; p[1] = (uint8_t)px[3 * i + 1]; p[2] = (uint8_t)px[3 * i + 2];
+        GOutBytes *p = (GOutBytes *)d.out + (size_t)(oy - out_y0) * d.out_pitch + (size_t)(ox - out_x0) * oc;
+        if (oc == 1) { p[0] = (uint8_t)px[i]; }
+        else { p[0] = (uint8_t)px[3 * i]; p[1] = (uint8_t)px[3 * i + 1]; p[2] = (uint8_t)px[3 * i + 2]; }
       }
       continue;
     }
-    GOutBytes *o = (GOutBytes *)d.out + (size_t)(y - out_y0) * d.out_pitch + (size_t)(x0 - out_x0) * 3;
+    GOutBytes *o = (GOutBytes *)d.out + (size_t)(y - out_y0) * d.out_pitch + (size_t)(x0 - out_x0) * oc;
     if (wide_stores) {
       uint32_t w[6];
 #pragma unroll
@@ -319,7 +349,7 @@ __global__ __launch_bounds__(kColorThreads) void JpegColorKernel(const daliamdJp
       o2[1] = u32x2{w[2], w[3]};
       o2[2] = u32x2{w[4], w[5]};
     } else {
-      for (int i = 0; i < npx * 3; i++) o[i] = (uint8_t)px[i];
+      for (int i = 0; i < npx * oc; i++) o[i] = (uint8_t)px[i];
     }
   }
 }
@@ -345,8 +375,11 @@ daliamdResult_t daliamdJpegColorSetup(daliamdJpegColorDesc *descs, int n, int *n
     DALIAMD_REQUIRE(d.roi_w > 0 || (d.out_x0 == 0 && d.out_y0 == 0), DALIAMD_ERROR_INVALID_ARGUMENT,
                     "daliamdJpegColorSetup: desc %d: output origin without a region of interest", i);
     const int pw = d.roi_w > 0 ? d.roi_w : d.width, ph = d.roi_w > 0 ? d.roi_h : d.height;  // produced source pixels
-    DALIAMD_REQUIRE(d.out_pitch >= 3 * (d.orientation >= 5 ? ph : pw), DALIAMD_ERROR_INVALID_ARGUMENT,
-                    "daliamdJpegColorSetup: desc %d out_pitch %d < 3*width", i, d.out_pitch);
+    DALIAMD_REQUIRE(d.out_format >= DALIAMD_JPEG_OUT_RGB && d.out_format <= DALIAMD_JPEG_OUT_YCBCR,
+                    DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdJpegColorSetup: desc %d: invalid output format %d", i, d.out_format);
+    const int oc = d.out_format == DALIAMD_JPEG_OUT_GRAY ? 1 : 3;
+    DALIAMD_REQUIRE(d.out_pitch >= oc * (d.orientation >= 5 ? ph : pw), DALIAMD_ERROR_INVALID_ARGUMENT,
+                    "daliamdJpegColorSetup: desc %d out_pitch %d < %d*width", i, d.out_pitch, oc);
     int ncomp = d.color == DALIAMD_JPEG_GRAY ? 1 : 3;
     int hmax = 1, vmax = 1;
     for (int c = 0; c < ncomp; c++) {

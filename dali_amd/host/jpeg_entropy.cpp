@@ -540,6 +540,10 @@ void FillInfo(const Decoder &d, daliamdJpegInfo *info) {
     else if (d.adobe) rgb = d.adobe_transform == 0;
     else rgb = d.comp[0].id == 'R' && d.comp[1].id == 'G' && d.comp[2].id == 'B';
     info->color = rgb ? 2 : 1;
+  } else if (d.ncomp == 4) {
+    // four components: CMYK, or YCCK when the Adobe marker says transform 2 (jdapimin.c default_decompress_parms);
+    // samples written by Adobe software are stored inverted (flag 8)
+    info->color = (d.adobe && d.adobe_transform == 2 ? 4 : 3) | (d.adobe ? 8 : 0);
   } else {
     info->color = -1;
   }
@@ -619,7 +623,7 @@ int daliamdJpegDecodeCoefficients(const uint8_t *data, size_t size, const daliam
                                   int16_t *const coef[4], uint16_t *quant) {
   using namespace daliamd_host;
   if (!data || !info || !coef || !quant) return Fail("daliamdJpegDecodeCoefficients: NULL argument");
-  if (info->num_components != 1 && info->num_components != 3)
+  if (info->num_components != 1 && info->num_components != 3 && info->num_components != 4)
     return Fail("JPEG with %d components is not supported", info->num_components);
   Decoder d;
   d.data = data; d.size = size;

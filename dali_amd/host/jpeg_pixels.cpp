@@ -169,14 +169,57 @@ static inline void UprightPos(int o, int y, int x, int H, int W, int *oy, int *o
 
 using namespace daliamd_host;
 
-extern "C" int daliamdJpegDecodeRgbHost(const uint8_t *data, size_t size, const daliamdJpegInfo *info, int orientation,
-                                        uint8_t *out, int64_t pitch) {
-  if (!data || !info || !out) return Fail("daliamdJpegDecodeRgbHost: NULL argument");
+// ---- output formats (decoders.image `output_type`) -------------------------------------------------------------
+// The decoder produces RGB (or the luma plane alone for GRAY: nvImageCodec is asked for P_Y then,
+// dali/operators/imgcodec/image_decoder.h:538-541) and ConvertCPU turns RGB into the other formats
+// (dali/operators/imgcodec/util/convert.h:140-192,260-280): BGR = channel swap, YCbCr = ITU-R BT.601 with head / foot
+// room (kernels/imgproc/color_manipulation/color_space_conversion_impl.h:62-103), float arithmetic, ConvertSat rounding.
+static inline uint8_t SatRound(float v) {  // ConvertSat<uint8_t>(float): clamp, round half away from zero
+  if (!(v > 0.0f)) return 0;
+  if (v >= 255.0f) return 255;
+  return (uint8_t)(v + 0.5f);
+}
+static inline void RgbToYcbcr601(const uint8_t *rgb, uint8_t *out) {
+  const float r = rgb[0], g = rgb[1], b = rgb[2];
+  out[0] = SatRound(0.25678823529f * r + 0.50412941176f * g + 0.09790588235f * b + 16.0f);
+  out[1] = SatRound(-0.14822289945f * r + -0.29099278682f * g + 0.43921568627f * b + 128.0f);
+  out[2] = SatRound(0.43921568627f * r + -0.36778831435f * g + -0.07142737192f * b + 128.0f);
+}
+static inline uint8_t RgbToGray(const uint8_t *rgb) {  // jpeg::rgb_to_y (:157-163)
+  return SatRound(0.299f * rgb[0] + 0.587f * rgb[1] + 0.114f * rgb[2]);
+}
+// Pillow's CMYK -> RGB (libImaging/Convert.c cmyk2rgb) on samples as an Adobe file stores them (inverted): the pin for
+// the four-component streams, whose conversion in the reference lives in un-vendored nvImageCodec.
+static inline uint8_t MulDiv255(int a, int b) {
+  const int t = a * b + 128;
+  return (uint8_t)(((t >> 8) + t) >> 8);
+}
+static inline void CmykToRgb(int c, int m, int y, int k, bool inverted, uint8_t *rgb) {
+  if (inverted) { c = 255 - c; m = 255 - m; y = 255 - y; k = 255 - k; }
+  const int nk = 255 - k;
+  rgb[0] = Clamp8(nk - MulDiv255(c, nk));
+  rgb[1] = Clamp8(nk - MulDiv255(m, nk));
+  rgb[2] = Clamp8(nk - MulDiv255(y, nk));
+}
+
+extern "C" int daliamdJpegOutputChannels(int num_components, int output_type) {
+  if (output_type == DALIAMD_IMAGE_GRAY) return 1;
+  if (output_type == DALIAMD_IMAGE_ANY) return num_components == 1 ? 1 : 3;
+  return 3;
+}
+
+extern "C" int daliamdJpegDecodeHost(const uint8_t *data, size_t size, const daliamdJpegInfo *info, int orientation,
+                                     int output_type, uint8_t *out, int64_t pitch) {
+  if (!data || !info || !out) return Fail("daliamdJpegDecodeHost: NULL argument");
   const int nc = info->num_components;
-  if (nc != 1 && nc != 3) return Fail("JPEG with %d components (CMYK/YCCK) is not supported", nc);
+  if (nc != 1 && nc != 3 && nc != 4) return Fail("JPEG with %d components is not supported", nc);
+  if (output_type != DALIAMD_IMAGE_RGB && output_type != DALIAMD_IMAGE_BGR && output_type != DALIAMD_IMAGE_GRAY &&
+      output_type != DALIAMD_IMAGE_YCBCR && output_type != DALIAMD_IMAGE_ANY)
+    return Fail("decoders.image: unsupported output_type %d", output_type);
+  const int oc = daliamdJpegOutputChannels(nc, output_type);
   const int W = info->width, H = info->height;
   const bool turned = orientation >= 5 && orientation <= 8;
-  if (pitch < (int64_t)3 * (turned ? H : W)) return Fail("daliamdJpegDecodeRgbHost: pitch too small");
+  if (pitch < (int64_t)oc * (turned ? H : W)) return Fail("daliamdJpegDecodeHost: pitch too small");
   // entropy decode
   std::vector<int16_t> coef_store;
   size_t total = 0;
@@ -189,12 +232,14 @@ extern "C" int daliamdJpegDecodeRgbHost(const uint8_t *data, size_t size, const 
   }
   uint16_t quant[4 * 64];
   if (daliamdJpegDecodeCoefficients(data, size, info, coef, quant) != 0) return 1;  // message already set
-  // planes
+  // planes: the luma plane alone is enough for a gray output of a YCbCr / gray stream (jdcolor.c grayscale_convert)
+  const bool luma_only = oc == 1 && (nc == 1 || (nc == 3 && info->color != 2));
+  const int nplanes = luma_only ? 1 : nc;
   std::vector<uint8_t> plane_store(total);
-  Comp comps[3];
+  Comp comps[4];
   {
     size_t off = 0;
-    for (int c = 0; c < nc; c++) {
+    for (int c = 0; c < nplanes; c++) {
       uint8_t *plane = plane_store.data() + off;
       IdctComponent(coef[c], quant + 64 * c, info->blocks_x[c], info->blocks_y[c], plane);
       comps[c] = Comp{plane, info->blocks_x[c] * 8, ModeOf(*info, c), info->hmax / std::max(1, info->h_samp[c]),
@@ -202,27 +247,87 @@ extern "C" int daliamdJpegDecodeRgbHost(const uint8_t *data, size_t size, const 
       off += (size_t)info->coef_elems[c];
     }
   }
-  // rows: upsample, convert, place
-  std::vector<uint8_t> rows((size_t)3 * W), px((size_t)3 * W);
+  const int base_color = info->color & 7;
+  const bool inverted = (info->color & 8) != 0;
+  // rows: upsample, convert to RGB, to the output format, place
+  std::vector<uint8_t> rows((size_t)4 * W), rgb((size_t)3 * W), px((size_t)3 * W);
   for (int y = 0; y < H; y++) {
-    for (int c = 0; c < nc; c++) UpsampleRow(comps[c], y, W, rows.data() + (size_t)c * W);
-    const uint8_t *r0 = rows.data(), *r1 = rows.data() + W, *r2 = rows.data() + 2 * (size_t)W;
-    if (nc == 1) {
-      for (int x = 0; x < W; x++) px[3 * x] = px[3 * x + 1] = px[3 * x + 2] = r0[x];
-    } else if (info->color == 2) {  // stored as RGB (Adobe transform 0)
-      for (int x = 0; x < W; x++) { px[3 * x] = r0[x]; px[3 * x + 1] = r1[x]; px[3 * x + 2] = r2[x]; }
+    for (int c = 0; c < nplanes; c++) UpsampleRow(comps[c], y, W, rows.data() + (size_t)c * W);
+    const uint8_t *r0 = rows.data(), *r1 = r0 + W, *r2 = r1 + W, *r3 = r2 + W;
+    if (luma_only) {
+      memcpy(px.data(), r0, W);
     } else {
-      for (int x = 0; x < W; x++) YccToRgb(r0[x], r1[x], r2[x], &px[3 * x]);
+      if (nc == 1) {
+        for (int x = 0; x < W; x++) rgb[3 * x] = rgb[3 * x + 1] = rgb[3 * x + 2] = r0[x];
+      } else if (nc == 3 && base_color == 2) {  // stored as RGB (Adobe transform 0)
+        for (int x = 0; x < W; x++) { rgb[3 * x] = r0[x]; rgb[3 * x + 1] = r1[x]; rgb[3 * x + 2] = r2[x]; }
+      } else if (nc == 3) {
+        for (int x = 0; x < W; x++) YccToRgb(r0[x], r1[x], r2[x], &rgb[3 * x]);
+      } else if (base_color == 4) {  // YCCK -> CMYK (jdcolor.c ycck_cmyk_convert: C, M, Y = 255 - R, G, B; K as it is)
+        for (int x = 0; x < W; x++) {
+          uint8_t t[3];
+          YccToRgb(r0[x], r1[x], r2[x], t);
+          CmykToRgb(255 - t[0], 255 - t[1], 255 - t[2], r3[x], inverted, &rgb[3 * x]);
+        }
+      } else {
+        for (int x = 0; x < W; x++) CmykToRgb(r0[x], r1[x], r2[x], r3[x], inverted, &rgb[3 * x]);
+      }
+      switch (output_type) {
+        case DALIAMD_IMAGE_BGR:
+          for (int x = 0; x < W; x++) { px[3 * x] = rgb[3 * x + 2]; px[3 * x + 1] = rgb[3 * x + 1]; px[3 * x + 2] = rgb[3 * x]; }
+          break;
+        case DALIAMD_IMAGE_YCBCR:
+          for (int x = 0; x < W; x++) RgbToYcbcr601(&rgb[3 * x], &px[3 * x]);
+          break;
+        case DALIAMD_IMAGE_GRAY:
+          for (int x = 0; x < W; x++) px[x] = RgbToGray(&rgb[3 * x]);
+          break;
+        default:
+          memcpy(px.data(), rgb.data(), (size_t)3 * W);
+      }
     }
     if (orientation <= 1 || orientation > 8) {
-      memcpy(out + (size_t)y * pitch, px.data(), (size_t)3 * W);
+      memcpy(out + (size_t)y * pitch, px.data(), (size_t)oc * W);
     } else {
       for (int x = 0; x < W; x++) {
         int oy, ox;
         UprightPos(orientation, y, x, H, W, &oy, &ox);
-        uint8_t *d = out + (size_t)oy * pitch + (size_t)3 * ox;
-        d[0] = px[3 * x]; d[1] = px[3 * x + 1]; d[2] = px[3 * x + 2];
+        uint8_t *d = out + (size_t)oy * pitch + (size_t)oc * ox;
+        for (int c = 0; c < oc; c++) d[c] = px[oc * x + c];
       }
+    }
+  }
+  return 0;
+}
+
+extern "C" int daliamdJpegDecodeRgbHost(const uint8_t *data, size_t size, const daliamdJpegInfo *info, int orientation,
+                                        uint8_t *out, int64_t pitch) {
+  return daliamdJpegDecodeHost(data, size, info, orientation, DALIAMD_IMAGE_RGB, out, pitch);
+}
+
+// In-place-free conversion of decoded RGB rows (raster formats decoded by daliamdImageDecodeRgb) to `output_type`.
+extern "C" int daliamdConvertRgbRows(const uint8_t *rgb, int64_t in_pitch, int width, int height, int output_type,
+                                     uint8_t *out, int64_t out_pitch) {
+  if (!rgb || !out) return Fail("daliamdConvertRgbRows: NULL argument");
+  for (int y = 0; y < height; y++) {
+    const uint8_t *s = rgb + (size_t)y * in_pitch;
+    uint8_t *d = out + (size_t)y * out_pitch;
+    switch (output_type) {
+      case DALIAMD_IMAGE_BGR:
+        for (int x = 0; x < width; x++) { const uint8_t r = s[3 * x], b = s[3 * x + 2]; d[3 * x] = b; d[3 * x + 1] = s[3 * x + 1]; d[3 * x + 2] = r; }
+        break;
+      case DALIAMD_IMAGE_YCBCR:
+        for (int x = 0; x < width; x++) { uint8_t t[3]; RgbToYcbcr601(&s[3 * x], t); d[3 * x] = t[0]; d[3 * x + 1] = t[1]; d[3 * x + 2] = t[2]; }
+        break;
+      case DALIAMD_IMAGE_GRAY:
+        for (int x = 0; x < width; x++) d[x] = RgbToGray(&s[3 * x]);
+        break;
+      case DALIAMD_IMAGE_RGB:
+      case DALIAMD_IMAGE_ANY:
+        if (d != s) memmove(d, s, (size_t)3 * width);
+        break;
+      default:
+        return Fail("decoders.image: unsupported output_type %d", output_type);
     }
   }
   return 0;

@@ -84,7 +84,11 @@ class ImageDecoderMixed : public OperatorBase {
  public:
   explicit ImageDecoderMixed(const OpSpec &spec, bool allow_cache = true) : OperatorBase(spec) {
     int64_t ot = spec.GetInt("output_type");
-    DALI_ENFORCE(ot == DALI_RGB || ot == DALI_ANY_DATA, "decoders.image: only output_type=RGB is supported, got ", ot);
+    DALI_ENFORCE(ot == DALI_RGB || ot == DALI_BGR || ot == DALI_GRAY || ot == DALI_YCbCr || ot == DALI_ANY_DATA,
+                 "decoders.image: unsupported output_type ", ot);
+    // ANY_DATA: colour streams come out as RGB (a grayscale stream as well here: one channel count per batch)
+    out_type_ = ot == DALI_ANY_DATA ? (int)DALI_RGB : (int)ot;
+    oc_ = out_type_ == DALI_GRAY ? 1 : 3;
     DALI_ENFORCE(spec.GetInt("dtype") == DALI_UINT8, "decoders.image: only dtype=UINT8 is supported");
     adjust_orientation_ = spec.GetBool("adjust_orientation");
     // Entropy decoding runs on the GPU for every stream the kernel supports.  An EXPLICIT hybrid_huffman_threshold
@@ -210,9 +214,10 @@ class ImageDecoderMixed : public OperatorBase {
         const uint8_t *data = static_cast<const uint8_t *>(in.raw(i));
         if (daliamdJpegParse(data, in.nbytes(i), &infos_[i]) != 0)
           DALI_FAIL("Failed to parse ", src(i), ": ", daliamdHostGetLastErrorMessage());
-        DALI_ENFORCE(infos_[i].num_components == 1 || infos_[i].num_components == 3, "Failed to decode ", src(i),
-                     ": JPEG with ", infos_[i].num_components, " components (CMYK/YCCK) is not supported");
         scans_[i].eligible = 0;
+        if (infos_[i].num_components == 4) return;  // CMYK / YCCK: the host decodes these (below)
+        DALI_ENFORCE(infos_[i].num_components == 1 || infos_[i].num_components == 3, "Failed to decode ", src(i),
+                     ": JPEG with ", infos_[i].num_components, " components is not supported");
         if (!host_huffman_only_ && (int64_t)infos_[i].width * infos_[i].height >= huffman_threshold_ &&
             daliamdJpegAnalyzeScan(data, in.nbytes(i), &infos_[i], &scans_[i]) != 0)
           scans_[i].eligible = 0;  // the host decoder will produce the diagnosis
@@ -222,6 +227,21 @@ class ImageDecoderMixed : public OperatorBase {
       }, (int64_t)in.nbytes(i));
     }
     ws.GetThreadPool().RunAll();
+    // Four-component streams (CMYK / YCCK; real ImageNet holds 22): not for the kernels - they join the samples the
+    // host decodes and uploads (daliamdJpegDecodeHost), and stop existing for the JPEG machinery
+    jpeg4_.assign(n, daliamdJpegInfo{});
+    for (int i = 0; i < n; i++) {
+      if (hit_[i] || infos_[i].num_components != 4) continue;
+      jpeg4_[i] = infos_[i];
+      const bool swap = adjust_orientation_ && infos_[i].orientation >= 5;
+      raster_hw_[2 * i] = swap ? infos_[i].width : infos_[i].height;
+      raster_hw_[2 * i + 1] = swap ? infos_[i].height : infos_[i].width;
+      infos_[i] = daliamdJpegInfo{};
+      raster_[i] = 2;
+      hit_[i] = 2;
+      nraster++;
+      nact--;
+    }
     lap(0);
     // ---- layout ----
     std::vector<TensorShape> shapes(n);
@@ -254,7 +274,7 @@ class ImageDecoderMixed : public OperatorBase {
       const auto &inf = infos_[i];
       if (raster_[i]) {
         const bool window = rois_[4 * i + 2] > 0;
-        shapes[i] = {window ? rois_[4 * i + 2] : upright_hw_[2 * i], window ? rois_[4 * i + 3] : upright_hw_[2 * i + 1], 3};
+        shapes[i] = {window ? rois_[4 * i + 2] : upright_hw_[2 * i], window ? rois_[4 * i + 3] : upright_hw_[2 * i + 1], oc_};
         continue;
       }
       if (hit_[i]) {
@@ -263,11 +283,11 @@ class ImageDecoderMixed : public OperatorBase {
         ext_pitch[i] = cached_[i].pitch;
         continue;
       }
-      shapes[i] = {upright_hw_[2 * i], upright_hw_[2 * i + 1], 3};
+      shapes[i] = {upright_hw_[2 * i], upright_hw_[2 * i + 1], oc_};
       if (cache_ && i < (int)in.source_info.size()) {
         // a miss the policy keeps is decoded straight into its cache slot
-        const int64_t pitch = (shapes[i][1] * 3 + kImagePitchAlign - 1) / kImagePitchAlign * kImagePitchAlign;
-        if (uint8_t *slot_ptr = cache_->Reserve(in.source_info[i], (int)shapes[i][0], (int)shapes[i][1], 3, pitch)) {
+        const int64_t pitch = (shapes[i][1] * oc_ + kImagePitchAlign - 1) / kImagePitchAlign * kImagePitchAlign;
+        if (uint8_t *slot_ptr = cache_->Reserve(in.source_info[i], (int)shapes[i][0], (int)shapes[i][1], oc_, pitch)) {
           ext_ptr[i] = slot_ptr;
           ext_pitch[i] = pitch;
           reserved.keys.push_back(in.source_info[i]);
@@ -278,7 +298,7 @@ class ImageDecoderMixed : public OperatorBase {
                                adjust_orientation_ ? inf.orientation : 1, rois_[4 * i], rois_[4 * i + 1], rois_[4 * i + 2],
                                rois_[4 * i + 3], &plans_[i]) != DALIAMD_SUCCESS)
           DALI_FAIL("Failed to decode ", src(i), ": ", daliamdGetLastErrorMessage());
-        shapes[i] = {rois_[4 * i + 2], rois_[4 * i + 3], 3};
+        shapes[i] = {rois_[4 * i + 2], rois_[4 * i + 3], oc_};
       }
       for (int c = 0; c < inf.num_components; c++) {
         coef_off_[i * 3 + c] = elems;
@@ -341,11 +361,32 @@ class ImageDecoderMixed : public OperatorBase {
         if (!raster_[i]) continue;
         ws.GetThreadPool().AddWork([&, i](int) {
           const bool window = rois_[4 * i + 2] > 0;
-          if (daliamdImageDecodeRgb(static_cast<const uint8_t *>(in.raw(i)), in.nbytes(i),
-                                    static_cast<uint8_t *>(rs.data()) + roff[i], out.row_pitch(i), window ? rois_[4 * i] : 0,
-                                    window ? rois_[4 * i + 1] : 0, window ? rois_[4 * i + 2] : 0,
-                                    window ? rois_[4 * i + 3] : 0) != 0)
-            DALI_FAIL("Failed to decode ", src(i), ": ", daliamdHostGetLastErrorMessage());
+          const uint8_t *data = static_cast<const uint8_t *>(in.raw(i));
+          uint8_t *dst = static_cast<uint8_t *>(rs.data()) + roff[i];
+          const int64_t pitch = out.row_pitch(i);
+          const int wy = window ? rois_[4 * i] : 0, wx = window ? rois_[4 * i + 1] : 0;
+          const int wh = (int)out.shape(i)[0], ww = (int)out.shape(i)[1];
+          int rc;
+          if (raster_[i] == 2) {
+            // CMYK / YCCK JPEG: the whole upright image on the host, then the window
+            const int H = raster_hw_[2 * i], W = raster_hw_[2 * i + 1];
+            const int orient = adjust_orientation_ ? jpeg4_[i].orientation : 1;
+            if (!window) {
+              rc = daliamdJpegDecodeHost(data, in.nbytes(i), &jpeg4_[i], orient, out_type_, dst, pitch);
+            } else {
+              std::vector<uint8_t> full((size_t)H * W * oc_);
+              rc = daliamdJpegDecodeHost(data, in.nbytes(i), &jpeg4_[i], orient, out_type_, full.data(), (int64_t)W * oc_);
+              for (int y = 0; rc == 0 && y < wh; y++)
+                memcpy(dst + (size_t)y * pitch, full.data() + ((size_t)(wy + y) * W + wx) * oc_, (size_t)ww * oc_);
+            }
+          } else if (out_type_ == DALI_RGB) {
+            rc = daliamdImageDecodeRgb(data, in.nbytes(i), dst, pitch, wy, wx, window ? wh : 0, window ? ww : 0);
+          } else {  // RGB rows first, then the requested format
+            std::vector<uint8_t> rgb((size_t)wh * ww * 3);
+            rc = daliamdImageDecodeRgb(data, in.nbytes(i), rgb.data(), (int64_t)ww * 3, wy, wx, window ? wh : 0, window ? ww : 0);
+            if (rc == 0) rc = daliamdConvertRgbRows(rgb.data(), (int64_t)ww * 3, ww, wh, out_type_, dst, pitch);
+          }
+          if (rc != 0) DALI_FAIL("Failed to decode ", src(i), ": ", daliamdHostGetLastErrorMessage());
         }, (int64_t)in.nbytes(i));
       }
       ws.GetThreadPool().RunAll();
@@ -458,6 +499,7 @@ class ImageDecoderMixed : public OperatorBase {
       cd.out = static_cast<uint8_t *>(out.raw(i));
       cd.out_pitch = (int32_t)out.row_pitch(i);
       cd.orientation = adjust_orientation_ ? inf.orientation : 1;
+      cd.out_format = out_type_;  // DALIImageType values = daliamdJpegOutFormat_t
       if (plans_[i].roi_w > 0) {
         cd.roi_x0 = plans_[i].roi_x0; cd.roi_y0 = plans_[i].roi_y0; cd.roi_w = plans_[i].roi_w; cd.roi_h = plans_[i].roi_h;
         cd.out_x0 = plans_[i].out_x0; cd.out_y0 = plans_[i].out_y0;
@@ -528,6 +570,8 @@ class ImageDecoderMixed : public OperatorBase {
   int64_t huffman_threshold_ = 0;
   int ring_;
   std::vector<std::unique_ptr<Buffer>> staging_, coef_dev_, planes_, ecs_stage_, ecs_dev_, scratch_, status_host_, raster_stage_;
+  int out_type_ = 0, oc_ = 3;            // output_type (DALIImageType) and its channel count
+  std::vector<daliamdJpegInfo> jpeg4_;   // four-component streams of the batch (decoded on the host)
   std::vector<daliamdJpegInfo> infos_;
   std::vector<daliamdJpegScan> scans_;
   std::vector<int> gpu_samples_;
@@ -659,7 +703,9 @@ class ImageDecoderCpu : public OperatorBase {
  public:
   explicit ImageDecoderCpu(const OpSpec &spec) : OperatorBase(spec) {
     const int64_t ot = spec.GetInt("output_type");
-    DALI_ENFORCE(ot == DALI_RGB || ot == DALI_ANY_DATA, "decoders.image: only output_type=RGB is supported, got ", ot);
+    DALI_ENFORCE(ot == DALI_RGB || ot == DALI_BGR || ot == DALI_GRAY || ot == DALI_YCbCr || ot == DALI_ANY_DATA,
+                 "decoders.image: unsupported output_type ", ot);
+    out_type_ = (int)ot;
     DALI_ENFORCE(spec.GetInt("dtype") == DALI_UINT8, "decoders.image: only dtype=UINT8 is supported");
     adjust_orientation_ = spec.GetBool("adjust_orientation");
   }
@@ -684,15 +730,14 @@ class ImageDecoderCpu : public OperatorBase {
       if (fmt == DALIAMD_IMAGE_JPEG) {
         if (daliamdJpegParse(data, size, &infos_[i]) != 0)
           DALI_FAIL("Failed to parse ", src(i), ": ", daliamdHostGetLastErrorMessage());
-        DALI_ENFORCE(infos_[i].num_components == 1 || infos_[i].num_components == 3, "Failed to decode ", src(i),
-                     ": JPEG with ", infos_[i].num_components, " components (CMYK/YCCK) is not supported");
         orient_[i] = adjust_orientation_ ? infos_[i].orientation : 1;
         w = infos_[i].width; h = infos_[i].height;
         if (orient_[i] >= 5 && orient_[i] <= 8) std::swap(w, h);
+        desc[0].shape[i] = TensorShape{h, w, daliamdJpegOutputChannels(infos_[i].num_components, out_type_)};
       } else {
         raster_[i] = 1;
+        desc[0].shape[i] = TensorShape{h, w, out_type_ == DALI_GRAY ? 1 : 3};
       }
-      desc[0].shape[i] = TensorShape{h, w, 3};
     }
     return true;
   }
@@ -707,9 +752,19 @@ class ImageDecoderCpu : public OperatorBase {
         const uint8_t *data = static_cast<const uint8_t *>(in.raw(i));
         const size_t size = (size_t)in.nbytes(i);
         uint8_t *dst = static_cast<uint8_t *>(out.raw(i));
-        const int64_t pitch = out.row_pitch(i) ? out.row_pitch(i) : out.shape(i)[1] * 3;
-        const int rc = raster_[i] ? daliamdImageDecodeRgb(data, size, dst, pitch, 0, 0, 0, 0)
-                                  : daliamdJpegDecodeRgbHost(data, size, &infos_[i], orient_[i], dst, pitch);
+        const int oc = (int)out.shape(i)[2];
+        const int64_t pitch = out.row_pitch(i) ? out.row_pitch(i) : out.shape(i)[1] * oc;
+        int rc;
+        if (!raster_[i]) {
+          rc = daliamdJpegDecodeHost(data, size, &infos_[i], orient_[i], out_type_, dst, pitch);
+        } else if (out_type_ == DALI_RGB || out_type_ == DALI_ANY_DATA) {
+          rc = daliamdImageDecodeRgb(data, size, dst, pitch, 0, 0, 0, 0);
+        } else {
+          const int h = (int)out.shape(i)[0], w = (int)out.shape(i)[1];
+          std::vector<uint8_t> rgb((size_t)h * w * 3);
+          rc = daliamdImageDecodeRgb(data, size, rgb.data(), (int64_t)w * 3, 0, 0, 0, 0);
+          if (rc == 0) rc = daliamdConvertRgbRows(rgb.data(), (int64_t)w * 3, w, h, out_type_, dst, pitch);
+        }
         if (rc != 0)
           DALI_FAIL("Failed to decode ", i < (int)in.source_info.size() ? in.source_info[i] : make_string("sample ", i), ": ",
                     daliamdHostGetLastErrorMessage());
@@ -721,6 +776,7 @@ class ImageDecoderCpu : public OperatorBase {
 
  private:
   bool adjust_orientation_;
+  int out_type_ = 0;
   std::vector<daliamdJpegInfo> infos_;
   std::vector<int> raster_, orient_;
 };

@@ -30,14 +30,15 @@ DALIAMD_HOST_API const char *daliamdHostGetLastErrorMessage(void);
  * -------------------------------------------------------------------------------------------- */
 typedef struct {
   int32_t width, height;
-  int32_t num_components;   /* 1 or 3 (4 = CMYK/YCCK: parsed, not decodable) */
+  int32_t num_components;   /* 1, 3 or 4 (CMYK / YCCK: decoded on the host only)  */
   int32_t progressive;
   int32_t h_samp[4], v_samp[4];
   int32_t hmax, vmax;
   int32_t blocks_x[4], blocks_y[4]; /* allocated blocks per component (padded to the MCU) */
   int32_t down_w[4], down_h[4];     /* ceil(width*h/hmax), ceil(height*v/vmax) */
   int32_t orientation;              /* EXIF orientation 1..8 (1 when absent) */
-  int32_t color;                    /* 0 gray, 1 YCbCr, 2 RGB (daliamdJpegColor_t) */
+  int32_t color;                    /* 0 gray, 1 YCbCr, 2 RGB (daliamdJpegColor_t); 4 components: 3 CMYK, 4 YCCK,
+                                       + 8 when an Adobe marker is present (samples stored inverted) */
   int32_t restart_interval;
   int64_t coef_elems[4];            /* int16 elements of each component's coefficient array */
 } daliamdJpegInfo;
@@ -59,6 +60,21 @@ DALIAMD_HOST_API int daliamdJpegDecodeCoefficients(const uint8_t *data, size_t s
  * image_decoder.h:613-880 / host_decoder.cc:35-48 over libjpeg-turbo; the same bytes the device path produces. */
 DALIAMD_HOST_API int daliamdJpegDecodeRgbHost(const uint8_t *data, size_t size, const daliamdJpegInfo *info,
                                              int orientation, uint8_t *out, int64_t pitch);
+/* The same with the decoder's `output_type` (values of DALIImageType, include/dali/core/common.h): RGB, BGR, GRAY
+ * (one channel: the luma plane of a YCbCr / gray stream as libjpeg-turbo's JCS_GRAYSCALE output gives it, else
+ * 0.299 R + 0.587 G + 0.114 B), YCbCr (ITU-R BT.601 with head room, as ConvertCPU: dali/operators/imgcodec/util/
+ * convert.h:140-192), ANY_DATA (gray stays one channel, everything else RGB).  CMYK / YCCK streams (4 components)
+ * become RGB with Pillow's formula (the reference's lives in un-vendored nvImageCodec; real ImageNet holds 22 such
+ * files).  Output rows hold daliamdJpegOutputChannels(...) bytes per pixel. */
+typedef enum {
+  DALIAMD_IMAGE_RGB = 0, DALIAMD_IMAGE_BGR = 1, DALIAMD_IMAGE_GRAY = 2, DALIAMD_IMAGE_YCBCR = 3, DALIAMD_IMAGE_ANY = 4
+} daliamdImageType;
+DALIAMD_HOST_API int daliamdJpegOutputChannels(int num_components, int output_type);
+DALIAMD_HOST_API int daliamdJpegDecodeHost(const uint8_t *data, size_t size, const daliamdJpegInfo *info, int orientation,
+                                          int output_type, uint8_t *out, int64_t pitch);
+/* RGB rows (e.g. from daliamdImageDecodeRgb) -> `output_type`; GRAY writes one byte per pixel. */
+DALIAMD_HOST_API int daliamdConvertRgbRows(const uint8_t *rgb, int64_t in_pitch, int width, int height, int output_type,
+                                          uint8_t *out, int64_t out_pitch);
 
 /* Scan analysis for the GPU entropy decoder (libdali_amd_kernels: daliamdJpegHuffman*).  A stream is eligible
  * when it is baseline (SOF0/SOF1), has ONE scan that interleaves all components (or is grayscale), and uses no

@@ -194,6 +194,14 @@ typedef enum {
   DALIAMD_JPEG_RGB = 2     /* 3 components stored as RGB (Adobe transform 0) */
 } daliamdJpegColor_t;
 
+/* Output format of the colour stage = the decoder's `output_type` (values of DALIImageType): RGB; BGR; GRAY - one
+ * byte per pixel, the luma plane of a gray / YCbCr stream (libjpeg-turbo's JCS_GRAYSCALE output) or
+ * 0.299 R + 0.587 G + 0.114 B; YCbCr - ITU-R BT.601 with head room computed from the RGB result in float
+ * (dali/operators/imgcodec/util/convert.h:140-192, kernels/imgproc/color_manipulation/color_space_conversion_impl.h). */
+typedef enum {
+  DALIAMD_JPEG_OUT_RGB = 0, DALIAMD_JPEG_OUT_BGR = 1, DALIAMD_JPEG_OUT_GRAY = 2, DALIAMD_JPEG_OUT_YCBCR = 3
+} daliamdJpegOutFormat_t;
+
 typedef struct {
   const uint8_t *plane[3]; /* device component planes (output of the IDCT)                  */
   int32_t pitch[3];
@@ -201,12 +209,12 @@ typedef struct {
   int32_t down_w[3], down_h[3]; /* downsampled_width/height of each component (samples)      */
   int32_t width, height;        /* image size                                                */
   int32_t color;                /* daliamdJpegColor_t                                        */
-  uint8_t *out;                 /* device: RGB u8 HWC                                        */
-  int32_t out_pitch;            /* bytes per output row (>= 3 * output width)                */
+  uint8_t *out;                 /* device: u8 HWC, 3 channels (1 for DALIAMD_JPEG_OUT_GRAY)   */
+  int32_t out_pitch;            /* bytes per output row (>= channels * output width)         */
   int32_t wg_start;             /* filled by Setup                                           */
   int32_t orientation;          /* EXIF orientation to undo while writing: 0/1 none, 2..8;   */
                                 /* for 5..8 the output is height x width transposed          */
-  int32_t reserved;
+  int32_t out_format;           /* daliamdJpegOutFormat_t (decoders.image output_type)        */
   /* Region-of-interest decode: only the source pixels [roi_y0, roi_y0 + roi_h) x [roi_x0, roi_x0 + roi_w) of the
    * (un-rotated) image are produced; `out` then receives the window whose upright-image origin is
    * (out_y0, out_x0), i.e. upright pixel (oy, ox) lands at out[(oy - out_y0) * out_pitch + 3 * (ox - out_x0)].
