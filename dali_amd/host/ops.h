@@ -1,6 +1,9 @@
 // Cross-file hooks between the pipeline/executor and operator implementations.
 #ifndef DALI_AMD_HOST_OPS_H_
 #define DALI_AMD_HOST_OPS_H_
+#include <deque>
+#include <random>
+
 #include "framework.h"
 
 namespace daliamd_host {
@@ -19,6 +22,38 @@ struct DeferredResample {
   std::shared_ptr<TensorList> source;                 // the producer's input (u8 HWC on the device)
   std::vector<daliamdResampleArgs> args;              // one per sample; `out*`/epilogue fields unset
   int out_h = 0, out_w = 0, channels = 0;
+};
+
+// The sample-index stream every reader draws from (Loader, dali/operators/reader/loader/loader.h:78-503,
+// loader.cc:78-87): sequential over the data set starting at this shard (start = size * shard_id / num_shards),
+// moving on to the next shard every epoch unless stick_to_shard, a shuffle reservoir of `initial_fill` samples,
+// padding of the last batch, epoch bookkeeping for the iterators (ReaderMeta) and a complete checkpoint.
+// A reader owns one, tells it the data set size once, and asks for one index per output sample.
+class Loader {
+ public:
+  explicit Loader(const OpSpec &spec);
+  void Init(int64_t size);          // after the data set has been discovered
+  int64_t Size() const { return size_; }
+  int64_t NextIndex(bool is_new_batch);
+  ReaderMeta Meta() const;
+  std::string Save() const;
+  void Restore(const std::string &state);
+
+ private:
+  void Reset(bool wrap_to_shard);
+  bool IsNextShard(int64_t idx) const;
+  int64_t ReadSequential();
+  bool shuffle_;
+  int initial_fill_, num_shards_, shard_id_;
+  bool stick_to_shard_, pad_last_batch_;
+  int64_t size_ = 0;
+  std::default_random_engine rng_;
+  int virtual_shard_id_ = 0;
+  int64_t current_index_ = 0, read_in_shard_ = 0, total_read_ = 0, consumed_ = 0, returned_ = 0, epoch_ = 0;
+  int64_t last_pick_ = -1;
+  bool filled_ = false;
+  std::vector<std::pair<int64_t, int64_t>> buffer_;  // (sequence number, dataset index)
+  std::deque<int64_t> shard_ends_;                   // sequence numbers at which an epoch (shard) ends
 };
 
 }  // namespace daliamd_host

@@ -152,45 +152,161 @@ static std::vector<std::string> ListDir(const std::string &dir, bool want_dirs, 
   return out;
 }
 
+// ---------------------------------------------------------------------------------------------- Loader
+Loader::Loader(const OpSpec &spec)
+    : shuffle_(spec.GetBool("random_shuffle")),
+      initial_fill_(shuffle_ ? (int)spec.GetInt("initial_fill") : 1),
+      num_shards_((int)spec.GetInt("num_shards")),
+      shard_id_((int)spec.GetInt("shard_id")),
+      stick_to_shard_(spec.GetBool("stick_to_shard")),
+      pad_last_batch_(spec.GetBool("pad_last_batch")) {
+  DALI_ENFORCE(num_shards_ > shard_id_, "num_shards needs to be greater than shard_id");
+  DALI_ENFORCE(shard_id_ >= 0, "shard_id must be non-negative");
+  DALI_ENFORCE(initial_fill_ > 0, "initial_fill must be positive");
+  std::seed_seq seq({spec.GetInt("seed")});
+  rng_ = std::default_random_engine(seq);
+  virtual_shard_id_ = shard_id_;
+}
+
+void Loader::Init(int64_t size) {
+  size_ = size;
+  DALI_ENFORCE((int64_t)num_shards_ <= size_, "The number of input samples: ", size_,
+               ", needs to be at least equal to the requested number of shards: ", num_shards_, ".");
+  Reset(true);
+}
+
+ReaderMeta Loader::Meta() const {
+  ReaderMeta m;
+  m.epoch_size = size_;
+  m.epoch_size_padded = pad_last_batch_ ? num_samples(num_shards_, size_) * num_shards_ : size_;
+  m.number_of_shards = num_shards_;
+  m.shard_id = shard_id_;
+  m.pad_last_batch = pad_last_batch_;
+  m.stick_to_shard = stick_to_shard_;
+  return m;
+}
+
+// checkpoint (loader.h:279,335,485-503): the COMPLETE state - position of the sequential stream, shard bookkeeping,
+// the samples sitting in the shuffle buffer (read ahead but not yet returned), the epoch end marks and the rng - so a
+// restored reader continues with exactly the sample the saved one would have returned next, whether it is a fresh
+// instance or one that has already run.
+std::string Loader::Save() const {
+  std::ostringstream ss;
+  ss << current_index_ << " " << virtual_shard_id_ << " " << read_in_shard_ << " " << total_read_ << " " << consumed_
+     << " " << returned_ << " " << epoch_ << " " << last_pick_ << " " << (filled_ ? 1 : 0) << " " << buffer_.size();
+  for (auto &b : buffer_) ss << " " << b.first << " " << b.second;
+  ss << " " << shard_ends_.size();
+  for (int64_t e : shard_ends_) ss << " " << e;
+  ss << " " << rng_;
+  return ss.str();
+}
+void Loader::Restore(const std::string &s) {
+  std::istringstream ss(s);
+  int filled = 0;
+  size_t nbuf = 0, nends = 0;
+  ss >> current_index_ >> virtual_shard_id_ >> read_in_shard_ >> total_read_ >> consumed_ >> returned_ >> epoch_ >>
+      last_pick_ >> filled >> nbuf;
+  DALI_ENFORCE(!ss.fail() && nbuf <= (size_t)initial_fill_, "reader: malformed checkpoint");
+  buffer_.assign(nbuf, {0, 0});
+  for (auto &b : buffer_) ss >> b.first >> b.second;
+  ss >> nends;
+  DALI_ENFORCE(!ss.fail() && nends <= (1u << 20), "reader: malformed checkpoint");
+  shard_ends_.assign(nends, 0);
+  for (auto &e : shard_ends_) ss >> e;
+  ss >> std::ws >> rng_;  // libstdc++ reads the engine with skipws cleared
+  DALI_ENFORCE(!ss.fail(), "reader: malformed checkpoint");
+  for (auto &b : buffer_) DALI_ENFORCE(b.second >= 0 && b.second < size_, "reader: checkpoint of another dataset");
+  DALI_ENFORCE(last_pick_ < size_ && current_index_ >= 0 && current_index_ <= size_, "reader: checkpoint of another dataset");
+  filled_ = filled != 0;
+}
+
+// sequential stream over the dataset, starting at this shard and (unless stick_to_shard) moving
+// on to the next shard every epoch (loader.h:413-452)
+void Loader::Reset(bool wrap_to_shard) {
+  current_index_ = wrap_to_shard ? (int64_t)start_index(virtual_shard_id_, num_shards_, size_) : 0;
+}
+bool Loader::IsNextShard(int64_t idx) const {
+  return idx >= size_ || (stick_to_shard_ && shard_id_ + 1 < num_shards_ &&
+                          idx >= (int64_t)start_index(shard_id_ + 1, num_shards_, size_));
+}
+int64_t Loader::ReadSequential() {
+  if (IsNextShard(current_index_)) Reset(stick_to_shard_);
+  int64_t idx = current_index_++;
+  // shard bookkeeping (IncreaseReadSampleCounter, loader.h:440-457)
+  read_in_shard_++;
+  int64_t rel_end = (int64_t)start_index(virtual_shard_id_ + 1, num_shards_, size_) -
+                    (int64_t)start_index(virtual_shard_id_, num_shards_, size_);
+  if (read_in_shard_ >= rel_end) {
+    shard_ends_.push_back(total_read_ + 1);
+    if (!stick_to_shard_) virtual_shard_id_ = (virtual_shard_id_ + 1) % num_shards_;
+    read_in_shard_ = 0;
+  }
+  total_read_++;
+  return idx;
+}
+
+// one sample of the output stream: shuffle buffer + last-batch padding (loader.h:207-345)
+int64_t Loader::NextIndex(bool is_new_batch) {
+  if (buffer_.empty() && !filled_) {
+    for (int i = 0; i < initial_fill_; i++) {
+      int64_t seq = total_read_;  // by value: ReadSequential() advances total_read_
+      int64_t idx = ReadSequential();
+      buffer_.push_back({seq, idx});
+    }
+    filled_ = true;
+  }
+  // the current epoch (shard) is depleted when everything read before its end mark was returned
+  if (!shard_ends_.empty() && consumed_ >= shard_ends_.front()) {
+    bool pad = (returned_ < num_samples(num_shards_, size_) || !is_new_batch) && pad_last_batch_;
+    if (pad && last_pick_ >= 0) {
+      returned_++;
+      return last_pick_;
+    }
+    shard_ends_.pop_front();
+    returned_ = 0;
+    epoch_++;
+  }
+  // candidates: buffered samples that belong to the current epoch
+  int64_t limit = shard_ends_.empty() ? total_read_ : shard_ends_.front();
+  int ncand = 0;
+  for (auto &b : buffer_) ncand += b.first < limit;
+  DALI_ENFORCE(ncand > 0, "Internal error: shuffle buffer has no sample of the current epoch");
+  int pick = 0;
+  if (shuffle_) pick = std::uniform_int_distribution<>(0, ncand - 1)(rng_);
+  int pos = -1;
+  for (int i = 0, k = 0; i < (int)buffer_.size(); i++) {
+    if (buffer_[i].first < limit) {
+      if (k == pick) { pos = i; break; }
+      k++;
+    }
+  }
+  int64_t idx = buffer_[pos].second;
+  {
+    int64_t seq = total_read_;
+    int64_t next = ReadSequential();
+    buffer_[pos] = {seq, next};
+  }
+  consumed_++;
+  returned_++;
+  last_pick_ = idx;
+  return idx;
+}
+
+// ---------------------------------------------------------------------------------------------- readers.file
 class FileReaderOp : public OperatorBase {
  public:
-  explicit FileReaderOp(const OpSpec &spec)
-      : OperatorBase(spec),
-        shuffle_(spec.GetBool("random_shuffle")),
-        initial_fill_(shuffle_ ? (int)spec.GetInt("initial_fill") : 1),
-        num_shards_((int)spec.GetInt("num_shards")),
-        shard_id_((int)spec.GetInt("shard_id")),
-        stick_to_shard_(spec.GetBool("stick_to_shard")),
-        pad_last_batch_(spec.GetBool("pad_last_batch")) {
-    DALI_ENFORCE(num_shards_ > shard_id_, "num_shards needs to be greater than shard_id");
-    DALI_ENFORCE(shard_id_ >= 0, "shard_id must be non-negative");
-    DALI_ENFORCE(initial_fill_ > 0, "initial_fill must be positive");
+  explicit FileReaderOp(const OpSpec &spec) : OperatorBase(spec), loader_(spec) {
     Discover();
-    DALI_ENFORCE((int64_t)num_shards_ <= Size(), "The number of input samples: ", Size(),
-                 ", needs to be at least equal to the requested number of shards: ", num_shards_, ".");
-    std::seed_seq seq({spec.GetInt("seed")});
-    rng_ = std::default_random_engine(seq);
-    virtual_shard_id_ = shard_id_;
-    Reset(true);
+    loader_.Init((int64_t)entries_.size());
   }
 
-  ReaderMeta GetReaderMeta() const override {
-    ReaderMeta m;
-    m.epoch_size = Size();
-    m.epoch_size_padded = pad_last_batch_ ? num_samples(num_shards_, Size()) * num_shards_ : Size();
-    m.number_of_shards = num_shards_;
-    m.shard_id = shard_id_;
-    m.pad_last_batch = pad_last_batch_;
-    m.stick_to_shard = stick_to_shard_;
-    return m;
-  }
-
+  ReaderMeta GetReaderMeta() const override { return loader_.Meta(); }
   bool SetupImpl(std::vector<OutputDesc> &, const Workspace &) override { return false; }
 
   void RunImpl(Workspace &ws) override {
     // one batch of (index) picks, then the file reads go to the thread pool
     std::vector<int64_t> picks(max_batch_size_);
-    for (int i = 0; i < max_batch_size_; i++) picks[i] = NextIndex(i == 0);
+    for (int i = 0; i < max_batch_size_; i++) picks[i] = loader_.NextIndex(i == 0);
     std::vector<TensorShape> shapes(max_batch_size_), lshape(max_batch_size_, TensorShape{1});
     std::vector<off_t> sizes(max_batch_size_);
     if (size_cache_.size() != entries_.size()) size_cache_.assign(entries_.size(), -1);
@@ -230,44 +346,12 @@ class FileReaderOp : public OperatorBase {
     ws.GetThreadPool().RunAll();
   }
 
-  // checkpoint (loader.h:279,335,485-503): the COMPLETE reader state - position of the sequential stream, shard
-  // bookkeeping, the samples sitting in the shuffle buffer (read ahead but not yet returned), the epoch end marks and
-  // the rng - so a restored reader continues with exactly the sample the saved one would have returned next, whether
-  // it is a fresh instance or one that has already run.
-  std::string SaveState() const override {
-    std::ostringstream ss;
-    ss << current_index_ << " " << virtual_shard_id_ << " " << read_in_shard_ << " " << total_read_ << " " << consumed_
-       << " " << returned_ << " " << epoch_ << " " << last_pick_ << " " << (filled_ ? 1 : 0) << " " << buffer_.size();
-    for (auto &b : buffer_) ss << " " << b.first << " " << b.second;
-    ss << " " << shard_ends_.size();
-    for (int64_t e : shard_ends_) ss << " " << e;
-    ss << " " << rng_;
-    return ss.str();
-  }
-  void RestoreState(const std::string &s) override {
-    std::istringstream ss(s);
-    int filled = 0;
-    size_t nbuf = 0, nends = 0;
-    ss >> current_index_ >> virtual_shard_id_ >> read_in_shard_ >> total_read_ >> consumed_ >> returned_ >> epoch_ >>
-        last_pick_ >> filled >> nbuf;
-    DALI_ENFORCE(!ss.fail() && nbuf <= (size_t)initial_fill_, "readers.file: malformed checkpoint");
-    buffer_.assign(nbuf, {0, 0});
-    for (auto &b : buffer_) ss >> b.first >> b.second;
-    ss >> nends;
-    DALI_ENFORCE(!ss.fail() && nends <= (1u << 20), "readers.file: malformed checkpoint");
-    shard_ends_.assign(nends, 0);
-    for (auto &e : shard_ends_) ss >> e;
-    ss >> std::ws >> rng_;  // libstdc++ reads the engine with skipws cleared
-    DALI_ENFORCE(!ss.fail(), "readers.file: malformed checkpoint");
-    for (auto &b : buffer_) DALI_ENFORCE(b.second >= 0 && b.second < Size(), "readers.file: checkpoint of another dataset");
-    DALI_ENFORCE(last_pick_ < Size() && current_index_ >= 0 && current_index_ <= Size(),
-                 "readers.file: checkpoint of another dataset");
-    filled_ = filled != 0;
-  }
+  std::string SaveState() const override { return loader_.Save(); }
+  void RestoreState(const std::string &s) override { loader_.Restore(s); }
 
  private:
+  Loader loader_;
   std::vector<off_t> size_cache_;
-  int64_t Size() const { return (int64_t)entries_.size(); }
   std::string Path(int64_t idx) const {
     const std::string &f = entries_[idx].first;
     return (root_.empty() || (!f.empty() && f[0] == '/')) ? f : root_ + "/" + f;
@@ -311,90 +395,8 @@ class FileReaderOp : public OperatorBase {
     DALI_ENFORCE(!entries_.empty(), "No files found.");
   }
 
-  // sequential stream over the dataset, starting at this shard and (unless stick_to_shard) moving
-  // on to the next shard every epoch (loader.h:413-452)
-  void Reset(bool wrap_to_shard) {
-    current_index_ = wrap_to_shard ? (int64_t)start_index(virtual_shard_id_, num_shards_, Size()) : 0;
-  }
-  bool IsNextShard(int64_t idx) const {
-    return idx >= Size() || (stick_to_shard_ && shard_id_ + 1 < num_shards_ &&
-                             idx >= (int64_t)start_index(shard_id_ + 1, num_shards_, Size()));
-  }
-  int64_t ReadSequential() {
-    if (IsNextShard(current_index_)) Reset(stick_to_shard_);
-    int64_t idx = current_index_++;
-    // shard bookkeeping (IncreaseReadSampleCounter, loader.h:440-457)
-    read_in_shard_++;
-    int64_t rel_end = (int64_t)start_index(virtual_shard_id_ + 1, num_shards_, Size()) -
-                      (int64_t)start_index(virtual_shard_id_, num_shards_, Size());
-    if (read_in_shard_ >= rel_end) {
-      shard_ends_.push_back(total_read_ + 1);
-      if (!stick_to_shard_) virtual_shard_id_ = (virtual_shard_id_ + 1) % num_shards_;
-      read_in_shard_ = 0;
-    }
-    total_read_++;
-    return idx;
-  }
-
-  // one sample of the output stream: shuffle buffer + last-batch padding (loader.h:207-345)
-  int64_t NextIndex(bool is_new_batch) {
-    if (buffer_.empty() && !filled_) {
-      for (int i = 0; i < initial_fill_; i++) {
-        int64_t seq = total_read_;  // by value: ReadSequential() advances total_read_
-        int64_t idx = ReadSequential();
-        buffer_.push_back({seq, idx});
-      }
-      filled_ = true;
-    }
-    // the current epoch (shard) is depleted when everything read before its end mark was returned
-    if (!shard_ends_.empty() && consumed_ >= shard_ends_.front()) {
-      bool pad = (returned_ < num_samples(num_shards_, Size()) || !is_new_batch) && pad_last_batch_;
-      if (pad && last_pick_ >= 0) {
-        returned_++;
-        return last_pick_;
-      }
-      shard_ends_.pop_front();
-      returned_ = 0;
-      epoch_++;
-    }
-    // candidates: buffered samples that belong to the current epoch
-    int64_t limit = shard_ends_.empty() ? total_read_ : shard_ends_.front();
-    int ncand = 0;
-    for (auto &b : buffer_) ncand += b.first < limit;
-    DALI_ENFORCE(ncand > 0, "Internal error: shuffle buffer has no sample of the current epoch");
-    int pick = 0;
-    if (shuffle_) pick = std::uniform_int_distribution<>(0, ncand - 1)(rng_);
-    int pos = -1;
-    for (int i = 0, k = 0; i < (int)buffer_.size(); i++) {
-      if (buffer_[i].first < limit) {
-        if (k == pick) { pos = i; break; }
-        k++;
-      }
-    }
-    int64_t idx = buffer_[pos].second;
-    {
-      int64_t seq = total_read_;
-      int64_t next = ReadSequential();
-      buffer_[pos] = {seq, next};
-    }
-    consumed_++;
-    returned_++;
-    last_pick_ = idx;
-    return idx;
-  }
-
-  bool shuffle_;
-  int initial_fill_, num_shards_, shard_id_;
-  bool stick_to_shard_, pad_last_batch_;
   std::string root_;
   std::vector<std::pair<std::string, int>> entries_;
-  std::default_random_engine rng_;
-  int virtual_shard_id_ = 0;
-  int64_t current_index_ = 0, read_in_shard_ = 0, total_read_ = 0, consumed_ = 0, returned_ = 0, epoch_ = 0;
-  int64_t last_pick_ = -1;
-  bool filled_ = false;
-  std::vector<std::pair<int64_t, int64_t>> buffer_;  // (sequence number, dataset index)
-  std::deque<int64_t> shard_ends_;                   // sequence numbers at which an epoch (shard) ends
 };
 DALI_REGISTER_OPERATOR(readers__File, FileReaderOp, CPU);
 DALI_REGISTER_OPERATOR(FileReader, FileReaderOp, CPU);
