@@ -52,6 +52,18 @@ def _choose_device(inputs):
     return "cpu"
 
 
+def _count_of(arg):
+    def count(init_args):
+        v = init_args.get(arg, [])
+        return 1 if isinstance(v, str) else len(v)
+    return count
+
+
+# operators whose number of outputs follows an argument (OpSchema::OutputFn in the reference)
+_OUTPUT_COUNT = {"readers__Webdataset": _count_of("ext"), "readers__TFRecord": _count_of("feature_names"),
+                 "TFRecordReader": _count_of("feature_names")}
+
+
 def _make_fn(schema_name, wrapper_name):
     schema = _b.get_schema(schema_name)
     arg_defs = {a["name"]: a for a in schema["args"]}
@@ -107,8 +119,11 @@ def _make_fn(schema_name, wrapper_name):
                 arg_inputs[k] = v
             else:
                 init_args[k] = v
-        outs = pipe._add_op(schema_name, device, init_args, flat_inputs, arg_inputs, schema["num_outputs"], name)
-        return outs[0] if len(outs) == 1 else outs
+        nout = schema["num_outputs"]
+        if schema_name in _OUTPUT_COUNT:      # the reference's OutputFn: the output count follows an argument
+            nout = _OUTPUT_COUNT[schema_name](init_args)
+        outs = pipe._add_op(schema_name, device, init_args, flat_inputs, arg_inputs, nout, name)
+        return outs[0] if len(outs) == 1 and schema_name not in _OUTPUT_COUNT else outs
 
     fn_wrapper.__name__ = fn_wrapper.__qualname__ = wrapper_name
     lines = [schema["doc"], "", "Keyword args", "------------"]
@@ -186,3 +201,28 @@ def external_source(source=None, num_outputs=None, *, cycle=None, name=None, dev
 
 
 _populate()
+
+
+def _wrap_tfrecord():
+    """fn.readers.tfrecord(path, index_path, features={name: tfrecord.FixedLenFeature / VarLenFeature}) -> dict of
+    outputs, like the reference (dali/python/nvidia/dali/ops/_operators/tfrecord.py): the dictionary is flattened
+    into the per-feature argument vectors of the operator."""
+    root = sys.modules[__name__]
+    raw = root.readers.tfrecord
+
+    def tfrecord(*, path, index_path, features, **kwargs):
+        names = list(features)
+        feats = [features[k] for k in names]
+        shapes = [e for f in feats for e in f.shape]
+        outs = raw(path=[path] if isinstance(path, str) else list(path),
+                   index_path=[index_path] if isinstance(index_path, str) else list(index_path), feature_names=names,
+                   feature_dtypes=[int(f.dtype) for f in feats], feature_has_shape=[int(f.has_shape) for f in feats],
+                   feature_ndims=[len(f.shape) for f in feats], **({"feature_shapes": shapes} if shapes else {}), **kwargs)
+        return dict(zip(names, outs))
+
+    tfrecord.__doc__ = raw.__doc__
+    tfrecord._schema_name = raw._schema_name
+    root.readers.tfrecord = tfrecord
+
+
+_wrap_tfrecord()
