@@ -52,16 +52,18 @@ def effective_cpu_count():
     return n
 
 
-def measured_traffic(kernel):
+def measured_traffic(kernel, workload=""):
     """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*_traffic.json, produced by
     tools/collect_profiles.sh: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH_SIZE correction).  bench.py
     cannot run rocprofv3 around itself, so this is the figure of the profiled run of this same command."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", f"*{workload}_traffic.json"))
+                   if workload or not any(w in os.path.basename(f) for w in ("heavy_aug", "audio")))
     if not files:
         return None, None
     try:
-        k = json.load(open(files[-1]))["kernels"].get(kernel, {})
+        ks = json.load(open(files[-1]))["kernels"]
+        k = ks.get(kernel) or next((v for n, v in ks.items() if n.startswith(kernel)), {})
         return k.get("hbm_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
     except (OSError, ValueError, KeyError):
         return None, None
@@ -376,6 +378,7 @@ def bench_heavy_aug(args, device):
         ms = float(np.mean([e[j].elapsed_time(e[j + 1]) for e in ev]))
         per[nm] = {"algorithmic_bytes": bytes_per, "avg_ms_incl_desc_upload": ms, "achieved_GBps": bytes_per / (ms * 1e-3) / 1e9}
     dom = max(per, key=lambda k: per[k]["avg_ms_incl_desc_upload"])
+    traffic, traffic_src = measured_traffic(dom.split("(")[0], "heavy_aug")
     print(json.dumps({"metric": "images/sec heavy-aug 512^2 b128 (warp_affine+gaussian_blur(sigma=3)+color_twist+erase)",
                       "value": n * args.steps / el, "unit": "images/s", "n_gpus": 1, "steps": args.steps,
                       "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
@@ -383,7 +386,7 @@ def bench_heavy_aug(args, device):
                       "config": {"workload": "configs[2]: 128 x 512x512x3 u8 resident in HBM"},
                       "roofline": {"bound": "hbm", "kernel": dom, "achieved": per[dom]["achieved_GBps"],
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": per[dom]["achieved_GBps"] / HBM_PEAK_GBS,
-                                   "traffic": None, "per_kernel": per}}))
+                                   "traffic": traffic, "traffic_source": traffic_src, "per_kernel": per}}))
 
 
 def bench_audio(args, device):
@@ -401,6 +404,7 @@ def bench_audio(args, device):
         spec = fn.spectrogram(x.gpu(), nfft=1024, window_length=1024, window_step=256)
         mel = fn.mel_filter_bank(spec, nfilter=80, sample_rate=16000.0, freq_high=8000.0)
         pipe.set_outputs(fn.to_decibels(mel, multiplier=10.0, cutoff_db=-80.0))
+    pipe.enable_operator_timing()
     pipe.build()
     frames = sum(len(s) // 256 + 1 for s in sigs)
     for _ in range(args.warmup):
@@ -414,17 +418,29 @@ def bench_audio(args, device):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     samples = sum(len(s) for s in sigs)
+    # algorithmic bytes per launch: every signal sample read once, every output element written once
     algo = {"SpectrogramKernel": 4 * samples + 4 * 513 * frames, "MelKernel": 4 * 513 * frames + 4 * 80 * frames,
             "DecibelKernel": 8 * 80 * frames}
+    op_of = {"SpectrogramKernel": "Spectrogram", "MelKernel": "MelFilterBank", "DecibelKernel": "ToDecibels"}
+    times = pipe.operator_device_times()   # events on the operators' stream around each operator's launches
+    per = {}
+    for kern, op in op_of.items():
+        ms = next((v for k, v in times.items() if op.lower() in k.lower().replace("_", "")), None)
+        if ms:
+            per[kern] = {"algorithmic_bytes": algo[kern], "avg_ms": ms, "achieved_GBps": algo[kern] / (ms * 1e-3) / 1e9}
+    dom = max(per, key=lambda k: per[k]["avg_ms"]) if per else None
+    traffic, traffic_src = measured_traffic(dom, "audio") if dom else (None, None)
+    ach = per[dom]["achieved_GBps"] if dom else None
     print(json.dumps({"metric": "utterances/sec spectrogram(1024)->mel(80)->dB b64 (incl. H2D of the signals)",
                       "value": n * args.steps / el, "unit": "utterances/s", "n_gpus": 1, "steps": args.steps,
                       "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
                       "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                       "config": {"workload": "configs[3]: 64 mono signals, 16 kHz, 8-16 s", "frames": frames,
-                                 "mel_gemm_flops": 2 * 80 * 513 * frames},
-                      "roofline": {"bound": "hbm", "kernel": "see profiles/ (rocprofv3 kernel trace)", "achieved": None,
-                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                                   "algorithmic_bytes": algo}}))
+                                 "samples": samples},
+                      "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": ach / HBM_PEAK_GBS if ach else None, "traffic": traffic,
+                                   "traffic_source": traffic_src, "per_kernel": per,
+                                   "operator_device_ms": times}}))
 
 
 def bench_cpu_backend(args):

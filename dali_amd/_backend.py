@@ -146,6 +146,18 @@ class BackendPipeline:
             self._lib.daliamdPipelineDestroy(self._h)
             self._h = None
 
+    def enable_operator_timing(self):
+        check(self._lib.daliamdPipelineEnableOperatorTiming(C.c_void_p(self._h), 1))
+
+    def operator_times(self):
+        """{operator instance name: average device ms} (after enable_operator_timing)."""
+        out = {}
+        for line in _string_out(self._lib.daliamdPipelineOperatorTimes, C.c_void_p(self._h)).split("\n"):
+            if line:
+                k, v = line.rsplit("\t", 1)
+                out[k] = float(v)
+        return out
+
     def add_operator(self, spec, name):
         check(self._lib.daliamdPipelineAddOperator(self._h, spec._h, name.encode()))
 

@@ -174,7 +174,7 @@ _KERNEL_SYMBOLS = [
     "daliamdWarpAffineSetup", "daliamdWarpAffineRun", "daliamdGaussianWindow", "daliamdGaussianBlurSetup",
     "daliamdGaussianBlurRun", "daliamdColorTwistMatrix", "daliamdPointwiseSetup", "daliamdPointwiseRun",
     "daliamdHannWindow", "daliamdSpectrogramSetup", "daliamdSpectrogramRun", "daliamdMelFilterBankWeights",
-    "daliamdMelFilterBankSetup", "daliamdMelFilterBankRun", "daliamdToDecibelsRun",
+    "daliamdMelFilterBankBands", "daliamdMelFilterBankSetup", "daliamdMelFilterBankRun", "daliamdToDecibelsRun",
     "daliamdNormalizeSetup", "daliamdNormalizeRun",
 ]
 

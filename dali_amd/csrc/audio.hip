@@ -1,5 +1,5 @@
-// Audio feature kernels for gfx950: spectrogram (fused windowing + in-LDS FFT + power), mel filter bank as an
-// f32 MFMA GEMM, and to_decibels with a per-sample max reduction.  See include/dali_amd_kernels.h for the
+// Audio feature kernels for gfx950: spectrogram (fused windowing + in-LDS radix-4 FFT + power), mel filter bank as a
+// banded matrix product, and to_decibels with a per-sample max reduction.  See include/dali_amd_kernels.h for the
 // reference counterparts.  f32 throughout; parity with the reference's CPU path is tolerance-based for the FFT
 // (its FFTS library is not available; tests use a float64 FFT like the reference's own tests do).
 #include <cmath>
@@ -8,11 +8,22 @@
 
 namespace daliamd {
 
+#pragma clang fp contract(fast)  // tolerance-based parity here (f32 FFT vs the oracle's f64): let the compiler form FMAs
+
 // =============================================================================================
 // spectrogram
+//
+// One frame per wave at a time, kFramesPerWave frames one after another.  The nfft real samples of a frame are packed
+// into N = nfft/2 complex points z[n] = x[2n] + i x[2n+1]; a Stockham radix-4 (+ one radix-2 step when log2 N is odd)
+// FFT runs in the wave's own LDS buffer - every lane keeps all the points of its butterflies in registers between the
+// read and the write of a step, so one buffer is enough and the only synchronisation is wave-local.  The spectrum of
+// the real signal is then X[k] = E[k] + W^k O[k], X[N-k] = conj(E[k] - W^k O[k]) with E / O the even / odd parts of Z.
+// Powers go to an LDS tile [bin][frame] so that the frequency-major output is written 16 frames (64 bytes) at a time.
 // =============================================================================================
-constexpr int kSpecThreads = 256;
-constexpr int kFramesPerWg = kSpecThreads / 64;  // one frame per wave
+constexpr int kSpecWaves = 4;
+constexpr int kSpecThreads = 64 * kSpecWaves;
+inline __host__ __device__ constexpr int SpecFramesPerWave(int nfft) { return nfft >= 4096 ? 2 : 4; }  // LDS budget
+inline int SpecFramesPerWg(int nfft) { return kSpecWaves * SpecFramesPerWave(nfft); }
 
 __device__ __forceinline__ long long Reflect101L(long long idx, long long size) {
   if (size < 2) return size - 1;
@@ -24,111 +35,239 @@ __device__ __forceinline__ long long Reflect101L(long long idx, long long size) 
   return idx;
 }
 
+__device__ __forceinline__ void SpecWaveSync() {  // LDS accesses of one wave execute in order; compiler fence only
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ float2 CMul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 CAdd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 CSub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+
+// tw[k] = exp(-2 pi i k / (2N)), k < N; the second half of the circle is the negated first half
+template <int N>
+__device__ __forceinline__ float2 Twiddle(const float2 *tw, int idx) {
+  float2 w = tw[idx & (N - 1)];
+  return idx >= N ? make_float2(-w.x, -w.y) : w;
+}
+
+// One Stockham step of radix R over the N points in `work`: butterfly j reads work[j + r N/R], multiplies by
+// exp(-2 pi i r k / (Ns R)), k = j mod Ns, and writes work[(j - k) R + k + r Ns].
+template <int N, int NS>
+__device__ __forceinline__ void Radix4Step(float2 *work, const float2 *tw, int lane) {
+  constexpr int per = N / 4, UB = (per + 63) / 64;
+  float2 v[UB][4];
+#pragma unroll
+  for (int u = 0; u < UB; u++) {
+    const int j = lane + 64 * u;
+    if (j < per) {
+      const int k = j & (NS - 1);
+      float2 a = work[j], b = work[j + per], c = work[j + 2 * per], d = work[j + 3 * per];
+      if (NS > 1) {
+        const int m = 2 * k * (N / (NS * 4));  // table resolution is 2N
+        b = CMul(b, Twiddle<N>(tw, m));
+        c = CMul(c, Twiddle<N>(tw, 2 * m));
+        d = CMul(d, Twiddle<N>(tw, 3 * m));
+      }
+      const float2 s0 = CAdd(a, c), s1 = CSub(a, c), s2 = CAdd(b, d), df = CSub(b, d);
+      const float2 s3 = make_float2(df.y, -df.x);  // -i (b - d)
+      v[u][0] = CAdd(s0, s2);
+      v[u][1] = CAdd(s1, s3);
+      v[u][2] = CSub(s0, s2);
+      v[u][3] = CSub(s1, s3);
+    }
+  }
+  SpecWaveSync();
+#pragma unroll
+  for (int u = 0; u < UB; u++) {
+    const int j = lane + 64 * u;
+    if (j < per) {
+      const int k = j & (NS - 1);
+      float2 *o = work + ((j - k) << 2) + k;
+#pragma unroll
+      for (int r = 0; r < 4; r++) o[r * NS] = v[u][r];
+    }
+  }
+  SpecWaveSync();
+}
+
+template <int N, int NS>
+__device__ __forceinline__ void Radix2Step(float2 *work, const float2 *tw, int lane) {
+  constexpr int per = N / 2, UB = (per + 63) / 64;
+  float2 v[UB][2];
+#pragma unroll
+  for (int u = 0; u < UB; u++) {
+    const int j = lane + 64 * u;
+    if (j < per) {
+      const int k = j & (NS - 1);
+      float2 a = work[j], b = work[j + per];
+      if (NS > 1) b = CMul(b, Twiddle<N>(tw, 2 * k * (N / (NS * 2))));
+      v[u][0] = CAdd(a, b);
+      v[u][1] = CSub(a, b);
+    }
+  }
+  SpecWaveSync();
+#pragma unroll
+  for (int u = 0; u < UB; u++) {
+    const int j = lane + 64 * u;
+    if (j < per) {
+      const int k = j & (NS - 1);
+      float2 *o = work + ((j - k) << 1) + k;
+      o[0] = v[u][0];
+      o[NS] = v[u][1];
+    }
+  }
+  SpecWaveSync();
+}
+
+template <int N, int LOG2N, int S>
+struct FftSteps {
+  static __device__ __forceinline__ void Run(float2 *work, const float2 *tw, int lane) {
+    if constexpr (LOG2N - S >= 2) {
+      Radix4Step<N, (1 << S)>(work, tw, lane);
+      FftSteps<N, LOG2N, S + 2>::Run(work, tw, lane);
+    } else if constexpr (LOG2N - S == 1) {
+      Radix2Step<N, (1 << S)>(work, tw, lane);
+    }
+  }
+};
+
+template <int LOG2N>  // N = nfft / 2 = 1 << LOG2N complex points per frame
 __global__ __launch_bounds__(kSpecThreads) void SpectrogramKernel(const daliamdSpectrogramDesc *__restrict__ descs, int ndesc,
                                                                   int total_wg, daliamdSpectrogramParams p,
                                                                   const float *__restrict__ window) {
+  constexpr int N = 1 << LOG2N, nfft = 2 * N;
+  constexpr int U = (N + 63) / 64;  // complex points per lane
+  constexpr int FPW = SpecFramesPerWave(nfft), FPG = FPW * kSpecWaves, TS = FPG + 1;
   extern __shared__ __attribute__((aligned(16))) float2 spec_lds[];
   int wg = XcdRemap(blockIdx.x, total_wg);
   if (wg < 0) return;
   const daliamdSpectrogramDesc &d = descs[FindDesc(descs, ndesc, wg)];
-  const int nfft = p.nfft, half = nfft >> 1;
-  const int log2n = 31 - __clz(nfft);
-  float2 *tw = spec_lds;                       // [nfft/2] twiddles exp(-2*pi*i*k/nfft)
-  float2 *buf = spec_lds + half;               // [kFramesPerWg][nfft]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int k = tid; k < half; k += kSpecThreads) {
-    float s, c;
-    sincospif(-2.0f * (float)k / (float)nfft, &s, &c);
-    tw[k] = make_float2(c, s);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float2 *tw = spec_lds;                              // [N]
+  float2 *work = spec_lds + N + wave * N;             // [N] per wave
+  float *tile = reinterpret_cast<float *>(spec_lds + N + kSpecWaves * N);  // [N + 1][TS]
+  for (int k = tid; k < N; k += kSpecThreads) {
+    float sn, cs;
+    sincospif(-(float)k / (float)N, &sn, &cs);
+    tw[k] = make_float2(cs, sn);
   }
-  const int t0 = (wg - d.wg_start) * kFramesPerWg;
-  const int frame = t0 + wave;
-  float2 *fb = buf + (size_t)wave * nfft;
-  // ---- windowed frame, bit-reversed placement (decimation in time) ----
-  const int pad0 = (nfft - p.window_length) / 2;  // window centred inside nfft (fft_cpu_impl_ffts.cc:108-110)
-  const long long start = (long long)frame * p.window_step - (p.center_windows ? p.window_length / 2 : 0);
-  for (int i = lane; i < nfft; i += 64) {
-    float v = 0.0f;
-    int wi = i - pad0;
-    if (frame < d.num_windows && wi >= 0 && wi < p.window_length) {
-      long long idx = start + wi;
-      if (p.reflect_padding) v = window[wi] * d.in[Reflect101L(idx, d.length)];
-      else if (idx >= 0 && idx < d.length) v = window[wi] * d.in[idx];
-    }
-    int j = (int)(__brev((unsigned)i) >> (32 - log2n));
-    fb[j] = make_float2(v, 0.0f);
+  // the window, centred inside nfft (fft_cpu_impl_ffts.cc:108-110), lives in registers for all the frames of the wave
+  const int pad0 = (nfft - p.window_length) / 2;
+  float2 wr[U];
+  unsigned inwin[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const int i = lane + 64 * u, w0 = 2 * i - pad0, w1 = w0 + 1;
+    const bool in0 = i < N && w0 >= 0 && w0 < p.window_length, in1 = i < N && w1 >= 0 && w1 < p.window_length;
+    wr[u] = make_float2(in0 ? window[w0] : 0.0f, in1 ? window[w1] : 0.0f);
+    inwin[u] = (in0 ? 1u : 0u) | (in1 ? 2u : 0u);
   }
   __syncthreads();
-  // ---- radix-2 butterflies ----
-  for (int s = 0; s < log2n; s++) {
-    const int hs = 1 << s;
-    const int tstride = half >> s;
-    for (int b = lane; b < half; b += 64) {
-      int pos = b & (hs - 1);
-      int i0 = ((b >> s) << (s + 1)) + pos, i1 = i0 + hs;
-      float2 w = tw[pos * tstride];
-      float2 x0 = fb[i0], x1 = fb[i1];
-      float2 t = make_float2(w.x * x1.x - w.y * x1.y, w.x * x1.y + w.y * x1.x);
-      fb[i0] = make_float2(x0.x + t.x, x0.y + t.y);
-      fb[i1] = make_float2(x0.x - t.x, x0.y - t.y);
-    }
-    __syncthreads();
-  }
-  // ---- power / magnitude, frequency-major output: 4 consecutive frames per bin ----
   const int T = d.num_windows;
-  const int nf = min(kFramesPerWg, T - t0);
-  for (int b = tid; b <= half; b += kSpecThreads) {
-    float *o = d.out + (size_t)b * T + t0;
-    for (int f = 0; f < nf; f++) {
-      float2 x = buf[(size_t)f * nfft + b];
-      float pw = x.x * x.x + x.y * x.y;
-      o[f] = p.power == 2 ? pw : sqrtf(pw);
+  const int t0 = (wg - d.wg_start) * FPG;
+  const float *__restrict__ in = d.in;
+  for (int f = 0; f < FPW; f++) {
+    const int fi = f * kSpecWaves + wave;  // frame slot inside the tile
+    const int frame = t0 + fi;
+    if (frame >= T) break;
+    // buffer position j holds window[j - pad0] * in[base + j]
+    const long long base = (long long)frame * p.window_step - (p.center_windows ? p.window_length / 2 : 0) - pad0;
+    if (base >= 0 && base + nfft <= d.length) {
+      const float *src = in + base;
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int i = lane + 64 * u;
+        if (i < N) {
+          const float x0 = src[2 * i], x1 = src[2 * i + 1];
+          work[i] = make_float2((inwin[u] & 1) ? wr[u].x * x0 : 0.0f, (inwin[u] & 2) ? wr[u].y * x1 : 0.0f);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int i = lane + 64 * u;
+        if (i < N) {
+          float x[2] = {0.0f, 0.0f};
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            if (!((inwin[u] >> h) & 1)) continue;
+            const long long idx = base + 2 * i + h;
+            const float w = h ? wr[u].y : wr[u].x;
+            if (p.reflect_padding) x[h] = w * in[Reflect101L(idx, d.length)];
+            else if (idx >= 0 && idx < d.length) x[h] = w * in[idx];
+          }
+          work[i] = make_float2(x[0], x[1]);
+        }
+      }
     }
+    SpecWaveSync();
+    FftSteps<N, LOG2N, 0>::Run(work, tw, lane);
+    // real-signal spectrum from the half-length transform, power / magnitude into the tile
+    constexpr int UP = (N / 2 + 1 + 63) / 64;
+#pragma unroll
+    for (int u = 0; u < UP; u++) {
+      const int k = lane + 64 * u;
+      if (k <= N / 2) {
+        const float2 zk = work[k & (N - 1)], zn = work[(N - k) & (N - 1)];
+        const float2 e = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+        const float2 o = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+        const float2 t = CMul(tw[k], o);
+        const float2 xa = CAdd(e, t), xb = CSub(e, t);
+        float pa = xa.x * xa.x + xa.y * xa.y, pb = xb.x * xb.x + xb.y * xb.y;
+        if (p.power != 2) {
+          pa = sqrtf(pa);
+          pb = sqrtf(pb);
+        }
+        tile[k * TS + fi] = pa;
+        tile[(N - k) * TS + fi] = pb;
+      }
+    }
+    SpecWaveSync();
+  }
+  __syncthreads();
+  // frequency-major output: FPG consecutive frames per bin
+  for (int idx = tid; idx < (N + 1) * FPG; idx += kSpecThreads) {
+    const int b = idx / FPG, f = idx % FPG;
+    if (t0 + f < T) d.out[(size_t)b * T + t0 + f] = tile[b * TS + f];
   }
 }
 
 // =============================================================================================
-// mel filter bank: out[nfilter][T] = W[nfilter][K] * S[K][T] on v_mfma_f32_16x16x4_f32
+// mel filter bank: out[m][t] = sum over the filter's band of W[m][k] * S[k][t].  The triangular filters overlap only
+// their neighbours, so the product is a banded one: 2 multiply-adds per spectrogram element, bound by reading S.  A
+// workgroup owns 64 frames (one 256-byte row segment per load); its waves take the filters round-robin, so the second
+// read of a bin (by the neighbouring filter) comes from the CU's cache.
 // =============================================================================================
-constexpr int kMelThreads = 256;  // 4 waves, each owns 16 frames (columns)
-typedef float floatx4 __attribute__((ext_vector_type(4)));
+constexpr int kMelWaves = 8;
+constexpr int kMelThreads = 64 * kMelWaves;
 
-template <int MT>
 __global__ __launch_bounds__(kMelThreads) void MelKernel(const daliamdMelDesc *__restrict__ descs, int ndesc, int total_wg,
-                                                         const float *__restrict__ W, int nfilter, int K) {
+                                                         const float *__restrict__ W, const int32_t *__restrict__ bands,
+                                                         int nfilter, int K) {
   int wg = XcdRemap(blockIdx.x, total_wg);
   if (wg < 0) return;
   const daliamdMelDesc &d = descs[FindDesc(descs, ndesc, wg)];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int T = d.frames;
-  const int t0 = ((wg - d.wg_start) * 4 + wave) * 16;
-  if (t0 >= T) return;
-  const int col = t0 + (lane & 15);      // B / D column owned by this lane
-  const int kq = lane >> 4;              // k offset inside a 4-deep step (A and B)
-  const int arow = lane & 15;            // A row inside a 16-row tile
-  floatx4 acc[MT];
-#pragma unroll
-  for (int m = 0; m < MT; m++) acc[m] = (floatx4){0, 0, 0, 0};
-  const bool col_ok = col < T;
-  for (int k0 = 0; k0 < K; k0 += 4) {
-    const int kk = k0 + kq;
-    const bool k_ok = kk < K;
-    float b = (k_ok && col_ok) ? d.in[(size_t)kk * T + col] : 0.0f;
-#pragma unroll
-    for (int m = 0; m < MT; m++) {
-      int i = 16 * m + arow;
-      float a = (k_ok && i < nfilter) ? W[(size_t)i * K + kk] : 0.0f;
-      acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[m], 0, 0, 0);
+  const int col = (wg - d.wg_start) * 64 + lane;
+  const bool ok = col < T;
+  const float *__restrict__ S = d.in + (ok ? col : 0);
+  for (int m = wave; m < nfilter; m += kMelWaves) {
+    const int kb = bands ? bands[2 * m] : 0, ke = bands ? bands[2 * m + 1] : K;
+    const float *__restrict__ w = W + (size_t)m * K;
+    float acc = 0.0f;
+    int k = kb;
+    for (; k + 4 <= ke; k += 4) {
+      const float s0 = S[(size_t)k * T], s1 = S[(size_t)(k + 1) * T], s2 = S[(size_t)(k + 2) * T], s3 = S[(size_t)(k + 3) * T];
+      acc = fmaf(w[k], s0, acc);
+      acc = fmaf(w[k + 1], s1, acc);
+      acc = fmaf(w[k + 2], s2, acc);
+      acc = fmaf(w[k + 3], s3, acc);
     }
-  }
-  if (!col_ok) return;
-#pragma unroll
-  for (int m = 0; m < MT; m++) {
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      int row = 16 * m + (lane >> 4) * 4 + r;
-      if (row < nfilter) d.out[(size_t)row * T + col] = acc[m][r];
-    }
+    for (; k < ke; k++) acc = fmaf(w[k], S[(size_t)k * T], acc);
+    if (ok) d.out[(size_t)m * T + col] = acc;
   }
 }
 
@@ -198,6 +337,7 @@ daliamdResult_t daliamdSpectrogramSetup(daliamdSpectrogramDesc *descs, int n, co
   DALIAMD_REQUIRE(p->power == 1 || p->power == 2, DALIAMD_ERROR_INVALID_ARGUMENT,
                   "`power` can be only 1 (energy) or 2 (power), received %d", p->power);
   int wg = 0;
+  const int fpg = SpecFramesPerWg(p->nfft);
   for (int i = 0; i < n; i++) {
     auto &d = descs[i];
     int64_t len = d.length;
@@ -206,10 +346,11 @@ daliamdResult_t daliamdSpectrogramSetup(daliamdSpectrogramDesc *descs, int n, co
                     "daliamdSpectrogramSetup: sample %d is shorter than the window", i);
     d.num_windows = (int32_t)(len / p->window_step + 1);  // extract_windows_args.h:38-43
     d.wg_start = wg;
-    wg += (d.num_windows + kFramesPerWg - 1) / kFramesPerWg;
+    wg += (d.num_windows + fpg - 1) / fpg;
   }
   *nwg = wg;
-  *lds_bytes = (p->nfft / 2 + kFramesPerWg * p->nfft) * (int)sizeof(float2);
+  const int N = p->nfft / 2;
+  *lds_bytes = (N + kSpecWaves * N) * (int)sizeof(float2) + (N + 1) * (fpg + 1) * (int)sizeof(float);
   return DALIAMD_SUCCESS;
 }
 
@@ -218,11 +359,23 @@ daliamdResult_t daliamdSpectrogramRun(daliamdStream_t stream, const daliamdSpect
   if (n == 0 || nwg == 0) return DALIAMD_SUCCESS;
   DALIAMD_REQUIRE(descs_dev && p && window_dev && n > 0 && nwg > 0, DALIAMD_ERROR_INVALID_ARGUMENT,
                   "daliamdSpectrogramRun: invalid argument");
-  if (lds_bytes > 64 * 1024)
-    DALIAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(SpectrogramKernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-  hipLaunchKernelGGL(SpectrogramKernel, dim3(XcdGrid(nwg)), dim3(kSpecThreads), lds_bytes, (hipStream_t)stream, descs_dev, n,
-                     nwg, *p, window_dev);
+  int log2n = 0;
+  while ((2 << log2n) < p->nfft) log2n++;
+  dim3 grid(XcdGrid(nwg)), block(kSpecThreads);
+  hipStream_t s = (hipStream_t)stream;
+#define SPEC_CASE(L)                                                                                                     \
+  case L:                                                                                                                \
+    if (lds_bytes > 64 * 1024)                                                                                           \
+      DALIAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(SpectrogramKernel<L>),                        \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));                     \
+    hipLaunchKernelGGL(SpectrogramKernel<L>, grid, block, lds_bytes, s, descs_dev, n, nwg, *p, window_dev);              \
+    break;
+  switch (log2n) {
+    SPEC_CASE(0) SPEC_CASE(1) SPEC_CASE(2) SPEC_CASE(3) SPEC_CASE(4) SPEC_CASE(5) SPEC_CASE(6) SPEC_CASE(7) SPEC_CASE(8)
+    SPEC_CASE(9) SPEC_CASE(10) SPEC_CASE(11)
+    default: DALIAMD_REQUIRE(false, DALIAMD_ERROR_UNSUPPORTED, "daliamdSpectrogramRun: unsupported nfft %d", p->nfft);
+  }
+#undef SPEC_CASE
   DALIAMD_HIP_CHECK(hipGetLastError());
   return DALIAMD_SUCCESS;
 }
@@ -282,20 +435,29 @@ daliamdResult_t daliamdMelFilterBankSetup(daliamdMelDesc *descs, int n, int *nwg
   return DALIAMD_SUCCESS;
 }
 
+daliamdResult_t daliamdMelFilterBankBands(const float *weights, int nfilter, int nbins, int32_t *bands) {
+  DALIAMD_REQUIRE(weights && bands && nfilter > 0 && nbins > 0, DALIAMD_ERROR_INVALID_ARGUMENT,
+                  "daliamdMelFilterBankBands: invalid argument");
+  for (int m = 0; m < nfilter; m++) {
+    int lo = nbins, hi = 0;
+    for (int k = 0; k < nbins; k++)
+      if (weights[(size_t)m * nbins + k] != 0.0f) {
+        if (k < lo) lo = k;
+        hi = k + 1;
+      }
+    if (lo > hi) lo = hi = 0;
+    bands[2 * m] = lo;
+    bands[2 * m + 1] = hi;
+  }
+  return DALIAMD_SUCCESS;
+}
+
 daliamdResult_t daliamdMelFilterBankRun(daliamdStream_t stream, const daliamdMelDesc *descs_dev, int n, int nwg,
-                                        const float *W, int nfilter, int nbins) {
+                                        const float *W, const int32_t *bands_dev, int nfilter, int nbins) {
   if (n == 0 || nwg == 0) return DALIAMD_SUCCESS;
   DALIAMD_REQUIRE(descs_dev && W && nfilter > 0 && nbins > 0, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdMelFilterBankRun: invalid argument");
-  int mt = (nfilter + 15) / 16;
-  DALIAMD_REQUIRE(mt <= 16, DALIAMD_ERROR_UNSUPPORTED, "daliamdMelFilterBankRun: at most 256 filters are supported, got %d", nfilter);
-  dim3 grid(XcdGrid(nwg)), block(kMelThreads);
-  hipStream_t s = (hipStream_t)stream;
-#define MEL_CASE(MT) case MT: hipLaunchKernelGGL(MelKernel<MT>, grid, block, 0, s, descs_dev, n, nwg, W, nfilter, nbins); break;
-  switch (mt) {
-    MEL_CASE(1) MEL_CASE(2) MEL_CASE(3) MEL_CASE(4) MEL_CASE(5) MEL_CASE(6) MEL_CASE(7) MEL_CASE(8)
-    default: hipLaunchKernelGGL(MelKernel<16>, grid, block, 0, s, descs_dev, n, nwg, W, nfilter, nbins); break;
-  }
-#undef MEL_CASE
+  hipLaunchKernelGGL(MelKernel, dim3(XcdGrid(nwg)), dim3(kMelThreads), 0, (hipStream_t)stream, descs_dev, n, nwg, W, bands_dev,
+                     nfilter, nbins);
   DALIAMD_HIP_CHECK(hipGetLastError());
   return DALIAMD_SUCCESS;
 }

@@ -169,6 +169,18 @@ API void *daliamdPipelineCreate(int batch_size, int num_threads, int device_id, 
 API int daliamdPipelineSetAffinity(void *h, int on) {
   return Guard([&] { static_cast<PipelineHandle *>(h)->pipe->SetAffinity(on != 0); });
 }
+// per-operator device time (timing events around the launches of every mixed / gpu operator); enable before Build()
+API int daliamdPipelineEnableOperatorTiming(void *h, int on) {
+  return Guard([&] { static_cast<PipelineHandle *>(h)->pipe->EnableOperatorTiming(on != 0); });
+}
+// "name\tms\n" per operator: average device milliseconds over the iterations handed out so far
+API int daliamdPipelineOperatorTimes(void *h, char *buf, int len) {
+  std::string s;
+  Guard([&] {
+    for (auto &kv : static_cast<PipelineHandle *>(h)->pipe->OperatorDeviceTimesMs()) s += kv.first + "\t" + std::to_string(kv.second) + "\n";
+  });
+  return CopyOut(s, buf, len);
+}
 API void daliamdPipelineDestroy(void *h) { delete static_cast<PipelineHandle *>(h); }
 API int64_t daliamdPipelineSeed(void *h) { return static_cast<PipelineHandle *>(h)->pipe->seed(); }
 

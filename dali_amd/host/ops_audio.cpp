@@ -259,17 +259,22 @@ class MelFilterBankGpu : public OperatorBase {
       weights_.resize((size_t)nfilter_ * nbins_);
       KCHECK(daliamdMelFilterBankWeights(nfilter_, 2 * (nbins_ - 1), sample_rate_, freq_low_, freq_high_, normalize_, formula_,
                                          weights_.data()));
-      weights_dev_.Reserve(weights_.size() * sizeof(float));
+      std::vector<int32_t> bands(2 * (size_t)nfilter_);
+      KCHECK(daliamdMelFilterBankBands(weights_.data(), nfilter_, nbins_, bands.data()));
+      const size_t wbytes = (weights_.size() * sizeof(float) + 15) / 16 * 16;
+      weights_dev_.Reserve(wbytes + bands.size() * sizeof(int32_t));
       KCHECK(daliamdMemcpyH2DAsync(weights_dev_.data(), weights_.data(), weights_.size() * sizeof(float), ws.stream));
-      KCHECK(daliamdStreamSynchronize(ws.stream));  // one-time upload read by later iterations on other streams
-      KCHECK(daliamdStreamSynchronize(ws.stream));  // one-time upload from pageable memory
+      bands_dev_ = reinterpret_cast<const int32_t *>(static_cast<char *>(weights_dev_.data()) + wbytes);
+      KCHECK(daliamdMemcpyH2DAsync(const_cast<int32_t *>(bands_dev_), bands.data(), bands.size() * sizeof(int32_t), ws.stream));
+      KCHECK(daliamdStreamSynchronize(ws.stream));  // one-time upload from pageable memory, read by later iterations
     }
     for (int i = 0; i < n; i++) descs_[i].out = static_cast<float *>(out.raw(i));
     int nwg = 0;
     KCHECK(daliamdMelFilterBankSetup(descs_.data(), n, &nwg));
     auto *dev = static_cast<const daliamdMelDesc *>(uploader_.Upload(descs_.data(), n * sizeof(descs_[0]), ws.stream, ws.ring + 1));
-    KCHECK(daliamdMelFilterBankRun(ws.stream, dev, n, nwg, static_cast<const float *>(weights_dev_.data()), nfilter_, nbins_));
-    NoteLaunch(ws, "mel_filter_bank_mfma");
+    KCHECK(daliamdMelFilterBankRun(ws.stream, dev, n, nwg, static_cast<const float *>(weights_dev_.data()), bands_dev_, nfilter_,
+                                   nbins_));
+    NoteLaunch(ws, "mel_filter_bank_banded");
   }
 
  private:
@@ -278,6 +283,7 @@ class MelFilterBankGpu : public OperatorBase {
   bool normalize_;
   std::vector<float> weights_;
   Buffer weights_dev_;
+  const int32_t *bands_dev_ = nullptr;
   std::vector<daliamdMelDesc> descs_;
   DescUploader uploader_;
 };

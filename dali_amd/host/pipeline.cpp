@@ -161,6 +161,16 @@ void Pipeline::Build(const std::vector<std::pair<std::string, std::string>> &out
   slot_events_.assign(ring_, nullptr);
   if (!streams_.empty())
     for (auto &e : slot_events_) KCHECK(daliamdEventCreate(&e, 0));
+  if (op_timing_ && !streams_.empty())
+    for (auto &n : nodes_) {
+      if (n.type == OpType::CPU) continue;
+      n.ev_begin.assign(ring_, nullptr);
+      n.ev_end.assign(ring_, nullptr);
+      for (int s2 = 0; s2 < ring_; s2++) {
+        KCHECK(daliamdEventCreate(&n.ev_begin[s2], 1));
+        KCHECK(daliamdEventCreate(&n.ev_end[s2], 1));
+      }
+    }
   built_ = true;
   if (params_.exec_async) {
     cpu_worker_ = std::thread([this] { BindThisThread(local_cpus_); CpuWorkerLoop(); });
@@ -233,7 +243,9 @@ void Pipeline::RunStage(bool device_stage, int64_t it, int slot, Iteration &res)
         if (n.op->SetupImpl(desc, ws)) {
           for (size_t k = 0; k < desc.size(); k++) ws.outputs[k]->Resize(desc[k].shape, desc[k].type, n.op->OutputPitchAlign((int)k));
         }
+        if (!n.ev_begin.empty()) daliamdEventRecord(n.ev_begin[slot], ws.stream);
         n.op->RunImpl(ws);
+        if (!n.ev_end.empty()) daliamdEventRecord(n.ev_end[slot], ws.stream);
         for (auto &chk : node_checks) {
           // same decoration as synchronous errors
           std::string where = make_string("Error in ", OpTypeName(n.type), " operator `", n.spec.SchemaName(),
@@ -350,6 +362,15 @@ std::vector<std::shared_ptr<TensorList>> Pipeline::Outputs() {
   }
   if (res.failed) throw std::runtime_error(res.error);
   if (!streams_.empty()) KCHECK(daliamdEventSynchronize(slot_events_[res.slot]));
+  if (op_timing_)
+    for (auto &n : nodes_) {
+      if (n.ev_begin.empty()) continue;
+      float ms = 0;
+      if (daliamdEventElapsedMs(n.ev_begin[res.slot], n.ev_end[res.slot], &ms) == DALIAMD_SUCCESS) {
+        n.device_ms += ms;
+        n.device_ms_count++;
+      }
+    }
   for (auto &chk : res.checks) chk();
   std::vector<std::shared_ptr<TensorList>> out;
   for (auto &o : outputs_) out.push_back(nodes_[o.first].out_ring[o.second][res.slot]);
@@ -365,6 +386,13 @@ void Pipeline::FeedInput(const std::string &op_name, const std::vector<const voi
     return;
   }
   DALI_FAIL("Could not find an ExternalSource operator named \"", op_name, "\"");
+}
+
+std::vector<std::pair<std::string, double>> Pipeline::OperatorDeviceTimesMs() const {
+  std::vector<std::pair<std::string, double>> out;
+  for (auto &n : nodes_)
+    if (n.device_ms_count > 0) out.push_back({n.name, n.device_ms / (double)n.device_ms_count});
+  return out;
 }
 
 ReaderMeta Pipeline::GetReaderMeta(const std::string &op_name) const {

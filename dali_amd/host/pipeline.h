@@ -57,6 +57,11 @@ class Pipeline {
   const PipelineParams &params() const { return params_; }
   int64_t seed() const { return original_seed_; }
   void SetAffinity(bool on) { params_.set_affinity = on; }  // before Build()
+  // Brackets every mixed / gpu operator's launches with timing events on its stream (before Build()); the elapsed
+  // times are collected when an iteration's outputs are handed out.  For benchmarks: per-operator device time
+  // measured live, on the stream the kernels run on.
+  void EnableOperatorTiming(bool on) { op_timing_ = on; }
+  std::vector<std::pair<std::string, double>> OperatorDeviceTimesMs() const;
   daliamdStream_t stream() const { return streams_.empty() ? nullptr : streams_[0]; }
   int ring() const { return ring_; }
 
@@ -70,6 +75,10 @@ class Pipeline {
     std::vector<std::pair<std::string, std::pair<int, int>>> arg_in;  // arg name -> producer
     std::vector<std::vector<std::shared_ptr<TensorList>>> out_ring;   // [output][slot]
     double host_seconds = 0;  // time the worker spent in SetupImpl + RunImpl (enqueueing included), DALI_AMD_TRACE=1
+    // device time of the operator (EnableOperatorTiming): events around its launches, one pair per ring slot
+    std::vector<daliamdEvent_t> ev_begin, ev_end;
+    double device_ms = 0;
+    int64_t device_ms_count = 0;
   };
   struct Iteration {
     int slot;
@@ -96,6 +105,7 @@ class Pipeline {
   std::map<std::string, std::pair<int, int>> tensor_producer_;  // "name_device" -> (node, out idx)
   std::vector<std::pair<int, int>> outputs_;
   bool built_ = false;
+  bool op_timing_ = false;
   bool trace_ = false;  // DALI_AMD_TRACE=1: per-operator host time summary on stderr when the pipeline is destroyed
   int64_t traced_iterations_ = 0;
   double slot_wait_seconds_ = 0;  // host stage blocked on the ring slot's previous user

@@ -37,6 +37,7 @@ class Pipeline:
         self._prefetch_queue_depth = int(prefetch_queue_depth) if exec_pipelined else 1
         self._exec_async = bool(exec_async and exec_pipelined)
         self._set_affinity = bool(set_affinity)
+        self._operator_timing = False
         self._enable_checkpointing = enable_checkpointing
         self._restore_from = checkpoint
         self._ops = []          # (schema_name, instance_name, device, init_args, inputs, arg_inputs, outputs)
@@ -140,6 +141,8 @@ class Pipeline:
             self.set_outputs(*(outs if isinstance(outs, (list, tuple)) else [outs]))
         be = _b.BackendPipeline(self._max_batch_size, self._num_threads, self._device_id, self._seed,
                                 self._prefetch_queue_depth, self._exec_async, self._set_affinity)
+        if getattr(self, "_operator_timing", False):
+            be.enable_operator_timing()
         for schema_name, inst, device, init_args, inputs, arg_inputs, outs in self._ops:
             spec = _b.OpSpec(schema_name)
             spec.add_arg("device", device)
@@ -240,6 +243,16 @@ class Pipeline:
             with open(filename, "w") as f:
                 f.write(cpt)
         return cpt
+
+    def enable_operator_timing(self):
+        """Benchmarks: time the device work of every mixed / gpu operator with events on its stream (call before
+        build()); read the averages with operator_device_times()."""
+        if self._built:
+            raise RuntimeError("enable_operator_timing() must be called before the pipeline is built")
+        self._operator_timing = True
+
+    def operator_device_times(self):
+        return self._backend.operator_times()
 
     def executed_kernels(self):
         """Names of the device kernels the most recent iteration launched (testing aid)."""

@@ -387,11 +387,12 @@ DALIAMD_API daliamdResult_t daliamdPointwiseRun(daliamdStream_t stream, const da
 
 /* ----------------------------------------------------------------------------------------------
  * Audio features (BASELINE.json configs[3]): spectrogram -> mel filter bank -> decibels, f32.
- *   spectrogram  window extraction (centred, reflect-101 / zero padding) fused with a radix-2 FFT in LDS and the
- *                power / magnitude spectrum; replaces ExtractWindows* + cuFFT R2C + fft_postprocess
+ *   spectrogram  window extraction (centred, reflect-101 / zero padding) fused with a half-length complex radix-4
+ *                Stockham FFT in LDS (one frame per wave, wave-local synchronisation only) and the power / magnitude
+ *                spectrum; replaces ExtractWindows* + cuFFT R2C + fft_postprocess
  *                (dali/kernels/signal/window/extract_windows_gpu.cuh:153-302, signal/fft/stft_gpu_impl.cu:116-265)
- *   mel          dense (nfilter x nbins) . (nbins x frames) GEMM on the f32 matrix cores
- *                (v_mfma_f32_16x16x4_f32); weights = the reference's triangular filters
+ *   mel          banded (nfilter x nbins) . (nbins x frames) product: each filter only visits its own bins (2 FMAs
+ *                per spectrogram element, bound by reading the spectrogram); weights = the reference's triangular filters
  *                (dali/kernels/audio/mel_scale/mel_scale.h:79-130, mel_filter_bank_cpu.cc:77-111)
  *   decibels     mul * log10(max(min_ratio, x / ref)), ref given or the per-sample maximum (wave64 shuffle +
  *                LDS reduction) (dali/kernels/signal/decibel/decibel_calculator.h:25-52, to_decibels_cpu.cc:54-66)
@@ -425,9 +426,13 @@ typedef struct {
 /* host helper: dense weights [nfilter][nfft/2+1]; mel_formula 0 = slaney, 1 = htk; freq_high <= 0 -> sample_rate/2 */
 DALIAMD_API daliamdResult_t daliamdMelFilterBankWeights(int nfilter, int nfft, float sample_rate, float freq_low,
                                                        float freq_high, int normalize, int mel_formula, float *weights);
+/* host helper: bands[2m], bands[2m+1] = [first, last+1) bin with a non-zero weight in filter m */
+DALIAMD_API daliamdResult_t daliamdMelFilterBankBands(const float *weights_host, int nfilter, int nbins, int32_t *bands);
 DALIAMD_API daliamdResult_t daliamdMelFilterBankSetup(daliamdMelDesc *descs_host, int n, int *num_workgroups);
+/* bands_dev: device copy of the band table, or NULL to visit every bin of every filter */
 DALIAMD_API daliamdResult_t daliamdMelFilterBankRun(daliamdStream_t stream, const daliamdMelDesc *descs_dev, int n,
-                                                   int num_workgroups, const float *weights_dev, int nfilter, int nbins);
+                                                   int num_workgroups, const float *weights_dev, const int32_t *bands_dev,
+                                                   int nfilter, int nbins);
 
 typedef struct {
   const float *in;

@@ -3,8 +3,8 @@ mel_filter_bank(80) -> to_decibels, against the numpy oracle (float64 FFT).
 
 Stated tolerances (the reference's own, dali/test/python/operator_2/test_spectrogram.py:188,
 operator_1/test_mel_filter_bank.py:199, operator_2/test_to_decibels.py:120):
-  spectrogram  |got - ref| <= 1e-4 * max(ref) + 1e-6        (f32 radix-2 FFT vs f64 FFT)
-  mel          |got - ref| <= 1e-3 relative to the row scale  (we hold 1e-5: MFMA fma chain vs mul+add)
+  spectrogram  |got - ref| <= 1e-4 * max(ref) + 1e-6        (f32 radix-4 FFT vs f64 FFT)
+  mel          |got - ref| <= 1e-3 relative to the row scale  (we hold 1e-5: fma chain vs mul+add)
   decibels     |got - ref| <= 1e-4 * |ref| + 1e-3 dB
 """
 import io
@@ -66,7 +66,7 @@ def test_audio_pipeline_matches_oracle(kw):
     pipe = _audio_pipe(len(wavs), **kw)
     pipe.feed_input("wav", wavs)
     audio, rate, spec, mel, db = pipe.run()
-    assert pipe.executed_kernels() == ["h2d_copy", "spectrogram", "mel_filter_bank_mfma", "to_decibels"]
+    assert pipe.executed_kernels() == ["h2d_copy", "spectrogram", "mel_filter_bank_banded", "to_decibels"]
     for i, w in enumerate(wavs):
         ref_audio, sr = A.decode_wav(w)
         assert np.array_equal(audio.at(i), ref_audio) and float(rate.at(i)) == sr == 16000.0
@@ -129,3 +129,29 @@ def test_to_decibels_reference_and_silence():
             want = A.to_decibels(d, mult, 0.0 if ref is None else ref, cutoff)
             got = out[i].as_cpu()
             assert np.abs(got - want).max() <= 1e-3 + 1e-4 * np.abs(want).max(), (i, ref)
+
+
+@pytest.mark.parametrize("nfft,wl,step", [(2, 2, 1), (8, 5, 3), (64, 64, 16), (128, 100, 50), (256, 256, 64),
+                                         (2048, 2048, 512), (4096, 3000, 1000)])
+def test_spectrogram_every_fft_size(nfft, wl, step):
+    """Every template instance of the half-length radix-4 FFT (odd and even log2, fewer butterflies than lanes, the
+    two-frames-per-wave nfft=4096 layout), with windows shorter than nfft and both padding modes."""
+    from dali_amd import fn
+    from dali_amd.pipeline import Pipeline
+    rng = np.random.default_rng(nfft)
+    sigs = [rng.normal(0, 0.3, n).astype(np.float32) for n in (max(wl, 37), 5000, 12345)]
+    for reflect, center, power in [(True, True, 2), (False, True, 1), (True, False, 2)]:
+        pipe = Pipeline(batch_size=len(sigs), num_threads=2, device_id=0, prefetch_queue_depth=1)
+        with pipe:
+            x = fn.external_source(name="x")
+            pipe.set_outputs(fn.spectrogram(x.gpu(), nfft=nfft, window_length=wl, window_step=step, power=power,
+                                            center_windows=center, reflect_padding=reflect))
+        pipe.feed_input("x", sigs)
+        (spec,) = pipe.run()
+        for i, s in enumerate(sigs):
+            ref = A.spectrogram(s, nfft=nfft, window_length=wl, window_step=step, power=power, center_windows=center,
+                                reflect_padding=reflect)
+            got = spec[i].as_cpu()
+            assert got.shape == ref.shape, (got.shape, ref.shape)
+            err = np.abs(got - ref).max()
+            assert err <= 1e-4 * ref.max() + 1e-6, (nfft, reflect, center, power, i, err, ref.max())
