@@ -481,12 +481,13 @@ class JpegBatchPlan:
             if self.roi_plans is not None:
                 for f in ("roi_x0", "roi_y0", "roi_w", "roi_h", "out_x0", "out_y0"):
                     color[f][:self.n] = np.where(self.has_roi, self.roi_plans[f], 0)
-        n_idct_wg, n_color_wg = C.c_int(0), C.c_int(0)
+        n_idct_wg, n_color_wg, color_mask_out = C.c_int(0), C.c_int(0), C.c_int(0)
         capi.check(lib.daliamdJpegIdctSetup(idct.ctypes.data_as(C.c_void_p), ncomp_total, C.byref(n_idct_wg)))
-        capi.check(lib.daliamdJpegColorSetup(color.ctypes.data_as(C.c_void_p), self.n, C.byref(n_color_wg)))
+        capi.check(lib.daliamdJpegColorSetup(color.ctypes.data_as(C.c_void_p), self.n, C.byref(n_color_wg),
+                                             C.byref(color_mask_out)))
         if len(cache) > 8:
             cache.clear()
-        cache[key] = ((idct, ncomp_total, n_idct_wg.value), (color, self.n, n_color_wg.value))
+        cache[key] = ((idct, ncomp_total, n_idct_wg.value), (color, self.n, (n_color_wg.value, color_mask_out.value)))
         return cache[key]
 
     def output_views(self, out_dev):
@@ -518,7 +519,7 @@ def jpeg_gpu_stage(plan, coef_dev, planes_dev, out_dev, descs=None, split_events
         capi.check(lib.daliamdJpegIdctRun(s, C.c_void_p(idct_dev.data_ptr()), n_idct, wg_idct))
     if split_events:
         split_events[0].record()
-    capi.check(lib.daliamdJpegColorRun(s, C.c_void_p(color_dev.data_ptr()), n_color, wg_color))
+    capi.check(lib.daliamdJpegColorRun(s, C.c_void_p(color_dev.data_ptr()), n_color, wg_color[0], wg_color[1]))
     return idct_dev, color_dev
 
 

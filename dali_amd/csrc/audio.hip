@@ -234,6 +234,271 @@ __global__ __launch_bounds__(kSpecThreads) void SpectrogramKernel(const daliamdS
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// nfft = 512 / 1024: the same transform with everything that does not depend on the frame in registers (window,
+// the twiddles of every step - read once from a host-made table) and the FC frames of a wave in flight at the same
+// time, which is what hides the LDS round trip of a step: a single frame per wave leaves the SIMDs 70 % idle.  The
+// first radix-4 step works on the samples as loaded (lane l holds points l + 64 u, exactly the operands of its own
+// butterflies); work buffers are padded by 2 points per 16 so that the strided writes of the early steps spread over
+// the banks; the power tile reuses the work buffers once every wave is done with them.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int PadIdx(int e) { return e + ((e >> 4) << 1); }
+// pointers read from a descriptor have no known address space: say "global" so that the loads do not become flat
+// ones, which tie up the LDS counter as well
+using GFloat = const float __attribute__((address_space(1)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+using GFloat2 = const floatx2 __attribute__((address_space(1)));
+using GOutFloat = float __attribute__((address_space(1)));
+
+template <int LOG2N, int FC>
+__global__ __launch_bounds__(kSpecThreads) void SpectrogramFastKernel(const daliamdSpectrogramDesc *__restrict__ descs,
+                                                                      int ndesc, int total_wg, daliamdSpectrogramParams p,
+                                                                      const float *__restrict__ window,
+                                                                      const float2 *__restrict__ twg) {
+  constexpr int N = 1 << LOG2N, nfft = 2 * N;
+  constexpr int U = N / 64;            // points per lane and frame
+  constexpr int UB = U / 4;            // radix-4 butterflies per lane and frame
+  constexpr int FPW = 4, FPG = FPW * kSpecWaves, TS = FPG + 1;
+  constexpr int WS = N + N / 8;        // padded work buffer (points)
+  constexpr int R4 = LOG2N / 2;        // radix-4 steps; one radix-2 step follows when LOG2N is odd
+  constexpr int UP = (N / 2 + 1 + 63) / 64;
+  static_assert(U >= 4 && R4 >= 2 && R4 <= 4 && FPW % FC == 0, "supported sizes: nfft 512, 1024");
+  extern __shared__ __attribute__((aligned(16))) float2 spec_lds[];
+  int wg = XcdRemap(blockIdx.x, total_wg);
+  if (wg < 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float2 *wbase = spec_lds + wave * (FC * WS);
+  float *tile = reinterpret_cast<float *>(spec_lds);  // [N + 1][TS], after the transforms
+  auto TwG = [&](int idx) {
+    float2 w = twg[idx & (N - 1)];
+    return idx >= N ? make_float2(-w.x, -w.y) : w;
+  };
+  // ---- per-lane constants ----
+  const int pad0 = (nfft - p.window_length) / 2;
+  float2 wr[U];
+  unsigned inwin = 0;
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const int i = lane + 64 * u, w0 = 2 * i - pad0, w1 = w0 + 1;
+    const bool in0 = w0 >= 0 && w0 < p.window_length, in1 = w1 >= 0 && w1 < p.window_length;
+    wr[u] = make_float2(in0 ? window[w0] : 0.0f, in1 ? window[w1] : 0.0f);
+    inwin |= (in0 ? 1u : 0u) << (2 * u) | (in1 ? 2u : 0u) << (2 * u);
+  }
+  float2 tw4[R4 - 1][3];  // steps NS = 4, 16, 64: k = j mod NS is the same for all the butterflies of a lane
+#pragma unroll
+  for (int s = 1; s < R4; s++) {
+    const int NS = 1 << (2 * s);
+    const int m = 2 * (lane & (NS - 1)) * (N / (NS * 4));
+    tw4[s - 1][0] = TwG(m);
+    tw4[s - 1][1] = TwG(2 * m);
+    tw4[s - 1][2] = TwG(3 * m);
+  }
+  float2 tw2[U / 2];      // the radix-2 step (NS = N / 2): k = j
+  if constexpr (LOG2N & 1) {
+#pragma unroll
+    for (int u = 0; u < U / 2; u++) tw2[u] = twg[2 * (lane + 64 * u)];
+  }
+  float2 twp[UP];
+#pragma unroll
+  for (int u = 0; u < UP; u++) twp[u] = twg[min(lane + 64 * u, N - 1)];
+  // the descriptor of this workgroup: one parallel look over the table instead of a chain of dependent loads
+  int di = 0;
+  for (int b0 = 0; b0 < ndesc; b0 += 64) {
+    const int i = b0 + lane;
+    const bool le = i < ndesc && descs[i].wg_start <= wg;
+    di += __popcll(__ballot(le));
+  }
+  const daliamdSpectrogramDesc &d = descs[__builtin_amdgcn_readfirstlane(di - 1)];
+  const int T = d.num_windows;
+  const int t0 = (wg - d.wg_start) * FPG;
+  GFloat *in = (GFloat *)d.in;
+  float pw[FPW][UP][2];
+#pragma unroll
+  for (int rd = 0; rd < FPW / FC; rd++) {
+    float2 v[FC][UB][4];
+    // ---- load and window the FC frames (frames past the end repeat the last one: no divergence, results unused) ----
+    float2 z[FC][U];
+    long long base[FC];
+    bool interior = true, pairs_aligned = true;
+#pragma unroll
+    for (int c = 0; c < FC; c++) {
+      const int frame = min(t0 + wave * FPW + rd * FC + c, T - 1);
+      base[c] = (long long)frame * p.window_step - (p.center_windows ? p.window_length / 2 : 0) - pad0;
+      interior = interior && base[c] >= 0 && base[c] + nfft <= d.length;
+      pairs_aligned = pairs_aligned && ((uintptr_t)(in + base[c]) & 7) == 0;
+    }
+    if (interior && pairs_aligned) {  // one 8-byte load per point
+#pragma unroll
+      for (int c = 0; c < FC; c++) {
+        GFloat2 *src = (GFloat2 *)(in + base[c]);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const floatx2 x = src[lane + 64 * u];
+          z[c][u] = make_float2((inwin >> (2 * u)) & 1 ? wr[u].x * x.x : 0.0f, (inwin >> (2 * u)) & 2 ? wr[u].y * x.y : 0.0f);
+        }
+      }
+    } else if (interior) {
+#pragma unroll
+      for (int c = 0; c < FC; c++) {
+        GFloat *src = in + base[c];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const int i = lane + 64 * u;
+          const float x0 = src[2 * i], x1 = src[2 * i + 1];
+          z[c][u] = make_float2((inwin >> (2 * u)) & 1 ? wr[u].x * x0 : 0.0f, (inwin >> (2 * u)) & 2 ? wr[u].y * x1 : 0.0f);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < FC; c++) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          float x[2] = {0.0f, 0.0f};
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            if (!((inwin >> (2 * u + h)) & 1)) continue;
+            const long long idx = base[c] + 2 * (lane + 64 * u) + h;
+            const float w = h ? wr[u].y : wr[u].x;
+            if (p.reflect_padding) x[h] = w * in[Reflect101L(idx, d.length)];
+            else if (idx >= 0 && idx < d.length) x[h] = w * in[idx];
+          }
+          z[c][u] = make_float2(x[0], x[1]);
+        }
+      }
+    }
+    // ---- first radix-4 step (no twiddles) straight from the registers ----
+#pragma unroll
+    for (int c = 0; c < FC; c++) {
+      float2 *work = wbase + c * WS;
+#pragma unroll
+      for (int ub = 0; ub < UB; ub++) {
+        const float2 a = z[c][ub], b = z[c][ub + UB], cc = z[c][ub + 2 * UB], dd = z[c][ub + 3 * UB];
+        const float2 s0 = CAdd(a, cc), s1 = CSub(a, cc), s2 = CAdd(b, dd), df = CSub(b, dd);
+        const float2 s3 = make_float2(df.y, -df.x);
+        const float2 o0 = CAdd(s0, s2), o1 = CAdd(s1, s3), o2 = CSub(s0, s2), o3 = CSub(s1, s3);
+        float4 *o = reinterpret_cast<float4 *>(work + PadIdx(4 * (lane + 64 * ub)));  // 4 consecutive points, 32-byte aligned
+        o[0] = make_float4(o0.x, o0.y, o1.x, o1.y);
+        o[1] = make_float4(o2.x, o2.y, o3.x, o3.y);
+      }
+    }
+    SpecWaveSync();
+    // ---- the remaining radix-4 steps ----
+#pragma unroll
+    for (int s = 1; s < R4; s++) {
+      const int NS = 1 << (2 * s);
+      constexpr int per = N / 4;
+#pragma unroll
+      for (int c = 0; c < FC; c++) {
+        const float2 *work = wbase + c * WS;
+#pragma unroll
+        for (int ub = 0; ub < UB; ub++) {
+          const int j = lane + 64 * ub;
+          const float2 a = work[PadIdx(j)];
+          const float2 b = CMul(work[PadIdx(j + per)], tw4[s - 1][0]);
+          const float2 cc = CMul(work[PadIdx(j + 2 * per)], tw4[s - 1][1]);
+          const float2 dd = CMul(work[PadIdx(j + 3 * per)], tw4[s - 1][2]);
+          const float2 s0 = CAdd(a, cc), s1 = CSub(a, cc), s2 = CAdd(b, dd), df = CSub(b, dd);
+          const float2 s3 = make_float2(df.y, -df.x);
+          v[c][ub][0] = CAdd(s0, s2);
+          v[c][ub][1] = CAdd(s1, s3);
+          v[c][ub][2] = CSub(s0, s2);
+          v[c][ub][3] = CSub(s1, s3);
+        }
+      }
+      SpecWaveSync();
+#pragma unroll
+      for (int c = 0; c < FC; c++) {
+        float2 *work = wbase + c * WS;
+#pragma unroll
+        for (int ub = 0; ub < UB; ub++) {
+          const int j = lane + 64 * ub, k = j & (NS - 1);
+          const int o = ((j - k) << 2) + k;
+#pragma unroll
+          for (int r = 0; r < 4; r++) work[PadIdx(o + r * NS)] = v[c][ub][r];
+        }
+      }
+      SpecWaveSync();
+    }
+    // ---- radix-2 step when log2 N is odd: NS = N / 2, so butterfly j writes j and j + NS ----
+    if constexpr (LOG2N & 1) {
+      constexpr int per = N / 2;
+      float2 v2[FC][U / 2][2];
+#pragma unroll
+      for (int c = 0; c < FC; c++) {
+        const float2 *work = wbase + c * WS;
+#pragma unroll
+        for (int u = 0; u < U / 2; u++) {
+          const int j = lane + 64 * u;
+          const float2 a = work[PadIdx(j)], b = CMul(work[PadIdx(j + per)], tw2[u]);
+          v2[c][u][0] = CAdd(a, b);
+          v2[c][u][1] = CSub(a, b);
+        }
+      }
+      SpecWaveSync();
+#pragma unroll
+      for (int c = 0; c < FC; c++) {
+        float2 *work = wbase + c * WS;
+#pragma unroll
+        for (int u = 0; u < U / 2; u++) {
+          const int j = lane + 64 * u;
+          work[PadIdx(j)] = v2[c][u][0];
+          work[PadIdx(j + per)] = v2[c][u][1];
+        }
+      }
+      SpecWaveSync();
+    }
+    // ---- spectrum of the real signal, power / magnitude ----
+#pragma unroll
+    for (int c = 0; c < FC; c++) {
+      const float2 *work = wbase + c * WS;
+#pragma unroll
+      for (int u = 0; u < UP; u++) {
+        const int k = min(lane + 64 * u, N / 2);
+        const float2 zk = work[PadIdx(k)], zn = work[PadIdx((N - k) & (N - 1))];
+        const float2 e = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+        const float2 o = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+        const float2 t = CMul(twp[u], o);
+        const float2 xa = CAdd(e, t), xb = CSub(e, t);
+        float pa = xa.x * xa.x + xa.y * xa.y, pb = xb.x * xb.x + xb.y * xb.y;
+        if (p.power != 2) {
+          pa = sqrtf(pa);
+          pb = sqrtf(pb);
+        }
+        pw[rd * FC + c][u][0] = pa;
+        pw[rd * FC + c][u][1] = pb;
+      }
+    }
+    SpecWaveSync();
+  }
+  __syncthreads();  // every wave is done with its work buffers: the tile may overwrite them
+#pragma unroll
+  for (int f = 0; f < FPW; f++) {
+    if (t0 + wave * FPW + f >= T) continue;
+#pragma unroll
+    for (int u = 0; u < UP; u++) {
+      const int k = lane + 64 * u;
+      if (k <= N / 2) {
+        tile[k * TS + wave * FPW + f] = pw[f][u][0];
+        tile[(N - k) * TS + wave * FPW + f] = pw[f][u][1];
+      }
+    }
+  }
+  __syncthreads();
+  GOutFloat *gout = (GOutFloat *)d.out;
+  for (int idx = tid; idx < (N + 1) * FPG; idx += kSpecThreads) {
+    const int b = idx / FPG, f = idx % FPG;
+    if (t0 + f < T) gout[(size_t)b * T + t0 + f] = tile[b * TS + f];
+  }
+}
+constexpr bool SpecFastPath(int nfft) { return nfft == 512 || nfft == 1024; }
+constexpr int kSpecFastConcurrent = 4;
+inline int SpecFastLds(int nfft) {
+  const int N = nfft / 2;
+  const int work = kSpecWaves * kSpecFastConcurrent * (N + N / 8) * (int)sizeof(float2);
+  const int tile = (N + 1) * (4 * kSpecWaves + 1) * (int)sizeof(float);
+  return work > tile ? work : tile;
+}
+
 // =============================================================================================
 // mel filter bank: out[m][t] = sum over the filter's band of W[m][k] * S[k][t].  The triangular filters overlap only
 // their neighbours, so the product is a banded one: 2 multiply-adds per spectrogram element, bound by reading S.  A
@@ -351,11 +616,21 @@ daliamdResult_t daliamdSpectrogramSetup(daliamdSpectrogramDesc *descs, int n, co
   *nwg = wg;
   const int N = p->nfft / 2;
   *lds_bytes = (N + kSpecWaves * N) * (int)sizeof(float2) + (N + 1) * (fpg + 1) * (int)sizeof(float);
+  if (SpecFastPath(p->nfft) && SpecFastLds(p->nfft) > *lds_bytes) *lds_bytes = SpecFastLds(p->nfft);
   return DALIAMD_SUCCESS;
 }
 
+void daliamdSpectrogramTwiddles(int nfft, float *twiddles) {  // exp(-2 pi i k / nfft), k < nfft / 2, in double
+  for (int k = 0; k < nfft / 2; k++) {
+    const double a = -2.0 * M_PI * k / nfft;
+    twiddles[2 * k] = (float)std::cos(a);
+    twiddles[2 * k + 1] = (float)std::sin(a);
+  }
+}
+
 daliamdResult_t daliamdSpectrogramRun(daliamdStream_t stream, const daliamdSpectrogramDesc *descs_dev, int n,
-                                      const daliamdSpectrogramParams *p, const float *window_dev, int nwg, int lds_bytes) {
+                                      const daliamdSpectrogramParams *p, const float *window_dev,
+                                      const float *twiddles_dev, int nwg, int lds_bytes) {
   if (n == 0 || nwg == 0) return DALIAMD_SUCCESS;
   DALIAMD_REQUIRE(descs_dev && p && window_dev && n > 0 && nwg > 0, DALIAMD_ERROR_INVALID_ARGUMENT,
                   "daliamdSpectrogramRun: invalid argument");
@@ -363,6 +638,24 @@ daliamdResult_t daliamdSpectrogramRun(daliamdStream_t stream, const daliamdSpect
   while ((2 << log2n) < p->nfft) log2n++;
   dim3 grid(XcdGrid(nwg)), block(kSpecThreads);
   hipStream_t s = (hipStream_t)stream;
+  if (twiddles_dev && SpecFastPath(p->nfft)) {
+    const int lds = SpecFastLds(p->nfft);
+    const float2 *tw = reinterpret_cast<const float2 *>(twiddles_dev);
+#define SPEC_FAST(L)                                                                                                     \
+  {                                                                                                                      \
+    auto kern = SpectrogramFastKernel<L, kSpecFastConcurrent>;                                                           \
+    DALIAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+    hipLaunchKernelGGL(kern, grid, block, lds, s, descs_dev, n, nwg, *p, window_dev, tw);                                \
+  }
+    if (p->nfft == 512) SPEC_FAST(8) else SPEC_FAST(9)
+#undef SPEC_FAST
+    DALIAMD_HIP_CHECK(hipGetLastError());
+    return DALIAMD_SUCCESS;
+  }
+  {
+    const int N = p->nfft / 2, fpg = SpecFramesPerWg(p->nfft);
+    lds_bytes = (N + kSpecWaves * N) * (int)sizeof(float2) + (N + 1) * (fpg + 1) * (int)sizeof(float);
+  }
 #define SPEC_CASE(L)                                                                                                     \
   case L:                                                                                                                \
     if (lds_bytes > 64 * 1024)                                                                                           \

@@ -231,12 +231,47 @@ __device__ __forceinline__ void ColorRows420(const daliamdJpegColorDesc &d, int 
   }
 }
 
+// The common case - YCbCr 4:2:0 to RGB, upright, aligned planes - has its own kernel: the general one needs 246
+// registers (one wave per SIMD), the 4:2:0 rows 143.  Both run over the same grid; a workgroup whose sample belongs to
+// the other kernel leaves at once, and Run only launches the kernels Setup found samples for.
+__host__ __device__ inline bool Fast420(const daliamdJpegColorDesc &d) {
+  if (d.out_format != DALIAMD_JPEG_OUT_RGB || d.color != DALIAMD_JPEG_YCC || d.orientation > 1) return false;
+  const int hmax = max(d.h_samp[0], max(d.h_samp[1], d.h_samp[2])), vmax = max(d.v_samp[0], max(d.v_samp[1], d.v_samp[2]));
+  if (d.h_samp[0] != hmax || d.v_samp[0] != vmax) return false;
+  for (int c = 1; c < 3; c++)
+    if (d.h_samp[c] * 2 != hmax || d.v_samp[c] * 2 != vmax || d.down_w[c] <= 2) return false;
+  const bool roi = d.roi_w > 0;
+  const int rx0 = roi ? d.roi_x0 : 0, ry0 = roi ? d.roi_y0 : 0;
+  return ((d.out_pitch & 7) == 0) && ((reinterpret_cast<uintptr_t>(d.out) & 7) == 0) && ((rx0 & 7) | (ry0 & 1)) == 0 &&
+         ((d.pitch[0] & 7) | (d.pitch[1] & 3) | (d.pitch[2] & 3)) == 0 && (reinterpret_cast<uintptr_t>(d.plane[0]) & 7) == 0 &&
+         ((reinterpret_cast<uintptr_t>(d.plane[1]) | reinterpret_cast<uintptr_t>(d.plane[2])) & 3) == 0;
+}
+
+__global__ __launch_bounds__(kColorThreads) void JpegColor420Kernel(const daliamdJpegColorDesc *__restrict__ descs,
+                                                                    int ndesc, int total_wg) {
+  int wg = XcdRemap(blockIdx.x, total_wg);
+  if (wg < 0) return;
+  const daliamdJpegColorDesc &d = descs[FindDesc(descs, ndesc, wg)];
+  if (!Fast420(d)) return;
+  const bool roi = d.roi_w > 0;
+  const int rx0 = roi ? d.roi_x0 : 0, ry0 = roi ? d.roi_y0 : 0;
+  const int rx1 = roi ? d.roi_x0 + d.roi_w : d.width, ry1 = roi ? d.roi_y0 + d.roi_h : d.height;
+  int tiles_x = (rx1 - rx0 + kTileW - 1) / kTileW;
+  int t = wg - d.wg_start;
+  int ty = t / tiles_x, tx = t - ty * tiles_x;
+  int x0 = rx0 + tx * kTileW + (threadIdx.x & 31) * 8;
+  const int y_first = ry0 + ty * kTileH + (threadIdx.x >> 5) * kRowsPerThread;
+  if (x0 >= rx1 || y_first >= ry1) return;
+  ColorRows420(d, x0, y_first, rx1, ry1, roi ? d.out_x0 : 0, roi ? d.out_y0 : 0);
+}
+
 __global__ __launch_bounds__(kColorThreads) void JpegColorKernel(const daliamdJpegColorDesc *__restrict__ descs,
                                                                  int ndesc, int total_wg) {
   int wg = XcdRemap(blockIdx.x, total_wg);
   if (wg < 0) return;
   int di = FindDesc(descs, ndesc, wg);
   const daliamdJpegColorDesc &d = descs[di];
+  if (Fast420(d)) return;
   // region of the (un-rotated) image to produce; the 8-pixel groups are aligned to its origin so that the output
   // rows keep their 8-byte store alignment
   const bool roi = d.roi_w > 0;
@@ -264,14 +299,6 @@ __global__ __launch_bounds__(kColorThreads) void JpegColorKernel(const daliamdJp
   const int out_x0 = roi ? d.out_x0 : 0, out_y0 = roi ? d.out_y0 : 0;
   const bool wide_ok = ((d.out_pitch & 7) == 0) && ((reinterpret_cast<uintptr_t>(d.out) & 7) == 0);
   const bool wide_stores = npx == 8 && wide_ok && oc == 3;
-  // wave-uniform: the whole image takes the fast path or none of it does
-  if (fmt == DALIAMD_JPEG_OUT_RGB && d.color == DALIAMD_JPEG_YCC && mode[0] == kFull && mode[1] == kH2V2 && mode[2] == kH2V2 && d.orientation <= 1 &&
-      wide_ok && ((rx0 & 7) | (ry0 & 1)) == 0 && ((d.pitch[0] & 7) | (d.pitch[1] & 3) | (d.pitch[2] & 3)) == 0 &&
-      (reinterpret_cast<uintptr_t>(d.plane[0]) & 7) == 0 &&
-      ((reinterpret_cast<uintptr_t>(d.plane[1]) | reinterpret_cast<uintptr_t>(d.plane[2])) & 3) == 0) {
-    ColorRows420(d, x0, y_first, rx1, ry1, out_x0, out_y0);
-    return;
-  }
 
   for (int row = 0; row < kRowsPerThread; row++) {
     const int y = y_first + row;
@@ -358,7 +385,7 @@ __global__ __launch_bounds__(kColorThreads) void JpegColorKernel(const daliamdJp
 
 extern "C" {
 
-daliamdResult_t daliamdJpegColorSetup(daliamdJpegColorDesc *descs, int n, int *num_workgroups) {
+daliamdResult_t daliamdJpegColorSetup(daliamdJpegColorDesc *descs, int n, int *num_workgroups, int *kernel_mask) {
   DALIAMD_REQUIRE(descs && num_workgroups && n >= 0, DALIAMD_ERROR_INVALID_ARGUMENT,
                   "daliamdJpegColorSetup: NULL argument");
   int wg = 0;
@@ -395,6 +422,11 @@ daliamdResult_t daliamdJpegColorSetup(daliamdJpegColorDesc *descs, int n, int *n
     wg += ((pw + daliamd::kTileW - 1) / daliamd::kTileW) * ((ph + daliamd::kTileH - 1) / daliamd::kTileH);
   }
   *num_workgroups = wg;
+  if (kernel_mask) {
+    int mask = 0;
+    for (int i = 0; i < n; i++) mask |= daliamd::Fast420(descs[i]) ? 1 : 2;
+    *kernel_mask = mask;
+  }
   return DALIAMD_SUCCESS;
 }
 
@@ -449,12 +481,16 @@ daliamdResult_t daliamdJpegPlanRoi(int width, int height, int num_components, co
 }
 
 daliamdResult_t daliamdJpegColorRun(daliamdStream_t stream, const daliamdJpegColorDesc *descs_dev, int n,
-                                    int num_workgroups) {
+                                    int num_workgroups, int kernel_mask) {
   if (n == 0 || num_workgroups == 0) return DALIAMD_SUCCESS;
   DALIAMD_REQUIRE(descs_dev && n > 0 && num_workgroups > 0, DALIAMD_ERROR_INVALID_ARGUMENT,
                   "daliamdJpegColorRun: invalid argument");
-  hipLaunchKernelGGL(daliamd::JpegColorKernel, dim3(daliamd::XcdGrid(num_workgroups)),
-                     dim3(daliamd::kColorThreads), 0, (hipStream_t)stream, descs_dev, n, num_workgroups);
+  if (kernel_mask & 1)
+    hipLaunchKernelGGL(daliamd::JpegColor420Kernel, dim3(daliamd::XcdGrid(num_workgroups)),
+                       dim3(daliamd::kColorThreads), 0, (hipStream_t)stream, descs_dev, n, num_workgroups);
+  if (kernel_mask & 2)
+    hipLaunchKernelGGL(daliamd::JpegColorKernel, dim3(daliamd::XcdGrid(num_workgroups)),
+                       dim3(daliamd::kColorThreads), 0, (hipStream_t)stream, descs_dev, n, num_workgroups);
   DALIAMD_HIP_CHECK(hipGetLastError());
   return DALIAMD_SUCCESS;
 }

@@ -181,7 +181,10 @@ __global__ __launch_bounds__(kResampleThreads) void ResampleKernel(const daliamd
   int *xt = yt + TH * sup_y;                              // [TW][sup_x] per-tap column offset (elements)
   int *iy = xt + TW * sup_x;                              // [TH]
   int *ix = iy + TH;                                      // [TW]
-  uint8_t *stage = reinterpret_cast<uint8_t *>((reinterpret_cast<uintptr_t>(ix + TW) + 15) & ~(uintptr_t)15);
+  // (byte offset from the LDS base, not a round trip through an integer: that would make every access behind it a
+  // generic one - flat loads that wait on both memory counters)
+  uint8_t *stage = reinterpret_cast<uint8_t *>(lds) +
+                   ((((size_t)2 * (TH * sup_y + TW * sup_x) + TH + TW) * sizeof(float) + 15) & ~(size_t)15);
 
   // ---- index / coefficient tables (InitializeResamplingFilter) ----
   for (int i = tid; i < th + tw; i += kResampleThreads) {
@@ -282,7 +285,8 @@ __global__ __launch_bounds__(kResampleThreads) void ResampleKernel(const daliamd
     }
   }
   __syncthreads();
-  const uint8_t *src = staged ? stage : win;  // byte-addressed source rows (LDS or global)
+  using GBytes = const uint8_t __attribute__((address_space(1)));
+  GBytes *gwin = (GBytes *)win;  // source rows when the window is not staged
 
   if (vfirst) {
     // ================= vertical pass (window rows -> tmp[th][NB]), then horizontal =================
@@ -322,7 +326,11 @@ __global__ __launch_bounds__(kResampleThreads) void ResampleKernel(const daliamd
         const int *ro = yt + y * sup_y;
         for (int e = tid & 63; e < NB; e += 64) {
           float a = 0;
-          for (int k = 0; k < sup_y; k++) a += (float)src[ro[k] + e] * co[k];
+          if (staged) {
+            for (int k = 0; k < sup_y; k++) a += (float)stage[ro[k] + e] * co[k];
+          } else {
+            for (int k = 0; k < sup_y; k++) a += (float)gwin[ro[k] + e] * co[k];
+          }
           tmp[y * NB + e] = a;
         }
       }
@@ -359,16 +367,27 @@ __global__ __launch_bounds__(kResampleThreads) void ResampleKernel(const daliamd
       const float *co = cx + x * sup_x;
       const int *xo = xt + x * sup_x;
       for (int r = tid >> tw_log2; r < nrows; r += kResampleThreads >> tw_log2) {
-        const uint8_t *srow = staged ? stage + r * LP + (int)((win_addr + (size_t)r * pitch) & 15)
-                                     : win + (size_t)r * pitch;
         float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        for (int k = 0; k < sup_x; k++) {
-          float w = co[k];
-          const uint8_t *p = srow + xo[k];
-          a0 += w * (float)p[0];
-          if (C > 1) a1 += w * (float)p[1];
-          if (C > 2) a2 += w * (float)p[2];
-          if (C > 3) a3 += w * (float)p[3];
+        if (staged) {
+          const uint8_t *srow = stage + r * LP + (int)((win_addr + (size_t)r * pitch) & 15);
+          for (int k = 0; k < sup_x; k++) {
+            float w = co[k];
+            const uint8_t *p = srow + xo[k];
+            a0 += w * (float)p[0];
+            if (C > 1) a1 += w * (float)p[1];
+            if (C > 2) a2 += w * (float)p[2];
+            if (C > 3) a3 += w * (float)p[3];
+          }
+        } else {
+          GBytes *srow = gwin + (size_t)r * pitch;
+          for (int k = 0; k < sup_x; k++) {
+            float w = co[k];
+            GBytes *p = srow + xo[k];
+            a0 += w * (float)p[0];
+            if (C > 1) a1 += w * (float)p[1];
+            if (C > 2) a2 += w * (float)p[2];
+            if (C > 3) a3 += w * (float)p[3];
+          }
         }
         float *tp = tmp + r * rowlen + x * C;
         tp[0] = a0;

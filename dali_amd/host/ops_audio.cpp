@@ -177,8 +177,12 @@ class SpectrogramGpu : public OperatorBase {
     int n = (int)descs_.size();
     if (!n) return;
     if (!window_uploaded_) {
-      window_dev_.Reserve(window_.size() * sizeof(float));
-      KCHECK(daliamdMemcpyH2DAsync(window_dev_.data(), window_.data(), window_.size() * sizeof(float), ws.stream));
+      std::vector<float> tables((window_.size() + 3) / 4 * 4 + p_.nfft);   // window, then the FFT twiddles (16-byte aligned)
+      std::copy(window_.begin(), window_.end(), tables.begin());
+      twiddle_offset_ = (window_.size() + 3) / 4 * 4;
+      daliamdSpectrogramTwiddles(p_.nfft, tables.data() + twiddle_offset_);
+      window_dev_.Reserve(tables.size() * sizeof(float));
+      KCHECK(daliamdMemcpyH2DAsync(window_dev_.data(), tables.data(), tables.size() * sizeof(float), ws.stream));
       // one-time upload shared by all later iterations, which run on other streams: make it visible to them
       KCHECK(daliamdStreamSynchronize(ws.stream));
       KCHECK(daliamdStreamSynchronize(ws.stream));  // one-time: `window_` is pageable host memory
@@ -186,7 +190,8 @@ class SpectrogramGpu : public OperatorBase {
     }
     for (int i = 0; i < n; i++) descs_[i].out = static_cast<float *>(out.raw(i));
     auto *dev = static_cast<const daliamdSpectrogramDesc *>(uploader_.Upload(descs_.data(), n * sizeof(descs_[0]), ws.stream, ws.ring + 1));
-    KCHECK(daliamdSpectrogramRun(ws.stream, dev, n, &p_, static_cast<const float *>(window_dev_.data()), nwg_, lds_));
+    const float *tables = static_cast<const float *>(window_dev_.data());
+    KCHECK(daliamdSpectrogramRun(ws.stream, dev, n, &p_, tables, tables + twiddle_offset_, nwg_, lds_));
     NoteLaunch(ws, "spectrogram");
   }
 
@@ -195,6 +200,7 @@ class SpectrogramGpu : public OperatorBase {
   std::vector<float> window_;
   Buffer window_dev_;
   bool window_uploaded_ = false;
+  size_t twiddle_offset_ = 0;
   int nwg_ = 0, lds_ = 0;
   std::vector<daliamdSpectrogramDesc> descs_;
   DescUploader uploader_;

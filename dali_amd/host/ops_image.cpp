@@ -505,10 +505,10 @@ class ImageDecoderMixed : public OperatorBase {
         cd.out_x0 = plans_[i].out_x0; cd.out_y0 = plans_[i].out_y0;
       }
     }
-    int wg_idct = 0, wg_color = 0;
+    int wg_idct = 0, wg_color = 0, color_kernels = 0;
     const int nidct = k;  // components of the host-decoded streams only
     KCHECK(daliamdJpegIdctSetup(idct, nidct, &wg_idct));
-    KCHECK(daliamdJpegColorSetup(color, nact, &wg_color));
+    KCHECK(daliamdJpegColorSetup(color, nact, &wg_color, &color_kernels));
     lap(3);
     // ---- ONE transfer (JPEG bytes + the three tables) on the copy stream: it overlaps the kernels of the previous
     // iteration; the compute stream waits for it through an event ----
@@ -540,7 +540,7 @@ class ImageDecoderMixed : public OperatorBase {
       KCHECK(daliamdJpegIdctRun(ws.stream, reinterpret_cast<const daliamdJpegIdctDesc *>(dev_base + idct_off), nidct,
                                 wg_idct));
     KCHECK(daliamdJpegColorRun(ws.stream, reinterpret_cast<const daliamdJpegColorDesc *>(dev_base + color_off), nact,
-                               wg_color));
+                               wg_color, color_kernels));
     if (nidct) NoteLaunch(ws, "jpeg_idct");
     NoteLaunch(ws, "jpeg_color");
     if (cache_) {

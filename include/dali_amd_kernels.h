@@ -222,7 +222,10 @@ typedef struct {
   int32_t roi_x0, roi_y0, roi_w, roi_h, out_x0, out_y0;
 } daliamdJpegColorDesc;
 
-DALIAMD_API daliamdResult_t daliamdJpegColorSetup(daliamdJpegColorDesc *descs_host, int n, int *num_workgroups);
+/* kernel_mask (out): bit 0 - some sample takes the YCbCr 4:2:0 -> RGB kernel, bit 1 - some sample the general one;
+ * hand it to Run, which launches only those (both walk the same grid). */
+DALIAMD_API daliamdResult_t daliamdJpegColorSetup(daliamdJpegColorDesc *descs_host, int n, int *num_workgroups,
+                                                  int *kernel_mask);
 
 /* Region-of-interest decode (the reference's decoders.image_crop / image_slice / image_random_crop hand a region to
  * nvImageCodec: dali/operators/imgcodec/image_decoder.h:683-716, roi_image_decoder.h:36-91).  Host helper: turns a
@@ -238,7 +241,7 @@ DALIAMD_API daliamdResult_t daliamdJpegPlanRoi(int width, int height, int num_co
                                                const int32_t *v_samp, int orientation, int up_y0, int up_x0, int up_h,
                                                int up_w, daliamdJpegRoiPlan *plan);
 DALIAMD_API daliamdResult_t daliamdJpegColorRun(daliamdStream_t stream, const daliamdJpegColorDesc *descs_dev,
-                                                int n, int num_workgroups);
+                                                int n, int num_workgroups, int kernel_mask);
 
 /* ----------------------------------------------------------------------------------------------
  * Separable resampling (RandomResizedCrop / Resize) with an optional fused
@@ -413,9 +416,14 @@ DALIAMD_API void daliamdHannWindow(int n, float *window);
 DALIAMD_API daliamdResult_t daliamdSpectrogramSetup(daliamdSpectrogramDesc *descs_host, int n,
                                                    const daliamdSpectrogramParams *params, int *num_workgroups,
                                                    int *lds_bytes);
+/* host helper: nfft floats = nfft/2 complex twiddles exp(-2 pi i k / nfft) */
+DALIAMD_API void daliamdSpectrogramTwiddles(int nfft, float *twiddles);
+/* twiddles_dev: device copy of that table; with it nfft = 512 / 1024 take the register-resident kernel (4 frames of
+ * a wave in flight).  NULL: every size runs the generic kernel, which derives its own twiddles.  lds_bytes: the value
+ * Setup returned (an upper bound; Run sizes the launch itself). */
 DALIAMD_API daliamdResult_t daliamdSpectrogramRun(daliamdStream_t stream, const daliamdSpectrogramDesc *descs_dev, int n,
                                                  const daliamdSpectrogramParams *params, const float *window_dev,
-                                                 int num_workgroups, int lds_bytes);
+                                                 const float *twiddles_dev, int num_workgroups, int lds_bytes);
 
 typedef struct {
   const float *in;      /* device: [nbins][frames] */
