@@ -320,9 +320,28 @@ def e2e_pipeline(root, batch, device_id, iters=200, threads=None, roi_decode=Fal
                     "H2D of the JPEG bytes on a copy stream, all device stages, fp16 CHW batch on the device)"}
 
 
+def kernel_timing(enable=None):
+    """Library-side kernel timing (include/dali_amd_kernels.h: daliamdKernelTimingEnable / Report): every launch is
+    bracketed by HIP events on its own stream.  enable=True/False switches it; None reads {kernel: (launches, avg_ms)}."""
+    from dali_amd import _capi as capi
+    lib = capi.kernels()
+    if enable is not None:
+        lib.daliamdKernelTimingEnable(1 if enable else 0)
+        return None
+    need = lib.daliamdKernelTimingReport(None, 0)
+    buf = C.create_string_buffer(need + 1)
+    lib.daliamdKernelTimingReport(buf, need + 1)
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, calls, ms = line.split("\t")
+        out[name] = (int(calls), float(ms))
+    return out
+
+
 def bench_heavy_aug(args, device):
     """configs[2]: warp_affine + gaussian_blur(sigma=3) + color_twist + erase on 512x512 u8 images, batch 128,
-    images resident in HBM.  One JSON line with per-kernel achieved GB/s (algorithmic bytes: 3*512*512 in + out)."""
+    images resident in HBM; colour twist and erase are one launch, as in a dali_amd.Pipeline (graph-level fusion).
+    One JSON line; per-kernel times from HIP events around each launch (algorithmic bytes: 3*512*512 in + out)."""
     import torch
     from dali_amd import backend as B
     from dali_amd.testing import synth_image
@@ -348,42 +367,39 @@ def bench_heavy_aug(args, device):
             regs.append([(int(a[0]), int(a[1]), int(a[0] + sh[0]), int(a[1] + sh[1]))])
         return mats, [t[0] for t in tw], [t[1] for t in tw], regs
 
-    names = ["WarpAffineKernel", "GaussianBlurKernel", "PointwiseKernel(color_twist)", "PointwiseKernel(erase)"]
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
+    param_sets = [params() for _ in range(4)]   # the random arguments of 4 batches, rotated (host RNG outside the timing)
 
-    def step(e=None):
-        mats, tm, to, regs = params()
-        if e: e[0].record()
+    def step(k):
+        mats, tm, to, regs = param_sets[k % len(param_sets)]
         x = B.warp_affine_batch(imgs, mats, fill_value=0.0)
-        if e: e[1].record()
         x = B.gaussian_blur_batch(x, sigma=3.0)
-        if e: e[2].record()
-        x = B.pointwise_batch(x, tm, to)
-        if e: e[3].record()
-        x = B.pointwise_batch(x, regions=regs, fill=(0.0,))
-        if e: e[4].record()
-        return x
+        return B.pointwise_batch(x, tm, to, regions=regs, fill=(0.0,))
 
-    for _ in range(args.warmup):
-        step()
+    for k in range(args.warmup):
+        step(k)
     torch.cuda.synchronize()
+    kernel_timing(True)
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(ev[k])
+        step(k)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    kernel_timing(False)
+    times = kernel_timing()
     per = {}
     bytes_per = 2 * 3 * 512 * 512 * n
-    for j, nm in enumerate(names):
-        ms = float(np.mean([e[j].elapsed_time(e[j + 1]) for e in ev]))
-        per[nm] = {"algorithmic_bytes": bytes_per, "avg_ms_incl_desc_upload": ms, "achieved_GBps": bytes_per / (ms * 1e-3) / 1e9}
-    dom = max(per, key=lambda k: per[k]["avg_ms_incl_desc_upload"])
-    traffic, traffic_src = measured_traffic(dom.split("(")[0], "heavy_aug")
+    for nm, (calls, ms) in times.items():
+        per[nm] = {"algorithmic_bytes": bytes_per, "launches": calls, "avg_ms": ms, "achieved_GBps": bytes_per / (ms * 1e-3) / 1e9}
+    dom = max(per, key=lambda k: per[k]["avg_ms"])
+    traffic, traffic_src = measured_traffic(dom, "heavy_aug")
+    kern_ms = sum(v["avg_ms"] for v in per.values())
     print(json.dumps({"metric": "images/sec heavy-aug 512^2 b128 (warp_affine+gaussian_blur(sigma=3)+color_twist+erase)",
                       "value": n * args.steps / el, "unit": "images/s", "n_gpus": 1, "steps": args.steps,
                       "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
                       "scaling": "weak", "vs_baseline": None, "dtype": "u8 in/out, f32 arithmetic", "data": "synthetic",
-                      "config": {"workload": "configs[2]: 128 x 512x512x3 u8 resident in HBM"},
+                      "config": {"workload": "configs[2]: 128 x 512x512x3 u8 resident in HBM",
+                                 "kernels_ms_per_step": kern_ms, "images_per_s_kernels_only": n / (kern_ms * 1e-3),
+                                 "note": "value includes the Python descriptor construction of dali_amd.backend (host-bound)"},
                       "roofline": {"bound": "hbm", "kernel": dom, "achieved": per[dom]["achieved_GBps"],
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": per[dom]["achieved_GBps"] / HBM_PEAK_GBS,
                                    "traffic": traffic, "traffic_source": traffic_src, "per_kernel": per}}))
@@ -411,6 +427,7 @@ def bench_audio(args, device):
         pipe.feed_input("x", sigs)
         pipe.run()
     torch.cuda.synchronize()
+    kernel_timing(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         pipe.feed_input("x", sigs)
@@ -421,13 +438,16 @@ def bench_audio(args, device):
     # algorithmic bytes per launch: every signal sample read once, every output element written once
     algo = {"SpectrogramKernel": 4 * samples + 4 * 513 * frames, "MelKernel": 4 * 513 * frames + 4 * 80 * frames,
             "DecibelKernel": 8 * 80 * frames}
-    op_of = {"SpectrogramKernel": "Spectrogram", "MelKernel": "MelFilterBank", "DecibelKernel": "ToDecibels"}
-    times = pipe.operator_device_times()   # events on the operators' stream around each operator's launches
+    kernel_timing(False)
+    ktimes = kernel_timing()               # HIP events around every launch, on the stream it is launched on
+    times = pipe.operator_device_times()   # ... and around each operator (descriptor upload + launches)
+    algo["DecibelMaxKernel"] = 4 * 80 * frames
+    algo["DecibelKernel"] = 8 * 80 * frames
     per = {}
-    for kern, op in op_of.items():
-        ms = next((v for k, v in times.items() if op.lower() in k.lower().replace("_", "")), None)
-        if ms:
-            per[kern] = {"algorithmic_bytes": algo[kern], "avg_ms": ms, "achieved_GBps": algo[kern] / (ms * 1e-3) / 1e9}
+    for kern, (calls, ms) in ktimes.items():
+        if kern in algo:
+            per[kern] = {"algorithmic_bytes": algo[kern], "launches": calls, "avg_ms": ms,
+                         "achieved_GBps": algo[kern] / (ms * 1e-3) / 1e9}
     dom = max(per, key=lambda k: per[k]["avg_ms"]) if per else None
     traffic, traffic_src = measured_traffic(dom, "audio") if dom else (None, None)
     ach = per[dom]["achieved_GBps"] if dom else None

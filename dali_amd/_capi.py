@@ -162,7 +162,7 @@ _host = None
 
 _KERNEL_SYMBOLS = [
     "daliamdGetLastErrorMessage", "daliamdClearLastError", "daliamdVersion", "daliamdDeviceCount",
-    "daliamdSetDevice", "daliamdDeviceInfo", "daliamdDevicePciBusId", "daliamdRangePush", "daliamdRangePop",
+    "daliamdSetDevice", "daliamdDeviceInfo", "daliamdDevicePciBusId", "daliamdRangePush", "daliamdRangePop", "daliamdKernelTimingEnable", "daliamdKernelTimingReport",
     "daliamdStreamCreate", "daliamdStreamDestroy",
     "daliamdStreamSynchronize", "daliamdStreamWaitEvent", "daliamdEventCreate",
     "daliamdEventDestroy", "daliamdEventRecord", "daliamdEventSynchronize", "daliamdEventQuery", "daliamdEventElapsedMs",
@@ -174,7 +174,7 @@ _KERNEL_SYMBOLS = [
     "daliamdWarpAffineSetup", "daliamdWarpAffineRun", "daliamdGaussianWindow", "daliamdGaussianBlurSetup",
     "daliamdGaussianBlurRun", "daliamdColorTwistMatrix", "daliamdPointwiseSetup", "daliamdPointwiseRun",
     "daliamdHannWindow", "daliamdSpectrogramTwiddles", "daliamdSpectrogramSetup", "daliamdSpectrogramRun", "daliamdMelFilterBankWeights",
-    "daliamdMelFilterBankBands", "daliamdMelFilterBankSetup", "daliamdMelFilterBankRun", "daliamdToDecibelsRun",
+    "daliamdMelFilterBankBands", "daliamdMelFilterBankSetup", "daliamdMelFilterBankRun", "daliamdToDecibelsSetup", "daliamdToDecibelsRun",
     "daliamdNormalizeSetup", "daliamdNormalizeRun",
 ]
 

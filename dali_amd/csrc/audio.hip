@@ -10,6 +10,13 @@ namespace daliamd {
 
 #pragma clang fp contract(fast)  // tolerance-based parity here (f32 FFT vs the oracle's f64): let the compiler form FMAs
 
+// pointers read from a descriptor have no known address space: say "global" so that the loads do not become flat
+// ones, which tie up the LDS counter as well
+using GFloat = const float __attribute__((address_space(1)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+using GFloat2 = const floatx2 __attribute__((address_space(1)));
+using GOutFloat = float __attribute__((address_space(1)));
+
 // =============================================================================================
 // spectrogram
 //
@@ -243,12 +250,6 @@ __global__ __launch_bounds__(kSpecThreads) void SpectrogramKernel(const daliamdS
 // the banks; the power tile reuses the work buffers once every wave is done with them.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int PadIdx(int e) { return e + ((e >> 4) << 1); }
-// pointers read from a descriptor have no known address space: say "global" so that the loads do not become flat
-// ones, which tie up the LDS counter as well
-using GFloat = const float __attribute__((address_space(1)));
-typedef float floatx2 __attribute__((ext_vector_type(2)));
-using GFloat2 = const floatx2 __attribute__((address_space(1)));
-using GOutFloat = float __attribute__((address_space(1)));
 
 template <int LOG2N, int FC>
 __global__ __launch_bounds__(kSpecThreads) void SpectrogramFastKernel(const daliamdSpectrogramDesc *__restrict__ descs,
@@ -518,10 +519,12 @@ __global__ __launch_bounds__(kMelThreads) void MelKernel(const daliamdMelDesc *_
   const int T = d.frames;
   const int col = (wg - d.wg_start) * 64 + lane;
   const bool ok = col < T;
-  const float *__restrict__ S = d.in + (ok ? col : 0);
+  GFloat *S = (GFloat *)d.in + (ok ? col : 0);
+  GOutFloat *out = (GOutFloat *)d.out;
   for (int m = wave; m < nfilter; m += kMelWaves) {
-    const int kb = bands ? bands[2 * m] : 0, ke = bands ? bands[2 * m + 1] : K;
-    const float *__restrict__ w = W + (size_t)m * K;
+    const int kb = bands ? ((const int32_t __attribute__((address_space(1))) *)bands)[2 * m] : 0;
+    const int ke = bands ? ((const int32_t __attribute__((address_space(1))) *)bands)[2 * m + 1] : K;
+    GFloat *w = (GFloat *)W + (size_t)m * K;
     float acc = 0.0f;
     int k = kb;
     for (; k + 4 <= ke; k += 4) {
@@ -532,40 +535,59 @@ __global__ __launch_bounds__(kMelThreads) void MelKernel(const daliamdMelDesc *_
       acc = fmaf(w[k + 3], s3, acc);
     }
     for (; k < ke; k++) acc = fmaf(w[k], S[(size_t)k * T], acc);
-    if (ok) d.out[(size_t)m * T + col] = acc;
+    if (ok) out[(size_t)m * T + col] = acc;
   }
 }
 
 // =============================================================================================
 // to_decibels
 // =============================================================================================
-constexpr int kDbThreads = 1024;
+// Two launches when the reference is the per-sample maximum: chunk maxima folded into the descriptor's `max_bits`
+// slot with an integer atomic max (the values are non-negative, so their bit patterns order like the floats), then
+// the element-wise pass.  A sample is cut into chunks of kDbChunk elements so that a batch of short utterances still
+// fills the chip (one workgroup per sample left it 3/4 idle).
+constexpr int kDbThreads = 256;
+constexpr int kDbChunk = kDbThreads * 16;
 
-__global__ __launch_bounds__(kDbThreads) void DecibelKernel(const daliamdDecibelDesc *__restrict__ descs, float mul_log2,
-                                                            float reference, float min_ratio) {
+__global__ __launch_bounds__(kDbThreads) void DecibelMaxKernel(daliamdDecibelDesc *__restrict__ descs, int ndesc, int total_wg) {
   __shared__ float red[kDbThreads / 64];
-  const daliamdDecibelDesc &d = descs[blockIdx.x];
+  int wg = XcdRemap(blockIdx.x, total_wg);
+  if (wg < 0) return;
+  const int di = FindDesc(descs, ndesc, wg);
+  const daliamdDecibelDesc &d = descs[di];
+  const int tid = threadIdx.x;
+  GFloat *in = (GFloat *)d.in;
+  const int64_t i0 = (int64_t)(wg - d.wg_start) * kDbChunk;
+  const int64_t i1 = min(i0 + kDbChunk, d.size);
+  float m = 0.0f;
+  for (int64_t i = i0 + tid; i < i1; i += kDbThreads) m = fmaxf(m, in[i]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));  // wave64 shuffle reduction
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < kDbThreads / 64; w++) m = fmaxf(m, red[w]);
+    if (m > 0.0f) atomicMax(&descs[di].max_bits, __float_as_uint(m));
+  }
+}
+
+__global__ __launch_bounds__(kDbThreads) void DecibelKernel(const daliamdDecibelDesc *__restrict__ descs, int ndesc, int total_wg,
+                                                            float mul_log2, float reference, float min_ratio) {
+  int wg = XcdRemap(blockIdx.x, total_wg);
+  if (wg < 0) return;
+  const daliamdDecibelDesc &d = descs[FindDesc(descs, ndesc, wg)];
   const int tid = threadIdx.x;
   float s_ref = reference;
   if (!(reference > 0.0f)) {
-    float m = 0.0f;
-    for (int64_t i = tid; i < d.size; i += kDbThreads) m = fmaxf(m, d.in[i]);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));  // wave64 shuffle reduction
-    if ((tid & 63) == 0) red[tid >> 6] = m;
-    __syncthreads();
-    if (tid < 64) {
-      float v = tid < kDbThreads / 64 ? red[tid] : 0.0f;
-#pragma unroll
-      for (int off = 8; off > 0; off >>= 1) v = fmaxf(v, __shfl_down(v, off, 64));
-      if (tid == 0) red[0] = v;
-    }
-    __syncthreads();
-    s_ref = red[0];
+    s_ref = __uint_as_float(d.max_bits);
     if (s_ref == 0.0f) s_ref = 1.0f;
   }
   const float inv = s_ref == 1.0f ? 1.0f : 1.0f / s_ref;
-  for (int64_t i = tid; i < d.size; i += kDbThreads) d.out[i] = mul_log2 * log2f(fmaxf(min_ratio, d.in[i] * inv));
+  GFloat *in = (GFloat *)d.in;
+  GOutFloat *out = (GOutFloat *)d.out;
+  const int64_t i0 = (int64_t)(wg - d.wg_start) * kDbChunk;
+  const int64_t i1 = min(i0 + kDbChunk, d.size);
+  for (int64_t i = i0 + tid; i < i1; i += kDbThreads) out[i] = mul_log2 * log2f(fmaxf(min_ratio, in[i] * inv));
 }
 
 // host: mel scales (mel_scale.h:27-73), all in double
@@ -638,6 +660,7 @@ daliamdResult_t daliamdSpectrogramRun(daliamdStream_t stream, const daliamdSpect
   while ((2 << log2n) < p->nfft) log2n++;
   dim3 grid(XcdGrid(nwg)), block(kSpecThreads);
   hipStream_t s = (hipStream_t)stream;
+  KernelTimer timer("SpectrogramKernel", s);
   if (twiddles_dev && SpecFastPath(p->nfft)) {
     const int lds = SpecFastLds(p->nfft);
     const float2 *tw = reinterpret_cast<const float2 *>(twiddles_dev);
@@ -749,20 +772,45 @@ daliamdResult_t daliamdMelFilterBankRun(daliamdStream_t stream, const daliamdMel
                                         const float *W, const int32_t *bands_dev, int nfilter, int nbins) {
   if (n == 0 || nwg == 0) return DALIAMD_SUCCESS;
   DALIAMD_REQUIRE(descs_dev && W && nfilter > 0 && nbins > 0, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdMelFilterBankRun: invalid argument");
-  hipLaunchKernelGGL(MelKernel, dim3(XcdGrid(nwg)), dim3(kMelThreads), 0, (hipStream_t)stream, descs_dev, n, nwg, W, bands_dev,
-                     nfilter, nbins);
+  {
+    daliamd::KernelTimer timer("MelKernel", (hipStream_t)stream);
+    hipLaunchKernelGGL(MelKernel, dim3(XcdGrid(nwg)), dim3(kMelThreads), 0, (hipStream_t)stream, descs_dev, n, nwg, W, bands_dev,
+                       nfilter, nbins);
+  }
   DALIAMD_HIP_CHECK(hipGetLastError());
   return DALIAMD_SUCCESS;
 }
 
-daliamdResult_t daliamdToDecibelsRun(daliamdStream_t stream, const daliamdDecibelDesc *descs_dev, int n, float multiplier,
+daliamdResult_t daliamdToDecibelsSetup(daliamdDecibelDesc *descs, int n, int *nwg) {
+  DALIAMD_REQUIRE(descs && nwg && n >= 0, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdToDecibelsSetup: NULL argument");
+  int wg = 0;
+  for (int i = 0; i < n; i++) {
+    DALIAMD_REQUIRE(descs[i].size >= 0, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdToDecibelsSetup: negative size");
+    descs[i].max_bits = 0;
+    descs[i].wg_start = wg;
+    wg += (int)((descs[i].size + kDbChunk - 1) / kDbChunk);
+  }
+  *nwg = wg;
+  return DALIAMD_SUCCESS;
+}
+
+daliamdResult_t daliamdToDecibelsRun(daliamdStream_t stream, daliamdDecibelDesc *descs_dev, int n, int nwg, float multiplier,
                                      float reference, float cutoff_db) {
-  if (n == 0) return DALIAMD_SUCCESS;
-  DALIAMD_REQUIRE(descs_dev && n > 0, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdToDecibelsRun: invalid argument");
+  if (n == 0 || nwg == 0) return DALIAMD_SUCCESS;
+  DALIAMD_REQUIRE(descs_dev && n > 0 && nwg > 0, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdToDecibelsRun: invalid argument");
   float min_ratio = std::pow(10.0f, cutoff_db / multiplier);        // to_decibels_op.h:41-49
   if (min_ratio == 0.0f) min_ratio = std::nextafter(0.0f, 1.0f);
   float mul_log2 = multiplier * 0.3010299956639812f;
-  hipLaunchKernelGGL(DecibelKernel, dim3(n), dim3(kDbThreads), 0, (hipStream_t)stream, descs_dev, mul_log2, reference, min_ratio);
+  if (!(reference > 0.0f))
+    {
+      daliamd::KernelTimer timer("DecibelMaxKernel", (hipStream_t)stream);
+      hipLaunchKernelGGL(DecibelMaxKernel, dim3(XcdGrid(nwg)), dim3(kDbThreads), 0, (hipStream_t)stream, descs_dev, n, nwg);
+    }
+  {
+    daliamd::KernelTimer timer("DecibelKernel", (hipStream_t)stream);
+    hipLaunchKernelGGL(DecibelKernel, dim3(XcdGrid(nwg)), dim3(kDbThreads), 0, (hipStream_t)stream, descs_dev, n, nwg, mul_log2,
+                       reference, min_ratio);
+  }
   DALIAMD_HIP_CHECK(hipGetLastError());
   return DALIAMD_SUCCESS;
 }

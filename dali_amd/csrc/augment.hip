@@ -26,15 +26,6 @@ constexpr int kWarpPx = 4;
 constexpr int kWarpTileW = 256;  // must equal the CPU re-anchoring period
 constexpr int kWarpRows = kWarpThreads / (kWarpTileW / kWarpPx);  // 4 rows per workgroup
 
-__device__ __forceinline__ float WarpFetch(const daliamdWarpAffineDesc &d, int x, int y, int c, float fillc) {
-  if ((unsigned)x < (unsigned)d.in_w && (unsigned)y < (unsigned)d.in_h)
-    return (float)d.in[(size_t)y * d.in_pitch + x * d.channels + c];
-  if (!d.border_clamp) return fillc;
-  x = ClampInt(x, 0, d.in_w - 1);
-  y = ClampInt(y, 0, d.in_h - 1);
-  return (float)d.in[(size_t)y * d.in_pitch + x * d.channels + c];
-}
-
 __global__ __launch_bounds__(kWarpThreads) void WarpAffineKernel(const daliamdWarpAffineDesc *__restrict__ descs,
                                                                  int ndesc, int total_wg) {
   int wg = XcdRemap(blockIdx.x, total_wg);
@@ -69,27 +60,44 @@ __global__ __launch_bounds__(kWarpThreads) void WarpAffineKernel(const daliamdWa
   }
   const int C = d.channels;
   const int npx = min(kWarpPx, d.out_w - x0);
-  uint8_t *o = d.out + (size_t)y * d.out_pitch + (size_t)x0 * C;
+  using GIn = const uint8_t __attribute__((address_space(1)));
+  using GOut = uint8_t __attribute__((address_space(1)));
+  GIn *in = (GIn *)d.in;
+  GOut *o = (GOut *)d.out + (size_t)y * d.out_pitch + (size_t)x0 * C;
   const bool fast3 = C == 3 && ((reinterpret_cast<uintptr_t>(d.in) | (uintptr_t)d.in_pitch) & 3) == 0;
   const float f0 = (float)SatU8(d.fill[0]), f1 = (float)SatU8(d.fill[1]), f2 = (float)SatU8(d.fill[2]),
               f3 = (float)SatU8(d.fill[3]);
-  for (int p = 0; p < npx; p++, sx += m0, sy += m3) {
+  auto fetch = [&](int x, int yy, int c, float fillc) -> float {
+    if ((unsigned)x < (unsigned)d.in_w && (unsigned)yy < (unsigned)d.in_h)
+      return (float)in[(size_t)yy * d.in_pitch + x * C + c];
+    if (!d.border_clamp) return fillc;
+    x = ClampInt(x, 0, d.in_w - 1);
+    yy = ClampInt(yy, 0, d.in_h - 1);
+    return (float)in[(size_t)yy * d.in_pitch + x * C + c];
+  };
+  // the kWarpPx pixels of a thread leave as dwords when they are 3-channel and the row is dword-aligned
+  const bool packed = C == 3 && npx == kWarpPx && ((uintptr_t)o & 3) == 0;
+  uint32_t ob[kWarpPx * 3];
+#pragma unroll
+  for (int p = 0; p < kWarpPx; p++, sx += m0, sy += m3) {
+    if (p >= npx) break;
+    uint32_t px[4] = {0, 0, 0, 0};
     if (d.interp == DALIAMD_INTERP_NN) {
       int ix = (int)floorf(sx), iy = (int)floorf(sy);
       for (int c = 0; c < C; c++) {
         float fc = c == 0 ? f0 : c == 1 ? f1 : c == 2 ? f2 : f3;
-        o[p * C + c] = (uint8_t)WarpFetch(d, ix, iy, c, fc);
+        px[c] = (uint32_t)fetch(ix, iy, c, fc);
       }
     } else {
       float fx = sx - 0.5f, fy = sy - 0.5f;
       int ix = (int)floorf(fx), iy = (int)floorf(fy);
-      float qx = fx - ix, px = 1 - qx, qy = fy - iy;
+      float qx = fx - ix, pxw = 1 - qx, qy = fy - iy;
       if (fast3 && ix >= 0 && iy >= 0 && ix + 4 < d.in_w && iy + 1 < d.in_h) {
         // interior, 3 channels: the 2 x 2 x 3 bytes as one 12-byte load per row (dword aligned) + byte alignment
         typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
         using GlobalTriple = const u32x3 __attribute__((address_space(1)));
         const size_t b0 = (size_t)iy * d.in_pitch + (size_t)ix * 3, b1 = b0 + d.in_pitch;
-        const u32x3 r0 = *(GlobalTriple *)(d.in + (b0 & ~(size_t)3)), r1 = *(GlobalTriple *)(d.in + (b1 & ~(size_t)3));
+        const u32x3 r0 = *(GlobalTriple *)(in + (b0 & ~(size_t)3)), r1 = *(GlobalTriple *)(in + (b1 & ~(size_t)3));
         const uint32_t h0 = (uint32_t)(b0 & 3), h1 = (uint32_t)(b1 & 3);
         const uint32_t a0 = __builtin_amdgcn_alignbyte(r0.y, r0.x, h0), a1 = __builtin_amdgcn_alignbyte(r0.z, r0.y, h0);
         const uint32_t c0 = __builtin_amdgcn_alignbyte(r1.y, r1.x, h1), c1 = __builtin_amdgcn_alignbyte(r1.z, r1.y, h1);
@@ -100,21 +108,34 @@ __global__ __launch_bounds__(kWarpThreads) void WarpAffineKernel(const daliamdWa
         const float t11[3] = {(float)(c0 >> 24), (float)(c1 & 255), (float)((c1 >> 8) & 255)};
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-          float s0 = t00[c] * px + t01[c] * qx;
-          float s1 = t10[c] * px + t11[c] * qx;
-          o[p * 3 + c] = (uint8_t)SatU8(s0 + (s1 - s0) * qy);
+          float s0 = t00[c] * pxw + t01[c] * qx;
+          float s1 = t10[c] * pxw + t11[c] * qx;
+          px[c] = SatU8(s0 + (s1 - s0) * qy);
         }
-        continue;
-      }
-      for (int c = 0; c < C; c++) {
-        float fc = c == 0 ? f0 : c == 1 ? f1 : c == 2 ? f2 : f3;
-        float s00 = WarpFetch(d, ix, iy, c, fc), s01 = WarpFetch(d, ix + 1, iy, c, fc);
-        float s10 = WarpFetch(d, ix, iy + 1, c, fc), s11 = WarpFetch(d, ix + 1, iy + 1, c, fc);
-        float s0 = s00 * px + s01 * qx;
-        float s1 = s10 * px + s11 * qx;
-        o[p * C + c] = (uint8_t)SatU8(s0 + (s1 - s0) * qy);
+      } else {
+        for (int c = 0; c < C; c++) {
+          float fc = c == 0 ? f0 : c == 1 ? f1 : c == 2 ? f2 : f3;
+          float s00 = fetch(ix, iy, c, fc), s01 = fetch(ix + 1, iy, c, fc);
+          float s10 = fetch(ix, iy + 1, c, fc), s11 = fetch(ix + 1, iy + 1, c, fc);
+          float s0 = s00 * pxw + s01 * qx;
+          float s1 = s10 * pxw + s11 * qx;
+          px[c] = SatU8(s0 + (s1 - s0) * qy);
+        }
       }
     }
+    if (packed) {
+      ob[3 * p] = px[0]; ob[3 * p + 1] = px[1]; ob[3 * p + 2] = px[2];
+    } else {
+      for (int c = 0; c < C; c++) o[p * C + c] = (uint8_t)px[c];
+    }
+  }
+  if (packed) {
+    typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+    u32x3 w;
+    w.x = ob[0] | (ob[1] << 8) | (ob[2] << 16) | (ob[3] << 24);
+    w.y = ob[4] | (ob[5] << 8) | (ob[6] << 16) | (ob[7] << 24);
+    w.z = ob[8] | (ob[9] << 8) | (ob[10] << 16) | (ob[11] << 24);
+    *(u32x3 __attribute__((address_space(1))) *)o = w;
   }
 }
 
@@ -123,6 +144,9 @@ __global__ __launch_bounds__(kWarpThreads) void WarpAffineKernel(const daliamdWa
 // =============================================================================================
 constexpr int kBlurThreads = 256;
 constexpr int kBlurMaxLds = 60 * 1024;
+constexpr int kBlurPx = 8;    // W pass: pixels per thread (and channel, and row of the pair)
+constexpr int kBlurRows = 8;  // H pass: output rows per thread
+typedef float floatx2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int Reflect101(int idx, int size) {
   if (size < 2) return size - 1;
@@ -148,7 +172,7 @@ __global__ __launch_bounds__(kBlurThreads) void GaussianBlurKernel(const daliamd
   const int tw = min(TW, d.w - ox0), th = min(TH, d.h - oy0);
   const int in_rows = th + 2 * ry, in_cols = tw + 2 * rx;
   const int row_elems = tw * C;                        // tmp row length
-  const int src_pitch = ((in_cols + 4) * C + 4 + 3) & ~3;  // staged source row pitch (bytes): + lead + blocking overrun
+  const int src_pitch = ((in_cols + kBlurPx) * C + 4 + 3) & ~3;  // staged source row pitch (bytes): + lead + blocking overrun
   float *wx = blur_lds;                                // [size_x]
   float *wy = wx + d.size_x;                           // [size_y]
   float *tmp = wy + d.size_y;                          // [in_rows][row_elems]
@@ -178,57 +202,90 @@ __global__ __launch_bounds__(kBlurThreads) void GaussianBlurKernel(const daliamd
     }
   }
   __syncthreads();
-  // ---- W pass: tmp[r][x*C+c] = sum_k src[r][(x+k)*C+c] * wx[k], taps in order.  Each thread produces 4 consecutive
-  // pixels of one channel: the 4 + size_x - 1 source bytes are read once and reused (register blocking) ----
-  const int groups = (tw + 3) >> 2;  // groups of 4 pixels per row
-  for (int r = tid / 64; r < in_rows; r += kBlurThreads / 64) {
-    const uint8_t *rowp = d.in + (size_t)Reflect101(oy0 - ry + r, d.h) * d.in_pitch + (size_t)(ox0 - rx) * C;
-    const int lead = interior_x ? (int)(reinterpret_cast<uintptr_t>(rowp) & 3) : 0;
-    const uint8_t *srow = src + r * src_pitch + lead;
-    float *trow = tmp + r * row_elems;
-    for (int item = tid % 64; item < groups * C; item += 64) {
-      const int g4 = item / C, c = item - g4 * C;
-      const int x = g4 * 4;
-      const uint8_t *p = srow + x * C + c;
-      float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-      float v0 = (float)p[0], v1 = (float)p[C], v2 = (float)p[2 * C], v3;
-#pragma unroll 4
+  // ---- W pass: tmp[r][x*C+c] = sum_k src[r][(x+k)*C+c] * wx[k], taps in order.  A thread owns kBlurPx consecutive
+  // pixels of one channel in TWO rows: the window of kBlurPx + size_x - 1 source bytes slides through registers (one
+  // byte load + conversion per tap and row), and the two rows make every multiply / add a packed one (the row pair is
+  // the vector; the weight is wave-uniform and comes from a scalar load of the descriptor) ----
+  {
+    const int groups = (tw + kBlurPx - 1) / kBlurPx;
+    const int row_pairs = (in_rows + 1) >> 1;
+    const int items = row_pairs * groups * C;
+    const float *__restrict__ gwx = d.window_x;
+    for (int item = tid; item < items; item += kBlurThreads) {
+      const int rp = item / (groups * C), rem = item - rp * (groups * C);
+      const int g = rem / C, c = rem - g * C;
+      const int x = g * kBlurPx;
+      const int ra = 2 * rp, rb = min(2 * rp + 1, in_rows - 1);
+      auto row_ptr = [&](int r) {
+        const uint8_t *rowp = d.in + (size_t)Reflect101(oy0 - ry + r, d.h) * d.in_pitch + (size_t)(ox0 - rx) * C;
+        const int lead = interior_x ? (int)(reinterpret_cast<uintptr_t>(rowp) & 3) : 0;
+        return src + r * src_pitch + lead + x * C + c;
+      };
+      const uint8_t *pa = row_ptr(ra), *pb = row_ptr(rb);
+      floatx2 acc[kBlurPx], v[kBlurPx];
+#pragma unroll
+      for (int j = 0; j < kBlurPx; j++) acc[j] = floatx2{0.0f, 0.0f};
+#pragma unroll
+      for (int j = 0; j < kBlurPx - 1; j++) v[j] = floatx2{(float)pa[j * C], (float)pb[j * C]};
+#pragma unroll 8
       for (int k = 0; k < d.size_x; k++) {
-        v3 = (float)p[(k + 3) * C];   // (x + 3 + k): in range for the last group too: the staged row is padded
-        const float w = wx[k];
-        a0 += v0 * w; a1 += v1 * w; a2 += v2 * w; a3 += v3 * w;
-        v0 = v1; v1 = v2; v2 = v3;
+        // (x + kBlurPx - 1 + k): in range for the last group too, the staged row is padded
+        v[kBlurPx - 1] = floatx2{(float)pa[(k + kBlurPx - 1) * C], (float)pb[(k + kBlurPx - 1) * C]};
+        const float w = gwx[k];
+#pragma unroll
+        for (int j = 0; j < kBlurPx; j++) acc[j] += v[j] * w;
+#pragma unroll
+        for (int j = 0; j < kBlurPx - 1; j++) v[j] = v[j + 1];
       }
-      float *t = trow + x * C + c;
-      t[0] = a0;
-      if (x + 1 < tw) t[C] = a1;
-      if (x + 2 < tw) t[2 * C] = a2;
-      if (x + 3 < tw) t[3 * C] = a3;
+      float *ta = tmp + ra * row_elems + x * C + c, *tb = tmp + rb * row_elems + x * C + c;
+#pragma unroll
+      for (int j = 0; j < kBlurPx; j++)
+        if (x + j < tw) {
+          ta[j * C] = acc[j].x;
+          tb[j * C] = acc[j].y;
+        }
     }
   }
   __syncthreads();
-  // ---- H pass: 4 consecutive rows per thread (register blocking over the taps), taps in order ----
-  const int rgroups = (th + 3) >> 2;
-  for (int yg = tid / 64; yg < rgroups; yg += kBlurThreads / 64) {
-    const int y = yg * 4;
-    for (int e = tid % 64; e < row_elems; e += 64) {
-      const float *p = tmp + y * row_elems + e;
-      float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-      // rows y+k .. y+k+3; rows beyond the staged area are only read for outputs that are not stored
-      const int last = in_rows - 1;
-      float v0 = p[0], v1 = p[min(1, last - y) * row_elems], v2 = p[min(2, last - y) * row_elems], v3;
-#pragma unroll 4
+  // ---- H pass: a thread owns two neighbouring elements of a row (the packed pair, one 8-byte LDS load per tap) in
+  // kBlurRows consecutive output rows; the rows slide through registers, taps in order ----
+  {
+    const int epairs = (row_elems + 1) >> 1;
+    const int rgroups = (th + kBlurRows - 1) / kBlurRows;
+    const float *__restrict__ gwy = d.window_y;
+    const int last = in_rows - 1;
+    using GOut = uint8_t __attribute__((address_space(1)));
+    for (int item = tid; item < epairs * rgroups; item += kBlurThreads) {
+      const int yg = item / epairs, ep = item - yg * epairs;
+      const int y = yg * kBlurRows, e = 2 * ep;
+      const bool two = e + 1 < row_elems;   // an odd row length leaves the last thread a single element
+      const float *p = tmp + e;
+      auto load = [&](int r) {
+        const float *q = p + min(r, last) * row_elems;  // rows beyond the staged area only feed outputs that are not stored
+        return two ? floatx2{q[0], q[1]} : floatx2{q[0], 0.0f};
+      };
+      floatx2 acc[kBlurRows], v[kBlurRows];
+#pragma unroll
+      for (int j = 0; j < kBlurRows; j++) acc[j] = floatx2{0.0f, 0.0f};
+#pragma unroll
+      for (int j = 0; j < kBlurRows - 1; j++) v[j] = load(y + j);
+#pragma unroll 8
       for (int k = 0; k < d.size_y; k++) {
-        v3 = p[min(k + 3, last - y) * row_elems];
-        const float w = wy[k];
-        a0 += w * v0; a1 += w * v1; a2 += w * v2; a3 += w * v3;
-        v0 = v1; v1 = v2; v2 = v3;
+        v[kBlurRows - 1] = load(y + k + kBlurRows - 1);
+        const float w = gwy[k];
+#pragma unroll
+        for (int j = 0; j < kBlurRows; j++) acc[j] += w * v[j];
+#pragma unroll
+        for (int j = 0; j < kBlurRows - 1; j++) v[j] = v[j + 1];
       }
-      uint8_t *o = d.out + (size_t)(oy0 + y) * d.out_pitch + (size_t)ox0 * C + e;
-      o[0] = (uint8_t)SatU8(a0);
-      if (y + 1 < th) o[d.out_pitch] = (uint8_t)SatU8(a1);
-      if (y + 2 < th) o[2 * (size_t)d.out_pitch] = (uint8_t)SatU8(a2);
-      if (y + 3 < th) o[3 * (size_t)d.out_pitch] = (uint8_t)SatU8(a3);
+      GOut *o = (GOut *)d.out + (size_t)(oy0 + y) * d.out_pitch + (size_t)ox0 * C + e;
+#pragma unroll
+      for (int j = 0; j < kBlurRows; j++)
+        if (y + j < th) {
+          GOut *oj = o + (size_t)j * d.out_pitch;
+          oj[0] = (uint8_t)SatU8(acc[j].x);
+          if (two) oj[1] = (uint8_t)SatU8(acc[j].y);
+        }
     }
   }
 }
@@ -251,14 +308,51 @@ __global__ __launch_bounds__(kPwThreads) void PointwiseKernel(const daliamdPoint
   int y = (int)(g / groups_per_row);
   int x0 = (int)(g - (long long)y * groups_per_row) * kPwPx;
   int npx = min(kPwPx, d.w - x0);
-  const uint8_t *ip = d.in + (size_t)y * d.in_pitch + (size_t)x0 * C;
-  uint8_t *op = d.out + (size_t)y * d.out_pitch + (size_t)x0 * C;
-  for (int p = 0; p < npx; p++) {
-    int x = x0 + p;
-    bool erased = false;
+  using GIn = const uint8_t __attribute__((address_space(1)));
+  using GOut = uint8_t __attribute__((address_space(1)));
+  typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+  GIn *ip = (GIn *)d.in + (size_t)y * d.in_pitch + (size_t)x0 * C;
+  GOut *op = (GOut *)d.out + (size_t)y * d.out_pitch + (size_t)x0 * C;
+  bool erased[kPwPx];
+#pragma unroll
+  for (int p = 0; p < kPwPx; p++) {
+    const int x = x0 + p;
+    bool e = false;
     for (int r = 0; r < d.num_regions; r++)
-      erased |= y >= d.region[r][0] && y < d.region[r][2] && x >= d.region[r][1] && x < d.region[r][3];
-    if (erased) {
+      e |= y >= d.region[r][0] && y < d.region[r][2] && x >= d.region[r][1] && x < d.region[r][3];
+    erased[p] = e;
+  }
+  if (C == 3 && npx == kPwPx && ((((uintptr_t)ip) | ((uintptr_t)op)) & 3) == 0) {
+    // 4 pixels = 12 bytes = three dwords in, three dwords out
+    const u32x3 v = *(const u32x3 __attribute__((address_space(1))) *)ip;
+    uint32_t b[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) b[i] = ((i < 4 ? v.x : i < 8 ? v.y : v.z) >> (8 * (i & 3))) & 255u;
+    const uint32_t f0 = SatU8(d.fill[0]), f1 = SatU8(d.fill[1]), f2 = SatU8(d.fill[2]);
+#pragma unroll
+    for (int p = 0; p < kPwPx; p++) {
+      if (erased[p]) {
+        b[3 * p] = f0; b[3 * p + 1] = f1; b[3 * p + 2] = f2;
+      } else if (d.transform) {
+        const float v0 = (float)b[3 * p], v1 = (float)b[3 * p + 1], v2 = (float)b[3 * p + 2];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          float s = d.matrix[3 * i] * v0;   // mat * vec: s = m[i][0]*v[0]; s += m[i][j]*v[j]   (mat.h:283-292)
+          s += d.matrix[3 * i + 1] * v1;
+          s += d.matrix[3 * i + 2] * v2;
+          b[3 * p + i] = SatU8(s + d.offset[i]);
+        }
+      }
+    }
+    u32x3 o;
+    o.x = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+    o.y = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+    o.z = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
+    *(u32x3 __attribute__((address_space(1))) *)op = o;
+    return;
+  }
+  for (int p = 0; p < npx; p++) {
+    if (erased[p]) {
       for (int c = 0; c < C; c++) op[p * C + c] = (uint8_t)SatU8(c == 0 ? d.fill[0] : c == 1 ? d.fill[1] : c == 2 ? d.fill[2] : d.fill[3]);
     } else if (d.transform) {
       float v0 = (float)ip[p * 3], v1 = (float)ip[p * 3 + 1], v2 = (float)ip[p * 3 + 2];
@@ -346,7 +440,10 @@ daliamdResult_t daliamdWarpAffineSetup(daliamdWarpAffineDesc *descs, int n, int 
 daliamdResult_t daliamdWarpAffineRun(daliamdStream_t stream, const daliamdWarpAffineDesc *descs_dev, int n, int nwg) {
   if (n == 0 || nwg == 0) return DALIAMD_SUCCESS;
   DALIAMD_REQUIRE(descs_dev && n > 0 && nwg > 0, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdWarpAffineRun: invalid argument");
-  hipLaunchKernelGGL(WarpAffineKernel, dim3(XcdGrid(nwg)), dim3(kWarpThreads), 0, (hipStream_t)stream, descs_dev, n, nwg);
+  {
+    daliamd::KernelTimer timer("WarpAffineKernel", (hipStream_t)stream);
+    hipLaunchKernelGGL(WarpAffineKernel, dim3(XcdGrid(nwg)), dim3(kWarpThreads), 0, (hipStream_t)stream, descs_dev, n, nwg);
+  }
   DALIAMD_HIP_CHECK(hipGetLastError());
   return DALIAMD_SUCCESS;
 }
@@ -392,10 +489,10 @@ daliamdResult_t daliamdGaussianBlurSetup(daliamdGaussianBlurDesc *descs, int n, 
                     d.size_y <= DALIAMD_MAX_BLUR_WINDOW && d.size_x > 0 && d.size_y > 0, DALIAMD_ERROR_UNSUPPORTED,
                     "daliamdGaussianBlurSetup: sample %d: window sizes must be odd and <= %d", i, DALIAMD_MAX_BLUR_WINDOW);
     // tall tiles: the W pass also runs over the 2 * radius halo rows, so its overhead is (th + 2r) / th
-    int tw = 64, th = 32;
+    int tw = 32, th = 64;
     auto need = [&](int tw_, int th_) {
       size_t rows = th_ + d.size_y - 1, cols = tw_ + d.size_x - 1;
-      size_t src_pitch = ((cols + 4) * d.channels + 4 + 3) & ~(size_t)3;  // + alignment lead + register-blocking overrun
+      size_t src_pitch = ((cols + kBlurPx) * d.channels + 4 + 3) & ~(size_t)3;  // + alignment lead + register-blocking overrun
       return (size_t)(d.size_x + d.size_y) * 4 + rows * tw_ * d.channels * 4 + rows * src_pitch + 16;
     };
     while (need(tw, th) > (size_t)kBlurMaxLds && (tw > 8 || th > 1)) {
@@ -420,8 +517,11 @@ daliamdResult_t daliamdGaussianBlurRun(daliamdStream_t stream, const daliamdGaus
   if (n == 0 || nwg == 0) return DALIAMD_SUCCESS;
   DALIAMD_REQUIRE(descs_dev && n > 0 && nwg > 0 && lds_bytes >= 0 && lds_bytes <= kBlurMaxLds,
                   DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdGaussianBlurRun: invalid argument");
-  hipLaunchKernelGGL(GaussianBlurKernel, dim3(XcdGrid(nwg)), dim3(kBlurThreads), lds_bytes, (hipStream_t)stream,
-                     descs_dev, n, nwg);
+  {
+    daliamd::KernelTimer timer("GaussianBlurKernel", (hipStream_t)stream);
+    hipLaunchKernelGGL(GaussianBlurKernel, dim3(XcdGrid(nwg)), dim3(kBlurThreads), lds_bytes, (hipStream_t)stream,
+                       descs_dev, n, nwg);
+  }
   DALIAMD_HIP_CHECK(hipGetLastError());
   return DALIAMD_SUCCESS;
 }
@@ -474,7 +574,10 @@ daliamdResult_t daliamdPointwiseSetup(daliamdPointwiseDesc *descs, int n, int *n
 daliamdResult_t daliamdPointwiseRun(daliamdStream_t stream, const daliamdPointwiseDesc *descs_dev, int n, int nwg) {
   if (n == 0 || nwg == 0) return DALIAMD_SUCCESS;
   DALIAMD_REQUIRE(descs_dev && n > 0 && nwg > 0, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdPointwiseRun: invalid argument");
-  hipLaunchKernelGGL(PointwiseKernel, dim3(XcdGrid(nwg)), dim3(kPwThreads), 0, (hipStream_t)stream, descs_dev, n, nwg);
+  {
+    daliamd::KernelTimer timer("PointwiseKernel", (hipStream_t)stream);
+    hipLaunchKernelGGL(PointwiseKernel, dim3(XcdGrid(nwg)), dim3(kPwThreads), 0, (hipStream_t)stream, descs_dev, n, nwg);
+  }
   DALIAMD_HIP_CHECK(hipGetLastError());
   return DALIAMD_SUCCESS;
 }

@@ -3,7 +3,12 @@
 // CUDAEventPool and mm:: resources (include/dali/core/cuda_stream_pool.h,
 // cuda_event_pool.h, mm/) without the host ever including HIP headers.
 #include <dlfcn.h>
+#include <atomic>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
 #include "common.h"
 
 namespace daliamd {
@@ -14,6 +19,29 @@ void SetLastError(const char *fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
   va_end(ap);
+}
+
+// ---- kernel timing (benchmarks) ----
+namespace {
+struct TimedLaunch { const char *name; hipEvent_t start, stop; };
+std::atomic<int> g_timing_on{0};
+std::mutex g_timing_mu;
+std::vector<TimedLaunch> g_timed;
+}  // namespace
+
+KernelTimer::KernelTimer(const char *name, hipStream_t stream) : name_(name), stream_(stream) {
+  if (!g_timing_on.load(std::memory_order_relaxed)) return;
+  if (hipEventCreate(&start_) != hipSuccess) { start_ = nullptr; return; }
+  (void)hipEventRecord(start_, stream_);
+}
+KernelTimer::~KernelTimer() {
+  if (!start_) return;
+  hipEvent_t stop = nullptr;
+  if (hipEventCreate(&stop) != hipSuccess) { (void)hipEventDestroy(start_); return; }
+  (void)hipEventRecord(stop, stream_);
+  std::lock_guard<std::mutex> lk(g_timing_mu);
+  if (g_timed.size() < (1u << 20)) g_timed.push_back({name_, start_, stop});
+  else { (void)hipEventDestroy(start_); (void)hipEventDestroy(stop); }
 }
 }  // namespace daliamd
 
@@ -69,6 +97,42 @@ daliamdResult_t daliamdDevicePciBusId(int device_id, char *bus_id, int len) {
   DALIAMD_REQUIRE(bus_id && len >= 16, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdDevicePciBusId: buffer of >= 16 bytes needed");
   DALIAMD_HIP_CHECK(hipDeviceGetPCIBusId(bus_id, len, device_id));
   return DALIAMD_SUCCESS;
+}
+
+void daliamdKernelTimingEnable(int on) {
+  daliamd::g_timing_on.store(on ? 1 : 0);
+}
+// "name\tlaunches\tavg_ms\n" per kernel for the launches recorded since the last report (which it consumes); waits for
+// them to finish.  Returns the length needed (excluding the terminator), writes at most len - 1 characters.
+int daliamdKernelTimingReport(char *buf, int len) {
+  static std::map<std::string, std::pair<int, double>> acc;   // launches read back so far, not yet handed out
+  static std::mutex acc_mu;
+  std::vector<daliamd::TimedLaunch> take;
+  {
+    std::lock_guard<std::mutex> lk(daliamd::g_timing_mu);
+    take.swap(daliamd::g_timed);
+  }
+  std::lock_guard<std::mutex> lk(acc_mu);
+  for (auto &t : take) {
+    float ms = 0;
+    if (hipEventSynchronize(t.stop) == hipSuccess && hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess) {
+      auto &a = acc[t.name];
+      a.first++;
+      a.second += ms;
+    }
+    (void)hipEventDestroy(t.start);
+    (void)hipEventDestroy(t.stop);
+  }
+  std::string out;
+  for (auto &kv : acc)
+    out += kv.first + "\t" + std::to_string(kv.second.first) + "\t" + std::to_string(kv.second.second / kv.second.first) + "\n";
+  if (buf && len > 0) {  // a call with a buffer hands the statistics out and starts over
+    int n = (int)out.size() < len - 1 ? (int)out.size() : len - 1;
+    memcpy(buf, out.data(), n);
+    buf[n] = 0;
+    acc.clear();
+  }
+  return (int)out.size();
 }
 
 void daliamdRangePush(const char *name) {

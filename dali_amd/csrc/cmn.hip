@@ -142,8 +142,11 @@ daliamdResult_t daliamdCmnRun(daliamdStream_t stream, const daliamdCmnDesc *desc
   if (n == 0 || num_workgroups == 0) return DALIAMD_SUCCESS;
   DALIAMD_REQUIRE(descs_dev && n > 0 && num_workgroups > 0, DALIAMD_ERROR_INVALID_ARGUMENT,
                   "daliamdCmnRun: invalid argument");
-  hipLaunchKernelGGL(daliamd::CmnKernel, dim3(daliamd::XcdGrid(num_workgroups)), dim3(daliamd::kCmnThreads), 0,
-                     (hipStream_t)stream, descs_dev, n, num_workgroups);
+  {
+    daliamd::KernelTimer timer("CmnKernel", (hipStream_t)stream);
+    hipLaunchKernelGGL(daliamd::CmnKernel, dim3(daliamd::XcdGrid(num_workgroups)), dim3(daliamd::kCmnThreads), 0,
+                       (hipStream_t)stream, descs_dev, n, num_workgroups);
+  }
   DALIAMD_HIP_CHECK(hipGetLastError());
   return DALIAMD_SUCCESS;
 }

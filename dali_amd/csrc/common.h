@@ -51,5 +51,21 @@ __device__ __forceinline__ int XcdRemap(int block, int logical_total) {
 }
 inline int XcdGrid(int logical_total) { return ((logical_total + 7) / 8) * 8; }
 
+// Kernel timing for benchmarks (daliamdKernelTimingEnable): while enabled, a KernelTimer around a launch records a pair
+// of timing events on the launch's stream; daliamdKernelTimingReport reads them back per kernel name.  Off: a relaxed
+// load and nothing else.
+class KernelTimer {
+ public:
+  KernelTimer(const char *name, hipStream_t stream);
+  ~KernelTimer();
+  KernelTimer(const KernelTimer &) = delete;
+  KernelTimer &operator=(const KernelTimer &) = delete;
+
+ private:
+  const char *name_;
+  hipStream_t stream_;
+  hipEvent_t start_ = nullptr;
+};
+
 }  // namespace daliamd
 #endif  // DALI_AMD_CSRC_COMMON_H_

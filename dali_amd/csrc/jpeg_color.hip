@@ -231,9 +231,7 @@ __device__ __forceinline__ void ColorRows420(const daliamdJpegColorDesc &d, int 
   }
 }
 
-// The common case - YCbCr 4:2:0 to RGB, upright, aligned planes - has its own kernel: the general one needs 246
-// registers (one wave per SIMD), the 4:2:0 rows 143.  Both run over the same grid; a workgroup whose sample belongs to
-// the other kernel leaves at once, and Run only launches the kernels Setup found samples for.
+// The common case: YCbCr 4:2:0 to RGB, upright, aligned planes.
 __host__ __device__ inline bool Fast420(const daliamdJpegColorDesc &d) {
   if (d.out_format != DALIAMD_JPEG_OUT_RGB || d.color != DALIAMD_JPEG_YCC || d.orientation > 1) return false;
   const int hmax = max(d.h_samp[0], max(d.h_samp[1], d.h_samp[2])), vmax = max(d.v_samp[0], max(d.v_samp[1], d.v_samp[2]));
@@ -247,31 +245,19 @@ __host__ __device__ inline bool Fast420(const daliamdJpegColorDesc &d) {
          ((reinterpret_cast<uintptr_t>(d.plane[1]) | reinterpret_cast<uintptr_t>(d.plane[2])) & 3) == 0;
 }
 
-__global__ __launch_bounds__(kColorThreads) void JpegColor420Kernel(const daliamdJpegColorDesc *__restrict__ descs,
-                                                                    int ndesc, int total_wg) {
-  int wg = XcdRemap(blockIdx.x, total_wg);
-  if (wg < 0) return;
-  const daliamdJpegColorDesc &d = descs[FindDesc(descs, ndesc, wg)];
-  if (!Fast420(d)) return;
-  const bool roi = d.roi_w > 0;
-  const int rx0 = roi ? d.roi_x0 : 0, ry0 = roi ? d.roi_y0 : 0;
-  const int rx1 = roi ? d.roi_x0 + d.roi_w : d.width, ry1 = roi ? d.roi_y0 + d.roi_h : d.height;
-  int tiles_x = (rx1 - rx0 + kTileW - 1) / kTileW;
-  int t = wg - d.wg_start;
-  int ty = t / tiles_x, tx = t - ty * tiles_x;
-  int x0 = rx0 + tx * kTileW + (threadIdx.x & 31) * 8;
-  const int y_first = ry0 + ty * kTileH + (threadIdx.x >> 5) * kRowsPerThread;
-  if (x0 >= rx1 || y_first >= ry1) return;
-  ColorRows420(d, x0, y_first, rx1, ry1, roi ? d.out_x0 : 0, roi ? d.out_y0 : 0);
+// kConvert: samples whose RGB result is converted on to BGR / YCbCr / gray (the conversion code costs 100 registers)
+__host__ __device__ inline bool NeedsConvert(const daliamdJpegColorDesc &d) {
+  return d.out_format != DALIAMD_JPEG_OUT_RGB && !(d.out_format == DALIAMD_JPEG_OUT_GRAY && d.color != DALIAMD_JPEG_RGB);
 }
 
+template <bool kConvert>
 __global__ __launch_bounds__(kColorThreads) void JpegColorKernel(const daliamdJpegColorDesc *__restrict__ descs,
                                                                  int ndesc, int total_wg) {
   int wg = XcdRemap(blockIdx.x, total_wg);
   if (wg < 0) return;
   int di = FindDesc(descs, ndesc, wg);
   const daliamdJpegColorDesc &d = descs[di];
-  if (Fast420(d)) return;
+  if (NeedsConvert(d) != kConvert) return;
   // region of the (un-rotated) image to produce; the 8-pixel groups are aligned to its origin so that the output
   // rows keep their 8-byte store alignment
   const bool roi = d.roi_w > 0;
@@ -299,6 +285,10 @@ __global__ __launch_bounds__(kColorThreads) void JpegColorKernel(const daliamdJp
   const int out_x0 = roi ? d.out_x0 : 0, out_y0 = roi ? d.out_y0 : 0;
   const bool wide_ok = ((d.out_pitch & 7) == 0) && ((reinterpret_cast<uintptr_t>(d.out) & 7) == 0);
   const bool wide_stores = npx == 8 && wide_ok && oc == 3;
+  if (!kConvert && Fast420(d)) {  // wave-uniform: the whole image takes the fast path or none of it does
+    ColorRows420(d, x0, y_first, rx1, ry1, out_x0, out_y0);
+    return;
+  }
 
   for (int row = 0; row < kRowsPerThread; row++) {
     const int y = y_first + row;
@@ -329,7 +319,7 @@ __global__ __launch_bounds__(kColorThreads) void JpegColorKernel(const daliamdJp
     }
     // RGB -> the requested format (ConvertCPU / ConvertGPU of the reference, operators/imgcodec/util/convert.h:140-192:
     // BGR = swap; YCbCr = ITU-R BT.601 with head room, float, ConvertSat; gray = 0.299 R + 0.587 G + 0.114 B)
-    if (!luma_only && fmt != DALIAMD_JPEG_OUT_RGB) {
+    if (kConvert) {
 #pragma unroll
       for (int i = 0; i < 8; i++) {
         const uint32_t r8 = px[3 * i], g8 = px[3 * i + 1], b8 = px[3 * i + 2];
@@ -424,7 +414,7 @@ daliamdResult_t daliamdJpegColorSetup(daliamdJpegColorDesc *descs, int n, int *n
   *num_workgroups = wg;
   if (kernel_mask) {
     int mask = 0;
-    for (int i = 0; i < n; i++) mask |= daliamd::Fast420(descs[i]) ? 1 : 2;
+    for (int i = 0; i < n; i++) mask |= daliamd::Fast420(descs[i]) ? 1 : daliamd::NeedsConvert(descs[i]) ? 4 : 2;
     *kernel_mask = mask;
   }
   return DALIAMD_SUCCESS;
@@ -485,12 +475,18 @@ daliamdResult_t daliamdJpegColorRun(daliamdStream_t stream, const daliamdJpegCol
   if (n == 0 || num_workgroups == 0) return DALIAMD_SUCCESS;
   DALIAMD_REQUIRE(descs_dev && n > 0 && num_workgroups > 0, DALIAMD_ERROR_INVALID_ARGUMENT,
                   "daliamdJpegColorRun: invalid argument");
-  if (kernel_mask & 1)
-    hipLaunchKernelGGL(daliamd::JpegColor420Kernel, dim3(daliamd::XcdGrid(num_workgroups)),
-                       dim3(daliamd::kColorThreads), 0, (hipStream_t)stream, descs_dev, n, num_workgroups);
-  if (kernel_mask & 2)
-    hipLaunchKernelGGL(daliamd::JpegColorKernel, dim3(daliamd::XcdGrid(num_workgroups)),
-                       dim3(daliamd::kColorThreads), 0, (hipStream_t)stream, descs_dev, n, num_workgroups);
+  if (kernel_mask & 3)
+    {
+      daliamd::KernelTimer timer("JpegColorKernel", (hipStream_t)stream);
+      hipLaunchKernelGGL(daliamd::JpegColorKernel<false>, dim3(daliamd::XcdGrid(num_workgroups)),
+                         dim3(daliamd::kColorThreads), 0, (hipStream_t)stream, descs_dev, n, num_workgroups);
+    }
+  if (kernel_mask & 4)
+    {
+      daliamd::KernelTimer timer("JpegColorKernel", (hipStream_t)stream);
+      hipLaunchKernelGGL(daliamd::JpegColorKernel<true>, dim3(daliamd::XcdGrid(num_workgroups)),
+                         dim3(daliamd::kColorThreads), 0, (hipStream_t)stream, descs_dev, n, num_workgroups);
+    }
   DALIAMD_HIP_CHECK(hipGetLastError());
   return DALIAMD_SUCCESS;
 }

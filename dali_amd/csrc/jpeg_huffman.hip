@@ -76,6 +76,8 @@ using GlobalBytes = uint8_t __attribute__((address_space(1)));
 using GlobalU32 = uint32_t __attribute__((address_space(1)));
 using GlobalI32 = int32_t __attribute__((address_space(1)));
 using GlobalU16 = uint16_t __attribute__((address_space(1)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+using GlobalQuad = u32x4 __attribute__((address_space(1)));
 
 // ------------------------------------------------------------------------------------------------ scratch layout
 struct LaneRec {      // one per slice
@@ -92,6 +94,7 @@ struct SegRec {  // one per segment
   int32_t reserved;
 };
 static_assert(sizeof(SegRec) == 32, "layout");
+constexpr int kSegRecInts = 8, kSegRecNstart = 2, kSegRecBlockBase = 3, kSegRecDcTotal = 4;  // int32 view of a SegRec
 
 struct ScratchLayout {
   size_t tile_kept, clean, tables, sync_tables, lanes, segs, seg_starts, blk_pos, blk_dc, blk_seg, total;
@@ -261,9 +264,12 @@ __global__ __launch_bounds__(kTileThreads) void UnstuffScatterKernel(const dalia
 // ------------------------------------------------------------------------------------------------ tables
 template <int THREADS, typename Tables>
 __device__ __forceinline__ void CopyTables(Tables &dst, const Tables *src) {
-  const uint4 *s = reinterpret_cast<const uint4 *>(src);
+  const GlobalQuad *s = (const GlobalQuad *)src;
   uint4 *t = reinterpret_cast<uint4 *>(&dst);
-  for (int i = threadIdx.x; i < (int)(sizeof(Tables) / 16); i += THREADS) t[i] = s[i];
+  for (int i = threadIdx.x; i < (int)(sizeof(Tables) / 16); i += THREADS) {
+    const u32x4 v = s[i];
+    t[i] = make_uint4(v.x, v.y, v.z, v.w);
+  }
 }
 
 // Code tables of one stream (all threads of a PrepareKernel workgroup); every entry is found independently
@@ -419,7 +425,7 @@ __global__ __launch_bounds__(kSegThreads) void SyncKernel(const daliamdJpegHuffD
   const daliamdJpegHuffDesc &d = *r.d;
   const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments, d.total_blocks);
   const int tid = threadIdx.x, seg = r.local;
-  const int clean_len = *reinterpret_cast<const int32_t *>(d.scratch);
+  const int clean_len = *(const GlobalI32 *)d.scratch;
   LaneRec *recs = reinterpret_cast<LaneRec *>(d.scratch + lay.lanes) + (size_t)seg * kSegLanes;
   SegRec *segrec = reinterpret_cast<SegRec *>(d.scratch + lay.segs) + seg;
   if (seg > 0 && (long long)seg * kSegBytes >= clean_len) {  // segment behind the end of the stream
@@ -456,7 +462,7 @@ __global__ __launch_bounds__(kSegThreads) void PropagateKernel(const daliamdJpeg
   const daliamdJpegHuffDesc &d = descs[blockIdx.x];
   const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments, d.total_blocks);
   const int tid = threadIdx.x;
-  const int clean_len = *reinterpret_cast<const int32_t *>(d.scratch);
+  const int clean_len = *(const GlobalI32 *)d.scratch;
   const uint32_t total_bits = (uint32_t)clean_len * 8u;
   LaneRec *all_recs = reinterpret_cast<LaneRec *>(d.scratch + lay.lanes);
   SegRec *segs = reinterpret_cast<SegRec *>(d.scratch + lay.segs);
@@ -539,12 +545,18 @@ struct HalfTables {
 template <int THREADS>
 __device__ __forceinline__ void CopyHalfTables(HalfTables &T, const HuffTables *H, int first) {
   const int tid = threadIdx.x;
-  const uint4 *s = reinterpret_cast<const uint4 *>(&H->fast[first][0]);
+  const GlobalQuad *s = (const GlobalQuad *)&H->fast[first][0];
   uint4 *t = reinterpret_cast<uint4 *>(&T.fast[0][0]);
-  for (int i = tid; i < (int)(sizeof(T.fast) / 16); i += THREADS) t[i] = s[i];
-  s = reinterpret_cast<const uint4 *>(&H->l2[first][0]);
+  for (int i = tid; i < (int)(sizeof(T.fast) / 16); i += THREADS) {
+    const u32x4 v = s[i];
+    t[i] = make_uint4(v.x, v.y, v.z, v.w);
+  }
+  s = (const GlobalQuad *)&H->l2[first][0];
   t = reinterpret_cast<uint4 *>(&T.l2[0][0]);
-  for (int i = tid; i < (int)(sizeof(T.l2) / 16); i += THREADS) t[i] = s[i];
+  for (int i = tid; i < (int)(sizeof(T.l2) / 16); i += THREADS) {
+    const u32x4 v = s[i];
+    t[i] = make_uint4(v.x, v.y, v.z, v.w);
+  }
   for (int i = tid; i < 2 * 256; i += THREADS) T.vals[i >> 8][i & 255] = H->vals[first + (i >> 8)][i & 255];
   if (tid < 36) {
     T.maxcode[tid / 18][tid % 18] = H->maxcode[first + tid / 18][tid % 18];
@@ -602,7 +614,7 @@ __global__ __launch_bounds__(kDcThreads) void DcKernel(const daliamdJpegHuffDesc
   const daliamdJpegHuffDesc &d = *r.d;
   const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments, d.total_blocks);
   const int tid = threadIdx.x, seg = r.local;
-  const int clean_len = *reinterpret_cast<const int32_t *>(d.scratch);
+  const int clean_len = *(const GlobalI32 *)d.scratch;
   SegRec *segrec = reinterpret_cast<SegRec *>(d.scratch + lay.segs) + seg;
   if (seg > 0 && (long long)seg * kSegBytes >= clean_len) return;  // dc_total is already zero
   CopyHalfTables<kDcThreads>(T, reinterpret_cast<const HuffTables *>(d.scratch + lay.tables), 0);
@@ -612,10 +624,11 @@ __global__ __launch_bounds__(kDcThreads) void DcKernel(const daliamdJpegHuffDesc
   }
   __syncthreads();
   const int bpm = d.blocks_per_mcu;
-  const int total_starts = reinterpret_cast<const int32_t *>(d.scratch)[2];
+  const int total_starts = ((const GlobalI32 *)d.scratch)[2];
   const int last_ordinal = LastOrdinal(d);
-  const int block_base = segrec->block_base;
-  int nstart = segrec->nstart_total;
+  GlobalI32 *segrec_i = (GlobalI32 *)segrec;
+  const int block_base = segrec_i[kSegRecBlockBase];
+  int nstart = segrec_i[kSegRecNstart];
   nstart = nstart < lay.seg_cap ? nstart : lay.seg_cap;
   GlobalWords *words = (GlobalWords *)(d.scratch + lay.clean);
   GlobalWords *starts = (GlobalWords *)(d.scratch + lay.seg_starts) + (size_t)seg * lay.seg_cap;
@@ -666,7 +679,7 @@ __global__ __launch_bounds__(kDcThreads) void DcKernel(const daliamdJpegHuffDesc
       }
     }
   }
-  if (tid < 3) segrec->dc_total[tid] = carry[tid];
+  if (tid < 3) segrec_i[kSegRecDcTotal + tid] = carry[tid];
 }
 
 // Value pass.  A workgroup owns a run of MCUs of one image; its waves take TASKS of 64 blocks that all use the same
@@ -759,7 +772,7 @@ __global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHu
       use_rect |= d.rect[comp][2] > d.rect[comp][0] && d.rect[comp][3] > d.rect[comp][1];
     }
     G.use_rect = use_rect;
-    G.total_starts = reinterpret_cast<const int32_t *>(d.scratch)[2];
+    G.total_starts = ((const GlobalI32 *)d.scratch)[2];
     G.fused = d.plane[d.comp_of_block[0]] != nullptr;
     int n0 = 0;
     for (int k = 0; k < d.blocks_per_mcu; k++)
@@ -779,7 +792,7 @@ __global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHu
   const GlobalU32 *blk_pos = (const GlobalU32 *)(d.scratch + lay.blk_pos);
   const GlobalI32 *blk_dc = (const GlobalI32 *)(d.scratch + lay.blk_dc);
   const GlobalU16 *blk_seg = (const GlobalU16 *)(d.scratch + lay.blk_seg);
-  const SegRec *segs = reinterpret_cast<const SegRec *>(d.scratch + lay.segs);
+  const GlobalI32 *segs_i = (const GlobalI32 *)(d.scratch + lay.segs);  // SegRec fields as ints (global loads, not flat)
   const int part = lane & 7, lb = lane >> 3;
   int zi[8];  // scan index of the coefficients of column `part`
 #pragma unroll
@@ -831,7 +844,7 @@ __global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHu
     p.win = OpenWindow(words, p.pos);
     // DC level: the block's level inside its segment + the differences of all the segments before (an image is a
     // handful of segments; only a stream of many megabytes makes this loop long)
-    for (int s = 0; s < p.seg; s++) p.dc += segs[s].dc_total[p.comp];
+    for (int s = 0; s < p.seg; s++) p.dc += segs_i[s * kSegRecInts + kSegRecDcTotal + p.comp];
   };
   auto idct = [&](int it) {
     const int b = it * 8 + lb;

@@ -105,8 +105,11 @@ daliamdResult_t daliamdJpegIdctRun(daliamdStream_t stream, const daliamdJpegIdct
   if (n == 0 || num_workgroups == 0) return DALIAMD_SUCCESS;
   DALIAMD_REQUIRE(descs_dev && n > 0 && num_workgroups > 0, DALIAMD_ERROR_INVALID_ARGUMENT,
                   "daliamdJpegIdctRun: invalid argument");
-  hipLaunchKernelGGL(daliamd::JpegIdctKernel, dim3(daliamd::XcdGrid(num_workgroups)),
-                     dim3(daliamd::kIdctThreads), 0, (hipStream_t)stream, descs_dev, n, num_workgroups);
+  {
+    daliamd::KernelTimer timer("JpegIdctKernel", (hipStream_t)stream);
+    hipLaunchKernelGGL(daliamd::JpegIdctKernel, dim3(daliamd::XcdGrid(num_workgroups)),
+                       dim3(daliamd::kIdctThreads), 0, (hipStream_t)stream, descs_dev, n, num_workgroups);
+  }
   DALIAMD_HIP_CHECK(hipGetLastError());
   return DALIAMD_SUCCESS;
 }

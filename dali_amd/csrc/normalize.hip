@@ -212,14 +212,29 @@ daliamdResult_t daliamdNormalizeRun(daliamdStream_t stream, const daliamdNormali
   hipStream_t s = (hipStream_t)stream;
   const dim3 fin((unsigned)((max_bins + 255) / 256), (unsigned)n);
   if (calc_mean) {
-    hipLaunchKernelGGL(NormalizeStatsKernel<false>, dim3(stat_workgroups), dim3(kNormThreads), 0, s, descs_dev, n);
-    hipLaunchKernelGGL(NormalizeFinalizeKernel<false>, fin, dim3(256), 0, s, descs_dev, n, epsilon, scale, ddof);
+    {
+      daliamd::KernelTimer timer("NormalizeStatsKernel", s);
+      hipLaunchKernelGGL(NormalizeStatsKernel<false>, dim3(stat_workgroups), dim3(kNormThreads), 0, s, descs_dev, n);
+    }
+    {
+      daliamd::KernelTimer timer("NormalizeFinalizeKernel", s);
+      hipLaunchKernelGGL(NormalizeFinalizeKernel<false>, fin, dim3(256), 0, s, descs_dev, n, epsilon, scale, ddof);
+    }
   }
   if (calc_stddev) {
-    hipLaunchKernelGGL(NormalizeStatsKernel<true>, dim3(stat_workgroups), dim3(kNormThreads), 0, s, descs_dev, n);
-    hipLaunchKernelGGL(NormalizeFinalizeKernel<true>, fin, dim3(256), 0, s, descs_dev, n, epsilon, scale, ddof);
+    {
+      daliamd::KernelTimer timer("NormalizeStatsKernel", s);
+      hipLaunchKernelGGL(NormalizeStatsKernel<true>, dim3(stat_workgroups), dim3(kNormThreads), 0, s, descs_dev, n);
+    }
+    {
+      daliamd::KernelTimer timer("NormalizeFinalizeKernel", s);
+      hipLaunchKernelGGL(NormalizeFinalizeKernel<true>, fin, dim3(256), 0, s, descs_dev, n, epsilon, scale, ddof);
+    }
   }
-  hipLaunchKernelGGL(NormalizeApplyKernel, dim3(apply_workgroups), dim3(kNormThreads), 0, s, descs_dev, n, shift);
+  {
+    daliamd::KernelTimer timer("NormalizeApplyKernel", s);
+    hipLaunchKernelGGL(NormalizeApplyKernel, dim3(apply_workgroups), dim3(kNormThreads), 0, s, descs_dev, n, shift);
+  }
   DALIAMD_HIP_CHECK(hipGetLastError());
   return DALIAMD_SUCCESS;
 }

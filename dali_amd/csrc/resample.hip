@@ -628,9 +628,12 @@ daliamdResult_t daliamdResampleRun(daliamdStream_t stream, const daliamdResample
   if (n == 0 || num_workgroups == 0) return DALIAMD_SUCCESS;
   DALIAMD_REQUIRE(descs_dev && n > 0 && num_workgroups > 0 && lds_bytes >= 0 && lds_bytes <= daliamd::kMaxLds,
                   DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdResampleRun: invalid argument");
-  hipLaunchKernelGGL(daliamd::ResampleKernel, dim3(daliamd::XcdGrid(num_workgroups)),
-                     dim3(daliamd::kResampleThreads), lds_bytes, (hipStream_t)stream, descs_dev, n,
-                     num_workgroups);
+  {
+    daliamd::KernelTimer timer("ResampleKernel", (hipStream_t)stream);
+    hipLaunchKernelGGL(daliamd::ResampleKernel, dim3(daliamd::XcdGrid(num_workgroups)),
+                       dim3(daliamd::kResampleThreads), lds_bytes, (hipStream_t)stream, descs_dev, n,
+                       num_workgroups);
+  }
   DALIAMD_HIP_CHECK(hipGetLastError());
   return DALIAMD_SUCCESS;
 }

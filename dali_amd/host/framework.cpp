@@ -128,6 +128,7 @@ void TensorList::Resize(const std::vector<TensorShape> &shapes, DALIDataType typ
   if (!buf_ || buf_.use_count() > 1) buf_ = std::make_shared<Buffer>(dev_);  // never resize shared storage
   buf_->Reserve(std::max<size_t>(off, 256));
   deferred.reset();
+  deferred_pointwise.reset();
 }
 
 bool TensorList::is_dense() const {
@@ -142,7 +143,7 @@ void TensorList::ShareData(const TensorList &o) {
   buf_ = o.buf_; dev_ = o.dev_; type_ = o.type_; layout_ = o.layout_; shapes_ = o.shapes_;
   offsets_ = o.offsets_; pitch_ = o.pitch_; sizes_ = o.sizes_; total_ = o.total_;
   ext_ = o.ext_; ext_owner_ = o.ext_owner_;
-  deferred = o.deferred; source_info = o.source_info;
+  deferred = o.deferred; deferred_pointwise = o.deferred_pointwise; source_info = o.source_info;
 }
 
 // ------------------------------------------------------------------------------------------ ThreadPool

@@ -108,6 +108,7 @@ class Buffer {
 };
 
 struct DeferredResample;  // see ops_image.cpp: RandomResizedCrop -> CropMirrorNormalize fusion
+struct DeferredPointwise;  // see ops_augment.cpp: ColorTwist -> Erase fusion
 
 class TensorList {
  public:
@@ -142,6 +143,7 @@ class TensorList {
   void ShareData(const TensorList &other);
   // metadata only; used when an operator's work is deferred to its consumer
   std::shared_ptr<DeferredResample> deferred;
+  std::shared_ptr<DeferredPointwise> deferred_pointwise;
 
   // source info (readers): file name per sample, used in error messages like the reference's
   std::vector<std::string> source_info;

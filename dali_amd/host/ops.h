@@ -24,6 +24,14 @@ struct DeferredResample {
   int out_h = 0, out_w = 0, channels = 0;
 };
 
+// Colour-twist arguments deferred to an Erase consumer: both are the same streaming kernel (transform and / or erase per
+// descriptor), so `erase(color_twist(x))` is one launch and the intermediate image never exists.
+struct DeferredPointwise {
+  std::shared_ptr<TensorList> source;                 // the producer's input (u8 HWC on the device)
+  std::vector<daliamdPointwiseDesc> descs;            // one per sample: in / shape / transform / matrix / offset set
+};
+void TryEnablePointwiseFusion(OperatorBase *producer, OperatorBase *consumer);
+
 // The sample-index stream every reader draws from (Loader, dali/operators/reader/loader/loader.h:78-503,
 // loader.cc:78-87): sequential over the data set starting at this shard (start = size * shard_id / num_shards),
 // moving on to the next shard every epoch unless stick_to_shard, a shuffle reservoir of `initial_fill` samples,

@@ -338,8 +338,10 @@ class ToDecibelsGpu : public OperatorBase {
       descs_[i].out = static_cast<float *>(out.raw(i));
       descs_[i].size = volume(in.shape(i));
     }
-    auto *dev = static_cast<const daliamdDecibelDesc *>(uploader_.Upload(descs_.data(), n * sizeof(descs_[0]), ws.stream, ws.ring + 1));
-    KCHECK(daliamdToDecibelsRun(ws.stream, dev, n, multiplier_, reference_, cutoff_));
+    int nwg = 0;
+    KCHECK(daliamdToDecibelsSetup(descs_.data(), n, &nwg));
+    auto *dev = static_cast<daliamdDecibelDesc *>(uploader_.Upload(descs_.data(), n * sizeof(descs_[0]), ws.stream, ws.ring + 1));
+    KCHECK(daliamdToDecibelsRun(ws.stream, dev, n, nwg, multiplier_, reference_, cutoff_));
     NoteLaunch(ws, "to_decibels");
   }
 

@@ -241,11 +241,25 @@ class ColorTwistGpu : public OperatorBase {
       d.offset[0] = d.offset[1] = d.offset[2] = off;
       desc[0].shape[i] = in.shape(i);
     }
-    return true;
+    return !fused_;  // fused: no buffer, the Erase behind this operator launches the kernel for both
   }
-  void RunImpl(Workspace &ws) override { LaunchPointwise(ws, uploader_, descs_, "color_twist"); }
+  void RunImpl(Workspace &ws) override {
+    if (!fused_) {
+      LaunchPointwise(ws, uploader_, descs_, "color_twist");
+      return;
+    }
+    TensorList &out = ws.Output(0);
+    auto d = std::make_shared<DeferredPointwise>();
+    d->source = ws.inputs[0];
+    d->descs = descs_;
+    out.Resize({}, DALI_UINT8);
+    out.deferred_pointwise = d;
+    out.SetLayout("HWC");
+  }
+  void EnableFusion() { fused_ = true; }
 
  private:
+  bool fused_ = false;
   std::vector<daliamdPointwiseDesc> descs_;
   DescUploader uploader_;
 };
@@ -298,8 +312,12 @@ class EraseGpu : public OperatorBase {
     }
     DALI_ENFORCE(!axes_.empty(), "At least one axis is required");
   }
+  void ExpectFusedInput() { fused_input_ = true; }
   bool SetupImpl(std::vector<OutputDesc> &desc, const Workspace &ws) override {
-    const TensorList &in = ws.Input(0);
+    // a fused ColorTwist in front: work on ITS input and carry its transform along
+    const DeferredPointwise *def = fused_input_ ? ws.Input(0).deferred_pointwise.get() : nullptr;
+    DALI_ENFORCE(!fused_input_ || def, "internal: Erase expected the deferred arguments of the ColorTwist in front of it");
+    const TensorList &in = def ? *def->source : ws.Input(0);
     CheckU8Hwc(in, "Erase");
     int n = in.num_samples();
     auto anchors = GetPerSampleFloatVec(spec_, ws, "anchor", n), shapes = GetPerSampleFloatVec(spec_, ws, "shape", n);
@@ -310,7 +328,8 @@ class EraseGpu : public OperatorBase {
     int naxes = (int)axes_.size();
     for (int i = 0; i < n; i++) {
       auto &d = descs_[i];
-      FillPointwiseCommon(d, in, i);
+      if (def) d = def->descs[i];
+      else FillPointwiseCommon(d, in, i);
       auto a = anchors[i], s = shapes[i];
       if (a.empty() && !s.empty()) a.assign(s.size(), 0.0f);
       DALI_ENFORCE(a.size() == s.size(), "`anchor` and `shape` must have the same number of elements");
@@ -339,14 +358,23 @@ class EraseGpu : public OperatorBase {
     }
     return true;
   }
-  void RunImpl(Workspace &ws) override { LaunchPointwise(ws, uploader_, descs_, "erase"); }
+  void RunImpl(Workspace &ws) override { LaunchPointwise(ws, uploader_, descs_, fused_input_ ? "color_twist+erase" : "erase"); }
 
  private:
+  bool fused_input_ = false;
   bool norm_anchor_, norm_shape_, centered_;
   std::vector<int> axes_;
   std::vector<daliamdPointwiseDesc> descs_;
   DescUploader uploader_;
 };
 DALI_REGISTER_OPERATOR(Erase, EraseGpu, GPU);
+
+void TryEnablePointwiseFusion(OperatorBase *producer, OperatorBase *consumer) {
+  auto *twist = dynamic_cast<ColorTwistGpu *>(producer);
+  auto *erase = dynamic_cast<EraseGpu *>(consumer);
+  if (!twist || !erase) return;
+  twist->EnableFusion();
+  erase->ExpectFusedInput();
+}
 
 }  // namespace daliamd_host

@@ -158,6 +158,12 @@ void Pipeline::Build(const std::vector<std::pair<std::string, std::string>> &out
     Node &p = nodes_[n.in_node[0]];
     if (consumers[n.in_node[0]] == 1 && p.type == OpType::GPU) TryEnableFusion(p.op.get(), n.op.get());
   }
+  // ... and a ColorTwist feeding ONLY an Erase becomes part of its launch
+  for (auto &n : nodes_) {
+    if (n.spec.SchemaName() != "Erase" || n.in_node.empty() || n.type != OpType::GPU) continue;
+    Node &p = nodes_[n.in_node[0]];
+    if (consumers[n.in_node[0]] == 1 && p.type == OpType::GPU) TryEnablePointwiseFusion(p.op.get(), n.op.get());
+  }
   slot_events_.assign(ring_, nullptr);
   if (!streams_.empty())
     for (auto &e : slot_events_) KCHECK(daliamdEventCreate(&e, 0));

@@ -60,6 +60,12 @@ DALIAMD_API daliamdResult_t daliamdDeviceInfo(int device_id, char *arch_name, in
 DALIAMD_API daliamdResult_t daliamdDevicePciBusId(int device_id, char *bus_id, int len);
 /* Profiler ranges around the executor's stages and operators (reference: include/dali/core/nvtx.h:53-82); roctx is
  * resolved at first use, both calls do nothing when it is not installed. */
+/* Benchmarks: while enabled every kernel launch of this library is bracketed by a pair of timing events on the stream it
+ * is launched on.  Report: "name\tlaunches\tavg_ms\n" per kernel for the launches since the previous report (waits for
+ * them); returns the length needed, writes at most len - 1 characters + terminator.  A call without a buffer only
+ * sizes; the call that receives the text also resets the statistics. */
+DALIAMD_API void daliamdKernelTimingEnable(int on);
+DALIAMD_API int daliamdKernelTimingReport(char *buf, int len);
 DALIAMD_API void daliamdRangePush(const char *name);
 DALIAMD_API void daliamdRangePop(void);
 DALIAMD_API daliamdResult_t daliamdStreamCreate(daliamdStream_t *stream, int non_blocking);
@@ -222,8 +228,10 @@ typedef struct {
   int32_t roi_x0, roi_y0, roi_w, roi_h, out_x0, out_y0;
 } daliamdJpegColorDesc;
 
-/* kernel_mask (out): bit 0 - some sample takes the YCbCr 4:2:0 -> RGB kernel, bit 1 - some sample the general one;
- * hand it to Run, which launches only those (both walk the same grid). */
+/* kernel_mask (out): which colour kernels have samples in this table - bits 0 / 1: the RGB kernel (YCbCr 4:2:0 fast
+ * path / general), bit 2: the kernel with a BGR / YCbCr / gray conversion behind it (100 registers more, kept out of
+ * the common kernel); hand it to Run, which launches only those (both walk the same grid, a workgroup of the other
+ * kernel's sample leaves at once). */
 DALIAMD_API daliamdResult_t daliamdJpegColorSetup(daliamdJpegColorDesc *descs_host, int n, int *num_workgroups,
                                                   int *kernel_mask);
 
@@ -397,8 +405,8 @@ DALIAMD_API daliamdResult_t daliamdPointwiseRun(daliamdStream_t stream, const da
  *   mel          banded (nfilter x nbins) . (nbins x frames) product: each filter only visits its own bins (2 FMAs
  *                per spectrogram element, bound by reading the spectrogram); weights = the reference's triangular filters
  *                (dali/kernels/audio/mel_scale/mel_scale.h:79-130, mel_filter_bank_cpu.cc:77-111)
- *   decibels     mul * log10(max(min_ratio, x / ref)), ref given or the per-sample maximum (wave64 shuffle +
- *                LDS reduction) (dali/kernels/signal/decibel/decibel_calculator.h:25-52, to_decibels_cpu.cc:54-66)
+ *   decibels     mul * log10(max(min_ratio, x / ref)), ref given or the per-sample maximum (chunk maxima by wave64
+ *                shuffles, folded with an atomic max; then the element-wise pass) (dali/kernels/signal/decibel/decibel_calculator.h:25-52, to_decibels_cpu.cc:54-66)
  * Layout: "ft" (frequency-major): spectrogram [nfft/2+1][frames], mel [nfilter][frames].
  * -------------------------------------------------------------------------------------------- */
 typedef struct {
@@ -446,10 +454,13 @@ typedef struct {
   const float *in;
   float *out;
   int64_t size;
+  uint32_t max_bits;    /* device scratch: bit pattern of the sample's maximum (Setup zeroes it; upload the table per run) */
+  int32_t wg_start;     /* filled by Setup */
 } daliamdDecibelDesc;
-/* reference <= 0: use the per-sample maximum (1 when that maximum is 0) */
-DALIAMD_API daliamdResult_t daliamdToDecibelsRun(daliamdStream_t stream, const daliamdDecibelDesc *descs_dev, int n,
-                                                float multiplier, float reference, float cutoff_db);
+DALIAMD_API daliamdResult_t daliamdToDecibelsSetup(daliamdDecibelDesc *descs_host, int n, int *num_workgroups);
+/* reference <= 0: use the per-sample maximum (1 when that maximum is 0); the kernels then write descs_dev[i].max_bits */
+DALIAMD_API daliamdResult_t daliamdToDecibelsRun(daliamdStream_t stream, daliamdDecibelDesc *descs_dev, int n,
+                                                int num_workgroups, float multiplier, float reference, float cutoff_db);
 
 /* ----------------------------------------------------------------------------------------------
  * fn.normalize: out = (in - mean) * scale / stddev + shift with mean / stddev given or computed over a contiguous group
