@@ -158,6 +158,141 @@ __device__ __forceinline__ int Reflect101(int idx, int size) {
   return idx;
 }
 
+// W pass: tmp[r][x*C+c] = sum_k src[r][(x+k)*C+c] * wx[k], taps in order.  A thread owns kBlurPx consecutive pixels
+// of one channel in TWO rows: the window of source bytes slides through registers (one byte load + conversion per tap
+// and row) and the row pair makes every multiply / add a packed one; the weight is wave-uniform and comes from a
+// scalar load of the descriptor.  Taps go in chunks of kBlurPx so that every register index is a constant (a window
+// that shifts by one per tap costs a move per value and tap outside a fully unrolled loop).
+template <int C>
+__device__ __forceinline__ void BlurWPass(const daliamdGaussianBlurDesc &d, const uint8_t *src, float *tmp, int src_pitch,
+                                          int tstride, int in_rows, int tw, int ox0, int oy0, int rx, int ry,
+                                          bool interior_x) {
+  constexpr int P = kBlurPx;
+  const int tid = threadIdx.x;
+  const int groups = (tw + P - 1) / P;
+  const int row_pairs = (in_rows + 1) >> 1;
+  const int items = row_pairs * groups * C;
+  const float *__restrict__ gw = d.window_x;
+  const int K = d.size_x;
+  for (int item = tid; item < items; item += kBlurThreads) {
+    const int rp = item / (groups * C), rem_i = item - rp * (groups * C);
+    const int g = rem_i / C, c = rem_i - g * C;
+    const int x = g * P;
+    const int ra = 2 * rp, rb = min(2 * rp + 1, in_rows - 1);
+    auto row_ptr = [&](int r) {
+      const uint8_t *rowp = d.in + (size_t)Reflect101(oy0 - ry + r, d.h) * d.in_pitch + (size_t)(ox0 - rx) * C;
+      const int lead = interior_x ? (int)(reinterpret_cast<uintptr_t>(rowp) & 3) : 0;
+      return src + r * src_pitch + lead + x * C + c;
+    };
+    const uint8_t *pa = row_ptr(ra), *pb = row_ptr(rb);
+    floatx2 acc[P], v[P - 1];
+#pragma unroll
+    for (int j = 0; j < P; j++) acc[j] = floatx2{0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < P - 1; i++) v[i] = floatx2{(float)pa[i * C], (float)pb[i * C]};
+    pa += (P - 1) * C;
+    pb += (P - 1) * C;
+    int k = 0;
+    for (; k + P <= K; k += P) {
+      floatx2 n[P];
+#pragma unroll
+      for (int i = 0; i < P; i++) n[i] = floatx2{(float)pa[i * C], (float)pb[i * C]};
+      pa += P * C;
+      pb += P * C;
+#pragma unroll
+      for (int t = 0; t < P; t++) {
+        const float w = gw[k + t];
+#pragma unroll
+        for (int j = 0; j < P; j++) acc[j] += (j + t < P - 1 ? v[j + t] : n[j + t - (P - 1)]) * w;
+      }
+#pragma unroll
+      for (int i = 0; i < P - 1; i++) v[i] = n[i + 1];
+    }
+    const int rem = K - k;  // < P taps left; only the bytes they need are read (the staged row ends soon after)
+    if (rem > 0) {
+      floatx2 n[P - 1];
+#pragma unroll
+      for (int i = 0; i < P - 1; i++) n[i] = i < rem ? floatx2{(float)pa[i * C], (float)pb[i * C]} : floatx2{0.0f, 0.0f};
+#pragma unroll
+      for (int t = 0; t < P - 1; t++) {
+        if (t >= rem) break;
+        const float w = gw[k + t];
+#pragma unroll
+        for (int j = 0; j < P; j++) acc[j] += (j + t < P - 1 ? v[j + t] : n[j + t - (P - 1)]) * w;
+      }
+    }
+    float *ta = tmp + ra * tstride + x * C + c, *tb = tmp + rb * tstride + x * C + c;
+#pragma unroll
+    for (int j = 0; j < P; j++)
+      if (x + j < tw) {
+        ta[j * C] = acc[j].x;
+        tb[j * C] = acc[j].y;
+      }
+  }
+}
+
+// H pass: a thread owns two neighbouring elements of a row (the packed pair, one 8-byte LDS load per tap) in kBlurRows
+// consecutive output rows; the rows slide through registers in chunks like the taps of the W pass.  tmp has
+// kBlurRows - 1 spare rows behind the staged ones: the rows read past the end only feed outputs that are not stored.
+__device__ __forceinline__ void BlurHPass(const daliamdGaussianBlurDesc &d, const float *tmp, int tstride, int row_elems,
+                                          int th, int ox0, int oy0) {
+  constexpr int R = kBlurRows;
+  const int tid = threadIdx.x;
+  const int epairs = (row_elems + 1) >> 1;
+  const int rgroups = (th + R - 1) / R;
+  const float *__restrict__ gw = d.window_y;
+  const int K = d.size_y;
+  const int C = d.channels;
+  using GOut = uint8_t __attribute__((address_space(1)));
+  for (int item = tid; item < epairs * rgroups; item += kBlurThreads) {
+    const int yg = item / epairs, ep = item - yg * epairs;
+    const int y = yg * R, e = 2 * ep;
+    const bool two = e + 1 < row_elems;   // an odd row length leaves the last thread a single element (the pad is read)
+    const floatx2 *p = reinterpret_cast<const floatx2 *>(tmp + y * tstride + e);
+    const int step = tstride >> 1;        // row stride in pairs (tstride is even)
+    floatx2 acc[R], v[R - 1];
+#pragma unroll
+    for (int j = 0; j < R; j++) acc[j] = floatx2{0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < R - 1; i++, p += step) v[i] = *p;
+    int k = 0;
+    for (; k + R <= K; k += R) {
+      floatx2 n[R];
+#pragma unroll
+      for (int i = 0; i < R; i++, p += step) n[i] = *p;
+#pragma unroll
+      for (int t = 0; t < R; t++) {
+        const float w = gw[k + t];
+#pragma unroll
+        for (int j = 0; j < R; j++) acc[j] += w * (j + t < R - 1 ? v[j + t] : n[j + t - (R - 1)]);
+      }
+#pragma unroll
+      for (int i = 0; i < R - 1; i++) v[i] = n[i + 1];
+    }
+    const int rem = K - k;
+    if (rem > 0) {
+      floatx2 n[R - 1];
+#pragma unroll
+      for (int i = 0; i < R - 1; i++, p += step) n[i] = i < rem ? *p : floatx2{0.0f, 0.0f};
+#pragma unroll
+      for (int t = 0; t < R - 1; t++) {
+        if (t >= rem) break;
+        const float w = gw[k + t];
+#pragma unroll
+        for (int j = 0; j < R; j++) acc[j] += w * (j + t < R - 1 ? v[j + t] : n[j + t - (R - 1)]);
+      }
+    }
+    GOut *o = (GOut *)d.out + (size_t)(oy0 + y) * d.out_pitch + (size_t)ox0 * C + e;
+#pragma unroll
+    for (int j = 0; j < R; j++)
+      if (y + j < th) {
+        GOut *oj = o + (size_t)j * d.out_pitch;
+        oj[0] = (uint8_t)SatU8(acc[j].x);
+        if (two) oj[1] = (uint8_t)SatU8(acc[j].y);
+      }
+  }
+}
+
 __global__ __launch_bounds__(kBlurThreads) void GaussianBlurKernel(const daliamdGaussianBlurDesc *__restrict__ descs,
                                                                    int ndesc, int total_wg) {
   extern __shared__ __attribute__((aligned(16))) float blur_lds[];
@@ -172,14 +307,11 @@ __global__ __launch_bounds__(kBlurThreads) void GaussianBlurKernel(const daliamd
   const int tw = min(TW, d.w - ox0), th = min(TH, d.h - oy0);
   const int in_rows = th + 2 * ry, in_cols = tw + 2 * rx;
   const int row_elems = tw * C;                        // tmp row length
+  const int tstride = (TW * C + 1) & ~1;               // tmp row stride: even, so that element pairs are 8-byte aligned
   const int src_pitch = ((in_cols + kBlurPx) * C + 4 + 3) & ~3;  // staged source row pitch (bytes): + lead + blocking overrun
-  float *wx = blur_lds;                                // [size_x]
-  float *wy = wx + d.size_x;                           // [size_y]
-  float *tmp = wy + d.size_y;                          // [in_rows][row_elems]
-  uint8_t *src = reinterpret_cast<uint8_t *>(tmp + (size_t)(TH + 2 * ry) * TW * C);  // [in_rows][src_pitch]
+  float *tmp = blur_lds;                               // [in_rows + kBlurRows - 1][tstride]
+  uint8_t *src = reinterpret_cast<uint8_t *>(tmp + (size_t)(TH + 2 * ry + kBlurRows - 1) * tstride);  // [in_rows][src_pitch]
   const int tid = threadIdx.x;
-  for (int i = tid; i < d.size_x; i += kBlurThreads) wx[i] = d.window_x[i];
-  for (int i = tid; i < d.size_y; i += kBlurThreads) wy[i] = d.window_y[i];
   // ---- stage the halo-extended source tile; reflect-101 indices are resolved here.  Interior tiles (no reflection
   // in x) copy whole aligned dwords: LDS byte i of a row <-> global byte (row start rounded down to 4) + i, the
   // passes below skip the `lead` bytes in front.  Edge tiles take the byte-wise path. ----
@@ -202,92 +334,14 @@ __global__ __launch_bounds__(kBlurThreads) void GaussianBlurKernel(const daliamd
     }
   }
   __syncthreads();
-  // ---- W pass: tmp[r][x*C+c] = sum_k src[r][(x+k)*C+c] * wx[k], taps in order.  A thread owns kBlurPx consecutive
-  // pixels of one channel in TWO rows: the window of kBlurPx + size_x - 1 source bytes slides through registers (one
-  // byte load + conversion per tap and row), and the two rows make every multiply / add a packed one (the row pair is
-  // the vector; the weight is wave-uniform and comes from a scalar load of the descriptor) ----
-  {
-    const int groups = (tw + kBlurPx - 1) / kBlurPx;
-    const int row_pairs = (in_rows + 1) >> 1;
-    const int items = row_pairs * groups * C;
-    const float *__restrict__ gwx = d.window_x;
-    for (int item = tid; item < items; item += kBlurThreads) {
-      const int rp = item / (groups * C), rem = item - rp * (groups * C);
-      const int g = rem / C, c = rem - g * C;
-      const int x = g * kBlurPx;
-      const int ra = 2 * rp, rb = min(2 * rp + 1, in_rows - 1);
-      auto row_ptr = [&](int r) {
-        const uint8_t *rowp = d.in + (size_t)Reflect101(oy0 - ry + r, d.h) * d.in_pitch + (size_t)(ox0 - rx) * C;
-        const int lead = interior_x ? (int)(reinterpret_cast<uintptr_t>(rowp) & 3) : 0;
-        return src + r * src_pitch + lead + x * C + c;
-      };
-      const uint8_t *pa = row_ptr(ra), *pb = row_ptr(rb);
-      floatx2 acc[kBlurPx], v[kBlurPx];
-#pragma unroll
-      for (int j = 0; j < kBlurPx; j++) acc[j] = floatx2{0.0f, 0.0f};
-#pragma unroll
-      for (int j = 0; j < kBlurPx - 1; j++) v[j] = floatx2{(float)pa[j * C], (float)pb[j * C]};
-#pragma unroll 8
-      for (int k = 0; k < d.size_x; k++) {
-        // (x + kBlurPx - 1 + k): in range for the last group too, the staged row is padded
-        v[kBlurPx - 1] = floatx2{(float)pa[(k + kBlurPx - 1) * C], (float)pb[(k + kBlurPx - 1) * C]};
-        const float w = gwx[k];
-#pragma unroll
-        for (int j = 0; j < kBlurPx; j++) acc[j] += v[j] * w;
-#pragma unroll
-        for (int j = 0; j < kBlurPx - 1; j++) v[j] = v[j + 1];
-      }
-      float *ta = tmp + ra * row_elems + x * C + c, *tb = tmp + rb * row_elems + x * C + c;
-#pragma unroll
-      for (int j = 0; j < kBlurPx; j++)
-        if (x + j < tw) {
-          ta[j * C] = acc[j].x;
-          tb[j * C] = acc[j].y;
-        }
-    }
+  switch (C) {
+    case 1: BlurWPass<1>(d, src, tmp, src_pitch, tstride, in_rows, tw, ox0, oy0, rx, ry, interior_x); break;
+    case 2: BlurWPass<2>(d, src, tmp, src_pitch, tstride, in_rows, tw, ox0, oy0, rx, ry, interior_x); break;
+    case 3: BlurWPass<3>(d, src, tmp, src_pitch, tstride, in_rows, tw, ox0, oy0, rx, ry, interior_x); break;
+    default: BlurWPass<4>(d, src, tmp, src_pitch, tstride, in_rows, tw, ox0, oy0, rx, ry, interior_x); break;
   }
   __syncthreads();
-  // ---- H pass: a thread owns two neighbouring elements of a row (the packed pair, one 8-byte LDS load per tap) in
-  // kBlurRows consecutive output rows; the rows slide through registers, taps in order ----
-  {
-    const int epairs = (row_elems + 1) >> 1;
-    const int rgroups = (th + kBlurRows - 1) / kBlurRows;
-    const float *__restrict__ gwy = d.window_y;
-    const int last = in_rows - 1;
-    using GOut = uint8_t __attribute__((address_space(1)));
-    for (int item = tid; item < epairs * rgroups; item += kBlurThreads) {
-      const int yg = item / epairs, ep = item - yg * epairs;
-      const int y = yg * kBlurRows, e = 2 * ep;
-      const bool two = e + 1 < row_elems;   // an odd row length leaves the last thread a single element
-      const float *p = tmp + e;
-      auto load = [&](int r) {
-        const float *q = p + min(r, last) * row_elems;  // rows beyond the staged area only feed outputs that are not stored
-        return two ? floatx2{q[0], q[1]} : floatx2{q[0], 0.0f};
-      };
-      floatx2 acc[kBlurRows], v[kBlurRows];
-#pragma unroll
-      for (int j = 0; j < kBlurRows; j++) acc[j] = floatx2{0.0f, 0.0f};
-#pragma unroll
-      for (int j = 0; j < kBlurRows - 1; j++) v[j] = load(y + j);
-#pragma unroll 8
-      for (int k = 0; k < d.size_y; k++) {
-        v[kBlurRows - 1] = load(y + k + kBlurRows - 1);
-        const float w = gwy[k];
-#pragma unroll
-        for (int j = 0; j < kBlurRows; j++) acc[j] += w * v[j];
-#pragma unroll
-        for (int j = 0; j < kBlurRows - 1; j++) v[j] = v[j + 1];
-      }
-      GOut *o = (GOut *)d.out + (size_t)(oy0 + y) * d.out_pitch + (size_t)ox0 * C + e;
-#pragma unroll
-      for (int j = 0; j < kBlurRows; j++)
-        if (y + j < th) {
-          GOut *oj = o + (size_t)j * d.out_pitch;
-          oj[0] = (uint8_t)SatU8(acc[j].x);
-          if (two) oj[1] = (uint8_t)SatU8(acc[j].y);
-        }
-    }
-  }
+  BlurHPass(d, tmp, tstride, row_elems, th, ox0, oy0);
 }
 
 // =============================================================================================
@@ -493,7 +547,8 @@ daliamdResult_t daliamdGaussianBlurSetup(daliamdGaussianBlurDesc *descs, int n, 
     auto need = [&](int tw_, int th_) {
       size_t rows = th_ + d.size_y - 1, cols = tw_ + d.size_x - 1;
       size_t src_pitch = ((cols + kBlurPx) * d.channels + 4 + 3) & ~(size_t)3;  // + alignment lead + register-blocking overrun
-      return (size_t)(d.size_x + d.size_y) * 4 + rows * tw_ * d.channels * 4 + rows * src_pitch + 16;
+      size_t tstride = ((size_t)tw_ * d.channels + 1) & ~(size_t)1;
+      return (rows + kBlurRows - 1) * tstride * 4 + rows * src_pitch + 16;
     };
     while (need(tw, th) > (size_t)kBlurMaxLds && (tw > 8 || th > 1)) {
       if (th > 1 && (th + d.size_y >= tw + d.size_x || tw <= 8)) th >>= 1; else tw >>= 1;
