@@ -89,7 +89,8 @@ class ResampleDesc(C.Structure):
                 ("tiles_y", C.c_int32), ("wg_start", C.c_int32), ("out_dtype", C.c_int32),
                 ("out_layout", C.c_int32), ("normalize", C.c_int32), ("mirror", C.c_int32),
                 ("mean", C.c_float * 4), ("inv_std", C.c_float * 4), ("even_mask", C.c_uint32 * 8),
-                ("lds_bytes", C.c_int32), ("staged", C.c_int32)]
+                ("lds_bytes", C.c_int32), ("staged", C.c_int32), ("table_off", C.c_int64),
+                ("tab_start", C.c_int32), ("use_lut", C.c_int32)]
 
 
 class CmnDesc(C.Structure):

@@ -563,6 +563,20 @@ def decode_jpeg_batch(encoded, device="cuda", num_threads=None, out_pitch_align=
 # =====================================================================================
 # Resample (+ fused CropMirrorNormalize)
 # =====================================================================================
+_workspaces = {}
+
+
+def _stream_workspace(dev, stream_ptr, nbytes):
+    """Device scratch of a launch sequence, one buffer per (device, stream): kernels of one stream are ordered, so the
+    next call's writes come after this call's reads."""
+    key = (str(dev), int(getattr(stream_ptr, "value", stream_ptr) or 0))
+    t = _workspaces.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(int(nbytes * 3 // 2), 1 << 20), dtype=torch.uint8, device=dev)
+        _workspaces[key] = t
+    return t
+
+
 def _fill4(dst, src):
     for i in range(4):
         dst[i] = float(src[i]) if i < len(src) else (float(src[-1]) if len(src) == 1 else 0.0)
@@ -697,14 +711,16 @@ def resample_batch(images, out_size, rois=None, interp_min=capi.INTERP_LINEAR, i
             _fill4(i4, inv_std)
             a["mean"], a["inv_std"] = m4, i4
     descs = np.zeros(max(n, 1), _dtype(capi.ResampleDesc))
-    nwg, lds = C.c_int(0), C.c_int(0)
+    nwg, lds, ws_bytes, entries = C.c_int(0), C.c_int(0), C.c_size_t(0), C.c_int(0)
     capi.check(lib.daliamdResampleSetup(args.ctypes.data_as(C.c_void_p), n, descs.ctypes.data_as(C.c_void_p),
-                                        C.byref(nwg), C.byref(lds)))
+                                        C.byref(nwg), C.byref(lds), C.byref(ws_bytes), C.byref(entries)))
     descs_dev = _uploader.upload(descs, dev)
+    stream_ptr = current_stream_ptr(dev)
+    ws = _stream_workspace(dev, stream_ptr, ws_bytes.value)
     if start_event is not None:
         start_event.record()
-    capi.check(lib.daliamdResampleRun(current_stream_ptr(dev), C.c_void_p(descs_dev.data_ptr()), n, nwg.value,
-                                      lds.value))
+    capi.check(lib.daliamdResampleRun(stream_ptr, C.c_void_p(descs_dev.data_ptr()), n, nwg.value, lds.value,
+                                      C.c_void_p(ws.data_ptr()), C.c_size_t(ws_bytes.value), entries.value))
     if return_descs:
         return out, descs, nwg.value, lds.value
     return out

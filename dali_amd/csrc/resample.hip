@@ -63,6 +63,9 @@ __host__ __device__ inline int FirstTap(int o, float scale, float start, float *
   return sx0;
 }
 
+#define SEL4(c, a0, a1, a2, a3) ((c) == 0 ? (a0) : (c) == 1 ? (a1) : (c) == 2 ? (a2) : (a3))
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+
 // ---------------------------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------------------------
@@ -117,6 +120,7 @@ struct Epilogue {
   void *out;
   int out_h, out_w, channels;
   int dtype, layout, normalize, mirror;
+  const uint16_t *lut;  // LDS: [channels][256] fp16 results of the normalisation, or null
 
   // element offset of (y, x, channel 0) and the per-channel stride
   __device__ __forceinline__ size_t Base(int y, int x, size_t *cstride) const {
@@ -126,7 +130,11 @@ struct Epilogue {
     return ((size_t)y * out_w + xo) * channels;
   }
   // mean / inv_std are passed by value: a runtime-indexed member array would live in scratch memory
-  __device__ __forceinline__ void Store(size_t o, uint32_t v, float mean, float inv_std) const {
+  __device__ __forceinline__ void Store(size_t o, int c, uint32_t v, float mean, float inv_std) const {
+    if (lut) {
+      ((uint16_t __attribute__((address_space(1))) *)out)[o] = lut[c * 256 + v];
+      return;
+    }
     float f = (float)v;
     if (dtype == DALIAMD_UINT8) {
       if (normalize) f = RoundU8((f - mean) * inv_std, false);
@@ -141,8 +149,74 @@ struct Epilogue {
 };
 
 // ---------------------------------------------------------------------------------------------
-// kernel
+// kernels
 // ---------------------------------------------------------------------------------------------
+// Per-sample tables (workspace words at desc.table_off), filled by ResampleTablesKernel once per sample instead of
+// once per tile:   xi[out_w] | xc[out_w][sup_x] | yi[out_h] | yc[out_h][sup_y] | lut: u16 [channels][256]
+// xi / yi = first tap of each output column / row, xc / yc its normalised coefficients (InitializeResamplingFilter);
+// lut[c][v] = fp16((v - mean[c]) * inv_std[c]), ties away: the fused epilogue of an fp16 output is one look-up, the
+// rounded u8 value being the index.
+struct TableLayout { int xi, xc, yi, yc, lut, words; };
+__host__ __device__ inline TableLayout MakeTableLayout(const daliamdResampleDesc &d) {
+  TableLayout l;
+  l.xi = 0;
+  l.xc = l.xi + d.out_w;
+  l.yi = l.xc + d.out_w * d.support[0];
+  l.yc = l.yi + d.out_h;
+  l.lut = l.yc + d.out_h * d.support[1];
+  l.words = l.lut + (d.use_lut ? d.channels * 128 : 0);
+  return l;
+}
+__host__ __device__ inline int TableEntries(const daliamdResampleDesc &d) {
+  return d.out_w + d.out_h + (d.use_lut ? d.channels * 256 : 0);
+}
+
+using GU32 = uint32_t __attribute__((address_space(1)));
+using GI32 = int32_t __attribute__((address_space(1)));
+using GF32 = float __attribute__((address_space(1)));
+using GU16 = uint16_t __attribute__((address_space(1)));
+using GBytes = const uint8_t __attribute__((address_space(1)));
+
+constexpr int kTableThreads = 256;
+__global__ __launch_bounds__(kTableThreads) void ResampleTablesKernel(const daliamdResampleDesc *__restrict__ descs, int ndesc,
+                                                                      int total_entries, uint8_t *__restrict__ workspace) {
+  const int e = blockIdx.x * kTableThreads + threadIdx.x;
+  if (e >= total_entries) return;
+  int lo = 0, hi = ndesc - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].tab_start <= e) lo = mid; else hi = mid - 1;
+  }
+  const daliamdResampleDesc &d = descs[lo];
+  const TableLayout L = MakeTableLayout(d);
+  GU32 *tab = (GU32 *)(workspace + d.table_off);
+  int local = e - d.tab_start;
+  if (local >= d.out_w + d.out_h) {  // epilogue look-up entry
+    const int q = local - d.out_w - d.out_h, c = q >> 8, v = q & 255;
+    const float f = ((float)v - SEL4(c, d.mean[0], d.mean[1], d.mean[2], d.mean[3])) *
+                    SEL4(c, d.inv_std[0], d.inv_std[1], d.inv_std[2], d.inv_std[3]);
+    ((GU16 *)(tab + L.lut))[q] = Float2HalfAway(f);
+    return;
+  }
+  const int axis = local < d.out_w ? 0 : 1;
+  const int o = axis ? local - d.out_w : local;
+  const int sup = d.support[axis];
+  GF32 *co = (GF32 *)(tab + (axis ? L.yc : L.xc)) + (size_t)o * sup;
+  const float start = FilterStart(d.origin[axis], d.scale[axis], d.fanchor[axis]);
+  float f0;
+  const int s0 = FirstTap(o, d.scale[axis], start, &f0);
+  float sum = 0;
+  for (int k = 0; k < sup; k++) {
+    float c = TriEval((f0 + k) * d.fscale[axis]);
+    co[k] = c;
+    sum += c;
+  }
+  if (sum) {
+    for (int k = 0; k < sup; k++) co[k] /= sum;
+  }
+  ((GI32 *)tab)[(axis ? L.yi : L.xi) + o] = s0;
+}
+
 // Descriptor lookup: tile counts are usually identical across the batch, so first try the uniform
 // guess (two independent loads); fall back to the binary search.
 __device__ __forceinline__ int FindResampleDesc(const daliamdResampleDesc *descs, int n, int wg, int total_wg) {
@@ -156,10 +230,9 @@ __device__ __forceinline__ void MinMax4(int a, int b, int c, int d, int *lo, int
   *hi = max(max(a, b), max(c, d));
 }
 
-#define SEL4(c, a0, a1, a2, a3) ((c) == 0 ? (a0) : (c) == 1 ? (a1) : (c) == 2 ? (a2) : (a3))
-
 __global__ __launch_bounds__(kResampleThreads) void ResampleKernel(const daliamdResampleDesc *__restrict__ descs,
-                                                                   int ndesc, int total_wg) {
+                                                                   int ndesc, int total_wg,
+                                                                   const uint8_t *__restrict__ workspace) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   int wg = XcdRemap(blockIdx.x, total_wg);
   if (wg < 0) return;
@@ -167,50 +240,34 @@ __global__ __launch_bounds__(kResampleThreads) void ResampleKernel(const daliamd
   const int tid = threadIdx.x;
   const int C = d.channels;
   const int TH = d.tile_h, TW = d.tile_w;       // powers of two
-  const int tw_log2 = 31 - __clz(TW);
+  const int tw_log2 = 31 - __clz(TW), th_log2 = 31 - __clz(TH);
   int t = wg - d.wg_start;
   int ty = t / d.tiles_x, tx = t - ty * d.tiles_x;
   const int oy0 = ty * TH, ox0 = tx * TW;
   const int th = min(TH, d.out_h - oy0), tw = min(TW, d.out_w - ox0);
   const int sup_x = d.support[0], sup_y = d.support[1];
+  const bool use_lut = d.use_lut != 0;
 
-  // LDS carve-up: coefficient tables, first-tap indices, per-tap source offsets, staged window, tmp
-  float *cy = lds;                                        // [TH][sup_y]
-  float *cx = cy + TH * sup_y;                            // [TW][sup_x]
-  int *yt = reinterpret_cast<int *>(cx + TW * sup_x);     // [TH][sup_y] per-tap row offset
-  int *xt = yt + TH * sup_y;                              // [TW][sup_x] per-tap column offset (elements)
-  int *iy = xt + TW * sup_x;                              // [TH]
-  int *ix = iy + TH;                                      // [TW]
-  // (byte offset from the LDS base, not a round trip through an integer: that would make every access behind it a
-  // generic one - flat loads that wait on both memory counters)
-  uint8_t *stage = reinterpret_cast<uint8_t *>(lds) +
-                   ((((size_t)2 * (TH * sup_y + TW * sup_x) + TH + TW) * sizeof(float) + 15) & ~(size_t)15);
+  // LDS carve-up: coefficients and per-tap source offsets (tap-major: entry k * TILE + i), the epilogue look-up
+  // table, the staged window, tmp.  Byte offsets from the LDS base, never a round trip through an integer: that
+  // would make every access behind it a generic one - flat loads that wait on both memory counters.
+  float *cy = lds;                                        // [sup_y][TH]
+  float *cx = cy + TH * sup_y;                            // [sup_x][TW]
+  int *yt = reinterpret_cast<int *>(cx + TW * sup_x);     // [sup_y][TH] per-tap row offset
+  int *xt = yt + TH * sup_y;                              // [sup_x][TW] per-tap column offset (elements)
+  uint16_t *lut = reinterpret_cast<uint16_t *>(xt + TW * sup_x);  // [C][256]
+  const size_t table_words = (size_t)2 * (TH * sup_y + TW * sup_x) + (use_lut ? C * 128 : 0);
+  uint8_t *stage = reinterpret_cast<uint8_t *>(lds) + ((table_words * sizeof(float) + 15) & ~(size_t)15);
 
-  // ---- index / coefficient tables (InitializeResamplingFilter) ----
-  for (int i = tid; i < th + tw; i += kResampleThreads) {
-    int axis = i < th ? 1 : 0;
-    int o = axis ? oy0 + i : ox0 + (i - th);
-    int sup = axis ? sup_y : sup_x;
-    float *co = axis ? cy + i * sup_y : cx + (i - th) * sup_x;
-    float start = FilterStart(d.origin[axis], d.scale[axis], d.fanchor[axis]);
-    float f0;
-    int s0 = FirstTap(o, d.scale[axis], start, &f0);
-    float sum = 0;
-    for (int k = 0; k < sup; k++) {
-      float c = TriEval((f0 + k) * d.fscale[axis]);
-      co[k] = c;
-      sum += c;
-    }
-    if (sum) {
-      for (int k = 0; k < sup; k++) co[k] /= sum;
-    }
-    if (axis) iy[i] = s0; else ix[i - th] = s0;
-  }
-  __syncthreads();
+  const TableLayout L = MakeTableLayout(d);
+  GU32 *tab = (GU32 *)(workspace + d.table_off);
+  GI32 *xi = (GI32 *)tab + L.xi, *yi = (GI32 *)tab + L.yi;
+  GF32 *xc = (GF32 *)(tab + L.xc), *yc = (GF32 *)(tab + L.yc);
 
   Epilogue ep;
   ep.out = d.out; ep.out_h = d.out_h; ep.out_w = d.out_w; ep.channels = C;
   ep.dtype = d.out_dtype; ep.layout = d.out_layout; ep.normalize = d.normalize; ep.mirror = d.mirror;
+  ep.lut = use_lut ? lut : nullptr;
   const float mean0 = d.mean[0], mean1 = d.mean[1], mean2 = d.mean[2], mean3 = d.mean[3];
   const float inv0 = d.inv_std[0], inv1 = d.inv_std[1], inv2 = d.inv_std[2], inv3 = d.inv_std[3];
 
@@ -223,10 +280,13 @@ __global__ __launch_bounds__(kResampleThreads) void ResampleKernel(const daliamd
   // first-pass axis: taps clamped to the whole image; second-pass axis: to the ROI window [lo, lo+ext)
   const int ex = d.ext[0] - 1, ey = d.ext[1] - 1;
   int x_lo, x_hi, y_lo, y_hi;
-  MinMax4(ClampI(ix[0], 0, ex), ClampI(ix[0] + sup_x - 1, 0, ex), ClampI(ix[tw - 1], 0, ex),
-          ClampI(ix[tw - 1] + sup_x - 1, 0, ex), &x_lo, &x_hi);
-  MinMax4(ClampI(iy[0], 0, ey), ClampI(iy[0] + sup_y - 1, 0, ey), ClampI(iy[th - 1], 0, ey),
-          ClampI(iy[th - 1] + sup_y - 1, 0, ey), &y_lo, &y_hi);
+  {
+    const int ix_a = xi[ox0], ix_b = xi[ox0 + tw - 1], iy_a = yi[oy0], iy_b = yi[oy0 + th - 1];
+    MinMax4(ClampI(ix_a, 0, ex), ClampI(ix_a + sup_x - 1, 0, ex), ClampI(ix_b, 0, ex), ClampI(ix_b + sup_x - 1, 0, ex),
+            &x_lo, &x_hi);
+    MinMax4(ClampI(iy_a, 0, ey), ClampI(iy_a + sup_y - 1, 0, ey), ClampI(iy_b, 0, ey), ClampI(iy_b + sup_y - 1, 0, ey),
+            &y_lo, &y_hi);
+  }
   const int ncols = x_hi - x_lo + 1, nrows = y_hi - y_lo + 1;
   const int NB = ncols * C;                              // bytes per window row
   const int LP = (NB + 15 + 15) & ~15;                   // LDS row pitch (room for the alignment shift)
@@ -235,22 +295,33 @@ __global__ __launch_bounds__(kResampleThreads) void ResampleKernel(const daliamd
   float *tmp = reinterpret_cast<float *>(stage + (staged ? (size_t)nrows * LP : 0));
   const int rowlen = tw * C;                             // H-first tmp row length
 
-  // ---- per-tap offset tables ----
+  // ---- coefficient / per-tap offset tables of the tile, from the per-sample tables ----
   //   xt: element offset of tap k of column x inside a window row
   //   yt: V-first: byte offset of element 0 of the tapped row inside `stage` (or `win` when not staged)
   //       H-first: element offset of the tapped row inside tmp
-  for (int i = tid; i < tw * sup_x; i += kResampleThreads) {
-    int x = i / sup_x, k = i - x * sup_x;
-    xt[i] = (ClampI(ix[x] + k, 0, ex) - x_lo) * C;
+  for (int i = tid; i < TW * sup_x; i += kResampleThreads) {
+    const int x = i & (TW - 1), k = i >> tw_log2;
+    if (x < tw) {
+      cx[i] = xc[(size_t)(ox0 + x) * sup_x + k];
+      xt[i] = (ClampI(xi[ox0 + x] + k, 0, ex) - x_lo) * C;
+    }
   }
-  for (int i = tid; i < th * sup_y; i += kResampleThreads) {
-    int y = i / sup_y, k = i - y * sup_y;
-    int r = ClampI(iy[y] + k, 0, ey) - y_lo;
-    int v;
-    if (!vfirst) v = r * rowlen;
-    else if (staged) v = r * LP + (int)((win_addr + (size_t)r * pitch) & 15);
-    else v = r * pitch;
-    yt[i] = v;
+  for (int i = tid; i < TH * sup_y; i += kResampleThreads) {
+    const int y = i & (TH - 1), k = i >> th_log2;
+    if (y < th) {
+      cy[i] = yc[(size_t)(oy0 + y) * sup_y + k];
+      const int r = ClampI(yi[oy0 + y] + k, 0, ey) - y_lo;
+      int v;
+      if (!vfirst) v = r * rowlen;
+      else if (staged) v = r * LP + (int)((win_addr + (size_t)r * pitch) & 15);
+      else v = r * pitch;
+      yt[i] = v;
+    }
+  }
+  if (use_lut) {
+    GU32 *src = tab + L.lut;
+    uint32_t *dst = reinterpret_cast<uint32_t *>(lut);
+    for (int i = tid; i < C * 128; i += kResampleThreads) dst[i] = src[i];
   }
 
   // ---- stage the window in LDS with 16-byte coalesced loads (each row keeps its own alignment shift) ----
@@ -267,14 +338,14 @@ __global__ __launch_bounds__(kResampleThreads) void ResampleKernel(const daliamd
         uint4 v;
         if (g >= buf_lo && g + 16 <= buf_hi) {
           typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-          const u32x4_t t = *(const u32x4_t __attribute__((address_space(1))) *)g;  // global, not generic: the loads
-          v = make_uint4(t.x, t.y, t.z, t.w);                                       // of a row may overlap the LDS stores
+          const u32x4_t t4 = *(const u32x4_t __attribute__((address_space(1))) *)g;  // global, not generic: the loads
+          v = make_uint4(t4.x, t4.y, t4.z, t4.w);                                     // of a row may overlap the LDS stores
         } else {  // chunk straddles the buffer boundary: assemble from the in-bounds bytes
           uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
 #pragma unroll
           for (int b = 0; b < 16; b++) {
             uintptr_t a = g + b;
-            uint32_t byte = (a >= buf_lo && a < buf_hi) ? (uint32_t)(*(const uint8_t __attribute__((address_space(1))) *)a) : 0u;
+            uint32_t byte = (a >= buf_lo && a < buf_hi) ? (uint32_t)(*(GBytes *)a) : 0u;
             byte <<= 8 * (b & 3);
             if (b < 4) w0 |= byte; else if (b < 8) w1 |= byte; else if (b < 12) w2 |= byte; else w3 |= byte;
           }
@@ -285,51 +356,50 @@ __global__ __launch_bounds__(kResampleThreads) void ResampleKernel(const daliamd
     }
   }
   __syncthreads();
-  using GBytes = const uint8_t __attribute__((address_space(1)));
   GBytes *gwin = (GBytes *)win;  // source rows when the window is not staged
 
   if (vfirst) {
     // ================= vertical pass (window rows -> tmp[th][NB]), then horizontal =================
     if (staged && (pitch & 3) == 0) {
-      // every row has the same shift modulo 4: produce 4 consecutive elements from one LDS dword per tap
+      // every row has the same shift modulo 4: produce 4 consecutive elements from one LDS dword per tap; the
+      // (row, dword) items are spread evenly over the threads
       const int s4 = (int)(win_addr & 3);
       const int ndw = (NB + s4 + 3) >> 2;
-      for (int y = tid >> 6; y < th; y += kResampleThreads / 64) {
-        const float *co = cy + y * sup_y;
-        const int *ro = yt + y * sup_y;
+      const float inv_ndw = 1.0f / (float)ndw;
+      for (int item = tid; item < th * ndw; item += kResampleThreads) {
+        const int y = (int)(((float)item + 0.5f) * inv_ndw);   // exact: item < 2^16
+        const int j = item - y * ndw;
+        const float *co = cy + y;
+        const int *ro = yt + y;
+        floatx2 a01 = {0.0f, 0.0f}, a23 = {0.0f, 0.0f};
+        const uint8_t *col = stage + 4 * j - s4;
+        for (int k = 0; k < sup_y; k++) {
+          const uint32_t v = *reinterpret_cast<const uint32_t *>(col + ro[k * TH]);
+          const float w = co[k * TH];
+          a01 += floatx2{(float)(v & 255), (float)((v >> 8) & 255)} * w;
+          a23 += floatx2{(float)((v >> 16) & 255), (float)(v >> 24)} * w;
+        }
         float *trow = tmp + y * NB;
-        for (int j = tid & 63; j < ndw; j += 64) {
-          float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-          const uint8_t *col = stage + 4 * j - s4;
-          for (int k = 0; k < sup_y; k++) {
-            uint32_t v = *reinterpret_cast<const uint32_t *>(col + ro[k]);
-            float w = co[k];
-            a0 += (float)(v & 255) * w;
-            a1 += (float)((v >> 8) & 255) * w;
-            a2 += (float)((v >> 16) & 255) * w;
-            a3 += (float)(v >> 24) * w;
-          }
-          int e = 4 * j - s4;
-          if (e >= 0 && e + 3 < NB) {
-            trow[e] = a0; trow[e + 1] = a1; trow[e + 2] = a2; trow[e + 3] = a3;
-          } else {
-            if (e >= 0 && e < NB) trow[e] = a0;
-            if (e + 1 >= 0 && e + 1 < NB) trow[e + 1] = a1;
-            if (e + 2 >= 0 && e + 2 < NB) trow[e + 2] = a2;
-            if (e + 3 >= 0 && e + 3 < NB) trow[e + 3] = a3;
-          }
+        const int e = 4 * j - s4;
+        if (e >= 0 && e + 3 < NB) {
+          trow[e] = a01.x; trow[e + 1] = a01.y; trow[e + 2] = a23.x; trow[e + 3] = a23.y;
+        } else {
+          if (e >= 0 && e < NB) trow[e] = a01.x;
+          if (e + 1 >= 0 && e + 1 < NB) trow[e + 1] = a01.y;
+          if (e + 2 >= 0 && e + 2 < NB) trow[e + 2] = a23.x;
+          if (e + 3 >= 0 && e + 3 < NB) trow[e + 3] = a23.y;
         }
       }
     } else {
       for (int y = tid >> 6; y < th; y += kResampleThreads / 64) {
-        const float *co = cy + y * sup_y;
-        const int *ro = yt + y * sup_y;
+        const float *co = cy + y;
+        const int *ro = yt + y;
         for (int e = tid & 63; e < NB; e += 64) {
           float a = 0;
           if (staged) {
-            for (int k = 0; k < sup_y; k++) a += (float)stage[ro[k] + e] * co[k];
+            for (int k = 0; k < sup_y; k++) a += (float)stage[ro[k * TH] + e] * co[k * TH];
           } else {
-            for (int k = 0; k < sup_y; k++) a += (float)gwin[ro[k] + e] * co[k];
+            for (int k = 0; k < sup_y; k++) a += (float)gwin[ro[k * TH] + e] * co[k * TH];
           }
           tmp[y * NB + e] = a;
         }
@@ -338,41 +408,41 @@ __global__ __launch_bounds__(kResampleThreads) void ResampleKernel(const daliamd
     __syncthreads();
     const int x = tid & (TW - 1);
     if (x < tw) {
-      const float *co = cx + x * sup_x;
-      const int *xo = xt + x * sup_x;
+      const float *co = cx + x;
+      const int *xo = xt + x;
       const int gx = ox0 + x;
       const bool even = (d.even_mask[(gx >> 5) & 7] >> (gx & 31)) & 1;
       for (int y = tid >> tw_log2; y < th; y += kResampleThreads >> tw_log2) {
         const float *trow = tmp + y * NB;
         float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
         for (int k = 0; k < sup_x; k++) {
-          float w = co[k];
-          const float *p = trow + xo[k];
+          float w = co[k * TW];
+          const float *p = trow + xo[k * TW];
           a0 += w * p[0];
           if (C > 1) a1 += w * p[1];
           if (C > 2) a2 += w * p[2];
           if (C > 3) a3 += w * p[3];
         }
         size_t cs, o = ep.Base(oy0 + y, gx, &cs);
-        ep.Store(o, RoundU8(a0, even), mean0, inv0);
-        if (C > 1) ep.Store(o + cs, RoundU8(a1, even), mean1, inv1);
-        if (C > 2) ep.Store(o + 2 * cs, RoundU8(a2, even), mean2, inv2);
-        if (C > 3) ep.Store(o + 3 * cs, RoundU8(a3, even), mean3, inv3);
+        ep.Store(o, 0, RoundU8(a0, even), mean0, inv0);
+        if (C > 1) ep.Store(o + cs, 1, RoundU8(a1, even), mean1, inv1);
+        if (C > 2) ep.Store(o + 2 * cs, 2, RoundU8(a2, even), mean2, inv2);
+        if (C > 3) ep.Store(o + 3 * cs, 3, RoundU8(a3, even), mean3, inv3);
       }
     }
   } else {
     // ================= horizontal pass (window rows -> tmp[nrows][tw*C]), then vertical =================
     const int x = tid & (TW - 1);
     if (x < tw) {
-      const float *co = cx + x * sup_x;
-      const int *xo = xt + x * sup_x;
+      const float *co = cx + x;
+      const int *xo = xt + x;
       for (int r = tid >> tw_log2; r < nrows; r += kResampleThreads >> tw_log2) {
         float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
         if (staged) {
           const uint8_t *srow = stage + r * LP + (int)((win_addr + (size_t)r * pitch) & 15);
           for (int k = 0; k < sup_x; k++) {
-            float w = co[k];
-            const uint8_t *p = srow + xo[k];
+            float w = co[k * TW];
+            const uint8_t *p = srow + xo[k * TW];
             a0 += w * (float)p[0];
             if (C > 1) a1 += w * (float)p[1];
             if (C > 2) a2 += w * (float)p[2];
@@ -381,8 +451,8 @@ __global__ __launch_bounds__(kResampleThreads) void ResampleKernel(const daliamd
         } else {
           GBytes *srow = gwin + (size_t)r * pitch;
           for (int k = 0; k < sup_x; k++) {
-            float w = co[k];
-            GBytes *p = srow + xo[k];
+            float w = co[k * TW];
+            GBytes *p = srow + xo[k * TW];
             a0 += w * (float)p[0];
             if (C > 1) a1 += w * (float)p[1];
             if (C > 2) a2 += w * (float)p[2];
@@ -400,13 +470,13 @@ __global__ __launch_bounds__(kResampleThreads) void ResampleKernel(const daliamd
     const int flat_w = d.out_w * C;
     if (x < tw) {
       for (int y = tid >> tw_log2; y < th; y += kResampleThreads >> tw_log2) {
-        const float *co = cy + y * sup_y;
-        const int *ro = yt + y * sup_y;
+        const float *co = cy + y;
+        const int *ro = yt + y;
         const float *tcol = tmp + x * C;
         float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
         for (int k = 0; k < sup_y; k++) {
-          float w = co[k];
-          const float *p = tcol + ro[k];
+          float w = co[k * TH];
+          const float *p = tcol + ro[k * TH];
           a0 += p[0] * w;
           if (C > 1) a1 += p[1] * w;
           if (C > 2) a2 += p[2] * w;
@@ -416,10 +486,10 @@ __global__ __launch_bounds__(kResampleThreads) void ResampleKernel(const daliamd
         int fi = (ox0 + x) * C;
         size_t cs, o = ep.Base(oy0 + y, ox0 + x, &cs);
 #define VLAST_EVEN(f) ((f) < ((f) & ~255) + ((min(((f) & ~255) + 256, flat_w) - ((f) & ~255)) & ~15))
-        ep.Store(o, RoundU8(a0, VLAST_EVEN(fi)), mean0, inv0);
-        if (C > 1) ep.Store(o + cs, RoundU8(a1, VLAST_EVEN(fi + 1)), mean1, inv1);
-        if (C > 2) ep.Store(o + 2 * cs, RoundU8(a2, VLAST_EVEN(fi + 2)), mean2, inv2);
-        if (C > 3) ep.Store(o + 3 * cs, RoundU8(a3, VLAST_EVEN(fi + 3)), mean3, inv3);
+        ep.Store(o, 0, RoundU8(a0, VLAST_EVEN(fi)), mean0, inv0);
+        if (C > 1) ep.Store(o + cs, 1, RoundU8(a1, VLAST_EVEN(fi + 1)), mean1, inv1);
+        if (C > 2) ep.Store(o + 2 * cs, 2, RoundU8(a2, VLAST_EVEN(fi + 2)), mean2, inv2);
+        if (C > 3) ep.Store(o + 3 * cs, 3, RoundU8(a3, VLAST_EVEN(fi + 3)), mean3, inv3);
 #undef VLAST_EVEN
       }
     }
@@ -467,6 +537,7 @@ static int SetupOne(const daliamdResampleArgs &a, daliamdResampleDesc &d, int in
   d.out_h = a.out_h; d.out_w = a.out_w;
   d.out_dtype = a.out_dtype; d.out_layout = a.out_layout; d.normalize = a.normalize; d.mirror = a.mirror;
   for (int c = 0; c < 4; c++) { d.mean[c] = a.mean[c]; d.inv_std[c] = a.inv_std[c]; }
+  d.use_lut = a.normalize && a.out_dtype == DALIAMD_FLOAT16;  // fused CMN to fp16: the epilogue is a 256-entry look-up
 
   const int in_size[2] = {a.in_w, a.in_h};
   const int out_size[2] = {a.out_w, a.out_h};
@@ -563,7 +634,7 @@ static int SetupOne(const daliamdResampleArgs &a, daliamdResampleDesc &d, int in
   // tile selection: keep tables + staged source window + tmp inside the LDS budget.  When even small tiles
   // cannot hold their source window (extreme down-scaling) fall back to reading the source from global memory.
   auto lds_need = [&](int tw_, int th_, bool staged) -> size_t {
-    size_t tables = 2 * ((size_t)th_ * d.support[1] + (size_t)tw_ * d.support[0]) + th_ + tw_;
+    size_t tables = 2 * ((size_t)th_ * d.support[1] + (size_t)tw_ * d.support[0]) + (d.use_lut ? a.channels * 128 : 0);
     size_t ncols = (size_t)std::ceil(tw_ * std::abs(d.scale[0])) + d.support[0] + 2;
     size_t nrows = (size_t)std::ceil(th_ * std::abs(d.scale[1])) + d.support[1] + 2;
     ncols = std::min<size_t>(ncols, a.in_w);
@@ -607,32 +678,48 @@ static int SetupOne(const daliamdResampleArgs &a, daliamdResampleDesc &d, int in
 extern "C" {
 
 daliamdResult_t daliamdResampleSetup(const daliamdResampleArgs *args, int n, daliamdResampleDesc *descs,
-                                     int *num_workgroups, int *lds_bytes) {
-  DALIAMD_REQUIRE(args && descs && num_workgroups && lds_bytes && n >= 0, DALIAMD_ERROR_INVALID_ARGUMENT,
+                                     int *num_workgroups, int *lds_bytes, size_t *workspace_bytes, int *table_entries) {
+  DALIAMD_REQUIRE(args && descs && num_workgroups && lds_bytes && workspace_bytes && table_entries && n >= 0, DALIAMD_ERROR_INVALID_ARGUMENT,
                   "daliamdResampleSetup: NULL argument");
-  int wg = 0, lds = 0;
+  int wg = 0, lds = 0, entries = 0;
+  size_t ws = 0;
   for (int i = 0; i < n; i++) {
     int rc = daliamd::SetupOne(args[i], descs[i], i);
     if (rc != DALIAMD_SUCCESS) return (daliamdResult_t)rc;
     descs[i].wg_start = wg;
     wg += descs[i].tiles_x * descs[i].tiles_y;
     lds = lds > descs[i].lds_bytes ? lds : descs[i].lds_bytes;
+    descs[i].table_off = (int64_t)ws;
+    descs[i].tab_start = entries;
+    ws += ((size_t)daliamd::MakeTableLayout(descs[i]).words * 4 + 15) & ~(size_t)15;
+    entries += daliamd::TableEntries(descs[i]);
   }
   *num_workgroups = wg;
   *lds_bytes = lds;
+  *workspace_bytes = ws;
+  *table_entries = entries;
   return DALIAMD_SUCCESS;
 }
 
 daliamdResult_t daliamdResampleRun(daliamdStream_t stream, const daliamdResampleDesc *descs_dev, int n,
-                                   int num_workgroups, int lds_bytes) {
+                                   int num_workgroups, int lds_bytes, void *workspace_dev, size_t workspace_bytes,
+                                   int table_entries) {
   if (n == 0 || num_workgroups == 0) return DALIAMD_SUCCESS;
   DALIAMD_REQUIRE(descs_dev && n > 0 && num_workgroups > 0 && lds_bytes >= 0 && lds_bytes <= daliamd::kMaxLds,
                   DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdResampleRun: invalid argument");
+  DALIAMD_REQUIRE(workspace_dev && workspace_bytes > 0 && table_entries > 0, DALIAMD_ERROR_INVALID_ARGUMENT,
+                  "daliamdResampleRun: the table workspace is missing (size it with daliamdResampleSetup)");
+  {
+    daliamd::KernelTimer timer("ResampleTablesKernel", (hipStream_t)stream);
+    hipLaunchKernelGGL(daliamd::ResampleTablesKernel, dim3((table_entries + daliamd::kTableThreads - 1) / daliamd::kTableThreads),
+                       dim3(daliamd::kTableThreads), 0, (hipStream_t)stream, descs_dev, n, table_entries,
+                       static_cast<uint8_t *>(workspace_dev));
+  }
   {
     daliamd::KernelTimer timer("ResampleKernel", (hipStream_t)stream);
     hipLaunchKernelGGL(daliamd::ResampleKernel, dim3(daliamd::XcdGrid(num_workgroups)),
                        dim3(daliamd::kResampleThreads), lds_bytes, (hipStream_t)stream, descs_dev, n,
-                       num_workgroups);
+                       num_workgroups, static_cast<const uint8_t *>(workspace_dev));
   }
   DALIAMD_HIP_CHECK(hipGetLastError());
   return DALIAMD_SUCCESS;

@@ -546,7 +546,7 @@ std::vector<std::vector<float>> GetPerSampleFloatVec(const OpSpec &spec, const W
 }
 
 // ------------------------------------------------------------------------------------------ DescUploader
-void *DescUploader::Upload(const void *host, size_t bytes, daliamdStream_t stream, int min_slots) {
+void *DescUploader::Upload(const void *host, size_t bytes, daliamdStream_t stream, int min_slots, size_t scratch_bytes) {
   if ((int)slots_.size() < min_slots) {  // grow: new (unused) slots go behind the cursor
     slots_.resize(min_slots);
   }
@@ -556,11 +556,16 @@ void *DescUploader::Upload(const void *host, size_t bytes, daliamdStream_t strea
   if (s.used) KCHECK(daliamdEventSynchronize(s.ev));  // the previous copy from this slot must be done
   if (bytes > s.cap) {
     if (s.pinned) daliamdHostFree(s.pinned);
-    if (s.dev) daliamdFree(s.dev);
     s.cap = (bytes * 3 / 2 + 4095) & ~(size_t)4095;
     KCHECK(daliamdHostAlloc(&s.pinned, s.cap));
-    KCHECK(daliamdMalloc(&s.dev, s.cap));
   }
+  const size_t table_bytes = (bytes + 255) & ~(size_t)255;
+  if (table_bytes + scratch_bytes > s.dev_cap) {
+    if (s.dev) daliamdFree(s.dev);
+    s.dev_cap = ((table_bytes + scratch_bytes) * 3 / 2 + 4095) & ~(size_t)4095;
+    KCHECK(daliamdMalloc(&s.dev, s.dev_cap));
+  }
+  scratch_ = scratch_bytes ? static_cast<char *>(s.dev) + table_bytes : nullptr;
   if (!s.ev) KCHECK(daliamdEventCreate(&s.ev, 0));
   memcpy(s.pinned, host, bytes);
   KCHECK(daliamdMemcpyH2DAsync(s.dev, s.pinned, bytes, stream));

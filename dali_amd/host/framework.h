@@ -423,11 +423,20 @@ class DescUploader {
   // copies `bytes` to a device buffer that stays valid for `min_slots` further uploads.  Consecutive iterations run
   // on different streams, so the reuse of a buffer is NOT ordered by a stream: callers pass the pipeline's ring
   // (Workspace::ring) + 1, and the executor guarantees that the iteration `ring` steps back has completed.
-  void *Upload(const void *host, size_t bytes, daliamdStream_t stream, int min_slots = 4);
+  // `scratch_bytes` more device bytes are set aside behind the table (256-byte aligned; nothing is copied there):
+  // kernel-side scratch that lives and dies with the table's slot; Scratch() returns it for the last upload.
+  void *Upload(const void *host, size_t bytes, daliamdStream_t stream, int min_slots = 4, size_t scratch_bytes = 0);
+  void *Scratch() const { return scratch_; }
   ~DescUploader();
 
  private:
-  struct Slot { void *pinned = nullptr, *dev = nullptr; size_t cap = 0; daliamdEvent_t ev = nullptr; bool used = false; };
+  struct Slot {
+    void *pinned = nullptr, *dev = nullptr;
+    size_t cap = 0, dev_cap = 0;
+    daliamdEvent_t ev = nullptr;
+    bool used = false;
+  };
+  void *scratch_ = nullptr;
   std::vector<Slot> slots_ = std::vector<Slot>(4);
   int next_ = 0;
 };

@@ -1020,8 +1020,9 @@ static void LaunchResample(Workspace &ws, DescUploader &up, std::vector<daliamdR
   int n = (int)args.size();
   if (!n) return;
   descs.resize(n);
-  int nwg = 0, lds = 0;
-  KCHECK(daliamdResampleSetup(args.data(), n, descs.data(), &nwg, &lds));
+  int nwg = 0, lds = 0, entries = 0;
+  size_t scratch = 0;
+  KCHECK(daliamdResampleSetup(args.data(), n, descs.data(), &nwg, &lds, &scratch, &entries));
   if (ws.backend == OpType::CPU) {
     // CPU backend: the same descriptors, one thread-pool task per sample (resize_op_impl_cpu.h:84-107)
     for (int i = 0; i < n; i++)
@@ -1032,8 +1033,9 @@ static void LaunchResample(Workspace &ws, DescUploader &up, std::vector<daliamdR
     NoteLaunch(ws, std::string("host_") + what);
     return;
   }
-  auto *dev = static_cast<const daliamdResampleDesc *>(up.Upload(descs.data(), descs.size() * sizeof(descs[0]), ws.stream, ws.ring + 1));
-  KCHECK(daliamdResampleRun(ws.stream, dev, n, nwg, lds));
+  auto *dev = static_cast<const daliamdResampleDesc *>(
+      up.Upload(descs.data(), descs.size() * sizeof(descs[0]), ws.stream, ws.ring + 1, scratch));
+  KCHECK(daliamdResampleRun(ws.stream, dev, n, nwg, lds, up.Scratch(), scratch, entries));
   NoteLaunch(ws, what);
 }
 

@@ -298,14 +298,23 @@ typedef struct {
   uint32_t even_mask[8];     /* H-last: per output column, 1 = round half to even               */
   int32_t lds_bytes;
   int32_t staged;            /* 1: the tile's source window is staged in LDS; 0: read from global memory */
+  /* per-sample tables in the workspace (first-tap indices and normalised coefficients of every output column and
+   * row, and - fused fp16 normalisation - the 256-entry result table per channel), filled by the first kernel of Run */
+  int64_t table_off;         /* byte offset of the sample's tables inside the workspace */
+  int32_t tab_start;         /* first table entry of the sample (work index of the tables kernel) */
+  int32_t use_lut;
 } daliamdResampleDesc;
 
 /* Fills descs_host[0..n); returns the grid size and the dynamic LDS bytes the launch needs. */
-DALIAMD_API daliamdResult_t daliamdResampleSetup(const daliamdResampleArgs *args_host, int n,
-                                                 daliamdResampleDesc *descs_host,
-                                                 int *num_workgroups, int *lds_bytes);
-DALIAMD_API daliamdResult_t daliamdResampleRun(daliamdStream_t stream, const daliamdResampleDesc *descs_dev,
-                                               int n, int num_workgroups, int lds_bytes);
+/* workspace_bytes / table_entries (out): size of the device scratch Run needs for the per-sample tables, and the number
+ * of table entries it computes; the workspace is written by Run's first kernel and read by its second one, so one
+ * buffer per stream (or per iteration in flight) is enough. */
+DALIAMD_API daliamdResult_t daliamdResampleSetup(const daliamdResampleArgs *args, int n, daliamdResampleDesc *descs_host,
+                                                int *num_workgroups, int *lds_bytes, size_t *workspace_bytes,
+                                                int *table_entries);
+DALIAMD_API daliamdResult_t daliamdResampleRun(daliamdStream_t stream, const daliamdResampleDesc *descs_dev, int n,
+                                              int num_workgroups, int lds_bytes, void *workspace_dev,
+                                              size_t workspace_bytes, int table_entries);
 
 /* ----------------------------------------------------------------------------------------------
  * Stand-alone CropMirrorNormalize: u8 HWC -> {fp16, fp32, u8, i8} HWC/CHW with crop, horizontal

@@ -62,17 +62,19 @@ def test_setup_functions_validate_arguments():
     import numpy as np
     args = np.zeros(1, np.dtype(capi.ResampleArgs))
     descs = np.zeros(1, np.dtype(capi.ResampleDesc))
-    nwg, lds = C.c_int(0), C.c_int(0)
+    nwg, lds, wsb, ent = C.c_int(0), C.c_int(0), C.c_size_t(0), C.c_int(0)
     rc = lib.daliamdResampleSetup(args.ctypes.data_as(C.c_void_p), 1, descs.ctypes.data_as(C.c_void_p), C.byref(nwg),
-                                  C.byref(lds))
+                                  C.byref(lds), C.byref(wsb), C.byref(ent))
     assert rc == 1 and b"empty" in lib.daliamdGetLastErrorMessage()
     a = args[0]
     a["in_h"], a["in_w"], a["channels"], a["in_pitch"], a["out_h"], a["out_w"] = 100, 80, 3, 240, 20, 30
     a["min_filter"], a["mag_filter"], a["antialias"] = 1, 1, 1
     rc = lib.daliamdResampleSetup(args.ctypes.data_as(C.c_void_p), 1, descs.ctypes.data_as(C.c_void_p), C.byref(nwg),
-                                  C.byref(lds))
+                                  C.byref(lds), C.byref(wsb), C.byref(ent))
     assert rc == 0 and nwg.value == descs[0]["tiles_x"] * descs[0]["tiles_y"] > 0 and 0 < lds.value <= 60 * 1024
+    # the per-sample tables: first tap + coefficients of 30 columns and 20 rows
+    assert ent.value == 50 and wsb.value >= 4 * (30 * (1 + descs[0]["support"][0]) + 20 * (1 + descs[0]["support"][1]))
     a["channels"] = 7
     rc = lib.daliamdResampleSetup(args.ctypes.data_as(C.c_void_p), 1, descs.ctypes.data_as(C.c_void_p), C.byref(nwg),
-                                  C.byref(lds))
+                                  C.byref(lds), C.byref(wsb), C.byref(ent))
     assert rc == 2  # DALIAMD_ERROR_UNSUPPORTED
