@@ -71,15 +71,14 @@ typedef float floatx2 __attribute__((ext_vector_type(2)));
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int ClampI(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
+// u8 rounding of the reference's two code paths: half-to-even (the SIMD body: cvtps with the default rounding mode) or
+// half-away-from-zero (ConvertSat in the scalar tails); NaN and negatives -> 0.  Both from one round-to-nearest-even:
+// it differs from half-away only at a tie that was rounded DOWN, where clamped - rounded is exactly +0.5.
 __device__ __forceinline__ uint32_t RoundU8(float v, bool half_even) {
-  if (half_even) {
-    float c = fminf(fmaxf(v, 0.0f), 255.0f);  // NaN -> 0 (fmaxf returns the non-NaN operand)
-    return (uint32_t)rintf(c);
-  }
-  if (!(v > 0.0f)) return 0;
-  float r = floorf(v);
-  r += (v - r >= 0.5f) ? 1.0f : 0.0f;
-  return (uint32_t)fminf(r, 255.0f);
+  const float c = fminf(fmaxf(v, 0.0f), 255.0f);  // NaN -> 0 (fmaxf returns the non-NaN operand)
+  float r = rintf(c);
+  if (!half_even && c - r == 0.5f) r += 1.0f;
+  return (uint32_t)r;
 }
 
 // half_float::detail::float2half_impl<round_to_nearest>, ties away from zero (half.hpp:464-536)
@@ -177,11 +176,92 @@ using GF32 = float __attribute__((address_space(1)));
 using GU16 = uint16_t __attribute__((address_space(1)));
 using GBytes = const uint8_t __attribute__((address_space(1)));
 
+// Tile record (workspace, 128 bytes per tile, written by ResampleTablesKernel): everything the prologue of a tile needs,
+// so that the staging loads can be issued after ONE dependent memory round trip (the record) instead of four
+// (descriptor index -> descriptor -> first taps of the tile's corners -> window).
+struct TileRec {
+  uint64_t win, buf_lo, buf_hi, tab;   // window origin, source buffer bounds, the sample's tables
+  int32_t pitch, nrows, NB, LP;
+  int32_t x_lo, y_lo, tmp_bytes, desc_idx;
+  int32_t ox0, oy0, tw, th;
+  int32_t TW, TH, sup_x, sup_y;
+  int32_t ex, ey, out_w, out_h;
+  int32_t flags, channels, rowlen, reserved;
+};
+static_assert(sizeof(TileRec) == 128, "layout");
+enum { kRecVFirst = 1, kRecStaged = 2, kRecUseLut = 4, kRecPrefetch = 8, kRecInBounds = 16 };
+constexpr int kLutLdsBytes = 2048;      // [4][256] fp16 at the start of the LDS block, whatever the tile
+constexpr int kPrefetchChunks = 4;      // staged rows per thread held in registers across the previous tile's passes
+#ifndef DALIAMD_RS_TILES
+#define DALIAMD_RS_TILES 2
+#endif
+constexpr int kTilesPerWg = DALIAMD_RS_TILES;
+
+__device__ __forceinline__ void MinMax4(int a, int b, int c, int d, int *lo, int *hi) {
+  *lo = min(min(a, b), min(c, d));
+  *hi = max(max(a, b), max(c, d));
+}
+
+// one thread per tile: the record
+__device__ void MakeTileRec(const daliamdResampleDesc *descs, int ndesc, int tile, uint8_t *workspace, TileRec *out) {
+  int lo = 0, hi = ndesc - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].wg_start <= tile) lo = mid; else hi = mid - 1;
+  }
+  const daliamdResampleDesc &d = descs[lo];
+  TileRec r;
+  const int C = d.channels, TH = d.tile_h, TW = d.tile_w;
+  const int t = tile - d.wg_start;
+  const int ty = t / d.tiles_x, tx = t - ty * d.tiles_x;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int th = min(TH, d.out_h - oy0), tw = min(TW, d.out_w - ox0);
+  const int sup_x = d.support[0], sup_y = d.support[1];
+  const int ex = d.ext[0] - 1, ey = d.ext[1] - 1;
+  float f0;
+  const float start_x = FilterStart(d.origin[0], d.scale[0], d.fanchor[0]);
+  const float start_y = FilterStart(d.origin[1], d.scale[1], d.fanchor[1]);
+  const int ix_a = FirstTap(ox0, d.scale[0], start_x, &f0), ix_b = FirstTap(ox0 + tw - 1, d.scale[0], start_x, &f0);
+  const int iy_a = FirstTap(oy0, d.scale[1], start_y, &f0), iy_b = FirstTap(oy0 + th - 1, d.scale[1], start_y, &f0);
+  int x_lo, x_hi, y_lo, y_hi;
+  MinMax4(ClampI(ix_a, 0, ex), ClampI(ix_a + sup_x - 1, 0, ex), ClampI(ix_b, 0, ex), ClampI(ix_b + sup_x - 1, 0, ex), &x_lo, &x_hi);
+  MinMax4(ClampI(iy_a, 0, ey), ClampI(iy_a + sup_y - 1, 0, ey), ClampI(iy_b, 0, ey), ClampI(iy_b + sup_y - 1, 0, ey), &y_lo, &y_hi);
+  const int ncols = x_hi - x_lo + 1, nrows = y_hi - y_lo + 1;
+  const int NB = ncols * C, LP = (NB + 15 + 15) & ~15;
+  const bool vfirst = d.first_axis == 1, staged = d.staged != 0;
+  r.win = reinterpret_cast<uint64_t>(d.in + (size_t)(d.lo[1] + y_lo) * d.in_pitch + (size_t)(d.lo[0] + x_lo) * C);
+  r.buf_lo = reinterpret_cast<uint64_t>(d.in);
+  r.buf_hi = r.buf_lo + (size_t)d.in_h * d.in_pitch;
+  r.tab = reinterpret_cast<uint64_t>(workspace + d.table_off);
+  r.pitch = d.in_pitch; r.nrows = nrows; r.NB = NB; r.LP = LP;
+  r.x_lo = x_lo; r.y_lo = y_lo;
+  r.tmp_bytes = 4 * (vfirst ? th * NB : nrows * tw * C);
+  r.desc_idx = lo;
+  r.ox0 = ox0; r.oy0 = oy0; r.tw = tw; r.th = th;
+  r.TW = TW; r.TH = TH; r.sup_x = sup_x; r.sup_y = sup_y;
+  r.ex = ex; r.ey = ey; r.out_w = d.out_w; r.out_h = d.out_h;
+  const bool prefetch = staged && NB <= 241 - 15 && nrows <= 16 * kPrefetchChunks && TW * sup_x <= kResampleThreads &&
+                        TH * sup_y <= kResampleThreads && d.in_pitch < (1 << 23);
+  // every 16-byte chunk of every window row lies inside the source buffer: no per-chunk bounds checks
+  const bool in_bounds = r.win >= r.buf_lo + 16 && r.win + (uint64_t)(nrows - 1) * d.in_pitch + NB + 32 <= r.buf_hi;
+  r.flags = (vfirst ? kRecVFirst : 0) | (staged ? kRecStaged : 0) | (d.use_lut ? kRecUseLut : 0) | (prefetch ? kRecPrefetch : 0) |
+            (in_bounds ? kRecInBounds : 0);
+  r.channels = C; r.rowlen = tw * C;
+  r.reserved = 0;
+  *out = r;
+}
+
 constexpr int kTableThreads = 256;
 __global__ __launch_bounds__(kTableThreads) void ResampleTablesKernel(const daliamdResampleDesc *__restrict__ descs, int ndesc,
-                                                                      int total_entries, uint8_t *__restrict__ workspace) {
+                                                                      int sample_entries, int total_tiles,
+                                                                      uint8_t *__restrict__ workspace, size_t tile_rec_off) {
   const int e = blockIdx.x * kTableThreads + threadIdx.x;
-  if (e >= total_entries) return;
+  if (e >= sample_entries + total_tiles) return;
+  if (e >= sample_entries) {  // one thread per tile: its record
+    const int tile = e - sample_entries;
+    MakeTileRec(descs, ndesc, tile, workspace, reinterpret_cast<TileRec *>(workspace + tile_rec_off) + tile);
+    return;
+  }
   int lo = 0, hi = ndesc - 1;
   while (lo < hi) {
     int mid = (lo + hi + 1) >> 1;
@@ -217,282 +297,359 @@ __global__ __launch_bounds__(kTableThreads) void ResampleTablesKernel(const dali
   ((GI32 *)tab)[(axis ? L.yi : L.xi) + o] = s0;
 }
 
-// Descriptor lookup: tile counts are usually identical across the batch, so first try the uniform
-// guess (two independent loads); fall back to the binary search.
-__device__ __forceinline__ int FindResampleDesc(const daliamdResampleDesc *descs, int n, int wg, int total_wg) {
-  int g = (int)(((long long)wg * n) / total_wg);
-  if (descs[g].wg_start <= wg && (g + 1 == n || wg < descs[g + 1].wg_start)) return g;
-  return FindDesc(descs, n, wg);
-}
+// What a thread fetches from global memory for one tile ahead of time: its chunks of the staged window and its entry
+// of the coefficient / first-tap tables of either axis.
+struct TilePrefetch {
+  uint4 chunk[kPrefetchChunks];
+  float cxv, cyv;
+  int xiv, yiv;
+};
 
-__device__ __forceinline__ void MinMax4(int a, int b, int c, int d, int *lo, int *hi) {
-  *lo = min(min(a, b), min(c, d));
-  *hi = max(max(a, b), max(c, d));
-}
-
-__global__ __launch_bounds__(kResampleThreads) void ResampleKernel(const daliamdResampleDesc *__restrict__ descs,
-                                                                   int ndesc, int total_wg,
-                                                                   const uint8_t *__restrict__ workspace) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  int wg = XcdRemap(blockIdx.x, total_wg);
-  if (wg < 0) return;
-  const daliamdResampleDesc &d = descs[FindResampleDesc(descs, ndesc, wg, total_wg)];
-  const int tid = threadIdx.x;
-  const int C = d.channels;
-  const int TH = d.tile_h, TW = d.tile_w;       // powers of two
-  const int tw_log2 = 31 - __clz(TW), th_log2 = 31 - __clz(TH);
-  int t = wg - d.wg_start;
-  int ty = t / d.tiles_x, tx = t - ty * d.tiles_x;
-  const int oy0 = ty * TH, ox0 = tx * TW;
-  const int th = min(TH, d.out_h - oy0), tw = min(TW, d.out_w - ox0);
-  const int sup_x = d.support[0], sup_y = d.support[1];
-  const bool use_lut = d.use_lut != 0;
-
-  // LDS carve-up: coefficients and per-tap source offsets (tap-major: entry k * TILE + i), the epilogue look-up
-  // table, the staged window, tmp.  Byte offsets from the LDS base, never a round trip through an integer: that
-  // would make every access behind it a generic one - flat loads that wait on both memory counters.
-  float *cy = lds;                                        // [sup_y][TH]
-  float *cx = cy + TH * sup_y;                            // [sup_x][TW]
-  int *yt = reinterpret_cast<int *>(cx + TW * sup_x);     // [sup_y][TH] per-tap row offset
-  int *xt = yt + TH * sup_y;                              // [sup_x][TW] per-tap column offset (elements)
-  uint16_t *lut = reinterpret_cast<uint16_t *>(xt + TW * sup_x);  // [C][256]
-  const size_t table_words = (size_t)2 * (TH * sup_y + TW * sup_x) + (use_lut ? C * 128 : 0);
-  uint8_t *stage = reinterpret_cast<uint8_t *>(lds) + ((table_words * sizeof(float) + 15) & ~(size_t)15);
-
-  const TableLayout L = MakeTableLayout(d);
-  GU32 *tab = (GU32 *)(workspace + d.table_off);
-  GI32 *xi = (GI32 *)tab + L.xi, *yi = (GI32 *)tab + L.yi;
-  GF32 *xc = (GF32 *)(tab + L.xc), *yc = (GF32 *)(tab + L.yc);
-
-  Epilogue ep;
-  ep.out = d.out; ep.out_h = d.out_h; ep.out_w = d.out_w; ep.channels = C;
-  ep.dtype = d.out_dtype; ep.layout = d.out_layout; ep.normalize = d.normalize; ep.mirror = d.mirror;
-  ep.lut = use_lut ? lut : nullptr;
-  const float mean0 = d.mean[0], mean1 = d.mean[1], mean2 = d.mean[2], mean3 = d.mean[3];
-  const float inv0 = d.inv_std[0], inv1 = d.inv_std[1], inv2 = d.inv_std[2], inv3 = d.inv_std[3];
-
-  const uint8_t *__restrict__ in = d.in;
-  const int pitch = d.in_pitch;
-  const bool vfirst = d.first_axis == 1;
-  const bool staged = d.staged != 0;  // 0: source window too large for LDS, read it from global memory
-
-  // ---- source window of this tile: rows [y_lo, y_hi] x columns [x_lo, x_hi] (in each axis' clamp frame) ----
-  // first-pass axis: taps clamped to the whole image; second-pass axis: to the ROI window [lo, lo+ext)
-  const int ex = d.ext[0] - 1, ey = d.ext[1] - 1;
-  int x_lo, x_hi, y_lo, y_hi;
-  {
-    const int ix_a = xi[ox0], ix_b = xi[ox0 + tw - 1], iy_a = yi[oy0], iy_b = yi[oy0 + th - 1];
-    MinMax4(ClampI(ix_a, 0, ex), ClampI(ix_a + sup_x - 1, 0, ex), ClampI(ix_b, 0, ex), ClampI(ix_b + sup_x - 1, 0, ex),
-            &x_lo, &x_hi);
-    MinMax4(ClampI(iy_a, 0, ey), ClampI(iy_a + sup_y - 1, 0, ey), ClampI(iy_b, 0, ey), ClampI(iy_b + sup_y - 1, 0, ey),
-            &y_lo, &y_hi);
+__device__ __forceinline__ uint4 LoadChunk(uintptr_t g, uintptr_t buf_lo, uintptr_t buf_hi) {
+  if (g >= buf_lo && g + 16 <= buf_hi) {
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    const u32x4_t t4 = *(const u32x4_t __attribute__((address_space(1))) *)g;
+    return make_uint4(t4.x, t4.y, t4.z, t4.w);
   }
-  const int ncols = x_hi - x_lo + 1, nrows = y_hi - y_lo + 1;
-  const int NB = ncols * C;                              // bytes per window row
-  const int LP = (NB + 15 + 15) & ~15;                   // LDS row pitch (room for the alignment shift)
-  const uint8_t *win = in + (size_t)(d.lo[1] + y_lo) * pitch + (size_t)(d.lo[0] + x_lo) * C;
-  const uintptr_t win_addr = reinterpret_cast<uintptr_t>(win);
-  float *tmp = reinterpret_cast<float *>(stage + (staged ? (size_t)nrows * LP : 0));
-  const int rowlen = tw * C;                             // H-first tmp row length
-
-  // ---- coefficient / per-tap offset tables of the tile, from the per-sample tables ----
-  //   xt: element offset of tap k of column x inside a window row
-  //   yt: V-first: byte offset of element 0 of the tapped row inside `stage` (or `win` when not staged)
-  //       H-first: element offset of the tapped row inside tmp
-  for (int i = tid; i < TW * sup_x; i += kResampleThreads) {
-    const int x = i & (TW - 1), k = i >> tw_log2;
-    if (x < tw) {
-      cx[i] = xc[(size_t)(ox0 + x) * sup_x + k];
-      xt[i] = (ClampI(xi[ox0 + x] + k, 0, ex) - x_lo) * C;
-    }
-  }
-  for (int i = tid; i < TH * sup_y; i += kResampleThreads) {
-    const int y = i & (TH - 1), k = i >> th_log2;
-    if (y < th) {
-      cy[i] = yc[(size_t)(oy0 + y) * sup_y + k];
-      const int r = ClampI(yi[oy0 + y] + k, 0, ey) - y_lo;
-      int v;
-      if (!vfirst) v = r * rowlen;
-      else if (staged) v = r * LP + (int)((win_addr + (size_t)r * pitch) & 15);
-      else v = r * pitch;
-      yt[i] = v;
-    }
-  }
-  if (use_lut) {
-    GU32 *src = tab + L.lut;
-    uint32_t *dst = reinterpret_cast<uint32_t *>(lut);
-    for (int i = tid; i < C * 128; i += kResampleThreads) dst[i] = src[i];
-  }
-
-  // ---- stage the window in LDS with 16-byte coalesced loads (each row keeps its own alignment shift) ----
-  if (staged) {
-    const uintptr_t buf_lo = reinterpret_cast<uintptr_t>(in);
-    const uintptr_t buf_hi = buf_lo + (size_t)d.in_h * pitch;
-    for (int r = tid >> 4; r < nrows; r += kResampleThreads / 16) {
-      uintptr_t ra = win_addr + (size_t)r * pitch;
-      int sh = (int)(ra & 15);
-      int nch = (sh + NB + 15) >> 4;
-      uint8_t *dst = stage + r * LP;
-      for (int q = tid & 15; q < nch; q += 16) {
-        uintptr_t g = ra - sh + 16 * q;
-        uint4 v;
-        if (g >= buf_lo && g + 16 <= buf_hi) {
-          typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-          const u32x4_t t4 = *(const u32x4_t __attribute__((address_space(1))) *)g;  // global, not generic: the loads
-          v = make_uint4(t4.x, t4.y, t4.z, t4.w);                                     // of a row may overlap the LDS stores
-        } else {  // chunk straddles the buffer boundary: assemble from the in-bounds bytes
-          uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+  // chunk straddles the buffer boundary: assemble from the in-bounds bytes
+  uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
 #pragma unroll
-          for (int b = 0; b < 16; b++) {
-            uintptr_t a = g + b;
-            uint32_t byte = (a >= buf_lo && a < buf_hi) ? (uint32_t)(*(GBytes *)a) : 0u;
-            byte <<= 8 * (b & 3);
-            if (b < 4) w0 |= byte; else if (b < 8) w1 |= byte; else if (b < 12) w2 |= byte; else w3 |= byte;
-          }
-          v = make_uint4(w0, w1, w2, w3);
-        }
-        *reinterpret_cast<uint4 *>(dst + 16 * q) = v;
-      }
-    }
+  for (int b = 0; b < 16; b++) {
+    uintptr_t a = g + b;
+    uint32_t byte = (a >= buf_lo && a < buf_hi) ? (uint32_t)(*(GBytes *)a) : 0u;
+    byte <<= 8 * (b & 3);
+    if (b < 4) w0 |= byte; else if (b < 8) w1 |= byte; else if (b < 12) w2 |= byte; else w3 |= byte;
   }
-  __syncthreads();
-  GBytes *gwin = (GBytes *)win;  // source rows when the window is not staged
+  return make_uint4(w0, w1, w2, w3);
+}
 
-  if (vfirst) {
-    // ================= vertical pass (window rows -> tmp[th][NB]), then horizontal =================
-    if (staged && (pitch & 3) == 0) {
-      // every row has the same shift modulo 4: produce 4 consecutive elements from one LDS dword per tap; the
-      // (row, dword) items are spread evenly over the threads
-      const int s4 = (int)(win_addr & 3);
-      const int ndw = (NB + s4 + 3) >> 2;
-      const float inv_ndw = 1.0f / (float)ndw;
-      for (int item = tid; item < th * ndw; item += kResampleThreads) {
-        const int y = (int)(((float)item + 0.5f) * inv_ndw);   // exact: item < 2^16
-        const int j = item - y * ndw;
-        const float *co = cy + y;
-        const int *ro = yt + y;
-        floatx2 a01 = {0.0f, 0.0f}, a23 = {0.0f, 0.0f};
-        const uint8_t *col = stage + 4 * j - s4;
-        for (int k = 0; k < sup_y; k++) {
-          const uint32_t v = *reinterpret_cast<const uint32_t *>(col + ro[k * TH]);
-          const float w = co[k * TH];
-          a01 += floatx2{(float)(v & 255), (float)((v >> 8) & 255)} * w;
-          a23 += floatx2{(float)((v >> 16) & 255), (float)(v >> 24)} * w;
+__device__ __forceinline__ void FetchTile(const TileRec &r, int tid, TilePrefetch &p) {
+  if (!(r.flags & kRecPrefetch)) return;
+  if (r.flags & kRecInBounds) {
+    // 32-bit offsets from a uniform base (16 bytes in front of the window, so that they stay non-negative)
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    const uint8_t __attribute__((address_space(1))) *base = (const uint8_t __attribute__((address_space(1))) *)(r.win - 16);
+    const uint32_t lo4 = (uint32_t)r.win & 15u;
+#pragma unroll
+    for (int i = 0; i < kPrefetchChunks; i++) {
+      const int row = (tid >> 4) + 16 * i, q = tid & 15;
+      p.chunk[i] = make_uint4(0, 0, 0, 0);
+      if (row < r.nrows) {
+        const uint32_t ro = (uint32_t)__mul24(row, r.pitch);
+        const uint32_t sh = (lo4 + ro) & 15u;
+        if (q < (int)((sh + (uint32_t)r.NB + 15u) >> 4)) {
+          const u32x4_t t4 = *(const u32x4_t __attribute__((address_space(1))) *)(base + (ro + 16u - sh + 16u * (uint32_t)q));
+          p.chunk[i] = make_uint4(t4.x, t4.y, t4.z, t4.w);
         }
-        float *trow = tmp + y * NB;
-        const int e = 4 * j - s4;
-        if (e >= 0 && e + 3 < NB) {
-          trow[e] = a01.x; trow[e + 1] = a01.y; trow[e + 2] = a23.x; trow[e + 3] = a23.y;
-        } else {
-          if (e >= 0 && e < NB) trow[e] = a01.x;
-          if (e + 1 >= 0 && e + 1 < NB) trow[e + 1] = a01.y;
-          if (e + 2 >= 0 && e + 2 < NB) trow[e + 2] = a23.x;
-          if (e + 3 >= 0 && e + 3 < NB) trow[e + 3] = a23.y;
-        }
-      }
-    } else {
-      for (int y = tid >> 6; y < th; y += kResampleThreads / 64) {
-        const float *co = cy + y;
-        const int *ro = yt + y;
-        for (int e = tid & 63; e < NB; e += 64) {
-          float a = 0;
-          if (staged) {
-            for (int k = 0; k < sup_y; k++) a += (float)stage[ro[k * TH] + e] * co[k * TH];
-          } else {
-            for (int k = 0; k < sup_y; k++) a += (float)gwin[ro[k * TH] + e] * co[k * TH];
-          }
-          tmp[y * NB + e] = a;
-        }
-      }
-    }
-    __syncthreads();
-    const int x = tid & (TW - 1);
-    if (x < tw) {
-      const float *co = cx + x;
-      const int *xo = xt + x;
-      const int gx = ox0 + x;
-      const bool even = (d.even_mask[(gx >> 5) & 7] >> (gx & 31)) & 1;
-      for (int y = tid >> tw_log2; y < th; y += kResampleThreads >> tw_log2) {
-        const float *trow = tmp + y * NB;
-        float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        for (int k = 0; k < sup_x; k++) {
-          float w = co[k * TW];
-          const float *p = trow + xo[k * TW];
-          a0 += w * p[0];
-          if (C > 1) a1 += w * p[1];
-          if (C > 2) a2 += w * p[2];
-          if (C > 3) a3 += w * p[3];
-        }
-        size_t cs, o = ep.Base(oy0 + y, gx, &cs);
-        ep.Store(o, 0, RoundU8(a0, even), mean0, inv0);
-        if (C > 1) ep.Store(o + cs, 1, RoundU8(a1, even), mean1, inv1);
-        if (C > 2) ep.Store(o + 2 * cs, 2, RoundU8(a2, even), mean2, inv2);
-        if (C > 3) ep.Store(o + 3 * cs, 3, RoundU8(a3, even), mean3, inv3);
       }
     }
   } else {
-    // ================= horizontal pass (window rows -> tmp[nrows][tw*C]), then vertical =================
-    const int x = tid & (TW - 1);
-    if (x < tw) {
-      const float *co = cx + x;
-      const int *xo = xt + x;
-      for (int r = tid >> tw_log2; r < nrows; r += kResampleThreads >> tw_log2) {
-        float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        if (staged) {
-          const uint8_t *srow = stage + r * LP + (int)((win_addr + (size_t)r * pitch) & 15);
-          for (int k = 0; k < sup_x; k++) {
-            float w = co[k * TW];
-            const uint8_t *p = srow + xo[k * TW];
-            a0 += w * (float)p[0];
-            if (C > 1) a1 += w * (float)p[1];
-            if (C > 2) a2 += w * (float)p[2];
-            if (C > 3) a3 += w * (float)p[3];
-          }
-        } else {
-          GBytes *srow = gwin + (size_t)r * pitch;
-          for (int k = 0; k < sup_x; k++) {
-            float w = co[k * TW];
-            GBytes *p = srow + xo[k * TW];
-            a0 += w * (float)p[0];
-            if (C > 1) a1 += w * (float)p[1];
-            if (C > 2) a2 += w * (float)p[2];
-            if (C > 3) a3 += w * (float)p[3];
-          }
-        }
-        float *tp = tmp + r * rowlen + x * C;
-        tp[0] = a0;
-        if (C > 1) tp[1] = a1;
-        if (C > 2) tp[2] = a2;
-        if (C > 3) tp[3] = a3;
+#pragma unroll
+    for (int i = 0; i < kPrefetchChunks; i++) {
+      const int row = (tid >> 4) + 16 * i, q = tid & 15;
+      p.chunk[i] = make_uint4(0, 0, 0, 0);
+      if (row < r.nrows) {
+        const uintptr_t ra = (uintptr_t)r.win + (size_t)row * r.pitch;
+        const int sh = (int)(ra & 15);
+        if (q < ((sh + r.NB + 15) >> 4)) p.chunk[i] = LoadChunk(ra - sh + 16 * q, (uintptr_t)r.buf_lo, (uintptr_t)r.buf_hi);
       }
     }
-    __syncthreads();
-    const int flat_w = d.out_w * C;
-    if (x < tw) {
-      for (int y = tid >> tw_log2; y < th; y += kResampleThreads >> tw_log2) {
-        const float *co = cy + y;
-        const int *ro = yt + y;
-        const float *tcol = tmp + x * C;
-        float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        for (int k = 0; k < sup_y; k++) {
-          float w = co[k * TH];
-          const float *p = tcol + ro[k * TH];
-          a0 += p[0] * w;
-          if (C > 1) a1 += p[1] * w;
-          if (C > 2) a2 += p[2] * w;
-          if (C > 3) a3 += p[3] * w;
+  }
+  GU32 *tab = (GU32 *)r.tab;
+  const int tw_log2 = 31 - __clz(r.TW), th_log2 = 31 - __clz(r.TH);
+  p.cxv = 0.0f; p.xiv = 0; p.cyv = 0.0f; p.yiv = 0;
+  {
+    const int x = tid & (r.TW - 1), k = tid >> tw_log2;
+    if (k < r.sup_x && x < r.tw) {
+      p.xiv = ((GI32 *)tab)[r.ox0 + x];
+      p.cxv = ((GF32 *)(tab + r.out_w))[(size_t)(r.ox0 + x) * r.sup_x + k];
+    }
+  }
+  {
+    const int y = tid & (r.TH - 1), k = tid >> th_log2;
+    if (k < r.sup_y && y < r.th) {
+      const int yi_off = r.out_w + r.out_w * r.sup_x;
+      p.yiv = ((GI32 *)tab)[yi_off + r.oy0 + y];
+      p.cyv = ((GF32 *)(tab + yi_off + r.out_h))[(size_t)(r.oy0 + y) * r.sup_y + k];
+    }
+  }
+}
+
+// Workgroup barrier that orders LDS accesses only: __syncthreads() also waits for every global load in flight
+// (its release fence covers all address spaces), which would make the next tile's prefetch wait at the first barrier.
+__device__ __forceinline__ void LdsBarrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+__global__ __launch_bounds__(kResampleThreads) void ResampleKernel(const daliamdResampleDesc *__restrict__ descs,
+                                                                   int ndesc, int total_wg, int total_tiles,
+                                                                   const uint8_t *__restrict__ workspace,
+                                                                   size_t tile_rec_off) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int wg = XcdRemap(blockIdx.x, total_wg);
+  if (wg < 0) return;
+  const int tid = threadIdx.x;
+  const TileRec *recs = reinterpret_cast<const TileRec *>(workspace + tile_rec_off);
+  const int t_begin = wg * kTilesPerWg, t_end = min(t_begin + kTilesPerWg, total_tiles);
+  uint16_t *lut = reinterpret_cast<uint16_t *>(lds);   // fixed place: survives from tile to tile of the same sample
+  int lut_desc = -1;
+
+  TileRec r = recs[t_begin];
+  TilePrefetch pf;
+  FetchTile(r, tid, pf);
+  for (int tile = t_begin; tile < t_end; tile++) {
+    const daliamdResampleDesc &d = descs[r.desc_idx];
+    const int C = r.channels, TH = r.TH, TW = r.TW;
+    const int tw_log2 = 31 - __clz(TW), th_log2 = 31 - __clz(TH);
+    const int oy0 = r.oy0, ox0 = r.ox0, th = r.th, tw = r.tw;
+    const int sup_x = r.sup_x, sup_y = r.sup_y;
+    const bool use_lut = (r.flags & kRecUseLut) != 0, vfirst = (r.flags & kRecVFirst) != 0, staged = (r.flags & kRecStaged) != 0;
+    const int ex = r.ex, ey = r.ey, x_lo = r.x_lo, y_lo = r.y_lo;
+    const int nrows = r.nrows, NB = r.NB, LP = r.LP, pitch = r.pitch, rowlen = r.rowlen;
+    const uintptr_t win_addr = (uintptr_t)r.win;
+
+    // LDS carve-up (byte offsets from the LDS base, never a round trip through an integer: that would make every
+    // access behind it a generic one): look-up table | staged window | tmp | coefficients and per-tap offsets
+    // (tap-major: entry k * TILE + i)
+    uint8_t *stage = reinterpret_cast<uint8_t *>(lds) + kLutLdsBytes;
+    float *tmp = reinterpret_cast<float *>(stage + (staged ? (size_t)nrows * LP : 0));
+    float *cy = tmp + (r.tmp_bytes >> 2);                   // [TH][sup_y] (row-major: a pass walks the taps of ONE row)
+    float *cx = cy + TH * sup_y;                            // [sup_x][TW]
+    int *yt = reinterpret_cast<int *>(cx + TW * sup_x);     // [TH][sup_y] per-tap row offset
+    int *xt = yt + TH * sup_y;                              // [sup_x][TW] per-tap column offset (elements)
+
+    GU32 *tab = (GU32 *)r.tab;
+    // ---- this tile's tables and window into LDS: from the registers filled one tile ago, or straight from memory ----
+    //   xt: element offset of tap k of column x inside a window row
+    //   yt: V-first: byte offset of element 0 of the tapped row inside `stage` (or `win` when not staged)
+    //       H-first: element offset of the tapped row inside tmp
+    auto y_offset = [&](int row) {
+      if (!vfirst) return row * rowlen;
+      if (staged) return row * LP + (int)((win_addr + (size_t)row * pitch) & 15);
+      return row * pitch;
+    };
+    if (r.flags & kRecPrefetch) {
+#pragma unroll
+      for (int i = 0; i < kPrefetchChunks; i++) {
+        const int row = (tid >> 4) + 16 * i, q = tid & 15;
+        if (row < nrows) {
+          const int sh = (int)(((uint32_t)win_addr + (uint32_t)__mul24(row, pitch)) & 15u);
+          if (q < ((sh + NB + 15) >> 4)) *reinterpret_cast<uint4 *>(stage + __mul24(row, LP) + 16 * q) = pf.chunk[i];
         }
-        // ResampleVert: 256-element tiles, 16-lane SIMD body then scalar tail
-        int fi = (ox0 + x) * C;
-        size_t cs, o = ep.Base(oy0 + y, ox0 + x, &cs);
+      }
+      {
+        const int x = tid & (TW - 1), k = tid >> tw_log2;
+        if (k < sup_x && x < tw) {
+          cx[tid] = pf.cxv;
+          xt[tid] = (ClampI(pf.xiv + k, 0, ex) - x_lo) * C;
+        }
+      }
+      {
+        const int y = tid & (TH - 1), k = tid >> th_log2;
+        if (k < sup_y && y < th) {
+          cy[y * sup_y + k] = pf.cyv;
+          yt[y * sup_y + k] = y_offset(ClampI(pf.yiv + k, 0, ey) - y_lo);
+        }
+      }
+    } else {
+      GI32 *xi = (GI32 *)tab, *yi = (GI32 *)tab + r.out_w + r.out_w * sup_x;
+      GF32 *xc = (GF32 *)(tab + r.out_w), *yc = (GF32 *)(tab + r.out_w + r.out_w * sup_x + r.out_h);
+      for (int i = tid; i < TW * sup_x; i += kResampleThreads) {
+        const int x = i & (TW - 1), k = i >> tw_log2;
+        if (x < tw) {
+          cx[i] = xc[(size_t)(ox0 + x) * sup_x + k];
+          xt[i] = (ClampI(xi[ox0 + x] + k, 0, ex) - x_lo) * C;
+        }
+      }
+      for (int i = tid; i < TH * sup_y; i += kResampleThreads) {
+        const int y = i & (TH - 1), k = i >> th_log2;
+        if (y < th) {
+          cy[y * sup_y + k] = yc[(size_t)(oy0 + y) * sup_y + k];
+          yt[y * sup_y + k] = y_offset(ClampI(yi[oy0 + y] + k, 0, ey) - y_lo);
+        }
+      }
+      if (staged) {  // 16-byte coalesced loads, each row keeps its own alignment shift
+        for (int row = tid >> 4; row < nrows; row += kResampleThreads / 16) {
+          const uintptr_t ra = win_addr + (size_t)row * pitch;
+          const int sh = (int)(ra & 15), nch = (sh + NB + 15) >> 4;
+          for (int q = tid & 15; q < nch; q += 16)
+            *reinterpret_cast<uint4 *>(stage + row * LP + 16 * q) = LoadChunk(ra - sh + 16 * q, (uintptr_t)r.buf_lo, (uintptr_t)r.buf_hi);
+        }
+      }
+    }
+    if (use_lut && lut_desc != r.desc_idx) {   // a new sample: its normalisation look-up table
+      const int words = C * 128;
+      GU32 *src = tab + (r.out_w + r.out_w * sup_x + r.out_h + r.out_h * sup_y);
+      uint32_t *dst = reinterpret_cast<uint32_t *>(lut);
+      for (int i = tid; i < words; i += kResampleThreads) dst[i] = src[i];
+      lut_desc = r.desc_idx;
+    }
+    // ---- the next tile's record and loads: in flight during this tile's passes ----
+    TileRec rn = r;
+    if (tile + 1 < t_end) {
+      rn = recs[tile + 1];
+      FetchTile(rn, tid, pf);
+    }
+    LdsBarrier();
+
+    Epilogue ep;
+    ep.out = d.out; ep.out_h = d.out_h; ep.out_w = d.out_w; ep.channels = C;
+    ep.dtype = d.out_dtype; ep.layout = d.out_layout; ep.normalize = d.normalize; ep.mirror = d.mirror;
+    ep.lut = use_lut ? lut : nullptr;
+    const float mean0 = d.mean[0], mean1 = d.mean[1], mean2 = d.mean[2], mean3 = d.mean[3];
+    const float inv0 = d.inv_std[0], inv1 = d.inv_std[1], inv2 = d.inv_std[2], inv3 = d.inv_std[3];
+    GBytes *gwin = (GBytes *)win_addr;  // source rows when the window is not staged
+
+    if (vfirst) {
+      // ================= vertical pass (window rows -> tmp[th][NB]), then horizontal =================
+      if (staged && (pitch & 3) == 0) {
+        // every row has the same shift modulo 4: produce 4 consecutive elements from one LDS dword per tap; the
+        // (row, dword) items are spread evenly over the threads
+        const int s4 = (int)(win_addr & 3);
+        const int ndw = (NB + s4 + 3) >> 2;
+        const float inv_ndw = 1.0f / (float)ndw;
+        for (int item = tid; item < th * ndw; item += kResampleThreads) {
+          const int y = (int)(((float)item + 0.5f) * inv_ndw);   // exact: item < 2^16
+          const int j = item - y * ndw;
+          const float *co = cy + y * sup_y;
+          const int *ro = yt + y * sup_y;
+          floatx2 a01 = {0.0f, 0.0f}, a23 = {0.0f, 0.0f};
+          const uint8_t *col = stage + 4 * j - s4;
+          for (int k = 0; k < sup_y; k++) {
+            const uint32_t v = *reinterpret_cast<const uint32_t *>(col + ro[k]);
+            const float w = co[k];
+            a01 += floatx2{(float)(v & 255), (float)((v >> 8) & 255)} * w;
+            a23 += floatx2{(float)((v >> 16) & 255), (float)(v >> 24)} * w;
+          }
+          float *trow = tmp + y * NB;
+          const int e = 4 * j - s4;
+          if (e >= 0 && e + 3 < NB) {
+            trow[e] = a01.x; trow[e + 1] = a01.y; trow[e + 2] = a23.x; trow[e + 3] = a23.y;
+          } else {
+            if (e >= 0 && e < NB) trow[e] = a01.x;
+            if (e + 1 >= 0 && e + 1 < NB) trow[e + 1] = a01.y;
+            if (e + 2 >= 0 && e + 2 < NB) trow[e + 2] = a23.x;
+            if (e + 3 >= 0 && e + 3 < NB) trow[e + 3] = a23.y;
+          }
+        }
+      } else {
+        for (int y = tid >> 6; y < th; y += kResampleThreads / 64) {
+          const float *co = cy + y * sup_y;
+          const int *ro = yt + y * sup_y;
+          for (int e = tid & 63; e < NB; e += 64) {
+            float a = 0;
+            if (staged) {
+              for (int k = 0; k < sup_y; k++) a += (float)stage[ro[k] + e] * co[k];
+            } else {
+              for (int k = 0; k < sup_y; k++) a += (float)gwin[ro[k] + e] * co[k];
+            }
+            tmp[y * NB + e] = a;
+          }
+        }
+      }
+      LdsBarrier();
+      const int x = tid & (TW - 1);
+      if (x < tw) {
+        const float *co = cx + x;
+        const int *xo = xt + x;
+        const int gx = ox0 + x;
+        const bool even = (d.even_mask[(gx >> 5) & 7] >> (gx & 31)) & 1;
+        for (int y = tid >> tw_log2; y < th; y += kResampleThreads >> tw_log2) {
+          const float *trow = tmp + y * NB;
+          float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+          if (C == 3) {  // the common case without the per-tap channel tests
+            for (int k = 0; k < sup_x; k++) {
+              const float w = co[k * TW];
+              const float *p = trow + xo[k * TW];
+              a0 += w * p[0];
+              a1 += w * p[1];
+              a2 += w * p[2];
+            }
+          } else {
+            for (int k = 0; k < sup_x; k++) {
+              float w = co[k * TW];
+              const float *p = trow + xo[k * TW];
+              a0 += w * p[0];
+              if (C > 1) a1 += w * p[1];
+              if (C > 2) a2 += w * p[2];
+              if (C > 3) a3 += w * p[3];
+            }
+          }
+          size_t cs, o = ep.Base(oy0 + y, gx, &cs);
+          ep.Store(o, 0, RoundU8(a0, even), mean0, inv0);
+          if (C > 1) ep.Store(o + cs, 1, RoundU8(a1, even), mean1, inv1);
+          if (C > 2) ep.Store(o + 2 * cs, 2, RoundU8(a2, even), mean2, inv2);
+          if (C > 3) ep.Store(o + 3 * cs, 3, RoundU8(a3, even), mean3, inv3);
+        }
+      }
+    } else {
+      // ================= horizontal pass (window rows -> tmp[nrows][tw*C]), then vertical =================
+      const int x = tid & (TW - 1);
+      if (x < tw) {
+        const float *co = cx + x;
+        const int *xo = xt + x;
+        for (int row = tid >> tw_log2; row < nrows; row += kResampleThreads >> tw_log2) {
+          float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+          if (staged) {
+            const uint8_t *srow = stage + row * LP + (int)((win_addr + (size_t)row * pitch) & 15);
+            for (int k = 0; k < sup_x; k++) {
+              float w = co[k * TW];
+              const uint8_t *p = srow + xo[k * TW];
+              a0 += w * (float)p[0];
+              if (C > 1) a1 += w * (float)p[1];
+              if (C > 2) a2 += w * (float)p[2];
+              if (C > 3) a3 += w * (float)p[3];
+            }
+          } else {
+            GBytes *srow = gwin + (size_t)row * pitch;
+            for (int k = 0; k < sup_x; k++) {
+              float w = co[k * TW];
+              GBytes *p = srow + xo[k * TW];
+              a0 += w * (float)p[0];
+              if (C > 1) a1 += w * (float)p[1];
+              if (C > 2) a2 += w * (float)p[2];
+              if (C > 3) a3 += w * (float)p[3];
+            }
+          }
+          float *tp = tmp + row * rowlen + x * C;
+          tp[0] = a0;
+          if (C > 1) tp[1] = a1;
+          if (C > 2) tp[2] = a2;
+          if (C > 3) tp[3] = a3;
+        }
+      }
+      LdsBarrier();
+      const int flat_w = d.out_w * C;
+      if (x < tw) {
+        for (int y = tid >> tw_log2; y < th; y += kResampleThreads >> tw_log2) {
+          const float *co = cy + y * sup_y;
+          const int *ro = yt + y * sup_y;
+          const float *tcol = tmp + x * C;
+          float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+          for (int k = 0; k < sup_y; k++) {
+            float w = co[k];
+            const float *p = tcol + ro[k];
+            a0 += p[0] * w;
+            if (C > 1) a1 += p[1] * w;
+            if (C > 2) a2 += p[2] * w;
+            if (C > 3) a3 += p[3] * w;
+          }
+          // ResampleVert: 256-element tiles, 16-lane SIMD body then scalar tail
+          int fi = (ox0 + x) * C;
+          size_t cs, o = ep.Base(oy0 + y, ox0 + x, &cs);
 #define VLAST_EVEN(f) ((f) < ((f) & ~255) + ((min(((f) & ~255) + 256, flat_w) - ((f) & ~255)) & ~15))
-        ep.Store(o, 0, RoundU8(a0, VLAST_EVEN(fi)), mean0, inv0);
-        if (C > 1) ep.Store(o + cs, 1, RoundU8(a1, VLAST_EVEN(fi + 1)), mean1, inv1);
-        if (C > 2) ep.Store(o + 2 * cs, 2, RoundU8(a2, VLAST_EVEN(fi + 2)), mean2, inv2);
-        if (C > 3) ep.Store(o + 3 * cs, 3, RoundU8(a3, VLAST_EVEN(fi + 3)), mean3, inv3);
+          ep.Store(o, 0, RoundU8(a0, VLAST_EVEN(fi)), mean0, inv0);
+          if (C > 1) ep.Store(o + cs, 1, RoundU8(a1, VLAST_EVEN(fi + 1)), mean1, inv1);
+          if (C > 2) ep.Store(o + 2 * cs, 2, RoundU8(a2, VLAST_EVEN(fi + 2)), mean2, inv2);
+          if (C > 3) ep.Store(o + 3 * cs, 3, RoundU8(a3, VLAST_EVEN(fi + 3)), mean3, inv3);
 #undef VLAST_EVEN
+        }
       }
     }
+    LdsBarrier();   // everyone is done with this tile's LDS before the next one's data lands there
+    r = rn;
   }
 }
 
@@ -634,7 +791,7 @@ static int SetupOne(const daliamdResampleArgs &a, daliamdResampleDesc &d, int in
   // tile selection: keep tables + staged source window + tmp inside the LDS budget.  When even small tiles
   // cannot hold their source window (extreme down-scaling) fall back to reading the source from global memory.
   auto lds_need = [&](int tw_, int th_, bool staged) -> size_t {
-    size_t tables = 2 * ((size_t)th_ * d.support[1] + (size_t)tw_ * d.support[0]) + (d.use_lut ? a.channels * 128 : 0);
+    size_t tables = 2 * ((size_t)th_ * d.support[1] + (size_t)tw_ * d.support[0]);
     size_t ncols = (size_t)std::ceil(tw_ * std::abs(d.scale[0])) + d.support[0] + 2;
     size_t nrows = (size_t)std::ceil(th_ * std::abs(d.scale[1])) + d.support[1] + 2;
     ncols = std::min<size_t>(ncols, a.in_w);
@@ -642,7 +799,7 @@ static int SetupOne(const daliamdResampleArgs &a, daliamdResampleDesc &d, int in
     size_t lp = (ncols * a.channels + 15 + 15) & ~(size_t)15;
     size_t stage = staged ? nrows * lp : 0;
     size_t tmp_elems = d.first_axis == 1 ? (size_t)th_ * ncols * a.channels : nrows * (size_t)tw_ * a.channels;
-    return tables * 4 + 16 + stage + tmp_elems * 4;
+    return kLutLdsBytes + tables * 4 + 16 + stage + tmp_elems * 4;
   };
   auto shrink = [&](int &tw_, int &th_, bool staged, int min_area, size_t budget) {
     tw_ = 32; th_ = 16;
@@ -696,7 +853,8 @@ daliamdResult_t daliamdResampleSetup(const daliamdResampleArgs *args, int n, dal
   }
   *num_workgroups = wg;
   *lds_bytes = lds;
-  *workspace_bytes = ws;
+  // ... and behind the tables one 128-byte record per tile
+  *workspace_bytes = ((ws + 127) & ~(size_t)127) + (size_t)wg * sizeof(daliamd::TileRec);
   *table_entries = entries;
   return DALIAMD_SUCCESS;
 }
@@ -709,17 +867,22 @@ daliamdResult_t daliamdResampleRun(daliamdStream_t stream, const daliamdResample
                   DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdResampleRun: invalid argument");
   DALIAMD_REQUIRE(workspace_dev && workspace_bytes > 0 && table_entries > 0, DALIAMD_ERROR_INVALID_ARGUMENT,
                   "daliamdResampleRun: the table workspace is missing (size it with daliamdResampleSetup)");
+  const size_t rec_bytes = (size_t)num_workgroups * sizeof(daliamd::TileRec);
+  DALIAMD_REQUIRE(workspace_bytes >= rec_bytes, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdResampleRun: workspace too small");
+  const size_t tile_rec_off = workspace_bytes - rec_bytes;   // as laid out by Setup
   {
     daliamd::KernelTimer timer("ResampleTablesKernel", (hipStream_t)stream);
-    hipLaunchKernelGGL(daliamd::ResampleTablesKernel, dim3((table_entries + daliamd::kTableThreads - 1) / daliamd::kTableThreads),
-                       dim3(daliamd::kTableThreads), 0, (hipStream_t)stream, descs_dev, n, table_entries,
-                       static_cast<uint8_t *>(workspace_dev));
+    const int total = table_entries + num_workgroups;
+    hipLaunchKernelGGL(daliamd::ResampleTablesKernel, dim3((total + daliamd::kTableThreads - 1) / daliamd::kTableThreads),
+                       dim3(daliamd::kTableThreads), 0, (hipStream_t)stream, descs_dev, n, table_entries, num_workgroups,
+                       static_cast<uint8_t *>(workspace_dev), tile_rec_off);
   }
   {
     daliamd::KernelTimer timer("ResampleKernel", (hipStream_t)stream);
-    hipLaunchKernelGGL(daliamd::ResampleKernel, dim3(daliamd::XcdGrid(num_workgroups)),
-                       dim3(daliamd::kResampleThreads), lds_bytes, (hipStream_t)stream, descs_dev, n,
-                       num_workgroups, static_cast<const uint8_t *>(workspace_dev));
+    const int wgs = (num_workgroups + daliamd::kTilesPerWg - 1) / daliamd::kTilesPerWg;
+    hipLaunchKernelGGL(daliamd::ResampleKernel, dim3(daliamd::XcdGrid(wgs)), dim3(daliamd::kResampleThreads), lds_bytes,
+                       (hipStream_t)stream, descs_dev, n, wgs, num_workgroups, static_cast<const uint8_t *>(workspace_dev),
+                       tile_rec_off);
   }
   DALIAMD_HIP_CHECK(hipGetLastError());
   return DALIAMD_SUCCESS;

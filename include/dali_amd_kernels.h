@@ -306,9 +306,10 @@ typedef struct {
 } daliamdResampleDesc;
 
 /* Fills descs_host[0..n); returns the grid size and the dynamic LDS bytes the launch needs. */
-/* workspace_bytes / table_entries (out): size of the device scratch Run needs for the per-sample tables, and the number
- * of table entries it computes; the workspace is written by Run's first kernel and read by its second one, so one
- * buffer per stream (or per iteration in flight) is enough. */
+/* num_workgroups (out): tiles of the batch (the resampling kernel takes a few consecutive tiles per workgroup).
+ * workspace_bytes / table_entries (out): size of the device scratch Run needs - the per-sample tables and one 128-byte
+ * record per tile - and the number of per-sample table entries; the workspace is written by Run's first kernel and
+ * read by its second one, so one buffer per stream (or per iteration in flight) is enough. */
 DALIAMD_API daliamdResult_t daliamdResampleSetup(const daliamdResampleArgs *args, int n, daliamdResampleDesc *descs_host,
                                                 int *num_workgroups, int *lds_bytes, size_t *workspace_bytes,
                                                 int *table_entries);
