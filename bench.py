@@ -63,7 +63,8 @@ def measured_traffic(kernel, workload=""):
         return None, None
     try:
         ks = json.load(open(files[-1]))["kernels"]
-        k = ks.get(kernel) or next((v for n, v in ks.items() if n.startswith(kernel)), {})
+        norm = lambda n: n.split("<")[0].replace("Fast", "")   # SpectrogramFastKernel<9, 4> is the SpectrogramKernel launch
+        k = ks.get(kernel) or next((v for n, v in ks.items() if norm(n) == norm(kernel)), {})
         return k.get("hbm_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
     except (OSError, ValueError, KeyError):
         return None, None

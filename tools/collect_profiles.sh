@@ -1,18 +1,32 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence behind bench.py's numbers on the GPU box (run through gpurun from the repo root):
-#   1. kernel trace + stats of the default bench command                       -> gpurun_out/prof_<tag>/stats
+#   per workload (headline, heavy_aug = configs[2], audio = configs[3]):
+#   1. kernel trace + stats of the bench command                              -> gpurun_out/prof_<tag>/<workload>/stats
 #   2. FETCH_SIZE and WRITE_SIZE in two separate --pmc passes (MI355X_MICROARCH.md: they do not fit in one pass;
-#      no sys/hip/hsa trace domains together with --pmc)                      -> gpurun_out/prof_<tag>/pmc_*
+#      no sys/hip/hsa trace domains together with --pmc)                      -> gpurun_out/prof_<tag>/<workload>/pmc_*
+#   3. the plain bench line (no profiler attached)                            -> gpurun_out/<tag>_summary/<tag>_<workload>_bench.json
 # then tools/summarize_profiles.py turns the CSVs into the small files committed under profiles/.
 set -u
 TAG=${1:-r01}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/prof_$TAG
-mkdir -p $OUT
+SUM=$R/gpurun_out/${TAG}_summary
+mkdir -p $SUM
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 20 --warmup 3 --no-cpu-baseline --no-e2e"
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
-for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-e2e --inflight 1 > /dev/null 2> $OUT/pmc_$C.log
+for W in headline heavy_aug audio; do
+  OUT=$R/gpurun_out/prof_$TAG/$W
+  mkdir -p $OUT
+  if [ $W = headline ]; then
+    ARGS="--steps 20 --warmup 3 --no-cpu-baseline --no-e2e"; PMCARGS="--steps 5 --warmup 1 --no-cpu-baseline --no-e2e --inflight 1"; SUF=""
+  else
+    ARGS="--workload $W --steps 20 --warmup 3"; PMCARGS="--workload $W --steps 5 --warmup 1"; SUF="_$W"
+  fi
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
+  for C in FETCH_SIZE WRITE_SIZE; do
+    timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -- python $R/bench.py $PMCARGS > /dev/null 2> $OUT/pmc_$C.log
+  done
+  python $R/tools/summarize_profiles.py $OUT $TAG$SUF $SUM
+  if [ $W != headline ]; then
+    (cd $R && timeout 300 python bench.py --workload $W 2>/dev/null | tail -1 > $SUM/${TAG}_${W}_bench.json)
+  fi
 done
-python $R/tools/summarize_profiles.py $OUT $TAG
+ls -la $SUM

@@ -16,7 +16,7 @@ from collections import defaultdict
 out_dir, tag = sys.argv[1], sys.argv[2]
 repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prof = os.path.join(out_dir if os.path.isabs(out_dir) else os.path.join(repo, out_dir))
-dst = os.path.join(repo, "gpurun_out", f"{tag}_summary")
+dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(repo, "gpurun_out", f"{tag}_summary")
 os.makedirs(dst, exist_ok=True)
 
 
