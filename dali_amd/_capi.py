@@ -175,7 +175,8 @@ _KERNEL_SYMBOLS = [
     "daliamdWarpAffineSetup", "daliamdWarpAffineRun", "daliamdGaussianWindow", "daliamdGaussianBlurSetup",
     "daliamdGaussianBlurRun", "daliamdColorTwistMatrix", "daliamdPointwiseSetup", "daliamdPointwiseRun",
     "daliamdHannWindow", "daliamdSpectrogramTwiddles", "daliamdSpectrogramSetup", "daliamdSpectrogramRun", "daliamdMelFilterBankWeights",
-    "daliamdMelFilterBankBands", "daliamdMelFilterBankSetup", "daliamdMelFilterBankRun", "daliamdToDecibelsSetup", "daliamdToDecibelsRun",
+    "daliamdMelFilterBankBands", "daliamdMelFilterBankSetup", "daliamdMelFilterBankRun", "daliamdToDecibelsSetup", "daliamdToDecibelsRun", "daliamdDctTable", "daliamdLifterCoeffs", "daliamdDctRun",
+    "daliamdAudioResampleLobes", "daliamdAudioResampleWindow", "daliamdAudioResampleSetup", "daliamdAudioResampleRun",
     "daliamdNormalizeSetup", "daliamdNormalizeRun",
 ]
 

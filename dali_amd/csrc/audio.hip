@@ -511,7 +511,7 @@ constexpr int kMelThreads = 64 * kMelWaves;
 
 __global__ __launch_bounds__(kMelThreads) void MelKernel(const daliamdMelDesc *__restrict__ descs, int ndesc, int total_wg,
                                                          const float *__restrict__ W, const int32_t *__restrict__ bands,
-                                                         int nfilter, int K) {
+                                                         const float *__restrict__ row_scale, int nfilter, int K) {
   int wg = XcdRemap(blockIdx.x, total_wg);
   if (wg < 0) return;
   const daliamdMelDesc &d = descs[FindDesc(descs, ndesc, wg)];
@@ -535,6 +535,7 @@ __global__ __launch_bounds__(kMelThreads) void MelKernel(const daliamdMelDesc *_
       acc = fmaf(w[k + 3], s3, acc);
     }
     for (; k < ke; k++) acc = fmaf(w[k], S[(size_t)k * T], acc);
+    if (row_scale) acc = ((GFloat *)row_scale)[m] * acc;   // DCT liftering: coefficient * sum, like ApplyLifter
     if (ok) out[(size_t)m * T + col] = acc;
   }
 }
@@ -588,6 +589,55 @@ __global__ __launch_bounds__(kDbThreads) void DecibelKernel(const daliamdDecibel
   const int64_t i0 = (int64_t)(wg - d.wg_start) * kDbChunk;
   const int64_t i1 = min(i0 + kDbChunk, d.size);
   for (int64_t i = i0 + tid; i < i1; i += kDbThreads) out[i] = mul_log2 * log2f(fmaxf(min_ratio, in[i] * inv));
+}
+
+// =============================================================================================
+// audio resampling: windowed sinc (Hann envelope), window coefficients from a table with linear interpolation
+// (dali/kernels/signal/resampling.h:33-106, resampling_cpu.cc:129-172).  A workgroup is one of the reference's blocks of
+// 256 outputs: the block's start is computed in double, the position inside it by repeated float additions of the
+// step - every thread replays that chain up to its own output, like the reference's loop does.
+// =============================================================================================
+constexpr int kRsThreads = 256;
+
+__global__ __launch_bounds__(kRsThreads) void AudioResampleKernel(const daliamdAudioResampleDesc *__restrict__ descs, int ndesc,
+                                                                  int total_wg, const float *__restrict__ lookup_g,
+                                                                  int lookup_size, float wscale, float wcenter, int lobes) {
+  extern __shared__ float rs_lookup[];
+  int wg = XcdRemap(blockIdx.x, total_wg);
+  if (wg < 0) return;
+  const daliamdAudioResampleDesc &d = descs[FindDesc(descs, ndesc, wg)];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < lookup_size; i += kRsThreads) rs_lookup[i] = ((GFloat *)lookup_g)[i];
+  __syncthreads();
+  const int64_t out_block = (int64_t)(wg - d.wg_start) * kRsThreads;
+  const int64_t out_pos = out_block + tid;
+  if (out_pos >= d.out_length) return;
+  const double scale = d.in_rate / d.out_rate;
+  const float fscale = (float)scale;
+  const double in_block_f = (double)out_block * scale;
+  const int64_t in_block_i = (int64_t)floor(in_block_f);
+  float in_pos = (float)(in_block_f - (double)in_block_i);
+  for (int j = 0; j < tid; j++) in_pos += fscale;
+  const int xc = (int)ceilf(in_pos);
+  int i0 = xc - lobes, i1 = xc + lobes;
+  if (i0 + in_block_i < 0) i0 = (int)-in_block_i;
+  if (i1 + in_block_i > d.in_length) i1 = (int)(d.in_length - in_block_i);
+  const int C = d.channels;
+  GFloat *in = (GFloat *)d.in + in_block_i * C;
+  GOutFloat *out = (GOutFloat *)d.out + out_pos * C;
+  for (int c = 0; c < C; c++) {
+    float f = 0.0f;
+    float x = (float)i0 - in_pos;
+    for (int i = i0; i < i1; i++, x += 1.0f) {
+      const float fi = x * wscale + wcenter;
+      const float fl = floorf(fi);
+      const float di = fi - fl;
+      const int li = (int)fl;
+      const float w = rs_lookup[li] + di * (rs_lookup[li + 1] - rs_lookup[li]);
+      f += in[(int64_t)i * C + c] * w;
+    }
+    out[c] = f;
+  }
 }
 
 // host: mel scales (mel_scale.h:27-73), all in double
@@ -775,7 +825,7 @@ daliamdResult_t daliamdMelFilterBankRun(daliamdStream_t stream, const daliamdMel
   {
     daliamd::KernelTimer timer("MelKernel", (hipStream_t)stream);
     hipLaunchKernelGGL(MelKernel, dim3(XcdGrid(nwg)), dim3(kMelThreads), 0, (hipStream_t)stream, descs_dev, n, nwg, W, bands_dev,
-                       nfilter, nbins);
+                       (const float *)nullptr, nfilter, nbins);
   }
   DALIAMD_HIP_CHECK(hipGetLastError());
   return DALIAMD_SUCCESS;
@@ -810,6 +860,132 @@ daliamdResult_t daliamdToDecibelsRun(daliamdStream_t stream, daliamdDecibelDesc 
     daliamd::KernelTimer timer("DecibelKernel", (hipStream_t)stream);
     hipLaunchKernelGGL(DecibelKernel, dim3(XcdGrid(nwg)), dim3(kDbThreads), 0, (hipStream_t)stream, descs_dev, n, nwg, mul_log2,
                        reference, min_ratio);
+  }
+  DALIAMD_HIP_CHECK(hipGetLastError());
+  return DALIAMD_SUCCESS;
+}
+
+// ---- DCT (MFCC): out[k][t] = lifter[k] * sum_n table[k][n] * in[n][t] ----
+static double DctEntry(int type, bool normalize, int64_t n_in, int64_t k, int64_t n) {  // dct/table.h:26-96
+  switch (type) {
+    case 1: {
+      if (n == 0) return 0.5;
+      if (n == n_in - 1) return k % 2 == 0 ? 0.5 : -0.5;
+      return std::cos(M_PI / (n_in - 1) * k * n);
+    }
+    case 2: {
+      double f = 1;
+      if (normalize) f = k == 0 ? 1.0 / std::sqrt((double)n_in) : std::sqrt(2.0 / n_in);
+      return f * std::cos(M_PI / n_in * (n + 0.5) * k);
+    }
+    case 3: {
+      double f0 = 0.5, fi = 1;
+      if (normalize) { fi = std::sqrt(2.0 / n_in); f0 = 1.0 / std::sqrt((double)n_in); }
+      return n == 0 ? f0 : fi * std::cos(M_PI / n_in * n * (k + 0.5));
+    }
+    default: {
+      double f = normalize ? std::sqrt(2.0 / n_in) : 1.0;
+      return f * std::cos(M_PI / n_in * (n + 0.5) * (k + 0.5));
+    }
+  }
+}
+
+daliamdResult_t daliamdDctTable(int dct_type, int normalize, int n_in, int ndct, float *table) {
+  DALIAMD_REQUIRE(table && n_in > 0 && ndct > 0 && ndct <= n_in, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdDctTable: invalid argument");
+  DALIAMD_REQUIRE(dct_type >= 1 && dct_type <= 4, DALIAMD_ERROR_INVALID_ARGUMENT, "Unsupported DCT type: %d. Supported types are: 1, 2, 3, 4", dct_type);
+  DALIAMD_REQUIRE(dct_type != 1 || n_in > 1, DALIAMD_ERROR_INVALID_ARGUMENT, "DCT type I requires an input length > 1");
+  if (dct_type == 1) normalize = 0;  // not defined for type I: ignored, like the reference (dct_cpu.cc:48-54)
+  for (int k = 0; k < ndct; k++)
+    for (int n = 0; n < n_in; n++) table[(size_t)k * n_in + n] = (float)DctEntry(dct_type, normalize != 0, n_in, k, n);
+  return DALIAMD_SUCCESS;
+}
+
+void daliamdLifterCoeffs(float lifter, int n, float *coeffs) {  // mfcc.h:43-48
+  const float ampl_mult = lifter / 2;
+  const float phase_mult = static_cast<float>(M_PI) / lifter;
+  for (int i = 0; i < n; i++) coeffs[i] = lifter == 0.0f ? 1.0f : 1.f + ampl_mult * std::sin(phase_mult * (i + 1));
+}
+
+daliamdResult_t daliamdDctRun(daliamdStream_t stream, const daliamdMelDesc *descs_dev, int n, int nwg, const float *table_dev,
+                              const float *lifter_dev, int ndct, int n_in) {
+  if (n == 0 || nwg == 0) return DALIAMD_SUCCESS;
+  DALIAMD_REQUIRE(descs_dev && table_dev && ndct > 0 && n_in > 0, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdDctRun: invalid argument");
+  {
+    daliamd::KernelTimer timer("DctKernel", (hipStream_t)stream);
+    hipLaunchKernelGGL(MelKernel, dim3(XcdGrid(nwg)), dim3(kMelThreads), 0, (hipStream_t)stream, descs_dev, n, nwg, table_dev,
+                       (const int32_t *)nullptr, lifter_dev, ndct, n_in);
+  }
+  DALIAMD_HIP_CHECK(hipGetLastError());
+  return DALIAMD_SUCCESS;
+}
+
+// ---- audio resampling ----
+static double SincD(double x) {  // include/dali/core/math_util.h:179-185
+  x *= M_PI;
+  if (std::abs(x) < 1e-8) return 1.0 - x * x * (1.0 / 6);
+  return std::sin(x) / x;
+}
+static float SincF(float x) {   // math_util.h:188-194 (the float overload is the one windowed_sinc calls)
+  x *= (float)M_PI;
+  if (std::abs(x) < 1e-5f) return 1.0f - x * x * (1.0f / 6);
+  return std::sin(x) / x;
+}
+
+int daliamdAudioResampleLobes(float quality) {  // resampling_params.h:27-30
+  return (int)std::round(0.007 * quality * quality - 0.09 * quality + 3);
+}
+
+daliamdResult_t daliamdAudioResampleWindow(int lobes, float *lookup, int lookup_capacity, int *lookup_size, float *scale,
+                                           float *center) {
+  DALIAMD_REQUIRE(lookup && lookup_size && scale && center && lobes > 0, DALIAMD_ERROR_INVALID_ARGUMENT,
+                  "daliamdAudioResampleWindow: invalid argument");
+  const int coeffs = lobes * 64 + 1;  // ResamplingParams::FromQuality
+  DALIAMD_REQUIRE(lookup_capacity >= coeffs + 5, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdAudioResampleWindow: %d floats needed",
+                  coeffs + 5);
+  (void)SincD;
+  // windowed_sinc (resampling.h:79-99)
+  const float wscale = 2.0f * lobes / (coeffs - 1);
+  const float scale_envelope = 2.0f / coeffs;
+  for (int i = 0; i < coeffs + 5; i++) lookup[i] = 0.0f;
+  const int c = (int)((coeffs - 1) * 0.5f);
+  for (int i = 0; i < coeffs; i++) {
+    float x = (i - c) * wscale;
+    float y = (i - c) * scale_envelope;
+    float w = (float)(SincF(x) * (0.5 * (1 + std::cos((double)y * M_PI))));
+    lookup[i + 1] = w;
+  }
+  *lookup_size = coeffs + 5;
+  *center = (float)(c + 1);
+  *scale = 1 / wscale;
+  return DALIAMD_SUCCESS;
+}
+
+daliamdResult_t daliamdAudioResampleSetup(daliamdAudioResampleDesc *descs, int n, int *nwg) {
+  DALIAMD_REQUIRE(descs && nwg && n >= 0, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdAudioResampleSetup: NULL argument");
+  int wg = 0;
+  for (int i = 0; i < n; i++) {
+    auto &d = descs[i];
+    DALIAMD_REQUIRE(d.in_length >= 0 && d.out_length >= 0 && d.channels >= 1, DALIAMD_ERROR_INVALID_ARGUMENT,
+                    "daliamdAudioResampleSetup: sample %d has an invalid shape", i);
+    DALIAMD_REQUIRE(d.in_rate > 0 && d.out_rate > 0, DALIAMD_ERROR_INVALID_ARGUMENT, "Sampling rate must be positive");
+    d.wg_start = wg;
+    wg += (int)((d.out_length + kRsThreads - 1) / kRsThreads);
+  }
+  *nwg = wg;
+  return DALIAMD_SUCCESS;
+}
+
+daliamdResult_t daliamdAudioResampleRun(daliamdStream_t stream, const daliamdAudioResampleDesc *descs_dev, int n, int nwg,
+                                        const float *lookup_dev, int lookup_size, float scale, float center, int lobes) {
+  if (n == 0 || nwg == 0) return DALIAMD_SUCCESS;
+  DALIAMD_REQUIRE(descs_dev && lookup_dev && lookup_size > 0 && lobes > 0, DALIAMD_ERROR_INVALID_ARGUMENT,
+                  "daliamdAudioResampleRun: invalid argument");
+  const int lds = lookup_size * (int)sizeof(float);
+  DALIAMD_REQUIRE(lds <= 64 * 1024, DALIAMD_ERROR_UNSUPPORTED, "daliamdAudioResampleRun: the window table does not fit in LDS");
+  {
+    daliamd::KernelTimer timer("AudioResampleKernel", (hipStream_t)stream);
+    hipLaunchKernelGGL(AudioResampleKernel, dim3(XcdGrid(nwg)), dim3(kRsThreads), lds, (hipStream_t)stream, descs_dev, n, nwg,
+                       lookup_dev, lookup_size, scale, center, lobes);
   }
   DALIAMD_HIP_CHECK(hipGetLastError());
   return DALIAMD_SUCCESS;

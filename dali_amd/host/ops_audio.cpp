@@ -352,4 +352,204 @@ class ToDecibelsGpu : public OperatorBase {
 };
 DALI_REGISTER_OPERATOR(ToDecibels, ToDecibelsGpu, GPU);
 
+// =============================================================================================
+// MFCC (dali/operators/audio/mfcc/mfcc.cc:24-182): DCT along the frequency axis + liftering
+// =============================================================================================
+DALI_SCHEMA(MFCC)
+    .DocStr("Computes Mel Frequency Cepstral Coefficients (MFCC) from a mel spectrogram.")
+    .NumInput(1)
+    .NumOutput(1)
+    .AddOptionalArg("n_mfcc", "Number of MFCC coefficients.", ArgValue::Int(20))
+    .AddOptionalArg("dct_type", "Discrete Cosine Transform type (1, 2, 3 or 4, as listed in "
+                    "https://en.wikipedia.org/wiki/Discrete_cosine_transform#Formal_definition).", ArgValue::Int(2))
+    .AddOptionalArg("normalize", "If set to True, the DCT uses an ortho-normal basis (not supported for dct_type=1).",
+                    ArgValue::Bool(false))
+    .AddOptionalArg("axis", "Axis over which the transform will be applied.", ArgValue::Int(0))
+    .AddOptionalArg("lifter", "Cepstral filtering (liftering) coefficient: MFCC[i] *= 1 + sin(pi * (i + 1) / lifter) * lifter / 2; "
+                    "0 disables it.", ArgValue::Float(0.0));
+
+class MfccGpu : public OperatorBase {
+ public:
+  explicit MfccGpu(const OpSpec &spec) : OperatorBase(spec), tables_dev_(StorageDevice::GPU) {
+    n_mfcc_ = (int)spec.GetInt("n_mfcc");
+    dct_type_ = (int)spec.GetInt("dct_type");
+    normalize_ = spec.GetBool("normalize");
+    axis_ = (int)spec.GetInt("axis");
+    lifter_ = (float)spec.GetFloat("lifter");
+    DALI_ENFORCE(dct_type_ >= 1 && dct_type_ <= 4, "Unsupported DCT type: ", dct_type_, ". Supported types are: 1, 2, 3, 4");
+    DALI_ENFORCE(!(normalize_ && dct_type_ == 1), "Ortho-normalization is not supported for DCT type I.");
+  }
+  bool SetupImpl(std::vector<OutputDesc> &desc, const Workspace &ws) override {
+    const TensorList &in = ws.Input(0);
+    DALI_ENFORCE(in.type() == DALI_FLOAT, "MFCC expects float32 input");
+    int n = in.num_samples();
+    descs_.assign(n, daliamdMelDesc{});
+    desc[0].type = DALI_FLOAT;
+    desc[0].shape.resize(n);
+    for (int i = 0; i < n; i++) {
+      int ndim = (int)in.shape(i).size();
+      DALI_ENFORCE(axis_ >= 0 && axis_ < ndim, "Axis ", axis_, " is out of bounds [0,", ndim, ")");
+      DALI_ENFORCE(ndim == 2 && axis_ == 0, "MFCC (gpu) transforms the first axis of a 2-D (frequency, time) input; got ", ndim,
+                   " dimensions, axis ", axis_);
+      int nin = (int)in.shape(i)[0];
+      DALI_ENFORCE(n_in_ == 0 || nin == n_in_, "All inputs must have the same number of mel bands (got ", nin, " after ", n_in_, ")");
+      n_in_ = nin;
+      descs_[i].in = static_cast<const float *>(in.raw(i));
+      descs_[i].frames = (int)in.shape(i)[1];
+    }
+    ndct_ = n_mfcc_ <= 0 || n_mfcc_ > n_in_ ? n_in_ : n_mfcc_;  // dct_cpu.cc:56-58
+    for (int i = 0; i < n; i++) desc[0].shape[i] = {ndct_, in.shape(i)[1]};
+    return true;
+  }
+  void RunImpl(Workspace &ws) override {
+    TensorList &out = ws.Output(0);
+    out.SetLayout(ws.Input(0).layout());
+    int n = (int)descs_.size();
+    if (!n) return;
+    if (tables_n_in_ != n_in_) {
+      std::vector<float> host((size_t)ndct_ * n_in_ + ndct_);
+      KCHECK(daliamdDctTable(dct_type_, normalize_, n_in_, ndct_, host.data()));
+      daliamdLifterCoeffs(lifter_, ndct_, host.data() + (size_t)ndct_ * n_in_);
+      tables_dev_.Reserve(host.size() * sizeof(float));
+      KCHECK(daliamdMemcpyH2DAsync(tables_dev_.data(), host.data(), host.size() * sizeof(float), ws.stream));
+      KCHECK(daliamdStreamSynchronize(ws.stream));  // one-time upload from pageable memory, read by later iterations
+      tables_n_in_ = n_in_;
+    }
+    for (int i = 0; i < n; i++) descs_[i].out = static_cast<float *>(out.raw(i));
+    int nwg = 0;
+    KCHECK(daliamdMelFilterBankSetup(descs_.data(), n, &nwg));
+    auto *dev = static_cast<const daliamdMelDesc *>(uploader_.Upload(descs_.data(), n * sizeof(descs_[0]), ws.stream, ws.ring + 1));
+    const float *table = static_cast<const float *>(tables_dev_.data());
+    KCHECK(daliamdDctRun(ws.stream, dev, n, nwg, table, lifter_ != 0.0f ? table + (size_t)ndct_ * n_in_ : nullptr, ndct_, n_in_));
+    NoteLaunch(ws, "mfcc_dct");
+  }
+
+ private:
+  int n_mfcc_, dct_type_, axis_, n_in_ = 0, ndct_ = 0, tables_n_in_ = -1;
+  bool normalize_;
+  float lifter_;
+  Buffer tables_dev_;
+  std::vector<daliamdMelDesc> descs_;
+  DescUploader uploader_;
+};
+DALI_REGISTER_OPERATOR(MFCC, MfccGpu, GPU);
+
+// =============================================================================================
+// AudioResample (dali/operators/audio/resample.cc:24-140, resample.h:30-140)
+// =============================================================================================
+DALI_SCHEMA(AudioResample)
+    .DocStr("Resamples an audio signal.\n\nThe resampling is achieved by applying a sinc filter with Hann window with an extent "
+            "controlled by the `quality` argument. The resampling ratio can be specified directly or as a ratio of target to "
+            "source sampling rate, or calculated from the ratio of the requested output length to the input length.")
+    .NumInput(1)
+    .NumOutput(1)
+    .AddOptionalTypeArg("in_rate", "Input sampling rate (only the ratio to `out_rate` matters).", ArgType::FLOAT, true)
+    .AddOptionalTypeArg("out_rate", "Output sampling rate.", ArgType::FLOAT, true)
+    .AddOptionalTypeArg("scale", "The scaling factor: the ratio of the target sampling rate to the source sampling rate.",
+                        ArgType::FLOAT, true)
+    .AddOptionalTypeArg("out_length", "The requested output length, in samples.", ArgType::INT, true)
+    .AddOptionalArg("quality", "Resampling quality, where 0 is the lowest, and 100 is the highest: 0 gives 3 lobes of the sinc "
+                    "filter, 50 gives 16 lobes, and 100 gives 64 lobes.", ArgValue::Float(50.0))
+    .AddOptionalTypeArg("dtype", "The output type (float32 only on this backend).", ArgType::INT);
+DALI_SCHEMA(experimental__AudioResample).DocStr("Legacy alias for :meth:`audio_resample`.").AddParent("AudioResample").NumInput(1).NumOutput(1);
+
+class AudioResampleGpu : public OperatorBase {
+ public:
+  explicit AudioResampleGpu(const OpSpec &spec) : OperatorBase(spec), lookup_dev_(StorageDevice::GPU) {
+    auto given = [&](const char *name) { return spec.Args().count(name) != 0 || spec.HasTensorArgument(name); };
+    has_rates_ = given("in_rate") || given("out_rate");
+    has_scale_ = given("scale");
+    has_len_ = given("out_length");
+    DALI_ENFORCE(given("in_rate") == given("out_rate"),
+                 "The parameters ``in_rate`` and ``out_rate`` must be specified together.");
+    DALI_ENFORCE((int)has_rates_ + (int)has_scale_ + (int)has_len_ <= 1,
+                 "The sampling rates, ``scale`` and ``out_length`` cannot be used together.");
+    DALI_ENFORCE(has_rates_ || has_scale_ || has_len_,
+                 "No resampling factor specified! Please supply either the scale, the output length or the input and output "
+                 "sampling rates.");
+    quality_ = (float)spec.GetFloat("quality");
+    DALI_ENFORCE(quality_ >= 0 && quality_ <= 100, "``quality`` out of range: ", quality_, "\nValid range is [0..100].");
+    if (const ArgValue *d = spec.TryArg("dtype"))
+      DALI_ENFORCE(d->i == DALI_FLOAT, "AudioResample (gpu) produces float32 output only");
+  }
+  bool SetupImpl(std::vector<OutputDesc> &desc, const Workspace &ws) override {
+    const TensorList &in = ws.Input(0);
+    DALI_ENFORCE(in.type() == DALI_FLOAT, "AudioResample expects float32 input");
+    int n = in.num_samples();
+    std::vector<float> in_rate, out_rate, scale;
+    std::vector<int> out_len;
+    if (has_rates_) {
+      in_rate = GetPerSampleFloat(spec_, ws, "in_rate", n);
+      out_rate = GetPerSampleFloat(spec_, ws, "out_rate", n);
+    } else if (has_scale_) {
+      scale = GetPerSampleFloat(spec_, ws, "scale", n);
+    } else {
+      out_len = GetPerSampleInt(spec_, ws, "out_length", n);
+    }
+    descs_.assign(n, daliamdAudioResampleDesc{});
+    desc[0].type = DALI_FLOAT;
+    desc[0].shape.resize(n);
+    for (int i = 0; i < n; i++) {
+      const TensorShape &s = in.shape(i);
+      DALI_ENFORCE(s.size() == 1 || s.size() == 2,
+                   "Audio resampling supports only time series data, with an optional innermost channel dimension.");
+      auto &d = descs_[i];
+      d.in = static_cast<const float *>(in.raw(i));
+      d.in_length = s[0];
+      d.channels = s.size() == 2 ? (int)s[1] : 1;
+      if (has_rates_) {
+        DALI_ENFORCE(in_rate[i] > 0, "Input sampling rates must be positive. Got in_rate == ", in_rate[i]);
+        DALI_ENFORCE(out_rate[i] >= 0, "Output sampling rates must be non-negative. Got out_rate == ", out_rate[i]);
+        d.in_rate = in_rate[i];
+        d.out_rate = out_rate[i];
+        d.out_length = (int64_t)std::ceil(d.in_length * d.out_rate / d.in_rate);  // resampled_length, resampling.h:101-103
+      } else if (has_scale_) {
+        DALI_ENFORCE(scale[i] >= 0, "The scaling factor must be non-negative. Got scale == ", scale[i]);
+        d.in_rate = 1.0;
+        d.out_rate = scale[i];
+        d.out_length = (int64_t)std::ceil(d.in_length * d.out_rate / d.in_rate);
+      } else {
+        DALI_ENFORCE(!(d.in_length == 0 && out_len[i] != 0), "Cannot produce a non-empty signal from an empty input.\nError at sample ", i);
+        d.in_rate = d.in_length ? (double)d.in_length : 1.0;
+        d.out_rate = out_len[i] ? (double)out_len[i] : 1.0;
+        d.out_length = out_len[i];
+      }
+      if (d.out_length == 0) d.out_rate = 1.0;  // nothing to produce; keeps the kernel-side validation simple
+      desc[0].shape[i] = s.size() == 2 ? TensorShape{d.out_length, s[1]} : TensorShape{d.out_length};
+    }
+    return true;
+  }
+  void RunImpl(Workspace &ws) override {
+    TensorList &out = ws.Output(0);
+    out.SetLayout(ws.Input(0).layout());
+    int n = (int)descs_.size();
+    if (!n) return;
+    if (!lookup_size_) {
+      lobes_ = daliamdAudioResampleLobes(quality_);
+      std::vector<float> lookup((size_t)lobes_ * 64 + 1 + 5);
+      KCHECK(daliamdAudioResampleWindow(lobes_, lookup.data(), (int)lookup.size(), &lookup_size_, &wscale_, &wcenter_));
+      lookup_dev_.Reserve(lookup.size() * sizeof(float));
+      KCHECK(daliamdMemcpyH2DAsync(lookup_dev_.data(), lookup.data(), lookup.size() * sizeof(float), ws.stream));
+      KCHECK(daliamdStreamSynchronize(ws.stream));  // one-time upload from pageable memory
+    }
+    for (int i = 0; i < n; i++) descs_[i].out = static_cast<float *>(out.raw(i));
+    int nwg = 0;
+    KCHECK(daliamdAudioResampleSetup(descs_.data(), n, &nwg));
+    auto *dev = static_cast<const daliamdAudioResampleDesc *>(uploader_.Upload(descs_.data(), n * sizeof(descs_[0]), ws.stream, ws.ring + 1));
+    KCHECK(daliamdAudioResampleRun(ws.stream, dev, n, nwg, static_cast<const float *>(lookup_dev_.data()), lookup_size_, wscale_,
+                                   wcenter_, lobes_));
+    NoteLaunch(ws, "audio_resample");
+  }
+
+ private:
+  bool has_rates_, has_scale_, has_len_;
+  float quality_, wscale_ = 0, wcenter_ = 0;
+  int lobes_ = 0, lookup_size_ = 0;
+  Buffer lookup_dev_;
+  std::vector<daliamdAudioResampleDesc> descs_;
+  DescUploader uploader_;
+};
+DALI_REGISTER_OPERATOR(AudioResample, AudioResampleGpu, GPU);
+DALI_REGISTER_OPERATOR(experimental__AudioResample, AudioResampleGpu, GPU);
+
 }  // namespace daliamd_host

@@ -472,6 +472,35 @@ DALIAMD_API daliamdResult_t daliamdToDecibelsSetup(daliamdDecibelDesc *descs_hos
 DALIAMD_API daliamdResult_t daliamdToDecibelsRun(daliamdStream_t stream, daliamdDecibelDesc *descs_dev, int n,
                                                 int num_workgroups, float multiplier, float reference, float cutoff_db);
 
+/* MFCC = DCT of the mel spectrogram along the frequency axis (types I-IV as en.wikipedia.org/wiki/Discrete_cosine_transform,
+ * optional ortho-normal basis) followed by liftering: out[k][t] = lifter[k] * sum_n table[k][n] * in[n][t]
+ * (dali/operators/audio/mfcc/mfcc.cc:24-182, mfcc.h:43-48, dali/kernels/signal/dct/{table.h:26-96,dct_cpu.cc:75-110}).
+ * Descriptors / Setup: daliamdMelDesc / daliamdMelFilterBankSetup (in [n_in][frames], out [ndct][frames]). */
+DALIAMD_API daliamdResult_t daliamdDctTable(int dct_type, int normalize, int n_in, int ndct, float *table /* [ndct][n_in] */);
+DALIAMD_API void daliamdLifterCoeffs(float lifter, int n, float *coeffs);   /* 1 everywhere when lifter == 0 */
+DALIAMD_API daliamdResult_t daliamdDctRun(daliamdStream_t stream, const daliamdMelDesc *descs_dev, int n, int num_workgroups,
+                                          const float *table_dev, const float *lifter_dev /* or NULL */, int ndct, int n_in);
+
+/* Audio resampling: windowed sinc with a Hann envelope, `lobes` zero crossings on each side, coefficients looked up in a
+ * table of lobes * 64 + 1 entries with linear interpolation; output i sits at input position i * in_rate / out_rate
+ * (dali/kernels/signal/resampling.h:33-106, resampling_cpu.cc:129-172, dali/operators/audio/resample.h:60-140,
+ * resampling_params.h:27-30).  f32 time series, optionally with an innermost channel dimension. */
+typedef struct {
+  const float *in;      /* device: [in_length][channels] */
+  float *out;           /* device: [out_length][channels] */
+  int64_t in_length, out_length;
+  double in_rate, out_rate;
+  int32_t channels;
+  int32_t wg_start;     /* filled by Setup */
+} daliamdAudioResampleDesc;
+DALIAMD_API int daliamdAudioResampleLobes(float quality);   /* 0 -> 3, 50 -> 16, 100 -> 64 */
+DALIAMD_API daliamdResult_t daliamdAudioResampleWindow(int lobes, float *lookup_host, int lookup_capacity, int *lookup_size,
+                                                      float *scale, float *center);
+DALIAMD_API daliamdResult_t daliamdAudioResampleSetup(daliamdAudioResampleDesc *descs_host, int n, int *num_workgroups);
+DALIAMD_API daliamdResult_t daliamdAudioResampleRun(daliamdStream_t stream, const daliamdAudioResampleDesc *descs_dev, int n,
+                                                   int num_workgroups, const float *lookup_dev, int lookup_size, float scale,
+                                                   float center, int lobes);
+
 /* ----------------------------------------------------------------------------------------------
  * fn.normalize: out = (in - mean) * scale / stddev + shift with mean / stddev given or computed over a contiguous group
  * of axes (dali/operators/math/normalize/normalize.cc:24-123, normalize_utils.h:133-220,

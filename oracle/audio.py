@@ -196,3 +196,113 @@ def decode_wav(data):
     else:
         raise ValueError("unsupported WAV encoding")
     return (a.reshape(-1, ch) if ch > 1 else a), float(rate)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# MFCC: DCT along the first axis + liftering (dali/kernels/signal/dct/table.h:26-96, dct_cpu.cc:75-110,
+# dali/operators/audio/mfcc/mfcc.h:43-48, mfcc.cc:41-60).  The table is built in double and rounded to float like
+# the reference's; the sum runs in float64 here (the comparison is tolerance-based: the reference's own test compares
+# with librosa at 1e-3, test_mfcc.py:153).
+# ---------------------------------------------------------------------------------------------------------------
+def dct_table(dct_type, normalize, n_in, ndct):
+    k = np.arange(ndct, dtype=np.float64)[:, None]
+    n = np.arange(n_in, dtype=np.float64)[None, :]
+    if dct_type == 1:
+        t = np.cos(np.pi / (n_in - 1) * k * n)
+        t[:, 0] = 0.5
+        t[:, n_in - 1] = np.where(np.arange(ndct) % 2 == 0, 0.5, -0.5)
+    elif dct_type == 2:
+        t = np.cos(np.pi / n_in * (n + 0.5) * k)
+        if normalize:
+            t *= np.where(np.arange(ndct)[:, None] == 0, 1.0 / np.sqrt(n_in), np.sqrt(2.0 / n_in))
+    elif dct_type == 3:
+        f0, fi = (1.0 / np.sqrt(n_in), np.sqrt(2.0 / n_in)) if normalize else (0.5, 1.0)
+        t = fi * np.cos(np.pi / n_in * n * (k + 0.5))
+        t[:, 0] = f0
+    elif dct_type == 4:
+        t = (np.sqrt(2.0 / n_in) if normalize else 1.0) * np.cos(np.pi / n_in * (n + 0.5) * (k + 0.5))
+    else:
+        raise ValueError(f"Unsupported DCT type: {dct_type}")
+    return t.astype(np.float32)
+
+
+def lifter_coeffs(lifter, n):
+    if lifter == 0:
+        return np.ones(n, np.float32)
+    i = np.arange(n, dtype=np.float32)
+    return (np.float32(1) + np.float32(lifter / 2) * np.sin(np.float32(np.pi) / np.float32(lifter) * (i + 1))).astype(np.float32)
+
+
+def mfcc(mel, n_mfcc=20, dct_type=2, normalize=False, lifter=0.0):
+    """mel: float32 [n_in, T] -> float32 [ndct, T]."""
+    mel = np.asarray(mel, np.float32)
+    n_in = mel.shape[0]
+    ndct = n_in if n_mfcc <= 0 or n_mfcc > n_in else n_mfcc
+    t = dct_table(dct_type, normalize and dct_type != 1, n_in, ndct).astype(np.float64)
+    out = t @ mel.astype(np.float64)
+    return (lifter_coeffs(lifter, ndct).astype(np.float64)[:, None] * out).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Audio resampling (dali/kernels/signal/resampling.h:33-106, resampling_cpu.cc:129-172, resampling_params.h:27-30).
+# The window table and the positions follow the reference in float32 (the table entries, the block start in double,
+# the position inside a block of 256 outputs by repeated float additions); the filter sum runs in float64.
+# ---------------------------------------------------------------------------------------------------------------
+def resample_lobes(quality):
+    return int(round(0.007 * quality * quality - 0.09 * quality + 3))
+
+
+def resample_window(lobes):
+    coeffs = lobes * 64 + 1
+    scale = np.float32(2.0 * lobes / (coeffs - 1))
+    scale_env = np.float32(2.0 / coeffs)
+    center = int((coeffs - 1) * 0.5)
+    i = np.arange(coeffs, dtype=np.float32)
+    x = ((i - center) * scale).astype(np.float32)
+    y = ((i - center) * scale_env).astype(np.float32)
+    xp = (x * np.float32(np.pi)).astype(np.float32)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        sinc = np.where(np.abs(xp) < 1e-5, np.float32(1) - xp * xp * np.float32(1.0 / 6), np.sin(xp) / xp).astype(np.float32)
+    hann = 0.5 * (1 + np.cos(y.astype(np.float64) * np.pi))
+    lookup = np.zeros(coeffs + 5, np.float32)
+    lookup[1:coeffs + 1] = (sinc * hann).astype(np.float32)
+    return lookup, np.float32(1) / scale, np.float32(center + 1)
+
+
+def audio_resample(x, in_rate, out_rate, quality=50.0, out_length=None):
+    """x: float32 [L] or [L, C].  Returns float32 [ceil(L * out_rate / in_rate)(, C)]."""
+    x = np.asarray(x, np.float32)
+    squeeze = x.ndim == 1
+    if squeeze:
+        x = x[:, None]
+    n_in = x.shape[0]
+    lobes = resample_lobes(quality)
+    lookup, wscale, wcenter = resample_window(lobes)
+    n_out = int(np.ceil(n_in * out_rate / in_rate)) if out_length is None else int(out_length)
+    scale = float(in_rate) / float(out_rate)
+    fscale = np.float32(scale)
+    out = np.zeros((n_out, x.shape[1]), np.float32)
+    xd = x.astype(np.float64)
+    for out_block in range(0, n_out, 256):
+        nb = min(256, n_out - out_block)
+        in_block_f = out_block * scale
+        in_block_i = int(np.floor(in_block_f))
+        steps = np.full(nb, fscale, np.float32)
+        steps[0] = np.float32(in_block_f - in_block_i)
+        in_pos = np.add.accumulate(steps, dtype=np.float32)     # p0, p0 + fscale, (p0 + fscale) + fscale, ...
+        for j in range(nb):
+            p = in_pos[j]
+            xc = int(np.ceil(p))
+            i0, i1 = xc - lobes, xc + lobes
+            i0 = max(i0, -in_block_i)
+            i1 = min(i1, n_in - in_block_i)
+            if i1 <= i0:
+                continue
+            xs = (np.arange(i0, i1, dtype=np.float32) - p).astype(np.float32)      # i - in_pos, then x++ (exact here)
+            fi = (xs * wscale + wcenter).astype(np.float32)
+            fl = np.floor(fi)
+            di = (fi - fl).astype(np.float32)
+            li = fl.astype(np.int64)
+            w = (lookup[li] + di * (lookup[li + 1] - lookup[li])).astype(np.float32)
+            out[out_block + j] = (xd[in_block_i + i0:in_block_i + i1] * w.astype(np.float64)[:, None]).sum(0)
+    return out[:, 0] if squeeze else out

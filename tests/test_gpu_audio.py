@@ -155,3 +155,104 @@ def test_spectrogram_every_fft_size(nfft, wl, step):
             assert got.shape == ref.shape, (got.shape, ref.shape)
             err = np.abs(got - ref).max()
             assert err <= 1e-4 * ref.max() + 1e-6, (nfft, reflect, center, power, i, err, ref.max())
+
+
+def test_spectrogram_quiet_bins_relative():
+    """a bound relative to max(ref) hides errors in quiet bins.  A signal with 60 dB of dynamic range
+    across the band: every bin above a floor of 1e-6 of the maximum is held to 2e-3 relative."""
+    from dali_amd import fn
+    from dali_amd.pipeline import Pipeline
+    rng = np.random.default_rng(21)
+    n = 20000
+    t = np.arange(n) / 16000.0
+    x = (0.5 * np.sin(2 * np.pi * 440 * t) + 5e-4 * np.sin(2 * np.pi * 3000 * t) + rng.normal(0, 2e-5, n)).astype(np.float32)
+    pipe = Pipeline(batch_size=1, num_threads=1, device_id=0, prefetch_queue_depth=1)
+    with pipe:
+        s = fn.external_source(name="x")
+        pipe.set_outputs(fn.spectrogram(s.gpu(), nfft=1024, window_length=1024, window_step=256, power=2))
+    pipe.feed_input("x", [x])
+    (spec,) = pipe.run()
+    got = spec[0].as_cpu().astype(np.float64)
+    ref = A.spectrogram(x, nfft=1024, window_length=1024, window_step=256, power=2).astype(np.float64)
+    loud = ref > 1e-6 * ref.max()
+    assert loud.mean() > 0.02
+    rel = np.abs(got[loud] - ref[loud]) / ref[loud]
+    assert rel.max() <= 2e-3, rel.max()
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(n_mfcc=13, dct_type=2, normalize=True, lifter=22.0),
+                                dict(n_mfcc=40, dct_type=3), dict(n_mfcc=8, dct_type=4, normalize=True),
+                                dict(n_mfcc=10, dct_type=1, lifter=5.0), dict(n_mfcc=200)])
+def test_mfcc_matches_oracle(kw):
+    from dali_amd import fn
+    from dali_amd.pipeline import Pipeline
+    rng = np.random.default_rng(31)
+    mels = [np.abs(rng.normal(0, 1, (64, t))).astype(np.float32) for t in (1, 37, 129, 400)]
+    pipe = Pipeline(batch_size=len(mels), num_threads=1, device_id=0, prefetch_queue_depth=1)
+    with pipe:
+        m = fn.external_source(name="mel", layout="ft")
+        pipe.set_outputs(fn.mfcc(m.gpu(), **kw))
+    pipe.feed_input("mel", mels, layout="ft")
+    (out,) = pipe.run()
+    assert pipe.executed_kernels() == ["h2d_copy", "mfcc_dct"]
+    for i, mel in enumerate(mels):
+        ref = A.mfcc(mel, n_mfcc=kw.get("n_mfcc", 20), dct_type=kw.get("dct_type", 2), normalize=kw.get("normalize", False),
+                     lifter=kw.get("lifter", 0.0))
+        got = out[i].as_cpu()
+        assert got.shape == ref.shape, (got.shape, ref.shape)
+        assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), (kw, i)
+
+
+def test_mfcc_rejects_what_the_reference_rejects():
+    from dali_amd import fn
+    from dali_amd.pipeline import Pipeline
+    for kw, msg in [(dict(dct_type=5), "Unsupported DCT type"), (dict(dct_type=1, normalize=True), "not supported")]:
+        pipe = Pipeline(batch_size=1, num_threads=1, device_id=0)
+        with pipe:
+            m = fn.external_source(name="mel")
+            pipe.set_outputs(fn.mfcc(m.gpu(), **kw))
+        with pytest.raises(Exception, match=msg):
+            pipe.build()
+
+
+@pytest.mark.parametrize("kw", [dict(in_rate=44100.0, out_rate=16000.0), dict(in_rate=16000.0, out_rate=22050.0, quality=0.0),
+                                dict(scale=0.37, quality=100.0), dict(out_length=777), dict(scale=1.0)])
+def test_audio_resample_matches_oracle(kw):
+    from dali_amd import fn
+    from dali_amd.pipeline import Pipeline
+    rng = np.random.default_rng(41)
+    sigs = [rng.normal(0, 0.3, n).astype(np.float32) for n in (1, 300, 5000)]
+    sigs.append(rng.normal(0, 0.3, (2000, 2)).astype(np.float32))
+    for group in (sigs[:3], sigs[3:]):
+        pipe = Pipeline(batch_size=len(group), num_threads=1, device_id=0, prefetch_queue_depth=1)
+        with pipe:
+            s = fn.external_source(name="x")
+            pipe.set_outputs(fn.audio_resample(s.gpu(), **kw))
+        pipe.feed_input("x", group)
+        (out,) = pipe.run()
+        assert pipe.executed_kernels() == ["h2d_copy", "audio_resample"]
+        for i, x in enumerate(group):
+            if "out_length" in kw:
+                ref = A.audio_resample(x, x.shape[0], kw["out_length"], kw.get("quality", 50.0), out_length=kw["out_length"])
+            elif "scale" in kw:
+                ref = A.audio_resample(x, 1.0, float(np.float32(kw["scale"])), kw.get("quality", 50.0))
+            else:
+                ref = A.audio_resample(x, kw["in_rate"], kw["out_rate"], kw.get("quality", 50.0))
+            got = out[i].as_cpu()
+            assert got.shape == ref.shape, (got.shape, ref.shape, kw)
+            # the reference's own cpu-vs-gpu bound (test_audio_resample.py:60): mean 1e-6, max 1e-4
+            err = np.abs(got - ref)
+            assert err.max() <= 1e-4 and err.mean() <= 1e-6, (kw, i, err.max(), err.mean())
+
+
+def test_audio_resample_argument_errors():
+    from dali_amd import fn
+    from dali_amd.pipeline import Pipeline
+    for kw, msg in [(dict(), "No resampling factor"), (dict(in_rate=1.0), "must be specified together"),
+                    (dict(scale=2.0, out_length=5), "cannot be used together"), (dict(scale=1.0, quality=101.0), "out of range")]:
+        pipe = Pipeline(batch_size=1, num_threads=1, device_id=0)
+        with pipe:
+            s = fn.external_source(name="x")
+            pipe.set_outputs(fn.audio_resample(s.gpu(), **kw))
+        with pytest.raises(Exception, match=msg):
+            pipe.build()
