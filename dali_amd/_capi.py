@@ -19,7 +19,7 @@ class DaliAmdError(RuntimeError):
 # ------------------------------------------------------------------ enums
 UINT8, FLOAT16, FLOAT, INT8 = 0, 1, 2, 3
 LAYOUT_HWC, LAYOUT_CHW = 0, 1
-INTERP_NN, INTERP_LINEAR, INTERP_TRIANGULAR = 0, 1, 2
+INTERP_NN, INTERP_LINEAR, INTERP_TRIANGULAR, INTERP_CUBIC, INTERP_LANCZOS3, INTERP_GAUSSIAN = 0, 1, 2, 3, 4, 5
 JPEG_GRAY, JPEG_YCC, JPEG_RGB = 0, 1, 2
 
 
@@ -90,7 +90,7 @@ class ResampleDesc(C.Structure):
                 ("out_layout", C.c_int32), ("normalize", C.c_int32), ("mirror", C.c_int32),
                 ("mean", C.c_float * 4), ("inv_std", C.c_float * 4), ("even_mask", C.c_uint32 * 8),
                 ("lds_bytes", C.c_int32), ("staged", C.c_int32), ("table_off", C.c_int64),
-                ("tab_start", C.c_int32), ("use_lut", C.c_int32)]
+                ("tab_start", C.c_int32), ("use_lut", C.c_int32), ("filter_kind", C.c_int32 * 2)]
 
 
 class CmnDesc(C.Structure):

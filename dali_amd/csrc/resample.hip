@@ -26,7 +26,9 @@
 // algorithmic traffic = source ROI bytes + output bytes.
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include "common.h"
+#include "dali_amd_resample_filters.h"
 
 namespace daliamd {
 
@@ -221,8 +223,21 @@ __device__ void MakeTileRec(const daliamdResampleDesc *descs, int ndesc, int til
   float f0;
   const float start_x = FilterStart(d.origin[0], d.scale[0], d.fanchor[0]);
   const float start_y = FilterStart(d.origin[1], d.scale[1], d.fanchor[1]);
-  const int ix_a = FirstTap(ox0, d.scale[0], start_x, &f0), ix_b = FirstTap(ox0 + tw - 1, d.scale[0], start_x, &f0);
-  const int iy_a = FirstTap(oy0, d.scale[1], start_y, &f0), iy_b = FirstTap(oy0 + th - 1, d.scale[1], start_y, &f0);
+  int ix_a, ix_b, iy_a, iy_b;
+  if (d.filter_kind[0] == DALIAMD_FK_NN) {
+    ix_a = daliamdNearestIndex(0, ox0, d.origin[0], d.scale[0]);
+    ix_b = daliamdNearestIndex(0, ox0 + tw - 1, d.origin[0], d.scale[0]);
+  } else {
+    ix_a = FirstTap(ox0, d.scale[0], start_x, &f0);
+    ix_b = FirstTap(ox0 + tw - 1, d.scale[0], start_x, &f0);
+  }
+  if (d.filter_kind[1] == DALIAMD_FK_NN) {
+    iy_a = daliamdNearestIndex(1, oy0, d.origin[1], d.scale[1]);
+    iy_b = daliamdNearestIndex(1, oy0 + th - 1, d.origin[1], d.scale[1]);
+  } else {
+    iy_a = FirstTap(oy0, d.scale[1], start_y, &f0);
+    iy_b = FirstTap(oy0 + th - 1, d.scale[1], start_y, &f0);
+  }
   int x_lo, x_hi, y_lo, y_hi;
   MinMax4(ClampI(ix_a, 0, ex), ClampI(ix_a + sup_x - 1, 0, ex), ClampI(ix_b, 0, ex), ClampI(ix_b + sup_x - 1, 0, ex), &x_lo, &x_hi);
   MinMax4(ClampI(iy_a, 0, ey), ClampI(iy_a + sup_y - 1, 0, ey), ClampI(iy_b, 0, ey), ClampI(iy_b + sup_y - 1, 0, ey), &y_lo, &y_hi);
@@ -254,7 +269,8 @@ __device__ void MakeTileRec(const daliamdResampleDesc *descs, int ndesc, int til
 constexpr int kTableThreads = 256;
 __global__ __launch_bounds__(kTableThreads) void ResampleTablesKernel(const daliamdResampleDesc *__restrict__ descs, int ndesc,
                                                                       int sample_entries, int total_tiles,
-                                                                      uint8_t *__restrict__ workspace, size_t tile_rec_off) {
+                                                                      uint8_t *__restrict__ workspace, size_t tile_rec_off,
+                                                                      const float *__restrict__ filter_tables) {
   const int e = blockIdx.x * kTableThreads + threadIdx.x;
   if (e >= sample_entries + total_tiles) return;
   if (e >= sample_entries) {  // one thread per tile: its record
@@ -282,12 +298,21 @@ __global__ __launch_bounds__(kTableThreads) void ResampleTablesKernel(const dali
   const int o = axis ? local - d.out_w : local;
   const int sup = d.support[axis];
   GF32 *co = (GF32 *)(tab + (axis ? L.yc : L.xc)) + (size_t)o * sup;
+  const int kind = d.filter_kind[axis];
+  if (kind == DALIAMD_FK_NN) {  // one tap of weight 1 on the nearest source pixel
+    co[0] = 1.0f;
+    ((GI32 *)tab)[(axis ? L.yi : L.xi) + o] = daliamdNearestIndex(axis, o, d.origin[axis], d.scale[axis]);
+    return;
+  }
   const float start = FilterStart(d.origin[axis], d.scale[axis], d.fanchor[axis]);
   float f0;
   const int s0 = FirstTap(o, d.scale[axis], start, &f0);
   float sum = 0;
+  const int ncoef = daliamdFilterTableSize(kind);
+  GF32 *ftab = (GF32 *)filter_tables + (kind == DALIAMD_FK_TRIANGULAR ? 0 : daliamdFilterTableOffset(kind));
   for (int k = 0; k < sup; k++) {
-    float c = TriEval((f0 + k) * d.fscale[axis]);
+    float c = kind == DALIAMD_FK_TRIANGULAR ? TriEval((f0 + k) * d.fscale[axis])
+                                            : daliamdFilterEval(ftab, ncoef, (f0 + k) * d.fscale[axis]);
     co[k] = c;
     sum += c;
   }
@@ -676,6 +701,32 @@ static HostFilter Triangular(float radius) {
   f.Rescale(std::max(1.0f, 2 * radius));
   return f;
 }
+// the tabulated filters: {size, anchor 1, scale (size - 1) / 2}, Lanczos rescaled to 6 and cubic to 4 at creation
+// (InitFilters, resampling_filters.cu:66-108), then the per-use rescale (resampling_filters.cu:115-137)
+static HostFilter Tabulated(int size) {
+  HostFilter f;
+  f.num_coeffs = size;
+  f.anchor = 1;
+  f.scale = (size - 1) * 0.5f;
+  return f;
+}
+static HostFilter Gaussian(float sigma) {
+  HostFilter f = Tabulated(DALIAMD_RF_GAUSSIAN_SIZE);
+  f.Rescale(std::max(1.0f, static_cast<float>(4 * M_SQRT2) * sigma));
+  return f;
+}
+static HostFilter Lanczos3(float radius) {
+  HostFilter f = Tabulated(DALIAMD_RF_LANCZOS_SIZE);
+  f.Rescale(6);
+  f.Rescale(2.0f * std::max(3.0f, radius));
+  return f;
+}
+static HostFilter Cubic(float radius) {
+  HostFilter f = Tabulated(DALIAMD_RF_CUBIC_SIZE);
+  f.Rescale(4);
+  f.Rescale(2.0f * std::max(2.0f, radius));
+  return f;
+}
 
 static int SetupOne(const daliamdResampleArgs &a, daliamdResampleDesc &d, int index) {
   DALIAMD_REQUIRE(a.in_h > 0 && a.in_w > 0 && a.out_h > 0 && a.out_w > 0, DALIAMD_ERROR_INVALID_ARGUMENT,
@@ -684,8 +735,9 @@ static int SetupOne(const daliamdResampleArgs &a, daliamdResampleDesc &d, int in
                   "daliamdResampleSetup: sample %d: %d channels (supported: 1..4)", index, a.channels);
   DALIAMD_REQUIRE(a.in_pitch >= a.in_w * a.channels, DALIAMD_ERROR_INVALID_ARGUMENT,
                   "daliamdResampleSetup: sample %d: pitch %d < row bytes", index, a.in_pitch);
-  DALIAMD_REQUIRE(a.min_filter != DALIAMD_INTERP_NN && a.mag_filter != DALIAMD_INTERP_NN,
-                  DALIAMD_ERROR_UNSUPPORTED, "daliamdResampleSetup: nearest-neighbour filter not supported");
+  DALIAMD_REQUIRE(a.min_filter >= DALIAMD_INTERP_NN && a.min_filter <= DALIAMD_INTERP_GAUSSIAN &&
+                  a.mag_filter >= DALIAMD_INTERP_NN && a.mag_filter <= DALIAMD_INTERP_GAUSSIAN, DALIAMD_ERROR_INVALID_ARGUMENT,
+                  "daliamdResampleSetup: sample %d: unknown interpolation type", index);
   DALIAMD_REQUIRE(a.out_dtype == DALIAMD_UINT8 || a.out_dtype == DALIAMD_FLOAT16 || a.out_dtype == DALIAMD_FLOAT,
                   DALIAMD_ERROR_UNSUPPORTED, "daliamdResampleSetup: unsupported output type %d", a.out_dtype);
   memset(&d, 0, sizeof(d));
@@ -711,15 +763,23 @@ static int SetupOne(const daliamdResampleArgs &a, daliamdResampleDesc &d, int in
     bool aa = a.antialias != 0;
     if (aa && type == DALIAMD_INTERP_LINEAR) type = DALIAMD_INTERP_TRIANGULAR;
     else if (!aa && type == DALIAMD_INTERP_TRIANGULAR) type = DALIAMD_INTERP_LINEAR;
-    float radius = 1;
-    if (type == DALIAMD_INTERP_TRIANGULAR) {
-      bool shrink = aa && (in_sz > out_size[axis]);
-      radius = shrink ? in_sz / out_size[axis] : 1;
+    // DefaultFilterRadius (params.h:40-55), GetResamplingFilter (resampling_setup.cc:27-44)
+    const bool shrink = aa && (in_sz > out_size[axis]);
+    const float ratio = in_sz / out_size[axis];
+    HostFilter f;
+    int kind;
+    switch (type) {
+      case DALIAMD_INTERP_NN: f.num_coeffs = 0; f.anchor = 0; f.scale = 1; kind = DALIAMD_FK_NN; break;
+      case DALIAMD_INTERP_LINEAR: f = Triangular(1.0f); kind = DALIAMD_FK_TRIANGULAR; break;
+      case DALIAMD_INTERP_TRIANGULAR: f = Triangular(shrink ? ratio : 1); kind = DALIAMD_FK_TRIANGULAR; break;
+      case DALIAMD_INTERP_GAUSSIAN: f = Gaussian((float)((shrink ? ratio : 1) * 0.5f / M_SQRT2)); kind = DALIAMD_FK_GAUSSIAN; break;
+      case DALIAMD_INTERP_CUBIC: f = Cubic(shrink ? 2 * ratio : 2); kind = DALIAMD_FK_CUBIC; break;
+      default: f = Lanczos3(shrink ? 3 * ratio : 3); kind = DALIAMD_FK_LANCZOS3; break;
     }
-    HostFilter f = Triangular(type == DALIAMD_INTERP_LINEAR ? 1.0f : radius);
+    d.filter_kind[axis] = kind;
     d.origin[axis] = roi_start;
     d.scale[axis] = (roi_end - roi_start) / out_size[axis];
-    int support = f.Support();
+    int support = f.num_coeffs ? f.Support() : 1;
     float lo, hi;
     if (roi_start <= roi_end) {
       lo = roi_start - f.anchor;
@@ -734,6 +794,8 @@ static int SetupOne(const daliamdResampleArgs &a, daliamdResampleDesc &d, int in
     d.fanchor[axis] = f.anchor;
     d.support[axis] = std::max(1, support);
   }
+  DALIAMD_REQUIRE((d.filter_kind[0] == DALIAMD_FK_NN) == (d.filter_kind[1] == DALIAMD_FK_NN), DALIAMD_ERROR_UNSUPPORTED,
+                  "daliamdResampleSetup: sample %d: nearest-neighbour resampling on one axis only is not supported", index);
   DALIAMD_REQUIRE(roi_hi[0] > roi_lo[0] && roi_hi[1] > roi_lo[1], DALIAMD_ERROR_INVALID_ARGUMENT,
                   "daliamdResampleSetup: sample %d: region of interest lies outside the image", index);
   // processing order (cost model)
@@ -859,6 +921,28 @@ daliamdResult_t daliamdResampleSetup(const daliamdResampleArgs *args, int n, dal
   return DALIAMD_SUCCESS;
 }
 
+// The tabulated filter windows live in device memory, one copy per device, uploaded synchronously at the first Run
+// of the process on that device (1.5 KB; built with the host's libm like the reference's InitFilters).
+static const float *DeviceFilterTables() {
+  static std::mutex mu;
+  static float *tables[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!tables[dev]) {
+    float host[DALIAMD_RF_TOTAL];
+    daliamdBuildFilterTables(host);
+    float *p = nullptr;
+    if (hipMalloc(&p, sizeof(host)) != hipSuccess) return nullptr;
+    if (hipMemcpy(p, host, sizeof(host), hipMemcpyHostToDevice) != hipSuccess) {
+      (void)hipFree(p);
+      return nullptr;
+    }
+    tables[dev] = p;
+  }
+  return tables[dev];
+}
+
 daliamdResult_t daliamdResampleRun(daliamdStream_t stream, const daliamdResampleDesc *descs_dev, int n,
                                    int num_workgroups, int lds_bytes, void *workspace_dev, size_t workspace_bytes,
                                    int table_entries) {
@@ -867,6 +951,8 @@ daliamdResult_t daliamdResampleRun(daliamdStream_t stream, const daliamdResample
                   DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdResampleRun: invalid argument");
   DALIAMD_REQUIRE(workspace_dev && workspace_bytes > 0 && table_entries > 0, DALIAMD_ERROR_INVALID_ARGUMENT,
                   "daliamdResampleRun: the table workspace is missing (size it with daliamdResampleSetup)");
+  const float *filter_tables = DeviceFilterTables();
+  DALIAMD_REQUIRE(filter_tables, DALIAMD_ERROR_HIP, "daliamdResampleRun: could not set up the filter tables on the device");
   const size_t rec_bytes = (size_t)num_workgroups * sizeof(daliamd::TileRec);
   DALIAMD_REQUIRE(workspace_bytes >= rec_bytes, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdResampleRun: workspace too small");
   const size_t tile_rec_off = workspace_bytes - rec_bytes;   // as laid out by Setup
@@ -875,7 +961,7 @@ daliamdResult_t daliamdResampleRun(daliamdStream_t stream, const daliamdResample
     const int total = table_entries + num_workgroups;
     hipLaunchKernelGGL(daliamd::ResampleTablesKernel, dim3((total + daliamd::kTableThreads - 1) / daliamd::kTableThreads),
                        dim3(daliamd::kTableThreads), 0, (hipStream_t)stream, descs_dev, n, table_entries, num_workgroups,
-                       static_cast<uint8_t *>(workspace_dev), tile_rec_off);
+                       static_cast<uint8_t *>(workspace_dev), tile_rec_off, filter_tables);
   }
   {
     daliamd::KernelTimer timer("ResampleKernel", (hipStream_t)stream);

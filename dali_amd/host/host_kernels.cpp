@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "dali_amd_host.h"
+#include "dali_amd_resample_filters.h"
 #include "host_common.h"
 
 namespace daliamd_host {
@@ -40,10 +41,28 @@ struct AxisTable {
   std::vector<int32_t> first;  // first tap of every output position
   std::vector<float> coef;     // [out][support], normalised
 };
-AxisTable BuildTable(int out_size, float origin, float scale, float fanchor, float fscale, int support) {
+const float *FilterTables() {  // the tabulated windows, built once (InitFilters, resampling_filters.cu:66-108)
+  static const std::vector<float> tables = [] {
+    std::vector<float> t(DALIAMD_RF_TOTAL);
+    daliamdBuildFilterTables(t.data());
+    return t;
+  }();
+  return tables.data();
+}
+
+AxisTable BuildTable(int axis, int kind, int out_size, float origin, float scale, float fanchor, float fscale, int support) {
   AxisTable t;
   t.first.resize(out_size);
   t.coef.resize((size_t)out_size * support);
+  if (kind == DALIAMD_FK_NN) {  // one tap of weight 1 on the nearest source pixel (ResampleNN)
+    for (int o = 0; o < out_size; o++) {
+      t.first[o] = daliamdNearestIndex(axis, o, origin, scale);
+      t.coef[o] = 1.0f;
+    }
+    return t;
+  }
+  const int ncoef = daliamdFilterTableSize(kind);
+  const float *ftab = kind == DALIAMD_FK_TRIANGULAR ? nullptr : FilterTables() + daliamdFilterTableOffset(kind);
   float start = origin;
   start += 0.5f * scale - 0.5f - fanchor;
   for (int o = 0; o < out_size; o++) {
@@ -53,7 +72,7 @@ AxisTable BuildTable(int out_size, float origin, float scale, float fanchor, flo
     float *co = &t.coef[(size_t)o * support];
     float sum = 0;
     for (int k = 0; k < support; k++) {
-      co[k] = TriEval((f0 + k) * fscale);
+      co[k] = ftab ? daliamdFilterEval(ftab, ncoef, (f0 + k) * fscale) : TriEval((f0 + k) * fscale);
       sum += co[k];
     }
     if (sum)
@@ -135,8 +154,8 @@ extern "C" int daliamdResampleRunHost(const daliamdResampleDesc *desc) {
   const int C = d.channels, pitch = d.in_pitch;
   if (C < 1 || C > 4) return Fail("daliamdResampleRunHost: %d channels (supported: 1..4)", C);
   const int sup_x = d.support[0], sup_y = d.support[1];
-  const AxisTable tx = BuildTable(d.out_w, d.origin[0], d.scale[0], d.fanchor[0], d.fscale[0], sup_x);
-  const AxisTable ty = BuildTable(d.out_h, d.origin[1], d.scale[1], d.fanchor[1], d.fscale[1], sup_y);
+  const AxisTable tx = BuildTable(0, d.filter_kind[0], d.out_w, d.origin[0], d.scale[0], d.fanchor[0], d.fscale[0], sup_x);
+  const AxisTable ty = BuildTable(1, d.filter_kind[1], d.out_h, d.origin[1], d.scale[1], d.fanchor[1], d.fscale[1], sup_y);
   // taps are clamped to [0, ext) inside the frame that starts at lo (first-pass axis: the whole image; second-pass
   // axis: the source region the first pass produced)
   const int ex = d.ext[0] - 1, ey = d.ext[1] - 1;

@@ -25,12 +25,14 @@ enum { DALI_INTERP_NN = 0, DALI_INTERP_LINEAR = 1, DALI_INTERP_CUBIC = 2, DALI_I
 enum { DALI_RGB = 0, DALI_BGR = 1, DALI_GRAY = 2, DALI_YCbCr = 3, DALI_ANY_DATA = 4 };
 
 static int ToKernelInterp(int64_t dali_interp) {
-  switch (dali_interp) {
+  switch (dali_interp) {  // DALIInterpType (include/dali/core/common.h): NN 0, LINEAR 1, CUBIC 2, LANCZOS3 3, TRIANGULAR 4, GAUSSIAN 5
+    case 0: return DALIAMD_INTERP_NN;
     case DALI_INTERP_LINEAR: return DALIAMD_INTERP_LINEAR;
+    case 2: return DALIAMD_INTERP_CUBIC;
+    case 3: return DALIAMD_INTERP_LANCZOS3;
     case DALI_INTERP_TRIANGULAR: return DALIAMD_INTERP_TRIANGULAR;
-    default:
-      DALI_FAIL("Interpolation type ", dali_interp, " is not supported by the MI355X resampling kernel yet "
-                "(supported: INTERP_LINEAR, INTERP_TRIANGULAR)");
+    case 5: return DALIAMD_INTERP_GAUSSIAN;
+    default: DALI_FAIL("Unknown interpolation type ", dali_interp);
   }
 }
 

@@ -261,7 +261,11 @@ DALIAMD_API daliamdResult_t daliamdJpegColorRun(daliamdStream_t stream, const da
  * reference pass order): dali/kernels/imgproc/resample/{resampling_impl_cpu.cc:22-47,
  * resampling_impl_cpu.h:50-390, separable_cpu.h:152-241}.
  * -------------------------------------------------------------------------------------------- */
-typedef enum { DALIAMD_INTERP_NN = 0, DALIAMD_INTERP_LINEAR = 1, DALIAMD_INTERP_TRIANGULAR = 2 } daliamdInterp_t;
+/* CUBIC / LANCZOS3 / GAUSSIAN: the reference's tabulated windows (resampling_filters.cu:38-142); NN on both axes only */
+typedef enum {
+  DALIAMD_INTERP_NN = 0, DALIAMD_INTERP_LINEAR = 1, DALIAMD_INTERP_TRIANGULAR = 2, DALIAMD_INTERP_CUBIC = 3,
+  DALIAMD_INTERP_LANCZOS3 = 4, DALIAMD_INTERP_GAUSSIAN = 5
+} daliamdInterp_t;
 
 typedef struct {
   /* input image, u8 HWC */
@@ -303,6 +307,7 @@ typedef struct {
   int64_t table_off;         /* byte offset of the sample's tables inside the workspace */
   int32_t tab_start;         /* first table entry of the sample (work index of the tables kernel) */
   int32_t use_lut;
+  int32_t filter_kind[2];    /* per axis: 0 nearest, 1 triangular, 2 Gaussian, 3 Lanczos3, 4 cubic (dali_amd_resample_filters.h) */
 } daliamdResampleDesc;
 
 /* Fills descs_host[0..n); returns the grid size and the dynamic LDS bytes the launch needs. */

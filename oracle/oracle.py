@@ -96,7 +96,15 @@ def crop_anchor(norm, crop, insz, rounding="round"):
 
 
 # ---------------------------------------------------------------- resample
-FILTER_NN, FILTER_LINEAR, FILTER_TRIANGULAR = 0, 1, 2
+FILTER_NN, FILTER_LINEAR, FILTER_TRIANGULAR, FILTER_CUBIC, FILTER_LANCZOS3, FILTER_GAUSSIAN = 0, 1, 2, 3, 4, 5
+
+
+def filter_table(ftype, radius):
+    """(coeffs, scale, anchor, support) of a tabulated resampling filter at the given radius."""
+    co = np.zeros(193, np.float32)
+    sc, an, sup = C.c_float(0), C.c_float(0), C.c_int(0)
+    n = lib().orc_filter_table(int(ftype), C.c_float(radius), _p(co, C.c_float), C.byref(sc), C.byref(an), C.byref(sup))
+    return co[:n].copy(), sc.value, an.value, sup.value
 
 
 def resample_u8(img, out_hw, roi=None, min_filter=FILTER_LINEAR, mag_filter=FILTER_LINEAR,

@@ -27,17 +27,26 @@
  * resize-vs-PIL tolerance of dali/test/python/operator_2/test_resize.py:96-121,582-589
  * are checked in tests/test_oracle_resample.py.
  */
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+#ifndef M_SQRT2
+#define M_SQRT2 1.41421356237309504880
+#endif
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
-enum { ORC_FILTER_NN = 0, ORC_FILTER_LINEAR = 1, ORC_FILTER_TRIANGULAR = 2 };
+/* CUBIC / LANCZOS3 / GAUSSIAN: the reference's tabulated windows (resampling_filters.cu:38-142, resampling_windows.h:44-65) */
+enum { ORC_FILTER_NN = 0, ORC_FILTER_LINEAR = 1, ORC_FILTER_TRIANGULAR = 2, ORC_FILTER_CUBIC = 3, ORC_FILTER_LANCZOS3 = 4,
+       ORC_FILTER_GAUSSIAN = 5 };
+#define ORC_MAX_COEFFS 193
 
 typedef struct {
   int num_coeffs;
   float anchor, scale;
-  float coeffs[3];
+  float coeffs[ORC_MAX_COEFFS];
 } orc_filter;
 
 /* resampling_filters.cuh:38-42 */
@@ -71,6 +80,67 @@ static orc_filter filter_triangular(float radius) {
   f.coeffs[0] = 0; f.coeffs[1] = 1; f.coeffs[2] = 0;
   float s = 2 * radius;
   filter_rescale(&f, s > 1.0f ? s : 1.0f);
+  return f;
+}
+
+/* include/dali/core/math_util.h:188-194 (float overload) */
+static float sincf_(float x) {
+  x = (float)(x * M_PI);   /* `x *= M_PI`: the product is formed in double */
+  if (fabsf(x) < 1e-5f) return 1.0f - x * x * (1.0f / 6);
+  return sinf(x) / x;
+}
+/* resampling_windows.h:44-48 */
+static float lanczos_window(float x, float a) {
+  if (fabsf(x) >= a) return 0.0f;
+  return sincf_(x) * sincf_(x / a);
+}
+/* resampling_windows.h:54-65 */
+static float cubic_window(float x) {
+  x = fabsf(x);
+  if (x >= 2) return 0;
+  float x2 = x * x, x3 = x2 * x;
+  if (x > 1) return -0.5f * x3 + 2.5f * x2 - 4.0f * x + 2.0f;
+  return 1.5f * x3 - 2.5f * x2 + 1.0f;
+}
+/* InitFilters, resampling_filters.cu:66-108: {coeffs, size, scale 1, anchor (size - 1) / 2}, Lanczos rescaled to 6,
+ * cubic to 4; then the per-use rescale of resampling_filters.cu:115-137 */
+static orc_filter filter_base(int size) {
+  orc_filter f;
+  memset(&f, 0, sizeof(f));
+  f.num_coeffs = size;
+  f.anchor = 1;               /* add_filter pushes {base, size, 1, (size - 1) * 0.5f}: the struct order is */
+  f.scale = (size - 1) * 0.5f; /* {coeffs, num_coeffs, anchor, scale}, so anchor = 1 and scale = (size - 1) / 2 */
+  return f;
+}
+static orc_filter filter_gaussian(float sigma) {
+  orc_filter f = filter_base(65);
+  for (int i = 0; i < 65; i++) {
+    float x = 4 * (i - (65 - 1) * 0.5f) / (65 - 1);
+    f.coeffs[i] = expf(-x * x);
+  }
+  float s = (float)(4 * M_SQRT2) * sigma;
+  filter_rescale(&f, s > 1.0f ? s : 1.0f);
+  return f;
+}
+static orc_filter filter_lanczos3(float radius) {
+  const int size = 2 * 3 * 32 + 1;
+  orc_filter f = filter_base(size);
+  for (int i = 0; i < size; i++) {
+    float x = 2 * 3.0f * (i - (size - 1) * 0.5f) / (size - 1);
+    f.coeffs[i] = lanczos_window(x, 3.0f);
+  }
+  filter_rescale(&f, 6);
+  filter_rescale(&f, 2.0f * (radius > 3.0f ? radius : 3.0f));
+  return f;
+}
+static orc_filter filter_cubic(float radius) {
+  orc_filter f = filter_base(129);
+  for (int i = 0; i < 129; i++) {
+    float x = 4 * (i - (129 - 1) * 0.5f) / (129 - 1);
+    f.coeffs[i] = cubic_window(x);
+  }
+  filter_rescale(&f, 4);
+  filter_rescale(&f, 2.0f * (radius > 2.0f ? radius : 2.0f));
   return f;
 }
 
@@ -175,14 +245,20 @@ static void setup_sample(orc_resample_setup *s, int H, int W, int use_roi, const
     }
     /* DefaultFilterRadius, params.h:43-60 */
     float radius = 1;
-    if (type == ORC_FILTER_TRIANGULAR) {
+    {
       int a = aa && (in_size > s->out_size[axis]);
-      radius = a ? in_size / s->out_size[axis] : 1;
+      float ratio = in_size / s->out_size[axis];
+      if (type == ORC_FILTER_TRIANGULAR || type == ORC_FILTER_GAUSSIAN) radius = a ? ratio : 1;
+      else if (type == ORC_FILTER_CUBIC) radius = a ? 2 * ratio : 2;
+      else if (type == ORC_FILTER_LANCZOS3) radius = a ? 3 * ratio : 3;
     }
     s->filter_type[axis] = type;
     if (type == ORC_FILTER_LINEAR) s->filter[axis] = filter_triangular(1);
     else if (type == ORC_FILTER_TRIANGULAR) s->filter[axis] = filter_triangular(radius);
-    else { s->filter[axis].num_coeffs = 0; s->filter[axis].anchor = 0; s->filter[axis].scale = 1; }
+    else if (type == ORC_FILTER_GAUSSIAN) s->filter[axis] = filter_gaussian((float)(radius * 0.5f / M_SQRT2));  /* GetResamplingFilter */
+    else if (type == ORC_FILTER_CUBIC) s->filter[axis] = filter_cubic(radius);
+    else if (type == ORC_FILTER_LANCZOS3) s->filter[axis] = filter_lanczos3(radius);
+    else { memset(&s->filter[axis], 0, sizeof(orc_filter)); s->filter[axis].num_coeffs = 0; s->filter[axis].anchor = 0; s->filter[axis].scale = 1; }
 
     /* ComputeScaleAndROI, resampling_setup.cc:84-122 */
     s->origin[axis] = roi_start;
@@ -237,7 +313,7 @@ static int resample_impl(const uint8_t *in, int H, int W, int C, int use_roi, co
   if (H <= 0 || W <= 0 || outH <= 0 || outW <= 0 || C <= 0) return 1;
   orc_resample_setup s;
   setup_sample(&s, H, W, use_roi, roi, outH, outW, min_filter, mag_filter, antialias);
-  if (s.filter_type[0] == ORC_FILTER_NN || s.filter_type[1] == ORC_FILTER_NN) return 2;
+  if ((s.filter_type[0] == ORC_FILTER_NN) != (s.filter_type[1] == ORC_FILTER_NN)) return 2;  /* mixed: not restated */
 
   int first = s.order[0], second = s.order[1];
   /* SetupSample tail, resampling_setup.cc:326-336: the non-first-pass axis is cut to the source
@@ -262,6 +338,29 @@ static int resample_impl(const uint8_t *in, int H, int W, int C, int use_roi, co
     info[4] = tmp_w; info[5] = tmp_h; info[6] = s.roi_lo[0]; info[7] = s.roi_lo[1];
   }
   if (tmp_w <= 0 || tmp_h <= 0) { if (out) memset(out, 0, (size_t)outH * outW * C); return 0; }
+  if (s.filter_type[0] == ORC_FILTER_NN) {
+    /* ResampleNN (resampling_impl_cpu.h:523-606) on the surface SetupSample leaves: whole image on the first-pass
+     * axis, the source ROI on the other.  Rows advance by repeated float additions, columns are computed directly;
+     * scale.x == 1 is the copy path with repeated borders. */
+    const uint8_t *base = in + ((size_t)in_off[1] * W + in_off[0]) * C;
+    float sy = origin[1] + 0.5f * s.scale[1];
+    int sx0 = (int)floorf(origin[0] + 0.5f);
+    for (int y = 0; y < outH; y++, sy += s.scale[1]) {
+      int srcy = clampi((int)floorf(sy), 0, in_ext[1] - 1);
+      for (int x = 0; x < outW; x++) {
+        int srcx;
+        if (s.scale[0] == 1) srcx = sx0 + x;
+        else srcx = (int)floorf(origin[0] + (x + 0.5f) * s.scale[0]);
+        srcx = clampi(srcx, 0, in_ext[0] - 1);
+        for (int c = 0; c < C; c++) {
+          uint8_t v = base[((size_t)srcy * W + srcx) * C + c];
+          if (out) out[((size_t)y * outW + x) * C + c] = v;
+          if (out_f32) out_f32[((size_t)y * outW + x) * C + c] = v;
+        }
+      }
+    }
+    return 0;
+  }
 
   float *tmp = (float *)malloc(sizeof(float) * (size_t)tmp_w * tmp_h * C);
   int max_out = outW > outH ? outW : outH;
@@ -374,6 +473,19 @@ int orc_resample_u8_to_f32(const uint8_t *in, int H, int W, int C, int use_roi, 
 }
 
 /* Known-answer helpers mirroring resampling_impl_cpu_test.cc:27-90 */
+/* coefficients of the tabulated filters for known-answer tests: type = ORC_FILTER_*, returns num_coeffs and fills
+ * coeffs[<= 193], *scale, *anchor for the given radius (sigma derived like GetResamplingFilter) */
+int orc_filter_table(int type, float radius, float *coeffs, float *scale, float *anchor, int *support) {
+  orc_filter f;
+  if (type == ORC_FILTER_GAUSSIAN) f = filter_gaussian((float)(radius * 0.5f / M_SQRT2));
+  else if (type == ORC_FILTER_CUBIC) f = filter_cubic(radius);
+  else if (type == ORC_FILTER_LANCZOS3) f = filter_lanczos3(radius);
+  else f = filter_triangular(radius);
+  memcpy(coeffs, f.coeffs, sizeof(float) * (size_t)f.num_coeffs);
+  *scale = f.scale; *anchor = f.anchor; *support = filter_support(&f);
+  return f.num_coeffs;
+}
+
 int orc_triangular_support(float radius) {
   orc_filter f = filter_triangular(radius);
   return filter_support(&f);

@@ -118,3 +118,24 @@ def test_cpu_resize_and_stand_alone_cmn_match_oracle(dataset):
         ay, ax = int(O.crop_anchor(0.75, 128, r.shape[0])), int(O.crop_anchor(0.25, 112, r.shape[1]))
         ref = O.cmn_u8(r, (ay, ax), (128, 112), mirror=True, mean=mean, inv_std=inv, dtype=O.F32, layout="HWC")
         assert np.array_equal(got.at(i), ref), i
+
+
+def test_cpu_resize_every_filter_matches_oracle(dataset):
+    """fn.resize on the CPU backend with nearest neighbour and the tabulated windows: product host code == oracle."""
+    from dali_amd import fn, types
+    from dali_amd.pipeline import Pipeline
+    root, files = dataset
+    B = 4
+    for name, of in [("INTERP_NN", O.FILTER_NN), ("INTERP_CUBIC", O.FILTER_CUBIC), ("INTERP_LANCZOS3", O.FILTER_LANCZOS3),
+                     ("INTERP_GAUSSIAN", O.FILTER_GAUSSIAN)]:
+        for size in ((100, 150), (400, 600)):
+            pipe = Pipeline(batch_size=B, num_threads=2, device_id=None, prefetch_queue_depth=1)
+            with pipe:
+                jpegs, _ = fn.readers.file(file_root=root)
+                images = fn.decoders.image(jpegs, device="cpu")
+                pipe.set_outputs(fn.resize(images, size=list(size), interp_type=getattr(types, name)))
+            (got,) = pipe.run()
+            for i in range(B):
+                img = O.jpeg_decode_rgb(open(files[i][0], "rb").read())
+                ref = O.resample_u8(img, size, min_filter=of, mag_filter=of)
+                assert np.array_equal(got.at(i), ref), (name, size, i)

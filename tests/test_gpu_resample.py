@@ -139,3 +139,31 @@ def test_checkerboard_vs_onnx_reference_on_the_gpu():
     for c in range(3):
         assert np.abs(got[:, :, c] - ref).max() <= 1.0, c
     assert np.array_equal(out[0].cpu().numpy(), O.resample_u8(img, (17, 13)))
+
+
+@pytest.mark.parametrize("filt", ["NN", "CUBIC", "LANCZOS3", "GAUSSIAN"])
+def test_other_filters_match_oracle(filt):
+    """Nearest neighbour and the reference's tabulated windows (cubic, Lanczos3, Gaussian): up- and down-scaling with
+    and without antialiasing, regions of interest, both pass orders - bit-identical to the oracle."""
+    from dali_amd import backend as B
+    from dali_amd import _capi as capi
+    kf, of = getattr(capi, "INTERP_" + filt), getattr(O, "FILTER_" + filt)
+    rng = np.random.default_rng(12)
+    cases = [((120, 160), (224, 224), None, True), ((300, 400), (93, 131), None, True), ((300, 400), (93, 131), None, False),
+             ((200, 90), (64, 200), (10.5, 5.25, 180.0, 80.5), True), ((97, 131), (97, 131), None, True),
+             ((64, 64), (7, 300), None, True), ((40, 300), (120, 60), (35.0, 290.0, 2.0, 11.0), True)]
+    for (h, w), osz, roi, aa in cases:
+        for c in (1, 3):
+            im = np.ascontiguousarray(synth_image(rng, h, w, 3)[:, :, :c])
+            out = B.resample_batch([_to_dev(im, 4)], osz, rois=None if roi is None else [roi], interp_min=kf, interp_mag=kf,
+                                   antialias=aa).cpu().numpy()[0]
+            ref = O.resample_u8(im, osz, roi=roi, min_filter=of, mag_filter=of, antialias=aa)
+            assert np.array_equal(out, ref), (filt, (h, w, c), osz, roi, aa, int(np.abs(out.astype(int) - ref).max()))
+
+
+def test_nearest_on_one_axis_only_is_refused():
+    from dali_amd import backend as B
+    from dali_amd import _capi as capi
+    im = synth_image(np.random.default_rng(1), 50, 80)
+    with pytest.raises(capi.DaliAmdError, match="one axis only"):
+        B.resample_batch([_to_dev(im)], (100, 20), interp_min=capi.INTERP_NN, interp_mag=capi.INTERP_LINEAR)

@@ -139,3 +139,40 @@ def test_checkerboard_vs_onnx_reference(antialias):
     u8 = O.resample_u8(board, (17, 13), antialias=antialias)[:, :, 0]
     clear = np.abs(ref - np.floor(ref) - 0.5) > 1e-2
     assert np.array_equal(u8[clear], np.floor(ref + 0.5).astype(np.uint8)[clear])
+
+
+def _cubic_coeffs(ratio, scale=None, A=-0.5):
+    """ONNX reference cubic_coeffs (onnx/reference/ops/op_resize.py) with the Catmull-Rom parameter DALI's window uses."""
+    return np.array([((A * (ratio + 1) - 5 * A) * (ratio + 1) + 8 * A) * (ratio + 1) - 4 * A,
+                     ((A + 2) * ratio - (A + 3)) * ratio * ratio + 1,
+                     ((A + 2) * (1 - ratio) - (A + 3)) * (1 - ratio) * (1 - ratio) + 1,
+                     ((A * ((1 - ratio) + 1) - 5 * A) * ((1 - ratio) + 1) + 8 * A) * ((1 - ratio) + 1) - 4 * A])
+
+
+def test_cubic_upscale_matches_onnx_reference_cubic():
+    """The tabulated cubic window (129 entries, linear interpolation) against the closed-form Catmull-Rom weights of the
+    ONNX reference on a checkerboard and on noise: the table's interpolation error stays far below half an LSB."""
+    from tests import onnx_resize_ref as R
+    rng = np.random.default_rng(4)
+    board = (np.indices((11, 13)).sum(0) % 2 * 255).astype(np.uint8)
+    noise = rng.integers(0, 256, (9, 12), dtype=np.uint8)
+    for img, osz in [(board, (29, 40)), (noise, (31, 25))]:
+        got = O.resample_f32(img[:, :, None], osz, min_filter=O.FILTER_CUBIC, mag_filter=O.FILTER_CUBIC, antialias=False)[:, :, 0]
+        ref = R.interpolate_nd(img, _cubic_coeffs, osz)
+        # ONNX excludes nothing at the borders (edge padding) and so does the reference's clamping of tap indices
+        assert np.abs(got - ref).max() < 0.25, np.abs(got - ref).max()
+
+
+def test_tabulated_filters_known_answers():
+    """resampling_filters.cu:66-137: table sizes, unit centre, symmetric, support = 2 * radius (cubic, Lanczos3) and the
+    Gaussian's 4 sqrt(2) sigma; nearest neighbour = pixel replication on an integer up-scale."""
+    for ftype, radius, n, sup in [(O.FILTER_CUBIC, 2, 129, 4), (O.FILTER_LANCZOS3, 3, 193, 6), (O.FILTER_CUBIC, 5, 129, 10),
+                                  (O.FILTER_GAUSSIAN, 1, 65, 2), (O.FILTER_GAUSSIAN, 3.3, 65, 7)]:
+        co, scale, anchor, support = O.filter_table(ftype, radius)
+        assert len(co) == n and support == sup, (ftype, radius, len(co), support)
+        assert co[n // 2] == 1.0 and np.allclose(co, co[::-1], atol=1e-6) and abs(anchor - (n - 1) / scale / 2) < 1e-4
+    img = np.random.default_rng(0).integers(0, 256, (5, 7, 3), dtype=np.uint8)
+    up = O.resample_u8(img, (15, 14), min_filter=O.FILTER_NN, mag_filter=O.FILTER_NN)
+    assert np.array_equal(up, img.repeat(3, 0).repeat(2, 1))
+    dn = O.resample_u8(up, (5, 7), min_filter=O.FILTER_NN, mag_filter=O.FILTER_NN)
+    assert np.array_equal(dn, img)
