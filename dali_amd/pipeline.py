@@ -206,11 +206,25 @@ class Pipeline:
     def feed_input(self, data_node, data, layout=None):
         self.build()
         name = data_node if isinstance(data_node, str) else data_node.source
+        def to_host(d):
+            # anything that speaks DLPack or the array interfaces (torch / cupy tensors on either device, DALI tensors):
+            # external_source.py:95-130 accepts them; the operator copies from host memory, so device data comes down
+            if isinstance(d, (bytes, bytearray)):
+                return np.frombuffer(d, np.uint8)
+            if isinstance(d, np.ndarray):
+                return d
+            if hasattr(d, "__dlpack__") or hasattr(d, "__cuda_array_interface__"):
+                import torch
+                t = torch.from_dlpack(d) if hasattr(d, "__dlpack__") else torch.as_tensor(d, device="cuda")
+                return t.detach().cpu().numpy()
+            return np.asarray(d)
         if isinstance(data, np.ndarray) and data.dtype != object:
             arrays = [np.ascontiguousarray(data[i]) for i in range(data.shape[0])]
+        elif not isinstance(data, (list, tuple)) and (hasattr(data, "__dlpack__") or hasattr(data, "__cuda_array_interface__")):
+            whole = to_host(data)      # one tensor = a batch along its first axis
+            arrays = [np.ascontiguousarray(whole[i]) for i in range(whole.shape[0])]
         else:
-            arrays = [np.ascontiguousarray(np.frombuffer(d, np.uint8) if isinstance(d, (bytes, bytearray)) else d)
-                      for d in data]
+            arrays = [np.ascontiguousarray(to_host(d)) for d in data]
         if not arrays:
             raise ValueError("Cannot feed an empty batch")
         dt = arrays[0].dtype

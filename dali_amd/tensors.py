@@ -37,6 +37,13 @@ class TensorCPU(_Tensor):
     def __array__(self, dtype=None, copy=None):
         return self.as_array() if dtype is None else self.as_array().astype(dtype)
 
+    # DLPack (dali/python/backend_impl.cc:623-740): a host tensor exports a copy through numpy's own exporter
+    def __dlpack__(self, stream=None, **kwargs):
+        return self.as_array().__dlpack__()
+
+    def __dlpack_device__(self):
+        return (1, 0)   # kDLCPU
+
     def as_array(self):
         np_t = np.dtype(types.to_numpy_type(self.dtype))
         n = int(np.prod(self._shape)) if len(self._shape) else 1
@@ -62,6 +69,16 @@ class TensorGPU(_Tensor):
     def as_cpu(self):
         t = self.as_torch().contiguous().cpu()
         return t.numpy()
+
+    # DLPack: a zero-copy view of the pipeline-owned buffer (valid until the next run()/outputs(), like the
+    # __cuda_array_interface__ view), exported through torch so that device type / id and strides follow the
+    # consumer's conventions (kDLROCM on this platform).  `stream`: the consumer's stream, as in the protocol.
+    def __dlpack__(self, stream=None, **kwargs):
+        t = self.as_torch()
+        return t.__dlpack__(stream=stream) if stream is not None else t.__dlpack__()
+
+    def __dlpack_device__(self):
+        return tuple(int(v) for v in self.as_torch().__dlpack_device__())
 
 
 def _torch_dtype(dali_type):

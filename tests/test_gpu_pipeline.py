@@ -269,3 +269,23 @@ def test_heavy_augmentation_pipeline_matches_oracle():
         ref = O.erase_u8(ref, anchor.at(i), shape.at(i), fill=(0.0,), normalized_anchor=True, normalized_shape=True)
         got = out[i].as_cpu()
         assert np.array_equal(got, ref), f"sample {i}: max diff {np.abs(got.astype(int) - ref).max()}"
+
+
+def test_gpu_tensor_dlpack_zero_copy_and_device_feed():
+    """TensorGPU.__dlpack__ is a zero-copy view (same address as the __cuda_array_interface__ view) on the ROCm device;
+    a CUDA torch tensor can be fed to external_source through DLPack."""
+    import torch
+    from dali_amd import fn
+    from dali_amd.pipeline import Pipeline
+    x = torch.arange(2 * 5 * 6, dtype=torch.float32, device="cuda").reshape(2, 5, 6)
+    pipe = Pipeline(batch_size=2, num_threads=1, device_id=0, prefetch_queue_depth=1)
+    with pipe:
+        pipe.set_outputs(fn.external_source(name="x").gpu())
+    pipe.feed_input("x", x)
+    (out,) = pipe.run()
+    t = out[1]
+    dev_type, dev_id = t.__dlpack_device__()
+    assert dev_id == 0 and dev_type in (2, 10)          # kDLCUDA / kDLROCM
+    view = torch.from_dlpack(t)
+    assert view.data_ptr() == t.data_ptr() and view.is_cuda
+    assert torch.equal(view, x[1])

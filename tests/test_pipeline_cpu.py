@@ -308,3 +308,25 @@ def test_reader_checkpoint_roundtrip(dataset, shuffle, pad):
     used._backend.restore(cpt)
     again, _ = _run_indices(used, 6)
     assert np.array_equal(again, expect)
+
+
+def test_dlpack_export_and_external_source_import():
+    """TensorCPU.__dlpack__ / __dlpack_device__ (backend_impl.cc:623-740) and DLPack producers as external_source input
+    (external_source.py:95-130): a torch tensor feeds the pipeline, the outputs come back through np.from_dlpack."""
+    import torch
+    from dali_amd import fn
+    from dali_amd.pipeline import Pipeline
+    batch = torch.arange(2 * 3 * 4, dtype=torch.float32).reshape(2, 3, 4)
+    pipe = Pipeline(batch_size=2, num_threads=1, device_id=None, prefetch_queue_depth=1)
+    with pipe:
+        pipe.set_outputs(fn.external_source(name="x"))
+    pipe.feed_input("x", batch)                       # one DLPack tensor = the batch
+    (out,) = pipe.run()
+    assert out.at(0).shape == (3, 4)
+    t0 = out[0]
+    assert t0.__dlpack_device__() == (1, 0)
+    assert np.array_equal(np.from_dlpack(t0), batch[0].numpy())
+    assert torch.equal(torch.from_dlpack(out[1]), batch[1])
+    pipe.feed_input("x", [batch[1], batch[0]])        # a list of DLPack tensors = the samples
+    (out,) = pipe.run()
+    assert np.array_equal(out.at(0), batch[1].numpy())
