@@ -554,11 +554,18 @@ def main():
     import torch
     import torch.distributed as dist
 
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # BENCH_TEST_SINGLE_DEVICE=1: every rank on cuda:0 with a gloo group - exercises the N > 1 code path (sharding, barrier,
+    # max over ranks, sharded end-to-end leg) on a one-GPU box.  Its numbers mean nothing; it is a smoke test.
+    single_device_test = world > 1 and os.environ.get("BENCH_TEST_SINGLE_DEVICE") == "1"
+    dev_index = 0 if single_device_test else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if single_device_test:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     if args.workload == "heavy_aug":
         return bench_heavy_aug(args, device)
@@ -594,7 +601,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if single_device_test else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -713,9 +720,9 @@ def main():
             write_dataset(root, enc_all, first_index=rank * per_rank)
             barrier()
             threads = max(2, effective_cpu_count() // max(1, local_world))
-            res = e2e_pipeline(root, args.e2e_batch, local_rank, iters=100, threads=threads, shard_id=rank,
+            res = e2e_pipeline(root, args.e2e_batch, dev_index, iters=100, threads=threads, shard_id=rank,
                                num_shards=world, sync=barrier, set_affinity=True)
-            t = torch.tensor([res["elapsed_s"]], dtype=torch.float64, device=device)
+            t = torch.tensor([res["elapsed_s"]], dtype=torch.float64, device="cpu" if single_device_test else device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             barrier()
             if rank == 0:
