@@ -166,7 +166,10 @@ daliamdResult_t daliamdStreamWaitEvent(daliamdStream_t stream, daliamdEvent_t ev
 daliamdResult_t daliamdEventCreate(daliamdEvent_t *event, int enable_timing) {
   DALIAMD_REQUIRE(event, DALIAMD_ERROR_INVALID_ARGUMENT, "event is NULL");
   hipEvent_t e;
-  DALIAMD_HIP_CHECK(hipEventCreateWithFlags(&e, enable_timing ? hipEventDefault : hipEventDisableTiming));
+  // enable_timing: bit 0 = timing, bit 1 = blocking synchronisation (the waiting thread sleeps instead of polling)
+  unsigned flags = (enable_timing & 1) ? hipEventDefault : hipEventDisableTiming;
+  if (enable_timing & 2) flags |= hipEventBlockingSync;
+  DALIAMD_HIP_CHECK(hipEventCreateWithFlags(&e, flags));
   *event = e;
   return DALIAMD_SUCCESS;
 }

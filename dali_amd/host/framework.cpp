@@ -218,39 +218,59 @@ void ThreadPool::AddWork(Work w, int64_t priority) { pending_.emplace_back(prior
 void ThreadPool::RunAll() {
   if (pending_.empty()) return;
   std::stable_sort(pending_.begin(), pending_.end(), [](const auto &a, const auto &b) { return a.first > b.first; });
+  auto batch = std::make_shared<Batch>();
+  batch->tasks = std::move(pending_);
+  pending_.clear();
   {
     std::lock_guard<std::mutex> g(m_);
-    running_ = std::move(pending_);
-    pending_.clear();
-    next_ = 0; done_ = 0;
-    errors_.clear();
+    batch_ = batch;
+    generation_++;
   }
-  cv_work_.notify_all();
-  std::unique_lock<std::mutex> lk(m_);
-  cv_done_.wait(lk, [this] { return done_ == running_.size(); });
-  running_.clear();
-  if (!errors_.empty()) {
-    std::string e = errors_.front();
-    errors_.clear();
-    throw std::runtime_error(e);
+  // wake no more workers than the batch can feed (a worker woken from a deep idle state for one 10 us task costs more
+  // than it contributes), and work on the batch from this thread as well: its share needs no wake-up at all
+  const size_t total = batch->tasks.size();
+  const size_t helpers = std::min(threads_.size(), (total + 3) / 4);
+  if (helpers >= threads_.size()) cv_work_.notify_all();
+  else for (size_t i = 0; i < helpers; i++) cv_work_.notify_one();
+  Drain(*batch, (int)threads_.size());
+  {
+    std::unique_lock<std::mutex> lk(m_);
+    cv_done_.wait(lk, [&] { return batch->done.load(std::memory_order_acquire) == total; });
+    batch_.reset();
+  }
+  if (!batch->errors.empty()) throw std::runtime_error(batch->errors.front());
+}
+
+void ThreadPool::Drain(Batch &batch, int tid) {
+  const size_t total = batch.tasks.size();
+  for (;;) {
+    const size_t idx = batch.next.fetch_add(1, std::memory_order_relaxed);
+    if (idx >= total) break;
+    std::string err;
+    try { batch.tasks[idx].second(tid); } catch (const std::exception &e) { err = e.what(); } catch (...) { err = "unknown error"; }
+    if (!err.empty()) {
+      std::lock_guard<std::mutex> g(batch.err_m);
+      batch.errors.push_back(err);
+    }
+    if (batch.done.fetch_add(1, std::memory_order_acq_rel) + 1 == total) {
+      std::lock_guard<std::mutex> g(m_);   // the waiter checks the counter under this lock: no lost wake-up
+      cv_done_.notify_all();
+    }
   }
 }
 
 void ThreadPool::Loop(int tid) {
-  std::unique_lock<std::mutex> lk(m_);
+  uint64_t seen = 0;
   for (;;) {
-    cv_work_.wait(lk, [this] { return stop_ || next_ < running_.size(); });
-    if (stop_) return;
-    while (next_ < running_.size()) {
-      size_t idx = next_++;
-      Work &w = running_[idx].second;
-      lk.unlock();
-      std::string err;
-      try { w(tid); } catch (const std::exception &e) { err = e.what(); } catch (...) { err = "unknown error"; }
-      lk.lock();
-      if (!err.empty()) errors_.push_back(err);
-      if (++done_ == running_.size()) cv_done_.notify_all();
+    std::shared_ptr<Batch> batch;
+    {
+      std::unique_lock<std::mutex> lk(m_);
+      cv_work_.wait(lk, [&] { return stop_ || (generation_ != seen && batch_); });
+      if (stop_) return;
+      seen = generation_;
+      batch = batch_;
     }
+    Drain(*batch, tid);
   }
 }
 

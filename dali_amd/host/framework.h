@@ -170,7 +170,7 @@ class ThreadPool {
   // GPU's NUMA node; the reference binds through NVML, dali/pipeline/util/thread_pool.cc)
   explicit ThreadPool(int num_threads, const std::vector<int> &cpus = {});
   ~ThreadPool();
-  using Work = std::function<void(int)>;
+  using Work = std::function<void(int)>;   // argument: worker index in [0, NumThreads()]; NumThreads() = the thread that called RunAll
   void AddWork(Work w, int64_t priority = 0);
   // runs everything added so far (highest priority first) and waits; rethrows the first exception
   void RunAll();
@@ -180,14 +180,24 @@ class ThreadPool {
   int NumThreads() const { return (int)threads_.size(); }
 
  private:
+  // One RunAll = one Batch.  Workers pick it up under the lock when the generation changes and then drain it with
+  // atomic counters only: a batch of 256 tasks of 20 us each must not serialise on a mutex per task.  A worker that
+  // is late only ever touches the batch it picked up (kept alive by the shared_ptr).
+  struct Batch {
+    std::vector<std::pair<int64_t, Work>> tasks;
+    std::atomic<size_t> next{0}, done{0};
+    std::mutex err_m;
+    std::vector<std::string> errors;
+  };
   void Loop(int tid);
+  void Drain(Batch &batch, int tid);
   std::vector<std::thread> threads_;
-  std::vector<std::pair<int64_t, Work>> pending_, running_;
+  std::vector<std::pair<int64_t, Work>> pending_;
+  std::shared_ptr<Batch> batch_;
+  uint64_t generation_ = 0;
   std::mutex m_;
   std::condition_variable cv_work_, cv_done_;
-  size_t next_ = 0, done_ = 0;
   bool stop_ = false;
-  std::vector<std::string> errors_;
 };
 
 // CPUs local to a device: /sys/bus/pci/devices/<bus id>/local_cpulist intersected with the CPUs this process may

@@ -166,7 +166,7 @@ void Pipeline::Build(const std::vector<std::pair<std::string, std::string>> &out
   }
   slot_events_.assign(ring_, nullptr);
   if (!streams_.empty())
-    for (auto &e : slot_events_) KCHECK(daliamdEventCreate(&e, 0));
+    for (auto &e : slot_events_) KCHECK(daliamdEventCreate(&e, 2));  // the consumer sleeps in Outputs(), it does not poll
   if (op_timing_ && !streams_.empty())
     for (auto &n : nodes_) {
       if (n.type == OpType::CPU) continue;

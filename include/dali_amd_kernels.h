@@ -72,6 +72,7 @@ DALIAMD_API daliamdResult_t daliamdStreamCreate(daliamdStream_t *stream, int non
 DALIAMD_API daliamdResult_t daliamdStreamDestroy(daliamdStream_t stream);
 DALIAMD_API daliamdResult_t daliamdStreamSynchronize(daliamdStream_t stream);
 DALIAMD_API daliamdResult_t daliamdStreamWaitEvent(daliamdStream_t stream, daliamdEvent_t event);
+/* enable_timing: bit 0 = the event records time stamps, bit 1 = daliamdEventSynchronize on it blocks (sleeps) instead of polling */
 DALIAMD_API daliamdResult_t daliamdEventCreate(daliamdEvent_t *event, int enable_timing);
 DALIAMD_API daliamdResult_t daliamdEventDestroy(daliamdEvent_t event);
 DALIAMD_API daliamdResult_t daliamdEventRecord(daliamdEvent_t event, daliamdStream_t stream);
