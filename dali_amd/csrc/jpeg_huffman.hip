@@ -60,8 +60,12 @@ constexpr int kSegBytes = kSegLanes * kSliceBytes;
 constexpr int kCleanPadBytes = 40;
 // Block-start lists of the synchronisation pass: kListCap entries per lane in LDS + one slot that swallows the
 // overflow; the stride (in 16-bit entries) is an odd number of dwords so that lanes at the same index hit different banks.
+// A slice with more starts is decoded once more after the relaxation, writing its starts directly.  Measured on the
+// bench set (sync pass, us): cap 65: 371, 33: 390, 17: 311, 9: 326, 5: 332, 1: 322 - the store inside the relaxation
+// loop costs more than one extra decode of the slices that overflow, and a 50 KB workgroup leaves LDS for the other
+// stream's kernels.
 #ifndef DALIAMD_LIST_CAP
-#define DALIAMD_LIST_CAP 65
+#define DALIAMD_LIST_CAP 17
 #endif
 constexpr int kListCap = DALIAMD_LIST_CAP;       // odd, so that the stride below is an odd number of dwords
 constexpr int kListStride = kListCap + 1;
