@@ -926,7 +926,7 @@ static double SincD(double x) {  // include/dali/core/math_util.h:179-185
   return std::sin(x) / x;
 }
 static float SincF(float x) {   // math_util.h:188-194 (the float overload is the one windowed_sinc calls)
-  x *= (float)M_PI;
+  x = (float)(x * M_PI);       // `x *= M_PI`: the product is formed in double
   if (std::abs(x) < 1e-5f) return 1.0f - x * x * (1.0f / 6);
   return std::sin(x) / x;
 }

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstring>
 
+#include "dali_amd_host.h"
 #include "ops.h"
 #include "pipeline.h"
 
@@ -22,9 +23,10 @@ DALI_SCHEMA(decoders__Audio)
     .NumOutput(2)
     .AddOptionalArg("downmix", "If set to True, downmix all input channels to mono (1-D output).", ArgValue::Bool(false))
     .AddOptionalArg("dtype", "Output data type (FLOAT only).", ArgValue::Int(DALI_FLOAT))
-    .AddOptionalTypeArg("sample_rate", "Resampling is not supported in this build; must match the file if given.",
+    .AddOptionalTypeArg("sample_rate", "If specified, the target sample rate, in Hz, to which the audio is resampled.",
                         ArgType::FLOAT, true)
-    .AddOptionalArg("quality", "Ignored (no resampling).", ArgValue::Float(50.0));
+    .AddOptionalArg("quality", "Resampling quality, 0 is lowest, 100 is highest: 0 corresponds to 3 lobes of the sinc "
+                    "filter; 50 gives 16 lobes and 100 gives 64 lobes.", ArgValue::Float(50.0));
 DALI_SCHEMA(AudioDecoder).DocStr("Legacy alias of decoders.audio").NumInput(1).NumOutput(2).AddParent("decoders__Audio");
 
 struct WavInfo { int channels = 0, bits = 0, tag = 0; int64_t frames = 0; double rate = 0; const uint8_t *data = nullptr; };
@@ -66,6 +68,8 @@ class AudioDecoderCpu : public OperatorBase {
  public:
   explicit AudioDecoderCpu(const OpSpec &spec) : OperatorBase(spec), downmix_(spec.GetBool("downmix")) {
     DALI_ENFORCE(spec.GetInt("dtype") == DALI_FLOAT, "decoders.audio: only dtype=FLOAT is supported");
+    quality_ = (float)spec.GetFloat("quality");
+    DALI_ENFORCE(quality_ >= 0 && quality_ <= 100, "Resampling quality must be in [0..100] range");
   }
   bool SetupImpl(std::vector<OutputDesc> &desc, const Workspace &ws) override {
     const TensorList &in = ws.Input(0);
@@ -76,14 +80,16 @@ class AudioDecoderCpu : public OperatorBase {
     for (int i = 0; i < n; i++) {
       std::string src = i < (int)in.source_info.size() && !in.source_info[i].empty() ? in.source_info[i] : make_string("sample #", i);
       infos_[i] = ParseWav(static_cast<const uint8_t *>(in.raw(i)), in.nbytes(i), src);
-      if (downmix_ || infos_[i].channels == 1) desc[0].shape[i] = {infos_[i].frames};
-      else desc[0].shape[i] = {infos_[i].frames, infos_[i].channels};
     }
-    if (spec_.ArgumentDefined("sample_rate")) {
-      auto sr = GetPerSampleFloat(spec_, ws, "sample_rate", n);
-      for (int i = 0; i < n; i++)
-        DALI_ENFORCE(sr[i] <= 0 || sr[i] == (float)infos_[i].rate, "decoders.audio: resampling (", infos_[i].rate, " -> ",
-                     sr[i], " Hz) is not supported in this build");
+    target_rate_.assign(n, 0.0f);
+    if (spec_.ArgumentDefined("sample_rate")) target_rate_ = GetPerSampleFloat(spec_, ws, "sample_rate", n);
+    for (int i = 0; i < n; i++) {
+      // DecodedAudioShape (audio_decoder_impl.cc:38-47)
+      const bool resample = target_rate_[i] > 0 && (float)infos_[i].rate != target_rate_[i];
+      int64_t len = infos_[i].frames;
+      if (resample) len = (int64_t)std::ceil(infos_[i].frames * (double)target_rate_[i] / infos_[i].rate);
+      if (downmix_ || infos_[i].channels == 1) desc[0].shape[i] = {len};
+      else desc[0].shape[i] = {len, infos_[i].channels};
     }
     return true;
   }
@@ -92,8 +98,14 @@ class AudioDecoderCpu : public OperatorBase {
     for (int i = 0; i < out.num_samples(); i++) {
       ws.GetThreadPool().AddWork([&, i](int) {
         const WavInfo &w = infos_[i];
-        float *o = static_cast<float *>(out.raw(i));
         bool mono_out = downmix_ || w.channels == 1;
+        const bool resample = target_rate_[i] > 0 && (float)w.rate != target_rate_[i];
+        // decode (+ downmix) first, into the output or - when resampling follows - into a scratch buffer
+        // (DecodeAudio, audio_decoder_impl.cc:49-120)
+        std::vector<float> scratch;
+        const int och = mono_out ? 1 : w.channels;
+        if (resample) scratch.resize((size_t)w.frames * och);
+        float *o = resample ? scratch.data() : static_cast<float *>(out.raw(i));
         for (int64_t f = 0; f < w.frames; f++) {
           float acc = 0;
           for (int c = 0; c < w.channels; c++) {
@@ -104,7 +116,13 @@ class AudioDecoderCpu : public OperatorBase {
           }
           if (mono_out) o[f] = w.channels == 1 ? acc : acc / w.channels;
         }
-        *static_cast<float *>(rate.raw(i)) = (float)w.rate;
+        if (resample) {
+          const int64_t out_len = out.shape(i)[0];
+          if (daliamdAudioResampleHost(scratch.data(), w.frames, och, w.rate, target_rate_[i], quality_,
+                                       static_cast<float *>(out.raw(i)), out_len) != 0)
+            DALI_FAIL(daliamdHostGetLastErrorMessage());
+        }
+        *static_cast<float *>(rate.raw(i)) = resample ? target_rate_[i] : (float)w.rate;
       }, infos_[i].frames);
     }
     ws.GetThreadPool().RunAll();
@@ -112,6 +130,8 @@ class AudioDecoderCpu : public OperatorBase {
 
  private:
   bool downmix_;
+  float quality_ = 50.0f;
+  std::vector<float> target_rate_;
   std::vector<WavInfo> infos_;
 };
 DALI_REGISTER_OPERATOR(decoders__Audio, AudioDecoderCpu, CPU);
@@ -470,7 +490,7 @@ class AudioResampleGpu : public OperatorBase {
     quality_ = (float)spec.GetFloat("quality");
     DALI_ENFORCE(quality_ >= 0 && quality_ <= 100, "``quality`` out of range: ", quality_, "\nValid range is [0..100].");
     if (const ArgValue *d = spec.TryArg("dtype"))
-      DALI_ENFORCE(d->i == DALI_FLOAT, "AudioResample (gpu) produces float32 output only");
+      DALI_ENFORCE(d->i == DALI_FLOAT, "AudioResample produces float32 output only in this build");
   }
   bool SetupImpl(std::vector<OutputDesc> &desc, const Workspace &ws) override {
     const TensorList &in = ws.Input(0);
@@ -524,6 +544,19 @@ class AudioResampleGpu : public OperatorBase {
     out.SetLayout(ws.Input(0).layout());
     int n = (int)descs_.size();
     if (!n) return;
+    if (ws.backend == OpType::CPU) {  // one thread-pool task per sample on the host kernel
+      for (int i = 0; i < n; i++) {
+        descs_[i].out = static_cast<float *>(out.raw(i));
+        ws.GetThreadPool().AddWork([this, i](int) {
+          const auto &d = descs_[i];
+          if (daliamdAudioResampleHost(d.in, d.in_length, d.channels, d.in_rate, d.out_rate, quality_, d.out, d.out_length) != 0)
+            DALI_FAIL(daliamdHostGetLastErrorMessage());
+        }, descs_[i].out_length);
+      }
+      ws.GetThreadPool().RunAll();
+      NoteLaunch(ws, "host_audio_resample");
+      return;
+    }
     if (!lookup_size_) {
       lobes_ = daliamdAudioResampleLobes(quality_);
       std::vector<float> lookup((size_t)lobes_ * 64 + 1 + 5);
@@ -551,5 +584,7 @@ class AudioResampleGpu : public OperatorBase {
 };
 DALI_REGISTER_OPERATOR(AudioResample, AudioResampleGpu, GPU);
 DALI_REGISTER_OPERATOR(experimental__AudioResample, AudioResampleGpu, GPU);
+DALI_REGISTER_OPERATOR(AudioResample, AudioResampleGpu, CPU);  // same class: the host kernel when run on the CPU
+DALI_REGISTER_OPERATOR(experimental__AudioResample, AudioResampleGpu, CPU);
 
 }  // namespace daliamd_host

@@ -169,6 +169,13 @@ DALIAMD_HOST_API int64_t daliamdImageCachePolicyOnDecode(void *policy, const cha
                                                          uint64_t stored_size);
 DALIAMD_HOST_API int64_t daliamdImageCachePolicyFind(void *policy, const char *key);
 
+/* Audio resampling on the host, the arithmetic of daliamdAudioResampleRun (windowed sinc, `quality` 0..100 -> 3..64
+ * lobes): decoders.audio(sample_rate=...) and audio_resample(device="cpu")
+ * (dali/operators/decoder/audio/audio_decoder_impl.cc:47-120, dali/kernels/signal/resampling_cpu.cc:129-236).
+ * in: [in_length][channels] f32, out: [out_length][channels] f32.  Returns 0 on success. */
+DALIAMD_HOST_API int daliamdAudioResampleHost(const float *in, int64_t in_length, int channels, double in_rate, double out_rate,
+                                              float quality, float *out, int64_t out_length);
+
 #ifdef __cplusplus
 }
 #endif

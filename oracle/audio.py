@@ -260,7 +260,7 @@ def resample_window(lobes):
     i = np.arange(coeffs, dtype=np.float32)
     x = ((i - center) * scale).astype(np.float32)
     y = ((i - center) * scale_env).astype(np.float32)
-    xp = (x * np.float32(np.pi)).astype(np.float32)
+    xp = (x.astype(np.float64) * np.pi).astype(np.float32)       # `x *= M_PI`: the product is formed in double
     with np.errstate(invalid="ignore", divide="ignore"):
         sinc = np.where(np.abs(xp) < 1e-5, np.float32(1) - xp * xp * np.float32(1.0 / 6), np.sin(xp) / xp).astype(np.float32)
     hann = 0.5 * (1 + np.cos(y.astype(np.float64) * np.pi))

@@ -330,3 +330,45 @@ def test_dlpack_export_and_external_source_import():
     pipe.feed_input("x", [batch[1], batch[0]])        # a list of DLPack tensors = the samples
     (out,) = pipe.run()
     assert np.array_equal(out.at(0), batch[1].numpy())
+
+
+def _wav(x, sr):
+    import io, struct
+    pcm = np.round(np.clip(x, -1, 1) * 32767).astype("<i2")
+    ch = 1 if pcm.ndim == 1 else pcm.shape[1]
+    b = io.BytesIO()
+    b.write(b"RIFF" + struct.pack("<I", 36 + pcm.nbytes) + b"WAVE")
+    b.write(b"fmt " + struct.pack("<IHHIIHH", 16, 1, ch, sr, sr * 2 * ch, 2 * ch, 16))
+    b.write(b"data" + struct.pack("<I", pcm.nbytes) + pcm.tobytes())
+    return b.getvalue()
+
+
+def test_audio_decoder_resamples_and_cpu_audio_resample_match_oracle():
+    """decoders.audio(sample_rate=...) = decode (+ downmix) then the windowed-sinc resampler
+    (audio_decoder_impl.cc:38-120); fn.audio_resample on the CPU backend runs the same host kernel."""
+    from oracle import audio as A
+    from dali_amd import fn
+    from dali_amd.pipeline import Pipeline
+    rng = np.random.default_rng(7)
+    t = np.arange(6000) / 22050.0
+    mono = 0.4 * np.sin(2 * np.pi * 330 * t) + rng.normal(0, 0.01, t.size)
+    stereo = np.stack([mono, 0.5 * mono[::-1]], 1)
+    wavs = [_wav(mono, 22050), _wav(stereo, 22050)]
+    for downmix in (False, True):
+        pipe = Pipeline(batch_size=2, num_threads=2, device_id=None, prefetch_queue_depth=1)
+        with pipe:
+            enc = fn.external_source(name="wav")
+            audio, rate = fn.decoders.audio(enc, sample_rate=16000.0, quality=50.0, downmix=downmix)
+            plain, _ = fn.decoders.audio(enc, downmix=downmix)
+            again = fn.audio_resample(plain, in_rate=22050.0, out_rate=16000.0)
+            pipe.set_outputs(audio, rate, plain, again)
+        pipe.feed_input("wav", wavs)
+        audio, rate, plain, again = pipe.run()
+        for i in range(2):
+            src = plain.at(i)
+            ref = A.audio_resample(src, 22050.0, 16000.0, 50.0)
+            got = audio.at(i)
+            assert got.shape == ref.shape and float(rate.at(i)) == 16000.0, (got.shape, ref.shape)
+            assert np.abs(got - ref).max() <= 1e-4 and np.abs(got - ref).mean() <= 1e-6
+            assert np.array_equal(again.at(i), got), "audio_resample(cpu) must equal the decoder's resampling"
+        assert (audio.at(1).ndim == 1) == downmix
