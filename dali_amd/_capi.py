@@ -185,7 +185,7 @@ _HOST_SYMBOLS = [
     "daliamdJpegAnalyzeScan",
     "daliamdRandomCropBatch", "daliamdCoinFlipBatch", "daliamdPhiloxAdvanceSequence",
     "daliamdPhiloxStateToString", "daliamdPhiloxStateFromString", "daliamdPhiloxGenerate",
-    "daliamdCmnNormArgs", "daliamdCropAnchor", "daliamdResampleRunHost", "daliamdCmnRunHost",
+    "daliamdCmnNormArgs", "daliamdCropAnchor", "daliamdResampleRunHost", "daliamdCmnRunHost", "daliamdAudioResampleHost",
     "daliamdImageCachePolicyCreate", "daliamdImageCachePolicyDestroy", "daliamdImageCachePolicyOnDecode",
     "daliamdImageCachePolicyFind", "daliamdImageProbe", "daliamdImageDecodeRgb",
 ]
