@@ -229,9 +229,9 @@ void ThreadPool::RunAll() {
   // wake no more workers than the batch can feed (a worker woken from a deep idle state for one 10 us task costs more
   // than it contributes), and work on the batch from this thread as well: its share needs no wake-up at all
   const size_t total = batch->tasks.size();
-  const size_t helpers = std::min(threads_.size(), (total + 3) / 4);
-  if (helpers >= threads_.size()) cv_work_.notify_all();
-  else for (size_t i = 0; i < helpers; i++) cv_work_.notify_one();
+  // (this thread is one of the `active` ones, so the pool never runs more threads than it was sized for)
+  const size_t active = std::min(threads_.size(), (total + 3) / 4);
+  for (size_t i = 0; i + 1 < active; i++) cv_work_.notify_one();
   Drain(*batch, (int)threads_.size());
   {
     std::unique_lock<std::mutex> lk(m_);

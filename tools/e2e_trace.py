@@ -11,7 +11,7 @@ import bench  # noqa: E402
 enc = bench.make_dataset(0, 1024, workers=8)
 root = tempfile.mkdtemp(prefix="dali_amd_e2e_")
 bench.write_dataset(root, enc)
-for threads in (16, 12):
+for threads in (16, 12, 16, 8):
     r = bench.e2e_pipeline(root, 256, 0, iters=100, threads=threads)
     print("threads", threads, round(r["value"]), r["ms_per_batch"], flush=True)
 shutil.rmtree(root, ignore_errors=True)
