@@ -17,7 +17,7 @@ class DaliAmdError(RuntimeError):
 
 
 # ------------------------------------------------------------------ enums
-UINT8, FLOAT16, FLOAT, INT8 = 0, 1, 2, 3
+UINT8, FLOAT16, FLOAT, INT8, INT16, UINT16 = 0, 1, 2, 3, 4, 5
 LAYOUT_HWC, LAYOUT_CHW = 0, 1
 INTERP_NN, INTERP_LINEAR, INTERP_TRIANGULAR, INTERP_CUBIC, INTERP_LANCZOS3, INTERP_GAUSSIAN = 0, 1, 2, 3, 4, 5
 JPEG_GRAY, JPEG_YCC, JPEG_RGB = 0, 1, 2
@@ -76,7 +76,7 @@ class ResampleArgs(C.Structure):
                 ("min_filter", C.c_int32), ("mag_filter", C.c_int32), ("antialias", C.c_int32),
                 ("out", C.c_void_p), ("out_dtype", C.c_int32), ("out_layout", C.c_int32),
                 ("normalize", C.c_int32), ("mirror", C.c_int32), ("mean", C.c_float * 4),
-                ("inv_std", C.c_float * 4)]
+                ("inv_std", C.c_float * 4), ("in_dtype", C.c_int32), ("unrounded", C.c_int32)]
 
 
 class ResampleDesc(C.Structure):
@@ -90,7 +90,14 @@ class ResampleDesc(C.Structure):
                 ("out_layout", C.c_int32), ("normalize", C.c_int32), ("mirror", C.c_int32),
                 ("mean", C.c_float * 4), ("inv_std", C.c_float * 4), ("even_mask", C.c_uint32 * 8),
                 ("lds_bytes", C.c_int32), ("staged", C.c_int32), ("table_off", C.c_int64),
-                ("tab_start", C.c_int32), ("use_lut", C.c_int32), ("filter_kind", C.c_int32 * 2)]
+                ("tab_start", C.c_int32), ("use_lut", C.c_int32), ("filter_kind", C.c_int32 * 2),
+                ("in_dtype", C.c_int32), ("unrounded", C.c_int32), ("generic", C.c_int32), ("round_lanes", C.c_int32),
+                ("tmp_w", C.c_int32), ("tmp_h", C.c_int32), ("tmp_off", C.c_int64), ("gen_start", C.c_int64 * 2)]
+
+
+class ResamplePlan(C.Structure):
+    _fields_ = [("num_tiles", C.c_int32), ("lds_bytes", C.c_int32), ("table_entries", C.c_int32), ("reserved", C.c_int32),
+                ("workspace_bytes", C.c_size_t), ("generic_items", C.c_int64 * 2)]
 
 
 class CmnDesc(C.Structure):

@@ -15,7 +15,8 @@ import torch
 from . import _capi as capi
 
 _TORCH_DTYPE = {capi.UINT8: torch.uint8, capi.FLOAT16: torch.float16, capi.FLOAT: torch.float32,
-                capi.INT8: torch.int8}
+                capi.INT8: torch.int8, capi.INT16: torch.int16, capi.UINT16: torch.uint16}
+_KERNEL_DTYPE = {torch.uint8: capi.UINT8, torch.int16: capi.INT16, torch.uint16: capi.UINT16, torch.float32: capi.FLOAT}
 
 
 def _align(v, a):
@@ -653,28 +654,37 @@ class ImageTable:
 
     def __init__(self, images):
         for img in images:
-            if img.dtype != torch.uint8 or img.dim() != 3 or img.stride(2) != 1 or img.stride(1) != img.shape[2]:
-                raise capi.DaliAmdError("expected u8 HWC tensors with dense pixels")
+            if img.dtype not in _KERNEL_DTYPE or img.dim() != 3 or img.stride(2) != 1 or img.stride(1) != img.shape[2]:
+                raise capi.DaliAmdError("expected u8 (or i16 / u16 / f32) HWC tensors with dense pixels")
         self.n = len(images)
+        self.dtype = _KERNEL_DTYPE[images[0].dtype] if images else capi.UINT8
+        if any(_KERNEL_DTYPE[img.dtype] != self.dtype for img in images):
+            raise capi.DaliAmdError("all images of a batch must have the same element type")
+        self.esize = images[0].element_size() if images else 1
         self.device = images[0].device if self.n else torch.device("cuda")
         self.ptr = np.array([img.data_ptr() for img in images], np.uint64)
         shp = np.array([tuple(img.shape) for img in images], np.int32).reshape(-1, 3)
         self.h, self.w, self.c = shp[:, 0], shp[:, 1], shp[:, 2]
-        self.pitch = np.array([img.stride(0) for img in images], np.int32)
+        self.pitch = np.array([img.stride(0) * img.element_size() for img in images], np.int32)   # bytes
         self.images = images   # keeps the storage alive
 
 
 def resample_batch(images, out_size, rois=None, interp_min=capi.INTERP_LINEAR, interp_mag=capi.INTERP_LINEAR,
                    antialias=True, out_dtype=capi.UINT8, out_layout=capi.LAYOUT_HWC, mean=None, inv_std=None,
-                   mirror=None, out=None, return_descs=False, start_event=None):
+                   mirror=None, out=None, return_descs=False, start_event=None, unrounded=False):
     """Resamples a batch of u8 HWC device tensors (possibly row-strided views) to out_size=(H, W).
 
     rois[i] = (y0, x0, y1, x1) in source pixels or None.  With mean/inv_std the CropMirrorNormalize
     epilogue is fused: output dtype float16/float32, layout CHW or HWC, optional per-sample mirror.
-    Returns a dense tensor [N, ...]."""
+    i16 / u16 / f32 images resample to their own type (pass out_dtype=None); unrounded=True returns the float result of
+    the second pass as it is (fn.resize(dtype=FLOAT)).  Returns a dense tensor [N, ...]."""
     lib = capi.kernels()
     tab = images if isinstance(images, ImageTable) else ImageTable(images)
     n = tab.n
+    if unrounded:
+        out_dtype = capi.FLOAT
+    elif out_dtype is None or (tab.dtype != capi.UINT8 and out_dtype == capi.UINT8 and mean is None):
+        out_dtype = tab.dtype
     oh, ow = int(out_size[0]), int(out_size[1])
     dev = tab.device
     ch = int(tab.c[0]) if n else 3
@@ -703,6 +713,7 @@ def resample_batch(images, out_size, rois=None, interp_min=capi.INTERP_LINEAR, i
         a["out"] = out.data_ptr() + per_sample * np.arange(n, dtype=np.int64)
         a["out_dtype"], a["out_layout"] = out_dtype, out_layout
         a["normalize"] = 1 if normalize else 0
+        a["in_dtype"], a["unrounded"] = tab.dtype, 1 if unrounded else 0
         if mirror is not None:
             a["mirror"] = np.asarray(mirror, np.int32)
         if normalize:
@@ -711,18 +722,16 @@ def resample_batch(images, out_size, rois=None, interp_min=capi.INTERP_LINEAR, i
             _fill4(i4, inv_std)
             a["mean"], a["inv_std"] = m4, i4
     descs = np.zeros(max(n, 1), _dtype(capi.ResampleDesc))
-    nwg, lds, ws_bytes, entries = C.c_int(0), C.c_int(0), C.c_size_t(0), C.c_int(0)
-    capi.check(lib.daliamdResampleSetup(args.ctypes.data_as(C.c_void_p), n, descs.ctypes.data_as(C.c_void_p),
-                                        C.byref(nwg), C.byref(lds), C.byref(ws_bytes), C.byref(entries)))
+    plan = capi.ResamplePlan()
+    capi.check(lib.daliamdResampleSetup(args.ctypes.data_as(C.c_void_p), n, descs.ctypes.data_as(C.c_void_p), C.byref(plan)))
     descs_dev = _uploader.upload(descs, dev)
     stream_ptr = current_stream_ptr(dev)
-    ws = _stream_workspace(dev, stream_ptr, ws_bytes.value)
+    ws = _stream_workspace(dev, stream_ptr, plan.workspace_bytes)
     if start_event is not None:
         start_event.record()
-    capi.check(lib.daliamdResampleRun(stream_ptr, C.c_void_p(descs_dev.data_ptr()), n, nwg.value, lds.value,
-                                      C.c_void_p(ws.data_ptr()), C.c_size_t(ws_bytes.value), entries.value))
+    capi.check(lib.daliamdResampleRun(stream_ptr, C.c_void_p(descs_dev.data_ptr()), n, C.byref(plan), C.c_void_p(ws.data_ptr())))
     if return_descs:
-        return out, descs, nwg.value, lds.value
+        return out, descs, plan.num_tiles, plan.lds_bytes
     return out
 
 

@@ -679,6 +679,103 @@ __global__ __launch_bounds__(kResampleThreads) void ResampleKernel(const daliamd
 }
 
 // ---------------------------------------------------------------------------------------------
+// The other element types (i16, u16, f32 input; the unrounded float result): a plain two-launch version of the same
+// arithmetic - pass 0 resamples the first axis into an fp32 intermediate in the workspace (the reference's tmp surface:
+// the source ROI with the first-pass axis replaced by the output size), pass 1 the second axis into the output.  One
+// thread per element, coefficients and first taps from the per-sample tables.  Correct, not tuned.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float LoadElem(const void *base, int dtype, size_t byte_off, size_t elem) {
+  const uint8_t __attribute__((address_space(1))) *p = (const uint8_t __attribute__((address_space(1))) *)base + byte_off;
+  switch (dtype) {
+    case DALIAMD_UINT8: return (float)p[elem];
+    case DALIAMD_INT16: return (float)((const int16_t __attribute__((address_space(1))) *)p)[elem];
+    case DALIAMD_UINT16: return (float)((const uint16_t __attribute__((address_space(1))) *)p)[elem];
+    default: return ((const float __attribute__((address_space(1))) *)p)[elem];
+  }
+}
+
+// ConvertSat of the scalar tails (clamp(std::round)) or the SIMD store (clamp, then round half to even)
+__device__ __forceinline__ float RoundTyped(float v, int dtype, bool even) {
+  if (dtype == DALIAMD_FLOAT) return v;
+  const float lo = dtype == DALIAMD_INT16 ? -32768.0f : 0.0f;
+  const float hi = dtype == DALIAMD_UINT8 ? 255.0f : dtype == DALIAMD_INT16 ? 32767.0f : 65535.0f;
+  if (even) return rintf(fminf(fmaxf(v, lo), hi));   // NaN -> lo
+  float r = roundf(v);
+  if (!(r > lo)) return lo;
+  return fminf(r, hi);
+}
+
+__global__ __launch_bounds__(256) void ResampleGenericKernel(const daliamdResampleDesc *__restrict__ descs, int ndesc, int pass,
+                                                             int total_items, uint8_t *__restrict__ workspace) {
+  const int item = blockIdx.x * 256 + threadIdx.x;
+  if (item >= total_items) return;
+  int lo = 0, hi = ndesc - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].gen_start[pass] <= item) lo = mid; else hi = mid - 1;
+  }
+  // samples without work in this pass share their successor's start: step forward to the one that owns the item
+  const daliamdResampleDesc &d = descs[lo];
+  if (!d.generic) return;
+  const int local = item - (int)d.gen_start[pass];
+  const int C = d.channels;
+  const TableLayout L = MakeTableLayout(d);
+  GU32 *tab = (GU32 *)(workspace + d.table_off);
+  GI32 *xi = (GI32 *)tab + L.xi, *yi = (GI32 *)tab + L.yi;
+  GF32 *xc = (GF32 *)(tab + L.xc), *yc = (GF32 *)(tab + L.yc);
+  GF32 *tmp = (GF32 *)(workspace + d.tmp_off);
+  const int sup_x = d.support[0], sup_y = d.support[1];
+  const int ex = d.ext[0] - 1, ey = d.ext[1] - 1;
+  const bool vfirst = d.first_axis == 1;
+  const int tmp_w = d.tmp_w;
+  if (pass == 0) {
+    const int c = local % C, x = (local / C) % tmp_w, y = local / (C * tmp_w);
+    float acc = 0;
+    if (vfirst) {  // rows of the whole image, columns of the source ROI
+      const size_t col = (size_t)(d.lo[0] + x) * C + c;
+      for (int k = 0; k < sup_y; k++) {
+        const int sy = ClampI(yi[y] + k, 0, ey) + d.lo[1];
+        acc += LoadElem(d.in, d.in_dtype, (size_t)sy * d.in_pitch, col) * yc[(size_t)y * sup_y + k];
+      }
+    } else {       // columns of the whole image, rows of the source ROI
+      const size_t row_off = (size_t)(d.lo[1] + y) * d.in_pitch;
+      for (int k = 0; k < sup_x; k++) {
+        const int sx = ClampI(xi[x] + k, 0, ex) + d.lo[0];
+        acc += xc[(size_t)x * sup_x + k] * LoadElem(d.in, d.in_dtype, row_off, (size_t)sx * C + c);
+      }
+    }
+    tmp[local] = acc;
+    return;
+  }
+  const int c = local % C, x = (local / C) % d.out_w, y = local / (C * d.out_w);
+  float acc = 0;
+  bool even;
+  if (vfirst) {  // horizontal pass over the intermediate; rounding regions of ResampleHorz
+    for (int k = 0; k < sup_x; k++) {
+      const int sx = ClampI(xi[x] + k, 0, tmp_w - 1);
+      acc += xc[(size_t)x * sup_x + k] * tmp[((size_t)y * tmp_w + sx) * C + c];
+    }
+    even = (d.even_mask[(x >> 5) & 7] >> (x & 31)) & 1;
+  } else {       // vertical pass; ResampleVert: 256-element tiles, SIMD body then scalar tail
+    for (int k = 0; k < sup_y; k++) {
+      const int sy = ClampI(yi[y] + k, 0, d.tmp_h - 1);
+      acc += tmp[((size_t)sy * tmp_w + x) * C + c] * yc[(size_t)y * sup_y + k];
+    }
+    const int flat_w = d.out_w * C, f = x * C + c, t0 = f & ~255;
+    even = f < t0 + ((min(t0 + 256, flat_w) - t0) / d.round_lanes) * d.round_lanes;
+  }
+  const int xo = d.mirror ? d.out_w - 1 - x : x;
+  const size_t o = d.out_layout == DALIAMD_LAYOUT_CHW ? ((size_t)c * d.out_h + y) * d.out_w + xo : ((size_t)y * d.out_w + xo) * C + c;
+  const float r = RoundTyped(acc, d.out_dtype, even);
+  switch (d.out_dtype) {
+    case DALIAMD_UINT8: ((uint8_t __attribute__((address_space(1))) *)d.out)[o] = (uint8_t)r; break;
+    case DALIAMD_INT16: ((int16_t __attribute__((address_space(1))) *)d.out)[o] = (int16_t)r; break;
+    case DALIAMD_UINT16: ((uint16_t __attribute__((address_space(1))) *)d.out)[o] = (uint16_t)r; break;
+    default: ((float __attribute__((address_space(1))) *)d.out)[o] = r; break;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host-side setup: SeparableResamplingSetup<2>::SetupSample restated for the fused kernel
 // (resampling_setup.cc:46-122,131-201,271-337; params.h:43-60; resampling_filters.cuh:38-46)
 // ---------------------------------------------------------------------------------------------
@@ -733,14 +830,32 @@ static int SetupOne(const daliamdResampleArgs &a, daliamdResampleDesc &d, int in
                   "daliamdResampleSetup: sample %d has an empty input or output", index);
   DALIAMD_REQUIRE(a.channels >= 1 && a.channels <= 4, DALIAMD_ERROR_UNSUPPORTED,
                   "daliamdResampleSetup: sample %d: %d channels (supported: 1..4)", index, a.channels);
-  DALIAMD_REQUIRE(a.in_pitch >= a.in_w * a.channels, DALIAMD_ERROR_INVALID_ARGUMENT,
-                  "daliamdResampleSetup: sample %d: pitch %d < row bytes", index, a.in_pitch);
+  {
+    const int esize = a.in_dtype == DALIAMD_UINT8 ? 1 : a.in_dtype == DALIAMD_FLOAT ? 4 : 2;
+    DALIAMD_REQUIRE(a.in_pitch >= a.in_w * a.channels * esize, DALIAMD_ERROR_INVALID_ARGUMENT,
+                    "daliamdResampleSetup: sample %d: pitch %d < row bytes", index, a.in_pitch);
+  }
   DALIAMD_REQUIRE(a.min_filter >= DALIAMD_INTERP_NN && a.min_filter <= DALIAMD_INTERP_GAUSSIAN &&
                   a.mag_filter >= DALIAMD_INTERP_NN && a.mag_filter <= DALIAMD_INTERP_GAUSSIAN, DALIAMD_ERROR_INVALID_ARGUMENT,
                   "daliamdResampleSetup: sample %d: unknown interpolation type", index);
-  DALIAMD_REQUIRE(a.out_dtype == DALIAMD_UINT8 || a.out_dtype == DALIAMD_FLOAT16 || a.out_dtype == DALIAMD_FLOAT,
-                  DALIAMD_ERROR_UNSUPPORTED, "daliamdResampleSetup: unsupported output type %d", a.out_dtype);
+  const bool generic = a.in_dtype != DALIAMD_UINT8 || a.unrounded;
+  if (!generic) {
+    DALIAMD_REQUIRE(a.out_dtype == DALIAMD_UINT8 || a.out_dtype == DALIAMD_FLOAT16 || a.out_dtype == DALIAMD_FLOAT,
+                    DALIAMD_ERROR_UNSUPPORTED, "daliamdResampleSetup: unsupported output type %d", a.out_dtype);
+  } else {
+    DALIAMD_REQUIRE(a.in_dtype == DALIAMD_UINT8 || a.in_dtype == DALIAMD_INT16 || a.in_dtype == DALIAMD_UINT16 ||
+                    a.in_dtype == DALIAMD_FLOAT, DALIAMD_ERROR_UNSUPPORTED,
+                    "daliamdResampleSetup: sample %d: unsupported input type %d (u8, i16, u16, f32)", index, a.in_dtype);
+    DALIAMD_REQUIRE(a.unrounded ? a.out_dtype == DALIAMD_FLOAT : a.out_dtype == a.in_dtype, DALIAMD_ERROR_UNSUPPORTED,
+                    "daliamdResampleSetup: sample %d: the output type must be the input type, or FLOAT with `unrounded`", index);
+    DALIAMD_REQUIRE(!a.normalize, DALIAMD_ERROR_UNSUPPORTED,
+                    "daliamdResampleSetup: sample %d: the fused normalisation needs u8 input", index);
+  }
   memset(&d, 0, sizeof(d));
+  d.in_dtype = a.in_dtype; d.unrounded = a.unrounded; d.generic = generic ? 1 : 0;
+  // lanes of the reference's SIMD store for the output type: 16 bytes / sizeof(Out) (simd.h:314-327)
+  // (the fused path rounds to u8 before its normalisation epilogue, whatever the final type)
+  d.round_lanes = !generic || a.out_dtype == DALIAMD_UINT8 ? 16 : (a.out_dtype == DALIAMD_INT16 || a.out_dtype == DALIAMD_UINT16) ? 8 : 4;
   d.in = a.in; d.out = a.out;
   d.in_h = a.in_h; d.in_w = a.in_w; d.channels = a.channels; d.in_pitch = a.in_pitch;
   d.out_h = a.out_h; d.out_w = a.out_w;
@@ -841,8 +956,9 @@ static int SetupOne(const daliamdResampleArgs &a, daliamdResampleDesc &d, int in
       int x = 0;
       for (int r = 0; r < 4; r++) {
         int ox1 = bounds[r + 1];
-        for (; x + 16 <= ox1; x += 16)
-          for (int l = 0; l < 16; l++) d.even_mask[(x + l) >> 5] |= 1u << ((x + l) & 31);
+        const int lanes = d.round_lanes;
+        for (; x + lanes <= ox1; x += lanes)
+          for (int l = 0; l < lanes; l++) d.even_mask[(x + l) >> 5] |= 1u << ((x + l) & 31);
         for (; x < ox1; x++) {}
       }
     } else {
@@ -888,6 +1004,12 @@ static int SetupOne(const daliamdResampleArgs &a, daliamdResampleDesc &d, int in
   d.tile_w = tw; d.tile_h = th;
   d.tiles_x = (a.out_w + tw - 1) / tw;
   d.tiles_y = (a.out_h + th - 1) / th;
+  if (generic) {  // the two-launch path: no tiles, an fp32 intermediate of the reference's shape in the workspace
+    d.tiles_x = d.tiles_y = 0;
+    d.tmp_w = d.first_axis == 0 ? a.out_w : d.ext[0];
+    d.tmp_h = d.first_axis == 1 ? a.out_h : d.ext[1];
+    d.use_lut = 0;
+  }
   d.lds_bytes = (int)lds_need(tw, th, staged);
   return DALIAMD_SUCCESS;
 }
@@ -897,27 +1019,39 @@ static int SetupOne(const daliamdResampleArgs &a, daliamdResampleDesc &d, int in
 extern "C" {
 
 daliamdResult_t daliamdResampleSetup(const daliamdResampleArgs *args, int n, daliamdResampleDesc *descs,
-                                     int *num_workgroups, int *lds_bytes, size_t *workspace_bytes, int *table_entries) {
-  DALIAMD_REQUIRE(args && descs && num_workgroups && lds_bytes && workspace_bytes && table_entries && n >= 0, DALIAMD_ERROR_INVALID_ARGUMENT,
-                  "daliamdResampleSetup: NULL argument");
+                                     daliamdResamplePlan *plan) {
+  DALIAMD_REQUIRE(args && descs && plan && n >= 0, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdResampleSetup: NULL argument");
   int wg = 0, lds = 0, entries = 0;
   size_t ws = 0;
+  int64_t gen[2] = {0, 0};
   for (int i = 0; i < n; i++) {
     int rc = daliamd::SetupOne(args[i], descs[i], i);
     if (rc != DALIAMD_SUCCESS) return (daliamdResult_t)rc;
     descs[i].wg_start = wg;
     wg += descs[i].tiles_x * descs[i].tiles_y;
-    lds = lds > descs[i].lds_bytes ? lds : descs[i].lds_bytes;
+    if (!descs[i].generic) lds = lds > descs[i].lds_bytes ? lds : descs[i].lds_bytes;
     descs[i].table_off = (int64_t)ws;
     descs[i].tab_start = entries;
     ws += ((size_t)daliamd::MakeTableLayout(descs[i]).words * 4 + 15) & ~(size_t)15;
     entries += daliamd::TableEntries(descs[i]);
+    descs[i].gen_start[0] = gen[0];
+    descs[i].gen_start[1] = gen[1];
+    if (descs[i].generic) {
+      descs[i].tmp_off = (int64_t)ws;
+      ws += ((size_t)descs[i].tmp_w * descs[i].tmp_h * descs[i].channels * 4 + 15) & ~(size_t)15;
+      gen[0] += (int64_t)descs[i].tmp_w * descs[i].tmp_h * descs[i].channels;
+      gen[1] += (int64_t)descs[i].out_w * descs[i].out_h * descs[i].channels;
+    }
   }
-  *num_workgroups = wg;
-  *lds_bytes = lds;
-  // ... and behind the tables one 128-byte record per tile
-  *workspace_bytes = ((ws + 127) & ~(size_t)127) + (size_t)wg * sizeof(daliamd::TileRec);
-  *table_entries = entries;
+  DALIAMD_REQUIRE(gen[0] < (1ll << 31) && gen[1] < (1ll << 31), DALIAMD_ERROR_UNSUPPORTED,
+                  "daliamdResampleSetup: too many elements for the generic path in one batch");
+  plan->num_tiles = wg;
+  plan->lds_bytes = lds;
+  plan->table_entries = entries;
+  // ... and behind the tables (and intermediates) one 128-byte record per tile
+  plan->workspace_bytes = ((ws + 127) & ~(size_t)127) + (size_t)wg * sizeof(daliamd::TileRec);
+  plan->generic_items[0] = gen[0];
+  plan->generic_items[1] = gen[1];
   return DALIAMD_SUCCESS;
 }
 
@@ -944,31 +1078,42 @@ static const float *DeviceFilterTables() {
 }
 
 daliamdResult_t daliamdResampleRun(daliamdStream_t stream, const daliamdResampleDesc *descs_dev, int n,
-                                   int num_workgroups, int lds_bytes, void *workspace_dev, size_t workspace_bytes,
-                                   int table_entries) {
-  if (n == 0 || num_workgroups == 0) return DALIAMD_SUCCESS;
-  DALIAMD_REQUIRE(descs_dev && n > 0 && num_workgroups > 0 && lds_bytes >= 0 && lds_bytes <= daliamd::kMaxLds,
-                  DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdResampleRun: invalid argument");
-  DALIAMD_REQUIRE(workspace_dev && workspace_bytes > 0 && table_entries > 0, DALIAMD_ERROR_INVALID_ARGUMENT,
+                                   const daliamdResamplePlan *plan, void *workspace_dev) {
+  if (n == 0) return DALIAMD_SUCCESS;
+  DALIAMD_REQUIRE(descs_dev && plan && n > 0, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdResampleRun: invalid argument");
+  const int num_tiles = plan->num_tiles, table_entries = plan->table_entries;
+  if (num_tiles == 0 && plan->generic_items[1] == 0) return DALIAMD_SUCCESS;
+  DALIAMD_REQUIRE(plan->lds_bytes >= 0 && plan->lds_bytes <= daliamd::kMaxLds, DALIAMD_ERROR_INVALID_ARGUMENT,
+                  "daliamdResampleRun: invalid plan");
+  DALIAMD_REQUIRE(workspace_dev && plan->workspace_bytes > 0 && table_entries > 0, DALIAMD_ERROR_INVALID_ARGUMENT,
                   "daliamdResampleRun: the table workspace is missing (size it with daliamdResampleSetup)");
   const float *filter_tables = DeviceFilterTables();
   DALIAMD_REQUIRE(filter_tables, DALIAMD_ERROR_HIP, "daliamdResampleRun: could not set up the filter tables on the device");
-  const size_t rec_bytes = (size_t)num_workgroups * sizeof(daliamd::TileRec);
-  DALIAMD_REQUIRE(workspace_bytes >= rec_bytes, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdResampleRun: workspace too small");
-  const size_t tile_rec_off = workspace_bytes - rec_bytes;   // as laid out by Setup
+  const size_t rec_bytes = (size_t)num_tiles * sizeof(daliamd::TileRec);
+  DALIAMD_REQUIRE(plan->workspace_bytes >= rec_bytes, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdResampleRun: workspace too small");
+  const size_t tile_rec_off = plan->workspace_bytes - rec_bytes;   // as laid out by Setup
+  uint8_t *ws = static_cast<uint8_t *>(workspace_dev);
   {
     daliamd::KernelTimer timer("ResampleTablesKernel", (hipStream_t)stream);
-    const int total = table_entries + num_workgroups;
+    const int total = table_entries + num_tiles;
     hipLaunchKernelGGL(daliamd::ResampleTablesKernel, dim3((total + daliamd::kTableThreads - 1) / daliamd::kTableThreads),
-                       dim3(daliamd::kTableThreads), 0, (hipStream_t)stream, descs_dev, n, table_entries, num_workgroups,
-                       static_cast<uint8_t *>(workspace_dev), tile_rec_off, filter_tables);
+                       dim3(daliamd::kTableThreads), 0, (hipStream_t)stream, descs_dev, n, table_entries, num_tiles, ws,
+                       tile_rec_off, filter_tables);
   }
-  {
+  if (num_tiles > 0) {
     daliamd::KernelTimer timer("ResampleKernel", (hipStream_t)stream);
-    const int wgs = (num_workgroups + daliamd::kTilesPerWg - 1) / daliamd::kTilesPerWg;
-    hipLaunchKernelGGL(daliamd::ResampleKernel, dim3(daliamd::XcdGrid(wgs)), dim3(daliamd::kResampleThreads), lds_bytes,
-                       (hipStream_t)stream, descs_dev, n, wgs, num_workgroups, static_cast<const uint8_t *>(workspace_dev),
-                       tile_rec_off);
+    const int wgs = (num_tiles + daliamd::kTilesPerWg - 1) / daliamd::kTilesPerWg;
+    hipLaunchKernelGGL(daliamd::ResampleKernel, dim3(daliamd::XcdGrid(wgs)), dim3(daliamd::kResampleThreads), plan->lds_bytes,
+                       (hipStream_t)stream, descs_dev, n, wgs, num_tiles, static_cast<const uint8_t *>(ws), tile_rec_off);
+  }
+  if (plan->generic_items[1] > 0) {  // samples of other element types: first-axis pass into the workspace, then the second
+    daliamd::KernelTimer timer("ResampleGenericKernel", (hipStream_t)stream);
+    for (int pass = 0; pass < 2; pass++) {
+      const int items = (int)plan->generic_items[pass];
+      if (items == 0) continue;
+      hipLaunchKernelGGL(daliamd::ResampleGenericKernel, dim3((items + 255) / 256), dim3(256), 0, (hipStream_t)stream, descs_dev,
+                         n, pass, items, ws);
+    }
   }
   DALIAMD_HIP_CHECK(hipGetLastError());
   return DALIAMD_SUCCESS;

@@ -150,11 +150,120 @@ struct Epilogue {
 
 using namespace daliamd_host;
 
+namespace {
+inline float LoadElem(const uint8_t *row, int dtype, size_t elem) {
+  switch (dtype) {
+    case DALIAMD_UINT8: return (float)row[elem];
+    case DALIAMD_INT16: { int16_t v; memcpy(&v, row + 2 * elem, 2); return (float)v; }
+    case DALIAMD_UINT16: { uint16_t v; memcpy(&v, row + 2 * elem, 2); return (float)v; }
+    default: { float v; memcpy(&v, row + 4 * elem, 4); return v; }
+  }
+}
+// ConvertSat of the scalar tails (clamp(std::round)) or the SIMD store (clamp, then round half to even)
+inline float RoundTyped(float v, int dtype, bool even) {
+  if (dtype == DALIAMD_FLOAT) return v;
+  const float lo = dtype == DALIAMD_INT16 ? -32768.0f : 0.0f;
+  const float hi = dtype == DALIAMD_UINT8 ? 255.0f : dtype == DALIAMD_INT16 ? 32767.0f : 65535.0f;
+  if (even) return std::nearbyint(std::fmin(std::fmax(v, lo), hi));
+  const float r = RoundAway(v);
+  if (!(r > lo)) return lo;
+  return std::fmin(r, hi);
+}
+inline void StoreTyped(void *out, int dtype, size_t o, float r) {
+  switch (dtype) {
+    case DALIAMD_UINT8: static_cast<uint8_t *>(out)[o] = (uint8_t)r; break;
+    case DALIAMD_INT16: static_cast<int16_t *>(out)[o] = (int16_t)r; break;
+    case DALIAMD_UINT16: static_cast<uint16_t *>(out)[o] = (uint16_t)r; break;
+    default: static_cast<float *>(out)[o] = r; break;
+  }
+}
+
+// i16 / u16 / f32 input or the unrounded float result: the same two passes, element by element (the device side's
+// ResampleGenericKernel)
+int ResampleGenericHost(const daliamdResampleDesc &d) {
+  const int C = d.channels, sup_x = d.support[0], sup_y = d.support[1];
+  const AxisTable tx = BuildTable(0, d.filter_kind[0], d.out_w, d.origin[0], d.scale[0], d.fanchor[0], d.fscale[0], sup_x);
+  const AxisTable ty = BuildTable(1, d.filter_kind[1], d.out_h, d.origin[1], d.scale[1], d.fanchor[1], d.fscale[1], sup_y);
+  const int ex = d.ext[0] - 1, ey = d.ext[1] - 1;
+  const uint8_t *in = d.in;
+  const int tmp_w = d.tmp_w, tmp_h = d.tmp_h;
+  std::vector<float> tmp((size_t)tmp_w * tmp_h * C);
+  const bool vfirst = d.first_axis == 1;
+  for (int y = 0; y < tmp_h; y++)
+    for (int x = 0; x < tmp_w; x++)
+      for (int c = 0; c < C; c++) {
+        float acc = 0;
+        if (vfirst) {
+          for (int k = 0; k < sup_y; k++) {
+            const int sy = ClampI(ty.first[y] + k, 0, ey) + d.lo[1];
+            acc += LoadElem(in + (size_t)sy * d.in_pitch, d.in_dtype, (size_t)(d.lo[0] + x) * C + c) * ty.coef[(size_t)y * sup_y + k];
+          }
+        } else {
+          const uint8_t *row = in + (size_t)(d.lo[1] + y) * d.in_pitch;
+          for (int k = 0; k < sup_x; k++) {
+            const int sx = ClampI(tx.first[x] + k, 0, ex) + d.lo[0];
+            acc += tx.coef[(size_t)x * sup_x + k] * LoadElem(row, d.in_dtype, (size_t)sx * C + c);
+          }
+        }
+        tmp[((size_t)y * tmp_w + x) * C + c] = acc;
+      }
+  // rounding regions of an H-last pass for any width, with the SIMD width of the output type
+  std::vector<uint8_t> even_col(d.out_w, 0);
+  const int lanes = d.round_lanes;
+  if (vfirst) {
+    const int ow = d.out_w, in_w = d.ext[0];
+    const bool flipped = tx.first[ow - 1] < tx.first[0];
+    int first_regular = 0, last_regular = ow - 1;
+    if (flipped) {
+      while (first_regular < ow && tx.first[first_regular] + sup_x > in_w) first_regular++;
+      while (last_regular >= 0 && tx.first[last_regular] < 0) last_regular--;
+    } else {
+      while (first_regular < ow && tx.first[first_regular] < 0) first_regular++;
+      while (last_regular >= 0 && tx.first[last_regular] + sup_x > in_w) last_regular--;
+    }
+    const int bounds[5] = {0, std::min(first_regular, last_regular + 1), first_regular, last_regular + 1, ow};
+    int x = 0;
+    for (int r = 0; r < 4; r++) {
+      const int ox1 = bounds[r + 1];
+      for (; x + lanes <= ox1; x += lanes)
+        for (int l = 0; l < lanes; l++) even_col[x + l] = 1;
+      x = std::max(x, ox1);
+    }
+  }
+  const int flat_w = d.out_w * C;
+  for (int y = 0; y < d.out_h; y++)
+    for (int x = 0; x < d.out_w; x++)
+      for (int c = 0; c < C; c++) {
+        float acc = 0;
+        bool even;
+        if (vfirst) {
+          for (int k = 0; k < sup_x; k++) {
+            const int sx = ClampI(tx.first[x] + k, 0, tmp_w - 1);
+            acc += tx.coef[(size_t)x * sup_x + k] * tmp[((size_t)y * tmp_w + sx) * C + c];
+          }
+          even = even_col[x] != 0;
+        } else {
+          for (int k = 0; k < sup_y; k++) {
+            const int sy = ClampI(ty.first[y] + k, 0, tmp_h - 1);
+            acc += tmp[((size_t)sy * tmp_w + x) * C + c] * ty.coef[(size_t)y * sup_y + k];
+          }
+          const int f = x * C + c, t0 = f & ~255;
+          even = f < t0 + ((std::min(t0 + 256, flat_w) - t0) / lanes) * lanes;
+        }
+        const int xo = d.mirror ? d.out_w - 1 - x : x;
+        const size_t o = d.out_layout == DALIAMD_LAYOUT_CHW ? ((size_t)c * d.out_h + y) * d.out_w + xo : ((size_t)y * d.out_w + xo) * C + c;
+        StoreTyped(d.out, d.out_dtype, o, RoundTyped(acc, d.out_dtype, even));
+      }
+  return 0;
+}
+}  // namespace
+
 extern "C" int daliamdResampleRunHost(const daliamdResampleDesc *desc) {
   if (!desc || !desc->in || !desc->out) return Fail("daliamdResampleRunHost: NULL descriptor or buffer");
   const daliamdResampleDesc &d = *desc;
   const int C = d.channels, pitch = d.in_pitch;
   if (C < 1 || C > 4) return Fail("daliamdResampleRunHost: %d channels (supported: 1..4)", C);
+  if (d.generic) return ResampleGenericHost(d);
   const int sup_x = d.support[0], sup_y = d.support[1];
   const AxisTable tx = BuildTable(0, d.filter_kind[0], d.out_w, d.origin[0], d.scale[0], d.fanchor[0], d.fscale[0], sup_x);
   const AxisTable ty = BuildTable(1, d.filter_kind[1], d.out_h, d.origin[1], d.scale[1], d.fanchor[1], d.fscale[1], sup_y);

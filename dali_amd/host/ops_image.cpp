@@ -974,7 +974,7 @@ DALI_SCHEMA(ResamplingFilterAttr)
     .AddOptionalArg("mag_filter", "Filter used when scaling up.", ArgValue::Int(DALI_INTERP_LINEAR), true)
     .AddOptionalArg("min_filter", "Filter used when scaling down.", ArgValue::Int(DALI_INTERP_LINEAR), true)
     .AddOptionalArg("antialias", "If enabled, it applies an antialiasing filter when scaling down.", ArgValue::Bool(true))
-    .AddOptionalTypeArg("dtype", "Output data type. Must be same as input type (uint8).", ArgType::INT)
+    .AddOptionalTypeArg("dtype", "Output data type: the input type (uint8, int16, uint16 or float) or FLOAT.", ArgType::INT)
     .AddOptionalArg("temp_buffer_hint", "Ignored (the intermediate lives in LDS).", ArgValue::Int(0))
     .AddOptionalArg("minibatch_size", "Ignored (one launch per batch).", ArgValue::Int(32));
 
@@ -1012,8 +1012,30 @@ struct FilterArgs {
     else if (has_interp) min_filter = ToKernelInterp(spec.GetInt("interp_type"));
     if (has_mag) mag_filter = ToKernelInterp(spec.GetInt("mag_filter"));
     else if (has_interp) mag_filter = ToKernelInterp(spec.GetInt("interp_type"));
-    if (const ArgValue *d = spec.TryArg("dtype"))
-      DALI_ENFORCE(d->i == DALI_UINT8, "Resampling output dtype must be the input type (uint8)");
+    if (const ArgValue *d = spec.TryArg("dtype")) dtype = (int)d->i;
+  }
+  int dtype = -1;  // `dtype` argument: absent = the input's type
+
+  // element types of one sample: u8 / i16 / u16 / f32 in (resize_base.cc:41,49), out = the input's type or FLOAT (the
+  // unrounded result).  Returns the DALI type of the output.
+  DALIDataType ApplyTypes(daliamdResampleArgs &a, DALIDataType in_type, const char *op) const {
+    switch (in_type) {
+      case DALI_UINT8: a.in_dtype = DALIAMD_UINT8; break;
+      case DALI_INT16: a.in_dtype = DALIAMD_INT16; break;
+      case DALI_UINT16: a.in_dtype = DALIAMD_UINT16; break;
+      case DALI_FLOAT: a.in_dtype = DALIAMD_FLOAT; break;
+      default: DALI_FAIL(op, ": unsupported input type ", TypeName(in_type), " (supported: uint8, int16, uint16, float)");
+    }
+    DALI_ENFORCE(dtype < 0 || dtype == (int)in_type || dtype == DALI_FLOAT, op,
+                 ": the output type must be the input type or FLOAT, got ", TypeName((DALIDataType)dtype));
+    if (dtype == DALI_FLOAT && in_type != DALI_FLOAT) {
+      a.unrounded = 1;
+      a.out_dtype = DALIAMD_FLOAT;
+      return DALI_FLOAT;
+    }
+    a.unrounded = 0;
+    a.out_dtype = a.in_dtype;
+    return in_type;
   }
 };
 
@@ -1022,9 +1044,8 @@ static void LaunchResample(Workspace &ws, DescUploader &up, std::vector<daliamdR
   int n = (int)args.size();
   if (!n) return;
   descs.resize(n);
-  int nwg = 0, lds = 0, entries = 0;
-  size_t scratch = 0;
-  KCHECK(daliamdResampleSetup(args.data(), n, descs.data(), &nwg, &lds, &scratch, &entries));
+  daliamdResamplePlan plan{};
+  KCHECK(daliamdResampleSetup(args.data(), n, descs.data(), &plan));
   if (ws.backend == OpType::CPU) {
     // CPU backend: the same descriptors, one thread-pool task per sample (resize_op_impl_cpu.h:84-107)
     for (int i = 0; i < n; i++)
@@ -1036,8 +1057,8 @@ static void LaunchResample(Workspace &ws, DescUploader &up, std::vector<daliamdR
     return;
   }
   auto *dev = static_cast<const daliamdResampleDesc *>(
-      up.Upload(descs.data(), descs.size() * sizeof(descs[0]), ws.stream, ws.ring + 1, scratch));
-  KCHECK(daliamdResampleRun(ws.stream, dev, n, nwg, lds, up.Scratch(), scratch, entries));
+      up.Upload(descs.data(), descs.size() * sizeof(descs[0]), ws.stream, ws.ring + 1, plan.workspace_bytes));
+  KCHECK(daliamdResampleRun(ws.stream, dev, n, &plan, up.Scratch()));
   NoteLaunch(ws, what);
 }
 
@@ -1046,7 +1067,7 @@ static void FillSourceArgs(daliamdResampleArgs &a, const TensorList &in, int i) 
   DALI_ENFORCE(s.size() == 3, "Expected a three-dimensional HWC input, got ", s.size(), " dimensions");
   a.in = static_cast<const uint8_t *>(in.raw(i));
   a.in_h = (int32_t)s[0]; a.in_w = (int32_t)s[1]; a.channels = (int32_t)s[2];
-  a.in_pitch = (int32_t)(in.row_pitch(i) ? in.row_pitch(i) : s[1] * s[2]);
+  a.in_pitch = (int32_t)(in.row_pitch(i) ? in.row_pitch(i) : s[1] * s[2] * TypeSize(in.type()));   // bytes
 }
 
 class RandomResizedCropGpu : public OperatorBase {
@@ -1072,7 +1093,6 @@ class RandomResizedCropGpu : public OperatorBase {
   bool SetupImpl(std::vector<OutputDesc> &desc, const Workspace &ws) override {
     const TensorList &in = ws.Input(0);
     int n = in.num_samples();
-    DALI_ENFORCE(in.type() == DALI_UINT8, "RandomResizedCrop (gpu): only uint8 input is supported, got ", TypeName(in.type()));
     shapes_hw_.resize(2 * n); anchors_.resize(2 * n); crops_.resize(2 * n);
     args_.assign(n, daliamdResampleArgs{});
     int ch = 3;
@@ -1091,18 +1111,20 @@ class RandomResizedCropGpu : public OperatorBase {
       a.roi_y1 = (float)(anchors_[2 * i] + crops_[2 * i]); a.roi_x1 = (float)(anchors_[2 * i + 1] + crops_[2 * i + 1]);
       a.out_h = out_h_; a.out_w = out_w_;
       a.min_filter = filters_.min_filter; a.mag_filter = filters_.mag_filter; a.antialias = filters_.antialias;
-      a.out_dtype = DALIAMD_UINT8; a.out_layout = DALIAMD_LAYOUT_HWC;
+      a.out_layout = DALIAMD_LAYOUT_HWC;
+      out_type_ = filters_.ApplyTypes(a, in.type(), "RandomResizedCrop");
     }
     n_ = n; ch_ = ch;
-    if (fused_) return false;  // no buffer: the consumer launches the fused kernel
-    desc[0].type = DALI_UINT8;
+    plain_u8_ = in.type() == DALI_UINT8 && out_type_ == DALI_UINT8;
+    if (fused_ && plain_u8_) return false;  // no buffer: the consumer launches the fused kernel
+    desc[0].type = n ? out_type_ : in.type();
     desc[0].shape.assign(n, TensorShape{out_h_, out_w_, ch});
     return true;
   }
 
   void RunImpl(Workspace &ws) override {
     TensorList &out = ws.Output(0);
-    if (fused_) {
+    if (fused_ && plain_u8_) {
       auto d = std::make_shared<DeferredResample>();
       d->source = ws.inputs[0];
       d->args = args_;
@@ -1111,6 +1133,7 @@ class RandomResizedCropGpu : public OperatorBase {
       out.deferred = d;
       out.SetLayout("HWC");
     } else {
+      out.deferred.reset();
       out.SetLayout("HWC");
       for (int i = 0; i < n_; i++) {
         // the kernel writes dense HWC rows; request that from the executor by a dense pitch
@@ -1136,7 +1159,8 @@ class RandomResizedCropGpu : public OperatorBase {
   int out_h_, out_w_, num_attempts_, n_ = 0, ch_ = 3;
   float ar_lo_, ar_hi_, area_lo_, area_hi_;
   daliamdPhiloxState master_;
-  bool fused_ = false;
+  bool fused_ = false, plain_u8_ = true;
+  DALIDataType out_type_ = DALI_UINT8;
   std::vector<int32_t> shapes_hw_, anchors_, crops_;
   std::vector<daliamdResampleArgs> args_;
   std::vector<daliamdResampleDesc> descs_;
@@ -1290,7 +1314,6 @@ class ResizeGpu : public OperatorBase {
   bool SetupImpl(std::vector<OutputDesc> &desc, const Workspace &ws) override {
     const TensorList &in = ws.Input(0);
     const int n = in.num_samples();
-    DALI_ENFORCE(in.type() == DALI_UINT8, "Resize (gpu): only uint8 input is supported, got ", TypeName(in.type()));
     std::vector<float> rx, ry, rs;
     std::vector<std::vector<float>> size, roi_start, roi_end;
     if (has_x_) rx = GetPerSampleFloat(spec_, ws, "resize_x", n);
@@ -1303,12 +1326,13 @@ class ResizeGpu : public OperatorBase {
       roi_end = GetPerSampleFloatVec(spec_, ws, "roi_end", n);
     }
     args_.assign(n, daliamdResampleArgs{});
-    desc[0].type = DALI_UINT8;
+    desc[0].type = in.type();
     desc[0].shape.resize(n);
     int ch = 3;
     for (int i = 0; i < n; i++) {
       auto &a = args_[i];
       FillSourceArgs(a, in, i);
+      desc[0].type = filters_.ApplyTypes(a, in.type(), "Resize");
       ch = a.channels;
       const int in_hw[2] = {a.in_h, a.in_w};
       float req[2] = {0, 0};  // H, W
@@ -1364,11 +1388,11 @@ class ResizeGpu : public OperatorBase {
       a.roi_y0 = lo[0]; a.roi_x0 = lo[1]; a.roi_y1 = hi[0]; a.roi_x1 = hi[1];
       a.out_h = out_hw[0]; a.out_w = out_hw[1];
       a.min_filter = filters_.min_filter; a.mag_filter = filters_.mag_filter; a.antialias = filters_.antialias;
-      a.out_dtype = DALIAMD_UINT8; a.out_layout = DALIAMD_LAYOUT_HWC;
+      a.out_layout = DALIAMD_LAYOUT_HWC;
       desc[0].shape[i] = TensorShape{out_hw[0], out_hw[1], ch};
     }
     n_ = n; ch_ = ch;
-    uniform_ = n > 0;
+    uniform_ = n > 0 && in.type() == DALI_UINT8 && desc[0].type == DALI_UINT8;   // only u8 -> u8 can be deferred
     for (int i = 1; i < n; i++) uniform_ &= args_[i].out_h == args_[0].out_h && args_[i].out_w == args_[0].out_w;
     if (fused_ && uniform_) return false;  // the consumer launches the fused kernel
     return true;

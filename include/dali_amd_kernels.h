@@ -93,7 +93,9 @@ DALIAMD_API daliamdResult_t daliamdMemcpy2DD2DAsync(void *dst, size_t dst_pitch,
                                                     size_t width_bytes, size_t height, daliamdStream_t s);
 
 /* Element types of kernel outputs (subset of DALIDataType, include/dali/core/dali_data_type.h) */
-typedef enum { DALIAMD_UINT8 = 0, DALIAMD_FLOAT16 = 1, DALIAMD_FLOAT = 2, DALIAMD_INT8 = 3 } daliamdDType_t;
+typedef enum {
+  DALIAMD_UINT8 = 0, DALIAMD_FLOAT16 = 1, DALIAMD_FLOAT = 2, DALIAMD_INT8 = 3, DALIAMD_INT16 = 4, DALIAMD_UINT16 = 5
+} daliamdDType_t;
 typedef enum { DALIAMD_LAYOUT_HWC = 0, DALIAMD_LAYOUT_CHW = 1 } daliamdLayout_t;
 
 /* ----------------------------------------------------------------------------------------------
@@ -284,6 +286,11 @@ typedef struct {
   int32_t normalize;  /* 1: out = (u8 - mean[c]) * inv_std[c] after rounding to u8 */
   int32_t mirror;     /* 1: horizontal flip of the output */
   float mean[4], inv_std[4];
+  /* Other element types (the reference resamples u8 / i16 / u16 / f32, resampling_batch.cu:125-152): in_dtype = UINT8
+   * (0, default), INT16, UINT16 or FLOAT; out_dtype then = in_dtype, or FLOAT with `unrounded` = 1 for the float result
+   * of the second pass as it is (fn.resize(dtype=FLOAT)).  These take a plain two-launch path (fp32 intermediate in the
+   * workspace), not the fused tile kernel; `normalize` must be 0. */
+  int32_t in_dtype, unrounded;
 } daliamdResampleArgs;
 
 typedef struct {
@@ -309,19 +316,29 @@ typedef struct {
   int32_t tab_start;         /* first table entry of the sample (work index of the tables kernel) */
   int32_t use_lut;
   int32_t filter_kind[2];    /* per axis: 0 nearest, 1 triangular, 2 Gaussian, 3 Lanczos3, 4 cubic (dali_amd_resample_filters.h) */
+  /* the two-launch path of the other element types (generic = 1): fp32 intermediate [tmp_h][tmp_w][channels] at
+   * tmp_off in the workspace, gen_start[p] = first work item of the sample in pass p */
+  int32_t in_dtype, unrounded, generic, round_lanes;
+  int32_t tmp_w, tmp_h;
+  int64_t tmp_off, gen_start[2];
 } daliamdResampleDesc;
 
 /* Fills descs_host[0..n); returns the grid size and the dynamic LDS bytes the launch needs. */
-/* num_workgroups (out): tiles of the batch (the resampling kernel takes a few consecutive tiles per workgroup).
- * workspace_bytes / table_entries (out): size of the device scratch Run needs - the per-sample tables and one 128-byte
- * record per tile - and the number of per-sample table entries; the workspace is written by Run's first kernel and
- * read by its second one, so one buffer per stream (or per iteration in flight) is enough. */
+/* What Setup hands to Run besides the descriptor table. */
+typedef struct {
+  int32_t num_tiles;          /* tiles of the batch (the resampling kernel takes a few consecutive tiles per workgroup) */
+  int32_t lds_bytes;          /* dynamic LDS of the launch */
+  int32_t table_entries;      /* per-sample table entries the first kernel computes */
+  int32_t reserved;
+  size_t workspace_bytes;     /* device scratch Run needs: per-sample tables, fp32 intermediates of the generic path and one
+                                 128-byte record per tile; written and read by Run's own kernels, so one buffer per stream
+                                 (or per iteration in flight) is enough */
+  int64_t generic_items[2];   /* elements of the two passes of the generic (non-u8 / unrounded) path */
+} daliamdResamplePlan;
 DALIAMD_API daliamdResult_t daliamdResampleSetup(const daliamdResampleArgs *args, int n, daliamdResampleDesc *descs_host,
-                                                int *num_workgroups, int *lds_bytes, size_t *workspace_bytes,
-                                                int *table_entries);
+                                                daliamdResamplePlan *plan);
 DALIAMD_API daliamdResult_t daliamdResampleRun(daliamdStream_t stream, const daliamdResampleDesc *descs_dev, int n,
-                                              int num_workgroups, int lds_bytes, void *workspace_dev,
-                                              size_t workspace_bytes, int table_entries);
+                                              const daliamdResamplePlan *plan, void *workspace_dev);
 
 /* ----------------------------------------------------------------------------------------------
  * Stand-alone CropMirrorNormalize: u8 HWC -> {fp16, fp32, u8, i8} HWC/CHW with crop, horizontal

@@ -127,6 +127,26 @@ def resample_u8(img, out_hw, roi=None, min_filter=FILTER_LINEAR, mag_filter=FILT
     return (out, info) if return_info else out
 
 
+T_U8, T_I16, T_U16, T_F32 = 0, 1, 2, 3
+_NP_OF_T = {0: np.uint8, 1: np.int16, 2: np.uint16, 3: np.float32}
+
+
+def resample_typed(img, out_hw, out_type=None, roi=None, min_filter=FILTER_LINEAR, mag_filter=FILTER_LINEAR, antialias=True):
+    """img: u8 / i16 / u16 / f32 HWC.  out_type: T_* (default: the input's type; T_F32 = the unrounded result)."""
+    img = np.ascontiguousarray(img)
+    in_t = {np.dtype(np.uint8): 0, np.dtype(np.int16): 1, np.dtype(np.uint16): 2, np.dtype(np.float32): 3}[img.dtype]
+    out_type = in_t if out_type is None else out_type
+    H, W, Cn = img.shape
+    oh, ow = out_hw
+    inf = np.ascontiguousarray(img.astype(np.float32))
+    out = np.zeros((oh, ow, Cn), np.float32)
+    r = np.zeros(4, np.float32) if roi is None else np.asarray(roi, np.float32)
+    rc = lib().orc_resample_typed(_p(inf, C.c_float), H, W, Cn, 0 if roi is None else 1, _p(r, C.c_float), oh, ow,
+                                  min_filter, mag_filter, 1 if antialias else 0, out_type, _p(out, C.c_float))
+    assert rc == 0, rc
+    return out.astype(_NP_OF_T[out_type])
+
+
 def resample_f32(img, out_hw, roi=None, min_filter=FILTER_LINEAR, mag_filter=FILTER_LINEAR, antialias=True):
     """Same as resample_u8 with the float result of the second pass (fn.resize(dtype=FLOAT))."""
     img = np.ascontiguousarray(img, dtype=np.uint8)

@@ -166,22 +166,6 @@ static void init_resampling_filter(int32_t *out_indices, float *out_coeffs, int 
   }
 }
 
-/* convert.h:306-321 (host): clamp<uint8_t>(std::round(v)) */
-static uint8_t sat_u8_half_away(float v) {
-  float r = roundf(v);
-  if (!(r > 0)) return 0; /* NaN -> 0 like clamp of a NaN compares false */
-  if (r > 255) return 255;
-  return (uint8_t)r;
-}
-
-/* simd.h:53-56 clamp_round + packs: clamp in float, then cvtps (round half to even) */
-static uint8_t sat_u8_half_even(float v) {
-  float c = v;
-  if (!(c > 0.0f)) c = 0.0f; /* _mm_max_ps(f, lo): NaN in first operand -> second */
-  if (c > 255.0f) c = 255.0f;
-  return (uint8_t)lrintf(c); /* default FE_TONEAREST == MXCSR default */
-}
-
 typedef struct {
   /* per axis: 0 = x (W), 1 = y (H); vec order as in the reference */
   int filter_type[2];
@@ -306,10 +290,34 @@ static void setup_sample(orc_resample_setup *s, int H, int W, int use_roi, const
  *             1 = half-away everywhere, 2 = half-even everywhere
  * Returns 0 on success.
  */
-static int resample_impl(const uint8_t *in, int H, int W, int C, int use_roi, const float *roi,
+/* element types of the typed entry point (the reference resamples u8 / i16 / u16 / f32, resampling_batch.cu:125-152) */
+enum { ORC_T_U8 = 0, ORC_T_I16 = 1, ORC_T_U16 = 2, ORC_T_F32 = 3 };
+
+/* store() of a SIMD body: clamp in float, then cvtps = round half to even (simd.h:53-56,228-267);
+ * scalar tails: ConvertSat = clamp(std::round) (convert.h:306-321).  Float outputs are not rounded. */
+static float sat_typed(float v, int type, int even) {
+  float lo = type == ORC_T_I16 ? -32768.0f : 0.0f;
+  float hi = type == ORC_T_U8 ? 255.0f : type == ORC_T_I16 ? 32767.0f : 65535.0f;
+  if (type == ORC_T_F32) return v;
+  if (even) {
+    float c = v;
+    if (!(c > lo)) c = lo;
+    if (c > hi) c = hi;
+    return (float)lrintf(c);
+  }
+  float r = roundf(v);
+  if (!(r > lo)) return lo;
+  if (r > hi) return hi;
+  return r;
+}
+
+/* core: input as float values (every u8 / i16 / u16 / f32 element is exactly a float), `out_vals` receives the output
+ * elements as floats (integers for the integer types), `out_f32` the unrounded sums. */
+static int resample_impl(const float *in, int H, int W, int C, int use_roi, const float *roi,
                          int outH, int outW, int min_filter, int mag_filter, int antialias,
-                         int round_mode, uint8_t *out, float *out_f32 /* optional: unrounded result */,
+                         int round_mode, int out_type, float *out, float *out_f32 /* optional: unrounded result */,
                          float *tmp_out /* optional */, int *info) {
+  const int lanes = out_type == ORC_T_U8 ? 16 : out_type == ORC_T_F32 ? 4 : 8;  /* 16 bytes / sizeof(Out) */
   if (H <= 0 || W <= 0 || outH <= 0 || outW <= 0 || C <= 0) return 1;
   orc_resample_setup s;
   setup_sample(&s, H, W, use_roi, roi, outH, outW, min_filter, mag_filter, antialias);
@@ -337,12 +345,12 @@ static int resample_impl(const uint8_t *in, int H, int W, int C, int use_roi, co
     info[0] = first; info[1] = second; info[2] = s.support[0]; info[3] = s.support[1];
     info[4] = tmp_w; info[5] = tmp_h; info[6] = s.roi_lo[0]; info[7] = s.roi_lo[1];
   }
-  if (tmp_w <= 0 || tmp_h <= 0) { if (out) memset(out, 0, (size_t)outH * outW * C); return 0; }
+  if (tmp_w <= 0 || tmp_h <= 0) { if (out) memset(out, 0, sizeof(float) * (size_t)outH * outW * C); return 0; }
   if (s.filter_type[0] == ORC_FILTER_NN) {
     /* ResampleNN (resampling_impl_cpu.h:523-606) on the surface SetupSample leaves: whole image on the first-pass
      * axis, the source ROI on the other.  Rows advance by repeated float additions, columns are computed directly;
      * scale.x == 1 is the copy path with repeated borders. */
-    const uint8_t *base = in + ((size_t)in_off[1] * W + in_off[0]) * C;
+    const float *base = in + ((size_t)in_off[1] * W + in_off[0]) * C;
     float sy = origin[1] + 0.5f * s.scale[1];
     int sx0 = (int)floorf(origin[0] + 0.5f);
     for (int y = 0; y < outH; y++, sy += s.scale[1]) {
@@ -353,7 +361,7 @@ static int resample_impl(const uint8_t *in, int H, int W, int C, int use_roi, co
         else srcx = (int)floorf(origin[0] + (x + 0.5f) * s.scale[0]);
         srcx = clampi(srcx, 0, in_ext[0] - 1);
         for (int c = 0; c < C; c++) {
-          uint8_t v = base[((size_t)srcy * W + srcx) * C + c];
+          float v = base[((size_t)srcy * W + srcx) * C + c];
           if (out) out[((size_t)y * outW + x) * C + c] = v;
           if (out_f32) out_f32[((size_t)y * outW + x) * C + c] = v;
         }
@@ -368,16 +376,17 @@ static int resample_impl(const uint8_t *in, int H, int W, int C, int use_roi, co
   int32_t *idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)max_out);
   float *coef = (float *)malloc(sizeof(float) * (size_t)max_out * max_sup);
   uint8_t *mask = (uint8_t *)malloc((size_t)(outW > 16 ? outW : 16));
+  (void)lanes;
 
   /* ---------- pass 0: u8 -> float tmp ---------- */
   {
     int axis = first;
     int sup = filter_support(&s.filter[axis]);
     init_resampling_filter(idx, coef, s.out_size[axis], origin[axis], s.scale[axis], &s.filter[axis]);
-    const uint8_t *base = in + ((size_t)in_off[1] * W + in_off[0]) * C;
+    const float *base = in + ((size_t)in_off[1] * W + in_off[0]) * C;
     if (axis == 0) { /* horizontal: rows = in_ext[1] (ROI rows), in width = W (whole) */
       for (int y = 0; y < tmp_h; y++) {
-        const uint8_t *row = base + (size_t)y * W * C;
+        const float *row = base + (size_t)y * W * C;
         float *orow = tmp + (size_t)y * tmp_w * C;
         for (int x = 0; x < tmp_w; x++) {
           int x0 = idx[x];
@@ -413,10 +422,10 @@ static int resample_impl(const uint8_t *in, int H, int W, int C, int use_roi, co
     int sup = filter_support(&s.filter[axis]);
     init_resampling_filter(idx, coef, s.out_size[axis], origin[axis], s.scale[axis], &s.filter[axis]);
     if (axis == 0) { /* horizontal over tmp rows (tmp_h == outH) */
-      horz_regions(outW, tmp_w, idx, sup, 16, mask);
+      horz_regions(outW, tmp_w, idx, sup, lanes, mask);
       for (int y = 0; y < outH; y++) {
         const float *row = tmp + (size_t)y * tmp_w * C;
-        uint8_t *orow = out ? out + (size_t)y * outW * C : NULL;
+        float *orow = out ? out + (size_t)y * outW * C : NULL;
         for (int x = 0; x < outW; x++) {
           int x0 = idx[x];
           int even = round_mode == 2 || (round_mode == 0 && mask[x]);
@@ -427,18 +436,18 @@ static int resample_impl(const uint8_t *in, int H, int W, int C, int use_roi, co
               acc += coef[x * sup + k] * row[sx * C + c];
             }
             if (out_f32) out_f32[((size_t)y * outW + x) * C + c] = acc;
-            if (out) orow[x * C + c] = even ? sat_u8_half_even(acc) : sat_u8_half_away(acc);
+            if (out) orow[x * C + c] = sat_typed(acc, out_type, even);
           }
         }
       }
     } else { /* vertical over tmp cols (tmp_w == outW) */
       int flat_w = outW * C;
       for (int y = 0; y < outH; y++) {
-        uint8_t *orow = out ? out + (size_t)y * outW * C : NULL;
+        float *orow = out ? out + (size_t)y * outW * C : NULL;
         for (int x0 = 0; x0 < flat_w; x0 += 256) { /* ResampleVert tile, resampling_impl_cpu.h:362-390 */
           int end = x0 + 256 <= flat_w ? x0 + 256 : flat_w;
           int i = x0;
-          int simd_end = x0 + ((end - x0) / 16) * 16;
+          int simd_end = x0 + ((end - x0) / lanes) * lanes;
           for (; i < end; i++) {
             float acc = 0;
             for (int k = 0; k < sup; k++) {
@@ -447,7 +456,7 @@ static int resample_impl(const uint8_t *in, int H, int W, int C, int use_roi, co
             }
             int even = round_mode == 2 || (round_mode == 0 && i < simd_end);
             if (out_f32) out_f32[(size_t)y * outW * C + i] = acc;
-            if (out) orow[i] = even ? sat_u8_half_even(acc) : sat_u8_half_away(acc);
+            if (out) orow[i] = sat_typed(acc, out_type, even);
           }
         }
       }
@@ -457,22 +466,46 @@ static int resample_impl(const uint8_t *in, int H, int W, int C, int use_roi, co
   return 0;
 }
 
+static float *to_float_u8(const uint8_t *in, size_t n) {
+  float *f = (float *)malloc(sizeof(float) * (n ? n : 1));
+  for (size_t i = 0; i < n; i++) f[i] = in[i];
+  return f;
+}
+
 int orc_resample_u8(const uint8_t *in, int H, int W, int C, int use_roi, const float *roi,
                     int outH, int outW, int min_filter, int mag_filter, int antialias,
                     int round_mode, uint8_t *out, float *tmp_out /* optional */, int *info) {
-  return resample_impl(in, H, W, C, use_roi, roi, outH, outW, min_filter, mag_filter, antialias, round_mode, out, NULL,
-                       tmp_out, info);
+  if (H <= 0 || W <= 0 || outH <= 0 || outW <= 0 || C <= 0) return 1;
+  size_t n_out = (size_t)outH * outW * C;
+  float *inf = to_float_u8(in, (size_t)H * W * C);
+  float *outf = (float *)malloc(sizeof(float) * n_out);
+  int rc = resample_impl(inf, H, W, C, use_roi, roi, outH, outW, min_filter, mag_filter, antialias, round_mode, ORC_T_U8,
+                         outf, NULL, tmp_out, info);
+  if (rc == 0) for (size_t i = 0; i < n_out; i++) out[i] = (uint8_t)outf[i];
+  free(inf); free(outf);
+  return rc;
 }
 
 /* Same resampling with the float result of the second pass returned as it is (fn.resize(dtype=FLOAT):
  * the final ConvertSat<float> is the identity).  out: float [outH][outW][C]. */
 int orc_resample_u8_to_f32(const uint8_t *in, int H, int W, int C, int use_roi, const float *roi,
                            int outH, int outW, int min_filter, int mag_filter, int antialias, float *out) {
-  return resample_impl(in, H, W, C, use_roi, roi, outH, outW, min_filter, mag_filter, antialias, 0, NULL, out, NULL,
+  if (H <= 0 || W <= 0 || outH <= 0 || outW <= 0 || C <= 0) return 1;
+  float *inf = to_float_u8(in, (size_t)H * W * C);
+  int rc = resample_impl(inf, H, W, C, use_roi, roi, outH, outW, min_filter, mag_filter, antialias, 0, ORC_T_U8, NULL, out, NULL,
+                         NULL);
+  free(inf);
+  return rc;
+}
+
+/* Typed entry point: `in` holds the elements of a u8 / i16 / u16 / f32 image as floats, `out` receives the elements of
+ * an image of type out_type (ORC_T_*; ORC_T_F32 = the unrounded result) as floats. */
+int orc_resample_typed(const float *in, int H, int W, int C, int use_roi, const float *roi, int outH, int outW,
+                       int min_filter, int mag_filter, int antialias, int out_type, float *out) {
+  return resample_impl(in, H, W, C, use_roi, roi, outH, outW, min_filter, mag_filter, antialias, 0, out_type, out, NULL, NULL,
                        NULL);
 }
 
-/* Known-answer helpers mirroring resampling_impl_cpu_test.cc:27-90 */
 /* coefficients of the tabulated filters for known-answer tests: type = ORC_FILTER_*, returns num_coeffs and fills
  * coeffs[<= 193], *scale, *anchor for the given radius (sigma derived like GetResamplingFilter) */
 int orc_filter_table(int type, float radius, float *coeffs, float *scale, float *anchor, int *support) {

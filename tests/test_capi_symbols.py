@@ -62,19 +62,23 @@ def test_setup_functions_validate_arguments():
     import numpy as np
     args = np.zeros(1, np.dtype(capi.ResampleArgs))
     descs = np.zeros(1, np.dtype(capi.ResampleDesc))
-    nwg, lds, wsb, ent = C.c_int(0), C.c_int(0), C.c_size_t(0), C.c_int(0)
-    rc = lib.daliamdResampleSetup(args.ctypes.data_as(C.c_void_p), 1, descs.ctypes.data_as(C.c_void_p), C.byref(nwg),
-                                  C.byref(lds), C.byref(wsb), C.byref(ent))
+    plan = capi.ResamplePlan()
+    rc = lib.daliamdResampleSetup(args.ctypes.data_as(C.c_void_p), 1, descs.ctypes.data_as(C.c_void_p), C.byref(plan))
     assert rc == 1 and b"empty" in lib.daliamdGetLastErrorMessage()
     a = args[0]
     a["in_h"], a["in_w"], a["channels"], a["in_pitch"], a["out_h"], a["out_w"] = 100, 80, 3, 240, 20, 30
     a["min_filter"], a["mag_filter"], a["antialias"] = 1, 1, 1
-    rc = lib.daliamdResampleSetup(args.ctypes.data_as(C.c_void_p), 1, descs.ctypes.data_as(C.c_void_p), C.byref(nwg),
-                                  C.byref(lds), C.byref(wsb), C.byref(ent))
-    assert rc == 0 and nwg.value == descs[0]["tiles_x"] * descs[0]["tiles_y"] > 0 and 0 < lds.value <= 60 * 1024
+    rc = lib.daliamdResampleSetup(args.ctypes.data_as(C.c_void_p), 1, descs.ctypes.data_as(C.c_void_p), C.byref(plan))
+    assert rc == 0 and plan.num_tiles == descs[0]["tiles_x"] * descs[0]["tiles_y"] > 0 and 0 < plan.lds_bytes <= 60 * 1024
     # the per-sample tables: first tap + coefficients of 30 columns and 20 rows
-    assert ent.value == 50 and wsb.value >= 4 * (30 * (1 + descs[0]["support"][0]) + 20 * (1 + descs[0]["support"][1]))
+    assert plan.table_entries == 50
+    assert plan.workspace_bytes >= 4 * (30 * (1 + descs[0]["support"][0]) + 20 * (1 + descs[0]["support"][1]))
+    # i16 input: the two-launch path - no tiles, an fp32 intermediate, one item per element and pass
+    a["in_dtype"], a["out_dtype"], a["in_pitch"] = capi.INT16, capi.INT16, 480
+    rc = lib.daliamdResampleSetup(args.ctypes.data_as(C.c_void_p), 1, descs.ctypes.data_as(C.c_void_p), C.byref(plan))
+    assert rc == 0 and plan.num_tiles == 0 and descs[0]["generic"] == 1 and plan.generic_items[1] == 20 * 30 * 3
+    assert plan.generic_items[0] == descs[0]["tmp_w"] * descs[0]["tmp_h"] * 3 > 0
+    a["in_dtype"], a["out_dtype"], a["in_pitch"] = capi.UINT8, capi.UINT8, 240
     a["channels"] = 7
-    rc = lib.daliamdResampleSetup(args.ctypes.data_as(C.c_void_p), 1, descs.ctypes.data_as(C.c_void_p), C.byref(nwg),
-                                  C.byref(lds), C.byref(wsb), C.byref(ent))
+    rc = lib.daliamdResampleSetup(args.ctypes.data_as(C.c_void_p), 1, descs.ctypes.data_as(C.c_void_p), C.byref(plan))
     assert rc == 2  # DALIAMD_ERROR_UNSUPPORTED

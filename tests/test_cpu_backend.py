@@ -139,3 +139,31 @@ def test_cpu_resize_every_filter_matches_oracle(dataset):
                 img = O.jpeg_decode_rgb(open(files[i][0], "rb").read())
                 ref = O.resample_u8(img, size, min_filter=of, mag_filter=of)
                 assert np.array_equal(got.at(i), ref), (name, size, i)
+
+
+def test_cpu_resize_other_element_types_match_oracle():
+    """fn.resize on i16 / u16 / f32 images and with dtype=FLOAT (the unrounded result): the typed two-pass path of the
+    host backend against the oracle, bit for bit (SIMD-store lanes = 16 bytes / sizeof(Out) decide the rounding regions)."""
+    from dali_amd import fn, types
+    from dali_amd.pipeline import Pipeline
+    rng = np.random.default_rng(3)
+    base = [rng.normal(0, 1, (h, w, c)) for h, w, c in [(60, 90, 3), (33, 47, 1), (120, 80, 3)]]
+    cases = [(np.int16, lambda a: np.clip(a * 9000, -32768, 32767)), (np.uint16, lambda a: np.clip(a * 9000 + 30000, 0, 65535)),
+             (np.float32, lambda a: a * 3), (np.uint8, lambda a: np.clip(a * 60 + 128, 0, 255))]
+    for np_t, conv in cases:
+        imgs = [conv(b).astype(np_t) for b in base]
+        for size, dtype in [((40, 50), None), ((150, 70), None), ((40, 50), types.FLOAT)]:
+            if np_t == np.uint8 and dtype is None:
+                continue       # the plain u8 path has its own tests
+            pipe = Pipeline(batch_size=len(imgs), num_threads=2, device_id=None, prefetch_queue_depth=1)
+            with pipe:
+                x = fn.external_source(name="x", layout="HWC")
+                kw = {} if dtype is None else {"dtype": dtype}
+                pipe.set_outputs(fn.resize(x, size=list(size), **kw))
+            pipe.feed_input("x", imgs, layout="HWC")
+            (out,) = pipe.run()
+            for i, im in enumerate(imgs):
+                ref = O.resample_typed(im, size, out_type=O.T_F32 if dtype is not None else None)
+                got = out.at(i)
+                assert got.dtype == ref.dtype and got.shape == ref.shape, (np_t, size, got.dtype, ref.dtype)
+                assert np.array_equal(got, ref), (np_t, size, dtype, i, np.abs(got.astype(np.float64) - ref).max())

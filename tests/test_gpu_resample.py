@@ -167,3 +167,49 @@ def test_nearest_on_one_axis_only_is_refused():
     im = synth_image(np.random.default_rng(1), 50, 80)
     with pytest.raises(capi.DaliAmdError, match="one axis only"):
         B.resample_batch([_to_dev(im)], (100, 20), interp_min=capi.INTERP_NN, interp_mag=capi.INTERP_LINEAR)
+
+
+@pytest.mark.parametrize("np_t", [np.int16, np.uint16, np.float32, np.uint8])
+def test_other_element_types_match_oracle(np_t):
+    """i16 / u16 / f32 images (output = input type) and the unrounded float result of u8 / i16 images: the two-launch
+    path of the kernel library against the oracle, bit for bit, in both pass orders, with a region of interest."""
+    from dali_amd import backend as B
+    rng = np.random.default_rng(14)
+    conv = {np.int16: lambda a: np.clip(a * 9000, -32768, 32767), np.uint16: lambda a: np.clip(a * 9000 + 30000, 0, 65535),
+            np.float32: lambda a: a * 3, np.uint8: lambda a: np.clip(a * 60 + 128, 0, 255)}[np_t]
+    orders = set()
+    for (h, w, c), osz, roi in [((60, 90, 3), (40, 50), None), ((33, 47, 1), (150, 70), None), ((120, 80, 3), (24, 64), None),
+                                ((200, 300, 3), (64, 64), (20.5, 30.0, 180.0, 250.25)), ((90, 400, 3), (224, 32), None)]:
+        im = conv(rng.normal(0, 1, (h, w, c))).astype(np_t)
+        dev = torch.from_numpy(im).cuda()
+        for unrounded in ((True,) if np_t == np.uint8 else (False, True)):
+            if unrounded and np_t == np.float32:
+                continue
+            out = B.resample_batch([dev], osz, rois=None if roi is None else [roi], out_dtype=None, unrounded=unrounded)
+            got = out.cpu().numpy()[0]
+            ref = O.resample_typed(im, osz, out_type=O.T_F32 if unrounded else None, roi=roi)
+            assert got.dtype == ref.dtype and got.shape == ref.shape
+            assert np.array_equal(got, ref), (np_t, (h, w, c), osz, unrounded, np.abs(got.astype(np.float64) - ref).max())
+        _, info = O.resample_u8(np.zeros((h, w, c), np.uint8), osz, roi=roi, return_info=True)
+        orders.add(int(info[0]))
+    assert orders == {0, 1}, "both pass orders must be exercised"
+
+
+def test_resize_operator_other_types_on_the_gpu():
+    from dali_amd import fn, types
+    from dali_amd.pipeline import Pipeline
+    rng = np.random.default_rng(15)
+    imgs = [(rng.normal(0, 1, (70, 50, 3)) * 8000).astype(np.int16), (rng.normal(0, 1, (31, 64, 3)) * 8000).astype(np.int16)]
+    for dtype in (None, types.FLOAT):
+        pipe = Pipeline(batch_size=2, num_threads=1, device_id=0, prefetch_queue_depth=1)
+        with pipe:
+            x = fn.external_source(name="x", layout="HWC")
+            kw = {} if dtype is None else {"dtype": dtype}
+            pipe.set_outputs(fn.resize(x.gpu(), resize_shorter=40, **kw))
+        pipe.feed_input("x", imgs, layout="HWC")
+        (out,) = pipe.run()
+        for i, im in enumerate(imgs):
+            out_hw, roi = O.resize_params(im.shape[:2], size=(40, 40), mode="not_smaller")
+            ref = O.resample_typed(im, out_hw, out_type=O.T_F32 if dtype is not None else None, roi=roi)
+            got = out[i].as_cpu()
+            assert got.dtype == ref.dtype and np.array_equal(got, ref), (dtype, i)
