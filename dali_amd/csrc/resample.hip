@@ -359,6 +359,7 @@ __device__ __forceinline__ void FetchTile(const TileRec &r, int tid, TilePrefetc
     for (int i = 0; i < kPrefetchChunks; i++) {
       const int row = (tid >> 4) + 16 * i, q = tid & 15;
       p.chunk[i] = make_uint4(0, 0, 0, 0);
+      if (16 * i >= r.nrows) continue;   // wave-uniform: a 31-row window skips the two upper chunk slots entirely
       if (row < r.nrows) {
         const uint32_t ro = (uint32_t)__mul24(row, r.pitch);
         const uint32_t sh = (lo4 + ro) & 15u;
@@ -459,6 +460,7 @@ __global__ __launch_bounds__(kResampleThreads) void ResampleKernel(const daliamd
 #pragma unroll
       for (int i = 0; i < kPrefetchChunks; i++) {
         const int row = (tid >> 4) + 16 * i, q = tid & 15;
+        if (16 * i >= nrows) continue;   // wave-uniform
         if (row < nrows) {
           const int sh = (int)(((uint32_t)win_addr + (uint32_t)__mul24(row, pitch)) & 15u);
           if (q < ((sh + NB + 15) >> 4)) *reinterpret_cast<uint4 *>(stage + __mul24(row, LP) + 16 * q) = pf.chunk[i];
