@@ -49,7 +49,10 @@ namespace daliamd {
 
 constexpr int kTileThreads = 1024;
 constexpr int kTileBytes = kTileThreads * 16;
-constexpr int kSliceBytes = 256;
+#ifndef DALIAMD_SLICE_BYTES
+#define DALIAMD_SLICE_BYTES 256
+#endif
+constexpr int kSliceBytes = DALIAMD_SLICE_BYTES;
 #ifndef DALIAMD_SEG_THREADS
 #define DALIAMD_SEG_THREADS 256
 #endif
