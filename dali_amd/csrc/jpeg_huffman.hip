@@ -695,14 +695,21 @@ __global__ __launch_bounds__(kDcThreads) void DcKernel(const daliamdJpegHuffDesc
 // slot in LDS (natural zig-zag order, plus the DC level), then the wave transforms its 64 blocks 8 at a time with 8
 // lanes per block - JpegIdctKernel's two passes (lane `part` owns column `part` in pass 1 and row `part` in pass 2),
 // reading the coefficients through the zig-zag - and stores the samples.  Waves never wait for each other.
+// Workgroup shape (MI355X, headline batch, waves x tasks per wave -> kernel time alone / images per second with two
+// batches in flight): 2x3 216 us / 311k, 3x2 201 / 303k, 4x3 204 / 318k, 6x2 258 / 288k (six waves sit 2-2-1-1 on the
+// SIMDs), 12x1 196 / 306k.  LDS bounds the kernel at 8-12 waves per CU whatever the shape; the 143 KB workgroup of 12x1
+// is the fastest alone but leaves no LDS for the kernels of the other batch in flight.
 #ifndef DALIAMD_BLOCK_WAVES
-#define DALIAMD_BLOCK_WAVES 2
+#define DALIAMD_BLOCK_WAVES 4
 #endif
 constexpr int kBlockWaves = DALIAMD_BLOCK_WAVES;  // per wave 8.4 KB of coefficients + 2.1 KB transpose buffer + 0.5 KB,
 constexpr int kBlockThreads = kBlockWaves * 64;   // + 11 KB of tables per workgroup
 constexpr int kCoefStride = 66;  // int16 per block: 64 coefficients, the scratch slot, one pad (33 dwords: odd -> no bank conflicts)
 constexpr int kTransStride = 68; // dwords per block in the transpose buffer
-constexpr int kBlocksPerWg = 192 * kBlockWaves;  // three tasks per wave
+#ifndef DALIAMD_BLOCK_TASKS
+#define DALIAMD_BLOCK_TASKS 3
+#endif
+constexpr int kBlocksPerWg = 64 * DALIAMD_BLOCK_TASKS * kBlockWaves;  // tasks per wave
 __host__ __device__ inline int McusPerWg(int bpm) {
   const int m = (kBlocksPerWg / bpm) / 32 * 32;
   return m > 32 ? m : 32;
@@ -808,7 +815,8 @@ __global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHu
   int16_t *mycoef = wcoef + lane * kCoefStride;
   // the waves share the tasks of each class evenly (a luma task takes 2-3 times as long as a chroma task)
   const int my0 = wave < tasks0 ? (tasks0 - wave + kBlockWaves - 1) / kBlockWaves : 0;
-  const int my1 = wave < tasks1 ? (tasks1 - wave + kBlockWaves - 1) / kBlockWaves : 0;
+  const int rwave = kBlockWaves - 1 - wave;  // the chroma tasks are dealt from the other end
+  const int my1 = rwave < tasks1 ? (tasks1 - rwave + kBlockWaves - 1) / kBlockWaves : 0;
   // One task ahead: what a lane needs to know about its block of the NEXT task - indices and output address, then
   // (stage A) its entries in the per-block arrays, then (stage B) the first three dwords of its bit stream - is
   // fetched while the wave transforms the blocks of the current task, so that a decode starts without a memory
@@ -827,7 +835,7 @@ __global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHu
     if (t >= my0 + my1) return p;
     const bool cls = t >= my0;
     const int ncls = cls ? n1 : n0;
-    const int j = ((cls ? t - my0 : t) * kBlockWaves + wave) * 64 + lane;
+    const int j = (cls ? (t - my0) * kBlockWaves + rwave : t * kBlockWaves + wave) * 64 + lane;
     const int mi = j / ncls, k = G.klist[(cls ? n0 : 0) + (j - mi * ncls)];
     const int mcu = m0 + mi, ordinal = mcu * bpm + k;
     const int my = mcu / G.mcus_x, mx = mcu - my * G.mcus_x;

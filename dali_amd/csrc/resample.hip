@@ -67,6 +67,7 @@ __host__ __device__ inline int FirstTap(int o, float scale, float start, float *
 
 #define SEL4(c, a0, a1, a2, a3) ((c) == 0 ? (a0) : (c) == 1 ? (a1) : (c) == 2 ? (a2) : (a3))
 typedef float floatx2 __attribute__((ext_vector_type(2)));
+typedef int intx2 __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------------------------------------
 // device helpers
@@ -129,6 +130,18 @@ struct Epilogue {
     if (layout == DALIAMD_LAYOUT_CHW) { *cstride = (size_t)out_h * out_w; return (size_t)y * out_w + xo; }
     *cstride = 1;
     return ((size_t)y * out_w + xo) * channels;
+  }
+  // Two neighbouring pixels (x even, x + 1) of a 3-channel fp16 CHW output through the look-up table: one dword per
+  // channel plane.  Needs an even out_w and a 4-byte aligned output (the caller checks).
+  __device__ __forceinline__ void StorePair(int y, int x, uint32_t r0, uint32_t r1, uint32_t g0, uint32_t g1, uint32_t b0,
+                                            uint32_t b1) const {
+    const int xo = mirror ? out_w - 2 - x : x;
+    const uint32_t plane = (uint32_t)(out_h * out_w);
+    uint16_t __attribute__((address_space(1))) *o = (uint16_t __attribute__((address_space(1))) *)out + ((size_t)y * out_w + xo);
+    const uint32_t l0 = lut[r0], l1 = lut[r1], l2 = lut[256 + g0], l3 = lut[256 + g1], l4 = lut[512 + b0], l5 = lut[512 + b1];
+    *(uint32_t __attribute__((address_space(1))) *)o = mirror ? (l1 | (l0 << 16)) : (l0 | (l1 << 16));
+    *(uint32_t __attribute__((address_space(1))) *)(o + plane) = mirror ? (l3 | (l2 << 16)) : (l2 | (l3 << 16));
+    *(uint32_t __attribute__((address_space(1))) *)(o + 2 * (size_t)plane) = mirror ? (l5 | (l4 << 16)) : (l4 | (l5 << 16));
   }
   // mean / inv_std are passed by value: a runtime-indexed member array would live in scratch memory
   __device__ __forceinline__ void Store(size_t o, int c, uint32_t v, float mean, float inv_std) const {
@@ -409,7 +422,66 @@ __device__ __forceinline__ void LdsBarrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-__global__ __launch_bounds__(kResampleThreads) void ResampleKernel(const daliamdResampleDesc *__restrict__ descs,
+// Four bytes at any byte offset of a 4-byte aligned LDS buffer: two aligned dwords and a byte funnel shift (an unaligned
+// ds_read_b32 works on gfx950 but is slow: the pass built on it measured 16 us slower per batch).
+__device__ __forceinline__ uint32_t LdsDwordAt(const uint8_t *base, int off) {
+  const uint32_t *q = reinterpret_cast<const uint32_t *>(base + (off & ~3));
+  return __builtin_amdgcn_alignbyte(q[1], q[0], (uint32_t)off & 3u);
+}
+
+// Vertical first pass over a staged window whose rows share their alignment modulo 4.  16 threads per output row; a
+// thread owns the dwords j, j + 16, ... (N of them) of that row's window: the row's tap offset and coefficient are read
+// once per tap for all of them, every dword gives 4 elements (packed multiply / add, separately rounded).
+template <int N>
+__device__ __forceinline__ void VPassItems(const uint8_t *stage, float *tmp, const float *cy, const int *yt, int tid, int th,
+                                           int NB, int sup_y, int s4, int ndw, int jbase) {
+  const int j0 = jbase + (tid & 15);
+  const uint8_t *col[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) col[i] = stage + 4 * min(j0 + 16 * i, ndw - 1) - s4;   // (clamped: no out-of-range reads)
+  for (int y = tid >> 4; y < th; y += kResampleThreads / 16) {
+    const float *co = cy + y * sup_y;
+    const int *ro = yt + y * sup_y;
+    floatx2 lo[N], hi[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) lo[i] = hi[i] = floatx2{0.0f, 0.0f};
+    const int nk = sup_y;
+    int off_next = ro[0];     // one tap ahead: the offset / coefficient reads travel with the previous tap's data reads
+    float w_next = co[0];
+    for (int k = 0; k < nk; k++) {
+      const int off = off_next;
+      const float w = w_next;
+      uint32_t v[N];
+#pragma unroll
+      for (int i = 0; i < N; i++) v[i] = *reinterpret_cast<const uint32_t *>(col[i] + off);
+      const int kn = min(k + 1, nk - 1);
+      off_next = ro[kn];
+      w_next = co[kn];
+#pragma unroll
+      for (int i = 0; i < N; i++) {
+        lo[i] += floatx2{(float)(v[i] & 255), (float)((v[i] >> 8) & 255)} * w;
+        hi[i] += floatx2{(float)((v[i] >> 16) & 255), (float)(v[i] >> 24)} * w;
+      }
+    }
+    float *trow = tmp + y * NB;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const int j = j0 + 16 * i, e = 4 * j - s4;
+      if (j >= ndw) continue;
+      if (e >= 0 && e + 3 < NB) {
+        trow[e] = lo[i].x; trow[e + 1] = lo[i].y; trow[e + 2] = hi[i].x; trow[e + 3] = hi[i].y;
+      } else {
+        if (e >= 0 && e < NB) trow[e] = lo[i].x;
+        if (e + 1 >= 0 && e + 1 < NB) trow[e + 1] = lo[i].y;
+        if (e + 2 >= 0 && e + 2 < NB) trow[e + 2] = hi[i].x;
+        if (e + 3 >= 0 && e + 3 < NB) trow[e + 3] = hi[i].y;
+      }
+    }
+  }
+}
+
+
+__global__ __launch_bounds__(kResampleThreads) __attribute__((amdgpu_waves_per_eu(6, 6))) void ResampleKernel(const daliamdResampleDesc *__restrict__ descs,
                                                                    int ndesc, int total_wg, int total_tiles,
                                                                    const uint8_t *__restrict__ workspace,
                                                                    size_t tile_rec_off) {
@@ -422,10 +494,12 @@ __global__ __launch_bounds__(kResampleThreads) void ResampleKernel(const daliamd
   uint16_t *lut = reinterpret_cast<uint16_t *>(lds);   // fixed place: survives from tile to tile of the same sample
   int lut_desc = -1;
 
-  TileRec r = recs[t_begin];
   TilePrefetch pf;
-  FetchTile(r, tid, pf);
+  FetchTile(recs[t_begin], tid, pf);
   for (int tile = t_begin; tile < t_end; tile++) {
+    // (re-read rather than carried over from the previous round: two live records are 64 scalar registers, and the
+    // second read of a record comes from the scalar cache)
+    const TileRec r = recs[tile];
     const daliamdResampleDesc &d = descs[r.desc_idx];
     const int C = r.channels, TH = r.TH, TW = r.TW;
     const int tw_log2 = 31 - __clz(TW), th_log2 = 31 - __clz(TH);
@@ -441,10 +515,12 @@ __global__ __launch_bounds__(kResampleThreads) void ResampleKernel(const daliamd
     // (tap-major: entry k * TILE + i)
     uint8_t *stage = reinterpret_cast<uint8_t *>(lds) + kLutLdsBytes;
     float *tmp = reinterpret_cast<float *>(stage + (staged ? (size_t)nrows * LP : 0));
-    float *cy = tmp + (r.tmp_bytes >> 2);                   // [TH][sup_y] (row-major: a pass walks the taps of ONE row)
-    float *cx = cy + TH * sup_y;                            // [sup_x][TW]
-    int *yt = reinterpret_cast<int *>(cx + TW * sup_x);     // [TH][sup_y] per-tap row offset
-    int *xt = yt + TH * sup_y;                              // [sup_x][TW] per-tap column offset (elements)
+    // (every table starts on 8 bytes: the pixel-pair passes read two columns' entries at once)
+    const int ny_tab = (TH * sup_y + 1) & ~1, nx_tab = (TW * sup_x + 1) & ~1;
+    float *cy = tmp + (((r.tmp_bytes >> 2) + 1) & ~1);      // [TH][sup_y] (row-major: a pass walks the taps of ONE row)
+    float *cx = cy + ny_tab;                                // [sup_x][TW]
+    int *yt = reinterpret_cast<int *>(cx + nx_tab);         // [TH][sup_y] per-tap row offset
+    int *xt = yt + ny_tab;                                  // [sup_x][TW] per-tap column offset (elements)
 
     GU32 *tab = (GU32 *)r.tab;
     // ---- this tile's tables and window into LDS: from the registers filled one tile ago, or straight from memory ----
@@ -514,11 +590,7 @@ __global__ __launch_bounds__(kResampleThreads) void ResampleKernel(const daliamd
       lut_desc = r.desc_idx;
     }
     // ---- the next tile's record and loads: in flight during this tile's passes ----
-    TileRec rn = r;
-    if (tile + 1 < t_end) {
-      rn = recs[tile + 1];
-      FetchTile(rn, tid, pf);
-    }
+    if (tile + 1 < t_end) FetchTile(recs[tile + 1], tid, pf);
     LdsBarrier();
 
     Epilogue ep;
@@ -528,38 +600,23 @@ __global__ __launch_bounds__(kResampleThreads) void ResampleKernel(const daliamd
     const float mean0 = d.mean[0], mean1 = d.mean[1], mean2 = d.mean[2], mean3 = d.mean[3];
     const float inv0 = d.inv_std[0], inv1 = d.inv_std[1], inv2 = d.inv_std[2], inv3 = d.inv_std[3];
     GBytes *gwin = (GBytes *)win_addr;  // source rows when the window is not staged
+    // the second pass two pixels per thread (packed multiply / add, one dword store per channel plane): the common
+    // fused case - three channels into an fp16 CHW batch of even width
+    const bool pair = C == 3 && use_lut && d.out_layout == DALIAMD_LAYOUT_CHW && (r.out_w & 1) == 0 && TW >= 2 &&
+                      ((uintptr_t)d.out & 3) == 0;
+    const int hw_log2 = tw_log2 - 1;
 
     if (vfirst) {
       // ================= vertical pass (window rows -> tmp[th][NB]), then horizontal =================
       if (staged && (pitch & 3) == 0) {
-        // every row has the same shift modulo 4: produce 4 consecutive elements from one LDS dword per tap; the
-        // (row, dword) items are spread evenly over the threads
+        // every row has the same shift modulo 4: 4 consecutive elements from one LDS dword per tap
         const int s4 = (int)(win_addr & 3);
         const int ndw = (NB + s4 + 3) >> 2;
-        const float inv_ndw = 1.0f / (float)ndw;
-        for (int item = tid; item < th * ndw; item += kResampleThreads) {
-          const int y = (int)(((float)item + 0.5f) * inv_ndw);   // exact: item < 2^16
-          const int j = item - y * ndw;
-          const float *co = cy + y * sup_y;
-          const int *ro = yt + y * sup_y;
-          floatx2 a01 = {0.0f, 0.0f}, a23 = {0.0f, 0.0f};
-          const uint8_t *col = stage + 4 * j - s4;
-          for (int k = 0; k < sup_y; k++) {
-            const uint32_t v = *reinterpret_cast<const uint32_t *>(col + ro[k]);
-            const float w = co[k];
-            a01 += floatx2{(float)(v & 255), (float)((v >> 8) & 255)} * w;
-            a23 += floatx2{(float)((v >> 16) & 255), (float)(v >> 24)} * w;
-          }
-          float *trow = tmp + y * NB;
-          const int e = 4 * j - s4;
-          if (e >= 0 && e + 3 < NB) {
-            trow[e] = a01.x; trow[e + 1] = a01.y; trow[e + 2] = a23.x; trow[e + 3] = a23.y;
-          } else {
-            if (e >= 0 && e < NB) trow[e] = a01.x;
-            if (e + 1 >= 0 && e + 1 < NB) trow[e + 1] = a01.y;
-            if (e + 2 >= 0 && e + 2 < NB) trow[e + 2] = a23.x;
-            if (e + 3 >= 0 && e + 3 < NB) trow[e + 3] = a23.y;
-          }
+        for (int jbase = 0; jbase < ndw; jbase += 48) {
+          const int rem = ndw - jbase;
+          if (rem > 32) VPassItems<3>(stage, tmp, cy, yt, tid, th, NB, sup_y, s4, ndw, jbase);
+          else if (rem > 16) VPassItems<2>(stage, tmp, cy, yt, tid, th, NB, sup_y, s4, ndw, jbase);
+          else VPassItems<1>(stage, tmp, cy, yt, tid, th, NB, sup_y, s4, ndw, jbase);
         }
       } else {
         for (int y = tid >> 6; y < th; y += kResampleThreads / 64) {
@@ -577,8 +634,31 @@ __global__ __launch_bounds__(kResampleThreads) void ResampleKernel(const daliamd
         }
       }
       LdsBarrier();
-      const int x = tid & (TW - 1);
-      if (x < tw) {
+      const int x = pair ? (tid & ((TW >> 1) - 1)) * 2 : tid & (TW - 1);
+      if (pair) {
+        if (x < tw) {
+          const floatx2 *co = reinterpret_cast<const floatx2 *>(cx + x);
+          const intx2 *xo = reinterpret_cast<const intx2 *>(xt + x);
+          const int gx = ox0 + x, half_tw = TW >> 1;
+          const uint32_t em = d.even_mask[(gx >> 5) & 7] >> (gx & 31);   // gx is even: gx + 1 sits in the same word
+          const bool even0 = em & 1, even1 = (em >> 1) & 1;
+          const int nk = sup_x;
+          for (int y = tid >> hw_log2; y < th; y += kResampleThreads >> hw_log2) {
+            const float *trow = tmp + y * NB;
+            floatx2 a0 = {0.0f, 0.0f}, a1 = {0.0f, 0.0f}, a2 = {0.0f, 0.0f};
+            for (int k = 0; k < nk; k++) {
+              const floatx2 w = co[k * half_tw];
+              const intx2 o = xo[k * half_tw];
+              const float *p = trow + o.x, *q = trow + o.y;
+              a0 += w * floatx2{p[0], q[0]};
+              a1 += w * floatx2{p[1], q[1]};
+              a2 += w * floatx2{p[2], q[2]};
+            }
+            ep.StorePair(oy0 + y, gx, RoundU8(a0.x, even0), RoundU8(a0.y, even1), RoundU8(a1.x, even0), RoundU8(a1.y, even1),
+                         RoundU8(a2.x, even0), RoundU8(a2.y, even1));
+          }
+        }
+      } else if (x < tw) {
         const float *co = cx + x;
         const int *xo = xt + x;
         const int gx = ox0 + x;
@@ -614,7 +694,32 @@ __global__ __launch_bounds__(kResampleThreads) void ResampleKernel(const daliamd
     } else {
       // ================= horizontal pass (window rows -> tmp[nrows][tw*C]), then vertical =================
       const int x = tid & (TW - 1);
-      if (x < tw) {
+      if (C == 3 && staged && TW >= 2 && (tw & 1) == 0) {
+        // two output columns per thread: each tap is the 4 bytes at the column's offset (3 channels + 1), packed multiply / add
+        const int x2 = (tid & ((TW >> 1) - 1)) * 2;
+        if (x2 < tw) {
+          const floatx2 *co = reinterpret_cast<const floatx2 *>(cx + x2);
+          const intx2 *xo = reinterpret_cast<const intx2 *>(xt + x2);
+          const int half_tw = TW >> 1;
+          const int nk = sup_x;
+          for (int row = tid >> hw_log2; row < nrows; row += kResampleThreads >> hw_log2) {
+            const int so = row * LP + (int)((win_addr + (size_t)row * pitch) & 15);   // stage is 16-byte aligned
+            floatx2 a0 = {0.0f, 0.0f}, a1 = {0.0f, 0.0f}, a2 = {0.0f, 0.0f};
+            for (int k = 0; k < nk; k++) {
+              const floatx2 w = co[k * half_tw];
+              const intx2 o = xo[k * half_tw];
+              const uint32_t u = LdsDwordAt(stage, so + o.x), v = LdsDwordAt(stage, so + o.y);
+              a0 += w * floatx2{(float)(u & 255), (float)(v & 255)};
+              a1 += w * floatx2{(float)((u >> 8) & 255), (float)((v >> 8) & 255)};
+              a2 += w * floatx2{(float)((u >> 16) & 255), (float)((v >> 16) & 255)};
+            }
+            floatx2 *tp = reinterpret_cast<floatx2 *>(tmp + row * rowlen + x2 * 3);   // rowlen = tw * 3 is even
+            tp[0] = floatx2{a0.x, a1.x};
+            tp[1] = floatx2{a2.x, a0.y};
+            tp[2] = floatx2{a1.y, a2.y};
+          }
+        }
+      } else if (x < tw) {
         const float *co = cx + x;
         const int *xo = xt + x;
         for (int row = tid >> tw_log2; row < nrows; row += kResampleThreads >> tw_log2) {
@@ -649,7 +754,34 @@ __global__ __launch_bounds__(kResampleThreads) void ResampleKernel(const daliamd
       }
       LdsBarrier();
       const int flat_w = d.out_w * C;
-      if (x < tw) {
+#define VLAST_EVEN(f) ((f) < ((f) & ~255) + ((min(((f) & ~255) + 256, flat_w) - ((f) & ~255)) & ~15))
+      if (pair) {
+        const int x2 = (tid & ((TW >> 1) - 1)) * 2;
+        if (x2 < tw) {
+          const int fi = (ox0 + x2) * 3;
+          bool e0 = true, e1 = true, e2 = true, e3 = true, e4 = true, e5 = true;
+          if (flat_w & 15) {   // a row whose last 256-element block has a scalar tail
+            e0 = VLAST_EVEN(fi); e1 = VLAST_EVEN(fi + 1); e2 = VLAST_EVEN(fi + 2);
+            e3 = VLAST_EVEN(fi + 3); e4 = VLAST_EVEN(fi + 4); e5 = VLAST_EVEN(fi + 5);
+          }
+          const floatx2 *tcol = reinterpret_cast<const floatx2 *>(tmp + x2 * 3);   // 6 floats: both pixels
+          const int nk = sup_y;
+          for (int y = tid >> hw_log2; y < th; y += kResampleThreads >> hw_log2) {
+            const float *co = cy + y * sup_y;
+            const int *ro = yt + y * sup_y;
+            floatx2 a01 = {0.0f, 0.0f}, a23 = {0.0f, 0.0f}, a45 = {0.0f, 0.0f};
+            for (int k = 0; k < nk; k++) {
+              const float w = co[k];
+              const floatx2 *p = tcol + (ro[k] >> 1);   // rowlen = tw * 3 is even
+              a01 += p[0] * w;
+              a23 += p[1] * w;
+              a45 += p[2] * w;
+            }
+            ep.StorePair(oy0 + y, ox0 + x2, RoundU8(a01.x, e0), RoundU8(a23.y, e3), RoundU8(a01.y, e1), RoundU8(a45.x, e4),
+                         RoundU8(a23.x, e2), RoundU8(a45.y, e5));
+          }
+        }
+      } else if (x < tw) {
         for (int y = tid >> tw_log2; y < th; y += kResampleThreads >> tw_log2) {
           const float *co = cy + y * sup_y;
           const int *ro = yt + y * sup_y;
@@ -666,17 +798,15 @@ __global__ __launch_bounds__(kResampleThreads) void ResampleKernel(const daliamd
           // ResampleVert: 256-element tiles, 16-lane SIMD body then scalar tail
           int fi = (ox0 + x) * C;
           size_t cs, o = ep.Base(oy0 + y, ox0 + x, &cs);
-#define VLAST_EVEN(f) ((f) < ((f) & ~255) + ((min(((f) & ~255) + 256, flat_w) - ((f) & ~255)) & ~15))
           ep.Store(o, 0, RoundU8(a0, VLAST_EVEN(fi)), mean0, inv0);
           if (C > 1) ep.Store(o + cs, 1, RoundU8(a1, VLAST_EVEN(fi + 1)), mean1, inv1);
           if (C > 2) ep.Store(o + 2 * cs, 2, RoundU8(a2, VLAST_EVEN(fi + 2)), mean2, inv2);
           if (C > 3) ep.Store(o + 3 * cs, 3, RoundU8(a3, VLAST_EVEN(fi + 3)), mean3, inv3);
-#undef VLAST_EVEN
         }
       }
+#undef VLAST_EVEN
     }
     LdsBarrier();   // everyone is done with this tile's LDS before the next one's data lands there
-    r = rn;
   }
 }
 
@@ -979,7 +1109,7 @@ static int SetupOne(const daliamdResampleArgs &a, daliamdResampleDesc &d, int in
     size_t lp = (ncols * a.channels + 15 + 15) & ~(size_t)15;
     size_t stage = staged ? nrows * lp : 0;
     size_t tmp_elems = d.first_axis == 1 ? (size_t)th_ * ncols * a.channels : nrows * (size_t)tw_ * a.channels;
-    return kLutLdsBytes + tables * 4 + 16 + stage + tmp_elems * 4;
+    return kLutLdsBytes + tables * 4 + 32 + stage + tmp_elems * 4;
   };
   auto shrink = [&](int &tw_, int &th_, bool staged, int min_area, size_t budget) {
     tw_ = 32; th_ = 16;
