@@ -403,22 +403,37 @@ class MfccGpu : public OperatorBase {
     const TensorList &in = ws.Input(0);
     DALI_ENFORCE(in.type() == DALI_FLOAT, "MFCC expects float32 input");
     int n = in.num_samples();
-    descs_.assign(n, daliamdMelDesc{});
+    descs_.clear();
+    slices_.assign(n, {0, 0});
     desc[0].type = DALI_FLOAT;
     desc[0].shape.resize(n);
+    // The sample is seen as [outer][n_in][inner] around `axis`: one descriptor per outer slice, the inner extent takes
+    // the place of the frames (mfcc.cc:128-172, dct_cpu.cc:39-62: the transform runs along `axis`, every other extent is kept).
     for (int i = 0; i < n; i++) {
-      int ndim = (int)in.shape(i).size();
+      const TensorShape &sh = in.shape(i);
+      int ndim = (int)sh.size();
       DALI_ENFORCE(axis_ >= 0 && axis_ < ndim, "Axis ", axis_, " is out of bounds [0,", ndim, ")");
-      DALI_ENFORCE(ndim == 2 && axis_ == 0, "MFCC (gpu) transforms the first axis of a 2-D (frequency, time) input; got ", ndim,
-                   " dimensions, axis ", axis_);
-      int nin = (int)in.shape(i)[0];
+      int nin = (int)sh[axis_];
       DALI_ENFORCE(n_in_ == 0 || nin == n_in_, "All inputs must have the same number of mel bands (got ", nin, " after ", n_in_, ")");
       n_in_ = nin;
-      descs_[i].in = static_cast<const float *>(in.raw(i));
-      descs_[i].frames = (int)in.shape(i)[1];
+      int64_t outer = 1, inner = 1;
+      for (int k = 0; k < axis_; k++) outer *= sh[k];
+      for (int k = axis_ + 1; k < ndim; k++) inner *= sh[k];
+      DALI_ENFORCE(inner < (1ll << 31) && outer < (1ll << 24), "MFCC: the input is too large");
+      slices_[i] = {outer, inner};
     }
     ndct_ = n_mfcc_ <= 0 || n_mfcc_ > n_in_ ? n_in_ : n_mfcc_;  // dct_cpu.cc:56-58
-    for (int i = 0; i < n; i++) desc[0].shape[i] = {ndct_, in.shape(i)[1]};
+    for (int i = 0; i < n; i++) {
+      desc[0].shape[i] = in.shape(i);
+      desc[0].shape[i][axis_] = ndct_;
+      const float *base = static_cast<const float *>(in.raw(i));
+      for (int64_t o = 0; o < slices_[i].first; o++) {
+        daliamdMelDesc d{};
+        d.in = base + o * n_in_ * slices_[i].second;
+        d.frames = (int)slices_[i].second;
+        descs_.push_back(d);
+      }
+    }
     return true;
   }
   void RunImpl(Workspace &ws) override {
@@ -435,7 +450,10 @@ class MfccGpu : public OperatorBase {
       KCHECK(daliamdStreamSynchronize(ws.stream));  // one-time upload from pageable memory, read by later iterations
       tables_n_in_ = n_in_;
     }
-    for (int i = 0; i < n; i++) descs_[i].out = static_cast<float *>(out.raw(i));
+    for (size_t i = 0, k = 0; i < slices_.size(); i++) {
+      float *base = static_cast<float *>(out.raw((int)i));
+      for (int64_t o = 0; o < slices_[i].first; o++) descs_[k++].out = base + o * ndct_ * slices_[i].second;
+    }
     int nwg = 0;
     KCHECK(daliamdMelFilterBankSetup(descs_.data(), n, &nwg));
     auto *dev = static_cast<const daliamdMelDesc *>(uploader_.Upload(descs_.data(), n * sizeof(descs_[0]), ws.stream, ws.ring + 1));
@@ -450,6 +468,7 @@ class MfccGpu : public OperatorBase {
   float lifter_;
   Buffer tables_dev_;
   std::vector<daliamdMelDesc> descs_;
+  std::vector<std::pair<int64_t, int64_t>> slices_;   // per sample: outer slices, inner extent
   DescUploader uploader_;
 };
 DALI_REGISTER_OPERATOR(MFCC, MfccGpu, GPU);

@@ -203,6 +203,28 @@ def test_mfcc_matches_oracle(kw):
         assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), (kw, i)
 
 
+@pytest.mark.parametrize("shape,axis", [((50, 64), 1), ((3, 64, 41), 1), ((2, 5, 32), 2), ((40, 7, 3), 0)])
+def test_mfcc_along_any_axis(shape, axis):
+    """The transform runs along `axis`, every other extent is kept (mfcc.cc:128-172)."""
+    from dali_amd import fn
+    from dali_amd.pipeline import Pipeline
+    rng = np.random.default_rng(33)
+    x = np.abs(rng.normal(0, 1, shape)).astype(np.float32)
+    pipe = Pipeline(batch_size=2, num_threads=1, device_id=0, prefetch_queue_depth=1)
+    with pipe:
+        m = fn.external_source(name="mel")
+        pipe.set_outputs(fn.mfcc(m.gpu(), axis=axis, n_mfcc=12, lifter=3.0))
+    pipe.feed_input("mel", [x, x[::-1].copy()])
+    (out,) = pipe.run()
+    for i, src in enumerate([x, x[::-1]]):
+        flat = np.moveaxis(src, axis, 0).reshape(shape[axis], -1)
+        ref = A.mfcc(flat, n_mfcc=12, lifter=3.0).reshape((12,) + tuple(np.delete(shape, axis)))
+        ref = np.moveaxis(ref, 0, axis)
+        got = out[i].as_cpu()
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+
+
 def test_mfcc_rejects_what_the_reference_rejects():
     from dali_amd import fn
     from dali_amd.pipeline import Pipeline

@@ -12,7 +12,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 SUM=$R/gpurun_out/${TAG}_summary
 mkdir -p $SUM
 cd /tmp && export TMPDIR=/tmp
-for W in headline heavy_aug audio; do
+for W in ${WORKLOADS:-headline heavy_aug audio}; do
   OUT=$R/gpurun_out/prof_$TAG/$W
   mkdir -p $OUT
   if [ $W = headline ]; then
