@@ -338,7 +338,7 @@ __global__ __launch_bounds__(kTableThreads) void ResampleTablesKernel(const dali
 // What a thread fetches from global memory for one tile ahead of time: its chunks of the staged window and its entry
 // of the coefficient / first-tap tables of either axis.
 struct TilePrefetch {
-  uint4 chunk[kPrefetchChunks];
+  uint4 chunk[kPrefetchChunks];   // (a slot is written to LDS under the condition it was loaded under: never initialised otherwise)
   float cxv, cyv;
   int xiv, yiv;
 };
@@ -371,7 +371,6 @@ __device__ __forceinline__ void FetchTile(const TileRec &r, int tid, TilePrefetc
 #pragma unroll
     for (int i = 0; i < kPrefetchChunks; i++) {
       const int row = (tid >> 4) + 16 * i, q = tid & 15;
-      p.chunk[i] = make_uint4(0, 0, 0, 0);
       if (16 * i >= r.nrows) continue;   // wave-uniform: a 31-row window skips the two upper chunk slots entirely
       if (row < r.nrows) {
         const uint32_t ro = (uint32_t)__mul24(row, r.pitch);
@@ -386,7 +385,6 @@ __device__ __forceinline__ void FetchTile(const TileRec &r, int tid, TilePrefetc
 #pragma unroll
     for (int i = 0; i < kPrefetchChunks; i++) {
       const int row = (tid >> 4) + 16 * i, q = tid & 15;
-      p.chunk[i] = make_uint4(0, 0, 0, 0);
       if (row < r.nrows) {
         const uintptr_t ra = (uintptr_t)r.win + (size_t)row * r.pitch;
         const int sh = (int)(ra & 15);
@@ -642,6 +640,9 @@ __global__ __launch_bounds__(kResampleThreads) __attribute__((amdgpu_waves_per_e
           const int gx = ox0 + x, half_tw = TW >> 1;
           const uint32_t em = d.even_mask[(gx >> 5) & 7] >> (gx & 31);   // gx is even: gx + 1 sits in the same word
           const bool even0 = em & 1, even1 = (em >> 1) & 1;
+          // the tile's columns sit in one word of the mask (TW <= 32 divides ox0)
+          const uint32_t need = (tw >= 32 ? 0xffffffffu : (1u << tw) - 1u) << (ox0 & 31);
+          const bool tile_even = (d.even_mask[(ox0 >> 5) & 7] & need) == need;
           const int nk = sup_x;
           for (int y = tid >> hw_log2; y < th; y += kResampleThreads >> hw_log2) {
             const float *trow = tmp + y * NB;
@@ -654,8 +655,12 @@ __global__ __launch_bounds__(kResampleThreads) __attribute__((amdgpu_waves_per_e
               a1 += w * floatx2{p[1], q[1]};
               a2 += w * floatx2{p[2], q[2]};
             }
-            ep.StorePair(oy0 + y, gx, RoundU8(a0.x, even0), RoundU8(a0.y, even1), RoundU8(a1.x, even0), RoundU8(a1.y, even1),
-                         RoundU8(a2.x, even0), RoundU8(a2.y, even1));
+            if (tile_even)   // (uniform) the usual case: every column of the tile rounds half-to-even
+              ep.StorePair(oy0 + y, gx, RoundU8(a0.x, true), RoundU8(a0.y, true), RoundU8(a1.x, true), RoundU8(a1.y, true),
+                           RoundU8(a2.x, true), RoundU8(a2.y, true));
+            else
+              ep.StorePair(oy0 + y, gx, RoundU8(a0.x, even0), RoundU8(a0.y, even1), RoundU8(a1.x, even0), RoundU8(a1.y, even1),
+                           RoundU8(a2.x, even0), RoundU8(a2.y, even1));
           }
         }
       } else if (x < tw) {
@@ -777,8 +782,12 @@ __global__ __launch_bounds__(kResampleThreads) __attribute__((amdgpu_waves_per_e
               a23 += p[1] * w;
               a45 += p[2] * w;
             }
-            ep.StorePair(oy0 + y, ox0 + x2, RoundU8(a01.x, e0), RoundU8(a23.y, e3), RoundU8(a01.y, e1), RoundU8(a45.x, e4),
-                         RoundU8(a23.x, e2), RoundU8(a45.y, e5));
+            if (!(flat_w & 15))
+              ep.StorePair(oy0 + y, ox0 + x2, RoundU8(a01.x, true), RoundU8(a23.y, true), RoundU8(a01.y, true),
+                           RoundU8(a45.x, true), RoundU8(a23.x, true), RoundU8(a45.y, true));
+            else
+              ep.StorePair(oy0 + y, ox0 + x2, RoundU8(a01.x, e0), RoundU8(a23.y, e3), RoundU8(a01.y, e1), RoundU8(a45.x, e4),
+                           RoundU8(a23.x, e2), RoundU8(a45.y, e5));
           }
         }
       } else if (x < tw) {

@@ -12,7 +12,8 @@ for SET in "$@"; do
   timeout 300 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT/set$i -- python $R/bench.py ${BENCH_ARGS:---steps 8 --warmup 4 --no-cpu-baseline --no-e2e --inflight 1} > /dev/null 2> $OUT/set$i.log
 done
 python - <<PY
-import csv, collections, glob
+import csv, collections, glob, json
+summary = collections.defaultdict(dict)
 for d in sorted(glob.glob("$OUT/set*")):
     for f in glob.glob(d+"/*/*_counter_collection.csv"):
         rows=list(csv.DictReader(open(f)))
@@ -21,5 +22,10 @@ for d in sorted(glob.glob("$OUT/set*")):
             acc[r["Kernel_Name"].split("(")[0][-28:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k,v in sorted(acc.items()):
             if "daliamd" in k or "Kernel" in k:
-                print(k, {c:round(sum(x)/len(x)) for c,x in v.items()}, "launches", len(next(iter(v.values()))))
+                avg = {c:round(sum(x)/len(x)) for c,x in v.items()}
+                print(k, avg, "launches", len(next(iter(v.values()))))
+                summary[k.split("::")[-1].split("<")[0]].update(avg)
+json.dump({"note": "rocprofv3 --pmc, averages per launch over the bench command (inflight 1); one pass per counter set; "
+           "SQ counters are summed over the shader engines as rocprofv3 reports them", "kernels": summary},
+          open("$OUT/summary.json", "w"), indent=1, sort_keys=True)
 PY
