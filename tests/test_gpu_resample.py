@@ -124,6 +124,29 @@ def test_fused_rrc_cmn_matches_oracle_composition(dtype, layout):
         _check(u8[i], O.resample_u8(im, (224, 224), roi=rois[i]), f"u8 sample {i}")
 
 
+@pytest.mark.parametrize("out_hw", [(37, 50), (45, 51), (16, 2), (100, 98), (33, 34), (224, 226)])
+def test_fused_fp16_chw_ragged_sizes_both_pass_orders(out_hw):
+    """The fp16 CHW epilogue takes two pixels per thread when the width is even (odd widths, 1-pixel tiles and other
+    layouts keep the one-pixel path): partial tiles, both pass orders (wide and tall sources), mirrored or not, against
+    the u8 kernel path + oracle CMN bit for bit and against the oracle's resampling."""
+    from dali_amd import backend as B
+    from dali_amd import _capi as capi
+    rng = np.random.default_rng(12)
+    imgs = [synth_image(rng, h, w) for (h, w) in [(90, 400), (400, 90), (130, 170), (64, 64), (301, 203), (203, 301)]]
+    rois = [(3.0, 5.0, h - 2.0, w - 4.0) if i % 2 else None for i, (h, w) in enumerate(im.shape[:2] for im in imgs)]
+    mirror = np.array([0, 1, 1, 0, 1, 0], np.int32)
+    mean, inv = O.cmn_norm_args([0.485 * 255, 0.456 * 255, 0.406 * 255], [0.229 * 255, 0.224 * 255, 0.225 * 255])
+    out, descs, _, _ = B.resample_batch([_to_dev(im, 16) for im in imgs], out_hw, rois=rois, out_dtype=capi.FLOAT16,
+                                        out_layout=capi.LAYOUT_CHW, mean=mean, inv_std=inv, mirror=mirror, return_descs=True)
+    assert set(descs["first_axis"].tolist()) == {0, 1}, "both pass orders must be exercised"
+    u8 = B.resample_batch([_to_dev(im, 16) for im in imgs], out_hw, rois=rois).cpu().numpy()
+    out = out.cpu().numpy()
+    for i, im in enumerate(imgs):
+        ref = O.cmn_u8(u8[i], (0, 0), out_hw, mirror=bool(mirror[i]), mean=mean, inv_std=inv, layout="CHW", dtype=O.F16)
+        assert np.array_equal(out[i].view(np.uint16), ref.view(np.uint16)), f"sample {i}"
+        _check(u8[i], O.resample_u8(im, out_hw, roi=rois[i]), f"u8 sample {i}")
+
+
 def test_checkerboard_vs_onnx_reference_on_the_gpu():
     """The reference's golden pin (test_resize.py:919-1029, atol 1) through the HIP kernel: 22 x 22 checkerboard ->
     17 x 13, antialiased linear (the kernel's triangular filter), against the ONNX reference restated in
