@@ -199,6 +199,16 @@ uint32_t LongCode(const Tables &L, uint32_t slot, uint32_t peek, bool is_dc) {
 // advances when the step ended a block (`ended`; the last report of an index is the one that counts).  A store into
 // LDS simply writes every time: no branch, no execution mask, off the dependency chain of the step.  A store that is
 // expensive (global memory) looks at `ended`.
+// Stream dword at BYTE offset kb (a multiple of 4).  On the device the offset stays a 32-bit register next to a
+// uniform base (no 64-bit address arithmetic in the decode loop).
+template <typename Words>
+HUFF_HD uint32_t WordAtByte(Words words, uint32_t kb) { return words[kb >> 2]; }
+#if defined(__HIPCC__)
+__device__ __forceinline__ uint32_t WordAtByte(const uint32_t __attribute__((address_space(1))) *words, uint32_t kb) {
+  return *(const uint32_t __attribute__((address_space(1))) *)((const uint8_t __attribute__((address_space(1))) *)words + kb);
+}
+#endif
+
 template <typename Tables, typename Words, typename Store>
 HUFF_HD int SyncDecodeRange(const Tables &L, Words words, DecodeState &st, uint32_t end_bits, Store store) {
   int nb = 0;
@@ -209,9 +219,9 @@ HUFF_HD int SyncDecodeRange(const Tables &L, Words words, DecodeState &st, uint3
     nb = 1;
   }
   // bit window: hi:lo = stream bits [32k, 32k+64), `off` of hi's bits already consumed; the following dword is in flight
-  int k = (int)(st.pos >> 5);
+  uint32_t kb = (st.pos >> 5) << 2;  // byte offset of hi's dword
   uint32_t off = st.pos & 31;
-  uint32_t hi = Bswap32(words[k]), lo = Bswap32(words[k + 1]), nxt = words[k + 2];
+  uint32_t hi = Bswap32(WordAtByte(words, kb)), lo = Bswap32(WordAtByte(words, kb + 4)), nxt = WordAtByte(words, kb + 8);
   const uint32_t dc_mask = HUFF_UNIFORM(L.dc_mask), ac_mask = HUFF_UNIFORM(L.ac_mask), bpm = HUFF_UNIFORM(L.bpm);
   // The report of a step is handed to `store` right BEHIND the table look-up of the next step: an LDS store issued
   // in front of the look-up would sit in front of it in the (in-order) LDS queue and add its service time to the
@@ -245,8 +255,8 @@ HUFF_HD int SyncDecodeRange(const Tables &L, Words words, DecodeState &st, uint3
     if (off >= 32) {
       hi = lo;
       lo = Bswap32(nxt);
-      k++;
-      nxt = words[k + 2];
+      nxt = WordAtByte(words + 3, kb);  // dword k + 3 of the window that starts at k (uniform base, 32-bit offset as it is)
+      kb += 4;
       off -= 32;
     }
     const bool end_of_block = z >= 64;
@@ -316,7 +326,7 @@ HUFF_HD BitWindow OpenWindow(Words words, uint32_t pos) {
 // corrupt stream), so the store needs no condition.  The block must be zero-filled by the caller.
 template <typename Tables, typename Words, typename Coef>
 HUFF_HD void DecodeBlockAc(const Tables &L, Words words, const BitWindow &win, uint32_t ac_slot, Coef coef) {
-  int k = win.k;
+  uint32_t kb = (uint32_t)win.k << 2;  // byte offset of hi's dword
   uint32_t off = win.off;
   uint32_t hi = Bswap32(win.hi), lo = Bswap32(win.lo), nxt = win.nxt;
   uint32_t z = 1;
@@ -333,8 +343,8 @@ HUFF_HD void DecodeBlockAc(const Tables &L, Words words, const BitWindow &win, u
     if (off >= 32) {
       hi = lo;
       lo = Bswap32(nxt);
-      k++;
-      nxt = words[k + 2];
+      nxt = WordAtByte(words + 3, kb);
+      kb += 4;
       off -= 32;
     }
   }
