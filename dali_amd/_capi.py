@@ -17,7 +17,7 @@ class DaliAmdError(RuntimeError):
 
 
 # ------------------------------------------------------------------ enums
-UINT8, FLOAT16, FLOAT, INT8, INT16, UINT16 = 0, 1, 2, 3, 4, 5
+UINT8, FLOAT16, FLOAT, INT8, INT16, UINT16, INT32, UINT32 = 0, 1, 2, 3, 4, 5, 6, 7
 LAYOUT_HWC, LAYOUT_CHW = 0, 1
 INTERP_NN, INTERP_LINEAR, INTERP_TRIANGULAR, INTERP_CUBIC, INTERP_LANCZOS3, INTERP_GAUSSIAN = 0, 1, 2, 3, 4, 5
 JPEG_GRAY, JPEG_YCC, JPEG_RGB = 0, 1, 2
@@ -184,6 +184,7 @@ _KERNEL_SYMBOLS = [
     "daliamdHannWindow", "daliamdSpectrogramTwiddles", "daliamdSpectrogramSetup", "daliamdSpectrogramRun", "daliamdMelFilterBankWeights",
     "daliamdMelFilterBankBands", "daliamdMelFilterBankSetup", "daliamdMelFilterBankRun", "daliamdToDecibelsSetup", "daliamdToDecibelsRun", "daliamdDctTable", "daliamdLifterCoeffs", "daliamdDctRun",
     "daliamdAudioResampleLobes", "daliamdAudioResampleWindow", "daliamdAudioResampleSetup", "daliamdAudioResampleRun",
+    "daliamdConvertNormSetup", "daliamdConvertNormRun",
     "daliamdNormalizeSetup", "daliamdNormalizeRun",
 ]
 
@@ -193,6 +194,7 @@ _HOST_SYMBOLS = [
     "daliamdRandomCropBatch", "daliamdCoinFlipBatch", "daliamdPhiloxAdvanceSequence",
     "daliamdPhiloxStateToString", "daliamdPhiloxStateFromString", "daliamdPhiloxGenerate",
     "daliamdCmnNormArgs", "daliamdCropAnchor", "daliamdResampleRunHost", "daliamdCmnRunHost", "daliamdAudioResampleHost",
+    "daliamdConvertNormHost",
     "daliamdImageCachePolicyCreate", "daliamdImageCachePolicyDestroy", "daliamdImageCachePolicyOnDecode",
     "daliamdImageCachePolicyFind", "daliamdImageProbe", "daliamdImageDecodeRgb",
 ]

@@ -652,6 +652,79 @@ static double MelToHz(double mel, int formula) {
   return mel >= min_log_mel ? min_log_hz * std::exp(step_log * (mel - min_log_mel)) : 0.0 + mel * fsp;
 }
 
+// =============================================================================================
+// Normalised sample-type conversion (ConvertSatNorm): see the header.  1024 elements per workgroup.
+// =============================================================================================
+constexpr int kCvtThreads = 256, kCvtPerWg = 1024;
+__device__ __forceinline__ float LoadNorm(const void *p, int dtype, int64_t i) {
+  using G = __attribute__((address_space(1))) const uint8_t;
+  G *b = (G *)p;
+  switch (dtype) {
+    case DALIAMD_INT8: return (float)((const int8_t __attribute__((address_space(1))) *)b)[i] * (1.0f / 127.0f);
+    case DALIAMD_UINT8: return (float)b[i] * (1.0f / 255.0f);
+    case DALIAMD_INT16: return (float)((const int16_t __attribute__((address_space(1))) *)b)[i] * (1.0f / 32767.0f);
+    case DALIAMD_UINT16: return (float)((const uint16_t __attribute__((address_space(1))) *)b)[i] * (1.0f / 65535.0f);
+    case DALIAMD_INT32: return (float)((const int32_t __attribute__((address_space(1))) *)b)[i] * (1.0f / 2147483648.0f);
+    case DALIAMD_UINT32: return (float)((const uint32_t __attribute__((address_space(1))) *)b)[i] * (1.0f / 4294967296.0f);
+    default: return ((const float __attribute__((address_space(1))) *)b)[i];
+  }
+}
+// clamp<Out>(std::round(v * max)): the bounds compare as floats (the int32 / uint32 maxima round up to 2^31 / 2^32)
+__device__ __forceinline__ void StoreNorm(void *p, int dtype, int64_t i, float v) {
+  using GB = __attribute__((address_space(1))) uint8_t;
+  GB *b = (GB *)p;
+  switch (dtype) {
+    case DALIAMD_INT8: {
+      const float r = roundf(v * 127.0f);
+      ((int8_t __attribute__((address_space(1))) *)b)[i] = (int8_t)(r <= -128.0f ? -128 : r >= 127.0f ? 127 : (int)r);
+      break;
+    }
+    case DALIAMD_UINT8: {
+      const float r = roundf(v * 255.0f);
+      b[i] = (uint8_t)(r <= 0.0f ? 0 : r >= 255.0f ? 255 : (int)r);
+      break;
+    }
+    case DALIAMD_INT16: {
+      const float r = roundf(v * 32767.0f);
+      ((int16_t __attribute__((address_space(1))) *)b)[i] = (int16_t)(r <= -32768.0f ? -32768 : r >= 32767.0f ? 32767 : (int)r);
+      break;
+    }
+    case DALIAMD_UINT16: {
+      const float r = roundf(v * 65535.0f);
+      ((uint16_t __attribute__((address_space(1))) *)b)[i] = (uint16_t)(r <= 0.0f ? 0 : r >= 65535.0f ? 65535 : (int)r);
+      break;
+    }
+    case DALIAMD_INT32: {
+      const float r = roundf(v * 2147483648.0f);
+      ((int32_t __attribute__((address_space(1))) *)b)[i] =
+          r <= -2147483648.0f ? (int32_t)0x80000000 : r >= 2147483648.0f ? 2147483647 : (int32_t)r;
+      break;
+    }
+    case DALIAMD_UINT32: {
+      const float r = roundf(v * 4294967296.0f);
+      ((uint32_t __attribute__((address_space(1))) *)b)[i] = r <= 0.0f ? 0u : r >= 4294967296.0f ? 4294967295u : (uint32_t)r;
+      break;
+    }
+    default: ((float __attribute__((address_space(1))) *)b)[i] = v;
+  }
+}
+__global__ __launch_bounds__(kCvtThreads) void ConvertNormKernel(const daliamdConvertNormDesc *__restrict__ descs, int ndesc,
+                                                                 int total_wg, int in_dtype, int out_dtype, int mode) {
+  const int wg = XcdRemap(blockIdx.x, total_wg);
+  if (wg < 0) return;
+  const int di = FindDesc(descs, ndesc, wg);
+  const daliamdConvertNormDesc &d = descs[di];
+  const int64_t base = (int64_t)(wg - d.wg_start) * kCvtPerWg;
+  for (int j = threadIdx.x; j < kCvtPerWg; j += kCvtThreads) {
+    const int64_t i = base + j;
+    if (i >= d.count) break;
+    float f = LoadNorm(d.in, in_dtype, i);
+    if (mode == 1) f = (f + 1.0f) * 0.5f;
+    else if (mode == 2) f = f * 2.0f - 1.0f;
+    StoreNorm(d.out, out_dtype, i, f);
+  }
+}
+
 }  // namespace daliamd
 
 extern "C" {
@@ -986,6 +1059,37 @@ daliamdResult_t daliamdAudioResampleRun(daliamdStream_t stream, const daliamdAud
     daliamd::KernelTimer timer("AudioResampleKernel", (hipStream_t)stream);
     hipLaunchKernelGGL(AudioResampleKernel, dim3(XcdGrid(nwg)), dim3(kRsThreads), lds, (hipStream_t)stream, descs_dev, n, nwg,
                        lookup_dev, lookup_size, scale, center, lobes);
+  }
+  DALIAMD_HIP_CHECK(hipGetLastError());
+  return DALIAMD_SUCCESS;
+}
+
+daliamdResult_t daliamdConvertNormSetup(daliamdConvertNormDesc *descs, int n, int *nwg) {
+  DALIAMD_REQUIRE(descs && nwg && n >= 0, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdConvertNormSetup: NULL argument");
+  int wg = 0;
+  for (int i = 0; i < n; i++) {
+    DALIAMD_REQUIRE(descs[i].count >= 0 && (descs[i].count == 0 || (descs[i].in && descs[i].out)), DALIAMD_ERROR_INVALID_ARGUMENT,
+                    "daliamdConvertNormSetup: sample %d: NULL buffer or negative count", i);
+    descs[i].wg_start = wg;
+    wg += (int)((descs[i].count + kCvtPerWg - 1) / kCvtPerWg);
+  }
+  *nwg = wg;
+  return DALIAMD_SUCCESS;
+}
+
+daliamdResult_t daliamdConvertNormRun(daliamdStream_t stream, const daliamdConvertNormDesc *descs_dev, int n, int nwg, int in_dtype,
+                                      int out_dtype, int mode) {
+  if (n == 0 || nwg == 0) return DALIAMD_SUCCESS;
+  auto known = [](int t) {
+    return t == DALIAMD_INT8 || t == DALIAMD_UINT8 || t == DALIAMD_INT16 || t == DALIAMD_UINT16 || t == DALIAMD_INT32 ||
+           t == DALIAMD_UINT32 || t == DALIAMD_FLOAT;
+  };
+  DALIAMD_REQUIRE(descs_dev && known(in_dtype) && known(out_dtype) && mode >= 0 && mode <= 2, DALIAMD_ERROR_INVALID_ARGUMENT,
+                  "daliamdConvertNormRun: invalid argument");
+  {
+    daliamd::KernelTimer timer("ConvertNormKernel", (hipStream_t)stream);
+    hipLaunchKernelGGL(ConvertNormKernel, dim3(XcdGrid(nwg)), dim3(kCvtThreads), 0, (hipStream_t)stream, descs_dev, n, nwg, in_dtype,
+                       out_dtype, mode);
   }
   DALIAMD_HIP_CHECK(hipGetLastError());
   return DALIAMD_SUCCESS;

@@ -481,3 +481,52 @@ extern "C" int daliamdAudioResampleHost(const float *in, int64_t in_length, int 
   }
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Normalised sample-type conversion (ConvertSatNorm<float>(int), ConvertSatNorm<int>(float): convert.h:262-350)
+// ---------------------------------------------------------------------------------------------
+namespace {
+template <typename T> float NormToFloat(T v, float inv_max) { return (float)v * inv_max; }
+template <typename T> T NormFromFloat(float v, float fmax, float fmin, T tmin, T tmax) {
+  const float r = std::round(v * fmax);
+  return r <= fmin ? tmin : r >= fmax ? tmax : (T)r;
+}
+float LoadNormHost(const void *p, int dtype, int64_t i) {
+  switch (dtype) {
+    case DALIAMD_INT8: return NormToFloat(((const int8_t *)p)[i], 1.0f / 127.0f);
+    case DALIAMD_UINT8: return NormToFloat(((const uint8_t *)p)[i], 1.0f / 255.0f);
+    case DALIAMD_INT16: return NormToFloat(((const int16_t *)p)[i], 1.0f / 32767.0f);
+    case DALIAMD_UINT16: return NormToFloat(((const uint16_t *)p)[i], 1.0f / 65535.0f);
+    case DALIAMD_INT32: return NormToFloat(((const int32_t *)p)[i], 1.0f / 2147483648.0f);
+    case DALIAMD_UINT32: return NormToFloat(((const uint32_t *)p)[i], 1.0f / 4294967296.0f);
+    default: return ((const float *)p)[i];
+  }
+}
+void StoreNormHost(void *p, int dtype, int64_t i, float v) {
+  switch (dtype) {
+    case DALIAMD_INT8: ((int8_t *)p)[i] = NormFromFloat<int8_t>(v, 127.0f, -128.0f, -128, 127); break;
+    case DALIAMD_UINT8: ((uint8_t *)p)[i] = NormFromFloat<uint8_t>(v, 255.0f, 0.0f, 0, 255); break;
+    case DALIAMD_INT16: ((int16_t *)p)[i] = NormFromFloat<int16_t>(v, 32767.0f, -32768.0f, -32768, 32767); break;
+    case DALIAMD_UINT16: ((uint16_t *)p)[i] = NormFromFloat<uint16_t>(v, 65535.0f, 0.0f, 0, 65535); break;
+    case DALIAMD_INT32: ((int32_t *)p)[i] = NormFromFloat<int32_t>(v, 2147483648.0f, -2147483648.0f, INT32_MIN, INT32_MAX); break;
+    case DALIAMD_UINT32: ((uint32_t *)p)[i] = NormFromFloat<uint32_t>(v, 4294967296.0f, 0.0f, 0u, UINT32_MAX); break;
+    default: ((float *)p)[i] = v;
+  }
+}
+}  // namespace
+
+extern "C" int daliamdConvertNormHost(const void *in, int in_dtype, void *out, int out_dtype, int64_t count, int mode) {
+  auto known = [](int t) {
+    return t == DALIAMD_INT8 || t == DALIAMD_UINT8 || t == DALIAMD_INT16 || t == DALIAMD_UINT16 || t == DALIAMD_INT32 ||
+           t == DALIAMD_UINT32 || t == DALIAMD_FLOAT;
+  };
+  if (count < 0 || (count > 0 && (!in || !out)) || !known(in_dtype) || !known(out_dtype) || mode < 0 || mode > 2)
+    return Fail("daliamdConvertNormHost: invalid argument");
+  for (int64_t i = 0; i < count; i++) {
+    float f = LoadNormHost(in, in_dtype, i);
+    if (mode == 1) f = (f + 1.0f) * 0.5f;
+    else if (mode == 2) f = f * 2.0f - 1.0f;
+    StoreNormHost(out, out_dtype, i, f);
+  }
+  return 0;
+}

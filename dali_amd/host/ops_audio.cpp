@@ -489,7 +489,8 @@ DALI_SCHEMA(AudioResample)
     .AddOptionalTypeArg("out_length", "The requested output length, in samples.", ArgType::INT, true)
     .AddOptionalArg("quality", "Resampling quality, where 0 is the lowest, and 100 is the highest: 0 gives 3 lobes of the sinc "
                     "filter, 50 gives 16 lobes, and 100 gives 64 lobes.", ArgValue::Float(50.0))
-    .AddOptionalTypeArg("dtype", "The output type (float32 only on this backend).", ArgType::INT);
+    .AddOptionalTypeArg("dtype", "The output type. If not specified, the output type is the same as the input type. Integer "
+                        "samples are normalised: signed types to -1..1, unsigned types to 0..1.", ArgType::INT);
 DALI_SCHEMA(experimental__AudioResample).DocStr("Legacy alias for :meth:`audio_resample`.").AddParent("AudioResample").NumInput(1).NumOutput(1);
 
 class AudioResampleGpu : public OperatorBase {
@@ -508,12 +509,36 @@ class AudioResampleGpu : public OperatorBase {
                  "sampling rates.");
     quality_ = (float)spec.GetFloat("quality");
     DALI_ENFORCE(quality_ >= 0 && quality_ <= 100, "``quality`` out of range: ", quality_, "\nValid range is [0..100].");
-    if (const ArgValue *d = spec.TryArg("dtype"))
-      DALI_ENFORCE(d->i == DALI_FLOAT, "AudioResample produces float32 output only in this build");
+    if (const ArgValue *d = spec.TryArg("dtype")) {
+      dtype_ = (DALIDataType)d->i;
+      DALI_ENFORCE(KernelType(dtype_) >= 0, "Unsupported output type: ", (int)dtype_,
+                   "\nSupported types are : int8, uint8, int16, uint16, int32, uint32, float");
+    }
   }
+  // daliamdDType_t of an audio sample type (AUDIO_RESAMPLE_TYPES, resample.h:28), -1 for anything else
+  static int KernelType(DALIDataType t) {
+    switch (t) {
+      case DALI_INT8: return DALIAMD_INT8;
+      case DALI_UINT8: return DALIAMD_UINT8;
+      case DALI_INT16: return DALIAMD_INT16;
+      case DALI_UINT16: return DALIAMD_UINT16;
+      case DALI_INT32: return DALIAMD_INT32;
+      case DALI_UINT32: return DALIAMD_UINT32;
+      case DALI_FLOAT: return DALIAMD_FLOAT;
+      default: return -1;
+    }
+  }
+  static bool IsUnsignedType(DALIDataType t) { return t == DALI_UINT8 || t == DALI_UINT16 || t == DALI_UINT32; }
   bool SetupImpl(std::vector<OutputDesc> &desc, const Workspace &ws) override {
     const TensorList &in = ws.Input(0);
-    DALI_ENFORCE(in.type() == DALI_FLOAT, "AudioResample expects float32 input");
+    in_type_ = in.type();
+    DALI_ENFORCE(KernelType(in_type_) >= 0, "Unsupported input type: ", (int)in_type_,
+                 "\nSupported types are : int8, uint8, int16, uint16, int32, uint32, float");
+    out_type_ = dtype_ == DALI_NO_TYPE ? in_type_ : dtype_;
+    // ConvertInput (resample.cc:160-192): what happens to the samples on their way to floats
+    const bool out_unsigned = IsUnsignedType(out_type_), in_unsigned = IsUnsignedType(in_type_);
+    if (in_type_ == DALI_FLOAT) in_mode_ = out_unsigned ? 1 : -1;                     // -1: the input is used as it is
+    else in_mode_ = out_unsigned && !in_unsigned ? 1 : !out_unsigned && in_unsigned ? 2 : 0;
     int n = in.num_samples();
     std::vector<float> in_rate, out_rate, scale;
     std::vector<int> out_len;
@@ -526,14 +551,16 @@ class AudioResampleGpu : public OperatorBase {
       out_len = GetPerSampleInt(spec_, ws, "out_length", n);
     }
     descs_.assign(n, daliamdAudioResampleDesc{});
-    desc[0].type = DALI_FLOAT;
+    in_raw_.assign(n, nullptr);
+    desc[0].type = out_type_;
     desc[0].shape.resize(n);
     for (int i = 0; i < n; i++) {
       const TensorShape &s = in.shape(i);
       DALI_ENFORCE(s.size() == 1 || s.size() == 2,
                    "Audio resampling supports only time series data, with an optional innermost channel dimension.");
       auto &d = descs_[i];
-      d.in = static_cast<const float *>(in.raw(i));
+      in_raw_[i] = in.raw(i);
+      d.in = static_cast<const float *>(in.raw(i));   // replaced by the float copy when the samples are converted
       d.in_length = s[0];
       d.channels = s.size() == 2 ? (int)s[1] : 1;
       if (has_rates_) {
@@ -563,12 +590,29 @@ class AudioResampleGpu : public OperatorBase {
     out.SetLayout(ws.Input(0).layout());
     int n = (int)descs_.size();
     if (!n) return;
-    if (ws.backend == OpType::CPU) {  // one thread-pool task per sample on the host kernel
+    const int kin = KernelType(in_type_), kout = KernelType(out_type_);
+    const bool cvt_in = in_mode_ >= 0, cvt_out = out_type_ != DALI_FLOAT;
+    if (ws.backend == OpType::CPU) {  // one thread-pool task per sample on the host kernels
       for (int i = 0; i < n; i++) {
-        descs_[i].out = static_cast<float *>(out.raw(i));
-        ws.GetThreadPool().AddWork([this, i](int) {
+        void *out_raw = out.raw(i);
+        ws.GetThreadPool().AddWork([this, i, out_raw, kin, kout, cvt_in, cvt_out](int) {
           const auto &d = descs_[i];
-          if (daliamdAudioResampleHost(d.in, d.in_length, d.channels, d.in_rate, d.out_rate, quality_, d.out, d.out_length) != 0)
+          std::vector<float> fin, fout;
+          const float *src = static_cast<const float *>(in_raw_[i]);
+          if (cvt_in) {
+            fin.resize((size_t)d.in_length * d.channels);
+            if (daliamdConvertNormHost(in_raw_[i], kin, fin.data(), DALIAMD_FLOAT, (int64_t)fin.size(), in_mode_) != 0)
+              DALI_FAIL(daliamdHostGetLastErrorMessage());
+            src = fin.data();
+          }
+          float *dst = static_cast<float *>(out_raw);
+          if (cvt_out) {
+            fout.resize((size_t)d.out_length * d.channels);
+            dst = fout.data();
+          }
+          if (daliamdAudioResampleHost(src, d.in_length, d.channels, d.in_rate, d.out_rate, quality_, dst, d.out_length) != 0)
+            DALI_FAIL(daliamdHostGetLastErrorMessage());
+          if (cvt_out && daliamdConvertNormHost(fout.data(), DALIAMD_FLOAT, out_raw, kout, (int64_t)fout.size(), 0) != 0)
             DALI_FAIL(daliamdHostGetLastErrorMessage());
         }, descs_[i].out_length);
       }
@@ -584,22 +628,72 @@ class AudioResampleGpu : public OperatorBase {
       KCHECK(daliamdMemcpyH2DAsync(lookup_dev_.data(), lookup.data(), lookup.size() * sizeof(float), ws.stream));
       KCHECK(daliamdStreamSynchronize(ws.stream));  // one-time upload from pageable memory
     }
-    for (int i = 0; i < n; i++) descs_[i].out = static_cast<float *>(out.raw(i));
+    // float copies of typed inputs / float results of typed outputs: scratch behind a table slot, 16-byte aligned per sample
+    size_t in_elems = 0, out_elems = 0;
+    std::vector<size_t> in_off(n), out_off(n);
+    for (int i = 0; i < n; i++) {
+      in_off[i] = in_elems;
+      out_off[i] = out_elems;
+      in_elems += ((size_t)descs_[i].in_length * descs_[i].channels + 3) & ~(size_t)3;
+      out_elems += ((size_t)descs_[i].out_length * descs_[i].channels + 3) & ~(size_t)3;
+    }
+    float *fin = nullptr, *fout = nullptr;
+    if (cvt_in || cvt_out) {  // the slot of a (dummy) table upload: reused only when the iteration `ring` steps back is done
+      const uint64_t tag = 0;
+      const size_t in_bytes = cvt_in ? (in_elems * sizeof(float) + 255) & ~(size_t)255 : 0;
+      scratch_up_.Upload(&tag, sizeof(tag), ws.stream, ws.ring + 1, in_bytes + std::max<size_t>(out_elems, 4) * sizeof(float));
+      char *base = static_cast<char *>(scratch_up_.Scratch());
+      fin = reinterpret_cast<float *>(base);
+      fout = reinterpret_cast<float *>(base + in_bytes);
+    }
+    if (cvt_in) {
+      cvt_.assign(n, daliamdConvertNormDesc{});
+      for (int i = 0; i < n; i++) {
+        cvt_[i].in = in_raw_[i];
+        cvt_[i].out = fin + in_off[i];
+        cvt_[i].count = descs_[i].in_length * descs_[i].channels;
+        descs_[i].in = fin + in_off[i];
+      }
+      int cwg = 0;
+      KCHECK(daliamdConvertNormSetup(cvt_.data(), n, &cwg));
+      auto *cdev = static_cast<const daliamdConvertNormDesc *>(cvt_uploader_[0].Upload(cvt_.data(), n * sizeof(cvt_[0]), ws.stream, ws.ring + 1));
+      KCHECK(daliamdConvertNormRun(ws.stream, cdev, n, cwg, kin, DALIAMD_FLOAT, in_mode_));
+      NoteLaunch(ws, "audio_samples_to_float");
+    }
+    for (int i = 0; i < n; i++) descs_[i].out = cvt_out ? fout + out_off[i] : static_cast<float *>(out.raw(i));
     int nwg = 0;
     KCHECK(daliamdAudioResampleSetup(descs_.data(), n, &nwg));
     auto *dev = static_cast<const daliamdAudioResampleDesc *>(uploader_.Upload(descs_.data(), n * sizeof(descs_[0]), ws.stream, ws.ring + 1));
     KCHECK(daliamdAudioResampleRun(ws.stream, dev, n, nwg, static_cast<const float *>(lookup_dev_.data()), lookup_size_, wscale_,
                                    wcenter_, lobes_));
+    if (cvt_out) {
+      NoteLaunch(ws, "audio_resample");
+      cvt_.assign(n, daliamdConvertNormDesc{});
+      for (int i = 0; i < n; i++) {
+        cvt_[i].in = fout + out_off[i];
+        cvt_[i].out = out.raw(i);
+        cvt_[i].count = descs_[i].out_length * descs_[i].channels;
+      }
+      int cwg = 0;
+      KCHECK(daliamdConvertNormSetup(cvt_.data(), n, &cwg));
+      auto *cdev = static_cast<const daliamdConvertNormDesc *>(cvt_uploader_[1].Upload(cvt_.data(), n * sizeof(cvt_[0]), ws.stream, ws.ring + 1));
+      KCHECK(daliamdConvertNormRun(ws.stream, cdev, n, cwg, DALIAMD_FLOAT, kout, 0));
+      NoteLaunch(ws, "audio_samples_from_float");
+      return;
+    }
     NoteLaunch(ws, "audio_resample");
   }
 
  private:
   bool has_rates_, has_scale_, has_len_;
   float quality_, wscale_ = 0, wcenter_ = 0;
-  int lobes_ = 0, lookup_size_ = 0;
+  int lobes_ = 0, lookup_size_ = 0, in_mode_ = -1;
+  DALIDataType dtype_ = DALI_NO_TYPE, in_type_ = DALI_FLOAT, out_type_ = DALI_FLOAT;
   Buffer lookup_dev_;
   std::vector<daliamdAudioResampleDesc> descs_;
-  DescUploader uploader_;
+  std::vector<daliamdConvertNormDesc> cvt_;
+  std::vector<const void *> in_raw_;
+  DescUploader uploader_, cvt_uploader_[2], scratch_up_;
 };
 DALI_REGISTER_OPERATOR(AudioResample, AudioResampleGpu, GPU);
 DALI_REGISTER_OPERATOR(experimental__AudioResample, AudioResampleGpu, GPU);

@@ -176,6 +176,11 @@ DALIAMD_HOST_API int64_t daliamdImageCachePolicyFind(void *policy, const char *k
 DALIAMD_HOST_API int daliamdAudioResampleHost(const float *in, int64_t in_length, int channels, double in_rate, double out_rate,
                                               float quality, float *out, int64_t out_length);
 
+/* Normalised sample-type conversion on the host, the arithmetic of daliamdConvertNormRun (daliamdDType_t codes, mode 0 / 1 / 2
+ * as there): the typed inputs and outputs of audio_resample(device="cpu") (dali/operators/audio/resample.cc:142-192,
+ * include/dali/core/convert.h:262-350).  Returns 0 on success. */
+DALIAMD_HOST_API int daliamdConvertNormHost(const void *in, int in_dtype, void *out, int out_dtype, int64_t count, int mode);
+
 #ifdef __cplusplus
 }
 #endif

@@ -94,7 +94,8 @@ DALIAMD_API daliamdResult_t daliamdMemcpy2DD2DAsync(void *dst, size_t dst_pitch,
 
 /* Element types of kernel outputs (subset of DALIDataType, include/dali/core/dali_data_type.h) */
 typedef enum {
-  DALIAMD_UINT8 = 0, DALIAMD_FLOAT16 = 1, DALIAMD_FLOAT = 2, DALIAMD_INT8 = 3, DALIAMD_INT16 = 4, DALIAMD_UINT16 = 5
+  DALIAMD_UINT8 = 0, DALIAMD_FLOAT16 = 1, DALIAMD_FLOAT = 2, DALIAMD_INT8 = 3, DALIAMD_INT16 = 4, DALIAMD_UINT16 = 5,
+  DALIAMD_INT32 = 6, DALIAMD_UINT32 = 7
 } daliamdDType_t;
 typedef enum { DALIAMD_LAYOUT_HWC = 0, DALIAMD_LAYOUT_CHW = 1 } daliamdLayout_t;
 
@@ -523,6 +524,22 @@ DALIAMD_API daliamdResult_t daliamdAudioResampleSetup(daliamdAudioResampleDesc *
 DALIAMD_API daliamdResult_t daliamdAudioResampleRun(daliamdStream_t stream, const daliamdAudioResampleDesc *descs_dev, int n,
                                                    int num_workgroups, const float *lookup_dev, int lookup_size, float scale,
                                                    float center, int lobes);
+
+/* Normalised sample-type conversion around the audio resampler (ConvertSatNorm, include/dali/core/convert.h:262-350;
+ * the input rules of dali/operators/audio/resample.cc:160-192): integers <-> floats in [-1, 1] (signed) or [0, 1]
+ * (unsigned): f = in / max(in type); mode 1: f = (f + 1) * 0.5 (signed source to an unsigned result), mode 2:
+ * f = f * 2 - 1 (unsigned source to a signed result); out = clamp(round_half_away(f * max(out type))) or f itself.
+ * Types: int8 / uint8 / int16 / uint16 / int32 / uint32 / float. */
+typedef struct {
+  const void *in;
+  void *out;
+  int64_t count;
+  int32_t wg_start;     /* filled by Setup */
+  int32_t reserved;
+} daliamdConvertNormDesc;
+DALIAMD_API daliamdResult_t daliamdConvertNormSetup(daliamdConvertNormDesc *descs_host, int n, int *num_workgroups);
+DALIAMD_API daliamdResult_t daliamdConvertNormRun(daliamdStream_t stream, const daliamdConvertNormDesc *descs_dev, int n,
+                                                 int num_workgroups, int in_dtype, int out_dtype, int mode);
 
 /* ----------------------------------------------------------------------------------------------
  * fn.normalize: out = (in - mean) * scale / stddev + shift with mean / stddev given or computed over a contiguous group

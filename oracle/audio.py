@@ -306,3 +306,51 @@ def audio_resample(x, in_rate, out_rate, quality=50.0, out_length=None):
             w = (lookup[li] + di * (lookup[li + 1] - lookup[li])).astype(np.float32)
             out[out_block + j] = (xd[in_block_i + i0:in_block_i + i1] * w.astype(np.float64)[:, None]).sum(0)
     return out[:, 0] if squeeze else out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Typed audio resampling (dali/operators/audio/resample.cc:142-192, include/dali/core/convert.h:262-350): integer
+# samples are normalised to floats (x / max of the type), squeezed to [0, 1] when a signed source feeds an unsigned
+# result or stretched to [-1, 1] the other way round, resampled as floats and converted back with
+# clamp(round_half_away(f * max)).
+# ---------------------------------------------------------------------------------------------------------------
+_NORM_MAX = {np.dtype(np.int8): 127.0, np.dtype(np.uint8): 255.0, np.dtype(np.int16): 32767.0, np.dtype(np.uint16): 65535.0,
+             np.dtype(np.int32): 2147483647.0, np.dtype(np.uint32): 4294967295.0}
+
+
+def convert_norm_to_float(x, out_dtype):
+    """ConvertInput: x of any audio sample type -> float32, as the operator prepares it for a result of `out_dtype`."""
+    x = np.asarray(x)
+    out_dtype = np.dtype(out_dtype)
+    out_unsigned = out_dtype.kind == "u"
+    if x.dtype == np.float32:
+        f = x
+        return ((f + np.float32(1)) * np.float32(0.5)).astype(np.float32) if out_unsigned else f
+    inv = np.float32(1) / np.float32(_NORM_MAX[x.dtype])          # Out(1) / max_value<In>(), the maximum converted to float
+    f = (x.astype(np.float32) * inv).astype(np.float32)
+    if out_unsigned and x.dtype.kind == "i":
+        return ((f + np.float32(1)) * np.float32(0.5)).astype(np.float32)
+    if not out_unsigned and x.dtype.kind == "u":
+        return (f * np.float32(2) - np.float32(1)).astype(np.float32)
+    return f
+
+
+def convert_norm_from_float(f, out_dtype):
+    """ConvertSatNorm<Out>(float): clamp(round(f * max)); halves away from zero; float results pass through."""
+    out_dtype = np.dtype(out_dtype)
+    f = np.asarray(f, np.float32)
+    if out_dtype == np.float32:
+        return f
+    fmax = np.float32(_NORM_MAX[out_dtype])
+    v = (f * fmax).astype(np.float32).astype(np.float64)
+    r = np.sign(v) * np.floor(np.abs(v) + 0.5)
+    info = np.iinfo(out_dtype)
+    return np.clip(r, info.min, info.max).astype(out_dtype)
+
+
+def audio_resample_typed(x, in_rate, out_rate, quality=50.0, out_length=None, out_dtype=None):
+    x = np.asarray(x)
+    out_dtype = np.dtype(x.dtype if out_dtype is None else out_dtype)
+    f = convert_norm_to_float(x, out_dtype)
+    y = audio_resample(f, in_rate, out_rate, quality=quality, out_length=out_length)
+    return convert_norm_from_float(y, out_dtype)

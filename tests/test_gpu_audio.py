@@ -278,3 +278,50 @@ def test_audio_resample_argument_errors():
             pipe.set_outputs(fn.audio_resample(s.gpu(), **kw))
         with pytest.raises(Exception, match=msg):
             pipe.build()
+
+
+@pytest.mark.parametrize("in_t,out_t", [(np.int16, None), (np.float32, np.int16), (np.uint8, np.float32), (np.int16, np.uint16),
+                                        (np.int32, np.int8)])
+def test_audio_resample_integer_sample_types_on_the_gpu(in_t, out_t):
+    """Typed samples: normalise -> float resampler -> saturating conversion, three launches; against the oracle with
+    the bound the CPU backend's test uses."""
+    from dali_amd import fn, types
+    from dali_amd.pipeline import Pipeline
+    rng = np.random.default_rng(6)
+    t = np.arange(4000) / 16000.0
+    sig = np.stack([0.8 * np.sin(2 * np.pi * 440 * t) + rng.normal(0, 0.05, t.size), 0.3 * np.cos(2 * np.pi * 90 * t)], 1)
+
+    def as_type(x):
+        if in_t == np.float32:
+            return (x * 1.3).astype(np.float32)
+        info = np.iinfo(in_t)
+        if info.min < 0:
+            return np.clip(np.round(x * info.max), info.min, info.max).astype(in_t)
+        return np.clip(np.round((x * 0.5 + 0.5) * info.max), 0, info.max).astype(in_t)
+
+    samples = [as_type(sig), as_type(sig[::-1].copy()), as_type(sig[:1])]
+    to_dali = {np.int8: types.INT8, np.uint8: types.UINT8, np.int16: types.INT16, np.uint16: types.UINT16,
+               np.int32: types.INT32, np.uint32: types.UINT32, np.float32: types.FLOAT}
+    pipe = Pipeline(batch_size=3, num_threads=1, device_id=0, prefetch_queue_depth=1)
+    with pipe:
+        x = fn.external_source(name="x")
+        kw = {} if out_t is None else {"dtype": to_dali[out_t]}
+        pipe.set_outputs(fn.audio_resample(x.gpu(), in_rate=16000.0, out_rate=22050.0, **kw))
+    for _ in range(2):
+        pipe.feed_input("x", samples)
+        (out,) = pipe.run()
+    want_t = np.dtype(in_t if out_t is None else out_t)
+    names = pipe.executed_kernels()
+    assert "audio_resample" in names and ("audio_samples_to_float" in names) == (in_t != np.float32 or want_t.kind == "u")
+    assert ("audio_samples_from_float" in names) == (want_t != np.float32)
+    for i, s in enumerate(samples):
+        ref = A.audio_resample_typed(s, 16000.0, 22050.0, out_dtype=want_t)
+        got = out[i].as_cpu()
+        assert got.dtype == want_t and got.shape == ref.shape
+        if want_t == np.float32:
+            assert np.abs(got - ref).max() <= 1e-4
+        else:
+            full = float(np.iinfo(want_t).max)
+            d = np.abs(got.astype(np.int64) - ref.astype(np.int64))
+            assert d.max() <= max(1.0, 2e-4 * full), (d.max(), full)
+            assert (d > max(1.0, 2e-6 * full)).mean() < 0.01

@@ -56,3 +56,17 @@ def test_resample_channels_and_out_length():
     assert y.shape == (700, 2)
     for c in range(2):
         assert np.array_equal(y[:, c], A.audio_resample(x[:, c], 1000, 700, out_length=700))
+
+
+def test_typed_resampling_oracle_reproduces_the_reference_known_answers():
+    """oracle.audio.audio_resample_typed against the reference's conversion table
+    (dali/test/python/operator_1/test_audio_resample.py:119-161): constant signals, scale 1, quality 0."""
+    from tests.test_audio_resample_types import _conversion_cases, DYNAMIC_RANGES, _NP
+    cases = _conversion_cases() + [(t, v, t, v, e) for t, v, e in DYNAMIC_RANGES]
+    for src, in_values, dst, out_values, eps in cases:
+        for x, want in zip(in_values, out_values):
+            sig = np.full(64, x, _NP[src])
+            got = A.audio_resample_typed(sig, 1.0, 1.0, quality=0.0, out_dtype=_NP[dst])
+            ref = np.full(64, want, _NP[dst])
+            assert got.dtype == _NP[dst]
+            assert np.allclose(got.astype(np.float64), ref.astype(np.float64), 1e-6, eps), (src, dst, x, got[:3], want)

@@ -372,3 +372,51 @@ def test_audio_decoder_resamples_and_cpu_audio_resample_match_oracle():
             assert np.abs(got - ref).max() <= 1e-4 and np.abs(got - ref).mean() <= 1e-6
             assert np.array_equal(again.at(i), got), "audio_resample(cpu) must equal the decoder's resampling"
         assert (audio.at(1).ndim == 1) == downmix
+
+
+@pytest.mark.parametrize("in_t,out_t", [(np.int16, None), (np.int16, np.float32), (np.float32, np.int16), (np.uint8, np.int16),
+                                        (np.int16, np.uint16), (np.float32, np.uint8), (np.int32, np.int32),
+                                        (np.uint32, np.int8), (np.int8, np.uint32)])
+def test_cpu_audio_resample_integer_sample_types(in_t, out_t):
+    """Integer samples are normalised to floats around the float resampler and converted back with saturation
+    (dali/operators/audio/resample.cc:142-192, convert.h:262-350): against the oracle's restatement.  The float
+    filter sum differs from the oracle's float64 sum in the last bits, which can move an integer result by one."""
+    from oracle import audio as A
+    from dali_amd import fn, types
+    from dali_amd.pipeline import Pipeline
+    rng = np.random.default_rng(5)
+    t = np.arange(3000) / 16000.0
+    sig = 0.8 * np.sin(2 * np.pi * 440 * t) + rng.normal(0, 0.05, t.size)
+    sig2 = np.stack([sig, -0.5 * sig], 1)
+
+    def as_type(x):
+        if in_t == np.float32:
+            return (x * 1.3).astype(np.float32)                       # beyond [-1, 1]: the integer results saturate
+        info = np.iinfo(in_t)
+        if info.min < 0:
+            return np.clip(np.round(x * info.max), info.min, info.max).astype(in_t)
+        return np.clip(np.round((x * 0.5 + 0.5) * info.max), 0, info.max).astype(in_t)
+
+    samples = [as_type(sig2), as_type(sig2[::-1].copy())] if out_t is not None else [as_type(sig), as_type(-sig)]
+    to_dali = {np.int8: types.INT8, np.uint8: types.UINT8, np.int16: types.INT16, np.uint16: types.UINT16,
+               np.int32: types.INT32, np.uint32: types.UINT32, np.float32: types.FLOAT}
+    pipe = Pipeline(batch_size=2, num_threads=2, device_id=None, prefetch_queue_depth=1)
+    with pipe:
+        x = fn.external_source(name="x")
+        kw = {} if out_t is None else {"dtype": to_dali[out_t]}
+        pipe.set_outputs(fn.audio_resample(x, in_rate=16000.0, out_rate=11025.0, **kw))
+    pipe.feed_input("x", samples)
+    (out,) = pipe.run()
+    want_t = np.dtype(in_t if out_t is None else out_t)
+    for i, s in enumerate(samples):
+        ref = A.audio_resample_typed(s, 16000.0, 11025.0, out_dtype=want_t)
+        got = out.at(i)
+        assert got.dtype == want_t and got.shape == ref.shape, (got.dtype, got.shape, ref.shape)
+        if want_t == np.float32:
+            assert np.abs(got - ref).max() <= 1e-4
+        else:
+            d = np.abs(got.astype(np.int64) - ref.astype(np.int64))
+            full = float(np.iinfo(want_t).max)
+            assert d.max() <= max(1.0, 2e-4 * full), (d.max(), full)    # the reference's own cpu-vs-gpu bound, scaled
+            assert (d > max(1.0, 2e-6 * full)).mean() < 0.01
+            assert got.min() >= np.iinfo(want_t).min and got.max() <= np.iinfo(want_t).max
