@@ -67,7 +67,9 @@ static WavInfo ParseWav(const uint8_t *p, size_t n, const std::string &src) {
 class AudioDecoderCpu : public OperatorBase {
  public:
   explicit AudioDecoderCpu(const OpSpec &spec) : OperatorBase(spec), downmix_(spec.GetBool("downmix")) {
-    DALI_ENFORCE(spec.GetInt("dtype") == DALI_FLOAT, "decoders.audio: only dtype=FLOAT is supported");
+    dtype_ = (DALIDataType)spec.GetInt("dtype");
+    DALI_ENFORCE(dtype_ == DALI_FLOAT || dtype_ == DALI_INT16 || dtype_ == DALI_INT32,
+                 "Unsupported output type: ", (int)dtype_, "\nSupported types are : int16, int32, float");   // audio_decoder_op.cc
     quality_ = (float)spec.GetFloat("quality");
     DALI_ENFORCE(quality_ >= 0 && quality_ <= 100, "Resampling quality must be in [0..100] range");
   }
@@ -75,7 +77,7 @@ class AudioDecoderCpu : public OperatorBase {
     const TensorList &in = ws.Input(0);
     int n = in.num_samples();
     infos_.resize(n);
-    desc[0].type = DALI_FLOAT; desc[1].type = DALI_FLOAT;
+    desc[0].type = dtype_; desc[1].type = DALI_FLOAT;
     desc[0].shape.resize(n); desc[1].shape.assign(n, TensorShape{});
     for (int i = 0; i < n; i++) {
       std::string src = i < (int)in.source_info.size() && !in.source_info[i].empty() ? in.source_info[i] : make_string("sample #", i);
@@ -100,26 +102,57 @@ class AudioDecoderCpu : public OperatorBase {
         const WavInfo &w = infos_[i];
         bool mono_out = downmix_ || w.channels == 1;
         const bool resample = target_rate_[i] > 0 && (float)w.rate != target_rate_[i];
-        // decode (+ downmix) first, into the output or - when resampling follows - into a scratch buffer
-        // (DecodeAudio, audio_decoder_impl.cc:49-120)
-        std::vector<float> scratch;
+        // DecodeAudio<T> (audio_decoder_impl.cc:49-120): without resampling and downmixing the frames are decoded
+        // straight to the output type (libsndfile's reads: PCM16 -> int16 as stored, -> int32 shifted up by 16 bits,
+        // -> float divided by 32768; float32 files are read as floats only).  Otherwise the frames are decoded to
+        // floats, downmixed with equal weights (kernels/signal/downmixing.h:50-76: the sum of sample * (1 / channels),
+        // accumulated in channel order) and / or resampled, and the LAST of these steps converts to the output type
+        // with ConvertSatNorm.
         const int och = mono_out ? 1 : w.channels;
-        if (resample) scratch.resize((size_t)w.frames * och);
-        float *o = resample ? scratch.data() : static_cast<float *>(out.raw(i));
+        const bool downmix = w.channels > 1 && downmix_;
+        const int kout = dtype_ == DALI_INT16 ? DALIAMD_INT16 : dtype_ == DALI_INT32 ? DALIAMD_INT32 : DALIAMD_FLOAT;
+        if (dtype_ != DALI_FLOAT) DALI_ENFORCE(w.tag == 1, "decoders.audio: integer output from a float32 file is not supported");
+        if (!resample && !downmix && dtype_ != DALI_FLOAT) {
+          const int64_t count = w.frames * w.channels;
+          if (dtype_ == DALI_INT16) {
+            memcpy(out.raw(i), w.data, (size_t)count * 2);
+          } else {
+            int32_t *o32 = static_cast<int32_t *>(out.raw(i));
+            for (int64_t k = 0; k < count; k++) { int16_t sv; memcpy(&sv, w.data + k * 2, 2); o32[k] = (int32_t)((uint32_t)(int32_t)sv << 16); }
+          }
+          *static_cast<float *>(rate.raw(i)) = (float)w.rate;
+          return;
+        }
+        std::vector<float> scratch, mixed;
+        const bool float_direct = dtype_ == DALI_FLOAT && !resample;   // the float result of decode / downmix IS the output
+        if (!float_direct) scratch.resize((size_t)w.frames * och);
+        float *o = float_direct ? static_cast<float *>(out.raw(i)) : scratch.data();
+        const float weight = 1.0f / w.channels;
         for (int64_t f = 0; f < w.frames; f++) {
           float acc = 0;
           for (int c = 0; c < w.channels; c++) {
             float v;
-            if (w.tag == 1) { int16_t s; memcpy(&s, w.data + (f * w.channels + c) * 2, 2); v = s * (1.0f / 32768); }
+            if (w.tag == 1) { int16_t sv; memcpy(&sv, w.data + (f * w.channels + c) * 2, 2); v = sv * (1.0f / 32768); }
             else memcpy(&v, w.data + (f * w.channels + c) * 4, 4);
-            if (mono_out) acc += v; else o[f * w.channels + c] = v;
+            if (!mono_out) o[f * w.channels + c] = v;
+            else if (w.channels == 1) acc = v;
+            else if (c == 0) acc = v * weight;
+            else acc += v * weight;
           }
-          if (mono_out) o[f] = w.channels == 1 ? acc : acc / w.channels;
+          if (mono_out) o[f] = acc;
         }
         if (resample) {
           const int64_t out_len = out.shape(i)[0];
-          if (daliamdAudioResampleHost(scratch.data(), w.frames, och, w.rate, target_rate_[i], quality_,
-                                       static_cast<float *>(out.raw(i)), out_len) != 0)
+          std::vector<float> res;
+          float *dst = static_cast<float *>(out.raw(i));
+          if (dtype_ != DALI_FLOAT) { res.resize((size_t)out_len * och); dst = res.data(); }
+          if (daliamdAudioResampleHost(scratch.data(), w.frames, och, w.rate, target_rate_[i], quality_, dst, out_len) != 0)
+            DALI_FAIL(daliamdHostGetLastErrorMessage());
+          if (dtype_ != DALI_FLOAT &&
+              daliamdConvertNormHost(res.data(), DALIAMD_FLOAT, out.raw(i), kout, (int64_t)res.size(), 0) != 0)
+            DALI_FAIL(daliamdHostGetLastErrorMessage());
+        } else if (dtype_ != DALI_FLOAT) {   // downmix only: ConvertSatNorm<Out>(sum)
+          if (daliamdConvertNormHost(scratch.data(), DALIAMD_FLOAT, out.raw(i), kout, (int64_t)scratch.size(), 0) != 0)
             DALI_FAIL(daliamdHostGetLastErrorMessage());
         }
         *static_cast<float *>(rate.raw(i)) = resample ? target_rate_[i] : (float)w.rate;
@@ -131,6 +164,7 @@ class AudioDecoderCpu : public OperatorBase {
  private:
   bool downmix_;
   float quality_ = 50.0f;
+  DALIDataType dtype_ = DALI_FLOAT;
   std::vector<float> target_rate_;
   std::vector<WavInfo> infos_;
 };

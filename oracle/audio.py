@@ -354,3 +354,36 @@ def audio_resample_typed(x, in_rate, out_rate, quality=50.0, out_length=None, ou
     f = convert_norm_to_float(x, out_dtype)
     y = audio_resample(f, in_rate, out_rate, quality=quality, out_length=out_length)
     return convert_norm_from_float(y, out_dtype)
+
+
+def decode_audio(pcm16, rate, out_dtype=np.float32, downmix=False, sample_rate=None, quality=50.0):
+    """DecodeAudio<T> (dali/operators/decoder/audio/audio_decoder_impl.cc:49-120) for PCM16 frames [L, C]:
+    straight to T when nothing else happens (int16 as stored, int32 = value << 16, float = value / 32768); otherwise
+    floats, equal-weight downmix (kernels/signal/downmixing.h:50-76) and / or resampling, the last step converting to T."""
+    pcm16 = np.asarray(pcm16, np.int16)
+    if pcm16.ndim == 1:
+        pcm16 = pcm16[:, None]
+    out_dtype = np.dtype(out_dtype)
+    ch = pcm16.shape[1]
+    resample = sample_rate is not None and sample_rate > 0 and float(rate) != float(sample_rate)
+    mix = downmix and ch > 1
+    mono = downmix or ch == 1
+    if not resample and not mix:
+        x = pcm16[:, 0] if mono else pcm16
+        if out_dtype == np.int16:
+            return x.copy()
+        if out_dtype == np.int32:
+            return x.astype(np.int32) << 16
+        return (x.astype(np.float32) * np.float32(1.0 / 32768)).astype(np.float32)
+    f = (pcm16.astype(np.float32) * np.float32(1.0 / 32768)).astype(np.float32)
+    if mix:
+        w = np.float32(1.0) / np.float32(ch)
+        acc = (f[:, 0] * w).astype(np.float32)
+        for c in range(1, ch):
+            acc = (acc + (f[:, c] * w).astype(np.float32)).astype(np.float32)
+        f = acc
+    elif mono:
+        f = f[:, 0]
+    if resample:
+        f = audio_resample(f, float(rate), float(sample_rate), quality=quality)
+    return convert_norm_from_float(f, out_dtype)

@@ -420,3 +420,46 @@ def test_cpu_audio_resample_integer_sample_types(in_t, out_t):
             assert d.max() <= max(1.0, 2e-4 * full), (d.max(), full)    # the reference's own cpu-vs-gpu bound, scaled
             assert (d > max(1.0, 2e-6 * full)).mean() < 0.01
             assert got.min() >= np.iinfo(want_t).min and got.max() <= np.iinfo(want_t).max
+
+
+@pytest.mark.parametrize("dtype", ["INT16", "INT32", "FLOAT"])
+@pytest.mark.parametrize("downmix", [False, True])
+@pytest.mark.parametrize("resample", [False, True])
+def test_audio_decoder_output_types(dtype, downmix, resample):
+    """decoders.audio(dtype=...): DecodeAudio<T> of the reference (audio_decoder_impl.cc:49-120) - raw frames when nothing
+    else happens, otherwise float frames, equal-weight downmix, resampling, ConvertSatNorm at the end."""
+    from oracle import audio as A
+    from dali_amd import fn, types
+    from dali_amd.pipeline import Pipeline
+    rng = np.random.default_rng(9)
+    t = np.arange(5000) / 22050.0
+    a = 0.9 * np.sin(2 * np.pi * 220 * t) + rng.normal(0, 0.02, t.size)
+    frames = [np.stack([a, 0.7 * a[::-1], -0.4 * a], 1), np.stack([a[:3000], -a[:3000], 0.1 * a[:3000]], 1)]
+    pcm = [np.clip(np.round(f * 32767), -32768, 32767).astype(np.int16) for f in frames]
+    wavs = [_wav(p.astype(np.float64) / 32767.0, 22050) for p in pcm]
+    kw = dict(dtype=getattr(types, dtype), downmix=downmix)
+    if resample:
+        kw["sample_rate"] = 16000.0
+    pipe = Pipeline(batch_size=2, num_threads=2, device_id=None, prefetch_queue_depth=1)
+    with pipe:
+        enc = fn.external_source(name="wav")
+        raw, _ = fn.decoders.audio(enc, dtype=types.INT16)
+        audio, rate = fn.decoders.audio(enc, **kw)
+        pipe.set_outputs(raw, audio, rate)
+    pipe.feed_input("wav", wavs)
+    raw, audio, rate = pipe.run()
+    np_t = {"INT16": np.int16, "INT32": np.int32, "FLOAT": np.float32}[dtype]
+    for i in range(2):
+        stored = raw.at(i)                      # the file's own PCM16 frames
+        assert stored.dtype == np.int16 and stored.shape == pcm[i].shape
+        ref = A.decode_audio(stored, 22050, np_t, downmix=downmix, sample_rate=16000.0 if resample else None)
+        got = audio.at(i)
+        assert got.dtype == np_t and got.shape == ref.shape, (got.dtype, got.shape, ref.shape)
+        assert float(rate.at(i)) == (16000.0 if resample else 22050.0)
+        if not resample:
+            assert np.array_equal(got, ref)     # decode, shift and the weighted downmix are exact restatements
+        elif np_t == np.float32:
+            assert np.abs(got - ref).max() <= 1e-4
+        else:
+            full = float(np.iinfo(np_t).max)
+            assert np.abs(got.astype(np.int64) - ref.astype(np.int64)).max() <= max(1.0, 2e-4 * full)
