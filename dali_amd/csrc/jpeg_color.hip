@@ -27,7 +27,10 @@ using GOutPair = u32x2 __attribute__((address_space(1)));
 
 constexpr int kColorThreads = 256;
 constexpr int kTileW = 256;  // pixels
-constexpr int kRowsPerThread = 4;  // consecutive rows per thread: the per-image set-up is paid once for all of them
+#ifndef DALIAMD_COLOR_ROWS
+#define DALIAMD_COLOR_ROWS 8
+#endif
+constexpr int kRowsPerThread = DALIAMD_COLOR_ROWS;  // consecutive rows per thread (even): the per-image set-up is paid once for all of them
 constexpr int kTileH = 8 * kRowsPerThread;
 
 #define SCALEBITS 16
@@ -155,26 +158,30 @@ __device__ __forceinline__ int ModeOf(const daliamdJpegColorDesc &d, int c, int 
 }
 
 // ---- the common case in one piece: YCbCr 4:2:0 (luma full, both chroma planes h2v2), 8-pixel groups aligned to the
-// planes, upright output.  A thread produces 8 x 4 pixels; the four output rows y0..y0+3 (y0 even) need the chroma rows
-// r-1 .. r+2 (r = y0/2).  ALL loads of the thread (8 luma + 24 chroma dwords) are issued before the first use, so one
-// memory round trip covers four rows (the row-by-row form cannot overlap them: the stores may alias the planes).
+// planes, upright output.  A thread produces 8 x ROWS pixels; the output rows y0..y0+ROWS-1 (y0 even) need the chroma
+// rows r-1 .. r+ROWS/2 (r = y0/2).  ALL loads of the thread (2 luma + 6 chroma dwords per row pair, + 12) are issued
+// before the first use, so one memory round trip covers all its rows (the row-by-row form cannot overlap them: the
+// stores may alias the planes), and the descriptor walk in front of them is paid once per 8 x ROWS pixels.
 __device__ __forceinline__ void Chroma7(uint32_t a, uint32_t b, uint32_t c, bool first, int s[7]) {
   s[0] = first ? (int)(b & 255) : (int)(a >> 24);
   s[1] = (int)(b & 255); s[2] = (int)((b >> 8) & 255); s[3] = (int)((b >> 16) & 255); s[4] = (int)(b >> 24);
   s[5] = (int)(c & 255); s[6] = (int)((c >> 8) & 255);
 }
+template <int ROWS>
 __device__ __forceinline__ void ColorRows420(const daliamdJpegColorDesc &d, int x0, int y0, int rx1, int ry1, int out_x0,
                                              int out_y0) {
+  static_assert(ROWS >= 2 && ROWS % 2 == 0, "row pairs");
+  constexpr int CR = ROWS / 2 + 2;
   const int k0 = x0 >> 1, r = y0 >> 1;
-  uint32_t ca[2][4], cb[2][4], cc[2][4];  // [component][chroma row r-1+j]: dwords left of / at / right of k0
-  u32x2 luma[4];
+  uint32_t ca[2][CR], cb[2][CR], cc[2][CR];  // [component][chroma row r-1+j]: dwords left of / at / right of k0
+  u32x2 luma[ROWS];
 #pragma unroll
   for (int c = 0; c < 2; c++) {
     GBytes *plane = (GBytes *)d.plane[1 + c];
     const int pitch = d.pitch[1 + c], dh = d.down_h[1 + c];
     const int ka = max(k0 - 4, 0), kc = min(k0 + 4, pitch - 4);
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < CR; j++) {
       GBytes *row = plane + (size_t)ClampI(r - 1 + j, 0, dh - 1) * pitch;
       ca[c][j] = *reinterpret_cast<GWords *>(row + ka);
       cb[c][j] = *reinterpret_cast<GWords *>(row + k0);
@@ -185,16 +192,16 @@ __device__ __forceinline__ void ColorRows420(const daliamdJpegColorDesc &d, int 
     GBytes *plane = (GBytes *)d.plane[0];
     const int pitch = d.pitch[0];
 #pragma unroll
-    for (int j = 0; j < 4; j++) luma[j] = *reinterpret_cast<GPair *>(plane + (size_t)min(y0 + j, ry1 - 1) * pitch + x0);
+    for (int j = 0; j < ROWS; j++) luma[j] = *reinterpret_cast<GPair *>(plane + (size_t)min(y0 + j, ry1 - 1) * pitch + x0);
   }
   const int npx = min(8, rx1 - x0);
   const int dw1 = d.down_w[1], dw2 = d.down_w[2];
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
+  for (int j = 0; j < ROWS; j++) {
     const int y = y0 + j;
     if (y >= ry1) break;
-    // output row y0+j: nearer chroma row r + (j >> 1), further one r - 1 (j = 0), r + 1 (j = 1), r (j = 2), r + 2 (j = 3)
-    const int near = 1 + (j >> 1), far = j == 0 ? 0 : j == 1 ? 2 : j == 2 ? 1 : 3;
+    // output row y0+j: the nearer chroma row is r + (j >> 1), the further one the row above it (j even) or below (j odd)
+    const int near = 1 + (j >> 1), far = (j & 1) ? near + 1 : near - 1;
     int up[2][8];
 #pragma unroll
     for (int c = 0; c < 2; c++) {
@@ -286,7 +293,7 @@ __global__ __launch_bounds__(kColorThreads) void JpegColorKernel(const daliamdJp
   const bool wide_ok = ((d.out_pitch & 7) == 0) && ((reinterpret_cast<uintptr_t>(d.out) & 7) == 0);
   const bool wide_stores = npx == 8 && wide_ok && oc == 3;
   if (!kConvert && Fast420(d)) {  // wave-uniform: the whole image takes the fast path or none of it does
-    ColorRows420(d, x0, y_first, rx1, ry1, out_x0, out_y0);
+    ColorRows420<kRowsPerThread>(d, x0, y_first, rx1, ry1, out_x0, out_y0);
     return;
   }
 
