@@ -60,12 +60,24 @@ long g_cls[4] = {0, 0, 0, 0};
 std::vector<long> g_wmax;
 
 // mirrors DecodeRange: symbols that START in [st.pos, end)
-static int Decode(const Image &im, State &st, uint32_t end, int &nsym, int &steps) {
+// `prev` (sorted block starts (pos << 8 | c) of the lane's previous decode) makes the decode stop where it meets that
+// trajectory at a block start: *met = index into prev.  `rec` receives this decode's block starts.
+static int Decode(const Image &im, State &st, uint32_t end, int &nsym, int &steps, const std::vector<uint64_t> *prev = nullptr,
+                  std::vector<uint64_t> *rec = nullptr, long *met = nullptr) {
   int nblk = 0;
   nsym = 0; steps = 0;
   uint32_t pos = st.pos, c = st.c, z = st.z;
+  if (met) *met = -1;
   while ((int)(end - pos) > 0) {
     const bool is_dc = z == 0;
+    if (is_dc) {
+      const uint64_t key = ((uint64_t)pos << 8) | c;
+      if (prev) {
+        auto it = std::lower_bound(prev->begin(), prev->end(), key);
+        if (it != prev->end() && *it == key) { *met = it - prev->begin(); break; }
+      }
+      if (rec) rec->push_back(key);
+    }
     const uint32_t slot = (((is_dc ? im.dc_mask : im.ac_mask) >> c) & 1u) + (is_dc ? 0u : 2u);
     uint32_t peek = Peek16(im, pos);
     uint32_t used, zinc;
@@ -166,7 +178,7 @@ int main(int argc, char **argv) {
     const long nslices = (im.total_bits / 8 + slice - 1) / slice;
     const long nseg = std::max<long>(1, (nslices + seg_lanes - 1) / seg_lanes);
     for (long seg = 0; seg < nseg; seg++) {
-      struct L { uint32_t begin, end; bool active; State in, out; bool has_in; int nsym, steps; };
+      struct L { uint32_t begin, end; bool active; State in, out; bool has_in; int nsym, steps; std::vector<uint64_t> traj; };
       std::vector<L> ln(T);
       std::vector<State> state(T);
       for (int t = 0; t < T; t++) {
@@ -208,7 +220,22 @@ int main(int argc, char **argv) {
               st = w;              // whatever state the private warm-up reached at the start of the slice
               l.has_in = false;    // a guess, never accepted as the final decode
             }
-            if (st.pos < l.end) Decode(im, st, l.end, l.nsym, l.steps);
+            static const bool early = getenv("SIM_EARLY") != nullptr;
+            if (st.pos < l.end) {
+              if (early && round >= 1 && !l.traj.empty()) {
+                std::vector<uint64_t> rec;
+                long met = -1;
+                Decode(im, st, l.end, l.nsym, l.steps, &l.traj, &rec, &met);
+                if (met >= 0) {  // the rest is the previous trajectory: keep its tail and its out state
+                  rec.insert(rec.end(), l.traj.begin() + met, l.traj.end());
+                  st = old_out;
+                }
+                l.traj.swap(rec);
+              } else {
+                l.traj.clear();
+                Decode(im, st, l.end, l.nsym, l.steps, nullptr, &l.traj, nullptr);
+              }
+            }
             l.steps += warm_steps;
             l.out = st;
             if (getenv("SIM_LANES") && round >= 2 && fn.find(getenv("SIM_LANES")) != std::string::npos)
