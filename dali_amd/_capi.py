@@ -194,7 +194,7 @@ _HOST_SYMBOLS = [
     "daliamdRandomCropBatch", "daliamdCoinFlipBatch", "daliamdPhiloxAdvanceSequence",
     "daliamdPhiloxStateToString", "daliamdPhiloxStateFromString", "daliamdPhiloxGenerate",
     "daliamdCmnNormArgs", "daliamdCropAnchor", "daliamdResampleRunHost", "daliamdCmnRunHost", "daliamdAudioResampleHost",
-    "daliamdConvertNormHost",
+    "daliamdConvertNormHost", "daliamdSpectrogramHost", "daliamdMelFilterBankHost", "daliamdToDecibelsHost", "daliamdDctHost",
     "daliamdImageCachePolicyCreate", "daliamdImageCachePolicyDestroy", "daliamdImageCachePolicyOnDecode",
     "daliamdImageCachePolicyFind", "daliamdImageProbe", "daliamdImageDecodeRgb",
 ]

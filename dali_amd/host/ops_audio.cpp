@@ -230,6 +230,19 @@ class SpectrogramGpu : public OperatorBase {
     out.SetLayout("ft");
     int n = (int)descs_.size();
     if (!n) return;
+    if (ws.backend == OpType::CPU) {  // one thread-pool task per sample on the host kernel
+      for (int i = 0; i < n; i++) {
+        float *dst = static_cast<float *>(out.raw(i));
+        ws.GetThreadPool().AddWork([this, i, dst](int) {
+          const auto &d = descs_[i];
+          if (daliamdSpectrogramHost(d.in, d.length, &p_, window_.data(), d.num_windows, dst) != 0)
+            DALI_FAIL(daliamdHostGetLastErrorMessage());
+        }, descs_[i].length);
+      }
+      ws.GetThreadPool().RunAll();
+      NoteLaunch(ws, "host_spectrogram");
+      return;
+    }
     if (!window_uploaded_) {
       std::vector<float> tables((window_.size() + 3) / 4 * 4 + p_.nfft);   // window, then the FFT twiddles (16-byte aligned)
       std::copy(window_.begin(), window_.end(), tables.begin());
@@ -260,6 +273,7 @@ class SpectrogramGpu : public OperatorBase {
   DescUploader uploader_;
 };
 DALI_REGISTER_OPERATOR(Spectrogram, SpectrogramGpu, GPU);
+DALI_REGISTER_OPERATOR(Spectrogram, SpectrogramGpu, CPU);  // same class: the host kernel when run on the CPU
 
 // =============================================================================================
 // MelFilterBank
@@ -315,6 +329,23 @@ class MelFilterBankGpu : public OperatorBase {
     out.SetLayout("ft");
     int n = (int)descs_.size();
     if (!n) return;
+    if (ws.backend == OpType::CPU) {
+      if (host_weights_.empty()) {
+        host_weights_.resize((size_t)nfilter_ * nbins_);
+        KCHECK(daliamdMelFilterBankWeights(nfilter_, 2 * (nbins_ - 1), sample_rate_, freq_low_, freq_high_, normalize_, formula_,
+                                           host_weights_.data()));
+      }
+      for (int i = 0; i < n; i++) {
+        float *dst = static_cast<float *>(out.raw(i));
+        ws.GetThreadPool().AddWork([this, i, dst](int) {
+          if (daliamdMelFilterBankHost(descs_[i].in, nbins_, descs_[i].frames, host_weights_.data(), nfilter_, dst) != 0)
+            DALI_FAIL(daliamdHostGetLastErrorMessage());
+        }, descs_[i].frames);
+      }
+      ws.GetThreadPool().RunAll();
+      NoteLaunch(ws, "host_mel_filter_bank");
+      return;
+    }
     if (weights_.empty()) {
       weights_.resize((size_t)nfilter_ * nbins_);
       KCHECK(daliamdMelFilterBankWeights(nfilter_, 2 * (nbins_ - 1), sample_rate_, freq_low_, freq_high_, normalize_, formula_,
@@ -341,13 +372,14 @@ class MelFilterBankGpu : public OperatorBase {
   int nfilter_, nbins_ = 0, formula_ = 0;
   float sample_rate_, freq_low_, freq_high_;
   bool normalize_;
-  std::vector<float> weights_;
+  std::vector<float> weights_, host_weights_;
   Buffer weights_dev_;
   const int32_t *bands_dev_ = nullptr;
   std::vector<daliamdMelDesc> descs_;
   DescUploader uploader_;
 };
 DALI_REGISTER_OPERATOR(MelFilterBank, MelFilterBankGpu, GPU);
+DALI_REGISTER_OPERATOR(MelFilterBank, MelFilterBankGpu, CPU);
 
 // =============================================================================================
 // ToDecibels
@@ -386,6 +418,19 @@ class ToDecibelsGpu : public OperatorBase {
     out.SetLayout(in.layout());
     int n = in.num_samples();
     if (!n) return;
+    if (ws.backend == OpType::CPU) {
+      for (int i = 0; i < n; i++) {
+        const float *src = static_cast<const float *>(in.raw(i));
+        float *dst = static_cast<float *>(out.raw(i));
+        const int64_t size = volume(in.shape(i));
+        ws.GetThreadPool().AddWork([this, src, dst, size](int) {
+          if (daliamdToDecibelsHost(src, size, multiplier_, reference_, cutoff_, dst) != 0) DALI_FAIL(daliamdHostGetLastErrorMessage());
+        }, size);
+      }
+      ws.GetThreadPool().RunAll();
+      NoteLaunch(ws, "host_to_decibels");
+      return;
+    }
     descs_.assign(n, daliamdDecibelDesc{});
     for (int i = 0; i < n; i++) {
       descs_[i].in = static_cast<const float *>(in.raw(i));
@@ -405,6 +450,7 @@ class ToDecibelsGpu : public OperatorBase {
   DescUploader uploader_;
 };
 DALI_REGISTER_OPERATOR(ToDecibels, ToDecibelsGpu, GPU);
+DALI_REGISTER_OPERATOR(ToDecibels, ToDecibelsGpu, CPU);
 
 // =============================================================================================
 // MFCC (dali/operators/audio/mfcc/mfcc.cc:24-182): DCT along the frequency axis + liftering
@@ -475,6 +521,30 @@ class MfccGpu : public OperatorBase {
     out.SetLayout(ws.Input(0).layout());
     int n = (int)descs_.size();
     if (!n) return;
+    if (ws.backend == OpType::CPU) {
+      if (host_tables_n_in_ != n_in_) {
+        host_tables_.resize((size_t)ndct_ * n_in_ + ndct_);
+        KCHECK(daliamdDctTable(dct_type_, normalize_, n_in_, ndct_, host_tables_.data()));
+        daliamdLifterCoeffs(lifter_, ndct_, host_tables_.data() + (size_t)ndct_ * n_in_);
+        host_tables_n_in_ = n_in_;
+      }
+      for (size_t i = 0, k = 0; i < slices_.size(); i++) {
+        float *base = static_cast<float *>(out.raw((int)i));
+        for (int64_t o = 0; o < slices_[i].first; o++, k++) {
+          const float *src = descs_[k].in;
+          float *dst = base + o * ndct_ * slices_[i].second;
+          const int64_t inner = slices_[i].second;
+          ws.GetThreadPool().AddWork([this, src, dst, inner](int) {
+            const float *table = host_tables_.data();
+            if (daliamdDctHost(src, n_in_, inner, table, lifter_ != 0.0f ? table + (size_t)ndct_ * n_in_ : nullptr, ndct_, dst) != 0)
+              DALI_FAIL(daliamdHostGetLastErrorMessage());
+          }, inner);
+        }
+      }
+      ws.GetThreadPool().RunAll();
+      NoteLaunch(ws, "host_mfcc_dct");
+      return;
+    }
     if (tables_n_in_ != n_in_) {
       std::vector<float> host((size_t)ndct_ * n_in_ + ndct_);
       KCHECK(daliamdDctTable(dct_type_, normalize_, n_in_, ndct_, host.data()));
@@ -497,7 +567,8 @@ class MfccGpu : public OperatorBase {
   }
 
  private:
-  int n_mfcc_, dct_type_, axis_, n_in_ = 0, ndct_ = 0, tables_n_in_ = -1;
+  int n_mfcc_, dct_type_, axis_, n_in_ = 0, ndct_ = 0, tables_n_in_ = -1, host_tables_n_in_ = -1;
+  std::vector<float> host_tables_;
   bool normalize_;
   float lifter_;
   Buffer tables_dev_;
@@ -506,6 +577,7 @@ class MfccGpu : public OperatorBase {
   DescUploader uploader_;
 };
 DALI_REGISTER_OPERATOR(MFCC, MfccGpu, GPU);
+DALI_REGISTER_OPERATOR(MFCC, MfccGpu, CPU);
 
 // =============================================================================================
 // AudioResample (dali/operators/audio/resample.cc:24-140, resample.h:30-140)

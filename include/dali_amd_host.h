@@ -176,6 +176,22 @@ DALIAMD_HOST_API int64_t daliamdImageCachePolicyFind(void *policy, const char *k
 DALIAMD_HOST_API int daliamdAudioResampleHost(const float *in, int64_t in_length, int channels, double in_rate, double out_rate,
                                               float quality, float *out, int64_t out_length);
 
+/* The audio feature operators on the host (CPU backend of Spectrogram / MelFilterBank / ToDecibels / MFCC): the
+ * arithmetic of the device kernels of include/dali_amd_kernels.h restated for one sample
+ * (dali/kernels/signal/window/extract_windows_cpu.cc:96-145, fft/fft_cpu_impl_ffts.cc:105-111,
+ * audio/mel_scale/mel_filter_bank_cpu.cc:77-111, signal/decibel/decibel_calculator.h:25-57, signal/dct/dct_cpu.cc:75-110).
+ * spectrogram: out [nfft/2+1][num_windows] (num_windows from daliamdSpectrogramSetup); mel: weights [nfilter][nbins] from
+ * daliamdMelFilterBankWeights; decibels: reference <= 0 takes the sample's maximum; dct: in [n_in][inner] -> out
+ * [ndct][inner] with the table of daliamdDctTable and optional liftering coefficients.  Return 0 on success. */
+DALIAMD_HOST_API int daliamdSpectrogramHost(const float *in, int64_t length, const daliamdSpectrogramParams *p, const float *window,
+                                            int64_t num_windows, float *out);
+DALIAMD_HOST_API int daliamdMelFilterBankHost(const float *spec, int nbins, int64_t frames, const float *weights, int nfilter,
+                                              float *out);
+DALIAMD_HOST_API int daliamdToDecibelsHost(const float *in, int64_t size, float multiplier, float reference, float cutoff_db,
+                                           float *out);
+DALIAMD_HOST_API int daliamdDctHost(const float *in, int n_in, int64_t inner, const float *table, const float *lifter, int ndct,
+                                    float *out);
+
 /* Normalised sample-type conversion on the host, the arithmetic of daliamdConvertNormRun (daliamdDType_t codes, mode 0 / 1 / 2
  * as there): the typed inputs and outputs of audio_resample(device="cpu") (dali/operators/audio/resample.cc:142-192,
  * include/dali/core/convert.h:262-350).  Returns 0 on success. */

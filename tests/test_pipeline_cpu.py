@@ -463,3 +463,51 @@ def test_audio_decoder_output_types(dtype, downmix, resample):
         else:
             full = float(np.iinfo(np_t).max)
             assert np.abs(got.astype(np.int64) - ref.astype(np.int64)).max() <= max(1.0, 2e-4 * full)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(nfft=512, wl=400, step=160, nfilter=64, formula="htk"),
+                                dict(power=1, center=False, nfilter=128), dict(reflect=False, normalize=False, nfilter=23)])
+def test_audio_feature_operators_on_the_cpu_backend(kw):
+    """configs[3] on the CPU backend: decoders.audio -> spectrogram -> mel_filter_bank -> to_decibels (+ mfcc) on the host
+    kernels against the oracle: the spectrogram within 1e-4 of the largest bin (the reference's own FFT tolerance,
+    test_spectrogram.py:188) and tighter on the loud bins, the mel product exactly (same order of float operations) on
+    the operator's own spectrogram, decibels and MFCC to float rounding."""
+    from oracle import audio as A
+    from dali_amd import fn
+    from dali_amd.pipeline import Pipeline
+    rng = np.random.default_rng(21)
+    sigs = []
+    for secs in (0.4, 1.1, 0.1):
+        t = np.arange(int(16000 * secs)) / 16000.0
+        sigs.append((0.5 * np.sin(2 * np.pi * (300 + 900 * t) * t) + rng.normal(0, 0.05, t.size)).astype(np.float64))
+    wavs = [_wav(s, 16000) for s in sigs]
+    pipe = Pipeline(batch_size=len(wavs), num_threads=3, device_id=None, prefetch_queue_depth=1)
+    with pipe:
+        enc = fn.external_source(name="wav")
+        audio, _ = fn.decoders.audio(enc, downmix=True)
+        spec = fn.spectrogram(audio, nfft=kw.get("nfft", 1024), window_length=kw.get("wl", 1024), window_step=kw.get("step", 256),
+                              power=kw.get("power", 2), center_windows=kw.get("center", True), reflect_padding=kw.get("reflect", True))
+        mel = fn.mel_filter_bank(spec, nfilter=kw.get("nfilter", 80), sample_rate=16000.0, freq_high=8000.0,
+                                 mel_formula=kw.get("formula", "slaney"), normalize=kw.get("normalize", True))
+        db = fn.to_decibels(mel, multiplier=10.0, cutoff_db=-80.0)
+        mfcc = fn.mfcc(db, n_mfcc=13, lifter=22.0)
+        pipe.set_outputs(audio, spec, mel, db, mfcc)
+    pipe.feed_input("wav", wavs)
+    audio, spec, mel, db, mfcc = pipe.run()
+    assert pipe.executed_kernels() == ["host_spectrogram", "host_mel_filter_bank", "host_to_decibels", "host_mfcc_dct"]
+    for i in range(len(wavs)):
+        x = audio.at(i)
+        ref_spec = A.spectrogram(x, nfft=kw.get("nfft", 1024), window_length=kw.get("wl", 1024), window_step=kw.get("step", 256),
+                                 power=kw.get("power", 2), center_windows=kw.get("center", True),
+                                 reflect_padding=kw.get("reflect", True))
+        got_spec = spec.at(i)
+        assert got_spec.shape == ref_spec.shape, (got_spec.shape, ref_spec.shape)
+        assert np.abs(got_spec - ref_spec).max() <= 1e-6 * max(1.0, ref_spec.max())
+        ref_mel = A.mel_filter_bank(got_spec, nfilter=kw.get("nfilter", 80), sample_rate=16000.0, freq_high=8000.0,
+                                    mel_formula=kw.get("formula", "slaney"), normalize=kw.get("normalize", True))
+        assert np.array_equal(mel.at(i), ref_mel)
+        ref_db = A.to_decibels(mel.at(i), multiplier=10.0, cutoff_db=-80.0)
+        assert np.abs(db.at(i) - ref_db).max() <= 1e-4
+        ref_mfcc = A.mfcc(db.at(i), n_mfcc=13, lifter=22.0)
+        assert mfcc.at(i).shape == ref_mfcc.shape
+        assert np.abs(mfcc.at(i) - ref_mfcc).max() <= 1e-5 * max(1.0, np.abs(ref_mfcc).max())
