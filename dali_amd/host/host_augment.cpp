@@ -1,0 +1,157 @@
+// Host kernels of the heavy-augmentation operators (configs[2]) for the CPU backend: warp_affine, gaussian_blur, colour
+// twist / erase.  Product code, one sample per call, driven by the same descriptors as the device kernels
+// (include/dali_amd_kernels.h); the arithmetic of the reference's CPU kernels operation by operation:
+//   warp    dali/kernels/imgproc/warp_cpu.h:143-178 (source coordinates advanced incrementally, re-anchored every
+//           256 pixels), sampler.h:60-175 (nearest, border), :258-338 (bilinear: s0 + (s1 - s0) * qy)
+//   blur    dali/kernels/imgproc/convolution/convolution_cpu.h:241-340, separable_convolution_cpu.h:91-110 (W pass
+//           then H pass, float intermediate, reflect-101 border, taps accumulated in order)
+//   twist   dali/kernels/imgproc/pointwise/linear_transformation_cpu.h:57-77 (M * px + offset, ConvertSat)
+//   erase   dali/kernels/erase/erase_cpu.h (copy + fill of the clipped regions)
+// Built with -ffp-contract=off like the rest of the host library: multiply and add are rounded separately.
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "dali_amd_host.h"
+#include "host_common.h"
+
+using daliamd_host::Fail;
+
+namespace {
+
+inline uint8_t SatU8(float v) {   // ConvertSat<uint8_t>(float): round half away from zero, clamp
+  const float r = std::round(v);
+  if (!(r > 0)) return 0;
+  if (r > 255) return 255;
+  return (uint8_t)r;
+}
+
+inline int Reflect101(int idx, int size) {
+  if (size < 2) return size - 1;
+  for (;;) {
+    if (idx < 0) idx = -idx;
+    else if (idx >= size) idx = 2 * size - 2 - idx;
+    else break;
+  }
+  return idx;
+}
+
+}  // namespace
+
+extern "C" int daliamdWarpAffineHost(const daliamdWarpAffineDesc *d) {
+  if (!d || !d->in || !d->out || d->in_h <= 0 || d->in_w <= 0 || d->channels < 1 || d->channels > 4)
+    return Fail("daliamdWarpAffineHost: invalid descriptor");
+  if (d->interp != DALIAMD_INTERP_NN && d->interp != DALIAMD_INTERP_LINEAR) return Fail("daliamdWarpAffineHost: unsupported interpolation");
+  const int H = d->in_h, W = d->in_w, C = d->channels;
+  const float *m = d->matrix;
+  float border[4];
+  for (int c = 0; c < 4; c++) border[c] = (float)SatU8(d->fill[c]);   // ConvertSat<In>(border value)
+  auto fetch = [&](int x, int y, int c) -> float {
+    if ((unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H) return d->in[(size_t)y * d->in_pitch + (size_t)x * C + c];
+    if (!d->border_clamp) return border[c];
+    x = x < 0 ? 0 : x > W - 1 ? W - 1 : x;
+    y = y < 0 ? 0 : y > H - 1 ? H - 1 : y;
+    return d->in[(size_t)y * d->in_pitch + (size_t)x * C + c];
+  };
+  const float dsdx_x = m[0], dsdx_y = m[3];
+  const int tile_w = 256;
+  const float dtx = tile_w * dsdx_x, dty = tile_w * dsdx_y;
+  for (int y = 0; y < d->out_h; y++) {
+    const float vx = 0 + 0.5f, vy = y + 0.5f;   // map_coords: the affine map of the pixel centre
+    float tx = m[2]; tx += m[0] * vx; tx += m[1] * vy;
+    float ty = m[5]; ty += m[3] * vx; ty += m[4] * vy;
+    for (int x_tile = 0; x_tile < d->out_w; x_tile += tile_w, tx += dtx, ty += dty) {
+      const int x_end = x_tile + tile_w < d->out_w ? x_tile + tile_w : d->out_w;
+      float sx = tx, sy = ty;
+      for (int x = x_tile; x < x_end; x++, sx += dsdx_x, sy += dsdx_y) {
+        uint8_t *o = d->out + (size_t)y * d->out_pitch + (size_t)x * C;
+        if (d->interp == DALIAMD_INTERP_NN) {
+          const int ix = (int)std::floor(sx), iy = (int)std::floor(sy);
+          for (int c = 0; c < C; c++) o[c] = (uint8_t)fetch(ix, iy, c);
+        } else {
+          const float fx = sx - 0.5f, fy = sy - 0.5f;
+          const int x0 = (int)std::floor(fx), y0 = (int)std::floor(fy);
+          const float qx = fx - x0, px = 1 - qx, qy = fy - y0;
+          for (int c = 0; c < C; c++) {
+            const float s00 = fetch(x0, y0, c), s01 = fetch(x0 + 1, y0, c), s10 = fetch(x0, y0 + 1, c), s11 = fetch(x0 + 1, y0 + 1, c);
+            const float s0 = s00 * px + s01 * qx;
+            const float s1 = s10 * px + s11 * qx;
+            o[c] = SatU8(s0 + (s1 - s0) * qy);
+          }
+        }
+      }
+    }
+  }
+  return 0;
+}
+
+extern "C" int daliamdGaussianBlurHost(const daliamdGaussianBlurDesc *d) {
+  if (!d || !d->in || !d->out || d->h <= 0 || d->w <= 0 || d->channels < 1) return Fail("daliamdGaussianBlurHost: invalid descriptor");
+  if (d->size_x < 1 || d->size_y < 1 || d->size_x > DALIAMD_MAX_BLUR_WINDOW || d->size_y > DALIAMD_MAX_BLUR_WINDOW ||
+      !(d->size_x & 1) || !(d->size_y & 1))
+    return Fail("daliamdGaussianBlurHost: window sizes must be odd and at most %d", DALIAMD_MAX_BLUR_WINDOW);
+  const int H = d->h, W = d->w, C = d->channels, rx = (d->size_x - 1) / 2, ry = (d->size_y - 1) / 2;
+  std::vector<float> tmp((size_t)H * W * C);
+  std::vector<int> sxs((size_t)d->size_x);
+  for (int y = 0; y < H; y++) {
+    const uint8_t *row = d->in + (size_t)y * d->in_pitch;
+    for (int x = 0; x < W; x++) {
+      for (int k = 0; k < d->size_x; k++) sxs[k] = Reflect101(x - rx + k, W) * C;
+      for (int c = 0; c < C; c++) {
+        float acc = 0;
+        for (int k = 0; k < d->size_x; k++) acc += row[sxs[k] + c] * d->window_x[k];
+        tmp[((size_t)y * W + x) * C + c] = acc;
+      }
+    }
+  }
+  std::vector<const float *> rows((size_t)d->size_y);
+  const size_t rowlen = (size_t)W * C;
+  for (int y = 0; y < H; y++) {
+    for (int k = 0; k < d->size_y; k++) rows[k] = tmp.data() + (size_t)Reflect101(y - ry + k, H) * rowlen;
+    uint8_t *o = d->out + (size_t)y * d->out_pitch;
+    for (size_t e = 0; e < rowlen; e++) {
+      float acc = 0;
+      for (int k = 0; k < d->size_y; k++) acc += d->window_y[k] * rows[k][e];
+      o[e] = SatU8(acc);
+    }
+  }
+  return 0;
+}
+
+extern "C" int daliamdPointwiseHost(const daliamdPointwiseDesc *d) {
+  if (!d || !d->in || !d->out || d->h <= 0 || d->w <= 0 || d->channels < 1 || d->channels > 4)
+    return Fail("daliamdPointwiseHost: invalid descriptor");
+  if (d->transform && d->channels != 3) return Fail("daliamdPointwiseHost: the colour transformation needs 3 channels");
+  if (d->num_regions < 0 || d->num_regions > DALIAMD_MAX_ERASE_REGIONS) return Fail("daliamdPointwiseHost: too many regions");
+  const int C = d->channels;
+  for (int y = 0; y < d->h; y++) {
+    const uint8_t *src = d->in + (size_t)y * d->in_pitch;
+    uint8_t *dst = d->out + (size_t)y * d->out_pitch;
+    if (!d->transform) {
+      if (dst != src) std::memmove(dst, src, (size_t)d->w * C);
+      continue;
+    }
+    for (int x = 0; x < d->w; x++) {
+      const float v0 = src[3 * x], v1 = src[3 * x + 1], v2 = src[3 * x + 2];
+      for (int i = 0; i < 3; i++) {
+        float s = d->matrix[3 * i] * v0;
+        s += d->matrix[3 * i + 1] * v1;
+        s += d->matrix[3 * i + 2] * v2;
+        dst[3 * x + i] = SatU8(s + d->offset[i]);
+      }
+    }
+  }
+  uint8_t fill[4];
+  for (int c = 0; c < 4; c++) fill[c] = SatU8(d->fill[c]);
+  for (int r = 0; r < d->num_regions; r++) {
+    const int y0 = d->region[r][0] < 0 ? 0 : d->region[r][0], x0 = d->region[r][1] < 0 ? 0 : d->region[r][1];
+    const int y1 = d->region[r][2] > d->h ? d->h : d->region[r][2], x1 = d->region[r][3] > d->w ? d->w : d->region[r][3];
+    for (int y = y0; y < y1; y++) {
+      uint8_t *dst = d->out + (size_t)y * d->out_pitch;
+      for (int x = x0; x < x1; x++)
+        for (int c = 0; c < C; c++) dst[(size_t)x * C + c] = fill[c];
+    }
+  }
+  return 0;
+}

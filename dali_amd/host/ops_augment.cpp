@@ -7,6 +7,7 @@
 
 #include "ops.h"
 #include "pipeline.h"
+#include "dali_amd_host.h"
 
 namespace daliamd_host {
 
@@ -102,6 +103,15 @@ class WarpAffineGpu : public OperatorBase {
     int n = (int)descs_.size();
     if (!n) return;
     for (int i = 0; i < n; i++) descs_[i].out = static_cast<uint8_t *>(out.raw(i));
+    if (ws.backend == OpType::CPU) {  // one thread-pool task per sample on the host kernel
+      for (int i = 0; i < n; i++)
+        ws.GetThreadPool().AddWork([this, i](int) {
+          if (daliamdWarpAffineHost(&descs_[i]) != 0) DALI_FAIL(daliamdHostGetLastErrorMessage());
+        }, (int64_t)descs_[i].out_h * descs_[i].out_w);
+      ws.GetThreadPool().RunAll();
+      NoteLaunch(ws, "host_warp_affine");
+      return;
+    }
     int nwg = 0;
     KCHECK(daliamdWarpAffineSetup(descs_.data(), n, &nwg));
     auto *dev = static_cast<const daliamdWarpAffineDesc *>(uploader_.Upload(descs_.data(), n * sizeof(descs_[0]), ws.stream, ws.ring + 1));
@@ -117,6 +127,7 @@ class WarpAffineGpu : public OperatorBase {
   DescUploader uploader_;
 };
 DALI_REGISTER_OPERATOR(WarpAffine, WarpAffineGpu, GPU);
+DALI_REGISTER_OPERATOR(WarpAffine, WarpAffineGpu, CPU);  // same class: the host kernel when run on the CPU
 
 // =============================================================================================
 DALI_SCHEMA(GaussianBlur)
@@ -169,6 +180,16 @@ class GaussianBlurGpu : public OperatorBase {
     int n = (int)descs_.size();
     if (!n) return;
     for (int i = 0; i < n; i++) descs_[i].out = static_cast<uint8_t *>(out.raw(i));
+    if (ws.backend == OpType::CPU) {
+      for (int i = 0; i < n; i++) {
+        ws.GetThreadPool().AddWork([this, i](int) {
+          if (daliamdGaussianBlurHost(&descs_[i]) != 0) DALI_FAIL(daliamdHostGetLastErrorMessage());
+        }, (int64_t)descs_[i].h * descs_[i].w);
+      }
+      ws.GetThreadPool().RunAll();
+      NoteLaunch(ws, "host_gaussian_blur");
+      return;
+    }
     int nwg = 0, lds = 0;
     KCHECK(daliamdGaussianBlurSetup(descs_.data(), n, &nwg, &lds));
     auto *dev = static_cast<const daliamdGaussianBlurDesc *>(uploader_.Upload(descs_.data(), n * sizeof(descs_[0]), ws.stream, ws.ring + 1));
@@ -181,6 +202,7 @@ class GaussianBlurGpu : public OperatorBase {
   DescUploader uploader_;
 };
 DALI_REGISTER_OPERATOR(GaussianBlur, GaussianBlurGpu, GPU);
+DALI_REGISTER_OPERATOR(GaussianBlur, GaussianBlurGpu, CPU);
 
 // =============================================================================================
 // ColorTwist and Erase share the pointwise kernel
@@ -197,6 +219,15 @@ static void LaunchPointwise(Workspace &ws, DescUploader &up, std::vector<daliamd
   int n = (int)descs.size();
   if (!n) return;
   for (int i = 0; i < n; i++) descs[i].out = static_cast<uint8_t *>(out.raw(i));
+  if (ws.backend == OpType::CPU) {
+    for (int i = 0; i < n; i++)
+      ws.GetThreadPool().AddWork([&descs, i](int) {
+        if (daliamdPointwiseHost(&descs[i]) != 0) DALI_FAIL(daliamdHostGetLastErrorMessage());
+      }, (int64_t)descs[i].h * descs[i].w);
+    ws.GetThreadPool().RunAll();
+    NoteLaunch(ws, (std::string("host_") + what).c_str());
+    return;
+  }
   int nwg = 0;
   KCHECK(daliamdPointwiseSetup(descs.data(), n, &nwg));
   auto *dev = static_cast<const daliamdPointwiseDesc *>(up.Upload(descs.data(), n * sizeof(descs[0]), ws.stream, ws.ring + 1));
@@ -264,6 +295,7 @@ class ColorTwistGpu : public OperatorBase {
   DescUploader uploader_;
 };
 DALI_REGISTER_OPERATOR(ColorTwist, ColorTwistGpu, GPU);
+DALI_REGISTER_OPERATOR(ColorTwist, ColorTwistGpu, CPU);
 
 DALI_SCHEMA(Erase)
     .DocStr("Erases one or more regions from the input tensors.\n\nThe region is specified by ``anchor`` (starting point) and "
@@ -368,6 +400,7 @@ class EraseGpu : public OperatorBase {
   DescUploader uploader_;
 };
 DALI_REGISTER_OPERATOR(Erase, EraseGpu, GPU);
+DALI_REGISTER_OPERATOR(Erase, EraseGpu, CPU);
 
 void TryEnablePointwiseFusion(OperatorBase *producer, OperatorBase *consumer) {
   auto *twist = dynamic_cast<ColorTwistGpu *>(producer);

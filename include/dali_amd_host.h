@@ -176,6 +176,14 @@ DALIAMD_HOST_API int64_t daliamdImageCachePolicyFind(void *policy, const char *k
 DALIAMD_HOST_API int daliamdAudioResampleHost(const float *in, int64_t in_length, int channels, double in_rate, double out_rate,
                                               float quality, float *out, int64_t out_length);
 
+/* The heavy-augmentation operators on the host (CPU backend of WarpAffine / GaussianBlur / ColorTwist / Erase): one
+ * sample per call, the descriptor of the device kernel with host pointers (the wg_* / tile_* fields are ignored), the
+ * same arithmetic (dali/kernels/imgproc/warp_cpu.h:143-178, sampler.h:258-338, convolution/convolution_cpu.h:241-340,
+ * pointwise/linear_transformation_cpu.h:57-77, erase/erase_cpu.h).  Return 0 on success. */
+DALIAMD_HOST_API int daliamdWarpAffineHost(const daliamdWarpAffineDesc *desc);
+DALIAMD_HOST_API int daliamdGaussianBlurHost(const daliamdGaussianBlurDesc *desc);
+DALIAMD_HOST_API int daliamdPointwiseHost(const daliamdPointwiseDesc *desc);
+
 /* The audio feature operators on the host (CPU backend of Spectrogram / MelFilterBank / ToDecibels / MFCC): the
  * arithmetic of the device kernels of include/dali_amd_kernels.h restated for one sample
  * (dali/kernels/signal/window/extract_windows_cpu.cc:96-145, fft/fft_cpu_impl_ffts.cc:105-111,

@@ -154,7 +154,7 @@ def test_graph_validation_errors(dataset):
         with pytest.raises(TypeError, match="unexpected keyword"):
             fn.random.coin_flip(probabilty=0.3)
         with pytest.raises(RuntimeError, match="not available for device \"cpu\""):
-            fn.gaussian_blur(d, sigma=1.0)             # no silent CPU fallback for device-only operators
+            fn.normalize(d)                            # no silent CPU fallback for device-only operators
         with pytest.raises(ValueError, match="expects between"):
             fn.random_resized_crop(size=[8, 8], device="gpu")
         with pytest.raises(ValueError, match="cannot take a GPU input"):
@@ -511,3 +511,56 @@ def test_audio_feature_operators_on_the_cpu_backend(kw):
         ref_mfcc = A.mfcc(db.at(i), n_mfcc=13, lifter=22.0)
         assert mfcc.at(i).shape == ref_mfcc.shape
         assert np.abs(mfcc.at(i) - ref_mfcc).max() <= 1e-5 * max(1.0, np.abs(ref_mfcc).max())
+
+
+@pytest.mark.parametrize("interp,fill", [("INTERP_LINEAR", 0.0), ("INTERP_NN", 17.0), ("INTERP_LINEAR", None)])
+def test_heavy_augmentation_operators_on_the_cpu_backend(interp, fill):
+    """configs[2] on the CPU backend: warp_affine + gaussian_blur + color_twist + erase through the host kernels, compared
+    with the oracle chain bit for bit (constant border, clamp border, nearest and bilinear sampling, random parameters)."""
+    from oracle import oracle as O
+    from tests.util import synth_image
+    from dali_amd import fn, types
+    from dali_amd.pipeline import Pipeline
+    rng = np.random.default_rng(15)
+    bs = 4
+    imgs = [synth_image(rng, h, w) for (h, w) in [(200, 300), (257, 190), (64, 520), (128, 128)]]
+    mats = []
+    for im in imgs:
+        t, s = np.deg2rad(rng.uniform(-30, 30)), rng.uniform(0.8, 1.2)
+        c, sn = np.cos(t) / s, np.sin(t) / s
+        cx, cy = im.shape[1] / 2, im.shape[0] / 2
+        m = np.array([[c, -sn, 0], [sn, c, 0]], np.float32)
+        m[0, 2] = cx - m[0, 0] * cx - m[0, 1] * cy
+        m[1, 2] = cy - m[1, 0] * cx - m[1, 1] * cy
+        mats.append(m.reshape(6))
+    pipe = Pipeline(batch_size=bs, num_threads=3, device_id=None, seed=17, prefetch_queue_depth=1)
+    with pipe:
+        x = fn.external_source(name="images", layout="HWC")
+        m = fn.external_source(name="matrix")
+        hue = fn.random.uniform(range=[-30.0, 30.0], seed=1)
+        sat = fn.random.uniform(range=[0.7, 1.3], seed=2)
+        bri = fn.random.uniform(range=[0.8, 1.2], seed=3)
+        con = fn.random.uniform(range=[0.8, 1.2], seed=4)
+        anchor = fn.random.uniform(range=[0.0, 0.7], shape=[2], seed=5)
+        shape = fn.random.uniform(range=[0.1, 0.3], shape=[2], seed=6)
+        kw = {} if fill is None else {"fill_value": fill}
+        y = fn.warp_affine(x, matrix=m, interp_type=getattr(types, interp), **kw)
+        y = fn.gaussian_blur(y, sigma=2.0)
+        y = fn.color_twist(y, hue=hue, saturation=sat, brightness=bri, contrast=con)
+        y = fn.erase(y, anchor=anchor, shape=shape, normalized=True, fill_value=3.0)
+        pipe.set_outputs(y, hue, sat, bri, con, anchor, shape)
+    pipe.build()
+    pipe.feed_input("images", imgs, layout="HWC")
+    pipe.feed_input("matrix", mats)
+    out, hue, sat, bri, con, anchor, shape = pipe.run()
+    assert pipe.executed_kernels() == ["host_warp_affine", "host_gaussian_blur", "host_color_twist", "host_erase"]
+    win = O.gaussian_window(2.0)
+    for i in range(bs):
+        ref = O.warp_affine_u8(imgs[i], mats[i], interp=1 if interp == "INTERP_LINEAR" else 0, fill=fill)
+        ref = O.gaussian_blur_u8(ref, win)
+        mm, off = O.color_twist_matrix(float(hue.at(i)), float(sat.at(i)), 1.0, float(bri.at(i)), float(con.at(i)))
+        ref = O.linear_transform_u8(ref, mm, off)
+        ref = O.erase_u8(ref, anchor.at(i), shape.at(i), fill=(3.0,), normalized_anchor=True, normalized_shape=True)
+        got = out.at(i)
+        assert got.shape == ref.shape
+        assert np.array_equal(got, ref), f"sample {i}: max diff {np.abs(got.astype(int) - ref).max()}"
