@@ -195,7 +195,7 @@ _HOST_SYMBOLS = [
     "daliamdPhiloxStateToString", "daliamdPhiloxStateFromString", "daliamdPhiloxGenerate",
     "daliamdCmnNormArgs", "daliamdCropAnchor", "daliamdResampleRunHost", "daliamdCmnRunHost", "daliamdAudioResampleHost",
     "daliamdConvertNormHost", "daliamdSpectrogramHost", "daliamdMelFilterBankHost", "daliamdToDecibelsHost", "daliamdDctHost",
-    "daliamdWarpAffineHost", "daliamdGaussianBlurHost", "daliamdPointwiseHost",
+    "daliamdWarpAffineHost", "daliamdGaussianBlurHost", "daliamdPointwiseHost", "daliamdNormalizeHost",
     "daliamdImageCachePolicyCreate", "daliamdImageCachePolicyDestroy", "daliamdImageCachePolicyOnDecode",
     "daliamdImageCachePolicyFind", "daliamdImageProbe", "daliamdImageDecodeRgb",
 ]

@@ -4,9 +4,11 @@
 // The reductions and the element-wise pass run in libdali_amd_kernels.so (csrc/normalize.hip).
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 
 #include "ops.h"
 #include "pipeline.h"
+#include "dali_amd_host.h"
 
 namespace daliamd_host {
 
@@ -56,7 +58,7 @@ class NormalizeGpu : public OperatorBase {
     has_axes_ = spec.ArgumentDefined("axes");
     has_axis_names_ = spec.ArgumentDefined("axis_names");
     DALI_ENFORCE(!(has_axes_ && has_axis_names_), "Normalize: Arguments `axes` and `axis_names` are mutually exclusive");
-    ring_ = (int)spec.GetInt("gpu_prefetch_queue_depth") + 1;
+    ring_ = spec.TryArg("gpu_prefetch_queue_depth") ? (int)spec.GetInt("gpu_prefetch_queue_depth") + 1 : 1;  // (not given to CPU operators)
   }
 
   bool SetupImpl(std::vector<OutputDesc> &desc, const Workspace &ws) override {
@@ -134,6 +136,40 @@ class NormalizeGpu : public OperatorBase {
       }
     }
     if (batch_) bins_total = descs_[0].outer * descs_[0].inner;
+    if (ws.backend == OpType::CPU) {  // host kernel: one task per sample, or one for the batch when it shares the statistics
+      DALI_ENFORCE(out_type_ != DALI_FLOAT16, "Normalize (cpu): float16 output is not supported");
+      float scalar_inv_std_cpu = 1;
+      if (has_stddev_)
+        scalar_inv_std_cpu = epsilon_ ? scale_ / std::sqrt(stddev_value_ * stddev_value_ + epsilon_) : scale_ / stddev_value_;
+      host_samples_.assign(n, daliamdNormalizeHostSample{});
+      host_dense_.resize(n);
+      for (int i = 0; i < n; i++) {
+        const TensorShape &sh = in.shape(i);
+        const void *src = in.raw(i);
+        if (dense_off[i] != (size_t)-1) {  // row-padded image: densify
+          const size_t row = (size_t)sh[1] * sh[2] * TypeSize(in.type());
+          host_dense_[i].resize(row * (size_t)sh[0]);
+          for (int64_t y = 0; y < sh[0]; y++)
+            std::memcpy(host_dense_[i].data() + y * row, static_cast<const uint8_t *>(src) + y * (size_t)in.row_pitch(i), row);
+          src = host_dense_[i].data();
+        }
+        host_samples_[i] = {src, out.raw(i), descs_[i].outer, descs_[i].reduced, descs_[i].inner};
+      }
+      const int kin = ToKernelDType(in.type()), kout = ToKernelDType(out_type_);
+      auto run = [this, kin, kout, scalar_inv_std_cpu](int first, int count) {
+        if (daliamdNormalizeHost(host_samples_.data() + first, count, kin, kout, has_mean_, mean_value_, has_stddev_, scalar_inv_std_cpu,
+                                 ddof_, epsilon_, scale_, shift_) != 0)
+          DALI_FAIL(daliamdHostGetLastErrorMessage());
+      };
+      if (batch_) {
+        run(0, n);
+      } else {
+        for (int i = 0; i < n; i++) ws.GetThreadPool().AddWork([run, i](int) { run(i, 1); }, volume(in.shape(i)));
+        ws.GetThreadPool().RunAll();
+      }
+      NoteLaunch(ws, "host_normalize");
+      return;
+    }
     if (scratch_.empty())
       for (int k = 0; k < ring_; k++) {
         scratch_.emplace_back(std::make_unique<Buffer>(StorageDevice::GPU));
@@ -187,9 +223,12 @@ class NormalizeGpu : public OperatorBase {
   int ddof_, ring_;
   DALIDataType out_type_;
   std::vector<daliamdNormalizeDesc> descs_;
+  std::vector<daliamdNormalizeHostSample> host_samples_;
+  std::vector<std::vector<uint8_t>> host_dense_;
   std::vector<std::unique_ptr<Buffer>> scratch_, dense_;
   DescUploader uploader_;
 };
 DALI_REGISTER_OPERATOR(Normalize, NormalizeGpu, GPU);
+DALI_REGISTER_OPERATOR(Normalize, NormalizeGpu, CPU);  // same class: the host kernel when run on the CPU
 
 }  // namespace daliamd_host

@@ -176,6 +176,20 @@ DALIAMD_HOST_API int64_t daliamdImageCachePolicyFind(void *policy, const char *k
 DALIAMD_HOST_API int daliamdAudioResampleHost(const float *in, int64_t in_length, int channels, double in_rate, double out_rate,
                                               float quality, float *out, int64_t out_length);
 
+/* fn.normalize on the host (CPU backend of Normalize; the arithmetic of daliamdNormalizeRun:
+ * dali/operators/math/normalize/normalize.cc:209-296, normalize_utils.h:133-220).  A sample is viewed as
+ * [outer][reduced][inner], dense; the `n` samples of a call share their statistics (1, or the batch for batch=True).
+ * in: uint8 or float; out: float, uint8 or int8 (daliamdDType_t).  has_stddev: scalar_inv_std = scale / stddev as the
+ * operator folds it.  Returns 0 on success. */
+typedef struct {
+  const void *in;
+  void *out;
+  int64_t outer, reduced, inner;
+} daliamdNormalizeHostSample;
+DALIAMD_HOST_API int daliamdNormalizeHost(const daliamdNormalizeHostSample *samples, int n, int in_dtype, int out_dtype, int has_mean,
+                                          float scalar_mean, int has_stddev, float scalar_inv_std, int ddof, float epsilon,
+                                          float scale, float shift);
+
 /* The heavy-augmentation operators on the host (CPU backend of WarpAffine / GaussianBlur / ColorTwist / Erase): one
  * sample per call, the descriptor of the device kernel with host pointers (the wg_* / tile_* fields are ignored), the
  * same arithmetic (dali/kernels/imgproc/warp_cpu.h:143-178, sampler.h:258-338, convolution/convolution_cpu.h:241-340,

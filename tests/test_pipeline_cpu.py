@@ -154,7 +154,7 @@ def test_graph_validation_errors(dataset):
         with pytest.raises(TypeError, match="unexpected keyword"):
             fn.random.coin_flip(probabilty=0.3)
         with pytest.raises(RuntimeError, match="not available for device \"cpu\""):
-            fn.normalize(d)                            # no silent CPU fallback for device-only operators
+            fn.decoders.image_crop(d, crop=[8, 8])     # no silent CPU fallback for an operator registered for "mixed" only
         with pytest.raises(ValueError, match="expects between"):
             fn.random_resized_crop(size=[8, 8], device="gpu")
         with pytest.raises(ValueError, match="cannot take a GPU input"):
