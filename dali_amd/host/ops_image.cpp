@@ -950,6 +950,117 @@ class ImageDecoderSliceMixed : public ImageDecoderMixed {
   bool named_;
   std::vector<int> axes_;
 };
+// ---- the region-of-interest decoders with device="cpu" ----------------------------------------------------------------
+// ImageDecoder<CPUBackend> with a CropWindowGenerator (roi_image_decoder.h:47-96, host_decoder.cc:35-48): the window
+// arithmetic IS the mixed operator's (its ComputeRois, its random-crop generator state and checkpoint); the decode is the
+// host decoder of decoders.image(device="cpu"), the window copied out of the upright image.  Nothing of the device path
+// of the base class runs: its buffers are allocated on first use only.
+template <class MixedRoiDecoder>
+class RoiDecoderCpu : public MixedRoiDecoder {
+ public:
+  explicit RoiDecoderCpu(const OpSpec &spec) : MixedRoiDecoder(WithQueueDepth(spec)) {
+    const int64_t ot = spec.GetInt("output_type");
+    cpu_out_type_ = (int)ot;
+    cpu_adjust_orientation_ = spec.GetBool("adjust_orientation");
+  }
+  int OutputPitchAlign(int) const override { return 1; }
+  bool SetupImpl(std::vector<OutputDesc> &, const Workspace &) override { return false; }
+  void RunImpl(Workspace &ws) override {
+    const TensorList &in = ws.Input(0);
+    TensorList &out = ws.Output(0);
+    const int n = in.num_samples();
+    DALI_ENFORCE(in.type() == DALI_UINT8, "decoders.image expects encoded streams as 1-D uint8 tensors");
+    auto src = [&](int i) { return i < (int)in.source_info.size() && !in.source_info[i].empty() ? in.source_info[i]
+                                                                                               : make_string("sample ", i); };
+    cpu_infos_.resize(n);
+    cpu_raster_.assign(n, 0);
+    cpu_orient_.assign(n, 1);
+    std::vector<int> channels(n, 3);
+    this->upright_hw_.assign(2 * (size_t)n, 0);
+    for (int i = 0; i < n; i++) {
+      const uint8_t *data = static_cast<const uint8_t *>(in.raw(i));
+      const size_t size = (size_t)in.nbytes(i);
+      daliamdImageFormat fmt = DALIAMD_IMAGE_UNKNOWN;
+      int32_t w = 0, h = 0;
+      if (daliamdImageProbe(data, size, &fmt, &w, &h) != 0) DALI_FAIL("Failed to decode ", src(i), ": ", daliamdHostGetLastErrorMessage());
+      if (fmt == DALIAMD_IMAGE_JPEG) {
+        if (daliamdJpegParse(data, size, &cpu_infos_[i]) != 0) DALI_FAIL("Failed to parse ", src(i), ": ", daliamdHostGetLastErrorMessage());
+        cpu_orient_[i] = cpu_adjust_orientation_ ? cpu_infos_[i].orientation : 1;
+        w = cpu_infos_[i].width; h = cpu_infos_[i].height;
+        if (cpu_orient_[i] >= 5 && cpu_orient_[i] <= 8) std::swap(w, h);
+        channels[i] = daliamdJpegOutputChannels(cpu_infos_[i].num_components, cpu_out_type_);
+      } else {
+        cpu_raster_[i] = 1;
+        channels[i] = cpu_out_type_ == DALI_GRAY ? 1 : 3;
+      }
+      this->upright_hw_[2 * i] = h;
+      this->upright_hw_[2 * i + 1] = w;
+    }
+    this->rois_.assign(4 * (size_t)n, 0);
+    this->ComputeRois(ws, n);
+    std::vector<TensorShape> shapes(n);
+    for (int i = 0; i < n; i++) {
+      const bool window = this->rois_[4 * i + 2] > 0;
+      shapes[i] = {window ? this->rois_[4 * i + 2] : this->upright_hw_[2 * i],
+                   window ? this->rois_[4 * i + 3] : this->upright_hw_[2 * i + 1], channels[i]};
+    }
+    out.Resize(shapes, DALI_UINT8);
+    out.SetLayout("HWC");
+    out.source_info = in.source_info;
+    for (int i = 0; i < n; i++) {
+      ws.GetThreadPool().AddWork([this, &in, &out, &channels, i, src](int) {
+        const uint8_t *data = static_cast<const uint8_t *>(in.raw(i));
+        const size_t size = (size_t)in.nbytes(i);
+        const int H = this->upright_hw_[2 * i], W = this->upright_hw_[2 * i + 1], oc = channels[i];
+        std::vector<uint8_t> full((size_t)H * W * oc);
+        const int64_t fpitch = (int64_t)W * oc;
+        int rc;
+        if (!cpu_raster_[i]) {
+          rc = daliamdJpegDecodeHost(data, size, &cpu_infos_[i], cpu_orient_[i], cpu_out_type_, full.data(), fpitch);
+        } else if (cpu_out_type_ == DALI_RGB || cpu_out_type_ == DALI_ANY_DATA) {
+          rc = daliamdImageDecodeRgb(data, size, full.data(), fpitch, 0, 0, 0, 0);
+        } else {
+          std::vector<uint8_t> rgb((size_t)H * W * 3);
+          rc = daliamdImageDecodeRgb(data, size, rgb.data(), (int64_t)W * 3, 0, 0, 0, 0);
+          if (rc == 0) rc = daliamdConvertRgbRows(rgb.data(), (int64_t)W * 3, W, H, cpu_out_type_, full.data(), fpitch);
+        }
+        if (rc != 0) DALI_FAIL("Failed to decode ", src(i), ": ", daliamdHostGetLastErrorMessage());
+        const bool window = this->rois_[4 * i + 2] > 0;
+        const int y0 = window ? this->rois_[4 * i] : 0, x0 = window ? this->rois_[4 * i + 1] : 0;
+        const int h = (int)out.shape(i)[0], w = (int)out.shape(i)[1];
+        uint8_t *dst = static_cast<uint8_t *>(out.raw(i));
+        const int64_t pitch = out.row_pitch(i) ? out.row_pitch(i) : (int64_t)w * oc;
+        for (int y = 0; y < h; y++)
+          memcpy(dst + y * pitch, full.data() + (size_t)(y0 + y) * fpitch + (size_t)x0 * oc, (size_t)w * oc);
+      }, in.nbytes(i));
+    }
+    ws.GetThreadPool().RunAll();
+    NoteLaunch(ws, "host_jpeg_decode_roi");
+  }
+
+ private:
+  static OpSpec WithQueueDepth(OpSpec spec) {  // the executor hands this argument to device operators only
+    if (!spec.Args().count("gpu_prefetch_queue_depth")) spec.AddArg("gpu_prefetch_queue_depth", ArgValue::Int(1));
+    return spec;
+  }
+  int cpu_out_type_ = 0;
+  bool cpu_adjust_orientation_ = true;
+  std::vector<daliamdJpegInfo> cpu_infos_;
+  std::vector<int> cpu_raster_, cpu_orient_;
+};
+using ImageDecoderRandomCropCpu = RoiDecoderCpu<ImageDecoderRandomCropMixed>;
+using ImageDecoderCropCpu = RoiDecoderCpu<ImageDecoderCropMixed>;
+using ImageDecoderSliceCpu = RoiDecoderCpu<ImageDecoderSliceMixed>;
+DALI_REGISTER_OPERATOR(decoders__ImageRandomCrop, ImageDecoderRandomCropCpu, CPU);
+DALI_REGISTER_OPERATOR(ImageDecoderRandomCrop, ImageDecoderRandomCropCpu, CPU);
+DALI_REGISTER_OPERATOR(experimental__decoders__ImageRandomCrop, ImageDecoderRandomCropCpu, CPU);
+DALI_REGISTER_OPERATOR(decoders__ImageCrop, ImageDecoderCropCpu, CPU);
+DALI_REGISTER_OPERATOR(ImageDecoderCrop, ImageDecoderCropCpu, CPU);
+DALI_REGISTER_OPERATOR(experimental__decoders__ImageCrop, ImageDecoderCropCpu, CPU);
+DALI_REGISTER_OPERATOR(decoders__ImageSlice, ImageDecoderSliceCpu, CPU);
+DALI_REGISTER_OPERATOR(ImageDecoderSlice, ImageDecoderSliceCpu, CPU);
+DALI_REGISTER_OPERATOR(experimental__decoders__ImageSlice, ImageDecoderSliceCpu, CPU);
+
 DALI_REGISTER_OPERATOR(decoders__ImageSlice, ImageDecoderSliceMixed, MIXED);
 DALI_REGISTER_OPERATOR(ImageDecoderSlice, ImageDecoderSliceMixed, MIXED);
 DALI_REGISTER_OPERATOR(experimental__decoders__ImageSlice, ImageDecoderSliceMixed, MIXED);

@@ -153,8 +153,8 @@ def test_graph_validation_errors(dataset):
         d, l = fn.readers.file(file_root=root)
         with pytest.raises(TypeError, match="unexpected keyword"):
             fn.random.coin_flip(probabilty=0.3)
-        with pytest.raises(RuntimeError, match="not available for device \"cpu\""):
-            fn.decoders.image_crop(d, crop=[8, 8])     # no silent CPU fallback for an operator registered for "mixed" only
+        with pytest.raises(RuntimeError, match="not available for device \"gpu\""):
+            fn.random.coin_flip(device="gpu")          # an operator runs where it is registered: no silent fallback
         with pytest.raises(ValueError, match="expects between"):
             fn.random_resized_crop(size=[8, 8], device="gpu")
         with pytest.raises(ValueError, match="cannot take a GPU input"):
