@@ -498,13 +498,84 @@ def bench_cpu_backend(args):
         el = time.perf_counter() - t0
     finally:
         shutil.rmtree(root, ignore_errors=True)
+    extra = {}
+    try:   # the other configurations on the CPU backend (side figures: the same host kernels the tests pin to the oracle)
+        extra = cpu_backend_side_configs(threads)
+    except Exception as e:   # never fatal for the configs[0] line
+        extra = {"error": str(e)[:200]}
     print(json.dumps({"metric": "images/sec JPEG->RRC->CMN 224^2 b32, CPU backend", "value": steps * B / el,
                       "unit": "images/s", "n_gpus": 0, "steps": steps, "warmup": max(1, args.warmup),
                       "ms_per_step": 1e3 * el / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                       "dtype": "u8/i32 decode, f32 resample, f16 out", "data": "synthetic",
                       "config": {"workload": "configs[0]: ImageNet train pipe on the CPU backend of dali_amd.Pipeline, "
                                              "batch 32, 224x224 fp16 CHW", "host_threads": threads,
-                                 "kernels": pipe.executed_kernels()}}))
+                                 "kernels": pipe.executed_kernels()},
+                      "cpu_backend_other_configs": extra}))
+
+
+def cpu_backend_side_configs(threads):
+    """configs[2] (512 x 512 heavy augmentation, batch 16 here) and configs[3] (spectrogram -> mel -> dB of 64 utterances)
+    through dali_amd.Pipeline on the CPU backend: images / utterances per second on this host."""
+    from dali_amd import fn, types
+    from dali_amd.pipeline import Pipeline
+    rng = np.random.default_rng(1234)
+    out = {}
+    # ---- configs[2]
+    bs = 16
+    base = rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)
+    imgs = [np.ascontiguousarray(np.kron(np.roll(base, i, 0), np.ones((8, 8, 1), np.uint8))) for i in range(bs)]
+    mats = []
+    for _ in range(bs):
+        t, sc = np.deg2rad(rng.uniform(-30, 30)), rng.uniform(0.8, 1.2)
+        c, sn = np.cos(t) / sc, np.sin(t) / sc
+        m = np.array([[c, -sn, 0], [sn, c, 0]], np.float32)
+        m[0, 2] = 256 - m[0, 0] * 256 - m[0, 1] * 256
+        m[1, 2] = 256 - m[1, 0] * 256 - m[1, 1] * 256
+        mats.append(m.reshape(6))
+    pipe = Pipeline(batch_size=bs, num_threads=threads, device_id=None, seed=17, prefetch_queue_depth=1)
+    with pipe:
+        x = fn.external_source(name="images", layout="HWC")
+        m = fn.external_source(name="matrix")
+        y = fn.warp_affine(x, matrix=m, fill_value=0.0, interp_type=types.INTERP_LINEAR)
+        y = fn.gaussian_blur(y, sigma=3.0)
+        y = fn.color_twist(y, hue=fn.random.uniform(range=[-30.0, 30.0], seed=1), saturation=fn.random.uniform(range=[0.7, 1.3], seed=2),
+                           brightness=fn.random.uniform(range=[0.8, 1.2], seed=3), contrast=fn.random.uniform(range=[0.8, 1.2], seed=4))
+        y = fn.erase(y, anchor=fn.random.uniform(range=[0.0, 0.7], shape=[2], seed=5),
+                     shape=fn.random.uniform(range=[0.1, 0.3], shape=[2], seed=6), normalized=True, fill_value=0.0)
+        pipe.set_outputs(y)
+    pipe.build()
+    reps = 3
+    t0 = None
+    for r in range(reps + 1):
+        if r == 1:
+            t0 = time.perf_counter()
+        pipe.feed_input("images", imgs, layout="HWC")
+        pipe.feed_input("matrix", mats)
+        pipe.run()
+    out["configs[2] heavy_aug 512x512"] = {"value": reps * bs / (time.perf_counter() - t0), "unit": "images/s", "batch": bs,
+                                           "kernels": pipe.executed_kernels()}
+    # ---- configs[3]
+    bs = 64
+    sigs = []
+    for _ in range(bs):
+        n = int(rng.uniform(8, 16) * 16000)
+        t = np.arange(n) / 16000.0
+        sigs.append((0.3 * np.sin(2 * np.pi * (200 + 50 * t) * t) + 0.05 * rng.standard_normal(n)).astype(np.float32))
+    pipe = Pipeline(batch_size=bs, num_threads=threads, device_id=None, prefetch_queue_depth=1)
+    with pipe:
+        x = fn.external_source(name="x")
+        spec = fn.spectrogram(x, nfft=1024, window_length=1024, window_step=256)
+        mel = fn.mel_filter_bank(spec, nfilter=80, sample_rate=16000.0, freq_high=8000.0)
+        pipe.set_outputs(fn.to_decibels(mel, multiplier=10.0, cutoff_db=-80.0))
+    pipe.build()
+    for r in range(reps + 1):
+        if r == 1:
+            t0 = time.perf_counter()
+        pipe.feed_input("x", sigs)
+        pipe.run()
+    out["configs[3] audio b64"] = {"value": reps * bs / (time.perf_counter() - t0), "unit": "utterances/s", "batch": bs,
+                                   "kernels": pipe.executed_kernels()}
+    return out
 
 
 def main():
