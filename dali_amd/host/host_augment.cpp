@@ -20,11 +20,14 @@ using daliamd_host::Fail;
 
 namespace {
 
-inline uint8_t SatU8(float v) {   // ConvertSat<uint8_t>(float): round half away from zero, clamp
-  const float r = std::round(v);
-  if (!(r > 0)) return 0;
-  if (r > 255) return 255;
-  return (uint8_t)r;
+// ConvertSat<uint8_t>(float) = clamp(roundf(v)), halves away from zero - without the library call: everything that
+// rounds to <= 0 (NaN included) gives 0, everything from 255.5 on gives 255, and in between the truncation is the floor
+// and the fraction v - floor(v) is exact.
+inline uint8_t SatU8(float v) {
+  if (!(v > 0)) return 0;
+  if (v >= 255.5f) return 255;
+  const int i = (int)v;
+  return (uint8_t)(i + ((v - (float)i) >= 0.5f ? 1 : 0));
 }
 
 inline int Reflect101(int idx, int size) {
@@ -92,29 +95,34 @@ extern "C" int daliamdGaussianBlurHost(const daliamdGaussianBlurDesc *d) {
       !(d->size_x & 1) || !(d->size_y & 1))
     return Fail("daliamdGaussianBlurHost: window sizes must be odd and at most %d", DALIAMD_MAX_BLUR_WINDOW);
   const int H = d->h, W = d->w, C = d->channels, rx = (d->size_x - 1) / 2, ry = (d->size_y - 1) / 2;
-  std::vector<float> tmp((size_t)H * W * C);
-  std::vector<int> sxs((size_t)d->size_x);
+  // Both passes run tap-outer / element-inner over a whole row: every element still accumulates its taps in order
+  // (acc = acc + sample * weight, multiply and add rounded separately), and the element loop vectorises.
+  const size_t rowlen = (size_t)W * C;
+  std::vector<float> tmp((size_t)H * rowlen), pad((size_t)(W + 2 * rx) * C), acc(rowlen);
   for (int y = 0; y < H; y++) {
     const uint8_t *row = d->in + (size_t)y * d->in_pitch;
-    for (int x = 0; x < W; x++) {
-      for (int k = 0; k < d->size_x; k++) sxs[k] = Reflect101(x - rx + k, W) * C;
-      for (int c = 0; c < C; c++) {
-        float acc = 0;
-        for (int k = 0; k < d->size_x; k++) acc += row[sxs[k] + c] * d->window_x[k];
-        tmp[((size_t)y * W + x) * C + c] = acc;
-      }
+    for (int x = -rx; x < W + rx; x++) {   // the row with its reflected borders, as floats
+      const uint8_t *src = row + (size_t)Reflect101(x, W) * C;
+      float *dst = pad.data() + (size_t)(x + rx) * C;
+      for (int c = 0; c < C; c++) dst[c] = (float)src[c];
     }
+    std::fill(acc.begin(), acc.end(), 0.0f);
+    for (int k = 0; k < d->size_x; k++) {
+      const float w = d->window_x[k];
+      const float *p = pad.data() + (size_t)k * C;
+      for (size_t e = 0; e < rowlen; e++) acc[e] += p[e] * w;
+    }
+    std::copy(acc.begin(), acc.end(), tmp.begin() + (size_t)y * rowlen);
   }
-  std::vector<const float *> rows((size_t)d->size_y);
-  const size_t rowlen = (size_t)W * C;
   for (int y = 0; y < H; y++) {
-    for (int k = 0; k < d->size_y; k++) rows[k] = tmp.data() + (size_t)Reflect101(y - ry + k, H) * rowlen;
-    uint8_t *o = d->out + (size_t)y * d->out_pitch;
-    for (size_t e = 0; e < rowlen; e++) {
-      float acc = 0;
-      for (int k = 0; k < d->size_y; k++) acc += d->window_y[k] * rows[k][e];
-      o[e] = SatU8(acc);
+    std::fill(acc.begin(), acc.end(), 0.0f);
+    for (int k = 0; k < d->size_y; k++) {
+      const float w = d->window_y[k];
+      const float *r = tmp.data() + (size_t)Reflect101(y - ry + k, H) * rowlen;
+      for (size_t e = 0; e < rowlen; e++) acc[e] += w * r[e];
     }
+    uint8_t *o = d->out + (size_t)y * d->out_pitch;
+    for (size_t e = 0; e < rowlen; e++) o[e] = SatU8(acc[e]);
   }
   return 0;
 }
