@@ -18,12 +18,14 @@
 //   * fused epilogue = CMN CPU arithmetic (slice_flip_normalize_permute_pad_cpu.h:41-42):
 //     (float(u8) - mean) * inv_std, fp16 stored round-to-nearest ties-away (util/half.hpp:231-243).
 //
-// MI355X design: ONE launch per batch; a workgroup owns a TILE_H x TILE_W output tile of one
-// sample (descriptor table + binary search, XCD-aware block remap so all tiles of a sample share
-// one XCD's L2).  Pass 1 reads the u8 source straight from global memory (dword loads when the
-// row pitch allows) and leaves its fp32 result in LDS; pass 2 reads LDS only.  The fp32
-// intermediate and the 224x224 u8 image of the unfused pipeline never touch HBM:
-// algorithmic traffic = source ROI bytes + output bytes.
+// MI355X design (round 2): two launches per batch.  ResampleTablesKernel fills, per SAMPLE, the first tap and the
+// normalised coefficients of every output column / row (and the 256-entry fp16 table of the fused normalisation) and,
+// per TILE, a 128-byte record with everything a tile's prologue needs.  ResampleKernel: a workgroup takes consecutive
+// 32 x 16 output tiles (XCD-aware remap: the tiles of a sample share one XCD's L2), stages the u8 source window in LDS
+// with 16-byte loads while the previous tile computes, runs pass 1 into an fp32 tile in LDS and pass 2 from LDS - two
+// pixels per thread on the common paths - and stores the (normalised) result.  The fp32 intermediate and the 224 x 224
+// u8 image of the unfused pipeline never touch HBM: algorithmic traffic = source ROI bytes + output bytes.  Other
+// element types and the unrounded float result take a plain two-launch path (ResampleGenericKernel).
 #include <cmath>
 #include <cstring>
 #include <mutex>
