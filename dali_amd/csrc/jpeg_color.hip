@@ -8,9 +8,10 @@
 // the neighbour index clamped to [0, downsampled_width-1]; rows above/below the component are
 // the replicated edge rows jdmainct.c provides as context => clamp to [0, downsampled_height-1].
 //
-// Mapping: one thread produces 8 consecutive output pixels (24 bytes) of one row: an 8-byte
-// luma load, <=3 small chroma loads per chroma row, three 8-byte stores when the output pitch
-// allows (pitch % 8 == 0), byte stores otherwise.  Workgroup = 32 x 8 threads = 256 x 8 px tile.
+// Mapping: a thread produces 8 consecutive output pixels (24 bytes) of kRowsPerThread rows: an 8-byte luma load and
+// <= 3 small chroma loads per chroma row, three 8-byte stores per row when the output pitch allows (pitch % 8 == 0),
+// byte stores otherwise; the common 4:2:0 case issues all its loads before the first use (ColorRows420).
+// Workgroup = 32 x 8 threads = a 256 x (8 * kRowsPerThread) pixel tile.
 // HBM traffic per pixel: 1 + 2/(h*v ratio) bytes read, 3 bytes written.
 #include "common.h"
 
