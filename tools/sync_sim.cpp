@@ -178,7 +178,8 @@ int main(int argc, char **argv) {
     const long nslices = (im.total_bits / 8 + slice - 1) / slice;
     const long nseg = std::max<long>(1, (nslices + seg_lanes - 1) / seg_lanes);
     for (long seg = 0; seg < nseg; seg++) {
-      struct L { uint32_t begin, end; bool active; State in, out; bool has_in; int nsym, steps; std::vector<uint64_t> traj; };
+      struct L { uint32_t begin, end; bool active; State in, out; bool has_in; int nsym, steps; std::vector<uint64_t> traj;
+                 std::vector<std::pair<State, State>> memo; };   // SIM_SPEC: in -> out of speculative decodes
       std::vector<L> ln(T);
       std::vector<State> state(T);
       for (int t = 0; t < T; t++) {
@@ -202,7 +203,40 @@ int main(int argc, char **argv) {
         bool any = false;
         for (int t = 0; t < T; t++) {
           L &l = ln[t];
+          static const bool spec = getenv("SIM_SPEC") != nullptr;
+          auto speculate = [&](int tt) {
+            // idle lanes decode slice tt from its present input with every other block index: if its predecessor's
+            // result changes in the block index only, this lane's result is there already
+            if (!(tt < T && ln[tt].active && ln[tt].has_in)) return;
+            L &nx = ln[tt];
+            for (uint32_t c = 0; c < im.bpm; c++) {
+              State cand = nx.in;
+              if (c == cand.c) continue;
+              cand.c = c;
+              bool have = false;
+              for (auto &m : nx.memo) have = have || m.first == cand;
+              if (have) continue;
+              State st2 = cand;
+              int ns = 0, stp = 0;
+              if (st2.pos < nx.end) Decode(im, st2, nx.end, ns, stp);
+              nx.memo.push_back({cand, st2});
+              wave_max[tt / 64] = std::max<long>(wave_max[tt / 64], stp);
+              total_steps += stp;
+            }
+          };
+          if (spec && l.active && l.has_in && !(l.in == state[t])) {   // a result decoded speculatively in an earlier round?
+            bool hit = false;
+            for (auto &m : l.memo)
+              if (m.first == state[t]) { l.in = state[t]; l.out = m.second; hit = true; break; }
+            if (hit) {                      // free: the state travels on within this round
+              if (t + 1 < T && !(state[t + 1] == l.out)) state[t + 1] = l.out;
+              if (getenv("SIM_SPEC")[0] == '2') speculate(t + 2);   // keep one lane ahead of the travelling state
+              any = true;
+              continue;
+            }
+          }
           if (l.active && !(l.has_in && l.in == state[t])) {
+            if (spec && round >= 2) speculate(t + 1);
             l.in = state[t]; l.has_in = true;
             const State old_out = l.out; const bool had = l.has_in;
             const State old_in = l.in;
