@@ -1,5 +1,6 @@
 #!/bin/bash
-# tools/fuzz_host_decoders.py against an AddressSanitizer build of the host library (restored afterwards).
+# tools/fuzz_host_decoders.py (or, with a second argument "readers", tools/fuzz_host_readers.py) against an AddressSanitizer
+# build of the host library (restored afterwards):  tools/asan_fuzz.sh [iterations] [decoders|readers]
 set -eu
 ASAN=$(gcc -print-file-name=libasan.so)
 STDCXX=$(gcc -print-file-name=libstdc++.so)
@@ -10,4 +11,6 @@ make -s -C dali_amd/host CXXFLAGS="-O1 -g -std=c++17 -fPIC -ffp-contract=off -fv
      $(cd dali_amd/host && ls *.cpp | sed 's|\(.*\)\.cpp|../build/host_\1.o|')
 g++ -shared -fPIC -pthread -fsanitize=address -o dali_amd/lib/libdali_amd_host.so dali_amd/build/host_*.o -Ldali_amd/lib \
     -ldali_amd_kernels -lz -Wl,-rpath,'$ORIGIN'
-LD_PRELOAD="$ASAN $STDCXX" ASAN_OPTIONS=detect_leaks=0 python tools/fuzz_host_decoders.py "${1:-300}"
+SCRIPT=tools/fuzz_host_decoders.py
+if [ "${2:-decoders}" = "readers" ]; then SCRIPT=tools/fuzz_host_readers.py; fi
+LD_PRELOAD="$ASAN $STDCXX" ASAN_OPTIONS=detect_leaks=0 python $SCRIPT "${1:-300}"
