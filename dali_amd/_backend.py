@@ -134,6 +134,7 @@ class OpSpec:
 class BackendPipeline:
     def __init__(self, batch_size, num_threads, device_id, seed, prefetch_queue_depth, exec_async, set_affinity=False):
         self._lib = _lib()
+        self.device_id = max(0, int(device_id))
         self._h = self._lib.daliamdPipelineCreate(batch_size, num_threads, device_id, seed, prefetch_queue_depth,
                                                   1 if exec_async else 0)
         if not self._h:

@@ -1,5 +1,6 @@
 """Functional operator API, generated from the operator schemas registered in the C++ host library
 (reference: dali/python/nvidia/dali/fn/__init__.py:31-148 -- `a__b__OpName` -> fn.a.b.op_name)."""
+import re
 import sys
 import types as _pytypes
 
@@ -9,38 +10,21 @@ from ..data_node import DataNode as _DataNode
 _special_case_mapping = {"b_box": "bbox", "mx_net": "mxnet", "tf_record": "tfrecord"}
 
 
+_WORD_BREAKS = (
+    (re.compile(r"([A-Z]+)([A-Z][a-z])"), r"\1_\2"),     # an acronym ends where a capitalised word starts: TFRecord
+    (re.compile(r"([a-z])([A-Z])"), r"\1_\2"),            # a word ends at the next capital: CoinFlip
+    (re.compile(r"([0-9])([A-Z][a-z])"), r"\1_\2"),       # ... also behind a digit (Caffe2Reader), but Warp3D stays whole
+)
+
+
 def _to_snake_case(pascal):
-    out = ""
-    nupper = 0
-    start = 0
-    for i, c in enumerate(pascal):
-        if c.isupper():
-            if nupper == 0:
-                start = i
-            nupper += 1
-        elif c.islower():
-            if nupper == 0:
-                out += c
-            else:
-                if len(out) > 0 and out[-1] != "_":
-                    out += "_"
-                if nupper > 1:
-                    out += pascal[start:i - 1].lower() + "_"
-                out += pascal[i - 1].lower()
-                out += c
-                nupper = 0
-            start = i + 1
-        else:
-            out += pascal[start:i + 1].lower()
-            start = i + 1
-            nupper = 0
-    if nupper > 0:
-        if len(out) and out[-1].islower():
-            out += "_"
-        out += pascal[start:].lower()
+    """`RandomResizedCrop` -> `random_resized_crop`, the naming rule of the reference's fn module."""
+    for pattern, repl in _WORD_BREAKS:
+        pascal = pattern.sub(repl, pascal)
+    snake = pascal.lower()
     for artifact, desired in _special_case_mapping.items():
-        out = out.replace(artifact, desired)
-    return out
+        snake = snake.replace(artifact, desired)
+    return snake
 
 
 def _choose_device(inputs):
@@ -123,7 +107,7 @@ def _make_fn(schema_name, wrapper_name):
         if schema_name in _OUTPUT_COUNT:      # the reference's OutputFn: the output count follows an argument
             nout = _OUTPUT_COUNT[schema_name](init_args)
         outs = pipe._add_op(schema_name, device, init_args, flat_inputs, arg_inputs, nout, name)
-        return outs[0] if len(outs) == 1 and schema_name not in _OUTPUT_COUNT else outs
+        return outs[0] if len(outs) == 1 else outs     # single outputs are unwrapped (ops/__init__.py:510-514)
 
     fn_wrapper.__name__ = fn_wrapper.__qualname__ = wrapper_name
     lines = [schema["doc"], "", "Keyword args", "------------"]
@@ -218,7 +202,7 @@ def _wrap_tfrecord():
                    index_path=[index_path] if isinstance(index_path, str) else list(index_path), feature_names=names,
                    feature_dtypes=[int(f.dtype) for f in feats], feature_has_shape=[int(f.has_shape) for f in feats],
                    feature_ndims=[len(f.shape) for f in feats], **({"feature_shapes": shapes} if shapes else {}), **kwargs)
-        return dict(zip(names, outs))
+        return dict(zip(names, outs if isinstance(outs, (list, tuple)) else [outs]))
 
     tfrecord.__doc__ = raw.__doc__
     tfrecord._schema_name = raw._schema_name

@@ -196,7 +196,7 @@ class TFRecordReaderOp : public OperatorBase {
       DALI_ENFORCE(f.type == DALI_INT64 || f.type == DALI_FLOAT || f.type == DALI_UINT8,
                    "readers.tfrecord: feature \"", names_[i], "\": unsupported type ", TypeName(f.type));
       f.has_shape = hs[i] != 0;
-      DALI_ENFORCE(pos + (size_t)nd[i] <= shapes.size(), "readers.tfrecord: inconsistent feature shapes");
+      DALI_ENFORCE(nd[i] >= 0 && (size_t)nd[i] <= shapes.size() - pos, "readers.tfrecord: inconsistent feature shapes");
       f.shape.assign(shapes.begin() + pos, shapes.begin() + pos + nd[i]);
       pos += (size_t)nd[i];
       features_.push_back(f);
@@ -206,7 +206,7 @@ class TFRecordReaderOp : public OperatorBase {
       DALI_ENFORCE(idx.good(), "Could not open index file ", index_paths[k]);
       int64_t off, size;
       while (idx >> off >> size) {
-        DALI_ENFORCE(off >= 0 && size >= 0 && off + size <= files_.sizes[k], "Index file ", index_paths[k],
+        DALI_ENFORCE(off >= 0 && size >= 0 && off <= files_.sizes[k] && size <= files_.sizes[k] - off, "Index file ", index_paths[k],
                      " does not describe ", files_.paths[k], " (record at ", off, " + ", size, ")");
         records_.push_back({off, size, (int)k});
       }
@@ -556,11 +556,14 @@ class WebdatasetReaderOp : public OperatorBase {
   struct Component { int64_t offset = 0, size = -1; };  // size < 0: the sample has no such component
   struct Sample { int file = 0; int64_t first_offset = 0; std::vector<Component> comp; };
 
-  int OutputOf(const std::string &ext) const {
+  // a component fills EVERY output whose extension set lists it (the ext -> outputs map of webdataset_loader.cc:413-460)
+  void Assign(Sample *s, const std::string &ext, int64_t offset, int64_t size) const {
     for (size_t o = 0; o < ext_.size(); o++)
       for (auto &a : ext_[o])
-        if (a == ext) return (int)o;
-    return -1;
+        if (a == ext) {
+          if (s->comp[o].size < 0) s->comp[o] = Component{offset, size};
+          break;
+        }
   }
   // base name / extension of a tar entry: the extension is the text behind the FIRST dot of the file name
   static bool SplitName(const std::string &path, std::string *base, std::string *ext) {
@@ -586,8 +589,7 @@ class WebdatasetReaderOp : public OperatorBase {
       out->push_back(s);
       *cur_base = base;
     }
-    const int o = OutputOf(lower(ext));
-    if (o >= 0 && out->back().comp[o].size < 0) out->back().comp[o] = Component{offset, size};
+    Assign(&out->back(), lower(ext), offset, size);
   }
   // POSIX ustar / GNU tar: 512-byte headers, name [0,100) (+ prefix [345,500)), size octal [124,136), type flag [156];
   // GNU long names (type 'L') carry the name of the next entry; data is padded to 512 bytes; two zero blocks end it.
@@ -601,11 +603,15 @@ class WebdatasetReaderOp : public OperatorBase {
       bool zero = true;
       for (int i = 0; i < 512 && zero; i++) zero = h[i] == 0;
       if (zero) break;
-      int64_t size = 0;
-      if (h[124] & 0x80) {  // base-256
-        for (int i = 125; i < 136; i++) size = (size << 8) | h[i];
+      uint64_t usize = 0;
+      bool size_ok = true;
+      if (h[124] & 0x80) {  // base-256 (GNU): 11 more bytes, big endian; anything that does not fit 63 bits is malformed
+        for (int i = 125; i < 136; i++) {
+          size_ok = size_ok && (usize >> 55) == 0;
+          usize = (usize << 8) | h[i];
+        }
       } else {
-        for (int i = 124; i < 136 && h[i] >= '0' && h[i] <= '7'; i++) size = size * 8 + (h[i] - '0');
+        for (int i = 124; i < 136 && h[i] >= '0' && h[i] <= '7'; i++) usize = usize * 8 + (uint64_t)(h[i] - '0');  // <= 36 bits
       }
       const char type = (char)h[156];
       std::string name(reinterpret_cast<const char *>(h), strnlen(reinterpret_cast<const char *>(h), 100));
@@ -614,7 +620,9 @@ class WebdatasetReaderOp : public OperatorBase {
         name = prefix + "/" + name;
       }
       const int64_t data = pos + 512;
-      DALI_ENFORCE(data + size <= files_.sizes[file], "Malformed tar archive ", files_.paths[file], " (entry at ", pos, ")");
+      DALI_ENFORCE(size_ok && usize <= (uint64_t)(files_.sizes[file] - data), "Malformed tar archive ", files_.paths[file],
+                   " (entry at ", pos, ")");
+      const int64_t size = (int64_t)usize;
       if (type == 'L') {
         long_name.resize((size_t)size);
         files_.Read(file, data, &long_name[0], size);
@@ -623,7 +631,7 @@ class WebdatasetReaderOp : public OperatorBase {
         if (!long_name.empty()) { name = long_name; long_name.clear(); }
         if (type == '0' || type == 0) AddEntry(out, &cur_base, file, name, data, size, lower);
       }
-      pos = data + ((size + 511) & ~(int64_t)511);
+      pos = data + ((size + 511) & ~(int64_t)511);  // size >= 0: pos strictly increases
     }
   }
   // index file: "v1.2 <num_samples>" then one line per sample: "<ext> <data offset> <size> [<source name>] ..." (v1.2 adds
@@ -650,11 +658,10 @@ class WebdatasetReaderOp : public OperatorBase {
       s.comp.assign(ext_.size(), Component{});
       for (size_t c = 0; c < tok.size(); c += per) {
         const int64_t off = std::stoll(tok[c + 1]), size = std::stoll(tok[c + 2]);
-        DALI_ENFORCE(off >= 0 && size >= 0 && off + size <= files_.sizes[file], "Index file ", path, " does not describe ",
+        DALI_ENFORCE(off >= 0 && size >= 0 && off <= files_.sizes[file] && size <= files_.sizes[file] - off, "Index file ", path, " does not describe ",
                      files_.paths[file]);
         if (c == 0) s.first_offset = off;
-        const int o = OutputOf(lower(tok[c]));
-        if (o >= 0 && s.comp[o].size < 0) s.comp[o] = Component{off, size};
+        Assign(&s, lower(tok[c]), off, size);
       }
       out->push_back(s);
     }

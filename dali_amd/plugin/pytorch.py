@@ -6,7 +6,11 @@ The device copy is ONE copy of the batch (viewed in place in the pipeline's buff
 -- the equivalent of the reference's feed_ndarray / copy_to_external -- issued on a side stream of the iterator and
 completed before __next__ returns: the pipeline reuses the buffer a few iterations later on its own streams, so the
 read must not be left pending on torch's stream (and waiting for torch's CURRENT stream would wait for the
-consumer's training step as well)."""
+consumer's training step as well).  Everything the copy touches is therefore created ON the side stream: the
+destination tensor (the caching allocator keeps one pool per stream, so the block cannot still be in use by kernels
+queued on the consumer's stream), the gathered source when the samples are not back to back (torch.stack), and the
+copy itself; the side stream is drained before the tensor is handed out and the tensor is recorded on the consumer's
+stream so that its block is not recycled under it."""
 import numpy as np
 import torch
 
@@ -15,18 +19,26 @@ from ..tensors import TensorListGPU
 from .base_iterator import LastBatchPolicy, _DaliBaseIterator  # noqa: F401
 
 
-def feed_ndarray(tensor_or_tl, arr, cuda_stream=None, non_blocking=False):
+def feed_ndarray(tensor_or_tl, arr, cuda_stream=None, non_blocking=False, _src=None):
     """Copies a dali_amd TensorList into a preallocated torch tensor (API parity with
     nvidia.dali.plugin.pytorch.feed_ndarray, torch_utils.py:34-75).  `cuda_stream`: the torch stream to copy on
     (default: the current one).  Unless `non_blocking`, the copy has completed on return, i.e. the pipeline may
     reuse the source buffer."""
-    if isinstance(tensor_or_tl, TensorListGPU):
-        src = tensor_or_tl.as_tensor()
+    stream = None
+    if arr.is_cuda:
+        stream = cuda_stream if isinstance(cuda_stream, torch.cuda.Stream) else torch.cuda.current_stream(arr.device)
+    if _src is not None:
+        src = _src
+    elif isinstance(tensor_or_tl, TensorListGPU):
+        if stream is not None:      # a gathered source (torch.stack) must be ordered in front of the copy
+            with torch.cuda.stream(stream):
+                src = tensor_or_tl.as_tensor()
+        else:
+            src = tensor_or_tl.as_tensor()
     else:
         src = torch.from_numpy(np.ascontiguousarray(tensor_or_tl.as_array()))
     assert tuple(src.shape) == tuple(arr.shape), f"Shapes do not match: DALI {tuple(src.shape)} vs torch {tuple(arr.shape)}"
     if arr.is_cuda:
-        stream = cuda_stream if isinstance(cuda_stream, torch.cuda.Stream) else torch.cuda.current_stream(arr.device)
         with torch.cuda.stream(stream):
             arr.copy_(src, non_blocking=True)
         if not non_blocking:
@@ -55,13 +67,15 @@ class DALIGenericIterator(_DaliBaseIterator):
             entry = {}
             for name, tl in zip(self.output_map, outs):
                 if isinstance(tl, TensorListGPU):
-                    src = tl.as_tensor()        # in-place view of the pipeline's buffer (or a gathered copy)
-                    side = self._copy_streams.get(src.device)
+                    dev = torch.device("cuda", tl.device_id())
+                    side = self._copy_streams.get(dev)
                     if side is None:
-                        side = self._copy_streams[src.device] = torch.cuda.Stream(device=src.device)
-                    t = torch.empty(src.shape, dtype=src.dtype, device=src.device)
-                    feed_ndarray(tl, t, cuda_stream=side)     # complete on return: the slot may be reused
-                    t.record_stream(side)
+                        side = self._copy_streams[dev] = torch.cuda.Stream(device=dev)
+                    with torch.cuda.stream(side):
+                        src = tl.as_tensor()    # in-place view of the pipeline's buffer, or a copy gathered on `side`
+                        t = torch.empty(src.shape, dtype=src.dtype, device=src.device)    # a block of side's pool
+                    feed_ndarray(tl, t, cuda_stream=side, _src=src)     # complete on return: the slot may be reused
+                    t.record_stream(torch.cuda.current_stream(dev))
                 else:
                     t = torch.from_numpy(np.ascontiguousarray(tl.as_array()))
                 if valid is not None and valid < t.shape[0]:

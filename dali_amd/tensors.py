@@ -135,6 +135,9 @@ class TensorListCPU(_TensorList):
 
 
 class TensorListGPU(_TensorList):
+    def device_id(self):
+        return getattr(self._pipe, "device_id", 0)
+
     def _contiguous_view(self):
         """Zero-copy [N, ...] view when the (uniform) samples sit back to back in the pipeline's buffer, else None."""
         import torch

@@ -89,7 +89,8 @@ def _pipe(bs, build, **kw):
     from dali_amd.pipeline import Pipeline
     pipe = Pipeline(batch_size=bs, num_threads=3, device_id=None, seed=7, prefetch_queue_depth=1, **kw)
     with pipe:
-        pipe.set_outputs(*build())
+        outs = build()
+        pipe.set_outputs(*(outs if isinstance(outs, (list, tuple)) else [outs]))
     pipe.build()
     return pipe
 
@@ -236,3 +237,49 @@ def test_webdataset_reader(tmp_path, images, with_index):
     pipe = _pipe(1, lambda: fn.readers.webdataset(paths=[t1], ext=["cls"], dtypes=[types.UINT8], **({"index_paths": [t1 + ".idx"]} if with_index else {})))
     (only,) = pipe.run()
     assert only.at(0).tobytes() == b"4"
+
+
+def test_webdataset_component_fills_every_output_that_lists_it(tmp_path, images):
+    """ext=['jpg', 'jpg;png']: the reference maps an extension to ALL outputs that name it
+    (webdataset_loader.cc:413-460), and a single-output reader returns a DataNode, not a list
+    (ops/__init__.py:510-514)."""
+    from dali_amd import fn
+    from dali_amd.data_node import DataNode
+    t = str(tmp_path / "s.tar")
+    _write_tar(t, [("0.jpg", images[0]), ("1.png", images[1])], None)
+    pipe = _pipe(2, lambda: fn.readers.webdataset(paths=[t], ext=["jpg", "jpg;png"], missing_component_behavior="empty"))
+    a, b = pipe.run()
+    assert a.at(0).tobytes() == images[0] and b.at(0).tobytes() == images[0]
+    assert a.at(1).size == 0 and b.at(1).tobytes() == images[1]
+    from dali_amd.pipeline import Pipeline
+    with Pipeline(batch_size=1, num_threads=1, device_id=None, seed=1):
+        assert isinstance(fn.readers.webdataset(paths=[t], ext=["jpg"]), DataNode)
+
+
+@pytest.mark.parametrize("size_field", [
+    b"\xff" * 10 + b"\xfe\x00",        # base-256, all ones: -512 as a signed 64-bit value (used to loop forever)
+    b"\xff" * 12,                        # -1
+    b"\x80" + b"\x00" * 3 + b"\x7f" + b"\xff" * 7,   # 2^63 - 1
+    b"\x80" + b"\x01" + b"\x00" * 10,    # does not fit 64 bits
+])
+def test_webdataset_rejects_malformed_tar_sizes(tmp_path, images, size_field):
+    from dali_amd import fn
+    t = str(tmp_path / "bad.tar")
+    _write_tar(t, [("0.jpg", images[0]), ("1.jpg", images[1])], None)
+    raw = bytearray(open(t, "rb").read())
+    raw[124:136] = size_field
+    raw[148:156] = b" " * 8
+    raw[148:156] = ("%06o\0 " % sum(raw[:512])).encode()
+    open(t, "wb").write(bytes(raw))
+    with pytest.raises(RuntimeError, match="Malformed tar archive"):
+        _pipe(1, lambda: fn.readers.webdataset(paths=[t], ext=["jpg"]))
+
+
+def test_reader_indexes_near_int64_max_are_refused(tmp_path, images):
+    from dali_amd import fn, tfrecord as tfrec
+    p = str(tmp_path / "a.tfrecord")
+    _write_tfrecord(p, [_example({"image": images[0]})])
+    open(p + ".idx", "w").write(f"{2**63 - 2} {2**63 - 2}\n")
+    with pytest.raises(RuntimeError, match="does not describe"):
+        _pipe(1, lambda: list(fn.readers.tfrecord(path=p, index_path=p + ".idx",
+                                                  features={"image": tfrec.FixedLenFeature((), tfrec.string, "")}).values()))
