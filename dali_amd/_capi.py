@@ -88,7 +88,7 @@ class ResampleDesc(C.Structure):
                 ("tile_w", C.c_int32), ("tile_h", C.c_int32), ("tiles_x", C.c_int32),
                 ("tiles_y", C.c_int32), ("wg_start", C.c_int32), ("out_dtype", C.c_int32),
                 ("out_layout", C.c_int32), ("normalize", C.c_int32), ("mirror", C.c_int32),
-                ("mean", C.c_float * 4), ("inv_std", C.c_float * 4), ("even_mask", C.c_uint32 * 8),
+                ("mean", C.c_float * 4), ("inv_std", C.c_float * 4), ("round_lo", C.c_int32 * 4), ("round_hi", C.c_int32 * 4),
                 ("lds_bytes", C.c_int32), ("staged", C.c_int32), ("table_off", C.c_int64),
                 ("tab_start", C.c_int32), ("use_lut", C.c_int32), ("filter_kind", C.c_int32 * 2),
                 ("in_dtype", C.c_int32), ("unrounded", C.c_int32), ("generic", C.c_int32), ("round_lanes", C.c_int32),

@@ -173,6 +173,11 @@ struct Epilogue {
 // lut[c][v] = fp16((v - mean[c]) * inv_std[c]), ties away: the fused epilogue of an fp16 output is one look-up, the
 // rounded u8 value being the index.
 struct TableLayout { int xi, xc, yi, yc, lut, words; };
+// does output column x of an H-last pass round half to even?  (descriptor regions, see daliamdResampleDesc)
+__host__ __device__ inline bool RoundsEven(const daliamdResampleDesc &d, int x) {
+  return (x >= d.round_lo[0] && x < d.round_hi[0]) || (x >= d.round_lo[1] && x < d.round_hi[1]) ||
+         (x >= d.round_lo[2] && x < d.round_hi[2]) || (x >= d.round_lo[3] && x < d.round_hi[3]);
+}
 __host__ __device__ inline TableLayout MakeTableLayout(const daliamdResampleDesc &d) {
   TableLayout l;
   l.xi = 0;
@@ -203,7 +208,8 @@ struct TileRec {
   int32_t ox0, oy0, tw, th;
   int32_t TW, TH, sup_x, sup_y;
   int32_t ex, ey, out_w, out_h;
-  int32_t flags, channels, rowlen, reserved;
+  int32_t flags, channels, rowlen;
+  uint32_t even_bits;   // bit x: column ox0 + x of an H-last pass rounds half to even (TW <= 32)
 };
 static_assert(sizeof(TileRec) == 128, "layout");
 enum { kRecVFirst = 1, kRecStaged = 2, kRecUseLut = 4, kRecPrefetch = 8, kRecInBounds = 16 };
@@ -277,7 +283,8 @@ __device__ void MakeTileRec(const daliamdResampleDesc *descs, int ndesc, int til
   r.flags = (vfirst ? kRecVFirst : 0) | (staged ? kRecStaged : 0) | (d.use_lut ? kRecUseLut : 0) | (prefetch ? kRecPrefetch : 0) |
             (in_bounds ? kRecInBounds : 0);
   r.channels = C; r.rowlen = tw * C;
-  r.reserved = 0;
+  r.even_bits = 0;
+  for (int x = 0; x < tw; x++) r.even_bits |= (RoundsEven(d, ox0 + x) ? 1u : 0u) << x;
   *out = r;
 }
 
@@ -640,11 +647,10 @@ __global__ __launch_bounds__(kResampleThreads) __attribute__((amdgpu_waves_per_e
           const floatx2 *co = reinterpret_cast<const floatx2 *>(cx + x);
           const intx2 *xo = reinterpret_cast<const intx2 *>(xt + x);
           const int gx = ox0 + x, half_tw = TW >> 1;
-          const uint32_t em = d.even_mask[(gx >> 5) & 7] >> (gx & 31);   // gx is even: gx + 1 sits in the same word
+          const uint32_t em = r.even_bits >> x;   // the tile's rounding bits ride in its record (TW <= 32)
           const bool even0 = em & 1, even1 = (em >> 1) & 1;
-          // the tile's columns sit in one word of the mask (TW <= 32 divides ox0)
-          const uint32_t need = (tw >= 32 ? 0xffffffffu : (1u << tw) - 1u) << (ox0 & 31);
-          const bool tile_even = (d.even_mask[(ox0 >> 5) & 7] & need) == need;
+          const uint32_t need = tw >= 32 ? 0xffffffffu : (1u << tw) - 1u;
+          const bool tile_even = (r.even_bits & need) == need;
           const int nk = sup_x;
           for (int y = tid >> hw_log2; y < th; y += kResampleThreads >> hw_log2) {
             const float *trow = tmp + y * NB;
@@ -669,7 +675,7 @@ __global__ __launch_bounds__(kResampleThreads) __attribute__((amdgpu_waves_per_e
         const float *co = cx + x;
         const int *xo = xt + x;
         const int gx = ox0 + x;
-        const bool even = (d.even_mask[(gx >> 5) & 7] >> (gx & 31)) & 1;
+        const bool even = (r.even_bits >> x) & 1;
         for (int y = tid >> tw_log2; y < th; y += kResampleThreads >> tw_log2) {
           const float *trow = tmp + y * NB;
           float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
@@ -898,7 +904,7 @@ __global__ __launch_bounds__(256) void ResampleGenericKernel(const daliamdResamp
       const int sx = ClampI(xi[x] + k, 0, tmp_w - 1);
       acc += xc[(size_t)x * sup_x + k] * tmp[((size_t)y * tmp_w + sx) * C + c];
     }
-    even = (d.even_mask[(x >> 5) & 7] >> (x & 31)) & 1;
+    even = RoundsEven(d, x);
   } else {       // vertical pass; ResampleVert: 256-element tiles, SIMD body then scalar tail
     for (int k = 0; k < sup_y; k++) {
       const int sy = ClampI(yi[y] + k, 0, d.tmp_h - 1);
@@ -1079,33 +1085,31 @@ static int SetupOne(const daliamdResampleArgs &a, daliamdResampleDesc &d, int in
   d.lo[second] = roi_lo[second]; d.ext[second] = roi_hi[second] - roi_lo[second];
   d.origin[second] -= roi_lo[second];
 
-  // rounding mask for an H-last pass: columns inside the SSE2 16-lane groups round half-to-even
+  // rounding regions of an H-last pass: the reference's row loop runs over four column regions (left border, the
+  // overlap of both borders, regular, right border); inside each, whole groups of `round_lanes` columns take the SIMD
+  // store (half to even), the rest of the region the scalar tail (half away).  Any width.
+  for (int r = 0; r < 4; r++) d.round_lo[r] = d.round_hi[r] = 0;
   if (d.first_axis == 1) {
-    if (a.out_w <= 256) {
-      int ow = a.out_w, in_w = d.ext[0], sup = d.support[0];
-      std::vector<int> idx(ow);
-      float start = FilterStart(d.origin[0], d.scale[0], d.fanchor[0]);
-      for (int x = 0; x < ow; x++) { float f0; idx[x] = FirstTap(x, d.scale[0], start, &f0); }
-      bool flipped = idx[ow - 1] < idx[0];
-      int first_regular = 0, last_regular = ow - 1;
-      if (flipped) {
-        while (first_regular < ow && idx[first_regular] + sup > in_w) first_regular++;
-        while (last_regular >= 0 && idx[last_regular] < 0) last_regular--;
-      } else {
-        while (first_regular < ow && idx[first_regular] < 0) first_regular++;
-        while (last_regular >= 0 && idx[last_regular] + sup > in_w) last_regular--;
-      }
-      int bounds[5] = {0, std::min(first_regular, last_regular + 1), first_regular, last_regular + 1, ow};
-      int x = 0;
-      for (int r = 0; r < 4; r++) {
-        int ox1 = bounds[r + 1];
-        const int lanes = d.round_lanes;
-        for (; x + lanes <= ox1; x += lanes)
-          for (int l = 0; l < lanes; l++) d.even_mask[(x + l) >> 5] |= 1u << ((x + l) & 31);
-        for (; x < ox1; x++) {}
-      }
+    int ow = a.out_w, in_w = d.ext[0], sup = d.support[0];
+    float start = FilterStart(d.origin[0], d.scale[0], d.fanchor[0]);
+    auto first_tap = [&](int x) { float f0; return FirstTap(x, d.scale[0], start, &f0); };
+    bool flipped = first_tap(ow - 1) < first_tap(0);
+    int first_regular = 0, last_regular = ow - 1;
+    if (flipped) {
+      while (first_regular < ow && first_tap(first_regular) + sup > in_w) first_regular++;
+      while (last_regular >= 0 && first_tap(last_regular) < 0) last_regular--;
     } else {
-      for (int i = 0; i < 8; i++) d.even_mask[i] = 0xffffffffu;  // wide outputs: SIMD rounding everywhere
+      while (first_regular < ow && first_tap(first_regular) < 0) first_regular++;
+      while (last_regular >= 0 && first_tap(last_regular) + sup > in_w) last_regular--;
+    }
+    int bounds[5] = {0, std::min(first_regular, last_regular + 1), first_regular, last_regular + 1, ow};
+    int x = 0;
+    for (int r = 0; r < 4; r++) {
+      const int ox1 = bounds[r + 1], lanes = d.round_lanes;
+      d.round_lo[r] = x;
+      if (ox1 > x) x += (ox1 - x) / lanes * lanes;
+      d.round_hi[r] = x;
+      x = std::max(x, ox1);
     }
   }
 

@@ -308,7 +308,10 @@ typedef struct {
   int32_t wg_start;
   int32_t out_dtype, out_layout, normalize, mirror;
   float mean[4], inv_std[4];
-  uint32_t even_mask[8];     /* H-last: per output column, 1 = round half to even               */
+  /* H-last pass: output column x rounds half to even (the SIMD body of the reference's row loop) iff
+   * round_lo[r] <= x < round_hi[r] for one of the four regions r, half away from zero otherwise (its scalar tails);
+   * any output width (kernels/common/simd.h:53-56 vs core/convert.h:306-321) */
+  int32_t round_lo[4], round_hi[4];
   int32_t lds_bytes;
   int32_t staged;            /* 1: the tile's source window is staged in LDS; 0: read from global memory */
   /* per-sample tables in the workspace (first-tap indices and normalised coefficients of every output column and

@@ -236,3 +236,52 @@ def test_resize_operator_other_types_on_the_gpu():
             ref = O.resample_typed(im, out_hw, out_type=O.T_F32 if dtype is not None else None, roi=roi)
             got = out[i].as_cpu()
             assert got.dtype == ref.dtype and np.array_equal(got, ref), (dtype, i)
+
+
+def _tie_rich(rng, h, w):
+    """Pixels whose 2x antialiased down-scale (taps 1/8 3/8 3/8 1/8 per axis: results are multiples of 1/64) lands on
+    exact .5 ties in about one output out of 64 - what tells the SIMD store's half-to-even from the scalar tail's
+    half-away rounding."""
+    return rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+
+
+@pytest.mark.parametrize("case", [
+    ((512, 682), (256, 341), None),                  # the ImageNet validation shape, exact 2x: ties everywhere
+    ((512, 1500), (256, 750), None),                 # three times the old 256-column mask
+    ((520, 700), (256, 341), (4.0, 9.0, 516.0, 691.0)),        # ROI: clamped border regions on both sides
+    ((520, 700), (256, 341), (4.0, 691.0, 516.0, 9.0)),        # ... flipped
+    ((375, 500), (256, 341), None), ((480, 640), (256, 341), None),   # resize_shorter=256 of the usual ImageNet sizes
+    ((600, 1100), (300, 550), None),
+])
+def test_wide_outputs_round_in_the_reference_regions(case):
+    """Outputs wider than 256 columns with an H-last pass: columns in whole 16-lane groups of each region round half to
+    even, the tail columns of the regions half away (simd.h:53-56 vs convert.h:306-321) - bit for bit like the oracle,
+    and NOT like "half to even everywhere" (round 2's approximation for wide outputs) when the image has ties there."""
+    from dali_amd import backend as B
+    (h, w), osz, roi = case
+    rng = np.random.default_rng(h * 7 + w)
+    im = _tie_rich(rng, h, w)
+    rois = None if roi is None else [roi]
+    out = B.resample_batch([_to_dev(im, 16)], osz, rois=rois).cpu().numpy()[0]
+    ref, info = O.resample_u8(im, osz, roi=roi, return_info=True)
+    assert int(info[0]) == 1, "the case must take the vertical pass first (H-last)"
+    assert np.array_equal(out, ref), f"{np.argwhere(out != ref)[:5]}"
+    if (h, w) == (512, 682) or (h, w) == (512, 1500):
+        all_even = O.resample_u8(im, osz, roi=roi, round_mode=2)
+        assert (all_even != ref).any(), "the case holds no tie in a tail column: it would not have caught the old mask"
+        assert (out != all_even).any()
+
+
+def test_wide_fused_fp16_output_rounds_in_the_reference_regions():
+    """Same through the fused CMN epilogue (pixel pairs + look-up table): fn.resize -> crop_mirror_normalize shapes."""
+    from dali_amd import backend as B
+    from dali_amd import _capi as capi
+    rng = np.random.default_rng(77)
+    im = _tie_rich(rng, 512, 684)
+    mean, inv = O.cmn_norm_args([0.485 * 255, 0.456 * 255, 0.406 * 255], [0.229 * 255, 0.224 * 255, 0.225 * 255])
+    for mirror in (0, 1):
+        out = B.resample_batch([_to_dev(im, 16)], (256, 342), out_dtype=capi.FLOAT16, out_layout=capi.LAYOUT_CHW, mean=mean,
+                               inv_std=inv, mirror=np.array([mirror], np.uint8)).cpu().numpy()[0]
+        u8 = O.resample_u8(im, (256, 342))
+        ref = O.cmn_u8(u8, (0, 0), (256, 342), mirror=bool(mirror), mean=mean, inv_std=inv, dtype=O.F16)
+        assert np.array_equal(out.view(np.uint16), ref.view(np.uint16)), mirror
