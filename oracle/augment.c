@@ -19,9 +19,19 @@
  *
  * Must be compiled with -ffp-contract=off.  Where the reference calls an unqualified exp()/cos()/sin() on a float
  * (overload resolution depends on which headers its TU sees) this file evaluates in double and rounds to float;
- * the two choices differ in at most the last bit of a window / matrix coefficient.  PARITY UNPINNED for that bit:
- * the reference's own tests compare these operators with OpenCV / numpy under tolerances
- * (dali/test/python/operator_2/test_gaussian_blur.py, operator_1/test_color_twist.py), not bit-exactly.
+ * the two choices differ in at most the last bit of a window / matrix coefficient.
+ *
+ * PINS (tests/test_oracle_augment_pins.py, against the independent models of tests/independent_models.py - the ones
+ * the reference's own tests use, at its own bounds or tighter):
+ *   Gaussian windows   every (size, sigma) pair of gaussian_blur_params_test.cc:33-57 against OpenCV's published
+ *                      getGaussianKernel, 1e-7 per coefficient (that test's bound)
+ *   Gaussian blur      float64 reflect-101 convolution, <= 1 LSB (operator_1/test_gaussian_blur.py:134,164)
+ *   color twist / hsv  the numpy model of operator_1/test_color_twist.py:68-104, abs 1 / rel 1/512 (its bound)
+ *   warp affine        exact float64 bilinear sampling with the matrices of operator_2/test_warp.py:31-52,197, <= 1 LSB
+ *                      (the reference allows 8 against OpenCV's fixed-point interpolation, test_warp.py:236)
+ *   erase              numpy slice assignment, exact
+ * What stays unobservable here is the last-bit behaviour of a shipped DALI binary (libm version, contraction choices);
+ * the reference's own tests do not pin it either.
  */
 #include <math.h>
 #include <stdint.h>
