@@ -24,9 +24,10 @@ for W in ${WORKLOADS:-headline heavy_aug audio}; do
   for C in FETCH_SIZE WRITE_SIZE; do
     timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -- python $R/bench.py $PMCARGS > /dev/null 2> $OUT/pmc_$C.log
   done
-  python $R/tools/summarize_profiles.py $OUT $TAG$SUF $SUM
+  python $R/tools/summarize_profiles.py $OUT $TAG$SUF $SUM || { echo "collect_profiles: $W summary FAILED"; tail -5 $OUT/*.log; FAILED=1; }
   if [ $W != headline ]; then
     (cd $R && timeout 300 python bench.py --workload $W 2>/dev/null | tail -1 > $SUM/${TAG}_${W}_bench.json)
   fi
 done
 ls -la $SUM
+exit ${FAILED:-0}

@@ -27,6 +27,8 @@ def short(name):
 stats = glob.glob(os.path.join(prof, "stats", "**", "*kernel_stats.csv"), recursive=True)
 if stats:
     shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
+if not stats:
+    sys.exit(f"summarize_profiles: no *kernel_stats.csv under {prof}/stats - the rocprofv3 --stats pass failed (see stats.log)")
 res = defaultdict(dict)
 if stats:
     for r in csv.DictReader(open(stats[0])):
@@ -37,6 +39,9 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter:
                 acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    if not acc:
+        sys.exit(f"summarize_profiles: the --pmc {counter} pass left no counter rows under {prof}/pmc_{counter} "
+                 f"(see pmc_{counter}.log): refusing to write half a traffic file")
     for k, v in acc.items():
         res[k][f"{counter}_per_launch_KB"] = sum(v) / len(v)
 for k, d in res.items():
@@ -46,6 +51,12 @@ for k, d in res.items():
         d["write_bytes_per_launch"] = 1024 * d["WRITE_SIZE_per_launch_KB"]
     if "read_bytes_per_launch_corrected" in d and "write_bytes_per_launch" in d:
         d["hbm_bytes_per_launch"] = d["read_bytes_per_launch_corrected"] + d["write_bytes_per_launch"]
-json.dump({"note": __doc__, "kernels": res}, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
+missing = [k for k, d in res.items() if "avg_ns" in d and d.get("pct", 0) >= 1.0 and "hbm_bytes_per_launch" not in d]
+if missing:
+    sys.exit(f"summarize_profiles: no FETCH_SIZE + WRITE_SIZE pair for {missing}")
+regime = ("kernel_stats: the bench command as the driver runs it (two batches in flight: durations include the overlap "
+          "with the other stream's kernels); FETCH_SIZE / WRITE_SIZE: separate passes with ONE batch in flight, so that a "
+          "counter window holds exactly one kernel - bytes per launch do not depend on the overlap, durations do")
+json.dump({"note": __doc__, "regime": regime, "kernels": res}, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
 for k, d in sorted(res.items(), key=lambda kv: -kv[1].get("avg_ns", 0)):
     print(f"{k:40s} {d.get('avg_ns', 0) / 1e3:9.1f} us  hbm/launch {d.get('hbm_bytes_per_launch', float('nan')) / 1e6:10.1f} MB")
