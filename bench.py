@@ -8,16 +8,20 @@ kernel and the CPU baseline (BASELINE.json metric).
 
 Data set: 1024 synthetic ImageNet-like JPEGs per GPU = 4 distinct batches of 256 which the steps
 rotate through (the entropy decoder's time depends on the content, one batch would be one sample of it).
-One "step" = one pass of the hot path over one batch whose inputs are already resident in HBM:
-  JPEG entropy-coded segments (bytes)  ->  zero-fill + un-stuff + Huffman decode  [UnstuffKernel, HuffmanDecodeKernel]
-                                       ->  dequant + IDCT                         [JpegIdctKernel]
-                                       ->  chroma upsample + YCbCr->RGB           [JpegColorKernel]
-  host Philox crop windows + mirror bits (in the timed region, host side)
-                                       ->  fused resample + CMN                   [ResampleKernel]
-Descriptor-table construction and upload are inside the timed region; the header parse / scan analysis of the
-(static) synthetic batch is done once at start-up.  `--huffman host` benchmarks the hybrid variant instead: the
-coefficient blocks are produced once by the host entropy decoder and are the HBM-resident input (the host Huffman
-time is then reported as `e2e_host_huffman`, never inside `value`).
+One "step" = one iteration of the PRODUCT pipeline (dali_amd.Pipeline: the C++ executor, its stage threads, its ring of
+HIP streams) over one batch whose inputs are already resident in HBM:
+  readers.file(skip_cached_images=True)          the files are resident: the reader emits empty samples (loader.h:466-480)
+  decoders.image(device="mixed", cache_type="encoded")
+      JPEG entropy-coded segments in HBM  ->  un-stuff + Huffman decode + fused dequant / IDCT   [6 kernels]
+                                          ->  chroma upsample + YCbCr->RGB                        [JpegColorKernel]
+  random_resized_crop -> crop_mirror_normalize(mirror=coin_flip)      host Philox windows + mirror bits, ONE fused
+                                                                      resample + CMN launch        [ResampleKernel]
+Everything a step costs is inside the timed region: the stage threads' descriptor construction and upload, the random
+numbers, every launch, and the Python call that hands the batch out.  What is NOT in it is what the metric excludes by
+definition (inputs resident in HBM): the file reads, header parse / scan analysis and the H2D of the JPEG bytes happen in
+the set-up epoch that makes the data set resident; the end-to-end figures WITH them are the `e2e_pipeline*` entries.
+`--driver python` runs the round-1/2 bench instead (kernel library driven from Python, dali_amd/backend.py): kept for the
+kernel experiments (`--huffman host`, `--no-fused-idct`), never the headline.
 
 Multi-GPU: sample sharding exactly like readers.file(shard_id, num_shards): rank r owns the contiguous shard
 [r*1024, (r+1)*1024) of a world*1024-image data set (loader.cc:78-87); no collective on the data path ("scaling":
@@ -323,13 +327,120 @@ def e2e_pipeline(root, batch, device_id, iters=200, threads=None, roi_decode=Fal
                     "H2D of the JPEG bytes on a copy stream, all device stages, fp16 CHW batch on the device)"}
 
 
+def batch_statistics(enc_batches, device, count_symbols=True):
+    """Per distinct batch: what the algorithmic-byte formulas need - entropy-coded bytes,
+    coefficient count, pixels, image shapes - from the product's own parser; Huffman symbols counted exactly from the
+    host decoder's coefficients (set-up only)."""
+    import torch
+    from dali_amd import backend as B
+    stats = []
+    for enc in enc_batches:
+        plan = B.JpegBatchPlan(enc, out_pitch_align=16)
+        if not plan.analyze_scans().all():
+            raise SystemExit("bench: the synthetic batch must be baseline single-scan JPEG")
+        shapes = np.array([(int(plan.inf["height"][i]), int(plan.inf["width"][i])) for i in range(plan.n)], np.int32)
+        st = {"stream_bytes": float(plan.scan["ecs_length"].sum()), "coef_elems": float(plan.coef_elems),
+              "pixels": float((shapes[:, 0].astype(np.int64) * shapes[:, 1]).sum()), "shapes": shapes, "symbols": None}
+        if count_symbols:
+            coef = torch.empty(plan.coef_elems, dtype=torch.int16, pin_memory=True)
+            plan.entropy_decode(coef, num_threads=effective_cpu_count())
+            st["symbols"] = float(B.count_huffman_symbols(coef.to(device), plan.coef_elems))
+            del coef
+        stats.append(st)
+    return stats
+
+
+def resident_pipeline(root, batch, device_id, depth, threads, shard_id=0, num_shards=1, cache_mb=4096):
+    """The headline pipeline: configs[1] with the data set resident in HBM as encoded streams."""
+    from dali_amd import fn, types
+    from dali_amd.pipeline import Pipeline
+    pipe = Pipeline(batch_size=batch, num_threads=threads, device_id=device_id, seed=1234, prefetch_queue_depth=depth)
+    with pipe:
+        jpegs, labels = fn.readers.file(file_root=root, name="Reader", shard_id=shard_id, num_shards=num_shards,
+                                        stick_to_shard=True, skip_cached_images=True)
+        images = fn.decoders.image(jpegs, device="mixed", output_type=types.RGB, cache_size=cache_mb, cache_type="encoded")
+        crops = fn.random_resized_crop(images, size=[224, 224])
+        out = fn.crop_mirror_normalize(crops, dtype=types.FLOAT16, output_layout="CHW",
+                                       mean=[0.485 * 255, 0.456 * 255, 0.406 * 255],
+                                       std=[0.229 * 255, 0.224 * 255, 0.225 * 255],
+                                       mirror=fn.random.coin_flip(probability=0.5))
+        pipe.set_outputs(out, labels)
+    pipe.build()
+    return pipe
+
+
+def run_resident_pipeline(args, root, enc_all, device, dev_index, rank, world, local_world, barrier, dist):
+    """Times K iterations of the product pipeline on the resident data set.  Returns what the JSON line is built from."""
+    import torch
+    from dali_amd import _backend, backend as Bk
+    B, nb = args.batch, max(1, args.batches)
+    per_rank = nb * B
+    depth = max(1, args.inflight)
+    threads = max(2, effective_cpu_count() // max(1, local_world) * 3 // 4)
+    stats = batch_statistics([enc_all[b * B:(b + 1) * B] for b in range(nb)], device)
+    # (one cache per device AND process: twice the shard's file bytes is room to spare for its entropy-coded segments)
+    pipe = resident_pipeline(root, B, dev_index, depth, threads, shard_id=rank, num_shards=world,
+                             cache_mb=max(64, int(2 * sum(len(e) for e in enc_all) / 2**20)))
+    # ---- set-up, untimed: epochs until the shard is resident, then until the reader (which runs ahead of the decoder)
+    # has stopped reading files and every ring slot has seen every distinct batch
+    done = 0
+    t_setup = time.perf_counter()
+    while _backend.encoded_cache_stats(dev_index)["streams"] < per_rank and done < 64 * nb:
+        pipe.run()
+        done += 1
+    for _ in range((depth + 2) * nb):
+        pipe.run()
+        done += 1
+    before = _backend.encoded_cache_stats(dev_index)
+    t_setup = time.perf_counter() - t_setup
+    for _ in range(args.warmup):
+        pipe.run()
+        done += 1
+    kernel_timing(12 * (args.steps + depth + 2))      # events for every launch of the timed region, created now
+    kernel_timing(False)
+    kernel_timing()                                   # (drop whatever the set-up recorded)
+    barrier()
+    pipe.operator_host_times()                        # opens the host-time window
+    kernel_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pipe.run()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_timing(False)
+    host_times = pipe.operator_host_times()
+    after = _backend.encoded_cache_stats(dev_index)
+    times = kernel_timing()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if os.environ.get("BENCH_TEST_SINGLE_DEVICE") == "1" else device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if after["hits"] - before["hits"] < B * (args.steps - depth - 1) or after["misses"] != before["misses"]:
+        raise SystemExit(f"bench: the timed region was not served from the resident streams ({before} -> {after})")
+    # batches the timed steps covered: the reader is sequential over the shard, iteration i = batch i mod nb
+    covered = [stats[(done + k) % nb] for k in range(args.steps)]
+    mean = lambda key: float(np.mean([c[key] for c in covered]))  # noqa: E731
+    # crop windows: drawn by the product's generator over the same image shapes (bench seed; the operator inside the
+    # pipeline has its own seed from the pipeline's seed sequence - same distribution, other sample)
+    master = Bk.philox_state(1234)
+    res_bytes = []
+    for k in range(args.steps):
+        _, crops = Bk.random_crop_batch(master, covered[k]["shapes"])
+        master.ctr[1] += B
+        res_bytes.append(float(3 * (crops[:, 0].astype(np.int64) * crops[:, 1]).sum() + 6 * 224 * 224 * B))
+    return {"pipe": pipe, "elapsed": elapsed, "times": times, "host_times": host_times, "mean": mean, "depth": depth,
+            "resample_bytes": float(np.mean(res_bytes)), "threads": threads, "setup_s": t_setup,
+            "setup_iterations": done - args.warmup, "cache": after, "symbols": float(np.mean([c["symbols"] for c in covered]))}
+
+
 def kernel_timing(enable=None):
     """Library-side kernel timing (include/dali_amd_kernels.h: daliamdKernelTimingEnable / Report): every launch is
     bracketed by HIP events on its own stream.  enable=True/False switches it; None reads {kernel: (launches, avg_ms)}."""
     from dali_amd import _capi as capi
     lib = capi.kernels()
     if enable is not None:
-        lib.daliamdKernelTimingEnable(1 if enable else 0)
+        # True / False switch it; an int > 1 switches it on and creates the events of that many launches up front
+        lib.daliamdKernelTimingEnable(int(enable) if not isinstance(enable, bool) else (1 if enable else 0))
         return None
     need = lib.daliamdKernelTimingReport(None, 0)
     buf = C.create_string_buffer(need + 1)
@@ -590,12 +701,16 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end dali_amd.Pipeline legs")
     ap.add_argument("--e2e-batch", type=int, default=512, help="batch per GPU of the sharded end-to-end leg (configs[4])")
     ap.add_argument("--inflight", type=int, default=2,
-                    help="batches processed concurrently, each on its own HIP stream (executor prefetch depth)")
+                    help="batches in flight on the GPU, each on its own HIP stream = the executor's prefetch_queue_depth")
     ap.add_argument("--huffman", default="gpu", choices=["gpu", "host"],
                     help="gpu: the step starts from JPEG bytes in HBM (default); host: from host-decoded coefficient blocks")
     ap.add_argument("--no-fused-idct", action="store_true",
                     help="store the coefficients and run the stand-alone IDCT kernel (the GPU entropy decoder's default is "
                          "to dequantise + inverse-transform the blocks itself)")
+    ap.add_argument("--driver", default="pipeline", choices=["pipeline", "python"],
+                    help="pipeline (default): the headline is timed through dali_amd.Pipeline, the product's C++ executor, "
+                         "on a data set resident in HBM as encoded streams; python: the kernel library driven from "
+                         "dali_amd/backend.py (kernel experiments: --huffman host, --no-fused-idct)")
     ap.add_argument("--workload", default="imagenet", choices=["imagenet", "heavy_aug", "audio", "cpu"],
                     help="imagenet = the headline metric (default); heavy_aug / audio = configs[2] / configs[3] side benches; "
                          "cpu = configs[0], the train pipe on the CPU backend (no GPU needed)")
@@ -610,6 +725,8 @@ def main():
 
     if args.workload == "cpu":
         return bench_cpu_backend(args)
+    if args.driver == "pipeline" and (args.huffman != "gpu" or args.no_fused_idct):
+        args.driver = "python"     # the kernel experiments exist in the Python driver only
     B = args.batch
     nb = max(1, args.batches)
     inflight = max(1, min(args.inflight, nb))
@@ -645,64 +762,100 @@ def main():
     if args.workload == "audio":
         return bench_audio(args, device)
 
-    streams = [torch.cuda.Stream(device=device) for _ in range(inflight)]
-    paths = [HotPath(enc_all[b * B:(b + 1) * B], device, streams[b % inflight], huffman=args.huffman,
-                     fused_idct=not args.no_fused_idct, first_iteration=b) for b in range(nb)]
-    fused = paths[0].fused_idct
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for w in range(args.warmup):
-        paths[w % nb].step(advance=nb)
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(7)] for _ in range(args.steps)]
-    kev = None
-    if args.huffman == "gpu":
-        from dali_amd import backend as _backend
-        kev = [_backend.KernelEvents(len(_backend.HUFFMAN_KERNELS)) for _ in range(args.steps)]
-    resample_bytes = []
-    barrier()
-    for hp in paths:
-        hp.host_s = 0.0
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        hp = paths[(args.warmup + k) % nb]
-        _, crops = hp.step(record=ev[k], kernel_events=kev[k] if kev else None, advance=nb)
-        resample_bytes.append(hp.resample_bytes(crops))
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if single_device_test else device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from dali_amd.backend import HUFFMAN_KERNELS, huffman_algorithmic_bytes
+    root = None
+    pipe_info = None
+    if args.driver == "pipeline":
+        import tempfile
+        fused = True
+        # the data set directory of readers.file: one per job, every rank writes its shard (configs[4] layout)
+        root = (tempfile.mkdtemp(prefix="dali_amd_bench_") if world == 1 else
+                os.path.join(tempfile.gettempdir(), f"dali_amd_bench_shared_{os.environ.get('MASTER_PORT', '0')}"))
+        write_dataset(root, enc_all, first_index=rank * per_rank)
+        barrier()
+        r = run_resident_pipeline(args, root, enc_all, device, dev_index, rank, world, local_world, barrier, dist)
+        elapsed, inflight = r["elapsed"], r["depth"]
+        stream_bytes, coef_elems_mean, pixels_mean = r["mean"]("stream_bytes"), r["mean"]("coef_elems"), r["mean"]("pixels")
+        resample_bytes, symbols = [r["resample_bytes"]], r["symbols"]
+        algo = dict(huffman_algorithmic_bytes(stream_bytes, coef_elems_mean, B, True))
+        algo["JpegColorKernel"] = coef_elems_mean + 3 * pixels_mean          # planes in + RGB out
+        algo["ResampleKernel"] = r["resample_bytes"]
+        algo["ResampleTablesKernel"] = 0.0
+        kern = {k: (float(algo.get(k, 0.0)), ms) for k, (calls, ms) in r["times"].items()}
+        launches = {k: calls for k, (calls, ms) in r["times"].items()}
+        huffman_total_ms = float(sum(kern[k][1] for k in HUFFMAN_KERNELS if k in kern))
+        host_ms_per_step = r["host_times"].get("<device stage>", 0.0)
+        pipe_info = {"driver": "dali_amd.Pipeline (C++ executor), data set resident in HBM as encoded streams "
+                               "(decoders.image cache_type='encoded' + readers.file skip_cached_images)",
+                     "host_threads": r["threads"], "prefetch_queue_depth": r["depth"],
+                     "host_stage_ms_per_step": r["host_times"].get("<host stage>"),
+                     "device_stage_ms_per_step": r["host_times"].get("<device stage>"),
+                     "host_ms_per_operator": {k: v for k, v in r["host_times"].items() if not k.startswith("<")},
+                     "setup_s": r["setup_s"], "setup_iterations": r["setup_iterations"], "encoded_cache": r["cache"],
+                     "launches_timed": launches, "kernels": r["pipe"].executed_kernels()}
+        del r
+    else:
+        streams = [torch.cuda.Stream(device=device) for _ in range(inflight)]
+        paths = [HotPath(enc_all[b * B:(b + 1) * B], device, streams[b % inflight], huffman=args.huffman,
+                         fused_idct=not args.no_fused_idct, first_iteration=b) for b in range(nb)]
+        fused = paths[0].fused_idct
 
-    # per-kernel average durations from the events recorded inside the timed region; algorithmic bytes averaged over
-    # the same steps (the batches differ)
-    step_paths = [paths[(args.warmup + k) % nb] for k in range(args.steps)]
-    mean_of = lambda f: float(np.mean([f(hp) for hp in step_paths]))  # noqa: E731
-    ms_idct = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
-    ms_color = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
-    ms_resample = float(np.mean([e[3].elapsed_time(e[4]) for e in ev]))
-    bytes_idct, bytes_color = mean_of(lambda hp: hp.bytes_idct), mean_of(lambda hp: hp.bytes_color)
-    stream_bytes = mean_of(lambda hp: hp.plan.stream_bytes) if args.huffman == "gpu" else None
-    kern = {
-        "JpegColorKernel": (bytes_color, ms_color),
-        "ResampleKernel": (float(np.mean(resample_bytes)), ms_resample),
-    }
-    if not fused:
-        kern["JpegIdctKernel"] = (bytes_idct, ms_idct)
-    if args.huffman == "gpu":
-        # per-kernel durations of the entropy decoder (events recorded between its launches, same stream)
-        per = np.array([ke.elapsed_ms() for ke in kev]).mean(0)
-        sb, ce = stream_bytes, mean_of(lambda hp: hp.plan.coef_elems)
-        symbols = float(np.mean([hp.symbols for hp in paths]))
-        from dali_amd.backend import HUFFMAN_KERNELS, huffman_algorithmic_bytes
-        huff_bytes = huffman_algorithmic_bytes(sb, ce, B, fused)
-        for name, ms in zip(HUFFMAN_KERNELS, per):
-            kern[name] = (huff_bytes[name], float(ms))
-        huffman_total_ms = float(np.mean([e[5].elapsed_time(e[6]) for e in ev]))
+        for w in range(args.warmup):
+            paths[w % nb].step(advance=nb)
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(7)] for _ in range(args.steps)]
+        kev = None
+        if args.huffman == "gpu":
+            from dali_amd import backend as _backend
+            kev = [_backend.KernelEvents(len(_backend.HUFFMAN_KERNELS)) for _ in range(args.steps)]
+        resample_bytes = []
+        barrier()
+        for hp in paths:
+            hp.host_s = 0.0
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            hp = paths[(args.warmup + k) % nb]
+            _, crops = hp.step(record=ev[k], kernel_events=kev[k] if kev else None, advance=nb)
+            resample_bytes.append(hp.resample_bytes(crops))
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if single_device_test else device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+
+        # per-kernel average durations from the events recorded inside the timed region; algorithmic bytes averaged over
+        # the same steps (the batches differ)
+        step_paths = [paths[(args.warmup + k) % nb] for k in range(args.steps)]
+        mean_of = lambda f: float(np.mean([f(hp) for hp in step_paths]))  # noqa: E731
+        ms_idct = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+        ms_color = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+        ms_resample = float(np.mean([e[3].elapsed_time(e[4]) for e in ev]))
+        bytes_idct, bytes_color = mean_of(lambda hp: hp.bytes_idct), mean_of(lambda hp: hp.bytes_color)
+        stream_bytes = mean_of(lambda hp: hp.plan.stream_bytes) if args.huffman == "gpu" else None
+        kern = {
+            "JpegColorKernel": (bytes_color, ms_color),
+            "ResampleKernel": (float(np.mean(resample_bytes)), ms_resample),
+        }
+        if not fused:
+            kern["JpegIdctKernel"] = (bytes_idct, ms_idct)
+        if args.huffman == "gpu":
+            # per-kernel durations of the entropy decoder (events recorded between its launches, same stream)
+            per = np.array([ke.elapsed_ms() for ke in kev]).mean(0)
+            sb, ce = stream_bytes, mean_of(lambda hp: hp.plan.coef_elems)
+            symbols = float(np.mean([hp.symbols for hp in paths]))
+            huff_bytes = huffman_algorithmic_bytes(sb, ce, B, fused)
+            for name, ms in zip(HUFFMAN_KERNELS, per):
+                kern[name] = (huff_bytes[name], float(ms))
+            huffman_total_ms = float(np.mean([e[5].elapsed_time(e[6]) for e in ev]))
+        coef_elems_mean, pixels_mean = mean_of(lambda hp: hp.plan.coef_elems), mean_of(lambda hp: hp.pixels)
+        host_ms_per_step = 1e3 * sum(hp.host_s for hp in paths) / args.steps
+        huffman_s = float(np.mean([hp.huffman_s for hp in paths]))
+        del paths, step_paths, hp
     dominant = max(kern, key=lambda k: kern[k][1])
     ach = kern[dominant][0] / (kern[dominant][1] * 1e-3) / 1e9
     traffic, traffic_src = measured_traffic(dominant)
@@ -714,8 +867,7 @@ def main():
         step_bytes = float(sum(v[0] for v in kern.values()))
         copy_ceiling = measured_copy_ceiling(device)
         # SURVEY.md 8(d) end-to-end formula: 6 P (coefficients in, RGB out) + 3 s P + 6 O (fused resample + CMN)
-        post_entropy = (2 * mean_of(lambda hp: hp.plan.coef_elems) + 3 * mean_of(lambda hp: hp.pixels) +
-                        float(np.mean(resample_bytes)))
+        post_entropy = 2 * coef_elems_mean + 3 * pixels_mean + float(np.mean(resample_bytes))
         nk = len(HUFFMAN_KERNELS) if args.huffman == "gpu" else 0
         line = {
             "metric": "images/sec JPEG->RRC->CMN 224^2 b256 per GPU",
@@ -732,10 +884,10 @@ def main():
                        "huffman": args.huffman, "fused_dequant_idct": fused, "batches_in_flight": inflight,
                        "distinct_batches": nb, "dataset_images_per_gpu": per_rank, "dataset_generation_s": t_gen,
                        f"huffman_ms_per_batch({nk} kernels)": huffman_total_ms if args.huffman == "gpu" else None,
-                       "host_ms_per_step": 1e3 * sum(hp.host_s for hp in paths) / args.steps,
+                       "host_ms_per_step": host_ms_per_step,
                        "jpeg_bytes_per_batch": stream_bytes,
                        "global_batch": world * B, "parallelism": f"shard{world} (shard_id/num_shards, no collective)",
-                       "pixels_per_batch": mean_of(lambda hp: hp.pixels)},
+                       "pixels_per_batch": pixels_mean, "driver": args.driver},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "measured_copy_ceiling_GBps": copy_ceiling, "frac_of_measured_ceiling": ach / copy_ceiling,
@@ -759,21 +911,26 @@ def main():
             "entropy_decode": ({"symbols_per_batch": symbols, "symbols_per_s": symbols / (huffman_total_ms * 1e-3),
                                 "bitstream_GBps": stream_bytes / (huffman_total_ms * 1e-3) / 1e9}
                                if args.huffman == "gpu" else None),
-            "e2e_host_huffman": {"huffman_s_per_batch": float(np.mean([hp.huffman_s for hp in paths])),
-                                 "host_threads": effective_cpu_count(),
-                                 "note": "host entropy decoder on the same batches (one pass, thread pool): the CPU half "
-                                         "of the hybrid variant (--huffman host); not part of `value`"},
         }
-    del paths, step_paths, hp
+        if pipe_info:
+            line["config"]["pipeline"] = pipe_info
+        else:
+            line["e2e_host_huffman"] = {"huffman_s_per_batch": huffman_s, "host_threads": effective_cpu_count(),
+                                        "note": "host entropy decoder on the same batches (one pass, thread pool): the "
+                                                "CPU half of the hybrid variant (--huffman host); not part of `value`"}
+    pipe_info = None
+    import gc
+    gc.collect()          # the headline pipeline (and with it the encoded-stream cache of the device) goes away here
     torch.cuda.empty_cache()
 
     if not args.no_e2e:
         import shutil
         import tempfile
         if world == 1:
-            root = tempfile.mkdtemp(prefix="dali_amd_bench_")
-            try:
+            if root is None:
+                root = tempfile.mkdtemp(prefix="dali_amd_bench_")
                 write_dataset(root, enc_all)
+            try:
                 line["e2e_pipeline"] = e2e_pipeline(root, B, local_rank)
                 line["e2e_pipeline_roi_decode"] = e2e_pipeline(root, B, local_rank, roi_decode=True)
                 line["e2e_pipeline_roi_decode"]["note"] = ("same, with decoders.image_random_crop -> resize -> "
@@ -789,10 +946,15 @@ def main():
             # BASELINE configs[4]: every rank runs the whole pipeline on its shard of the SHARED data set directory
             # (readers.file(shard_id=rank, num_shards=world)), batch 512 per GPU, host threads split between the
             # ranks of the node and pinned to their GPU's NUMA node (set_affinity)
-            root = os.path.join(tempfile.gettempdir(), f"dali_amd_bench_shared_{os.environ.get('MASTER_PORT', '0')}")
-            write_dataset(root, enc_all, first_index=rank * per_rank)
-            barrier()
+            if root is None:
+                root = os.path.join(tempfile.gettempdir(), f"dali_amd_bench_shared_{os.environ.get('MASTER_PORT', '0')}")
+                write_dataset(root, enc_all, first_index=rank * per_rank)
+                barrier()
             threads = max(2, effective_cpu_count() // max(1, local_world))
+            if rank == 0:
+                print(f"bench: {local_world} ranks share {effective_cpu_count()} usable host cores: {threads} worker threads "
+                      f"per rank" + (" - fewer than 4: the end-to-end leg will be host-bound" if threads < 4 else ""),
+                      file=sys.stderr)
             res = e2e_pipeline(root, args.e2e_batch, dev_index, iters=100, threads=threads, shard_id=rank,
                                num_shards=world, sync=barrier, set_affinity=True)
             t = torch.tensor([res["elapsed_s"]], dtype=torch.float64, device="cpu" if single_device_test else device)
@@ -806,6 +968,11 @@ def main():
                                f"{res['batch']}/GPU, {threads} host threads per rank, set_affinity=True; barrier + max over ranks")
                 line["e2e_pipeline_sharded"] = res
                 shutil.rmtree(root, ignore_errors=True)
+    if args.no_e2e and root is not None:
+        import shutil
+        barrier()
+        if rank == 0:
+            shutil.rmtree(root, ignore_errors=True)
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(enc_all[:B])

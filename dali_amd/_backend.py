@@ -131,10 +131,19 @@ class OpSpec:
         self._lib.daliamdOpSpecAddArgumentInput(self._h, arg.encode(), tensor_name.encode())
 
 
+def encoded_cache_stats(device_id=0):
+    """Encoded-stream cache of the device (decoders.image(cache_type="encoded")): resident streams, bytes used, lookups
+    that hit / missed so far."""
+    out = (C.c_int64 * 4)()
+    check(_lib().daliamdEncodedCacheStats(int(device_id), out))
+    return dict(streams=int(out[0]), bytes_used=int(out[1]), hits=int(out[2]), misses=int(out[3]))
+
+
 class BackendPipeline:
     def __init__(self, batch_size, num_threads, device_id, seed, prefetch_queue_depth, exec_async, set_affinity=False):
         self._lib = _lib()
         self.device_id = max(0, int(device_id))
+        self.generation = 0      # of the outputs currently handed out (TensorLists fetch their sample tables lazily)
         self._h = self._lib.daliamdPipelineCreate(batch_size, num_threads, device_id, seed, prefetch_queue_depth,
                                                   1 if exec_async else 0)
         if not self._h:
@@ -159,6 +168,16 @@ class BackendPipeline:
                 out[k] = float(v)
         return out
 
+    def operator_host_times(self):
+        """{operator instance name: host ms per iteration on its stage thread} since the last call (+ the "<host stage>",
+        "<device stage>", "<slot wait>" sums and "<iterations>"); resets the window."""
+        out = {}
+        for line in _string_out(self._lib.daliamdPipelineOperatorHostTimes, C.c_void_p(self._h)).split("\n"):
+            if line:
+                k, v = line.rsplit("\t", 1)
+                out[k] = float(v)
+        return out
+
     def add_operator(self, spec, name):
         check(self._lib.daliamdPipelineAddOperator(self._h, spec._h, name.encode()))
 
@@ -172,6 +191,7 @@ class BackendPipeline:
 
     def outputs(self):
         n = C.c_int(0)
+        self.generation += 1
         check(self._lib.daliamdPipelineOutputs(self._h, C.byref(n)))
         return n.value
 

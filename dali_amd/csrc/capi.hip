@@ -27,21 +27,48 @@ struct TimedLaunch { const char *name; hipEvent_t start, stop; };
 std::atomic<int> g_timing_on{0};
 std::mutex g_timing_mu;
 std::vector<TimedLaunch> g_timed;
+std::vector<hipEvent_t> g_event_pool;   // events handed back by the report: a timed launch costs two records, no creation
+hipEvent_t TakeEvent() {
+  {
+    std::lock_guard<std::mutex> lk(g_timing_mu);
+    if (!g_event_pool.empty()) {
+      hipEvent_t e = g_event_pool.back();
+      g_event_pool.pop_back();
+      return e;
+    }
+  }
+  hipEvent_t e = nullptr;
+  return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+}
 }  // namespace
 
 KernelTimer::KernelTimer(const char *name, hipStream_t stream) : name_(name), stream_(stream) {
   if (!g_timing_on.load(std::memory_order_relaxed)) return;
-  if (hipEventCreate(&start_) != hipSuccess) { start_ = nullptr; return; }
-  (void)hipEventRecord(start_, stream_);
+  start_ = TakeEvent();
+  if (start_) (void)hipEventRecord(start_, stream_);
 }
 KernelTimer::~KernelTimer() {
   if (!start_) return;
-  hipEvent_t stop = nullptr;
-  if (hipEventCreate(&stop) != hipSuccess) { (void)hipEventDestroy(start_); return; }
-  (void)hipEventRecord(stop, stream_);
+  hipEvent_t stop = TakeEvent();
+  if (stop) (void)hipEventRecord(stop, stream_);
   std::lock_guard<std::mutex> lk(g_timing_mu);
-  if (g_timed.size() < (1u << 20)) g_timed.push_back({name_, start_, stop});
-  else { (void)hipEventDestroy(start_); (void)hipEventDestroy(stop); }
+  if (stop && g_timed.size() < (1u << 20)) {
+    g_timed.push_back({name_, start_, stop});
+  } else {
+    g_event_pool.push_back(start_);
+    if (stop) g_event_pool.push_back(stop);
+  }
+}
+// events for `launches` timed launches, created ahead of a measurement so that none is created inside it
+void ReserveTimingEvents(int launches) {
+  std::vector<hipEvent_t> fresh;
+  for (int i = 0; i < 2 * launches; i++) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) break;
+    fresh.push_back(e);
+  }
+  std::lock_guard<std::mutex> lk(g_timing_mu);
+  g_event_pool.insert(g_event_pool.end(), fresh.begin(), fresh.end());
 }
 }  // namespace daliamd
 
@@ -100,6 +127,8 @@ daliamdResult_t daliamdDevicePciBusId(int device_id, char *bus_id, int len) {
 }
 
 void daliamdKernelTimingEnable(int on) {
+  // on > 1: also set aside the events of `on` timed launches now (none is created while the measurement runs)
+  if (on > 1) daliamd::ReserveTimingEvents(on);
   daliamd::g_timing_on.store(on ? 1 : 0);
 }
 // "name\tlaunches\tavg_ms\n" per kernel for the launches recorded since the last report (which it consumes); waits for
@@ -120,8 +149,13 @@ int daliamdKernelTimingReport(char *buf, int len) {
       a.first++;
       a.second += ms;
     }
-    (void)hipEventDestroy(t.start);
-    (void)hipEventDestroy(t.stop);
+  }
+  {
+    std::lock_guard<std::mutex> lk2(daliamd::g_timing_mu);
+    for (auto &t : take) {
+      daliamd::g_event_pool.push_back(t.start);
+      daliamd::g_event_pool.push_back(t.stop);
+    }
   }
   std::string out;
   for (auto &kv : acc)

@@ -1002,19 +1002,39 @@ static daliamdResult_t LaunchHuffman(daliamdStream_t stream, const daliamdJpegHu
   const int seg_grid = XcdGrid(num_segments);
   int e = 0;
   auto mark = [&]() -> hipError_t { return events ? hipEventRecord((hipEvent_t)events[e++], s) : hipSuccess; };
+  // (each launch also sits in a KernelTimer scope: daliamdKernelTimingEnable times the product path's launches
+  // by name; `events` is the explicit variant of the same thing for callers that bring their own events)
   DALIAMD_HIP_CHECK(mark());
-  hipLaunchKernelGGL(PrepareKernel, dim3(num_tiles + n), dim3(kTileThreads), 0, s, descs_dev, n, num_tiles);
+  {
+    KernelTimer timer("PrepareKernel", s);
+    hipLaunchKernelGGL(PrepareKernel, dim3(num_tiles + n), dim3(kTileThreads), 0, s, descs_dev, n, num_tiles);
+  }
   DALIAMD_HIP_CHECK(mark());
-  hipLaunchKernelGGL(UnstuffScatterKernel, dim3(num_tiles), dim3(kTileThreads), 0, s, descs_dev, n);
+  {
+    KernelTimer timer("UnstuffScatterKernel", s);
+    hipLaunchKernelGGL(UnstuffScatterKernel, dim3(num_tiles), dim3(kTileThreads), 0, s, descs_dev, n);
+  }
   DALIAMD_HIP_CHECK(mark());
-  hipLaunchKernelGGL(SyncKernel, dim3(seg_grid), dim3(kSegThreads), 0, s, descs_dev, n, num_segments);
+  {
+    KernelTimer timer("SyncKernel", s);
+    hipLaunchKernelGGL(SyncKernel, dim3(seg_grid), dim3(kSegThreads), 0, s, descs_dev, n, num_segments);
+  }
   DALIAMD_HIP_CHECK(mark());
-  hipLaunchKernelGGL(PropagateKernel, dim3(n), dim3(kSegThreads), 0, s, descs_dev);
+  {
+    KernelTimer timer("PropagateKernel", s);
+    hipLaunchKernelGGL(PropagateKernel, dim3(n), dim3(kSegThreads), 0, s, descs_dev);
+  }
   DALIAMD_HIP_CHECK(mark());
-  hipLaunchKernelGGL(DcKernel, dim3(seg_grid), dim3(kDcThreads), 0, s, descs_dev, n, num_segments);
+  {
+    KernelTimer timer("DcKernel", s);
+    hipLaunchKernelGGL(DcKernel, dim3(seg_grid), dim3(kDcThreads), 0, s, descs_dev, n, num_segments);
+  }
   DALIAMD_HIP_CHECK(mark());
-  hipLaunchKernelGGL(BlockKernel, dim3(XcdGrid(num_block_workgroups)), dim3(kBlockThreads), 0, s, descs_dev, n,
-                     num_block_workgroups);
+  {
+    KernelTimer timer("BlockKernel", s);
+    hipLaunchKernelGGL(BlockKernel, dim3(XcdGrid(num_block_workgroups)), dim3(kBlockThreads), 0, s, descs_dev, n,
+                       num_block_workgroups);
+  }
   DALIAMD_HIP_CHECK(mark());
   DALIAMD_HIP_CHECK(hipGetLastError());
   return DALIAMD_SUCCESS;

@@ -7,6 +7,7 @@
 #include "host_common.h"
 #include <dlfcn.h>
 
+#include "image_cache.h"
 #include "pipeline.h"
 
 using namespace daliamd_host;
@@ -180,6 +181,26 @@ API int daliamdPipelineOperatorTimes(void *h, char *buf, int len) {
     for (auto &kv : static_cast<PipelineHandle *>(h)->pipe->OperatorDeviceTimesMs()) s += kv.first + "\t" + std::to_string(kv.second) + "\n";
   });
   return CopyOut(s, buf, len);
+}
+// "name\tms\n": host milliseconds per iteration of every operator (SetupImpl + RunImpl on its stage thread) since the last
+// call, then "<host stage>", "<device stage>", "<slot wait>" and "<iterations>"; the call resets the window
+API int daliamdPipelineOperatorHostTimes(void *h, char *buf, int len) {
+  static thread_local std::string s;   // (the two-call protocol - size, then contents - must see ONE snapshot)
+  if (!buf || len <= 0) {
+    s.clear();
+    Guard([&] {
+      for (auto &kv : static_cast<PipelineHandle *>(h)->pipe->OperatorHostTimesMs()) s += kv.first + "\t" + std::to_string(kv.second) + "\n";
+    });
+  }
+  return CopyOut(s, buf, len);
+}
+// {streams resident, bytes used, lookups that hit, lookups that missed} of the encoded-stream cache of the device
+// (decoders.image(cache_type="encoded")); zeros when there is none
+API int daliamdEncodedCacheStats(int device_id, int64_t *out4) {
+  return Guard([&] {
+    out4[0] = out4[1] = out4[2] = out4[3] = 0;
+    if (auto c = StreamCache::Find(device_id)) c->Stats(out4);
+  });
 }
 API void daliamdPipelineDestroy(void *h) { delete static_cast<PipelineHandle *>(h); }
 API int64_t daliamdPipelineSeed(void *h) { return static_cast<PipelineHandle *>(h)->pipe->seed(); }

@@ -110,6 +110,17 @@ std::shared_ptr<ImageCache> ImageCache::Get(int device_id, const Params &params)
   return c;
 }
 
+std::shared_ptr<ImageCache> ImageCache::Find(int device_id) {
+  std::lock_guard<std::mutex> g(g_factory_mutex);
+  auto it = g_caches.find(device_id);
+  return it == g_caches.end() ? nullptr : it->second.cache.lock();
+}
+
+bool ImageCache::IsCached(const std::string &key) const {
+  std::lock_guard<std::mutex> g(m_);
+  return entries_.count(key) != 0;
+}
+
 ImageCache::ImageCache(const Params &params) : params_(params), policy_(params.type, params.size, params.threshold) {
   void *p = nullptr;
   KCHECK(daliamdMalloc(&p, std::max<size_t>(params.size, 256)));
@@ -209,6 +220,137 @@ void ImageCache::PrintStats() const {
     out << std::endl;
   }
   out << "#################### END   STATS ####################" << std::endl;
+}
+
+// ------------------------------------------------------------------------------------------ encoded streams
+namespace {
+struct StreamInstance { std::weak_ptr<StreamCache> cache; size_t bytes; };
+std::map<int, StreamInstance> g_stream_caches;
+}  // namespace
+
+std::shared_ptr<StreamCache> StreamCache::Get(int device_id, size_t bytes, bool debug) {
+  std::lock_guard<std::mutex> g(g_factory_mutex);
+  auto it = g_stream_caches.find(device_id);
+  if (it != g_stream_caches.end()) {
+    if (auto c = it->second.cache.lock()) {
+      DALI_ENFORCE(it->second.bytes == bytes, "Encoded-stream cache for device ", device_id,
+                   " was already initialized with another size");
+      return c;
+    }
+  }
+  std::shared_ptr<StreamCache> c(new StreamCache(bytes, debug));
+  g_stream_caches[device_id] = {c, bytes};
+  return c;
+}
+
+std::shared_ptr<StreamCache> StreamCache::Find(int device_id) {
+  std::lock_guard<std::mutex> g(g_factory_mutex);
+  auto it = g_stream_caches.find(device_id);
+  return it == g_stream_caches.end() ? nullptr : it->second.cache.lock();
+}
+
+StreamCache::StreamCache(size_t bytes, bool debug) : size_(bytes), debug_(debug) {
+  void *p = nullptr;
+  KCHECK(daliamdMalloc(&p, std::max<size_t>(bytes, 256)));
+  blob_ = static_cast<uint8_t *>(p);
+}
+
+StreamCache::~StreamCache() {
+  if (debug_)
+    fprintf(stderr, "[dali_amd] encoded-stream cache: %zu streams, %.1f of %.1f MB used%s, %lld hits, %lld misses\n",
+            entries_.size(), tail_ / 1048576.0, size_ / 1048576.0, full_ ? " (full)" : "", (long long)hits_,
+            (long long)misses_);
+  entries_.clear();
+  if (blob_) daliamdFree(blob_);
+}
+
+bool StreamCache::IsCached(const std::string &key) const {
+  std::lock_guard<std::mutex> g(m_);
+  return entries_.count(key) != 0;
+}
+
+int StreamCache::Lookup(const std::vector<std::string> &keys, const std::vector<uint8_t> &skip,
+                        std::vector<std::shared_ptr<const Record>> *out, daliamdStream_t stream) {
+  int found = 0;
+  const ImageCache::Fence *waited = nullptr;  // a batch is usually behind ONE fence: wait for it once
+  std::lock_guard<std::mutex> g(m_);
+  for (size_t i = 0; i < out->size(); i++) {
+    (*out)[i].reset();
+    if (i >= keys.size() || keys[i].empty() || (i < skip.size() && skip[i])) continue;
+    auto it = entries_.find(keys[i]);
+    if (it == entries_.end()) { misses_++; continue; }
+    Slot &s = it->second;
+    if (s.fence && s.fence.get() != waited) {
+      if (!s.fence->done) {
+        int done = 0;
+        KCHECK(daliamdEventQuery(s.fence->event, &done));
+        s.fence->done = done != 0;
+      }
+      if (!s.fence->done) {
+        KCHECK(daliamdStreamWaitEvent(stream, s.fence->event));
+        waited = s.fence.get();
+      }
+    }
+    if (s.fence && s.fence->done) s.fence.reset();
+    (*out)[i] = s.rec;
+    found++;
+  }
+  hits_ += found;
+  return found;
+}
+
+uint8_t *StreamCache::Reserve(const std::string &key, size_t bytes) {
+  if (key.empty() || full_) return nullptr;
+  // (segments start at 64-byte multiples and own 64 bytes of slack behind their last byte: the kernels read whole
+  // 16-byte chunks)
+  const size_t stored = ((bytes + 64 + 63) / 64) * 64;
+  std::lock_guard<std::mutex> g(m_);
+  if (entries_.count(key) || pending_.count(key)) return nullptr;
+  if (size_ - tail_ < stored) {
+    full_ = true;
+    return nullptr;
+  }
+  uint8_t *at = blob_ + tail_;
+  tail_ += stored;
+  pending_[key] = at;
+  return at;
+}
+
+void StreamCache::Commit(const std::vector<std::string> &keys, const std::vector<const daliamdJpegInfo *> &infos,
+                         const std::vector<const daliamdJpegScan *> &scans, daliamdStream_t stream) {
+  if (keys.empty()) return;
+  auto fence = std::make_shared<ImageCache::Fence>();
+  KCHECK(daliamdEventCreate(&fence->event, 0));
+  KCHECK(daliamdEventRecord(fence->event, stream));
+  // (records are built outside the lock: 3 KB of tables each)
+  std::vector<std::shared_ptr<Record>> recs(keys.size());
+  for (size_t k = 0; k < keys.size(); k++) {
+    recs[k] = std::make_shared<Record>();
+    recs[k]->info = *infos[k];
+    recs[k]->scan = *scans[k];
+  }
+  std::lock_guard<std::mutex> g(m_);
+  for (size_t k = 0; k < keys.size(); k++) {
+    auto it = pending_.find(keys[k]);
+    if (it == pending_.end()) continue;
+    recs[k]->ecs = it->second;
+    entries_[keys[k]] = Slot{recs[k], fence};
+    pending_.erase(it);
+  }
+}
+
+void StreamCache::Invalidate(const std::string &key) {
+  std::lock_guard<std::mutex> g(m_);
+  entries_.erase(key);   // (the space is not reclaimed)
+  pending_.erase(key);
+}
+
+bool DecoderCacheHolds(int device_id, const std::string &key) {
+  if (auto c = ImageCache::Find(device_id))
+    if (c->IsCached(key)) return true;
+  if (auto c = StreamCache::Find(device_id))
+    if (c->IsCached(key)) return true;
+  return false;
 }
 
 }  // namespace daliamd_host

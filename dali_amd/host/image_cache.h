@@ -23,6 +23,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "dali_amd_host.h"
 #include "dali_amd_kernels.h"
 
 namespace daliamd_host {
@@ -81,6 +82,9 @@ class ImageCache {
 
   // the cache of `device_id`, shared by every decoder instance on that device (all must ask for the same parameters)
   static std::shared_ptr<ImageCache> Get(int device_id, const Params &params);
+  // the live cache of the device, if any operator holds one (readers: `skip_cached_images`, loader.h:466-480)
+  static std::shared_ptr<ImageCache> Find(int device_id);
+  bool IsCached(const std::string &key) const;
   ~ImageCache();
 
   // A committed entry.  Makes `stream` wait for the entry's write when that may still be in flight.
@@ -104,6 +108,63 @@ class ImageCache {
   std::unordered_map<std::string, Entry> entries_, pending_;
   std::map<std::string, Stats> stats_;
 };
+
+// Encoded-stream cache: `cache_type="encoded"` - an MI355X extension of the reference's decoder cache.
+//
+// What stays resident is not the decoded image but everything the GPU entropy decoder needs to decode it again: the
+// entropy-coded segment of the JPEG (in one HBM blob) and the parse results (header fields, scan analysis with the
+// Huffman / quantisation tables; host memory).  A whole ImageNet shard's JPEG bytes fit in a fraction of the 288 GB
+// of one MI355X (the full training set is ~140 GB), seven times less than its decoded pixels.  From the second epoch
+// on a sample costs no file read (readers: `skip_cached_images`), no header parse, no staging copy and no
+// host->device transfer - the decode itself still runs, so region-of-interest decoding and everything behind the
+// decoder see fresh work every epoch.  Only streams the GPU entropy decoder takes are kept.
+// Same rules as the decoded cache: one per device, fill until full, nothing is evicted, entries become visible when
+// the copy that fills them has been enqueued (readers on other streams wait for its event).
+class StreamCache {
+ public:
+  struct Record {
+    const uint8_t *ecs = nullptr;  // the entropy-coded segment in the blob (device), scan.ecs_length bytes
+    daliamdJpegInfo info;
+    daliamdJpegScan scan;
+  };
+  static std::shared_ptr<StreamCache> Get(int device_id, size_t bytes, bool debug);
+  static std::shared_ptr<StreamCache> Find(int device_id);
+  ~StreamCache();
+
+  bool IsCached(const std::string &key) const;
+  // out[i] = the record of keys[i] or null; samples with skip[i] != 0 are not looked up.  Makes `stream` wait for the
+  // copies behind the returned records where they may still be in flight.  One lock for the whole batch.
+  int Lookup(const std::vector<std::string> &keys, const std::vector<uint8_t> &skip,
+             std::vector<std::shared_ptr<const Record>> *out, daliamdStream_t stream);
+  // room for the `bytes` of a new segment, or nullptr (known key, or the blob is full)
+  uint8_t *Reserve(const std::string &key, size_t bytes);
+  // the copies into the slots reserved for `keys` are enqueued on `stream`
+  void Commit(const std::vector<std::string> &keys, const std::vector<const daliamdJpegInfo *> &infos,
+              const std::vector<const daliamdJpegScan *> &scans, daliamdStream_t stream);
+  void Invalidate(const std::string &key);
+  size_t bytes_used() const { return tail_; }
+  void Stats(int64_t *out4) const {
+    std::lock_guard<std::mutex> g(m_);
+    out4[0] = (int64_t)entries_.size(); out4[1] = (int64_t)tail_; out4[2] = hits_; out4[3] = misses_;
+  }
+
+ private:
+  StreamCache(size_t bytes, bool debug);
+  struct Slot {
+    std::shared_ptr<const Record> rec;
+    std::shared_ptr<ImageCache::Fence> fence;  // null once the copy is known to have finished
+  };
+  size_t size_, tail_ = 0;
+  bool debug_, full_ = false;
+  uint8_t *blob_ = nullptr;
+  mutable std::mutex m_;
+  std::unordered_map<std::string, Slot> entries_;
+  std::unordered_map<std::string, uint8_t *> pending_;
+  int64_t hits_ = 0, misses_ = 0;
+};
+
+// `skip_cached_images` of the readers: is the sample held by a decoder cache (of either kind) of the device?
+bool DecoderCacheHolds(int device_id, const std::string &key);
 
 }  // namespace daliamd_host
 

@@ -73,7 +73,11 @@ DALI_SCHEMA(decoders__Image)
                     "are larger than `cache_threshold` will be cached in GPU memory.", ArgValue::Int(0))
     .AddOptionalArg("cache_type", "``threshold``: caches every image with a size that is larger than `cache_threshold` "
                     "until the cache is full (warm-up: 1 epoch). ``largest``: stores the largest images that can fit in "
-                    "the cache (warm-up: 2 epochs).", ArgValue::Str(""))
+                    "the cache (warm-up: 2 epochs). ``encoded`` (MI355X extension): keeps the entropy-coded segment and "
+                    "the parse results of every JPEG the GPU entropy decoder takes resident in GPU memory instead of "
+                    "the decoded pixels - from the second epoch on a sample needs no file read (with the reader's "
+                    "``skip_cached_images``), no header parse and no host-to-device transfer, and is still decoded anew "
+                    "(warm-up: 1 epoch).", ArgValue::Str(""))
     .AddOptionalArg("cache_threshold", "The size threshold, in bytes, for decoded images to be cached.", ArgValue::Int(0))
     .AddOptionalArg("cache_debug", "Prints the debug information about the decoder cache.", ArgValue::Bool(false))
     .AddOptionalArg("cache_batch_copy", "Accepted for compatibility: cached images are handed out in place, there is no "
@@ -110,7 +114,11 @@ class ImageDecoderMixed : public OperatorBase {
     }
     h2d_done_.assign(ring_, nullptr);
     // decoded-image cache (cached_decoder_impl.cc:24-48); the fused crop decoders have no cache options
-    if (allow_cache && spec.Args().count("cache_size")) {
+    if (spec.Args().count("cache_size") && spec.GetString("cache_type") == "encoded") {
+      // the encoded-stream cache (image_cache.h); also for the region-of-interest decoders: they decode from it
+      const size_t bytes = (size_t)spec.GetInt("cache_size") * 1024 * 1024;
+      if (bytes > 0) stream_cache_ = StreamCache::Get((int)spec.GetInt("device_id"), bytes, spec.GetBool("cache_debug"));
+    } else if (allow_cache && spec.Args().count("cache_size")) {
       const size_t bytes = (size_t)spec.GetInt("cache_size") * 1024 * 1024;
       const size_t threshold = (size_t)spec.GetInt("cache_threshold");
       if (bytes > 0 && bytes >= threshold)
@@ -167,13 +175,18 @@ class ImageDecoderMixed : public OperatorBase {
         }
       }
     }
+    // ---- encoded-stream cache: a resident sample brings its parse results and its entropy-coded segment (in HBM);
+    // the input bytes are not looked at (the reader may have skipped the file: they are empty then) ----
+    erec_.assign(n, nullptr);
+    int nehit = 0;
+    if (stream_cache_) nehit = stream_cache_->Lookup(in.source_info, hit_, &erec_, ws.stream);
     // Samples that are not JPEG (PNG, BMP, PNM): decoded on the host thread pool further down and uploaded; for the JPEG
     // machinery they do not exist, like cache hits.
     raster_.assign(n, 0);
     int nraster = 0;
     for (int i = 0; i < n; i++) {
       const uint8_t *b = static_cast<const uint8_t *>(in.raw(i));
-      if (!hit_[i] && !(in.nbytes(i) >= 3 && b[0] == 0xFF && b[1] == 0xD8 && b[2] == 0xFF)) {
+      if (!hit_[i] && !erec_[i] && !(in.nbytes(i) >= 3 && b[0] == 0xFF && b[1] == 0xD8 && b[2] == 0xFF)) {
         raster_[i] = 1;
         hit_[i] = 2;  // skipped by every JPEG loop
         nraster++;
@@ -185,13 +198,14 @@ class ImageDecoderMixed : public OperatorBase {
     // is and the entropy-coded segments are addressed inside it - no staging copy of the JPEG bytes.  (With cache
     // hits in the batch, or input from elsewhere, the segments of the active samples are packed into the staging
     // buffer as before.)
-    const bool direct = nact == n && n > 0 && in.device() == StorageDevice::CPU && in.pinned() && !in.is_external(0);
+    const bool direct = nact == n && nehit == 0 && n > 0 && in.device() == StorageDevice::CPU && in.pinned() &&
+                        !in.is_external(0);
     ecs_off_.assign(n, 0);
     size_t ecs_bytes = 0;
     for (int i = 0; i < n; i++) {
       ecs_off_[i] = direct ? (size_t)(static_cast<const uint8_t *>(in.raw(i)) - static_cast<const uint8_t *>(in.base()))
                            : ecs_bytes;
-      if (!hit_[i]) ecs_bytes += ((size_t)in.nbytes(i) + 15) & ~(size_t)15;
+      if (!hit_[i] && !erec_[i]) ecs_bytes += ((size_t)in.nbytes(i) + 15) & ~(size_t)15;
     }
     if (direct) ecs_bytes = (in.total_bytes() + 15) & ~(size_t)15;
     // the three descriptor tables of the iteration live behind the JPEG bytes in the same staging buffer, so that
@@ -212,6 +226,10 @@ class ImageDecoderMixed : public OperatorBase {
         }
         continue;
       }
+      if (erec_[i]) {
+        infos_[i] = erec_[i]->info;
+        continue;
+      }
       ws.GetThreadPool().AddWork([&, i](int) {
         const uint8_t *data = static_cast<const uint8_t *>(in.raw(i));
         if (daliamdJpegParse(data, in.nbytes(i), &infos_[i]) != 0)
@@ -228,7 +246,9 @@ class ImageDecoderMixed : public OperatorBase {
                  (size_t)scans_[i].ecs_length);
       }, (int64_t)in.nbytes(i));
     }
-    ws.GetThreadPool().RunAll();
+    if (nact > nehit) ws.GetThreadPool().RunAll();
+    // the scan analysis of sample i: its own, or the resident one
+    auto scan = [&](int i) -> const daliamdJpegScan & { return erec_[i] ? erec_[i]->scan : scans_[i]; };
     // Four-component streams (CMYK / YCCK; real ImageNet holds 22): not for the kernels - they join the samples the
     // host decodes and uploads (daliamdJpegDecodeHost), and stop existing for the JPEG machinery
     jpeg4_.assign(n, daliamdJpegInfo{});
@@ -307,11 +327,11 @@ class ImageDecoderMixed : public OperatorBase {
         elems += inf.coef_elems[c];
         ncomp_total++;
       }
-      if (scans_[i].eligible) {
-        DALI_ENFORCE(scans_[i].ecs_length < (int64_t)1 << 30, "Failed to decode ", src(i), ": entropy-coded segment too long");
+      if (scan(i).eligible) {
+        DALI_ENFORCE(scan(i).ecs_length < (int64_t)1 << 30, "Failed to decode ", src(i), ": entropy-coded segment too long");
         size_t need = 0;
-        KCHECK(daliamdJpegHuffmanScratchBytes((int)scans_[i].ecs_length,
-                                              scans_[i].mcus_x * scans_[i].mcus_y * scans_[i].blocks_per_mcu, &need));
+        KCHECK(daliamdJpegHuffmanScratchBytes((int)scan(i).ecs_length,
+                                              scan(i).mcus_x * scan(i).mcus_y * scan(i).blocks_per_mcu, &need));
         scratch_off_[i] = scratch_bytes;
         scratch_bytes += need;
         gpu_samples_.push_back(i);
@@ -336,10 +356,7 @@ class ImageDecoderMixed : public OperatorBase {
     int16_t *coef_host = static_cast<int16_t *>(stage.data());
     for (int i = 0; i < n; i++) {
       if (hit_[i]) continue;
-      if (scans_[i].eligible) {
-        for (int c = 0; c < infos_[i].num_components; c++) memcpy(&quant_[(size_t)i * 192 + c * 64], scans_[i].quant[c], 128);
-        continue;
-      }
+      if (scan(i).eligible) continue;   // (its quantisation tables go from the scan analysis into the descriptor)
       ws.GetThreadPool().AddWork([&, i](int) {
         const uint8_t *data = static_cast<const uint8_t *>(in.raw(i));
         int16_t *ptrs[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -423,9 +440,9 @@ class ImageDecoderMixed : public OperatorBase {
       for (int j = 0; j < ngpu; j++) {
         const int i = gpu_samples_[j];
         const auto &inf = infos_[i];
-        const auto &sc = scans_[i];
+        const auto &sc = scan(i);
         auto &d = huff[j];
-        d.ecs = dev_base + ecs_off_[i] + (direct ? (size_t)sc.ecs_offset : 0);
+        d.ecs = erec_[i] ? erec_[i]->ecs : dev_base + ecs_off_[i] + (direct ? (size_t)sc.ecs_offset : 0);
         d.scratch = static_cast<uint8_t *>(scratch.data()) + scratch_off_[i];
         d.status = status + j;
         d.ecs_len = (int32_t)sc.ecs_length;
@@ -437,7 +454,7 @@ class ImageDecoderMixed : public OperatorBase {
           // fused output: the decoder dequantises + inverse-transforms its blocks and writes the planes itself
           d.plane[c] = static_cast<uint8_t *>(planes.data()) + coef_off_[i * 3 + c];
           d.plane_pitch[c] = inf.blocks_x[c] * 8;
-          memcpy(d.quant[c], &quant_[(size_t)i * 192 + c * 64], 128);
+          memcpy(d.quant[c], sc.quant[c], 128);
           d.blocks_x[c] = inf.blocks_x[c];
           d.h_samp[c] = inf.h_samp[c];
           d.v_samp[c] = inf.v_samp[c];
@@ -461,9 +478,12 @@ class ImageDecoderMixed : public OperatorBase {
       for (int j = 0; j < ngpu; j++) names[j] = src(gpu_samples_[j]);
       const int32_t *st = status;
       std::shared_ptr<ImageCache> cache = cache_;
-      ws.AddCompletionCheck([st, names, cache] {
+      std::shared_ptr<StreamCache> scache = stream_cache_;
+      ws.AddCompletionCheck([st, names, cache, scache] {
         for (size_t j = 0; j < names.size(); j++)
           if (st[j] != 0 && cache) cache->Invalidate(names[j]);  // a slot may hold the broken image
+        for (size_t j = 0; j < names.size(); j++)
+          if (st[j] != 0 && scache) scache->Invalidate(names[j]);
         for (size_t j = 0; j < names.size(); j++)
           if (st[j] != 0)
             DALI_FAIL("Failed to decode ", names[j], ": corrupt JPEG data: the entropy-coded segment ends before the "
@@ -479,7 +499,7 @@ class ImageDecoderMixed : public OperatorBase {
       for (int c = 0; c < inf.num_components; c++) {
         cd.plane[c] = static_cast<uint8_t *>(planes.data()) + coef_off_[i * 3 + c];
         cd.pitch[c] = inf.blocks_x[c] * 8;
-        if (!scans_[i].eligible) {  // host-decoded coefficients: the stand-alone IDCT kernel
+        if (!scan(i).eligible) {  // host-decoded coefficients: the stand-alone IDCT kernel
           auto &d = idct[k++];
           d.coef = coef + coef_off_[i * 3 + c];
           d.plane = static_cast<uint8_t *>(planes.data()) + coef_off_[i * 3 + c];
@@ -521,10 +541,33 @@ class ImageDecoderMixed : public OperatorBase {
     } else {
       KCHECK(daliamdMemcpyH2DAsync(ecs_dev.data(), ecs_stage.data(), upload_bytes, cs));
     }
+    // encoded-stream cache: the segments of this batch that the cache has room for stay resident - one device-to-device
+    // copy each, behind the transfer, out of this iteration's buffer (which is reused ring_ iterations from now)
+    std::vector<std::pair<int, uint8_t *>> keep;
+    if (stream_cache_ && ngpu > nehit)
+      for (int j = 0; j < ngpu; j++) {
+        const int i = gpu_samples_[j];
+        if (erec_[i] || i >= (int)in.source_info.size()) continue;
+        if (uint8_t *slot_ptr = stream_cache_->Reserve(in.source_info[i], (size_t)scans_[i].ecs_length))
+          keep.push_back({j, slot_ptr});
+      }
     if (cs != ws.stream) {
       if (!h2d_done_[slot]) KCHECK(daliamdEventCreate(&h2d_done_[slot], 0));
       KCHECK(daliamdEventRecord(h2d_done_[slot], cs));
       KCHECK(daliamdStreamWaitEvent(ws.stream, h2d_done_[slot]));
+    }
+    if (!keep.empty()) {
+      std::vector<std::string> keys;
+      std::vector<const daliamdJpegInfo *> kinfos;
+      std::vector<const daliamdJpegScan *> kscans;
+      for (auto &k : keep) {
+        const int i = gpu_samples_[k.first];
+        KCHECK(daliamdMemcpyD2DAsync(k.second, huff[k.first].ecs, (size_t)scans_[i].ecs_length, ws.stream));
+        keys.push_back(in.source_info[i]);
+        kinfos.push_back(&infos_[i]);
+        kscans.push_back(&scans_[i]);
+      }
+      stream_cache_->Commit(keys, kinfos, kscans, ws.stream);
     }
     if (ngpu) {
       KCHECK(daliamdJpegHuffmanRun(ws.stream, reinterpret_cast<const daliamdJpegHuffDesc *>(dev_base + huff_off), ngpu,
@@ -533,7 +576,7 @@ class ImageDecoderMixed : public OperatorBase {
     }
     // host-decoded streams (progressive, restart markers, multi-scan, below the threshold): H2D of their coefficients
     for (int i = 0; i < n; i++) {
-      if (scans_[i].eligible || hit_[i]) continue;
+      if (scan(i).eligible || hit_[i]) continue;
       int64_t first = coef_off_[i * 3], count = 0;
       for (int c = 0; c < infos_[i].num_components; c++) count += infos_[i].coef_elems[c];
       KCHECK(daliamdMemcpyH2DAsync(coef + first, coef_host + first, (size_t)count * 2, ws.stream));
@@ -563,6 +606,8 @@ class ImageDecoderMixed : public OperatorBase {
   double trace_s_[5] = {0, 0, 0, 0, 0};
   int64_t trace_runs_ = 0;
   std::shared_ptr<ImageCache> cache_;
+  std::shared_ptr<StreamCache> stream_cache_;
+  std::vector<std::shared_ptr<const StreamCache::Record>> erec_;   // resident samples of the batch
   std::vector<uint8_t> hit_, raster_;
   std::vector<int32_t> raster_hw_;
   std::vector<ImageCache::Entry> cached_;

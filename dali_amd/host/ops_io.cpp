@@ -15,6 +15,7 @@
 #include <fstream>
 #include <random>
 
+#include "image_cache.h"
 #include "ops.h"
 #include "pipeline.h"
 
@@ -102,7 +103,8 @@ DALI_SCHEMA(LoaderBase)
                     "through the entire dataset.", ArgValue::Bool(false))
     .AddOptionalArg("read_ahead", "Determines whether the accessed data should be read ahead.", ArgValue::Bool(false))
     .AddOptionalArg("prefetch_queue_depth", "Number of batches prefetched by the internal loader.", ArgValue::Int(1))
-    .AddOptionalArg("skip_cached_images", "Ignored (no decoder cache).", ArgValue::Bool(false))
+    .AddOptionalArg("skip_cached_images", "If set to True, the loading data will be skipped when the sample is in the "
+                    "decoder cache. In this case, the output of the loader will be empty.", ArgValue::Bool(false))
     .AddOptionalArg("lazy_init", "Parse and prepare the dataset metadata only during the first run.", ArgValue::Bool(false))
     .AddOptionalArg("pad_last_batch", "If set to True, pads the shard by repeating the last sample.", ArgValue::Bool(false))
     .AddOptionalArg("dont_use_mmap", "Use plain file I/O instead of memory mapping (always the case here).",
@@ -295,7 +297,9 @@ int64_t Loader::NextIndex(bool is_new_batch) {
 // ---------------------------------------------------------------------------------------------- readers.file
 class FileReaderOp : public OperatorBase {
  public:
-  explicit FileReaderOp(const OpSpec &spec) : OperatorBase(spec), loader_(spec) {
+  explicit FileReaderOp(const OpSpec &spec)
+      : OperatorBase(spec), loader_(spec), skip_cached_(spec.GetBool("skip_cached_images")),
+        device_id_((int)spec.GetInt("device_id")) {
     Discover();
     loader_.Init((int64_t)entries_.size());
   }
@@ -310,7 +314,22 @@ class FileReaderOp : public OperatorBase {
     std::vector<TensorShape> shapes(max_batch_size_), lshape(max_batch_size_, TensorShape{1});
     std::vector<off_t> sizes(max_batch_size_);
     if (size_cache_.size() != entries_.size()) size_cache_.assign(entries_.size(), -1);
+    // skip_cached_images (loader.h:466-480, file_label_loader.cc:49-56): a sample the decoder cache of this device holds
+    // is not read - its tensor is empty, the decoder finds it by its source_info.  The caches are looked up at run time:
+    // the decoder that owns them may be constructed after the reader.
+    std::shared_ptr<ImageCache> decoded = skip_cached_ ? ImageCache::Find(device_id_) : nullptr;
+    std::shared_ptr<StreamCache> encoded = skip_cached_ ? StreamCache::Find(device_id_) : nullptr;
+    std::vector<uint8_t> skip(max_batch_size_, 0);
     for (int i = 0; i < max_batch_size_; i++) {
+      if (decoded || encoded) {
+        const std::string path = Path(picks[i]);
+        skip[i] = (decoded && decoded->IsCached(path)) || (encoded && encoded->IsCached(path));
+        if (skip[i]) {
+          sizes[i] = 0;
+          shapes[i] = {0};
+          continue;
+        }
+      }
       off_t &cached = size_cache_[picks[i]];  // the dataset is static: one stat() per file, not one per epoch
       if (cached < 0) {
         struct stat s;
@@ -328,6 +347,7 @@ class FileReaderOp : public OperatorBase {
     for (int i = 0; i < max_batch_size_; i++) {
       *static_cast<int32_t *>(labels.raw(i)) = entries_[picks[i]].second;
       data.source_info[i] = Path(picks[i]);
+      if (skip[i]) continue;
       ws.GetThreadPool().AddWork([this, &data, &picks, &sizes, i](int) {
         const std::string path = Path(picks[i]);
         int fd = open(path.c_str(), O_RDONLY);
@@ -351,6 +371,8 @@ class FileReaderOp : public OperatorBase {
 
  private:
   Loader loader_;
+  bool skip_cached_;
+  int device_id_;
   std::vector<off_t> size_cache_;
   std::string Path(int64_t idx) const {
     const std::string &f = entries_[idx].first;

@@ -223,7 +223,10 @@ void Pipeline::RunStage(bool device_stage, int64_t it, int slot, Iteration &res)
           if (stop_) return;
         }
         KCHECK(daliamdEventSynchronize(slot_events_[slot]));
-        if (trace_) slot_wait_seconds_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait).count();
+        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait).count();
+        slot_wait_seconds_ += waited;
+        std::lock_guard<std::mutex> g(host_times_m_);
+        slot_wait_window_ += waited;
       }
     }
     for (auto &n : nodes_) {
@@ -270,9 +273,18 @@ void Pipeline::RunStage(bool device_stage, int64_t it, int slot, Iteration &res)
         DALI_FAIL("Error in ", OpTypeName(n.type), " operator `", n.spec.SchemaName(), "` (instance \"", n.name, "\"): ",
                   e.what());
       }
-      if (trace_) n.host_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_node).count();
+      {
+        const double spent = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_node).count();
+        std::lock_guard<std::mutex> g(host_times_m_);
+        n.host_seconds += spent;
+        n.host_seconds_window += spent;
+      }
     }
-    if (trace_ && device_stage) traced_iterations_++;
+    if (device_stage) {
+      traced_iterations_++;
+      std::lock_guard<std::mutex> g(host_times_m_);
+      window_iterations_++;
+    }
   } catch (const std::exception &e) {
     res.failed = true;
     res.error = e.what();
@@ -398,6 +410,25 @@ std::vector<std::pair<std::string, double>> Pipeline::OperatorDeviceTimesMs() co
   std::vector<std::pair<std::string, double>> out;
   for (auto &n : nodes_)
     if (n.device_ms_count > 0) out.push_back({n.name, n.device_ms / (double)n.device_ms_count});
+  return out;
+}
+
+std::vector<std::pair<std::string, double>> Pipeline::OperatorHostTimesMs() {
+  std::vector<std::pair<std::string, double>> out;
+  std::lock_guard<std::mutex> g(host_times_m_);
+  const double per = window_iterations_ > 0 ? 1e3 / (double)window_iterations_ : 0.0;
+  double stage[2] = {0, 0};
+  for (auto &n : nodes_) {
+    out.push_back({n.name, n.host_seconds_window * per});
+    stage[n.type == OpType::CPU ? 0 : 1] += n.host_seconds_window;
+    n.host_seconds_window = 0;
+  }
+  out.push_back({"<host stage>", stage[0] * per});
+  out.push_back({"<device stage>", stage[1] * per});
+  out.push_back({"<slot wait>", slot_wait_window_ * per});
+  out.push_back({"<iterations>", (double)window_iterations_});
+  slot_wait_window_ = 0;
+  window_iterations_ = 0;
   return out;
 }
 

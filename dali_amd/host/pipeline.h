@@ -62,6 +62,11 @@ class Pipeline {
   // measured live, on the stream the kernels run on.
   void EnableOperatorTiming(bool on) { op_timing_ = on; }
   std::vector<std::pair<std::string, double>> OperatorDeviceTimesMs() const;
+  // Host time of the stage threads since the last call (which resets the counters): per operator the average
+  // milliseconds per iteration its SetupImpl + RunImpl took (enqueueing included), "<host stage>" / "<device stage>" =
+  // the sums per stage, "<slot wait>" = the host stage blocked on the ring slot's previous user.  Always collected (two
+  // clock reads per operator and iteration).
+  std::vector<std::pair<std::string, double>> OperatorHostTimesMs();
   daliamdStream_t stream() const { return streams_.empty() ? nullptr : streams_[0]; }
   int ring() const { return ring_; }
 
@@ -74,7 +79,8 @@ class Pipeline {
     std::vector<int> in_node, in_idx;                 // producer of each regular input
     std::vector<std::pair<std::string, std::pair<int, int>>> arg_in;  // arg name -> producer
     std::vector<std::vector<std::shared_ptr<TensorList>>> out_ring;   // [output][slot]
-    double host_seconds = 0;  // time the worker spent in SetupImpl + RunImpl (enqueueing included), DALI_AMD_TRACE=1
+    double host_seconds = 0;  // time the worker spent in SetupImpl + RunImpl (enqueueing included)
+    double host_seconds_window = 0;   // ... since the last OperatorHostTimesMs()
     // device time of the operator (EnableOperatorTiming): events around its launches, one pair per ring slot
     std::vector<daliamdEvent_t> ev_begin, ev_end;
     double device_ms = 0;
@@ -109,6 +115,9 @@ class Pipeline {
   bool trace_ = false;  // DALI_AMD_TRACE=1: per-operator host time summary on stderr when the pipeline is destroyed
   int64_t traced_iterations_ = 0;
   double slot_wait_seconds_ = 0;  // host stage blocked on the ring slot's previous user
+  std::mutex host_times_m_;       // the *_window counters: written by the stage threads, read + reset by the consumer
+  double slot_wait_window_ = 0;
+  int64_t window_iterations_ = 0;
   bool have_gpu_ = false;
   std::unique_ptr<ThreadPool> thread_pool_;      // device-stage operators (e.g. the decoder's header parsing)
   std::unique_ptr<ThreadPool> cpu_thread_pool_;  // host-stage operators (e.g. the reader's file reads)

@@ -268,6 +268,10 @@ class Pipeline:
     def operator_device_times(self):
         return self._backend.operator_times()
 
+    def operator_host_times(self):
+        """Host milliseconds per iteration of every operator on its stage thread since the last call."""
+        return self._backend.operator_host_times()
+
     def executed_kernels(self):
         """Names of the device kernels the most recent iteration launched (testing aid)."""
         return self._backend.last_launches()

@@ -94,7 +94,19 @@ class _TensorList:
         self.dtype = [e for e in vars(types.DALIDataType).values()
                       if isinstance(e, types.DALIDataType) and int(e) == info["dtype"]][0]
         self._layout, self._n, self._dense, self._gpu = info["layout"], info["num_samples"], info["dense"], info["gpu"]
-        self._samples = backend_pipe.output_samples(idx, self._n)
+        # the per-sample table (pointer, shape, pitch) is fetched when something asks for it: an iterator that only
+        # counts batches, or a benchmark loop, pays for one call into the library per output, not for 3 x N Python objects
+        self._generation = getattr(backend_pipe, "generation", 0)
+        self._sample_table = None
+
+    @property
+    def _samples(self):
+        if self._sample_table is None:
+            if getattr(self._pipe, "generation", 0) != self._generation:
+                raise RuntimeError("The outputs of this iteration were released (a later run() / outputs() call): "
+                                   "the TensorList can no longer be read")
+            self._sample_table = self._pipe.output_samples(self._idx, self._n)
+        return self._sample_table
 
     def __len__(self):
         return self._n

@@ -63,7 +63,8 @@ DALIAMD_API daliamdResult_t daliamdDevicePciBusId(int device_id, char *bus_id, i
 /* Benchmarks: while enabled every kernel launch of this library is bracketed by a pair of timing events on the stream it
  * is launched on.  Report: "name\tlaunches\tavg_ms\n" per kernel for the launches since the previous report (waits for
  * them); returns the length needed, writes at most len - 1 characters + terminator.  A call without a buffer only
- * sizes; the call that receives the text also resets the statistics. */
+ * sizes; the call that receives the text also resets the statistics.  on > 1 additionally creates the events of `on`
+ * launches up front, so that no event is created inside the measured region. */
 DALIAMD_API void daliamdKernelTimingEnable(int on);
 DALIAMD_API int daliamdKernelTimingReport(char *buf, int len);
 DALIAMD_API void daliamdRangePush(const char *name);

@@ -1,0 +1,165 @@
+"""GPU: the encoded-stream cache of the image decoders (`cache_type="encoded"`, an MI355X extension of the reference's
+decoder cache) together with the readers' `skip_cached_images` (loader.h:466-480): from the second epoch on the reader
+emits EMPTY samples and the decoder decodes from the segments resident in HBM - the pixels must be those of a fresh
+decode, for whole images, region-of-interest decodes and batches that mix resident, new, progressive (never kept) and
+PNG samples."""
+import gc
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.util import encode_jpeg, synth_image
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [(120, 160), (200, 150), (97, 131), (240, 320), (64, 48), (333, 500), (180, 180), (75, 211)]
+
+
+@pytest.fixture(scope="module")
+def files(tmp_path_factory):
+    root = tmp_path_factory.mktemp("ecache")
+    rng = np.random.default_rng(15)
+    out = []
+    for i, hw in enumerate(SIZES):
+        kw = dict(subsampling=["4:2:0", "4:4:4", "4:2:2"][i % 3])
+        if i == 3:
+            kw["progressive"] = True          # host entropy decoder: not kept
+        p = root / f"img{i}.jpg"
+        p.write_bytes(encode_jpeg(synth_image(rng, *hw), 85, **kw))
+        out.append(str(p))
+    return out
+
+
+@pytest.fixture(scope="module")
+def decoded(files):
+    return [O.jpeg_decode_rgb(open(f, "rb").read()) for f in files]
+
+
+@pytest.fixture(autouse=True)
+def _collect():
+    gc.collect()
+    yield
+    gc.collect()
+
+
+def _pipe(files, batch, decoder="image", skip=True, outputs="image", **decoder_kw):
+    from dali_amd import fn
+    from dali_amd.pipeline import Pipeline
+    pipe = Pipeline(batch_size=batch, num_threads=3, device_id=0, prefetch_queue_depth=2, seed=11)
+    with pipe:
+        enc, _ = fn.readers.file(files=files, skip_cached_images=skip)
+        img = getattr(fn.decoders, decoder)(enc, device="mixed", cache_size=64, cache_type="encoded", **decoder_kw)
+        pipe.set_outputs(*((img, enc) if outputs == "both" else (img,)))
+    return pipe
+
+
+def test_second_epoch_decodes_from_hbm_without_reading_the_files(files, decoded):
+    pipe = _pipe(files, 4, outputs="both")
+    for it in range(8):                                   # 4 epochs of 2 iterations
+        img, enc = pipe.run()
+        for i in range(4):
+            k = (4 * it + i) % len(files)
+            assert np.array_equal(img[i].as_cpu(), decoded[k]), (it, i)
+            nbytes = enc.at(i).size
+            if it >= 3 and k != 3:    # (epoch 1 fills; the reader runs up to two batches ahead of the decoder)
+                assert nbytes == 0, f"iteration {it}: sample {k} was read again ({nbytes} bytes)"
+            if k == 3:
+                assert nbytes > 0, "the progressive stream is not kept: it must be read every epoch"
+        assert "jpeg_huffman" in pipe.executed_kernels()   # a hit is decoded anew
+
+
+def test_files_may_disappear_once_resident(tmp_path, decoded, files):
+    import shutil
+    mine = []
+    for i in (0, 1, 2, 4):
+        dst = tmp_path / f"c{i}.jpg"
+        shutil.copy(files[i], dst)
+        mine.append(str(dst))
+    pipe = _pipe(mine, 4)
+    for it in range(3):                                   # (the reader is a few batches ahead: let it catch up with the cache)
+        pipe.run()
+    sizes = [open(f, "rb").read() for f in mine]
+    for f in mine:
+        open(f, "wb").close()                             # truncate: a read of it now yields an invalid stream
+    for it in range(4):
+        (img,) = pipe.run()
+        for j, i in enumerate((0, 1, 2, 4)):
+            assert np.array_equal(img[j].as_cpu(), decoded[i]), (it, i)
+    assert all(len(s) > 0 for s in sizes)
+
+
+def test_roi_decoders_decode_windows_from_the_resident_streams(files, decoded):
+    base = [f for k, f in enumerate(files) if k != 3]
+    ref = [d for k, d in enumerate(decoded) if k != 3]
+    pipe = _pipe(base, len(base), decoder="image_random_crop", random_area=[0.2, 0.8], seed=1234, outputs="both")
+    for it in range(5):
+        out, enc = pipe.run()
+        anchors, crops = O.rrc_batch(1234, it, [r.shape[:2] for r in ref], area=(0.2, 0.8))
+        for i, r in enumerate(ref):
+            (y0, x0), (h, w) = anchors[i], crops[i]
+            assert np.array_equal(out[i].as_cpu(), r[y0:y0 + h, x0:x0 + w]), (it, i)
+    assert all(enc.at(i).size == 0 for i in range(len(base)))
+
+
+def test_mixed_batches_resident_new_and_other_formats(tmp_path, files, decoded):
+    """Epoch 2 of a data set that grew: resident samples, a stream the cache has not seen, the progressive one and a
+    PNG in one batch."""
+    import io
+    from PIL import Image
+    png = tmp_path / "extra.png"
+    rng = np.random.default_rng(3)
+    pix = synth_image(rng, 50, 70)
+    Image.fromarray(pix).save(png)
+    first = [files[0], files[1], files[3], files[5]]
+    pipe = _pipe(first, 4)
+    for it in range(3):
+        (img,) = pipe.run()
+    del pipe
+    # (the cache lives as long as a pipeline holds it: build the second pipeline before dropping the first one)
+    pipe1 = _pipe(first, 4)
+    pipe1.run()
+    mixed = [files[0], files[2], str(png), files[3], files[5], files[6]]
+    pipe2 = _pipe(mixed, 6, outputs="both")
+    want = [decoded[0], decoded[2], pix, decoded[3], decoded[5], decoded[6]]
+    for it in range(3):
+        img, enc = pipe2.run()
+        for i in range(6):
+            assert np.array_equal(img[i].as_cpu(), want[i]), (it, i)
+    assert enc.at(0).size == 0 and enc.at(4).size == 0        # resident from pipe1's epoch
+    assert enc.at(2).size > 0 and enc.at(3).size > 0           # PNG and progressive JPEG are read every time
+
+
+def test_without_skip_the_reader_still_reads_but_the_decoder_uses_the_cache(files, decoded):
+    pipe = _pipe(files, 8, skip=False, outputs="both")
+    for it in range(3):
+        img, enc = pipe.run()
+        for i in range(8):
+            assert np.array_equal(img[i].as_cpu(), decoded[i]), (it, i)
+            assert enc.at(i).size > 0
+
+
+def test_cache_too_small_keeps_what_fits_and_decodes_the_rest(files, decoded):
+    from dali_amd import fn
+    from dali_amd.pipeline import Pipeline
+    rng = np.random.default_rng(9)
+    import tempfile, os
+    d = tempfile.mkdtemp()
+    big, ref = [], []
+    for i in range(6):
+        img = rng.integers(0, 256, (300, 400, 3), dtype=np.uint8)    # noise: ~290 KB per stream at q95: three fit in 1 MB
+        enc = encode_jpeg(img, 95, subsampling="4:4:4")
+        p = os.path.join(d, f"n{i}.jpg")
+        open(p, "wb").write(enc)
+        big.append(p)
+        ref.append(O.jpeg_decode_rgb(enc))
+    pipe = Pipeline(batch_size=6, num_threads=3, device_id=0, prefetch_queue_depth=1, seed=1)
+    with pipe:
+        enc, _ = fn.readers.file(files=big, skip_cached_images=True)
+        pipe.set_outputs(fn.decoders.image(enc, device="mixed", cache_size=1, cache_type="encoded"), enc)
+    for it in range(4):
+        img, e = pipe.run()
+        for i in range(6):
+            assert np.array_equal(img[i].as_cpu(), ref[i]), (it, i)
+    sizes = [e.at(i).size for i in range(6)]
+    assert 0 < sum(s == 0 for s in sizes) < 6, sizes          # some resident, some read every epoch
