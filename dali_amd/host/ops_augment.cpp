@@ -42,30 +42,28 @@ DALI_SCHEMA(WarpAffine)
     .AddOptionalTypeArg("dtype", "Output data type (same as input).", ArgType::INT)
     .InputLayout(0, {"HWC"});
 
-class WarpAffineGpu : public OperatorBase {
+// Shared by WarpAffine and Rotate: the operators differ in where the destination->source matrix and the output size
+// of a sample come from (WarpParamProvider subclasses in the reference: warp_affine_params.h, rotate_params.h).
+class WarpGpuBase : public OperatorBase {
  public:
-  explicit WarpAffineGpu(const OpSpec &spec) : OperatorBase(spec) {
-    CheckOutDtype(spec, "WarpAffine");
+  WarpGpuBase(const OpSpec &spec, const char *name) : OperatorBase(spec), name_(name) {
+    CheckOutDtype(spec, name);
     int64_t it = spec.GetInt("interp_type");
-    DALI_ENFORCE(it == DALI_INTERP_NN || it == DALI_INTERP_LINEAR, "WarpAffine supports INTERP_NN and INTERP_LINEAR, got ", it);
+    DALI_ENFORCE(it == DALI_INTERP_NN || it == DALI_INTERP_LINEAR, name, " supports INTERP_NN and INTERP_LINEAR, got ", it);
     interp_ = it == DALI_INTERP_NN ? DALIAMD_INTERP_NN : DALIAMD_INTERP_LINEAR;
-    invert_ = !spec.GetBool("inverse_map");
     has_fill_ = spec.TryArg("fill_value") != nullptr;
     if (has_fill_) fill_ = (float)spec.GetFloat("fill_value");
-    DALI_ENFORCE(spec.ArgumentDefined("matrix"), "`matrix` argument must be provided");
   }
   bool SetupImpl(std::vector<OutputDesc> &desc, const Workspace &ws) override {
     const TensorList &in = ws.Input(0);
-    CheckU8Hwc(in, "WarpAffine");
+    CheckU8Hwc(in, name_);
     int n = in.num_samples();
-    auto mats = GetPerSampleFloatVec(spec_, ws, "matrix", n);
     std::vector<std::vector<float>> sizes;
     if (spec_.ArgumentDefined("size")) sizes = GetPerSampleFloatVec(spec_, ws, "size", n);
     descs_.assign(n, daliamdWarpAffineDesc{});
     desc[0].type = DALI_UINT8;
     desc[0].shape.resize(n);
     for (int i = 0; i < n; i++) {
-      DALI_ENFORCE(mats[i].size() == 6, "`matrix` parameter must have 6 elements, got ", mats[i].size());
       auto &d = descs_[i];
       const TensorShape &s = in.shape(i);
       d.in = static_cast<const uint8_t *>(in.raw(i));
@@ -76,23 +74,14 @@ class WarpAffineGpu : public OperatorBase {
         d.out_h = (int)sizes[i][0]; d.out_w = (int)sizes[i][1];
         DALI_ENFORCE(d.out_h > 0 && d.out_w > 0, "`size` must be positive");
       }
-      d.out_pitch = d.out_w * d.channels;
-      const float *m = mats[i].data();
-      if (invert_) {
-        // affine_mat_inv (include/dali/core/geom/transform.h:166-174; 2x2 inverse mat.h:610-622)
-        float det = m[0] * m[4] - m[1] * m[3];
-        DALI_ENFORCE(det != 0, "Cannot calculate the inverse of a singular matrix.");
-        float i00 = m[4] / det, i01 = -m[1] / det, i10 = -m[3] / det, i11 = m[0] / det;
-        float t0 = (-i00) * m[2]; t0 += (-i01) * m[5];
-        float t1 = (-i10) * m[2]; t1 += (-i11) * m[5];
-        float inv[6] = {i00, i01, t0, i10, i11, t1};
-        memcpy(d.matrix, inv, sizeof(inv));
-      } else {
-        memcpy(d.matrix, m, 6 * sizeof(float));
-      }
       d.interp = interp_;
       d.border_clamp = !has_fill_;
       for (int c = 0; c < 4; c++) d.fill[c] = fill_;
+    }
+    SampleParams(ws, n, !sizes.empty());
+    for (int i = 0; i < n; i++) {
+      auto &d = descs_[i];
+      d.out_pitch = d.out_w * d.channels;
       desc[0].shape[i] = {d.out_h, d.out_w, d.channels};
     }
     return true;
@@ -119,15 +108,110 @@ class WarpAffineGpu : public OperatorBase {
     NoteLaunch(ws, "warp_affine");
   }
 
- private:
-  int interp_;
-  bool invert_, has_fill_;
-  float fill_ = 0;
+ protected:
+  // fills descs_[i].matrix (destination -> source) and, unless `explicit_size`, may set descs_[i].out_h / out_w
+  virtual void SampleParams(const Workspace &ws, int n, bool explicit_size) = 0;
   std::vector<daliamdWarpAffineDesc> descs_;
+
+ private:
+  const char *name_;
+  int interp_;
+  bool has_fill_;
+  float fill_ = 0;
   DescUploader uploader_;
+};
+
+class WarpAffineGpu : public WarpGpuBase {
+ public:
+  explicit WarpAffineGpu(const OpSpec &spec) : WarpGpuBase(spec, "WarpAffine") {
+    invert_ = !spec.GetBool("inverse_map");
+    DALI_ENFORCE(spec.ArgumentDefined("matrix"), "`matrix` argument must be provided");
+  }
+
+ protected:
+  void SampleParams(const Workspace &ws, int n, bool) override {
+    auto mats = GetPerSampleFloatVec(spec_, ws, "matrix", n);
+    for (int i = 0; i < n; i++) {
+      DALI_ENFORCE(mats[i].size() == 6, "`matrix` parameter must have 6 elements, got ", mats[i].size());
+      auto &d = descs_[i];
+      const float *m = mats[i].data();
+      if (invert_) {
+        // affine_mat_inv (include/dali/core/geom/transform.h:166-174; 2x2 inverse mat.h:610-622)
+        float det = m[0] * m[4] - m[1] * m[3];
+        DALI_ENFORCE(det != 0, "Cannot calculate the inverse of a singular matrix.");
+        float i00 = m[4] / det, i01 = -m[1] / det, i10 = -m[3] / det, i11 = m[0] / det;
+        float t0 = (-i00) * m[2]; t0 += (-i01) * m[5];
+        float t1 = (-i10) * m[2]; t1 += (-i11) * m[5];
+        float inv[6] = {i00, i01, t0, i10, i11, t1};
+        memcpy(d.matrix, inv, sizeof(inv));
+      } else {
+        memcpy(d.matrix, m, 6 * sizeof(float));
+      }
+    }
+  }
+
+ private:
+  bool invert_;
 };
 DALI_REGISTER_OPERATOR(WarpAffine, WarpAffineGpu, GPU);
 DALI_REGISTER_OPERATOR(WarpAffine, WarpAffineGpu, CPU);  // same class: the host kernel when run on the CPU
+
+// ---- Rotate: the warp kernel with the matrix and canvas of rotate_params.h (dali/operators/image/remap/rotate.cc:19-44)
+DALI_SCHEMA(Rotate)
+    .DocStr("Rotates the images by the specified angle.\n\nThe rotation is counter-clockwise, assuming the top-left corner "
+            "is at ``(0,0)``.  Unless ``size`` or ``keep_size`` is given, the canvas is adjusted to accommodate the rotated "
+            "image with the least padding possible (its parity follows the input's to reduce blur).")
+    .NumInput(1)
+    .NumOutput(1)
+    .AddArg("angle", "Angle, in degrees, by which the image is rotated.", ArgType::FLOAT, true)
+    .AddOptionalArg("keep_size", "If True, original canvas size is kept.", ArgValue::Bool(false))
+    .AddOptionalTypeArg("axis", "3D rotation only: not supported (two-dimensional HWC images).", ArgType::FLOAT_VEC, true)
+    .AddOptionalTypeArg("size", "Output size, in pixels (H, W).", ArgType::FLOAT_VEC, true)
+    .AddOptionalTypeArg("fill_value", "Value used to fill areas that are outside the source image. If not specified, "
+                        "the source coordinates are clamped (border pixels are repeated).", ArgType::FLOAT)
+    .AddOptionalArg("interp_type", "Type of interpolation used (INTERP_NN or INTERP_LINEAR).", ArgValue::Int(DALI_INTERP_LINEAR))
+    .AddOptionalTypeArg("dtype", "Output data type (same as input).", ArgType::INT)
+    .InputLayout(0, {"HWC"});
+
+class RotateGpu : public WarpGpuBase {
+ public:
+  explicit RotateGpu(const OpSpec &spec) : WarpGpuBase(spec, "Rotate"), keep_size_(spec.GetBool("keep_size")) {
+    DALI_ENFORCE(!spec.ArgumentDefined("axis"), "Rotate: `axis` applies to volumetric input, which this build does not take");
+  }
+
+ protected:
+  void SampleParams(const Workspace &ws, int n, bool explicit_size) override {
+    auto angles = GetPerSampleFloat(spec_, ws, "angle", n);
+    for (int i = 0; i < n; i++) {
+      auto &d = descs_[i];
+      const float a = -angles[i];                          // SetParams: positive = counter-clockwise with (0,0) top-left
+      const float rad = a * (float)(M_PI / 180);           // deg2rad(float), math_util.h:153-157
+      if (!explicit_size && !keep_size_) {
+        // RotatedCanvasSize (rotate_params.h:33-52) + the parity correction of InferSize (:285) for one frame
+        const double eps = 1e-2, abs_cos = std::abs(std::cos((double)rad)), abs_sin = std::abs(std::sin((double)rad));
+        const int w = d.in_w, h = d.in_h;
+        int w_out = (int)std::ceil(abs_cos * w + abs_sin * h - eps), h_out = (int)std::ceil(abs_cos * h + abs_sin * w - eps);
+        const int par_w = abs_sin <= abs_cos ? w % 2 : h % 2, par_h = abs_sin <= abs_cos ? h % 2 : w % 2;
+        w_out += (w_out % 2) ^ par_w;
+        h_out += (h_out % 2) ^ par_h;
+        d.out_w = w_out; d.out_h = h_out;
+      }
+      // M = translation(in_size / 2) * rotation2D(-a) * translation(-out_size / 2)   (rotate_params.h:225-226), float
+      // products in the order of mat.h (s = a0 * b0; s += a1 * b1; s += a2 * b2)
+      const float c = std::cos(-rad), sn = std::sin(-rad);
+      const float tx = d.in_w * 0.5f, ty = d.in_h * 0.5f, ox = -(d.out_w * 0.5f), oy = -(d.out_h * 0.5f);
+      float m02 = c * ox; m02 += (-sn) * oy; m02 += tx;
+      float m12 = sn * ox; m12 += c * oy; m12 += ty;
+      const float m[6] = {c, -sn, m02, sn, c, m12};
+      memcpy(d.matrix, m, sizeof(m));
+    }
+  }
+
+ private:
+  bool keep_size_;
+};
+DALI_REGISTER_OPERATOR(Rotate, RotateGpu, GPU);
+DALI_REGISTER_OPERATOR(Rotate, RotateGpu, CPU);
 
 // =============================================================================================
 DALI_SCHEMA(GaussianBlur)
@@ -249,6 +333,35 @@ DALI_SCHEMA(ColorTwist)
     .AddOptionalTypeArg("dtype", "Output data type (same as input).", ArgType::INT)
     .InputLayout(0, {"HWC"});
 
+// The siblings that are the same operator class under other schemas (color_twist.cc:26-103,142-144): arguments a
+// schema does not define keep the neutral value.
+DALI_SCHEMA(Hsv)
+    .DocStr("Adjusts hue, saturation and value (brightness) of the images.\n\nThe operation is approximated by a linear "
+            "transform in the RGB space: the color vector is projected along the neutral (gray) axis, rotated based on the "
+            "hue delta, scaled based on the value and saturation multipliers, and restored to the original color space.")
+    .NumInput(1)
+    .NumOutput(1)
+    .AddOptionalArg("hue", "Hue delta, in degrees.", ArgValue::Float(0.0), true)
+    .AddOptionalArg("saturation", "The saturation multiplier.", ArgValue::Float(1.0), true)
+    .AddOptionalArg("value", "The value multiplier.", ArgValue::Float(1.0), true)
+    .AddOptionalTypeArg("dtype", "Output data type (same as input).", ArgType::INT)
+    .InputLayout(0, {"HWC"});
+DALI_SCHEMA(Hue)
+    .DocStr("Changes the hue level of the image.")
+    .NumInput(1)
+    .NumOutput(1)
+    .AddOptionalArg("hue", "The hue change in degrees.", ArgValue::Float(0.0), true)
+    .AddOptionalTypeArg("dtype", "Output data type (same as input).", ArgType::INT)
+    .InputLayout(0, {"HWC"});
+DALI_SCHEMA(Saturation)
+    .DocStr("Changes the saturation level of the image.")
+    .NumInput(1)
+    .NumOutput(1)
+    .AddOptionalArg("saturation", "The saturation change factor (0: completely desaturated, 1: no change).",
+                    ArgValue::Float(1.0), true)
+    .AddOptionalTypeArg("dtype", "Output data type (same as input).", ArgType::INT)
+    .InputLayout(0, {"HWC"});
+
 class ColorTwistGpu : public OperatorBase {
  public:
   explicit ColorTwistGpu(const OpSpec &spec) : OperatorBase(spec) { CheckOutDtype(spec, "ColorTwist"); }
@@ -256,9 +369,12 @@ class ColorTwistGpu : public OperatorBase {
     const TensorList &in = ws.Input(0);
     CheckU8Hwc(in, "ColorTwist");
     int n = in.num_samples();
-    auto hue = GetPerSampleFloat(spec_, ws, "hue", n), sat = GetPerSampleFloat(spec_, ws, "saturation", n),
-         val = GetPerSampleFloat(spec_, ws, "value", n), bri = GetPerSampleFloat(spec_, ws, "brightness", n),
-         con = GetPerSampleFloat(spec_, ws, "contrast", n);
+    // (AcquireArguments, color_twist.h:111-141: an argument the schema does not define keeps its neutral value)
+    auto arg = [&](const char *name, float neutral) {
+      return spec_.ArgumentDefined(name) ? GetPerSampleFloat(spec_, ws, name, n) : std::vector<float>(n, neutral);
+    };
+    auto hue = arg("hue", 0.f), sat = arg("saturation", 1.f), val = arg("value", 1.f), bri = arg("brightness", 1.f),
+         con = arg("contrast", 1.f);
     descs_.assign(n, daliamdPointwiseDesc{});
     desc[0].type = DALI_UINT8;
     desc[0].shape.resize(n);
@@ -296,6 +412,12 @@ class ColorTwistGpu : public OperatorBase {
 };
 DALI_REGISTER_OPERATOR(ColorTwist, ColorTwistGpu, GPU);
 DALI_REGISTER_OPERATOR(ColorTwist, ColorTwistGpu, CPU);
+DALI_REGISTER_OPERATOR(Hsv, ColorTwistGpu, GPU);
+DALI_REGISTER_OPERATOR(Hsv, ColorTwistGpu, CPU);
+DALI_REGISTER_OPERATOR(Hue, ColorTwistGpu, GPU);
+DALI_REGISTER_OPERATOR(Hue, ColorTwistGpu, CPU);
+DALI_REGISTER_OPERATOR(Saturation, ColorTwistGpu, GPU);
+DALI_REGISTER_OPERATOR(Saturation, ColorTwistGpu, CPU);
 
 DALI_SCHEMA(Erase)
     .DocStr("Erases one or more regions from the input tensors.\n\nThe region is specified by ``anchor`` (starting point) and "

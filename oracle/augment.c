@@ -7,6 +7,7 @@
  *       dali/kernels/imgproc/warp_cpu.h:143-178 (incremental source coordinates, re-anchored every 256 px)
  *       dali/kernels/imgproc/warp/map_coords.h:32-40, include/dali/core/geom/transform.h:132-145 (affine())
  *       dali/kernels/imgproc/sampler.h:60-175 (nearest + border), :258-338 (bilinear)
+ *   rotate (the same warp; matrix and canvas of dali/operators/image/remap/rotate_params.h)
  *   gaussian_blur (separable, reflect-101 border, float intermediate)
  *       dali/operators/image/convolution/gaussian_blur_params.h:27-83 (diameter, window)
  *       dali/kernels/imgproc/convolution/convolution_cpu.h:152-186,241-340, separable_convolution_cpu.h:70-113
@@ -29,6 +30,8 @@
  *   color twist / hsv  the numpy model of operator_1/test_color_twist.py:68-104, abs 1 / rel 1/512 (its bound)
  *   warp affine        exact float64 bilinear sampling with the matrices of operator_2/test_warp.py:31-52,197, <= 1 LSB
  *                      (the reference allows 8 against OpenCV's fixed-point interpolation, test_warp.py:236)
+ *   rotate             canvas sizes against the reference's own model (operator_2/test_rotate.py:39-60), pixels against
+ *                      the exact bilinear model with the float64 matrix of test_rotate.py:111-120, <= 1 LSB
  *   erase              numpy slice assignment, exact
  * What stays unobservable here is the last-bit behaviour of a shipped DALI binary (libm version, contraction choices);
  * the reference's own tests do not pin it either.
@@ -143,6 +146,34 @@ void orc_affine_inverse_2x3(const float *m, float *out) {
   float t1 = n10 * m[2]; t1 += n11 * m[5];
   out[0] = i00; out[1] = i01; out[2] = t0;
   out[3] = i10; out[4] = i11; out[5] = t1;
+}
+
+/* ---------------------------------------------------------------------------------------------- rotate */
+/* fn.rotate, two-dimensional: the destination->source matrix and canvas of dali/operators/image/remap/rotate_params.h
+ * (:33-52 RotatedCanvasSize, :126-127 sign of the angle, :216-228 AdjustParams, :273-291 parity correction for ONE
+ * frame), then the warp above.  out_hw: in = explicit size (or 0 0), out = the size used; keep_size: the input's. */
+void orc_rotate_params(float angle_deg, int in_h, int in_w, int keep_size, int *out_hw, float *matrix) {
+  const float a = -angle_deg;
+  const float rad = a * (float)(M_PI / 180);
+  if (!(out_hw[0] > 0 && out_hw[1] > 0)) {
+    if (keep_size) {
+      out_hw[0] = in_h; out_hw[1] = in_w;
+    } else {
+      const double eps = 1e-2, abs_cos = fabs(cos((double)rad)), abs_sin = fabs(sin((double)rad));
+      int w_out = (int)ceil(abs_cos * in_w + abs_sin * in_h - eps), h_out = (int)ceil(abs_cos * in_h + abs_sin * in_w - eps);
+      const int par_w = abs_sin <= abs_cos ? in_w % 2 : in_h % 2, par_h = abs_sin <= abs_cos ? in_h % 2 : in_w % 2;
+      w_out += (w_out % 2) ^ par_w;
+      h_out += (h_out % 2) ^ par_h;
+      out_hw[0] = h_out; out_hw[1] = w_out;
+    }
+  }
+  /* translation(in / 2) * rotation2D(-a) * translation(-out / 2); mat.h product order */
+  const float c = cosf(-rad), sn = sinf(-rad);
+  const float tx = in_w * 0.5f, ty = in_h * 0.5f, ox = -(out_hw[1] * 0.5f), oy = -(out_hw[0] * 0.5f);
+  float m02 = c * ox; m02 += (-sn) * oy; m02 += tx;
+  float m12 = sn * ox; m12 += c * oy; m12 += ty;
+  matrix[0] = c; matrix[1] = -sn; matrix[2] = m02;
+  matrix[3] = sn; matrix[4] = c; matrix[5] = m12;
 }
 
 /* ---------------------------------------------------------------------------------------------- gaussian_blur */

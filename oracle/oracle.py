@@ -295,6 +295,19 @@ def warp_affine_u8(img, matrix, out_hw=None, interp=1, fill=None):
     return out
 
 
+def rotate_params(angle, in_hw, size=None, keep_size=False):
+    """fn.rotate: (destination->source matrix 2x3, (out_h, out_w))."""
+    hw = np.array(size if size is not None else (0, 0), np.int32)
+    m = np.zeros(6, np.float32)
+    lib().orc_rotate_params(C.c_float(angle), int(in_hw[0]), int(in_hw[1]), 1 if keep_size else 0, _p(hw, C.c_int), _p(m, C.c_float))
+    return m.reshape(2, 3), (int(hw[0]), int(hw[1]))
+
+
+def rotate_u8(img, angle, size=None, keep_size=False, interp=1, fill=None):
+    m, hw = rotate_params(angle, img.shape[:2], size, keep_size)
+    return warp_affine_u8(img, m, out_hw=hw, interp=interp, fill=fill)
+
+
 def affine_inverse(matrix):
     m = np.ascontiguousarray(matrix, np.float32).reshape(6)
     out = np.zeros(6, np.float32)

@@ -76,6 +76,27 @@ def warp_affine(img_u8, matrix_dst_to_src, out_hw, fill=None, interp="linear"):
     return np.round(np.clip(top * (1 - qy) + bot * qy, 0, 255)).astype(np.uint8)
 
 
+def rotate_output_size(angle_deg, in_hw):
+    """The reference's own model of the rotated canvas (operator_2/test_rotate.py:39-60): the bounding box of the turned
+    image, grown by one where its parity differs from the input side that dominates it."""
+    # (the operator's angle is a float32 in radians: at exactly 45 degrees that decides which side "dominates")
+    a = float(np.float32(-angle_deg) * np.float32(math.pi / 180))
+    cosa, sina = abs(math.cos(a)), abs(math.sin(a))
+    h, w = in_hw
+    out_w, out_h = int(math.ceil(w * cosa + h * sina - 1e-2)), int(math.ceil(h * cosa + w * sina - 1e-2))
+    ref_w, ref_h = (w, h) if sina <= cosa else (h, w)
+    return out_h + (out_h % 2 != ref_h % 2), out_w + (out_w % 2 != ref_w % 2)
+
+
+def rotate_matrix(angle_deg, in_hw, out_hw):
+    """Destination -> source, float64: move the output centre to the origin, turn, move to the input centre
+    (test_rotate.py:111-120)."""
+    a = math.radians(angle_deg)
+    c, s = math.cos(a), math.sin(a)
+    (ih, iw), (oh, ow) = in_hw, out_hw
+    return np.array([[c, -s, iw / 2 - c * ow / 2 + s * oh / 2], [s, c, ih / 2 - s * ow / 2 - c * oh / 2]], np.float64)
+
+
 def convolve_reflect101(img_u8, win_x, win_y):
     def along(a, win, axis):
         r = (len(win) - 1) // 2

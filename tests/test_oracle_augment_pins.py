@@ -133,3 +133,25 @@ def test_erase_against_numpy_slices():
     ref = img.copy()
     ref[15:45, 30:50] = 9
     assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("angle", [0.0, 10.0, -33.3, 45.0, 90.0, 135.0, 180.0, 270.0, 301.5])
+@pytest.mark.parametrize("hw", [(120, 161), (97, 64), (50, 50)])
+def test_rotate_canvas_and_pixels(angle, hw):
+    """fn.rotate: canvas size = the reference's own model (operator_2/test_rotate.py:39-60), pixels = exact bilinear sampling
+    through the float64 matrix of test_rotate.py:111-120 (the reference allows 8 against OpenCV, :177)."""
+    rng = np.random.default_rng(int(abs(angle) * 10) + hw[0])
+    img = synth_image(rng, *hw)
+    m, out_hw = O.rotate_params(angle, hw)
+    assert out_hw == M.rotate_output_size(angle, hw), (angle, hw)
+    assert np.allclose(m, M.rotate_matrix(angle, hw, out_hw), rtol=1e-5, atol=2e-4)
+    got = O.rotate_u8(img, angle, fill=42.0)
+    ref = M.warp_affine(img, M.rotate_matrix(angle, hw, out_hw), out_hw, fill=42.0)
+    d = np.abs(got.astype(int) - ref.astype(int))
+    assert d.max() <= 1 or (d > 1).mean() < 2e-3, (d.max(), (d > 1).mean())   # (multiples of 90 degrees put coordinates ON pixel edges)
+    assert (d > 0).mean() < 0.08
+    # keep_size / explicit size keep the canvas and re-centre
+    m2, hw2 = O.rotate_params(angle, hw, keep_size=True)
+    assert hw2 == hw and np.allclose(m2, M.rotate_matrix(angle, hw, hw), rtol=1e-5, atol=2e-4)
+    m3, hw3 = O.rotate_params(angle, hw, size=(70, 33))
+    assert hw3 == (70, 33) and np.allclose(m3, M.rotate_matrix(angle, hw, (70, 33)), rtol=1e-5, atol=2e-4)

@@ -564,3 +564,44 @@ def test_heavy_augmentation_operators_on_the_cpu_backend(interp, fill):
         got = out.at(i)
         assert got.shape == ref.shape
         assert np.array_equal(got, ref), f"sample {i}: max diff {np.abs(got.astype(int) - ref).max()}"
+
+
+@pytest.mark.parametrize("device", ["cpu", pytest.param("gpu", marks=pytest.mark.gpu)])
+def test_rotate_and_the_colour_twist_siblings(device):
+    """fn.rotate (rotate.cc:19-44: canvas inferred / keep_size / explicit size, per-sample angles) and fn.hsv / fn.hue /
+    fn.saturation (color_twist.cc:26-103,142-144: the ColorTwist class under schemas with fewer arguments) against the oracle
+    bit for bit, on the host kernels and on the device kernels."""
+    from oracle import oracle as O
+    from tests.util import synth_image
+    from dali_amd import fn, types
+    from dali_amd.pipeline import Pipeline
+    rng = np.random.default_rng(23)
+    imgs = [synth_image(rng, h, w) for (h, w) in [(120, 161), (97, 64), (50, 50), (200, 131)]]
+    angles = [np.float32(a) for a in (10.0, -33.3, 90.0, 217.5)]
+    pipe = Pipeline(batch_size=4, num_threads=3, device_id=None if device == "cpu" else 0, seed=3, prefetch_queue_depth=1)
+    with pipe:
+        x = fn.external_source(name="images", layout="HWC")
+        a = fn.external_source(name="angle")
+        xd = x if device == "cpu" else x.gpu()
+        r0 = fn.rotate(xd, angle=a, fill_value=42.0)
+        r1 = fn.rotate(xd, angle=a, keep_size=True)
+        r2 = fn.rotate(xd, angle=25.0, size=[70, 33], interp_type=types.INTERP_NN, fill_value=0.0)
+        h0 = fn.hsv(xd, hue=120.0, saturation=0.5, value=1.25)
+        h1 = fn.hue(xd, hue=-45.0)
+        h2 = fn.saturation(xd, saturation=1.7)
+        pipe.set_outputs(r0, r1, r2, h0, h1, h2)
+    pipe.build()
+    pipe.feed_input("images", imgs, layout="HWC")
+    pipe.feed_input("angle", angles)
+    outs = pipe.run()
+    get = (lambda tl, i: tl.at(i)) if device == "cpu" else (lambda tl, i: tl[i].as_cpu())
+    for i, im in enumerate(imgs):
+        assert np.array_equal(get(outs[0], i), O.rotate_u8(im, float(angles[i]), fill=42.0)), i
+        assert np.array_equal(get(outs[1], i), O.rotate_u8(im, float(angles[i]), keep_size=True)), i
+        assert np.array_equal(get(outs[2], i), O.rotate_u8(im, 25.0, size=(70, 33), interp=0, fill=0.0)), i
+        for k, (hue, sat, val) in enumerate([(120.0, 0.5, 1.25), (-45.0, 1.0, 1.0), (0.0, 1.7, 1.0)]):
+            m, off = O.color_twist_matrix(hue, sat, val, 1.0, 1.0)
+            assert np.array_equal(get(outs[3 + k], i), O.linear_transform_u8(im, m, off)), (i, k)
+    with pytest.raises(TypeError, match="unexpected keyword"):
+        with Pipeline(batch_size=1, num_threads=1, device_id=None):
+            fn.hue(fn.external_source(name="q"), saturation=2.0)
