@@ -557,6 +557,8 @@ def bench_audio(args, device):
     times = pipe.operator_device_times()   # ... and around each operator (descriptor upload + launches)
     algo["DecibelMaxKernel"] = 4 * 80 * frames
     algo["DecibelKernel"] = 8 * 80 * frames
+    # the fused launch (graph-level fusion of the chain): signal in, mel energies out - the spectrogram stays in LDS
+    algo["SpectrogramMelMfmaKernel"] = algo["SpectrogramMelKernel"] = 4 * samples + 4 * 80 * frames
     per = {}
     for kern, (calls, ms) in ktimes.items():
         if kern in algo:
@@ -570,7 +572,12 @@ def bench_audio(args, device):
                       "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
                       "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                       "config": {"workload": "configs[3]: 64 mono signals, 16 kHz, 8-16 s", "frames": frames,
-                                 "samples": samples},
+                                 "samples": samples, "kernels": pipe.executed_kernels(),
+                                 "kernels_ms_per_step": sum(v["avg_ms"] for v in per.values()),
+                                 "utterances_per_s_kernels_only": n / (1e-3 * sum(v["avg_ms"] for v in per.values())) if per else None,
+                                 "algorithmic_MB_per_step": sum(v["algorithmic_bytes"] for v in per.values()) / 1e6,
+                                 "mel_variant": "valu" if os.environ.get("DALI_AMD_MEL_VALU") == "1" else "mfma",
+                                 "note": "value includes feeding 49 MB of host signals per step (external_source copy + H2D)"},
                       "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": ach / HBM_PEAK_GBS if ach else None, "traffic": traffic,
                                    "traffic_source": traffic_src, "per_kernel": per,

@@ -182,7 +182,7 @@ _KERNEL_SYMBOLS = [
     "daliamdWarpAffineSetup", "daliamdWarpAffineRun", "daliamdGaussianWindow", "daliamdGaussianBlurSetup",
     "daliamdGaussianBlurRun", "daliamdColorTwistMatrix", "daliamdPointwiseSetup", "daliamdPointwiseRun",
     "daliamdHannWindow", "daliamdSpectrogramTwiddles", "daliamdSpectrogramSetup", "daliamdSpectrogramRun", "daliamdMelFilterBankWeights",
-    "daliamdMelFilterBankBands", "daliamdMelFilterBankSetup", "daliamdMelFilterBankRun", "daliamdToDecibelsSetup", "daliamdToDecibelsRun", "daliamdDctTable", "daliamdLifterCoeffs", "daliamdDctRun",
+    "daliamdMelFilterBankBands", "daliamdMelFilterBankSetup", "daliamdMelFilterBankRun", "daliamdMelFilterBankMfmaLayout", "daliamdSpectrogramMelRun", "daliamdToDecibelsSetup", "daliamdToDecibelsRun", "daliamdDctTable", "daliamdLifterCoeffs", "daliamdDctRun",
     "daliamdAudioResampleLobes", "daliamdAudioResampleWindow", "daliamdAudioResampleSetup", "daliamdAudioResampleRun",
     "daliamdConvertNormSetup", "daliamdConvertNormRun",
     "daliamdNormalizeSetup", "daliamdNormalizeRun",
@@ -198,6 +198,7 @@ _HOST_SYMBOLS = [
     "daliamdWarpAffineHost", "daliamdGaussianBlurHost", "daliamdPointwiseHost", "daliamdNormalizeHost",
     "daliamdImageCachePolicyCreate", "daliamdImageCachePolicyDestroy", "daliamdImageCachePolicyOnDecode",
     "daliamdImageCachePolicyFind", "daliamdImageProbe", "daliamdImageDecodeRgb",
+    "daliamdFlacProbe", "daliamdFlacDecode",
 ]
 
 

@@ -2,6 +2,7 @@
 // banded matrix product, and to_decibels with a per-sample max reduction.  See include/dali_amd_kernels.h for the
 // reference counterparts.  f32 throughout; parity with the reference's CPU path is tolerance-based for the FFT
 // (its FFTS library is not available; tests use a float64 FFT like the reference's own tests do).
+#include <algorithm>
 #include <cmath>
 #include <vector>
 #include "common.h"
@@ -251,11 +252,90 @@ __global__ __launch_bounds__(kSpecThreads) void SpectrogramKernel(const daliamdS
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int PadIdx(int e) { return e + ((e >> 4) << 1); }
 
-template <int LOG2N, int FC>
+// MEL != 0: the spectrogram never leaves the workgroup.  Its 16-frame power tile is multiplied by the mel filter bank
+// where it sits in LDS and only the [nfilter][frames] result (mel energies, or their decibels) is written - see MelFromTile.
+struct MelFuse {
+  const float *tiles;       // MFMA variant: the filter bank as 16 x 4 tiles in A-operand lane order
+  const int32_t *row_blocks;
+  const float *weights;     // VALU variant: dense [nfilter][nbins] + bands
+  const int32_t *bands;
+  int32_t num_row_blocks, nfilter, nbins, decibels;
+  float mul_log2, inv_ref, min_ratio;
+  uint32_t *max_bits;
+  int32_t max_stride;
+};
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// out[m][t0 + f] = sum_k W[m][k] * tile[k][f] for the FPG = 16 frames of the tile.
+//   MEL == 1  v_mfma_f32_16x16x4_f32: D[16 filters][16 frames] += A[16 filters][4 bins] . B[4 bins][16 frames].  The 16 frames
+//             of the tile ARE the N of the instruction; B comes straight from LDS (lane l: tile[k0 + l / 16][l % 16]), A from
+//             a host-made table of 16 x 4 tiles in lane order (one coalesced 256-byte load per instruction, L2-resident:
+//             the table is the same for every workgroup).  The filters are triangles that overlap only their neighbours,
+//             so a row block of 16 filters touches a contiguous range of bins: only those tiles exist (about 150 of the
+//             5 x 129 of the dense product for 80 filters x 513 bins).  f32 in, f32 accumulate: the result is the ascending-k
+//             fmaf chain of the banded product (zero weights add exact zeros).
+//   MEL == 2  the banded product on the VALU, MelKernel's loop: thread = (filter, frame), 2 FMAs per tile element.
+template <int MEL, int N, int TS>
+__device__ __forceinline__ void MelFromTile(const float *tile, const MelFuse &mel, float *out, int T, int t0, int di, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  GOutFloat *gout = (GOutFloat *)out;
+  float vmax = 0.0f;
+  auto emit = [&](int m, int f, float acc) {
+    if (m >= mel.nfilter || t0 + f >= T) return;
+    vmax = fmaxf(vmax, acc);
+    if (mel.decibels) acc = mel.mul_log2 * log2f(fmaxf(mel.min_ratio, acc * mel.inv_ref));
+    gout[(size_t)m * T + t0 + f] = acc;
+  };
+  if constexpr (MEL == 1) {
+    const int kk = lane >> 4, j = lane & 15;
+    for (int mb = 0; mb < mel.num_row_blocks; mb++) {
+      const int32_t __attribute__((address_space(1))) *rb = (const int32_t __attribute__((address_space(1))) *)mel.row_blocks + 4 * mb;
+      if (rb[3] != wave) continue;   // the host dealt the row blocks to the waves by their tile counts
+      const int first = rb[0], count = rb[1], k0 = rb[2];
+      GFloat *a = (GFloat *)mel.tiles + (size_t)first * 64 + lane;
+      const float *b = tile + (k0 + kk) * TS + j;
+      f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+      int i = 0;
+      // eight operand pairs in flight in front of the eight dependent instructions: the A tiles come from L2 (a few
+      // hundred cycles), and ONE accumulator keeps the sum the ascending-k chain of the banded product
+      for (; i + 8 <= count; i += 8) {
+        float av[8], bv[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) av[q] = a[(i + q) * 64];
+#pragma unroll
+        for (int q = 0; q < 8; q++) bv[q] = b[(i + q) * 4 * TS];
+#pragma unroll
+        for (int q = 0; q < 8; q++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bv[q], acc, 0, 0, 0);
+      }
+      for (; i < count; i++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i * 64], b[i * 4 * TS], acc, 0, 0, 0);
+      // D: column = lane % 16 (frame), rows 4 * (lane / 16) + r (filter inside the row block)
+#pragma unroll
+      for (int r = 0; r < 4; r++) emit(mb * 16 + kk * 4 + r, j, acc[r]);
+    }
+  } else {
+    const int f = tid & 15;
+    for (int m = tid >> 4; m < mel.nfilter; m += kSpecThreads / 16) {
+      const int kb = ((const int32_t __attribute__((address_space(1))) *)mel.bands)[2 * m];
+      const int ke = ((const int32_t __attribute__((address_space(1))) *)mel.bands)[2 * m + 1];
+      GFloat *w = (GFloat *)mel.weights + (size_t)m * mel.nbins;
+      float acc = 0.0f;
+      for (int k = kb; k < ke; k++) acc = fmaf(w[k], tile[k * TS + f], acc);
+      emit(m, f, acc);
+    }
+  }
+  if (mel.max_bits) {   // to_decibels(reference = the sample's maximum): fold this tile's maximum in
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
+    if (lane == 0 && vmax > 0.0f)
+      atomicMax((uint32_t *)((uint8_t *)mel.max_bits + (size_t)di * mel.max_stride), __float_as_uint(vmax));
+  }
+}
+
+template <int LOG2N, int FC, int MEL = 0>
 __global__ __launch_bounds__(kSpecThreads) void SpectrogramFastKernel(const daliamdSpectrogramDesc *__restrict__ descs,
                                                                       int ndesc, int total_wg, daliamdSpectrogramParams p,
                                                                       const float *__restrict__ window,
-                                                                      const float2 *__restrict__ twg) {
+                                                                      const float2 *__restrict__ twg, MelFuse mel) {
   constexpr int N = 1 << LOG2N, nfft = 2 * N;
   constexpr int U = N / 64;            // points per lane and frame
   constexpr int UB = U / 4;            // radix-4 butterflies per lane and frame
@@ -309,7 +389,8 @@ __global__ __launch_bounds__(kSpecThreads) void SpectrogramFastKernel(const dali
     const bool le = i < ndesc && descs[i].wg_start <= wg;
     di += __popcll(__ballot(le));
   }
-  const daliamdSpectrogramDesc &d = descs[__builtin_amdgcn_readfirstlane(di - 1)];
+  di = __builtin_amdgcn_readfirstlane(di - 1);
+  const daliamdSpectrogramDesc &d = descs[di];
   const int T = d.num_windows;
   const int t0 = (wg - d.wg_start) * FPG;
   GFloat *in = (GFloat *)d.in;
@@ -484,11 +565,18 @@ __global__ __launch_bounds__(kSpecThreads) void SpectrogramFastKernel(const dali
       }
     }
   }
+  if constexpr (MEL == 1) {   // the last tile of a row block may reach three bins past the spectrum: they must read as zero
+    if (tid < 3 * TS) tile[(N + 1) * TS + tid] = 0.0f;
+  }
   __syncthreads();
-  GOutFloat *gout = (GOutFloat *)d.out;
-  for (int idx = tid; idx < (N + 1) * FPG; idx += kSpecThreads) {
-    const int b = idx / FPG, f = idx % FPG;
-    if (t0 + f < T) gout[(size_t)b * T + t0 + f] = tile[b * TS + f];
+  if constexpr (MEL != 0) {
+    MelFromTile<MEL, N, TS>(tile, mel, d.out, T, t0, di, tid);
+  } else {
+    GOutFloat *gout = (GOutFloat *)d.out;
+    for (int idx = tid; idx < (N + 1) * FPG; idx += kSpecThreads) {
+      const int b = idx / FPG, f = idx % FPG;
+      if (t0 + f < T) gout[(size_t)b * T + t0 + f] = tile[b * TS + f];
+    }
   }
 }
 constexpr bool SpecFastPath(int nfft) { return nfft == 512 || nfft == 1024; }
@@ -496,7 +584,7 @@ constexpr int kSpecFastConcurrent = 4;
 inline int SpecFastLds(int nfft) {
   const int N = nfft / 2;
   const int work = kSpecWaves * kSpecFastConcurrent * (N + N / 8) * (int)sizeof(float2);
-  const int tile = (N + 1) * (4 * kSpecWaves + 1) * (int)sizeof(float);
+  const int tile = (N + 1 + 3) * (4 * kSpecWaves + 1) * (int)sizeof(float);   // (+ 3 zero rows for the fused mel product)
   return work > tile ? work : tile;
 }
 
@@ -791,7 +879,7 @@ daliamdResult_t daliamdSpectrogramRun(daliamdStream_t stream, const daliamdSpect
   {                                                                                                                      \
     auto kern = SpectrogramFastKernel<L, kSpecFastConcurrent>;                                                           \
     DALIAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
-    hipLaunchKernelGGL(kern, grid, block, lds, s, descs_dev, n, nwg, *p, window_dev, tw);                                \
+    hipLaunchKernelGGL(kern, grid, block, lds, s, descs_dev, n, nwg, *p, window_dev, tw, MelFuse{});                     \
   }
     if (p->nfft == 512) SPEC_FAST(8) else SPEC_FAST(9)
 #undef SPEC_FAST
@@ -904,6 +992,95 @@ daliamdResult_t daliamdMelFilterBankRun(daliamdStream_t stream, const daliamdMel
   return DALIAMD_SUCCESS;
 }
 
+daliamdResult_t daliamdMelFilterBankMfmaLayout(const float *weights, int nfilter, int nbins, float *tiles, int32_t *row_blocks,
+                                               int *num_tiles) {
+  DALIAMD_REQUIRE(weights && num_tiles && nfilter > 0 && nbins > 0, DALIAMD_ERROR_INVALID_ARGUMENT,
+                  "daliamdMelFilterBankMfmaLayout: invalid argument");
+  const int nrb = (nfilter + 15) / 16;
+  int total = 0;
+  for (int mb = 0; mb < nrb; mb++) {
+    int lo = nbins, hi = 0;   // bins any of the block's filters weighs
+    for (int m = mb * 16; m < std::min(nfilter, mb * 16 + 16); m++)
+      for (int k = 0; k < nbins; k++)
+        if (weights[(size_t)m * nbins + k] != 0.0f) {
+          lo = std::min(lo, k);
+          hi = std::max(hi, k + 1);
+        }
+    if (lo >= hi) lo = hi = 0;
+    const int k0 = lo & ~3, count = (hi - k0 + 3) / 4;
+    if (row_blocks) {
+      row_blocks[4 * mb] = total; row_blocks[4 * mb + 1] = count; row_blocks[4 * mb + 2] = k0; row_blocks[4 * mb + 3] = 0;
+    }
+    if (tiles)
+      for (int t = 0; t < count; t++)
+        for (int l = 0; l < 64; l++) {   // A operand of v_mfma_f32_16x16x4_f32: lane l holds A[l % 16][l / 16]
+          const int m = mb * 16 + (l & 15), k = k0 + 4 * t + (l >> 4);
+          tiles[(size_t)(total + t) * 64 + l] = m < nfilter && k < nbins ? weights[(size_t)m * nbins + k] : 0.0f;
+        }
+    total += count;
+  }
+  if (row_blocks) {   // deal the row blocks to the 4 waves of a workgroup: largest first, to the least loaded wave
+    std::vector<int> order(nrb);
+    for (int i = 0; i < nrb; i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](int x, int y) { return row_blocks[4 * x + 1] > row_blocks[4 * y + 1]; });
+    int load[kSpecWaves] = {0, 0, 0, 0};
+    for (int mb : order) {
+      int w = 0;
+      for (int q = 1; q < kSpecWaves; q++)
+        if (load[q] < load[w]) w = q;
+      row_blocks[4 * mb + 3] = w;
+      load[w] += row_blocks[4 * mb + 1];
+    }
+  }
+  *num_tiles = total;
+  return DALIAMD_SUCCESS;
+}
+
+daliamdResult_t daliamdSpectrogramMelRun(daliamdStream_t stream, const daliamdSpectrogramDesc *descs_dev, int n,
+                                         const daliamdSpectrogramParams *p, const float *window_dev, const float *twiddles_dev,
+                                         const daliamdSpecMelParams *m, int nwg) {
+  if (n == 0 || nwg == 0) return DALIAMD_SUCCESS;
+  DALIAMD_REQUIRE(descs_dev && p && window_dev && twiddles_dev && m && n > 0 && nwg > 0, DALIAMD_ERROR_INVALID_ARGUMENT,
+                  "daliamdSpectrogramMelRun: invalid argument");
+  DALIAMD_REQUIRE(SpecFastPath(p->nfft), DALIAMD_ERROR_UNSUPPORTED,
+                  "daliamdSpectrogramMelRun: the fused kernel exists for nfft 512 and 1024, got %d", p->nfft);
+  DALIAMD_REQUIRE(m->nbins == p->nfft / 2 + 1 && m->nfilter > 0, DALIAMD_ERROR_INVALID_ARGUMENT,
+                  "daliamdSpectrogramMelRun: the filter bank is made for %d bins, the transform has %d", m->nbins, p->nfft / 2 + 1);
+  const bool mfma = m->mfma_tiles != nullptr;
+  DALIAMD_REQUIRE(mfma ? m->row_blocks != nullptr : (m->weights && m->bands), DALIAMD_ERROR_INVALID_ARGUMENT,
+                  "daliamdSpectrogramMelRun: filter bank tables missing");
+  MelFuse f{};
+  f.tiles = m->mfma_tiles; f.row_blocks = m->row_blocks; f.weights = m->weights; f.bands = m->bands;
+  f.num_row_blocks = (m->nfilter + 15) / 16; f.nfilter = m->nfilter; f.nbins = m->nbins;
+  f.decibels = m->decibels;
+  if (m->decibels) {
+    DALIAMD_REQUIRE(m->reference > 0.0f, DALIAMD_ERROR_INVALID_ARGUMENT,
+                    "daliamdSpectrogramMelRun: fused decibels need an explicit reference (the per-sample maximum is only known "
+                    "after the launch: pass max_bits and run daliamdToDecibelsRun on the result)");
+    f.min_ratio = std::pow(10.0f, m->cutoff_db / m->multiplier);
+    if (f.min_ratio == 0.0f) f.min_ratio = std::nextafter(0.0f, 1.0f);
+    f.mul_log2 = m->multiplier * 0.3010299956639812f;
+    f.inv_ref = m->reference == 1.0f ? 1.0f : 1.0f / m->reference;
+  }
+  f.max_bits = m->max_bits; f.max_stride = m->max_stride;
+  dim3 grid(XcdGrid(nwg)), block(kSpecThreads);
+  hipStream_t s = (hipStream_t)stream;
+  const int lds = SpecFastLds(p->nfft);
+  const float2 *tw = reinterpret_cast<const float2 *>(twiddles_dev);
+  KernelTimer timer(mfma ? "SpectrogramMelMfmaKernel" : "SpectrogramMelKernel", s);
+#define SPEC_MEL(L, MODE)                                                                                                \
+  {                                                                                                                      \
+    auto kern = SpectrogramFastKernel<L, kSpecFastConcurrent, MODE>;                                                     \
+    DALIAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+    hipLaunchKernelGGL(kern, grid, block, lds, s, descs_dev, n, nwg, *p, window_dev, tw, f);                             \
+  }
+  if (p->nfft == 512) { if (mfma) SPEC_MEL(8, 1) else SPEC_MEL(8, 2) }
+  else { if (mfma) SPEC_MEL(9, 1) else SPEC_MEL(9, 2) }
+#undef SPEC_MEL
+  DALIAMD_HIP_CHECK(hipGetLastError());
+  return DALIAMD_SUCCESS;
+}
+
 daliamdResult_t daliamdToDecibelsSetup(daliamdDecibelDesc *descs, int n, int *nwg) {
   DALIAMD_REQUIRE(descs && nwg && n >= 0, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdToDecibelsSetup: NULL argument");
   int wg = 0;
@@ -924,7 +1101,9 @@ daliamdResult_t daliamdToDecibelsRun(daliamdStream_t stream, daliamdDecibelDesc 
   float min_ratio = std::pow(10.0f, cutoff_db / multiplier);        // to_decibels_op.h:41-49
   if (min_ratio == 0.0f) min_ratio = std::nextafter(0.0f, 1.0f);
   float mul_log2 = multiplier * 0.3010299956639812f;
-  if (!(reference > 0.0f))
+  // reference == 0: the per-sample maximum, found here; reference < 0: the maximum is ALREADY in descs_dev[i].max_bits
+  // (daliamdSpectrogramMelRun left it there)
+  if (reference == 0.0f)
     {
       daliamd::KernelTimer timer("DecibelMaxKernel", (hipStream_t)stream);
       hipLaunchKernelGGL(DecibelMaxKernel, dim3(XcdGrid(nwg)), dim3(kDbThreads), 0, (hipStream_t)stream, descs_dev, n, nwg);

@@ -32,6 +32,25 @@ struct DeferredPointwise {
 };
 void TryEnablePointwiseFusion(OperatorBase *producer, OperatorBase *consumer);
 
+// Spectrogram -> MelFilterBank (-> ToDecibels): the power spectrum is consumed where it is produced.  A 513-bin
+// spectrogram is 6.4 times the size of its 80-filter mel reduction; written to HBM and read back it is the whole traffic
+// of the audio path.  The fused kernel multiplies every 16-frame tile by the filter bank while it sits in LDS
+// (daliamdSpectrogramMelRun), so the spectrogram operator only hands its arguments on and the LAST operator of the chain
+// launches: MelFilterBank, or ToDecibels (inside the same launch when `reference` is given; as an in-place pass behind it
+// when the reference is the sample's maximum, which the fused kernel collects).
+struct DeferredAudio {
+  std::shared_ptr<TensorList> source;                 // the signal
+  daliamdSpectrogramParams params;
+  const float *window_dev = nullptr, *twiddles_dev = nullptr;
+  std::vector<daliamdSpectrogramDesc> descs;          // in / length / num_windows / wg_start set
+  int nwg = 0;
+  // set by a MelFilterBank that defers to a ToDecibels behind it
+  bool has_mel = false;
+  daliamdSpecMelParams mel{};
+};
+// true when the pair was fused (the pipeline then tries to extend the chain)
+bool TryEnableAudioFusion(OperatorBase *producer, OperatorBase *consumer);
+
 // The sample-index stream every reader draws from (Loader, dali/operators/reader/loader/loader.h:78-503,
 // loader.cc:78-87): sequential over the data set starting at this shard (start = size * shard_id / num_shards),
 // moving on to the next shard every epoch unless stick_to_shard, a shuffle reservoir of `initial_fill` samples,

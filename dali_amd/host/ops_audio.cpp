@@ -14,11 +14,14 @@
 namespace daliamd_host {
 
 // =============================================================================================
-// decoders.audio: PCM WAV (16-bit integer or 32-bit float) -> float32, like libsndfile's sf_readf_float
+// decoders.audio: RIFF/WAVE (8- / 16- / 24- / 32-bit PCM, 32-bit float) and FLAC, read the way libsndfile's
+// sf_readf_short / sf_readf_int / sf_readf_float read them (generic_decoder.cc:170-183): integer samples of b bits
+// become floats by 1 / 2^(b-1), int16 by keeping the top 16 bits (or shifting narrower ones up), int32 by shifting up
 // =============================================================================================
 DALI_SCHEMA(decoders__Audio)
-    .DocStr("Decodes waveforms from encoded audio data.\n\nSupported in this build: RIFF/WAVE with 16-bit PCM or 32-bit "
-            "float samples. The output is float32 in [-1, 1); the second output is the sampling rate.")
+    .DocStr("Decodes waveforms from encoded audio data.\n\nSupported in this build: RIFF/WAVE (8-, 16-, 24-, 32-bit PCM and "
+            "32-bit float samples) and FLAC; Ogg/Vorbis is refused. The output is float32 in [-1, 1) (or int16 / int32, "
+            "see `dtype`); the second output is the sampling rate.")
     .NumInput(1)
     .NumOutput(2)
     .AddOptionalArg("downmix", "If set to True, downmix all input channels to mono (1-D output).", ArgValue::Bool(false))
@@ -29,12 +32,24 @@ DALI_SCHEMA(decoders__Audio)
                     "filter; 50 gives 16 lobes and 100 gives 64 lobes.", ArgValue::Float(50.0));
 DALI_SCHEMA(AudioDecoder).DocStr("Legacy alias of decoders.audio").NumInput(1).NumOutput(2).AddParent("decoders__Audio");
 
-struct WavInfo { int channels = 0, bits = 0, tag = 0; int64_t frames = 0; double rate = 0; const uint8_t *data = nullptr; };
+// tag: 1 = integer PCM in the file (`bits` wide, little endian; 8-bit is unsigned), 3 = float32, 0xF1AC = FLAC (decoded
+// to int32 on demand)
+struct WavInfo { int channels = 0, bits = 0, tag = 0; int64_t frames = 0; double rate = 0; const uint8_t *data = nullptr;
+                 size_t nbytes = 0; };
+enum { kTagFlac = 0xF1AC };
 
 static WavInfo ParseWav(const uint8_t *p, size_t n, const std::string &src) {
   auto fail = [&](const char *why) { DALI_FAIL("Failed to decode ", src, ": ", why); };
-  if (n < 12 || memcmp(p, "RIFF", 4) || memcmp(p + 8, "WAVE", 4)) fail("not a RIFF/WAVE stream (only WAV is supported)");
   WavInfo w;
+  if (n >= 4 && !memcmp(p, "fLaC", 4)) {
+    daliamdAudioStreamInfo si;
+    if (daliamdFlacProbe(p, n, &si) != 0) fail(daliamdHostGetLastErrorMessage());
+    w.tag = kTagFlac; w.channels = si.channels; w.bits = si.bits_per_sample; w.rate = si.sample_rate; w.frames = si.frames;
+    w.data = p; w.nbytes = n;
+    return w;
+  }
+  if (n >= 4 && !memcmp(p, "OggS", 4)) fail("Ogg streams are not supported by this build (WAV and FLAC are)");
+  if (n < 12 || memcmp(p, "RIFF", 4) || memcmp(p + 8, "WAVE", 4)) fail("not a RIFF/WAVE or FLAC stream");
   size_t pos = 12;
   bool have_fmt = false;
   while (pos + 8 <= n) {
@@ -52,7 +67,8 @@ static WavInfo ParseWav(const uint8_t *p, size_t n, const std::string &src) {
     } else if (!memcmp(p + pos, "data", 4)) {
       if (!have_fmt) fail("data chunk before fmt chunk");
       size_t avail = std::min<size_t>(size, n - (pos + 8));
-      if (!((w.tag == 1 && w.bits == 16) || (w.tag == 3 && w.bits == 32))) fail("unsupported sample format (PCM16 / float32 only)");
+      if (!((w.tag == 1 && (w.bits == 8 || w.bits == 16 || w.bits == 24 || w.bits == 32)) || (w.tag == 3 && w.bits == 32)))
+        fail("unsupported sample format (8- / 16- / 24- / 32-bit PCM and 32-bit float are supported)");
       if (w.channels < 1) fail("no channels");
       w.frames = (int64_t)(avail / (w.bits / 8) / w.channels);
       w.data = body;
@@ -111,14 +127,36 @@ class AudioDecoderCpu : public OperatorBase {
         const int och = mono_out ? 1 : w.channels;
         const bool downmix = w.channels > 1 && downmix_;
         const int kout = dtype_ == DALI_INT16 ? DALIAMD_INT16 : dtype_ == DALI_INT32 ? DALIAMD_INT32 : DALIAMD_FLOAT;
-        if (dtype_ != DALI_FLOAT) DALI_ENFORCE(w.tag == 1, "decoders.audio: integer output from a float32 file is not supported");
+        if (dtype_ != DALI_FLOAT) DALI_ENFORCE(w.tag != 3, "decoders.audio: integer output from a float32 file is not supported");
+        // integer samples in the stream's own range (`bits` wide): straight from the WAV bytes, or a decoded FLAC stream
+        std::vector<int32_t> flac;
+        if (w.tag == kTagFlac) {
+          flac.resize((size_t)w.frames * w.channels);
+          if (daliamdFlacDecode(w.data, w.nbytes, flac.data(), w.frames) != 0)
+            DALI_FAIL("Failed to decode ", i < (int)ws.Input(0).source_info.size() ? ws.Input(0).source_info[i] : make_string("sample #", i),
+                      ": ", daliamdHostGetLastErrorMessage());
+        }
+        const int bits = w.bits;
+        auto isample = [&](int64_t k) -> int32_t {
+          if (w.tag == kTagFlac) return flac[k];
+          const uint8_t *q = w.data + k * (bits / 8);
+          switch (bits) {
+            case 8: return (int32_t)q[0] - 128;   // 8-bit WAV is unsigned
+            case 16: { int16_t sv; memcpy(&sv, q, 2); return sv; }
+            case 24: return (int32_t)((uint32_t)q[0] << 8 | (uint32_t)q[1] << 16 | (uint32_t)q[2] << 24) >> 8;
+            default: { int32_t sv; memcpy(&sv, q, 4); return sv; }
+          }
+        };
+        const float to_float = 1.0f / (float)((int64_t)1 << (bits - 1));
         if (!resample && !downmix && dtype_ != DALI_FLOAT) {
           const int64_t count = w.frames * w.channels;
           if (dtype_ == DALI_INT16) {
-            memcpy(out.raw(i), w.data, (size_t)count * 2);
+            int16_t *o16 = static_cast<int16_t *>(out.raw(i));
+            if (w.tag == 1 && bits == 16) memcpy(o16, w.data, (size_t)count * 2);
+            else for (int64_t k = 0; k < count; k++) o16[k] = (int16_t)(bits > 16 ? isample(k) >> (bits - 16) : isample(k) * (1 << (16 - bits)));
           } else {
             int32_t *o32 = static_cast<int32_t *>(out.raw(i));
-            for (int64_t k = 0; k < count; k++) { int16_t sv; memcpy(&sv, w.data + k * 2, 2); o32[k] = (int32_t)((uint32_t)(int32_t)sv << 16); }
+            for (int64_t k = 0; k < count; k++) o32[k] = (int32_t)((uint32_t)isample(k) << (32 - bits));
           }
           *static_cast<float *>(rate.raw(i)) = (float)w.rate;
           return;
@@ -132,7 +170,7 @@ class AudioDecoderCpu : public OperatorBase {
           float acc = 0;
           for (int c = 0; c < w.channels; c++) {
             float v;
-            if (w.tag == 1) { int16_t sv; memcpy(&sv, w.data + (f * w.channels + c) * 2, 2); v = sv * (1.0f / 32768); }
+            if (w.tag != 3) v = (float)isample(f * w.channels + c) * to_float;
             else memcpy(&v, w.data + (f * w.channels + c) * 4, 4);
             if (!mono_out) o[f * w.channels + c] = v;
             else if (w.channels == 1) acc = v;
@@ -223,7 +261,12 @@ class SpectrogramGpu : public OperatorBase {
     desc[0].type = DALI_FLOAT;
     desc[0].shape.resize(n);
     for (int i = 0; i < n; i++) desc[0].shape[i] = {p_.nfft / 2 + 1, descs_[i].num_windows};
-    return true;
+    return !(fused_ && ws.backend != OpType::CPU);   // fused: no buffer, the mel filter bank behind launches for both
+  }
+  // MelFilterBank is the only consumer: hand the arguments on (nfft 512 / 1024: the sizes the fused kernel exists for)
+  bool EnableFusion() {
+    fused_ = p_.nfft == 512 || p_.nfft == 1024;
+    return fused_;
   }
   void RunImpl(Workspace &ws) override {
     TensorList &out = ws.Output(0);
@@ -255,9 +298,21 @@ class SpectrogramGpu : public OperatorBase {
       KCHECK(daliamdStreamSynchronize(ws.stream));  // one-time: `window_` is pageable host memory
       window_uploaded_ = true;
     }
+    const float *tables = static_cast<const float *>(window_dev_.data());
+    if (fused_) {
+      auto d = std::make_shared<DeferredAudio>();
+      d->source = ws.inputs[0];
+      d->params = p_;
+      d->window_dev = tables;
+      d->twiddles_dev = tables + twiddle_offset_;
+      d->descs = descs_;
+      d->nwg = nwg_;
+      out.Resize({}, DALI_FLOAT);
+      out.deferred_audio = d;
+      return;
+    }
     for (int i = 0; i < n; i++) descs_[i].out = static_cast<float *>(out.raw(i));
     auto *dev = static_cast<const daliamdSpectrogramDesc *>(uploader_.Upload(descs_.data(), n * sizeof(descs_[0]), ws.stream, ws.ring + 1));
-    const float *tables = static_cast<const float *>(window_dev_.data());
     KCHECK(daliamdSpectrogramRun(ws.stream, dev, n, &p_, tables, tables + twiddle_offset_, nwg_, lds_));
     NoteLaunch(ws, "spectrogram");
   }
@@ -269,6 +324,7 @@ class SpectrogramGpu : public OperatorBase {
   bool window_uploaded_ = false;
   size_t twiddle_offset_ = 0;
   int nwg_ = 0, lds_ = 0;
+  bool fused_ = false;
   std::vector<daliamdSpectrogramDesc> descs_;
   DescUploader uploader_;
 };
@@ -305,8 +361,22 @@ class MelFilterBankGpu : public OperatorBase {
     formula_ = f == "htk";
     DALI_ENFORCE(nfilter_ > 0, "`nfilter` must be positive");
   }
+  void ExpectFusedInput() { fused_input_ = true; }
+  bool HasFusedInput() const { return fused_input_; }
+  void DeferToDecibels() { defer_ = true; }
   bool SetupImpl(std::vector<OutputDesc> &desc, const Workspace &ws) override {
     const TensorList &in = ws.Input(0);
+    if (fused_input_ && ws.backend != OpType::CPU) {
+      const DeferredAudio *def = in.deferred_audio.get();
+      DALI_ENFORCE(def, "internal: MelFilterBank expected the deferred arguments of the Spectrogram in front of it");
+      const int n = (int)def->descs.size(), nb = def->params.nfft / 2 + 1;
+      DALI_ENFORCE(nbins_ == 0 || nb == nbins_, "All spectrograms must have the same number of frequency bins");
+      nbins_ = nb;
+      desc[0].type = DALI_FLOAT;
+      desc[0].shape.resize(n);
+      for (int i = 0; i < n; i++) desc[0].shape[i] = {nfilter_, def->descs[i].num_windows};
+      return !defer_;
+    }
     DALI_ENFORCE(in.type() == DALI_FLOAT, "MelFilterBank expects float32 input");
     int n = in.num_samples();
     descs_.assign(n, daliamdMelDesc{});
@@ -328,8 +398,8 @@ class MelFilterBankGpu : public OperatorBase {
     TensorList &out = ws.Output(0);
     out.SetLayout("ft");
     int n = (int)descs_.size();
-    if (!n) return;
     if (ws.backend == OpType::CPU) {
+      if (!n) return;
       if (host_weights_.empty()) {
         host_weights_.resize((size_t)nfilter_ * nbins_);
         KCHECK(daliamdMelFilterBankWeights(nfilter_, 2 * (nbins_ - 1), sample_rate_, freq_low_, freq_high_, normalize_, formula_,
@@ -346,18 +416,61 @@ class MelFilterBankGpu : public OperatorBase {
       NoteLaunch(ws, "host_mel_filter_bank");
       return;
     }
+    const DeferredAudio *def = fused_input_ ? ws.Input(0).deferred_audio.get() : nullptr;
+    if (def) n = (int)def->descs.size();
+    if (!n) return;
     if (weights_.empty()) {
       weights_.resize((size_t)nfilter_ * nbins_);
       KCHECK(daliamdMelFilterBankWeights(nfilter_, 2 * (nbins_ - 1), sample_rate_, freq_low_, freq_high_, normalize_, formula_,
                                          weights_.data()));
       std::vector<int32_t> bands(2 * (size_t)nfilter_);
       KCHECK(daliamdMelFilterBankBands(weights_.data(), nfilter_, nbins_, bands.data()));
-      const size_t wbytes = (weights_.size() * sizeof(float) + 15) / 16 * 16;
-      weights_dev_.Reserve(wbytes + bands.size() * sizeof(int32_t));
-      KCHECK(daliamdMemcpyH2DAsync(weights_dev_.data(), weights_.data(), weights_.size() * sizeof(float), ws.stream));
-      bands_dev_ = reinterpret_cast<const int32_t *>(static_cast<char *>(weights_dev_.data()) + wbytes);
+      // the same filters as 16 x 4 tiles for the matrix cores (the fused kernel)
+      int ntiles = 0;
+      const int nrb = (nfilter_ + 15) / 16;
+      KCHECK(daliamdMelFilterBankMfmaLayout(weights_.data(), nfilter_, nbins_, nullptr, nullptr, &ntiles));
+      std::vector<float> tiles((size_t)ntiles * 64);
+      std::vector<int32_t> row_blocks(4 * (size_t)nrb);
+      KCHECK(daliamdMelFilterBankMfmaLayout(weights_.data(), nfilter_, nbins_, tiles.data(), row_blocks.data(), &ntiles));
+      auto pad16 = [](size_t b) { return (b + 15) / 16 * 16; };
+      const size_t wbytes = pad16(weights_.size() * sizeof(float)), bbytes = pad16(bands.size() * sizeof(int32_t)),
+                   tbytes = pad16(tiles.size() * sizeof(float));
+      weights_dev_.Reserve(wbytes + bbytes + tbytes + row_blocks.size() * sizeof(int32_t));
+      char *base = static_cast<char *>(weights_dev_.data());
+      bands_dev_ = reinterpret_cast<const int32_t *>(base + wbytes);
+      tiles_dev_ = reinterpret_cast<const float *>(base + wbytes + bbytes);
+      row_blocks_dev_ = reinterpret_cast<const int32_t *>(base + wbytes + bbytes + tbytes);
+      KCHECK(daliamdMemcpyH2DAsync(base, weights_.data(), weights_.size() * sizeof(float), ws.stream));
       KCHECK(daliamdMemcpyH2DAsync(const_cast<int32_t *>(bands_dev_), bands.data(), bands.size() * sizeof(int32_t), ws.stream));
+      KCHECK(daliamdMemcpyH2DAsync(const_cast<float *>(tiles_dev_), tiles.data(), tiles.size() * sizeof(float), ws.stream));
+      KCHECK(daliamdMemcpyH2DAsync(const_cast<int32_t *>(row_blocks_dev_), row_blocks.data(), row_blocks.size() * sizeof(int32_t),
+                                   ws.stream));
       KCHECK(daliamdStreamSynchronize(ws.stream));  // one-time upload from pageable memory, read by later iterations
+    }
+    if (def) {
+      // fused: spectrogram + filter bank in one launch - here, or (deferred once more) by the ToDecibels behind
+      daliamdSpecMelParams mp{};
+      const bool use_valu = getenv("DALI_AMD_MEL_VALU") && atoi(getenv("DALI_AMD_MEL_VALU")) != 0;   // (benchmarks: the banded VALU variant)
+      mp.mfma_tiles = use_valu ? nullptr : tiles_dev_;
+      mp.row_blocks = row_blocks_dev_;
+      mp.weights = static_cast<const float *>(weights_dev_.data());
+      mp.bands = bands_dev_;
+      mp.nfilter = nfilter_;
+      mp.nbins = nbins_;
+      if (defer_) {
+        auto d = std::make_shared<DeferredAudio>(*def);
+        d->has_mel = true;
+        d->mel = mp;
+        out.Resize({}, DALI_FLOAT);
+        out.deferred_audio = d;
+        return;
+      }
+      std::vector<daliamdSpectrogramDesc> descs = def->descs;
+      for (int i = 0; i < n; i++) descs[i].out = static_cast<float *>(out.raw(i));
+      auto *dev = static_cast<const daliamdSpectrogramDesc *>(uploader_.Upload(descs.data(), n * sizeof(descs[0]), ws.stream, ws.ring + 1));
+      KCHECK(daliamdSpectrogramMelRun(ws.stream, dev, n, &def->params, def->window_dev, def->twiddles_dev, &mp, def->nwg));
+      NoteLaunch(ws, use_valu ? "spectrogram_mel_fused" : "spectrogram_mel_fused_mfma");
+      return;
     }
     for (int i = 0; i < n; i++) descs_[i].out = static_cast<float *>(out.raw(i));
     int nwg = 0;
@@ -374,7 +487,9 @@ class MelFilterBankGpu : public OperatorBase {
   bool normalize_;
   std::vector<float> weights_, host_weights_;
   Buffer weights_dev_;
-  const int32_t *bands_dev_ = nullptr;
+  const int32_t *bands_dev_ = nullptr, *row_blocks_dev_ = nullptr;
+  const float *tiles_dev_ = nullptr;
+  bool fused_input_ = false, defer_ = false;
   std::vector<daliamdMelDesc> descs_;
   DescUploader uploader_;
 };
@@ -404,8 +519,17 @@ class ToDecibelsGpu : public OperatorBase {
       DALI_ENFORCE(reference_ > 0, "`reference` must be positive");
     }
   }
+  void ExpectFusedInput() { fused_input_ = true; }
   bool SetupImpl(std::vector<OutputDesc> &desc, const Workspace &ws) override {
     const TensorList &in = ws.Input(0);
+    if (fused_input_ && ws.backend != OpType::CPU) {
+      const DeferredAudio *def = in.deferred_audio.get();
+      DALI_ENFORCE(def && def->has_mel, "internal: ToDecibels expected the deferred arguments of the MelFilterBank in front of it");
+      desc[0].type = DALI_FLOAT;
+      desc[0].shape.clear();
+      for (auto &d : def->descs) desc[0].shape.push_back({def->mel.nfilter, d.num_windows});
+      return true;
+    }
     DALI_ENFORCE(in.type() == DALI_FLOAT, "ToDecibels expects float32 input");
     desc[0].type = DALI_FLOAT;
     desc[0].shape.clear();
@@ -416,6 +540,42 @@ class ToDecibelsGpu : public OperatorBase {
     const TensorList &in = ws.Input(0);
     TensorList &out = ws.Output(0);
     out.SetLayout(in.layout());
+    if (const DeferredAudio *def = fused_input_ && ws.backend != OpType::CPU ? in.deferred_audio.get() : nullptr) {
+      // spectrogram + filter bank + decibels.  With a given reference it is ONE launch; with the sample's maximum as the
+      // reference the fused kernel leaves the mel energies in the output and their maxima in this operator's descriptor
+      // table, and the element-wise pass runs in place behind it.
+      out.SetLayout("ft");
+      const int n = (int)def->descs.size();
+      if (!n) return;
+      std::vector<daliamdSpectrogramDesc> sd = def->descs;
+      descs_.assign(n, daliamdDecibelDesc{});
+      for (int i = 0; i < n; i++) {
+        sd[i].out = static_cast<float *>(out.raw(i));
+        descs_[i].in = descs_[i].out = sd[i].out;
+        descs_[i].size = (int64_t)def->mel.nfilter * sd[i].num_windows;
+      }
+      daliamdSpecMelParams mp = def->mel;
+      const bool by_max = !(reference_ > 0.0f);
+      int nwg = 0;
+      daliamdDecibelDesc *ddev = nullptr;
+      if (by_max) {
+        KCHECK(daliamdToDecibelsSetup(descs_.data(), n, &nwg));
+        ddev = static_cast<daliamdDecibelDesc *>(uploader_.Upload(descs_.data(), n * sizeof(descs_[0]), ws.stream, ws.ring + 1));
+        mp.max_bits = &ddev->max_bits;
+        mp.max_stride = (int32_t)sizeof(daliamdDecibelDesc);
+      } else {
+        mp.decibels = 1;
+        mp.multiplier = multiplier_; mp.reference = reference_; mp.cutoff_db = cutoff_;
+      }
+      auto *dev = static_cast<const daliamdSpectrogramDesc *>(spec_uploader_.Upload(sd.data(), n * sizeof(sd[0]), ws.stream, ws.ring + 1));
+      KCHECK(daliamdSpectrogramMelRun(ws.stream, dev, n, &def->params, def->window_dev, def->twiddles_dev, &mp, def->nwg));
+      NoteLaunch(ws, mp.mfma_tiles ? "spectrogram_mel_fused_mfma" : "spectrogram_mel_fused");
+      if (by_max) {
+        KCHECK(daliamdToDecibelsRun(ws.stream, ddev, n, nwg, multiplier_, -1.0f, cutoff_));
+        NoteLaunch(ws, "to_decibels");
+      }
+      return;
+    }
     int n = in.num_samples();
     if (!n) return;
     if (ws.backend == OpType::CPU) {
@@ -446,11 +606,30 @@ class ToDecibelsGpu : public OperatorBase {
 
  private:
   float multiplier_, cutoff_, reference_ = 0.0f;
+  bool fused_input_ = false;
   std::vector<daliamdDecibelDesc> descs_;
-  DescUploader uploader_;
+  DescUploader uploader_, spec_uploader_;
 };
 DALI_REGISTER_OPERATOR(ToDecibels, ToDecibelsGpu, GPU);
 DALI_REGISTER_OPERATOR(ToDecibels, ToDecibelsGpu, CPU);
+
+bool TryEnableAudioFusion(OperatorBase *producer, OperatorBase *consumer) {
+  if (getenv("DALI_AMD_NO_AUDIO_FUSION") && atoi(getenv("DALI_AMD_NO_AUDIO_FUSION")) != 0) return false;
+  if (auto *spec = dynamic_cast<SpectrogramGpu *>(producer)) {
+    auto *mel = dynamic_cast<MelFilterBankGpu *>(consumer);
+    if (!mel || !spec->EnableFusion()) return false;
+    mel->ExpectFusedInput();
+    return true;
+  }
+  if (auto *mel = dynamic_cast<MelFilterBankGpu *>(producer)) {
+    auto *db = dynamic_cast<ToDecibelsGpu *>(consumer);
+    if (!db || !mel->HasFusedInput()) return false;
+    mel->DeferToDecibels();
+    db->ExpectFusedInput();
+    return true;
+  }
+  return false;
+}
 
 // =============================================================================================
 // MFCC (dali/operators/audio/mfcc/mfcc.cc:24-182): DCT along the frequency axis + liftering

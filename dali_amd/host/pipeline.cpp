@@ -164,6 +164,15 @@ void Pipeline::Build(const std::vector<std::pair<std::string, std::string>> &out
     Node &p = nodes_[n.in_node[0]];
     if (consumers[n.in_node[0]] == 1 && p.type == OpType::GPU) TryEnablePointwiseFusion(p.op.get(), n.op.get());
   }
+  // ... and Spectrogram -> MelFilterBank (-> ToDecibels) chains with single consumers are one launch (two when the decibel
+  // reference is the sample's maximum); in graph order, so that the mel operator knows about its input before the
+  // decibel operator asks it
+  for (auto &n : nodes_) {
+    const std::string &sn = n.spec.SchemaName();
+    if ((sn != "MelFilterBank" && sn != "ToDecibels") || n.in_node.empty() || n.type != OpType::GPU) continue;
+    Node &p = nodes_[n.in_node[0]];
+    if (consumers[n.in_node[0]] == 1 && p.type == OpType::GPU) TryEnableAudioFusion(p.op.get(), n.op.get());
+  }
   slot_events_.assign(ring_, nullptr);
   if (!streams_.empty())
     for (auto &e : slot_events_) KCHECK(daliamdEventCreate(&e, 2));  // the consumer sleeps in Outputs(), it does not poll

@@ -143,7 +143,21 @@ class Pipeline:
                                 self._prefetch_queue_depth, self._exec_async, self._set_affinity)
         if getattr(self, "_operator_timing", False):
             be.enable_operator_timing()
+        # Operators that do not contribute to an output are pruned, like the reference's graph lowering does
+        # (pipeline.cc: "prune" of unused operators; `preserve=True` keeps one alive)
+        by_inst = {op[1]: op for op in self._ops}
+        needed, stack = set(), [o.source for o in self._outputs]
+        stack += [op[1] for op in self._ops if op[3].get("preserve")]
+        while stack:
+            inst = stack.pop()
+            if inst in needed or inst not in by_inst:
+                continue
+            needed.add(inst)
+            op = by_inst[inst]
+            stack += [n.source for n in op[4]] + [n.source for n in op[5].values()]
         for schema_name, inst, device, init_args, inputs, arg_inputs, outs in self._ops:
+            if inst not in needed:
+                continue
             spec = _b.OpSpec(schema_name)
             spec.add_arg("device", device)
             for k, v in init_args.items():

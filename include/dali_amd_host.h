@@ -219,6 +219,22 @@ DALIAMD_HOST_API int daliamdDctHost(const float *in, int n_in, int64_t inner, co
  * include/dali/core/convert.h:262-350).  Returns 0 on success. */
 DALIAMD_HOST_API int daliamdConvertNormHost(const void *in, int in_dtype, void *out, int out_dtype, int64_t count, int mode);
 
+/* ----------------------------------------------------------------------------------------------
+ * FLAC streams for decoders.audio (the reference decodes them through libsndfile / libFLAC:
+ * dali/operators/decoder/audio/generic_decoder.cc:180-206; LibriSpeech ships as FLAC).  RFC 9639: constant, verbatim,
+ * fixed-predictor and LPC subframes, partitioned Rice residuals with escapes, wasted bits, the three stereo
+ * decorrelation modes, 4 to 32 bits per sample; CRC-8 / CRC-16 of every frame are checked.  Probe reads STREAMINFO
+ * (frames = samples per channel; a stream that does not state it is walked once); Decode writes `frames` x channels
+ * interleaved samples in the stream's own integer range.
+ * -------------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t channels, bits_per_sample;
+  double sample_rate;
+  int64_t frames;
+} daliamdAudioStreamInfo;
+DALIAMD_HOST_API int daliamdFlacProbe(const uint8_t *data, size_t size, daliamdAudioStreamInfo *info);
+DALIAMD_HOST_API int daliamdFlacDecode(const uint8_t *data, size_t size, int32_t *pcm, int64_t frames);
+
 #ifdef __cplusplus
 }
 #endif

@@ -488,6 +488,36 @@ DALIAMD_API daliamdResult_t daliamdMelFilterBankRun(daliamdStream_t stream, cons
                                                    int num_workgroups, const float *weights_dev, const int32_t *bands_dev,
                                                    int nfilter, int nbins);
 
+/* The same product for the f32 matrix cores: the filter bank cut into 16-filter x 4-bin tiles in the A-operand lane
+ * order of v_mfma_f32_16x16x4_f32 (lane l: W[16 b + l % 16][k0 + 4 t + l / 16]); a row block of 16 filters only owns the
+ * tiles between its first and last weighted bin.  tiles = NULL: *num_tiles is the count to allocate (64 floats each);
+ * row_blocks: 4 ints per row block {first tile, tile count, first bin, wave of the workgroup that takes it}. */
+DALIAMD_API daliamdResult_t daliamdMelFilterBankMfmaLayout(const float *weights_host, int nfilter, int nbins, float *tiles,
+                                                          int32_t *row_blocks, int *num_tiles);
+/* Spectrogram -> mel filter bank (-> decibels) in ONE launch: the power spectrum of a 16-frame tile is multiplied by the
+ * filter bank where it sits in LDS; what reaches HBM is [nfilter][frames] only.  descs as for daliamdSpectrogramRun
+ * (Setup included) with out = [nfilter][num_windows]; nfft 512 / 1024.  mfma_tiles != NULL: the product runs on the matrix
+ * cores (reference: the filterbank x frames GEMM of dali/kernels/audio/mel_scale/mel_filter_bank_gpu.cu:104-128), else as
+ * the banded VALU product of daliamdMelFilterBankRun.  decibels: also apply daliamdToDecibelsRun's formula with the given
+ * reference (> 0).  max_bits: optional, per sample i at byte offset i * max_stride: receives the bit pattern of the
+ * maximum mel value (zero it first) - for to_decibels(reference = maximum): pass the max_bits field of the uploaded
+ * daliamdDecibelDesc table and call daliamdToDecibelsRun with reference = -1 afterwards. */
+typedef struct {
+  const float *mfma_tiles;
+  const int32_t *row_blocks;
+  const float *weights;       /* dense [nfilter][nbins] and bands: the VALU variant */
+  const int32_t *bands;
+  int32_t nfilter, nbins;
+  int32_t decibels;
+  float multiplier, reference, cutoff_db;
+  uint32_t *max_bits;
+  int32_t max_stride;
+} daliamdSpecMelParams;
+DALIAMD_API daliamdResult_t daliamdSpectrogramMelRun(daliamdStream_t stream, const daliamdSpectrogramDesc *descs_dev, int n,
+                                                    const daliamdSpectrogramParams *params, const float *window_dev,
+                                                    const float *twiddles_dev, const daliamdSpecMelParams *mel,
+                                                    int num_workgroups);
+
 typedef struct {
   const float *in;
   float *out;
@@ -496,7 +526,8 @@ typedef struct {
   int32_t wg_start;     /* filled by Setup */
 } daliamdDecibelDesc;
 DALIAMD_API daliamdResult_t daliamdToDecibelsSetup(daliamdDecibelDesc *descs_host, int n, int *num_workgroups);
-/* reference <= 0: use the per-sample maximum (1 when that maximum is 0); the kernels then write descs_dev[i].max_bits */
+/* reference == 0: use the per-sample maximum (1 when that maximum is 0), found by a first kernel that writes
+ * descs_dev[i].max_bits; reference < 0: the maximum is already there (daliamdSpectrogramMelRun); `in` may equal `out` */
 DALIAMD_API daliamdResult_t daliamdToDecibelsRun(daliamdStream_t stream, daliamdDecibelDesc *descs_dev, int n,
                                                 int num_workgroups, float multiplier, float reference, float cutoff_db);
 

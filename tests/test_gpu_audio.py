@@ -325,3 +325,78 @@ def test_audio_resample_integer_sample_types_on_the_gpu(in_t, out_t):
             d = np.abs(got.astype(np.int64) - ref.astype(np.int64))
             assert d.max() <= max(1.0, 2e-4 * full), (d.max(), full)
             assert (d > max(1.0, 2e-6 * full)).mean() < 0.01
+
+
+def _chain_pipe(bs, outputs, reference=None, **kw):
+    """spectrogram -> mel_filter_bank -> to_decibels with ONLY `outputs` leaving the pipeline: a chain whose spectrogram
+    (and mel energies) have a single consumer is fused into one launch (ops.h: DeferredAudio)."""
+    from dali_amd import fn
+    from dali_amd.pipeline import Pipeline
+    pipe = Pipeline(batch_size=bs, num_threads=2, device_id=0, prefetch_queue_depth=1)
+    with pipe:
+        x = fn.external_source(name="x")
+        spec = fn.spectrogram(x.gpu(), nfft=kw.get("nfft", 1024), window_length=kw.get("wl", 1024),
+                              window_step=kw.get("step", 256), power=kw.get("power", 2),
+                              center_windows=kw.get("center", True), reflect_padding=kw.get("reflect", True))
+        mel = fn.mel_filter_bank(spec, nfilter=kw.get("nfilter", 80), sample_rate=16000.0, freq_high=8000.0,
+                                 mel_formula=kw.get("formula", "slaney"), normalize=kw.get("normalize", True))
+        ref = {} if reference is None else {"reference": reference}
+        db = fn.to_decibels(mel, multiplier=10.0, cutoff_db=-80.0, **ref)
+        nodes = dict(spec=spec, mel=mel, db=db)
+        pipe.set_outputs(*[nodes[o] for o in outputs])
+    pipe.build()
+    return pipe
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(nfft=512, wl=400, step=160, nfilter=64, formula="htk"),
+                                dict(power=1, center=False, nfilter=128), dict(reflect=False, normalize=False, nfilter=23)])
+@pytest.mark.parametrize("variant", ["mfma", "valu"])
+def test_fused_spectrogram_mel_decibels_equals_the_three_launches(kw, variant, monkeypatch):
+    """The fused launch (power tile -> filter bank in LDS, on the f32 matrix cores or as the banded VALU product) gives
+    what the three separate kernels give: the mel energies are the same ascending-k fma chain (f32 MFMA accumulates
+    exactly like fmaf; zero weights add exact zeros), so the comparison is bit for bit; the unfused chain itself is held
+    to the oracle by test_audio_pipeline_matches_oracle."""
+    monkeypatch.setenv("DALI_AMD_MEL_VALU", "1" if variant == "valu" else "0")
+    rng = np.random.default_rng(21)
+    sigs = [synth_signal(rng, s).astype(np.float32) for s in (1.3, 2.0, 0.05 if kw.get("center", True) else 0.7, 3.1, 0.9)]
+    name = "spectrogram_mel_fused" + ("_mfma" if variant == "mfma" else "")
+    plain = _chain_pipe(len(sigs), ["spec", "mel", "db"], **kw)
+    plain.feed_input("x", sigs)
+    _, mel0, db0 = plain.run()
+    assert plain.executed_kernels() == ["h2d_copy", "spectrogram", "mel_filter_bank_banded", "to_decibels"]
+    # 1. mel only
+    p1 = _chain_pipe(len(sigs), ["mel"], **kw)
+    p1.feed_input("x", sigs)
+    (mel1,) = p1.run()
+    assert p1.executed_kernels() == ["h2d_copy", name]
+    # 2. decibels against the sample's maximum: fused launch (collects the maxima) + the in-place element-wise pass
+    p2 = _chain_pipe(len(sigs), ["db"], **kw)
+    p2.feed_input("x", sigs)
+    (db2,) = p2.run()
+    assert p2.executed_kernels() == ["h2d_copy", name, "to_decibels"]
+    # 3. decibels against a given reference: one launch
+    plain3 = _chain_pipe(len(sigs), ["mel", "db"], reference=0.37, **kw)
+    plain3.feed_input("x", sigs)
+    _, db3_ref = plain3.run()
+    p3 = _chain_pipe(len(sigs), ["db"], reference=0.37, **kw)
+    p3.feed_input("x", sigs)
+    (db3,) = p3.run()
+    assert p3.executed_kernels() == ["h2d_copy", name]
+    for i in range(len(sigs)):
+        a, b = mel0[i].as_cpu(), mel1[i].as_cpu()
+        assert a.shape == b.shape == (kw.get("nfilter", 80), a.shape[1])
+        assert np.array_equal(a, b), f"mel sample {i}: max rel diff {(np.abs(a - b) / (np.abs(a).max() + 1e-30)).max()}"
+        assert np.array_equal(db0[i].as_cpu(), db2[i].as_cpu()), f"dB (max reference) sample {i}"
+        assert np.array_equal(db3_ref[i].as_cpu(), db3[i].as_cpu()), f"dB (reference 0.37) sample {i}"
+
+
+def test_chains_the_fused_kernel_does_not_cover_run_unfused():
+    rng = np.random.default_rng(4)
+    sigs = [synth_signal(rng, 0.5).astype(np.float32) for _ in range(2)]
+    pipe = _chain_pipe(2, ["db"], nfft=2048, wl=2048, step=512)       # only nfft 512 / 1024 have the register-resident FFT
+    pipe.feed_input("x", sigs)
+    (db,) = pipe.run()
+    assert pipe.executed_kernels() == ["h2d_copy", "spectrogram", "mel_filter_bank_banded", "to_decibels"]
+    ref = A.to_decibels(A.mel_filter_bank(A.spectrogram(sigs[0], nfft=2048, window_length=2048, window_step=512), 80, 16000.0, 0.0,
+                                          8000.0, True, "slaney"), 10.0, 0.0, -80.0)
+    assert np.abs(db[0].as_cpu() - ref).max() <= 2e-2
