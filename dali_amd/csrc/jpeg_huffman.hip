@@ -702,10 +702,19 @@ __global__ __launch_bounds__(kDcThreads) void DcKernel(const daliamdJpegHuffDesc
 #ifndef DALIAMD_BLOCK_WAVES
 #define DALIAMD_BLOCK_WAVES 4
 #endif
-constexpr int kBlockWaves = DALIAMD_BLOCK_WAVES;  // per wave 8.4 KB of coefficients + 2.1 KB transpose buffer + 0.5 KB,
-constexpr int kBlockThreads = kBlockWaves * 64;   // + 11 KB of tables per workgroup
-constexpr int kCoefStride = 66;  // int16 per block: 64 coefficients, the scratch slot, one pad (33 dwords: odd -> no bank conflicts)
-constexpr int kTransStride = 68; // dwords per block in the transpose buffer
+constexpr int kBlockWaves = DALIAMD_BLOCK_WAVES;  // per wave 8.3 KB of coefficients, + 11 KB of tables per workgroup
+constexpr int kBlockThreads = kBlockWaves * 64;
+// Coefficients of a wave's 64 blocks in LDS, COEFFICIENT-major: element k of lane l's block is the int16 at k * 64 + l
+// (row 64 swallows the stores that carry nothing).  Whatever positions the lanes of a wave store to in one step of the
+// decode loop, lane l only ever touches bank l / 2 (+ 32 for odd k): at most two lanes meet in a bank, where the
+// block-major layout this replaces (33 dwords per block) spread 64 unrelated positions over the banks at random and
+// paid 3-4 conflict cycles per store (SQ_LDS_BANK_CONFLICT 12.6 M against 8.6 M busy LDS cycles in round 2's profile).
+// Reading a fixed coefficient for all lanes (the IDCT below) is one contiguous 128-byte row: conflict-free.
+constexpr int kCoefRows = 65;
+struct LaneCoef {   // what DecodeBlockAc stores through
+  int16_t *base;
+  __device__ __forceinline__ int16_t &operator[](uint32_t k) const { return base[k * 64]; }
+};
 #ifndef DALIAMD_BLOCK_TASKS
 #define DALIAMD_BLOCK_TASKS 3
 #endif
@@ -731,6 +740,14 @@ __device__ __constant__ uint8_t kScanIndexOfColMajor[64] = {
     14, 16, 25, 31, 39, 46, 50, 57, 15, 26, 30, 40, 45, 51, 56, 58, 27, 29, 41, 44, 52, 55, 59, 62, 28, 42, 43, 53, 54, 60,
     61, 63};
 
+// the same as a compile-time function (LDS offsets of the IDCT's reads become immediates)
+__host__ __device__ constexpr int kScanIndexOfColMajorHost(int p) {
+  constexpr uint8_t t[64] = {0, 2, 3, 9, 10, 20, 21, 35, 1, 4, 8, 11, 19, 22, 34, 36, 5, 7, 12, 18, 23, 33, 37, 48, 6, 13, 17, 24,
+                             32, 38, 47, 49, 14, 16, 25, 31, 39, 46, 50, 57, 15, 26, 30, 40, 45, 51, 56, 58, 27, 29, 41, 44, 52, 55,
+                             59, 62, 28, 42, 43, 53, 54, 60, 61, 63};
+  return t[p];
+}
+
 // LDS accesses of one wave are executed in order; this only keeps the compiler from moving them across the point
 __device__ __forceinline__ void WaveSync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -740,9 +757,7 @@ __device__ __forceinline__ void WaveSync() {
 
 __global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHuffDesc *__restrict__ descs, int n, int nwg) {
   __shared__ __attribute__((aligned(16))) HalfTables T;
-  __shared__ __attribute__((aligned(16))) int16_t coef[kBlockWaves][64 * kCoefStride];
-  __shared__ __attribute__((aligned(16))) int32_t trans[kBlockWaves][8][kTransStride];
-  __shared__ __attribute__((aligned(16))) uint64_t info[kBlockWaves][64];
+  __shared__ __attribute__((aligned(16))) int16_t coef[kBlockWaves][kCoefRows * 64];
   __shared__ __attribute__((aligned(16))) uint16_t quant[3][64];
   __shared__ BlockGeom G;
   const int wg = XcdRemap(blockIdx.x, nwg);
@@ -807,12 +822,8 @@ __global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHu
   const GlobalI32 *blk_dc = (const GlobalI32 *)(d.scratch + lay.blk_dc);
   const GlobalU16 *blk_seg = (const GlobalU16 *)(d.scratch + lay.blk_seg);
   const GlobalI32 *segs_i = (const GlobalI32 *)(d.scratch + lay.segs);  // SegRec fields as ints (global loads, not flat)
-  const int part = lane & 7, lb = lane >> 3;
-  int zi[8];  // scan index of the coefficients of column `part`
-#pragma unroll
-  for (int r8 = 0; r8 < 8; r8++) zi[r8] = kScanIndexOfColMajor[part * 8 + r8];
   int16_t *wcoef = &coef[wave][0];
-  int16_t *mycoef = wcoef + lane * kCoefStride;
+  const LaneCoef mycoef{wcoef + lane};
   // the waves share the tasks of each class evenly (a luma task takes 2-3 times as long as a chroma task)
   const int my0 = wave < tasks0 ? (tasks0 - wave + kBlockWaves - 1) / kBlockWaves : 0;
   const int rwave = kBlockWaves - 1 - wave;  // the chroma tasks are dealt from the other end
@@ -861,38 +872,45 @@ __global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHu
     // handful of segments; only a stream of many megabytes makes this loop long)
     for (int s = 0; s < p.seg; s++) p.dc += segs_i[s * kSegRecInts + kSegRecDcTotal + p.comp];
   };
-  auto idct = [&](int it) {
-    const int b = it * 8 + lb;
-    const uint64_t bi = info[wave][b];
-    const bool live = (bi & kInfoNeeded) != 0;
-    const uint64_t bi_dst = bi & ((1ull << 48) - 1);
-    const int16_t *cb = wcoef + b * kCoefStride;
-    if (!G.fused) {
-      if (live) {  // the block as one 128-byte line of column-major coefficients, 16 bytes per lane
+  // The lane's own block, start to end in its registers: dequantisation, the eight column passes, the eight row passes
+  // of the islow IDCT, eight 8-byte row stores.  (Round 2 spread a block over 8 lanes with an int32 transpose through
+  // LDS between the passes: the same number of butterflies per wave, plus 2 LDS round trips and 16 wave-wide fences.)
+  // Two halves so that the next task's stream words can be requested in between.
+  int32_t ws[8][8];
+  auto idct_columns = [&](const Prepared &p) {
+    if (!p.needed || !G.fused) return;
+    const uint16_t *q = &quant[p.comp][0];
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      int32_t in[8], o[8];
+#pragma unroll
+      for (int r8 = 0; r8 < 8; r8++)
+        in[r8] = __mul24((int32_t)wcoef[kScanIndexOfColMajorHost(c * 8 + r8) * 64 + lane], (int32_t)q[c * 8 + r8]);
+      Butterfly8(in, o);
+#pragma unroll
+      for (int r8 = 0; r8 < 8; r8++) ws[r8][c] = Descale(o[r8], CONST_BITS - PASS1_BITS);
+    }
+  };
+  auto idct_rows = [&](const Prepared &p) {
+    if (!p.needed) return;
+    const uint64_t dst = p.info & ((1ull << 48) - 1);
+    if (!G.fused) {   // the block as one 128-byte line of column-major coefficients
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
         uint32_t w[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) w[q] = (uint32_t)(uint16_t)cb[zi[2 * q]] | ((uint32_t)(uint16_t)cb[zi[2 * q + 1]] << 16);
-        reinterpret_cast<uint4 *>((uintptr_t)bi_dst)[part] = make_uint4(w[0], w[1], w[2], w[3]);
+        for (int qd = 0; qd < 4; qd++)
+          w[qd] = (uint32_t)(uint16_t)wcoef[kScanIndexOfColMajorHost(c * 8 + 2 * qd) * 64 + lane] |
+                  ((uint32_t)(uint16_t)wcoef[kScanIndexOfColMajorHost(c * 8 + 2 * qd + 1) * 64 + lane] << 16);
+        ((GlobalQuad *)(uintptr_t)dst)[c] = u32x4{w[0], w[1], w[2], w[3]};
       }
       return;
     }
-    const int c = (int)(bi >> 48) & 3;
-    if (live) {
-      int32_t in[8], o[8];
+    const int pitch = G.comp_pitch[p.comp];
 #pragma unroll
-      for (int r8 = 0; r8 < 8; r8++) in[r8] = __mul24((int32_t)cb[zi[r8]], (int32_t)quant[c][part * 8 + r8]);
-      Butterfly8(in, o);
-      int32_t *w = &trans[wave][lb][part];
-#pragma unroll
-      for (int r8 = 0; r8 < 8; r8++) w[r8 * 8] = Descale(o[r8], CONST_BITS - PASS1_BITS);
-    }
-    WaveSync();
-    if (live) {
-      const int4 *rp = reinterpret_cast<const int4 *>(&trans[wave][lb][part * 8]);
-      const int4 a = rp[0], bq = rp[1];
-      int32_t in[8] = {a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w};
+    for (int r8 = 0; r8 < 8; r8++) {
       int32_t o[8];
-      Butterfly8(in, o);
+      Butterfly8(ws[r8], o);
       const int S = CONST_BITS + PASS1_BITS + 3;
       const uint32_t lo32 = RangeLimit(Descale(o[0], S)) | (RangeLimit(Descale(o[1], S)) << 8) |
                             (RangeLimit(Descale(o[2], S)) << 16) | (RangeLimit(Descale(o[3], S)) << 24);
@@ -900,18 +918,15 @@ __global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHu
                             (RangeLimit(Descale(o[6], S)) << 16) | (RangeLimit(Descale(o[7], S)) << 24);
       typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
       using GlobalPair = u32x2_t __attribute__((address_space(1)));
-      GlobalPair *dst = (GlobalPair *)((GlobalBytes *)(uintptr_t)bi_dst + (size_t)part * G.comp_pitch[c]);
-      *dst = u32x2_t{lo32, hi32};
+      *(GlobalPair *)((GlobalBytes *)(uintptr_t)dst + (size_t)r8 * pitch) = u32x2_t{lo32, hi32};
     }
-    WaveSync();
   };
   Prepared cur = stage_a(0);
   stage_b(cur);
   for (int t = 0; t < my0 + my1; t++) {
     {
-      uint4 *z = reinterpret_cast<uint4 *>(wcoef);
-      for (int i = lane; i < 64 * kCoefStride * 2 / 16; i += 64) z[i] = make_uint4(0, 0, 0, 0);
-      info[wave][lane] = cur.info;
+      uint4 *z = reinterpret_cast<uint4 *>(wcoef);   // the 64 coefficient rows (the 65th only swallows)
+      for (int i = lane; i < 64 * 64 * 2 / 16; i += 64) z[i] = make_uint4(0, 0, 0, 0);
     }
     WaveSync();
     if (cur.needed) {
@@ -920,11 +935,10 @@ __global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHu
     }
     WaveSync();
     Prepared nxt = stage_a(t + 1);
-#pragma unroll 1
-    for (int it = 0; it < 4; it++) idct(it);
+    idct_columns(cur);
     stage_b(nxt);
-#pragma unroll 1
-    for (int it = 4; it < 8; it++) idct(it);
+    idct_rows(cur);
+    WaveSync();   // the next round's zero-fill must not overtake this round's reads
     cur = nxt;
   }
 }
