@@ -350,16 +350,23 @@ def batch_statistics(enc_batches, device, count_symbols=True):
     return stats
 
 
-def resident_pipeline(root, batch, device_id, depth, threads, shard_id=0, num_shards=1, cache_mb=4096):
-    """The headline pipeline: configs[1] with the data set resident in HBM as encoded streams."""
+def resident_pipeline(root, batch, device_id, depth, threads, shard_id=0, num_shards=1, cache_mb=4096, roi_decode=False):
+    """The headline pipeline: configs[1] with the data set resident in HBM as encoded streams.  roi_decode: the fused
+    variant decoders.image_random_crop -> resize -> crop_mirror_normalize (only the crop window is dequantised,
+    transformed and colour-converted), on the same resident streams."""
     from dali_amd import fn, types
     from dali_amd.pipeline import Pipeline
     pipe = Pipeline(batch_size=batch, num_threads=threads, device_id=device_id, seed=1234, prefetch_queue_depth=depth)
     with pipe:
         jpegs, labels = fn.readers.file(file_root=root, name="Reader", shard_id=shard_id, num_shards=num_shards,
                                         stick_to_shard=True, skip_cached_images=True)
-        images = fn.decoders.image(jpegs, device="mixed", output_type=types.RGB, cache_size=cache_mb, cache_type="encoded")
-        crops = fn.random_resized_crop(images, size=[224, 224])
+        if roi_decode:
+            images = fn.decoders.image_random_crop(jpegs, device="mixed", output_type=types.RGB, cache_size=cache_mb,
+                                                   cache_type="encoded")
+            crops = fn.resize(images, size=[224, 224])
+        else:
+            images = fn.decoders.image(jpegs, device="mixed", output_type=types.RGB, cache_size=cache_mb, cache_type="encoded")
+            crops = fn.random_resized_crop(images, size=[224, 224])
         out = fn.crop_mirror_normalize(crops, dtype=types.FLOAT16, output_layout="CHW",
                                        mean=[0.485 * 255, 0.456 * 255, 0.406 * 255],
                                        std=[0.229 * 255, 0.224 * 255, 0.225 * 255],
@@ -453,18 +460,28 @@ def kernel_timing(enable=None):
 
 
 def bench_heavy_aug(args, device):
-    """configs[2]: warp_affine + gaussian_blur(sigma=3) + color_twist + erase on 512x512 u8 images, batch 128,
-    images resident in HBM; colour twist and erase are one launch, as in a dali_amd.Pipeline (graph-level fusion).
-    One JSON line; per-kernel times from HIP events around each launch (algorithmic bytes: 3*512*512 in + out)."""
+    """configs[2]: warp_affine + gaussian_blur(sigma=3) + color_twist + erase on 512x512 u8 images, batch 128, through
+    the PRODUCT pipeline with the images resident in HBM: readers.file(skip_cached_images) -> decoders.image(mixed,
+    decoded-image cache) hands out the 128 cached images in place (no file read, no decode, no copy after the first
+    epoch), the per-sample matrices come from an external source, the colour / erase arguments from the random operators.
+    Colour twist + erase are one launch (graph-level fusion); fusing them into the blur's write-out as well is opt-in
+    (DALI_AMD_BLUR_FUSION=1): measured slower.
+    One JSON line; per-kernel times from HIP events around each launch (algorithmic bytes: 3 * 512 * 512 in + out per launch)."""
+    import shutil
+    import tempfile
     import torch
-    from dali_amd import backend as B
+    from PIL import Image
+    from dali_amd import fn, types
+    from dali_amd.pipeline import Pipeline
     from dali_amd.testing import synth_image
     n = 128
     rng = np.random.default_rng(1234)
-    base = [torch.from_numpy(synth_image(rng, 512, 512)).to(device) for _ in range(8)]
-    imgs = [base[i % 8].clone() for i in range(n)]
+    root = tempfile.mkdtemp(prefix="dali_amd_bench_aug_")
+    os.makedirs(os.path.join(root, "0"))
+    for i in range(n):      # (JPEG: the decoded-image cache keeps what the GPU decoder produces)
+        Image.fromarray(synth_image(rng, 512, 512)).save(os.path.join(root, "0", f"img_{i:04d}.jpg"), quality=95)
 
-    def params():
+    def matrices():
         mats = []
         for _ in range(n):
             t, s = np.deg2rad(rng.uniform(-30, 30)), rng.uniform(0.8, 1.2)
@@ -472,34 +489,54 @@ def bench_heavy_aug(args, device):
             m = np.array([[c, -sn, 0], [sn, c, 0]], np.float32)
             m[0, 2] = 256 - m[0, 0] * 256 - m[0, 1] * 256
             m[1, 2] = 256 - m[1, 0] * 256 - m[1, 1] * 256
-            mats.append(m)
-        tw = [B.color_twist_matrix(rng.uniform(-30, 30), rng.uniform(.7, 1.3), 1.0, rng.uniform(.8, 1.2),
-                                   rng.uniform(.8, 1.2)) for _ in range(n)]
-        regs = []
-        for _ in range(n):
-            a, sh = rng.uniform(0, .7, 2) * 512, rng.uniform(.1, .3, 2) * 512
-            regs.append([(int(a[0]), int(a[1]), int(a[0] + sh[0]), int(a[1] + sh[1]))])
-        return mats, [t[0] for t in tw], [t[1] for t in tw], regs
+            mats.append(m.reshape(6))
+        return mats
 
-    param_sets = [params() for _ in range(4)]   # the random arguments of 4 batches, rotated (host RNG outside the timing)
+    mat_sets = [matrices() for _ in range(4)]
+    depth = max(1, min(args.inflight, 4))
+    try:
+        pipe = Pipeline(batch_size=n, num_threads=max(2, effective_cpu_count() * 3 // 4), device_id=device.index or 0, seed=1234,
+                        prefetch_queue_depth=depth)
+        with pipe:
+            enc, _ = fn.readers.file(file_root=root, skip_cached_images=True)
+            x = fn.decoders.image(enc, device="mixed", cache_size=256, cache_type="threshold")
+            m = fn.external_source(name="matrix")
+            y = fn.warp_affine(x, matrix=m, fill_value=0.0)
+            y = fn.gaussian_blur(y, sigma=3.0)
+            y = fn.color_twist(y, hue=fn.random.uniform(range=[-30.0, 30.0]), saturation=fn.random.uniform(range=[0.7, 1.3]),
+                               brightness=fn.random.uniform(range=[0.8, 1.2]), contrast=fn.random.uniform(range=[0.8, 1.2]))
+            y = fn.erase(y, anchor=fn.random.uniform(range=[0.0, 0.7], shape=[2]), shape=fn.random.uniform(range=[0.1, 0.3], shape=[2]),
+                         normalized=True, fill_value=0.0)
+            pipe.set_outputs(y)
+        pipe.build()
+        fed = [0]
 
-    def step(k):
-        mats, tm, to, regs = param_sets[k % len(param_sets)]
-        x = B.warp_affine_batch(imgs, mats, fill_value=0.0)
-        x = B.gaussian_blur_batch(x, sigma=3.0)
-        return B.pointwise_batch(x, tm, to, regions=regs, fill=(0.0,))
+        def run():
+            # the external source is consumed one batch per scheduled iteration: keep its queue as deep as the prefetch
+            while fed[0] < pipe._scheduled + depth + 1:
+                pipe.feed_input("matrix", mat_sets[fed[0] % len(mat_sets)])
+                fed[0] += 1
+            return pipe.run()
 
-    for k in range(args.warmup):
-        step(k)
-    torch.cuda.synchronize()
-    kernel_timing(True)
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k)
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    kernel_timing(False)
-    times = kernel_timing()
+        for _ in range(4 * (depth + 1) + args.warmup):     # epoch 1 decodes the files into the cache; then every slot is warm
+            run()
+        torch.cuda.synchronize()
+        kernel_timing(12 * (args.steps + depth + 2))
+        kernel_timing(False)
+        kernel_timing()
+        pipe.operator_host_times()
+        kernel_timing(True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        kernel_timing(False)
+        times = kernel_timing()
+        host = pipe.operator_host_times()
+        kernels = pipe.executed_kernels()
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
     per = {}
     bytes_per = 2 * 3 * 512 * 512 * n
     for nm, (calls, ms) in times.items():
@@ -511,9 +548,11 @@ def bench_heavy_aug(args, device):
                       "value": n * args.steps / el, "unit": "images/s", "n_gpus": 1, "steps": args.steps,
                       "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
                       "scaling": "weak", "vs_baseline": None, "dtype": "u8 in/out, f32 arithmetic", "data": "synthetic",
-                      "config": {"workload": "configs[2]: 128 x 512x512x3 u8 resident in HBM",
+                      "config": {"workload": "configs[2]: 128 x 512x512x3 u8 resident in HBM (decoded-image cache), through "
+                                             "dali_amd.Pipeline", "kernels": kernels, "prefetch_queue_depth": depth,
                                  "kernels_ms_per_step": kern_ms, "images_per_s_kernels_only": n / (kern_ms * 1e-3),
-                                 "note": "value includes the Python descriptor construction of dali_amd.backend (host-bound)"},
+                                 "host_ms_per_step": host.get("<device stage>"), "host_stage_ms_per_step": host.get("<host stage>"),
+                                 "host_ms_per_operator": {k: v for k, v in host.items() if not k.startswith("<")}},
                       "roofline": {"bound": "hbm", "kernel": dom, "achieved": per[dom]["achieved_GBps"],
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": per[dom]["achieved_GBps"] / HBM_PEAK_GBS,
                                    "traffic": traffic, "traffic_source": traffic_src, "per_kernel": per}}))
@@ -707,7 +746,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end dali_amd.Pipeline legs")
     ap.add_argument("--e2e-batch", type=int, default=512, help="batch per GPU of the sharded end-to-end leg (configs[4])")
-    ap.add_argument("--inflight", type=int, default=2,
+    ap.add_argument("--inflight", type=int, default=4,
                     help="batches in flight on the GPU, each on its own HIP stream = the executor's prefetch_queue_depth")
     ap.add_argument("--huffman", default="gpu", choices=["gpu", "host"],
                     help="gpu: the step starts from JPEG bytes in HBM (default); host: from host-decoded coefficient blocks")
@@ -805,6 +844,26 @@ def main():
                      "host_ms_per_operator": {k: v for k, v in r["host_times"].items() if not k.startswith("<")},
                      "setup_s": r["setup_s"], "setup_iterations": r["setup_iterations"], "encoded_cache": r["cache"],
                      "launches_timed": launches, "kernels": r["pipe"].executed_kernels()}
+        if world == 1 and not args.no_e2e:
+            # the same resident streams through the fused ROI decoder (what NVIDIA's own decoder benchmark times,
+            # hw_decoder_bench.py:178-188): informational, never `value`
+            pipe2 = resident_pipeline(root, B, dev_index, r["depth"], r["threads"],
+                                      cache_mb=max(64, int(2 * sum(len(e) for e in enc_all) / 2**20)), roi_decode=True)
+            for _ in range((r["depth"] + 2) * nb + args.warmup):
+                pipe2.run()
+            torch.cuda.synchronize()
+            t_roi = time.perf_counter()
+            for _ in range(args.steps):
+                pipe2.run()
+            torch.cuda.synchronize()
+            t_roi = time.perf_counter() - t_roi
+            pipe_info["resident_roi_decode"] = {
+                "value": B * args.steps / t_roi, "unit": "images/s", "ms_per_step": 1e3 * t_roi / args.steps,
+                "kernels": pipe2.executed_kernels(),
+                "note": "decoders.image_random_crop -> resize -> crop_mirror_normalize on the same resident streams: the "
+                        "entropy decoder stops at the last MCU row of the crop window, only the window's blocks are "
+                        "transformed and colour-converted"}
+            del pipe2
         del r
     else:
         streams = [torch.cuda.Stream(device=device) for _ in range(inflight)]

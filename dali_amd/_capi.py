@@ -180,7 +180,7 @@ _KERNEL_SYMBOLS = [
     "daliamdJpegHuffmanRun", "daliamdJpegHuffmanRunProfiled", "daliamdJpegColorSetup", "daliamdJpegPlanRoi", "daliamdJpegColorRun",
     "daliamdResampleSetup", "daliamdResampleRun", "daliamdCmnSetup", "daliamdCmnRun",
     "daliamdWarpAffineSetup", "daliamdWarpAffineRun", "daliamdGaussianWindow", "daliamdGaussianBlurSetup",
-    "daliamdGaussianBlurRun", "daliamdColorTwistMatrix", "daliamdPointwiseSetup", "daliamdPointwiseRun",
+    "daliamdGaussianBlurRun", "daliamdGaussianBlurPointwiseRun", "daliamdColorTwistMatrix", "daliamdPointwiseSetup", "daliamdPointwiseRun",
     "daliamdHannWindow", "daliamdSpectrogramTwiddles", "daliamdSpectrogramSetup", "daliamdSpectrogramRun", "daliamdMelFilterBankWeights",
     "daliamdMelFilterBankBands", "daliamdMelFilterBankSetup", "daliamdMelFilterBankRun", "daliamdMelFilterBankMfmaLayout", "daliamdSpectrogramMelRun", "daliamdToDecibelsSetup", "daliamdToDecibelsRun", "daliamdDctTable", "daliamdLifterCoeffs", "daliamdDctRun",
     "daliamdAudioResampleLobes", "daliamdAudioResampleWindow", "daliamdAudioResampleSetup", "daliamdAudioResampleRun",

@@ -234,16 +234,15 @@ __device__ __forceinline__ void BlurWPass(const daliamdGaussianBlurDesc &d, cons
 // H pass: a thread owns two neighbouring elements of a row (the packed pair, one 8-byte LDS load per tap) in kBlurRows
 // consecutive output rows; the rows slide through registers in chunks like the taps of the W pass.  tmp has
 // kBlurRows - 1 spare rows behind the staged ones: the rows read past the end only feed outputs that are not stored.
+template <bool STAGED>
 __device__ __forceinline__ void BlurHPass(const daliamdGaussianBlurDesc &d, const float *tmp, int tstride, int row_elems,
-                                          int th, int ox0, int oy0) {
+                                          int th, uint8_t *outb, int opitch, int ox0, int oy0) {
   constexpr int R = kBlurRows;
   const int tid = threadIdx.x;
   const int epairs = (row_elems + 1) >> 1;
   const int rgroups = (th + R - 1) / R;
   const float *__restrict__ gw = d.window_y;
   const int K = d.size_y;
-  const int C = d.channels;
-  using GOut = uint8_t __attribute__((address_space(1)));
   for (int item = tid; item < epairs * rgroups; item += kBlurThreads) {
     const int yg = item / epairs, ep = item - yg * epairs;
     const int y = yg * R, e = 2 * ep;
@@ -282,23 +281,104 @@ __device__ __forceinline__ void BlurHPass(const daliamdGaussianBlurDesc &d, cons
         for (int j = 0; j < R; j++) acc[j] += w * (j + t < R - 1 ? v[j + t] : n[j + t - (R - 1)]);
       }
     }
-    GOut *o = (GOut *)d.out + (size_t)(oy0 + y) * d.out_pitch + (size_t)ox0 * C + e;
+    if constexpr (STAGED) {
+      // a pointwise operator is fused behind the blur: the rounded bytes go to an LDS tile (the staged source is dead by
+      // now), where the write-out sees whole pixels
+      uint8_t *o = outb + y * opitch + e;
 #pragma unroll
-    for (int j = 0; j < R; j++)
-      if (y + j < th) {
-        GOut *oj = o + (size_t)j * d.out_pitch;
-        oj[0] = (uint8_t)SatU8(acc[j].x);
-        if (two) oj[1] = (uint8_t)SatU8(acc[j].y);
+      for (int j = 0; j < R; j++)
+        if (y + j < th) {
+          const uint32_t b0 = SatU8(acc[j].x), b1 = two ? SatU8(acc[j].y) : 0u;
+          *reinterpret_cast<uint16_t *>(o + j * opitch) = (uint16_t)(b0 | (b1 << 8));   // (e and opitch are even)
+        }
+    } else {
+      using GOut = uint8_t __attribute__((address_space(1)));
+      GOut *o = (GOut *)d.out + (size_t)(oy0 + y) * d.out_pitch + (size_t)ox0 * d.channels + e;
+#pragma unroll
+      for (int j = 0; j < R; j++)
+        if (y + j < th) {
+          GOut *oj = o + (size_t)j * d.out_pitch;
+          oj[0] = (uint8_t)SatU8(acc[j].x);
+          if (two) oj[1] = (uint8_t)SatU8(acc[j].y);
+        }
+    }
+  }
+}
+
+// colour twist and / or erase of one pixel (PointwiseKernel's arithmetic)
+__device__ __forceinline__ void PointwisePixel(const daliamdPointwiseDesc &pw, int y, int x, uint32_t b[3]) {
+  bool erased = false;
+  for (int r = 0; r < pw.num_regions; r++)
+    erased |= y >= pw.region[r][0] && y < pw.region[r][2] && x >= pw.region[r][1] && x < pw.region[r][3];
+  if (erased) {
+    b[0] = SatU8(pw.fill[0]); b[1] = SatU8(pw.fill[1]); b[2] = SatU8(pw.fill[2]);
+  } else if (pw.transform) {
+    const float v0 = (float)b[0], v1 = (float)b[1], v2 = (float)b[2];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      float s = pw.matrix[3 * i] * v0;
+      s += pw.matrix[3 * i + 1] * v1;
+      s += pw.matrix[3 * i + 2] * v2;
+      b[i] = SatU8(s + pw.offset[i]);
+    }
+  }
+}
+
+// The tile's bytes from LDS to the image: 4 pixels (12 bytes, three dwords) per thread when the rows allow it, the
+// pointwise operator (if one is fused behind the blur) applied on the way.
+__device__ __forceinline__ void BlurWriteOut(const daliamdGaussianBlurDesc &d, const daliamdPointwiseDesc *pw, const uint8_t *outb,
+                                             int opitch, int tw, int th, int ox0, int oy0) {
+  using GOut = uint8_t __attribute__((address_space(1)));
+  typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+  const int C = d.channels, tid = threadIdx.x;
+  GOut *base = (GOut *)d.out + (size_t)oy0 * d.out_pitch + (size_t)ox0 * C;
+  if (C == 3 && (tw & 3) == 0 && ((d.out_pitch | (int)(reinterpret_cast<uintptr_t>(base) & 0xffff)) & 3) == 0) {
+    const int quads = tw >> 2;
+    for (int item = tid; item < quads * th; item += kBlurThreads) {
+      const int y = item / quads, q = item - y * quads;
+      const uint32_t *src = reinterpret_cast<const uint32_t *>(outb + y * opitch) + 3 * q;   // (opitch is a multiple of 4)
+      uint32_t w[3] = {src[0], src[1], src[2]};
+      if (pw) {
+        uint32_t b[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) b[i] = (w[i >> 2] >> (8 * (i & 3))) & 255u;
+#pragma unroll
+        for (int px = 0; px < 4; px++) PointwisePixel(*pw, oy0 + y, ox0 + 4 * q + px, b + 3 * px);
+#pragma unroll
+        for (int i = 0; i < 3; i++) w[i] = b[4 * i] | (b[4 * i + 1] << 8) | (b[4 * i + 2] << 16) | (b[4 * i + 3] << 24);
       }
+      *(u32x3 __attribute__((address_space(1))) *)(base + (size_t)y * d.out_pitch + 12 * q) = u32x3{w[0], w[1], w[2]};
+    }
+    return;
+  }
+  for (int item = tid; item < tw * th; item += kBlurThreads) {
+    const int y = item / tw, x = item - y * tw;
+    const uint8_t *src = outb + y * opitch + x * C;
+    GOut *o = base + (size_t)y * d.out_pitch + (size_t)x * C;
+    if (pw && C == 3) {
+      uint32_t b[3] = {src[0], src[1], src[2]};
+      PointwisePixel(*pw, oy0 + y, ox0 + x, b);
+      o[0] = (uint8_t)b[0]; o[1] = (uint8_t)b[1]; o[2] = (uint8_t)b[2];
+    } else if (pw) {   // other channel counts: erase only (the colour transform is defined for three channels)
+      bool erased = false;
+      for (int r = 0; r < pw->num_regions; r++)
+        erased |= oy0 + y >= pw->region[r][0] && oy0 + y < pw->region[r][2] && ox0 + x >= pw->region[r][1] && ox0 + x < pw->region[r][3];
+      for (int c = 0; c < C; c++)
+        o[c] = erased ? (uint8_t)SatU8(c == 0 ? pw->fill[0] : c == 1 ? pw->fill[1] : c == 2 ? pw->fill[2] : pw->fill[3]) : src[c];
+    } else {
+      for (int c = 0; c < C; c++) o[c] = src[c];
+    }
   }
 }
 
 __global__ __launch_bounds__(kBlurThreads) void GaussianBlurKernel(const daliamdGaussianBlurDesc *__restrict__ descs,
-                                                                   int ndesc, int total_wg) {
+                                                                   int ndesc, int total_wg,
+                                                                   const daliamdPointwiseDesc *__restrict__ pointwise) {
   extern __shared__ __attribute__((aligned(16))) float blur_lds[];
   int wg = XcdRemap(blockIdx.x, total_wg);
   if (wg < 0) return;
-  const daliamdGaussianBlurDesc &d = descs[FindDesc(descs, ndesc, wg)];
+  const int di = FindDesc(descs, ndesc, wg);
+  const daliamdGaussianBlurDesc &d = descs[di];
   const int C = d.channels, TW = d.tile_w, TH = d.tile_h;
   const int rx = (d.size_x - 1) / 2, ry = (d.size_y - 1) / 2;
   int t = wg - d.wg_start;
@@ -341,7 +421,15 @@ __global__ __launch_bounds__(kBlurThreads) void GaussianBlurKernel(const daliamd
     default: BlurWPass<4>(d, src, tmp, src_pitch, tstride, in_rows, tw, ox0, oy0, rx, ry, interior_x); break;
   }
   __syncthreads();
-  BlurHPass(d, tmp, tstride, row_elems, th, ox0, oy0);
+  if (!pointwise) {
+    BlurHPass<false>(d, tmp, tstride, row_elems, th, nullptr, 0, ox0, oy0);
+    return;
+  }
+  const int opitch = (TW * C + 3) & ~3;   // <= src_pitch, and the staged source has at least th rows
+  BlurHPass<true>(d, tmp, tstride, row_elems, th, src, opitch, ox0, oy0);
+  __syncthreads();
+  const daliamdPointwiseDesc pw = pointwise[di];   // (a private copy: the stores below cannot alias it)
+  BlurWriteOut(d, &pw, src, opitch, tw, th, ox0, oy0);
 }
 
 // =============================================================================================
@@ -567,18 +655,22 @@ daliamdResult_t daliamdGaussianBlurSetup(daliamdGaussianBlurDesc *descs, int n, 
   return DALIAMD_SUCCESS;
 }
 
-daliamdResult_t daliamdGaussianBlurRun(daliamdStream_t stream, const daliamdGaussianBlurDesc *descs_dev, int n, int nwg,
-                                       int lds_bytes) {
+daliamdResult_t daliamdGaussianBlurPointwiseRun(daliamdStream_t stream, const daliamdGaussianBlurDesc *descs_dev, int n, int nwg,
+                                                int lds_bytes, const daliamdPointwiseDesc *pointwise_dev) {
   if (n == 0 || nwg == 0) return DALIAMD_SUCCESS;
   DALIAMD_REQUIRE(descs_dev && n > 0 && nwg > 0 && lds_bytes >= 0 && lds_bytes <= kBlurMaxLds,
                   DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdGaussianBlurRun: invalid argument");
   {
     daliamd::KernelTimer timer("GaussianBlurKernel", (hipStream_t)stream);
     hipLaunchKernelGGL(GaussianBlurKernel, dim3(XcdGrid(nwg)), dim3(kBlurThreads), lds_bytes, (hipStream_t)stream,
-                       descs_dev, n, nwg);
+                       descs_dev, n, nwg, pointwise_dev);
   }
   DALIAMD_HIP_CHECK(hipGetLastError());
   return DALIAMD_SUCCESS;
+}
+daliamdResult_t daliamdGaussianBlurRun(daliamdStream_t stream, const daliamdGaussianBlurDesc *descs_dev, int n, int nwg,
+                                       int lds_bytes) {
+  return daliamdGaussianBlurPointwiseRun(stream, descs_dev, n, nwg, lds_bytes, nullptr);
 }
 
 void daliamdColorTwistMatrix(float hue, float saturation, float value, float brightness, float contrast, float *matrix,

@@ -109,6 +109,7 @@ class Buffer {
 
 struct DeferredResample;  // see ops_image.cpp: RandomResizedCrop -> CropMirrorNormalize fusion
 struct DeferredPointwise;  // see ops_augment.cpp: ColorTwist -> Erase fusion
+struct DeferredBlur;       // see ops_augment.cpp: GaussianBlur -> ColorTwist / Erase fusion
 struct DeferredAudio;      // see ops_audio.cpp: Spectrogram -> MelFilterBank (-> ToDecibels) fusion
 
 class TensorList {
@@ -146,6 +147,7 @@ class TensorList {
   std::shared_ptr<DeferredResample> deferred;
   std::shared_ptr<DeferredPointwise> deferred_pointwise;
   std::shared_ptr<DeferredAudio> deferred_audio;
+  std::shared_ptr<DeferredBlur> deferred_blur;
 
   // source info (readers): file name per sample, used in error messages like the reference's
   std::vector<std::string> source_info;

@@ -26,11 +26,20 @@ struct DeferredResample {
 
 // Colour-twist arguments deferred to an Erase consumer: both are the same streaming kernel (transform and / or erase per
 // descriptor), so `erase(color_twist(x))` is one launch and the intermediate image never exists.
+// A Gaussian blur whose only consumer is a pointwise operator (ColorTwist and its siblings, Erase, or the two fused):
+// the blur kernel applies the pointwise arithmetic to the rounded pixels of a tile before they leave the workgroup
+// (daliamdGaussianBlurPointwiseRun) - no launch and no pass over the image for the operators behind the blur.
+struct DeferredBlur {
+  std::shared_ptr<TensorList> source;                 // the blur's input (u8 HWC on the device)
+  std::vector<daliamdGaussianBlurDesc> descs;         // one per sample: in / shape / windows set
+};
 struct DeferredPointwise {
   std::shared_ptr<TensorList> source;                 // the producer's input (u8 HWC on the device)
   std::vector<daliamdPointwiseDesc> descs;            // one per sample: in / shape / transform / matrix / offset set
+  std::shared_ptr<DeferredBlur> blur;                 // a blur fused in front of the pair
 };
 void TryEnablePointwiseFusion(OperatorBase *producer, OperatorBase *consumer);
+void TryEnableBlurFusion(OperatorBase *producer, OperatorBase *consumer);
 
 // Spectrogram -> MelFilterBank (-> ToDecibels): the power spectrum is consumed where it is produced.  A 513-bin
 // spectrogram is 6.4 times the size of its 80-filter mel reduction; written to HBM and read back it is the whole traffic

@@ -256,12 +256,21 @@ class GaussianBlurGpu : public OperatorBase {
       d.size_x = dx; d.size_y = dy;
       desc[0].shape[i] = s;
     }
-    return true;
+    return !(fused_ && ws.backend != OpType::CPU);   // fused: no buffer, the pointwise operator behind launches for both
   }
+  void EnableFusion() { fused_ = true; }
   void RunImpl(Workspace &ws) override {
     TensorList &out = ws.Output(0);
     out.SetLayout("HWC");
     int n = (int)descs_.size();
+    if (fused_ && ws.backend != OpType::CPU) {
+      auto d = std::make_shared<DeferredBlur>();
+      d->source = ws.inputs[0];
+      d->descs = descs_;
+      out.Resize({}, DALI_UINT8);
+      out.deferred_blur = d;
+      return;
+    }
     if (!n) return;
     for (int i = 0; i < n; i++) descs_[i].out = static_cast<uint8_t *>(out.raw(i));
     if (ws.backend == OpType::CPU) {
@@ -282,6 +291,7 @@ class GaussianBlurGpu : public OperatorBase {
   }
 
  private:
+  bool fused_ = false;
   std::vector<daliamdGaussianBlurDesc> descs_;
   DescUploader uploader_;
 };
@@ -297,12 +307,24 @@ static void FillPointwiseCommon(daliamdPointwiseDesc &d, const TensorList &in, i
   d.h = (int)s[0]; d.w = (int)s[1]; d.channels = (int)s[2]; d.in_pitch = InPitch(in, i);
   d.out_pitch = d.w * d.channels;
 }
-static void LaunchPointwise(Workspace &ws, DescUploader &up, std::vector<daliamdPointwiseDesc> &descs, const char *what) {
+static void LaunchPointwise(Workspace &ws, DescUploader &up, std::vector<daliamdPointwiseDesc> &descs, const char *what,
+                            const DeferredBlur *blur = nullptr, DescUploader *blur_up = nullptr) {
   TensorList &out = ws.Output(0);
   out.SetLayout("HWC");
   int n = (int)descs.size();
   if (!n) return;
   for (int i = 0; i < n; i++) descs[i].out = static_cast<uint8_t *>(out.raw(i));
+  if (blur) {   // the blur in front runs here, with this operator's arithmetic in its write-out
+    std::vector<daliamdGaussianBlurDesc> bd = blur->descs;
+    for (int i = 0; i < n; i++) bd[i].out = descs[i].out;
+    int nwg = 0, lds = 0;
+    KCHECK(daliamdGaussianBlurSetup(bd.data(), n, &nwg, &lds));
+    auto *pdev = static_cast<const daliamdPointwiseDesc *>(up.Upload(descs.data(), n * sizeof(descs[0]), ws.stream, ws.ring + 1));
+    auto *bdev = static_cast<const daliamdGaussianBlurDesc *>(blur_up->Upload(bd.data(), n * sizeof(bd[0]), ws.stream, ws.ring + 1));
+    KCHECK(daliamdGaussianBlurPointwiseRun(ws.stream, bdev, n, nwg, lds, pdev));
+    NoteLaunch(ws, (std::string("gaussian_blur+") + what).c_str());
+    return;
+  }
   if (ws.backend == OpType::CPU) {
     for (int i = 0; i < n; i++)
       ws.GetThreadPool().AddWork([&descs, i](int) {
@@ -365,8 +387,11 @@ DALI_SCHEMA(Saturation)
 class ColorTwistGpu : public OperatorBase {
  public:
   explicit ColorTwistGpu(const OpSpec &spec) : OperatorBase(spec) { CheckOutDtype(spec, "ColorTwist"); }
+  void ExpectBlurInput() { blur_input_ = true; }
   bool SetupImpl(std::vector<OutputDesc> &desc, const Workspace &ws) override {
-    const TensorList &in = ws.Input(0);
+    blur_ = blur_input_ && ws.backend != OpType::CPU ? ws.Input(0).deferred_blur : nullptr;
+    DALI_ENFORCE(!blur_input_ || ws.backend == OpType::CPU || blur_, "internal: expected the deferred arguments of the GaussianBlur in front");
+    const TensorList &in = blur_ ? *blur_->source : ws.Input(0);
     CheckU8Hwc(in, "ColorTwist");
     int n = in.num_samples();
     // (AcquireArguments, color_twist.h:111-141: an argument the schema does not define keeps its neutral value)
@@ -392,12 +417,13 @@ class ColorTwistGpu : public OperatorBase {
   }
   void RunImpl(Workspace &ws) override {
     if (!fused_) {
-      LaunchPointwise(ws, uploader_, descs_, "color_twist");
+      LaunchPointwise(ws, uploader_, descs_, "color_twist", blur_.get(), &blur_uploader_);
       return;
     }
     TensorList &out = ws.Output(0);
     auto d = std::make_shared<DeferredPointwise>();
-    d->source = ws.inputs[0];
+    d->source = blur_ ? blur_->source : ws.inputs[0];
+    d->blur = blur_;
     d->descs = descs_;
     out.Resize({}, DALI_UINT8);
     out.deferred_pointwise = d;
@@ -406,9 +432,10 @@ class ColorTwistGpu : public OperatorBase {
   void EnableFusion() { fused_ = true; }
 
  private:
-  bool fused_ = false;
+  bool fused_ = false, blur_input_ = false;
+  std::shared_ptr<DeferredBlur> blur_;
   std::vector<daliamdPointwiseDesc> descs_;
-  DescUploader uploader_;
+  DescUploader uploader_, blur_uploader_;
 };
 DALI_REGISTER_OPERATOR(ColorTwist, ColorTwistGpu, GPU);
 DALI_REGISTER_OPERATOR(ColorTwist, ColorTwistGpu, CPU);
@@ -471,7 +498,10 @@ class EraseGpu : public OperatorBase {
     // a fused ColorTwist in front: work on ITS input and carry its transform along
     const DeferredPointwise *def = fused_input_ ? ws.Input(0).deferred_pointwise.get() : nullptr;
     DALI_ENFORCE(!fused_input_ || def, "internal: Erase expected the deferred arguments of the ColorTwist in front of it");
-    const TensorList &in = def ? *def->source : ws.Input(0);
+    // a blur fused in front: directly, or in front of the fused ColorTwist
+    blur_ = def ? def->blur : (blur_input_ && ws.backend != OpType::CPU ? ws.Input(0).deferred_blur : nullptr);
+    DALI_ENFORCE(def || !blur_input_ || ws.backend == OpType::CPU || blur_, "internal: expected the deferred arguments of the GaussianBlur in front");
+    const TensorList &in = def ? *def->source : (blur_ ? *blur_->source : ws.Input(0));
     CheckU8Hwc(in, "Erase");
     int n = in.num_samples();
     auto anchors = GetPerSampleFloatVec(spec_, ws, "anchor", n), shapes = GetPerSampleFloatVec(spec_, ws, "shape", n);
@@ -512,10 +542,15 @@ class EraseGpu : public OperatorBase {
     }
     return true;
   }
-  void RunImpl(Workspace &ws) override { LaunchPointwise(ws, uploader_, descs_, fused_input_ ? "color_twist+erase" : "erase"); }
+  void RunImpl(Workspace &ws) override {
+    LaunchPointwise(ws, uploader_, descs_, fused_input_ ? "color_twist+erase" : "erase", blur_.get(), &blur_uploader_);
+  }
+  void ExpectBlurInput() { blur_input_ = true; }
 
  private:
-  bool fused_input_ = false;
+  bool fused_input_ = false, blur_input_ = false;
+  std::shared_ptr<DeferredBlur> blur_;
+  DescUploader blur_uploader_;
   bool norm_anchor_, norm_shape_, centered_;
   std::vector<int> axes_;
   std::vector<daliamdPointwiseDesc> descs_;
@@ -523,6 +558,23 @@ class EraseGpu : public OperatorBase {
 };
 DALI_REGISTER_OPERATOR(Erase, EraseGpu, GPU);
 DALI_REGISTER_OPERATOR(Erase, EraseGpu, CPU);
+
+void TryEnableBlurFusion(OperatorBase *producer, OperatorBase *consumer) {
+  // OPT-IN (DALI_AMD_BLUR_FUSION=1).  Measured on configs[2] (512 x 512, batch 128, four batches in flight): the fused
+  // write-out needs the rounded tile in LDS and a workgroup barrier in front of it, which costs the blur more (930 ->
+  // 1 244 us) than the pointwise launch it replaces (104 us) - the 201 MB it keeps out of HBM are not the bound of this
+  // VALU-heavy kernel.  Kept for the parity tests and for a version of the H pass that owns whole pixels in registers.
+  if (!(getenv("DALI_AMD_BLUR_FUSION") && atoi(getenv("DALI_AMD_BLUR_FUSION")) != 0)) return;
+  auto *blur = dynamic_cast<GaussianBlurGpu *>(producer);
+  if (!blur) return;
+  if (auto *twist = dynamic_cast<ColorTwistGpu *>(consumer)) {
+    blur->EnableFusion();
+    twist->ExpectBlurInput();
+  } else if (auto *erase = dynamic_cast<EraseGpu *>(consumer)) {
+    blur->EnableFusion();
+    erase->ExpectBlurInput();
+  }
+}
 
 void TryEnablePointwiseFusion(OperatorBase *producer, OperatorBase *consumer) {
   auto *twist = dynamic_cast<ColorTwistGpu *>(producer);

@@ -164,6 +164,16 @@ void Pipeline::Build(const std::vector<std::pair<std::string, std::string>> &out
     Node &p = nodes_[n.in_node[0]];
     if (consumers[n.in_node[0]] == 1 && p.type == OpType::GPU) TryEnablePointwiseFusion(p.op.get(), n.op.get());
   }
+  // ... and a GaussianBlur feeding ONLY a pointwise operator applies it in its own write-out
+  for (auto &n : nodes_) {
+    const std::string &sn = n.spec.SchemaName();
+    if ((sn != "ColorTwist" && sn != "Hsv" && sn != "Hue" && sn != "Saturation" && sn != "Erase") || n.in_node.empty() ||
+        n.type != OpType::GPU)
+      continue;
+    Node &p = nodes_[n.in_node[0]];
+    if (consumers[n.in_node[0]] == 1 && p.type == OpType::GPU && p.spec.SchemaName() == "GaussianBlur")
+      TryEnableBlurFusion(p.op.get(), n.op.get());
+  }
   // ... and Spectrogram -> MelFilterBank (-> ToDecibels) chains with single consumers are one launch (two when the decibel
   // reference is the sample's maximum); in graph order, so that the mel operator knows about its input before the
   // decibel operator asks it

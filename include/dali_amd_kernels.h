@@ -433,6 +433,12 @@ DALIAMD_API void daliamdColorTwistMatrix(float hue, float saturation, float valu
 DALIAMD_API daliamdResult_t daliamdPointwiseSetup(daliamdPointwiseDesc *descs_host, int n, int *num_workgroups);
 DALIAMD_API daliamdResult_t daliamdPointwiseRun(daliamdStream_t stream, const daliamdPointwiseDesc *descs_dev, int n,
                                                 int num_workgroups);
+/* The blur with a pointwise operator in its write-out: pointwise_dev[i] (transform / regions / fill of sample i; its
+ * in / out / pitch fields are not used) is applied to the rounded pixels of sample i before they leave the workgroup -
+ * color_twist / erase behind a gaussian_blur cost no launch and no pass over the image.  NULL: the plain blur. */
+DALIAMD_API daliamdResult_t daliamdGaussianBlurPointwiseRun(daliamdStream_t stream, const daliamdGaussianBlurDesc *descs_dev,
+                                                           int n, int num_workgroups, int lds_bytes,
+                                                           const daliamdPointwiseDesc *pointwise_dev);
 
 /* ----------------------------------------------------------------------------------------------
  * Audio features (BASELINE.json configs[3]): spectrogram -> mel filter bank -> decibels, f32.

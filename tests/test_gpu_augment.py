@@ -112,3 +112,75 @@ def test_color_twist_and_erase_match_oracle():
     out = B.pointwise_batch([_dev(im)], regions=[regs], fill=(1.0, 2.0, 3.0))[0].cpu().numpy()
     assert np.array_equal(out, ref)
     assert (out != im).any() and (out == im).any()
+
+
+def _heavy_pipe(bs, chain, fill=0.0):
+    """external_source -> warp_affine -> gaussian_blur -> `chain` of pointwise operators, random per-sample parameters."""
+    from dali_amd import fn
+    from dali_amd.pipeline import Pipeline
+    pipe = Pipeline(batch_size=bs, num_threads=3, device_id=0, seed=17, prefetch_queue_depth=1)
+    with pipe:
+        x = fn.external_source(name="images", layout="HWC")
+        m = fn.external_source(name="matrix")
+        hue = fn.random.uniform(range=[-30.0, 30.0], seed=1)
+        sat = fn.random.uniform(range=[0.7, 1.3], seed=2)
+        bri = fn.random.uniform(range=[0.8, 1.2], seed=3)
+        con = fn.random.uniform(range=[0.8, 1.2], seed=4)
+        anchor = fn.random.uniform(range=[0.0, 0.7], shape=[2], seed=5)
+        shape = fn.random.uniform(range=[0.1, 0.3], shape=[2], seed=6)
+        y = fn.warp_affine(x.gpu(), matrix=m, fill_value=fill)
+        y = fn.gaussian_blur(y, sigma=2.0)
+        if "twist" in chain:
+            y = fn.color_twist(y, hue=hue, saturation=sat, brightness=bri, contrast=con)
+        if "erase" in chain:
+            y = fn.erase(y, anchor=anchor, shape=shape, normalized=True, fill_value=[3.0, 200.0, 77.0])
+        pipe.set_outputs(y, hue, sat, bri, con, anchor, shape)
+    pipe.build()
+    return pipe
+
+
+@pytest.mark.parametrize("chain,kernel", [(("twist", "erase"), "gaussian_blur+color_twist+erase"), (("twist",), "gaussian_blur+color_twist"),
+                                          (("erase",), "gaussian_blur+erase")])
+def test_pointwise_operators_behind_a_blur_run_in_its_write_out(chain, kernel, monkeypatch):
+    """configs[2] through the pipeline with DALI_AMD_BLUR_FUSION=1 (opt-in: measured slower than the separate launch, see
+    ops_augment.cpp): colour twist and / or erase behind gaussian_blur run in the blur's write-out (graph-level fusion, ops.h:
+    DeferredBlur) and give the oracle chain bit for bit - odd sizes, tiles at the image border included."""
+    monkeypatch.setenv("DALI_AMD_BLUR_FUSION", "1")
+    rng = np.random.default_rng(15)
+    imgs = [synth_image(rng, h, w) for (h, w) in [(200, 300), (257, 190), (64, 520), (128, 128), (61, 67)]]
+    mats = [_rot_matrix(rng.uniform(-30, 30), rng.uniform(0.8, 1.2), im.shape[1] / 2, im.shape[0] / 2).reshape(6) for im in imgs]
+    pipe = _heavy_pipe(len(imgs), chain)
+    pipe.feed_input("images", imgs, layout="HWC")
+    pipe.feed_input("matrix", mats)
+    out, hue, sat, bri, con, anchor, shape = pipe.run()
+    assert pipe.executed_kernels() == ["h2d_copy", "warp_affine", kernel]
+    win = O.gaussian_window(2.0)
+    for i, im in enumerate(imgs):
+        ref = O.gaussian_blur_u8(O.warp_affine_u8(im, mats[i], interp=1, fill=0.0), win)
+        if "twist" in chain:
+            mm, off = O.color_twist_matrix(float(hue.at(i)), float(sat.at(i)), 1.0, float(bri.at(i)), float(con.at(i)))
+            ref = O.linear_transform_u8(ref, mm, off)
+        if "erase" in chain:
+            ref = O.erase_u8(ref, anchor.at(i), shape.at(i), fill=(3.0, 200.0, 77.0), normalized_anchor=True, normalized_shape=True)
+        got = out[i].as_cpu()
+        assert np.array_equal(got, ref), f"sample {i}: max diff {np.abs(got.astype(int) - ref).max()}"
+
+
+def test_erase_behind_a_blur_of_single_channel_images(monkeypatch):
+    monkeypatch.setenv("DALI_AMD_BLUR_FUSION", "1")
+    from dali_amd import fn
+    from dali_amd.pipeline import Pipeline
+    rng = np.random.default_rng(3)
+    imgs = [np.ascontiguousarray(synth_image(rng, 90, 123)[:, :, :1]) for _ in range(2)]
+    pipe = Pipeline(batch_size=2, num_threads=2, device_id=0, prefetch_queue_depth=1)
+    with pipe:
+        x = fn.external_source(name="images", layout="HWC")
+        pipe.set_outputs(fn.erase(fn.gaussian_blur(x.gpu(), sigma=1.5), anchor=[10.0, 20.0], shape=[30.0, 40.0], fill_value=9.0))
+    pipe.build()
+    pipe.feed_input("images", imgs, layout="HWC")
+    (out,) = pipe.run()
+    assert pipe.executed_kernels() == ["h2d_copy", "gaussian_blur+erase"]
+    for i, im in enumerate(imgs):
+        ref = O.gaussian_blur_u8(im, O.gaussian_window(1.5))
+        ref[10:40, 20:60] = 9
+        assert np.array_equal(out[i].as_cpu(), ref), i
