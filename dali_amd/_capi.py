@@ -37,7 +37,7 @@ class JpegHuffDesc(C.Structure):
                 ("total_blocks", C.c_int32), ("blocks_x", C.c_int32 * 3), ("h_samp", C.c_int32 * 3),
                 ("v_samp", C.c_int32 * 3), ("tile_start", C.c_int32), ("num_tiles", C.c_int32),
                 ("seg_start", C.c_int32), ("num_segments", C.c_int32), ("blk_wg_start", C.c_int32),
-                ("reserved", C.c_int32), ("comp_of_block", C.c_uint8 * 12), ("h_of_block", C.c_uint8 * 12),
+                ("table_owner", C.c_int32), ("comp_of_block", C.c_uint8 * 12), ("h_of_block", C.c_uint8 * 12),
                 ("v_of_block", C.c_uint8 * 12), ("dc_sel", C.c_uint8 * 4), ("ac_sel", C.c_uint8 * 4),
                 ("bits", (C.c_uint8 * 16) * 4), ("vals", (C.c_uint8 * 256) * 4), ("rect", (C.c_int32 * 4) * 3),
                 ("plane", C.c_void_p * 3), ("plane_pitch", C.c_int32 * 3), ("reserved2", C.c_int32),

@@ -9,7 +9,7 @@
 // state at an arbitrary byte falls into step with the true decoder after a while.  Work is cut into pieces whose
 // size does not depend on the image (so a batch with one 500 KB stream and many 50 KB streams still fills the chip):
 //
-//   tile     16 KB of the stuffed stream    (un-stuffing, 1024 lanes x 16 bytes)
+//   tile     8 KB of the stuffed stream     (un-stuffing, 512 lanes x 16 bytes)
 //   slice    256 bytes of the clean stream  (one decoder lane of the synchronisation)
 //   segment  244 slices = 61 KB             (one 256-lane workgroup: 12 warm-up lanes + 244 slices)
 //   block    one 8x8 block                  (one lane of the value pass)
@@ -41,13 +41,17 @@
 // of each block again: 2 x 137 MB of scratch traffic per 256-image batch and 0.36 ms.  Knowing the block starts makes
 // the value pass embarrassingly parallel, its inner loop three times shorter, and the record stream disappears.
 #include <cstring>
+#include <vector>
 #include "common.h"
 #include "huff_core.h"
 #include "jpeg_idct_math.h"
 
 namespace daliamd {
 
-constexpr int kTileThreads = 1024;
+#ifndef DALIAMD_TILE_THREADS
+#define DALIAMD_TILE_THREADS 512   // 8 KB tiles (MI355X, 4 batches in flight: 1024 threads 358k img/s, 512: 378k, 256: 351k - a 16-wave workgroup waits for a whole free CU)
+#endif
+constexpr int kTileThreads = DALIAMD_TILE_THREADS;
 constexpr int kTileBytes = kTileThreads * 16;
 #ifndef DALIAMD_SLICE_BYTES
 #define DALIAMD_SLICE_BYTES 256
@@ -158,6 +162,16 @@ __device__ __forceinline__ ImageRef FindImage(const daliamdJpegHuffDesc *descs, 
     if (start <= wg) lo = mid; else hi = mid - 1;
   }
   return ImageRef{descs + lo, wg - (TILES ? descs[lo].tile_start : descs[lo].seg_start)};
+}
+
+// Code tables are built once per DISTINCT set of Huffman tables of the batch (most JPEG files carry the standard
+// tables of Annex K: a batch of 256 images is usually one or two sets): `table_owner` (Setup) names the stream in whose
+// scratch the tables of this stream live.  PrepareKernel builds 1-3 sets instead of 256, and every workgroup of the
+// decode passes copies its 36 KB of tables from the same few L2-resident lines.
+__device__ __forceinline__ const uint8_t *TablesBase(const daliamdJpegHuffDesc *descs, const daliamdJpegHuffDesc &d, bool sync_tables) {
+  const daliamdJpegHuffDesc &o = descs[d.table_owner];
+  const ScratchLayout lay = MakeLayout(o.ecs_len, o.num_tiles, o.num_segments, o.total_blocks);
+  return o.scratch + (sync_tables ? lay.sync_tables : lay.tables);
 }
 
 // Exclusive scan of one int per lane over the workgroup (NW waves); returns the exclusive prefix, sets `total`.
@@ -346,8 +360,11 @@ __global__ __launch_bounds__(kTileThreads) void PrepareKernel(const daliamdJpegH
                                                               int num_tiles) {
   __shared__ __attribute__((aligned(16))) HuffTables L;
   __shared__ int wave_sums[kTileThreads / 64];
-  if ((int)blockIdx.x < n) BuildTables(descs[blockIdx.x], L);
-  else CountTile(descs, n, (int)blockIdx.x - n, wave_sums);
+  if ((int)blockIdx.x < n) {
+    if (descs[blockIdx.x].table_owner == (int)blockIdx.x) BuildTables(descs[blockIdx.x], L);   // (uniform per workgroup)
+  } else {
+    CountTile(descs, n, (int)blockIdx.x - n, wave_sums);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ synchronisation
@@ -440,7 +457,7 @@ __global__ __launch_bounds__(kSegThreads) void SyncKernel(const daliamdJpegHuffD
     if (tid == 0) *segrec = SegRec{kNoState, 0, 0, {0, 0, 0}, 0};
     return;
   }
-  CopyTables<kSegThreads>(L, reinterpret_cast<const SyncTables *>(d.scratch + lay.sync_tables));
+  CopyTables<kSegThreads>(L, reinterpret_cast<const SyncTables *>(TablesBase(descs, d, true)));
   const uint32_t total_bits = (uint32_t)clean_len * 8u;
   // lanes [0, kWarmLanes) replay the last slices of the previous segment, lanes [kWarmLanes, ..) are this segment's
   Lane ln = MakeLane((long long)seg * kSegLanes + tid - kWarmLanes, total_bits);
@@ -489,7 +506,7 @@ __global__ __launch_bounds__(kSegThreads) void PropagateKernel(const daliamdJpeg
     if (total_bits != 0 && recs[0].in != truth) {
       // The warm-up lanes did not synchronise before this segment (long flat or periodic content): repair it.
       if (!tables_loaded) {
-        CopyTables<kSegThreads>(L, reinterpret_cast<const SyncTables *>(d.scratch + lay.sync_tables));
+        CopyTables<kSegThreads>(L, reinterpret_cast<const SyncTables *>(TablesBase(descs, d, true)));
         tables_loaded = true;
       }
       // every lane decodes again (its start list lives in LDS only while the kernel that decoded it runs)
@@ -624,7 +641,7 @@ __global__ __launch_bounds__(kDcThreads) void DcKernel(const daliamdJpegHuffDesc
   const int clean_len = *(const GlobalI32 *)d.scratch;
   SegRec *segrec = reinterpret_cast<SegRec *>(d.scratch + lay.segs) + seg;
   if (seg > 0 && (long long)seg * kSegBytes >= clean_len) return;  // dc_total is already zero
-  CopyHalfTables<kDcThreads>(T, reinterpret_cast<const HuffTables *>(d.scratch + lay.tables), 0);
+  CopyHalfTables<kDcThreads>(T, reinterpret_cast<const HuffTables *>(TablesBase(descs, d, false)), 0);
   if (tid < d.blocks_per_mcu) {
     comp_of[tid] = d.comp_of_block[tid];
     dcsel_of[tid] = d.dc_sel[d.comp_of_block[tid]] & 1;
@@ -770,7 +787,7 @@ __global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHu
   }
   const daliamdJpegHuffDesc &d = descs[lo];
   const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments, d.total_blocks);
-  const HuffTables *H = reinterpret_cast<const HuffTables *>(d.scratch + lay.tables);
+  const HuffTables *H = reinterpret_cast<const HuffTables *>(TablesBase(descs, d, false));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   CopyHalfTables<kBlockThreads>(T, H, 2);  // the AC tables
   if (tid < 12 && tid < d.blocks_per_mcu) {
@@ -959,8 +976,18 @@ daliamdResult_t daliamdJpegHuffmanSetup(daliamdJpegHuffDesc *descs_host, int n, 
   DALIAMD_REQUIRE(n >= 0 && (n == 0 || descs_host) && num_tiles && num_segments && num_block_workgroups,
                   DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdJpegHuffmanSetup: invalid argument");
   int tiles = 0, segs = 0, bwgs = 0;
+  std::vector<int> owners;   // one stream per distinct table set seen so far
+  auto same_tables = [](const daliamdJpegHuffDesc &a, const daliamdJpegHuffDesc &b) {
+    return a.blocks_per_mcu == b.blocks_per_mcu && !memcmp(a.bits, b.bits, sizeof(a.bits)) && !memcmp(a.vals, b.vals, sizeof(a.vals)) &&
+           !memcmp(a.comp_of_block, b.comp_of_block, sizeof(a.comp_of_block)) && !memcmp(a.dc_sel, b.dc_sel, sizeof(a.dc_sel)) &&
+           !memcmp(a.ac_sel, b.ac_sel, sizeof(a.ac_sel));
+  };
   for (int i = 0; i < n; i++) {
     daliamdJpegHuffDesc &d = descs_host[i];
+    d.table_owner = i;
+    for (int o : owners)
+      if (same_tables(descs_host[o], d)) { d.table_owner = o; break; }
+    if (d.table_owner == i && owners.size() < 64) owners.push_back(i);
     DALIAMD_REQUIRE(d.ecs && d.scratch && d.status && d.ecs_len >= 0, DALIAMD_ERROR_INVALID_ARGUMENT,
                     "daliamdJpegHuffmanSetup: sample %d: NULL buffer or negative length", i);
     DALIAMD_REQUIRE((reinterpret_cast<uintptr_t>(d.scratch) & 15) == 0, DALIAMD_ERROR_INVALID_ARGUMENT,

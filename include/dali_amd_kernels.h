@@ -142,7 +142,7 @@ DALIAMD_API daliamdResult_t daliamdJpegIdctRun(daliamdStream_t stream, const dal
  *   - provides `scratch`: daliamdJpegHuffmanScratchBytes(ecs_len, total_blocks) bytes, 16-byte aligned (clean
  *     stream, code tables, per-slice decoder states, the block starts of every segment, 10 bytes per block),
  *   - calls daliamdJpegHuffmanSetup on the host table, copies it to the device, calls daliamdJpegHuffmanRun.
- * The work is cut into image-independent pieces (16 KB tiles for the byte un-stuffing, 61 KB segments of 256-byte
+ * The work is cut into image-independent pieces (8 KB tiles for the byte un-stuffing, 61 KB segments of 256-byte
  * slices for the self-synchronising parallel decode, one lane per 8x8 block for the values), so a batch of very differently sized streams still fills
  * the device.  After the launch *status is 0 on success, 2 when the segment holds fewer blocks than the frame
  * header promises (truncated / corrupt stream: decode it with the host decoder to get the diagnosis).
@@ -161,7 +161,9 @@ typedef struct {
   int32_t h_samp[3], v_samp[3];
   int32_t tile_start, num_tiles;   /* filled by Setup: un-stuffing workgroups of this stream       */
   int32_t seg_start, num_segments; /* filled by Setup: decoding workgroups of this stream          */
-  int32_t blk_wg_start, reserved;  /* filled by Setup: block-decoding workgroups of this stream    */
+  int32_t blk_wg_start;            /* filled by Setup: block-decoding workgroups of this stream    */
+  int32_t table_owner;             /* filled by Setup: index of the stream that builds (and holds) the code tables this
+                                      stream uses - streams with identical DHT contents and MCU structure share them */
   uint8_t comp_of_block[12];  /* component of the k-th block of an MCU                             */
   uint8_t h_of_block[12], v_of_block[12]; /* its position inside the component's MCU footprint     */
   uint8_t dc_sel[4], ac_sel[4];  /* per component: table selector, 0 or 1                           */

@@ -97,7 +97,7 @@ def test_huffman_setup_sizes_the_three_grids_and_validates():
     descs = (capi.JpegHuffDesc * 3)(_huff_desc(5000, 600), _huff_desc(100_000, 6000), _huff_desc(40_000, 2400))
     tiles, segs, bwg = C.c_int(), C.c_int(), C.c_int()
     assert lib.daliamdJpegHuffmanSetup(descs, 3, C.byref(tiles), C.byref(segs), C.byref(bwg)) == 0
-    assert [d.tile_start for d in descs] == [0, 1, 8] and tiles.value == 11          # 16 KB tiles
+    assert [d.tile_start for d in descs] == [0, 1, 14] and tiles.value == 19         # 8 KB tiles
     assert [d.seg_start for d in descs] == [0, 1, 3] and segs.value == 4             # 244 slices of 256 bytes
     # block-decoding workgroups: the same number of MCUs (a multiple of 32) per workgroup for streams of the same geometry
     counts = [descs[1].blk_wg_start - descs[0].blk_wg_start, descs[2].blk_wg_start - descs[1].blk_wg_start,
@@ -109,6 +109,20 @@ def test_huffman_setup_sizes_the_three_grids_and_validates():
     one_bit = (capi.JpegHuffDesc * 1)(_huff_desc(bits0=1))                           # a 1-bit code: host decoder's job
     assert lib.daliamdJpegHuffmanSetup(one_bit, 1, C.byref(tiles), C.byref(segs), C.byref(bwg)) == 2   # UNSUPPORTED
     assert b"1-bit code" in lib.daliamdGetLastErrorMessage()
+
+
+def test_huffman_setup_shares_code_tables_between_streams_with_the_same_dht():
+    """table_owner: streams whose DHT contents and MCU structure are identical use the tables the first of them builds."""
+    lib = capi.kernels()
+    descs = (capi.JpegHuffDesc * 5)(*[_huff_desc(5000 + 100 * i, 600) for i in range(5)])
+    descs[2].vals[1][3] = 7                      # another symbol list
+    descs[4].vals[1][3] = 7                      # ... the same as stream 2's
+    descs[3].blocks_per_mcu, descs[3].total_blocks = 3, 600
+    for k, comp in enumerate([0, 1, 2, 0, 0, 0]):
+        descs[3].comp_of_block[k] = comp         # 4:4:4: another MCU structure with the standard DHT
+    tiles, segs, bwg = C.c_int(), C.c_int(), C.c_int()
+    assert lib.daliamdJpegHuffmanSetup(descs, 5, C.byref(tiles), C.byref(segs), C.byref(bwg)) == 0
+    assert [d.table_owner for d in descs] == [0, 0, 2, 3, 2]
 
 
 def test_normalize_setup_views_and_grids():
