@@ -252,6 +252,23 @@ __global__ __launch_bounds__(kSpecThreads) void SpectrogramKernel(const daliamdS
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int PadIdx(int e) { return e + ((e >> 4) << 1); }
 
+// 8-point DFT (forward): three radix-2 stages, the only products are the two rotations by 45 degrees.
+__device__ __forceinline__ float2 MulNegI(float2 v) { return make_float2(v.y, -v.x); }   // v * (-i)
+__device__ __forceinline__ void Dft8(const float2 x[8], float2 X[8]) {
+  constexpr float kS = 0.70710678118654752f;
+  const float2 a0 = CAdd(x[0], x[4]), a1 = CSub(x[0], x[4]), a2 = CAdd(x[2], x[6]), a3 = MulNegI(CSub(x[2], x[6]));
+  const float2 a4 = CAdd(x[1], x[5]), a5 = CSub(x[1], x[5]), a6 = CAdd(x[3], x[7]), a7 = MulNegI(CSub(x[3], x[7]));
+  const float2 b0 = CAdd(a0, a2), b1 = CSub(a0, a2), b2 = CAdd(a1, a3), b3 = CSub(a1, a3);
+  const float2 b4 = CAdd(a4, a6), b5 = MulNegI(CSub(a4, a6));
+  const float2 s6 = CAdd(a5, a7), s7 = CSub(a5, a7);
+  const float2 b6 = make_float2(kS * (s6.x + s6.y), kS * (s6.y - s6.x));      // * (1 - i) / sqrt 2
+  const float2 b7 = make_float2(kS * (s7.y - s7.x), -kS * (s7.x + s7.y));     // * (-1 - i) / sqrt 2
+  X[0] = CAdd(b0, b4); X[4] = CSub(b0, b4);
+  X[2] = CAdd(b1, b5); X[6] = CSub(b1, b5);
+  X[1] = CAdd(b2, b6); X[5] = CSub(b2, b6);
+  X[3] = CAdd(b3, b7); X[7] = CSub(b3, b7);
+}
+
 // MEL != 0: the spectrogram never leaves the workgroup.  Its 16-frame power tile is multiplied by the mel filter bank
 // where it sits in LDS and only the [nfilter][frames] result (mel energies, or their decibels) is written - see MelFromTile.
 struct MelFuse {
@@ -379,6 +396,17 @@ __global__ __launch_bounds__(kSpecThreads) void SpectrogramFastKernel(const dali
 #pragma unroll
     for (int u = 0; u < U / 2; u++) tw2[u] = twg[2 * (lane + 64 * u)];
   }
+  // N = 512 (nfft 1024) runs as three radix-8 Stockham steps - 512 = 8 x 8 x 8, one butterfly per lane and step, THREE
+  // LDS round trips where four radix-4 steps and a radix-2 step take five: exp(-2 pi i r k / (8 NS)), k = lane mod NS
+  constexpr bool kRadix8 = LOG2N == 9;
+  float2 tw8b[7], tw8c[7];
+  if constexpr (kRadix8) {
+#pragma unroll
+    for (int r = 1; r < 8; r++) {
+      tw8b[r - 1] = TwG(r * (lane & 7) * (2 * N / 64));
+      tw8c[r - 1] = TwG(r * lane * (2 * N / 512));
+    }
+  }
   float2 twp[UP];
 #pragma unroll
   for (int u = 0; u < UP; u++) twp[u] = twg[min(lane + 64 * u, N - 1)];
@@ -448,6 +476,51 @@ __global__ __launch_bounds__(kSpecThreads) void SpectrogramFastKernel(const dali
         }
       }
     }
+    if constexpr (kRadix8) {
+      float2 X[FC][8];
+      // ---- step 1 (NS = 1, no twiddles) straight from the registers: lane l holds the points l + 64 r of its butterfly;
+      // its 8 results are consecutive points ----
+#pragma unroll
+      for (int c = 0; c < FC; c++) {
+        Dft8(z[c], X[c]);
+        float4 *o = reinterpret_cast<float4 *>(wbase + c * WS + PadIdx(8 * lane));   // 64 bytes, 16-byte aligned
+#pragma unroll
+        for (int q = 0; q < 4; q++) o[q] = make_float4(X[c][2 * q].x, X[c][2 * q].y, X[c][2 * q + 1].x, X[c][2 * q + 1].y);
+      }
+      SpecWaveSync();
+      // ---- step 2 (NS = 8) ----
+#pragma unroll
+      for (int c = 0; c < FC; c++) {
+        const float2 *work = wbase + c * WS;
+        float2 v8[8];
+        v8[0] = work[PadIdx(lane)];
+#pragma unroll
+        for (int r = 1; r < 8; r++) v8[r] = CMul(work[PadIdx(lane + 64 * r)], tw8b[r - 1]);
+        Dft8(v8, X[c]);
+      }
+      SpecWaveSync();
+#pragma unroll
+      for (int c = 0; c < FC; c++) {
+        float2 *work = wbase + c * WS;
+        const int k = lane & 7, o = ((lane - k) << 3) + k;
+#pragma unroll
+        for (int r = 0; r < 8; r++) work[PadIdx(o + 8 * r)] = X[c][r];
+      }
+      SpecWaveSync();
+      // ---- step 3 (NS = 64): butterfly l reads and writes the points l + 64 r - in place, no hazard between lanes ----
+#pragma unroll
+      for (int c = 0; c < FC; c++) {
+        float2 *work = wbase + c * WS;
+        float2 v8[8];
+        v8[0] = work[PadIdx(lane)];
+#pragma unroll
+        for (int r = 1; r < 8; r++) v8[r] = CMul(work[PadIdx(lane + 64 * r)], tw8c[r - 1]);
+        Dft8(v8, X[c]);
+#pragma unroll
+        for (int r = 0; r < 8; r++) work[PadIdx(lane + 64 * r)] = X[c][r];
+      }
+      SpecWaveSync();
+    } else {
     // ---- first radix-4 step (no twiddles) straight from the registers ----
 #pragma unroll
     for (int c = 0; c < FC; c++) {
@@ -529,6 +602,7 @@ __global__ __launch_bounds__(kSpecThreads) void SpectrogramFastKernel(const dali
       }
       SpecWaveSync();
     }
+    }   // radix-4 path
     // ---- spectrum of the real signal, power / magnitude ----
 #pragma unroll
     for (int c = 0; c < FC; c++) {

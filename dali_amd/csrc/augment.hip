@@ -3,6 +3,7 @@
 // wg_start prefix (common.h).  Arithmetic order follows the reference's CPU kernels (see the header).
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 #include "common.h"
 
 namespace daliamd {
@@ -158,12 +159,21 @@ __device__ __forceinline__ int Reflect101(int idx, int size) {
   return idx;
 }
 
+// acc + v * w: two roundings (multiply, add) like the reference's CPU backend - the default, bit-exact against the oracle -
+// or ONE (fused multiply-add, what the reference's GPU backend does): opt-in, within the 1 LSB the reference allows
+// between its own backends (operator_1/test_gaussian_blur.py:134,164).
+template <bool FMA>
+__device__ __forceinline__ floatx2 BlurMad(floatx2 acc, floatx2 v, float w) {
+  if constexpr (FMA) return __builtin_elementwise_fma(v, floatx2{w, w}, acc);
+  else return acc + v * w;
+}
+
 // W pass: tmp[r][x*C+c] = sum_k src[r][(x+k)*C+c] * wx[k], taps in order.  A thread owns kBlurPx consecutive pixels
 // of one channel in TWO rows: the window of source bytes slides through registers (one byte load + conversion per tap
 // and row) and the row pair makes every multiply / add a packed one; the weight is wave-uniform and comes from a
 // scalar load of the descriptor.  Taps go in chunks of kBlurPx so that every register index is a constant (a window
 // that shifts by one per tap costs a move per value and tap outside a fully unrolled loop).
-template <int C>
+template <int C, bool FMA>
 __device__ __forceinline__ void BlurWPass(const daliamdGaussianBlurDesc &d, const uint8_t *src, float *tmp, int src_pitch,
                                           int tstride, int in_rows, int tw, int ox0, int oy0, int rx, int ry,
                                           bool interior_x) {
@@ -203,7 +213,7 @@ __device__ __forceinline__ void BlurWPass(const daliamdGaussianBlurDesc &d, cons
       for (int t = 0; t < P; t++) {
         const float w = gw[k + t];
 #pragma unroll
-        for (int j = 0; j < P; j++) acc[j] += (j + t < P - 1 ? v[j + t] : n[j + t - (P - 1)]) * w;
+        for (int j = 0; j < P; j++) acc[j] = BlurMad<FMA>(acc[j], j + t < P - 1 ? v[j + t] : n[j + t - (P - 1)], w);
       }
 #pragma unroll
       for (int i = 0; i < P - 1; i++) v[i] = n[i + 1];
@@ -218,7 +228,7 @@ __device__ __forceinline__ void BlurWPass(const daliamdGaussianBlurDesc &d, cons
         if (t >= rem) break;
         const float w = gw[k + t];
 #pragma unroll
-        for (int j = 0; j < P; j++) acc[j] += (j + t < P - 1 ? v[j + t] : n[j + t - (P - 1)]) * w;
+        for (int j = 0; j < P; j++) acc[j] = BlurMad<FMA>(acc[j], j + t < P - 1 ? v[j + t] : n[j + t - (P - 1)], w);
       }
     }
     float *ta = tmp + ra * tstride + x * C + c, *tb = tmp + rb * tstride + x * C + c;
@@ -234,7 +244,7 @@ __device__ __forceinline__ void BlurWPass(const daliamdGaussianBlurDesc &d, cons
 // H pass: a thread owns two neighbouring elements of a row (the packed pair, one 8-byte LDS load per tap) in kBlurRows
 // consecutive output rows; the rows slide through registers in chunks like the taps of the W pass.  tmp has
 // kBlurRows - 1 spare rows behind the staged ones: the rows read past the end only feed outputs that are not stored.
-template <bool STAGED>
+template <bool STAGED, bool FMA>
 __device__ __forceinline__ void BlurHPass(const daliamdGaussianBlurDesc &d, const float *tmp, int tstride, int row_elems,
                                           int th, uint8_t *outb, int opitch, int ox0, int oy0) {
   constexpr int R = kBlurRows;
@@ -263,7 +273,7 @@ __device__ __forceinline__ void BlurHPass(const daliamdGaussianBlurDesc &d, cons
       for (int t = 0; t < R; t++) {
         const float w = gw[k + t];
 #pragma unroll
-        for (int j = 0; j < R; j++) acc[j] += w * (j + t < R - 1 ? v[j + t] : n[j + t - (R - 1)]);
+        for (int j = 0; j < R; j++) acc[j] = BlurMad<FMA>(acc[j], j + t < R - 1 ? v[j + t] : n[j + t - (R - 1)], w);
       }
 #pragma unroll
       for (int i = 0; i < R - 1; i++) v[i] = n[i + 1];
@@ -278,7 +288,7 @@ __device__ __forceinline__ void BlurHPass(const daliamdGaussianBlurDesc &d, cons
         if (t >= rem) break;
         const float w = gw[k + t];
 #pragma unroll
-        for (int j = 0; j < R; j++) acc[j] += w * (j + t < R - 1 ? v[j + t] : n[j + t - (R - 1)]);
+        for (int j = 0; j < R; j++) acc[j] = BlurMad<FMA>(acc[j], j + t < R - 1 ? v[j + t] : n[j + t - (R - 1)], w);
       }
     }
     if constexpr (STAGED) {
@@ -371,6 +381,7 @@ __device__ __forceinline__ void BlurWriteOut(const daliamdGaussianBlurDesc &d, c
   }
 }
 
+template <bool FMA>
 __global__ __launch_bounds__(kBlurThreads) void GaussianBlurKernel(const daliamdGaussianBlurDesc *__restrict__ descs,
                                                                    int ndesc, int total_wg,
                                                                    const daliamdPointwiseDesc *__restrict__ pointwise) {
@@ -415,18 +426,18 @@ __global__ __launch_bounds__(kBlurThreads) void GaussianBlurKernel(const daliamd
   }
   __syncthreads();
   switch (C) {
-    case 1: BlurWPass<1>(d, src, tmp, src_pitch, tstride, in_rows, tw, ox0, oy0, rx, ry, interior_x); break;
-    case 2: BlurWPass<2>(d, src, tmp, src_pitch, tstride, in_rows, tw, ox0, oy0, rx, ry, interior_x); break;
-    case 3: BlurWPass<3>(d, src, tmp, src_pitch, tstride, in_rows, tw, ox0, oy0, rx, ry, interior_x); break;
-    default: BlurWPass<4>(d, src, tmp, src_pitch, tstride, in_rows, tw, ox0, oy0, rx, ry, interior_x); break;
+    case 1: BlurWPass<1, FMA>(d, src, tmp, src_pitch, tstride, in_rows, tw, ox0, oy0, rx, ry, interior_x); break;
+    case 2: BlurWPass<2, FMA>(d, src, tmp, src_pitch, tstride, in_rows, tw, ox0, oy0, rx, ry, interior_x); break;
+    case 3: BlurWPass<3, FMA>(d, src, tmp, src_pitch, tstride, in_rows, tw, ox0, oy0, rx, ry, interior_x); break;
+    default: BlurWPass<4, FMA>(d, src, tmp, src_pitch, tstride, in_rows, tw, ox0, oy0, rx, ry, interior_x); break;
   }
   __syncthreads();
   if (!pointwise) {
-    BlurHPass<false>(d, tmp, tstride, row_elems, th, nullptr, 0, ox0, oy0);
+    BlurHPass<false, FMA>(d, tmp, tstride, row_elems, th, nullptr, 0, ox0, oy0);
     return;
   }
   const int opitch = (TW * C + 3) & ~3;   // <= src_pitch, and the staged source has at least th rows
-  BlurHPass<true>(d, tmp, tstride, row_elems, th, src, opitch, ox0, oy0);
+  BlurHPass<true, FMA>(d, tmp, tstride, row_elems, th, src, opitch, ox0, oy0);
   __syncthreads();
   const daliamdPointwiseDesc pw = pointwise[di];   // (a private copy: the stores below cannot alias it)
   BlurWriteOut(d, &pw, src, opitch, tw, th, ox0, oy0);
@@ -660,10 +671,17 @@ daliamdResult_t daliamdGaussianBlurPointwiseRun(daliamdStream_t stream, const da
   if (n == 0 || nwg == 0) return DALIAMD_SUCCESS;
   DALIAMD_REQUIRE(descs_dev && n > 0 && nwg > 0 && lds_bytes >= 0 && lds_bytes <= kBlurMaxLds,
                   DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdGaussianBlurRun: invalid argument");
+  // DALI_AMD_BLUR_FMA=1: fused multiply-add accumulation (<= 1 LSB from the default, which replays the reference CPU
+  // backend's separately rounded multiply and add bit for bit)
+  static const bool fma = getenv("DALI_AMD_BLUR_FMA") && atoi(getenv("DALI_AMD_BLUR_FMA")) != 0;
   {
     daliamd::KernelTimer timer("GaussianBlurKernel", (hipStream_t)stream);
-    hipLaunchKernelGGL(GaussianBlurKernel, dim3(XcdGrid(nwg)), dim3(kBlurThreads), lds_bytes, (hipStream_t)stream,
-                       descs_dev, n, nwg, pointwise_dev);
+    if (fma)
+      hipLaunchKernelGGL(GaussianBlurKernel<true>, dim3(XcdGrid(nwg)), dim3(kBlurThreads), lds_bytes, (hipStream_t)stream,
+                         descs_dev, n, nwg, pointwise_dev);
+    else
+      hipLaunchKernelGGL(GaussianBlurKernel<false>, dim3(XcdGrid(nwg)), dim3(kBlurThreads), lds_bytes, (hipStream_t)stream,
+                         descs_dev, n, nwg, pointwise_dev);
   }
   DALIAMD_HIP_CHECK(hipGetLastError());
   return DALIAMD_SUCCESS;

@@ -140,6 +140,8 @@ class TensorList {
   // the one block behind the samples (raw(i) - base() is sample i's offset) and whether it is page-locked: a device
   // operator may then transfer straight from it instead of staging a copy
   const void *base() const { return buf_->data(); }
+  // holders of the storage block (this list included): 1 = nobody else reads it any more
+  long buffer_use_count() const { return buf_.use_count(); }
   bool pinned() const { return buf_->pinned(); }
   // shares storage and metadata (zero-copy pass-through)
   void ShareData(const TensorList &other);

@@ -50,7 +50,20 @@ class ExternalSourceOp : public OperatorBase {
                    TypeName(type));
     if (const ArgValue *nd = spec_.TryArg("ndim"))
       for (auto &s : shapes) DALI_ENFORCE((int64_t)s.size() == nd->i, "ExternalSource expected ", nd->i, "-D data");
-    auto tl = std::make_shared<TensorList>(StorageDevice::CPU);
+    // Storage is recycled: a page-locked block that no ring slot refers to any more takes the next batch.  Allocating
+    // (and, worse, FREEING: hipHostFree waits for the device to go idle) a pinned block per fed batch stalled the
+    // host stage for about a millisecond per iteration with several batches in flight.
+    std::shared_ptr<TensorList> tl;
+    {
+      std::lock_guard<std::mutex> g(m_);
+      for (auto it = recycle_.begin(); it != recycle_.end(); ++it)
+        if ((*it)->buffer_use_count() == 1) {
+          tl = std::move(*it);
+          recycle_.erase(it);
+          break;
+        }
+    }
+    if (!tl) tl = std::make_shared<TensorList>(StorageDevice::CPU);
     tl->Resize(shapes, type);
     tl->SetLayout(layout);
     for (size_t i = 0; i < data.size(); i++) memcpy(tl->raw((int)i), data[i], tl->nbytes((int)i));
@@ -69,6 +82,10 @@ class ExternalSourceOp : public OperatorBase {
       queue_.pop_front();
     }
     ws.Output(0).ShareData(*tl);
+    {
+      std::lock_guard<std::mutex> g(m_);
+      if (recycle_.size() < 32) recycle_.push_back(std::move(tl));   // (its block is free again once the ring slot moves on)
+    }
     if (const ArgValue *l = spec_.TryArg("layout"))
       if (ws.Output(0).layout().empty()) ws.Output(0).SetLayout(l->s);
   }
@@ -76,6 +93,7 @@ class ExternalSourceOp : public OperatorBase {
  private:
   std::mutex m_;
   std::deque<std::shared_ptr<TensorList>> queue_;
+  std::vector<std::shared_ptr<TensorList>> recycle_;
 };
 DALI_REGISTER_OPERATOR(ExternalSource, ExternalSourceOp, CPU);
 

@@ -184,3 +184,39 @@ def test_erase_behind_a_blur_of_single_channel_images(monkeypatch):
         ref = O.gaussian_blur_u8(im, O.gaussian_window(1.5))
         ref[10:40, 20:60] = 9
         assert np.array_equal(out[i].as_cpu(), ref), i
+
+
+def test_blur_fma_variant_stays_within_the_reference_tolerance():
+    """DALI_AMD_BLUR_FMA=1 (opt-in, read once per process): fused multiply-add accumulation like the reference's GPU
+    backend - no longer bit-identical to the CPU arithmetic, but within the 1 LSB the reference allows between its own
+    backends (operator_1/test_gaussian_blur.py:134,164) and within 1 LSB of the float64 convolution."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+from dali_amd import backend as B
+from oracle import oracle as O
+from tests import independent_models as M
+from tests.util import synth_image
+rng = np.random.default_rng(31)
+imgs = [synth_image(rng, h, w) for h, w in [(200, 300), (97, 131), (512, 512)]] + [rng.integers(0, 256, (128, 160, 3), dtype=np.uint8)]
+outs = B.gaussian_blur_batch([torch.from_numpy(im).cuda() for im in imgs], sigma=3.0)
+win = O.gaussian_window(3.0)
+ndiff = 0
+for im, o in zip(imgs, outs):
+    got = o.cpu().numpy()
+    ref = O.gaussian_blur_u8(im, win)
+    d = np.abs(got.astype(int) - ref)
+    assert d.max() <= 1, d.max()
+    ndiff += int((d > 0).sum())
+    exact = M.convolve_reflect101(im, M.gaussian_kernel(win.size, 3.0), M.gaussian_kernel(win.size, 3.0))
+    assert np.abs(got - exact).max() <= 0.5 + 2e-3
+print("FMA_BLUR_OK", ndiff)
+''' % root
+    res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DALI_AMD_BLUR_FMA="1"), capture_output=True, text=True,
+                         timeout=300)
+    assert res.returncode == 0 and "FMA_BLUR_OK" in res.stdout, res.stderr[-2000:]
