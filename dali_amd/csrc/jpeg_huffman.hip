@@ -33,8 +33,8 @@
 //                           sums per component inside the segment; notes the bit position behind the DC symbol
 //   6 BlockKernel           one lane per block: AC symbols -> coefficients of the lane's block in LDS (the loop knows
 //                           nothing but one code table: no DC / block bookkeeping, ~26 instructions per symbol); then
-//                           the wave dequantises + inverse-transforms its 64 blocks, 8 lanes per block, and stores the
-//                           8x8 samples to the component plane (or the coefficients, for callers that want them)
+//                           every lane dequantises + inverse-transforms ITS block in its registers and stores the 8x8
+//                           samples to the component plane (or the coefficients, for callers that want them)
 //
 // Round 1's decoder ran a second full sequential decode per half slice that appended one 32-bit record per symbol to
 // a stream in HBM (WriteKernel, 80 instructions per symbol), a DC scan and an expand kernel that gathered the records
@@ -709,13 +709,12 @@ __global__ __launch_bounds__(kDcThreads) void DcKernel(const daliamdJpegHuffDesc
 // Value pass.  A workgroup owns a run of MCUs of one image; its waves take TASKS of 64 blocks that all use the same
 // AC table (luma / chroma blocks differ 2-3x in their number of symbols: a wave's loop lasts as long as its longest
 // block), one block per lane: the lane zero-fills nothing but decodes its AC symbols straight into its 64-coefficient
-// slot in LDS (natural zig-zag order, plus the DC level), then the wave transforms its 64 blocks 8 at a time with 8
-// lanes per block - JpegIdctKernel's two passes (lane `part` owns column `part` in pass 1 and row `part` in pass 2),
-// reading the coefficients through the zig-zag - and stores the samples.  Waves never wait for each other.
-// Workgroup shape (MI355X, headline batch, waves x tasks per wave -> kernel time alone / images per second with two
-// batches in flight): 2x3 216 us / 311k, 3x2 201 / 303k, 4x3 204 / 318k, 6x2 258 / 288k (six waves sit 2-2-1-1 on the
-// SIMDs), 12x1 196 / 306k.  LDS bounds the kernel at 8-12 waves per CU whatever the shape; the 143 KB workgroup of 12x1
-// is the fastest alone but leaves no LDS for the kernels of the other batch in flight.
+// slot in LDS (natural zig-zag order, plus the DC level; coefficient-major, see kCoefRows), then transforms that block in
+// its own registers - the two passes of JpegIdctKernel, sixteen 8-point butterflies - and stores its eight rows of samples.
+// Waves never wait for each other.
+// Workgroup shape (MI355X, headline batch, waves x tasks per wave; round 3, four batches in flight through the product
+// pipeline): 4x3 (45 KB of LDS: three workgroups per CU) 150 us alone / 384k images per second, 3x4 377k, 6x2 356k.
+// (Round 2, block-major LDS with the 8-lanes-per-block IDCT: 2x3 216 us, 3x2 201, 4x3 204, 6x2 258, 12x1 196.)
 #ifndef DALIAMD_BLOCK_WAVES
 #define DALIAMD_BLOCK_WAVES 4
 #endif
@@ -751,13 +750,8 @@ struct BlockGeom {
 // Per block of a task, where its output goes: bits 0-47 the address (fused: top-left sample of the block in its
 // plane; else the block's 64 coefficients), bits 48-49 the component, bit 50 "needed".
 constexpr uint64_t kInfoNeeded = 1ull << 50;
-// position in the scan (zig-zag index) of the coefficient at column-major block position p = column * 8 + row
-__device__ __constant__ uint8_t kScanIndexOfColMajor[64] = {
-    0, 2, 3, 9, 10, 20, 21, 35, 1, 4, 8, 11, 19, 22, 34, 36, 5, 7, 12, 18, 23, 33, 37, 48, 6, 13, 17, 24, 32, 38, 47, 49,
-    14, 16, 25, 31, 39, 46, 50, 57, 15, 26, 30, 40, 45, 51, 56, 58, 27, 29, 41, 44, 52, 55, 59, 62, 28, 42, 43, 53, 54, 60,
-    61, 63};
-
-// the same as a compile-time function (LDS offsets of the IDCT's reads become immediates)
+// position in the scan (zig-zag index) of the coefficient at column-major block position p = column * 8 + row,
+// a compile-time function (LDS offsets of the IDCT's reads become immediates)
 __host__ __device__ constexpr int kScanIndexOfColMajorHost(int p) {
   constexpr uint8_t t[64] = {0, 2, 3, 9, 10, 20, 21, 35, 1, 4, 8, 11, 19, 22, 34, 36, 5, 7, 12, 18, 23, 33, 37, 48, 6, 13, 17, 24,
                              32, 38, 47, 49, 14, 16, 25, 31, 39, 46, 50, 57, 15, 26, 30, 40, 45, 51, 56, 58, 27, 29, 41, 44, 52, 55,
