@@ -31,6 +31,18 @@ def test_host_library_exports_all_declared_symbols():
         assert hasattr(lib, n), f"{n} is declared in include/dali_amd_host.h but not exported"
 
 
+def test_pipeline_c_api_exports_all_declared_symbols_and_nothing_undeclared():
+    """include/dali_amd_pipeline.h: the flat pipeline API the Python front end binds (dali_amd/_backend.py)."""
+    names = _declared("dali_amd_pipeline.h", "DALIAMD_PIPE_API")
+    assert len(names) >= 35
+    lib = capi.host()
+    for n in names:
+        assert hasattr(lib, n), f"{n} is declared in include/dali_amd_pipeline.h but not exported"
+    src = open(os.path.join(ROOT, "dali_amd", "host", "c_api.cpp")).read()
+    defined = set(re.findall(r"^API\s+[\w\s\*]+?\b(daliamd\w+)\s*\(", src, re.M))
+    assert defined == set(names), sorted(defined ^ set(names))
+
+
 def test_struct_sizes_match_the_c_headers():
     """ctypes mirrors are compiled against: build a tiny C program printing sizeof() of each struct."""
     import subprocess
