@@ -439,14 +439,18 @@ __device__ __forceinline__ uint32_t LdsDwordAt(const uint8_t *base, int off) {
 // Vertical first pass over a staged window whose rows share their alignment modulo 4.  16 threads per output row; a
 // thread owns the dwords j, j + 16, ... (N of them) of that row's window: the row's tap offset and coefficient are read
 // once per tap for all of them, every dword gives 4 elements (packed multiply / add, separately rounded).
+#ifndef DALIAMD_RS_LPR
+#define DALIAMD_RS_LPR 16
+#endif
+constexpr int kVLanesPerRow = DALIAMD_RS_LPR;   // lanes that share one output row of the vertical first pass
 template <int N>
 __device__ __forceinline__ void VPassItems(const uint8_t *stage, float *tmp, const float *cy, const int *yt, int tid, int th,
                                            int NB, int sup_y, int s4, int ndw, int jbase) {
-  const int j0 = jbase + (tid & 15);
+  const int j0 = jbase + (tid & (kVLanesPerRow - 1));
   const uint8_t *col[N];
 #pragma unroll
-  for (int i = 0; i < N; i++) col[i] = stage + 4 * min(j0 + 16 * i, ndw - 1) - s4;   // (clamped: no out-of-range reads)
-  for (int y = tid >> 4; y < th; y += kResampleThreads / 16) {
+  for (int i = 0; i < N; i++) col[i] = stage + 4 * min(j0 + kVLanesPerRow * i, ndw - 1) - s4;   // (clamped: no out-of-range reads)
+  for (int y = tid / kVLanesPerRow; y < th; y += kResampleThreads / kVLanesPerRow) {
     const float *co = cy + y * sup_y;
     const int *ro = yt + y * sup_y;
     floatx2 lo[N], hi[N];
@@ -473,7 +477,7 @@ __device__ __forceinline__ void VPassItems(const uint8_t *stage, float *tmp, con
     float *trow = tmp + y * NB;
 #pragma unroll
     for (int i = 0; i < N; i++) {
-      const int j = j0 + 16 * i, e = 4 * j - s4;
+      const int j = j0 + kVLanesPerRow * i, e = 4 * j - s4;
       if (j >= ndw) continue;
       if (e >= 0 && e + 3 < NB) {
         trow[e] = lo[i].x; trow[e + 1] = lo[i].y; trow[e + 2] = hi[i].x; trow[e + 3] = hi[i].y;
@@ -619,10 +623,10 @@ __global__ __launch_bounds__(kResampleThreads) __attribute__((amdgpu_waves_per_e
         // every row has the same shift modulo 4: 4 consecutive elements from one LDS dword per tap
         const int s4 = (int)(win_addr & 3);
         const int ndw = (NB + s4 + 3) >> 2;
-        for (int jbase = 0; jbase < ndw; jbase += 48) {
+        for (int jbase = 0; jbase < ndw; jbase += 3 * kVLanesPerRow) {
           const int rem = ndw - jbase;
-          if (rem > 32) VPassItems<3>(stage, tmp, cy, yt, tid, th, NB, sup_y, s4, ndw, jbase);
-          else if (rem > 16) VPassItems<2>(stage, tmp, cy, yt, tid, th, NB, sup_y, s4, ndw, jbase);
+          if (rem > 2 * kVLanesPerRow) VPassItems<3>(stage, tmp, cy, yt, tid, th, NB, sup_y, s4, ndw, jbase);
+          else if (rem > kVLanesPerRow) VPassItems<2>(stage, tmp, cy, yt, tid, th, NB, sup_y, s4, ndw, jbase);
           else VPassItems<1>(stage, tmp, cy, yt, tid, th, NB, sup_y, s4, ndw, jbase);
         }
       } else {
