@@ -20,44 +20,63 @@ __device__ __forceinline__ int ClampInt(int v, int lo, int hi) { return min(max(
 // warp_affine
 // =============================================================================================
 // The CPU kernel walks each output row adding ds/dx per pixel, re-anchoring every 256 pixels
-// (warp_cpu.h:160-176).  To be bit-identical every thread replays that chain of float additions up to its
-// first pixel (<= 255 dependent adds; cheap next to the 4-tap gather) and then produces kWarpPx pixels.
+// (warp_cpu.h:160-176).  To be bit-identical the source coordinates of a row ARE that chain of float additions.
+// Round 2 let every thread replay the chain up to its first pixel: a wave = one row of 256 pixels executed the 252-step
+// loop of its last lane, 504 dependent additions for 280 instructions of sampling - two thirds of the kernel.  Now a
+// workgroup owns 16 rows x 256 pixels: lanes of its first wave walk the chains of the ROWS side by side (lane = row: the
+// same 504 additions serve 16 rows) and leave the coordinates of every fourth pixel in LDS; then all four waves sample, a
+// wave per row and a lane per 4 pixels as before.  Measured (configs[2], us alone / images per second with four batches
+// in flight): replay per thread 332 / 122k; shared chains with 64 rows per workgroup 558 / 117k (a wave walks 16 rows one
+// after the other: the gathers of a row wait for the previous row's), 32 rows 373 / 128k, 16 rows 311 / 130k, 8 rows
+// 298 / 122k - the kernel is bound by the latency of its 12-byte gathers, not by the additions.
 constexpr int kWarpThreads = 256;
 constexpr int kWarpPx = 4;
 constexpr int kWarpTileW = 256;  // must equal the CPU re-anchoring period
-constexpr int kWarpRows = kWarpThreads / (kWarpTileW / kWarpPx);  // 4 rows per workgroup
+#ifndef DALIAMD_WARP_ROWS
+#define DALIAMD_WARP_ROWS 16
+#endif
+constexpr int kWarpRows = DALIAMD_WARP_ROWS;    // rows per workgroup = lanes of the wave that walks the chains (<= 64)
+constexpr int kWarpGroups = kWarpTileW / kWarpPx;   // 4-pixel groups per row of the tile = lanes per row
+constexpr int kWarpChainPitch = kWarpGroups + 1;    // float2 per row in LDS (+ 1: the walkers' strided stores spread over the banks)
 
 __global__ __launch_bounds__(kWarpThreads) void WarpAffineKernel(const daliamdWarpAffineDesc *__restrict__ descs,
                                                                  int ndesc, int total_wg) {
+  __shared__ float2 chain[kWarpRows * kWarpChainPitch];
   int wg = XcdRemap(blockIdx.x, total_wg);
   if (wg < 0) return;
   const daliamdWarpAffineDesc &d = descs[FindDesc(descs, ndesc, wg)];
   const int tiles_x = (d.out_w + kWarpTileW - 1) / kWarpTileW;
   int t = wg - d.wg_start;
   int ty = t / tiles_x, tx = t - ty * tiles_x;
-  int y = ty * kWarpRows + threadIdx.x / (kWarpTileW / kWarpPx);
-  int x_tile = tx * kWarpTileW;
-  int x0 = x_tile + (threadIdx.x % (kWarpTileW / kWarpPx)) * kWarpPx;
-  if (y >= d.out_h || x0 >= d.out_w) return;
+  const int x_tile = tx * kWarpTileW, y_tile = ty * kWarpRows;
   const float m0 = d.matrix[0], m1 = d.matrix[1], m2 = d.matrix[2], m3 = d.matrix[3], m4 = d.matrix[4], m5 = d.matrix[5];
-  // map_coords(mapping, (0, y)): affine(M, (0.5, y + 0.5)), sum = t; sum += m*v (transform.h:134-145)
-  float vx = 0 + 0.5f, vy = y + 0.5f;
-  float sx = m2; sx += m0 * vx; sx += m1 * vy;
-  float sy = m5; sy += m3 * vx; sy += m4 * vy;
-  const float dtx = kWarpTileW * m0, dty = kWarpTileW * m3;
-  for (int k = 0; k < tx; k++) { sx += dtx; sy += dty; }
-  // x0 - x_tile = kWarpPx * lane: the replayed additions in groups of kWarpPx * 2 with a remainder, so that the loop
-  // overhead (per-lane trip count = a divergent branch per iteration) is paid once per eight additions
-  {
-    const int hops = (x0 - x_tile) / kWarpPx;  // lane index inside the row
-    for (int k = 0; k + 2 <= hops; k += 2) {
-#pragma unroll
-      for (int q = 0; q < 2 * kWarpPx; q++) { sx += m0; sy += m3; }
-    }
-    if (hops & 1) {
+  if (threadIdx.x < kWarpRows) {   // the first wave: lane = row of the tile
+    const int yr = y_tile + (int)threadIdx.x;
+    // map_coords(mapping, (0, y)): affine(M, (0.5, y + 0.5)), sum = t; sum += m*v (transform.h:134-145)
+    float vx = 0 + 0.5f, vy = yr + 0.5f;
+    float sx = m2; sx += m0 * vx; sx += m1 * vy;
+    float sy = m5; sy += m3 * vx; sy += m4 * vy;
+    const float dtx = kWarpTileW * m0, dty = kWarpTileW * m3;
+    for (int k = 0; k < tx; k++) { sx += dtx; sy += dty; }
+    float2 *row = chain + threadIdx.x * kWarpChainPitch;
+    const int groups = min(kWarpGroups, (d.out_w - x_tile + kWarpPx - 1) / kWarpPx);
+    for (int g = 0; g < groups; g++) {
+      row[g] = make_float2(sx, sy);
 #pragma unroll
       for (int q = 0; q < kWarpPx; q++) { sx += m0; sy += m3; }
     }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int x0 = x_tile + lane * kWarpPx;
+  if (x0 >= d.out_w) return;
+  for (int ry = wave; ry < kWarpRows; ry += kWarpThreads / 64) {
+  const int y = y_tile + ry;
+  if (y >= d.out_h) break;
+  float sx, sy;
+  {
+    const float2 s0 = chain[ry * kWarpChainPitch + lane];
+    sx = s0.x; sy = s0.y;
   }
   const int C = d.channels;
   const int npx = min(kWarpPx, d.out_w - x0);
@@ -138,6 +157,7 @@ __global__ __launch_bounds__(kWarpThreads) void WarpAffineKernel(const daliamdWa
     w.z = ob[8] | (ob[9] << 8) | (ob[10] << 16) | (ob[11] << 24);
     *(u32x3 __attribute__((address_space(1))) *)o = w;
   }
+  }   // rows of the tile
 }
 
 // =============================================================================================
