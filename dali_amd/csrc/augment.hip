@@ -21,72 +21,136 @@ __device__ __forceinline__ int ClampInt(int v, int lo, int hi) { return min(max(
 // =============================================================================================
 // The CPU kernel walks each output row adding ds/dx per pixel, re-anchoring every 256 pixels
 // (warp_cpu.h:160-176).  To be bit-identical the source coordinates of a row ARE that chain of float additions.
-// Round 2 let every thread replay the chain up to its first pixel: a wave = one row of 256 pixels executed the 252-step
-// loop of its last lane, 504 dependent additions for 280 instructions of sampling - two thirds of the kernel.  Now a
-// workgroup owns 16 rows x 256 pixels: lanes of its first wave walk the chains of the ROWS side by side (lane = row: the
-// same 504 additions serve 16 rows) and leave the coordinates of every fourth pixel in LDS; then all four waves sample, a
-// wave per row and a lane per 4 pixels as before.  Measured (configs[2], us alone / images per second with four batches
-// in flight): replay per thread 332 / 122k; shared chains with 64 rows per workgroup 558 / 117k (a wave walks 16 rows one
-// after the other: the gathers of a row wait for the previous row's), 32 rows 373 / 128k, 16 rows 311 / 130k, 8 rows
-// 298 / 122k - the kernel is bound by the latency of its 12-byte gathers, not by the additions.
+//
+// Round 3: LDS-staged tiles.  A workgroup owns 32 rows of one 256-pixel segment = eight 32 x 32 output tiles.
+//   1. 32 lanes of its first wave walk the coordinate chains of the 32 ROWS side by side (lane = row: one pass of 256
+//      additions per coordinate serves all rows and all eight tiles; round 2 let every thread replay the chain of its own
+//      row up to its own pixel) and leave the coordinates of every fourth pixel in LDS;
+//   then, tile by tile:
+//   2. the bounding box of the tile's source footprint (from its four corners, one pixel of margin; for the +-30 degree,
+//      0.8-1.2x warps of configs[2] about 58 x 58 source pixels) is copied into LDS with coalesced 16-byte loads, rows
+//      keeping their alignment shift - the same staging as the resampling kernel;
+//   3. every thread samples its 4 pixels: the 2 x 2 x 3 bytes of a bilinear tap come from LDS (three aligned dwords per
+//      row + a byte funnel shift) when the tap lies inside the staged footprint, from memory - with the border rules -
+//      when it does not (tiles at the image border; footprints too large for LDS: strong down-scaling).
+// Round 2 fetched every tap as two unaligned 12-byte gathers from memory: 338 us for 201 MB, bound by their latency.
 constexpr int kWarpThreads = 256;
 constexpr int kWarpPx = 4;
-constexpr int kWarpTileW = 256;  // must equal the CPU re-anchoring period
-#ifndef DALIAMD_WARP_ROWS
-#define DALIAMD_WARP_ROWS 16
-#endif
-constexpr int kWarpRows = DALIAMD_WARP_ROWS;    // rows per workgroup = lanes of the wave that walks the chains (<= 64)
-constexpr int kWarpGroups = kWarpTileW / kWarpPx;   // 4-pixel groups per row of the tile = lanes per row
-constexpr int kWarpChainPitch = kWarpGroups + 1;    // float2 per row in LDS (+ 1: the walkers' strided stores spread over the banks)
+constexpr int kWarpSegW = 256;   // the CPU re-anchoring period
+constexpr int kWarpTileW = 32, kWarpTileH = 32;
+constexpr int kWarpGroups = kWarpTileW / kWarpPx;   // 4-pixel groups per tile row
+constexpr int kWarpTilesPerWg = kWarpSegW / kWarpTileW;
+constexpr int kWarpSegGroups = kWarpSegW / kWarpPx;
+constexpr int kWarpStageBytes = 14 * 1024;
+
+// 16 bytes at a 16-byte aligned address; bytes outside [lo, hi) read as zero (never used: they lie outside the footprint)
+__device__ __forceinline__ uint4 WarpLoadChunk(uintptr_t g, uintptr_t lo, uintptr_t hi) {
+  if (g >= lo && g + 16 <= hi) {
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    const u32x4_t t4 = *(const u32x4_t __attribute__((address_space(1))) *)g;
+    return make_uint4(t4.x, t4.y, t4.z, t4.w);
+  }
+  uint32_t w[4] = {0, 0, 0, 0};
+  for (int b = 0; b < 16; b++) {
+    const uintptr_t a = g + b;
+    if (a >= lo && a < hi) w[b >> 2] |= (uint32_t)(*(const uint8_t __attribute__((address_space(1))) *)a) << (8 * (b & 3));
+  }
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
 
 __global__ __launch_bounds__(kWarpThreads) void WarpAffineKernel(const daliamdWarpAffineDesc *__restrict__ descs,
                                                                  int ndesc, int total_wg) {
-  __shared__ float2 chain[kWarpRows * kWarpChainPitch];
+  __shared__ float2 chain[kWarpTileH][kWarpSegGroups + 1];
+  __shared__ int box[4];                    // x_lo, x_hi, y_lo, y_hi of the staged footprint (x_lo > x_hi: nothing staged)
+  __shared__ __attribute__((aligned(16))) uint8_t stage[kWarpStageBytes];
   int wg = XcdRemap(blockIdx.x, total_wg);
   if (wg < 0) return;
   const daliamdWarpAffineDesc &d = descs[FindDesc(descs, ndesc, wg)];
-  const int tiles_x = (d.out_w + kWarpTileW - 1) / kWarpTileW;
-  int t = wg - d.wg_start;
-  int ty = t / tiles_x, tx = t - ty * tiles_x;
-  const int x_tile = tx * kWarpTileW, y_tile = ty * kWarpRows;
+  const int segs_x = (d.out_w + kWarpSegW - 1) / kWarpSegW;
+  const int t = wg - d.wg_start;
+  const int ty = t / segs_x, seg = t - ty * segs_x;
+  const int x_seg = seg * kWarpSegW, y_tile = ty * kWarpTileH;
+  const int tid = threadIdx.x;
+  const int C = d.channels;
   const float m0 = d.matrix[0], m1 = d.matrix[1], m2 = d.matrix[2], m3 = d.matrix[3], m4 = d.matrix[4], m5 = d.matrix[5];
-  if (threadIdx.x < kWarpRows) {   // the first wave: lane = row of the tile
-    const int yr = y_tile + (int)threadIdx.x;
+  using GIn = const uint8_t __attribute__((address_space(1)));
+  using GOut = uint8_t __attribute__((address_space(1)));
+  GIn *in = (GIn *)d.in;
+  // ---- 1. the coordinate chains of the 32 rows over the segment ----
+  if (tid < kWarpTileH) {
+    const int yr = y_tile + tid;
     // map_coords(mapping, (0, y)): affine(M, (0.5, y + 0.5)), sum = t; sum += m*v (transform.h:134-145)
     float vx = 0 + 0.5f, vy = yr + 0.5f;
     float sx = m2; sx += m0 * vx; sx += m1 * vy;
     float sy = m5; sy += m3 * vx; sy += m4 * vy;
-    const float dtx = kWarpTileW * m0, dty = kWarpTileW * m3;
-    for (int k = 0; k < tx; k++) { sx += dtx; sy += dty; }
-    float2 *row = chain + threadIdx.x * kWarpChainPitch;
-    const int groups = min(kWarpGroups, (d.out_w - x_tile + kWarpPx - 1) / kWarpPx);
+    const float dtx = kWarpSegW * m0, dty = kWarpSegW * m3;
+    for (int k = 0; k < seg; k++) { sx += dtx; sy += dty; }   // the re-anchoring steps in front of the segment
+    const int groups = min(kWarpSegGroups, (d.out_w - x_seg + kWarpPx - 1) / kWarpPx);
     for (int g = 0; g < groups; g++) {
-      row[g] = make_float2(sx, sy);
+      chain[tid][g] = make_float2(sx, sy);
 #pragma unroll
       for (int q = 0; q < kWarpPx; q++) { sx += m0; sy += m3; }
     }
   }
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int x0 = x_tile + lane * kWarpPx;
-  if (x0 >= d.out_w) return;
-  for (int ry = wave; ry < kWarpRows; ry += kWarpThreads / 64) {
-  const int y = y_tile + ry;
-  if (y >= d.out_h) break;
-  float sx, sy;
-  {
-    const float2 s0 = chain[ry * kWarpChainPitch + lane];
-    sx = s0.x; sy = s0.y;
-  }
-  const int C = d.channels;
-  const int npx = min(kWarpPx, d.out_w - x0);
-  using GIn = const uint8_t __attribute__((address_space(1)));
-  using GOut = uint8_t __attribute__((address_space(1)));
-  GIn *in = (GIn *)d.in;
-  GOut *o = (GOut *)d.out + (size_t)y * d.out_pitch + (size_t)x0 * C;
+  const uintptr_t buf_lo = reinterpret_cast<uintptr_t>(d.in), buf_hi = buf_lo + (size_t)d.in_h * d.in_pitch;
   const bool fast3 = C == 3 && ((reinterpret_cast<uintptr_t>(d.in) | (uintptr_t)d.in_pitch) & 3) == 0;
   const float f0 = (float)SatU8(d.fill[0]), f1 = (float)SatU8(d.fill[1]), f2 = (float)SatU8(d.fill[2]),
               f3 = (float)SatU8(d.fill[3]);
+  const int ry = tid / kWarpGroups, g = tid % kWarpGroups;
+  const int y = y_tile + ry;
+  const int rows = min(kWarpTileH, d.out_h - y_tile);
+  for (int st = 0; st < kWarpTilesPerWg; st++) {
+  const int x_tile = x_seg + st * kWarpTileW;
+  if (x_tile >= d.out_w) break;   // (uniform)
+  __syncthreads();   // the chains are complete (first tile) / the previous tile's samplers are done with `stage`
+  if (tid == 0) {
+    // the tile's footprint is a parallelogram: its bounding box from the four corner pixels (+ 1 pixel: the chains carry
+    // rounding errors far below that; a tap outside the box is fetched from memory anyway)
+    const int cols = min(kWarpTileW, d.out_w - x_tile);
+    float lo_x = 3e38f, hi_x = -3e38f, lo_y = 3e38f, hi_y = -3e38f;
+    for (int corner = 0; corner < 4; corner++) {
+      const int r = (corner & 1) ? rows - 1 : 0, c = (corner & 2) ? cols - 1 : 0;
+      float2 v = chain[r][(st * kWarpTileW + c) / kWarpPx];
+      for (int q = 0; q < c % kWarpPx; q++) { v.x += m0; v.y += m3; }
+      lo_x = fminf(lo_x, v.x); hi_x = fmaxf(hi_x, v.x);
+      lo_y = fminf(lo_y, v.y); hi_y = fmaxf(hi_y, v.y);
+    }
+    const bool bad = !(lo_x == lo_x) || !(hi_x == hi_x) || !(lo_y == lo_y) || !(hi_y == hi_y);
+    // taps of a pixel at (sx, sy): columns floor(sx - 0.5) .. + 1 (linear) or floor(sx) (nearest); rows alike
+    auto lo_of = [](float v) { return (int)floorf(fminf(fmaxf(v - 0.5f, -1e9f), 1e9f)) - 1; };
+    auto hi_of = [](float v) { return (int)floorf(fminf(fmaxf(v - 0.5f, -1e9f), 1e9f)) + 2; };
+    int x_lo = max(lo_of(lo_x), 0), x_hi = min(hi_of(hi_x), d.in_w - 1);
+    int y_lo = max(lo_of(lo_y), 0), y_hi = min(hi_of(hi_y), d.in_h - 1);
+    const long long NBl = (long long)(x_hi - x_lo + 1) * 3, LPl = (NBl + 15 + 12 + 15) & ~15ll;
+    if (bad || C != 3 || x_lo > x_hi || y_lo > y_hi || LPl * (y_hi - y_lo + 1) > kWarpStageBytes) { x_lo = 1; x_hi = 0; }
+    box[0] = x_lo; box[1] = x_hi; box[2] = y_lo; box[3] = y_hi;
+  }
+  __syncthreads();
+  const int x_lo = box[0], x_hi = box[1], y_lo = box[2], y_hi = box[3];
+  const bool staged = x_lo <= x_hi;
+  const int NB = (x_hi - x_lo + 1) * 3, LP = (NB + 15 + 12 + 15) & ~15;
+  const uintptr_t win = reinterpret_cast<uintptr_t>(d.in) + (size_t)y_lo * d.in_pitch + (size_t)x_lo * 3;
+  // ---- 2. the source footprint into LDS ----
+  if (staged) {
+    const int nrows = y_hi - y_lo + 1;
+    for (int row = tid >> 4; row < nrows; row += kWarpThreads / 16) {
+      const uintptr_t ra = win + (size_t)row * d.in_pitch;
+      const int sh = (int)(ra & 15), nch = (sh + NB + 15) >> 4;
+      for (int q = tid & 15; q < nch; q += 16)
+        *reinterpret_cast<uint4 *>(stage + row * LP + 16 * q) = WarpLoadChunk(ra - sh + 16 * q, buf_lo, buf_hi);
+    }
+    __syncthreads();
+  }
+  // ---- 3. sampling ----
+  const int x0 = x_tile + g * kWarpPx;
+  if (y >= d.out_h || x0 >= d.out_w) continue;
+  float sx, sy;
+  {
+    const float2 s0 = chain[ry][st * kWarpGroups + g];
+    sx = s0.x; sy = s0.y;
+  }
+  const int npx = min(kWarpPx, d.out_w - x0);
+  GOut *o = (GOut *)d.out + (size_t)y * d.out_pitch + (size_t)x0 * C;
   auto fetch = [&](int x, int yy, int c, float fillc) -> float {
     if ((unsigned)x < (unsigned)d.in_w && (unsigned)yy < (unsigned)d.in_h)
       return (float)in[(size_t)yy * d.in_pitch + x * C + c];
@@ -94,6 +158,16 @@ __global__ __launch_bounds__(kWarpThreads) void WarpAffineKernel(const daliamdWa
     x = ClampInt(x, 0, d.in_w - 1);
     yy = ClampInt(yy, 0, d.in_h - 1);
     return (float)in[(size_t)yy * d.in_pitch + x * C + c];
+  };
+  // bytes [off, off + 6) of the staged footprint as two dwords (the first holds bytes 0..3): three aligned LDS reads
+  const uint32_t sh0 = (uint32_t)(win & 15), pmod = (uint32_t)d.in_pitch & 15u;
+  auto staged6 = [&](int ix, int iy, uint32_t *a0, uint32_t *a1) {
+    const int r = iy - y_lo;
+    const uint32_t off = (uint32_t)(r * LP) + ((sh0 + (uint32_t)r * pmod) & 15u) + (uint32_t)(ix - x_lo) * 3u;
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(stage + (off & ~3u));
+    const uint32_t w0 = q[0], w1 = q[1], w2 = q[2], h = off & 3u;
+    *a0 = __builtin_amdgcn_alignbyte(w1, w0, h);
+    *a1 = __builtin_amdgcn_alignbyte(w2, w1, h);
   };
   // the kWarpPx pixels of a thread leave as dwords when they are 3-channel and the row is dword-aligned
   const bool packed = C == 3 && npx == kWarpPx && ((uintptr_t)o & 3) == 0;
@@ -104,23 +178,36 @@ __global__ __launch_bounds__(kWarpThreads) void WarpAffineKernel(const daliamdWa
     uint32_t px[4] = {0, 0, 0, 0};
     if (d.interp == DALIAMD_INTERP_NN) {
       int ix = (int)floorf(sx), iy = (int)floorf(sy);
-      for (int c = 0; c < C; c++) {
-        float fc = c == 0 ? f0 : c == 1 ? f1 : c == 2 ? f2 : f3;
-        px[c] = (uint32_t)fetch(ix, iy, c, fc);
+      if (staged && ix >= x_lo && ix <= x_hi && iy >= y_lo && iy <= y_hi) {
+        uint32_t a0, a1;
+        staged6(ix, iy, &a0, &a1);
+        px[0] = a0 & 255; px[1] = (a0 >> 8) & 255; px[2] = (a0 >> 16) & 255;
+      } else {
+        for (int c = 0; c < C; c++) {
+          float fc = c == 0 ? f0 : c == 1 ? f1 : c == 2 ? f2 : f3;
+          px[c] = (uint32_t)fetch(ix, iy, c, fc);
+        }
       }
     } else {
       float fx = sx - 0.5f, fy = sy - 0.5f;
       int ix = (int)floorf(fx), iy = (int)floorf(fy);
       float qx = fx - ix, pxw = 1 - qx, qy = fy - iy;
-      if (fast3 && ix >= 0 && iy >= 0 && ix + 4 < d.in_w && iy + 1 < d.in_h) {
-        // interior, 3 channels: the 2 x 2 x 3 bytes as one 12-byte load per row (dword aligned) + byte alignment
-        typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
-        using GlobalTriple = const u32x3 __attribute__((address_space(1)));
-        const size_t b0 = (size_t)iy * d.in_pitch + (size_t)ix * 3, b1 = b0 + d.in_pitch;
-        const u32x3 r0 = *(GlobalTriple *)(in + (b0 & ~(size_t)3)), r1 = *(GlobalTriple *)(in + (b1 & ~(size_t)3));
-        const uint32_t h0 = (uint32_t)(b0 & 3), h1 = (uint32_t)(b1 & 3);
-        const uint32_t a0 = __builtin_amdgcn_alignbyte(r0.y, r0.x, h0), a1 = __builtin_amdgcn_alignbyte(r0.z, r0.y, h0);
-        const uint32_t c0 = __builtin_amdgcn_alignbyte(r1.y, r1.x, h1), c1 = __builtin_amdgcn_alignbyte(r1.z, r1.y, h1);
+      const bool in_stage = staged && ix >= x_lo && ix + 1 <= x_hi && iy >= y_lo && iy + 1 <= y_hi;
+      if (in_stage || (fast3 && ix >= 0 && iy >= 0 && ix + 4 < d.in_w && iy + 1 < d.in_h)) {
+        uint32_t a0, a1, c0, c1;
+        if (in_stage) {
+          staged6(ix, iy, &a0, &a1);
+          staged6(ix, iy + 1, &c0, &c1);
+        } else {
+          // interior, 3 channels, not staged: the 2 x 2 x 3 bytes as one 12-byte load per row (dword aligned) + byte alignment
+          typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+          using GlobalTriple = const u32x3 __attribute__((address_space(1)));
+          const size_t b0 = (size_t)iy * d.in_pitch + (size_t)ix * 3, b1 = b0 + d.in_pitch;
+          const u32x3 r0 = *(GlobalTriple *)(in + (b0 & ~(size_t)3)), r1 = *(GlobalTriple *)(in + (b1 & ~(size_t)3));
+          const uint32_t h0 = (uint32_t)(b0 & 3), h1 = (uint32_t)(b1 & 3);
+          a0 = __builtin_amdgcn_alignbyte(r0.y, r0.x, h0); a1 = __builtin_amdgcn_alignbyte(r0.z, r0.y, h0);
+          c0 = __builtin_amdgcn_alignbyte(r1.y, r1.x, h1); c1 = __builtin_amdgcn_alignbyte(r1.z, r1.y, h1);
+        }
         // bytes: a0 = {s00.0, s00.1, s00.2, s01.0}, a1 = {s01.1, s01.2, ..}; same for the lower row
         const float t00[3] = {(float)(a0 & 255), (float)((a0 >> 8) & 255), (float)((a0 >> 16) & 255)};
         const float t01[3] = {(float)(a0 >> 24), (float)(a1 & 255), (float)((a1 >> 8) & 255)};
@@ -157,7 +244,7 @@ __global__ __launch_bounds__(kWarpThreads) void WarpAffineKernel(const daliamdWa
     w.z = ob[8] | (ob[9] << 8) | (ob[10] << 16) | (ob[11] << 24);
     *(u32x3 __attribute__((address_space(1))) *)o = w;
   }
-  }   // rows of the tile
+  }   // tiles of the segment
 }
 
 // =============================================================================================
@@ -604,7 +691,7 @@ daliamdResult_t daliamdWarpAffineSetup(daliamdWarpAffineDesc *descs, int n, int 
     DALIAMD_REQUIRE(d.interp == DALIAMD_INTERP_NN || d.interp == DALIAMD_INTERP_LINEAR, DALIAMD_ERROR_UNSUPPORTED,
                     "daliamdWarpAffineSetup: only nearest and linear interpolation are supported");
     d.wg_start = wg;
-    wg += ((d.out_w + kWarpTileW - 1) / kWarpTileW) * ((d.out_h + kWarpRows - 1) / kWarpRows);
+    wg += ((d.out_w + kWarpSegW - 1) / kWarpSegW) * ((d.out_h + kWarpTileH - 1) / kWarpTileH);
   }
   *num_workgroups = wg;
   return DALIAMD_SUCCESS;
