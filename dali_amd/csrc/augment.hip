@@ -61,7 +61,7 @@ __device__ __forceinline__ uint4 WarpLoadChunk(uintptr_t g, uintptr_t lo, uintpt
 __global__ __launch_bounds__(kWarpThreads) void WarpAffineKernel(const daliamdWarpAffineDesc *__restrict__ descs,
                                                                  int ndesc, int total_wg) {
   __shared__ float2 chain[kWarpTileH][kWarpSegGroups + 1];
-  __shared__ int box[4];                    // x_lo, x_hi, y_lo, y_hi of the staged footprint (x_lo > x_hi: nothing staged)
+  __shared__ int boxes[kWarpTilesPerWg][4];  // per tile: x_lo, x_hi, y_lo, y_hi of the staged footprint (x_lo > x_hi: nothing staged)
   __shared__ __attribute__((aligned(16))) uint8_t stage[kWarpStageBytes];
   int wg = XcdRemap(blockIdx.x, total_wg);
   if (wg < 0) return;
@@ -99,18 +99,16 @@ __global__ __launch_bounds__(kWarpThreads) void WarpAffineKernel(const daliamdWa
   const int ry = tid / kWarpGroups, g = tid % kWarpGroups;
   const int y = y_tile + ry;
   const int rows = min(kWarpTileH, d.out_h - y_tile);
-  for (int st = 0; st < kWarpTilesPerWg; st++) {
-  const int x_tile = x_seg + st * kWarpTileW;
-  if (x_tile >= d.out_w) break;   // (uniform)
-  __syncthreads();   // the chains are complete (first tile) / the previous tile's samplers are done with `stage`
-  if (tid == 0) {
-    // the tile's footprint is a parallelogram: its bounding box from the four corner pixels (+ 1 pixel: the chains carry
-    // rounding errors far below that; a tap outside the box is fetched from memory anyway)
+  __syncthreads();   // the chains are complete
+  if (tid < kWarpTilesPerWg && x_seg + tid * kWarpTileW < d.out_w) {
+    // a tile's footprint is a parallelogram: its bounding box from the four corner pixels (+ 1 pixel: the chains carry
+    // rounding errors far below that; a tap outside the box is fetched from memory anyway).  One thread per tile.
+    const int x_tile = x_seg + tid * kWarpTileW;
     const int cols = min(kWarpTileW, d.out_w - x_tile);
     float lo_x = 3e38f, hi_x = -3e38f, lo_y = 3e38f, hi_y = -3e38f;
     for (int corner = 0; corner < 4; corner++) {
       const int r = (corner & 1) ? rows - 1 : 0, c = (corner & 2) ? cols - 1 : 0;
-      float2 v = chain[r][(st * kWarpTileW + c) / kWarpPx];
+      float2 v = chain[r][(tid * kWarpTileW + c) / kWarpPx];
       for (int q = 0; q < c % kWarpPx; q++) { v.x += m0; v.y += m3; }
       lo_x = fminf(lo_x, v.x); hi_x = fmaxf(hi_x, v.x);
       lo_y = fminf(lo_y, v.y); hi_y = fmaxf(hi_y, v.y);
@@ -123,24 +121,49 @@ __global__ __launch_bounds__(kWarpThreads) void WarpAffineKernel(const daliamdWa
     int y_lo = max(lo_of(lo_y), 0), y_hi = min(hi_of(hi_y), d.in_h - 1);
     const long long NBl = (long long)(x_hi - x_lo + 1) * 3, LPl = (NBl + 15 + 12 + 15) & ~15ll;
     if (bad || C != 3 || x_lo > x_hi || y_lo > y_hi || LPl * (y_hi - y_lo + 1) > kWarpStageBytes) { x_lo = 1; x_hi = 0; }
-    box[0] = x_lo; box[1] = x_hi; box[2] = y_lo; box[3] = y_hi;
+    boxes[tid][0] = x_lo; boxes[tid][1] = x_hi; boxes[tid][2] = y_lo; boxes[tid][3] = y_hi;
   }
   __syncthreads();
-  const int x_lo = box[0], x_hi = box[1], y_lo = box[2], y_hi = box[3];
+  // The footprint of the NEXT tile is requested (into registers) before this tile is sampled: its load latency hides
+  // behind the sampling instead of standing between two barriers.  Chunk i of a footprint = 16 bytes at row i / CH,
+  // position i % CH of the row's LP = 16 CH bytes (rows keep their alignment shift).
+  constexpr int kWarpPf = kWarpStageBytes / 16 / kWarpThreads + 1;
+  uint4 pf[kWarpPf];
+  auto fetch_tile = [&](int tile) {
+    const int x_lo = boxes[tile][0], x_hi = boxes[tile][1], y_lo = boxes[tile][2], y_hi = boxes[tile][3];
+    if (x_lo > x_hi) return;
+    const int NB = (x_hi - x_lo + 1) * 3, CH = ((NB + 15 + 12 + 15) & ~15) >> 4, total = CH * (y_hi - y_lo + 1);
+    const uintptr_t win = reinterpret_cast<uintptr_t>(d.in) + (size_t)y_lo * d.in_pitch + (size_t)x_lo * 3;
+#pragma unroll
+    for (int j = 0; j < kWarpPf; j++) {
+      const int i = tid + j * kWarpThreads;
+      if (i < total) {
+        const int row = i / CH, q = i - row * CH;
+        const uintptr_t ra = win + (size_t)row * d.in_pitch;
+        pf[j] = WarpLoadChunk(ra - (ra & 15) + 16 * q, buf_lo, buf_hi);
+      }
+    }
+  };
+  fetch_tile(0);
+  for (int st = 0; st < kWarpTilesPerWg; st++) {
+  const int x_tile = x_seg + st * kWarpTileW;
+  if (x_tile >= d.out_w) break;   // (uniform)
+  const int x_lo = boxes[st][0], x_hi = boxes[st][1], y_lo = boxes[st][2], y_hi = boxes[st][3];
   const bool staged = x_lo <= x_hi;
   const int NB = (x_hi - x_lo + 1) * 3, LP = (NB + 15 + 12 + 15) & ~15;
   const uintptr_t win = reinterpret_cast<uintptr_t>(d.in) + (size_t)y_lo * d.in_pitch + (size_t)x_lo * 3;
-  // ---- 2. the source footprint into LDS ----
+  // ---- 2. the source footprint into LDS (requested one tile ago) ----
+  if (st > 0) __syncthreads();   // the previous tile's samplers are done with `stage`
   if (staged) {
-    const int nrows = y_hi - y_lo + 1;
-    for (int row = tid >> 4; row < nrows; row += kWarpThreads / 16) {
-      const uintptr_t ra = win + (size_t)row * d.in_pitch;
-      const int sh = (int)(ra & 15), nch = (sh + NB + 15) >> 4;
-      for (int q = tid & 15; q < nch; q += 16)
-        *reinterpret_cast<uint4 *>(stage + row * LP + 16 * q) = WarpLoadChunk(ra - sh + 16 * q, buf_lo, buf_hi);
+    const int total = (LP >> 4) * (y_hi - y_lo + 1);
+#pragma unroll
+    for (int j = 0; j < kWarpPf; j++) {
+      const int i = tid + j * kWarpThreads;
+      if (i < total) *reinterpret_cast<uint4 *>(stage + 16 * i) = pf[j];
     }
-    __syncthreads();
   }
+  __syncthreads();
+  if (st + 1 < kWarpTilesPerWg && x_tile + kWarpTileW < d.out_w) fetch_tile(st + 1);
   // ---- 3. sampling ----
   const int x0 = x_tile + g * kWarpPx;
   if (y >= d.out_h || x0 >= d.out_w) continue;
