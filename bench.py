@@ -746,8 +746,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end dali_amd.Pipeline legs")
     ap.add_argument("--e2e-batch", type=int, default=512, help="batch per GPU of the sharded end-to-end leg (configs[4])")
-    ap.add_argument("--inflight", type=int, default=4,
-                    help="batches in flight on the GPU, each on its own HIP stream = the executor's prefetch_queue_depth")
+    ap.add_argument("--inflight", type=int, default=5,
+                    help="batches in flight on the GPU = the executor's prefetch_queue_depth (iterations rotate over its three compute streams)")
     ap.add_argument("--huffman", default="gpu", choices=["gpu", "host"],
                     help="gpu: the step starts from JPEG bytes in HBM (default); host: from host-decoded coefficient blocks")
     ap.add_argument("--no-fused-idct", action="store_true",

@@ -171,7 +171,7 @@ _host = None
 _KERNEL_SYMBOLS = [
     "daliamdGetLastErrorMessage", "daliamdClearLastError", "daliamdVersion", "daliamdDeviceCount",
     "daliamdSetDevice", "daliamdDeviceInfo", "daliamdDevicePciBusId", "daliamdRangePush", "daliamdRangePop", "daliamdKernelTimingEnable", "daliamdKernelTimingReport",
-    "daliamdStreamCreate", "daliamdStreamDestroy",
+    "daliamdStreamCreate", "daliamdStreamCreateWithPriority", "daliamdStreamDestroy",
     "daliamdStreamSynchronize", "daliamdStreamWaitEvent", "daliamdEventCreate",
     "daliamdEventDestroy", "daliamdEventRecord", "daliamdEventSynchronize", "daliamdEventQuery", "daliamdEventElapsedMs",
     "daliamdMalloc", "daliamdFree", "daliamdHostAlloc", "daliamdHostFree", "daliamdMemcpyH2DAsync",

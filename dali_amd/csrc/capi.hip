@@ -185,6 +185,16 @@ daliamdResult_t daliamdStreamCreate(daliamdStream_t *stream, int non_blocking) {
   *stream = s;
   return DALIAMD_SUCCESS;
 }
+daliamdResult_t daliamdStreamCreateWithPriority(daliamdStream_t *stream, int non_blocking, int priority) {
+  DALIAMD_REQUIRE(stream, DALIAMD_ERROR_INVALID_ARGUMENT, "stream is NULL");
+  int least = 0, greatest = 0;   // numerically: greatest priority = the lowest number
+  DALIAMD_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  const int p = priority < 0 ? greatest : priority > 0 ? least : (least + greatest) / 2;
+  hipStream_t s;
+  DALIAMD_HIP_CHECK(hipStreamCreateWithPriority(&s, non_blocking ? hipStreamNonBlocking : hipStreamDefault, p));
+  *stream = s;
+  return DALIAMD_SUCCESS;
+}
 daliamdResult_t daliamdStreamDestroy(daliamdStream_t stream) {
   DALIAMD_HIP_CHECK(hipStreamDestroy((hipStream_t)stream));
   return DALIAMD_SUCCESS;

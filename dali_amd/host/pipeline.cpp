@@ -48,7 +48,8 @@ Pipeline::~Pipeline() {
   nodes_.clear();
   for (auto e : slot_events_) if (e) daliamdEventDestroy(e);
   if (copy_stream_) daliamdStreamDestroy(copy_stream_);
-  for (auto st : streams_) daliamdStreamDestroy(st);
+  for (size_t i = 0; i < streams_.size(); i++)
+    if (std::find(streams_.begin(), streams_.begin() + i, streams_[i]) == streams_.begin() + i) daliamdStreamDestroy(streams_[i]);
 }
 
 static std::string TensorKey(const std::string &name, StorageDevice d) {
@@ -123,8 +124,27 @@ void Pipeline::Build(const std::vector<std::pair<std::string, std::string>> &out
                  "is available. There is no CPU fallback for device operators.");
     KCHECK(daliamdSetDevice(params_.device_id));
     streams_.assign(ring_, nullptr);
-    for (auto &st : streams_) KCHECK(daliamdStreamCreate(&st, 1));
-    KCHECK(daliamdStreamCreate(&copy_stream_, 1));
+    // Compute streams: iteration i runs on stream (i mod ring) mod kComputeStreams.  More batches than that in
+    // flight do not help - two position passes of the entropy decoder side by side each take twice as long - but
+    // which streams end up SHARING an in-order hardware queue does: the runtime spreads the streams of one priority
+    // over four hardware queues in creation order, so with one stream per ring slot the throughput depended on the
+    // ring size and on every other stream of the process (prefetch_queue_depth 4 / 5 / 6: 370 / 450 / 413 k images/s
+    // on the resident hot path; one unrelated stream created first: 386 / 390 / 400).  Three streams - the batch
+    // whose positions are being decoded, the one in its throughput-bound kernels, the one finishing - map to three
+    // hardware queues whatever the depth: 431 / 437 k at depth 4 / 5 (gpurun_out/r03a[d-g]_env).
+    // DALI_AMD_PIPELINE_STREAMS overrides the count (0 = one per ring slot).
+    int distinct = std::min(ring_, kComputeStreams);
+    if (const char *e = getenv("DALI_AMD_PIPELINE_STREAMS")) {
+      const int v = atoi(e);
+      distinct = v <= 0 ? ring_ : std::min(ring_, v);
+    }
+    for (int i = 0; i < ring_; i++) {
+      if (i < distinct) KCHECK(daliamdStreamCreate(&streams_[i], 1));
+      else streams_[i] = streams_[i % distinct];
+    }
+    // The copy stream carries the descriptor tables (and the JPEG bytes) of the NEXT iteration: highest priority = a
+    // hardware queue it does not share with any compute stream, or the upload waits behind a 0.3 ms kernel
+    KCHECK(daliamdStreamCreateWithPriority(&copy_stream_, 1, -1));
   }
   for (auto &o : outputs) {
     StorageDevice d = o.second == "gpu" ? StorageDevice::GPU : StorageDevice::CPU;

@@ -121,10 +121,12 @@ class Pipeline {
   bool have_gpu_ = false;
   std::unique_ptr<ThreadPool> thread_pool_;      // device-stage operators (e.g. the decoder's header parsing)
   std::unique_ptr<ThreadPool> cpu_thread_pool_;  // host-stage operators (e.g. the reader's file reads)
-  // one compute stream per ring slot: consecutive iterations use different streams, so the latency-bound tail of one
-  // batch's kernels (the entropy decoder's relaxation rounds) overlaps the start of the next batch's
+  // the compute stream of every ring slot (kComputeStreams distinct ones, see Build()): consecutive iterations use
+  // different streams, so the latency-bound tail of one batch's kernels (the entropy decoder's relaxation rounds)
+  // overlaps the start of the next batch's
+  static constexpr int kComputeStreams = 3;
   std::vector<daliamdStream_t> streams_;
-  daliamdStream_t copy_stream_ = nullptr;  // bulk H2D staging, overlaps the compute streams
+  daliamdStream_t copy_stream_ = nullptr;  // bulk H2D staging (highest stream priority), overlaps the compute streams
   int ring_ = 3;
 
   // scheduling

@@ -70,6 +70,10 @@ DALIAMD_API int daliamdKernelTimingReport(char *buf, int len);
 DALIAMD_API void daliamdRangePush(const char *name);
 DALIAMD_API void daliamdRangePop(void);
 DALIAMD_API daliamdResult_t daliamdStreamCreate(daliamdStream_t *stream, int non_blocking);
+/* priority < 0: the device's highest stream priority, 0: the default, > 0: the lowest.  The ROCm runtime keeps one set
+ * of hardware queues PER PRIORITY: a stream of another priority never shares an in-order hardware queue with the
+ * default-priority streams of the process (torch's, the null stream). */
+DALIAMD_API daliamdResult_t daliamdStreamCreateWithPriority(daliamdStream_t *stream, int non_blocking, int priority);
 DALIAMD_API daliamdResult_t daliamdStreamDestroy(daliamdStream_t stream);
 DALIAMD_API daliamdResult_t daliamdStreamSynchronize(daliamdStream_t stream);
 DALIAMD_API daliamdResult_t daliamdStreamWaitEvent(daliamdStream_t stream, daliamdEvent_t event);
