@@ -410,8 +410,15 @@ def run_resident_pipeline(args, root, enc_all, device, dev_index, rank, world, l
     pipe.operator_host_times()                        # opens the host-time window
     kernel_timing(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        pipe.run()
+    if os.environ.get("BENCH_STEP_TIMES") == "1":     # debugging: when each step of the timed region returned
+        stamps = []
+        for _ in range(args.steps):
+            pipe.run()
+            stamps.append(time.perf_counter() - t0)
+        print("step return times (ms):", " ".join(f"{1e3 * x:.2f}" for x in stamps), file=sys.stderr)
+    else:
+        for _ in range(args.steps):
+            pipe.run()
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_timing(False)

@@ -20,9 +20,9 @@ for W in ${WORKLOADS:-headline heavy_aug audio}; do
   else
     ARGS="--workload $W --steps 20 --warmup 3"; PMCARGS="--workload $W --steps 5 --warmup 1"; SUF="_$W"
   fi
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
+  timeout ${PROF_TIMEOUT:-300} rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
   for C in FETCH_SIZE WRITE_SIZE; do
-    timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -- python $R/bench.py $PMCARGS > /dev/null 2> $OUT/pmc_$C.log
+    timeout ${PROF_TIMEOUT:-300} rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -- python $R/bench.py $PMCARGS > /dev/null 2> $OUT/pmc_$C.log
   done
   python $R/tools/summarize_profiles.py $OUT $TAG$SUF $SUM || { echo "collect_profiles: $W summary FAILED"; tail -5 $OUT/*.log; FAILED=1; }
   if [ $W != headline ]; then

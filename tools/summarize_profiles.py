@@ -54,7 +54,7 @@ for k, d in res.items():
 missing = [k for k, d in res.items() if "avg_ns" in d and d.get("pct", 0) >= 1.0 and "hbm_bytes_per_launch" not in d]
 if missing:
     sys.exit(f"summarize_profiles: no FETCH_SIZE + WRITE_SIZE pair for {missing}")
-regime = ("kernel_stats: the bench command as the driver runs it (two batches in flight: durations include the overlap "
+regime = ("kernel_stats: the bench command as the driver runs it (several batches in flight, see --inflight: durations include the overlap "
           "with the other stream's kernels); FETCH_SIZE / WRITE_SIZE: separate passes with ONE batch in flight, so that a "
           "counter window holds exactly one kernel - bytes per launch do not depend on the overlap, durations do")
 json.dump({"note": __doc__, "regime": regime, "kernels": res}, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
