@@ -23,8 +23,14 @@
 
 namespace daliamd {
 
-constexpr int kFastBits = 11;    // first-level window of every code table
-constexpr int kL2Entries = 512;  // direct second-level table for the codes longer than kFastBits
+#ifndef DALIAMD_FAST_BITS
+#define DALIAMD_FAST_BITS 11
+#endif
+#ifndef DALIAMD_L2_ENTRIES
+#define DALIAMD_L2_ENTRIES 512
+#endif
+constexpr int kFastBits = DALIAMD_FAST_BITS;    // first-level window of every code table
+constexpr int kL2Entries = DALIAMD_L2_ENTRIES;  // direct second-level table for the codes longer than kFastBits
 constexpr int kSyncGroup = 3;    // symbols one look-up of the position-only pass may step over
 
 // Table entry: bits 0-6 zig-zag advance (1..64), 7-11 bits consumed (code length + magnitude bits s), 12-15 s.

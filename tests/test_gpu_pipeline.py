@@ -35,10 +35,10 @@ def jpeg_dir(tmp_path_factory):
     return str(root), files
 
 
-def _train_pipe(root, bs, fused=True, **reader_kw):
+def _train_pipe(root, bs, fused=True, depth=2, **reader_kw):
     from dali_amd import fn, types
     from dali_amd.pipeline import Pipeline
-    pipe = Pipeline(batch_size=bs, num_threads=4, device_id=0, seed=3, prefetch_queue_depth=2)
+    pipe = Pipeline(batch_size=bs, num_threads=4, device_id=0, seed=3, prefetch_queue_depth=depth)
     with pipe:
         jpegs, labels = fn.readers.file(file_root=root, name="Reader", **reader_kw)
         images = fn.decoders.image(jpegs, device="mixed", output_type=types.RGB)
@@ -90,6 +90,24 @@ def test_train_pipeline_matches_oracle(jpeg_dir, fused):
         # (the stand-alone IDCT kernel only runs for streams the host entropy decoder took: the GPU decoder's block
         # output is already dequantised and inverse-transformed)
         assert "jpeg_huffman" in kernels and "jpeg_color" in kernels
+
+
+@pytest.mark.parametrize("depth,streams", [(5, None), (7, None), (5, "0"), (4, "2")])
+def test_deep_prefetch_shares_compute_streams_and_stays_exact(jpeg_dir, depth, streams, monkeypatch):
+    # more iterations in flight than the executor's three compute streams (pipeline.cpp: slot s on stream s mod 3;
+    # DALI_AMD_PIPELINE_STREAMS=0: one per slot): every iteration of two epochs still matches the oracle bit for bit
+    root, files = jpeg_dir
+    if streams is not None:
+        monkeypatch.setenv("DALI_AMD_PIPELINE_STREAMS", streams)
+    bs = 8
+    pipe = _train_pipe(root, bs, depth=depth)
+    for it in range(2 * len(files) // bs + depth):
+        outs = pipe.run()
+        data = outs[0].as_tensor().cpu().numpy()
+        picks = [(it * bs + i) % len(files) for i in range(bs)]
+        assert list(outs[1].as_array().reshape(-1)) == [files[k][1] for k in picks]
+        _, ref_f16 = _oracle_batch(files, picks, it, bs)
+        assert np.array_equal(data.view(np.uint16), ref_f16.view(np.uint16)), f"iteration {it}"
 
 
 def test_decoder_output_and_exif_orientation(tmp_path):
