@@ -273,7 +273,10 @@ __global__ __launch_bounds__(kWarpThreads) void WarpAffineKernel(const daliamdWa
 // =============================================================================================
 // gaussian blur: LDS-tiled separable convolution, both passes in one kernel
 // =============================================================================================
-constexpr int kBlurThreads = 256;
+#ifndef DALIAMD_BLUR_THREADS
+#define DALIAMD_BLUR_THREADS 256
+#endif
+constexpr int kBlurThreads = DALIAMD_BLUR_THREADS;
 constexpr int kBlurMaxLds = 60 * 1024;
 constexpr int kBlurPx = 8;    // W pass: pixels per thread (and channel, and row of the pair)
 constexpr int kBlurRows = 8;  // H pass: output rows per thread
