@@ -317,14 +317,20 @@ __device__ __forceinline__ void BlurWPass(const daliamdGaussianBlurDesc &d, cons
   const int items = row_pairs * groups * C;
   const float *__restrict__ gw = d.window_x;
   const int K = d.size_x;
+  // alignment lead of a staged row (the staging loop's): the same for every row when the pitch is a multiple of 4
+  const bool same_lead = (d.in_pitch & 3) == 0;
+  const int lead0 = interior_x ? (int)((reinterpret_cast<uintptr_t>(d.in) + (size_t)(ox0 - rx) * C) & 3) : 0;
   for (int item = tid; item < items; item += kBlurThreads) {
     const int rp = item / (groups * C), rem_i = item - rp * (groups * C);
     const int g = rem_i / C, c = rem_i - g * C;
     const int x = g * P;
     const int ra = 2 * rp, rb = min(2 * rp + 1, in_rows - 1);
     auto row_ptr = [&](int r) {
-      const uint8_t *rowp = d.in + (size_t)Reflect101(oy0 - ry + r, d.h) * d.in_pitch + (size_t)(ox0 - rx) * C;
-      const int lead = interior_x ? (int)(reinterpret_cast<uintptr_t>(rowp) & 3) : 0;
+      int lead = lead0;
+      if (interior_x && !same_lead) {
+        const uint8_t *rowp = d.in + (size_t)Reflect101(oy0 - ry + r, d.h) * d.in_pitch + (size_t)(ox0 - rx) * C;
+        lead = (int)(reinterpret_cast<uintptr_t>(rowp) & 3);
+      }
       return src + r * src_pitch + lead + x * C + c;
     };
     const uint8_t *pa = row_ptr(ra), *pb = row_ptr(rb);
@@ -436,13 +442,21 @@ __device__ __forceinline__ void BlurHPass(const daliamdGaussianBlurDesc &d, cons
         }
     } else {
       using GOut = uint8_t __attribute__((address_space(1)));
+      using GOut16 = uint16_t __attribute__((address_space(1)));
       GOut *o = (GOut *)d.out + (size_t)(oy0 + y) * d.out_pitch + (size_t)ox0 * d.channels + e;
+      // (e is even: the pair leaves as one 16-bit store when every row of the tile starts at an even address)
+      const bool even = ((d.out_pitch | (int)((reinterpret_cast<uintptr_t>(d.out) + (size_t)ox0 * d.channels) & 1)) & 1) == 0;
 #pragma unroll
       for (int j = 0; j < R; j++)
         if (y + j < th) {
           GOut *oj = o + (size_t)j * d.out_pitch;
-          oj[0] = (uint8_t)SatU8(acc[j].x);
-          if (two) oj[1] = (uint8_t)SatU8(acc[j].y);
+          const uint32_t b0 = SatU8(acc[j].x);
+          if (two && even) {
+            *(GOut16 *)oj = (uint16_t)(b0 | (SatU8(acc[j].y) << 8));
+          } else {
+            oj[0] = (uint8_t)b0;
+            if (two) oj[1] = (uint8_t)SatU8(acc[j].y);
+          }
         }
     }
   }
