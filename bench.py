@@ -752,6 +752,9 @@ def main():
                     help="distinct batches the steps rotate through (data set = batches * batch images per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end dali_amd.Pipeline legs")
+    ap.add_argument("--no-side-legs", action="store_true",
+                    help="skip the one-batch-in-flight leg as well (profiling: every launch of the process then belongs to "
+                         "the set-up or the timed region, both at the full depth)")
     ap.add_argument("--e2e-batch", type=int, default=512, help="batch per GPU of the sharded end-to-end leg (configs[4])")
     ap.add_argument("--inflight", type=int, default=5,
                     help="batches in flight on the GPU = the executor's prefetch_queue_depth (iterations rotate over its three compute streams)")
@@ -853,7 +856,7 @@ def main():
                      "launches_timed": launches, "kernels": r["pipe"].executed_kernels()}
         huffman_single_ms = None
         single_stream = None
-        if r["depth"] > 1:
+        if r["depth"] > 1 and not args.no_side_legs:
             # ONE batch in flight: per-kernel durations without another batch's kernels on the same CUs - what a kernel
             # costs, as opposed to how long it lasts inside the overlapped schedule of the timed region above
             pipe1 = resident_pipeline(root, B, dev_index, 1, r["threads"], shard_id=rank, num_shards=world,

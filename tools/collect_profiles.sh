@@ -16,7 +16,7 @@ for W in ${WORKLOADS:-headline heavy_aug audio}; do
   OUT=$R/gpurun_out/prof_$TAG/$W
   mkdir -p $OUT
   if [ $W = headline ]; then
-    ARGS="--steps 20 --warmup 3 --no-cpu-baseline --no-e2e"; PMCARGS="--steps 5 --warmup 1 --no-cpu-baseline --no-e2e --inflight 1"; SUF=""
+    ARGS="--steps 40 --warmup 3 --no-cpu-baseline --no-e2e --no-side-legs"; PMCARGS="--steps 5 --warmup 1 --no-cpu-baseline --no-e2e --inflight 1"; SUF=""
   else
     ARGS="--workload $W --steps 20 --warmup 3"; PMCARGS="--workload $W --steps 5 --warmup 1"; SUF="_$W"
   fi
