@@ -170,9 +170,23 @@ bool ReadSubframe(BitReader &br, int blocksize, int bps, int64_t *out) {
 
 struct StreamInfo { int channels = 0, bps = 0; double rate = 0; int64_t total = 0; size_t first_frame = 0; int max_block = 0; };
 
+// A leading ID3v2 tag (libFLAC / libsndfile skip it): "ID3", version (2 bytes), flags, size as four 7-bit bytes;
+// flag 0x10 = a 10-byte footer behind the tag.
+size_t SkipId3v2(const uint8_t *p, size_t n) {
+  size_t pos = 0;
+  while (n - pos >= 10 && !memcmp(p + pos, "ID3", 3) && !((p[pos + 6] | p[pos + 7] | p[pos + 8] | p[pos + 9]) & 0x80)) {
+    const size_t len = ((size_t)p[pos + 6] << 21) | ((size_t)p[pos + 7] << 14) | ((size_t)p[pos + 8] << 7) | p[pos + 9];
+    const size_t total = 10 + len + ((p[pos + 5] & 0x10) ? 10 : 0);
+    if (total > n - pos) break;
+    pos += total;
+  }
+  return pos;
+}
+
 int ParseHeader(const uint8_t *p, size_t n, StreamInfo *si) {
-  if (n < 4 + 4 + 34 || memcmp(p, "fLaC", 4)) return Fail("not a FLAC stream");
-  size_t pos = 4;
+  const size_t lead = SkipId3v2(p, n);
+  if (n - lead < 4 + 4 + 34 || memcmp(p + lead, "fLaC", 4)) return Fail("not a FLAC stream");
+  size_t pos = lead + 4;
   bool last = false, have_info = false;
   while (!last) {
     if (pos + 4 > n) return Fail("FLAC: truncated metadata");
@@ -197,6 +211,12 @@ int ParseHeader(const uint8_t *p, size_t n, StreamInfo *si) {
   }
   if (!have_info || si->rate <= 0) return Fail("FLAC: no STREAMINFO block");
   si->first_frame = pos;
+  // The 36-bit sample count comes from the file: a frame is at least 10 bytes (header 5 + CRC-8, a constant subframe
+  // of two bytes, CRC-16) and carries at most 65 536 samples, so `n` bytes cannot hold more than this - a crafted
+  // header must not make the caller allocate terabytes.
+  const int64_t most = (int64_t)((n - pos) / 10 + 1) * 65536;
+  if (si->total > most) return Fail("FLAC: STREAMINFO promises %lld samples per channel, the file's %zu bytes cannot hold them",
+                                    (long long)si->total, n);
   return 0;
 }
 
@@ -206,7 +226,8 @@ int DecodeFrame(const uint8_t *p, size_t n, size_t *pos, const StreamInfo &si, s
                 int64_t written, int64_t capacity) {
   if (*pos + 2 > n) return 0;
   BitReader br{p + *pos, n - *pos};
-  if (br.Bits(14) != 0x3ffe) return -1;
+  // no sync code behind the first frame: trailing data (an ID3v1 tag, padding) - the stream ends here, as in libFLAC
+  if (br.Bits(14) != 0x3ffe) return *pos > si.first_frame ? 0 : -1;
   if (br.Bits(1) != 0) return -1;
   br.Bits(1);   // blocking strategy: only changes the meaning of the coded number
   const int bs_code = (int)br.Bits(4), sr_code = (int)br.Bits(4), ch_code = (int)br.Bits(4), ss_code = (int)br.Bits(3);

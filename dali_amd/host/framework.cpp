@@ -129,6 +129,8 @@ void TensorList::Resize(const std::vector<TensorShape> &shapes, DALIDataType typ
   buf_->Reserve(std::max<size_t>(off, 256));
   deferred.reset();
   deferred_pointwise.reset();
+  deferred_audio.reset();
+  deferred_blur.reset();
 }
 
 bool TensorList::is_dense() const {
@@ -143,7 +145,8 @@ void TensorList::ShareData(const TensorList &o) {
   buf_ = o.buf_; dev_ = o.dev_; type_ = o.type_; layout_ = o.layout_; shapes_ = o.shapes_;
   offsets_ = o.offsets_; pitch_ = o.pitch_; sizes_ = o.sizes_; total_ = o.total_;
   ext_ = o.ext_; ext_owner_ = o.ext_owner_;
-  deferred = o.deferred; deferred_pointwise = o.deferred_pointwise; source_info = o.source_info;
+  deferred = o.deferred; deferred_pointwise = o.deferred_pointwise; deferred_audio = o.deferred_audio;
+  deferred_blur = o.deferred_blur; source_info = o.source_info;
 }
 
 // ------------------------------------------------------------------------------------------ ThreadPool

@@ -312,7 +312,7 @@ uint8_t *StreamCache::Reserve(const std::string &key, size_t bytes) {
   }
   uint8_t *at = blob_ + tail_;
   tail_ += stored;
-  pending_[key] = at;
+  pending_[key] = {at, stored};
   return at;
 }
 
@@ -333,7 +333,7 @@ void StreamCache::Commit(const std::vector<std::string> &keys, const std::vector
   for (size_t k = 0; k < keys.size(); k++) {
     auto it = pending_.find(keys[k]);
     if (it == pending_.end()) continue;
-    recs[k]->ecs = it->second;
+    recs[k]->ecs = it->second.first;
     entries_[keys[k]] = Slot{recs[k], fence};
     pending_.erase(it);
   }
@@ -343,6 +343,19 @@ void StreamCache::Invalidate(const std::string &key) {
   std::lock_guard<std::mutex> g(m_);
   entries_.erase(key);   // (the space is not reclaimed)
   pending_.erase(key);
+}
+
+void StreamCache::Abandon(const std::vector<std::string> &keys) {
+  std::lock_guard<std::mutex> g(m_);
+  for (auto k = keys.rbegin(); k != keys.rend(); ++k) {   // latest reservation first: the blob is a stack
+    auto it = pending_.find(*k);
+    if (it == pending_.end()) continue;
+    if (it->second.first + it->second.second == blob_ + tail_) {
+      tail_ -= it->second.second;
+      full_ = false;
+    }
+    pending_.erase(it);
+  }
 }
 
 bool DecoderCacheHolds(int device_id, const std::string &key) {

@@ -142,6 +142,9 @@ class StreamCache {
   void Commit(const std::vector<std::string> &keys, const std::vector<const daliamdJpegInfo *> &infos,
               const std::vector<const daliamdJpegScan *> &scans, daliamdStream_t stream);
   void Invalidate(const std::string &key);
+  // Reservations that will never be committed (an exception between Reserve and Commit): the keys become reservable
+  // again and the space of those that still sit at the end of the blob is handed back.
+  void Abandon(const std::vector<std::string> &keys);
   size_t bytes_used() const { return tail_; }
   void Stats(int64_t *out4) const {
     std::lock_guard<std::mutex> g(m_);
@@ -159,7 +162,7 @@ class StreamCache {
   uint8_t *blob_ = nullptr;
   mutable std::mutex m_;
   std::unordered_map<std::string, Slot> entries_;
-  std::unordered_map<std::string, uint8_t *> pending_;
+  std::unordered_map<std::string, std::pair<uint8_t *, size_t>> pending_;   // slot, bytes it occupies in the blob
   int64_t hits_ = 0, misses_ = 0;
 };
 

@@ -544,12 +544,19 @@ class ImageDecoderMixed : public OperatorBase {
     // encoded-stream cache: the segments of this batch that the cache has room for stay resident - one device-to-device
     // copy each, behind the transfer, out of this iteration's buffer (which is reused ring_ iterations from now)
     std::vector<std::pair<int, uint8_t *>> keep;
+    struct ReservedStreams {   // reservations of this run; handed back unless the copies get enqueued and committed
+      StreamCache *cache;
+      std::vector<std::string> keys;
+      ~ReservedStreams() { if (cache && !keys.empty()) cache->Abandon(keys); }
+    } reserved_streams{stream_cache_.get(), {}};
     if (stream_cache_ && ngpu > nehit)
       for (int j = 0; j < ngpu; j++) {
         const int i = gpu_samples_[j];
         if (erec_[i] || i >= (int)in.source_info.size()) continue;
-        if (uint8_t *slot_ptr = stream_cache_->Reserve(in.source_info[i], (size_t)scans_[i].ecs_length))
+        if (uint8_t *slot_ptr = stream_cache_->Reserve(in.source_info[i], (size_t)scans_[i].ecs_length)) {
           keep.push_back({j, slot_ptr});
+          reserved_streams.keys.push_back(in.source_info[i]);
+        }
       }
     if (cs != ws.stream) {
       if (!h2d_done_[slot]) KCHECK(daliamdEventCreate(&h2d_done_[slot], 0));
@@ -568,6 +575,7 @@ class ImageDecoderMixed : public OperatorBase {
         kscans.push_back(&scans_[i]);
       }
       stream_cache_->Commit(keys, kinfos, kscans, ws.stream);
+      reserved_streams.keys.clear();
     }
     if (ngpu) {
       KCHECK(daliamdJpegHuffmanRun(ws.stream, reinterpret_cast<const daliamdJpegHuffDesc *>(dev_base + huff_off), ngpu,

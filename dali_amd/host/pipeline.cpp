@@ -48,8 +48,7 @@ Pipeline::~Pipeline() {
   nodes_.clear();
   for (auto e : slot_events_) if (e) daliamdEventDestroy(e);
   if (copy_stream_) daliamdStreamDestroy(copy_stream_);
-  for (size_t i = 0; i < streams_.size(); i++)
-    if (std::find(streams_.begin(), streams_.begin() + i, streams_[i]) == streams_.begin() + i) daliamdStreamDestroy(streams_[i]);
+  for (auto st : streams_) daliamdStreamDestroy(st);
 }
 
 static std::string TensorKey(const std::string &name, StorageDevice d) {
@@ -123,8 +122,10 @@ void Pipeline::Build(const std::vector<std::pair<std::string, std::string>> &out
     DALI_ENFORCE(have_gpu_, "The pipeline contains device (\"gpu\"/\"mixed\") operators but no MI355X/ROCm device "
                  "is available. There is no CPU fallback for device operators.");
     KCHECK(daliamdSetDevice(params_.device_id));
-    streams_.assign(ring_, nullptr);
-    // Compute streams: iteration i runs on stream (i mod ring) mod kComputeStreams.  More batches than that in
+    // Compute streams: iteration i runs on stream i mod kComputeStreams (chosen by ITERATION, not by ring slot: with a
+    // ring size that is not a multiple of the stream count the last slot and slot 0 would share a stream and two
+    // consecutive iterations would be serialised once per revolution; the host stage waits for the slot's event
+    // before it reuses a slot, so a slot may be written from any stream).  More batches than that in
     // flight do not help - two position passes of the entropy decoder side by side each take twice as long - but
     // which streams end up SHARING an in-order hardware queue does: the runtime spreads the streams of one priority
     // over four hardware queues in creation order, so with one stream per ring slot the throughput depended on the
@@ -138,10 +139,8 @@ void Pipeline::Build(const std::vector<std::pair<std::string, std::string>> &out
       const int v = atoi(e);
       distinct = v <= 0 ? ring_ : std::min(ring_, v);
     }
-    for (int i = 0; i < ring_; i++) {
-      if (i < distinct) KCHECK(daliamdStreamCreate(&streams_[i], 1));
-      else streams_[i] = streams_[i % distinct];
-    }
+    streams_.assign(distinct, nullptr);
+    for (int i = 0; i < distinct; i++) KCHECK(daliamdStreamCreate(&streams_[i], 1));
     // The copy stream carries the descriptor tables (and the JPEG bytes) of the NEXT iteration: highest priority = a
     // hardware queue it does not share with any compute stream, or the upload waits behind a 0.3 ms kernel
     KCHECK(daliamdStreamCreateWithPriority(&copy_stream_, 1, -1));
@@ -274,7 +273,7 @@ void Pipeline::RunStage(bool device_stage, int64_t it, int slot, Iteration &res)
       ws.pipeline = this;
       ws.backend = n.type;
       ws.thread_pool = device_stage ? thread_pool_.get() : cpu_thread_pool_.get();
-      ws.stream = streams_.empty() ? nullptr : streams_[slot];
+      ws.stream = streams_.empty() ? nullptr : streams_[it % (int64_t)streams_.size()];
       ws.copy_stream = copy_stream_;
       ws.ring = ring_;
       ws.batch_size = params_.batch_size;
@@ -330,7 +329,7 @@ void Pipeline::RunStage(bool device_stage, int64_t it, int slot, Iteration &res)
   }
   if (device_stage) {
     // recorded even after a failure: the slot's next user waits for this event
-    if (!streams_.empty()) daliamdEventRecord(slot_events_[slot], streams_[slot]);
+    if (!streams_.empty()) daliamdEventRecord(slot_events_[slot], streams_[it % (int64_t)streams_.size()]);
     {
       std::lock_guard<std::mutex> g(m_);
       device_stages_done_ = it + 1;

@@ -121,9 +121,9 @@ class Pipeline {
   bool have_gpu_ = false;
   std::unique_ptr<ThreadPool> thread_pool_;      // device-stage operators (e.g. the decoder's header parsing)
   std::unique_ptr<ThreadPool> cpu_thread_pool_;  // host-stage operators (e.g. the reader's file reads)
-  // the compute stream of every ring slot (kComputeStreams distinct ones, see Build()): consecutive iterations use
-  // different streams, so the latency-bound tail of one batch's kernels (the entropy decoder's relaxation rounds)
-  // overlaps the start of the next batch's
+  // the compute streams (kComputeStreams distinct ones, see Build()): iteration i runs on stream i mod their count, so
+  // consecutive iterations always use different streams and the latency-bound tail of one batch's kernels (the entropy
+  // decoder's relaxation rounds) overlaps the start of the next batch's
   static constexpr int kComputeStreams = 3;
   std::vector<daliamdStream_t> streams_;
   daliamdStream_t copy_stream_ = nullptr;  // bulk H2D staging (highest stream priority), overlaps the compute streams
