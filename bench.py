@@ -267,6 +267,23 @@ def pillow_baseline(enc, seconds_budget=20.0):
                       f"BILINEAR) + numpy CMN, ThreadPoolExecutor({cores}), {el:.2f} s wall"}
 
 
+def thread_cpu_seconds():
+    """CPU seconds (user + system) every thread of this process has used so far, summed by thread name with the
+    trailing index stripped (the product names its threads: dali-rd<i> = file reader, dali-cpupool<i> / dali-devpool<i> =
+    the two operator thread pools, dali-cpustage / dali-devstage = the executor's stage threads)."""
+    out = {}
+    for tid in os.listdir("/proc/self/task"):
+        try:
+            with open(f"/proc/self/task/{tid}/comm") as f:
+                name = f.read().strip().rstrip("0123456789")
+            with open(f"/proc/self/task/{tid}/schedstat") as f:
+                ns = int(f.read().split()[0])          # time spent on a CPU, nanoseconds
+        except (OSError, ValueError, IndexError):
+            continue
+        out[name] = out.get(name, 0.0) + ns * 1e-9
+    return out
+
+
 def write_dataset(root, enc, first_index=0):
     """Data set directory for readers.file: root/<class 0..9>/img_<global index>.jpg (sorted order = index order
     inside a class; labels = class directory)."""
@@ -278,8 +295,8 @@ def write_dataset(root, enc, first_index=0):
             f.write(e)
 
 
-def e2e_pipeline(root, batch, device_id, iters=200, threads=None, roi_decode=False, cache_mb=0, shard_id=0, num_shards=1,
-                 depth=4, sync=None, set_affinity=False):
+def e2e_pipeline(root, batch, device_id, iters=400, threads=None, roi_decode=False, cache_mb=0, shard_id=0, num_shards=1,
+                 depth=5, sync=None, set_affinity=False, reader_depth=2):
     """The same hot path through the product's DALI-style pipeline (C++ host framework): readers.file (page cache)
     -> decoders.image(mixed: header parse + scan analysis on the host thread pool, H2D of the entropy-coded
     segments, GPU Huffman/IDCT/colour) -> random_resized_crop + crop_mirror_normalize (fused).  PCIe-inclusive and
@@ -294,7 +311,8 @@ def e2e_pipeline(root, batch, device_id, iters=200, threads=None, roi_decode=Fal
     pipe = Pipeline(batch_size=batch, num_threads=threads, device_id=device_id, seed=1234, prefetch_queue_depth=depth,
                     set_affinity=set_affinity)
     with pipe:
-        jpegs, labels = fn.readers.file(file_root=root, name="Reader", shard_id=shard_id, num_shards=num_shards)
+        jpegs, labels = fn.readers.file(file_root=root, name="Reader", shard_id=shard_id, num_shards=num_shards,
+                                        prefetch_queue_depth=reader_depth)
         if roi_decode:   # the variant NVIDIA's own benchmark uses (hw_decoder_bench.py:178-188): ROI decode + resize
             images = fn.decoders.image_random_crop(jpegs, device="mixed", output_type=types.RGB)
             crops = fn.resize(images, size=[224, 224])
@@ -314,14 +332,26 @@ def e2e_pipeline(root, batch, device_id, iters=200, threads=None, roi_decode=Fal
         pipe.run()
     if sync:
         sync()
+    pipe.operator_host_times()                        # opens the host-time window
+    cpu0 = thread_cpu_seconds()
     t0 = time.perf_counter()
     for _ in range(iters):
         pipe.run()
     if sync:
         sync()
     el = time.perf_counter() - t0
+    cpu1 = thread_cpu_seconds()
+    host_times = pipe.operator_host_times()
+    cpu = {k: round(1e3 * (v - cpu0.get(k, 0.0)) / iters, 3) for k, v in cpu1.items() if v - cpu0.get(k, 0.0) > 0}
     return {"value": iters * batch / el, "unit": "images/s", "ms_per_batch": 1e3 * el / iters, "elapsed_s": el,
             "batch": batch, "iters": iters, "host_threads": threads, "prefetch_queue_depth": depth,
+            "reader_prefetch_queue_depth": reader_depth,
+            "host_ms_per_operator": {k: round(v, 4) for k, v in host_times.items() if not k.startswith("<")},
+            "host_stage_ms_per_batch": host_times.get("<host stage>"),
+            "device_stage_ms_per_batch": host_times.get("<device stage>"),
+            "slot_wait_ms_per_batch": host_times.get("<slot wait>"),
+            "cpu_ms_per_batch_by_thread_group": cpu, "cpu_ms_per_batch": round(sum(cpu.values()), 3),
+            "cpus_busy": round(sum(cpu.values()) / (1e3 * el / iters), 2),
             "shard_id": shard_id, "num_shards": num_shards, "kernels": pipe.executed_kernels(),
             "note": "dali_amd.Pipeline end to end from encoded files in the page cache (file read, header parse, "
                     "H2D of the JPEG bytes on a copy stream, all device stages, fp16 CHW batch on the device)"}
@@ -350,10 +380,13 @@ def batch_statistics(enc_batches, device, count_symbols=True):
     return stats
 
 
-def resident_pipeline(root, batch, device_id, depth, threads, shard_id=0, num_shards=1, cache_mb=4096, roi_decode=False):
+def resident_pipeline(root, batch, device_id, depth, threads, shard_id=0, num_shards=1, cache_mb=4096, roi_decode=False,
+                      crop_seed=None, flip_seed=None):
     """The headline pipeline: configs[1] with the data set resident in HBM as encoded streams.  roi_decode: the fused
     variant decoders.image_random_crop -> resize -> crop_mirror_normalize (only the crop window is dequantised,
-    transformed and colour-converted), on the same resident streams."""
+    transformed and colour-converted), on the same resident streams.  crop_seed / flip_seed: explicit operator seeds
+    (tests/test_gpu_headline.py holds exactly this graph to the oracle); default: from the pipeline's seed."""
+    seeded = lambda seed: {} if seed is None else {"seed": seed}  # noqa: E731
     from dali_amd import fn, types
     from dali_amd.pipeline import Pipeline
     pipe = Pipeline(batch_size=batch, num_threads=threads, device_id=device_id, seed=1234, prefetch_queue_depth=depth)
@@ -366,11 +399,11 @@ def resident_pipeline(root, batch, device_id, depth, threads, shard_id=0, num_sh
             crops = fn.resize(images, size=[224, 224])
         else:
             images = fn.decoders.image(jpegs, device="mixed", output_type=types.RGB, cache_size=cache_mb, cache_type="encoded")
-            crops = fn.random_resized_crop(images, size=[224, 224])
+            crops = fn.random_resized_crop(images, size=[224, 224], **seeded(crop_seed))
         out = fn.crop_mirror_normalize(crops, dtype=types.FLOAT16, output_layout="CHW",
                                        mean=[0.485 * 255, 0.456 * 255, 0.406 * 255],
                                        std=[0.229 * 255, 0.224 * 255, 0.225 * 255],
-                                       mirror=fn.random.coin_flip(probability=0.5))
+                                       mirror=fn.random.coin_flip(probability=0.5, **seeded(flip_seed)))
         pipe.set_outputs(out, labels)
     pipe.build()
     return pipe
@@ -1039,7 +1072,7 @@ def main():
                 line["e2e_pipeline_roi_decode"] = e2e_pipeline(root, B, local_rank, roi_decode=True)
                 line["e2e_pipeline_roi_decode"]["note"] = ("same, with decoders.image_random_crop -> resize -> "
                                                            "crop_mirror_normalize: only the crop window is decoded")
-                line["e2e_pipeline_decoder_cache"] = e2e_pipeline(root, B, local_rank, iters=300, cache_mb=1024)
+                line["e2e_pipeline_decoder_cache"] = e2e_pipeline(root, B, local_rank, cache_mb=1024)
                 line["e2e_pipeline_decoder_cache"]["note"] = (
                     "same as e2e_pipeline with decoders.image(cache_size=1024, cache_type='threshold'): epoch >= 2 of a "
                     "data set whose decoded images fit in HBM.  The files are still read; decoded images are handed to "

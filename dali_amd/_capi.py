@@ -40,7 +40,7 @@ class JpegHuffDesc(C.Structure):
                 ("table_owner", C.c_int32), ("comp_of_block", C.c_uint8 * 12), ("h_of_block", C.c_uint8 * 12),
                 ("v_of_block", C.c_uint8 * 12), ("dc_sel", C.c_uint8 * 4), ("ac_sel", C.c_uint8 * 4),
                 ("bits", (C.c_uint8 * 16) * 4), ("vals", (C.c_uint8 * 256) * 4), ("rect", (C.c_int32 * 4) * 3),
-                ("plane", C.c_void_p * 3), ("plane_pitch", C.c_int32 * 3), ("reserved2", C.c_int32),
+                ("plane", C.c_void_p * 3), ("plane_pitch", C.c_int32 * 3), ("restart_interval", C.c_int32),
                 ("quant", (C.c_uint16 * 64) * 3)]
 
 
@@ -157,7 +157,8 @@ class JpegScan(C.Structure):
                 ("v_of_block", C.c_uint8 * 10), ("dc_sel", C.c_uint8 * 4), ("ac_sel", C.c_uint8 * 4),
                 ("dc_bits", (C.c_uint8 * 16) * 4), ("dc_vals", (C.c_uint8 * 256) * 4),
                 ("ac_bits", (C.c_uint8 * 16) * 4), ("ac_vals", (C.c_uint8 * 256) * 4),
-                ("quant", (C.c_uint16 * 64) * 4)]
+                ("quant", (C.c_uint16 * 64) * 4), ("restart_interval", C.c_int32),
+                ("length_is_upper_bound", C.c_int32)]
 
 
 class PhiloxState(C.Structure):
@@ -176,7 +177,7 @@ _KERNEL_SYMBOLS = [
     "daliamdEventDestroy", "daliamdEventRecord", "daliamdEventSynchronize", "daliamdEventQuery", "daliamdEventElapsedMs",
     "daliamdMalloc", "daliamdFree", "daliamdHostAlloc", "daliamdHostFree", "daliamdMemcpyH2DAsync",
     "daliamdMemcpyD2HAsync", "daliamdMemcpyD2DAsync", "daliamdMemsetAsync", "daliamdMemcpy2DD2DAsync",
-    "daliamdJpegIdctSetup", "daliamdJpegIdctRun", "daliamdJpegHuffmanScratchBytes", "daliamdJpegHuffmanSetup",
+    "daliamdJpegIdctSetup", "daliamdJpegIdctRun", "daliamdJpegHuffmanScratchBytes", "daliamdJpegHuffmanScratchBytesRestart", "daliamdJpegHuffmanSetup",
     "daliamdJpegHuffmanRun", "daliamdJpegHuffmanRunProfiled", "daliamdJpegColorSetup", "daliamdJpegPlanRoi", "daliamdJpegColorRun",
     "daliamdResampleSetup", "daliamdResampleRun", "daliamdCmnSetup", "daliamdCmnRun",
     "daliamdWarpAffineSetup", "daliamdWarpAffineRun", "daliamdGaussianWindow", "daliamdGaussianBlurSetup",
@@ -190,7 +191,7 @@ _KERNEL_SYMBOLS = [
 
 _HOST_SYMBOLS = [
     "daliamdHostGetLastErrorMessage", "daliamdJpegParse", "daliamdJpegDecodeCoefficients", "daliamdJpegDecodeRgbHost", "daliamdJpegOutputChannels", "daliamdJpegDecodeHost", "daliamdConvertRgbRows",
-    "daliamdJpegAnalyzeScan",
+    "daliamdJpegAnalyzeScan", "daliamdJpegAnalyzeHeader",
     "daliamdRandomCropBatch", "daliamdCoinFlipBatch", "daliamdPhiloxAdvanceSequence",
     "daliamdPhiloxStateToString", "daliamdPhiloxStateFromString", "daliamdPhiloxGenerate",
     "daliamdCmnNormArgs", "daliamdCropAnchor", "daliamdResampleRunHost", "daliamdCmnRunHost", "daliamdAudioResampleHost",

@@ -161,10 +161,12 @@ def _dtype(ctypes_struct):
 class JpegBatchPlan:
     """Geometry + buffer layout of one batch of JPEG streams (host side, no device work)."""
 
-    def __init__(self, encoded, out_pitch_align=16, rois=None):
+    def __init__(self, encoded, out_pitch_align=16, rois=None, exact_scan=True):
         """rois: optional per-sample windows (y0, x0, h, w) in image pixels (None entries = whole image): only the
-        window is decoded (region-of-interest decode; EXIF orientation is not applied by this driver)."""
+        window is decoded (region-of-interest decode; EXIF orientation is not applied by this driver).
+        exact_scan: see analyze_scans (False = what the decoders.image operator does)."""
         host = capi.host()
+        self.exact_scan = exact_scan
         self.n = len(encoded)
         self.encoded = [np.frombuffer(e, dtype=np.uint8) if not isinstance(e, np.ndarray) else
                         np.ascontiguousarray(e, dtype=np.uint8).reshape(-1) for e in encoded]
@@ -241,14 +243,23 @@ class JpegBatchPlan:
         else:
             list(_thread_pool(num_threads).map(one, range(self.n)))
 
-    def analyze_scans(self):
-        """Scan analysis of every stream (daliamdJpegAnalyzeScan): eligibility for the GPU Huffman decoder,
-        Huffman/quantisation tables, position of the entropy-coded segment."""
+    def analyze_scans(self, exact=None):
+        """Scan analysis of every stream: eligibility for the GPU Huffman decoder, Huffman/quantisation tables,
+        position of the entropy-coded segment.  exact: daliamdJpegAnalyzeScan walks the scan and reports its exact
+        length; else daliamdJpegAnalyzeHeader (what decoders.image runs): headers only, the segment is "everything
+        behind SOS" and the un-stuffing kernel finds its end."""
         host = capi.host()
+        exact = self.exact_scan if exact is None else exact
         self.scans = (capi.JpegScan * max(self.n, 1))()
         for i, e in enumerate(self.encoded):
-            capi.check_host(host.daliamdJpegAnalyzeScan(e.ctypes.data_as(C.c_void_p), C.c_size_t(e.size),
-                                                        C.byref(self.infos[i]), C.byref(self.scans[i])))
+            if exact:
+                capi.check_host(host.daliamdJpegAnalyzeScan(e.ctypes.data_as(C.c_void_p), C.c_size_t(e.size),
+                                                            C.byref(self.infos[i]), C.byref(self.scans[i])))
+            else:
+                info = capi.JpegInfo()
+                capi.check_host(host.daliamdJpegAnalyzeHeader(e.ctypes.data_as(C.c_void_p), C.c_size_t(e.size),
+                                                              C.byref(info), C.byref(self.scans[i])))
+                assert bytes(info) == bytes(self.infos[i]), "daliamdJpegAnalyzeHeader and daliamdJpegParse disagree"
         self.scan = np.frombuffer(self.scans, dtype=_dtype(capi.JpegScan))[:self.n]
         self.gpu_eligible = self.scan["eligible"].astype(bool) if self.n else np.zeros(0, bool)
         return self.gpu_eligible
@@ -270,8 +281,11 @@ class JpegBatchPlan:
         need = np.zeros(len(sel), np.int64)
         nb = C.c_size_t(0)
         total_blocks = (sc["mcus_x"][sel] * sc["mcus_y"][sel] * sc["blocks_per_mcu"][sel]).astype(np.int64)
+        mcus, ri = (sc["mcus_x"][sel] * sc["mcus_y"][sel]).astype(np.int64), sc["restart_interval"][sel].astype(np.int64)
+        intervals = np.where(ri > 0, (mcus + np.maximum(ri, 1) - 1) // np.maximum(ri, 1), 0)
         for j in range(len(sel)):
-            capi.check(lib.daliamdJpegHuffmanScratchBytes(int(ecs_len[j]), int(total_blocks[j]), C.byref(nb)))
+            capi.check(lib.daliamdJpegHuffmanScratchBytesRestart(int(ecs_len[j]), int(total_blocks[j]), int(intervals[j]),
+                                                                 C.byref(nb)))
             need[j] = nb.value
         self._scratch_off = np.concatenate([[0], np.cumsum(need)[:-1]]).astype(np.int64)
         stage = torch.empty(max(int(_align(ecs_len, 16).sum()), 16), dtype=torch.uint8, pin_memory=True)
@@ -316,6 +330,7 @@ class JpegBatchPlan:
             t["blocks_per_mcu"] = sc["blocks_per_mcu"][sel]
             t["mcus_x"] = sc["mcus_x"][sel]
             t["total_blocks"] = sc["mcus_x"][sel] * sc["mcus_y"][sel] * sc["blocks_per_mcu"][sel]
+            t["restart_interval"] = sc["restart_interval"][sel]
             t["blocks_x"] = inf["blocks_x"][sel, :3]
             t["h_samp"] = inf["h_samp"][sel, :3]
             t["v_samp"] = inf["v_samp"][sel, :3]
@@ -378,7 +393,7 @@ class JpegBatchPlan:
 
     def entropy_decode_gpu(self, coef_dev, num_threads=None, planes_dev=None):
         """Entropy-decodes the batch into `coef_dev` (int16 device tensor of self.coef_elems elements):
-        eligible streams on the GPU (daliamdJpegHuffmanRun), the rest (progressive, restart markers,
+        eligible streams on the GPU (daliamdJpegHuffmanRun), the rest (progressive,
         multi-scan) on the host.  Returns the device status tensor (one int32 per GPU-decoded stream) and the
         list of sample indices it refers to; call `check_gpu_status` once the stream is synchronised."""
         dev = coef_dev.device
@@ -429,8 +444,10 @@ class JpegBatchPlan:
         bad = np.nonzero(st)[0]
         if len(bad):
             i = int(self._huff_sel[bad[0]])
-            raise capi.DaliAmdError(f"sample {i}: corrupt JPEG data: the entropy-coded segment ends before the last "
-                                    f"MCU (GPU Huffman status {int(st[bad[0]])})")
+            why = {3: "restart markers in a stream without a restart interval",
+                   4: "a restart interval does not end where its marker is"}.get(
+                       int(st[bad[0]]), "the entropy-coded segment ends before the last MCU")
+            raise capi.DaliAmdError(f"sample {i}: corrupt JPEG data: {why} (GPU Huffman status {int(st[bad[0]])})")
 
     def build_descs(self, coef_dev, planes_dev, out_dev, fused_huffman=False):
         """IDCT + colour descriptor tables (numpy structured arrays mirroring the C structs).
@@ -524,7 +541,7 @@ def jpeg_gpu_stage(plan, coef_dev, planes_dev, out_dev, descs=None, split_events
     return idct_dev, color_dev
 
 
-def decode_jpeg_batch(encoded, device="cuda", num_threads=None, out_pitch_align=16, huffman="gpu", rois=None):
+def decode_jpeg_batch(encoded, device="cuda", num_threads=None, out_pitch_align=16, huffman="gpu", rois=None, exact_scan=True):
     """Decodes a batch of JPEG byte strings -> list of u8 HWC RGB device tensors.
     rois: optional per-sample windows (y0, x0, h, w): region-of-interest decode (decoders.image_crop & co.).
 
@@ -532,7 +549,7 @@ def decode_jpeg_batch(encoded, device="cuda", num_threads=None, out_pitch_align=
     huffman="host": header parse + Huffman on the host thread pool into pinned memory (the hybrid path).
     Dequantisation, IDCT, upsampling and colour conversion always run on the device."""
     device = torch.device(device)
-    plan = JpegBatchPlan(encoded, out_pitch_align, rois=rois)
+    plan = JpegBatchPlan(encoded, out_pitch_align, rois=rois, exact_scan=exact_scan)
     status = None
     planes = torch.empty(max(plan.plane_bytes, 1), dtype=torch.uint8, device=device)
     if huffman == "gpu":

@@ -166,6 +166,18 @@ HUFF_HD DecodeState Unpack(uint64_t v) {
 }
 constexpr uint64_t kNoState = ~0ull;  // unpacks to a position past any stream
 
+// Restart intervals (T.81 B.2.4.4 DRI, E.2.4, F.1.2.3): every `interval` MCUs the encoder pads the stream to a byte
+// boundary with one-bits, writes an RSTn marker and resets the DC predictions.  The un-stuffing pass removes the markers
+// and notes the CLEAN byte offset behind each one (`pos`, ascending, `n` of them): there the next interval starts with
+// the decoder state (c = 0, z = 0) whatever came before - a synchronisation point that needs no relaxation.
+template <typename RstPos>
+struct RestartView {
+  RstPos pos;
+  int n;
+  uint32_t interval;  // MCUs per interval; 0: the stream has none
+  int hint;           // index of the first boundary that can matter to the caller (at or behind its slice)
+};
+
 HUFF_HD uint32_t Bswap32(uint32_t v) { return __builtin_bswap32(v); }
 
 // Rare path: the code is longer than kFastBits bits (or is not a code at all).  Out of line on the device.
@@ -215,11 +227,28 @@ __device__ __forceinline__ uint32_t WordAtByte(const uint32_t __attribute__((add
 }
 #endif
 
-template <typename Tables, typename Words, typename Store>
-HUFF_HD int SyncDecodeRange(const Tables &L, Words words, DecodeState &st, uint32_t end_bits, Store store) {
+//
+// RST: the stream has restart intervals (`rst`).  (1) A decode that has just finished an MCU less than 8 bits in front
+// of a boundary, with nothing but one-bits in between, has finished the interval: a complete symbol always holds a
+// zero bit (no code word is all ones), so those bits cannot be another MCU - they are the padding.  It steps over them
+// and goes on at the boundary.  (2) A decode that finds itself BEHIND a boundary it did not arrive at that way either
+// started from a wrong guess (it continues from the boundary with the state every interval starts in: each boundary is
+// a point where guessed states become true ones) or the stream's padding is not the one-bits of the standard;
+// `*crossed` reports it, and the caller refuses the stream when that happens to a decode that started from the truth.
+template <bool RST, typename Tables, typename Words, typename RstPos, typename Store>
+HUFF_HD int SyncDecodeRangeT(const Tables &L, Words words, DecodeState &st, uint32_t end_bits, const RestartView<RstPos> &rst,
+                             Store store, bool *crossed) {
   int nb = 0;
   uint32_t c = st.c, z = st.z;
   int rem = (int)(end_bits - st.pos);  // bits left before the end of the slice (<= 0: done)
+  constexpr int kFar = 1 << 30;
+  int ri = 0, rem_r = kFar;            // next boundary: its index, the bits up to it
+  bool dirty = false;
+  if (RST) {
+    ri = rst.hint;
+    while (ri < rst.n && rst.pos[ri] <= (st.pos >> 3)) ri++;   // first boundary behind the position (hint: 0-1 steps)
+    if (ri < rst.n) rem_r = (int)(rst.pos[ri] * 8u - st.pos);
+  }
   if (st.pos == 0) {                   // the stream's first block
     store(0, rem, true);
     nb = 1;
@@ -273,12 +302,51 @@ HUFF_HD int SyncDecodeRange(const Tables &L, Words words, DecodeState &st, uint3
     z = end_of_block ? 0 : z;
     c = end_of_block ? c1 : c;
     nb += end_of_block ? 1 : 0;
+    if (RST) {
+      rem_r -= (int)used;
+      if (__builtin_expect(rem_r < 8, 0)) {   // (rem_r stays far away behind the last boundary)
+        bool jump = rem_r < 0;
+        dirty = dirty || jump;
+        if (!jump && end_of_block && c1 == 0) {   // an MCU ends here: only padding up to the boundary?
+          const uint32_t ahead = (uint32_t)(((((uint64_t)hi << 32) | lo) << off) >> 32);
+          const uint32_t zeros = rem_r ? ~ahead >> (32 - rem_r) : 0u;   // zero bits among the rem_r bits ahead
+          jump = zeros == 0;
+        }
+        if (jump) {
+          // on to the boundary: the block that ended here (or that the boundary cuts off) is followed by one that
+          // starts AT the boundary
+          if (!end_of_block) nb++;
+          rem -= rem_r;
+          c = 0; z = 0;
+          s_nb = nb - 1; s_rem = rem; s_ended = true;
+          const uint32_t at = end_bits - (uint32_t)rem;
+          kb = (at >> 5) << 2;
+          off = at & 31;
+          hi = Bswap32(WordAtByte(words, kb)); lo = Bswap32(WordAtByte(words, kb + 4)); nxt = WordAtByte(words, kb + 8);
+          ri++;
+          rem_r = ri < rst.n ? (int)(rst.pos[ri] * 8u - at) : kFar;
+        }
+      }
+    }
   }
   store(s_nb, s_rem, s_ended);
   st.pos = end_bits - (uint32_t)rem;
   st.c = c;
   st.z = z;
+  if (RST) *crossed = dirty;
   return nb;
+}
+template <typename Tables, typename Words, typename Store>
+HUFF_HD int SyncDecodeRange(const Tables &L, Words words, DecodeState &st, uint32_t end_bits, Store store) {
+  return SyncDecodeRangeT<false>(L, words, st, end_bits, RestartView<const uint32_t *>{nullptr, 0, 0, 0}, store, nullptr);
+}
+// the stream's own variant (rst.interval decides; uniform per stream)
+template <typename Tables, typename Words, typename RstPos, typename Store>
+HUFF_HD int SyncDecodeRange(const Tables &L, Words words, DecodeState &st, uint32_t end_bits, const RestartView<RstPos> &rst,
+                            Store store, bool *crossed) {
+  *crossed = false;
+  if (rst.interval) return SyncDecodeRangeT<true>(L, words, st, end_bits, rst, store, crossed);
+  return SyncDecodeRangeT<false>(L, words, st, end_bits, rst, store, crossed);
 }
 
 // ------------------------------------------------------------------------------------------------ value passes

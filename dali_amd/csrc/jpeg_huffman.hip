@@ -1,4 +1,4 @@
-// GPU Huffman entropy decoder for baseline JPEG (one interleaved scan, no restart markers) on gfx950.
+// GPU Huffman entropy decoder for baseline JPEG (one interleaved scan, with or without restart intervals) on gfx950.
 //
 // Reference counterpart: the GPU Huffman stage of nvJPEG inside nvImageCodec, reached from
 // ImageDecoder::RunImplImpl (dali/operators/imgcodec/image_decoder.h:810-815).  The output is what the host decoder
@@ -14,7 +14,9 @@
 //   segment  244 slices = 61 KB             (one 256-lane workgroup: 12 warm-up lanes + 244 slices)
 //   block    one 8x8 block                  (one lane of the value pass)
 //
-//   1 PrepareKernel         per tile: number of bytes that survive the removal of the 0xFF00 stuffing; and, in extra
+//   1 PrepareKernel         per tile: number of bytes that survive the removal of the 0xFF00 stuffing and of the RSTn
+//                           markers, and WHERE THE SEGMENT ENDS (the first marker that is not RSTn: the host only
+//                           parses the headers and hands over "everything behind SOS"); and, in extra
 //                           workgroups of the same launch (they need nothing but the descriptor), per image: two-level
 //                           code tables (11-bit first level, direct second level for the long codes) and the
 //                           symbol-group tables of the position-only passes -> global scratch
@@ -76,8 +78,8 @@ constexpr int kCleanPadBytes = 40;
 #endif
 constexpr int kListCap = DALIAMD_LIST_CAP;       // odd, so that the stride below is an odd number of dwords
 constexpr int kListStride = kListCap + 1;
-// A block takes at least 4 bits (streams with a 1-bit code are refused), a group may overshoot the slice by 3 symbols.
-constexpr int kMaxStartsPerSlice = kSliceBytes * 8 / 4 + 32;
+// A block takes at least 2 bits (a 1-bit DC code + a 1-bit end-of-block), a group may overshoot the slice by 3 symbols.
+constexpr int kMaxStartsPerSlice = kSliceBytes * 8 / 2 + 32;
 
 // Explicit global address space: a generic pointer would make these `flat` accesses, which count against the LDS
 // counter as well and would serialise the table look-ups behind the stream prefetch.
@@ -102,21 +104,32 @@ struct SegRec {  // one per segment
   int32_t nstart_total;  // block starts found in the segment
   int32_t block_base;    // ... in the segments before it = ordinal of the segment's first start (PropagateKernel)
   int32_t dc_total[3];   // DcKernel: sum of the DC differences of the segment's blocks, per component
-  int32_t reserved;
+  int32_t crossed;       // restart intervals: a lane's final decode ran over a boundary (Lane::crossed)
 };
 static_assert(sizeof(SegRec) == 32, "layout");
 constexpr int kSegRecInts = 8, kSegRecNstart = 2, kSegRecBlockBase = 3, kSegRecDcTotal = 4;  // int32 view of a SegRec
 
+struct TileRec {   // one per tile of the stuffed stream (PrepareKernel)
+  int32_t kept;    // bytes of the tile that go into the clean stream (up to the end of the segment, if it ends here)
+  int32_t ended;   // the segment ends in this tile: a marker other than RSTn (or a fill byte's 0xFF) was found
+  int32_t nrst;    // RSTn markers in front of that
+  int32_t reserved;
+};
+static_assert(sizeof(TileRec) == 16, "layout");
 struct ScratchLayout {
-  size_t tile_kept, clean, tables, sync_tables, lanes, segs, seg_starts, blk_pos, blk_dc, blk_seg, total;
+  size_t tile_recs, clean, tables, sync_tables, lanes, segs, seg_starts, blk_pos, blk_dc, blk_seg, rst_pos, total;
   int seg_cap;  // entries per segment in seg_starts
+  int rst_cap;  // entries in rst_pos
 };
 __host__ __device__ inline size_t AlignUp(size_t v, size_t a) { return (v + a - 1) / a * a; }
-__host__ __device__ inline ScratchLayout MakeLayout(int ecs_len, int num_tiles, int num_segments, int total_blocks) {
+// num_intervals: restart intervals of the frame (0: the stream has none) - their array comes LAST, so every other offset
+// is the same whatever it is.
+__host__ __device__ inline ScratchLayout MakeLayout(int ecs_len, int num_tiles, int num_segments, int total_blocks,
+                                                    int num_intervals) {
   ScratchLayout l;
-  size_t o = 16;  // int32 [0] clean_len, [2] block starts found in the whole stream
-  l.tile_kept = o;
-  o += AlignUp(sizeof(int32_t) * (size_t)num_tiles, 16);
+  size_t o = 16;  // int32 [0] clean_len, [1] restart boundaries found, [2] block starts found in the whole stream
+  l.tile_recs = o;
+  o += sizeof(TileRec) * (size_t)num_tiles;
   l.clean = o;
   o += AlignUp((size_t)ecs_len + 256, 16);
   l.tables = o;
@@ -139,8 +152,18 @@ __host__ __device__ inline ScratchLayout MakeLayout(int ecs_len, int num_tiles, 
   o += AlignUp(sizeof(int32_t) * (size_t)total_blocks, 16);
   l.blk_seg = o;   // per block: the segment it starts in
   o += AlignUp(sizeof(uint16_t) * (size_t)total_blocks, 16);
+  l.rst_pos = o;   // per restart boundary: clean byte offset at which the next interval starts
+  l.rst_cap = num_intervals;
+  o += AlignUp(sizeof(uint32_t) * (size_t)num_intervals, 16);
   l.total = AlignUp(o, 256);
   return l;
+}
+__host__ __device__ inline int NumIntervals(int total_blocks, int blocks_per_mcu, int restart_interval) {
+  return restart_interval > 0 ? (total_blocks / blocks_per_mcu + restart_interval - 1) / restart_interval : 0;
+}
+__host__ __device__ inline ScratchLayout LayoutOf(const daliamdJpegHuffDesc &d) {
+  return MakeLayout(d.ecs_len, d.num_tiles, d.num_segments, d.total_blocks,
+                    NumIntervals(d.total_blocks, d.blocks_per_mcu, d.restart_interval));
 }
 inline int NumTiles(int head, int len) {
   int t = (head + len + kTileBytes - 1) / kTileBytes;
@@ -170,7 +193,7 @@ __device__ __forceinline__ ImageRef FindImage(const daliamdJpegHuffDesc *descs, 
 // decode passes copies its 36 KB of tables from the same few L2-resident lines.
 __device__ __forceinline__ const uint8_t *TablesBase(const daliamdJpegHuffDesc *descs, const daliamdJpegHuffDesc &d, bool sync_tables) {
   const daliamdJpegHuffDesc &o = descs[d.table_owner];
-  const ScratchLayout lay = MakeLayout(o.ecs_len, o.num_tiles, o.num_segments, o.total_blocks);
+  const ScratchLayout lay = LayoutOf(o);
   return o.scratch + (sync_tables ? lay.sync_tables : lay.tables);
 }
 
@@ -199,60 +222,125 @@ __device__ __forceinline__ int WorkgroupExclusiveScan(int v, int *wave_sums, int
 }
 
 // ------------------------------------------------------------------------------------------------ un-stuffing
-// 16 bytes of the stuffed stream per lane -> mask of the bytes that stay (bit j = byte j).
+// 16 bytes of the stuffed stream per lane -> mask of the bytes that stay (bit j = byte j).  What goes: the zero behind
+// a 0xFF (byte stuffing), both bytes of an RSTn marker, fill bytes (a 0xFF in front of a 0xFF), and everything from the
+// first other marker on - that is where the entropy-coded segment ENDS, wherever the caller said it does (ecs_len may
+// be "the rest of the file": the host does not walk the scan, jpeg_entropy.cpp: daliamdJpegAnalyzeHeader).
 struct TileChunk {
   uint32_t w[4];
   uint32_t keep;
+  uint32_t rst;   // bit j: byte j is the 0xFF of an RSTn marker
+  int end_j;      // first byte of this lane that starts an ending marker (16: none)
 };
 __device__ __forceinline__ TileChunk LoadChunk(const daliamdJpegHuffDesc &d, int tile) {
   const int head = (int)(reinterpret_cast<uintptr_t>(d.ecs) & 15);  // bytes between the 16-byte boundary and the segment
   const int end = head + d.ecs_len;
   const int g = tile * kTileBytes + (int)threadIdx.x * 16;
-  TileChunk c{{0, 0, 0, 0}, 0};
-  uint32_t prev = 0;
+  TileChunk c{{0, 0, 0, 0}, 0, 0, 16};
+  uint32_t prev = 0, behind = 0;
   if (g < end) {
     GlobalWords *p = (GlobalWords *)__builtin_assume_aligned((const void *)(d.ecs - head + g), 16);
     c.w[0] = p[0]; c.w[1] = p[1]; c.w[2] = p[2]; c.w[3] = p[3];
     if (g > head) prev = ((const GlobalBytes *)(d.ecs - head))[g - 1];
+    if (g + 16 < end) behind = ((const GlobalBytes *)(d.ecs - head))[g + 16];
   }
 #pragma unroll
   for (int j = 0; j < 16; j++) {
-    uint32_t b = (c.w[j >> 2] >> (8 * (j & 3))) & 255u;
-    bool valid = g + j >= head && g + j < end;
-    bool stuffed = b == 0 && prev == 0xFF && g + j > head;  // the first byte of the segment has no predecessor
-    if (valid && !stuffed) c.keep |= 1u << j;
+    const uint32_t b = (c.w[j >> 2] >> (8 * (j & 3))) & 255u;
+    // the byte behind this one (zero past the end: a last 0xFF stays what it would be in front of a stuffed zero)
+    const uint32_t nb = j < 15 ? ((c.w[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 255u) : behind;
+    const bool valid = g + j >= head && g + j < end;
+    const bool next_valid = g + j + 1 < end;
+    const bool after_ff = prev == 0xFF && g + j > head;   // the first byte of the segment has no predecessor
+    const bool marker = b == 0xFF && next_valid && nb != 0;            // RSTn, fill byte or the end
+    const bool is_rst = marker && (nb & 0xF8u) == 0xD0u;
+    const bool is_end = marker && !is_rst && nb != 0xFF;
+    const bool dropped = marker || (after_ff && (b == 0 || (b & 0xF8u) == 0xD0u));
+    if (valid && !dropped) c.keep |= 1u << j;
+    if (valid && is_rst) c.rst |= 1u << j;
+    if (valid && is_end && c.end_j == 16) c.end_j = j;
     prev = b;
   }
   return c;
 }
 
-// First pass of the un-stuffing: bytes each tile keeps (PrepareKernel).
-__device__ __forceinline__ void CountTile(const daliamdJpegHuffDesc *__restrict__ descs, int n, int tile, int *wave_sums) {
+// Where the segment ends inside the tile, from the lanes' end_j: index of the first ending byte (kTileBytes: none).
+// One barrier pair; `slot` is a shared int the caller provides.
+__device__ __forceinline__ int TileEnd(const TileChunk &c, int *slot) {
+  if (threadIdx.x == 0) *slot = kTileBytes;
+  __syncthreads();
+  if (c.end_j < 16) atomicMin(slot, (int)threadIdx.x * 16 + c.end_j);
+  __syncthreads();
+  return *slot;
+}
+// Cuts a lane's masks at the end of the segment.
+__device__ __forceinline__ void CutChunk(TileChunk &c, int tile_end) {
+  const int mine = tile_end - (int)threadIdx.x * 16;   // bytes of this lane in front of the end
+  const uint32_t m = mine >= 16 ? 0xFFFFu : (mine <= 0 ? 0u : (1u << mine) - 1u);
+  c.keep &= m;
+  c.rst &= m;
+}
+
+// First pass of the un-stuffing: what each tile keeps (PrepareKernel).
+__device__ __forceinline__ void CountTile(const daliamdJpegHuffDesc *__restrict__ descs, int n, int tile, int *wave_sums, int *slot) {
   const ImageRef r = FindImage<true>(descs, n, tile);
   const daliamdJpegHuffDesc &d = *r.d;
-  const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments, d.total_blocks);
+  const ScratchLayout lay = LayoutOf(d);
   TileChunk c = LoadChunk(d, r.local);
-  int total;
+  const int tile_end = TileEnd(c, slot);
+  CutChunk(c, tile_end);
+  if (!d.restart_interval && c.rst) *d.status = 3;   // RSTn markers in a stream without DRI
+  int total, nrst = 0;
   WorkgroupExclusiveScan<kTileThreads / 64>(__popc(c.keep), wave_sums, total);
-  if (threadIdx.x == 0) reinterpret_cast<int32_t *>(d.scratch + lay.tile_kept)[r.local] = total;
+  if (d.restart_interval) WorkgroupExclusiveScan<kTileThreads / 64>(__popc(c.rst), wave_sums, nrst);   // (uniform)
+  if (threadIdx.x == 0)
+    reinterpret_cast<TileRec *>(d.scratch + lay.tile_recs)[r.local] = TileRec{total, tile_end < kTileBytes ? 1 : 0, nrst, 0};
 }
 
 __global__ __launch_bounds__(kTileThreads) void UnstuffScatterKernel(const daliamdJpegHuffDesc *__restrict__ descs, int n) {
   __shared__ uint32_t stage[kTileBytes / 4 + 4];
   __shared__ int wave_sums[kTileThreads / 64];
+  __shared__ int slot;
   const ImageRef r = FindImage<true>(descs, n, blockIdx.x);
   const daliamdJpegHuffDesc &d = *r.d;
-  const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments, d.total_blocks);
+  const ScratchLayout lay = LayoutOf(d);
   const int tid = threadIdx.x;
-  // clean-stream position of this tile = bytes kept by the tiles before it
-  const int32_t *tile_kept = reinterpret_cast<const int32_t *>(d.scratch + lay.tile_kept);
-  int before = 0, base;
-  for (int t = tid; t < r.local; t += kTileThreads) before += tile_kept[t];
+  // clean-stream position of this tile = bytes kept by the tiles before it, up to the tile the segment ends in
+  const TileRec *recs = reinterpret_cast<const TileRec *>(d.scratch + lay.tile_recs);
+  if (tid == 0) slot = d.num_tiles;
+  __syncthreads();
+  for (int t = tid; t < r.local; t += kTileThreads)
+    if (recs[t].ended) atomicMin(&slot, t);
+  __syncthreads();
+  const int end_tile = slot;          // first tile (in front of this one) in which the segment ends
+  const bool dead = end_tile < r.local;  // this tile lies behind the end
+  __syncthreads();                    // (slot is reused below)
+  int before = 0, rst_before = 0, base, rst_base;
+  for (int t = tid; t < r.local && t <= end_tile; t += kTileThreads) {
+    before += recs[t].kept;
+    rst_before += recs[t].nrst;
+  }
   WorkgroupExclusiveScan<kTileThreads / 64>(before, wave_sums, base);
   const int shift = base & 3;  // stage byte i <-> clean byte (base - shift) + i
   TileChunk c = LoadChunk(d, r.local);
+  CutChunk(c, dead ? 0 : TileEnd(c, &slot));
   int total;
   int o = shift + WorkgroupExclusiveScan<kTileThreads / 64>(__popc(c.keep), wave_sums, total);
+  if (d.restart_interval) {   // (uniform) where the intervals start in the clean stream
+    WorkgroupExclusiveScan<kTileThreads / 64>(rst_before, wave_sums, rst_base);
+    int nrst;
+    int k = rst_base + WorkgroupExclusiveScan<kTileThreads / 64>(__popc(c.rst), wave_sums, nrst);
+    GlobalU32 *rst_pos = (GlobalU32 *)(d.scratch + lay.rst_pos);
+    for (uint32_t m = c.rst; m; m &= m - 1) {
+      const int j = __ffs(m) - 1;
+      if (k < lay.rst_cap) rst_pos[k] = (uint32_t)(base - shift + o + __popc(c.keep & ((1u << j) - 1u)));
+      k++;
+    }
+    if (r.local == d.num_tiles - 1 && tid == 0) {
+      const int found = rst_base + nrst;
+      reinterpret_cast<int32_t *>(d.scratch)[1] = found < lay.rst_cap ? found : lay.rst_cap;
+    }
+  }
   uint8_t *stage_b = reinterpret_cast<uint8_t *>(stage);
   if (c.keep == 0xFFFFu && (o & 3) == 0) {
     uint32_t *p = stage + (o >> 2);  // common case: nothing to drop, dword aligned
@@ -276,7 +364,10 @@ __global__ __launch_bounds__(kTileThreads) void UnstuffScatterKernel(const dalia
   }
   if (r.local == d.num_tiles - 1) {
     const int clean_len = base + total;
-    if (tid == 0) *reinterpret_cast<int32_t *>(d.scratch) = clean_len;
+    if (tid == 0) {
+      *reinterpret_cast<int32_t *>(d.scratch) = clean_len;
+      if (!d.restart_interval) reinterpret_cast<int32_t *>(d.scratch)[1] = 0;
+    }
     // all-ones padding: never a valid code, lets the bit window run past the end
     if (tid < kCleanPadBytes) ((GlobalBytes *)(d.scratch + lay.clean))[clean_len + tid] = 0xFF;
   }
@@ -297,7 +388,7 @@ __device__ __forceinline__ void CopyTables(Tables &dst, const Tables *src) {
 // (huff_core.h: FastEntry / L2Entry / SyncEntry).
 __device__ __forceinline__ void BuildTables(const daliamdJpegHuffDesc &d, HuffTables &L) {
   constexpr int NT = kTileThreads;
-  const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments, d.total_blocks);
+  const ScratchLayout lay = LayoutOf(d);
   const int tid = threadIdx.x;
   {
     uint4 *z = reinterpret_cast<uint4 *>(&L);
@@ -360,10 +451,11 @@ __global__ __launch_bounds__(kTileThreads) void PrepareKernel(const daliamdJpegH
                                                               int num_tiles) {
   __shared__ __attribute__((aligned(16))) HuffTables L;
   __shared__ int wave_sums[kTileThreads / 64];
+  __shared__ int slot;
   if ((int)blockIdx.x < n) {
     if (descs[blockIdx.x].table_owner == (int)blockIdx.x) BuildTables(descs[blockIdx.x], L);   // (uniform per workgroup)
   } else {
-    CountTile(descs, n, (int)blockIdx.x - n, wave_sums);
+    CountTile(descs, n, (int)blockIdx.x - n, wave_sums, &slot);
   }
 }
 
@@ -374,6 +466,7 @@ struct Lane {
   bool active;          // the slice holds data
   uint64_t in = kNoState, out = kNoState;
   int nstart = 0;       // blocks that start in the slice, by the lane's latest decode
+  bool crossed = false; // that decode ran over a restart boundary it did not see coming (huff_core.h)
 };
 
 __device__ __forceinline__ Lane MakeLane(long long slice_index, uint32_t total_bits) {
@@ -394,7 +487,25 @@ __device__ __forceinline__ Lane MakeLane(long long slice_index, uint32_t total_b
 // state[t] is the published input of lane t; lanes whose `in` already equals it do not decode.  Lane 0's input is
 // never written here, so whatever the caller put there is taken as the truth; each round fixes at least one more
 // lane, which bounds the loop by the lane count.  `list` = this lane's block-start list in LDS.
-__device__ __forceinline__ void Relax(const SyncTables &L, GlobalWords *words, uint64_t *state, Lane &ln, uint16_t *list) {
+using RstView = RestartView<GlobalWords *>;
+// The stream's restart boundaries as the lane at bit `begin` needs them: hint = the first one at or behind its slice.
+__device__ __forceinline__ RstView MakeRstView(const daliamdJpegHuffDesc &d, const ScratchLayout &lay, uint32_t begin_bits) {
+  RstView v{(GlobalWords *)(d.scratch + lay.rst_pos), 0, (uint32_t)d.restart_interval, 0};
+  if (d.restart_interval) {
+    v.n = ((const GlobalI32 *)d.scratch)[1];
+    const uint32_t want = begin_bits >> 3;
+    int lo = 0, hi = v.n;   // first k with pos[k] >= want
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (v.pos[mid] < want) lo = mid + 1; else hi = mid;
+    }
+    v.hint = lo;
+  }
+  return v;
+}
+
+__device__ __forceinline__ void Relax(const SyncTables &L, GlobalWords *words, uint64_t *state, Lane &ln, uint16_t *list,
+                                      const RstView &rst) {
   const int tid = threadIdx.x;
   for (int round = 0; round <= kSegThreads; round++) {
     const uint64_t ni = state[tid];
@@ -403,7 +514,8 @@ __device__ __forceinline__ void Relax(const SyncTables &L, GlobalWords *words, u
       DecodeState st = Unpack(ni);
       ln.nstart = 0;
       if (st.pos < ln.end)
-        ln.nstart = SyncDecodeRange(L, words, st, ln.end, [&](int nb, int rem, bool) { list[nb < kListCap ? nb : kListCap] = (uint16_t)rem; });
+        ln.nstart = SyncDecodeRange(L, words, st, ln.end, rst, [&](int nb, int rem, bool) { list[nb < kListCap ? nb : kListCap] = (uint16_t)rem; },
+                                    &ln.crossed);
       ln.out = Pack(st);
     }
     __syncthreads();
@@ -421,7 +533,7 @@ __device__ __forceinline__ void Relax(const SyncTables &L, GlobalWords *words, u
 // previous one).  Lanes whose list outgrew its LDS slots (long runs of nearly empty blocks) decode once more,
 // writing straight to memory.  Returns the number of starts in the segment.
 __device__ __forceinline__ int WriteSegmentStarts(const SyncTables &L, GlobalWords *words, const Lane &ln, const uint16_t *list,
-                                                  bool mine, GlobalU32 *seg_starts, int seg_cap, int *wave_sums) {
+                                                  bool mine, GlobalU32 *seg_starts, int seg_cap, int *wave_sums, const RstView &rst) {
   int total;
   const int base = WorkgroupExclusiveScan<kSegThreads / 64>(mine ? ln.nstart : 0, wave_sums, total);
   if (mine && ln.nstart <= kListCap) {
@@ -431,9 +543,10 @@ __device__ __forceinline__ int WriteSegmentStarts(const SyncTables &L, GlobalWor
     DecodeState st = Unpack(ln.in);
     const uint32_t end = ln.end;
     const int count = ln.nstart;  // the slot behind the last start is "in progress" for ever: it belongs to the next lane
-    SyncDecodeRange(L, words, st, end, [&](int nb, int rem, bool ended) {  // one store per block, not per step
+    bool crossed;
+    SyncDecodeRange(L, words, st, end, rst, [&](int nb, int rem, bool ended) {  // one store per block, not per step
       if (ended && nb < count && base + nb < seg_cap) seg_starts[base + nb] = end - (uint32_t)rem;
-    });
+    }, &crossed);
   }
   return total;
 }
@@ -447,7 +560,7 @@ __global__ __launch_bounds__(kSegThreads) void SyncKernel(const daliamdJpegHuffD
   if (wg < 0) return;
   const ImageRef r = FindImage<false>(descs, n, wg);
   const daliamdJpegHuffDesc &d = *r.d;
-  const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments, d.total_blocks);
+  const ScratchLayout lay = LayoutOf(d);
   const int tid = threadIdx.x, seg = r.local;
   const int clean_len = *(const GlobalI32 *)d.scratch;
   LaneRec *recs = reinterpret_cast<LaneRec *>(d.scratch + lay.lanes) + (size_t)seg * kSegLanes;
@@ -465,15 +578,19 @@ __global__ __launch_bounds__(kSegThreads) void SyncKernel(const daliamdJpegHuffD
   __syncthreads();
   GlobalWords *words = (GlobalWords *)(d.scratch + lay.clean);
   uint16_t *list = lists + tid * kListStride;
-  Relax(L, words, state, ln, list);
+  const RstView rst = MakeRstView(d, lay, ln.begin);
+  Relax(L, words, state, ln, list, rst);
   const bool mine = tid >= kWarmLanes;
   const int total = WriteSegmentStarts(L, words, ln, list, mine, (GlobalU32 *)(d.scratch + lay.seg_starts) + (size_t)seg * lay.seg_cap,
-                                       lay.seg_cap, wave_sums);
+                                       lay.seg_cap, wave_sums, rst);
+  // restart intervals: did a lane's last decode run over a boundary?  (Wrong when the lanes started from the truth -
+  // PropagateKernel knows whether they did.)
+  const int crossed = d.restart_interval ? __syncthreads_or(mine && ln.active && ln.crossed) : 0;
   if (mine) {
     recs[tid - kWarmLanes] = LaneRec{ln.in, ln.out, ln.nstart, 0};
     // the last slice with data ends the segment (an empty stream: the first lane passes its input on)
     const bool next_has_data = tid + 1 < kSegThreads && ln.end < total_bits;
-    if (ln.active && !next_has_data) *segrec = SegRec{ln.out, total, 0, {0, 0, 0}, 0};
+    if (ln.active && !next_has_data) *segrec = SegRec{ln.out, total, 0, {0, 0, 0}, crossed};
     if (total_bits == 0 && tid == kWarmLanes) *segrec = SegRec{Pack(DecodeState{0, 0, 0}), 0, 0, {0, 0, 0}, 0};
   }
 }
@@ -484,7 +601,7 @@ __global__ __launch_bounds__(kSegThreads) void PropagateKernel(const daliamdJpeg
   __shared__ uint16_t lists[kSegThreads * kListStride];
   __shared__ int wave_sums[kSegThreads / 64];
   const daliamdJpegHuffDesc &d = descs[blockIdx.x];
-  const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments, d.total_blocks);
+  const ScratchLayout lay = LayoutOf(d);
   const int tid = threadIdx.x;
   const int clean_len = *(const GlobalI32 *)d.scratch;
   const uint32_t total_bits = (uint32_t)clean_len * 8u;
@@ -515,21 +632,27 @@ __global__ __launch_bounds__(kSegThreads) void PropagateKernel(const daliamdJpeg
       state[tid] = tid == 0 ? truth : (mine ? recs[tid].in : kNoState);
       __syncthreads();
       uint16_t *list = lists + tid * kListStride;
-      Relax(L, words, state, ln, list);
+      const RstView rst = MakeRstView(d, lay, ln.begin);
+      Relax(L, words, state, ln, list, rst);
       const int total = WriteSegmentStarts(L, words, ln, list, mine,
                                            (GlobalU32 *)(d.scratch + lay.seg_starts) + (size_t)seg * lay.seg_cap, lay.seg_cap,
-                                           wave_sums);
+                                           wave_sums, rst);
+      const int crossed = d.restart_interval ? __syncthreads_or(mine && ln.active && ln.crossed) : 0;
       if (mine) {
         recs[tid] = LaneRec{ln.in, ln.out, ln.nstart, 0};
         const bool next_has_data = tid + 1 < kSegLanes && ln.end < total_bits;
         if (ln.active && !next_has_data) {
           segs[seg].out = ln.out;
           segs[seg].nstart_total = total;
+          segs[seg].crossed = crossed;
         }
       }
       __threadfence();
       __syncthreads();  // the records written above are read below (same workgroup)
     }
+    // every lane of the segment has decoded from the true state by now: a restart boundary met in the middle of an MCU
+    // means the intervals are not padded with one-bits (or hold the wrong number of MCUs) - not for this decoder
+    if (tid == 0 && segs[seg].crossed) *d.status = 4;
     if (tid == 0) segs[seg].block_base = block_base;
     block_base += segs[seg].nstart_total;
     truth = segs[seg].out;
@@ -636,7 +759,7 @@ __global__ __launch_bounds__(kDcThreads) void DcKernel(const daliamdJpegHuffDesc
   if (wg < 0) return;
   const ImageRef r = FindImage<false>(descs, n, wg);
   const daliamdJpegHuffDesc &d = *r.d;
-  const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments, d.total_blocks);
+  const ScratchLayout lay = LayoutOf(d);
   const int tid = threadIdx.x, seg = r.local;
   const int clean_len = *(const GlobalI32 *)d.scratch;
   SegRec *segrec = reinterpret_cast<SegRec *>(d.scratch + lay.segs) + seg;
@@ -741,6 +864,8 @@ __host__ __device__ inline int McusPerWg(int bpm) {
 }
 struct BlockGeom {
   int32_t bpm, mcus_x, total_mcus, last_ordinal, use_rect, total_starts, fused, n0;
+  int32_t interval_blocks;  // blocks per restart interval (0: none)
+  uint8_t klast[4];   // per component: its last block inside the MCU
   uint8_t klist[12];  // block indices of the MCU, the ones with AC table 0 first
   uint8_t comp[12], acs[12], hs[12], vs[12], ho[12], vo[12];
   int32_t sx[12], sy[12], rect[12][4], pitch[12], comp_pitch[4];
@@ -780,7 +905,7 @@ __global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHu
     if (descs[mid].blk_wg_start <= wg) lo = mid; else hi = mid - 1;
   }
   const daliamdJpegHuffDesc &d = descs[lo];
-  const ScratchLayout lay = MakeLayout(d.ecs_len, d.num_tiles, d.num_segments, d.total_blocks);
+  const ScratchLayout lay = LayoutOf(d);
   const HuffTables *H = reinterpret_cast<const HuffTables *>(TablesBase(descs, d, false));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   CopyHalfTables<kBlockThreads>(T, H, 2);  // the AC tables
@@ -814,6 +939,8 @@ __global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHu
     G.use_rect = use_rect;
     G.total_starts = ((const GlobalI32 *)d.scratch)[2];
     G.fused = d.plane[d.comp_of_block[0]] != nullptr;
+    G.interval_blocks = d.restart_interval * d.blocks_per_mcu;
+    for (int k = 0; k < d.blocks_per_mcu; k++) G.klast[d.comp_of_block[k]] = (uint8_t)k;
     int n0 = 0;
     for (int k = 0; k < d.blocks_per_mcu; k++)
       if ((d.ac_sel[d.comp_of_block[k]] & 1) == 0) G.klist[n0++] = (uint8_t)k;
@@ -845,14 +972,14 @@ __global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHu
   // round trip (three dependent ones otherwise: block arrays, segment totals, stream).
   struct Prepared {
     uint64_t info;
-    int ordinal, comp, acs, dc, seg;
+    int ordinal, comp, acs, dc, seg, seg0;
     uint32_t pos;
     bool needed;
     BitWindow win;
   };
   auto stage_a = [&](int t) -> Prepared {
     Prepared p;
-    p.needed = false; p.info = 0; p.ordinal = 0; p.comp = 0; p.acs = 0; p.dc = 0; p.seg = 0; p.pos = 0;
+    p.needed = false; p.info = 0; p.ordinal = 0; p.comp = 0; p.acs = 0; p.dc = 0; p.seg = 0; p.seg0 = 0; p.pos = 0;
     p.win = BitWindow{0, 0, 0, 0, 0};
     if (t >= my0 + my1) return p;
     const bool cls = t >= my0;
@@ -873,6 +1000,16 @@ __global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHu
       p.pos = blk_pos[ordinal];
       p.dc = blk_dc[ordinal];
       p.seg = blk_seg[ordinal];
+      if (G.interval_blocks) {
+        // restart intervals: the DC prediction starts at zero in every interval.  DcKernel's sums run through the whole
+        // stream; what lies in front of the interval is the sum at the component's last block of the MCU before it
+        const int first = ordinal / G.interval_blocks * G.interval_blocks;
+        if (first > 0) {
+          const int q = first - bpm + G.klast[comp];
+          p.dc -= blk_dc[q];
+          p.seg0 = blk_seg[q];
+        }
+      }
     }
     return p;
   };
@@ -881,7 +1018,7 @@ __global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHu
     p.win = OpenWindow(words, p.pos);
     // DC level: the block's level inside its segment + the differences of all the segments before (an image is a
     // handful of segments; only a stream of many megabytes makes this loop long)
-    for (int s = 0; s < p.seg; s++) p.dc += segs_i[s * kSegRecInts + kSegRecDcTotal + p.comp];
+    for (int s = p.seg0; s < p.seg; s++) p.dc += segs_i[s * kSegRecInts + kSegRecDcTotal + p.comp];
   };
   // The lane's own block, start to end in its registers: dequantisation, the eight column passes, the eight row passes
   // of the islow IDCT, eight 8-byte row stores.  (Round 2 spread a block over 8 lanes with an int32 transpose through
@@ -959,9 +1096,14 @@ __global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHu
 extern "C" {
 
 daliamdResult_t daliamdJpegHuffmanScratchBytes(int ecs_len, int total_blocks, size_t *bytes) {
-  DALIAMD_REQUIRE(ecs_len >= 0 && total_blocks >= 0 && bytes, DALIAMD_ERROR_INVALID_ARGUMENT,
+  return daliamdJpegHuffmanScratchBytesRestart(ecs_len, total_blocks, 0, bytes);
+}
+
+daliamdResult_t daliamdJpegHuffmanScratchBytesRestart(int ecs_len, int total_blocks, int num_intervals, size_t *bytes) {
+  DALIAMD_REQUIRE(ecs_len >= 0 && total_blocks >= 0 && num_intervals >= 0 && bytes, DALIAMD_ERROR_INVALID_ARGUMENT,
                   "daliamdJpegHuffmanScratchBytes: invalid argument");
-  *bytes = daliamd::MakeLayout(ecs_len, daliamd::NumTiles(15, ecs_len), daliamd::NumSegments(ecs_len), total_blocks).total;
+  *bytes = daliamd::MakeLayout(ecs_len, daliamd::NumTiles(15, ecs_len), daliamd::NumSegments(ecs_len), total_blocks,
+                               num_intervals).total;
   return DALIAMD_SUCCESS;
 }
 
@@ -1006,9 +1148,8 @@ daliamdResult_t daliamdJpegHuffmanSetup(daliamdJpegHuffDesc *descs_host, int n, 
                         "daliamdJpegHuffmanSetup: sample %d: coefficient arrays must be 16-byte aligned", i);
       }
     }
-    for (int t = 0; t < 4; t++)  // a block takes at least four bits then: bounds the block-start lists
-      DALIAMD_REQUIRE(d.bits[t][0] == 0, DALIAMD_ERROR_UNSUPPORTED,
-                      "daliamdJpegHuffmanSetup: sample %d: Huffman table %d has a 1-bit code (decode it on the host)", i, t);
+    DALIAMD_REQUIRE(d.restart_interval >= 0 && d.restart_interval <= 65535, DALIAMD_ERROR_INVALID_ARGUMENT,
+                    "daliamdJpegHuffmanSetup: sample %d: restart interval %d", i, d.restart_interval);
     d.tile_start = tiles;
     d.num_tiles = daliamd::NumTiles((int)(reinterpret_cast<uintptr_t>(d.ecs) & 15), d.ecs_len);
     d.seg_start = segs;

@@ -150,10 +150,14 @@ void TensorList::ShareData(const TensorList &o) {
 }
 
 // ------------------------------------------------------------------------------------------ ThreadPool
-ThreadPool::ThreadPool(int n, const std::vector<int> &cpus) {
+void NameThisThread(const std::string &name) { pthread_setname_np(pthread_self(), name.substr(0, 15).c_str()); }
+
+ThreadPool::ThreadPool(int n, const std::vector<int> &cpus, const char *name) {
   n = std::max(1, n);
+  const std::string base = name;
   for (int i = 0; i < n; i++)
-    threads_.emplace_back([this, i, cpus] {
+    threads_.emplace_back([this, i, cpus, base] {
+      NameThisThread(base + std::to_string(i));
       BindThisThread(cpus);
       Loop(i);
     });

@@ -174,7 +174,8 @@ class ThreadPool {
  public:
   // cpus: when not empty, every worker is bound to this CPU set (Pipeline(set_affinity=True): the cores local to the
   // GPU's NUMA node; the reference binds through NVML, dali/pipeline/util/thread_pool.cc)
-  explicit ThreadPool(int num_threads, const std::vector<int> &cpus = {});
+  // name: the workers show up as <name><index> in /proc/<pid>/task/*/comm (15 characters: tools, bench.py's CPU account)
+  explicit ThreadPool(int num_threads, const std::vector<int> &cpus = {}, const char *name = "dali-pool");
   ~ThreadPool();
   using Work = std::function<void(int)>;   // argument: worker index in [0, NumThreads()]; NumThreads() = the thread that called RunAll
   void AddWork(Work w, int64_t priority = 0);
@@ -213,6 +214,8 @@ std::vector<int> DeviceLocalCpus(int device_id);
 std::vector<int> ParseCpuList(const std::string &list);
 // binds the calling thread to `cpus` (no-op for an empty set)
 void BindThisThread(const std::vector<int> &cpus);
+// names the calling thread (pthread_setname_np; truncated to 15 characters)
+void NameThisThread(const std::string &name);
 
 // ---------------------------------------------------------------------------------------------
 // Arguments, OpSchema, OpSpec

@@ -181,6 +181,8 @@ struct Decoder {
   bool analyze_only = false;                // stop at the first SOS and report it instead of decoding
   int num_scans = 0;
   size_t first_ecs = 0;
+  // what the markers in front of SOF said (daliamdJpegParse stops there; a run that goes on to SOS reports the same)
+  struct AtSof { bool jfif, adobe; int adobe_transform, orientation, restart_interval; } at_sof{false, false, 0, 1, 0};
 
   static int R16(const uint8_t *p) { return (p[0] << 8) | p[1]; }
 
@@ -483,6 +485,7 @@ struct Decoder {
         case 0xC0: case 0xC1: case 0xC2:
           if (have_frame) return Fail("multiple SOF markers");
           rc = ParseSof(p, plen, m == 0xC2);
+          at_sof = AtSof{jfif, adobe, adobe_transform, orientation, restart_interval};
           if (!rc && headers_only) return 0;
           break;
         case 0xC3: case 0xC5: case 0xC6: case 0xC7: case 0xC9: case 0xCA: case 0xCB: case 0xCD: case 0xCE:
@@ -526,7 +529,7 @@ void FillInfo(const Decoder &d, daliamdJpegInfo *info) {
   memset(info, 0, sizeof(*info));
   info->width = d.width; info->height = d.height; info->num_components = d.ncomp;
   info->progressive = d.progressive; info->hmax = d.hmax; info->vmax = d.vmax;
-  info->orientation = d.orientation; info->restart_interval = d.restart_interval;
+  info->orientation = d.at_sof.orientation; info->restart_interval = d.at_sof.restart_interval;
   for (int i = 0; i < d.ncomp; i++) {
     info->h_samp[i] = d.comp[i].h; info->v_samp[i] = d.comp[i].v;
     info->blocks_x[i] = d.comp[i].bx; info->blocks_y[i] = d.comp[i].by;
@@ -536,14 +539,14 @@ void FillInfo(const Decoder &d, daliamdJpegInfo *info) {
   if (d.ncomp == 1) info->color = 0;
   else if (d.ncomp == 3) {
     bool rgb;
-    if (d.jfif) rgb = false;
-    else if (d.adobe) rgb = d.adobe_transform == 0;
+    if (d.at_sof.jfif) rgb = false;
+    else if (d.at_sof.adobe) rgb = d.at_sof.adobe_transform == 0;
     else rgb = d.comp[0].id == 'R' && d.comp[1].id == 'G' && d.comp[2].id == 'B';
     info->color = rgb ? 2 : 1;
   } else if (d.ncomp == 4) {
     // four components: CMYK, or YCCK when the Adobe marker says transform 2 (jdapimin.c default_decompress_parms);
     // samples written by Adobe software are stored inverted (flag 8)
-    info->color = (d.adobe && d.adobe_transform == 2 ? 4 : 3) | (d.adobe ? 8 : 0);
+    info->color = (d.at_sof.adobe && d.at_sof.adobe_transform == 2 ? 4 : 3) | (d.at_sof.adobe ? 8 : 0);
   } else {
     info->color = -1;
   }
@@ -567,28 +570,22 @@ int daliamdJpegParse(const uint8_t *data, size_t size, daliamdJpegInfo *info) {
   return 0;
 }
 
-int daliamdJpegAnalyzeScan(const uint8_t *data, size_t size, const daliamdJpegInfo *info, daliamdJpegScan *scan) {
-  using namespace daliamd_host;
-  if (!data || !info || !scan) return Fail("daliamdJpegAnalyzeScan: NULL argument");
+namespace daliamd_host {
+namespace {
+// What the GPU entropy decoder needs to know about the (first) scan: eligibility, MCU structure, DHT / DQT contents,
+// where the entropy-coded segment starts.  `d` has run up to the SOS header (analyze_only).
+void FillScan(const Decoder &d, daliamdJpegScan *scan) {
   memset(scan, 0, sizeof(*scan));
-  Decoder d;
-  d.data = data; d.size = size;
-  d.analyze_only = true;
-  int rc = d.Run(false);
-  if (rc) return rc;
-  if (d.num_scans != 1 || d.progressive || d.restart_interval != 0 || d.ns != d.ncomp || (d.ncomp != 1 && d.ncomp != 3))
-    return 0;  // not eligible (scan->eligible stays 0)
+  if (d.num_scans != 1 || d.progressive || d.ns != d.ncomp || (d.ncomp != 1 && d.ncomp != 3)) return;  // not eligible
   for (int s = 0; s < d.ns; s++)
-    if (d.scomp[s] != s) return 0;  // components out of order: leave it to the host decoder
+    if (d.scomp[s] != s) return;  // components out of order: leave it to the host decoder
   int bpm = 0;
   for (int c = 0; c < d.ncomp; c++) {
-    if (d.std_[c] > 1 || d.sta[c] > 1) return 0;  // the kernel keeps two DC + two AC tables (baseline limit)
-    // the kernel's record buffer is sized for symbols of at least two bits
-    if (d.dc[d.std_[c]].bits[1] != 0 || d.ac[d.sta[c]].bits[1] != 0) return 0;
-    if (!d.dc[d.std_[c]].present || !d.ac[d.sta[c]].present || !d.qt_present[d.comp[c].tq]) return 0;
+    if (d.std_[c] > 1 || d.sta[c] > 1) return;  // the kernel keeps two DC + two AC tables (baseline limit)
+    if (!d.dc[d.std_[c]].present || !d.ac[d.sta[c]].present || !d.qt_present[d.comp[c].tq]) return;
     for (int v = 0; v < d.comp[c].v; v++)
       for (int h = 0; h < d.comp[c].h; h++) {
-        if (bpm >= 10) return 0;
+        if (bpm >= 10) return;
         scan->comp_of_block[bpm] = (uint8_t)c; scan->h_of_block[bpm] = (uint8_t)h; scan->v_of_block[bpm] = (uint8_t)v;
         bpm++;
       }
@@ -602,20 +599,56 @@ int daliamdJpegAnalyzeScan(const uint8_t *data, size_t size, const daliamdJpegIn
   scan->blocks_per_mcu = bpm;
   scan->mcus_x = (d.width + 8 * d.hmax - 1) / (8 * d.hmax);
   scan->mcus_y = (d.height + 8 * d.vmax - 1) / (8 * d.vmax);
-  // entropy-coded segment: from the end of the SOS header to the next real marker
+  scan->restart_interval = d.restart_interval;
+  scan->ecs_offset = (int64_t)d.first_ecs;
+  scan->ecs_length = (int64_t)(d.size - d.first_ecs);   // everything behind the SOS header
+  scan->length_is_upper_bound = 1;
+  scan->eligible = 1;
+}
+}  // namespace
+}  // namespace daliamd_host
+
+int daliamdJpegAnalyzeScan(const uint8_t *data, size_t size, const daliamdJpegInfo *info, daliamdJpegScan *scan) {
+  using namespace daliamd_host;
+  if (!data || !info || !scan) return Fail("daliamdJpegAnalyzeScan: NULL argument");
+  memset(scan, 0, sizeof(*scan));
+  Decoder d;
+  d.data = data; d.size = size;
+  d.analyze_only = true;
+  int rc = d.Run(false);
+  if (rc) return rc;
+  FillScan(d, scan);
+  if (!scan->eligible) return 0;
+  // entropy-coded segment: from the end of the SOS header to the next real marker (RSTn belong to the segment)
   size_t q = d.first_ecs;
+  bool rst_seen = false;
   while (q + 1 < size) {  // memchr: about one byte in 256 is 0xFF, the rest is skipped at memory speed
     const void *hit = memchr(data + q, 0xFF, size - 1 - q);
     if (!hit) { q = size; break; }
     q = (size_t)(static_cast<const uint8_t *>(hit) - data);
-    if (data[q + 1] != 0 && data[q + 1] != 0xFF) break;
+    const uint8_t m = data[q + 1];
+    if (m >= 0xD0 && m <= 0xD7) rst_seen = true;
+    else if (m != 0 && m != 0xFF) break;
     q++;
   }
   if (q + 1 >= size) q = size;
-  if (q < size && data[q] == 0xFF && data[q + 1] >= 0xD0 && data[q + 1] <= 0xD7) return 0;  // RST without DRI: host path
-  scan->ecs_offset = (int64_t)d.first_ecs;
+  if (rst_seen && d.restart_interval == 0) { scan->eligible = 0; return 0; }  // RST without DRI: host path
   scan->ecs_length = (int64_t)(q - d.first_ecs);
-  scan->eligible = 1;
+  scan->length_is_upper_bound = 0;
+  return 0;
+}
+
+int daliamdJpegAnalyzeHeader(const uint8_t *data, size_t size, daliamdJpegInfo *info, daliamdJpegScan *scan) {
+  using namespace daliamd_host;
+  if (!data || !info || !scan) return Fail("daliamdJpegAnalyzeHeader: NULL argument");
+  memset(scan, 0, sizeof(*scan));
+  Decoder d;
+  d.data = data; d.size = size;
+  d.analyze_only = true;
+  int rc = d.Run(false);
+  if (rc) return rc;
+  FillInfo(d, info);
+  if (d.num_scans == 1 && info->num_components != 4) FillScan(d, scan);
   return 0;
 }
 

@@ -232,15 +232,18 @@ class ImageDecoderMixed : public OperatorBase {
       }
       ws.GetThreadPool().AddWork([&, i](int) {
         const uint8_t *data = static_cast<const uint8_t *>(in.raw(i));
-        if (daliamdJpegParse(data, in.nbytes(i), &infos_[i]) != 0)
-          DALI_FAIL("Failed to parse ", src(i), ": ", daliamdHostGetLastErrorMessage());
-        scans_[i].eligible = 0;
-        if (infos_[i].num_components == 4) return;  // CMYK / YCCK: the host decodes these (below)
+        // ONE pass over the headers, up to SOS: frame geometry + what the GPU entropy decoder needs.  The scan itself is
+        // not walked here - its end (the first marker that is not RSTn) is found by the un-stuffing kernel, which
+        // looks at every byte anyway (the memchr walk was two thirds of this operator's host time per sample).
+        if (host_huffman_only_ || daliamdJpegAnalyzeHeader(data, in.nbytes(i), &infos_[i], &scans_[i]) != 0) {
+          scans_[i].eligible = 0;  // (a broken table or SOS header: the host decoder will produce the diagnosis)
+          if (daliamdJpegParse(data, in.nbytes(i), &infos_[i]) != 0)
+            DALI_FAIL("Failed to parse ", src(i), ": ", daliamdHostGetLastErrorMessage());
+        }
+        if (infos_[i].num_components == 4) { scans_[i].eligible = 0; return; }  // CMYK / YCCK: the host decodes these (below)
         DALI_ENFORCE(infos_[i].num_components == 1 || infos_[i].num_components == 3, "Failed to decode ", src(i),
                      ": JPEG with ", infos_[i].num_components, " components is not supported");
-        if (!host_huffman_only_ && (int64_t)infos_[i].width * infos_[i].height >= huffman_threshold_ &&
-            daliamdJpegAnalyzeScan(data, in.nbytes(i), &infos_[i], &scans_[i]) != 0)
-          scans_[i].eligible = 0;  // the host decoder will produce the diagnosis
+        if ((int64_t)infos_[i].width * infos_[i].height < huffman_threshold_) scans_[i].eligible = 0;
         if (scans_[i].eligible && !direct)
           memcpy(static_cast<uint8_t *>(ecs_stage.data()) + ecs_off_[i], data + scans_[i].ecs_offset,
                  (size_t)scans_[i].ecs_length);
@@ -330,8 +333,9 @@ class ImageDecoderMixed : public OperatorBase {
       if (scan(i).eligible) {
         DALI_ENFORCE(scan(i).ecs_length < (int64_t)1 << 30, "Failed to decode ", src(i), ": entropy-coded segment too long");
         size_t need = 0;
-        KCHECK(daliamdJpegHuffmanScratchBytes((int)scan(i).ecs_length,
-                                              scan(i).mcus_x * scan(i).mcus_y * scan(i).blocks_per_mcu, &need));
+        const int mcus = scan(i).mcus_x * scan(i).mcus_y, ri = scan(i).restart_interval;
+        KCHECK(daliamdJpegHuffmanScratchBytesRestart((int)scan(i).ecs_length, mcus * scan(i).blocks_per_mcu,
+                                                     ri > 0 ? (mcus + ri - 1) / ri : 0, &need));
         scratch_off_[i] = scratch_bytes;
         scratch_bytes += need;
         gpu_samples_.push_back(i);
@@ -449,6 +453,7 @@ class ImageDecoderMixed : public OperatorBase {
         d.blocks_per_mcu = sc.blocks_per_mcu;
         d.mcus_x = sc.mcus_x;
         d.total_blocks = sc.mcus_x * sc.mcus_y * sc.blocks_per_mcu;
+        d.restart_interval = sc.restart_interval;
         for (int c = 0; c < inf.num_components; c++) {
           d.coef[c] = coef + coef_off_[i * 3 + c];
           // fused output: the decoder dequantises + inverse-transforms its blocks and writes the planes itself
@@ -486,8 +491,11 @@ class ImageDecoderMixed : public OperatorBase {
           if (st[j] != 0 && scache) scache->Invalidate(names[j]);
         for (size_t j = 0; j < names.size(); j++)
           if (st[j] != 0)
-            DALI_FAIL("Failed to decode ", names[j], ": corrupt JPEG data: the entropy-coded segment ends before the "
-                      "last MCU (GPU Huffman status ", st[j], ")");
+            DALI_FAIL("Failed to decode ", names[j], ": corrupt JPEG data: ",
+                      st[j] == 3 ? "restart markers in a stream without a restart interval"
+                      : st[j] == 4 ? "a restart interval does not end where its marker is"
+                                   : "the entropy-coded segment ends before the last MCU",
+                      " (GPU Huffman status ", st[j], ")");
       });
     }
     // ---- dequantisation + IDCT, upsampling + colour conversion: descriptors ----

@@ -363,7 +363,9 @@ class FileReaderOp : public OperatorBase {
     if (const char *e = getenv("DALI_AMD_READER_FD_CAP")) fd_cap_ = (size_t)std::max(1, atoi(e));   // (tests: forces evictions)
     int workers = std::max(1, (int)spec.GetInt("num_threads"));
     if (const char *e = getenv("DALI_AMD_READER_THREADS")) workers = std::max(1, atoi(e));
-    num_workers_ = std::min(workers, 16);
+    // eight readers copy a 25 MB batch out of the page cache in 0.3 ms; more only contend inside the kernel (MI355X host,
+    // 16-CPU quota: 6 / 8 / 12 / 16 readers spend 3.4 / 2.8 / 5.5 / 6.2 ms of CPU per batch, gpurun_out/r4d)
+    num_workers_ = getenv("DALI_AMD_READER_THREADS") ? std::min(workers, 64) : std::min(workers, 8);
   }
 
   ~FileReaderOp() override {
@@ -432,8 +434,9 @@ class FileReaderOp : public OperatorBase {
     if (started_) return;
     stop_ = false;
     started_ = true;
-    planner_ = std::thread([this] { PlannerLoop(); });
-    for (int i = 0; i < num_workers_; i++) workers_.emplace_back([this] { WorkerLoop(); });
+    planner_ = std::thread([this] { NameThisThread("dali-rd-plan"); PlannerLoop(); });
+    for (int i = 0; i < num_workers_; i++)
+      workers_.emplace_back([this, i] { NameThisThread("dali-rd" + std::to_string(i)); WorkerLoop(); });
   }
   void StopThreads() {
     {

@@ -155,8 +155,8 @@ void Pipeline::Build(const std::vector<std::pair<std::string, std::string>> &out
   // set_affinity: worker threads (and with them the first touch of their pinned staging buffers) stay on the
   // GPU's NUMA node - with 8 GPUs behind two sockets the H2D copies otherwise cross the socket link
   if (params_.set_affinity && needs_gpu) local_cpus_ = DeviceLocalCpus(params_.device_id);
-  thread_pool_ = std::make_unique<ThreadPool>(params_.num_threads, local_cpus_);
-  cpu_thread_pool_ = std::make_unique<ThreadPool>(params_.num_threads, local_cpus_);
+  thread_pool_ = std::make_unique<ThreadPool>(params_.num_threads, local_cpus_, "dali-devpool");
+  cpu_thread_pool_ = std::make_unique<ThreadPool>(params_.num_threads, local_cpus_, "dali-cpupool");
   // instantiate operators (InstantiateOperator, operator.cc:157-169) and their output rings
   for (auto &n : nodes_) {
     try {
@@ -217,8 +217,8 @@ void Pipeline::Build(const std::vector<std::pair<std::string, std::string>> &out
     }
   built_ = true;
   if (params_.exec_async) {
-    cpu_worker_ = std::thread([this] { BindThisThread(local_cpus_); CpuWorkerLoop(); });
-    worker_ = std::thread([this] { BindThisThread(local_cpus_); DeviceWorkerLoop(); });
+    cpu_worker_ = std::thread([this] { NameThisThread("dali-cpustage"); BindThisThread(local_cpus_); CpuWorkerLoop(); });
+    worker_ = std::thread([this] { NameThisThread("dali-devstage"); BindThisThread(local_cpus_); DeviceWorkerLoop(); });
   }
 }
 

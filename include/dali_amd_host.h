@@ -77,8 +77,9 @@ DALIAMD_HOST_API int daliamdConvertRgbRows(const uint8_t *rgb, int64_t in_pitch,
                                           uint8_t *out, int64_t out_pitch);
 
 /* Scan analysis for the GPU entropy decoder (libdali_amd_kernels: daliamdJpegHuffman*).  A stream is eligible
- * when it is baseline (SOF0/SOF1), has ONE scan that interleaves all components (or is grayscale), and uses no
- * restart markers; everything else (progressive, multi-scan, DRI) goes through daliamdJpegDecodeCoefficients. */
+ * when it is baseline (SOF0/SOF1) and has ONE scan that interleaves all components (or is grayscale), with or without
+ * restart intervals; everything else (progressive, multi-scan, more than two tables per class) goes through
+ * daliamdJpegDecodeCoefficients. */
 typedef struct {
   int32_t eligible;
   int32_t blocks_per_mcu, mcus_x, mcus_y;
@@ -89,9 +90,19 @@ typedef struct {
   uint8_t dc_bits[4][16], dc_vals[4][256]; /* DHT contents per slot (class 0) */
   uint8_t ac_bits[4][16], ac_vals[4][256]; /* DHT contents per slot (class 1) */
   uint16_t quant[4][64];              /* per component, column-major element order (as daliamdJpegIdctDesc.quant) */
+  int32_t restart_interval;           /* DRI: MCUs per restart interval, 0 = none (-> daliamdJpegHuffDesc.restart_interval) */
+  int32_t length_is_upper_bound;      /* ecs_length runs to the end of the stream; the segment ends at the first marker
+                                         that is not RSTn, which the GPU decoder's un-stuffing pass finds by itself */
 } daliamdJpegScan;
+/* Walks the scan: ecs_length is exact (one memchr pass over the entropy-coded bytes). */
 DALIAMD_HOST_API int daliamdJpegAnalyzeScan(const uint8_t *data, size_t size, const daliamdJpegInfo *info,
                                            daliamdJpegScan *scan);
+/* Header parse and scan analysis in ONE pass that stops at the SOS header (a few hundred bytes): fills `info` like
+ * daliamdJpegParse and `scan` like daliamdJpegAnalyzeScan, except that ecs_length is "the rest of the stream"
+ * (length_is_upper_bound = 1).  This is what decoders.image(device="mixed") runs per sample: the bytes of the scan are
+ * first looked at on the device. */
+DALIAMD_HOST_API int daliamdJpegAnalyzeHeader(const uint8_t *data, size_t size, daliamdJpegInfo *info,
+                                             daliamdJpegScan *scan);
 
 /* ----------------------------------------------------------------------------------------------
  * Random machinery, bit-compatible with the reference's host code.

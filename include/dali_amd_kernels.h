@@ -133,23 +133,30 @@ DALIAMD_API daliamdResult_t daliamdJpegIdctRun(daliamdStream_t stream, const dal
                                                int n, int num_workgroups);
 
 /* ----------------------------------------------------------------------------------------------
- * JPEG Huffman entropy decoding on the GPU (baseline, one interleaved scan, no restart markers).
+ * JPEG Huffman entropy decoding on the GPU (baseline, one interleaved scan, with or without restart intervals).
  * Replaces the GPU Huffman stage nvJPEG runs for device="mixed" when the stream is larger than
  * hybrid_huffman_threshold (dali/operators/imgcodec/image_decoder.h:810-815,
  * dali/operators/imgcodec/decoder_schema.cc "hybrid_huffman_threshold").  Output layout and values
  * are those of daliamdJpegDecodeCoefficients (dali_amd_host.h), i.e. the input of daliamdJpegIdctRun.
- * The caller fills the descriptor from the scan analysis (daliamdJpegAnalyzeScan) and
- *   - uploads the entropy-coded segment (without the trailing marker) to `ecs`; the bytes up to the next
- *     16-byte boundary behind it must be readable,
+ * The caller fills the descriptor from the scan analysis (daliamdJpegAnalyzeScan / daliamdJpegAnalyzeHeader) and
+ *   - uploads the entropy-coded segment to `ecs`; the bytes up to the next 16-byte boundary behind it must be
+ *     readable.  The segment ENDS at the first marker that is not RSTn (0xFF followed by anything but 0x00, 0xFF,
+ *     0xD0-0xD7): the un-stuffing pass finds it, so `ecs_len` may include the EOI marker and whatever follows it -
+ *     "the rest of the file" - and the host never has to walk the scan,
  *   - zero-fills `status` before the launch (the coefficient arrays need no initialisation: every block that is
  *     decoded is written exactly once, as a full 128-byte line),
- *   - provides `scratch`: daliamdJpegHuffmanScratchBytes(ecs_len, total_blocks) bytes, 16-byte aligned (clean
- *     stream, code tables, per-slice decoder states, the block starts of every segment, 10 bytes per block),
+ *   - provides `scratch`: daliamdJpegHuffmanScratchBytes(ecs_len, total_blocks) bytes (streams with restart
+ *     intervals: daliamdJpegHuffmanScratchBytesRestart), 16-byte aligned (clean stream, code tables, per-slice
+ *     decoder states, the block starts of every segment, 10 bytes per block, 4 bytes per restart interval),
  *   - calls daliamdJpegHuffmanSetup on the host table, copies it to the device, calls daliamdJpegHuffmanRun.
  * The work is cut into image-independent pieces (8 KB tiles for the byte un-stuffing, 61 KB segments of 256-byte
  * slices for the self-synchronising parallel decode, one lane per 8x8 block for the values), so a batch of very differently sized streams still fills
- * the device.  After the launch *status is 0 on success, 2 when the segment holds fewer blocks than the frame
- * header promises (truncated / corrupt stream: decode it with the host decoder to get the diagnosis).
+ * the device.  Restart intervals: the RSTn markers are removed with the byte stuffing and every boundary is a point
+ * where the parallel decode knows its state; the DC predictions restart per interval.
+ * After the launch *status is 0 on success, 2 when the segment holds fewer blocks than the frame
+ * header promises (truncated / corrupt stream: decode it with the host decoder to get the diagnosis), 3 when RSTn
+ * markers turn up in a stream whose header announces none, 4 when a restart interval does not end the way T.81
+ * F.1.2.3 prescribes (wrong MCU count or a padding that is not one-bits).
  * -------------------------------------------------------------------------------------------- */
 #define DALIAMD_JPEG_MAX_BLOCKS_PER_MCU 10
 typedef struct {
@@ -184,13 +191,15 @@ typedef struct {
    * disappear.  plane[c] must be 8-byte aligned, plane_pitch[c] a multiple of 8 (>= blocks_x[c] * 8). */
   uint8_t *plane[3];
   int32_t plane_pitch[3];
-  int32_t reserved2;
+  int32_t restart_interval; /* MCUs per restart interval (DRI), 0: the stream has no RSTn markers  */
   uint16_t quant[3][64];   /* per component, column-major element order as daliamdJpegIdctDesc.quant */
 } daliamdJpegHuffDesc;
 
 DALIAMD_API daliamdResult_t daliamdJpegHuffmanScratchBytes(int ecs_len, int total_blocks, size_t *bytes);
-/* Validates the table (DALIAMD_ERROR_UNSUPPORTED for a Huffman table with a 1-bit code: use the host decoder), fills
- * tile_start/num_tiles/seg_start/num_segments/blk_wg_start, returns the three grid sizes. */
+/* num_intervals = ceil(MCUs of the frame / restart_interval), 0 without restart intervals */
+DALIAMD_API daliamdResult_t daliamdJpegHuffmanScratchBytesRestart(int ecs_len, int total_blocks, int num_intervals,
+                                                                  size_t *bytes);
+/* Validates the table, fills tile_start/num_tiles/seg_start/num_segments/blk_wg_start, returns the three grid sizes. */
 DALIAMD_API daliamdResult_t daliamdJpegHuffmanSetup(daliamdJpegHuffDesc *descs_host, int n, int *num_tiles,
                                                     int *num_segments, int *num_block_workgroups);
 /* Six launches: prepare (un-stuff count + code tables), un-stuff scatter, synchronise (positions + block starts),

@@ -17,7 +17,7 @@ def _decode_gpu(enc, **kw):
     return [v.cpu().numpy() for v in views]
 
 
-@pytest.mark.parametrize("huffman", ["gpu", "host"])
+@pytest.mark.parametrize("huffman", ["gpu", "gpu-header-only", "host"])
 def test_decode_matches_oracle_all_modes(huffman):
     rng = np.random.default_rng(7)
     enc = []
@@ -29,17 +29,22 @@ def test_decode_matches_oracle_all_modes(huffman):
             enc.append(encode_jpeg(synth_image(rng, h, w), **({"quality": 85} | kw)))
         enc.append(encode_jpeg(synth_image(rng, h, w, 1), 80))
         enc.append(encode_jpeg(synth_image(rng, h, w, 1), 80, progressive=True))
-    got = _decode_gpu(enc, huffman=huffman)
+        enc.append(encode_jpeg(synth_image(rng, h, w, 1), 80, restart_marker_blocks=2))
+        enc.append(encode_jpeg(synth_image(rng, h, w), 70, subsampling="4:4:4", restart_marker_rows=1) + b"\xff\xd8tail" * 9)
+    # "gpu-header-only": what decoders.image does - the host parses the headers only, the segment handed to the kernels is
+    # everything behind SOS (EOI marker, trailing bytes) and the un-stuffing pass finds where it ends
+    kw = dict(huffman="gpu", exact_scan=False) if huffman == "gpu-header-only" else dict(huffman=huffman)
+    got = _decode_gpu(enc, **kw)
     for i, e in enumerate(enc):
         ref = O.jpeg_decode_rgb(e)
         assert got[i].shape == ref.shape
         assert np.array_equal(got[i], ref), f"sample {i}: max diff {np.abs(got[i].astype(int) - ref).max()}"
 
 
-def _coefficients(enc, huffman):
+def _coefficients(enc, huffman, exact_scan=True):
     """Raw entropy-decoder output (int16 coefficient arrays) of both decoders."""
     from dali_amd import backend as B
-    plan = B.JpegBatchPlan(enc)
+    plan = B.JpegBatchPlan(enc, exact_scan=exact_scan)
     if huffman == "gpu":
         coef = torch.full((max(plan.coef_elems, 1),), 0x5555, dtype=torch.int16, device="cuda")  # the decoder zero-fills
         status, sel = plan.entropy_decode_gpu(coef)
@@ -51,7 +56,8 @@ def _coefficients(enc, huffman):
     return coef.numpy(), plan
 
 
-def test_gpu_huffman_coefficients_equal_host_decoder():
+@pytest.mark.parametrize("exact_scan", [True, False])
+def test_gpu_huffman_coefficients_equal_host_decoder(exact_scan):
     """The GPU entropy decoder must reproduce the host decoder's coefficient arrays exactly: sizes from one
     block to 6 MP, every subsampling, optimised Huffman tables, flat images (which never self-synchronise and
     exercise the relaxation's worst case) and noise at quality 100 (long codes, many stuffed bytes)."""
@@ -69,10 +75,20 @@ def test_gpu_huffman_coefficients_equal_host_decoder():
     half = synth_image(rng, 300, 400)
     half[:, 200:] = 7                                                                       # half flat
     enc.append(encode_jpeg(half, 85))
-    got, plan = _coefficients(enc, "gpu")
-    # everything goes through the GPU decoder except streams whose (optimised) Huffman tables contain a 1-bit code:
-    # those take the host decoder by design (the record buffer is sized for symbols of >= 2 bits)
-    assert plan.gpu_eligible.sum() >= len(enc) - 12
+    # restart intervals: one MCU, a few MCUs, rows, intervals longer than a 61 KB segment; flat gray content whose
+    # MCUs are shorter than a byte; a flat image with optimised tables (a 1-bit code) - all on the GPU decoder
+    for (h, w), kw in [((375, 500), dict(restart_marker_blocks=1)), ((375, 500), dict(restart_marker_blocks=5)),
+                       ((500, 375), dict(restart_marker_rows=1, subsampling="4:4:4")),
+                       ((1080, 1920), dict(restart_marker_rows=2)), ((1080, 1920), dict(restart_marker_rows=40, quality=95)),
+                       ((64, 48), dict(restart_marker_blocks=2, subsampling="4:2:2", optimize=True))]:
+        enc.append(encode_jpeg(synth_image(rng, h, w), **({"quality": 85} | kw)))
+    flat_gray = np.full((256, 1024), 128, np.uint8)
+    flat_gray[:, 700:] = rng.integers(0, 255, (256, 324))
+    enc.append(encode_jpeg(flat_gray, 75, restart_marker_blocks=3))
+    enc.append(encode_jpeg(np.full((128, 192, 3), 90, np.uint8), 75, optimize=True))
+    enc.append(encode_jpeg(synth_image(rng, 300, 200), 85) + bytes(5000))                  # bytes behind EOI
+    got, plan = _coefficients(enc, "gpu", exact_scan)
+    assert plan.gpu_eligible.all(), "every baseline single-scan stream takes the GPU decoder"
     ref, _ = _coefficients(enc, "host")
     assert got.shape == ref.shape
     if not np.array_equal(got, ref):
@@ -121,7 +137,7 @@ def test_gpu_huffman_eligibility_and_mixed_batches():
            encode_jpeg(img[..., 0], 85), encode_jpeg(img, 85, optimize=True)]
     from dali_amd import backend as B
     plan = B.JpegBatchPlan(enc)
-    assert plan.analyze_scans().tolist() == [True, False, False, True, True]
+    assert plan.analyze_scans().tolist() == [True, False, True, True, True]
     got = _decode_gpu(enc, huffman="gpu")
     for i, e in enumerate(enc):
         assert np.array_equal(got[i], O.jpeg_decode_rgb(e)), f"sample {i}"

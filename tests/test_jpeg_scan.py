@@ -39,7 +39,8 @@ def test_eligibility_rules():
     assert _analyze(encode_jpeg(img, 85, optimize=True))[2].eligible == 1
     assert _analyze(encode_jpeg(img[..., 0], 85))[2].eligible == 1
     assert _analyze(encode_jpeg(img, 85, progressive=True))[2].eligible == 0
-    assert _analyze(encode_jpeg(img, 85, restart_marker_blocks=2))[2].eligible == 0
+    rst = _analyze(encode_jpeg(img, 85, restart_marker_blocks=2))[2]
+    assert rst.eligible == 1 and rst.restart_interval == 2
 
 
 def test_scan_geometry_tables_and_segment_bounds():
@@ -71,5 +72,33 @@ def test_golden_files_classification():
         seen[os.path.basename(path)] = _analyze(e)[2].eligible
     assert any(seen.values()) and not all(seen.values())
     for name, eligible in seen.items():
-        if "prog" in name or "rst" in name:
+        if "prog" in name:
             assert eligible == 0, name
+        if "rst" in name:     # restart intervals run on the GPU decoder since round 4
+            assert eligible == 1, name
+
+
+def test_header_analysis_agrees_with_the_walk():
+    """daliamdJpegAnalyzeHeader (what decoders.image runs: one pass up to SOS) reports what daliamdJpegParse +
+    daliamdJpegAnalyzeScan report, except that the segment is 'everything behind SOS'."""
+    host = capi.host()
+    rng = np.random.default_rng(8)
+    streams = [open(f, "rb").read() for f in sorted(glob.glob(os.path.join(GOLDEN, "*.jpg")))]
+    streams += [encode_jpeg(synth_image(rng, 40, 56), 85, restart_marker_rows=1),
+                encode_jpeg(synth_image(rng, 40, 56), 85) + b"\x00" * 100]
+    for e in streams:
+        buf, info, scan = _analyze(e)
+        info2, scan2 = capi.JpegInfo(), capi.JpegScan()
+        capi.check_host(host.daliamdJpegAnalyzeHeader(buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.size), C.byref(info2),
+                                                      C.byref(scan2)))
+        assert bytes(info) == bytes(info2)
+        if info.num_components == 4:
+            assert scan2.eligible == 0
+            continue
+        assert scan.eligible == scan2.eligible
+        if scan.eligible:
+            assert scan2.length_is_upper_bound == 1 and scan.length_is_upper_bound == 0
+            assert scan2.ecs_offset == scan.ecs_offset and scan2.ecs_offset + scan2.ecs_length == buf.size
+            assert scan2.ecs_length >= scan.ecs_length
+            scan2.ecs_length, scan2.length_is_upper_bound = scan.ecs_length, 0
+            assert bytes(scan) == bytes(scan2)

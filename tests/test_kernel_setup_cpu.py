@@ -106,9 +106,16 @@ def test_huffman_setup_sizes_the_three_grids_and_validates():
     assert any(counts == [-(-m // mpw) for m in (100, 1000, 400)] for mpw in range(32, 513, 32)), counts
     bad = (capi.JpegHuffDesc * 1)(_huff_desc(total_blocks=601))                      # not a whole number of MCUs
     assert lib.daliamdJpegHuffmanSetup(bad, 1, C.byref(tiles), C.byref(segs), C.byref(bwg)) != 0
-    one_bit = (capi.JpegHuffDesc * 1)(_huff_desc(bits0=1))                           # a 1-bit code: host decoder's job
-    assert lib.daliamdJpegHuffmanSetup(one_bit, 1, C.byref(tiles), C.byref(segs), C.byref(bwg)) == 2   # UNSUPPORTED
-    assert b"1-bit code" in lib.daliamdGetLastErrorMessage()
+    one_bit = (capi.JpegHuffDesc * 1)(_huff_desc(bits0=1))                           # a 1-bit code is fine (round 4)
+    assert lib.daliamdJpegHuffmanSetup(one_bit, 1, C.byref(tiles), C.byref(segs), C.byref(bwg)) == 0
+    bad = (capi.JpegHuffDesc * 1)(_huff_desc())
+    bad[0].restart_interval = 70000                                                  # DRI is a 16-bit field
+    assert lib.daliamdJpegHuffmanSetup(bad, 1, C.byref(tiles), C.byref(segs), C.byref(bwg)) != 0
+    # scratch: the restart boundaries (4 bytes per interval) come behind everything else
+    plain, rst = C.c_size_t(), C.c_size_t()
+    assert lib.daliamdJpegHuffmanScratchBytes(100_000, 6000, C.byref(plain)) == 0
+    assert lib.daliamdJpegHuffmanScratchBytesRestart(100_000, 6000, 1000, C.byref(rst)) == 0
+    assert 4000 - 256 <= rst.value - plain.value <= 4000 + 256                    # (the total is rounded up to 256 bytes)
 
 
 def test_huffman_setup_shares_code_tables_between_streams_with_the_same_dht():

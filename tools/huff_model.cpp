@@ -33,6 +33,7 @@ struct Lane {
   bool active = false;
   uint64_t in = kNoState, out = kNoState;
   int nstart = 0;
+  bool crossed = false;
   std::vector<uint16_t> list;  // cap + 1 slots
 };
 
@@ -40,6 +41,7 @@ struct SegRec {
   uint64_t out = kNoState;
   int nstart_total = 0, block_base = 0;
   int dc_total[3] = {0, 0, 0};
+  bool crossed = false;
   std::vector<uint32_t> starts;
   std::vector<Lane> lanes;  // the segment's own lanes (LaneRec)
 };
@@ -61,7 +63,17 @@ struct Model {
   uint32_t total_bits = 0;
   HuffTables H;
   SyncTables S;
-  int rounds_max = 0, repairs = 0, overflow_lanes = 0;
+  std::vector<uint32_t> rst_pos;  // clean byte offsets at which the restart intervals start (UnstuffScatterKernel)
+  uint32_t restart_interval = 0;
+  int rounds_max = 0, repairs = 0, overflow_lanes = 0, jumps = 0;
+
+  // MakeRstView: hint = the first boundary at or behind the lane's slice
+  RestartView<const uint32_t *> Rst(uint32_t begin_bits) const {
+    RestartView<const uint32_t *> v{rst_pos.data(), (int)rst_pos.size(), restart_interval, 0};
+    if (restart_interval)
+      v.hint = (int)(std::lower_bound(rst_pos.begin(), rst_pos.end(), begin_bits >> 3) - rst_pos.begin());
+    return v;
+  }
 
   void Relax(std::vector<Lane> &ln, std::vector<uint64_t> &state) {
     const int T = (int)ln.size();
@@ -75,8 +87,8 @@ struct Model {
           l.nstart = 0;
           if (st.pos < l.end) {
             const int cap = P.list_cap;
-            l.nstart = SyncDecodeRange(S, words.data(), st, l.end,
-                                       [&](int nb, int rem, bool) { l.list[nb < cap ? nb : cap] = (uint16_t)rem; });
+            l.nstart = SyncDecodeRange(S, words.data(), st, l.end, Rst(l.begin),
+                                       [&](int nb, int rem, bool) { l.list[nb < cap ? nb : cap] = (uint16_t)rem; }, &l.crossed);
           }
           l.out = Pack(st);
         }
@@ -107,9 +119,10 @@ struct Model {
         DecodeState st = Unpack(l.in);
         const uint32_t end = l.end;
         const int b = base, cnt = l.nstart;
-        SyncDecodeRange(S, words.data(), st, end, [&](int nb, int rem, bool ended) {
+        bool crossed;
+        SyncDecodeRange(S, words.data(), st, end, Rst(l.begin), [&](int nb, int rem, bool ended) {
           if (ended && nb < cnt && b + nb < seg_cap) starts[b + nb] = end - (uint32_t)rem;
-        });
+        }, &crossed);
       }
     }
     return bases[count];
@@ -132,8 +145,8 @@ int Fail(const char *fmt, ...) {
 extern "C" const char *huff_model_message() { return g_msg.c_str(); }
 
 // Decodes `jpeg` with the model and compares with the host entropy decoder.  params: {slice_bytes, seg_threads,
-// warm_lanes, list_cap, blocks_per_wg} or NULL for the kernel's constants.  stats (optional, 6 ints): segments,
-// relaxation rounds (max), repaired segments, lanes that took the list-overflow path, blocks, block starts found.
+// warm_lanes, list_cap, blocks_per_wg} or NULL for the kernel's constants.  stats (optional, 7 ints): segments,
+// relaxation rounds (max), repaired segments, lanes that took the list-overflow path, blocks, block starts found, restart boundaries.
 // Returns 0 when every coefficient matches, 1 on a mismatch / error (huff_model_message()), 2 when the stream is not
 // eligible for the GPU decoder.
 extern "C" int huff_model_check(const uint8_t *jpeg, size_t size, const int *params, int *stats) {
@@ -146,9 +159,19 @@ extern "C" int huff_model_check(const uint8_t *jpeg, size_t size, const int *par
   daliamdJpegInfo info;
   daliamdJpegScan sc;
   if (daliamdJpegParse(jpeg, size, &info) != 0) return Fail("parse: %s", daliamdHostGetLastErrorMessage());
-  if (daliamdJpegAnalyzeScan(jpeg, size, &info, &sc) != 0 || !sc.eligible) return 2;
-  for (int t = 0; t < 2; t++)
-    if (sc.dc_bits[t][0] || sc.ac_bits[t][0]) return 2;  // 1-bit code: refused by daliamdJpegHuffmanSetup
+  {
+    // the operator's analysis: headers only, the segment is "the rest of the file"; the exact walk must agree on
+    // everything but the length
+    daliamdJpegInfo info2;
+    daliamdJpegScan exact;
+    if (daliamdJpegAnalyzeHeader(jpeg, size, &info2, &sc) != 0 || !sc.eligible) return 2;
+    if (memcmp(&info, &info2, sizeof info)) return Fail("daliamdJpegAnalyzeHeader and daliamdJpegParse disagree");
+    if (daliamdJpegAnalyzeScan(jpeg, size, &info, &exact) != 0 || !exact.eligible) return 2;
+    if (!sc.length_is_upper_bound || exact.length_is_upper_bound || exact.ecs_length > sc.ecs_length)
+      return Fail("scan lengths: header %lld, walk %lld", (long long)sc.ecs_length, (long long)exact.ecs_length);
+    exact.ecs_length = sc.ecs_length; exact.length_is_upper_bound = 1;
+    if (memcmp(&exact, &sc, sizeof sc)) return Fail("daliamdJpegAnalyzeHeader and daliamdJpegAnalyzeScan disagree");
+  }
   // ---- reference: the host entropy decoder (column-major blocks) ----
   std::vector<std::vector<int16_t>> ref(info.num_components);
   int16_t *ptrs[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -159,12 +182,30 @@ extern "C" int huff_model_check(const uint8_t *jpeg, size_t size, const int *par
   uint16_t quant[4 * 64];
   if (daliamdJpegDecodeCoefficients(jpeg, size, &info, ptrs, quant) != 0)
     return Fail("host decode: %s", daliamdHostGetLastErrorMessage());
-  // ---- un-stuffing (UnstuffScatterKernel): clean stream + all-ones padding ----
+  // ---- un-stuffing (PrepareKernel / UnstuffScatterKernel: LoadChunk's rules byte by byte): clean stream + all-ones
+  // padding, the restart boundaries, the end of the segment ----
   std::vector<uint8_t> clean;
   const uint8_t *p = jpeg + sc.ecs_offset;
+  bool rst_without_dri = false;
   for (int64_t i = 0; i < sc.ecs_length; i++) {
-    clean.push_back(p[i]);
-    if (p[i] == 0xFF && i + 1 < sc.ecs_length && p[i + 1] == 0) i++;
+    const bool next_valid = i + 1 < sc.ecs_length;
+    const uint8_t b = p[i], nb = next_valid ? p[i + 1] : 0;
+    const bool after_ff = i > 0 && p[i - 1] == 0xFF;
+    const bool marker = b == 0xFF && next_valid && nb != 0;
+    const bool is_rst = marker && (nb & 0xF8) == 0xD0;
+    if (marker && !is_rst && nb != 0xFF) break;   // the segment ends here
+    if (is_rst) {
+      if (sc.restart_interval) M.rst_pos.push_back((uint32_t)clean.size()); else rst_without_dri = true;
+    }
+    if (marker || (after_ff && (b == 0 || (b & 0xF8) == 0xD0))) continue;
+    clean.push_back(b);
+  }
+  if (rst_without_dri) return Fail("status 3: RSTn markers without DRI");
+  M.restart_interval = (uint32_t)sc.restart_interval;
+  {
+    const int mcus = sc.mcus_x * sc.mcus_y;
+    const size_t cap = sc.restart_interval ? (size_t)(mcus + sc.restart_interval - 1) / sc.restart_interval : 0;
+    if (M.rst_pos.size() > cap) M.rst_pos.resize(cap);
   }
   const uint32_t clean_len = (uint32_t)clean.size();
   M.total_bits = clean_len * 8;
@@ -203,7 +244,7 @@ extern "C" int huff_model_check(const uint8_t *jpeg, size_t size, const int *par
   const int total_blocks = sc.mcus_x * sc.mcus_y * bpm;
   const int seg_lanes = P.seg_threads - P.warm_lanes, seg_bytes = seg_lanes * P.slice_bytes;
   const int nseg = (int)clean_len > seg_bytes ? ((int)clean_len + seg_bytes - 1) / seg_bytes : 1;
-  const long long by_slices = (long long)seg_lanes * (P.slice_bytes * 8 / 4 + 32), by_blocks = (long long)total_blocks + 128;
+  const long long by_slices = (long long)seg_lanes * (P.slice_bytes * 8 / 2 + 32), by_blocks = (long long)total_blocks + 128;
   const int seg_cap = (int)std::min(by_slices, by_blocks);
   std::vector<SegRec> segs(nseg);
   // ---- SyncKernel, one "workgroup" per segment ----
@@ -222,9 +263,11 @@ extern "C" int huff_model_check(const uint8_t *jpeg, size_t size, const int *par
     M.Relax(ln, state);
     const int total = M.WriteStarts(ln, P.warm_lanes, seg_lanes, sr.starts, seg_cap);
     sr.lanes.assign(ln.begin() + P.warm_lanes, ln.end());
+    bool crossed = false;
+    for (int t = P.warm_lanes; t < P.seg_threads; t++) crossed |= ln[t].active && ln[t].crossed;
     for (int t = P.warm_lanes; t < P.seg_threads; t++) {
       const bool next_has_data = t + 1 < P.seg_threads && ln[t].end < M.total_bits;
-      if (ln[t].active && !next_has_data) { sr.out = ln[t].out; sr.nstart_total = total; }
+      if (ln[t].active && !next_has_data) { sr.out = ln[t].out; sr.nstart_total = total; sr.crossed = crossed; }
     }
     if (M.total_bits == 0) { sr.out = Pack(DecodeState{0, 0, 0}); sr.nstart_total = 0; }
   }
@@ -248,12 +291,15 @@ extern "C" int huff_model_check(const uint8_t *jpeg, size_t size, const int *par
       }
       M.Relax(ln, state);
       const int total = M.WriteStarts(ln, 0, seg_lanes, sr.starts, seg_cap);
+      bool crossed = false;
+      for (int t = 0; t < seg_lanes; t++) crossed |= ln[t].active && ln[t].crossed;
       for (int t = 0; t < seg_lanes; t++) {
         sr.lanes[t] = ln[t];
         const bool next_has_data = t + 1 < seg_lanes && ln[t].end < M.total_bits;
-        if (ln[t].active && !next_has_data) { sr.out = ln[t].out; sr.nstart_total = total; }
+        if (ln[t].active && !next_has_data) { sr.out = ln[t].out; sr.nstart_total = total; sr.crossed = crossed; }
       }
     }
+    if (sr.crossed) return Fail("status 4: segment %d: a decode from the true state ran over a restart boundary", seg);
     sr.block_base = block_base;
     block_base += sr.nstart_total;
     truth = sr.out;
@@ -312,8 +358,19 @@ extern "C" int huff_model_check(const uint8_t *jpeg, size_t size, const int *par
         const int comp = sc.comp_of_block[k];
         int16_t coef[66];
         memset(coef, 0, sizeof coef);
-        int dc = blk_dc[ordinal];
-        for (int s = 0; s < blk_seg[ordinal]; s++) dc += segs[s].dc_total[comp];
+        int dc = blk_dc[ordinal], seg0 = 0;
+        const int interval_blocks = sc.restart_interval * bpm;
+        if (interval_blocks) {
+          const int first = ordinal / interval_blocks * interval_blocks;
+          if (first > 0) {
+            int klast = 0;
+            for (int kk = 0; kk < bpm; kk++) if (sc.comp_of_block[kk] == comp) klast = kk;
+            const int q = first - bpm + klast;
+            dc -= blk_dc[q];
+            seg0 = blk_seg[q];
+          }
+        }
+        for (int s = seg0; s < blk_seg[ordinal]; s++) dc += segs[s].dc_total[comp];
         coef[0] = (int16_t)dc;
         if (blk_pos[ordinal] == 0xFFFFFFFFu) return Fail("block %d has no position", ordinal);
         DecodeBlockAc(H, M.words.data(), blk_pos[ordinal], 2u + (sc.ac_sel[comp] & 1), coef);
@@ -336,7 +393,7 @@ extern "C" int huff_model_check(const uint8_t *jpeg, size_t size, const int *par
     if (!seen[o]) return Fail("block %d is never decoded", o);
   if (stats) {
     stats[0] = nseg; stats[1] = M.rounds_max; stats[2] = M.repairs; stats[3] = M.overflow_lanes; stats[4] = total_blocks;
-    stats[5] = total_starts;
+    stats[5] = total_starts; stats[6] = (int)M.rst_pos.size();
   }
   return mismatches ? 1 : 0;
 }
