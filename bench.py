@@ -67,7 +67,14 @@ def measured_traffic(kernel, workload=""):
         return None, None
     try:
         ks = json.load(open(files[-1]))["kernels"]
-        norm = lambda n: n.split("<")[0].replace("Fast", "")   # SpectrogramFastKernel<9, 4> is the SpectrogramKernel launch
+        def norm(n):
+            # rocprofv3 reports the instantiation, the KernelTimer scopes of the library a role: SpectrogramFastKernel<9, 4, 0>
+            # is the SpectrogramKernel launch, <9, 4, 1 / 2> (MEL != 0) the fused SpectrogramMel(Mfma)Kernel launch
+            base, _, targs = n.partition("<")
+            if base == "SpectrogramFastKernel":
+                mel = targs.rstrip(">").split(",")[2:3]
+                return "SpectrogramMelKernel" if mel and mel[0].strip() != "0" else "SpectrogramKernel"
+            return base.replace("MelMfma", "Mel")
         k = ks.get(kernel) or next((v for n, v in ks.items() if norm(n) == norm(kernel)), {})
         return k.get("hbm_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
     except (OSError, ValueError, KeyError):
@@ -499,14 +506,31 @@ def kernel_timing(enable=None):
     return out
 
 
-def bench_heavy_aug(args, device):
+def _oracle_rate(work, items, seconds_budget, unit):
+    """Bounded CPU-baseline sample: `work(i)` (oracle code, one item) on every usable core until about `seconds_budget`
+    seconds of wall time have passed.  Returns the cpu_baseline object (kind "port")."""
+    from concurrent.futures import ThreadPoolExecutor
+    cores = effective_cpu_count()
+    done, t0 = 0, time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        while True:
+            list(ex.map(work, range(items)))
+            done += items
+            el = time.perf_counter() - t0
+            if el * (done + items) / done > seconds_budget:
+                break
+    return {"value": done / el, "unit": unit, "cores": cores, "kind": "port", "wall_s": round(el, 2), "items": done}
+
+
+def bench_heavy_aug(args, device, steps=None, cpu_seconds=8.0):
     """configs[2]: warp_affine + gaussian_blur(sigma=3) + color_twist + erase on 512x512 u8 images, batch 128, through
     the PRODUCT pipeline with the images resident in HBM: readers.file(skip_cached_images) -> decoders.image(mixed,
     decoded-image cache) hands out the 128 cached images in place (no file read, no decode, no copy after the first
     epoch), the per-sample matrices come from an external source, the colour / erase arguments from the random operators.
     Colour twist + erase are one launch (graph-level fusion); fusing them into the blur's write-out as well is opt-in
     (DALI_AMD_BLUR_FUSION=1): measured slower.
-    One JSON line; per-kernel times from HIP events around each launch (algorithmic bytes: 3 * 512 * 512 in + out per launch)."""
+    Returns the JSON object; per-kernel times from HIP events around each launch (algorithmic bytes: 3 * 512 * 512 in +
+    out per launch); cpu_baseline = the same four operations of the C oracle on the host cores."""
     import shutil
     import tempfile
     import torch
@@ -514,12 +538,14 @@ def bench_heavy_aug(args, device):
     from dali_amd import fn, types
     from dali_amd.pipeline import Pipeline
     from dali_amd.testing import synth_image
+    steps = steps or args.steps
     n = 128
     rng = np.random.default_rng(1234)
     root = tempfile.mkdtemp(prefix="dali_amd_bench_aug_")
     os.makedirs(os.path.join(root, "0"))
+    images = [synth_image(rng, 512, 512) for _ in range(n)]
     for i in range(n):      # (JPEG: the decoded-image cache keeps what the GPU decoder produces)
-        Image.fromarray(synth_image(rng, 512, 512)).save(os.path.join(root, "0", f"img_{i:04d}.jpg"), quality=95)
+        Image.fromarray(images[i]).save(os.path.join(root, "0", f"img_{i:04d}.jpg"), quality=95)
 
     def matrices():
         mats = []
@@ -561,13 +587,13 @@ def bench_heavy_aug(args, device):
         for _ in range(4 * (depth + 1) + args.warmup):     # epoch 1 decodes the files into the cache; then every slot is warm
             run()
         torch.cuda.synchronize()
-        kernel_timing(12 * (args.steps + depth + 2))
+        kernel_timing(12 * (steps + depth + 2))
         kernel_timing(False)
         kernel_timing()
         pipe.operator_host_times()
         kernel_timing(True)
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             run()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
@@ -575,6 +601,7 @@ def bench_heavy_aug(args, device):
         times = kernel_timing()
         host = pipe.operator_host_times()
         kernels = pipe.executed_kernels()
+        del pipe
     finally:
         shutil.rmtree(root, ignore_errors=True)
     per = {}
@@ -584,60 +611,107 @@ def bench_heavy_aug(args, device):
     dom = max(per, key=lambda k: per[k]["avg_ms"])
     traffic, traffic_src = measured_traffic(dom, "heavy_aug")
     kern_ms = sum(v["avg_ms"] for v in per.values())
-    print(json.dumps({"metric": "images/sec heavy-aug 512^2 b128 (warp_affine+gaussian_blur(sigma=3)+color_twist+erase)",
-                      "value": n * args.steps / el, "unit": "images/s", "n_gpus": 1, "steps": args.steps,
-                      "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
-                      "scaling": "weak", "vs_baseline": None, "dtype": "u8 in/out, f32 arithmetic", "data": "synthetic",
-                      "config": {"workload": "configs[2]: 128 x 512x512x3 u8 resident in HBM (decoded-image cache), through "
-                                             "dali_amd.Pipeline", "kernels": kernels, "prefetch_queue_depth": depth,
-                                 "kernels_ms_per_step": kern_ms, "images_per_s_kernels_only": n / (kern_ms * 1e-3),
-                                 "host_ms_per_step": host.get("<device stage>"), "host_stage_ms_per_step": host.get("<host stage>"),
-                                 "host_ms_per_operator": {k: v for k, v in host.items() if not k.startswith("<")}},
-                      "roofline": {"bound": "hbm", "kernel": dom, "achieved": per[dom]["achieved_GBps"],
-                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": per[dom]["achieved_GBps"] / HBM_PEAK_GBS,
-                                   "traffic": traffic, "traffic_source": traffic_src, "per_kernel": per}}))
+    out = {"metric": "images/sec heavy-aug 512^2 b128 (warp_affine+gaussian_blur(sigma=3)+color_twist+erase)",
+           "value": n * steps / el, "unit": "images/s", "n_gpus": 1, "steps": steps,
+           "warmup": args.warmup, "ms_per_step": 1e3 * el / steps, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "u8 in/out, f32 arithmetic", "data": "synthetic",
+           "config": {"workload": "configs[2]: 128 x 512x512x3 u8 resident in HBM (decoded-image cache), through "
+                                  "dali_amd.Pipeline", "kernels": kernels, "prefetch_queue_depth": depth,
+                      "kernels_ms_per_step": kern_ms, "images_per_s_kernels_only": n / (kern_ms * 1e-3),
+                      "host_ms_per_step": host.get("<device stage>"), "host_stage_ms_per_step": host.get("<host stage>"),
+                      "host_ms_per_operator": {k: v for k, v in host.items() if not k.startswith("<")}},
+           "roofline": {"bound": "hbm", "kernel": dom, "achieved": per[dom]["achieved_GBps"],
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": per[dom]["achieved_GBps"] / HBM_PEAK_GBS,
+                        "traffic": traffic, "traffic_source": traffic_src, "per_kernel": per}}
+    if cpu_seconds and not args.no_cpu_baseline:
+        from oracle import oracle as O
+        win = O.gaussian_window(3.0)
+        twist = O.color_twist_matrix(hue=15.0, saturation=1.1, brightness=1.1, contrast=0.9)
+        mats = mat_sets[0]
+
+        def one(i):
+            y = O.warp_affine_u8(images[i], mats[i].reshape(2, 3), fill=(0.0,))
+            y = O.gaussian_blur_u8(y, win)
+            y = O.linear_transform_u8(y, *twist)
+            O.erase_u8(y, [(0.3, 0.2)], [(0.2, 0.25)], normalized_anchor=True, normalized_shape=True)
+
+        base = _oracle_rate(one, 32, cpu_seconds, "images/s")
+        base["sample"] = (f"{base['items']} images = {base['items'] // 32} pass(es) over the first 32 of the 128 images: warp_affine + "
+                          f"gaussian_blur(sigma=3) + colour twist + erase per image on the C oracle, one task per image, "
+                          f"{base['cores']} threads, {base['wall_s']} s wall")
+        out["cpu_baseline"] = base
+    return out
 
 
-def bench_audio(args, device):
-    """configs[3]: spectrogram(nfft=1024, step 256) -> mel_filter_bank(80) -> to_decibels on 64 signals of 8-16 s at
-    16 kHz, signals resident in HBM."""
+def _wav16(x, rate):
+    import struct
+    pcm = np.round(np.clip(x, -1, 1) * 32767).astype("<i2")
+    return (b"RIFF" + struct.pack("<I", 36 + pcm.nbytes) + b"WAVE" + b"fmt " +
+            struct.pack("<IHHIIHH", 16, 1, 1, rate, rate * 2, 2, 16) + b"data" + struct.pack("<I", pcm.nbytes) + pcm.tobytes())
+
+
+def bench_audio(args, device, steps=None, cpu_seconds=8.0):
+    """configs[3] as BASELINE.json names it: decoders.audio -> spectrogram(nfft=1024, step 256) -> mel_filter_bank(80) ->
+    to_decibels on 64 utterances of 8-16 s at 16 kHz (LibriSpeech shape), from 16-bit WAV FILES: readers.file (loader
+    threads, page cache) -> decoders.audio on the host thread pool (audio_decoder_op.cc:36-100) -> H2D -> one fused
+    launch (+ the dB pair), asynchronous executor, two batches in flight.  Returns the JSON object; cpu_baseline = the
+    numpy oracle (decode + float64 FFT spectrogram + mel + dB per utterance) on the host cores."""
+    import shutil
+    import tempfile
     import torch
     from dali_amd import fn
     from dali_amd.pipeline import Pipeline
+    steps = steps or args.steps
     rng = np.random.default_rng(1234)
     n = 64
     sigs = [rng.normal(0, 0.1, int(rng.uniform(8, 16) * 16000)).astype(np.float32) for _ in range(n)]
-    pipe = Pipeline(batch_size=n, num_threads=4, device_id=device.index or 0, prefetch_queue_depth=1, exec_async=False)
-    with pipe:
-        x = fn.external_source(name="x")
-        spec = fn.spectrogram(x.gpu(), nfft=1024, window_length=1024, window_step=256)
-        mel = fn.mel_filter_bank(spec, nfilter=80, sample_rate=16000.0, freq_high=8000.0)
-        pipe.set_outputs(fn.to_decibels(mel, multiplier=10.0, cutoff_db=-80.0))
-    pipe.enable_operator_timing()
-    pipe.build()
-    frames = sum(len(s) // 256 + 1 for s in sigs)
-    for _ in range(args.warmup):
-        pipe.feed_input("x", sigs)
-        pipe.run()
-    torch.cuda.synchronize()
-    kernel_timing(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        pipe.feed_input("x", sigs)
-        pipe.run()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
+    wavs = [_wav16(s, 16000) for s in sigs]
+    root = tempfile.mkdtemp(prefix="dali_amd_bench_audio_")
+    os.makedirs(os.path.join(root, "0"))
+    for i, w in enumerate(wavs):
+        with open(os.path.join(root, "0", f"utt_{i:04d}.wav"), "wb") as f:
+            f.write(w)
+    depth = 2
+    threads = max(2, effective_cpu_count() * 3 // 4)
+    try:
+        pipe = Pipeline(batch_size=n, num_threads=threads, device_id=device.index or 0, prefetch_queue_depth=depth,
+                        exec_async=True, seed=1234)
+        with pipe:
+            enc, _ = fn.readers.file(file_root=root, file_filters=["*.wav"], prefetch_queue_depth=2)
+            audio, _rate = fn.decoders.audio(enc, downmix=True)
+            spec = fn.spectrogram(audio.gpu(), nfft=1024, window_length=1024, window_step=256)
+            mel = fn.mel_filter_bank(spec, nfilter=80, sample_rate=16000.0, freq_high=8000.0)
+            pipe.set_outputs(fn.to_decibels(mel, multiplier=10.0, cutoff_db=-80.0))
+        pipe.enable_operator_timing()
+        pipe.build()
+        frames = sum(len(s) // 256 + 1 for s in sigs)
+        for _ in range(args.warmup + 2 * (depth + 1)):
+            pipe.run()
+        torch.cuda.synchronize()
+        kernel_timing(8 * (steps + depth + 2))
+        kernel_timing(False)
+        kernel_timing()
+        pipe.operator_host_times()
+        kernel_timing(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            pipe.run()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        kernel_timing(False)
+        ktimes = kernel_timing()               # HIP events around every launch, on the stream it is launched on
+        host = pipe.operator_host_times()
+        times = pipe.operator_device_times()   # ... and around each operator (descriptor upload + launches)
+        kernels = pipe.executed_kernels()
+        del pipe
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
     samples = sum(len(s) for s in sigs)
     # algorithmic bytes per launch: every signal sample read once, every output element written once
     algo = {"SpectrogramKernel": 4 * samples + 4 * 513 * frames, "MelKernel": 4 * 513 * frames + 4 * 80 * frames,
-            "DecibelKernel": 8 * 80 * frames}
-    kernel_timing(False)
-    ktimes = kernel_timing()               # HIP events around every launch, on the stream it is launched on
-    times = pipe.operator_device_times()   # ... and around each operator (descriptor upload + launches)
-    algo["DecibelMaxKernel"] = 4 * 80 * frames
-    algo["DecibelKernel"] = 8 * 80 * frames
+            "DecibelMaxKernel": 4 * 80 * frames, "DecibelKernel": 8 * 80 * frames}
     # the fused launch (graph-level fusion of the chain): signal in, mel energies out - the spectrogram stays in LDS
-    algo["SpectrogramMelMfmaKernel"] = algo["SpectrogramMelKernel"] = 4 * samples + 4 * 80 * frames
+    algo["SpectrogramMelMfmaKernel"] = algo["SpectrogramMelKernel"] = algo["SpectrogramFastKernel"] = 4 * samples + 4 * 80 * frames
     per = {}
     for kern, (calls, ms) in ktimes.items():
         if kern in algo:
@@ -646,21 +720,39 @@ def bench_audio(args, device):
     dom = max(per, key=lambda k: per[k]["avg_ms"]) if per else None
     traffic, traffic_src = measured_traffic(dom, "audio") if dom else (None, None)
     ach = per[dom]["achieved_GBps"] if dom else None
-    print(json.dumps({"metric": "utterances/sec spectrogram(1024)->mel(80)->dB b64 (incl. H2D of the signals)",
-                      "value": n * args.steps / el, "unit": "utterances/s", "n_gpus": 1, "steps": args.steps,
-                      "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
-                      "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                      "config": {"workload": "configs[3]: 64 mono signals, 16 kHz, 8-16 s", "frames": frames,
-                                 "samples": samples, "kernels": pipe.executed_kernels(),
-                                 "kernels_ms_per_step": sum(v["avg_ms"] for v in per.values()),
-                                 "utterances_per_s_kernels_only": n / (1e-3 * sum(v["avg_ms"] for v in per.values())) if per else None,
-                                 "algorithmic_MB_per_step": sum(v["algorithmic_bytes"] for v in per.values()) / 1e6,
-                                 "mel_variant": "valu" if os.environ.get("DALI_AMD_MEL_VALU") == "1" else "mfma",
-                                 "note": "value includes feeding 49 MB of host signals per step (external_source copy + H2D)"},
-                      "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": ach / HBM_PEAK_GBS if ach else None, "traffic": traffic,
-                                   "traffic_source": traffic_src, "per_kernel": per,
-                                   "operator_device_ms": times}}))
+    out = {"metric": "utterances/sec decoders.audio->spectrogram(1024)->mel(80)->dB b64, from 16-bit WAV files",
+           "value": n * steps / el, "unit": "utterances/s", "n_gpus": 1, "steps": steps,
+           "warmup": args.warmup, "ms_per_step": 1e3 * el / steps, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "configs[3]: 64 mono utterances, 16 kHz, 8-16 s, 16-bit WAV files in the page cache -> "
+                                  "readers.file -> decoders.audio (host) -> H2D -> spectrogram -> mel -> dB (device)",
+                      "frames": frames, "samples": samples, "kernels": kernels, "prefetch_queue_depth": depth,
+                      "exec_async": True, "host_threads": threads,
+                      "kernels_ms_per_step": sum(v["avg_ms"] for v in per.values()),
+                      "utterances_per_s_kernels_only": n / (1e-3 * sum(v["avg_ms"] for v in per.values())) if per else None,
+                      "algorithmic_MB_per_step": sum(v["algorithmic_bytes"] for v in per.values()) / 1e6,
+                      "mel_variant": "valu" if os.environ.get("DALI_AMD_MEL_VALU") == "1" else "mfma",
+                      "host_ms_per_operator": {k: v for k, v in host.items() if not k.startswith("<")},
+                      "host_stage_ms_per_step": host.get("<host stage>"), "device_stage_ms_per_step": host.get("<device stage>"),
+                      "note": "value is end to end from files: 98 MB of 16-bit PCM decoded to 49 MB of float on the host and "
+                              "copied to the device per step"},
+           "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS if ach else None, "traffic": traffic,
+                        "traffic_source": traffic_src, "per_kernel": per, "operator_device_ms": times}}
+    if cpu_seconds and not args.no_cpu_baseline:
+        from oracle import audio as A
+
+        def one(i):
+            x, _rate = A.decode_wav(wavs[i])
+            spec = A.spectrogram(x, nfft=1024, window_length=1024, window_step=256)
+            A.to_decibels(A.mel_filter_bank(spec, nfilter=80, sample_rate=16000.0, freq_high=8000.0), multiplier=10.0, cutoff_db=-80.0)
+
+        base = _oracle_rate(one, n, cpu_seconds, "utterances/s")
+        base["sample"] = (f"{base['items']} utterances = {base['items'] // n} pass(es) over the 64 files: WAV decode + spectrogram "
+                          f"(float64 FFT) + mel + dB per utterance on the numpy oracle, one task per utterance, "
+                          f"{base['cores']} threads, {base['wall_s']} s wall")
+        out["cpu_baseline"] = base
+    return out
 
 
 def bench_cpu_backend(args):
@@ -847,9 +939,9 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     if args.workload == "heavy_aug":
-        return bench_heavy_aug(args, device)
+        return print(json.dumps(bench_heavy_aug(args, device)))
     if args.workload == "audio":
-        return bench_audio(args, device)
+        return print(json.dumps(bench_audio(args, device)))
 
     def barrier():
         if world > 1:
@@ -1114,6 +1206,18 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(enc_all[:B])
             line["cpu_baseline_pillow"] = pillow_baseline(enc_all[:B])
+        if world == 1 and not args.no_side_legs:
+            # BASELINE.json configs[2] and configs[3], compact: the same legs `--workload heavy_aug` / `--workload audio`
+            # run, each with its own roofline and oracle cpu_baseline (same cores, same run)
+            import gc
+            gc.collect()
+            side_steps = max(10, min(args.steps, 100))
+            for key, leg in (("heavy_aug", bench_heavy_aug), ("audio", bench_audio)):
+                try:
+                    line[key] = leg(args, device, steps=side_steps, cpu_seconds=6.0)
+                except Exception as e:  # noqa: BLE001 - a side leg must not take the headline line with it
+                    line[key] = {"error": f"{type(e).__name__}: {e}"}
+                gc.collect()
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -161,6 +161,17 @@ class AudioDecoderCpu : public OperatorBase {
           *static_cast<float *>(rate.raw(i)) = (float)w.rate;
           return;
         }
+        if (dtype_ == DALI_FLOAT && !resample && !downmix && w.tag == 1 && bits == 16) {
+          // the common case (16-bit PCM files, float output, nothing to mix): one pass the compiler vectorises - the
+          // general loop below picks the sample width per sample (0.35 ms per 12 s utterance against 0.03 ms)
+          typedef int16_t __attribute__((aligned(1), may_alias)) pcm16_t;   // the data chunk starts wherever the header ends
+          const pcm16_t *src = reinterpret_cast<const pcm16_t *>(w.data);
+          float *dst = static_cast<float *>(out.raw(i));
+          const int64_t count = w.frames * w.channels;
+          for (int64_t k = 0; k < count; k++) dst[k] = (float)src[k] * to_float;
+          *static_cast<float *>(rate.raw(i)) = (float)w.rate;
+          return;
+        }
         std::vector<float> scratch, mixed;
         const bool float_direct = dtype_ == DALI_FLOAT && !resample;   // the float result of decode / downmix IS the output
         if (!float_direct) scratch.resize((size_t)w.frames * och);
