@@ -416,6 +416,37 @@ def resident_pipeline(root, batch, device_id, depth, threads, shard_id=0, num_sh
     return pipe
 
 
+def iterator_leg(args, root, enc_all, dev_index, steps):
+    """The headline pipeline behind DALIGenericIterator (plugin/pytorch.py: every output is copied into a torch tensor of
+    the consumer on a side stream and the copy has completed when __next__ returns): the rate a PyTorch training loop
+    sees.  Same resident data set, same depth; one extra 77 MB device-to-device copy per batch."""
+    import torch
+    from dali_amd import _backend
+    from dali_amd.plugin.pytorch import DALIGenericIterator
+    B, nb = args.batch, max(1, args.batches)
+    depth = max(1, args.inflight)
+    threads = max(2, effective_cpu_count() * 3 // 4)
+    pipe = resident_pipeline(root, B, dev_index, depth, threads, cache_mb=max(64, int(2 * sum(len(e) for e in enc_all) / 2**20)))
+    it = DALIGenericIterator([pipe], ["data", "label"])
+    done = 0
+    while _backend.encoded_cache_stats(dev_index)["streams"] < nb * B and done < 64 * nb:
+        next(it)
+        done += 1
+    for _ in range((depth + 2) * nb + args.warmup):
+        next(it)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = next(it)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    shape = tuple(out[0]["data"].shape)
+    del it, pipe, out
+    return {"value": steps * B / el, "unit": "images/s", "ms_per_step": 1e3 * el / steps, "steps": steps,
+            "output": f"torch.float16 {shape} on the consumer's stream + labels",
+            "note": "bench.resident_pipeline consumed through dali_amd.plugin.pytorch.DALIGenericIterator"}
+
+
 def run_resident_pipeline(args, root, enc_all, device, dev_index, rank, world, local_world, barrier, dist):
     """Times K iterations of the product pipeline on the resident data set.  Returns what the JSON line is built from."""
     import torch
@@ -881,6 +912,9 @@ def main():
                     help="skip the one-batch-in-flight leg as well (profiling: every launch of the process then belongs to "
                          "the set-up or the timed region, both at the full depth)")
     ap.add_argument("--e2e-batch", type=int, default=512, help="batch per GPU of the sharded end-to-end leg (configs[4])")
+    ap.add_argument("--emulate-local-world", type=int, default=8,
+                    help="single-GPU runs: one more end-to-end leg with the CPUs one rank of a node with this many GPUs would "
+                         "get (0 / 1: skip)")
     ap.add_argument("--inflight", type=int, default=5,
                     help="batches in flight on the GPU = the executor's prefetch_queue_depth (iterations rotate over its three compute streams)")
     ap.add_argument("--huffman", default="gpu", choices=["gpu", "host"],
@@ -1164,11 +1198,34 @@ def main():
                 line["e2e_pipeline_roi_decode"] = e2e_pipeline(root, B, local_rank, roi_decode=True)
                 line["e2e_pipeline_roi_decode"]["note"] = ("same, with decoders.image_random_crop -> resize -> "
                                                            "crop_mirror_normalize: only the crop window is decoded")
+                if not args.no_side_legs:
+                    line["iterator"] = iterator_leg(args, root, enc_all, dev_index, max(20, min(args.steps, 200)))
+                    line["iterator"]["fraction_of_value"] = line["iterator"]["value"] / line["value"]
+                    gc.collect()
                 line["e2e_pipeline_decoder_cache"] = e2e_pipeline(root, B, local_rank, cache_mb=1024)
                 line["e2e_pipeline_decoder_cache"]["note"] = (
                     "same as e2e_pipeline with decoders.image(cache_size=1024, cache_type='threshold'): epoch >= 2 of a "
                     "data set whose decoded images fit in HBM.  The files are still read; decoded images are handed to "
                     "the fused resample kernel in place from the cache blob")
+                if args.emulate_local_world > 1:
+                    # 8-GPU readiness without 8 GPUs: this rank with the share of the host an N-rank node would leave
+                    # it - the process (and every thread it creates from here on) bound to usable / N CPUs, thread pools
+                    # sized for them - so that the per-rank end-to-end rate under that split is a measured number
+                    K = args.emulate_local_world
+                    share = max(1, effective_cpu_count() // K)
+                    allowed = sorted(os.sched_getaffinity(0))
+                    os.sched_setaffinity(0, set(allowed[:share]))
+                    try:
+                        res = e2e_pipeline(root, args.e2e_batch, local_rank, iters=100, threads=max(2, share))
+                    finally:
+                        os.sched_setaffinity(0, set(allowed))
+                    res["emulated_local_world"] = K
+                    res["cpus"] = share
+                    res["note"] = (f"e2e_pipeline at batch {args.e2e_batch} with the host share of one rank of a {K}-GPU node: "
+                                   f"{share} of the {effective_cpu_count()} usable CPUs (affinity mask), thread pools of "
+                                   f"{max(2, share)}; the GPU is not shared - a host-side bound for configs[4], not a scaling "
+                                   "measurement")
+                    line[f"e2e_pipeline_local_world{K}"] = res
             finally:
                 shutil.rmtree(root, ignore_errors=True)
         else:

@@ -222,6 +222,20 @@ class BackendPipeline:
         pl, sl, nl, tl = ptrs.tolist(), shapes.tolist(), ndims.tolist(), pitches.tolist()
         return [(pl[i], tuple(sl[i][:nl[i]]), tl[i]) for i in range(n)]
 
+    def output_samples_arrays(self, idx, n):
+        """The same table as numpy arrays (pointers, shapes [n, 8], ndims, pitches): whole-batch questions - are the samples
+        uniform and back to back? - without a Python object per sample."""
+        import numpy as np
+        ptrs = np.zeros(max(n, 1), np.uint64)
+        shapes = np.zeros((max(n, 1), 8), np.int64)
+        ndims = np.zeros(max(n, 1), np.int32)
+        pitches = np.zeros(max(n, 1), np.int64)
+        if n:
+            check(self._lib.daliamdPipelineOutputSamples(self._h, idx, ptrs.ctypes.data_as(C.c_void_p),
+                                                         shapes.ctypes.data_as(C.c_void_p), ndims.ctypes.data_as(C.c_void_p),
+                                                         pitches.ctypes.data_as(C.c_void_p)))
+        return ptrs[:n].astype(np.int64), shapes[:n], ndims[:n], pitches[:n]
+
     def feed_input(self, name, arrays, dtype, layout):
         import numpy as np
         n = len(arrays)

@@ -80,6 +80,17 @@ static WavInfo ParseWav(const uint8_t *p, size_t n, const std::string &src) {
   return w;
 }
 
+// 16-bit little-endian PCM (at any byte alignment: the data chunk starts wherever the header ends) -> float, value *
+// scale.  AVX2 clone where the CPU has it (8 samples per instruction), same arithmetic: one conversion, one product.
+__attribute__((target_clones("avx2", "default")))
+static void Pcm16ToFloat(const uint8_t *__restrict src, float *__restrict dst, int64_t count, float scale) {
+  for (int64_t k = 0; k < count; k++) {
+    int16_t v;
+    memcpy(&v, src + 2 * k, 2);
+    dst[k] = (float)v * scale;
+  }
+}
+
 class AudioDecoderCpu : public OperatorBase {
  public:
   explicit AudioDecoderCpu(const OpSpec &spec) : OperatorBase(spec), downmix_(spec.GetBool("downmix")) {
@@ -164,11 +175,7 @@ class AudioDecoderCpu : public OperatorBase {
         if (dtype_ == DALI_FLOAT && !resample && !downmix && w.tag == 1 && bits == 16) {
           // the common case (16-bit PCM files, float output, nothing to mix): one pass the compiler vectorises - the
           // general loop below picks the sample width per sample (0.35 ms per 12 s utterance against 0.03 ms)
-          typedef int16_t __attribute__((aligned(1), may_alias)) pcm16_t;   // the data chunk starts wherever the header ends
-          const pcm16_t *src = reinterpret_cast<const pcm16_t *>(w.data);
-          float *dst = static_cast<float *>(out.raw(i));
-          const int64_t count = w.frames * w.channels;
-          for (int64_t k = 0; k < count; k++) dst[k] = (float)src[k] * to_float;
+          Pcm16ToFloat(w.data, static_cast<float *>(out.raw(i)), w.frames * w.channels, to_float);
           *static_cast<float *>(rate.raw(i)) = (float)w.rate;
           return;
         }

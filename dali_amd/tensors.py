@@ -137,6 +137,19 @@ class _TensorList:
 class TensorListCPU(_TensorList):
     def as_array(self):
         assert self.is_dense_tensor(), "All samples must have the same shape to form a dense array"
+        # samples of one shape sitting back to back in the pipeline's buffer (labels, fixed-size outputs): ONE view + one
+        # copy instead of a Python object, a ctypes buffer and a copy per sample (1 ms for 256 labels: it was what kept
+        # DALIGenericIterator at half the pipeline's rate)
+        ptr0, shape, pitch = self._samples[0]
+        np_t = np.dtype(types.to_numpy_type(self.dtype))
+        nbytes = int(np.prod(shape)) * np_t.itemsize if len(shape) else np_t.itemsize
+        if nbytes and not (pitch and len(shape) == 3 and pitch != shape[1] * shape[2] * np_t.itemsize):
+            ptrs = np.fromiter((smp[0] for smp in self._samples), np.int64, self._n)
+            stride = int(ptrs[1] - ptrs[0]) if self._n > 1 else nbytes      # (samples start at 256-byte multiples)
+            if stride >= nbytes and np.array_equal(ptrs, ptr0 + stride * np.arange(self._n, dtype=np.int64)):
+                buf = (C.c_char * (stride * (self._n - 1) + nbytes)).from_address(ptr0)
+                inner = np.empty(shape, np_t).strides
+                return np.ndarray((self._n,) + tuple(shape), np_t, buf, 0, (stride,) + inner).copy()
         return np.stack([self[i].as_array() for i in range(self._n)])
 
     def as_tensor(self):
@@ -153,7 +166,27 @@ class TensorListGPU(_TensorList):
     def _contiguous_view(self):
         """Zero-copy [N, ...] view when the (uniform) samples sit back to back in the pipeline's buffer, else None."""
         import torch
-        if self._n == 0 or not self.is_dense_tensor():
+        if self._n == 0:
+            return None
+        if self._sample_table is None and hasattr(self._pipe, "output_samples_arrays"):
+            # whole-batch check on arrays: the per-sample tuples (0.1 ms for 256 samples) are only built when asked for
+            if getattr(self._pipe, "generation", 0) != self._generation:
+                raise RuntimeError("The outputs of this iteration were released (a later run() / outputs() call): "
+                                   "the TensorList can no longer be read")
+            ptrs, shapes, ndims, pitches = self._pipe.output_samples_arrays(self._idx, self._n)
+            nd = int(ndims[0])
+            if (ndims != nd).any() or (shapes[:, :nd] != shapes[0, :nd]).any():
+                return None
+            ptr0, shape, pitch = int(ptrs[0]), tuple(int(v) for v in shapes[0, :nd]), int(pitches[0])
+            np_t = np.dtype(types.to_numpy_type(self.dtype))
+            nbytes = int(np.prod(shape)) * np_t.itemsize
+            if nbytes == 0 or (pitch and len(shape) == 3 and pitch != shape[1] * shape[2] * np_t.itemsize):
+                return None
+            if (ptrs != ptr0 + nbytes * np.arange(self._n, dtype=np.int64)).any():
+                return None
+            iface = {"shape": (self._n,) + shape, "typestr": np_t.str, "data": (ptr0, False), "version": 3}
+            return torch.as_tensor(_Interface(iface, self), device="cuda")
+        if not self.is_dense_tensor():
             return None
         ptr0, shape, pitch = self._samples[0]
         np_t = np.dtype(types.to_numpy_type(self.dtype))

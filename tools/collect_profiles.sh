@@ -12,20 +12,25 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 SUM=$R/gpurun_out/${TAG}_summary
 mkdir -p $SUM
 cd /tmp && export TMPDIR=/tmp
-for W in ${WORKLOADS:-headline heavy_aug audio}; do
+for W in ${WORKLOADS:-headline heavy_aug audio normalize}; do
   OUT=$R/gpurun_out/prof_$TAG/$W
   mkdir -p $OUT
+  CMD="python $R/bench.py"
   if [ $W = headline ]; then
-    ARGS="--steps 40 --warmup 3 --no-cpu-baseline --no-e2e --no-side-legs"; PMCARGS="--steps 5 --warmup 1 --no-cpu-baseline --no-e2e --inflight 1"; SUF=""
+    ARGS="--steps 40 --warmup 3 --no-cpu-baseline --no-e2e --no-side-legs"; PMCARGS="--steps 5 --warmup 1 --no-cpu-baseline --no-e2e --no-side-legs --inflight 1"; SUF=""
+  elif [ $W = normalize ]; then   # fn.normalize (wave64 mean / stddev reductions) + the stand-alone CropMirrorNormalize kernel
+    CMD="python $R/tools/normalize_prof.py"; ARGS="20"; PMCARGS="5"; SUF="_$W"
   else
-    ARGS="--workload $W --steps 20 --warmup 3"; PMCARGS="--workload $W --steps 5 --warmup 1"; SUF="_$W"
+    ARGS="--workload $W --steps 20 --warmup 3 --no-cpu-baseline"; PMCARGS="--workload $W --steps 5 --warmup 1 --no-cpu-baseline"; SUF="_$W"
   fi
-  timeout ${PROF_TIMEOUT:-300} rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
+  timeout ${PROF_TIMEOUT:-300} rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
   for C in FETCH_SIZE WRITE_SIZE; do
-    timeout ${PROF_TIMEOUT:-300} rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -- python $R/bench.py $PMCARGS > /dev/null 2> $OUT/pmc_$C.log
+    timeout ${PROF_TIMEOUT:-300} rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -- $CMD $PMCARGS > /dev/null 2> $OUT/pmc_$C.log
   done
   python $R/tools/summarize_profiles.py $OUT $TAG$SUF $SUM || { echo "collect_profiles: $W summary FAILED"; tail -5 $OUT/*.log; FAILED=1; }
-  if [ $W != headline ]; then
+  if [ $W = normalize ]; then
+    (cd $R && timeout 300 python tools/normalize_prof.py 2>/dev/null | tail -1 > $SUM/${TAG}_${W}_bench.json)
+  elif [ $W != headline ]; then
     (cd $R && timeout 300 python bench.py --workload $W 2>/dev/null | tail -1 > $SUM/${TAG}_${W}_bench.json)
   fi
 done
