@@ -238,11 +238,18 @@ __device__ __forceinline__ TileChunk LoadChunk(const daliamdJpegHuffDesc &d, int
   const int g = tile * kTileBytes + (int)threadIdx.x * 16;
   TileChunk c{{0, 0, 0, 0}, 0, 0, 16};
   uint32_t prev = 0, behind = 0;
+  const int lane = threadIdx.x & 63;
   if (g < end) {
     GlobalWords *p = (GlobalWords *)__builtin_assume_aligned((const void *)(d.ecs - head + g), 16);
     c.w[0] = p[0]; c.w[1] = p[1]; c.w[2] = p[2]; c.w[3] = p[3];
-    if (g > head) prev = ((const GlobalBytes *)(d.ecs - head))[g - 1];
-    if (g + 16 < end) behind = ((const GlobalBytes *)(d.ecs - head))[g + 16];
+    // the bytes next to the chunk: the neighbouring lanes hold them (below) - only the ends of a wave load theirs
+    if (lane == 0 && g > head) prev = ((const GlobalBytes *)(d.ecs - head))[g - 1];
+    if (lane == 63 && g + 16 < end) behind = ((const GlobalBytes *)(d.ecs - head))[g + 16];
+  }
+  {
+    const uint32_t from_below = __shfl_up(c.w[3] >> 24, 1, 64), from_above = __shfl_down(c.w[0] & 255u, 1, 64);
+    if (lane != 0) prev = from_below;              // (a lane past the end of the segment holds zeros: "no byte behind")
+    if (lane != 63) behind = g + 16 < end ? from_above : 0u;
   }
 #pragma unroll
   for (int j = 0; j < 16; j++) {
@@ -264,70 +271,115 @@ __device__ __forceinline__ TileChunk LoadChunk(const daliamdJpegHuffDesc &d, int
   return c;
 }
 
-// Where the segment ends inside the tile, from the lanes' end_j: index of the first ending byte (kTileBytes: none).
-// One barrier pair; `slot` is a shared int the caller provides.
-__device__ __forceinline__ int TileEnd(const TileChunk &c, int *slot) {
-  if (threadIdx.x == 0) *slot = kTileBytes;
+// Exclusive scan over the workgroup of the bytes each lane keeps (`c.keep` as loaded, not yet cut) together with the
+// search for the end of the segment (the lanes' end_j) - ONE pair of barriers for both: the prefix of a lane in front
+// of the end does not depend on what the lanes behind it hold.  Returns the lane's exclusive prefix (meaningless behind
+// the end); `tile_end` = index of the first ending byte in the tile (kTileBytes: none), `total` = bytes the tile keeps in
+// front of it.  Cuts c.keep / c.rst at the end.  `wave_sums`: kTileThreads / 64 + 1 ints, `wave_ends`: kTileThreads / 64.
+__device__ __forceinline__ int ScanKeepAndEnd(TileChunk &c, int *wave_sums, int *wave_ends, int &tile_end, int &total) {
+  constexpr int NW = kTileThreads / 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int v = __popc(c.keep);
+  int incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    int t = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += t;
+  }
+  // first lane of the wave that holds an end (ballot: nearly always zero, no shuffles then)
+  const unsigned long long ends = __ballot(c.end_j < 16);
+  int wave_end = kTileBytes;
+  if (ends) {
+    const int first = __ffsll((long long)ends) - 1;
+    wave_end = (wave * 64 + first) * 16 + __shfl(c.end_j, first, 64);
+  }
+  if (lane == 63) wave_sums[wave] = incl;
+  if (lane == 0) wave_ends[wave] = wave_end;
   __syncthreads();
-  if (c.end_j < 16) atomicMin(slot, (int)threadIdx.x * 16 + c.end_j);
-  __syncthreads();
-  return *slot;
-}
-// Cuts a lane's masks at the end of the segment.
-__device__ __forceinline__ void CutChunk(TileChunk &c, int tile_end) {
-  const int mine = tile_end - (int)threadIdx.x * 16;   // bytes of this lane in front of the end
+  int base = 0, tot = 0, te = kTileBytes;
+#pragma unroll
+  for (int w = 0; w < NW; w++) {
+    const int sum = wave_sums[w];
+    if (w < wave) base += sum;
+    tot += sum;
+    te = min(te, wave_ends[w]);
+  }
+  const int excl = base + incl - v;
+  tile_end = te;
+  // cut at the end; the lane that holds it knows how many bytes the tile keeps in front of it
+  const int mine = te - (int)threadIdx.x * 16;
   const uint32_t m = mine >= 16 ? 0xFFFFu : (mine <= 0 ? 0u : (1u << mine) - 1u);
   c.keep &= m;
   c.rst &= m;
+  if (te < kTileBytes && mine >= 0 && mine < 16) wave_sums[NW] = excl + __popc(c.keep);
+  __syncthreads();  // (wave_sums may be reused by the caller's next scan)
+  total = te < kTileBytes ? wave_sums[NW] : tot;
+  return excl;
 }
 
 // First pass of the un-stuffing: what each tile keeps (PrepareKernel).
-__device__ __forceinline__ void CountTile(const daliamdJpegHuffDesc *__restrict__ descs, int n, int tile, int *wave_sums, int *slot) {
+__device__ __forceinline__ void CountTile(const daliamdJpegHuffDesc *__restrict__ descs, int n, int tile, int *wave_sums, int *wave_ends) {
   const ImageRef r = FindImage<true>(descs, n, tile);
   const daliamdJpegHuffDesc &d = *r.d;
   const ScratchLayout lay = LayoutOf(d);
   TileChunk c = LoadChunk(d, r.local);
-  const int tile_end = TileEnd(c, slot);
-  CutChunk(c, tile_end);
+  int tile_end, total, nrst = 0;
+  ScanKeepAndEnd(c, wave_sums, wave_ends, tile_end, total);
   if (!d.restart_interval && c.rst) *d.status = 3;   // RSTn markers in a stream without DRI
-  int total, nrst = 0;
-  WorkgroupExclusiveScan<kTileThreads / 64>(__popc(c.keep), wave_sums, total);
-  if (d.restart_interval) WorkgroupExclusiveScan<kTileThreads / 64>(__popc(c.rst), wave_sums, nrst);   // (uniform)
+  if (d.restart_interval) {   // (uniform)
+    __syncthreads();          // wave_sums[NW] was read above
+    WorkgroupExclusiveScan<kTileThreads / 64>(__popc(c.rst), wave_sums, nrst);
+  }
   if (threadIdx.x == 0)
     reinterpret_cast<TileRec *>(d.scratch + lay.tile_recs)[r.local] = TileRec{total, tile_end < kTileBytes ? 1 : 0, nrst, 0};
 }
 
 __global__ __launch_bounds__(kTileThreads) void UnstuffScatterKernel(const daliamdJpegHuffDesc *__restrict__ descs, int n) {
   __shared__ uint32_t stage[kTileBytes / 4 + 4];
-  __shared__ int wave_sums[kTileThreads / 64];
-  __shared__ int slot;
+  __shared__ int wave_sums[kTileThreads / 64 + 1];
+  __shared__ int wave_ends[kTileThreads / 64];
+  __shared__ int wave_pre[kTileThreads / 64][3];
+  constexpr int NW = kTileThreads / 64;
   const ImageRef r = FindImage<true>(descs, n, blockIdx.x);
   const daliamdJpegHuffDesc &d = *r.d;
   const ScratchLayout lay = LayoutOf(d);
-  const int tid = threadIdx.x;
-  // clean-stream position of this tile = bytes kept by the tiles before it, up to the tile the segment ends in
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // clean-stream position of this tile = bytes kept by the tiles before it, up to (and including) the tile the segment
+  // ends in; a tile behind that one is dead.  One barrier pair: per wave the sums over its lanes up to its first tile
+  // with the end flag, and whether it holds one.
   const TileRec *recs = reinterpret_cast<const TileRec *>(d.scratch + lay.tile_recs);
-  if (tid == 0) slot = d.num_tiles;
-  __syncthreads();
-  for (int t = tid; t < r.local; t += kTileThreads)
-    if (recs[t].ended) atomicMin(&slot, t);
-  __syncthreads();
-  const int end_tile = slot;          // first tile (in front of this one) in which the segment ends
-  const bool dead = end_tile < r.local;  // this tile lies behind the end
-  __syncthreads();                    // (slot is reused below)
-  int before = 0, rst_before = 0, base, rst_base;
-  for (int t = tid; t < r.local && t <= end_tile; t += kTileThreads) {
-    before += recs[t].kept;
-    rst_before += recs[t].nrst;
+  int base = 0, rst_base = 0;
+  bool dead = false;
+  for (int t0 = 0; t0 < r.local && !dead; t0 += kTileThreads) {   // (one round unless the stream has > 4 MB in front of the tile)
+    const int t = t0 + tid;
+    TileRec rec{0, 0, 0, 0};
+    if (t < r.local) rec = recs[t];
+    const unsigned long long ended = __ballot(rec.ended != 0);
+    const int first = ended ? __ffsll((long long)ended) - 1 : 64;
+    int kept = lane <= first ? rec.kept : 0, nrst = lane <= first ? rec.nrst : 0;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      kept += __shfl_xor(kept, off, 64);
+      nrst += __shfl_xor(nrst, off, 64);
+    }
+    if (lane == 0) { wave_pre[wave][0] = kept; wave_pre[wave][1] = nrst; wave_pre[wave][2] = ended != 0; }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+      if (dead) break;
+      base += wave_pre[w][0];
+      rst_base += wave_pre[w][1];
+      dead = wave_pre[w][2] != 0;
+    }
+    __syncthreads();
   }
-  WorkgroupExclusiveScan<kTileThreads / 64>(before, wave_sums, base);
   const int shift = base & 3;  // stage byte i <-> clean byte (base - shift) + i
   TileChunk c = LoadChunk(d, r.local);
-  CutChunk(c, dead ? 0 : TileEnd(c, &slot));
-  int total;
-  int o = shift + WorkgroupExclusiveScan<kTileThreads / 64>(__popc(c.keep), wave_sums, total);
+  int tile_end, total;
+  int o = shift + ScanKeepAndEnd(c, wave_sums, wave_ends, tile_end, total);
+  if (dead) { c.keep = 0; c.rst = 0; total = 0; }
   if (d.restart_interval) {   // (uniform) where the intervals start in the clean stream
-    WorkgroupExclusiveScan<kTileThreads / 64>(rst_before, wave_sums, rst_base);
+    __syncthreads();          // wave_sums[NW] was read above
     int nrst;
     int k = rst_base + WorkgroupExclusiveScan<kTileThreads / 64>(__popc(c.rst), wave_sums, nrst);
     GlobalU32 *rst_pos = (GlobalU32 *)(d.scratch + lay.rst_pos);
@@ -450,12 +502,12 @@ __device__ __forceinline__ void BuildTables(const daliamdJpegHuffDesc &d, HuffTa
 __global__ __launch_bounds__(kTileThreads) void PrepareKernel(const daliamdJpegHuffDesc *__restrict__ descs, int n,
                                                               int num_tiles) {
   __shared__ __attribute__((aligned(16))) HuffTables L;
-  __shared__ int wave_sums[kTileThreads / 64];
-  __shared__ int slot;
+  __shared__ int wave_sums[kTileThreads / 64 + 1];
+  __shared__ int wave_ends[kTileThreads / 64];
   if ((int)blockIdx.x < n) {
     if (descs[blockIdx.x].table_owner == (int)blockIdx.x) BuildTables(descs[blockIdx.x], L);   // (uniform per workgroup)
   } else {
-    CountTile(descs, n, (int)blockIdx.x - n, wave_sums, &slot);
+    CountTile(descs, n, (int)blockIdx.x - n, wave_sums, wave_ends);
   }
 }
 
