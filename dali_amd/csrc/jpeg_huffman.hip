@@ -251,23 +251,32 @@ __device__ __forceinline__ TileChunk LoadChunk(const daliamdJpegHuffDesc &d, int
     if (lane != 0) prev = from_below;              // (a lane past the end of the segment holds zeros: "no byte behind")
     if (lane != 63) behind = g + 16 < end ? from_above : 0u;
   }
+  // Sixteen bytes at once (a byte loop costs 20 instructions per byte): per dword the bytes that are 0xFF, 0x00 or RSTn's
+  // second byte as 0x80 flags (exact zero-byte test, no borrow between bytes), gathered into 16-bit masks, bit j = byte j.
+  auto zero_bytes = [](uint32_t x) { return ~((((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) | 0x7F7F7F7Fu); };
+  auto gather = [](uint32_t y) { return ((y >> 7) * 0x01020408u) >> 24; };   // flags of bytes 0..3 -> bits 0..3
+  uint32_t F = 0, Z = 0, D = 0;
 #pragma unroll
-  for (int j = 0; j < 16; j++) {
-    const uint32_t b = (c.w[j >> 2] >> (8 * (j & 3))) & 255u;
-    // the byte behind this one (zero past the end: a last 0xFF stays what it would be in front of a stuffed zero)
-    const uint32_t nb = j < 15 ? ((c.w[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 255u) : behind;
-    const bool valid = g + j >= head && g + j < end;
-    const bool next_valid = g + j + 1 < end;
-    const bool after_ff = prev == 0xFF && g + j > head;   // the first byte of the segment has no predecessor
-    const bool marker = b == 0xFF && next_valid && nb != 0;            // RSTn, fill byte or the end
-    const bool is_rst = marker && (nb & 0xF8u) == 0xD0u;
-    const bool is_end = marker && !is_rst && nb != 0xFF;
-    const bool dropped = marker || (after_ff && (b == 0 || (b & 0xF8u) == 0xD0u));
-    if (valid && !dropped) c.keep |= 1u << j;
-    if (valid && is_rst) c.rst |= 1u << j;
-    if (valid && is_end && c.end_j == 16) c.end_j = j;
-    prev = b;
+  for (int i = 0; i < 4; i++) {
+    F |= gather(zero_bytes(~c.w[i])) << (4 * i);
+    Z |= gather(zero_bytes(c.w[i])) << (4 * i);
+    D |= gather(zero_bytes((c.w[i] & 0xF8F8F8F8u) ^ 0xD0D0D0D0u)) << (4 * i);
   }
+  auto below = [](int k) { return k >= 16 ? 0xFFFFu : (k <= 0 ? 0u : (1u << k) - 1u); };   // bits [0, k)
+  const uint32_t valid = below(end - g) & ~below(head - g);      // bytes of the segment
+  const uint32_t next_valid = below(end - g - 1);                 // ... whose successor is one, too
+  F &= valid;
+  // what the byte BEHIND byte j is (byte 15: the neighbour's first; zero past the end: a last 0xFF stays what it would be
+  // in front of a stuffed zero)
+  const uint32_t nZ = (Z >> 1) | ((behind == 0u) << 15), nD = (D >> 1) | (((behind & 0xF8u) == 0xD0u) << 15),
+                 nF = (F >> 1) | ((behind == 0xFFu) << 15);
+  const uint32_t marker = F & next_valid & ~nZ;                   // RSTn, fill byte or the end
+  const uint32_t is_rst = marker & nD, is_end = marker & ~nD & ~nF;
+  // a byte behind a 0xFF: the stuffed zero, or the second byte of RSTn (the first byte of the segment has no predecessor)
+  const uint32_t after_ff = ((F << 1) | (prev == 0xFFu && g > head ? 1u : 0u)) & 0xFFFFu;
+  c.keep = valid & ~(marker | (after_ff & (Z | D)));
+  c.rst = is_rst;
+  c.end_j = is_end ? __ffs(is_end) - 1 : 16;
   return c;
 }
 

@@ -37,6 +37,20 @@ namespace daliamd {
 constexpr int kResampleThreads = 256;
 constexpr int kMaxLds = 60 * 1024;
 constexpr int kTargetLds = 26 * 1024;
+// Pitch of a staged window row in LDS: room for the row at any 16-byte phase (NB + 15 + 15).  DALIAMD_RS_ROW_PAD=1 makes it
+// congruent to 64 modulo 128 bytes: the vertical first pass reads 16 consecutive dwords per output row, two output rows
+// per 32-lane group of a ds_read_b32 (32 banks); when these tap neighbouring window rows, a pitch of 16 dwords modulo 32
+// puts the two runs on disjoint banks.  Measured (round 4, gpurun_out/r4i_pmc): SQ_LDS_BANK_CONFLICT 8.68 M -> 8.44 M per
+// launch, no change in time - rows two apart then collide instead, and the conflicts that count are elsewhere: the four
+// dword stores per item of the first pass (lane stride 4 dwords: two-way) and the second pass's gathers from tmp (16 pixel
+// pairs of a row spread over ~125 dwords: three to four lanes per bank).  Off: it costs 20 % more window LDS.
+#ifndef DALIAMD_RS_ROW_PAD
+#define DALIAMD_RS_ROW_PAD 0
+#endif
+__host__ __device__ inline int StagedRowPitch(int nb) {
+  const int need = (nb + 15 + 15) & ~15;
+  return DALIAMD_RS_ROW_PAD ? ((need - 64 + 127) & ~127) + 64 : need;
+}
 
 // ---------------------------------------------------------------------------------------------
 // shared host/device arithmetic
@@ -263,7 +277,7 @@ __device__ void MakeTileRec(const daliamdResampleDesc *descs, int ndesc, int til
   MinMax4(ClampI(ix_a, 0, ex), ClampI(ix_a + sup_x - 1, 0, ex), ClampI(ix_b, 0, ex), ClampI(ix_b + sup_x - 1, 0, ex), &x_lo, &x_hi);
   MinMax4(ClampI(iy_a, 0, ey), ClampI(iy_a + sup_y - 1, 0, ey), ClampI(iy_b, 0, ey), ClampI(iy_b + sup_y - 1, 0, ey), &y_lo, &y_hi);
   const int ncols = x_hi - x_lo + 1, nrows = y_hi - y_lo + 1;
-  const int NB = ncols * C, LP = (NB + 15 + 15) & ~15;
+  const int NB = ncols * C, LP = StagedRowPitch(NB);
   const bool vfirst = d.first_axis == 1, staged = d.staged != 0;
   r.win = reinterpret_cast<uint64_t>(d.in + (size_t)(d.lo[1] + y_lo) * d.in_pitch + (size_t)(d.lo[0] + x_lo) * C);
   r.buf_lo = reinterpret_cast<uint64_t>(d.in);
@@ -1125,7 +1139,7 @@ static int SetupOne(const daliamdResampleArgs &a, daliamdResampleDesc &d, int in
     size_t nrows = (size_t)std::ceil(th_ * std::abs(d.scale[1])) + d.support[1] + 2;
     ncols = std::min<size_t>(ncols, a.in_w);
     nrows = std::min<size_t>(nrows, a.in_h);
-    size_t lp = (ncols * a.channels + 15 + 15) & ~(size_t)15;
+    size_t lp = (size_t)StagedRowPitch((int)(ncols * a.channels));
     size_t stage = staged ? nrows * lp : 0;
     size_t tmp_elems = d.first_axis == 1 ? (size_t)th_ * ncols * a.channels : nrows * (size_t)tw_ * a.channels;
     return kLutLdsBytes + tables * 4 + 32 + stage + tmp_elems * 4;
