@@ -32,6 +32,8 @@ def _lib():
         lib.daliamdPipelineBuild.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int]
         lib.daliamdPipelineRun.argtypes = [C.c_void_p]
         lib.daliamdPipelineOutputs.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        lib.daliamdPipelineOutputsOnStream.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        lib.daliamdPipelineReleaseOnStream.argtypes = [C.c_void_p, C.c_void_p]
         lib.daliamdPipelineOutputInfo.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_char_p, C.c_int]
         lib.daliamdPipelineOutputSample.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p),
                                                     C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int64)]
@@ -194,6 +196,16 @@ class BackendPipeline:
         self.generation += 1
         check(self._lib.daliamdPipelineOutputs(self._h, C.byref(n)))
         return n.value
+
+    def outputs_on_stream(self, stream_handle):
+        """Stream-ordered hand-over: `stream_handle` (hipStream_t as an integer) waits for the iteration, the host does not."""
+        n = C.c_int(0)
+        self.generation += 1
+        check(self._lib.daliamdPipelineOutputsOnStream(self._h, C.c_void_p(stream_handle), C.byref(n)))
+        return n.value
+
+    def release_on_stream(self, stream_handle):
+        check(self._lib.daliamdPipelineReleaseOnStream(self._h, C.c_void_p(stream_handle)))
 
     def output_info(self, idx):
         info = (C.c_int64 * 4)()

@@ -224,6 +224,17 @@ API int daliamdPipelineOutputs(void *h, int *num_outputs) {
     *num_outputs = (int)ph->outputs.size();
   });
 }
+API int daliamdPipelineOutputsOnStream(void *h, void *consumer_stream, int *num_outputs) {
+  return Guard([&] {
+    auto *ph = static_cast<PipelineHandle *>(h);
+    ph->outputs.clear();
+    ph->outputs = ph->pipe->OutputsOnStream(consumer_stream);
+    *num_outputs = (int)ph->outputs.size();
+  });
+}
+API int daliamdPipelineReleaseOnStream(void *h, void *consumer_stream) {
+  return Guard([&] { static_cast<PipelineHandle *>(h)->pipe->ReleaseOnStream(consumer_stream); });
+}
 // info: [0] device (0 cpu / 1 gpu), [1] dtype, [2] num_samples, [3] dense (1) or row-padded (0)
 API int daliamdPipelineOutputInfo(void *h, int idx, int64_t *info, char *layout, int layout_len) {
   return Guard([&] {

@@ -7,6 +7,7 @@
 #include <dirent.h>
 #include <fcntl.h>
 #include <fnmatch.h>
+#include <sys/mman.h>
 #include <sys/resource.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -130,8 +131,9 @@ DALI_SCHEMA(LoaderBase)
                     "decoder cache. In this case, the output of the loader will be empty.", ArgValue::Bool(false))
     .AddOptionalArg("lazy_init", "Parse and prepare the dataset metadata only during the first run.", ArgValue::Bool(false))
     .AddOptionalArg("pad_last_batch", "If set to True, pads the shard by repeating the last sample.", ArgValue::Bool(false))
-    .AddOptionalArg("dont_use_mmap", "Use plain file I/O instead of memory mapping (always the case here).",
-                    ArgValue::Bool(false))
+    .AddOptionalArg("dont_use_mmap", "If set to True, the loader uses plain file I/O instead of mapping the files in "
+                    "memory.  (readers.file: mapped files stay mapped - up to DALI_AMD_READER_MMAP_MB, 4096 by default - and "
+                    "later epochs copy them from the mapping; the other readers always use plain I/O.)", ArgValue::Bool(false))
     .AddRandomSeedArg();
 
 DALI_SCHEMA(readers__File)
@@ -335,7 +337,8 @@ class FileReaderOp : public OperatorBase {
  public:
   explicit FileReaderOp(const OpSpec &spec)
       : OperatorBase(spec), loader_(spec), skip_cached_(spec.GetBool("skip_cached_images")),
-        read_ahead_(spec.GetBool("read_ahead")), device_id_((int)spec.GetInt("device_id")),
+        read_ahead_(spec.GetBool("read_ahead")), use_mmap_(!spec.GetBool("dont_use_mmap")),
+        device_id_((int)spec.GetInt("device_id")),
         depth_(std::max(1, (int)spec.GetInt("prefetch_queue_depth"))), consumed_state_(loader_) {
     Discover();
     loader_.Init((int64_t)entries_.size());
@@ -346,6 +349,16 @@ class FileReaderOp : public OperatorBase {
     size_cache_.assign(entries_.size(), -1);
     fds_ = std::make_unique<std::atomic<int>[]>(entries_.size());
     for (size_t i = 0; i < entries_.size(); i++) fds_[i].store(-1, std::memory_order_relaxed);
+    // long-lived mappings (the reference's default, file_loader / dont_use_mmap = False: FileStream::Open(.., mmap)): a
+    // file is mapped - populated - the first time it is read and stays mapped, so from the second epoch on a sample is
+    // one memcpy out of the mapping: no system call and none of the page cache's per-page work (the part of pread that
+    // does not scale with the number of reader threads).  Mappings are never taken down while the reader lives (munmap
+    // means TLB shoot-downs on every core the process runs on); files beyond the budget are read with pread.
+    maps_ = std::make_unique<std::atomic<const char *>[]>(entries_.size());
+    for (size_t i = 0; i < entries_.size(); i++) maps_[i].store(nullptr, std::memory_order_relaxed);
+    map_budget_ = (int64_t)4096 << 20;
+    if (const char *e = getenv("DALI_AMD_READER_MMAP_MB")) map_budget_ = (int64_t)(std::max(0.0, atof(e)) * 1048576.0);
+    if (!use_mmap_) map_budget_ = 0;
     // long-lived descriptors: at most half of what the process may open (the soft limit is raised to the hard one when a
     // small data set would otherwise not fit - every file of the shard is then opened once, not once per epoch)
     struct rlimit rl;
@@ -373,6 +386,8 @@ class FileReaderOp : public OperatorBase {
     for (size_t i = 0; i < entries_.size(); i++) {
       const int fd = fds_[i].load(std::memory_order_relaxed);
       if (fd >= 0) close(fd);
+      const char *m = maps_[i].load(std::memory_order_relaxed);
+      if (m && m != kNoMapping) munmap(const_cast<char *>(m), (size_t)size_cache_[i]);
     }
   }
 
@@ -605,11 +620,48 @@ class FileReaderOp : public OperatorBase {
     return fd;
   }
 
+  // The file's persistent mapping, made on first use while the budget lasts (nullptr: read it with pread).
+  const char *Mapping(int64_t idx, int fd, off_t size) {
+    const char *m = maps_[idx].load(std::memory_order_acquire);
+    if (m) return m == kNoMapping ? nullptr : m;
+    if (size <= 0 || mapped_bytes_.fetch_add((int64_t)size, std::memory_order_relaxed) + (int64_t)size > map_budget_) {
+      mapped_bytes_.fetch_sub(size > 0 ? (int64_t)size : 0, std::memory_order_relaxed);
+      maps_[idx].store(kNoMapping, std::memory_order_release);
+      return nullptr;
+    }
+    void *p = mmap(nullptr, (size_t)size, PROT_READ, MAP_SHARED | MAP_POPULATE, fd, 0);
+    if (p == MAP_FAILED) {
+      mapped_bytes_.fetch_sub((int64_t)size, std::memory_order_relaxed);
+      maps_[idx].store(kNoMapping, std::memory_order_release);
+      return nullptr;
+    }
+    const char *expected = nullptr;
+    if (!maps_[idx].compare_exchange_strong(expected, static_cast<const char *>(p), std::memory_order_acq_rel)) {
+      munmap(p, (size_t)size);   // another reader mapped the same file (a sample repeated inside the batches in flight)
+      mapped_bytes_.fetch_sub((int64_t)size, std::memory_order_relaxed);
+      return expected == kNoMapping ? nullptr : expected;
+    }
+    return static_cast<const char *>(p);
+  }
+
   std::string ReadSample(Prefetched &b, int i) {
     const int64_t idx = b.picks[i];
+    char *dst = static_cast<char *>(b.data.raw(i));
+    if (map_budget_ > 0) {   // already mapped: no descriptor needed (it may have been evicted)
+      const char *m = maps_[idx].load(std::memory_order_acquire);
+      if (m && m != kNoMapping) {
+        memcpy(dst, m, (size_t)b.sizes[i]);
+        return "";
+      }
+    }
     const int fd = Descriptor(idx);
     if (fd < 0) return make_string("Could not open file ", paths_[idx]);
-    char *dst = static_cast<char *>(b.data.raw(i));
+    if (map_budget_ > 0) {
+      if (const char *m = Mapping(idx, fd, b.sizes[i])) {
+        memcpy(dst, m, (size_t)b.sizes[i]);
+        return "";
+      }
+    }
     off_t got = 0;
     while (got < b.sizes[i]) {
       const ssize_t r = pread(fd, dst + got, (size_t)(b.sizes[i] - got), got);
@@ -626,7 +678,11 @@ class FileReaderOp : public OperatorBase {
   }
 
   Loader loader_;                 // planner thread only once the threads run
-  bool skip_cached_, read_ahead_;
+  bool skip_cached_, read_ahead_, use_mmap_;
+  std::unique_ptr<std::atomic<const char *>[]> maps_;   // per file: nullptr = not tried yet, kNoMapping = pread, else the mapping
+  static inline const char *const kNoMapping = reinterpret_cast<const char *>(1);
+  std::atomic<int64_t> mapped_bytes_{0};
+  int64_t map_budget_ = 0;
   int device_id_, depth_, num_workers_ = 1;
   std::vector<off_t> size_cache_;  // planner thread
   std::vector<std::string> paths_;

@@ -47,6 +47,7 @@ Pipeline::~Pipeline() {
   }
   nodes_.clear();
   for (auto e : slot_events_) if (e) daliamdEventDestroy(e);
+  for (auto e : release_events_) if (e) daliamdEventDestroy(e);
   if (copy_stream_) daliamdStreamDestroy(copy_stream_);
   for (auto st : streams_) daliamdStreamDestroy(st);
 }
@@ -205,6 +206,10 @@ void Pipeline::Build(const std::vector<std::pair<std::string, std::string>> &out
   slot_events_.assign(ring_, nullptr);
   if (!streams_.empty())
     for (auto &e : slot_events_) KCHECK(daliamdEventCreate(&e, 2));  // the consumer sleeps in Outputs(), it does not poll
+  release_events_.assign(ring_, nullptr);
+  release_pending_.assign(ring_, 0);
+  if (!streams_.empty())
+    for (auto &e : release_events_) KCHECK(daliamdEventCreate(&e, 2));
   if (op_timing_ && !streams_.empty())
     for (auto &n : nodes_) {
       if (n.type == OpType::CPU) continue;
@@ -261,6 +266,10 @@ void Pipeline::RunStage(bool device_stage, int64_t it, int slot, Iteration &res)
           if (stop_) return;
         }
         KCHECK(daliamdEventSynchronize(slot_events_[slot]));
+        if (release_pending_[slot]) {  // a stream-ordered consumer may still be reading the slot's outputs
+          KCHECK(daliamdEventSynchronize(release_events_[slot]));
+          release_pending_[slot] = 0;
+        }
         const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait).count();
         slot_wait_seconds_ += waited;
         std::lock_guard<std::mutex> g(host_times_m_);
@@ -400,9 +409,23 @@ void Pipeline::Run() {
   }
 }
 
-std::vector<std::shared_ptr<TensorList>> Pipeline::Outputs() {
+void Pipeline::RunPendingChecks() {
+  if (pending_checks_.slot < 0) return;
+  PendingChecks p = std::move(pending_checks_);
+  pending_checks_ = PendingChecks{};
+  KCHECK(daliamdEventSynchronize(slot_events_[p.slot]));
+  for (auto &chk : p.checks) chk();
+}
+
+std::vector<std::shared_ptr<TensorList>> Pipeline::Outputs() { return TakeOutputs(nullptr, false); }
+std::vector<std::shared_ptr<TensorList>> Pipeline::OutputsOnStream(daliamdStream_t consumer_stream) {
+  return TakeOutputs(consumer_stream, true);
+}
+
+std::vector<std::shared_ptr<TensorList>> Pipeline::TakeOutputs(daliamdStream_t consumer_stream, bool on_stream) {
   DALI_ENFORCE(built_, "\"Build()\" must be called before \"Outputs()\"");
   DALI_ENFORCE(scheduled_ > consumed_, "There are no iterations scheduled; call Run() before Outputs()");
+  RunPendingChecks();  // of the previous stream-ordered hand-over (throws that iteration's error)
   Iteration res;
   {
     std::unique_lock<std::mutex> lk(m_);
@@ -412,13 +435,24 @@ std::vector<std::shared_ptr<TensorList>> Pipeline::Outputs() {
   }
   consumed_++;
   holding_ = true;
+  held_slot_ = res.slot;
   {
     std::lock_guard<std::mutex> g(launches_m_);
     last_launches_ = res.launches;
   }
   if (res.failed) throw std::runtime_error(res.error);
-  if (!streams_.empty()) KCHECK(daliamdEventSynchronize(slot_events_[res.slot]));
-  if (op_timing_)
+  bool complete = true;
+  if (!streams_.empty()) {
+    if (on_stream) {
+      KCHECK(daliamdStreamWaitEvent(consumer_stream, slot_events_[res.slot]));
+      int done = 0;
+      KCHECK(daliamdEventQuery(slot_events_[res.slot], &done));
+      complete = done != 0;
+    } else {
+      KCHECK(daliamdEventSynchronize(slot_events_[res.slot]));
+    }
+  }
+  if (op_timing_ && complete)
     for (auto &n : nodes_) {
       if (n.ev_begin.empty()) continue;
       float ms = 0;
@@ -427,10 +461,22 @@ std::vector<std::shared_ptr<TensorList>> Pipeline::Outputs() {
         n.device_ms_count++;
       }
     }
-  for (auto &chk : res.checks) chk();
+  if (complete) {
+    for (auto &chk : res.checks) chk();
+  } else if (!res.checks.empty()) {
+    pending_checks_.slot = res.slot;
+    pending_checks_.checks = std::move(res.checks);
+  }
   std::vector<std::shared_ptr<TensorList>> out;
   for (auto &o : outputs_) out.push_back(nodes_[o.first].out_ring[o.second][res.slot]);
   return out;
+}
+
+void Pipeline::ReleaseOnStream(daliamdStream_t consumer_stream) {
+  if (streams_.empty() || held_slot_ < 0) return;
+  KCHECK(daliamdEventRecord(release_events_[held_slot_], consumer_stream));
+  release_pending_[held_slot_] = 1;
+  held_slot_ = -1;
 }
 
 void Pipeline::FeedInput(const std::string &op_name, const std::vector<const void *> &data,

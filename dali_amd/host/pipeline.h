@@ -43,6 +43,16 @@ class Pipeline {
   void Run();
   // waits for the oldest scheduled iteration and returns its outputs (released at the next call)
   std::vector<std::shared_ptr<TensorList>> Outputs();
+  // The same for a consumer that works on a HIP stream of its own (a framework iterator): the host does not wait for
+  // the iteration's device work - `consumer_stream` does (stream-ordered hand-over), so the consumer's copy queues
+  // behind the batch and the call returns as soon as the iteration has been enqueued.  The operators' completion
+  // checks (decoder status words) run here when the work happens to be complete and otherwise at the next Outputs*()
+  // call: an error of iteration i is raised by the call for i or for i + 1.
+  std::vector<std::shared_ptr<TensorList>> OutputsOnStream(daliamdStream_t consumer_stream);
+  // The consumer's reads of the outputs handed out last are enqueued on `consumer_stream`: their ring slot is not
+  // written again before everything in that stream up to this call has completed.  (Without this call a consumer
+  // that took the outputs with OutputsOnStream must have finished reading on its own.)
+  void ReleaseOnStream(daliamdStream_t consumer_stream);
   // feed one batch to an ExternalSource operator instance
   void FeedInput(const std::string &op_name, const std::vector<const void *> &data,
                  const std::vector<TensorShape> &shapes, DALIDataType type, const std::string &layout);
@@ -139,6 +149,17 @@ class Pipeline {
   std::deque<Iteration> results_;
   int64_t device_stages_done_ = 0;  // iterations whose device stage has been enqueued (slot event recorded)
   std::vector<daliamdEvent_t> slot_events_;
+  // OutputsOnStream / ReleaseOnStream: per ring slot, the event the consumer's stream recorded behind its reads
+  // (written by the consumer thread before it schedules the slot's next user: Run() publishes it under m_)
+  std::vector<daliamdEvent_t> release_events_;
+  std::vector<char> release_pending_;
+  int held_slot_ = -1;
+  struct PendingChecks {
+    int slot = -1;
+    std::vector<std::function<void()>> checks;
+  } pending_checks_;
+  void RunPendingChecks();
+  std::vector<std::shared_ptr<TensorList>> TakeOutputs(daliamdStream_t consumer_stream, bool on_stream);
   int64_t scheduled_ = 0, consumed_ = 0;
   bool stop_ = false;
   bool holding_ = false;  // the consumer holds the outputs of iteration consumed_-1

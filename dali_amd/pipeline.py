@@ -190,10 +190,12 @@ class Pipeline:
         while self._scheduled - self._consumed < self._prefetch_queue_depth:
             self.schedule_run()
 
-    def share_outputs(self):
+    def share_outputs(self, cuda_stream=None):
+        """`cuda_stream` (a hipStream_t handle, e.g. torch.cuda.Stream.cuda_stream): stream-ordered hand-over - the host
+        does not wait for the iteration's device work, that stream does; release with release_outputs(cuda_stream)."""
         if self._scheduled <= self._consumed:
             raise RuntimeError("There are no scheduled runs; call schedule_run() first")
-        n = self._backend.outputs()
+        n = self._backend.outputs() if cuda_stream is None else self._backend.outputs_on_stream(int(cuda_stream))
         self._consumed += 1
         outs = []
         for i in range(n):
@@ -202,7 +204,11 @@ class Pipeline:
         self._held = outs
         return tuple(outs)
 
-    def release_outputs(self):
+    def release_outputs(self, cuda_stream=None):
+        """`cuda_stream`: the outputs are still being read by work enqueued on that stream; their buffers are not
+        reused before the stream has passed this point."""
+        if cuda_stream is not None and self._held is not None:
+            self._backend.release_on_stream(int(cuda_stream))
         self._held = None
 
     def outputs(self):

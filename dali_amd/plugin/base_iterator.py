@@ -124,6 +124,11 @@ class _DaliBaseIterator:
     def _convert(self, outputs_per_pipe, valid_per_pipe):
         raise NotImplementedError
 
+    def _run_pipe(self, pipe):
+        """One iteration of one pipeline; a plugin whose consumer works on a device stream overrides this with the
+        stream-ordered hand-over (Pipeline.share_outputs(cuda_stream=...))."""
+        return pipe.run()
+
     # ---- epoch logic
     def _fetch(self):
         if self._size > 0 and self._counter >= self._size:
@@ -131,7 +136,7 @@ class _DaliBaseIterator:
         drop = (self._book.should_drop_next(self._counter) if self._book
                 else self._policy == LastBatchPolicy.DROP and self._size > 0 and
                 self._counter + self._num_gpus * self.batch_size > self._size)
-        outs = [p.run() for p in self._pipes]
+        outs = [self._run_pipe(p) for p in self._pipes]
         self._counter += self.batch_size if self._book else self._num_gpus * self.batch_size
         if drop:
             self._end_epoch()

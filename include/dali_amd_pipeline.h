@@ -57,6 +57,14 @@ DALIAMD_PIPE_API int daliamdPipelineRun(void *pipe);                            
 /* c_api.h:487-498 daliOutput / daliShareOutput: waits for the oldest scheduled iteration, releases the previous one;
  * the outputs stay valid until the next call */
 DALIAMD_PIPE_API int daliamdPipelineOutputs(void *pipe, int *num_outputs);
+/* c_api.h:560-590 daliOutputCopy with a caller stream / dali/python/nvidia/dali/plugin/pytorch/torch_utils.py:34-75
+ * feed_ndarray(cuda_stream=..., non_blocking): the stream-ordered hand-over.  OutputsOnStream does not wait on the host for
+ * the iteration's device work; `consumer_stream` (hipStream_t) is made to wait for it, so whatever the consumer enqueues
+ * there afterwards reads finished outputs.  ReleaseOnStream marks the point in that stream behind which the outputs are no
+ * longer read: their buffers are not written again before the stream has passed it.  Completion checks (decoder status)
+ * of an iteration are raised by the Outputs* call for it or by the next one. */
+DALIAMD_PIPE_API int daliamdPipelineOutputsOnStream(void *pipe, void *consumer_stream, int *num_outputs);
+DALIAMD_PIPE_API int daliamdPipelineReleaseOnStream(void *pipe, void *consumer_stream);
 /* info: [0] device (0 cpu / 1 gpu), [1] dtype (DALIDataType), [2] num_samples, [3] 1 = dense rows */
 DALIAMD_PIPE_API int daliamdPipelineOutputInfo(void *pipe, int output, int64_t *info4, char *layout, int layout_len);
 DALIAMD_PIPE_API int daliamdPipelineOutputSample(void *pipe, int output, int sample, void **ptr, int64_t *shape8, int *ndim,

@@ -89,6 +89,48 @@ def test_descriptor_cache_evicts_without_losing_a_read(dataset, monkeypatch):
     assert len(os.listdir("/proc/self/fd")) < 200
 
 
+@pytest.mark.parametrize("budget_mb, dont_use_mmap", [(None, False), ("0", False), (None, True)])
+def test_mapped_and_plain_reads_agree(dataset, monkeypatch, budget_mb, dont_use_mmap):
+    """Persistent mappings (default, file_loader's dont_use_mmap=False), no budget for them, and dont_use_mmap=True: the
+    same bytes in the same order over several epochs, also with descriptors being evicted under the mappings."""
+    root, files = dataset
+    if budget_mb is not None:
+        monkeypatch.setenv("DALI_AMD_READER_MMAP_MB", budget_mb)
+    monkeypatch.setenv("DALI_AMD_READER_FD_CAP", "5")
+    pipe = _pipe(root, 16, prefetch_queue_depth=3, dont_use_mmap=dont_use_mmap)
+    got = _take(pipe, 26, files)                          # four epochs, every byte compared
+    assert got[:103] == list(range(103))
+
+
+def test_mapping_budget_falls_back_to_plain_reads(dataset, monkeypatch):
+    """0.1 MB of mappings for a larger data set: the files behind the budget are read with pread, every byte still right."""
+    root, files = dataset
+    total = sum(os.path.getsize(f) for f, _ in files) if isinstance(files[0], tuple) else sum(os.path.getsize(f) for f in files)
+    assert total > 200000
+    import gc
+    gc.collect()                                              # (readers of earlier tests take their mappings with them)
+    before = len(_smaps_of(root))
+    monkeypatch.setenv("DALI_AMD_READER_MMAP_MB", "0.1")
+    pipe = _pipe(root, 16, prefetch_queue_depth=2)
+    got = _take(pipe, 20, files)
+    assert got[:103] == list(range(103))
+    maps = _smaps_of(root)
+    mapped = sum(int(l.split()[1]) for l in maps) * 1024      # (page granular: up to 4 KB more than a file's size)
+    if before == 0:
+        assert 0 < len(maps) < 103 and mapped <= 104858 + 4096 * len(maps)
+
+
+def _smaps_of(root):
+    out, keep = [], False
+    for line in open("/proc/self/smaps"):
+        head = line.split()
+        if head and not head[0].endswith(":"):        # "start-end perms offset dev inode [path]": a new mapping
+            keep = len(head) >= 6 and head[-1].startswith(str(root))
+        elif keep and line.startswith("Size:"):
+            out.append(line)
+    return out
+
+
 def test_a_vanished_file_is_reported_with_its_name(dataset, tmp_path):
     from dali_amd import fn
     from dali_amd.pipeline import Pipeline
