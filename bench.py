@@ -982,7 +982,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    from dali_amd.backend import HUFFMAN_KERNELS, huffman_algorithmic_bytes
+    from dali_amd.backend import HUFFMAN_KERNELS, HUFFMAN_KERNEL_NAMES, huffman_algorithmic_bytes
     root = None
     pipe_info = None
     if args.driver == "pipeline":
@@ -999,11 +999,14 @@ def main():
         resample_bytes, symbols = [r["resample_bytes"]], r["symbols"]
         algo = dict(huffman_algorithmic_bytes(stream_bytes, coef_elems_mean, B, True))
         algo["JpegColorKernel"] = coef_elems_mean + 3 * pixels_mean          # planes in + RGB out
+        # the block kernel with the fused colour output: stream + per-block position / level in, RGB out (no planes)
+        algo["BlockColorKernel"] = algo["BlockKernel"] - coef_elems_mean + 3 * pixels_mean
+        algo["SeamKernel"] = 0.0
         algo["ResampleKernel"] = r["resample_bytes"]
         algo["ResampleTablesKernel"] = 0.0
         kern = {k: (float(algo.get(k, 0.0)), ms) for k, (calls, ms) in r["times"].items()}
         launches = {k: calls for k, (calls, ms) in r["times"].items()}
-        huffman_total_ms = float(sum(kern[k][1] for k in HUFFMAN_KERNELS if k in kern))
+        huffman_total_ms = float(sum(kern[k][1] for k in HUFFMAN_KERNEL_NAMES if k in kern))
         host_ms_per_step = r["host_times"].get("<device stage>", 0.0)
         pipe_info = {"driver": "dali_amd.Pipeline (C++ executor), data set resident in HBM as encoded streams "
                                "(decoders.image cache_type='encoded' + readers.file skip_cached_images)",
@@ -1051,7 +1054,7 @@ def main():
                         "transformed and colour-converted"}
             del pipe2
         if single_stream:
-            huffman_single_ms = float(sum(single_stream.get(k, 0.0) for k in HUFFMAN_KERNELS))
+            huffman_single_ms = float(sum(single_stream.get(k, 0.0) for k in HUFFMAN_KERNEL_NAMES))
             pipe_info["single_stream_kernel_ms"] = single_stream
             pipe_info["single_stream_note"] = ("per-kernel durations with ONE batch in flight (prefetch_queue_depth=1, same "
                                                "resident streams, HIP events around every launch): kernel cost; the per_kernel "
@@ -1152,7 +1155,9 @@ def main():
                          "measured_copy_ceiling_GBps": copy_ceiling, "frac_of_measured_ceiling": ach / copy_ceiling,
                          "note": "the entropy decoder's kernels are serial-bit decode loops, not HBM streams (SURVEY.md "
                                  "8(d)); whole_step prices one pass by the end-to-end formula 6P + 3sP + 6O (+ the JPEG "
-                                 "bytes), i.e. WITHOUT the decoder's internal scratch traffic",
+                                 "bytes), i.e. WITHOUT the decoder's internal scratch traffic (the formula of every round: "
+                                 "since round 4 the 1.5 P of component planes written and read back inside it no longer "
+                                 "exist when BlockColorKernel is in launches_timed)",
                          "whole_step": {"algorithmic_bytes": post_entropy + (stream_bytes or 0),
                                         "achieved_GBps": (post_entropy + (stream_bytes or 0)) / (step_ms * 1e-3) / 1e9,
                                         "frac": (post_entropy + (stream_bytes or 0)) / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

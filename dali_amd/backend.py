@@ -306,16 +306,19 @@ class JpegBatchPlan:
         return {"scratch": torch.empty(max(self.huffman_scratch_bytes, 256), dtype=torch.uint8, device=device),
                 "status": torch.zeros(max(len(self._huff_sel), 1), dtype=torch.int32, device=device)}
 
-    def huffman_descs(self, coef_dev, ws=None, planes_dev=None):
+    def huffman_descs(self, coef_dev, ws=None, planes_dev=None, rgb_dev=None):
         """daliamdJpegHuffDesc table of the GPU-eligible streams (numpy structured array) + the grid sizes.
         planes_dev: fused output - the decoder dequantises and inverse-transforms the blocks itself and writes the
-        component planes (the input of the colour kernel); coef_dev may be None then."""
+        component planes (the input of the colour kernel); coef_dev may be None then.
+        rgb_dev: the batch's output buffer (JpegBatchPlan.out_off / out_pitch layout) - streams whose geometry allows it
+        (YCbCr 4:2:0, no region of interest) leave the decoder as RGB (fused colour output; self.fused_color says which)."""
         lib = capi.kernels()
         ws = ws or self._huff_ws
         # the table only depends on the plan and on where the buffers are: a caller that decodes the same resident batch
         # into the same buffers again (benchmarks) gets the table it built the first time
         key = (ws["scratch"].data_ptr(), ws["status"].data_ptr(), None if coef_dev is None else coef_dev.data_ptr(),
-               None if planes_dev is None else planes_dev.data_ptr(), self._ecs_dev.data_ptr())
+               None if planes_dev is None else planes_dev.data_ptr(), self._ecs_dev.data_ptr(),
+               None if rgb_dev is None else rgb_dev.data_ptr())
         cache = self.__dict__.setdefault("_huff_desc_cache", {})
         if key in cache:
             return cache[key]
@@ -358,40 +361,59 @@ class JpegBatchPlan:
             d["plane"] = np.where(self.comp_mask[sel], planes_dev.data_ptr() + self.plane_off[sel], 0)
         else:
             d["plane_pitch"] = 0
-        ntiles, nsegs, nbwg = C.c_int(0), C.c_int(0), C.c_int(0)
-        capi.check(lib.daliamdJpegHuffmanSetup(d.ctypes.data_as(C.c_void_p), m, C.byref(ntiles), C.byref(nsegs),
-                                               C.byref(nbwg)))
+        fused = np.zeros(self.n, bool)
+        if rgb_dev is not None and m:
+            rgb_ptr = rgb_dev.data_ptr() + self.out_off[sel]
+            ok = (inf["color"][sel] != capi.JPEG_RGB) & ((inf["width"][sel] > 4) | (sc["blocks_per_mcu"][sel] != 6)) & \
+                (self.out_pitch[sel] % 8 == 0) & (rgb_ptr % 8 == 0)
+            if self.roi_plans is not None:
+                ok &= ~self.has_roi[sel]
+            one = _dtype(capi.JpegHuffDesc).itemsize
+            base = d.ctypes.data
+            for j in np.nonzero(ok)[0]:
+                ok[j] = bool(lib.daliamdJpegHuffmanColorFusable(C.c_void_p(base + int(j) * one)))
+            d["rgb"] = np.where(ok, rgb_ptr, 0)
+            d["rgb_pitch"] = np.where(ok, self.out_pitch[sel], 0)
+            d["width"] = inf["width"][sel]
+            d["height"] = inf["height"][sel]
+            fused[sel] = ok
+        self.fused_color = fused
+        ntiles, nsegs, nbwg, kinds = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        capi.check(lib.daliamdJpegHuffmanSetupColor(d.ctypes.data_as(C.c_void_p), m, C.byref(ntiles), C.byref(nsegs),
+                                                    C.byref(nbwg), C.byref(kinds)))
         if len(cache) > 8:
             cache.clear()
-        cache[key] = (d, ntiles.value, nsegs.value, nbwg.value)
+        cache[key] = _HuffDescs((d, ntiles.value, nsegs.value, nbwg.value), kinds.value, fused)
         return cache[key]
 
-    def run_gpu_huffman(self, coef_dev, descs=None, events=None, ws=None, kernel_events=None, planes_dev=None):
+    def run_gpu_huffman(self, coef_dev, descs=None, events=None, ws=None, kernel_events=None, planes_dev=None, rgb_dev=None):
         """Launches the GPU entropy decoder for the uploaded streams on the current stream (every decoded block is
         written exactly once as a full line: no zero-fill).  events: optional (before, after) events for timing.
-        planes_dev: fused dequantisation + IDCT (see huffman_descs)."""
+        planes_dev: fused dequantisation + IDCT; rgb_dev: fused colour output where possible (see huffman_descs)."""
         lib = capi.kernels()
-        dev = (coef_dev if coef_dev is not None else planes_dev).device
+        dev = (coef_dev if coef_dev is not None else planes_dev if planes_dev is not None else rgb_dev).device
         m = len(self._huff_sel)
         ws = ws or self._huff_ws
         if descs is None:
-            descs = self.huffman_descs(coef_dev, ws, planes_dev)
+            descs = self.huffman_descs(coef_dev, ws, planes_dev, rgb_dev)
         table, ntiles, nsegs, nbwg = descs
+        kinds = getattr(descs, "kinds", 1)
+        self.fused_color = getattr(descs, "fused", np.zeros(self.n, bool))
         d_dev = _uploader.upload(table, dev) if m else None
         s = current_stream_ptr(dev)
         if events:
             events[0].record()
         if m and kernel_events is not None:   # ctypes array of daliamdEvent_t (see KernelEvents)
-            capi.check(lib.daliamdJpegHuffmanRunProfiled(s, C.c_void_p(d_dev.data_ptr()), m, ntiles, nsegs, nbwg,
-                                                         kernel_events))
+            capi.check(lib.daliamdJpegHuffmanRunProfiledColor(s, C.c_void_p(d_dev.data_ptr()), m, ntiles, nsegs, nbwg, kinds,
+                                                              kernel_events))
         elif m:
-            capi.check(lib.daliamdJpegHuffmanRun(s, C.c_void_p(d_dev.data_ptr()), m, ntiles, nsegs, nbwg))
+            capi.check(lib.daliamdJpegHuffmanRunColor(s, C.c_void_p(d_dev.data_ptr()), m, ntiles, nsegs, nbwg, kinds))
         if events:
             events[1].record()
         self._huff_keep = [d_dev]
         return ws["status"][:m]
 
-    def entropy_decode_gpu(self, coef_dev, num_threads=None, planes_dev=None):
+    def entropy_decode_gpu(self, coef_dev, num_threads=None, planes_dev=None, rgb_dev=None):
         """Entropy-decodes the batch into `coef_dev` (int16 device tensor of self.coef_elems elements):
         eligible streams on the GPU (daliamdJpegHuffmanRun), the rest (progressive,
         multi-scan) on the host.  Returns the device status tensor (one int32 per GPU-decoded stream) and the
@@ -400,7 +422,7 @@ class JpegBatchPlan:
         self.upload_streams(dev)
         sel = self._huff_sel
         rest = np.nonzero(~self.gpu_eligible)[0]
-        status = self.run_gpu_huffman(coef_dev, planes_dev=planes_dev)
+        status = self.run_gpu_huffman(coef_dev, planes_dev=planes_dev, rgb_dev=rgb_dev)
         keep = []
         if len(rest):
             host = capi.host()
@@ -454,7 +476,9 @@ class JpegBatchPlan:
         fused_huffman: the GPU entropy decoder already wrote the planes of the streams it decoded (huffman_descs with
         planes_dev): only the host-decoded streams go through the IDCT kernel."""
         lib = capi.kernels()
-        key = (coef_dev.data_ptr(), planes_dev.data_ptr(), out_dev.data_ptr(), bool(fused_huffman))
+        skip = getattr(self, "fused_color", None) if fused_huffman else None   # left the entropy decoder as RGB
+        key = (coef_dev.data_ptr(), planes_dev.data_ptr(), out_dev.data_ptr(), bool(fused_huffman),
+               None if skip is None else skip.tobytes())
         cache = self.__dict__.setdefault("_stage_desc_cache", {})
         if key in cache:
             return cache[key]
@@ -499,13 +523,18 @@ class JpegBatchPlan:
             if self.roi_plans is not None:
                 for f in ("roi_x0", "roi_y0", "roi_w", "roi_h", "out_x0", "out_y0"):
                     color[f][:self.n] = np.where(self.has_roi, self.roi_plans[f], 0)
+        n_color = self.n
+        if skip is not None and skip.any():
+            kept = color[:self.n][~skip]
+            n_color = len(kept)
+            color = np.ascontiguousarray(kept) if n_color else np.zeros(1, _dtype(capi.JpegColorDesc))
         n_idct_wg, n_color_wg, color_mask_out = C.c_int(0), C.c_int(0), C.c_int(0)
         capi.check(lib.daliamdJpegIdctSetup(idct.ctypes.data_as(C.c_void_p), ncomp_total, C.byref(n_idct_wg)))
-        capi.check(lib.daliamdJpegColorSetup(color.ctypes.data_as(C.c_void_p), self.n, C.byref(n_color_wg),
+        capi.check(lib.daliamdJpegColorSetup(color.ctypes.data_as(C.c_void_p), n_color, C.byref(n_color_wg),
                                              C.byref(color_mask_out)))
         if len(cache) > 8:
             cache.clear()
-        cache[key] = ((idct, ncomp_total, n_idct_wg.value), (color, self.n, (n_color_wg.value, color_mask_out.value)))
+        cache[key] = ((idct, ncomp_total, n_idct_wg.value), (color, n_color, (n_color_wg.value, color_mask_out.value)))
         return cache[key]
 
     def output_views(self, out_dev):
@@ -541,30 +570,44 @@ def jpeg_gpu_stage(plan, coef_dev, planes_dev, out_dev, descs=None, split_events
     return idct_dev, color_dev
 
 
-def decode_jpeg_batch(encoded, device="cuda", num_threads=None, out_pitch_align=16, huffman="gpu", rois=None, exact_scan=True):
+class _HuffDescs(tuple):
+    """(table, tiles, segments, block workgroups) of JpegBatchPlan.huffman_descs + which block kernel instances the table
+    needs (`kinds`: bit 0 planes / coefficients, bit 1 fused colour output) and which samples leave as RGB (`fused`)."""
+
+    def __new__(cls, items, kinds, fused):
+        self = super().__new__(cls, items)
+        self.kinds, self.fused = kinds, fused
+        return self
+
+
+def decode_jpeg_batch(encoded, device="cuda", num_threads=None, out_pitch_align=16, huffman="gpu", rois=None, exact_scan=True,
+                      fuse_color=False):
     """Decodes a batch of JPEG byte strings -> list of u8 HWC RGB device tensors.
     rois: optional per-sample windows (y0, x0, h, w): region-of-interest decode (decoders.image_crop & co.).
 
     huffman="gpu": entropy decoding on the device for baseline single-scan streams (host for the rest);
     huffman="host": header parse + Huffman on the host thread pool into pinned memory (the hybrid path).
+    fuse_color: 4:2:0 / 4:4:4 / grayscale streams leave the GPU entropy decoder as RGB (daliamdJpegHuffDesc.rgb; same bits,
+    fewer bytes moved, measured slower on MI355X - see DESIGN.md section 9 - hence opt-in).
     Dequantisation, IDCT, upsampling and colour conversion always run on the device."""
     device = torch.device(device)
     plan = JpegBatchPlan(encoded, out_pitch_align, rois=rois, exact_scan=exact_scan)
     status = None
     planes = torch.empty(max(plan.plane_bytes, 1), dtype=torch.uint8, device=device)
+    out = torch.empty(max(plan.out_bytes, 1), dtype=torch.uint8, device=device)
     if huffman == "gpu":
         # the GPU entropy decoder writes the component planes itself (fused dequantisation + IDCT); the coefficient
         # buffer only carries the host-decoded streams (progressive, restart markers, ...) to the IDCT kernel
         coef_host = None
         coef_dev = torch.empty(max(plan.coef_elems, 1), dtype=torch.int16, device=device)
-        status, _ = plan.entropy_decode_gpu(coef_dev, num_threads, planes_dev=planes)
+        # ... and, fuse_color, the RGB image of every YCbCr 4:2:0 stream (no colour launch for those)
+        status, _ = plan.entropy_decode_gpu(coef_dev, num_threads, planes_dev=planes, rgb_dev=out if fuse_color else None)
     elif huffman == "host":
         coef_host = torch.empty(max(plan.coef_elems, 1), dtype=torch.int16, pin_memory=True)
         plan.entropy_decode(coef_host, num_threads)
         coef_dev = coef_host.to(device, non_blocking=True)
     else:
         raise ValueError(f"huffman must be 'gpu' or 'host', got {huffman!r}")
-    out = torch.empty(max(plan.out_bytes, 1), dtype=torch.uint8, device=device)
     keep = jpeg_gpu_stage(plan, coef_dev, planes, out,
                           descs=plan.build_descs(coef_dev, planes, out, fused_huffman=huffman == "gpu"))
     views = plan.output_views(out)
@@ -601,6 +644,9 @@ def _fill4(dst, src):
 
 
 HUFFMAN_KERNELS = ("PrepareKernel", "UnstuffScatterKernel", "SyncKernel", "PropagateKernel", "DcKernel", "BlockKernel")
+# names the launches of daliamdJpegHuffmanRunColor are timed under (daliamdKernelTimingReport): the six stages above, the
+# block kernel's instance with the fused colour output and the seam launch behind it
+HUFFMAN_KERNEL_NAMES = HUFFMAN_KERNELS + ("BlockColorKernel", "SeamKernel")
 
 
 def huffman_algorithmic_bytes(stream_bytes, coef_elems, num_streams, fused):

@@ -14,17 +14,9 @@
 // Workgroup = 32 x 8 threads = a 256 x (8 * kRowsPerThread) pixel tile.
 // HBM traffic per pixel: 1 + 2/(h*v ratio) bytes read, 3 bytes written.
 #include "common.h"
+#include "jpeg_color_math.h"
 
 namespace daliamd {
-
-// Explicit global address space: the pointers come out of a descriptor in memory, and the generic ("flat") accesses
-// the compiler would otherwise emit are slower and tie up the LDS counter as well.
-using GBytes = const uint8_t __attribute__((address_space(1)));
-using GWords = const uint32_t __attribute__((address_space(1)));
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-using GPair = const u32x2 __attribute__((address_space(1)));
-using GOutBytes = uint8_t __attribute__((address_space(1)));
-using GOutPair = u32x2 __attribute__((address_space(1)));
 
 constexpr int kColorThreads = 256;
 constexpr int kTileW = 256;  // pixels
@@ -33,57 +25,6 @@ constexpr int kTileW = 256;  // pixels
 #endif
 constexpr int kRowsPerThread = DALIAMD_COLOR_ROWS;  // consecutive rows per thread (even): the per-image set-up is paid once for all of them
 constexpr int kTileH = 8 * kRowsPerThread;
-
-#define SCALEBITS 16
-#define ONE_HALF (1 << (SCALEBITS - 1))
-#define FIXC(x) ((int32_t)((x) * (1L << SCALEBITS) + 0.5))
-
-__device__ __forceinline__ uint32_t Clamp8(int v) { return (uint32_t)min(max(v, 0), 255); }
-// ConvertSat<uint8_t>(float): clamp, round half away from zero
-__device__ __forceinline__ uint32_t SatRound8(float v) { return !(v > 0.0f) ? 0u : v >= 255.0f ? 255u : (uint32_t)(v + 0.5f); }
-
-enum UpsampleMode { kFull = 0, kH2V1 = 1, kH2V2 = 2, kH1V2 = 3, kBox = 4 };
-
-__device__ __forceinline__ int ClampI(int v, int lo, int hi) { return min(max(v, lo), hi); }
-
-// Triangle filter along x for the pixels x0..x0+7 from the (already vertically combined) samples around them.
-// sv[i] = sample (x0 >> 1) - 1 + i (clamped), i = 0..6; SHIFT/BIAS as in jdsample.c (h2v1: 2 / 1,2; h2v2: 4 / 8,7).
-template <int SHIFT, int BIAS_EVEN, int BIAS_ODD>
-__device__ __forceinline__ void TriangleX8(const int sv[7], bool odd, int out[8]) {
-  if (!odd) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      out[2 * i] = (sv[1 + i] * 3 + sv[i] + BIAS_EVEN) >> SHIFT;
-      out[2 * i + 1] = (sv[1 + i] * 3 + sv[2 + i] + BIAS_ODD) >> SHIFT;
-    }
-  } else {  // x0 odd: the first pixel is the odd half of sample (x0 >> 1)
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      out[2 * i] = (sv[1 + i] * 3 + sv[2 + i] + BIAS_ODD) >> SHIFT;
-      out[2 * i + 1] = (sv[2 + i] * 3 + sv[1 + i] + BIAS_EVEN) >> SHIFT;
-    }
-  }
-}
-
-// Samples k0-1 .. k0+5 of one row with three dword loads instead of seven byte loads (k0 and the row start are
-// multiples of 4; rows are padded to 8-sample blocks, so the dword behind k0 is inside the row unless k0 is its last
-// dword - then the samples it would hold are beyond the component anyway and ClampRight7 replaces them).
-// The left neighbour of sample 0 is sample 0.
-__device__ __forceinline__ void LoadSamples7(GBytes *__restrict__ row, int pitch, int k0, int s[7]) {
-  const uint32_t a = *reinterpret_cast<GWords *>(row + max(k0 - 4, 0));
-  const uint32_t b = *reinterpret_cast<GWords *>(row + k0);
-  const uint32_t c = *reinterpret_cast<GWords *>(row + min(k0 + 4, pitch - 4));
-  s[0] = k0 ? (int)(a >> 24) : (int)(b & 255);
-  s[1] = (int)(b & 255); s[2] = (int)((b >> 8) & 255); s[3] = (int)((b >> 16) & 255); s[4] = (int)(b >> 24);
-  s[5] = (int)(c & 255); s[6] = (int)((c >> 8) & 255);
-}
-// Neighbour indices are clamped to the last sample dw-1 (>= k0): every later entry repeats its predecessor.
-__device__ __forceinline__ void ClampRight7(int s[7], int k0, int dw) {
-  if (k0 + 5 > dw - 1) {
-#pragma unroll
-    for (int i = 2; i < 7; i++) s[i] = k0 - 1 + i > dw - 1 ? s[i - 1] : s[i];
-  }
-}
 
 // Fetches the 8 upsampled samples of one component for pixels x0..x0+7 of output row y (any x0: with a region of
 // interest the 8-pixel groups are aligned to the region, not to the image).
@@ -163,11 +104,6 @@ __device__ __forceinline__ int ModeOf(const daliamdJpegColorDesc &d, int c, int 
 // rows r-1 .. r+ROWS/2 (r = y0/2).  ALL loads of the thread (2 luma + 6 chroma dwords per row pair, + 12) are issued
 // before the first use, so one memory round trip covers all its rows (the row-by-row form cannot overlap them: the
 // stores may alias the planes), and the descriptor walk in front of them is paid once per 8 x ROWS pixels.
-__device__ __forceinline__ void Chroma7(uint32_t a, uint32_t b, uint32_t c, bool first, int s[7]) {
-  s[0] = first ? (int)(b & 255) : (int)(a >> 24);
-  s[1] = (int)(b & 255); s[2] = (int)((b >> 8) & 255); s[3] = (int)((b >> 16) & 255); s[4] = (int)(b >> 24);
-  s[5] = (int)(c & 255); s[6] = (int)((c >> 8) & 255);
-}
 template <int ROWS>
 __device__ __forceinline__ void ColorRows420(const daliamdJpegColorDesc &d, int x0, int y0, int rx1, int ry1, int out_x0,
                                              int out_y0) {

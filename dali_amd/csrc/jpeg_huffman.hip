@@ -47,6 +47,7 @@
 #include "common.h"
 #include "huff_core.h"
 #include "jpeg_idct_math.h"
+#include "jpeg_color_math.h"
 
 namespace daliamd {
 
@@ -117,7 +118,7 @@ struct TileRec {   // one per tile of the stuffed stream (PrepareKernel)
 };
 static_assert(sizeof(TileRec) == 16, "layout");
 struct ScratchLayout {
-  size_t tile_recs, clean, tables, sync_tables, lanes, segs, seg_starts, blk_pos, blk_dc, blk_seg, rst_pos, total;
+  size_t tile_recs, clean, tables, sync_tables, lanes, segs, seg_starts, blk_pos, blk_dc, blk_seg, seams, rst_pos, total;
   int seg_cap;  // entries per segment in seg_starts
   int rst_cap;  // entries in rst_pos
 };
@@ -152,6 +153,10 @@ __host__ __device__ inline ScratchLayout MakeLayout(int ecs_len, int num_tiles, 
   o += AlignUp(sizeof(int32_t) * (size_t)total_blocks, 16);
   l.blk_seg = o;   // per block: the segment it starts in
   o += AlignUp(sizeof(uint16_t) * (size_t)total_blocks, 16);
+  // fused colour output: per band of MCU rows two strips (its first and its last pixel row: 16 luma + 2 x 8 chroma
+  // bytes per MCU column) for the seam launch; bands <= MCU rows, so 64 bytes per MCU = 10.7 per block of a 4:2:0 frame
+  l.seams = o;
+  o += AlignUp((size_t)total_blocks * 11 + 64, 16);
   l.rst_pos = o;   // per restart boundary: clean byte offset at which the next interval starts
   l.rst_cap = num_intervals;
   o += AlignUp(sizeof(uint32_t) * (size_t)num_intervals, 16);
@@ -932,7 +937,20 @@ struct BlockGeom {
   int32_t sx[12], sy[12], rect[12][4], pitch[12], comp_pitch[4];
   GlobalCoef *base[12];
   GlobalBytes *plane[12];
+  // fused colour output (BlockKernel<true>)
+  int32_t band_rows, band_c0, band_c1, bands;  // MCU rows per band; chroma rows [c0, c1) of this workgroup's band
+  int32_t width, height, dw, dh, rgb_pitch;
+  GlobalBytes *rgb, *seams;
 };
+// Fused colour output: a workgroup owns a band of whole MCU rows, as many as fit kColorBandMcus MCUs (the chroma tile
+// in LDS: 2 x 64 bytes per MCU).
+constexpr int kColorBandMcus = 128;
+__host__ __device__ inline int ColorBandRows(int mcus_x) {
+  const int r = kColorBandMcus / mcus_x;
+  return r > 1 ? r : 1;
+}
+// seam strip `side` (0: first pixel row, 1: last pixel row) of band b: [0, 16 mx) luma, [16 mx, 24 mx) Cb, [24 mx, 32 mx) Cr
+__host__ __device__ inline size_t SeamStrip(int band, int side, int mcus_x) { return (size_t)(band * 2 + side) * 32u * (size_t)mcus_x; }
 // Per block of a task, where its output goes: bits 0-47 the address (fused: top-left sample of the block in its
 // plane; else the block's 64 coefficients), bits 48-49 the component, bit 50 "needed".
 constexpr uint64_t kInfoNeeded = 1ull << 50;
@@ -952,11 +970,15 @@ __device__ __forceinline__ void WaveSync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+template <bool kColor>
 __global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHuffDesc *__restrict__ descs, int n, int nwg) {
   __shared__ __attribute__((aligned(16))) HalfTables T;
   __shared__ __attribute__((aligned(16))) int16_t coef[kBlockWaves][kCoefRows * 64];
   __shared__ __attribute__((aligned(16))) uint16_t quant[3][64];
   __shared__ BlockGeom G;
+  // kColor: the chroma samples of the band, [Cb | Cr][chroma row of the band][8 * mcus_x] - 64 bytes per MCU and component
+  constexpr int kChromaTile = kColorBandMcus * 64;
+  __shared__ __attribute__((aligned(16))) uint8_t ctile[kColor ? 2 * kChromaTile : 16];
   const int wg = XcdRemap(blockIdx.x, nwg);
   if (wg < 0) return;
   // workgroup -> image (descriptors sorted by blk_wg_start)
@@ -966,6 +988,7 @@ __global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHu
     if (descs[mid].blk_wg_start <= wg) lo = mid; else hi = mid - 1;
   }
   const daliamdJpegHuffDesc &d = descs[lo];
+  if ((d.rgb != nullptr) != kColor) return;   // the other instance's stream (uniform)
   const ScratchLayout lay = LayoutOf(d);
   const HuffTables *H = reinterpret_cast<const HuffTables *>(TablesBase(descs, d, false));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -999,19 +1022,44 @@ __global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHu
     }
     G.use_rect = use_rect;
     G.total_starts = ((const GlobalI32 *)d.scratch)[2];
-    G.fused = d.plane[d.comp_of_block[0]] != nullptr;
+    G.fused = kColor || d.plane[d.comp_of_block[0]] != nullptr;
     G.interval_blocks = d.restart_interval * d.blocks_per_mcu;
     for (int k = 0; k < d.blocks_per_mcu; k++) G.klast[d.comp_of_block[k]] = (uint8_t)k;
+    // the two task classes: by AC table - or, with the fused colour output, luma / chroma (usually the same split)
     int n0 = 0;
     for (int k = 0; k < d.blocks_per_mcu; k++)
-      if ((d.ac_sel[d.comp_of_block[k]] & 1) == 0) G.klist[n0++] = (uint8_t)k;
+      if (kColor ? d.comp_of_block[k] == 0 : (d.ac_sel[d.comp_of_block[k]] & 1) == 0) G.klist[n0++] = (uint8_t)k;
     G.n0 = n0;
     for (int k = 0; k < d.blocks_per_mcu; k++)
-      if ((d.ac_sel[d.comp_of_block[k]] & 1) != 0) G.klist[n0++] = (uint8_t)k;
+      if (kColor ? d.comp_of_block[k] != 0 : (d.ac_sel[d.comp_of_block[k]] & 1) != 0) G.klist[n0++] = (uint8_t)k;
+    if (kColor) {
+      const int rows = ColorBandRows(d.mcus_x), band = wg - d.blk_wg_start, mcus_y = d.total_blocks / d.blocks_per_mcu / d.mcus_x;
+      G.band_rows = rows;
+      G.bands = (mcus_y + rows - 1) / rows;
+      G.band_c0 = band * rows * 8;
+      G.band_c1 = min((band + 1) * rows, mcus_y) * 8;
+      G.width = d.width; G.height = d.height;
+      G.dw = (d.width + 1) >> 1; G.dh = (d.height + 1) >> 1;
+      G.rgb_pitch = d.rgb_pitch;
+      G.rgb = (GlobalBytes *)d.rgb;
+      G.seams = (GlobalBytes *)(d.scratch + lay.seams);
+    }
   }
   __syncthreads();
-  const int bpm = G.bpm, mpw = McusPerWg(bpm);
-  const int m0 = (wg - d.blk_wg_start) * mpw;
+  const int bpm = G.bpm, mpw = kColor ? G.band_rows * G.mcus_x : McusPerWg(bpm);
+  const int band = wg - d.blk_wg_start;
+  const int m0 = band * mpw;
+  // fused colour output: the band's geometry in scalar registers (G is LDS: the byte stores into the chroma tile would make
+  // the compiler read it again and again)
+  const int cmx = (int)HUFF_UNIFORM(G.mcus_x), cpitch = cmx * 8;   // cpitch: bytes per chroma row of the band's tile
+  const int cmode = (int)HUFF_UNIFORM(G.bpm) == 6 ? 0 : (int)HUFF_UNIFORM(G.bpm) == 3 ? 1 : 2;   // 4:2:0 / 4:4:4 / grayscale
+  const int band_c0 = kColor ? (int)HUFF_UNIFORM(G.band_c0) : 0, band_c1 = kColor ? (int)HUFF_UNIFORM(G.band_c1) : 0;
+  const int nbands = kColor ? (int)HUFF_UNIFORM(G.bands) : 0;
+  const int cwidth = kColor ? (int)HUFF_UNIFORM(G.width) : 0, cheight = kColor ? (int)HUFF_UNIFORM(G.height) : 0;
+  const int cdw = (cwidth + 1) >> 1, cdh = (cheight + 1) >> 1;
+  const int crgb_pitch = kColor ? (int)HUFF_UNIFORM(G.rgb_pitch) : 0;
+  GlobalBytes *rgb = kColor ? (GlobalBytes *)d.rgb : nullptr;
+  GlobalBytes *seams = kColor ? (GlobalBytes *)(d.scratch + lay.seams) : nullptr;
   if ((long long)m0 * bpm >= G.last_ordinal) return;  // behind the last needed MCU row (uniform)
   const int M = min(mpw, G.total_mcus - m0);
   const int n0 = G.n0, n1 = bpm - n0;
@@ -1034,19 +1082,35 @@ __global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHu
   struct Prepared {
     uint64_t info;
     int ordinal, comp, acs, dc, seg, seg0;
+    int bx, by;   // the block's position in its component, in blocks
     uint32_t pos;
     bool needed;
     BitWindow win;
   };
+  // task t of this wave -> (class, index inside the class).  Fused colour output: the chroma tasks come first - the luma
+  // lanes read the band's chroma samples from LDS behind one workgroup barrier
+  const int nfirst = kColor ? my1 : my0;
   auto stage_a = [&](int t) -> Prepared {
     Prepared p;
     p.needed = false; p.info = 0; p.ordinal = 0; p.comp = 0; p.acs = 0; p.dc = 0; p.seg = 0; p.seg0 = 0; p.pos = 0;
     p.win = BitWindow{0, 0, 0, 0, 0};
+    p.bx = 0; p.by = 0;
     if (t >= my0 + my1) return p;
-    const bool cls = t >= my0;
+    const bool cls = kColor ? t < nfirst : t >= nfirst;
+    const int tt = t < nfirst ? t : t - nfirst;
     const int ncls = cls ? n1 : n0;
-    const int j = (cls ? (t - my0) * kBlockWaves + rwave : t * kBlockWaves + wave) * 64 + lane;
-    const int mi = j / ncls, k = G.klist[(cls ? n0 : 0) + (j - mi * ncls)];
+    const int j = (cls ? tt * kBlockWaves + rwave : tt * kBlockWaves + wave) * 64 + lane;
+    int mi = j / ncls, k = G.klist[(cls ? n0 : 0) + (j - mi * ncls)];
+    if (kColor && !cls) {
+      // luma blocks of the band in raster order of BLOCKS: the lanes of a wave own x-adjacent blocks of one block row, so
+      // their 24-byte RGB segments of an output row are one contiguous run (MCU order would spread a store instruction
+      // over two pixel rows and leave gaps between the pairs)
+      // (luma sampling 2 x 2 with 4:2:0 - the MCU's luma blocks are k = 2 v + h -, 1 x 1 otherwise: k = 0)
+      const int ls = cmode == 0 ? 1 : 0;   // log2 of the luma sampling factor (both directions)
+      const int bw = cmx << ls, brow = j / bw, bcol = j - brow * bw;
+      mi = (brow >> ls) * cmx + (bcol >> ls);
+      k = ls ? ((brow & 1) << 1) | (bcol & 1) : 0;
+    }
     const int mcu = m0 + mi, ordinal = mcu * bpm + k;
     const int my = mcu / G.mcus_x, mx = mcu - my * G.mcus_x;
     const int bx = mx * G.hs[k] + G.ho[k], by = my * G.vs[k] + G.vo[k];
@@ -1057,6 +1121,7 @@ __global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHu
                                  : (uint64_t)(uintptr_t)(G.base[k] + ((size_t)my * (size_t)G.sy[k] + (size_t)(mx * G.sx[k])));
     p.info = (dst & ((1ull << 48) - 1)) | ((uint64_t)comp << 48) | (needed ? kInfoNeeded : 0ull);
     p.needed = needed; p.ordinal = ordinal; p.comp = comp; p.acs = G.acs[k];
+    p.bx = bx; p.by = by;
     if (needed) {
       p.pos = blk_pos[ordinal];
       p.dc = blk_dc[ordinal];
@@ -1115,19 +1180,128 @@ __global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHu
       }
       return;
     }
-    const int pitch = G.comp_pitch[p.comp];
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+    using GlobalPair = u32x2_t __attribute__((address_space(1)));
+    constexpr int S = CONST_BITS + PASS1_BITS + 3;
+    if (!kColor) {
+      const int pitch = G.comp_pitch[p.comp];
+#pragma unroll
+      for (int r8 = 0; r8 < 8; r8++) {
+        int32_t o[8];
+        Butterfly8(ws[r8], o);
+        const uint32_t lo32 = RangeLimit(Descale(o[0], S)) | (RangeLimit(Descale(o[1], S)) << 8) |
+                              (RangeLimit(Descale(o[2], S)) << 16) | (RangeLimit(Descale(o[3], S)) << 24);
+        const uint32_t hi32 = RangeLimit(Descale(o[4], S)) | (RangeLimit(Descale(o[5], S)) << 8) |
+                              (RangeLimit(Descale(o[6], S)) << 16) | (RangeLimit(Descale(o[7], S)) << 24);
+        *(GlobalPair *)((GlobalBytes *)(uintptr_t)dst + (size_t)r8 * pitch) = u32x2_t{lo32, hi32};
+      }
+      return;
+    }
+    if (p.comp != 0) {
+      // ---- a chroma block: its 8 x 8 samples go to the band's tile in LDS; the band's first / last chroma row also to
+      // the seam strips (the neighbouring bands' edge rows interpolate towards them)
+      uint8_t *tile = ctile + (p.comp - 1) * kChromaTile + (p.by * 8 - band_c0) * cpitch + p.bx * 8;
+      const bool top = cmode == 0 && p.by * 8 == band_c0 && band > 0;
+      const bool bottom = cmode == 0 && p.by * 8 + 8 == band_c1 && band + 1 < nbands;
+#pragma unroll
+      for (int r8 = 0; r8 < 8; r8++) {
+        int32_t o[8];
+        Butterfly8(ws[r8], o);
+        const uint32_t lo32 = RangeLimit(Descale(o[0], S)) | (RangeLimit(Descale(o[1], S)) << 8) |
+                              (RangeLimit(Descale(o[2], S)) << 16) | (RangeLimit(Descale(o[3], S)) << 24);
+        const uint32_t hi32 = RangeLimit(Descale(o[4], S)) | (RangeLimit(Descale(o[5], S)) << 8) |
+                              (RangeLimit(Descale(o[6], S)) << 16) | (RangeLimit(Descale(o[7], S)) << 24);
+        *reinterpret_cast<uint2 *>(tile + r8 * cpitch) = make_uint2(lo32, hi32);
+        if ((r8 == 0 && top) || (r8 == 7 && bottom))
+          *(GlobalPair *)(seams + SeamStrip(band, r8 == 7, cmx) + (size_t)(8 + 8 * p.comp) * cmx + p.bx * 8) = u32x2_t{lo32, hi32};
+      }
+      return;
+    }
+    if (cmode != 0) {
+      // ---- a luma block of a 4:4:4 stream (its chroma samples are the tile's block at the same place) or of a grayscale
+      // stream (R = G = B = the sample)
+      const int x0 = p.bx * 8, npx = min(8, cwidth - x0);
+      const uint8_t *tile = ctile + (p.by * 8 - band_c0) * cpitch + p.bx * 8;
+#pragma unroll
+      for (int r8 = 0; r8 < 8; r8++) {
+        const int y = p.by * 8 + r8;
+        int32_t o[8];
+        Butterfly8(ws[r8], o);
+        int yy[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) yy[i] = (int)RangeLimit(Descale(o[i], S));
+        if (y >= cheight || npx <= 0) continue;
+        uint32_t px[24];
+        if (cmode == 1) {
+          int up[2][8];
+#pragma unroll
+          for (int c = 0; c < 2; c++) {
+            const uint2 v = *reinterpret_cast<const uint2 *>(tile + c * kChromaTile + r8 * cpitch);
+#pragma unroll
+            for (int i = 0; i < 4; i++) { up[c][i] = (int)((v.x >> (8 * i)) & 255); up[c][4 + i] = (int)((v.y >> (8 * i)) & 255); }
+          }
+          YccToRgb8(yy, up, px);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; i++) px[3 * i] = px[3 * i + 1] = px[3 * i + 2] = (uint32_t)yy[i];
+        }
+        StoreRgb8((GOutBytes *)(rgb + (size_t)y * crgb_pitch + (size_t)x0 * 3), px, npx);
+      }
+      return;
+    }
+    // ---- a luma block of a 4:2:0 stream: fancy h2v2 upsampling of the chroma around it (rows 4 by - 1 .. 4 by + 4 of the
+    // tile, samples 4 bx - 1 .. 4 bx + 4) and YCbCr -> RGB, the arithmetic of jpeg_color.hip's ColorRows420; eight rows of
+    // 24 bytes
+    const int k0 = p.bx * 4;
+    const int ka = max(k0 - 4, 0), kc = min(k0 + 4, cpitch - 4);
+    uint32_t ca[2][6], cb[2][6], cc[2][6];   // [component][chroma row 4 by - 1 + j]: dwords left of / at / right of k0
+    const int r_above = ClampI(p.by * 4 - 1, 0, cdh - 1), r_below = ClampI(p.by * 4 + 4, 0, cdh - 1);
+    const bool seam_top = r_above < band_c0, seam_bottom = r_below >= band_c1;   // rows of a neighbouring band
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      int r = ClampI(p.by * 4 - 1 + j, 0, cdh - 1) - band_c0;
+      r = ClampI(r, 0, band_c1 - band_c0 - 1);   // (seam rows: read something valid, the row is not produced here)
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        const uint8_t *row = ctile + c * kChromaTile + r * cpitch;
+        ca[c][j] = *reinterpret_cast<const uint32_t *>(row + ka);
+        cb[c][j] = *reinterpret_cast<const uint32_t *>(row + k0);
+        cc[c][j] = *reinterpret_cast<const uint32_t *>(row + kc);
+      }
+    }
+    const int x0 = p.bx * 8, npx = min(8, cwidth - x0);
 #pragma unroll
     for (int r8 = 0; r8 < 8; r8++) {
+      const int y = p.by * 8 + r8;
       int32_t o[8];
       Butterfly8(ws[r8], o);
-      const int S = CONST_BITS + PASS1_BITS + 3;
-      const uint32_t lo32 = RangeLimit(Descale(o[0], S)) | (RangeLimit(Descale(o[1], S)) << 8) |
-                            (RangeLimit(Descale(o[2], S)) << 16) | (RangeLimit(Descale(o[3], S)) << 24);
-      const uint32_t hi32 = RangeLimit(Descale(o[4], S)) | (RangeLimit(Descale(o[5], S)) << 8) |
-                            (RangeLimit(Descale(o[6], S)) << 16) | (RangeLimit(Descale(o[7], S)) << 24);
-      typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-      using GlobalPair = u32x2_t __attribute__((address_space(1)));
-      *(GlobalPair *)((GlobalBytes *)(uintptr_t)dst + (size_t)r8 * pitch) = u32x2_t{lo32, hi32};
+      int yy[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) yy[i] = (int)RangeLimit(Descale(o[i], S));
+      if (y >= cheight || npx <= 0) continue;
+      if ((r8 == 0 && seam_top) || (r8 == 7 && seam_bottom)) {   // the seam launch finishes this row
+        const uint32_t lo32 = yy[0] | (yy[1] << 8) | (yy[2] << 16) | (yy[3] << 24);
+        const uint32_t hi32 = yy[4] | (yy[5] << 8) | (yy[6] << 16) | (yy[7] << 24);
+        *(GlobalPair *)(seams + SeamStrip(band, r8 == 7, cmx) + p.bx * 8) = u32x2_t{lo32, hi32};
+        continue;
+      }
+      // output row y: the nearer chroma row is 4 by + (r8 >> 1) (index 1 + (r8 >> 1) above), the further one the row
+      // above it (r8 even) or below it (r8 odd)
+      const int near = 1 + (r8 >> 1), far = (r8 & 1) ? near + 1 : near - 1;
+      int up[2][8];
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        int n7[7], f7[7], sv[7];
+        Chroma7(ca[c][near], cb[c][near], cc[c][near], k0 == 0, n7);
+        Chroma7(ca[c][far], cb[c][far], cc[c][far], k0 == 0, f7);
+#pragma unroll
+        for (int i = 0; i < 7; i++) sv[i] = n7[i] * 3 + f7[i];
+        ClampRight7(sv, k0, cdw);
+        TriangleX8<4, 8, 7>(sv, false, up[c]);
+      }
+      uint32_t px[24];
+      YccToRgb8(yy, up, px);
+      StoreRgb8((GOutBytes *)(rgb + (size_t)y * crgb_pitch + (size_t)x0 * 3), px, npx);
     }
   };
   Prepared cur = stage_a(0);
@@ -1146,9 +1320,67 @@ __global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHu
     Prepared nxt = stage_a(t + 1);
     idct_columns(cur);
     stage_b(nxt);
+    // fused colour output: the wave's first luma task reads the chroma tile every wave has written by now (each wave
+    // passes exactly one barrier: here, or behind the loop when it has no luma task)
+    if (kColor && t == nfirst && my0 > 0) __syncthreads();
     idct_rows(cur);
     WaveSync();   // the next round's zero-fill must not overtake this round's reads
     cur = nxt;
+  }
+  if (kColor && my0 == 0) __syncthreads();
+}
+
+// Fused colour output, the seams: output rows 16 R b - 1 and 16 R b (R MCU rows per band) interpolate between the last
+// chroma row of band b - 1 and the first one of band b.  One workgroup per band (the first has no seam above it), a
+// thread per 8 pixels of both rows; luma and chroma come from the strips the block kernel left in the scratch.
+constexpr int kSeamThreads = 256;
+__global__ __launch_bounds__(kSeamThreads) void SeamKernel(const daliamdJpegHuffDesc *__restrict__ descs, int n, int nwg) {
+  const int wg = XcdRemap(blockIdx.x, nwg);
+  if (wg < 0) return;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].blk_wg_start <= wg) lo = mid; else hi = mid - 1;
+  }
+  const daliamdJpegHuffDesc &d = descs[lo];
+  const int band = wg - d.blk_wg_start;
+  if (d.rgb == nullptr || band == 0 || d.blocks_per_mcu != 6) return;   // (4:4:4 / grayscale: nothing is interpolated)
+  const int rows = ColorBandRows(d.mcus_x);
+  const int y_up = 16 * rows * band - 1;   // last pixel row of the band above; y_up + 1: first row of this band
+  if (y_up + 1 >= d.height) return;
+  const ScratchLayout lay = LayoutOf(d);
+  GBytes *seams = (GBytes *)(d.scratch + lay.seams);
+  const int mx = d.mcus_x, cpitch = mx * 8, dw = (d.width + 1) >> 1;
+  GBytes *up = seams + SeamStrip(band - 1, 1, mx), *dn = seams + SeamStrip(band, 0, mx);
+  GOutBytes *rgb = (GOutBytes *)d.rgb;
+  for (int x0 = threadIdx.x * 8; x0 < d.width; x0 += kSeamThreads * 8) {
+    const int k0 = x0 >> 1, npx = min(8, d.width - x0);
+    int cu[2][7], cd[2][7];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      LoadSamples7(up + (16 + 8 * c) * mx, cpitch, k0, cu[c]);
+      LoadSamples7(dn + (16 + 8 * c) * mx, cpitch, k0, cd[c]);
+    }
+    const u32x2 yu = *reinterpret_cast<GPair *>(up + x0), yd = *reinterpret_cast<GPair *>(dn + x0);
+#pragma unroll
+    for (int side = 0; side < 2; side++) {   // 0: the row above the seam (near = up, far = down); 1: the row below it
+      int uv[2][8];
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        int sv[7];
+#pragma unroll
+        for (int i = 0; i < 7; i++) sv[i] = side == 0 ? cu[c][i] * 3 + cd[c][i] : cd[c][i] * 3 + cu[c][i];
+        ClampRight7(sv, k0, dw);
+        TriangleX8<4, 8, 7>(sv, false, uv[c]);
+      }
+      const u32x2 yv = side == 0 ? yu : yd;
+      int yy[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) yy[i] = (int)(((i < 4 ? yv.x : yv.y) >> (8 * (i & 3))) & 255);
+      uint32_t px[24];
+      YccToRgb8(yy, uv, px);
+      StoreRgb8(rgb + (size_t)(y_up + side) * d.rgb_pitch + (size_t)x0 * 3, px, npx);
+    }
   }
 }
 
@@ -1168,11 +1400,42 @@ daliamdResult_t daliamdJpegHuffmanScratchBytesRestart(int ecs_len, int total_blo
   return DALIAMD_SUCCESS;
 }
 
+int daliamdJpegHuffmanColorFusable(const daliamdJpegHuffDesc *d) {
+  if (!d || d->mcus_x < 1 || d->mcus_x > daliamd::kColorBandMcus) return 0;
+  for (int c = 0; c < 3; c++)
+    for (int j = 0; j < 4; j++)
+      if (d->rect[c][j]) return 0;
+  if (d->blocks_per_mcu == 6) {          // YCbCr 4:2:0
+    static const uint8_t comp[6] = {0, 0, 0, 0, 1, 2}, ho[6] = {0, 1, 0, 1, 0, 0}, vo[6] = {0, 0, 1, 1, 0, 0};
+    if (memcmp(d->comp_of_block, comp, 6) || memcmp(d->h_of_block, ho, 6) || memcmp(d->v_of_block, vo, 6)) return 0;
+    return d->h_samp[0] == 2 && d->v_samp[0] == 2 && d->h_samp[1] == 1 && d->v_samp[1] == 1 && d->h_samp[2] == 1 && d->v_samp[2] == 1;
+  }
+  if (d->blocks_per_mcu == 3) {          // YCbCr 4:4:4
+    static const uint8_t comp[3] = {0, 1, 2}, zero[3] = {0, 0, 0};
+    if (memcmp(d->comp_of_block, comp, 3) || memcmp(d->h_of_block, zero, 3) || memcmp(d->v_of_block, zero, 3)) return 0;
+    return d->h_samp[0] == d->h_samp[1] && d->h_samp[1] == d->h_samp[2] && d->v_samp[0] == d->v_samp[1] && d->v_samp[1] == d->v_samp[2];
+  }
+  if (d->blocks_per_mcu == 1)            // grayscale
+    return d->comp_of_block[0] == 0 && d->h_of_block[0] == 0 && d->v_of_block[0] == 0;
+  return 0;
+}
+
 daliamdResult_t daliamdJpegHuffmanSetup(daliamdJpegHuffDesc *descs_host, int n, int *num_tiles, int *num_segments,
                                         int *num_block_workgroups) {
-  DALIAMD_REQUIRE(n >= 0 && (n == 0 || descs_host) && num_tiles && num_segments && num_block_workgroups,
+  int kinds = 0;
+  daliamdResult_t r = daliamdJpegHuffmanSetupColor(descs_host, n, num_tiles, num_segments, num_block_workgroups, &kinds);
+  if (r != DALIAMD_SUCCESS) return r;
+  DALIAMD_REQUIRE(!(kinds & 2), DALIAMD_ERROR_INVALID_ARGUMENT,
+                  "daliamdJpegHuffmanSetup: a stream asks for the fused colour output (rgb != NULL): use "
+                  "daliamdJpegHuffmanSetupColor / daliamdJpegHuffmanRunColor");
+  return DALIAMD_SUCCESS;
+}
+
+daliamdResult_t daliamdJpegHuffmanSetupColor(daliamdJpegHuffDesc *descs_host, int n, int *num_tiles, int *num_segments,
+                                             int *num_block_workgroups, int *block_kernels) {
+  DALIAMD_REQUIRE(n >= 0 && (n == 0 || descs_host) && num_tiles && num_segments && num_block_workgroups && block_kernels,
                   DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdJpegHuffmanSetup: invalid argument");
-  int tiles = 0, segs = 0, bwgs = 0;
+  int tiles = 0, segs = 0, bwgs = 0, kinds = 0;
   std::vector<int> owners;   // one stream per distinct table set seen so far
   auto same_tables = [](const daliamdJpegHuffDesc &a, const daliamdJpegHuffDesc &b) {
     return a.blocks_per_mcu == b.blocks_per_mcu && !memcmp(a.bits, b.bits, sizeof(a.bits)) && !memcmp(a.vals, b.vals, sizeof(a.vals)) &&
@@ -1192,8 +1455,23 @@ daliamdResult_t daliamdJpegHuffmanSetup(daliamdJpegHuffDesc *descs_host, int n, 
     DALIAMD_REQUIRE(d.blocks_per_mcu >= 1 && d.blocks_per_mcu <= DALIAMD_JPEG_MAX_BLOCKS_PER_MCU && d.mcus_x >= 1 &&
                         d.total_blocks >= 1 && d.total_blocks % d.blocks_per_mcu == 0,
                     DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdJpegHuffmanSetup: sample %d: bad MCU geometry", i);
-    const bool fused = d.comp_of_block[0] < 3 && d.plane[d.comp_of_block[0]] != nullptr;
-    for (int k = 0; k < d.blocks_per_mcu; k++) {
+    const bool color = d.rgb != nullptr;
+    kinds |= color ? 2 : 1;
+    if (color) {
+      DALIAMD_REQUIRE(daliamdJpegHuffmanColorFusable(&d), DALIAMD_ERROR_UNSUPPORTED,
+                      "daliamdJpegHuffmanSetup: sample %d: the fused colour output needs a 4:2:0 / 4:4:4 / one-component stream "
+                      "in the usual block order, at most %d MCUs wide, without a block rectangle", i, daliamd::kColorBandMcus);
+      const int mcu_px = d.blocks_per_mcu == 6 ? 16 : 8;
+      DALIAMD_REQUIRE((reinterpret_cast<uintptr_t>(d.rgb) & 7) == 0 && (d.rgb_pitch & 7) == 0 && d.height > 0 &&
+                          d.width > (d.blocks_per_mcu == 6 ? 4 : 0) && d.rgb_pitch >= 3 * d.width &&
+                          (d.width + mcu_px - 1) / mcu_px == d.mcus_x &&
+                          (d.height + mcu_px - 1) / mcu_px == d.total_blocks / d.blocks_per_mcu / d.mcus_x,
+                      DALIAMD_ERROR_INVALID_ARGUMENT,
+                      "daliamdJpegHuffmanSetup: sample %d: rgb must be 8-byte aligned with a pitch that is a multiple of 8 "
+                      "and covers 3 * width bytes; width (4:2:0: > 4) and height must match the MCU geometry", i);
+    }
+    const bool fused = !color && d.comp_of_block[0] < 3 && d.plane[d.comp_of_block[0]] != nullptr;
+    for (int k = 0; k < d.blocks_per_mcu && !color; k++) {
       const int comp = d.comp_of_block[k];
       DALIAMD_REQUIRE(comp < 3 && (fused ? d.plane[comp] != nullptr : d.coef[comp] != nullptr),
                       DALIAMD_ERROR_INVALID_ARGUMENT,
@@ -1220,17 +1498,19 @@ daliamdResult_t daliamdJpegHuffmanSetup(daliamdJpegHuffDesc *descs_host, int n, 
     d.blk_wg_start = bwgs;
     tiles += d.num_tiles;
     segs += d.num_segments;
-    const int mcus = d.total_blocks / d.blocks_per_mcu, mpw = daliamd::McusPerWg(d.blocks_per_mcu);
+    const int mcus = d.total_blocks / d.blocks_per_mcu;
+    const int mpw = color ? daliamd::ColorBandRows(d.mcus_x) * d.mcus_x : daliamd::McusPerWg(d.blocks_per_mcu);
     bwgs += (mcus + mpw - 1) / mpw;
   }
   *num_tiles = tiles;
   *num_segments = segs;
   *num_block_workgroups = bwgs;
+  *block_kernels = kinds;
   return DALIAMD_SUCCESS;
 }
 
 static daliamdResult_t LaunchHuffman(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev, int n, int num_tiles,
-                                     int num_segments, int num_block_workgroups, daliamdEvent_t *events) {
+                                     int num_segments, int num_block_workgroups, daliamdEvent_t *events, int block_kernels) {
   if (n == 0) return DALIAMD_SUCCESS;
   DALIAMD_REQUIRE(descs_dev && n > 0 && num_tiles >= n && num_segments >= n && num_block_workgroups >= n,
                   DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdJpegHuffmanRun: invalid argument");
@@ -1267,9 +1547,21 @@ static daliamdResult_t LaunchHuffman(daliamdStream_t stream, const daliamdJpegHu
     hipLaunchKernelGGL(DcKernel, dim3(seg_grid), dim3(kDcThreads), 0, s, descs_dev, n, num_segments);
   }
   DALIAMD_HIP_CHECK(mark());
-  {
+  // bit 0: streams with plane / coefficient output, bit 1: streams with the fused colour output (both instances walk the
+  // same grid; a workgroup of the other instance's stream leaves at once)
+  if (block_kernels & 1) {
     KernelTimer timer("BlockKernel", s);
-    hipLaunchKernelGGL(BlockKernel, dim3(XcdGrid(num_block_workgroups)), dim3(kBlockThreads), 0, s, descs_dev, n,
+    hipLaunchKernelGGL(BlockKernel<false>, dim3(XcdGrid(num_block_workgroups)), dim3(kBlockThreads), 0, s, descs_dev, n,
+                       num_block_workgroups);
+  }
+  if (block_kernels & 2) {
+    {
+      KernelTimer timer("BlockColorKernel", s);
+      hipLaunchKernelGGL(BlockKernel<true>, dim3(XcdGrid(num_block_workgroups)), dim3(kBlockThreads), 0, s, descs_dev, n,
+                         num_block_workgroups);
+    }
+    KernelTimer timer("SeamKernel", s);
+    hipLaunchKernelGGL(SeamKernel, dim3(XcdGrid(num_block_workgroups)), dim3(kSeamThreads), 0, s, descs_dev, n,
                        num_block_workgroups);
   }
   DALIAMD_HIP_CHECK(mark());
@@ -1279,14 +1571,26 @@ static daliamdResult_t LaunchHuffman(daliamdStream_t stream, const daliamdJpegHu
 
 daliamdResult_t daliamdJpegHuffmanRun(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev, int n, int num_tiles,
                                       int num_segments, int num_block_workgroups) {
-  return LaunchHuffman(stream, descs_dev, n, num_tiles, num_segments, num_block_workgroups, nullptr);
+  return LaunchHuffman(stream, descs_dev, n, num_tiles, num_segments, num_block_workgroups, nullptr, 1);
+}
+
+daliamdResult_t daliamdJpegHuffmanRunColor(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev, int n, int num_tiles,
+                                           int num_segments, int num_block_workgroups, int block_kernels) {
+  return LaunchHuffman(stream, descs_dev, n, num_tiles, num_segments, num_block_workgroups, nullptr, block_kernels & 3);
 }
 
 daliamdResult_t daliamdJpegHuffmanRunProfiled(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev, int n,
                                               int num_tiles, int num_segments, int num_block_workgroups,
                                               daliamdEvent_t *events) {
   DALIAMD_REQUIRE(events, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdJpegHuffmanRunProfiled: events is NULL");
-  return LaunchHuffman(stream, descs_dev, n, num_tiles, num_segments, num_block_workgroups, events);
+  return LaunchHuffman(stream, descs_dev, n, num_tiles, num_segments, num_block_workgroups, events, 1);
+}
+
+daliamdResult_t daliamdJpegHuffmanRunProfiledColor(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev, int n,
+                                                   int num_tiles, int num_segments, int num_block_workgroups,
+                                                   int block_kernels, daliamdEvent_t *events) {
+  DALIAMD_REQUIRE(events, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdJpegHuffmanRunProfiledColor: events is NULL");
+  return LaunchHuffman(stream, descs_dev, n, num_tiles, num_segments, num_block_workgroups, events, block_kernels & 3);
 }
 
 }  // extern "C"

@@ -101,6 +101,11 @@ class ImageDecoderMixed : public OperatorBase {
     // keeps the reference's meaning: streams with fewer pixels than that are Huffman-decoded on the host.
     if (spec.Args().count("hybrid_huffman_threshold")) huffman_threshold_ = spec.GetInt("hybrid_huffman_threshold");
     if (const char *env = getenv("DALI_AMD_HOST_HUFFMAN")) host_huffman_only_ = atoi(env) != 0;
+    // DALI_AMD_FUSE_COLOR=1: upsampling + colour conversion inside the entropy decoder's block kernel (no component planes,
+    // no colour launch; bit-identical).  Off by default: measured on MI355X it moves 25 % fewer bytes and is 10 % SLOWER
+    // (397 000 against 443 000 images/s, gpurun_out/r04c3) - the step is bound by instruction issue, not by HBM, the fused
+    // kernel issues the same colour arithmetic and holds 62 KB of LDS + 191 registers per workgroup.
+    if (const char *env = getenv("DALI_AMD_FUSE_COLOR")) fuse_color_ = atoi(env) != 0;
     ring_ = (int)spec.GetInt("gpu_prefetch_queue_depth") + 1;
     for (int i = 0; i < ring_; i++) {
       staging_.emplace_back(std::make_unique<Buffer>(StorageDevice::CPU));
@@ -436,7 +441,8 @@ class ImageDecoderMixed : public OperatorBase {
     daliamdJpegIdctDesc *idct = reinterpret_cast<daliamdJpegIdctDesc *>(tab_host + (idct_off - huff_off));
     daliamdJpegColorDesc *color = reinterpret_cast<daliamdJpegColorDesc *>(tab_host + (color_off - huff_off));
     memset(tab_host, 0, upload_bytes - huff_off);
-    int ntiles = 0, nsegs = 0, nbwg = 0;
+    int ntiles = 0, nsegs = 0, nbwg = 0, block_kernels = 0;
+    fused_color_.assign(n, 0);
     if (ngpu) {
       // status words: pinned host memory the kernels write directly (no copy back); cleared here by the CPU
       int32_t *status = static_cast<int32_t *>(status_host.data());
@@ -470,6 +476,19 @@ class ImageDecoderMixed : public OperatorBase {
         memcpy(d.h_of_block, sc.h_of_block, 10);
         memcpy(d.v_of_block, sc.v_of_block, 10);
         if (plans_[i].roi_w > 0) memcpy(d.rect, plans_[i].rect, sizeof(d.rect));
+        // fused colour output: an upright RGB image of a YCbCr 4:2:0 stream leaves the entropy decoder as RGB - no
+        // component planes, no colour launch for this sample
+        fused_color_[i] = 0;
+        if (fuse_color_ && (inf.color == DALIAMD_JPEG_YCC || inf.color == DALIAMD_JPEG_GRAY) && out_type_ == DALI_RGB &&
+            plans_[i].roi_w == 0 && (inf.width > 4 || sc.blocks_per_mcu != 6) &&
+            (adjust_orientation_ ? inf.orientation : 1) <= 1 && (out.row_pitch(i) & 7) == 0 &&
+            (reinterpret_cast<uintptr_t>(out.raw(i)) & 7) == 0 && daliamdJpegHuffmanColorFusable(&d)) {
+          d.rgb = static_cast<uint8_t *>(out.raw(i));
+          d.rgb_pitch = (int32_t)out.row_pitch(i);
+          d.width = inf.width;
+          d.height = inf.height;
+          fused_color_[i] = 1;
+        }
         for (int t = 0; t < 2; t++) {
           memcpy(d.bits[t], sc.dc_bits[t], 16);
           memcpy(d.bits[2 + t], sc.ac_bits[t], 16);
@@ -477,7 +496,7 @@ class ImageDecoderMixed : public OperatorBase {
           memcpy(d.vals[2 + t], sc.ac_vals[t], 256);
         }
       }
-      KCHECK(daliamdJpegHuffmanSetup(huff, ngpu, &ntiles, &nsegs, &nbwg));
+      KCHECK(daliamdJpegHuffmanSetupColor(huff, ngpu, &ntiles, &nsegs, &nbwg, &block_kernels));
       // the status words are valid once the iteration has finished: checked when its outputs are handed over
       std::vector<std::string> names(ngpu);
       for (int j = 0; j < ngpu; j++) names[j] = src(gpu_samples_[j]);
@@ -501,7 +520,7 @@ class ImageDecoderMixed : public OperatorBase {
     // ---- dequantisation + IDCT, upsampling + colour conversion: descriptors ----
     int k = 0, kc = 0;
     for (int i = 0; i < n; i++) {
-      if (hit_[i]) continue;
+      if (hit_[i] || fused_color_[i]) continue;
       const auto &inf = infos_[i];
       auto &cd = color[kc++];
       for (int c = 0; c < inf.num_components; c++) {
@@ -538,7 +557,8 @@ class ImageDecoderMixed : public OperatorBase {
     int wg_idct = 0, wg_color = 0, color_kernels = 0;
     const int nidct = k;  // components of the host-decoded streams only
     KCHECK(daliamdJpegIdctSetup(idct, nidct, &wg_idct));
-    KCHECK(daliamdJpegColorSetup(color, nact, &wg_color, &color_kernels));
+    const int ncolor = kc;   // samples that go through the colour launch (the others left the entropy decoder as RGB)
+    KCHECK(daliamdJpegColorSetup(color, ncolor, &wg_color, &color_kernels));
     lap(3);
     // ---- ONE transfer (JPEG bytes + the three tables) on the copy stream: it overlaps the kernels of the previous
     // iteration; the compute stream waits for it through an event ----
@@ -586,8 +606,8 @@ class ImageDecoderMixed : public OperatorBase {
       reserved_streams.keys.clear();
     }
     if (ngpu) {
-      KCHECK(daliamdJpegHuffmanRun(ws.stream, reinterpret_cast<const daliamdJpegHuffDesc *>(dev_base + huff_off), ngpu,
-                                   ntiles, nsegs, nbwg));
+      KCHECK(daliamdJpegHuffmanRunColor(ws.stream, reinterpret_cast<const daliamdJpegHuffDesc *>(dev_base + huff_off), ngpu,
+                                        ntiles, nsegs, nbwg, block_kernels));
       NoteLaunch(ws, "jpeg_huffman");
     }
     // host-decoded streams (progressive, restart markers, multi-scan, below the threshold): H2D of their coefficients
@@ -600,10 +620,11 @@ class ImageDecoderMixed : public OperatorBase {
     if (nidct)
       KCHECK(daliamdJpegIdctRun(ws.stream, reinterpret_cast<const daliamdJpegIdctDesc *>(dev_base + idct_off), nidct,
                                 wg_idct));
-    KCHECK(daliamdJpegColorRun(ws.stream, reinterpret_cast<const daliamdJpegColorDesc *>(dev_base + color_off), nact,
+    KCHECK(daliamdJpegColorRun(ws.stream, reinterpret_cast<const daliamdJpegColorDesc *>(dev_base + color_off), ncolor,
                                wg_color, color_kernels));
     if (nidct) NoteLaunch(ws, "jpeg_idct");
-    NoteLaunch(ws, "jpeg_color");
+    if (block_kernels & 2) NoteLaunch(ws, "jpeg_huffman_rgb");
+    if (ncolor) NoteLaunch(ws, "jpeg_color");
     if (cache_) {
       cache_->Commit(reserved.keys, ws.stream);  // visible to later iterations (and other pipelines) from here on
       reserved.keys.clear();
@@ -638,6 +659,8 @@ class ImageDecoderMixed : public OperatorBase {
   std::vector<daliamdJpegInfo> infos_;
   std::vector<daliamdJpegScan> scans_;
   std::vector<int> gpu_samples_;
+  std::vector<char> fused_color_;        // per sample: the entropy decoder writes its RGB image (no colour launch)
+  bool fuse_color_ = false;
   std::vector<int64_t> coef_off_;
   std::vector<size_t> ecs_off_, scratch_off_;
   std::vector<uint16_t> quant_;

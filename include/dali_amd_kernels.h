@@ -193,7 +193,25 @@ typedef struct {
   int32_t plane_pitch[3];
   int32_t restart_interval; /* MCUs per restart interval (DRI), 0: the stream has no RSTn markers  */
   uint16_t quant[3][64];   /* per component, column-major element order as daliamdJpegIdctDesc.quant */
+  /* Optional fused colour output (round 4).  With rgb != NULL the decoder also upsamples the chroma (libjpeg-turbo's
+   * fancy h2v2 triangle filter) and converts to RGB where the samples are - the chroma blocks of a band of MCU rows in
+   * LDS, the luma block of a lane in its registers - and writes interleaved RGB: no component planes, no
+   * daliamdJpegColorRun for this stream (the arithmetic is that kernel's: same bits).  The first / last pixel row
+   * of a band needs the chroma row of the neighbouring band: the bands leave those rows in `scratch` and one small
+   * launch behind the block kernel finishes the seams.  Only for streams daliamdJpegHuffmanColorFusable accepts
+   * (YCbCr 4:2:0 or 4:4:4 in the usual block order, or one component - its samples become R = G = B -, at most 128 MCUs
+   * wide = 2048 / 1024 pixels, no rect); the caller vouches for the rest: a YCbCr or grayscale stream (not RGB-coded),
+   * upright 3-channel RGB output wanted, 4:2:0: width > 4.  rgb 8-byte aligned, rgb_pitch a multiple of 8
+   * (>= 3 * width); plane[] / coef[] are not used. */
+  uint8_t *rgb;
+  int32_t rgb_pitch;
+  int32_t width, height;   /* image size in pixels */
+  int32_t reserved;
 } daliamdJpegHuffDesc;
+
+/* 1 when the stream's geometry (blocks_per_mcu, comp_of_block, h/v_of_block, h/v_samp, mcus_x, rect) allows the fused
+ * colour output, else 0.  Host helper, looks at nothing else. */
+DALIAMD_API int daliamdJpegHuffmanColorFusable(const daliamdJpegHuffDesc *desc);
 
 DALIAMD_API daliamdResult_t daliamdJpegHuffmanScratchBytes(int ecs_len, int total_blocks, size_t *bytes);
 /* num_intervals = ceil(MCUs of the frame / restart_interval), 0 without restart intervals */
@@ -203,16 +221,31 @@ DALIAMD_API daliamdResult_t daliamdJpegHuffmanScratchBytesRestart(int ecs_len, i
 DALIAMD_API daliamdResult_t daliamdJpegHuffmanSetup(daliamdJpegHuffDesc *descs_host, int n, int *num_tiles,
                                                     int *num_segments, int *num_block_workgroups);
 /* Six launches: prepare (un-stuff count + code tables), un-stuff scatter, synchronise (positions + block starts),
- * propagate (segment hand-over, block ordinals), DC (one lane per block), block decode + dequantisation + IDCT. */
+ * propagate (segment hand-over, block ordinals), DC (one lane per block), block decode + dequantisation + IDCT
+ * (+ the seam launch when a stream of the table has a fused colour output). */
 DALIAMD_API daliamdResult_t daliamdJpegHuffmanRun(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev, int n,
                                                   int num_tiles, int num_segments, int num_block_workgroups);
 /* Same launches with events[0..6] (created with timing enabled) recorded before each kernel and after the last:
  * events[i] .. events[i+1] brackets kernel i of {prepare, un-stuff scatter, synchronise, propagate, DC, block}.
  * For benchmarks. */
+/* The same three calls for tables in which streams ask for the fused colour output (rgb != NULL; the plain Setup
+ * refuses those).  block_kernels (out of Setup, into Run): bit 0 - streams with plane / coefficient output, bit 1 -
+ * streams with the fused colour output; Run launches the block kernel instance(s) that have streams, and the seam
+ * launch behind the colour instance. */
+DALIAMD_API daliamdResult_t daliamdJpegHuffmanSetupColor(daliamdJpegHuffDesc *descs_host, int n, int *num_tiles,
+                                                         int *num_segments, int *num_block_workgroups, int *block_kernels);
+DALIAMD_API daliamdResult_t daliamdJpegHuffmanRunColor(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev, int n,
+                                                       int num_tiles, int num_segments, int num_block_workgroups,
+                                                       int block_kernels);
 #define DALIAMD_JPEG_HUFFMAN_KERNELS 6
 DALIAMD_API daliamdResult_t daliamdJpegHuffmanRunProfiled(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev,
                                                           int n, int num_tiles, int num_segments,
                                                           int num_block_workgroups, daliamdEvent_t *events);
+/* (the last bracket holds the block kernel instance(s) and the seam launch) */
+DALIAMD_API daliamdResult_t daliamdJpegHuffmanRunProfiledColor(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev,
+                                                               int n, int num_tiles, int num_segments,
+                                                               int num_block_workgroups, int block_kernels,
+                                                               daliamdEvent_t *events);
 
 typedef enum {
   DALIAMD_JPEG_GRAY = 0,   /* 1 component                                   */

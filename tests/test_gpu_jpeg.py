@@ -41,6 +41,41 @@ def test_decode_matches_oracle_all_modes(huffman):
         assert np.array_equal(got[i], ref), f"sample {i}: max diff {np.abs(got[i].astype(int) - ref).max()}"
 
 
+def test_fused_colour_output_equals_the_colour_kernel_and_the_oracle():
+    """Round 4: YCbCr 4:2:0 streams leave the entropy decoder as RGB (chroma of a band of MCU rows in LDS, fancy
+    upsampling + colour conversion in the luma lanes, the band seams finished by a second small launch).  Sizes that move
+    the seams around (1 .. 24 MCU rows per band, widths up to the 2048-pixel limit and beyond it - those fall back), odd
+    sizes, a restart-interval stream, a flat image; the result must equal the planes + colour-kernel path and the oracle."""
+    from dali_amd import backend as B
+    rng = np.random.default_rng(5)
+    enc, want_fused = [], []
+    for (h, w) in [(16, 16), (17, 33), (33, 17), (5, 5), (1, 6), (31, 2048), (47, 2047), (64, 2049), (48, 1025), (49, 1024),
+                   (375, 500), (500, 375), (333, 517), (129, 640), (128, 641), (640, 129), (1080, 1920), (97, 131), (160, 8),
+                   (240, 320), (1200, 40)]:
+        enc.append(encode_jpeg(synth_image(rng, h, w), 85, subsampling="4:2:0"))
+        want_fused.append(w <= 2048)
+    enc.append(encode_jpeg(synth_image(rng, 375, 500), 90, subsampling="4:2:0", restart_marker_blocks=7)); want_fused.append(True)
+    enc.append(encode_jpeg(np.full((480, 640, 3), (200, 30, 90), np.uint8), 90)); want_fused.append(True)
+    enc.append(encode_jpeg(rng.integers(0, 256, (130, 262, 3), dtype=np.uint8), 100, subsampling="4:2:0")); want_fused.append(True)
+    enc.append(encode_jpeg(synth_image(rng, 120, 160), 85, subsampling="4:2:0", optimize=True)); want_fused.append(True)
+    # 4:4:4 (chroma block = luma block, nothing interpolated) and grayscale (R = G = B) also leave as RGB, up to 128 MCUs
+    # = 1024 pixels wide; 4:2:2 and everything else keeps the colour kernel
+    for (h, w) in [(100, 150), (375, 500), (8, 8), (1, 1), (65, 1024), (33, 1025), (130, 517)]:
+        enc.append(encode_jpeg(synth_image(rng, h, w), 85, subsampling="4:4:4")); want_fused.append(w <= 1024)
+        enc.append(encode_jpeg(synth_image(rng, h, w, 1), 80)); want_fused.append(w <= 1024)
+    enc.append(encode_jpeg(synth_image(rng, 100, 150), 85, subsampling="4:2:2")); want_fused.append(False)
+    enc.append(encode_jpeg(synth_image(rng, 64, 4), 85, subsampling="4:2:0")); want_fused.append(False)   # chroma 2 wide: box
+    views, plan = B.decode_jpeg_batch(enc, device="cuda", fuse_color=True)
+    torch.cuda.synchronize()
+    assert list(plan.fused_color) == want_fused
+    fused = [v.cpu().numpy() for v in views]
+    plain = _decode_gpu(enc, fuse_color=False)
+    for i, e in enumerate(enc):
+        assert np.array_equal(fused[i], plain[i]), \
+            f"sample {i} {fused[i].shape}: rows {sorted(set(np.nonzero((fused[i] != plain[i]).any(axis=(1, 2)))[0]))[:12]} differ"
+        assert np.array_equal(fused[i], O.jpeg_decode_rgb(e)), f"sample {i}"
+
+
 def _coefficients(enc, huffman, exact_scan=True):
     """Raw entropy-decoder output (int16 coefficient arrays) of both decoders."""
     from dali_amd import backend as B

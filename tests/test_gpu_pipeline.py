@@ -89,7 +89,25 @@ def test_train_pipeline_matches_oracle(jpeg_dir, fused):
             assert np.array_equal(outs[2].as_tensor().cpu().numpy(), ref_u8)
         # (the stand-alone IDCT kernel only runs for streams the host entropy decoder took: the GPU decoder's block
         # output is already dequantised and inverse-transformed)
-        assert "jpeg_huffman" in kernels and "jpeg_color" in kernels
+        # (... and, round 4, usually colour-converted as well: "jpeg_huffman_rgb"; the colour launch is for the rest)
+        assert "jpeg_huffman" in kernels and ("jpeg_color" in kernels or "jpeg_huffman_rgb" in kernels)
+
+
+def test_train_pipeline_with_the_fused_colour_output(jpeg_dir, monkeypatch):
+    """DALI_AMD_FUSE_COLOR=1: decoders.image hands the entropy decoder the output images (daliamdJpegHuffDesc.rgb) and
+    launches the colour kernel only for what is left; the batches stay bit-identical to the oracle."""
+    monkeypatch.setenv("DALI_AMD_FUSE_COLOR", "1")
+    root, files = jpeg_dir
+    bs = 8
+    pipe = _train_pipe(root, bs, fused=False)
+    for it in range(4):
+        outs = pipe.run()
+        picks = [(it * bs + i) % len(files) for i in range(bs)]
+        ref_u8, ref_f16 = _oracle_batch(files, picks, it, bs)
+        assert np.array_equal(outs[0].as_tensor().cpu().numpy().view(np.uint16), ref_f16.view(np.uint16)), f"iteration {it}"
+        assert np.array_equal(outs[2].as_tensor().cpu().numpy(), ref_u8)
+        kernels = pipe.executed_kernels()
+        assert "jpeg_huffman_rgb" in kernels and "jpeg_color" not in kernels
 
 
 @pytest.mark.parametrize("depth,streams", [(5, None), (7, None), (5, "0"), (4, "2")])

@@ -174,3 +174,55 @@ def test_huffman_setup_fused_output_needs_aligned_planes_not_coefficients():
     for c in range(3):
         neither.coef[c] = 0
     assert lib.daliamdJpegHuffmanSetup((capi.JpegHuffDesc * 1)(neither), 1, C.byref(tiles), C.byref(segs), C.byref(bwg)) != 0
+
+
+def test_huffman_setup_fused_colour_output():
+    """rgb != NULL (round 4): only through SetupColor, only for 4:2:0 streams in the usual block order up to 128 MCUs
+    wide without a block rectangle; the block grid is one workgroup per band of whole MCU rows."""
+    lib = capi.kernels()
+    tiles, segs, bwg, kinds = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+
+    def color(mcus_x=10, mcus_y=10, width=None, height=None, rgb=0x80000, pitch=None):
+        d = _huff_desc(total_blocks=mcus_x * mcus_y * 6)
+        d.mcus_x = mcus_x
+        for k, (ho, vo) in enumerate([(0, 0), (1, 0), (0, 1), (1, 1), (0, 0), (0, 0)]):
+            d.h_of_block[k], d.v_of_block[k] = ho, vo
+        d.width = mcus_x * 16 - 3 if width is None else width
+        d.height = mcus_y * 16 - 5 if height is None else height
+        d.rgb, d.rgb_pitch = rgb, (3 * d.width + 7) // 8 * 8 if pitch is None else pitch
+        return d
+
+    def setup(*descs):
+        arr = (capi.JpegHuffDesc * len(descs))(*descs)
+        rc = lib.daliamdJpegHuffmanSetupColor(arr, len(descs), C.byref(tiles), C.byref(segs), C.byref(bwg), C.byref(kinds))
+        return rc, arr
+
+    assert lib.daliamdJpegHuffmanColorFusable(C.byref(color())) == 1
+    rc, arr = setup(color(10, 10), _huff_desc(), color(128, 3), color(33, 7), color(64, 5))
+    assert rc == 0 and kinds.value == 3
+    # bands: 12 MCU rows of 10 MCUs -> 1 band; the plain stream 100 MCUs -> its own count; 128 wide: one row per band;
+    # 33 wide: 3 rows per band -> 3 bands; 64 wide: 2 rows per band -> 3 bands
+    starts = [d.blk_wg_start for d in arr] + [bwg.value]
+    counts = [b - a for a, b in zip(starts, starts[1:])]
+    assert counts[0] == 1 and counts[2] == 3 and counts[3] == 3 and counts[4] == 3, counts
+    rc, _ = setup(_huff_desc())
+    assert rc == 0 and kinds.value == 1
+    # the plain entry points refuse a table with rgb outputs
+    assert lib.daliamdJpegHuffmanSetup((capi.JpegHuffDesc * 1)(color()), 1, C.byref(tiles), C.byref(segs), C.byref(bwg)) != 0
+    assert b"daliamdJpegHuffmanSetupColor" in lib.daliamdGetLastErrorMessage()
+    # geometry the fused output does not take
+    wide = color(129, 2)
+    assert lib.daliamdJpegHuffmanColorFusable(C.byref(wide)) == 0 and setup(wide)[0] != 0
+    sub = color()
+    sub.h_samp[0] = 1
+    assert lib.daliamdJpegHuffmanColorFusable(C.byref(sub)) == 0
+    rect = color()
+    rect.rect[0][2] = 4
+    assert lib.daliamdJpegHuffmanColorFusable(C.byref(rect)) == 0
+    order = color()
+    order.comp_of_block[4], order.comp_of_block[5] = 2, 1
+    assert lib.daliamdJpegHuffmanColorFusable(C.byref(order)) == 0
+    # buffer rules: alignment, pitch, size consistent with the MCU grid, more than 4 pixels wide
+    for bad in (color(rgb=0x80004), color(pitch=3 * 157 + 5), color(pitch=8), color(width=170), color(height=200),
+                color(1, 4, width=4)):
+        assert setup(bad)[0] != 0, "accepted a bad descriptor"
