@@ -239,6 +239,14 @@ __device__ __forceinline__ void MinMax4(int a, int b, int c, int d, int *lo, int
   *hi = max(max(a, b), max(c, d));
 }
 
+// Elements per row of the fp32 intermediate of a V-first tile.  The packed vertical pass produces the four elements of
+// one staged DWORD per item: with the rows laid out on the window's dword grid (element e of the tile at index e + s4, s4 =
+// the window's byte offset inside its first dword) an item's result is ONE aligned 16-byte store - the four dword stores
+// at a lane stride of four dwords it replaces hit every bank four times per wave.
+__host__ __device__ inline int TmpRowPitch(int NB, bool vfirst, bool staged, int pitch, uint64_t win) {
+  return vfirst && staged && (pitch & 3) == 0 ? (NB + (int)(win & 3) + 3) & ~3 : NB;
+}
+
 // one thread per tile: the record
 __device__ void MakeTileRec(const daliamdResampleDesc *descs, int ndesc, int tile, uint8_t *workspace, TileRec *out) {
   int lo = 0, hi = ndesc - 1;
@@ -285,7 +293,7 @@ __device__ void MakeTileRec(const daliamdResampleDesc *descs, int ndesc, int til
   r.tab = reinterpret_cast<uint64_t>(workspace + d.table_off);
   r.pitch = d.in_pitch; r.nrows = nrows; r.NB = NB; r.LP = LP;
   r.x_lo = x_lo; r.y_lo = y_lo;
-  r.tmp_bytes = 4 * (vfirst ? th * NB : nrows * tw * C);
+  r.tmp_bytes = 4 * (vfirst ? th * TmpRowPitch(NB, vfirst, staged, d.in_pitch, r.win) : nrows * tw * C);
   r.desc_idx = lo;
   r.ox0 = ox0; r.oy0 = oy0; r.tw = tw; r.th = th;
   r.TW = TW; r.TH = TH; r.sup_x = sup_x; r.sup_y = sup_y;
@@ -459,7 +467,7 @@ __device__ __forceinline__ uint32_t LdsDwordAt(const uint8_t *base, int off) {
 constexpr int kVLanesPerRow = DALIAMD_RS_LPR;   // lanes that share one output row of the vertical first pass
 template <int N>
 __device__ __forceinline__ void VPassItems(const uint8_t *stage, float *tmp, const float *cy, const int *yt, int tid, int th,
-                                           int NB, int sup_y, int s4, int ndw, int jbase) {
+                                           int sup_y, int s4, int ndw, int jbase) {
   const int j0 = jbase + (tid & (kVLanesPerRow - 1));
   const uint8_t *col[N];
 #pragma unroll
@@ -488,19 +496,11 @@ __device__ __forceinline__ void VPassItems(const uint8_t *stage, float *tmp, con
         hi[i] += floatx2{(float)((v[i] >> 16) & 255), (float)(v[i] >> 24)} * w;
       }
     }
-    float *trow = tmp + y * NB;
+    float4 *trow = reinterpret_cast<float4 *>(tmp + y * (4 * ndw));   // rows on the dword grid: TmpRowPitch
 #pragma unroll
     for (int i = 0; i < N; i++) {
-      const int j = j0 + kVLanesPerRow * i, e = 4 * j - s4;
-      if (j >= ndw) continue;
-      if (e >= 0 && e + 3 < NB) {
-        trow[e] = lo[i].x; trow[e + 1] = lo[i].y; trow[e + 2] = hi[i].x; trow[e + 3] = hi[i].y;
-      } else {
-        if (e >= 0 && e < NB) trow[e] = lo[i].x;
-        if (e + 1 >= 0 && e + 1 < NB) trow[e + 1] = lo[i].y;
-        if (e + 2 >= 0 && e + 2 < NB) trow[e + 2] = hi[i].x;
-        if (e + 3 >= 0 && e + 3 < NB) trow[e + 3] = hi[i].y;
-      }
+      const int j = j0 + kVLanesPerRow * i;
+      if (j < ndw) trow[j] = make_float4(lo[i].x, lo[i].y, hi[i].x, hi[i].y);
     }
   }
 }
@@ -534,6 +534,9 @@ __global__ __launch_bounds__(kResampleThreads) __attribute__((amdgpu_waves_per_e
     const int ex = r.ex, ey = r.ey, x_lo = r.x_lo, y_lo = r.y_lo;
     const int nrows = r.nrows, NB = r.NB, LP = r.LP, pitch = r.pitch, rowlen = r.rowlen;
     const uintptr_t win_addr = (uintptr_t)r.win;
+    // V-first: pitch of a row of the fp32 intermediate and where element 0 sits in it (TmpRowPitch)
+    const int NBp = TmpRowPitch(NB, vfirst, staged, pitch, r.win);
+    const int tshift = NBp != NB || (vfirst && staged && (pitch & 3) == 0) ? (int)(win_addr & 3) : 0;
 
     // LDS carve-up (byte offsets from the LDS base, never a round trip through an integer: that would make every
     // access behind it a generic one): look-up table | staged window | tmp | coefficients and per-tap offsets
@@ -571,7 +574,7 @@ __global__ __launch_bounds__(kResampleThreads) __attribute__((amdgpu_waves_per_e
         const int x = tid & (TW - 1), k = tid >> tw_log2;
         if (k < sup_x && x < tw) {
           cx[tid] = pf.cxv;
-          xt[tid] = (ClampI(pf.xiv + k, 0, ex) - x_lo) * C;
+          xt[tid] = (ClampI(pf.xiv + k, 0, ex) - x_lo) * C + tshift;
         }
       }
       {
@@ -588,7 +591,7 @@ __global__ __launch_bounds__(kResampleThreads) __attribute__((amdgpu_waves_per_e
         const int x = i & (TW - 1), k = i >> tw_log2;
         if (x < tw) {
           cx[i] = xc[(size_t)(ox0 + x) * sup_x + k];
-          xt[i] = (ClampI(xi[ox0 + x] + k, 0, ex) - x_lo) * C;
+          xt[i] = (ClampI(xi[ox0 + x] + k, 0, ex) - x_lo) * C + tshift;
         }
       }
       for (int i = tid; i < TH * sup_y; i += kResampleThreads) {
@@ -639,9 +642,9 @@ __global__ __launch_bounds__(kResampleThreads) __attribute__((amdgpu_waves_per_e
         const int ndw = (NB + s4 + 3) >> 2;
         for (int jbase = 0; jbase < ndw; jbase += 3 * kVLanesPerRow) {
           const int rem = ndw - jbase;
-          if (rem > 2 * kVLanesPerRow) VPassItems<3>(stage, tmp, cy, yt, tid, th, NB, sup_y, s4, ndw, jbase);
-          else if (rem > kVLanesPerRow) VPassItems<2>(stage, tmp, cy, yt, tid, th, NB, sup_y, s4, ndw, jbase);
-          else VPassItems<1>(stage, tmp, cy, yt, tid, th, NB, sup_y, s4, ndw, jbase);
+          if (rem > 2 * kVLanesPerRow) VPassItems<3>(stage, tmp, cy, yt, tid, th, sup_y, s4, ndw, jbase);
+          else if (rem > kVLanesPerRow) VPassItems<2>(stage, tmp, cy, yt, tid, th, sup_y, s4, ndw, jbase);
+          else VPassItems<1>(stage, tmp, cy, yt, tid, th, sup_y, s4, ndw, jbase);
         }
       } else {
         for (int y = tid >> 6; y < th; y += kResampleThreads / 64) {
@@ -654,7 +657,7 @@ __global__ __launch_bounds__(kResampleThreads) __attribute__((amdgpu_waves_per_e
             } else {
               for (int k = 0; k < sup_y; k++) a += (float)gwin[ro[k] + e] * co[k];
             }
-            tmp[y * NB + e] = a;
+            tmp[y * NBp + e] = a;
           }
         }
       }
@@ -671,7 +674,7 @@ __global__ __launch_bounds__(kResampleThreads) __attribute__((amdgpu_waves_per_e
           const bool tile_even = (r.even_bits & need) == need;
           const int nk = sup_x;
           for (int y = tid >> hw_log2; y < th; y += kResampleThreads >> hw_log2) {
-            const float *trow = tmp + y * NB;
+            const float *trow = tmp + y * NBp;
             floatx2 a0 = {0.0f, 0.0f}, a1 = {0.0f, 0.0f}, a2 = {0.0f, 0.0f};
             for (int k = 0; k < nk; k++) {
               const floatx2 w = co[k * half_tw];
@@ -695,7 +698,7 @@ __global__ __launch_bounds__(kResampleThreads) __attribute__((amdgpu_waves_per_e
         const int gx = ox0 + x;
         const bool even = (r.even_bits >> x) & 1;
         for (int y = tid >> tw_log2; y < th; y += kResampleThreads >> tw_log2) {
-          const float *trow = tmp + y * NB;
+          const float *trow = tmp + y * NBp;
           float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
           if (C == 3) {  // the common case without the per-tap channel tests
             for (int k = 0; k < sup_x; k++) {
@@ -1141,7 +1144,8 @@ static int SetupOne(const daliamdResampleArgs &a, daliamdResampleDesc &d, int in
     nrows = std::min<size_t>(nrows, a.in_h);
     size_t lp = (size_t)StagedRowPitch((int)(ncols * a.channels));
     size_t stage = staged ? nrows * lp : 0;
-    size_t tmp_elems = d.first_axis == 1 ? (size_t)th_ * ncols * a.channels : nrows * (size_t)tw_ * a.channels;
+    // (V-first: rows of the intermediate on the window's dword grid, TmpRowPitch: up to 3 + 3 elements more)
+    size_t tmp_elems = d.first_axis == 1 ? (size_t)th_ * (ncols * a.channels + 6) : nrows * (size_t)tw_ * a.channels;
     return kLutLdsBytes + tables * 4 + 32 + stage + tmp_elems * 4;
   };
   auto shrink = [&](int &tw_, int &th_, bool staged, int min_area, size_t budget) {
