@@ -756,7 +756,7 @@ def bench_audio(args, device, steps=None, cpu_seconds=8.0):
            "warmup": args.warmup, "ms_per_step": 1e3 * el / steps, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "configs[3]: 64 mono utterances, 16 kHz, 8-16 s, 16-bit WAV files in the page cache -> "
-                                  "readers.file -> decoders.audio (host) -> H2D -> spectrogram -> mel -> dB (device)",
+                                  "readers.file -> decoders.audio (host: header parse) -> H2D -> spectrogram -> mel -> dB (device)",
                       "frames": frames, "samples": samples, "kernels": kernels, "prefetch_queue_depth": depth,
                       "exec_async": True, "host_threads": threads,
                       "kernels_ms_per_step": sum(v["avg_ms"] for v in per.values()),
@@ -765,8 +765,12 @@ def bench_audio(args, device, steps=None, cpu_seconds=8.0):
                       "mel_variant": "valu" if os.environ.get("DALI_AMD_MEL_VALU") == "1" else "mfma",
                       "host_ms_per_operator": {k: v for k, v in host.items() if not k.startswith("<")},
                       "host_stage_ms_per_step": host.get("<host stage>"), "device_stage_ms_per_step": host.get("<device stage>"),
-                      "note": "value is end to end from files: 98 MB of 16-bit PCM decoded to 49 MB of float on the host and "
-                              "copied to the device per step"},
+                      "pcm16_fusion": os.environ.get("DALI_AMD_NO_PCM16_FUSION", "0") in ("", "0"),
+                      "note": "value is end to end from files.  Round 4: the decoded audio feeds only the copy in front of the "
+                              "gpu spectrogram, so the 25 MB of 16-bit PCM of a step cross the bus as they are (decoders.audio hands "
+                              "out a view of the files' data chunks, one H2D transfer of the reader's block) and the spectrogram "
+                              "kernel's load divides by 32768 - the same bits as converting to 50 MB of float on the host "
+                              "(DALI_AMD_NO_PCM16_FUSION=1: that path, tests/test_gpu_audio.py holds the two to each other)"},
            "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": ach / HBM_PEAK_GBS if ach else None, "traffic": traffic,
                         "traffic_source": traffic_src, "per_kernel": per, "operator_device_ms": times}}

@@ -17,6 +17,13 @@ using GFloat = const float __attribute__((address_space(1)));
 typedef float floatx2 __attribute__((ext_vector_type(2)));
 using GFloat2 = const floatx2 __attribute__((address_space(1)));
 using GOutFloat = float __attribute__((address_space(1)));
+using GInt16 = const int16_t __attribute__((address_space(1)));
+using GWord = const uint32_t __attribute__((address_space(1)));
+// daliamdSpectrogramParams.input_pcm16: the signal as 16-bit PCM, sample / 32768 (exact in float)
+constexpr float kPcm16Scale = 1.0f / 32768.0f;
+__device__ __forceinline__ float SampleAt(GFloat *in, bool pcm16, long long idx) {
+  return pcm16 ? (float)((GInt16 *)in)[idx] * kPcm16Scale : in[idx];
+}
 
 // =============================================================================================
 // spectrogram
@@ -175,7 +182,8 @@ __global__ __launch_bounds__(kSpecThreads) void SpectrogramKernel(const daliamdS
   __syncthreads();
   const int T = d.num_windows;
   const int t0 = (wg - d.wg_start) * FPG;
-  const float *__restrict__ in = d.in;
+  GFloat *in = (GFloat *)d.in;
+  const bool pcm16 = p.input_pcm16 != 0;
   for (int f = 0; f < FPW; f++) {
     const int fi = f * kSpecWaves + wave;  // frame slot inside the tile
     const int frame = t0 + fi;
@@ -183,12 +191,11 @@ __global__ __launch_bounds__(kSpecThreads) void SpectrogramKernel(const daliamdS
     // buffer position j holds window[j - pad0] * in[base + j]
     const long long base = (long long)frame * p.window_step - (p.center_windows ? p.window_length / 2 : 0) - pad0;
     if (base >= 0 && base + nfft <= d.length) {
-      const float *src = in + base;
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const int i = lane + 64 * u;
         if (i < N) {
-          const float x0 = src[2 * i], x1 = src[2 * i + 1];
+          const float x0 = SampleAt(in, pcm16, base + 2 * i), x1 = SampleAt(in, pcm16, base + 2 * i + 1);
           work[i] = make_float2((inwin[u] & 1) ? wr[u].x * x0 : 0.0f, (inwin[u] & 2) ? wr[u].y * x1 : 0.0f);
         }
       }
@@ -203,8 +210,8 @@ __global__ __launch_bounds__(kSpecThreads) void SpectrogramKernel(const daliamdS
             if (!((inwin[u] >> h) & 1)) continue;
             const long long idx = base + 2 * i + h;
             const float w = h ? wr[u].y : wr[u].x;
-            if (p.reflect_padding) x[h] = w * in[Reflect101L(idx, d.length)];
-            else if (idx >= 0 && idx < d.length) x[h] = w * in[idx];
+            if (p.reflect_padding) x[h] = w * SampleAt(in, pcm16, Reflect101L(idx, d.length));
+            else if (idx >= 0 && idx < d.length) x[h] = w * SampleAt(in, pcm16, idx);
           }
           work[i] = make_float2(x[0], x[1]);
         }
@@ -422,6 +429,7 @@ __global__ __launch_bounds__(kSpecThreads) void SpectrogramFastKernel(const dali
   const int T = d.num_windows;
   const int t0 = (wg - d.wg_start) * FPG;
   GFloat *in = (GFloat *)d.in;
+  const bool pcm16 = p.input_pcm16 != 0;
   float pw[FPW][UP][2];
 #pragma unroll
   for (int rd = 0; rd < FPW / FC; rd++) {
@@ -435,9 +443,20 @@ __global__ __launch_bounds__(kSpecThreads) void SpectrogramFastKernel(const dali
       const int frame = min(t0 + wave * FPW + rd * FC + c, T - 1);
       base[c] = (long long)frame * p.window_step - (p.center_windows ? p.window_length / 2 : 0) - pad0;
       interior = interior && base[c] >= 0 && base[c] + nfft <= d.length;
-      pairs_aligned = pairs_aligned && ((uintptr_t)(in + base[c]) & 7) == 0;
+      pairs_aligned = pairs_aligned && (pcm16 ? ((uintptr_t)((GInt16 *)in + base[c]) & 3) == 0 : ((uintptr_t)(in + base[c]) & 7) == 0);
     }
-    if (interior && pairs_aligned) {  // one 8-byte load per point
+    if (interior && pairs_aligned && pcm16) {  // one 4-byte load per point: two 16-bit samples
+#pragma unroll
+      for (int c = 0; c < FC; c++) {
+        GWord *src = (GWord *)((GInt16 *)in + base[c]);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const uint32_t w = src[lane + 64 * u];
+          const float x0 = (float)(int16_t)(w & 0xffffu) * kPcm16Scale, x1 = (float)(int16_t)(w >> 16) * kPcm16Scale;
+          z[c][u] = make_float2((inwin >> (2 * u)) & 1 ? wr[u].x * x0 : 0.0f, (inwin >> (2 * u)) & 2 ? wr[u].y * x1 : 0.0f);
+        }
+      }
+    } else if (interior && pairs_aligned) {  // one 8-byte load per point
 #pragma unroll
       for (int c = 0; c < FC; c++) {
         GFloat2 *src = (GFloat2 *)(in + base[c]);
@@ -450,11 +469,10 @@ __global__ __launch_bounds__(kSpecThreads) void SpectrogramFastKernel(const dali
     } else if (interior) {
 #pragma unroll
       for (int c = 0; c < FC; c++) {
-        GFloat *src = in + base[c];
 #pragma unroll
         for (int u = 0; u < U; u++) {
           const int i = lane + 64 * u;
-          const float x0 = src[2 * i], x1 = src[2 * i + 1];
+          const float x0 = SampleAt(in, pcm16, base[c] + 2 * i), x1 = SampleAt(in, pcm16, base[c] + 2 * i + 1);
           z[c][u] = make_float2((inwin >> (2 * u)) & 1 ? wr[u].x * x0 : 0.0f, (inwin >> (2 * u)) & 2 ? wr[u].y * x1 : 0.0f);
         }
       }
@@ -469,8 +487,8 @@ __global__ __launch_bounds__(kSpecThreads) void SpectrogramFastKernel(const dali
             if (!((inwin >> (2 * u + h)) & 1)) continue;
             const long long idx = base[c] + 2 * (lane + 64 * u) + h;
             const float w = h ? wr[u].y : wr[u].x;
-            if (p.reflect_padding) x[h] = w * in[Reflect101L(idx, d.length)];
-            else if (idx >= 0 && idx < d.length) x[h] = w * in[idx];
+            if (p.reflect_padding) x[h] = w * SampleAt(in, pcm16, Reflect101L(idx, d.length));
+            else if (idx >= 0 && idx < d.length) x[h] = w * SampleAt(in, pcm16, idx);
           }
           z[c][u] = make_float2(x[0], x[1]);
         }

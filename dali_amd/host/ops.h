@@ -59,6 +59,8 @@ struct DeferredAudio {
 };
 // true when the pair was fused (the pipeline then tries to extend the chain)
 bool TryEnableAudioFusion(OperatorBase *producer, OperatorBase *consumer);
+// decoders.audio -> copy to the device -> Spectrogram (gpu): 16-bit PCM travels as int16, the kernel's load converts
+void TryEnablePcm16Fusion(OperatorBase *decoder, OperatorBase *spectrogram);
 
 // The sample-index stream every reader draws from (Loader, dali/operators/reader/loader/loader.h:78-503,
 // loader.cc:78-87): sequential over the data set starting at this shard (start = size * shard_id / num_shards),

@@ -112,6 +112,20 @@ class AudioDecoderCpu : public OperatorBase {
     }
     target_rate_.assign(n, 0.0f);
     if (spec_.ArgumentDefined("sample_rate")) target_rate_ = GetPerSampleFloat(spec_, ws, "sample_rate", n);
+    // Graph-level fusion with a GPU Spectrogram behind the copy to the device (EmitPcm16): a batch of single-channel
+    // 16-bit streams that needs no resampling leaves as the int16 samples the files hold - half the bytes through the
+    // host's memory and over the bus, and no conversion pass here; the spectrogram kernel's load divides by 32768.
+    batch_pcm16_ = emit_pcm16_ && dtype_ == DALI_FLOAT && n > 0;
+    for (int i = 0; i < n && batch_pcm16_; i++) {
+      const WavInfo &w = infos_[i];
+      const bool resample = target_rate_[i] > 0 && (float)w.rate != target_rate_[i];
+      batch_pcm16_ = !resample && w.channels == 1 && w.bits == 16 && (w.tag == 1 || w.tag == kTagFlac);
+    }
+    if (batch_pcm16_) desc[0].type = DALI_INT16;
+    // ... and when every stream is a WAV file the samples are where the reader put them: the output is a VIEW of the
+    // input (sample i = the data chunk of file i), nothing is copied on the host at all
+    view_ = batch_pcm16_;
+    for (int i = 0; i < n && view_; i++) view_ = infos_[i].tag == 1 && (reinterpret_cast<uintptr_t>(infos_[i].data) & 1) == 0;
     for (int i = 0; i < n; i++) {
       // DecodedAudioShape (audio_decoder_impl.cc:38-47)
       const bool resample = target_rate_[i] > 0 && (float)infos_[i].rate != target_rate_[i];
@@ -120,10 +134,25 @@ class AudioDecoderCpu : public OperatorBase {
       if (downmix_ || infos_[i].channels == 1) desc[0].shape[i] = {len};
       else desc[0].shape[i] = {len, infos_[i].channels};
     }
+    if (view_) {
+      view_shapes_ = desc[0].shape;
+      return false;   // RunImpl sizes the outputs itself
+    }
     return true;
   }
   void RunImpl(Workspace &ws) override {
     TensorList &out = ws.Output(0), &rate = ws.Output(1);
+    if (view_) {
+      const int n = (int)infos_.size();
+      std::vector<void *> ptrs(n);
+      for (int i = 0; i < n; i++) ptrs[i] = const_cast<uint8_t *>(infos_[i].data);
+      // (the input list keeps the reader's block alive as long as this view exists: the ring slot of the same iteration)
+      out.Resize(view_shapes_, DALI_INT16, 1, ptrs, std::vector<int64_t>(n, 0), ws.inputs[0]);
+      out.source_info = ws.Input(0).source_info;
+      rate.Resize(std::vector<TensorShape>(n, TensorShape{}), DALI_FLOAT);
+      for (int i = 0; i < n; i++) *static_cast<float *>(rate.raw(i)) = (float)infos_[i].rate;
+      return;
+    }
     for (int i = 0; i < out.num_samples(); i++) {
       ws.GetThreadPool().AddWork([&, i](int) {
         const WavInfo &w = infos_[i];
@@ -146,6 +175,13 @@ class AudioDecoderCpu : public OperatorBase {
           if (daliamdFlacDecode(w.data, w.nbytes, flac.data(), w.frames) != 0)
             DALI_FAIL("Failed to decode ", i < (int)ws.Input(0).source_info.size() ? ws.Input(0).source_info[i] : make_string("sample #", i),
                       ": ", daliamdHostGetLastErrorMessage());
+        }
+        if (batch_pcm16_) {   // (SetupImpl: mono, 16 bits, no resampling)
+          int16_t *o16 = static_cast<int16_t *>(out.raw(i));
+          if (w.tag == 1) memcpy(o16, w.data, (size_t)w.frames * 2);
+          else for (int64_t k = 0; k < w.frames; k++) o16[k] = (int16_t)flac[k];
+          *static_cast<float *>(rate.raw(i)) = (float)w.rate;
+          return;
         }
         const int bits = w.bits;
         auto isample = [&](int64_t k) -> int32_t {
@@ -217,8 +253,14 @@ class AudioDecoderCpu : public OperatorBase {
     ws.GetThreadPool().RunAll();
   }
 
+  // decoders.audio -> copy to the device -> Spectrogram (gpu), each the only consumer of the one before
+  bool CanEmitPcm16() const { return dtype_ == DALI_FLOAT; }
+  void EmitPcm16() { emit_pcm16_ = true; }
+
  private:
   bool downmix_;
+  bool emit_pcm16_ = false, batch_pcm16_ = false, view_ = false;
+  std::vector<TensorShape> view_shapes_;
   float quality_ = 50.0f;
   DALIDataType dtype_ = DALI_FLOAT;
   std::vector<float> target_rate_;
@@ -267,7 +309,9 @@ class SpectrogramGpu : public OperatorBase {
   }
   bool SetupImpl(std::vector<OutputDesc> &desc, const Workspace &ws) override {
     const TensorList &in = ws.Input(0);
-    DALI_ENFORCE(in.type() == DALI_FLOAT, "Spectrogram expects float32 input, got ", TypeName(in.type()));
+    DALI_ENFORCE(in.type() == DALI_FLOAT || (accept_pcm16_ && in.type() == DALI_INT16),
+                 "Spectrogram expects float32 input, got ", TypeName(in.type()));
+    p_.input_pcm16 = in.type() == DALI_INT16;   // (only from a decoders.audio fused in front: see AcceptPcm16)
     int n = in.num_samples();
     descs_.assign(n, daliamdSpectrogramDesc{});
     for (int i = 0; i < n; i++) {
@@ -281,6 +325,7 @@ class SpectrogramGpu : public OperatorBase {
     for (int i = 0; i < n; i++) desc[0].shape[i] = {p_.nfft / 2 + 1, descs_[i].num_windows};
     return !(fused_ && ws.backend != OpType::CPU);   // fused: no buffer, the mel filter bank behind launches for both
   }
+  void AcceptPcm16() { accept_pcm16_ = true; }
   // MelFilterBank is the only consumer: hand the arguments on (nfft 512 / 1024: the sizes the fused kernel exists for)
   bool EnableFusion() {
     fused_ = p_.nfft == 512 || p_.nfft == 1024;
@@ -337,6 +382,7 @@ class SpectrogramGpu : public OperatorBase {
 
  private:
   daliamdSpectrogramParams p_{};
+  bool accept_pcm16_ = false;
   std::vector<float> window_;
   Buffer window_dev_;
   bool window_uploaded_ = false;
@@ -630,6 +676,15 @@ class ToDecibelsGpu : public OperatorBase {
 };
 DALI_REGISTER_OPERATOR(ToDecibels, ToDecibelsGpu, GPU);
 DALI_REGISTER_OPERATOR(ToDecibels, ToDecibelsGpu, CPU);
+
+void TryEnablePcm16Fusion(OperatorBase *decoder, OperatorBase *spectrogram) {
+  if (getenv("DALI_AMD_NO_PCM16_FUSION") && atoi(getenv("DALI_AMD_NO_PCM16_FUSION")) != 0) return;
+  auto *dec = dynamic_cast<AudioDecoderCpu *>(decoder);
+  auto *spec = dynamic_cast<SpectrogramGpu *>(spectrogram);
+  if (!dec || !spec || !dec->CanEmitPcm16()) return;
+  dec->EmitPcm16();
+  spec->AcceptPcm16();
+}
 
 bool TryEnableAudioFusion(OperatorBase *producer, OperatorBase *consumer) {
   if (getenv("DALI_AMD_NO_AUDIO_FUSION") && atoi(getenv("DALI_AMD_NO_AUDIO_FUSION")) != 0) return false;

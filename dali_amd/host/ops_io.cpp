@@ -758,11 +758,54 @@ class CopyToGpuOp : public OperatorBase {
     desc[0].type = in.type();
     desc[0].shape.clear();
     for (int i = 0; i < in.num_samples(); i++) desc[0].shape.push_back(in.shape(i));
-    return true;
+    // A list that is a VIEW of one host block (decoders.audio over the files of a batch: every sample is the data chunk of
+    // a file the reader put into one page-locked block) goes over as that block, in ONE transfer - 64 transfers of 0.4 MB
+    // run at a third of the rate of one of 25 MB - and the output views the device copy the same way.
+    block_ = false;
+    const int n = in.num_samples();
+    if (n > 1) {
+      uintptr_t lo = UINTPTR_MAX, hi = 0;
+      size_t sum = 0;
+      bool all_ext = true;
+      for (int i = 0; i < n && all_ext; i++) {
+        all_ext = in.is_external(i) && in.row_pitch(i) == 0;
+        const uintptr_t p = reinterpret_cast<uintptr_t>(in.raw(i));
+        lo = std::min(lo, p);
+        hi = std::max(hi, p + in.nbytes(i));
+        sum += in.nbytes(i);
+      }
+      if (all_ext && hi - lo <= sum + sum / 4 + (64 << 10)) {
+        block_ = true;
+        block_lo_ = lo;
+        block_bytes_ = hi - lo;
+      }
+    }
+    return !block_;
   }
   void RunImpl(Workspace &ws) override {
     const TensorList &in = ws.Input(0);
     TensorList &out = ws.Output(0);
+    if (block_) {
+      if ((int)blocks_.size() < ws.ring) blocks_.resize(ws.ring);
+      auto &blk = blocks_[ws.iteration % ws.ring];   // (its last reader finished before this ring slot came round again)
+      if (!blk) blk = std::make_shared<Buffer>(StorageDevice::GPU);
+      blk->Reserve(block_bytes_ + 512);
+      // (device addresses congruent to the host's modulo 256: whatever alignment the consumer's loads found there holds here)
+      uint8_t *dst = static_cast<uint8_t *>(blk->data()) + (block_lo_ & 255);
+      const int n = in.num_samples();
+      std::vector<TensorShape> shapes(n);
+      std::vector<void *> ptrs(n);
+      for (int i = 0; i < n; i++) {
+        shapes[i] = in.shape(i);
+        ptrs[i] = dst + (reinterpret_cast<uintptr_t>(in.raw(i)) - block_lo_);
+      }
+      out.Resize(shapes, in.type(), 1, ptrs, std::vector<int64_t>(n, 0), blk);
+      out.SetLayout(in.layout());
+      out.source_info = in.source_info;
+      KCHECK(daliamdMemcpyH2DAsync(dst, reinterpret_cast<const void *>(block_lo_), block_bytes_, ws.stream));
+      NoteLaunch(ws, "h2d_copy");
+      return;
+    }
     out.SetLayout(in.layout());
     out.source_info = in.source_info;
     // both lists use the same 256-byte-aligned packing: one copy
@@ -774,6 +817,12 @@ class CopyToGpuOp : public OperatorBase {
     }
     NoteLaunch(ws, "h2d_copy");
   }
+
+ private:
+  bool block_ = false;
+  uintptr_t block_lo_ = 0;
+  size_t block_bytes_ = 0;
+  std::vector<std::shared_ptr<Buffer>> blocks_;   // one device copy of the host block per ring slot
 };
 DALI_REGISTER_OPERATOR(_CopyToGpu, CopyToGpuOp, MIXED);
 

@@ -203,6 +203,24 @@ void Pipeline::Build(const std::vector<std::pair<std::string, std::string>> &out
     Node &p = nodes_[n.in_node[0]];
     if (consumers[n.in_node[0]] == 1 && p.type == OpType::GPU) TryEnableAudioFusion(p.op.get(), n.op.get());
   }
+  // ... and the audio samples of a decoders.audio whose ONLY consumer is the copy to the device in front of a gpu
+  // Spectrogram (itself that copy's only consumer) cross the bus as the 16-bit PCM the files hold
+  for (auto &n : nodes_) {
+    if (n.spec.SchemaName() != "Spectrogram" || n.type != OpType::GPU || n.in_node.empty()) continue;
+    const int c = n.in_node[0];
+    Node &copy = nodes_[c];
+    if (copy.spec.SchemaName() != "_CopyToGpu" || consumers[c] != 1 || copy.in_node.empty() || copy.in_idx[0] != 0) continue;
+    const int q = copy.in_node[0];
+    const std::string &dn = nodes_[q].spec.SchemaName();
+    if (dn != "decoders__Audio" && dn != "AudioDecoder") continue;
+    int uses = 0;   // of the decoder's first output (the second one is the sampling rate)
+    for (auto &m : nodes_) {
+      for (size_t k = 0; k < m.in_node.size(); k++) uses += m.in_node[k] == q && m.in_idx[k] == 0;
+      for (auto &a : m.arg_in) uses += a.second.first == q && a.second.second == 0;
+    }
+    for (auto &o : outputs_) uses += 2 * (o.first == q && o.second == 0);
+    if (uses == 1) TryEnablePcm16Fusion(nodes_[q].op.get(), n.op.get());
+  }
   slot_events_.assign(ring_, nullptr);
   if (!streams_.empty())
     for (auto &e : slot_events_) KCHECK(daliamdEventCreate(&e, 2));  // the consumer sleeps in Outputs(), it does not poll

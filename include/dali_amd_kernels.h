@@ -511,6 +511,11 @@ typedef struct {
 typedef struct {
   int32_t nfft, window_length, window_step;
   int32_t center_windows, reflect_padding, power; /* power: 1 magnitude, 2 power */
+  /* 0: the signals are float32.  1: daliamdSpectrogramDesc.in points to int16 samples that stand for sample / 32768 -
+   * 16-bit PCM as decoders.audio finds it in the file (audio_decoder_impl.cc:49-120: libsndfile's float read of PCM16
+   * divides by 32768): the conversion happens in the kernel's load, the signal crosses the bus at 2 bytes per sample
+   * (round 4; same bits as converting on the host). */
+  int32_t input_pcm16;
 } daliamdSpectrogramParams;
 DALIAMD_API void daliamdHannWindow(int n, float *window);
 DALIAMD_API daliamdResult_t daliamdSpectrogramSetup(daliamdSpectrogramDesc *descs_host, int n,

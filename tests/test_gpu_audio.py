@@ -89,6 +89,72 @@ def test_audio_pipeline_matches_oracle(kw):
         assert got_db.max() <= 1e-4 and got_db.min() >= -80.0 - 1e-3
 
 
+def _pcm_chain(bs, nfft, wl, step, center, reflect, dtype=None):
+    """decoders.audio -> gpu -> spectrogram -> mel -> dB with the decoded audio used by the spectrogram ONLY."""
+    from dali_amd import fn, types
+    from dali_amd.pipeline import Pipeline
+    pipe = Pipeline(batch_size=bs, num_threads=4, device_id=0, prefetch_queue_depth=1)
+    with pipe:
+        enc = fn.external_source(name="wav")
+        audio, rate = fn.decoders.audio(enc, downmix=True, **({"dtype": dtype} if dtype is not None else {}))
+        spec = fn.spectrogram(audio.gpu(), nfft=nfft, window_length=wl, window_step=step, center_windows=center,
+                              reflect_padding=reflect)
+        mel = fn.mel_filter_bank(spec, nfilter=80, sample_rate=16000.0, freq_high=8000.0)
+        pipe.set_outputs(fn.to_decibels(mel, multiplier=10.0, cutoff_db=-80.0), rate)
+    pipe.build()
+    return pipe
+
+
+@pytest.mark.parametrize("nfft,wl,step,center,reflect", [(1024, 1024, 256, True, True), (512, 400, 160, True, False),
+                                                         (1024, 800, 200, False, True), (256, 256, 64, True, True),
+                                                         (1024, 1024, 255, True, True)])
+def test_pcm16_crosses_the_bus_as_int16_and_gives_the_same_bits(nfft, wl, step, center, reflect, monkeypatch):
+    """Round 4 graph-level fusion: when the decoded audio feeds nothing but the copy in front of a gpu Spectrogram, a
+    batch of mono 16-bit streams travels as int16 and the spectrogram kernel's load divides by 32768.  The results must be
+    the bits of the unfused graph (DALI_AMD_NO_PCM16_FUSION=1): odd lengths (unaligned sample pairs), odd hops, every
+    padding mode, the generic kernel (nfft 256) and the register-resident one; a batch with a stereo file falls back."""
+    rng = np.random.default_rng(3)
+    sigs = [synth_signal(rng, s) for s in (1.3, 0.40006, 2.1, 0.9)]          # (6401 samples: an odd length)
+    wavs = [to_wav(s) for s in sigs]
+    outs = {}
+    for fused in (True, False):
+        if not fused:
+            monkeypatch.setenv("DALI_AMD_NO_PCM16_FUSION", "1")
+        pipe = _pcm_chain(len(wavs), nfft, wl, step, center, reflect)
+        res = []
+        for _ in range(3):                                                    # (ring slots are reused)
+            pipe.feed_input("wav", wavs)
+            db, rate = pipe.run()
+            res.append([db[i].as_cpu().copy() for i in range(len(wavs))])
+            assert [float(rate.at(i)) for i in range(len(wavs))] == [16000.0] * len(wavs)
+        outs[fused] = res
+    for a, b in zip(outs[True], outs[False]):
+        for i, (x, y) in enumerate(zip(a, b)):
+            assert x.shape == y.shape and np.array_equal(x.view(np.uint32), y.view(np.uint32)), f"sample {i}"
+
+
+def test_pcm16_fusion_falls_back_when_a_stream_needs_the_host_path(monkeypatch):
+    """A stereo file (downmixed on the host in float), a float32 WAV or a resampled stream in the batch: the whole batch is
+    decoded to float as before."""
+    rng = np.random.default_rng(4)
+    a, b = synth_signal(rng, 0.8), synth_signal(rng, 0.8)
+    pcm = np.round(np.stack([a, b], axis=1) * 32767).astype("<i2")
+    buf = io.BytesIO()
+    buf.write(b"RIFF" + struct.pack("<I", 36 + pcm.nbytes) + b"WAVE")
+    buf.write(b"fmt " + struct.pack("<IHHIIHH", 16, 1, 2, 16000, 16000 * 4, 4, 16))
+    buf.write(b"data" + struct.pack("<I", pcm.nbytes) + pcm.tobytes())
+    wavs = [to_wav(a), buf.getvalue()]
+    pipe = _pcm_chain(2, 1024, 1024, 256, True, True)
+    pipe.feed_input("wav", wavs)
+    db, _ = pipe.run()
+    monkeypatch.setenv("DALI_AMD_NO_PCM16_FUSION", "1")
+    ref = _pcm_chain(2, 1024, 1024, 256, True, True)
+    ref.feed_input("wav", wavs)
+    rdb, _ = ref.run()
+    for i in range(2):
+        assert np.array_equal(db[i].as_cpu(), rdb[i].as_cpu())
+
+
 def test_mel_weights_match_oracle_and_reference_properties():
     import ctypes as C
     from dali_amd import _capi as capi
