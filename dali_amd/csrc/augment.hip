@@ -8,11 +8,11 @@
 
 namespace daliamd {
 
-__device__ __forceinline__ uint32_t SatU8(float v) {  // ConvertSat<uint8_t>: std::round then clamp
-  if (!(v > 0.0f)) return 0;
-  float r = floorf(v);
-  r += (v - r >= 0.5f) ? 1.0f : 0.0f;
-  return (uint32_t)fminf(r, 255.0f);
+// ConvertSat<uint8_t>: round half away from zero, then clamp (NaN and negatives -> 0).  One addition of the float below
+// 0.5, clamp, truncate: equal to the definition (floor(v) + (v - floor(v) >= 0.5)) for EVERY float - checked exhaustively
+// by tools/satu8_check.c (tests/test_satu8_rounding.py); v + 0.5 would be wrong for exactly one input, the float below 0.5.
+__device__ __forceinline__ uint32_t SatU8(float v) {
+  return (uint32_t)__builtin_amdgcn_fmed3f(v + 0.49999997f, 0.0f, 255.0f);
 }
 __device__ __forceinline__ int ClampInt(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
@@ -278,8 +278,14 @@ __global__ __launch_bounds__(kWarpThreads) void WarpAffineKernel(const daliamdWa
 #endif
 constexpr int kBlurThreads = DALIAMD_BLUR_THREADS;
 constexpr int kBlurMaxLds = 60 * 1024;
-constexpr int kBlurPx = 8;    // W pass: pixels per thread (and channel, and row of the pair)
-constexpr int kBlurRows = 8;  // H pass: output rows per thread
+#ifndef DALIAMD_BLUR_PX
+#define DALIAMD_BLUR_PX 8
+#endif
+#ifndef DALIAMD_BLUR_ROWS
+#define DALIAMD_BLUR_ROWS 8
+#endif
+constexpr int kBlurPx = DALIAMD_BLUR_PX;      // W pass: pixels per thread (and channel, and row of the pair)
+constexpr int kBlurRows = DALIAMD_BLUR_ROWS;  // H pass: output rows per thread
 typedef float floatx2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int Reflect101(int idx, int size) {
