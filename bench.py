@@ -344,6 +344,7 @@ def e2e_pipeline(root, batch, device_id, iters=400, threads=None, roi_decode=Fal
     t0 = time.perf_counter()
     for _ in range(iters):
         pipe.run()
+    pipe._backend.wait_enqueued()                      # (see run_resident_pipeline: the clock stops when all of them are done)
     if sync:
         sync()
     el = time.perf_counter() - t0
@@ -438,6 +439,7 @@ def iterator_leg(args, root, enc_all, dev_index, steps):
     t0 = time.perf_counter()
     for _ in range(steps):
         out = next(it)
+    pipe._backend.wait_enqueued()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     shape = tuple(out[0]["data"].shape)
@@ -490,6 +492,10 @@ def run_resident_pipeline(args, root, enc_all, device, dev_index, rank, world, l
     else:
         for _ in range(args.steps):
             pipe.run()
+    # K iterations were scheduled since t0 (the `depth` batches handed out first were complete before it: barrier above);
+    # the clock stops when all K are done - the last ones may still be with the executor's threads, so wait until they
+    # are on the streams before synchronising the device (no batch is credited that the region did not produce)
+    pipe._backend.wait_enqueued()
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_timing(False)
@@ -626,6 +632,7 @@ def bench_heavy_aug(args, device, steps=None, cpu_seconds=8.0):
         t0 = time.perf_counter()
         for _ in range(steps):
             run()
+        pipe._backend.wait_enqueued()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         kernel_timing(False)
@@ -727,6 +734,7 @@ def bench_audio(args, device, steps=None, cpu_seconds=8.0):
         t0 = time.perf_counter()
         for _ in range(steps):
             pipe.run()
+        pipe._backend.wait_enqueued()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         kernel_timing(False)
@@ -1048,6 +1056,7 @@ def main():
             t_roi = time.perf_counter()
             for _ in range(args.steps):
                 pipe2.run()
+            pipe2._backend.wait_enqueued()
             torch.cuda.synchronize()
             t_roi = time.perf_counter() - t_roi
             pipe_info["resident_roi_decode"] = {

@@ -34,6 +34,7 @@ def _lib():
         lib.daliamdPipelineOutputs.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         lib.daliamdPipelineOutputsOnStream.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         lib.daliamdPipelineReleaseOnStream.argtypes = [C.c_void_p, C.c_void_p]
+        lib.daliamdPipelineWaitEnqueued.argtypes = [C.c_void_p]
         lib.daliamdPipelineOutputInfo.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_char_p, C.c_int]
         lib.daliamdPipelineOutputSample.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p),
                                                     C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int64)]
@@ -203,6 +204,10 @@ class BackendPipeline:
         self.generation += 1
         check(self._lib.daliamdPipelineOutputsOnStream(self._h, C.c_void_p(stream_handle), C.byref(n)))
         return n.value
+
+    def wait_enqueued(self):
+        """Every scheduled iteration's device work is on the streams when this returns (then synchronise the device)."""
+        check(self._lib.daliamdPipelineWaitEnqueued(self._h))
 
     def release_on_stream(self, stream_handle):
         check(self._lib.daliamdPipelineReleaseOnStream(self._h, C.c_void_p(stream_handle)))

@@ -232,6 +232,9 @@ API int daliamdPipelineOutputsOnStream(void *h, void *consumer_stream, int *num_
     *num_outputs = (int)ph->outputs.size();
   });
 }
+API int daliamdPipelineWaitEnqueued(void *h) {
+  return Guard([&] { static_cast<PipelineHandle *>(h)->pipe->WaitEnqueued(); });
+}
 API int daliamdPipelineReleaseOnStream(void *h, void *consumer_stream) {
   return Guard([&] { static_cast<PipelineHandle *>(h)->pipe->ReleaseOnStream(consumer_stream); });
 }

@@ -490,6 +490,11 @@ std::vector<std::shared_ptr<TensorList>> Pipeline::TakeOutputs(daliamdStream_t c
   return out;
 }
 
+void Pipeline::WaitEnqueued() {
+  std::unique_lock<std::mutex> lk(m_);
+  cv_res_.wait(lk, [this] { return (int64_t)results_.size() >= scheduled_ - consumed_; });
+}
+
 void Pipeline::ReleaseOnStream(daliamdStream_t consumer_stream) {
   if (streams_.empty() || held_slot_ < 0) return;
   KCHECK(daliamdEventRecord(release_events_[held_slot_], consumer_stream));

@@ -53,6 +53,10 @@ class Pipeline {
   // written again before everything in that stream up to this call has completed.  (Without this call a consumer
   // that took the outputs with OutputsOnStream must have finished reading on its own.)
   void ReleaseOnStream(daliamdStream_t consumer_stream);
+  // blocks until the device work of every scheduled iteration has been ENQUEUED (its host and device stages have run);
+  // a device synchronisation behind this call then covers everything Run() has asked for (benchmarks: the end of a
+  // timed region)
+  void WaitEnqueued();
   // feed one batch to an ExternalSource operator instance
   void FeedInput(const std::string &op_name, const std::vector<const void *> &data,
                  const std::vector<TensorShape> &shapes, DALIDataType type, const std::string &layout);

@@ -65,6 +65,9 @@ DALIAMD_PIPE_API int daliamdPipelineOutputs(void *pipe, int *num_outputs);
  * of an iteration are raised by the Outputs* call for it or by the next one. */
 DALIAMD_PIPE_API int daliamdPipelineOutputsOnStream(void *pipe, void *consumer_stream, int *num_outputs);
 DALIAMD_PIPE_API int daliamdPipelineReleaseOnStream(void *pipe, void *consumer_stream);
+/* Blocks until the device work of every iteration scheduled so far has been enqueued on the pipeline's streams: a device
+ * synchronisation behind it covers all of it (the end of a benchmark's timed region). */
+DALIAMD_PIPE_API int daliamdPipelineWaitEnqueued(void *pipe);
 /* info: [0] device (0 cpu / 1 gpu), [1] dtype (DALIDataType), [2] num_samples, [3] 1 = dense rows */
 DALIAMD_PIPE_API int daliamdPipelineOutputInfo(void *pipe, int output, int64_t *info4, char *layout, int layout_len);
 DALIAMD_PIPE_API int daliamdPipelineOutputSample(void *pipe, int output, int sample, void **ptr, int64_t *shape8, int *ndim,
