@@ -745,6 +745,30 @@ __device__ __forceinline__ int LastOrdinal(const daliamdJpegHuffDesc &d) {
   return use_rect && last < d.total_blocks ? (int)last : d.total_blocks;
 }
 
+// Region-of-interest decode: the rectangle of MCUs that holds every block some component's rect asks for
+// ({x0, y0, cols, rows} in MCUs; false: no rect, every MCU).  The block kernel's workgroups walk THIS rectangle in raster
+// order - the MCUs outside it are parsed by the position passes (the stream is serial) but get no lane of the value pass.
+__host__ __device__ inline bool RectMcus(const daliamdJpegHuffDesc &d, int out[4]) {
+  int x0 = 1 << 30, y0 = 1 << 30, x1 = 0, y1 = 0, any = 0;
+  for (int k = 0; k < d.blocks_per_mcu; k++) {
+    const int comp = d.comp_of_block[k];
+    const int32_t *r = d.rect[comp];
+    if (!(r[2] > r[0] && r[3] > r[1])) continue;
+    any = 1;
+    const int hs = d.h_samp[comp], vs = d.v_samp[comp];
+    x0 = r[0] / hs < x0 ? r[0] / hs : x0;
+    y0 = r[1] / vs < y0 ? r[1] / vs : y0;
+    x1 = (r[2] + hs - 1) / hs > x1 ? (r[2] + hs - 1) / hs : x1;
+    y1 = (r[3] + vs - 1) / vs > y1 ? (r[3] + vs - 1) / vs : y1;
+  }
+  if (!any) return false;
+  const int mcus_y = d.total_blocks / d.blocks_per_mcu / d.mcus_x;
+  x1 = x1 < d.mcus_x ? x1 : d.mcus_x;
+  y1 = y1 < mcus_y ? y1 : mcus_y;
+  out[0] = x0; out[1] = y0; out[2] = x1 > x0 ? x1 - x0 : 0; out[3] = y1 > y0 ? y1 - y0 : 0;
+  return true;
+}
+
 // The DC or the AC half of HuffTables in LDS, indexed by table selector (LongCode / DecodeDc / DecodeBlockAc address
 // the members by name).
 struct HalfTables {
@@ -938,6 +962,7 @@ struct BlockGeom {
   GlobalCoef *base[12];
   GlobalBytes *plane[12];
   // fused colour output (BlockKernel<true>)
+  int32_t roi_x0, roi_y0, roi_cols, roi_mcus;  // region-of-interest decode: the MCU rectangle the workgroups walk (RectMcus)
   int32_t band_rows, band_c0, band_c1, bands;  // MCU rows per band; chroma rows [c0, c1) of this workgroup's band
   int32_t width, height, dw, dh, rgb_pitch;
   GlobalBytes *rgb, *seams;
@@ -1021,6 +1046,9 @@ __global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHu
       use_rect |= d.rect[comp][2] > d.rect[comp][0] && d.rect[comp][3] > d.rect[comp][1];
     }
     G.use_rect = use_rect;
+    int rm[4] = {0, 0, 0, 0};
+    const bool roi = !kColor && RectMcus(d, rm);
+    G.roi_x0 = rm[0]; G.roi_y0 = rm[1]; G.roi_cols = roi ? rm[2] : 0; G.roi_mcus = rm[2] * rm[3];
     G.total_starts = ((const GlobalI32 *)d.scratch)[2];
     G.fused = kColor || d.plane[d.comp_of_block[0]] != nullptr;
     G.interval_blocks = d.restart_interval * d.blocks_per_mcu;
@@ -1060,8 +1088,9 @@ __global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHu
   const int crgb_pitch = kColor ? (int)HUFF_UNIFORM(G.rgb_pitch) : 0;
   GlobalBytes *rgb = kColor ? (GlobalBytes *)d.rgb : nullptr;
   GlobalBytes *seams = kColor ? (GlobalBytes *)(d.scratch + lay.seams) : nullptr;
-  if ((long long)m0 * bpm >= G.last_ordinal) return;  // behind the last needed MCU row (uniform)
-  const int M = min(mpw, G.total_mcus - m0);
+  const int roi_cols = (int)HUFF_UNIFORM(G.roi_cols);   // > 0: m0 / M count MCUs of the region's rectangle, not of the frame
+  if (roi_cols ? m0 >= G.roi_mcus : (long long)m0 * bpm >= G.last_ordinal) return;  // nothing needed here (uniform)
+  const int M = min(mpw, (roi_cols ? G.roi_mcus : G.total_mcus) - m0);
   const int n0 = G.n0, n1 = bpm - n0;
   const int tasks0 = (M * n0 + 63) >> 6, tasks1 = (M * n1 + 63) >> 6;
   GlobalWords *words = (GlobalWords *)(d.scratch + lay.clean);
@@ -1111,8 +1140,16 @@ __global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHu
       mi = (brow >> ls) * cmx + (bcol >> ls);
       k = ls ? ((brow & 1) << 1) | (bcol & 1) : 0;
     }
-    const int mcu = m0 + mi, ordinal = mcu * bpm + k;
-    const int my = mcu / G.mcus_x, mx = mcu - my * G.mcus_x;
+    int my, mx;
+    if (roi_cols) {   // the (m0 + mi)-th MCU of the region's rectangle
+      const int ry = (m0 + mi) / roi_cols;
+      my = G.roi_y0 + ry;
+      mx = G.roi_x0 + (m0 + mi) - ry * roi_cols;
+    } else {
+      my = (m0 + mi) / G.mcus_x;
+      mx = (m0 + mi) - my * G.mcus_x;
+    }
+    const int mcu = my * G.mcus_x + mx, ordinal = mcu * bpm + k;
     const int bx = mx * G.hs[k] + G.ho[k], by = my * G.vs[k] + G.vo[k];
     bool needed = mi < M && ordinal < G.last_ordinal && ordinal + 1 < G.total_starts;
     if (G.use_rect) needed = needed && bx >= G.rect[k][0] && by >= G.rect[k][1] && bx < G.rect[k][2] && by < G.rect[k][3];
@@ -1498,7 +1535,8 @@ daliamdResult_t daliamdJpegHuffmanSetupColor(daliamdJpegHuffDesc *descs_host, in
     d.blk_wg_start = bwgs;
     tiles += d.num_tiles;
     segs += d.num_segments;
-    const int mcus = d.total_blocks / d.blocks_per_mcu;
+    int mcus = d.total_blocks / d.blocks_per_mcu, rm[4];
+    if (!color && daliamd::RectMcus(d, rm)) mcus = rm[2] * rm[3] > 0 ? rm[2] * rm[3] : 1;   // region of interest: its MCU rectangle
     const int mpw = color ? daliamd::ColorBandRows(d.mcus_x) * d.mcus_x : daliamd::McusPerWg(d.blocks_per_mcu);
     bwgs += (mcus + mpw - 1) / mpw;
   }
