@@ -291,13 +291,15 @@ class TFRecordReaderOp : public OperatorBase {
         out.source_info[i] = make_string(files_.paths[r.file], " at index ", r.offset);
         const Parsed &p = parsed_[(size_t)i * nf + f];
         if (!p.present) continue;
-        if (fs.type == DALI_UINT8) memcpy(out.raw(i), p.value.bytes[0].p, (size_t)out.nbytes(i));
-        else if (fs.type == DALI_INT64) {
+        // (an empty feature has no storage: memcpy must not see its null pointer, even with a length of zero)
+        if (fs.type == DALI_UINT8) {
+          if (out.nbytes(i)) memcpy(out.raw(i), p.value.bytes[0].p, (size_t)out.nbytes(i));
+        } else if (fs.type == DALI_INT64) {
           memset(out.raw(i), 0, (size_t)out.nbytes(i));
-          memcpy(out.raw(i), p.value.ints.data(), p.value.ints.size() * sizeof(int64_t));
+          if (!p.value.ints.empty()) memcpy(out.raw(i), p.value.ints.data(), p.value.ints.size() * sizeof(int64_t));
         } else {
           memset(out.raw(i), 0, (size_t)out.nbytes(i));
-          memcpy(out.raw(i), p.value.floats.data(), p.value.floats.size() * sizeof(float));
+          if (!p.value.floats.empty()) memcpy(out.raw(i), p.value.floats.data(), p.value.floats.size() * sizeof(float));
         }
       }
     }
