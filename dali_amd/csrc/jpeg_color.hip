@@ -278,7 +278,66 @@ __host__ __device__ inline bool NeedsConvert(const daliamdJpegColorDesc &d) {
   return d.out_format != DALIAMD_JPEG_OUT_RGB && !(d.out_format == DALIAMD_JPEG_OUT_GRAY && d.color != DALIAMD_JPEG_RGB);
 }
 
-template <bool kConvert>
+// ---- full-resolution components (YCbCr 4:4:4, grayscale) to RGB, upright, 8-pixel groups aligned to the planes: nothing
+// is interpolated, so the thread's ROWS x (1 or 3) 8-byte loads go out together and the rows follow (the row-by-row code
+// below walks its mode tests and one memory round trip per row: the 15 % of a mixed batch that took it cost as much as
+// the 85 % on the 4:2:0 fast path).
+template <int ROWS>
+__device__ __forceinline__ void ColorRowsFull(const daliamdJpegColorDesc &d, int x0, int y0, int rx1, int ry1, int out_x0,
+                                              int out_y0) {
+  const bool gray = d.color == DALIAMD_JPEG_GRAY;
+  u32x2 v[3][ROWS];
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    if (c > 0 && gray) break;
+    GBytes *plane = (GBytes *)d.plane[c];
+    const int pitch = d.pitch[c];
+#pragma unroll
+    for (int j = 0; j < ROWS; j++) v[c][j] = *reinterpret_cast<GPair *>(plane + (size_t)min(y0 + j, ry1 - 1) * pitch + x0);
+  }
+  const int npx = min(8, rx1 - x0);
+#pragma unroll
+  for (int j = 0; j < ROWS; j++) {
+    const int y = y0 + j;
+    if (y >= ry1) break;
+    int yy[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) yy[i] = (int)(((i < 4 ? v[0][j].x : v[0][j].y) >> (8 * (i & 3))) & 255);
+    uint32_t px[24];
+    if (gray) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) px[3 * i] = px[3 * i + 1] = px[3 * i + 2] = (uint32_t)yy[i];
+    } else {
+      int up[2][8];
+#pragma unroll
+      for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) up[c][i] = (int)(((i < 4 ? v[1 + c][j].x : v[1 + c][j].y) >> (8 * (i & 3))) & 255);
+      YccToRgb8(yy, up, px);
+    }
+    StoreRgb8((GOutBytes *)d.out + (size_t)(y - out_y0) * d.out_pitch + (size_t)(x0 - out_x0) * 3, px, npx);
+  }
+}
+__host__ __device__ inline bool FastFull(const daliamdJpegColorDesc &d) {
+  if (d.out_format != DALIAMD_JPEG_OUT_RGB || d.orientation > 1 || d.color == DALIAMD_JPEG_RGB) return false;
+  const int nc = d.color == DALIAMD_JPEG_GRAY ? 1 : 3;
+  for (int c = 0; c < nc; c++)
+    if (d.h_samp[c] != d.h_samp[0] || d.v_samp[c] != d.v_samp[0] || (d.pitch[c] & 7) != 0 ||
+        (reinterpret_cast<uintptr_t>(d.plane[c]) & 7) != 0)
+      return false;
+  return (d.out_pitch & 7) == 0 && (reinterpret_cast<uintptr_t>(d.out) & 7) == 0 && (d.roi_w <= 0 || (d.roi_x0 & 7) == 0);
+}
+
+// does the 4:2:0 fast path's window start where its 8 x 2 pixel groups are aligned to the planes?
+__host__ __device__ inline bool AlignedOrigin(const daliamdJpegColorDesc &d) {
+  return d.roi_w <= 0 || ((d.roi_x0 & 7) | (d.roi_y0 & 1)) == 0;
+}
+
+// kPath: 0 = the common instance - the 4:2:0 fast path (ColorRows420) for planes-aligned windows and the row-by-row code
+// for every other sampling; 2 = the fast path for windows that start anywhere (ColorRows420Any; region-of-interest
+// decode).  An instance of its own for the aligned fast path as well (99 registers instead of 159) was measured: a mixed
+// batch then needs two launches and loses 2.5 % (438 000 against 450 000 images/s), so the two stay together.
+template <bool kConvert, int kPath = 0>
 __global__ __launch_bounds__(kColorThreads) void JpegColorKernel(const daliamdJpegColorDesc *__restrict__ descs,
                                                                  int ndesc, int total_wg) {
   int wg = XcdRemap(blockIdx.x, total_wg);
@@ -286,6 +345,7 @@ __global__ __launch_bounds__(kColorThreads) void JpegColorKernel(const daliamdJp
   int di = FindDesc(descs, ndesc, wg);
   const daliamdJpegColorDesc &d = descs[di];
   if (NeedsConvert(d) != kConvert) return;
+  if (!kConvert && (Fast420(d) && !AlignedOrigin(d) ? 2 : 0) != kPath) return;
   // region of the (un-rotated) image to produce; the 8-pixel groups are aligned to its origin so that the output
   // rows keep their 8-byte store alignment
   const bool roi = d.roi_w > 0;
@@ -313,9 +373,14 @@ __global__ __launch_bounds__(kColorThreads) void JpegColorKernel(const daliamdJp
   const int out_x0 = roi ? d.out_x0 : 0, out_y0 = roi ? d.out_y0 : 0;
   const bool wide_ok = ((d.out_pitch & 7) == 0) && ((reinterpret_cast<uintptr_t>(d.out) & 7) == 0);
   const bool wide_stores = npx == 8 && wide_ok && oc == 3;
-  if (!kConvert && Fast420(d)) {  // wave-uniform: the whole image takes the fast path or none of it does
-    if (((rx0 & 7) | (ry0 & 1)) == 0) ColorRows420<kRowsPerThread>(d, x0, y_first, rx1, ry1, out_x0, out_y0);
-    else ColorRows420Any<kRowsPerThread>(d, x0, y_first, rx1, ry1, out_x0, out_y0);
+  if constexpr (kPath == 2) {
+    ColorRows420Any<kRowsPerThread>(d, x0, y_first, rx1, ry1, out_x0, out_y0);
+    return;
+  } else if (!kConvert && Fast420(d)) {  // wave-uniform: the whole image takes the fast path or none of it does
+    ColorRows420<kRowsPerThread>(d, x0, y_first, rx1, ry1, out_x0, out_y0);
+    return;
+  } else if (!kConvert && FastFull(d)) {
+    ColorRowsFull<kRowsPerThread>(d, x0, y_first, rx1, ry1, out_x0, out_y0);
     return;
   }
 
@@ -443,7 +508,8 @@ daliamdResult_t daliamdJpegColorSetup(daliamdJpegColorDesc *descs, int n, int *n
   *num_workgroups = wg;
   if (kernel_mask) {
     int mask = 0;
-    for (int i = 0; i < n; i++) mask |= daliamd::Fast420(descs[i]) ? 1 : daliamd::NeedsConvert(descs[i]) ? 4 : 2;
+    for (int i = 0; i < n; i++)
+      mask |= daliamd::NeedsConvert(descs[i]) ? 4 : !daliamd::Fast420(descs[i]) ? 2 : daliamd::AlignedOrigin(descs[i]) ? 1 : 8;
     *kernel_mask = mask;
   }
   return DALIAMD_SUCCESS;
@@ -507,7 +573,13 @@ daliamdResult_t daliamdJpegColorRun(daliamdStream_t stream, const daliamdJpegCol
   if (kernel_mask & 3)
     {
       daliamd::KernelTimer timer("JpegColorKernel", (hipStream_t)stream);
-      hipLaunchKernelGGL(daliamd::JpegColorKernel<false>, dim3(daliamd::XcdGrid(num_workgroups)),
+      hipLaunchKernelGGL((daliamd::JpegColorKernel<false, 0>), dim3(daliamd::XcdGrid(num_workgroups)),
+                         dim3(daliamd::kColorThreads), 0, (hipStream_t)stream, descs_dev, n, num_workgroups);
+    }
+  if (kernel_mask & 8)
+    {
+      daliamd::KernelTimer timer("JpegColorKernel", (hipStream_t)stream);
+      hipLaunchKernelGGL((daliamd::JpegColorKernel<false, 2>), dim3(daliamd::XcdGrid(num_workgroups)),
                          dim3(daliamd::kColorThreads), 0, (hipStream_t)stream, descs_dev, n, num_workgroups);
     }
   if (kernel_mask & 4)

@@ -661,8 +661,9 @@ __global__ __launch_bounds__(kSegThreads) void SyncKernel(const daliamdJpegHuffD
   }
 }
 
+// (The code tables of the rare repair stay in global memory: a 50 KB workgroup - the tables are 36 KB of it - waits for a
+// CU with that much LDS free, which inside the five-batch schedule made this 10 us kernel last 50 us.)
 __global__ __launch_bounds__(kSegThreads) void PropagateKernel(const daliamdJpegHuffDesc *__restrict__ descs) {
-  __shared__ __attribute__((aligned(16))) SyncTables L;
   __shared__ uint64_t state[kSegThreads];
   __shared__ uint16_t lists[kSegThreads * kListStride];
   __shared__ int wave_sums[kSegThreads / 64];
@@ -676,7 +677,7 @@ __global__ __launch_bounds__(kSegThreads) void PropagateKernel(const daliamdJpeg
   GlobalWords *words = (GlobalWords *)(d.scratch + lay.clean);
   uint64_t truth = Pack(DecodeState{0, 0, 0});
   int block_base = 0;
-  bool tables_loaded = false;
+  const SyncTables &L = *reinterpret_cast<const SyncTables *>(TablesBase(descs, d, true));
   for (int seg = 0; seg < d.num_segments; seg++) {
     if (seg > 0 && (long long)seg * kSegBytes >= clean_len) {
       if (tid == 0) {
@@ -688,10 +689,6 @@ __global__ __launch_bounds__(kSegThreads) void PropagateKernel(const daliamdJpeg
     LaneRec *recs = all_recs + (size_t)seg * kSegLanes;
     if (total_bits != 0 && recs[0].in != truth) {
       // The warm-up lanes did not synchronise before this segment (long flat or periodic content): repair it.
-      if (!tables_loaded) {
-        CopyTables<kSegThreads>(L, reinterpret_cast<const SyncTables *>(TablesBase(descs, d, true)));
-        tables_loaded = true;
-      }
       // every lane decodes again (its start list lives in LDS only while the kernel that decoded it runs)
       const bool mine = tid < kSegLanes;
       Lane ln = MakeLane(mine ? (long long)seg * kSegLanes + tid : -1, total_bits);
