@@ -56,6 +56,13 @@ def effective_cpu_count():
     return n
 
 
+# Pipeline(set_affinity=True) - the reference's argument (pipeline.py: "set_affinity: set CPU affinity mask to the closest
+# one to the GPU"): the executor's threads and the first touch of their page-locked buffers stay on the GPU's NUMA node.
+# On the two-socket bench host: 20-step `value` 430 000 against 416 000, end to end from files 355-387 000 against
+# 319-364 000 (gpurun_out/r04o, r04p).  BENCH_AFFINITY=0 switches it off.
+AFFINITY = os.environ.get("BENCH_AFFINITY", "1") == "1"
+
+
 def measured_traffic(kernel, workload=""):
     """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*_traffic.json, produced by
     tools/collect_profiles.sh: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH_SIZE correction).  bench.py
@@ -315,6 +322,7 @@ def e2e_pipeline(root, batch, device_id, iters=400, threads=None, roi_decode=Fal
     # usable cores each keeps their sum near the CPU quota instead of far above it (16 -> 12: +25 % on the bench box)
     threads = threads or max(2, effective_cpu_count() * 3 // 4)
     # four sequential stages (file reads | parse + staging | H2D | kernels) need several batches in flight to overlap
+    set_affinity = set_affinity or AFFINITY
     pipe = Pipeline(batch_size=batch, num_threads=threads, device_id=device_id, seed=1234, prefetch_queue_depth=depth,
                     set_affinity=set_affinity)
     with pipe:
@@ -397,7 +405,8 @@ def resident_pipeline(root, batch, device_id, depth, threads, shard_id=0, num_sh
     seeded = lambda seed: {} if seed is None else {"seed": seed}  # noqa: E731
     from dali_amd import fn, types
     from dali_amd.pipeline import Pipeline
-    pipe = Pipeline(batch_size=batch, num_threads=threads, device_id=device_id, seed=1234, prefetch_queue_depth=depth)
+    pipe = Pipeline(batch_size=batch, num_threads=threads, device_id=device_id, seed=1234, prefetch_queue_depth=depth,
+                    set_affinity=AFFINITY)
     with pipe:
         jpegs, labels = fn.readers.file(file_root=root, name="Reader", shard_id=shard_id, num_shards=num_shards,
                                         stick_to_shard=True, skip_cached_images=True)
@@ -599,7 +608,7 @@ def bench_heavy_aug(args, device, steps=None, cpu_seconds=8.0):
     depth = max(1, min(args.inflight, 4))
     try:
         pipe = Pipeline(batch_size=n, num_threads=max(2, effective_cpu_count() * 3 // 4), device_id=device.index or 0, seed=1234,
-                        prefetch_queue_depth=depth)
+                        prefetch_queue_depth=depth, set_affinity=AFFINITY)
         with pipe:
             enc, _ = fn.readers.file(file_root=root, skip_cached_images=True)
             x = fn.decoders.image(enc, device="mixed", cache_size=256, cache_type="threshold")
@@ -713,7 +722,7 @@ def bench_audio(args, device, steps=None, cpu_seconds=8.0):
     threads = max(2, effective_cpu_count() * 3 // 4)
     try:
         pipe = Pipeline(batch_size=n, num_threads=threads, device_id=device.index or 0, prefetch_queue_depth=depth,
-                        exec_async=True, seed=1234)
+                        exec_async=True, seed=1234, set_affinity=AFFINITY)
         with pipe:
             enc, _ = fn.readers.file(file_root=root, file_filters=["*.wav"], prefetch_queue_depth=2)
             audio, _rate = fn.decoders.audio(enc, downmix=True)
