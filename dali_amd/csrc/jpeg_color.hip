@@ -333,10 +333,17 @@ __host__ __device__ inline bool AlignedOrigin(const daliamdJpegColorDesc &d) {
   return d.roi_w <= 0 || ((d.roi_x0 & 7) | (d.roi_y0 & 1)) == 0;
 }
 
-// kPath: 0 = the common instance - the 4:2:0 fast path (ColorRows420) for planes-aligned windows and the row-by-row code
-// for every other sampling; 2 = the fast path for windows that start anywhere (ColorRows420Any; region-of-interest
-// decode).  An instance of its own for the aligned fast path as well (99 registers instead of 159) was measured: a mixed
-// batch then needs two launches and loses 2.5 % (438 000 against 450 000 images/s), so the two stay together.
+// which instance of the non-converting kernel takes the sample (see kPath)
+__host__ __device__ inline int ColorPath(const daliamdJpegColorDesc &d) {
+  if (Fast420(d)) return AlignedOrigin(d) ? 1 : 2;
+  return FastFull(d) ? 1 : 0;
+}
+
+// kPath: 1 = the fast paths for planes-aligned windows - 4:2:0 (ColorRows420) and full-resolution components
+// (ColorRowsFull) - in one instance: what a batch of camera / ImageNet JPEGs takes, in ONE launch, at 100 registers;
+// 0 = every other sampling / orientation, row by row (159 registers); 2 = the 4:2:0 fast path for windows that start
+// anywhere (ColorRows420Any; region-of-interest decode).  (Before the full-resolution path existed the 4:4:4 / gray samples of
+// a mixed batch needed the row-by-row instance: two launches per batch, 2.5 % slower than everything in one kernel.)
 template <bool kConvert, int kPath = 0>
 __global__ __launch_bounds__(kColorThreads) void JpegColorKernel(const daliamdJpegColorDesc *__restrict__ descs,
                                                                  int ndesc, int total_wg) {
@@ -345,7 +352,7 @@ __global__ __launch_bounds__(kColorThreads) void JpegColorKernel(const daliamdJp
   int di = FindDesc(descs, ndesc, wg);
   const daliamdJpegColorDesc &d = descs[di];
   if (NeedsConvert(d) != kConvert) return;
-  if (!kConvert && (Fast420(d) && !AlignedOrigin(d) ? 2 : 0) != kPath) return;
+  if (!kConvert && ColorPath(d) != kPath) return;
   // region of the (un-rotated) image to produce; the 8-pixel groups are aligned to its origin so that the output
   // rows keep their 8-byte store alignment
   const bool roi = d.roi_w > 0;
@@ -376,11 +383,9 @@ __global__ __launch_bounds__(kColorThreads) void JpegColorKernel(const daliamdJp
   if constexpr (kPath == 2) {
     ColorRows420Any<kRowsPerThread>(d, x0, y_first, rx1, ry1, out_x0, out_y0);
     return;
-  } else if (!kConvert && Fast420(d)) {  // wave-uniform: the whole image takes the fast path or none of it does
-    ColorRows420<kRowsPerThread>(d, x0, y_first, rx1, ry1, out_x0, out_y0);
-    return;
-  } else if (!kConvert && FastFull(d)) {
-    ColorRowsFull<kRowsPerThread>(d, x0, y_first, rx1, ry1, out_x0, out_y0);
+  } else if constexpr (kPath == 1) {  // wave-uniform: the whole image takes one path
+    if (Fast420(d)) ColorRows420<kRowsPerThread>(d, x0, y_first, rx1, ry1, out_x0, out_y0);
+    else ColorRowsFull<kRowsPerThread>(d, x0, y_first, rx1, ry1, out_x0, out_y0);
     return;
   }
 
@@ -509,7 +514,7 @@ daliamdResult_t daliamdJpegColorSetup(daliamdJpegColorDesc *descs, int n, int *n
   if (kernel_mask) {
     int mask = 0;
     for (int i = 0; i < n; i++)
-      mask |= daliamd::NeedsConvert(descs[i]) ? 4 : !daliamd::Fast420(descs[i]) ? 2 : daliamd::AlignedOrigin(descs[i]) ? 1 : 8;
+      mask |= daliamd::NeedsConvert(descs[i]) ? 4 : daliamd::ColorPath(descs[i]) == 1 ? 1 : daliamd::ColorPath(descs[i]) == 2 ? 8 : 2;
     *kernel_mask = mask;
   }
   return DALIAMD_SUCCESS;
@@ -570,7 +575,13 @@ daliamdResult_t daliamdJpegColorRun(daliamdStream_t stream, const daliamdJpegCol
   if (n == 0 || num_workgroups == 0) return DALIAMD_SUCCESS;
   DALIAMD_REQUIRE(descs_dev && n > 0 && num_workgroups > 0, DALIAMD_ERROR_INVALID_ARGUMENT,
                   "daliamdJpegColorRun: invalid argument");
-  if (kernel_mask & 3)
+  if (kernel_mask & 1)
+    {
+      daliamd::KernelTimer timer("JpegColorKernel", (hipStream_t)stream);
+      hipLaunchKernelGGL((daliamd::JpegColorKernel<false, 1>), dim3(daliamd::XcdGrid(num_workgroups)),
+                         dim3(daliamd::kColorThreads), 0, (hipStream_t)stream, descs_dev, n, num_workgroups);
+    }
+  if (kernel_mask & 2)
     {
       daliamd::KernelTimer timer("JpegColorKernel", (hipStream_t)stream);
       hipLaunchKernelGGL((daliamd::JpegColorKernel<false, 0>), dim3(daliamd::XcdGrid(num_workgroups)),

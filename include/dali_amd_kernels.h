@@ -281,8 +281,8 @@ typedef struct {
   int32_t roi_x0, roi_y0, roi_w, roi_h, out_x0, out_y0;
 } daliamdJpegColorDesc;
 
-/* kernel_mask (out): which colour kernels have samples in this table - bits 0 / 1: the RGB kernel (YCbCr 4:2:0 fast
- * path / general), bit 2: the kernel with a BGR / YCbCr / gray conversion behind it (100 registers more, kept out of
+/* kernel_mask (out): which colour kernels have samples in this table - bits 0 / 1: the RGB kernel (fast paths: YCbCr
+ * 4:2:0, 4:4:4, grayscale in planes-aligned windows / every other sampling and orientation), bit 2: the kernel with a BGR / YCbCr / gray conversion behind it (100 registers more, kept out of
  * the common kernel), bit 3: the 4:2:0 fast path for windows that start anywhere (region-of-interest decode); hand it to
  * Run, which launches only those (all walk the same grid, a workgroup of another kernel's sample leaves at once). */
 DALIAMD_API daliamdResult_t daliamdJpegColorSetup(daliamdJpegColorDesc *descs_host, int n, int *num_workgroups,
