@@ -534,7 +534,9 @@ __device__ __forceinline__ void BlurWriteOut(const daliamdGaussianBlurDesc &d, c
   }
 }
 
-template <bool FMA>
+// PW: a pointwise operator is fused behind the blur (its own instance: the private copy of its descriptor lives in scratch
+// memory and its write-out in registers the plain blur should not pay for)
+template <bool FMA, bool PW>
 __global__ __launch_bounds__(kBlurThreads) void GaussianBlurKernel(const daliamdGaussianBlurDesc *__restrict__ descs,
                                                                    int ndesc, int total_wg,
                                                                    const daliamdPointwiseDesc *__restrict__ pointwise) {
@@ -585,15 +587,15 @@ __global__ __launch_bounds__(kBlurThreads) void GaussianBlurKernel(const daliamd
     default: BlurWPass<4, FMA>(d, src, tmp, src_pitch, tstride, in_rows, tw, ox0, oy0, rx, ry, interior_x); break;
   }
   __syncthreads();
-  if (!pointwise) {
+  if constexpr (!PW) {
     BlurHPass<false, FMA>(d, tmp, tstride, row_elems, th, nullptr, 0, ox0, oy0);
-    return;
+  } else {
+    const int opitch = (TW * C + 3) & ~3;   // <= src_pitch, and the staged source has at least th rows
+    BlurHPass<true, FMA>(d, tmp, tstride, row_elems, th, src, opitch, ox0, oy0);
+    __syncthreads();
+    const daliamdPointwiseDesc pw = pointwise[di];   // (a private copy: the stores below cannot alias it)
+    BlurWriteOut(d, &pw, src, opitch, tw, th, ox0, oy0);
   }
-  const int opitch = (TW * C + 3) & ~3;   // <= src_pitch, and the staged source has at least th rows
-  BlurHPass<true, FMA>(d, tmp, tstride, row_elems, th, src, opitch, ox0, oy0);
-  __syncthreads();
-  const daliamdPointwiseDesc pw = pointwise[di];   // (a private copy: the stores below cannot alias it)
-  BlurWriteOut(d, &pw, src, opitch, tw, th, ox0, oy0);
 }
 
 // =============================================================================================
@@ -829,12 +831,10 @@ daliamdResult_t daliamdGaussianBlurPointwiseRun(daliamdStream_t stream, const da
   static const bool fma = getenv("DALI_AMD_BLUR_FMA") && atoi(getenv("DALI_AMD_BLUR_FMA")) != 0;
   {
     daliamd::KernelTimer timer("GaussianBlurKernel", (hipStream_t)stream);
-    if (fma)
-      hipLaunchKernelGGL(GaussianBlurKernel<true>, dim3(XcdGrid(nwg)), dim3(kBlurThreads), lds_bytes, (hipStream_t)stream,
-                         descs_dev, n, nwg, pointwise_dev);
-    else
-      hipLaunchKernelGGL(GaussianBlurKernel<false>, dim3(XcdGrid(nwg)), dim3(kBlurThreads), lds_bytes, (hipStream_t)stream,
-                         descs_dev, n, nwg, pointwise_dev);
+    auto kern = fma ? (pointwise_dev ? GaussianBlurKernel<true, true> : GaussianBlurKernel<true, false>)
+                    : (pointwise_dev ? GaussianBlurKernel<false, true> : GaussianBlurKernel<false, false>);
+    hipLaunchKernelGGL(kern, dim3(XcdGrid(nwg)), dim3(kBlurThreads), lds_bytes, (hipStream_t)stream, descs_dev, n, nwg,
+                       pointwise_dev);
   }
   DALIAMD_HIP_CHECK(hipGetLastError());
   return DALIAMD_SUCCESS;
