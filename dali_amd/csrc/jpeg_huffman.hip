@@ -570,28 +570,82 @@ __device__ __forceinline__ RstView MakeRstView(const daliamdJpegHuffDesc &d, con
   return v;
 }
 
-__device__ __forceinline__ void Relax(const SyncTables &L, GlobalWords *words, uint64_t *state, Lane &ln, uint16_t *list,
-                                      const RstView &rst) {
-  const int tid = threadIdx.x;
+// Round 4: the lanes that have to decode in a round are PACKED into the first waves (a work list in LDS).  Rounds 1 and 2
+// keep nearly every lane busy; from round 3 on a handful of slices re-decode, and with lane = slice each of them kept its
+// whole wave issuing for the length of a slice.  Host model on the bench's first batch (tools/sync_sim.cpp): 1 089 136
+// wave-steps become 863 814 (0.79) - the critical path is the same, the instructions are not.  The lane states live
+// in LDS, indexed by slice; `ln` receives this thread's own slice at the end.
+#ifndef DALIAMD_SYNC_COMPACT
+#define DALIAMD_SYNC_COMPACT 1
+#endif
+struct RelaxShared {
+  uint64_t state[kSegThreads + 1];   // state[t]: the published input of lane t; state[t + 1] = what lane t reached
+  uint64_t last_in[kSegThreads];     // the input lane t last decoded from (kNoState: never)
+  uint16_t nstart[kSegThreads];      // blocks that start in slice t, by its latest decode
+  uint8_t work[kSegThreads];         // this round's work list: slices whose input changed
+  uint8_t crossed[kSegThreads];
+  int wave_count[kSegThreads / 64];
+};
+static_assert(kSegThreads <= 256, "the work list holds 8-bit lane numbers");
+
+// slice_of(t): index of lane t's slice in the stream (negative: the lane has none)
+template <typename SliceOf>
+__device__ __forceinline__ void Relax(const SyncTables &L, GlobalWords *words, RelaxShared &R, uint16_t *lists, Lane &ln,
+                                      uint32_t total_bits, const daliamdJpegHuffDesc &d, const ScratchLayout &lay,
+                                      SliceOf slice_of) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  ln = MakeLane(slice_of(tid), total_bits);
+  R.last_in[tid] = kNoState;
+  R.nstart[tid] = 0;
+  R.crossed[tid] = 0;
+  __syncthreads();   // (also: the caller's R.state is complete)
   for (int round = 0; round <= kSegThreads; round++) {
-    const uint64_t ni = state[tid];
-    if (ln.active && ni != ln.in) {
-      ln.in = ni;
-      DecodeState st = Unpack(ni);
-      ln.nstart = 0;
-      if (st.pos < ln.end)
-        ln.nstart = SyncDecodeRange(L, words, st, ln.end, rst, [&](int nb, int rem, bool) { list[nb < kListCap ? nb : kListCap] = (uint16_t)rem; },
-                                    &ln.crossed);
-      ln.out = Pack(st);
-    }
+    const bool want = ln.active && R.state[tid] != R.last_in[tid];
+#if DALIAMD_SYNC_COMPACT
+    const unsigned long long m = __ballot(want);
+    if (lane == 0) R.wave_count[wave] = __popcll(m);
     __syncthreads();
-    int changed = 0;
-    if (ln.active && tid + 1 < kSegThreads && state[tid + 1] != ln.out) {
-      state[tid + 1] = ln.out;
-      changed = 1;
+    int base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kSegThreads / 64; w++) {
+      const int c = R.wave_count[w];
+      base += w < wave ? c : 0;
+      total += c;
     }
-    if (!__syncthreads_or(changed)) break;
+    if (want) R.work[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)tid;
+    __syncthreads();
+    if (total == 0) break;
+    const int s = tid < total ? (int)R.work[tid] : -1;
+#else
+    if (!__syncthreads_or(want)) break;
+    const int s = want ? tid : -1;
+#endif
+    uint64_t out = 0;
+    if (s >= 0) {
+      const Lane w = MakeLane(slice_of(s), total_bits);
+      const uint64_t ni = R.state[s];
+      R.last_in[s] = ni;
+      DecodeState st = Unpack(ni);
+      int n = 0;
+      bool crossed = false;
+      if (st.pos < w.end) {
+        const RstView rst = MakeRstView(d, lay, w.begin);
+        uint16_t *list = lists + s * kListStride;
+        n = SyncDecodeRange(L, words, st, w.end, rst, [&](int nb, int rem, bool) { list[nb < kListCap ? nb : kListCap] = (uint16_t)rem; },
+                            &crossed);
+      }
+      R.nstart[s] = (uint16_t)n;
+      R.crossed[s] = crossed ? 1 : 0;
+      out = Pack(st);
+    }
+    __syncthreads();   // every decode of the round has read its input
+    if (s >= 0) R.state[s + 1] = out;
+    __syncthreads();
   }
+  ln.in = R.last_in[tid];
+  ln.out = ln.in != kNoState ? R.state[tid + 1] : kNoState;
+  ln.nstart = R.nstart[tid];
+  ln.crossed = R.crossed[tid] != 0;
 }
 
 // After the relaxation: the segment's block starts, densely, as absolute bit positions (the lists of its lanes one
@@ -619,7 +673,7 @@ __device__ __forceinline__ int WriteSegmentStarts(const SyncTables &L, GlobalWor
 
 __global__ __launch_bounds__(kSegThreads) void SyncKernel(const daliamdJpegHuffDesc *__restrict__ descs, int n, int nseg) {
   __shared__ __attribute__((aligned(16))) SyncTables L;
-  __shared__ uint64_t state[kSegThreads];
+  __shared__ RelaxShared R;
   __shared__ uint16_t lists[kSegThreads * kListStride];
   __shared__ int wave_sums[kSegThreads / 64];
   const int wg = XcdRemap(blockIdx.x, nseg);
@@ -639,13 +693,13 @@ __global__ __launch_bounds__(kSegThreads) void SyncKernel(const daliamdJpegHuffD
   CopyTables<kSegThreads>(L, reinterpret_cast<const SyncTables *>(TablesBase(descs, d, true)));
   const uint32_t total_bits = (uint32_t)clean_len * 8u;
   // lanes [0, kWarmLanes) replay the last slices of the previous segment, lanes [kWarmLanes, ..) are this segment's
-  Lane ln = MakeLane((long long)seg * kSegLanes + tid - kWarmLanes, total_bits);
-  state[tid] = Pack(DecodeState{ln.begin, 0, 0});  // the guess; exact for the very first slice of the image
-  __syncthreads();
+  auto slice_of = [&](int t) { return (long long)seg * kSegLanes + t - kWarmLanes; };
+  Lane ln = MakeLane(slice_of(tid), total_bits);
+  R.state[tid] = Pack(DecodeState{ln.begin, 0, 0});  // the guess; exact for the very first slice of the image
   GlobalWords *words = (GlobalWords *)(d.scratch + lay.clean);
   uint16_t *list = lists + tid * kListStride;
+  Relax(L, words, R, lists, ln, total_bits, d, lay, slice_of);
   const RstView rst = MakeRstView(d, lay, ln.begin);
-  Relax(L, words, state, ln, list, rst);
   const bool mine = tid >= kWarmLanes;
   const int total = WriteSegmentStarts(L, words, ln, list, mine, (GlobalU32 *)(d.scratch + lay.seg_starts) + (size_t)seg * lay.seg_cap,
                                        lay.seg_cap, wave_sums, rst);
@@ -664,7 +718,7 @@ __global__ __launch_bounds__(kSegThreads) void SyncKernel(const daliamdJpegHuffD
 // (The code tables of the rare repair stay in global memory: a 50 KB workgroup - the tables are 36 KB of it - waits for a
 // CU with that much LDS free, which inside the five-batch schedule made this 10 us kernel last 50 us.)
 __global__ __launch_bounds__(kSegThreads) void PropagateKernel(const daliamdJpegHuffDesc *__restrict__ descs) {
-  __shared__ uint64_t state[kSegThreads];
+  __shared__ RelaxShared R;
   __shared__ uint16_t lists[kSegThreads * kListStride];
   __shared__ int wave_sums[kSegThreads / 64];
   const daliamdJpegHuffDesc &d = descs[blockIdx.x];
@@ -691,12 +745,12 @@ __global__ __launch_bounds__(kSegThreads) void PropagateKernel(const daliamdJpeg
       // The warm-up lanes did not synchronise before this segment (long flat or periodic content): repair it.
       // every lane decodes again (its start list lives in LDS only while the kernel that decoded it runs)
       const bool mine = tid < kSegLanes;
-      Lane ln = MakeLane(mine ? (long long)seg * kSegLanes + tid : -1, total_bits);
-      state[tid] = tid == 0 ? truth : (mine ? recs[tid].in : kNoState);
-      __syncthreads();
+      auto slice_of = [&](int t) { return t < kSegLanes ? (long long)seg * kSegLanes + t : -1ll; };
+      Lane ln;
+      R.state[tid] = tid == 0 ? truth : (mine ? recs[tid].in : kNoState);
       uint16_t *list = lists + tid * kListStride;
+      Relax(L, words, R, lists, ln, total_bits, d, lay, slice_of);
       const RstView rst = MakeRstView(d, lay, ln.begin);
-      Relax(L, words, state, ln, list, rst);
       const int total = WriteSegmentStarts(L, words, ln, list, mine,
                                            (GlobalU32 *)(d.scratch + lay.seg_starts) + (size_t)seg * lay.seg_cap, lay.seg_cap,
                                            wave_sums, rst);

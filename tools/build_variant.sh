@@ -7,6 +7,6 @@ R=$(cd $(dirname $0)/.. && pwd)
 mkdir -p $R/build_variants /tmp/variant_$NAME
 cd $R/dali_amd/csrc
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -I../../include -Wno-unused-function $FLAGS -c $SRC -o /tmp/variant_$NAME/obj.o
-OBJS=$(ls ../build/*.o | grep -v "/$(basename $SRC .hip).o")
+OBJS=$(ls ../build/*.o | grep -v "/host_" | grep -v "/$(basename $SRC .hip).o")
 hipcc --offload-arch=gfx950 -shared -fPIC -o $R/build_variants/libdali_amd_kernels_$NAME.so $OBJS /tmp/variant_$NAME/obj.o
 echo built $NAME

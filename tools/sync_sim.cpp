@@ -171,7 +171,7 @@ int main(int argc, char **argv) {
   closedir(dp);
   std::sort(files.begin(), files.end());
   std::vector<long> wg_path, wg_rounds;
-  long total_steps = 0, total_syms = 0, ideal_syms = 0, busy_wave_steps = 0;
+  long total_steps = 0, total_syms = 0, ideal_syms = 0, busy_wave_steps = 0, compact_wave_steps = 0;
   for (auto &fn : files) {
     Image im;
     if (!Load(fn, im)) { fprintf(stderr, "skip %s\n", fn.c_str()); continue; }
@@ -200,6 +200,7 @@ int main(int argc, char **argv) {
       std::string trace;
       for (int round = 0; round <= T; round++) {
         long wave_max[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        std::vector<long> round_steps;   // of the lanes that decode in this round, in lane order (compaction model)
         bool any = false;
         for (int t = 0; t < T; t++) {
           L &l = ln[t];
@@ -279,12 +280,20 @@ int main(int argc, char **argv) {
               if (st == old_out) g_cls[0]++; else if (st.pos == old_out.pos && st.z == old_out.z) g_cls[1]++; else g_cls[2]++;
             }
             wave_max[t / 64] = std::max<long>(wave_max[t / 64], l.steps);
+            round_steps.push_back(l.steps);
             total_steps += l.steps; total_syms += l.nsym;
             any = true;
           }
         }
         long m = 0;
         for (int w = 0; w < T / 64; w++) { m = std::max(m, wave_max[w]); busy_wave_steps += wave_max[w]; }
+        // the same round with the decoding lanes packed into the first waves (work list): a wave lasts as long as its
+        // longest lane, waves without work issue nothing
+        for (size_t i = 0; i < round_steps.size(); i += 64) {
+          long wm = 0;
+          for (size_t j = i; j < std::min(round_steps.size(), i + 64); j++) wm = std::max(wm, round_steps[j]);
+          compact_wave_steps += wm;
+        }
         path += m;
         if (any) { rounds++; trace += " " + std::to_string(m); }
         bool changed = false;
@@ -310,6 +319,8 @@ int main(int argc, char **argv) {
   printf("rounds: p50 %ld p90 %ld p99 %ld max %ld\n", pct(wg_rounds, .5), pct(wg_rounds, .9), pct(wg_rounds, .99), wg_rounds.back());
   printf("critical path (steps): mean %.0f p50 %ld p90 %ld p99 %ld max %ld   wave-steps total %ld\n", mean_path, pct(wg_path, .5),
          pct(wg_path, .9), pct(wg_path, .99), wg_path.back(), busy_wave_steps);
+  printf("wave-steps with the decoding lanes of a round packed into the first waves: %ld (%.3f of the above)\n", compact_wave_steps,
+         (double)compact_wave_steps / busy_wave_steps);
   std::sort(g_wmax.begin(), g_wmax.end());
   printf("write pass: longest lane (symbols) per workgroup: p50 %ld p90 %ld p99 %ld max %ld\n", pct(g_wmax, .5), pct(g_wmax, .9), pct(g_wmax, .99), g_wmax.back());
   printf("re-decodes in rounds >= 2: same out %ld, same (pos,z) other c %ld, other pos %ld\n", g_cls[0], g_cls[1], g_cls[2]);
