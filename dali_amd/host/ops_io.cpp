@@ -629,7 +629,11 @@ class FileReaderOp : public OperatorBase {
       maps_[idx].store(kNoMapping, std::memory_order_release);
       return nullptr;
     }
-    void *p = mmap(nullptr, (size_t)size, PROT_READ, MAP_SHARED | MAP_POPULATE, fd, 0);
+    // (a file that is no longer as long as the index says must fail with a message, not with a bus error in memcpy:
+    // such a file is read with pread, which notices)
+    struct stat st;
+    void *p = fstat(fd, &st) == 0 && st.st_size == size
+                  ? mmap(nullptr, (size_t)size, PROT_READ, MAP_SHARED | MAP_POPULATE, fd, 0) : MAP_FAILED;
     if (p == MAP_FAILED) {
       mapped_bytes_.fetch_sub((int64_t)size, std::memory_order_relaxed);
       maps_[idx].store(kNoMapping, std::memory_order_release);
