@@ -63,6 +63,23 @@ def effective_cpu_count():
 AFFINITY = os.environ.get("BENCH_AFFINITY", "1") == "1"
 
 
+def device_local_cpus(device_index):
+    """CPUs of the GPU's NUMA node that this process may use (what Pipeline(set_affinity=True) binds to); [] when unknown."""
+    try:
+        import ctypes as C
+        from dali_amd import _capi as capi
+        buf = C.create_string_buffer(64)
+        if capi.kernels().daliamdDevicePciBusId(int(device_index), buf, 64) != 0:
+            return []
+        cpus = set()
+        for part in open(f"/sys/bus/pci/devices/{buf.value.decode().lower()}/local_cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        return sorted(cpus & set(os.sched_getaffinity(0)))
+    except (OSError, ValueError, AttributeError):
+        return []
+
+
 def measured_traffic(kernel, workload=""):
     """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*_traffic.json, produced by
     tools/collect_profiles.sh: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH_SIZE correction).  bench.py
@@ -1241,7 +1258,8 @@ def main():
                     K = args.emulate_local_world
                     share = max(1, effective_cpu_count() // K)
                     allowed = sorted(os.sched_getaffinity(0))
-                    os.sched_setaffinity(0, set(allowed[:share]))
+                    near = device_local_cpus(dev_index) or allowed      # a rank's share lies on its GPU's NUMA node
+                    os.sched_setaffinity(0, set(near[:share]))
                     try:
                         res = e2e_pipeline(root, args.e2e_batch, local_rank, iters=100, threads=max(2, share))
                     finally:

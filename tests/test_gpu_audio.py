@@ -8,6 +8,7 @@ operator_1/test_mel_filter_bank.py:199, operator_2/test_to_decibels.py:120):
   decibels     |got - ref| <= 1e-4 * |ref| + 1e-3 dB
 """
 import io
+import os
 import struct
 
 import numpy as np
@@ -131,6 +132,25 @@ def test_pcm16_crosses_the_bus_as_int16_and_gives_the_same_bits(nfft, wl, step, 
     for a, b in zip(outs[True], outs[False]):
         for i, (x, y) in enumerate(zip(a, b)):
             assert x.shape == y.shape and np.array_equal(x.view(np.uint32), y.view(np.uint32)), f"sample {i}"
+
+
+def test_pcm16_fusion_with_flac_streams_in_the_batch(monkeypatch):
+    """Mono 16-bit FLAC next to WAV: the batch still travels as int16 (the FLAC samples are decoded to int16 on the host, so
+    the output is a copy, not a view of the files); same bits as the float path."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    rng = np.random.default_rng(8)
+    batch = [open(os.path.join(here, "golden", "flac", "mono16_fixed.flac"), "rb").read(), to_wav(synth_signal(rng, 0.9)),
+             open(os.path.join(here, "golden", "flac", "nolength.flac"), "rb").read()]
+    outs = []
+    for fused in (True, False):
+        if not fused:
+            monkeypatch.setenv("DALI_AMD_NO_PCM16_FUSION", "1")
+        pipe = _pcm_chain(len(batch), 1024, 1024, 256, True, True)
+        pipe.feed_input("wav", batch)
+        db, _ = pipe.run()
+        outs.append([db[i].as_cpu().copy() for i in range(len(batch))])
+    for i, (x, y) in enumerate(zip(*outs)):
+        assert x.shape == y.shape and np.array_equal(x.view(np.uint32), y.view(np.uint32)), f"sample {i}"
 
 
 def test_pcm16_fusion_falls_back_when_a_stream_needs_the_host_path(monkeypatch):
