@@ -154,3 +154,20 @@ def test_a_vanished_file_is_reported_with_its_name(dataset, tmp_path):
     pipe2.build()
     with pytest.raises(RuntimeError, match="gone.jpg"):
         pipe2.run()
+
+
+def test_stream_ordered_handover_calls_are_harmless_without_a_device(dataset):
+    """Pipeline.share_outputs(cuda_stream=...) / release_outputs(cuda_stream=...) on a CPU-only pipeline: there is nothing
+    to order, the outputs are the same as through run()."""
+    root, files = dataset
+    a, b = _pipe(root, 8, prefetch_queue_depth=2), _pipe(root, 8, prefetch_queue_depth=2)
+    for _ in range(5):
+        want = a.run()
+        b._prefetch()
+        b.release_outputs(cuda_stream=0)
+        got = b.share_outputs(cuda_stream=0)
+        for i in range(8):
+            assert got[0].at(i).tobytes() == want[0].at(i).tobytes()
+            assert int(np.asarray(got[1].at(i)).reshape(-1)[0]) == int(np.asarray(want[1].at(i)).reshape(-1)[0])
+    b.release_outputs(cuda_stream=0)
+    b._backend.wait_enqueued()
