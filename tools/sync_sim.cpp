@@ -57,6 +57,7 @@ static int g_pair_bits = 0;
 static int g_group = 2;      // symbols per look-up at most
 static int g_dc_chain = 0;   // DC entries continue into the AC table of the same class
 long g_cls[4] = {0, 0, 0, 0};
+long g_pm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 std::vector<long> g_wmax;
 
 // mirrors DecodeRange: symbols that START in [st.pos, end)
@@ -175,6 +176,55 @@ int main(int argc, char **argv) {
   for (auto &fn : files) {
     Image im;
     if (!Load(fn, im)) { fprintf(stderr, "skip %s\n", fn.c_str()); continue; }
+    if (getenv("SIM_PHASEMAP")) {
+      // Model of the phase-map scheme: round A decodes every slice from its first bit with z = 0 for
+      // EVERY block index inside the MCU; round B decodes slice k from every distinct state slice k - 1's candidates
+      // reached.  Slice k is settled after the two rounds iff the TRUE state at its start is among those states; the
+      // others need one more decode each, one after the other along a run of unsettled slices.
+      extern long g_pm[8];
+      const long n = (im.total_bits / 8 + slice - 1) / slice;
+      std::vector<State> truth(n + 1);
+      State t{0, 0, 0};
+      truth[0] = t;
+      for (long k = 0; k < n; k++) {
+        const uint32_t end = (uint32_t)std::min<unsigned long long>((unsigned long long)(k + 1) * slice * 8ull, im.total_bits);
+        int ns = 0, st = 0;
+        if (t.pos < end) Decode(im, t, end, ns, st);
+        truth[k + 1] = t;
+        g_pm[5] += st;   // steps of the plain sequential decode
+      }
+      std::vector<std::vector<State>> exits(n);
+      for (long k = 0; k < n; k++) {
+        const uint32_t begin = (uint32_t)((unsigned long long)k * slice * 8ull);
+        const uint32_t end = (uint32_t)std::min<unsigned long long>((unsigned long long)(k + 1) * slice * 8ull, im.total_bits);
+        for (uint32_t c = 0; c < im.bpm; c++) {
+          State st{begin, c, 0};
+          int ns = 0, steps = 0;
+          Decode(im, st, end, ns, steps);
+          g_pm[0] += steps;   // round A
+          bool have = false;
+          for (auto &e : exits[k]) have = have || e == st;
+          if (!have) exits[k].push_back(st);
+        }
+        g_pm[1] += (long)exits[k].size();
+      }
+      long run = 0;
+      for (long k = 1; k < n; k++) {
+        const uint32_t end = (uint32_t)std::min<unsigned long long>((unsigned long long)(k + 1) * slice * 8ull, im.total_bits);
+        bool settled = false;
+        for (auto &e : exits[k - 1]) {
+          State st = e;
+          int ns = 0, steps = 0;
+          if (st.pos < end) Decode(im, st, end, ns, steps);
+          g_pm[2] += steps;   // round B
+          settled = settled || e == truth[k];
+        }
+        g_pm[3]++;
+        if (!settled) { g_pm[4]++; run++; g_pm[6] = std::max(g_pm[6], run); } else run = 0;
+      }
+      g_pm[7] += n;
+      continue;
+    }
     const long nslices = (im.total_bits / 8 + slice - 1) / slice;
     const long nseg = std::max<long>(1, (nslices + seg_lanes - 1) / seg_lanes);
     for (long seg = 0; seg < nseg; seg++) {
@@ -308,6 +358,13 @@ int main(int argc, char **argv) {
       wg_path.push_back(path);
       wg_rounds.push_back(rounds);
     }
+  }
+  if (getenv("SIM_PHASEMAP")) {
+    printf("phase map, slice %d: %ld slices; distinct exit states per slice %.2f; lane-steps round A %ld + round B %ld = %.2f x the "
+           "sequential decode (%ld); slices not settled by the two rounds %ld of %ld (%.3f), longest run of them %ld\n",
+           slice, g_pm[7], (double)g_pm[1] / g_pm[7], g_pm[0], g_pm[2], (double)(g_pm[0] + g_pm[2]) / g_pm[5], g_pm[5], g_pm[4], g_pm[3],
+           (double)g_pm[4] / g_pm[3], g_pm[6]);
+    return 0;
   }
   std::sort(wg_path.begin(), wg_path.end());
   std::sort(wg_rounds.begin(), wg_rounds.end());
