@@ -226,3 +226,43 @@ def test_huffman_setup_fused_colour_output():
     for bad in (color(rgb=0x80004), color(pitch=3 * 157 + 5), color(pitch=8), color(width=170), color(height=200),
                 color(1, 4, width=4)):
         assert setup(bad)[0] != 0, "accepted a bad descriptor"
+
+
+def test_huffman_setup_sizes_the_block_grid_from_the_region_of_interest():
+    """Region-of-interest decode (daliamdJpegHuffDesc.rect): the block kernel's workgroups walk the bounding rectangle of
+    the MCUs that hold a wanted block of any component, so the grid is ceil(rectangle MCUs / MCUs per workgroup) - checked
+    against a brute-force walk over the MCUs for random rectangles of a 4:2:0 frame (the planner's shapes: luma rect in
+    blocks, chroma rect = luma / 2 with a margin)."""
+    lib = capi.kernels()
+    rng = np.random.default_rng(5)
+    tiles, segs, bwg = C.c_int(), C.c_int(), C.c_int()
+    full = _huff_desc(total_blocks=40 * 30 * 6)
+    full.mcus_x = 40
+    assert lib.daliamdJpegHuffmanSetup((capi.JpegHuffDesc * 1)(full), 1, C.byref(tiles), C.byref(segs), C.byref(bwg)) == 0
+    mpw = -(-40 * 30 // bwg.value)            # MCUs per workgroup (a multiple of 32), from the whole-frame grid
+    mpw = next(m for m in range(32, 513, 32) if -(-40 * 30 // m) == bwg.value)
+    for _ in range(200):
+        mx, my = 40, 30
+        x0, y0 = int(rng.integers(0, 2 * mx - 1)), int(rng.integers(0, 2 * my - 1))
+        x1, y1 = int(rng.integers(x0 + 1, 2 * mx + 1)), int(rng.integers(y0 + 1, 2 * my + 1))
+        d = _huff_desc(total_blocks=mx * my * 6)
+        d.mcus_x = mx
+        for k, (ho, vo) in enumerate([(0, 0), (1, 0), (0, 1), (1, 1), (0, 0), (0, 0)]):
+            d.h_of_block[k], d.v_of_block[k] = ho, vo
+        rects = {0: (x0, y0, x1, y1),
+                 1: (max(x0 // 2 - 1, 0), max(y0 // 2 - 1, 0), min((x1 + 1) // 2 + 1, mx), min((y1 + 1) // 2 + 1, my))}
+        rects[2] = rects[1]
+        for c, r in rects.items():
+            for j in range(4):
+                d.rect[c][j] = r[j]
+        assert lib.daliamdJpegHuffmanSetup((capi.JpegHuffDesc * 1)(d), 1, C.byref(tiles), C.byref(segs), C.byref(bwg)) == 0
+        need = np.zeros((my, mx), bool)       # MCUs with a wanted block
+        for yy in range(my):
+            for xx in range(mx):
+                luma = any(rects[0][0] <= 2 * xx + ho < rects[0][2] and rects[0][1] <= 2 * yy + vo < rects[0][3]
+                           for ho in (0, 1) for vo in (0, 1))
+                chroma = rects[1][0] <= xx < rects[1][2] and rects[1][1] <= yy < rects[1][3]
+                need[yy, xx] = luma or chroma
+        ys, xs = np.nonzero(need)
+        box = (xs.max() - xs.min() + 1) * (ys.max() - ys.min() + 1)
+        assert bwg.value == -(-box // mpw), (rects, box, bwg.value)
