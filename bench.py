@@ -735,7 +735,7 @@ def bench_audio(args, device, steps=None, cpu_seconds=8.0):
     for i, w in enumerate(wavs):
         with open(os.path.join(root, "0", f"utt_{i:04d}.wav"), "wb") as f:
             f.write(w)
-    depth = 2
+    depth = int(os.environ.get("BENCH_AUDIO_DEPTH", "2"))
     threads = max(2, effective_cpu_count() * 3 // 4)
     try:
         pipe = Pipeline(batch_size=n, num_threads=threads, device_id=device.index or 0, prefetch_queue_depth=depth,
