@@ -287,6 +287,25 @@ __global__ __launch_bounds__(kWarpThreads) void WarpAffineKernel(const daliamdWa
 #endif
 constexpr int kBlurThreads = DALIAMD_BLUR_THREADS;
 constexpr int kBlurMaxLds = 60 * 1024;
+// LDS pitches of the blur's two tiles (shared by the kernel and Setup).  DALIAMD_BLUR_TPAD: floats added to a row of the
+// fp32 intermediate (even); DALIAMD_BLUR_SMOD: when non-zero the staged source pitch is raised to SMOD modulo 64 bytes.
+// The W pass's lanes are (row pair, 8-pixel group, channel): the four groups of a row pair sit 6 dwords apart in the staged
+// source and 24 floats apart in the intermediate, so a row-pair stride of 2 dwords (source pitch 4 modulo 64 bytes) / 4
+// floats (intermediate pitch 2 modulo 16) modulo the 32 banks keeps the two or three row pairs of an LDS pass on disjoint
+// banks (a pitch of 96 floats put every row pair on the same ones).  Measured (tools/aug_variants.sh, bit-exact): 0.477 ->
+// 0.473 (intermediate) / 0.473 (source) / 0.469 ms (both) - the kernel is bound by vector issue, not by these conflicts.
+#ifndef DALIAMD_BLUR_TPAD
+#define DALIAMD_BLUR_TPAD 2
+#endif
+#ifndef DALIAMD_BLUR_SMOD
+#define DALIAMD_BLUR_SMOD 4
+#endif
+__host__ __device__ inline int BlurTmpStride(int tile_w, int channels) { return ((tile_w * channels + 1) & ~1) + DALIAMD_BLUR_TPAD; }
+__host__ __device__ inline int BlurSrcPitch(int in_cols, int channels, int px) {
+  int p = ((in_cols + px) * channels + 4 + 3) & ~3;   // + alignment lead + register-blocking overrun
+  if (DALIAMD_BLUR_SMOD) p += ((DALIAMD_BLUR_SMOD - p) % 64 + 64) % 64;
+  return p;
+}
 #ifndef DALIAMD_BLUR_PX
 #define DALIAMD_BLUR_PX 8
 #endif
@@ -562,8 +581,8 @@ __global__ __launch_bounds__(kBlurThreads) void GaussianBlurKernel(const daliamd
   const int tw = min(TW, d.w - ox0), th = min(TH, d.h - oy0);
   const int in_rows = th + 2 * ry, in_cols = tw + 2 * rx;
   const int row_elems = tw * C;                        // tmp row length
-  const int tstride = (TW * C + 1) & ~1;               // tmp row stride: even, so that element pairs are 8-byte aligned
-  const int src_pitch = ((in_cols + kBlurPx) * C + 4 + 3) & ~3;  // staged source row pitch (bytes): + lead + blocking overrun
+  const int tstride = BlurTmpStride(TW, C);            // tmp row stride: even, so that element pairs are 8-byte aligned
+  const int src_pitch = BlurSrcPitch(in_cols, C, kBlurPx);   // staged source row pitch (bytes)
   float *tmp = blur_lds;                               // [in_rows + kBlurRows - 1][tstride]
   uint8_t *src = reinterpret_cast<uint8_t *>(tmp + (size_t)(TH + 2 * ry + kBlurRows - 1) * tstride);  // [in_rows][src_pitch]
   const int tid = threadIdx.x;
@@ -809,8 +828,8 @@ daliamdResult_t daliamdGaussianBlurSetup(daliamdGaussianBlurDesc *descs, int n, 
     int tw = 32, th = 64;
     auto need = [&](int tw_, int th_) {
       size_t rows = th_ + d.size_y - 1, cols = tw_ + d.size_x - 1;
-      size_t src_pitch = ((cols + kBlurPx) * d.channels + 4 + 3) & ~(size_t)3;  // + alignment lead + register-blocking overrun
-      size_t tstride = ((size_t)tw_ * d.channels + 1) & ~(size_t)1;
+      size_t src_pitch = (size_t)BlurSrcPitch((int)cols, d.channels, kBlurPx);
+      size_t tstride = (size_t)BlurTmpStride(tw_, d.channels);
       return (rows + kBlurRows - 1) * tstride * 4 + rows * src_pitch + 16;
     };
     while (need(tw, th) > (size_t)kBlurMaxLds && (tw > 8 || th > 1)) {
