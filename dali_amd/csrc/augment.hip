@@ -630,7 +630,11 @@ __global__ __launch_bounds__(kBlurThreads) void GaussianBlurKernel(const daliamd
 // pointwise: colour twist (3x3 matrix + offset) and / or erase, 4 pixels per thread
 // =============================================================================================
 constexpr int kPwThreads = 256;
-constexpr int kPwPx = 4;
+#ifndef DALIAMD_PW_PX
+#define DALIAMD_PW_PX 16
+#endif
+constexpr int kPwPx = DALIAMD_PW_PX;   // pixels per thread: 16 x 3 bytes = three 16-byte loads and stores (4: one 12-byte pair, round 3)
+static_assert(kPwPx == 4 || kPwPx == 8 || kPwPx == 16 || kPwPx == 32, "whole dwords of 3-byte pixels");
 
 __global__ __launch_bounds__(kPwThreads) void PointwiseKernel(const daliamdPointwiseDesc *__restrict__ descs, int ndesc,
                                                               int total_wg) {
@@ -646,49 +650,68 @@ __global__ __launch_bounds__(kPwThreads) void PointwiseKernel(const daliamdPoint
   int npx = min(kPwPx, d.w - x0);
   using GIn = const uint8_t __attribute__((address_space(1)));
   using GOut = uint8_t __attribute__((address_space(1)));
-  typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
   GIn *ip = (GIn *)d.in + (size_t)y * d.in_pitch + (size_t)x0 * C;
   GOut *op = (GOut *)d.out + (size_t)y * d.out_pitch + (size_t)x0 * C;
-  bool erased[kPwPx];
-#pragma unroll
-  for (int p = 0; p < kPwPx; p++) {
-    const int x = x0 + p;
-    bool e = false;
-    for (int r = 0; r < d.num_regions; r++)
-      e |= y >= d.region[r][0] && y < d.region[r][2] && x >= d.region[r][1] && x < d.region[r][3];
-    erased[p] = e;
+  // which of the thread's pixels lie in an erase region: one bit each (a region covers a run of them)
+  uint32_t erased = 0;
+  for (int r = 0; r < d.num_regions; r++) {
+    if (y < d.region[r][0] || y >= d.region[r][2]) continue;
+    const int xa = max(d.region[r][1], x0) - x0, xb = min(d.region[r][3], x0 + kPwPx) - x0;
+    if (xb > xa) erased |= (xb - xa >= 32 ? 0xffffffffu : (1u << (xb - xa)) - 1u) << xa;
   }
-  if (C == 3 && npx == kPwPx && ((((uintptr_t)ip) | ((uintptr_t)op)) & 3) == 0) {
-    // 4 pixels = 12 bytes = three dwords in, three dwords out
-    const u32x3 v = *(const u32x3 __attribute__((address_space(1))) *)ip;
-    uint32_t b[12];
+  constexpr int kDw = kPwPx * 3 / 4;   // dwords of a thread's pixels
+  constexpr int kAlign = kDw % 4 == 0 ? 16 : 4;
+  if (C == 3 && npx == kPwPx && ((((uintptr_t)ip) | ((uintptr_t)op)) & (kAlign - 1)) == 0) {
+    uint32_t w[kDw];
+    if constexpr (kDw % 4 == 0) {
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-    for (int i = 0; i < 12; i++) b[i] = ((i < 4 ? v.x : i < 8 ? v.y : v.z) >> (8 * (i & 3))) & 255u;
+      for (int q = 0; q < kDw / 4; q++) {
+        const u32x4 v = ((const u32x4 __attribute__((address_space(1))) *)ip)[q];
+        w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < kDw; q++) w[q] = ((const uint32_t __attribute__((address_space(1))) *)ip)[q];
+    }
     const uint32_t f0 = SatU8(d.fill[0]), f1 = SatU8(d.fill[1]), f2 = SatU8(d.fill[2]);
+    const bool transform = d.transform != 0;
+    uint32_t o[kDw];
+#pragma unroll
+    for (int q = 0; q < kDw; q++) o[q] = 0;
 #pragma unroll
     for (int p = 0; p < kPwPx; p++) {
-      if (erased[p]) {
-        b[3 * p] = f0; b[3 * p + 1] = f1; b[3 * p + 2] = f2;
-      } else if (d.transform) {
-        const float v0 = (float)b[3 * p], v1 = (float)b[3 * p + 1], v2 = (float)b[3 * p + 2];
+      uint32_t b[3];
+#pragma unroll
+      for (int i = 0; i < 3; i++) b[i] = (w[(3 * p + i) >> 2] >> (8 * ((3 * p + i) & 3))) & 255u;
+      if ((erased >> p) & 1u) {
+        b[0] = f0; b[1] = f1; b[2] = f2;
+      } else if (transform) {
+        const float v0 = (float)b[0], v1 = (float)b[1], v2 = (float)b[2];
 #pragma unroll
         for (int i = 0; i < 3; i++) {
           float s = d.matrix[3 * i] * v0;   // mat * vec: s = m[i][0]*v[0]; s += m[i][j]*v[j]   (mat.h:283-292)
           s += d.matrix[3 * i + 1] * v1;
           s += d.matrix[3 * i + 2] * v2;
-          b[3 * p + i] = SatU8(s + d.offset[i]);
+          b[i] = SatU8(s + d.offset[i]);
         }
       }
+#pragma unroll
+      for (int i = 0; i < 3; i++) o[(3 * p + i) >> 2] |= b[i] << (8 * ((3 * p + i) & 3));
     }
-    u32x3 o;
-    o.x = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
-    o.y = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
-    o.z = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
-    *(u32x3 __attribute__((address_space(1))) *)op = o;
+    if constexpr (kDw % 4 == 0) {
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+      for (int q = 0; q < kDw / 4; q++)
+        ((u32x4 __attribute__((address_space(1))) *)op)[q] = u32x4{o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
+    } else {
+#pragma unroll
+      for (int q = 0; q < kDw; q++) ((uint32_t __attribute__((address_space(1))) *)op)[q] = o[q];
+    }
     return;
   }
   for (int p = 0; p < npx; p++) {
-    if (erased[p]) {
+    if ((erased >> p) & 1u) {
       for (int c = 0; c < C; c++) op[p * C + c] = (uint8_t)SatU8(c == 0 ? d.fill[0] : c == 1 ? d.fill[1] : c == 2 ? d.fill[2] : d.fill[3]);
     } else if (d.transform) {
       float v0 = (float)ip[p * 3], v1 = (float)ip[p * 3 + 1], v2 = (float)ip[p * 3 + 2];
