@@ -110,6 +110,42 @@ def test_decoder_output_with_padded_rows(tmp_path):
         _check([out[i].as_cpu()], [ON.normalize(img, (0, 1)).astype(np.float32)])
 
 
+@pytest.mark.parametrize("channels", [1, 2, 3, 4])
+def test_u8_images_of_one_to_four_channels_exact_means(channels):
+    """The 16-bytes-per-lane path of the statistics kernels (u8, inner <= 4): ragged tails, several 65536-element chunks
+    (a chunk start is not a multiple of 3), every channel count.  With stddev=1 the output is fl(x - mean) and the u8
+    mean is an exact integer sum -> bit-exact against numpy's fp64 mean."""
+    rng = np.random.default_rng(20 + channels)
+    shapes = [(1, 1), (3, 5), (37, 53), (257, 259), (300, 437), (16, 4096)]
+    batch = [rng.integers(0, 256, (h, w, channels), dtype=np.uint8) for (h, w) in shapes]
+    got = _run(batch, "HWC", axes=[0, 1], stddev=1.0)
+    for g, b in zip(got, batch):
+        m = b.reshape(-1, channels).astype(np.float64).mean(axis=0).astype(np.float32)
+        assert np.array_equal(g, b.astype(np.float32) - m)
+    got = _run(batch, "HWC", axes=[0, 1])
+    _check(got, [ON.normalize(b, (0, 1)).astype(np.float32) for b in batch], rtol=1e-5, atol=1e-5)
+    got = _run(batch, "HWC")                      # one bin per sample: inner == 1, reduced = H * W * C
+    _check(got, [ON.normalize(b, None).astype(np.float32) for b in batch], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("out_name", ["FLOAT16", "INT8", "UINT8"])
+def test_narrow_outputs_and_row_statistics(out_name):
+    """Vector stores of the apply pass for every output type; per-row statistics (outer = H, planes of odd length, so
+    most row starts are unaligned and 4-element groups straddle rows)."""
+    from dali_amd import types
+    rng = np.random.default_rng(31)
+    batch = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for (h, w) in [(37, 53), (5, 1), (64, 171), (130, 333)]]
+    got = _run(batch, "HWC", axes=[1, 2], scale=40.0, shift=100.0 if out_name == "UINT8" else 0.0,
+               dtype=getattr(types, out_name))
+    for g, b in zip(got, batch):
+        ref = ON.normalize(b, (1, 2), scale=40.0, shift=100.0 if out_name == "UINT8" else 0.0)
+        if out_name == "FLOAT16":
+            assert g.dtype == np.float16 and np.allclose(g.astype(np.float32), ref, rtol=2e-3, atol=2e-2)
+        else:
+            lo, hi = (0, 255) if out_name == "UINT8" else (-128, 127)
+            assert np.abs(g.astype(np.int32) - np.clip(np.rint(ref), lo, hi).astype(np.int32)).max() <= 1
+
+
 def test_non_adjacent_axes_are_rejected():
     with pytest.raises(RuntimeError, match="adjacent"):
         _run([np.zeros((4, 5, 3), np.float32)], "HWC", axes=[0, 2])

@@ -26,7 +26,7 @@ dev = torch.device("cuda", 0)
 images = [torch.randint(0, 256, (h, w, 3), dtype=torch.uint8, device=dev) for (h, w) in shapes]
 pixels = sum(h * w for h, w in shapes)
 
-pipe = Pipeline(batch_size=N, num_threads=4, device_id=0, prefetch_queue_depth=2, seed=1)
+pipe = Pipeline(batch_size=N, num_threads=4, device_id=0, prefetch_queue_depth=1, seed=1)
 with pipe:
     x = fn.external_source(name="x", device="gpu", layout="HWC")
     stats = fn.normalize(x, axes=[0, 1])                                        # per-channel mean / stddev of every sample
