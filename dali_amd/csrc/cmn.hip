@@ -12,8 +12,8 @@
 // only is when std == 1.
 //
 // Mapping: a workgroup owns 1024 consecutive crop pixels (row-major); each thread handles 4
-// consecutive pixels of one row segment: 12 source bytes in, 4 values per output channel plane
-// out (8-byte fp16 stores for CHW).  HBM traffic: C bytes read + Cout*sizeof(Out) written per pixel.
+// consecutive pixels of one row segment: 12 source bytes in (all loads issued before the first
+// use), 4 values per output channel plane out (8-byte fp16 stores for CHW).  HBM traffic: C bytes read + Cout*sizeof(Out) written per pixel.
 #include "common.h"
 
 namespace daliamd {
@@ -79,37 +79,57 @@ __global__ __launch_bounds__(kCmnThreads) void CmnKernel(const daliamdCmnDesc *_
   bool row_in = sy >= 0 && sy < d.in_h;
   const uint8_t *row = d.in + (size_t)(row_in ? sy : 0) * d.in_pitch;
 
+  // all the source bytes of the thread first (16 predicated loads in flight, not a load and a wait per element),
+  // then the arithmetic
+  using GByte = const uint8_t __attribute__((address_space(1)));
+  GByte *grow = (GByte *)row;
+  uint32_t raw[kCmnPxPerThread][4];
+  bool inside[kCmnPxPerThread];
+#pragma unroll
+  for (int p = 0; p < kCmnPxPerThread; p++) {
+    const int x = x0 + p;
+    const int sx = d.mirror ? d.anchor_x + (cw - 1 - x) : d.anchor_x + x;
+    inside[p] = p < npx && row_in && sx >= 0 && sx < d.in_w;
+    GByte *px = grow + (size_t)(inside[p] ? sx : 0) * C;
+#pragma unroll
+    for (int c = 0; c < 4; c++) raw[p][c] = (inside[p] && c < C) ? px[c] : 0u;
+  }
+  float mean[4], inv_std[4], fill[4];
+#pragma unroll
+  for (int c = 0; c < 4; c++) { mean[c] = d.mean[c]; inv_std[c] = d.inv_std[c]; fill[c] = d.fill[c]; }
+  const bool norm = d.normalize != 0;
   float vals[4][kCmnPxPerThread];
-  for (int p = 0; p < npx; p++) {
-    int x = x0 + p;
-    int sx = d.mirror ? d.anchor_x + (cw - 1 - x) : d.anchor_x + x;
-    bool inside = row_in && sx >= 0 && sx < d.in_w;
-    for (int c = 0; c < Co; c++) {
-      float v;
-      if (c < C && inside) {
-        v = (float)row[(size_t)sx * C + c];
-        if (d.normalize) v = (v - d.mean[c]) * d.inv_std[c];
-      } else {
-        v = d.fill[c];
-      }
-      vals[c][p] = v;
+#pragma unroll
+  for (int p = 0; p < kCmnPxPerThread; p++) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      float v = (float)raw[p][c];
+      if (norm) v = (v - mean[c]) * inv_std[c];
+      vals[c][p] = (c < C && inside[p]) ? v : fill[c];
     }
   }
   bool chw = d.out_layout == DALIAMD_LAYOUT_CHW;
   if (chw && d.out_dtype == DALIAMD_FLOAT16 && npx == 4 && ((cw & 3) == 0) &&
       ((reinterpret_cast<uintptr_t>(d.out) & 7) == 0)) {
-    for (int c = 0; c < Co; c++) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      if (c >= Co) break;
       uint32_t lo = F2HAway(vals[c][0]) | ((uint32_t)F2HAway(vals[c][1]) << 16);
       uint32_t hi = F2HAway(vals[c][2]) | ((uint32_t)F2HAway(vals[c][3]) << 16);
       size_t o = ((size_t)c * ch + y) * cw + x0;
       *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(d.out) + o) = make_uint2(lo, hi);
     }
   } else {
-    for (int p = 0; p < npx; p++)
-      for (int c = 0; c < Co; c++) {
+#pragma unroll
+    for (int p = 0; p < kCmnPxPerThread; p++) {
+      if (p >= npx) break;
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        if (c >= Co) break;
         size_t o = chw ? ((size_t)c * ch + y) * cw + (x0 + p) : ((size_t)y * cw + (x0 + p)) * Co + c;
         StoreElem(d.out, o, d.out_dtype, vals[c][p]);
       }
+    }
   }
 }
 
