@@ -22,7 +22,8 @@ constexpr int kCmnThreads = 256;
 constexpr int kCmnPxPerThread = 4;
 constexpr int kCmnPxPerWg = kCmnThreads * kCmnPxPerThread;
 
-__device__ __forceinline__ uint16_t F2HAway(float f) {
+// half_float round-to-nearest, ties away from zero (half.hpp:464-536), every exponent range
+__device__ __noinline__ uint16_t F2HAwaySlow(float f) {
   uint32_t bits = __float_as_uint(f);
   uint32_t e = (bits >> 23) & 0xff;
   uint32_t sign = (bits >> 16) & 0x8000;
@@ -37,6 +38,21 @@ __device__ __forceinline__ uint16_t F2HAway(float f) {
   uint32_t h = (base | sign) + (mant >> shift);
   uint32_t rnd = ((mant >> (shift - 1)) | (e == 102 ? 1u : 0u)) & ((h & 0x7C00) != 0x7C00 ? 1u : 0u);
   return (uint16_t)(h + rnd);
+}
+
+// In the normal half range the ties-away result is the hardware round-to-nearest-even result, plus one unit in the
+// last place exactly when the dropped bits are a tie and RNE rounded down (the fused epilogue of resample.hip does the same)
+__device__ __forceinline__ uint16_t F2HAway(float f) {
+  const uint32_t bits = __float_as_uint(f);
+  const uint32_t e = (bits >> 23) & 0xff;
+  if (e >= 113 && e < 142) {
+    const _Float16 hf = (_Float16)f;  // v_cvt_f16_f32
+    const uint16_t h = __builtin_bit_cast(uint16_t, hf);
+    const bool tie_down = ((bits & 0x1FFF) == 0x1000) && ((bits & 0x2000) == 0);
+    return tie_down ? (uint16_t)(h + 1) : h;
+  }
+  if ((bits & 0x7fffffff) == 0) return (uint16_t)(bits >> 16);
+  return F2HAwaySlow(f);
 }
 
 __device__ __forceinline__ float RoundAway(float v) {  // std::round
