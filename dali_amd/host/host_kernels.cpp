@@ -15,6 +15,7 @@
 // This file is built with -ffp-contract=off: multiply and add are rounded separately, as on baseline x86-64.
 #include <algorithm>
 #include <cmath>
+#include <emmintrin.h>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -258,6 +259,89 @@ int ResampleGenericHost(const daliamdResampleDesc &d) {
 }
 }  // namespace
 
+namespace {
+// clamp, then round half to even: cvtss2si under the default MXCSR rounding mode (= std::nearbyint, without the call)
+inline uint32_t RoundU8Even(float v) {
+  const float c = std::fmin(std::fmax(v, 0.0f), 255.0f);  // NaN -> 0
+  return (uint32_t)_mm_cvtss_si32(_mm_set_ss(c));
+}
+inline uint32_t RoundU8Fast(float v, bool half_even) { return half_even ? RoundU8Even(v) : RoundU8(v, false); }
+
+// The epilogue's output element is a function of (channel, rounded u8 value): 256 results per channel (the device
+// kernel keeps the same table in LDS), as raw bits of the output type
+struct EpilogueLut {
+  uint32_t bits[4][256];
+  void *out;
+  int dtype;
+  EpilogueLut(const Epilogue &ep, const float *mean, const float *inv_std) : out(ep.out), dtype(ep.dtype) {
+    for (int c = 0; c < ep.channels; c++)
+      for (uint32_t v = 0; v < 256; v++) {
+        float f = (float)v;
+        if (ep.dtype == DALIAMD_UINT8) {
+          bits[c][v] = ep.normalize ? RoundU8((f - mean[c]) * inv_std[c], false) : v;
+        } else {
+          if (ep.normalize) f = (f - mean[c]) * inv_std[c];
+          if (ep.dtype == DALIAMD_FLOAT16) bits[c][v] = Float2HalfAway(f);
+          else memcpy(&bits[c][v], &f, 4);
+        }
+      }
+  }
+  inline void Store(size_t o, int c, uint32_t v) const {
+    const uint32_t b = bits[c][v];
+    if (dtype == DALIAMD_FLOAT16) static_cast<uint16_t *>(out)[o] = (uint16_t)b;
+    else if (dtype == DALIAMD_UINT8) static_cast<uint8_t *>(out)[o] = (uint8_t)b;
+    else static_cast<uint32_t *>(out)[o] = b;
+  }
+};
+
+// A finished row of `n` float results -> rounded u8, written contiguously (u8 output, no normalisation, HWC, not
+// mirrored): 16 elements at a time where all 16 round half to even - clamp, cvtps2dq, pack: the reference's SSE2 store -
+// and element by element elsewhere
+inline void StoreRowU8(const float *v, const uint8_t *even, int n, uint8_t *dst) {
+  const __m128 lo = _mm_setzero_ps(), hi = _mm_set1_ps(255.0f);
+  int e = 0;
+  while (e < n) {
+    if (e + 16 <= n && _mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i *)(even + e)), _mm_set1_epi8(1))) == 0xffff) {
+      __m128i q[4];
+      // max(v, 0) with v as the FIRST operand returns 0 for a NaN, like std::fmax(v, 0) in RoundU8Even
+      for (int j = 0; j < 4; j++) q[j] = _mm_cvtps_epi32(_mm_min_ps(_mm_max_ps(_mm_loadu_ps(v + e + 4 * j), lo), hi));
+      _mm_storeu_si128((__m128i *)(dst + e), _mm_packus_epi16(_mm_packs_epi32(q[0], q[1]), _mm_packs_epi32(q[2], q[3])));
+      e += 16;
+    } else {
+      dst[e] = (uint8_t)RoundU8Fast(v[e], even[e] != 0);
+      e++;
+    }
+  }
+}
+
+// One row of the horizontal pass: dst[x][c] = sum_k coef[x][k] * src[xoff[x][k] + c], taps in order, product then sum
+// (ResampleCol, resampling_impl_cpu.h:50-86).  Four lanes per pixel whatever C is: src and dst carry 3 floats of padding.
+inline void HorzRow(const float *src, const int *xoff, const float *coef, int out_w, int sup, int C, float *dst) {
+  for (int x = 0; x < out_w; x++) {
+    const int *xo = xoff + (size_t)x * sup;
+    const float *co = coef + (size_t)x * sup;
+    __m128 acc = _mm_setzero_ps();
+    for (int k = 0; k < sup; k++) acc = _mm_add_ps(acc, _mm_mul_ps(_mm_set1_ps(co[k]), _mm_loadu_ps(src + xo[k])));
+    _mm_storeu_ps(dst + (size_t)x * C, acc);
+  }
+}
+
+// dst[e] += (float)row[e] * w over a source row / dst[e] += row[e] * w over an intermediate row: one tap of the
+// vertical pass for every element (ResampleVert, resampling_impl_cpu.h:362-390: taps in order, product then sum)
+__attribute__((target_clones("avx2", "default")))
+void VertTapU8(float *dst, const uint8_t *row, float w, int n) {
+  for (int e = 0; e < n; e++) dst[e] += (float)row[e] * w;
+}
+__attribute__((target_clones("avx2", "default")))
+void VertTapF32(float *dst, const float *row, float w, int n) {
+  for (int e = 0; e < n; e++) dst[e] += row[e] * w;
+}
+__attribute__((target_clones("avx2", "default")))
+void RowToFloat(float *dst, const uint8_t *row, int n) {
+  for (int e = 0; e < n; e++) dst[e] = (float)row[e];
+}
+}  // namespace
+
 extern "C" int daliamdResampleRunHost(const daliamdResampleDesc *desc) {
   if (!desc || !desc->in || !desc->out) return Fail("daliamdResampleRunHost: NULL descriptor or buffer");
   const daliamdResampleDesc &d = *desc;
@@ -272,21 +356,17 @@ extern "C" int daliamdResampleRunHost(const daliamdResampleDesc *desc) {
   const int ex = d.ext[0] - 1, ey = d.ext[1] - 1;
   const uint8_t *base = d.in + (size_t)d.lo[1] * pitch + (size_t)d.lo[0] * C;
   Epilogue ep{d.out, d.out_h, d.out_w, C, d.out_dtype, d.out_layout, d.normalize, d.mirror};
+  const EpilogueLut lut(ep, d.mean, d.inv_std);
+  // element offsets of the clamped taps of every output column
+  std::vector<int> xoff((size_t)d.out_w * sup_x);
+  for (int x = 0; x < d.out_w; x++)
+    for (int k = 0; k < sup_x; k++) xoff[(size_t)x * sup_x + k] = ClampI(tx.first[x] + k, 0, ex) * C;
+  const int rowlen = d.out_w * C;
+  const bool plain_u8 = d.out_dtype == DALIAMD_UINT8 && !d.normalize && !d.mirror && d.out_layout != DALIAMD_LAYOUT_CHW;
   if (d.first_axis == 1) {
-    // vertical pass: tmp[out_h][ext_x * C], then horizontal
+    // vertical pass into one intermediate row [ext_x * C], horizontal pass on it, epilogue: row by row
     const int NB = d.ext[0] * C;
-    std::vector<float> tmp((size_t)d.out_h * NB);
-    std::vector<const uint8_t *> rows(sup_y);
-    for (int y = 0; y < d.out_h; y++) {
-      const float *co = &ty.coef[(size_t)y * sup_y];
-      for (int k = 0; k < sup_y; k++) rows[k] = base + (size_t)ClampI(ty.first[y] + k, 0, ey) * pitch;
-      float *trow = &tmp[(size_t)y * NB];
-      for (int e = 0; e < NB; e++) {
-        float a = 0;
-        for (int k = 0; k < sup_y; k++) a += (float)rows[k][e] * co[k];
-        trow[e] = a;
-      }
-    }
+    std::vector<float> trow(NB + 4), orow(rowlen + 4);
     // Rounding of an H-last pass (ResampleHorz, resampling_impl_cpu.h:286-336,477-485): the row is cut into the
     // left-clamped / regular / right-clamped column regions, every region runs 16 columns at a time through the SSE2
     // body (half to even) and finishes in a scalar tail (half away from zero).  The descriptor carries this as a
@@ -312,53 +392,51 @@ extern "C" int daliamdResampleRunHost(const daliamdResampleDesc *desc) {
         x = std::max(x, ox1);
       }
     }
-    std::vector<int> xo(sup_x);
-    for (int x = 0; x < d.out_w; x++) {
-      const float *co = &tx.coef[(size_t)x * sup_x];
-      for (int k = 0; k < sup_x; k++) xo[k] = ClampI(tx.first[x] + k, 0, ex) * C;
-      const bool even = even_col[x] != 0;
-      for (int y = 0; y < d.out_h; y++) {
-        const float *trow = &tmp[(size_t)y * NB];
-        float a[4] = {0, 0, 0, 0};
-        for (int k = 0; k < sup_x; k++)
-          for (int c = 0; c < C; c++) a[c] += co[k] * trow[xo[k] + c];
+    std::vector<uint8_t> even_el(rowlen);
+    for (int x = 0; x < d.out_w; x++)
+      for (int c = 0; c < C; c++) even_el[(size_t)x * C + c] = even_col[x];
+    for (int y = 0; y < d.out_h; y++) {
+      const float *co = &ty.coef[(size_t)y * sup_y];
+      std::fill(trow.begin(), trow.end(), 0.0f);
+      for (int k = 0; k < sup_y; k++) VertTapU8(trow.data(), base + (size_t)ClampI(ty.first[y] + k, 0, ey) * pitch, co[k], NB);
+      HorzRow(trow.data(), xoff.data(), tx.coef.data(), d.out_w, sup_x, C, orow.data());
+      if (plain_u8) { StoreRowU8(orow.data(), even_el.data(), rowlen, static_cast<uint8_t *>(d.out) + (size_t)y * rowlen); continue; }
+      for (int x = 0; x < d.out_w; x++) {
         size_t cs;
         const size_t o = ep.Base(y, x, &cs);
-        for (int c = 0; c < C; c++) ep.Store(o + c * cs, RoundU8(a[c], even), d.mean[c], d.inv_std[c]);
+        const bool even = even_col[x] != 0;
+        for (int c = 0; c < C; c++) lut.Store(o + c * cs, c, RoundU8Fast(orow[(size_t)x * C + c], even));
       }
     }
   } else {
     // horizontal pass: tmp[ext_y][out_w * C], then vertical
-    const int rowlen = d.out_w * C, nrows = d.ext[1];
-    std::vector<float> tmp((size_t)nrows * rowlen);
-    std::vector<int> xo(sup_x);
-    for (int x = 0; x < d.out_w; x++) {
-      const float *co = &tx.coef[(size_t)x * sup_x];
-      for (int k = 0; k < sup_x; k++) xo[k] = ClampI(tx.first[x] + k, 0, ex) * C;
-      for (int r = 0; r < nrows; r++) {
-        const uint8_t *srow = base + (size_t)r * pitch;
-        float a[4] = {0, 0, 0, 0};
-        for (int k = 0; k < sup_x; k++)
-          for (int c = 0; c < C; c++) a[c] += co[k] * (float)srow[xo[k] + c];
-        for (int c = 0; c < C; c++) tmp[(size_t)r * rowlen + (size_t)x * C + c] = a[c];
-      }
+    const int nrows = d.ext[1], NB = d.ext[0] * C;
+    const size_t tpitch = (size_t)rowlen + 4;
+    std::vector<float> tmp((size_t)nrows * tpitch), frow(NB + 4), acc(rowlen);
+    // ResampleVert: 256-element tiles, 16-lane SIMD body (half to even) then scalar tail (half away)
+    std::vector<uint8_t> even_el(rowlen);
+    for (int fi = 0; fi < rowlen; fi++) {
+      const int t0 = fi & ~255, tend = std::min(t0 + 256, rowlen);
+      even_el[fi] = fi < t0 + ((tend - t0) & ~15);
     }
-    const int flat_w = rowlen;
-    std::vector<const float *> rows(sup_y);
+    for (int r = 0; r < nrows; r++) {
+      RowToFloat(frow.data(), base + (size_t)r * pitch, NB);
+      HorzRow(frow.data(), xoff.data(), tx.coef.data(), d.out_w, sup_x, C, &tmp[(size_t)r * tpitch]);
+    }
     for (int y = 0; y < d.out_h; y++) {
       const float *co = &ty.coef[(size_t)y * sup_y];
-      for (int k = 0; k < sup_y; k++) rows[k] = &tmp[(size_t)ClampI(ty.first[y] + k, 0, ey) * rowlen];
+      std::fill(acc.begin(), acc.end(), 0.0f);
+      for (int k = 0; k < sup_y; k++) VertTapF32(acc.data(), &tmp[(size_t)ClampI(ty.first[y] + k, 0, ey) * tpitch], co[k], rowlen);
+      if (plain_u8) { StoreRowU8(acc.data(), even_el.data(), rowlen, static_cast<uint8_t *>(d.out) + (size_t)y * rowlen); continue; }
       for (int x = 0; x < d.out_w; x++) {
         size_t cs;
         const size_t o = ep.Base(y, x, &cs);
         for (int c = 0; c < C; c++) {
           const int fi = x * C + c;
-          float a = 0;
-          for (int k = 0; k < sup_y; k++) a += rows[k][fi] * co[k];
           // ResampleVert: 256-element tiles, 16-lane SIMD body (half to even) then scalar tail (half away)
-          const int t0 = fi & ~255, tend = std::min(t0 + 256, flat_w);
+          const int t0 = fi & ~255, tend = std::min(t0 + 256, rowlen);
           const bool even = fi < t0 + ((tend - t0) & ~15);
-          ep.Store(o + c * cs, RoundU8(a, even), d.mean[c], d.inv_std[c]);
+          lut.Store(o + c * cs, c, RoundU8Fast(acc[fi], even));
         }
       }
     }
@@ -366,42 +444,82 @@ extern "C" int daliamdResampleRunHost(const daliamdResampleDesc *desc) {
   return 0;
 }
 
-extern "C" int daliamdCmnRunHost(const daliamdCmnDesc *desc) {
-  if (!desc || !desc->in || !desc->out) return Fail("daliamdCmnRunHost: NULL descriptor or buffer");
-  const daliamdCmnDesc &d = *desc;
+namespace {
+// ConvertSat<Out> of one CropMirrorNormalize value, as the bits of the output element
+inline uint32_t CmnElemBits(float v, int dtype) {
+  switch (dtype) {
+    case DALIAMD_FLOAT: { uint32_t b; memcpy(&b, &v, 4); return b; }
+    case DALIAMD_FLOAT16: return Float2HalfAway(v);
+    case DALIAMD_UINT8: {
+      const float r = RoundAway(v);
+      return (uint8_t)(!(r > 0.0f) ? 0.0f : std::fmin(r, 255.0f));
+    }
+    default: {
+      float r = RoundAway(v);
+      r = r != r ? 0.0f : std::fmin(std::fmax(r, -128.0f), 127.0f);
+      return (uint8_t)(int8_t)r;
+    }
+  }
+}
+
+// Every output element is a function of (channel, u8 sample) alone: 256 results per channel, computed with the
+// element-wise arithmetic above, then the crop is a table look-up per element.  T = the output element as raw bits.
+template <typename T>
+void CmnRowsLut(const daliamdCmnDesc &d) {
   const int cw = d.crop_w, ch = d.crop_h, C = d.channels, Co = d.out_channels;
   const bool chw = d.out_layout == DALIAMD_LAYOUT_CHW;
+  T lut[4][256], fillv[4];
+  for (int c = 0; c < 4; c++) {
+    fillv[c] = (T)CmnElemBits(d.fill[c], d.out_dtype);
+    for (int v = 0; v < 256; v++) {
+      float f = (float)v;
+      if (d.normalize) f = (f - d.mean[c]) * d.inv_std[c];
+      lut[c][v] = (T)CmnElemBits(f, d.out_dtype);
+    }
+  }
+  // columns whose source pixel lies inside the image: [x_lo, x_hi)
+  int x_lo, x_hi;
+  if (d.mirror) { x_lo = std::max(0, d.anchor_x + cw - d.in_w); x_hi = std::min(cw, d.anchor_x + cw); }
+  else { x_lo = std::max(0, -d.anchor_x); x_hi = std::min(cw, d.in_w - d.anchor_x); }
+  x_hi = std::max(x_hi, x_lo);
+  T *out = static_cast<T *>(d.out);
+  const size_t plane = (size_t)ch * cw;
   for (int y = 0; y < ch; y++) {
     const int sy = d.anchor_y + y;
     const bool row_in = sy >= 0 && sy < d.in_h;
-    const uint8_t *row = d.in + (size_t)(row_in ? sy : 0) * d.in_pitch;
-    for (int x = 0; x < cw; x++) {
-      const int sx = d.mirror ? d.anchor_x + (cw - 1 - x) : d.anchor_x + x;
-      const bool inside = row_in && sx >= 0 && sx < d.in_w;
-      for (int c = 0; c < Co; c++) {
-        float v;
-        if (c < C && inside) {
-          v = (float)row[(size_t)sx * C + c];
-          if (d.normalize) v = (v - d.mean[c]) * d.inv_std[c];
-        } else {
-          v = d.fill[c];
-        }
-        const size_t o = chw ? ((size_t)c * ch + y) * cw + x : ((size_t)y * cw + x) * Co + c;
-        switch (d.out_dtype) {
-          case DALIAMD_FLOAT: static_cast<float *>(d.out)[o] = v; break;
-          case DALIAMD_FLOAT16: static_cast<uint16_t *>(d.out)[o] = Float2HalfAway(v); break;
-          case DALIAMD_UINT8: {
-            const float r = RoundAway(v);
-            static_cast<uint8_t *>(d.out)[o] = (uint8_t)(!(r > 0.0f) ? 0.0f : std::fmin(r, 255.0f));
-          } break;
-          default: {
-            float r = RoundAway(v);
-            r = r != r ? 0.0f : std::fmin(std::fmax(r, -128.0f), 127.0f);
-            static_cast<int8_t *>(d.out)[o] = (int8_t)r;
-          }
-        }
+    const int lo = row_in ? x_lo : cw, hi = row_in ? x_hi : cw;   // outside rows: fill only
+    auto fill = [&](int x0, int x1) {
+      for (int x = x0; x < x1; x++)
+        for (int c = 0; c < Co; c++) out[chw ? c * plane + (size_t)y * cw + x : ((size_t)y * cw + x) * Co + c] = fillv[c];
+    };
+    fill(0, std::min(lo, cw));
+    fill(std::max(hi, lo), cw);
+    if (!row_in || lo >= hi) continue;
+    const int step = d.mirror ? -C : C;
+    const uint8_t *px = d.in + (size_t)sy * d.in_pitch + (size_t)(d.mirror ? d.anchor_x + (cw - 1 - lo) : d.anchor_x + lo) * C;
+    if (chw && C == 3 && Co == 3) {
+      T *o0 = out + (size_t)y * cw, *o1 = o0 + plane, *o2 = o1 + plane;
+      for (int x = lo; x < hi; x++, px += step) {
+        o0[x] = lut[0][px[0]];
+        o1[x] = lut[1][px[1]];
+        o2[x] = lut[2][px[2]];
       }
+    } else {
+      for (int x = lo; x < hi; x++, px += step)
+        for (int c = 0; c < Co; c++)
+          out[chw ? c * plane + (size_t)y * cw + x : ((size_t)y * cw + x) * Co + c] = c < C ? lut[c][px[c]] : fillv[c];
     }
+  }
+}
+}  // namespace
+
+extern "C" int daliamdCmnRunHost(const daliamdCmnDesc *desc) {
+  if (!desc || !desc->in || !desc->out) return Fail("daliamdCmnRunHost: NULL descriptor or buffer");
+  const daliamdCmnDesc &d = *desc;
+  switch (d.out_dtype) {
+    case DALIAMD_FLOAT: CmnRowsLut<uint32_t>(d); break;
+    case DALIAMD_FLOAT16: CmnRowsLut<uint16_t>(d); break;
+    default: CmnRowsLut<uint8_t>(d); break;
   }
   return 0;
 }
