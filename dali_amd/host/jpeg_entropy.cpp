@@ -135,6 +135,8 @@ struct BitReader {
       cnt += 8;
     }
   }
+  // at least 32 valid bits: a symbol (<= 16) and its extra bits (<= 15) without looking at the stream again
+  inline void Need32() { if (cnt < 32) Refill(); }
   inline uint32_t Peek(int n) { return (uint32_t)(buf >> (64 - n)); }
   inline void Drop(int n) { buf <<= n; cnt -= n; }
   inline int Get(int n) { uint32_t v = Peek(n); Drop(n); return (int)v; }
@@ -280,14 +282,14 @@ struct Decoder {
   inline void BlockSeq(BitReader &br, int16_t *blk, int s_idx) {
     int ci = scomp[s_idx];
     const HuffTable &dt = dc[std_[s_idx]], &at = ac[sta[s_idx]];
-    br.Refill();
+    br.Need32();
     int s = DecodeSymbol(br, dt) & 15;  // a (corrupt) table may list categories > 15: keep the bit count sane (the
                                         // GPU decoder's table entries mask the symbol the same way)
-    if (s) { br.Refill(); s = Extend(br.Get(s), s); }
+    if (s) s = Extend(br.Get(s), s);
     last_dc[ci] += s;
     blk[0] = (int16_t)last_dc[ci];
     for (int k = 1; k < 64;) {
-      br.Refill();
+      br.Need32();
       int fa = at.fast_ac[br.Peek(kLookBits)];
       if (fa) {
         k += (fa >> 4) & 15;
@@ -300,7 +302,7 @@ struct Decoder {
       s = rs & 15;
       if (s) {
         k += r;
-        blk[kZZ.v[k++]] = (int16_t)Extend(br.Get(s), s);  // >= 41 bits left after the symbol
+        blk[kZZ.v[k++]] = (int16_t)Extend(br.Get(s), s);  // >= 16 bits left after the symbol
       } else {
         if (r != 15) break;
         k += 16;

@@ -7,8 +7,11 @@
 // is the published libjpeg-turbo arithmetic (jidctint.c "islow", jdsample.c triangle filters, jdcolor.c 16-bit
 // fixed-point BT.601), the same the device kernels implement (csrc/jpeg_idct_math.h, csrc/jpeg_color.hip): both
 // paths produce the same bytes.
+#include <immintrin.h>
+
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -26,18 +29,20 @@ constexpr int32_t F_0_298631336 = 2446, F_0_390180644 = 3196, F_0_541196100 = 44
 inline int32_t Descale(int32_t x, int n) { return (x + (1 << (n - 1))) >> n; }
 
 // one 8-point pass of the islow butterfly (jidctint.c), not yet descaled
-inline void Butterfly8(const int32_t in[8], int32_t out[8]) {
-  int32_t z2 = in[2], z3 = in[6];
-  int32_t z1 = (z2 + z3) * F_0_541196100;
-  int32_t tmp2 = z1 + z3 * (-F_1_847759065);
-  int32_t tmp3 = z1 + z2 * F_0_765366865;
-  int32_t tmp0 = (in[0] + in[4]) * (1 << kConstBits);
-  int32_t tmp1 = (in[0] - in[4]) * (1 << kConstBits);
-  const int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+// (T = int32_t, or eight of them side by side: wrap-around integer arithmetic lane by lane either way)
+template <typename T>
+__attribute__((always_inline)) inline void Butterfly8(const T in[8], T out[8]) {
+  T z2 = in[2], z3 = in[6];
+  T z1 = (z2 + z3) * F_0_541196100;
+  T tmp2 = z1 + z3 * (-F_1_847759065);
+  T tmp3 = z1 + z2 * F_0_765366865;
+  T tmp0 = (in[0] + in[4]) * (1 << kConstBits);
+  T tmp1 = (in[0] - in[4]) * (1 << kConstBits);
+  const T tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
   tmp0 = in[7]; tmp1 = in[5]; tmp2 = in[3]; tmp3 = in[1];
   z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
-  int32_t z4 = tmp1 + tmp3;
-  const int32_t z5 = (z3 + z4) * F_1_175875602;
+  T z4 = tmp1 + tmp3;
+  const T z5 = (z3 + z4) * F_1_175875602;
   tmp0 *= F_0_298631336; tmp1 *= F_2_053119869; tmp2 *= F_3_072711026; tmp3 *= F_1_501321110;
   z1 *= -F_0_899976223; z2 *= -F_2_562915447; z3 *= -F_1_961570560; z4 *= -F_0_390180644;
   z3 += z5; z4 += z5;
@@ -53,9 +58,65 @@ inline uint8_t RangeLimit(int32_t x) {
   return (uint8_t)std::min(std::max(v, 0), 255);
 }
 
+typedef int32_t v8i __attribute__((vector_size(32)));
+
+// 8 x 8 transpose of 32-bit elements
+__attribute__((target("avx2"), always_inline)) inline void Transpose8(const v8i r[8], v8i out[8]) {
+  const __m256i t0 = _mm256_unpacklo_epi32((__m256i)r[0], (__m256i)r[1]), t1 = _mm256_unpackhi_epi32((__m256i)r[0], (__m256i)r[1]);
+  const __m256i t2 = _mm256_unpacklo_epi32((__m256i)r[2], (__m256i)r[3]), t3 = _mm256_unpackhi_epi32((__m256i)r[2], (__m256i)r[3]);
+  const __m256i t4 = _mm256_unpacklo_epi32((__m256i)r[4], (__m256i)r[5]), t5 = _mm256_unpackhi_epi32((__m256i)r[4], (__m256i)r[5]);
+  const __m256i t6 = _mm256_unpacklo_epi32((__m256i)r[6], (__m256i)r[7]), t7 = _mm256_unpackhi_epi32((__m256i)r[6], (__m256i)r[7]);
+  const __m256i u0 = _mm256_unpacklo_epi64(t0, t2), u1 = _mm256_unpackhi_epi64(t0, t2);
+  const __m256i u2 = _mm256_unpacklo_epi64(t1, t3), u3 = _mm256_unpackhi_epi64(t1, t3);
+  const __m256i u4 = _mm256_unpacklo_epi64(t4, t6), u5 = _mm256_unpackhi_epi64(t4, t6);
+  const __m256i u6 = _mm256_unpacklo_epi64(t5, t7), u7 = _mm256_unpackhi_epi64(t5, t7);
+  out[0] = (v8i)_mm256_permute2x128_si256(u0, u4, 0x20);
+  out[1] = (v8i)_mm256_permute2x128_si256(u1, u5, 0x20);
+  out[2] = (v8i)_mm256_permute2x128_si256(u2, u6, 0x20);
+  out[3] = (v8i)_mm256_permute2x128_si256(u3, u7, 0x20);
+  out[4] = (v8i)_mm256_permute2x128_si256(u0, u4, 0x31);
+  out[5] = (v8i)_mm256_permute2x128_si256(u1, u5, 0x31);
+  out[6] = (v8i)_mm256_permute2x128_si256(u2, u6, 0x31);
+  out[7] = (v8i)_mm256_permute2x128_si256(u3, u7, 0x31);
+}
+
+// The same two passes with the eight columns (then the eight rows) of a block side by side in one register: the
+// integer arithmetic of every lane is that of the scalar code below
+__attribute__((target("avx2")))
+void IdctComponentAvx2(const int16_t *coef, const uint16_t *quant, int blocks_x, int blocks_y, uint8_t *plane) {
+  const int pitch = blocks_x * 8;
+  v8i q[8];
+  for (int col = 0; col < 8; col++) q[col] = (v8i)_mm256_cvtepu16_epi32(_mm_loadu_si128((const __m128i *)(quant + col * 8)));
+  for (int by = 0; by < blocks_y; by++)
+    for (int bx = 0; bx < blocks_x; bx++) {
+      const int16_t *b = coef + ((size_t)by * blocks_x + bx) * 64;
+      v8i v[8], in[8], o[8], ws[8];
+      // v[col] = the dequantised column (lanes = rows); in[row] = lanes over the columns
+      for (int col = 0; col < 8; col++)
+        v[col] = (v8i)_mm256_mullo_epi32(_mm256_cvtepi16_epi32(_mm_loadu_si128((const __m128i *)(b + col * 8))), (__m256i)q[col]);
+      Transpose8(v, in);
+      Butterfly8(in, o);
+      for (int r = 0; r < 8; r++) ws[r] = (o[r] + (1 << (kConstBits - kPass1Bits - 1))) >> (kConstBits - kPass1Bits);
+      Transpose8(ws, in);   // in[column] = lanes over the rows
+      Butterfly8(in, o);    // o[column] = lanes over the rows
+      for (int c = 0; c < 8; c++) {
+        const v8i x = (o[c] + (1 << (kConstBits + kPass1Bits + 3 - 1))) >> (kConstBits + kPass1Bits + 3);
+        const v8i w = ((x & 1023) ^ 512) - 512 + 128;
+        o[c] = (v8i)_mm256_min_epi32(_mm256_max_epi32((__m256i)w, _mm256_setzero_si256()), _mm256_set1_epi32(255));
+      }
+      Transpose8(o, ws);    // ws[row] = lanes over the columns
+      for (int r = 0; r < 8; r++) {
+        const __m128i p16 = _mm_packs_epi32(_mm256_castsi256_si128((__m256i)ws[r]), _mm256_extracti128_si256((__m256i)ws[r], 1));
+        _mm_storel_epi64((__m128i *)(plane + (size_t)(by * 8 + r) * pitch + bx * 8), _mm_packus_epi16(p16, p16));
+      }
+    }
+}
+
 // coef: [blocks_y][blocks_x][64] column-major blocks; quant: 64 values in the same element order -> plane rows of
 // blocks_x * 8 samples
 void IdctComponent(const int16_t *coef, const uint16_t *quant, int blocks_x, int blocks_y, uint8_t *plane) {
+  static const bool avx2 = __builtin_cpu_supports("avx2") && !getenv("DALI_AMD_HOST_NO_AVX2");   // (the variable: tests)
+  if (avx2) return IdctComponentAvx2(coef, quant, blocks_x, blocks_y, plane);
   const int pitch = blocks_x * 8;
   for (int by = 0; by < blocks_y; by++)
     for (int bx = 0; bx < blocks_x; bx++) {
@@ -84,39 +145,53 @@ struct Comp {
   int pitch, mode, hx, vx, dw, dh;
 };
 
+// Row kernels of the fancy up-sampling, written for the vectoriser: `t` holds the (vertically blended) chroma row
+// with one copy of the edge sample on either side - the clamped neighbour index of the edge columns - and the row is
+// produced for all 2 * dw columns (the caller's row buffers have room for the odd one past the image width)
+__attribute__((target_clones("avx2", "default")))
+void H2V2Row(const uint8_t *p0, const uint8_t *p1, int dw, int16_t *t, uint8_t *out) {
+  for (int k = 0; k < dw; k++) t[k + 1] = (int16_t)(p0[k] * 3 + p1[k]);
+  t[0] = t[1];
+  t[dw + 1] = t[dw];
+  for (int k = 0; k < dw; k++) {
+    out[2 * k] = (uint8_t)((t[k + 1] * 3 + t[k] + 8) >> 4);
+    out[2 * k + 1] = (uint8_t)((t[k + 1] * 3 + t[k + 2] + 7) >> 4);
+  }
+}
+__attribute__((target_clones("avx2", "default")))
+void H2V1Row(const uint8_t *p, int dw, int16_t *t, uint8_t *out) {
+  for (int k = 0; k < dw; k++) t[k + 1] = p[k];
+  t[0] = t[1];
+  t[dw + 1] = t[dw];
+  for (int k = 0; k < dw; k++) {
+    out[2 * k] = (uint8_t)((t[k + 1] * 3 + t[k] + 1) >> 2);
+    out[2 * k + 1] = (uint8_t)((t[k + 1] * 3 + t[k + 2] + 2) >> 2);
+  }
+}
+__attribute__((target_clones("avx2", "default")))
+void H1V2Row(const uint8_t *p0, const uint8_t *p1, int bias, int width, uint8_t *out) {
+  for (int x = 0; x < width; x++) out[x] = (uint8_t)((p0[x] * 3 + p1[x] + bias) >> 2);
+}
+
 // one output row of one component, up-sampled to the image width (jdsample.c: h2v1 / h2v2 / h1v2 fancy, box otherwise;
 // the edge columns / rows are the general formulas with the neighbour index clamped)
-void UpsampleRow(const Comp &c, int y, int width, uint8_t *out) {
+// `out` has room for width + 1 samples, `scratch` for dw + 2 values
+void UpsampleRow(const Comp &c, int y, int width, uint8_t *out, int16_t *scratch) {
   switch (c.mode) {
     case kFull:
       memcpy(out, c.plane + (size_t)y * c.pitch, width);
       break;
-    case kH2V1: {
-      const uint8_t *p = c.plane + (size_t)y * c.pitch;
-      for (int x = 0; x < width; x++) {
-        const int k = x >> 1;
-        const int s = p[k];
-        out[x] = (x & 1) ? (uint8_t)((s * 3 + p[ClampI(k + 1, 0, c.dw - 1)] + 2) >> 2)
-                         : (uint8_t)((s * 3 + p[ClampI(k - 1, 0, c.dw - 1)] + 1) >> 2);
-      }
+    case kH2V1:
+      H2V1Row(c.plane + (size_t)y * c.pitch, c.dw, scratch, out);
       break;
-    }
     case kH2V2: {
       const int r = y >> 1, r1 = ClampI((y & 1) ? r + 1 : r - 1, 0, c.dh - 1);
-      const uint8_t *p0 = c.plane + (size_t)r * c.pitch, *p1 = c.plane + (size_t)r1 * c.pitch;
-      for (int x = 0; x < width; x++) {
-        const int k = x >> 1;
-        const int kn = ClampI((x & 1) ? k + 1 : k - 1, 0, c.dw - 1);
-        const int v = p0[k] * 3 + p1[k], vn = p0[kn] * 3 + p1[kn];
-        out[x] = (uint8_t)((v * 3 + vn + ((x & 1) ? 7 : 8)) >> 4);
-      }
+      H2V2Row(c.plane + (size_t)r * c.pitch, c.plane + (size_t)r1 * c.pitch, c.dw, scratch, out);
       break;
     }
     case kH1V2: {
       const int r = y >> 1, r1 = ClampI((y & 1) ? r + 1 : r - 1, 0, c.dh - 1);
-      const int bias = (y & 1) ? 2 : 1;
-      const uint8_t *p0 = c.plane + (size_t)r * c.pitch, *p1 = c.plane + (size_t)r1 * c.pitch;
-      for (int x = 0; x < width; x++) out[x] = (uint8_t)((p0[x] * 3 + p1[x] + bias) >> 2);
+      H1V2Row(c.plane + (size_t)r * c.pitch, c.plane + (size_t)r1 * c.pitch, (y & 1) ? 2 : 1, width, out);
       break;
     }
     default: {
@@ -146,6 +221,19 @@ inline void YccToRgb(int y, int cb, int cr, uint8_t *rgb) {
   rgb[0] = Clamp8(y + ((Fix(1.40200) * v + kOneHalf) >> kScaleBits));
   rgb[1] = Clamp8(y + (((-Fix(0.34414)) * u + kOneHalf + (-Fix(0.71414)) * v) >> kScaleBits));
   rgb[2] = Clamp8(y + ((Fix(1.77200) * u + kOneHalf) >> kScaleBits));
+}
+
+__attribute__((target_clones("avx2", "default")))
+void YccRowToRgb(const uint8_t *y, const uint8_t *cb, const uint8_t *cr, int n, uint8_t *rgb) {
+  for (int x = 0; x < n; x++) {
+    const int u = cb[x] - 128, v = cr[x] - 128, yy = y[x];
+    const int r = yy + ((Fix(1.40200) * v + kOneHalf) >> kScaleBits);
+    const int g = yy + (((-Fix(0.34414)) * u + kOneHalf + (-Fix(0.71414)) * v) >> kScaleBits);
+    const int b = yy + ((Fix(1.77200) * u + kOneHalf) >> kScaleBits);
+    rgb[3 * x] = (uint8_t)std::min(std::max(r, 0), 255);
+    rgb[3 * x + 1] = (uint8_t)std::min(std::max(g, 0), 255);
+    rgb[3 * x + 2] = (uint8_t)std::min(std::max(b, 0), 255);
+  }
 }
 
 }  // namespace
@@ -221,10 +309,12 @@ extern "C" int daliamdJpegDecodeHost(const uint8_t *data, size_t size, const dal
   const bool turned = orientation >= 5 && orientation <= 8;
   if (pitch < (int64_t)oc * (turned ? H : W)) return Fail("daliamdJpegDecodeHost: pitch too small");
   // entropy decode
-  std::vector<int16_t> coef_store;
+  // per-thread work buffers, kept between calls: a fresh half-megabyte allocation per image is a round of page faults
+  static thread_local std::vector<int16_t> coef_store, scratch;
+  static thread_local std::vector<uint8_t> plane_store, rows, rgb, px;
   size_t total = 0;
   for (int c = 0; c < nc; c++) total += (size_t)info->coef_elems[c];
-  coef_store.resize(total);
+  if (coef_store.size() < total) coef_store.resize(total);
   int16_t *coef[4] = {nullptr, nullptr, nullptr, nullptr};
   {
     size_t off = 0;
@@ -235,7 +325,7 @@ extern "C" int daliamdJpegDecodeHost(const uint8_t *data, size_t size, const dal
   // planes: the luma plane alone is enough for a gray output of a YCbCr / gray stream (jdcolor.c grayscale_convert)
   const bool luma_only = oc == 1 && (nc == 1 || (nc == 3 && info->color != 2));
   const int nplanes = luma_only ? 1 : nc;
-  std::vector<uint8_t> plane_store(total);
+  if (plane_store.size() < total) plane_store.resize(total);
   Comp comps[4];
   {
     size_t off = 0;
@@ -250,10 +340,13 @@ extern "C" int daliamdJpegDecodeHost(const uint8_t *data, size_t size, const dal
   const int base_color = info->color & 7;
   const bool inverted = (info->color & 8) != 0;
   // rows: upsample, convert to RGB, to the output format, place
-  std::vector<uint8_t> rows((size_t)4 * W), rgb((size_t)3 * W), px((size_t)3 * W);
+  const size_t rs = (size_t)W + 16;   // row stride of the component rows: room for the odd column of a 2x row
+  if (rows.size() < 4 * rs) rows.resize(4 * rs);
+  if (rgb.size() < (size_t)3 * W) { rgb.resize((size_t)3 * W); px.resize((size_t)3 * W); }
+  if (scratch.size() < rs) scratch.resize(rs);
   for (int y = 0; y < H; y++) {
-    for (int c = 0; c < nplanes; c++) UpsampleRow(comps[c], y, W, rows.data() + (size_t)c * W);
-    const uint8_t *r0 = rows.data(), *r1 = r0 + W, *r2 = r1 + W, *r3 = r2 + W;
+    for (int c = 0; c < nplanes; c++) UpsampleRow(comps[c], y, W, rows.data() + c * rs, scratch.data());
+    const uint8_t *r0 = rows.data(), *r1 = r0 + rs, *r2 = r1 + rs, *r3 = r2 + rs;
     if (luma_only) {
       memcpy(px.data(), r0, W);
     } else {
@@ -262,7 +355,7 @@ extern "C" int daliamdJpegDecodeHost(const uint8_t *data, size_t size, const dal
       } else if (nc == 3 && base_color == 2) {  // stored as RGB (Adobe transform 0)
         for (int x = 0; x < W; x++) { rgb[3 * x] = r0[x]; rgb[3 * x + 1] = r1[x]; rgb[3 * x + 2] = r2[x]; }
       } else if (nc == 3) {
-        for (int x = 0; x < W; x++) YccToRgb(r0[x], r1[x], r2[x], &rgb[3 * x]);
+        YccRowToRgb(r0, r1, r2, W, rgb.data());
       } else if (base_color == 4) {  // YCCK -> CMYK (jdcolor.c ycck_cmyk_convert: C, M, Y = 255 - R, G, B; K as it is)
         for (int x = 0; x < W; x++) {
           uint8_t t[3];

@@ -167,3 +167,44 @@ def test_cpu_resize_other_element_types_match_oracle():
                 got = out.at(i)
                 assert got.dtype == ref.dtype and got.shape == ref.shape, (np_t, size, got.dtype, ref.dtype)
                 assert np.array_equal(got, ref), (np_t, size, dtype, i, np.abs(got.astype(np.float64) - ref).max())
+
+
+def test_scalar_and_avx2_idct_give_the_oracle_bytes(tmp_path):
+    """decoders.image(device="cpu") picks the eight-lanes-per-register inverse DCT where the CPU has AVX2; the scalar
+    loop it replaces must stay the same function (DALI_AMD_HOST_NO_AVX2=1 selects it: a fresh process, the choice is
+    made once).  Both against the oracle on 4:2:0 / 4:4:4 / 4:2:2 / gray streams of ragged sizes."""
+    import subprocess
+    import sys
+    rng = np.random.default_rng(77)
+    cases = [((37, 53), "4:2:0", 75), ((64, 48), "4:4:4", 90), ((121, 200), "4:2:2", 60), ((50, 70), "4:2:0", 98)]
+    paths = []
+    for i, ((h, w), sub, q) in enumerate(cases):
+        p = tmp_path / f"s{i}.jpg"
+        p.write_bytes(encode_jpeg(synth_image(rng, h, w), q, subsampling=sub))
+        paths.append(str(p))
+    g = tmp_path / "g.jpg"
+    buf = io.BytesIO()
+    Image.fromarray(synth_image(rng, 45, 67)[:, :, 0]).save(buf, "JPEG", quality=80)
+    g.write_bytes(buf.getvalue())
+    paths.append(str(g))
+    script = (
+        "import sys, numpy as np\n"
+        "from dali_amd import fn, types\n"
+        "from dali_amd.pipeline import Pipeline\n"
+        "files = sys.argv[2:]\n"
+        "pipe = Pipeline(batch_size=len(files), num_threads=2, device_id=None)\n"
+        "with pipe:\n"
+        "    enc, _ = fn.readers.file(files=files)\n"
+        "    pipe.set_outputs(fn.decoders.image(enc, device='cpu', output_type=types.RGB))\n"
+        "pipe.build()\n"
+        "(out,) = pipe.run()\n"
+        "np.savez(sys.argv[1], *[np.asarray(out.at(i)) for i in range(len(files))])\n")
+    for tag, env in (("avx2", {}), ("scalar", {"DALI_AMD_HOST_NO_AVX2": "1"})):
+        dst = str(tmp_path / f"{tag}.npz")
+        e = dict(os.environ, **env)
+        e["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + os.pathsep + e.get("PYTHONPATH", "")
+        subprocess.run([sys.executable, "-c", script, dst] + paths, check=True, env=e, timeout=300)
+        got = np.load(dst)
+        for i, p in enumerate(paths):
+            ref = O.jpeg_decode_rgb(open(p, "rb").read())
+            assert np.array_equal(got[f"arr_{i}"], ref), (tag, p)
