@@ -29,6 +29,64 @@ inline uint8_t SatU8(float v) {
   const int i = (int)v;
   return (uint8_t)(i + ((v - (float)i) >= 0.5f ? 1 : 0));
 }
+// the same function without branches, for loops the compiler turns into vector code: NaN and everything <= 0 become 0,
+// everything from 255.5 on becomes exactly 255
+inline uint8_t SatU8Flat(float v) {
+  float c = v > 0.0f ? v : 0.0f;
+  c = c < 255.5f ? c : 255.0f;
+  const int i = (int)c;
+  return (uint8_t)(i + ((c - (float)i) >= 0.5f));
+}
+// (int)std::floor(f) without the library call (baseline x86-64 has no rounding instruction); far outside the range of
+// image coordinates the library call decides
+inline int FloorI(float f) {
+  if (!(f > -1e9f && f < 1e9f)) return (int)std::floor(f);
+  const int i = (int)f;
+  return i - ((float)i > f);
+}
+
+// whole-row loops, one clone per instruction set: the element arithmetic is the scalar code's
+// dst[e] = sum over k of rows[k][e] * w[k], taps in order, product then sum - sixteen elements at a time with the
+// running sums in registers (every element still sees acc = acc + sample * weight for k = 0, 1, ...)
+__attribute__((target_clones("avx2", "default")))
+void TapSum(float *dst, const float *const *rows, const float *w, int taps, size_t n) {
+  size_t e = 0;
+  for (; e + 16 <= n; e += 16) {
+    float a[16];
+    for (int j = 0; j < 16; j++) a[j] = 0.0f;
+    for (int k = 0; k < taps; k++) {
+      const float *r = rows[k] + e;
+      const float wk = w[k];
+      for (int j = 0; j < 16; j++) a[j] += r[j] * wk;
+    }
+    for (int j = 0; j < 16; j++) dst[e + j] = a[j];
+  }
+  for (; e < n; e++) {
+    float a = 0.0f;
+    for (int k = 0; k < taps; k++) a += rows[k][e] * w[k];
+    dst[e] = a;
+  }
+}
+__attribute__((target_clones("avx2", "default")))
+void RowU8ToFloat(float *dst, const uint8_t *src, size_t n) {
+  for (size_t e = 0; e < n; e++) dst[e] = (float)src[e];
+}
+__attribute__((target_clones("avx2", "default")))
+void RowFloatToU8(uint8_t *dst, const float *src, size_t n) {
+  for (size_t e = 0; e < n; e++) dst[e] = SatU8Flat(src[e]);
+}
+__attribute__((target_clones("avx2", "default")))
+void TwistRow(uint8_t *dst, const uint8_t *src, int w, const float *m, const float *off) {
+  for (int x = 0; x < w; x++) {
+    const float v0 = src[3 * x], v1 = src[3 * x + 1], v2 = src[3 * x + 2];
+    float s0 = m[0] * v0; s0 += m[1] * v1; s0 += m[2] * v2;
+    float s1 = m[3] * v0; s1 += m[4] * v1; s1 += m[5] * v2;
+    float s2 = m[6] * v0; s2 += m[7] * v1; s2 += m[8] * v2;
+    dst[3 * x] = SatU8Flat(s0 + off[0]);
+    dst[3 * x + 1] = SatU8Flat(s1 + off[1]);
+    dst[3 * x + 2] = SatU8Flat(s2 + off[2]);
+  }
+}
 
 inline int Reflect101(int idx, int size) {
   if (size < 2) return size - 1;
@@ -70,17 +128,32 @@ extern "C" int daliamdWarpAffineHost(const daliamdWarpAffineDesc *d) {
       for (int x = x_tile; x < x_end; x++, sx += dsdx_x, sy += dsdx_y) {
         uint8_t *o = d->out + (size_t)y * d->out_pitch + (size_t)x * C;
         if (d->interp == DALIAMD_INTERP_NN) {
-          const int ix = (int)std::floor(sx), iy = (int)std::floor(sy);
-          for (int c = 0; c < C; c++) o[c] = (uint8_t)fetch(ix, iy, c);
+          const int ix = FloorI(sx), iy = FloorI(sy);
+          if ((unsigned)ix < (unsigned)W && (unsigned)iy < (unsigned)H) {
+            const uint8_t *p = d->in + (size_t)iy * d->in_pitch + (size_t)ix * C;
+            for (int c = 0; c < C; c++) o[c] = p[c];
+          } else {
+            for (int c = 0; c < C; c++) o[c] = (uint8_t)fetch(ix, iy, c);
+          }
         } else {
           const float fx = sx - 0.5f, fy = sy - 0.5f;
-          const int x0 = (int)std::floor(fx), y0 = (int)std::floor(fy);
+          const int x0 = FloorI(fx), y0 = FloorI(fy);
           const float qx = fx - x0, px = 1 - qx, qy = fy - y0;
-          for (int c = 0; c < C; c++) {
-            const float s00 = fetch(x0, y0, c), s01 = fetch(x0 + 1, y0, c), s10 = fetch(x0, y0 + 1, c), s11 = fetch(x0 + 1, y0 + 1, c);
-            const float s0 = s00 * px + s01 * qx;
-            const float s1 = s10 * px + s11 * qx;
-            o[c] = SatU8(s0 + (s1 - s0) * qy);
+          if (x0 >= 0 && y0 >= 0 && x0 + 1 < W && y0 + 1 < H) {   // all four taps inside: no border logic per tap
+            const uint8_t *p0 = d->in + (size_t)y0 * d->in_pitch + (size_t)x0 * C, *p1 = p0 + d->in_pitch;
+            for (int c = 0; c < C; c++) {
+              const float s00 = p0[c], s01 = p0[C + c], s10 = p1[c], s11 = p1[C + c];
+              const float s0 = s00 * px + s01 * qx;
+              const float s1 = s10 * px + s11 * qx;
+              o[c] = SatU8(s0 + (s1 - s0) * qy);
+            }
+          } else {
+            for (int c = 0; c < C; c++) {
+              const float s00 = fetch(x0, y0, c), s01 = fetch(x0 + 1, y0, c), s10 = fetch(x0, y0 + 1, c), s11 = fetch(x0 + 1, y0 + 1, c);
+              const float s0 = s00 * px + s01 * qx;
+              const float s1 = s10 * px + s11 * qx;
+              o[c] = SatU8(s0 + (s1 - s0) * qy);
+            }
           }
         }
       }
@@ -95,34 +168,28 @@ extern "C" int daliamdGaussianBlurHost(const daliamdGaussianBlurDesc *d) {
       !(d->size_x & 1) || !(d->size_y & 1))
     return Fail("daliamdGaussianBlurHost: window sizes must be odd and at most %d", DALIAMD_MAX_BLUR_WINDOW);
   const int H = d->h, W = d->w, C = d->channels, rx = (d->size_x - 1) / 2, ry = (d->size_y - 1) / 2;
-  // Both passes run tap-outer / element-inner over a whole row: every element still accumulates its taps in order
-  // (acc = acc + sample * weight, multiply and add rounded separately), and the element loop vectorises.
+  // Both passes: sixteen elements of a row at a time, their taps in order (acc = acc + sample * weight, multiply and
+  // add rounded separately) with the sums in registers.
   const size_t rowlen = (size_t)W * C;
   std::vector<float> tmp((size_t)H * rowlen), pad((size_t)(W + 2 * rx) * C), acc(rowlen);
+  std::vector<const float *> taps(DALIAMD_MAX_BLUR_WINDOW);
   for (int y = 0; y < H; y++) {
     const uint8_t *row = d->in + (size_t)y * d->in_pitch;
-    for (int x = -rx; x < W + rx; x++) {   // the row with its reflected borders, as floats
-      const uint8_t *src = row + (size_t)Reflect101(x, W) * C;
-      float *dst = pad.data() + (size_t)(x + rx) * C;
-      for (int c = 0; c < C; c++) dst[c] = (float)src[c];
-    }
-    std::fill(acc.begin(), acc.end(), 0.0f);
-    for (int k = 0; k < d->size_x; k++) {
-      const float w = d->window_x[k];
-      const float *p = pad.data() + (size_t)k * C;
-      for (size_t e = 0; e < rowlen; e++) acc[e] += p[e] * w;
-    }
-    std::copy(acc.begin(), acc.end(), tmp.begin() + (size_t)y * rowlen);
+    // the row with its reflected borders, as floats
+    RowU8ToFloat(pad.data() + (size_t)rx * C, row, rowlen);
+    for (int side = 0; side < 2; side++)
+      for (int x = side ? W : -rx; x < (side ? W + rx : 0); x++) {
+        const uint8_t *src = row + (size_t)Reflect101(x, W) * C;
+        float *dst = pad.data() + (size_t)(x + rx) * C;
+        for (int c = 0; c < C; c++) dst[c] = (float)src[c];
+      }
+    for (int k = 0; k < d->size_x; k++) taps[k] = pad.data() + (size_t)k * C;
+    TapSum(tmp.data() + (size_t)y * rowlen, taps.data(), d->window_x, d->size_x, rowlen);
   }
   for (int y = 0; y < H; y++) {
-    std::fill(acc.begin(), acc.end(), 0.0f);
-    for (int k = 0; k < d->size_y; k++) {
-      const float w = d->window_y[k];
-      const float *r = tmp.data() + (size_t)Reflect101(y - ry + k, H) * rowlen;
-      for (size_t e = 0; e < rowlen; e++) acc[e] += w * r[e];
-    }
-    uint8_t *o = d->out + (size_t)y * d->out_pitch;
-    for (size_t e = 0; e < rowlen; e++) o[e] = SatU8(acc[e]);
+    for (int k = 0; k < d->size_y; k++) taps[k] = tmp.data() + (size_t)Reflect101(y - ry + k, H) * rowlen;
+    TapSum(acc.data(), taps.data(), d->window_y, d->size_y, rowlen);
+    RowFloatToU8(d->out + (size_t)y * d->out_pitch, acc.data(), rowlen);
   }
   return 0;
 }
@@ -140,15 +207,7 @@ extern "C" int daliamdPointwiseHost(const daliamdPointwiseDesc *d) {
       if (dst != src) std::memmove(dst, src, (size_t)d->w * C);
       continue;
     }
-    for (int x = 0; x < d->w; x++) {
-      const float v0 = src[3 * x], v1 = src[3 * x + 1], v2 = src[3 * x + 2];
-      for (int i = 0; i < 3; i++) {
-        float s = d->matrix[3 * i] * v0;
-        s += d->matrix[3 * i + 1] * v1;
-        s += d->matrix[3 * i + 2] * v2;
-        dst[3 * x + i] = SatU8(s + d->offset[i]);
-      }
-    }
+    TwistRow(dst, src, d->w, d->matrix, d->offset);
   }
   uint8_t fill[4];
   for (int c = 0; c < 4; c++) fill[c] = SatU8(d->fill[c]);
