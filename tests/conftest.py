@@ -19,4 +19,10 @@ def _built_libraries():
     import subprocess
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "dali_amd", "host")])
+    if os.environ.get("DALI_AMD_HIPEMU"):
+        # developer switch: run the selected tests (the gpu-marked ones included) on the CPU model of the kernels
+        # (tools/hipemu); DALI_AMD_HIPEMU=address for the AddressSanitizer build (needs LD_PRELOAD of the runtime)
+        from tests import hipemu_env
+        san = os.environ["DALI_AMD_HIPEMU"]
+        hipemu_env.activate("" if san in ("1", "on") else san)
     yield

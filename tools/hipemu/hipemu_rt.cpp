@@ -1,0 +1,410 @@
+// hipemu runtime: fibers, the workgroup scheduler, wave collectives, allocation.  TEST INFRASTRUCTURE ONLY
+// (see include/hip/hip_runtime.h in this directory).
+#include <hip/hip_runtime.h>
+
+#include <sys/mman.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+extern "C" void hipemu_switch(void **save_sp, void *load_sp);
+asm(R"(
+.text
+.hidden hipemu_switch
+.globl hipemu_switch
+.type hipemu_switch,@function
+hipemu_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size hipemu_switch,.-hipemu_switch
+)");
+
+namespace hipemu {
+
+thread_local ThreadState tls;
+
+namespace {
+
+enum State : uint8_t { kReady, kWaitWave, kWaitBlock, kDone };
+
+int EnvInt(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+
+}  // namespace
+
+struct Lane {
+  void *sp;
+  State state;
+  dim3 tid;
+  Op op;
+  int arg, width, in_bytes, out_bytes;
+  int site;
+  const void *address;
+  void *out;
+  int barrier_pred, barrier_or;
+  alignas(16) unsigned char in[32];
+};
+
+namespace {
+
+struct Worker {
+  void *sched_sp = nullptr;
+  Lane *lanes = nullptr;
+  int max_lanes = 0;
+  char *stacks = nullptr;
+  size_t stride = 0, stack_bytes = 0;
+  const std::function<void()> *body = nullptr;
+  Lane *current = nullptr;
+  std::vector<char> dyn_shared;
+  ~Worker() {
+    if (stacks) munmap(stacks, stride * (size_t)max_lanes);
+    delete[] lanes;
+  }
+  void Reserve(int n) {
+    if (n <= max_lanes) return;
+    if (stacks) munmap(stacks, stride * (size_t)max_lanes);
+    delete[] lanes;
+    stack_bytes = (size_t)EnvInt("HIPEMU_STACK_KB", 256) << 10;
+    stride = stack_bytes + 4096;  // one inaccessible page under every stack
+    max_lanes = std::max(n, 1024);
+    stacks = (char *)mmap(nullptr, stride * (size_t)max_lanes, PROT_READ | PROT_WRITE,
+                          MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (stacks == MAP_FAILED) { perror("hipemu: mmap of the fiber stacks"); abort(); }
+    for (int i = 0; i < max_lanes; i++) mprotect(stacks + stride * (size_t)i, 4096, PROT_NONE);
+    lanes = new Lane[max_lanes];
+  }
+};
+thread_local Worker worker;
+
+void FiberEntry() {
+  Worker &w = worker;
+  (*w.body)();
+  Worker &w2 = worker;
+  w2.current->state = kDone;
+  hipemu_switch(&w2.current->sp, w2.sched_sp);
+  __builtin_trap();
+}
+
+void RunLane(Worker &w, Lane *l) {
+  w.current = l;
+  tls.thread_idx = l->tid;
+  tls.lane = l;
+  hipemu_switch(&w.sched_sp, l->sp);
+}
+
+[[noreturn]] void Die(const char *what) {
+  fprintf(stderr, "hipemu: %s (block %u,%u,%u)\n", what, tls.block_idx.x, tls.block_idx.y, tls.block_idx.z);
+  abort();
+}
+
+std::atomic<long> g_inactive_reads{0};
+
+// One group of lanes of a wave (bit i of `mask` = lane base + i) waits at the same collective: compute what each gets.
+void Resolve(Lane *wave, int nlanes, uint64_t mask) {
+  (void)nlanes;
+  int first = __builtin_ctzll(mask);
+  const Op op = wave[first].op;
+  switch (op) {
+    case kWaveBarrier: break;
+    case kBallot: {
+      uint64_t r = 0;
+      for (uint64_t m = mask; m; m &= m - 1) {
+        int i = __builtin_ctzll(m);
+        int pred;
+        memcpy(&pred, wave[i].in, sizeof(pred));
+        if (pred) r |= 1ull << i;
+      }
+      for (uint64_t m = mask; m; m &= m - 1) memcpy(wave[__builtin_ctzll(m)].out, &r, sizeof(r));
+    } break;
+    case kFirstLane:
+      for (uint64_t m = mask; m; m &= m - 1) memcpy(wave[__builtin_ctzll(m)].out, wave[first].in, 4);
+      break;
+    case kShflIdx: case kShflUp: case kShflDown: case kShflXor:
+      for (uint64_t m = mask; m; m &= m - 1) {
+        int i = __builtin_ctzll(m);
+        Lane &l = wave[i];
+        const int w = l.width, sb = i & ~(w - 1);
+        int src;
+        if (op == kShflIdx) src = sb + (l.arg & (w - 1));
+        else if (op == kShflUp) { src = i - l.arg; if (src < sb) src = i; }
+        else if (op == kShflDown) { src = i + l.arg; if (src >= sb + w) src = i; }
+        else { src = i ^ l.arg; if (src >= sb + w) src = i; }
+        if (src < 0 || src > 63 || !((mask >> src) & 1)) {
+          // a lane that is not there: the hardware's ds_bpermute hands out 0
+          g_inactive_reads++;
+          memset(l.out, 0, (size_t)l.out_bytes);
+        } else {
+          memcpy(l.out, wave[src].in, (size_t)l.out_bytes);
+        }
+      }
+      break;
+    case kMfma16x16x4F32: {
+      if (mask != ~0ull) Die("MFMA with inactive lanes");
+      float a[64], b[64], c[64][4];
+      for (int l = 0; l < 64; l++) {
+        float in[6];
+        memcpy(in, wave[l].in, sizeof(in));
+        a[l] = in[0]; b[l] = in[1];
+        for (int v = 0; v < 4; v++) c[l][v] = in[2 + v];
+      }
+      for (int l = 0; l < 64; l++) {
+        float d[4];
+        const int j = l & 15;
+        for (int v = 0; v < 4; v++) {
+          const int i = 4 * (l >> 4) + v;
+          float acc = c[l][v];
+          for (int k = 0; k < 4; k++) acc = fmaf(a[k * 16 + i], b[k * 16 + j], acc);
+          d[v] = acc;
+        }
+        memcpy(wave[l].out, d, sizeof(d));
+      }
+    } break;
+  }
+  for (uint64_t m = mask; m; m &= m - 1) wave[__builtin_ctzll(m)].state = kReady;
+}
+
+void RunBlock(Worker &w, dim3 block, int nthreads) {
+  // fresh fibers
+  for (int t = 0; t < nthreads; t++) {
+    Lane &l = w.lanes[t];
+    l.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+    l.state = kReady;
+    char *top = w.stacks + w.stride * (size_t)t + w.stride;
+    void **sp = reinterpret_cast<void **>(top);
+    *--sp = nullptr;                                  // the return address FiberEntry never uses
+    *--sp = reinterpret_cast<void *>(&FiberEntry);    // popped by hipemu_switch's ret
+    for (int r = 0; r < 6; r++) *--sp = nullptr;      // rbp rbx r12-r15
+    l.sp = sp;
+  }
+  const int nwaves = (nthreads + 63) / 64;
+  for (;;) {
+    int done = 0;
+    for (int wv = 0; wv < nwaves; wv++) {
+      Lane *wave = w.lanes + wv * 64;
+      const int n = std::min(64, nthreads - wv * 64);
+      for (;;) {
+        for (int i = 0; i < n; i++)
+          if (wave[i].state == kReady) RunLane(w, &wave[i]);
+        // the waiting lanes' collective with the lowest code address goes first: the arms of a branch and the body of
+        // a loop come before the code behind them
+        const void *address = nullptr;
+        int site = 0;
+        bool waiting = false;
+        for (int i = 0; i < n; i++)
+          if (wave[i].state == kWaitWave && (!waiting || wave[i].address < address)) {
+            address = wave[i].address; site = wave[i].site; waiting = true;
+          }
+        if (!waiting) break;
+        uint64_t mask = 0;
+        for (int i = 0; i < n; i++)
+          if (wave[i].state == kWaitWave && wave[i].site == site) mask |= 1ull << i;
+        Resolve(wave, n, mask);
+      }
+      for (int i = 0; i < n; i++) done += wave[i].state == kDone;
+    }
+    if (done == nthreads) break;
+    int any = 0;
+    for (int t = 0; t < nthreads; t++)
+      if (w.lanes[t].state == kWaitBlock) any |= w.lanes[t].barrier_pred;
+    for (int t = 0; t < nthreads; t++)
+      if (w.lanes[t].state == kWaitBlock) { w.lanes[t].barrier_or = any; w.lanes[t].state = kReady; }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ launch pool
+struct Job {
+  dim3 grid, block;
+  size_t dyn_shared = 0;
+  const std::function<void()> *body = nullptr;
+  std::atomic<long> next{0};
+  long total = 0;
+};
+
+void WorkOn(Job &job) {
+  Worker &w = worker;
+  const int nthreads = (int)(job.block.x * job.block.y * job.block.z);
+  w.Reserve(nthreads);
+  w.body = job.body;
+  if (w.dyn_shared.size() < job.dyn_shared + 64) w.dyn_shared.resize(job.dyn_shared + 64);
+  ThreadState saved = tls;
+  tls.block_dim = job.block;
+  tls.grid_dim = job.grid;
+  tls.dyn_shared = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(w.dyn_shared.data()) + 63) & ~(uintptr_t)63);
+  for (;;) {
+    long b = job.next.fetch_add(1);
+    if (b >= job.total) break;
+    tls.block_idx = dim3((uint32_t)(b % job.grid.x), (uint32_t)((b / job.grid.x) % job.grid.y),
+                         (uint32_t)(b / ((long)job.grid.x * job.grid.y)));
+    RunBlock(w, job.block, nthreads);
+  }
+  w.current = nullptr;
+  tls = saved;
+}
+
+class Pool {
+ public:
+  static Pool &Get() {
+    static Pool *pool = nullptr;
+    static pid_t owner = 0;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> g(mu);
+    if (!pool || owner != getpid()) {  // a forked child starts its own threads (the parent's do not exist in it)
+      pool = new Pool(std::max(1, EnvInt("HIPEMU_THREADS", (int)std::min(8u, std::thread::hardware_concurrency()))));
+      owner = getpid();
+    }
+    return *pool;
+  }
+  void Run(Job &job) {
+    std::lock_guard<std::mutex> launch(launch_mu_);  // one launch at a time
+    const int helpers = (int)std::min<long>((long)threads_.size(), job.total - 1);
+    if (helpers > 0) {
+      {
+        std::lock_guard<std::mutex> g(mu_);
+        job_ = &job;
+        pending_ = helpers;
+        wanted_ = helpers;
+        generation_++;
+      }
+      cv_.notify_all();
+    }
+    WorkOn(job);
+    if (helpers > 0) {
+      std::unique_lock<std::mutex> g(mu_);
+      done_cv_.wait(g, [&] { return pending_ == 0; });
+      job_ = nullptr;
+    }
+  }
+
+ private:
+  explicit Pool(int n) {
+    for (int i = 1; i < n; i++) threads_.emplace_back([this, i] { Loop(i); });
+    for (auto &t : threads_) t.detach();
+  }
+  void Loop(int index) {
+    long seen = 0;
+    for (;;) {
+      Job *job;
+      {
+        std::unique_lock<std::mutex> g(mu_);
+        cv_.wait(g, [&] { return generation_ != seen; });
+        seen = generation_;
+        if (index > wanted_) continue;
+        job = job_;
+      }
+      WorkOn(*job);
+      {
+        std::lock_guard<std::mutex> g(mu_);
+        if (--pending_ == 0) done_cv_.notify_all();
+      }
+    }
+  }
+  std::vector<std::thread> threads_;
+  std::mutex launch_mu_, mu_;
+  std::condition_variable cv_, done_cv_;
+  Job *job_ = nullptr;
+  int pending_ = 0, wanted_ = 0;
+  long generation_ = 0;
+};
+
+}  // namespace
+
+void Launch(dim3 grid, dim3 block, size_t dyn_shared_bytes, const std::function<void()> &body) {
+  Job job;
+  job.grid = grid;
+  job.block = block;
+  job.dyn_shared = dyn_shared_bytes;
+  job.body = &body;
+  job.total = (long)grid.x * grid.y * grid.z;
+  if (job.total == 0 || block.x * block.y * block.z == 0) return;
+  if (block.x * block.y * block.z > 1024) Die("more than 1024 threads in a workgroup");
+  if (worker.current) Die("nested launch");
+  Pool::Get().Run(job);
+}
+
+int BlockBarrierOr(int pred) {
+  Worker &w = worker;
+  Lane *l = w.current;
+  l->barrier_pred = pred != 0;
+  l->state = kWaitBlock;
+  hipemu_switch(&l->sp, w.sched_sp);
+  return l->barrier_or;
+}
+
+void BlockBarrier() { BlockBarrierOr(0); }
+
+uint64_t Collective(Op op, const void *in, int in_bytes, int arg, int width, void *out, int out_bytes, int site,
+                    const void *address) {
+  Worker &w = worker;
+  Lane *l = w.current;
+  l->op = op;
+  l->arg = arg;
+  l->width = (width <= 0 || width > 64) ? 64 : width;
+  l->in_bytes = in_bytes;
+  l->out_bytes = out_bytes;
+  l->site = site;
+  l->address = address;
+  l->out = out;
+  if (in_bytes) memcpy(l->in, in, (size_t)in_bytes);
+  l->state = kWaitWave;
+  hipemu_switch(&l->sp, w.sched_sp);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ memory, events
+namespace {
+constexpr size_t kSlack = 256;  // the device allocator's granularity is far coarser than a kernel's 16-byte over-read
+void *Alloc(size_t n) {
+  void *p = nullptr;
+  if (posix_memalign(&p, 256, n + kSlack) != 0) return nullptr;
+  if (EnvInt("HIPEMU_POISON", 1)) memset(p, 0xCD, n + kSlack);  // hipMalloc does not hand out zeros either
+  return p;
+}
+}  // namespace
+
+hipError_t Malloc(void **p, size_t n) { *p = Alloc(n); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t Free(void *p) { free(p); return hipSuccess; }
+hipError_t HostMalloc(void **p, size_t n) { *p = Alloc(n); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t HostFree(void *p) { free(p); return hipSuccess; }
+
+}  // namespace hipemu
+
+struct hipemuStream { int unused; };
+struct hipemuEvent { std::chrono::steady_clock::time_point t; };
+
+namespace hipemu {
+hipError_t EventCreate(hipEvent_t *e) { *e = new hipemuEvent(); return hipSuccess; }
+hipError_t EventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+hipError_t EventRecord(hipEvent_t e) { if (e) e->t = std::chrono::steady_clock::now(); return hipSuccess; }
+hipError_t EventElapsed(float *ms, hipEvent_t a, hipEvent_t b) {
+  *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
+  return hipSuccess;
+}
+hipError_t StreamCreate(hipStream_t *s) { *s = new hipemuStream(); return hipSuccess; }
+hipError_t StreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
+}  // namespace hipemu
+
+extern "C" __attribute__((visibility("default"))) long hipemuInactiveLaneReads() {
+  return hipemu::g_inactive_reads.load();
+}
+extern "C" __attribute__((visibility("default"))) int hipemuIsEmulator() { return 1; }
