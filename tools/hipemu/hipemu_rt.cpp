@@ -373,11 +373,13 @@ uint64_t Collective(Op op, const void *in, int in_bytes, int arg, int width, voi
 
 // ------------------------------------------------------------------------------------------------ memory, events
 namespace {
-constexpr size_t kSlack = 256;  // the device allocator's granularity is far coarser than a kernel's 16-byte over-read
+// HIPEMU_SLACK bytes behind every allocation (default 256: the device allocator's granularity is far coarser than the
+// 16-byte accesses with which some kernels read up to the end of a row; 0 under AddressSanitizer shows every such access)
 void *Alloc(size_t n) {
+  static const size_t slack = (size_t)EnvInt("HIPEMU_SLACK", 256);
   void *p = nullptr;
-  if (posix_memalign(&p, 256, n + kSlack) != 0) return nullptr;
-  if (EnvInt("HIPEMU_POISON", 1)) memset(p, 0xCD, n + kSlack);  // hipMalloc does not hand out zeros either
+  if (posix_memalign(&p, 256, n + slack) != 0) return nullptr;
+  if (EnvInt("HIPEMU_POISON", 1)) memset(p, 0xCD, n + slack);  // hipMalloc does not hand out zeros either
   return p;
 }
 }  // namespace

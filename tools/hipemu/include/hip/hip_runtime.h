@@ -37,6 +37,8 @@
 #define __noinline__ __attribute__((noinline, convergent))
 #define __launch_bounds__(...)
 #define amdgpu_waves_per_eu(...) unused
+// pointers are host pointers: __attribute__((address_space(1))) becomes the empty attribute
+#define address_space(n)
 #define amdgpu_flat_work_group_size(...) unused
 #define __shared__ static thread_local
 #define __constant__ static const
@@ -68,6 +70,12 @@ HIPEMU_VEC4(float4, float, 16)
 #undef HIPEMU_VEC2
 #undef HIPEMU_VEC3
 #undef HIPEMU_VEC4
+
+namespace hipemu {
+// 12 bytes, stored and loaded as 12 bytes: the x86 front end widens a 3-element ext_vector_type to 16 (the amdgcn one
+// keeps it: global_load / store_dwordx3).  The build's sed puts this in place of the kernels' typedef.
+template <typename T> struct Vec3 { T x, y, z; };
+}  // namespace hipemu
 
 // ------------------------------------------------------------------------------------------------ runtime types
 typedef enum hipError_t {
@@ -249,49 +257,63 @@ __attribute__((noinline, convergent)) hipemu_float4_vec Mfma16x16x4F32(float a, 
 }  // namespace hipemu
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(...) ::hipemu::Mfma16x16x4F32<__COUNTER__>(__VA_ARGS__)
 
-// atomics (workgroups run on several OS threads)
-template <typename T> static inline T hipemu_atomic_add_int(T *p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
-static inline int atomicAdd(int *p, int v) { return hipemu_atomic_add_int(p, v); }
-static inline unsigned atomicAdd(unsigned *p, unsigned v) { return hipemu_atomic_add_int(p, v); }
-static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { return hipemu_atomic_add_int(p, v); }
-template <typename F, typename U> static inline F hipemu_atomic_add_fp(F *p, F v) {
-  U *q = reinterpret_cast<U *>(p);
-  U old = __atomic_load_n(q, __ATOMIC_SEQ_CST), neu;
-  F f;
+// atomics (workgroups run on several OS threads).  The build caps the alignment assumed for pointers at 4 bytes (the
+// device's vector loads need no more), so the 8-byte ones go through a type that states its alignment.
+typedef uint32_t hipemu_a32 __attribute__((aligned(4)));
+typedef uint64_t hipemu_a64 __attribute__((aligned(8)));
+// (the typedefs are used directly: an alignment attribute does not survive a trip through a template parameter)
+static inline uint32_t hipemu_load(void *p, uint32_t) { return __atomic_load_n((hipemu_a32 *)p, __ATOMIC_SEQ_CST); }
+static inline uint64_t hipemu_load(void *p, uint64_t) { return __atomic_load_n((hipemu_a64 *)p, __ATOMIC_SEQ_CST); }
+static inline bool hipemu_cas(void *p, uint32_t *expected, uint32_t v) {
+  return __atomic_compare_exchange_n((hipemu_a32 *)p, expected, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
+}
+static inline bool hipemu_cas(void *p, uint64_t *expected, uint64_t v) {
+  return __atomic_compare_exchange_n((hipemu_a64 *)p, expected, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
+}
+template <size_t N> struct hipemu_rep;
+template <> struct hipemu_rep<4> { typedef uint32_t plain; };
+template <> struct hipemu_rep<8> { typedef uint64_t plain; };
+// *p = f(*p, v) atomically; returns the old value
+template <typename T, typename F> static inline T hipemu_atomic_rmw(T *p, T v, F f) {
+  typedef typename hipemu_rep<sizeof(T)>::plain Plain;
+  Plain old = hipemu_load(p, Plain()), neu;
+  T cur;
   do {
-    memcpy(&f, &old, sizeof(F));
-    F s = f + v;
-    memcpy(&neu, &s, sizeof(F));
-  } while (!__atomic_compare_exchange_n(q, &old, neu, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST));
-  return f;
+    memcpy(&cur, &old, sizeof(T));
+    const T res = f(cur, v);
+    memcpy(&neu, &res, sizeof(T));
+  } while (!hipemu_cas(p, &old, neu));
+  return cur;
 }
-static inline float atomicAdd(float *p, float v) { return hipemu_atomic_add_fp<float, uint32_t>(p, v); }
-static inline double atomicAdd(double *p, double v) { return hipemu_atomic_add_fp<double, uint64_t>(p, v); }
-template <typename T> static inline T hipemu_atomic_max(T *p, T v) {
-  T old = __atomic_load_n(p, __ATOMIC_SEQ_CST);
-  while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {}
+#define HIPEMU_ATOMIC(name, T, expr) \
+  static inline T name(T *p, T v) { return hipemu_atomic_rmw(p, v, [](T a, T b) { return (T)(expr); }); }
+HIPEMU_ATOMIC(atomicAdd, int, a + b) HIPEMU_ATOMIC(atomicAdd, unsigned, a + b)
+HIPEMU_ATOMIC(atomicAdd, unsigned long long, a + b) HIPEMU_ATOMIC(atomicAdd, float, a + b)
+HIPEMU_ATOMIC(atomicAdd, double, a + b)
+HIPEMU_ATOMIC(atomicSub, int, a - b) HIPEMU_ATOMIC(atomicSub, unsigned, a - b)
+HIPEMU_ATOMIC(atomicMax, int, a > b ? a : b) HIPEMU_ATOMIC(atomicMax, unsigned, a > b ? a : b)
+HIPEMU_ATOMIC(atomicMax, unsigned long long, a > b ? a : b)
+HIPEMU_ATOMIC(atomicMin, int, a < b ? a : b) HIPEMU_ATOMIC(atomicMin, unsigned, a < b ? a : b)
+HIPEMU_ATOMIC(atomicMin, unsigned long long, a < b ? a : b)
+HIPEMU_ATOMIC(atomicOr, int, a | b) HIPEMU_ATOMIC(atomicOr, unsigned, a | b)
+HIPEMU_ATOMIC(atomicOr, unsigned long long, a | b)
+HIPEMU_ATOMIC(atomicAnd, int, a & b) HIPEMU_ATOMIC(atomicAnd, unsigned, a & b)
+HIPEMU_ATOMIC(atomicExch, int, b) HIPEMU_ATOMIC(atomicExch, unsigned, b) HIPEMU_ATOMIC(atomicExch, float, b)
+#undef HIPEMU_ATOMIC
+template <typename T> static inline T hipemu_atomic_cas(T *p, T cmp, T v) {
+  typedef typename hipemu_rep<sizeof(T)>::plain Plain;
+  Plain c, n;
+  memcpy(&c, &cmp, sizeof(T));
+  memcpy(&n, &v, sizeof(T));
+  hipemu_cas(p, &c, n);
+  T old;
+  memcpy(&old, &c, sizeof(T));
   return old;
 }
-static inline int atomicMax(int *p, int v) { return hipemu_atomic_max(p, v); }
-static inline unsigned atomicMax(unsigned *p, unsigned v) { return hipemu_atomic_max(p, v); }
-static inline unsigned long long atomicMax(unsigned long long *p, unsigned long long v) { return hipemu_atomic_max(p, v); }
-template <typename T> static inline T hipemu_atomic_min(T *p, T v) {
-  T old = __atomic_load_n(p, __ATOMIC_SEQ_CST);
-  while (old > v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {}
-  return old;
-}
-static inline int atomicMin(int *p, int v) { return hipemu_atomic_min(p, v); }
-static inline unsigned atomicMin(unsigned *p, unsigned v) { return hipemu_atomic_min(p, v); }
-static inline unsigned atomicOr(unsigned *p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
-static inline int atomicOr(int *p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
-static inline unsigned atomicExch(unsigned *p, unsigned v) { return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST); }
-static inline int atomicCAS(int *p, int cmp, int v) {
-  __atomic_compare_exchange_n(p, &cmp, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
-  return cmp;
-}
-static inline unsigned atomicCAS(unsigned *p, unsigned cmp, unsigned v) {
-  __atomic_compare_exchange_n(p, &cmp, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
-  return cmp;
+static inline int atomicCAS(int *p, int cmp, int v) { return hipemu_atomic_cas(p, cmp, v); }
+static inline unsigned atomicCAS(unsigned *p, unsigned cmp, unsigned v) { return hipemu_atomic_cas(p, cmp, v); }
+static inline unsigned long long atomicCAS(unsigned long long *p, unsigned long long cmp, unsigned long long v) {
+  return hipemu_atomic_cas(p, cmp, v);
 }
 
 // ------------------------------------------------------------------------------------------------ host API
