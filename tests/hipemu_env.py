@@ -9,8 +9,10 @@ EMU_DIR = os.path.join(ROOT, "tools", "hipemu")
 
 
 def build(san=""):
-    args = ["make", "-s", "-j8", "-C", EMU_DIR] + ([f"SAN={san}"] if san else [])
-    subprocess.check_call(args)
+    """san: "" (plain), "address" / "undefined" (sanitizer builds of the kernels; LD_PRELOAD the clang runtime), "race"
+    (the kernels' memory accesses go through the lane-level race detector, hipemuRaceCount())."""
+    extra = ["RACE=1"] if san == "race" else ([f"SAN={san}"] if san else [])
+    subprocess.check_call(["make", "-s", "-j8", "-C", EMU_DIR] + extra)
     return os.path.join(EMU_DIR, "_build" + (f"_{san}" if san else ""), "lib")
 
 

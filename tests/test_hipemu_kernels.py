@@ -65,6 +65,63 @@ def test_gpu_parity_tests_pass_on_the_cpu_model(group):
     assert " passed" in out.stdout and "failed" not in out.stdout.splitlines()[-1], tail
 
 
+# Racecheck (make RACE=1): the kernel sources carry ThreadSanitizer's access hooks, answered by the model's lane-level
+# detector - two lanes touching the same bytes, one of them writing, with no workgroup barrier (different waves) or no
+# wave-wide operation (same wave) in between.  Findings that are not defects, by the text of a source line or the name
+# of an (inlined) function of one of the two accesses (line numbers move):
+BENIGN_RACES = {
+    # LdsDwordAt reads the two aligned dwords around a 4-byte tap; of the last tap of the staged window only three
+    # bytes are used, the rest of its second dword can belong to the fp32 intermediate behind the window that other
+    # waves are already writing.  The funnel shift drops those bytes.
+    "LdsDwordAt",
+    # the lanes of the blocks of one colour component all store that component's pitch: same value
+    "G.comp_pitch[comp] = d.plane_pitch[comp];",
+}
+RACE_GROUPS = {"race_resample_cmn_normalize": ["tests/test_gpu_resample.py", "tests/test_gpu_cmn.py",
+                                               "tests/test_gpu_normalize.py"]}
+if os.environ.get("DALI_AMD_HIPEMU_FULL"):
+    RACE_GROUPS["race_jpeg"] = ["tests/test_gpu_jpeg.py", "tests/test_gpu_roi_resize.py", "tests/test_gpu_config1.py"]
+    RACE_GROUPS["race_augment_audio"] = ["tests/test_gpu_augment.py", "tests/test_gpu_audio.py"]
+
+
+def test_racecheck_selftest():
+    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "tools", "hipemu"), "RACE=1"])
+    out = subprocess.run([os.path.join(ROOT, "tools", "hipemu", "_build_race", "racetest")], capture_output=True, text=True)
+    assert out.returncode == 0 and "racetest OK" in out.stdout, out.stdout + out.stderr[-2000:]
+    for kind in ("different waves, no barrier", "lanes of one wave", "write-write"):
+        assert kind in out.stderr, kind
+
+
+@pytest.mark.parametrize("group", sorted(RACE_GROUPS))
+def test_kernels_are_race_free_on_the_cpu_model(group):
+    import re
+    emu = os.path.join(ROOT, "tools", "hipemu")
+    subprocess.check_call(["make", "-s", "-j8", "-C", emu, "RACE=1"])
+    env = dict(os.environ, DALI_AMD_HIPEMU="race")
+    env.pop("LD_PRELOAD", None)
+    cmd = [sys.executable, "-m", "pytest", "-q", "-s", "-m", "gpu", "-p", "no:cacheprovider", "-p", "no:xdist"] + RACE_GROUPS[group]
+    for t in NOT_ON_THE_MODEL:
+        if t.split("::")[0] in RACE_GROUPS[group]:
+            cmd += ["--deselect", t]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=3000)
+    assert out.returncode == 0, "\n".join(out.stdout.splitlines()[-40:]) + out.stderr[-2000:]
+    lib = os.path.join(emu, "_build_race", "lib", "libdali_amd_kernels.so")
+    pairs = set(re.findall(r"racecheck: (\S+) race .*? at \+(0x[0-9a-f]+), then lane \d+ at \+(0x[0-9a-f]+)", out.stdout + out.stderr))
+    defects = []
+    for kind, first, second in sorted(pairs):
+        sym = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-symbolizer", "-e", lib, first, second], capture_output=True,
+                             text=True).stdout.split("\n\n")
+        # file:line:col of every (inlined) frame of the two accesses
+        where = [ln for blk in sym for ln in blk.strip().splitlines() if re.search(r":\d+:\d+$", ln)]
+        texts = [ln.strip() for blk in sym for ln in blk.strip().splitlines() if not re.search(r":\d+:\d+$", ln)]
+        for w in where:
+            path, line = w.rsplit(":", 2)[0], int(w.rsplit(":", 2)[1])
+            texts.append(open(path).read().splitlines()[line - 1].strip() if line > 0 and os.path.exists(path) else "?")
+        if not any(t in BENIGN_RACES for t in texts):
+            defects.append((kind, where, texts))
+    assert not defects, defects
+
+
 def test_the_product_does_not_know_the_model():
     """No file of the product or of the timed benchmark mentions the model or its libraries."""
     for base in ("dali_amd", "include"):

@@ -2,6 +2,7 @@
 // (see include/hip/hip_runtime.h in this directory).
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
 #include <sys/mman.h>
 #include <unistd.h>
 
@@ -68,7 +69,29 @@ struct Lane {
 
 namespace {
 
+// ---- racecheck (the build with instrumented kernels: make RACE=1) ----
+// One cell per 4-byte granule, direct mapped; a cell remembers the last write and the last two reads of the granule by
+// (lane, workgroup-barrier epoch, wave epoch).  Two accesses of different lanes to the same bytes, one of them a write,
+// race unless a barrier lies between them: a workgroup barrier for lanes of different waves, any wave-wide operation
+// (wave barrier, shuffle, ballot ...) or a workgroup barrier for lanes of one wave.
+struct RaceAccessRec {
+  uint16_t tid;
+  uint8_t bytes;     // mask of the granule's bytes touched
+  uint8_t valid;
+  uint32_t block_epoch, wave_epoch;
+  const void *pc;
+};
+struct RaceCell {
+  uintptr_t granule;
+  uint32_t generation;
+  RaceAccessRec write, read[2];
+};
+constexpr int kRaceCellsLog2 = 20;
+
 struct Worker {
+  std::vector<RaceCell> race_cells;
+  uint32_t race_generation = 0, block_epoch = 0;
+  uint32_t wave_epoch[16] = {};
   void *sched_sp = nullptr;
   Lane *lanes = nullptr;
   int max_lanes = 0;
@@ -185,6 +208,7 @@ void Resolve(Lane *wave, int nlanes, uint64_t mask) {
 }
 
 void RunBlock(Worker &w, dim3 block, int nthreads) {
+  w.race_generation++;   // empties the racecheck cells
   // fresh fibers
   for (int t = 0; t < nthreads; t++) {
     Lane &l = w.lanes[t];
@@ -220,10 +244,13 @@ void RunBlock(Worker &w, dim3 block, int nthreads) {
         for (int i = 0; i < n; i++)
           if (wave[i].state == kWaitWave && wave[i].site == site) mask |= 1ull << i;
         Resolve(wave, n, mask);
+        w.wave_epoch[wv]++;
       }
       for (int i = 0; i < n; i++) done += wave[i].state == kDone;
     }
     if (done == nthreads) break;
+    w.block_epoch++;
+    for (int wv = 0; wv < nwaves; wv++) w.wave_epoch[wv]++;
     int any = 0;
     for (int t = 0; t < nthreads; t++)
       if (w.lanes[t].state == kWaitBlock) any |= w.lanes[t].barrier_pred;
@@ -329,6 +356,73 @@ class Pool {
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------ racecheck
+namespace {
+std::atomic<long> g_races{0};
+std::mutex g_race_mu;
+std::vector<std::pair<const void *, const void *>> g_race_seen;
+
+void ReportRace(const char *kind, const void *addr, const RaceAccessRec &prev, int tid, const void *pc, bool same_wave) {
+  g_races++;
+  std::lock_guard<std::mutex> g(g_race_mu);
+  for (auto &p : g_race_seen)
+    if (p.first == prev.pc && p.second == pc) return;
+  g_race_seen.emplace_back(prev.pc, pc);
+  // pcs as offsets into the library: `llvm-symbolizer -e <library> <offset>` names the source lines
+  auto offset = [](const void *p) {
+    Dl_info info;
+    return dladdr(p, &info) && info.dli_fbase ? (uintptr_t)p - (uintptr_t)info.dli_fbase : (uintptr_t)p;
+  };
+  fprintf(stderr, "hipemu racecheck: %s race on %p (%s): lane %d at +0x%zx, then lane %d at +0x%zx, block %u,%u,%u\n", kind,
+          addr, same_wave ? "lanes of one wave, no wave-wide operation in between" : "different waves, no barrier in between",
+          (int)prev.tid, (size_t)offset(prev.pc), tid, (size_t)offset(pc), tls.block_idx.x, tls.block_idx.y, tls.block_idx.z);
+}
+}  // namespace
+
+void RaceAccess(const void *addr, size_t size, bool is_write, const void *pc) {
+  Worker &w = worker;
+  Lane *l = w.current;
+  if (!l) return;
+  const uintptr_t a = reinterpret_cast<uintptr_t>(addr);
+  const uintptr_t stacks = reinterpret_cast<uintptr_t>(w.stacks);
+  if (a >= stacks && a < stacks + w.stride * (size_t)w.max_lanes) return;   // a lane's own stack
+  if (w.race_cells.empty()) w.race_cells.resize((size_t)1 << kRaceCellsLog2);
+  const int tid = (int)(l - w.lanes), wave = tid >> 6;
+  const uint32_t be = w.block_epoch, we = w.wave_epoch[wave];
+  for (uintptr_t g = a >> 2; g <= (a + size - 1) >> 2; g++) {
+    const uintptr_t lo = std::max(a, g << 2), hi = std::min(a + size, (g + 1) << 2);
+    const uint8_t bytes = (uint8_t)(((1u << (hi - lo)) - 1) << (lo & 3));
+    RaceCell &c = w.race_cells[(g * 0x9E3779B97F4A7C15ull) >> (64 - kRaceCellsLog2)];
+    if (c.granule != g || c.generation != w.race_generation) {
+      c.granule = g;
+      c.generation = w.race_generation;
+      c.write.valid = c.read[0].valid = c.read[1].valid = 0;
+    }
+    auto unordered = [&](const RaceAccessRec &p) {
+      if (!p.valid || p.tid == tid || !(p.bytes & bytes)) return false;
+      return (p.tid >> 6) == wave ? p.wave_epoch == we : p.block_epoch == be;
+    };
+    if (unordered(c.write)) ReportRace(is_write ? "write-write" : "write-read", addr, c.write, tid, pc, (c.write.tid >> 6) == wave);
+    if (is_write)
+      for (auto &r : c.read)
+        if (unordered(r)) ReportRace("read-write", addr, r, tid, pc, (r.tid >> 6) == wave);
+    RaceAccessRec rec{(uint16_t)tid, bytes, 1, be, we, pc};
+    if (is_write) {
+      // bytes of an earlier write that this one does not cover stay attributed to it only when it was this lane
+      if (c.write.valid && c.write.tid == tid && c.write.block_epoch == be && c.write.wave_epoch == we) rec.bytes |= c.write.bytes;
+      c.write = rec;
+    } else if (c.read[0].valid && c.read[0].tid == tid) {
+      if (c.read[0].block_epoch == be && c.read[0].wave_epoch == we) rec.bytes |= c.read[0].bytes;
+      c.read[0] = rec;
+    } else {
+      c.read[1] = c.read[0];
+      c.read[0] = rec;
+    }
+  }
+}
+
+long RaceCount() { return g_races.load(); }
+
 void Launch(dim3 grid, dim3 block, size_t dyn_shared_bytes, const std::function<void()> &body) {
   Job job;
   job.grid = grid;
@@ -410,3 +504,4 @@ extern "C" __attribute__((visibility("default"))) long hipemuInactiveLaneReads()
   return hipemu::g_inactive_reads.load();
 }
 extern "C" __attribute__((visibility("default"))) int hipemuIsEmulator() { return 1; }
+extern "C" __attribute__((visibility("default"))) long hipemuRaceCount() { return hipemu::RaceCount(); }

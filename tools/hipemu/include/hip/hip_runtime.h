@@ -132,6 +132,8 @@ __attribute__((convergent)) int BlockBarrierOr(int pred);  // __syncthreads_or
 // took part
 __attribute__((convergent)) uint64_t Collective(Op op, const void *in, int in_bytes, int arg, int width, void *out, int out_bytes, int site, const void *address);
 inline char *DynamicShared() { return tls.dyn_shared; }
+void RaceAccess(const void *addr, size_t size, bool is_write, const void *pc);   // racecheck build
+long RaceCount();
 inline int LaneId() {
   const ThreadState &t = tls;
   return (int)((t.thread_idx.x + t.block_dim.x * (t.thread_idx.y + t.block_dim.y * t.thread_idx.z)) & 63);
