@@ -12,8 +12,12 @@ def build(san=""):
     """san: "" (plain), "address" / "undefined" (sanitizer builds of the kernels; LD_PRELOAD the clang runtime), "race"
     (the kernels' memory accesses go through the lane-level race detector, hipemuRaceCount())."""
     extra = ["RACE=1"] if san == "race" else ([f"SAN={san}"] if san else [])
+    # a build of the kernels with other -DDALIAMD_... knobs (tools/hipemu/ldsprof.py compares LDS layouts with it)
+    tag, flags = os.environ.get("HIPEMU_TAG", ""), os.environ.get("HIPEMU_EXTRA", "")
+    if tag:
+        extra += [f"TAG={tag}", f"EXTRA={flags}"]
     subprocess.check_call(["make", "-s", "-j8", "-C", EMU_DIR] + extra)
-    return os.path.join(EMU_DIR, "_build" + (f"_{san}" if san else ""), "lib")
+    return os.path.join(EMU_DIR, "_build" + (f"_{san}" if san else "") + (f"_{tag}" if tag else ""), "lib")
 
 
 def activate(san=""):

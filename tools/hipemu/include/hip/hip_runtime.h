@@ -134,6 +134,7 @@ __attribute__((convergent)) uint64_t Collective(Op op, const void *in, int in_by
 inline char *DynamicShared() { return tls.dyn_shared; }
 void RaceAccess(const void *addr, size_t size, bool is_write, const void *pc);   // racecheck build
 long RaceCount();
+extern const void *launch_kernel;   // ldsprof: the kernel function of the launch being issued
 inline int LaneId() {
   const ThreadState &t = tls;
   return (int)((t.thread_idx.x + t.block_dim.x * (t.thread_idx.y + t.block_dim.y * t.thread_idx.z)) & 63);
@@ -409,6 +410,7 @@ template <typename... Params, typename... Args>
 static inline void hipLaunchKernelGGL(void (*kernel)(Params...), dim3 grid, dim3 block, size_t dyn_shared,
                                       hipStream_t, Args &&...args) {
   std::tuple<std::decay_t<Params>...> params(std::forward<Args>(args)...);
+  ::hipemu::launch_kernel = reinterpret_cast<const void *>(kernel);
   ::hipemu::Launch(grid, block, dyn_shared, [&]() { std::apply(kernel, params); });
 }
 
