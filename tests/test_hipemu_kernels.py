@@ -122,6 +122,21 @@ def test_kernels_are_race_free_on_the_cpu_model(group):
     assert not defects, defects
 
 
+def test_device_decoder_survives_damaged_streams():
+    """tools/fuzz_gpu_decoder.py: mutated entropy-coded segments / tables through the GPU entropy decoder on the
+    AddressSanitizer build of the model with zero slack behind the allocations - every batch decodes or raises, no kernel
+    leaves its buffers, none loops (on the device: silent corruption of HBM, or a hung GPU)."""
+    env = dict(os.environ)
+    env.pop("DALI_AMD_HIPEMU", None)
+    runs = [("250", "5", {})]
+    if os.environ.get("DALI_AMD_HIPEMU_FULL"):
+        runs += [("1500", "7", {}), ("150", "3", {"FUZZ_BIG": "1"})]
+    for iterations, seed, extra in runs:
+        out = subprocess.run([os.path.join(ROOT, "tools", "fuzz_gpu_decoder.sh"), iterations, seed], cwd=ROOT, env=dict(env, **extra),
+                             capture_output=True, text=True, timeout=3000)
+        assert out.returncode == 0 and "fuzz_gpu_decoder OK" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+
+
 def test_the_product_does_not_know_the_model():
     """No file of the product or of the timed benchmark mentions the model or its libraries."""
     for base in ("dali_amd", "include"):

@@ -1,0 +1,148 @@
+"""Mutation fuzzing of the DEVICE side of the JPEG decoder (TEST TOOL): valid baseline streams (4:2:0 / 4:2:2 / 4:4:4 /
+grey, optimised tables, restart intervals) are truncated, bit-flipped, overwritten and spliced BEHIND their headers (and
+sometimes inside the DHT / DQT / SOF / SOS segments), then decoded through the GPU entropy decoder
+(backend.decode_jpeg_batch(huffman="gpu")) on the CPU model of the kernels built with AddressSanitizer
+(tools/hipemu, make SAN=address) with zero slack behind the allocations.  A decode either succeeds or raises
+DaliAmdError; a sanitizer report, a crash or a decode that does not come back is a defect of a kernel (an out-of-bounds
+access that corrupts HBM or a loop that hangs the GPU on the real device).
+
+    tools/fuzz_gpu_decoder.sh [iterations] [seed]
+"""
+import io
+import os
+import signal
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+from PIL import Image
+
+
+def seeds(rng):
+    from tests.util import synth_image
+    out = []
+    for (h, w), kw in [((61, 83), dict(subsampling="4:2:0")), ((48, 64), dict(subsampling="4:4:4")),
+                       ((40, 72), dict(subsampling="4:2:2")), ((64, 64), dict(subsampling="4:2:0", optimize=True)),
+                       ((72, 96), dict(subsampling="4:2:0", restart_marker_blocks=2)),
+                       ((50, 70), dict(subsampling="4:2:0", restart_marker_rows=1)),
+                       ((120, 160), dict(subsampling="4:2:0", quality=95))]:
+        b = io.BytesIO()
+        Image.fromarray(synth_image(rng, h, w)).save(b, "JPEG", **dict(dict(quality=80), **kw))
+        out.append(b.getvalue())
+    b = io.BytesIO()
+    Image.fromarray(synth_image(rng, 40, 56)).convert("L").save(b, "JPEG", quality=75)
+    out.append(b.getvalue())
+    if os.environ.get("FUZZ_BIG") == "1":   # streams of several 61 KB segments (the serial repair pass over segments) and tiles
+        out = []
+        for (h, w), kw in [((600, 800), dict(subsampling="4:2:0", quality=97)), ((500, 700), dict(subsampling="4:4:4", quality=95)),
+                           ((640, 640), dict(subsampling="4:2:0", quality=96, restart_marker_rows=4))]:
+            b = io.BytesIO()
+            noisy = np.clip(synth_image(rng, h, w).astype(np.int16) + rng.integers(-20, 21, (h, w, 3)), 0, 255).astype(np.uint8)
+            Image.fromarray(noisy).save(b, "JPEG", **kw)
+            out.append(b.getvalue())
+    return out
+
+
+def sos_offset(d):
+    i = d.find(b"\xff\xda")
+    return i if i > 0 else len(d) // 2
+
+
+def mutate(rng, data, others):
+    d = bytearray(data)
+    body = sos_offset(d) + 14
+    # nine times in ten the damage is in the entropy-coded segment (what only the device looks at), else anywhere
+    lo = body if rng.random() < 0.9 and body < len(d) - 2 else 2
+    kind = rng.integers(0, 7)
+    if kind == 0:
+        del d[rng.integers(lo, len(d)):]
+        if rng.random() < 0.5:
+            d += b"\xff\xd9"
+    elif kind == 1:
+        for _ in range(rng.integers(1, 8)):
+            i = rng.integers(lo, len(d)); d[i] ^= 1 << rng.integers(0, 8)
+    elif kind == 2:
+        i = rng.integers(lo, len(d)); n = min(len(d) - i, int(rng.integers(1, 64)))
+        d[i:i + n] = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+    elif kind == 3:
+        i = rng.integers(lo, len(d)); n = min(len(d) - i, int(rng.integers(1, 40)))
+        d[i:i + n] = bytes([0xFF if rng.integers(0, 2) else 0x00]) * n
+    elif kind == 4:   # a stray marker (RSTn, EOI, DNL ...) in the middle of the segment
+        i = rng.integers(lo, len(d))
+        d[i:i + 2] = bytes([0xFF, int(rng.choice([0xD0, 0xD3, 0xD7, 0xD9, 0xDC, 0xC4, 0x01, 0xFF]))])
+    elif kind == 5:   # the entropy-coded segment of another stream behind this one's headers
+        o = others[rng.integers(0, len(others))]
+        d[body:] = o[sos_offset(o) + 14:]
+    else:             # delete a run (every later restart marker arrives early)
+        i = rng.integers(lo, len(d)); n = min(len(d) - i, int(rng.integers(1, 200)))
+        del d[i:i + n]
+    return bytes(d)
+
+
+def main():
+    iterations = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    from tests import hipemu_env
+    hipemu_env.activate("address")
+    from dali_amd import backend as B
+    from dali_amd._capi import DaliAmdError
+    rng = np.random.default_rng(seed)
+    base = seeds(rng)
+    for e in base:   # the seeds themselves decode
+        B.decode_jpeg_batch([np.frombuffer(e, np.uint8)], device="cuda", huffman="gpu")
+    ok = rejected = on_device = 0
+    # every third batch goes through the PRODUCT pipeline instead (decoders.image(device="mixed") behind an external
+    # source: the operator's header-only parse and the upload of "everything behind SOS", the end of the scan found on
+    # the device, the status word read back when the outputs are requested)
+    from dali_amd import fn
+    from dali_amd.pipeline import Pipeline
+    pipes = {}
+
+    def through_pipeline(batch):
+        n = len(batch)
+        if n not in pipes:
+            pipe = Pipeline(batch_size=n, num_threads=2, device_id=0, prefetch_queue_depth=1, exec_async=False, exec_pipelined=False)
+            with pipe:
+                pipe.set_outputs(fn.decoders.image(fn.external_source(name="enc"), device="mixed"))
+            pipe.build()
+            pipes[n] = pipe
+        pipes[n].feed_input("enc", [np.frombuffer(b, np.uint8) for b in batch])
+        try:
+            pipes[n].run()
+        except RuntimeError:
+            del pipes[n]    # an iteration that failed leaves the pipeline unusable, as in the reference
+            raise
+
+    def hung(*_):
+        raise SystemExit(f"fuzz_gpu_decoder: a decode did not come back within 120 s (iteration {it}, seed {seed})")
+    signal.signal(signal.SIGALRM, hung)
+    for it in range(iterations):
+        batch = [mutate(rng, base[rng.integers(0, len(base))], base) for _ in range(int(rng.integers(1, 4)))]
+        if rng.random() < 0.3:   # a sound stream next to the damaged ones
+            batch.insert(int(rng.integers(0, len(batch) + 1)), base[rng.integers(0, len(base))])
+        signal.alarm(120)
+        try:
+            try:
+                plan = B.JpegBatchPlan([np.frombuffer(b, np.uint8) for b in batch]) if hasattr(B, "JpegBatchPlan") else None
+                if plan is not None:
+                    on_device += int(np.sum(plan.analyze_scans()))
+            except DaliAmdError:
+                pass
+            if it % 3 == 2:
+                through_pipeline(batch)
+            else:
+                B.decode_jpeg_batch([np.frombuffer(b, np.uint8) for b in batch], device="cuda", huffman="gpu")
+            ok += 1
+        except (DaliAmdError, RuntimeError):
+            rejected += 1
+        finally:
+            signal.alarm(0)
+        if (it + 1) % 50 == 0:
+            print(f"{it + 1}: {ok} decoded, {rejected} rejected", flush=True)
+    print(f"fuzz_gpu_decoder OK: {iterations} batches, {ok} decoded, {rejected} rejected, {on_device} streams took the device path")
+
+
+if __name__ == "__main__":
+    main()
