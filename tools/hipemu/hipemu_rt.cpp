@@ -121,6 +121,7 @@ struct Worker {
   uintptr_t tls_lo = 0, tls_hi = 0;
   const void *kernel = nullptr;
   size_t dyn_bytes = 0;
+  std::vector<uint32_t> init_static, init_dyn;   // initcheck: the workgroup (race_generation) that wrote the byte last
   std::vector<RaceCell> race_cells;
   uint32_t race_generation = 0, block_epoch = 0;
   uint32_t wave_epoch[16] = {};
@@ -509,19 +510,67 @@ int TlsRangeCallback(struct dl_phdr_info *info, size_t, void *data) {
   return 0;
 }
 
-void LdsAccess(Worker &w, Lane *l, uintptr_t a, size_t size, bool is_write, const void *pc) {
+// Is the address in the workgroup's LDS?  Static __shared__ variables are thread_local objects of the worker thread (the
+// TLS block of this library minus the runtime's own two), dynamic LDS is the worker's buffer.
+bool IsLds(Worker &w, uintptr_t a) {
   if (!w.tls_lo) {
     uintptr_t range[2] = {1, 1};
     dl_iterate_phdr(TlsRangeCallback, range);
     w.tls_lo = range[0]; w.tls_hi = range[1];
   }
   const uintptr_t dyn = reinterpret_cast<uintptr_t>(tls.dyn_shared);
-  bool lds = a >= dyn && a < dyn + w.dyn_bytes;
-  if (!lds && a >= w.tls_lo && a < w.tls_hi) {
+  if (a >= dyn && a < dyn + w.dyn_bytes) return true;
+  if (a >= w.tls_lo && a < w.tls_hi) {
     const uintptr_t t = reinterpret_cast<uintptr_t>(&tls), k = reinterpret_cast<uintptr_t>(&w);
-    lds = !(a >= t && a < t + sizeof(tls)) && !(a >= k && a < k + sizeof(Worker));
+    return !(a >= t && a < t + sizeof(tls)) && !(a >= k && a < k + sizeof(Worker));
   }
-  if (!lds) return;
+  return false;
+}
+
+// Uninitialised LDS: the LDS of a workgroup holds what the workgroups before it on the CU left there.  A read of bytes
+// that no lane of THIS workgroup has written yet is reported once per code address (initcheck; part of racecheck).
+std::atomic<long> g_uninit{0};
+void LdsInitCheck(Worker &w, Lane *l, uintptr_t a, size_t size, bool is_read, bool is_write, const void *pc) {
+  static const bool enabled = EnvInt("HIPEMU_INITCHECK", 1) != 0;
+  if (!enabled || !IsLds(w, a)) return;
+  const uintptr_t dyn = reinterpret_cast<uintptr_t>(tls.dyn_shared);
+  const bool in_dyn = a >= dyn && a < dyn + w.dyn_bytes;
+  std::vector<uint32_t> &marks = in_dyn ? w.init_dyn : w.init_static;
+  const size_t index = in_dyn ? a - dyn : a - w.tls_lo, extent = in_dyn ? w.dyn_bytes : w.tls_hi - w.tls_lo;
+  if (marks.size() < extent) marks.resize(extent, 0);
+  if (index + size > marks.size()) return;
+  if (is_read) {
+    for (size_t i = 0; i < size; i++)
+      if (marks[index + i] != w.race_generation) {
+        // what such a read gets on the device is arbitrary: hand it all-ones bytes (a NaN where floats are read; =2: bytes that
+        // change from workgroup to workgroup), so that a result that depends on it fails its test instead of inheriting the
+        // plausible values of the workgroup before
+        static const int poison = EnvInt("HIPEMU_LDS_POISON", 1);
+        if (poison)
+          for (size_t j = i; j < size; j++)
+            if (marks[index + j] != w.race_generation)
+              reinterpret_cast<unsigned char *>(a)[j] = poison == 1 ? 0xFF : (unsigned char)(((index + j) * 2654435761u + w.race_generation * 40503u) >> 13);
+        g_uninit++;
+        std::lock_guard<std::mutex> g(g_race_mu);
+        bool seen = false;
+        for (auto &p : g_race_seen) seen = seen || (p.first == nullptr && p.second == pc);
+        if (!seen) {
+          g_race_seen.emplace_back(nullptr, pc);
+          Dl_info info;
+          const uintptr_t off = dladdr(pc, &info) && info.dli_fbase ? (uintptr_t)pc - (uintptr_t)info.dli_fbase : (uintptr_t)pc;
+          fprintf(stderr, "hipemu racecheck: uninitialised read of %s LDS byte %zu (+%zu of a %zu-byte access): lane %d at +0x%zx, block %u,%u,%u\n",
+                  in_dyn ? "dynamic" : "static", index + i, i, size, (int)(l - w.lanes), (size_t)off, tls.block_idx.x, tls.block_idx.y,
+                  tls.block_idx.z);
+        }
+        break;
+      }
+  }
+  if (is_write)
+    for (size_t i = 0; i < size; i++) marks[index + i] = w.race_generation;
+}
+
+void LdsAccess(Worker &w, Lane *l, uintptr_t a, size_t size, bool is_write, const void *pc) {
+  if (!IsLds(w, a)) return;
   const int tid = (int)(l - w.lanes), wave = tid >> 6;
   LdsWave &lw = w.lds_wave[wave];
   if (lw.epoch != w.wave_epoch[wave]) { LdsFlush(w, lw); lw.epoch = w.wave_epoch[wave]; lw.lane = -1; }
@@ -561,6 +610,7 @@ void RaceAccess(const void *addr, size_t size, bool is_write, const void *pc) {
   const uintptr_t a = reinterpret_cast<uintptr_t>(addr);
   const uintptr_t stacks = reinterpret_cast<uintptr_t>(w.stacks);
   if (a >= stacks && a < stacks + w.stride * (size_t)w.max_lanes) return;   // a lane's own stack
+  LdsInitCheck(w, l, a, size, !is_write, is_write, pc);
   if (w.race_cells.empty()) w.race_cells.resize((size_t)1 << kRaceCellsLog2);
   const int tid = (int)(l - w.lanes), wave = tid >> 6;
   const uint32_t be = w.block_epoch, we = w.wave_epoch[wave];
@@ -597,6 +647,12 @@ void RaceAccess(const void *addr, size_t size, bool is_write, const void *pc) {
 }
 
 long RaceCount() { return g_races.load(); }
+long UninitCount() { return g_uninit.load(); }
+// an atomic read-modify-write: no data race, but it reads what it updates
+void RaceAtomic(const void *addr, size_t size, bool reads, bool writes, const void *pc) {
+  Worker &w = worker;
+  if (w.current && !g_ldsprof_path) LdsInitCheck(w, w.current, reinterpret_cast<uintptr_t>(addr), size, reads, writes, pc);
+}
 
 void Launch(dim3 grid, dim3 block, size_t dyn_shared_bytes, const std::function<void()> &body) {
   Job job;
@@ -681,3 +737,4 @@ extern "C" __attribute__((visibility("default"))) long hipemuInactiveLaneReads()
 }
 extern "C" __attribute__((visibility("default"))) int hipemuIsEmulator() { return 1; }
 extern "C" __attribute__((visibility("default"))) long hipemuRaceCount() { return hipemu::RaceCount(); }
+extern "C" __attribute__((visibility("default"))) long hipemuUninitCount() { return hipemu::UninitCount(); }

@@ -134,6 +134,8 @@ __attribute__((convergent)) uint64_t Collective(Op op, const void *in, int in_by
 inline char *DynamicShared() { return tls.dyn_shared; }
 void RaceAccess(const void *addr, size_t size, bool is_write, const void *pc);   // racecheck build
 long RaceCount();
+long UninitCount();
+void RaceAtomic(const void *addr, size_t size, bool reads, bool writes, const void *pc);
 extern const void *launch_kernel;   // ldsprof: the kernel function of the launch being issued
 inline int LaneId() {
   const ThreadState &t = tls;

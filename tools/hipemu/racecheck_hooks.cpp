@@ -33,23 +33,27 @@ API void *__tsan_memset(void *d, int v, size_t n) {
 // atomics are not data races; they keep their meaning (the memory-order arguments are the __ATOMIC_* values)
 API void __tsan_atomic_thread_fence(int) { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 API void __tsan_atomic_signal_fence(int) {}
+#define RMW(p, r, w) ::hipemu::RaceAtomic(const_cast<const void *>(reinterpret_cast<const volatile void *>(p)), sizeof(*(p)), r, w, PC)
 #define ATOMIC(bits, T)                                                                                          \
-  API T __tsan_atomic##bits##_load(const volatile T *p, int) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }     \
-  API void __tsan_atomic##bits##_store(volatile T *p, T v, int) { __atomic_store_n(p, v, __ATOMIC_SEQ_CST); }     \
-  API T __tsan_atomic##bits##_exchange(volatile T *p, T v, int) { return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST); } \
-  API T __tsan_atomic##bits##_fetch_add(volatile T *p, T v, int) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); } \
-  API T __tsan_atomic##bits##_fetch_sub(volatile T *p, T v, int) { return __atomic_fetch_sub(p, v, __ATOMIC_SEQ_CST); } \
-  API T __tsan_atomic##bits##_fetch_and(volatile T *p, T v, int) { return __atomic_fetch_and(p, v, __ATOMIC_SEQ_CST); } \
-  API T __tsan_atomic##bits##_fetch_or(volatile T *p, T v, int) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }  \
-  API T __tsan_atomic##bits##_fetch_xor(volatile T *p, T v, int) { return __atomic_fetch_xor(p, v, __ATOMIC_SEQ_CST); } \
+  API T __tsan_atomic##bits##_load(const volatile T *p, int) { RMW(p, true, false); return __atomic_load_n(p, __ATOMIC_SEQ_CST); }     \
+  API void __tsan_atomic##bits##_store(volatile T *p, T v, int) { RMW(p, false, true); __atomic_store_n(p, v, __ATOMIC_SEQ_CST); }     \
+  API T __tsan_atomic##bits##_exchange(volatile T *p, T v, int) { RMW(p, false, true); return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST); } \
+  API T __tsan_atomic##bits##_fetch_add(volatile T *p, T v, int) { RMW(p, true, true); return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); } \
+  API T __tsan_atomic##bits##_fetch_sub(volatile T *p, T v, int) { RMW(p, true, true); return __atomic_fetch_sub(p, v, __ATOMIC_SEQ_CST); } \
+  API T __tsan_atomic##bits##_fetch_and(volatile T *p, T v, int) { RMW(p, true, true); return __atomic_fetch_and(p, v, __ATOMIC_SEQ_CST); } \
+  API T __tsan_atomic##bits##_fetch_or(volatile T *p, T v, int) { RMW(p, true, true); return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }  \
+  API T __tsan_atomic##bits##_fetch_xor(volatile T *p, T v, int) { RMW(p, true, true); return __atomic_fetch_xor(p, v, __ATOMIC_SEQ_CST); } \
   API T __tsan_atomic##bits##_compare_exchange_val(volatile T *p, T c, T v, int, int) {                          \
+    RMW(p, true, true);                                                                                           \
     __atomic_compare_exchange_n(p, &c, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);                             \
     return c;                                                                                                     \
   }                                                                                                               \
   API int __tsan_atomic##bits##_compare_exchange_strong(volatile T *p, T *c, T v, int, int) {                     \
+    RMW(p, true, true);                                                                                           \
     return __atomic_compare_exchange_n(p, c, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);                       \
   }                                                                                                               \
   API int __tsan_atomic##bits##_compare_exchange_weak(volatile T *p, T *c, T v, int, int) {                       \
+    RMW(p, true, true);                                                                                           \
     return __atomic_compare_exchange_n(p, c, v, true, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);                        \
   }
 ATOMIC(8, uint8_t) ATOMIC(16, uint16_t) ATOMIC(32, uint32_t) ATOMIC(64, uint64_t)
