@@ -533,6 +533,22 @@ std::atomic<long> g_uninit{0};
 void LdsInitCheck(Worker &w, Lane *l, uintptr_t a, size_t size, bool is_read, bool is_write, const void *pc) {
   static const bool enabled = EnvInt("HIPEMU_INITCHECK", 1) != 0;
   if (!enabled || !IsLds(w, a)) return;
+  // an 8- / 16-byte LDS access is one ds_read/write_b64 / b128 on the device only if the compiler may assume the type's
+  // alignment; an address that does not have it is listed (HIPEMU_LDS_ALIGN=1; informational - clang for x86-64 also merges
+  // neighbouring narrower accesses into such an access where the device compiler would not)
+  static const bool align = EnvInt("HIPEMU_LDS_ALIGN", 0) != 0;
+  if (align && (size == 8 || size == 16) && (a & (size - 1))) {
+    std::lock_guard<std::mutex> g(g_race_mu);
+    bool seen = false;
+    for (auto &p : g_race_seen) seen = seen || (p.first == (const void *)1 && p.second == pc);
+    if (!seen) {
+      g_race_seen.emplace_back((const void *)1, pc);
+      Dl_info info;
+      const uintptr_t off = dladdr(pc, &info) && info.dli_fbase ? (uintptr_t)pc - (uintptr_t)info.dli_fbase : (uintptr_t)pc;
+      fprintf(stderr, "hipemu racecheck: %zu-byte LDS access at an address that is %zu modulo %zu: lane %d at +0x%zx\n", size,
+              (size_t)(a & (size - 1)), size, (int)(l - w.lanes), (size_t)off);
+    }
+  }
   const uintptr_t dyn = reinterpret_cast<uintptr_t>(tls.dyn_shared);
   const bool in_dyn = a >= dyn && a < dyn + w.dyn_bytes;
   std::vector<uint32_t> &marks = in_dyn ? w.init_dyn : w.init_static;
