@@ -1,4 +1,4 @@
-"""Multi-process path on CPU (gloo, world_size 2): every rank builds the same reader pipeline with
+"""Multi-process path on CPU (gloo, world_size 2 and 8): every rank builds the same reader pipeline with
 shard_id=rank / num_shards=world, exactly as bench.py and a DDP training script do.  The ranks exchange what
 they read (test-only all_gather -- the data path itself has no collective) and check that the shards are
 disjoint, cover the dataset, and rotate between epochs."""
@@ -51,10 +51,16 @@ WORKER = textwrap.dedent('''
 ''')
 
 
-def test_two_rank_sharded_readers(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("world,classes,expected", [(2, (("a", 7), ("b", 10), ("c", 6)), "SHARDING_OK 23 12"),
+                                                    # the driver's largest launch: 8 ranks, shards of 11 and 12 samples (the short ones padded)
+                                                    (8, (("a", 40), ("b", 30), ("c", 22)), "SHARDING_OK 92 12")])
+def test_sharded_readers(tmp_path, world, classes, expected):
     root = tmp_path / "ds"
     k = 0
-    for c, n in (("a", 7), ("b", 10), ("c", 6)):
+    for c, n in classes:
         os.makedirs(root / c)
         for i in range(n):
             (root / c / f"f{i:02d}.jpg").write_bytes(np.int32(k).tobytes())
@@ -62,8 +68,8 @@ def test_two_rank_sharded_readers(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", str(script), ROOT, str(root)]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29533 + world), str(script), ROOT, str(root)]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
-    assert "SHARDING_OK 23 12" in res.stdout
+    assert expected in res.stdout, res.stdout[-500:]
