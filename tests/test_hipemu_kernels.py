@@ -142,6 +142,33 @@ def test_device_decoder_survives_damaged_streams():
         assert out.returncode == 0 and "fuzz_gpu_decoder OK" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
 
 
+def test_smoke_and_bench_scripts_run_on_the_cpu_model():
+    """Dry runs of the two scripts the driver executes on the MI355X, with the kernels on the model: __graft_entry__.smoke()
+    (its own comparison against the oracle included) and - DALI_AMD_HIPEMU_FULL, 2 minutes - the default bench.py line with
+    every leg at a small batch: the scripts' host paths still run end to end and print what the driver parses."""
+    import json
+    env = dict(os.environ)
+    env.pop("DALI_AMD_HIPEMU", None)
+    runner = [sys.executable, os.path.join(ROOT, "tools", "hipemu", "run_on_model.py")]
+    out = subprocess.run(runner + ["-c", "import __graft_entry__ as g; g.smoke()"], cwd=ROOT, env=env, capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0 and "smoke OK" in out.stdout, out.stdout[-1000:] + out.stderr[-3000:]
+    if not os.environ.get("DALI_AMD_HIPEMU_FULL"):
+        return
+    out = subprocess.run(runner + ["bench.py", "--steps", "2", "--warmup", "1", "--batch", "8", "--batches", "2", "--e2e-batch", "8"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=3000)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline", "heavy_aug", "audio", "e2e_pipeline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["roofline"]["bound"] == "hbm"
+    for leg in ("heavy_aug", "audio"):
+        assert "roofline" in line[leg] and "cpu_baseline" in line[leg], leg
+
+
 def test_the_product_does_not_know_the_model():
     """No file of the product or of the timed benchmark mentions the model or its libraries."""
     for base in ("dali_amd", "include"):
