@@ -169,6 +169,29 @@ def test_smoke_and_bench_scripts_run_on_the_cpu_model():
         assert "roofline" in line[leg] and "cpu_baseline" in line[leg], leg
 
 
+@pytest.mark.parametrize("ranks", [2, 8] if os.environ.get("DALI_AMD_HIPEMU_FULL") else [2])
+def test_multi_rank_bench_launch_runs_on_the_cpu_model(ranks):
+    """The driver's N > 1 launch of bench.py (python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N), every
+    rank with the kernels on the model and a gloo group (BENCH_TEST_SINGLE_DEVICE=1, as tests/test_bench_multirank.py does on
+    one real device): the sharded pipelines build, the barrier / max-over-ranks timing runs, rank 0 prints ONE line whose
+    value counts every rank's batches.  8 ranks - the driver's largest launch - under DALI_AMD_HIPEMU_FULL (70 s)."""
+    import json
+    env = dict(os.environ, BENCH_TEST_SINGLE_DEVICE="1", MASTER_ADDR="127.0.0.1", HIPEMU_THREADS=str(max(1, 8 // ranks)))
+    env.pop("DALI_AMD_HIPEMU", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(29580 + ranks), os.path.join(ROOT, "tools", "hipemu", "run_on_model.py"), "bench.py", "--gpus", str(ranks),
+           "--steps", "2", "--warmup", "1", "--batch", "8", "--batches", "2", "--e2e-batch", "8"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=3000)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, f"rank 0 must print exactly one JSON line, got {len(lines)}"
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == ranks and line["scaling"] == "weak" and line["config"]["global_batch"] == 8 * ranks
+    assert f"shard{ranks}" in line["config"]["parallelism"]
+    assert abs(line["value"] - ranks * 8 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]
+    assert line["e2e_pipeline_sharded"]["num_shards"] == ranks
+
+
 def test_the_product_does_not_know_the_model():
     """No file of the product or of the timed benchmark mentions the model or its libraries."""
     for base in ("dali_amd", "include"):
