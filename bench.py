@@ -38,6 +38,10 @@ import time
 
 import numpy as np
 
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL's communicator set-up fails with `hipIpcGetMemHandle: invalid
+# argument` otherwise); the driver exports it - kept here for a launch from a bare shell
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
