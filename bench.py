@@ -418,7 +418,7 @@ def batch_statistics(enc_batches, device, count_symbols=True):
 
 
 def resident_pipeline(root, batch, device_id, depth, threads, shard_id=0, num_shards=1, cache_mb=4096, roi_decode=False,
-                      crop_seed=None, flip_seed=None):
+                      crop_seed=None, flip_seed=None, roi_fusion=True):
     """The headline pipeline: configs[1] with the data set resident in HBM as encoded streams.  roi_decode: the fused
     variant decoders.image_random_crop -> resize -> crop_mirror_normalize (only the crop window is dequantised,
     transformed and colour-converted), on the same resident streams.  crop_seed / flip_seed: explicit operator seeds
@@ -443,7 +443,19 @@ def resident_pipeline(root, batch, device_id, depth, threads, shard_id=0, num_sh
                                        std=[0.229 * 255, 0.224 * 255, 0.225 * 255],
                                        mirror=fn.random.coin_flip(probability=0.5, **seeded(flip_seed)))
         pipe.set_outputs(out, labels)
-    pipe.build()
+    # roi_fusion=False: the executor's graph-level fusion "a decoders.image that feeds only a random_resized_crop decodes the
+    # windows that operator draws" is switched off for this pipeline (read when the pipeline is built)
+    saved = os.environ.get("DALI_AMD_ROI_FUSION")
+    if not roi_fusion:
+        os.environ["DALI_AMD_ROI_FUSION"] = "0"
+    try:
+        pipe.build()
+    finally:
+        if not roi_fusion:
+            if saved is None:
+                os.environ.pop("DALI_AMD_ROI_FUSION", None)
+            else:
+                os.environ["DALI_AMD_ROI_FUSION"] = saved
     return pipe
 
 
@@ -545,11 +557,30 @@ def run_resident_pipeline(args, root, enc_all, device, dev_index, rank, world, l
     # pipeline has its own seed from the pipeline's seed sequence - same distribution, other sample)
     master = Bk.philox_state(1234)
     res_bytes = []
+    # ... and, when the decoder decodes only the windows (graph-level fusion): what share of a batch's blocks / MCU rows /
+    # pixels the value passes and the colour kernel serve - the crop window + the filter's reach (ceil(scale) + 2 pixels
+    # for the triangular filter, RandomResizedCropGpu::DrawWindows) on the 16 x 16 MCU grid of 4:2:0 streams
+    roi_fused = "windows_of_the_consumer" in pipe.executed_kernels()
+    win_px, rect_blocks, row_blocks, all_blocks = [], [], [], []
     for k in range(args.steps):
-        _, crops = Bk.random_crop_batch(master, covered[k]["shapes"])
+        anchors, crops = Bk.random_crop_batch(master, covered[k]["shapes"])
         master.ctr[1] += B
         res_bytes.append(float(3 * (crops[:, 0].astype(np.int64) * crops[:, 1]).sum() + 6 * 224 * 224 * B))
-    return {"pipe": pipe, "elapsed": elapsed, "times": times, "host_times": host_times, "mean": mean, "depth": depth,
+        if roi_fused:
+            shp = covered[k]["shapes"].astype(np.int64)
+            a, c = np.asarray(anchors, np.int64), np.asarray(crops, np.int64)
+            reach = np.ceil(np.maximum(c / 224.0, 1.0)).astype(np.int64) + 2
+            lo, hi = np.maximum(a - reach, 0), np.minimum(a + c + reach, shp)
+            win_px.append(float(((hi - lo)[:, 0] * (hi - lo)[:, 1]).sum()))
+            m_lo, m_hi, m_all = lo // 16, -(-hi // 16), -(-shp // 16)
+            rect_blocks.append(float(((m_hi - m_lo)[:, 0] * (m_hi - m_lo)[:, 1]).sum()))
+            row_blocks.append(float((m_hi[:, 0] * m_all[:, 1]).sum()))
+            all_blocks.append(float((m_all[:, 0] * m_all[:, 1]).sum()))
+    roi = None
+    if roi_fused:
+        roi = {"window_pixels": float(np.mean(win_px)), "rect_share": float(np.sum(rect_blocks) / np.sum(all_blocks)),
+               "row_share": float(np.sum(row_blocks) / np.sum(all_blocks))}
+    return {"roi": roi, "pipe": pipe, "elapsed": elapsed, "times": times, "host_times": host_times, "mean": mean, "depth": depth,
             "resample_bytes": float(np.mean(res_bytes)), "threads": threads, "setup_s": t_setup,
             "setup_iterations": done - args.warmup, "cache": after, "symbols": float(np.mean([c["symbols"] for c in covered]))}
 
@@ -1046,6 +1077,15 @@ def main():
         algo["SeamKernel"] = 0.0
         algo["ResampleKernel"] = r["resample_bytes"]
         algo["ResampleTablesKernel"] = 0.0
+        if r["roi"]:
+            # the decoder decodes windows: the position passes still see every byte (the stream is serial), the DC pass stops
+            # behind the window's last MCU row, the block kernel serves the window's MCU rectangle, the colour kernel its pixels
+            blocks = coef_elems_mean / 64
+            rect, rows = r["roi"]["rect_share"], r["roi"]["row_share"]
+            algo["DcKernel"] = (4 + 10) * blocks * rows
+            algo["BlockKernel"] = rect * (stream_bytes + 10 * blocks + coef_elems_mean)
+            algo["JpegColorKernel"] = (coef_elems_mean / pixels_mean + 3) * r["roi"]["window_pixels"]
+            algo["BlockColorKernel"] = rect * (stream_bytes + 10 * blocks) + 3 * r["roi"]["window_pixels"]
         kern = {k: (float(algo.get(k, 0.0)), ms) for k, (calls, ms) in r["times"].items()}
         launches = {k: calls for k, (calls, ms) in r["times"].items()}
         huffman_total_ms = float(sum(kern[k][1] for k in HUFFMAN_KERNEL_NAMES if k in kern))
@@ -1057,7 +1097,12 @@ def main():
                      "device_stage_ms_per_step": r["host_times"].get("<device stage>"),
                      "host_ms_per_operator": {k: v for k, v in r["host_times"].items() if not k.startswith("<")},
                      "setup_s": r["setup_s"], "setup_iterations": r["setup_iterations"], "encoded_cache": r["cache"],
-                     "launches_timed": launches, "kernels": r["pipe"].executed_kernels()}
+                     "launches_timed": launches, "kernels": r["pipe"].executed_kernels(),
+                     "roi_decode_fusion": r["roi"] and dict(r["roi"], note=(
+                         "graph-level fusion of the executor: this decoders.image feeds only the random_resized_crop, so that "
+                         "operator's windows (+ the resampling filter's reach) are what is decoded; the batch is bit-identical "
+                         "to the one a full decode gives (tests/test_gpu_roi_fusion.py, tests/test_gpu_headline.py); "
+                         "`resident_full_decode` below is the same pipeline with DALI_AMD_ROI_FUSION=0"))}
         huffman_single_ms = None
         single_stream = None
         if r["depth"] > 1 and not args.no_side_legs:
@@ -1096,6 +1141,25 @@ def main():
                         "entropy decoder stops at the last MCU row of the crop window, only the window's blocks are "
                         "transformed and colour-converted"}
             del pipe2
+            if r["roi"]:
+                # ... and the headline graph with the fusion switched off: every image decoded whole, as in rounds 1-3
+                pipe3 = resident_pipeline(root, B, dev_index, r["depth"], r["threads"],
+                                          cache_mb=max(64, int(2 * sum(len(e) for e in enc_all) / 2**20)), roi_fusion=False)
+                for _ in range((r["depth"] + 2) * nb + args.warmup):
+                    pipe3.run()
+                torch.cuda.synchronize()
+                t_full = time.perf_counter()
+                for _ in range(args.steps):
+                    pipe3.run()
+                pipe3._backend.wait_enqueued()
+                torch.cuda.synchronize()
+                t_full = time.perf_counter() - t_full
+                pipe_info["resident_full_decode"] = {
+                    "value": B * args.steps / t_full, "unit": "images/s", "ms_per_step": 1e3 * t_full / args.steps,
+                    "kernels": pipe3.executed_kernels(),
+                    "note": "the headline graph with DALI_AMD_ROI_FUSION=0: every image is decoded whole and the crop window is "
+                            "taken by the resampling kernel (the form `value` was measured in up to round 4's collection)"}
+                del pipe3
         if single_stream:
             huffman_single_ms = float(sum(single_stream.get(k, 0.0) for k in HUFFMAN_KERNEL_NAMES))
             pipe_info["single_stream_kernel_ms"] = single_stream
@@ -1192,7 +1256,10 @@ def main():
                        "host_ms_per_step": host_ms_per_step,
                        "jpeg_bytes_per_batch": stream_bytes,
                        "global_batch": world * B, "parallelism": f"shard{world} (shard_id/num_shards, no collective)",
-                       "pixels_per_batch": pixels_mean, "driver": args.driver},
+                       "pixels_per_batch": pixels_mean, "driver": args.driver,
+                       # the executor decodes only the windows the random_resized_crop draws (bit-identical batch; details
+                       # and the full-decode rate of the same graph under config.pipeline)
+                       "roi_decode_fusion": bool(pipe_info and pipe_info.get("roi_decode_fusion"))},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "measured_copy_ceiling_GBps": copy_ceiling, "frac_of_measured_ceiling": ach / copy_ceiling,

@@ -77,7 +77,8 @@ class ResampleArgs(C.Structure):
                 ("min_filter", C.c_int32), ("mag_filter", C.c_int32), ("antialias", C.c_int32),
                 ("out", C.c_void_p), ("out_dtype", C.c_int32), ("out_layout", C.c_int32),
                 ("normalize", C.c_int32), ("mirror", C.c_int32), ("mean", C.c_float * 4),
-                ("inv_std", C.c_float * 4), ("in_dtype", C.c_int32), ("unrounded", C.c_int32)]
+                ("inv_std", C.c_float * 4), ("in_dtype", C.c_int32), ("unrounded", C.c_int32),
+                ("full_h", C.c_int32), ("full_w", C.c_int32), ("org_y", C.c_int32), ("org_x", C.c_int32)]
 
 
 class ResampleDesc(C.Structure):

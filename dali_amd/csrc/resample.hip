@@ -1033,7 +1033,15 @@ static int SetupOne(const daliamdResampleArgs &a, daliamdResampleDesc &d, int in
   for (int c = 0; c < 4; c++) { d.mean[c] = a.mean[c]; d.inv_std[c] = a.inv_std[c]; }
   d.use_lut = a.normalize && a.out_dtype == DALIAMD_FLOAT16;  // fused CMN to fp16: the epilogue is a 256-entry look-up
 
-  const int in_size[2] = {a.in_w, a.in_h};
+  // (a.full_h > 0: the buffer is a window of the image the region of interest refers to - the arithmetic below is that
+  // image's, only the addresses are the window's)
+  const bool windowed = a.full_h > 0;
+  if (windowed)
+    DALIAMD_REQUIRE(a.use_roi && a.full_w > 0 && a.org_y >= 0 && a.org_x >= 0 && a.org_y + a.in_h <= a.full_h &&
+                    a.org_x + a.in_w <= a.full_w, DALIAMD_ERROR_INVALID_ARGUMENT,
+                    "daliamdResampleSetup: sample %d: a %d x %d window at (%d, %d) of a %d x %d image needs a region of interest "
+                    "and must lie inside the image", index, a.in_h, a.in_w, a.org_y, a.org_x, a.full_h, a.full_w);
+  const int in_size[2] = {windowed ? a.full_w : a.in_w, windowed ? a.full_h : a.in_h};
   const int out_size[2] = {a.out_w, a.out_h};
   int roi_lo[2], roi_hi[2];
   for (int dim = 0; dim < 2; dim++) {  // dim 0 = H, 1 = W; axis: 0 = x, 1 = y
@@ -1105,6 +1113,16 @@ static int SetupOne(const daliamdResampleArgs &a, daliamdResampleDesc &d, int in
   d.lo[d.first_axis] = 0; d.ext[d.first_axis] = in_size[d.first_axis];
   d.lo[second] = roi_lo[second]; d.ext[second] = roi_hi[second] - roi_lo[second];
   d.origin[second] -= roi_lo[second];
+  if (windowed) {
+    const int org[2] = {a.org_x, a.org_y}, win[2] = {a.in_w, a.in_h};
+    for (int axis = 0; axis < 2; axis++) {
+      // [roi_lo, roi_hi) is every source position a tap can take on the axis after the clamp to the image
+      DALIAMD_REQUIRE(org[axis] <= roi_lo[axis] && roi_hi[axis] <= org[axis] + win[axis], DALIAMD_ERROR_INVALID_ARGUMENT,
+                      "daliamdResampleSetup: sample %d: the window [%d, %d) does not hold the source range [%d, %d) of axis %d",
+                      index, org[axis], org[axis] + win[axis], roi_lo[axis], roi_hi[axis], axis);
+      d.lo[axis] -= org[axis];
+    }
+  }
 
   // rounding regions of an H-last pass: the reference's row loop runs over four column regions (left border, the
   // overlap of both borders, regular, right border); inside each, whole groups of `round_lanes` columns take the SIMD

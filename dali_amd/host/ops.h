@@ -16,6 +16,10 @@ void FeedExternalSource(OperatorBase *op, const std::vector<const void *> &data,
 // CropMirrorNormalize, the producer stops launching its own kernel and hands its per-sample resampling
 // arguments to the consumer, which launches ONE fused resample + normalise kernel.
 void TryEnableFusion(OperatorBase *producer, OperatorBase *consumer);
+// A decoders.image (mixed) whose ONLY consumer is a RandomResizedCrop decodes only the windows that operator draws (the
+// operator draws them when the decoder's stage runs; same generator, same sequence): bit-identical output, no work for
+// the part of every image the crop discards.  DALI_AMD_ROI_FUSION=0 switches it off.  Returns true when the pair was fused.
+bool TryEnableRoiDecodeFusion(OperatorBase *decoder, OperatorBase *consumer);
 
 // Resampling arguments deferred from a producer to its CropMirrorNormalize consumer.
 struct DeferredResample {

@@ -9,6 +9,9 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <deque>
+#include <functional>
+#include <mutex>
 
 #include "dali_amd_host.h"
 #include "image_cache.h"
@@ -625,6 +628,7 @@ class ImageDecoderMixed : public OperatorBase {
     if (nidct) NoteLaunch(ws, "jpeg_idct");
     if (block_kernels & 2) NoteLaunch(ws, "jpeg_huffman_rgb");
     if (ncolor) NoteLaunch(ws, "jpeg_color");
+    if (roi_source_) NoteLaunch(ws, "windows_of_the_consumer");   // (not a kernel: the graph-level fusion was in effect)
     if (cache_) {
       cache_->Commit(reserved.keys, ws.stream);  // visible to later iterations (and other pipelines) from here on
       reserved.keys.clear();
@@ -634,8 +638,25 @@ class ImageDecoderMixed : public OperatorBase {
 
  protected:
   // Fills rois_[4*i .. 4*i+3] = {y0, x0, h, w} (h == 0: whole image) from upright_hw_ = {H, W} per sample.
-  virtual void ComputeRois(const Workspace &, int) {}
+  virtual void ComputeRois(const Workspace &, int n) {
+    if (roi_source_) roi_source_(n, upright_hw_.data(), rois_.data());
+  }
   std::vector<int32_t> upright_hw_, rois_;
+
+ public:
+  // Graph-level fusion (pipeline.cpp, TryEnableRoiDecodeFusion): the ONLY consumer of this decoders.image is a
+  // RandomResizedCrop.  That operator draws the windows of the batch here - from ITS generator, in iteration order, so they
+  // are the windows it would have drawn in its own Setup - and only they are decoded: the entropy decoder stops at the
+  // window's last MCU row, the block and colour kernels serve its MCU rectangle.  The pixels the consumer resamples are
+  // the ones a full decode holds at those positions (tests/test_gpu_jpeg.py: a window decode equals decode-then-crop),
+  // so the pipeline's output does not change by a bit; what disappears is the 58 % of every image the crop throws away.
+  using RoiSource = std::function<void(int n, const int32_t *upright_hw, int32_t *rois)>;
+  // (the decoded-image cache keeps whole images; the opt-in colour output of the block kernel works on whole frames)
+  bool CanTakeRoiSource() const { return cache_ == nullptr && !fuse_color_; }
+  void SetRoiSource(RoiSource source) { roi_source_ = std::move(source); }
+
+ protected:
+  RoiSource roi_source_;
 
  private:
   std::vector<daliamdJpegRoiPlan> plans_;
@@ -1285,6 +1306,41 @@ class RandomResizedCropGpu : public OperatorBase {
   }
   void EnableFusion() { fused_ = true; }
 
+  // The producer decodes only the windows (ImageDecoderMixed::SetRoiSource): it asks for them when ITS stage runs, an
+  // iteration or more ahead of this operator's Setup, which then finds its input already cropped.  Same generator, same
+  // order of draws, same advance per batch as without the fusion.
+  // (the Gaussian window's reach is not a multiple of the scale that is written down anywhere: no fusion for it)
+  bool CanTakeCroppedInput() const {
+    return filters_.min_filter != DALIAMD_INTERP_GAUSSIAN && filters_.mag_filter != DALIAMD_INTERP_GAUSSIAN && filters_.dtype < 0;
+  }
+  void ExpectCroppedInput() { cropped_input_ = true; }
+  // rois[4 i ..] = the window of image i to DECODE: the crop window plus the reach of the resampling filter on every side
+  // (the filters' taps at the window's edge are pixels of the image, not repetitions of the edge), cut to the image.  The
+  // resampling set-up is told where that window sits (daliamdResampleArgs.full_h ...) and refuses one that is too small.
+  void DrawWindows(int n, const int32_t *shapes_hw, int32_t *rois) {
+    Drawn d;
+    d.anchors.resize(2 * n); d.crops.resize(2 * n); d.full_hw.assign(shapes_hw, shapes_hw + 2 * n); d.window.resize(4 * n);
+    std::lock_guard<std::mutex> g(drawn_mu_);
+    d.state_before = master_;
+    if (daliamdRandomCropBatch(&master_, n, shapes_hw, ar_lo_, ar_hi_, area_lo_, area_hi_, num_attempts_, d.anchors.data(),
+                               d.crops.data()) != 0)
+      DALI_FAIL(daliamdHostGetLastErrorMessage());
+    daliamdPhiloxAdvanceSequence(&master_, (uint64_t)n);  // OperatorWithRng::Advance(batch)
+    const int out[2] = {out_h_, out_w_};
+    for (int i = 0; i < n; i++)
+      for (int a = 0; a < 2; a++) {   // a = 0: rows, 1: columns
+        const int crop = d.crops[2 * i + a], anchor = d.anchors[2 * i + a], size = shapes_hw[2 * i + a];
+        const int type = out[a] < crop ? filters_.min_filter : filters_.mag_filter;
+        const float per_unit = type == DALIAMD_INTERP_LANCZOS3 ? 3.0f : type == DALIAMD_INTERP_CUBIC ? 2.0f : 1.0f;
+        const float ratio = filters_.antialias && crop > out[a] ? (float)crop / (float)out[a] : 1.0f;
+        const int reach = (int)std::ceil(per_unit * ratio) + 2;
+        const int lo = std::max(0, anchor - reach), hi = std::min(size, anchor + crop + reach);
+        d.window[4 * i + a] = lo; d.window[4 * i + 2 + a] = hi - lo;
+        rois[4 * i + a] = lo; rois[4 * i + 2 + a] = hi - lo;
+      }
+    drawn_.push_back(std::move(d));
+  }
+
   bool SetupImpl(std::vector<OutputDesc> &desc, const Workspace &ws) override {
     const TensorList &in = ws.Input(0);
     int n = in.num_samples();
@@ -1296,9 +1352,26 @@ class RandomResizedCropGpu : public OperatorBase {
       shapes_hw_[2 * i] = args_[i].in_h; shapes_hw_[2 * i + 1] = args_[i].in_w;
       ch = args_[i].channels;
     }
-    if (daliamdRandomCropBatch(&master_, n, shapes_hw_.data(), ar_lo_, ar_hi_, area_lo_, area_hi_, num_attempts_,
-                               anchors_.data(), crops_.data()) != 0)
+    if (cropped_input_) {
+      // the windows of this iteration were drawn when the producer ran: the input IS the window
+      std::lock_guard<std::mutex> g(drawn_mu_);
+      DALI_ENFORCE(!drawn_.empty() && (int)drawn_.front().crops.size() == 2 * n,
+                   "internal: RandomResizedCrop expected the windows its producer decoded");
+      Drawn d = std::move(drawn_.front());
+      drawn_.pop_front();
+      crops_ = std::move(d.crops);
+      anchors_ = std::move(d.anchors);
+      for (int i = 0; i < n; i++) {
+        DALI_ENFORCE(shapes_hw_[2 * i] == d.window[4 * i + 2] && shapes_hw_[2 * i + 1] == d.window[4 * i + 3],
+                     "internal: RandomResizedCrop expected a ", d.window[4 * i + 2], " x ", d.window[4 * i + 3], " window, got ",
+                     shapes_hw_[2 * i], " x ", shapes_hw_[2 * i + 1]);
+        args_[i].full_h = d.full_hw[2 * i]; args_[i].full_w = d.full_hw[2 * i + 1];
+        args_[i].org_y = d.window[4 * i]; args_[i].org_x = d.window[4 * i + 1];
+      }
+    } else if (daliamdRandomCropBatch(&master_, n, shapes_hw_.data(), ar_lo_, ar_hi_, area_lo_, area_hi_, num_attempts_,
+                                      anchors_.data(), crops_.data()) != 0) {
       DALI_FAIL(daliamdHostGetLastErrorMessage());
+    }
     for (int i = 0; i < n; i++) {
       auto &a = args_[i];
       a.use_roi = 1;
@@ -1337,19 +1410,31 @@ class RandomResizedCropGpu : public OperatorBase {
       DALI_ENFORCE(out.is_dense() || n_ == 0, "internal: resample output must be dense");
       LaunchResample(ws, uploader_, args_, descs_, "resample");
     }
-    daliamdPhiloxAdvanceSequence(&master_, (uint64_t)n_);  // OperatorWithRng::Advance(batch)
+    if (!cropped_input_) daliamdPhiloxAdvanceSequence(&master_, (uint64_t)n_);  // OperatorWithRng::Advance(batch)
   }
 
   std::string SaveState() const override {
     char buf[96];
-    daliamdPhiloxStateToString(&master_, buf, sizeof(buf));
+    std::lock_guard<std::mutex> g(drawn_mu_);
+    // (windows drawn for iterations this operator has not run yet are not part of what has been handed out)
+    daliamdPhiloxStateToString(drawn_.empty() ? &master_ : &drawn_.front().state_before, buf, sizeof(buf));
     return buf;
   }
   void RestoreState(const std::string &s) override {
+    std::lock_guard<std::mutex> g(drawn_mu_);
+    drawn_.clear();
     DALI_ENFORCE(daliamdPhiloxStateFromString(&master_, s.c_str()) == 0, daliamdHostGetLastErrorMessage());
   }
 
  private:
+  struct Drawn {
+    daliamdPhiloxState state_before;
+    std::vector<int32_t> anchors, crops;   // the crop windows, in image coordinates
+    std::vector<int32_t> full_hw, window;  // the images' sizes; what the producer decodes: {y0, x0, h, w} per sample
+  };
+  bool cropped_input_ = false;
+  mutable std::mutex drawn_mu_;
+  std::deque<Drawn> drawn_;
   FilterArgs filters_;
   int out_h_, out_w_, num_attempts_, n_ = 0, ch_ = 3;
   float ar_lo_, ar_hi_, area_lo_, area_hi_;
@@ -1926,6 +2011,18 @@ class CropMirrorNormalizeGpu : public OperatorBase {
 };
 DALI_REGISTER_OPERATOR(CropMirrorNormalize, CropMirrorNormalizeGpu, GPU);
 DALI_REGISTER_OPERATOR(CropMirrorNormalize, CropMirrorNormalizeGpu, CPU);  // same class: host kernels when run on the CPU
+
+bool TryEnableRoiDecodeFusion(OperatorBase *decoder, OperatorBase *consumer) {
+  auto *dec = dynamic_cast<ImageDecoderMixed *>(decoder);
+  auto *rrc = dynamic_cast<RandomResizedCropGpu *>(consumer);
+  // (the crop decoders are ImageDecoderMixed too: they have their own windows)
+  if (!dec || !rrc || !dec->CanTakeRoiSource() || !rrc->CanTakeCroppedInput() || dynamic_cast<ImageDecoderRandomCropMixed *>(decoder) ||
+      dynamic_cast<ImageDecoderCropMixed *>(decoder) || dynamic_cast<ImageDecoderSliceMixed *>(decoder))
+    return false;
+  rrc->ExpectCroppedInput();
+  dec->SetRoiSource([rrc](int n, const int32_t *hw, int32_t *rois) { rrc->DrawWindows(n, hw, rois); });
+  return true;
+}
 
 void TryEnableFusion(OperatorBase *producer, OperatorBase *consumer) {
   auto *rrc = dynamic_cast<RandomResizedCropGpu *>(producer);

@@ -178,6 +178,19 @@ void Pipeline::Build(const std::vector<std::pair<std::string, std::string>> &out
     Node &p = nodes_[n.in_node[0]];
     if (consumers[n.in_node[0]] == 1 && p.type == OpType::GPU) TryEnableFusion(p.op.get(), n.op.get());
   }
+  // ... and a decoders.image feeding ONLY a RandomResizedCrop decodes just the windows that operator draws
+  {
+    const char *env = getenv("DALI_AMD_ROI_FUSION");
+    if (!env || atoi(env) != 0)
+      for (auto &n : nodes_) {
+        if (n.spec.SchemaName() != "RandomResizedCrop" || n.in_node.empty() || n.type != OpType::GPU) continue;
+        Node &p = nodes_[n.in_node[0]];
+        const std::string &pn = p.spec.SchemaName();
+        if (consumers[n.in_node[0]] == 1 && p.type == OpType::MIXED &&
+            (pn == "decoders__Image" || pn == "ImageDecoder" || pn == "experimental__decoders__Image"))
+          roi_decode_fused_ = TryEnableRoiDecodeFusion(p.op.get(), n.op.get()) || roi_decode_fused_;
+      }
+  }
   // ... and a ColorTwist feeding ONLY an Erase becomes part of its launch
   for (auto &n : nodes_) {
     if (n.spec.SchemaName() != "Erase" || n.in_node.empty() || n.type != OpType::GPU) continue;

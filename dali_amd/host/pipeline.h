@@ -126,6 +126,7 @@ class Pipeline {
   std::vector<std::pair<int, int>> outputs_;
   bool built_ = false;
   bool op_timing_ = false;
+  bool roi_decode_fused_ = false;   // a decoders.image -> random_resized_crop pair decodes windows only (Build)
   bool trace_ = false;  // DALI_AMD_TRACE=1: per-operator host time summary on stderr when the pipeline is destroyed
   int64_t traced_iterations_ = 0;
   double slot_wait_seconds_ = 0;  // host stage blocked on the ring slot's previous user

@@ -341,6 +341,12 @@ typedef struct {
    * of the second pass as it is (fn.resize(dtype=FLOAT)).  These take a plain two-launch path (fp32 intermediate in the
    * workspace), not the fused tile kernel; `normalize` must be 0. */
   int32_t in_dtype, unrounded;
+  /* full_h > 0: `in` holds only the window [org_y, org_y + in_h) x [org_x, org_x + in_w) of a full_h x full_w image, and
+   * the region of interest (required) is given in THAT image's coordinates.  All coordinate arithmetic - filter centres,
+   * coefficients, pass order, border clamping - is the full image's, so the result equals resampling the full image bit
+   * for bit; the window must contain every source pixel the filters touch (the set-up refuses it otherwise).  This is
+   * what lets a decoder that feeds only a RandomResizedCrop decode the crop window instead of the image. */
+  int32_t full_h, full_w, org_y, org_x;
 } daliamdResampleArgs;
 
 typedef struct {
