@@ -126,7 +126,7 @@ void TensorList::Resize(const std::vector<TensorShape> &shapes, DALIDataType typ
   }
   total_ = off;
   if (!buf_ || buf_.use_count() > 1) buf_ = std::make_shared<Buffer>(dev_);  // never resize shared storage
-  buf_->Reserve(std::max<size_t>(off, 256));
+  buf_->Reserve(std::max<size_t>(std::max(off, min_reserve_), 256));
   deferred.reset();
   deferred_pointwise.reset();
   deferred_audio.reset();

@@ -127,9 +127,14 @@ class TensorList {
   size_t nbytes(int i) const { return sizes_[i]; }
   bool is_dense() const;
   size_t total_bytes() const { return total_; }
+  size_t min_reserve_ = 0;
 
   // Allocates one contiguous block; every sample starts at a 256-byte boundary.  For 3-D u8 samples
   // `pitch_align` > 1 pads each row to that many bytes (internal hand-off between device operators).
+  // Storage is never smaller than this from the next Resize on (a producer whose sample sizes change from iteration to
+  // iteration - decoded crop windows - names its upper bound once instead of growing, i.e. re-allocating device memory,
+  // whenever a batch sets a new record)
+  void SetMinReserve(size_t bytes) { if (bytes > min_reserve_) min_reserve_ = bytes; }
   void Resize(const std::vector<TensorShape> &shapes, DALIDataType type, int pitch_align = 1);
   // Same, but sample i lives in caller-owned memory when ext_ptr[i] != nullptr (row pitch ext_pitch[i]): no space is
   // set aside for it in the block and raw(i) returns that pointer.  `keepalive` owns the external memory (the decoded

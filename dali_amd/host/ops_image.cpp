@@ -359,6 +359,18 @@ class ImageDecoderMixed : public OperatorBase {
     ecs_dev.Reserve(ecs_bytes + table_bytes + 256);
     scratch.Reserve(scratch_bytes + 256);
     status_host.Reserve(sizeof(int32_t) * (size_t)std::max(n, 1));
+    {
+      // windows change from iteration to iteration: the output is sized for the whole images once, so that a batch with a
+      // new record of window bytes does not re-allocate device memory (a synchronising call) in the middle of an epoch
+      size_t whole = 0;
+      bool windows = false;
+      for (int i = 0; i < n; i++) {
+        windows = windows || rois_[4 * i + 2] > 0;
+        const size_t row = ((size_t)upright_hw_[2 * i + 1] * oc_ + kImagePitchAlign - 1) / kImagePitchAlign * kImagePitchAlign;
+        whole += (row * (size_t)upright_hw_[2 * i] + 255) & ~(size_t)255;
+      }
+      if (windows && !cache_) out.SetMinReserve(whole);
+    }
     out.Resize(shapes, DALI_UINT8, kImagePitchAlign, ext_ptr, ext_pitch, cache_);
     out.SetLayout("HWC");
     out.source_info = in.source_info;
