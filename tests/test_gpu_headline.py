@@ -5,6 +5,7 @@ rotation, each iteration bit for bit equal to decode -> RandomResizedCrop -> Cro
 batch 512, the per-GPU batch of BASELINE.json configs[4].  (Each ingredient has its own test - test_gpu_config1,
 test_gpu_encoded_cache, test_gpu_pipeline; this is their product.)"""
 import gc
+import os
 
 import numpy as np
 import pytest
@@ -54,3 +55,30 @@ def test_resident_pipeline_of_the_bench_equals_oracle(tmp_path, batch, batches, 
     assert after["streams"] - before["streams"] == n
     assert after["hits"] - before["hits"] >= batch * (batches * (epochs - 1) - depth - 1)
     assert "jpeg_huffman" in pipe.executed_kernels() and "fused_resample_cmn" in pipe.executed_kernels()
+    # the graph-level fusion (the decoder decodes the windows the crop draws) is the default: bench.py's algorithmic bytes
+    # and config.roi_decode_fusion follow executed_kernels(), so a fusion that silently disengaged must fail HERE
+    if os.environ.get("DALI_AMD_ROI_FUSION", "1") != "0":
+        assert "windows_of_the_consumer" in pipe.executed_kernels()
+
+
+def test_fused_equals_unfused_at_the_bench_shape(tmp_path):
+    """The headline composition itself - batch 256, prefetch_queue_depth 5 (three compute streams), resident streams - with
+    the window decode on and off: the same bits, iteration by iteration, over three epochs (test_gpu_roi_fusion.py holds
+    the two to each other at batch 10, depth 2, from files)."""
+    import bench
+    from dali_amd.testing import synth_dataset
+    batch, batches, epochs, depth = 256, 2, 3, 5
+    n = batch * batches
+    enc = synth_dataset(0, n, seed=1234, workers=4)
+    bench.write_dataset(str(tmp_path), enc)
+    runs = {}
+    for fusion in (True, False):
+        pipe = bench.resident_pipeline(str(tmp_path), batch, 0, depth, 8, cache_mb=max(64, int(2 * sum(map(len, enc)) / 2**20)),
+                                       crop_seed=1234, flip_seed=1235, roi_fusion=fusion)
+        runs[fusion] = [pipe.run()[0].as_tensor().cpu().numpy().view(np.uint16).copy() for _ in range(batches * epochs)]
+        assert ("windows_of_the_consumer" in pipe.executed_kernels()) == fusion
+        del pipe
+        gc.collect()
+    for it, (a, b) in enumerate(zip(runs[True], runs[False])):
+        bad = np.nonzero((a != b).reshape(batch, -1).any(1))[0]
+        assert bad.size == 0, f"iteration {it}: samples {bad[:8].tolist()} differ between the fused and the full decode"
