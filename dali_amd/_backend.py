@@ -35,6 +35,7 @@ def _lib():
         lib.daliamdPipelineOutputsOnStream.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         lib.daliamdPipelineReleaseOnStream.argtypes = [C.c_void_p, C.c_void_p]
         lib.daliamdPipelineWaitEnqueued.argtypes = [C.c_void_p]
+        lib.daliamdPipelineFlushChecks.argtypes = [C.c_void_p]
         lib.daliamdPipelineOutputInfo.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_char_p, C.c_int]
         lib.daliamdPipelineOutputSample.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p),
                                                     C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int64)]
@@ -211,6 +212,10 @@ class BackendPipeline:
 
     def release_on_stream(self, stream_handle):
         check(self._lib.daliamdPipelineReleaseOnStream(self._h, C.c_void_p(stream_handle)))
+
+    def flush_checks(self):
+        """Raises the deferred completion checks (decoder status) of the last stream-ordered hand-over, if any."""
+        check(self._lib.daliamdPipelineFlushChecks(self._h))
 
     def output_info(self, idx):
         info = (C.c_int64 * 4)()

@@ -238,6 +238,9 @@ API int daliamdPipelineWaitEnqueued(void *h) {
 API int daliamdPipelineReleaseOnStream(void *h, void *consumer_stream) {
   return Guard([&] { static_cast<PipelineHandle *>(h)->pipe->ReleaseOnStream(consumer_stream); });
 }
+API int daliamdPipelineFlushChecks(void *h) {
+  return Guard([&] { static_cast<PipelineHandle *>(h)->pipe->FlushChecks(); });
+}
 // info: [0] device (0 cpu / 1 gpu), [1] dtype, [2] num_samples, [3] dense (1) or row-padded (0)
 API int daliamdPipelineOutputInfo(void *h, int idx, int64_t *info, char *layout, int layout_len) {
   return Guard([&] {

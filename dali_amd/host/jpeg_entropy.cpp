@@ -603,7 +603,14 @@ void FillScan(const Decoder &d, daliamdJpegScan *scan) {
   scan->mcus_y = (d.height + 8 * d.vmax - 1) / (8 * d.vmax);
   scan->restart_interval = d.restart_interval;
   scan->ecs_offset = (int64_t)d.first_ecs;
-  scan->ecs_length = (int64_t)(d.size - d.first_ecs);   // everything behind the SOS header
+  // Everything behind the SOS header, cut at the LAST end-of-image marker of the file (a backwards look that ends after
+  // two bytes on nearly every file): what follows an EOI - padding, an appended thumbnail's tail, trailing data - is not
+  // scan data, and without the cut it would be uploaded every iteration and held by the encoded-stream cache.
+  // Still an upper bound: the un-stuffing kernel finds where the scan really ends (an EOI further in front, if there is one).
+  size_t end = d.size;
+  for (size_t p = d.size; p >= d.first_ecs + 2; p--)
+    if (d.data[p - 2] == 0xFF && d.data[p - 1] == 0xD9) { end = p; break; }   // (the marker stays in: it ends the segment)
+  scan->ecs_length = (int64_t)(end - d.first_ecs);
   scan->length_is_upper_bound = 1;
   scan->eligible = 1;
 }

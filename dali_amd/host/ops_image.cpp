@@ -294,6 +294,15 @@ class ImageDecoderMixed : public OperatorBase {
     }
     rois_.assign(4 * n, 0);
     ComputeRois(ws, n);
+    // Windows drawn for this iteration belong to it: when the decode fails on the way out (a corrupt stream met by a host
+    // decoder, an oversized segment, a kernel-library error) the consumer never runs for this iteration, so the draw is
+    // taken back - the next iteration then gets the windows it would have got without the fusion
+    struct RoiDraw {
+      std::function<void(int64_t)> undo;
+      int64_t iteration;
+      bool armed;
+      ~RoiDraw() { if (armed && undo) undo(iteration); }
+    } roi_draw{roi_undo_, (int64_t)ws.iteration, roi_source_ != nullptr};
     plans_.assign(n, daliamdJpegRoiPlan{});
     std::vector<void *> ext_ptr(cache_ ? n : 0, nullptr);
     std::vector<int64_t> ext_pitch(cache_ ? n : 0, 0);
@@ -441,7 +450,7 @@ class ImageDecoderMixed : public OperatorBase {
       ws.GetThreadPool().RunAll();
     }
     lap(2);
-    if (nact == 0) return;  // empty batch, or every sample came from the cache / was not a JPEG
+    if (nact == 0) { roi_draw.armed = false; return; }  // empty batch, or every sample came from the cache / was not a JPEG
     // ---- entropy decoding on the device ----
     int16_t *coef = static_cast<int16_t *>(cdev.data());
     // descriptor tables: built in the pinned staging buffer, addressed on the device at the same offsets
@@ -645,13 +654,14 @@ class ImageDecoderMixed : public OperatorBase {
       cache_->Commit(reserved.keys, ws.stream);  // visible to later iterations (and other pipelines) from here on
       reserved.keys.clear();
     }
+    roi_draw.armed = false;
     lap(4);
   }
 
  protected:
   // Fills rois_[4*i .. 4*i+3] = {y0, x0, h, w} (h == 0: whole image) from upright_hw_ = {H, W} per sample.
-  virtual void ComputeRois(const Workspace &, int n) {
-    if (roi_source_) roi_source_(n, upright_hw_.data(), rois_.data());
+  virtual void ComputeRois(const Workspace &ws, int n) {
+    if (roi_source_) roi_source_((int64_t)ws.iteration, n, upright_hw_.data(), rois_.data());
   }
   std::vector<int32_t> upright_hw_, rois_;
 
@@ -662,13 +672,15 @@ class ImageDecoderMixed : public OperatorBase {
   // window's last MCU row, the block and colour kernels serve its MCU rectangle.  The pixels the consumer resamples are
   // the ones a full decode holds at those positions (tests/test_gpu_jpeg.py: a window decode equals decode-then-crop),
   // so the pipeline's output does not change by a bit; what disappears is the 58 % of every image the crop throws away.
-  using RoiSource = std::function<void(int n, const int32_t *upright_hw, int32_t *rois)>;
+  using RoiSource = std::function<void(int64_t iteration, int n, const int32_t *upright_hw, int32_t *rois)>;
   // (the decoded-image cache keeps whole images; the opt-in colour output of the block kernel works on whole frames)
   bool CanTakeRoiSource() const { return cache_ == nullptr && !fuse_color_; }
-  void SetRoiSource(RoiSource source) { roi_source_ = std::move(source); }
+  // undo(iteration): the windows drawn for `iteration` will not be decoded (the decoder failed behind the draw)
+  void SetRoiSource(RoiSource source, std::function<void(int64_t)> undo) { roi_source_ = std::move(source); roi_undo_ = std::move(undo); }
 
  protected:
   RoiSource roi_source_;
+  std::function<void(int64_t)> roi_undo_;
 
  private:
   std::vector<daliamdJpegRoiPlan> plans_;
@@ -1329,8 +1341,9 @@ class RandomResizedCropGpu : public OperatorBase {
   // rois[4 i ..] = the window of image i to DECODE: the crop window plus the reach of the resampling filter on every side
   // (the filters' taps at the window's edge are pixels of the image, not repetitions of the edge), cut to the image.  The
   // resampling set-up is told where that window sits (daliamdResampleArgs.full_h ...) and refuses one that is too small.
-  void DrawWindows(int n, const int32_t *shapes_hw, int32_t *rois) {
+  void DrawWindows(int64_t iteration, int n, const int32_t *shapes_hw, int32_t *rois) {
     Drawn d;
+    d.iteration = iteration;
     d.anchors.resize(2 * n); d.crops.resize(2 * n); d.full_hw.assign(shapes_hw, shapes_hw + 2 * n); d.window.resize(4 * n);
     std::lock_guard<std::mutex> g(drawn_mu_);
     d.state_before = master_;
@@ -1352,6 +1365,15 @@ class RandomResizedCropGpu : public OperatorBase {
       }
     drawn_.push_back(std::move(d));
   }
+  // The producer failed behind its draw for `iteration`: that iteration never reaches this operator.  The generator goes
+  // back to where it stood, so the next iteration draws what it would have drawn without the fusion (there the operator
+  // simply does not run in a failed iteration).  The producer draws in iteration order: the entry is the newest one.
+  void UndoDraw(int64_t iteration) {
+    std::lock_guard<std::mutex> g(drawn_mu_);
+    if (drawn_.empty() || drawn_.back().iteration != iteration) return;
+    master_ = drawn_.back().state_before;
+    drawn_.pop_back();
+  }
 
   bool SetupImpl(std::vector<OutputDesc> &desc, const Workspace &ws) override {
     const TensorList &in = ws.Input(0);
@@ -1367,7 +1389,10 @@ class RandomResizedCropGpu : public OperatorBase {
     if (cropped_input_) {
       // the windows of this iteration were drawn when the producer ran: the input IS the window
       std::lock_guard<std::mutex> g(drawn_mu_);
-      DALI_ENFORCE(!drawn_.empty() && (int)drawn_.front().crops.size() == 2 * n,
+      // (windows of an iteration that never got here - belt and braces next to UndoDraw - are not this iteration's)
+      while (!drawn_.empty() && drawn_.front().iteration < (int64_t)ws.iteration) drawn_.pop_front();
+      DALI_ENFORCE(!drawn_.empty() && drawn_.front().iteration == (int64_t)ws.iteration &&
+                       (int)drawn_.front().crops.size() == 2 * n,
                    "internal: RandomResizedCrop expected the windows its producer decoded");
       Drawn d = std::move(drawn_.front());
       drawn_.pop_front();
@@ -1440,6 +1465,7 @@ class RandomResizedCropGpu : public OperatorBase {
 
  private:
   struct Drawn {
+    int64_t iteration = 0;
     daliamdPhiloxState state_before;
     std::vector<int32_t> anchors, crops;   // the crop windows, in image coordinates
     std::vector<int32_t> full_hw, window;  // the images' sizes; what the producer decodes: {y0, x0, h, w} per sample
@@ -2032,7 +2058,8 @@ bool TryEnableRoiDecodeFusion(OperatorBase *decoder, OperatorBase *consumer) {
       dynamic_cast<ImageDecoderCropMixed *>(decoder) || dynamic_cast<ImageDecoderSliceMixed *>(decoder))
     return false;
   rrc->ExpectCroppedInput();
-  dec->SetRoiSource([rrc](int n, const int32_t *hw, int32_t *rois) { rrc->DrawWindows(n, hw, rois); });
+  dec->SetRoiSource([rrc](int64_t it, int n, const int32_t *hw, int32_t *rois) { rrc->DrawWindows(it, n, hw, rois); },
+                    [rrc](int64_t it) { rrc->UndoDraw(it); });
   return true;
 }
 

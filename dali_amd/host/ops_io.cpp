@@ -132,8 +132,10 @@ DALI_SCHEMA(LoaderBase)
     .AddOptionalArg("lazy_init", "Parse and prepare the dataset metadata only during the first run.", ArgValue::Bool(false))
     .AddOptionalArg("pad_last_batch", "If set to True, pads the shard by repeating the last sample.", ArgValue::Bool(false))
     .AddOptionalArg("dont_use_mmap", "If set to True, the loader uses plain file I/O instead of mapping the files in "
-                    "memory.  (readers.file: mapped files stay mapped - up to DALI_AMD_READER_MMAP_MB, 4096 by default - and "
-                    "later epochs copy them from the mapping; the other readers always use plain I/O.)", ArgValue::Bool(false))
+                    "memory.  (readers.file: mapped files stay mapped - all readers of the process together up to the environment "
+                    "variable DALI_AMD_READER_MMAP_MB, 4096 by default, 0 = plain reads - and later epochs copy them from the "
+                    "mapping; a reader keeps at most DALI_AMD_READER_FD_CAP descriptors open, by default a quarter of the "
+                    "process's soft RLIMIT_NOFILE, which it never changes; the other readers always use plain I/O.)", ArgValue::Bool(false))
     .AddRandomSeedArg();
 
 DALI_SCHEMA(readers__File)
@@ -356,24 +358,20 @@ class FileReaderOp : public OperatorBase {
     // means TLB shoot-downs on every core the process runs on); files beyond the budget are read with pread.
     maps_ = std::make_unique<std::atomic<const char *>[]>(entries_.size());
     for (size_t i = 0; i < entries_.size(); i++) maps_[i].store(nullptr, std::memory_order_relaxed);
+    // Both budgets are PROCESS-wide: the mappings of all readers of the process together stay below
+    // DALI_AMD_READER_MMAP_MB (4096 by default; 0: plain reads) - SharedMappedBytes() - and a reader keeps at most
+    // DALI_AMD_READER_FD_CAP descriptors open, by default a quarter of the soft limit the process was STARTED with.  The
+    // limit itself is the host application's: an operator does not raise it (descriptors above 1023 break select()-based
+    // code elsewhere in the process).
     map_budget_ = (int64_t)4096 << 20;
     if (const char *e = getenv("DALI_AMD_READER_MMAP_MB")) map_budget_ = (int64_t)(std::max(0.0, atof(e)) * 1048576.0);
     if (!use_mmap_) map_budget_ = 0;
-    // long-lived descriptors: at most half of what the process may open (the soft limit is raised to the hard one when a
-    // small data set would otherwise not fit - every file of the shard is then opened once, not once per epoch)
     struct rlimit rl;
     size_t cap = 256;
-    if (getrlimit(RLIMIT_NOFILE, &rl) == 0) {
-      if (rl.rlim_cur != RLIM_INFINITY && rl.rlim_cur < entries_.size() * 2 + 512 && rl.rlim_cur < rl.rlim_max) {
-        rlimit want = rl;
-        want.rlim_cur = rl.rlim_max == RLIM_INFINITY ? (rlim_t)(entries_.size() * 2 + 512)
-                                                     : std::min<rlim_t>(rl.rlim_max, (rlim_t)(entries_.size() * 2 + 512));
-        if (setrlimit(RLIMIT_NOFILE, &want) == 0) rl = want;
-      }
-      cap = rl.rlim_cur == RLIM_INFINITY ? 65536 : (size_t)std::min<rlim_t>(rl.rlim_cur / 2, 65536);
-    }
-    fd_cap_ = std::max<size_t>(64, cap);
-    if (const char *e = getenv("DALI_AMD_READER_FD_CAP")) fd_cap_ = (size_t)std::max(1, atoi(e));   // (tests: forces evictions)
+    if (getrlimit(RLIMIT_NOFILE, &rl) == 0)
+      cap = rl.rlim_cur == RLIM_INFINITY ? 16384 : (size_t)std::min<rlim_t>(rl.rlim_cur / 4, 16384);
+    fd_cap_ = std::max<size_t>(16, cap);
+    if (const char *e = getenv("DALI_AMD_READER_FD_CAP")) fd_cap_ = (size_t)std::max(1, atoi(e));
     int workers = std::max(1, (int)spec.GetInt("num_threads"));
     if (const char *e = getenv("DALI_AMD_READER_THREADS")) workers = std::max(1, atoi(e));
     // eight readers copy a 25 MB batch out of the page cache in 0.3 ms; more only contend inside the kernel (MI355X host,
@@ -387,7 +385,10 @@ class FileReaderOp : public OperatorBase {
       const int fd = fds_[i].load(std::memory_order_relaxed);
       if (fd >= 0) close(fd);
       const char *m = maps_[i].load(std::memory_order_relaxed);
-      if (m && m != kNoMapping) munmap(const_cast<char *>(m), (size_t)size_cache_[i]);
+      if (m && m != kNoMapping) {
+        munmap(const_cast<char *>(m), (size_t)size_cache_[i]);
+        SharedMappedBytes().fetch_sub((int64_t)size_cache_[i], std::memory_order_relaxed);
+      }
     }
   }
 
@@ -624,8 +625,8 @@ class FileReaderOp : public OperatorBase {
   const char *Mapping(int64_t idx, int fd, off_t size) {
     const char *m = maps_[idx].load(std::memory_order_acquire);
     if (m) return m == kNoMapping ? nullptr : m;
-    if (size <= 0 || mapped_bytes_.fetch_add((int64_t)size, std::memory_order_relaxed) + (int64_t)size > map_budget_) {
-      mapped_bytes_.fetch_sub(size > 0 ? (int64_t)size : 0, std::memory_order_relaxed);
+    if (size <= 0 || SharedMappedBytes().fetch_add((int64_t)size, std::memory_order_relaxed) + (int64_t)size > map_budget_) {
+      SharedMappedBytes().fetch_sub(size > 0 ? (int64_t)size : 0, std::memory_order_relaxed);
       maps_[idx].store(kNoMapping, std::memory_order_release);
       return nullptr;
     }
@@ -635,14 +636,14 @@ class FileReaderOp : public OperatorBase {
     void *p = fstat(fd, &st) == 0 && st.st_size == size
                   ? mmap(nullptr, (size_t)size, PROT_READ, MAP_SHARED | MAP_POPULATE, fd, 0) : MAP_FAILED;
     if (p == MAP_FAILED) {
-      mapped_bytes_.fetch_sub((int64_t)size, std::memory_order_relaxed);
+      SharedMappedBytes().fetch_sub((int64_t)size, std::memory_order_relaxed);
       maps_[idx].store(kNoMapping, std::memory_order_release);
       return nullptr;
     }
     const char *expected = nullptr;
     if (!maps_[idx].compare_exchange_strong(expected, static_cast<const char *>(p), std::memory_order_acq_rel)) {
       munmap(p, (size_t)size);   // another reader mapped the same file (a sample repeated inside the batches in flight)
-      mapped_bytes_.fetch_sub((int64_t)size, std::memory_order_relaxed);
+      SharedMappedBytes().fetch_sub((int64_t)size, std::memory_order_relaxed);
       return expected == kNoMapping ? nullptr : expected;
     }
     return static_cast<const char *>(p);
@@ -685,7 +686,8 @@ class FileReaderOp : public OperatorBase {
   bool skip_cached_, read_ahead_, use_mmap_;
   std::unique_ptr<std::atomic<const char *>[]> maps_;   // per file: nullptr = not tried yet, kNoMapping = pread, else the mapping
   static inline const char *const kNoMapping = reinterpret_cast<const char *>(1);
-  std::atomic<int64_t> mapped_bytes_{0};
+  // bytes mapped by every readers.file of the process (the budget is per process, not per reader)
+  static std::atomic<int64_t> &SharedMappedBytes() { static std::atomic<int64_t> v{0}; return v; }
   int64_t map_budget_ = 0;
   int device_id_, depth_, num_workers_ = 1;
   std::vector<off_t> size_cache_;  // planner thread

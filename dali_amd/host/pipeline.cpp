@@ -37,6 +37,13 @@ Pipeline::~Pipeline() {
   if (cpu_worker_.joinable()) cpu_worker_.join();
   if (worker_.joinable()) worker_.join();
   for (auto st : streams_) daliamdStreamSynchronize(st);
+  // a deferred completion check that nobody asked for any more (the last stream-ordered hand-over before the pipeline
+  // went away): a destructor cannot throw - say what it found
+  try {
+    RunPendingChecks();
+  } catch (const std::exception &e) {
+    fprintf(stderr, "[dali_amd] error of the last iteration handed out, found when the pipeline was destroyed: %s\n", e.what());
+  }
   if (trace_ && traced_iterations_ > 0) {
     fprintf(stderr, "[dali_amd trace] host time per iteration over %lld iterations (worker thread):\n",
             (long long)traced_iterations_);

@@ -53,6 +53,10 @@ class Pipeline {
   // written again before everything in that stream up to this call has completed.  (Without this call a consumer
   // that took the outputs with OutputsOnStream must have finished reading on its own.)
   void ReleaseOnStream(daliamdStream_t consumer_stream);
+  // Completion checks of a stream-ordered hand-over that were deferred (the iteration was still running): waits for that
+  // iteration and raises its error now - the iterator calls this behind the last batch of an epoch, where no later
+  // Outputs*() call would.
+  void FlushChecks() { RunPendingChecks(); }
   // blocks until the device work of every scheduled iteration has been ENQUEUED (its host and device stages have run);
   // a device synchronisation behind this call then covers everything Run() has asked for (benchmarks: the end of a
   // timed region)

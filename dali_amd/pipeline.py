@@ -195,8 +195,12 @@ class Pipeline:
         does not wait for the iteration's device work, that stream does; release with release_outputs(cuda_stream)."""
         if self._scheduled <= self._consumed:
             raise RuntimeError("There are no scheduled runs; call schedule_run() first")
-        n = self._backend.outputs() if cuda_stream is None else self._backend.outputs_on_stream(int(cuda_stream))
-        self._consumed += 1
+        try:
+            n = self._backend.outputs() if cuda_stream is None else self._backend.outputs_on_stream(int(cuda_stream))
+        finally:
+            # an iteration that failed is consumed all the same (the executor has counted it and goes on with the next one):
+            # the pipeline stays usable, the error belongs to this call only
+            self._consumed += 1
         outs = []
         for i in range(n):
             info = self._backend.output_info(i)
@@ -210,6 +214,13 @@ class Pipeline:
         if cuda_stream is not None and self._held is not None:
             self._backend.release_on_stream(int(cuda_stream))
         self._held = None
+
+    def flush_checks(self):
+        """Stream-ordered hand-over (share_outputs(cuda_stream=...)): the completion checks of an iteration whose device work
+        was still running when it was handed out are raised by the NEXT share_outputs call - or by this one, which waits for
+        that iteration (the iterators call it behind the last batch of an epoch)."""
+        if self._built:
+            self._backend.flush_checks()
 
     def outputs(self):
         self.release_outputs()

@@ -129,6 +129,11 @@ class _DaliBaseIterator:
         stream-ordered hand-over (Pipeline.share_outputs(cuda_stream=...))."""
         return pipe.run()
 
+    def _epoch_ended(self):
+        """Hook: the epoch is over, nothing handed out so far is followed by another fetch."""
+        for p in self._pipes:
+            p.flush_checks()
+
     # ---- epoch logic
     def _fetch(self):
         if self._size > 0 and self._counter >= self._size:
@@ -155,6 +160,7 @@ class _DaliBaseIterator:
         return self._convert(outs, valid)
 
     def _end_epoch(self):
+        self._epoch_ended()
         if self._auto_reset == "yes":
             self.reset()
         raise StopIteration

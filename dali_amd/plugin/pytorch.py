@@ -76,15 +76,26 @@ class DALIGenericIterator(_DaliBaseIterator):
         self._handed.append((pipe, stream))
         return outs
 
+    def _epoch_ended(self):
+        # outputs taken by _run_pipe for a batch that is dropped (the epoch ends instead of a conversion): nothing reads
+        # them, release them without a stream; then the deferred checks of the last batch that WAS handed out
+        handed, self._handed = self._handed, []
+        for pipe, _stream in handed:
+            pipe.release_outputs()
+        super()._epoch_ended()
+
     def _convert(self, outputs_per_pipe, valid_per_pipe):
         result = []
         handed, self._handed = self._handed, []
+        # the stream each pipeline's outputs were handed over on (share_outputs made THAT stream wait for the batch): the
+        # copies run there and the release is recorded there, whatever the caller's current stream has become since
+        stream_of = {id(pipe): stream for pipe, stream in handed}
         try:
             for g, outs in enumerate(outputs_per_pipe):
                 assert len(outs) == len(self.output_map), \
                     f"The pipeline returns {len(outs)} outputs but output_map has {len(self.output_map)} names"
                 valid = None if valid_per_pipe is None else int(valid_per_pipe[g])
-                stream = self._consumer_stream(self._pipes[g])
+                stream = stream_of.get(id(self._pipes[g])) or self._consumer_stream(self._pipes[g])
                 entry = {}
                 for name, tl in zip(self.output_map, outs):
                     if isinstance(tl, TensorListGPU):

@@ -65,6 +65,10 @@ DALIAMD_PIPE_API int daliamdPipelineOutputs(void *pipe, int *num_outputs);
  * of an iteration are raised by the Outputs* call for it or by the next one. */
 DALIAMD_PIPE_API int daliamdPipelineOutputsOnStream(void *pipe, void *consumer_stream, int *num_outputs);
 DALIAMD_PIPE_API int daliamdPipelineReleaseOnStream(void *pipe, void *consumer_stream);
+/* The completion checks of the last OutputsOnStream hand-over, if they were deferred: waits for that iteration's device work
+ * and reports its error (the reference raises at the iteration that failed; a stream-ordered hand-over raises at the next
+ * Outputs* call, or here - the iterator calls this behind the last batch of an epoch). */
+DALIAMD_PIPE_API int daliamdPipelineFlushChecks(void *pipe);
 /* Blocks until the device work of every iteration scheduled so far has been enqueued on the pipeline's streams: a device
  * synchronisation behind it covers all of it (the end of a benchmark's timed region). */
 DALIAMD_PIPE_API int daliamdPipelineWaitEnqueued(void *pipe);

@@ -171,3 +171,53 @@ def test_checkpoint_resumes_the_window_sequence(tmp_path):
     got = [b.run()[0].as_tensor().cpu().numpy().copy() for _ in range(3)]
     for x, y in zip(want, got):
         assert np.array_equal(x, y)
+
+
+def test_failed_decode_does_not_shift_the_window_sequence(tmp_path):
+    """the windows of an iteration are drawn when the DECODER runs.  A decode that fails behind the draw (here: a
+    PNG whose header parses and whose pixel data is cut off) must take the draw back - the crop operator never runs for
+    that iteration - so that every later iteration succeeds and gets the windows it gets without the fusion."""
+    from dali_amd import fn, types
+    from dali_amd.pipeline import Pipeline
+    rng = np.random.default_rng(11)
+    os.makedirs(tmp_path / "0")
+    for i in range(12):
+        buf = io.BytesIO()
+        if i == 5:
+            Image.fromarray(synth_image(rng, 90, 120)).save(buf, "PNG")
+            data = buf.getvalue()[:200]          # signature + IHDR + the start of IDAT
+        else:
+            Image.fromarray(synth_image(rng, 100 + 8 * i, 160)).save(buf, "JPEG", quality=85)
+            data = buf.getvalue()
+        (tmp_path / "0" / f"img_{i:03d}.{'png' if i == 5 else 'jpg'}").write_bytes(data)
+
+    def run(fusion):
+        old = os.environ.get("DALI_AMD_ROI_FUSION")
+        os.environ["DALI_AMD_ROI_FUSION"] = "1" if fusion else "0"
+        try:
+            pipe = Pipeline(batch_size=4, num_threads=2, device_id=0, seed=3, prefetch_queue_depth=2)
+            with pipe:
+                jpegs, _ = fn.readers.file(file_root=str(tmp_path), name="Reader")
+                images = fn.decoders.image(jpegs, device="mixed", output_type=types.RGB)
+                pipe.set_outputs(fn.random_resized_crop(images, size=[64, 64], seed=99))
+            pipe.build()
+        finally:
+            if old is None:
+                os.environ.pop("DALI_AMD_ROI_FUSION", None)
+            else:
+                os.environ["DALI_AMD_ROI_FUSION"] = old
+        res = []
+        for _ in range(6):
+            try:
+                res.append(pipe.run()[0].as_tensor().cpu().numpy().copy())
+            except RuntimeError as e:
+                assert "img_005" in str(e), str(e)
+                res.append(None)
+        return res, pipe.executed_kernels()
+    fused, k1 = run(True)
+    plain, k0 = run(False)
+    assert "windows_of_the_consumer" in k1 and "windows_of_the_consumer" not in k0
+    assert [r is None for r in fused] == [r is None for r in plain] == [False, True, False, False, True, False]
+    for it, (a, b) in enumerate(zip(fused, plain)):
+        if a is not None:
+            assert np.array_equal(a, b), it
