@@ -301,6 +301,25 @@ class JpegBatchPlan:
         # quantisation tables of the GPU-decoded streams come from the scan analysis
         self.quant[sel] = sc["quant"][sel, :3]
 
+    def set_index_mode(self, mode, device=None):
+        """None / "build" / "use" (see huffman_descs).  The entries live in one device buffer of the plan."""
+        assert mode in (None, "build", "use")
+        if mode and getattr(self, "_index_dev", None) is None:
+            self.upload_streams(device)
+            lib = capi.kernels()
+            nb = C.c_size_t(0)
+            sizes = []
+            for l in self._ecs_len:
+                capi.check(lib.daliamdJpegHuffmanIndexBytes(int(l), C.byref(nb)))
+                sizes.append(nb.value)
+            sizes = np.asarray(sizes, np.int64)
+            self._index_off = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64) if len(sizes) else np.zeros(0, np.int64)
+            self.index_bytes = int(sizes.sum())
+            base = torch.zeros(max(self.index_bytes, 64) + 64, dtype=torch.uint8, device=device)
+            self._index_base = base
+            self._index_dev = base[(-base.data_ptr()) % 64:]      # 64-byte aligned entries
+        self.index_mode = mode
+
     def new_huffman_workspace(self, device):
         """Decoder scratch + status words for one batch in flight (pipelined callers keep one per slot)."""
         return {"scratch": torch.empty(max(self.huffman_scratch_bytes, 256), dtype=torch.uint8, device=device),
@@ -318,7 +337,7 @@ class JpegBatchPlan:
         # into the same buffers again (benchmarks) gets the table it built the first time
         key = (ws["scratch"].data_ptr(), ws["status"].data_ptr(), None if coef_dev is None else coef_dev.data_ptr(),
                None if planes_dev is None else planes_dev.data_ptr(), self._ecs_dev.data_ptr(),
-               None if rgb_dev is None else rgb_dev.data_ptr())
+               None if rgb_dev is None else rgb_dev.data_ptr(), getattr(self, "index_mode", None))
         cache = self.__dict__.setdefault("_huff_desc_cache", {})
         if key in cache:
             return cache[key]
@@ -355,6 +374,14 @@ class JpegBatchPlan:
         d["ecs"] = self._ecs_dev.data_ptr() + self._ecs_off
         d["scratch"] = ws["scratch"].data_ptr() + self._scratch_off
         d["status"] = ws["status"].data_ptr() + 4 * np.arange(m)
+        mode = getattr(self, "index_mode", None)
+        if mode and m:
+            # side information of resident streams (daliamdJpegHuffDesc.index / index_out): "build" - this decode leaves an
+            # index entry per stream in self._index_dev; "use" - decode from those entries (the segments are not looked at)
+            ok = sc["restart_interval"][sel] == 0
+            d["index_out" if mode == "build" else "index"] = np.where(ok, self._index_dev.data_ptr() + self._index_off, 0)
+            if mode == "use":
+                d["ecs"] = np.where(ok, 0, d["ecs"])
         if coef_dev is not None:
             d["coef"] = np.where(self.comp_mask[sel], coef_dev.data_ptr() + 2 * self.coef_off[sel], 0)
         if planes_dev is not None:
@@ -581,7 +608,7 @@ class _HuffDescs(tuple):
 
 
 def decode_jpeg_batch(encoded, device="cuda", num_threads=None, out_pitch_align=16, huffman="gpu", rois=None, exact_scan=True,
-                      fuse_color=False):
+                      fuse_color=False, index=None, index_from=None):
     """Decodes a batch of JPEG byte strings -> list of u8 HWC RGB device tensors.
     rois: optional per-sample windows (y0, x0, h, w): region-of-interest decode (decoders.image_crop & co.).
 
@@ -592,6 +619,14 @@ def decode_jpeg_batch(encoded, device="cuda", num_threads=None, out_pitch_align=
     Dequantisation, IDCT, upsampling and colour conversion always run on the device."""
     device = torch.device(device)
     plan = JpegBatchPlan(encoded, out_pitch_align, rois=rois, exact_scan=exact_scan)
+    if index:
+        # index="build": the decode leaves the side information of every stream in the plan; index="use" with
+        # index_from=<the plan of a "build" decode of the same streams>: decode from it (other windows are fine)
+        if index == "use":
+            plan.upload_streams(device)
+            plan._index_dev, plan._index_off, plan.index_bytes = index_from._index_dev, index_from._index_off, index_from.index_bytes
+            assert np.array_equal(plan._ecs_len, index_from._ecs_len)
+        plan.set_index_mode(index, device)
     status = None
     planes = torch.empty(max(plan.plane_bytes, 1), dtype=torch.uint8, device=device)
     out = torch.empty(max(plan.out_bytes, 1), dtype=torch.uint8, device=device)
@@ -646,7 +681,7 @@ def _fill4(dst, src):
 HUFFMAN_KERNELS = ("PrepareKernel", "UnstuffScatterKernel", "SyncKernel", "PropagateKernel", "DcKernel", "BlockKernel")
 # names the launches of daliamdJpegHuffmanRunColor are timed under (daliamdKernelTimingReport): the six stages above, the
 # block kernel's instance with the fused colour output and the seam launch behind it
-HUFFMAN_KERNEL_NAMES = HUFFMAN_KERNELS + ("BlockColorKernel", "SeamKernel")
+HUFFMAN_KERNEL_NAMES = HUFFMAN_KERNELS + ("BlockColorKernel", "SeamKernel", "IndexedSyncKernel", "IndexBuildKernel")
 
 
 def huffman_algorithmic_bytes(stream_bytes, coef_elems, num_streams, fused):

@@ -176,6 +176,28 @@ inline int NumTiles(int head, int len) {
 }
 inline int NumSegments(int len) { return len > kSegBytes ? (len + kSegBytes - 1) / kSegBytes : 1; }
 
+// ------------------------------------------------------------------------------------------------ resident index
+// Index entry of a resident stream (daliamdJpegHuffDesc.index / index_out; huff_core.h: SliceIndex): a 64-byte header,
+// the CLEAN stream (un-stuffed, markers removed, all-ones padding behind it) and one SliceIndex per slice + a sentinel.
+// Sized by the upper bound ecs_len (the clean stream is never longer than the stuffed one).
+struct IndexHeader {
+  int32_t clean_len;      // bytes of the clean stream
+  int32_t total_starts;   // block starts the stream holds (blocks + 1 for a complete stream)
+  int32_t num_slices;     // entries that describe data
+  int32_t reserved[13];
+};
+static_assert(sizeof(IndexHeader) == 64, "layout");
+__host__ __device__ inline int IndexSliceCap(int ecs_len) { return (ecs_len + kSliceBytes - 1) / kSliceBytes; }
+__host__ __device__ inline size_t IndexCleanOffset() { return sizeof(IndexHeader); }
+__host__ __device__ inline size_t IndexEntriesOffset(int ecs_len) { return sizeof(IndexHeader) + AlignUp((size_t)ecs_len + 256, 64); }
+__host__ __device__ inline size_t IndexBytes(int ecs_len) {
+  return AlignUp(IndexEntriesOffset(ecs_len) + sizeof(SliceIndex) * (size_t)(IndexSliceCap(ecs_len) + 1), 64);
+}
+// the clean stream a decode of `d` reads: the resident one, or the one this batch's un-stuffing wrote
+__device__ __forceinline__ const uint8_t *CleanStream(const daliamdJpegHuffDesc &d, const ScratchLayout &lay) {
+  return d.index ? d.index + IndexCleanOffset() : d.scratch + lay.clean;
+}
+
 struct ImageRef {
   const daliamdJpegHuffDesc *d;
   int local;  // tile / segment index inside the image
@@ -680,6 +702,7 @@ __global__ __launch_bounds__(kSegThreads) void SyncKernel(const daliamdJpegHuffD
   if (wg < 0) return;
   const ImageRef r = FindImage<false>(descs, n, wg);
   const daliamdJpegHuffDesc &d = *r.d;
+  if (d.index) return;   // a resident stream with its index: IndexedSyncKernel (uniform)
   const ScratchLayout lay = LayoutOf(d);
   const int tid = threadIdx.x, seg = r.local;
   const int clean_len = *(const GlobalI32 *)d.scratch;
@@ -722,6 +745,7 @@ __global__ __launch_bounds__(kSegThreads) void PropagateKernel(const daliamdJpeg
   __shared__ uint16_t lists[kSegThreads * kListStride];
   __shared__ int wave_sums[kSegThreads / 64];
   const daliamdJpegHuffDesc &d = descs[blockIdx.x];
+  if (d.index) return;
   const ScratchLayout lay = LayoutOf(d);
   const int tid = threadIdx.x;
   const int clean_len = *(const GlobalI32 *)d.scratch;
@@ -900,6 +924,7 @@ __global__ __launch_bounds__(kDcThreads) void DcKernel(const daliamdJpegHuffDesc
   if (wg < 0) return;
   const ImageRef r = FindImage<false>(descs, n, wg);
   const daliamdJpegHuffDesc &d = *r.d;
+  if (d.index) return;   // (the indexed pass knows the DC predictors)
   const ScratchLayout lay = LayoutOf(d);
   const int tid = threadIdx.x, seg = r.local;
   const int clean_len = *(const GlobalI32 *)d.scratch;
@@ -913,7 +938,8 @@ __global__ __launch_bounds__(kDcThreads) void DcKernel(const daliamdJpegHuffDesc
   __syncthreads();
   const int bpm = d.blocks_per_mcu;
   const int total_starts = ((const GlobalI32 *)d.scratch)[2];
-  const int last_ordinal = LastOrdinal(d);
+  // (a decode that also builds the stream's index needs the DC level in front of EVERY slice, not only up to the window)
+  const int last_ordinal = d.index_out ? d.total_blocks : LastOrdinal(d);
   GlobalI32 *segrec_i = (GlobalI32 *)segrec;
   const int block_base = segrec_i[kSegRecBlockBase];
   int nstart = segrec_i[kSegRecNstart];
@@ -968,6 +994,185 @@ __global__ __launch_bounds__(kDcThreads) void DcKernel(const daliamdJpegHuffDesc
     }
   }
   if (tid < 3) segrec_i[kSegRecDcTotal + tid] = carry[tid];
+}
+
+// ------------------------------------------------------------------------------------------------ resident streams
+// Per block of an indexed stream: {bit position behind its DC symbol, DC level (mod 2^16)} - one 8-byte record where the
+// other path keeps blk_pos / blk_dc / blk_seg (the two arrays are adjacent in the scratch: the records lie over them).
+typedef uint32_t u32x2p __attribute__((ext_vector_type(2)));
+using GlobalPosDc = u32x2p __attribute__((address_space(1)));
+using GlobalIndex = const SliceIndex __attribute__((address_space(1)));
+__device__ __forceinline__ SliceIndex LoadIndex(GlobalIndex *p) { return SliceIndex{p->w0, p->w1, p->w2}; }
+
+// Position pass of the streams that bring their index (daliamdJpegHuffDesc.index): workgroup = a segment's 244 slices as
+// in SyncKernel (same grid), ONE decode per slice from its recorded entry state, the DC symbol of every block start on
+// the way (huff_core.h: IndexedDecodeSlice), results straight into the per-block records.  With a region of interest
+// the slices whose blocks it does not need are not decoded (their ordinals are in the index), and the slices that are
+// get packed into the first waves; a segment without any leaves before it copies its tables.
+__global__ __launch_bounds__(kSegThreads) void IndexedSyncKernel(const daliamdJpegHuffDesc *__restrict__ descs, int n, int nseg) {
+  __shared__ __attribute__((aligned(16))) SyncTables L;
+  __shared__ __attribute__((aligned(16))) HalfTables D;
+  __shared__ uint8_t work[kSegThreads];
+  __shared__ int wave_count[kSegThreads / 64];
+  const int wg = XcdRemap(blockIdx.x, nseg);
+  if (wg < 0) return;
+  const ImageRef r = FindImage<false>(descs, n, wg);
+  const daliamdJpegHuffDesc &d = *r.d;
+  if (!d.index) return;   // (uniform)
+  const ScratchLayout lay = LayoutOf(d);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, seg = r.local;
+  const IndexHeader *hdr = reinterpret_cast<const IndexHeader *>(d.index);
+  const int clean_len = ((const GlobalI32 *)hdr)[0];
+  if ((long long)seg * kSegBytes >= clean_len) return;
+  const uint32_t total_bits = (uint32_t)clean_len * 8u;
+  GlobalIndex *entries = (GlobalIndex *)(d.index + IndexEntriesOffset(d.ecs_len));
+  // what the decode needs of this stream: blocks below `last` inside the MCU rectangle `rm` (no rectangle: all of them)
+  const int bpm = d.blocks_per_mcu, mcus_x = d.mcus_x;
+  const int last = min(LastOrdinal(d), d.total_blocks);
+  int rm[4] = {0, 0, 0, 0};
+  const bool use_rect = RectMcus(d, rm);
+  auto needed = [&](int b0, int b1) {   // any block of [b0, b1) inside the rectangle?
+    b1 = min(b1, last);
+    if (b0 >= b1) return false;
+    if (!use_rect) return true;
+    const int m0 = b0 / bpm, m1 = (b1 - 1) / bpm;
+    const int r0 = m0 / mcus_x, r1 = m1 / mcus_x;
+    const int c0 = m0 - r0 * mcus_x, c1 = m1 - r1 * mcus_x;
+    const int x0 = rm[0], x1 = rm[0] + rm[2], y0 = rm[1], y1 = rm[1] + rm[3];
+    if (x1 <= x0) return false;
+    auto row = [&](int ry, int lo, int hi) { return ry >= y0 && ry < y1 && lo < x1 && hi >= x0; };   // columns [lo, hi]
+    if (r0 == r1) return row(r0, c0, c1);
+    return row(r0, c0, mcus_x - 1) || row(r1, 0, c1) || (max(r0 + 1, y0) < min(r1, y1));
+  };
+  const long long slice = (long long)seg * kSegLanes + tid;
+  const bool has = tid < kSegLanes && slice * (kSliceBytes * 8ll) < (long long)total_bits;
+  bool want = false;
+  if (has) {
+    const uint32_t b0 = entries[slice].w0 & kIndexOrdinalMask, b1 = entries[slice + 1].w0 & kIndexOrdinalMask;
+    want = needed((int)b0, (int)b1);
+  }
+  // the slices to decode, packed into the first lanes
+  const unsigned long long m = __ballot(want);
+  if (lane == 0) wave_count[wave] = __popcll(m);
+  __syncthreads();
+  int base = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < kSegThreads / 64; w++) {
+    const int c = wave_count[w];
+    base += w < wave ? c : 0;
+    total += c;
+  }
+  if (total == 0) return;   // (uniform: nothing of this segment is needed)
+  if (want) work[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)tid;
+  CopyTables<kSegThreads>(L, reinterpret_cast<const SyncTables *>(TablesBase(descs, d, true)));
+  CopyHalfTables<kSegThreads>(D, reinterpret_cast<const HuffTables *>(TablesBase(descs, d, false)), 0);
+  __syncthreads();
+  if (tid >= total) return;
+  const long long s = (long long)seg * kSegLanes + work[tid];
+  const SliceIndex e = LoadIndex(entries + s);
+  const uint32_t begin = (uint32_t)(s * (kSliceBytes * 8ll));
+  const uint32_t end = begin + kSliceBytes * 8u < total_bits ? begin + kSliceBytes * 8u : total_bits;
+  DecodeState st = IndexEntryState(e);
+  st.pos += begin;
+  if (st.pos >= end) return;
+  uint32_t comp_of = 0;   // two bits per block of the MCU
+  for (int k = 0; k < bpm; k++) comp_of |= (uint32_t)(d.comp_of_block[k] & 3) << (2 * k);
+  comp_of = HUFF_UNIFORM(comp_of);
+  int dc0 = (int)(e.w1 >> 16), dc1 = (int)(e.w2 & 0xFFFFu), dc2 = (int)(e.w2 >> 16);
+  uint32_t b = IndexFirstBlock(e);
+  const uint32_t total_blocks = (uint32_t)d.total_blocks;
+  GlobalPosDc *blk = (GlobalPosDc *)(d.scratch + lay.blk_pos);
+  GlobalWords *words = (GlobalWords *)(d.index + IndexCleanOffset());
+  IndexedDecodeSlice(L, D, words, st, end, [&](uint32_t c, uint32_t pos, int diff) {
+    const uint32_t comp = (comp_of >> (2 * c)) & 3u;
+    dc0 += comp == 0 ? diff : 0;
+    dc1 += comp == 1 ? diff : 0;
+    dc2 += comp == 2 ? diff : 0;
+    const int level = comp == 0 ? dc0 : comp == 1 ? dc1 : dc2;
+    if (b < total_blocks) blk[b] = u32x2p{pos, (uint32_t)level};
+    b++;
+  });
+}
+
+// Builds the index entry of a stream (daliamdJpegHuffDesc.index_out) from what this batch's position passes left in the
+// scratch - behind PropagateKernel (every slice's input state is the truth by then) and a DcKernel that covered every
+// block.  Workgroup = segment: copies its part of the clean stream, writes the entries of its slices.
+__global__ __launch_bounds__(kSegThreads) void IndexBuildKernel(const daliamdJpegHuffDesc *__restrict__ descs, int n, int nseg) {
+  __shared__ int wave_sums[kSegThreads / 64];
+  const int wg = XcdRemap(blockIdx.x, nseg);
+  if (wg < 0) return;
+  const ImageRef r = FindImage<false>(descs, n, wg);
+  const daliamdJpegHuffDesc &d = *r.d;
+  if (!d.index_out || d.index) return;   // (uniform)
+  const ScratchLayout lay = LayoutOf(d);
+  const int tid = threadIdx.x, seg = r.local;
+  const int clean_len = *(const GlobalI32 *)d.scratch;
+  const int total_starts = ((const GlobalI32 *)d.scratch)[2];
+  const int cap = IndexSliceCap(d.ecs_len);
+  GlobalU32 *out_entries = (GlobalU32 *)(d.index_out + IndexEntriesOffset(d.ecs_len));
+  auto put = [&](long long slice, const SliceIndex &e) {
+    out_entries[3 * slice] = e.w0; out_entries[3 * slice + 1] = e.w1; out_entries[3 * slice + 2] = e.w2;
+  };
+  const uint32_t zero3[3] = {0, 0, 0};
+  const SliceIndex none = PackSliceIndex((uint32_t)total_starts, DecodeState{0, 0, 0}, zero3);
+  if (seg == 0 && tid == kSegThreads - 1) {
+    GlobalI32 *h = (GlobalI32 *)d.index_out;
+    h[0] = clean_len; h[1] = total_starts; h[2] = (clean_len + kSliceBytes - 1) / kSliceBytes;
+    for (int i = 3; i < 16; i++) h[i] = 0;
+    put(cap, none);   // the sentinel behind the last slice
+  }
+  // ---- the clean bytes of the segment (the last one: with the all-ones padding behind the stream)
+  {
+    const long long first = (long long)seg * kSegBytes;
+    const long long stream_end = (long long)AlignUp((size_t)clean_len + kCleanPadBytes, 16);
+    const long long stop = min(first + kSegBytes, stream_end);
+    const GlobalQuad *src = (const GlobalQuad *)(d.scratch + lay.clean);
+    GlobalQuad *dst = (GlobalQuad *)(d.index_out + IndexCleanOffset());
+    for (long long q = first / 16 + tid; q * 16 < stop; q += kSegThreads) dst[q] = src[q];
+  }
+  // ---- the entries of its slices
+  const long long slice = (long long)seg * kSegLanes + tid;
+  const bool mine = tid < kSegLanes && slice < cap;
+  const bool active = mine && slice * (long long)kSliceBytes < clean_len;
+  const LaneRec *recs = reinterpret_cast<const LaneRec *>(d.scratch + lay.lanes) + (size_t)seg * kSegLanes;
+  const GlobalI32 *segs_i = (const GlobalI32 *)(d.scratch + lay.segs);
+  uint64_t in = kNoState;
+  int nstart = 0;
+  if (active) {
+    in = recs[tid].in;
+    nstart = recs[tid].nstart;
+  }
+  int total;
+  const int excl = WorkgroupExclusiveScan<kSegThreads / 64>(nstart, wave_sums, total);
+  if (!mine) return;
+  if (!active || in == kNoState) {
+    put(slice, none);
+    return;
+  }
+  const int ord = segs_i[seg * kSegRecInts + kSegRecBlockBase] + excl;   // first start this slice's decode FOUND
+  DecodeState st = Unpack(in);
+  // ... the first block whose DC symbol it DECODES: a block that starts exactly at the entry position was found by the
+  // slice before (the step that ended its predecessor) and is decoded here - except the stream's very first block
+  const int first_block = ord - (st.z == 0 && st.pos != 0 ? 1 : 0);
+  // DC level of every component in front of that block: its last block before, relative to its segment + the segments before
+  const GlobalI32 *blk_dc = (const GlobalI32 *)(d.scratch + lay.blk_dc);
+  const GlobalU16 *blk_seg = (const GlobalU16 *)(d.scratch + lay.blk_seg);
+  uint32_t dc[3] = {0, 0, 0};
+  uint32_t found = 0;
+  for (int j = 1; j <= d.blocks_per_mcu && found != 7u; j++) {
+    const int q = first_block - j;
+    if (q < 0) break;
+    const int comp = d.comp_of_block[q % d.blocks_per_mcu];
+    if (comp > 2 || (found >> comp) & 1u) continue;
+    found |= 1u << comp;
+    if (q >= d.total_blocks || q + 1 >= total_starts) continue;   // (a block the stream does not really hold)
+    int level = blk_dc[q];
+    const int qs = blk_seg[q];
+    for (int sg = 0; sg < qs; sg++) level += segs_i[sg * kSegRecInts + kSegRecDcTotal + comp];
+    dc[comp] = (uint32_t)level & 0xFFFFu;
+  }
+  st.pos -= (uint32_t)(slice * (long long)(kSliceBytes * 8));
+  put(slice, PackSliceIndex((uint32_t)first_block, st, dc));
 }
 
 // Value pass.  A workgroup owns a run of MCUs of one image; its waves take TASKS of 64 blocks that all use the same
@@ -1100,9 +1305,10 @@ __global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHu
     int rm[4] = {0, 0, 0, 0};
     const bool roi = !kColor && RectMcus(d, rm);
     G.roi_x0 = rm[0]; G.roi_y0 = rm[1]; G.roi_cols = roi ? rm[2] : 0; G.roi_mcus = rm[2] * rm[3];
-    G.total_starts = ((const GlobalI32 *)d.scratch)[2];
+    // (a resident stream with its index: the header of the index knows, and the per-block records hold absolute levels)
+    G.total_starts = d.index ? ((const GlobalI32 *)d.index)[1] : ((const GlobalI32 *)d.scratch)[2];
     G.fused = kColor || d.plane[d.comp_of_block[0]] != nullptr;
-    G.interval_blocks = d.restart_interval * d.blocks_per_mcu;
+    G.interval_blocks = d.index ? 0 : d.restart_interval * d.blocks_per_mcu;
     for (int k = 0; k < d.blocks_per_mcu; k++) G.klast[d.comp_of_block[k]] = (uint8_t)k;
     // the two task classes: by AC table - or, with the fused colour output, luma / chroma (usually the same split)
     int n0 = 0;
@@ -1144,8 +1350,10 @@ __global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHu
   const int M = min(mpw, (roi_cols ? G.roi_mcus : G.total_mcus) - m0);
   const int n0 = G.n0, n1 = bpm - n0;
   const int tasks0 = (M * n0 + 63) >> 6, tasks1 = (M * n1 + 63) >> 6;
-  GlobalWords *words = (GlobalWords *)(d.scratch + lay.clean);
+  GlobalWords *words = (GlobalWords *)CleanStream(d, lay);
+  const bool indexed = d.index != nullptr;   // (uniform)
   const GlobalU32 *blk_pos = (const GlobalU32 *)(d.scratch + lay.blk_pos);
+  const GlobalPosDc *blk_pd = (const GlobalPosDc *)(d.scratch + lay.blk_pos);
   const GlobalI32 *blk_dc = (const GlobalI32 *)(d.scratch + lay.blk_dc);
   const GlobalU16 *blk_seg = (const GlobalU16 *)(d.scratch + lay.blk_seg);
   const GlobalI32 *segs_i = (const GlobalI32 *)(d.scratch + lay.segs);  // SegRec fields as ints (global loads, not flat)
@@ -1210,7 +1418,11 @@ __global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHu
     p.info = (dst & ((1ull << 48) - 1)) | ((uint64_t)comp << 48) | (needed ? kInfoNeeded : 0ull);
     p.needed = needed; p.ordinal = ordinal; p.comp = comp; p.acs = G.acs[k];
     p.bx = bx; p.by = by;
-    if (needed) {
+    if (needed && indexed) {   // IndexedSyncKernel's record: position and absolute level (mod 2^16) in one load
+      const u32x2p pd = blk_pd[ordinal];
+      p.pos = pd.x;
+      p.dc = (int)pd.y;
+    } else if (needed) {
       p.pos = blk_pos[ordinal];
       p.dc = blk_dc[ordinal];
       p.seg = blk_seg[ordinal];
@@ -1488,6 +1700,12 @@ daliamdResult_t daliamdJpegHuffmanScratchBytesRestart(int ecs_len, int total_blo
   return DALIAMD_SUCCESS;
 }
 
+daliamdResult_t daliamdJpegHuffmanIndexBytes(int ecs_len, size_t *bytes) {
+  DALIAMD_REQUIRE(ecs_len >= 0 && bytes, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdJpegHuffmanIndexBytes: invalid argument");
+  *bytes = daliamd::IndexBytes(ecs_len);
+  return DALIAMD_SUCCESS;
+}
+
 int daliamdJpegHuffmanColorFusable(const daliamdJpegHuffDesc *d) {
   if (!d || d->mcus_x < 1 || d->mcus_x > daliamd::kColorBandMcus) return 0;
   for (int c = 0; c < 3; c++)
@@ -1516,6 +1734,9 @@ daliamdResult_t daliamdJpegHuffmanSetup(daliamdJpegHuffDesc *descs_host, int n, 
   DALIAMD_REQUIRE(!(kinds & 2), DALIAMD_ERROR_INVALID_ARGUMENT,
                   "daliamdJpegHuffmanSetup: a stream asks for the fused colour output (rgb != NULL): use "
                   "daliamdJpegHuffmanSetupColor / daliamdJpegHuffmanRunColor");
+  DALIAMD_REQUIRE(!(kinds & (DALIAMD_JPEG_HUFFMAN_INDEXED | DALIAMD_JPEG_HUFFMAN_BUILD_INDEX)), DALIAMD_ERROR_INVALID_ARGUMENT,
+                  "daliamdJpegHuffmanSetup: a stream brings or asks for an index: use daliamdJpegHuffmanSetupColor / "
+                  "daliamdJpegHuffmanRunColor");
   return DALIAMD_SUCCESS;
 }
 
@@ -1536,8 +1757,19 @@ daliamdResult_t daliamdJpegHuffmanSetupColor(daliamdJpegHuffDesc *descs_host, in
     for (int o : owners)
       if (same_tables(descs_host[o], d)) { d.table_owner = o; break; }
     if (d.table_owner == i && owners.size() < 64) owners.push_back(i);
-    DALIAMD_REQUIRE(d.ecs && d.scratch && d.status && d.ecs_len >= 0, DALIAMD_ERROR_INVALID_ARGUMENT,
+    DALIAMD_REQUIRE((d.ecs || d.index) && d.scratch && d.status && d.ecs_len >= 0, DALIAMD_ERROR_INVALID_ARGUMENT,
                     "daliamdJpegHuffmanSetup: sample %d: NULL buffer or negative length", i);
+    if (d.index || d.index_out) {
+      DALIAMD_REQUIRE(!(d.index && d.index_out), DALIAMD_ERROR_INVALID_ARGUMENT,
+                      "daliamdJpegHuffmanSetup: sample %d: index and index_out are exclusive", i);
+      DALIAMD_REQUIRE(d.restart_interval == 0 && d.total_blocks + 128 < (1 << 26), DALIAMD_ERROR_UNSUPPORTED,
+                      "daliamdJpegHuffmanSetup: sample %d: no index for streams with restart intervals or %d blocks and more", i,
+                      (1 << 26) - 128);
+      DALIAMD_REQUIRE(((reinterpret_cast<uintptr_t>(d.index) | reinterpret_cast<uintptr_t>(d.index_out)) & 63) == 0,
+                      DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdJpegHuffmanSetup: sample %d: index entries must be 64-byte aligned", i);
+    }
+    kinds |= d.index ? DALIAMD_JPEG_HUFFMAN_INDEXED : DALIAMD_JPEG_HUFFMAN_PARSED;
+    if (d.index_out) kinds |= DALIAMD_JPEG_HUFFMAN_BUILD_INDEX;
     DALIAMD_REQUIRE((reinterpret_cast<uintptr_t>(d.scratch) & 15) == 0, DALIAMD_ERROR_INVALID_ARGUMENT,
                     "daliamdJpegHuffmanSetup: sample %d: scratch must be 16-byte aligned", i);
     DALIAMD_REQUIRE(d.blocks_per_mcu >= 1 && d.blocks_per_mcu <= DALIAMD_JPEG_MAX_BLOCKS_PER_MCU && d.mcus_x >= 1 &&
@@ -1578,7 +1810,8 @@ daliamdResult_t daliamdJpegHuffmanSetupColor(daliamdJpegHuffDesc *descs_host, in
     DALIAMD_REQUIRE(d.restart_interval >= 0 && d.restart_interval <= 65535, DALIAMD_ERROR_INVALID_ARGUMENT,
                     "daliamdJpegHuffmanSetup: sample %d: restart interval %d", i, d.restart_interval);
     d.tile_start = tiles;
-    d.num_tiles = daliamd::NumTiles((int)(reinterpret_cast<uintptr_t>(d.ecs) & 15), d.ecs_len);
+    // (a stream that brings its index is not un-stuffed again: no tiles)
+    d.num_tiles = d.index ? 0 : daliamd::NumTiles((int)(reinterpret_cast<uintptr_t>(d.ecs) & 15), d.ecs_len);
     d.seg_start = segs;
     d.num_segments = daliamd::NumSegments(d.ecs_len);
     DALIAMD_REQUIRE(d.num_segments <= 65535, DALIAMD_ERROR_UNSUPPORTED,
@@ -1601,7 +1834,7 @@ daliamdResult_t daliamdJpegHuffmanSetupColor(daliamdJpegHuffDesc *descs_host, in
 static daliamdResult_t LaunchHuffman(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev, int n, int num_tiles,
                                      int num_segments, int num_block_workgroups, daliamdEvent_t *events, int block_kernels) {
   if (n == 0) return DALIAMD_SUCCESS;
-  DALIAMD_REQUIRE(descs_dev && n > 0 && num_tiles >= n && num_segments >= n && num_block_workgroups >= n,
+  DALIAMD_REQUIRE(descs_dev && n > 0 && num_tiles >= 0 && num_segments >= n && num_block_workgroups >= n,
                   DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdJpegHuffmanRun: invalid argument");
   using namespace daliamd;
   hipStream_t s = (hipStream_t)stream;
@@ -1610,28 +1843,37 @@ static daliamdResult_t LaunchHuffman(daliamdStream_t stream, const daliamdJpegHu
   auto mark = [&]() -> hipError_t { return events ? hipEventRecord((hipEvent_t)events[e++], s) : hipSuccess; };
   // (each launch also sits in a KernelTimer scope: daliamdKernelTimingEnable times the product path's launches
   // by name; `events` is the explicit variant of the same thing for callers that bring their own events)
+  // which streams the table holds (Setup): PARSED - un-stuffing, relaxation, hand-over check, DC pass; INDEXED - resident
+  // streams that bring their index: one launch instead of those four (+ the table build, which every stream needs)
+  const bool parsed = (block_kernels & DALIAMD_JPEG_HUFFMAN_PARSED) != 0 ||
+                      !(block_kernels & (DALIAMD_JPEG_HUFFMAN_PARSED | DALIAMD_JPEG_HUFFMAN_INDEXED));
+  const bool indexed = (block_kernels & DALIAMD_JPEG_HUFFMAN_INDEXED) != 0;
   DALIAMD_HIP_CHECK(mark());
   {
     KernelTimer timer("PrepareKernel", s);
     hipLaunchKernelGGL(PrepareKernel, dim3(num_tiles + n), dim3(kTileThreads), 0, s, descs_dev, n, num_tiles);
   }
   DALIAMD_HIP_CHECK(mark());
-  {
+  if (parsed && num_tiles > 0) {
     KernelTimer timer("UnstuffScatterKernel", s);
     hipLaunchKernelGGL(UnstuffScatterKernel, dim3(num_tiles), dim3(kTileThreads), 0, s, descs_dev, n);
   }
   DALIAMD_HIP_CHECK(mark());
-  {
+  if (parsed) {
     KernelTimer timer("SyncKernel", s);
     hipLaunchKernelGGL(SyncKernel, dim3(seg_grid), dim3(kSegThreads), 0, s, descs_dev, n, num_segments);
   }
+  if (indexed) {
+    KernelTimer timer("IndexedSyncKernel", s);
+    hipLaunchKernelGGL(IndexedSyncKernel, dim3(seg_grid), dim3(kSegThreads), 0, s, descs_dev, n, num_segments);
+  }
   DALIAMD_HIP_CHECK(mark());
-  {
+  if (parsed) {
     KernelTimer timer("PropagateKernel", s);
     hipLaunchKernelGGL(PropagateKernel, dim3(n), dim3(kSegThreads), 0, s, descs_dev);
   }
   DALIAMD_HIP_CHECK(mark());
-  {
+  if (parsed) {
     KernelTimer timer("DcKernel", s);
     hipLaunchKernelGGL(DcKernel, dim3(seg_grid), dim3(kDcThreads), 0, s, descs_dev, n, num_segments);
   }
@@ -1653,6 +1895,10 @@ static daliamdResult_t LaunchHuffman(daliamdStream_t stream, const daliamdJpegHu
     hipLaunchKernelGGL(SeamKernel, dim3(XcdGrid(num_block_workgroups)), dim3(kSeamThreads), 0, s, descs_dev, n,
                        num_block_workgroups);
   }
+  if (block_kernels & DALIAMD_JPEG_HUFFMAN_BUILD_INDEX) {   // (behind the value pass: off this batch's critical path)
+    KernelTimer timer("IndexBuildKernel", s);
+    hipLaunchKernelGGL(IndexBuildKernel, dim3(seg_grid), dim3(kSegThreads), 0, s, descs_dev, n, num_segments);
+  }
   DALIAMD_HIP_CHECK(mark());
   DALIAMD_HIP_CHECK(hipGetLastError());
   return DALIAMD_SUCCESS;
@@ -1665,7 +1911,7 @@ daliamdResult_t daliamdJpegHuffmanRun(daliamdStream_t stream, const daliamdJpegH
 
 daliamdResult_t daliamdJpegHuffmanRunColor(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev, int n, int num_tiles,
                                            int num_segments, int num_block_workgroups, int block_kernels) {
-  return LaunchHuffman(stream, descs_dev, n, num_tiles, num_segments, num_block_workgroups, nullptr, block_kernels & 3);
+  return LaunchHuffman(stream, descs_dev, n, num_tiles, num_segments, num_block_workgroups, nullptr, block_kernels & 31);
 }
 
 daliamdResult_t daliamdJpegHuffmanRunProfiled(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev, int n,
@@ -1679,7 +1925,7 @@ daliamdResult_t daliamdJpegHuffmanRunProfiledColor(daliamdStream_t stream, const
                                                    int num_tiles, int num_segments, int num_block_workgroups,
                                                    int block_kernels, daliamdEvent_t *events) {
   DALIAMD_REQUIRE(events, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdJpegHuffmanRunProfiledColor: events is NULL");
-  return LaunchHuffman(stream, descs_dev, n, num_tiles, num_segments, num_block_workgroups, events, block_kernels & 3);
+  return LaunchHuffman(stream, descs_dev, n, num_tiles, num_segments, num_block_workgroups, events, block_kernels & 31);
 }
 
 }  // extern "C"

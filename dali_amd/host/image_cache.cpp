@@ -317,7 +317,8 @@ uint8_t *StreamCache::Reserve(const std::string &key, size_t bytes) {
 }
 
 void StreamCache::Commit(const std::vector<std::string> &keys, const std::vector<const daliamdJpegInfo *> &infos,
-                         const std::vector<const daliamdJpegScan *> &scans, daliamdStream_t stream) {
+                         const std::vector<const daliamdJpegScan *> &scans, daliamdStream_t stream,
+                         const std::vector<uint8_t> &indexed) {
   if (keys.empty()) return;
   auto fence = std::make_shared<ImageCache::Fence>();
   KCHECK(daliamdEventCreate(&fence->event, 0));
@@ -333,7 +334,8 @@ void StreamCache::Commit(const std::vector<std::string> &keys, const std::vector
   for (size_t k = 0; k < keys.size(); k++) {
     auto it = pending_.find(keys[k]);
     if (it == pending_.end()) continue;
-    recs[k]->ecs = it->second.first;
+    if (k < indexed.size() && indexed[k]) recs[k]->index = it->second.first;
+    else recs[k]->ecs = it->second.first;
     entries_[keys[k]] = Slot{recs[k], fence};
     pending_.erase(it);
   }

@@ -124,6 +124,10 @@ class StreamCache {
  public:
   struct Record {
     const uint8_t *ecs = nullptr;  // the entropy-coded segment in the blob (device), scan.ecs_length bytes
+    // `cache_type="indexed"` (round 5): what is resident is the stream's index entry instead (daliamdJpegHuffDesc.index:
+    // the un-stuffed stream + 12 bytes of decoder state per 256-byte slice, written by the decode that made it resident);
+    // `ecs` is null then
+    const uint8_t *index = nullptr;
     daliamdJpegInfo info;
     daliamdJpegScan scan;
   };
@@ -139,8 +143,10 @@ class StreamCache {
   // room for the `bytes` of a new segment, or nullptr (known key, or the blob is full)
   uint8_t *Reserve(const std::string &key, size_t bytes);
   // the copies into the slots reserved for `keys` are enqueued on `stream`
+  // indexed[k] != 0: the slot of keys[k] holds an index entry (built by the decode enqueued on `stream`), not the raw segment
   void Commit(const std::vector<std::string> &keys, const std::vector<const daliamdJpegInfo *> &infos,
-              const std::vector<const daliamdJpegScan *> &scans, daliamdStream_t stream);
+              const std::vector<const daliamdJpegScan *> &scans, daliamdStream_t stream,
+              const std::vector<uint8_t> &indexed = {});
   void Invalidate(const std::string &key);
   // Reservations that will never be committed (an exception between Reserve and Commit): the keys become reservable
   // again and the space of those that still sit at the end of the blob is handed back.

@@ -80,7 +80,11 @@ DALI_SCHEMA(decoders__Image)
                     "the parse results of every JPEG the GPU entropy decoder takes resident in GPU memory instead of "
                     "the decoded pixels - from the second epoch on a sample needs no file read (with the reader's "
                     "``skip_cached_images``), no header parse and no host-to-device transfer, and is still decoded anew "
-                    "(warm-up: 1 epoch).", ArgValue::Str(""))
+                    "(warm-up: 1 epoch).  ``indexed`` (MI355X extension): like ``encoded``, and the stream is kept UN-STUFFED "
+                    "together with the decoder state in front of each of its 256-byte slices (12 bytes per slice, 5 % of the "
+                    "stream) as its first decode found them: later decodes skip the un-stuffing, the parallel "
+                    "synchronisation and the DC pass, and a window decode skips the slices outside the window.  Same pixels.",
+                    ArgValue::Str(""))
     .AddOptionalArg("cache_threshold", "The size threshold, in bytes, for decoded images to be cached.", ArgValue::Int(0))
     .AddOptionalArg("cache_debug", "Prints the debug information about the decoder cache.", ArgValue::Bool(false))
     .AddOptionalArg("cache_batch_copy", "Accepted for compatibility: cached images are handed out in place, there is no "
@@ -122,10 +126,13 @@ class ImageDecoderMixed : public OperatorBase {
     }
     h2d_done_.assign(ring_, nullptr);
     // decoded-image cache (cached_decoder_impl.cc:24-48); the fused crop decoders have no cache options
-    if (spec.Args().count("cache_size") && spec.GetString("cache_type") == "encoded") {
+    if (spec.Args().count("cache_size") && (spec.GetString("cache_type") == "encoded" || spec.GetString("cache_type") == "indexed")) {
       // the encoded-stream cache (image_cache.h); also for the region-of-interest decoders: they decode from it
       const size_t bytes = (size_t)spec.GetInt("cache_size") * 1024 * 1024;
       if (bytes > 0) stream_cache_ = StreamCache::Get((int)spec.GetInt("device_id"), bytes, spec.GetBool("cache_debug"));
+      // "indexed": a stream becomes resident together with the side information its first decode found (un-stuffed bytes,
+      // the decoder state in front of every 256-byte slice) and is decoded from that afterwards
+      index_streams_ = spec.GetString("cache_type") == "indexed";
     } else if (allow_cache && spec.Args().count("cache_size")) {
       const size_t bytes = (size_t)spec.GetInt("cache_size") * 1024 * 1024;
       const size_t threshold = (size_t)spec.GetInt("cache_threshold");
@@ -467,6 +474,29 @@ class ImageDecoderMixed : public OperatorBase {
     memset(tab_host, 0, upload_bytes - huff_off);
     int ntiles = 0, nsegs = 0, nbwg = 0, block_kernels = 0;
     fused_color_.assign(n, 0);
+    // encoded-stream cache: the streams of this batch that the cache has room for become resident - as they are (one
+    // device-to-device copy each, behind the transfer, out of this iteration's buffer, which is reused ring_ iterations from
+    // now) or, cache_type="indexed", as the index entry the entropy decoder leaves behind this decode
+    struct Kept { int j; uint8_t *slot; bool indexed; };
+    std::vector<Kept> keep;
+    struct ReservedStreams {   // reservations of this run; handed back unless the copies get enqueued and committed
+      StreamCache *cache;
+      std::vector<std::string> keys;
+      ~ReservedStreams() { if (cache && !keys.empty()) cache->Abandon(keys); }
+    } reserved_streams{stream_cache_.get(), {}};
+    if (stream_cache_ && ngpu > nehit)
+      for (int j = 0; j < ngpu; j++) {
+        const int i = gpu_samples_[j];
+        if (erec_[i] || i >= (int)in.source_info.size()) continue;
+        const bool indexed = index_streams_ && scans_[i].restart_interval == 0 &&
+                             (int64_t)scans_[i].mcus_x * scans_[i].mcus_y * scans_[i].blocks_per_mcu + 128 < ((int64_t)1 << 26);
+        size_t bytes = (size_t)scans_[i].ecs_length;
+        if (indexed) KCHECK(daliamdJpegHuffmanIndexBytes((int)scans_[i].ecs_length, &bytes));
+        if (uint8_t *slot_ptr = stream_cache_->Reserve(in.source_info[i], bytes)) {
+          keep.push_back({j, slot_ptr, indexed});
+          reserved_streams.keys.push_back(in.source_info[i]);
+        }
+      }
     if (ngpu) {
       // status words: pinned host memory the kernels write directly (no copy back); cleared here by the CPU
       int32_t *status = static_cast<int32_t *>(status_host.data());
@@ -477,6 +507,7 @@ class ImageDecoderMixed : public OperatorBase {
         const auto &sc = scan(i);
         auto &d = huff[j];
         d.ecs = erec_[i] ? erec_[i]->ecs : dev_base + ecs_off_[i] + (direct ? (size_t)sc.ecs_offset : 0);
+        d.index = erec_[i] ? erec_[i]->index : nullptr;   // a resident stream with its side information: decoded from that
         d.scratch = static_cast<uint8_t *>(scratch.data()) + scratch_off_[i];
         d.status = status + j;
         d.ecs_len = (int32_t)sc.ecs_length;
@@ -520,6 +551,8 @@ class ImageDecoderMixed : public OperatorBase {
           memcpy(d.vals[2 + t], sc.ac_vals[t], 256);
         }
       }
+      for (auto &k : keep)
+        if (k.indexed) huff[k.j].index_out = k.slot;
       KCHECK(daliamdJpegHuffmanSetupColor(huff, ngpu, &ntiles, &nsegs, &nbwg, &block_kernels));
       // the status words are valid once the iteration has finished: checked when its outputs are handed over
       std::vector<std::string> names(ngpu);
@@ -593,47 +626,38 @@ class ImageDecoderMixed : public OperatorBase {
     } else {
       KCHECK(daliamdMemcpyH2DAsync(ecs_dev.data(), ecs_stage.data(), upload_bytes, cs));
     }
-    // encoded-stream cache: the segments of this batch that the cache has room for stay resident - one device-to-device
-    // copy each, behind the transfer, out of this iteration's buffer (which is reused ring_ iterations from now)
-    std::vector<std::pair<int, uint8_t *>> keep;
-    struct ReservedStreams {   // reservations of this run; handed back unless the copies get enqueued and committed
-      StreamCache *cache;
-      std::vector<std::string> keys;
-      ~ReservedStreams() { if (cache && !keys.empty()) cache->Abandon(keys); }
-    } reserved_streams{stream_cache_.get(), {}};
-    if (stream_cache_ && ngpu > nehit)
-      for (int j = 0; j < ngpu; j++) {
-        const int i = gpu_samples_[j];
-        if (erec_[i] || i >= (int)in.source_info.size()) continue;
-        if (uint8_t *slot_ptr = stream_cache_->Reserve(in.source_info[i], (size_t)scans_[i].ecs_length)) {
-          keep.push_back({j, slot_ptr});
-          reserved_streams.keys.push_back(in.source_info[i]);
-        }
-      }
     if (cs != ws.stream) {
       if (!h2d_done_[slot]) KCHECK(daliamdEventCreate(&h2d_done_[slot], 0));
       KCHECK(daliamdEventRecord(h2d_done_[slot], cs));
       KCHECK(daliamdStreamWaitEvent(ws.stream, h2d_done_[slot]));
     }
-    if (!keep.empty()) {
+    // resident from here on (visible to later iterations, the reader's skip_cached_images and other pipelines): the streams
+    // kept as they are, once their copies are on the stream; the ones kept with their index, behind the decode that builds it
+    auto commit = [&](bool indexed) {
       std::vector<std::string> keys;
       std::vector<const daliamdJpegInfo *> kinfos;
       std::vector<const daliamdJpegScan *> kscans;
       for (auto &k : keep) {
-        const int i = gpu_samples_[k.first];
-        KCHECK(daliamdMemcpyD2DAsync(k.second, huff[k.first].ecs, (size_t)scans_[i].ecs_length, ws.stream));
+        if (k.indexed != indexed) continue;
+        const int i = gpu_samples_[k.j];
+        if (!indexed) KCHECK(daliamdMemcpyD2DAsync(k.slot, huff[k.j].ecs, (size_t)scans_[i].ecs_length, ws.stream));
         keys.push_back(in.source_info[i]);
         kinfos.push_back(&infos_[i]);
         kscans.push_back(&scans_[i]);
       }
-      stream_cache_->Commit(keys, kinfos, kscans, ws.stream);
-      reserved_streams.keys.clear();
-    }
+      if (keys.empty()) return;
+      stream_cache_->Commit(keys, kinfos, kscans, ws.stream, std::vector<uint8_t>(keys.size(), indexed ? 1 : 0));
+      auto &pending = reserved_streams.keys;
+      for (auto &key : keys) pending.erase(std::remove(pending.begin(), pending.end(), key), pending.end());
+    };
+    commit(false);
     if (ngpu) {
       KCHECK(daliamdJpegHuffmanRunColor(ws.stream, reinterpret_cast<const daliamdJpegHuffDesc *>(dev_base + huff_off), ngpu,
                                         ntiles, nsegs, nbwg, block_kernels));
       NoteLaunch(ws, "jpeg_huffman");
+      if (block_kernels & DALIAMD_JPEG_HUFFMAN_INDEXED) NoteLaunch(ws, "jpeg_huffman_indexed");   // (streams decoded from their index)
     }
+    commit(true);
     // host-decoded streams (progressive, restart markers, multi-scan, below the threshold): H2D of their coefficients
     for (int i = 0; i < n; i++) {
       if (scan(i).eligible || hit_[i]) continue;
@@ -689,6 +713,7 @@ class ImageDecoderMixed : public OperatorBase {
   int64_t trace_runs_ = 0;
   std::shared_ptr<ImageCache> cache_;
   std::shared_ptr<StreamCache> stream_cache_;
+  bool index_streams_ = false;                                     // cache_type="indexed"
   std::vector<std::shared_ptr<const StreamCache::Record>> erec_;   // resident samples of the batch
   std::vector<uint8_t> hit_, raster_;
   std::vector<int32_t> raster_hw_;

@@ -207,7 +207,26 @@ typedef struct {
   int32_t rgb_pitch;
   int32_t width, height;   /* image size in pixels */
   int32_t reserved;
+  /* Side information of a RESIDENT stream (round 5; the reference indexes what it reads again and again - tools/tfrecord2idx,
+   * tools/wds2idx.py, tools/rec2idx.py -, and its decoder cache keeps what epoch 2 would otherwise recompute,
+   * dali/operators/decoder/cache/cached_decoder_impl.cc:124-141).  A stream that stays in device memory is parsed identically in
+   * every epoch: where its stuffing bytes are and in which state a decoder reaches each 256-byte slice does not change.
+   * index_out != NULL: this decode also leaves an index entry there - a 64-byte header, the un-stuffed stream and 12 bytes per
+   * slice (entry bit position, block index inside the MCU, zig-zag index, ordinal of the first block, DC predictors):
+   * daliamdJpegHuffmanIndexBytes(ecs_len) bytes, 64-byte aligned, valid once the launch has finished with *status == 0.
+   * index != NULL: decode from such an entry - `ecs` is not looked at (may be NULL; ecs_len must be the value the entry was
+   * built with): no un-stuffing, one decode per slice instead of the relaxation, no hand-over check, no DC pass, and under a
+   * region of interest (rect) only the slices that hold blocks of it.  The output is the same bits.  Streams with restart
+   * intervals take neither (Setup refuses). */
+  const uint8_t *index;
+  uint8_t *index_out;
 } daliamdJpegHuffDesc;
+
+/* kinds of streams in a table, OR-ed into *block_kernels by daliamdJpegHuffmanSetupColor next to bits 0 / 1 */
+#define DALIAMD_JPEG_HUFFMAN_PARSED 4       /* streams that are un-stuffed and synchronised in this launch */
+#define DALIAMD_JPEG_HUFFMAN_INDEXED 8      /* streams that bring their index                              */
+#define DALIAMD_JPEG_HUFFMAN_BUILD_INDEX 16 /* streams whose index entry is built behind the decode        */
+DALIAMD_API daliamdResult_t daliamdJpegHuffmanIndexBytes(int ecs_len, size_t *bytes);
 
 /* 1 when the stream's geometry (blocks_per_mcu, comp_of_block, h/v_of_block, h/v_samp, mcus_x, rect) allows the fused
  * colour output, else 0.  Host helper, looks at nothing else. */

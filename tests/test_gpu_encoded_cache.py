@@ -36,8 +36,14 @@ def decoded(files):
     return [O.jpeg_decode_rgb(open(f, "rb").read()) for f in files]
 
 
-@pytest.fixture(autouse=True)
-def _collect():
+CACHE_TYPE = ["encoded"]
+
+
+@pytest.fixture(autouse=True, params=["encoded", "indexed"])
+def _collect(request):
+    # every test with both forms of residency: the segments as they are in the file, and (round 5) the un-stuffed stream
+    # with the decoder state in front of every slice, from which later epochs decode without parsing it again
+    CACHE_TYPE[0] = request.param
     gc.collect()
     yield
     gc.collect()
@@ -49,7 +55,7 @@ def _pipe(files, batch, decoder="image", skip=True, outputs="image", **decoder_k
     pipe = Pipeline(batch_size=batch, num_threads=3, device_id=0, prefetch_queue_depth=2, seed=11)
     with pipe:
         enc, _ = fn.readers.file(files=files, skip_cached_images=skip)
-        img = getattr(fn.decoders, decoder)(enc, device="mixed", cache_size=64, cache_type="encoded", **decoder_kw)
+        img = getattr(fn.decoders, decoder)(enc, device="mixed", cache_size=64, cache_type=CACHE_TYPE[0], **decoder_kw)
         pipe.set_outputs(*((img, enc) if outputs == "both" else (img,)))
     return pipe
 
@@ -62,11 +68,15 @@ def test_second_epoch_decodes_from_hbm_without_reading_the_files(files, decoded)
             k = (4 * it + i) % len(files)
             assert np.array_equal(img[i].as_cpu(), decoded[k]), (it, i)
             nbytes = enc.at(i).size
-            if it >= 3 and k != 3:    # (epoch 1 fills; the reader runs up to two batches ahead of the decoder)
+            # (epoch 1 fills; the reader runs up to two batches ahead of the decoder; a stream kept with its index becomes
+            # resident behind the launch of the decode that builds it, a stream kept as it is in front of it)
+            if it >= (3 if CACHE_TYPE[0] == "encoded" else 4) and k != 3:
                 assert nbytes == 0, f"iteration {it}: sample {k} was read again ({nbytes} bytes)"
             if k == 3:
                 assert nbytes > 0, "the progressive stream is not kept: it must be read every epoch"
         assert "jpeg_huffman" in pipe.executed_kernels()   # a hit is decoded anew
+        if it >= 4:
+            assert ("jpeg_huffman_indexed" in pipe.executed_kernels()) == (CACHE_TYPE[0] == "indexed")
 
 
 def test_files_may_disappear_once_resident(tmp_path, decoded, files):
@@ -156,7 +166,7 @@ def test_cache_too_small_keeps_what_fits_and_decodes_the_rest(files, decoded):
     pipe = Pipeline(batch_size=6, num_threads=3, device_id=0, prefetch_queue_depth=1, seed=1)
     with pipe:
         enc, _ = fn.readers.file(files=big, skip_cached_images=True)
-        pipe.set_outputs(fn.decoders.image(enc, device="mixed", cache_size=1, cache_type="encoded"), enc)
+        pipe.set_outputs(fn.decoders.image(enc, device="mixed", cache_size=1, cache_type=CACHE_TYPE[0]), enc)
     for it in range(4):
         img, e = pipe.run()
         for i in range(6):

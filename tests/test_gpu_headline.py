@@ -25,8 +25,8 @@ def _collect():   # the encoded-stream cache of a device lives as long as a pipe
     gc.collect()
 
 
-@pytest.mark.parametrize("batch,batches,epochs", [(256, 2, 4), (512, 1, 4)])
-def test_resident_pipeline_of_the_bench_equals_oracle(tmp_path, batch, batches, epochs):
+@pytest.mark.parametrize("batch,batches,epochs,cache_type", [(256, 2, 4, "encoded"), (512, 1, 4, "encoded"), (256, 2, 4, "indexed")])
+def test_resident_pipeline_of_the_bench_equals_oracle(tmp_path, batch, batches, epochs, cache_type):
     import bench
     from dali_amd import _backend
     from dali_amd.testing import synth_dataset
@@ -36,8 +36,8 @@ def test_resident_pipeline_of_the_bench_equals_oracle(tmp_path, batch, batches, 
     order = sorted(range(n), key=lambda g: (g % 10, g))  # readers.file: class directories sorted, files sorted inside
     depth = 5                                            # bench.py --inflight default
     before = _backend.encoded_cache_stats(0)
-    pipe = bench.resident_pipeline(str(tmp_path), batch, 0, depth, 8, cache_mb=max(64, int(2 * sum(map(len, enc)) / 2**20)),
-                                   crop_seed=1234, flip_seed=1235)
+    pipe = bench.resident_pipeline(str(tmp_path), batch, 0, depth, 8, cache_mb=max(64, int(2.2 * sum(map(len, enc)) / 2**20)),
+                                   crop_seed=1234, flip_seed=1235, cache_type=cache_type)
     mean, inv = O.cmn_norm_args(MEAN, STD)
     for it in range(batches * epochs):
         data, lab = pipe.run()
@@ -59,6 +59,8 @@ def test_resident_pipeline_of_the_bench_equals_oracle(tmp_path, batch, batches, 
     # and config.roi_decode_fusion follow executed_kernels(), so a fusion that silently disengaged must fail HERE
     if os.environ.get("DALI_AMD_ROI_FUSION", "1") != "0":
         assert "windows_of_the_consumer" in pipe.executed_kernels()
+    # cache_type="indexed" (bench.py's resident_indexed leg): the later epochs decoded from the streams' side information
+    assert ("jpeg_huffman_indexed" in pipe.executed_kernels()) == (cache_type == "indexed")
 
 
 def test_fused_equals_unfused_at_the_bench_shape(tmp_path):

@@ -1,0 +1,93 @@
+"""Side information of resident streams (daliamdJpegHuffDesc.index / index_out, round 5): a decode that builds the index
+of its streams, then decodes FROM the index - no un-stuffing, one decode per 256-byte slice from its recorded entry state,
+DC predictors from the index, slices outside a region of interest skipped - must give the same bits as the full parse and
+as the oracle.  Kernel level (the C ABI through dali_amd/backend.py); the operator level is tests/test_gpu_encoded_cache.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests.util import encode_jpeg, synth_image
+
+pytestmark = pytest.mark.gpu
+
+
+def _streams(rng):
+    enc = []
+    for (h, w) in [(1, 1), (8, 8), (17, 23), (100, 75), (375, 500), (500, 375), (257, 255), (5, 640), (480, 640)]:
+        for kw in [dict(subsampling="4:4:4"), dict(subsampling="4:2:2"), dict(subsampling="4:2:0"), dict(subsampling="4:1:1"),
+                   dict(subsampling="4:2:0", quality=100), dict(subsampling="4:2:0", quality=5),
+                   dict(subsampling="4:2:0", optimize=True)]:
+            enc.append(encode_jpeg(synth_image(rng, h, w), **({"quality": 85} | kw)))
+        enc.append(encode_jpeg(synth_image(rng, h, w, 1), 80))
+    # flat content (hundreds of blocks per slice), noise at q100 (a block spans slices), trailing bytes behind EOI, a
+    # restart-interval stream (takes the ordinary path inside the same table) and a progressive one (host decoder)
+    enc.append(encode_jpeg(np.full((480, 640, 3), (200, 30, 90), np.uint8), 90))
+    enc.append(encode_jpeg(rng.integers(0, 256, (130, 262, 3), dtype=np.uint8), 100, subsampling="4:4:4"))
+    enc.append(encode_jpeg(synth_image(rng, 120, 160), 85) + b"\x00\xff\xd8tail" * 9)
+    enc.append(encode_jpeg(synth_image(rng, 200, 300), 85, subsampling="4:2:0", restart_marker_blocks=7))
+    enc.append(encode_jpeg(synth_image(rng, 64, 80), 85, progressive=True))
+    enc.append(encode_jpeg(synth_image(rng, 1200, 1600), 92, subsampling="4:2:0"))   # several segments
+    return enc
+
+
+@pytest.mark.parametrize("exact_scan", [True, False])
+def test_indexed_decode_equals_full_parse_and_oracle(exact_scan):
+    from dali_amd import backend as B
+    enc = _streams(np.random.default_rng(21))
+    first, plan = B.decode_jpeg_batch(enc, device="cuda", exact_scan=exact_scan, index="build")
+    torch.cuda.synchronize()
+    first = [v.cpu().numpy() for v in first]
+    again, plan2 = B.decode_jpeg_batch(enc, device="cuda", exact_scan=exact_scan, index="use", index_from=plan)
+    torch.cuda.synchronize()
+    again = [v.cpu().numpy() for v in again]
+    for i, e in enumerate(enc):
+        ref = O.jpeg_decode_rgb(e)
+        assert np.array_equal(first[i], ref), f"sample {i} (decode that builds the index)"
+        assert np.array_equal(again[i], ref), f"sample {i} (decode from the index): {np.argwhere((again[i] != ref).any(2))[:4].tolist()}"
+    # 12 bytes per 256-byte slice + the header: a few per cent of the stream
+    assert plan.index_bytes < 1.10 * plan.stream_bytes + 1024 * len(enc)
+
+
+def test_indexed_window_decode(tmp_path):
+    """Windows (region-of-interest decode) from the index: only the slices that hold blocks of the window's MCU rectangle
+    are decoded; every window - other ones than the decode that built the index saw - equals the crop of the oracle."""
+    from dali_amd import backend as B
+    rng = np.random.default_rng(22)
+    enc = [e for e in _streams(rng)]
+    shapes = [O.jpeg_decode_rgb(e).shape[:2] for e in enc]
+
+    def windows(seed):
+        r = np.random.default_rng(seed)
+        out = []
+        for (h, w) in shapes:
+            wh, ww = int(r.integers(1, h + 1)), int(r.integers(1, w + 1))
+            out.append((int(r.integers(0, h - wh + 1)), int(r.integers(0, w - ww + 1)), wh, ww))
+        return out
+    _, plan = B.decode_jpeg_batch(enc, device="cuda", exact_scan=False, index="build", rois=windows(1))
+    torch.cuda.synchronize()
+    for seed in (2, 3):
+        rois = windows(seed)
+        got, _ = B.decode_jpeg_batch(enc, device="cuda", exact_scan=False, index="use", index_from=plan, rois=rois)
+        torch.cuda.synchronize()
+        for i, (e, (y, x, h, w)) in enumerate(zip(enc, rois)):
+            ref = O.jpeg_decode_rgb(e)[y:y + h, x:x + w]
+            assert np.array_equal(got[i].cpu().numpy(), ref), f"sample {i} window {(y, x, h, w)}"
+
+
+def test_setup_refuses_what_has_no_index():
+    """The plain Setup entry point refuses tables with index pointers; restart-interval streams take neither."""
+    import ctypes as C
+    from dali_amd import _capi as capi, backend as B
+    rng = np.random.default_rng(23)
+    enc = [encode_jpeg(synth_image(rng, 64, 64), 85, restart_marker_blocks=3)]
+    plan = B.JpegBatchPlan(enc)
+    plan.set_index_mode("build", torch.device("cuda"))
+    planes = torch.empty(plan.plane_bytes, dtype=torch.uint8, device="cuda")
+    table = plan.huffman_descs(None, planes_dev=planes)[0]
+    assert table["index_out"][0] == 0                       # (the driver leaves restart-interval streams alone)
+    table = table.copy()
+    table["index_out"] = plan._index_dev.data_ptr()
+    a, b, c, k = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+    rc = capi.kernels().daliamdJpegHuffmanSetupColor(table.ctypes.data_as(C.c_void_p), 1, C.byref(a), C.byref(b), C.byref(c), C.byref(k))
+    assert rc != 0 and b"restart" in capi.kernels().daliamdGetLastErrorMessage()
