@@ -42,7 +42,7 @@ class JpegHuffDesc(C.Structure):
                 ("bits", (C.c_uint8 * 16) * 4), ("vals", (C.c_uint8 * 256) * 4), ("rect", (C.c_int32 * 4) * 3),
                 ("plane", C.c_void_p * 3), ("plane_pitch", C.c_int32 * 3), ("restart_interval", C.c_int32),
                 ("quant", (C.c_uint16 * 64) * 3), ("rgb", C.c_void_p), ("rgb_pitch", C.c_int32), ("width", C.c_int32),
-                ("height", C.c_int32), ("reserved", C.c_int32), ("index", C.c_void_p), ("index_out", C.c_void_p)]
+                ("height", C.c_int32), ("reserved", C.c_int32), ("index", C.c_void_p), ("index_out", C.c_void_p), ("tables", C.c_void_p)]
 
 
 class JpegColorDesc(C.Structure):
@@ -181,8 +181,8 @@ _KERNEL_SYMBOLS = [
     "daliamdMemcpyD2HAsync", "daliamdMemcpyD2DAsync", "daliamdMemsetAsync", "daliamdMemcpy2DD2DAsync",
     "daliamdJpegIdctSetup", "daliamdJpegIdctRun", "daliamdJpegHuffmanScratchBytes", "daliamdJpegHuffmanScratchBytesRestart", "daliamdJpegHuffmanSetup",
     "daliamdJpegHuffmanRun", "daliamdJpegHuffmanRunProfiled", "daliamdJpegHuffmanSetupColor", "daliamdJpegHuffmanRunColor",
-    "daliamdJpegHuffmanRunProfiledColor", "daliamdJpegHuffmanColorFusable", "daliamdJpegHuffmanIndexBytes", "daliamdJpegColorSetup", "daliamdJpegPlanRoi", "daliamdJpegColorRun",
-    "daliamdResampleSetup", "daliamdResampleRun", "daliamdCmnSetup", "daliamdCmnRun",
+    "daliamdJpegHuffmanRunProfiledColor", "daliamdJpegHuffmanColorFusable", "daliamdJpegHuffmanIndexBytes", "daliamdJpegHuffmanTablesBytes", "daliamdJpegHuffmanTablesBuild", "daliamdJpegColorSetup", "daliamdJpegPlanRoi", "daliamdJpegColorRun",
+    "daliamdResampleSetup", "daliamdResampleRun", "daliamdResampleRunTables", "daliamdResampleRunPasses", "daliamdCmnSetup", "daliamdCmnRun",
     "daliamdWarpAffineSetup", "daliamdWarpAffineRun", "daliamdGaussianWindow", "daliamdGaussianBlurSetup",
     "daliamdGaussianBlurRun", "daliamdGaussianBlurPointwiseRun", "daliamdColorTwistMatrix", "daliamdPointwiseSetup", "daliamdPointwiseRun",
     "daliamdHannWindow", "daliamdSpectrogramTwiddles", "daliamdSpectrogramSetup", "daliamdSpectrogramRun", "daliamdMelFilterBankWeights",

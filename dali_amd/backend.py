@@ -301,6 +301,23 @@ class JpegBatchPlan:
         # quantisation tables of the GPU-decoded streams come from the scan analysis
         self.quant[sel] = sc["quant"][sel, :3]
 
+    def _device_tables(self, table, device):
+        """Per stream of `table`: device address of its finished code tables (one buffer per distinct set, kept by the plan)."""
+        lib = capi.kernels()
+        nb = C.c_size_t(0)
+        capi.check(lib.daliamdJpegHuffmanTablesBytes(C.byref(nb)))
+        store = self.__dict__.setdefault("_table_store", {})
+        one = table.dtype.itemsize
+        out = np.zeros(len(table), np.uint64)
+        for j in range(len(table)):
+            key = b"".join(table[f][j].tobytes() for f in ("blocks_per_mcu", "comp_of_block", "dc_sel", "ac_sel", "bits", "vals"))
+            if key not in store:
+                host = torch.empty(nb.value, dtype=torch.uint8)
+                capi.check(lib.daliamdJpegHuffmanTablesBuild(C.c_void_p(table.ctypes.data + j * one), C.c_void_p(host.data_ptr())))
+                store[key] = host.to(device)
+            out[j] = store[key].data_ptr()
+        return out
+
     def set_index_mode(self, mode, device=None):
         """None / "build" / "use" (see huffman_descs).  The entries live in one device buffer of the plan."""
         assert mode in (None, "build", "use")
@@ -337,7 +354,8 @@ class JpegBatchPlan:
         # into the same buffers again (benchmarks) gets the table it built the first time
         key = (ws["scratch"].data_ptr(), ws["status"].data_ptr(), None if coef_dev is None else coef_dev.data_ptr(),
                None if planes_dev is None else planes_dev.data_ptr(), self._ecs_dev.data_ptr(),
-               None if rgb_dev is None else rgb_dev.data_ptr(), getattr(self, "index_mode", None))
+               None if rgb_dev is None else rgb_dev.data_ptr(), getattr(self, "index_mode", None),
+               getattr(self, "host_tables", False))
         cache = self.__dict__.setdefault("_huff_desc_cache", {})
         if key in cache:
             return cache[key]
@@ -374,6 +392,10 @@ class JpegBatchPlan:
         d["ecs"] = self._ecs_dev.data_ptr() + self._ecs_off
         d["scratch"] = ws["scratch"].data_ptr() + self._scratch_off
         d["status"] = ws["status"].data_ptr() + 4 * np.arange(m)
+        if getattr(self, "host_tables", False) and m:
+            # code tables built on the host, once per distinct DHT contents + MCU structure of the batch, resident on the
+            # device (daliamdJpegHuffDesc.tables): the launch builds nothing
+            d["tables"] = self._device_tables(d, ws["scratch"].device)
         mode = getattr(self, "index_mode", None)
         if mode and m:
             # side information of resident streams (daliamdJpegHuffDesc.index / index_out): "build" - this decode leaves an
@@ -608,7 +630,7 @@ class _HuffDescs(tuple):
 
 
 def decode_jpeg_batch(encoded, device="cuda", num_threads=None, out_pitch_align=16, huffman="gpu", rois=None, exact_scan=True,
-                      fuse_color=False, index=None, index_from=None):
+                      fuse_color=False, index=None, index_from=None, host_tables=False):
     """Decodes a batch of JPEG byte strings -> list of u8 HWC RGB device tensors.
     rois: optional per-sample windows (y0, x0, h, w): region-of-interest decode (decoders.image_crop & co.).
 
@@ -619,6 +641,7 @@ def decode_jpeg_batch(encoded, device="cuda", num_threads=None, out_pitch_align=
     Dequantisation, IDCT, upsampling and colour conversion always run on the device."""
     device = torch.device(device)
     plan = JpegBatchPlan(encoded, out_pitch_align, rois=rois, exact_scan=exact_scan)
+    plan.host_tables = host_tables
     if index:
         # index="build": the decode leaves the side information of every stream in the plan; index="use" with
         # index_from=<the plan of a "build" decode of the same streams>: decode from it (other windows are fine)

@@ -285,8 +285,18 @@ __global__ __launch_bounds__(kWarpThreads) void WarpAffineKernel(const daliamdWa
 #ifndef DALIAMD_BLUR_THREADS
 #define DALIAMD_BLUR_THREADS 256
 #endif
+#ifndef DALIAMD_BLUR_MFMA_DEFAULT
+#define DALIAMD_BLUR_MFMA_DEFAULT 0
+#endif
 constexpr int kBlurThreads = DALIAMD_BLUR_THREADS;
 constexpr int kBlurMaxLds = 60 * 1024;
+constexpr int kBlurMfmaFlag = 1 << 30;   // in the `lds_bytes` Setup hands to Run: the table is tiled for GaussianBlurMfmaKernel
+// DALI_AMD_BLUR_MFMA: 1 = the matrix-core variant where it applies (<= 1 LSB from the CPU order of roundings), 0 = the VALU
+// kernel (bit-exact against it).  Default: see the measurement in DESIGN.md.
+inline bool BlurMfmaEnabled() {
+  static const bool on = [] { const char *e = getenv("DALI_AMD_BLUR_MFMA"); return e ? atoi(e) != 0 : DALIAMD_BLUR_MFMA_DEFAULT != 0; }();
+  return on;
+}
 // LDS pitches of the blur's two tiles (shared by the kernel and Setup).  DALIAMD_BLUR_TPAD: floats added to a row of the
 // fp32 intermediate (even); DALIAMD_BLUR_SMOD: when non-zero the staged source pitch is raised to SMOD modulo 64 bytes.
 // The W pass's lanes are (row pair, 8-pixel group, channel): the four groups of a row pair sit 6 dwords apart in the staged
@@ -627,6 +637,154 @@ __global__ __launch_bounds__(kBlurThreads) void GaussianBlurKernel(const daliamd
 }
 
 // =============================================================================================
+// gaussian blur on the matrix cores (round 5): the taps as a banded Toeplitz product
+// =============================================================================================
+// A separable convolution is a product with a banded Toeplitz matrix: 16 outputs of a line need 16 + K - 1 inputs,
+// out[m] = sum_k T[m][k] in[k] with T[m][k] = w[k - m] inside the band, 0 outside.  v_mfma_f32_16x16x4_f32 (f32 in, f32
+// accumulate - on gfx950 bitwise an fmaf chain in ascending k) multiplies a 16 x 4 slice of T by the 4 x 16 tile "those 4
+// inputs of 16 independent lines": ceil((16 + K - 1) / 4) instructions for 16 x 16 outputs (9 for the 19 taps of sigma = 3:
+// 47 % of the multiplies hit the band, the rest multiply by zero - and add nothing: fmaf(0, x, acc) = acc for finite x).
+// The VALU kernel above issues one multiply and one add per tap and output, 38 per output byte, and is bound by exactly
+// that; here an output costs 9 / 256 of a 32-cycle instruction per pass and the vector ALU only converts and moves.
+//   W pass  lines = 16 staged rows, inputs = pixels x .. x + 35 of ONE channel (bytes 3 bytes apart in the staged HWC
+//           tile, converted on the way: B operand = one byte load + one conversion), outputs = 16 pixels; the three
+//           channels of the same 16 x 16 tile leave as 12 consecutive floats per lane of the fp32 intermediate
+//   H pass  lines = 16 consecutive floats of an intermediate row (B = one dword load), inputs = rows y .. y + 35,
+//           outputs = 16 rows; rounded (ConvertSat) into the LDS tile the write-out - and a fused pointwise operator -
+//           reads whole pixels from
+// The result is the fused-multiply-add chain over the taps in order, i.e. the bits of GaussianBlurKernel<FMA = true>
+// (DALI_AMD_BLUR_FMA=1), which is within 1 LSB of the separately rounded CPU order - the tolerance the reference allows its
+// own GPU convolution (a GEMM as well, dali/kernels/imgproc/convolution/convolution_gpu.h:88-240) against its CPU one
+// (operator_1/test_gaussian_blur.py:134,164: max_allowed_error = 1).  Three channels, windows up to 21 taps.
+constexpr int kBlurMfmaTW = 32;            // output pixels per tile row
+constexpr int kBlurMfmaInRows = 64;        // staged rows = intermediate rows (4 row tiles of 16)
+constexpr int kBlurMfmaMaxWindow = 21;     // 16 + 21 - 1 = 36 inputs = 9 steps of 4
+constexpr int kBlurMfmaSteps = 9;
+constexpr int kBlurMfmaTmpStride = 112;    // floats: 96 + 16, so that the two rows of a 32-lane LDS group sit on disjoint banks
+__host__ __device__ inline int BlurMfmaTileH(int size_y) { return kBlurMfmaInRows - (size_y - 1); }
+__host__ __device__ inline int BlurMfmaSrcPitch(int size_x) {   // bytes: (TW + K - 1 + 2 overrun pixels) * 3 + alignment lead
+  int p = (kBlurMfmaTW + size_x - 1 + 2) * 3 + 3;
+  p = (p + 15) & ~15;
+  return p + 8;    // = 8 modulo 16: sixteen rows start on sixteen different even banks
+}
+__host__ __device__ inline int BlurMfmaLdsBytes(int size_x) {
+  return kBlurMfmaInRows * kBlurMfmaTmpStride * 4 + kBlurMfmaInRows * BlurMfmaSrcPitch(size_x) + 16;
+}
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+template <bool PW>
+__global__ __launch_bounds__(kBlurThreads) void GaussianBlurMfmaKernel(const daliamdGaussianBlurDesc *__restrict__ descs,
+                                                                       int ndesc, int total_wg,
+                                                                       const daliamdPointwiseDesc *__restrict__ pointwise) {
+  extern __shared__ __attribute__((aligned(16))) float blur_lds[];
+  int wg = XcdRemap(blockIdx.x, total_wg);
+  if (wg < 0) return;
+  const int di = FindDesc(descs, ndesc, wg);
+  const daliamdGaussianBlurDesc &d = descs[di];
+  constexpr int C = 3, TW = kBlurMfmaTW, IN_ROWS = kBlurMfmaInRows, TS = kBlurMfmaTmpStride;
+  const int TH = d.tile_h;
+  const int Kx = d.size_x, Ky = d.size_y;
+  const int rx = (Kx - 1) / 2, ry = (Ky - 1) / 2;
+  const int t = wg - d.wg_start;
+  const int ty = t / d.tiles_x, tx = t - ty * d.tiles_x;
+  const int ox0 = tx * TW, oy0 = ty * TH;
+  const int tw = min(TW, d.w - ox0), th = min(TH, d.h - oy0);
+  const int in_cols = TW + 2 * rx;
+  const int src_pitch = BlurMfmaSrcPitch(Kx);
+  float *tmp = blur_lds;                                                   // [IN_ROWS][TS]
+  uint8_t *src = reinterpret_cast<uint8_t *>(tmp + IN_ROWS * TS);          // [IN_ROWS][src_pitch]; later the rounded tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // ---- stage the halo-extended source tile (always the full tile: a partial one computes outputs nobody stores) ----
+  const bool interior_x = ox0 - rx >= 0 && ox0 + TW + rx <= d.w;
+  const bool same_lead = (d.in_pitch & 3) == 0;
+  for (int r = tid / 64; r < IN_ROWS; r += kBlurThreads / 64) {
+    const uint8_t *row = d.in + (size_t)Reflect101(oy0 - ry + r, d.h) * d.in_pitch;
+    uint8_t *dst = src + r * src_pitch;
+    if (interior_x) {
+      const uint8_t *g = row + (size_t)(ox0 - rx) * C;
+      const int lead = (int)(reinterpret_cast<uintptr_t>(g) & 3);
+      const uint32_t *gw = reinterpret_cast<const uint32_t *>(g - lead);
+      uint32_t *dw = reinterpret_cast<uint32_t *>(dst);
+      const int ndw = (lead + in_cols * C + 3) >> 2;
+      for (int j = lane; j < ndw; j += 64) dw[j] = gw[j];
+    } else {
+      for (int cx = lane; cx < in_cols; cx += 64) {
+        const uint8_t *p = row + (size_t)Reflect101(ox0 - rx + cx, d.w) * C;
+        for (int c = 0; c < C; c++) dst[cx * C + c] = p[c];
+      }
+    }
+  }
+  // the band of the two Toeplitz matrices as this lane holds it: A[m = lane & 15][k = 4 s + (lane >> 4)] = w[k - m]
+  const int m = lane & 15, kq = lane >> 4;
+  float ax[kBlurMfmaSteps], ay[kBlurMfmaSteps];
+#pragma unroll
+  for (int s4 = 0; s4 < kBlurMfmaSteps; s4++) {
+    const int idx = 4 * s4 + kq - m;
+    ax[s4] = idx >= 0 && idx < Kx ? d.window_x[idx] : 0.0f;
+    ay[s4] = idx >= 0 && idx < Ky ? d.window_y[idx] : 0.0f;
+  }
+  const int steps_x = (16 + Kx - 1 + 3) >> 2, steps_y = (16 + Ky - 1 + 3) >> 2;
+  const int lead0 = interior_x ? (int)((reinterpret_cast<uintptr_t>(d.in) + (size_t)(ox0 - rx) * C) & 3) : 0;
+  __syncthreads();
+  // ---- W pass: items = (row tile, pixel tile); lane (n = lane & 15: staged row, kq: which of the 4 inputs of a step) ----
+  for (int item = wave; item < (IN_ROWS / 16) * (TW / 16); item += kBlurThreads / 64) {
+    const int rt = item / (TW / 16), pt = item - rt * (TW / 16);
+    const int r = 16 * rt + m;   // (the B operand's line index is lane & 15 as well)
+    int lead = lead0;
+    if (interior_x && !same_lead) {
+      const uint8_t *rowp = d.in + (size_t)Reflect101(oy0 - ry + r, d.h) * d.in_pitch + (size_t)(ox0 - rx) * C;
+      lead = (int)(reinterpret_cast<uintptr_t>(rowp) & 3);
+    }
+    const uint8_t *bp = src + r * src_pitch + lead + (16 * pt + kq) * C;
+    floatx4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+#pragma unroll
+    for (int s4 = 0; s4 < kBlurMfmaSteps; s4++) {
+      if (s4 < steps_x) {   // (uniform)
+        const float b0 = (float)bp[12 * s4], b1 = (float)bp[12 * s4 + 1], b2 = (float)bp[12 * s4 + 2];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[s4], b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[s4], b1, acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[s4], b2, acc2, 0, 0, 0);
+      }
+    }
+    // result: row 16 rt + (lane & 15), pixels 16 pt + 4 kq + i (i = 0..3), three channels: 12 consecutive floats
+    float4 *o = reinterpret_cast<float4 *>(tmp + r * TS + (16 * pt + 4 * kq) * C);
+    o[0] = make_float4(acc0[0], acc1[0], acc2[0], acc0[1]);
+    o[1] = make_float4(acc1[1], acc2[1], acc0[2], acc1[2]);
+    o[2] = make_float4(acc2[2], acc0[3], acc1[3], acc2[3]);
+  }
+  __syncthreads();
+  // ---- H pass: items = (output row tile, 16 floats of the row); the rounded bytes go where the staged source was ----
+  uint8_t *outb = src;
+  constexpr int opitch = TW * C;   // 96
+  const int row_tiles = (TH + 15) >> 4;
+  for (int item = wave; item < row_tiles * (TW * C / 16); item += kBlurThreads / 64) {
+    const int yt = item / (TW * C / 16), ft = item - yt * (TW * C / 16);
+    const float *bp = tmp + 16 * ft + m;
+    floatx4 acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int s4 = 0; s4 < kBlurMfmaSteps; s4++) {
+      if (s4 < steps_y) {
+        // (rows behind the last staged one only meet zero weights - but must be finite: clamped)
+        const int row = min(16 * yt + 4 * s4 + kq, IN_ROWS - 1);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ay[s4], bp[row * TS], acc, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int y = 16 * yt + 4 * kq + i;
+      if (y < TH) outb[y * opitch + 16 * ft + m] = (uint8_t)SatU8(acc[i]);
+    }
+  }
+  __syncthreads();
+  if constexpr (PW) {
+    const daliamdPointwiseDesc pw = pointwise[di];   // (a private copy: the stores below cannot alias it)
+    BlurWriteOut(d, &pw, outb, opitch, tw, th, ox0, oy0);
+  } else {
+    BlurWriteOut(d, nullptr, outb, opitch, tw, th, ox0, oy0);
+  }
+}
+
+// =============================================================================================
 // pointwise: colour twist (3x3 matrix + offset) and / or erase, 4 pixels per thread
 // =============================================================================================
 constexpr int kPwThreads = 256;
@@ -840,6 +998,13 @@ daliamdResult_t daliamdGaussianBlurSetup(daliamdGaussianBlurDesc *descs, int n, 
   DALIAMD_REQUIRE(descs && num_workgroups && lds_bytes && n >= 0, DALIAMD_ERROR_INVALID_ARGUMENT,
                   "daliamdGaussianBlurSetup: NULL argument");
   int wg = 0, lds = 0;
+  // The matrix-core variant (GaussianBlurMfmaKernel) serves a table whose samples ALL have three channels and windows of at
+  // most 21 taps; the choice travels to Run in bit 30 of *lds_bytes.  DALI_AMD_BLUR_MFMA=0: the VALU kernel (bit-exact
+  // against the CPU order of roundings) for everything.
+  bool mfma = BlurMfmaEnabled() && n > 0;
+  for (int i = 0; i < n && mfma; i++)
+    mfma = descs[i].channels == 3 && descs[i].size_x > 0 && descs[i].size_y > 0 && descs[i].size_x <= kBlurMfmaMaxWindow &&
+           descs[i].size_y <= kBlurMfmaMaxWindow;
   for (int i = 0; i < n; i++) {
     auto &d = descs[i];
     DALIAMD_REQUIRE(d.h > 0 && d.w > 0 && d.channels >= 1 && d.channels <= 4, DALIAMD_ERROR_INVALID_ARGUMENT,
@@ -847,6 +1012,16 @@ daliamdResult_t daliamdGaussianBlurSetup(daliamdGaussianBlurDesc *descs, int n, 
     DALIAMD_REQUIRE((d.size_x & 1) && (d.size_y & 1) && d.size_x <= DALIAMD_MAX_BLUR_WINDOW &&
                     d.size_y <= DALIAMD_MAX_BLUR_WINDOW && d.size_x > 0 && d.size_y > 0, DALIAMD_ERROR_UNSUPPORTED,
                     "daliamdGaussianBlurSetup: sample %d: window sizes must be odd and <= %d", i, DALIAMD_MAX_BLUR_WINDOW);
+    if (mfma) {   // the banded-Toeplitz kernel's fixed tile: 32 pixels x (64 - 2 radius) rows
+      const int tw = kBlurMfmaTW, th = BlurMfmaTileH(d.size_y);
+      d.tile_w = tw; d.tile_h = th;
+      d.tiles_x = (d.w + tw - 1) / tw;
+      d.lds_bytes = BlurMfmaLdsBytes(d.size_x);
+      d.wg_start = wg;
+      wg += d.tiles_x * ((d.h + th - 1) / th);
+      lds = lds > d.lds_bytes ? lds : d.lds_bytes;
+      continue;
+    }
     // tall tiles: the W pass also runs over the 2 * radius halo rows, so its overhead is (th + 2r) / th
     int tw = 32, th = 64;
     auto need = [&](int tw_, int th_) {
@@ -868,15 +1043,25 @@ daliamdResult_t daliamdGaussianBlurSetup(daliamdGaussianBlurDesc *descs, int n, 
     lds = lds > d.lds_bytes ? lds : d.lds_bytes;
   }
   *num_workgroups = wg;
-  *lds_bytes = lds;
+  *lds_bytes = lds | (mfma ? kBlurMfmaFlag : 0);
   return DALIAMD_SUCCESS;
 }
 
 daliamdResult_t daliamdGaussianBlurPointwiseRun(daliamdStream_t stream, const daliamdGaussianBlurDesc *descs_dev, int n, int nwg,
                                                 int lds_bytes, const daliamdPointwiseDesc *pointwise_dev) {
   if (n == 0 || nwg == 0) return DALIAMD_SUCCESS;
+  const bool mfma = lds_bytes >= 0 && (lds_bytes & kBlurMfmaFlag) != 0;
+  if (lds_bytes >= 0) lds_bytes &= ~kBlurMfmaFlag;
   DALIAMD_REQUIRE(descs_dev && n > 0 && nwg > 0 && lds_bytes >= 0 && lds_bytes <= kBlurMaxLds,
                   DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdGaussianBlurRun: invalid argument");
+  if (mfma) {
+    daliamd::KernelTimer timer("GaussianBlurMfmaKernel", (hipStream_t)stream);
+    auto kern = pointwise_dev ? GaussianBlurMfmaKernel<true> : GaussianBlurMfmaKernel<false>;
+    hipLaunchKernelGGL(kern, dim3(XcdGrid(nwg)), dim3(kBlurThreads), lds_bytes, (hipStream_t)stream, descs_dev, n, nwg,
+                       pointwise_dev);
+    DALIAMD_HIP_CHECK(hipGetLastError());
+    return DALIAMD_SUCCESS;
+  }
   // DALI_AMD_BLUR_FMA=1: fused multiply-add accumulation (<= 1 LSB from the default, which replays the reference CPU
   // backend's separately rounded multiply and add bit for bit)
   static const bool fma = getenv("DALI_AMD_BLUR_FMA") && atoi(getenv("DALI_AMD_BLUR_FMA")) != 0;

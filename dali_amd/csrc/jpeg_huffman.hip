@@ -218,7 +218,10 @@ __device__ __forceinline__ ImageRef FindImage(const daliamdJpegHuffDesc *descs, 
 // tables of Annex K: a batch of 256 images is usually one or two sets): `table_owner` (Setup) names the stream in whose
 // scratch the tables of this stream live.  PrepareKernel builds 1-3 sets instead of 256, and every workgroup of the
 // decode passes copies its 36 KB of tables from the same few L2-resident lines.
+// (round 5) A stream whose caller brings finished tables (daliamdJpegHuffDesc.tables: built on the host once per distinct
+// DHT contents, daliamdJpegHuffmanTablesBuild) reads those; nobody builds anything for it.
 __device__ __forceinline__ const uint8_t *TablesBase(const daliamdJpegHuffDesc *descs, const daliamdJpegHuffDesc &d, bool sync_tables) {
+  if (d.tables) return d.tables + (sync_tables ? sizeof(HuffTables) : 0);
   const daliamdJpegHuffDesc &o = descs[d.table_owner];
   const ScratchLayout lay = LayoutOf(o);
   return o.scratch + (sync_tables ? lay.sync_tables : lay.tables);
@@ -535,15 +538,17 @@ __device__ __forceinline__ void BuildTables(const daliamdJpegHuffDesc &d, HuffTa
 // One launch for the two jobs that only need the descriptors: workgroups [0, n) build the code tables of one stream
 // each (a long chain of short phases: they go first so that they run next to the tile workgroups instead of behind
 // them), workgroups [n, n + num_tiles) count the bytes their tile of the stuffed stream keeps.
+// (ntab = n when some stream of the table needs its code tables built here, 0 when every stream brought them)
 __global__ __launch_bounds__(kTileThreads) void PrepareKernel(const daliamdJpegHuffDesc *__restrict__ descs, int n,
-                                                              int num_tiles) {
+                                                              int num_tiles, int ntab) {
   __shared__ __attribute__((aligned(16))) HuffTables L;
   __shared__ int wave_sums[kTileThreads / 64 + 1];
   __shared__ int wave_ends[kTileThreads / 64];
-  if ((int)blockIdx.x < n) {
-    if (descs[blockIdx.x].table_owner == (int)blockIdx.x) BuildTables(descs[blockIdx.x], L);   // (uniform per workgroup)
+  if ((int)blockIdx.x < ntab) {
+    const daliamdJpegHuffDesc &d = descs[blockIdx.x];
+    if (d.table_owner == (int)blockIdx.x && !d.tables) BuildTables(d, L);   // (uniform per workgroup)
   } else {
-    CountTile(descs, n, (int)blockIdx.x - n, wave_sums, wave_ends);
+    CountTile(descs, n, (int)blockIdx.x - ntab, wave_sums, wave_ends);
   }
 }
 
@@ -1700,6 +1705,46 @@ daliamdResult_t daliamdJpegHuffmanScratchBytesRestart(int ecs_len, int total_blo
   return DALIAMD_SUCCESS;
 }
 
+daliamdResult_t daliamdJpegHuffmanTablesBytes(size_t *bytes) {
+  DALIAMD_REQUIRE(bytes, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdJpegHuffmanTablesBytes: NULL argument");
+  *bytes = sizeof(daliamd::HuffTables) + sizeof(daliamd::SyncTables);
+  return DALIAMD_SUCCESS;
+}
+
+// The code tables of one stream on the HOST: the functions BuildTables runs on the device (huff_core.h compiles for both),
+// entry by entry - the same bytes.
+daliamdResult_t daliamdJpegHuffmanTablesBuild(const daliamdJpegHuffDesc *d, void *out_host) {
+  using namespace daliamd;
+  DALIAMD_REQUIRE(d && out_host && d->blocks_per_mcu >= 1 && d->blocks_per_mcu <= DALIAMD_JPEG_MAX_BLOCKS_PER_MCU,
+                  DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdJpegHuffmanTablesBuild: invalid argument");
+  memset(out_host, 0, sizeof(HuffTables) + sizeof(SyncTables));
+  HuffTables &L = *static_cast<HuffTables *>(out_host);
+  SyncTables &S = *reinterpret_cast<SyncTables *>(static_cast<uint8_t *>(out_host) + sizeof(HuffTables));
+  memcpy(L.vals, d->vals, sizeof(L.vals));
+  for (int k = 0; k < d->blocks_per_mcu; k++) {
+    const int comp = d->comp_of_block[k];
+    DALIAMD_REQUIRE(comp < 3, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdJpegHuffmanTablesBuild: block %d refers to component %d", k, comp);
+    L.dc_mask |= (uint32_t)(d->dc_sel[comp] & 1) << k;
+    L.ac_mask |= (uint32_t)(d->ac_sel[comp] & 1) << k;
+  }
+  L.bpm = d->blocks_per_mcu;
+  for (int t = 0; t < 4; t++) CodeRanges(d->bits[t], L.maxcode[t], L.valoff[t], &L.l2_first[t], &L.l2_size[t]);
+  for (int t = 0; t < 4; t++) {
+    for (int w = 0; w < (1 << kFastBits); w++) L.fast[t][w] = FastEntry(L, t, w);
+    for (int j = 0; j < kL2Entries; j++) L.l2[t][j] = L2Entry(L, t, j);
+  }
+  for (int t = 0; t < 4; t++)
+    for (int w = 0; w < (1 << kFastBits); w++) S.t32[t][w] = SyncEntry(L, t, w);
+  memcpy(S.l2, L.l2, sizeof(S.l2));
+  memcpy(S.l2_first, L.l2_first, sizeof(S.l2_first));
+  memcpy(S.l2_size, L.l2_size, sizeof(S.l2_size));
+  memcpy(S.maxcode, L.maxcode, sizeof(S.maxcode));
+  memcpy(S.valoff, L.valoff, sizeof(S.valoff));
+  memcpy(S.vals, L.vals, sizeof(S.vals));
+  S.dc_mask = L.dc_mask; S.ac_mask = L.ac_mask; S.bpm = L.bpm; S.reserved = 0;
+  return DALIAMD_SUCCESS;
+}
+
 daliamdResult_t daliamdJpegHuffmanIndexBytes(int ecs_len, size_t *bytes) {
   DALIAMD_REQUIRE(ecs_len >= 0 && bytes, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdJpegHuffmanIndexBytes: invalid argument");
   *bytes = daliamd::IndexBytes(ecs_len);
@@ -1754,9 +1799,15 @@ daliamdResult_t daliamdJpegHuffmanSetupColor(daliamdJpegHuffDesc *descs_host, in
   for (int i = 0; i < n; i++) {
     daliamdJpegHuffDesc &d = descs_host[i];
     d.table_owner = i;
-    for (int o : owners)
-      if (same_tables(descs_host[o], d)) { d.table_owner = o; break; }
-    if (d.table_owner == i && owners.size() < 64) owners.push_back(i);
+    if (!d.tables) {   // (a stream that brings its tables owns nothing and needs no owner)
+      for (int o : owners)
+        if (same_tables(descs_host[o], d)) { d.table_owner = o; break; }
+      if (d.table_owner == i && owners.size() < 64) owners.push_back(i);
+      kinds |= DALIAMD_JPEG_HUFFMAN_BUILD_TABLES;
+    } else {
+      DALIAMD_REQUIRE((reinterpret_cast<uintptr_t>(d.tables) & 15) == 0, DALIAMD_ERROR_INVALID_ARGUMENT,
+                      "daliamdJpegHuffmanSetup: sample %d: tables must be 16-byte aligned", i);
+    }
     DALIAMD_REQUIRE((d.ecs || d.index) && d.scratch && d.status && d.ecs_len >= 0, DALIAMD_ERROR_INVALID_ARGUMENT,
                     "daliamdJpegHuffmanSetup: sample %d: NULL buffer or negative length", i);
     if (d.index || d.index_out) {
@@ -1848,10 +1899,14 @@ static daliamdResult_t LaunchHuffman(daliamdStream_t stream, const daliamdJpegHu
   const bool parsed = (block_kernels & DALIAMD_JPEG_HUFFMAN_PARSED) != 0 ||
                       !(block_kernels & (DALIAMD_JPEG_HUFFMAN_PARSED | DALIAMD_JPEG_HUFFMAN_INDEXED));
   const bool indexed = (block_kernels & DALIAMD_JPEG_HUFFMAN_INDEXED) != 0;
+  // (callers of the plain entry points pass no kinds: build)
+  const bool build_tables = (block_kernels & DALIAMD_JPEG_HUFFMAN_BUILD_TABLES) != 0 ||
+                            !(block_kernels & (DALIAMD_JPEG_HUFFMAN_PARSED | DALIAMD_JPEG_HUFFMAN_INDEXED));
+  const int ntab = build_tables ? n : 0;
   DALIAMD_HIP_CHECK(mark());
-  {
+  if (num_tiles + ntab > 0) {
     KernelTimer timer("PrepareKernel", s);
-    hipLaunchKernelGGL(PrepareKernel, dim3(num_tiles + n), dim3(kTileThreads), 0, s, descs_dev, n, num_tiles);
+    hipLaunchKernelGGL(PrepareKernel, dim3(num_tiles + ntab), dim3(kTileThreads), 0, s, descs_dev, n, num_tiles, ntab);
   }
   DALIAMD_HIP_CHECK(mark());
   if (parsed && num_tiles > 0) {
@@ -1911,7 +1966,7 @@ daliamdResult_t daliamdJpegHuffmanRun(daliamdStream_t stream, const daliamdJpegH
 
 daliamdResult_t daliamdJpegHuffmanRunColor(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev, int n, int num_tiles,
                                            int num_segments, int num_block_workgroups, int block_kernels) {
-  return LaunchHuffman(stream, descs_dev, n, num_tiles, num_segments, num_block_workgroups, nullptr, block_kernels & 31);
+  return LaunchHuffman(stream, descs_dev, n, num_tiles, num_segments, num_block_workgroups, nullptr, block_kernels & 63);
 }
 
 daliamdResult_t daliamdJpegHuffmanRunProfiled(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev, int n,
@@ -1925,7 +1980,7 @@ daliamdResult_t daliamdJpegHuffmanRunProfiledColor(daliamdStream_t stream, const
                                                    int num_tiles, int num_segments, int num_block_workgroups,
                                                    int block_kernels, daliamdEvent_t *events) {
   DALIAMD_REQUIRE(events, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdJpegHuffmanRunProfiledColor: events is NULL");
-  return LaunchHuffman(stream, descs_dev, n, num_tiles, num_segments, num_block_workgroups, events, block_kernels & 31);
+  return LaunchHuffman(stream, descs_dev, n, num_tiles, num_segments, num_block_workgroups, events, block_kernels & 63);
 }
 
 }  // extern "C"

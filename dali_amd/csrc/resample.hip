@@ -1264,29 +1264,50 @@ static const float *DeviceFilterTables() {
   return tables[dev];
 }
 
-daliamdResult_t daliamdResampleRun(daliamdStream_t stream, const daliamdResampleDesc *descs_dev, int n,
-                                   const daliamdResamplePlan *plan, void *workspace_dev) {
+// The two halves of daliamdResampleRun.  The first needs nothing but the descriptor table: a caller can run it on a side
+// stream while `stream` is still busy with the kernels that produce the source images (order the two with an event).
+static daliamdResult_t CheckResamplePlan(const daliamdResampleDesc *descs_dev, int n, const daliamdResamplePlan *plan,
+                                         void *workspace_dev, bool *nothing) {
+  *nothing = true;
   if (n == 0) return DALIAMD_SUCCESS;
   DALIAMD_REQUIRE(descs_dev && plan && n > 0, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdResampleRun: invalid argument");
-  const int num_tiles = plan->num_tiles, table_entries = plan->table_entries;
-  if (num_tiles == 0 && plan->generic_items[1] == 0) return DALIAMD_SUCCESS;
+  if (plan->num_tiles == 0 && plan->generic_items[1] == 0) return DALIAMD_SUCCESS;
   DALIAMD_REQUIRE(plan->lds_bytes >= 0 && plan->lds_bytes <= daliamd::kMaxLds, DALIAMD_ERROR_INVALID_ARGUMENT,
                   "daliamdResampleRun: invalid plan");
-  DALIAMD_REQUIRE(workspace_dev && plan->workspace_bytes > 0 && table_entries > 0, DALIAMD_ERROR_INVALID_ARGUMENT,
+  DALIAMD_REQUIRE(workspace_dev && plan->workspace_bytes > 0 && plan->table_entries > 0, DALIAMD_ERROR_INVALID_ARGUMENT,
                   "daliamdResampleRun: the table workspace is missing (size it with daliamdResampleSetup)");
+  DALIAMD_REQUIRE(plan->workspace_bytes >= (size_t)plan->num_tiles * sizeof(daliamd::TileRec), DALIAMD_ERROR_INVALID_ARGUMENT,
+                  "daliamdResampleRun: workspace too small");
+  *nothing = false;
+  return DALIAMD_SUCCESS;
+}
+
+daliamdResult_t daliamdResampleRunTables(daliamdStream_t stream, const daliamdResampleDesc *descs_dev, int n,
+                                         const daliamdResamplePlan *plan, void *workspace_dev) {
+  bool nothing;
+  daliamdResult_t rc = CheckResamplePlan(descs_dev, n, plan, workspace_dev, &nothing);
+  if (rc != DALIAMD_SUCCESS || nothing) return rc;
   const float *filter_tables = DeviceFilterTables();
   DALIAMD_REQUIRE(filter_tables, DALIAMD_ERROR_HIP, "daliamdResampleRun: could not set up the filter tables on the device");
-  const size_t rec_bytes = (size_t)num_tiles * sizeof(daliamd::TileRec);
-  DALIAMD_REQUIRE(plan->workspace_bytes >= rec_bytes, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdResampleRun: workspace too small");
-  const size_t tile_rec_off = plan->workspace_bytes - rec_bytes;   // as laid out by Setup
+  const int num_tiles = plan->num_tiles, table_entries = plan->table_entries;
+  const size_t tile_rec_off = plan->workspace_bytes - (size_t)num_tiles * sizeof(daliamd::TileRec);   // as laid out by Setup
+  daliamd::KernelTimer timer("ResampleTablesKernel", (hipStream_t)stream);
+  const int total = table_entries + num_tiles;
+  hipLaunchKernelGGL(daliamd::ResampleTablesKernel, dim3((total + daliamd::kTableThreads - 1) / daliamd::kTableThreads),
+                     dim3(daliamd::kTableThreads), 0, (hipStream_t)stream, descs_dev, n, table_entries, num_tiles,
+                     static_cast<uint8_t *>(workspace_dev), tile_rec_off, filter_tables);
+  DALIAMD_HIP_CHECK(hipGetLastError());
+  return DALIAMD_SUCCESS;
+}
+
+daliamdResult_t daliamdResampleRunPasses(daliamdStream_t stream, const daliamdResampleDesc *descs_dev, int n,
+                                         const daliamdResamplePlan *plan, void *workspace_dev) {
+  bool nothing;
+  daliamdResult_t rc = CheckResamplePlan(descs_dev, n, plan, workspace_dev, &nothing);
+  if (rc != DALIAMD_SUCCESS || nothing) return rc;
+  const int num_tiles = plan->num_tiles;
+  const size_t tile_rec_off = plan->workspace_bytes - (size_t)num_tiles * sizeof(daliamd::TileRec);
   uint8_t *ws = static_cast<uint8_t *>(workspace_dev);
-  {
-    daliamd::KernelTimer timer("ResampleTablesKernel", (hipStream_t)stream);
-    const int total = table_entries + num_tiles;
-    hipLaunchKernelGGL(daliamd::ResampleTablesKernel, dim3((total + daliamd::kTableThreads - 1) / daliamd::kTableThreads),
-                       dim3(daliamd::kTableThreads), 0, (hipStream_t)stream, descs_dev, n, table_entries, num_tiles, ws,
-                       tile_rec_off, filter_tables);
-  }
   if (num_tiles > 0) {
     daliamd::KernelTimer timer("ResampleKernel", (hipStream_t)stream);
     const int wgs = (num_tiles + daliamd::kTilesPerWg - 1) / daliamd::kTilesPerWg;
@@ -1304,6 +1325,12 @@ daliamdResult_t daliamdResampleRun(daliamdStream_t stream, const daliamdResample
   }
   DALIAMD_HIP_CHECK(hipGetLastError());
   return DALIAMD_SUCCESS;
+}
+
+daliamdResult_t daliamdResampleRun(daliamdStream_t stream, const daliamdResampleDesc *descs_dev, int n,
+                                   const daliamdResamplePlan *plan, void *workspace_dev) {
+  daliamdResult_t rc = daliamdResampleRunTables(stream, descs_dev, n, plan, workspace_dev);
+  return rc != DALIAMD_SUCCESS ? rc : daliamdResampleRunPasses(stream, descs_dev, n, plan, workspace_dev);
 }
 
 }  // extern "C"

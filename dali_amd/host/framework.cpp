@@ -597,6 +597,7 @@ void *DescUploader::Upload(const void *host, size_t bytes, daliamdStream_t strea
   memcpy(s.pinned, host, bytes);
   KCHECK(daliamdMemcpyH2DAsync(s.dev, s.pinned, bytes, stream));
   KCHECK(daliamdEventRecord(s.ev, stream));
+  last_ev_ = s.ev;
   s.used = true;
   return s.dev;
 }

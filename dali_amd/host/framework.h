@@ -367,6 +367,9 @@ class Workspace {
   // Second stream for bulk host->device transfers: a copy issued here for iteration i+1 overlaps the kernels of
   // iteration i on `stream`.  The operator orders the two with an event (record on copy_stream, wait on stream).
   daliamdStream_t copy_stream = nullptr;
+  // A third stream for small set-up launches that depend on host data only (descriptor uploads, the resampling tables):
+  // they run while `stream` is still busy with the iteration's earlier kernels; same ordering rule (event).
+  daliamdStream_t aux_stream = nullptr;
   int ring = 3;                      // iterations that may be in flight (prefetch_queue_depth + 1)
   int batch_size = 0;                // requested (max) batch size of this iteration
   int64_t iteration = 0;
@@ -451,6 +454,9 @@ class DescUploader {
   // kernel-side scratch that lives and dies with the table's slot; Scratch() returns it for the last upload.
   void *Upload(const void *host, size_t bytes, daliamdStream_t stream, int min_slots = 4, size_t scratch_bytes = 0);
   void *Scratch() const { return scratch_; }
+  // the event of the slot the last Upload used (recorded behind its copy): a caller that enqueues more work on the upload's
+  // stream and wants the slot guarded by that too records it again behind that work
+  daliamdEvent_t LastEvent() const { return last_ev_; }
   ~DescUploader();
 
  private:
@@ -461,6 +467,7 @@ class DescUploader {
     bool used = false;
   };
   void *scratch_ = nullptr;
+  daliamdEvent_t last_ev_ = nullptr;
   std::vector<Slot> slots_ = std::vector<Slot>(4);
   int next_ = 0;
 };

@@ -1,6 +1,8 @@
 // Decoded-image cache: see image_cache.h for the reference files this follows.
 #include "image_cache.h"
 
+#include <algorithm>
+
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -318,7 +320,7 @@ uint8_t *StreamCache::Reserve(const std::string &key, size_t bytes) {
 
 void StreamCache::Commit(const std::vector<std::string> &keys, const std::vector<const daliamdJpegInfo *> &infos,
                          const std::vector<const daliamdJpegScan *> &scans, daliamdStream_t stream,
-                         const std::vector<uint8_t> &indexed) {
+                         const std::vector<uint8_t> &indexed, int device_id) {
   if (keys.empty()) return;
   auto fence = std::make_shared<ImageCache::Fence>();
   KCHECK(daliamdEventCreate(&fence->event, 0));
@@ -329,6 +331,7 @@ void StreamCache::Commit(const std::vector<std::string> &keys, const std::vector
     recs[k] = std::make_shared<Record>();
     recs[k]->info = *infos[k];
     recs[k]->scan = *scans[k];
+    if (device_id >= 0) recs[k]->tables = HuffTableStore::Get(device_id, *scans[k]);
   }
   std::lock_guard<std::mutex> g(m_);
   for (size_t k = 0; k < keys.size(); k++) {
@@ -358,6 +361,60 @@ void StreamCache::Abandon(const std::vector<std::string> &keys) {
     }
     pending_.erase(it);
   }
+}
+
+// ------------------------------------------------------------------------------------------ code tables
+bool HuffTableStore::SameTables(const daliamdJpegScan &a, const daliamdJpegScan &b) {
+  return a.blocks_per_mcu == b.blocks_per_mcu && !memcmp(a.comp_of_block, b.comp_of_block, sizeof(a.comp_of_block)) &&
+         !memcmp(a.dc_sel, b.dc_sel, sizeof(a.dc_sel)) && !memcmp(a.ac_sel, b.ac_sel, sizeof(a.ac_sel)) &&
+         !memcmp(a.dc_bits, b.dc_bits, 2 * sizeof(a.dc_bits[0])) && !memcmp(a.ac_bits, b.ac_bits, 2 * sizeof(a.ac_bits[0])) &&
+         !memcmp(a.dc_vals, b.dc_vals, 2 * sizeof(a.dc_vals[0])) && !memcmp(a.ac_vals, b.ac_vals, 2 * sizeof(a.ac_vals[0]));
+}
+
+const uint8_t *HuffTableStore::Get(int device_id, const daliamdJpegScan &scan) {
+  static std::mutex m;
+  static std::vector<Set> sets;
+  if (getenv("DALI_AMD_NO_HOST_TABLES") && atoi(getenv("DALI_AMD_NO_HOST_TABLES"))) return nullptr;
+  std::lock_guard<std::mutex> g(m);
+  Set *hit = nullptr;
+  for (auto &s : sets)
+    if (s.device_id == device_id && SameTables(s.scan, scan)) { hit = &s; break; }
+  if (!hit) {
+    if (sets.size() >= kMaxSets) {
+      // full: the sets seen only once make room (streams with tables of their own), the built ones stay
+      auto it = std::find_if(sets.begin(), sets.end(), [](const Set &s) { return !s.tables; });
+      if (it == sets.end()) return nullptr;
+      sets.erase(it);
+    }
+    sets.push_back(Set{scan, device_id, 1, nullptr});
+    return nullptr;
+  }
+  hit->seen++;
+  if (hit->tables || hit->seen < 2) return hit->tables;
+  // second sighting: build on the host, upload, wait (once per set: a 59 KB copy)
+  daliamdJpegHuffDesc d{};
+  d.blocks_per_mcu = scan.blocks_per_mcu;
+  memcpy(d.comp_of_block, scan.comp_of_block, 10);
+  memcpy(d.dc_sel, scan.dc_sel, 4);
+  memcpy(d.ac_sel, scan.ac_sel, 4);
+  for (int t = 0; t < 2; t++) {
+    memcpy(d.bits[t], scan.dc_bits[t], 16);
+    memcpy(d.bits[2 + t], scan.ac_bits[t], 16);
+    memcpy(d.vals[t], scan.dc_vals[t], 256);
+    memcpy(d.vals[2 + t], scan.ac_vals[t], 256);
+  }
+  size_t bytes = 0;
+  if (daliamdJpegHuffmanTablesBytes(&bytes) != DALIAMD_SUCCESS) return nullptr;
+  std::vector<uint8_t> host(bytes);
+  if (daliamdJpegHuffmanTablesBuild(&d, host.data()) != DALIAMD_SUCCESS) return nullptr;   // (the launch will say why)
+  void *dev = nullptr;
+  if (daliamdMalloc(&dev, bytes) != DALIAMD_SUCCESS) return nullptr;
+  if (daliamdMemcpyH2DAsync(dev, host.data(), bytes, nullptr) != DALIAMD_SUCCESS || daliamdStreamSynchronize(nullptr) != DALIAMD_SUCCESS) {
+    daliamdFree(dev);
+    return nullptr;
+  }
+  hit->tables = static_cast<const uint8_t *>(dev);
+  return hit->tables;
 }
 
 bool DecoderCacheHolds(int device_id, const std::string &key) {

@@ -128,6 +128,7 @@ class StreamCache {
     // the un-stuffed stream + 12 bytes of decoder state per 256-byte slice, written by the decode that made it resident);
     // `ecs` is null then
     const uint8_t *index = nullptr;
+    const uint8_t *tables = nullptr;   // HuffTableStore: the stream's finished code tables, when its set is kept
     daliamdJpegInfo info;
     daliamdJpegScan scan;
   };
@@ -146,7 +147,7 @@ class StreamCache {
   // indexed[k] != 0: the slot of keys[k] holds an index entry (built by the decode enqueued on `stream`), not the raw segment
   void Commit(const std::vector<std::string> &keys, const std::vector<const daliamdJpegInfo *> &infos,
               const std::vector<const daliamdJpegScan *> &scans, daliamdStream_t stream,
-              const std::vector<uint8_t> &indexed = {});
+              const std::vector<uint8_t> &indexed = {}, int device_id = -1);
   void Invalidate(const std::string &key);
   // Reservations that will never be committed (an exception between Reserve and Commit): the keys become reservable
   // again and the space of those that still sit at the end of the blob is handed back.
@@ -170,6 +171,28 @@ class StreamCache {
   std::unordered_map<std::string, Slot> entries_;
   std::unordered_map<std::string, std::pair<uint8_t *, size_t>> pending_;   // slot, bytes it occupies in the blob
   int64_t hits_ = 0, misses_ = 0;
+};
+
+// Finished code tables of the GPU entropy decoder, per device and distinct table set (daliamdJpegHuffDesc.tables, round 5).
+// The tables depend on the DHT contents and the MCU structure of a stream and on nothing else, and nearly every file of a
+// data set carries the same ones (T.81 Annex K): they are built ONCE on the host (daliamdJpegHuffmanTablesBuild: the
+// functions the device runs), uploaded, and every later launch reads them - no table-building workgroups, and for a batch
+// of indexed resident streams no first kernel at all.  A set is built when it is seen the SECOND time (a file with
+// optimised tables of its own is seen once per epoch), at most kMaxSets sets are kept; anything else gets nullptr and has
+// its tables built inside the launch as before.  Process-wide, never freed (a few times 59 KB).
+class HuffTableStore {
+ public:
+  static const uint8_t *Get(int device_id, const daliamdJpegScan &scan);
+
+ private:
+  static constexpr size_t kMaxSets = 32;
+  struct Set {
+    daliamdJpegScan scan;   // (the fields that decide the tables)
+    int device_id;
+    int seen;
+    const uint8_t *tables;  // device; null until built
+  };
+  static bool SameTables(const daliamdJpegScan &a, const daliamdJpegScan &b);
 };
 
 // `skip_cached_images` of the readers: is the sample held by a decoder cache (of either kind) of the device?

@@ -104,6 +104,7 @@ class ImageDecoderMixed : public OperatorBase {
     oc_ = out_type_ == DALI_GRAY ? 1 : 3;
     DALI_ENFORCE(spec.GetInt("dtype") == DALI_UINT8, "decoders.image: only dtype=UINT8 is supported");
     adjust_orientation_ = spec.GetBool("adjust_orientation");
+    device_id_ = (int)spec.GetInt("device_id");
     // Entropy decoding runs on the GPU for every stream the kernel supports.  An EXPLICIT hybrid_huffman_threshold
     // keeps the reference's meaning: streams with fewer pixels than that are Huffman-decoded on the host.
     if (spec.Args().count("hybrid_huffman_threshold")) huffman_threshold_ = spec.GetInt("hybrid_huffman_threshold");
@@ -508,6 +509,8 @@ class ImageDecoderMixed : public OperatorBase {
         auto &d = huff[j];
         d.ecs = erec_[i] ? erec_[i]->ecs : dev_base + ecs_off_[i] + (direct ? (size_t)sc.ecs_offset : 0);
         d.index = erec_[i] ? erec_[i]->index : nullptr;   // a resident stream with its side information: decoded from that
+        // finished code tables of the stream's table set, when the store keeps them (else: built inside the launch)
+        d.tables = erec_[i] ? erec_[i]->tables : HuffTableStore::Get(device_id_, sc);
         d.scratch = static_cast<uint8_t *>(scratch.data()) + scratch_off_[i];
         d.status = status + j;
         d.ecs_len = (int32_t)sc.ecs_length;
@@ -646,7 +649,7 @@ class ImageDecoderMixed : public OperatorBase {
         kscans.push_back(&scans_[i]);
       }
       if (keys.empty()) return;
-      stream_cache_->Commit(keys, kinfos, kscans, ws.stream, std::vector<uint8_t>(keys.size(), indexed ? 1 : 0));
+      stream_cache_->Commit(keys, kinfos, kscans, ws.stream, std::vector<uint8_t>(keys.size(), indexed ? 1 : 0), device_id_);
       auto &pending = reserved_streams.keys;
       for (auto &key : keys) pending.erase(std::remove(pending.begin(), pending.end(), key), pending.end());
     };
@@ -714,6 +717,7 @@ class ImageDecoderMixed : public OperatorBase {
   std::shared_ptr<ImageCache> cache_;
   std::shared_ptr<StreamCache> stream_cache_;
   bool index_streams_ = false;                                     // cache_type="indexed"
+  int device_id_ = 0;
   std::vector<std::shared_ptr<const StreamCache::Record>> erec_;   // resident samples of the batch
   std::vector<uint8_t> hit_, raster_;
   std::vector<int32_t> raster_hw_;
@@ -1321,9 +1325,17 @@ static void LaunchResample(Workspace &ws, DescUploader &up, std::vector<daliamdR
     NoteLaunch(ws, std::string("host_") + what);
     return;
   }
+  // The descriptor upload and the table launch need host data only: on the side stream they run while ws.stream is still
+  // with the decoder's kernels of this iteration, and the passes wait for them through the slot's event.
+  daliamdStream_t side = ws.aux_stream ? ws.aux_stream : ws.stream;
   auto *dev = static_cast<const daliamdResampleDesc *>(
-      up.Upload(descs.data(), descs.size() * sizeof(descs[0]), ws.stream, ws.ring + 1, plan.workspace_bytes));
-  KCHECK(daliamdResampleRun(ws.stream, dev, n, &plan, up.Scratch()));
+      up.Upload(descs.data(), descs.size() * sizeof(descs[0]), side, ws.ring + 1, plan.workspace_bytes));
+  KCHECK(daliamdResampleRunTables(side, dev, n, &plan, up.Scratch()));
+  if (side != ws.stream) {
+    KCHECK(daliamdEventRecord(up.LastEvent(), side));
+    KCHECK(daliamdStreamWaitEvent(ws.stream, up.LastEvent()));
+  }
+  KCHECK(daliamdResampleRunPasses(ws.stream, dev, n, &plan, up.Scratch()));
   NoteLaunch(ws, what);
 }
 

@@ -56,6 +56,7 @@ Pipeline::~Pipeline() {
   for (auto e : slot_events_) if (e) daliamdEventDestroy(e);
   for (auto e : release_events_) if (e) daliamdEventDestroy(e);
   if (copy_stream_) daliamdStreamDestroy(copy_stream_);
+  if (aux_stream_) daliamdStreamDestroy(aux_stream_);
   for (auto st : streams_) daliamdStreamDestroy(st);
 }
 
@@ -152,6 +153,10 @@ void Pipeline::Build(const std::vector<std::pair<std::string, std::string>> &out
     // The copy stream carries the descriptor tables (and the JPEG bytes) of the NEXT iteration: highest priority = a
     // hardware queue it does not share with any compute stream, or the upload waits behind a 0.3 ms kernel
     KCHECK(daliamdStreamCreateWithPriority(&copy_stream_, 1, -1));
+    // ... and one for the small set-up launches of an iteration that need host data only (DALI_AMD_AUX_STREAM=0: none,
+    // they stay on the compute stream)
+    if (!(getenv("DALI_AMD_AUX_STREAM") && atoi(getenv("DALI_AMD_AUX_STREAM")) == 0))
+      KCHECK(daliamdStreamCreateWithPriority(&aux_stream_, 1, -1));
   }
   for (auto &o : outputs) {
     StorageDevice d = o.second == "gpu" ? StorageDevice::GPU : StorageDevice::CPU;
@@ -322,6 +327,7 @@ void Pipeline::RunStage(bool device_stage, int64_t it, int slot, Iteration &res)
       ws.thread_pool = device_stage ? thread_pool_.get() : cpu_thread_pool_.get();
       ws.stream = streams_.empty() ? nullptr : streams_[it % (int64_t)streams_.size()];
       ws.copy_stream = copy_stream_;
+      ws.aux_stream = aux_stream_;
       ws.ring = ring_;
       ws.batch_size = params_.batch_size;
       ws.iteration = it;

@@ -145,6 +145,7 @@ class Pipeline {
   // decoder's relaxation rounds) overlaps the start of the next batch's
   static constexpr int kComputeStreams = 3;
   std::vector<daliamdStream_t> streams_;
+  daliamdStream_t aux_stream_ = nullptr;   // small set-up launches that depend on host data only (Workspace::aux_stream)
   daliamdStream_t copy_stream_ = nullptr;  // bulk H2D staging (highest stream priority), overlaps the compute streams
   int ring_ = 3;
 

@@ -220,12 +220,22 @@ typedef struct {
    * intervals take neither (Setup refuses). */
   const uint8_t *index;
   uint8_t *index_out;
+  /* Finished code tables in device memory (round 5): daliamdJpegHuffmanTablesBytes() bytes as daliamdJpegHuffmanTablesBuild makes
+   * them on the host from this descriptor's bits / vals / comp_of_block / dc_sel / ac_sel / blocks_per_mcu, 16-byte aligned.
+   * They depend on nothing else, and a data set holds a handful of distinct sets (most files carry the tables of T.81 Annex K):
+   * a caller that keeps them per set spares every launch the table-building workgroups - and an all-indexed launch its whole
+   * first kernel.  NULL: built in the launch, once per distinct set of the table, as before. */
+  const uint8_t *tables;
 } daliamdJpegHuffDesc;
 
 /* kinds of streams in a table, OR-ed into *block_kernels by daliamdJpegHuffmanSetupColor next to bits 0 / 1 */
 #define DALIAMD_JPEG_HUFFMAN_PARSED 4       /* streams that are un-stuffed and synchronised in this launch */
 #define DALIAMD_JPEG_HUFFMAN_INDEXED 8      /* streams that bring their index                              */
 #define DALIAMD_JPEG_HUFFMAN_BUILD_INDEX 16 /* streams whose index entry is built behind the decode        */
+#define DALIAMD_JPEG_HUFFMAN_BUILD_TABLES 32 /* streams that do not bring their code tables                 */
+DALIAMD_API daliamdResult_t daliamdJpegHuffmanTablesBytes(size_t *bytes);
+/* host only: out_host receives daliamdJpegHuffmanTablesBytes() bytes */
+DALIAMD_API daliamdResult_t daliamdJpegHuffmanTablesBuild(const daliamdJpegHuffDesc *desc, void *out_host);
 DALIAMD_API daliamdResult_t daliamdJpegHuffmanIndexBytes(int ecs_len, size_t *bytes);
 
 /* 1 when the stream's geometry (blocks_per_mcu, comp_of_block, h/v_of_block, h/v_samp, mcus_x, rect) allows the fused
@@ -417,6 +427,13 @@ DALIAMD_API daliamdResult_t daliamdResampleSetup(const daliamdResampleArgs *args
                                                 daliamdResamplePlan *plan);
 DALIAMD_API daliamdResult_t daliamdResampleRun(daliamdStream_t stream, const daliamdResampleDesc *descs_dev, int n,
                                               const daliamdResamplePlan *plan, void *workspace_dev);
+/* daliamdResampleRun = RunTables + RunPasses on one stream.  RunTables (per-sample coefficient tables and per-tile records into
+ * the workspace) reads nothing but the descriptor table: it may run on a side stream while `stream` still executes the kernels
+ * that produce the source images; the caller then orders RunPasses behind it with an event. */
+DALIAMD_API daliamdResult_t daliamdResampleRunTables(daliamdStream_t stream, const daliamdResampleDesc *descs_dev, int n,
+                                                     const daliamdResamplePlan *plan, void *workspace_dev);
+DALIAMD_API daliamdResult_t daliamdResampleRunPasses(daliamdStream_t stream, const daliamdResampleDesc *descs_dev, int n,
+                                                     const daliamdResamplePlan *plan, void *workspace_dev);
 
 /* ----------------------------------------------------------------------------------------------
  * Stand-alone CropMirrorNormalize: u8 HWC -> {fp16, fp32, u8, i8} HWC/CHW with crop, horizontal

@@ -220,3 +220,49 @@ print("FMA_BLUR_OK", ndiff)
     res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DALI_AMD_BLUR_FMA="1"), capture_output=True, text=True,
                          timeout=300)
     assert res.returncode == 0 and "FMA_BLUR_OK" in res.stdout, res.stderr[-2000:]
+
+
+def test_blur_on_the_matrix_cores_is_the_fma_chain_and_within_the_reference_tolerance(tmp_path):
+    """DALI_AMD_BLUR_MFMA=1 (read once per process): the taps as a banded Toeplitz product on v_mfma_f32_16x16x4_f32.  That
+    instruction is an fmaf chain in ascending k, and a zero of the band adds nothing, so the result must be - bit for bit -
+    the fused-multiply-add variant of the VALU kernel (DALI_AMD_BLUR_FMA=1), which in turn is within the 1 LSB the reference
+    allows between its own backends (operator_1/test_gaussian_blur.py:134,164: max_allowed_error = 1) of the oracle's
+    separately rounded CPU order; stated tolerance: <= 1 LSB on < 0.1 % of the elements."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+from dali_amd import backend as B
+from oracle import oracle as O
+from tests.util import synth_image
+rng = np.random.default_rng(31)
+shapes = [(200, 300), (97, 131), (512, 512), (46, 32), (47, 33), (5, 9), (130, 257), (64, 31), (1, 1), (1000, 37)]
+imgs = [synth_image(rng, h, w) for h, w in shapes] + [rng.integers(0, 256, (128, 160, 3), dtype=np.uint8)]
+res, ndiff, total = {}, 0, 0
+for sigma, window in [(3.0, 0), (1.0, 0), (0.0, 5), (0.8, 11), (3.3, 21)]:
+    outs = B.gaussian_blur_batch([torch.from_numpy(im).cuda() for im in imgs], sigma=sigma, window_size=window)
+    torch.cuda.synchronize()
+    win = O.gaussian_window(sigma, window)
+    for i, (im, o) in enumerate(zip(imgs, outs)):
+        got = o.cpu().numpy()
+        d = np.abs(got.astype(int) - O.gaussian_blur_u8(im, win))
+        assert d.max() <= 1, (sigma, window, im.shape, d.max())
+        ndiff += int((d > 0).sum()); total += d.size
+        res["%%s_%%s_%%d" %% (sigma, window, i)] = got
+assert ndiff < 1e-3 * total, (ndiff, total)
+np.savez(sys.argv[1], **res)
+print("BLUR_OK", ndiff, total)
+''' % root
+    out = {}
+    for name, env in (("mfma", dict(DALI_AMD_BLUR_MFMA="1")), ("fma", dict(DALI_AMD_BLUR_MFMA="0", DALI_AMD_BLUR_FMA="1"))):
+        path = str(tmp_path / f"{name}.npz")
+        res = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0 and "BLUR_OK" in res.stdout, res.stderr[-2000:]
+        out[name] = np.load(path)
+    assert sorted(out["mfma"].files) == sorted(out["fma"].files)
+    bad = [k for k in out["mfma"].files if not np.array_equal(out["mfma"][k], out["fma"][k])]
+    assert not bad, bad

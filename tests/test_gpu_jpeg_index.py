@@ -91,3 +91,49 @@ def test_setup_refuses_what_has_no_index():
     a, b, c, k = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
     rc = capi.kernels().daliamdJpegHuffmanSetupColor(table.ctypes.data_as(C.c_void_p), 1, C.byref(a), C.byref(b), C.byref(c), C.byref(k))
     assert rc != 0 and b"restart" in capi.kernels().daliamdGetLastErrorMessage()
+
+
+def test_host_built_code_tables_are_the_device_built_ones():
+    """daliamdJpegHuffDesc.tables: the code tables of a stream built on the host (daliamdJpegHuffmanTablesBuild) are byte for
+    byte what PrepareKernel's table workgroups leave in the scratch, and a decode that brings them - the launch then builds
+    nothing - gives the same pixels; with an index on top the launch starts at IndexedSyncKernel."""
+    import ctypes as C
+    import bench
+    from dali_amd import _capi as capi, backend as B
+    rng = np.random.default_rng(24)
+    enc = [encode_jpeg(synth_image(rng, 200, 300), 85), encode_jpeg(synth_image(rng, 120, 160), 90, optimize=True),
+           encode_jpeg(synth_image(rng, 64, 64, 1), 70), encode_jpeg(synth_image(rng, 96, 96), 60, subsampling="4:4:4", optimize=True),
+           encode_jpeg(synth_image(rng, 200, 300), 85, subsampling="4:2:0", restart_marker_blocks=5)]
+    plain, plan = B.decode_jpeg_batch(enc, device="cuda")
+    torch.cuda.synchronize()
+    lib = capi.kernels()
+    nb = C.c_size_t(0)
+    capi.check(lib.daliamdJpegHuffmanTablesBytes(C.byref(nb)))
+    table = plan.huffman_descs(None, planes_dev=torch.empty(max(plan.plane_bytes, 1), dtype=torch.uint8, device="cuda"))[0]
+    scratch = plan._huff_ws["scratch"].cpu().numpy()
+    for j in range(len(enc)):
+        if table["table_owner"][j] != j:
+            continue        # (built in its owner's scratch)
+        host = np.zeros(nb.value, np.uint8)
+        capi.check(lib.daliamdJpegHuffmanTablesBuild(C.c_void_p(table.ctypes.data + j * table.dtype.itemsize), host.ctypes.data_as(C.c_void_p)))
+        ecs_len, head = int(table["ecs_len"][j]), int(table["ecs"][j]) % 16
+        off = int(plan._scratch_off[j]) + 16 + 16 * int(table["num_tiles"][j]) + (ecs_len + 256 + 15) // 16 * 16
+        assert int(table["num_tiles"][j]) == max(1, -(-(head + ecs_len) // 8192))
+        dev = scratch[off:off + nb.value]
+        assert np.array_equal(dev, host), f"stream {j}: {np.nonzero(dev != host)[0][:8].tolist()}"
+    bench.kernel_timing(True)
+    brought, _ = B.decode_jpeg_batch(enc, device="cuda", host_tables=True)
+    torch.cuda.synchronize()
+    _, p1 = B.decode_jpeg_batch(enc[:4], device="cuda", host_tables=True, index="build")
+    torch.cuda.synchronize()
+    bench.kernel_timing()
+    again, _ = B.decode_jpeg_batch(enc[:4], device="cuda", host_tables=True, index="use", index_from=p1)
+    torch.cuda.synchronize()
+    bench.kernel_timing(False)
+    launched = bench.kernel_timing()
+    assert "IndexedSyncKernel" in launched and "PrepareKernel" not in launched and "SyncKernel" not in launched, launched
+    for i, e in enumerate(enc):
+        ref = O.jpeg_decode_rgb(e)
+        assert np.array_equal(plain[i].cpu().numpy(), ref) and np.array_equal(brought[i].cpu().numpy(), ref), i
+        if i < 4:
+            assert np.array_equal(again[i].cpu().numpy(), ref), i
