@@ -761,6 +761,10 @@ def bench_heavy_aug(args, device, steps=None, cpu_seconds=8.0):
            "scaling": "weak", "vs_baseline": None, "dtype": "u8 in/out, f32 arithmetic", "data": "synthetic",
            "config": {"workload": "configs[2]: 128 x 512x512x3 u8 resident in HBM (decoded-image cache), through "
                                   "dali_amd.Pipeline", "kernels": kernels, "prefetch_queue_depth": depth,
+                      "blur": ("matrix cores (v_mfma_f32_16x16x4_f32, banded Toeplitz): the fmaf chain over the taps, <= 1 LSB on "
+                               "< 0.1 % of the elements against the CPU order of roundings (tests/test_gpu_augment.py); "
+                               "DALI_AMD_BLUR_MFMA=0: the VALU kernel, bit-exact"
+                               if "GaussianBlurMfmaKernel" in per else "VALU kernel, bit-exact against the oracle"),
                       "kernels_ms_per_step": kern_ms, "images_per_s_kernels_only": n / (kern_ms * 1e-3),
                       "kernels_ms_note": "sum of the per-launch durations with ONE batch in flight (cost); "
                                          "roofline.per_kernel[*].in_schedule_ms = durations inside the overlapped timed region",

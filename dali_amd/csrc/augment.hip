@@ -286,16 +286,18 @@ __global__ __launch_bounds__(kWarpThreads) void WarpAffineKernel(const daliamdWa
 #define DALIAMD_BLUR_THREADS 256
 #endif
 #ifndef DALIAMD_BLUR_MFMA_DEFAULT
-#define DALIAMD_BLUR_MFMA_DEFAULT 0
+#define DALIAMD_BLUR_MFMA_DEFAULT 1   // measured on MI355X (configs[2]): 0.318 ms per batch against 0.469 for the VALU kernel
 #endif
 constexpr int kBlurThreads = DALIAMD_BLUR_THREADS;
 constexpr int kBlurMaxLds = 60 * 1024;
 constexpr int kBlurMfmaFlag = 1 << 30;   // in the `lds_bytes` Setup hands to Run: the table is tiled for GaussianBlurMfmaKernel
+constexpr int kBlurMfmaShortFlag = 1 << 29;   // ... and every window of the table has at most 9 taps (6 steps instead of 9)
 // DALI_AMD_BLUR_MFMA: 1 = the matrix-core variant where it applies (<= 1 LSB from the CPU order of roundings), 0 = the VALU
 // kernel (bit-exact against it).  Default: see the measurement in DESIGN.md.
+// (read at every Setup: a process can run both - the tests that hold the blur to the oracle bit for bit switch it off)
 inline bool BlurMfmaEnabled() {
-  static const bool on = [] { const char *e = getenv("DALI_AMD_BLUR_MFMA"); return e ? atoi(e) != 0 : DALIAMD_BLUR_MFMA_DEFAULT != 0; }();
-  return on;
+  const char *e = getenv("DALI_AMD_BLUR_MFMA");
+  return e ? atoi(e) != 0 : DALIAMD_BLUR_MFMA_DEFAULT != 0;
 }
 // LDS pitches of the blur's two tiles (shared by the kernel and Setup).  DALIAMD_BLUR_TPAD: floats added to a row of the
 // fp32 intermediate (even); DALIAMD_BLUR_SMOD: when non-zero the staged source pitch is raised to SMOD modulo 64 bytes.
@@ -655,24 +657,31 @@ __global__ __launch_bounds__(kBlurThreads) void GaussianBlurKernel(const daliamd
 // The result is the fused-multiply-add chain over the taps in order, i.e. the bits of GaussianBlurKernel<FMA = true>
 // (DALI_AMD_BLUR_FMA=1), which is within 1 LSB of the separately rounded CPU order - the tolerance the reference allows its
 // own GPU convolution (a GEMM as well, dali/kernels/imgproc/convolution/convolution_gpu.h:88-240) against its CPU one
-// (operator_1/test_gaussian_blur.py:134,164: max_allowed_error = 1).  Three channels, windows up to 21 taps.
+// (operator_1/test_gaussian_blur.py:134,164: max_allowed_error = 1).  Three channels, windows up to 19 taps (sigma <= 3 with the default window).
+// Round 5, second form: a workgroup walks a vertical STRIP of tiles.  The first measurement of one-tile workgroups (32 x 46
+// pixels each) gave 0.44 ms for 0.47 of the VALU kernel: 36 matrix instructions per wave sat behind a descriptor search, 18
+// weight loads and 16 dependent global-load -> LDS-store round trips of the staging loop, repeated 24 576 times per batch.
+// A strip keeps the intermediate rows in a RING (80 rows): the 18 halo rows two vertically adjacent tiles share are
+// computed once, the prologue is paid once per 192 output rows, and the source rows of the next batch of rows are
+// requested (into registers) before this batch's passes start.
 constexpr int kBlurMfmaTW = 32;            // output pixels per tile row
-constexpr int kBlurMfmaInRows = 64;        // staged rows = intermediate rows (4 row tiles of 16)
-constexpr int kBlurMfmaMaxWindow = 21;     // 16 + 21 - 1 = 36 inputs = 9 steps of 4
+constexpr int kBlurMfmaTileRows = 48;      // output rows per tile = three 16-row chunks of the intermediate per step
+constexpr int kBlurMfmaStripTiles = 4;     // tiles per workgroup
+constexpr int kBlurMfmaRing = 80;          // intermediate rows kept (5 chunks): 48 + 18 halo rows, rounded up to chunks
+constexpr int kBlurMfmaBatchRows = 48;     // source rows staged at a time
+constexpr int kBlurMfmaMaxWindow = 19;     // 48 + 18 <= 80 - 14: the ring holds a tile's rows (16 + 19 - 1 = 34 inputs = 9 steps)
 constexpr int kBlurMfmaSteps = 9;
 constexpr int kBlurMfmaTmpStride = 112;    // floats: 96 + 16, so that the two rows of a 32-lane LDS group sit on disjoint banks
-__host__ __device__ inline int BlurMfmaTileH(int size_y) { return kBlurMfmaInRows - (size_y - 1); }
-__host__ __device__ inline int BlurMfmaSrcPitch(int size_x) {   // bytes: (TW + K - 1 + 2 overrun pixels) * 3 + alignment lead
-  int p = (kBlurMfmaTW + size_x - 1 + 2) * 3 + 3;
-  p = (p + 15) & ~15;
-  return p + 8;    // = 8 modulo 16: sixteen rows start on sixteen different even banks
-}
-__host__ __device__ inline int BlurMfmaLdsBytes(int size_x) {
-  return kBlurMfmaInRows * kBlurMfmaTmpStride * 4 + kBlurMfmaInRows * BlurMfmaSrcPitch(size_x) + 16;
+constexpr int kBlurMfmaRowDwords = 40;     // dwords of a staged row (32 + 18 pixels x 3 bytes + 3 bytes of lead = 153 bytes)
+__host__ __device__ constexpr int BlurMfmaSrcPitch() { return kBlurMfmaRowDwords * 4 + 8; }   // = 8 modulo 16
+__host__ __device__ inline int BlurMfmaLdsBytes() {
+  return kBlurMfmaRing * kBlurMfmaTmpStride * 4 + kBlurMfmaBatchRows * BlurMfmaSrcPitch() + 16;
 }
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-template <bool PW>
+// STEPS: matrix instructions per 16 x 16 outputs = ceil((16 + window - 1) / 4) for the largest window of the table (9 for 19
+// taps, 6 for up to 9) - a compile-time count: the steps are straight-line code, their operand loads issued together.
+template <bool PW, int STEPS>
 __global__ __launch_bounds__(kBlurThreads) void GaussianBlurMfmaKernel(const daliamdGaussianBlurDesc *__restrict__ descs,
                                                                        int ndesc, int total_wg,
                                                                        const daliamdPointwiseDesc *__restrict__ pointwise) {
@@ -681,106 +690,170 @@ __global__ __launch_bounds__(kBlurThreads) void GaussianBlurMfmaKernel(const dal
   if (wg < 0) return;
   const int di = FindDesc(descs, ndesc, wg);
   const daliamdGaussianBlurDesc &d = descs[di];
-  constexpr int C = 3, TW = kBlurMfmaTW, IN_ROWS = kBlurMfmaInRows, TS = kBlurMfmaTmpStride;
-  const int TH = d.tile_h;
+  constexpr int C = 3, TW = kBlurMfmaTW, TR = kBlurMfmaTileRows, RING = kBlurMfmaRing, TS = kBlurMfmaTmpStride;
+  constexpr int BR = kBlurMfmaBatchRows, RDW = kBlurMfmaRowDwords;
+  const int SH = d.tile_h;                     // strip height in output rows
   const int Kx = d.size_x, Ky = d.size_y;
   const int rx = (Kx - 1) / 2, ry = (Ky - 1) / 2;
   const int t = wg - d.wg_start;
-  const int ty = t / d.tiles_x, tx = t - ty * d.tiles_x;
-  const int ox0 = tx * TW, oy0 = ty * TH;
-  const int tw = min(TW, d.w - ox0), th = min(TH, d.h - oy0);
+  const int sy = t / d.tiles_x, tx = t - sy * d.tiles_x;
+  const int ox0 = tx * TW, oy0 = sy * SH;
+  const int tw = min(TW, d.w - ox0), sh = min(SH, d.h - oy0);
+  const int ntiles = (sh + TR - 1) / TR;
   const int in_cols = TW + 2 * rx;
-  const int src_pitch = BlurMfmaSrcPitch(Kx);
-  float *tmp = blur_lds;                                                   // [IN_ROWS][TS]
-  uint8_t *src = reinterpret_cast<uint8_t *>(tmp + IN_ROWS * TS);          // [IN_ROWS][src_pitch]; later the rounded tile
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // ---- stage the halo-extended source tile (always the full tile: a partial one computes outputs nobody stores) ----
-  const bool interior_x = ox0 - rx >= 0 && ox0 + TW + rx <= d.w;
+  constexpr int src_pitch = BlurMfmaSrcPitch();
+  float *tmp = blur_lds;                                                // ring: [RING][TS]
+  uint8_t *src = reinterpret_cast<uint8_t *>(tmp + RING * TS);          // [BR][src_pitch]; between the passes: the rounded tile
+  // (the wave index as a scalar: everything derived from an item's number - tile, channel, ring row - is scalar arithmetic)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // (aligned dwords of a row's window: its last one may reach 3 bytes past the window - two more pixels of the row keep
+  // that inside the row, and so inside the image's buffer on its last row)
+  const bool interior_x = ox0 - rx >= 0 && ox0 + TW + rx + 2 <= d.w;
   const bool same_lead = (d.in_pitch & 3) == 0;
-  for (int r = tid / 64; r < IN_ROWS; r += kBlurThreads / 64) {
-    const uint8_t *row = d.in + (size_t)Reflect101(oy0 - ry + r, d.h) * d.in_pitch;
-    uint8_t *dst = src + r * src_pitch;
-    if (interior_x) {
-      const uint8_t *g = row + (size_t)(ox0 - rx) * C;
-      const int lead = (int)(reinterpret_cast<uintptr_t>(g) & 3);
-      const uint32_t *gw = reinterpret_cast<const uint32_t *>(g - lead);
-      uint32_t *dw = reinterpret_cast<uint32_t *>(dst);
-      const int ndw = (lead + in_cols * C + 3) >> 2;
-      for (int j = lane; j < ndw; j += 64) dw[j] = gw[j];
-    } else {
-      for (int cx = lane; cx < in_cols; cx += 64) {
-        const uint8_t *p = row + (size_t)Reflect101(ox0 - rx + cx, d.w) * C;
-        for (int c = 0; c < C; c++) dst[cx * C + c] = p[c];
-      }
-    }
-  }
   // the band of the two Toeplitz matrices as this lane holds it: A[m = lane & 15][k = 4 s + (lane >> 4)] = w[k - m]
   const int m = lane & 15, kq = lane >> 4;
-  float ax[kBlurMfmaSteps], ay[kBlurMfmaSteps];
+  float ax[STEPS], ay[STEPS];
 #pragma unroll
-  for (int s4 = 0; s4 < kBlurMfmaSteps; s4++) {
+  for (int s4 = 0; s4 < STEPS; s4++) {
     const int idx = 4 * s4 + kq - m;
     ax[s4] = idx >= 0 && idx < Kx ? d.window_x[idx] : 0.0f;
     ay[s4] = idx >= 0 && idx < Ky ? d.window_y[idx] : 0.0f;
   }
-  const int steps_x = (16 + Kx - 1 + 3) >> 2, steps_y = (16 + Ky - 1 + 3) >> 2;
-  const int lead0 = interior_x ? (int)((reinterpret_cast<uintptr_t>(d.in) + (size_t)(ox0 - rx) * C) & 3) : 0;
-  __syncthreads();
-  // ---- W pass: items = (row tile, pixel tile); lane (n = lane & 15: staged row, kq: which of the 4 inputs of a step) ----
-  for (int item = wave; item < (IN_ROWS / 16) * (TW / 16); item += kBlurThreads / 64) {
-    const int rt = item / (TW / 16), pt = item - rt * (TW / 16);
-    const int r = 16 * rt + m;   // (the B operand's line index is lane & 15 as well)
-    int lead = lead0;
-    if (interior_x && !same_lead) {
-      const uint8_t *rowp = d.in + (size_t)Reflect101(oy0 - ry + r, d.h) * d.in_pitch + (size_t)(ox0 - rx) * C;
-      lead = (int)(reinterpret_cast<uintptr_t>(rowp) & 3);
-    }
-    const uint8_t *bp = src + r * src_pitch + lead + (16 * pt + kq) * C;
-    floatx4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+  // (the weights have arrived before the first source rows are requested: no later wait for them can hold up those loads)
+  __builtin_amdgcn_s_waitcnt(0);
+  using GDwords = const uint32_t __attribute__((address_space(1)));
+  // source row of intermediate row q of the strip (q = 0: image row oy0 - ry) and the alignment lead of its window
+  auto row_window = [&](int q, int *lead) -> const uint8_t * {
+    const uint8_t *g = d.in + (size_t)Reflect101(oy0 - ry + q, d.h) * d.in_pitch + (size_t)(ox0 - rx) * C;
+    *lead = interior_x ? (int)(reinterpret_cast<uintptr_t>(g) & 3) : 0;
+    return g;
+  };
+  // ---- batches of source rows: 2 chunks first, then 3 per tile; the NEXT batch's dwords wait in registers.  Thread ->
+  // (row tid / 16 of a 16-row chunk, dwords tid % 16 + 16 i): the row's address is computed once per chunk ----
+  constexpr int kColIters = (RDW + 15) / 16;           // 3
+  uint32_t pre[(BR / 16) * kColIters];
+  const int srow = tid >> 4, scol = tid & 15;
+  auto fetch = [&](int q0, int nrows) {      // interior tiles: aligned dwords of rows q0 .. q0 + nrows - 1 into registers
+    if (!interior_x) return;
 #pragma unroll
-    for (int s4 = 0; s4 < kBlurMfmaSteps; s4++) {
-      if (s4 < steps_x) {   // (uniform)
-        const float b0 = (float)bp[12 * s4], b1 = (float)bp[12 * s4 + 1], b2 = (float)bp[12 * s4 + 2];
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[s4], b0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[s4], b1, acc1, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[s4], b2, acc2, 0, 0, 0);
+    for (int cb = 0; cb < BR / 16; cb++) {
+      if (16 * cb >= nrows) break;           // (uniform)
+      int lead;
+      GDwords *g = (GDwords *)(row_window(q0 + 16 * cb + srow, &lead) - lead);
+      const int ndw = (lead + in_cols * C + 3) >> 2;
+#pragma unroll
+      for (int i = 0; i < kColIters; i++) pre[cb * kColIters + i] = scol + 16 * i < ndw ? g[scol + 16 * i] : 0u;
+    }
+  };
+  auto stage = [&](int q0, int nrows) {      // ... and into the LDS rows 0 .. nrows - 1 (edge tiles: byte-wise, reflected)
+    if (interior_x) {
+#pragma unroll
+      for (int cb = 0; cb < BR / 16; cb++) {
+        if (16 * cb >= nrows) break;
+        uint32_t *row = reinterpret_cast<uint32_t *>(src + (16 * cb + srow) * src_pitch);
+#pragma unroll
+        for (int i = 0; i < kColIters; i++)
+          if (scol + 16 * i < RDW) row[scol + 16 * i] = pre[cb * kColIters + i];
+      }
+    } else {
+      for (int it = tid; it < nrows * in_cols; it += kBlurThreads) {
+        const int row = it / in_cols, cx = it - row * in_cols;
+        int lead;
+        const uint8_t *g = row_window(q0 + row, &lead);
+        const uint8_t *p = g + ((ptrdiff_t)Reflect101(ox0 - rx + cx, d.w) - (ox0 - rx)) * C;
+        uint8_t *dst = src + row * src_pitch + cx * C;
+        dst[0] = p[0]; dst[1] = p[1]; dst[2] = p[2];
       }
     }
-    // result: row 16 rt + (lane & 15), pixels 16 pt + 4 kq + i (i = 0..3), three channels: 12 consecutive floats
-    float4 *o = reinterpret_cast<float4 *>(tmp + r * TS + (16 * pt + 4 * kq) * C);
-    o[0] = make_float4(acc0[0], acc1[0], acc2[0], acc0[1]);
-    o[1] = make_float4(acc1[1], acc2[1], acc0[2], acc1[2]);
-    o[2] = make_float4(acc2[2], acc0[3], acc1[3], acc2[3]);
+  };
+  // (barriers that order LDS accesses only: __syncthreads() would also wait for the next batch's loads and this tile's stores)
+  auto lds_barrier = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+  };
+  int filled = 0;                            // intermediate rows computed so far (multiple of 16)
+  int next_rows = 32;                        // rows of the batch in the registers
+  fetch(0, next_rows);
+  // the fused pointwise operator's arguments: one copy in LDS for the workgroup (a private copy - its arrays are indexed in
+  // loops - lives in scratch memory: the write-out with it cost 0.31 ms per batch, three times the blur's own passes)
+  __shared__ daliamdPointwiseDesc pw_lds;
+  if (PW) {
+    const uint32_t *from = reinterpret_cast<const uint32_t *>(pointwise + di);
+    uint32_t *to = reinterpret_cast<uint32_t *>(&pw_lds);
+    for (int i = tid; i < (int)(sizeof(daliamdPointwiseDesc) / 4); i += kBlurThreads) to[i] = from[i];
   }
-  __syncthreads();
-  // ---- H pass: items = (output row tile, 16 floats of the row); the rounded bytes go where the staged source was ----
-  uint8_t *outb = src;
-  constexpr int opitch = TW * C;   // 96
-  const int row_tiles = (TH + 15) >> 4;
-  for (int item = wave; item < row_tiles * (TW * C / 16); item += kBlurThreads / 64) {
-    const int yt = item / (TW * C / 16), ft = item - yt * (TW * C / 16);
-    const float *bp = tmp + 16 * ft + m;
-    floatx4 acc = {0, 0, 0, 0};
+  const int total_rows = (TR * ntiles + 2 * ry + 15) & ~15;
+  const int lead_same = interior_x ? (int)((reinterpret_cast<uintptr_t>(d.in) + (size_t)(ox0 - rx) * C) & 3) : 0;
+  for (int tile = 0; tile < ntiles; tile++) {
+    const int need = (TR * (tile + 1) + 2 * ry + 15) & ~15;   // intermediate rows the tile's H pass reads: 80, 128, 176, 224
+    while (filled < need) {
+      const int q0 = filled, nrows = next_rows;
+      stage(q0, nrows);
+      filled += nrows;
+      next_rows = BR;
+      if (filled < total_rows) fetch(filled, next_rows);   // in flight during the passes below
+      lds_barrier();
+      // ---- W pass: items = (chunk of 16 rows, 16 pixels, channel).  The DATA is the A operand (lane: row lane & 15, input
+      // 4 s + (lane >> 4): one byte load + conversion), the band the B operand (w[k - n], n = lane & 15 the output pixel):
+      // the same products in the same order as with the roles swapped, but a lane then owns 4 ROWS of one pixel and the 32
+      // lanes of an LDS store group write 16 pixels x 2 rows (2-way conflicts; 16 rows x 2 pixel groups hit 4 banks) ----
+      const int items = (nrows >> 4) * (TW / 16) * C;
+      const int qring = q0 % RING;           // (a batch never wraps: chunks are aligned and RING is a multiple of 16... per chunk)
+      for (int item = wave; item < items; item += kBlurThreads / 64) {
+        const int c = item % C, pt = (item / C) % (TW / 16), cb = item / (C * (TW / 16));
+        const int r = 16 * cb + m;
+        int lead = lead_same;
+        if (interior_x && !same_lead) (void)row_window(q0 + r, &lead);
+        const uint8_t *ap = src + r * src_pitch + lead + (16 * pt + kq) * C + c;
+        floatx4 acc = {0, 0, 0, 0};
+        uint32_t a[STEPS];
 #pragma unroll
-    for (int s4 = 0; s4 < kBlurMfmaSteps; s4++) {
-      if (s4 < steps_y) {
-        // (rows behind the last staged one only meet zero weights - but must be finite: clamped)
-        const int row = min(16 * yt + 4 * s4 + kq, IN_ROWS - 1);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ay[s4], bp[row * TS], acc, 0, 0, 0);
+        for (int s4 = 0; s4 < STEPS; s4++) a[s4] = ap[12 * s4];
+#pragma unroll
+        for (int s4 = 0; s4 < STEPS; s4++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32((float)a[s4], ax[s4], acc, 0, 0, 0);
+        // result: intermediate rows q0 + 16 cb + 4 kq + i (i = 0..3), pixel 16 pt + (lane & 15), channel c
+        int ring_row = qring + 16 * cb;
+        ring_row -= ring_row >= RING ? RING : 0;
+        float *o = tmp + (ring_row + 4 * kq) * TS + (16 * pt + m) * C + c;
+        o[0] = acc[0]; o[TS] = acc[1]; o[2 * TS] = acc[2]; o[3 * TS] = acc[3];
       }
+      lds_barrier();
     }
+    // ---- H pass of the tile: items = (16 output rows, 16 floats of the row); rounded bytes go where the source rows were.
+    // The tile's 68 input rows sit in the ring from row (48 tile) % 80 on and wrap at most once, at a step that is the same
+    // for every lane: two base pointers, a uniform choice per step, immediate offsets ----
+    uint8_t *outb = src;
+    constexpr int opitch = TW * C;   // 96
+    const int qt = (TR * tile) % RING;        // the tile's first intermediate row in the ring
+    for (int item = wave; item < (TR / 16) * (TW * C / 16); item += kBlurThreads / 64) {
+      const int yt = item / (TW * C / 16), ft = item - yt * (TW * C / 16);
+      int base = qt + 16 * yt;
+      base -= base >= RING ? RING : 0;
+      const int wrap_step = (RING - base) >> 2;        // first step whose rows lie behind the ring's end (uniform)
+      const float *p_lo = tmp + (base + kq) * TS + 16 * ft + m, *p_hi = p_lo - RING * TS;
+      floatx4 acc = {0, 0, 0, 0};
+      float b[STEPS];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int y = 16 * yt + 4 * kq + i;
-      if (y < TH) outb[y * opitch + 16 * ft + m] = (uint8_t)SatU8(acc[i]);
+      for (int s4 = 0; s4 < STEPS; s4++) {
+        // (the rows behind the tile's last input only meet zero weights; they hold finite intermediates of the ring)
+        const float *p = s4 < wrap_step ? p_lo : p_hi;
+        b[s4] = p[4 * s4 * TS];
+      }
+#pragma unroll
+      for (int s4 = 0; s4 < STEPS; s4++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ay[s4], b[s4], acc, 0, 0, 0);
+      uint8_t *ob = outb + (16 * yt + 4 * kq) * opitch + 16 * ft + m;
+      ob[0] = (uint8_t)SatU8(acc[0]); ob[opitch] = (uint8_t)SatU8(acc[1]);
+      ob[2 * opitch] = (uint8_t)SatU8(acc[2]); ob[3 * opitch] = (uint8_t)SatU8(acc[3]);
     }
-  }
-  __syncthreads();
-  if constexpr (PW) {
-    const daliamdPointwiseDesc pw = pointwise[di];   // (a private copy: the stores below cannot alias it)
-    BlurWriteOut(d, &pw, outb, opitch, tw, th, ox0, oy0);
-  } else {
-    BlurWriteOut(d, nullptr, outb, opitch, tw, th, ox0, oy0);
+    lds_barrier();
+    const int th = min(TR, sh - TR * tile);
+    if constexpr (PW) {
+      BlurWriteOut(d, &pw_lds, outb, opitch, tw, th, ox0, oy0 + TR * tile);   // (complete: barriers lie in between)
+    } else {
+      BlurWriteOut(d, nullptr, outb, opitch, tw, th, ox0, oy0 + TR * tile);
+    }
+    lds_barrier();   // the next batch of source rows lands where the tile's bytes were
   }
 }
 
@@ -999,7 +1072,7 @@ daliamdResult_t daliamdGaussianBlurSetup(daliamdGaussianBlurDesc *descs, int n, 
                   "daliamdGaussianBlurSetup: NULL argument");
   int wg = 0, lds = 0;
   // The matrix-core variant (GaussianBlurMfmaKernel) serves a table whose samples ALL have three channels and windows of at
-  // most 21 taps; the choice travels to Run in bit 30 of *lds_bytes.  DALI_AMD_BLUR_MFMA=0: the VALU kernel (bit-exact
+  // most 19 taps; the choice travels to Run in bit 30 of *lds_bytes.  DALI_AMD_BLUR_MFMA=0: the VALU kernel (bit-exact
   // against the CPU order of roundings) for everything.
   bool mfma = BlurMfmaEnabled() && n > 0;
   for (int i = 0; i < n && mfma; i++)
@@ -1012,11 +1085,11 @@ daliamdResult_t daliamdGaussianBlurSetup(daliamdGaussianBlurDesc *descs, int n, 
     DALIAMD_REQUIRE((d.size_x & 1) && (d.size_y & 1) && d.size_x <= DALIAMD_MAX_BLUR_WINDOW &&
                     d.size_y <= DALIAMD_MAX_BLUR_WINDOW && d.size_x > 0 && d.size_y > 0, DALIAMD_ERROR_UNSUPPORTED,
                     "daliamdGaussianBlurSetup: sample %d: window sizes must be odd and <= %d", i, DALIAMD_MAX_BLUR_WINDOW);
-    if (mfma) {   // the banded-Toeplitz kernel's fixed tile: 32 pixels x (64 - 2 radius) rows
-      const int tw = kBlurMfmaTW, th = BlurMfmaTileH(d.size_y);
+    if (mfma) {   // the banded-Toeplitz kernel: a workgroup owns a strip of 32 pixels x (4 tiles of 48 rows)
+      const int tw = kBlurMfmaTW, th = kBlurMfmaTileRows * kBlurMfmaStripTiles;
       d.tile_w = tw; d.tile_h = th;
       d.tiles_x = (d.w + tw - 1) / tw;
-      d.lds_bytes = BlurMfmaLdsBytes(d.size_x);
+      d.lds_bytes = BlurMfmaLdsBytes();
       d.wg_start = wg;
       wg += d.tiles_x * ((d.h + th - 1) / th);
       lds = lds > d.lds_bytes ? lds : d.lds_bytes;
@@ -1043,7 +1116,9 @@ daliamdResult_t daliamdGaussianBlurSetup(daliamdGaussianBlurDesc *descs, int n, 
     lds = lds > d.lds_bytes ? lds : d.lds_bytes;
   }
   *num_workgroups = wg;
-  *lds_bytes = lds | (mfma ? kBlurMfmaFlag : 0);
+  bool short_windows = mfma;
+  for (int i = 0; i < n && short_windows; i++) short_windows = descs[i].size_x <= 9 && descs[i].size_y <= 9;
+  *lds_bytes = lds | (mfma ? kBlurMfmaFlag : 0) | (short_windows ? kBlurMfmaShortFlag : 0);
   return DALIAMD_SUCCESS;
 }
 
@@ -1051,12 +1126,14 @@ daliamdResult_t daliamdGaussianBlurPointwiseRun(daliamdStream_t stream, const da
                                                 int lds_bytes, const daliamdPointwiseDesc *pointwise_dev) {
   if (n == 0 || nwg == 0) return DALIAMD_SUCCESS;
   const bool mfma = lds_bytes >= 0 && (lds_bytes & kBlurMfmaFlag) != 0;
-  if (lds_bytes >= 0) lds_bytes &= ~kBlurMfmaFlag;
+  const bool short_windows = lds_bytes >= 0 && (lds_bytes & kBlurMfmaShortFlag) != 0;
+  if (lds_bytes >= 0) lds_bytes &= ~(kBlurMfmaFlag | kBlurMfmaShortFlag);
   DALIAMD_REQUIRE(descs_dev && n > 0 && nwg > 0 && lds_bytes >= 0 && lds_bytes <= kBlurMaxLds,
                   DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdGaussianBlurRun: invalid argument");
   if (mfma) {
     daliamd::KernelTimer timer("GaussianBlurMfmaKernel", (hipStream_t)stream);
-    auto kern = pointwise_dev ? GaussianBlurMfmaKernel<true> : GaussianBlurMfmaKernel<false>;
+    auto kern = short_windows ? (pointwise_dev ? GaussianBlurMfmaKernel<true, 6> : GaussianBlurMfmaKernel<false, 6>)
+                              : (pointwise_dev ? GaussianBlurMfmaKernel<true, 9> : GaussianBlurMfmaKernel<false, 9>);
     hipLaunchKernelGGL(kern, dim3(XcdGrid(nwg)), dim3(kBlurThreads), lds_bytes, (hipStream_t)stream, descs_dev, n, nwg,
                        pointwise_dev);
     DALIAMD_HIP_CHECK(hipGetLastError());
@@ -1064,7 +1141,7 @@ daliamdResult_t daliamdGaussianBlurPointwiseRun(daliamdStream_t stream, const da
   }
   // DALI_AMD_BLUR_FMA=1: fused multiply-add accumulation (<= 1 LSB from the default, which replays the reference CPU
   // backend's separately rounded multiply and add bit for bit)
-  static const bool fma = getenv("DALI_AMD_BLUR_FMA") && atoi(getenv("DALI_AMD_BLUR_FMA")) != 0;
+  const bool fma = getenv("DALI_AMD_BLUR_FMA") && atoi(getenv("DALI_AMD_BLUR_FMA")) != 0;   // (read per launch: tests use both)
   {
     daliamd::KernelTimer timer("GaussianBlurKernel", (hipStream_t)stream);
     auto kern = fma ? (pointwise_dev ? GaussianBlurKernel<true, true> : GaussianBlurKernel<true, false>)

@@ -1271,9 +1271,13 @@ DALI_SCHEMA(RandomResizedCrop)
 // per-operator filter arguments -> kernel enums (ResamplingFilterAttr::PrepareFilterParams, resampling_attr.cc:76-121)
 struct FilterArgs {
   int min_filter = DALIAMD_INTERP_LINEAR, mag_filter = DALIAMD_INTERP_LINEAR, antialias = 1;
+  // `interp_type` / `min_filter` / `mag_filter` may be tensor arguments, one value per sample (resampling_attr.cc:25-37: the
+  // trailing `true` of their schema entries; GetPerSampleArgument in PrepareFilterParams): Resolve() reads them per batch
+  bool per_sample = false;
   explicit FilterArgs(const OpSpec &spec) {
-    DALI_ENFORCE(!spec.HasTensorArgument("interp_type") && !spec.HasTensorArgument("min_filter") &&
-                 !spec.HasTensorArgument("mag_filter"), "Per-sample interpolation types are not supported yet");
+    t_interp_ = spec.HasTensorArgument("interp_type"); t_min_ = spec.HasTensorArgument("min_filter");
+    t_mag_ = spec.HasTensorArgument("mag_filter");
+    per_sample = t_interp_ || t_min_ || t_mag_;
     antialias = spec.GetBool("antialias");
     bool has_interp = spec.Args().count("interp_type"), has_min = spec.Args().count("min_filter"),
          has_mag = spec.Args().count("mag_filter");
@@ -1283,6 +1287,32 @@ struct FilterArgs {
     else if (has_interp) mag_filter = ToKernelInterp(spec.GetInt("interp_type"));
     if (const ArgValue *d = spec.TryArg("dtype")) dtype = (int)d->i;
   }
+  // the filters of the batch's samples: min_filter / mag_filter win over interp_type, tensor or not, as in the reference
+  void Resolve(const OpSpec &spec, const Workspace &ws, int n) {
+    if (!per_sample) return;
+    min_v_.assign(n, min_filter);
+    mag_v_.assign(n, mag_filter);
+    auto read = [&](const char *name) {
+      std::vector<int> v = GetPerSampleInt(spec, ws, name, n), out(n);
+      for (int i = 0; i < n; i++) out[i] = ToKernelInterp(v[i]);
+      return out;
+    };
+    if (t_interp_) {
+      const std::vector<int> v = read("interp_type");
+      if (!t_min_ && !spec.Args().count("min_filter")) min_v_ = v;
+      if (!t_mag_ && !spec.Args().count("mag_filter")) mag_v_ = v;
+    }
+    if (t_min_) min_v_ = read("min_filter");
+    if (t_mag_) mag_v_ = read("mag_filter");
+  }
+  int Min(int i) const { return per_sample ? min_v_[i] : min_filter; }
+  int Mag(int i) const { return per_sample ? mag_v_[i] : mag_filter; }
+
+ private:
+  bool t_interp_ = false, t_min_ = false, t_mag_ = false;
+  std::vector<int> min_v_, mag_v_;
+
+ public:
   int dtype = -1;  // `dtype` argument: absent = the input's type
 
   // element types of one sample: u8 / i16 / u16 / f32 in (resize_base.cc:41,49), out = the input's type or FLOAT (the
@@ -1372,7 +1402,9 @@ class RandomResizedCropGpu : public OperatorBase {
   // order of draws, same advance per batch as without the fusion.
   // (the Gaussian window's reach is not a multiple of the scale that is written down anywhere: no fusion for it)
   bool CanTakeCroppedInput() const {
-    return filters_.min_filter != DALIAMD_INTERP_GAUSSIAN && filters_.mag_filter != DALIAMD_INTERP_GAUSSIAN && filters_.dtype < 0;
+    // (per-sample filters: the reach of a window would differ from sample to sample and is only known with the batch)
+    return !filters_.per_sample && filters_.min_filter != DALIAMD_INTERP_GAUSSIAN && filters_.mag_filter != DALIAMD_INTERP_GAUSSIAN &&
+           filters_.dtype < 0;
   }
   void ExpectCroppedInput() { cropped_input_ = true; }
   // rois[4 i ..] = the window of image i to DECODE: the crop window plus the reach of the resampling filter on every side
@@ -1416,6 +1448,7 @@ class RandomResizedCropGpu : public OperatorBase {
     const TensorList &in = ws.Input(0);
     int n = in.num_samples();
     shapes_hw_.resize(2 * n); anchors_.resize(2 * n); crops_.resize(2 * n);
+    filters_.Resolve(spec_, ws, n);
     args_.assign(n, daliamdResampleArgs{});
     int ch = 3;
     for (int i = 0; i < n; i++) {
@@ -1452,7 +1485,7 @@ class RandomResizedCropGpu : public OperatorBase {
       a.roi_y0 = (float)anchors_[2 * i]; a.roi_x0 = (float)anchors_[2 * i + 1];
       a.roi_y1 = (float)(anchors_[2 * i] + crops_[2 * i]); a.roi_x1 = (float)(anchors_[2 * i + 1] + crops_[2 * i + 1]);
       a.out_h = out_h_; a.out_w = out_w_;
-      a.min_filter = filters_.min_filter; a.mag_filter = filters_.mag_filter; a.antialias = filters_.antialias;
+      a.min_filter = filters_.Min(i); a.mag_filter = filters_.Mag(i); a.antialias = filters_.antialias;
       a.out_layout = DALIAMD_LAYOUT_HWC;
       out_type_ = filters_.ApplyTypes(a, in.type(), "RandomResizedCrop");
     }
@@ -1680,6 +1713,7 @@ class ResizeGpu : public OperatorBase {
       roi_start = GetPerSampleFloatVec(spec_, ws, "roi_start", n);
       roi_end = GetPerSampleFloatVec(spec_, ws, "roi_end", n);
     }
+    filters_.Resolve(spec_, ws, n);
     args_.assign(n, daliamdResampleArgs{});
     desc[0].type = in.type();
     desc[0].shape.resize(n);
@@ -1742,7 +1776,7 @@ class ResizeGpu : public OperatorBase {
       a.use_roi = 1;
       a.roi_y0 = lo[0]; a.roi_x0 = lo[1]; a.roi_y1 = hi[0]; a.roi_x1 = hi[1];
       a.out_h = out_hw[0]; a.out_w = out_hw[1];
-      a.min_filter = filters_.min_filter; a.mag_filter = filters_.mag_filter; a.antialias = filters_.antialias;
+      a.min_filter = filters_.Min(i); a.mag_filter = filters_.Mag(i); a.antialias = filters_.antialias;
       a.out_layout = DALIAMD_LAYOUT_HWC;
       desc[0].shape[i] = TensorShape{out_hw[0], out_hw[1], ch};
     }

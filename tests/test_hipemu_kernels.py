@@ -22,7 +22,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # their own python without the model
 NOT_ON_THE_MODEL = [
     "tests/test_gpu_augment.py::test_blur_fma_variant_stays_within_the_reference_tolerance",
-    "tests/test_gpu_augment.py::test_blur_on_the_matrix_cores_is_the_fma_chain_and_within_the_reference_tolerance",
     "tests/test_gpu_pipeline.py::test_iterator_two_shards",
     "tests/test_gpu_pipeline.py::test_gpu_tensor_dlpack_zero_copy_and_device_feed",
 ]

@@ -249,6 +249,7 @@ static inline float __builtin_amdgcn_fmed3f(float a, float b, float c) {
 static inline __attribute__((convergent)) void __builtin_amdgcn_s_barrier() { ::hipemu::BlockBarrier(); }
 #define __builtin_amdgcn_fence(...) __atomic_thread_fence(__ATOMIC_SEQ_CST)
 static inline void __builtin_amdgcn_s_sleep(int) {}
+static inline void __builtin_amdgcn_s_waitcnt(int) {}   // (the model has no counters to wait for: memory operations complete in order)
 
 typedef float hipemu_float4_vec __attribute__((ext_vector_type(4)));
 namespace hipemu {
