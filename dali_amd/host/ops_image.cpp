@@ -1259,14 +1259,16 @@ DALI_SCHEMA(RandomCropAttr)
 
 DALI_SCHEMA(RandomResizedCrop)
     .DocStr("Performs a crop with a randomly selected area and aspect ratio and resizes it to the specified size.\n\n"
-            "Expects a three-dimensional input with samples in height, width, channels (HWC) layout.")
+            "Expects an input with samples in height, width, channels (HWC) layout, or any layout in which W follows H "
+            "(FHWC video, CHW, FCHW, CFHW): the dimensions in front of H are frames that share the sample's crop window, the "
+            "ones behind W channels (1 to 4).")
     .NumInput(1)
     .NumOutput(1)
     .AddArg("size", "Size of the resized image.", ArgType::INT_VEC)
     .AddParent("RandomCropAttr")
     .AddParent("ResamplingFilterAttr")
     .AllowSequences()
-    .InputLayout(0, {"HWC"});
+    .InputLayout(0, {"HWC", "CHW", "FHWC", "FCHW", "CFHW"});
 
 // per-operator filter arguments -> kernel enums (ResamplingFilterAttr::PrepareFilterParams, resampling_attr.cc:76-121)
 struct FilterArgs {
@@ -1369,12 +1371,48 @@ static void LaunchResample(Workspace &ws, DescUploader &up, std::vector<daliamdR
   NoteLaunch(ws, what);
 }
 
-static void FillSourceArgs(daliamdResampleArgs &a, const TensorList &in, int i) {
+// A sample of the resizing operators as FRAMES of H x W x C images, the way the reference's resize implementation sees any
+// layout in which W follows H (ResizeBase::SetupResize(.., first_spatial_dim), resize_base.cc:33-52, resize_op_impl_*:
+// the dimensions in front of H are flattened into frames, the ones behind W into channels): "HWC" one frame, "FHWC" video,
+// "CHW" C single-channel frames, "FCHW" / "CFHW" F x C of them.  Frames of a sample share its arguments (region of
+// interest, filters - one crop window per video, random_resized_crop.h:62-85).
+struct FrameView {
+  int64_t frames = 1;
+  int h = 0, w = 0, c = 1, hi = 0;   // hi: index of H in the shape
+  bool plain_hwc = true;             // three-dimensional HWC: the case the fused paths are written for
+};
+static FrameView SplitFrames(const TensorList &in, int i, const char *op) {
   const TensorShape &s = in.shape(i);
-  DALI_ENFORCE(s.size() == 3, "Expected a three-dimensional HWC input, got ", s.size(), " dimensions");
-  a.in = static_cast<const uint8_t *>(in.raw(i));
-  a.in_h = (int32_t)s[0]; a.in_w = (int32_t)s[1]; a.channels = (int32_t)s[2];
-  a.in_pitch = (int32_t)(in.row_pitch(i) ? in.row_pitch(i) : s[1] * s[2] * TypeSize(in.type()));   // bytes
+  std::string layout = in.layout();
+  if (layout.empty()) layout = s.size() == 3 ? "HWC" : s.size() == 2 ? "HW" : "";
+  const size_t hi = layout.find('H');
+  DALI_ENFORCE(layout.size() == s.size() && hi != std::string::npos && hi + 1 < layout.size() && layout[hi + 1] == 'W', op,
+               ": expected a layout in which W follows H (HWC, FHWC, CHW, FCHW, CFHW, HW) that matches the ", s.size(),
+               "-dimensional input, got \"", in.layout(), "\"");
+  FrameView v;
+  v.hi = (int)hi;
+  for (size_t k = 0; k < hi; k++) v.frames *= s[k];
+  v.h = (int)s[hi]; v.w = (int)s[hi + 1];
+  int64_t c = 1;
+  for (size_t k = hi + 2; k < s.size(); k++) c *= s[k];
+  DALI_ENFORCE(c >= 1 && c <= 4, op, ": ", c, " channels behind the width (supported: 1..4; put the channels in front - CHW - for more)");
+  v.c = (int)c;
+  v.plain_hwc = layout == "HWC";
+  const int64_t dense = (int64_t)v.w * v.c * (int64_t)TypeSize(in.type());
+  DALI_ENFORCE(v.plain_hwc || !in.row_pitch(i) || in.row_pitch(i) == dense, op, ": frames need densely packed rows");
+  return v;
+}
+static void FillSourceArgs(daliamdResampleArgs &a, const TensorList &in, int i, const FrameView &v, int64_t frame) {
+  const int64_t row = (int64_t)v.w * v.c * (int64_t)TypeSize(in.type());
+  a.in_h = v.h; a.in_w = v.w; a.channels = v.c;
+  a.in_pitch = (int32_t)(v.plain_hwc && in.row_pitch(i) ? in.row_pitch(i) : row);   // bytes
+  a.in = static_cast<const uint8_t *>(in.raw(i)) + frame * (int64_t)v.h * a.in_pitch;
+}
+// the output shape of a sample: its input shape with H and W replaced
+static TensorShape ResizedShape(const TensorList &in, int i, const FrameView &v, int out_h, int out_w) {
+  TensorShape s = in.shape(i);
+  s[v.hi] = out_h; s[v.hi + 1] = out_w;
+  return s;
 }
 
 class RandomResizedCropGpu : public OperatorBase {
@@ -1449,12 +1487,22 @@ class RandomResizedCropGpu : public OperatorBase {
     int n = in.num_samples();
     shapes_hw_.resize(2 * n); anchors_.resize(2 * n); crops_.resize(2 * n);
     filters_.Resolve(spec_, ws, n);
-    args_.assign(n, daliamdResampleArgs{});
-    int ch = 3;
+    // one resampling job per FRAME (SplitFrames); a sample's frames share its window
+    views_.resize(n);
+    arg_sample_.clear(); arg_frame_.clear();
+    bool plain = true;
     for (int i = 0; i < n; i++) {
-      FillSourceArgs(args_[i], in, i);
-      shapes_hw_[2 * i] = args_[i].in_h; shapes_hw_[2 * i + 1] = args_[i].in_w;
-      ch = args_[i].channels;
+      views_[i] = SplitFrames(in, i, "RandomResizedCrop");
+      plain = plain && views_[i].plain_hwc;
+      for (int64_t f = 0; f < views_[i].frames; f++) { arg_sample_.push_back(i); arg_frame_.push_back(f); }
+    }
+    const int na = (int)arg_sample_.size();
+    args_.assign(na, daliamdResampleArgs{});
+    int ch = 3;
+    for (int k = 0; k < na; k++) FillSourceArgs(args_[k], in, arg_sample_[k], views_[arg_sample_[k]], arg_frame_[k]);
+    for (int i = 0; i < n; i++) {
+      shapes_hw_[2 * i] = views_[i].h; shapes_hw_[2 * i + 1] = views_[i].w;
+      ch = views_[i].c;
     }
     if (cropped_input_) {
       // the windows of this iteration were drawn when the producer ran: the input IS the window
@@ -1468,6 +1516,7 @@ class RandomResizedCropGpu : public OperatorBase {
       drawn_.pop_front();
       crops_ = std::move(d.crops);
       anchors_ = std::move(d.anchors);
+      DALI_ENFORCE(plain && na == n, "internal: RandomResizedCrop expected HWC images from its producer");
       for (int i = 0; i < n; i++) {
         DALI_ENFORCE(shapes_hw_[2 * i] == d.window[4 * i + 2] && shapes_hw_[2 * i + 1] == d.window[4 * i + 3],
                      "internal: RandomResizedCrop expected a ", d.window[4 * i + 2], " x ", d.window[4 * i + 3], " window, got ",
@@ -1479,8 +1528,9 @@ class RandomResizedCropGpu : public OperatorBase {
                                       anchors_.data(), crops_.data()) != 0) {
       DALI_FAIL(daliamdHostGetLastErrorMessage());
     }
-    for (int i = 0; i < n; i++) {
-      auto &a = args_[i];
+    for (int k = 0; k < na; k++) {
+      const int i = arg_sample_[k];
+      auto &a = args_[k];
       a.use_roi = 1;
       a.roi_y0 = (float)anchors_[2 * i]; a.roi_x0 = (float)anchors_[2 * i + 1];
       a.roi_y1 = (float)(anchors_[2 * i] + crops_[2 * i]); a.roi_x1 = (float)(anchors_[2 * i + 1] + crops_[2 * i + 1]);
@@ -1490,10 +1540,12 @@ class RandomResizedCropGpu : public OperatorBase {
       out_type_ = filters_.ApplyTypes(a, in.type(), "RandomResizedCrop");
     }
     n_ = n; ch_ = ch;
-    plain_u8_ = in.type() == DALI_UINT8 && out_type_ == DALI_UINT8;
+    plain_u8_ = plain && in.type() == DALI_UINT8 && out_type_ == DALI_UINT8;
+    layout_ = in.layout().empty() ? std::string("HWC") : in.layout();
     if (fused_ && plain_u8_) return false;  // no buffer: the consumer launches the fused kernel
     desc[0].type = n ? out_type_ : in.type();
-    desc[0].shape.assign(n, TensorShape{out_h_, out_w_, ch});
+    desc[0].shape.resize(n);
+    for (int i = 0; i < n; i++) desc[0].shape[i] = ResizedShape(in, i, views_[i], out_h_, out_w_);
     return true;
   }
 
@@ -1509,10 +1561,11 @@ class RandomResizedCropGpu : public OperatorBase {
       out.SetLayout("HWC");
     } else {
       out.deferred.reset();
-      out.SetLayout("HWC");
-      for (int i = 0; i < n_; i++) {
+      out.SetLayout(layout_);
+      const int64_t frame_bytes = (int64_t)out_h_ * out_w_ * ch_ * (int64_t)TypeSize(out_type_);
+      for (size_t k = 0; k < args_.size(); k++) {
         // the kernel writes dense HWC rows; request that from the executor by a dense pitch
-        args_[i].out = out.raw(i);
+        args_[k].out = static_cast<uint8_t *>(out.raw(arg_sample_[k])) + arg_frame_[k] * frame_bytes;
       }
       DALI_ENFORCE(out.is_dense() || n_ == 0, "internal: resample output must be dense");
       LaunchResample(ws, uploader_, args_, descs_, "resample");
@@ -1550,6 +1603,10 @@ class RandomResizedCropGpu : public OperatorBase {
   bool fused_ = false, plain_u8_ = true;
   DALIDataType out_type_ = DALI_UINT8;
   std::vector<int32_t> shapes_hw_, anchors_, crops_;
+  std::vector<FrameView> views_;                 // per sample
+  std::vector<int> arg_sample_;                  // per resampling job (frame): its sample ...
+  std::vector<int64_t> arg_frame_;               // ... and its frame inside it
+  std::string layout_ = "HWC";
   std::vector<daliamdResampleArgs> args_;
   std::vector<daliamdResampleDesc> descs_;
   DescUploader uploader_;
@@ -1590,12 +1647,14 @@ DALI_SCHEMA(ResizeAttr)
     .AddParent("ResizeAttrBase");
 
 DALI_SCHEMA(Resize)
-    .DocStr("Resize images.\n\nExpects a three-dimensional uint8 input in HWC layout.")
+    .DocStr("Resize images.\n\nExpects an input in HWC layout, or any layout in which W follows H (FHWC video, CHW, FCHW, "
+            "CFHW): the dimensions in front of H are frames that share the sample's arguments, the ones behind W channels (1 to 4).")
     .NumInput(1)
     .NumOutput(1)
     .AddParent("ResizeAttr")
     .AddParent("ResamplingFilterAttr")
-    .InputLayout(0, {"HWC"});
+    .AllowSequences()
+    .InputLayout(0, {"HWC", "CHW", "FHWC", "FCHW", "CFHW"});
 
 enum class ResizeMode { Default, Stretch, NotLarger, NotSmaller };
 
@@ -1714,13 +1773,25 @@ class ResizeGpu : public OperatorBase {
       roi_end = GetPerSampleFloatVec(spec_, ws, "roi_end", n);
     }
     filters_.Resolve(spec_, ws, n);
-    args_.assign(n, daliamdResampleArgs{});
+    // one resampling job per FRAME (SplitFrames): a sample's arguments are worked out once, on its first frame, and copied
+    views_.resize(n);
+    arg_sample_.clear(); arg_frame_.clear();
+    first_arg_.assign(n, 0);
+    bool plain = true;
+    for (int i = 0; i < n; i++) {
+      views_[i] = SplitFrames(in, i, "Resize");
+      plain = plain && views_[i].plain_hwc;
+      first_arg_[i] = (int)arg_sample_.size();
+      for (int64_t f = 0; f < std::max<int64_t>(views_[i].frames, 0); f++) { arg_sample_.push_back(i); arg_frame_.push_back(f); }
+    }
+    args_.assign(arg_sample_.size(), daliamdResampleArgs{});
     desc[0].type = in.type();
     desc[0].shape.resize(n);
     int ch = 3;
     for (int i = 0; i < n; i++) {
-      auto &a = args_[i];
-      FillSourceArgs(a, in, i);
+      daliamdResampleArgs first{};
+      auto &a = views_[i].frames > 0 ? args_[first_arg_[i]] : first;
+      FillSourceArgs(a, in, i, views_[i], 0);
       desc[0].type = filters_.ApplyTypes(a, in.type(), "Resize");
       ch = a.channels;
       const int in_hw[2] = {a.in_h, a.in_w};
@@ -1778,18 +1849,25 @@ class ResizeGpu : public OperatorBase {
       a.out_h = out_hw[0]; a.out_w = out_hw[1];
       a.min_filter = filters_.Min(i); a.mag_filter = filters_.Mag(i); a.antialias = filters_.antialias;
       a.out_layout = DALIAMD_LAYOUT_HWC;
-      desc[0].shape[i] = TensorShape{out_hw[0], out_hw[1], ch};
+      desc[0].shape[i] = ResizedShape(in, i, views_[i], out_hw[0], out_hw[1]);
+      for (int64_t f = 1; f < views_[i].frames; f++) {   // the sample's other frames: the same job on the next image
+        args_[first_arg_[i] + f] = a;
+        FillSourceArgs(args_[first_arg_[i] + f], in, i, views_[i], f);
+      }
     }
     n_ = n; ch_ = ch;
-    uniform_ = n > 0 && in.type() == DALI_UINT8 && desc[0].type == DALI_UINT8;   // only u8 -> u8 can be deferred
-    for (int i = 1; i < n; i++) uniform_ &= args_[i].out_h == args_[0].out_h && args_[i].out_w == args_[0].out_w;
+    layout_ = in.layout().empty() ? std::string("HWC") : in.layout();
+    out_elem_ = (int64_t)TypeSize(desc[0].type);
+    // only u8 -> u8 HWC images of one size can be deferred to a consumer's fused kernel
+    uniform_ = n > 0 && plain && in.type() == DALI_UINT8 && desc[0].type == DALI_UINT8;
+    for (int i = 1; i < n && uniform_; i++) uniform_ &= args_[i].out_h == args_[0].out_h && args_[i].out_w == args_[0].out_w;
     if (fused_ && uniform_) return false;  // the consumer launches the fused kernel
     return true;
   }
 
   void RunImpl(Workspace &ws) override {
     TensorList &out = ws.Output(0);
-    out.SetLayout("HWC");
+    out.SetLayout(layout_);
     if (fused_ && uniform_) {
       auto d = std::make_shared<DeferredResample>();
       d->source = ws.inputs[0];
@@ -1800,7 +1878,9 @@ class ResizeGpu : public OperatorBase {
       return;
     }
     out.deferred.reset();
-    for (int i = 0; i < n_; i++) args_[i].out = out.raw(i);
+    for (size_t k = 0; k < args_.size(); k++)
+      args_[k].out = static_cast<uint8_t *>(out.raw(arg_sample_[k])) +
+                     arg_frame_[k] * (int64_t)args_[k].out_h * args_[k].out_w * args_[k].channels * out_elem_;
     LaunchResample(ws, uploader_, args_, descs_, "resample");
   }
 
@@ -1816,6 +1896,11 @@ class ResizeGpu : public OperatorBase {
   float max_size_[2] = {0, 0};
   bool fused_ = false, uniform_ = false;
   int n_ = 0, ch_ = 3;
+  std::vector<FrameView> views_;                 // per sample
+  std::vector<int> arg_sample_, first_arg_;      // per resampling job (frame): its sample; per sample: its first job
+  std::vector<int64_t> arg_frame_;
+  std::string layout_ = "HWC";
+  int64_t out_elem_ = 1;
   std::vector<daliamdResampleArgs> args_;
   std::vector<daliamdResampleDesc> descs_;
   DescUploader uploader_;
