@@ -2,6 +2,7 @@
 #include "image_cache.h"
 
 #include <algorithm>
+#include <atomic>
 
 #include <cstdio>
 #include <cstdlib>
@@ -415,6 +416,71 @@ const uint8_t *HuffTableStore::Get(int device_id, const daliamdJpegScan &scan) {
   }
   hit->tables = static_cast<const uint8_t *>(dev);
   return hit->tables;
+}
+
+// ------------------------------------------------------------------------------------------ parse results
+namespace {
+struct HeaderEntry {
+  int64_t size;
+  daliamdJpegInfo info;
+  int32_t eligible, mcus_x, mcus_y, length_is_upper_bound;
+  int64_t ecs_offset, ecs_length;
+  std::shared_ptr<const daliamdJpegScan> common;   // everything else of the scan analysis, shared between files
+};
+constexpr int kHeaderShards = 32;
+struct HeaderShard {
+  std::mutex m;
+  std::unordered_map<std::string, HeaderEntry> map;
+};
+HeaderShard g_header_shards[kHeaderShards];
+std::mutex g_header_common_m;
+std::vector<std::shared_ptr<const daliamdJpegScan>> g_header_common;
+std::atomic<int64_t> g_header_entries{0};
+int64_t HeaderCacheCap() {
+  static const int64_t cap = [] { const char *e = getenv("DALI_AMD_HEADER_CACHE_ENTRIES"); return e ? atoll(e) : (int64_t)2000000; }();
+  return cap;
+}
+daliamdJpegScan CommonPart(const daliamdJpegScan &s) {
+  daliamdJpegScan c = s;
+  c.eligible = 0; c.mcus_x = c.mcus_y = 0; c.ecs_offset = c.ecs_length = 0; c.length_is_upper_bound = 0;
+  return c;
+}
+}  // namespace
+
+bool HeaderCache::Find(const std::string &key, int64_t stream_size, daliamdJpegInfo *info, daliamdJpegScan *scan) {
+  if (key.empty() || HeaderCacheCap() <= 0) return false;
+  HeaderShard &sh = g_header_shards[std::hash<std::string>()(key) % kHeaderShards];
+  std::lock_guard<std::mutex> g(sh.m);
+  auto it = sh.map.find(key);
+  if (it == sh.map.end() || it->second.size != stream_size) return false;
+  const HeaderEntry &e = it->second;
+  *info = e.info;
+  *scan = *e.common;
+  scan->eligible = e.eligible; scan->mcus_x = e.mcus_x; scan->mcus_y = e.mcus_y;
+  scan->ecs_offset = e.ecs_offset; scan->ecs_length = e.ecs_length; scan->length_is_upper_bound = e.length_is_upper_bound;
+  return true;
+}
+
+void HeaderCache::Put(const std::string &key, int64_t stream_size, const daliamdJpegInfo &info, const daliamdJpegScan &scan) {
+  if (key.empty() || g_header_entries.load(std::memory_order_relaxed) >= HeaderCacheCap()) return;
+  const daliamdJpegScan common = CommonPart(scan);
+  std::shared_ptr<const daliamdJpegScan> shared;
+  {
+    std::lock_guard<std::mutex> g(g_header_common_m);
+    for (auto &c : g_header_common)
+      if (!memcmp(c.get(), &common, sizeof(common))) { shared = c; break; }
+    if (!shared) {
+      if (g_header_common.size() >= 4096) return;   // (a data set of files with tables of their own: not worth keeping)
+      shared = std::make_shared<const daliamdJpegScan>(common);
+      g_header_common.push_back(shared);
+    }
+  }
+  HeaderShard &sh = g_header_shards[std::hash<std::string>()(key) % kHeaderShards];
+  std::lock_guard<std::mutex> g(sh.m);
+  auto ins = sh.map.emplace(key, HeaderEntry{});
+  if (ins.second) g_header_entries.fetch_add(1, std::memory_order_relaxed);
+  ins.first->second = HeaderEntry{stream_size, info, scan.eligible, scan.mcus_x, scan.mcus_y, scan.length_is_upper_bound,
+                                  scan.ecs_offset, scan.ecs_length, shared};
 }
 
 bool DecoderCacheHolds(int device_id, const std::string &key) {

@@ -195,6 +195,19 @@ class HuffTableStore {
   static bool SameTables(const daliamdJpegScan &a, const daliamdJpegScan &b);
 };
 
+// Parse results of files the decoder has seen before (round 5): epoch >= 2 of a shard that is NOT resident still reads its
+// files, but their headers say what they said in epoch 1 - the reference keeps such epoch-invariant facts in index files
+// (tools/tfrecord2idx, tools/wds2idx.py).  Keyed by the sample's source (the file path), valid while the size of the
+// encoded stream is the one recorded; a hit spares the header parse and scan analysis (4 us of host time per image, a third of a
+// decoder thread's work when eight ranks share a host).  The table-heavy part of a scan analysis (DHT / DQT contents,
+// 2.9 KB) is shared between the files that have the same: an entry costs about 250 bytes.  Process-wide, at most
+// DALI_AMD_HEADER_CACHE_ENTRIES entries (default 2 M; 0 switches it off), filled until full.
+class HeaderCache {
+ public:
+  static bool Find(const std::string &key, int64_t stream_size, daliamdJpegInfo *info, daliamdJpegScan *scan);
+  static void Put(const std::string &key, int64_t stream_size, const daliamdJpegInfo &info, const daliamdJpegScan &scan);
+};
+
 // `skip_cached_images` of the readers: is the sample held by a decoder cache (of either kind) of the device?
 bool DecoderCacheHolds(int device_id, const std::string &key);
 

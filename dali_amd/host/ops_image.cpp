@@ -248,13 +248,19 @@ class ImageDecoderMixed : public OperatorBase {
       }
       ws.GetThreadPool().AddWork([&, i](int) {
         const uint8_t *data = static_cast<const uint8_t *>(in.raw(i));
+        // a file this process has parsed before (epoch >= 2 of a shard that is not resident): what its headers said
+        const bool named = i < (int)in.source_info.size() && !in.source_info[i].empty();
+        const bool known = named && !host_huffman_only_ && HeaderCache::Find(in.source_info[i], in.nbytes(i), &infos_[i], &scans_[i]);
         // ONE pass over the headers, up to SOS: frame geometry + what the GPU entropy decoder needs.  The scan itself is
         // not walked here - its end (the first marker that is not RSTn) is found by the un-stuffing kernel, which
         // looks at every byte anyway (the memchr walk was two thirds of this operator's host time per sample).
-        if (host_huffman_only_ || daliamdJpegAnalyzeHeader(data, in.nbytes(i), &infos_[i], &scans_[i]) != 0) {
+        if (known) {
+        } else if (host_huffman_only_ || daliamdJpegAnalyzeHeader(data, in.nbytes(i), &infos_[i], &scans_[i]) != 0) {
           scans_[i].eligible = 0;  // (a broken table or SOS header: the host decoder will produce the diagnosis)
           if (daliamdJpegParse(data, in.nbytes(i), &infos_[i]) != 0)
             DALI_FAIL("Failed to parse ", src(i), ": ", daliamdHostGetLastErrorMessage());
+        } else if (named) {
+          HeaderCache::Put(in.source_info[i], in.nbytes(i), infos_[i], scans_[i]);
         }
         if (infos_[i].num_components == 4) { scans_[i].eligible = 0; return; }  // CMYK / YCCK: the host decodes these (below)
         DALI_ENFORCE(infos_[i].num_components == 1 || infos_[i].num_components == 3, "Failed to decode ", src(i),
