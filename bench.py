@@ -328,6 +328,9 @@ def thread_cpu_seconds():
         try:
             with open(f"/proc/self/task/{tid}/comm") as f:
                 name = f.read().strip().rstrip("0123456789")
+            if not name.startswith("dali-"):
+                # the interpreter's main thread, or a thread somebody else made (HIP / ROCr runtime helpers, torch pools)
+                name = "main" if int(tid) == os.getpid() else f"other({name})"
             with open(f"/proc/self/task/{tid}/schedstat") as f:
                 ns = int(f.read().split()[0])          # time spent on a CPU, nanoseconds
         except (OSError, ValueError, IndexError):

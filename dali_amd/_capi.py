@@ -181,7 +181,7 @@ _KERNEL_SYMBOLS = [
     "daliamdMemcpyD2HAsync", "daliamdMemcpyD2DAsync", "daliamdMemsetAsync", "daliamdMemcpy2DD2DAsync",
     "daliamdJpegIdctSetup", "daliamdJpegIdctRun", "daliamdJpegHuffmanScratchBytes", "daliamdJpegHuffmanScratchBytesRestart", "daliamdJpegHuffmanSetup",
     "daliamdJpegHuffmanRun", "daliamdJpegHuffmanRunProfiled", "daliamdJpegHuffmanSetupColor", "daliamdJpegHuffmanRunColor",
-    "daliamdJpegHuffmanRunProfiledColor", "daliamdJpegHuffmanColorFusable", "daliamdJpegHuffmanIndexBytes", "daliamdJpegHuffmanTablesBytes", "daliamdJpegHuffmanTablesBuild", "daliamdJpegColorSetup", "daliamdJpegPlanRoi", "daliamdJpegColorRun",
+    "daliamdJpegHuffmanRunProfiledColor", "daliamdJpegHuffmanColorFusable", "daliamdJpegHuffmanIndexBytes", "daliamdJpegHuffmanRunFront", "daliamdJpegHuffmanRunBack", "daliamdJpegHuffmanTablesBytes", "daliamdJpegHuffmanTablesBuild", "daliamdJpegColorSetup", "daliamdJpegPlanRoi", "daliamdJpegColorRun",
     "daliamdResampleSetup", "daliamdResampleRun", "daliamdResampleRunTables", "daliamdResampleRunPasses", "daliamdCmnSetup", "daliamdCmnRun",
     "daliamdWarpAffineSetup", "daliamdWarpAffineRun", "daliamdGaussianWindow", "daliamdGaussianBlurSetup",
     "daliamdGaussianBlurRun", "daliamdGaussianBlurPointwiseRun", "daliamdColorTwistMatrix", "daliamdPointwiseSetup", "daliamdPointwiseRun",

@@ -1882,8 +1882,11 @@ daliamdResult_t daliamdJpegHuffmanSetupColor(daliamdJpegHuffDesc *descs_host, in
   return DALIAMD_SUCCESS;
 }
 
+// parts: bit 0 - the front (code tables + un-stuffing: needs the descriptors and the streams' bytes, nothing else), bit 1 - the
+// rest.  A caller may run the front on a side stream as soon as the bytes are on the device and order the rest behind it.
 static daliamdResult_t LaunchHuffman(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev, int n, int num_tiles,
-                                     int num_segments, int num_block_workgroups, daliamdEvent_t *events, int block_kernels) {
+                                     int num_segments, int num_block_workgroups, daliamdEvent_t *events, int block_kernels,
+                                     int parts = 3) {
   if (n == 0) return DALIAMD_SUCCESS;
   DALIAMD_REQUIRE(descs_dev && n > 0 && num_tiles >= 0 && num_segments >= n && num_block_workgroups >= n,
                   DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdJpegHuffmanRun: invalid argument");
@@ -1904,16 +1907,20 @@ static daliamdResult_t LaunchHuffman(daliamdStream_t stream, const daliamdJpegHu
                             !(block_kernels & (DALIAMD_JPEG_HUFFMAN_PARSED | DALIAMD_JPEG_HUFFMAN_INDEXED));
   const int ntab = build_tables ? n : 0;
   DALIAMD_HIP_CHECK(mark());
-  if (num_tiles + ntab > 0) {
+  if ((parts & 1) && num_tiles + ntab > 0) {
     KernelTimer timer("PrepareKernel", s);
     hipLaunchKernelGGL(PrepareKernel, dim3(num_tiles + ntab), dim3(kTileThreads), 0, s, descs_dev, n, num_tiles, ntab);
   }
   DALIAMD_HIP_CHECK(mark());
-  if (parsed && num_tiles > 0) {
+  if ((parts & 1) && parsed && num_tiles > 0) {
     KernelTimer timer("UnstuffScatterKernel", s);
     hipLaunchKernelGGL(UnstuffScatterKernel, dim3(num_tiles), dim3(kTileThreads), 0, s, descs_dev, n);
   }
   DALIAMD_HIP_CHECK(mark());
+  if (!(parts & 2)) {
+    DALIAMD_HIP_CHECK(hipGetLastError());
+    return DALIAMD_SUCCESS;
+  }
   if (parsed) {
     KernelTimer timer("SyncKernel", s);
     hipLaunchKernelGGL(SyncKernel, dim3(seg_grid), dim3(kSegThreads), 0, s, descs_dev, n, num_segments);
@@ -1967,6 +1974,15 @@ daliamdResult_t daliamdJpegHuffmanRun(daliamdStream_t stream, const daliamdJpegH
 daliamdResult_t daliamdJpegHuffmanRunColor(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev, int n, int num_tiles,
                                            int num_segments, int num_block_workgroups, int block_kernels) {
   return LaunchHuffman(stream, descs_dev, n, num_tiles, num_segments, num_block_workgroups, nullptr, block_kernels & 63);
+}
+
+daliamdResult_t daliamdJpegHuffmanRunFront(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev, int n, int num_tiles,
+                                           int num_segments, int num_block_workgroups, int block_kernels) {
+  return LaunchHuffman(stream, descs_dev, n, num_tiles, num_segments, num_block_workgroups, nullptr, block_kernels & 63, 1);
+}
+daliamdResult_t daliamdJpegHuffmanRunBack(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev, int n, int num_tiles,
+                                          int num_segments, int num_block_workgroups, int block_kernels) {
+  return LaunchHuffman(stream, descs_dev, n, num_tiles, num_segments, num_block_workgroups, nullptr, block_kernels & 63, 2);
 }
 
 daliamdResult_t daliamdJpegHuffmanRunProfiled(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev, int n,

@@ -273,7 +273,7 @@ bool StreamCache::IsCached(const std::string &key) const {
 }
 
 int StreamCache::Lookup(const std::vector<std::string> &keys, const std::vector<uint8_t> &skip,
-                        std::vector<std::shared_ptr<const Record>> *out, daliamdStream_t stream) {
+                        std::vector<std::shared_ptr<const Record>> *out, daliamdStream_t stream, daliamdStream_t also) {
   int found = 0;
   const ImageCache::Fence *waited = nullptr;  // a batch is usually behind ONE fence: wait for it once
   std::lock_guard<std::mutex> g(m_);
@@ -291,6 +291,7 @@ int StreamCache::Lookup(const std::vector<std::string> &keys, const std::vector<
       }
       if (!s.fence->done) {
         KCHECK(daliamdStreamWaitEvent(stream, s.fence->event));
+        if (also && also != stream) KCHECK(daliamdStreamWaitEvent(also, s.fence->event));
         waited = s.fence.get();
       }
     }

@@ -139,8 +139,9 @@ class StreamCache {
   bool IsCached(const std::string &key) const;
   // out[i] = the record of keys[i] or null; samples with skip[i] != 0 are not looked up.  Makes `stream` wait for the
   // copies behind the returned records where they may still be in flight.  One lock for the whole batch.
+  // `also`: a second stream that will read the records' device data (the decoder's side stream), made to wait the same way
   int Lookup(const std::vector<std::string> &keys, const std::vector<uint8_t> &skip,
-             std::vector<std::shared_ptr<const Record>> *out, daliamdStream_t stream);
+             std::vector<std::shared_ptr<const Record>> *out, daliamdStream_t stream, daliamdStream_t also = nullptr);
   // room for the `bytes` of a new segment, or nullptr (known key, or the blob is full)
   uint8_t *Reserve(const std::string &key, size_t bytes);
   // the copies into the slots reserved for `keys` are enqueued on `stream`

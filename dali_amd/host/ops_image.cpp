@@ -126,6 +126,8 @@ class ImageDecoderMixed : public OperatorBase {
       raster_stage_.emplace_back(std::make_unique<Buffer>(StorageDevice::CPU));
     }
     h2d_done_.assign(ring_, nullptr);
+    front_done_.assign(ring_, nullptr);
+    if (const char *env = getenv("DALI_AMD_DECODER_FRONT_ON_SIDE_STREAM")) keep_front_on_compute_ = atoi(env) == 0;
     // decoded-image cache (cached_decoder_impl.cc:24-48); the fused crop decoders have no cache options
     if (spec.Args().count("cache_size") && (spec.GetString("cache_type") == "encoded" || spec.GetString("cache_type") == "indexed")) {
       // the encoded-stream cache (image_cache.h); also for the region-of-interest decoders: they decode from it
@@ -144,6 +146,8 @@ class ImageDecoderMixed : public OperatorBase {
   }
   ~ImageDecoderMixed() override {
     for (auto e : h2d_done_)
+      if (e) daliamdEventDestroy(e);
+    for (auto e : front_done_)
       if (e) daliamdEventDestroy(e);
     if (trace_ && trace_runs_ > 0) {
       static const char *names[] = {"parse + scan analysis + staging copy (thread pool)", "layout, windows, allocation",
@@ -195,7 +199,7 @@ class ImageDecoderMixed : public OperatorBase {
     // the input bytes are not looked at (the reader may have skipped the file: they are empty then) ----
     erec_.assign(n, nullptr);
     int nehit = 0;
-    if (stream_cache_) nehit = stream_cache_->Lookup(in.source_info, hit_, &erec_, ws.stream);
+    if (stream_cache_) nehit = stream_cache_->Lookup(in.source_info, hit_, &erec_, ws.stream, ws.aux_stream);
     // Samples that are not JPEG (PNG, BMP, PNM): decoded on the host thread pool further down and uploaded; for the JPEG
     // machinery they do not exist, like cache hits.
     raster_.assign(n, 0);
@@ -635,10 +639,22 @@ class ImageDecoderMixed : public OperatorBase {
     } else {
       KCHECK(daliamdMemcpyH2DAsync(ecs_dev.data(), ecs_stage.data(), upload_bytes, cs));
     }
+    // The front of the entropy decoder (un-stuffing, code tables of streams that do not bring them) needs the transfer and
+    // nothing else: on the side stream it runs while ws.stream is still with the previous iteration's kernels.
+    daliamdStream_t side = ws.aux_stream && cs != ws.stream && ngpu && !keep_front_on_compute_ ? ws.aux_stream : nullptr;
     if (cs != ws.stream) {
       if (!h2d_done_[slot]) KCHECK(daliamdEventCreate(&h2d_done_[slot], 0));
       KCHECK(daliamdEventRecord(h2d_done_[slot], cs));
-      KCHECK(daliamdStreamWaitEvent(ws.stream, h2d_done_[slot]));
+      if (side) {
+        KCHECK(daliamdStreamWaitEvent(side, h2d_done_[slot]));
+        KCHECK(daliamdJpegHuffmanRunFront(side, reinterpret_cast<const daliamdJpegHuffDesc *>(dev_base + huff_off), ngpu, ntiles,
+                                          nsegs, nbwg, block_kernels));
+        if (!front_done_[slot]) KCHECK(daliamdEventCreate(&front_done_[slot], 0));
+        KCHECK(daliamdEventRecord(front_done_[slot], side));
+        KCHECK(daliamdStreamWaitEvent(ws.stream, front_done_[slot]));
+      } else {
+        KCHECK(daliamdStreamWaitEvent(ws.stream, h2d_done_[slot]));
+      }
     }
     // resident from here on (visible to later iterations, the reader's skip_cached_images and other pipelines): the streams
     // kept as they are, once their copies are on the stream; the ones kept with their index, behind the decode that builds it
@@ -661,8 +677,12 @@ class ImageDecoderMixed : public OperatorBase {
     };
     commit(false);
     if (ngpu) {
-      KCHECK(daliamdJpegHuffmanRunColor(ws.stream, reinterpret_cast<const daliamdJpegHuffDesc *>(dev_base + huff_off), ngpu,
-                                        ntiles, nsegs, nbwg, block_kernels));
+      if (side)
+        KCHECK(daliamdJpegHuffmanRunBack(ws.stream, reinterpret_cast<const daliamdJpegHuffDesc *>(dev_base + huff_off), ngpu,
+                                         ntiles, nsegs, nbwg, block_kernels));
+      else
+        KCHECK(daliamdJpegHuffmanRunColor(ws.stream, reinterpret_cast<const daliamdJpegHuffDesc *>(dev_base + huff_off), ngpu,
+                                          ntiles, nsegs, nbwg, block_kernels));
       NoteLaunch(ws, "jpeg_huffman");
       if (block_kernels & DALIAMD_JPEG_HUFFMAN_INDEXED) NoteLaunch(ws, "jpeg_huffman_indexed");   // (streams decoded from their index)
     }
@@ -728,7 +748,8 @@ class ImageDecoderMixed : public OperatorBase {
   std::vector<uint8_t> hit_, raster_;
   std::vector<int32_t> raster_hw_;
   std::vector<ImageCache::Entry> cached_;
-  std::vector<daliamdEvent_t> h2d_done_;
+  std::vector<daliamdEvent_t> h2d_done_, front_done_;
+  bool keep_front_on_compute_ = false;   // DALI_AMD_DECODER_FRONT_ON_SIDE_STREAM=0
   bool adjust_orientation_;
   bool host_huffman_only_ = false;
   int64_t huffman_threshold_ = 0;

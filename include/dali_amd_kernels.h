@@ -266,6 +266,15 @@ DALIAMD_API daliamdResult_t daliamdJpegHuffmanSetupColor(daliamdJpegHuffDesc *de
 DALIAMD_API daliamdResult_t daliamdJpegHuffmanRunColor(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev, int n,
                                                        int num_tiles, int num_segments, int num_block_workgroups,
                                                        int block_kernels);
+/* daliamdJpegHuffmanRunColor in two halves.  The front (code tables of the streams that do not bring them, un-stuffing) needs
+ * the descriptor table and the streams' bytes on the device and nothing else: it may run on a side stream while `stream` is
+ * still busy with the previous batch, the back (everything else) then waits for it through an event of the caller's. */
+DALIAMD_API daliamdResult_t daliamdJpegHuffmanRunFront(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev, int n,
+                                                       int num_tiles, int num_segments, int num_block_workgroups,
+                                                       int block_kernels);
+DALIAMD_API daliamdResult_t daliamdJpegHuffmanRunBack(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev, int n,
+                                                      int num_tiles, int num_segments, int num_block_workgroups,
+                                                      int block_kernels);
 #define DALIAMD_JPEG_HUFFMAN_KERNELS 6
 DALIAMD_API daliamdResult_t daliamdJpegHuffmanRunProfiled(daliamdStream_t stream, const daliamdJpegHuffDesc *descs_dev,
                                                           int n, int num_tiles, int num_segments,
