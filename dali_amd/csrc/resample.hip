@@ -93,7 +93,19 @@ __device__ __forceinline__ int ClampI(int v, int lo, int hi) { return min(max(v,
 // u8 rounding of the reference's two code paths: half-to-even (the SIMD body: cvtps with the default rounding mode) or
 // half-away-from-zero (ConvertSat in the scalar tails); NaN and negatives -> 0.  Both from one round-to-nearest-even:
 // it differs from half-away only at a tie that was rounded DOWN, where clamped - rounded is exactly +0.5.
-__device__ __forceinline__ uint32_t RoundU8(float v, bool half_even) {
+// half-to-even only (the common tile: every column in a SIMD body): one instruction - v_cvt_pk_u8_f32 converts with the
+// current rounding mode (nearest even) and saturates to 0..255 (NaN -> 0); the clamp + rint + convert above cost four
+__device__ __forceinline__ uint32_t RoundU8Even(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_cvt_pk_u8_f32(v, 0u, 0u);
+#else
+  const float c = fminf(fmaxf(v, 0.0f), 255.0f);
+  return (uint32_t)rintf(c);
+#endif
+}
+__device__ __forceinline__ uint32_t RoundU8Slow(float v, bool half_even);
+__device__ __forceinline__ uint32_t RoundU8(float v, bool half_even) { return RoundU8Slow(v, half_even); }
+__device__ __forceinline__ uint32_t RoundU8Slow(float v, bool half_even) {
   const float c = fminf(fmaxf(v, 0.0f), 255.0f);  // NaN -> 0 (fmaxf returns the non-NaN operand)
   float r = rintf(c);
   if (!half_even && c - r == 0.5f) r += 1.0f;
@@ -216,7 +228,10 @@ using GBytes = const uint8_t __attribute__((address_space(1)));
 // so that the staging loads can be issued after ONE dependent memory round trip (the record) instead of four
 // (descriptor index -> descriptor -> first taps of the tile's corners -> window).
 struct TileRec {
-  uint64_t win, buf_lo, buf_hi, tab;   // window origin, source buffer bounds, the sample's tables
+  uint64_t win, out, tab;   // window origin, the sample's output, the sample's tables
+  // what the epilogue needs to know (round 5: in the record, so that the common path - fp16 CHW through the look-up table -
+  // never waits for the descriptor behind desc_idx): bit 0 mirror, bit 1 CHW, bit 2 normalize, bits 4-7 output type
+  uint32_t epi, reserved;
   int32_t pitch, nrows, NB, LP;
   int32_t x_lo, y_lo, tmp_bytes, desc_idx;
   int32_t ox0, oy0, tw, th;
@@ -288,8 +303,10 @@ __device__ void MakeTileRec(const daliamdResampleDesc *descs, int ndesc, int til
   const int NB = ncols * C, LP = StagedRowPitch(NB);
   const bool vfirst = d.first_axis == 1, staged = d.staged != 0;
   r.win = reinterpret_cast<uint64_t>(d.in + (size_t)(d.lo[1] + y_lo) * d.in_pitch + (size_t)(d.lo[0] + x_lo) * C);
-  r.buf_lo = reinterpret_cast<uint64_t>(d.in);
-  r.buf_hi = r.buf_lo + (size_t)d.in_h * d.in_pitch;
+  const uint64_t buf_lo = reinterpret_cast<uint64_t>(d.in), buf_hi = buf_lo + (size_t)d.in_h * d.in_pitch;
+  r.out = reinterpret_cast<uint64_t>(d.out);
+  r.epi = (d.mirror ? 1u : 0u) | (d.out_layout == DALIAMD_LAYOUT_CHW ? 2u : 0u) | (d.normalize ? 4u : 0u) | ((uint32_t)d.out_dtype << 4);
+  r.reserved = 0;
   r.tab = reinterpret_cast<uint64_t>(workspace + d.table_off);
   r.pitch = d.in_pitch; r.nrows = nrows; r.NB = NB; r.LP = LP;
   r.x_lo = x_lo; r.y_lo = y_lo;
@@ -301,7 +318,7 @@ __device__ void MakeTileRec(const daliamdResampleDesc *descs, int ndesc, int til
   const bool prefetch = staged && NB <= 241 - 15 && nrows <= 16 * kPrefetchChunks && TW * sup_x <= kResampleThreads &&
                         TH * sup_y <= kResampleThreads && d.in_pitch < (1 << 23);
   // every 16-byte chunk of every window row lies inside the source buffer: no per-chunk bounds checks
-  const bool in_bounds = r.win >= r.buf_lo + 16 && r.win + (uint64_t)(nrows - 1) * d.in_pitch + NB + 32 <= r.buf_hi;
+  const bool in_bounds = r.win >= buf_lo + 16 && r.win + (uint64_t)(nrows - 1) * d.in_pitch + NB + 32 <= buf_hi;
   r.flags = (vfirst ? kRecVFirst : 0) | (staged ? kRecStaged : 0) | (d.use_lut ? kRecUseLut : 0) | (prefetch ? kRecPrefetch : 0) |
             (in_bounds ? kRecInBounds : 0);
   r.channels = C; r.rowlen = tw * C;
@@ -392,7 +409,7 @@ __device__ __forceinline__ uint4 LoadChunk(uintptr_t g, uintptr_t buf_lo, uintpt
   return make_uint4(w0, w1, w2, w3);
 }
 
-__device__ __forceinline__ void FetchTile(const TileRec &r, int tid, TilePrefetch &p) {
+__device__ __forceinline__ void FetchTile(const TileRec &r, const daliamdResampleDesc *descs, int tid, TilePrefetch &p) {
   if (!(r.flags & kRecPrefetch)) return;
   if (r.flags & kRecInBounds) {
     // 32-bit offsets from a uniform base (16 bytes in front of the window, so that they stay non-negative)
@@ -413,13 +430,16 @@ __device__ __forceinline__ void FetchTile(const TileRec &r, int tid, TilePrefetc
       }
     }
   } else {
+    // (a window at the edge of its buffer: the bounds come from the descriptor - the rare path pays the round trip)
+    const daliamdResampleDesc &d = descs[r.desc_idx];
+    const uintptr_t buf_lo = (uintptr_t)d.in, buf_hi = buf_lo + (size_t)d.in_h * d.in_pitch;
 #pragma unroll
     for (int i = 0; i < kPrefetchChunks; i++) {
       const int row = (tid >> 4) + 16 * i, q = tid & 15;
       if (row < r.nrows) {
         const uintptr_t ra = (uintptr_t)r.win + (size_t)row * r.pitch;
         const int sh = (int)(ra & 15);
-        if (q < ((sh + r.NB + 15) >> 4)) p.chunk[i] = LoadChunk(ra - sh + 16 * q, (uintptr_t)r.buf_lo, (uintptr_t)r.buf_hi);
+        if (q < ((sh + r.NB + 15) >> 4)) p.chunk[i] = LoadChunk(ra - sh + 16 * q, buf_lo, buf_hi);
       }
     }
   }
@@ -520,7 +540,7 @@ __global__ __launch_bounds__(kResampleThreads) __attribute__((amdgpu_waves_per_e
   int lut_desc = -1;
 
   TilePrefetch pf;
-  FetchTile(recs[t_begin], tid, pf);
+  FetchTile(recs[t_begin], descs, tid, pf);
   for (int tile = t_begin; tile < t_end; tile++) {
     // (re-read rather than carried over from the previous round: two live records are 64 scalar registers, and the
     // second read of a record comes from the scalar cache)
@@ -606,7 +626,8 @@ __global__ __launch_bounds__(kResampleThreads) __attribute__((amdgpu_waves_per_e
           const uintptr_t ra = win_addr + (size_t)row * pitch;
           const int sh = (int)(ra & 15), nch = (sh + NB + 15) >> 4;
           for (int q = tid & 15; q < nch; q += 16)
-            *reinterpret_cast<uint4 *>(stage + row * LP + 16 * q) = LoadChunk(ra - sh + 16 * q, (uintptr_t)r.buf_lo, (uintptr_t)r.buf_hi);
+            *reinterpret_cast<uint4 *>(stage + row * LP + 16 * q) =
+                LoadChunk(ra - sh + 16 * q, (uintptr_t)d.in, (uintptr_t)d.in + (size_t)d.in_h * d.in_pitch);
         }
       }
     }
@@ -618,20 +639,24 @@ __global__ __launch_bounds__(kResampleThreads) __attribute__((amdgpu_waves_per_e
       lut_desc = r.desc_idx;
     }
     // ---- the next tile's record and loads: in flight during this tile's passes ----
-    if (tile + 1 < t_end) FetchTile(recs[tile + 1], tid, pf);
+    if (tile + 1 < t_end) FetchTile(recs[tile + 1], descs, tid, pf);
     LdsBarrier();
 
     Epilogue ep;
-    ep.out = d.out; ep.out_h = d.out_h; ep.out_w = d.out_w; ep.channels = C;
-    ep.dtype = d.out_dtype; ep.layout = d.out_layout; ep.normalize = d.normalize; ep.mirror = d.mirror;
+    ep.out = (void *)(uintptr_t)r.out; ep.out_h = r.out_h; ep.out_w = r.out_w; ep.channels = C;
+    ep.dtype = (int)(r.epi >> 4); ep.layout = (r.epi & 2u) ? DALIAMD_LAYOUT_CHW : DALIAMD_LAYOUT_HWC;
+    ep.normalize = (r.epi & 4u) != 0; ep.mirror = (r.epi & 1u) != 0;
     ep.lut = use_lut ? lut : nullptr;
-    const float mean0 = d.mean[0], mean1 = d.mean[1], mean2 = d.mean[2], mean3 = d.mean[3];
-    const float inv0 = d.inv_std[0], inv1 = d.inv_std[1], inv2 = d.inv_std[2], inv3 = d.inv_std[3];
+    // (with the look-up table nobody needs these: the descriptor is then not read at all on the common path)
+    float mean0 = 0, mean1 = 0, mean2 = 0, mean3 = 0, inv0 = 1, inv1 = 1, inv2 = 1, inv3 = 1;
+    if (!use_lut) {
+      mean0 = d.mean[0]; mean1 = d.mean[1]; mean2 = d.mean[2]; mean3 = d.mean[3];
+      inv0 = d.inv_std[0]; inv1 = d.inv_std[1]; inv2 = d.inv_std[2]; inv3 = d.inv_std[3];
+    }
     GBytes *gwin = (GBytes *)win_addr;  // source rows when the window is not staged
     // the second pass two pixels per thread (packed multiply / add, one dword store per channel plane): the common
     // fused case - three channels into an fp16 CHW batch of even width
-    const bool pair = C == 3 && use_lut && d.out_layout == DALIAMD_LAYOUT_CHW && (r.out_w & 1) == 0 && TW >= 2 &&
-                      ((uintptr_t)d.out & 3) == 0;
+    const bool pair = C == 3 && use_lut && (r.epi & 2u) && (r.out_w & 1) == 0 && TW >= 2 && (r.out & 3) == 0;
     const int hw_log2 = tw_log2 - 1;
 
     if (vfirst) {
@@ -685,8 +710,8 @@ __global__ __launch_bounds__(kResampleThreads) __attribute__((amdgpu_waves_per_e
               a2 += w * floatx2{p[2], q[2]};
             }
             if (tile_even)   // (uniform) the usual case: every column of the tile rounds half-to-even
-              ep.StorePair(oy0 + y, gx, RoundU8(a0.x, true), RoundU8(a0.y, true), RoundU8(a1.x, true), RoundU8(a1.y, true),
-                           RoundU8(a2.x, true), RoundU8(a2.y, true));
+              ep.StorePair(oy0 + y, gx, RoundU8Even(a0.x), RoundU8Even(a0.y), RoundU8Even(a1.x), RoundU8Even(a1.y),
+                           RoundU8Even(a2.x), RoundU8Even(a2.y));
             else
               ep.StorePair(oy0 + y, gx, RoundU8(a0.x, even0), RoundU8(a0.y, even1), RoundU8(a1.x, even0), RoundU8(a1.y, even1),
                            RoundU8(a2.x, even0), RoundU8(a2.y, even1));
@@ -787,7 +812,7 @@ __global__ __launch_bounds__(kResampleThreads) __attribute__((amdgpu_waves_per_e
         }
       }
       LdsBarrier();
-      const int flat_w = d.out_w * C;
+      const int flat_w = r.out_w * C;
 #define VLAST_EVEN(f) ((f) < ((f) & ~255) + ((min(((f) & ~255) + 256, flat_w) - ((f) & ~255)) & ~15))
       if (pair) {
         const int x2 = (tid & ((TW >> 1) - 1)) * 2;
@@ -812,8 +837,8 @@ __global__ __launch_bounds__(kResampleThreads) __attribute__((amdgpu_waves_per_e
               a45 += p[2] * w;
             }
             if (!(flat_w & 15))
-              ep.StorePair(oy0 + y, ox0 + x2, RoundU8(a01.x, true), RoundU8(a23.y, true), RoundU8(a01.y, true),
-                           RoundU8(a45.x, true), RoundU8(a23.x, true), RoundU8(a45.y, true));
+              ep.StorePair(oy0 + y, ox0 + x2, RoundU8Even(a01.x), RoundU8Even(a23.y), RoundU8Even(a01.y),
+                           RoundU8Even(a45.x), RoundU8Even(a23.x), RoundU8Even(a45.y));
             else
               ep.StorePair(oy0 + y, ox0 + x2, RoundU8(a01.x, e0), RoundU8(a23.y, e3), RoundU8(a01.y, e1), RoundU8(a45.x, e4),
                            RoundU8(a23.x, e2), RoundU8(a45.y, e5));
