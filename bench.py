@@ -524,7 +524,7 @@ def run_resident_pipeline(args, root, enc_all, device, dev_index, rank, world, l
     stats = batch_statistics([enc_all[b * B:(b + 1) * B] for b in range(nb)], device)
     # (one cache per device AND process: twice the shard's file bytes is room to spare for its entropy-coded segments)
     pipe = resident_pipeline(root, B, dev_index, depth, threads, shard_id=rank, num_shards=world,
-                             cache_mb=max(64, int(2 * sum(len(e) for e in enc_all) / 2**20)))
+                             cache_mb=max(64, int(2.2 * sum(len(e) for e in enc_all) / 2**20)), cache_type=args.cache_type)
     # ---- set-up, untimed: epochs until the shard is resident, then until the reader (which runs ahead of the decoder)
     # has stopped reading files and every ring slot has seen every distinct batch
     done = 0
@@ -1071,6 +1071,10 @@ def main():
                     help="pipeline (default): the headline is timed through dali_amd.Pipeline, the product's C++ executor, "
                          "on a data set resident in HBM as encoded streams; python: the kernel library driven from "
                          "dali_amd/backend.py (kernel experiments: --huffman host, --no-fused-idct)")
+    ap.add_argument("--cache-type", default="encoded", choices=["encoded", "indexed"],
+                    help="how the timed streams are resident (decoders.image cache_type): encoded = as they are in the file, every "
+                         "epoch parses them anew - the meaning of `value` in every round; indexed = with the side information of "
+                         "their first decode (profiling aid: the default run reports that rate as config.resident_indexed_images_per_s)")
     ap.add_argument("--workload", default="imagenet", choices=["imagenet", "heavy_aug", "audio", "cpu"],
                     help="imagenet = the headline metric (default); heavy_aug / audio = configs[2] / configs[3] side benches; "
                          "cpu = configs[0], the train pipe on the CPU backend (no GPU needed)")
@@ -1148,6 +1152,7 @@ def main():
         # the block kernel with the fused colour output: stream + per-block position / level in, RGB out (no planes)
         algo["BlockColorKernel"] = algo["BlockKernel"] - coef_elems_mean + 3 * pixels_mean
         algo["SeamKernel"] = 0.0
+        algo["IndexedSyncKernel"] = stream_bytes + 8 * coef_elems_mean / 64   # stream in (the needed slices at most), 8 B per block out
         algo["ResampleKernel"] = r["resample_bytes"]
         algo["ResampleTablesKernel"] = 0.0
         if r["roi"]:
@@ -1182,7 +1187,7 @@ def main():
             # ONE batch in flight: per-kernel durations without another batch's kernels on the same CUs - what a kernel
             # costs, as opposed to how long it lasts inside the overlapped schedule of the timed region above
             pipe1 = resident_pipeline(root, B, dev_index, 1, r["threads"], shard_id=rank, num_shards=world,
-                                      cache_mb=max(64, int(2 * sum(len(e) for e in enc_all) / 2**20)))
+                                      cache_mb=max(64, int(2.2 * sum(len(e) for e in enc_all) / 2**20)), cache_type=args.cache_type)
             for _ in range(3 * nb):
                 pipe1.run()
             torch.cuda.synchronize()
@@ -1197,7 +1202,8 @@ def main():
             # the same resident streams through the fused ROI decoder (what NVIDIA's own decoder benchmark times,
             # hw_decoder_bench.py:178-188): informational, never `value`
             pipe2 = resident_pipeline(root, B, dev_index, r["depth"], r["threads"],
-                                      cache_mb=max(64, int(2 * sum(len(e) for e in enc_all) / 2**20)), roi_decode=True)
+                                      cache_mb=max(64, int(2.2 * sum(len(e) for e in enc_all) / 2**20)), roi_decode=True,
+                                      cache_type=args.cache_type)
             for _ in range((r["depth"] + 2) * nb + args.warmup):
                 pipe2.run()
             torch.cuda.synchronize()
@@ -1217,7 +1223,8 @@ def main():
             if r["roi"]:
                 # ... and the headline graph with the fusion switched off: every image decoded whole, as in rounds 1-3
                 pipe3 = resident_pipeline(root, B, dev_index, r["depth"], r["threads"],
-                                          cache_mb=max(64, int(2 * sum(len(e) for e in enc_all) / 2**20)), roi_fusion=False)
+                                          cache_mb=max(64, int(2.2 * sum(len(e) for e in enc_all) / 2**20)), roi_fusion=False,
+                                          cache_type=args.cache_type)
                 for _ in range((r["depth"] + 2) * nb + args.warmup):
                     pipe3.run()
                 torch.cuda.synchronize()
@@ -1332,7 +1339,8 @@ def main():
                        "pixels_per_batch": pixels_mean, "driver": args.driver,
                        # the executor decodes only the windows the random_resized_crop draws (bit-identical batch; details
                        # and the full-decode rate of the same graph under config.pipeline)
-                       "roi_decode_fusion": bool(pipe_info and pipe_info.get("roi_decode_fusion"))},
+                       "roi_decode_fusion": bool(pipe_info and pipe_info.get("roi_decode_fusion")),
+                       "cache_type": args.cache_type},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "measured_copy_ceiling_GBps": copy_ceiling, "frac_of_measured_ceiling": ach / copy_ceiling,
@@ -1374,7 +1382,7 @@ def main():
     import gc
     gc.collect()          # the headline pipeline (and with it the encoded-stream cache of the device) goes away here
     torch.cuda.empty_cache()
-    if have_pipe_info and world == 1 and not args.no_e2e and rank == 0:
+    if have_pipe_info and world == 1 and not args.no_e2e and rank == 0 and args.cache_type == "encoded":
         # Round 5: the same graph, the same streams, resident WITH their side information (cache_type="indexed": un-stuffed
         # bytes + 12 bytes of decoder state per 256-byte slice, left behind by the first decode).  `value` keeps its meaning
         # (streams resident as they are in the file, every epoch parses them anew); this is the rate when the epoch-invariant

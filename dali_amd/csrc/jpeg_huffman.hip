@@ -465,14 +465,25 @@ __global__ __launch_bounds__(kTileThreads) void UnstuffScatterKernel(const dalia
 }
 
 // ------------------------------------------------------------------------------------------------ tables
+// `count` 16-byte chunks from global memory to LDS.  The loads of a thread are issued TOGETHER (up to 9 in flight), then
+// stored: the loop "load, wait, store" this replaces paid one memory round trip per chunk - nine in a row for the 36 KB of
+// the position passes' tables, 4-5 us at the start of every one of their 500 workgroups (round 5, from the ISA listing).
+template <int THREADS>
+__device__ __forceinline__ void CopyChunks(uint4 *t, const GlobalQuad *s, int count) {
+  constexpr int kInFlight = 9;
+  for (int i0 = threadIdx.x; i0 < count; i0 += THREADS * kInFlight) {
+    u32x4 v[kInFlight];
+#pragma unroll
+    for (int k = 0; k < kInFlight; k++)
+      if (i0 + k * THREADS < count) v[k] = s[i0 + k * THREADS];
+#pragma unroll
+    for (int k = 0; k < kInFlight; k++)
+      if (i0 + k * THREADS < count) t[i0 + k * THREADS] = make_uint4(v[k].x, v[k].y, v[k].z, v[k].w);
+  }
+}
 template <int THREADS, typename Tables>
 __device__ __forceinline__ void CopyTables(Tables &dst, const Tables *src) {
-  const GlobalQuad *s = (const GlobalQuad *)src;
-  uint4 *t = reinterpret_cast<uint4 *>(&dst);
-  for (int i = threadIdx.x; i < (int)(sizeof(Tables) / 16); i += THREADS) {
-    const u32x4 v = s[i];
-    t[i] = make_uint4(v.x, v.y, v.z, v.w);
-  }
+  CopyChunks<THREADS>(reinterpret_cast<uint4 *>(&dst), (const GlobalQuad *)src, (int)(sizeof(Tables) / 16));
 }
 
 // Code tables of one stream (all threads of a PrepareKernel workgroup); every entry is found independently
@@ -862,19 +873,10 @@ struct HalfTables {
 template <int THREADS>
 __device__ __forceinline__ void CopyHalfTables(HalfTables &T, const HuffTables *H, int first) {
   const int tid = threadIdx.x;
-  const GlobalQuad *s = (const GlobalQuad *)&H->fast[first][0];
-  uint4 *t = reinterpret_cast<uint4 *>(&T.fast[0][0]);
-  for (int i = tid; i < (int)(sizeof(T.fast) / 16); i += THREADS) {
-    const u32x4 v = s[i];
-    t[i] = make_uint4(v.x, v.y, v.z, v.w);
-  }
-  s = (const GlobalQuad *)&H->l2[first][0];
-  t = reinterpret_cast<uint4 *>(&T.l2[0][0]);
-  for (int i = tid; i < (int)(sizeof(T.l2) / 16); i += THREADS) {
-    const u32x4 v = s[i];
-    t[i] = make_uint4(v.x, v.y, v.z, v.w);
-  }
-  for (int i = tid; i < 2 * 256; i += THREADS) T.vals[i >> 8][i & 255] = H->vals[first + (i >> 8)][i & 255];
+  CopyChunks<THREADS>(reinterpret_cast<uint4 *>(&T.fast[0][0]), (const GlobalQuad *)&H->fast[first][0], (int)(sizeof(T.fast) / 16));
+  CopyChunks<THREADS>(reinterpret_cast<uint4 *>(&T.l2[0][0]), (const GlobalQuad *)&H->l2[first][0], (int)(sizeof(T.l2) / 16));
+  // (vals[first .. first + 1] are 512 contiguous bytes in both structures)
+  CopyChunks<THREADS>(reinterpret_cast<uint4 *>(&T.vals[0][0]), (const GlobalQuad *)&H->vals[first][0], (int)(sizeof(T.vals) / 16));
   if (tid < 36) {
     T.maxcode[tid / 18][tid % 18] = H->maxcode[first + tid / 18][tid % 18];
     T.valoff[tid / 18][tid % 18] = H->valoff[first + tid / 18][tid % 18];
