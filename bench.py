@@ -90,7 +90,7 @@ def measured_traffic(kernel, workload=""):
     cannot run rocprofv3 around itself, so this is the figure of the profiled run of this same command."""
     import glob
     files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", f"*{workload}_traffic.json"))
-                   if workload or not any(w in os.path.basename(f) for w in ("heavy_aug", "audio")))
+                   if workload or not any(w in os.path.basename(f) for w in ("heavy_aug", "audio", "indexed", "normalize", "fused_colour")))
     if not files:
         return None, None
     try:
@@ -1307,7 +1307,7 @@ def main():
         del paths, step_paths, hp
     dominant = max(kern, key=lambda k: kern[k][1])
     ach = kern[dominant][0] / (kern[dominant][1] * 1e-3) / 1e9
-    traffic, traffic_src = measured_traffic(dominant)
+    traffic, traffic_src = measured_traffic(dominant, "indexed" if args.cache_type == "indexed" else "")
 
     line = None
     if rank == 0:

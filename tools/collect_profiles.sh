@@ -12,12 +12,14 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 SUM=$R/gpurun_out/${TAG}_summary
 mkdir -p $SUM
 cd /tmp && export TMPDIR=/tmp
-for W in ${WORKLOADS:-headline heavy_aug audio normalize}; do
+for W in ${WORKLOADS:-headline indexed heavy_aug audio normalize}; do
   OUT=$R/gpurun_out/prof_$TAG/$W
   mkdir -p $OUT
   CMD="python $R/bench.py"
   if [ $W = headline ]; then
     ARGS="--steps 40 --warmup 3 --no-cpu-baseline --no-e2e --no-side-legs"; PMCARGS="--steps 5 --warmup 1 --no-cpu-baseline --no-e2e --no-side-legs --inflight 1"; SUF=""
+  elif [ $W = indexed ]; then     # the headline graph on streams resident WITH their side information (cache_type="indexed")
+    ARGS="--cache-type indexed --steps 40 --warmup 3 --no-cpu-baseline --no-e2e --no-side-legs"; PMCARGS="--cache-type indexed --steps 5 --warmup 1 --no-cpu-baseline --no-e2e --no-side-legs --inflight 1"; SUF="_indexed"
   elif [ $W = normalize ]; then   # fn.normalize (wave64 mean / stddev reductions) + the stand-alone CropMirrorNormalize kernel
     CMD="python $R/tools/normalize_prof.py"; ARGS="20"; PMCARGS="5"; SUF="_$W"
   else
@@ -30,6 +32,8 @@ for W in ${WORKLOADS:-headline heavy_aug audio normalize}; do
   python $R/tools/summarize_profiles.py $OUT $TAG$SUF $SUM || { echo "collect_profiles: $W summary FAILED"; tail -5 $OUT/*.log; FAILED=1; }
   if [ $W = normalize ]; then
     (cd $R && timeout 300 python tools/normalize_prof.py 2>/dev/null | tail -1 > $SUM/${TAG}_${W}_bench.json)
+  elif [ $W = indexed ]; then
+    (cd $R && timeout 300 python bench.py --cache-type indexed --no-e2e --no-cpu-baseline 2>/dev/null | tail -1 > $SUM/${TAG}_${W}_bench.json)
   elif [ $W != headline ]; then
     (cd $R && timeout 300 python bench.py --workload $W 2>/dev/null | tail -1 > $SUM/${TAG}_${W}_bench.json)
   fi
