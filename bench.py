@@ -593,6 +593,7 @@ def run_resident_pipeline(args, root, enc_all, device, dev_index, rank, world, l
             a, c = np.asarray(anchors, np.int64), np.asarray(crops, np.int64)
             reach = np.ceil(np.maximum(c / 224.0, 1.0)).astype(np.int64) + 2
             lo, hi = np.maximum(a - reach, 0), np.minimum(a + c + reach, shp)
+            lo = lo // np.array([2, 8]) * np.array([2, 8])      # (windows start on the colour kernel's grid: DrawWindows)
             win_px.append(float(((hi - lo)[:, 0] * (hi - lo)[:, 1]).sum()))
             m_lo, m_hi, m_all = lo // 16, -(-hi // 16), -(-shp // 16)
             rect_blocks.append(float(((m_hi - m_lo)[:, 0] * (m_hi - m_lo)[:, 1]).sum()))

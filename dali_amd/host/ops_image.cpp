@@ -1497,7 +1497,13 @@ class RandomResizedCropGpu : public OperatorBase {
         const float per_unit = type == DALIAMD_INTERP_LANCZOS3 ? 3.0f : type == DALIAMD_INTERP_CUBIC ? 2.0f : 1.0f;
         const float ratio = filters_.antialias && crop > out[a] ? (float)crop / (float)out[a] : 1.0f;
         const int reach = (int)std::ceil(per_unit * ratio) + 2;
-        const int lo = std::max(0, anchor - reach), hi = std::min(size, anchor + crop + reach);
+        // The window starts on the colour kernel's grid - a multiple of 8 columns, an even row -: every upright sample then
+        // takes its planes-aligned fast path, ONE launch per batch where windows that start anywhere need up to three
+        // (row-by-row instance for 4:4:4 / 4:2:2 / gray samples, any-origin 4:2:0 instance, aligned instance: 0.18 ms of
+        // mostly idle launches inside the schedule, profiles/r05_kernel_stats.csv).  At most 7 more columns are converted;
+        // the value passes work on whole MCUs anyway.
+        const int grid = a == 1 ? 8 : 2;
+        const int lo = std::max(0, anchor - reach) / grid * grid, hi = std::min(size, anchor + crop + reach);
         d.window[4 * i + a] = lo; d.window[4 * i + 2 + a] = hi - lo;
         rois[4 * i + a] = lo; rois[4 * i + 2 + a] = hi - lo;
       }
