@@ -1541,7 +1541,7 @@ def main():
             # run, each with its own roofline and oracle cpu_baseline (same cores, same run)
             import gc
             gc.collect()
-            side_steps = max(10, min(args.steps, 100))
+            side_steps = max(60, min(args.steps, 100))   # (a 20-step region from an idle GPU is half ramp-up for these legs: 155 k against 240 k)
             for key, leg in (("heavy_aug", bench_heavy_aug), ("audio", bench_audio)):
                 try:
                     line[key] = leg(args, device, steps=side_steps, cpu_seconds=6.0)
