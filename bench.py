@@ -1153,6 +1153,7 @@ def main():
         # the block kernel with the fused colour output: stream + per-block position / level in, RGB out (no planes)
         algo["BlockColorKernel"] = algo["BlockKernel"] - coef_elems_mean + 3 * pixels_mean
         algo["SeamKernel"] = 0.0
+        algo["PrepareKernel"] = stream_bytes   # (round 5: the code tables come from the host, built once per DHT set - the launch only counts the tiles' kept bytes)
         algo["IndexedSyncKernel"] = stream_bytes + 8 * coef_elems_mean / 64   # stream in (the needed slices at most), 8 B per block out
         algo["ResampleKernel"] = r["resample_bytes"]
         algo["ResampleTablesKernel"] = 0.0
