@@ -154,10 +154,11 @@ class ImageDecoderMixed : public OperatorBase {
     for (auto e : front_done_)
       if (e) daliamdEventDestroy(e);
     if (trace_ && trace_runs_ > 0) {
-      static const char *names[] = {"parse + scan analysis + staging copy (thread pool)", "layout, windows, allocation",
+      static const char *names[] = {"parse + scan analysis + staging copy (thread pool)", "layout: plans, scratch sizes",
                                     "host entropy decode of the other streams", "descriptor tables",
-                                    "transfer + kernel launches"};
-      for (int i = 0; i < 5; i++)
+                                    "transfer + kernel launches", "layout: windows (the consumer's draw)",
+                                    "layout: buffers, output resize"};
+      for (int i = 0; i < 7; i++)
         fprintf(stderr, "[dali_amd trace]     decoder: %-52s %8.3f ms\n", names[i], 1e3 * trace_s_[i] / trace_runs_);
     }
   }
@@ -315,7 +316,9 @@ class ImageDecoderMixed : public OperatorBase {
       if (raster_[i]) { upright_hw_[2 * i] = raster_hw_[2 * i]; upright_hw_[2 * i + 1] = raster_hw_[2 * i + 1]; }
     }
     rois_.assign(4 * n, 0);
+    lap(1);
     ComputeRois(ws, n);
+    lap(5);
     // Windows drawn for this iteration belong to it: when the decode fails on the way out (a corrupt stream met by a host
     // decoder, an oversized segment, a kernel-library error) the consumer never runs for this iteration, so the draw is
     // taken back - the next iteration then gets the windows it would have got without the fusion
@@ -381,6 +384,7 @@ class ImageDecoderMixed : public OperatorBase {
       }
     }
     const int ngpu = (int)gpu_samples_.size();
+    lap(1);
     Buffer &stage = *staging_[slot], &cdev = *coef_dev_[slot], &planes = *planes_[slot];
     Buffer &ecs_dev = *ecs_dev_[slot], &scratch = *scratch_[slot];
     Buffer &status_host = *status_host_[slot];
@@ -406,7 +410,7 @@ class ImageDecoderMixed : public OperatorBase {
     out.SetLayout("HWC");
     out.source_info = in.source_info;
     quant_.assign((size_t)n * 3 * 64, 0);
-    lap(1);
+    lap(6);
     // ---- host entropy decode of the streams the GPU kernel does not take (thread pool) ----
     int16_t *coef_host = static_cast<int16_t *>(stage.data());
     for (int i = 0; i < n; i++) {
@@ -486,7 +490,9 @@ class ImageDecoderMixed : public OperatorBase {
     daliamdJpegHuffDesc *huff = reinterpret_cast<daliamdJpegHuffDesc *>(tab_host);
     daliamdJpegIdctDesc *idct = reinterpret_cast<daliamdJpegIdctDesc *>(tab_host + (idct_off - huff_off));
     daliamdJpegColorDesc *color = reinterpret_cast<daliamdJpegColorDesc *>(tab_host + (color_off - huff_off));
-    memset(tab_host, 0, upload_bytes - huff_off);
+    // (the Huffman descriptors are cleared one by one below - around the 1 088 bytes of DHT contents a stream with finished
+    // code tables neither fills nor reads -, the other two tables here)
+    memset(tab_host + (idct_off - huff_off), 0, upload_bytes - idct_off);
     int ntiles = 0, nsegs = 0, nbwg = 0, block_kernels = 0;
     fused_color_.assign(n, 0);
     // encoded-stream cache: the streams of this batch that the cache has room for become resident - as they are (one
@@ -521,10 +527,17 @@ class ImageDecoderMixed : public OperatorBase {
         const auto &inf = infos_[i];
         const auto &sc = scan(i);
         auto &d = huff[j];
+        // finished code tables of the stream's table set, when the store keeps them (else: built inside the launch)
+        const uint8_t *tables = erec_[i] ? erec_[i]->tables : HuffTableStore::Get(device_id_, sc);
+        {
+          constexpr size_t dht0 = offsetof(daliamdJpegHuffDesc, bits), dht1 = offsetof(daliamdJpegHuffDesc, rect);
+          uint8_t *raw = reinterpret_cast<uint8_t *>(&d);
+          memset(raw, 0, tables ? dht0 : dht1);
+          memset(raw + dht1, 0, sizeof(d) - dht1);
+        }
+        d.tables = tables;
         d.ecs = erec_[i] ? erec_[i]->ecs : dev_base + ecs_off_[i] + (direct ? (size_t)sc.ecs_offset : 0);
         d.index = erec_[i] ? erec_[i]->index : nullptr;   // a resident stream with its side information: decoded from that
-        // finished code tables of the stream's table set, when the store keeps them (else: built inside the launch)
-        d.tables = erec_[i] ? erec_[i]->tables : HuffTableStore::Get(device_id_, sc);
         d.scratch = static_cast<uint8_t *>(scratch.data()) + scratch_off_[i];
         d.status = status + j;
         d.ecs_len = (int32_t)sc.ecs_length;
@@ -561,7 +574,7 @@ class ImageDecoderMixed : public OperatorBase {
           d.height = inf.height;
           fused_color_[i] = 1;
         }
-        for (int t = 0; t < 2; t++) {
+        for (int t = 0; t < 2 && !tables; t++) {   // (nobody reads the DHT contents of a stream that brings its tables)
           memcpy(d.bits[t], sc.dc_bits[t], 16);
           memcpy(d.bits[2 + t], sc.ac_bits[t], 16);
           memcpy(d.vals[t], sc.dc_vals[t], 256);
@@ -571,13 +584,22 @@ class ImageDecoderMixed : public OperatorBase {
       for (auto &k : keep)
         if (k.indexed) huff[k.j].index_out = k.slot;
       KCHECK(daliamdJpegHuffmanSetupColor(huff, ngpu, &ntiles, &nsegs, &nbwg, &block_kernels));
-      // the status words are valid once the iteration has finished: checked when its outputs are handed over
-      std::vector<std::string> names(ngpu);
-      for (int j = 0; j < ngpu; j++) names[j] = src(gpu_samples_[j]);
+      // the status words are valid once the iteration has finished: checked when its outputs are handed over.  (The
+      // samples' names are looked up only when a word is set: the input of this iteration - a ring slot that is not written
+      // again before the iteration has been handed out - is kept instead of 256 copied strings per batch.)
       const int32_t *st = status;
       std::shared_ptr<ImageCache> cache = cache_;
       std::shared_ptr<StreamCache> scache = stream_cache_;
-      ws.AddCompletionCheck([st, names, cache, scache] {
+      std::shared_ptr<TensorList> input = ws.inputs[0];
+      std::vector<int> samples = gpu_samples_;
+      ws.AddCompletionCheck([st, input, samples, cache, scache] {
+        bool any = false;
+        for (size_t j = 0; j < samples.size(); j++) any = any || st[j] != 0;
+        if (!any) return;
+        std::vector<std::string> names(samples.size());
+        for (size_t j = 0; j < samples.size(); j++)
+          names[j] = samples[j] < (int)input->source_info.size() && !input->source_info[samples[j]].empty()
+                         ? input->source_info[samples[j]] : make_string("sample #", samples[j]);
         for (size_t j = 0; j < names.size(); j++)
           if (st[j] != 0 && cache) cache->Invalidate(names[j]);  // a slot may hold the broken image
         for (size_t j = 0; j < names.size(); j++)
@@ -742,7 +764,7 @@ class ImageDecoderMixed : public OperatorBase {
  private:
   std::vector<daliamdJpegRoiPlan> plans_;
   bool trace_ = getenv("DALI_AMD_TRACE") && atoi(getenv("DALI_AMD_TRACE")) != 0;
-  double trace_s_[5] = {0, 0, 0, 0, 0};
+  double trace_s_[7] = {0, 0, 0, 0, 0, 0, 0};
   int64_t trace_runs_ = 0;
   std::shared_ptr<ImageCache> cache_;
   std::shared_ptr<StreamCache> stream_cache_;
