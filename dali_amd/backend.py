@@ -326,10 +326,8 @@ class JpegBatchPlan:
             lib = capi.kernels()
             nb = C.c_size_t(0)
             sizes = []
-            sc, sel = self.scan, self._huff_sel
-            blocks = (sc["mcus_x"][sel] * sc["mcus_y"][sel] * sc["blocks_per_mcu"][sel]).astype(np.int64)
-            for l, tb in zip(self._ecs_len, blocks):
-                capi.check(lib.daliamdJpegHuffmanIndexBytes(int(l), int(tb), C.byref(nb)))
+            for l in self._ecs_len:
+                capi.check(lib.daliamdJpegHuffmanIndexBytes(int(l), C.byref(nb)))
                 sizes.append(nb.value)
             sizes = np.asarray(sizes, np.int64)
             self._index_off = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64) if len(sizes) else np.zeros(0, np.int64)

@@ -354,39 +354,41 @@ HUFF_HD int SyncDecodeRange(const Tables &L, Words words, DecodeState &st, uint3
 HUFF_HD int Extend(uint32_t bits, uint32_t s);
 
 // ------------------------------------------------------------------------------------------------ indexed pass
-// Side information of a RESIDENT stream (round 5): where the blocks of a stream start and what the DC predictors are
-// there does not change from epoch to epoch, so the first decode of a stream that stays in HBM keeps it for every
-// kIndexGroup-th block - 12 bytes per 16 blocks (about 3 % of the stream):
-//   w0  bit position of the group's first block in the clean stream
-//   w1  DC levels of components 0 and 1 in front of that block (16 bits each, modulo 2^16: only differences and 16-bit
-//       results are ever used);  w2  component 2 the same way
-// A block start is the one place where the decoder state is known without decoding (zig-zag index 0, block index inside
-// the MCU = ordinal modulo blocks per MCU): a later decode starts every group from the truth - one decode per group, no
-// relaxation, no hand-over check, no separate DC pass - and, the ordinals being the index, a group whose blocks a
-// region-of-interest decode does not need is not decoded at all.  Groups of BLOCKS (the first form of the round indexed
-// 256-byte slices: 0.131 ms for the slowest slice's chain - a slice of flat content holds hundreds of blocks, one step
-// each) give every lane the same number of blocks to walk.
-constexpr int kIndexGroup = 16;
+// Side information of a RESIDENT stream (round 5): what the relaxation of the position pass finds out about a 256-byte
+// slice of the clean stream does not change from epoch to epoch, so the first decode of a stream that stays in HBM
+// keeps it - 12 bytes per slice, 4.7 % of the stream - and every later decode starts each slice from the truth:
+//   w0  bits 0-25  ordinal of the first block whose DC symbol lies in the slice's decode | bits 26-31 zig-zag index at entry
+//   w1  bits 0-11  entry position, in bits behind the slice's first bit | 12-15 block index inside the MCU | 16-31 DC level
+//                  of component 0 in front of that block (mod 2^16: only differences and 16-bit results are used)
+//   w2  DC levels of components 1 and 2 the same way
+// One decode per slice, no relaxation, no hand-over check, no separate DC pass (the predictors are known), and - the
+// ordinals being known - a slice whose blocks a region-of-interest decode does not need is not decoded at all.
 struct SliceIndex {
   uint32_t w0, w1, w2;
 };
+constexpr uint32_t kIndexOrdinalMask = (1u << 26) - 1u;
+HUFF_HD SliceIndex PackSliceIndex(uint32_t first_block, const DecodeState &rel, const uint32_t dc[3]) {
+  return SliceIndex{(first_block & kIndexOrdinalMask) | (rel.z << 26), (rel.pos & 4095u) | ((rel.c & 15u) << 12) | (dc[0] << 16),
+                    (dc[1] & 0xFFFFu) | (dc[2] << 16)};
+}
+HUFF_HD uint32_t IndexFirstBlock(const SliceIndex &e) { return e.w0 & kIndexOrdinalMask; }
+// entry state with the position relative to the slice's first bit
+HUFF_HD DecodeState IndexEntryState(const SliceIndex &e) { return DecodeState{e.w1 & 4095u, (e.w1 >> 12) & 15u, e.w0 >> 26}; }
 
-// Decodes `nblocks` blocks from the start of a block at bit `pos` (block index inside the MCU `c`): positions with the
-// symbol-group tables `L` as the relaxation does, and at every block start the DC symbol with the value tables `D` (one
-// more look-up in the same step, off the chain).  emit(c, pos_behind_dc, diff): block index inside the MCU, bit position
-// of the block's first AC symbol, DC difference - in stream order.  Never reads behind `limit_bits` + the stream's padding
-// (an entry of a stream that turned out to be corrupt may point anywhere).
+// Decodes the slice [st.pos, end_bits) once from its TRUE entry state: positions with the symbol-group tables `L` as the
+// relaxation does, and at every block start the DC symbol with the value tables `D` (one more look-up in the same
+// step, off the chain).  emit(c, pos_behind_dc, diff): block index inside the MCU, bit position of the block's first AC
+// symbol, DC difference - in stream order, for every block whose DC symbol starts in front of end_bits.
 template <typename STables, typename DTables, typename Words, typename Emit>
-HUFF_HD void IndexedDecodeBlocks(const STables &L, const DTables &D, Words words, uint32_t pos, uint32_t c, int nblocks,
-                                 uint32_t limit_bits, Emit emit) {
-  uint32_t z = 0;
-  int rem = (int)(limit_bits - pos);   // bits up to the end of the stream
-  uint32_t kb = (pos >> 5) << 2;     // byte offset of hi's dword
-  uint32_t off = pos & 31;
+HUFF_HD void IndexedDecodeSlice(const STables &L, const DTables &D, Words words, const DecodeState &st, uint32_t end_bits,
+                                Emit emit) {
+  uint32_t c = st.c, z = st.z;
+  int rem = (int)(end_bits - st.pos);
+  uint32_t kb = (st.pos >> 5) << 2;  // byte offset of hi's dword
+  uint32_t off = st.pos & 31;
   uint32_t hi = Bswap32(WordAtByte(words, kb)), lo = Bswap32(WordAtByte(words, kb + 4)), nxt = WordAtByte(words, kb + 8);
   const uint32_t dc_mask = HUFF_UNIFORM(L.dc_mask), ac_mask = HUFF_UNIFORM(L.ac_mask), bpm = HUFF_UNIFORM(L.bpm);
-  int left = nblocks;
-  while (left > 0 && rem > 0) {
+  while (rem > 0) {
     const uint32_t peek = (uint32_t)(((((uint64_t)hi << 32) | lo) << off) >> 32);
     const bool is_dc = z == 0;
     const uint32_t sel = (dc_mask >> c) & 1u;
@@ -396,7 +398,7 @@ HUFF_HD void IndexedDecodeBlocks(const STables &L, const DTables &D, Words words
       uint32_t ed = D.fast[sel][peek >> (32 - kFastBits)];
       if (__builtin_expect(ed == 0, 0)) ed = LongCode(D, sel, peek, true);
       const uint32_t used1 = (ed >> 7) & 31, s = ed >> 12;
-      emit(c, limit_bits - (uint32_t)rem + used1, Extend(peek >> (32 - used1), s));
+      emit(c, end_bits - (uint32_t)rem + used1, Extend(peek >> (32 - used1), s));
     }
     if (__builtin_expect(e == 0, 0)) {
       const uint32_t e16 = LongCode(L, slot, peek, is_dc);
@@ -424,7 +426,6 @@ HUFF_HD void IndexedDecodeBlocks(const STables &L, const DTables &D, Words words
     const uint32_t c1 = c + 1 == bpm ? 0 : c + 1;
     z = end_of_block ? 0 : z;
     c = end_of_block ? c1 : c;
-    left -= end_of_block ? 1 : 0;
   }
 }
 

@@ -166,39 +166,32 @@ __host__ __device__ inline ScratchLayout MakeLayout(int ecs_len, int num_tiles, 
 __host__ __device__ inline int NumIntervals(int total_blocks, int blocks_per_mcu, int restart_interval) {
   return restart_interval > 0 ? (total_blocks / blocks_per_mcu + restart_interval - 1) / restart_interval : 0;
 }
-__host__ __device__ inline int NumTiles(int head, int len) {
+__host__ __device__ inline ScratchLayout LayoutOf(const daliamdJpegHuffDesc &d) {
+  return MakeLayout(d.ecs_len, d.num_tiles, d.num_segments, d.total_blocks,
+                    NumIntervals(d.total_blocks, d.blocks_per_mcu, d.restart_interval));
+}
+inline int NumTiles(int head, int len) {
   int t = (head + len + kTileBytes - 1) / kTileBytes;
   return t > 0 ? t : 1;
 }
-__host__ __device__ inline int NumSegments(int len) { return len > kSegBytes ? (len + kSegBytes - 1) / kSegBytes : 1; }
-// (a stream that brings its index has no tiles, and its `num_segments` counts the workgroups of the indexed pass: its
-// scratch keeps the layout the caller sized - daliamdJpegHuffmanScratchBytes - whatever those two say)
-__host__ __device__ inline ScratchLayout LayoutOf(const daliamdJpegHuffDesc &d) {
-  return MakeLayout(d.ecs_len, d.index ? NumTiles(15, d.ecs_len) : d.num_tiles, d.index ? NumSegments(d.ecs_len) : d.num_segments,
-                    d.total_blocks, NumIntervals(d.total_blocks, d.blocks_per_mcu, d.restart_interval));
-}
+inline int NumSegments(int len) { return len > kSegBytes ? (len + kSegBytes - 1) / kSegBytes : 1; }
 
 // ------------------------------------------------------------------------------------------------ resident index
 // Index entry of a resident stream (daliamdJpegHuffDesc.index / index_out; huff_core.h: SliceIndex): a 64-byte header,
-// the CLEAN stream (un-stuffed, markers removed, all-ones padding behind it) and one SliceIndex per group of kIndexGroup
-// blocks.  Sized by the upper bound ecs_len (the clean stream is never longer than the stuffed one) and the block count.
+// the CLEAN stream (un-stuffed, markers removed, all-ones padding behind it) and one SliceIndex per slice + a sentinel.
+// Sized by the upper bound ecs_len (the clean stream is never longer than the stuffed one).
 struct IndexHeader {
   int32_t clean_len;      // bytes of the clean stream
   int32_t total_starts;   // block starts the stream holds (blocks + 1 for a complete stream)
-  int32_t num_groups;     // entries
+  int32_t num_slices;     // entries that describe data
   int32_t reserved[13];
 };
 static_assert(sizeof(IndexHeader) == 64, "layout");
-__host__ __device__ inline int IndexGroups(int total_blocks) { return (total_blocks + kIndexGroup - 1) / kIndexGroup; }
+__host__ __device__ inline int IndexSliceCap(int ecs_len) { return (ecs_len + kSliceBytes - 1) / kSliceBytes; }
 __host__ __device__ inline size_t IndexCleanOffset() { return sizeof(IndexHeader); }
 __host__ __device__ inline size_t IndexEntriesOffset(int ecs_len) { return sizeof(IndexHeader) + AlignUp((size_t)ecs_len + 256, 64); }
-__host__ __device__ inline size_t IndexBytes(int ecs_len, int total_blocks) {
-  return AlignUp(IndexEntriesOffset(ecs_len) + sizeof(SliceIndex) * (size_t)IndexGroups(total_blocks), 64);
-}
-// workgroups of the indexed position pass: kSegThreads groups each (the stream's `num_segments` when it brings its index)
-__host__ __device__ inline int IndexWorkgroups(int total_blocks) {
-  const int g = IndexGroups(total_blocks);
-  return g > kSegThreads ? (g + kSegThreads - 1) / kSegThreads : 1;
+__host__ __device__ inline size_t IndexBytes(int ecs_len) {
+  return AlignUp(IndexEntriesOffset(ecs_len) + sizeof(SliceIndex) * (size_t)(IndexSliceCap(ecs_len) + 1), 64);
 }
 // the clean stream a decode of `d` reads: the resident one, or the one this batch's un-stuffing wrote
 __device__ __forceinline__ const uint8_t *CleanStream(const daliamdJpegHuffDesc &d, const ScratchLayout &lay) {
@@ -1018,12 +1011,11 @@ using GlobalPosDc = u32x2p __attribute__((address_space(1)));
 using GlobalIndex = const SliceIndex __attribute__((address_space(1)));
 __device__ __forceinline__ SliceIndex LoadIndex(GlobalIndex *p) { return SliceIndex{p->w0, p->w1, p->w2}; }
 
-// Position pass of the streams that bring their index (daliamdJpegHuffDesc.index): lane = a group of kIndexGroup blocks,
-// workgroup = 256 groups (the stream's `num_segments` counts THESE workgroups: Setup), ONE decode per group from its
-// recorded start, the DC symbol of every block on the way (huff_core.h: IndexedDecodeBlocks), results straight into the
-// per-block records.  With a region of interest the groups whose blocks it does not need are not decoded (their
-// ordinals are their index), and the groups that are get packed into the first waves; a workgroup without any leaves
-// before it copies its tables.
+// Position pass of the streams that bring their index (daliamdJpegHuffDesc.index): workgroup = a segment's 244 slices as
+// in SyncKernel (same grid), ONE decode per slice from its recorded entry state, the DC symbol of every block start on
+// the way (huff_core.h: IndexedDecodeSlice), results straight into the per-block records.  With a region of interest
+// the slices whose blocks it does not need are not decoded (their ordinals are in the index), and the slices that are
+// get packed into the first waves; a segment without any leaves before it copies its tables.
 __global__ __launch_bounds__(kSegThreads) void IndexedSyncKernel(const daliamdJpegHuffDesc *__restrict__ descs, int n, int nseg) {
   __shared__ __attribute__((aligned(16))) SyncTables L;
   __shared__ __attribute__((aligned(16))) HalfTables D;
@@ -1035,10 +1027,11 @@ __global__ __launch_bounds__(kSegThreads) void IndexedSyncKernel(const daliamdJp
   const daliamdJpegHuffDesc &d = *r.d;
   if (!d.index) return;   // (uniform)
   const ScratchLayout lay = LayoutOf(d);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int clean_len = ((const GlobalI32 *)d.index)[0];
-  // (an entry of a stream that turned out to be corrupt may hold anything: nothing is read behind the stream it was sized for)
-  const uint32_t total_bits = (uint32_t)min(clean_len, d.ecs_len) * 8u;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, seg = r.local;
+  const IndexHeader *hdr = reinterpret_cast<const IndexHeader *>(d.index);
+  const int clean_len = ((const GlobalI32 *)hdr)[0];
+  if ((long long)seg * kSegBytes >= clean_len) return;
+  const uint32_t total_bits = (uint32_t)clean_len * 8u;
   GlobalIndex *entries = (GlobalIndex *)(d.index + IndexEntriesOffset(d.ecs_len));
   // what the decode needs of this stream: blocks below `last` inside the MCU rectangle `rm` (no rectangle: all of them)
   const int bpm = d.blocks_per_mcu, mcus_x = d.mcus_x;
@@ -1058,10 +1051,14 @@ __global__ __launch_bounds__(kSegThreads) void IndexedSyncKernel(const daliamdJp
     if (r0 == r1) return row(r0, c0, c1);
     return row(r0, c0, mcus_x - 1) || row(r1, 0, c1) || (max(r0 + 1, y0) < min(r1, y1));
   };
-  const int groups = IndexGroups(d.total_blocks);
-  const int g = r.local * kSegThreads + tid;
-  const bool want = g < groups && needed(g * kIndexGroup, g * kIndexGroup + kIndexGroup);
-  // the groups to decode, packed into the first lanes
+  const long long slice = (long long)seg * kSegLanes + tid;
+  const bool has = tid < kSegLanes && slice * (kSliceBytes * 8ll) < (long long)total_bits;
+  bool want = false;
+  if (has) {
+    const uint32_t b0 = entries[slice].w0 & kIndexOrdinalMask, b1 = entries[slice + 1].w0 & kIndexOrdinalMask;
+    want = needed((int)b0, (int)b1);
+  }
+  // the slices to decode, packed into the first lanes
   const unsigned long long m = __ballot(want);
   if (lane == 0) wave_count[wave] = __popcll(m);
   __syncthreads();
@@ -1072,25 +1069,28 @@ __global__ __launch_bounds__(kSegThreads) void IndexedSyncKernel(const daliamdJp
     base += w < wave ? c : 0;
     total += c;
   }
-  if (total == 0) return;   // (uniform: nothing of these groups is needed)
+  if (total == 0) return;   // (uniform: nothing of this segment is needed)
   if (want) work[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)tid;
   CopyTables<kSegThreads>(L, reinterpret_cast<const SyncTables *>(TablesBase(descs, d, true)));
   CopyHalfTables<kSegThreads>(D, reinterpret_cast<const HuffTables *>(TablesBase(descs, d, false)), 0);
   __syncthreads();
   if (tid >= total) return;
-  const int mine = r.local * kSegThreads + work[tid];
-  const SliceIndex e = LoadIndex(entries + mine);
-  if (e.w0 >= total_bits) return;
+  const long long s = (long long)seg * kSegLanes + work[tid];
+  const SliceIndex e = LoadIndex(entries + s);
+  const uint32_t begin = (uint32_t)(s * (kSliceBytes * 8ll));
+  const uint32_t end = begin + kSliceBytes * 8u < total_bits ? begin + kSliceBytes * 8u : total_bits;
+  DecodeState st = IndexEntryState(e);
+  st.pos += begin;
+  if (st.pos >= end) return;
   uint32_t comp_of = 0;   // two bits per block of the MCU
   for (int k = 0; k < bpm; k++) comp_of |= (uint32_t)(d.comp_of_block[k] & 3) << (2 * k);
   comp_of = HUFF_UNIFORM(comp_of);
-  int dc0 = (int)(e.w1 & 0xFFFFu), dc1 = (int)(e.w1 >> 16), dc2 = (int)(e.w2 & 0xFFFFu);
-  uint32_t b = (uint32_t)mine * kIndexGroup;
+  int dc0 = (int)(e.w1 >> 16), dc1 = (int)(e.w2 & 0xFFFFu), dc2 = (int)(e.w2 >> 16);
+  uint32_t b = IndexFirstBlock(e);
   const uint32_t total_blocks = (uint32_t)d.total_blocks;
-  const int nblocks = (int)min((uint32_t)kIndexGroup, total_blocks - b);
   GlobalPosDc *blk = (GlobalPosDc *)(d.scratch + lay.blk_pos);
   GlobalWords *words = (GlobalWords *)(d.index + IndexCleanOffset());
-  IndexedDecodeBlocks(L, D, words, e.w0, b % (uint32_t)bpm, nblocks, total_bits, [&](uint32_t c, uint32_t pos, int diff) {
+  IndexedDecodeSlice(L, D, words, st, end, [&](uint32_t c, uint32_t pos, int diff) {
     const uint32_t comp = (comp_of >> (2 * c)) & 3u;
     dc0 += comp == 0 ? diff : 0;
     dc1 += comp == 1 ? diff : 0;
@@ -1102,9 +1102,10 @@ __global__ __launch_bounds__(kSegThreads) void IndexedSyncKernel(const daliamdJp
 }
 
 // Builds the index entry of a stream (daliamdJpegHuffDesc.index_out) from what this batch's position passes left in the
-// scratch - behind PropagateKernel (block ordinals) and a DcKernel that covered every block.  Workgroup = segment: copies
-// its part of the clean stream and writes the entry of every kIndexGroup-th block that starts in it.
+// scratch - behind PropagateKernel (every slice's input state is the truth by then) and a DcKernel that covered every
+// block.  Workgroup = segment: copies its part of the clean stream, writes the entries of its slices.
 __global__ __launch_bounds__(kSegThreads) void IndexBuildKernel(const daliamdJpegHuffDesc *__restrict__ descs, int n, int nseg) {
+  __shared__ int wave_sums[kSegThreads / 64];
   const int wg = XcdRemap(blockIdx.x, nseg);
   if (wg < 0) return;
   const ImageRef r = FindImage<false>(descs, n, wg);
@@ -1114,13 +1115,19 @@ __global__ __launch_bounds__(kSegThreads) void IndexBuildKernel(const daliamdJpe
   const int tid = threadIdx.x, seg = r.local;
   const int clean_len = *(const GlobalI32 *)d.scratch;
   const int total_starts = ((const GlobalI32 *)d.scratch)[2];
+  const int cap = IndexSliceCap(d.ecs_len);
   GlobalU32 *out_entries = (GlobalU32 *)(d.index_out + IndexEntriesOffset(d.ecs_len));
+  auto put = [&](long long slice, const SliceIndex &e) {
+    out_entries[3 * slice] = e.w0; out_entries[3 * slice + 1] = e.w1; out_entries[3 * slice + 2] = e.w2;
+  };
+  const uint32_t zero3[3] = {0, 0, 0};
+  const SliceIndex none = PackSliceIndex((uint32_t)total_starts, DecodeState{0, 0, 0}, zero3);
   if (seg == 0 && tid == kSegThreads - 1) {
     GlobalI32 *h = (GlobalI32 *)d.index_out;
-    h[0] = clean_len; h[1] = total_starts; h[2] = IndexGroups(d.total_blocks);
+    h[0] = clean_len; h[1] = total_starts; h[2] = (clean_len + kSliceBytes - 1) / kSliceBytes;
     for (int i = 3; i < 16; i++) h[i] = 0;
+    put(cap, none);   // the sentinel behind the last slice
   }
-  if (seg > 0 && (long long)seg * kSegBytes >= clean_len) return;   // (a segment behind the end of the stream)
   // ---- the clean bytes of the segment (the last one: with the all-ones padding behind the stream)
   {
     const long long first = (long long)seg * kSegBytes;
@@ -1130,40 +1137,49 @@ __global__ __launch_bounds__(kSegThreads) void IndexBuildKernel(const daliamdJpe
     GlobalQuad *dst = (GlobalQuad *)(d.index_out + IndexCleanOffset());
     for (long long q = first / 16 + tid; q * 16 < stop; q += kSegThreads) dst[q] = src[q];
   }
-  // ---- the entries of the groups whose first block starts in this segment
+  // ---- the entries of its slices
+  const long long slice = (long long)seg * kSegLanes + tid;
+  const bool mine = tid < kSegLanes && slice < cap;
+  const bool active = mine && slice * (long long)kSliceBytes < clean_len;
+  const LaneRec *recs = reinterpret_cast<const LaneRec *>(d.scratch + lay.lanes) + (size_t)seg * kSegLanes;
   const GlobalI32 *segs_i = (const GlobalI32 *)(d.scratch + lay.segs);
-  const int block_base = segs_i[seg * kSegRecInts + kSegRecBlockBase];
-  int nstart = segs_i[seg * kSegRecInts + kSegRecNstart];
-  nstart = nstart < lay.seg_cap ? nstart : lay.seg_cap;
-  GlobalWords *starts = (GlobalWords *)(d.scratch + lay.seg_starts) + (size_t)seg * lay.seg_cap;
+  uint64_t in = kNoState;
+  int nstart = 0;
+  if (active) {
+    in = recs[tid].in;
+    nstart = recs[tid].nstart;
+  }
+  int total;
+  const int excl = WorkgroupExclusiveScan<kSegThreads / 64>(nstart, wave_sums, total);
+  if (!mine) return;
+  if (!active || in == kNoState) {
+    put(slice, none);
+    return;
+  }
+  const int ord = segs_i[seg * kSegRecInts + kSegRecBlockBase] + excl;   // first start this slice's decode FOUND
+  DecodeState st = Unpack(in);
+  // ... the first block whose DC symbol it DECODES: a block that starts exactly at the entry position was found by the
+  // slice before (the step that ended its predecessor) and is decoded here - except the stream's very first block
+  const int first_block = ord - (st.z == 0 && st.pos != 0 ? 1 : 0);
+  // DC level of every component in front of that block: its last block before, relative to its segment + the segments before
   const GlobalI32 *blk_dc = (const GlobalI32 *)(d.scratch + lay.blk_dc);
   const GlobalU16 *blk_seg = (const GlobalU16 *)(d.scratch + lay.blk_seg);
-  const int bpm = d.blocks_per_mcu;
-  // first start of the segment whose ordinal is a multiple of the group size
-  const int first_j = (kIndexGroup - block_base % kIndexGroup) % kIndexGroup;
-  for (int j = first_j + tid * kIndexGroup; j < nstart; j += kSegThreads * kIndexGroup) {
-    const int b = block_base + j;
-    if (b >= d.total_blocks) break;
-    // DC level of every component in front of block b: its last block before, relative to its segment + the segments before
-    uint32_t dc[3] = {0, 0, 0};
-    uint32_t found = 0;
-    for (int k = 1; k <= bpm && found != 7u; k++) {
-      const int q = b - k;
-      if (q < 0) break;
-      const int comp = d.comp_of_block[q % bpm];
-      if (comp > 2 || (found >> comp) & 1u) continue;
-      found |= 1u << comp;
-      if (q + 1 >= total_starts) continue;   // (a block the stream does not really hold)
-      int level = blk_dc[q];
-      const int qs = blk_seg[q];
-      for (int sg = 0; sg < qs; sg++) level += segs_i[sg * kSegRecInts + kSegRecDcTotal + comp];
-      dc[comp] = (uint32_t)level & 0xFFFFu;
-    }
-    const int grp = b / kIndexGroup;
-    out_entries[3 * grp] = starts[j];
-    out_entries[3 * grp + 1] = dc[0] | (dc[1] << 16);
-    out_entries[3 * grp + 2] = dc[2];
+  uint32_t dc[3] = {0, 0, 0};
+  uint32_t found = 0;
+  for (int j = 1; j <= d.blocks_per_mcu && found != 7u; j++) {
+    const int q = first_block - j;
+    if (q < 0) break;
+    const int comp = d.comp_of_block[q % d.blocks_per_mcu];
+    if (comp > 2 || (found >> comp) & 1u) continue;
+    found |= 1u << comp;
+    if (q >= d.total_blocks || q + 1 >= total_starts) continue;   // (a block the stream does not really hold)
+    int level = blk_dc[q];
+    const int qs = blk_seg[q];
+    for (int sg = 0; sg < qs; sg++) level += segs_i[sg * kSegRecInts + kSegRecDcTotal + comp];
+    dc[comp] = (uint32_t)level & 0xFFFFu;
   }
+  st.pos -= (uint32_t)(slice * (long long)(kSliceBytes * 8));
+  put(slice, PackSliceIndex((uint32_t)first_block, st, dc));
 }
 
 // Value pass.  A workgroup owns a run of MCUs of one image; its waves take TASKS of 64 blocks that all use the same
@@ -1731,10 +1747,9 @@ daliamdResult_t daliamdJpegHuffmanTablesBuild(const daliamdJpegHuffDesc *d, void
   return DALIAMD_SUCCESS;
 }
 
-daliamdResult_t daliamdJpegHuffmanIndexBytes(int ecs_len, int total_blocks, size_t *bytes) {
-  DALIAMD_REQUIRE(ecs_len >= 0 && total_blocks >= 0 && bytes, DALIAMD_ERROR_INVALID_ARGUMENT,
-                  "daliamdJpegHuffmanIndexBytes: invalid argument");
-  *bytes = daliamd::IndexBytes(ecs_len, total_blocks);
+daliamdResult_t daliamdJpegHuffmanIndexBytes(int ecs_len, size_t *bytes) {
+  DALIAMD_REQUIRE(ecs_len >= 0 && bytes, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdJpegHuffmanIndexBytes: invalid argument");
+  *bytes = daliamd::IndexBytes(ecs_len);
   return DALIAMD_SUCCESS;
 }
 
@@ -1851,8 +1866,7 @@ daliamdResult_t daliamdJpegHuffmanSetupColor(daliamdJpegHuffDesc *descs_host, in
     // (a stream that brings its index is not un-stuffed again: no tiles)
     d.num_tiles = d.index ? 0 : daliamd::NumTiles((int)(reinterpret_cast<uintptr_t>(d.ecs) & 15), d.ecs_len);
     d.seg_start = segs;
-    // (a stream that brings its index: workgroups of the indexed pass, 256 groups of blocks each)
-    d.num_segments = d.index ? daliamd::IndexWorkgroups(d.total_blocks) : daliamd::NumSegments(d.ecs_len);
+    d.num_segments = daliamd::NumSegments(d.ecs_len);
     DALIAMD_REQUIRE(d.num_segments <= 65535, DALIAMD_ERROR_UNSUPPORTED,
                     "daliamdJpegHuffmanSetup: sample %d: entropy-coded segment too long (decode it on the host)", i);
     d.blk_wg_start = bwgs;

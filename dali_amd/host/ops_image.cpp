@@ -512,8 +512,7 @@ class ImageDecoderMixed : public OperatorBase {
         const bool indexed = index_streams_ && scans_[i].restart_interval == 0 &&
                              (int64_t)scans_[i].mcus_x * scans_[i].mcus_y * scans_[i].blocks_per_mcu + 128 < ((int64_t)1 << 26);
         size_t bytes = (size_t)scans_[i].ecs_length;
-        if (indexed)
-          KCHECK(daliamdJpegHuffmanIndexBytes((int)scans_[i].ecs_length, scans_[i].mcus_x * scans_[i].mcus_y * scans_[i].blocks_per_mcu, &bytes));
+        if (indexed) KCHECK(daliamdJpegHuffmanIndexBytes((int)scans_[i].ecs_length, &bytes));
         if (uint8_t *slot_ptr = stream_cache_->Reserve(in.source_info[i], bytes)) {
           keep.push_back({j, slot_ptr, indexed});
           reserved_streams.keys.push_back(in.source_info[i]);

@@ -212,13 +212,12 @@ typedef struct {
    * dali/operators/decoder/cache/cached_decoder_impl.cc:124-141).  A stream that stays in device memory is parsed identically in
    * every epoch: where its stuffing bytes are and in which state a decoder reaches each 256-byte slice does not change.
    * index_out != NULL: this decode also leaves an index entry there - a 64-byte header, the un-stuffed stream and 12 bytes per
-   * group of 16 blocks (bit position of the group's first block, DC predictors in front of it):
-   * daliamdJpegHuffmanIndexBytes(ecs_len, total_blocks) bytes, 64-byte aligned, valid once the launch has finished with
-   * *status == 0.
-   * index != NULL: decode from such an entry - `ecs` is not looked at (may be NULL; ecs_len and total_blocks must be the values
-   * the entry was built with): no un-stuffing, one decode per group instead of the relaxation, no hand-over check, no DC pass,
-   * and under a region of interest (rect) only the groups that hold blocks of it.  The output is the same bits.  Streams with
-   * restart intervals take neither (Setup refuses). */
+   * slice (entry bit position, block index inside the MCU, zig-zag index, ordinal of the first block, DC predictors):
+   * daliamdJpegHuffmanIndexBytes(ecs_len) bytes, 64-byte aligned, valid once the launch has finished with *status == 0.
+   * index != NULL: decode from such an entry - `ecs` is not looked at (may be NULL; ecs_len must be the value the entry was
+   * built with): no un-stuffing, one decode per slice instead of the relaxation, no hand-over check, no DC pass, and under a
+   * region of interest (rect) only the slices that hold blocks of it.  The output is the same bits.  Streams with restart
+   * intervals take neither (Setup refuses). */
   const uint8_t *index;
   uint8_t *index_out;
   /* Finished code tables in device memory (round 5): daliamdJpegHuffmanTablesBytes() bytes as daliamdJpegHuffmanTablesBuild makes
@@ -237,7 +236,7 @@ typedef struct {
 DALIAMD_API daliamdResult_t daliamdJpegHuffmanTablesBytes(size_t *bytes);
 /* host only: out_host receives daliamdJpegHuffmanTablesBytes() bytes */
 DALIAMD_API daliamdResult_t daliamdJpegHuffmanTablesBuild(const daliamdJpegHuffDesc *desc, void *out_host);
-DALIAMD_API daliamdResult_t daliamdJpegHuffmanIndexBytes(int ecs_len, int total_blocks, size_t *bytes);
+DALIAMD_API daliamdResult_t daliamdJpegHuffmanIndexBytes(int ecs_len, size_t *bytes);
 
 /* 1 when the stream's geometry (blocks_per_mcu, comp_of_block, h/v_of_block, h/v_samp, mcus_x, rect) allows the fused
  * colour output, else 0.  Host helper, looks at nothing else. */
