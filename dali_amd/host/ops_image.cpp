@@ -528,7 +528,8 @@ class ImageDecoderMixed : public OperatorBase {
         const auto &sc = scan(i);
         auto &d = huff[j];
         // finished code tables of the stream's table set, when the store keeps them (else: built inside the launch)
-        const uint8_t *tables = erec_[i] ? erec_[i]->tables : HuffTableStore::Get(device_id_, sc);
+        // (a resident record made before its table set was built - the set's first sighting - asks the store again)
+        const uint8_t *tables = erec_[i] && erec_[i]->tables ? erec_[i]->tables : HuffTableStore::Get(device_id_, sc);
         {
           constexpr size_t dht0 = offsetof(daliamdJpegHuffDesc, bits), dht1 = offsetof(daliamdJpegHuffDesc, rect);
           uint8_t *raw = reinterpret_cast<uint8_t *>(&d);
