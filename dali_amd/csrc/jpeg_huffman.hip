@@ -608,6 +608,41 @@ __device__ __forceinline__ RstView MakeRstView(const daliamdJpegHuffDesc &d, con
   return v;
 }
 
+#ifdef DALIAMD_EXP_STAMPS
+// Development probe (tools/stamp_probe.py; never in the shipped library): wall-clock stamps (100 MHz) per workgroup of the
+// two position kernels - where a launch's time goes, workgroup by workgroup.
+__device__ unsigned long long g_stamps[2][8192 * 16];
+__device__ __forceinline__ void Stamp(int which, int k) {
+  if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps[which][blockIdx.x * 16 + k] = wall_clock64();
+}
+__device__ __forceinline__ void StampMax(int which, int k) {
+  if (blockIdx.x < 8192) atomicMax(&g_stamps[which][blockIdx.x * 16 + k], (unsigned long long)wall_clock64());
+}
+__device__ __forceinline__ void StampIds(int which, int wg) {
+  if (threadIdx.x == 0 && blockIdx.x < 8192) {
+    g_stamps[which][blockIdx.x * 16 + 13] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
+    g_stamps[which][blockIdx.x * 16 + 14] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
+    g_stamps[which][blockIdx.x * 16 + 15] = (unsigned long long)wg;
+  }
+}
+extern "C" DALIAMD_API int daliamdDebugReadStamps(int which, void *dst, size_t bytes, int clear) {
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), bytes, (size_t)which * sizeof(g_stamps[0])) != hipSuccess) return 2;
+  if (clear) {
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_stamps)) != hipSuccess) return 3;
+    if (hipMemset((char *)p + (size_t)which * sizeof(g_stamps[0]), 0, sizeof(g_stamps[0])) != hipSuccess) return 4;
+  }
+  return 0;
+}
+#define STAMP(which, k) Stamp(which, k)
+#define STAMP_MAX(which, k) StampMax(which, k)
+#define STAMP_IDS(which, wg) StampIds(which, wg)
+#else
+#define STAMP(which, k)
+#define STAMP_MAX(which, k)
+#define STAMP_IDS(which, wg)
+#endif
 // Round 4: the lanes that have to decode in a round are PACKED into the first waves (a work list in LDS).  Rounds 1 and 2
 // keep nearly every lane busy; from round 3 on a handful of slices re-decode, and with lane = slice each of them kept its
 // whole wave issuing for the length of a slice.  Host model on the bench's first batch (tools/sync_sim.cpp): 1 089 136
@@ -679,6 +714,7 @@ __device__ __forceinline__ void Relax(const SyncTables &L, GlobalWords *words, R
     __syncthreads();   // every decode of the round has read its input
     if (s >= 0) R.state[s + 1] = out;
     __syncthreads();
+    STAMP(0, 2 + (round < 8 ? round : 8));
   }
   ln.in = R.last_in[tid];
   ln.out = ln.in != kNoState ? R.state[tid + 1] : kNoState;
@@ -687,23 +723,79 @@ __device__ __forceinline__ void Relax(const SyncTables &L, GlobalWords *words, R
 }
 
 // After the relaxation: the segment's block starts, densely, as absolute bit positions (the lists of its lanes one
-// after the other).  `first` = the first lane that belongs to the segment (the warm-up lanes before it replayed the
-// previous one).  Lanes whose list outgrew its LDS slots (long runs of nearly empty blocks) decode once more,
-// writing straight to memory.  Returns the number of starts in the segment.
-__device__ __forceinline__ int WriteSegmentStarts(const SyncTables &L, GlobalWords *words, const Lane &ln, const uint16_t *list,
-                                                  bool mine, GlobalU32 *seg_starts, int seg_cap, int *wave_sums, const RstView &rst) {
+// after the other).  Returns the number of starts in the segment.
+//  * The lists leave WAVE by wave, one lane's list per step: 64 consecutive dwords per store instruction where a lane
+//    walking its own list touched 64 cache lines with every one of its stores.
+//  * A lane whose list outgrew its LDS slots (kListCap; a quarter of the bench's slices) decodes once more, writing
+//    straight to memory - these lanes are PACKED into the first waves (the work list of the relaxation rounds): measured
+//    with per-workgroup time stamps (round 5), that extra decode kept all four waves of nearly every workgroup issuing
+//    for the length of a slice, 45 us of the kernel's 305 and a third of its instructions.
+struct WriteShared {
+  uint32_t bases[kSegThreads], ends[kSegThreads], counts[kSegThreads];
+  uint64_t in[kSegThreads];
+  uint8_t work[kSegThreads];
+  int wave_count[kSegThreads / 64];
+};
+union SegShared {   // the relaxation's state is dead when the lists leave (the scan's barriers lie in between)
+  RelaxShared R;
+  WriteShared W;
+};
+template <typename LaneOf>
+__device__ __forceinline__ int WriteSegmentStarts(const SyncTables &L, GlobalWords *words, const Lane &ln, const uint16_t *lists,
+                                                  bool mine, GlobalU32 *seg_starts, int seg_cap, int *wave_sums, WriteShared &W,
+                                                  const daliamdJpegHuffDesc &d, const ScratchLayout &lay, LaneOf lane_of) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wave_first = tid & ~63;
+  const int count = mine ? ln.nstart : 0;
   int total;
-  const int base = WorkgroupExclusiveScan<kSegThreads / 64>(mine ? ln.nstart : 0, wave_sums, total);
-  if (mine && ln.nstart <= kListCap) {
-    for (int j = 0; j < ln.nstart; j++)
-      if (base + j < seg_cap) seg_starts[base + j] = ln.end - (uint32_t)(int32_t)(int16_t)list[j];
-  } else if (mine) {
-    DecodeState st = Unpack(ln.in);
-    const uint32_t end = ln.end;
-    const int count = ln.nstart;  // the slot behind the last start is "in progress" for ever: it belongs to the next lane
-    bool crossed;
+  const int base = WorkgroupExclusiveScan<kSegThreads / 64>(count, wave_sums, total);
+  W.bases[tid] = (uint32_t)base;
+  W.ends[tid] = ln.end;
+  W.counts[tid] = (uint32_t)count;
+  W.in[tid] = ln.in;
+  const bool over = count > kListCap;
+  const unsigned long long m = __ballot(over);
+  if (lane == 0) W.wave_count[wave] = __popcll(m);
+  __syncthreads();
+  for (int l = 0; l < 64; l++) {
+    const int src = wave_first + l;
+    const int n = min((int)W.counts[src], kListCap);   // (uniform per wave: one address)
+    if (n == 0) continue;
+    const uint32_t b = W.bases[src], e = W.ends[src];
+    const uint16_t *list = lists + src * kListStride;
+    for (int j = lane; j < n; j += 64)
+      if ((int)b + j < seg_cap) seg_starts[b + j] = e - (uint32_t)(int32_t)(int16_t)list[j];
+  }
+  int first = 0, nover = 0;
+#pragma unroll
+  for (int w = 0; w < kSegThreads / 64; w++) {
+    const int c = W.wave_count[w];
+    first += w < wave ? c : 0;
+    nover += c;
+  }
+  if (nover == 0) return total;   // (uniform)
+  if (over) W.work[first + __popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)tid;
+  __syncthreads();
+  if (tid < nover) {
+    const int s = (int)W.work[tid];
+    // ... from the LAST start its list holds (entry j = the end of the slice's (j + 1)-th block: zig-zag index 0, block
+    // index inside the MCU advanced by j + 1), not from the slice's first bit: the entries in front left with the lists
+    const Lane w = lane_of(s);
+    const uint32_t end = w.end;
+    // (the stream's first slice lists the START of its first block too: one block fewer has ended at the same entry;
+    // restart intervals reset the block index at every boundary: those streams decode the slice from its first bit)
+    DecodeState st = Unpack(W.in[s]);
+    const int kept = d.restart_interval ? 0 : kListCap;   // entries the lists delivered
+    if (kept) {
+      const uint32_t ended = (uint32_t)kept - (st.pos == 0 ? 1u : 0u);
+      st.pos = end - (uint32_t)(int32_t)(int16_t)lists[s * kListStride + kept - 1];
+      st.c = (st.c + ended) % (uint32_t)d.blocks_per_mcu;
+      st.z = 0;
+    }
+    const int cnt = (int)W.counts[s] - kept, b = (int)W.bases[s] + kept;
+    const RstView rst = MakeRstView(d, lay, st.pos);
+    bool crossed;   // the slot behind the last start is "in progress" for ever: it belongs to the next lane
     SyncDecodeRange(L, words, st, end, rst, [&](int nb, int rem, bool ended) {  // one store per block, not per step
-      if (ended && nb < count && base + nb < seg_cap) seg_starts[base + nb] = end - (uint32_t)rem;
+      if (ended && nb < cnt && b + nb < seg_cap) seg_starts[b + nb] = end - (uint32_t)rem;
     }, &crossed);
   }
   return total;
@@ -711,7 +803,8 @@ __device__ __forceinline__ int WriteSegmentStarts(const SyncTables &L, GlobalWor
 
 __global__ __launch_bounds__(kSegThreads) void SyncKernel(const daliamdJpegHuffDesc *__restrict__ descs, int n, int nseg) {
   __shared__ __attribute__((aligned(16))) SyncTables L;
-  __shared__ RelaxShared R;
+  __shared__ SegShared S;
+  RelaxShared &R = S.R;
   __shared__ uint16_t lists[kSegThreads * kListStride];
   __shared__ int wave_sums[kSegThreads / 64];
   const int wg = XcdRemap(blockIdx.x, nseg);
@@ -729,19 +822,21 @@ __global__ __launch_bounds__(kSegThreads) void SyncKernel(const daliamdJpegHuffD
     if (tid == 0) *segrec = SegRec{kNoState, 0, 0, {0, 0, 0}, 0};
     return;
   }
+  STAMP(0, 0);
+  STAMP_IDS(0, wg);
   CopyTables<kSegThreads>(L, reinterpret_cast<const SyncTables *>(TablesBase(descs, d, true)));
+  STAMP(0, 1);
   const uint32_t total_bits = (uint32_t)clean_len * 8u;
   // lanes [0, kWarmLanes) replay the last slices of the previous segment, lanes [kWarmLanes, ..) are this segment's
   auto slice_of = [&](int t) { return (long long)seg * kSegLanes + t - kWarmLanes; };
   Lane ln = MakeLane(slice_of(tid), total_bits);
   R.state[tid] = Pack(DecodeState{ln.begin, 0, 0});  // the guess; exact for the very first slice of the image
   GlobalWords *words = (GlobalWords *)(d.scratch + lay.clean);
-  uint16_t *list = lists + tid * kListStride;
   Relax(L, words, R, lists, ln, total_bits, d, lay, slice_of);
-  const RstView rst = MakeRstView(d, lay, ln.begin);
+  STAMP(0, 11);
   const bool mine = tid >= kWarmLanes;
-  const int total = WriteSegmentStarts(L, words, ln, list, mine, (GlobalU32 *)(d.scratch + lay.seg_starts) + (size_t)seg * lay.seg_cap,
-                                       lay.seg_cap, wave_sums, rst);
+  const int total = WriteSegmentStarts(L, words, ln, lists, mine, (GlobalU32 *)(d.scratch + lay.seg_starts) + (size_t)seg * lay.seg_cap,
+                                       lay.seg_cap, wave_sums, S.W, d, lay, [&](int t) { return MakeLane(slice_of(t), total_bits); });
   // restart intervals: did a lane's last decode run over a boundary?  (Wrong when the lanes started from the truth -
   // PropagateKernel knows whether they did.)
   const int crossed = d.restart_interval ? __syncthreads_or(mine && ln.active && ln.crossed) : 0;
@@ -752,12 +847,14 @@ __global__ __launch_bounds__(kSegThreads) void SyncKernel(const daliamdJpegHuffD
     if (ln.active && !next_has_data) *segrec = SegRec{ln.out, total, 0, {0, 0, 0}, crossed};
     if (total_bits == 0 && tid == kWarmLanes) *segrec = SegRec{Pack(DecodeState{0, 0, 0}), 0, 0, {0, 0, 0}, 0};
   }
+  STAMP(0, 12);
 }
 
 // (The code tables of the rare repair stay in global memory: a 50 KB workgroup - the tables are 36 KB of it - waits for a
 // CU with that much LDS free, which inside the five-batch schedule made this 10 us kernel last 50 us.)
 __global__ __launch_bounds__(kSegThreads) void PropagateKernel(const daliamdJpegHuffDesc *__restrict__ descs) {
-  __shared__ RelaxShared R;
+  __shared__ SegShared S;
+  RelaxShared &R = S.R;
   __shared__ uint16_t lists[kSegThreads * kListStride];
   __shared__ int wave_sums[kSegThreads / 64];
   const daliamdJpegHuffDesc &d = descs[blockIdx.x];
@@ -788,12 +885,10 @@ __global__ __launch_bounds__(kSegThreads) void PropagateKernel(const daliamdJpeg
       auto slice_of = [&](int t) { return t < kSegLanes ? (long long)seg * kSegLanes + t : -1ll; };
       Lane ln;
       R.state[tid] = tid == 0 ? truth : (mine ? recs[tid].in : kNoState);
-      uint16_t *list = lists + tid * kListStride;
       Relax(L, words, R, lists, ln, total_bits, d, lay, slice_of);
-      const RstView rst = MakeRstView(d, lay, ln.begin);
-      const int total = WriteSegmentStarts(L, words, ln, list, mine,
+      const int total = WriteSegmentStarts(L, words, ln, lists, mine,
                                            (GlobalU32 *)(d.scratch + lay.seg_starts) + (size_t)seg * lay.seg_cap, lay.seg_cap,
-                                           wave_sums, rst);
+                                           wave_sums, S.W, d, lay, [&](int t) { return MakeLane(slice_of(t), total_bits); });
       const int crossed = d.restart_interval ? __syncthreads_or(mine && ln.active && ln.crossed) : 0;
       if (mine) {
         recs[tid] = LaneRec{ln.in, ln.out, ln.nstart, 0};
@@ -1052,6 +1147,8 @@ __global__ __launch_bounds__(kSegThreads) void IndexedSyncKernel(const daliamdJp
     return row(r0, c0, mcus_x - 1) || row(r1, 0, c1) || (max(r0 + 1, y0) < min(r1, y1));
   };
   const long long slice = (long long)seg * kSegLanes + tid;
+  STAMP(1, 0);
+  STAMP_IDS(1, wg);
   const bool has = tid < kSegLanes && slice * (kSliceBytes * 8ll) < (long long)total_bits;
   bool want = false;
   if (has) {
@@ -1074,6 +1171,7 @@ __global__ __launch_bounds__(kSegThreads) void IndexedSyncKernel(const daliamdJp
   CopyTables<kSegThreads>(L, reinterpret_cast<const SyncTables *>(TablesBase(descs, d, true)));
   CopyHalfTables<kSegThreads>(D, reinterpret_cast<const HuffTables *>(TablesBase(descs, d, false)), 0);
   __syncthreads();
+  STAMP(1, 1);
   if (tid >= total) return;
   const long long s = (long long)seg * kSegLanes + work[tid];
   const SliceIndex e = LoadIndex(entries + s);
@@ -1099,6 +1197,7 @@ __global__ __launch_bounds__(kSegThreads) void IndexedSyncKernel(const daliamdJp
     if (b < total_blocks) blk[b] = u32x2p{pos, (uint32_t)level};
     b++;
   });
+  STAMP_MAX(1, 2 + wave);
 }
 
 // Builds the index entry of a stream (daliamdJpegHuffDesc.index_out) from what this batch's position passes left in the

@@ -59,6 +59,7 @@ static int g_dc_chain = 0;   // DC entries continue into the AC table of the sam
 long g_cls[4] = {0, 0, 0, 0};
 long g_pm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 std::vector<long> g_wmax;
+std::vector<long> g_nblk;   // histogram: block starts per slice (final decode)
 
 // mirrors DecodeRange: symbols that START in [st.pos, end)
 // `prev` (sorted block starts (pos << 8 | c) of the lane's previous decode) makes the decode stop where it meets that
@@ -353,6 +354,7 @@ int main(int argc, char **argv) {
       }
       { extern std::vector<long> g_wmax; long m = 0; for (int t = warm; t < T; t++) m = std::max<long>(m, ln[t].nsym); g_wmax.push_back(m); }
       for (int t = warm; t < T; t++) ideal_syms += ln[t].nsym;
+      { extern std::vector<long> g_nblk; for (int t = warm; t < T; t++) if (ln[t].active) { size_t n = ln[t].traj.size(); if (g_nblk.size() <= n) g_nblk.resize(n + 1); g_nblk[n]++; } }
       if (getenv("SIM_TRACE") && path > atol(getenv("SIM_TRACE")))
         printf("  %s seg %ld/%ld path %ld rounds:%s\n", fn.c_str() + fn.size() - 8, seg, nseg, path, trace.c_str());
       wg_path.push_back(path);
@@ -380,6 +382,10 @@ int main(int argc, char **argv) {
          (double)compact_wave_steps / busy_wave_steps);
   std::sort(g_wmax.begin(), g_wmax.end());
   printf("write pass: longest lane (symbols) per workgroup: p50 %ld p90 %ld p99 %ld max %ld\n", pct(g_wmax, .5), pct(g_wmax, .9), pct(g_wmax, .99), g_wmax.back());
+  { long tot = 0, acc = 0; for (long v : g_nblk) tot += v;
+    printf("block starts per slice: ");
+    for (size_t n = 0; n < g_nblk.size(); n++) { acc += g_nblk[n]; if (n == 17 || n == 21 || n == 25 || n == 29 || n == 33 || n == 41 || n == 65) printf(" <=%zu: %.4f", n, (double)acc / tot); }
+    printf("  max %zu\n", g_nblk.size() - 1); }
   printf("re-decodes in rounds >= 2: same out %ld, same (pos,z) other c %ld, other pos %ld\n", g_cls[0], g_cls[1], g_cls[2]);
   return 0;
 }
