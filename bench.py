@@ -1454,8 +1454,19 @@ def main():
                 root = tempfile.mkdtemp(prefix="dali_amd_bench_")
                 write_dataset(root, enc_all)
             try:
-                line["e2e_pipeline"] = e2e_pipeline(root, B, local_rank)
-                line["e2e_pipeline_roi_decode"] = e2e_pipeline(root, B, local_rank, roi_decode=True)
+                # what an end-to-end leg cannot exceed on this box: every encoded byte crosses the bus once per image
+                h2d_peak = measured_h2d_ceiling(torch.device("cuda", dev_index))
+                mean_file = float(np.mean([len(e) for e in enc_all]))
+
+                def with_pcie(res):
+                    ach = res["value"] * mean_file / 1e9
+                    res["pcie"] = {"bound": "pcie", "achieved": ach, "peak": h2d_peak, "unit": "GB/s",
+                                   "frac": ach / h2d_peak if h2d_peak else None, "bytes_per_image": mean_file,
+                                   "images_per_s_at_peak": h2d_peak * 1e9 / mean_file if h2d_peak else None,
+                                   "peak_source": "pinned host -> device copies of 256 MiB on one stream, measured in this run"}
+                    return res
+                line["e2e_pipeline"] = with_pcie(e2e_pipeline(root, B, local_rank))
+                line["e2e_pipeline_roi_decode"] = with_pcie(e2e_pipeline(root, B, local_rank, roi_decode=True))
                 line["e2e_pipeline_roi_decode"]["note"] = ("same, with decoders.image_random_crop -> resize -> "
                                                            "crop_mirror_normalize: only the crop window is decoded")
                 if not args.no_side_legs:
@@ -1534,6 +1545,9 @@ def main():
             cfg[key] = src["value"] if isinstance(src, dict) and "value" in src else None
         if isinstance(pl.get("resident_indexed"), dict):
             cfg["index_bytes_per_image"] = pl["resident_indexed"].get("index_bytes_per_image")
+        if isinstance(line.get("e2e_pipeline"), dict) and "pcie" in line["e2e_pipeline"]:
+            cfg["e2e_pcie_frac"] = line["e2e_pipeline"]["pcie"]["frac"]
+            cfg["e2e_images_per_s_at_pcie_peak"] = line["e2e_pipeline"]["pcie"]["images_per_s_at_peak"]
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(enc_all[:B])
             line["cpu_baseline_pillow"] = pillow_baseline(enc_all[:B])
