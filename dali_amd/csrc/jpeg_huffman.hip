@@ -611,7 +611,7 @@ __device__ __forceinline__ RstView MakeRstView(const daliamdJpegHuffDesc &d, con
 #ifdef DALIAMD_EXP_STAMPS
 // Development probe (tools/stamp_probe.py; never in the shipped library): wall-clock stamps (100 MHz) per workgroup of the
 // two position kernels - where a launch's time goes, workgroup by workgroup.
-__device__ unsigned long long g_stamps[2][8192 * 16];
+__device__ unsigned long long g_stamps[3][8192 * 16];
 __device__ __forceinline__ void Stamp(int which, int k) {
   if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps[which][blockIdx.x * 16 + k] = wall_clock64();
 }
@@ -1376,6 +1376,8 @@ __global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHu
   }
   const daliamdJpegHuffDesc &d = descs[lo];
   if ((d.rgb != nullptr) != kColor) return;   // the other instance's stream (uniform)
+  STAMP(2, 0);
+  STAMP_IDS(2, wg);
   const ScratchLayout lay = LayoutOf(d);
   const HuffTables *H = reinterpret_cast<const HuffTables *>(TablesBase(descs, d, false));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1437,6 +1439,7 @@ __global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHu
     }
   }
   __syncthreads();
+  STAMP(2, 1);
   const int bpm = G.bpm, mpw = kColor ? G.band_rows * G.mcus_x : McusPerWg(bpm);
   const int band = wg - d.blk_wg_start;
   const int m0 = band * mpw;
@@ -1734,6 +1737,10 @@ __global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHu
     cur = nxt;
   }
   if (kColor && my0 == 0) __syncthreads();
+  STAMP_MAX(2, 2);
+#ifdef DALIAMD_EXP_STAMPS
+  if (tid == 0 && blockIdx.x < 8192) g_stamps[2][blockIdx.x * 16 + 12] = (unsigned long long)(tasks0 * 1000 + tasks1);
+#endif
 }
 
 // Fused colour output, the seams: output rows 16 R b - 1 and 16 R b (R MCU rows per band) interpolate between the last
