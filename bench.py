@@ -410,6 +410,9 @@ def e2e_pipeline(root, batch, device_id, iters=400, threads=None, roi_decode=Fal
             "cpu_ms_per_batch_by_thread_group": cpu, "cpu_ms_per_batch": round(sum(cpu.values()), 3),
             "cpus_busy": round(sum(cpu.values()) / (1e3 * el / iters), 2),
             "shard_id": shard_id, "num_shards": num_shards, "kernels": pipe.executed_kernels(),
+            # readers.file handed out its registered file mappings and the device fetched the bytes itself (round 5; the
+            # reader's default: only when the process may use fewer than four CPUs - DESIGN.md section 6c)
+            "reader_zero_copy": "gather_encoded" in pipe.executed_kernels(),
             "note": "dali_amd.Pipeline end to end from encoded files in the page cache (file read, header parse, "
                     "H2D of the JPEG bytes on a copy stream, all device stages, fp16 CHW batch on the device)"}
 

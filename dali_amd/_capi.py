@@ -31,6 +31,11 @@ class JpegIdctDesc(C.Structure):
                 ("rect_w", C.c_int32), ("reserved", C.c_int32)]
 
 
+class GatherDesc(C.Structure):
+    """daliamdGatherDesc (include/dali_amd_kernels.h): one record of the batched device-side copy."""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("bytes", C.c_uint64), ("reserved", C.c_uint64)]
+
+
 class JpegHuffDesc(C.Structure):
     _fields_ = [("ecs", C.c_void_p), ("scratch", C.c_void_p), ("status", C.c_void_p), ("coef", C.c_void_p * 3),
                 ("ecs_len", C.c_int32), ("blocks_per_mcu", C.c_int32), ("mcus_x", C.c_int32),
@@ -179,6 +184,7 @@ _KERNEL_SYMBOLS = [
     "daliamdEventDestroy", "daliamdEventRecord", "daliamdEventSynchronize", "daliamdEventQuery", "daliamdEventElapsedMs",
     "daliamdMalloc", "daliamdFree", "daliamdHostAlloc", "daliamdHostFree", "daliamdMemcpyH2DAsync",
     "daliamdMemcpyD2HAsync", "daliamdMemcpyD2DAsync", "daliamdMemsetAsync", "daliamdMemcpy2DD2DAsync",
+    "daliamdHostRegister", "daliamdHostUnregister", "daliamdGatherCopy",
     "daliamdJpegIdctSetup", "daliamdJpegIdctRun", "daliamdJpegHuffmanScratchBytes", "daliamdJpegHuffmanScratchBytesRestart", "daliamdJpegHuffmanSetup",
     "daliamdJpegHuffmanRun", "daliamdJpegHuffmanRunProfiled", "daliamdJpegHuffmanSetupColor", "daliamdJpegHuffmanRunColor",
     "daliamdJpegHuffmanRunProfiledColor", "daliamdJpegHuffmanColorFusable", "daliamdJpegHuffmanIndexBytes", "daliamdJpegHuffmanRunFront", "daliamdJpegHuffmanRunBack", "daliamdJpegHuffmanTablesBytes", "daliamdJpegHuffmanTablesBuild", "daliamdJpegColorSetup", "daliamdJpegPlanRoi", "daliamdJpegColorRun",

@@ -255,6 +255,99 @@ daliamdResult_t daliamdFree(void *ptr) {
   DALIAMD_HIP_CHECK(hipFree(ptr));
   return DALIAMD_SUCCESS;
 }
+daliamdResult_t daliamdHostRegister(void *ptr, size_t bytes, int *same_address) {
+  DALIAMD_REQUIRE(ptr && bytes > 0 && same_address, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdHostRegister: empty range or NULL result");
+  *same_address = 0;
+  if (hipHostRegister(ptr, bytes, hipHostRegisterDefault) != hipSuccess) {
+    (void)hipGetLastError();   // "cannot be page-locked" is an answer: the caller keeps copying
+    return DALIAMD_ERROR_HIP;
+  }
+  void *dev = nullptr;
+  if (hipHostGetDevicePointer(&dev, ptr, 0) == hipSuccess) *same_address = dev == ptr ? 1 : 0;
+  else (void)hipGetLastError();
+  return DALIAMD_SUCCESS;
+}
+daliamdResult_t daliamdHostUnregister(void *ptr) {
+  DALIAMD_HIP_CHECK(hipHostUnregister(ptr));
+  return DALIAMD_SUCCESS;
+}
+
+namespace daliamd {
+// Workgroup (x = chunk, y = record): kGatherChunk bytes of one record, 16 bytes per lane and load; the loads of a lane
+// are all issued before its stores (a read out of host memory takes microseconds: the bus is kept busy by the bytes
+// in flight, 4 KB per wave here).  Source and destination share no alignment: the 16-byte units are laid on the
+// SOURCE's grid (every load is one aligned bus read inside the record - never a byte in front of it or behind it, the
+// neighbouring page of a file mapping may not exist), the stores go out as they fall.
+#ifndef DALIAMD_GATHER_UNITS
+#define DALIAMD_GATHER_UNITS 4
+#endif
+#ifndef DALIAMD_GATHER_THREADS
+#define DALIAMD_GATHER_THREADS 256
+#endif
+constexpr int kGatherThreads = DALIAMD_GATHER_THREADS, kGatherUnits = DALIAMD_GATHER_UNITS, kGatherChunk = kGatherThreads * kGatherUnits * 16;
+// A FEW workgroups walk all the chunks of all the records (measured inside the pipeline, round 5: one workgroup per chunk -
+// 2 300 of them, every CU's vector-memory queue full of reads that take microseconds - doubled the duration of every other
+// kernel on the device; the bus needs about 200 KB in flight, not 37 MB).
+__global__ __launch_bounds__(kGatherThreads) void GatherCopyKernel(const daliamdGatherDesc *__restrict__ descs, int n, unsigned chunks) {
+  // (its waves issue first where they share a SIMD with compute waves: they have a handful of instructions between loads
+  // that take microseconds - starved of issue slots, a launch inside the pipeline took twice the time the bus needs)
+  __builtin_amdgcn_s_setprio(3);
+ for (unsigned long long work = blockIdx.x; work < (unsigned long long)n * chunks; work += gridDim.x) {
+  const daliamdGatherDesc d = descs[work / chunks];
+  const uint64_t first = (uint64_t)(work % chunks) * kGatherChunk;
+  const uint8_t *src = static_cast<const uint8_t *>(d.src);
+  uint8_t *dst = static_cast<uint8_t *>(d.dst);
+  // unit k covers the source bytes [base + 16 k, base + 16 k + 16), base = the source rounded down to 16
+  const uint64_t lead = (uint64_t)(reinterpret_cast<uintptr_t>(src) & 15);
+  const uint64_t total = lead + d.bytes;                     // bytes from `base` to the record's end
+  if (first >= total) continue;
+  const uint64_t u0 = first / 16, u1 = (first + kGatherChunk < total ? first + kGatherChunk : total + 15) / 16;
+  const uint8_t *base = src - lead;
+  uint4 v[kGatherUnits];
+  bool whole[kGatherUnits];
+#pragma unroll
+  for (int q = 0; q < kGatherUnits; q++) {
+    const uint64_t u = u0 + (uint64_t)q * kGatherThreads + threadIdx.x;
+    whole[q] = u < u1 && u * 16 >= lead && u * 16 + 16 <= total;
+    if (whole[q]) v[q] = *reinterpret_cast<const uint4 *>(base + u * 16);
+  }
+#pragma unroll
+  for (int q = 0; q < kGatherUnits; q++) {
+    const uint64_t u = u0 + (uint64_t)q * kGatherThreads + threadIdx.x;
+    if (u >= u1) continue;
+    if (whole[q]) {
+      uint8_t *o = dst + (u * 16 - lead);
+      if ((reinterpret_cast<uintptr_t>(o) & 15) == 0) {
+        *reinterpret_cast<uint4 *>(o) = v[q];
+      } else {
+        const uint32_t w[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+        for (int b = 0; b < 16; b++) o[b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
+      }
+    } else {   // the record's first or last unit: the bytes that belong to it, one by one
+      const uint64_t lo = u * 16 < lead ? lead : u * 16, hi = u * 16 + 16 < total ? u * 16 + 16 : total;
+      for (uint64_t b = lo; b < hi; b++) dst[b - lead] = base[b];
+    }
+  }
+ }
+}
+}  // namespace daliamd
+
+daliamdResult_t daliamdGatherCopy(const daliamdGatherDesc *descs, int n, size_t max_bytes, daliamdStream_t s) {
+  DALIAMD_REQUIRE(n >= 0 && (n == 0 || descs), DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdGatherCopy: NULL table");
+  if (n == 0 || max_bytes == 0) return DALIAMD_SUCCESS;
+  const size_t chunks = (max_bytes + 15 + daliamd::kGatherChunk - 1) / daliamd::kGatherChunk;
+  DALIAMD_REQUIRE(chunks <= 0x7fffffffu, DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdGatherCopy: record too long");
+  {
+    daliamd::KernelTimer timer("GatherCopyKernel", (hipStream_t)s);
+    static const int wgs = [] { const char *e = getenv("DALI_AMD_GATHER_WGS"); return e && atoi(e) > 0 ? atoi(e) : 64; }();
+    const unsigned long long work = (unsigned long long)n * chunks;
+    hipLaunchKernelGGL(daliamd::GatherCopyKernel, dim3((unsigned)(work < (unsigned long long)wgs ? work : wgs)), dim3(daliamd::kGatherThreads), 0,
+                       (hipStream_t)s, descs, n, (unsigned)chunks);
+  }
+  DALIAMD_HIP_CHECK(hipGetLastError());
+  return DALIAMD_SUCCESS;
+}
 daliamdResult_t daliamdHostAlloc(void **ptr, size_t bytes) {
   DALIAMD_REQUIRE(ptr, DALIAMD_ERROR_INVALID_ARGUMENT, "ptr is NULL");
   DALIAMD_HIP_CHECK(hipHostMalloc(ptr, bytes, hipHostMallocDefault));

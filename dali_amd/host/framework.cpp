@@ -101,6 +101,7 @@ void TensorList::Resize(const std::vector<TensorShape> &shapes, DALIDataType typ
   for (void *p : ext_ptr) any_ext |= p != nullptr;
   if (any_ext) { ext_ = ext_ptr; ext_.resize(n, nullptr); ext_owner_ = std::move(keepalive); }
   else { ext_.clear(); ext_owner_.reset(); }
+  ext_device_visible_ = false;
   size_t off = 0;
   int esz = TypeSize(type);
   for (int i = 0; i < n; i++) {
@@ -144,7 +145,7 @@ bool TensorList::is_dense() const {
 void TensorList::ShareData(const TensorList &o) {
   buf_ = o.buf_; dev_ = o.dev_; type_ = o.type_; layout_ = o.layout_; shapes_ = o.shapes_;
   offsets_ = o.offsets_; pitch_ = o.pitch_; sizes_ = o.sizes_; total_ = o.total_;
-  ext_ = o.ext_; ext_owner_ = o.ext_owner_;
+  ext_ = o.ext_; ext_owner_ = o.ext_owner_; ext_device_visible_ = o.ext_device_visible_;
   deferred = o.deferred; deferred_pointwise = o.deferred_pointwise; deferred_audio = o.deferred_audio;
   deferred_blur = o.deferred_blur; source_info = o.source_info;
 }

@@ -142,6 +142,11 @@ class TensorList {
   void Resize(const std::vector<TensorShape> &shapes, DALIDataType type, int pitch_align, const std::vector<void *> &ext_ptr,
               const std::vector<int64_t> &ext_pitch, std::shared_ptr<void> keepalive);
   bool is_external(int i) const { return !ext_.empty() && ext_[i]; }
+  bool has_external() const { for (void *p : ext_) if (p) return true; return false; }
+  // external CPU samples that the device can read where they are (host memory registered with the device at the same
+  // address: readers.file hands out its registered file mappings this way; daliamdHostRegister)
+  bool ext_device_visible() const { return ext_device_visible_; }
+  void SetExtDeviceVisible(bool v) { ext_device_visible_ = v; }
   // the one block behind the samples (raw(i) - base() is sample i's offset) and whether it is page-locked: a device
   // operator may then transfer straight from it instead of staging a copy
   const void *base() const { return buf_->data(); }
@@ -170,6 +175,7 @@ class TensorList {
   size_t total_ = 0;
   std::vector<void *> ext_;
   std::shared_ptr<void> ext_owner_;
+  bool ext_device_visible_ = false;
 };
 
 // ---------------------------------------------------------------------------------------------

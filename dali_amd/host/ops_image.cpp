@@ -224,7 +224,14 @@ class ImageDecoderMixed : public OperatorBase {
     // hits in the batch, or input from elsewhere, the segments of the active samples are packed into the staging
     // buffer as before.)
     const bool direct = nact == n && nehit == 0 && n > 0 && in.device() == StorageDevice::CPU && in.pinned() &&
-                        !in.is_external(0);
+                        !in.has_external();
+    // Round 5: the reader handed out its file mappings, registered with the device (TensorList::ext_device_visible) - the
+    // device fetches the entropy-coded segments itself (daliamdGatherCopy on the copy stream, where the transfer was): the
+    // bytes cross the bus once and no host core touches them; only the descriptor tables are still uploaded.  All or
+    // nothing: a batch with a sample that is not in such a mapping yet (its first sighting) is staged as before.
+    bool gather = !direct && nact > nehit && in.device() == StorageDevice::CPU && in.ext_device_visible();
+    for (int i = 0; i < n && gather; i++)
+      if (!hit_[i] && !erec_[i] && !in.is_external(i)) gather = false;
     ecs_off_.assign(n, 0);
     size_t ecs_bytes = 0;
     for (int i = 0; i < n; i++) {
@@ -237,8 +244,8 @@ class ImageDecoderMixed : public OperatorBase {
     // ONE host->device copy (on the copy stream) carries everything the kernels need
     auto align16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
     const size_t table_bytes = align16((size_t)n * sizeof(daliamdJpegHuffDesc)) + align16((size_t)n * 3 * sizeof(daliamdJpegIdctDesc)) +
-                               align16((size_t)n * sizeof(daliamdJpegColorDesc));
-    ecs_stage.Reserve((direct ? 0 : ecs_bytes) + table_bytes + 256);
+                               align16((size_t)n * sizeof(daliamdJpegColorDesc)) + align16((size_t)n * sizeof(daliamdGatherDesc));
+    ecs_stage.Reserve((direct || gather ? 0 : ecs_bytes) + table_bytes + 256);
     for (int i = 0; i < n; i++) {
       if (hit_[i]) {
         infos_[i] = daliamdJpegInfo{};  // no components: every per-component loop below skips the sample
@@ -275,7 +282,7 @@ class ImageDecoderMixed : public OperatorBase {
         DALI_ENFORCE(infos_[i].num_components == 1 || infos_[i].num_components == 3, "Failed to decode ", src(i),
                      ": JPEG with ", infos_[i].num_components, " components is not supported");
         if ((int64_t)infos_[i].width * infos_[i].height < huffman_threshold_) scans_[i].eligible = 0;
-        if (scans_[i].eligible && !direct)
+        if (scans_[i].eligible && !direct && !gather)
           memcpy(static_cast<uint8_t *>(ecs_stage.data()) + ecs_off_[i], data + scans_[i].ecs_offset,
                  (size_t)scans_[i].ecs_length);
       }, (int64_t)in.nbytes(i));
@@ -484,9 +491,12 @@ class ImageDecoderMixed : public OperatorBase {
     const uint8_t *dev_base = static_cast<const uint8_t *>(ecs_dev.data());
     const size_t huff_off = align16(ecs_bytes), idct_off = huff_off + align16((size_t)ngpu * sizeof(daliamdJpegHuffDesc));
     const size_t color_off = idct_off + align16((size_t)ncomp_total * sizeof(daliamdJpegIdctDesc));
-    const size_t upload_bytes = color_off + align16((size_t)nact * sizeof(daliamdJpegColorDesc));
-    // host copy of the tables: behind the packed segments, or (direct transfer) at the start of the staging buffer
-    uint8_t *tab_host = stage_base + (direct ? 0 : huff_off);
+    const size_t gather_off = color_off + align16((size_t)nact * sizeof(daliamdJpegColorDesc));
+    const size_t upload_bytes = gather_off + (gather ? align16((size_t)ngpu * sizeof(daliamdGatherDesc)) : 0);
+    // host copy of the tables: behind the packed segments, or (direct transfer, device-side fetch) at the start of the staging buffer
+    uint8_t *tab_host = stage_base + (direct || gather ? 0 : huff_off);
+    daliamdGatherDesc *fetch = reinterpret_cast<daliamdGatherDesc *>(tab_host + (gather_off - huff_off));
+    size_t fetch_max = 0;
     daliamdJpegHuffDesc *huff = reinterpret_cast<daliamdJpegHuffDesc *>(tab_host);
     daliamdJpegIdctDesc *idct = reinterpret_cast<daliamdJpegIdctDesc *>(tab_host + (idct_off - huff_off));
     daliamdJpegColorDesc *color = reinterpret_cast<daliamdJpegColorDesc *>(tab_host + (color_off - huff_off));
@@ -538,6 +548,14 @@ class ImageDecoderMixed : public OperatorBase {
         }
         d.tables = tables;
         d.ecs = erec_[i] ? erec_[i]->ecs : dev_base + ecs_off_[i] + (direct ? (size_t)sc.ecs_offset : 0);
+        if (gather) {
+          // the segment where the file's mapping holds it -> its place in this iteration's buffer, on the source's 16-byte grid
+          const uint8_t *src = static_cast<const uint8_t *>(in.raw(i)) + sc.ecs_offset;
+          const size_t shift = reinterpret_cast<uintptr_t>(src) & 15;
+          if (!erec_[i]) d.ecs = dev_base + ecs_off_[i] + shift;
+          fetch[j] = daliamdGatherDesc{src, const_cast<uint8_t *>(d.ecs), erec_[i] ? 0u : (uint64_t)sc.ecs_length, 0};
+          if (!erec_[i]) fetch_max = std::max(fetch_max, (size_t)sc.ecs_length);
+        }
         d.index = erec_[i] ? erec_[i]->index : nullptr;   // a resident stream with its side information: decoded from that
         d.scratch = static_cast<uint8_t *>(scratch.data()) + scratch_off_[i];
         d.status = status + j;
@@ -663,6 +681,10 @@ class ImageDecoderMixed : public OperatorBase {
     if (direct) {
       KCHECK(daliamdMemcpyH2DAsync(ecs_dev.data(), in.base(), in.total_bytes(), cs));
       KCHECK(daliamdMemcpyH2DAsync(static_cast<uint8_t *>(ecs_dev.data()) + huff_off, tab_host, upload_bytes - huff_off, cs));
+    } else if (gather) {
+      KCHECK(daliamdMemcpyH2DAsync(static_cast<uint8_t *>(ecs_dev.data()) + huff_off, tab_host, upload_bytes - huff_off, cs));
+      KCHECK(daliamdGatherCopy(reinterpret_cast<const daliamdGatherDesc *>(dev_base + gather_off), ngpu, fetch_max, cs));
+      NoteLaunch(ws, "gather_encoded");
     } else {
       KCHECK(daliamdMemcpyH2DAsync(ecs_dev.data(), ecs_stage.data(), upload_bytes, cs));
     }

@@ -8,6 +8,7 @@
 #include <dirent.h>
 #include <fcntl.h>
 #include <fnmatch.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/resource.h>
 #include <sys/stat.h>
@@ -359,6 +360,26 @@ class FileReaderOp : public OperatorBase {
     // means TLB shoot-downs on every core the process runs on); files beyond the budget are read with pread.
     maps_ = std::make_unique<std::atomic<const char *>[]>(entries_.size());
     for (size_t i = 0; i < entries_.size(); i++) maps_[i].store(nullptr, std::memory_order_relaxed);
+    // Round 5: a mapping is also REGISTERED with the device (daliamdHostRegister: the page cache's pages, page-locked and
+    // addressed by the device where they are).  From its second sighting on such a file is not copied at all: the sample
+    // the reader hands out IS the mapping, and a mixed decoder fetches the bytes with a device-side copy - they cross the
+    // bus once and no host core touches them (the copy out of the mapping was 60 % of the pipeline's host time per
+    // image).  Bounded by the mapping budget below.
+    // WHEN: measured on the bench box (gpurun_out/r05_r, r05_t - r05_v), the device-side fetch is the better way when host
+    // cores are what a rank lacks - one rank of eight on 2 of 16 CPUs: 314 k img/s against 238 k, 3.9 ms of CPU per
+    // 512-image batch against 5.6 - and the worse one when they are not: alone it runs at the bus rate (56 GB/s, the copy
+    // engine out of page-locked memory: 52), but inside the busy pipeline it takes 0.6-0.8 ms per batch instead of 0.43
+    // and the kernels next to it run 1.3-1.8 times longer (one rank on 16 CPUs: 300 k against 410-480 k).  Hence the
+    // default: on when this process may run on fewer than four CPUs, off otherwise; DALI_AMD_READER_ZERO_COPY=1 / 0 decides.
+    visible_ = std::make_unique<std::atomic<uint8_t>[]>(entries_.size());
+    for (size_t i = 0; i < entries_.size(); i++) visible_[i].store(0, std::memory_order_relaxed);
+    {
+      cpu_set_t set;
+      CPU_ZERO(&set);
+      const int cpus = sched_getaffinity(0, sizeof(set), &set) == 0 ? CPU_COUNT(&set) : 0;
+      zero_copy_ = cpus > 0 && cpus < 4;
+    }
+    if (const char *e = getenv("DALI_AMD_READER_ZERO_COPY")) zero_copy_ = atoi(e) != 0;
     // Both budgets are PROCESS-wide: the mappings of all readers of the process together stay below
     // DALI_AMD_READER_MMAP_MB (4096 by default; 0: plain reads) - SharedMappedBytes() - and a reader keeps at most
     // DALI_AMD_READER_FD_CAP descriptors open, by default a quarter of the soft limit the process was STARTED with.  The
@@ -387,6 +408,7 @@ class FileReaderOp : public OperatorBase {
       if (fd >= 0) close(fd);
       const char *m = maps_[i].load(std::memory_order_relaxed);
       if (m && m != kNoMapping) {
+        if (visible_[i].load(std::memory_order_relaxed) & 2) daliamdHostUnregister(const_cast<char *>(m));
         munmap(const_cast<char *>(m), (size_t)size_cache_[i]);
         SharedMappedBytes().fetch_sub((int64_t)size_cache_[i], std::memory_order_relaxed);
       }
@@ -515,6 +537,8 @@ class FileReaderOp : public OperatorBase {
     b.tasks.clear();
     b.next_task = 0;
     std::vector<TensorShape> shapes(n), lshape(n, TensorShape{1});
+    std::vector<void *> ext(n, nullptr);
+    bool any_ext = false;
     // skip_cached_images (loader.h:466-480, file_label_loader.cc:49-56): a sample the decoder cache of this device holds
     // is not read - its tensor is empty, the decoder finds it by its source_info.  The caches are looked up at run time:
     // the decoder that owns them may be constructed after the reader.
@@ -534,9 +558,20 @@ class FileReaderOp : public OperatorBase {
       }
       b.sizes[i] = cached;
       shapes[i] = {(int64_t)cached};
+      if (zero_copy_ && cached > 0 && (visible_[idx].load(std::memory_order_acquire) & 1)) {
+        // mapped, registered, device-visible: the sample is the mapping (which stays until the reader goes)
+        ext[i] = const_cast<char *>(maps_[idx].load(std::memory_order_acquire));
+        any_ext = true;
+        continue;
+      }
       b.tasks.push_back(i);
     }
-    b.data.Resize(shapes, DALI_UINT8);
+    if (any_ext) {
+      b.data.Resize(shapes, DALI_UINT8, 1, ext, std::vector<int64_t>(n, 0), nullptr);
+      b.data.SetExtDeviceVisible(true);
+    } else {
+      b.data.Resize(shapes, DALI_UINT8);
+    }
     b.labels.Resize(lshape, DALI_INT32);
     b.data.source_info.resize(n);
     for (int i = 0; i < n; i++) {
@@ -574,6 +609,7 @@ class FileReaderOp : public OperatorBase {
 
   // ---- readers ----
   void WorkerLoop() {
+    if (HaveDevice()) daliamdSetDevice(device_id_);   // mappings are registered with this pipeline's device
     for (;;) {
       std::shared_ptr<Prefetched> b;
       size_t t0 = 0, t1 = 0;
@@ -647,6 +683,12 @@ class FileReaderOp : public OperatorBase {
       SharedMappedBytes().fetch_sub((int64_t)size, std::memory_order_relaxed);
       return expected == kNoMapping ? nullptr : expected;
     }
+    if (zero_copy_ && HaveDevice()) {
+      // bit 1: registered (to be taken back before the mapping goes), bit 0: and the device reads it at this address
+      int same = 0;
+      if (daliamdHostRegister(p, (size_t)size, &same) == DALIAMD_SUCCESS)
+        visible_[idx].store(same ? 3 : 2, std::memory_order_release);
+    }
     return static_cast<const char *>(p);
   }
 
@@ -709,6 +751,8 @@ class FileReaderOp : public OperatorBase {
 
   Loader loader_;                 // planner thread only once the threads run
   bool skip_cached_, read_ahead_, use_mmap_;
+  std::unique_ptr<std::atomic<uint8_t>[]> visible_;      // per file: see Mapping()
+  bool zero_copy_ = false;
   std::unique_ptr<std::atomic<const char *>[]> maps_;   // per file: nullptr = not tried yet, kNoMapping = pread, else the mapping
   static inline const char *const kNoMapping = reinterpret_cast<const char *>(1);
   // bytes mapped by every readers.file of the process (the budget is per process, not per reader)

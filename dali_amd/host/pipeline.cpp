@@ -152,7 +152,8 @@ void Pipeline::Build(const std::vector<std::pair<std::string, std::string>> &out
     for (int i = 0; i < distinct; i++) KCHECK(daliamdStreamCreate(&streams_[i], 1));
     // The copy stream carries the descriptor tables (and the JPEG bytes) of the NEXT iteration: highest priority = a
     // hardware queue it does not share with any compute stream, or the upload waits behind a 0.3 ms kernel
-    KCHECK(daliamdStreamCreateWithPriority(&copy_stream_, 1, -1));
+    // (DALI_AMD_COPY_STREAM_PRIORITY: -1 / 0 / 1, for measurements)
+    KCHECK(daliamdStreamCreateWithPriority(&copy_stream_, 1, getenv("DALI_AMD_COPY_STREAM_PRIORITY") ? atoi(getenv("DALI_AMD_COPY_STREAM_PRIORITY")) : -1));
     // ... and one for the small set-up launches of an iteration that need host data only (DALI_AMD_AUX_STREAM=0: none,
     // they stay on the compute stream)
     if (!(getenv("DALI_AMD_AUX_STREAM") && atoi(getenv("DALI_AMD_AUX_STREAM")) == 0))

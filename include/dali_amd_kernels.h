@@ -93,6 +93,25 @@ DALIAMD_API daliamdResult_t daliamdMemcpyH2DAsync(void *dst, const void *src, si
 DALIAMD_API daliamdResult_t daliamdMemcpyD2HAsync(void *dst, const void *src, size_t bytes, daliamdStream_t s);
 DALIAMD_API daliamdResult_t daliamdMemcpyD2DAsync(void *dst, const void *src, size_t bytes, daliamdStream_t s);
 DALIAMD_API daliamdResult_t daliamdMemsetAsync(void *dst, int value, size_t bytes, daliamdStream_t s);
+/* Host memory the device reads IN PLACE (round 5; no reference counterpart: the reference's readers copy every file out of
+ * its mapping, dali/util/mmaped_file.cc / operators/reader/loader/file_label_loader.cc, and the mixed decoder copies it
+ * again to the device): page-locks [ptr, ptr + bytes) - e.g. a read-only file mapping, i.e. the page cache's own pages -
+ * and reports in *same_address whether the device addresses the range at the same addresses (it does on MI355X; a caller
+ * that gets 0 keeps copying).  Measured on the bench box: a device-side copy out of such a mapping runs at the bus rate
+ * (57 GB/s), the registration of 64 MiB takes 0.2 ms (tools/probes/hostreg_probe.py). */
+DALIAMD_API daliamdResult_t daliamdHostRegister(void *ptr, size_t bytes, int *same_address);
+DALIAMD_API daliamdResult_t daliamdHostUnregister(void *ptr);
+/* Batched device-side copy: record i moves `bytes` bytes from src (device-visible memory: device, page-locked or
+ * registered host memory) to dst (device), any alignment; one launch for the whole table (`descs`: device-visible,
+ * `max_bytes` >= every record's bytes).  The mixed decoders fetch the encoded files of a batch with it straight out of
+ * the reader's registered file mappings - the files cross the bus once and no host core touches their bytes. */
+typedef struct {
+  const void *src;
+  void *dst;
+  uint64_t bytes;
+  uint64_t reserved;
+} daliamdGatherDesc;
+DALIAMD_API daliamdResult_t daliamdGatherCopy(const daliamdGatherDesc *descs, int n, size_t max_bytes, daliamdStream_t s);
 /* rows of `width_bytes` between two pitched device buffers (e.g. a row-padded image -> dense) */
 DALIAMD_API daliamdResult_t daliamdMemcpy2DD2DAsync(void *dst, size_t dst_pitch, const void *src, size_t src_pitch,
                                                     size_t width_bytes, size_t height, daliamdStream_t s);

@@ -211,6 +211,7 @@ template <int Site, typename T> T ShflXor(T v, int m, int width = 64) { return S
 #define __ballot(...) ::hipemu::Ballot<__COUNTER__>(__VA_ARGS__)
 #define __any(...) (::hipemu::Ballot<__COUNTER__>(__VA_ARGS__) != 0)
 #define __builtin_amdgcn_readfirstlane(...) ::hipemu::FirstLane<__COUNTER__>((uint32_t)(__VA_ARGS__))
+#define __builtin_amdgcn_s_setprio(p) ((void)0)
 #define __builtin_amdgcn_wave_barrier() ::hipemu::WaveBarrier<__COUNTER__>()
 static inline unsigned __lane_id() { return (unsigned)::hipemu::LaneId(); }
 
@@ -369,6 +370,11 @@ template <typename T> static inline hipError_t hipHostMalloc(T **p, size_t n, un
   return ::hipemu::HostMalloc((void **)p, n);
 }
 static inline hipError_t hipHostFree(void *p) { return ::hipemu::HostFree(p); }
+// host memory registered for device access: the model's "device" reads host memory anyway
+enum { hipHostRegisterDefault = 0 };
+static inline hipError_t hipHostRegister(void *, size_t, unsigned) { return hipSuccess; }
+static inline hipError_t hipHostUnregister(void *) { return hipSuccess; }
+static inline hipError_t hipHostGetDevicePointer(void **dev, void *host, unsigned) { *dev = host; return hipSuccess; }
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) {
   if (n) memmove(d, s, n);
   return hipSuccess;
