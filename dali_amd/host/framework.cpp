@@ -1,4 +1,5 @@
 #include "framework.h"
+#include <time.h>
 
 #include <pthread.h>
 #include <sched.h>
@@ -573,6 +574,21 @@ std::vector<std::vector<float>> GetPerSampleFloatVec(const OpSpec &spec, const W
   return out;
 }
 
+void SleepWaitEvent(daliamdEvent_t event) {
+  static const bool poll = [] { const char *e = getenv("DALI_AMD_OUTPUT_WAIT"); return !(e && std::string(e) == "block"); }();
+  if (!poll) {
+    KCHECK(daliamdEventSynchronize(event));
+    return;
+  }
+  for (;;) {
+    int done = 0;
+    KCHECK(daliamdEventQuery(event, &done));
+    if (done) return;
+    struct timespec ts{0, 50000};
+    nanosleep(&ts, nullptr);
+  }
+}
+
 // ------------------------------------------------------------------------------------------ DescUploader
 void *DescUploader::Upload(const void *host, size_t bytes, daliamdStream_t stream, int min_slots, size_t scratch_bytes) {
   if ((int)slots_.size() < min_slots) {  // grow: new (unused) slots go behind the cursor
@@ -581,7 +597,7 @@ void *DescUploader::Upload(const void *host, size_t bytes, daliamdStream_t strea
   if (next_ >= (int)slots_.size()) next_ = 0;
   Slot &s = slots_[next_];
   next_ = (next_ + 1) % (int)slots_.size();
-  if (s.used) KCHECK(daliamdEventSynchronize(s.ev));  // the previous copy from this slot must be done
+  if (s.used) SleepWaitEvent(s.ev);  // the previous copy from this slot must be done
   if (bytes > s.cap) {
     if (s.pinned) daliamdHostFree(s.pinned);
     s.cap = (bytes * 3 / 2 + 4095) & ~(size_t)4095;

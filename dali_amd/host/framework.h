@@ -451,6 +451,14 @@ std::vector<std::vector<float>> GetPerSampleFloatVec(const OpSpec &spec, const W
                                                      int nsamples);
 
 // Pinned staging + asynchronous upload of descriptor tables, shared by device operators.
+// Waits for `event` without keeping the calling thread on a CPU: asks, sleeps 50 us, asks again.  hipEventSynchronize - on
+// an event made with hipEventBlockingSync as well - stayed on a CPU for the whole wait on the bench box: the consumer's wait
+// for an iteration's device work cost 1.5 ms of the main thread's CPU per 2.9 ms batch for one rank's share of an 8-GPU node
+// (40 % of the pipeline's host cost), 0.65 ms per 0.62 ms batch with 16 CPUs; asking and sleeping: 0.03-0.05 ms, the same rate
+// (gpurun_out/r05_w; the consumer is `prefetch_queue_depth` iterations behind the producer - the wait usually finds the work
+// done).  DALI_AMD_OUTPUT_WAIT=block: hipEventSynchronize as before.
+void SleepWaitEvent(daliamdEvent_t event);
+
 class DescUploader {
  public:
   // copies `bytes` to a device buffer that stays valid for `min_slots` further uploads.  Consecutive iterations run

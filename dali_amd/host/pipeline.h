@@ -169,6 +169,7 @@ class Pipeline {
     std::vector<std::function<void()>> checks;
   } pending_checks_;
   void RunPendingChecks();
+  void WaitForSlot(int slot);
   std::vector<std::shared_ptr<TensorList>> TakeOutputs(daliamdStream_t consumer_stream, bool on_stream);
   int64_t scheduled_ = 0, consumed_ = 0;
   bool stop_ = false;

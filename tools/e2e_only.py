@@ -21,14 +21,20 @@ for variant in sys.argv[1:] or [""]:
     for kv in variant.split():
         k, v = kv.split("=")
         os.environ[k] = v
-    bench.e2e_pipeline(root, 256, 0, iters=60)                       # warm: mappings made and registered
+    kw = dict(batch=256, iters=200, threads=None)
+    allowed = sorted(os.sched_getaffinity(0))
+    if os.environ.get("E2E_WORLD8", "0") != "0":   # bench.py's e2e_pipeline_local_world8: 2 of the usable CPUs, batch 512, thread pools of 2
+        os.sched_setaffinity(0, set(allowed[:2]))
+        kw = dict(batch=512, iters=100, threads=2)
+    bench.e2e_pipeline(root, kw["batch"], 0, iters=60, threads=kw["threads"])                       # warm: mappings made and registered
     lib.daliamdKernelTimingEnable(4096)
-    res = bench.e2e_pipeline(root, 256, 0, iters=200)
+    res = bench.e2e_pipeline(root, kw["batch"], 0, iters=kw["iters"], threads=kw["threads"])
+    os.sched_setaffinity(0, set(allowed))
     buf = C.create_string_buffer(1 << 16)
     lib.daliamdKernelTimingReport(buf, len(buf))
     lib.daliamdKernelTimingEnable(0)
     kern = {ln.split("\t")[0].replace("Kernel", ""): round(float(ln.split("\t")[2]), 3) for ln in buf.value.decode().splitlines() if ln}
-    print("%-60s %8.0f img/s  cpu %.2f ms/batch  gather %s\n      %s" % (variant or "(default)", res["value"], res["cpu_ms_per_batch"],
-                                                                     "gather_encoded" in res["kernels"], kern), flush=True)
+    print("%-60s %8.0f img/s  cpu %.2f ms/batch %s gather %s\n      %s" % (variant or "(default)", res["value"], res["cpu_ms_per_batch"],
+                                                                     res["cpu_ms_per_batch_by_thread_group"], "gather_encoded" in res["kernels"], kern), flush=True)
     os.environ.clear()
     os.environ.update(saved)
