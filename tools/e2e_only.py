@@ -28,7 +28,33 @@ for variant in sys.argv[1:] or [""]:
         kw = dict(batch=512, iters=100, threads=2)
     bench.e2e_pipeline(root, kw["batch"], 0, iters=60, threads=kw["threads"])                       # warm: mappings made and registered
     lib.daliamdKernelTimingEnable(4096)
+
+    def per_thread():
+        out = {}
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                comm = open(f"/proc/self/task/{tid}/comm").read().strip()
+                ns = int(open(f"/proc/self/task/{tid}/schedstat").read().split()[0])
+                st = open(f"/proc/self/task/{tid}/stat").read().rsplit(")", 1)[1].split()
+                wchan = open(f"/proc/self/task/{tid}/wchan").read().strip()
+                try:
+                    sysc = open(f"/proc/self/task/{tid}/syscall").read().split()[0]
+                except OSError:
+                    sysc = "?"
+                out[int(tid)] = (comm, ns * 1e-9, st[0], wchan, sysc, int(st[11]) + int(st[12]))
+            except (OSError, ValueError, IndexError):
+                pass
+        return out
+    before = per_thread()
     res = bench.e2e_pipeline(root, kw["batch"], 0, iters=kw["iters"], threads=kw["threads"])
+    after = per_thread()
+    if os.environ.get("E2E_THREADS"):
+        rows = sorted(((after[t][1] - before.get(t, after[t])[1], t) for t in after), reverse=True)[:8]
+        for dt, t in rows:
+            c = after[t]
+            print("      tid %d (%s, %s main) cpu %.3f s = %.3f ms/batch  state %s wchan %s syscall %s" % (
+                t, c[0], "is" if t == os.getpid() else "not", dt, 1e3 * dt / kw["iters"], c[2], c[3], c[4]), flush=True)
+        print("      threads of the process, in creation order:", [(t, after[t][0]) for t in sorted(after)], flush=True)
     os.sched_setaffinity(0, set(allowed))
     buf = C.create_string_buffer(1 << 16)
     lib.daliamdKernelTimingReport(buf, len(buf))
