@@ -371,6 +371,11 @@ class FileReaderOp : public OperatorBase {
     // engine out of page-locked memory: 52), but inside the busy pipeline it takes 0.6-0.8 ms per batch instead of 0.43
     // and the kernels next to it run 1.3-1.8 times longer (one rank on 16 CPUs: 300 k against 410-480 k).  Hence the
     // default: on when this process may run on fewer than four CPUs, off otherwise; DALI_AMD_READER_ZERO_COPY=1 / 0 decides.
+    // Rule that comes with it: a data set file must not be TRUNCATED while a reader that registered it lives - the pages are
+    // page-locked for the device, the driver evicts the process's queues when they go away and cannot bring them back
+    // (measured: tests/test_gpu_encoded_cache.py's "files may disappear" case stalled for minutes with the switch on; with the
+    // copying reader the same act is a SIGBUS in memcpy, as in the reference's mmap loader).  Deleting or replacing files
+    // (unlink, rename) is fine: the mapping keeps the old inode.
     visible_ = std::make_unique<std::atomic<uint8_t>[]>(entries_.size());
     for (size_t i = 0; i < entries_.size(); i++) visible_[i].store(0, std::memory_order_relaxed);
     {
