@@ -337,6 +337,37 @@ int64_t Loader::NextIndex(bool is_new_batch) {
 //                 the output - no copy; the block goes back to the planner when no ring slot refers to it any more.
 //                 The decoder transfers the page-locked block to the device as it is.
 // Checkpoints describe what has been HANDED OUT: every planned batch carries the Loader's state behind its picks.
+// CPUs this process can count on: the affinity mask, capped by the cgroup's CPU quota (v2: cpu.max, v1: cfs_quota_us /
+// cfs_period_us), shared between the ranks a launcher put on this node (LOCAL_WORLD_SIZE; 1 when unset).  0: unknown.
+static double UsableCpusPerRank() {
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  double cpus = sched_getaffinity(0, sizeof(set), &set) == 0 ? (double)CPU_COUNT(&set) : 0.0;
+  if (cpus <= 0) return 0.0;
+  auto read_pair = [](const char *path, double *a, double *b) {
+    FILE *f = fopen(path, "r");
+    if (!f) return 0;
+    char first[64] = {0};
+    double second = 0;
+    const int n = fscanf(f, "%63s %lf", first, &second);
+    fclose(f);
+    if (n < 1 || !strcmp(first, "max")) return 0;
+    *a = atof(first);
+    if (b) *b = second;
+    return n;
+  };
+  double quota = 0, period = 0;
+  if (read_pair("/sys/fs/cgroup/cpu.max", &quota, &period) == 2 && quota > 0 && period > 0) {
+    cpus = std::min(cpus, quota / period);
+  } else if (read_pair("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", &quota, nullptr) >= 1 && quota > 0 &&
+             read_pair("/sys/fs/cgroup/cpu/cpu.cfs_period_us", &period, nullptr) >= 1 && period > 0) {
+    cpus = std::min(cpus, quota / period);
+  }
+  int ranks = 1;
+  if (const char *e = getenv("LOCAL_WORLD_SIZE")) ranks = std::max(1, atoi(e));
+  return cpus / ranks;
+}
+
 class FileReaderOp : public OperatorBase {
  public:
   explicit FileReaderOp(const OpSpec &spec)
@@ -370,7 +401,10 @@ class FileReaderOp : public OperatorBase {
     // 512-image batch against 5.6 - and the worse one when they are not: alone it runs at the bus rate (56 GB/s, the copy
     // engine out of page-locked memory: 52), but inside the busy pipeline it takes 0.6-0.8 ms per batch instead of 0.43
     // and the kernels next to it run 1.3-1.8 times longer (one rank on 16 CPUs: 300 k against 410-480 k).  Hence the
-    // default: on when this process may run on fewer than four CPUs, off otherwise; DALI_AMD_READER_ZERO_COPY=1 / 0 decides.
+    // default: on when this process has at most four CPUs to itself - affinity mask and cgroup CPU quota, divided by the
+    // ranks of the node (LOCAL_WORLD_SIZE) -, off otherwise (the copying path needs 3.1-3.5 ms of CPU per 256-image batch:
+    // with four CPUs it is host-bound at about the rate the device-side fetch reaches);
+    // DALI_AMD_READER_ZERO_COPY=1 / 0 decides.
     // Rule that comes with it: a data set file must not be TRUNCATED while a reader that registered it lives - the pages are
     // page-locked for the device, the driver evicts the process's queues when they go away and cannot bring them back
     // (measured: tests/test_gpu_encoded_cache.py's "files may disappear" case stalled for minutes with the switch on; with the
@@ -379,10 +413,8 @@ class FileReaderOp : public OperatorBase {
     visible_ = std::make_unique<std::atomic<uint8_t>[]>(entries_.size());
     for (size_t i = 0; i < entries_.size(); i++) visible_[i].store(0, std::memory_order_relaxed);
     {
-      cpu_set_t set;
-      CPU_ZERO(&set);
-      const int cpus = sched_getaffinity(0, sizeof(set), &set) == 0 ? CPU_COUNT(&set) : 0;
-      zero_copy_ = cpus > 0 && cpus < 4;
+      const double cpus = UsableCpusPerRank();
+      zero_copy_ = cpus > 0 && cpus <= 4.0;
     }
     if (const char *e = getenv("DALI_AMD_READER_ZERO_COPY")) zero_copy_ = atoi(e) != 0;
     // Both budgets are PROCESS-wide: the mappings of all readers of the process together stay below
