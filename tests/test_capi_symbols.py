@@ -52,11 +52,11 @@ def test_struct_sizes_match_the_c_headers():
 #include "dali_amd_kernels.h"
 #include "dali_amd_host.h"
 int main() {
-  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(daliamdJpegIdctDesc), sizeof(daliamdJpegColorDesc),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(daliamdJpegIdctDesc), sizeof(daliamdJpegColorDesc),
          sizeof(daliamdResampleArgs), sizeof(daliamdResampleDesc), sizeof(daliamdCmnDesc), sizeof(daliamdJpegInfo),
          sizeof(daliamdPhiloxState), sizeof(daliamdWarpAffineDesc), sizeof(daliamdGaussianBlurDesc),
          sizeof(daliamdPointwiseDesc), sizeof(daliamdJpegHuffDesc), sizeof(daliamdJpegScan),
-         sizeof(daliamdJpegRoiPlan), sizeof(daliamdNormalizeDesc));
+         sizeof(daliamdJpegRoiPlan), sizeof(daliamdNormalizeDesc), sizeof(daliamdGatherDesc));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as d:
@@ -65,7 +65,7 @@ int main() {
         sizes = [int(x) for x in subprocess.check_output([os.path.join(d, "s")]).split()]
     mirrors = [capi.JpegIdctDesc, capi.JpegColorDesc, capi.ResampleArgs, capi.ResampleDesc, capi.CmnDesc,
                capi.JpegInfo, capi.PhiloxState, capi.WarpAffineDesc, capi.GaussianBlurDesc, capi.PointwiseDesc,
-               capi.JpegHuffDesc, capi.JpegScan, capi.JpegRoiPlan, capi.NormalizeDesc]
+               capi.JpegHuffDesc, capi.JpegScan, capi.JpegRoiPlan, capi.NormalizeDesc, capi.GatherDesc]
     assert sizes == [C.sizeof(m) for m in mirrors]
 
 
