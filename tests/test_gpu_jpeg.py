@@ -246,3 +246,37 @@ def test_corrupt_stream_raises():
     from dali_amd._capi import DaliAmdError
     with pytest.raises(DaliAmdError):
         B.decode_jpeg_batch([b"not a jpeg at all"], device="cuda")
+
+
+def test_slices_with_more_block_starts_than_their_lds_list_holds():
+    """SyncKernel's write phase (round 5): a lane whose list of block starts outgrew its 17 LDS slots decodes again FROM THE
+    LAST START ITS LIST HOLDS - block index inside the MCU advanced by the blocks that ended, one block fewer for the stream's
+    very first slice (whose list begins with the start of block 0), from the slice's first bit for restart-interval streams.
+    Flat and nearly flat content (2-6 bits per block: hundreds of starts per 256-byte slice) in every MCU structure, with
+    texture in between so that overflowing and ordinary slices alternate inside one workgroup; several segments."""
+    rng = np.random.default_rng(31)
+    enc = []
+
+    def striped(h, w, ch=3):
+        # flat bands (hundreds of blocks per slice) between textured ones (a dozen)
+        img = synth_image(rng, h, w, ch).copy()
+        for y0 in range(0, h, 96):
+            img[y0:y0 + 56] = rng.integers(0, 256, ch if ch > 1 else 1, dtype=np.uint8) if ch > 1 else rng.integers(0, 256)
+        return img
+    for sub in ("4:2:0", "4:2:2", "4:4:4", "4:1:1"):
+        enc.append(encode_jpeg(np.full((264, 520, 3), (17, 200, 90), np.uint8), 90, subsampling=sub))     # flat from the first bit
+        enc.append(encode_jpeg(striped(400, 600), 88, subsampling=sub))
+        enc.append(encode_jpeg(striped(400, 600), 88, subsampling=sub, restart_marker_blocks=11))
+        enc.append(encode_jpeg(striped(300, 420), 60, subsampling=sub, optimize=True))
+    enc.append(encode_jpeg(np.full((512, 512), 77, np.uint8), 90))                                         # grayscale: one block per MCU
+    enc.append(encode_jpeg(striped(480, 640, 1), 85))
+    enc.append(encode_jpeg(striped(480, 640, 1), 85, restart_marker_rows=2))
+    enc.append(encode_jpeg(striped(1600, 2000), 80, subsampling="4:2:0"))                                  # several segments
+    for kw in (dict(huffman="gpu"), dict(huffman="gpu", exact_scan=False)):
+        got = _decode_gpu(enc, **kw)
+        for i, e in enumerate(enc):
+            ref = O.jpeg_decode_rgb(e)
+            assert np.array_equal(got[i], ref), f"sample {i} ({kw}): rows {sorted(set(np.nonzero((got[i] != ref).any(axis=(1, 2)))[0]))[:8]}"
+    a, plan = _coefficients(enc, "gpu")
+    b, _ = _coefficients(enc, "host")
+    assert np.array_equal(a, b)
