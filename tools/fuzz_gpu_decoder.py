@@ -34,6 +34,14 @@ def seeds(rng):
     b = io.BytesIO()
     Image.fromarray(synth_image(rng, 40, 56)).convert("L").save(b, "JPEG", quality=75)
     out.append(b.getvalue())
+    # flat and banded content: hundreds of block starts per 256-byte slice - the lanes whose start list outgrows its LDS slots
+    # and decode again from its last entry (round 5)
+    for sub, rst in (("4:2:0", {}), ("4:4:4", {}), ("4:2:0", dict(restart_marker_blocks=5))):
+        img = synth_image(rng, 160, 240).copy()
+        img[24:120] = (90, 200, 30)
+        b = io.BytesIO()
+        Image.fromarray(img).save(b, "JPEG", quality=90, subsampling=sub, **rst)
+        out.append(b.getvalue())
     if os.environ.get("FUZZ_BIG") == "1":   # streams of several 61 KB segments (the serial repair pass over segments) and tiles
         out = []
         for (h, w), kw in [((600, 800), dict(subsampling="4:2:0", quality=97)), ((500, 700), dict(subsampling="4:4:4", quality=95)),
