@@ -1566,6 +1566,18 @@ def main():
                 except Exception as e:  # noqa: BLE001 - a side leg must not take the headline line with it
                     line[key] = {"error": f"{type(e).__name__}: {e}"}
                 gc.collect()
+        # (more scalars for a reader that keeps `config`'s scalars only: the side legs' rates, the host cost of the file-fed
+        # legs, which reader fed the rank-of-eight leg, the dominant kernel's duration with one batch in flight)
+        def scalar(obj, *path):
+            for k in path:
+                obj = obj.get(k) if isinstance(obj, dict) else None
+            return obj if isinstance(obj, (int, float, bool)) else None
+        cfg["heavy_aug_images_per_s"] = scalar(line, "heavy_aug", "value")
+        cfg["audio_utterances_per_s"] = scalar(line, "audio", "value")
+        cfg["e2e_cpu_ms_per_batch"] = scalar(line, "e2e_pipeline", "cpu_ms_per_batch")
+        cfg["e2e_local_world8_cpu_ms_per_batch"] = scalar(line, "e2e_pipeline_local_world8", "cpu_ms_per_batch")
+        cfg["e2e_local_world8_reader_zero_copy"] = scalar(line, "e2e_pipeline_local_world8", "reader_zero_copy")
+        cfg["sync_kernel_single_stream_ms"] = scalar(pl, "single_stream_kernel_ms", "SyncKernel")
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
