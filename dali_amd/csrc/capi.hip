@@ -288,19 +288,13 @@ constexpr int kGatherThreads = DALIAMD_GATHER_THREADS, kGatherUnits = DALIAMD_GA
 // A FEW workgroups walk all the chunks of all the records (measured inside the pipeline, round 5: one workgroup per chunk -
 // 2 300 of them, every CU's vector-memory queue full of reads that take microseconds - doubled the duration of every other
 // kernel on the device; the bus needs about 200 KB in flight, not 37 MB).
-__global__ __launch_bounds__(kGatherThreads) void GatherCopyKernel(const daliamdGatherDesc *__restrict__ descs, int n, unsigned chunks) {
-  // (its waves issue first where they share a SIMD with compute waves: they have a handful of instructions between loads
-  // that take microseconds - starved of issue slots, a launch inside the pipeline took twice the time the bus needs)
-  __builtin_amdgcn_s_setprio(3);
- for (unsigned long long work = blockIdx.x; work < (unsigned long long)n * chunks; work += gridDim.x) {
-  const daliamdGatherDesc d = descs[work / chunks];
-  const uint64_t first = (uint64_t)(work % chunks) * kGatherChunk;
+__device__ __forceinline__ void GatherChunk(const daliamdGatherDesc &d, uint64_t first) {
   const uint8_t *src = static_cast<const uint8_t *>(d.src);
   uint8_t *dst = static_cast<uint8_t *>(d.dst);
   // unit k covers the source bytes [base + 16 k, base + 16 k + 16), base = the source rounded down to 16
   const uint64_t lead = (uint64_t)(reinterpret_cast<uintptr_t>(src) & 15);
   const uint64_t total = lead + d.bytes;                     // bytes from `base` to the record's end
-  if (first >= total) continue;
+  if (first >= total) return;
   const uint64_t u0 = first / 16, u1 = (first + kGatherChunk < total ? first + kGatherChunk : total + 15) / 16;
   const uint8_t *base = src - lead;
   uint4 v[kGatherUnits];
@@ -329,7 +323,13 @@ __global__ __launch_bounds__(kGatherThreads) void GatherCopyKernel(const daliamd
       for (uint64_t b = lo; b < hi; b++) dst[b - lead] = base[b];
     }
   }
- }
+}
+__global__ __launch_bounds__(kGatherThreads) void GatherCopyKernel(const daliamdGatherDesc *__restrict__ descs, int n, unsigned chunks) {
+  // (raised wave priority: these waves have a handful of instructions between loads that take microseconds.  Measured
+  // inside the pipeline it changes nothing either way - 0.62 against 0.62 ms per launch, gpurun_out/r05_v - and stays.)
+  __builtin_amdgcn_s_setprio(3);
+  for (unsigned long long work = blockIdx.x; work < (unsigned long long)n * chunks; work += gridDim.x)
+    GatherChunk(descs[work / chunks], (uint64_t)(work % chunks) * kGatherChunk);
 }
 }  // namespace daliamd
 
