@@ -1047,6 +1047,74 @@ def cpu_backend_side_configs(threads):
     return out
 
 
+COMPACT_LINE_LIMIT = 4000   # bytes; the driver keeps an 8 KB tail of stdout and parses its last line (tests/test_bench_line.py)
+
+
+def compact_line(full, details_path=None):
+    """The ONE line the driver parses: the contract's keys, `config` = the workload string + the scalars the round's story
+    rests on, `roofline` of the dominant kernel only, `cpu_baseline` without its prose.  Everything else (per-kernel tables,
+    every leg's host account, notes) lives in the details file.  The reference's own benchmark prints one number
+    (internal_tools/hw_decoder_bench.py:651)."""
+    def num(x, nd=6):
+        return float(f"{x:.{nd}g}") if isinstance(x, float) else x
+    cfg_full = full.get("config", {})
+    keep = ("global_batch", "parallelism", "batches_in_flight", "distinct_batches", "dataset_images_per_gpu", "cache_type",
+            "resident_set_MB", "jpeg_bytes_per_batch", "host_ms_per_step", "decoder_single_stream_ms",
+            "sync_kernel_single_stream_ms", "whole_step_frac", "e2e_images_per_s", "e2e_pcie_frac",
+            "e2e_images_per_s_at_pcie_peak", "e2e_indexed_images_per_s", "e2e_sharded_images_per_s",
+            "resident_indexed_images_per_s", "resident_full_decode_images_per_s", "resident_roi_decode_images_per_s",
+            "iterator_images_per_s", "e2e_local_world8_images_per_s", "heavy_aug_images_per_s", "audio_utterances_per_s",
+            "value_distinct_dht", "value_mixed", "value_large_images", "value_resident_4GB", "resident_4GB_set_MB",
+            "graph_replay", "commands_per_iteration")
+    cfg = {"workload": str(cfg_full.get("workload", ""))[:420]}
+    for k in keep:
+        v = cfg_full.get(k)
+        if isinstance(v, (int, float, bool, str)):
+            cfg[k] = num(v)
+    if details_path:
+        cfg["details"] = details_path
+    out = {k: num(full.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                         "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    out["config"] = cfg
+    rf = full.get("roofline") or {}
+    per = (rf.get("per_kernel") or {}).get(rf.get("kernel"), {})
+    out["roofline"] = {k: num(rf.get(k)) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic")}
+    out["roofline"]["algorithmic_bytes"] = num(per.get("algorithmic_bytes"))
+    out["roofline"]["avg_ms"] = num(per.get("avg_ms"))
+    out["roofline"]["alone_ms"] = num(((cfg_full.get("pipeline") or {}).get("single_stream_kernel_ms") or {}).get(rf.get("kernel")))
+    out["roofline"]["whole_step_frac"] = num((rf.get("whole_step") or {}).get("frac"))
+    out["roofline"]["traffic_source"] = rf.get("traffic_source")
+    cb = full.get("cpu_baseline")
+    if isinstance(cb, dict):
+        out["cpu_baseline"] = {"value": num(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"),
+                               "kind": cb.get("kind"), "sample": str(cb.get("sample", ""))[:200]}
+    text = json.dumps(out)
+    if len(text) > COMPACT_LINE_LIMIT:      # never hand the driver a line it cannot keep: drop the prose first
+        out["config"]["workload"] = out["config"]["workload"][:120]
+        if "cpu_baseline" in out:
+            out["cpu_baseline"]["sample"] = out["cpu_baseline"]["sample"][:80]
+    assert len(json.dumps(out)) <= COMPACT_LINE_LIMIT, len(json.dumps(out))
+    return out
+
+
+def emit(line, full=False):
+    """Writes the details object next to the bench (bench_details.json in the repo root and, on a gpurun box, under
+    gpurun_out/ so that it travels back), then prints the compact line as the LAST line of stdout."""
+    paths = [os.environ.get("BENCH_DETAILS") or os.path.join(ROOT, "bench_details.json")]
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")) and not os.environ.get("BENCH_DETAILS"):
+        paths.append(os.path.join(ROOT, "gpurun_out", "bench_details.json"))
+    written = None
+    for p in paths:
+        try:
+            with open(p, "w") as f:
+                json.dump(line, f, indent=1)
+            written = written or os.path.relpath(p, ROOT)
+        except OSError:
+            pass
+    sys.stdout.flush()
+    print(json.dumps(line if full else compact_line(line, written)), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1060,6 +1128,13 @@ def main():
     ap.add_argument("--no-side-legs", action="store_true",
                     help="skip the one-batch-in-flight leg as well (profiling: every launch of the process then belongs to "
                          "the set-up or the timed region, both at the full depth)")
+    ap.add_argument("--side-legs", action="store_true",
+                    help="also run the informational legs the default (driver) command leaves out: ROI-decoder and full-decode "
+                         "variants of the resident graph, DALIGenericIterator, decoded-image cache, the rank-of-eight host share, "
+                         "the Pillow baseline, configs[2] heavy_aug and configs[3] audio (tools/collect_profiles.sh passes it)")
+    ap.add_argument("--full-line", action="store_true",
+                    help="print the whole details object as the last stdout line instead of the compact line (tools/*.sh that "
+                         "read roofline.per_kernel); the details are written to bench_details.json either way")
     ap.add_argument("--e2e-batch", type=int, default=512, help="batch per GPU of the sharded end-to-end leg (configs[4])")
     ap.add_argument("--emulate-local-world", type=int, default=8,
                     help="single-GPU runs: one more end-to-end leg with the CPUs one rank of a node with this many GPUs would "
@@ -1203,7 +1278,7 @@ def main():
             kernel_timing(False)
             single_stream = {k: ms for k, (calls, ms) in kernel_timing().items()}
             del pipe1
-        if world == 1 and not args.no_e2e:
+        if world == 1 and not args.no_e2e and args.side_legs:
             # the same resident streams through the fused ROI decoder (what NVIDIA's own decoder benchmark times,
             # hw_decoder_bench.py:178-188): informational, never `value`
             pipe2 = resident_pipeline(root, B, dev_index, r["depth"], r["threads"],
@@ -1469,19 +1544,19 @@ def main():
                                    "peak_source": "pinned host -> device copies of 256 MiB on one stream, measured in this run"}
                     return res
                 line["e2e_pipeline"] = with_pcie(e2e_pipeline(root, B, local_rank))
-                line["e2e_pipeline_roi_decode"] = with_pcie(e2e_pipeline(root, B, local_rank, roi_decode=True))
-                line["e2e_pipeline_roi_decode"]["note"] = ("same, with decoders.image_random_crop -> resize -> "
-                                                           "crop_mirror_normalize: only the crop window is decoded")
-                if not args.no_side_legs:
+                if args.side_legs:
+                    line["e2e_pipeline_roi_decode"] = with_pcie(e2e_pipeline(root, B, local_rank, roi_decode=True))
+                    line["e2e_pipeline_roi_decode"]["note"] = ("same, with decoders.image_random_crop -> resize -> "
+                                                               "crop_mirror_normalize: only the crop window is decoded")
                     line["iterator"] = iterator_leg(args, root, enc_all, dev_index, max(20, min(args.steps, 200)))
                     line["iterator"]["fraction_of_value"] = line["iterator"]["value"] / line["value"]
                     gc.collect()
-                line["e2e_pipeline_decoder_cache"] = e2e_pipeline(root, B, local_rank, cache_mb=1024)
-                line["e2e_pipeline_decoder_cache"]["note"] = (
-                    "same as e2e_pipeline with decoders.image(cache_size=1024, cache_type='threshold'): epoch >= 2 of a "
-                    "data set whose decoded images fit in HBM.  The files are still read; decoded images are handed to "
-                    "the fused resample kernel in place from the cache blob")
-                if args.emulate_local_world > 1:
+                    line["e2e_pipeline_decoder_cache"] = e2e_pipeline(root, B, local_rank, cache_mb=1024)
+                    line["e2e_pipeline_decoder_cache"]["note"] = (
+                        "same as e2e_pipeline with decoders.image(cache_size=1024, cache_type='threshold'): epoch >= 2 of a "
+                        "data set whose decoded images fit in HBM.  The files are still read; decoded images are handed to "
+                        "the fused resample kernel in place from the cache blob")
+                if args.side_legs and args.emulate_local_world > 1:
                     # 8-GPU readiness without 8 GPUs: this rank with the share of the host an N-rank node would leave
                     # it - the process (and every thread it creates from here on) bound to usable / N CPUs, thread pools
                     # sized for them - so that the per-rank end-to-end rate under that split is a measured number
@@ -1553,8 +1628,9 @@ def main():
             cfg["e2e_images_per_s_at_pcie_peak"] = line["e2e_pipeline"]["pcie"]["images_per_s_at_peak"]
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(enc_all[:B])
-            line["cpu_baseline_pillow"] = pillow_baseline(enc_all[:B])
-        if world == 1 and not args.no_side_legs:
+            if args.side_legs:
+                line["cpu_baseline_pillow"] = pillow_baseline(enc_all[:B])
+        if world == 1 and args.side_legs:
             # BASELINE.json configs[2] and configs[3], compact: the same legs `--workload heavy_aug` / `--workload audio`
             # run, each with its own roofline and oracle cpu_baseline (same cores, same run)
             import gc
@@ -1578,7 +1654,9 @@ def main():
         cfg["e2e_local_world8_cpu_ms_per_batch"] = scalar(line, "e2e_pipeline_local_world8", "cpu_ms_per_batch")
         cfg["e2e_local_world8_reader_zero_copy"] = scalar(line, "e2e_pipeline_local_world8", "reader_zero_copy")
         cfg["sync_kernel_single_stream_ms"] = scalar(pl, "single_stream_kernel_ms", "SyncKernel")
-        print(json.dumps(line))
+        if args.driver == "pipeline":
+            cfg["resident_set_MB"] = stream_bytes_total / 1e6
+        emit(line, full=args.full_line)
     if world > 1:
         dist.destroy_process_group()
 

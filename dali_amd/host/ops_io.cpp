@@ -137,7 +137,12 @@ DALI_SCHEMA(LoaderBase)
                     "memory.  (readers.file: mapped files stay mapped - all readers of the process together up to the environment "
                     "variable DALI_AMD_READER_MMAP_MB, 4096 by default, 0 = plain reads - and later epochs copy them from the "
                     "mapping; a reader keeps at most DALI_AMD_READER_FD_CAP descriptors open, by default a quarter of the "
-                    "process's soft RLIMIT_NOFILE, which it never changes; the other readers always use plain I/O.)", ArgValue::Bool(false))
+                    "process's soft RLIMIT_NOFILE, which it never changes; the other readers always use plain I/O.  The data set is "
+                    "taken to be static while a reader lives: a mapped file must not be truncated - the copy out of the mapping "
+                    "then ends in SIGBUS, as with the reference's mmap loader.  With DALI_AMD_READER_ZERO_COPY=1 - the default "
+                    "only when the process has at most four CPUs to itself - readers.file keeps a page-locked copy of every "
+                    "file, up to DALI_AMD_READER_PINNED_MB = 4096 per process, which mixed decoders fetch with a device-side "
+                    "copy; later changes to such a file are not seen, and cannot disturb the device.)", ArgValue::Bool(false))
     .AddRandomSeedArg();
 
 DALI_SCHEMA(readers__File)
@@ -337,8 +342,11 @@ int64_t Loader::NextIndex(bool is_new_batch) {
 //                 the output - no copy; the block goes back to the planner when no ring slot refers to it any more.
 //                 The decoder transfers the page-locked block to the device as it is.
 // Checkpoints describe what has been HANDED OUT: every planned batch carries the Loader's state behind its picks.
-// CPUs this process can count on: the affinity mask, capped by the cgroup's CPU quota (v2: cpu.max, v1: cfs_quota_us /
-// cfs_period_us), shared between the ranks a launcher put on this node (LOCAL_WORLD_SIZE; 1 when unset).  0: unknown.
+// CPUs this process can count on.  The cgroup's CPU quota (v2: cpu.max, v1: cfs_quota_us / cfs_period_us) belongs to the
+// node's job and is shared between the ranks a launcher put on this node (LOCAL_WORLD_SIZE; 1 when unset).  The affinity
+// mask is the PROCESS's: a mask narrower than the machine means the launcher (or Pipeline(set_affinity=True)) already gave
+// this rank its own CPUs - that share is not divided again; a mask that still spans the whole machine is
+// shared like the quota.  0: unknown.
 static double UsableCpusPerRank() {
   cpu_set_t set;
   CPU_ZERO(&set);
@@ -356,16 +364,18 @@ static double UsableCpusPerRank() {
     if (b) *b = second;
     return n;
   };
-  double quota = 0, period = 0;
-  if (read_pair("/sys/fs/cgroup/cpu.max", &quota, &period) == 2 && quota > 0 && period > 0) {
-    cpus = std::min(cpus, quota / period);
-  } else if (read_pair("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", &quota, nullptr) >= 1 && quota > 0 &&
-             read_pair("/sys/fs/cgroup/cpu/cpu.cfs_period_us", &period, nullptr) >= 1 && period > 0) {
-    cpus = std::min(cpus, quota / period);
-  }
   int ranks = 1;
   if (const char *e = getenv("LOCAL_WORLD_SIZE")) ranks = std::max(1, atoi(e));
-  return cpus / ranks;
+  const long online = sysconf(_SC_NPROCESSORS_ONLN);
+  if (online <= 0 || cpus >= (double)online) cpus /= ranks;   // the whole machine: every rank sees the same mask
+  double quota = 0, period = 0;
+  if (read_pair("/sys/fs/cgroup/cpu.max", &quota, &period) == 2 && quota > 0 && period > 0) {
+    cpus = std::min(cpus, quota / period / ranks);
+  } else if (read_pair("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", &quota, nullptr) >= 1 && quota > 0 &&
+             read_pair("/sys/fs/cgroup/cpu/cpu.cfs_period_us", &period, nullptr) >= 1 && period > 0) {
+    cpus = std::min(cpus, quota / period / ranks);
+  }
+  return cpus;
 }
 
 class FileReaderOp : public OperatorBase {
@@ -391,32 +401,34 @@ class FileReaderOp : public OperatorBase {
     // means TLB shoot-downs on every core the process runs on); files beyond the budget are read with pread.
     maps_ = std::make_unique<std::atomic<const char *>[]>(entries_.size());
     for (size_t i = 0; i < entries_.size(); i++) maps_[i].store(nullptr, std::memory_order_relaxed);
-    // Round 5: a mapping is also REGISTERED with the device (daliamdHostRegister: the page cache's pages, page-locked and
-    // addressed by the device where they are).  From its second sighting on such a file is not copied at all: the sample
-    // the reader hands out IS the mapping, and a mixed decoder fetches the bytes with a device-side copy - they cross the
-    // bus once and no host core touches them (the copy out of the mapping was 60 % of the pipeline's host time per
-    // image).  Bounded by the mapping budget below.
+    // Device-side fetch ("zero copy", round 5; re-built in round 6): from its second sighting on a file is not copied by
+    // any host core: the sample the reader hands out is a page-locked RESIDENT COPY of the file (made once, on the first
+    // read, in blocks from daliamdHostAlloc) and a mixed decoder fetches the bytes with a device-side copy - they cross the
+    // bus once (the copy out of the mapping was 60 % of the pipeline's host time per image).
+    // Round 5 handed out the file MAPPINGS themselves, registered with the device (hipHostRegister on page-cache pages).
+    // That tied the device to the files: truncating one made the driver evict the process's queues for minutes, with no
+    // error.  The resident copy is anonymous memory of this process: whatever happens to the file
+    // afterwards - truncate, rewrite, unlink - the reader keeps handing out the bytes it read, exactly like the decoder
+    // caches do.  Budget: DALI_AMD_READER_PINNED_MB (process-wide, default 4096); files beyond it are copied per epoch as
+    // before.
     // WHEN: measured on the bench box (gpurun_out/r05_r, r05_t - r05_v), the device-side fetch is the better way when host
     // cores are what a rank lacks - one rank of eight on 2 of 16 CPUs: 314 k img/s against 238 k, 3.9 ms of CPU per
     // 512-image batch against 5.6 - and the worse one when they are not: alone it runs at the bus rate (56 GB/s, the copy
     // engine out of page-locked memory: 52), but inside the busy pipeline it takes 0.6-0.8 ms per batch instead of 0.43
     // and the kernels next to it run 1.3-1.8 times longer (one rank on 16 CPUs: 300 k against 410-480 k).  Hence the
-    // default: on when this process has at most four CPUs to itself - affinity mask and cgroup CPU quota, divided by the
-    // ranks of the node (LOCAL_WORLD_SIZE) -, off otherwise (the copying path needs 3.1-3.5 ms of CPU per 256-image batch:
-    // with four CPUs it is host-bound at about the rate the device-side fetch reaches);
-    // DALI_AMD_READER_ZERO_COPY=1 / 0 decides.
-    // Rule that comes with it: a data set file must not be TRUNCATED while a reader that registered it lives - the pages are
-    // page-locked for the device, the driver evicts the process's queues when they go away and cannot bring them back
-    // (measured: tests/test_gpu_encoded_cache.py's "files may disappear" case stalled for minutes with the switch on; with the
-    // copying reader the same act is a SIGBUS in memcpy, as in the reference's mmap loader).  Deleting or replacing files
-    // (unlink, rename) is fine: the mapping keeps the old inode.
-    visible_ = std::make_unique<std::atomic<uint8_t>[]>(entries_.size());
-    for (size_t i = 0; i < entries_.size(); i++) visible_[i].store(0, std::memory_order_relaxed);
+    // default: on when this process has at most four CPUs to itself (UsableCpusPerRank above), off otherwise (the copying
+    // path needs 3.1-3.5 ms of CPU per 256-image batch: with four CPUs it is host-bound at about the rate the device-side
+    // fetch reaches); DALI_AMD_READER_ZERO_COPY=1 / 0 decides.
+    resident_ = std::make_unique<std::atomic<const char *>[]>(entries_.size());
+    for (size_t i = 0; i < entries_.size(); i++) resident_[i].store(nullptr, std::memory_order_relaxed);
     {
       const double cpus = UsableCpusPerRank();
       zero_copy_ = cpus > 0 && cpus <= 4.0;
     }
     if (const char *e = getenv("DALI_AMD_READER_ZERO_COPY")) zero_copy_ = atoi(e) != 0;
+    zero_copy_ = zero_copy_ && HaveDevice();
+    pinned_budget_ = (int64_t)4096 << 20;
+    if (const char *e = getenv("DALI_AMD_READER_PINNED_MB")) pinned_budget_ = (int64_t)(std::max(0.0, atof(e)) * 1048576.0);
     // Both budgets are PROCESS-wide: the mappings of all readers of the process together stay below
     // DALI_AMD_READER_MMAP_MB (4096 by default; 0: plain reads) - SharedMappedBytes() - and a reader keeps at most
     // DALI_AMD_READER_FD_CAP descriptors open, by default a quarter of the soft limit the process was STARTED with.  The
@@ -445,11 +457,11 @@ class FileReaderOp : public OperatorBase {
       if (fd >= 0) close(fd);
       const char *m = maps_[i].load(std::memory_order_relaxed);
       if (m && m != kNoMapping) {
-        if (visible_[i].load(std::memory_order_relaxed) & 2) daliamdHostUnregister(const_cast<char *>(m));
         munmap(const_cast<char *>(m), (size_t)size_cache_[i]);
         SharedMappedBytes().fetch_sub((int64_t)size_cache_[i], std::memory_order_relaxed);
       }
     }
+    // (the resident copies go with the last batch that refers to them: every such batch holds the arena)
   }
 
   ReaderMeta GetReaderMeta() const override { return loader_.Meta(); }
@@ -595,16 +607,19 @@ class FileReaderOp : public OperatorBase {
       }
       b.sizes[i] = cached;
       shapes[i] = {(int64_t)cached};
-      if (zero_copy_ && cached > 0 && (visible_[idx].load(std::memory_order_acquire) & 1)) {
-        // mapped, registered, device-visible: the sample is the mapping (which stays until the reader goes)
-        ext[i] = const_cast<char *>(maps_[idx].load(std::memory_order_acquire));
-        any_ext = true;
-        continue;
+      if (zero_copy_ && cached > 0) {
+        // resident in page-locked memory of this reader (which stays until the reader goes): the sample IS that copy
+        const char *r = resident_[idx].load(std::memory_order_acquire);
+        if (r && r != kFilling && r != kNoRoom) {
+          ext[i] = const_cast<char *>(r);
+          any_ext = true;
+          continue;
+        }
       }
       b.tasks.push_back(i);
     }
     if (any_ext) {
-      b.data.Resize(shapes, DALI_UINT8, 1, ext, std::vector<int64_t>(n, 0), nullptr);
+      b.data.Resize(shapes, DALI_UINT8, 1, ext, std::vector<int64_t>(n, 0), arena_);
       b.data.SetExtDeviceVisible(true);
     } else {
       b.data.Resize(shapes, DALI_UINT8);
@@ -720,12 +735,6 @@ class FileReaderOp : public OperatorBase {
       SharedMappedBytes().fetch_sub((int64_t)size, std::memory_order_relaxed);
       return expected == kNoMapping ? nullptr : expected;
     }
-    if (zero_copy_ && HaveDevice()) {
-      // bit 1: registered (to be taken back before the mapping goes), bit 0: and the device reads it at this address
-      int same = 0;
-      if (daliamdHostRegister(p, (size_t)size, &same) == DALIAMD_SUCCESS)
-        visible_[idx].store(same ? 3 : 2, std::memory_order_release);
-    }
     return static_cast<const char *>(p);
   }
 
@@ -753,9 +762,66 @@ class FileReaderOp : public OperatorBase {
     memcpy(dst + 64 * blocks, src + 64 * blocks, n - 64 * blocks);
   }
 
+  // Page-locked room for one file's resident copy (nullptr: budget spent, or the file is larger than a block).  Blocks of
+  // 32 MB, bump-allocated, 64-byte aligned, never handed back before the reader goes.
+  char *ReserveResident(size_t size) {
+    constexpr size_t kBlock = (size_t)32 << 20;
+    const size_t need = (size + 63) & ~(size_t)63;
+    if (need == 0 || need > kBlock / 4) return nullptr;
+    std::lock_guard<std::mutex> g(arena_->m);
+    auto &pinned_blocks_ = arena_->blocks;
+    auto &pinned_used_ = arena_->used;
+    if (pinned_blocks_.empty() || pinned_used_ + need > kBlock) {
+      if (SharedPinnedBytes().fetch_add((int64_t)kBlock, std::memory_order_relaxed) + (int64_t)kBlock > pinned_budget_) {
+        SharedPinnedBytes().fetch_sub((int64_t)kBlock, std::memory_order_relaxed);
+        return nullptr;
+      }
+      void *p = nullptr;
+      if (daliamdHostAlloc(&p, kBlock) != DALIAMD_SUCCESS || !p) {
+        SharedPinnedBytes().fetch_sub((int64_t)kBlock, std::memory_order_relaxed);
+        return nullptr;
+      }
+      pinned_blocks_.push_back({p, kBlock});
+      pinned_used_ = 0;
+    }
+    char *slot = static_cast<char *>(pinned_blocks_.back().first) + pinned_used_;
+    pinned_used_ += need;
+    return slot;
+  }
+
   std::string ReadSample(Prefetched &b, int i) {
     const int64_t idx = b.picks[i];
     char *dst = static_cast<char *>(b.data.raw(i));
+    if (zero_copy_) {
+      // first sighting of a file that may become resident: read it INTO its page-locked place (one thread per file; a
+      // second reader of the same file inside the batches in flight takes the ordinary path below), then copy it out for
+      // this batch, whose layout was planned before the copy existed
+      const char *expected = nullptr;
+      if (resident_[idx].compare_exchange_strong(expected, kFilling, std::memory_order_acq_rel)) {
+        char *slot = ReserveResident((size_t)b.sizes[i]);
+        if (!slot) {
+          resident_[idx].store(kNoRoom, std::memory_order_release);
+        } else {
+          const int fd = Descriptor(idx);
+          off_t got = 0;
+          while (fd >= 0 && got < b.sizes[i]) {
+            const ssize_t r = pread(fd, slot + got, (size_t)(b.sizes[i] - got), got);
+            if (r <= 0) break;
+            got += r;
+          }
+          if (got != b.sizes[i]) {
+            resident_[idx].store(nullptr, std::memory_order_release);   // (the slot is lost; the next sighting tries again)
+            return make_string(fd < 0 ? "Could not open file " : "Failed to read file ", paths_[idx]);
+          }
+          CopyOut(dst, slot, (size_t)b.sizes[i]);
+          resident_[idx].store(slot, std::memory_order_release);
+          return "";
+        }
+      } else if (expected != kFilling && expected != kNoRoom) {
+        CopyOut(dst, expected, (size_t)b.sizes[i]);   // became resident after this batch was planned
+        return "";
+      }
+    }
     if (map_budget_ > 0) {   // already mapped: no descriptor needed (it may have been evicted)
       const char *m = maps_[idx].load(std::memory_order_acquire);
       if (m && m != kNoMapping) {
@@ -788,8 +854,26 @@ class FileReaderOp : public OperatorBase {
 
   Loader loader_;                 // planner thread only once the threads run
   bool skip_cached_, read_ahead_, use_mmap_;
-  std::unique_ptr<std::atomic<uint8_t>[]> visible_;      // per file: see Mapping()
+  // per file: nullptr = not seen yet, kFilling = a reader thread is making the resident copy, kNoRoom = stays a copied
+  // file, else the page-locked resident copy (see ReadSample)
+  std::unique_ptr<std::atomic<const char *>[]> resident_;
+  static inline const char *const kFilling = reinterpret_cast<const char *>(1);
+  static inline const char *const kNoRoom = reinterpret_cast<const char *>(2);
   bool zero_copy_ = false;
+  struct ResidentArena {
+    std::mutex m;
+    std::vector<std::pair<void *, size_t>> blocks;
+    size_t used = 0;                                    // of the newest block
+    ~ResidentArena() {
+      for (auto &blk : blocks) {
+        daliamdHostFree(blk.first);
+        SharedPinnedBytes().fetch_sub((int64_t)blk.second, std::memory_order_relaxed);
+      }
+    }
+  };
+  std::shared_ptr<ResidentArena> arena_ = std::make_shared<ResidentArena>();
+  int64_t pinned_budget_ = 0;
+  static std::atomic<int64_t> &SharedPinnedBytes() { static std::atomic<int64_t> v{0}; return v; }
   std::unique_ptr<std::atomic<const char *>[]> maps_;   // per file: nullptr = not tried yet, kNoMapping = pread, else the mapping
   static inline const char *const kNoMapping = reinterpret_cast<const char *>(1);
   // bytes mapped by every readers.file of the process (the budget is per process, not per reader)

@@ -15,8 +15,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_ranks_on_one_device_produce_one_sharded_line():
-    env = dict(os.environ, BENCH_TEST_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+def test_two_ranks_on_one_device_produce_one_sharded_line(tmp_path):
+    details_path = str(tmp_path / "details.json")
+    env = dict(os.environ, BENCH_TEST_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1",
+               BENCH_DETAILS=details_path)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
            "--batch", "64", "--batches", "2", "--e2e-batch", "64"]
@@ -24,11 +26,14 @@ def test_two_ranks_on_one_device_produce_one_sharded_line():
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, f"rank 0 must print exactly one JSON line, got {len(lines)}"
+    assert res.stdout.strip().splitlines()[-1] == lines[0] and len(lines[0]) < 4000   # the driver parses the LAST line
     line = json.loads(lines[0])
+    details = json.load(open(details_path))
     assert line["n_gpus"] == 2 and line["steps"] == 4 and line["scaling"] == "weak"
     assert line["config"]["global_batch"] == 128 and "shard2" in line["config"]["parallelism"]
     assert abs(line["value"] - 2 * 64 * 4 / (line["ms_per_step"] * 4e-3)) < 1e-6 * line["value"]
-    sharded = line["e2e_pipeline_sharded"]
+    sharded = details["e2e_pipeline_sharded"]
     assert sharded["num_shards"] == 2 and sharded["value"] > 0 and sharded["elapsed_s_max_over_ranks"] >= sharded["elapsed_s"] - 1e-9
-    assert line["config"]["pipeline"]["encoded_cache"]["streams"] == 128      # rank 0's shard, resident
+    assert abs(line["config"]["e2e_sharded_images_per_s"] - sharded["value"]) <= 1e-5 * sharded["value"]
+    assert details["config"]["pipeline"]["encoded_cache"]["streams"] == 128      # rank 0's shard, resident
     assert "threads per rank" in res.stderr                                    # the thread split is printed

@@ -79,12 +79,13 @@ def test_second_epoch_decodes_from_hbm_without_reading_the_files(files, decoded)
             assert ("jpeg_huffman_indexed" in pipe.executed_kernels()) == (CACHE_TYPE[0] == "indexed")
 
 
-def test_files_may_disappear_once_resident(tmp_path, decoded, files, monkeypatch):
-    # (with the copying reader: a file whose mapping is REGISTERED with the device - DALI_AMD_READER_ZERO_COPY=1, the default
-    # only for a process with fewer than four CPUs - must not be truncated while the reader lives: the driver evicts the
-    # process's queues when page-locked pages of a mapping go away and cannot restore them, measured as minutes of stall.  The
-    # reference's mmap reader has the same rule for the same files - there it is a SIGBUS in the copy.)
-    monkeypatch.setenv("DALI_AMD_READER_ZERO_COPY", "0")
+@pytest.mark.parametrize("zero_copy", ["0", "1"])
+def test_files_may_disappear_once_resident(tmp_path, decoded, files, monkeypatch, zero_copy):
+    # Both readers: the copying one and the one that hands out page-locked resident copies for a device-side fetch
+    # (DALI_AMD_READER_ZERO_COPY=1, the default for a process with at most four CPUs).  Round 5's zero-copy reader registered
+    # the file MAPPINGS with the device and this very test stalled for minutes when the files were truncated (the driver
+    # evicted the process's queues); round 6 keeps anonymous page-locked copies, which no change to the file can touch.
+    monkeypatch.setenv("DALI_AMD_READER_ZERO_COPY", zero_copy)
     import shutil
     mine = []
     for i in (0, 1, 2, 4):

@@ -1,6 +1,8 @@
-"""GPU: readers.file hands out its REGISTERED file mappings from a file's second sighting on (no copy out of the page cache)
-and the mixed decoder fetches the entropy-coded segments with a device-side copy (round 5; `gather_encoded` in
-executed_kernels()).  The batches must be those of the copying path, bit for bit: whole images, region-of-interest decodes,
+"""GPU: readers.file hands out page-locked RESIDENT COPIES of its files from a file's second sighting on (no host copy per
+epoch) and the mixed decoder fetches the entropy-coded segments with a device-side copy (`gather_encoded` in
+executed_kernels()).  Round 5 handed out the file mappings themselves, registered with the device: truncating a file then
+hung the process's GPU queues for minutes.  The resident copies are anonymous memory: the last test truncates the files
+under a live reader and the pipeline keeps producing the same batches.  The batches must be those of the copying path, bit for bit: whole images, region-of-interest decodes,
 batches that mix JPEGs the device decodes, a progressive one (host decoder, reads the mapping itself) and a PNG."""
 import numpy as np
 import pytest
@@ -64,7 +66,7 @@ def test_second_sighting_is_fetched_by_the_device_and_decodes_to_the_same_bits(d
             assert bytes(np.asarray(enc.at(i))) == open(files[k], "rb").read(), (it, i)   # the hand-out IS the file
         if "gather_encoded" in pipe.executed_kernels():
             seen = True
-    assert seen, "no batch was fetched out of the registered mappings"
+    assert seen, "no batch was fetched out of the resident copies"
 
 
 def test_region_of_interest_decoders_from_the_mappings(dataset):
@@ -89,3 +91,35 @@ def test_switched_off_the_reader_copies_as_before(dataset, monkeypatch):
         for i in range(3):
             assert np.array_equal(img[i].as_cpu(), want[i])
     assert "gather_encoded" not in pipe.executed_kernels()
+
+
+def test_truncating_the_files_under_a_live_zero_copy_reader_neither_hangs_nor_changes_the_batches(dataset, tmp_path):
+    """a data set file rewritten in place during training must not be a hung job.  No decoder cache
+    here - every epoch the device fetches the reader's resident copies."""
+    import shutil
+    import time
+    files, want = dataset
+    mine = []
+    for k in (0, 1, 2, 4, 5, 6):
+        dst = tmp_path / f"t{k}.jpg"
+        shutil.copy(files[k], dst)
+        mine.append(str(dst))
+    ref = [want[k] for k in (0, 1, 2, 4, 5, 6)]
+    pipe = _pipe(mine, 3)
+    for it in range(6):                                   # three epochs: every file is resident, the reader is ahead
+        (img,) = pipe.run()
+    assert "gather_encoded" in pipe.executed_kernels()
+    for f in mine[:3]:
+        open(f, "wb").close()                             # truncate to nothing
+    for f in mine[3:]:
+        with open(f, "r+b") as fh:                        # rewrite in place with other bytes of the same length
+            n = len(fh.read())
+            fh.seek(0)
+            fh.write(b"\x00" * n)
+    t0 = time.perf_counter()
+    for it in range(8):
+        (img,) = pipe.run()
+        for i in range(3):
+            assert np.array_equal(img[i].as_cpu(), ref[(3 * it + i) % 6]), (it, i)
+    assert time.perf_counter() - t0 < 30.0
+    assert "gather_encoded" in pipe.executed_kernels()

@@ -11,16 +11,16 @@ for V in mfma valu unfused; do
   export DALI_AMD_MEL_VALU=0 DALI_AMD_NO_AUDIO_FUSION=0
   [ $V = valu ] && export DALI_AMD_MEL_VALU=1
   [ $V = unfused ] && export DALI_AMD_NO_AUDIO_FUSION=1
-  python $R/bench.py --workload audio --steps 30 --warmup 5 > $OUT/bench_$V.json 2> $OUT/bench_$V.err
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$V -- python $R/bench.py --workload audio --steps 20 --warmup 3 > /dev/null 2> $OUT/stats_$V.log
+  python $R/bench.py --full-line --workload audio --steps 30 --warmup 5 > $OUT/bench_$V.json 2> $OUT/bench_$V.err
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$V -- python $R/bench.py --full-line --workload audio --steps 20 --warmup 3 > /dev/null 2> $OUT/stats_$V.log
   for C in FETCH_SIZE WRITE_SIZE; do
-    timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_${V}_$C -- python $R/bench.py --workload audio --steps 5 --warmup 1 > /dev/null 2> $OUT/pmc_${V}_$C.log
+    timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_${V}_$C -- python $R/bench.py --full-line --workload audio --steps 5 --warmup 1 > /dev/null 2> $OUT/pmc_${V}_$C.log
   done
 done
 export DALI_AMD_MEL_VALU=0 DALI_AMD_NO_AUDIO_FUSION=0
 # matrix-core counters of the MFMA variant (own pass; no trace domains next to --pmc)
-timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA --output-format csv -d $OUT/pmc_mfma_SQ -- python $R/bench.py --workload audio --steps 5 --warmup 1 > /dev/null 2> $OUT/pmc_mfma_SQ.log
-timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc_mfma_SQ2 -- python $R/bench.py --workload audio --steps 5 --warmup 1 > /dev/null 2> $OUT/pmc_mfma_SQ2.log
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA --output-format csv -d $OUT/pmc_mfma_SQ -- python $R/bench.py --full-line --workload audio --steps 5 --warmup 1 > /dev/null 2> $OUT/pmc_mfma_SQ.log
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc_mfma_SQ2 -- python $R/bench.py --full-line --workload audio --steps 5 --warmup 1 > /dev/null 2> $OUT/pmc_mfma_SQ2.log
 python - <<PY
 import csv, glob, json, collections
 out = {}

@@ -5,7 +5,7 @@ TAG=${1:-audio_prof}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --workload ${WORKLOAD:-audio} --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/stats.log
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --full-line --workload ${WORKLOAD:-audio} --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/stats.log
 python - <<PY
 import csv,glob
 for f in glob.glob("$OUT/stats/*/*kernel_stats.csv"):

@@ -7,7 +7,7 @@ OUT=$R/gpurun_out/${TAG}_blur
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export DALI_AMD_BLUR_MFMA=${DALI_AMD_BLUR_MFMA:-1}
-CMD="python $R/bench.py --workload heavy_aug --steps 5 --warmup 1 --no-cpu-baseline --inflight 1"
+CMD="python $R/bench.py --full-line --workload heavy_aug --steps 5 --warmup 1 --no-cpu-baseline --inflight 1"
 pass() { timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/pmc_$1 -- $CMD > /dev/null 2> $OUT/pmc_$1.log; }
 pass SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32
 pass SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT

@@ -33,9 +33,9 @@ for W in ${WORKLOADS:-headline indexed heavy_aug audio normalize}; do
   if [ $W = normalize ]; then
     (cd $R && timeout 300 python tools/normalize_prof.py 2>/dev/null | tail -1 > $SUM/${TAG}_${W}_bench.json)
   elif [ $W = indexed ]; then
-    (cd $R && timeout 300 python bench.py --cache-type indexed --no-e2e --no-cpu-baseline 2>/dev/null | tail -1 > $SUM/${TAG}_${W}_bench.json)
+    (cd $R && timeout 300 python bench.py --full-line --cache-type indexed --no-e2e --no-cpu-baseline 2>/dev/null | tail -1 > $SUM/${TAG}_${W}_bench.json)
   elif [ $W != headline ]; then
-    (cd $R && timeout 300 python bench.py --workload $W 2>/dev/null | tail -1 > $SUM/${TAG}_${W}_bench.json)
+    (cd $R && timeout 300 python bench.py --full-line --workload $W 2>/dev/null | tail -1 > $SUM/${TAG}_${W}_bench.json)
   fi
 done
 ls -la $SUM

@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/stats_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout ${PROF_TIMEOUT:-120} rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --steps 40 --warmup 3 --no-cpu-baseline --no-e2e --no-side-legs > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
+timeout ${PROF_TIMEOUT:-120} rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --full-line --steps 40 --warmup 3 --no-cpu-baseline --no-e2e --no-side-legs > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
 best=$(ls -S $OUT/stats/*/*kernel_stats.csv | head -1)
 cp "$best" $OUT/${TAG}_kernel_stats_full_depth.csv
 head -12 "$best" | cut -c1-160

@@ -15,12 +15,12 @@ if [ $RC -ne 0 ]; then echo "decoder tests failed (rc $RC): stopping"; exit 1; f
 ( time timeout 900 python -m pytest tests -m gpu -x -q ) > $OUT/pytest.log 2>&1
 tail -5 $OUT/pytest.log
 if [ "$MODE" = "tests" ]; then exit 0; fi
-( time timeout 600 python bench.py ) > $OUT/bench_default.json 2> $OUT/bench_default.err
+( time timeout 600 python bench.py --full-line ) > $OUT/bench_default.json 2> $OUT/bench_default.err
 tail -c 600 $OUT/bench_default.err
 for IF in 1 4; do
-  timeout 300 python bench.py --inflight $IF --no-e2e --no-cpu-baseline > $OUT/bench_inflight$IF.json 2> $OUT/bench_inflight$IF.err
+  timeout 300 python bench.py --full-line --inflight $IF --no-e2e --no-cpu-baseline > $OUT/bench_inflight$IF.json 2> $OUT/bench_inflight$IF.err
 done
-timeout 300 python bench.py --batch 512 --batches 2 --inflight 2 --no-e2e --no-cpu-baseline > $OUT/bench_b512.json 2> $OUT/bench_b512.err
+timeout 300 python bench.py --full-line --batch 512 --batches 2 --inflight 2 --no-e2e --no-cpu-baseline > $OUT/bench_b512.json 2> $OUT/bench_b512.err
 python - <<PY
 import json,glob
 for f in sorted(glob.glob("$OUT/bench_*.json")):

@@ -12,7 +12,7 @@ for E in "$@"; do
   i=$((i+1))
   [ "$E" = "-" ] && E=""
   for IF in ${INFLIGHTS:-4}; do
-    env $E timeout 300 python bench.py --steps ${STEPS:-60} --warmup 8 --inflight $IF --no-e2e --no-cpu-baseline > $OUT/e${i}_inflight$IF.json 2> $OUT/e${i}_inflight$IF.err || tail -3 $OUT/e${i}_inflight$IF.err
+    env $E timeout 300 python bench.py --full-line --steps ${STEPS:-60} --warmup 8 --inflight $IF --no-e2e --no-cpu-baseline > $OUT/e${i}_inflight$IF.json 2> $OUT/e${i}_inflight$IF.err || tail -3 $OUT/e${i}_inflight$IF.err
   done
   echo "env $i: $E"
 done

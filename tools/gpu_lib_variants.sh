@@ -13,7 +13,7 @@ for V in "$@"; do
   if [ $V = main ]; then cp /tmp/main_kernels.so dali_amd/lib/libdali_amd_kernels.so; else cp build_variants/libdali_amd_kernels_$V.so dali_amd/lib/libdali_amd_kernels.so; fi
   timeout 200 python -m pytest ${VARIANT_TESTS:-tests/test_gpu_jpeg.py} -m gpu -q -x 2>&1 | tail -1
   for IF in ${INFLIGHTS:-1 5}; do
-    timeout 200 python bench.py ${BENCH_ARGS:---steps 400 --warmup 8 --no-e2e --no-cpu-baseline} --inflight $IF > $OUT/${V}_inflight$IF.json 2> $OUT/${V}_inflight$IF.err || tail -3 $OUT/${V}_inflight$IF.err
+    timeout 200 python bench.py --full-line ${BENCH_ARGS:---steps 400 --warmup 8 --no-e2e --no-cpu-baseline} --inflight $IF > $OUT/${V}_inflight$IF.json 2> $OUT/${V}_inflight$IF.err || tail -3 $OUT/${V}_inflight$IF.err
   done
 done
 cp /tmp/main_kernels.so dali_amd/lib/libdali_amd_kernels.so

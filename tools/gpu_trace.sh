@@ -10,7 +10,7 @@ i=0
 for E in "$@"; do
   i=$((i+1))
   [ "$E" = "-" ] && E=""
-  env $E timeout 150 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr$i -- python $R/bench.py --steps 40 --warmup 8 --inflight $IF --no-e2e --no-cpu-baseline > $OUT/t$i.json 2> $OUT/t$i.err
+  env $E timeout 150 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr$i -- python $R/bench.py --full-line --steps 40 --warmup 8 --inflight $IF --no-e2e --no-cpu-baseline > $OUT/t$i.json 2> $OUT/t$i.err
   # the trace of the process with the most dispatches
   best=$(ls -S /tmp/tr$i/*/*kernel_trace.csv | head -1)
   python - "$best" $OUT/t${i}_trace.csv.gz <<'PY'

@@ -14,7 +14,7 @@ for FL in "$@"; do
   make -C dali_amd/csrc CXXFLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -I../../include -Wno-unused-function $FL" > $OUT/build$i.log 2>&1 || { tail -5 $OUT/build$i.log; continue; }
   make -C dali_amd/host > /dev/null 2>&1
   for IF in ${INFLIGHTS:-1 4}; do
-    timeout 300 python bench.py --steps 40 --warmup 5 --inflight $IF --no-e2e --no-cpu-baseline > $OUT/v${i}_inflight$IF.json 2> $OUT/v${i}_inflight$IF.err || tail -3 $OUT/v${i}_inflight$IF.err
+    timeout 300 python bench.py --full-line --steps 40 --warmup 5 --inflight $IF --no-e2e --no-cpu-baseline > $OUT/v${i}_inflight$IF.json 2> $OUT/v${i}_inflight$IF.err || tail -3 $OUT/v${i}_inflight$IF.err
   done
   echo "variant $i: $FL"
 done

@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for SET in "$@"; do
   i=$((i+1))
-  timeout ${PROF_TIMEOUT:-300} rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT/set$i -- python $R/bench.py ${BENCH_ARGS:---steps 8 --warmup 4 --no-cpu-baseline --no-e2e --inflight 1} > /dev/null 2> $OUT/set$i.log
+  timeout ${PROF_TIMEOUT:-300} rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT/set$i -- python $R/bench.py --full-line ${BENCH_ARGS:---steps 8 --warmup 4 --no-cpu-baseline --no-e2e --inflight 1} > /dev/null 2> $OUT/set$i.log
 done
 python - <<PY
 import csv, collections, glob, json
