@@ -32,6 +32,10 @@ def synth_image(rng, h, w, c=3, octaves=6, decay=0.85, noise=3.0):
 def encode_jpeg(img, quality=85, subsampling="4:2:0", **kw):
     b = io.BytesIO()
     im = Image.fromarray(img)
+    if kw.get("optimize") or kw.get("progressive"):
+        # Pillow hands the encoder ONE buffer for such a stream (it is written in one piece): make it large enough
+        from PIL import ImageFile
+        ImageFile.MAXBLOCK = max(ImageFile.MAXBLOCK, int(img.size) + 65536)
     if im.mode == "L":
         im.save(b, "JPEG", quality=quality, **kw)
     else:
@@ -42,9 +46,10 @@ def encode_jpeg(img, quality=85, subsampling="4:2:0", **kw):
 IMAGENET_LIKE_SIZES = [(375, 500), (500, 375), (480, 640), (500, 333), (500, 500), (384, 256), (768, 1024)]
 
 
-def synth_jpeg_batch(rng, n, sizes=None, gray_frac=0.05):
+def synth_jpeg_batch(rng, n, sizes=None, gray_frac=0.05, **save_kw):
     """n encoded streams drawn like SURVEY.md section 8(d): 80 % q75 / 20 % q90; 85 % 4:2:0, 10 % 4:4:4,
-    5 % grayscale; sizes ImageNet-like."""
+    5 % grayscale; sizes ImageNet-like.  `save_kw`: passed to the encoder (optimize=True: Huffman tables optimised per
+    image; progressive=True)."""
     sizes = sizes or IMAGENET_LIKE_SIZES
     out = []
     for _ in range(n):
@@ -56,26 +61,59 @@ def synth_jpeg_batch(rng, n, sizes=None, gray_frac=0.05):
         q = 90 if rng.random() < 0.2 else 75
         r = rng.random()
         if r < gray_frac:
-            out.append(encode_jpeg(synth_image(rng, h, w, 1), q))
+            out.append(encode_jpeg(synth_image(rng, h, w, 1), q, **save_kw))
         elif r < gray_frac + 0.10:
-            out.append(encode_jpeg(synth_image(rng, h, w), q, "4:4:4"))
+            out.append(encode_jpeg(synth_image(rng, h, w), q, "4:4:4", **save_kw))
         else:
-            out.append(encode_jpeg(synth_image(rng, h, w), q, "4:2:0"))
+            out.append(encode_jpeg(synth_image(rng, h, w), q, "4:2:0", **save_kw))
     return out
 
 
-def synth_dataset_image(index, seed=1234):
-    """Image `index` of the synthetic data set: depends only on (seed, index), so every rank of a sharded run
-    generates exactly its own shard and all ranks agree on the whole set."""
-    return synth_jpeg_batch(np.random.default_rng([seed, int(index)]), 1)[0]
+DATASET_VARIANTS = ("baseline", "distinct_dht", "mixed", "large")
+LARGE_IMAGE_HW = (3000, 4000)     # 12 MP
 
 
-def synth_dataset(first_index, count, seed=1234, workers=0):
+def synth_dataset_image(index, seed=1234, variant="baseline"):
+    """Image `index` of the synthetic data set: depends only on (seed, index, variant), so every rank of a sharded run
+    generates exactly its own shard and all ranks agree on the whole set.  Variants (what real collections hold that the
+    baseline set does not - VERDICT r05 missing 3; the reference takes all of them in one batch, image_decoder.h:613-880):
+      baseline      the SURVEY 8(d) mix, encoder's default tables: ONE set of Huffman tables for the whole data set
+      distinct_dht  the same images saved with optimize=True: every file brings its own four Huffman tables
+      mixed         5 % progressive and 2 % CMYK (Adobe, four components) among the baseline streams (+ its 5 % grayscale)
+      large         2 % 12-megapixel images (3000 x 4000) among the baseline sizes"""
+    rng = np.random.default_rng([seed, int(index)])
+    if variant == "baseline":
+        return synth_jpeg_batch(rng, 1)[0]
+    pick = np.random.default_rng([seed, int(index), 77]).random()
+    if variant == "distinct_dht":
+        return synth_jpeg_batch(rng, 1, optimize=True)[0]
+    if variant == "mixed":
+        if pick < 0.05:
+            return synth_jpeg_batch(rng, 1, gray_frac=0.0, progressive=True)[0]
+        if pick < 0.07:
+            h, w = IMAGENET_LIKE_SIZES[int(rng.integers(0, 6))]
+            b = io.BytesIO()
+            Image.fromarray(synth_image(rng, h, w)).convert("CMYK").save(b, "JPEG", quality=85)
+            return b.getvalue()
+        return synth_jpeg_batch(rng, 1)[0]
+    if variant == "large":
+        if pick < 0.02:
+            return synth_jpeg_batch(rng, 1, sizes=[LARGE_IMAGE_HW], gray_frac=0.0)[0]
+        return synth_jpeg_batch(rng, 1)[0]
+    raise ValueError(f"unknown data set variant {variant!r}")
+
+
+def _synth_dataset_job(job):
+    return synth_dataset_image(*job)
+
+
+def synth_dataset(first_index, count, seed=1234, workers=0, variant="baseline"):
     """Encoded JPEGs [first_index, first_index + count) of the synthetic data set; `workers` > 1 forks that many
     generator processes (call before the GPU runtime is initialised in this process)."""
-    idx = range(int(first_index), int(first_index) + int(count))
+    jobs = [(i, seed, variant) for i in range(int(first_index), int(first_index) + int(count))]
     if workers and workers > 1 and count >= 2 * workers:
         import multiprocessing as mp
         with mp.get_context("fork").Pool(workers) as pool:
-            return pool.map(synth_dataset_image, idx, chunksize=max(1, count // (4 * workers)))
-    return [synth_dataset_image(i, seed) for i in idx]
+            # (chunks of a few images: the 12-megapixel ones of "large" take a hundred times as long as the others)
+            return pool.map(_synth_dataset_job, jobs, chunksize=max(1, min(8, count // (4 * workers))))
+    return [_synth_dataset_job(j) for j in jobs]
