@@ -961,6 +961,15 @@ __global__ __launch_bounds__(256) void ResampleGenericKernel(const daliamdResamp
   }
   const int xo = d.mirror ? d.out_w - 1 - x : x;
   const size_t o = d.out_layout == DALIAMD_LAYOUT_CHW ? ((size_t)c * d.out_h + y) * d.out_w + xo : ((size_t)y * d.out_w + xo) * C + c;
+  if (d.generic == 2) {
+    // u8 samples the tile kernel serves badly (extreme down-scaling, SetupOne): the resampled value is rounded to u8 by the
+    // rule of its column, then the fused CropMirrorNormalize epilogue - the arithmetic of Epilogue::Store, whose look-up
+    // table holds exactly these results
+    const uint32_t v = RoundU8Slow(acc, even);
+    Epilogue ep{d.out, d.out_h, d.out_w, C, d.out_dtype, d.out_layout, d.normalize, d.mirror, nullptr};
+    ep.Store(o, c, v, SEL4(c, d.mean[0], d.mean[1], d.mean[2], d.mean[3]), SEL4(c, d.inv_std[0], d.inv_std[1], d.inv_std[2], d.inv_std[3]));
+    return;
+  }
   const float r = RoundTyped(acc, d.out_dtype, even);
   switch (d.out_dtype) {
     case DALIAMD_UINT8: ((uint8_t __attribute__((address_space(1))) *)d.out)[o] = (uint8_t)r; break;
@@ -1033,7 +1042,7 @@ static int SetupOne(const daliamdResampleArgs &a, daliamdResampleDesc &d, int in
   DALIAMD_REQUIRE(a.min_filter >= DALIAMD_INTERP_NN && a.min_filter <= DALIAMD_INTERP_GAUSSIAN &&
                   a.mag_filter >= DALIAMD_INTERP_NN && a.mag_filter <= DALIAMD_INTERP_GAUSSIAN, DALIAMD_ERROR_INVALID_ARGUMENT,
                   "daliamdResampleSetup: sample %d: unknown interpolation type", index);
-  const bool generic = a.in_dtype != DALIAMD_UINT8 || a.unrounded;
+  bool generic = a.in_dtype != DALIAMD_UINT8 || a.unrounded;
   if (!generic) {
     DALIAMD_REQUIRE(a.out_dtype == DALIAMD_UINT8 || a.out_dtype == DALIAMD_FLOAT16 || a.out_dtype == DALIAMD_FLOAT,
                     DALIAMD_ERROR_UNSUPPORTED, "daliamdResampleSetup: unsupported output type %d", a.out_dtype);
@@ -1216,6 +1225,17 @@ static int SetupOne(const daliamdResampleArgs &a, daliamdResampleDesc &d, int in
   d.tile_w = tw; d.tile_h = th;
   d.tiles_x = (a.out_w + tw - 1) / tw;
   d.tiles_y = (a.out_h + th - 1) / th;
+  // Extreme down-scaling (round 6; a 12-megapixel photograph into 224 x 224: scale 10-13, 25 taps per axis): the source
+  // window of even a handful of output pixels fills the LDS budget - tiles of 4 x 4 outputs whose windows overlap three
+  // times, 3 000 workgroup passes per image, 1.2 ms per batch for five such images among 251 ordinary ones.  Such a
+  // sample takes the two-launch path instead (first-axis pass of the whole region into an fp32 intermediate in the
+  // workspace, second pass + the fused epilogue from it: generic = 2), about as much arithmetic and no overlap.
+  // DALI_AMD_RESAMPLE_TWO_PASS_AREA: tiles of at most this many outputs go there (default 64; 0 = never, large = always).
+  static const int two_pass_area = [] { const char *e = getenv("DALI_AMD_RESAMPLE_TWO_PASS_AREA"); return e ? atoi(e) : 64; }();
+  if (!generic && (tw * th <= two_pass_area || (!staged && two_pass_area > 0))) {
+    generic = true;
+    d.generic = 2;
+  }
   if (generic) {  // the two-launch path: no tiles, an fp32 intermediate of the reference's shape in the workspace
     d.tiles_x = d.tiles_y = 0;
     d.tmp_w = d.first_axis == 0 ? a.out_w : d.ext[0];

@@ -347,7 +347,7 @@ extern "C" int daliamdResampleRunHost(const daliamdResampleDesc *desc) {
   const daliamdResampleDesc &d = *desc;
   const int C = d.channels, pitch = d.in_pitch;
   if (C < 1 || C > 4) return Fail("daliamdResampleRunHost: %d channels (supported: 1..4)", C);
-  if (d.generic) return ResampleGenericHost(d);
+  if (d.generic == 1) return ResampleGenericHost(d);   // (2: a u8 sample the DEVICE runs in two launches; here it is an ordinary one)
   const int sup_x = d.support[0], sup_y = d.support[1];
   const AxisTable tx = BuildTable(0, d.filter_kind[0], d.out_w, d.origin[0], d.scale[0], d.fanchor[0], d.fscale[0], sup_x);
   const AxisTable ty = BuildTable(1, d.filter_kind[1], d.out_h, d.origin[1], d.scale[1], d.fanchor[1], d.fscale[1], sup_y);

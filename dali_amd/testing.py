@@ -9,7 +9,7 @@ import numpy as np
 from PIL import Image
 
 
-def synth_image(rng, h, w, c=3, octaves=6, decay=0.85, noise=3.0):
+def synth_image(rng, h, w, c=3, octaves=6, decay=0.85, noise=3.0, gradient=0.2):
     """1/f-like multi-octave value noise + linear gradients + sensor noise: compresses like a natural
     photograph (about 100 KB at ImageNet sizes with the q75/q90 mix of synth_jpeg_batch)."""
     acc = np.zeros((h, w, c), np.float32)
@@ -22,7 +22,7 @@ def synth_image(rng, h, w, c=3, octaves=6, decay=0.85, noise=3.0):
     acc = acc / np.sqrt((decay ** (2 * np.arange(octaves))).sum()) * 1.6 + 128.0
     yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
     for _ in range(2):
-        a, b = rng.uniform(-0.2, 0.2, 2)
+        a, b = rng.uniform(-gradient, gradient, 2)
         acc += (a * xx + b * yy)[:, :, None]
     acc += rng.normal(0, noise, acc.shape)
     img = np.clip(acc, 0, 255).astype(np.uint8)
@@ -46,11 +46,12 @@ def encode_jpeg(img, quality=85, subsampling="4:2:0", **kw):
 IMAGENET_LIKE_SIZES = [(375, 500), (500, 375), (480, 640), (500, 333), (500, 500), (384, 256), (768, 1024)]
 
 
-def synth_jpeg_batch(rng, n, sizes=None, gray_frac=0.05, **save_kw):
+def synth_jpeg_batch(rng, n, sizes=None, gray_frac=0.05, image_kw=None, **save_kw):
     """n encoded streams drawn like SURVEY.md section 8(d): 80 % q75 / 20 % q90; 85 % 4:2:0, 10 % 4:4:4,
     5 % grayscale; sizes ImageNet-like.  `save_kw`: passed to the encoder (optimize=True: Huffman tables optimised per
     image; progressive=True)."""
     sizes = sizes or IMAGENET_LIKE_SIZES
+    image_kw = image_kw or {}
     out = []
     for _ in range(n):
         if sizes is IMAGENET_LIKE_SIZES:
@@ -61,11 +62,11 @@ def synth_jpeg_batch(rng, n, sizes=None, gray_frac=0.05, **save_kw):
         q = 90 if rng.random() < 0.2 else 75
         r = rng.random()
         if r < gray_frac:
-            out.append(encode_jpeg(synth_image(rng, h, w, 1), q, **save_kw))
+            out.append(encode_jpeg(synth_image(rng, h, w, 1, **image_kw), q, **save_kw))
         elif r < gray_frac + 0.10:
-            out.append(encode_jpeg(synth_image(rng, h, w), q, "4:4:4", **save_kw))
+            out.append(encode_jpeg(synth_image(rng, h, w, **image_kw), q, "4:4:4", **save_kw))
         else:
-            out.append(encode_jpeg(synth_image(rng, h, w), q, "4:2:0", **save_kw))
+            out.append(encode_jpeg(synth_image(rng, h, w, **image_kw), q, "4:2:0", **save_kw))
     return out
 
 
@@ -98,7 +99,11 @@ def synth_dataset_image(index, seed=1234, variant="baseline"):
         return synth_jpeg_batch(rng, 1)[0]
     if variant == "large":
         if pick < 0.02:
-            return synth_jpeg_batch(rng, 1, sizes=[LARGE_IMAGE_HW], gray_frac=0.0)[0]
+            # (the illumination gradients keep the brightness range of the small images: with their per-pixel slope a
+            # 4000-pixel image saturates to black / white over most of its area - 0.5 bits per pixel, hundreds of empty
+            # blocks per 256 bytes of stream, which no camera produces)
+            return synth_jpeg_batch(rng, 1, sizes=[LARGE_IMAGE_HW], gray_frac=0.0,
+                                    image_kw=dict(gradient=0.2 * 500 / max(LARGE_IMAGE_HW)))[0]
         return synth_jpeg_batch(rng, 1)[0]
     raise ValueError(f"unknown data set variant {variant!r}")
 

@@ -432,8 +432,9 @@ typedef struct {
   int32_t tab_start;         /* first table entry of the sample (work index of the tables kernel) */
   int32_t use_lut;
   int32_t filter_kind[2];    /* per axis: 0 nearest, 1 triangular, 2 Gaussian, 3 Lanczos3, 4 cubic (dali_amd_resample_filters.h) */
-  /* the two-launch path of the other element types (generic = 1): fp32 intermediate [tmp_h][tmp_w][channels] at
-   * tmp_off in the workspace, gen_start[p] = first work item of the sample in pass p */
+  /* the two-launch path: fp32 intermediate [tmp_h][tmp_w][channels] at tmp_off in the workspace, gen_start[p] = first work
+   * item of the sample in pass p.  generic = 1: the other element types; generic = 2: a u8 sample whose down-scaling is too
+   * extreme for the tile kernel (its fused epilogue - normalize, mirror, layout, fp16 - runs in the second launch) */
   int32_t in_dtype, unrounded, generic, round_lanes;
   int32_t tmp_w, tmp_h;
   int64_t tmp_off, gen_start[2];

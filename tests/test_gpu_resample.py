@@ -285,3 +285,58 @@ def test_wide_fused_fp16_output_rounds_in_the_reference_regions():
         u8 = O.resample_u8(im, (256, 342))
         ref = O.cmn_u8(u8, (0, 0), (256, 342), mirror=bool(mirror), mean=mean, inv_std=inv, dtype=O.F16)
         assert np.array_equal(out.view(np.uint16), ref.view(np.uint16)), mirror
+
+
+def _kernel_launches():
+    import ctypes as C
+    from dali_amd import _capi as capi
+    lib = capi.kernels()
+    need = lib.daliamdKernelTimingReport(None, 0)
+    buf = C.create_string_buffer(need + 1)
+    lib.daliamdKernelTimingReport(buf, need + 1)
+    return {ln.split("\t")[0]: int(ln.split("\t")[1]) for ln in buf.value.decode().splitlines()}
+
+
+@pytest.mark.parametrize("dtype", ["uint8", "float16"])
+def test_twelve_megapixel_crops_take_the_two_launch_path_in_a_mixed_batch(dtype):
+    """Round 6: a 12-megapixel photograph among ImageNet-sized images (the `large` data set variant of bench.py).  Its
+    crop windows shrink 9-13 x into 224 x 224: the tile kernel would serve them with 4 x 4-pixel tiles (1.2 ms per batch for
+    five such images); SetupOne routes them to the two-launch path with the fused epilogue (generic = 2).  Same bits as the
+    oracle - both pass orders, mirrored, normalised fp16 CHW - next to ordinary samples on the tile path in one Run."""
+    from dali_amd import backend as B
+    from dali_amd import _capi as capi
+    rng = np.random.default_rng(31)
+    base = synth_image(rng, 750, 1000)
+    big = np.ascontiguousarray(np.kron(base, np.ones((4, 4, 1), np.uint8)))            # 3000 x 4000
+    big = (big.astype(np.int16) + rng.integers(-20, 21, big.shape, dtype=np.int16)).clip(0, 255).astype(np.uint8)
+    imgs = [big, synth_image(rng, 375, 500), big, synth_image(rng, 480, 640), big]
+    rois = [(100.0, 200.0, 2900.0, 3300.0),      # wide: 2800 x 3100
+            (10.0, 20.0, 300.0, 420.0),
+            (50.5, 1000.25, 2950.0, 2400.75),    # tall and fractional: 2900 x 1400
+            (0.0, 0.0, 480.0, 640.0),
+            (2999.0, 3999.0, 0.0, 0.0)]          # the whole image, flipped in both axes
+    mirror = np.array([1, 0, 0, 1, 1], np.int32)
+    mean, inv = O.cmn_norm_args([0.485 * 255, 0.456 * 255, 0.406 * 255], [0.229 * 255, 0.224 * 255, 0.225 * 255])
+    lib = capi.kernels()
+    _kernel_launches()
+    lib.daliamdKernelTimingEnable(1)
+    dev = [_to_dev(im, 16) for im in imgs]
+    if dtype == "uint8":
+        out = B.resample_batch(dev, (224, 224), rois=rois).cpu().numpy()
+    else:
+        out = B.resample_batch(dev, (224, 224), rois=rois, out_dtype=capi.FLOAT16, out_layout=capi.LAYOUT_CHW,
+                               mean=mean, inv_std=inv, mirror=mirror).cpu().numpy()
+    torch.cuda.synchronize()
+    lib.daliamdKernelTimingEnable(0)
+    launched = _kernel_launches()
+    assert launched.get("ResampleGenericKernel", 0) >= 1 and launched.get("ResampleKernel", 0) >= 1, launched
+    orders = []
+    for i, im in enumerate(imgs):
+        ref, info = O.resample_u8(im, (224, 224), roi=rois[i], return_info=True)
+        orders.append(int(info[0]))
+        if dtype == "uint8":
+            assert np.array_equal(out[i], ref), f"sample {i}: {int((out[i] != ref).sum())} elements differ"
+        else:
+            want = O.cmn_u8(ref, (0, 0), (224, 224), mirror=bool(mirror[i]), mean=mean, inv_std=inv, dtype=O.F16)
+            assert np.array_equal(out[i].view(np.uint16), want.view(np.uint16)), f"sample {i}"
+    assert {orders[0], orders[2]} == {0, 1}, f"both pass orders on the large samples: {orders}"
