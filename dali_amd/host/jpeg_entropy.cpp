@@ -661,6 +661,166 @@ int daliamdJpegAnalyzeHeader(const uint8_t *data, size_t size, daliamdJpegInfo *
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Baseline re-encoding of decoded coefficients (round 6).  The GPU entropy decoder takes baseline streams with one
+// interleaved scan; a progressive (multi-scan, spectral-selection / successive-approximation) stream holds the SAME
+// quantised coefficients in another order.  Writing them out again as one sequential Huffman scan - what `jpegtran` does,
+// lossless by construction - gives a stream the GPU decodes to the identical blocks, so the encoded-stream cache can keep
+// such a file resident in that form: its host decode (4-5 ms of CPU per ImageNet-sized image, every epoch) is paid once.
+// Code tables: the typical tables of ITU-T T.81 Annex K.3 (what libjpeg writes by default) - one table set for every
+// re-encoded stream, shared with ordinary files in the decoder's table store.
+namespace daliamd_host {
+namespace {
+const uint8_t kStdDcLumBits[16] = {0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0};
+const uint8_t kStdDcChrBits[16] = {0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0};
+const uint8_t kStdDcVals[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+const uint8_t kStdAcLumBits[16] = {0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 0x7d};
+const uint8_t kStdAcLumVals[162] = {
+    0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07, 0x22, 0x71, 0x14, 0x32, 0x81,
+    0x91, 0xa1, 0x08, 0x23, 0x42, 0xb1, 0xc1, 0x15, 0x52, 0xd1, 0xf0, 0x24, 0x33, 0x62, 0x72, 0x82, 0x09, 0x0a, 0x16, 0x17, 0x18,
+    0x19, 0x1a, 0x25, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x34, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48,
+    0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75,
+    0x76, 0x77, 0x78, 0x79, 0x7a, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99,
+    0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3,
+    0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe1, 0xe2, 0xe3, 0xe4, 0xe5,
+    0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+const uint8_t kStdAcChrBits[16] = {0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 0x77};
+const uint8_t kStdAcChrVals[162] = {
+    0x00, 0x01, 0x02, 0x03, 0x11, 0x04, 0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07, 0x61, 0x71, 0x13, 0x22, 0x32, 0x81, 0x08,
+    0x14, 0x42, 0x91, 0xa1, 0xb1, 0xc1, 0x09, 0x23, 0x33, 0x52, 0xf0, 0x15, 0x62, 0x72, 0xd1, 0x0a, 0x16, 0x24, 0x34, 0xe1, 0x25,
+    0xf1, 0x17, 0x18, 0x19, 0x1a, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47,
+    0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74,
+    0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x82, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97,
+    0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba,
+    0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe2, 0xe3, 0xe4,
+    0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+
+struct EncTable {
+  uint16_t code[256];
+  uint8_t size[256];   // 0: the symbol has no code
+  EncTable(const uint8_t *bits16, const uint8_t *vals, int nvals) {
+    memset(code, 0, sizeof(code));
+    memset(size, 0, sizeof(size));
+    uint32_t c = 0;
+    int p = 0;
+    for (int l = 1; l <= 16; l++) {
+      for (int i = 0; i < bits16[l - 1] && p < nvals; i++, p++) { code[vals[p]] = (uint16_t)c++; size[vals[p]] = (uint8_t)l; }
+      c <<= 1;
+    }
+  }
+};
+
+struct BitWriter {
+  uint8_t *p, *end;
+  uint64_t acc = 0;
+  int n = 0;          // bits held in acc (< 32 between calls)
+  bool overflow = false;
+  BitWriter(uint8_t *b, uint8_t *e) : p(b), end(e) {}
+  inline void Put(uint32_t bits, int len) {   // len <= 26
+    acc = (acc << len) | (bits & ((1u << len) - 1));
+    n += len;
+    while (n >= 8) {
+      const uint8_t byte = (uint8_t)(acc >> (n - 8));
+      n -= 8;
+      if (end - p < 2) { overflow = true; return; }
+      *p++ = byte;
+      if (byte == 0xFF) *p++ = 0;   // byte stuffing (T.81 F.1.2.3)
+    }
+  }
+  void Flush() {   // pad the last byte with 1-bits
+    if (n > 0) Put((1u << (8 - n)) - 1, 8 - n);
+  }
+};
+
+inline int BitSize(int v) {   // category of |v| (T.81 Table F.1 / F.2)
+  v = v < 0 ? -v : v;
+  return v ? 32 - __builtin_clz((unsigned)v) : 0;
+}
+}  // namespace
+}  // namespace daliamd_host
+
+int daliamdJpegEncodeBaselineScan(const daliamdJpegInfo *info, const int16_t *const coef[4], const uint16_t *quant, uint8_t *out,
+                                  size_t capacity, size_t *length, daliamdJpegScan *scan) {
+  using namespace daliamd_host;
+  if (!info || !coef || !quant || !out || !length || !scan) return Fail("daliamdJpegEncodeBaselineScan: NULL argument");
+  const int nc = info->num_components;
+  if (nc != 1 && nc != 3) return Fail("daliamdJpegEncodeBaselineScan: %d components (1 or 3)", nc);
+  static const EncTable dc_lum(kStdDcLumBits, kStdDcVals, 12), dc_chr(kStdDcChrBits, kStdDcVals, 12);
+  static const EncTable ac_lum(kStdAcLumBits, kStdAcLumVals, 162), ac_chr(kStdAcChrBits, kStdAcChrVals, 162);
+  memset(scan, 0, sizeof(*scan));
+  int bpm = 0;
+  for (int c = 0; c < nc; c++) {
+    if (!coef[c]) return Fail("daliamdJpegEncodeBaselineScan: coef[%d] is NULL", c);
+    const int H = nc == 1 ? 1 : info->h_samp[c], V = nc == 1 ? 1 : info->v_samp[c];
+    for (int v = 0; v < V; v++)
+      for (int h = 0; h < H; h++) {
+        if (bpm >= 10) return Fail("daliamdJpegEncodeBaselineScan: more than 10 blocks per MCU");
+        scan->comp_of_block[bpm] = (uint8_t)c; scan->h_of_block[bpm] = (uint8_t)h; scan->v_of_block[bpm] = (uint8_t)v;
+        bpm++;
+      }
+    scan->dc_sel[c] = scan->ac_sel[c] = (uint8_t)(c == 0 ? 0 : 1);
+    memcpy(scan->quant[c], quant + 64 * c, 128);
+  }
+  memcpy(scan->dc_bits[0], kStdDcLumBits, 16); memcpy(scan->dc_vals[0], kStdDcVals, 12);
+  memcpy(scan->ac_bits[0], kStdAcLumBits, 16); memcpy(scan->ac_vals[0], kStdAcLumVals, 162);
+  if (nc == 3) {
+    memcpy(scan->dc_bits[1], kStdDcChrBits, 16); memcpy(scan->dc_vals[1], kStdDcVals, 12);
+    memcpy(scan->ac_bits[1], kStdAcChrBits, 16); memcpy(scan->ac_vals[1], kStdAcChrVals, 162);
+  }
+  const int hmax = nc == 1 ? 1 : info->hmax, vmax = nc == 1 ? 1 : info->vmax;
+  scan->blocks_per_mcu = bpm;
+  scan->mcus_x = (info->width + 8 * hmax - 1) / (8 * hmax);
+  scan->mcus_y = (info->height + 8 * vmax - 1) / (8 * vmax);
+  for (int c = 0; c < nc; c++) {   // the arrays must hold the MCU-padded grid (daliamdJpegDecodeCoefficients' layout)
+    const int H = nc == 1 ? 1 : info->h_samp[c], V = nc == 1 ? 1 : info->v_samp[c];
+    if (info->blocks_x[c] < scan->mcus_x * H || info->blocks_y[c] < scan->mcus_y * V)
+      return Fail("daliamdJpegEncodeBaselineScan: component %d holds %d x %d blocks, the MCU grid needs %d x %d", c,
+                  info->blocks_x[c], info->blocks_y[c], scan->mcus_x * H, scan->mcus_y * V);
+  }
+  BitWriter bw(out, out + capacity);
+  int pred[4] = {0, 0, 0, 0};
+  for (int my = 0; my < scan->mcus_y; my++)
+    for (int mx = 0; mx < scan->mcus_x; mx++)
+      for (int b = 0; b < bpm; b++) {
+        const int c = scan->comp_of_block[b];
+        const int H = nc == 1 ? 1 : info->h_samp[c], V = nc == 1 ? 1 : info->v_samp[c];
+        const int by = my * V + scan->v_of_block[b], bx = mx * H + scan->h_of_block[b];
+        const int16_t *blk = coef[c] + ((size_t)by * info->blocks_x[c] + bx) * 64;
+        const EncTable &dct = c == 0 ? dc_lum : dc_chr, &act = c == 0 ? ac_lum : ac_chr;
+        // DC difference (F.1.2.1)
+        const int diff = blk[0] - pred[c];
+        pred[c] = blk[0];
+        const int ds = BitSize(diff);
+        if (ds > 11) return Fail("daliamdJpegEncodeBaselineScan: DC difference %d outside the baseline range", diff);
+        bw.Put(dct.code[ds], dct.size[ds]);
+        if (ds) bw.Put((uint32_t)(diff < 0 ? diff - 1 : diff), ds);
+        // AC coefficients in zig-zag order (F.1.2.2)
+        int run = 0;
+        for (int k = 1; k < 64; k++) {
+          const int v = blk[kZZ.v[k]];
+          if (v == 0) { run++; continue; }
+          while (run > 15) { bw.Put(act.code[0xF0], act.size[0xF0]); run -= 16; }
+          const int sz = BitSize(v);
+          if (sz > 10) return Fail("daliamdJpegEncodeBaselineScan: AC coefficient %d outside the baseline range", v);
+          const int sym = (run << 4) | sz;
+          bw.Put(act.code[sym], act.size[sym]);
+          bw.Put((uint32_t)(v < 0 ? v - 1 : v), sz);
+          run = 0;
+        }
+        if (run > 0) bw.Put(act.code[0], act.size[0]);
+        if (bw.overflow) return Fail("daliamdJpegEncodeBaselineScan: the output buffer (%zu bytes) is too small", capacity);
+      }
+  bw.Flush();
+  if (bw.overflow) return Fail("daliamdJpegEncodeBaselineScan: the output buffer (%zu bytes) is too small", capacity);
+  *length = (size_t)(bw.p - out);
+  scan->ecs_offset = 0;
+  scan->ecs_length = (int64_t)*length;
+  scan->length_is_upper_bound = 0;
+  scan->restart_interval = 0;
+  scan->eligible = 1;
+  return 0;
+}
+
 int daliamdJpegDecodeCoefficients(const uint8_t *data, size_t size, const daliamdJpegInfo *info,
                                   int16_t *const coef[4], uint16_t *quant) {
   using namespace daliamd_host;

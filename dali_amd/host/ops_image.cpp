@@ -180,6 +180,8 @@ class ImageDecoderMixed : public OperatorBase {
     trace_runs_++;
     infos_.resize(n);
     scans_.resize(n);
+    tscans_.resize(n);
+    if (transcoded_.size() != (size_t)ring_) transcoded_.resize(ring_);
     auto src = [&](int i) { return i < (int)in.source_info.size() && !in.source_info[i].empty() ? in.source_info[i]
                                                                                                : make_string("sample #", i); };
     // ---- one thread-pool pass per sample: header parse, scan analysis and (GPU path) the copy of the entropy-coded
@@ -187,6 +189,8 @@ class ImageDecoderMixed : public OperatorBase {
     // no second pass is needed once the segment lengths are known (cost: the transfer is longer by the few hundred
     // header bytes of each file).
     const int slot = (int)(ws.iteration % ring_);
+    transcoded_[slot].resize(n);
+    for (auto &t : transcoded_[slot]) t.clear();
     Buffer &ecs_stage = *ecs_stage_[slot];
     // ---- decoded-image cache: a hit needs no work at all, its output sample IS the cache entry ----
     hit_.assign(n, 0);
@@ -202,6 +206,7 @@ class ImageDecoderMixed : public OperatorBase {
     }
     // ---- encoded-stream cache: a resident sample brings its parse results and its entropy-coded segment (in HBM);
     // the input bytes are not looked at (the reader may have skipped the file: they are empty then) ----
+    structural_.assign(n, 0);
     erec_.assign(n, nullptr);
     int nehit = 0;
     if (stream_cache_) nehit = stream_cache_->Lookup(in.source_info, hit_, &erec_, ws.stream, ws.aux_stream);
@@ -281,6 +286,9 @@ class ImageDecoderMixed : public OperatorBase {
         if (infos_[i].num_components == 4) { scans_[i].eligible = 0; return; }  // CMYK / YCCK: the host decodes these (below)
         DALI_ENFORCE(infos_[i].num_components == 1 || infos_[i].num_components == 3, "Failed to decode ", src(i),
                      ": JPEG with ", infos_[i].num_components, " components is not supported");
+        // (a stream the kernels do not take because of its STRUCTURE - progressive, several scans ... - can be kept resident
+        // re-encoded, below; one that stays on the host because of the caller's threshold cannot)
+        structural_[i] = !scans_[i].eligible && !host_huffman_only_;
         if ((int64_t)infos_[i].width * infos_[i].height < huffman_threshold_) scans_[i].eligible = 0;
         if (scans_[i].eligible && !direct && !gather)
           memcpy(static_cast<uint8_t *>(ecs_stage.data()) + ecs_off_[i], data + scans_[i].ecs_offset,
@@ -429,6 +437,21 @@ class ImageDecoderMixed : public OperatorBase {
         for (int c = 0; c < infos_[i].num_components; c++) ptrs[c] = coef_host + coef_off_[i * 3 + c];
         if (daliamdJpegDecodeCoefficients(data, in.nbytes(i), &infos_[i], ptrs, &quant_[(size_t)i * 192]) != 0)
           DALI_FAIL("Failed to decode ", src(i), ": ", daliamdHostGetLastErrorMessage());
+        // Round 6: the encoded-stream cache keeps such a stream too - as the baseline re-encoding of the coefficients just
+        // decoded (lossless: daliamdJpegEncodeBaselineScan), which the device decodes from the next epoch on.  A progressive
+        // ImageNet-sized file costs 4-5 ms of host decode; 5 % of them in every batch held the resident pipeline at 24 000
+        // images/s (bench.py value_mixed).  A stream whose coefficients do not fit the baseline code stays a host decode.
+        if (stream_cache_ && structural_[i] && i < (int)in.source_info.size() && !in.source_info[i].empty() &&
+            (infos_[i].num_components == 1 || infos_[i].num_components == 3) && transcode_) {
+          auto &t = transcoded_[slot][i];
+          t.resize(2 * in.nbytes(i) + 4096);
+          size_t len = 0;
+          const int16_t *cptrs[4] = {ptrs[0], ptrs[1], ptrs[2], ptrs[3]};
+          if (daliamdJpegEncodeBaselineScan(&infos_[i], cptrs, &quant_[(size_t)i * 192], t.data(), t.size(), &len, &tscans_[i]) == 0)
+            t.resize(len);
+          else
+            t.clear();
+        }
       }, (int64_t)in.nbytes(i));
     }
     // ---- the other container formats: host decode into page-locked memory laid out like the output, one upload each
@@ -725,6 +748,27 @@ class ImageDecoderMixed : public OperatorBase {
       for (auto &key : keys) pending.erase(std::remove(pending.begin(), pending.end(), key), pending.end());
     };
     commit(false);
+    if (stream_cache_ && ngpu < nact) {   // the re-encoded streams of this batch's host decodes become resident
+      std::vector<std::string> keys;
+      std::vector<const daliamdJpegInfo *> kinfos;
+      std::vector<const daliamdJpegScan *> kscans;
+      for (int i = 0; i < n; i++) {
+        if (hit_[i] || erec_[i] || scan(i).eligible || !structural_[i] || transcoded_[slot][i].empty()) continue;
+        auto &t = transcoded_[slot][i];
+        if (uint8_t *slot_ptr = stream_cache_->Reserve(in.source_info[i], t.size())) {
+          reserved_streams.keys.push_back(in.source_info[i]);
+          KCHECK(daliamdMemcpyH2DAsync(slot_ptr, t.data(), t.size(), ws.stream));
+          keys.push_back(in.source_info[i]);
+          kinfos.push_back(&infos_[i]);
+          kscans.push_back(&tscans_[i]);
+        }
+      }
+      if (!keys.empty()) {
+        stream_cache_->Commit(keys, kinfos, kscans, ws.stream, std::vector<uint8_t>(keys.size(), 0), device_id_);
+        auto &pending = reserved_streams.keys;
+        for (auto &key : keys) pending.erase(std::remove(pending.begin(), pending.end(), key), pending.end());
+      }
+    }
     if (ngpu) {
       if (side)
         KCHECK(daliamdJpegHuffmanRunBack(ws.stream, reinterpret_cast<const daliamdJpegHuffDesc *>(dev_base + huff_off), ngpu,
@@ -808,6 +852,12 @@ class ImageDecoderMixed : public OperatorBase {
   std::vector<daliamdJpegInfo> jpeg4_;   // four-component streams of the batch (decoded on the host)
   std::vector<daliamdJpegInfo> infos_;
   std::vector<daliamdJpegScan> scans_;
+  // host-decoded streams kept resident as their baseline re-encoding (round 6): per ring slot and sample the bytes (they are
+  // the source of an asynchronous upload), per sample the scan analysis that goes with them
+  std::vector<std::vector<std::vector<uint8_t>>> transcoded_;
+  std::vector<daliamdJpegScan> tscans_;
+  std::vector<uint8_t> structural_;
+  bool transcode_ = !(getenv("DALI_AMD_TRANSCODE_PROGRESSIVE") && atoi(getenv("DALI_AMD_TRANSCODE_PROGRESSIVE")) == 0);
   std::vector<int> gpu_samples_;
   std::vector<char> fused_color_;        // per sample: the entropy decoder writes its RGB image (no colour launch)
   bool fuse_color_ = false;

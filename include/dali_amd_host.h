@@ -104,6 +104,16 @@ DALIAMD_HOST_API int daliamdJpegAnalyzeScan(const uint8_t *data, size_t size, co
 DALIAMD_HOST_API int daliamdJpegAnalyzeHeader(const uint8_t *data, size_t size, daliamdJpegInfo *info,
                                              daliamdJpegScan *scan);
 
+/* Writes decoded coefficient arrays (the layout of daliamdJpegDecodeCoefficients) out again as ONE sequential, interleaved
+ * baseline Huffman scan with the typical code tables of T.81 Annex K.3: the lossless re-encoding `jpegtran` performs.  `out`
+ * receives the entropy-coded segment (byte-stuffed, no markers), `scan` the analysis the GPU entropy decoder needs for it
+ * (eligible = 1, ecs_offset 0, exact ecs_length, the Annex K tables, `quant` as given).  decoders.image(mixed) uses it to
+ * keep progressive / multi-scan streams resident in the encoded-stream cache in a form the device decodes (the reference
+ * hands such streams to nvJPEG's hybrid decoder every epoch: image_decoder.h:810-834).  Returns 0 on success; coefficients
+ * outside the baseline range (|AC| > 1023, |DC difference| > 2047) or a too small buffer are errors. */
+DALIAMD_HOST_API int daliamdJpegEncodeBaselineScan(const daliamdJpegInfo *info, const int16_t *const coef[4], const uint16_t *quant,
+                                                  uint8_t *out, size_t capacity, size_t *length, daliamdJpegScan *scan);
+
 /* ----------------------------------------------------------------------------------------------
  * Random machinery, bit-compatible with the reference's host code.
  *   Philox4x32-10                 include/dali/core/random/philox.h:27-160

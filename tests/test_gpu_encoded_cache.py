@@ -1,8 +1,9 @@
 """GPU: the encoded-stream cache of the image decoders (`cache_type="encoded"`, an MI355X extension of the reference's
 decoder cache) together with the readers' `skip_cached_images` (loader.h:466-480): from the second epoch on the reader
 emits EMPTY samples and the decoder decodes from the segments resident in HBM - the pixels must be those of a fresh
-decode, for whole images, region-of-interest decodes and batches that mix resident, new, progressive (never kept) and
-PNG samples."""
+decode, for whole images, region-of-interest decodes and batches that mix resident, new, progressive and PNG samples.
+Round 6: a progressive stream (host entropy decoder) is kept too - as the lossless baseline re-encoding of its coefficients
+(daliamdJpegEncodeBaselineScan), which the device decodes from then on; DALI_AMD_TRANSCODE_PROGRESSIVE=0 switches that off."""
 import gc
 
 import numpy as np
@@ -24,7 +25,7 @@ def files(tmp_path_factory):
     for i, hw in enumerate(SIZES):
         kw = dict(subsampling=["4:2:0", "4:4:4", "4:2:2"][i % 3])
         if i == 3:
-            kw["progressive"] = True          # host entropy decoder: not kept
+            kw["progressive"] = True          # host entropy decoder; kept resident re-encoded as a baseline stream
         p = root / f"img{i}.jpg"
         p.write_bytes(encode_jpeg(synth_image(rng, *hw), 85, **kw))
         out.append(str(p))
@@ -70,10 +71,8 @@ def test_second_epoch_decodes_from_hbm_without_reading_the_files(files, decoded)
             nbytes = enc.at(i).size
             # (epoch 1 fills; the reader runs up to two batches ahead of the decoder; a stream kept with its index becomes
             # resident behind the launch of the decode that builds it, a stream kept as it is in front of it)
-            if it >= (3 if CACHE_TYPE[0] == "encoded" else 4) and k != 3:
+            if it >= (3 if CACHE_TYPE[0] == "encoded" else 4):
                 assert nbytes == 0, f"iteration {it}: sample {k} was read again ({nbytes} bytes)"
-            if k == 3:
-                assert nbytes > 0, "the progressive stream is not kept: it must be read every epoch"
         assert "jpeg_huffman" in pipe.executed_kernels()   # a hit is decoded anew
         if it >= 4:
             assert ("jpeg_huffman_indexed" in pipe.executed_kernels()) == (CACHE_TYPE[0] == "indexed")
@@ -143,7 +142,19 @@ def test_mixed_batches_resident_new_and_other_formats(tmp_path, files, decoded):
         for i in range(6):
             assert np.array_equal(img[i].as_cpu(), want[i]), (it, i)
     assert enc.at(0).size == 0 and enc.at(4).size == 0        # resident from pipe1's epoch
-    assert enc.at(2).size > 0 and enc.at(3).size > 0           # PNG and progressive JPEG are read every time
+    assert enc.at(2).size > 0                                  # a PNG is read (and decoded on the host) every time
+    assert enc.at(3).size == 0                                 # the progressive JPEG: resident re-encoded since pipe1's epoch
+
+
+def test_progressive_streams_stay_host_decoded_when_the_reencoding_is_switched_off(files, decoded, monkeypatch):
+    monkeypatch.setenv("DALI_AMD_TRANSCODE_PROGRESSIVE", "0")
+    pipe = _pipe([files[3], files[0]], 2, outputs="both")
+    for it in range(6):
+        img, enc = pipe.run()
+        assert np.array_equal(img[0].as_cpu(), decoded[3]) and np.array_equal(img[1].as_cpu(), decoded[0]), it
+        assert enc.at(0).size > 0, "not kept: read and decoded on the host every epoch"
+    assert enc.at(1).size == 0
+    assert "jpeg_idct" in pipe.executed_kernels()              # the stand-alone IDCT of host-decoded coefficients still runs
 
 
 def test_without_skip_the_reader_still_reads_but_the_decoder_uses_the_cache(files, decoded):

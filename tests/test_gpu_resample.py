@@ -312,7 +312,7 @@ def test_twelve_megapixel_crops_take_the_two_launch_path_in_a_mixed_batch(dtype)
     imgs = [big, synth_image(rng, 375, 500), big, synth_image(rng, 480, 640), big]
     rois = [(100.0, 200.0, 2900.0, 3300.0),      # wide: 2800 x 3100
             (10.0, 20.0, 300.0, 420.0),
-            (50.5, 1000.25, 2950.0, 2400.75),    # tall and fractional: 2900 x 1400
+            (1000.5, 50.25, 1700.0, 3950.75),    # short, wide and fractional (700 x 3900): the horizontal pass goes first
             (0.0, 0.0, 480.0, 640.0),
             (2999.0, 3999.0, 0.0, 0.0)]          # the whole image, flipped in both axes
     mirror = np.array([1, 0, 0, 1, 1], np.int32)
@@ -329,14 +329,21 @@ def test_twelve_megapixel_crops_take_the_two_launch_path_in_a_mixed_batch(dtype)
     torch.cuda.synchronize()
     lib.daliamdKernelTimingEnable(0)
     launched = _kernel_launches()
-    assert launched.get("ResampleGenericKernel", 0) >= 1 and launched.get("ResampleKernel", 0) >= 1, launched
-    orders = []
+    assert launched.get("ResampleGenericKernel", 0) >= 1, launched
+    import os
+    if int(os.environ.get("DALI_AMD_RESAMPLE_TWO_PASS_AREA", "64")) <= 512:     # (the suite is also run with everything forced there)
+        assert launched.get("ResampleKernel", 0) >= 1, launched
+    orders, bad = [], []
     for i, im in enumerate(imgs):
         ref, info = O.resample_u8(im, (224, 224), roi=rois[i], return_info=True)
         orders.append(int(info[0]))
         if dtype == "uint8":
-            assert np.array_equal(out[i], ref), f"sample {i}: {int((out[i] != ref).sum())} elements differ"
+            if not np.array_equal(out[i], ref):
+                d = np.abs(out[i].astype(int) - ref.astype(int))
+                bad.append((i, int((d > 0).sum()), int(d.max()), np.argwhere(d > 0)[:4].tolist()))
         else:
             want = O.cmn_u8(ref, (0, 0), (224, 224), mirror=bool(mirror[i]), mean=mean, inv_std=inv, dtype=O.F16)
-            assert np.array_equal(out[i].view(np.uint16), want.view(np.uint16)), f"sample {i}"
+            if not np.array_equal(out[i].view(np.uint16), want.view(np.uint16)):
+                bad.append((i, int((out[i].view(np.uint16) != want.view(np.uint16)).sum())))
+    assert not bad, f"(sample, differing elements, ...): {bad}; pass orders {orders}"
     assert {orders[0], orders[2]} == {0, 1}, f"both pass orders on the large samples: {orders}"
