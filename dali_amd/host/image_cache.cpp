@@ -346,6 +346,22 @@ void StreamCache::Commit(const std::vector<std::string> &keys, const std::vector
   }
 }
 
+void StreamCache::CommitRaster(const std::string &key, int h, int w, int c, int64_t pitch, int image_type, daliamdStream_t stream) {
+  auto fence = std::make_shared<ImageCache::Fence>();
+  KCHECK(daliamdEventCreate(&fence->event, 0));
+  KCHECK(daliamdEventRecord(fence->event, stream));
+  auto rec = std::make_shared<Record>();
+  rec->info = daliamdJpegInfo{};
+  rec->scan = daliamdJpegScan{};
+  rec->h = h; rec->w = w; rec->c = c; rec->pitch = pitch; rec->image_type = image_type;
+  std::lock_guard<std::mutex> g(m_);
+  auto it = pending_.find(key);
+  if (it == pending_.end()) return;
+  rec->pixels = it->second.first;
+  entries_[key] = Slot{rec, fence};
+  pending_.erase(it);
+}
+
 void StreamCache::Invalidate(const std::string &key) {
   std::lock_guard<std::mutex> g(m_);
   entries_.erase(key);   // (the space is not reclaimed)

@@ -129,6 +129,12 @@ class StreamCache {
     // `ecs` is null then
     const uint8_t *index = nullptr;
     const uint8_t *tables = nullptr;   // HuffTableStore: the stream's finished code tables, when its set is kept
+    // Round 6, "raster resident": a sample the device cannot decode at all (CMYK / YCCK JPEG, PNG, BMP, PNM - host pixel
+    // decoders, 4-7 ms each, on the critical path of the batch they sit in) is kept as its DECODED upright image: h x w x c
+    // bytes, rows `pitch` apart, in the decoder's output_type `image_type`.  `ecs` and `index` are null then.
+    const uint8_t *pixels = nullptr;
+    int32_t h = 0, w = 0, c = 0, image_type = 0;
+    int64_t pitch = 0;
     daliamdJpegInfo info;
     daliamdJpegScan scan;
   };
@@ -149,6 +155,8 @@ class StreamCache {
   void Commit(const std::vector<std::string> &keys, const std::vector<const daliamdJpegInfo *> &infos,
               const std::vector<const daliamdJpegScan *> &scans, daliamdStream_t stream,
               const std::vector<uint8_t> &indexed = {}, int device_id = -1);
+  // the slot reserved for `key` holds a decoded image (Record::pixels) once `stream` has passed this point
+  void CommitRaster(const std::string &key, int h, int w, int c, int64_t pitch, int image_type, daliamdStream_t stream);
   void Invalidate(const std::string &key);
   // Reservations that will never be committed (an exception between Reserve and Commit): the keys become reservable
   // again and the space of those that still sit at the end of the blob is handed back.

@@ -224,6 +224,22 @@ class ImageDecoderMixed : public OperatorBase {
       }
     }
     raster_hw_.assign(2 * (size_t)n, 0);
+    // "raster residents" (round 6): samples of formats the device cannot decode, kept in the encoded-stream cache as their
+    // decoded upright image - handed out in place (a window of one: a view), no host decode, no upload, no file read
+    rres_.assign(n, nullptr);
+    rkeep_.assign(n, nullptr);
+    for (int i = 0; i < n && nehit > 0; i++) {
+      if (!erec_[i] || !erec_[i]->pixels) continue;
+      DALI_ENFORCE(erec_[i]->image_type == out_type_, "Failed to decode ", src(i), ": it is resident as a decoded image of another "
+                   "output_type (decoders that share a device's encoded cache must agree on output_type for non-JPEG samples)");
+      rres_[i] = std::move(erec_[i]);
+      erec_[i] = nullptr;
+      raster_[i] = 3;
+      raster_hw_[2 * i] = rres_[i]->h; raster_hw_[2 * i + 1] = rres_[i]->w;
+      hit_[i] = 2;
+      nehit--;
+      nact--;
+    }
     // The reader's output already sits in page-locked memory (Buffer::Reserve): the whole block is transferred as it
     // is and the entropy-coded segments are addressed inside it - no staging copy of the JPEG bytes.  (With cache
     // hits in the batch, or input from elsewhere, the segments of the active samples are packed into the staging
@@ -255,7 +271,7 @@ class ImageDecoderMixed : public OperatorBase {
       if (hit_[i]) {
         infos_[i] = daliamdJpegInfo{};  // no components: every per-component loop below skips the sample
         scans_[i].eligible = 0;
-        if (raster_[i]) {
+        if (raster_[i] == 1) {
           daliamdImageFormat fmt;
           if (daliamdImageProbe(static_cast<const uint8_t *>(in.raw(i)), in.nbytes(i), &fmt, &raster_hw_[2 * i + 1],
                                 &raster_hw_[2 * i]) != 0)
@@ -344,8 +360,13 @@ class ImageDecoderMixed : public OperatorBase {
       ~RoiDraw() { if (armed && undo) undo(iteration); }
     } roi_draw{roi_undo_, (int64_t)ws.iteration, roi_source_ != nullptr};
     plans_.assign(n, daliamdJpegRoiPlan{});
-    std::vector<void *> ext_ptr(cache_ ? n : 0, nullptr);
-    std::vector<int64_t> ext_pitch(cache_ ? n : 0, 0);
+    std::vector<void *> ext_ptr(cache_ || stream_cache_ ? n : 0, nullptr);
+    std::vector<int64_t> ext_pitch(cache_ || stream_cache_ ? n : 0, 0);
+    struct ReservedRasters {   // raster slots reserved in this run; handed back unless their uploads get enqueued and committed
+      StreamCache *cache;
+      std::vector<std::string> keys;
+      ~ReservedRasters() { if (cache && !keys.empty()) cache->Abandon(keys); }
+    } reserved_rasters{stream_cache_.get(), {}};
     // slots reserved in this run; dropped again unless the decodes get enqueued (an exception on the way out)
     struct Reserved {
       ImageCache *cache;
@@ -357,6 +378,21 @@ class ImageDecoderMixed : public OperatorBase {
       if (raster_[i]) {
         const bool window = rois_[4 * i + 2] > 0;
         shapes[i] = {window ? rois_[4 * i + 2] : upright_hw_[2 * i], window ? rois_[4 * i + 3] : upright_hw_[2 * i + 1], oc_};
+        const int wy = window ? rois_[4 * i] : 0, wx = window ? rois_[4 * i + 1] : 0;
+        if (raster_[i] == 3) {   // resident: the output sample is (the window of) the resident image
+          DALI_ENFORCE(rres_[i]->c == oc_, "Failed to decode ", src(i), ": resident decoded image has ", rres_[i]->c, " channels");
+          ext_ptr[i] = const_cast<uint8_t *>(rres_[i]->pixels) + (size_t)wy * rres_[i]->pitch + (size_t)wx * oc_;
+          ext_pitch[i] = rres_[i]->pitch;
+        } else if (stream_cache_ && raster_residents_ && i < (int)in.source_info.size() && !in.source_info[i].empty()) {
+          // becomes resident now: the WHOLE upright image is decoded into the cache slot, this iteration's sample is a view
+          const int64_t pitch = ((int64_t)upright_hw_[2 * i + 1] * oc_ + kImagePitchAlign - 1) / kImagePitchAlign * kImagePitchAlign;
+          if (uint8_t *slot_ptr = stream_cache_->Reserve(in.source_info[i], (size_t)upright_hw_[2 * i] * (size_t)pitch)) {
+            reserved_rasters.keys.push_back(in.source_info[i]);
+            rkeep_[i] = slot_ptr;
+            ext_ptr[i] = slot_ptr + (size_t)wy * pitch + (size_t)wx * oc_;
+            ext_pitch[i] = pitch;
+          }
+        }
         continue;
       }
       if (hit_[i]) {
@@ -421,7 +457,8 @@ class ImageDecoderMixed : public OperatorBase {
       }
       if (windows && !cache_) out.SetMinReserve(whole);
     }
-    out.Resize(shapes, DALI_UINT8, kImagePitchAlign, ext_ptr, ext_pitch, cache_);
+    out.Resize(shapes, DALI_UINT8, kImagePitchAlign, ext_ptr, ext_pitch,
+               cache_ ? std::shared_ptr<void>(cache_) : std::shared_ptr<void>(stream_cache_));
     out.SetLayout("HWC");
     out.source_info = in.source_info;
     quant_.assign((size_t)n * 3 * 64, 0);
@@ -460,20 +497,22 @@ class ImageDecoderMixed : public OperatorBase {
       std::vector<size_t> roff(n, 0);
       size_t rbytes = 0;
       for (int i = 0; i < n; i++) {
-        if (!raster_[i]) continue;
+        if (raster_[i] != 1 && raster_[i] != 2) continue;   // (3: resident, nothing to decode)
         roff[i] = rbytes;
-        rbytes += ((size_t)out.shape(i)[0] * (size_t)out.row_pitch(i) + 255) & ~(size_t)255;
+        // a sample that becomes resident is decoded WHOLE (its slot holds the upright image); any other only its window
+        const size_t rows = rkeep_[i] ? (size_t)upright_hw_[2 * i] : (size_t)out.shape(i)[0];
+        rbytes += (rows * (size_t)out.row_pitch(i) + 255) & ~(size_t)255;
       }
       rs.Reserve(rbytes + 256);
       for (int i = 0; i < n; i++) {
-        if (!raster_[i]) continue;
+        if (raster_[i] != 1 && raster_[i] != 2) continue;
         ws.GetThreadPool().AddWork([&, i](int) {
-          const bool window = rois_[4 * i + 2] > 0;
+          const bool window = rois_[4 * i + 2] > 0 && !rkeep_[i];
           const uint8_t *data = static_cast<const uint8_t *>(in.raw(i));
           uint8_t *dst = static_cast<uint8_t *>(rs.data()) + roff[i];
           const int64_t pitch = out.row_pitch(i);
           const int wy = window ? rois_[4 * i] : 0, wx = window ? rois_[4 * i + 1] : 0;
-          const int wh = (int)out.shape(i)[0], ww = (int)out.shape(i)[1];
+          const int wh = window ? (int)out.shape(i)[0] : upright_hw_[2 * i], ww = window ? (int)out.shape(i)[1] : upright_hw_[2 * i + 1];
           int rc;
           if (raster_[i] == 2) {
             // CMYK / YCCK JPEG: the whole upright image on the host, then the window
@@ -498,10 +537,20 @@ class ImageDecoderMixed : public OperatorBase {
         }, (int64_t)in.nbytes(i));
       }
       ws.GetThreadPool().RunAll();
-      for (int i = 0; i < n; i++)
-        if (raster_[i])
+      for (int i = 0; i < n; i++) {
+        if (raster_[i] != 1 && raster_[i] != 2) continue;
+        if (rkeep_[i]) {   // the whole image into its cache slot (this iteration's output sample is a view of it), resident from here on
+          KCHECK(daliamdMemcpyH2DAsync(rkeep_[i], static_cast<uint8_t *>(rs.data()) + roff[i],
+                                       (size_t)upright_hw_[2 * i] * (size_t)out.row_pitch(i), ws.stream));
+          stream_cache_->CommitRaster(in.source_info[i], upright_hw_[2 * i], upright_hw_[2 * i + 1], oc_, out.row_pitch(i), out_type_,
+                                      ws.stream);
+          auto &pending = reserved_rasters.keys;
+          pending.erase(std::remove(pending.begin(), pending.end(), in.source_info[i]), pending.end());
+        } else {
           KCHECK(daliamdMemcpyH2DAsync(out.raw(i), static_cast<uint8_t *>(rs.data()) + roff[i],
                                        (size_t)out.shape(i)[0] * (size_t)out.row_pitch(i), ws.stream));
+        }
+      }
     } else if (ngpu < nact) {
       ws.GetThreadPool().RunAll();
     }
@@ -857,6 +906,9 @@ class ImageDecoderMixed : public OperatorBase {
   std::vector<std::vector<std::vector<uint8_t>>> transcoded_;
   std::vector<daliamdJpegScan> tscans_;
   std::vector<uint8_t> structural_;
+  std::vector<std::shared_ptr<const StreamCache::Record>> rres_;   // raster residents of the batch (decoded images kept in the encoded cache)
+  std::vector<uint8_t *> rkeep_;                                   // cache slots of the rasters that become resident in this iteration
+  bool raster_residents_ = !(getenv("DALI_AMD_RASTER_RESIDENTS") && atoi(getenv("DALI_AMD_RASTER_RESIDENTS")) == 0);
   bool transcode_ = !(getenv("DALI_AMD_TRANSCODE_PROGRESSIVE") && atoi(getenv("DALI_AMD_TRANSCODE_PROGRESSIVE")) == 0);
   std::vector<int> gpu_samples_;
   std::vector<char> fused_color_;        // per sample: the entropy decoder writes its RGB image (no colour launch)

@@ -137,13 +137,48 @@ def test_mixed_batches_resident_new_and_other_formats(tmp_path, files, decoded):
     mixed = [files[0], files[2], str(png), files[3], files[5], files[6]]
     pipe2 = _pipe(mixed, 6, outputs="both")
     want = [decoded[0], decoded[2], pix, decoded[3], decoded[5], decoded[6]]
-    for it in range(3):
+    for it in range(6):
         img, enc = pipe2.run()
         for i in range(6):
             assert np.array_equal(img[i].as_cpu(), want[i]), (it, i)
+        if it == 0:
+            assert enc.at(2).size > 0                          # the PNG's first sighting: read, decoded on the host
     assert enc.at(0).size == 0 and enc.at(4).size == 0        # resident from pipe1's epoch
-    assert enc.at(2).size > 0                                  # a PNG is read (and decoded on the host) every time
     assert enc.at(3).size == 0                                 # the progressive JPEG: resident re-encoded since pipe1's epoch
+    assert enc.at(2).size == 0                                 # round 6: the PNG is resident as its decoded image ("raster resident")
+
+
+def test_raster_residents_serve_windows_as_views(tmp_path):
+    """CMYK JPEG + PNG + BMP through the region-of-interest decoder with the encoded cache: first sighting decodes the whole
+    image into the cache slot, every later epoch hands out a window of the resident image - no file read, no host decode."""
+    import io
+    from PIL import Image
+    rng = np.random.default_rng(21)
+    files, ref = [], []
+    pix = synth_image(rng, 90, 120)
+    cm = Image.fromarray(pix).convert("CMYK")
+    b = io.BytesIO()
+    cm.save(b, "JPEG", quality=90)
+    (tmp_path / "a_cmyk.jpg").write_bytes(b.getvalue())
+    files.append(str(tmp_path / "a_cmyk.jpg"))
+    ref.append(np.asarray(Image.open(io.BytesIO(b.getvalue())).convert("RGB")))
+    for name in ("b.png", "c.bmp"):
+        pix = synth_image(rng, 70, 101)
+        Image.fromarray(pix).save(tmp_path / name)
+        files.append(str(tmp_path / name))
+        ref.append(pix)
+    jp = encode_jpeg(synth_image(rng, 64, 80), 85)
+    (tmp_path / "d.jpg").write_bytes(jp)
+    files.append(str(tmp_path / "d.jpg"))
+    ref.append(O.jpeg_decode_rgb(jp))
+    pipe = _pipe(files, 4, decoder="image_random_crop", random_area=[0.2, 0.8], seed=1234, outputs="both")
+    for it in range(6):
+        out, enc = pipe.run()
+        anchors, crops = O.rrc_batch(1234, it, [r.shape[:2] for r in ref], area=(0.2, 0.8))
+        for i, r in enumerate(ref):
+            (y0, x0), (h, w) = anchors[i], crops[i]
+            assert np.array_equal(out[i].as_cpu(), r[y0:y0 + h, x0:x0 + w]), (it, i)
+    assert all(enc.at(i).size == 0 for i in range(4)), [enc.at(i).size for i in range(4)]
 
 
 def test_progressive_streams_stay_host_decoded_when_the_reencoding_is_switched_off(files, decoded, monkeypatch):
