@@ -155,8 +155,10 @@ def test_smoke_and_bench_scripts_run_on_the_cpu_model():
     assert out.returncode == 0 and "smoke OK" in out.stdout, out.stdout[-1000:] + out.stderr[-3000:]
     if not os.environ.get("DALI_AMD_HIPEMU_FULL"):
         return
-    out = subprocess.run(runner + ["bench.py", "--steps", "2", "--warmup", "1", "--batch", "8", "--batches", "2", "--e2e-batch", "8"],
-                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=3000)
+    # (--side-legs --full-line: every leg, the whole details object on stdout; --no-variants: no 12-megapixel decodes on the model)
+    out = subprocess.run(runner + ["bench.py", "--steps", "2", "--warmup", "1", "--batch", "8", "--batches", "2", "--e2e-batch", "8",
+                                   "--side-legs", "--full-line", "--no-variants"],
+                         cwd=ROOT, env=dict(env, BENCH_DETAILS=os.devnull), capture_output=True, text=True, timeout=3000)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
@@ -170,13 +172,15 @@ def test_smoke_and_bench_scripts_run_on_the_cpu_model():
 
 
 @pytest.mark.parametrize("ranks", [2, 8] if os.environ.get("DALI_AMD_HIPEMU_FULL") else [2])
-def test_multi_rank_bench_launch_runs_on_the_cpu_model(ranks):
+def test_multi_rank_bench_launch_runs_on_the_cpu_model(ranks, tmp_path):
     """The driver's N > 1 launch of bench.py (python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N), every
     rank with the kernels on the model and a gloo group (BENCH_TEST_SINGLE_DEVICE=1, as tests/test_bench_multirank.py does on
     one real device): the sharded pipelines build, the barrier / max-over-ranks timing runs, rank 0 prints ONE line whose
     value counts every rank's batches.  8 ranks - the driver's largest launch - under DALI_AMD_HIPEMU_FULL (70 s)."""
     import json
-    env = dict(os.environ, BENCH_TEST_SINGLE_DEVICE="1", MASTER_ADDR="127.0.0.1", HIPEMU_THREADS=str(max(1, 8 // ranks)))
+    details = str(tmp_path / "details.json")
+    env = dict(os.environ, BENCH_TEST_SINGLE_DEVICE="1", MASTER_ADDR="127.0.0.1", HIPEMU_THREADS=str(max(1, 8 // ranks)),
+               BENCH_DETAILS=details)
     env.pop("DALI_AMD_HIPEMU", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
            "--master-port", str(29580 + ranks), os.path.join(ROOT, "tools", "hipemu", "run_on_model.py"), "bench.py", "--gpus", str(ranks),
@@ -189,7 +193,8 @@ def test_multi_rank_bench_launch_runs_on_the_cpu_model(ranks):
     assert line["n_gpus"] == ranks and line["scaling"] == "weak" and line["config"]["global_batch"] == 8 * ranks
     assert f"shard{ranks}" in line["config"]["parallelism"]
     assert abs(line["value"] - ranks * 8 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]
-    assert line["e2e_pipeline_sharded"]["num_shards"] == ranks
+    assert len(lines[0]) < 4000 and out.stdout.strip().splitlines()[-1] == lines[0]      # the compact line, last on stdout
+    assert json.load(open(details))["e2e_pipeline_sharded"]["num_shards"] == ranks and line["config"]["e2e_sharded_images_per_s"] > 0
 
 
 def test_the_product_does_not_know_the_model():
