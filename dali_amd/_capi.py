@@ -184,7 +184,7 @@ _KERNEL_SYMBOLS = [
     "daliamdEventDestroy", "daliamdEventRecord", "daliamdEventSynchronize", "daliamdEventQuery", "daliamdEventElapsedMs",
     "daliamdMalloc", "daliamdFree", "daliamdHostAlloc", "daliamdHostFree", "daliamdMemcpyH2DAsync",
     "daliamdMemcpyD2HAsync", "daliamdMemcpyD2DAsync", "daliamdMemsetAsync", "daliamdMemcpy2DD2DAsync",
-    "daliamdHostRegister", "daliamdHostUnregister", "daliamdGatherCopy",
+    "daliamdHostRegister", "daliamdHostUnregister", "daliamdGatherCopy", "daliamdJpegHuffmanIndexBuildHost",
     "daliamdJpegIdctSetup", "daliamdJpegIdctRun", "daliamdJpegHuffmanScratchBytes", "daliamdJpegHuffmanScratchBytesRestart", "daliamdJpegHuffmanSetup",
     "daliamdJpegHuffmanRun", "daliamdJpegHuffmanRunProfiled", "daliamdJpegHuffmanSetupColor", "daliamdJpegHuffmanRunColor",
     "daliamdJpegHuffmanRunProfiledColor", "daliamdJpegHuffmanColorFusable", "daliamdJpegHuffmanIndexBytes", "daliamdJpegHuffmanRunFront", "daliamdJpegHuffmanRunBack", "daliamdJpegHuffmanTablesBytes", "daliamdJpegHuffmanTablesBuild", "daliamdJpegColorSetup", "daliamdJpegPlanRoi", "daliamdJpegColorRun",
@@ -199,7 +199,7 @@ _KERNEL_SYMBOLS = [
 ]
 
 _HOST_SYMBOLS = [
-    "daliamdHostGetLastErrorMessage", "daliamdJpegParse", "daliamdJpegDecodeCoefficients", "daliamdJpegEncodeBaselineScan", "daliamdJpegDecodeRgbHost", "daliamdJpegOutputChannels", "daliamdJpegDecodeHost", "daliamdConvertRgbRows",
+    "daliamdHostGetLastErrorMessage", "daliamdJpegParse", "daliamdJpegDecodeCoefficients", "daliamdJpegEncodeBaselineScan", "daliamdJpegIndexedIs", "daliamdJpegIndexedParse", "daliamdJpegIndexedBuild", "daliamdJpegDecodeRgbHost", "daliamdJpegOutputChannels", "daliamdJpegDecodeHost", "daliamdConvertRgbRows",
     "daliamdJpegAnalyzeScan", "daliamdJpegAnalyzeHeader",
     "daliamdRandomCropBatch", "daliamdCoinFlipBatch", "daliamdPhiloxAdvanceSequence",
     "daliamdPhiloxStateToString", "daliamdPhiloxStateFromString", "daliamdPhiloxGenerate",

@@ -337,6 +337,25 @@ class JpegBatchPlan:
             self._index_dev = base[(-base.data_ptr()) % 64:]      # 64-byte aligned entries
         self.index_mode = mode
 
+    def host_index(self, j):
+        """Index entry of GPU-eligible stream j (position in the decoder's table) built on the HOST
+        (daliamdJpegHuffmanIndexBuildHost: what tools/jpeg2idx.py writes next to a file).  Returns (bytes as uint8 array,
+        status)."""
+        lib = capi.kernels()
+        if getattr(self, "_huff_template", None) is None:
+            raise RuntimeError("host_index: build the decoder's table first (huffman_descs)")
+        d = self._huff_template[j:j + 1].copy()
+        i = int(self._huff_sel[j])
+        o, l = int(self.scan["ecs_offset"][i]), int(self._ecs_len[j])
+        seg = np.ascontiguousarray(self.encoded[i][o:o + l])
+        d["ecs"] = seg.ctypes.data
+        nb = C.c_size_t(0)
+        capi.check(lib.daliamdJpegHuffmanIndexBytes(l, C.byref(nb)))
+        out = np.zeros(nb.value, np.uint8)
+        status = C.c_int32(0)
+        capi.check(lib.daliamdJpegHuffmanIndexBuildHost(d.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.byref(status)))
+        return out, status.value
+
     def new_huffman_workspace(self, device):
         """Decoder scratch + status words for one batch in flight (pipelined callers keep one per slot)."""
         return {"scratch": torch.empty(max(self.huffman_scratch_bytes, 256), dtype=torch.uint8, device=device),

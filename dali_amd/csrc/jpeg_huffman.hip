@@ -1859,6 +1859,101 @@ daliamdResult_t daliamdJpegHuffmanIndexBytes(int ecs_len, size_t *bytes) {
   return DALIAMD_SUCCESS;
 }
 
+// The index entry of a stream, built on the HOST (round 6: tools/jpeg2idx.py writes it next to the file, the mixed decoder
+// uploads it with - instead of - the entropy-coded segment, so that a COLD process and epoch 1 from files decode from the
+// index too).  The same per-lane functions the device runs (huff_core.h compiles for both), in sequence: where the kernels'
+// relaxation CONVERGES to the state in front of every slice, a sequential walk simply has it.  The bytes the device's
+// IndexBuildKernel defines - header, clean stream with its all-ones padding, entries and sentinel - are the same bytes
+// (tests/test_gpu_jpeg_index.py holds the two to each other); what lies between them is zero here.
+// `d`: bits / vals / comp_of_block / dc_sel / ac_sel / blocks_per_mcu / total_blocks / ecs_len as for a decode, `ecs` a HOST
+// pointer to the byte-stuffed segment (ecs_len may run past its end marker).  *status: 0, or 2 / 3 like a decode.
+daliamdResult_t daliamdJpegHuffmanIndexBuildHost(const daliamdJpegHuffDesc *d, void *index_out_host, int32_t *status) {
+  using namespace daliamd;
+  DALIAMD_REQUIRE(d && index_out_host && status && d->ecs && d->ecs_len >= 0 && d->restart_interval == 0 &&
+                      d->blocks_per_mcu >= 1 && d->blocks_per_mcu <= DALIAMD_JPEG_MAX_BLOCKS_PER_MCU && d->total_blocks >= 0,
+                  DALIAMD_ERROR_INVALID_ARGUMENT, "daliamdJpegHuffmanIndexBuildHost: invalid argument (streams with restart intervals have no index)");
+  DALIAMD_REQUIRE((long long)d->total_blocks + 128 < (1ll << 26), DALIAMD_ERROR_UNSUPPORTED,
+                  "daliamdJpegHuffmanIndexBuildHost: %d blocks do not fit the 26-bit ordinals of an index entry", d->total_blocks);
+  *status = 0;
+  const int ecs_len = d->ecs_len;
+  uint8_t *out = static_cast<uint8_t *>(index_out_host);
+  memset(out, 0, IndexBytes(ecs_len));
+  // ---- un-stuffing (LoadChunk's rules, byte by byte): the zero behind a 0xFF goes, fill bytes go, the segment ends at the
+  // first marker; a last 0xFF without a successor stays
+  uint8_t *clean = out + IndexCleanOffset();
+  int clean_len = 0;
+  for (int i = 0; i < ecs_len;) {
+    const uint8_t b = d->ecs[i];
+    if (b == 0xFF && i + 1 < ecs_len) {
+      const uint8_t nx = d->ecs[i + 1];
+      if (nx == 0x00) { clean[clean_len++] = 0xFF; i += 2; continue; }
+      if (nx == 0xFF) { i += 1; continue; }
+      if (nx >= 0xD0 && nx <= 0xD7) { *status = 3; return DALIAMD_SUCCESS; }   // RSTn in a stream that announces none
+      break;
+    }
+    clean[clean_len++] = b;
+    i++;
+  }
+  memset(clean + clean_len, 0xFF, kCleanPadBytes);   // (what UnstuffScatterKernel leaves behind the stream)
+  // ---- code tables
+  std::vector<uint8_t> tab(sizeof(HuffTables) + sizeof(SyncTables));
+  daliamdResult_t rc = daliamdJpegHuffmanTablesBuild(d, tab.data());
+  if (rc != DALIAMD_SUCCESS) return rc;
+  const HuffTables &D = *reinterpret_cast<const HuffTables *>(tab.data());
+  const SyncTables &L = *reinterpret_cast<const SyncTables *>(tab.data() + sizeof(HuffTables));
+  const uint32_t *words = reinterpret_cast<const uint32_t *>(clean);
+  // ---- every slice from the state its predecessor ended in: entry states, block starts found, DC level of every block
+  const uint32_t total_bits = (uint32_t)clean_len * 8u;
+  const int num_slices = (clean_len + kSliceBytes - 1) / kSliceBytes, cap = IndexSliceCap(ecs_len);
+  std::vector<DecodeState> in((size_t)num_slices);
+  std::vector<int> ord((size_t)num_slices + 1, 0);
+  std::vector<int32_t> level_of;           // absolute DC level of block q (blk_dc + the segments' totals on the device)
+  level_of.reserve((size_t)d->total_blocks + 64);
+  int level[3] = {0, 0, 0};
+  DecodeState st{0, 0, 0};
+  for (int s = 0; s < num_slices; s++) {
+    const uint32_t begin = (uint32_t)s * (kSliceBytes * 8u);
+    const uint32_t end = begin + kSliceBytes * 8u < total_bits ? begin + kSliceBytes * 8u : total_bits;
+    in[s] = st;
+    if (st.pos < end)
+      IndexedDecodeSlice(L, D, words, st, end, [&](uint32_t c, uint32_t, int diff) {
+        const int comp = d->comp_of_block[c] < 3 ? d->comp_of_block[c] : 0;
+        level[comp] += diff;
+        level_of.push_back(level[comp]);
+      });
+    ord[s + 1] = ord[s] + SyncDecodeRange(L, words, st, end, [](int, int, bool) {});
+  }
+  const int total_starts = ord[num_slices];
+  if (total_starts - 1 < d->total_blocks) *status = 2;   // (PropagateKernel: every block must start AND end inside the segment)
+  int32_t *h = reinterpret_cast<int32_t *>(out);
+  h[0] = clean_len; h[1] = total_starts; h[2] = num_slices;
+  uint32_t *entries = reinterpret_cast<uint32_t *>(out + IndexEntriesOffset(ecs_len));
+  auto put = [&](long long slice, const SliceIndex &e) {
+    entries[3 * slice] = e.w0; entries[3 * slice + 1] = e.w1; entries[3 * slice + 2] = e.w2;
+  };
+  const uint32_t zero3[3] = {0, 0, 0};
+  const SliceIndex none = PackSliceIndex((uint32_t)total_starts, DecodeState{0, 0, 0}, zero3);
+  for (int s = num_slices; s <= cap; s++) put(s, none);
+  for (int s = 0; s < num_slices; s++) {   // (IndexBuildKernel, lane by lane)
+    DecodeState e = in[s];
+    const int first_block = ord[s] - (e.z == 0 && e.pos != 0 ? 1 : 0);
+    uint32_t dc[3] = {0, 0, 0};
+    uint32_t found = 0;
+    for (int j = 1; j <= d->blocks_per_mcu && found != 7u; j++) {
+      const int q = first_block - j;
+      if (q < 0) break;
+      const int comp = d->comp_of_block[q % d->blocks_per_mcu];
+      if (comp > 2 || (found >> comp) & 1u) continue;
+      found |= 1u << comp;
+      if (q >= d->total_blocks || q + 1 >= total_starts || q >= (int)level_of.size()) continue;
+      dc[comp] = (uint32_t)level_of[q] & 0xFFFFu;
+    }
+    e.pos -= (uint32_t)s * (kSliceBytes * 8u);
+    put(s, PackSliceIndex((uint32_t)first_block, e, dc));
+  }
+  return DALIAMD_SUCCESS;
+}
+
 int daliamdJpegHuffmanColorFusable(const daliamdJpegHuffDesc *d) {
   if (!d || d->mcus_x < 1 || d->mcus_x > daliamd::kColorBandMcus) return 0;
   for (int c = 0; c < 3; c++)

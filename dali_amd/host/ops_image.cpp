@@ -207,6 +207,7 @@ class ImageDecoderMixed : public OperatorBase {
     // ---- encoded-stream cache: a resident sample brings its parse results and its entropy-coded segment (in HBM);
     // the input bytes are not looked at (the reader may have skipped the file: they are empty then) ----
     structural_.assign(n, 0);
+    boxed_.assign(n, 0);
     erec_.assign(n, nullptr);
     int nehit = 0;
     if (stream_cache_) nehit = stream_cache_->Lookup(in.source_info, hit_, &erec_, ws.stream, ws.aux_stream);
@@ -216,7 +217,8 @@ class ImageDecoderMixed : public OperatorBase {
     int nraster = 0;
     for (int i = 0; i < n; i++) {
       const uint8_t *b = static_cast<const uint8_t *>(in.raw(i));
-      if (!hit_[i] && !erec_[i] && !(in.nbytes(i) >= 3 && b[0] == 0xFF && b[1] == 0xD8 && b[2] == 0xFF)) {
+      if (!hit_[i] && !erec_[i] && !(in.nbytes(i) >= 3 && b[0] == 0xFF && b[1] == 0xD8 && b[2] == 0xFF) &&
+          !daliamdJpegIndexedIs(b, in.nbytes(i))) {
         raster_[i] = 1;
         hit_[i] = 2;  // skipped by every JPEG loop
         nraster++;
@@ -258,7 +260,7 @@ class ImageDecoderMixed : public OperatorBase {
     for (int i = 0; i < n; i++) {
       ecs_off_[i] = direct ? (size_t)(static_cast<const uint8_t *>(in.raw(i)) - static_cast<const uint8_t *>(in.base()))
                            : ecs_bytes;
-      if (!hit_[i] && !erec_[i]) ecs_bytes += ((size_t)in.nbytes(i) + 15) & ~(size_t)15;
+      if (!hit_[i] && !erec_[i]) ecs_bytes += ((size_t)in.nbytes(i) + 63) & ~(size_t)63;   // (64: an indexed container's entry)
     }
     if (direct) ecs_bytes = (in.total_bytes() + 15) & ~(size_t)15;
     // the three descriptor tables of the iteration live behind the JPEG bytes in the same staging buffer, so that
@@ -287,6 +289,25 @@ class ImageDecoderMixed : public OperatorBase {
         const uint8_t *data = static_cast<const uint8_t *>(in.raw(i));
         // a file this process has parsed before (epoch >= 2 of a shard that is not resident): what its headers said
         const bool named = i < (int)in.source_info.size() && !in.source_info[i].empty();
+        if (daliamdJpegIndexedIs(data, in.nbytes(i))) {
+          // Indexed container (tools/jpeg2idx.py, host/jpeg_indexed.cpp): the headers of the JPEG + the index entry of its
+          // entropy-coded segment, made offline.  The entry goes where the segment would go and the stream is decoded FROM it
+          // (daliamdJpegHuffDesc.index) - in the first epoch, in a cold process: the position passes never run for it.
+          daliamdJpegIndexedView view;
+          if (daliamdJpegIndexedParse(data, in.nbytes(i), &view) != 0 ||
+              daliamdJpegAnalyzeHeader(view.header, (size_t)view.header_len, &infos_[i], &scans_[i]) != 0)
+            DALI_FAIL("Failed to parse ", src(i), ": ", daliamdHostGetLastErrorMessage());
+          DALI_ENFORCE(scans_[i].eligible && scans_[i].restart_interval == 0 && !host_huffman_only_, "Failed to decode ", src(i),
+                       ": an indexed JPEG container holds a stream for the GPU entropy decoder"
+                       " (not usable with device=\"cpu\" semantics / hybrid_huffman_threshold forcing the host decoder)");
+          scans_[i].ecs_offset = view.index_offset;
+          scans_[i].ecs_length = view.ecs_len;
+          scans_[i].length_is_upper_bound = 0;
+          boxed_[i] = view.index_bytes;
+          if (!direct && !gather)
+            memcpy(static_cast<uint8_t *>(ecs_stage.data()) + ecs_off_[i], data + view.index_offset, (size_t)view.index_bytes);
+          return;
+        }
         const bool known = named && !host_huffman_only_ && HeaderCache::Find(in.source_info[i], in.nbytes(i), &infos_[i], &scans_[i]);
         // ONE pass over the headers, up to SOS: frame geometry + what the GPU entropy decoder needs.  The scan itself is
         // not walked here - its end (the first marker that is not RSTn) is found by the un-stuffing kernel, which
@@ -580,7 +601,7 @@ class ImageDecoderMixed : public OperatorBase {
     // encoded-stream cache: the streams of this batch that the cache has room for become resident - as they are (one
     // device-to-device copy each, behind the transfer, out of this iteration's buffer, which is reused ring_ iterations from
     // now) or, cache_type="indexed", as the index entry the entropy decoder leaves behind this decode
-    struct Kept { int j; uint8_t *slot; bool indexed; };
+    struct Kept { int j; uint8_t *slot; bool indexed, boxed; };
     std::vector<Kept> keep;
     struct ReservedStreams {   // reservations of this run; handed back unless the copies get enqueued and committed
       StreamCache *cache;
@@ -591,12 +612,13 @@ class ImageDecoderMixed : public OperatorBase {
       for (int j = 0; j < ngpu; j++) {
         const int i = gpu_samples_[j];
         if (erec_[i] || i >= (int)in.source_info.size()) continue;
-        const bool indexed = index_streams_ && scans_[i].restart_interval == 0 &&
-                             (int64_t)scans_[i].mcus_x * scans_[i].mcus_y * scans_[i].blocks_per_mcu + 128 < ((int64_t)1 << 26);
+        // (a sample that arrived as an indexed container stays what it is: resident WITH its entry, whatever cache_type says)
+        const bool indexed = boxed_[i] > 0 || (index_streams_ && scans_[i].restart_interval == 0 &&
+                             (int64_t)scans_[i].mcus_x * scans_[i].mcus_y * scans_[i].blocks_per_mcu + 128 < ((int64_t)1 << 26));
         size_t bytes = (size_t)scans_[i].ecs_length;
         if (indexed) KCHECK(daliamdJpegHuffmanIndexBytes((int)scans_[i].ecs_length, &bytes));
         if (uint8_t *slot_ptr = stream_cache_->Reserve(in.source_info[i], bytes)) {
-          keep.push_back({j, slot_ptr, indexed});
+          keep.push_back({j, slot_ptr, indexed, boxed_[i] > 0});
           reserved_streams.keys.push_back(in.source_info[i]);
         }
       }
@@ -625,10 +647,15 @@ class ImageDecoderMixed : public OperatorBase {
           const uint8_t *src = static_cast<const uint8_t *>(in.raw(i)) + sc.ecs_offset;
           const size_t shift = reinterpret_cast<uintptr_t>(src) & 15;
           if (!erec_[i]) d.ecs = dev_base + ecs_off_[i] + shift;
-          fetch[j] = daliamdGatherDesc{src, const_cast<uint8_t *>(d.ecs), erec_[i] ? 0u : (uint64_t)sc.ecs_length, 0};
-          if (!erec_[i]) fetch_max = std::max(fetch_max, (size_t)sc.ecs_length);
+          const size_t fetch_bytes = boxed_[i] ? (size_t)boxed_[i] : (size_t)sc.ecs_length;
+          fetch[j] = daliamdGatherDesc{src, const_cast<uint8_t *>(d.ecs), erec_[i] ? 0u : (uint64_t)fetch_bytes, 0};
+          if (!erec_[i]) fetch_max = std::max(fetch_max, fetch_bytes);
         }
         d.index = erec_[i] ? erec_[i]->index : nullptr;   // a resident stream with its side information: decoded from that
+        if (boxed_[i] && !erec_[i]) {   // an indexed container: its entry sits where the segment of an ordinary file would
+          d.index = d.ecs;
+          d.ecs = nullptr;
+        }
         d.scratch = static_cast<uint8_t *>(scratch.data()) + scratch_off_[i];
         d.status = status + j;
         d.ecs_len = (int32_t)sc.ecs_length;
@@ -673,7 +700,7 @@ class ImageDecoderMixed : public OperatorBase {
         }
       }
       for (auto &k : keep)
-        if (k.indexed) huff[k.j].index_out = k.slot;
+        if (k.indexed && !k.boxed) huff[k.j].index_out = k.slot;
       KCHECK(daliamdJpegHuffmanSetupColor(huff, ngpu, &ntiles, &nsegs, &nbwg, &block_kernels));
       // the status words are valid once the iteration has finished: checked when its outputs are handed over.  (The
       // samples' names are looked up only when a word is set: the input of this iteration - a ring slot that is not written
@@ -787,6 +814,7 @@ class ImageDecoderMixed : public OperatorBase {
         if (k.indexed != indexed) continue;
         const int i = gpu_samples_[k.j];
         if (!indexed) KCHECK(daliamdMemcpyD2DAsync(k.slot, huff[k.j].ecs, (size_t)scans_[i].ecs_length, ws.stream));
+        else if (k.boxed) KCHECK(daliamdMemcpyD2DAsync(k.slot, huff[k.j].index, (size_t)boxed_[i], ws.stream));   // the entry it came with
         keys.push_back(in.source_info[i]);
         kinfos.push_back(&infos_[i]);
         kscans.push_back(&scans_[i]);
@@ -906,6 +934,7 @@ class ImageDecoderMixed : public OperatorBase {
   std::vector<std::vector<std::vector<uint8_t>>> transcoded_;
   std::vector<daliamdJpegScan> tscans_;
   std::vector<uint8_t> structural_;
+  std::vector<int64_t> boxed_;           // per sample: bytes of the index entry it brings (an indexed JPEG container), else 0
   std::vector<std::shared_ptr<const StreamCache::Record>> rres_;   // raster residents of the batch (decoded images kept in the encoded cache)
   std::vector<uint8_t *> rkeep_;                                   // cache slots of the rasters that become resident in this iteration
   bool raster_residents_ = !(getenv("DALI_AMD_RASTER_RESIDENTS") && atoi(getenv("DALI_AMD_RASTER_RESIDENTS")) == 0);

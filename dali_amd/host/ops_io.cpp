@@ -160,6 +160,12 @@ DALI_SCHEMA(readers__File)
     .AddOptionalArg("case_sensitive_filter", "Match the filters case-sensitively.", ArgValue::Bool(false))
     .AddOptionalArg("shuffle_after_epoch", "Reshuffle the whole dataset after each epoch.", ArgValue::Bool(false))
     .AddOptionalArg("shuffle_after_epoch_seed", "Seed for shuffle_after_epoch.", ArgValue::Int(0))
+    .AddOptionalTypeArg("index_path", "MI355X extension: root of a tree of indexed JPEG containers made offline by "
+                        "``tools/jpeg2idx.py`` (``<index_path>/<relative file name>.didx``).  Where a container exists it is read "
+                        "in place of the file; ``decoders.image(device=\"mixed\")`` decodes it from its index (no position passes "
+                        "in the GPU entropy decoder, also in the first epoch).  The sample keeps the file's name and label.  The "
+                        "reference indexes its containers offline the same way (tools/tfrecord2idx, tools/wds2idx.py).",
+                        ArgType::STRING)
     .AddParent("LoaderBase");
 
 DALI_SCHEMA(FileReader).DocStr("Legacy alias of readers.file").NumInput(0).NumOutput(2).AddParent("readers__File");
@@ -399,6 +405,25 @@ class FileReaderOp : public OperatorBase {
     paths_.reserve(entries_.size());
     for (auto &e : entries_)
       paths_.push_back((root_.empty() || (!e.first.empty() && e.first[0] == '/')) ? e.first : root_ + "/" + e.first);
+    // index_path (round 6): a tree of indexed JPEG containers made offline by tools/jpeg2idx.py - <index_path>/<name as
+    // under file_root>.didx.  Where one exists it is READ IN PLACE OF the file (the mixed decoders take it wherever they take
+    // a JPEG and decode it from its index entry); the sample keeps the file's name - labels, error messages and the decoder
+    // caches' keys do not change.  Files without one (progressive, PNG ...) are read as they are.
+    read_paths_ = paths_;
+    if (const ArgValue *ip = spec.TryArg("index_path")) {
+      const std::string base = ip->s;
+      for (size_t i = 0; i < entries_.size() && !base.empty(); i++) {
+        std::string rel = entries_[i].first;
+        if (!rel.empty() && rel[0] == '/') {   // an absolute name: relative to file_root when it lies below it, else its base name
+          if (!root_.empty() && rel.compare(0, root_.size(), root_) == 0 && rel.size() > root_.size() && rel[root_.size()] == '/')
+            rel = rel.substr(root_.size() + 1);
+          else
+            rel = rel.substr(rel.rfind('/') + 1);
+        }
+        const std::string cand = base + "/" + rel + ".didx";
+        if (access(cand.c_str(), R_OK) == 0) { read_paths_[i] = cand; indexed_files_++; }
+      }
+    }
     size_cache_.assign(entries_.size(), -1);
     fds_ = std::make_unique<std::atomic<int>[]>(entries_.size());
     for (size_t i = 0; i < entries_.size(); i++) fds_[i].store(-1, std::memory_order_relaxed);
@@ -610,7 +635,7 @@ class FileReaderOp : public OperatorBase {
       off_t &cached = size_cache_[idx];  // the dataset is static: one stat() per file, not one per epoch
       if (cached < 0) {
         struct stat st;
-        DALI_ENFORCE(stat(paths_[idx].c_str(), &st) == 0, "Could not open file ", paths_[idx]);
+        DALI_ENFORCE(stat(read_paths_[idx].c_str(), &st) == 0, "Could not open file ", read_paths_[idx]);
         cached = st.st_size;
       }
       b.sizes[i] = cached;
@@ -704,7 +729,7 @@ class FileReaderOp : public OperatorBase {
   int Descriptor(int64_t idx) {
     int fd = fds_[idx].load(std::memory_order_acquire);
     if (fd >= 0) return fd;
-    fd = open(paths_[idx].c_str(), O_RDONLY | O_CLOEXEC);
+    fd = open(read_paths_[idx].c_str(), O_RDONLY | O_CLOEXEC);
     if (fd < 0) return -1;
     // read_ahead: the whole file is wanted, tell the kernel before the first byte is asked for
     if (read_ahead_) posix_fadvise(fd, 0, 0, POSIX_FADV_WILLNEED);
@@ -819,7 +844,7 @@ class FileReaderOp : public OperatorBase {
           }
           if (got != b.sizes[i]) {
             resident_[idx].store(nullptr, std::memory_order_release);   // (the slot is lost; the next sighting tries again)
-            return make_string(fd < 0 ? "Could not open file " : "Failed to read file ", paths_[idx]);
+            return make_string(fd < 0 ? "Could not open file " : "Failed to read file ", read_paths_[idx]);
           }
           CopyOut(dst, slot, (size_t)b.sizes[i]);
           resident_[idx].store(slot, std::memory_order_release);
@@ -838,7 +863,7 @@ class FileReaderOp : public OperatorBase {
       }
     }
     const int fd = Descriptor(idx);
-    if (fd < 0) return make_string("Could not open file ", paths_[idx]);
+    if (fd < 0) return make_string("Could not open file ", read_paths_[idx]);
     if (map_budget_ > 0) {
       if (const char *m = Mapping(idx, fd, b.sizes[i])) {
         CopyOut(dst, m, (size_t)b.sizes[i]);
@@ -851,7 +876,7 @@ class FileReaderOp : public OperatorBase {
       if (r <= 0) break;
       got += r;
     }
-    if (got != b.sizes[i]) return make_string("Failed to read file ", paths_[idx]);
+    if (got != b.sizes[i]) return make_string("Failed to read file ", read_paths_[idx]);
     return "";
   }
 
@@ -889,7 +914,9 @@ class FileReaderOp : public OperatorBase {
   int64_t map_budget_ = 0;
   int device_id_, depth_, num_workers_ = 1;
   std::vector<off_t> size_cache_;  // planner thread
-  std::vector<std::string> paths_;
+  std::vector<std::string> paths_;       // the samples' names (source_info, cache keys)
+  std::vector<std::string> read_paths_;  // what is opened for them: the same, or the file's indexed container (index_path)
+  int64_t indexed_files_ = 0;
   std::unique_ptr<std::atomic<int>[]> fds_;
   std::mutex fd_m_;
   std::deque<int64_t> open_fifo_;

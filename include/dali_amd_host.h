@@ -104,6 +104,25 @@ DALIAMD_HOST_API int daliamdJpegAnalyzeScan(const uint8_t *data, size_t size, co
 DALIAMD_HOST_API int daliamdJpegAnalyzeHeader(const uint8_t *data, size_t size, daliamdJpegInfo *info,
                                              daliamdJpegScan *scan);
 
+/* Indexed JPEG container (".didx"; dali_amd/host/jpeg_indexed.cpp, tools/jpeg2idx.py): a baseline JPEG prepared offline for
+ * the GPU entropy decoder - its headers up to SOS as they are, its entropy-coded segment replaced by the index entry of
+ * daliamdJpegHuffDesc.index (daliamdJpegHuffmanIndexBuildHost).  decoders.image(device="mixed") takes such samples wherever it
+ * takes JPEG files and decodes them from the entry: the position passes of the decoder do not run, in the first epoch and in a
+ * cold process too (the reference's offline indices: tools/tfrecord2idx, tools/wds2idx.py, tools/rec2idx.py).
+ * Build: out == NULL returns the size in *length.  Returns 0 on success; a stream the GPU decoder does not take (progressive,
+ * restart intervals, four components, truncated) is an error with a message - such files stay what they are. */
+typedef struct {
+  const uint8_t *header;   /* the JPEG's bytes up to and including its SOS header */
+  int32_t header_len;
+  int32_t ecs_len;         /* length of the original entropy-coded segment: daliamdJpegHuffDesc.ecs_len of the decode */
+  int64_t index_offset;    /* offset of the index entry inside the container (a multiple of 64) */
+  int64_t index_bytes;
+  int64_t jpeg_size;       /* size of the file the container was made from */
+} daliamdJpegIndexedView;
+DALIAMD_HOST_API int daliamdJpegIndexedIs(const uint8_t *data, size_t size);
+DALIAMD_HOST_API int daliamdJpegIndexedParse(const uint8_t *data, size_t size, daliamdJpegIndexedView *view);
+DALIAMD_HOST_API int daliamdJpegIndexedBuild(const uint8_t *jpeg, size_t size, uint8_t *out, size_t capacity, size_t *length);
+
 /* Writes decoded coefficient arrays (the layout of daliamdJpegDecodeCoefficients) out again as ONE sequential, interleaved
  * baseline Huffman scan with the typical code tables of T.81 Annex K.3: the lossless re-encoding `jpegtran` performs.  `out`
  * receives the entropy-coded segment (byte-stuffed, no markers), `scan` the analysis the GPU entropy decoder needs for it

@@ -256,6 +256,12 @@ DALIAMD_API daliamdResult_t daliamdJpegHuffmanTablesBytes(size_t *bytes);
 /* host only: out_host receives daliamdJpegHuffmanTablesBytes() bytes */
 DALIAMD_API daliamdResult_t daliamdJpegHuffmanTablesBuild(const daliamdJpegHuffDesc *desc, void *out_host);
 DALIAMD_API daliamdResult_t daliamdJpegHuffmanIndexBytes(int ecs_len, size_t *bytes);
+/* host only: the index entry (daliamdJpegHuffmanIndexBytes(desc->ecs_len) bytes at index_out_host) of the stream whose
+ * byte-stuffed segment `desc->ecs` points to IN HOST MEMORY - what a decode with index_out leaves behind on the device, made
+ * offline (the reference indexes its containers offline: tools/tfrecord2idx, tools/wds2idx.py, tools/rec2idx.py).  Needs the
+ * descriptor's code-table and MCU fields, total_blocks, ecs_len; restart_interval must be 0.  *status: 0, or 2 / 3 as after
+ * a decode (truncated stream / restart markers) - such a stream gets no index. */
+DALIAMD_API daliamdResult_t daliamdJpegHuffmanIndexBuildHost(const daliamdJpegHuffDesc *desc, void *index_out_host, int32_t *status);
 
 /* 1 when the stream's geometry (blocks_per_mcu, comp_of_block, h/v_of_block, h/v_samp, mcus_x, rect) allows the fused
  * colour output, else 0.  Host helper, looks at nothing else. */

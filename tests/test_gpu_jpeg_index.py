@@ -137,3 +137,43 @@ def test_host_built_code_tables_are_the_device_built_ones():
         assert np.array_equal(plain[i].cpu().numpy(), ref) and np.array_equal(brought[i].cpu().numpy(), ref), i
         if i < 4:
             assert np.array_equal(again[i].cpu().numpy(), ref), i
+
+
+@pytest.mark.parametrize("exact_scan", [True, False])
+def test_host_built_index_is_the_device_built_one(exact_scan):
+    """daliamdJpegHuffmanIndexBuildHost (round 6: the sidecar tools/jpeg2idx.py writes, so that a cold process and epoch 1 from
+    files decode from the index too): byte for byte what IndexBuildKernel leaves behind a decode - header, clean stream with
+    its all-ones padding, every slice entry and the sentinel - and a decode FROM the host-built entries gives the oracle's
+    pixels.  (The device leaves the bytes between those regions unwritten; the host zeroes them.)"""
+    from dali_amd import backend as B
+    enc = _streams(np.random.default_rng(21))
+    _, plan = B.decode_jpeg_batch(enc, device="cuda", exact_scan=exact_scan, index="build")
+    torch.cuda.synchronize()
+    dev = plan._index_dev.cpu().numpy()
+    host_all = np.zeros_like(dev)
+    checked = 0
+    for j, i in enumerate(plan._huff_sel):
+        off, ecs_len = int(plan._index_off[j]), int(plan._ecs_len[j])
+        if plan.scan["restart_interval"][i] != 0:
+            continue                                                     # (no index for restart-interval streams)
+        host, status = plan.host_index(j)
+        assert status == 0, (i, status)
+        d = dev[off:off + host.size]
+        clean_len, total_starts, num_slices = (int(x) for x in d[:12].view(np.int32))
+        assert bytes(host[:64]) == bytes(d[:64]), f"stream {i}: header {host[:12].view(np.int32)} vs {d[:12].view(np.int32)}"
+        stream_end = clean_len + 40                                      # the stream and its 40 bytes of all-ones padding
+        assert np.array_equal(host[64:64 + stream_end], d[64:64 + stream_end]), f"stream {i}: clean stream"
+        eoff = 64 + (ecs_len + 256 + 63) // 64 * 64
+        cap = (ecs_len + 255) // 256
+        he, de = host[eoff:eoff + 12 * (cap + 1)].view(np.uint32).reshape(-1, 3), d[eoff:eoff + 12 * (cap + 1)].view(np.uint32).reshape(-1, 3)
+        bad = np.nonzero((he != de).any(1))[0]
+        assert bad.size == 0, f"stream {i} ({num_slices} slices, {total_starts} starts): entries {bad[:6].tolist()} differ: {he[bad[:3]].tolist()} vs {de[bad[:3]].tolist()}"
+        host_all[off:off + host.size] = host
+        checked += 1
+    assert checked >= len(enc) - 3
+    # decode from the HOST-built entries
+    plan._index_dev.copy_(torch.from_numpy(host_all))
+    again, _ = B.decode_jpeg_batch(enc, device="cuda", exact_scan=exact_scan, index="use", index_from=plan)
+    torch.cuda.synchronize()
+    for i, e in enumerate(enc):
+        assert np.array_equal(again[i].cpu().numpy(), O.jpeg_decode_rgb(e)), f"sample {i} (decode from the host-built index)"
