@@ -42,14 +42,20 @@ def build_one(job):
     return src, int(n.value), ""
 
 
-def index_tree(file_root, index_root, workers=0, filters=("*.jpg", "*.jpeg", "*.JPG", "*.JPEG"), quiet=False):
+def index_tree(file_root, index_root, workers=0, filters=("*.jpg", "*.jpeg", "*.JPG", "*.JPEG"), quiet=False, threads=False):
+    """threads: a thread pool instead of forked workers (the library calls release the GIL) - for a process that has already
+    initialised the GPU runtime."""
     jobs = []
     for dirpath, _, files in os.walk(file_root):
         for f in sorted(files):
             if any(fnmatch.fnmatch(f, p) for p in filters):
                 src = os.path.join(dirpath, f)
                 jobs.append((src, os.path.join(index_root, os.path.relpath(src, file_root) + ".didx")))
-    if workers and workers > 1 and len(jobs) >= 2 * workers:
+    if threads and workers and workers > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(workers) as pool:
+            results = list(pool.map(build_one, jobs))
+    elif workers and workers > 1 and len(jobs) >= 2 * workers:
         import multiprocessing as mp
         with mp.get_context("fork").Pool(workers) as pool:
             results = pool.map(build_one, jobs, chunksize=max(1, len(jobs) // (8 * workers)))
