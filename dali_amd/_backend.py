@@ -52,10 +52,15 @@ def _lib():
     return lib
 
 
+class PipelineError(RuntimeError):
+    """An error the executor reports through the C ABI (an operator failed in the iteration that was being handed out, ...):
+    a RuntimeError, as before; its own type so that a caller can tell it from an error raised in front of the call."""
+
+
 def check(rc):
     if rc != 0:
         msg = _lib().daliamdHostGetLastErrorMessage()
-        raise RuntimeError(msg.decode(errors="replace") if msg else "unknown error")
+        raise PipelineError(msg.decode(errors="replace") if msg else "unknown error")
 
 
 def _string_out(fn, *args):

@@ -427,7 +427,11 @@ const uint8_t *HuffTableStore::Get(int device_id, const daliamdJpegScan &scan) {
   if (daliamdJpegHuffmanTablesBuild(&d, host.data()) != DALIAMD_SUCCESS) return nullptr;   // (the launch will say why)
   void *dev = nullptr;
   if (daliamdMalloc(&dev, bytes) != DALIAMD_SUCCESS) return nullptr;
-  if (daliamdMemcpyH2DAsync(dev, host.data(), bytes, nullptr) != DALIAMD_SUCCESS || daliamdStreamSynchronize(nullptr) != DALIAMD_SUCCESS) {
+  // (on a stream of its own, never the legacy NULL stream: in a training process that one is the framework's default stream,
+  // and waiting for it means waiting for everything the training loop has queued - ADVICE r05)
+  static daliamdStream_t upload_stream = [] { daliamdStream_t s = nullptr; daliamdStreamCreate(&s, 1); return s; }();
+  if (!upload_stream || daliamdMemcpyH2DAsync(dev, host.data(), bytes, upload_stream) != DALIAMD_SUCCESS ||
+      daliamdStreamSynchronize(upload_stream) != DALIAMD_SUCCESS) {
     daliamdFree(dev);
     return nullptr;
   }
@@ -439,11 +443,30 @@ const uint8_t *HuffTableStore::Get(int device_id, const daliamdJpegScan &scan) {
 namespace {
 struct HeaderEntry {
   int64_t size;
+  uint64_t header_hash;   // of the bytes in front of the entropy-coded segment (the headers the entry describes)
   daliamdJpegInfo info;
   int32_t eligible, mcus_x, mcus_y, length_is_upper_bound;
   int64_t ecs_offset, ecs_length;
   std::shared_ptr<const daliamdJpegScan> common;   // everything else of the scan analysis, shared between files
 };
+// The key - source path + stream size - does not change when a file is rewritten in place with another image of the same
+// size (tests and jobs that regenerate a data set in one process); the entry would then describe headers that
+// no longer exist: stale dimensions, tables, segment offset.  A hit therefore also needs the same HEADER BYTES (a 64-bit
+// hash of everything in front of the segment, at most 4 KB: a few hundred bytes, 0.1 us).
+uint64_t HeaderHash(const uint8_t *data, size_t size, int64_t ecs_offset) {
+  size_t n = (size_t)std::max<int64_t>(0, std::min<int64_t>(ecs_offset, 4096));
+  n = std::min(n, size);
+  uint64_t h = 0xcbf29ce484222325ull ^ (uint64_t)n;
+  size_t i = 0;
+  for (; i + 8 <= n; i += 8) {
+    uint64_t w;
+    memcpy(&w, data + i, 8);
+    h = (h ^ w) * 0x100000001b3ull;
+    h ^= h >> 29;
+  }
+  for (; i < n; i++) h = (h ^ data[i]) * 0x100000001b3ull;
+  return h;
+}
 constexpr int kHeaderShards = 32;
 struct HeaderShard {
   std::mutex m;
@@ -464,13 +487,18 @@ daliamdJpegScan CommonPart(const daliamdJpegScan &s) {
 }
 }  // namespace
 
-bool HeaderCache::Find(const std::string &key, int64_t stream_size, daliamdJpegInfo *info, daliamdJpegScan *scan) {
-  if (key.empty() || HeaderCacheCap() <= 0) return false;
+bool HeaderCache::Find(const std::string &key, const uint8_t *data, int64_t stream_size, daliamdJpegInfo *info, daliamdJpegScan *scan) {
+  if (key.empty() || !data || HeaderCacheCap() <= 0) return false;
   HeaderShard &sh = g_header_shards[std::hash<std::string>()(key) % kHeaderShards];
   std::lock_guard<std::mutex> g(sh.m);
   auto it = sh.map.find(key);
   if (it == sh.map.end() || it->second.size != stream_size) return false;
   const HeaderEntry &e = it->second;
+  if (e.ecs_offset > stream_size || HeaderHash(data, (size_t)stream_size, e.ecs_offset) != e.header_hash) {
+    sh.map.erase(it);   // another file under the same name and size: parsed anew (and stored again) by the caller
+    g_header_entries.fetch_sub(1, std::memory_order_relaxed);
+    return false;
+  }
   *info = e.info;
   *scan = *e.common;
   scan->eligible = e.eligible; scan->mcus_x = e.mcus_x; scan->mcus_y = e.mcus_y;
@@ -478,8 +506,16 @@ bool HeaderCache::Find(const std::string &key, int64_t stream_size, daliamdJpegI
   return true;
 }
 
-void HeaderCache::Put(const std::string &key, int64_t stream_size, const daliamdJpegInfo &info, const daliamdJpegScan &scan) {
-  if (key.empty() || g_header_entries.load(std::memory_order_relaxed) >= HeaderCacheCap()) return;
+void HeaderCache::Invalidate(const std::string &key) {
+  if (key.empty()) return;
+  HeaderShard &sh = g_header_shards[std::hash<std::string>()(key) % kHeaderShards];
+  std::lock_guard<std::mutex> g(sh.m);
+  if (sh.map.erase(key)) g_header_entries.fetch_sub(1, std::memory_order_relaxed);
+}
+
+void HeaderCache::Put(const std::string &key, const uint8_t *data, int64_t stream_size, const daliamdJpegInfo &info,
+                      const daliamdJpegScan &scan) {
+  if (key.empty() || !data || g_header_entries.load(std::memory_order_relaxed) >= HeaderCacheCap()) return;
   const daliamdJpegScan common = CommonPart(scan);
   std::shared_ptr<const daliamdJpegScan> shared;
   {
@@ -496,7 +532,7 @@ void HeaderCache::Put(const std::string &key, int64_t stream_size, const daliamd
   std::lock_guard<std::mutex> g(sh.m);
   auto ins = sh.map.emplace(key, HeaderEntry{});
   if (ins.second) g_header_entries.fetch_add(1, std::memory_order_relaxed);
-  ins.first->second = HeaderEntry{stream_size, info, scan.eligible, scan.mcus_x, scan.mcus_y, scan.length_is_upper_bound,
+  ins.first->second = HeaderEntry{stream_size, HeaderHash(data, (size_t)stream_size, scan.ecs_offset), info, scan.eligible, scan.mcus_x, scan.mcus_y, scan.length_is_upper_bound,
                                   scan.ecs_offset, scan.ecs_length, shared};
 }
 

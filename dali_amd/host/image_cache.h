@@ -213,8 +213,11 @@ class HuffTableStore {
 // DALI_AMD_HEADER_CACHE_ENTRIES entries (default 2 M; 0 switches it off), filled until full.
 class HeaderCache {
  public:
-  static bool Find(const std::string &key, int64_t stream_size, daliamdJpegInfo *info, daliamdJpegScan *scan);
-  static void Put(const std::string &key, int64_t stream_size, const daliamdJpegInfo &info, const daliamdJpegScan &scan);
+  // `data`: the stream as it is now - an entry only answers for the header bytes it was made from (a file rewritten in place
+  // under the same name and size is parsed anew)
+  static bool Find(const std::string &key, const uint8_t *data, int64_t stream_size, daliamdJpegInfo *info, daliamdJpegScan *scan);
+  static void Put(const std::string &key, const uint8_t *data, int64_t stream_size, const daliamdJpegInfo &info, const daliamdJpegScan &scan);
+  static void Invalidate(const std::string &key);   // (a decode of the stream failed: whatever the entry says is suspect)
 };
 
 // `skip_cached_images` of the readers: is the sample held by a decoder cache (of either kind) of the device?

@@ -51,8 +51,10 @@ DALI_SCHEMA(decoders__Image)
             "libjpeg-turbo's accurate integer path, i.e. with DALI's CPU backend.\n\nThe output is in HWC layout.")
     .NumInput(1)
     .NumOutput(1)
-    .AddOptionalArg("output_type", "The color space of the output image (RGB or GRAY-as-RGB inputs only).",
-                    ArgValue::Int(DALI_RGB))
+    .AddOptionalArg("output_type", "The color space of the output image: RGB (default), BGR, GRAY (one channel: the luma plane "
+                    "of a YCbCr / grayscale stream, 0.299 R + 0.587 G + 0.114 B otherwise), YCbCr (ITU-R BT.601 with head room) or "
+                    "ANY_DATA (grayscale streams stay one channel, everything else RGB); CMYK / YCCK streams are converted to RGB "
+                    "first.", ArgValue::Int(DALI_RGB))
     .AddOptionalArg("dtype", "Output data type.", ArgValue::Int(DALI_UINT8))
     .AddOptionalArg("adjust_orientation", "Use EXIF orientation metadata to rectify the images.", ArgValue::Bool(true))
     .AddOptionalArg("use_fast_idct", "Ignored: the accurate integer IDCT is always used.", ArgValue::Bool(false))
@@ -308,7 +310,7 @@ class ImageDecoderMixed : public OperatorBase {
             memcpy(static_cast<uint8_t *>(ecs_stage.data()) + ecs_off_[i], data + view.index_offset, (size_t)view.index_bytes);
           return;
         }
-        const bool known = named && !host_huffman_only_ && HeaderCache::Find(in.source_info[i], in.nbytes(i), &infos_[i], &scans_[i]);
+        const bool known = named && !host_huffman_only_ && HeaderCache::Find(in.source_info[i], data, in.nbytes(i), &infos_[i], &scans_[i]);
         // ONE pass over the headers, up to SOS: frame geometry + what the GPU entropy decoder needs.  The scan itself is
         // not walked here - its end (the first marker that is not RSTn) is found by the un-stuffing kernel, which
         // looks at every byte anyway (the memchr walk was two thirds of this operator's host time per sample).
@@ -318,7 +320,7 @@ class ImageDecoderMixed : public OperatorBase {
           if (daliamdJpegParse(data, in.nbytes(i), &infos_[i]) != 0)
             DALI_FAIL("Failed to parse ", src(i), ": ", daliamdHostGetLastErrorMessage());
         } else if (named) {
-          HeaderCache::Put(in.source_info[i], in.nbytes(i), infos_[i], scans_[i]);
+          HeaderCache::Put(in.source_info[i], data, in.nbytes(i), infos_[i], scans_[i]);
         }
         if (infos_[i].num_components == 4) { scans_[i].eligible = 0; return; }  // CMYK / YCCK: the host decodes these (below)
         DALI_ENFORCE(infos_[i].num_components == 1 || infos_[i].num_components == 3, "Failed to decode ", src(i),
@@ -708,20 +710,34 @@ class ImageDecoderMixed : public OperatorBase {
       const int32_t *st = status;
       std::shared_ptr<ImageCache> cache = cache_;
       std::shared_ptr<StreamCache> scache = stream_cache_;
-      std::shared_ptr<TensorList> input = ws.inputs[0];
-      std::vector<int> samples = gpu_samples_;
-      ws.AddCompletionCheck([st, input, samples, cache, scache] {
+      // The names of the decoded samples, kept by THIS operator per ring slot (the check runs when the iteration
+      // is handed out; the input list it used to read belongs to the host stage, which may be rewriting that slot for
+      // iteration it + ring by then - wrong names in the message, the wrong cache entry dropped).  This slot's copy is next
+      // written by this operator's run for iteration it + ring, i.e. after the outputs of `it` have been handed over.  The
+      // strings keep their capacity: no allocation per batch.
+      if (check_names_.size() != (size_t)ring_) {
+        check_names_.resize(ring_);
+        for (auto &p : check_names_) p = std::make_shared<std::vector<std::string>>();
+      }
+      std::shared_ptr<std::vector<std::string>> names_ptr = check_names_[slot];
+      names_ptr->resize(ngpu);
+      for (int j = 0; j < ngpu; j++) {
+        const int i = gpu_samples_[j];
+        if (i < (int)in.source_info.size() && !in.source_info[i].empty()) (*names_ptr)[j].assign(in.source_info[i]);
+        else (*names_ptr)[j] = make_string("sample #", i);
+      }
+      const size_t nsamples = (size_t)ngpu;
+      ws.AddCompletionCheck([st, names_ptr, nsamples, cache, scache] {
         bool any = false;
-        for (size_t j = 0; j < samples.size(); j++) any = any || st[j] != 0;
+        for (size_t j = 0; j < nsamples; j++) any = any || st[j] != 0;
         if (!any) return;
-        std::vector<std::string> names(samples.size());
-        for (size_t j = 0; j < samples.size(); j++)
-          names[j] = samples[j] < (int)input->source_info.size() && !input->source_info[samples[j]].empty()
-                         ? input->source_info[samples[j]] : make_string("sample #", samples[j]);
+        const std::vector<std::string> names(names_ptr->begin(), names_ptr->begin() + nsamples);
         for (size_t j = 0; j < names.size(); j++)
           if (st[j] != 0 && cache) cache->Invalidate(names[j]);  // a slot may hold the broken image
         for (size_t j = 0; j < names.size(); j++)
           if (st[j] != 0 && scache) scache->Invalidate(names[j]);
+        for (size_t j = 0; j < names.size(); j++)
+          if (st[j] != 0) HeaderCache::Invalidate(names[j]);
         for (size_t j = 0; j < names.size(); j++)
           if (st[j] != 0)
             DALI_FAIL("Failed to decode ", names[j], ": corrupt JPEG data: ",
@@ -934,6 +950,7 @@ class ImageDecoderMixed : public OperatorBase {
   std::vector<std::vector<std::vector<uint8_t>>> transcoded_;
   std::vector<daliamdJpegScan> tscans_;
   std::vector<uint8_t> structural_;
+  std::vector<std::shared_ptr<std::vector<std::string>>> check_names_;   // per ring slot: names of the device-decoded samples
   std::vector<int64_t> boxed_;           // per sample: bytes of the index entry it brings (an indexed JPEG container), else 0
   std::vector<std::shared_ptr<const StreamCache::Record>> rres_;   // raster residents of the batch (decoded images kept in the encoded cache)
   std::vector<uint8_t *> rkeep_;                                   // cache slots of the rasters that become resident in this iteration

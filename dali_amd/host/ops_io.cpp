@@ -4,7 +4,9 @@
 //   Loader (shards, shuffle)       dali/operators/reader/loader/loader.h:78-503, loader.cc:78-87
 //   discovery (sorted dirs/files)  dali/operators/reader/loader/discover_files.cc:38-143
 //   ExternalSource                 dali/pipeline/operator/builtin/external_source.{h,cc}
+#if defined(__SSE2__)
 #include <emmintrin.h>
+#endif
 #include <dirent.h>
 #include <fcntl.h>
 #include <fnmatch.h>
@@ -776,6 +778,10 @@ class FileReaderOp : public OperatorBase {
   // pull the destination lines into the cache first - 8.2 against 6.2 GB/s per core for 94 KB copies out of cold memory
   // (tools/microbench note in DESIGN.md section 6c), a quarter of a reader thread's time per image.
   static void CopyOut(char *dst, const char *src, size_t n) {
+#if !defined(__SSE2__)
+    memcpy(dst, src, n);   // (no streaming stores on this host: aarch64 nodes with AMD GPUs exist)
+    return;
+#else
     if (n < 4096) { memcpy(dst, src, n); return; }
     size_t head = (64 - (reinterpret_cast<uintptr_t>(dst) & 63)) & 63;
     memcpy(dst, src, head);
@@ -793,6 +799,7 @@ class FileReaderOp : public OperatorBase {
     }
     _mm_sfence();
     memcpy(dst + 64 * blocks, src + 64 * blocks, n - 64 * blocks);
+#endif
   }
 
   // Page-locked room for one file's resident copy (nullptr: budget spent, or the file is larger than a block).  Blocks of

@@ -197,10 +197,13 @@ class Pipeline:
             raise RuntimeError("There are no scheduled runs; call schedule_run() first")
         try:
             n = self._backend.outputs() if cuda_stream is None else self._backend.outputs_on_stream(int(cuda_stream))
-        finally:
-            # an iteration that failed is consumed all the same (the executor has counted it and goes on with the next one):
-            # the pipeline stays usable, the error belongs to this call only
+        except _b.PipelineError:
+            # an iteration that failed is consumed all the same (the executor has popped it and goes on with the next one):
+            # the pipeline stays usable, the error belongs to this call only.  Anything raised in FRONT of the executor's
+            # call (a bad stream handle, an interrupt) has consumed nothing and does not touch the accounting.
             self._consumed += 1
+            raise
+        self._consumed += 1
         outs = []
         for i in range(n):
             info = self._backend.output_info(i)

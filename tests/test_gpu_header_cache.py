@@ -51,3 +51,26 @@ def test_later_epochs_and_replaced_files(tmp_path):
         (img,) = pipe2.run()
         for i in range(6):
             assert np.array_equal(img[i].as_cpu(), ref2[i]), (it, i)
+
+
+def test_a_file_rewritten_under_the_same_name_AND_size_is_parsed_anew(tmp_path):
+    """the entry is keyed by path + size; a data set regenerated in place can keep both.  An entry only answers
+    for the header bytes it was made from (a hash of everything in front of the entropy-coded segment)."""
+    rng = np.random.default_rng(62)
+    a = encode_jpeg(synth_image(rng, 120, 160), 85, subsampling="4:2:0")
+    b = encode_jpeg(synth_image(rng, 64, 200), 60, subsampling="4:4:4", optimize=True)     # other geometry, other tables
+    size = max(len(a), len(b)) + 16
+    a, b = a + bytes(size - len(a)), b + bytes(size - len(b))      # same size on disk (bytes behind EOI are not scan data)
+    p = tmp_path / "same.jpg"
+    p.write_bytes(a)
+    pipe = _pipe([str(p)], 1)
+    for _ in range(3):
+        (img,) = pipe.run()
+        assert np.array_equal(img[0].as_cpu(), O.jpeg_decode_rgb(a))
+    del pipe
+    p.write_bytes(b)
+    assert os.path.getsize(p) == size
+    pipe2 = _pipe([str(p)], 1)
+    for _ in range(3):
+        (img,) = pipe2.run()
+        assert np.array_equal(img[0].as_cpu(), O.jpeg_decode_rgb(b))
