@@ -411,7 +411,7 @@ def e2e_pipeline(root, batch, device_id, iters=400, threads=None, roi_decode=Fal
             "cpus_busy": round(sum(cpu.values()) / (1e3 * el / iters), 2),
             "shard_id": shard_id, "num_shards": num_shards, "kernels": pipe.executed_kernels(),
             # readers.file handed out its registered file mappings and the device fetched the bytes itself (round 5; the
-            # reader's default: only when the process may use fewer than four CPUs - DESIGN.md section 6c)
+            # reader's default: only when the process may use fewer than four CPUs - DESIGN.md section 4)
             "reader_zero_copy": "gather_encoded" in pipe.executed_kernels(),
             "note": "dali_amd.Pipeline end to end from encoded files in the page cache (file read, header parse, "
                     "H2D of the JPEG bytes on a copy stream, all device stages, fp16 CHW batch on the device)"}
@@ -1512,16 +1512,17 @@ def main():
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "measured_copy_ceiling_GBps": copy_ceiling, "frac_of_measured_ceiling": ach / copy_ceiling,
                          "note": "the entropy decoder's kernels are serial-bit decode loops, not HBM streams (SURVEY.md "
-                                 "8(d)); whole_step prices one pass by the end-to-end formula 6P + 3sP + 6O (+ the JPEG "
-                                 "bytes), i.e. WITHOUT the decoder's internal scratch traffic (the formula of every round: "
-                                 "since round 4 the 1.5 P of component planes written and read back inside it no longer "
-                                 "exist when BlockColorKernel is in launches_timed)",
-                         "whole_step": {"algorithmic_bytes": post_entropy + (stream_bytes or 0),
-                                        "achieved_GBps": (post_entropy + (stream_bytes or 0)) / (step_ms * 1e-3) / 1e9,
-                                        "frac": (post_entropy + (stream_bytes or 0)) / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                        "frac_of_measured_ceiling":
-                                            (post_entropy + (stream_bytes or 0)) / (step_ms * 1e-3) / 1e9 / copy_ceiling,
-                                        "sum_of_per_kernel_algorithmic_bytes": step_bytes},
+                                 "8(d)): the dominant one's fraction of the HBM peak says how far a latency chain is from a "
+                                 "stream, not that bytes are wasted (traffic = counter bytes per launch of the profiled run)",
+                         # whole_step (round 6): the algorithmic bytes of the work the step DOES - the sum of
+                         # its kernels' figures, i.e. with the window decode only the blocks / pixels the crop keeps - over the
+                         # step's duration.  The SURVEY 8(d) formula 6P + 3sP + 6O prices whole images and stays next to it.
+                         "whole_step": {"algorithmic_bytes": step_bytes,
+                                        "achieved_GBps": step_bytes / (step_ms * 1e-3) / 1e9,
+                                        "frac": step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        "frac_of_measured_ceiling": step_bytes / (step_ms * 1e-3) / 1e9 / copy_ceiling,
+                                        "survey_formula_bytes": post_entropy + (stream_bytes or 0),
+                                        "survey_formula_frac": (post_entropy + (stream_bytes or 0)) / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                          "per_kernel": {k: {"algorithmic_bytes": v[0], "avg_ms": v[1],
                                             "achieved_GBps": v[0] / (v[1] * 1e-3) / 1e9} for k, v in kern.items()}},
             "ceilings": {

@@ -656,7 +656,7 @@ def decode_jpeg_batch(encoded, device="cuda", num_threads=None, out_pitch_align=
     huffman="gpu": entropy decoding on the device for baseline single-scan streams (host for the rest);
     huffman="host": header parse + Huffman on the host thread pool into pinned memory (the hybrid path).
     fuse_color: 4:2:0 / 4:4:4 / grayscale streams leave the GPU entropy decoder as RGB (daliamdJpegHuffDesc.rgb; same bits,
-    fewer bytes moved, measured slower on MI355X - see DESIGN.md section 9 - hence opt-in).
+    fewer bytes moved, measured slower on MI355X - see HISTORY.md section 9 - hence opt-in).
     Dequantisation, IDCT, upsampling and colour conversion always run on the device."""
     device = torch.device(device)
     plan = JpegBatchPlan(encoded, out_pitch_align, rois=rois, exact_scan=exact_scan)

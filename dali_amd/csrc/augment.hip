@@ -293,7 +293,7 @@ constexpr int kBlurMaxLds = 60 * 1024;
 constexpr int kBlurMfmaFlag = 1 << 30;   // in the `lds_bytes` Setup hands to Run: the table is tiled for GaussianBlurMfmaKernel
 constexpr int kBlurMfmaShortFlag = 1 << 29;   // ... and every window of the table has at most 9 taps (6 steps instead of 9)
 // DALI_AMD_BLUR_MFMA: 1 = the matrix-core variant where it applies (<= 1 LSB from the CPU order of roundings), 0 = the VALU
-// kernel (bit-exact against it).  Default: see the measurement in DESIGN.md.
+// kernel (bit-exact against it).  Default: see the measurement in HISTORY.md section 6c.
 // (read at every Setup: a process can run both - the tests that hold the blur to the oracle bit for bit switch it off)
 inline bool BlurMfmaEnabled() {
   const char *e = getenv("DALI_AMD_BLUR_MFMA");

@@ -114,7 +114,7 @@ class ImageDecoderMixed : public OperatorBase {
     // DALI_AMD_FUSE_COLOR=1: upsampling + colour conversion inside the entropy decoder's block kernel (no component planes,
     // no colour launch; bit-identical).  Off by default: measured on MI355X it moves 25 % fewer bytes and is 10 % SLOWER
     // (397 000 against 443 000 images/s, gpurun_out/r04c3) - the step is bound by instruction issue, not by HBM, the fused
-    // kernel issues the same colour arithmetic and holds 62 KB of LDS + 191 registers per workgroup.
+    // kernel issues the same colour arithmetic and holds 62 KB of LDS + 191 registers per workgroup (HISTORY.md section 9).
     if (const char *env = getenv("DALI_AMD_FUSE_COLOR")) fuse_color_ = atoi(env) != 0;
     ring_ = (int)spec.GetInt("gpu_prefetch_queue_depth") + 1;
     for (int i = 0; i < ring_; i++) {

@@ -776,7 +776,7 @@ class FileReaderOp : public OperatorBase {
   // A file's bytes from its mapping into the page-locked block the host->device transfer reads.  Nothing on the host looks
   // at most of these bytes again (the decoder parses the headers, the copy engine takes the rest): streaming stores do not
   // pull the destination lines into the cache first - 8.2 against 6.2 GB/s per core for 94 KB copies out of cold memory
-  // (tools/microbench note in DESIGN.md section 6c), a quarter of a reader thread's time per image.
+  // (tools/microbench note in HISTORY.md section 6c), a quarter of a reader thread's time per image.
   static void CopyOut(char *dst, const char *src, size_t n) {
 #if !defined(__SSE2__)
     memcpy(dst, src, n);   // (no streaming stores on this host: aarch64 nodes with AMD GPUs exist)

@@ -142,7 +142,7 @@ void Pipeline::Build(const std::vector<std::pair<std::string, std::string>> &out
     // ring size and on every other stream of the process (prefetch_queue_depth 4 / 5 / 6: 370 / 450 / 413 k images/s
     // on the resident hot path; one unrelated stream created first: 386 / 390 / 400).  Three streams - the batch
     // whose positions are being decoded, the one in its throughput-bound kernels, the one finishing - map to three
-    // hardware queues whatever the depth: 431 / 437 k at depth 4 / 5 (gpurun_out/r03a[d-g]_env).
+    // hardware queues whatever the depth: 431 / 437 k at depth 4 / 5 (gpurun_out/r03a[d-g]_env, HISTORY.md section 6).
     // DALI_AMD_PIPELINE_STREAMS overrides the count (0 = one per ring slot).
     int distinct = std::min(ring_, kComputeStreams);
     if (const char *e = getenv("DALI_AMD_PIPELINE_STREAMS")) {

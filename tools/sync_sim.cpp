@@ -178,7 +178,7 @@ int main(int argc, char **argv) {
     Image im;
     if (!Load(fn, im)) { fprintf(stderr, "skip %s\n", fn.c_str()); continue; }
     if (getenv("SIM_PHASEMAP")) {
-      // Model of the phase-map scheme: round A decodes every slice from its first bit with z = 0 for
+      // Model of the phase-map scheme (HISTORY.md section 9): round A decodes every slice from its first bit with z = 0 for
       // EVERY block index inside the MCU; round B decodes slice k from every distinct state slice k - 1's candidates
       // reached.  Slice k is settled after the two rounds iff the TRUE state at its start is among those states; the
       // others need one more decode each, one after the other along a run of unsettled slices.
