@@ -429,7 +429,11 @@ const uint8_t *HuffTableStore::Get(int device_id, const daliamdJpegScan &scan) {
   if (daliamdMalloc(&dev, bytes) != DALIAMD_SUCCESS) return nullptr;
   // (on a stream of its own, never the legacy NULL stream: in a training process that one is the framework's default stream,
   // and waiting for it means waiting for everything the training loop has queued - ADVICE r05)
-  static daliamdStream_t upload_stream = [] { daliamdStream_t s = nullptr; daliamdStreamCreate(&s, 1); return s; }();
+  // (one per device: the caller - a pipeline's device-stage thread - has its device current; a stream belongs to the device
+  // it was made on)
+  static daliamdStream_t upload_streams[64] = {};
+  daliamdStream_t &upload_stream = upload_streams[(unsigned)device_id % 64];
+  if (!upload_stream) daliamdStreamCreate(&upload_stream, 1);
   if (!upload_stream || daliamdMemcpyH2DAsync(dev, host.data(), bytes, upload_stream) != DALIAMD_SUCCESS ||
       daliamdStreamSynchronize(upload_stream) != DALIAMD_SUCCESS) {
     daliamdFree(dev);
