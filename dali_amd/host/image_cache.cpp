@@ -392,7 +392,8 @@ bool HuffTableStore::SameTables(const daliamdJpegScan &a, const daliamdJpegScan 
 const uint8_t *HuffTableStore::Get(int device_id, const daliamdJpegScan &scan) {
   static std::mutex m;
   static std::vector<Set> sets;
-  if (getenv("DALI_AMD_NO_HOST_TABLES") && atoi(getenv("DALI_AMD_NO_HOST_TABLES"))) return nullptr;
+  static const bool off = getenv("DALI_AMD_NO_HOST_TABLES") && atoi(getenv("DALI_AMD_NO_HOST_TABLES"));   // (read once: ADVICE r05)
+  if (off) return nullptr;
   std::lock_guard<std::mutex> g(m);
   Set *hit = nullptr;
   for (auto &s : sets)
