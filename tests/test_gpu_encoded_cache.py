@@ -225,3 +225,29 @@ def test_cache_too_small_keeps_what_fits_and_decodes_the_rest(files, decoded):
             assert np.array_equal(img[i].as_cpu(), ref[i]), (it, i)
     sizes = [e.at(i).size for i in range(6)]
     assert 0 < sum(s == 0 for s in sizes) < 6, sizes          # some resident, some read every epoch
+
+
+def test_flat_streams_are_kept_with_their_index_whatever_the_cache_type(tmp_path):
+    """Content that compresses to a few bits per block (large flat areas) never re-synchronises inside a 256-byte slice: the
+    position pass of the entropy decoder then relaxes lane by lane.  Such a stream becomes resident WITH its index under
+    cache_type="encoded" too and is decoded from it from the second epoch on (an ordinary stream next to it is not)."""
+    if CACHE_TYPE[0] != "encoded":
+        pytest.skip("the other cache type indexes everything")
+    rng = np.random.default_rng(17)
+    flat = np.full((480, 640, 3), (250, 250, 250), np.uint8)
+    flat[200:260, 300:380] = synth_image(rng, 60, 80)                  # a small textured patch in a blank frame
+    a = encode_jpeg(flat, 85, subsampling="4:2:0")
+    b = encode_jpeg(synth_image(rng, 240, 320), 85, subsampling="4:2:0")
+    assert len(a) * 8 < 64 * (30 * 40 * 6)                             # fewer than 64 bits per block
+    for name, data in (("flat.jpg", a), ("busy.jpg", b)):
+        (tmp_path / name).write_bytes(data)
+    ref = {"flat.jpg": O.jpeg_decode_rgb(a), "busy.jpg": O.jpeg_decode_rgb(b)}
+    for name, indexed in (("flat.jpg", True), ("busy.jpg", False)):
+        pipe = _pipe([str(tmp_path / name)], 1, outputs="both")
+        for it in range(6):
+            img, enc = pipe.run()
+            assert np.array_equal(img[0].as_cpu(), ref[name]), (name, it)
+        assert enc.at(0).size == 0
+        assert ("jpeg_huffman_indexed" in pipe.executed_kernels()) == indexed, name
+        del pipe
+        gc.collect()
