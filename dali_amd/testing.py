@@ -70,7 +70,7 @@ def synth_jpeg_batch(rng, n, sizes=None, gray_frac=0.05, image_kw=None, **save_k
     return out
 
 
-DATASET_VARIANTS = ("baseline", "distinct_dht", "mixed", "large")
+DATASET_VARIANTS = ("baseline", "distinct_dht", "mixed", "large", "flat")
 LARGE_IMAGE_HW = (3000, 4000)     # 12 MP
 
 
@@ -81,7 +81,8 @@ def synth_dataset_image(index, seed=1234, variant="baseline"):
       baseline      the SURVEY 8(d) mix, encoder's default tables: ONE set of Huffman tables for the whole data set
       distinct_dht  the same images saved with optimize=True: every file brings its own four Huffman tables
       mixed         5 % progressive and 2 % CMYK (Adobe, four components) among the baseline streams (+ its 5 % grayscale)
-      large         2 % 12-megapixel images (3000 x 4000) among the baseline sizes"""
+      large         2 % 12-megapixel images (3000 x 4000) among the baseline sizes
+      flat          2 % 12-megapixel frames that are mostly saturated (the position pass's worst case; tools only)"""
     rng = np.random.default_rng([seed, int(index)])
     if variant == "baseline":
         return synth_jpeg_batch(rng, 1)[0]
@@ -104,6 +105,13 @@ def synth_dataset_image(index, seed=1234, variant="baseline"):
             # blocks per 256 bytes of stream, which no camera produces)
             return synth_jpeg_batch(rng, 1, sizes=[LARGE_IMAGE_HW], gray_frac=0.0,
                                     image_kw=dict(gradient=0.2 * 500 / max(LARGE_IMAGE_HW)))[0]
+        return synth_jpeg_batch(rng, 1)[0]
+    if variant == "flat":
+        # 2 % 12-megapixel frames whose illumination gradients keep the per-pixel slope of the small images: most of the frame
+        # saturates to black / white - 0.5 bits per pixel, hundreds of empty blocks per 256 bytes of stream.  Not what a camera
+        # produces; what a scan, a screenshot or a product shot on a blank background looks like to the entropy decoder.
+        if pick < 0.02:
+            return synth_jpeg_batch(rng, 1, sizes=[LARGE_IMAGE_HW], gray_frac=0.0)[0]
         return synth_jpeg_batch(rng, 1)[0]
     raise ValueError(f"unknown data set variant {variant!r}")
 
