@@ -923,6 +923,72 @@ __global__ __launch_bounds__(256) void ResampleGenericKernel(const daliamdResamp
   const int ex = d.ext[0] - 1, ey = d.ext[1] - 1;
   const bool vfirst = d.first_axis == 1;
   const int tmp_w = d.tmp_w;
+  if (pass == 0 && d.generic == 2) {
+    // u8 samples (extreme down-scaling): the first pass is where the work is - 25 taps for every element of an intermediate
+    // as wide (or as tall) as the source region.  A thread takes FOUR neighbouring bytes of a source row per tap (vertical
+    // pass first) or the C channel bytes of one source pixel (horizontal pass first) out of the aligned dword pair that
+    // holds them - one address, two loads, one funnel shift instead of four byte loads with their address arithmetic -,
+    // the taps in increasing k, multiply and add rounded separately: the bits of the element-by-element form below.
+    // The launch is sized for one thread per element; the threads behind the last group leave at once.
+    const size_t extent = (size_t)d.in_h * (size_t)d.in_pitch;           // bytes of the source buffer the descriptor vouches for
+    GBytes *src = (GBytes *)d.in;
+    auto four_bytes = [&](size_t off) -> uint32_t {                         // bytes off .. off + 3 (little endian)
+      if (off + 8 <= extent) {
+        const size_t a = off & ~(size_t)3;
+        const uint32_t w0 = *(const GU32 *)(src + a), w1 = *(const GU32 *)(src + a + 4);
+        return (uint32_t)((((uint64_t)w1 << 32) | w0) >> ((uint32_t)(off & 3) * 8u));   // (one v_alignbit_b32)
+      }
+      uint32_t v = 0;
+      for (int b = 0; b < 4; b++)
+        if (off + b < extent) v |= (uint32_t)src[off + b] << (8 * b);
+      return v;
+    };
+    if (vfirst) {
+      const int row_elems = tmp_w * C, ne4 = (row_elems + 3) >> 2;
+      if (local >= d.tmp_h * ne4) return;
+      const int y = local / ne4, e0 = (local - y * ne4) * 4;
+      const size_t col = (size_t)d.lo[0] * C + e0;
+      float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+      const int first = yi[y];
+      GF32 *co = yc + (size_t)y * sup_y;
+      for (int k = 0; k < sup_y; k++) {
+        const int sy = ClampI(first + k, 0, ey) + d.lo[1];
+        const uint32_t v = four_bytes((size_t)sy * d.in_pitch + col);
+        const float w = co[k];
+        a0 += (float)(v & 255u) * w;
+        a1 += (float)((v >> 8) & 255u) * w;
+        a2 += (float)((v >> 16) & 255u) * w;
+        a3 += (float)(v >> 24) * w;
+      }
+      GF32 *o = tmp + (size_t)y * row_elems + e0;
+      o[0] = a0;
+      if (e0 + 1 < row_elems) o[1] = a1;
+      if (e0 + 2 < row_elems) o[2] = a2;
+      if (e0 + 3 < row_elems) o[3] = a3;
+    } else {
+      if (local >= d.tmp_h * tmp_w) return;
+      const int y = local / tmp_w, x = local - y * tmp_w;
+      const size_t row_off = (size_t)(d.lo[1] + y) * d.in_pitch;
+      float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+      const int first = xi[x];
+      GF32 *co = xc + (size_t)x * sup_x;
+      for (int k = 0; k < sup_x; k++) {
+        const int sx = ClampI(first + k, 0, ex) + d.lo[0];
+        const uint32_t v = four_bytes(row_off + (size_t)sx * C);
+        const float w = co[k];
+        a0 += w * (float)(v & 255u);
+        a1 += w * (float)((v >> 8) & 255u);
+        a2 += w * (float)((v >> 16) & 255u);
+        a3 += w * (float)(v >> 24);
+      }
+      GF32 *o = tmp + ((size_t)y * tmp_w + x) * C;
+      o[0] = a0;
+      if (C > 1) o[1] = a1;
+      if (C > 2) o[2] = a2;
+      if (C > 3) o[3] = a3;
+    }
+    return;
+  }
   if (pass == 0) {
     const int c = local % C, x = (local / C) % tmp_w, y = local / (C * tmp_w);
     float acc = 0;
