@@ -199,7 +199,7 @@ _KERNEL_SYMBOLS = [
 ]
 
 _HOST_SYMBOLS = [
-    "daliamdHostGetLastErrorMessage", "daliamdJpegParse", "daliamdJpegDecodeCoefficients", "daliamdJpegEncodeBaselineScan", "daliamdJpegIndexedIs", "daliamdJpegIndexedParse", "daliamdJpegIndexedBuild", "daliamdJpegDecodeRgbHost", "daliamdJpegOutputChannels", "daliamdJpegDecodeHost", "daliamdConvertRgbRows",
+    "daliamdHostGetLastErrorMessage", "daliamdJpegParse", "daliamdJpegDecodeCoefficients", "daliamdJpegEncodeBaselineScan", "daliamdJpegIndexedIs", "daliamdJpegIndexedParse", "daliamdJpegIndexedValidate", "daliamdJpegIndexedBuild", "daliamdJpegDecodeRgbHost", "daliamdJpegOutputChannels", "daliamdJpegDecodeHost", "daliamdConvertRgbRows",
     "daliamdJpegAnalyzeScan", "daliamdJpegAnalyzeHeader",
     "daliamdRandomCropBatch", "daliamdCoinFlipBatch", "daliamdPhiloxAdvanceSequence",
     "daliamdPhiloxStateToString", "daliamdPhiloxStateFromString", "daliamdPhiloxGenerate",

@@ -1316,6 +1316,7 @@ __host__ __device__ inline int McusPerWg(int bpm) {
 }
 struct BlockGeom {
   int32_t bpm, mcus_x, total_mcus, last_ordinal, use_rect, total_starts, fused, n0;
+  uint32_t total_bits;   // of the clean stream
   int32_t interval_blocks;  // blocks per restart interval (0: none)
   uint8_t klast[4];   // per component: its last block inside the MCU
   uint8_t klist[12];  // block indices of the MCU, the ones with AC table 0 first
@@ -1415,6 +1416,7 @@ __global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHu
     G.roi_x0 = rm[0]; G.roi_y0 = rm[1]; G.roi_cols = roi ? rm[2] : 0; G.roi_mcus = rm[2] * rm[3];
     // (a resident stream with its index: the header of the index knows, and the per-block records hold absolute levels)
     G.total_starts = d.index ? ((const GlobalI32 *)d.index)[1] : ((const GlobalI32 *)d.scratch)[2];
+    G.total_bits = (uint32_t)(d.index ? ((const GlobalI32 *)d.index)[0] : ((const GlobalI32 *)d.scratch)[0]) * 8u;
     G.fused = kColor || d.plane[d.comp_of_block[0]] != nullptr;
     G.interval_blocks = d.index ? 0 : d.restart_interval * d.blocks_per_mcu;
     for (int k = 0; k < d.blocks_per_mcu; k++) G.klast[d.comp_of_block[k]] = (uint8_t)k;
@@ -1529,7 +1531,9 @@ __global__ __launch_bounds__(kBlockThreads) void BlockKernel(const daliamdJpegHu
     p.bx = bx; p.by = by;
     if (needed && indexed) {   // IndexedSyncKernel's record: position and absolute level (mod 2^16) in one load
       const u32x2p pd = blk_pd[ordinal];
-      p.pos = pd.x;
+      // (an index entry may come from a FILE - an indexed container - and say anything: a block its slices never reached
+      // keeps whatever the scratch held; no position leaves the stream)
+      p.pos = min(pd.x, G.total_bits);
       p.dc = (int)pd.y;
     } else if (needed) {
       p.pos = blk_pos[ordinal];

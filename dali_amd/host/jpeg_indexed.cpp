@@ -61,6 +61,44 @@ int daliamdJpegIndexedParse(const uint8_t *data, size_t size, daliamdJpegIndexed
   return 0;
 }
 
+// The entry of a container comes from a FILE: before the device decodes from it, what can be checked without decoding is -
+// a complete stream's worth of block starts, slice ordinals that start at zero, never decrease and stay inside the stream,
+// block indices inside the MCU.  (What cannot: whether every slice really holds the blocks its ordinals promise.  The kernels
+// do not trust that either - positions are clamped to the stream, blocks are only written inside the frame - so a forged entry
+// yields wrong pixels or a decode error, never an access outside the decode's buffers: tools/fuzz_gpu_decoder.py FUZZ_CONTAINERS.)
+int daliamdJpegIndexedValidate(const uint8_t *data, size_t size, const daliamdJpegIndexedView *view, int blocks_per_mcu,
+                               int total_blocks) {
+  using namespace daliamd_host;
+  if (!data || !view || blocks_per_mcu < 1 || total_blocks < 0) return Fail("daliamdJpegIndexedValidate: invalid argument");
+  if ((size_t)(view->index_offset + view->index_bytes) > size) return Fail("corrupt indexed JPEG container (entry outside the file)");
+  const uint8_t *entry = data + view->index_offset;
+  int32_t ih[3];
+  memcpy(ih, entry, sizeof(ih));
+  const int32_t clean_len = ih[0], total_starts = ih[1], num_slices = ih[2];
+  if (clean_len < 0 || clean_len > view->ecs_len || num_slices != (clean_len + 255) / 256 ||
+      total_starts < total_blocks + 1 || total_starts > total_blocks + 128)
+    return Fail("corrupt indexed JPEG container (%d clean bytes, %d block starts for a frame of %d blocks)", clean_len, total_starts,
+                total_blocks);
+  const size_t entries_off = 64 + (((size_t)view->ecs_len + 256 + 63) & ~(size_t)63);
+  const int cap = (view->ecs_len + 255) / 256;
+  if (entries_off + 12 * (size_t)(cap + 1) > (size_t)view->index_bytes || num_slices > cap)
+    return Fail("corrupt indexed JPEG container (slice entries outside the index)");
+  uint32_t prev = 0;
+  for (int s2 = 0; s2 <= cap; s2++) {
+    uint32_t w[3];
+    memcpy(w, entry + entries_off + 12 * (size_t)s2, 12);
+    const uint32_t ordinal = w[0] & ((1u << 26) - 1u), c = (w[1] >> 12) & 15u, pos = w[1] & 4095u;
+    if (s2 >= num_slices) {
+      if (ordinal != (uint32_t)total_starts) return Fail("corrupt indexed JPEG container (slice %d behind the stream)", s2);
+      continue;
+    }
+    if (ordinal < prev || ordinal > (uint32_t)total_starts || c >= (uint32_t)blocks_per_mcu || (s2 == 0 && (ordinal != 0 || pos != 0 || c != 0)))
+      return Fail("corrupt indexed JPEG container (slice %d: ordinal %u after %u, block %u of %d)", s2, ordinal, prev, c, blocks_per_mcu);
+    prev = ordinal;
+  }
+  return 0;
+}
+
 int daliamdJpegIndexedBuild(const uint8_t *jpeg, size_t size, uint8_t *out, size_t capacity, size_t *length) {
   using namespace daliamd_host;
   if (!jpeg || !length) return Fail("daliamdJpegIndexedBuild: NULL argument");

@@ -302,6 +302,9 @@ class ImageDecoderMixed : public OperatorBase {
           DALI_ENFORCE(scans_[i].eligible && scans_[i].restart_interval == 0 && !host_huffman_only_, "Failed to decode ", src(i),
                        ": an indexed JPEG container holds a stream for the GPU entropy decoder"
                        " (not usable with device=\"cpu\" semantics / hybrid_huffman_threshold forcing the host decoder)");
+          if (daliamdJpegIndexedValidate(data, in.nbytes(i), &view, scans_[i].blocks_per_mcu,
+                                         scans_[i].mcus_x * scans_[i].mcus_y * scans_[i].blocks_per_mcu) != 0)
+            DALI_FAIL("Failed to decode ", src(i), ": ", daliamdHostGetLastErrorMessage());
           scans_[i].ecs_offset = view.index_offset;
           scans_[i].ecs_length = view.ecs_len;
           scans_[i].length_is_upper_bound = 0;

@@ -121,6 +121,10 @@ typedef struct {
 } daliamdJpegIndexedView;
 DALIAMD_HOST_API int daliamdJpegIndexedIs(const uint8_t *data, size_t size);
 DALIAMD_HOST_API int daliamdJpegIndexedParse(const uint8_t *data, size_t size, daliamdJpegIndexedView *view);
+/* What can be checked about a container's index entry without decoding (see jpeg_indexed.cpp): called by the mixed decoders with
+ * the MCU structure the container's own headers announce, before anything is uploaded. */
+DALIAMD_HOST_API int daliamdJpegIndexedValidate(const uint8_t *data, size_t size, const daliamdJpegIndexedView *view,
+                                               int blocks_per_mcu, int total_blocks);
 DALIAMD_HOST_API int daliamdJpegIndexedBuild(const uint8_t *jpeg, size_t size, uint8_t *out, size_t capacity, size_t *length);
 
 /* Writes decoded coefficient arrays (the layout of daliamdJpegDecodeCoefficients) out again as ONE sequential, interleaved

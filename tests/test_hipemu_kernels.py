@@ -133,7 +133,9 @@ def test_device_decoder_survives_damaged_streams():
     leaves its buffers, none loops (on the device: silent corruption of HBM, or a hung GPU)."""
     env = dict(os.environ)
     env.pop("DALI_AMD_HIPEMU", None)
-    runs = [("250", "5", {})]
+    # FUZZ_CONTAINERS (round 6): indexed JPEG containers with damage anywhere - their index entries come from a FILE and reach
+    # the device as they are
+    runs = [("250", "5", {}), ("120", "9", {"FUZZ_CONTAINERS": "1"})]
     if os.environ.get("DALI_AMD_HIPEMU_FULL"):
         runs += [("1500", "7", {}), ("150", "3", {"FUZZ_BIG": "1"})]
     for iterations, seed, extra in runs:

@@ -89,6 +89,58 @@ def mutate(rng, data, others):
     return bytes(d)
 
 
+def containers(base):
+    """Indexed JPEG containers (tools/jpeg2idx.py) of the seeds that can have one."""
+    import ctypes as C
+    from dali_amd import _capi as capi
+    host = capi.host()
+    out = []
+    for e in base:
+        data = np.frombuffer(e, np.uint8)
+        n = C.c_size_t(0)
+        if host.daliamdJpegIndexedBuild(data.ctypes.data_as(C.c_void_p), C.c_size_t(data.size), None, C.c_size_t(0), C.byref(n)) != 0:
+            continue
+        box = np.zeros(n.value, np.uint8)
+        if host.daliamdJpegIndexedBuild(data.ctypes.data_as(C.c_void_p), C.c_size_t(data.size), box.ctypes.data_as(C.c_void_p),
+                                        C.c_size_t(box.size), C.byref(n)) == 0:
+            out.append(box.tobytes())
+    return out
+
+
+def mutate_container(rng, box):
+    """Damage anywhere in a container: its own header, the JPEG headers it carries, the clean stream, the slice entries (ordinals,
+    entry positions, block indices, DC predictors), the entry's header (lengths, block-start count); truncation."""
+    d = bytearray(box)
+    hlen = int.from_bytes(d[8:12], "little")
+    idx = 64 + ((hlen + 63) & ~63)
+    ecs_len = int.from_bytes(d[12:16], "little")
+    entries = idx + 64 + ((ecs_len + 256 + 63) & ~63)
+    kind = rng.integers(0, 7)
+    if kind == 0:     # bit flips in the slice entries
+        for _ in range(rng.integers(1, 12)):
+            i = rng.integers(min(entries, len(d) - 1), len(d)); d[i] ^= 1 << rng.integers(0, 8)
+    elif kind == 1:   # the entry's header: clean length / block starts / slices
+        i = idx + 4 * int(rng.integers(0, 3))
+        d[i:i + 4] = int(rng.integers(0, 1 << 31)).to_bytes(4, "little") if rng.random() < 0.5 else \
+            int(max(0, int.from_bytes(d[i:i + 4], "little") + int(rng.integers(-3, 4)))).to_bytes(4, "little")
+    elif kind == 2:   # the clean stream
+        for _ in range(rng.integers(1, 10)):
+            i = rng.integers(idx + 64, max(idx + 65, entries)); d[min(i, len(d) - 1)] ^= 1 << rng.integers(0, 8)
+    elif kind == 3:   # ordinals shifted / entries overwritten wholesale
+        i = entries + 12 * int(rng.integers(0, max(1, (len(d) - entries) // 12)))
+        n = min(len(d) - i, 12 * int(rng.integers(1, 6)))
+        d[i:i + n] = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+    elif kind == 4:   # the container's own header or the JPEG headers inside it
+        i = rng.integers(0, idx); d[i] ^= 1 << rng.integers(0, 8)
+    elif kind == 5:
+        del d[rng.integers(16, len(d)):]
+    else:             # entries of another position of the same file (plausible but wrong)
+        a = entries + 12 * int(rng.integers(0, max(1, (len(d) - entries) // 12 - 2)))
+        b = entries + 12 * int(rng.integers(0, max(1, (len(d) - entries) // 12 - 2)))
+        d[a:a + 12], d[b:b + 12] = d[b:b + 12], d[a:a + 12]
+    return bytes(d)
+
+
 def main():
     iterations = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -126,7 +178,28 @@ def main():
     def hung(*_):
         raise SystemExit(f"fuzz_gpu_decoder: a decode did not come back within 120 s (iteration {it}, seed {seed})")
     signal.signal(signal.SIGALRM, hung)
+    boxes = containers(base) if os.environ.get("FUZZ_CONTAINERS") == "1" else []
+    if os.environ.get("FUZZ_CONTAINERS") == "1":
+        assert len(boxes) >= 6
+        through_pipeline(boxes[:3])     # the sound containers decode
     for it in range(iterations):
+        if boxes:
+            # FUZZ_CONTAINERS=1: indexed containers with damage anywhere - the index entries reach the DEVICE as they are, so a
+            # forged entry must end in wrong pixels or an error, never outside the decode's buffers
+            batch = [mutate_container(rng, boxes[rng.integers(0, len(boxes))]) for _ in range(int(rng.integers(1, 4)))]
+            if rng.random() < 0.3:
+                batch.insert(int(rng.integers(0, len(batch) + 1)), boxes[rng.integers(0, len(boxes))])
+            signal.alarm(120)
+            try:
+                through_pipeline(batch)
+                ok += 1
+            except (DaliAmdError, RuntimeError):
+                rejected += 1
+            finally:
+                signal.alarm(0)
+            if (it + 1) % 50 == 0:
+                print(f"{it + 1}: {ok} decoded, {rejected} rejected", flush=True)
+            continue
         batch = [mutate(rng, base[rng.integers(0, len(base))], base) for _ in range(int(rng.integers(1, 4)))]
         if rng.random() < 0.3:   # a sound stream next to the damaged ones
             batch.insert(int(rng.integers(0, len(batch) + 1)), base[rng.integers(0, len(base))])
