@@ -1347,6 +1347,10 @@ def main():
         algo["SeamKernel"] = 0.0
         algo["PrepareKernel"] = stream_bytes   # (round 5: the code tables come from the host, built once per DHT set - the launch only counts the tiles' kept bytes)
         algo["IndexedSyncKernel"] = stream_bytes + 8 * coef_elems_mean / 64   # stream in (the needed slices at most), 8 B per block out
+        if args.cache_type == "encoded":
+            # (under cache_type="encoded" only FLAT streams - fewer than 64 bits per block, 1 of the 1 024 bench files, 0.1 % of the
+            # bytes - are kept with their index and take this kernel: its bytes are not the batch's)
+            algo["IndexedSyncKernel"] = 0.0
         algo["ResampleKernel"] = r["resample_bytes"]
         algo["ResampleTablesKernel"] = 0.0
         if r["roi"]:
