@@ -126,7 +126,7 @@ def measured_copy_ceiling(device, mib=1024, iters=10):
     return 2.0 * (mib << 20) * iters / (a.elapsed_time(b) * 1e-3) / 1e9
 
 
-def measured_h2d_ceiling(device, mib=256, iters=6):
+def measured_h2d_ceiling(device, mib=256, iters=4):
     """Host->device rate of this box (GB/s): pinned source, one stream, 256 MiB copies - the ceiling of anything that has
     to cross the bus once per step."""
     import torch
@@ -134,13 +134,15 @@ def measured_h2d_ceiling(device, mib=256, iters=6):
     dst = torch.empty(mib * 2**20, dtype=torch.uint8, device=device)
     dst.copy_(src, non_blocking=True)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        dst.copy_(src, non_blocking=True)
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
+    best = 0.0
+    for _ in range(3):      # the best of three trains (one disturbed train made a leg look faster than the bus: frac 1.3)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        best = max(best, iters * mib * 2**20 / (time.perf_counter() - t0) / 1e9)
     del src, dst
-    return iters * mib * 2**20 / el / 1e9
+    return best
 
 
 def make_dataset(first_index, count, workers=0, variant="baseline"):
