@@ -179,6 +179,9 @@ class ImageDecoderMixed : public OperatorBase {
       trace_s_[phase] += std::chrono::duration<double>(t - t_last).count();
       t_last = t;
     };
+    // DALI_AMD_TRACE_SKIP=N: the first N runs (set-up epochs: file reads, first decodes, buffer growth) are not counted
+    static const int64_t trace_skip = getenv("DALI_AMD_TRACE_SKIP") ? atoll(getenv("DALI_AMD_TRACE_SKIP")) : 0;
+    if (trace_ && ++trace_seen_ == trace_skip) { for (double &t : trace_s_) t = 0; trace_runs_ = 0; }
     trace_runs_++;
     infos_.resize(n);
     scans_.resize(n);
@@ -935,7 +938,7 @@ class ImageDecoderMixed : public OperatorBase {
   std::vector<daliamdJpegRoiPlan> plans_;
   bool trace_ = getenv("DALI_AMD_TRACE") && atoi(getenv("DALI_AMD_TRACE")) != 0;
   double trace_s_[7] = {0, 0, 0, 0, 0, 0, 0};
-  int64_t trace_runs_ = 0;
+  int64_t trace_runs_ = 0, trace_seen_ = 0;
   std::shared_ptr<ImageCache> cache_;
   std::shared_ptr<StreamCache> stream_cache_;
   bool index_streams_ = false;                                     // cache_type="indexed"
