@@ -32,7 +32,8 @@ GROUPS = {
     "augment_audio": ["tests/test_gpu_augment.py", "tests/test_gpu_audio.py", "tests/test_output_types.py",
                       "tests/test_gpu_formats.py"],
     "pipelines": ["tests/test_gpu_config1.py", "tests/test_gpu_roi_resize.py", "tests/test_gpu_pipeline.py",
-                  "tests/test_gpu_decoder_cache.py", "tests/test_gpu_encoded_cache.py", "tests/test_gpu_roi_fusion.py"],
+                  "tests/test_gpu_decoder_cache.py", "tests/test_gpu_encoded_cache.py", "tests/test_gpu_roi_fusion.py",
+                  "tests/test_gpu_jpeg_indexed_files.py", "tests/test_gpu_reader_zero_copy.py"],   # (round 6)
 }
 if os.environ.get("DALI_AMD_HIPEMU_FULL"):
     GROUPS["headline"] = ["tests/test_gpu_headline.py"]   # b256 x 3 epochs + b512 through the bench's graph: 85 s
