@@ -251,3 +251,40 @@ def test_flat_streams_are_kept_with_their_index_whatever_the_cache_type(tmp_path
         assert ("jpeg_huffman_indexed" in pipe.executed_kernels()) == indexed, name
         del pipe
         gc.collect()
+
+
+def test_a_full_cache_leaves_progressive_and_raster_samples_as_host_decodes(tmp_path):
+    """The re-encoded progressive stream and the decoded PNG / CMYK images need room like any other resident; when the blob is
+    full they stay what they were - host decodes every epoch - and the batches do not change."""
+    import io
+    from PIL import Image
+    from dali_amd import fn
+    from dali_amd.pipeline import Pipeline
+    rng = np.random.default_rng(19)
+    files, ref = [], []
+    noise = rng.integers(0, 256, (420, 560, 3), dtype=np.uint8)
+    a = encode_jpeg(noise, 97, subsampling="4:4:4")                      # ~0.6 MB: takes most of the 1 MB cache
+    (tmp_path / "0_big.jpg").write_bytes(a)
+    files.append(str(tmp_path / "0_big.jpg")); ref.append(O.jpeg_decode_rgb(a))
+    b = encode_jpeg(rng.integers(0, 256, (300, 400, 3), dtype=np.uint8), 95, subsampling="4:4:4", progressive=True)
+    (tmp_path / "1_prog.jpg").write_bytes(b)
+    files.append(str(tmp_path / "1_prog.jpg")); ref.append(O.jpeg_decode_rgb(b))
+    pix = rng.integers(0, 256, (400, 500, 3), dtype=np.uint8)            # 0.6 MB decoded
+    Image.fromarray(pix).save(tmp_path / "2_img.png")
+    files.append(str(tmp_path / "2_img.png")); ref.append(pix)
+    cm = Image.fromarray(synth_image(rng, 300, 420)).convert("CMYK")
+    buf = io.BytesIO(); cm.save(buf, "JPEG", quality=90)
+    (tmp_path / "3_cmyk.jpg").write_bytes(buf.getvalue())
+    files.append(str(tmp_path / "3_cmyk.jpg")); ref.append(np.asarray(Image.open(io.BytesIO(buf.getvalue())).convert("RGB")))
+    pipe = Pipeline(batch_size=4, num_threads=3, device_id=0, prefetch_queue_depth=2, seed=1)
+    with pipe:
+        enc, _ = fn.readers.file(files=files, skip_cached_images=True)
+        pipe.set_outputs(fn.decoders.image(enc, device="mixed", cache_size=1, cache_type=CACHE_TYPE[0]), enc)
+    for it in range(6):
+        img, e = pipe.run()
+        for i in range(4):
+            assert np.array_equal(img[i].as_cpu(), ref[i]), (it, i)
+    sizes = [e.at(i).size for i in range(4)]
+    # (what fits is resident - the samples that reserve first: the decoded rasters -, the rest found no room and is read and
+    # decoded every epoch)
+    assert 0 < sum(s == 0 for s in sizes) < 4, sizes

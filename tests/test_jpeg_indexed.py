@@ -116,3 +116,18 @@ def test_reader_hands_out_containers_under_the_files_names(tmp_path):
         assert got[0] == (idx / "a" / "x.jpg.didx").read_bytes() and got[0][:4] == b"DAJX"
         assert got[1] == encs[("a", "y.jpg")]                       # no container: the file as it is
         assert got[2] == (idx / "b" / "z.jpg.didx").read_bytes()
+
+
+def test_command_line_tool(tmp_path):
+    import subprocess
+    rng = np.random.default_rng(7)
+    root, idx = tmp_path / "d", tmp_path / "i"
+    os.makedirs(root / "c")
+    for k in range(5):
+        (root / "c" / f"f{k}.jpg").write_bytes(encode_jpeg(synth_image(rng, 48, 64), 80, **({"progressive": True} if k == 4 else {})))
+    (root / "c" / "notes.txt").write_text("not an image")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "jpeg2idx.py"), str(root), str(idx), "--workers", "2"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert "4 containers" in out.stdout and "1 files left as they are" in out.stdout, out.stdout
+    assert sorted(os.listdir(idx / "c")) == [f"f{k}.jpg.didx" for k in range(4)]
