@@ -371,6 +371,9 @@ def write_dataset(root, enc, first_index=0):
         g = first_index + i
         with open(os.path.join(root, f"{g % 10:02d}", f"img_{g:07d}.jpg"), "wb") as f:
             f.write(e)
+    # the files' dirty pages go to the disk NOW, not when the kernel's flusher wakes up in the middle of a 9 ms timed region
+    # (the legs that follow a freshly written data set showed one-off dips of 10-25 %, gpurun_out/r06_final3)
+    os.sync()
 
 
 def e2e_pipeline(root, batch, device_id, iters=400, threads=None, roi_decode=False, cache_mb=0, shard_id=0, num_shards=1,
