@@ -288,3 +288,24 @@ def test_a_full_cache_leaves_progressive_and_raster_samples_as_host_decodes(tmp_
     # (what fits is resident - the samples that reserve first: the decoded rasters -, the rest found no room and is read and
     # decoded every epoch)
     assert 0 < sum(s == 0 for s in sizes) < 4, sizes
+
+
+def test_windows_from_reencoded_and_raster_residents(tmp_path, files, decoded):
+    """Region-of-interest decoding over residents of every kind at once: a baseline stream, the progressive one (resident as its
+    baseline re-encoding: the window is decoded on the device from the second epoch on), a PNG (resident decoded: the window is a
+    view).  Every window of every epoch equals the crop of the oracle's image."""
+    from PIL import Image
+    rng = np.random.default_rng(23)
+    pix = synth_image(rng, 90, 130)
+    Image.fromarray(pix).save(tmp_path / "w.png")
+    mine = [files[0], files[3], str(tmp_path / "w.png"), files[5]]
+    ref = [decoded[0], decoded[3], pix, decoded[5]]
+    pipe = _pipe(mine, 4, decoder="image_random_crop", random_area=[0.1, 0.9], seed=4321, outputs="both")
+    for it in range(7):
+        out, enc = pipe.run()
+        anchors, crops = O.rrc_batch(4321, it, [r.shape[:2] for r in ref], area=(0.1, 0.9))
+        for i, r in enumerate(ref):
+            (y0, x0), (h, w) = anchors[i], crops[i]
+            assert np.array_equal(out[i].as_cpu(), r[y0:y0 + h, x0:x0 + w]), (it, i)
+    assert all(enc.at(i).size == 0 for i in range(4)), [enc.at(i).size for i in range(4)]
+    assert "jpeg_idct" not in pipe.executed_kernels()        # (no host-decoded coefficients any more: everything JPEG is a device decode)
