@@ -98,13 +98,18 @@ DALIAMD_API daliamdResult_t daliamdMemsetAsync(void *dst, int value, size_t byte
  * again to the device): page-locks [ptr, ptr + bytes) - e.g. a read-only file mapping, i.e. the page cache's own pages -
  * and reports in *same_address whether the device addresses the range at the same addresses (it does on MI355X; a caller
  * that gets 0 keeps copying).  Measured on the bench box: a device-side copy out of such a mapping runs at the bus rate
- * (57 GB/s), the registration of 64 MiB takes 0.2 ms (tools/probes/hostreg_probe.py). */
+ * (57 GB/s), the registration of 64 MiB takes 0.2 ms (tools/probes/hostreg_probe.py).
+ * CAUTION (round 6): pages registered this way must stay what they are while the registration lives.  Round 5's readers.file
+ * registered its file mappings; truncating such a file made the driver evict the process's queues for minutes.  The reader
+ * now hands out page-locked COPIES (daliamdHostAlloc) for the device-side fetch and no longer calls this; the entry stays
+ * for callers that own the memory they register. */
 DALIAMD_API daliamdResult_t daliamdHostRegister(void *ptr, size_t bytes, int *same_address);
 DALIAMD_API daliamdResult_t daliamdHostUnregister(void *ptr);
 /* Batched device-side copy: record i moves `bytes` bytes from src (device-visible memory: device, page-locked or
  * registered host memory) to dst (device), any alignment; one launch for the whole table (`descs`: device-visible,
  * `max_bytes` >= every record's bytes).  The mixed decoders fetch the encoded files of a batch with it straight out of
- * the reader's registered file mappings - the files cross the bus once and no host core touches their bytes. */
+ * the reader's page-locked resident copies (DALI_AMD_READER_ZERO_COPY) - the files cross the bus once and no host core touches
+ * their bytes again. */
 typedef struct {
   const void *src;
   void *dst;
